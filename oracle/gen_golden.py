@@ -1,0 +1,425 @@
+"""Generates tests/golden/ from the reference itself.  RUNS IN THE BUILD CONTAINER ONLY
+(needs /root/reference; the GPU box never sees it -- only the committed fixtures travel).
+
+What is captured (data only: inputs and the reference's outputs; no reference source):
+  tokenizer_cases.json   crafted + fuzzed FASTA/FASTQ byte strings and the .list file that
+                         /root/reference/bin/glistmaker 4.2.3 wrote for each (base64)
+  ds_omitB/, ds_bonf/    small synthetic genome sets (FASTA, gz) + data.pheno and, from the
+                         reference run through oracle/ref_shim.py: per-sample .list digests,
+                         the union k-mer words, one glistquery mapping, chi2_results TSVs,
+                         <pheno>_MLdf.csv
+  chi2_kat.json          phenotypes.conduct_chi_squared_test called directly on random rows
+                         (weights, NA, filters, Bonferroni) -> its return value
+  welch_kat.json         scipy.stats.ttest_ind(equal_var=False) on random rows, unit weights
+                         and integer frequency weights (replicated observations)
+  model_kat.npz/json     sklearn liblinear L1 logistic regression and Lasso, converged
+                         (tol 1e-10), plus StratifiedKFold/KFold splits and CV scores
+  gmer_counter.json      /root/reference/bin/gmer_counter outputs for the prediction path
+
+Usage:  python oracle/gen_golden.py   (takes ~1 min)
+"""
+import base64
+import gzip
+import hashlib
+import json
+import os
+import random
+import shutil
+import subprocess
+import sys
+import tempfile
+
+import numpy as np
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(HERE)
+sys.path.insert(0, ROOT)
+sys.path.insert(0, HERE)
+GOLD = os.path.join(ROOT, "tests", "golden")
+REFBIN = "/root/reference/bin"
+ENV = dict(os.environ, PATH=REFBIN + ":" + os.environ["PATH"])
+
+from phenotypeseeker_amd.synth import GenomeSet, fastq_reads  # noqa: E402
+
+
+def sh(cmd, cwd, stdout=None):
+    return subprocess.run(cmd, shell=True, cwd=cwd, env=ENV, stdout=stdout or subprocess.DEVNULL,
+                          stderr=subprocess.DEVNULL)
+
+
+def b64(b):
+    return base64.b64encode(b).decode()
+
+
+def glistmaker_list(data, k, tmp):
+    """Run the reference binary on `data`; return the .list bytes or None."""
+    p = os.path.join(tmp, "in.dat")
+    with open(p, "wb") as f:
+        f.write(data)
+    out = os.path.join(tmp, "out_%d.list" % k)
+    if os.path.exists(out):
+        os.remove(out)
+    sh("glistmaker in.dat -o out -w %d" % k, tmp)
+    if not os.path.exists(out):
+        return None
+    with open(out, "rb") as f:
+        return f.read()
+
+
+# ------------------------------------------------------------------------------------------
+def gen_tokenizer_cases():
+    crafted = [
+        (b">r1 desc\nACGTACGTAC\nGTNACGTTGCA\n\nacgtu\r\nGGGCC\n>r2\nAC-GT\n", 5),
+        (b">r1\nACGTA>CGTAC\nACGTACC\n", 5),
+        (b"ACGTACGTAC\n>r\nCCCCCC", 5),
+        (b">r\nACGTA CGTAC\nAC\tGTACC\n", 5),
+        (b">r\nACGTAC\n@notheader\nGTACC\n", 5),
+        (b">r\nACGTAC\n  >x\nGTACCA\n", 5),
+        (b"\n\n>r\nACGTAC\n", 5),
+        (b"\n>r\nACGTAC\n", 5),
+        (b"XX@q\nACGTAC\n+\nIIIIII\n", 5),
+        (b"XX>r\nACGTAC\n", 5),
+        (b">r\nACGTA\x00CGTAC\nACGTAC\n", 5),
+        (b">r\nACGTAC\x0bCGT\x01AC\n", 5),
+        (b">r1\n>r2\nACGTAC\n", 5),
+        (b">r1", 5),
+        (b"", 5),
+        (b">r1\nACGTAC\n>", 5),
+        (b">r1\nACG\n\n\nTAC\n", 5),
+        (b">r\nACGT\n", 5),
+        (b">pal\nACGTACGT\n", 4),
+        (b">pal\nAATTAATT\n", 4),
+        (b">k1\nACGTNACGT\n", 1),
+        (b">k32\n" + b"ACGTTGCAAGCTTAGCCGATCGATTAGCAGCTAGCTAGGATCCAAGTC" + b"\n", 32),
+        (b">k31\n" + b"ACGTTGCAAGCTTAGCCGATCGATTAGCAGCTAGCTAGGATCCAAGTC" + b"\n", 31),
+        (b">allT\n" + b"T" * 40 + b"\n", 13),
+        (b">allA\n" + b"A" * 40 + b"\n", 16),
+        (b"@q1\nACGTACGTAC\n+\n@CGTACGTAC\n@q2\nTTTTTGGGGG\n+q2\nACGTACGTAC\n", 5),
+        (b"@q1\nACGTA\nCGTAC\n+\nIIIII\nIIIII\n@q2\nTTTTTGGGGG\n+\nIIIIIIIIII\n", 5),
+        (b"@q1\nACGTACGTAC\n+\nIIIIIIIIII\n\n@q2\nTTTTTGGGGG\n+\nIIIIIIIIII", 5),
+        (b"@q1\nACGTAC\n+\nIIIIII\n\n\n@q2\nTTTTTG\n+\nIIIIII\n", 5),
+        (b"@q1\nACGTAC\n+\nIIIIII\nXX\n@q2\nTTTTTG\n+\nIIIIII\n", 5),
+        (b"@q1\nACGTAC\n+\n\n@q2\nTTTTTG\n+\nIIIIII\n", 5),
+        (b"@q1\n\n+\n\n@q2\nTTTTTG\n+\nIIIIII\n", 5),
+        (b"@q1\r\nACGTAC\r\n+\r\nIIIIII\r\n@q2\r\nTTTTTG\r\n+\r\nIIIIII\r\n", 5),
+        (b"@q1\nACGTAC\n+\nII\n@III\n@q2\nTTTTTG\n+\nIIIIII\n", 5),
+        (b"@q\nACGTAC\n+\nIIIIII\n>r\nCCCCCC\n", 5),
+        (b"@r\nACGTAC>ACGTAC\n+\nIIIIII\n", 5),
+        (b">r\nACGTAC\n@q\nCCCCCC\n+\nGGGGGG\n", 5),
+        (b"@q\nACGTAC\n@q2\nCCCCCC\n", 5),
+        (b"@q1\nACG\n\nTAC\n+\nIIIIII\n", 5),
+        (b"@q\nACGTACG", 5),
+        (b"@q\nACGTAC\n+", 5),
+    ]
+    rnd = random.Random(20260101)
+    fuzz = []
+    for _ in range(120):
+        k = rnd.choice([1, 2, 3, 5, 7, 13, 16, 31, 32])
+        mode = rnd.choice(["fa", "fq", "mix"])
+        n = rnd.randint(0, 300)
+        if mode == "fa":
+            s = ">h\n" + "".join(rnd.choice("ACGT" * 6 + "acgtuNn>@+ \t\r\n\n-") for _ in range(n))
+        elif mode == "fq":
+            recs = []
+            for r in range(rnd.randint(1, 5)):
+                L = rnd.randint(0, 70)
+                seq = "".join(rnd.choice("ACGT" * 8 + "Nn") for _ in range(L))
+                q = "".join(rnd.choice("I@+>AC#") for _ in range(L))
+                recs.append("@r%d\n%s\n+\n%s\n" % (r, seq, q))
+                if rnd.random() < 0.2:
+                    recs.append(rnd.choice(["\n", "\n\n", "XX\n", "@\n", ">r\nACGTACGTAGCTAGCTAGCATCGATCGA\n"]))
+            s = "".join(recs)
+            if rnd.random() < 0.3:
+                s = s.rstrip("\n")
+        else:
+            s = "".join(rnd.choice("ACGT" * 4 + "acgtu>@+ \t\r\n\n-NI") for _ in range(n))
+        fuzz.append((s.encode(), k))
+    cases = []
+    with tempfile.TemporaryDirectory() as tmp:
+        for data, k in crafted + fuzz:
+            lst = glistmaker_list(data, k, tmp)
+            cases.append({"k": k, "input_b64": b64(data), "list_b64": None if lst is None else b64(lst)})
+    with open(os.path.join(GOLD, "tokenizer_cases.json"), "w") as f:
+        json.dump({"source": "glistmaker 4.2.3 (reference bin/)", "cases": cases}, f)
+    print("tokenizer cases:", len(cases))
+
+
+# ------------------------------------------------------------------------------------------
+def run_reference_dataset(tag, gs, na, flags, k=13, nt=4, fastq_for=()):
+    """Write the dataset, run the reference pipeline on it, capture the artefacts."""
+    out = os.path.join(GOLD, tag)
+    shutil.rmtree(out, ignore_errors=True)
+    os.makedirs(out)
+    tmp = tempfile.mkdtemp(prefix="psk_gold_")
+    rows = ["ID\tAddresses\tPheno"]
+    names = []
+    for i in range(gs.n):
+        name, fa = gs.sample(i)
+        names.append(name)
+        if i in fastq_for:  # this sample is handed over as FASTQ reads instead of an assembly
+            fa = fastq_reads(gs.codes(i), n_reads=600, read_len=100, seed=[gs.seed, 77, i])
+            fn = name + ".fastq"
+        else:
+            fn = name + ".fasta"
+        with open(os.path.join(tmp, fn), "wb") as f:
+            f.write(fa)
+        with gzip.GzipFile(os.path.join(out, fn + ".gz"), "wb", mtime=0) as f:
+            f.write(fa)
+        ph = "NA" if i in na else gs.phenotype(i)
+        rows.append("%s\t%s\t%s" % (name, fn, ph))
+    pheno_txt = "\n".join(rows) + "\n"
+    with open(os.path.join(tmp, "data.pheno"), "w") as f:
+        f.write(pheno_txt)
+    with open(os.path.join(out, "data.pheno"), "w") as f:
+        f.write(pheno_txt)
+
+    # k-mer plane artefacts straight from the binaries (same commands as modeling.py:308-311,
+    # :376-379, :324-329)
+    meta = {"k": k, "flags": flags, "nt": nt, "lists": {}}
+    os.makedirs(os.path.join(tmp, "L"))
+    for line in rows[1:]:
+        name, fn, _ = line.split("\t")
+        sh("glistmaker %s -o L/%s_0 -w %d -c 1" % (fn, name, k), tmp)
+        with open(os.path.join(tmp, "L", "%s_0_%d.list" % (name, k)), "rb") as f:
+            data = f.read()
+        h64 = np.frombuffer(data, dtype="<u8", count=3, offset=16)
+        meta["lists"][name] = {"sha256": hashlib.sha256(data).hexdigest(), "n_unique": int(h64[0]),
+                               "n_total": int(h64[1])}
+        if name == names[0]:
+            with open(os.path.join(out, "%s_0_%d.list" % (name, k)), "wb") as f:
+                f.write(data)
+    all_lists = " ".join("L/%s_0_%d.list" % (n, k) for n in names)
+    # glistcompare takes 2-3 lists at a time in the reference's tree; the union of all is the
+    # same set, so build it pairwise here
+    cur = "L/%s_0_%d.list" % (names[0], k)
+    for j, n in enumerate(names[1:]):
+        sh("glistcompare -u -o L/u%d %s L/%s_0_%d.list" % (j, cur, n, k), tmp)
+        cur = "L/u%d_%d_union.list" % (j, k)
+    with open(os.path.join(tmp, cur), "rb") as f:
+        udata = f.read()
+    urec = np.frombuffer(udata, dtype=np.dtype([("word", "<u8"), ("freq", "<u4")]),
+                         count=int(np.frombuffer(udata, dtype="<u8", count=1, offset=16)[0]), offset=40)
+    np.save(os.path.join(out, "union_words.npy"), urec["word"])
+    np.save(os.path.join(out, "union_freqs.npy"), urec["freq"])
+    meta["union_sha256"] = hashlib.sha256(udata).hexdigest()
+    meta["n_union"] = int(len(urec))
+    with open(os.path.join(tmp, "map0.txt"), "wb") as f:
+        sh("glistquery L/%s_0_%d.list -l %s" % (names[1], k, cur), tmp, stdout=f)
+    with open(os.path.join(tmp, "map0.txt"), "rb") as f:
+        meta["mapped_sample"] = names[1]
+        meta["mapped_sha256"] = hashlib.sha256(f.read()).hexdigest()
+    del all_lists
+
+    # the reference pipeline itself
+    with open(os.path.join(tmp, "stderr.txt"), "w") as err:
+        subprocess.run([sys.executable, os.path.join(HERE, "ref_shim.py"), "modeling", "data.pheno", "-nt", str(nt),
+                        "-l", str(k)] + flags, cwd=tmp, env=ENV, stderr=err, stdout=err)
+    for fn in sorted(os.listdir(tmp)):
+        if fn.startswith("chi2_results_") or fn.endswith("_MLdf.csv"):
+            shutil.copy(os.path.join(tmp, fn), os.path.join(out, fn))
+    meta["reference_outputs"] = sorted(fn for fn in os.listdir(out) if fn.startswith("chi2_") or fn.endswith(".csv"))
+    with open(os.path.join(out, "meta.json"), "w") as f:
+        json.dump(meta, f, indent=1, sort_keys=True)
+    shutil.rmtree(tmp, ignore_errors=True)
+    print(tag, "M =", meta["n_union"], "outputs:", meta["reference_outputs"])
+
+
+# ------------------------------------------------------------------------------------------
+def gen_chi2_kat():
+    import ref_shim
+    M = ref_shim.load_modeling()
+    rng = np.random.default_rng(4242)
+    cases = []
+
+    def run(pheno, pres, weights, mn, mx, cutoff, omit_B, n_kmers):
+        M.Samples.no_samples = 0
+        samples = [M.Samples("s%02d" % i, "x", {"P": pheno[i]}, weights[i]) for i in range(len(pheno))]
+        M.Samples.min_samples, M.Samples.max_samples = mn, mx
+        M.phenotypes.pvalue_cutoff = cutoff
+        M.phenotypes.omit_B = omit_B
+        M.phenotypes.no_kmers_to_analyse = n_kmers
+        ph = M.phenotypes("P")
+        try:
+            r = ph.conduct_chi_squared_test("ACGTACGTACGTA", list(pres), samples)
+        except ValueError as e:  # scipy>=1.14 raises where the pinned scipy 1.4.1 returned NaN
+            r = "ValueError"
+        if r is not None and r != "ValueError":
+            r = [r[0], float(r[1]), r[2], int(r[3]), r[4]] + [int(x) for x in r[5:]]
+        cases.append({"pheno": list(pheno), "presence": [int(x) for x in pres],
+                      "weights": [float(w) if not isinstance(w, int) else w for w in weights], "min": mn, "max": mx,
+                      "pvalue_cutoff": cutoff, "omit_B": omit_B, "n_kmers": n_kmers, "result": r})
+
+    # the survey's hand KATs
+    run([1, 1, 1, 0, 0, 0, 1, 0], [1, 1, 1, 0, 0, 0, 0, 1], [1] * 8, 2, 6, 0.5, True, 10)
+    run([1] * 6 + [0] * 6, [1] * 6 + [0] * 6, [1] * 12, 2, 10, 0.05, True, 10)
+    run([1, 1, 1, "NA", 0, 0, 0, "NA", 1, 0], [1, 1, 0, 1, 0, 0, 1, 1, 1, 0], [1] * 10, 2, 8, 0.5, True, 10)
+    run([1, 1, 1, 0, 0, 0, 1, 0], [1, 1, 1, 0, 0, 0, 0, 1], [.5, 1.5, 1, 2, .25, 1, .75, 1], 2, 6, 0.5, True, 10)
+    run([1] * 6 + [0] * 6, [1] * 6 + [0] * 6, [1] * 12, 2, 10, 0.05, False, 10)
+    run([1] * 6 + [0] * 6, [1] * 6 + [0] * 6, [1] * 12, 2, 10, 0.05, False, 100)
+    run([0] * 8, [1, 1, 1, 0, 0, 0, 0, 1], [1] * 8, 2, 6, 0.5, True, 10)
+    run([1, 1, 1, 0, 0, 0, 1, 0], [1, 0, 0, 0, 0, 0, 0, 0], [1] * 8, 2, 6, 0.5, True, 10)   # n_w = 1
+    run([1, 1, 1, 0, 0, 0, 1, 0], [1, 1, 1, 1, 1, 1, 1, 0], [1] * 8, 2, 6, 0.5, True, 10)   # n_wo = 1
+    run([1, 1, 1, 0, 0, 0, 1, 0], [1, 1, 1, 1, 1, 1, 0, 0], [1] * 8, 2, 5, 0.5, True, 10)   # n_w > max
+    run([1, 1, 1, 0, 0, 0, 1, 0], [2, 5, 1, 0, 0, 0, 0, 3], [1] * 8, 2, 6, 0.5, True, 10)   # real counts
+    for _ in range(300):
+        n = int(rng.integers(6, 70))
+        pheno = [("NA" if rng.random() < 0.1 else int(rng.random() < 0.5)) for _ in range(n)]
+        assoc = rng.random()
+        pres = [int(rng.random() < (0.15 + 0.7 * assoc * (p == 1))) if p != "NA" else int(rng.random() < 0.5)
+                for p in pheno]
+        if rng.random() < 0.5:
+            weights = [1] * n
+        else:
+            weights = [float(np.round(rng.uniform(0.05, 3.0), 6)) for _ in range(n)]
+        mn = int(rng.integers(1, 4))
+        mx = int(n - rng.integers(0, 4))
+        cutoff = float(rng.choice([0.05, 0.5, 0.9, 1e-3]))
+        omit_B = bool(rng.random() < 0.5)
+        n_kmers = int(rng.choice([1, 10, 1000, 100000]))
+        run(pheno, pres, weights, mn, mx, cutoff, omit_B, n_kmers)
+    with open(os.path.join(GOLD, "chi2_kat.json"), "w") as f:
+        json.dump({"source": "PhenotypeSeeker.modeling.phenotypes.conduct_chi_squared_test (modeling.py:759-798)",
+                   "cases": cases}, f)
+    print("chi2 KATs:", len(cases), "kept:", sum(1 for c in cases if c["result"] not in (None, "ValueError")),
+          "ValueError:", sum(1 for c in cases if c["result"] == "ValueError"))
+
+
+def gen_welch_kat():
+    from scipy import stats
+    rng = np.random.default_rng(777)
+    cases = []
+    for it in range(200):
+        n = int(rng.integers(6, 80))
+        pres = (rng.random(n) < rng.uniform(0.2, 0.8)).astype(int)
+        if pres.sum() < 2 or (1 - pres).sum() < 2:
+            continue
+        vals = np.round(rng.normal(0, 1, n) * rng.uniform(0.1, 5) + pres * rng.uniform(-2, 2) + rng.uniform(-10, 10), 4)
+        integer_w = it % 2 == 1
+        w = rng.integers(1, 5, n) if integer_w else np.ones(n, dtype=int)
+        x = np.repeat(vals[pres == 1], w[pres == 1])
+        y = np.repeat(vals[pres == 0], w[pres == 0])
+        r = stats.ttest_ind(x, y, equal_var=False)
+        cases.append({"values": vals.tolist(), "presence": pres.tolist(), "weights": w.tolist(),
+                      "t": float(r.statistic), "p": float(r.pvalue), "df": float(r.df),
+                      "mean_x": float(np.average(vals[pres == 1], weights=w[pres == 1])),
+                      "mean_y": float(np.average(vals[pres == 0], weights=w[pres == 0]))})
+    # Student-t survival function table
+    tsf = [{"t": float(t), "df": float(df), "p": float(2 * stats.t.sf(abs(t), df))}
+           for t in (0.0, 0.1, 0.5, 1.0, 2.0, 3.5, 6.0, 12.0, 40.0) for df in (1.0, 1.7, 2.0, 5.5, 10.0, 30.0, 250.0, 2046.0)]
+    with open(os.path.join(GOLD, "welch_kat.json"), "w") as f:
+        json.dump({"source": "scipy.stats.ttest_ind(equal_var=False); integer weights = replicated observations "
+                             "(frequency-weight identity of statsmodels DescrStatsW, modeling.py:734)",
+                   "cases": cases, "t_sf": tsf}, f)
+    print("welch KATs:", len(cases))
+
+
+def gen_model_kat():
+    """Converged optima of the two estimators the reference fits (modeling.py:999-1014,
+    :1075-1085, :1208-1216) + the CV splitters GridSearchCV uses for an integer cv."""
+    import pandas as pd
+    from sklearn.linear_model import Lasso, LogisticRegression
+    from sklearn.model_selection import GridSearchCV, KFold, StratifiedKFold
+    df = pd.read_csv(os.path.join(GOLD, "ds_omitB", "Pheno_MLdf.csv"), index_col=0)
+    X = df.iloc[:, 0:-2].values.astype(np.float64)
+    y = df.iloc[:, -1].values.astype(int)
+    rng = np.random.default_rng(99)
+    # a second, less degenerate design: random sparse binary columns with a planted signal
+    n2, p2 = 60, 40
+    X2 = (rng.random((n2, p2)) < 0.3).astype(np.float64)
+    logit = 2.5 * X2[:, 0] - 2.0 * X2[:, 1] + 1.5 * X2[:, 2] - 0.5
+    y2 = (rng.random(n2) < 1 / (1 + np.exp(-logit))).astype(int)
+    yc2 = 1.5 * X2[:, 0] - 2.0 * X2[:, 3] + 0.7 * X2[:, 5] + rng.normal(0, 0.3, n2) + 4.0
+    Cs = [1 / a for a in np.logspace(-3, 3, 13)]
+    out = {"X1": X, "y1": y, "X2": X2, "y2": y2, "yc2": yc2, "Cs": np.array(Cs)}
+    for tag, XX, yy in (("1", X, y), ("2", X2, y2)):
+        coefs, icpts, objs = [], [], []
+        for C in Cs:
+            m = LogisticRegression(penalty="l1", solver="liblinear", C=C, tol=1e-10, max_iter=20000,
+                                   random_state=0).fit(XX, yy)
+            w, b = m.coef_[0], m.intercept_[0]
+            z = XX @ w + b
+            ypm = 2 * yy - 1
+            obj = np.abs(w).sum() + abs(b) + C * np.logaddexp(0, -ypm * z).sum()
+            coefs.append(w); icpts.append(b); objs.append(obj)
+        out["logreg_coef" + tag] = np.array(coefs)
+        out["logreg_icpt" + tag] = np.array(icpts)
+        out["logreg_obj" + tag] = np.array(objs)
+        cv = int(min(np.bincount(yy).min(), 10))
+        folds = np.full(len(yy), -1)
+        for f, (_, te) in enumerate(StratifiedKFold(n_splits=cv).split(XX, yy)):
+            folds[te] = f
+        out["skf_folds" + tag] = folds
+        gs = GridSearchCV(LogisticRegression(penalty="l1", solver="liblinear", tol=1e-10, max_iter=20000,
+                                             random_state=0), {"C": Cs}, cv=cv).fit(XX, yy)
+        out["gs_mean_score" + tag] = gs.cv_results_["mean_test_score"]
+        out["gs_std_score" + tag] = gs.cv_results_["std_test_score"]
+        out["gs_best_C" + tag] = np.array(gs.best_params_["C"])
+    alphas = np.logspace(-3, 3, 13)
+    lc, li = [], []
+    for a in alphas:
+        m = Lasso(alpha=a, tol=1e-13, max_iter=1000000).fit(X2, yc2)
+        lc.append(m.coef_); li.append(m.intercept_)
+    out["alphas"] = alphas
+    out["lasso_coef2"] = np.array(lc)
+    out["lasso_icpt2"] = np.array(li)
+    kfolds = np.full(n2, -1)
+    for f, (_, te) in enumerate(KFold(n_splits=10).split(X2)):
+        kfolds[te] = f
+    out["kf_folds2"] = kfolds
+    gs = GridSearchCV(Lasso(tol=1e-13, max_iter=1000000), {"alpha": alphas}, cv=10).fit(X2, yc2)
+    out["lasso_gs_mean_score2"] = gs.cv_results_["mean_test_score"]
+    out["lasso_gs_best_alpha2"] = np.array(gs.best_params_["alpha"])
+    np.savez_compressed(os.path.join(GOLD, "model_kat.npz"), **out)
+    print("model KATs: logreg best C", out["gs_best_C1"], out["gs_best_C2"], "lasso best alpha",
+          out["lasso_gs_best_alpha2"])
+
+
+def gen_gmer_counter():
+    """prediction.py:72-80,145-148: db line 'KMER\\t1\\tKMER', output parsed at :82-100."""
+    gs = GenomeSet(4, 6000, seed=31, gene_len=200)
+    k = 13
+    cases = []
+    rng = np.random.default_rng(5)
+    with tempfile.TemporaryDirectory() as tmp:
+        name, fa = gs.sample(0)
+        codes = gs.codes(0)
+        # dictionary: k-mers taken from the genome (either strand as written), some absent ones
+        kmers = []
+        for s in rng.integers(0, len(codes) - k, 25):
+            kmers.append("".join("ACGT"[c] for c in codes[s:s + k]))
+        kmers += ["ACGTACGTACGTA", "TTTTTTTTTTTTT", "GGGGGGGGGGGGC"]
+        kmers = list(dict.fromkeys(kmers))
+        with open(os.path.join(tmp, "db.txt"), "w") as f:
+            for km in kmers:
+                f.write("%s\t1\t%s\n" % (km, km))
+        for i in range(3):
+            name, fa = gs.sample(i)
+            with open(os.path.join(tmp, name + ".fasta"), "wb") as f:
+                f.write(fa)
+            with open(os.path.join(tmp, "o.txt"), "wb") as f:
+                sh("gmer_counter -db db.txt %s.fasta" % name, tmp, stdout=f)
+            with open(os.path.join(tmp, "o.txt")) as f:
+                txt = f.read()
+            cases.append({"fasta_gz_b64": b64(gzip.compress(fa, mtime=0)), "output": txt})
+    with open(os.path.join(GOLD, "gmer_counter.json"), "w") as f:
+        json.dump({"source": "gmer_counter 4.2.7 (reference bin/)", "k": k, "kmers": kmers, "cases": cases}, f)
+    print("gmer_counter cases:", len(cases))
+
+
+if __name__ == "__main__":
+    os.makedirs(GOLD, exist_ok=True)
+    what = sys.argv[1:] or ["tok", "ds", "chi2", "welch", "model", "gmer"]
+    if "tok" in what:
+        gen_tokenizer_cases()
+    if "ds" in what:
+        run_reference_dataset("ds_omitB", GenomeSet(20, 10000, seed=11, gene_len=300), na={3, 14},
+                              flags=["--omit_B_correction", "--n_kmers", "100"], fastq_for={5})
+        run_reference_dataset("ds_bonf", GenomeSet(44, 6000, seed=23, gene_len=150), na={9}, flags=[])
+    if "chi2" in what:
+        gen_chi2_kat()
+    if "welch" in what:
+        gen_welch_kat()
+    if "model" in what:
+        gen_model_kat()
+    if "gmer" in what:
+        gen_gmer_counter()

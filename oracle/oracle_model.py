@@ -1,0 +1,131 @@
+"""CPU oracle for the model stage (numpy).  TEST INFRASTRUCTURE ONLY (see psk_oracle.c).
+
+Restates what the reference asks of scikit-learn (pinned scikit-learn==0.22.1, not vendored):
+  * LogisticRegression(penalty='l1', solver='liblinear')       modeling.py:1011-1014
+      liblinear L1R_LR objective:  ||w||_1 + |b| + C * sum_i log(1 + exp(-y_i (w.x_i + b)))
+      (the intercept is a constant-1 feature and is penalised; y in {-1,+1})
+  * Lasso(alpha)                                               modeling.py:999-1000
+      (1/2n) ||y - Xw - b||^2 + alpha ||w||_1, unpenalised intercept
+  * GridSearchCV(model, {'C'|'alpha': grid}, cv=int)           modeling.py:1075-1085,1208-1216
+      StratifiedKFold (classifier) / KFold (regressor), no shuffling; accuracy / R^2;
+      best = first candidate with the highest mean test score; refit on everything.
+Parity: pinned against converged scikit-learn 1.7.2 solutions in tests/golden/model_kat.npz
+(objective value, intercept, linear predictor, CV folds and CV scores).  Raw per-column
+coefficients are only unique up to identical columns.
+"""
+import ctypes
+
+import numpy as np
+
+
+def _clib():
+    from . import oracle as _o
+    L = _o.lib()
+    if not getattr(L, "_model_sigs", False):
+        c = ctypes
+        L.orc_logreg_l1_fit.argtypes = [c.c_void_p, c.c_void_p, c.c_int, c.c_int, c.c_double, c.c_double, c.c_int,
+                                        c.c_void_p, c.POINTER(c.c_double)]
+        L.orc_logreg_l1_fit.restype = c.c_int
+        L.orc_lasso_fit.argtypes = [c.c_void_p, c.c_void_p, c.c_int, c.c_int, c.c_double, c.c_double, c.c_int,
+                                    c.c_void_p, c.POINTER(c.c_double)]
+        L.orc_lasso_fit.restype = c.c_int
+        L._model_sigs = True
+    return L
+
+
+def stratified_kfold(y, n_splits):
+    """test-fold id per sample, as sklearn.model_selection.StratifiedKFold(n_splits) without
+    shuffling assigns them (the 0.22+ allocation rule: classes encoded in order of first
+    appearance, samples of the sorted class vector dealt round-robin to the folds)."""
+    y = np.asarray(y)
+    _, y_idx, y_inv = np.unique(y, return_index=True, return_inverse=True)
+    _, class_perm = np.unique(y_idx, return_inverse=True)
+    y_enc = class_perm[y_inv]
+    n_classes = len(y_idx)
+    y_order = np.sort(y_enc)
+    allocation = np.asarray([np.bincount(y_order[i::n_splits], minlength=n_classes) for i in range(n_splits)])
+    folds = np.empty(len(y), dtype=np.int64)
+    for k in range(n_classes):
+        folds[y_enc == k] = np.arange(n_splits).repeat(allocation[:, k])
+    return folds
+
+
+def kfold(n, n_splits):
+    """sklearn KFold(n_splits) without shuffling: contiguous blocks, the first n % k one longer."""
+    sizes = np.full(n_splits, n // n_splits)
+    sizes[: n % n_splits] += 1
+    return np.repeat(np.arange(n_splits), sizes)
+
+
+def logreg_l1_objective(X, y01, w, b, C):
+    z = X @ w + b
+    ypm = 2.0 * np.asarray(y01, dtype=np.float64) - 1.0
+    return np.abs(w).sum() + abs(b) + C * np.logaddexp(0.0, -ypm * z).sum()
+
+
+def logreg_l1_fit(X, y01, C, tol=1e-10, max_sweeps=200000):
+    """Cyclic coordinate descent with 1-D Newton steps and backtracking (the CDN scheme of
+    Yuan et al. 2010, which liblinear's L1R_LR solver descends from) run to convergence.
+    The loop itself is orc_logreg_l1_fit in psk_oracle.c."""
+    X = np.ascontiguousarray(X, dtype=np.float64)
+    y = np.ascontiguousarray(y01, dtype=np.int32)
+    n, p = X.shape
+    w = np.zeros(p)
+    b = ctypes.c_double()
+    rc = _clib().orc_logreg_l1_fit(X.ctypes.data, y.ctypes.data, n, p, float(C), float(tol), int(max_sweeps),
+                                   w.ctypes.data, ctypes.byref(b))
+    if rc < 0:
+        raise MemoryError
+    return w, b.value
+
+
+def logreg_predict(X, w, b):
+    return (np.asarray(X) @ w + b > 0).astype(np.int64)
+
+
+def lasso_fit(X, y, alpha, tol=1e-14, max_sweeps=1000000):
+    """Cyclic coordinate descent on the centred problem (intercept unpenalised);
+    the loop is orc_lasso_fit in psk_oracle.c."""
+    X = np.ascontiguousarray(X, dtype=np.float64)
+    y = np.ascontiguousarray(y, dtype=np.float64)
+    n, p = X.shape
+    w = np.zeros(p)
+    b = ctypes.c_double()
+    rc = _clib().orc_lasso_fit(X.ctypes.data, y.ctypes.data, n, p, float(alpha), float(tol), int(max_sweeps),
+                               w.ctypes.data, ctypes.byref(b))
+    if rc < 0:
+        raise MemoryError
+    return w, b.value
+
+
+def r2_score(y, pred):
+    y = np.asarray(y, dtype=np.float64)
+    ss_res = ((y - pred) ** 2).sum()
+    ss_tot = ((y - y.mean()) ** 2).sum()
+    return 1.0 - ss_res / ss_tot
+
+
+def grid_search(X, y, grid, kind, cv):
+    """GridSearchCV restatement.  kind: 'logreg' (grid of C) or 'lasso' (grid of alpha).
+    Returns dict(mean_test_score, std_test_score, best_index, coef, intercept)."""
+    X = np.asarray(X, dtype=np.float64)
+    y = np.asarray(y)
+    folds = stratified_kfold(y, cv) if kind == "logreg" else kfold(len(y), cv)
+    scores = np.zeros((len(grid), cv))
+    for gi, g in enumerate(grid):
+        for f in range(cv):
+            tr, te = folds != f, folds == f
+            if kind == "logreg":
+                w, b = logreg_l1_fit(X[tr], y[tr], g)
+                scores[gi, f] = (logreg_predict(X[te], w, b) == y[te]).mean()
+            else:
+                w, b = lasso_fit(X[tr], y[tr], g)
+                scores[gi, f] = r2_score(y[te], X[te] @ w + b)
+    mean = scores.mean(axis=1)
+    best = int(np.argmax(mean))  # first maximum, as rank_test_score.argmin() picks
+    if kind == "logreg":
+        w, b = logreg_l1_fit(X, y, grid[best])
+    else:
+        w, b = lasso_fit(X, y, grid[best])
+    return {"mean_test_score": mean, "std_test_score": scores.std(axis=1), "best_index": best, "coef": w,
+            "intercept": b, "folds": folds}

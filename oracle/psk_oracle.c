@@ -1,0 +1,576 @@
+/*
+ * psk_oracle.c -- CPU restatement of the PhenotypeSeeker k-mer association hot path.
+ *
+ * TEST INFRASTRUCTURE ONLY.  Nothing in phenotypeseeker_amd/ (the product) may link,
+ * import or call this file.  Only tests/, __graft_entry__.smoke() and the cpu_baseline
+ * leg of bench.py use it, and only as the checker / the reported CPU baseline.
+ *
+ * Parity status: PINNED for the k-mer plane and the chi-squared scan -- every function
+ * below is checked in tests/test_oracle_golden.py against fixtures under tests/golden/
+ * that were produced in the build container by the reference's own binaries
+ * (/root/reference/bin/glistmaker, glistcompare, glistquery, gmer_counter) and by the
+ * reference's own Python (PhenotypeSeeker/modeling.py imported through oracle/ref_shim.py);
+ * generator: oracle/gen_golden.py.  The weighted Welch test is pinned against
+ * scipy.stats.ttest_ind(equal_var=False) at unit weights only (statsmodels, the library the
+ * reference calls at modeling.py:734, is not installed here): "parity unpinned" for
+ * non-unit weights.
+ *
+ * Plain scalar C, one thread.  Each function cites the reference lines it follows.
+ */
+#include <math.h>
+#include <stdint.h>
+#include <stdio.h>
+#include <stdlib.h>
+#include <string.h>
+
+/* ------------------------------------------------------------------------------------------
+ * 1. Tokeniser + canonical k-mer extraction.
+ *    Replaces: `glistmaker <file> -o <prefix> -w <k>`  (modeling.py:308-311; binary
+ *    bin/glistmaker 4.2.3, source not vendored).  The byte-level state machine below was
+ *    established by black-box probing of that binary (DESIGN.md "Tokeniser contract"):
+ *      - before the first record every byte is ignored until '>' (FASTA) or '@' (FASTQ);
+ *      - a header runs to the next '\n';
+ *      - in sequence text  A C G T U (either case, U==T) extend the window, bytes 1..31
+ *        (newline, CR, tab, ...) are skipped, NUL ends the input, every other byte breaks
+ *        the window; in a FASTA record '>' (anywhere) starts the next header;
+ *      - in a FASTQ record, after each '\n' of the sequence text the next byte is consumed:
+ *        '+' starts the separator line, anything else is DROPPED (a glistmaker quirk that
+ *        only shows on multi-line FASTQ); the separator line and ONE quality line are
+ *        skipped; then lines are skipped until one whose first byte is '@' -- where a line
+ *        whose first byte is '\n' swallows the following line as well.
+ *    Canonical form: A=0 C=1 G=2 T=3, first base most significant, min(word, revcomp).
+ * ------------------------------------------------------------------------------------------ */
+
+static inline int base_code(unsigned char c)
+{
+    switch (c) {
+    case 'A': case 'a': return 0;
+    case 'C': case 'c': return 1;
+    case 'G': case 'g': return 2;
+    case 'T': case 't': case 'U': case 'u': return 3;
+    default: return -1;
+    }
+}
+
+typedef struct {
+    uint64_t *v;
+    size_t n, cap;
+} u64vec;
+
+static int vec_push(u64vec *a, uint64_t x)
+{
+    if (a->n == a->cap) {
+        size_t nc = a->cap ? a->cap * 2 : 1 << 16;
+        uint64_t *nv = (uint64_t *)realloc(a->v, nc * sizeof(uint64_t));
+        if (!nv) return -1;
+        a->v = nv;
+        a->cap = nc;
+    }
+    a->v[a->n++] = x;
+    return 0;
+}
+
+enum { ST_INIT, ST_FA_HDR, ST_FA_SEQ, ST_FQ_HDR, ST_FQ_SEQ, ST_FQ_PLUS, ST_FQ_QUAL, ST_FQ_H, ST_FQ_HSKIP };
+
+/* Appends every canonical k-mer occurrence of buf to `out`.  Returns 0, or -1 on OOM. */
+static int tokenize(const uint8_t *buf, size_t len, int k, u64vec *out)
+{
+    const uint64_t mask = (k == 32) ? ~0ULL : ((1ULL << (2 * k)) - 1);
+    const int rcshift = 2 * (k - 1);
+    uint64_t fw = 0, rc = 0;
+    int run = 0; /* number of consecutive bases in the current window, capped at k */
+    int st = ST_INIT;
+    for (size_t i = 0; i < len; i++) {
+        unsigned char c = buf[i];
+        if (c == 0) break; /* NUL terminates the input */
+        switch (st) {
+        case ST_INIT:
+            if (c == '>') st = ST_FA_HDR;
+            else if (c == '@') st = ST_FQ_HDR;
+            break;
+        case ST_FA_HDR:
+            if (c == '\n') { st = ST_FA_SEQ; run = 0; }
+            break;
+        case ST_FQ_HDR:
+            if (c == '\n') { st = ST_FQ_SEQ; run = 0; }
+            break;
+        case ST_FA_SEQ:
+        case ST_FQ_SEQ: {
+            int code = base_code(c);
+            if (code >= 0) {
+                fw = ((fw << 2) | (uint64_t)code) & mask;
+                rc = (rc >> 2) | ((uint64_t)(3 - code) << rcshift);
+                if (run < k) run++;
+                if (run == k) {
+                    if (vec_push(out, fw < rc ? fw : rc)) return -1;
+                }
+            } else if (st == ST_FA_SEQ && c == '>') {
+                run = 0;
+                st = ST_FA_HDR;
+            } else if (c < 32) {
+                if (st == ST_FQ_SEQ && c == '\n') {
+                    /* consume the byte after the newline */
+                    if (i + 1 < len) {
+                        unsigned char c2 = buf[++i];
+                        if (c2 == 0) return 0;
+                        if (c2 == '+') st = ST_FQ_PLUS;
+                        /* else: dropped */
+                    }
+                }
+                /* control bytes are skipped, the window survives */
+            } else {
+                run = 0; /* any other byte breaks the window */
+            }
+            break;
+        }
+        case ST_FQ_PLUS:
+            if (c == '\n') st = ST_FQ_QUAL;
+            break;
+        case ST_FQ_QUAL:
+            if (c == '\n') st = ST_FQ_H;
+            break;
+        case ST_FQ_H: /* first byte of a line after the quality line */
+            if (c == '@') { st = ST_FQ_HDR; run = 0; }
+            else st = ST_FQ_HSKIP; /* also when c == '\n': the NEXT line is swallowed too */
+            break;
+        case ST_FQ_HSKIP:
+            if (c == '\n') st = ST_FQ_H;
+            break;
+        }
+    }
+    return 0;
+}
+
+/* LSD radix sort, 8-bit digits, over the low `bits` bits. */
+static int radix_sort_u64(uint64_t *a, size_t n, int bits)
+{
+    uint64_t *tmp = (uint64_t *)malloc((n ? n : 1) * sizeof(uint64_t));
+    if (!tmp) return -1;
+    uint64_t *src = a, *dst = tmp;
+    for (int sh = 0; sh < bits; sh += 8) {
+        size_t cnt[256];
+        memset(cnt, 0, sizeof cnt);
+        for (size_t i = 0; i < n; i++) cnt[(src[i] >> sh) & 255]++;
+        size_t pos = 0;
+        for (int d = 0; d < 256; d++) { size_t c = cnt[d]; cnt[d] = pos; pos += c; }
+        for (size_t i = 0; i < n; i++) dst[cnt[(src[i] >> sh) & 255]++] = src[i];
+        uint64_t *t = src; src = dst; dst = t;
+    }
+    if (src != a) memcpy(a, src, n * sizeof(uint64_t));
+    free(tmp);
+    return 0;
+}
+
+/*
+ * orc_count_kmers: canonical k-mer multiset of one (already inflated) FASTA/FASTQ buffer,
+ * as sorted unique words + u32 frequencies -- the content of glistmaker's .list file
+ * (modeling.py:303-315).  Output arrays are malloc'd; release with orc_free.
+ * Returns 0 on success.
+ */
+int orc_count_kmers(const uint8_t *buf, size_t len, int k, uint64_t **words_out, uint32_t **freqs_out,
+                    uint64_t *n_unique_out, uint64_t *n_total_out)
+{
+    if (k < 1 || k > 32) return -2;
+    u64vec v = {0, 0, 0};
+    if (tokenize(buf, len, k, &v)) { free(v.v); return -1; }
+    if (radix_sort_u64(v.v, v.n, 2 * k)) { free(v.v); return -1; }
+    size_t nu = 0;
+    for (size_t i = 0; i < v.n; i++)
+        if (i == 0 || v.v[i] != v.v[i - 1]) nu++;
+    uint64_t *w = (uint64_t *)malloc((nu ? nu : 1) * sizeof(uint64_t));
+    uint32_t *f = (uint32_t *)malloc((nu ? nu : 1) * sizeof(uint32_t));
+    if (!w || !f) { free(v.v); free(w); free(f); return -1; }
+    size_t j = 0;
+    for (size_t i = 0; i < v.n; i++) {
+        if (i == 0 || v.v[i] != v.v[i - 1]) { w[j] = v.v[i]; f[j] = 1; j++; }
+        else f[j - 1]++;
+    }
+    *words_out = w;
+    *freqs_out = f;
+    *n_unique_out = nu;
+    *n_total_out = v.n;
+    free(v.v);
+    return 0;
+}
+
+void orc_free(void *p) { free(p); }
+
+/* ------------------------------------------------------------------------------------------
+ * 2. GenomeTester4 .list file (produced at modeling.py:308-311,
+ *    consumed at modeling.py:326-327,371,379).  Little-endian, 40-byte header, packed
+ *    12-byte {u64 word; u32 freq} records in ascending word order.
+ * ------------------------------------------------------------------------------------------ */
+int orc_write_list(const char *path, int k, const uint64_t *words, const uint32_t *freqs, uint64_t n)
+{
+    FILE *fp = fopen(path, "wb");
+    if (!fp) return -1;
+    uint64_t total = 0;
+    for (uint64_t i = 0; i < n; i++) total += freqs[i];
+    uint32_t h32[4] = {0x47543443u, 4u, 2u, (uint32_t)k};
+    uint64_t h64[3] = {n, total, 40};
+    fwrite(h32, 4, 4, fp);
+    fwrite(h64, 8, 3, fp);
+    for (uint64_t i = 0; i < n; i++) {
+        fwrite(&words[i], 8, 1, fp);
+        fwrite(&freqs[i], 4, 1, fp);
+    }
+    return fclose(fp) ? -1 : 0;
+}
+
+/* ------------------------------------------------------------------------------------------
+ * 3. Chi-squared association test of one k-mer row.
+ *    Follows phenotypes.conduct_chi_squared_test (modeling.py:759-798) with
+ *    get_samples_distribution_for_chisquared (:800-828), get_totals_in_classes (:831-843),
+ *    get_expected_distribution (:846-858) and scipy.stats.chisquare(obs, exp, ddof=1)
+ *    (:782-792): 4 cells, df = 4-1-1 = 2, so the survival function is exp(-x/2).
+ *
+ *    presence[i] != 0  <=> sample i carries the k-mer (counts allowed, :811/:818)
+ *    pheno[i]: 1, 0, or -1 for 'NA' (NA samples take part in nothing, :810/:817)
+ *    weight[i]: GSC weight (1.0 when -w is off); summed sequentially in sample order.
+ *    Returns 1 and fills chi2/p/n_with when the row passes the frequency filter
+ *    (:770-772); returns 0 when the filter drops it.  The p-value filter (:795) is
+ *    applied by orc_chi2_keep below so that tests can look at both.
+ * ------------------------------------------------------------------------------------------ */
+int orc_chi2_row(const uint8_t *presence, const int8_t *pheno, const double *weight, int n_samples,
+                 int min_samples, int max_samples, double *chi2_out, double *p_out, int *n_with_out)
+{
+    double w_pheno_w_kmer = 0, w_pheno_wo_kmer = 0, wo_pheno_w_kmer = 0, wo_pheno_wo_kmer = 0;
+    int n_with = 0, n_without = 0;
+    for (int i = 0; i < n_samples; i++) {
+        if (pheno[i] == 1) {
+            if (presence[i] != 0) { w_pheno_w_kmer += weight[i]; n_with++; }
+            else { w_pheno_wo_kmer += weight[i]; n_without++; }
+        } else if (pheno[i] == 0) {
+            if (presence[i] != 0) { wo_pheno_w_kmer += weight[i]; n_with++; }
+            else { wo_pheno_wo_kmer += weight[i]; n_without++; }
+        }
+    }
+    *n_with_out = n_with;
+    if (n_with < min_samples || n_without < 2 || n_with > max_samples) return 0;
+    double w_pheno = w_pheno_w_kmer + w_pheno_wo_kmer;
+    double wo_pheno = wo_pheno_w_kmer + wo_pheno_wo_kmer;
+    double w_kmer = w_pheno_w_kmer + wo_pheno_w_kmer;
+    double wo_kmer = w_pheno_wo_kmer + wo_pheno_wo_kmer;
+    double total = w_pheno + wo_pheno;
+    double obs[4] = {w_pheno_w_kmer, w_pheno_wo_kmer, wo_pheno_w_kmer, wo_pheno_wo_kmer};
+    double exp_[4] = {(w_pheno * w_kmer) / total, (w_pheno * wo_kmer) / total, (wo_pheno * w_kmer) / total,
+                      (wo_pheno * wo_kmer) / total};
+    double stat = 0.0;
+    for (int j = 0; j < 4; j++) {
+        double d = obs[j] - exp_[j];
+        stat += (d * d) / exp_[j]; /* 0/0 -> NaN, as numpy does */
+    }
+    *chi2_out = stat;
+    *p_out = exp(-0.5 * stat); /* chi2.sf(stat, df=2) */
+    return 1;
+}
+
+/* modeling.py:795 -- NaN compares false on both sides, so NaN rows are dropped. */
+int orc_chi2_keep(double p, double pvalue_cutoff, int omit_B, uint64_t n_kmers_to_analyse)
+{
+    return (omit_B && p < pvalue_cutoff) || (p < (pvalue_cutoff / (double)n_kmers_to_analyse));
+}
+
+/*
+ * orc_chi2_scan: the reference's hot loop (modeling.py:677-714 driving :759-798) over a
+ * bit-packed presence matrix: row r = words bits[r*wpr .. r*wpr+wpr), sample i = bit (i&63)
+ * of word i>>6.  For every row writes keep[r] (0/1), chi2[r], p[r], n_with[r]
+ * (chi2/p are NaN-free only where the frequency filter passed; 0 elsewhere).
+ * This is also the function bench.py times as cpu_baseline ("port", 1 thread).
+ */
+void orc_chi2_scan(const uint64_t *bits, uint64_t n_rows, int wpr, const int8_t *pheno, const double *weight,
+                   int n_samples, int min_samples, int max_samples, double pvalue_cutoff, int omit_B,
+                   uint64_t n_kmers_to_analyse, uint8_t *keep, double *chi2, double *p, int32_t *n_with)
+{
+    uint8_t *pres = (uint8_t *)malloc((size_t)n_samples + 1);
+    for (uint64_t r = 0; r < n_rows; r++) {
+        const uint64_t *row = bits + r * (uint64_t)wpr;
+        for (int i = 0; i < n_samples; i++) pres[i] = (uint8_t)((row[i >> 6] >> (i & 63)) & 1);
+        double c = 0, pv = 0;
+        int nw = 0;
+        int ok = orc_chi2_row(pres, pheno, weight, n_samples, min_samples, max_samples, &c, &pv, &nw);
+        n_with[r] = nw;
+        if (ok) {
+            chi2[r] = c;
+            p[r] = pv;
+            keep[r] = (uint8_t)orc_chi2_keep(pv, pvalue_cutoff, omit_B, n_kmers_to_analyse);
+        } else {
+            chi2[r] = 0;
+            p[r] = 0;
+            keep[r] = 0;
+        }
+    }
+    free(pres);
+}
+
+/* ------------------------------------------------------------------------------------------
+ * 4. Weighted Welch t-test of one k-mer row.
+ *    Follows phenotypes.conduct_t_test (modeling.py:716-741) with
+ *    get_samples_distribution_for_ttest (:743-757) and statsmodels
+ *    ttest_ind(x, y, usevar='unequal', weights=(xw, yw)) (:734) restated from its documented
+ *    algorithm: DescrStatsW with ddof=0, nobs = sum of weights,
+ *    std_meandiff_separatevar, Satterthwaite dof, two-sided Student-t survival function.
+ *    pheno[i] is the phenotype value, valid[i]==0 marks 'NA'.
+ *    Returns 1 when the row passes the frequency filter (:731).
+ * ------------------------------------------------------------------------------------------ */
+
+/* regularised incomplete beta I_x(a,b) by the Lentz continued fraction */
+static double betacf(double a, double b, double x)
+{
+    const double TINY = 1e-300, EPS = 1e-16;
+    double qab = a + b, qap = a + 1.0, qam = a - 1.0;
+    double c = 1.0, d = 1.0 - qab * x / qap;
+    if (fabs(d) < TINY) d = TINY;
+    d = 1.0 / d;
+    double h = d;
+    for (int m = 1; m <= 10000; m++) {
+        int m2 = 2 * m;
+        double aa = m * (b - m) * x / ((qam + m2) * (a + m2));
+        d = 1.0 + aa * d; if (fabs(d) < TINY) d = TINY;
+        c = 1.0 + aa / c; if (fabs(c) < TINY) c = TINY;
+        d = 1.0 / d;
+        h *= d * c;
+        aa = -(a + m) * (qab + m) * x / ((a + m2) * (qap + m2));
+        d = 1.0 + aa * d; if (fabs(d) < TINY) d = TINY;
+        c = 1.0 + aa / c; if (fabs(c) < TINY) c = TINY;
+        d = 1.0 / d;
+        double del = d * c;
+        h *= del;
+        if (fabs(del - 1.0) < EPS) break;
+    }
+    return h;
+}
+
+double orc_betainc(double a, double b, double x)
+{
+    if (!(x > 0.0)) return (x == 0.0) ? 0.0 : NAN;
+    if (!(x < 1.0)) return (x == 1.0) ? 1.0 : NAN;
+    double lbt = lgamma(a + b) - lgamma(a) - lgamma(b) + a * log(x) + b * log1p(-x);
+    double bt = exp(lbt);
+    if (x < (a + 1.0) / (a + b + 2.0)) return bt * betacf(a, b, x) / a;
+    return 1.0 - bt * betacf(b, a, 1.0 - x) / b;
+}
+
+/* two-sided p-value of Student's t with df degrees of freedom: 2*sf(|t|) = I_{df/(df+t^2)}(df/2, 1/2) */
+double orc_t_two_sided_p(double t, double df)
+{
+    if (isnan(t) || isnan(df) || !(df > 0)) return NAN;
+    if (isinf(t)) return 0.0;
+    double x = df / (df + t * t);
+    return orc_betainc(0.5 * df, 0.5, x);
+}
+
+int orc_ttest_row(const uint8_t *presence, const double *pheno, const uint8_t *valid, const double *weight,
+                  int n_samples, int min_samples, int max_samples, double *t_out, double *p_out,
+                  double *mean_x_out, double *mean_y_out, int *n_with_out)
+{
+    double nx = 0, ny = 0, sx = 0, sy = 0;
+    int cx = 0, cy = 0;
+    for (int i = 0; i < n_samples; i++) {
+        if (!valid[i]) continue;
+        if (presence[i] == 0) { ny += weight[i]; sy += weight[i] * pheno[i]; cy++; }
+        else { nx += weight[i]; sx += weight[i] * pheno[i]; cx++; }
+    }
+    *n_with_out = cx;
+    if (cx < min_samples || cy < 2 || cx > max_samples) return 0;
+    double mx = sx / nx, my = sy / ny;
+    double qx = 0, qy = 0;
+    for (int i = 0; i < n_samples; i++) {
+        if (!valid[i]) continue;
+        if (presence[i] == 0) { double d = pheno[i] - my; qy += weight[i] * d * d; }
+        else { double d = pheno[i] - mx; qx += weight[i] * d * d; }
+    }
+    double vx = qx / nx, vy = qy / ny;          /* ddof = 0 */
+    double sem1 = vx / (nx - 1.0), sem2 = vy / (ny - 1.0);
+    double semsum = sem1 + sem2;
+    double t = (mx - my) / sqrt(semsum);
+    double z1 = (sem1 / semsum) * (sem1 / semsum) / (nx - 1.0);
+    double z2 = (sem2 / semsum) * (sem2 / semsum) / (ny - 1.0);
+    double df = 1.0 / (z1 + z2);
+    *t_out = t;
+    *p_out = orc_t_two_sided_p(t, df);
+    *mean_x_out = mx;
+    *mean_y_out = my;
+    return 1;
+}
+
+/* modeling.py:738 -- the t-test path always applies Bonferroni (omit_B is not consulted). */
+int orc_ttest_keep(double p, double pvalue_cutoff, uint64_t n_kmers_to_analyse)
+{
+    return p < (pvalue_cutoff / (double)n_kmers_to_analyse);
+}
+
+void orc_ttest_scan(const uint64_t *bits, uint64_t n_rows, int wpr, const double *pheno, const uint8_t *valid,
+                    const double *weight, int n_samples, int min_samples, int max_samples, double pvalue_cutoff,
+                    uint64_t n_kmers_to_analyse, uint8_t *keep, double *t, double *p, double *mean_x,
+                    double *mean_y, int32_t *n_with)
+{
+    uint8_t *pres = (uint8_t *)malloc((size_t)n_samples + 1);
+    for (uint64_t r = 0; r < n_rows; r++) {
+        const uint64_t *row = bits + r * (uint64_t)wpr;
+        for (int i = 0; i < n_samples; i++) pres[i] = (uint8_t)((row[i >> 6] >> (i & 63)) & 1);
+        double tt = 0, pv = 0, mx = 0, my = 0;
+        int nw = 0;
+        int ok = orc_ttest_row(pres, pheno, valid, weight, n_samples, min_samples, max_samples, &tt, &pv, &mx,
+                               &my, &nw);
+        n_with[r] = nw;
+        t[r] = ok ? tt : 0;
+        p[r] = ok ? pv : 0;
+        mean_x[r] = ok ? mx : 0;
+        mean_y[r] = ok ? my : 0;
+        keep[r] = (uint8_t)(ok && orc_ttest_keep(pv, pvalue_cutoff, n_kmers_to_analyse));
+    }
+    free(pres);
+}
+
+/* ------------------------------------------------------------------------------------------
+ * 5. Fixed-dictionary k-mer counting (prediction path).
+ *    Replaces `gmer_counter -db <txt> <file>` (prediction.py:72-80): for every dictionary
+ *    k-mer the number of windows of the input whose canonical form equals the dictionary
+ *    k-mer's canonical form (both strands, with multiplicity).  dict_words must be canonical.
+ * ------------------------------------------------------------------------------------------ */
+int orc_count_dict(const uint8_t *buf, size_t len, int k, const uint64_t *dict_words, uint64_t n_dict,
+                   uint32_t *counts_out)
+{
+    u64vec v = {0, 0, 0};
+    if (tokenize(buf, len, k, &v)) { free(v.v); return -1; }
+    if (radix_sort_u64(v.v, v.n, 2 * k)) { free(v.v); return -1; }
+    for (uint64_t d = 0; d < n_dict; d++) {
+        uint64_t key = dict_words[d];
+        size_t lo = 0, hi = v.n;
+        while (lo < hi) { size_t mid = (lo + hi) / 2; if (v.v[mid] < key) lo = mid + 1; else hi = mid; }
+        size_t first = lo;
+        hi = v.n;
+        while (lo < hi) { size_t mid = (lo + hi) / 2; if (v.v[mid] <= key) lo = mid + 1; else hi = mid; }
+        counts_out[d] = (uint32_t)(lo - first);
+    }
+    free(v.v);
+    return 0;
+}
+
+/* ------------------------------------------------------------------------------------------
+ * 6. Model stage oracles (converged optima of the estimators the reference asks
+ *    scikit-learn 0.22.1 for; modeling.py:999-1014, :1208-1216).  Pinned by
+ *    tests/golden/model_kat.npz (scikit-learn fits at tol 1e-10).
+ *
+ *    orc_logreg_l1_fit: liblinear L1R_LR objective
+ *        ||w||_1 + |b| + C * sum_i log(1 + exp(-y_i (w.x_i + b))),  y in {-1,+1},
+ *    intercept = penalised constant-1 feature; cyclic coordinate descent with 1-D Newton
+ *    steps and backtracking (CDN, Yuan et al. 2010).  X row-major n x p.
+ * ------------------------------------------------------------------------------------------ */
+static double log1pexp(double x) /* log(1+exp(x)) without overflow */
+{
+    if (x > 35.0) return x;
+    if (x < -35.0) return exp(x);
+    return log1p(exp(x));
+}
+
+int orc_logreg_l1_fit(const double *X, const int32_t *y01, int n, int p, double C, double tol, int max_sweeps,
+                      double *w_out, double *b_out)
+{
+    double *w = (double *)calloc((size_t)p + 1, sizeof(double));
+    double *z = (double *)calloc((size_t)n, sizeof(double));
+    double *ypm = (double *)malloc((size_t)n * sizeof(double));
+    double *xj = (double *)malloc((size_t)n * sizeof(double));
+    if (!w || !z || !ypm || !xj) return -1;
+    for (int i = 0; i < n; i++) ypm[i] = y01[i] ? 1.0 : -1.0;
+    const double sigma = 0.01, beta = 0.5;
+    int sweep;
+    for (sweep = 0; sweep < max_sweeps; sweep++) {
+        double viol_max = 0.0;
+        for (int j = 0; j <= p; j++) {
+            for (int i = 0; i < n; i++) xj[i] = (j < p) ? X[(size_t)i * p + j] : 1.0;
+            double g = 0.0, h = 0.0, loss0 = 0.0;
+            for (int i = 0; i < n; i++) {
+                double yz = ypm[i] * z[i];
+                double s = 1.0 / (1.0 + exp(-yz));
+                g += (s - 1.0) * ypm[i] * xj[i];
+                h += xj[i] * xj[i] * s * (1.0 - s);
+                loss0 += log1pexp(-yz);
+            }
+            g *= C; h = h * C + 1e-12; loss0 *= C;
+            double wj = w[j], v;
+            if (wj > 0) v = fabs(g + 1.0);
+            else if (wj < 0) v = fabs(g - 1.0);
+            else { v = 0.0; if (g - 1.0 > v) v = g - 1.0; if (-1.0 - g > v) v = -1.0 - g; }
+            if (v > viol_max) viol_max = v;
+            if (v < 1e-16) continue;
+            double d;
+            if (g + 1.0 <= h * wj) d = -(g + 1.0) / h;
+            else if (g - 1.0 >= h * wj) d = -(g - 1.0) / h;
+            else d = -wj;
+            if (d == 0.0) continue;
+            double delta = g * d + fabs(wj + d) - fabs(wj);
+            double lam = 1.0;
+            int ok = 0;
+            for (int it = 0; it < 60; it++) {
+                double loss = 0.0;
+                for (int i = 0; i < n; i++) loss += log1pexp(-ypm[i] * (z[i] + lam * d * xj[i]));
+                double diff = fabs(wj + lam * d) - fabs(wj) + C * loss - loss0;
+                if (diff <= sigma * lam * delta) { ok = 1; break; }
+                lam *= beta;
+            }
+            if (!ok) continue;
+            w[j] = wj + lam * d;
+            for (int i = 0; i < n; i++) z[i] += lam * d * xj[i];
+        }
+        if (viol_max < tol) break;
+    }
+    memcpy(w_out, w, (size_t)p * sizeof(double));
+    *b_out = w[p];
+    free(w); free(z); free(ypm); free(xj);
+    return sweep;
+}
+
+/*    orc_lasso_fit: sklearn Lasso objective (1/2n)||y - Xw - b||^2 + alpha ||w||_1 with an
+ *    unpenalised intercept (fit on centred data), cyclic coordinate descent. */
+int orc_lasso_fit(const double *X, const double *y, int n, int p, double alpha, double tol, int max_sweeps,
+                  double *w_out, double *b_out)
+{
+    double *Xc = (double *)malloc((size_t)n * p * sizeof(double)); /* column-major centred */
+    double *xm = (double *)calloc((size_t)p, sizeof(double));
+    double *norms = (double *)calloc((size_t)p, sizeof(double));
+    double *r = (double *)malloc((size_t)n * sizeof(double));
+    double *w = (double *)calloc((size_t)p, sizeof(double));
+    if (!Xc || !xm || !norms || !r || !w) return -1;
+    double ym = 0.0;
+    for (int i = 0; i < n; i++) ym += y[i];
+    ym /= n;
+    for (int j = 0; j < p; j++) {
+        double s = 0.0;
+        for (int i = 0; i < n; i++) s += X[(size_t)i * p + j];
+        xm[j] = s / n;
+        for (int i = 0; i < n; i++) {
+            double v = X[(size_t)i * p + j] - xm[j];
+            Xc[(size_t)j * n + i] = v;
+            norms[j] += v * v;
+        }
+    }
+    for (int i = 0; i < n; i++) r[i] = y[i] - ym;
+    int sweep;
+    for (sweep = 0; sweep < max_sweeps; sweep++) {
+        double dmax = 0.0, wmax = 0.0;
+        for (int j = 0; j < p; j++) {
+            if (norms[j] == 0.0) continue;
+            const double *xc = Xc + (size_t)j * n;
+            double wj = w[j], rho = 0.0;
+            for (int i = 0; i < n; i++) rho += xc[i] * r[i];
+            rho += norms[j] * wj;
+            double mag = fabs(rho) - alpha * n;
+            double nw = (mag > 0.0) ? (rho > 0 ? mag : -mag) / norms[j] : 0.0;
+            if (nw != wj) {
+                double dd = nw - wj;
+                for (int i = 0; i < n; i++) r[i] -= dd * xc[i];
+                w[j] = nw;
+            }
+            if (fabs(nw - wj) > dmax) dmax = fabs(nw - wj);
+            if (fabs(nw) > wmax) wmax = fabs(nw);
+        }
+        if (dmax == 0.0 || dmax <= tol * (wmax > 1e-300 ? wmax : 1e-300)) break;
+    }
+    double b = ym;
+    for (int j = 0; j < p; j++) { w_out[j] = w[j]; b -= xm[j] * w[j]; }
+    *b_out = b;
+    free(Xc); free(xm); free(norms); free(r); free(w);
+    return sweep;
+}

@@ -1,0 +1,172 @@
+"""CPU tests: the oracle (oracle/) against the fixtures captured from the reference itself
+(tests/golden/, generator oracle/gen_golden.py).  This is what pins the oracle."""
+import hashlib
+import json
+import os
+
+import numpy as np
+import pytest
+
+from helpers import GOLDEN, load_dataset, read_results_tsv, tokenizer_cases
+
+
+def test_tokenizer_cases_byte_identical_to_glistmaker(oracle):
+    cases = tokenizer_cases()
+    assert len(cases) > 100
+    for data, k, ref in cases:
+        w, f, nt = oracle.count_kmers(data, k)
+        if ref is None:
+            assert len(w) == 0
+        else:
+            assert oracle.list_bytes(k, w, f) == ref, (data[:60], k)
+
+
+@pytest.mark.parametrize("tag", ["ds_omitB", "ds_bonf"])
+def test_dataset_lists_union_mapping(oracle, tag):
+    ds = load_dataset(tag)
+    k = ds["meta"]["k"]
+    lists = {}
+    for name in ds["names"]:
+        w, f, nt = oracle.count_kmers(ds["files"][name], k)
+        img = oracle.list_bytes(k, w, f)
+        m = ds["meta"]["lists"][name]
+        assert (len(w), nt) == (m["n_unique"], m["n_total"])
+        assert hashlib.sha256(img).hexdigest() == m["sha256"], name
+        lists[name] = (w, f)
+    first = ds["names"][0]
+    with open(os.path.join(ds["dir"], "%s_0_%d.list" % (first, k)), "rb") as fh:
+        assert fh.read() == oracle.list_bytes(k, *lists[first])
+    # glistcompare -u : key set and summed frequencies
+    uw, uf = oracle.union_freqs([lists[n] for n in ds["names"]])
+    assert np.array_equal(uw, np.load(os.path.join(ds["dir"], "union_words.npy")))
+    assert np.array_equal(uf, np.load(os.path.join(ds["dir"], "union_freqs.npy")))
+    assert hashlib.sha256(oracle.list_bytes(k, uw, uf)).hexdigest() == ds["meta"]["union_sha256"]
+    assert np.array_equal(uw, oracle.union([lists[n][0] for n in ds["names"]]))
+    # glistquery -l : text mapping of one sample onto the union
+    ms = ds["meta"]["mapped_sample"]
+    counts = oracle.map_counts(lists[ms][0], lists[ms][1], uw)
+    txt = "".join("%s\t%d\n" % (oracle.word_to_kmer(w, k), c) for w, c in zip(uw, counts))
+    assert hashlib.sha256(txt.encode()).hexdigest() == ds["meta"]["mapped_sha256"]
+
+
+def _oracle_rows(oracle, ds, omit_B, pvalue=0.05):
+    k = ds["meta"]["k"]
+    names = ds["names"]
+    wl = [oracle.count_kmers(ds["files"][n], k)[0] for n in names]
+    uw = oracle.union(wl)
+    bits = oracle.presence_bits(wl, uw)
+    n = len(names)
+    res = oracle.chi2_scan(bits, ds["pheno"], np.ones(n), n, 2, n - 2, pvalue, omit_B, len(uw))
+    rows = {}
+    for r in np.nonzero(res["keep"])[0]:
+        pres = [(int(bits[r, i >> 6]) >> (i & 63)) & 1 for i in range(n)]
+        with_names = [names[i] for i in range(n) if pres[i] and ds["pheno"][i] != "NA"]
+        rows[oracle.word_to_kmer(uw[r], k)] = (repr(oracle.round2(res["stat"][r])), oracle.pstring(res["p"][r]),
+                                                str(int(res["n_with"][r])), " ".join(["|"] + with_names), pres)
+    return rows
+
+
+@pytest.mark.parametrize("tag,omit_B", [("ds_omitB", True), ("ds_bonf", False)])
+def test_chi2_results_tsv_matches_reference(oracle, tag, omit_B):
+    ds = load_dataset(tag)
+    rows = _oracle_rows(oracle, ds, omit_B)
+    header, ref = read_results_tsv(os.path.join(ds["dir"], "chi2_results_Pheno.tsv"))
+    assert header == ["k-mer", "chi2", "p-value", "num_samples_w_kmer", "samples_with_kmer"]
+    assert len(ref) > 50
+    assert {r[0] for r in ref} == set(rows)
+    for kmer, stat, p, nw, nm in ref:
+        assert rows[kmer][:4] == (stat, p, nw, nm), kmer
+    # ordering contract (a9): p-value strings ascending lexicographically
+    order = oracle.select_order([r[0] for r in ref], [r[2] for r in ref])
+    assert [ref[i][2] for i in order] == [r[2] for r in ref]
+    # the MLdf.csv presence columns
+    import csv
+    with open(os.path.join(ds["dir"], "Pheno_MLdf.csv")) as f:
+        rd = list(csv.reader(f))
+    cols = rd[0][1:-2]
+    non_na = [i for i, p in enumerate(ds["pheno"]) if p != "NA"]
+    assert [r[0] for r in rd[1:]] == [ds["names"][i] for i in non_na]
+    for j, kmer in enumerate(cols):
+        assert [int(r[1 + j]) for r in rd[1:]] == [rows[kmer][4][i] for i in non_na]
+    assert [int(float(r[-1])) for r in rd[1:]] == [ds["pheno"][i] for i in non_na]
+
+
+def test_chi2_kats_from_reference_function(oracle):
+    with open(os.path.join(GOLDEN, "chi2_kat.json")) as f:
+        cases = json.load(f)["cases"]
+    kept = 0
+    for c in cases:
+        assert c["result"] != "ValueError"
+        r = oracle.chi2_row(c["presence"], c["pheno"], c["weights"], c["min"], c["max"])
+        if r is not None and not oracle.chi2_keep(r[1], c["pvalue_cutoff"], c["omit_B"], c["n_kmers"]):
+            r = None
+        if c["result"] is None:
+            assert r is None, c
+            continue
+        kept += 1
+        assert r is not None, c
+        ref = c["result"]
+        assert oracle.round2(r[0]) == ref[1]
+        assert oracle.pstring(r[1]) == ref[2]
+        assert r[2] == ref[3]
+    assert kept > 100
+
+
+def test_welch_kats(oracle):
+    with open(os.path.join(GOLDEN, "welch_kat.json")) as f:
+        d = json.load(f)
+    for c in d["t_sf"]:
+        assert oracle.t_two_sided_p(c["t"], c["df"]) == pytest.approx(c["p"], rel=1e-10, abs=1e-300)
+    for c in d["cases"]:
+        r = oracle.ttest_row(c["presence"], c["values"], c["weights"], 1, len(c["values"]))
+        assert r is not None
+        t, p, mx, my, nw = r
+        assert t == pytest.approx(c["t"], rel=1e-9)
+        assert p == pytest.approx(c["p"], rel=1e-8, abs=1e-300)
+        assert mx == pytest.approx(c["mean_x"], rel=1e-12)
+        assert my == pytest.approx(c["mean_y"], rel=1e-12)
+        assert nw == sum(c["presence"])
+
+
+def test_gmer_counter_outputs(oracle):
+    import base64
+    import gzip
+    with open(os.path.join(GOLDEN, "gmer_counter.json")) as f:
+        d = json.load(f)
+    k = d["k"]
+    words = [oracle.canonical_word(oracle.kmer_to_word(km), k) for km in d["kmers"]]
+    for c in d["cases"]:
+        fa = gzip.decompress(base64.b64decode(c["fasta_gz_b64"]))
+        counts = oracle.count_dict(fa, k, words)
+        lines = c["output"].splitlines()
+        assert lines[0].startswith("#") and lines[1].startswith("#")
+        body = [l.split("\t") for l in lines[2:]]
+        assert [b[0] for b in body] == d["kmers"]
+        assert [int(b[2]) for b in body] == counts.tolist()
+
+
+def test_model_oracle_against_converged_sklearn():
+    from oracle import oracle_model as OM
+    z = np.load(os.path.join(GOLDEN, "model_kat.npz"))
+    for tag in ("1", "2"):
+        X, y = z["X" + tag], z["y" + tag]
+        cv = int(min(np.bincount(y).min(), 10))
+        assert np.array_equal(OM.stratified_kfold(y, cv), z["skf_folds" + tag])
+        # C=1000 on the 18-sample, near-separable design 1 is ill-conditioned for plain CDN
+        # (0.15 % above liblinear's optimum after 2000 sweeps) -- not used as a pin
+        for ci in ((3, 4, 6, 9, 12) if tag == "1" else (0, 4, 6, 9, 12)):
+            C = float(z["Cs"][ci])
+            w, b = OM.logreg_l1_fit(X, y, C, tol=1e-9, max_sweeps=20000)
+            obj = OM.logreg_l1_objective(X, y, w, b, C)
+            ref_obj = float(z["logreg_obj" + tag][ci])
+            assert obj <= ref_obj * (1 + 1e-6) + 1e-9
+            assert obj == pytest.approx(ref_obj, rel=2e-5)
+    X2, yc2 = z["X2"], z["yc2"]
+    assert np.array_equal(OM.kfold(len(yc2), 10), z["kf_folds2"])
+    for ai in (0, 3, 5, 6, 8):
+        w, b = OM.lasso_fit(X2, yc2, float(z["alphas"][ai]))
+        assert np.allclose(w, z["lasso_coef2"][ai], rtol=1e-7, atol=1e-9)
+        assert b == pytest.approx(float(z["lasso_icpt2"][ai]), rel=1e-8)
+    gs = OM.grid_search(X2, yc2, [float(a) for a in z["alphas"]], "lasso", 10)
+    assert np.allclose(gs["mean_test_score"], z["lasso_gs_mean_score2"], rtol=1e-6, atol=1e-8)
+    assert float(z["alphas"][gs["best_index"]]) == float(z["lasso_gs_best_alpha2"])
