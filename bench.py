@@ -1,0 +1,168 @@
+#!/usr/bin/env python3
+"""bench.py -- the north-star metric on MI355X: k-mer x sample chi-squared cells per second.
+
+  python bench.py [--gpus N --steps K --warmup W]            (N = 1: plain process)
+  python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N ...   (one rank per GPU)
+
+Workload (BASELINE.json configs[1]): synthetic 256 x 5-Mbp FASTA, binary phenotype, k = 13.
+The genome set is generated on the host, every sample is counted on the GPU (psk_count_kmers)
+and the union + bit-packed presence matrix is built on the GPU (psk_build_presence) BEFORE the
+timed region; the matrix is then resident in HBM.  One "step" = one pass of the chi-squared
+scan + filter over the whole resident matrix (psk_chi2_scan: kernel, survivor count read-back),
+followed on N > 1 by the two collectives of the sharded path (all-reduce of the union size,
+all-gather of the survivors).  value = rows x samples x steps / wall time, whole job.
+
+N > 1 is weak scaling: every rank owns one slab of the word space and the slabs are the same
+size at every N (rank r's slab is generated from seed + r), so per-GPU work is fixed.
+
+Printed JSON also carries "roofline" (dominant kernel = chi2_scan_kernel, HBM-bound; achieved =
+algorithmic bytes / mean HIP-event duration of the kernel over the timed steps) and
+"cpu_baseline" (the C oracle's scan, one thread, on a bounded sample of the same rows).
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: 8 TB/s spec (6.3 TB/s measured float4 copy)
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=50)
+    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--samples", type=int, default=256)
+    ap.add_argument("--length", type=int, default=5_000_000)
+    ap.add_argument("--kmer", type=int, default=13)
+    ap.add_argument("--workload", default="fasta", choices=["fasta", "matrix"],
+                    help="fasta: count synthetic genomes on the GPU (default, BASELINE cfg 2); "
+                         "matrix: device-generated presence matrix of --rows rows (quick runs)")
+    ap.add_argument("--rows", type=int, default=1 << 25)
+    ap.add_argument("--cpu-sample-rows", type=int, default=1_500_000)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    args = ap.parse_args()
+
+    from phenotypeseeker_amd import dist as psk_dist
+    from phenotypeseeker_amd.engine import PskContext
+    from phenotypeseeker_amd.synth import GenomeSet
+
+    grp = psk_dist.Group()
+    if grp.world != args.gpus:
+        if grp.world == 1 and args.gpus > 1:
+            sys.exit("bench.py --gpus %d must be launched with torch.distributed.run (one rank per GPU)" % args.gpus)
+    grp.init()
+    rank, world = grp.rank, grp.world
+    n, k = args.samples, args.kmer
+
+    ctx = PskContext(grp.local_rank)
+    info = ctx.device_info()
+    t_setup = time.time()
+    pheno = np.array([1 if i % 2 == 0 else 0 for i in range(n)], dtype=np.int8)
+    ingest = {}
+    if args.workload == "fasta":
+        gs = GenomeSet(n, args.length, seed=12345 + rank)
+        ctx.begin(k, n)
+        t_gen = t_cnt = 0.0
+        tot_unique = 0
+        for i in range(n):
+            t0 = time.time()
+            _, fa = gs.sample(i)
+            t1 = time.time()
+            nu, nt = ctx.count_kmers(i, fa)
+            t2 = time.time()
+            t_gen += t1 - t0
+            t_cnt += t2 - t1
+            tot_unique += nu
+        t0 = time.time()
+        M = ctx.build_presence()
+        t_build = time.time() - t0
+        ingest = {"generate_s": round(t_gen, 2), "count_s": round(t_cnt, 2), "presence_s": round(t_build, 2),
+                  "pairs": tot_unique, "bases": n * args.length}
+        workload = "synthetic %d x %.1f-Mbp FASTA, binary phenotype, k=%d" % (n, args.length / 1e6, k)
+    else:
+        M = args.rows
+        ctx.synth_presence(M, n, seed=7 + rank)
+        workload = "device-generated presence matrix %d rows x %d samples" % (M, n)
+    _, wpr, _ = ctx.presence_shape()
+    t_setup = time.time() - t_setup
+
+    M_global = grp.allreduce_sum(int(M))
+
+    def step():
+        npass = ctx.chi2_scan(pheno, None, 2, n - 2, 0.05, False, M_global)
+        ms = ctx.last_scan_ms()
+        if world > 1:
+            # the sharded path's exchange: global union size, then the survivors of every slab
+            grp.allreduce_sum(int(M))
+            res = ctx.get_results(npass)
+            bits = ctx.get_rows(res["row"])
+            psk_dist.merge_candidates(grp.allgather_bytes(psk_dist.pack_candidates(res, bits)))
+        return npass, ms
+
+    for _ in range(args.warmup):
+        npass, _ = step()
+    grp.barrier()
+    kernel_ms = []
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        npass, ms = step()
+        kernel_ms.append(ms)
+    grp.barrier()
+    elapsed = time.perf_counter() - t0
+    elapsed = grp.allreduce_max(elapsed)
+    cells_total = grp.allreduce_sum(int(M) * n) * args.steps
+    value = cells_total / elapsed
+
+    # roofline of the dominant kernel (this rank): algorithmic bytes = M * 8 * ceil(N/64)
+    # (1 bit per cell; the kernel does not read the key array)
+    alg_words = (n + 63) // 64
+    alg_bytes = M * 8 * alg_words
+    mean_ms = float(np.mean(kernel_ms))
+    achieved = alg_bytes / (mean_ms * 1e-3) / 1e9
+    out = {
+        "metric": "k-mer x sample chi2 cells/sec", "value": value, "unit": "cells/s", "n_gpus": world,
+        "steps": args.steps, "warmup": args.warmup, "ms_per_step": elapsed / args.steps * 1e3,
+        "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "u64 popcount + f64",
+        "data": "synthetic",
+        "config": {"workload": workload, "n_samples": n, "k": k, "rows_per_gpu": int(M),
+                   "words_per_row_stored": wpr, "survivors": int(npass), "device": info["name"],
+                   "setup_s": round(t_setup, 2), "ingest": ingest},
+        "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                     "frac": achieved / HBM_PEAK_GBS, "traffic": None, "kernel": "chi2_scan_kernel",
+                     "kernel_ms": mean_ms, "algorithmic_bytes_per_launch": alg_bytes,
+                     "stored_bytes_per_launch": int(M) * 8 * wpr},
+    }
+
+    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+        # CPU baseline: the oracle's scan (C restatement of modeling.py:677-858, "port"), one
+        # thread, on the first rows of the same matrix; checked equal to the GPU's answer first.
+        from oracle import oracle as O
+        ns = int(min(args.cpu_sample_rows, M))
+        rows = ctx.get_rows(np.arange(ns, dtype=np.uint64))
+        t0 = time.perf_counter()
+        ref = O.chi2_scan(rows, pheno.tolist(), np.ones(n), n, 2, n - 2, 0.05, False, M_global)
+        dt = time.perf_counter() - t0
+        res = ctx.get_results(npass)
+        sel = res["row"] < ns
+        same = bool(np.array_equal(res["row"][sel], np.nonzero(ref["keep"])[0].astype(np.uint64)) and
+                    np.allclose(res["stat"][sel], ref["stat"][ref["keep"]], rtol=1e-12))
+        out["cpu_baseline"] = {"value": ns * n / dt, "unit": "cells/s", "cores": 1, "kind": "port",
+                               "sample": "first %d rows of the same matrix (%d samples), oracle/psk_oracle.c "
+                                         "orc_chi2_scan, %.1f s" % (ns, n, dt),
+                               "matches_gpu": same,
+                               "reference_python_8proc_cells_per_s": 7.4e6}
+    if rank == 0:
+        print(json.dumps(out))
+    ctx.close()
+    grp.close()
+
+
+if __name__ == "__main__":
+    main()

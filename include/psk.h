@@ -1,0 +1,162 @@
+/*
+ * psk.h -- C ABI of libpsk.so, the MI355X (gfx950) k-mer association engine that replaces the
+ * hot path of bioinfo-ut/PhenotypeSeeker's `modeling` / `prediction` commands.
+ *
+ * Plain C: opaque context, caller-owned host buffers in and out, sizes as integers, every
+ * function returns 0 on success or a negative PSK_E* code (psk_last_error() has the text).
+ * No torch types, no C++ types.  One context drives one GPU from one host thread; create one
+ * context per rank for multi-GPU runs (the k-mer word space is range-sharded, see psk_begin).
+ *
+ * Each entry point cites the reference interface it replaces (paths under /root/reference;
+ * modeling.py = PhenotypeSeeker/modeling.py, prediction.py = PhenotypeSeeker/prediction.py).
+ * The reference's own boundary for this path is a set of subprocess command lines plus Python
+ * methods; INTEGRATION.md shows the ctypes stubs that rebind those call sites to this ABI.
+ */
+#ifndef PSK_H
+#define PSK_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct psk_ctx psk_ctx;
+
+enum {
+    PSK_OK = 0,
+    PSK_EINVAL = -1,   /* bad argument / call order */
+    PSK_ENOMEM = -2,   /* host or device allocation failed */
+    PSK_EHIP = -3,     /* a HIP runtime call failed */
+    PSK_ERANGE = -4,   /* caller buffer too small / size limit exceeded */
+    PSK_ESTATE = -5    /* required earlier stage has not been run */
+};
+
+/* ---- lifecycle --------------------------------------------------------------------------- */
+
+/* Binds a context to HIP device `device` (creates its stream and timing events). */
+int psk_init(int device, psk_ctx **ctx_out);
+void psk_free(psk_ctx *ctx);
+/* Text of the last error on this context (or of the failed psk_init when ctx is NULL). */
+const char *psk_last_error(const psk_ctx *ctx);
+/* ABI version of the library: (major << 16) | minor. */
+int psk_version(void);
+/* Device facts for reports: name (NUL-terminated, truncated to name_cap), CU count, HBM bytes. */
+int psk_device_info(psk_ctx *ctx, char *name, int name_cap, int *n_cu, uint64_t *hbm_bytes);
+
+/*
+ * Starts a k-mer run: word length k (1..32; modeling.py:161 `-l`), the number of samples that
+ * will be counted, and this context's shard [slab_lo, slab_hi) of the canonical 2k-bit word
+ * space (slab_hi == 0 means "to the end"; one GPU: 0, 0).  Drops all state of a previous run.
+ */
+int psk_begin(psk_ctx *ctx, int k, int n_samples, uint64_t slab_lo, uint64_t slab_hi);
+
+/* ---- a1: per-sample k-mer list ------------------------------------------------------------
+ * Replaces `glistmaker <addr> -o K-mer_lists/<name>_0 -w <k> -c <cutoff>`
+ * (Samples.get_kmer_lists, modeling.py:303-315; bundled binary bin/glistmaker 4.2.3).
+ * `bytes` is the inflated FASTA/FASTQ file image.  The sorted canonical list (words + u32
+ * frequencies, exactly the records of glistmaker's .list file, restricted to the slab) stays
+ * in HBM under `sample_idx`; n_unique / n_total report its size.  As in the bundled binary,
+ * no frequency cut-off is applied.
+ */
+int psk_count_kmers(psk_ctx *ctx, int sample_idx, const uint8_t *bytes, size_t len, uint64_t *n_unique,
+                    uint64_t *n_total);
+/* Copies sample_idx's list to the host (for writing .list files / parity checks). */
+int psk_get_list(psk_ctx *ctx, int sample_idx, uint64_t *words, uint32_t *freqs, uint64_t cap);
+/* Frequencies of `n` given canonical words in sample_idx's list (0 if absent): the
+ * `glistquery <sample>.list -l` mapping of modeling.py:324-329 restricted to the k-mers the
+ * caller still needs (--real_counts columns of the ML matrix, modeling.py:693-695). */
+int psk_lookup_counts(psk_ctx *ctx, int sample_idx, const uint64_t *words, uint64_t n, uint32_t *freqs);
+
+/* ---- a2+a3: feature vector (union) and the k-mer x sample presence matrix ------------------
+ * Replaces the `glistcompare -u` reduction tree (Samples.get_feature_vector / get_union,
+ * modeling.py:350-380) and the per-sample `glistquery ... -l feature_vector.list` + `split`
+ * text mapping (Samples.map_samples, modeling.py:317-348).  Result, resident in HBM:
+ *   words[M]            ascending canonical words of the union (this slab)
+ *   bits[M][wpr]        u64 words, sample i = bit (i & 63) of word (i >> 6), wpr even
+ * n_kmers = M is this slab's share of phenotypes.no_kmers_to_analyse (modeling.py:644).
+ */
+int psk_build_presence(psk_ctx *ctx, uint64_t *n_kmers);
+int psk_presence_shape(psk_ctx *ctx, uint64_t *n_kmers, int *words_per_row, int *n_samples);
+int psk_get_union(psk_ctx *ctx, uint64_t *words, uint64_t cap);
+/* Gathers `n` rows (by row index) of the matrix: bits_out[n][words_per_row]. */
+int psk_get_rows(psk_ctx *ctx, const uint64_t *row_idx, uint64_t n, uint64_t *bits_out);
+/* `--kmerDB`: keeps only rows whose word occurs in the (sorted, canonical) db word list --
+ * `glistcompare -i` of Samples.get_db_kmers, modeling.py:367-372. */
+int psk_intersect_db(psk_ctx *ctx, const uint64_t *db_words, uint64_t n_db, uint64_t *n_kmers);
+/* Loads an externally built matrix instead (tests, benchmarks): words may be NULL. */
+int psk_set_presence(psk_ctx *ctx, const uint64_t *words, const uint64_t *bits, uint64_t n_kmers,
+                     int words_per_row, int n_samples);
+/* Fills the resident matrix with a synthetic pattern on the device (benchmark only):
+ * row r is present in sample i with a probability that depends on r; see DESIGN.md. */
+int psk_synth_presence(psk_ctx *ctx, uint64_t n_kmers, int n_samples, uint64_t seed);
+
+/* ---- a4-a6: chi-squared scan ---------------------------------------------------------------
+ * Replaces phenotypes.get_kmers_tested + conduct_chi_squared_test and helpers
+ * (modeling.py:677-714, :759-858) for one binary phenotype.
+ *   pheno[n_samples]    1, 0, or -1 for 'NA' (modeling.py:122-126, :810/:817)
+ *   weights[n_samples]  GSC weights, or NULL for unit weights (modeling.py:284,:812-822)
+ *   min/max_samples     Samples.min_samples / max_samples (modeling.py:233-242,:770-772)
+ *   pvalue_cutoff, omit_B, n_kmers_global   the filter of modeling.py:795; n_kmers_global is
+ *                       the Bonferroni denominator = union size summed over all slabs
+ * Surviving rows are kept on the device; fetch them with psk_get_results.
+ */
+int psk_chi2_scan(psk_ctx *ctx, const int8_t *pheno, const double *weights, int min_samples, int max_samples,
+                  double pvalue_cutoff, int omit_B, uint64_t n_kmers_global, uint64_t *n_pass);
+
+/* ---- a7: weighted Welch t-test scan ---------------------------------------------------------
+ * Replaces conduct_t_test + get_samples_distribution_for_ttest (modeling.py:716-757) for one
+ * continuous phenotype; valid[i] == 0 marks 'NA'.  Bonferroni is always applied (:738).
+ */
+int psk_ttest_scan(psk_ctx *ctx, const double *pheno, const uint8_t *valid, const double *weights,
+                   int min_samples, int max_samples, double pvalue_cutoff, uint64_t n_kmers_global,
+                   uint64_t *n_pass);
+
+/* Results of the last scan, ascending by row index (= ascending k-mer).  Any pointer may be
+ * NULL.  stat = chi2 or t; mean_x / mean_y are filled by the t-test only. */
+int psk_get_results(psk_ctx *ctx, uint64_t *row_idx, uint64_t *words, double *stat, double *p, double *mean_x,
+                    double *mean_y, int32_t *n_with, uint64_t cap);
+/* HIP-event duration of the last scan kernel launch in milliseconds (for bench.py). */
+double psk_last_scan_ms(const psk_ctx *ctx);
+/* Re-launches the last chi2 scan `reps` times back to back on the context's stream and
+ * returns the mean kernel duration in ms measured with HIP events on that stream. */
+int psk_rescan_timed(psk_ctx *ctx, int reps, double *mean_ms);
+
+/* ---- a10: L1 models over the selected k-mers ------------------------------------------------
+ * Replaces the estimator fits behind GridSearchCV (modeling.py:994-1014, :1075-1085,
+ * :1208-1216): every (grid value, fold) pair and the refits are independent problems and are
+ * solved one per workgroup.
+ *   X[n][p]      row-major uint8 design matrix (presence, or counts with --real_counts)
+ *   fold[n]      test-fold id of each sample in 0..n_folds-1; a fit with fold id f trains on
+ *                samples whose fold != f; fit_fold[j] == -1 trains on all samples
+ *   fit_param[j] C (logistic) or alpha (lasso) of fit j;  n_fits fits in total
+ *   coef_out[n_fits][p], icpt_out[n_fits]
+ * Logistic: liblinear's L1R_LR objective ||w||_1 + |b| + C sum log(1+exp(-y(w.x+b))).
+ * Lasso: (1/2n)||y - Xw - b||^2 + alpha ||w||_1, unpenalised intercept.
+ */
+int psk_logreg_l1_fit(psk_ctx *ctx, const uint8_t *X, const int32_t *y01, int n, int p, const int32_t *fold,
+                      const double *fit_param, const int32_t *fit_fold, int n_fits, double tol, int max_iter,
+                      double *coef_out, double *icpt_out, int32_t *iters_out);
+int psk_lasso_fit(psk_ctx *ctx, const uint8_t *X, const double *y, int n, int p, const int32_t *fold,
+                  const double *fit_param, const int32_t *fit_fold, int n_fits, double tol, int max_iter,
+                  double *coef_out, double *icpt_out, int32_t *iters_out);
+
+/* ---- f1: fixed-dictionary counting (prediction) ---------------------------------------------
+ * Replaces `gmer_counter -db <txt> <addr>` (prediction.Samples.map_samples, prediction.py:72-80):
+ * occurrences, both strands with multiplicity, of each dictionary k-mer (canonical words) in
+ * the file image.  counts_out[n_dict], in dictionary order.
+ */
+int psk_count_dict(psk_ctx *ctx, const uint8_t *bytes, size_t len, int k, const uint64_t *dict_words,
+                   uint64_t n_dict, uint32_t *counts_out);
+
+/* ---- helpers shared with the host side ------------------------------------------------------ */
+/* Host-only: the cleaned sequence stream the tokeniser hands to the GPU (bases kept, window
+ * breaks collapsed to '\n', everything else dropped).  Returns the length written (<= len), or
+ * a negative code.  Exposed for tests of the tokeniser contract. */
+int64_t psk_frame_sequence(const uint8_t *bytes, size_t len, uint8_t *out, size_t out_cap);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* PSK_H */

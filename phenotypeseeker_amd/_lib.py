@@ -1,0 +1,75 @@
+"""ctypes binding of libpsk.so (include/psk.h).  Loading fails loudly: there is no CPU path."""
+import ctypes
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libpsk.so")
+
+
+class PskError(RuntimeError):
+    pass
+
+
+c = ctypes
+_u64p = c.POINTER(c.c_uint64)
+_SIGNATURES = {
+    # name: (restype, argtypes)   -- one entry per declaration in include/psk.h
+    "psk_init": (c.c_int, [c.c_int, c.POINTER(c.c_void_p)]),
+    "psk_free": (None, [c.c_void_p]),
+    "psk_last_error": (c.c_char_p, [c.c_void_p]),
+    "psk_version": (c.c_int, []),
+    "psk_device_info": (c.c_int, [c.c_void_p, c.c_char_p, c.c_int, c.POINTER(c.c_int), _u64p]),
+    "psk_begin": (c.c_int, [c.c_void_p, c.c_int, c.c_int, c.c_uint64, c.c_uint64]),
+    "psk_count_kmers": (c.c_int, [c.c_void_p, c.c_int, c.c_char_p, c.c_size_t, _u64p, _u64p]),
+    "psk_get_list": (c.c_int, [c.c_void_p, c.c_int, c.c_void_p, c.c_void_p, c.c_uint64]),
+    "psk_lookup_counts": (c.c_int, [c.c_void_p, c.c_int, c.c_void_p, c.c_uint64, c.c_void_p]),
+    "psk_build_presence": (c.c_int, [c.c_void_p, _u64p]),
+    "psk_presence_shape": (c.c_int, [c.c_void_p, _u64p, c.POINTER(c.c_int), c.POINTER(c.c_int)]),
+    "psk_get_union": (c.c_int, [c.c_void_p, c.c_void_p, c.c_uint64]),
+    "psk_get_rows": (c.c_int, [c.c_void_p, c.c_void_p, c.c_uint64, c.c_void_p]),
+    "psk_intersect_db": (c.c_int, [c.c_void_p, c.c_void_p, c.c_uint64, _u64p]),
+    "psk_set_presence": (c.c_int, [c.c_void_p, c.c_void_p, c.c_void_p, c.c_uint64, c.c_int, c.c_int]),
+    "psk_synth_presence": (c.c_int, [c.c_void_p, c.c_uint64, c.c_int, c.c_uint64]),
+    "psk_chi2_scan": (c.c_int, [c.c_void_p, c.c_void_p, c.c_void_p, c.c_int, c.c_int, c.c_double, c.c_int,
+                                c.c_uint64, _u64p]),
+    "psk_ttest_scan": (c.c_int, [c.c_void_p, c.c_void_p, c.c_void_p, c.c_void_p, c.c_int, c.c_int, c.c_double,
+                                 c.c_uint64, _u64p]),
+    "psk_get_results": (c.c_int, [c.c_void_p] + [c.c_void_p] * 7 + [c.c_uint64]),
+    "psk_last_scan_ms": (c.c_double, [c.c_void_p]),
+    "psk_rescan_timed": (c.c_int, [c.c_void_p, c.c_int, c.POINTER(c.c_double)]),
+    "psk_logreg_l1_fit": (c.c_int, [c.c_void_p, c.c_void_p, c.c_void_p, c.c_int, c.c_int, c.c_void_p, c.c_void_p,
+                                    c.c_void_p, c.c_int, c.c_double, c.c_int, c.c_void_p, c.c_void_p, c.c_void_p]),
+    "psk_lasso_fit": (c.c_int, [c.c_void_p, c.c_void_p, c.c_void_p, c.c_int, c.c_int, c.c_void_p, c.c_void_p,
+                                c.c_void_p, c.c_int, c.c_double, c.c_int, c.c_void_p, c.c_void_p, c.c_void_p]),
+    "psk_count_dict": (c.c_int, [c.c_void_p, c.c_char_p, c.c_size_t, c.c_int, c.c_void_p, c.c_uint64, c.c_void_p]),
+    "psk_frame_sequence": (c.c_int64, [c.c_char_p, c.c_size_t, c.c_void_p, c.c_size_t]),
+}
+
+_lib = None
+
+
+def load():
+    """Returns the bound library; raises PskError if libpsk.so is absent or unloadable."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise PskError("libpsk.so is missing (%s): build it with `python -c 'import __graft_entry__ as g; "
+                       "g.build()'` or `make -C phenotypeseeker_amd/csrc`; there is no CPU fallback" % LIB_PATH)
+    try:
+        lib = ctypes.CDLL(LIB_PATH)
+    except OSError as e:
+        raise PskError("cannot load %s: %s" % (LIB_PATH, e))
+    for name, (res, args) in _SIGNATURES.items():
+        try:
+            fn = getattr(lib, name)
+        except AttributeError:
+            raise PskError("libpsk.so does not export %s (stale build?)" % name)
+        fn.restype = res
+        fn.argtypes = args
+    _lib = lib
+    return lib
+
+
+def exported_names():
+    return sorted(_SIGNATURES)

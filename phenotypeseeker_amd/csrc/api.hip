@@ -1,0 +1,130 @@
+// Context lifecycle, error reporting and device-memory helpers of libpsk.so.
+#include "psk_internal.h"
+
+static thread_local std::string g_init_error;
+
+int psk_fail(psk_ctx *ctx, int code, const char *fmt, ...)
+{
+    char buf[512];
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(buf, sizeof buf, fmt, ap);
+    va_end(ap);
+    if (ctx) ctx->err = buf;
+    else g_init_error = buf;
+    return code;
+}
+
+int dev_reserve(psk_ctx *ctx, DevBuf &b, size_t bytes)
+{
+    if (bytes <= b.cap && b.p) return PSK_OK;
+    if (b.p) { (void)hipFree(b.p); b.p = nullptr; b.cap = 0; }
+    size_t want = bytes + bytes / 8 + 256;  // slack so that slowly growing samples do not realloc each time
+    hipError_t e = hipMalloc(&b.p, want);
+    if (e != hipSuccess) {
+        (void)hipGetLastError();
+        want = bytes ? bytes : 256;
+        e = hipMalloc(&b.p, want);
+    }
+    if (e != hipSuccess) {
+        b.p = nullptr;
+        return psk_fail(ctx, PSK_ENOMEM, "hipMalloc(%zu bytes) failed: %s", want, hipGetErrorString(e));
+    }
+    b.cap = want;
+    return PSK_OK;
+}
+
+void dev_release(DevBuf &b)
+{
+    if (b.p) (void)hipFree(b.p);
+    b.p = nullptr;
+    b.cap = 0;
+}
+
+void reset_lists(psk_ctx *ctx, int n_samples)
+{
+    for (auto &L : ctx->lists) {
+        if (L.words) (void)hipFree(L.words);
+        if (L.freqs) (void)hipFree(L.freqs);
+    }
+    ctx->lists.assign((size_t)(n_samples > 0 ? n_samples : 0), SampleList());
+}
+
+extern "C" int psk_version(void) { return (1 << 16) | 0; }
+
+extern "C" const char *psk_last_error(const psk_ctx *ctx) { return ctx ? ctx->err.c_str() : g_init_error.c_str(); }
+
+extern "C" int psk_init(int device, psk_ctx **ctx_out)
+{
+    if (!ctx_out) return PSK_EINVAL;
+    *ctx_out = nullptr;
+    int n = 0;
+    hipError_t e = hipGetDeviceCount(&n);
+    if (e != hipSuccess || n <= 0)
+        return psk_fail(nullptr, PSK_EHIP, "no HIP device available (%s)", hipGetErrorString(e));
+    if (device < 0 || device >= n) return psk_fail(nullptr, PSK_EINVAL, "device %d out of range (0..%d)", device, n - 1);
+    e = hipSetDevice(device);
+    if (e != hipSuccess) return psk_fail(nullptr, PSK_EHIP, "hipSetDevice failed: %s", hipGetErrorString(e));
+    psk_ctx *ctx = new (std::nothrow) psk_ctx();
+    if (!ctx) return psk_fail(nullptr, PSK_ENOMEM, "out of host memory");
+    ctx->device = device;
+    hipDeviceProp_t prop;
+    if (hipGetDeviceProperties(&prop, device) == hipSuccess) ctx->n_cu = prop.multiProcessorCount;
+    if (hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking) != hipSuccess ||
+        hipEventCreate(&ctx->ev0) != hipSuccess || hipEventCreate(&ctx->ev1) != hipSuccess) {
+        delete ctx;
+        return psk_fail(nullptr, PSK_EHIP, "stream/event creation failed");
+    }
+    *ctx_out = ctx;
+    return PSK_OK;
+}
+
+extern "C" void psk_free(psk_ctx *ctx)
+{
+    if (!ctx) return;
+    (void)hipSetDevice(ctx->device);
+    if (ctx->stream) (void)hipStreamSynchronize(ctx->stream);
+    reset_lists(ctx, 0);
+    DevBuf *bufs[] = {&ctx->raw, &ctx->keysA, &ctx->keysB, &ctx->hist, &ctx->scan_tmp, &ctx->flags, &ctx->starts,
+                      &ctx->misc, &ctx->union_words, &ctx->bits, &ctx->mask1, &ctx->mask0, &ctx->wts, &ctx->phe,
+                      &ctx->res, &ctx->res_count, &ctx->res_sorted};
+    for (DevBuf *b : bufs) dev_release(*b);
+    if (ctx->ev0) (void)hipEventDestroy(ctx->ev0);
+    if (ctx->ev1) (void)hipEventDestroy(ctx->ev1);
+    if (ctx->stream) (void)hipStreamDestroy(ctx->stream);
+    delete ctx;
+}
+
+extern "C" int psk_device_info(psk_ctx *ctx, char *name, int name_cap, int *n_cu, uint64_t *hbm_bytes)
+{
+    if (!ctx) return PSK_EINVAL;
+    hipDeviceProp_t prop;
+    PSK_HIP(ctx, hipGetDeviceProperties(&prop, ctx->device));
+    if (name && name_cap > 0) {
+        // gcnArchName tells gfx950 apart; name is the marketing string
+        snprintf(name, (size_t)name_cap, "%s (%s)", prop.name, prop.gcnArchName);
+    }
+    if (n_cu) *n_cu = prop.multiProcessorCount;
+    if (hbm_bytes) *hbm_bytes = (uint64_t)prop.totalGlobalMem;
+    return PSK_OK;
+}
+
+extern "C" int psk_begin(psk_ctx *ctx, int k, int n_samples, uint64_t slab_lo, uint64_t slab_hi)
+{
+    if (!ctx) return PSK_EINVAL;
+    if (k < 1 || k > 32) return psk_fail(ctx, PSK_EINVAL, "k-mer length must be 1..32, got %d", k);
+    if (n_samples < 1) return psk_fail(ctx, PSK_EINVAL, "n_samples must be >= 1");
+    if (slab_hi != 0 && slab_hi <= slab_lo) return psk_fail(ctx, PSK_EINVAL, "empty slab");
+    PSK_HIP(ctx, hipSetDevice(ctx->device));
+    reset_lists(ctx, n_samples);
+    ctx->k = k;
+    ctx->n_samples = n_samples;
+    ctx->slab_lo = slab_lo;
+    ctx->slab_hi = slab_hi;
+    ctx->n_kmers = 0;
+    ctx->have_presence = false;
+    ctx->last = ScanParams();
+    ctx->last_scan_kind = 0;
+    ctx->n_pass = 0;
+    return PSK_OK;
+}

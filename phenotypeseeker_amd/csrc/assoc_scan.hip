@@ -1,0 +1,591 @@
+// a4-a7: per-k-mer association scans over the bit-packed presence matrix.
+//
+// chi2_scan_kernel   replaces phenotypes.get_kmers_tested / conduct_chi_squared_test and helpers
+//                    (modeling.py:677-714, :759-858)
+// ttest_scan_kernel  replaces conduct_t_test / get_samples_distribution_for_ttest (:716-757)
+//
+// Layout: bits[M][wpr] u64, wpr even, so a row is wpr/2 16-byte chunks.  G = next power of two
+// >= wpr/2 lanes own one row; every lane issues one 16-byte load per row (global_load_dwordx4,
+// consecutive lanes -> consecutive addresses), popcounts its two words against the phenotype
+// masks and the group combines with xor-shuffles.  A wave covers 64/G rows per step and keeps
+// UNROLL steps of loads in flight.  HBM-read bound: 1 bit per k-mer x sample cell; no LDS, no MFMA.
+//
+// Exactness: the 2x2 table is integer (unit weights), and the statistic is evaluated with the
+// reference's own operation order in IEEE double (this file is compiled with -ffp-contract=off),
+// so round(chi2, 2) and "%.2E" % p come out string-identical.  The expensive exact evaluation only
+// runs on rows that a division-free test T*(ad-bc)^2 >= thr*R1*R0*K1*K0*(1-1e-9) cannot rule out.
+#include "dev_utils.h"
+#include "psk_internal.h"
+
+#include <algorithm>
+#include <cmath>
+#include <numeric>
+
+namespace {
+
+constexpr int SC_THREADS = 256;
+constexpr int SC_UNROLL = 4;
+typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+
+struct ScanArgs {
+    const u32x4 *bits;
+    uint64_t M;
+    int cpr;  // 16-byte chunks per row = wpr / 2
+    // chi2
+    const uint64_t *m1, *m0;   // phenotype == 1 / == 0 masks (wpr words each)
+    const double *w1, *w0;     // weights gated by phenotype (weighted only), wpr*64 entries
+    int n1, n0;                // popcounts of the masks
+    double W1, W0;             // weight totals of the two phenotype classes
+    // t-test
+    const uint64_t *mvalid;    // non-NA mask
+    const double *val, *wt;    // phenotype values and weights (0 where NA), wpr*64 entries
+    int nvalid;
+    // filters
+    int min_samples, max_samples;
+    double pcut, pcut_bonf, thr;  // thr: statistic threshold of the division-free pre-test
+    int omit_B;
+    // output (SoA), counter
+    uint64_t *res_row;
+    double *res_stat, *res_p, *res_mx, *res_my;
+    int32_t *res_nw;
+    uint32_t *counter;
+};
+
+// modeling.py:773-794 in the reference's operation order.
+__device__ __forceinline__ double chi2_exact(double A, double B, double C, double D)
+{
+    const double w_pheno = A + B, wo_pheno = C + D, w_kmer = A + C, wo_kmer = B + D;
+    const double total = w_pheno + wo_pheno;
+    const double e0 = (w_pheno * w_kmer) / total, e1 = (w_pheno * wo_kmer) / total;
+    const double e2 = (wo_pheno * w_kmer) / total, e3 = (wo_pheno * wo_kmer) / total;
+    double stat = 0.0, d;
+    d = A - e0; stat += (d * d) / e0;
+    d = B - e1; stat += (d * d) / e1;
+    d = C - e2; stat += (d * d) / e2;
+    d = D - e3; stat += (d * d) / e3;
+    return stat;
+}
+
+template <int G, bool WEIGHTED>
+__global__ __launch_bounds__(SC_THREADS) void chi2_scan_kernel(const ScanArgs P)
+{
+    constexpr int RPW = 64 / G;  // rows per wave step
+    const int lane = threadIdx.x & 63;
+    const int g = lane & (G - 1);
+    const int rsub = lane / G;
+    const uint64_t n_steps = (P.M + RPW - 1) / RPW;
+    const uint64_t wave_global = (uint64_t)blockIdx.x * (SC_THREADS / 64) + (threadIdx.x >> 6);
+    const uint64_t total_waves = (uint64_t)gridDim.x * (SC_THREADS / 64);
+    const bool has_chunk = g < P.cpr;
+    uint64_t m1a = 0, m1b = 0, m0a = 0, m0b = 0;
+    if (has_chunk) { m1a = P.m1[2 * g]; m1b = P.m1[2 * g + 1]; m0a = P.m0[2 * g]; m0b = P.m0[2 * g + 1]; }
+
+    for (uint64_t s0 = wave_global * SC_UNROLL; s0 < n_steps; s0 += total_waves * SC_UNROLL) {
+        u32x4 x[SC_UNROLL];
+#pragma unroll
+        for (int u = 0; u < SC_UNROLL; u++) {
+            const uint64_t row = (s0 + u) * RPW + rsub;
+            x[u] = (u32x4)(0u);
+            if (row < P.M && has_chunk) x[u] = __builtin_nontemporal_load(&P.bits[row * (uint64_t)P.cpr + g]);
+        }
+#pragma unroll
+        for (int u = 0; u < SC_UNROLL; u++) {
+            const uint64_t row = (s0 + u) * RPW + rsub;
+            const uint64_t xa = ((uint64_t)x[u].y << 32) | x[u].x, xb = ((uint64_t)x[u].w << 32) | x[u].z;
+            uint32_t a = __popcll(xa & m1a) + __popcll(xb & m1b);
+            uint32_t c = __popcll(xa & m0a) + __popcll(xb & m0b);
+            if (P.cpr > G) {  // rows wider than 64 chunks (more than 8192 samples)
+                if (row < P.M)
+                    for (int ch = g + G; ch < P.cpr; ch += G) {
+                        const u32x4 y = P.bits[row * (uint64_t)P.cpr + ch];
+                        const uint64_t ya = ((uint64_t)y.y << 32) | y.x, yb = ((uint64_t)y.w << 32) | y.z;
+                        a += __popcll(ya & P.m1[2 * ch]) + __popcll(yb & P.m1[2 * ch + 1]);
+                        c += __popcll(ya & P.m0[2 * ch]) + __popcll(yb & P.m0[2 * ch + 1]);
+                    }
+            }
+#pragma unroll
+            for (int d = G / 2; d > 0; d >>= 1) {
+                a += __shfl_xor(a, d, 64);
+                c += __shfl_xor(c, d, 64);
+            }
+            const int n_w = (int)(a + c);
+            const int n_wo = (P.n1 - (int)a) + (P.n0 - (int)c);
+            const bool freq_ok = (row < P.M) && !(n_w < P.min_samples || n_wo < 2 || n_w > P.max_samples);
+            if (!freq_ok) continue;
+            double A, B, C, D;
+            if (WEIGHTED) {
+                double wa = 0.0, wc = 0.0;
+                if (has_chunk) {
+                    uint64_t v = xa & (m1a | m0a);
+                    while (v) {
+                        const int b = __ffsll((unsigned long long)v) - 1;
+                        v &= v - 1;
+                        wa += P.w1[(2 * g) * 64 + b];
+                        wc += P.w0[(2 * g) * 64 + b];
+                    }
+                    v = xb & (m1b | m0b);
+                    while (v) {
+                        const int b = __ffsll((unsigned long long)v) - 1;
+                        v &= v - 1;
+                        wa += P.w1[(2 * g + 1) * 64 + b];
+                        wc += P.w0[(2 * g + 1) * 64 + b];
+                    }
+                    for (int ch = g + G; ch < P.cpr; ch += G) {
+                        const u32x4 y = P.bits[row * (uint64_t)P.cpr + ch];
+                        uint64_t yy[2] = {((uint64_t)y.y << 32) | y.x, ((uint64_t)y.w << 32) | y.z};
+                        for (int h = 0; h < 2; h++) {
+                            uint64_t vv = yy[h] & (P.m1[2 * ch + h] | P.m0[2 * ch + h]);
+                            while (vv) {
+                                const int b = __ffsll((unsigned long long)vv) - 1;
+                                vv &= vv - 1;
+                                wa += P.w1[(2 * ch + h) * 64 + b];
+                                wc += P.w0[(2 * ch + h) * 64 + b];
+                            }
+                        }
+                    }
+                }
+#pragma unroll
+                for (int d = G / 2; d > 0; d >>= 1) {
+                    wa += psk_shfl_xor_f64(wa, d);
+                    wc += psk_shfl_xor_f64(wc, d);
+                }
+                A = wa; B = P.W1 - wa; C = wc; D = P.W0 - wc;
+            } else {
+                A = (double)a; B = (double)(P.n1 - (int)a); C = (double)c; D = (double)(P.n0 - (int)c);
+            }
+            if (g != 0) continue;
+            // division-free pre-test: chi2 = T (AD - BC)^2 / (R1 R0 K1 K0)
+            const double R1 = A + B, R0 = C + D, K1 = A + C, K0 = B + D, T = R1 + R0;
+            const double det = A * D - B * C;
+            const double lhs = T * det * det, rhs = P.thr * R1 * R0 * K1 * K0;
+            if (lhs < rhs * (1.0 - 1e-9)) continue;  // NaN compares false -> falls through to the exact path
+            const double stat = chi2_exact(A, B, C, D);
+            const double p = exp(-0.5 * stat);  // chi2.sf(stat, df = 2), modeling.py:782-792
+            const bool keep = (P.omit_B && p < P.pcut) || (p < P.pcut_bonf);  // modeling.py:795
+            if (keep) {
+                const uint32_t idx = atomicAdd(P.counter, 1u);
+                P.res_row[idx] = row;
+                P.res_stat[idx] = stat;
+                P.res_p[idx] = p;
+                P.res_nw[idx] = n_w;
+            }
+        }
+    }
+}
+
+// ---- Student-t two-sided p-value: I_{df/(df+t^2)}(df/2, 1/2), Lentz continued fraction ---------
+__device__ double dev_betacf(double a, double b, double x)
+{
+    const double TINY = 1e-300, EPS = 1e-16;
+    const double qab = a + b, qap = a + 1.0, qam = a - 1.0;
+    double c = 1.0, d = 1.0 - qab * x / qap;
+    if (fabs(d) < TINY) d = TINY;
+    d = 1.0 / d;
+    double h = d;
+    for (int m = 1; m <= 10000; m++) {
+        const int m2 = 2 * m;
+        double aa = m * (b - m) * x / ((qam + m2) * (a + m2));
+        d = 1.0 + aa * d; if (fabs(d) < TINY) d = TINY;
+        c = 1.0 + aa / c; if (fabs(c) < TINY) c = TINY;
+        d = 1.0 / d;
+        h *= d * c;
+        aa = -(a + m) * (qab + m) * x / ((a + m2) * (qap + m2));
+        d = 1.0 + aa * d; if (fabs(d) < TINY) d = TINY;
+        c = 1.0 + aa / c; if (fabs(c) < TINY) c = TINY;
+        d = 1.0 / d;
+        const double del = d * c;
+        h *= del;
+        if (fabs(del - 1.0) < EPS) break;
+    }
+    return h;
+}
+
+__device__ double dev_betainc(double a, double b, double x)
+{
+    if (!(x > 0.0)) return (x == 0.0) ? 0.0 : NAN;
+    if (!(x < 1.0)) return (x == 1.0) ? 1.0 : NAN;
+    const double lbt = lgamma(a + b) - lgamma(a) - lgamma(b) + a * log(x) + b * log1p(-x);
+    const double bt = exp(lbt);
+    if (x < (a + 1.0) / (a + b + 2.0)) return bt * dev_betacf(a, b, x) / a;
+    return 1.0 - bt * dev_betacf(b, a, 1.0 - x) / b;
+}
+
+__device__ double dev_t_two_sided_p(double t, double df)
+{
+    if (isnan(t) || isnan(df) || !(df > 0)) return NAN;
+    if (isinf(t)) return 0.0;
+    return dev_betainc(0.5 * df, 0.5, df / (df + t * t));
+}
+
+template <int G>
+__global__ __launch_bounds__(SC_THREADS) void ttest_scan_kernel(const ScanArgs P)
+{
+    constexpr int RPW = 64 / G;
+    const int lane = threadIdx.x & 63;
+    const int g = lane & (G - 1);
+    const int rsub = lane / G;
+    const uint64_t n_steps = (P.M + RPW - 1) / RPW;
+    const uint64_t wave_global = (uint64_t)blockIdx.x * (SC_THREADS / 64) + (threadIdx.x >> 6);
+    const uint64_t total_waves = (uint64_t)gridDim.x * (SC_THREADS / 64);
+    const int wpr = 2 * P.cpr;
+
+    for (uint64_t s = wave_global; s < n_steps; s += total_waves) {
+        const uint64_t row = s * RPW + rsub;
+        const uint64_t *rp = reinterpret_cast<const uint64_t *>(P.bits) + row * (uint64_t)wpr;
+        uint32_t cnt = 0;
+        if (row < P.M)
+            for (int w = g; w < wpr; w += G) cnt += __popcll(rp[w] & P.mvalid[w]);
+#pragma unroll
+        for (int d = G / 2; d > 0; d >>= 1) cnt += __shfl_xor(cnt, d, 64);
+        const int n_w = (int)cnt, n_wo = P.nvalid - (int)cnt;
+        // modeling.py:731
+        const bool freq_ok = (row < P.M) && !(n_w < P.min_samples || n_wo < 2 || n_w > P.max_samples);
+        if (!freq_ok) continue;
+        // pass 1: weighted sums per group (weights are 0 where the phenotype is NA)
+        double nx = 0, sx = 0, ny = 0, sy = 0;
+        for (int w = g; w < wpr; w += G) {
+            const uint64_t x = rp[w];
+            const uint64_t mv = P.mvalid[w];
+            for (int b = 0; b < 64; b++) {
+                if (!((mv >> b) & 1)) continue;
+                const double wt = P.wt[w * 64 + b], v = P.val[w * 64 + b];
+                if ((x >> b) & 1) { nx += wt; sx += wt * v; } else { ny += wt; sy += wt * v; }
+            }
+        }
+#pragma unroll
+        for (int d = G / 2; d > 0; d >>= 1) {
+            nx += psk_shfl_xor_f64(nx, d); sx += psk_shfl_xor_f64(sx, d);
+            ny += psk_shfl_xor_f64(ny, d); sy += psk_shfl_xor_f64(sy, d);
+        }
+        const double mx = sx / nx, my = sy / ny;
+        // pass 2: weighted sums of squared deviations (DescrStatsW, ddof = 0)
+        double qx = 0, qy = 0;
+        for (int w = g; w < wpr; w += G) {
+            const uint64_t x = rp[w];
+            const uint64_t mv = P.mvalid[w];
+            for (int b = 0; b < 64; b++) {
+                if (!((mv >> b) & 1)) continue;
+                const double wt = P.wt[w * 64 + b], v = P.val[w * 64 + b];
+                if ((x >> b) & 1) { const double dd = v - mx; qx += wt * dd * dd; }
+                else { const double dd = v - my; qy += wt * dd * dd; }
+            }
+        }
+#pragma unroll
+        for (int d = G / 2; d > 0; d >>= 1) {
+            qx += psk_shfl_xor_f64(qx, d);
+            qy += psk_shfl_xor_f64(qy, d);
+        }
+        if (g != 0) continue;
+        const double vx = qx / nx, vy = qy / ny;
+        const double sem1 = vx / (nx - 1.0), sem2 = vy / (ny - 1.0);
+        const double semsum = sem1 + sem2;
+        const double t = (mx - my) / sqrt(semsum);
+        // Student's t has heavier tails than the normal: p_t >= erfc(|t|/sqrt 2); cheap rejection
+        if (erfc(fabs(t) * 0.70710678118654752440) >= P.pcut_bonf) continue;
+        const double z1 = (sem1 / semsum) * (sem1 / semsum) / (nx - 1.0);
+        const double z2 = (sem2 / semsum) * (sem2 / semsum) / (ny - 1.0);
+        const double df = 1.0 / (z1 + z2);
+        const double p = dev_t_two_sided_p(t, df);
+        if (p < P.pcut_bonf) {  // modeling.py:738 (Bonferroni always)
+            const uint32_t idx = atomicAdd(P.counter, 1u);
+            P.res_row[idx] = row;
+            P.res_stat[idx] = t;
+            P.res_p[idx] = p;
+            P.res_mx[idx] = mx;
+            P.res_my[idx] = my;
+            P.res_nw[idx] = n_w;
+        }
+    }
+}
+
+template <bool WEIGHTED>
+void launch_chi2(int G, dim3 grid, hipStream_t st, const ScanArgs &a)
+{
+    switch (G) {
+    case 1: chi2_scan_kernel<1, WEIGHTED><<<grid, SC_THREADS, 0, st>>>(a); break;
+    case 2: chi2_scan_kernel<2, WEIGHTED><<<grid, SC_THREADS, 0, st>>>(a); break;
+    case 4: chi2_scan_kernel<4, WEIGHTED><<<grid, SC_THREADS, 0, st>>>(a); break;
+    case 8: chi2_scan_kernel<8, WEIGHTED><<<grid, SC_THREADS, 0, st>>>(a); break;
+    case 16: chi2_scan_kernel<16, WEIGHTED><<<grid, SC_THREADS, 0, st>>>(a); break;
+    case 32: chi2_scan_kernel<32, WEIGHTED><<<grid, SC_THREADS, 0, st>>>(a); break;
+    default: chi2_scan_kernel<64, WEIGHTED><<<grid, SC_THREADS, 0, st>>>(a); break;
+    }
+}
+
+void launch_ttest(int G, dim3 grid, hipStream_t st, const ScanArgs &a)
+{
+    switch (G) {
+    case 1: ttest_scan_kernel<1><<<grid, SC_THREADS, 0, st>>>(a); break;
+    case 2: ttest_scan_kernel<2><<<grid, SC_THREADS, 0, st>>>(a); break;
+    case 4: ttest_scan_kernel<4><<<grid, SC_THREADS, 0, st>>>(a); break;
+    case 8: ttest_scan_kernel<8><<<grid, SC_THREADS, 0, st>>>(a); break;
+    case 16: ttest_scan_kernel<16><<<grid, SC_THREADS, 0, st>>>(a); break;
+    case 32: ttest_scan_kernel<32><<<grid, SC_THREADS, 0, st>>>(a); break;
+    default: ttest_scan_kernel<64><<<grid, SC_THREADS, 0, st>>>(a); break;
+    }
+}
+
+int group_lanes(int cpr)
+{
+    int G = 1;
+    while (G < cpr && G < 64) G <<= 1;
+    return G;
+}
+
+// result arrays (SoA) inside ctx->res: row u64 | stat f64 | p f64 | mx f64 | my f64 | nw i32
+int setup_results(psk_ctx *ctx, ScanArgs &a)
+{
+    const uint64_t cap = ctx->n_kmers ? ctx->n_kmers : 1;
+    PSK_TRY(dev_reserve(ctx, ctx->res, cap * 44 + 64));
+    uint8_t *b = ctx->res.as<uint8_t>();
+    a.res_row = reinterpret_cast<uint64_t *>(b);
+    a.res_stat = reinterpret_cast<double *>(b + cap * 8);
+    a.res_p = reinterpret_cast<double *>(b + cap * 16);
+    a.res_mx = reinterpret_cast<double *>(b + cap * 24);
+    a.res_my = reinterpret_cast<double *>(b + cap * 32);
+    a.res_nw = reinterpret_cast<int32_t *>(b + cap * 40);
+    PSK_TRY(dev_reserve(ctx, ctx->res_count, 64));
+    a.counter = ctx->res_count.as<uint32_t>();
+    return PSK_OK;
+}
+
+dim3 scan_grid(const psk_ctx *ctx, uint64_t M, int G, int unroll)
+{
+    const uint64_t rpw = 64 / G;
+    const uint64_t steps = (M + rpw - 1) / rpw;
+    const uint64_t waves = (steps + unroll - 1) / unroll;
+    uint64_t blocks = (waves + SC_THREADS / 64 - 1) / (SC_THREADS / 64);
+    const uint64_t cap = (uint64_t)(ctx->n_cu > 0 ? ctx->n_cu : 256) * 8;
+    if (blocks > cap) blocks = cap;
+    if (blocks < 1) blocks = 1;
+    return dim3((unsigned)blocks);
+}
+
+int run_chi2(psk_ctx *ctx, ScanArgs &a, bool weighted, int reps, double *ms_total)
+{
+    const int G = group_lanes(a.cpr);
+    const dim3 grid = scan_grid(ctx, a.M, G, SC_UNROLL);
+    *ms_total = 0;
+    for (int r = 0; r < reps; r++) {
+        PSK_HIP(ctx, hipMemsetAsync(a.counter, 0, 4, ctx->stream));
+        PSK_HIP(ctx, hipEventRecord(ctx->ev0, ctx->stream));
+        if (weighted) launch_chi2<true>(G, grid, ctx->stream, a);
+        else launch_chi2<false>(G, grid, ctx->stream, a);
+        PSK_HIP(ctx, hipGetLastError());
+        PSK_HIP(ctx, hipEventRecord(ctx->ev1, ctx->stream));
+        PSK_HIP(ctx, hipEventSynchronize(ctx->ev1));
+        float ms = 0;
+        PSK_HIP(ctx, hipEventElapsedTime(&ms, ctx->ev0, ctx->ev1));
+        *ms_total += ms;
+    }
+    return PSK_OK;
+}
+
+}  // namespace
+
+static int fill_chi2_args(psk_ctx *ctx, ScanArgs &a)
+{
+    const ScanParams &L = ctx->last;
+    a = ScanArgs();
+    a.bits = reinterpret_cast<const u32x4 *>(ctx->bits.p);
+    a.M = ctx->n_kmers;
+    a.cpr = ctx->wpr / 2;
+    a.m1 = ctx->mask1.as<uint64_t>();
+    a.m0 = ctx->mask0.as<uint64_t>();
+    a.w1 = ctx->wts.as<double>();
+    a.w0 = ctx->wts.as<double>() + (size_t)ctx->wpr * 64;
+    a.min_samples = L.min_samples;
+    a.max_samples = L.max_samples;
+    a.pcut = L.pvalue_cutoff;
+    a.pcut_bonf = L.pvalue_cutoff / (double)L.n_kmers_global;
+    a.omit_B = L.omit_B;
+    double pmax = a.pcut_bonf;
+    if (L.omit_B && a.pcut > pmax) pmax = a.pcut;
+    if (pmax >= 1.0) a.thr = 0.0;
+    else if (pmax <= 0.0) a.thr = INFINITY;
+    else a.thr = -2.0 * log(pmax);
+    return setup_results(ctx, a);
+}
+
+extern "C" int psk_chi2_scan(psk_ctx *ctx, const int8_t *pheno, const double *weights, int min_samples,
+                             int max_samples, double pvalue_cutoff, int omit_B, uint64_t n_kmers_global,
+                             uint64_t *n_pass)
+{
+    if (!ctx) return PSK_EINVAL;
+    if (!ctx->have_presence) return psk_fail(ctx, PSK_ESTATE, "no presence matrix (psk_build_presence first)");
+    if (!pheno) return psk_fail(ctx, PSK_EINVAL, "null phenotype vector");
+    if (n_kmers_global == 0) n_kmers_global = ctx->n_kmers ? ctx->n_kmers : 1;
+    PSK_HIP(ctx, hipSetDevice(ctx->device));
+    const int N = ctx->n_samples, wpr = ctx->wpr;
+    std::vector<uint64_t> m1(wpr, 0), m0(wpr, 0);
+    std::vector<double> w(2 * (size_t)wpr * 64, 0.0);
+    double W1 = 0, W0 = 0;
+    int n1 = 0, n0 = 0;
+    for (int i = 0; i < N; i++) {
+        const double wi = weights ? weights[i] : 1.0;
+        if (pheno[i] == 1) { m1[i >> 6] |= 1ull << (i & 63); w[i] = wi; W1 += wi; n1++; }
+        else if (pheno[i] == 0) { m0[i >> 6] |= 1ull << (i & 63); w[(size_t)wpr * 64 + i] = wi; W0 += wi; n0++; }
+    }
+    PSK_TRY(dev_reserve(ctx, ctx->mask1, wpr * 8));
+    PSK_TRY(dev_reserve(ctx, ctx->mask0, wpr * 8));
+    PSK_TRY(dev_reserve(ctx, ctx->wts, w.size() * 8));
+    PSK_HIP(ctx, hipMemcpyAsync(ctx->mask1.p, m1.data(), wpr * 8, hipMemcpyHostToDevice, ctx->stream));
+    PSK_HIP(ctx, hipMemcpyAsync(ctx->mask0.p, m0.data(), wpr * 8, hipMemcpyHostToDevice, ctx->stream));
+    PSK_HIP(ctx, hipMemcpyAsync(ctx->wts.p, w.data(), w.size() * 8, hipMemcpyHostToDevice, ctx->stream));
+    PSK_HIP(ctx, hipStreamSynchronize(ctx->stream));
+
+    ctx->last.valid = true;
+    ctx->last.weighted = weights != nullptr;
+    ctx->last.min_samples = min_samples;
+    ctx->last.max_samples = max_samples;
+    ctx->last.pvalue_cutoff = pvalue_cutoff;
+    ctx->last.omit_B = omit_B ? 1 : 0;
+    ctx->last.n_kmers_global = n_kmers_global;
+    ScanArgs a;
+    PSK_TRY(fill_chi2_args(ctx, a));
+    a.n1 = n1; a.n0 = n0; a.W1 = W1; a.W0 = W0;
+    ctx->last.n1 = n1; ctx->last.n0 = n0; ctx->last.W1 = W1; ctx->last.W0 = W0;
+    ctx->n_pass = 0;
+    ctx->last_scan_kind = 1;
+    if (ctx->n_kmers) {
+        double ms = 0;
+        PSK_TRY(run_chi2(ctx, a, ctx->last.weighted, 1, &ms));
+        ctx->last_scan_ms = ms;
+        uint32_t np = 0;
+        PSK_HIP(ctx, hipMemcpy(&np, a.counter, 4, hipMemcpyDeviceToHost));
+        ctx->n_pass = np;
+    }
+    if (n_pass) *n_pass = ctx->n_pass;
+    return PSK_OK;
+}
+
+extern "C" int psk_rescan_timed(psk_ctx *ctx, int reps, double *mean_ms)
+{
+    if (!ctx) return PSK_EINVAL;
+    if (!ctx->have_presence || !ctx->last.valid || ctx->last_scan_kind != 1)
+        return psk_fail(ctx, PSK_ESTATE, "no chi2 scan to repeat");
+    if (reps < 1) return psk_fail(ctx, PSK_EINVAL, "reps must be >= 1");
+    PSK_HIP(ctx, hipSetDevice(ctx->device));
+    ScanArgs a;
+    PSK_TRY(fill_chi2_args(ctx, a));
+    a.n1 = ctx->last.n1; a.n0 = ctx->last.n0; a.W1 = ctx->last.W1; a.W0 = ctx->last.W0;
+    double ms = 0;
+    PSK_TRY(run_chi2(ctx, a, ctx->last.weighted, reps, &ms));
+    ctx->last_scan_ms = ms / reps;
+    uint32_t np = 0;
+    PSK_HIP(ctx, hipMemcpy(&np, a.counter, 4, hipMemcpyDeviceToHost));
+    ctx->n_pass = np;
+    if (mean_ms) *mean_ms = ms / reps;
+    return PSK_OK;
+}
+
+extern "C" int psk_ttest_scan(psk_ctx *ctx, const double *pheno, const uint8_t *valid, const double *weights,
+                              int min_samples, int max_samples, double pvalue_cutoff, uint64_t n_kmers_global,
+                              uint64_t *n_pass)
+{
+    if (!ctx) return PSK_EINVAL;
+    if (!ctx->have_presence) return psk_fail(ctx, PSK_ESTATE, "no presence matrix (psk_build_presence first)");
+    if (!pheno || !valid) return psk_fail(ctx, PSK_EINVAL, "null phenotype vector");
+    if (n_kmers_global == 0) n_kmers_global = ctx->n_kmers ? ctx->n_kmers : 1;
+    PSK_HIP(ctx, hipSetDevice(ctx->device));
+    const int N = ctx->n_samples, wpr = ctx->wpr;
+    std::vector<uint64_t> mv(wpr, 0);
+    std::vector<double> vw(2 * (size_t)wpr * 64, 0.0);  // values | weights
+    int nvalid = 0;
+    for (int i = 0; i < N; i++) {
+        if (!valid[i]) continue;
+        mv[i >> 6] |= 1ull << (i & 63);
+        vw[i] = pheno[i];
+        vw[(size_t)wpr * 64 + i] = weights ? weights[i] : 1.0;
+        nvalid++;
+    }
+    PSK_TRY(dev_reserve(ctx, ctx->mask1, wpr * 8));
+    PSK_TRY(dev_reserve(ctx, ctx->phe, vw.size() * 8));
+    PSK_HIP(ctx, hipMemcpyAsync(ctx->mask1.p, mv.data(), wpr * 8, hipMemcpyHostToDevice, ctx->stream));
+    PSK_HIP(ctx, hipMemcpyAsync(ctx->phe.p, vw.data(), vw.size() * 8, hipMemcpyHostToDevice, ctx->stream));
+    PSK_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    ScanArgs a = ScanArgs();
+    a.bits = reinterpret_cast<const u32x4 *>(ctx->bits.p);
+    a.M = ctx->n_kmers;
+    a.cpr = wpr / 2;
+    a.mvalid = ctx->mask1.as<uint64_t>();
+    a.val = ctx->phe.as<double>();
+    a.wt = ctx->phe.as<double>() + (size_t)wpr * 64;
+    a.nvalid = nvalid;
+    a.min_samples = min_samples;
+    a.max_samples = max_samples;
+    a.pcut = pvalue_cutoff;
+    a.pcut_bonf = pvalue_cutoff / (double)n_kmers_global;
+    PSK_TRY(setup_results(ctx, a));
+    ctx->n_pass = 0;
+    ctx->last_scan_kind = 2;
+    ctx->last.valid = false;
+    if (ctx->n_kmers) {
+        const int G = group_lanes(a.cpr);
+        const dim3 grid = scan_grid(ctx, a.M, G, 1);
+        PSK_HIP(ctx, hipMemsetAsync(a.counter, 0, 4, ctx->stream));
+        PSK_HIP(ctx, hipEventRecord(ctx->ev0, ctx->stream));
+        launch_ttest(G, grid, ctx->stream, a);
+        PSK_HIP(ctx, hipGetLastError());
+        PSK_HIP(ctx, hipEventRecord(ctx->ev1, ctx->stream));
+        PSK_HIP(ctx, hipEventSynchronize(ctx->ev1));
+        float ms = 0;
+        PSK_HIP(ctx, hipEventElapsedTime(&ms, ctx->ev0, ctx->ev1));
+        ctx->last_scan_ms = ms;
+        uint32_t np = 0;
+        PSK_HIP(ctx, hipMemcpy(&np, a.counter, 4, hipMemcpyDeviceToHost));
+        ctx->n_pass = np;
+    }
+    if (n_pass) *n_pass = ctx->n_pass;
+    return PSK_OK;
+}
+
+extern "C" int psk_get_results(psk_ctx *ctx, uint64_t *row_idx, uint64_t *words, double *stat, double *p,
+                               double *mean_x, double *mean_y, int32_t *n_with, uint64_t cap)
+{
+    if (!ctx) return PSK_EINVAL;
+    if (!ctx->last_scan_kind) return psk_fail(ctx, PSK_ESTATE, "no scan has been run");
+    const uint64_t n = ctx->n_pass;
+    if (cap < n) return psk_fail(ctx, PSK_ERANGE, "buffer too small: %llu < %llu", (unsigned long long)cap,
+                                 (unsigned long long)n);
+    if (n == 0) return PSK_OK;
+    PSK_HIP(ctx, hipSetDevice(ctx->device));
+    const uint64_t c = ctx->n_kmers ? ctx->n_kmers : 1;
+    const uint8_t *b = ctx->res.as<uint8_t>();
+    std::vector<uint64_t> rows(n);
+    std::vector<double> st(n), pv(n), mx(n), my(n);
+    std::vector<int32_t> nw(n);
+    PSK_HIP(ctx, hipMemcpy(rows.data(), b, n * 8, hipMemcpyDeviceToHost));
+    PSK_HIP(ctx, hipMemcpy(st.data(), b + c * 8, n * 8, hipMemcpyDeviceToHost));
+    PSK_HIP(ctx, hipMemcpy(pv.data(), b + c * 16, n * 8, hipMemcpyDeviceToHost));
+    if (ctx->last_scan_kind == 2) {
+        PSK_HIP(ctx, hipMemcpy(mx.data(), b + c * 24, n * 8, hipMemcpyDeviceToHost));
+        PSK_HIP(ctx, hipMemcpy(my.data(), b + c * 32, n * 8, hipMemcpyDeviceToHost));
+    }
+    PSK_HIP(ctx, hipMemcpy(nw.data(), b + c * 40, n * 4, hipMemcpyDeviceToHost));
+    // the append order of the scan is not deterministic: order by row (= ascending k-mer)
+    std::vector<uint64_t> ord(n);
+    std::iota(ord.begin(), ord.end(), 0);
+    std::sort(ord.begin(), ord.end(), [&](uint64_t x, uint64_t y) { return rows[x] < rows[y]; });
+    std::vector<uint64_t> wbuf;
+    if (words) {
+        // gather the words of the passing rows on the device side would need another kernel;
+        // the union list is small compared with the matrix, fetch the needed entries one by one
+        // only when few, else the whole list
+        wbuf.resize(ctx->n_kmers);
+        PSK_HIP(ctx, hipMemcpy(wbuf.data(), ctx->union_words.p, ctx->n_kmers * 8, hipMemcpyDeviceToHost));
+    }
+    for (uint64_t i = 0; i < n; i++) {
+        const uint64_t j = ord[i];
+        if (row_idx) row_idx[i] = rows[j];
+        if (words) words[i] = wbuf[rows[j]];
+        if (stat) stat[i] = st[j];
+        if (p) p[i] = pv[j];
+        if (mean_x) mean_x[i] = (ctx->last_scan_kind == 2) ? mx[j] : 0.0;
+        if (mean_y) mean_y[i] = (ctx->last_scan_kind == 2) ? my[j] : 0.0;
+        if (n_with) n_with[i] = nw[j];
+    }
+    return PSK_OK;
+}
+
+extern "C" double psk_last_scan_ms(const psk_ctx *ctx) { return ctx ? ctx->last_scan_ms : 0.0; }

@@ -1,0 +1,422 @@
+// a1: per-sample canonical k-mer list (replaces bin/glistmaker; modeling.py:303-315), the
+// count lookups of modeling.py:324-329 and the fixed-dictionary counting of prediction.py:72-80.
+//
+//   host   frame_sequence_host   record framing only (headers, FASTQ separator/quality lines,
+//                                control bytes) -> clean stream: bases + '\n' window breaks
+//   device extract_kernel        2-bit encode, rolling forward/reverse words, canonical min,
+//                                slab filter, wave-aggregated append
+//          dev_radix_sort_u64    LSD radix sort on the 2k significant bits
+//          rle_* kernels         run heads -> unique words + u32 frequencies
+#include "dev_utils.h"
+#include "psk_internal.h"
+
+// ------------------------------------------------------------------------------------------------
+// Host framing.  Tokeniser contract of glistmaker 4.2.3 as established by probing the binary
+// (DESIGN.md "Tokeniser contract"; fixtures tests/golden/tokenizer_cases.json).
+// ------------------------------------------------------------------------------------------------
+namespace {
+enum { ST_INIT, ST_FA_HDR, ST_FA_SEQ, ST_FQ_HDR, ST_FQ_SEQ, ST_FQ_PLUS, ST_FQ_QUAL, ST_FQ_H, ST_FQ_HSKIP };
+enum { CL_BREAK = 0, CL_BASE = 1, CL_SKIP = 2 };
+
+struct ClassTable {
+    uint8_t t[256];
+    ClassTable()
+    {
+        for (int c = 0; c < 256; c++) t[c] = (c < 32) ? CL_SKIP : CL_BREAK;
+        for (const char *p = "ACGTUacgtu"; *p; p++) t[(unsigned char)*p] = CL_BASE;
+    }
+};
+const ClassTable g_cls;
+}  // namespace
+
+int64_t frame_sequence_host(const uint8_t *bytes, size_t len, uint8_t *out, size_t out_cap)
+{
+    size_t o = 0;
+    int st = ST_INIT;
+    bool last_break = true;  // collapse runs of breaks; no leading break needed
+    auto put_break = [&]() {
+        if (!last_break) { out[o++] = '\n'; last_break = true; }
+    };
+    if (out_cap < len) return PSK_ERANGE;
+    for (size_t i = 0; i < len; i++) {
+        const uint8_t c = bytes[i];
+        if (c == 0) break;
+        switch (st) {
+        case ST_INIT:
+            if (c == '>') st = ST_FA_HDR;
+            else if (c == '@') st = ST_FQ_HDR;
+            break;
+        case ST_FA_HDR:
+            if (c == '\n') { st = ST_FA_SEQ; put_break(); }
+            break;
+        case ST_FQ_HDR:
+            if (c == '\n') { st = ST_FQ_SEQ; put_break(); }
+            break;
+        case ST_FA_SEQ:
+        case ST_FQ_SEQ: {
+            const uint8_t cl = g_cls.t[c];
+            if (cl == CL_BASE) {
+                out[o++] = c;
+                last_break = false;
+            } else if (st == ST_FA_SEQ && c == '>') {
+                put_break();
+                st = ST_FA_HDR;
+            } else if (cl == CL_SKIP) {
+                if (st == ST_FQ_SEQ && c == '\n' && i + 1 < len) {
+                    const uint8_t c2 = bytes[++i];  // the byte after a sequence newline is consumed
+                    if (c2 == 0) return (int64_t)o;
+                    if (c2 == '+') st = ST_FQ_PLUS;
+                }
+            } else {
+                put_break();
+            }
+            break;
+        }
+        case ST_FQ_PLUS:
+            if (c == '\n') st = ST_FQ_QUAL;
+            break;
+        case ST_FQ_QUAL:
+            if (c == '\n') st = ST_FQ_H;
+            break;
+        case ST_FQ_H:
+            if (c == '@') { st = ST_FQ_HDR; put_break(); }
+            else st = ST_FQ_HSKIP;
+            break;
+        case ST_FQ_HSKIP:
+            if (c == '\n') st = ST_FQ_H;
+            break;
+        }
+    }
+    return (int64_t)o;
+}
+
+extern "C" int64_t psk_frame_sequence(const uint8_t *bytes, size_t len, uint8_t *out, size_t out_cap)
+{
+    if ((!bytes && len) || !out) return PSK_EINVAL;
+    return frame_sequence_host(bytes, len, out, out_cap);
+}
+
+// ------------------------------------------------------------------------------------------------
+// Device kernels
+// ------------------------------------------------------------------------------------------------
+namespace {
+
+constexpr int EX_THREADS = 256;
+constexpr int EX_SEG = 32;  // window-end positions per thread
+
+struct Roll {
+    uint64_t fw, rc;
+    int run;
+};
+
+__device__ __forceinline__ void roll_byte(Roll &r, uint32_t c, uint64_t mask, int rcshift, int k)
+{
+    if (c == '\n') {
+        r.run = 0;
+    } else {
+        const uint64_t code = ((c >> 1) ^ (c >> 2)) & 3u;  // A/a 0, C/c 1, G/g 2, T/t/U/u 3
+        r.fw = ((r.fw << 2) | code) & mask;
+        r.rc = (r.rc >> 2) | ((3ull - code) << rcshift);
+        r.run = (r.run < k) ? r.run + 1 : k;
+    }
+}
+
+// clean: bases and '\n' breaks, 16-byte aligned, padded with '\n' to a multiple of EX_SEG.
+__global__ __launch_bounds__(EX_THREADS) void extract_kernel(const uint8_t *__restrict__ clean, uint64_t len, int k,
+                                                              uint64_t lo, uint64_t hi, uint64_t *__restrict__ out,
+                                                              uint32_t *__restrict__ n_out)
+{
+    const uint64_t g = (uint64_t)blockIdx.x * EX_THREADS + threadIdx.x;
+    const uint64_t s = g * EX_SEG;
+    const int lane = threadIdx.x & 63;
+    const uint64_t mask = (k == 32) ? ~0ull : ((1ull << (2 * k)) - 1ull);
+    const int rcshift = 2 * (k - 1);
+    const bool active = s < len;
+
+    uint32_t cur[8], prev[8];
+#pragma unroll
+    for (int j = 0; j < 8; j++) { cur[j] = 0x0a0a0a0au; prev[j] = 0x0a0a0a0au; }
+    if (active) {
+        const uint4 *p = reinterpret_cast<const uint4 *>(clean + s);
+        uint4 a = p[0], b = p[1];
+        cur[0] = a.x; cur[1] = a.y; cur[2] = a.z; cur[3] = a.w;
+        cur[4] = b.x; cur[5] = b.y; cur[6] = b.z; cur[7] = b.w;
+        if (s >= EX_SEG) {
+            const uint4 *q = reinterpret_cast<const uint4 *>(clean + s - EX_SEG);
+            uint4 c = q[0], d = q[1];
+            prev[0] = c.x; prev[1] = c.y; prev[2] = c.z; prev[3] = c.w;
+            prev[4] = d.x; prev[5] = d.y; prev[6] = d.z; prev[7] = d.w;
+        }
+    }
+    Roll r{0, 0, 0};
+    // warm-up over the k-1 bytes before s (k-1 <= 31 < EX_SEG)
+#pragma unroll
+    for (int j = 0; j < EX_SEG; j++) {
+        if (j >= EX_SEG - (k - 1)) {
+            const uint32_t c = (prev[j >> 2] >> ((j & 3) * 8)) & 0xffu;
+            roll_byte(r, c, mask, rcshift, k);
+        }
+    }
+#pragma unroll
+    for (int j = 0; j < EX_SEG; j++) {
+        const uint32_t c = (cur[j >> 2] >> ((j & 3) * 8)) & 0xffu;
+        roll_byte(r, c, mask, rcshift, k);
+        const uint64_t w = (r.fw < r.rc) ? r.fw : r.rc;
+        const bool valid = active && (s + j < len) && (r.run >= k) && (w >= lo) && (hi == 0 || w < hi);
+        const uint64_t bal = __ballot(valid);
+        if (bal) {
+            uint32_t base = 0;
+            const int leader = __ffsll((unsigned long long)bal) - 1;
+            if (lane == leader) base = atomicAdd(n_out, (uint32_t)__popcll(bal));
+            base = __shfl(base, leader, 64);
+            if (valid) out[base + __popcll(bal & psk_lanemask_lt(lane))] = w;
+        }
+    }
+}
+
+__global__ void rle_flags_kernel(const uint64_t *__restrict__ keys, uint64_t n, uint32_t *__restrict__ flags)
+{
+    const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) flags[i] = (i == 0 || keys[i] != keys[i - 1]) ? 1u : 0u;
+}
+
+// pos = exclusive scan of the head flags.  Heads write their word and their start index.
+__global__ void rle_scatter_kernel(const uint64_t *__restrict__ keys, uint64_t n, const uint32_t *__restrict__ pos,
+                                   uint64_t *__restrict__ words, uint32_t *__restrict__ starts)
+{
+    const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const bool head = (i == 0) || keys[i] != keys[i - 1];
+    if (head) {
+        const uint32_t j = pos[i];
+        words[j] = keys[i];
+        starts[j] = (uint32_t)i;
+    }
+}
+
+__global__ void rle_counts_kernel(const uint32_t *__restrict__ starts, uint64_t nu, uint64_t n,
+                                  uint32_t *__restrict__ freqs)
+{
+    const uint64_t j = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (j < nu) freqs[j] = ((j + 1 < nu) ? starts[j + 1] : (uint32_t)n) - starts[j];
+}
+
+// binary search of `n` query words in a sorted list; 0 if absent
+__global__ void lookup_counts_kernel(const uint64_t *__restrict__ words, const uint32_t *__restrict__ freqs,
+                                     uint64_t nu, const uint64_t *__restrict__ q, uint64_t n,
+                                     uint32_t *__restrict__ out)
+{
+    const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const uint64_t key = q[i];
+    uint64_t lo = 0, hi = nu;
+    while (lo < hi) {
+        const uint64_t mid = (lo + hi) >> 1;
+        if (words[mid] < key) lo = mid + 1; else hi = mid;
+    }
+    out[i] = (lo < nu && words[lo] == key) ? freqs[lo] : 0u;
+}
+
+// prediction path: every window's canonical word is probed in an LDS open-addressing table of the
+// dictionary; hits bump the dictionary entry's counter.
+constexpr int DICT_SLOTS = 4096;  // power of two, >= 2 * n_dict
+__device__ __forceinline__ uint32_t dict_hash(uint64_t w) { return (uint32_t)((w * 0x9E3779B97F4A7C15ull) >> 40); }
+
+__global__ __launch_bounds__(EX_THREADS) void dict_count_kernel(const uint8_t *__restrict__ clean, uint64_t len, int k,
+                                                                 const uint64_t *__restrict__ slot_word,
+                                                                 const int32_t *__restrict__ slot_idx,
+                                                                 uint32_t *__restrict__ counts)
+{
+    __shared__ uint64_t sw[DICT_SLOTS];
+    __shared__ int32_t si[DICT_SLOTS];
+    for (int i = threadIdx.x; i < DICT_SLOTS; i += EX_THREADS) { sw[i] = slot_word[i]; si[i] = slot_idx[i]; }
+    __syncthreads();
+    const uint64_t g = (uint64_t)blockIdx.x * EX_THREADS + threadIdx.x;
+    const uint64_t s = g * EX_SEG;
+    if (s >= len) return;
+    const uint64_t mask = (k == 32) ? ~0ull : ((1ull << (2 * k)) - 1ull);
+    const int rcshift = 2 * (k - 1);
+    Roll r{0, 0, 0};
+    const uint64_t start = (s >= (uint64_t)(k - 1)) ? s - (k - 1) : 0;
+    for (uint64_t i = start; i < s; i++) roll_byte(r, clean[i], mask, rcshift, k);
+    for (int j = 0; j < EX_SEG && s + j < len; j++) {
+        roll_byte(r, clean[s + j], mask, rcshift, k);
+        if (r.run >= k) {
+            const uint64_t w = (r.fw < r.rc) ? r.fw : r.rc;
+            uint32_t h = dict_hash(w) & (DICT_SLOTS - 1);
+            while (si[h] >= 0) {
+                if (sw[h] == w) { atomicAdd(&counts[si[h]], 1u); break; }
+                h = (h + 1) & (DICT_SLOTS - 1);
+            }
+        }
+    }
+}
+
+int upload_clean(psk_ctx *ctx, const uint8_t *bytes, size_t len, uint64_t *clean_len)
+{
+    ctx->host_clean.resize(len + 2 * EX_SEG);
+    int64_t n = frame_sequence_host(bytes, len, ctx->host_clean.data(), len + 2 * EX_SEG);
+    if (n < 0) return psk_fail(ctx, (int)n, "framing failed");
+    const uint64_t padded = ((uint64_t)n + EX_SEG - 1) / EX_SEG * EX_SEG + EX_SEG;
+    ctx->host_clean.resize(padded);
+    memset(ctx->host_clean.data() + n, '\n', padded - n);
+    PSK_TRY(dev_reserve(ctx, ctx->raw, padded));
+    PSK_HIP(ctx, hipMemcpyAsync(ctx->raw.p, ctx->host_clean.data(), padded, hipMemcpyHostToDevice, ctx->stream));
+    *clean_len = (uint64_t)n;
+    return PSK_OK;
+}
+
+}  // namespace
+
+int launch_extract(psk_ctx *ctx, const uint8_t *clean, uint64_t len, int k, uint64_t lo, uint64_t hi, uint64_t *out,
+                   uint32_t *n_out)
+{
+    if (len == 0) return PSK_OK;
+    const uint64_t threads = (len + EX_SEG - 1) / EX_SEG;
+    extract_kernel<<<div_up(threads, EX_THREADS), EX_THREADS, 0, ctx->stream>>>(clean, len, k, lo, hi, out, n_out);
+    PSK_HIP(ctx, hipGetLastError());
+    return PSK_OK;
+}
+
+extern "C" int psk_count_kmers(psk_ctx *ctx, int sample_idx, const uint8_t *bytes, size_t len, uint64_t *n_unique,
+                               uint64_t *n_total)
+{
+    if (!ctx) return PSK_EINVAL;
+    if (ctx->k == 0) return psk_fail(ctx, PSK_ESTATE, "psk_begin has not been called");
+    if (sample_idx < 0 || sample_idx >= ctx->n_samples) return psk_fail(ctx, PSK_EINVAL, "sample_idx out of range");
+    if (!bytes && len) return psk_fail(ctx, PSK_EINVAL, "null input");
+    PSK_HIP(ctx, hipSetDevice(ctx->device));
+    SampleList &L = ctx->lists[sample_idx];
+    if (L.words) { (void)hipFree(L.words); L.words = nullptr; }
+    if (L.freqs) { (void)hipFree(L.freqs); L.freqs = nullptr; }
+    L = SampleList();
+    ctx->have_presence = false;
+
+    uint64_t clean_len = 0;
+    PSK_TRY(upload_clean(ctx, bytes, len, &clean_len));
+    if (clean_len >= (1ull << 32)) return psk_fail(ctx, PSK_ERANGE, "sample larger than 4 Gbases");
+    const uint64_t cap = clean_len ? clean_len : 1;
+    PSK_TRY(dev_reserve(ctx, ctx->keysA, cap * 8));
+    PSK_TRY(dev_reserve(ctx, ctx->keysB, cap * 8));
+    PSK_TRY(dev_reserve(ctx, ctx->misc, 64));
+    uint32_t *d_n = ctx->misc.as<uint32_t>();
+    PSK_HIP(ctx, hipMemsetAsync(d_n, 0, 16, ctx->stream));
+    PSK_TRY(launch_extract(ctx, ctx->raw.as<uint8_t>(), clean_len, ctx->k, ctx->slab_lo, ctx->slab_hi,
+                           ctx->keysA.as<uint64_t>(), d_n));
+    uint32_t n32 = 0;
+    PSK_HIP(ctx, hipMemcpyAsync(&n32, d_n, 4, hipMemcpyDeviceToHost, ctx->stream));
+    PSK_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    const uint64_t n = n32;
+    uint64_t nu = 0;
+    if (n > 0) {
+        uint64_t *sorted = nullptr;
+        PSK_TRY(dev_radix_sort_u64(ctx, ctx->keysA.as<uint64_t>(), ctx->keysB.as<uint64_t>(), n, 0, 2 * ctx->k, &sorted));
+        uint64_t *other = (sorted == ctx->keysA.as<uint64_t>()) ? ctx->keysB.as<uint64_t>() : ctx->keysA.as<uint64_t>();
+        PSK_TRY(dev_reserve(ctx, ctx->flags, n * 4));
+        PSK_TRY(dev_reserve(ctx, ctx->starts, n * 4));
+        uint32_t *flags = ctx->flags.as<uint32_t>();
+        rle_flags_kernel<<<div_up(n, 256), 256, 0, ctx->stream>>>(sorted, n, flags);
+        PSK_HIP(ctx, hipGetLastError());
+        PSK_TRY(dev_exclusive_scan_u32(ctx, flags, flags, n, d_n + 1));
+        // unique words go to the other key buffer, starts to ctx->starts
+        rle_scatter_kernel<<<div_up(n, 256), 256, 0, ctx->stream>>>(sorted, n, flags, other, ctx->starts.as<uint32_t>());
+        PSK_HIP(ctx, hipGetLastError());
+        uint32_t nu32 = 0;
+        PSK_HIP(ctx, hipMemcpyAsync(&nu32, d_n + 1, 4, hipMemcpyDeviceToHost, ctx->stream));
+        PSK_HIP(ctx, hipStreamSynchronize(ctx->stream));
+        nu = nu32;
+        PSK_HIP(ctx, hipMalloc((void **)&L.words, nu * 8));
+        PSK_HIP(ctx, hipMalloc((void **)&L.freqs, nu * 4));
+        PSK_HIP(ctx, hipMemcpyAsync(L.words, other, nu * 8, hipMemcpyDeviceToDevice, ctx->stream));
+        rle_counts_kernel<<<div_up(nu, 256), 256, 0, ctx->stream>>>(ctx->starts.as<uint32_t>(), nu, n, L.freqs);
+        PSK_HIP(ctx, hipGetLastError());
+        PSK_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    }
+    L.n_unique = nu;
+    L.n_total = n;
+    L.done = true;
+    if (n_unique) *n_unique = nu;
+    if (n_total) *n_total = n;
+    return PSK_OK;
+}
+
+extern "C" int psk_get_list(psk_ctx *ctx, int sample_idx, uint64_t *words, uint32_t *freqs, uint64_t cap)
+{
+    if (!ctx) return PSK_EINVAL;
+    if (sample_idx < 0 || sample_idx >= ctx->n_samples || !ctx->lists[sample_idx].done)
+        return psk_fail(ctx, PSK_ESTATE, "sample %d has not been counted", sample_idx);
+    const SampleList &L = ctx->lists[sample_idx];
+    if (cap < L.n_unique) return psk_fail(ctx, PSK_ERANGE, "buffer too small: %llu < %llu", (unsigned long long)cap,
+                                          (unsigned long long)L.n_unique);
+    PSK_HIP(ctx, hipSetDevice(ctx->device));
+    if (L.n_unique) {
+        if (words) PSK_HIP(ctx, hipMemcpy(words, L.words, L.n_unique * 8, hipMemcpyDeviceToHost));
+        if (freqs) PSK_HIP(ctx, hipMemcpy(freqs, L.freqs, L.n_unique * 4, hipMemcpyDeviceToHost));
+    }
+    return PSK_OK;
+}
+
+extern "C" int psk_lookup_counts(psk_ctx *ctx, int sample_idx, const uint64_t *words, uint64_t n, uint32_t *freqs)
+{
+    if (!ctx) return PSK_EINVAL;
+    if (sample_idx < 0 || sample_idx >= ctx->n_samples || !ctx->lists[sample_idx].done)
+        return psk_fail(ctx, PSK_ESTATE, "sample %d has not been counted", sample_idx);
+    if (n == 0) return PSK_OK;
+    if (!words || !freqs) return psk_fail(ctx, PSK_EINVAL, "null buffer");
+    PSK_HIP(ctx, hipSetDevice(ctx->device));
+    const SampleList &L = ctx->lists[sample_idx];
+    PSK_TRY(dev_reserve(ctx, ctx->flags, n * 8));
+    PSK_TRY(dev_reserve(ctx, ctx->starts, n * 4));
+    PSK_HIP(ctx, hipMemcpyAsync(ctx->flags.p, words, n * 8, hipMemcpyHostToDevice, ctx->stream));
+    lookup_counts_kernel<<<div_up(n, 256), 256, 0, ctx->stream>>>(L.words, L.freqs, L.n_unique, ctx->flags.as<uint64_t>(),
+                                                                  n, ctx->starts.as<uint32_t>());
+    PSK_HIP(ctx, hipGetLastError());
+    PSK_HIP(ctx, hipMemcpyAsync(freqs, ctx->starts.p, n * 4, hipMemcpyDeviceToHost, ctx->stream));
+    PSK_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    return PSK_OK;
+}
+
+extern "C" int psk_count_dict(psk_ctx *ctx, const uint8_t *bytes, size_t len, int k, const uint64_t *dict_words,
+                              uint64_t n_dict, uint32_t *counts_out)
+{
+    if (!ctx) return PSK_EINVAL;
+    if (k < 1 || k > 32) return psk_fail(ctx, PSK_EINVAL, "k must be 1..32");
+    if (n_dict == 0) return PSK_OK;
+    if (!dict_words || !counts_out || (!bytes && len)) return psk_fail(ctx, PSK_EINVAL, "null buffer");
+    if (n_dict * 2 > DICT_SLOTS) return psk_fail(ctx, PSK_ERANGE, "dictionary of %llu k-mers exceeds %d",
+                                                  (unsigned long long)n_dict, DICT_SLOTS / 2);
+    PSK_HIP(ctx, hipSetDevice(ctx->device));
+    // host-built open-addressing table; duplicate dictionary words share the first entry's slot
+    std::vector<uint64_t> sw(DICT_SLOTS, 0);
+    std::vector<int32_t> si(DICT_SLOTS, -1);
+    std::vector<int32_t> alias(n_dict, -1);
+    for (uint64_t d = 0; d < n_dict; d++) {
+        const uint64_t w = dict_words[d];
+        uint32_t h = (uint32_t)((w * 0x9E3779B97F4A7C15ull) >> 40) & (DICT_SLOTS - 1);
+        while (si[h] >= 0 && sw[h] != w) h = (h + 1) & (DICT_SLOTS - 1);
+        if (si[h] >= 0) alias[d] = si[h];
+        else { sw[h] = w; si[h] = (int32_t)d; }
+    }
+    uint64_t clean_len = 0;
+    PSK_TRY(upload_clean(ctx, bytes, len, &clean_len));
+    const size_t tbl = DICT_SLOTS * 8 + DICT_SLOTS * 4 + n_dict * 4;
+    PSK_TRY(dev_reserve(ctx, ctx->flags, tbl));
+    uint8_t *base = ctx->flags.as<uint8_t>();
+    uint64_t *d_sw = reinterpret_cast<uint64_t *>(base);
+    int32_t *d_si = reinterpret_cast<int32_t *>(base + DICT_SLOTS * 8);
+    uint32_t *d_cnt = reinterpret_cast<uint32_t *>(base + DICT_SLOTS * 12);
+    PSK_HIP(ctx, hipMemcpyAsync(d_sw, sw.data(), DICT_SLOTS * 8, hipMemcpyHostToDevice, ctx->stream));
+    PSK_HIP(ctx, hipMemcpyAsync(d_si, si.data(), DICT_SLOTS * 4, hipMemcpyHostToDevice, ctx->stream));
+    PSK_HIP(ctx, hipMemsetAsync(d_cnt, 0, n_dict * 4, ctx->stream));
+    if (clean_len) {
+        const uint64_t threads = (clean_len + EX_SEG - 1) / EX_SEG;
+        dict_count_kernel<<<div_up(threads, EX_THREADS), EX_THREADS, 0, ctx->stream>>>(ctx->raw.as<uint8_t>(), clean_len,
+                                                                                      k, d_sw, d_si, d_cnt);
+        PSK_HIP(ctx, hipGetLastError());
+    }
+    PSK_HIP(ctx, hipMemcpyAsync(counts_out, d_cnt, n_dict * 4, hipMemcpyDeviceToHost, ctx->stream));
+    PSK_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    for (uint64_t d = 0; d < n_dict; d++)
+        if (alias[d] >= 0) counts_out[d] = counts_out[alias[d]];
+    return PSK_OK;
+}

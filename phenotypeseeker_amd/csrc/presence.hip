@@ -1,0 +1,336 @@
+// a2+a3: union of the per-sample lists and the bit-packed k-mer x sample presence matrix.
+// Replaces the glistcompare -u tree (modeling.py:350-380) and the glistquery -l / split text
+// mapping (modeling.py:317-348): every (word, sample) pair of the run is packed into one u64
+// (word << sbits | sample), the pairs are radix-sorted on the word bits, run heads number the
+// rows, and each pair sets its sample bit in its row.  Rows come out in ascending word order,
+// i.e. in glistmaker/glistcompare list order.
+#include "dev_utils.h"
+#include "psk_internal.h"
+
+namespace {
+
+__global__ void pack_pairs_kernel(const uint64_t *__restrict__ words, uint64_t n, int sbits, uint64_t sample,
+                                  uint64_t *__restrict__ out)
+{
+    const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) out[i] = (words[i] << sbits) | sample;
+}
+
+__global__ void pair_head_flags_kernel(const uint64_t *__restrict__ pairs, uint64_t n, int sbits,
+                                       uint32_t *__restrict__ flags)
+{
+    const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) flags[i] = (i == 0 || (pairs[i] >> sbits) != (pairs[i - 1] >> sbits)) ? 1u : 0u;
+}
+
+// rowpos = exclusive scan of head flags; row of pair i = rowpos[i] + head(i) - 1
+__global__ void presence_fill_kernel(const uint64_t *__restrict__ pairs, uint64_t n, int sbits,
+                                     const uint32_t *__restrict__ rowpos, int wpr, uint64_t *__restrict__ words,
+                                     unsigned long long *__restrict__ bits)
+{
+    const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const uint64_t pr = pairs[i];
+    const uint64_t w = pr >> sbits;
+    const bool head = (i == 0) || (pairs[i - 1] >> sbits) != w;
+    const uint64_t row = (uint64_t)rowpos[i] + (head ? 1u : 0u) - 1u;
+    const uint32_t s = (uint32_t)(pr & ((1ull << sbits) - 1ull));
+    if (head) words[row] = w;
+    atomicOr(&bits[row * (uint64_t)wpr + (s >> 6)], 1ull << (s & 63));
+}
+
+__global__ void gather_rows_kernel(const uint64_t *__restrict__ bits, int wpr, const uint64_t *__restrict__ idx,
+                                   uint64_t n, uint64_t *__restrict__ out)
+{
+    const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n * (uint64_t)wpr) return;
+    const uint64_t r = i / wpr, c = i % wpr;
+    out[i] = bits[idx[r] * (uint64_t)wpr + c];
+}
+
+// keep[r] = 1 if words[r] occurs in the sorted db list
+__global__ void db_member_kernel(const uint64_t *__restrict__ words, uint64_t m, const uint64_t *__restrict__ db,
+                                 uint64_t ndb, uint32_t *__restrict__ keep)
+{
+    const uint64_t r = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (r >= m) return;
+    const uint64_t key = words[r];
+    uint64_t lo = 0, hi = ndb;
+    while (lo < hi) {
+        const uint64_t mid = (lo + hi) >> 1;
+        if (db[mid] < key) lo = mid + 1; else hi = mid;
+    }
+    keep[r] = (lo < ndb && db[lo] == key) ? 1u : 0u;
+}
+
+__global__ void compact_rows_kernel(const uint64_t *__restrict__ words, const uint64_t *__restrict__ bits, int wpr,
+                                    uint64_t m, const uint32_t *__restrict__ pos, uint64_t *__restrict__ words_out,
+                                    uint64_t *__restrict__ bits_out)
+{
+    const uint64_t r = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (r >= m) return;
+    if (pos[r + 1] == pos[r]) return;  // pos has m + 1 entries (caller appends a sentinel)
+    const uint64_t j = pos[r];
+    words_out[j] = words[r];
+    for (int c = 0; c < wpr; c++) bits_out[j * (uint64_t)wpr + c] = bits[r * (uint64_t)wpr + c];
+}
+
+__device__ __forceinline__ uint64_t splitmix64(uint64_t x)
+{
+    x += 0x9E3779B97F4A7C15ull;
+    x = (x ^ (x >> 30)) * 0xBF58476D1CE4E5B9ull;
+    x = (x ^ (x >> 27)) * 0x94D049BB133111EBull;
+    return x ^ (x >> 31);
+}
+
+// Benchmark-only synthetic matrix.  Row classes mimic a real union (DESIGN.md "Synthetic matrix"):
+//   ~45 % of rows: k-mer of a single sample (mutation-born singletons)
+//   ~35 % of rows: present in (almost) every sample (ancestral)
+//   ~20 % of rows: random subset with a row-specific density
+__global__ void synth_presence_kernel(uint64_t *__restrict__ bits, uint64_t m, int wpr, int n_samples, uint64_t seed)
+{
+    const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= m * (uint64_t)wpr) return;
+    const uint64_t r = i / wpr;
+    const int c = (int)(i % wpr);
+    const uint64_t hr = splitmix64(seed ^ (r * 0xD1342543DE82EF95ull));
+    const uint32_t cls = (uint32_t)(hr % 100u);
+    uint64_t word = 0;
+    const int base = c * 64;
+    if (cls < 45) {
+        const int s = (int)((hr >> 20) % (uint64_t)n_samples);
+        if (s >= base && s < base + 64) word = 1ull << (s - base);
+    } else if (cls < 80) {
+        word = ~0ull;
+        const int s = (int)((hr >> 20) % (uint64_t)n_samples);
+        if (((hr >> 50) & 3) == 0 && s >= base && s < base + 64) word &= ~(1ull << (s - base));
+    } else {
+        const uint32_t dens = (uint32_t)((hr >> 24) & 0xff);  // per-row density /256
+        for (int b = 0; b < 64; b += 8) {
+            uint64_t h = splitmix64(hr ^ ((uint64_t)(c * 8 + (b >> 3)) * 0x2545F4914F6CDD1Dull));
+            for (int q = 0; q < 8; q++)
+                if (((h >> (8 * q)) & 0xff) < dens) word |= 1ull << (b + q);
+        }
+    }
+    if (base + 64 > n_samples) {
+        const int valid = n_samples - base;
+        word &= (valid <= 0) ? 0ull : ((valid >= 64) ? ~0ull : ((1ull << valid) - 1ull));
+    }
+    bits[i] = word;
+}
+
+__global__ void iota_words_kernel(uint64_t *__restrict__ words, uint64_t m)
+{
+    const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < m) words[i] = i;
+}
+
+int sample_bits(int n_samples)
+{
+    int b = 1;
+    while ((1 << b) < n_samples) b++;
+    return b;
+}
+
+}  // namespace
+
+static int padded_wpr(int n_samples)
+{
+    int w = (n_samples + 63) / 64;
+    return (w + 1) & ~1;  // even: rows are 16-byte aligned
+}
+
+extern "C" int psk_build_presence(psk_ctx *ctx, uint64_t *n_kmers)
+{
+    if (!ctx) return PSK_EINVAL;
+    if (ctx->k == 0) return psk_fail(ctx, PSK_ESTATE, "psk_begin has not been called");
+    PSK_HIP(ctx, hipSetDevice(ctx->device));
+    uint64_t total = 0;
+    for (int i = 0; i < ctx->n_samples; i++) {
+        if (!ctx->lists[i].done) return psk_fail(ctx, PSK_ESTATE, "sample %d has not been counted", i);
+        total += ctx->lists[i].n_unique;
+    }
+    const int sbits = sample_bits(ctx->n_samples);
+    if (2 * ctx->k + sbits > 64)
+        return psk_fail(ctx, PSK_ERANGE, "k=%d with %d samples needs %d bits per (word, sample) pair (max 64)", ctx->k,
+                        ctx->n_samples, 2 * ctx->k + sbits);
+    if (total >= (1ull << 32)) return psk_fail(ctx, PSK_ERANGE, "%llu (word, sample) pairs exceed 2^32 per GPU; "
+                                                                "shard the word space over more GPUs",
+                                               (unsigned long long)total);
+    ctx->wpr = padded_wpr(ctx->n_samples);
+    ctx->n_kmers = 0;
+    ctx->have_presence = false;
+    if (total == 0) {
+        ctx->have_presence = true;
+        if (n_kmers) *n_kmers = 0;
+        return PSK_OK;
+    }
+    PSK_TRY(dev_reserve(ctx, ctx->keysA, total * 8));
+    PSK_TRY(dev_reserve(ctx, ctx->keysB, total * 8));
+    uint64_t off = 0;
+    for (int i = 0; i < ctx->n_samples; i++) {
+        const SampleList &L = ctx->lists[i];
+        if (!L.n_unique) continue;
+        pack_pairs_kernel<<<div_up(L.n_unique, 256), 256, 0, ctx->stream>>>(L.words, L.n_unique, sbits, (uint64_t)i,
+                                                                            ctx->keysA.as<uint64_t>() + off);
+        PSK_HIP(ctx, hipGetLastError());
+        off += L.n_unique;
+    }
+    uint64_t *sorted = nullptr;
+    PSK_TRY(dev_radix_sort_u64(ctx, ctx->keysA.as<uint64_t>(), ctx->keysB.as<uint64_t>(), total, sbits,
+                               sbits + 2 * ctx->k, &sorted));
+    PSK_TRY(dev_reserve(ctx, ctx->flags, total * 4));
+    PSK_TRY(dev_reserve(ctx, ctx->misc, 64));
+    uint32_t *flags = ctx->flags.as<uint32_t>();
+    uint32_t *d_m = ctx->misc.as<uint32_t>() + 2;
+    pair_head_flags_kernel<<<div_up(total, 256), 256, 0, ctx->stream>>>(sorted, total, sbits, flags);
+    PSK_HIP(ctx, hipGetLastError());
+    PSK_TRY(dev_exclusive_scan_u32(ctx, flags, flags, total, d_m));
+    uint32_t m32 = 0;
+    PSK_HIP(ctx, hipMemcpyAsync(&m32, d_m, 4, hipMemcpyDeviceToHost, ctx->stream));
+    PSK_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    const uint64_t M = m32;
+    PSK_TRY(dev_reserve(ctx, ctx->union_words, M * 8));
+    PSK_TRY(dev_reserve(ctx, ctx->bits, M * (uint64_t)ctx->wpr * 8));
+    PSK_HIP(ctx, hipMemsetAsync(ctx->bits.p, 0, M * (uint64_t)ctx->wpr * 8, ctx->stream));
+    presence_fill_kernel<<<div_up(total, 256), 256, 0, ctx->stream>>>(
+        sorted, total, sbits, flags, ctx->wpr, ctx->union_words.as<uint64_t>(),
+        reinterpret_cast<unsigned long long *>(ctx->bits.p));
+    PSK_HIP(ctx, hipGetLastError());
+    PSK_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    ctx->n_kmers = M;
+    ctx->have_presence = true;
+    ctx->last.valid = false;
+    if (n_kmers) *n_kmers = M;
+    return PSK_OK;
+}
+
+extern "C" int psk_presence_shape(psk_ctx *ctx, uint64_t *n_kmers, int *words_per_row, int *n_samples)
+{
+    if (!ctx) return PSK_EINVAL;
+    if (!ctx->have_presence) return psk_fail(ctx, PSK_ESTATE, "no presence matrix");
+    if (n_kmers) *n_kmers = ctx->n_kmers;
+    if (words_per_row) *words_per_row = ctx->wpr;
+    if (n_samples) *n_samples = ctx->n_samples;
+    return PSK_OK;
+}
+
+extern "C" int psk_get_union(psk_ctx *ctx, uint64_t *words, uint64_t cap)
+{
+    if (!ctx) return PSK_EINVAL;
+    if (!ctx->have_presence) return psk_fail(ctx, PSK_ESTATE, "no presence matrix");
+    if (cap < ctx->n_kmers) return psk_fail(ctx, PSK_ERANGE, "buffer too small");
+    PSK_HIP(ctx, hipSetDevice(ctx->device));
+    if (ctx->n_kmers && words)
+        PSK_HIP(ctx, hipMemcpy(words, ctx->union_words.p, ctx->n_kmers * 8, hipMemcpyDeviceToHost));
+    return PSK_OK;
+}
+
+extern "C" int psk_get_rows(psk_ctx *ctx, const uint64_t *row_idx, uint64_t n, uint64_t *bits_out)
+{
+    if (!ctx) return PSK_EINVAL;
+    if (!ctx->have_presence) return psk_fail(ctx, PSK_ESTATE, "no presence matrix");
+    if (n == 0) return PSK_OK;
+    if (!row_idx || !bits_out) return psk_fail(ctx, PSK_EINVAL, "null buffer");
+    for (uint64_t i = 0; i < n; i++)
+        if (row_idx[i] >= ctx->n_kmers) return psk_fail(ctx, PSK_EINVAL, "row index out of range");
+    PSK_HIP(ctx, hipSetDevice(ctx->device));
+    const uint64_t nb = n * (uint64_t)ctx->wpr * 8;
+    PSK_TRY(dev_reserve(ctx, ctx->flags, n * 8));
+    PSK_TRY(dev_reserve(ctx, ctx->starts, nb));
+    PSK_HIP(ctx, hipMemcpyAsync(ctx->flags.p, row_idx, n * 8, hipMemcpyHostToDevice, ctx->stream));
+    gather_rows_kernel<<<div_up(n * (uint64_t)ctx->wpr, 256), 256, 0, ctx->stream>>>(
+        ctx->bits.as<uint64_t>(), ctx->wpr, ctx->flags.as<uint64_t>(), n, ctx->starts.as<uint64_t>());
+    PSK_HIP(ctx, hipGetLastError());
+    PSK_HIP(ctx, hipMemcpyAsync(bits_out, ctx->starts.p, nb, hipMemcpyDeviceToHost, ctx->stream));
+    PSK_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    return PSK_OK;
+}
+
+extern "C" int psk_intersect_db(psk_ctx *ctx, const uint64_t *db_words, uint64_t n_db, uint64_t *n_kmers)
+{
+    if (!ctx) return PSK_EINVAL;
+    if (!ctx->have_presence) return psk_fail(ctx, PSK_ESTATE, "no presence matrix");
+    PSK_HIP(ctx, hipSetDevice(ctx->device));
+    const uint64_t M = ctx->n_kmers;
+    if (M == 0) { if (n_kmers) *n_kmers = 0; return PSK_OK; }
+    PSK_TRY(dev_reserve(ctx, ctx->keysA, (n_db ? n_db : 1) * 8));
+    if (n_db) PSK_HIP(ctx, hipMemcpyAsync(ctx->keysA.p, db_words, n_db * 8, hipMemcpyHostToDevice, ctx->stream));
+    PSK_TRY(dev_reserve(ctx, ctx->flags, (M + 1) * 4));
+    PSK_TRY(dev_reserve(ctx, ctx->misc, 64));
+    uint32_t *keep = ctx->flags.as<uint32_t>();
+    uint32_t *d_m = ctx->misc.as<uint32_t>() + 4;
+    db_member_kernel<<<div_up(M, 256), 256, 0, ctx->stream>>>(ctx->union_words.as<uint64_t>(), M,
+                                                             ctx->keysA.as<uint64_t>(), n_db, keep);
+    PSK_HIP(ctx, hipGetLastError());
+    // sentinel so that pos[M] = number kept; compact_rows reads pos[r+1] != pos[r]
+    PSK_HIP(ctx, hipMemsetAsync(keep + M, 0, 4, ctx->stream));
+    PSK_TRY(dev_exclusive_scan_u32(ctx, keep, keep, M + 1, d_m));
+    uint32_t kept = 0;
+    PSK_HIP(ctx, hipMemcpyAsync(&kept, d_m, 4, hipMemcpyDeviceToHost, ctx->stream));
+    PSK_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    PSK_TRY(dev_reserve(ctx, ctx->keysB, (uint64_t)(kept ? kept : 1) * (1 + ctx->wpr) * 8));
+    uint64_t *w2 = ctx->keysB.as<uint64_t>();
+    uint64_t *b2 = w2 + (kept ? kept : 1);
+    compact_rows_kernel<<<div_up(M, 256), 256, 0, ctx->stream>>>(ctx->union_words.as<uint64_t>(),
+                                                                ctx->bits.as<uint64_t>(), ctx->wpr, M, keep, w2, b2);
+    PSK_HIP(ctx, hipGetLastError());
+    PSK_HIP(ctx, hipMemcpyAsync(ctx->union_words.p, w2, (uint64_t)kept * 8, hipMemcpyDeviceToDevice, ctx->stream));
+    PSK_HIP(ctx, hipMemcpyAsync(ctx->bits.p, b2, (uint64_t)kept * ctx->wpr * 8, hipMemcpyDeviceToDevice, ctx->stream));
+    PSK_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    ctx->n_kmers = kept;
+    ctx->last.valid = false;
+    if (n_kmers) *n_kmers = kept;
+    return PSK_OK;
+}
+
+extern "C" int psk_set_presence(psk_ctx *ctx, const uint64_t *words, const uint64_t *bits, uint64_t n_kmers,
+                                int words_per_row, int n_samples)
+{
+    if (!ctx) return PSK_EINVAL;
+    if (n_samples < 1 || words_per_row != padded_wpr(n_samples))
+        return psk_fail(ctx, PSK_EINVAL, "words_per_row must be %d for %d samples", padded_wpr(n_samples), n_samples);
+    if (!bits && n_kmers) return psk_fail(ctx, PSK_EINVAL, "null matrix");
+    PSK_HIP(ctx, hipSetDevice(ctx->device));
+    reset_lists(ctx, n_samples);
+    ctx->n_samples = n_samples;
+    ctx->wpr = words_per_row;
+    ctx->n_kmers = n_kmers;
+    const uint64_t m1 = n_kmers ? n_kmers : 1;
+    PSK_TRY(dev_reserve(ctx, ctx->union_words, m1 * 8));
+    PSK_TRY(dev_reserve(ctx, ctx->bits, m1 * (uint64_t)words_per_row * 8));
+    if (n_kmers) {
+        if (words) PSK_HIP(ctx, hipMemcpy(ctx->union_words.p, words, n_kmers * 8, hipMemcpyHostToDevice));
+        else {
+            iota_words_kernel<<<div_up(n_kmers, 256), 256, 0, ctx->stream>>>(ctx->union_words.as<uint64_t>(), n_kmers);
+            PSK_HIP(ctx, hipGetLastError());
+        }
+        PSK_HIP(ctx, hipMemcpy(ctx->bits.p, bits, n_kmers * (uint64_t)words_per_row * 8, hipMemcpyHostToDevice));
+    }
+    PSK_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    ctx->have_presence = true;
+    ctx->last.valid = false;
+    return PSK_OK;
+}
+
+extern "C" int psk_synth_presence(psk_ctx *ctx, uint64_t n_kmers, int n_samples, uint64_t seed)
+{
+    if (!ctx) return PSK_EINVAL;
+    if (n_samples < 1 || n_kmers < 1) return psk_fail(ctx, PSK_EINVAL, "bad shape");
+    PSK_HIP(ctx, hipSetDevice(ctx->device));
+    reset_lists(ctx, n_samples);
+    ctx->n_samples = n_samples;
+    ctx->wpr = padded_wpr(n_samples);
+    ctx->n_kmers = n_kmers;
+    PSK_TRY(dev_reserve(ctx, ctx->union_words, n_kmers * 8));
+    PSK_TRY(dev_reserve(ctx, ctx->bits, n_kmers * (uint64_t)ctx->wpr * 8));
+    iota_words_kernel<<<div_up(n_kmers, 256), 256, 0, ctx->stream>>>(ctx->union_words.as<uint64_t>(), n_kmers);
+    PSK_HIP(ctx, hipGetLastError());
+    synth_presence_kernel<<<div_up(n_kmers * (uint64_t)ctx->wpr, 256), 256, 0, ctx->stream>>>(
+        ctx->bits.as<uint64_t>(), n_kmers, ctx->wpr, n_samples, seed);
+    PSK_HIP(ctx, hipGetLastError());
+    PSK_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    ctx->have_presence = true;
+    ctx->last.valid = false;
+    return PSK_OK;
+}

@@ -1,0 +1,109 @@
+// Internal declarations shared by the translation units of libpsk.so (gfx950 only).
+#pragma once
+#include <hip/hip_runtime.h>
+
+#include <cstdarg>
+#include <cstdint>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <string>
+#include <vector>
+
+#include "../../include/psk.h"
+
+#define PSK_WAVE 64
+
+// ---- growable device buffer -------------------------------------------------------------------
+struct DevBuf {
+    void *p = nullptr;
+    size_t cap = 0;  // bytes
+    template <class T> T *as() const { return reinterpret_cast<T *>(p); }
+};
+
+struct SampleList {
+    uint64_t *words = nullptr;  // device, ascending canonical words (this slab)
+    uint32_t *freqs = nullptr;  // device
+    uint64_t n_unique = 0;
+    uint64_t n_total = 0;
+    bool done = false;
+};
+
+struct ScanParams {  // what psk_rescan_timed needs to re-launch the last chi2 scan
+    bool valid = false;
+    bool weighted = false;
+    int min_samples = 0, max_samples = 0;
+    double pvalue_cutoff = 0;
+    int omit_B = 0;
+    uint64_t n_kmers_global = 0;
+    int n1 = 0, n0 = 0;      // class sizes of the last chi2 scan
+    double W1 = 0, W0 = 0;   // class weight totals
+};
+
+struct psk_ctx {
+    int device = 0;
+    hipStream_t stream = nullptr;
+    hipEvent_t ev0 = nullptr, ev1 = nullptr;
+    std::string err;
+    int n_cu = 0;
+
+    // run configuration
+    int k = 0;
+    int n_samples = 0;
+    uint64_t slab_lo = 0, slab_hi = 0;  // slab_hi == 0: unbounded
+    std::vector<SampleList> lists;
+
+    // scratch for per-sample counting
+    DevBuf raw, keysA, keysB, hist, scan_tmp, flags, starts, misc;
+    std::vector<uint8_t> host_clean;
+
+    // presence matrix
+    uint64_t n_kmers = 0;
+    int wpr = 0;  // u64 words per row (even)
+    DevBuf union_words, bits;
+    bool have_presence = false;
+
+    // scan state
+    DevBuf mask1, mask0, wts, phe, res, res_count, res_sorted;
+    uint64_t n_pass = 0;
+    int last_scan_kind = 0;  // 1 chi2, 2 ttest
+    double last_scan_ms = 0;
+    ScanParams last;
+};
+
+// ---- error helpers ----------------------------------------------------------------------------
+int psk_fail(psk_ctx *ctx, int code, const char *fmt, ...);
+
+#define PSK_HIP(ctx, call)                                                                            \
+    do {                                                                                              \
+        hipError_t e_ = (call);                                                                       \
+        if (e_ != hipSuccess)                                                                         \
+            return psk_fail((ctx), PSK_EHIP, "%s failed: %s (%s:%d)", #call, hipGetErrorString(e_), \
+                            __FILE__, __LINE__);                                                      \
+    } while (0)
+
+#define PSK_TRY(expr)              \
+    do {                           \
+        int rc_ = (expr);          \
+        if (rc_ != PSK_OK) return rc_; \
+    } while (0)
+
+int dev_reserve(psk_ctx *ctx, DevBuf &b, size_t bytes);  // grow-only, contents NOT preserved
+void dev_release(DevBuf &b);
+void reset_lists(psk_ctx *ctx, int n_samples);  // frees the per-sample lists, resizes to n_samples
+
+static inline unsigned div_up(uint64_t a, uint64_t b) { return (unsigned)((a + b - 1) / b); }
+
+// ---- device primitives (scan.hip / radix_sort.hip) ---------------------------------------------
+// Exclusive prefix sum of n u32 values (in == out allowed).  total_out (device u32*) may be null.
+int dev_exclusive_scan_u32(psk_ctx *ctx, const uint32_t *in, uint32_t *out, uint64_t n, uint32_t *total_out);
+// Stable LSD radix sort of n u64 keys on bits [bit_lo, bit_hi).  Sorted data ends in *sorted_out
+// (either a or b).  n < 2^32.
+int dev_radix_sort_u64(psk_ctx *ctx, uint64_t *a, uint64_t *b, uint64_t n, int bit_lo, int bit_hi,
+                       uint64_t **sorted_out);
+
+// ---- stages --------------------------------------------------------------------------------------
+int64_t frame_sequence_host(const uint8_t *bytes, size_t len, uint8_t *out, size_t out_cap);
+// clean stream (device) -> canonical words inside [lo, hi) appended to out; *n_out (device u32) counts them
+int launch_extract(psk_ctx *ctx, const uint8_t *clean, uint64_t len, int k, uint64_t lo, uint64_t hi, uint64_t *out,
+                   uint32_t *n_out);

@@ -1,0 +1,141 @@
+"""Range sharding of the canonical k-mer word space over the GPUs of one node, and the two small
+collectives the sharded path needs:
+
+  1. all-reduce(sum) of the per-slab union sizes -> the global Bonferroni denominator
+     (phenotypes.no_kmers_to_analyse, modeling.py:644,:738,:795) BEFORE any filtering;
+  2. all-gather(v) of each slab's surviving rows (word, statistic, p, n_with, presence bits).
+
+One process per GPU under torch.distributed (backend "nccl" = RCCL over xGMI on the GPU box,
+"gloo" in the CPU tests).  torch is plumbing here: the data path never leaves libpsk.so.  With
+world size 1 nothing in this module touches torch.
+"""
+import os
+
+import numpy as np
+
+
+def slab_bounds(k, world, rank):
+    """Contiguous slab [lo, hi) of the 2k-bit word space for `rank`; hi == 0 means "to the end"
+    (the psk_begin convention, needed because 4**32 does not fit in u64).  Concatenating the
+    slabs in rank order reproduces glistmaker's ascending list order."""
+    space = 1 << (2 * k)
+    lo = (space * rank) // world
+    hi = (space * (rank + 1)) // world
+    if rank == world - 1:
+        hi = 0
+    return lo, hi
+
+
+class Group:
+    """Thin view of the default torch.distributed process group (or a no-op for one rank)."""
+
+    def __init__(self):
+        self.world = int(os.environ.get("WORLD_SIZE", "1"))
+        self.rank = int(os.environ.get("RANK", "0"))
+        self.local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+        self._dist = None
+        self._dev = None
+
+    def init(self, backend=None):
+        if self.world == 1:
+            return self
+        import torch
+        import torch.distributed as dist
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29533")
+        if backend is None:
+            backend = "nccl" if torch.cuda.is_available() else "gloo"
+        if backend == "nccl":
+            torch.cuda.set_device(self.local_rank)
+            self._dev = torch.device("cuda", self.local_rank)
+        else:
+            self._dev = torch.device("cpu")
+        if not dist.is_initialized():
+            dist.init_process_group(backend=backend, rank=self.rank, world_size=self.world)
+        self._dist = dist
+        return self
+
+    def barrier(self):
+        if self._dist is not None:
+            self._dist.barrier()
+
+    def close(self):
+        if self._dist is not None and self._dist.is_initialized():
+            self._dist.destroy_process_group()
+        self._dist = None
+
+    # -- collectives on small host arrays ---------------------------------------------------------
+    def allreduce_sum(self, value):
+        """Sum of a python int / float over ranks (exact for ints below 2^63)."""
+        if self._dist is None:
+            return value
+        import torch
+        is_int = isinstance(value, (int, np.integer))
+        t = torch.tensor([int(value) if is_int else float(value)],
+                         dtype=torch.int64 if is_int else torch.float64, device=self._dev)
+        self._dist.all_reduce(t, op=self._dist.ReduceOp.SUM)
+        return int(t.item()) if is_int else float(t.item())
+
+    def allreduce_max(self, value):
+        if self._dist is None:
+            return float(value)
+        import torch
+        t = torch.tensor([float(value)], dtype=torch.float64, device=self._dev)
+        self._dist.all_reduce(t, op=self._dist.ReduceOp.MAX)
+        return float(t.item())
+
+    def allgather_bytes(self, payload):
+        """all-gather(v) of one bytes object per rank -> list of bytes in rank order."""
+        if self._dist is None:
+            return [payload]
+        import torch
+        n = torch.tensor([len(payload)], dtype=torch.int64, device=self._dev)
+        sizes = [torch.zeros(1, dtype=torch.int64, device=self._dev) for _ in range(self.world)]
+        self._dist.all_gather(sizes, n)
+        sizes = [int(s.item()) for s in sizes]
+        cap = max(max(sizes), 1)
+        buf = torch.zeros(cap, dtype=torch.uint8, device=self._dev)
+        if len(payload):
+            buf[: len(payload)] = torch.frombuffer(bytearray(payload), dtype=torch.uint8).to(self._dev)
+        outs = [torch.zeros(cap, dtype=torch.uint8, device=self._dev) for _ in range(self.world)]
+        self._dist.all_gather(outs, buf)
+        return [bytes(o[:s].cpu().numpy().tobytes()) for o, s in zip(outs, sizes)]
+
+
+_FIELDS = (("word", np.uint64), ("stat", np.float64), ("p", np.float64), ("mean_x", np.float64),
+           ("mean_y", np.float64), ("n_with", np.int32))
+
+
+def pack_candidates(res, bits):
+    """One slab's surviving rows -> bytes: header (n, wpr) + the SoA columns + presence rows."""
+    n = len(res["word"])
+    wpr = bits.shape[1] if n else 0
+    parts = [np.array([n, wpr], dtype=np.int64).tobytes()]
+    for name, dt in _FIELDS:
+        parts.append(np.ascontiguousarray(res[name], dtype=dt).tobytes())
+    parts.append(np.ascontiguousarray(bits, dtype=np.uint64).tobytes())
+    return b"".join(parts)
+
+
+def unpack_candidates(payload):
+    n, wpr = (int(x) for x in np.frombuffer(payload, dtype=np.int64, count=2))
+    off = 16
+    res = {}
+    for name, dt in _FIELDS:
+        sz = n * np.dtype(dt).itemsize
+        res[name] = np.frombuffer(payload, dtype=dt, count=n, offset=off).copy()
+        off += sz
+    bits = np.frombuffer(payload, dtype=np.uint64, count=n * wpr, offset=off).reshape(n, wpr).copy() if n else \
+        np.zeros((0, wpr), dtype=np.uint64)
+    return res, bits
+
+
+def merge_candidates(payloads):
+    """Concatenate the slabs in rank order: slabs are ascending ranges, so the result is in
+    ascending word order -- byte-identical to what one GPU produces for the whole space."""
+    parts = [unpack_candidates(p) for p in payloads]
+    res = {name: np.concatenate([p[0][name] for p in parts]) for name, _ in _FIELDS}
+    wpr = max([p[1].shape[1] for p in parts] + [0])
+    bits = np.concatenate([p[1] if p[1].shape[1] == wpr else np.zeros((0, wpr), np.uint64) for p in parts]) \
+        if parts else np.zeros((0, wpr), np.uint64)
+    return res, bits

@@ -1,0 +1,208 @@
+"""PskContext: numpy-level wrapper over the C ABI (one context = one GPU = one rank)."""
+import ctypes
+
+import numpy as np
+
+from . import _lib
+from ._lib import PskError
+
+
+def words_per_row(n_samples):
+    """u64 words per presence row: ceil(n/64) rounded up to even (rows are 16-byte aligned)."""
+    return (((n_samples + 63) // 64) + 1) & ~1
+
+
+def _ptr(a):
+    return None if a is None else a.ctypes.data
+
+
+class PskContext:
+    def __init__(self, device=0):
+        self._lib = _lib.load()
+        h = ctypes.c_void_p()
+        rc = self._lib.psk_init(int(device), ctypes.byref(h))
+        if rc != 0:
+            raise PskError("psk_init(%d) failed: %s" % (device, self._lib.psk_last_error(None).decode()))
+        self._h = h
+        self.device = device
+        self.k = None
+        self.n_samples = None
+
+    # -- plumbing -------------------------------------------------------------------------------
+    def _check(self, rc, what):
+        if rc != 0:
+            raise PskError("%s failed (%d): %s" % (what, rc, self._lib.psk_last_error(self._h).decode()))
+
+    def close(self):
+        if getattr(self, "_h", None):
+            self._lib.psk_free(self._h)
+            self._h = None
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *a):
+        self.close()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def device_info(self):
+        name = ctypes.create_string_buffer(256)
+        ncu = ctypes.c_int()
+        mem = ctypes.c_uint64()
+        self._check(self._lib.psk_device_info(self._h, name, 256, ctypes.byref(ncu), ctypes.byref(mem)), "device_info")
+        return {"name": name.value.decode(), "n_cu": ncu.value, "hbm_bytes": mem.value}
+
+    # -- k-mer plane ----------------------------------------------------------------------------
+    def begin(self, k, n_samples, slab_lo=0, slab_hi=0):
+        self._check(self._lib.psk_begin(self._h, int(k), int(n_samples), int(slab_lo), int(slab_hi)), "psk_begin")
+        self.k, self.n_samples = int(k), int(n_samples)
+
+    def count_kmers(self, sample_idx, data):
+        data = bytes(data)
+        nu, nt = ctypes.c_uint64(), ctypes.c_uint64()
+        self._check(self._lib.psk_count_kmers(self._h, int(sample_idx), data, len(data), ctypes.byref(nu),
+                                              ctypes.byref(nt)), "psk_count_kmers")
+        return nu.value, nt.value
+
+    def get_list(self, sample_idx, n_unique):
+        words = np.empty(n_unique, dtype=np.uint64)
+        freqs = np.empty(n_unique, dtype=np.uint32)
+        self._check(self._lib.psk_get_list(self._h, int(sample_idx), _ptr(words), _ptr(freqs), n_unique), "psk_get_list")
+        return words, freqs
+
+    def lookup_counts(self, sample_idx, words):
+        words = np.ascontiguousarray(words, dtype=np.uint64)
+        out = np.zeros(len(words), dtype=np.uint32)
+        self._check(self._lib.psk_lookup_counts(self._h, int(sample_idx), _ptr(words), len(words), _ptr(out)),
+                    "psk_lookup_counts")
+        return out
+
+    def build_presence(self):
+        m = ctypes.c_uint64()
+        self._check(self._lib.psk_build_presence(self._h, ctypes.byref(m)), "psk_build_presence")
+        return m.value
+
+    def presence_shape(self):
+        m, w, n = ctypes.c_uint64(), ctypes.c_int(), ctypes.c_int()
+        self._check(self._lib.psk_presence_shape(self._h, ctypes.byref(m), ctypes.byref(w), ctypes.byref(n)),
+                    "psk_presence_shape")
+        return m.value, w.value, n.value
+
+    def get_union(self):
+        m, _, _ = self.presence_shape()
+        words = np.empty(m, dtype=np.uint64)
+        self._check(self._lib.psk_get_union(self._h, _ptr(words), m), "psk_get_union")
+        return words
+
+    def get_rows(self, row_idx):
+        row_idx = np.ascontiguousarray(row_idx, dtype=np.uint64)
+        _, wpr, _ = self.presence_shape()
+        out = np.zeros((len(row_idx), wpr), dtype=np.uint64)
+        self._check(self._lib.psk_get_rows(self._h, _ptr(row_idx), len(row_idx), _ptr(out)), "psk_get_rows")
+        return out
+
+    def intersect_db(self, db_words):
+        db = np.ascontiguousarray(np.unique(np.asarray(db_words, dtype=np.uint64)))
+        m = ctypes.c_uint64()
+        self._check(self._lib.psk_intersect_db(self._h, _ptr(db), len(db), ctypes.byref(m)), "psk_intersect_db")
+        return m.value
+
+    def set_presence(self, bits, n_samples, words=None):
+        bits = np.ascontiguousarray(bits, dtype=np.uint64)
+        m, wpr = bits.shape
+        if words is not None:
+            words = np.ascontiguousarray(words, dtype=np.uint64)
+        self._check(self._lib.psk_set_presence(self._h, _ptr(words), _ptr(bits), m, wpr, int(n_samples)),
+                    "psk_set_presence")
+        self.n_samples = int(n_samples)
+
+    def synth_presence(self, n_kmers, n_samples, seed=1):
+        self._check(self._lib.psk_synth_presence(self._h, int(n_kmers), int(n_samples), int(seed)), "psk_synth_presence")
+        self.n_samples = int(n_samples)
+
+    # -- association scans ----------------------------------------------------------------------
+    def chi2_scan(self, pheno, weights, min_samples, max_samples, pvalue_cutoff, omit_B, n_kmers_global=0):
+        """pheno: int8 array, 1 / 0 / -1 (NA).  Returns the number of surviving k-mers."""
+        ph = np.ascontiguousarray(pheno, dtype=np.int8)
+        w = None if weights is None else np.ascontiguousarray(weights, dtype=np.float64)
+        n = ctypes.c_uint64()
+        self._check(self._lib.psk_chi2_scan(self._h, _ptr(ph), _ptr(w), int(min_samples), int(max_samples),
+                                            float(pvalue_cutoff), int(bool(omit_B)), int(n_kmers_global),
+                                            ctypes.byref(n)), "psk_chi2_scan")
+        return n.value
+
+    def ttest_scan(self, values, valid, weights, min_samples, max_samples, pvalue_cutoff, n_kmers_global=0):
+        v = np.ascontiguousarray(values, dtype=np.float64)
+        ok = np.ascontiguousarray(valid, dtype=np.uint8)
+        w = None if weights is None else np.ascontiguousarray(weights, dtype=np.float64)
+        n = ctypes.c_uint64()
+        self._check(self._lib.psk_ttest_scan(self._h, _ptr(v), _ptr(ok), _ptr(w), int(min_samples), int(max_samples),
+                                             float(pvalue_cutoff), int(n_kmers_global), ctypes.byref(n)),
+                    "psk_ttest_scan")
+        return n.value
+
+    def get_results(self, n_pass):
+        n = int(n_pass)
+        out = {"row": np.zeros(n, np.uint64), "word": np.zeros(n, np.uint64), "stat": np.zeros(n), "p": np.zeros(n),
+               "mean_x": np.zeros(n), "mean_y": np.zeros(n), "n_with": np.zeros(n, np.int32)}
+        self._check(self._lib.psk_get_results(self._h, _ptr(out["row"]), _ptr(out["word"]), _ptr(out["stat"]),
+                                              _ptr(out["p"]), _ptr(out["mean_x"]), _ptr(out["mean_y"]),
+                                              _ptr(out["n_with"]), n), "psk_get_results")
+        return out
+
+    def last_scan_ms(self):
+        return self._lib.psk_last_scan_ms(self._h)
+
+    def rescan_timed(self, reps):
+        ms = ctypes.c_double()
+        self._check(self._lib.psk_rescan_timed(self._h, int(reps), ctypes.byref(ms)), "psk_rescan_timed")
+        return ms.value
+
+    # -- models -----------------------------------------------------------------------------------
+    def _fit(self, fn, name, X, y, ydtype, fold, fit_param, fit_fold, tol, max_iter):
+        X = np.ascontiguousarray(X, dtype=np.uint8)
+        n, p = X.shape
+        y = np.ascontiguousarray(y, dtype=ydtype)
+        fold = np.ascontiguousarray(fold, dtype=np.int32)
+        fit_param = np.ascontiguousarray(fit_param, dtype=np.float64)
+        fit_fold = np.ascontiguousarray(fit_fold, dtype=np.int32)
+        nf = len(fit_param)
+        coef = np.zeros((nf, p))
+        icpt = np.zeros(nf)
+        iters = np.zeros(nf, dtype=np.int32)
+        self._check(fn(self._h, _ptr(X), _ptr(y), n, p, _ptr(fold), _ptr(fit_param), _ptr(fit_fold), nf, float(tol),
+                       int(max_iter), _ptr(coef), _ptr(icpt), _ptr(iters)), name)
+        return coef, icpt, iters
+
+    def logreg_l1_fit(self, X, y01, fold, fit_param, fit_fold, tol=1e-4, max_iter=1000):
+        return self._fit(self._lib.psk_logreg_l1_fit, "psk_logreg_l1_fit", X, y01, np.int32, fold, fit_param, fit_fold,
+                         tol, max_iter)
+
+    def lasso_fit(self, X, y, fold, fit_param, fit_fold, tol=1e-4, max_iter=1000):
+        return self._fit(self._lib.psk_lasso_fit, "psk_lasso_fit", X, y, np.float64, fold, fit_param, fit_fold, tol,
+                         max_iter)
+
+    # -- prediction -------------------------------------------------------------------------------
+    def count_dict(self, data, k, dict_words):
+        data = bytes(data)
+        d = np.ascontiguousarray(dict_words, dtype=np.uint64)
+        out = np.zeros(len(d), dtype=np.uint32)
+        self._check(self._lib.psk_count_dict(self._h, data, len(data), int(k), _ptr(d), len(d), _ptr(out)),
+                    "psk_count_dict")
+        return out
+
+
+def frame_sequence(data):
+    """Host-only tokeniser framing (psk_frame_sequence): the clean stream handed to the GPU."""
+    lib = _lib.load()
+    data = bytes(data)
+    out = np.zeros(max(len(data), 1), dtype=np.uint8)
+    n = lib.psk_frame_sequence(data, len(data), out.ctypes.data, len(out))
+    if n < 0:
+        raise PskError("psk_frame_sequence failed: %d" % n)
+    return out[:n].tobytes()

@@ -1,0 +1,270 @@
+"""GPU parity tests proper (-m gpu): the HIP path, called through the C ABI (libpsk.so via
+ctypes), against the CPU oracle on the same inputs and against the committed golden fixtures.
+Bit-exact for words / counts / bit rows / row sets; statistic tolerances are written below."""
+import base64
+import gzip
+import hashlib
+import json
+import os
+
+import numpy as np
+import pytest
+
+from helpers import GOLDEN, load_dataset, read_results_tsv, tokenizer_cases
+
+pytestmark = pytest.mark.gpu
+
+CHI2_RTOL = 1e-12   # north_star asks 1e-6 relative; unit-weight rows are evaluated in the same order
+WEIGHTED_RTOL = 1e-9  # weighted sums are accumulated in a different order than the reference's loop
+T_RTOL = 1e-8
+
+
+@pytest.fixture(scope="module")
+def ctx():
+    from phenotypeseeker_amd.engine import PskContext
+    c = PskContext(0)
+    yield c
+    c.close()
+
+
+def test_tokenizer_cases_bit_exact(ctx, oracle):
+    for data, k, ref in tokenizer_cases():
+        ctx.begin(k, 1)
+        nu, nt = ctx.count_kmers(0, data)
+        w, f = ctx.get_list(0, nu)
+        if ref is None:
+            assert nu == 0
+        else:
+            assert oracle.list_bytes(k, w, f) == ref, (data[:60], k)
+
+
+@pytest.mark.parametrize("k", [5, 13, 16, 21, 31, 32])
+def test_megabase_genome_list_bit_exact(ctx, oracle, k):
+    from phenotypeseeker_amd.synth import GenomeSet
+    gs = GenomeSet(2, 1_000_003, seed=5 + k)
+    name, fa = gs.sample(1)
+    # sprinkle window breaks and lower case
+    b = bytearray(fa)
+    rng = np.random.default_rng(k)
+    for pos in rng.integers(20, len(b), 300):
+        if b[pos] != 10:
+            b[pos] = ord("N") if pos % 3 else ord("a")
+    fa = bytes(b)
+    ow, of, ont = oracle.count_kmers(fa, k)
+    ctx.begin(k, 1)
+    nu, nt = ctx.count_kmers(0, fa)
+    assert (nu, nt) == (len(ow), ont)
+    w, f = ctx.get_list(0, nu)
+    assert np.array_equal(w, ow)
+    assert np.array_equal(f, of)
+
+
+def test_slab_sharding_concatenates_to_full_list(ctx, oracle):
+    from phenotypeseeker_amd.synth import GenomeSet
+    k = 13
+    name, fa = GenomeSet(1, 200_000, seed=3).sample(0)
+    ow, of, _ = oracle.count_kmers(fa, k)
+    space = 1 << (2 * k)
+    parts_w, parts_f = [], []
+    edges = [0, space // 7, space // 3, space // 2 + 12345, 0]
+    for lo, hi in zip(edges[:-1], edges[1:]):
+        ctx.begin(k, 1, lo, hi)
+        nu, nt = ctx.count_kmers(0, fa)
+        w, f = ctx.get_list(0, nu)
+        if len(w):
+            assert w.min() >= lo and (hi == 0 or w.max() < hi)
+        parts_w.append(w)
+        parts_f.append(f)
+    assert np.array_equal(np.concatenate(parts_w), ow)
+    assert np.array_equal(np.concatenate(parts_f), of)
+
+
+@pytest.mark.parametrize("tag", ["ds_omitB", "ds_bonf"])
+def test_dataset_union_and_presence(ctx, oracle, tag):
+    ds = load_dataset(tag)
+    k, names = ds["meta"]["k"], ds["names"]
+    ctx.begin(k, len(names))
+    lists = []
+    for i, n in enumerate(names):
+        nu, nt = ctx.count_kmers(i, ds["files"][n])
+        m = ds["meta"]["lists"][n]
+        assert (nu, nt) == (m["n_unique"], m["n_total"])
+        w, f = ctx.get_list(i, nu)
+        assert hashlib.sha256(oracle.list_bytes(k, w, f)).hexdigest() == m["sha256"]
+        lists.append(w)
+    M = ctx.build_presence()
+    assert M == ds["meta"]["n_union"]
+    uw = ctx.get_union()
+    assert np.array_equal(uw, np.load(os.path.join(ds["dir"], "union_words.npy")))
+    bits = ctx.get_rows(np.arange(M, dtype=np.uint64))
+    ref_bits = oracle.presence_bits(lists, uw, wpr=bits.shape[1])
+    assert np.array_equal(bits, ref_bits)
+    # glistquery -l mapping of one sample = per-word count lookup
+    ms = names.index(ds["meta"]["mapped_sample"])
+    counts = ctx.lookup_counts(ms, uw)
+    txt = "".join("%s\t%d\n" % (oracle.word_to_kmer(w, k), c) for w, c in zip(uw, counts))
+    assert hashlib.sha256(txt.encode()).hexdigest() == ds["meta"]["mapped_sha256"]
+
+
+@pytest.mark.parametrize("tag,omit_B", [("ds_omitB", True), ("ds_bonf", False)])
+def test_chi2_results_match_reference_tsv(ctx, oracle, tag, omit_B):
+    ds = load_dataset(tag)
+    k, names = ds["meta"]["k"], ds["names"]
+    n = len(names)
+    ctx.begin(k, n)
+    for i, nm in enumerate(names):
+        ctx.count_kmers(i, ds["files"][nm])
+    M = ctx.build_presence()
+    ph = np.array([-1 if p == "NA" else p for p in ds["pheno"]], dtype=np.int8)
+    npass = ctx.chi2_scan(ph, None, 2, n - 2, 0.05, omit_B, M)
+    res = ctx.get_results(npass)
+    header, ref = read_results_tsv(os.path.join(ds["dir"], "chi2_results_Pheno.tsv"))
+    assert npass == len(ref)
+    rows = ctx.get_rows(res["row"])
+    got = {}
+    for j in range(npass):
+        pres = [(int(rows[j, i >> 6]) >> (i & 63)) & 1 for i in range(n)]
+        with_names = [names[i] for i in range(n) if pres[i] and ds["pheno"][i] != "NA"]
+        got[oracle.word_to_kmer(res["word"][j], k)] = (repr(oracle.round2(res["stat"][j])), oracle.pstring(res["p"][j]),
+                                                         str(int(res["n_with"][j])), " ".join(["|"] + with_names))
+    assert set(got) == {r[0] for r in ref}
+    for kmer, stat, p, nw, nmz in ref:
+        assert got[kmer] == (stat, p, nw, nmz), kmer
+
+
+def _random_matrix(rng, m, n, wpr):
+    """rows with varied densities, incl. all-zero / all-one rows"""
+    dens = rng.random(m) ** 2
+    dens[: m // 10] = 0.0
+    dens[m // 10: m // 5] = 1.0
+    pres = rng.random((m, n)) < dens[:, None]
+    bits = np.zeros((m, wpr), dtype=np.uint64)
+    for i in range(n):
+        bits[:, i >> 6] |= pres[:, i].astype(np.uint64) << np.uint64(i & 63)
+    return bits
+
+
+@pytest.mark.parametrize("n", [3, 30, 64, 65, 100, 128, 150, 256, 384, 1000, 1024, 2048, 9000])
+@pytest.mark.parametrize("weighted", [False, True])
+def test_chi2_scan_vs_oracle(ctx, oracle, n, weighted):
+    from phenotypeseeker_amd.engine import words_per_row
+    rng = np.random.default_rng(1000 + n + int(weighted))
+    m = 6000 if n <= 2048 else 1500
+    wpr = words_per_row(n)
+    bits = _random_matrix(rng, m, n, wpr)
+    pheno = rng.integers(0, 2, n).astype(object)
+    pheno[rng.random(n) < 0.07] = "NA"
+    # associate some rows with the phenotype so that small p-values occur
+    p1 = np.array([p == 1 for p in pheno])
+    for r in range(0, m, 7):
+        row = np.zeros(n, dtype=bool)
+        row[p1] = rng.random(p1.sum()) < 0.9
+        row[~p1] = rng.random((~p1).sum()) < 0.1
+        bits[r] = 0
+        for i in np.nonzero(row)[0]:
+            bits[r, i >> 6] |= np.uint64(1) << np.uint64(i & 63)
+    weights = np.round(rng.uniform(0.05, 3.0, n), 6) if weighted else np.ones(n)
+    ph8 = np.array([-1 if p == "NA" else p for p in pheno], dtype=np.int8)
+    for (mn, mx, cut, omit_B, nk) in [(2, n - 2, 0.05, True, m), (2, n - 2, 0.05, False, m), (1, n, 1.5, True, 10),
+                                      (3, max(n // 2, 3), 1e-3, True, 1000)]:
+        ref = oracle.chi2_scan(bits, list(pheno), weights, n, mn, mx, cut, omit_B, nk)
+        ctx.set_presence(bits, n)
+        npass = ctx.chi2_scan(ph8, weights if weighted else None, mn, mx, cut, omit_B, nk)
+        res = ctx.get_results(npass)
+        keep = np.nonzero(ref["keep"])[0]
+        if not weighted:
+            assert np.array_equal(res["row"], keep.astype(np.uint64))
+            assert np.array_equal(res["n_with"], ref["n_with"][keep])
+            assert np.allclose(res["stat"], ref["stat"][keep], rtol=CHI2_RTOL, atol=0)
+            assert np.allclose(res["p"], ref["p"][keep], rtol=1e-12, atol=0)
+            # string-level identity of what the reference prints
+            assert [oracle.pstring(x) for x in res["p"]] == [oracle.pstring(x) for x in ref["p"][keep]]
+            assert [oracle.round2(x) for x in res["stat"]] == [oracle.round2(x) for x in ref["stat"][keep]]
+        else:
+            # rows within rounding distance of the cut may flip; compare the common rows, bound the rest
+            got = dict(zip(res["row"].tolist(), range(npass)))
+            common = [r for r in keep.tolist() if r in got]
+            assert len(common) >= len(keep) - 2 and npass - len(common) <= 2
+            gi = [got[r] for r in common]
+            assert np.allclose(res["stat"][gi], ref["stat"][common], rtol=WEIGHTED_RTOL, atol=1e-12)
+            assert np.allclose(res["p"][gi], ref["p"][common], rtol=1e-8, atol=0)
+            assert np.array_equal(res["n_with"][gi], ref["n_with"][common])
+
+
+@pytest.mark.parametrize("n", [12, 64, 100, 256, 1024])
+@pytest.mark.parametrize("weighted", [False, True])
+def test_ttest_scan_vs_oracle(ctx, oracle, n, weighted):
+    from phenotypeseeker_amd.engine import words_per_row
+    rng = np.random.default_rng(77 + n + int(weighted))
+    m = 3000
+    wpr = words_per_row(n)
+    bits = _random_matrix(rng, m, n, wpr)
+    vals = np.round(rng.normal(3.0, 1.5, n), 4)
+    valid = rng.random(n) > 0.06
+    for r in range(0, m, 5):  # planted associations
+        row = vals + rng.normal(0, 0.7, n) > 3.4
+        bits[r] = 0
+        for i in np.nonzero(row)[0]:
+            bits[r, i >> 6] |= np.uint64(1) << np.uint64(i & 63)
+    weights = np.round(rng.uniform(0.2, 3.0, n), 6) if weighted else np.ones(n)
+    pheno = [float(v) if ok else "NA" for v, ok in zip(vals, valid)]
+    for (mn, mx, cut, nk) in [(2, n - 2, 0.05, 100), (2, n - 2, 0.9, 1), (3, n // 2, 0.05, m)]:
+        ref = oracle.ttest_scan(bits, pheno, weights, n, mn, mx, cut, nk)
+        ctx.set_presence(bits, n)
+        npass = ctx.ttest_scan(vals, valid, weights if weighted else None, mn, mx, cut, nk)
+        res = ctx.get_results(npass)
+        keep = np.nonzero(ref["keep"])[0]
+        got = dict(zip(res["row"].tolist(), range(npass)))
+        common = [r for r in keep.tolist() if r in got]
+        assert len(common) >= len(keep) - 2 and npass - len(common) <= 2
+        assert len(common) > 0 or len(keep) == 0
+        gi = [got[r] for r in common]
+        assert np.allclose(res["stat"][gi], ref["stat"][common], rtol=T_RTOL, atol=1e-12)
+        assert np.allclose(res["p"][gi], ref["p"][common], rtol=1e-6, atol=1e-300)
+        assert np.allclose(res["mean_x"][gi], ref["mean_x"][common], rtol=1e-12)
+        assert np.allclose(res["mean_y"][gi], ref["mean_y"][common], rtol=1e-12)
+        assert np.array_equal(res["n_with"][gi], ref["n_with"][common])
+
+
+def test_count_dict_matches_gmer_counter(ctx, oracle):
+    with open(os.path.join(GOLDEN, "gmer_counter.json")) as f:
+        d = json.load(f)
+    k = d["k"]
+    words = [oracle.canonical_word(oracle.kmer_to_word(km), k) for km in d["kmers"]]
+    for c in d["cases"]:
+        fa = gzip.decompress(base64.b64decode(c["fasta_gz_b64"]))
+        counts = ctx.count_dict(fa, k, words)
+        body = [l.split("\t") for l in c["output"].splitlines()[2:]]
+        assert [int(b[2]) for b in body] == counts.tolist()
+
+
+def test_full_size_scan_properties(ctx):
+    """BASELINE config-2 sized matrix (2^25 rows x 256 samples): size-independent properties --
+    the scan is idempotent, its survivors come back in ascending row order, flipping the
+    phenotype labels leaves chi2 unchanged, and the NA-everything phenotype yields nothing."""
+    n, m = 256, 1 << 25
+    ctx.synth_presence(m, n, seed=9)
+    ph = (np.arange(n) % 2).astype(np.int8)
+    a = ctx.chi2_scan(ph, None, 2, n - 2, 0.05, False, m)
+    ra = ctx.get_results(a)
+    b = ctx.chi2_scan(ph, None, 2, n - 2, 0.05, False, m)
+    rb = ctx.get_results(b)
+    assert a == b and a > 0
+    assert np.array_equal(ra["row"], rb["row"]) and np.array_equal(ra["stat"], rb["stat"])
+    assert np.all(np.diff(ra["row"].astype(np.int64)) > 0)
+    c = ctx.chi2_scan(1 - ph, None, 2, n - 2, 0.05, False, m)
+    rc = ctx.get_results(c)
+    assert np.array_equal(ra["row"], rc["row"]) and np.allclose(ra["stat"], rc["stat"], rtol=1e-12)
+    assert ctx.chi2_scan(np.full(n, -1, np.int8), None, 2, n - 2, 0.05, True, m) == 0
+    # a sample of survivors re-checked on the CPU by the closed 2x2 formula
+    rows = ctx.get_rows(ra["row"][:200])
+    m1 = np.zeros(rows.shape[1], dtype=np.uint64)
+    for i in np.nonzero(ph == 1)[0]:
+        m1[i >> 6] |= np.uint64(1) << np.uint64(i & 63)
+    for j in range(len(rows)):
+        aa = sum(bin(int(x & y)).count("1") for x, y in zip(rows[j], m1))
+        tot = sum(bin(int(x)).count("1") for x in rows[j])
+        cc = tot - aa
+        A, B, C, D = aa, 128 - aa, cc, 128 - cc
+        chi = 256.0 * (A * D - B * C) ** 2 / ((A + B) * (C + D) * (A + C) * (B + D))
+        assert ra["stat"][j] == pytest.approx(chi, rel=1e-9)
