@@ -86,7 +86,9 @@ __device__ __forceinline__ uint64_t splitmix64(uint64_t x)
 // Benchmark-only synthetic matrix.  Row classes mimic a real union (DESIGN.md "Synthetic matrix"):
 //   ~45 % of rows: k-mer of a single sample (mutation-born singletons)
 //   ~35 % of rows: present in (almost) every sample (ancestral)
-//   ~20 % of rows: random subset with a row-specific density
+//   ~19 % of rows: random subset with a row-specific density
+//   ~ 1 % of rows: "gene" k-mers: 90 % of the even samples, 10 % of the odd ones (bench.py and the
+//                  tests use phenotype = 1 for even samples, so these rows survive the filter)
 __global__ void synth_presence_kernel(uint64_t *__restrict__ bits, uint64_t m, int wpr, int n_samples, uint64_t seed)
 {
     const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
@@ -105,11 +107,14 @@ __global__ void synth_presence_kernel(uint64_t *__restrict__ bits, uint64_t m, i
         const int s = (int)((hr >> 20) % (uint64_t)n_samples);
         if (((hr >> 50) & 3) == 0 && s >= base && s < base + 64) word &= ~(1ull << (s - base));
     } else {
+        const bool gene = cls == 99;
         const uint32_t dens = (uint32_t)((hr >> 24) & 0xff);  // per-row density /256
         for (int b = 0; b < 64; b += 8) {
             uint64_t h = splitmix64(hr ^ ((uint64_t)(c * 8 + (b >> 3)) * 0x2545F4914F6CDD1Dull));
-            for (int q = 0; q < 8; q++)
-                if (((h >> (8 * q)) & 0xff) < dens) word |= 1ull << (b + q);
+            for (int q = 0; q < 8; q++) {
+                const uint32_t thr = gene ? (((b + q) & 1) ? 26u : 230u) : dens;
+                if (((h >> (8 * q)) & 0xff) < thr) word |= 1ull << (b + q);
+            }
         }
     }
     if (base + 64 > n_samples) {
