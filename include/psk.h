@@ -127,7 +127,7 @@ int psk_rescan_timed(psk_ctx *ctx, int reps, double *mean_ms);
  * Replaces the estimator fits behind GridSearchCV (modeling.py:994-1014, :1075-1085,
  * :1208-1216): every (grid value, fold) pair and the refits are independent problems and are
  * solved one per workgroup.
- *   X[n][p]      row-major uint8 design matrix (presence, or counts with --real_counts)
+ *   X[n][p]      row-major float design matrix (presence 0/1, or counts with --real_counts)
  *   fold[n]      test-fold id of each sample in 0..n_folds-1; a fit with fold id f trains on
  *                samples whose fold != f; fit_fold[j] == -1 trains on all samples
  *   fit_param[j] C (logistic) or alpha (lasso) of fit j;  n_fits fits in total
@@ -135,10 +135,10 @@ int psk_rescan_timed(psk_ctx *ctx, int reps, double *mean_ms);
  * Logistic: liblinear's L1R_LR objective ||w||_1 + |b| + C sum log(1+exp(-y(w.x+b))).
  * Lasso: (1/2n)||y - Xw - b||^2 + alpha ||w||_1, unpenalised intercept.
  */
-int psk_logreg_l1_fit(psk_ctx *ctx, const uint8_t *X, const int32_t *y01, int n, int p, const int32_t *fold,
+int psk_logreg_l1_fit(psk_ctx *ctx, const float *X, const int32_t *y01, int n, int p, const int32_t *fold,
                       const double *fit_param, const int32_t *fit_fold, int n_fits, double tol, int max_iter,
                       double *coef_out, double *icpt_out, int32_t *iters_out);
-int psk_lasso_fit(psk_ctx *ctx, const uint8_t *X, const double *y, int n, int p, const int32_t *fold,
+int psk_lasso_fit(psk_ctx *ctx, const float *X, const double *y, int n, int p, const int32_t *fold,
                   const double *fit_param, const int32_t *fit_fold, int n_fits, double tol, int max_iter,
                   double *coef_out, double *icpt_out, int32_t *iters_out);
 

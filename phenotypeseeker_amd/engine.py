@@ -165,7 +165,7 @@ class PskContext:
 
     # -- models -----------------------------------------------------------------------------------
     def _fit(self, fn, name, X, y, ydtype, fold, fit_param, fit_fold, tol, max_iter):
-        X = np.ascontiguousarray(X, dtype=np.uint8)
+        X = np.ascontiguousarray(X, dtype=np.float32)
         n, p = X.shape
         y = np.ascontiguousarray(y, dtype=ydtype)
         fold = np.ascontiguousarray(fold, dtype=np.int32)

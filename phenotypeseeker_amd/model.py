@@ -1,0 +1,179 @@
+"""The estimator boundary: picklable stand-ins for what the reference stores in
+its .pkl -- a fitted GridSearchCV over LogisticRegression(penalty='l1', solver='liblinear') or
+Lasso (modeling.py:994-1014, :1075-1085, :1208-1216, :975-979) -- exposing the attributes the
+reference reads: predict / predict_proba / score, cv_results_['mean_test_score' |
+'std_test_score' | 'params'], best_params_, best_estimator_.coef_ (modeling.py:1226-1247,
+:1427-1436; prediction.py:126-129,:168-172).  All fits of a grid search (grid x folds + the
+refit) are solved on the GPU in one psk_logreg_l1_fit / psk_lasso_fit launch.
+"""
+import numpy as np
+
+from . import cv as _cv
+
+
+class L1LogisticRegression:
+    """liblinear-style L1 logistic regression: ||w||_1 + |b| + C sum log(1+exp(-y(w.x+b)))."""
+
+    def __init__(self, C=1.0, tol=1e-4, max_iter=1000):
+        self.C, self.tol, self.max_iter = C, tol, max_iter
+        self.penalty, self.solver = "l1", "liblinear"
+        self.classes_ = np.array([0, 1])
+        self.coef_ = None
+        self.intercept_ = None
+
+    def __repr__(self):
+        return "LogisticRegression(max_iter=%r, penalty='l1', solver='liblinear', tol=%r)" % (self.max_iter, self.tol)
+
+    def _set(self, coef, icpt):
+        self.coef_ = np.asarray(coef, dtype=np.float64).reshape(1, -1)
+        self.intercept_ = np.array([float(icpt)])
+        self.n_features_in_ = self.coef_.shape[1]
+        return self
+
+    def decision_function(self, X):
+        return np.asarray(X, dtype=np.float64) @ self.coef_[0] + self.intercept_[0]
+
+    def predict(self, X):
+        return self.classes_[(self.decision_function(X) > 0).astype(int)]
+
+    def predict_proba(self, X):
+        p1 = 1.0 / (1.0 + np.exp(-self.decision_function(X)))
+        return np.column_stack([1.0 - p1, p1])
+
+    def score(self, X, y):
+        return np.float64(np.mean(self.predict(X) == np.asarray(y)))
+
+
+class LassoRegression:
+    """(1/2n)||y - Xw - b||^2 + alpha ||w||_1."""
+
+    def __init__(self, alpha=1.0, tol=1e-4, max_iter=1000):
+        self.alpha, self.tol, self.max_iter = alpha, tol, max_iter
+        self.coef_ = None
+        self.intercept_ = None
+
+    def __repr__(self):
+        return "Lasso(max_iter=%r, tol=%r)" % (self.max_iter, self.tol)
+
+    def _set(self, coef, icpt):
+        self.coef_ = np.asarray(coef, dtype=np.float64).ravel()
+        self.intercept_ = float(icpt)
+        self.n_features_in_ = len(self.coef_)
+        return self
+
+    def predict(self, X):
+        return np.asarray(X, dtype=np.float64) @ self.coef_ + self.intercept_
+
+    def score(self, X, y):
+        y = np.asarray(y, dtype=np.float64)
+        res = ((y - self.predict(X)) ** 2).sum()
+        tot = ((y - y.mean()) ** 2).sum()
+        return np.float64(1.0 - res / tot)
+
+
+class GridSearch:
+    """GridSearchCV(model, {'C' | 'alpha': grid}, cv=int) with refit.  `engine_ctx` is only needed
+    by fit(); the fitted object pickles without it."""
+
+    def __init__(self, estimator, param_name, grid, cv):
+        self.estimator = estimator
+        self.param_name = param_name
+        self.param_grid = {param_name: list(grid)}
+        self.cv = int(cv)
+
+    def fit(self, X, y, engine_ctx):
+        X = np.asarray(X, dtype=np.float64)
+        y = np.asarray(y)
+        n = len(y)
+        grid = self.param_grid[self.param_name]
+        is_clf = isinstance(self.estimator, L1LogisticRegression)
+        if self.cv < 2:
+            raise ValueError("k-fold cross-validation requires at least one train/test split by setting "
+                             "n_splits=2 or more, got n_splits=%d." % self.cv)
+        folds = _cv.stratified_kfold(y, self.cv) if is_clf else _cv.kfold(n, self.cv)
+        fit_param, fit_fold = [], []
+        for g in grid:
+            for f in range(self.cv):
+                fit_param.append(float(g))
+                fit_fold.append(f)
+        for g in grid:  # refit candidates on everything: pick after scoring, all in one launch
+            fit_param.append(float(g))
+            fit_fold.append(-1)
+        tol, mi = self.estimator.tol, int(self.estimator.max_iter)
+        if is_clf:
+            coef, icpt, iters = engine_ctx.logreg_l1_fit(X, y.astype(np.int32), folds, fit_param, fit_fold, tol, mi)
+        else:
+            coef, icpt, iters = engine_ctx.lasso_fit(X, y.astype(np.float64), folds, fit_param, fit_fold, tol, mi)
+        scores = np.zeros((len(grid), self.cv))
+        for gi in range(len(grid)):
+            for f in range(self.cv):
+                j = gi * self.cv + f
+                te = folds == f
+                est = type(self.estimator)(**{self.param_name: grid[gi]})._set(coef[j], icpt[j])
+                scores[gi, f] = est.score(X[te], y[te])
+        mean = scores.mean(axis=1)
+        std = scores.std(axis=1)
+        self.cv_results_ = {"mean_test_score": mean, "std_test_score": std,
+                            "params": [{self.param_name: g} for g in grid],
+                            "rank_test_score": _rank_min(-mean)}
+        for f in range(self.cv):
+            self.cv_results_["split%d_test_score" % f] = scores[:, f]
+        self.best_index_ = int(np.argmin(self.cv_results_["rank_test_score"]))
+        self.best_params_ = {self.param_name: grid[self.best_index_]}
+        self.best_score_ = float(mean[self.best_index_])
+        j = len(grid) * self.cv + self.best_index_
+        best = type(self.estimator)(**{self.param_name: grid[self.best_index_]})
+        best.tol, best.max_iter = self.estimator.tol, self.estimator.max_iter
+        self.best_estimator_ = best._set(coef[j], icpt[j])
+        self.n_splits_ = self.cv
+        self.n_iter_ = iters
+        self.test_folds_ = folds
+        return self
+
+    def predict(self, X):
+        return self.best_estimator_.predict(X)
+
+    def predict_proba(self, X):
+        return self.best_estimator_.predict_proba(X)
+
+    def score(self, X, y):
+        return self.best_estimator_.score(X, y)
+
+    def to_sklearn(self):
+        """The same fitted model as real scikit-learn objects (for users whose downstream code
+        insists on them); needs scikit-learn importable."""
+        from sklearn.linear_model import Lasso, LogisticRegression
+        from sklearn.model_selection import GridSearchCV
+        be = self.best_estimator_
+        if isinstance(be, L1LogisticRegression):
+            est = LogisticRegression(penalty="l1", solver="liblinear", C=be.C, tol=be.tol, max_iter=int(be.max_iter))
+            est.classes_ = np.array([0, 1])
+            est.coef_, est.intercept_ = be.coef_.copy(), be.intercept_.copy()
+            est.n_iter_ = np.array([0], dtype=np.int32)
+            proto = LogisticRegression(penalty="l1", solver="liblinear", tol=be.tol, max_iter=int(be.max_iter))
+        else:
+            est = Lasso(alpha=be.alpha, tol=be.tol, max_iter=int(be.max_iter))
+            est.coef_, est.intercept_ = be.coef_.copy(), be.intercept_
+            est.n_iter_ = 0
+            proto = Lasso(tol=be.tol, max_iter=int(be.max_iter))
+        est.n_features_in_ = be.n_features_in_
+        gs = GridSearchCV(proto, self.param_grid, cv=self.cv)
+        gs.best_estimator_, gs.best_params_ = est, dict(self.best_params_)
+        gs.best_index_, gs.best_score_ = self.best_index_, self.best_score_
+        gs.cv_results_ = dict(self.cv_results_)
+        gs.n_splits_, gs.refit_time_, gs.multimetric_ = self.n_splits_, 0.0, False
+        gs.scorer_ = None
+        return gs
+
+
+def _rank_min(a):
+    """scipy.stats.rankdata(a, method='min') for a 1-D array."""
+    a = np.asarray(a)
+    order = np.argsort(a, kind="stable")
+    ranks = np.empty(len(a), dtype=np.int32)
+    r = 0
+    for pos, idx in enumerate(order):
+        if pos == 0 or a[idx] != a[order[pos - 1]]:
+            r = pos + 1
+        ranks[idx] = r
+    return ranks

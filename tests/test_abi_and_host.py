@@ -85,3 +85,24 @@ def test_host_framing_reproduces_glistmaker(oracle):
 def test_words_per_row_is_even():
     from phenotypeseeker_amd.engine import words_per_row
     assert [words_per_row(n) for n in (1, 64, 65, 128, 129, 256, 2048)] == [2, 2, 2, 2, 4, 4, 32]
+
+
+def test_cv_splitters_match_sklearn_fixtures():
+    from phenotypeseeker_amd import cv
+    from helpers import GOLDEN
+    z = np.load(os.path.join(GOLDEN, "model_kat.npz"))
+    for tag in ("1", "2"):
+        y = z["y" + tag]
+        k = int(min(np.bincount(y).min(), 10))
+        assert np.array_equal(cv.stratified_kfold(y, k), z["skf_folds" + tag])
+    assert np.array_equal(cv.kfold(len(z["yc2"]), 10), z["kf_folds2"])
+    rng = np.random.default_rng(0)
+    from oracle import oracle_model as OM
+    for _ in range(50):
+        n = int(rng.integers(8, 90))
+        y = (rng.random(n) < rng.uniform(0.2, 0.8)).astype(int)
+        if min(np.bincount(y, minlength=2)) < 2:
+            continue
+        k = int(min(np.bincount(y).min(), rng.integers(2, 11)))
+        assert np.array_equal(cv.stratified_kfold(y, k), OM.stratified_kfold(y, k))
+        assert np.array_equal(cv.kfold(n, k), OM.kfold(n, k))

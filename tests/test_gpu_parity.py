@@ -268,3 +268,70 @@ def test_full_size_scan_properties(ctx):
         A, B, C, D = aa, 128 - aa, cc, 128 - cc
         chi = 256.0 * (A * D - B * C) ** 2 / ((A + B) * (C + D) * (A + C) * (B + D))
         assert ra["stat"][j] == pytest.approx(chi, rel=1e-9)
+
+
+def _pattern_sums(X, w):
+    """coefficient mass per distinct column pattern (identical columns share it arbitrarily)"""
+    pats = {}
+    for j in range(X.shape[1]):
+        pats.setdefault(X[:, j].tobytes(), 0.0)
+        pats[X[:, j].tobytes()] += w[j]
+    return pats
+
+
+def test_l1_logreg_solver_reaches_liblinear_optimum(ctx):
+    """a10 contract: objective, ||w||_1+|b|, linear predictor on the training rows and the
+    per-distinct-pattern coefficient sums of the converged scikit-learn/liblinear solution."""
+    from oracle import oracle_model as OM
+    z = np.load(os.path.join(GOLDEN, "model_kat.npz"))
+    for tag, cis in (("1", (3, 4, 6, 9, 12)), ("2", (0, 2, 4, 6, 9, 12))):
+        X, y = z["X" + tag], z["y" + tag]
+        Cs = [float(z["Cs"][ci]) for ci in cis]
+        coef, icpt, iters = ctx.logreg_l1_fit(X, y, np.zeros(len(y), np.int32), Cs, [-1] * len(Cs), tol=1e-10,
+                                              max_iter=50000)
+        for j, ci in enumerate(cis):
+            C = Cs[j]
+            obj = OM.logreg_l1_objective(X, y, coef[j], icpt[j], C)
+            ref_obj = float(z["logreg_obj" + tag][ci])
+            assert obj == pytest.approx(ref_obj, rel=1e-6), (tag, C, iters[j])
+            rw, rb = z["logreg_coef" + tag][ci], float(z["logreg_icpt" + tag][ci])
+            assert np.allclose(X @ coef[j] + icpt[j], X @ rw + rb, rtol=1e-3, atol=2e-3), (tag, C)
+            assert np.abs(coef[j]).sum() + abs(icpt[j]) == pytest.approx(np.abs(rw).sum() + abs(rb), rel=1e-3, abs=1e-4)
+            if tag == "2":  # no duplicated columns here: the coefficients themselves are unique
+                assert np.allclose(coef[j], rw, rtol=1e-3, atol=2e-4), (C,)
+                assert icpt[j] == pytest.approx(rb, rel=1e-3, abs=2e-4)
+            else:
+                a, b = _pattern_sums(X, coef[j]), _pattern_sums(X, rw)
+                for k in a:
+                    assert a[k] == pytest.approx(b[k], rel=1e-3, abs=2e-4)
+
+
+def test_lasso_solver_matches_sklearn(ctx):
+    z = np.load(os.path.join(GOLDEN, "model_kat.npz"))
+    X, y = z["X2"], z["yc2"]
+    alphas = [float(a) for a in z["alphas"]]
+    coef, icpt, iters = ctx.lasso_fit(X, y, np.zeros(len(y), np.int32), alphas, [-1] * len(alphas), tol=1e-13,
+                                      max_iter=200000)
+    assert np.allclose(coef, z["lasso_coef2"], rtol=1e-6, atol=1e-8)
+    assert np.allclose(icpt, z["lasso_icpt2"], rtol=1e-8)
+
+
+def test_grid_search_matches_sklearn_cv(ctx):
+    from phenotypeseeker_amd.model import GridSearch, L1LogisticRegression, LassoRegression
+    z = np.load(os.path.join(GOLDEN, "model_kat.npz"))
+    X, y = z["X2"], z["y2"]
+    Cs = [float(c) for c in z["Cs"]]
+    cv = int(min(np.bincount(y).min(), 10))
+    gs = GridSearch(L1LogisticRegression(tol=1e-10, max_iter=50000), "C", Cs, cv).fit(X, y, ctx)
+    assert np.array_equal(gs.test_folds_, z["skf_folds2"])
+    # accuracy on tiny folds is piecewise constant: allow one flipped test sample per candidate
+    assert np.allclose(gs.cv_results_["mean_test_score"], z["gs_mean_score2"], atol=1.0 / len(y) + 1e-12)
+    assert gs.best_params_["C"] == pytest.approx(float(z["gs_best_C2"]))
+    yc = z["yc2"]
+    alphas = [float(a) for a in z["alphas"]]
+    gl = GridSearch(LassoRegression(tol=1e-13, max_iter=200000), "alpha", alphas, 10).fit(X, yc, ctx)
+    assert np.allclose(gl.cv_results_["mean_test_score"], z["lasso_gs_mean_score2"], rtol=1e-6, atol=1e-8)
+    assert gl.best_params_["alpha"] == pytest.approx(float(z["lasso_gs_best_alpha2"]))
+    import pickle
+    g2 = pickle.loads(pickle.dumps(gs))
+    assert np.array_equal(g2.predict(X), gs.predict(X)) and g2.predict_proba(X).shape == (len(y), 2)
