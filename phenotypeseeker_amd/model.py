@@ -22,7 +22,16 @@ class L1LogisticRegression:
         self.intercept_ = None
 
     def __repr__(self):
-        return "LogisticRegression(max_iter=%r, penalty='l1', solver='liblinear', tol=%r)" % (self.max_iter, self.tol)
+        # scikit-learn prints only the parameters that differ from its defaults, alphabetically
+        parts = []
+        if self.C != 1.0:
+            parts.append("C=%r" % self.C)
+        if repr(self.max_iter) != "100":
+            parts.append("max_iter=%r" % self.max_iter)
+        parts += ["penalty='l1'", "solver='liblinear'"]
+        if self.tol != 1e-4:
+            parts.append("tol=%r" % self.tol)
+        return "LogisticRegression(%s)" % ", ".join(parts)
 
     def _set(self, coef, icpt):
         self.coef_ = np.asarray(coef, dtype=np.float64).reshape(1, -1)
@@ -53,7 +62,14 @@ class LassoRegression:
         self.intercept_ = None
 
     def __repr__(self):
-        return "Lasso(max_iter=%r, tol=%r)" % (self.max_iter, self.tol)
+        parts = []
+        if self.alpha != 1.0:
+            parts.append("alpha=%r" % self.alpha)
+        if repr(self.max_iter) != "1000":
+            parts.append("max_iter=%r" % self.max_iter)
+        if self.tol != 1e-4:
+            parts.append("tol=%r" % self.tol)
+        return "Lasso(%s)" % ", ".join(parts)
 
     def _set(self, coef, icpt):
         self.coef_ = np.asarray(coef, dtype=np.float64).ravel()

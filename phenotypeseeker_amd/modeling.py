@@ -1,0 +1,543 @@
+"""`phenotypeseeker modeling` on the MI355X engine.
+
+Host-side mirror of the reference's modeling module for the hot path (names, argument meaning
+and output files follow /root/reference/PhenotypeSeeker/modeling.py; line numbers below cite
+it).  The four GenomeTester4 call sites and the per-k-mer Python loop are replaced by libpsk.so
+calls (phenotypeseeker_amd.engine); everything here is orchestration and formatting:
+
+    Input.get_input_data / Input.Input_args      data.pheno parsing and option plumbing (:74-264)
+    Samples.get_kmer_lists                       psk_count_kmers            (was glistmaker, :303-315)
+    Samples.get_feature_vector + map_samples     psk_build_presence         (was glistcompare/glistquery, :317-380)
+    phenotypes.test_kmers_association_with_phenotype   psk_chi2_scan / psk_ttest_scan (:659-858)
+    phenotypes.get_ML_df                         ordering, TSV/CSV writers  (:1112-1145)
+    phenotypes.machine_learning_modelling        GPU grid search + reports  (:860-988)
+
+A single process drives the GPU (no fork pools: the HIP runtime is not fork-safe).
+"""
+import math
+import os
+import sys
+import time
+from collections import OrderedDict
+
+import numpy as np
+
+from . import dist as _dist
+from . import formats, metrics, _stats
+from .engine import PskContext
+from .model import GridSearch, L1LogisticRegression, LassoRegression
+
+RED_BANNER = "\x1b[1;1;101m%s\x1b[0m\n"
+GREEN = "\x1b[1;32m%s\x1b[0m"
+YELLOW = "\x1b[1;33m%s\x1b[0m\n"
+
+
+def _err(text):
+    sys.stderr.write(text)
+    sys.stderr.flush()
+
+
+def timer(f):
+    """Appends 'Func <f> took <s> secs' to ./log.txt like the reference's decorator (:54-61)."""
+    def wrapper(*args):
+        start = time.time()
+        f(*args)
+        with open("log.txt", "a") as log:
+            log.write("Func %s took %s secs\n" % (f, time.time() - start))
+    return wrapper
+
+
+class Samples:
+    """One row of data.pheno (:266-301)."""
+    no_samples = 0
+    phenotypes = []          # header names
+    take_logs = None
+    kmer_length = None
+    cutoff = None
+    min_samples = None
+    max_samples = None
+    kmerDB = None
+
+    def __init__(self, name, address, phenotypes, weight=1):
+        self.name = name
+        self.address = address
+        self.phenotypes = phenotypes
+        self.weight = weight
+        Samples.no_samples += 1
+
+    @classmethod
+    def from_inputfile(cls, line):
+        fields = line.split()
+        name, address, values = fields[0], fields[1], fields[2:]
+        if any(v not in ("0", "1", "NA") for v in values):
+            phenotypes.pred_scale = "continuous"
+        return cls(name, address, dict(zip(cls.phenotypes, values)))
+
+    # ---- k-mer plane -----------------------------------------------------------------------
+    def get_kmer_lists(self, ctx, index):
+        """was: glistmaker <address> -o K-mer_lists/<name>_0 -w <k> -c <cutoff>  (:303-315).
+        As with the bundled glistmaker 4.2.3, the cut-off does not change the list."""
+        data = formats.read_sequence_file(self.address)
+        self.n_unique, self.n_total = ctx.count_kmers(index, data)
+        stderr_print.currentSampleNum += 1
+        stderr_print.print_progress("lists generated.")
+
+    @classmethod
+    def get_feature_vector(cls, ctx):
+        """was: the glistcompare -u tree, optionally intersected with --kmerDB (:350-372)."""
+        m = ctx.build_presence()
+        if cls.kmerDB:
+            with PskContext(ctx.device) as db_ctx:
+                db_ctx.begin(int(cls.kmer_length), 1)
+                nu, _ = db_ctx.count_kmers(0, formats.read_sequence_file(cls.kmerDB))
+                db_words, _ = db_ctx.get_list(0, nu)
+            m = ctx.intersect_db(db_words)
+        return m
+
+
+class stderr_print:
+    """Progress banners on stderr (:507-537) without the lock-guarded counters."""
+    currentSampleNum = 0
+
+    def __init__(self, data):
+        _err("\r\x1b[K\x1b[1;32m" + str(data) + "\x1b[0m")
+
+    @classmethod
+    def print_progress(cls, txt):
+        if cls.currentSampleNum != Samples.no_samples:
+            cls("\t\x1b[1;91m%d\x1b[1;32m of %d %s" % (cls.currentSampleNum, Samples.no_samples, txt))
+        else:
+            cls("\t%d of %d %s" % (cls.currentSampleNum, Samples.no_samples, txt))
+
+
+class Input:
+    samples = OrderedDict()
+    phenotypes_to_analyse = OrderedDict()
+    jump_to = None
+    num_threads = 8
+
+    @classmethod
+    def reset(cls):
+        cls.samples = OrderedDict()
+        cls.phenotypes_to_analyse = OrderedDict()
+        cls.jump_to = None
+        Samples.no_samples = 0
+        Samples.phenotypes = []
+        phenotypes.pred_scale = "binary"
+        phenotypes.no_results = []
+        phenotypes.model_package = {}
+        stderr_print.currentSampleNum = 0
+
+    @classmethod
+    def get_input_data(cls, inputfilename, take_logs, mpheno):
+        """data.pheno: header 'ID Addresses pheno...', then 'name address value...' (:74-97)."""
+        Samples.take_logs = take_logs
+        with open(inputfilename) as fh:
+            header = fh.readline().split()
+            Samples.phenotypes = header[2:]
+            for ph in Samples.phenotypes:
+                try:
+                    float(ph)
+                except ValueError:
+                    continue
+                _err(YELLOW % "Warning! It seems that the input file is missing header row!")
+                break
+            for line in fh:
+                if line.strip():
+                    cls.samples[line.split()[0]] = Samples.from_inputfile(line)
+        n_ph = len(Samples.phenotypes)
+        columns = range(n_ph) if not mpheno else [m - 1 for m in mpheno]
+        for c in columns:
+            cls.phenotypes_to_analyse[Samples.phenotypes[c]] = phenotypes(Samples.phenotypes[c])
+        cls._set_phenotype_values(take_logs)
+
+    @classmethod
+    def _set_phenotype_values(cls, take_logs):
+        """int() / float() (optionally log2); anything unparsable stays as its string, 'NA' in
+        practice, and lowers the phenotype's sample count (:109-126)."""
+        for sample in cls.samples.values():
+            for ph in cls.phenotypes_to_analyse.values():
+                raw = sample.phenotypes[ph.name]
+                try:
+                    if phenotypes.pred_scale == "continuous":
+                        v = float(raw)
+                        if take_logs:
+                            v = math.log(v, 2)
+                    else:
+                        v = int(raw)
+                    sample.phenotypes[ph.name] = v
+                except (ValueError, TypeError):
+                    ph.no_samples -= 1
+
+    @classmethod
+    def pop_phenos_out_of_kmers(cls):
+        for name in phenotypes.no_results:
+            cls.phenotypes_to_analyse.pop(name, None)
+        if not cls.phenotypes_to_analyse:
+            _err(YELLOW % "There are no k-mers left for modelling for any phenotype.")
+            _err(YELLOW % "Exiting PhenotypeSeeker")
+            _err("\n" + RED_BANNER % "######          PhenotypeSeeker modeling finished          ######")
+            raise SystemExit()
+
+    @classmethod
+    def Input_args(cls, alphas, alpha_min, alpha_max, n_alphas, gammas, gamma_min, gamma_max, n_gammas,
+                   min_samples, max_samples, kmer_length, cutoff, num_threads, pvalue_cutoff, kmer_limit,
+                   binary_classifier, regressor, penalty, max_iter, tol, l1_ratio, n_splits_cv_outer, kernel,
+                   n_iter, n_splits_cv_inner, testset_size, train_on_whole, logreg_solver, jump_to, pca,
+                   real_counts, omit_B, kmerDB):
+        """Same positional signature as the reference (:141-183).  Options that select estimators
+        outside the hot path (SVM/RF/DT/NB, L2/elastic net, saga, PCA) are rejected here."""
+        if alphas is None:
+            phenotypes.alphas = np.logspace(math.log10(alpha_min), math.log10(alpha_max), num=n_alphas)
+        else:
+            phenotypes.alphas = np.array(alphas)
+        mn, mx = int(min_samples), int(max_samples)
+        Samples.min_samples = mn if mn != 0 else 2
+        Samples.max_samples = mx if mx != 0 else Samples.no_samples - 2
+        Samples.kmer_length = str(kmer_length)
+        Samples.cutoff = cutoff
+        Samples.kmerDB = kmerDB
+        cls.num_threads = num_threads
+        cls.jump_to = jump_to
+        phenotypes.pvalue_cutoff = pvalue_cutoff
+        phenotypes.kmer_limit = kmer_limit
+        phenotypes.penalty = penalty.upper()
+        phenotypes.max_iter = max_iter
+        phenotypes.tol = tol
+        phenotypes.n_splits_cv_outer = n_splits_cv_outer
+        phenotypes.n_splits_cv_inner = n_splits_cv_inner
+        phenotypes.testset_size = testset_size
+        phenotypes.train_on_whole = train_on_whole
+        phenotypes.real_counts = real_counts
+        phenotypes.omit_B = omit_B
+        phenotypes.pca = pca
+        if phenotypes.pred_scale == "continuous":
+            if regressor != "lin":
+                raise SystemExit("Only the linear (Lasso) regressor runs on the GPU engine, got %r." % regressor)
+            phenotypes.model_name_long, phenotypes.model_name_short = "linear regression", "linreg"
+        else:
+            if binary_classifier != "log":
+                raise SystemExit("Only the logistic-regression classifier runs on the GPU engine, got %r "
+                                 "(SVM/RF/DT/NB are outside the accelerated path)." % binary_classifier)
+            phenotypes.model_name_long, phenotypes.model_name_short = "logistic regression", "log_reg"
+            if logreg_solver not in (None, "liblinear"):
+                raise SystemExit("Logistic Regression with L1 penalty on the GPU engine implements the "
+                                 "liblinear objective only, got {}.".format(logreg_solver))
+        if phenotypes.penalty != "L1":
+            raise SystemExit("Only the L1 penalty runs on the GPU engine, got %r." % penalty)
+        if pca:
+            raise SystemExit("--pca is outside the accelerated path.")
+        if n_splits_cv_outer or testset_size:
+            raise SystemExit("-cv1 / -ts outer splits are not implemented on the GPU engine yet "
+                             "(the default whole-set training path, modeling.py:953, is).")
+
+
+class phenotypes:
+    pred_scale = "binary"
+    real_counts = False
+    model_name_long = None
+    model_name_short = None
+    no_kmers_to_analyse = 0
+    pvalue_cutoff = None
+    kmer_limit = None
+    omit_B = None
+    penalty = None
+    max_iter = None
+    tol = None
+    alphas = None
+    n_splits_cv_outer = None
+    n_splits_cv_inner = None
+    testset_size = None
+    train_on_whole = None
+    pca = None
+    no_results = []
+    model_package = {}
+
+    def __init__(self, name):
+        self.name = name
+        self.no_samples = Samples.no_samples
+        self.rows = None      # surviving k-mers of the scan (dict of arrays + kmer strings)
+        self.ML = None        # selected design matrix etc.
+        self.model_fitted = None
+
+    # ---- association scan ----------------------------------------------------------------------
+    @classmethod
+    def kmer_testing_setup(cls, n_union_global):
+        """The Bonferroni denominator is the size of the WHOLE union (:640-644)."""
+        label = "Welch t-tests" if cls.pred_scale == "continuous" else "chi-square tests"
+        _err("\n" + GREEN % ("Conducting the k-mer specific %s:" % label) + "\n")
+        cls.no_kmers_to_analyse = int(n_union_global)
+
+    def _phenotype_vectors(self):
+        samples = list(Input.samples.values())
+        weights = np.array([float(s.weight) for s in samples])
+        unit = all(s.weight == 1 for s in samples)
+        if self.pred_scale == "binary":
+            ph = np.array([s.phenotypes[self.name] if s.phenotypes[self.name] in (0, 1) else -1 for s in samples],
+                          dtype=np.int8)
+            return ph, None, (None if unit else weights)
+        vals = np.zeros(len(samples))
+        valid = np.zeros(len(samples), dtype=np.uint8)
+        for i, s in enumerate(samples):
+            v = s.phenotypes[self.name]
+            if v != "NA" and not isinstance(v, str):
+                vals[i], valid[i] = float(v), 1
+        return vals, valid, (None if unit else weights)
+
+    def test_kmers_association_with_phenotype(self, ctx, group):
+        """was: Pool.map(get_kmers_tested) over text chunks (:659-714).  One scan kernel launch
+        per phenotype; with several GPUs every rank scans its slab and the survivors are
+        all-gathered in slab order."""
+        start = time.time()
+        n = Samples.no_samples
+        a, b, w = self._phenotype_vectors()
+        if self.pred_scale == "binary":
+            npass = ctx.chi2_scan(a, w, Samples.min_samples, Samples.max_samples, self.pvalue_cutoff, self.omit_B,
+                                  self.no_kmers_to_analyse)
+        else:
+            npass = ctx.ttest_scan(a, b, w, Samples.min_samples, Samples.max_samples, self.pvalue_cutoff,
+                                   self.no_kmers_to_analyse)
+        res = ctx.get_results(npass)
+        bits = ctx.get_rows(res["row"])
+        counts = None
+        if self.real_counts and npass:
+            counts = np.stack([ctx.lookup_counts(i, res["word"]) for i in range(n)], axis=1)
+        if group.world > 1:
+            payloads = group.allgather_bytes(_dist.pack_candidates(res, bits))
+            res, bits = _dist.merge_candidates(payloads)
+            if self.real_counts:
+                cp = group.allgather_bytes(np.ascontiguousarray(counts if counts is not None else
+                                                                np.zeros((0, n), np.uint32)).tobytes())
+                counts = np.concatenate([np.frombuffer(c, dtype=np.uint32).reshape(-1, n) for c in cp])
+        k = int(Samples.kmer_length)
+        presence = ((bits[:, np.arange(n) >> 6] >> (np.arange(n, dtype=np.uint64) & np.uint64(63))) & np.uint64(1)) \
+            .astype(np.uint8) if len(bits) else np.zeros((0, n), np.uint8)
+        self.rows = {"kmer": formats.words_to_kmers(res["word"], k), "stat": res["stat"], "p": res["p"],
+                     "mean_x": res["mean_x"], "mean_y": res["mean_y"], "n_with": res["n_with"],
+                     "presence": presence, "vector": counts.astype(np.int64) if counts is not None else presence}
+        _err("\t%s: 100%% tests conducted.\n" % self.name)
+        if len(self.rows["kmer"]) == 0:
+            self.no_results.append(self.name)
+        with open("log.txt", "a") as log:
+            log.write("Func test_kmers_association_with_phenotype took %s secs (scan kernel %.3f ms)\n"
+                      % (time.time() - start, ctx.last_scan_ms()))
+
+    # ---- selection (:1112-1145) ------------------------------------------------------------------
+    def get_ML_df(self):
+        start = time.time()
+        names = list(Input.samples.keys())
+        samples = list(Input.samples.values())
+        if Input.jump_to == "modelling":
+            self._load_MLdf()
+        else:
+            r = self.rows
+            binary = self.pred_scale == "binary"
+            pstr = [formats.pstring(p) for p in r["p"]]
+            # the reference sorts the columns by the p-value STRINGS (:1128); ties, which numpy's
+            # unstable sort leaves in an arbitrary order there, are broken by k-mer text here
+            order = sorted(range(len(pstr)), key=lambda i: (pstr[i], r["kmer"][i]))
+            valid = [s.phenotypes[self.name] != "NA" and not isinstance(s.phenotypes[self.name], str) for s in samples]
+            lines = []
+            for i in order:
+                with_names = [names[j] for j in range(len(names)) if r["presence"][i, j] and valid[j]]
+                stat = repr(formats.round2(r["stat"][i]))
+                if binary:
+                    fields = [r["kmer"][i], stat, pstr[i], str(int(r["n_with"][i])), " ".join(["|"] + with_names)]
+                else:
+                    fields = [r["kmer"][i], stat, pstr[i], repr(formats.round2(r["mean_x"][i])),
+                              repr(formats.round2(r["mean_y"][i])), str(int(r["n_with"][i])),
+                              " ".join(["|"] + with_names)]
+                lines.append("\t".join(fields))
+            if binary:
+                head, stem = "k-mer\tchi2\tp-value\tnum_samples_w_kmer\tsamples_with_kmer", "chi2"
+            else:
+                head, stem = ("k-mer\tt-test\tp-value\t+_group_mean\t-_group_mean\tnum_samples_w_kmer\t"
+                              "samples_with_kmer"), "t-test"
+            with open("%s_results_%s.tsv" % (stem, self.name), "w") as f:
+                f.write("\n".join([head] + lines) + "\n")
+            if self.kmer_limit:
+                order = order[: self.kmer_limit]
+                with open("%s_results_%s_top%s.tsv" % (stem, self.name, self.kmer_limit), "w") as f:
+                    f.write("\n".join([head] + lines[: self.kmer_limit]) + "\n")
+            keep = [j for j in range(len(names)) if valid[j]]
+            self.ML = {"kmers": [r["kmer"][i] for i in order],
+                       "index": [names[j] for j in keep],
+                       "X": r["vector"][order][:, keep].T.astype(np.int64) if order else np.zeros((len(keep), 0), np.int64),
+                       "weights": [samples[j].weight for j in keep],
+                       "phenotype": [samples[j].phenotypes[self.name] for j in keep]}
+            self._write_MLdf()
+        self.model_package["kmers"] = np.array(self.ML["kmers"], dtype=object)
+        with open("log.txt", "a") as log:
+            log.write("Func get_ML_df took %s secs\n" % (time.time() - start))
+
+    def _write_MLdf(self):
+        """<pheno>_MLdf.csv as pandas wrote it: samples x (k-mers + weights + phenotype) (:1144)."""
+        ml = self.ML
+        with open(self.name + "_MLdf.csv", "w") as f:
+            f.write(",".join([""] + ml["kmers"] + ["weights", "phenotype"]) + "\n")
+            for i, name in enumerate(ml["index"]):
+                w, p = ml["weights"][i], ml["phenotype"][i]
+                f.write(",".join([name] + [str(int(v)) for v in ml["X"][i]] +
+                                 [repr(w) if isinstance(w, float) else str(w),
+                                  repr(p) if isinstance(p, float) else str(p)]) + "\n")
+
+    def _load_MLdf(self):
+        with open(self.name + "_MLdf.csv") as f:
+            head = f.readline().rstrip("\n").split(",")
+            kmers = head[1:-2]
+            idx, X, wts, ph = [], [], [], []
+            for line in f:
+                c = line.rstrip("\n").split(",")
+                idx.append(c[0])
+                X.append([int(float(v)) for v in c[1:-2]])
+                wts.append(float(c[-2]) if "." in c[-2] else int(c[-2]))
+                ph.append(float(c[-1]) if self.pred_scale == "continuous" else int(float(c[-1])))
+        self.ML = {"kmers": kmers, "index": idx, "X": np.array(X, dtype=np.int64).reshape(len(idx), len(kmers)),
+                   "weights": wts, "phenotype": ph}
+
+    # ---- model (:860-988) -------------------------------------------------------------------------
+    def assert_n_splits_cv_inner(self, n_splits_cv_inner, y_train):
+        """min(class count or sample count, requested) (:1512-1524)."""
+        if self.pred_scale == "continuous":
+            least = len(y_train)
+        else:
+            least = int(np.min(np.bincount(np.asarray(y_train, dtype=np.int64))))
+        self.n_splits_cv_inner = int(min(least, n_splits_cv_inner))
+
+    def machine_learning_modelling(self, ctx):
+        _err("\x1b[1;32m\t" + self.name + ".\x1b[0m\n")
+        self.get_ML_df()
+        short = self.model_name_short
+        summary = open("summary_of_%s_analysis_%s.txt" % (short, self.name), "w")
+        coeff = open("k-mers_and_coefficients_in_%s_model_%s.txt" % (short, self.name), "w")
+        X = self.ML["X"].astype(np.float64)
+        if self.pred_scale == "binary":
+            y = np.array(self.ML["phenotype"], dtype=np.int64)
+            est = L1LogisticRegression(tol=self.tol, max_iter=self.max_iter)
+            grid, pname = [1.0 / a for a in self.alphas], "C"
+        else:
+            y = np.array(self.ML["phenotype"], dtype=np.float64)
+            est = LassoRegression(tol=self.tol, max_iter=self.max_iter)
+            grid, pname = [float(a) for a in self.alphas], "alpha"
+        self.assert_n_splits_cv_inner(phenotypes.n_splits_cv_inner, y)
+        self.model_fitted = GridSearch(est, pname, grid, self.n_splits_cv_inner).fit(X, y, ctx)
+        self._cross_validation_results(summary, est)
+        self._predict_report(summary, X, y)
+        summary.write("\n### Outputting the model to a model file! ###\n")
+        import joblib
+        package = dict(self.model_package)
+        package.update({"model": self.model_fitted, "pca": self.pca, "pred_scale": self.pred_scale})
+        with open("%s_model_%s.pkl" % (short, self.name), "wb") as fh:
+            joblib.dump(package, fh)
+        self._write_model_coefficients(coeff)
+        summary.close()
+        coeff.close()
+
+    def _cross_validation_results(self, out, est):
+        """(:1219-1237)"""
+        out.write("Parameters:\n%s\n\n" % est)
+        out.write("Grid scores (%s) on development set: \n" %
+                  ("R2 score" if self.pred_scale == "continuous" else "mean accuracy"))
+        cvr = self.model_fitted.cv_results_
+        for mean, std, param in zip(cvr["mean_test_score"], cvr["std_test_score"], cvr["params"]):
+            out.write("%0.3f (+/-%0.03f) for %r \n" % (mean, std * 2, param))
+        out.write("\nBest parameters found on development set: \n")
+        for key, value in self.model_fitted.best_params_.items():
+            out.write(key + " : " + str(value) + "\n")
+
+    def _predict_report(self, out, X, y):
+        """(:1239-1253, :1255-1288, :1314-1380)"""
+        pred = self.model_fitted.predict(X)
+        out.write("\nModel predictions on samples:\nSample_ID Acutal_phenotype Predicted_phenotype\n")
+        for name, actual, p in zip(self.ML["index"], self.ML["phenotype"], pred):
+            out.write("%s %s %s\n" % (name, actual, p))
+        out.write("\n")
+        if self.pred_scale == "continuous":
+            out.write("\nMean squared error: %s\n" % metrics.mean_squared_error(y, pred).round(2))
+            out.write("The coefficient of determination: %s\n" % round(self.model_fitted.score(X, y), 2))
+            r, pv = _stats.spearmanr(y, pred)
+            out.write("The Spearman correlation coefficient and p-value: %s, %s \n" % (round(r, 2), round(pv, 2)))
+            r, pv = _stats.pearsonr(y, pred)
+            out.write("The Pearson correlation coefficient and p-value:  %s, %s \n" % (round(r, 2), round(pv, 2)))
+            out.write("The plus/minus 1 dilution factor accuracy (for MICs): %s \n\n"
+                      % metrics.within_1_tier_accuracy(y, pred))
+            return
+        proba = self.model_fitted.predict_proba(X)[:, 1]
+        out.write("F1-score of positive class: %s\n" % metrics.f1(y, pred).round(2))
+        out.write("Mean accuracy: %s\n" % self.model_fitted.score(X, y).round(2))
+        out.write("Sensitivity: %s\n" % metrics.recall(y, pred).round(2))
+        out.write("Specificity: %s\n" % metrics.recall(y, pred, positive=0).round(2))
+        out.write("AUC-ROC: %s\n" % metrics.roc_auc(y, pred).round(2))
+        out.write("Average precision: %s\n" % metrics.average_precision(y, proba).round(2))
+        out.write("MCC: %s\n" % round(metrics.matthews(y, pred), 2))
+        out.write("Cohen kappa: %s\n" % metrics.cohen_kappa(y, pred).round(2))
+        out.write("Very major error rate: %s\n" % metrics.very_major_error(y, pred))
+        out.write("Major error rate: %s\n" % metrics.major_error(y, pred))
+        out.write("Classification report:\n\n %s\n" % metrics.classification_report(y, pred))
+        cm = metrics.confusion(y, pred)
+        out.write("Confusion matrix:\n")
+        out.write("Predicted\t0\t1:\n")
+        out.write("Actual\n")
+        out.write("0\t\t%s\t%s\n" % tuple(cm[0]))
+        out.write("1\t\t%s\t%s\n\n" % tuple(cm[1]))
+
+    def _write_model_coefficients(self, out):
+        """(:1414-1455)"""
+        out.write("K-mer\tcoef._in_" + self.model_name_short + "_model\tNo._of_samples_with_k-mer\tSamples_with_k-mer\n")
+        be = self.model_fitted.best_estimator_
+        coefs = be.coef_[0] if self.pred_scale == "binary" else be.coef_
+        X, index = self.ML["X"], self.ML["index"]
+        for j, kmer in enumerate(self.ML["kmers"]):
+            with_kmer = [index[i] for i in range(len(index)) if X[i, j] != 0]
+            out.write("%s\t%s\t%d\t| %s\n" % (kmer, repr(float(coefs[j])), len(with_kmer), " ".join(with_kmer)))
+
+
+def modeling(args):
+    """The main function of `phenotypeseeker modeling` (:1624-1709)."""
+    _err(RED_BANNER % "######                   PhenotypeSeeker                   ######")
+    _err(RED_BANNER % "######                      modeling                       ######" + "\n")
+    Input.reset()
+    Input.get_input_data(args.inputfile, args.take_logs, args.mpheno)
+    Input.Input_args(
+        args.alphas, args.alpha_min, args.alpha_max, args.n_alphas, args.gammas, args.gamma_min, args.gamma_max,
+        args.n_gammas, args.min, args.max, args.kmer_length, args.cutoff, args.num_threads, args.pvalue,
+        args.n_kmers, args.binary_classifier, args.regressor, args.penalty, args.max_iter, args.tolerance,
+        args.l1_ratio, args.n_splits_cv_outer, args.kernel, args.n_iter, args.n_splits_cv_inner, args.testset_size,
+        args.train_on_whole, args.logreg_solver, args.jump_to, args.pca, args.real_counts, args.omit_B_correction,
+        args.kmerDB)
+    if getattr(args, "weights", False):
+        raise SystemExit("-w/--weights (Mash-based GSC weights) is not implemented on the GPU engine yet; the "
+                         "weighted scans themselves are (pass weights through the Python API).")
+    group = _dist.Group().init()
+    ctx = PskContext(group.local_rank)
+    try:
+        if not Input.jump_to:
+            k = int(Samples.kmer_length)
+            lo, hi = _dist.slab_bounds(k, group.world, group.rank)
+            ctx.begin(k, Samples.no_samples, lo, hi)
+            _err(GREEN % "Generating the k-mer lists for input samples:" + "\n")
+            for i, sample in enumerate(Input.samples.values()):
+                sample.get_kmer_lists(ctx, i)
+            _err("\n" + GREEN % "Generating the k-mer feature vector." + "\n")
+            m_local = Samples.get_feature_vector(ctx)
+            _err(GREEN % "Mapping samples to the feature vector space:" + "\n")
+            stderr_print("\t%d of %d samples mapped." % (Samples.no_samples, Samples.no_samples))
+            phenotypes.kmer_testing_setup(group.allreduce_sum(int(m_local)))
+            for ph in Input.phenotypes_to_analyse.values():
+                ph.test_kmers_association_with_phenotype(ctx, group)
+            Input.pop_phenos_out_of_kmers()
+        # 'modelling' / 'modeling' both run the model stage; 'PCA' runs nothing (:1689)
+        if not Input.jump_to or Input.jump_to in ("modelling", "modeling"):
+            if Input.jump_to:
+                Input.jump_to = "modelling"
+            _err(GREEN % ("Generating the " + phenotypes.model_name_long + " model for phenotype: ") + "\n")
+            if group.rank == 0:
+                for ph in Input.phenotypes_to_analyse.values():
+                    ph.machine_learning_modelling(ctx)
+            group.barrier()
+        if getattr(args, "assembly", False):
+            _err(YELLOW % "-a/--assembly is outside the accelerated path and is skipped.")
+    finally:
+        ctx.close()
+        group.close()
+    _err("\n" + RED_BANNER % "######          PhenotypeSeeker modeling finished          ######")

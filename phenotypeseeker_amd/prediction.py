@@ -1,0 +1,122 @@
+"""`phenotypeseeker prediction` on the MI355X engine (mirror of /root/reference/PhenotypeSeeker/
+prediction.py; line numbers cite it).  The `gmer_counter -db` subprocess per sample (:72-80) is
+replaced by psk_count_dict; the k-mer text database and the per-sample count files are never
+written.  The model file is the reference's joblib dict {'model', 'kmers', 'pca', 'pred_scale'}."""
+import sys
+import time
+from collections import OrderedDict
+
+import numpy as np
+
+from . import formats
+from .engine import PskContext
+
+
+def timer(f):
+    def wrapper(*args):
+        start = time.time()
+        f(*args)
+        with open("log.txt", "a") as log:
+            log.write("Func %s took %s secs\n" % (f, time.time() - start))
+    return wrapper
+
+
+class Samples:
+    no_samples = 0
+
+    def __init__(self, name, address):
+        self.name, self.address = name, address
+        Samples.no_samples += 1
+
+    @classmethod
+    def from_inputfile(cls, line):
+        fields = line.split()
+        return cls(fields[0], fields[1])
+
+    def map_samples(self, ctx, pheno):
+        """was: gmer_counter -db K-mer_lists/k-mer_db_<pheno>.txt <address> (:72-80) followed by the
+        >= cutoff thresholding of kmer_counts (:82-100)."""
+        counts = ctx.count_dict(formats.read_sequence_file(self.address), pheno.k, pheno.words)
+        return (counts >= Phenotypes.cutoff).astype(np.float64)
+
+
+class Phenotypes:
+    cutoff = 1
+    no_phenotypes = 0
+
+    def __init__(self, name, model, kmers, pca, pred_scale):
+        self.name, self.model, self.kmers, self.pca, self.pred_scale = name, model, kmers, pca, pred_scale
+        self.k = len(str(kmers[0])) if kmers.shape[0] else 0
+        self.words = np.array([formats.canonical(formats.kmer_to_word(str(km)), self.k) for km in kmers],
+                              dtype=np.uint64)
+        self.matrix = np.empty(shape=(Samples.no_samples, kmers.shape[0]))
+        Phenotypes.no_phenotypes += 1
+
+    @classmethod
+    def from_inputfile(cls, line):
+        """'<phenotype> <model.pkl>' (:123-143)"""
+        import joblib
+        name, path = line.split()[0], line.split()[1]
+        pkg = joblib.load(path)
+        if pkg.get("pca"):
+            raise SystemExit("PCA models are outside the accelerated path.")
+        return cls(name, pkg["model"], np.asarray(pkg["kmers"]), False, pkg["pred_scale"])
+
+    def get_inp_matrix(self, ctx):
+        for i, sample in enumerate(Input.samples.values()):
+            self.matrix[i, :] = sample.map_samples(ctx, self)
+
+    def predict(self):
+        """predictions_<pheno>.txt (:165-182)"""
+        predictions = self.model.predict(self.matrix)
+        with open("predictions_" + self.name + ".txt", "w+") as out:
+            if self.pred_scale == "binary":
+                proba = self.model.predict_proba(self.matrix)
+                out.write("Sample_ID\tpredicted_phenotype\tprobability_for_predicted_class\n")
+                for sample, pred, pr in zip(Input.samples.keys(), predictions, proba):
+                    out.write("%s\t%s\t%s\n" % (sample, str(pred), str(round(pr[1], 2))))
+            else:
+                out.write("Sample_ID\tpredicted_phenotype\n")
+                for sample, pred in zip(Input.samples.keys(), predictions):
+                    out.write(sample + "\t" + str(pred) + "\n")
+
+
+class Input:
+    samples = OrderedDict()
+    phenos = OrderedDict()
+
+    @classmethod
+    def reset(cls):
+        cls.samples, cls.phenos = OrderedDict(), OrderedDict()
+        Samples.no_samples = 0
+        Phenotypes.no_phenotypes = 0
+
+    @classmethod
+    def get_samples(cls, inputfile):
+        with open(inputfile) as fh:
+            for line in fh:
+                if line.strip():
+                    cls.samples[line.split()[0]] = Samples.from_inputfile(line)
+
+    @classmethod
+    def get_phenos(cls, inputfile):
+        with open(inputfile) as fh:
+            for line in fh:
+                if line.strip():
+                    cls.phenos[line.split()[0]] = Phenotypes.from_inputfile(line)
+
+
+@timer
+def prediction(args):
+    sys.stderr.write("\x1b[1;1;101m######                   PhenotypeSeeker                   ######\x1b[0m\n")
+    sys.stderr.write("\x1b[1;1;101m######                     prediction                      ######\x1b[0m\n\n")
+    Input.reset()
+    Phenotypes.cutoff = args.c
+    Input.get_samples(args.inputfile1)
+    Input.get_phenos(args.inputfile2)
+    with PskContext(0) as ctx:
+        for pheno in Input.phenos.values():
+            sys.stderr.write("\x1b[1;32mPredicting the phenotypes for %s.\x1b[0m\n" % pheno.name)
+            pheno.get_inp_matrix(ctx)
+            pheno.predict()
+    sys.stderr.write("\n\x1b[1;1;101m######          PhenotypeSeeker prediction finished          ######\x1b[0m\n")

@@ -1,0 +1,130 @@
+"""GPU end-to-end tests (-m gpu): `phenotypeseeker modeling` and `prediction` on the golden
+datasets, through the CLI parser and the C ABI, against the files the reference wrote."""
+import csv
+import os
+
+import numpy as np
+import pytest
+
+from helpers import load_dataset, read_results_tsv
+from test_host_modeling import _write_dataset
+
+pytestmark = pytest.mark.gpu
+
+
+def _run(tmp, argv):
+    from phenotypeseeker_amd.cli import build_parser
+    os.chdir(tmp)
+    args = build_parser().parse_args(argv)
+    args.func(args)
+
+
+@pytest.mark.parametrize("tag,extra", [("ds_omitB", ["--omit_B_correction", "--n_kmers", "100"]), ("ds_bonf", [])])
+def test_modeling_and_prediction_end_to_end(tmp_path, tag, extra):
+    import joblib
+    ds = load_dataset(tag)
+    _write_dataset(ds, str(tmp_path))
+    _run(tmp_path, ["modeling", "data.pheno"] + extra)
+    head, ref = read_results_tsv(os.path.join(ds["dir"], "chi2_results_Pheno.tsv"))
+    head2, got = read_results_tsv("chi2_results_Pheno.tsv")
+    assert head2 == head and sorted(got) == sorted(ref)
+    assert [g[2] for g in got] == [r[2] for r in ref]
+    limit = 100 if extra else 1000
+    _, ref_top = read_results_tsv(os.path.join(ds["dir"], "chi2_results_Pheno_top%d.tsv" % limit))
+    _, got_top = read_results_tsv("chi2_results_Pheno_top%d.tsv" % limit)
+    assert [g[2] for g in got_top] == [r[2] for r in ref_top]
+    with open(os.path.join(ds["dir"], "Pheno_MLdf.csv")) as f:
+        ref_csv = list(csv.reader(f))
+    with open("Pheno_MLdf.csv") as f:
+        got_csv = list(csv.reader(f))
+    assert [r[0] for r in got_csv] == [r[0] for r in ref_csv] and [r[-2:] for r in got_csv] == [r[-2:] for r in ref_csv]
+    if not extra:
+        assert sorted(got_csv[0][1:-2]) == sorted(ref_csv[0][1:-2])
+    # model artefacts
+    pkg = joblib.load("log_reg_model_Pheno.pkl")
+    assert set(pkg) >= {"model", "kmers", "pca", "pred_scale"} and pkg["pred_scale"] == "binary"
+    kmers = list(pkg["kmers"])
+    assert kmers == got_csv[0][1:-2]
+    X = np.array([[int(v) for v in r[1:-2]] for r in got_csv[1:]], dtype=np.float64)
+    y = np.array([int(r[-1]) for r in got_csv[1:]])
+    model = pkg["model"]
+    assert model.best_params_["C"] in [1.0 / a for a in np.logspace(-3, 3, 13)]
+    assert (model.predict(X) == y).mean() >= 0.9      # the planted gene separates the classes
+    lines = open("k-mers_and_coefficients_in_log_reg_model_Pheno.txt").read().splitlines()
+    assert lines[0] == "K-mer\tcoef._in_log_reg_model\tNo._of_samples_with_k-mer\tSamples_with_k-mer"
+    assert [l.split("\t")[0] for l in lines[1:]] == kmers
+    assert np.allclose([float(l.split("\t")[1]) for l in lines[1:]], model.best_estimator_.coef_[0])
+    summary = open("summary_of_log_reg_analysis_Pheno.txt").read()
+    for needle in ("Parameters:\nLogisticRegression(max_iter=1000, penalty='l1', solver='liblinear')",
+                   "Grid scores (mean accuracy) on development set:", "Best parameters found on development set:",
+                   "Model predictions on samples:", "Classification report:", "Confusion matrix:",
+                   "### Outputting the model to a model file! ###"):
+        assert needle in summary, needle
+    assert "Func" in open("log.txt").read()
+
+    # --jump_to modelling re-fits from <pheno>_MLdf.csv and must reproduce the model
+    coef0 = model.best_estimator_.coef_.copy()
+    _run(tmp_path, ["modeling", "data.pheno", "-jt", "modelling"] + extra)
+    pkg2 = joblib.load("log_reg_model_Pheno.pkl")
+    assert np.allclose(pkg2["model"].best_estimator_.coef_, coef0, atol=1e-9)
+    assert list(pkg2["kmers"]) == kmers
+
+    # prediction: same samples through psk_count_dict + the stored model
+    with open("samples.txt", "w") as f:
+        for line in open("data.pheno").read().splitlines()[1:]:
+            f.write("\t".join(line.split()[:2]) + "\n")
+    with open("phenos.txt", "w") as f:
+        f.write("Pheno\tlog_reg_model_Pheno.pkl\n")
+    _run(tmp_path, ["prediction", "samples.txt", "phenos.txt"])
+    out = open("predictions_Pheno.txt").read().splitlines()
+    assert out[0] == "Sample_ID\tpredicted_phenotype\tprobability_for_predicted_class"
+    assert [l.split("\t")[0] for l in out[1:]] == ds["names"]
+    non_na = {r[0]: i for i, r in enumerate(got_csv[1:])}
+    pred = model.predict(X)
+    proba = model.predict_proba(X)
+    for l in out[1:]:
+        name, p, pr = l.split("\t")
+        if name in non_na:
+            assert int(p) == pred[non_na[name]]
+            assert pr == str(round(proba[non_na[name]][1], 2))
+
+
+def test_continuous_phenotype_end_to_end(tmp_path, oracle):
+    """Welch t-test + Lasso path: the written t-test rows equal the oracle's, the model explains
+    the planted effect."""
+    import joblib
+    from phenotypeseeker_amd.synth import GenomeSet
+    gs = GenomeSet(40, 8000, seed=41, gene_len=150)
+    os.chdir(tmp_path)
+    rows = ["ID\tAddresses\tMIC"]
+    pheno = []
+    for i in range(gs.n):
+        name, fa = gs.sample(i)
+        with open(name + ".fasta", "wb") as f:
+            f.write(fa)
+        v = "NA" if i == 7 else repr(round(gs.continuous_phenotype(i), 4))
+        pheno.append(v)
+        rows.append("%s\t%s.fasta\t%s" % (name, name, v))
+    with open("data.pheno", "w") as f:
+        f.write("\n".join(rows) + "\n")
+    _run(tmp_path, ["modeling", "data.pheno", "--pvalue", "0.05"])
+    head, got = read_results_tsv("t-test_results_MIC.tsv")
+    assert head == ["k-mer", "t-test", "p-value", "+_group_mean", "-_group_mean", "num_samples_w_kmer", "samples_with_kmer"]
+    assert len(got) > 20
+    # oracle on the same data
+    k, n = 13, gs.n
+    wl = [oracle.count_kmers(gs.sample(i)[1], k)[0] for i in range(n)]
+    uw = oracle.union(wl)
+    bits = oracle.presence_bits(wl, uw)
+    ph = [("NA" if p == "NA" else float(p)) for p in pheno]
+    ref = oracle.ttest_scan(bits, ph, np.ones(n), n, 2, n - 2, 0.05, len(uw))
+    keep = np.nonzero(ref["keep"])[0]
+    want = {oracle.word_to_kmer(uw[r], k): (repr(oracle.round2(ref["stat"][r])), oracle.pstring(ref["p"][r]),
+                                             repr(oracle.round2(ref["mean_x"][r])), repr(oracle.round2(ref["mean_y"][r])),
+                                             str(int(ref["n_with"][r]))) for r in keep}
+    assert {g[0] for g in got} == set(want)
+    for g in got:
+        assert tuple(g[1:6]) == want[g[0]], g[0]
+    pkg = joblib.load("linreg_model_MIC.pkl")
+    assert pkg["pred_scale"] == "continuous"
+    assert "Parameters:\nLasso()" in open("summary_of_linreg_analysis_MIC.txt").read()

@@ -1,0 +1,150 @@
+"""CPU tests of the host mirror (phenotypeseeker_amd.modeling) against the reference's own
+output files in tests/golden/: data.pheno parsing, option defaults, and the selection stage
+(get_ML_df: p-value-string ordering, TSV / MLdf.csv writers) fed with rows from the oracle."""
+import csv
+import os
+
+import numpy as np
+import pytest
+
+from helpers import load_dataset, read_results_tsv
+
+
+def _write_dataset(ds, tmp):
+    for name, data in ds["files"].items():
+        fn = [l.split()[1] for l in open(os.path.join(ds["dir"], "data.pheno")).read().splitlines()[1:]
+              if l.split()[0] == name][0]
+        with open(os.path.join(tmp, fn), "wb") as f:
+            f.write(data)
+    with open(os.path.join(ds["dir"], "data.pheno")) as f:
+        txt = f.read()
+    with open(os.path.join(tmp, "data.pheno"), "w") as f:
+        f.write(txt)
+
+
+def _args(extra=()):
+    from phenotypeseeker_amd.cli import build_parser
+    return build_parser().parse_args(["modeling", "data.pheno"] + list(extra))
+
+
+def _setup(tmp_path, tag, extra=()):
+    from phenotypeseeker_amd import modeling as M
+    ds = load_dataset(tag)
+    _write_dataset(ds, str(tmp_path))
+    os.chdir(tmp_path)
+    a = _args(extra)
+    M.Input.reset()
+    M.Input.get_input_data(a.inputfile, a.take_logs, a.mpheno)
+    M.Input.Input_args(a.alphas, a.alpha_min, a.alpha_max, a.n_alphas, a.gammas, a.gamma_min, a.gamma_max, a.n_gammas,
+                       a.min, a.max, a.kmer_length, a.cutoff, a.num_threads, a.pvalue, a.n_kmers, a.binary_classifier,
+                       a.regressor, a.penalty, a.max_iter, a.tolerance, a.l1_ratio, a.n_splits_cv_outer, a.kernel,
+                       a.n_iter, a.n_splits_cv_inner, a.testset_size, a.train_on_whole, a.logreg_solver, a.jump_to,
+                       a.pca, a.real_counts, a.omit_B_correction, a.kmerDB)
+    return M, ds
+
+
+def test_input_parsing_and_defaults(tmp_path):
+    M, ds = _setup(tmp_path, "ds_omitB", ["--omit_B_correction", "--n_kmers", "100"])
+    assert list(M.Input.samples) == ds["names"]
+    assert M.Samples.no_samples == 20 and M.phenotypes.pred_scale == "binary"
+    ph = M.Input.phenotypes_to_analyse["Pheno"]
+    assert ph.no_samples == 18  # two NA rows
+    assert [s.phenotypes["Pheno"] for s in M.Input.samples.values()] == ds["pheno"]
+    assert (M.Samples.min_samples, M.Samples.max_samples) == (2, 18)  # --min 0 -> 2, --max 0 -> N - 2
+    assert np.allclose(M.phenotypes.alphas, np.logspace(-3, 3, 13))
+    assert M.phenotypes.penalty == "L1" and M.phenotypes.max_iter == 1000.0 and M.phenotypes.kmer_limit == 100
+
+
+def test_continuous_detection_and_logs(tmp_path):
+    from phenotypeseeker_amd import modeling as M
+    os.chdir(tmp_path)
+    with open("d.pheno", "w") as f:
+        f.write("ID\tAddr\tMIC\tbin\nA\ta.fa\t0.25\t1\nB\tb.fa\tNA\t0\nC\tc.fa\t8\tNA\n\n")
+    M.Input.reset()
+    M.Input.get_input_data("d.pheno", True, [1])
+    assert M.phenotypes.pred_scale == "continuous"
+    assert list(M.Input.phenotypes_to_analyse) == ["MIC"]
+    vals = [s.phenotypes["MIC"] for s in M.Input.samples.values()]
+    assert vals == [-2.0, "NA", 3.0]
+    assert M.Input.phenotypes_to_analyse["MIC"].no_samples == 2
+
+
+def test_rejects_options_outside_the_hot_path(tmp_path):
+    with pytest.raises(SystemExit):
+        _setup(tmp_path, "ds_bonf", ["-bc", "SVM"])
+    with pytest.raises(SystemExit):
+        _setup(tmp_path, "ds_bonf", ["--penalty", "L2"])
+
+
+@pytest.mark.parametrize("tag,extra", [("ds_omitB", ["--omit_B_correction", "--n_kmers", "100"]), ("ds_bonf", [])])
+def test_selection_stage_matches_reference_files(tmp_path, oracle, tag, extra):
+    M, ds = _setup(tmp_path, tag, extra)
+    k, names, n = ds["meta"]["k"], ds["names"], len(ds["names"])
+    wl = [oracle.count_kmers(ds["files"][nm], k)[0] for nm in names]
+    uw = oracle.union(wl)
+    bits = oracle.presence_bits(wl, uw)
+    res = oracle.chi2_scan(bits, ds["pheno"], np.ones(n), n, 2, n - 2, 0.05, bool(extra), len(uw))
+    keep = np.nonzero(res["keep"])[0]
+    pres = np.array([[(int(bits[r, i >> 6]) >> (i & 63)) & 1 for i in range(n)] for r in keep], dtype=np.uint8)
+    ph = M.Input.phenotypes_to_analyse["Pheno"]
+    ph.rows = {"kmer": [oracle.word_to_kmer(uw[r], k) for r in keep], "stat": res["stat"][keep], "p": res["p"][keep],
+               "mean_x": np.zeros(len(keep)), "mean_y": np.zeros(len(keep)), "n_with": res["n_with"][keep],
+               "presence": pres, "vector": pres}
+    ph.get_ML_df()
+    head, ref = read_results_tsv(os.path.join(ds["dir"], "chi2_results_Pheno.tsv"))
+    head2, got = read_results_tsv("chi2_results_Pheno.tsv")
+    assert head2 == head
+    assert sorted(got) == sorted(ref)                      # same rows, byte for byte
+    assert [g[2] for g in got] == [r[2] for r in ref]      # same p-string order (ties broken by k-mer here)
+    top = "chi2_results_Pheno_top%d.tsv" % M.phenotypes.kmer_limit
+    _, ref_top = read_results_tsv(os.path.join(ds["dir"], top))
+    _, got_top = read_results_tsv(top)
+    assert [g[2] for g in got_top] == [r[2] for r in ref_top]
+    with open(os.path.join(ds["dir"], "Pheno_MLdf.csv")) as f:
+        ref_csv = list(csv.reader(f))
+    with open("Pheno_MLdf.csv") as f:
+        got_csv = list(csv.reader(f))
+    assert [r[0] for r in got_csv] == [r[0] for r in ref_csv]
+    assert [r[-2:] for r in got_csv] == [r[-2:] for r in ref_csv]
+    ref_cols = {ref_csv[0][j]: [r[j] for r in ref_csv[1:]] for j in range(1, len(ref_csv[0]) - 2)}
+    got_cols = {got_csv[0][j]: [r[j] for r in got_csv[1:]] for j in range(1, len(got_csv[0]) - 2)}
+    if len(ref) <= M.phenotypes.kmer_limit:               # no cut inside a tie class: identical column set
+        assert got_cols == ref_cols
+    else:
+        assert len(got_cols) == len(ref_cols)
+        for kmer in set(got_cols) & set(ref_cols):
+            assert got_cols[kmer] == ref_cols[kmer]
+
+
+def test_list_file_round_trip(tmp_path, oracle):
+    from phenotypeseeker_amd import formats
+    ds = load_dataset("ds_omitB")
+    k = ds["meta"]["k"]
+    first = ds["names"][0]
+    ref_path = os.path.join(ds["dir"], "%s_0_%d.list" % (first, k))
+    kk, w, f = formats.read_list(ref_path)
+    assert kk == k
+    out = os.path.join(tmp_path, "x.list")
+    formats.write_list(out, k, w, f)
+    assert open(out, "rb").read() == open(ref_path, "rb").read()
+    assert formats.words_to_kmers(w[:5], k) == [oracle.word_to_kmer(x, k) for x in w[:5]]
+    assert [formats.canonical(formats.kmer_to_word(s), k) for s in formats.words_to_kmers(w[:50], k)] == w[:50].tolist()
+
+
+def test_metrics_match_sklearn():
+    sk = pytest.importorskip("sklearn.metrics")
+    from phenotypeseeker_amd import metrics as Mx
+    rng = np.random.default_rng(0)
+    for _ in range(20):
+        n = int(rng.integers(10, 60))
+        y = (rng.random(n) < 0.5).astype(int)
+        p = (rng.random(n) < 0.5).astype(int)
+        s = rng.random(n).round(1)
+        if y.sum() in (0, n):
+            continue
+        assert Mx.f1(y, p) == pytest.approx(sk.f1_score(y, p))
+        assert Mx.roc_auc(y, s) == pytest.approx(sk.roc_auc_score(y, s))
+        assert Mx.average_precision(y, s) == pytest.approx(sk.average_precision_score(y, s))
+        assert Mx.matthews(y, p) == pytest.approx(sk.matthews_corrcoef(y, p))
+        assert Mx.cohen_kappa(y, p) == pytest.approx(sk.cohen_kappa_score(y, p))
+        assert Mx.classification_report(y, p) == sk.classification_report(y, p, target_names=["sensitive", "resistant"])
