@@ -19,6 +19,8 @@ def slab_bounds(k, world, rank):
     (the psk_begin convention, needed because 4**32 does not fit in u64).  Concatenating the
     slabs in rank order reproduces glistmaker's ascending list order."""
     space = 1 << (2 * k)
+    if world > space:
+        raise ValueError("more ranks (%d) than canonical %d-mer words (%d)" % (world, k, space))
     lo = (space * rank) // world
     hi = (space * (rank + 1)) // world
     if rank == world - 1:
