@@ -10,6 +10,10 @@
 #include "dev_utils.h"
 #include "psk_internal.h"
 
+#if defined(__SSE2__)
+#include <emmintrin.h>
+#endif
+
 // ------------------------------------------------------------------------------------------------
 // Host framing.  Tokeniser contract of glistmaker 4.2.3 as established by probing the binary
 // (DESIGN.md "Tokeniser contract"; fixtures tests/golden/tokenizer_cases.json).
@@ -27,6 +31,34 @@ struct ClassTable {
     }
 };
 const ClassTable g_cls;
+
+static inline bool is_base_byte(uint8_t c)
+{
+    const uint8_t x = c | 0x20;  // fold case
+    return (x == 'a') | (x == 'c') | (x == 'g') | (x == 't') | (x == 'u');
+}
+
+// length of the leading run of base bytes of p[0..n): 16 bytes per step on the host's SSE2 unit
+static inline size_t base_run_length(const uint8_t *p, size_t n)
+{
+    size_t j = 0;
+#if defined(__SSE2__)
+    const __m128i fold = _mm_set1_epi8(0x20);
+    const __m128i ca = _mm_set1_epi8('a'), cc = _mm_set1_epi8('c'), cg = _mm_set1_epi8('g'), ct = _mm_set1_epi8('t'),
+                  cu = _mm_set1_epi8('u');
+    while (j + 16 <= n) {
+        const __m128i v = _mm_or_si128(_mm_loadu_si128(reinterpret_cast<const __m128i *>(p + j)), fold);
+        const __m128i ok = _mm_or_si128(_mm_or_si128(_mm_cmpeq_epi8(v, ca), _mm_cmpeq_epi8(v, cc)),
+                                        _mm_or_si128(_mm_or_si128(_mm_cmpeq_epi8(v, cg), _mm_cmpeq_epi8(v, ct)),
+                                                     _mm_cmpeq_epi8(v, cu)));
+        const unsigned m = (unsigned)_mm_movemask_epi8(ok);
+        if (m != 0xffffu) return j + (size_t)__builtin_ctz(~m);
+        j += 16;
+    }
+#endif
+    while (j < n && is_base_byte(p[j])) j++;
+    return j;
+}
 }  // namespace
 
 int64_t frame_sequence_host(const uint8_t *bytes, size_t len, uint8_t *out, size_t out_cap)
@@ -54,6 +86,15 @@ int64_t frame_sequence_host(const uint8_t *bytes, size_t len, uint8_t *out, size
             break;
         case ST_FA_SEQ:
         case ST_FQ_SEQ: {
+            // fast path: a run of base bytes is copied in one go (vectorisable scan, no table look-up)
+            if (is_base_byte(c)) {
+                const size_t j = i + base_run_length(bytes + i, len - i);
+                memcpy(out + o, bytes + i, j - i);
+                o += j - i;
+                last_break = false;
+                i = j - 1;
+                break;
+            }
             const uint8_t cl = g_cls.t[c];
             if (cl == CL_BASE) {
                 out[o++] = c;
@@ -122,13 +163,17 @@ __device__ __forceinline__ void roll_byte(Roll &r, uint32_t c, uint64_t mask, in
 }
 
 // clean: bases and '\n' breaks, 16-byte aligned, padded with '\n' to a multiple of EX_SEG.
+// Every lane rolls EX_SEG consecutive window ends; the wave compacts its valid words into its own
+// 16 KiB LDS region (ballot ranks, wave-uniform running count), reserves its output range with ONE
+// atomic and spills the region with consecutive lanes on consecutive addresses.
 __global__ __launch_bounds__(EX_THREADS) void extract_kernel(const uint8_t *__restrict__ clean, uint64_t len, int k,
                                                               uint64_t lo, uint64_t hi, uint64_t *__restrict__ out,
                                                               uint32_t *__restrict__ n_out)
 {
+    __shared__ uint64_t stage[EX_THREADS / 64][64 * EX_SEG];
     const uint64_t g = (uint64_t)blockIdx.x * EX_THREADS + threadIdx.x;
     const uint64_t s = g * EX_SEG;
-    const int lane = threadIdx.x & 63;
+    const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
     const uint64_t mask = (k == 32) ? ~0ull : ((1ull << (2 * k)) - 1ull);
     const int rcshift = 2 * (k - 1);
     const bool active = s < len;
@@ -157,6 +202,7 @@ __global__ __launch_bounds__(EX_THREADS) void extract_kernel(const uint8_t *__re
             roll_byte(r, c, mask, rcshift, k);
         }
     }
+    uint32_t wcount = 0;  // wave-uniform
 #pragma unroll
     for (int j = 0; j < EX_SEG; j++) {
         const uint32_t c = (cur[j >> 2] >> ((j & 3) * 8)) & 0xffu;
@@ -164,14 +210,13 @@ __global__ __launch_bounds__(EX_THREADS) void extract_kernel(const uint8_t *__re
         const uint64_t w = (r.fw < r.rc) ? r.fw : r.rc;
         const bool valid = active && (s + j < len) && (r.run >= k) && (w >= lo) && (hi == 0 || w < hi);
         const uint64_t bal = __ballot(valid);
-        if (bal) {
-            uint32_t base = 0;
-            const int leader = __ffsll((unsigned long long)bal) - 1;
-            if (lane == leader) base = atomicAdd(n_out, (uint32_t)__popcll(bal));
-            base = __shfl(base, leader, 64);
-            if (valid) out[base + __popcll(bal & psk_lanemask_lt(lane))] = w;
-        }
+        if (valid) stage[wid][wcount + __popcll(bal & psk_lanemask_lt(lane))] = w;
+        wcount += (uint32_t)__popcll(bal);
     }
+    uint32_t base = 0;
+    if (lane == 0 && wcount) base = atomicAdd(n_out, wcount);
+    base = __shfl(base, 0, 64);
+    for (uint32_t i = lane; i < wcount; i += 64) out[(uint64_t)base + i] = stage[wid][i];
 }
 
 __global__ void rle_flags_kernel(const uint64_t *__restrict__ keys, uint64_t n, uint32_t *__restrict__ flags)
@@ -254,14 +299,24 @@ __global__ __launch_bounds__(EX_THREADS) void dict_count_kernel(const uint8_t *_
 
 int upload_clean(psk_ctx *ctx, const uint8_t *bytes, size_t len, uint64_t *clean_len)
 {
-    ctx->host_clean.resize(len + 2 * EX_SEG);
-    int64_t n = frame_sequence_host(bytes, len, ctx->host_clean.data(), len + 2 * EX_SEG);
+    // frame straight into a pinned staging buffer (grow-only), then one async H2D copy
+    const size_t need = len + 2 * EX_SEG;
+    if (need > ctx->pinned_cap) {
+        if (ctx->pinned) (void)hipHostFree(ctx->pinned);
+        ctx->pinned = nullptr;
+        ctx->pinned_cap = 0;
+        const size_t want = need + need / 4;
+        hipError_t e = hipHostMalloc(&ctx->pinned, want, hipHostMallocDefault);
+        if (e != hipSuccess) return psk_fail(ctx, PSK_ENOMEM, "hipHostMalloc(%zu) failed: %s", want, hipGetErrorString(e));
+        ctx->pinned_cap = want;
+    }
+    uint8_t *stage = static_cast<uint8_t *>(ctx->pinned);
+    int64_t n = frame_sequence_host(bytes, len, stage, need);
     if (n < 0) return psk_fail(ctx, (int)n, "framing failed");
     const uint64_t padded = ((uint64_t)n + EX_SEG - 1) / EX_SEG * EX_SEG + EX_SEG;
-    ctx->host_clean.resize(padded);
-    memset(ctx->host_clean.data() + n, '\n', padded - n);
+    memset(stage + n, '\n', padded - n);
     PSK_TRY(dev_reserve(ctx, ctx->raw, padded));
-    PSK_HIP(ctx, hipMemcpyAsync(ctx->raw.p, ctx->host_clean.data(), padded, hipMemcpyHostToDevice, ctx->stream));
+    PSK_HIP(ctx, hipMemcpyAsync(ctx->raw.p, stage, padded, hipMemcpyHostToDevice, ctx->stream));
     *clean_len = (uint64_t)n;
     return PSK_OK;
 }

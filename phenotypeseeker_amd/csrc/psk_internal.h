@@ -55,7 +55,8 @@ struct psk_ctx {
 
     // scratch for per-sample counting
     DevBuf raw, keysA, keysB, hist, scan_tmp, flags, starts, misc;
-    std::vector<uint8_t> host_clean;
+    void *pinned = nullptr;   // pinned host staging for the clean stream
+    size_t pinned_cap = 0;
 
     // presence matrix
     uint64_t n_kmers = 0;
