@@ -41,12 +41,43 @@ void dev_release(DevBuf &b)
     b.cap = 0;
 }
 
+int arena_alloc(psk_ctx *ctx, size_t bytes, void **out)
+{
+    Arena &A = ctx->arena;
+    bytes = (bytes + 255) & ~size_t(255);
+    if (bytes == 0) bytes = 256;
+    while (A.cur < A.chunks.size()) {  // first chunk, from the current one on, with room
+        if (A.off + bytes <= A.sizes[A.cur]) {
+            *out = static_cast<uint8_t *>(A.chunks[A.cur]) + A.off;
+            A.off += bytes;
+            return PSK_OK;
+        }
+        A.cur++;
+        A.off = 0;
+    }
+    const size_t sz = bytes > Arena::CHUNK ? bytes : Arena::CHUNK;
+    void *p = nullptr;
+    hipError_t e = hipMalloc(&p, sz);
+    if (e != hipSuccess) return psk_fail(ctx, PSK_ENOMEM, "hipMalloc(%zu bytes) failed: %s", sz, hipGetErrorString(e));
+    A.chunks.push_back(p);
+    A.sizes.push_back(sz);
+    A.cur = A.chunks.size() - 1;
+    A.off = bytes;
+    *out = p;
+    return PSK_OK;
+}
+
+void arena_release(psk_ctx *ctx)
+{
+    for (void *p : ctx->arena.chunks) (void)hipFree(p);
+    ctx->arena = Arena();
+}
+
 void reset_lists(psk_ctx *ctx, int n_samples)
 {
-    for (auto &L : ctx->lists) {
-        if (L.words) (void)hipFree(L.words);
-        if (L.freqs) (void)hipFree(L.freqs);
-    }
+    // list storage lives in the arena: rewind it (chunks are kept for the next run)
+    ctx->arena.cur = 0;
+    ctx->arena.off = 0;
     ctx->lists.assign((size_t)(n_samples > 0 ? n_samples : 0), SampleList());
 }
 
@@ -85,6 +116,7 @@ extern "C" void psk_free(psk_ctx *ctx)
     (void)hipSetDevice(ctx->device);
     if (ctx->stream) (void)hipStreamSynchronize(ctx->stream);
     reset_lists(ctx, 0);
+    arena_release(ctx);
     DevBuf *bufs[] = {&ctx->raw, &ctx->keysA, &ctx->keysB, &ctx->hist, &ctx->scan_tmp, &ctx->flags, &ctx->starts,
                       &ctx->misc, &ctx->union_words, &ctx->bits, &ctx->mask1, &ctx->mask0, &ctx->wts, &ctx->phe,
                       &ctx->res, &ctx->res_count, &ctx->res_sorted};

@@ -25,6 +25,11 @@ namespace {
 
 constexpr int SC_THREADS = 256;
 constexpr int SC_UNROLL = 4;
+// Survivors are appended to SC_NSEG independent segments (segment = blockIdx % SC_NSEG), each with its
+// own counter on its own 128-byte line: one shared counter serialises at ~11 ns per append (r01: a
+// matrix with 1 % survivors ran 15x slower than the stream rate).
+constexpr int SC_NSEG = 256;
+constexpr int SC_CNT_STRIDE = 32;  // u32 per counter slot
 typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
 
 struct ScanArgs {
@@ -48,8 +53,16 @@ struct ScanArgs {
     uint64_t *res_row;
     double *res_stat, *res_p, *res_mx, *res_my;
     int32_t *res_nw;
-    uint32_t *counter;
+    uint32_t *counter;   // SC_NSEG slots, SC_CNT_STRIDE u32 apart
+    uint32_t seg_cap;    // entries per segment
 };
+
+__device__ __forceinline__ uint64_t reserve_slot(const ScanArgs &P)
+{
+    const uint32_t seg = blockIdx.x & (SC_NSEG - 1);
+    const uint32_t idx = atomicAdd(&P.counter[seg * SC_CNT_STRIDE], 1u);
+    return (uint64_t)seg * P.seg_cap + (idx < P.seg_cap ? idx : P.seg_cap - 1);
+}
 
 // modeling.py:773-794 in the reference's operation order.
 __device__ __forceinline__ double chi2_exact(double A, double B, double C, double D)
@@ -163,7 +176,7 @@ __global__ __launch_bounds__(SC_THREADS) void chi2_scan_kernel(const ScanArgs P)
             const double p = exp(-0.5 * stat);  // chi2.sf(stat, df = 2), modeling.py:782-792
             const bool keep = (P.omit_B && p < P.pcut) || (p < P.pcut_bonf);  // modeling.py:795
             if (keep) {
-                const uint32_t idx = atomicAdd(P.counter, 1u);
+                const uint64_t idx = reserve_slot(P);
                 P.res_row[idx] = row;
                 P.res_stat[idx] = stat;
                 P.res_p[idx] = p;
@@ -287,7 +300,7 @@ __global__ __launch_bounds__(SC_THREADS) void ttest_scan_kernel(const ScanArgs P
         const double df = 1.0 / (z1 + z2);
         const double p = dev_t_two_sided_p(t, df);
         if (p < P.pcut_bonf) {  // modeling.py:738 (Bonferroni always)
-            const uint32_t idx = atomicAdd(P.counter, 1u);
+            const uint64_t idx = reserve_slot(P);
             P.res_row[idx] = row;
             P.res_stat[idx] = t;
             P.res_p[idx] = p;
@@ -332,10 +345,19 @@ int group_lanes(int cpr)
     return G;
 }
 
-// result arrays (SoA) inside ctx->res: row u64 | stat f64 | p f64 | mx f64 | my f64 | nw i32
-int setup_results(psk_ctx *ctx, ScanArgs &a)
+// result arrays (SoA) inside ctx->res: row u64 | stat f64 | p f64 | mx f64 | my f64 | nw i32, each
+// SC_NSEG * seg_cap entries; seg_cap bounds the rows the blocks of one segment can visit
+int setup_results(psk_ctx *ctx, ScanArgs &a, dim3 grid, int G, int unroll)
 {
-    const uint64_t cap = ctx->n_kmers ? ctx->n_kmers : 1;
+    const uint64_t rpw = 64 / G;
+    const uint64_t n_steps = (a.M + rpw - 1) / rpw;
+    const uint64_t total_waves = (uint64_t)grid.x * (SC_THREADS / 64);
+    const uint64_t iters = (n_steps + total_waves * unroll - 1) / (total_waves * unroll);
+    const uint64_t blocks_per_seg = ((uint64_t)grid.x + SC_NSEG - 1) / SC_NSEG;
+    uint64_t seg_cap = blocks_per_seg * (SC_THREADS / 64) * iters * unroll * rpw;
+    if (seg_cap < 64) seg_cap = 64;
+    if (seg_cap >= (1ull << 32)) return psk_fail(ctx, PSK_ERANGE, "result segment too large");
+    const uint64_t cap = seg_cap * SC_NSEG;
     PSK_TRY(dev_reserve(ctx, ctx->res, cap * 44 + 64));
     uint8_t *b = ctx->res.as<uint8_t>();
     a.res_row = reinterpret_cast<uint64_t *>(b);
@@ -344,9 +366,45 @@ int setup_results(psk_ctx *ctx, ScanArgs &a)
     a.res_mx = reinterpret_cast<double *>(b + cap * 24);
     a.res_my = reinterpret_cast<double *>(b + cap * 32);
     a.res_nw = reinterpret_cast<int32_t *>(b + cap * 40);
-    PSK_TRY(dev_reserve(ctx, ctx->res_count, 64));
+    PSK_TRY(dev_reserve(ctx, ctx->res_count, SC_NSEG * SC_CNT_STRIDE * 4));
     a.counter = ctx->res_count.as<uint32_t>();
+    a.seg_cap = (uint32_t)seg_cap;
+    ctx->res_seg_cap = seg_cap;
     return PSK_OK;
+}
+
+// pulls the per-segment counters to the host; n_pass = their sum
+int fetch_counts(psk_ctx *ctx, const ScanArgs &a)
+{
+    std::vector<uint32_t> raw((size_t)SC_NSEG * SC_CNT_STRIDE);
+    PSK_HIP(ctx, hipMemcpy(raw.data(), a.counter, raw.size() * 4, hipMemcpyDeviceToHost));
+    ctx->seg_counts.assign(SC_NSEG, 0);
+    uint64_t tot = 0;
+    for (int s = 0; s < SC_NSEG; s++) {
+        uint32_t c = raw[(size_t)s * SC_CNT_STRIDE];
+        if (c > a.seg_cap) return psk_fail(ctx, PSK_ERANGE, "result segment %d overflowed (%u > %u)", s, c, a.seg_cap);
+        ctx->seg_counts[s] = c;
+        tot += c;
+    }
+    ctx->n_pass = tot;
+    return PSK_OK;
+}
+
+// one block per segment: copies the segment's entries to their place in the contiguous arrays
+__global__ void pack_segments_kernel(const uint8_t *__restrict__ src, uint64_t cap, uint32_t seg_cap,
+                                     const uint32_t *__restrict__ counts, const uint64_t *__restrict__ offsets,
+                                     uint8_t *__restrict__ dst, uint64_t n)
+{
+    const uint32_t seg = blockIdx.x;
+    const uint32_t c = counts[seg];
+    const uint64_t in0 = (uint64_t)seg * seg_cap, out0 = offsets[seg];
+    const uint64_t *r = reinterpret_cast<const uint64_t *>(src);
+    uint64_t *d = reinterpret_cast<uint64_t *>(dst);
+    for (uint32_t i = threadIdx.x; i < c; i += blockDim.x) {
+#pragma unroll
+        for (int f = 0; f < 5; f++) d[(uint64_t)f * n + out0 + i] = r[(uint64_t)f * cap + in0 + i];
+        reinterpret_cast<int32_t *>(dst + 40 * n)[out0 + i] = reinterpret_cast<const int32_t *>(src + 40 * cap)[in0 + i];
+    }
 }
 
 dim3 scan_grid(const psk_ctx *ctx, uint64_t M, int G, int unroll)
@@ -367,7 +425,7 @@ int run_chi2(psk_ctx *ctx, ScanArgs &a, bool weighted, int reps, double *ms_tota
     const dim3 grid = scan_grid(ctx, a.M, G, SC_UNROLL);
     *ms_total = 0;
     for (int r = 0; r < reps; r++) {
-        PSK_HIP(ctx, hipMemsetAsync(a.counter, 0, 4, ctx->stream));
+        PSK_HIP(ctx, hipMemsetAsync(a.counter, 0, SC_NSEG * SC_CNT_STRIDE * 4, ctx->stream));
         PSK_HIP(ctx, hipEventRecord(ctx->ev0, ctx->stream));
         if (weighted) launch_chi2<true>(G, grid, ctx->stream, a);
         else launch_chi2<false>(G, grid, ctx->stream, a);
@@ -404,7 +462,8 @@ static int fill_chi2_args(psk_ctx *ctx, ScanArgs &a)
     if (pmax >= 1.0) a.thr = 0.0;
     else if (pmax <= 0.0) a.thr = INFINITY;
     else a.thr = -2.0 * log(pmax);
-    return setup_results(ctx, a);
+    const int G = group_lanes(a.cpr);
+    return setup_results(ctx, a, scan_grid(ctx, a.M, G, SC_UNROLL), G, SC_UNROLL);
 }
 
 extern "C" int psk_chi2_scan(psk_ctx *ctx, const int8_t *pheno, const double *weights, int min_samples,
@@ -451,9 +510,7 @@ extern "C" int psk_chi2_scan(psk_ctx *ctx, const int8_t *pheno, const double *we
         double ms = 0;
         PSK_TRY(run_chi2(ctx, a, ctx->last.weighted, 1, &ms));
         ctx->last_scan_ms = ms;
-        uint32_t np = 0;
-        PSK_HIP(ctx, hipMemcpy(&np, a.counter, 4, hipMemcpyDeviceToHost));
-        ctx->n_pass = np;
+        PSK_TRY(fetch_counts(ctx, a));
     }
     if (n_pass) *n_pass = ctx->n_pass;
     return PSK_OK;
@@ -472,9 +529,7 @@ extern "C" int psk_rescan_timed(psk_ctx *ctx, int reps, double *mean_ms)
     double ms = 0;
     PSK_TRY(run_chi2(ctx, a, ctx->last.weighted, reps, &ms));
     ctx->last_scan_ms = ms / reps;
-    uint32_t np = 0;
-    PSK_HIP(ctx, hipMemcpy(&np, a.counter, 4, hipMemcpyDeviceToHost));
-    ctx->n_pass = np;
+    PSK_TRY(fetch_counts(ctx, a));
     if (mean_ms) *mean_ms = ms / reps;
     return PSK_OK;
 }
@@ -516,14 +571,14 @@ extern "C" int psk_ttest_scan(psk_ctx *ctx, const double *pheno, const uint8_t *
     a.max_samples = max_samples;
     a.pcut = pvalue_cutoff;
     a.pcut_bonf = pvalue_cutoff / (double)n_kmers_global;
-    PSK_TRY(setup_results(ctx, a));
+    const int G = group_lanes(a.cpr);
+    const dim3 grid = scan_grid(ctx, a.M, G, 1);
+    PSK_TRY(setup_results(ctx, a, grid, G, 1));
     ctx->n_pass = 0;
     ctx->last_scan_kind = 2;
     ctx->last.valid = false;
     if (ctx->n_kmers) {
-        const int G = group_lanes(a.cpr);
-        const dim3 grid = scan_grid(ctx, a.M, G, 1);
-        PSK_HIP(ctx, hipMemsetAsync(a.counter, 0, 4, ctx->stream));
+        PSK_HIP(ctx, hipMemsetAsync(a.counter, 0, SC_NSEG * SC_CNT_STRIDE * 4, ctx->stream));
         PSK_HIP(ctx, hipEventRecord(ctx->ev0, ctx->stream));
         launch_ttest(G, grid, ctx->stream, a);
         PSK_HIP(ctx, hipGetLastError());
@@ -532,9 +587,7 @@ extern "C" int psk_ttest_scan(psk_ctx *ctx, const double *pheno, const uint8_t *
         float ms = 0;
         PSK_HIP(ctx, hipEventElapsedTime(&ms, ctx->ev0, ctx->ev1));
         ctx->last_scan_ms = ms;
-        uint32_t np = 0;
-        PSK_HIP(ctx, hipMemcpy(&np, a.counter, 4, hipMemcpyDeviceToHost));
-        ctx->n_pass = np;
+        PSK_TRY(fetch_counts(ctx, a));
     }
     if (n_pass) *n_pass = ctx->n_pass;
     return PSK_OK;
@@ -550,8 +603,25 @@ extern "C" int psk_get_results(psk_ctx *ctx, uint64_t *row_idx, uint64_t *words,
                                  (unsigned long long)n);
     if (n == 0) return PSK_OK;
     PSK_HIP(ctx, hipSetDevice(ctx->device));
-    const uint64_t c = ctx->n_kmers ? ctx->n_kmers : 1;
-    const uint8_t *b = ctx->res.as<uint8_t>();
+    // pack the segments into contiguous SoA arrays of n entries
+    {
+        std::vector<uint64_t> offs(SC_NSEG);
+        uint64_t acc = 0;
+        for (int sgm = 0; sgm < SC_NSEG; sgm++) { offs[sgm] = acc; acc += ctx->seg_counts[sgm]; }
+        PSK_TRY(dev_reserve(ctx, ctx->res_sorted, n * 44 + 64 + SC_NSEG * 12));
+        uint8_t *aux = ctx->res_sorted.as<uint8_t>() + ((n * 44 + 63) & ~63ull);
+        uint32_t *d_cnt = reinterpret_cast<uint32_t *>(aux + SC_NSEG * 8);
+        PSK_HIP(ctx, hipMemcpyAsync(aux, offs.data(), SC_NSEG * 8, hipMemcpyHostToDevice, ctx->stream));
+        PSK_HIP(ctx, hipMemcpyAsync(d_cnt, ctx->seg_counts.data(), SC_NSEG * 4, hipMemcpyHostToDevice, ctx->stream));
+        pack_segments_kernel<<<SC_NSEG, 256, 0, ctx->stream>>>(ctx->res.as<uint8_t>(), ctx->res_seg_cap * SC_NSEG,
+                                                             (uint32_t)ctx->res_seg_cap, d_cnt,
+                                                             reinterpret_cast<const uint64_t *>(aux),
+                                                             ctx->res_sorted.as<uint8_t>(), n);
+        PSK_HIP(ctx, hipGetLastError());
+        PSK_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    }
+    const uint64_t c = n;
+    const uint8_t *b = ctx->res_sorted.as<uint8_t>();
     std::vector<uint64_t> rows(n);
     std::vector<double> st(n), pv(n), mx(n), my(n);
     std::vector<int32_t> nw(n);

@@ -73,6 +73,15 @@ int64_t frame_sequence_host(const uint8_t *bytes, size_t len, uint8_t *out, size
     for (size_t i = 0; i < len; i++) {
         const uint8_t c = bytes[i];
         if (c == 0) break;
+        if ((st == ST_FA_HDR || st == ST_FQ_HDR || st == ST_FQ_PLUS || st == ST_FQ_QUAL || st == ST_FQ_HSKIP) && c != '\n') {
+            // skip to the end of this line in one go
+            const void *nl = memchr(bytes + i, '\n', len - i);
+            const size_t j = nl ? (size_t)(static_cast<const uint8_t *>(nl) - bytes) : len;
+            if (memchr(bytes + i, 0, j - i)) break;  // a NUL inside the skipped text ends the input
+            if (j >= len) break;
+            i = j - 1;  // the newline itself goes through the state machine
+            continue;
+        }
         switch (st) {
         case ST_INIT:
             if (c == '>') st = ST_FA_HDR;
@@ -342,9 +351,7 @@ extern "C" int psk_count_kmers(psk_ctx *ctx, int sample_idx, const uint8_t *byte
     if (!bytes && len) return psk_fail(ctx, PSK_EINVAL, "null input");
     PSK_HIP(ctx, hipSetDevice(ctx->device));
     SampleList &L = ctx->lists[sample_idx];
-    if (L.words) { (void)hipFree(L.words); L.words = nullptr; }
-    if (L.freqs) { (void)hipFree(L.freqs); L.freqs = nullptr; }
-    L = SampleList();
+    L = SampleList();  // a re-counted sample simply takes fresh arena space
     ctx->have_presence = false;
 
     uint64_t clean_len = 0;
@@ -380,8 +387,8 @@ extern "C" int psk_count_kmers(psk_ctx *ctx, int sample_idx, const uint8_t *byte
         PSK_HIP(ctx, hipMemcpyAsync(&nu32, d_n + 1, 4, hipMemcpyDeviceToHost, ctx->stream));
         PSK_HIP(ctx, hipStreamSynchronize(ctx->stream));
         nu = nu32;
-        PSK_HIP(ctx, hipMalloc((void **)&L.words, nu * 8));
-        PSK_HIP(ctx, hipMalloc((void **)&L.freqs, nu * 4));
+        PSK_TRY(arena_alloc(ctx, nu * 8, (void **)&L.words));
+        PSK_TRY(arena_alloc(ctx, nu * 4, (void **)&L.freqs));
         PSK_HIP(ctx, hipMemcpyAsync(L.words, other, nu * 8, hipMemcpyDeviceToDevice, ctx->stream));
         rle_counts_kernel<<<div_up(nu, 256), 256, 0, ctx->stream>>>(ctx->starts.as<uint32_t>(), nu, n, L.freqs);
         PSK_HIP(ctx, hipGetLastError());

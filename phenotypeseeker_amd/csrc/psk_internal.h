@@ -21,6 +21,16 @@ struct DevBuf {
     template <class T> T *as() const { return reinterpret_cast<T *>(p); }
 };
 
+// Bump allocator for the per-sample lists: thousands of odd-sized hipMallocs fragment the device
+// address space (the 5 GB matrix allocated afterwards then streams at a fraction of HBM speed, r01
+// cfg-3 probe), so lists are carved out of a few 1 GiB chunks instead.
+struct Arena {
+    std::vector<void *> chunks;
+    std::vector<size_t> sizes;
+    size_t cur = 0, off = 0;
+    static constexpr size_t CHUNK = 1ull << 30;
+};
+
 struct SampleList {
     uint64_t *words = nullptr;  // device, ascending canonical words (this slab)
     uint32_t *freqs = nullptr;  // device
@@ -52,6 +62,7 @@ struct psk_ctx {
     int n_samples = 0;
     uint64_t slab_lo = 0, slab_hi = 0;  // slab_hi == 0: unbounded
     std::vector<SampleList> lists;
+    Arena arena;
 
     // scratch for per-sample counting
     DevBuf raw, keysA, keysB, hist, scan_tmp, flags, starts, misc;
@@ -67,6 +78,8 @@ struct psk_ctx {
     // scan state
     DevBuf mask1, mask0, wts, phe, res, res_count, res_sorted;
     uint64_t n_pass = 0;
+    uint64_t res_seg_cap = 0;            // entries per result segment of the last scan
+    std::vector<uint32_t> seg_counts;    // survivors per segment
     int last_scan_kind = 0;  // 1 chi2, 2 ttest
     double last_scan_ms = 0;
     ScanParams last;
@@ -91,7 +104,9 @@ int psk_fail(psk_ctx *ctx, int code, const char *fmt, ...);
 
 int dev_reserve(psk_ctx *ctx, DevBuf &b, size_t bytes);  // grow-only, contents NOT preserved
 void dev_release(DevBuf &b);
-void reset_lists(psk_ctx *ctx, int n_samples);  // frees the per-sample lists, resizes to n_samples
+void reset_lists(psk_ctx *ctx, int n_samples);
+int arena_alloc(psk_ctx *ctx, size_t bytes, void **out);   // 256-byte aligned, freed by reset_lists
+void arena_release(psk_ctx *ctx);  // frees the per-sample lists, resizes to n_samples
 
 static inline unsigned div_up(uint64_t a, uint64_t b) { return (unsigned)((a + b - 1) / b); }
 
