@@ -122,6 +122,7 @@ extern "C" void psk_free(psk_ctx *ctx)
                       &ctx->res, &ctx->res_count, &ctx->res_sorted};
     for (DevBuf *b : bufs) dev_release(*b);
     if (ctx->pinned) (void)hipHostFree(ctx->pinned);
+    if (ctx->scan_pinned) (void)hipHostFree(ctx->scan_pinned);
     if (ctx->ev0) (void)hipEventDestroy(ctx->ev0);
     if (ctx->ev1) (void)hipEventDestroy(ctx->ev1);
     if (ctx->stream) (void)hipStreamDestroy(ctx->stream);

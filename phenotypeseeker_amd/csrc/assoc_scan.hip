@@ -230,83 +230,129 @@ __device__ double dev_t_two_sided_p(double t, double df)
     return dev_betainc(0.5 * df, 0.5, df / (df + t * t));
 }
 
-template <int G>
-__global__ __launch_bounds__(SC_THREADS) void ttest_scan_kernel(const ScanArgs P)
+__device__ __forceinline__ double wave_sum_f64(double v)
 {
+#pragma unroll
+    for (int d = 32; d > 0; d >>= 1) v += psk_shfl_xor_f64(v, d);
+    return v;
+}
+
+// Welch scan.  Phase A is the chi2 kernel's streaming shape (one 16-byte load per lane per row, popcount
+// against the non-NA mask, group reduce, frequency filter of modeling.py:731).  Rows that pass are then
+// handled one at a time by the WHOLE wave (phase B): lane l owns samples l, l+64, ... so the phenotype
+// values / weights are read from LDS conflict-free and the two passes of weighted sums (DescrStatsW,
+// ddof 0) finish with a 64-lane butterfly.  r01 ran the passes inside the owning lane group (G lanes,
+// per-bit global loads): 80 ms for 16 M x 1024; this shape is bound by the f64 work of surviving rows only.
+template <int G>
+__global__ __launch_bounds__(SC_THREADS) void ttest_scan_kernel(const ScanArgs P, const int use_lds)
+{
+    extern __shared__ double sm[];  // val[wpr*64] | wt[wpr*64] when use_lds
     constexpr int RPW = 64 / G;
     const int lane = threadIdx.x & 63;
     const int g = lane & (G - 1);
     const int rsub = lane / G;
+    const int wpr = 2 * P.cpr;
     const uint64_t n_steps = (P.M + RPW - 1) / RPW;
     const uint64_t wave_global = (uint64_t)blockIdx.x * (SC_THREADS / 64) + (threadIdx.x >> 6);
     const uint64_t total_waves = (uint64_t)gridDim.x * (SC_THREADS / 64);
-    const int wpr = 2 * P.cpr;
+    const bool has_chunk = g < P.cpr;
+    const double *val = P.val, *wt = P.wt;
+    if (use_lds) {
+        for (int i = threadIdx.x; i < wpr * 64; i += SC_THREADS) { sm[i] = P.val[i]; sm[wpr * 64 + i] = P.wt[i]; }
+        __syncthreads();
+        val = sm;
+        wt = sm + wpr * 64;
+    }
+    uint64_t mva = 0, mvb = 0;
+    if (has_chunk) { mva = P.mvalid[2 * g]; mvb = P.mvalid[2 * g + 1]; }
+    const uint64_t *bits64 = reinterpret_cast<const uint64_t *>(P.bits);
 
-    for (uint64_t s = wave_global; s < n_steps; s += total_waves) {
-        const uint64_t row = s * RPW + rsub;
-        const uint64_t *rp = reinterpret_cast<const uint64_t *>(P.bits) + row * (uint64_t)wpr;
-        uint32_t cnt = 0;
-        if (row < P.M)
-            for (int w = g; w < wpr; w += G) cnt += __popcll(rp[w] & P.mvalid[w]);
+    for (uint64_t s0 = wave_global * SC_UNROLL; s0 < n_steps; s0 += total_waves * SC_UNROLL) {
+        u32x4 x[SC_UNROLL];
 #pragma unroll
-        for (int d = G / 2; d > 0; d >>= 1) cnt += __shfl_xor(cnt, d, 64);
-        const int n_w = (int)cnt, n_wo = P.nvalid - (int)cnt;
-        // modeling.py:731
-        const bool freq_ok = (row < P.M) && !(n_w < P.min_samples || n_wo < 2 || n_w > P.max_samples);
-        if (!freq_ok) continue;
-        // pass 1: weighted sums per group (weights are 0 where the phenotype is NA)
-        double nx = 0, sx = 0, ny = 0, sy = 0;
-        for (int w = g; w < wpr; w += G) {
-            const uint64_t x = rp[w];
-            const uint64_t mv = P.mvalid[w];
-            for (int b = 0; b < 64; b++) {
-                if (!((mv >> b) & 1)) continue;
-                const double wt = P.wt[w * 64 + b], v = P.val[w * 64 + b];
-                if ((x >> b) & 1) { nx += wt; sx += wt * v; } else { ny += wt; sy += wt * v; }
+        for (int u = 0; u < SC_UNROLL; u++) {
+            const uint64_t row = (s0 + u) * RPW + rsub;
+            x[u] = (u32x4)(0u);
+            if (row < P.M && has_chunk) x[u] = __builtin_nontemporal_load(&P.bits[row * (uint64_t)P.cpr + g]);
+        }
+#pragma unroll
+        for (int u = 0; u < SC_UNROLL; u++) {
+            const uint64_t row = (s0 + u) * RPW + rsub;
+            const uint64_t xa = ((uint64_t)x[u].y << 32) | x[u].x, xb = ((uint64_t)x[u].w << 32) | x[u].z;
+            uint32_t cnt = __popcll(xa & mva) + __popcll(xb & mvb);
+            if (P.cpr > G && row < P.M)
+                for (int ch = g + G; ch < P.cpr; ch += G) {
+                    const u32x4 y = P.bits[row * (uint64_t)P.cpr + ch];
+                    cnt += __popcll((((uint64_t)y.y << 32) | y.x) & P.mvalid[2 * ch]) +
+                           __popcll((((uint64_t)y.w << 32) | y.z) & P.mvalid[2 * ch + 1]);
+                }
+#pragma unroll
+            for (int d = G / 2; d > 0; d >>= 1) cnt += __shfl_xor(cnt, d, 64);
+            const int n_w = (int)cnt, n_wo = P.nvalid - (int)cnt;
+            const bool freq_ok = (row < P.M) && !(n_w < P.min_samples || n_wo < 2 || n_w > P.max_samples);
+            uint64_t todo = __ballot(freq_ok && g == 0);
+            while (todo) {  // wave-uniform loop over the rows of this step that passed the frequency filter
+                const int src = __ffsll((unsigned long long)todo) - 1;
+                todo &= todo - 1;
+                const uint64_t r = (s0 + u) * RPW + (uint64_t)(src / G);
+                const int r_nw = __builtin_amdgcn_readlane(n_w, src);
+                const uint64_t *rp = bits64 + r * (uint64_t)wpr;
+                const int wreg = (P.cpr <= G) ? wpr : 2 * G;  // words of the row held in the group's registers
+                double nx = 0, sx = 0, ny = 0, sy = 0;
+                for (int t = 0; t < wpr; t++) {
+                    // word t of row r: broadcast from the register of the lane that loaded it in phase A
+                    // (rows wider than the lane group fall back to a broadcast load, an L1/L2 hit)
+                    uint64_t xw;
+                    if (t < wreg) {
+                        xw = psk_readlane_u64((t & 1) ? xb : xa, src + (t >> 1));  // scalar lane read, no LDS
+                    } else {
+                        xw = rp[t];
+                    }
+                    const double w = wt[t * 64 + lane], v = val[t * 64 + lane];  // w == 0 where NA / padding
+                    const bool pres = (xw >> lane) & 1;
+                    const double wv = w * v;
+                    nx += pres ? w : 0.0; sx += pres ? wv : 0.0;
+                    ny += pres ? 0.0 : w; sy += pres ? 0.0 : wv;
+                }
+                nx = psk_wave_sum_f64_dpp(nx); sx = psk_wave_sum_f64_dpp(sx);
+                ny = psk_wave_sum_f64_dpp(ny); sy = psk_wave_sum_f64_dpp(sy);
+                const double mx = sx / nx, my = sy / ny;
+                double qx = 0, qy = 0;
+                for (int t = 0; t < wpr; t++) {
+                    uint64_t xw;
+                    if (t < wreg) {
+                        xw = psk_readlane_u64((t & 1) ? xb : xa, src + (t >> 1));  // scalar lane read, no LDS
+                    } else {
+                        xw = rp[t];
+                    }
+                    const double w = wt[t * 64 + lane], v = val[t * 64 + lane];
+                    const bool pres = (xw >> lane) & 1;
+                    const double dd = v - (pres ? mx : my);
+                    const double c = w * dd * dd;
+                    qx += pres ? c : 0.0;
+                    qy += pres ? 0.0 : c;
+                }
+                qx = psk_wave_sum_f64_dpp(qx); qy = psk_wave_sum_f64_dpp(qy);
+                const double vx = qx / nx, vy = qy / ny;  // ddof = 0
+                const double sem1 = vx / (nx - 1.0), sem2 = vy / (ny - 1.0);
+                const double semsum = sem1 + sem2;
+                const double tstat = (mx - my) / sqrt(semsum);
+                // Student's t has heavier tails than the normal: p_t >= erfc(|t|/sqrt 2); cheap rejection
+                if (erfc(fabs(tstat) * 0.70710678118654752440) >= P.pcut_bonf) continue;
+                const double z1 = (sem1 / semsum) * (sem1 / semsum) / (nx - 1.0);
+                const double z2 = (sem2 / semsum) * (sem2 / semsum) / (ny - 1.0);
+                const double df = 1.0 / (z1 + z2);
+                const double p = dev_t_two_sided_p(tstat, df);  // every lane computes the same value
+                if (p < P.pcut_bonf && lane == 0) {  // modeling.py:738 (Bonferroni always)
+                    const uint64_t idx = reserve_slot(P);
+                    P.res_row[idx] = r;
+                    P.res_stat[idx] = tstat;
+                    P.res_p[idx] = p;
+                    P.res_mx[idx] = mx;
+                    P.res_my[idx] = my;
+                    P.res_nw[idx] = r_nw;
+                }
             }
-        }
-#pragma unroll
-        for (int d = G / 2; d > 0; d >>= 1) {
-            nx += psk_shfl_xor_f64(nx, d); sx += psk_shfl_xor_f64(sx, d);
-            ny += psk_shfl_xor_f64(ny, d); sy += psk_shfl_xor_f64(sy, d);
-        }
-        const double mx = sx / nx, my = sy / ny;
-        // pass 2: weighted sums of squared deviations (DescrStatsW, ddof = 0)
-        double qx = 0, qy = 0;
-        for (int w = g; w < wpr; w += G) {
-            const uint64_t x = rp[w];
-            const uint64_t mv = P.mvalid[w];
-            for (int b = 0; b < 64; b++) {
-                if (!((mv >> b) & 1)) continue;
-                const double wt = P.wt[w * 64 + b], v = P.val[w * 64 + b];
-                if ((x >> b) & 1) { const double dd = v - mx; qx += wt * dd * dd; }
-                else { const double dd = v - my; qy += wt * dd * dd; }
-            }
-        }
-#pragma unroll
-        for (int d = G / 2; d > 0; d >>= 1) {
-            qx += psk_shfl_xor_f64(qx, d);
-            qy += psk_shfl_xor_f64(qy, d);
-        }
-        if (g != 0) continue;
-        const double vx = qx / nx, vy = qy / ny;
-        const double sem1 = vx / (nx - 1.0), sem2 = vy / (ny - 1.0);
-        const double semsum = sem1 + sem2;
-        const double t = (mx - my) / sqrt(semsum);
-        // Student's t has heavier tails than the normal: p_t >= erfc(|t|/sqrt 2); cheap rejection
-        if (erfc(fabs(t) * 0.70710678118654752440) >= P.pcut_bonf) continue;
-        const double z1 = (sem1 / semsum) * (sem1 / semsum) / (nx - 1.0);
-        const double z2 = (sem2 / semsum) * (sem2 / semsum) / (ny - 1.0);
-        const double df = 1.0 / (z1 + z2);
-        const double p = dev_t_two_sided_p(t, df);
-        if (p < P.pcut_bonf) {  // modeling.py:738 (Bonferroni always)
-            const uint64_t idx = reserve_slot(P);
-            P.res_row[idx] = row;
-            P.res_stat[idx] = t;
-            P.res_p[idx] = p;
-            P.res_mx[idx] = mx;
-            P.res_my[idx] = my;
-            P.res_nw[idx] = n_w;
         }
     }
 }
@@ -327,14 +373,18 @@ void launch_chi2(int G, dim3 grid, hipStream_t st, const ScanArgs &a)
 
 void launch_ttest(int G, dim3 grid, hipStream_t st, const ScanArgs &a)
 {
+    // phenotype values + weights in LDS when they fit in 64 KiB (<= 4096 samples), else from L1/L2
+    const size_t need = (size_t)a.cpr * 2 * 64 * 2 * sizeof(double);
+    const int use_lds = need <= 65536 ? 1 : 0;
+    const size_t lds = use_lds ? need : 0;
     switch (G) {
-    case 1: ttest_scan_kernel<1><<<grid, SC_THREADS, 0, st>>>(a); break;
-    case 2: ttest_scan_kernel<2><<<grid, SC_THREADS, 0, st>>>(a); break;
-    case 4: ttest_scan_kernel<4><<<grid, SC_THREADS, 0, st>>>(a); break;
-    case 8: ttest_scan_kernel<8><<<grid, SC_THREADS, 0, st>>>(a); break;
-    case 16: ttest_scan_kernel<16><<<grid, SC_THREADS, 0, st>>>(a); break;
-    case 32: ttest_scan_kernel<32><<<grid, SC_THREADS, 0, st>>>(a); break;
-    default: ttest_scan_kernel<64><<<grid, SC_THREADS, 0, st>>>(a); break;
+    case 1: ttest_scan_kernel<1><<<grid, SC_THREADS, lds, st>>>(a, use_lds); break;
+    case 2: ttest_scan_kernel<2><<<grid, SC_THREADS, lds, st>>>(a, use_lds); break;
+    case 4: ttest_scan_kernel<4><<<grid, SC_THREADS, lds, st>>>(a, use_lds); break;
+    case 8: ttest_scan_kernel<8><<<grid, SC_THREADS, lds, st>>>(a, use_lds); break;
+    case 16: ttest_scan_kernel<16><<<grid, SC_THREADS, lds, st>>>(a, use_lds); break;
+    case 32: ttest_scan_kernel<32><<<grid, SC_THREADS, lds, st>>>(a, use_lds); break;
+    default: ttest_scan_kernel<64><<<grid, SC_THREADS, lds, st>>>(a, use_lds); break;
     }
 }
 
@@ -449,9 +499,9 @@ static int fill_chi2_args(psk_ctx *ctx, ScanArgs &a)
     a.M = ctx->n_kmers;
     a.cpr = ctx->wpr / 2;
     a.m1 = ctx->mask1.as<uint64_t>();
-    a.m0 = ctx->mask0.as<uint64_t>();
-    a.w1 = ctx->wts.as<double>();
-    a.w0 = ctx->wts.as<double>() + (size_t)ctx->wpr * 64;
+    a.m0 = a.m1 + ctx->wpr;
+    a.w1 = reinterpret_cast<const double *>(a.m1 + 2 * (size_t)ctx->wpr);
+    a.w0 = a.w1 + (size_t)ctx->wpr * 64;
     a.min_samples = L.min_samples;
     a.max_samples = L.max_samples;
     a.pcut = L.pvalue_cutoff;
@@ -476,22 +526,28 @@ extern "C" int psk_chi2_scan(psk_ctx *ctx, const int8_t *pheno, const double *we
     if (n_kmers_global == 0) n_kmers_global = ctx->n_kmers ? ctx->n_kmers : 1;
     PSK_HIP(ctx, hipSetDevice(ctx->device));
     const int N = ctx->n_samples, wpr = ctx->wpr;
-    std::vector<uint64_t> m1(wpr, 0), m0(wpr, 0);
-    std::vector<double> w(2 * (size_t)wpr * 64, 0.0);
+    // one pinned staging block [m1 | m0 | w1 | w0] and ONE stream-ordered upload (weights only when given)
+    const size_t n_mask = 2 * (size_t)wpr, n_w = 2 * (size_t)wpr * 64;
+    const size_t stage_bytes = (n_mask + n_w) * 8;
+    if (stage_bytes > ctx->scan_pinned_cap) {
+        if (ctx->scan_pinned) (void)hipHostFree(ctx->scan_pinned);
+        ctx->scan_pinned = nullptr;
+        ctx->scan_pinned_cap = 0;
+        PSK_HIP(ctx, hipHostMalloc(&ctx->scan_pinned, stage_bytes, hipHostMallocDefault));
+        ctx->scan_pinned_cap = stage_bytes;
+    }
+    uint64_t *m1 = static_cast<uint64_t *>(ctx->scan_pinned), *m0 = m1 + wpr;
+    double *w = reinterpret_cast<double *>(m1 + n_mask);
+    memset(m1, 0, weights ? stage_bytes : n_mask * 8);
     double W1 = 0, W0 = 0;
     int n1 = 0, n0 = 0;
     for (int i = 0; i < N; i++) {
         const double wi = weights ? weights[i] : 1.0;
-        if (pheno[i] == 1) { m1[i >> 6] |= 1ull << (i & 63); w[i] = wi; W1 += wi; n1++; }
-        else if (pheno[i] == 0) { m0[i >> 6] |= 1ull << (i & 63); w[(size_t)wpr * 64 + i] = wi; W0 += wi; n0++; }
+        if (pheno[i] == 1) { m1[i >> 6] |= 1ull << (i & 63); if (weights) w[i] = wi; W1 += wi; n1++; }
+        else if (pheno[i] == 0) { m0[i >> 6] |= 1ull << (i & 63); if (weights) w[(size_t)wpr * 64 + i] = wi; W0 += wi; n0++; }
     }
-    PSK_TRY(dev_reserve(ctx, ctx->mask1, wpr * 8));
-    PSK_TRY(dev_reserve(ctx, ctx->mask0, wpr * 8));
-    PSK_TRY(dev_reserve(ctx, ctx->wts, w.size() * 8));
-    PSK_HIP(ctx, hipMemcpyAsync(ctx->mask1.p, m1.data(), wpr * 8, hipMemcpyHostToDevice, ctx->stream));
-    PSK_HIP(ctx, hipMemcpyAsync(ctx->mask0.p, m0.data(), wpr * 8, hipMemcpyHostToDevice, ctx->stream));
-    PSK_HIP(ctx, hipMemcpyAsync(ctx->wts.p, w.data(), w.size() * 8, hipMemcpyHostToDevice, ctx->stream));
-    PSK_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    PSK_TRY(dev_reserve(ctx, ctx->mask1, stage_bytes));
+    PSK_HIP(ctx, hipMemcpyAsync(ctx->mask1.p, m1, weights ? stage_bytes : n_mask * 8, hipMemcpyHostToDevice, ctx->stream));
 
     ctx->last.valid = true;
     ctx->last.weighted = weights != nullptr;
@@ -572,8 +628,8 @@ extern "C" int psk_ttest_scan(psk_ctx *ctx, const double *pheno, const uint8_t *
     a.pcut = pvalue_cutoff;
     a.pcut_bonf = pvalue_cutoff / (double)n_kmers_global;
     const int G = group_lanes(a.cpr);
-    const dim3 grid = scan_grid(ctx, a.M, G, 1);
-    PSK_TRY(setup_results(ctx, a, grid, G, 1));
+    const dim3 grid = scan_grid(ctx, a.M, G, SC_UNROLL);
+    PSK_TRY(setup_results(ctx, a, grid, G, SC_UNROLL));
     ctx->n_pass = 0;
     ctx->last_scan_kind = 2;
     ctx->last.valid = false;

@@ -43,3 +43,44 @@ __device__ __forceinline__ double psk_shfl_xor_f64(double v, int d)
     hi = __shfl_xor(hi, d, 64);
     return __hiloint2double(hi, lo);
 }
+
+// ---- LDS-free cross-lane helpers (DPP + v_readlane) ---------------------------------------------
+// ds_bpermute-based shuffles issue on the CU's single LDS pipe; a phase that is already LDS-heavy
+// (t-test phase B) is better served by data-parallel-primitive moves and scalar lane reads.
+__device__ __forceinline__ double psk_dpp_f64(double v, const int ctrl_tag)
+{
+    int lo = __double2loint(v), hi = __double2hiint(v);
+    switch (ctrl_tag) {  // constant-folded: the builtin needs an immediate control word
+    case 0: lo = __builtin_amdgcn_update_dpp(lo, lo, 0xB1, 0xF, 0xF, false); hi = __builtin_amdgcn_update_dpp(hi, hi, 0xB1, 0xF, 0xF, false); break;    // quad_perm [1,0,3,2]
+    case 1: lo = __builtin_amdgcn_update_dpp(lo, lo, 0x4E, 0xF, 0xF, false); hi = __builtin_amdgcn_update_dpp(hi, hi, 0x4E, 0xF, 0xF, false); break;    // quad_perm [2,3,0,1]
+    case 2: lo = __builtin_amdgcn_update_dpp(lo, lo, 0x141, 0xF, 0xF, false); hi = __builtin_amdgcn_update_dpp(hi, hi, 0x141, 0xF, 0xF, false); break;  // row_half_mirror
+    default: lo = __builtin_amdgcn_update_dpp(lo, lo, 0x140, 0xF, 0xF, false); hi = __builtin_amdgcn_update_dpp(hi, hi, 0x140, 0xF, 0xF, false); break; // row_mirror
+    }
+    return __hiloint2double(hi, lo);
+}
+
+__device__ __forceinline__ double psk_readlane_f64(double v, int lane_uniform)
+{
+    const int lo = __builtin_amdgcn_readlane(__double2loint(v), lane_uniform);
+    const int hi = __builtin_amdgcn_readlane(__double2hiint(v), lane_uniform);
+    return __hiloint2double(hi, lo);
+}
+
+// Sum over the 64 lanes, result uniform.  After the two quad steps every lane of a quad holds the quad
+// sum, so the mirrors act as xor-4 / xor-8 butterflies; the four 16-lane row sums are combined by
+// scalar lane reads.  Requires all 64 lanes active.
+__device__ __forceinline__ double psk_wave_sum_f64_dpp(double v)
+{
+    v += psk_dpp_f64(v, 0);
+    v += psk_dpp_f64(v, 1);
+    v += psk_dpp_f64(v, 2);
+    v += psk_dpp_f64(v, 3);
+    return (psk_readlane_f64(v, 0) + psk_readlane_f64(v, 16)) + (psk_readlane_f64(v, 32) + psk_readlane_f64(v, 48));
+}
+
+__device__ __forceinline__ uint64_t psk_readlane_u64(uint64_t v, int lane_uniform)
+{
+    const uint32_t lo = (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)v, lane_uniform);
+    const uint32_t hi = (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)(v >> 32), lane_uniform);
+    return ((uint64_t)hi << 32) | lo;
+}
