@@ -150,6 +150,16 @@ int psk_lasso_fit(psk_ctx *ctx, const float *X, const double *y, int n, int p, c
 int psk_count_dict(psk_ctx *ctx, const uint8_t *bytes, size_t len, int k, const uint64_t *dict_words,
                    uint64_t n_dict, uint32_t *counts_out);
 
+/* ---- f2: MinHash sketch for the population-structure weights ---------------------------------
+ * Replaces `mash sketch -r <addr> -o K-mer_lists/<name>` (Samples.get_mash_sketches,
+ * modeling.py:386-390; bundled binary bin/mash 2.2): the `sketch_size` smallest distinct
+ * MurmurHash3_x64_128(seed) hashes of the sample's canonical k-mers, ascending -- exactly the hash
+ * list `mash info -d` prints.  Mash's defaults are k = 21, sketch_size = 1000, seed = 42.
+ * hashes_out must hold sketch_size entries; *n_out receives how many were written.
+ */
+int psk_minhash_sketch(psk_ctx *ctx, const uint8_t *bytes, size_t len, int k, int sketch_size, uint32_t seed,
+                       uint64_t *hashes_out, uint64_t *n_out);
+
 /* ---- helpers shared with the host side ------------------------------------------------------ */
 /* Host-only: the cleaned sequence stream the tokeniser hands to the GPU (bases kept, window
  * breaks collapsed to '\n', everything else dropped).  Returns the length written (<= len), or

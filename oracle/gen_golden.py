@@ -15,6 +15,7 @@ What is captured (data only: inputs and the reference's outputs; no reference so
   model_kat.npz/json     sklearn liblinear L1 logistic regression and Lasso, converged
                          (tol 1e-10), plus StratifiedKFold/KFold splits and CV scores
   gmer_counter.json      /root/reference/bin/gmer_counter outputs for the prediction path
+  mash.json              /root/reference/bin/mash sketches (hash lists) and `mash dist` table (-w path)
 
 Usage:  python oracle/gen_golden.py   (takes ~1 min)
 """
@@ -406,9 +407,42 @@ def gen_gmer_counter():
     print("gmer_counter cases:", len(cases))
 
 
+def gen_mash():
+    """modeling.py:386-412: `mash sketch -r` per sample, `mash paste`, `mash dist` (bin/mash 2.2)."""
+    env_run = lambda cmd, cwd: subprocess.run(cmd, shell=True, cwd=cwd, env=ENV, capture_output=True, text=True)
+    gs = GenomeSet(6, 12000, seed=77, gene_len=400)
+    out = {"source": "mash 2.2 (reference bin/): `mash sketch -r`, `mash info -d`, `mash paste`, `mash dist`",
+           "k": 21, "sketch_size": 1000, "seed": 42, "samples": []}
+    with tempfile.TemporaryDirectory() as tmp:
+        names = []
+        for i in range(gs.n):
+            name, fa = gs.sample(i)
+            if i == 2:   # lower case + N runs
+                fa = fa.replace(b"ACGT", b"acgt", 50).replace(b"GATT", b"GNNT", 3)
+            if i == 5:   # fewer than sketch_size distinct k-mers
+                fa = b">short\n" + fa.split(b"\n", 1)[1][:700] + b"\n"
+            with open(os.path.join(tmp, name + ".fasta"), "wb") as f:
+                f.write(fa)
+            env_run("mash sketch -r %s.fasta -o %s" % (name, name), tmp)
+            info = json.loads(env_run("mash info -d %s.msh" % name, tmp).stdout)
+            out["samples"].append({"name": name, "fasta_gz_b64": b64(gzip.compress(fa, mtime=0)),
+                                   "hashes": info["sketches"][0]["hashes"]})
+            names.append(name)
+        env_run("mash paste reference " + " ".join(n + ".msh" for n in names), tmp)
+        out["dist_table"] = env_run("mash dist reference.msh reference.msh", tmp).stdout
+        env_run("mash sketch -k 17 -s 50 %s.fasta -o small" % names[0], tmp)
+        out["k17_s50_hashes"] = json.loads(env_run("mash info -d small.msh", tmp).stdout)["sketches"][0]["hashes"]
+        env_run("mash sketch -k 15 -s 40 %s.fasta -o k15" % names[0], tmp)
+        info = json.loads(env_run("mash info -d k15.msh", tmp).stdout)
+        out["k15_s40_hashes"], out["k15_bits"] = info["sketches"][0]["hashes"], info["hashBits"]
+    with open(os.path.join(GOLD, "mash.json"), "w") as f:
+        json.dump(out, f)
+    print("mash sketches:", [len(s["hashes"]) for s in out["samples"]])
+
+
 if __name__ == "__main__":
     os.makedirs(GOLD, exist_ok=True)
-    what = sys.argv[1:] or ["tok", "ds", "chi2", "welch", "model", "gmer"]
+    what = sys.argv[1:] or ["tok", "ds", "chi2", "welch", "model", "gmer", "mash"]
     if "tok" in what:
         gen_tokenizer_cases()
     if "ds" in what:
@@ -423,3 +457,5 @@ if __name__ == "__main__":
         gen_model_kat()
     if "gmer" in what:
         gen_gmer_counter()
+    if "mash" in what:
+        gen_mash()

@@ -332,6 +332,11 @@ int upload_clean(psk_ctx *ctx, const uint8_t *bytes, size_t len, uint64_t *clean
 
 }  // namespace
 
+int upload_clean_stream(psk_ctx *ctx, const uint8_t *bytes, size_t len, uint64_t *clean_len)
+{
+    return upload_clean(ctx, bytes, len, clean_len);
+}
+
 int launch_extract(psk_ctx *ctx, const uint8_t *clean, uint64_t len, int k, uint64_t lo, uint64_t hi, uint64_t *out,
                    uint32_t *n_out)
 {

@@ -1,0 +1,137 @@
+// f2: Mash-compatible MinHash sketch of one sample (replaces `mash sketch -r <addr>`,
+// Samples.get_mash_sketches, modeling.py:386-390; bundled binary bin/mash 2.2).
+// Mash 2.2 defaults, established by probing the binary and pinned by tests/golden/mash.json:
+// canonical k-mer = alphabetical minimum of the k-mer and its reverse complement, hashed as its
+// upper-case ASCII string with MurmurHash3_x64_128 (seed 42); the hash is the first 8 output bytes
+// (first 4 when 4^k <= 2^32); the sketch is the `sketch_size` smallest DISTINCT hashes, ascending.
+//
+//   extract_kernel (kmer_count.hip)  canonical 2-bit words of every window (same tokeniser as a1)
+//   kmer_hash_kernel                 word -> ASCII -> MurmurHash3 h1, in place
+//   dev_radix_sort_u64 + run heads   ascending distinct hashes; the first `sketch_size` go to the host
+#include "dev_utils.h"
+#include "psk_internal.h"
+
+namespace {
+
+__device__ __forceinline__ uint64_t rotl64(uint64_t x, int r) { return (x << r) | (x >> (64 - r)); }
+
+__device__ __forceinline__ uint64_t fmix64(uint64_t k)
+{
+    k ^= k >> 33; k *= 0xff51afd7ed558ccdull;
+    k ^= k >> 33; k *= 0xc4ceb9fe1a85ec53ull;
+    k ^= k >> 33;
+    return k;
+}
+
+// MurmurHash3_x64_128 (public-domain algorithm by Austin Appleby) of the k-byte ASCII spelling of a
+// 2-bit word; returns h1 (the first 8 bytes of the 128-bit digest).
+__device__ __forceinline__ uint64_t murmur3_kmer(uint64_t word, int k, uint64_t seed)
+{
+    const uint64_t c1 = 0x87c37b91114253d5ull, c2 = 0x4cf5ad432745937full;
+    // spell the k-mer: byte j = "ACGT"[code j], packed little-endian into four u64 lanes
+    uint64_t lane[4] = {0, 0, 0, 0};
+#pragma unroll
+    for (int j = 0; j < 32; j++) {
+        if (j < k) {
+            const uint32_t code = (uint32_t)(word >> (2 * (k - 1 - j))) & 3u;
+            const uint64_t ch = (0x54474341u >> (8 * code)) & 0xffu;  // 'A','C','G','T'
+            lane[j >> 3] |= ch << (8 * (j & 7));
+        }
+    }
+    uint64_t h1 = seed, h2 = seed;
+    const int nblocks = k / 16;
+    for (int b = 0; b < nblocks; b++) {
+        uint64_t k1 = lane[2 * b], k2 = lane[2 * b + 1];
+        k1 *= c1; k1 = rotl64(k1, 31); k1 *= c2; h1 ^= k1;
+        h1 = rotl64(h1, 27); h1 += h2; h1 = h1 * 5 + 0x52dce729ull;
+        k2 *= c2; k2 = rotl64(k2, 33); k2 *= c1; h2 ^= k2;
+        h2 = rotl64(h2, 31); h2 += h1; h2 = h2 * 5 + 0x38495ab5ull;
+    }
+    const int tail = k & 15;
+    if (tail > 8) {
+        uint64_t k2 = lane[2 * nblocks + 1];
+        k2 *= c2; k2 = rotl64(k2, 33); k2 *= c1; h2 ^= k2;
+    }
+    if (tail > 0) {
+        uint64_t k1 = lane[2 * nblocks];
+        k1 *= c1; k1 = rotl64(k1, 31); k1 *= c2; h1 ^= k1;
+    }
+    h1 ^= (uint64_t)k; h2 ^= (uint64_t)k;
+    h1 += h2; h2 += h1;
+    h1 = fmix64(h1); h2 = fmix64(h2);
+    h1 += h2;
+    return h1;
+}
+
+__global__ void kmer_hash_kernel(uint64_t *__restrict__ words, uint64_t n, int k, uint64_t seed, uint64_t mask)
+{
+    const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) words[i] = murmur3_kmer(words[i], k, seed) & mask;
+}
+
+__global__ void head_flags_kernel(const uint64_t *__restrict__ keys, uint64_t n, uint32_t *__restrict__ flags)
+{
+    const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) flags[i] = (i == 0 || keys[i] != keys[i - 1]) ? 1u : 0u;
+}
+
+// heads whose rank is below `limit` are written to out[rank]
+__global__ void take_first_heads_kernel(const uint64_t *__restrict__ keys, uint64_t n, const uint32_t *__restrict__ pos,
+                                        uint32_t limit, uint64_t *__restrict__ out)
+{
+    const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const bool head = (i == 0) || keys[i] != keys[i - 1];
+    if (head && pos[i] < limit) out[pos[i]] = keys[i];
+}
+
+}  // namespace
+
+int upload_clean_stream(psk_ctx *ctx, const uint8_t *bytes, size_t len, uint64_t *clean_len);  // kmer_count.hip
+
+extern "C" int psk_minhash_sketch(psk_ctx *ctx, const uint8_t *bytes, size_t len, int k, int sketch_size, uint32_t seed,
+                                  uint64_t *hashes_out, uint64_t *n_out)
+{
+    if (!ctx) return PSK_EINVAL;
+    if (k < 1 || k > 32) return psk_fail(ctx, PSK_EINVAL, "k must be 1..32");
+    if (sketch_size < 1) return psk_fail(ctx, PSK_EINVAL, "sketch_size must be >= 1");
+    if (!hashes_out || !n_out || (!bytes && len)) return psk_fail(ctx, PSK_EINVAL, "null buffer");
+    PSK_HIP(ctx, hipSetDevice(ctx->device));
+    uint64_t clean_len = 0;
+    PSK_TRY(upload_clean_stream(ctx, bytes, len, &clean_len));
+    *n_out = 0;
+    if (clean_len == 0) return PSK_OK;
+    if (clean_len >= (1ull << 32)) return psk_fail(ctx, PSK_ERANGE, "sample larger than 4 Gbases");
+    PSK_TRY(dev_reserve(ctx, ctx->keysA, clean_len * 8));
+    PSK_TRY(dev_reserve(ctx, ctx->keysB, clean_len * 8));
+    PSK_TRY(dev_reserve(ctx, ctx->misc, 64));
+    uint32_t *d_n = ctx->misc.as<uint32_t>() + 8;
+    PSK_HIP(ctx, hipMemsetAsync(d_n, 0, 8, ctx->stream));
+    PSK_TRY(launch_extract(ctx, ctx->raw.as<uint8_t>(), clean_len, k, 0, 0, ctx->keysA.as<uint64_t>(), d_n));
+    uint32_t n32 = 0;
+    PSK_HIP(ctx, hipMemcpyAsync(&n32, d_n, 4, hipMemcpyDeviceToHost, ctx->stream));
+    PSK_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    const uint64_t n = n32;
+    if (n == 0) return PSK_OK;
+    const bool wide = (k > 16);  // Mash keeps 64-bit hashes only when 4^k exceeds 2^32
+    kmer_hash_kernel<<<div_up(n, 256), 256, 0, ctx->stream>>>(ctx->keysA.as<uint64_t>(), n, k, (uint64_t)seed,
+                                                             wide ? ~0ull : 0xffffffffull);
+    PSK_HIP(ctx, hipGetLastError());
+    uint64_t *sorted = nullptr;
+    PSK_TRY(dev_radix_sort_u64(ctx, ctx->keysA.as<uint64_t>(), ctx->keysB.as<uint64_t>(), n, 0, wide ? 64 : 32, &sorted));
+    uint64_t *other = (sorted == ctx->keysA.as<uint64_t>()) ? ctx->keysB.as<uint64_t>() : ctx->keysA.as<uint64_t>();
+    PSK_TRY(dev_reserve(ctx, ctx->flags, n * 4));
+    uint32_t *flags = ctx->flags.as<uint32_t>();
+    head_flags_kernel<<<div_up(n, 256), 256, 0, ctx->stream>>>(sorted, n, flags);
+    PSK_HIP(ctx, hipGetLastError());
+    PSK_TRY(dev_exclusive_scan_u32(ctx, flags, flags, n, d_n + 1));
+    take_first_heads_kernel<<<div_up(n, 256), 256, 0, ctx->stream>>>(sorted, n, flags, (uint32_t)sketch_size, other);
+    PSK_HIP(ctx, hipGetLastError());
+    uint32_t nu = 0;
+    PSK_HIP(ctx, hipMemcpyAsync(&nu, d_n + 1, 4, hipMemcpyDeviceToHost, ctx->stream));
+    PSK_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    const uint64_t take = nu < (uint32_t)sketch_size ? nu : (uint32_t)sketch_size;
+    if (take) PSK_HIP(ctx, hipMemcpy(hashes_out, other, take * 8, hipMemcpyDeviceToHost));
+    *n_out = take;
+    return PSK_OK;
+}

@@ -187,6 +187,15 @@ class PskContext:
         return self._fit(self._lib.psk_lasso_fit, "psk_lasso_fit", X, y, np.float64, fold, fit_param, fit_fold, tol,
                          max_iter)
 
+    # -- population-structure weights --------------------------------------------------------------
+    def minhash_sketch(self, data, k=21, sketch_size=1000, seed=42):
+        data = bytes(data)
+        out = np.zeros(int(sketch_size), dtype=np.uint64)
+        n = ctypes.c_uint64()
+        self._check(self._lib.psk_minhash_sketch(self._h, data, len(data), int(k), int(sketch_size), int(seed),
+                                                 _ptr(out), ctypes.byref(n)), "psk_minhash_sketch")
+        return out[: n.value].copy()
+
     # -- prediction -------------------------------------------------------------------------------
     def count_dict(self, data, k, dict_words):
         data = bytes(data)

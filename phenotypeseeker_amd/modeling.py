@@ -57,6 +57,8 @@ class Samples:
     min_samples = None
     max_samples = None
     kmerDB = None
+    use_weights = False
+    tree = None
 
     def __init__(self, name, address, phenotypes, weight=1):
         self.name = name
@@ -79,8 +81,19 @@ class Samples:
         As with the bundled glistmaker 4.2.3, the cut-off does not change the list."""
         data = formats.read_sequence_file(self.address)
         self.n_unique, self.n_total = ctx.count_kmers(index, data)
+        if Samples.use_weights:  # was: mash sketch -r <address> -o K-mer_lists/<name>  (:386-390)
+            self.sketch = ctx.minhash_sketch(data).tolist()
         stderr_print.currentSampleNum += 1
         stderr_print.print_progress("lists generated.")
+
+    @classmethod
+    def get_weights(cls):
+        """was: mash paste / mash dist -> NJ tree -> GSC weights (:392-503)"""
+        from . import weights as _w
+        names = list(Input.samples.keys())
+        w, cls.tree = _w.weights_from_sketches(names, {n: Input.samples[n].sketch for n in names})
+        for name, value in w.items():
+            Input.samples[name].weight = value
 
     @classmethod
     def get_feature_vector(cls, ctx):
@@ -127,6 +140,8 @@ class Input:
         phenotypes.no_results = []
         phenotypes.model_package = {}
         stderr_print.currentSampleNum = 0
+        Samples.use_weights = False
+        Samples.tree = None
 
     @classmethod
     def get_input_data(cls, inputfilename, take_logs, mpheno):
@@ -505,9 +520,7 @@ def modeling(args):
         args.l1_ratio, args.n_splits_cv_outer, args.kernel, args.n_iter, args.n_splits_cv_inner, args.testset_size,
         args.train_on_whole, args.logreg_solver, args.jump_to, args.pca, args.real_counts, args.omit_B_correction,
         args.kmerDB)
-    if getattr(args, "weights", False):
-        raise SystemExit("-w/--weights (Mash-based GSC weights) is not implemented on the GPU engine yet; the "
-                         "weighted scans themselves are (pass weights through the Python API).")
+    Samples.use_weights = bool(getattr(args, "weights", False))
     group = _dist.Group().init()
     ctx = PskContext(group.local_rank)
     try:
@@ -522,6 +535,10 @@ def modeling(args):
             m_local = Samples.get_feature_vector(ctx)
             _err(GREEN % "Mapping samples to the feature vector space:" + "\n")
             stderr_print("\t%d of %d samples mapped." % (Samples.no_samples, Samples.no_samples))
+            if Samples.use_weights:
+                _err("\n" + GREEN % "Estimating the Mash distances between samples..." + "\n")
+                stderr_print(GREEN % "Calculating the GSC weights from mash distance matrix...")
+                Samples.get_weights()
             phenotypes.kmer_testing_setup(group.allreduce_sum(int(m_local)))
             for ph in Input.phenotypes_to_analyse.values():
                 ph.test_kmers_association_with_phenotype(ctx, group)

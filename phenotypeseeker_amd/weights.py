@@ -1,0 +1,176 @@
+"""`-w/--weights`: Gerstein-Sonnhammer-Chothia sample weights from Mash distances
+(Samples.get_weights and helpers, modeling.py:392-503).
+
+    sketches            psk_minhash_sketch on the GPU            (was `mash sketch -r`, :386-390)
+    mash_distance       Jaccard of two bottom-s sketches -> Mash distance, rounded to the 6
+                        significant digits `mash dist` prints and the reference re-parses (:411-421)
+    distance_matrix     the N x N table with the reference's row labelling (:415-428)
+    nj                  neighbour joining as Bio.Phylo.TreeConstruction.DistanceTreeConstructor.nj
+                        builds it, branch lengths then rounded like the newick writer ("%1.5f") the
+                        reference round-trips through (:447-458)
+    gsc_weights         clip to [1e-9, 1e9], BranchSum / NodeWeight recursion, mean-1 scaling (:461-503)
+
+Parity: sketches and distances are pinned against the bundled mash binary
+(tests/golden/mash.json).  Biopython 1.76 / ete3 3.1.1 are not installed in the build container,
+so the tree step is restated from their documented behaviour: PARITY UNPINNED for nj + newick
+rounding.
+"""
+import math
+
+
+def mash_distance(a, b, k, sketch_size):
+    """a, b: ascending distinct hash lists (bottom-s sketches).  Returns (distance, shared, denom)."""
+    i = j = common = denom = 0
+    na, nb = len(a), len(b)
+    while denom < sketch_size and i < na and j < nb:
+        if a[i] < b[j]:
+            i += 1
+        elif a[i] > b[j]:
+            j += 1
+        else:
+            i += 1
+            j += 1
+            common += 1
+        denom += 1
+    if denom < sketch_size:
+        if i < na:
+            denom += na - i
+        if j < nb:
+            denom += nb - j
+        if denom > sketch_size:
+            denom = sketch_size
+    if denom == 0:
+        return 1.0, 0, 0
+    jac = common / denom
+    if common == denom:
+        d = 0.0
+    elif common == 0:
+        d = 1.0
+    else:
+        d = -math.log(2.0 * jac / (1.0 + jac)) / k
+    return float("%g" % d), common, denom  # `mash dist` prints 6 significant digits
+
+
+def distance_matrix(names, sketches, k=21, sketch_size=1000):
+    """names: sample names in data.pheno order; sketches: dict name -> hashes.
+    `mash paste reference.msh K-mer_lists/*.msh` orders the sketches by FILE NAME (shell glob), while
+    the reference labels the rows of the resulting table in data.pheno order (:415-428): when the
+    pheno file is not sorted by sample name the labels are permuted.  Reproduced here."""
+    by_file = sorted(names)
+    n = len(names)
+    mat = [[0.0] * n for _ in range(n)]
+    for r in range(n):
+        for c in range(r + 1):
+            d = mash_distance(sketches[by_file[r]], sketches[by_file[c]], k, sketch_size)[0]
+            mat[r][c] = mat[c][r] = d
+    return list(names), mat
+
+
+class _Node:
+    __slots__ = ("name", "dist", "children", "up", "BranchSum", "NodeWeight")
+
+    def __init__(self, name, dist=0.0):
+        self.name, self.dist, self.children, self.up = name, dist, [], None
+
+    def add(self, child):
+        child.up = self
+        self.children.append(child)
+
+
+def nj(names, mat):
+    """Neighbour joining with Biopython's tie-breaking and rooting conventions (see module doc)."""
+    n = len(names)
+    dm = [[mat[i][j] for j in range(n)] for i in range(n)]
+    clades = [_Node(nm) for nm in names]
+    if n == 1:
+        return clades[0]
+    if n == 2:
+        root = _Node("Inner")
+        clades[1].dist = dm[1][0] / 2.0
+        clades[0].dist = dm[1][0] - clades[1].dist
+        root.add(clades[1])
+        root.add(clades[0])
+        return root
+    inner = None
+    count = 0
+    while len(dm) > 2:
+        m = len(dm)
+        node_dist = [sum(dm[i]) / (m - 2) for i in range(m)]
+        min_dist = dm[1][0] - node_dist[1] - node_dist[0]
+        mi, mj = 0, 1
+        for i in range(1, m):
+            for j in range(i):
+                t = dm[i][j] - node_dist[i] - node_dist[j]
+                if min_dist > t:
+                    min_dist, mi, mj = t, i, j
+        c1, c2 = clades[mi], clades[mj]
+        count += 1
+        inner = _Node("Inner%d" % count)
+        inner.add(c1)
+        inner.add(c2)
+        c1.dist = (dm[mi][mj] + node_dist[mi] - node_dist[mj]) / 2.0
+        c2.dist = dm[mi][mj] - c1.dist
+        clades[mj] = inner
+        del clades[mi]
+        for kk in range(m):
+            if kk != mi and kk != mj:
+                v = (dm[mi][kk] + dm[mj][kk] - dm[mi][mj]) / 2.0
+                dm[mj][kk] = dm[kk][mj] = v
+        del dm[mi]
+        for row in dm:
+            del row[mi]
+    if clades[0] is inner:
+        clades[0].dist = 0.0
+        clades[1].dist = dm[1][0]
+        clades[0].add(clades[1])
+        root = clades[0]
+    else:
+        clades[0].dist = dm[1][0]
+        clades[1].dist = 0.0
+        clades[1].add(clades[0])
+        root = clades[1]
+    return root
+
+
+def _walk(node, order="pre"):
+    if order == "pre":
+        yield node
+    for c in node.children:
+        yield from _walk(c, order)
+    if order == "post":
+        yield node
+
+
+def newick_round_trip(root):
+    """Branch lengths as they come back from the phyloxml -> newick ("%1.5f") -> ete3 round trip."""
+    for nd in _walk(root):
+        nd.dist = float("%1.5f" % (nd.dist if nd.dist is not None else 0.0))
+    return root
+
+
+def to_newick(root):
+    def rec(nd):
+        inner = "(" + ",".join(rec(c) for c in nd.children) + ")" if nd.children else ""
+        return "%s%s:%1.5f" % (inner, nd.name, nd.dist)
+    return rec(root) + ";"
+
+
+def gsc_weights(root, min_val=1e-9, max_val=1e9):
+    """Leaf name -> GSC weight scaled to mean 1 (normalize='mean1', :461-503)."""
+    for nd in _walk(root):
+        nd.dist = min(max(nd.dist, min_val), max_val)
+    for nd in _walk(root, "post"):
+        nd.BranchSum = sum(c.BranchSum + c.dist for c in nd.children)
+    for nd in _walk(root):
+        if nd.up is None:
+            nd.NodeWeight = 1.0
+        else:
+            nd.NodeWeight = nd.up.NodeWeight * (nd.dist + nd.BranchSum) / nd.up.BranchSum
+    leaves = [nd for nd in _walk(root) if not nd.children]
+    return {nd.name: nd.NodeWeight * len(leaves) for nd in leaves}
+
+
+def weights_from_sketches(names, sketches, k=21, sketch_size=1000):
+    labels, mat = distance_matrix(names, sketches, k, sketch_size)
+    tree = newick_round_trip(nj(labels, mat))
+    return gsc_weights(tree), tree

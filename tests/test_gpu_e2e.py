@@ -128,3 +128,44 @@ def test_continuous_phenotype_end_to_end(tmp_path, oracle):
     pkg = joblib.load("linreg_model_MIC.pkl")
     assert pkg["pred_scale"] == "continuous"
     assert "Parameters:\nLasso()" in open("summary_of_linreg_analysis_MIC.txt").read()
+
+
+def test_weighted_modeling_end_to_end(tmp_path, oracle):
+    """-w: GPU MinHash sketches -> Mash distances -> NJ -> GSC weights -> weighted chi2 scan.
+    The weights the CLI used must equal the ones derived from the oracle's sketches, and the written
+    rows must equal the oracle's weighted scan with those weights."""
+    from oracle import oracle_weights as OW
+    from phenotypeseeker_amd import modeling as M, weights as W
+    ds = load_dataset("ds_omitB")
+    _write_dataset(ds, str(tmp_path))
+    _run(tmp_path, ["modeling", "data.pheno", "-w", "--omit_B_correction", "--n_kmers", "100"])
+    names, n, k = ds["names"], len(ds["names"]), ds["meta"]["k"]
+    got_w = [M.Input.samples[nm].weight for nm in names]
+    # sample 5 is FASTQ in this dataset: the oracle sketch works on FASTA text, so sketch the reads' sequences
+    sk = {}
+    for nm in names:
+        data = ds["files"][nm]
+        if data[:1] == b"@":
+            lines = data.decode().split("\n")
+            data = "".join(">r\n%s\n" % lines[i + 1] for i in range(0, len(lines) - 1, 4)).encode()
+        sk[nm] = OW.sketch(data)
+    want_w, _ = W.weights_from_sketches(names, sk)
+    assert np.allclose(got_w, [want_w[nm] for nm in names], rtol=1e-12)
+    assert sum(got_w) == pytest.approx(n) and max(got_w) > 1.0 > min(got_w)
+    wl = [oracle.count_kmers(ds["files"][nm], k)[0] for nm in names]
+    uw = oracle.union(wl)
+    bits = oracle.presence_bits(wl, uw)
+    ref = oracle.chi2_scan(bits, ds["pheno"], np.array(got_w), n, 2, n - 2, 0.05, True, len(uw))
+    keep = np.nonzero(ref["keep"])[0]
+    want = {oracle.word_to_kmer(uw[r], k): (oracle.round2(ref["stat"][r]), oracle.pstring(ref["p"][r])) for r in keep}
+    head, got = read_results_tsv("chi2_results_Pheno.tsv")
+    assert abs(len(got) - len(want)) <= 2
+    n_same = 0
+    for g in got:
+        if g[0] in want:
+            assert abs(float(g[1]) - want[g[0]][0]) <= 0.011 and g[2][-4:] == want[g[0]][1][-4:]
+            n_same += 1
+    assert n_same >= len(want) - 2
+    with open("Pheno_MLdf.csv") as f:
+        rows = list(csv.reader(f))
+    assert np.allclose([float(r[-2]) for r in rows[1:]], [w for w, p in zip(got_w, ds["pheno"]) if p != "NA"])

@@ -1,0 +1,110 @@
+"""-w path: MinHash sketches and Mash distances against the bundled mash binary's output
+(tests/golden/mash.json); neighbour joining + GSC weights on properties (their third-party
+implementations, Biopython / ete3, are absent: parity unpinned)."""
+import base64
+import gzip
+import json
+import os
+
+import numpy as np
+import pytest
+
+from helpers import GOLDEN
+
+
+@pytest.fixture(scope="module")
+def mash():
+    with open(os.path.join(GOLDEN, "mash.json")) as f:
+        d = json.load(f)
+    for s in d["samples"]:
+        s["fasta"] = gzip.decompress(base64.b64decode(s["fasta_gz_b64"]))
+    return d
+
+
+def test_oracle_sketch_equals_mash(mash):
+    from oracle import oracle_weights as OW
+    for s in mash["samples"]:
+        assert OW.sketch(s["fasta"]) == s["hashes"], s["name"]
+    assert OW.sketch(mash["samples"][0]["fasta"], k=17, sketch_size=50) == mash["k17_s50_hashes"]
+    assert mash["k15_bits"] == 32
+    assert OW.sketch(mash["samples"][0]["fasta"], k=15, sketch_size=40) == mash["k15_s40_hashes"]
+
+
+def test_mash_distance_matches_mash_dist(mash):
+    from phenotypeseeker_amd import weights as W
+    sk = {s["name"] + ".fasta": s["hashes"] for s in mash["samples"]}
+    n = 0
+    for line in mash["dist_table"].strip().splitlines():
+        ref, qry, dist, _, shared = line.split("\t")
+        d, common, denom = W.mash_distance(sk[ref], sk[qry], 21, 1000)
+        assert "%d/%d" % (common, denom) == shared
+        assert d == float(dist), (ref, qry)
+        n += 1
+    assert n == 36
+
+
+def test_distance_matrix_reproduces_the_glob_order_labelling():
+    from phenotypeseeker_amd import weights as W
+    sk = {"b": [1, 2, 3, 4], "a": [1, 2, 3, 9], "c": [5, 6, 7, 8]}
+    labels, mat = W.distance_matrix(["b", "a", "c"], sk, k=21, sketch_size=4)
+    assert labels == ["b", "a", "c"]           # labels in data.pheno order ...
+    d_ab = W.mash_distance(sk["a"], sk["b"], 21, 4)[0]
+    assert mat[0][1] == d_ab and mat[0][2] == 1.0 and mat[1][2] == 1.0   # ... rows in file-name order a, b, c
+
+
+def _tree_leaves(root):
+    from phenotypeseeker_amd.weights import _walk
+    return [n for n in _walk(root) if not n.children]
+
+
+def test_nj_recovers_additive_tree_and_gsc_properties():
+    from phenotypeseeker_amd import weights as W
+    # additive distances of the tree ((A:1,B:2):1.5,(C:1,D:3):0.5)
+    names = ["A", "B", "C", "D"]
+    D = [[0, 3, 4, 6], [3, 0, 5, 7], [4, 5, 0, 4], [6, 7, 4, 0]]
+    root = W.nj(names, [[float(x) for x in r] for r in D])
+    leaves = {n.name: n for n in _tree_leaves(root)}
+    assert set(leaves) == set(names)
+
+    def path(a, b):
+        def up(n):
+            out = []
+            while n is not None:
+                out.append(n)
+                n = n.up
+            return out
+        pa, pb = up(leaves[a]), up(leaves[b])
+        common = next(x for x in pa if x in pb)
+        return sum(x.dist for x in pa[:pa.index(common)]) + sum(x.dist for x in pb[:pb.index(common)])
+    for i, a in enumerate(names):
+        for j, b in enumerate(names):
+            if i < j:
+                assert path(a, b) == pytest.approx(D[i][j])
+    w = W.gsc_weights(W.newick_round_trip(root))
+    assert sum(w.values()) == pytest.approx(4.0)                  # mean 1
+    assert w["D"] > w["C"] and w["B"] > w["A"]                    # longer private branch, larger weight
+    assert W.to_newick(root).endswith(";") and W.to_newick(root).count("(") >= 2
+
+
+def test_gsc_identical_samples_share_weight_and_negative_branches_clip():
+    from phenotypeseeker_amd import weights as W
+    names = ["s1", "s2", "s3", "s4", "s5"]
+    sk = {"s1": list(range(0, 1000)), "s2": list(range(0, 1000)), "s3": list(range(100, 1100)),
+          "s4": list(range(500, 1500)), "s5": list(range(5000, 6000))}
+    w, tree = W.weights_from_sketches(names, sk)
+    assert sum(w.values()) == pytest.approx(5.0)
+    assert w["s1"] == pytest.approx(w["s2"], rel=1e-6) and w["s5"] > w["s1"]
+    from phenotypeseeker_amd.weights import _walk
+    assert all(n.dist >= 1e-9 for n in _walk(tree))
+
+
+@pytest.mark.gpu
+def test_gpu_sketch_equals_mash(mash):
+    from phenotypeseeker_amd.engine import PskContext
+    with PskContext(0) as ctx:
+        for s in mash["samples"]:
+            got = ctx.minhash_sketch(s["fasta"])
+            assert got.tolist() == s["hashes"], s["name"]
+        assert ctx.minhash_sketch(mash["samples"][0]["fasta"], k=17, sketch_size=50).tolist() == mash["k17_s50_hashes"]
+        assert ctx.minhash_sketch(mash["samples"][0]["fasta"], k=15, sketch_size=40).tolist() == mash["k15_s40_hashes"]
+        assert len(ctx.minhash_sketch(b">e\nACGT\n")) == 0
