@@ -65,6 +65,10 @@ def main():
     ap.add_argument("--rows", type=int, default=1 << 25)
     ap.add_argument("--cpu-sample-rows", type=int, default=40_000_000)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--backend", default=None, choices=[None, "nccl", "gloo"],
+                    help="torch.distributed backend for N > 1 (default: nccl = RCCL when GPUs are visible). "
+                         "gloo + --share-gpu lets two ranks exercise the N > 1 path on a one-GPU box.")
+    ap.add_argument("--share-gpu", action="store_true", help="map ranks onto the visible GPUs modulo their count")
     args = ap.parse_args()
 
     from phenotypeseeker_amd import dist as psk_dist
@@ -75,11 +79,15 @@ def main():
     if grp.world != args.gpus:
         if grp.world == 1 and args.gpus > 1:
             sys.exit("bench.py --gpus %d must be launched with torch.distributed.run (one rank per GPU)" % args.gpus)
-    grp.init()
+    grp.init(args.backend)
     rank, world = grp.rank, grp.world
     n, k = args.samples, args.kmer
 
-    ctx = PskContext(grp.local_rank)
+    device = grp.local_rank
+    if args.share_gpu:
+        import torch
+        device = grp.local_rank % max(torch.cuda.device_count(), 1)
+    ctx = PskContext(device)
     info = ctx.device_info()
     t_setup = time.time()
     pheno = np.array([1 if i % 2 == 0 else 0 for i in range(n)], dtype=np.int8)
@@ -113,25 +121,42 @@ def main():
 
     M_global = grp.allreduce_sum(int(M))
 
+    # The sharded path: the union size is all-reduced ONCE (Bonferroni denominator, above); every scan
+    # is followed by one all-gather of its survivors.  The gather is device-to-device (RCCL) and
+    # double-buffered, so the collective of scan i runs while scan i+1 streams the matrix -- as it
+    # does in a run with several phenotypes.  N = 1 has no exchange.
+    xch = psk_dist.SurvivorExchange(grp, wpr) if world > 1 else None
+    pending = []
+    gathered = [0]
+
+    def drain(limit):
+        while len(pending) > limit:
+            out = xch.finish(pending.pop(0))
+            if out is None:
+                raise RuntimeError("survivor buffer overflow in bench")
+            gathered[0] = len(out[0]["word"])
+
     def step():
         npass = ctx.chi2_scan(pheno, None, 2, n - 2, 0.05, False, M_global)
         ms = ctx.last_scan_ms()
-        if world > 1:
-            # the sharded path's exchange: global union size, then the survivors of every slab
-            grp.allreduce_sum(int(M))
-            res = ctx.get_results(npass)
-            bits = ctx.get_rows(res["row"])
-            psk_dist.merge_candidates(grp.allgather_bytes(psk_dist.pack_candidates(res, bits)))
+        if xch is not None:
+            s_, _ = xch.start(ctx)
+            pending.append(s_)
+            drain(1)
         return npass, ms
 
     for _ in range(args.warmup):
         npass, _ = step()
+    if xch is not None:
+        drain(0)
     grp.barrier()
     kernel_ms = []
     t0 = time.perf_counter()
     for _ in range(args.steps):
         npass, ms = step()
         kernel_ms.append(ms)
+    if xch is not None:
+        drain(0)   # the last exchange completes inside the timed region
     grp.barrier()
     elapsed = time.perf_counter() - t0
     elapsed = grp.allreduce_max(elapsed)
@@ -151,7 +176,8 @@ def main():
         "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "u64 popcount + f64",
         "data": "synthetic",
         "config": {"workload": workload, "n_samples": n, "k": k, "rows_per_gpu": int(M),
-                   "words_per_row_stored": wpr, "survivors": int(npass), "device": info["name"],
+                   "words_per_row_stored": wpr, "survivors": int(npass), "survivors_all_slabs": int(gathered[0]) if world > 1
+                   else int(npass), "device": info["name"],
                    "setup_s": round(t_setup, 2), "ingest": ingest},
         "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                      "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "kernel": "chi2_scan_kernel",

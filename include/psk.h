@@ -117,6 +117,12 @@ int psk_ttest_scan(psk_ctx *ctx, const double *pheno, const uint8_t *valid, cons
  * NULL.  stat = chi2 or t; mean_x / mean_y are filled by the t-test only. */
 int psk_get_results(psk_ctx *ctx, uint64_t *row_idx, uint64_t *words, double *stat, double *p, double *mean_x,
                     double *mean_y, int32_t *n_with, uint64_t cap);
+/* Multi-GPU hand-off: writes the survivors of the last scan, unsorted, as records of (6 + words_per_row)
+ * u64 { word, stat, p, mean_x, mean_y (f64 bit patterns), n_with (i64), bits[words_per_row] } into a
+ * caller-provided DEVICE buffer of 1 + cap_records records; record 0 is a header whose first u64 is the
+ * record count.  The buffer can be handed to an RCCL all-gather as is (phenotypeseeker_amd/dist.py).
+ * n_records returns the count; records beyond cap_records are dropped (caller retries with a larger cap). */
+int psk_export_survivors(psk_ctx *ctx, void *device_dst, uint64_t cap_records, uint64_t *n_records);
 /* HIP-event duration of the last scan kernel launch in milliseconds (for bench.py). */
 double psk_last_scan_ms(const psk_ctx *ctx);
 /* Re-launches the last chi2 scan `reps` times back to back on the context's stream and

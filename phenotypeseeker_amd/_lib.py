@@ -35,6 +35,7 @@ _SIGNATURES = {
     "psk_ttest_scan": (c.c_int, [c.c_void_p, c.c_void_p, c.c_void_p, c.c_void_p, c.c_int, c.c_int, c.c_double,
                                  c.c_uint64, _u64p]),
     "psk_get_results": (c.c_int, [c.c_void_p] + [c.c_void_p] * 7 + [c.c_uint64]),
+    "psk_export_survivors": (c.c_int, [c.c_void_p, c.c_void_p, c.c_uint64, _u64p]),
     "psk_last_scan_ms": (c.c_double, [c.c_void_p]),
     "psk_rescan_timed": (c.c_int, [c.c_void_p, c.c_int, c.POINTER(c.c_double)]),
     "psk_logreg_l1_fit": (c.c_int, [c.c_void_p, c.c_void_p, c.c_void_p, c.c_int, c.c_int, c.c_void_p, c.c_void_p,
@@ -54,6 +55,17 @@ def load():
     global _lib
     if _lib is not None:
         return _lib
+    # PyTorch's ROCm wheel bundles its own HIP/HSA runtime under the same soname (libamdhip64.so.7) as
+    # the system one libpsk.so links to; two HSA runtimes in one process cannot both open the GPU.
+    # Whichever is loaded first serves both, and only "torch first" works -- so multi-rank runs (which
+    # use torch.distributed for the collectives) import torch before libpsk.so is opened.
+    if int(os.environ.get("WORLD_SIZE", "1")) > 1 or os.environ.get("PSK_WITH_TORCH") == "1":
+        import sys
+        if "torch" not in sys.modules:
+            try:
+                import torch  # noqa: F401
+            except ImportError:
+                pass
     if not os.path.exists(LIB_PATH):
         raise PskError("libpsk.so is missing (%s): build it with `python -c 'import __graft_entry__ as g; "
                        "g.build()'` or `make -C phenotypeseeker_amd/csrc`; there is no CPU fallback" % LIB_PATH)

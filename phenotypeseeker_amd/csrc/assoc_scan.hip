@@ -714,4 +714,61 @@ extern "C" int psk_get_results(psk_ctx *ctx, uint64_t *row_idx, uint64_t *words,
     return PSK_OK;
 }
 
+// one block per result segment: writes the segment's survivors as AoS records into a caller buffer
+__global__ void export_records_kernel(const uint8_t *__restrict__ res, uint64_t cap, uint32_t seg_cap,
+                                      const uint32_t *__restrict__ counts, const uint64_t *__restrict__ offsets,
+                                      const uint64_t *__restrict__ union_words, const uint64_t *__restrict__ bits, int wpr,
+                                      uint64_t *__restrict__ dst, uint64_t cap_records, uint64_t total)
+{
+    const uint32_t seg = blockIdx.x;
+    const uint32_t c = counts[seg];
+    const uint64_t in0 = (uint64_t)seg * seg_cap, out0 = offsets[seg];
+    const uint64_t rec_words = 6 + (uint64_t)wpr;
+    const uint64_t *row = reinterpret_cast<const uint64_t *>(res);
+    const uint64_t *f64s = reinterpret_cast<const uint64_t *>(res);  // stat/p/mx/my copied as raw 64-bit patterns
+    const int32_t *nw = reinterpret_cast<const int32_t *>(res + 40 * cap);
+    if (seg == 0 && threadIdx.x == 0) {  // header record: number of records that follow
+        dst[0] = total;
+        for (uint64_t j = 1; j < rec_words; j++) dst[j] = 0;
+    }
+    for (uint32_t i = threadIdx.x; i < c; i += blockDim.x) {
+        const uint64_t o = out0 + i;
+        if (o >= cap_records) continue;
+        uint64_t *rec = dst + (o + 1) * rec_words;
+        const uint64_t r = row[in0 + i];
+        rec[0] = union_words[r];
+        rec[1] = f64s[1 * cap + in0 + i];
+        rec[2] = f64s[2 * cap + in0 + i];
+        rec[3] = f64s[3 * cap + in0 + i];
+        rec[4] = f64s[4 * cap + in0 + i];
+        rec[5] = (uint64_t)(int64_t)nw[in0 + i];
+        for (int w = 0; w < wpr; w++) rec[6 + w] = bits[r * (uint64_t)wpr + w];
+    }
+}
+
+extern "C" int psk_export_survivors(psk_ctx *ctx, void *device_dst, uint64_t cap_records, uint64_t *n_records)
+{
+    if (!ctx) return PSK_EINVAL;
+    if (!ctx->last_scan_kind) return psk_fail(ctx, PSK_ESTATE, "no scan has been run");
+    if (!device_dst || cap_records < 1) return psk_fail(ctx, PSK_EINVAL, "bad destination");
+    PSK_HIP(ctx, hipSetDevice(ctx->device));
+    const uint64_t n = ctx->n_pass;
+    if (n_records) *n_records = n;
+    std::vector<uint64_t> offs(SC_NSEG);
+    uint64_t acc = 0;
+    for (int sgm = 0; sgm < SC_NSEG; sgm++) { offs[sgm] = acc; acc += ctx->seg_counts[sgm]; }
+    PSK_TRY(dev_reserve(ctx, ctx->res_sorted, SC_NSEG * 12 + 64));
+    uint8_t *aux = ctx->res_sorted.as<uint8_t>();
+    uint32_t *d_cnt = reinterpret_cast<uint32_t *>(aux + SC_NSEG * 8);
+    PSK_HIP(ctx, hipMemcpyAsync(aux, offs.data(), SC_NSEG * 8, hipMemcpyHostToDevice, ctx->stream));
+    PSK_HIP(ctx, hipMemcpyAsync(d_cnt, ctx->seg_counts.data(), SC_NSEG * 4, hipMemcpyHostToDevice, ctx->stream));
+    export_records_kernel<<<SC_NSEG, 256, 0, ctx->stream>>>(
+        ctx->res.as<uint8_t>(), ctx->res_seg_cap * SC_NSEG, (uint32_t)ctx->res_seg_cap, d_cnt,
+        reinterpret_cast<const uint64_t *>(aux), ctx->union_words.as<uint64_t>(), ctx->bits.as<uint64_t>(), ctx->wpr,
+        static_cast<uint64_t *>(device_dst), cap_records, n);
+    PSK_HIP(ctx, hipGetLastError());
+    PSK_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    return PSK_OK;
+}
+
 extern "C" double psk_last_scan_ms(const psk_ctx *ctx) { return ctx ? ctx->last_scan_ms : 0.0; }

@@ -38,8 +38,8 @@ class Group:
         self._dist = None
         self._dev = None
 
-    def init(self, backend=None):
-        if self.world == 1:
+    def init(self, backend=None, force=False):
+        if self.world == 1 and not force:
             return self
         import torch
         import torch.distributed as dist
@@ -55,6 +55,7 @@ class Group:
         if not dist.is_initialized():
             dist.init_process_group(backend=backend, rank=self.rank, world_size=self.world)
         self._dist = dist
+        self.backend = backend
         return self
 
     def barrier(self):
@@ -141,3 +142,74 @@ def merge_candidates(payloads):
     bits = np.concatenate([p[1] if p[1].shape[1] == wpr else np.zeros((0, wpr), np.uint64) for p in parts]) \
         if parts else np.zeros((0, wpr), np.uint64)
     return res, bits
+
+
+class SurvivorExchange:
+    """All-gather(v) of the scan survivors without leaving the GPU (RCCL over xGMI): every rank packs
+    its survivors into a fixed-capacity device buffer (psk_export_survivors), one
+    all_gather_into_tensor moves all slabs, and the copy is double-buffered so that the collective of
+    scan i overlaps scan i+1 (several phenotypes are scanned back to back).  With the gloo backend
+    (CPU tests, one-GPU dry runs) the packed buffer is staged through host tensors instead."""
+
+    def __init__(self, group, words_per_row, cap_records=4096):
+        import torch
+        self.g = group
+        self.wpr = int(words_per_row)
+        self.rec_words = 6 + self.wpr
+        self.torch = torch
+        self.slot = 0
+        self.work = [None, None]
+        self._alloc(int(cap_records))
+
+    def _alloc(self, cap):
+        torch = self.torch
+        self.cap = cap
+        n = (cap + 1) * self.rec_words
+        dev = torch.device("cuda", torch.cuda.current_device()) if torch.cuda.is_available() else torch.device("cpu")
+        self.dev = dev
+        self.send = [torch.zeros(n, dtype=torch.int64, device=dev) for _ in range(2)]
+        nccl = getattr(self.g, "backend", None) == "nccl"
+        rdev = dev if nccl else torch.device("cpu")
+        self.recv = [torch.zeros(self.g.world * n, dtype=torch.int64, device=rdev) for _ in range(2)]
+        self.nccl = nccl
+
+    def start(self, ctx):
+        """Call right after a scan: packs this rank's survivors and launches the collective."""
+        s = self.slot
+        self.slot ^= 1
+        n_local = ctx.export_survivors(self.send[s].data_ptr(), self.cap)
+        dist = self.g._dist
+        if self.nccl:
+            self.work[s] = dist.all_gather_into_tensor(self.recv[s], self.send[s], async_op=True)
+        else:
+            parts = list(self.recv[s].chunk(self.g.world))
+            self.work[s] = dist.all_gather(parts, self.send[s].cpu(), async_op=True)
+        return s, n_local
+
+    def finish(self, s):
+        """Waits for slot s; returns (res dict, bits) of ALL slabs, ascending by word.  Returns None
+        when some rank had more survivors than the buffers hold (caller grows and repeats the scan's
+        exchange)."""
+        self.work[s].wait()
+        host = self.recv[s].cpu().numpy().view(np.uint64).reshape(self.g.world, self.cap + 1, self.rec_words)
+        counts = host[:, 0, 0].astype(np.int64)
+        if (counts > self.cap).any():
+            return None
+        recs = np.concatenate([host[r, 1:1 + counts[r]] for r in range(self.g.world)]) if counts.sum() else \
+            np.zeros((0, self.rec_words), dtype=np.uint64)
+        order = np.argsort(recs[:, 0], kind="stable")
+        recs = recs[order]
+        res = {"word": recs[:, 0].copy(), "stat": recs[:, 1].copy().view(np.float64), "p": recs[:, 2].copy().view(np.float64),
+               "mean_x": recs[:, 3].copy().view(np.float64), "mean_y": recs[:, 4].copy().view(np.float64),
+               "n_with": recs[:, 5].copy().view(np.int64).astype(np.int32)}
+        return res, np.ascontiguousarray(recs[:, 6:])
+
+    def gather(self, ctx):
+        """Synchronous form used by the pipeline: exchange the survivors of the last scan, growing the
+        buffers if any slab overflowed."""
+        while True:
+            s, _ = self.start(ctx)
+            out = self.finish(s)
+            if out is not None:
+                return out
+            self._alloc(self.cap * 4)

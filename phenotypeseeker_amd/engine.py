@@ -155,6 +155,13 @@ class PskContext:
                                               _ptr(out["n_with"]), n), "psk_get_results")
         return out
 
+    def export_survivors(self, device_ptr, cap_records):
+        """Packs the last scan's survivors into a caller DEVICE buffer (see psk_export_survivors)."""
+        n = ctypes.c_uint64()
+        self._check(self._lib.psk_export_survivors(self._h, ctypes.c_void_p(int(device_ptr)), int(cap_records),
+                                                   ctypes.byref(n)), "psk_export_survivors")
+        return n.value
+
     def last_scan_ms(self):
         return self._lib.psk_last_scan_ms(self._h)
 

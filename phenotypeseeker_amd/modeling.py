@@ -139,6 +139,7 @@ class Input:
         phenotypes.pred_scale = "binary"
         phenotypes.no_results = []
         phenotypes.model_package = {}
+        phenotypes._exchange = None
         stderr_print.currentSampleNum = 0
         Samples.use_weights = False
         Samples.tree = None
@@ -267,6 +268,7 @@ class phenotypes:
     pca = None
     no_results = []
     model_package = {}
+    _exchange = None
 
     def __init__(self, name):
         self.name = name
@@ -312,18 +314,30 @@ class phenotypes:
         else:
             npass = ctx.ttest_scan(a, b, w, Samples.min_samples, Samples.max_samples, self.pvalue_cutoff,
                                    self.no_kmers_to_analyse)
-        res = ctx.get_results(npass)
-        bits = ctx.get_rows(res["row"])
         counts = None
-        if self.real_counts and npass:
-            counts = np.stack([ctx.lookup_counts(i, res["word"]) for i in range(n)], axis=1)
         if group.world > 1:
-            payloads = group.allgather_bytes(_dist.pack_candidates(res, bits))
-            res, bits = _dist.merge_candidates(payloads)
+            # survivors of every slab, gathered GPU-to-GPU and merged in ascending word order
+            if phenotypes._exchange is None:
+                phenotypes._exchange = _dist.SurvivorExchange(group, ctx.presence_shape()[1])
+            local = ctx.get_results(npass) if self.real_counts else None
+            res, bits = phenotypes._exchange.gather(ctx)
             if self.real_counts:
-                cp = group.allgather_bytes(np.ascontiguousarray(counts if counts is not None else
-                                                                np.zeros((0, n), np.uint32)).tobytes())
-                counts = np.concatenate([np.frombuffer(c, dtype=np.uint32).reshape(-1, n) for c in cp])
+                mine = np.stack([ctx.lookup_counts(i, local["word"]) for i in range(n)], axis=1) if npass else \
+                    np.zeros((0, n), np.uint32)
+                cp = group.allgather_bytes(np.ascontiguousarray(local["word"]).tobytes() +
+                                           np.ascontiguousarray(mine, dtype=np.uint32).tobytes())
+                cw, cc = [], []
+                for blob in cp:
+                    m = len(blob) // (8 + 4 * n)
+                    cw.append(np.frombuffer(blob, dtype=np.uint64, count=m))
+                    cc.append(np.frombuffer(blob, dtype=np.uint32, offset=8 * m).reshape(m, n))
+                cw, cc = np.concatenate(cw), np.concatenate(cc)
+                counts = cc[np.argsort(cw, kind="stable")]
+        else:
+            res = ctx.get_results(npass)
+            bits = ctx.get_rows(res["row"])
+            if self.real_counts and npass:
+                counts = np.stack([ctx.lookup_counts(i, res["word"]) for i in range(n)], axis=1)
         k = int(Samples.kmer_length)
         presence = ((bits[:, np.arange(n) >> 6] >> (np.arange(n, dtype=np.uint64) & np.uint64(63))) & np.uint64(1)) \
             .astype(np.uint8) if len(bits) else np.zeros((0, n), np.uint8)

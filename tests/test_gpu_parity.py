@@ -335,3 +335,16 @@ def test_grid_search_matches_sklearn_cv(ctx):
     import pickle
     g2 = pickle.loads(pickle.dumps(gs))
     assert np.array_equal(g2.predict(X), gs.predict(X)) and g2.predict_proba(X).shape == (len(y), 2)
+
+
+def test_device_survivor_exchange_matches_get_results():
+    """The multi-GPU hand-off (psk_export_survivors + RCCL all_gather_into_tensor) as a one-rank nccl
+    group, in a fresh process (torch's bundled HIP runtime must be loaded before libpsk.so, see
+    phenotypeseeker_amd/_lib.py): the gathered records equal psk_get_results / psk_get_rows."""
+    import subprocess
+    import sys
+    from helpers import ROOT
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "tests", "_exchange_worker.py")], cwd=ROOT, timeout=600,
+                       capture_output=True, text=True)
+    assert r.returncode == 0, (r.stdout[-1500:], r.stderr[-3000:])
+    assert "exchange ok" in r.stdout
