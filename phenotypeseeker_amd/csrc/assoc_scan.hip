@@ -714,28 +714,39 @@ extern "C" int psk_get_results(psk_ctx *ctx, uint64_t *row_idx, uint64_t *words,
     return PSK_OK;
 }
 
-// one block per result segment: writes the segment's survivors as AoS records into a caller buffer
+// one block per result segment: writes the segment's survivors as AoS records into a caller buffer.
+// Segment offsets are computed on the device from the scan's own counters (no host round trip).
 __global__ void export_records_kernel(const uint8_t *__restrict__ res, uint64_t cap, uint32_t seg_cap,
-                                      const uint32_t *__restrict__ counts, const uint64_t *__restrict__ offsets,
-                                      const uint64_t *__restrict__ union_words, const uint64_t *__restrict__ bits, int wpr,
-                                      uint64_t *__restrict__ dst, uint64_t cap_records, uint64_t total)
+                                      const uint32_t *__restrict__ counters, const uint64_t *__restrict__ union_words,
+                                      const uint64_t *__restrict__ bits, int wpr, uint64_t *__restrict__ dst,
+                                      uint64_t cap_records)
 {
+    __shared__ uint32_t cnt[SC_NSEG];
+    __shared__ uint64_t s_off, s_total;
     const uint32_t seg = blockIdx.x;
-    const uint32_t c = counts[seg];
-    const uint64_t in0 = (uint64_t)seg * seg_cap, out0 = offsets[seg];
+    cnt[threadIdx.x] = counters[threadIdx.x * SC_CNT_STRIDE];  // blockDim.x == SC_NSEG
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        uint64_t off = 0, tot = 0;
+        for (int j = 0; j < SC_NSEG; j++) { if (j == (int)seg) off = tot; tot += cnt[j]; }
+        s_off = off;
+        s_total = tot;
+    }
+    __syncthreads();
+    const uint32_t c = cnt[seg];
+    const uint64_t in0 = (uint64_t)seg * seg_cap, out0 = s_off;
     const uint64_t rec_words = 6 + (uint64_t)wpr;
-    const uint64_t *row = reinterpret_cast<const uint64_t *>(res);
-    const uint64_t *f64s = reinterpret_cast<const uint64_t *>(res);  // stat/p/mx/my copied as raw 64-bit patterns
+    const uint64_t *f64s = reinterpret_cast<const uint64_t *>(res);  // row / stat / p / mx / my as raw 64-bit patterns
     const int32_t *nw = reinterpret_cast<const int32_t *>(res + 40 * cap);
     if (seg == 0 && threadIdx.x == 0) {  // header record: number of records that follow
-        dst[0] = total;
+        dst[0] = s_total;
         for (uint64_t j = 1; j < rec_words; j++) dst[j] = 0;
     }
     for (uint32_t i = threadIdx.x; i < c; i += blockDim.x) {
         const uint64_t o = out0 + i;
         if (o >= cap_records) continue;
         uint64_t *rec = dst + (o + 1) * rec_words;
-        const uint64_t r = row[in0 + i];
+        const uint64_t r = f64s[in0 + i];
         rec[0] = union_words[r];
         rec[1] = f64s[1 * cap + in0 + i];
         rec[2] = f64s[2 * cap + in0 + i];
@@ -752,20 +763,11 @@ extern "C" int psk_export_survivors(psk_ctx *ctx, void *device_dst, uint64_t cap
     if (!ctx->last_scan_kind) return psk_fail(ctx, PSK_ESTATE, "no scan has been run");
     if (!device_dst || cap_records < 1) return psk_fail(ctx, PSK_EINVAL, "bad destination");
     PSK_HIP(ctx, hipSetDevice(ctx->device));
-    const uint64_t n = ctx->n_pass;
-    if (n_records) *n_records = n;
-    std::vector<uint64_t> offs(SC_NSEG);
-    uint64_t acc = 0;
-    for (int sgm = 0; sgm < SC_NSEG; sgm++) { offs[sgm] = acc; acc += ctx->seg_counts[sgm]; }
-    PSK_TRY(dev_reserve(ctx, ctx->res_sorted, SC_NSEG * 12 + 64));
-    uint8_t *aux = ctx->res_sorted.as<uint8_t>();
-    uint32_t *d_cnt = reinterpret_cast<uint32_t *>(aux + SC_NSEG * 8);
-    PSK_HIP(ctx, hipMemcpyAsync(aux, offs.data(), SC_NSEG * 8, hipMemcpyHostToDevice, ctx->stream));
-    PSK_HIP(ctx, hipMemcpyAsync(d_cnt, ctx->seg_counts.data(), SC_NSEG * 4, hipMemcpyHostToDevice, ctx->stream));
-    export_records_kernel<<<SC_NSEG, 256, 0, ctx->stream>>>(
-        ctx->res.as<uint8_t>(), ctx->res_seg_cap * SC_NSEG, (uint32_t)ctx->res_seg_cap, d_cnt,
-        reinterpret_cast<const uint64_t *>(aux), ctx->union_words.as<uint64_t>(), ctx->bits.as<uint64_t>(), ctx->wpr,
-        static_cast<uint64_t *>(device_dst), cap_records, n);
+    if (n_records) *n_records = ctx->n_pass;
+    export_records_kernel<<<SC_NSEG, SC_NSEG, 0, ctx->stream>>>(
+        ctx->res.as<uint8_t>(), ctx->res_seg_cap * SC_NSEG, (uint32_t)ctx->res_seg_cap, ctx->res_count.as<uint32_t>(),
+        ctx->union_words.as<uint64_t>(), ctx->bits.as<uint64_t>(), ctx->wpr, static_cast<uint64_t *>(device_dst),
+        cap_records);
     PSK_HIP(ctx, hipGetLastError());
     PSK_HIP(ctx, hipStreamSynchronize(ctx->stream));
     return PSK_OK;

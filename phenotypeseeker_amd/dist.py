@@ -204,6 +204,13 @@ class SurvivorExchange:
                "n_with": recs[:, 5].copy().view(np.int64).astype(np.int32)}
         return res, np.ascontiguousarray(recs[:, 6:])
 
+    def finish_counts(self, s):
+        """Waits for slot s and reads back only the per-slab record counts (the records stay on the
+        device); used where the merged table is not needed on the host right away."""
+        self.work[s].wait()
+        hdr = self.recv[s].view(self.g.world, self.cap + 1, self.rec_words)[:, 0, 0]
+        return hdr.cpu().numpy().astype(np.int64)
+
     def gather(self, ctx):
         """Synchronous form used by the pipeline: exchange the survivors of the last scan, growing the
         buffers if any slab overflowed."""
