@@ -440,9 +440,32 @@ def gen_mash():
     print("mash sketches:", [len(s["hashes"]) for s in out["samples"]])
 
 
+def gen_split():
+    """modeling.py:924-934: train_test_split(ML_df, test_size, random_state=55, stratify=...)."""
+    from sklearn.model_selection import train_test_split
+    rng = np.random.default_rng(8)
+    cases = []
+    for _ in range(40):
+        n = int(rng.integers(8, 120))
+        ts = float(rng.choice([0.1, 0.2, 0.25, 0.3, 0.5]))
+        y = (rng.random(n) < rng.uniform(0.25, 0.75)).astype(int)
+        if min(np.bincount(y, minlength=2)) < 2:
+            continue
+        for strat in (True, False):
+            try:
+                tr, te = train_test_split(np.arange(n), test_size=ts, random_state=55, stratify=y if strat else None)
+            except ValueError:
+                continue
+            cases.append({"n": n, "test_size": ts, "y": y.tolist() if strat else None, "train": tr.tolist(),
+                          "test": te.tolist()})
+    with open(os.path.join(GOLD, "split_kat.json"), "w") as f:
+        json.dump({"source": "sklearn.model_selection.train_test_split(random_state=55)", "cases": cases}, f)
+    print("split KATs:", len(cases))
+
+
 if __name__ == "__main__":
     os.makedirs(GOLD, exist_ok=True)
-    what = sys.argv[1:] or ["tok", "ds", "chi2", "welch", "model", "gmer", "mash"]
+    what = sys.argv[1:] or ["tok", "ds", "chi2", "welch", "model", "gmer", "mash", "split"]
     if "tok" in what:
         gen_tokenizer_cases()
     if "ds" in what:
@@ -459,3 +482,5 @@ if __name__ == "__main__":
         gen_gmer_counter()
     if "mash" in what:
         gen_mash()
+    if "split" in what:
+        gen_split()

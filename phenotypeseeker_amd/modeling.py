@@ -243,9 +243,6 @@ class Input:
             raise SystemExit("Only the L1 penalty runs on the GPU engine, got %r." % penalty)
         if pca:
             raise SystemExit("--pca is outside the accelerated path.")
-        if n_splits_cv_outer or testset_size:
-            raise SystemExit("-cv1 / -ts outer splits are not implemented on the GPU engine yet "
-                             "(the default whole-set training path, modeling.py:953, is).")
 
 
 class phenotypes:
@@ -425,13 +422,42 @@ class phenotypes:
                    "weights": wts, "phenotype": ph}
 
     # ---- model (:860-988) -------------------------------------------------------------------------
-    def assert_n_splits_cv_inner(self, n_splits_cv_inner, y_train):
-        """min(class count or sample count, requested) (:1512-1524)."""
-        if self.pred_scale == "continuous":
-            least = len(y_train)
+    def assert_n_splits_cv_outer(self, n_splits_cv_outer, y):
+        """(:1498-1510)"""
+        if self.pred_scale == "continuous" and n_splits_cv_outer > self.no_samples // 2:
+            self.n_splits_cv_outer = self.no_samples // 2
+            _err(YELLOW % ("Warning! The 'n_splits_cv_outer' parameter is too high to \n"
+                           "leave the required 2 samples into test set for each split!"))
+            _err(YELLOW % ("Setting number of train/test splits equal to " + str(self.n_splits_cv_outer) + "!") + "\n")
+        elif self.pred_scale == "binary" and np.min(np.bincount(y)) < n_splits_cv_outer:
+            self.n_splits_cv_outer = int(np.min(np.bincount(y)))
+            _err(YELLOW % ("Setting number of train/test splits equal to minor phenotype count - "
+                           + str(self.n_splits_cv_outer) + "!") + "\n")
         else:
-            least = int(np.min(np.bincount(np.asarray(y_train, dtype=np.int64))))
+            self.n_splits_cv_outer = n_splits_cv_outer
+
+    def assert_n_splits_cv_inner(self, n_splits_cv_inner, y_all, y_train=None):
+        """min(what the smallest training fold allows, requested) (:1512-1524)."""
+        outer = getattr(self, "n_splits_cv_outer", None)
+        if self.pred_scale == "continuous":
+            least = self.no_samples - math.ceil(self.no_samples / outer) if outer else len(y_train)
+        else:
+            if outer:
+                min_class = int(np.min(np.bincount(np.asarray(y_all, dtype=np.int64))))
+                least = min_class - math.ceil(min_class / outer)
+            else:
+                least = int(np.min(np.bincount(np.asarray(y_train, dtype=np.int64))))
         self.n_splits_cv_inner = int(min(least, n_splits_cv_inner))
+
+    def _new_estimator(self):
+        if self.pred_scale == "binary":
+            return L1LogisticRegression(tol=self.tol, max_iter=self.max_iter), "C", [1.0 / a for a in self.alphas]
+        return LassoRegression(tol=self.tol, max_iter=self.max_iter), "alpha", [float(a) for a in self.alphas]
+
+    def _fit(self, ctx, X, y):
+        est, pname, grid = self._new_estimator()
+        self.model = est
+        self.model_fitted = GridSearch(est, pname, grid, self.n_splits_cv_inner).fit(X, y, ctx)
 
     def machine_learning_modelling(self, ctx):
         _err("\x1b[1;32m\t" + self.name + ".\x1b[0m\n")
@@ -440,19 +466,58 @@ class phenotypes:
         summary = open("summary_of_%s_analysis_%s.txt" % (short, self.name), "w")
         coeff = open("k-mers_and_coefficients_in_%s_model_%s.txt" % (short, self.name), "w")
         X = self.ML["X"].astype(np.float64)
-        if self.pred_scale == "binary":
-            y = np.array(self.ML["phenotype"], dtype=np.int64)
-            est = L1LogisticRegression(tol=self.tol, max_iter=self.max_iter)
-            grid, pname = [1.0 / a for a in self.alphas], "C"
-        else:
-            y = np.array(self.ML["phenotype"], dtype=np.float64)
-            est = LassoRegression(tol=self.tol, max_iter=self.max_iter)
-            grid, pname = [float(a) for a in self.alphas], "alpha"
-        self.assert_n_splits_cv_inner(phenotypes.n_splits_cv_inner, y)
-        self.model_fitted = GridSearch(est, pname, grid, self.n_splits_cv_inner).fit(X, y, ctx)
-        self._cross_validation_results(summary, est)
-        self._predict_report(summary, X, y)
-        summary.write("\n### Outputting the model to a model file! ###\n")
+        index = list(self.ML["index"])
+        binary = self.pred_scale == "binary"
+        y = np.array(self.ML["phenotype"], dtype=np.int64 if binary else np.float64)
+        self.n_splits_cv_outer = None
+        m_train, m_test = _metric_store(), _metric_store()
+        if phenotypes.n_splits_cv_outer:
+            # -cv1: outer (Stratified)KFold, a grid search per training fold (:871-922)
+            self.assert_n_splits_cv_outer(phenotypes.n_splits_cv_outer, y)
+            self.assert_n_splits_cv_inner(phenotypes.n_splits_cv_inner, y)
+            from . import cv as _cv
+            folds = _cv.stratified_kfold(y, self.n_splits_cv_outer) if binary else _cv.kfold(len(y), self.n_splits_cv_outer)
+            for f in range(self.n_splits_cv_outer):
+                tr, te = np.nonzero(folds != f)[0], np.nonzero(folds == f)[0]
+                self._fit(ctx, X[tr], y[tr])
+                summary.write("\n##### Train/test split nr.%d: #####\n" % (f + 1))
+                self._cross_validation_results(summary)
+                summary.write("\nTraining set:\n")
+                self._predict_report(summary, [index[i] for i in tr], X[tr], y[tr], m_train)
+                summary.write("\nTest set:\n")
+                self._predict_report(summary, [index[i] for i in te], X[te], y[te], m_test)
+            if not self.train_on_whole:
+                summary.write("\n### Outputting the last model to a model file! ###\n")
+            summary.write("\nMean performance metrics over all train splits: \n\n")
+            self._mean_report(summary, m_train)
+            summary.write("\nMean performance metrics over all test splits: \n\n")
+            self._mean_report(summary, m_test)
+        elif self.testset_size:
+            # -ts: one hold-out split, train_test_split(random_state=55, stratified for classes) (:924-951)
+            from . import cv as _cv
+            tr, te = _cv.train_test_split_indices(len(y), self.testset_size, y if binary else None, 55)
+            self.assert_n_splits_cv_inner(phenotypes.n_splits_cv_inner, y, y[tr])
+            self._fit(ctx, X[tr], y[tr])
+            self._cross_validation_results(summary)
+            summary.write("\nTraining set:\n")
+            self._predict_report(summary, [index[i] for i in tr], X[tr], y[tr], m_train)
+            summary.write("\nTest set:\n")
+            self._predict_report(summary, [index[i] for i in te], X[te], y[te], m_test)
+            if not self.train_on_whole:
+                summary.write("\n### Outputting the model to a file! ###\n")
+        split = bool(phenotypes.n_splits_cv_outer or self.testset_size)
+        if not split or self.train_on_whole:
+            # the default: train on everything (:953-973)
+            if split:
+                summary.write("\nThe final output model training on the whole dataset:\n")
+            self.assert_n_splits_cv_inner(phenotypes.n_splits_cv_inner, y, y)
+            self._fit(ctx, X, y)
+            self._cross_validation_results(summary)
+            self._predict_report(summary, index, X, y, None)
+            if split:
+                summary.write("\n### Outputting the last model trained on whole data to a model file! ###\n")
+            else:
+                summary.write("\n### Outputting the model to a model file! ###\n")
         import joblib
         package = dict(self.model_package)
         package.update({"model": self.model_fitted, "pca": self.pca, "pred_scale": self.pred_scale})
@@ -462,9 +527,9 @@ class phenotypes:
         summary.close()
         coeff.close()
 
-    def _cross_validation_results(self, out, est):
+    def _cross_validation_results(self, out):
         """(:1219-1237)"""
-        out.write("Parameters:\n%s\n\n" % est)
+        out.write("Parameters:\n%s\n\n" % self.model)
         out.write("Grid scores (%s) on development set: \n" %
                   ("R2 score" if self.pred_scale == "continuous" else "mean accuracy"))
         cvr = self.model_fitted.cv_results_
@@ -474,34 +539,41 @@ class phenotypes:
         for key, value in self.model_fitted.best_params_.items():
             out.write(key + " : " + str(value) + "\n")
 
-    def _predict_report(self, out, X, y):
-        """(:1239-1253, :1255-1288, :1314-1380)"""
+    def _predict_report(self, out, index, X, y, store):
+        """(:1239-1253, :1255-1288, :1314-1380); `store` collects the per-split metrics for the means."""
         pred = self.model_fitted.predict(X)
         out.write("\nModel predictions on samples:\nSample_ID Acutal_phenotype Predicted_phenotype\n")
-        for name, actual, p in zip(self.ML["index"], self.ML["phenotype"], pred):
+        for name, actual, p in zip(index, y, pred):
             out.write("%s %s %s\n" % (name, actual, p))
         out.write("\n")
+
+        def keep(key, value):
+            if store is not None:
+                store[key].append(value)
+            return value
         if self.pred_scale == "continuous":
-            out.write("\nMean squared error: %s\n" % metrics.mean_squared_error(y, pred).round(2))
-            out.write("The coefficient of determination: %s\n" % round(self.model_fitted.score(X, y), 2))
+            out.write("\nMean squared error: %s\n" % keep("MSE", metrics.mean_squared_error(y, pred).round(2)))
+            out.write("The coefficient of determination: %s\n" % keep("CoD", round(self.model_fitted.score(X, y), 2)))
             r, pv = _stats.spearmanr(y, pred)
-            out.write("The Spearman correlation coefficient and p-value: %s, %s \n" % (round(r, 2), round(pv, 2)))
+            out.write("The Spearman correlation coefficient and p-value: %s, %s \n"
+                      % (keep("SpCC", round(r, 2)), keep("Sp_pval", round(pv, 2))))
             r, pv = _stats.pearsonr(y, pred)
-            out.write("The Pearson correlation coefficient and p-value:  %s, %s \n" % (round(r, 2), round(pv, 2)))
+            out.write("The Pearson correlation coefficient and p-value:  %s, %s \n"
+                      % (keep("PeCC", round(r, 2)), keep("Pe_pval", round(pv, 2))))
             out.write("The plus/minus 1 dilution factor accuracy (for MICs): %s \n\n"
-                      % metrics.within_1_tier_accuracy(y, pred))
+                      % keep("DFA", metrics.within_1_tier_accuracy(y, pred)))
             return
         proba = self.model_fitted.predict_proba(X)[:, 1]
-        out.write("F1-score of positive class: %s\n" % metrics.f1(y, pred).round(2))
-        out.write("Mean accuracy: %s\n" % self.model_fitted.score(X, y).round(2))
-        out.write("Sensitivity: %s\n" % metrics.recall(y, pred).round(2))
-        out.write("Specificity: %s\n" % metrics.recall(y, pred, positive=0).round(2))
-        out.write("AUC-ROC: %s\n" % metrics.roc_auc(y, pred).round(2))
-        out.write("Average precision: %s\n" % metrics.average_precision(y, proba).round(2))
-        out.write("MCC: %s\n" % round(metrics.matthews(y, pred), 2))
-        out.write("Cohen kappa: %s\n" % metrics.cohen_kappa(y, pred).round(2))
-        out.write("Very major error rate: %s\n" % metrics.very_major_error(y, pred))
-        out.write("Major error rate: %s\n" % metrics.major_error(y, pred))
+        out.write("F1-score of positive class: %s\n" % keep("F1_sc", metrics.f1(y, pred).round(2)))
+        out.write("Mean accuracy: %s\n" % keep("Acc", self.model_fitted.score(X, y).round(2)))
+        out.write("Sensitivity: %s\n" % keep("Sn", metrics.recall(y, pred).round(2)))
+        out.write("Specificity: %s\n" % keep("Sp", metrics.recall(y, pred, positive=0).round(2)))
+        out.write("AUC-ROC: %s\n" % keep("AUCROC", metrics.roc_auc(y, pred).round(2)))
+        out.write("Average precision: %s\n" % keep("Pr", metrics.average_precision(y, proba).round(2)))
+        out.write("MCC: %s\n" % keep("MCC", round(metrics.matthews(y, pred), 2)))
+        out.write("Cohen kappa: %s\n" % keep("kappa", metrics.cohen_kappa(y, pred).round(2)))
+        out.write("Very major error rate: %s\n" % keep("VME", metrics.very_major_error(y, pred)))
+        out.write("Major error rate: %s\n" % keep("ME", metrics.major_error(y, pred)))
         out.write("Classification report:\n\n %s\n" % metrics.classification_report(y, pred))
         cm = metrics.confusion(y, pred)
         out.write("Confusion matrix:\n")
@@ -509,6 +581,21 @@ class phenotypes:
         out.write("Actual\n")
         out.write("0\t\t%s\t%s\n" % tuple(cm[0]))
         out.write("1\t\t%s\t%s\n\n" % tuple(cm[1]))
+
+    def _mean_report(self, out, store):
+        """(:1290-1312, :1382-1412)"""
+        mean = {k: np.mean(v).round(2) for k, v in store.items() if len(v)}
+        if self.pred_scale == "continuous":
+            out.write("\nMean squared error: %s\n" % mean["MSE"])
+            out.write("The coefficient of determination: %s\n" % mean["CoD"])
+            out.write("The Spearman correlation coefficient and p-value: %s, %s \n" % (mean["SpCC"], mean["Sp_pval"]))
+            out.write("The Pearson correlation coefficient and p-value:  %s, %s \n" % (mean["PeCC"], mean["Pe_pval"]))
+            out.write("The plus/minus 1 dilution factor accuracy (for MICs): %s \n\n" % mean["DFA"])
+            return
+        for label, key in (("F1-score of positive class", "F1_sc"), ("Mean accuracy", "Acc"), ("Sensitivity", "Sn"),
+                           ("Specificity", "Sp"), ("AUC-ROC", "AUCROC"), ("Average precision", "Pr"), ("MCC", "MCC"),
+                           ("Cohen kappa", "kappa"), ("Very major error rate", "VME"), ("Major error rate", "ME")):
+            out.write("%s: %s\n" % (label, mean[key]))
 
     def _write_model_coefficients(self, out):
         """(:1414-1455)"""
@@ -519,6 +606,11 @@ class phenotypes:
         for j, kmer in enumerate(self.ML["kmers"]):
             with_kmer = [index[i] for i in range(len(index)) if X[i, j] != 0]
             out.write("%s\t%s\t%d\t| %s\n" % (kmer, repr(float(coefs[j])), len(with_kmer), " ".join(with_kmer)))
+
+
+def _metric_store():
+    return {k: [] for k in ("MSE", "CoD", "SpCC", "Sp_pval", "PeCC", "Pe_pval", "DFA", "Acc", "Sn", "Sp", "AUCROC",
+                            "Pr", "MCC", "kappa", "VME", "ME", "F1_sc")}
 
 
 def modeling(args):

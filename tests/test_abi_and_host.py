@@ -106,3 +106,15 @@ def test_cv_splitters_match_sklearn_fixtures():
         k = int(min(np.bincount(y).min(), rng.integers(2, 11)))
         assert np.array_equal(cv.stratified_kfold(y, k), OM.stratified_kfold(y, k))
         assert np.array_equal(cv.kfold(n, k), OM.kfold(n, k))
+
+
+def test_train_test_split_matches_sklearn_fixture():
+    import json
+    from phenotypeseeker_amd import cv
+    from helpers import GOLDEN
+    with open(os.path.join(GOLDEN, "split_kat.json")) as f:
+        cases = json.load(f)["cases"]
+    assert len(cases) >= 60
+    for c in cases:
+        tr, te = cv.train_test_split_indices(c["n"], c["test_size"], None if c["y"] is None else np.array(c["y"]), 55)
+        assert list(tr) == c["train"] and list(te) == c["test"]

@@ -169,3 +169,48 @@ def test_weighted_modeling_end_to_end(tmp_path, oracle):
     with open("Pheno_MLdf.csv") as f:
         rows = list(csv.reader(f))
     assert np.allclose([float(r[-2]) for r in rows[1:]], [w for w, p in zip(got_w, ds["pheno"]) if p != "NA"])
+
+
+def test_outer_cv_and_holdout_modes(tmp_path):
+    """-cv1 (outer StratifiedKFold) and -ts/-tow (hold-out with random_state 55): sections of the
+    summary, and the hold-out model equals a direct grid search on the same training rows."""
+    import joblib
+    from phenotypeseeker_amd import cv
+    from phenotypeseeker_amd.engine import PskContext
+    from phenotypeseeker_amd.model import GridSearch, L1LogisticRegression
+    ds = load_dataset("ds_bonf")
+    _write_dataset(ds, str(tmp_path))
+    _run(tmp_path, ["modeling", "data.pheno", "-cv1", "3"])
+    txt = open("summary_of_log_reg_analysis_Pheno.txt").read()
+    for k in (1, 2, 3):
+        assert "##### Train/test split nr.%d: #####" % k in txt
+    assert "Mean performance metrics over all train splits:" in txt and "Mean performance metrics over all test splits:" in txt
+    assert "### Outputting the last model to a model file! ###" in txt and txt.count("Test set:") == 3
+    assert os.path.exists("log_reg_model_Pheno.pkl")
+
+    _run(tmp_path, ["modeling", "data.pheno", "-jt", "modelling", "-ts", "0.25", "-tow"])
+    txt = open("summary_of_log_reg_analysis_Pheno.txt").read()
+    assert "Training set:" in txt and "Test set:" in txt
+    assert "The final output model training on the whole dataset:" in txt
+    assert "### Outputting the last model trained on whole data to a model file! ###" in txt
+
+    _run(tmp_path, ["modeling", "data.pheno", "-jt", "modelling", "-ts", "0.25"])
+    pkg = joblib.load("log_reg_model_Pheno.pkl")
+    with open("Pheno_MLdf.csv") as f:
+        rows = list(csv.reader(f))
+    X = np.array([[int(v) for v in r[1:-2]] for r in rows[1:]], dtype=np.float64)
+    y = np.array([int(r[-1]) for r in rows[1:]])
+    tr, te = cv.train_test_split_indices(len(y), 0.25, y, 55)
+    assert len(te) == int(np.ceil(0.25 * len(y)))
+    inner = int(min(np.bincount(y[tr]).min(), 10))
+    with PskContext(0) as ctx:
+        ref = GridSearch(L1LogisticRegression(tol=1e-4, max_iter=1000), "C", [1.0 / a for a in np.logspace(-3, 3, 13)],
+                         inner).fit(X[tr], y[tr], ctx)
+    assert pkg["model"].best_params_ == ref.best_params_
+    assert np.allclose(pkg["model"].best_estimator_.coef_, ref.best_estimator_.coef_, atol=1e-9)
+    txt = open("summary_of_log_reg_analysis_Pheno.txt").read()
+    assert "### Outputting the model to a file! ###" in txt
+    # the listed training samples are the split's, in its order
+    block = txt.split("Training set:")[1].split("Test set:")[0]
+    listed = [l.split()[0] for l in block.splitlines() if l.startswith("S0")]
+    assert listed == [rows[1 + i][0] for i in tr]
