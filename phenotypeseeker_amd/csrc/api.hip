@@ -117,7 +117,7 @@ extern "C" void psk_free(psk_ctx *ctx)
     if (ctx->stream) (void)hipStreamSynchronize(ctx->stream);
     reset_lists(ctx, 0);
     arena_release(ctx);
-    DevBuf *bufs[] = {&ctx->raw, &ctx->keysA, &ctx->keysB, &ctx->hist, &ctx->scan_tmp, &ctx->flags, &ctx->starts,
+    DevBuf *bufs[] = {&ctx->raw, &ctx->keysA, &ctx->keysB, &ctx->valsA, &ctx->valsB, &ctx->hist, &ctx->scan_tmp, &ctx->flags, &ctx->starts,
                       &ctx->misc, &ctx->union_words, &ctx->bits, &ctx->mask1, &ctx->mask0, &ctx->wts, &ctx->phe,
                       &ctx->res, &ctx->res_count, &ctx->res_sorted};
     for (DevBuf *b : bufs) dev_release(*b);

@@ -28,11 +28,14 @@ struct PhaseTimer {
     }
 };
 
+// vals == nullptr: pair = word << sbits | sample in one u64; else key = word, payload = sample
 __global__ void pack_pairs_kernel(const uint64_t *__restrict__ words, uint64_t n, int sbits, uint64_t sample,
-                                  uint64_t *__restrict__ out)
+                                  uint64_t *__restrict__ out, uint32_t *__restrict__ vals)
 {
     const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (i < n) out[i] = (words[i] << sbits) | sample;
+    if (i >= n) return;
+    if (vals) { out[i] = words[i]; vals[i] = (uint32_t)sample; }
+    else out[i] = (words[i] << sbits) | sample;
 }
 
 __global__ void pair_head_flags_kernel(const uint64_t *__restrict__ pairs, uint64_t n, int sbits,
@@ -50,7 +53,8 @@ __global__ void pair_head_flags_kernel(const uint64_t *__restrict__ pairs, uint6
 __global__ __launch_bounds__(256) void presence_fill_kernel(const uint64_t *__restrict__ pairs, uint64_t n, int sbits,
                                                              const uint32_t *__restrict__ rowpos, int wpr,
                                                              uint64_t *__restrict__ words,
-                                                             unsigned long long *__restrict__ bits)
+                                                             unsigned long long *__restrict__ bits,
+                                                             const uint32_t *__restrict__ vals)
 {
     const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
     const int lane = threadIdx.x & 63;
@@ -60,7 +64,7 @@ __global__ __launch_bounds__(256) void presence_fill_kernel(const uint64_t *__re
         const uint64_t w = pr >> sbits;
         const bool head = (i == 0) || (pairs[i - 1] >> sbits) != w;
         const uint64_t row = (uint64_t)rowpos[i] + (head ? 1u : 0u) - 1u;
-        const uint32_t s = (uint32_t)(pr & ((1ull << sbits) - 1ull));
+        const uint32_t s = vals ? vals[i] : (uint32_t)(pr & ((1ull << sbits) - 1ull));
         if (head) words[row] = w;
         key = row * (uint64_t)wpr + (s >> 6);
         val = 1ull << (s & 63);
@@ -192,10 +196,11 @@ extern "C" int psk_build_presence(psk_ctx *ctx, uint64_t *n_kmers)
         if (!ctx->lists[i].done) return psk_fail(ctx, PSK_ESTATE, "sample %d has not been counted", i);
         total += ctx->lists[i].n_unique;
     }
-    const int sbits = sample_bits(ctx->n_samples);
-    if (2 * ctx->k + sbits > 64)
-        return psk_fail(ctx, PSK_ERANGE, "k=%d with %d samples needs %d bits per (word, sample) pair (max 64)", ctx->k,
-                        ctx->n_samples, 2 * ctx->k + sbits);
+    int sbits = sample_bits(ctx->n_samples);
+    // word and sample share one u64 when they fit (k <= 26 at 4096 samples); otherwise the sample id
+    // travels as a u32 payload of the sort
+    const bool kv = 2 * ctx->k + sbits > 64;
+    if (kv) sbits = 0;
     if (total >= (1ull << 32)) return psk_fail(ctx, PSK_ERANGE, "%llu (word, sample) pairs exceed 2^32 per GPU; "
                                                                 "shard the word space over more GPUs",
                                                (unsigned long long)total);
@@ -210,20 +215,27 @@ extern "C" int psk_build_presence(psk_ctx *ctx, uint64_t *n_kmers)
     PhaseTimer pt(ctx->stream);
     PSK_TRY(dev_reserve(ctx, ctx->keysA, total * 8));
     PSK_TRY(dev_reserve(ctx, ctx->keysB, total * 8));
+    if (kv) {
+        PSK_TRY(dev_reserve(ctx, ctx->valsA, total * 4));
+        PSK_TRY(dev_reserve(ctx, ctx->valsB, total * 4));
+    }
     pt.mark("alloc pairs");
     uint64_t off = 0;
     for (int i = 0; i < ctx->n_samples; i++) {
         const SampleList &L = ctx->lists[i];
         if (!L.n_unique) continue;
-        pack_pairs_kernel<<<div_up(L.n_unique, 256), 256, 0, ctx->stream>>>(L.words, L.n_unique, sbits, (uint64_t)i,
-                                                                            ctx->keysA.as<uint64_t>() + off);
+        pack_pairs_kernel<<<div_up(L.n_unique, 256), 256, 0, ctx->stream>>>(
+            L.words, L.n_unique, sbits, (uint64_t)i, ctx->keysA.as<uint64_t>() + off,
+            kv ? ctx->valsA.as<uint32_t>() + off : nullptr);
         PSK_HIP(ctx, hipGetLastError());
         off += L.n_unique;
     }
     pt.mark("pack");
     uint64_t *sorted = nullptr;
-    PSK_TRY(dev_radix_sort_u64(ctx, ctx->keysA.as<uint64_t>(), ctx->keysB.as<uint64_t>(), total, sbits,
-                               sbits + 2 * ctx->k, &sorted));
+    uint32_t *sorted_vals = nullptr;
+    PSK_TRY(dev_radix_sort_kv(ctx, ctx->keysA.as<uint64_t>(), ctx->keysB.as<uint64_t>(),
+                              kv ? ctx->valsA.as<uint32_t>() : nullptr, kv ? ctx->valsB.as<uint32_t>() : nullptr, total,
+                              sbits, sbits + 2 * ctx->k, &sorted, &sorted_vals));
     pt.mark("sort");
     PSK_TRY(dev_reserve(ctx, ctx->flags, total * 4));
     PSK_TRY(dev_reserve(ctx, ctx->misc, 64));
@@ -245,7 +257,7 @@ extern "C" int psk_build_presence(psk_ctx *ctx, uint64_t *n_kmers)
     PSK_HIP(ctx, hipMemsetAsync(ctx->bits.p, 0, M * (uint64_t)ctx->wpr * 8, ctx->stream));
     presence_fill_kernel<<<div_up(total, 256), 256, 0, ctx->stream>>>(
         sorted, total, sbits, flags, ctx->wpr, ctx->union_words.as<uint64_t>(),
-        reinterpret_cast<unsigned long long *>(ctx->bits.p));
+        reinterpret_cast<unsigned long long *>(ctx->bits.p), kv ? sorted_vals : nullptr);
     PSK_HIP(ctx, hipGetLastError());
     PSK_HIP(ctx, hipStreamSynchronize(ctx->stream));
     pt.mark("fill");

@@ -65,7 +65,7 @@ struct psk_ctx {
     Arena arena;
 
     // scratch for per-sample counting
-    DevBuf raw, keysA, keysB, hist, scan_tmp, flags, starts, misc;
+    DevBuf raw, keysA, keysB, valsA, valsB, hist, scan_tmp, flags, starts, misc;
     void *pinned = nullptr;   // pinned host staging for the clean stream
     size_t pinned_cap = 0;
     void *scan_pinned = nullptr;  // pinned staging for the scan's masks / weights
@@ -119,6 +119,10 @@ int dev_exclusive_scan_u32(psk_ctx *ctx, const uint32_t *in, uint32_t *out, uint
 // (either a or b).  n < 2^32.
 int dev_radix_sort_u64(psk_ctx *ctx, uint64_t *a, uint64_t *b, uint64_t n, int bit_lo, int bit_hi,
                        uint64_t **sorted_out);
+
+// Same with a u32 payload per key (va/vb double buffer); sorted payloads end in *sorted_vals_out.
+int dev_radix_sort_kv(psk_ctx *ctx, uint64_t *a, uint64_t *b, uint32_t *va, uint32_t *vb, uint64_t n, int bit_lo,
+                      int bit_hi, uint64_t **sorted_out, uint32_t **sorted_vals_out);
 
 // ---- stages --------------------------------------------------------------------------------------
 int64_t frame_sequence_host(const uint8_t *bytes, size_t len, uint8_t *out, size_t out_cap);

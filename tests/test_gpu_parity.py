@@ -348,3 +348,23 @@ def test_device_survivor_exchange_matches_get_results():
                        capture_output=True, text=True)
     assert r.returncode == 0, (r.stdout[-1500:], r.stderr[-3000:])
     assert "exchange ok" in r.stdout
+
+
+@pytest.mark.parametrize("k,n,length", [(31, 40, 3000), (32, 3, 5000), (27, 3000, 120), (26, 4096, 100)])
+def test_presence_when_word_and_sample_do_not_fit_one_u64(ctx, oracle, k, n, length):
+    """2k + ceil(log2 N) > 64 (k = 27..32 with many samples) takes the key + payload sort; k = 26 with
+    4096 samples is the largest packed case.  Union and bit rows must equal the oracle's either way."""
+    from phenotypeseeker_amd.synth import GenomeSet
+    gs = GenomeSet(n, length, seed=k * 7 + n, gene_len=40, sub_rate=0.01)
+    ctx.begin(k, n)
+    lists = []
+    for i in range(n):
+        _, fa = gs.sample(i)
+        nu, _ = ctx.count_kmers(i, fa)
+        lists.append(oracle.count_kmers(fa, k)[0])
+        assert nu == len(lists[-1])
+    M = ctx.build_presence()
+    uw = oracle.union(lists)
+    assert M == len(uw) and np.array_equal(ctx.get_union(), uw)
+    bits = ctx.get_rows(np.arange(M, dtype=np.uint64))
+    assert np.array_equal(bits, oracle.presence_bits(lists, uw, wpr=bits.shape[1]))
