@@ -3,7 +3,7 @@ import ctypes
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libpsk.so")
+LIB_PATH = os.environ.get("PSK_LIB") or os.path.join(_HERE, "libpsk.so")  # PSK_LIB: A/B builds (tools/)
 
 
 class PskError(RuntimeError):

@@ -23,8 +23,18 @@
 
 namespace {
 
+// tuning knobs (overridable at build time for A/B runs: tools/scan_variants.sh)
+#ifndef PSK_SC_UNROLL
+#define PSK_SC_UNROLL 4
+#endif
+#ifndef PSK_SC_GRID_MULT
+#define PSK_SC_GRID_MULT 16
+#endif
+#ifndef PSK_SC_NT
+#define PSK_SC_NT 1
+#endif
 constexpr int SC_THREADS = 256;
-constexpr int SC_UNROLL = 4;
+constexpr int SC_UNROLL = PSK_SC_UNROLL;
 // Survivors are appended to SC_NSEG independent segments (segment = blockIdx % SC_NSEG), each with its
 // own counter on its own 128-byte line: one shared counter serialises at ~11 ns per append (r01: a
 // matrix with 1 % survivors ran 15x slower than the stream rate).
@@ -99,7 +109,13 @@ __global__ __launch_bounds__(SC_THREADS) void chi2_scan_kernel(const ScanArgs P)
         for (int u = 0; u < SC_UNROLL; u++) {
             const uint64_t row = (s0 + u) * RPW + rsub;
             x[u] = (u32x4)(0u);
-            if (row < P.M && has_chunk) x[u] = __builtin_nontemporal_load(&P.bits[row * (uint64_t)P.cpr + g]);
+            if (row < P.M && has_chunk) {
+#if PSK_SC_NT
+                x[u] = __builtin_nontemporal_load(&P.bits[row * (uint64_t)P.cpr + g]);
+#else
+                x[u] = P.bits[row * (uint64_t)P.cpr + g];
+#endif
+            }
         }
 #pragma unroll
         for (int u = 0; u < SC_UNROLL; u++) {
@@ -463,7 +479,7 @@ dim3 scan_grid(const psk_ctx *ctx, uint64_t M, int G, int unroll)
     const uint64_t steps = (M + rpw - 1) / rpw;
     const uint64_t waves = (steps + unroll - 1) / unroll;
     uint64_t blocks = (waves + SC_THREADS / 64 - 1) / (SC_THREADS / 64);
-    const uint64_t cap = (uint64_t)(ctx->n_cu > 0 ? ctx->n_cu : 256) * 8;
+    const uint64_t cap = (uint64_t)(ctx->n_cu > 0 ? ctx->n_cu : 256) * PSK_SC_GRID_MULT;
     if (blocks > cap) blocks = cap;
     if (blocks < 1) blocks = 1;
     return dim3((unsigned)blocks);
