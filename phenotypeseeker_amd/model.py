@@ -98,9 +98,13 @@ class GridSearch:
         self.cv = int(cv)
 
     def fit(self, X, y, engine_ctx):
-        X = np.asarray(X, dtype=np.float64)
+        X_full = np.asarray(X, dtype=np.float64)
         y = np.asarray(y)
         n = len(y)
+        # Identical columns (k-mers of one gene share a presence pattern) are solved once: an L1
+        # optimum may place a pattern's weight on any of its copies, here on the first (which is also
+        # what cyclic coordinate descent -- scikit-learn's Lasso -- does).
+        X, first, inverse = _unique_columns(X_full)
         grid = self.param_grid[self.param_name]
         is_clf = isinstance(self.estimator, L1LogisticRegression)
         if self.cv < 2:
@@ -140,7 +144,10 @@ class GridSearch:
         j = len(grid) * self.cv + self.best_index_
         best = type(self.estimator)(**{self.param_name: grid[self.best_index_]})
         best.tol, best.max_iter = self.estimator.tol, self.estimator.max_iter
-        self.best_estimator_ = best._set(coef[j], icpt[j])
+        full = np.zeros(X_full.shape[1])
+        full[first] = coef[j]
+        self.best_estimator_ = best._set(full, icpt[j])
+        self.n_unique_columns_ = int(X.shape[1])
         self.n_splits_ = self.cv
         self.n_iter_ = iters
         self.test_folds_ = folds
@@ -180,6 +187,23 @@ class GridSearch:
         gs.n_splits_, gs.refit_time_, gs.multimetric_ = self.n_splits_, 0.0, False
         gs.scorer_ = None
         return gs
+
+
+def _unique_columns(X):
+    """Distinct columns of X in order of first appearance: (X_unique, first_index[], inverse[])."""
+    seen = {}
+    first, inverse = [], np.empty(X.shape[1], dtype=np.int64)
+    cols = np.ascontiguousarray(X.T)
+    for j in range(X.shape[1]):
+        key = cols[j].tobytes()
+        u = seen.get(key)
+        if u is None:
+            u = len(first)
+            seen[key] = u
+            first.append(j)
+        inverse[j] = u
+    first = np.array(first, dtype=np.int64)
+    return np.ascontiguousarray(X[:, first]) if len(first) else X[:, :0], first, inverse
 
 
 def _rank_min(a):

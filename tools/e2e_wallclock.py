@@ -1,0 +1,44 @@
+#!/usr/bin/env python3
+"""End-to-end `phenotypeseeker modeling` wall-clock (FASTA files on disk -> .pkl written), the second
+half of the north-star metric.  Writes a synthetic genome set to a scratch directory, runs the CLI
+entry point in-process and prints one JSON line with the stage timings.
+usage: tools/e2e_wallclock.py N LENGTH [extra CLI flags]"""
+import json
+import os
+import shutil
+import sys
+import tempfile
+import time
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+from phenotypeseeker_amd.cli import build_parser  # noqa: E402
+from phenotypeseeker_amd.synth import GenomeSet  # noqa: E402
+
+n, length = int(sys.argv[1]), int(sys.argv[2])
+extra = sys.argv[3:]
+tmp = tempfile.mkdtemp(prefix="psk_e2e_")
+gs = GenomeSet(n, length, seed=12345)
+t0 = time.time()
+rows = ["ID\tAddresses\tPheno"]
+for i in range(n):
+    name, fa = gs.sample(i)
+    with open(os.path.join(tmp, name + ".fasta"), "wb") as f:
+        f.write(fa)
+    rows.append("%s\t%s.fasta\t%d" % (name, name, gs.phenotype(i)))
+with open(os.path.join(tmp, "data.pheno"), "w") as f:
+    f.write("\n".join(rows) + "\n")
+t_write = time.time() - t0
+os.chdir(tmp)
+args = build_parser().parse_args(["modeling", "data.pheno"] + extra)
+err = sys.stderr
+sys.stderr = open(os.devnull, "w")
+t0 = time.time()
+args.func(args)
+wall = time.time() - t0
+sys.stderr = err
+log = open("log.txt").read().strip().splitlines()
+out = {"samples": n, "length": length, "flags": extra, "write_dataset_s": round(t_write, 2), "modeling_wall_s": round(wall, 3),
+       "log": log, "outputs": sorted(f for f in os.listdir(".") if not f.endswith(".fasta"))}
+print(json.dumps(out))
+shutil.rmtree(tmp, ignore_errors=True)
