@@ -368,3 +368,73 @@ def test_presence_when_word_and_sample_do_not_fit_one_u64(ctx, oracle, k, n, len
     assert M == len(uw) and np.array_equal(ctx.get_union(), uw)
     bits = ctx.get_rows(np.arange(M, dtype=np.uint64))
     assert np.array_equal(bits, oracle.presence_bits(lists, uw, wpr=bits.shape[1]))
+
+
+def test_full_size_ingest_properties(ctx, oracle):
+    """BASELINE config-2 sized ingest (256 x 5 Mbp, k = 13) checked through size-independent
+    properties: every list is strictly ascending with sum(freq) = number of windows, the union is
+    strictly ascending, every matrix row has at least one bit, the column sums of the matrix equal the
+    per-sample list lengths, and a sample of rows/lists equals the oracle's."""
+    from phenotypeseeker_amd.synth import GenomeSet
+    n, L, k = 256, 5_000_000, 13
+    gs = GenomeSet(n, L, seed=4242)
+    ctx.begin(k, n)
+    uniq = []
+    for i in range(n):
+        _, fa = gs.sample(i)
+        nu, nt = ctx.count_kmers(i, fa)
+        uniq.append(nu)
+        assert nt == len(gs.codes(i)) - k + 1 if i % 64 == 0 else nt > L - k
+    for i in (0, 77, 255):
+        w, f = ctx.get_list(i, uniq[i])
+        assert np.all(np.diff(w.astype(np.int64)) > 0) and int(f.sum()) > L - k
+        if i == 77:
+            ow, of, _ = oracle.count_kmers(gs.sample(i)[1], k)
+            assert np.array_equal(w, ow) and np.array_equal(f, of)
+    M = ctx.build_presence()
+    assert max(uniq) <= M <= min(sum(uniq), 1 << (2 * k - 1) + (1 << (k - 1)))
+    uw = ctx.get_union()
+    assert np.all(np.diff(uw.astype(np.int64)) > 0)
+    colsum = np.zeros(n, dtype=np.int64)
+    chunk = 1 << 21
+    for lo in range(0, M, chunk):
+        rows = ctx.get_rows(np.arange(lo, min(lo + chunk, M), dtype=np.uint64))
+        assert np.all(rows.any(axis=1))
+        b = np.unpackbits(rows.view(np.uint8), axis=1, bitorder="little")[:, :n]
+        colsum += b.sum(axis=0, dtype=np.int64)
+    assert colsum.tolist() == uniq
+    # rows of sample 77's first words carry bit 77
+    w77, _ = ctx.get_list(77, uniq[77])
+    idx = np.searchsorted(uw, w77[:1000])
+    assert np.array_equal(uw[idx], w77[:1000])
+    r = ctx.get_rows(idx.astype(np.uint64))
+    assert np.all((r[:, 77 >> 6] >> np.uint64(77 & 63)) & np.uint64(1))
+
+
+def test_abi_misuse_returns_errors_not_crashes(ctx):
+    from phenotypeseeker_amd._lib import PskError
+    from phenotypeseeker_amd.engine import PskContext
+    with PskContext(0) as c:
+        with pytest.raises(PskError, match="psk_begin"):
+            c.count_kmers(0, b">r\nACGT\n")
+        with pytest.raises(PskError):
+            c.begin(0, 1)
+        with pytest.raises(PskError):
+            c.begin(33, 1)
+        c.begin(13, 2)
+        with pytest.raises(PskError, match="out of range"):
+            c.count_kmers(5, b">r\nACGT\n")
+        c.count_kmers(0, b">r\nACGTACGTACGTACGTACGT\n")
+        with pytest.raises(PskError, match="has not been counted"):
+            c.build_presence()
+        with pytest.raises(PskError, match="no presence matrix"):
+            c.chi2_scan(np.zeros(2, np.int8), None, 1, 2, 0.05, True, 1)
+        c.count_kmers(1, b"")                       # empty sample is legal
+        assert c.build_presence() == 2
+        with pytest.raises(PskError, match="row index"):
+            c.get_rows(np.array([99], dtype=np.uint64))
+        with pytest.raises(PskError, match="no scan"):
+            c.get_results(1)
+        assert c.chi2_scan(np.array([1, 0], np.int8), None, 1, 2, 1.5, True, 2) >= 0
+    with pytest.raises(PskError):
+        PskContext(99)
