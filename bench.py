@@ -97,15 +97,15 @@ def main():
         ctx.begin(k, n)
         t_gen = t_cnt = 0.0
         tot_unique = 0
-        for i in range(n):
+        for lo in range(0, n, 16):
             t0 = time.time()
-            _, fa = gs.sample(i)
+            fas = [gs.sample(i)[1] for i in range(lo, min(lo + 16, n))]
             t1 = time.time()
-            nu, nt = ctx.count_kmers(i, fa)
+            nus, _ = ctx.count_kmers_batch(lo, fas, 4)
             t2 = time.time()
             t_gen += t1 - t0
             t_cnt += t2 - t1
-            tot_unique += nu
+            tot_unique += sum(nus)
         t0 = time.time()
         M = ctx.build_presence()
         t_build = time.time() - t0

@@ -62,6 +62,11 @@ int psk_begin(psk_ctx *ctx, int k, int n_samples, uint64_t slab_lo, uint64_t sla
  */
 int psk_count_kmers(psk_ctx *ctx, int sample_idx, const uint8_t *bytes, size_t len, uint64_t *n_unique,
                     uint64_t *n_total);
+/* Batch form of psk_count_kmers for samples first_sample_idx .. first_sample_idx + n - 1: n_threads host
+ * threads tokenise ahead into a ring of pinned buffers while the calling thread drives the GPU half
+ * in order, so host framing overlaps device work.  n_unique / n_total: n entries each (may be NULL). */
+int psk_count_kmers_batch(psk_ctx *ctx, int first_sample_idx, int n, const uint8_t *const *bytes, const size_t *lens,
+                          uint64_t *n_unique, uint64_t *n_total, int n_threads);
 /* Copies sample_idx's list to the host (for writing .list files / parity checks). */
 int psk_get_list(psk_ctx *ctx, int sample_idx, uint64_t *words, uint32_t *freqs, uint64_t cap);
 /* Frequencies of `n` given canonical words in sample_idx's list (0 if absent): the

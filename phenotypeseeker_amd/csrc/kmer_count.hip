@@ -13,6 +13,10 @@
 #if defined(__SSE2__)
 #include <emmintrin.h>
 #endif
+#include <atomic>
+#include <condition_variable>
+#include <mutex>
+#include <thread>
 
 // ------------------------------------------------------------------------------------------------
 // Host framing.  Tokeniser contract of glistmaker 4.2.3 as established by probing the binary
@@ -306,29 +310,7 @@ __global__ __launch_bounds__(EX_THREADS) void dict_count_kernel(const uint8_t *_
     }
 }
 
-int upload_clean(psk_ctx *ctx, const uint8_t *bytes, size_t len, uint64_t *clean_len)
-{
-    // frame straight into a pinned staging buffer (grow-only), then one async H2D copy
-    const size_t need = len + 2 * EX_SEG;
-    if (need > ctx->pinned_cap) {
-        if (ctx->pinned) (void)hipHostFree(ctx->pinned);
-        ctx->pinned = nullptr;
-        ctx->pinned_cap = 0;
-        const size_t want = need + need / 4;
-        hipError_t e = hipHostMalloc(&ctx->pinned, want, hipHostMallocDefault);
-        if (e != hipSuccess) return psk_fail(ctx, PSK_ENOMEM, "hipHostMalloc(%zu) failed: %s", want, hipGetErrorString(e));
-        ctx->pinned_cap = want;
-    }
-    uint8_t *stage = static_cast<uint8_t *>(ctx->pinned);
-    int64_t n = frame_sequence_host(bytes, len, stage, need);
-    if (n < 0) return psk_fail(ctx, (int)n, "framing failed");
-    const uint64_t padded = ((uint64_t)n + EX_SEG - 1) / EX_SEG * EX_SEG + EX_SEG;
-    memset(stage + n, '\n', padded - n);
-    PSK_TRY(dev_reserve(ctx, ctx->raw, padded));
-    PSK_HIP(ctx, hipMemcpyAsync(ctx->raw.p, stage, padded, hipMemcpyHostToDevice, ctx->stream));
-    *clean_len = (uint64_t)n;
-    return PSK_OK;
-}
+int upload_clean(psk_ctx *ctx, const uint8_t *bytes, size_t len, uint64_t *clean_len);
 
 }  // namespace
 
@@ -347,21 +329,28 @@ int launch_extract(psk_ctx *ctx, const uint8_t *clean, uint64_t len, int k, uint
     return PSK_OK;
 }
 
-extern "C" int psk_count_kmers(psk_ctx *ctx, int sample_idx, const uint8_t *bytes, size_t len, uint64_t *n_unique,
-                               uint64_t *n_total)
+// frames `bytes` into `stage` (host, thread-safe) and pads it for the extract kernel
+static int frame_into(uint8_t *stage, size_t stage_cap, const uint8_t *bytes, size_t len, uint64_t *clean_len,
+                      uint64_t *padded_len)
 {
-    if (!ctx) return PSK_EINVAL;
-    if (ctx->k == 0) return psk_fail(ctx, PSK_ESTATE, "psk_begin has not been called");
-    if (sample_idx < 0 || sample_idx >= ctx->n_samples) return psk_fail(ctx, PSK_EINVAL, "sample_idx out of range");
-    if (!bytes && len) return psk_fail(ctx, PSK_EINVAL, "null input");
-    PSK_HIP(ctx, hipSetDevice(ctx->device));
+    int64_t n = frame_sequence_host(bytes, len, stage, stage_cap);
+    if (n < 0) return (int)n;
+    const uint64_t padded = ((uint64_t)n + EX_SEG - 1) / EX_SEG * EX_SEG + EX_SEG;
+    memset(stage + n, '\n', padded - n);
+    *clean_len = (uint64_t)n;
+    *padded_len = padded;
+    return PSK_OK;
+}
+
+// GPU half of a1: clean stream (pinned host memory) -> sorted unique words + counts in the arena
+static int count_from_stage(psk_ctx *ctx, int sample_idx, const uint8_t *stage, uint64_t clean_len, uint64_t padded)
+{
     SampleList &L = ctx->lists[sample_idx];
     L = SampleList();  // a re-counted sample simply takes fresh arena space
     ctx->have_presence = false;
-
-    uint64_t clean_len = 0;
-    PSK_TRY(upload_clean(ctx, bytes, len, &clean_len));
     if (clean_len >= (1ull << 32)) return psk_fail(ctx, PSK_ERANGE, "sample larger than 4 Gbases");
+    PSK_TRY(dev_reserve(ctx, ctx->raw, padded));
+    PSK_HIP(ctx, hipMemcpyAsync(ctx->raw.p, stage, padded, hipMemcpyHostToDevice, ctx->stream));
     const uint64_t cap = clean_len ? clean_len : 1;
     PSK_TRY(dev_reserve(ctx, ctx->keysA, cap * 8));
     PSK_TRY(dev_reserve(ctx, ctx->keysB, cap * 8));
@@ -402,10 +391,134 @@ extern "C" int psk_count_kmers(psk_ctx *ctx, int sample_idx, const uint8_t *byte
     L.n_unique = nu;
     L.n_total = n;
     L.done = true;
-    if (n_unique) *n_unique = nu;
-    if (n_total) *n_total = n;
     return PSK_OK;
 }
+
+static int ensure_pinned(psk_ctx *ctx, void **buf, size_t *cap, size_t need)
+{
+    if (need <= *cap && *buf) return PSK_OK;
+    if (*buf) (void)hipHostFree(*buf);
+    *buf = nullptr;
+    *cap = 0;
+    const size_t want = need + need / 4;
+    hipError_t e = hipHostMalloc(buf, want, hipHostMallocDefault);
+    if (e != hipSuccess) return psk_fail(ctx, PSK_ENOMEM, "hipHostMalloc(%zu) failed: %s", want, hipGetErrorString(e));
+    *cap = want;
+    return PSK_OK;
+}
+
+extern "C" int psk_count_kmers(psk_ctx *ctx, int sample_idx, const uint8_t *bytes, size_t len, uint64_t *n_unique,
+                               uint64_t *n_total)
+{
+    if (!ctx) return PSK_EINVAL;
+    if (ctx->k == 0) return psk_fail(ctx, PSK_ESTATE, "psk_begin has not been called");
+    if (sample_idx < 0 || sample_idx >= ctx->n_samples) return psk_fail(ctx, PSK_EINVAL, "sample_idx out of range");
+    if (!bytes && len) return psk_fail(ctx, PSK_EINVAL, "null input");
+    PSK_HIP(ctx, hipSetDevice(ctx->device));
+    PSK_TRY(ensure_pinned(ctx, &ctx->pinned, &ctx->pinned_cap, len + 2 * EX_SEG));
+    uint64_t clean_len = 0, padded = 0;
+    int rc = frame_into(static_cast<uint8_t *>(ctx->pinned), ctx->pinned_cap, bytes, len, &clean_len, &padded);
+    if (rc) return psk_fail(ctx, rc, "framing failed");
+    PSK_TRY(count_from_stage(ctx, sample_idx, static_cast<uint8_t *>(ctx->pinned), clean_len, padded));
+    if (n_unique) *n_unique = ctx->lists[sample_idx].n_unique;
+    if (n_total) *n_total = ctx->lists[sample_idx].n_total;
+    return PSK_OK;
+}
+
+// Batch form: `n_threads` host threads frame samples ahead into a ring of pinned buffers while the calling
+// thread drives the GPU half of the samples in order, so host tokenisation overlaps device work.
+extern "C" int psk_count_kmers_batch(psk_ctx *ctx, int first_sample_idx, int n, const uint8_t *const *bytes,
+                                     const size_t *lens, uint64_t *n_unique, uint64_t *n_total, int n_threads)
+{
+    if (!ctx) return PSK_EINVAL;
+    if (ctx->k == 0) return psk_fail(ctx, PSK_ESTATE, "psk_begin has not been called");
+    if (n < 0 || first_sample_idx < 0 || first_sample_idx + n > ctx->n_samples)
+        return psk_fail(ctx, PSK_EINVAL, "sample range out of bounds");
+    if (n == 0) return PSK_OK;
+    if (!bytes || !lens) return psk_fail(ctx, PSK_EINVAL, "null input");
+    PSK_HIP(ctx, hipSetDevice(ctx->device));
+    if (n_threads < 1) n_threads = 1;
+    if (n_threads > 16) n_threads = 16;
+    if (n_threads > n) n_threads = n;
+    const int R = n_threads + 1;  // ring slots
+    size_t max_len = 0;
+    for (int i = 0; i < n; i++) {
+        if (!bytes[i] && lens[i]) return psk_fail(ctx, PSK_EINVAL, "null input %d", i);
+        if (lens[i] > max_len) max_len = lens[i];
+    }
+    if ((int)ctx->ring.size() < R) { ctx->ring.resize(R, nullptr); ctx->ring_cap.resize(R, 0); }
+    for (int s = 0; s < R; s++) PSK_TRY(ensure_pinned(ctx, &ctx->ring[s], &ctx->ring_cap[s], max_len + 2 * EX_SEG));
+
+    std::mutex mu;
+    std::condition_variable cv;
+    std::vector<int> state(n, 0);          // 0 pending, 1 framed, -1 framing failed
+    std::vector<uint64_t> clen(n, 0), plen(n, 0);
+    int consumed = 0;                      // samples whose GPU half is finished
+    bool abort = false;
+    std::atomic<int> next(0);
+    auto worker = [&]() {
+        for (;;) {
+            const int i = next.fetch_add(1);
+            if (i >= n) return;
+            {
+                std::unique_lock<std::mutex> lk(mu);
+                cv.wait(lk, [&] { return abort || consumed > i - R; });  // slot i % R is free again
+                if (abort) return;
+            }
+            uint64_t c = 0, p = 0;
+            const int rc = frame_into(static_cast<uint8_t *>(ctx->ring[i % R]), ctx->ring_cap[i % R], bytes[i], lens[i], &c, &p);
+            {
+                std::lock_guard<std::mutex> lk(mu);
+                clen[i] = c; plen[i] = p;
+                state[i] = rc ? -1 : 1;
+            }
+            cv.notify_all();
+        }
+    };
+    std::vector<std::thread> pool;
+    for (int t = 0; t < n_threads; t++) pool.emplace_back(worker);
+    int rc = PSK_OK;
+    for (int i = 0; i < n && rc == PSK_OK; i++) {
+        {
+            std::unique_lock<std::mutex> lk(mu);
+            cv.wait(lk, [&] { return state[i] != 0; });
+            if (state[i] < 0) rc = psk_fail(ctx, PSK_ERANGE, "framing of sample %d failed", first_sample_idx + i);
+        }
+        if (rc == PSK_OK)
+            rc = count_from_stage(ctx, first_sample_idx + i, static_cast<uint8_t *>(ctx->ring[i % R]), clen[i], plen[i]);
+        if (rc == PSK_OK) {
+            if (n_unique) n_unique[i] = ctx->lists[first_sample_idx + i].n_unique;
+            if (n_total) n_total[i] = ctx->lists[first_sample_idx + i].n_total;
+        }
+        {
+            std::lock_guard<std::mutex> lk(mu);
+            consumed = i + 1;
+            if (rc != PSK_OK) abort = true;
+        }
+        cv.notify_all();
+    }
+    {
+        std::lock_guard<std::mutex> lk(mu);
+        if (rc != PSK_OK) abort = true;
+    }
+    cv.notify_all();
+    for (auto &t : pool) t.join();
+    return rc;
+}
+
+namespace {
+// frame into the context's single pinned buffer and upload (dictionary counting, MinHash)
+int upload_clean(psk_ctx *ctx, const uint8_t *bytes, size_t len, uint64_t *clean_len)
+{
+    PSK_TRY(ensure_pinned(ctx, &ctx->pinned, &ctx->pinned_cap, len + 2 * EX_SEG));
+    uint64_t padded = 0;
+    int rc = frame_into(static_cast<uint8_t *>(ctx->pinned), ctx->pinned_cap, bytes, len, clean_len, &padded);
+    if (rc) return psk_fail(ctx, rc, "framing failed");
+    PSK_TRY(dev_reserve(ctx, ctx->raw, padded));
+    PSK_HIP(ctx, hipMemcpyAsync(ctx->raw.p, ctx->pinned, padded, hipMemcpyHostToDevice, ctx->stream));
+    return PSK_OK;
+}
+}  // namespace
 
 extern "C" int psk_get_list(psk_ctx *ctx, int sample_idx, uint64_t *words, uint32_t *freqs, uint64_t cap)
 {

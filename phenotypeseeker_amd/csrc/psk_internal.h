@@ -68,6 +68,8 @@ struct psk_ctx {
     DevBuf raw, keysA, keysB, valsA, valsB, hist, scan_tmp, flags, starts, misc;
     void *pinned = nullptr;   // pinned host staging for the clean stream
     size_t pinned_cap = 0;
+    std::vector<void *> ring;       // pinned ring of the batch counter
+    std::vector<size_t> ring_cap;
     void *scan_pinned = nullptr;  // pinned staging for the scan's masks / weights
     size_t scan_pinned_cap = 0;
 

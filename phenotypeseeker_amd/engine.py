@@ -69,6 +69,18 @@ class PskContext:
                                               ctypes.byref(nt)), "psk_count_kmers")
         return nu.value, nt.value
 
+    def count_kmers_batch(self, first_idx, datas, n_threads=4):
+        """Counts several samples in one call; host tokenisation runs ahead on n_threads threads."""
+        datas = [bytes(d) for d in datas]
+        n = len(datas)
+        arr = (ctypes.c_char_p * n)(*datas)
+        lens = (ctypes.c_size_t * n)(*[len(d) for d in datas])
+        nu = np.zeros(n, dtype=np.uint64)
+        nt = np.zeros(n, dtype=np.uint64)
+        self._check(self._lib.psk_count_kmers_batch(self._h, int(first_idx), n, arr, lens, _ptr(nu), _ptr(nt),
+                                                    int(n_threads)), "psk_count_kmers_batch")
+        return nu.astype(np.int64).tolist(), nt.astype(np.int64).tolist()
+
     def get_list(self, sample_idx, n_unique):
         words = np.empty(n_unique, dtype=np.uint64)
         freqs = np.empty(n_unique, dtype=np.uint32)

@@ -87,6 +87,23 @@ class Samples:
         stderr_print.print_progress("lists generated.")
 
     @classmethod
+    def get_kmer_lists_batched(cls, ctx, samples, n_threads, chunk=16):
+        """All samples through psk_count_kmers_batch: files are read (and inflated) by a small thread
+        pool, host tokenisation runs ahead of the GPU inside the library."""
+        from concurrent.futures import ThreadPoolExecutor
+        with ThreadPoolExecutor(max_workers=n_threads) as pool:
+            for lo in range(0, len(samples), chunk):
+                part = samples[lo:lo + chunk]
+                datas = list(pool.map(lambda s: formats.read_sequence_file(s.address), part))
+                nu, nt = ctx.count_kmers_batch(lo, datas, n_threads)
+                for j, s in enumerate(part):
+                    s.n_unique, s.n_total = nu[j], nt[j]
+                    if cls.use_weights:  # was: mash sketch -r <address> -o K-mer_lists/<name>  (:386-390)
+                        s.sketch = ctx.minhash_sketch(datas[j]).tolist()
+                    stderr_print.currentSampleNum += 1
+                    stderr_print.print_progress("lists generated.")
+
+    @classmethod
     def get_weights(cls):
         """was: mash paste / mash dist -> NJ tree -> GSC weights (:392-503)"""
         from . import weights as _w
@@ -635,8 +652,7 @@ def modeling(args):
             lo, hi = _dist.slab_bounds(k, group.world, group.rank)
             ctx.begin(k, Samples.no_samples, lo, hi)
             _err(GREEN % "Generating the k-mer lists for input samples:" + "\n")
-            for i, sample in enumerate(Input.samples.values()):
-                sample.get_kmer_lists(ctx, i)
+            Samples.get_kmer_lists_batched(ctx, list(Input.samples.values()), max(1, min(int(Input.num_threads), 8)))
             _err("\n" + GREEN % "Generating the k-mer feature vector." + "\n")
             m_local = Samples.get_feature_vector(ctx)
             _err(GREEN % "Mapping samples to the feature vector space:" + "\n")

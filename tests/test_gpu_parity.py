@@ -438,3 +438,21 @@ def test_abi_misuse_returns_errors_not_crashes(ctx):
         assert c.chi2_scan(np.array([1, 0], np.int8), None, 1, 2, 1.5, True, 2) >= 0
     with pytest.raises(PskError):
         PskContext(99)
+
+
+def test_batch_counting_equals_single_calls(ctx, oracle):
+    ds = load_dataset("ds_bonf")
+    k, names = ds["meta"]["k"], ds["names"]
+    datas = [ds["files"][n] for n in names]
+    ctx.begin(k, len(names))
+    nu, nt = ctx.count_kmers_batch(0, datas[:30], 3)
+    nu2, nt2 = ctx.count_kmers_batch(30, datas[30:], 8)
+    for i, nm in enumerate(names):
+        m = ds["meta"]["lists"][nm]
+        assert ((nu + nu2)[i], (nt + nt2)[i]) == (m["n_unique"], m["n_total"])
+        w, f = ctx.get_list(i, m["n_unique"])
+        assert hashlib.sha256(oracle.list_bytes(k, w, f)).hexdigest() == m["sha256"]
+    assert ctx.build_presence() == ds["meta"]["n_union"]
+    from phenotypeseeker_amd._lib import PskError
+    with pytest.raises(PskError):
+        ctx.count_kmers_batch(40, datas[:10], 2)   # runs past the declared sample count
