@@ -90,8 +90,9 @@ __device__ __forceinline__ double chi2_exact(double A, double B, double C, doubl
 }
 
 template <int G, bool WEIGHTED>
-__global__ __launch_bounds__(SC_THREADS) void chi2_scan_kernel(const ScanArgs P)
+__global__ __launch_bounds__(SC_THREADS) void chi2_scan_kernel(const ScanArgs P, const int use_lds)
 {
+    extern __shared__ double sm[];  // weighted only: w1[wpr*64] | w0[wpr*64] when use_lds
     constexpr int RPW = 64 / G;  // rows per wave step
     const int lane = threadIdx.x & 63;
     const int g = lane & (G - 1);
@@ -102,6 +103,14 @@ __global__ __launch_bounds__(SC_THREADS) void chi2_scan_kernel(const ScanArgs P)
     const bool has_chunk = g < P.cpr;
     uint64_t m1a = 0, m1b = 0, m0a = 0, m0b = 0;
     if (has_chunk) { m1a = P.m1[2 * g]; m1b = P.m1[2 * g + 1]; m0a = P.m0[2 * g]; m0b = P.m0[2 * g + 1]; }
+    const double *w1 = P.w1, *w0 = P.w0;
+    if (WEIGHTED && use_lds) {
+        const int nw = 2 * P.cpr * 64;
+        for (int i = threadIdx.x; i < nw; i += SC_THREADS) { sm[i] = P.w1[i]; sm[nw + i] = P.w0[i]; }
+        __syncthreads();
+        w1 = sm;
+        w0 = sm + nw;
+    }
 
     for (uint64_t s0 = wave_global * SC_UNROLL; s0 < n_steps; s0 += total_waves * SC_UNROLL) {
         u32x4 x[SC_UNROLL];
@@ -140,49 +149,48 @@ __global__ __launch_bounds__(SC_THREADS) void chi2_scan_kernel(const ScanArgs P)
             const int n_w = (int)(a + c);
             const int n_wo = (P.n1 - (int)a) + (P.n0 - (int)c);
             const bool freq_ok = (row < P.M) && !(n_w < P.min_samples || n_wo < 2 || n_w > P.max_samples);
-            if (!freq_ok) continue;
-            double A, B, C, D;
             if (WEIGHTED) {
-                double wa = 0.0, wc = 0.0;
-                if (has_chunk) {
-                    uint64_t v = xa & (m1a | m0a);
-                    while (v) {
-                        const int b = __ffsll((unsigned long long)v) - 1;
-                        v &= v - 1;
-                        wa += P.w1[(2 * g) * 64 + b];
-                        wc += P.w0[(2 * g) * 64 + b];
+                // rows that passed the frequency filter are handled one at a time by the whole wave:
+                // lane l owns samples l, l+64, ... (weights in LDS), row words come from the loading
+                // lanes' registers by scalar lane reads, the two class sums finish with DPP reductions
+                const int wpr = 2 * P.cpr;
+                const int wreg = (P.cpr <= G) ? wpr : 2 * G;
+                uint64_t todo = __ballot(freq_ok && g == 0);
+                while (todo) {
+                    const int src = __ffsll((unsigned long long)todo) - 1;
+                    todo &= todo - 1;
+                    const uint64_t r = (s0 + u) * RPW + (uint64_t)(src / G);
+                    const int r_nw = __builtin_amdgcn_readlane(n_w, src);
+                    const uint64_t *rp = reinterpret_cast<const uint64_t *>(P.bits) + r * (uint64_t)wpr;
+                    double wa = 0.0, wc = 0.0;
+                    for (int t = 0; t < wpr; t++) {
+                        const uint64_t xw = (t < wreg) ? psk_readlane_u64((t & 1) ? xb : xa, src + (t >> 1)) : rp[t];
+                        const bool pres = (xw >> lane) & 1;
+                        wa += pres ? w1[t * 64 + lane] : 0.0;   // w1 is zero unless the phenotype is 1
+                        wc += pres ? w0[t * 64 + lane] : 0.0;
                     }
-                    v = xb & (m1b | m0b);
-                    while (v) {
-                        const int b = __ffsll((unsigned long long)v) - 1;
-                        v &= v - 1;
-                        wa += P.w1[(2 * g + 1) * 64 + b];
-                        wc += P.w0[(2 * g + 1) * 64 + b];
-                    }
-                    for (int ch = g + G; ch < P.cpr; ch += G) {
-                        const u32x4 y = P.bits[row * (uint64_t)P.cpr + ch];
-                        uint64_t yy[2] = {((uint64_t)y.y << 32) | y.x, ((uint64_t)y.w << 32) | y.z};
-                        for (int h = 0; h < 2; h++) {
-                            uint64_t vv = yy[h] & (P.m1[2 * ch + h] | P.m0[2 * ch + h]);
-                            while (vv) {
-                                const int b = __ffsll((unsigned long long)vv) - 1;
-                                vv &= vv - 1;
-                                wa += P.w1[(2 * ch + h) * 64 + b];
-                                wc += P.w0[(2 * ch + h) * 64 + b];
-                            }
-                        }
+                    wa = psk_wave_sum_f64_dpp(wa);
+                    wc = psk_wave_sum_f64_dpp(wc);
+                    const double A = wa, B = P.W1 - wa, C = wc, D = P.W0 - wc;
+                    const double R1 = A + B, R0 = C + D, K1 = A + C, K0 = B + D, T = R1 + R0;
+                    const double det = A * D - B * C;
+                    const double lhs = T * det * det, rhs = P.thr * R1 * R0 * K1 * K0;
+                    if (lhs < rhs * (1.0 - 1e-9)) continue;
+                    const double stat = chi2_exact(A, B, C, D);
+                    const double p = exp(-0.5 * stat);
+                    const bool keep = (P.omit_B && p < P.pcut) || (p < P.pcut_bonf);
+                    if (keep && lane == 0) {
+                        const uint64_t idx = reserve_slot(P);
+                        P.res_row[idx] = r;
+                        P.res_stat[idx] = stat;
+                        P.res_p[idx] = p;
+                        P.res_nw[idx] = r_nw;
                     }
                 }
-#pragma unroll
-                for (int d = G / 2; d > 0; d >>= 1) {
-                    wa += psk_shfl_xor_f64(wa, d);
-                    wc += psk_shfl_xor_f64(wc, d);
-                }
-                A = wa; B = P.W1 - wa; C = wc; D = P.W0 - wc;
-            } else {
-                A = (double)a; B = (double)(P.n1 - (int)a); C = (double)c; D = (double)(P.n0 - (int)c);
+                continue;
             }
-            if (g != 0) continue;
+            if (!freq_ok || g != 0) continue;
+            const double A = (double)a, B = (double)(P.n1 - (int)a), C = (double)c, D = (double)(P.n0 - (int)c);
             // division-free pre-test: chi2 = T (AD - BC)^2 / (R1 R0 K1 K0)
             const double R1 = A + B, R0 = C + D, K1 = A + C, K0 = B + D, T = R1 + R0;
             const double det = A * D - B * C;
@@ -376,14 +384,18 @@ __global__ __launch_bounds__(SC_THREADS) void ttest_scan_kernel(const ScanArgs P
 template <bool WEIGHTED>
 void launch_chi2(int G, dim3 grid, hipStream_t st, const ScanArgs &a)
 {
+    // weighted: the two gated weight vectors live in LDS when they fit in 64 KiB (<= 4096 samples)
+    const size_t need = WEIGHTED ? (size_t)a.cpr * 2 * 64 * 2 * sizeof(double) : 0;
+    const int use_lds = (WEIGHTED && need <= 65536) ? 1 : 0;
+    const size_t lds = use_lds ? need : 0;
     switch (G) {
-    case 1: chi2_scan_kernel<1, WEIGHTED><<<grid, SC_THREADS, 0, st>>>(a); break;
-    case 2: chi2_scan_kernel<2, WEIGHTED><<<grid, SC_THREADS, 0, st>>>(a); break;
-    case 4: chi2_scan_kernel<4, WEIGHTED><<<grid, SC_THREADS, 0, st>>>(a); break;
-    case 8: chi2_scan_kernel<8, WEIGHTED><<<grid, SC_THREADS, 0, st>>>(a); break;
-    case 16: chi2_scan_kernel<16, WEIGHTED><<<grid, SC_THREADS, 0, st>>>(a); break;
-    case 32: chi2_scan_kernel<32, WEIGHTED><<<grid, SC_THREADS, 0, st>>>(a); break;
-    default: chi2_scan_kernel<64, WEIGHTED><<<grid, SC_THREADS, 0, st>>>(a); break;
+    case 1: chi2_scan_kernel<1, WEIGHTED><<<grid, SC_THREADS, lds, st>>>(a, use_lds); break;
+    case 2: chi2_scan_kernel<2, WEIGHTED><<<grid, SC_THREADS, lds, st>>>(a, use_lds); break;
+    case 4: chi2_scan_kernel<4, WEIGHTED><<<grid, SC_THREADS, lds, st>>>(a, use_lds); break;
+    case 8: chi2_scan_kernel<8, WEIGHTED><<<grid, SC_THREADS, lds, st>>>(a, use_lds); break;
+    case 16: chi2_scan_kernel<16, WEIGHTED><<<grid, SC_THREADS, lds, st>>>(a, use_lds); break;
+    case 32: chi2_scan_kernel<32, WEIGHTED><<<grid, SC_THREADS, lds, st>>>(a, use_lds); break;
+    default: chi2_scan_kernel<64, WEIGHTED><<<grid, SC_THREADS, lds, st>>>(a, use_lds); break;
     }
 }
 
