@@ -214,3 +214,57 @@ def test_outer_cv_and_holdout_modes(tmp_path):
     block = txt.split("Training set:")[1].split("Test set:")[0]
     listed = [l.split()[0] for l in block.splitlines() if l.startswith("S0")]
     assert listed == [rows[1 + i][0] for i in tr]
+
+
+def test_kmerdb_real_counts_and_mpheno(tmp_path, oracle):
+    """--kmerDB (glistcompare -i of modeling.py:367-372), -rc (counts instead of presence in the ML matrix,
+    :693-695) and --mpheno (second phenotype column only) through the CLI, against the oracle."""
+    from phenotypeseeker_amd.synth import GenomeSet
+    gs = GenomeSet(24, 6000, seed=91, gene_len=120)
+    k, n = 13, gs.n
+    os.chdir(tmp_path)
+    rows = ["ID\tAddresses\tdummy\tPheno"]
+    files = []
+    for i in range(n):
+        name, fa = gs.sample(i)
+        if i % 3 == 0:   # duplicate a stretch so that some k-mers occur twice in the sample
+            body = fa.split(b"\n", 1)[1].replace(b"\n", b"")
+            fa = fa + b">dup\n" + body[2980:3100] + b"\n"
+        files.append(fa)
+        with open(name + ".fasta", "wb") as f:
+            f.write(fa)
+        rows.append("%s\t%s.fasta\t%d\t%d" % (name, name, (i // 3) % 2, gs.phenotype(i)))
+    with open("data.pheno", "w") as f:
+        f.write("\n".join(rows) + "\n")
+    # database = the planted gene +- flanks of the ancestor
+    anc = gs.ancestor
+    db_codes = np.concatenate([anc[2500:3000], gs.gene, anc[3000:3300]])
+    from phenotypeseeker_amd.synth import wrap_fasta
+    with open("db.fasta", "wb") as f:
+        f.write(wrap_fasta("db", db_codes))
+    _run(tmp_path, ["modeling", "data.pheno", "--mpheno", "2", "-rc", "--kmerDB", "db.fasta", "--omit_B_correction",
+                    "--pvalue", "0.5"])
+    assert not os.path.exists("chi2_results_dummy.tsv")
+    head, got = read_results_tsv("chi2_results_Pheno.tsv")
+    lists = [oracle.count_kmers(fa, k) for fa in files]
+    dbw = oracle.count_kmers(open("db.fasta", "rb").read(), k)[0]
+    uw = oracle.intersect(oracle.union([l[0] for l in lists]), dbw)
+    bits = oracle.presence_bits([l[0] for l in lists], uw)
+    pheno = [gs.phenotype(i) for i in range(n)]
+    ref = oracle.chi2_scan(bits, pheno, np.ones(n), n, 2, n - 2, 0.5, True, len(uw))
+    keep = np.nonzero(ref["keep"])[0]
+    want = {oracle.word_to_kmer(uw[r], k): (repr(oracle.round2(ref["stat"][r])), oracle.pstring(ref["p"][r])) for r in keep}
+    assert {g[0] for g in got} == set(want) and len(want) > 30
+    for g in got:
+        assert (g[1], g[2]) == want[g[0]]
+    with open("Pheno_MLdf.csv") as f:
+        ml = list(csv.reader(f))
+    cols = ml[0][1:-2]
+    saw_multi = False
+    for j, kmer in enumerate(cols):
+        w = oracle.canonical_word(oracle.kmer_to_word(kmer), k)
+        for i in range(n):
+            cnt = oracle.map_counts(lists[i][0], lists[i][1], np.array([w], dtype=np.uint64))[0]
+            assert int(ml[1 + i][1 + j]) == cnt
+            saw_multi |= cnt > 1
+    assert saw_multi
