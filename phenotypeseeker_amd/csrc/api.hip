@@ -123,6 +123,7 @@ extern "C" void psk_free(psk_ctx *ctx)
     for (DevBuf *b : bufs) dev_release(*b);
     if (ctx->pinned) (void)hipHostFree(ctx->pinned);
     if (ctx->scan_pinned) (void)hipHostFree(ctx->scan_pinned);
+    if (ctx->cnt_pinned) (void)hipHostFree(ctx->cnt_pinned);
     for (void *r : ctx->ring) if (r) (void)hipHostFree(r);
     if (ctx->ev0) (void)hipEventDestroy(ctx->ev0);
     if (ctx->ev1) (void)hipEventDestroy(ctx->ev1);

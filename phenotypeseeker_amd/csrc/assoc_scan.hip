@@ -452,10 +452,19 @@ int setup_results(psk_ctx *ctx, ScanArgs &a, dim3 grid, int G, int unroll)
 }
 
 // pulls the per-segment counters to the host; n_pass = their sum
+// stream-ordered read-back of the counters into pinned host memory (call before the final sync)
+int enqueue_counts_readback(psk_ctx *ctx, const ScanArgs &a)
+{
+    const size_t bytes = (size_t)SC_NSEG * SC_CNT_STRIDE * 4;
+    if (!ctx->cnt_pinned) PSK_HIP(ctx, hipHostMalloc(&ctx->cnt_pinned, bytes, hipHostMallocDefault));
+    PSK_HIP(ctx, hipMemcpyAsync(ctx->cnt_pinned, a.counter, bytes, hipMemcpyDeviceToHost, ctx->stream));
+    return PSK_OK;
+}
+
+// per-segment counters (already copied to pinned memory and synchronised); n_pass = their sum
 int fetch_counts(psk_ctx *ctx, const ScanArgs &a)
 {
-    std::vector<uint32_t> raw((size_t)SC_NSEG * SC_CNT_STRIDE);
-    PSK_HIP(ctx, hipMemcpy(raw.data(), a.counter, raw.size() * 4, hipMemcpyDeviceToHost));
+    const uint32_t *raw = static_cast<const uint32_t *>(ctx->cnt_pinned);
     ctx->seg_counts.assign(SC_NSEG, 0);
     uint64_t tot = 0;
     for (int s = 0; s < SC_NSEG; s++) {
@@ -471,7 +480,8 @@ int fetch_counts(psk_ctx *ctx, const ScanArgs &a)
 // one block per segment: copies the segment's entries to their place in the contiguous arrays
 __global__ void pack_segments_kernel(const uint8_t *__restrict__ src, uint64_t cap, uint32_t seg_cap,
                                      const uint32_t *__restrict__ counts, const uint64_t *__restrict__ offsets,
-                                     uint8_t *__restrict__ dst, uint64_t n)
+                                     uint8_t *__restrict__ dst, uint64_t n, const uint64_t *__restrict__ union_words,
+                                     uint64_t *__restrict__ words_out)
 {
     const uint32_t seg = blockIdx.x;
     const uint32_t c = counts[seg];
@@ -482,6 +492,7 @@ __global__ void pack_segments_kernel(const uint8_t *__restrict__ src, uint64_t c
 #pragma unroll
         for (int f = 0; f < 5; f++) d[(uint64_t)f * n + out0 + i] = r[(uint64_t)f * cap + in0 + i];
         reinterpret_cast<int32_t *>(dst + 40 * n)[out0 + i] = reinterpret_cast<const int32_t *>(src + 40 * cap)[in0 + i];
+        words_out[out0 + i] = union_words[r[in0 + i]];  // the k-mer word of the surviving row
     }
 }
 
@@ -509,7 +520,8 @@ int run_chi2(psk_ctx *ctx, ScanArgs &a, bool weighted, int reps, double *ms_tota
         else launch_chi2<false>(G, grid, ctx->stream, a);
         PSK_HIP(ctx, hipGetLastError());
         PSK_HIP(ctx, hipEventRecord(ctx->ev1, ctx->stream));
-        PSK_HIP(ctx, hipEventSynchronize(ctx->ev1));
+        if (r == reps - 1) PSK_TRY(enqueue_counts_readback(ctx, a));  // rides on the same synchronisation
+        PSK_HIP(ctx, hipStreamSynchronize(ctx->stream));
         float ms = 0;
         PSK_HIP(ctx, hipEventElapsedTime(&ms, ctx->ev0, ctx->ev1));
         *ms_total += ms;
@@ -667,7 +679,8 @@ extern "C" int psk_ttest_scan(psk_ctx *ctx, const double *pheno, const uint8_t *
         launch_ttest(G, grid, ctx->stream, a);
         PSK_HIP(ctx, hipGetLastError());
         PSK_HIP(ctx, hipEventRecord(ctx->ev1, ctx->stream));
-        PSK_HIP(ctx, hipEventSynchronize(ctx->ev1));
+        PSK_TRY(enqueue_counts_readback(ctx, a));
+        PSK_HIP(ctx, hipStreamSynchronize(ctx->stream));
         float ms = 0;
         PSK_HIP(ctx, hipEventElapsedTime(&ms, ctx->ev0, ctx->ev1));
         ctx->last_scan_ms = ms;
@@ -692,15 +705,17 @@ extern "C" int psk_get_results(psk_ctx *ctx, uint64_t *row_idx, uint64_t *words,
         std::vector<uint64_t> offs(SC_NSEG);
         uint64_t acc = 0;
         for (int sgm = 0; sgm < SC_NSEG; sgm++) { offs[sgm] = acc; acc += ctx->seg_counts[sgm]; }
-        PSK_TRY(dev_reserve(ctx, ctx->res_sorted, n * 44 + 64 + SC_NSEG * 12));
-        uint8_t *aux = ctx->res_sorted.as<uint8_t>() + ((n * 44 + 63) & ~63ull);
+        PSK_TRY(dev_reserve(ctx, ctx->res_sorted, n * 52 + 128 + SC_NSEG * 12));
+        uint8_t *aux = ctx->res_sorted.as<uint8_t>() + ((n * 52 + 63) & ~63ull);
         uint32_t *d_cnt = reinterpret_cast<uint32_t *>(aux + SC_NSEG * 8);
         PSK_HIP(ctx, hipMemcpyAsync(aux, offs.data(), SC_NSEG * 8, hipMemcpyHostToDevice, ctx->stream));
         PSK_HIP(ctx, hipMemcpyAsync(d_cnt, ctx->seg_counts.data(), SC_NSEG * 4, hipMemcpyHostToDevice, ctx->stream));
         pack_segments_kernel<<<SC_NSEG, 256, 0, ctx->stream>>>(ctx->res.as<uint8_t>(), ctx->res_seg_cap * SC_NSEG,
                                                              (uint32_t)ctx->res_seg_cap, d_cnt,
                                                              reinterpret_cast<const uint64_t *>(aux),
-                                                             ctx->res_sorted.as<uint8_t>(), n);
+                                                             ctx->res_sorted.as<uint8_t>(), n,
+                                                             ctx->union_words.as<uint64_t>(),
+                                                             reinterpret_cast<uint64_t *>(ctx->res_sorted.as<uint8_t>() + ((n * 44 + 7) & ~7ull)));
         PSK_HIP(ctx, hipGetLastError());
         PSK_HIP(ctx, hipStreamSynchronize(ctx->stream));
     }
@@ -722,17 +737,14 @@ extern "C" int psk_get_results(psk_ctx *ctx, uint64_t *row_idx, uint64_t *words,
     std::iota(ord.begin(), ord.end(), 0);
     std::sort(ord.begin(), ord.end(), [&](uint64_t x, uint64_t y) { return rows[x] < rows[y]; });
     std::vector<uint64_t> wbuf;
-    if (words) {
-        // gather the words of the passing rows on the device side would need another kernel;
-        // the union list is small compared with the matrix, fetch the needed entries one by one
-        // only when few, else the whole list
-        wbuf.resize(ctx->n_kmers);
-        PSK_HIP(ctx, hipMemcpy(wbuf.data(), ctx->union_words.p, ctx->n_kmers * 8, hipMemcpyDeviceToHost));
+    if (words) {  // gathered on the device by pack_segments_kernel, same (segment) order as the other columns
+        wbuf.resize(n);
+        PSK_HIP(ctx, hipMemcpy(wbuf.data(), b + ((n * 44 + 7) & ~7ull), n * 8, hipMemcpyDeviceToHost));
     }
     for (uint64_t i = 0; i < n; i++) {
         const uint64_t j = ord[i];
         if (row_idx) row_idx[i] = rows[j];
-        if (words) words[i] = wbuf[rows[j]];
+        if (words) words[i] = wbuf[j];
         if (stat) stat[i] = st[j];
         if (p) p[i] = pv[j];
         if (mean_x) mean_x[i] = (ctx->last_scan_kind == 2) ? mx[j] : 0.0;

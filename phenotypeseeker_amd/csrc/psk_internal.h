@@ -72,6 +72,7 @@ struct psk_ctx {
     std::vector<size_t> ring_cap;
     void *scan_pinned = nullptr;  // pinned staging for the scan's masks / weights
     size_t scan_pinned_cap = 0;
+    void *cnt_pinned = nullptr;   // pinned landing buffer of the scan's result counters
 
     // presence matrix
     uint64_t n_kmers = 0;
