@@ -58,6 +58,7 @@ struct ScanArgs {
     // filters
     int min_samples, max_samples;
     double pcut, pcut_bonf, thr;  // thr: statistic threshold of the division-free pre-test
+    double tcrit;                 // t-test: |t| a row must exceed to be a candidate
     int omit_B;
     // output (SoA), counter
     uint64_t *res_row;
@@ -247,7 +248,7 @@ __device__ double dev_betainc(double a, double b, double x)
     return 1.0 - bt * dev_betacf(b, a, 1.0 - x) / b;
 }
 
-__device__ double dev_t_two_sided_p(double t, double df)
+__device__ __attribute__((noinline)) double dev_t_two_sided_p(double t, double df)
 {
     if (isnan(t) || isnan(df) || !(df > 0)) return NAN;
     if (isinf(t)) return 0.0;
@@ -263,33 +264,74 @@ __device__ __forceinline__ double wave_sum_f64(double v)
 
 // Welch scan.  Phase A is the chi2 kernel's streaming shape (one 16-byte load per lane per row, popcount
 // against the non-NA mask, group reduce, frequency filter of modeling.py:731).  Rows that pass are then
-// handled one at a time by the WHOLE wave (phase B): lane l owns samples l, l+64, ... so the phenotype
-// values / weights are read from LDS conflict-free and the two passes of weighted sums (DescrStatsW,
-// ddof 0) finish with a 64-lane butterfly.  r01 ran the passes inside the owning lane group (G lanes,
-// per-bit global loads): 80 ms for 16 M x 1024; this shape is bound by the f64 work of surviving rows only.
+// handled one at a time by the WHOLE wave (phase B): lane l owns samples l, l+64, ...; the phenotype values
+// (shifted by their global weighted mean, so that one pass of weighted moments suffices) and the weights
+// are read from LDS conflict-free, row words come from the loading lanes' registers by scalar lane reads,
+// and six DPP wave sums give (n, sum, sum of squares) of both groups.  The sums of up to 64 rows are
+// queued in LDS and the tail (means, variances, t, erfc pre-test, incomplete beta) is then evaluated
+// lane-parallel, one row per lane (phase C).
+constexpr int TT_QUEUE = 64;
+constexpr int TT_SLOT = 8;  // doubles per queued row: nx sx qx ny sy qy row n_with
+
 template <int G>
-__global__ __launch_bounds__(SC_THREADS) void ttest_scan_kernel(const ScanArgs P, const int use_lds)
+__global__ __launch_bounds__(SC_THREADS) void ttest_scan_kernel(const ScanArgs P, const int use_lds, const double mu)
 {
-    extern __shared__ double sm[];  // val[wpr*64] | wt[wpr*64] when use_lds
+    extern __shared__ double sm[];  // queue[4 waves][TT_QUEUE][TT_SLOT] | val[wpr*64] | wt[wpr*64] (when use_lds)
     constexpr int RPW = 64 / G;
-    const int lane = threadIdx.x & 63;
+    const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
     const int g = lane & (G - 1);
     const int rsub = lane / G;
     const int wpr = 2 * P.cpr;
     const uint64_t n_steps = (P.M + RPW - 1) / RPW;
-    const uint64_t wave_global = (uint64_t)blockIdx.x * (SC_THREADS / 64) + (threadIdx.x >> 6);
+    const uint64_t wave_global = (uint64_t)blockIdx.x * (SC_THREADS / 64) + wid;
     const uint64_t total_waves = (uint64_t)gridDim.x * (SC_THREADS / 64);
     const bool has_chunk = g < P.cpr;
-    const double *val = P.val, *wt = P.wt;
+    double *queue = sm + (size_t)wid * TT_QUEUE * TT_SLOT;
+    const double *val = P.val, *wt = P.wt;  // val holds v - mu
     if (use_lds) {
-        for (int i = threadIdx.x; i < wpr * 64; i += SC_THREADS) { sm[i] = P.val[i]; sm[wpr * 64 + i] = P.wt[i]; }
+        double *lv = sm + (size_t)(SC_THREADS / 64) * TT_QUEUE * TT_SLOT;
+        for (int i = threadIdx.x; i < wpr * 64; i += SC_THREADS) { lv[i] = P.val[i]; lv[wpr * 64 + i] = P.wt[i]; }
         __syncthreads();
-        val = sm;
-        wt = sm + wpr * 64;
+        val = lv;
+        wt = lv + wpr * 64;
     }
     uint64_t mva = 0, mvb = 0;
     if (has_chunk) { mva = P.mvalid[2 * g]; mvb = P.mvalid[2 * g + 1]; }
     const uint64_t *bits64 = reinterpret_cast<const uint64_t *>(P.bits);
+    const int wreg = (P.cpr <= G) ? wpr : 2 * G;  // words of a row held in the group's registers
+    int q = 0;  // queued rows (wave-uniform)
+
+    // phase C: one queued row per lane
+    auto flush = [&]() {
+        if (lane < q) {
+            const double *sl = queue + lane * TT_SLOT;
+            const double nx = sl[0], sx = sl[1], qx = sl[2], ny = sl[3], sy = sl[4], qy = sl[5];
+            const uint64_t r = (uint64_t)__double_as_longlong(sl[6]);
+            const int r_nw = (int)__double_as_longlong(sl[7]);
+            const double dx = sx / nx, dy = sy / ny;              // group means minus mu
+            const double vx = (qx - sx * dx) / nx, vy = (qy - sy * dy) / ny;  // ddof = 0
+            const double sem1 = vx / (nx - 1.0), sem2 = vy / (ny - 1.0);
+            const double semsum = sem1 + sem2;
+            const double tstat = (dx - dy) / sqrt(semsum);
+            // Student's t has heavier tails than the normal, p_t >= erfc(|t|/sqrt 2): rows with
+            // |t| <= t_crit (erfc(t_crit/sqrt 2) = cut, solved on the host) cannot pass.  Candidates are
+            // stored with their Satterthwaite df in the p slot; ttest_finalize_kernel turns that into
+            // the exact p-value and drops the ones that fail (keeps erfc / incomplete-beta code, and
+            // its ~90 VGPRs, out of this kernel: 2 -> 5 waves per SIMD).
+            if (fabs(tstat) > P.tcrit) {
+                const double z1 = (sem1 / semsum) * (sem1 / semsum) / (nx - 1.0);
+                const double z2 = (sem2 / semsum) * (sem2 / semsum) / (ny - 1.0);
+                const uint64_t idx = reserve_slot(P);
+                P.res_row[idx] = r;
+                P.res_stat[idx] = tstat;
+                P.res_p[idx] = 1.0 / (z1 + z2);
+                P.res_mx[idx] = mu + dx;
+                P.res_my[idx] = mu + dy;
+                P.res_nw[idx] = r_nw;
+            }
+        }
+        q = 0;
+    };
 
     for (uint64_t s0 = wave_global * SC_UNROLL; s0 < n_steps; s0 += total_waves * SC_UNROLL) {
         u32x4 x[SC_UNROLL];
@@ -321,63 +363,32 @@ __global__ __launch_bounds__(SC_THREADS) void ttest_scan_kernel(const ScanArgs P
                 const uint64_t r = (s0 + u) * RPW + (uint64_t)(src / G);
                 const int r_nw = __builtin_amdgcn_readlane(n_w, src);
                 const uint64_t *rp = bits64 + r * (uint64_t)wpr;
-                const int wreg = (P.cpr <= G) ? wpr : 2 * G;  // words of the row held in the group's registers
-                double nx = 0, sx = 0, ny = 0, sy = 0;
+                // moments of the k-mer-present group only; the absent group follows from the totals
+                // (values are shifted by their weighted mean, so sum_all w*u = 0 and the differences
+                // below lose no precision that matters: DESIGN.md section 5)
+                double nx = 0, sx = 0, qx = 0;
                 for (int t = 0; t < wpr; t++) {
-                    // word t of row r: broadcast from the register of the lane that loaded it in phase A
+                    // word t of row r: scalar read from the register of the lane that loaded it in phase A
                     // (rows wider than the lane group fall back to a broadcast load, an L1/L2 hit)
-                    uint64_t xw;
-                    if (t < wreg) {
-                        xw = psk_readlane_u64((t & 1) ? xb : xa, src + (t >> 1));  // scalar lane read, no LDS
-                    } else {
-                        xw = rp[t];
-                    }
+                    const uint64_t xw = (t < wreg) ? psk_readlane_u64((t & 1) ? xb : xa, src + (t >> 1)) : rp[t];
                     const double w = wt[t * 64 + lane], v = val[t * 64 + lane];  // w == 0 where NA / padding
-                    const bool pres = (xw >> lane) & 1;
-                    const double wv = w * v;
-                    nx += pres ? w : 0.0; sx += pres ? wv : 0.0;
-                    ny += pres ? 0.0 : w; sy += pres ? 0.0 : wv;
+                    const double wb = ((xw >> lane) & 1) ? w : 0.0;
+                    const double wv = wb * v;
+                    nx += wb; sx += wv; qx += wv * v;
                 }
-                nx = psk_wave_sum_f64_dpp(nx); sx = psk_wave_sum_f64_dpp(sx);
-                ny = psk_wave_sum_f64_dpp(ny); sy = psk_wave_sum_f64_dpp(sy);
-                const double mx = sx / nx, my = sy / ny;
-                double qx = 0, qy = 0;
-                for (int t = 0; t < wpr; t++) {
-                    uint64_t xw;
-                    if (t < wreg) {
-                        xw = psk_readlane_u64((t & 1) ? xb : xa, src + (t >> 1));  // scalar lane read, no LDS
-                    } else {
-                        xw = rp[t];
-                    }
-                    const double w = wt[t * 64 + lane], v = val[t * 64 + lane];
-                    const bool pres = (xw >> lane) & 1;
-                    const double dd = v - (pres ? mx : my);
-                    const double c = w * dd * dd;
-                    qx += pres ? c : 0.0;
-                    qy += pres ? 0.0 : c;
+                nx = psk_wave_sum_f64_dpp(nx); sx = psk_wave_sum_f64_dpp(sx); qx = psk_wave_sum_f64_dpp(qx);
+                const double ny = P.W1 - nx, sy = P.W0 - sx, qy = P.thr - qx;  // totals: W1 = sum w, W0 = sum w*u, thr = sum w*u^2
+                if (lane == 0) {
+                    double *sl = queue + q * TT_SLOT;
+                    sl[0] = nx; sl[1] = sx; sl[2] = qx; sl[3] = ny; sl[4] = sy; sl[5] = qy;
+                    sl[6] = __longlong_as_double((long long)r);
+                    sl[7] = __longlong_as_double((long long)r_nw);
                 }
-                qx = psk_wave_sum_f64_dpp(qx); qy = psk_wave_sum_f64_dpp(qy);
-                const double vx = qx / nx, vy = qy / ny;  // ddof = 0
-                const double sem1 = vx / (nx - 1.0), sem2 = vy / (ny - 1.0);
-                const double semsum = sem1 + sem2;
-                const double tstat = (mx - my) / sqrt(semsum);
-                // Student's t has heavier tails than the normal: p_t >= erfc(|t|/sqrt 2); cheap rejection
-                if (erfc(fabs(tstat) * 0.70710678118654752440) >= P.pcut_bonf) continue;
-                const double z1 = (sem1 / semsum) * (sem1 / semsum) / (nx - 1.0);
-                const double z2 = (sem2 / semsum) * (sem2 / semsum) / (ny - 1.0);
-                const double df = 1.0 / (z1 + z2);
-                const double p = dev_t_two_sided_p(tstat, df);  // every lane computes the same value
-                if (p < P.pcut_bonf && lane == 0) {  // modeling.py:738 (Bonferroni always)
-                    const uint64_t idx = reserve_slot(P);
-                    P.res_row[idx] = r;
-                    P.res_stat[idx] = tstat;
-                    P.res_p[idx] = p;
-                    P.res_mx[idx] = mx;
-                    P.res_my[idx] = my;
-                    P.res_nw[idx] = r_nw;
-                }
+                q++;
+                if (q == TT_QUEUE) flush();
             }
         }
+        if (q) flush();
     }
 }
 
@@ -399,21 +410,59 @@ void launch_chi2(int G, dim3 grid, hipStream_t st, const ScanArgs &a)
     }
 }
 
-void launch_ttest(int G, dim3 grid, hipStream_t st, const ScanArgs &a)
+// Second pass of the Welch scan: one workgroup per result segment turns (t, df) of every candidate into
+// the two-sided p-value, keeps p < cut / M (modeling.py:738) and compacts the segment in place.
+__global__ __launch_bounds__(256) void ttest_finalize_kernel(const ScanArgs P)
 {
-    // phenotype values + weights in LDS when they fit in 64 KiB (<= 4096 samples), else from L1/L2
-    const size_t need = (size_t)a.cpr * 2 * 64 * 2 * sizeof(double);
-    const int use_lds = need <= 65536 ? 1 : 0;
-    const size_t lds = use_lds ? need : 0;
-    switch (G) {
-    case 1: ttest_scan_kernel<1><<<grid, SC_THREADS, lds, st>>>(a, use_lds); break;
-    case 2: ttest_scan_kernel<2><<<grid, SC_THREADS, lds, st>>>(a, use_lds); break;
-    case 4: ttest_scan_kernel<4><<<grid, SC_THREADS, lds, st>>>(a, use_lds); break;
-    case 8: ttest_scan_kernel<8><<<grid, SC_THREADS, lds, st>>>(a, use_lds); break;
-    case 16: ttest_scan_kernel<16><<<grid, SC_THREADS, lds, st>>>(a, use_lds); break;
-    case 32: ttest_scan_kernel<32><<<grid, SC_THREADS, lds, st>>>(a, use_lds); break;
-    default: ttest_scan_kernel<64><<<grid, SC_THREADS, lds, st>>>(a, use_lds); break;
+    __shared__ uint32_t scan_lds[4];
+    __shared__ uint32_t s_out;
+    const uint32_t seg = blockIdx.x;
+    const uint32_t c = P.counter[seg * SC_CNT_STRIDE];
+    const uint64_t base = (uint64_t)seg * P.seg_cap;
+    if (threadIdx.x == 0) s_out = 0;
+    __syncthreads();
+    for (uint32_t s0 = 0; s0 < c; s0 += 256) {
+        const uint32_t i = s0 + threadIdx.x;
+        const bool valid = i < c;
+        uint64_t row = 0; double t = 0, p = 0, mx = 0, my = 0; int32_t nw = 0;
+        bool keep = false;
+        if (valid) {
+            row = P.res_row[base + i]; t = P.res_stat[base + i]; mx = P.res_mx[base + i]; my = P.res_my[base + i];
+            nw = P.res_nw[base + i];
+            p = dev_t_two_sided_p(t, P.res_p[base + i]);
+            keep = p < P.pcut_bonf;
+        }
+        uint32_t tot;
+        const uint32_t pos = psk_block_excl_scan_u32<256>(keep ? 1u : 0u, &tot, scan_lds);  // barriers inside
+        const uint32_t out = s_out;
+        if (keep) {
+            const uint64_t o = base + out + pos;  // <= base + i: compaction only moves entries down
+            P.res_row[o] = row; P.res_stat[o] = t; P.res_p[o] = p; P.res_mx[o] = mx; P.res_my[o] = my; P.res_nw[o] = nw;
+        }
+        __syncthreads();
+        if (threadIdx.x == 0) s_out = out + tot;
+        __syncthreads();
     }
+    if (threadIdx.x == 0) P.counter[seg * SC_CNT_STRIDE] = s_out;
+}
+
+void launch_ttest(int G, dim3 grid, hipStream_t st, const ScanArgs &a, double mu)
+{
+    // row queues always in LDS; phenotype values + weights too when they fit (<= ~3000 samples at 64 KiB)
+    const size_t qbytes = (size_t)(SC_THREADS / 64) * TT_QUEUE * TT_SLOT * sizeof(double);
+    const size_t need = (size_t)a.cpr * 2 * 64 * 2 * sizeof(double);
+    const int use_lds = (qbytes + need <= 65536) ? 1 : 0;
+    const size_t lds = qbytes + (use_lds ? need : 0);
+    switch (G) {
+    case 1: ttest_scan_kernel<1><<<grid, SC_THREADS, lds, st>>>(a, use_lds, mu); break;
+    case 2: ttest_scan_kernel<2><<<grid, SC_THREADS, lds, st>>>(a, use_lds, mu); break;
+    case 4: ttest_scan_kernel<4><<<grid, SC_THREADS, lds, st>>>(a, use_lds, mu); break;
+    case 8: ttest_scan_kernel<8><<<grid, SC_THREADS, lds, st>>>(a, use_lds, mu); break;
+    case 16: ttest_scan_kernel<16><<<grid, SC_THREADS, lds, st>>>(a, use_lds, mu); break;
+    case 32: ttest_scan_kernel<32><<<grid, SC_THREADS, lds, st>>>(a, use_lds, mu); break;
+    default: ttest_scan_kernel<64><<<grid, SC_THREADS, lds, st>>>(a, use_lds, mu); break;
+    }
+    ttest_finalize_kernel<<<SC_NSEG, 256, 0, st>>>(a);
 }
 
 int group_lanes(int cpr)
@@ -643,11 +692,22 @@ extern "C" int psk_ttest_scan(psk_ctx *ctx, const double *pheno, const uint8_t *
     std::vector<uint64_t> mv(wpr, 0);
     std::vector<double> vw(2 * (size_t)wpr * 64, 0.0);  // values | weights
     int nvalid = 0;
+    double sw = 0.0, swv = 0.0;
+    for (int i = 0; i < N; i++) {
+        if (!valid[i]) continue;
+        const double wi = weights ? weights[i] : 1.0;
+        sw += wi;
+        swv += wi * pheno[i];
+    }
+    const double mu = sw > 0 ? swv / sw : 0.0;  // the kernel accumulates moments of (value - mu)
+    double tot_w = 0.0, tot_wu = 0.0, tot_wuu = 0.0;
     for (int i = 0; i < N; i++) {
         if (!valid[i]) continue;
         mv[i >> 6] |= 1ull << (i & 63);
-        vw[i] = pheno[i];
-        vw[(size_t)wpr * 64 + i] = weights ? weights[i] : 1.0;
+        const double u = pheno[i] - mu, wi = weights ? weights[i] : 1.0;
+        vw[i] = u;
+        vw[(size_t)wpr * 64 + i] = wi;
+        tot_w += wi; tot_wu += wi * u; tot_wuu += wi * u * u;
         nvalid++;
     }
     PSK_TRY(dev_reserve(ctx, ctx->mask1, wpr * 8));
@@ -667,6 +727,19 @@ extern "C" int psk_ttest_scan(psk_ctx *ctx, const double *pheno, const uint8_t *
     a.max_samples = max_samples;
     a.pcut = pvalue_cutoff;
     a.pcut_bonf = pvalue_cutoff / (double)n_kmers_global;
+    a.W1 = tot_w; a.W0 = tot_wu; a.thr = tot_wuu;  // totals over the non-NA samples (shifted values)
+    {   // t_crit: erfc(t_crit / sqrt 2) = cut / M by bisection (0 when everything may pass)
+        const double cut = a.pcut_bonf;
+        double lo = 0.0, hi = 40.0;
+        if (!(cut < 1.0)) hi = 0.0;
+        else if (std::erfc(hi * 0.70710678118654752440) >= cut) lo = hi;  // cut below double's erfc range
+        else
+            for (int it = 0; it < 200; it++) {
+                const double mid = 0.5 * (lo + hi);
+                if (std::erfc(mid * 0.70710678118654752440) >= cut) lo = mid; else hi = mid;
+            }
+        a.tcrit = lo * (1.0 - 1e-12);  // err on the side of keeping candidates
+    }
     const int G = group_lanes(a.cpr);
     const dim3 grid = scan_grid(ctx, a.M, G, SC_UNROLL);
     PSK_TRY(setup_results(ctx, a, grid, G, SC_UNROLL));
@@ -676,7 +749,7 @@ extern "C" int psk_ttest_scan(psk_ctx *ctx, const double *pheno, const uint8_t *
     if (ctx->n_kmers) {
         PSK_HIP(ctx, hipMemsetAsync(a.counter, 0, SC_NSEG * SC_CNT_STRIDE * 4, ctx->stream));
         PSK_HIP(ctx, hipEventRecord(ctx->ev0, ctx->stream));
-        launch_ttest(G, grid, ctx->stream, a);
+        launch_ttest(G, grid, ctx->stream, a, mu);
         PSK_HIP(ctx, hipGetLastError());
         PSK_HIP(ctx, hipEventRecord(ctx->ev1, ctx->stream));
         PSK_TRY(enqueue_counts_readback(ctx, a));
