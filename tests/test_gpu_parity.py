@@ -456,3 +456,26 @@ def test_batch_counting_equals_single_calls(ctx, oracle):
     from phenotypeseeker_amd._lib import PskError
     with pytest.raises(PskError):
         ctx.count_kmers_batch(40, datas[:10], 2)   # runs past the declared sample count
+
+
+def test_fastq_reads_and_gzip_input(ctx, oracle, tmp_path):
+    """cfg-5 shape at test size: raw reads as FASTQ (constant quality line 'I...'), gzip-compressed on
+    disk; the file reader inflates on the host, the list must equal the oracle's on the inflated bytes."""
+    import gzip as _gz
+    from phenotypeseeker_amd import formats
+    from phenotypeseeker_amd.synth import GenomeSet, fastq_reads
+    gs = GenomeSet(1, 300_000, seed=8)
+    fq = fastq_reads(gs.codes(0), n_reads=20_000, read_len=150, seed=3)
+    path = os.path.join(tmp_path, "reads.fastq.gz")
+    with _gz.open(path, "wb", compresslevel=1) as f:
+        f.write(fq)
+    data = formats.read_sequence_file(path)
+    assert data == fq
+    for k in (13, 21):
+        ow, of, ont = oracle.count_kmers(fq, k)
+        assert ont == 20_000 * (150 - k + 1)
+        ctx.begin(k, 1)
+        nu, nt = ctx.count_kmers(0, data)
+        w, f = ctx.get_list(0, nu)
+        assert nt == ont and np.array_equal(w, ow) and np.array_equal(f, of)
+    assert int(of.max()) > 3   # coverage 10x: counts well above 1 are exercised
