@@ -192,15 +192,20 @@ def main():
         ns = int(min(args.cpu_sample_rows, M))
         rows = ctx.get_rows(np.arange(ns, dtype=np.uint64))
         t0 = time.perf_counter()
-        ref = O.chi2_scan(rows, pheno.tolist(), np.ones(n), n, 2, n - 2, 0.05, False, M_global)
-        dt = time.perf_counter() - t0
+        reps = 0
+        while True:   # bounded sample: repeat the pass until about 10 s of CPU work have been timed
+            ref = O.chi2_scan(rows, pheno.tolist(), np.ones(n), n, 2, n - 2, 0.05, False, M_global)
+            reps += 1
+            dt = time.perf_counter() - t0
+            if dt >= 10.0 or reps >= 4:
+                break
         res = ctx.get_results(npass)
         sel = res["row"] < ns
         same = bool(np.array_equal(res["row"][sel], np.nonzero(ref["keep"])[0].astype(np.uint64)) and
                     np.allclose(res["stat"][sel], ref["stat"][ref["keep"]], rtol=1e-12))
-        out["cpu_baseline"] = {"value": ns * n / dt, "unit": "cells/s", "cores": 1, "kind": "port",
-                               "sample": "first %d rows of the same matrix (%d samples), oracle/psk_oracle.c "
-                                         "orc_chi2_scan, %.1f s" % (ns, n, dt),
+        out["cpu_baseline"] = {"value": reps * ns * n / dt, "unit": "cells/s", "cores": 1, "kind": "port",
+                               "sample": "%d pass(es) over the first %d rows of the same matrix (%d samples), "
+                                         "oracle/psk_oracle.c orc_chi2_scan, %.1f s" % (reps, ns, n, dt),
                                "matches_gpu": same,
                                "reference_python_8proc_cells_per_s": 7.4e6}
     if rank == 0:
