@@ -129,12 +129,16 @@ def main():
     pending = []
     gathered = [0]
 
-    def drain(limit):
+    def drain(limit, read_counts=False):
         while len(pending) > limit:
-            counts = xch.finish_counts(pending.pop(0))   # gathered table stays on the device
-            if (counts > xch.cap).any():
-                raise RuntimeError("survivor buffer overflow in bench")
-            gathered[0] = int(counts.sum())
+            s_ = pending.pop(0)
+            if read_counts or not pending:
+                counts = xch.finish_counts(s_)       # gathered table stays on the device
+                if (counts > xch.cap).any():
+                    raise RuntimeError("survivor buffer overflow in bench")
+                gathered[0] = int(counts.sum())
+            else:
+                xch.wait(s_)                         # completion only: the slot's buffers are reused next step
 
     def step():
         npass = ctx.chi2_scan(pheno, None, 2, n - 2, 0.05, False, M_global)
@@ -142,7 +146,8 @@ def main():
         if xch is not None:
             s_, _ = xch.start(ctx)
             pending.append(s_)
-            drain(1)
+            if len(pending) > 1:
+                xch.wait(pending.pop(0))
         return npass, ms
 
     for _ in range(args.warmup):

@@ -204,6 +204,13 @@ class SurvivorExchange:
                "n_with": recs[:, 5].copy().view(np.int64).astype(np.int32)}
         return res, np.ascontiguousarray(recs[:, 6:])
 
+    def wait(self, s):
+        """Blocks until the collective of slot s has completed (so that its send buffer may be packed
+        again) without copying anything back."""
+        self.work[s].wait()
+        if self.nccl:
+            self.torch.cuda.current_stream().synchronize()
+
     def finish_counts(self, s):
         """Waits for slot s and reads back only the per-slab record counts (the records stay on the
         device); used where the merged table is not needed on the host right away."""
