@@ -118,7 +118,7 @@ extern "C" void psk_free(psk_ctx *ctx)
     reset_lists(ctx, 0);
     arena_release(ctx);
     DevBuf *bufs[] = {&ctx->raw, &ctx->keysA, &ctx->keysB, &ctx->valsA, &ctx->valsB, &ctx->hist, &ctx->scan_tmp, &ctx->flags, &ctx->starts,
-                      &ctx->misc, &ctx->union_words, &ctx->bits, &ctx->mask1, &ctx->mask0, &ctx->wts, &ctx->phe,
+                      &ctx->misc, &ctx->union_words, &ctx->bits, &ctx->mask1, &ctx->phe,
                       &ctx->res, &ctx->res_count, &ctx->res_sorted};
     for (DevBuf *b : bufs) dev_release(*b);
     if (ctx->pinned) (void)hipHostFree(ctx->pinned);

@@ -4,7 +4,7 @@
 //   host   frame_sequence_host   record framing only (headers, FASTQ separator/quality lines,
 //                                control bytes) -> clean stream: bases + '\n' window breaks
 //   device extract_kernel        2-bit encode, rolling forward/reverse words, canonical min,
-//                                slab filter, wave-aggregated append
+//                                slab filter, per-wave LDS compaction + one reservation per wave
 //          dev_radix_sort_u64    LSD radix sort on the 2k significant bits
 //          rle_* kernels         run heads -> unique words + u32 frequencies
 #include "dev_utils.h"

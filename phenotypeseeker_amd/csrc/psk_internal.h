@@ -12,8 +12,6 @@
 
 #include "../../include/psk.h"
 
-#define PSK_WAVE 64
-
 // ---- growable device buffer -------------------------------------------------------------------
 struct DevBuf {
     void *p = nullptr;
@@ -81,7 +79,7 @@ struct psk_ctx {
     bool have_presence = false;
 
     // scan state
-    DevBuf mask1, mask0, wts, phe, res, res_count, res_sorted;
+    DevBuf mask1, phe, res, res_count, res_sorted;
     uint64_t n_pass = 0;
     uint64_t res_seg_cap = 0;            // entries per result segment of the last scan
     std::vector<uint32_t> seg_counts;    // survivors per segment

@@ -15,7 +15,6 @@ calls (phenotypeseeker_amd.engine); everything here is orchestration and formatt
 A single process drives the GPU (no fork pools: the HIP runtime is not fork-safe).
 """
 import math
-import os
 import sys
 import time
 from collections import OrderedDict

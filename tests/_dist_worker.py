@@ -2,7 +2,6 @@
 Each rank plays one slab of the range-sharded path with the oracle standing in for the GPU
 engine (no GPU in the CPU suite); what is under test is phenotypeseeker_amd.dist: slab bounds,
 the all-reduce of the union size and the all-gather(v)/merge of the per-slab survivors."""
-import json
 import os
 import sys
 

@@ -6,7 +6,6 @@ import gzip
 import json
 import os
 
-import numpy as np
 import pytest
 
 from helpers import GOLDEN
