@@ -3,10 +3,10 @@
 // refit is an independent small problem (N <= a few thousand samples x <= ~1000 selected k-mers),
 // so one workgroup solves one fit and all fits of a grid search run in ONE launch.
 //
-//   logreg_l1_kernel  liblinear's L1R_LR objective  ||w||_1 + |b| + C sum log(1+exp(-y(w.x+b)))
-//                     (intercept = penalised constant-1 feature), cyclic coordinate descent with
-//                     1-D Newton steps and an Armijo line search (CDN, Yuan et al. 2010); four step
-//                     lengths are evaluated per workgroup reduction.
+//   logreg_newglmnet_*  liblinear's L1R_LR objective  ||w||_1 + |b| + C sum log(1+exp(-y(w.x+b)))
+//                     (intercept = penalised constant-1 feature) by the improved GLMNET scheme liblinear
+//                     itself uses: outer Newton steps, inner coordinate descent with shrinking on the
+//                     quadratic model, one line search per outer step; a bit-packed form for 0/1 designs.
 //   lasso_kernel      (1/2n)||y - Xw - b||^2 + alpha ||w||_1, unpenalised intercept, cyclic
 //                     coordinate descent on the centred problem.
 //
@@ -38,108 +38,515 @@ __device__ __forceinline__ double lane0_load(const double *p, int lane)
 
 __device__ __forceinline__ double log1pexp_from_e(double e) { return (e > 1e300) ? log(e) : log1p(e); }
 
-// z = linear predictor, e = exp(-y z) per sample.  With e cached, the gradient/curvature pass needs no
-// transcendental at all (s = 1/(1+e)); only samples touched by an accepted step recompute e.
-__global__ __launch_bounds__(SV_THREADS) void logreg_l1_kernel(const float *__restrict__ XT, const int8_t *__restrict__ ypm,
-                                                                const int32_t *__restrict__ fold, int n, int p,
-                                                                const double *__restrict__ fit_param,
-                                                                const int32_t *__restrict__ fit_fold, double tol,
-                                                                int max_iter, double *__restrict__ coef,
-                                                                double *__restrict__ icpt, int32_t *__restrict__ iters,
-                                                                double *__restrict__ work, const int use_lds)
+// L1 logistic regression by the improved GLMNET scheme (Yuan, Ho & Lin, JMLR 2012 -- the method behind
+// liblinear's L1R_LR solver, which is what the reference's LogisticRegression(penalty='l1',
+// solver='liblinear') runs): outer Newton iterations build a quadratic model from cached
+// tau_i = C/(1+exp(w.x_i)) and D_i = C exp(w.x_i)/(1+exp(w.x_i))^2; an inner cyclic coordinate descent
+// with shrinking solves the model WITHOUT any transcendental per coordinate; one Armijo line search per
+// outer iteration (<= 20 halvings) needs exp/log once per sample.  Same stopping rule as liblinear:
+// ||violation||_1 <= tol * min(#pos, #neg)/l * ||violation at w = 0||_1.
+// Per-fit state: five feature arrays (w, w+d, diag H, grad, sum of C*x over the y=-1 rows) and five sample
+// arrays (exp(w.x), its trial value, tau, D, x.d), in LDS when they fit (up to 160 KiB per workgroup).
+#define FLD(ptr) (f_lds ? *(ptr) : lane0_load((ptr), lane))
+__global__ __launch_bounds__(SV_THREADS) void logreg_newglmnet_kernel(
+    const float *__restrict__ XT, const int8_t *__restrict__ ypm, const int32_t *__restrict__ fold, int n, int p,
+    const double *__restrict__ fit_param, const int32_t *__restrict__ fit_fold, double tol, int max_newton,
+    double *__restrict__ coef, double *__restrict__ icpt, int32_t *__restrict__ iters, double *__restrict__ work,
+    int32_t *__restrict__ iwork, const int f_lds, const int s_lds)
 {
     extern __shared__ double sm[];
     const int fit = blockIdx.x, lane = threadIdx.x;
     const double C = fit_param[fit];
     const int tf = fit_fold[fit];
-    double *w = coef + (size_t)fit * p;
-    double *z = use_lds ? sm : work + (size_t)fit * 2 * n;
-    double *E = z + n;
+    const int P1 = p + 1;
+    double *gw = work + (size_t)fit * (5 * (size_t)P1 + 5 * (size_t)n);
+    double *F = f_lds ? sm : gw;
+    double *S = s_lds ? (sm + (f_lds ? 5 * P1 : 0)) : (gw + 5 * (size_t)P1);
+    double *w = F, *wpd = F + P1, *Hd = F + 2 * P1, *Gr = F + 3 * P1, *xjneg = F + 4 * P1;
+    double *ewx = S, *ewxn = S + n, *tau = S + 2 * (size_t)n, *D = S + 3 * (size_t)n, *xTd = S + 4 * (size_t)n;
+    int32_t *act = iwork + (size_t)fit * P1;
+    const double nu = 1e-12, sigma = 0.01;
 
-    for (int j = lane; j < p; j += SV_THREADS) w[j] = 0.0;
     double npos = 0, nneg = 0;
     for (int i = lane; i < n; i += SV_THREADS) {
-        z[i] = 0.0;
-        E[i] = 1.0;  // exp(-y * 0)
+        ewx[i] = 1.0; tau[i] = C * 0.5; D[i] = C * 0.25; xTd[i] = 0.0;
         if (fold[i] != tf) { if (ypm[i] > 0) npos += 1; else nneg += 1; }
     }
     npos = psk_wave_sum_f64_dpp(npos);
     nneg = psk_wave_sum_f64_dpp(nneg);
-    const double ntrain = npos + nneg;
+    const double l = npos + nneg;
     double mn = npos < nneg ? npos : nneg;
     if (mn < 1.0) mn = 1.0;
-    const double eps = tol * mn / (ntrain > 0 ? ntrain : 1.0);  // liblinear's primal_solver_tol
-    double wb = 0.0;
-    double gnorm_init = -1.0;
-    const double sigma = 0.01;
-    int sweep = 0;
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
-    __builtin_amdgcn_wave_barrier();
-
-    for (sweep = 0; sweep < max_iter; sweep++) {
-        double gnorm = 0.0;
-        for (int j = 0; j <= p; j++) {
+    const double eps = tol * mn / (l > 0 ? l : 1.0);
+    for (int j = 0; j < P1; j++) {  // feature arrays are written by lane 0 only (see lane0_load)
+        const float *col = XT + (size_t)j * n;
+        double sneg = 0.0;
+        for (int i = lane; i < n; i += SV_THREADS)
+            if (fold[i] != tf && ypm[i] < 0) sneg += C * ((j < p) ? (double)col[i] : 1.0);
+        sneg = psk_wave_sum_f64_dpp(sneg);
+        if (lane == 0) { w[j] = 0.0; wpd[j] = 0.0; xjneg[j] = sneg; act[j] = j; }
+    }
+    double w_norm = 0.0, Gmax_old = 1e300, Gnorm1_init = -1.0, inner_eps = 1.0;
+    int newton = 0;
+    for (newton = 0; newton < max_newton; newton++) {
+        double Gmax_new = 0.0, Gnorm1_new = 0.0;
+        int active = P1;
+        for (int sidx = 0; sidx < active; sidx++) {
+            const int j = __builtin_amdgcn_readfirstlane(lane == 0 ? act[sidx] : 0);
             const float *col = XT + (size_t)j * n;
-            double g = 0.0, h = 0.0;
+            double hd = 0.0, tmp = 0.0;
             for (int i = lane; i < n; i += SV_THREADS) {
                 if (fold[i] == tf) continue;
                 const double x = (j < p) ? (double)col[i] : 1.0;
                 if (x == 0.0) continue;
-                const double y = (double)ypm[i];
-                const double s = 1.0 / (1.0 + E[i]);  // sigma(y z)
-                g += (s - 1.0) * y * x;
-                h += x * x * s * (1.0 - s);
+                hd += x * x * D[i];
+                tmp += x * tau[i];
             }
-            g = C * psk_wave_sum_f64_dpp(g);
-            h = C * psk_wave_sum_f64_dpp(h) + 1e-12;
-            const double wj = (j < p) ? lane0_load(&w[j], lane) : wb;
-            double v;
-            if (wj > 0) v = fabs(g + 1.0);
-            else if (wj < 0) v = fabs(g - 1.0);
-            else { v = 0.0; if (g - 1.0 > v) v = g - 1.0; if (-1.0 - g > v) v = -1.0 - g; }
-            gnorm += v;
-            double d;
-            if (g + 1.0 <= h * wj) d = -(g + 1.0) / h;
-            else if (g - 1.0 >= h * wj) d = -(g - 1.0) / h;
-            else d = -wj;
-            if (v < 1e-16 || d == 0.0) continue;  // wave-uniform
-            const double delta = g * d + fabs(wj + d) - fabs(wj);
-            // Armijo backtracking; the full Newton step is accepted almost always
-            double lam = 1.0;
-            bool found = false;
-            for (int trial = 0; trial < 40; trial++) {
-                double dl = 0.0;
+            hd = psk_wave_sum_f64_dpp(hd) + nu;
+            tmp = psk_wave_sum_f64_dpp(tmp);
+            const double grad = -tmp + FLD(&xjneg[j]);
+            const double wj = FLD(&w[j]);
+            const double Gp = grad + 1.0, Gn = grad - 1.0;
+            double viol = 0.0;
+            if (wj == 0.0) {
+                if (Gp < 0) viol = -Gp;
+                else if (Gn > 0) viol = Gn;
+                else if (Gp > Gmax_old / l && Gn < -Gmax_old / l) {  // outer-level shrinking
+                    active--;
+                    if (lane == 0) { const int32_t t = act[sidx]; act[sidx] = act[active]; act[active] = t; }
+                    sidx--;
+                    continue;
+                }
+            } else if (wj > 0) viol = fabs(Gp);
+            else viol = fabs(Gn);
+            if (lane == 0) { Hd[j] = hd; Gr[j] = grad; }
+            if (viol > Gmax_new) Gmax_new = viol;
+            Gnorm1_new += viol;
+        }
+        if (newton == 0) Gnorm1_init = Gnorm1_new;
+        if (Gnorm1_new <= eps * Gnorm1_init) break;
+
+        // inner coordinate descent on the quadratic model
+        for (int i = lane; i < n; i += SV_THREADS) xTd[i] = 0.0;
+        double QP_Gmax_old = 1e300;
+        int QP_active = active, iter = 0;
+        while (iter < 1000) {
+            double QP_Gmax_new = 0.0, QP_Gnorm1_new = 0.0;
+            for (int sidx = 0; sidx < QP_active; sidx++) {
+                const int j = __builtin_amdgcn_readfirstlane(lane == 0 ? act[sidx] : 0);
+                const float *col = XT + (size_t)j * n;
+                const double H = FLD(&Hd[j]);
+                const double wp = FLD(&wpd[j]);
+                double G = 0.0;
                 for (int i = lane; i < n; i += SV_THREADS) {
                     if (fold[i] == tf) continue;
                     const double x = (j < p) ? (double)col[i] : 1.0;
-                    if (x == 0.0) continue;
-                    const double y = (double)ypm[i];
-                    const double e_new = exp(-y * (z[i] + lam * d * x));
-                    dl += log1pexp_from_e(e_new) - log1pexp_from_e(E[i]);
+                    if (x != 0.0) G += x * D[i] * xTd[i];
                 }
-                dl = psk_wave_sum_f64_dpp(dl);
-                const double diff = fabs(wj + lam * d) - fabs(wj) + C * dl;
-                if (diff <= sigma * lam * delta) { found = true; break; }
-                lam *= 0.5;
+                G = psk_wave_sum_f64_dpp(G) + FLD(&Gr[j]) + (wp - FLD(&w[j])) * nu;
+                const double Gp = G + 1.0, Gn = G - 1.0;
+                double viol = 0.0;
+                if (wp == 0.0) {
+                    if (Gp < 0) viol = -Gp;
+                    else if (Gn > 0) viol = Gn;
+                    else if (Gp > QP_Gmax_old / l && Gn < -QP_Gmax_old / l) {  // inner shrinking
+                        QP_active--;
+                        if (lane == 0) { const int32_t t = act[sidx]; act[sidx] = act[QP_active]; act[QP_active] = t; }
+                        sidx--;
+                        continue;
+                    }
+                } else if (wp > 0) viol = fabs(Gp);
+                else viol = fabs(Gn);
+                if (viol > QP_Gmax_new) QP_Gmax_new = viol;
+                QP_Gnorm1_new += viol;
+                double z;
+                if (Gp < H * wp) z = -Gp / H;
+                else if (Gn > H * wp) z = -Gn / H;
+                else z = -wp;
+                if (fabs(z) < 1e-12) continue;
+                z = fmin(fmax(z, -10.0), 10.0);
+                if (lane == 0) wpd[j] = wp + z;
+                for (int i = lane; i < n; i += SV_THREADS) {
+                    if (fold[i] == tf) continue;
+                    const double x = (j < p) ? (double)col[i] : 1.0;
+                    if (x != 0.0) xTd[i] += x * z;
+                }
             }
-            if (!found) continue;
-            const double dw = lam * d;
-            if (j < p) { if (lane == 0) w[j] = wj + dw; } else wb = wj + dw;
+            iter++;
+            if (QP_Gnorm1_new <= inner_eps * Gnorm1_init) {
+                if (QP_active == active) break;       // inner problem solved
+                QP_active = active;                   // re-check the shrunk coordinates
+                QP_Gmax_old = 1e300;
+                continue;
+            }
+            QP_Gmax_old = QP_Gmax_new;
+        }
+
+        // line search along d = wpd - w
+        double delta = 0.0, w_norm_new = 0.0;
+        for (int j = 0; j < P1; j++) {
+            const double wp = FLD(&wpd[j]);
+            delta += FLD(&Gr[j]) * (wp - FLD(&w[j]));
+            w_norm_new += fabs(wp);
+        }
+        delta += (w_norm_new - w_norm);
+        double negsum = 0.0;
+        for (int i = lane; i < n; i += SV_THREADS)
+            if (fold[i] != tf && ypm[i] < 0) negsum += C * xTd[i];
+        negsum = psk_wave_sum_f64_dpp(negsum);
+        bool accepted = false;
+        for (int ls = 0; ls < 20; ls++) {
+            double cs = 0.0;
             for (int i = lane; i < n; i += SV_THREADS) {
                 if (fold[i] == tf) continue;
-                const double x = (j < p) ? (double)col[i] : 1.0;
-                if (x != 0.0) {
-                    const double zi = z[i] + dw * x;
-                    z[i] = zi;
-                    E[i] = exp(-(double)ypm[i] * zi);
+                const double ex = exp(xTd[i]);
+                const double en = ewx[i] * ex;
+                ewxn[i] = en;
+                cs += C * log((1.0 + en) / (ex + en));
+            }
+            const double cond = w_norm_new - w_norm + negsum - sigma * delta + psk_wave_sum_f64_dpp(cs);
+            if (cond <= 0.0) {
+                w_norm = w_norm_new;
+                for (int j = 0; j < P1; j++) { if (lane == 0) w[j] = wpd[j]; }
+                for (int i = lane; i < n; i += SV_THREADS) {
+                    if (fold[i] == tf) continue;
+                    const double en = ewxn[i];
+                    const double tt = 1.0 / (1.0 + en);
+                    ewx[i] = en; tau[i] = C * tt; D[i] = C * en * tt * tt;
+                }
+                accepted = true;
+                break;
+            }
+            w_norm_new = 0.0;
+            for (int j = 0; j < P1; j++) {
+                const double v = 0.5 * (FLD(&w[j]) + FLD(&wpd[j]));
+                if (lane == 0) wpd[j] = v;
+                w_norm_new += fabs(v);
+            }
+            delta *= 0.5;
+            negsum *= 0.5;
+            for (int i = lane; i < n; i += SV_THREADS) xTd[i] *= 0.5;
+        }
+        if (!accepted) {  // the step was rejected 20 times: fall back to the current w
+            for (int j = 0; j < P1; j++) { if (lane == 0) wpd[j] = w[j]; }
+        }
+        if (iter == 1) inner_eps *= 0.25;
+        Gmax_old = Gmax_new;
+    }
+    for (int j = 0; j < p; j++) { if (lane == 0) coef[(size_t)fit * p + j] = w[j]; }
+    if (lane == 0) { icpt[fit] = w[p]; iters[fit] = newton; }
+}
+#undef FLD
+
+// Presence/absence designs (the default: 0/1 columns) take a bit-packed form of the same algorithm:
+// column j is W = ceil(n/64) u64 words, sample i = bit (i & 63) of word (i >> 6), i.e. lane l owns exactly
+// the bit-l samples.  A coordinate step loads its column with ONE coalesced load (lane t holds word t,
+// AND-ed with the fit's training mask), then walks the words with scalar lane reads: no global load
+// inside the loops, only the LDS-resident per-sample arrays.  (The float form pays an L2 round trip per
+// 64 samples, ~7 us per coordinate at n = 2048 on a lone wave; this form ~0.3 us.)
+#define FLD(ptr) (f_lds ? *(ptr) : lane0_load((ptr), lane))
+__global__ __launch_bounds__(SV_THREADS) void logreg_newglmnet_bits_kernel(
+    const uint64_t *__restrict__ colbits, const int8_t *__restrict__ ypm, const int32_t *__restrict__ fold, int n, int p,
+    int W, const double *__restrict__ fit_param, const int32_t *__restrict__ fit_fold, double tol, int max_newton,
+    double *__restrict__ coef, double *__restrict__ icpt, int32_t *__restrict__ iters, double *__restrict__ work,
+    int32_t *__restrict__ iwork, const int f_lds, const int s_lds, const int c_lds, const int q_lds)
+{
+    extern __shared__ double sm_all[];
+    double *Qm = sm_all;  // 64 x 64 Gram block of the small-active-set QP (q_lds)
+    double *sm = sm_all + (q_lds ? 64 * 64 : 0);
+    const int fit = blockIdx.x, lane = threadIdx.x;
+    const double C = fit_param[fit];
+    const int tf = fit_fold[fit];
+    const int P1 = p + 1, NP = W * 64;  // sample arrays are padded to whole words
+    double *gw = work + (size_t)fit * (5 * (size_t)P1 + 5 * (size_t)NP);
+    // LDS layout: [feature arrays 5*P1 | active list P1 ints (padded)] if f_lds, [sample arrays 5*NP] if s_lds,
+    // [column bit words P1*W] if c_lds
+    const size_t f_words = f_lds ? (5 * (size_t)P1 + (((size_t)P1 + 1) >> 1)) : 0;
+    double *F = f_lds ? sm : gw;
+    double *S = s_lds ? (sm + f_words) : (gw + 5 * (size_t)P1);
+    const uint64_t *cb = colbits;
+    if (c_lds) {
+        uint64_t *lc = reinterpret_cast<uint64_t *>(sm + f_words + (s_lds ? 5 * (size_t)NP : 0));
+        for (size_t q = lane; q < (size_t)P1 * W; q += SV_THREADS) lc[q] = colbits[q];
+        cb = lc;
+    }
+    double *w = F, *wpd = F + P1, *Hd = F + 2 * P1, *Gr = F + 3 * P1, *xjneg = F + 4 * P1;
+    double *ewx = S, *ewxn = S + NP, *tau = S + 2 * (size_t)NP, *D = S + 3 * (size_t)NP, *xTd = S + 4 * (size_t)NP;
+    int32_t *act = f_lds ? reinterpret_cast<int32_t *>(sm + 5 * (size_t)P1) : iwork + (size_t)fit * P1;
+    const double nu = 1e-12, sigma = 0.01;
+
+    // training mask and (training & y = -1) mask of this fit: lane t keeps word t (W <= 64, i.e. n <= 4096)
+    uint64_t trainw = 0, negw = 0;
+    double npos = 0, nneg = 0;
+    for (int t = 0; t < W; t++) {
+        const int i = t * 64 + lane;
+        const bool tr = (i < n) && fold[i] != tf;
+        const bool ng = tr && ypm[i] < 0;
+        const uint64_t bt = __ballot(tr), bn = __ballot(ng);
+        if (lane == t) { trainw = bt; negw = bn; }
+        npos += (tr && !ng) ? 1.0 : 0.0;
+        nneg += ng ? 1.0 : 0.0;
+        ewx[i] = 1.0; tau[i] = C * 0.5; D[i] = C * 0.25; xTd[i] = 0.0; ewxn[i] = 1.0;
+    }
+    npos = psk_wave_sum_f64_dpp(npos);
+    nneg = psk_wave_sum_f64_dpp(nneg);
+    const double l = npos + nneg;
+    double mn = npos < nneg ? npos : nneg;
+    if (mn < 1.0) mn = 1.0;
+    const double eps = tol * mn / (l > 0 ? l : 1.0);
+
+    // column j restricted to the training rows: word `lane` in lane `lane`
+    auto load_col = [&](int j) -> uint64_t { return (lane < W) ? (cb[(size_t)j * W + lane] & trainw) : 0ull; };
+
+    for (int j = 0; j < P1; j++) {
+        double sneg = (lane < W) ? C * (double)__popcll(cb[(size_t)j * W + lane] & negw) : 0.0;
+        sneg = psk_wave_sum_f64_dpp(sneg);
+        if (lane == 0) { w[j] = 0.0; wpd[j] = 0.0; xjneg[j] = sneg; act[j] = j; }
+    }
+    double w_norm = 0.0, Gmax_old = 1e300, Gnorm1_init = -1.0, inner_eps = 1.0;
+    int newton = 0;
+    for (newton = 0; newton < max_newton; newton++) {
+        double Gmax_new = 0.0, Gnorm1_new = 0.0;
+        int active = P1;
+        for (int sidx = 0; sidx < active; sidx++) {
+            const int j = f_lds ? act[sidx] : __builtin_amdgcn_readfirstlane(lane == 0 ? act[sidx] : 0);
+            double hd = 0.0, tmp = 0.0;
+            {
+                const uint64_t cw = load_col(j);
+                for (int t = 0; t < W; t++) {
+                    const uint64_t xw = psk_readlane_u64(cw, t);
+                    const double b = ((xw >> lane) & 1) ? 1.0 : 0.0;
+                    const int i = t * 64 + lane;
+                    hd += b * D[i];
+                    tmp += b * tau[i];
                 }
             }
+            hd = psk_wave_sum_f64_dpp(hd) + nu;
+            tmp = psk_wave_sum_f64_dpp(tmp);
+            const double grad = -tmp + FLD(&xjneg[j]);
+            const double wj = FLD(&w[j]);
+            const double Gp = grad + 1.0, Gn = grad - 1.0;
+            double viol = 0.0;
+            if (wj == 0.0) {
+                if (Gp < 0) viol = -Gp;
+                else if (Gn > 0) viol = Gn;
+                else if (Gp > Gmax_old / l && Gn < -Gmax_old / l) {
+                    active--;
+                    if (lane == 0) { const int32_t tt = act[sidx]; act[sidx] = act[active]; act[active] = tt; }
+                    sidx--;
+                    continue;
+                }
+            } else if (wj > 0) viol = fabs(Gp);
+            else viol = fabs(Gn);
+            if (lane == 0) { Hd[j] = hd; Gr[j] = grad; }
+            if (viol > Gmax_new) Gmax_new = viol;
+            Gnorm1_new += viol;
         }
-        if (gnorm_init < 0) gnorm_init = gnorm;
-        if (gnorm <= eps * gnorm_init || gnorm == 0.0) { sweep++; break; }
+        if (newton == 0) Gnorm1_init = Gnorm1_new;
+        if (Gnorm1_new <= eps * Gnorm1_init) break;
+
+        for (int t = 0; t < W; t++) xTd[t * 64 + lane] = 0.0;
+        double QP_Gmax_old = 1e300;
+        int QP_active = active, iter = 0;
+        if (q_lds && active <= 64) {
+            // Covariance form of the same QP (active set small enough for one feature per lane): lane s
+            // owns feature act[s]; g = Gr + Q d with Q = X_A' D X_A (+ nu on the diagonal) is kept in a
+            // register per lane, so a coordinate step is three readlanes, the scalar update and one FMA
+            // instead of a reduction over the samples.  Columns of Q are built the first time a
+            // feature moves.  Same visiting order, shrinking and stopping rule as the loop below.
+            const bool mine = lane < active;
+            const int fj = mine ? act[lane] : 0;
+            double g = mine ? FLD(&Gr[fj]) : 0.0;
+            const double h = mine ? FLD(&Hd[fj]) : 1.0;
+            const double hinv = 1.0 / h;  // one division per feature and Newton step instead of one per coordinate step
+            const double wr = mine ? FLD(&w[fj]) : 0.0;
+            double wp_r = wr;
+            int perm = lane;
+            uint64_t have = 0;
+            while (iter < 1000) {
+                double QP_Gmax_new = 0.0, QP_Gnorm1_new = 0.0;
+                for (int sidx = 0; sidx < QP_active; sidx++) {
+                    const int m = __builtin_amdgcn_readlane(perm, sidx);
+                    double qcol = Qm[m * 64 + lane];
+                    const double G = psk_readlane_f64(g, m), H = psk_readlane_f64(h, m), Hi = psk_readlane_f64(hinv, m),
+                                 wp = psk_readlane_f64(wp_r, m);
+                    const double Gp = G + 1.0, Gn = G - 1.0;
+                    double viol = 0.0;
+                    if (wp == 0.0) {
+                        if (Gp < 0) viol = -Gp;
+                        else if (Gn > 0) viol = Gn;
+                        else if (Gp > QP_Gmax_old / l && Gn < -QP_Gmax_old / l) {
+                            QP_active--;
+                            const int last = __builtin_amdgcn_readlane(perm, QP_active);
+                            if (lane == sidx) perm = last;
+                            if (lane == QP_active) perm = m;
+                            sidx--;
+                            continue;
+                        }
+                    } else if (wp > 0) viol = fabs(Gp);
+                    else viol = fabs(Gn);
+                    if (viol > QP_Gmax_new) QP_Gmax_new = viol;
+                    QP_Gnorm1_new += viol;
+                    double z;
+                    if (Gp < H * wp) z = -Gp * Hi;
+                    else if (Gn > H * wp) z = -Gn * Hi;
+                    else z = -wp;
+                    if (fabs(z) < 1e-12) continue;
+                    z = fmin(fmax(z, -10.0), 10.0);
+                    if (!((have >> m) & 1)) {
+                        have |= 1ull << m;
+                        const int fm = __builtin_amdgcn_readlane(fj, m);
+                        double acc = 0.0;
+                        for (int t = 0; t < W; t++) {
+                            const uint64_t tw = psk_readlane_u64(trainw, t);
+                            uint64_t x = mine ? (cb[(size_t)fm * W + t] & cb[(size_t)fj * W + t] & tw) : 0ull;
+                            while (x) {
+                                acc += D[t * 64 + __builtin_ctzll(x)];
+                                x &= x - 1;
+                            }
+                        }
+                        if (lane == m) acc = h;
+                        Qm[m * 64 + lane] = acc;
+                        qcol = acc;
+                    }
+                    if (lane == m) wp_r += z;
+                    g += z * qcol;
+                }
+                iter++;
+                if (QP_Gnorm1_new <= inner_eps * Gnorm1_init) {
+                    if (QP_active == active) break;
+                    QP_active = active;
+                    QP_Gmax_old = 1e300;
+                    continue;
+                }
+                QP_Gmax_old = QP_Gmax_new;
+            }
+            // back to the array form: new visiting order, wpd, and xTd = X_A d
+            const int fnew = __shfl(fj, perm);
+            if (mine) { wpd[fj] = wp_r; act[lane] = fnew; }
+            const double dr = wp_r - wr;
+            for (int sidx = 0; sidx < active; sidx++) {
+                const double d = psk_readlane_f64(dr, sidx);
+                if (d == 0.0) continue;
+                const uint64_t cw = load_col(__builtin_amdgcn_readlane(fj, sidx));
+                for (int t = 0; t < W; t++) {
+                    const uint64_t xw = psk_readlane_u64(cw, t);
+                    if ((xw >> lane) & 1) xTd[t * 64 + lane] += d;
+                }
+            }
+        } else
+        while (iter < 1000) {
+            double QP_Gmax_new = 0.0, QP_Gnorm1_new = 0.0;
+            for (int sidx = 0; sidx < QP_active; sidx++) {
+                const int j = f_lds ? act[sidx] : __builtin_amdgcn_readfirstlane(lane == 0 ? act[sidx] : 0);
+                const double H = FLD(&Hd[j]);
+                const double wp = FLD(&wpd[j]);
+                const uint64_t cw = load_col(j);
+                double G = 0.0;
+                for (int t = 0; t < W; t++) {
+                    const uint64_t xw = psk_readlane_u64(cw, t);
+                    const double b = ((xw >> lane) & 1) ? 1.0 : 0.0;
+                    const int i = t * 64 + lane;
+                    G += b * D[i] * xTd[i];
+                }
+                G = psk_wave_sum_f64_dpp(G) + FLD(&Gr[j]) + (wp - FLD(&w[j])) * nu;
+                const double Gp = G + 1.0, Gn = G - 1.0;
+                double viol = 0.0;
+                if (wp == 0.0) {
+                    if (Gp < 0) viol = -Gp;
+                    else if (Gn > 0) viol = Gn;
+                    else if (Gp > QP_Gmax_old / l && Gn < -QP_Gmax_old / l) {
+                        QP_active--;
+                        if (lane == 0) { const int32_t tt = act[sidx]; act[sidx] = act[QP_active]; act[QP_active] = tt; }
+                        sidx--;
+                        continue;
+                    }
+                } else if (wp > 0) viol = fabs(Gp);
+                else viol = fabs(Gn);
+                if (viol > QP_Gmax_new) QP_Gmax_new = viol;
+                QP_Gnorm1_new += viol;
+                double z;
+                if (Gp < H * wp) z = -Gp / H;
+                else if (Gn > H * wp) z = -Gn / H;
+                else z = -wp;
+                if (fabs(z) < 1e-12) continue;
+                z = fmin(fmax(z, -10.0), 10.0);
+                if (lane == 0) wpd[j] = wp + z;
+                for (int t = 0; t < W; t++) {
+                    const uint64_t xw = psk_readlane_u64(cw, t);
+                    if ((xw >> lane) & 1) xTd[t * 64 + lane] += z;
+                }
+            }
+            iter++;
+            if (QP_Gnorm1_new <= inner_eps * Gnorm1_init) {
+                if (QP_active == active) break;
+                QP_active = active;
+                QP_Gmax_old = 1e300;
+                continue;
+            }
+            QP_Gmax_old = QP_Gmax_new;
+        }
+
+        double delta = 0.0, w_norm_new = 0.0;
+        for (int j = 0; j < P1; j++) {
+            const double wp = FLD(&wpd[j]);
+            delta += FLD(&Gr[j]) * (wp - FLD(&w[j]));
+            w_norm_new += fabs(wp);
+        }
+        delta += (w_norm_new - w_norm);
+        double negsum = 0.0;
+        for (int t = 0; t < W; t++) {
+            const uint64_t nw = psk_readlane_u64(negw, t);
+            if ((nw >> lane) & 1) negsum += C * xTd[t * 64 + lane];
+        }
+        negsum = psk_wave_sum_f64_dpp(negsum);
+        bool accepted = false;
+        for (int ls = 0; ls < 20; ls++) {
+            double cs = 0.0;
+            for (int t = 0; t < W; t++) {
+                const uint64_t tw = psk_readlane_u64(trainw, t);
+                if (!((tw >> lane) & 1)) continue;
+                const int i = t * 64 + lane;
+                const double ex = exp(xTd[i]);
+                const double en = ewx[i] * ex;
+                ewxn[i] = en;
+                cs += C * log((1.0 + en) / (ex + en));
+            }
+            const double cond = w_norm_new - w_norm + negsum - sigma * delta + psk_wave_sum_f64_dpp(cs);
+            if (cond <= 0.0) {
+                w_norm = w_norm_new;
+                for (int j = 0; j < P1; j++) { if (lane == 0) w[j] = wpd[j]; }
+                for (int t = 0; t < W; t++) {
+                    const uint64_t tw = psk_readlane_u64(trainw, t);
+                    if (!((tw >> lane) & 1)) continue;
+                    const int i = t * 64 + lane;
+                    const double en = ewxn[i];
+                    const double tt = 1.0 / (1.0 + en);
+                    ewx[i] = en; tau[i] = C * tt; D[i] = C * en * tt * tt;
+                }
+                accepted = true;
+                break;
+            }
+            w_norm_new = 0.0;
+            for (int j = 0; j < P1; j++) {
+                const double v = 0.5 * (FLD(&w[j]) + FLD(&wpd[j]));
+                if (lane == 0) wpd[j] = v;
+                w_norm_new += fabs(v);
+            }
+            delta *= 0.5;
+            negsum *= 0.5;
+            for (int t = 0; t < W; t++) xTd[t * 64 + lane] *= 0.5;
+        }
+        if (!accepted) {
+            for (int j = 0; j < P1; j++) { if (lane == 0) wpd[j] = w[j]; }
+        }
+        if (iter == 1) inner_eps *= 0.25;
+        Gmax_old = Gmax_new;
     }
-    if (lane == 0) { icpt[fit] = wb; iters[fit] = sweep; }
+    for (int j = 0; j < p; j++) { if (lane == 0) coef[(size_t)fit * p + j] = w[j]; }
+    if (lane == 0) { icpt[fit] = w[p]; iters[fit] = newton; }
 }
+#undef FLD
 
 __global__ __launch_bounds__(SV_THREADS) void lasso_kernel(const float *__restrict__ XT, const double *__restrict__ y,
                                                             const int32_t *__restrict__ fold, int n, int p,
@@ -223,10 +630,10 @@ void transpose_f32(const float *X, int n, int p, std::vector<float> &XT)
 
 struct SolverBufs {
     void *xt = nullptr, *y = nullptr, *fold = nullptr, *param = nullptr, *ffold = nullptr, *coef = nullptr,
-         *icpt = nullptr, *iters = nullptr, *work = nullptr;
+         *icpt = nullptr, *iters = nullptr, *work = nullptr, *iwork = nullptr, *bits = nullptr;
     ~SolverBufs()
     {
-        void *ps[] = {xt, y, fold, param, ffold, coef, icpt, iters, work};
+        void *ps[] = {xt, y, fold, param, ffold, coef, icpt, iters, work, iwork, bits};
         for (void *q : ps) if (q) (void)hipFree(q);
     }
 };
@@ -264,18 +671,63 @@ extern "C" int psk_logreg_l1_fit(psk_ctx *ctx, const float *X, const int32_t *y0
     SV_ALLOC(b.coef, (size_t)n_fits * p * 8);
     SV_ALLOC(b.icpt, (size_t)n_fits * 8);
     SV_ALLOC(b.iters, (size_t)n_fits * 4);
-    const int use_lds = n <= SV_LDS_N ? 1 : 0;
-    const size_t lds = use_lds ? (size_t)2 * n * sizeof(double) : 0;
-    SV_ALLOC(b.work, use_lds ? 8 : (size_t)n_fits * 2 * n * 8);
-    PSK_HIP(ctx, hipMemcpyAsync(b.xt, XT.data(), XT.size() * sizeof(float), hipMemcpyHostToDevice, ctx->stream));
+    // presence/absence design (every entry 0 or 1)?  -> bit-packed kernel
+    bool binary = n <= 4096;  // the bit-packed kernel keeps a column in one register per lane (64 words)
+    for (size_t q = 0; binary && q < (size_t)n * p; q++) binary = (X[q] == 0.0f || X[q] == 1.0f);
+    const int W = (n + 63) / 64;
+    const size_t n_state = binary ? (size_t)W * 64 : (size_t)n;
+    // placement of the per-fit state: everything in LDS when it fits the 160 KiB of a CU, else the sample
+    // arrays only, else global scratch
+    const size_t fbytes = 5 * (size_t)(p + 1) * 8, sbytes = 5 * n_state * 8, lds_max = 160 * 1024 - 512;
+    int f_lds = 0, s_lds = 0;
+    if (fbytes + sbytes <= lds_max) f_lds = s_lds = 1;
+    else if (sbytes <= lds_max) s_lds = 1;
+    else if (fbytes <= lds_max) f_lds = 1;
+    const size_t lds = (f_lds ? fbytes : 0) + (s_lds ? sbytes : 0);
+    SV_ALLOC(b.work, (size_t)n_fits * (fbytes + sbytes));
+    SV_ALLOC(b.iwork, (size_t)n_fits * (p + 1) * 4);
     PSK_HIP(ctx, hipMemcpyAsync(b.y, ypm.data(), n, hipMemcpyHostToDevice, ctx->stream));
     PSK_HIP(ctx, hipMemcpyAsync(b.fold, fold, (size_t)n * 4, hipMemcpyHostToDevice, ctx->stream));
     PSK_HIP(ctx, hipMemcpyAsync(b.param, fit_param, (size_t)n_fits * 8, hipMemcpyHostToDevice, ctx->stream));
     PSK_HIP(ctx, hipMemcpyAsync(b.ffold, fit_fold, (size_t)n_fits * 4, hipMemcpyHostToDevice, ctx->stream));
-    logreg_l1_kernel<<<n_fits, SV_THREADS, lds, ctx->stream>>>(
-        (const float *)b.xt, (const int8_t *)b.y, (const int32_t *)b.fold, n, p, (const double *)b.param,
-        (const int32_t *)b.ffold, tol, max_iter, (double *)b.coef, (double *)b.icpt, (int32_t *)b.iters,
-        (double *)b.work, use_lds);
+    if (binary) {
+        // LDS budget of the bit-packed kernel: sample arrays first, then feature arrays + active list, then
+        // the column bit words themselves
+        const size_t fa = fbytes + (((size_t)(p + 1) + 1) / 2) * 8, cbytes = (size_t)(p + 1) * W * 8;
+        size_t left = lds_max;
+        s_lds = sbytes <= left ? 1 : 0; left -= s_lds ? sbytes : 0;
+        const size_t qbytes = 64 * 64 * 8;
+        const int q_lds = (s_lds && qbytes <= left) ? 1 : 0; left -= q_lds ? qbytes : 0;
+        f_lds = fa <= left ? 1 : 0; left -= f_lds ? fa : 0;
+        const int c_lds = cbytes <= left ? 1 : 0;
+        const size_t lds_b = (s_lds ? sbytes : 0) + (q_lds ? qbytes : 0) + (f_lds ? fa : 0) + (c_lds ? cbytes : 0);
+        std::vector<uint64_t> bits((size_t)(p + 1) * W, 0);
+        for (int i = 0; i < n; i++) {
+            for (int j = 0; j < p; j++)
+                if (X[(size_t)i * p + j] != 0.0f) bits[(size_t)j * W + (i >> 6)] |= 1ull << (i & 63);
+            bits[(size_t)p * W + (i >> 6)] |= 1ull << (i & 63);  // constant-1 intercept column
+        }
+        SV_ALLOC(b.bits, bits.size() * 8);
+        PSK_HIP(ctx, hipMemcpyAsync(b.bits, bits.data(), bits.size() * 8, hipMemcpyHostToDevice, ctx->stream));
+        if (lds_b > 64 * 1024)
+            PSK_HIP(ctx, hipFuncSetAttribute(reinterpret_cast<const void *>(logreg_newglmnet_bits_kernel),
+                                             hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_b));
+        logreg_newglmnet_bits_kernel<<<n_fits, SV_THREADS, lds_b, ctx->stream>>>(
+            (const uint64_t *)b.bits, (const int8_t *)b.y, (const int32_t *)b.fold, n, p, W, (const double *)b.param,
+            (const int32_t *)b.ffold, tol, max_iter, (double *)b.coef, (double *)b.icpt, (int32_t *)b.iters,
+            (double *)b.work, (int32_t *)b.iwork, f_lds, s_lds, c_lds, q_lds);
+        PSK_HIP(ctx, hipGetLastError());
+        PSK_HIP(ctx, hipStreamSynchronize(ctx->stream));  // `bits` (host) must outlive the copy
+    } else {
+        PSK_HIP(ctx, hipMemcpyAsync(b.xt, XT.data(), XT.size() * sizeof(float), hipMemcpyHostToDevice, ctx->stream));
+        if (lds > 64 * 1024)
+            PSK_HIP(ctx, hipFuncSetAttribute(reinterpret_cast<const void *>(logreg_newglmnet_kernel),
+                                             hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        logreg_newglmnet_kernel<<<n_fits, SV_THREADS, lds, ctx->stream>>>(
+            (const float *)b.xt, (const int8_t *)b.y, (const int32_t *)b.fold, n, p, (const double *)b.param,
+            (const int32_t *)b.ffold, tol, max_iter, (double *)b.coef, (double *)b.icpt, (int32_t *)b.iters,
+            (double *)b.work, (int32_t *)b.iwork, f_lds, s_lds);
+    }
     PSK_HIP(ctx, hipGetLastError());
     PSK_HIP(ctx, hipMemcpyAsync(coef_out, b.coef, (size_t)n_fits * p * 8, hipMemcpyDeviceToHost, ctx->stream));
     PSK_HIP(ctx, hipMemcpyAsync(icpt_out, b.icpt, (size_t)n_fits * 8, hipMemcpyDeviceToHost, ctx->stream));

@@ -31,6 +31,28 @@ with open(os.path.join(tmp, "data.pheno"), "w") as f:
 t_write = time.time() - t0
 os.chdir(tmp)
 args = build_parser().parse_args(["modeling", "data.pheno"] + extra)
+# stage timers (monkey-patched wrappers around the host pipeline's stages)
+from phenotypeseeker_amd import modeling as _M  # noqa: E402
+stage = {}
+
+
+def _timed(cls, name):
+    orig = getattr(cls, name)
+    fn = orig.__func__ if hasattr(orig, "__func__") else orig
+
+    def wrapper(*a, **k):
+        t = time.time()
+        r = fn(*a, **k)
+        stage[name] = round(stage.get(name, 0.0) + time.time() - t, 3)
+        return r
+    setattr(cls, name, classmethod(wrapper) if isinstance(cls.__dict__[name], classmethod) else wrapper)
+
+
+_timed(_M.Samples, "get_kmer_lists_batched")
+_timed(_M.Samples, "get_feature_vector")
+_timed(_M.phenotypes, "test_kmers_association_with_phenotype")
+_timed(_M.phenotypes, "get_ML_df")
+_timed(_M.phenotypes, "machine_learning_modelling")
 err = sys.stderr
 sys.stderr = open(os.devnull, "w")
 t0 = time.time()
@@ -38,7 +60,7 @@ args.func(args)
 wall = time.time() - t0
 sys.stderr = err
 log = open("log.txt").read().strip().splitlines()
-out = {"samples": n, "length": length, "flags": extra, "write_dataset_s": round(t_write, 2), "modeling_wall_s": round(wall, 3),
+out = {"samples": n, "length": length, "flags": extra, "write_dataset_s": round(t_write, 2), "modeling_wall_s": round(wall, 3), "stages_s": stage,
        "log": log, "outputs": sorted(f for f in os.listdir(".") if not f.endswith(".fasta"))}
 print(json.dumps(out))
 shutil.rmtree(tmp, ignore_errors=True)

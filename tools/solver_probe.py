@@ -1,0 +1,45 @@
+#!/usr/bin/env python3
+"""Times the L1 solver on the (grid x fold) problem of a real modeling run.
+usage: tools/solver_probe.py dump N LENGTH out.npz   -- run the pipeline, save the solver inputs
+       tools/solver_probe.py time in.npz             -- time every fit of the saved problem alone"""
+import os
+import subprocess
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+
+if sys.argv[1] == "dump":
+    out = os.path.abspath(sys.argv[4])
+    from phenotypeseeker_amd import engine
+    orig = engine.PskContext._fit
+
+    def spy(self, fn, name, X, y, ydtype, fold, fit_param, fit_fold, tol, max_iter):
+        t = time.time()
+        r = orig(self, fn, name, X, y, ydtype, fold, fit_param, fit_fold, tol, max_iter)
+        np.savez(out, X=X, y=y, fold=fold, fit_param=fit_param, fit_fold=fit_fold, tol=tol, max_iter=max_iter,
+                 iters=r[2], secs=time.time() - t)
+        return r
+    engine.PskContext._fit = spy
+    sys.argv = [sys.argv[0], sys.argv[2], sys.argv[3]]
+    exec(open(os.path.join(ROOT, "tools", "e2e_wallclock.py")).read())
+else:
+    from phenotypeseeker_amd.engine import PskContext
+    d = np.load(sys.argv[2])
+    X, y, fold, fp, ff = d["X"], d["y"], d["fold"], d["fit_param"], d["fit_fold"]
+    tol, mi = float(d["tol"]), int(d["max_iter"])
+    print("X", X.shape, "fits", len(fp), "whole call", float(d["secs"]), "iters", d["iters"].tolist())
+    ctx = PskContext(0)
+    ctx.logreg_l1_fit(X, y, fold, fp[:1], ff[:1], tol, mi)
+    t = time.time()
+    ctx.logreg_l1_fit(X, y, fold, fp, ff, tol, mi)
+    print("all fits again: %.3f s" % (time.time() - t))
+    for i in range(len(fp)):
+        t = time.time()
+        c, b, it = ctx.logreg_l1_fit(X, y, fold, fp[i:i + 1], ff[i:i + 1], tol, mi)
+        dt = time.time() - t
+        if dt > 0.02 or i % 13 == 0:
+            print("fit %3d C=%-8g fold=%2d newton=%4d nnz=%4d  %.4f s" % (i, fp[i], ff[i], it[0], (c != 0).sum(), dt))
