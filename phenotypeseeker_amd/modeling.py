@@ -91,9 +91,13 @@ class Samples:
         pool, host tokenisation runs ahead of the GPU inside the library."""
         from concurrent.futures import ThreadPoolExecutor
         with ThreadPoolExecutor(max_workers=n_threads) as pool:
+            def submit(lo):
+                return [pool.submit(formats.read_sequence_file, s.address) for s in samples[lo:lo + chunk]]
+            pending = submit(0)
             for lo in range(0, len(samples), chunk):
                 part = samples[lo:lo + chunk]
-                datas = list(pool.map(lambda s: formats.read_sequence_file(s.address), part))
+                datas = [f.result() for f in pending]
+                pending = submit(lo + chunk)  # the next chunk is read while this one is counted
                 nu, nt = ctx.count_kmers_batch(lo, datas, n_threads)
                 for j, s in enumerate(part):
                     s.n_unique, s.n_total = nu[j], nt[j]

@@ -53,6 +53,9 @@ _timed(_M.Samples, "get_feature_vector")
 _timed(_M.phenotypes, "test_kmers_association_with_phenotype")
 _timed(_M.phenotypes, "get_ML_df")
 _timed(_M.phenotypes, "machine_learning_modelling")
+from phenotypeseeker_amd import engine as _E  # noqa: E402
+_timed(_E.PskContext, "count_kmers_batch")
+_timed(_E.PskContext, "_fit")
 err = sys.stderr
 sys.stderr = open(os.devnull, "w")
 t0 = time.time()
