@@ -153,6 +153,25 @@ int psk_lasso_fit(psk_ctx *ctx, const float *X, const double *y, int n, int p, c
                   const double *fit_param, const int32_t *fit_fold, int n_fits, double tol, int max_iter,
                   double *coef_out, double *icpt_out, int32_t *iters_out);
 
+/* ---- f4: the `--penalty L2` estimators --------------------------------------------------------
+ * Replaces GridSearchCV over Ridge (set_model, modeling.py:1001-1002) and over
+ * LogisticRegression(penalty='l2', solver=<-ls>) (modeling.py:1015-1019, get_logreg_solver :256-264).
+ * Same batching and argument meaning as the L1 fits above.
+ * Ridge: ||y - Xw - b||^2 + alpha ||w||^2 over the training rows, unpenalised intercept (sklearn's
+ *   fit_intercept centring); solved to convergence (scikit-learn's dense solve is direct), so there is
+ *   no tol / max_iter.  iters_out = conjugate-gradient steps.
+ * Logistic: 0.5 (w'w [+ b^2]) + C sum log(1+exp(-y(w.x+b))); penalise_intercept = 1 for the liblinear
+ *   solver (intercept is a penalised constant feature), 0 for lbfgs / newton-cg / sag / saga.  Stops on
+ *   liblinear's relative gradient rule or, for the others, max|grad| <= tol * C (scikit-learn 0.22 hands
+ *   tol to L-BFGS as gtol on objective / C).  iters_out = Newton steps.
+ */
+int psk_ridge_fit(psk_ctx *ctx, const float *X, const double *y, int n, int p, const int32_t *fold,
+                  const double *fit_param, const int32_t *fit_fold, int n_fits, double *coef_out, double *icpt_out,
+                  int32_t *iters_out);
+int psk_logreg_l2_fit(psk_ctx *ctx, const float *X, const int32_t *y01, int n, int p, const int32_t *fold,
+                      const double *fit_param, const int32_t *fit_fold, int n_fits, double tol, int max_iter,
+                      int penalise_intercept, double *coef_out, double *icpt_out, int32_t *iters_out);
+
 /* ---- f1: fixed-dictionary counting (prediction) ---------------------------------------------
  * Replaces `gmer_counter -db <txt> <addr>` (prediction.Samples.map_samples, prediction.py:72-80):
  * occurrences, both strands with multiplicity, of each dictionary k-mer (canonical words) in

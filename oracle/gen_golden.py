@@ -375,6 +375,55 @@ def gen_model_kat():
           out["lasso_gs_best_alpha2"])
 
 
+def gen_model_l2_kat():
+    """Converged optima of the `--penalty L2` estimators (set_model, modeling.py:1001-1002, :1015-1019) on
+    the designs of model_kat.npz: Ridge (direct solve) and LogisticRegression(penalty='l2') with a free
+    intercept (newton-cg stands for lbfgs/newton-cg/sag/saga: one objective) and with liblinear's
+    penalised one; plus the GridSearchCV scores."""
+    from sklearn.linear_model import LogisticRegression, Ridge
+    from sklearn.model_selection import GridSearchCV
+    z = np.load(os.path.join(GOLD, "model_kat.npz"))
+    X2, y2, yc2, Cs, alphas = z["X2"], z["y2"], z["yc2"], z["Cs"], z["alphas"]
+    X1, y1 = z["X1"], z["y1"]
+    rng = np.random.default_rng(7)
+    yc1 = 3.0 * X1[:, 0] + rng.normal(0, 0.5, X1.shape[0]) + 1.0  # continuous target on the degenerate design
+    out = {"yc1": yc1}
+    for tag, XX, yy in (("1", X1, yc1), ("2", X2, yc2)):
+        rc, ri = [], []
+        for a in alphas:
+            m = Ridge(alpha=a).fit(XX, yy)
+            rc.append(m.coef_); ri.append(m.intercept_)
+        out["ridge_coef" + tag], out["ridge_icpt" + tag] = np.array(rc), np.array(ri)
+    gs = GridSearchCV(Ridge(), {"alpha": list(alphas)}, cv=10).fit(X2, yc2)
+    out["ridge_gs_mean_score2"] = gs.cv_results_["mean_test_score"]
+    out["ridge_gs_best_alpha2"] = np.array(gs.best_params_["alpha"])
+    for tag, XX, yy in (("1", X1, y1), ("2", X2, y2)):
+        ypm = 2.0 * yy - 1.0
+        for name, kw in (("free", dict(solver="newton-cg", tol=1e-13, max_iter=100000)),
+                         ("liblinear", dict(solver="liblinear", tol=1e-13, max_iter=100000))):
+            cc, ii, gg = [], [], []
+            for C in Cs:
+                m = LogisticRegression(penalty="l2", C=C, **kw).fit(XX, yy)
+                w, b = m.coef_[0], m.intercept_[0]
+                s = 1.0 / (1.0 + np.exp(ypm * (XX @ w + b)))
+                gw = w - C * (XX.T @ (ypm * s))
+                gb = (b if name == "liblinear" else 0.0) - C * (ypm * s).sum()
+                cc.append(w); ii.append(b); gg.append(max(np.abs(gw).max(), abs(gb)) / max(C, 1.0))
+            out["l2_%s_coef%s" % (name, tag)] = np.array(cc)
+            out["l2_%s_icpt%s" % (name, tag)] = np.array(ii)
+            out["l2_%s_gradmax%s" % (name, tag)] = np.array(gg)
+        cv = int(min(np.bincount(yy).min(), 10))
+        gs = GridSearchCV(LogisticRegression(penalty="l2", solver="newton-cg", tol=1e-13, max_iter=100000),
+                          {"C": list(Cs)}, cv=cv).fit(XX, yy)
+        out["l2_gs_mean_score" + tag] = gs.cv_results_["mean_test_score"]
+        out["l2_gs_best_C" + tag] = np.array(gs.best_params_["C"])
+    np.savez_compressed(os.path.join(GOLD, "model_l2_kat.npz"), **out)
+    print("L2 model KATs: worst scaled gradient free %.2e liblinear %.2e; best alpha %g best C %g %g" % (
+        max(out["l2_free_gradmax1"].max(), out["l2_free_gradmax2"].max()),
+        max(out["l2_liblinear_gradmax1"].max(), out["l2_liblinear_gradmax2"].max()),
+        out["ridge_gs_best_alpha2"], out["l2_gs_best_C1"], out["l2_gs_best_C2"]))
+
+
 def gen_gmer_counter():
     """prediction.py:72-80,145-148: db line 'KMER\\t1\\tKMER', output parsed at :82-100."""
     gs = GenomeSet(4, 6000, seed=31, gene_len=200)
@@ -465,7 +514,7 @@ def gen_split():
 
 if __name__ == "__main__":
     os.makedirs(GOLD, exist_ok=True)
-    what = sys.argv[1:] or ["tok", "ds", "chi2", "welch", "model", "gmer", "mash", "split"]
+    what = sys.argv[1:] or ["tok", "ds", "chi2", "welch", "model", "model_l2", "gmer", "mash", "split"]
     if "tok" in what:
         gen_tokenizer_cases()
     if "ds" in what:
@@ -478,6 +527,8 @@ if __name__ == "__main__":
         gen_welch_kat()
     if "model" in what:
         gen_model_kat()
+    if "model_l2" in what:
+        gen_model_l2_kat()
     if "gmer" in what:
         gen_gmer_counter()
     if "mash" in what:

@@ -98,6 +98,53 @@ def lasso_fit(X, y, alpha, tol=1e-14, max_sweeps=1000000):
     return w, b.value
 
 
+def ridge_fit(X, y, alpha):
+    """sklearn Ridge(alpha), fit_intercept=True, dense X (set_model, modeling.py:1001-1002): centre X and y by
+    their column means, solve (Xc'Xc + alpha I) w = Xc'yc directly, intercept = ybar - xbar.w."""
+    X = np.asarray(X, dtype=np.float64)
+    y = np.asarray(y, dtype=np.float64)
+    xm, ym = X.mean(axis=0), y.mean()
+    Xc, yc = X - xm, y - ym
+    w = np.linalg.solve(Xc.T @ Xc + alpha * np.eye(X.shape[1]), Xc.T @ yc)
+    return w, float(ym - xm @ w)
+
+
+def logreg_l2_objective(X, y01, w, b, C, penalise_intercept=False):
+    z = X @ w + b
+    ypm = 2.0 * np.asarray(y01, dtype=np.float64) - 1.0
+    return 0.5 * (w @ w + (b * b if penalise_intercept else 0.0)) + C * np.logaddexp(0.0, -ypm * z).sum()
+
+
+def logreg_l2_fit(X, y01, C, penalise_intercept=False, iters=200):
+    """LogisticRegression(penalty='l2') (set_model, modeling.py:1015-1019): 0.5 w'w + C sum log(1+exp(-y z)),
+    z = Xw + b.  The intercept is free for lbfgs/newton-cg/sag/saga and a penalised constant feature for
+    liblinear.  Exact Newton steps with halving until the gradient vanishes (strictly convex)."""
+    X = np.asarray(X, dtype=np.float64)
+    ypm = 2.0 * np.asarray(y01, dtype=np.float64) - 1.0
+    n, p = X.shape
+    A = np.hstack([X, np.ones((n, 1))])
+    R = np.eye(p + 1)
+    if not penalise_intercept:
+        R[p, p] = 0.0
+    th = np.zeros(p + 1)
+
+    def f(t):
+        return 0.5 * t @ R @ t + C * np.logaddexp(0.0, -ypm * (A @ t)).sum()
+    for _ in range(iters):
+        z = A @ th
+        s = 1.0 / (1.0 + np.exp(ypm * z))
+        g = R @ th - C * (A.T @ (ypm * s))
+        if np.abs(g).max() < 1e-13 * max(1.0, C):
+            break
+        H = R + C * (A.T * (s * (1 - s))) @ A
+        d = np.linalg.solve(H, -g)
+        t, f0 = 1.0, f(th)
+        while f(th + t * d) > f0 + 1e-4 * t * (g @ d) and t > 1e-12:
+            t *= 0.5
+        th = th + t * d
+    return th[:p].copy(), float(th[p])
+
+
 def r2_score(y, pred):
     y = np.asarray(y, dtype=np.float64)
     ss_res = ((y - pred) ** 2).sum()
@@ -106,26 +153,27 @@ def r2_score(y, pred):
 
 
 def grid_search(X, y, grid, kind, cv):
-    """GridSearchCV restatement.  kind: 'logreg' (grid of C) or 'lasso' (grid of alpha).
+    """GridSearchCV restatement.  kind: 'logreg' | 'logreg_l2' | 'logreg_l2_liblinear' (grid of C) or
+    'lasso' | 'ridge' (grid of alpha).
     Returns dict(mean_test_score, std_test_score, best_index, coef, intercept)."""
     X = np.asarray(X, dtype=np.float64)
     y = np.asarray(y)
-    folds = stratified_kfold(y, cv) if kind == "logreg" else kfold(len(y), cv)
+    is_clf = kind.startswith("logreg")
+    fit = {"logreg": logreg_l1_fit, "logreg_l2": logreg_l2_fit,
+           "logreg_l2_liblinear": lambda A, t, g: logreg_l2_fit(A, t, g, True),
+           "lasso": lasso_fit, "ridge": ridge_fit}[kind]
+    folds = stratified_kfold(y, cv) if is_clf else kfold(len(y), cv)
     scores = np.zeros((len(grid), cv))
     for gi, g in enumerate(grid):
         for f in range(cv):
             tr, te = folds != f, folds == f
-            if kind == "logreg":
-                w, b = logreg_l1_fit(X[tr], y[tr], g)
+            w, b = fit(X[tr], y[tr], g)
+            if is_clf:
                 scores[gi, f] = (logreg_predict(X[te], w, b) == y[te]).mean()
             else:
-                w, b = lasso_fit(X[tr], y[tr], g)
                 scores[gi, f] = r2_score(y[te], X[te] @ w + b)
     mean = scores.mean(axis=1)
     best = int(np.argmax(mean))  # first maximum, as rank_test_score.argmin() picks
-    if kind == "logreg":
-        w, b = logreg_l1_fit(X, y, grid[best])
-    else:
-        w, b = lasso_fit(X, y, grid[best])
+    w, b = fit(X, y, grid[best])
     return {"mean_test_score": mean, "std_test_score": scores.std(axis=1), "best_index": best, "coef": w,
             "intercept": b, "folds": folds}

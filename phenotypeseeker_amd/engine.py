@@ -206,6 +206,34 @@ class PskContext:
         return self._fit(self._lib.psk_lasso_fit, "psk_lasso_fit", X, y, np.float64, fold, fit_param, fit_fold, tol,
                          max_iter)
 
+    def ridge_fit(self, X, y, fold, fit_param, fit_fold):
+        """Ridge fits (psk_ridge_fit): same batching as lasso_fit, solved to convergence."""
+        X = np.ascontiguousarray(X, dtype=np.float32)
+        n, p = X.shape
+        y = np.ascontiguousarray(y, dtype=np.float64)
+        fold = np.ascontiguousarray(fold, dtype=np.int32)
+        fit_param = np.ascontiguousarray(fit_param, dtype=np.float64)
+        fit_fold = np.ascontiguousarray(fit_fold, dtype=np.int32)
+        nf = len(fit_param)
+        coef, icpt, iters = np.zeros((nf, p)), np.zeros(nf), np.zeros(nf, dtype=np.int32)
+        self._check(self._lib.psk_ridge_fit(self._h, _ptr(X), _ptr(y), n, p, _ptr(fold), _ptr(fit_param), _ptr(fit_fold),
+                                            nf, _ptr(coef), _ptr(icpt), _ptr(iters)), "psk_ridge_fit")
+        return coef, icpt, iters
+
+    def logreg_l2_fit(self, X, y01, fold, fit_param, fit_fold, tol=1e-4, max_iter=1000, penalise_intercept=False):
+        X = np.ascontiguousarray(X, dtype=np.float32)
+        n, p = X.shape
+        y = np.ascontiguousarray(y01, dtype=np.int32)
+        fold = np.ascontiguousarray(fold, dtype=np.int32)
+        fit_param = np.ascontiguousarray(fit_param, dtype=np.float64)
+        fit_fold = np.ascontiguousarray(fit_fold, dtype=np.int32)
+        nf = len(fit_param)
+        coef, icpt, iters = np.zeros((nf, p)), np.zeros(nf), np.zeros(nf, dtype=np.int32)
+        self._check(self._lib.psk_logreg_l2_fit(self._h, _ptr(X), _ptr(y), n, p, _ptr(fold), _ptr(fit_param),
+                                                _ptr(fit_fold), nf, float(tol), int(max_iter), int(bool(penalise_intercept)),
+                                                _ptr(coef), _ptr(icpt), _ptr(iters)), "psk_logreg_l2_fit")
+        return coef, icpt, iters
+
     # -- population-structure weights --------------------------------------------------------------
     def minhash_sketch(self, data, k=21, sketch_size=1000, seed=42):
         data = bytes(data)

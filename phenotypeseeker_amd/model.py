@@ -4,7 +4,9 @@ Lasso (modeling.py:994-1014, :1075-1085, :1208-1216, :975-979) -- exposing the a
 reference reads: predict / predict_proba / score, cv_results_['mean_test_score' |
 'std_test_score' | 'params'], best_params_, best_estimator_.coef_ (modeling.py:1226-1247,
 :1427-1436; prediction.py:126-129,:168-172).  All fits of a grid search (grid x folds + the
-refit) are solved on the GPU in one psk_logreg_l1_fit / psk_lasso_fit launch.
+refit) are solved on the GPU in one psk_logreg_l1_fit / psk_lasso_fit launch.  `--penalty L2`
+(modeling.py:1001-1002, :1015-1019) maps to RidgeRegression / L2LogisticRegression over
+psk_ridge_fit / psk_logreg_l2_fit in the same way.
 """
 import numpy as np
 
@@ -13,6 +15,8 @@ from . import cv as _cv
 
 class L1LogisticRegression:
     """liblinear-style L1 logistic regression: ||w||_1 + |b| + C sum log(1+exp(-y(w.x+b)))."""
+    _is_classifier = True
+    _dedupe = True  # an L1 optimum may sit on any copy of a repeated column: solve each pattern once
 
     def __init__(self, C=1.0, tol=1e-4, max_iter=1000):
         self.C, self.tol, self.max_iter = C, tol, max_iter
@@ -32,6 +36,12 @@ class L1LogisticRegression:
         if self.tol != 1e-4:
             parts.append("tol=%r" % self.tol)
         return "LogisticRegression(%s)" % ", ".join(parts)
+
+    def _clone(self, **params):
+        return type(self)(**params)
+
+    def _engine_fit(self, ctx, X, y, folds, fit_param, fit_fold):
+        return ctx.logreg_l1_fit(X, y.astype(np.int32), folds, fit_param, fit_fold, self.tol, int(self.max_iter))
 
     def _set(self, coef, icpt):
         self.coef_ = np.asarray(coef, dtype=np.float64).reshape(1, -1)
@@ -53,8 +63,42 @@ class L1LogisticRegression:
         return np.float64(np.mean(self.predict(X) == np.asarray(y)))
 
 
+class L2LogisticRegression(L1LogisticRegression):
+    """0.5 w'w + C sum log(1+exp(-y(w.x+b))): LogisticRegression(penalty='l2', solver=...)
+    (modeling.py:1015-1019).  The intercept is free for lbfgs / newton-cg / sag / saga and a penalised
+    constant feature for liblinear (get_logreg_solver, modeling.py:256-264); the optimum is unique
+    either way, so one Newton solver serves all five names."""
+    _dedupe = False
+
+    def __init__(self, C=1.0, tol=1e-4, max_iter=1000, solver="lbfgs"):
+        super().__init__(C, tol, max_iter)
+        self.penalty, self.solver = "l2", solver
+
+    def __repr__(self):
+        parts = []
+        if self.C != 1.0:
+            parts.append("C=%r" % self.C)
+        if repr(self.max_iter) != "100":
+            parts.append("max_iter=%r" % self.max_iter)
+        if self.solver != "lbfgs":
+            parts.append("solver=%r" % self.solver)
+        if self.tol != 1e-4:
+            parts.append("tol=%r" % self.tol)
+        return "LogisticRegression(%s)" % ", ".join(parts)
+
+    def _clone(self, **params):
+        return type(self)(solver=self.solver, **params)
+
+    def _engine_fit(self, ctx, X, y, folds, fit_param, fit_fold):
+        return ctx.logreg_l2_fit(X, y.astype(np.int32), folds, fit_param, fit_fold, self.tol, int(self.max_iter),
+                                 self.solver == "liblinear")
+
+
 class LassoRegression:
     """(1/2n)||y - Xw - b||^2 + alpha ||w||_1."""
+    _is_classifier = False
+    _dedupe = True
+    _sk_name = "Lasso"
 
     def __init__(self, alpha=1.0, tol=1e-4, max_iter=1000):
         self.alpha, self.tol, self.max_iter = alpha, tol, max_iter
@@ -69,7 +113,13 @@ class LassoRegression:
             parts.append("max_iter=%r" % self.max_iter)
         if self.tol != 1e-4:
             parts.append("tol=%r" % self.tol)
-        return "Lasso(%s)" % ", ".join(parts)
+        return "%s(%s)" % (self._sk_name, ", ".join(parts))
+
+    def _clone(self, **params):
+        return type(self)(**params)
+
+    def _engine_fit(self, ctx, X, y, folds, fit_param, fit_fold):
+        return ctx.lasso_fit(X, y.astype(np.float64), folds, fit_param, fit_fold, self.tol, int(self.max_iter))
 
     def _set(self, coef, icpt):
         self.coef_ = np.asarray(coef, dtype=np.float64).ravel()
@@ -85,6 +135,26 @@ class LassoRegression:
         res = ((y - self.predict(X)) ** 2).sum()
         tot = ((y - y.mean()) ** 2).sum()
         return np.float64(1.0 - res / tot)
+
+
+class RidgeRegression(LassoRegression):
+    """||y - Xw - b||^2 + alpha ||w||^2: sklearn Ridge (modeling.py:1001-1002).  max_iter / tol are
+    carried for the repr only -- the dense solve is direct in scikit-learn and converged here."""
+    _dedupe = False
+    _sk_name = "Ridge"
+
+    def __repr__(self):
+        parts = []
+        if self.alpha != 1.0:
+            parts.append("alpha=%r" % self.alpha)
+        if self.max_iter is not None:
+            parts.append("max_iter=%r" % self.max_iter)
+        if self.tol != 1e-3:
+            parts.append("tol=%r" % self.tol)
+        return "Ridge(%s)" % ", ".join(parts)
+
+    def _engine_fit(self, ctx, X, y, folds, fit_param, fit_fold):
+        return ctx.ridge_fit(X, y.astype(np.float64), folds, fit_param, fit_fold)
 
 
 class GridSearch:
@@ -104,9 +174,12 @@ class GridSearch:
         # Identical columns (k-mers of one gene share a presence pattern) are solved once: an L1
         # optimum may place a pattern's weight on any of its copies, here on the first (which is also
         # what cyclic coordinate descent -- scikit-learn's Lasso -- does).
-        X, first, inverse = _unique_columns(X_full)
+        if self.estimator._dedupe:
+            X, first, inverse = _unique_columns(X_full)
+        else:  # an L2 optimum spreads a pattern's weight over its copies: every column stays
+            X, first = X_full, np.arange(X_full.shape[1])
         grid = self.param_grid[self.param_name]
-        is_clf = isinstance(self.estimator, L1LogisticRegression)
+        is_clf = self.estimator._is_classifier
         if self.cv < 2:
             raise ValueError("k-fold cross-validation requires at least one train/test split by setting "
                              "n_splits=2 or more, got n_splits=%d." % self.cv)
@@ -119,17 +192,13 @@ class GridSearch:
         for g in grid:  # refit candidates on everything: pick after scoring, all in one launch
             fit_param.append(float(g))
             fit_fold.append(-1)
-        tol, mi = self.estimator.tol, int(self.estimator.max_iter)
-        if is_clf:
-            coef, icpt, iters = engine_ctx.logreg_l1_fit(X, y.astype(np.int32), folds, fit_param, fit_fold, tol, mi)
-        else:
-            coef, icpt, iters = engine_ctx.lasso_fit(X, y.astype(np.float64), folds, fit_param, fit_fold, tol, mi)
+        coef, icpt, iters = self.estimator._engine_fit(engine_ctx, X, y, folds, fit_param, fit_fold)
         scores = np.zeros((len(grid), self.cv))
         for gi in range(len(grid)):
             for f in range(self.cv):
                 j = gi * self.cv + f
                 te = folds == f
-                est = type(self.estimator)(**{self.param_name: grid[gi]})._set(coef[j], icpt[j])
+                est = self.estimator._clone(**{self.param_name: grid[gi]})._set(coef[j], icpt[j])
                 scores[gi, f] = est.score(X[te], y[te])
         mean = scores.mean(axis=1)
         std = scores.std(axis=1)
@@ -142,7 +211,7 @@ class GridSearch:
         self.best_params_ = {self.param_name: grid[self.best_index_]}
         self.best_score_ = float(mean[self.best_index_])
         j = len(grid) * self.cv + self.best_index_
-        best = type(self.estimator)(**{self.param_name: grid[self.best_index_]})
+        best = self.estimator._clone(**{self.param_name: grid[self.best_index_]})
         best.tol, best.max_iter = self.estimator.tol, self.estimator.max_iter
         full = np.zeros(X_full.shape[1])
         full[first] = coef[j]
@@ -165,20 +234,22 @@ class GridSearch:
     def to_sklearn(self):
         """The same fitted model as real scikit-learn objects (for users whose downstream code
         insists on them); needs scikit-learn importable."""
-        from sklearn.linear_model import Lasso, LogisticRegression
+        from sklearn.linear_model import Lasso, LogisticRegression, Ridge
         from sklearn.model_selection import GridSearchCV
         be = self.best_estimator_
         if isinstance(be, L1LogisticRegression):
-            est = LogisticRegression(penalty="l1", solver="liblinear", C=be.C, tol=be.tol, max_iter=int(be.max_iter))
+            kw = dict(penalty=be.penalty, solver=be.solver, tol=be.tol, max_iter=int(be.max_iter))
+            est = LogisticRegression(C=be.C, **kw)
             est.classes_ = np.array([0, 1])
             est.coef_, est.intercept_ = be.coef_.copy(), be.intercept_.copy()
             est.n_iter_ = np.array([0], dtype=np.int32)
-            proto = LogisticRegression(penalty="l1", solver="liblinear", tol=be.tol, max_iter=int(be.max_iter))
+            proto = LogisticRegression(**kw)
         else:
-            est = Lasso(alpha=be.alpha, tol=be.tol, max_iter=int(be.max_iter))
+            cls = Ridge if isinstance(be, RidgeRegression) else Lasso
+            est = cls(alpha=be.alpha, tol=be.tol, max_iter=int(be.max_iter))
             est.coef_, est.intercept_ = be.coef_.copy(), be.intercept_
-            est.n_iter_ = 0
-            proto = Lasso(tol=be.tol, max_iter=int(be.max_iter))
+            est.n_iter_ = None if cls is Ridge else 0
+            proto = cls(tol=be.tol, max_iter=int(be.max_iter))
         est.n_features_in_ = be.n_features_in_
         gs = GridSearchCV(proto, self.param_grid, cv=self.cv)
         gs.best_estimator_, gs.best_params_ = est, dict(self.best_params_)

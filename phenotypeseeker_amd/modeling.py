@@ -24,7 +24,7 @@ import numpy as np
 from . import dist as _dist
 from . import formats, metrics, _stats
 from .engine import PskContext
-from .model import GridSearch, L1LogisticRegression, LassoRegression
+from .model import GridSearch, L1LogisticRegression, L2LogisticRegression, LassoRegression, RidgeRegression
 
 RED_BANNER = "\x1b[1;1;101m%s\x1b[0m\n"
 GREEN = "\x1b[1;32m%s\x1b[0m"
@@ -256,11 +256,25 @@ class Input:
                 raise SystemExit("Only the logistic-regression classifier runs on the GPU engine, got %r "
                                  "(SVM/RF/DT/NB are outside the accelerated path)." % binary_classifier)
             phenotypes.model_name_long, phenotypes.model_name_short = "logistic regression", "log_reg"
-            if logreg_solver not in (None, "liblinear"):
-                raise SystemExit("Logistic Regression with L1 penalty on the GPU engine implements the "
-                                 "liblinear objective only, got {}.".format(logreg_solver))
-        if phenotypes.penalty != "L1":
-            raise SystemExit("Only the L1 penalty runs on the GPU engine, got %r." % penalty)
+            # get_logreg_solver (:245-264): L1 -> liblinear (saga's objective leaves the intercept free and
+            # is not implemented); L2 -> lbfgs by default, all five names share one strictly convex optimum
+            if phenotypes.penalty == "L1":
+                if logreg_solver not in (None, "liblinear"):
+                    raise SystemExit("Logistic Regression with L1 penalty on the GPU engine implements the "
+                                     "liblinear objective only, got {}.".format(logreg_solver))
+                phenotypes.logreg_solver = "liblinear"
+            elif phenotypes.penalty == "L2":
+                if logreg_solver is None:
+                    logreg_solver = "lbfgs"
+                if logreg_solver not in ("liblinear", "newton-cg", "lbfgs", "sag", "saga"):
+                    raise SystemExit("Logistic Regression with L2 penalty supports only "
+                                     "solvers in ['liblinear', 'newton-cg', 'lbfgs', 'sag', 'saga'], "
+                                     "got {}.".format(logreg_solver))
+                phenotypes.logreg_solver = logreg_solver
+        if phenotypes.penalty not in ("L1", "L2"):
+            # L1+L2 cannot complete in the reference either: GridSearchCV is handed {'C': ...} for an
+            # SGDClassifier (:1020-1024, :1045-1047) and fit_model skips the ElasticNet fit (:1211-1214)
+            raise SystemExit("Only the L1 and L2 penalties run on the GPU engine, got %r." % penalty)
         if pca:
             raise SystemExit("--pca is outside the accelerated path.")
 
@@ -275,6 +289,7 @@ class phenotypes:
     kmer_limit = None
     omit_B = None
     penalty = None
+    logreg_solver = None
     max_iter = None
     tol = None
     alphas = None
@@ -471,7 +486,12 @@ class phenotypes:
 
     def _new_estimator(self):
         if self.pred_scale == "binary":
-            return L1LogisticRegression(tol=self.tol, max_iter=self.max_iter), "C", [1.0 / a for a in self.alphas]
+            grid = [1.0 / a for a in self.alphas]
+            if self.penalty == "L2":
+                return L2LogisticRegression(tol=self.tol, max_iter=self.max_iter, solver=self.logreg_solver), "C", grid
+            return L1LogisticRegression(tol=self.tol, max_iter=self.max_iter), "C", grid
+        if self.penalty == "L2":
+            return RidgeRegression(tol=self.tol, max_iter=self.max_iter), "alpha", [float(a) for a in self.alphas]
         return LassoRegression(tol=self.tol, max_iter=self.max_iter), "alpha", [float(a) for a in self.alphas]
 
     def _fit(self, ctx, X, y):

@@ -268,3 +268,49 @@ def test_kmerdb_real_counts_and_mpheno(tmp_path, oracle):
             assert int(ml[1 + i][1 + j]) == cnt
             saw_multi |= cnt > 1
     assert saw_multi
+
+
+def test_l2_penalty_end_to_end(tmp_path):
+    """`--penalty L2` (set_model, modeling.py:1001-1002, :1015-1019): Ridge for a continuous phenotype, L2
+    logistic regression (lbfgs objective by default, liblinear's with -ls) for a binary one; the stored model
+    is the unique optimum of its objective on the written <pheno>_MLdf.csv."""
+    import joblib
+    from oracle import oracle_model as OM
+    from phenotypeseeker_amd.synth import GenomeSet
+    gs = GenomeSet(40, 8000, seed=41, gene_len=150)
+    os.chdir(tmp_path)
+    for col, val in (("MIC", lambda i: repr(round(gs.continuous_phenotype(i), 4))), ("Pheno", lambda i: str(gs.phenotype(i)))):
+        rows = ["ID\tAddresses\t" + col]
+        for i in range(gs.n):
+            name, fa = gs.sample(i)
+            with open(name + ".fasta", "wb") as f:
+                f.write(fa)
+            rows.append("%s\t%s.fasta\t%s" % (name, name, val(i)))
+        with open("data_%s.pheno" % col, "w") as f:
+            f.write("\n".join(rows) + "\n")
+
+    def design(csv_name):
+        with open(csv_name) as f:
+            rows = list(csv.reader(f))
+        return (np.array([[float(v) for v in r[1:-2]] for r in rows[1:]]), np.array([float(r[-1]) for r in rows[1:]]))
+
+    _run(tmp_path, ["modeling", "data_MIC.pheno", "--pvalue", "0.05", "--penalty", "L2", "--n_kmers", "60"])
+    pkg = joblib.load("linreg_model_MIC.pkl")
+    X, y = design("MIC_MLdf.csv")
+    m = pkg["model"]
+    w, b = OM.ridge_fit(X, y, m.best_params_["alpha"])
+    assert np.allclose(m.best_estimator_.coef_, w, rtol=1e-6, atol=1e-8) and m.best_estimator_.intercept_ == pytest.approx(b, rel=1e-7)
+    assert "Parameters:\nRidge(" in open("summary_of_linreg_analysis_MIC.txt").read()
+
+    for extra, pen in (([], False), (["-ls", "liblinear"], True)):
+        _run(tmp_path, ["modeling", "data_Pheno.pheno", "--omit_B_correction", "--penalty", "L2", "--n_kmers", "60",
+                        "--tolerance", "1e-10"] + extra)
+        pkg = joblib.load("log_reg_model_Pheno.pkl")
+        X, y = design("Pheno_MLdf.csv")
+        m = pkg["model"]
+        w, b = OM.logreg_l2_fit(X, y.astype(int), m.best_params_["C"], penalise_intercept=pen)
+        assert np.allclose(m.best_estimator_.coef_[0], w, rtol=1e-5, atol=1e-7), extra
+        assert m.best_estimator_.intercept_[0] == pytest.approx(b, rel=1e-5, abs=1e-7)
+        assert (m.predict(X) == y).mean() >= 0.9
+        summary = open("summary_of_log_reg_analysis_Pheno.txt").read()
+        assert "Parameters:\nLogisticRegression(max_iter=1000" in summary and "penalty='l1'" not in summary

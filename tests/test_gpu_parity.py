@@ -337,6 +337,73 @@ def test_grid_search_matches_sklearn_cv(ctx):
     assert np.array_equal(g2.predict(X), gs.predict(X)) and g2.predict_proba(X).shape == (len(y), 2)
 
 
+def test_ridge_solver_matches_sklearn(ctx):
+    """f4 / `--penalty L2`, continuous: unique optimum, coefficients pinned (tests/golden/model_l2_kat.npz)."""
+    from oracle import oracle_model as OM
+    z = np.load(os.path.join(GOLDEN, "model_kat.npz"))
+    g = np.load(os.path.join(GOLDEN, "model_l2_kat.npz"))
+    alphas = [float(a) for a in z["alphas"]]
+    for tag, X, y in (("1", z["X1"], g["yc1"]), ("2", z["X2"], z["yc2"])):
+        coef, icpt, iters = ctx.ridge_fit(X, y, np.zeros(len(y), np.int32), alphas, [-1] * len(alphas))
+        assert np.allclose(coef, g["ridge_coef" + tag], rtol=1e-6, atol=1e-8), (tag, iters)
+        assert np.allclose(icpt, g["ridge_icpt" + tag], rtol=1e-7, atol=1e-9)
+    # held-out folds: every (alpha, fold) fit equals the oracle's fit on the training rows
+    X, y = z["X2"], z["yc2"]
+    folds = OM.kfold(len(y), 10).astype(np.int32)
+    fp = [a for a in alphas[::4] for _ in range(10)]
+    ff = [f for _ in alphas[::4] for f in range(10)]
+    coef, icpt, _ = ctx.ridge_fit(X, y, folds, fp, ff)
+    for j in range(len(fp)):
+        w, b = OM.ridge_fit(X[folds != ff[j]], y[folds != ff[j]], fp[j])
+        assert np.allclose(coef[j], w, rtol=1e-6, atol=1e-8) and icpt[j] == pytest.approx(b, rel=1e-7, abs=1e-9)
+
+
+def test_l2_logreg_solver_matches_sklearn(ctx):
+    """f4 / `--penalty L2`, binary: free intercept (lbfgs & co.) and liblinear's penalised intercept."""
+    from oracle import oracle_model as OM
+    z = np.load(os.path.join(GOLDEN, "model_kat.npz"))
+    g = np.load(os.path.join(GOLDEN, "model_l2_kat.npz"))
+    Cs = [float(c) for c in z["Cs"]]
+    for tag in ("1", "2"):
+        X, y = z["X" + tag], z["y" + tag]
+        for name, pen, rtol in (("free", False, 1e-6), ("liblinear", True, 2e-5)):
+            coef, icpt, iters = ctx.logreg_l2_fit(X, y, np.zeros(len(y), np.int32), Cs, [-1] * len(Cs), tol=1e-12,
+                                                  max_iter=200, penalise_intercept=pen)
+            assert np.allclose(coef, g["l2_%s_coef%s" % (name, tag)], rtol=rtol, atol=rtol * 0.1), (tag, name, iters)
+            assert np.allclose(icpt, g["l2_%s_icpt%s" % (name, tag)], rtol=rtol, atol=rtol * 0.1)
+            assert iters.max() < 60
+    X, y = z["X2"], z["y2"]
+    cv = int(min(np.bincount(y).min(), 10))
+    folds = OM.stratified_kfold(y, cv).astype(np.int32)
+    fp = [c for c in Cs[::4] for _ in range(cv)]
+    ff = [f for _ in Cs[::4] for f in range(cv)]
+    coef, icpt, _ = ctx.logreg_l2_fit(X, y, folds, fp, ff, tol=1e-12, max_iter=200)
+    for j in range(0, len(fp), 3):
+        w, b = OM.logreg_l2_fit(X[folds != ff[j]], y[folds != ff[j]], fp[j])
+        assert np.allclose(coef[j], w, rtol=1e-6, atol=1e-8) and icpt[j] == pytest.approx(b, rel=1e-6, abs=1e-8)
+
+
+def test_l2_grid_search_matches_sklearn_cv(ctx):
+    from phenotypeseeker_amd.model import GridSearch, L2LogisticRegression, RidgeRegression
+    z = np.load(os.path.join(GOLDEN, "model_kat.npz"))
+    g = np.load(os.path.join(GOLDEN, "model_l2_kat.npz"))
+    X, y, yc = z["X2"], z["y2"], z["yc2"]
+    alphas, Cs = [float(a) for a in z["alphas"]], [float(c) for c in z["Cs"]]
+    gr = GridSearch(RidgeRegression(tol=1e-4, max_iter=1000), "alpha", alphas, 10).fit(X, yc, ctx)
+    assert np.allclose(gr.cv_results_["mean_test_score"], g["ridge_gs_mean_score2"], rtol=1e-6, atol=1e-8)
+    assert gr.best_params_["alpha"] == pytest.approx(float(g["ridge_gs_best_alpha2"]))
+    assert gr.n_unique_columns_ == X.shape[1]  # no column de-duplication under an L2 penalty
+    cv = int(min(np.bincount(y).min(), 10))
+    gl = GridSearch(L2LogisticRegression(tol=1e-10, max_iter=200), "C", Cs, cv).fit(X, y, ctx)
+    assert np.allclose(gl.cv_results_["mean_test_score"], g["l2_gs_mean_score2"], atol=1e-12)
+    assert gl.best_params_["C"] == pytest.approx(float(g["l2_gs_best_C2"]))
+    sk = gl.to_sklearn()
+    assert np.array_equal(sk.predict(X), gl.predict(X)) and "penalty='l1'" not in repr(gl.best_estimator_)
+    import pickle
+    g2 = pickle.loads(pickle.dumps(gr))
+    assert np.allclose(g2.predict(X), gr.predict(X))
+
+
 def test_device_survivor_exchange_matches_get_results():
     """The multi-GPU hand-off (psk_export_survivors + RCCL all_gather_into_tensor) as a one-rank nccl
     group, in a fresh process (torch's bundled HIP runtime must be loaded before libpsk.so, see

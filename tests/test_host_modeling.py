@@ -73,7 +73,11 @@ def test_rejects_options_outside_the_hot_path(tmp_path):
     with pytest.raises(SystemExit):
         _setup(tmp_path, "ds_bonf", ["-bc", "SVM"])
     with pytest.raises(SystemExit):
-        _setup(tmp_path, "ds_bonf", ["--penalty", "L2"])
+        _setup(tmp_path, "ds_bonf", ["--penalty", "L1+L2"])
+    with pytest.raises(SystemExit):
+        _setup(tmp_path, "ds_bonf", ["--penalty", "L2", "-ls", "newton"])
+    M, _ = _setup(tmp_path, "ds_bonf", ["--penalty", "L2"])
+    assert M.phenotypes.penalty == "L2" and M.phenotypes.logreg_solver == "lbfgs"
 
 
 @pytest.mark.parametrize("tag,extra", [("ds_omitB", ["--omit_B_correction", "--n_kmers", "100"]), ("ds_bonf", [])])

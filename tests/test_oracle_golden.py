@@ -170,3 +170,34 @@ def test_model_oracle_against_converged_sklearn():
     gs = OM.grid_search(X2, yc2, [float(a) for a in z["alphas"]], "lasso", 10)
     assert np.allclose(gs["mean_test_score"], z["lasso_gs_mean_score2"], rtol=1e-6, atol=1e-8)
     assert float(z["alphas"][gs["best_index"]]) == float(z["lasso_gs_best_alpha2"])
+
+
+def test_l2_model_oracle_against_sklearn():
+    """`--penalty L2` (set_model, modeling.py:1001-1002, :1015-1019): both objectives are strictly convex, so
+    the coefficients themselves are pinned."""
+    from oracle import oracle_model as OM
+    z = np.load(os.path.join(GOLDEN, "model_kat.npz"))
+    g = np.load(os.path.join(GOLDEN, "model_l2_kat.npz"))
+    for tag, X, y in (("1", z["X1"], g["yc1"]), ("2", z["X2"], z["yc2"])):
+        for ai in (0, 4, 6, 9, 12):
+            w, b = OM.ridge_fit(X, y, float(z["alphas"][ai]))
+            assert np.allclose(w, g["ridge_coef" + tag][ai], rtol=1e-7, atol=1e-9)
+            assert b == pytest.approx(float(g["ridge_icpt" + tag][ai]), rel=1e-8, abs=1e-10)
+    gs = OM.grid_search(z["X2"], z["yc2"], [float(a) for a in z["alphas"]], "ridge", 10)
+    assert np.allclose(gs["mean_test_score"], g["ridge_gs_mean_score2"], rtol=1e-8, atol=1e-10)
+    assert float(z["alphas"][gs["best_index"]]) == float(g["ridge_gs_best_alpha2"])
+    for tag in ("1", "2"):
+        X, y = z["X" + tag], z["y" + tag]
+        for ci in (0, 3, 6, 9, 12):
+            C = float(z["Cs"][ci])
+            w, b = OM.logreg_l2_fit(X, y, C)
+            assert np.allclose(w, g["l2_free_coef" + tag][ci], rtol=1e-6, atol=1e-8), (tag, C)
+            assert b == pytest.approx(float(g["l2_free_icpt" + tag][ci]), rel=1e-6, abs=1e-8)
+            w, b = OM.logreg_l2_fit(X, y, C, penalise_intercept=True)
+            assert np.allclose(w, g["l2_liblinear_coef" + tag][ci], rtol=2e-5, atol=2e-6), (tag, C)
+            assert b == pytest.approx(float(g["l2_liblinear_icpt" + tag][ci]), rel=2e-5, abs=2e-6)
+    X, y = z["X2"], z["y2"]
+    cv = int(min(np.bincount(y).min(), 10))
+    gs = OM.grid_search(X, y, [float(c) for c in z["Cs"]], "logreg_l2", cv)
+    assert np.allclose(gs["mean_test_score"], g["l2_gs_mean_score2"], atol=1e-12)
+    assert float(z["Cs"][gs["best_index"]]) == pytest.approx(float(g["l2_gs_best_C2"]))
