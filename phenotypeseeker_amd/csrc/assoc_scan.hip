@@ -48,12 +48,11 @@ struct ScanArgs {
     int cpr;  // 16-byte chunks per row = wpr / 2
     // chi2
     const uint64_t *m1, *m0;   // phenotype == 1 / == 0 masks (wpr words each)
-    const double *w1, *w0;     // weights gated by phenotype (weighted only), wpr*64 entries
+    const double *tab;         // per-sample table of the lane-per-row pass: [wpr*64][NM] doubles (see row_moments)
     int n1, n0;                // popcounts of the masks
     double W1, W0;             // weight totals of the two phenotype classes
     // t-test
     const uint64_t *mvalid;    // non-NA mask
-    const double *val, *wt;    // phenotype values and weights (0 where NA), wpr*64 entries
     int nvalid;
     // filters
     int min_samples, max_samples;
@@ -90,10 +89,80 @@ __device__ __forceinline__ double chi2_exact(double A, double B, double C, doubl
     return stat;
 }
 
-template <int G, bool WEIGHTED>
-__global__ __launch_bounds__(SC_THREADS) void chi2_scan_kernel(const ScanArgs P, const int use_lds)
+
+// ---- lane-per-row moments -----------------------------------------------------------------------
+// Rows that pass the popcount frequency filter need f64 sums over their present samples (class weight
+// sums for the weighted chi2, weighted moments for Welch).  They are queued per wave and handled 64 at a
+// time, ONE ROW PER LANE: every lane walks its own row while all lanes visit the same sample s at the
+// same time, so the per-sample table entries tab[s][0..NM) are wave-uniform and come through the scalar
+// data cache into SGPRs (constant address space => s_load), not through LDS or the vector pipe.  A cell
+// costs 2 + NM VALU ops: the presence bit becomes 0.0 / 1.0 (v_bfe_i32 + v_and 0x3FF00000 on the high
+// word), then one v_fma_f64 per moment with the table entry as an SGPR operand -- no cross-lane
+// reduction at all, and the sums run in sample order like the reference's Python loops.
+// (r01: the previous whole-wave-per-row form spent ~1000 cycles per row in LDS latency and three DPP wave
+// sums: 11.1 ms for 16 M x 1024 with a third of the rows passing.)
+typedef const __attribute__((address_space(4))) double *cdptr;
+constexpr int RQ_CAP = 128;  // queue entries per wave: < 64 carried over + <= 64 appended per step
+
+template <int NM>
+__device__ __forceinline__ void row_moments(const u32x4 *__restrict__ rp, int cpr, cdptr tab, double *acc)
 {
-    extern __shared__ double sm[];  // weighted only: w1[wpr*64] | w0[wpr*64] when use_lds
+    double a0[NM], a1[NM];
+#pragma unroll
+    for (int m = 0; m < NM; m++) { a0[m] = 0.0; a1[m] = 0.0; }
+    u32x4 y = rp[0];
+    for (int ch = 0; ch < cpr; ch++) {
+        const uint32_t w4[4] = {y.x, y.y, y.z, y.w};
+        if (ch + 1 < cpr) y = rp[ch + 1];
+        cdptr tp = tab + (size_t)ch * 128 * NM;
+#pragma unroll
+        for (int h = 0; h < 4; h++) {
+#pragma unroll
+            for (int b = 0; b < 32; b += 2) {
+                const uint32_t h0 = (uint32_t)(((int32_t)(w4[h] << (31 - b))) >> 31) & 0x3FF00000u;
+                const uint32_t h1 = (uint32_t)(((int32_t)(w4[h] << (30 - b))) >> 31) & 0x3FF00000u;
+                const double f0 = __hiloint2double((int)h0, 0), f1 = __hiloint2double((int)h1, 0);
+#pragma unroll
+                for (int m = 0; m < NM; m++) {
+                    a0[m] = fma(f0, tp[(h * 32 + b) * NM + m], a0[m]);
+                    a1[m] = fma(f1, tp[(h * 32 + b + 1) * NM + m], a1[m]);
+                }
+            }
+        }
+    }
+#pragma unroll
+    for (int m = 0; m < NM; m++) acc[m] = a0[m] + a1[m];
+}
+
+// appends the rows flagged in this step (one flag per lane group leader) to the wave's queue
+__device__ __forceinline__ int queue_rows(bool flag, uint64_t row, int n_w, uint64_t *q_row, int *q_nw, int q, int lane)
+{
+    const uint64_t todo = __ballot(flag);
+    if (flag) {
+        const int pos = q + __popcll(todo & ((1ull << lane) - 1ull));
+        q_row[pos] = row;
+        q_nw[pos] = n_w;
+    }
+    return q + __popcll(todo);
+}
+
+// drops the first 64 entries of the wave's queue
+__device__ __forceinline__ int queue_pop64(uint64_t *q_row, int *q_nw, int q, int lane)
+{
+    const int rest = q - 64;
+    uint64_t r = 0;
+    int n = 0;
+    if (lane < rest) { r = q_row[64 + lane]; n = q_nw[64 + lane]; }
+    __builtin_amdgcn_wave_barrier();
+    if (lane < rest) { q_row[lane] = r; q_nw[lane] = n; }
+    return rest;
+}
+
+template <int G, bool WEIGHTED>
+__global__ __launch_bounds__(SC_THREADS) void chi2_scan_kernel(const ScanArgs P)
+{
+    __shared__ uint64_t s_qrow[WEIGHTED ? SC_THREADS / 64 : 1][WEIGHTED ? RQ_CAP : 1];
+    __shared__ int s_qnw[WEIGHTED ? SC_THREADS / 64 : 1][WEIGHTED ? RQ_CAP : 1];
     constexpr int RPW = 64 / G;  // rows per wave step
     const int lane = threadIdx.x & 63;
     const int g = lane & (G - 1);
@@ -104,14 +173,34 @@ __global__ __launch_bounds__(SC_THREADS) void chi2_scan_kernel(const ScanArgs P,
     const bool has_chunk = g < P.cpr;
     uint64_t m1a = 0, m1b = 0, m0a = 0, m0b = 0;
     if (has_chunk) { m1a = P.m1[2 * g]; m1b = P.m1[2 * g + 1]; m0a = P.m0[2 * g]; m0b = P.m0[2 * g + 1]; }
-    const double *w1 = P.w1, *w0 = P.w0;
-    if (WEIGHTED && use_lds) {
-        const int nw = 2 * P.cpr * 64;
-        for (int i = threadIdx.x; i < nw; i += SC_THREADS) { sm[i] = P.w1[i]; sm[nw + i] = P.w0[i]; }
-        __syncthreads();
-        w1 = sm;
-        w0 = sm + nw;
-    }
+    uint64_t *q_row = s_qrow[WEIGHTED ? (threadIdx.x >> 6) : 0];
+    int *q_nw = s_qnw[WEIGHTED ? (threadIdx.x >> 6) : 0];
+    int q = 0;
+    // weighted: `cnt` queued rows, one per lane -- class weight sums in sample order, then the same
+    // pre-test / exact statistic / keep rule as the unweighted path
+    auto process = [&](int cnt) {
+        const bool act = lane < cnt;
+        const uint64_t r = q_row[act ? lane : 0];
+        const int r_nw = q_nw[act ? lane : 0];
+        double ws[2];
+        row_moments<2>(P.bits + r * (uint64_t)P.cpr, P.cpr, (cdptr)P.tab, ws);
+        if (!act) return;
+        const double A = ws[0], B = P.W1 - ws[0], C = ws[1], D = P.W0 - ws[1];
+        const double R1 = A + B, R0 = C + D, K1 = A + C, K0 = B + D, T = R1 + R0;
+        const double det = A * D - B * C;
+        const double lhs = T * det * det, rhs = P.thr * R1 * R0 * K1 * K0;
+        if (lhs < rhs * (1.0 - 1e-9)) return;
+        const double stat = chi2_exact(A, B, C, D);
+        const double p = exp(-0.5 * stat);
+        const bool keep = (P.omit_B && p < P.pcut) || (p < P.pcut_bonf);
+        if (keep) {
+            const uint64_t idx = reserve_slot(P);
+            P.res_row[idx] = r;
+            P.res_stat[idx] = stat;
+            P.res_p[idx] = p;
+            P.res_nw[idx] = r_nw;
+        }
+    };
 
     for (uint64_t s0 = wave_global * SC_UNROLL; s0 < n_steps; s0 += total_waves * SC_UNROLL) {
         u32x4 x[SC_UNROLL];
@@ -151,42 +240,10 @@ __global__ __launch_bounds__(SC_THREADS) void chi2_scan_kernel(const ScanArgs P,
             const int n_wo = (P.n1 - (int)a) + (P.n0 - (int)c);
             const bool freq_ok = (row < P.M) && !(n_w < P.min_samples || n_wo < 2 || n_w > P.max_samples);
             if (WEIGHTED) {
-                // rows that passed the frequency filter are handled one at a time by the whole wave:
-                // lane l owns samples l, l+64, ... (weights in LDS), row words come from the loading
-                // lanes' registers by scalar lane reads, the two class sums finish with DPP reductions
-                const int wpr = 2 * P.cpr;
-                const int wreg = (P.cpr <= G) ? wpr : 2 * G;
-                uint64_t todo = __ballot(freq_ok && g == 0);
-                while (todo) {
-                    const int src = __ffsll((unsigned long long)todo) - 1;
-                    todo &= todo - 1;
-                    const uint64_t r = (s0 + u) * RPW + (uint64_t)(src / G);
-                    const int r_nw = __builtin_amdgcn_readlane(n_w, src);
-                    const uint64_t *rp = reinterpret_cast<const uint64_t *>(P.bits) + r * (uint64_t)wpr;
-                    double wa = 0.0, wc = 0.0;
-                    for (int t = 0; t < wpr; t++) {
-                        const uint64_t xw = (t < wreg) ? psk_readlane_u64((t & 1) ? xb : xa, src + (t >> 1)) : rp[t];
-                        const bool pres = (xw >> lane) & 1;
-                        wa += pres ? w1[t * 64 + lane] : 0.0;   // w1 is zero unless the phenotype is 1
-                        wc += pres ? w0[t * 64 + lane] : 0.0;
-                    }
-                    wa = psk_wave_sum_f64_dpp(wa);
-                    wc = psk_wave_sum_f64_dpp(wc);
-                    const double A = wa, B = P.W1 - wa, C = wc, D = P.W0 - wc;
-                    const double R1 = A + B, R0 = C + D, K1 = A + C, K0 = B + D, T = R1 + R0;
-                    const double det = A * D - B * C;
-                    const double lhs = T * det * det, rhs = P.thr * R1 * R0 * K1 * K0;
-                    if (lhs < rhs * (1.0 - 1e-9)) continue;
-                    const double stat = chi2_exact(A, B, C, D);
-                    const double p = exp(-0.5 * stat);
-                    const bool keep = (P.omit_B && p < P.pcut) || (p < P.pcut_bonf);
-                    if (keep && lane == 0) {
-                        const uint64_t idx = reserve_slot(P);
-                        P.res_row[idx] = r;
-                        P.res_stat[idx] = stat;
-                        P.res_p[idx] = p;
-                        P.res_nw[idx] = r_nw;
-                    }
+                q = queue_rows(freq_ok && g == 0, row, n_w, q_row, q_nw, q, lane);
+                if (q >= 64) {
+                    process(64);
+                    q = queue_pop64(q_row, q_nw, q, lane);
                 }
                 continue;
             }
@@ -209,6 +266,7 @@ __global__ __launch_bounds__(SC_THREADS) void chi2_scan_kernel(const ScanArgs P,
             }
         }
     }
+    if (WEIGHTED && q) process(q);
 }
 
 // ---- Student-t two-sided p-value: I_{df/(df+t^2)}(df/2, 1/2), Lentz continued fraction ---------
@@ -255,82 +313,63 @@ __device__ __attribute__((noinline)) double dev_t_two_sided_p(double t, double d
     return dev_betainc(0.5 * df, 0.5, df / (df + t * t));
 }
 
-__device__ __forceinline__ double wave_sum_f64(double v)
-{
-#pragma unroll
-    for (int d = 32; d > 0; d >>= 1) v += psk_shfl_xor_f64(v, d);
-    return v;
-}
-
 // Welch scan.  Phase A is the chi2 kernel's streaming shape (one 16-byte load per lane per row, popcount
-// against the non-NA mask, group reduce, frequency filter of modeling.py:731).  Rows that pass are then
-// handled one at a time by the WHOLE wave (phase B): lane l owns samples l, l+64, ...; the phenotype values
-// (shifted by their global weighted mean, so that one pass of weighted moments suffices) and the weights
-// are read from LDS conflict-free, row words come from the loading lanes' registers by scalar lane reads,
-// and six DPP wave sums give (n, sum, sum of squares) of both groups.  The sums of up to 64 rows are
-// queued in LDS and the tail (means, variances, t, erfc pre-test, incomplete beta) is then evaluated
-// lane-parallel, one row per lane (phase C).
-constexpr int TT_QUEUE = 64;
-constexpr int TT_SLOT = 8;  // doubles per queued row: nx sx qx ny sy qy row n_with
-
-template <int G>
-__global__ __launch_bounds__(SC_THREADS) void ttest_scan_kernel(const ScanArgs P, const int use_lds, const double mu)
+// against the non-NA mask, group reduce, frequency filter of modeling.py:731).  Rows that pass are queued
+// per wave and handled 64 at a time, one row per lane (row_moments): ONE pass of (weighted) moments of the
+// k-mer-present group over phenotype values shifted by their global weighted mean -- the absent group
+// follows from the totals -- then means, variances, t and the Satterthwaite df in the same lane.
+// Table layout: unit weights tab[s] = {u, u*u} (n comes from the popcount); GSC weights {w, w*u, w*u*u};
+// zeros for NA samples and padding.
+template <int G, bool WT>
+__global__ __launch_bounds__(SC_THREADS) void ttest_scan_kernel(const ScanArgs P, const double mu)
 {
-    extern __shared__ double sm[];  // queue[4 waves][TT_QUEUE][TT_SLOT] | val[wpr*64] | wt[wpr*64] (when use_lds)
+    __shared__ uint64_t s_qrow[SC_THREADS / 64][RQ_CAP];
+    __shared__ int s_qnw[SC_THREADS / 64][RQ_CAP];
     constexpr int RPW = 64 / G;
+    constexpr int NM = WT ? 3 : 2;
     const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
     const int g = lane & (G - 1);
     const int rsub = lane / G;
-    const int wpr = 2 * P.cpr;
     const uint64_t n_steps = (P.M + RPW - 1) / RPW;
     const uint64_t wave_global = (uint64_t)blockIdx.x * (SC_THREADS / 64) + wid;
     const uint64_t total_waves = (uint64_t)gridDim.x * (SC_THREADS / 64);
     const bool has_chunk = g < P.cpr;
-    double *queue = sm + (size_t)wid * TT_QUEUE * TT_SLOT;
-    const double *val = P.val, *wt = P.wt;  // val holds v - mu
-    if (use_lds) {
-        double *lv = sm + (size_t)(SC_THREADS / 64) * TT_QUEUE * TT_SLOT;
-        for (int i = threadIdx.x; i < wpr * 64; i += SC_THREADS) { lv[i] = P.val[i]; lv[wpr * 64 + i] = P.wt[i]; }
-        __syncthreads();
-        val = lv;
-        wt = lv + wpr * 64;
-    }
     uint64_t mva = 0, mvb = 0;
     if (has_chunk) { mva = P.mvalid[2 * g]; mvb = P.mvalid[2 * g + 1]; }
-    const uint64_t *bits64 = reinterpret_cast<const uint64_t *>(P.bits);
-    const int wreg = (P.cpr <= G) ? wpr : 2 * G;  // words of a row held in the group's registers
+    uint64_t *q_row = s_qrow[wid];
+    int *q_nw = s_qnw[wid];
     int q = 0;  // queued rows (wave-uniform)
 
-    // phase C: one queued row per lane
-    auto flush = [&]() {
-        if (lane < q) {
-            const double *sl = queue + lane * TT_SLOT;
-            const double nx = sl[0], sx = sl[1], qx = sl[2], ny = sl[3], sy = sl[4], qy = sl[5];
-            const uint64_t r = (uint64_t)__double_as_longlong(sl[6]);
-            const int r_nw = (int)__double_as_longlong(sl[7]);
-            const double dx = sx / nx, dy = sy / ny;              // group means minus mu
-            const double vx = (qx - sx * dx) / nx, vy = (qy - sy * dy) / ny;  // ddof = 0
-            const double sem1 = vx / (nx - 1.0), sem2 = vy / (ny - 1.0);
-            const double semsum = sem1 + sem2;
-            const double tstat = (dx - dy) / sqrt(semsum);
-            // Student's t has heavier tails than the normal, p_t >= erfc(|t|/sqrt 2): rows with
-            // |t| <= t_crit (erfc(t_crit/sqrt 2) = cut, solved on the host) cannot pass.  Candidates are
-            // stored with their Satterthwaite df in the p slot; ttest_finalize_kernel turns that into
-            // the exact p-value and drops the ones that fail (keeps erfc / incomplete-beta code, and
-            // its ~90 VGPRs, out of this kernel: 2 -> 5 waves per SIMD).
-            if (fabs(tstat) > P.tcrit) {
-                const double z1 = (sem1 / semsum) * (sem1 / semsum) / (nx - 1.0);
-                const double z2 = (sem2 / semsum) * (sem2 / semsum) / (ny - 1.0);
-                const uint64_t idx = reserve_slot(P);
-                P.res_row[idx] = r;
-                P.res_stat[idx] = tstat;
-                P.res_p[idx] = 1.0 / (z1 + z2);
-                P.res_mx[idx] = mu + dx;
-                P.res_my[idx] = mu + dy;
-                P.res_nw[idx] = r_nw;
-            }
+    auto process = [&](int cnt) {
+        const bool act = lane < cnt;
+        const uint64_t r = q_row[act ? lane : 0];
+        const int r_nw = q_nw[act ? lane : 0];
+        double mo[NM];
+        row_moments<NM>(P.bits + r * (uint64_t)P.cpr, P.cpr, (cdptr)P.tab, mo);
+        if (!act) return;
+        const double nx = WT ? mo[0] : (double)r_nw, sx = mo[NM - 2], qx = mo[NM - 1];
+        const double ny = P.W1 - nx, sy = P.W0 - sx, qy = P.thr - qx;  // totals: W1 = sum w, W0 = sum w*u, thr = sum w*u^2
+        const double dx = sx / nx, dy = sy / ny;              // group means minus mu
+        const double vx = (qx - sx * dx) / nx, vy = (qy - sy * dy) / ny;  // ddof = 0
+        const double sem1 = vx / (nx - 1.0), sem2 = vy / (ny - 1.0);
+        const double semsum = sem1 + sem2;
+        const double tstat = (dx - dy) / sqrt(semsum);
+        // Student's t has heavier tails than the normal, p_t >= erfc(|t|/sqrt 2): rows with
+        // |t| <= t_crit (erfc(t_crit/sqrt 2) = cut, solved on the host) cannot pass.  Candidates are
+        // stored with their Satterthwaite df in the p slot; ttest_finalize_kernel turns that into
+        // the exact p-value and drops the ones that fail (keeps erfc / incomplete-beta code, and
+        // its ~90 VGPRs, out of this kernel).
+        if (fabs(tstat) > P.tcrit) {
+            const double z1 = (sem1 / semsum) * (sem1 / semsum) / (nx - 1.0);
+            const double z2 = (sem2 / semsum) * (sem2 / semsum) / (ny - 1.0);
+            const uint64_t idx = reserve_slot(P);
+            P.res_row[idx] = r;
+            P.res_stat[idx] = tstat;
+            P.res_p[idx] = 1.0 / (z1 + z2);
+            P.res_mx[idx] = mu + dx;
+            P.res_my[idx] = mu + dy;
+            P.res_nw[idx] = r_nw;
         }
-        q = 0;
     };
 
     for (uint64_t s0 = wave_global * SC_UNROLL; s0 < n_steps; s0 += total_waves * SC_UNROLL) {
@@ -356,57 +395,27 @@ __global__ __launch_bounds__(SC_THREADS) void ttest_scan_kernel(const ScanArgs P
             for (int d = G / 2; d > 0; d >>= 1) cnt += __shfl_xor(cnt, d, 64);
             const int n_w = (int)cnt, n_wo = P.nvalid - (int)cnt;
             const bool freq_ok = (row < P.M) && !(n_w < P.min_samples || n_wo < 2 || n_w > P.max_samples);
-            uint64_t todo = __ballot(freq_ok && g == 0);
-            while (todo) {  // wave-uniform loop over the rows of this step that passed the frequency filter
-                const int src = __ffsll((unsigned long long)todo) - 1;
-                todo &= todo - 1;
-                const uint64_t r = (s0 + u) * RPW + (uint64_t)(src / G);
-                const int r_nw = __builtin_amdgcn_readlane(n_w, src);
-                const uint64_t *rp = bits64 + r * (uint64_t)wpr;
-                // moments of the k-mer-present group only; the absent group follows from the totals
-                // (values are shifted by their weighted mean, so sum_all w*u = 0 and the differences
-                // below lose no precision that matters: DESIGN.md section 5)
-                double nx = 0, sx = 0, qx = 0;
-                for (int t = 0; t < wpr; t++) {
-                    // word t of row r: scalar read from the register of the lane that loaded it in phase A
-                    // (rows wider than the lane group fall back to a broadcast load, an L1/L2 hit)
-                    const uint64_t xw = (t < wreg) ? psk_readlane_u64((t & 1) ? xb : xa, src + (t >> 1)) : rp[t];
-                    const double w = wt[t * 64 + lane], v = val[t * 64 + lane];  // w == 0 where NA / padding
-                    const double wb = ((xw >> lane) & 1) ? w : 0.0;
-                    const double wv = wb * v;
-                    nx += wb; sx += wv; qx += wv * v;
-                }
-                nx = psk_wave_sum_f64_dpp(nx); sx = psk_wave_sum_f64_dpp(sx); qx = psk_wave_sum_f64_dpp(qx);
-                const double ny = P.W1 - nx, sy = P.W0 - sx, qy = P.thr - qx;  // totals: W1 = sum w, W0 = sum w*u, thr = sum w*u^2
-                if (lane == 0) {
-                    double *sl = queue + q * TT_SLOT;
-                    sl[0] = nx; sl[1] = sx; sl[2] = qx; sl[3] = ny; sl[4] = sy; sl[5] = qy;
-                    sl[6] = __longlong_as_double((long long)r);
-                    sl[7] = __longlong_as_double((long long)r_nw);
-                }
-                q++;
-                if (q == TT_QUEUE) flush();
+            q = queue_rows(freq_ok && g == 0, row, n_w, q_row, q_nw, q, lane);
+            if (q >= 64) {
+                process(64);
+                q = queue_pop64(q_row, q_nw, q, lane);
             }
         }
-        if (q) flush();
     }
+    if (q) process(q);
 }
 
 template <bool WEIGHTED>
 void launch_chi2(int G, dim3 grid, hipStream_t st, const ScanArgs &a)
 {
-    // weighted: the two gated weight vectors live in LDS when they fit in 64 KiB (<= 4096 samples)
-    const size_t need = WEIGHTED ? (size_t)a.cpr * 2 * 64 * 2 * sizeof(double) : 0;
-    const int use_lds = (WEIGHTED && need <= 65536) ? 1 : 0;
-    const size_t lds = use_lds ? need : 0;
     switch (G) {
-    case 1: chi2_scan_kernel<1, WEIGHTED><<<grid, SC_THREADS, lds, st>>>(a, use_lds); break;
-    case 2: chi2_scan_kernel<2, WEIGHTED><<<grid, SC_THREADS, lds, st>>>(a, use_lds); break;
-    case 4: chi2_scan_kernel<4, WEIGHTED><<<grid, SC_THREADS, lds, st>>>(a, use_lds); break;
-    case 8: chi2_scan_kernel<8, WEIGHTED><<<grid, SC_THREADS, lds, st>>>(a, use_lds); break;
-    case 16: chi2_scan_kernel<16, WEIGHTED><<<grid, SC_THREADS, lds, st>>>(a, use_lds); break;
-    case 32: chi2_scan_kernel<32, WEIGHTED><<<grid, SC_THREADS, lds, st>>>(a, use_lds); break;
-    default: chi2_scan_kernel<64, WEIGHTED><<<grid, SC_THREADS, lds, st>>>(a, use_lds); break;
+    case 1: chi2_scan_kernel<1, WEIGHTED><<<grid, SC_THREADS, 0, st>>>(a); break;
+    case 2: chi2_scan_kernel<2, WEIGHTED><<<grid, SC_THREADS, 0, st>>>(a); break;
+    case 4: chi2_scan_kernel<4, WEIGHTED><<<grid, SC_THREADS, 0, st>>>(a); break;
+    case 8: chi2_scan_kernel<8, WEIGHTED><<<grid, SC_THREADS, 0, st>>>(a); break;
+    case 16: chi2_scan_kernel<16, WEIGHTED><<<grid, SC_THREADS, 0, st>>>(a); break;
+    case 32: chi2_scan_kernel<32, WEIGHTED><<<grid, SC_THREADS, 0, st>>>(a); break;
+    default: chi2_scan_kernel<64, WEIGHTED><<<grid, SC_THREADS, 0, st>>>(a); break;
     }
 }
 
@@ -446,22 +455,24 @@ __global__ __launch_bounds__(256) void ttest_finalize_kernel(const ScanArgs P)
     if (threadIdx.x == 0) P.counter[seg * SC_CNT_STRIDE] = s_out;
 }
 
-void launch_ttest(int G, dim3 grid, hipStream_t st, const ScanArgs &a, double mu)
+template <bool WT>
+void launch_ttest_w(int G, dim3 grid, hipStream_t st, const ScanArgs &a, double mu)
 {
-    // row queues always in LDS; phenotype values + weights too when they fit (<= ~3000 samples at 64 KiB)
-    const size_t qbytes = (size_t)(SC_THREADS / 64) * TT_QUEUE * TT_SLOT * sizeof(double);
-    const size_t need = (size_t)a.cpr * 2 * 64 * 2 * sizeof(double);
-    const int use_lds = (qbytes + need <= 65536) ? 1 : 0;
-    const size_t lds = qbytes + (use_lds ? need : 0);
     switch (G) {
-    case 1: ttest_scan_kernel<1><<<grid, SC_THREADS, lds, st>>>(a, use_lds, mu); break;
-    case 2: ttest_scan_kernel<2><<<grid, SC_THREADS, lds, st>>>(a, use_lds, mu); break;
-    case 4: ttest_scan_kernel<4><<<grid, SC_THREADS, lds, st>>>(a, use_lds, mu); break;
-    case 8: ttest_scan_kernel<8><<<grid, SC_THREADS, lds, st>>>(a, use_lds, mu); break;
-    case 16: ttest_scan_kernel<16><<<grid, SC_THREADS, lds, st>>>(a, use_lds, mu); break;
-    case 32: ttest_scan_kernel<32><<<grid, SC_THREADS, lds, st>>>(a, use_lds, mu); break;
-    default: ttest_scan_kernel<64><<<grid, SC_THREADS, lds, st>>>(a, use_lds, mu); break;
+    case 1: ttest_scan_kernel<1, WT><<<grid, SC_THREADS, 0, st>>>(a, mu); break;
+    case 2: ttest_scan_kernel<2, WT><<<grid, SC_THREADS, 0, st>>>(a, mu); break;
+    case 4: ttest_scan_kernel<4, WT><<<grid, SC_THREADS, 0, st>>>(a, mu); break;
+    case 8: ttest_scan_kernel<8, WT><<<grid, SC_THREADS, 0, st>>>(a, mu); break;
+    case 16: ttest_scan_kernel<16, WT><<<grid, SC_THREADS, 0, st>>>(a, mu); break;
+    case 32: ttest_scan_kernel<32, WT><<<grid, SC_THREADS, 0, st>>>(a, mu); break;
+    default: ttest_scan_kernel<64, WT><<<grid, SC_THREADS, 0, st>>>(a, mu); break;
     }
+}
+
+void launch_ttest(int G, dim3 grid, hipStream_t st, const ScanArgs &a, double mu, bool weighted)
+{
+    if (weighted) launch_ttest_w<true>(G, grid, st, a, mu);
+    else launch_ttest_w<false>(G, grid, st, a, mu);
     ttest_finalize_kernel<<<SC_NSEG, 256, 0, st>>>(a);
 }
 
@@ -589,8 +600,7 @@ static int fill_chi2_args(psk_ctx *ctx, ScanArgs &a)
     a.cpr = ctx->wpr / 2;
     a.m1 = ctx->mask1.as<uint64_t>();
     a.m0 = a.m1 + ctx->wpr;
-    a.w1 = reinterpret_cast<const double *>(a.m1 + 2 * (size_t)ctx->wpr);
-    a.w0 = a.w1 + (size_t)ctx->wpr * 64;
+    a.tab = reinterpret_cast<const double *>(a.m1 + 2 * (size_t)ctx->wpr);  // [sample][w if pheno 1 | w if pheno 0]
     a.min_samples = L.min_samples;
     a.max_samples = L.max_samples;
     a.pcut = L.pvalue_cutoff;
@@ -632,8 +642,8 @@ extern "C" int psk_chi2_scan(psk_ctx *ctx, const int8_t *pheno, const double *we
     int n1 = 0, n0 = 0;
     for (int i = 0; i < N; i++) {
         const double wi = weights ? weights[i] : 1.0;
-        if (pheno[i] == 1) { m1[i >> 6] |= 1ull << (i & 63); if (weights) w[i] = wi; W1 += wi; n1++; }
-        else if (pheno[i] == 0) { m0[i >> 6] |= 1ull << (i & 63); if (weights) w[(size_t)wpr * 64 + i] = wi; W0 += wi; n0++; }
+        if (pheno[i] == 1) { m1[i >> 6] |= 1ull << (i & 63); if (weights) w[2 * (size_t)i] = wi; W1 += wi; n1++; }
+        else if (pheno[i] == 0) { m0[i >> 6] |= 1ull << (i & 63); if (weights) w[2 * (size_t)i + 1] = wi; W0 += wi; n0++; }
     }
     PSK_TRY(dev_reserve(ctx, ctx->mask1, stage_bytes));
     PSK_HIP(ctx, hipMemcpyAsync(ctx->mask1.p, m1, weights ? stage_bytes : n_mask * 8, hipMemcpyHostToDevice, ctx->stream));
@@ -690,7 +700,10 @@ extern "C" int psk_ttest_scan(psk_ctx *ctx, const double *pheno, const uint8_t *
     PSK_HIP(ctx, hipSetDevice(ctx->device));
     const int N = ctx->n_samples, wpr = ctx->wpr;
     std::vector<uint64_t> mv(wpr, 0);
-    std::vector<double> vw(2 * (size_t)wpr * 64, 0.0);  // values | weights
+    bool unit_w = true;
+    for (int i = 0; weights && i < N; i++) if (valid[i] && weights[i] != 1.0) unit_w = false;
+    const int NM = unit_w ? 2 : 3;
+    std::vector<double> vw((size_t)NM * wpr * 64, 0.0);  // row_moments table: {u, u^2} or {w, w u, w u^2} per sample
     int nvalid = 0;
     double sw = 0.0, swv = 0.0;
     for (int i = 0; i < N; i++) {
@@ -705,8 +718,8 @@ extern "C" int psk_ttest_scan(psk_ctx *ctx, const double *pheno, const uint8_t *
         if (!valid[i]) continue;
         mv[i >> 6] |= 1ull << (i & 63);
         const double u = pheno[i] - mu, wi = weights ? weights[i] : 1.0;
-        vw[i] = u;
-        vw[(size_t)wpr * 64 + i] = wi;
+        if (unit_w) { vw[2 * (size_t)i] = u; vw[2 * (size_t)i + 1] = u * u; }
+        else { vw[3 * (size_t)i] = wi; vw[3 * (size_t)i + 1] = wi * u; vw[3 * (size_t)i + 2] = wi * u * u; }
         tot_w += wi; tot_wu += wi * u; tot_wuu += wi * u * u;
         nvalid++;
     }
@@ -720,8 +733,7 @@ extern "C" int psk_ttest_scan(psk_ctx *ctx, const double *pheno, const uint8_t *
     a.M = ctx->n_kmers;
     a.cpr = wpr / 2;
     a.mvalid = ctx->mask1.as<uint64_t>();
-    a.val = ctx->phe.as<double>();
-    a.wt = ctx->phe.as<double>() + (size_t)wpr * 64;
+    a.tab = ctx->phe.as<double>();
     a.nvalid = nvalid;
     a.min_samples = min_samples;
     a.max_samples = max_samples;
@@ -749,7 +761,7 @@ extern "C" int psk_ttest_scan(psk_ctx *ctx, const double *pheno, const uint8_t *
     if (ctx->n_kmers) {
         PSK_HIP(ctx, hipMemsetAsync(a.counter, 0, SC_NSEG * SC_CNT_STRIDE * 4, ctx->stream));
         PSK_HIP(ctx, hipEventRecord(ctx->ev0, ctx->stream));
-        launch_ttest(G, grid, ctx->stream, a, mu);
+        launch_ttest(G, grid, ctx->stream, a, mu, !unit_w);
         PSK_HIP(ctx, hipGetLastError());
         PSK_HIP(ctx, hipEventRecord(ctx->ev1, ctx->stream));
         PSK_TRY(enqueue_counts_readback(ctx, a));
