@@ -19,6 +19,7 @@
 
 #include <algorithm>
 #include <cmath>
+#include <cstdlib>
 #include <numeric>
 
 namespace {
@@ -102,7 +103,8 @@ __device__ __forceinline__ double chi2_exact(double A, double B, double C, doubl
 // (r01: the previous whole-wave-per-row form spent ~1000 cycles per row in LDS latency and three DPP wave
 // sums: 11.1 ms for 16 M x 1024 with a third of the rows passing.)
 typedef const __attribute__((address_space(4))) double *cdptr;
-constexpr int RQ_CAP = 128;  // queue entries per wave: < 64 carried over + <= 64 appended per step
+// queue entries per wave: < 64 carried over + <= 64 / G appended per step of an unrolled batch
+constexpr int rq_cap(int G) { return 64 + (64 / G) * SC_UNROLL; }
 
 template <int NM>
 __device__ __forceinline__ void row_moments(const u32x4 *__restrict__ rp, int cpr, cdptr tab, double *acc)
@@ -135,34 +137,39 @@ __device__ __forceinline__ void row_moments(const u32x4 *__restrict__ rp, int cp
 }
 
 // appends the rows flagged in this step (one flag per lane group leader) to the wave's queue
-__device__ __forceinline__ int queue_rows(bool flag, uint64_t row, int n_w, uint64_t *q_row, int *q_nw, int q, int lane)
+__device__ __forceinline__ int queue_rows(bool flag, uint64_t row, int2 v, uint64_t *q_row, int2 *q_val, int q, int lane)
 {
     const uint64_t todo = __ballot(flag);
+    if (!todo) return q;
     if (flag) {
         const int pos = q + __popcll(todo & ((1ull << lane) - 1ull));
         q_row[pos] = row;
-        q_nw[pos] = n_w;
+        q_val[pos] = v;
     }
-    return q + __popcll(todo);
+    return __builtin_amdgcn_readfirstlane(q + __popcll(todo));  // keep the count in an SGPR
 }
 
-// drops the first 64 entries of the wave's queue
-__device__ __forceinline__ int queue_pop64(uint64_t *q_row, int *q_nw, int q, int lane)
+// drops the first 64 entries of the wave's queue (the rest moves down 64 places, 64 entries at a time)
+__device__ __forceinline__ int queue_pop64(uint64_t *q_row, int2 *q_val, int q, int lane)
 {
     const int rest = q - 64;
-    uint64_t r = 0;
-    int n = 0;
-    if (lane < rest) { r = q_row[64 + lane]; n = q_nw[64 + lane]; }
-    __builtin_amdgcn_wave_barrier();
-    if (lane < rest) { q_row[lane] = r; q_nw[lane] = n; }
-    return rest;
+    for (int base = 0; base < rest; base += 64) {
+        uint64_t r = 0;
+        int2 n = make_int2(0, 0);
+        const bool mv = base + lane < rest;
+        if (mv) { r = q_row[64 + base + lane]; n = q_val[64 + base + lane]; }
+        __builtin_amdgcn_wave_barrier();
+        if (mv) { q_row[base + lane] = r; q_val[base + lane] = n; }
+        __builtin_amdgcn_wave_barrier();
+    }
+    return __builtin_amdgcn_readfirstlane(rest > 0 ? rest : 0);
 }
 
 template <int G, bool WEIGHTED>
 __global__ __launch_bounds__(SC_THREADS) void chi2_scan_kernel(const ScanArgs P)
 {
-    __shared__ uint64_t s_qrow[WEIGHTED ? SC_THREADS / 64 : 1][WEIGHTED ? RQ_CAP : 1];
-    __shared__ int s_qnw[WEIGHTED ? SC_THREADS / 64 : 1][WEIGHTED ? RQ_CAP : 1];
+    __shared__ uint64_t s_qrow[WEIGHTED ? SC_THREADS / 64 : 1][WEIGHTED ? rq_cap(G) : 1];  // weighted only
+    __shared__ int2 s_qval[WEIGHTED ? SC_THREADS / 64 : 1][WEIGHTED ? rq_cap(G) : 1];
     constexpr int RPW = 64 / G;  // rows per wave step
     const int lane = threadIdx.x & 63;
     const int g = lane & (G - 1);
@@ -174,14 +181,16 @@ __global__ __launch_bounds__(SC_THREADS) void chi2_scan_kernel(const ScanArgs P)
     uint64_t m1a = 0, m1b = 0, m0a = 0, m0b = 0;
     if (has_chunk) { m1a = P.m1[2 * g]; m1b = P.m1[2 * g + 1]; m0a = P.m0[2 * g]; m0b = P.m0[2 * g + 1]; }
     uint64_t *q_row = s_qrow[WEIGHTED ? (threadIdx.x >> 6) : 0];
-    int *q_nw = s_qnw[WEIGHTED ? (threadIdx.x >> 6) : 0];
+    int2 *q_val = s_qval[WEIGHTED ? (threadIdx.x >> 6) : 0];
     int q = 0;
     // weighted: `cnt` queued rows, one per lane -- class weight sums in sample order, then the same
-    // pre-test / exact statistic / keep rule as the unweighted path
+    // pre-test / exact statistic / keep rule as the unweighted path.  (The unweighted path keeps its exact
+    // evaluation in line: queueing its pre-test survivors as well makes a scan with 1 % survivors 35 %
+    // faster but costs the usual sparse case 4 %, r01 A/B on cfg 2: 110.7 vs 115.2 us.)
     auto process = [&](int cnt) {
         const bool act = lane < cnt;
         const uint64_t r = q_row[act ? lane : 0];
-        const int r_nw = q_nw[act ? lane : 0];
+        const int r_nw = q_val[act ? lane : 0].x;
         double ws[2];
         row_moments<2>(P.bits + r * (uint64_t)P.cpr, P.cpr, (cdptr)P.tab, ws);
         if (!act) return;
@@ -202,7 +211,17 @@ __global__ __launch_bounds__(SC_THREADS) void chi2_scan_kernel(const ScanArgs P)
         }
     };
 
-    for (uint64_t s0 = wave_global * SC_UNROLL; s0 < n_steps; s0 += total_waves * SC_UNROLL) {
+    // one copy of process(): the queue is drained after each unrolled batch and, once the rows run out,
+    // down to empty (keeps its registers and code out of the streaming part)
+    for (uint64_t s0 = wave_global * SC_UNROLL;; s0 += total_waves * SC_UNROLL) {
+        const bool more = s0 < n_steps;
+        if (WEIGHTED) {
+            while (q >= 64 || (!more && q > 0)) {
+                process(q < 64 ? q : 64);
+                q = queue_pop64(q_row, q_val, q, lane);
+            }
+        }
+        if (!more) break;
         u32x4 x[SC_UNROLL];
 #pragma unroll
         for (int u = 0; u < SC_UNROLL; u++) {
@@ -240,11 +259,7 @@ __global__ __launch_bounds__(SC_THREADS) void chi2_scan_kernel(const ScanArgs P)
             const int n_wo = (P.n1 - (int)a) + (P.n0 - (int)c);
             const bool freq_ok = (row < P.M) && !(n_w < P.min_samples || n_wo < 2 || n_w > P.max_samples);
             if (WEIGHTED) {
-                q = queue_rows(freq_ok && g == 0, row, n_w, q_row, q_nw, q, lane);
-                if (q >= 64) {
-                    process(64);
-                    q = queue_pop64(q_row, q_nw, q, lane);
-                }
+                q = queue_rows(freq_ok && g == 0, row, make_int2(n_w, 0), q_row, q_val, q, lane);
                 continue;
             }
             if (!freq_ok || g != 0) continue;
@@ -266,7 +281,6 @@ __global__ __launch_bounds__(SC_THREADS) void chi2_scan_kernel(const ScanArgs P)
             }
         }
     }
-    if (WEIGHTED && q) process(q);
 }
 
 // ---- Student-t two-sided p-value: I_{df/(df+t^2)}(df/2, 1/2), Lentz continued fraction ---------
@@ -323,8 +337,8 @@ __device__ __attribute__((noinline)) double dev_t_two_sided_p(double t, double d
 template <int G, bool WT>
 __global__ __launch_bounds__(SC_THREADS) void ttest_scan_kernel(const ScanArgs P, const double mu)
 {
-    __shared__ uint64_t s_qrow[SC_THREADS / 64][RQ_CAP];
-    __shared__ int s_qnw[SC_THREADS / 64][RQ_CAP];
+    __shared__ uint64_t s_qrow[SC_THREADS / 64][rq_cap(G)];
+    __shared__ int2 s_qval[SC_THREADS / 64][rq_cap(G)];
     constexpr int RPW = 64 / G;
     constexpr int NM = WT ? 3 : 2;
     const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
@@ -337,13 +351,13 @@ __global__ __launch_bounds__(SC_THREADS) void ttest_scan_kernel(const ScanArgs P
     uint64_t mva = 0, mvb = 0;
     if (has_chunk) { mva = P.mvalid[2 * g]; mvb = P.mvalid[2 * g + 1]; }
     uint64_t *q_row = s_qrow[wid];
-    int *q_nw = s_qnw[wid];
+    int2 *q_val = s_qval[wid];
     int q = 0;  // queued rows (wave-uniform)
 
     auto process = [&](int cnt) {
         const bool act = lane < cnt;
         const uint64_t r = q_row[act ? lane : 0];
-        const int r_nw = q_nw[act ? lane : 0];
+        const int r_nw = q_val[act ? lane : 0].x;
         double mo[NM];
         row_moments<NM>(P.bits + r * (uint64_t)P.cpr, P.cpr, (cdptr)P.tab, mo);
         if (!act) return;
@@ -372,7 +386,15 @@ __global__ __launch_bounds__(SC_THREADS) void ttest_scan_kernel(const ScanArgs P
         }
     };
 
-    for (uint64_t s0 = wave_global * SC_UNROLL; s0 < n_steps; s0 += total_waves * SC_UNROLL) {
+    // one copy of process(): the queue is drained after each unrolled batch and, once the rows run out,
+    // down to empty (keeps its registers and code out of the streaming part)
+    for (uint64_t s0 = wave_global * SC_UNROLL;; s0 += total_waves * SC_UNROLL) {
+        const bool more = s0 < n_steps;
+        while (q >= 64 || (!more && q > 0)) {
+            process(q < 64 ? q : 64);
+            q = queue_pop64(q_row, q_val, q, lane);
+        }
+        if (!more) break;
         u32x4 x[SC_UNROLL];
 #pragma unroll
         for (int u = 0; u < SC_UNROLL; u++) {
@@ -395,14 +417,9 @@ __global__ __launch_bounds__(SC_THREADS) void ttest_scan_kernel(const ScanArgs P
             for (int d = G / 2; d > 0; d >>= 1) cnt += __shfl_xor(cnt, d, 64);
             const int n_w = (int)cnt, n_wo = P.nvalid - (int)cnt;
             const bool freq_ok = (row < P.M) && !(n_w < P.min_samples || n_wo < 2 || n_w > P.max_samples);
-            q = queue_rows(freq_ok && g == 0, row, n_w, q_row, q_nw, q, lane);
-            if (q >= 64) {
-                process(64);
-                q = queue_pop64(q_row, q_nw, q, lane);
-            }
+            q = queue_rows(freq_ok && g == 0, row, make_int2(n_w, 0), q_row, q_val, q, lane);
         }
     }
-    if (q) process(q);
 }
 
 template <bool WEIGHTED>
@@ -562,7 +579,8 @@ dim3 scan_grid(const psk_ctx *ctx, uint64_t M, int G, int unroll)
     const uint64_t steps = (M + rpw - 1) / rpw;
     const uint64_t waves = (steps + unroll - 1) / unroll;
     uint64_t blocks = (waves + SC_THREADS / 64 - 1) / (SC_THREADS / 64);
-    const uint64_t cap = (uint64_t)(ctx->n_cu > 0 ? ctx->n_cu : 256) * PSK_SC_GRID_MULT;
+    static const int mult = [] { const char *e = getenv("PSK_GRID_MULT"); const int v = e ? atoi(e) : 0; return v > 0 ? v : PSK_SC_GRID_MULT; }();
+    const uint64_t cap = (uint64_t)(ctx->n_cu > 0 ? ctx->n_cu : 256) * mult;
     if (blocks > cap) blocks = cap;
     if (blocks < 1) blocks = 1;
     return dim3((unsigned)blocks);
