@@ -238,6 +238,29 @@ def test_count_dict_matches_gmer_counter(ctx, oracle):
         assert [int(b[2]) for b in body] == counts.tolist()
 
 
+def test_full_size_fastq_sample_properties(ctx, oracle):
+    """BASELINE config-5 sized sample (2 M reads x 150 bp, ~0.63 GB of FASTQ, 276 M windows): the window
+    count is reads x (150 - k + 1), the counts add up to it, the words come back strictly ascending, and
+    a 20000-read prefix equals the oracle word for word."""
+    from phenotypeseeker_amd.synth import GenomeSet, fastq_reads
+    reads, k = 2_000_000, 13
+    gs = GenomeSet(2, 5_000_000, seed=99)
+    data = fastq_reads(gs.codes(0), reads, 150, seed=[5, 0])
+    ctx.begin(k, 1)
+    nu, nt = ctx.count_kmers(0, data)
+    assert nt == reads * (150 - k + 1)
+    words, freqs = ctx.get_list(0, nu)
+    assert int(freqs.astype(np.uint64).sum()) == nt and np.all(words[1:] > words[:-1])
+    cut = 0
+    for _ in range(4 * 20000):
+        cut = data.index(b"\n", cut) + 1
+    ow, of = oracle.count_kmers(data[:cut], k)[:2]
+    ctx.begin(k, 1)
+    nu2, _ = ctx.count_kmers(0, data[:cut])
+    w2, f2 = ctx.get_list(0, nu2)
+    assert np.array_equal(w2, ow) and np.array_equal(f2, of)
+
+
 def test_full_size_scan_properties(ctx):
     """BASELINE config-2 sized matrix (2^25 rows x 256 samples): size-independent properties --
     the scan is idempotent, its survivors come back in ascending row order, flipping the
