@@ -254,7 +254,9 @@ extern "C" int psk_build_presence(psk_ctx *ctx, uint64_t *n_kmers)
     pt.mark("heads+scan");
     PSK_TRY(dev_reserve(ctx, ctx->union_words, M * 8));
     PSK_TRY(dev_reserve(ctx, ctx->bits, M * (uint64_t)ctx->wpr * 8));
+    pt.mark("alloc matrix");
     PSK_HIP(ctx, hipMemsetAsync(ctx->bits.p, 0, M * (uint64_t)ctx->wpr * 8, ctx->stream));
+    pt.mark("zero matrix");
     presence_fill_kernel<<<div_up(total, 256), 256, 0, ctx->stream>>>(
         sorted, total, sbits, flags, ctx->wpr, ctx->union_words.as<uint64_t>(),
         reinterpret_cast<unsigned long long *>(ctx->bits.p), kv ? sorted_vals : nullptr);
