@@ -121,6 +121,16 @@ extern "C" void psk_free(psk_ctx *ctx)
                       &ctx->misc, &ctx->union_words, &ctx->bits, &ctx->mask1, &ctx->phe,
                       &ctx->res, &ctx->res_count, &ctx->res_sorted};
     for (DevBuf *b : bufs) dev_release(*b);
+    if (ctx->copy_stream) (void)hipStreamSynchronize(ctx->copy_stream);
+    for (CountLane &L : ctx->lane) {
+        DevBuf *lb[] = {&L.raw, &L.keysA, &L.keysB, &L.starts, &L.cnt};
+        for (DevBuf *b : lb) dev_release(*b);
+        if (L.pinned_cnt) (void)hipHostFree(L.pinned_cnt);
+        if (L.done) (void)hipEventDestroy(L.done);
+        if (L.raw_ready) (void)hipEventDestroy(L.raw_ready);
+        if (L.raw_free) (void)hipEventDestroy(L.raw_free);
+    }
+    if (ctx->copy_stream) (void)hipStreamDestroy(ctx->copy_stream);
     if (ctx->pinned) (void)hipHostFree(ctx->pinned);
     if (ctx->scan_pinned) (void)hipHostFree(ctx->scan_pinned);
     if (ctx->cnt_pinned) (void)hipHostFree(ctx->cnt_pinned);

@@ -65,13 +65,27 @@ static inline size_t base_run_length(const uint8_t *p, size_t n)
 }
 }  // namespace
 
-int64_t frame_sequence_host(const uint8_t *bytes, size_t len, uint8_t *out, size_t out_cap)
+// k > 0: *n_windows receives the number of k-base windows of the clean stream (sum over its runs of
+// max(0, run - k + 1)), i.e. the number of words the extract kernel emits when no slab filter is set.
+static int64_t frame_sequence_counting(const uint8_t *bytes, size_t len, uint8_t *out, size_t out_cap, int k,
+                                       uint64_t *n_windows)
 {
     size_t o = 0;
     int st = ST_INIT;
     bool last_break = true;  // collapse runs of breaks; no leading break needed
+    size_t run_start = 0;    // output offset where the current run of bases began
+    uint64_t wins = 0;
+    auto close_run = [&]() {
+        const size_t run = o - run_start;
+        if (k > 0 && run >= (size_t)k) wins += run - (size_t)k + 1;
+    };
     auto put_break = [&]() {
-        if (!last_break) { out[o++] = '\n'; last_break = true; }
+        if (!last_break) { close_run(); out[o++] = '\n'; last_break = true; run_start = o; }
+    };
+    auto finish = [&]() -> int64_t {
+        if (!last_break) close_run();
+        if (n_windows) *n_windows = wins;
+        return (int64_t)o;
     };
     if (out_cap < len) return PSK_ERANGE;
     for (size_t i = 0; i < len; i++) {
@@ -118,7 +132,7 @@ int64_t frame_sequence_host(const uint8_t *bytes, size_t len, uint8_t *out, size
             } else if (cl == CL_SKIP) {
                 if (st == ST_FQ_SEQ && c == '\n' && i + 1 < len) {
                     const uint8_t c2 = bytes[++i];  // the byte after a sequence newline is consumed
-                    if (c2 == 0) return (int64_t)o;
+                    if (c2 == 0) return finish();
                     if (c2 == '+') st = ST_FQ_PLUS;
                 }
             } else {
@@ -141,7 +155,12 @@ int64_t frame_sequence_host(const uint8_t *bytes, size_t len, uint8_t *out, size
             break;
         }
     }
-    return (int64_t)o;
+    return finish();
+}
+
+int64_t frame_sequence_host(const uint8_t *bytes, size_t len, uint8_t *out, size_t out_cap)
+{
+    return frame_sequence_counting(bytes, len, out, out_cap, 0, nullptr);
 }
 
 extern "C" int64_t psk_frame_sequence(const uint8_t *bytes, size_t len, uint8_t *out, size_t out_cap)
@@ -331,9 +350,9 @@ int launch_extract(psk_ctx *ctx, const uint8_t *clean, uint64_t len, int k, uint
 
 // frames `bytes` into `stage` (host, thread-safe) and pads it for the extract kernel
 static int frame_into(uint8_t *stage, size_t stage_cap, const uint8_t *bytes, size_t len, uint64_t *clean_len,
-                      uint64_t *padded_len)
+                      uint64_t *padded_len, int k = 0, uint64_t *n_windows = nullptr)
 {
-    int64_t n = frame_sequence_host(bytes, len, stage, stage_cap);
+    int64_t n = frame_sequence_counting(bytes, len, stage, stage_cap, k, n_windows);
     if (n < 0) return (int)n;
     const uint64_t padded = ((uint64_t)n + EX_SEG - 1) / EX_SEG * EX_SEG + EX_SEG;
     memset(stage + n, '\n', padded - n);
@@ -394,6 +413,92 @@ static int count_from_stage(psk_ctx *ctx, int sample_idx, const uint8_t *stage, 
     return PSK_OK;
 }
 
+// ---- pipelined form of the GPU half (psk_count_kmers_batch, whole-space runs) ---------------------
+// The window count is known from the framing, so nothing has to come back from the GPU before the sort is
+// launched; the only value the host needs -- the number of unique words, for the arena allocation -- is
+// picked up one sample late: chain i is queued on buffer set i & 1, then sample i - 1 is finalised (its
+// event has long fired while chain i keeps the GPU busy).  Uploads run on their own stream.
+static int lane_prepare(psk_ctx *ctx, CountLane &L)
+{
+    if (!L.done) {
+        PSK_HIP(ctx, hipEventCreateWithFlags(&L.done, hipEventDisableTiming));
+        PSK_HIP(ctx, hipEventCreateWithFlags(&L.raw_ready, hipEventDisableTiming));
+        PSK_HIP(ctx, hipEventCreateWithFlags(&L.raw_free, hipEventDisableTiming));
+        PSK_HIP(ctx, hipHostMalloc(reinterpret_cast<void **>(&L.pinned_cnt), 64, hipHostMallocDefault));
+    }
+    if (!ctx->copy_stream) PSK_HIP(ctx, hipStreamCreateWithFlags(&ctx->copy_stream, hipStreamNonBlocking));
+    return PSK_OK;
+}
+
+static int chain_enqueue(psk_ctx *ctx, CountLane &L, int sample_idx, const uint8_t *stage, uint64_t clean_len,
+                         uint64_t padded, uint64_t n)
+{
+    ctx->lists[sample_idx] = SampleList();
+    ctx->have_presence = false;
+    if (clean_len >= (1ull << 32)) return psk_fail(ctx, PSK_ERANGE, "sample larger than 4 Gbases");
+    L.sample = sample_idx;
+    L.n = n;
+    L.uniq = nullptr;
+    if (n == 0) return PSK_OK;
+    PSK_TRY(lane_prepare(ctx, L));
+    PSK_TRY(dev_reserve(ctx, L.raw, padded));
+    PSK_TRY(dev_reserve(ctx, L.keysA, n * 8));
+    PSK_TRY(dev_reserve(ctx, L.keysB, n * 8));
+    PSK_TRY(dev_reserve(ctx, L.starts, n * 4));
+    PSK_TRY(dev_reserve(ctx, L.cnt, 64));
+    PSK_TRY(dev_reserve(ctx, ctx->flags, n * 4));
+    // upload on the copy stream, after the extract of the sample that used this raw buffer before
+    if (L.raw_used) PSK_HIP(ctx, hipStreamWaitEvent(ctx->copy_stream, L.raw_free, 0));
+    PSK_HIP(ctx, hipMemcpyAsync(L.raw.p, stage, padded, hipMemcpyHostToDevice, ctx->copy_stream));
+    PSK_HIP(ctx, hipEventRecord(L.raw_ready, ctx->copy_stream));
+    PSK_HIP(ctx, hipStreamWaitEvent(ctx->stream, L.raw_ready, 0));
+    uint32_t *d_n = L.cnt.as<uint32_t>();
+    PSK_HIP(ctx, hipMemsetAsync(d_n, 0, 16, ctx->stream));
+    PSK_TRY(launch_extract(ctx, L.raw.as<uint8_t>(), clean_len, ctx->k, ctx->slab_lo, ctx->slab_hi, L.keysA.as<uint64_t>(),
+                           d_n));
+    PSK_HIP(ctx, hipEventRecord(L.raw_free, ctx->stream));
+    L.raw_used = true;
+    uint64_t *sorted = nullptr;
+    PSK_TRY(dev_radix_sort_u64(ctx, L.keysA.as<uint64_t>(), L.keysB.as<uint64_t>(), n, 0, 2 * ctx->k, &sorted));
+    uint64_t *other = (sorted == L.keysA.as<uint64_t>()) ? L.keysB.as<uint64_t>() : L.keysA.as<uint64_t>();
+    uint32_t *flags = ctx->flags.as<uint32_t>();
+    rle_flags_kernel<<<div_up(n, 256), 256, 0, ctx->stream>>>(sorted, n, flags);
+    PSK_HIP(ctx, hipGetLastError());
+    PSK_TRY(dev_exclusive_scan_u32(ctx, flags, flags, n, d_n + 1));
+    rle_scatter_kernel<<<div_up(n, 256), 256, 0, ctx->stream>>>(sorted, n, flags, other, L.starts.as<uint32_t>());
+    PSK_HIP(ctx, hipGetLastError());
+    PSK_HIP(ctx, hipMemcpyAsync(L.pinned_cnt, d_n, 8, hipMemcpyDeviceToHost, ctx->stream));
+    PSK_HIP(ctx, hipEventRecord(L.done, ctx->stream));
+    L.uniq = other;
+    return PSK_OK;
+}
+
+// second half: arena allocation + copy-out of the sample whose chain ran on this set
+static int chain_finalize(psk_ctx *ctx, CountLane &L)
+{
+    if (L.sample < 0) return PSK_OK;
+    SampleList &S = ctx->lists[L.sample];
+    const int sample = L.sample;
+    L.sample = -1;
+    uint64_t nu = 0;
+    if (L.n > 0) {
+        PSK_HIP(ctx, hipEventSynchronize(L.done));
+        if (L.pinned_cnt[0] != (uint32_t)L.n)
+            return psk_fail(ctx, PSK_ESTATE, "sample %d: the GPU saw %u windows, the framing counted %llu", sample,
+                            L.pinned_cnt[0], (unsigned long long)L.n);
+        nu = L.pinned_cnt[1];
+        PSK_TRY(arena_alloc(ctx, nu * 8, (void **)&S.words));
+        PSK_TRY(arena_alloc(ctx, nu * 4, (void **)&S.freqs));
+        PSK_HIP(ctx, hipMemcpyAsync(S.words, L.uniq, nu * 8, hipMemcpyDeviceToDevice, ctx->stream));
+        rle_counts_kernel<<<div_up(nu, 256), 256, 0, ctx->stream>>>(L.starts.as<uint32_t>(), nu, L.n, S.freqs);
+        PSK_HIP(ctx, hipGetLastError());
+    }
+    S.n_unique = nu;
+    S.n_total = L.n;
+    S.done = true;
+    return PSK_OK;
+}
+
 static int ensure_pinned(psk_ctx *ctx, void **buf, size_t *cap, size_t need)
 {
     if (need <= *cap && *buf) return PSK_OK;
@@ -440,7 +545,10 @@ extern "C" int psk_count_kmers_batch(psk_ctx *ctx, int first_sample_idx, int n, 
     if (n_threads < 1) n_threads = 1;
     if (n_threads > 16) n_threads = 16;
     if (n_threads > n) n_threads = n;
-    const int R = n_threads + 1;  // ring slots
+    // whole-space runs take the pipelined path (see chain_enqueue); with a slab filter the window count is
+    // only known on the GPU and the samples go through count_from_stage one after the other
+    const bool pipelined = ctx->slab_lo == 0 && ctx->slab_hi == 0;
+    const int R = n_threads + 2;  // ring slots (the pipelined path releases a slot one sample late)
     size_t max_len = 0;
     for (int i = 0; i < n; i++) {
         if (!bytes[i] && lens[i]) return psk_fail(ctx, PSK_EINVAL, "null input %d", i);
@@ -452,10 +560,11 @@ extern "C" int psk_count_kmers_batch(psk_ctx *ctx, int first_sample_idx, int n, 
     std::mutex mu;
     std::condition_variable cv;
     std::vector<int> state(n, 0);          // 0 pending, 1 framed, -1 framing failed
-    std::vector<uint64_t> clen(n, 0), plen(n, 0);
-    int consumed = 0;                      // samples whose GPU half is finished
+    std::vector<uint64_t> clen(n, 0), plen(n, 0), wins(n, 0);
+    int consumed = 0;                      // samples whose ring slot may be overwritten
     bool abort = false;
     std::atomic<int> next(0);
+    const int k = ctx->k;
     auto worker = [&]() {
         for (;;) {
             const int i = next.fetch_add(1);
@@ -465,11 +574,12 @@ extern "C" int psk_count_kmers_batch(psk_ctx *ctx, int first_sample_idx, int n, 
                 cv.wait(lk, [&] { return abort || consumed > i - R; });  // slot i % R is free again
                 if (abort) return;
             }
-            uint64_t c = 0, p = 0;
-            const int rc = frame_into(static_cast<uint8_t *>(ctx->ring[i % R]), ctx->ring_cap[i % R], bytes[i], lens[i], &c, &p);
+            uint64_t c = 0, p = 0, w = 0;
+            const int rc = frame_into(static_cast<uint8_t *>(ctx->ring[i % R]), ctx->ring_cap[i % R], bytes[i], lens[i], &c, &p,
+                                      k, &w);
             {
                 std::lock_guard<std::mutex> lk(mu);
-                clen[i] = c; plen[i] = p;
+                clen[i] = c; plen[i] = p; wins[i] = w;
                 state[i] = rc ? -1 : 1;
             }
             cv.notify_all();
@@ -478,25 +588,54 @@ extern "C" int psk_count_kmers_batch(psk_ctx *ctx, int first_sample_idx, int n, 
     std::vector<std::thread> pool;
     for (int t = 0; t < n_threads; t++) pool.emplace_back(worker);
     int rc = PSK_OK;
+    auto release_upto = [&](int upto) {
+        {
+            std::lock_guard<std::mutex> lk(mu);
+            consumed = upto;
+            if (rc != PSK_OK) abort = true;
+        }
+        cv.notify_all();
+    };
+    auto report = [&](int i) {
+        if (n_unique) n_unique[i] = ctx->lists[first_sample_idx + i].n_unique;
+        if (n_total) n_total[i] = ctx->lists[first_sample_idx + i].n_total;
+    };
+    for (CountLane &L : ctx->lane) L.sample = -1;
     for (int i = 0; i < n && rc == PSK_OK; i++) {
         {
             std::unique_lock<std::mutex> lk(mu);
             cv.wait(lk, [&] { return state[i] != 0; });
             if (state[i] < 0) rc = psk_fail(ctx, PSK_ERANGE, "framing of sample %d failed", first_sample_idx + i);
         }
-        if (rc == PSK_OK)
-            rc = count_from_stage(ctx, first_sample_idx + i, static_cast<uint8_t *>(ctx->ring[i % R]), clen[i], plen[i]);
-        if (rc == PSK_OK) {
-            if (n_unique) n_unique[i] = ctx->lists[first_sample_idx + i].n_unique;
-            if (n_total) n_total[i] = ctx->lists[first_sample_idx + i].n_total;
+        if (rc != PSK_OK) break;
+        uint8_t *stage = static_cast<uint8_t *>(ctx->ring[i % R]);
+        if (!pipelined) {
+            rc = count_from_stage(ctx, first_sample_idx + i, stage, clen[i], plen[i]);
+            if (rc == PSK_OK) report(i);
+            release_upto(i + 1);
+            continue;
         }
-        {
-            std::lock_guard<std::mutex> lk(mu);
-            consumed = i + 1;
-            if (rc != PSK_OK) abort = true;
+        if (wins[i] >= (1ull << 32)) { rc = psk_fail(ctx, PSK_ERANGE, "sample with more than 2^32 windows"); break; }
+        rc = chain_enqueue(ctx, ctx->lane[i & 1], first_sample_idx + i, stage, clen[i], plen[i], wins[i]);
+        if (rc == PSK_OK && i > 0) {
+            rc = chain_finalize(ctx, ctx->lane[(i - 1) & 1]);  // waits for chain i - 1: its upload is done too
+            if (rc == PSK_OK) report(i - 1);
+            release_upto(i);
         }
-        cv.notify_all();
     }
+    if (pipelined) {
+        if (rc == PSK_OK && n > 0) {
+            rc = chain_finalize(ctx, ctx->lane[(n - 1) & 1]);
+            if (rc == PSK_OK) report(n - 1);
+        }
+        // nothing of this call may still be in flight when it returns (the ring and the caller's buffers)
+        const hipError_t e1 = hipStreamSynchronize(ctx->copy_stream ? ctx->copy_stream : ctx->stream);
+        const hipError_t e2 = hipStreamSynchronize(ctx->stream);
+        if (rc == PSK_OK && (e1 != hipSuccess || e2 != hipSuccess))
+            rc = psk_fail(ctx, PSK_EHIP, "stream synchronisation failed: %s", hipGetErrorString(e1 != hipSuccess ? e1 : e2));
+        for (CountLane &L : ctx->lane) L.sample = -1;
+    }
+    release_upto(n);
     {
         std::lock_guard<std::mutex> lk(mu);
         if (rc != PSK_OK) abort = true;

@@ -37,6 +37,18 @@ struct SampleList {
     bool done = false;
 };
 
+// One of the two buffer sets of the pipelined batch counter (psk_count_kmers_batch): the chain of sample i
+// runs on set i & 1 while the host finalises sample i - 1 from the other set.
+struct CountLane {
+    DevBuf raw, keysA, keysB, starts, cnt;
+    uint32_t *pinned_cnt = nullptr;  // pinned host landing: [0] windows seen by the GPU, [1] unique words
+    hipEvent_t done = nullptr, raw_ready = nullptr, raw_free = nullptr;
+    bool raw_used = false;
+    int sample = -1;                 // sample whose chain is in flight on this set (-1: none)
+    uint64_t n = 0;                  // its window count (known on the host from the framing)
+    uint64_t *uniq = nullptr;        // device: its unique words (one of keysA / keysB)
+};
+
 struct ScanParams {  // what psk_rescan_timed needs to re-launch the last chi2 scan
     bool valid = false;
     bool weighted = false;
@@ -71,6 +83,8 @@ struct psk_ctx {
     void *scan_pinned = nullptr;  // pinned staging for the scan's masks / weights
     size_t scan_pinned_cap = 0;
     void *cnt_pinned = nullptr;   // pinned landing buffer of the scan's result counters
+    CountLane lane[2];
+    hipStream_t copy_stream = nullptr;  // uploads of the batch counter overlap the previous sample's kernels
 
     // presence matrix
     uint64_t n_kmers = 0;

@@ -15,6 +15,7 @@ calls (phenotypeseeker_amd.engine); everything here is orchestration and formatt
 A single process drives the GPU (no fork pools: the HIP runtime is not fork-safe).
 """
 import math
+import os
 import sys
 import time
 from collections import OrderedDict
@@ -86,18 +87,31 @@ class Samples:
         stderr_print.print_progress("lists generated.")
 
     @classmethod
-    def get_kmer_lists_batched(cls, ctx, samples, n_threads, chunk=16):
+    def get_kmer_lists_batched(cls, ctx, samples, n_threads, chunk=None):
         """All samples through psk_count_kmers_batch: files are read (and inflated) by a small thread
         pool, host tokenisation runs ahead of the GPU inside the library."""
         from concurrent.futures import ThreadPoolExecutor
+        if chunk is None:  # about half a gigabyte of file images per call, two calls' worth in memory
+            try:
+                biggest = max(os.path.getsize(s.address) for s in samples)
+            except OSError:
+                biggest = 1 << 29
+            chunk = int(min(64, max(1, (1 << 29) // max(biggest, 1))))
+        # chunk boundaries ramp up (8, 16, 32, ...): the first read is short, later calls amortise their set-up
+        bounds, lo, step = [], 0, min(chunk, 8)
+        while lo < len(samples):
+            bounds.append((lo, min(len(samples), lo + step)))
+            lo += step
+            step = min(chunk, step * 2)
         with ThreadPoolExecutor(max_workers=n_threads) as pool:
-            def submit(lo):
-                return [pool.submit(formats.read_sequence_file, s.address) for s in samples[lo:lo + chunk]]
-            pending = submit(0)
-            for lo in range(0, len(samples), chunk):
-                part = samples[lo:lo + chunk]
+            def submit(b):
+                return [pool.submit(formats.read_sequence_file, s.address) for s in samples[b[0]:b[1]]]
+            pending = submit(bounds[0])
+            for bi, (lo, hi) in enumerate(bounds):
+                part = samples[lo:hi]
                 datas = [f.result() for f in pending]
-                pending = submit(lo + chunk)  # the next chunk is read while this one is counted
+                # the next chunk is read while this one is counted
+                pending = submit(bounds[bi + 1]) if bi + 1 < len(bounds) else []
                 nu, nt = ctx.count_kmers_batch(lo, datas, n_threads)
                 for j, s in enumerate(part):
                     s.n_unique, s.n_total = nu[j], nt[j]
