@@ -43,3 +43,12 @@ else:
         dt = time.time() - t
         if dt > 0.02 or i % 13 == 0:
             print("fit %3d C=%-8g fold=%2d newton=%4d nnz=%4d  %.4f s" % (i, fp[i], ff[i], it[0], (c != 0).sum(), dt))
+    # objective of every fit (liblinear L1R_LR, training rows only): lets runs with different settings be compared
+    ypm = 2.0 * y - 1.0
+    coef, icpt, it = ctx.logreg_l1_fit(X, y, fold, fp, ff, tol, mi)
+    objs = []
+    for i in range(len(fp)):
+        tr = fold != ff[i]
+        z = X[tr] @ coef[i] + icpt[i]
+        objs.append(np.abs(coef[i]).sum() + abs(icpt[i]) + fp[i] * np.logaddexp(0, -ypm[tr] * z).sum())
+    print("objective sum %.10f  newton total %d max %d" % (sum(objs), it.sum(), it.max()))
