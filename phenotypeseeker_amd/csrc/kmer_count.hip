@@ -251,31 +251,150 @@ __global__ __launch_bounds__(EX_THREADS) void extract_kernel(const uint8_t *__re
     for (uint32_t i = lane; i < wcount; i += 64) out[(uint64_t)base + i] = stage[wid][i];
 }
 
-__global__ void rle_flags_kernel(const uint64_t *__restrict__ keys, uint64_t n, uint32_t *__restrict__ flags)
+// ---- run-length encoding of the sorted words: unique words + u32 counts ---------------------------
+// Two passes over the sorted keys and one tiny scan instead of flags / scan / scatter / counts:
+//   rle_tile_kernel   per tile of 4096 keys: number of run heads, position of the first head
+//   rle_tile_scan     one workgroup: exclusive scan of the head counts (-> output offset of every tile, total =
+//                     number of unique words) and a suffix minimum of the first-head positions (-> where the
+//                     run that is open at the end of a tile ends)
+//   rle_emit_kernel   per tile again: head h writes its word and (position of the next head - its position)
+// A wave covers 16 rows of 64 consecutive keys; the heads of a row are one ballot, so ranks and "next head"
+// positions are scalar bit operations on wave-uniform masks.
+constexpr int RLE_THREADS = 256;
+constexpr int RLE_ROWS = 16;
+constexpr int RLE_WAVE_KEYS = 64 * RLE_ROWS;                    // 1024
+constexpr int RLE_TILE = RLE_WAVE_KEYS * (RLE_THREADS / 64);    // 4096
+
+__device__ __forceinline__ uint64_t rle_row_heads(const uint64_t *__restrict__ keys, uint64_t n, uint64_t i, uint64_t *key_out)
 {
-    const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (i < n) flags[i] = (i == 0 || keys[i] != keys[i - 1]) ? 1u : 0u;
+    bool head = false;
+    uint64_t k = 0;
+    if (i < n) {
+        k = keys[i];
+        head = (i == 0) || keys[i - 1] != k;
+    }
+    *key_out = k;
+    return __ballot(head);
 }
 
-// pos = exclusive scan of the head flags.  Heads write their word and their start index.
-__global__ void rle_scatter_kernel(const uint64_t *__restrict__ keys, uint64_t n, const uint32_t *__restrict__ pos,
-                                   uint64_t *__restrict__ words, uint32_t *__restrict__ starts)
+__global__ __launch_bounds__(RLE_THREADS) void rle_tile_kernel(const uint64_t *__restrict__ keys, uint64_t n,
+                                                               uint32_t *__restrict__ tile_cnt,
+                                                               uint32_t *__restrict__ tile_first)
 {
-    const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= n) return;
-    const bool head = (i == 0) || keys[i] != keys[i - 1];
-    if (head) {
-        const uint32_t j = pos[i];
-        words[j] = keys[i];
-        starts[j] = (uint32_t)i;
+    __shared__ uint32_t s_cnt[RLE_THREADS / 64], s_first[RLE_THREADS / 64];
+    const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
+    const uint64_t base = (uint64_t)blockIdx.x * RLE_TILE + (uint64_t)wid * RLE_WAVE_KEYS;
+    uint32_t cnt = 0, first = 0xffffffffu;
+#pragma unroll
+    for (int r = 0; r < RLE_ROWS; r++) {
+        uint64_t k;
+        const uint64_t m = rle_row_heads(keys, n, base + (uint64_t)r * 64 + lane, &k);
+        if (m && first == 0xffffffffu) first = (uint32_t)(base + (uint64_t)r * 64 + __builtin_ctzll(m));
+        cnt += __popcll(m);
+    }
+    if (lane == 0) { s_cnt[wid] = cnt; s_first[wid] = first; }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        uint32_t c = 0, f = 0xffffffffu;
+        for (int w = 0; w < RLE_THREADS / 64; w++) { c += s_cnt[w]; if (s_first[w] < f) f = s_first[w]; }
+        tile_cnt[blockIdx.x] = c;
+        tile_first[blockIdx.x] = f;
     }
 }
 
-__global__ void rle_counts_kernel(const uint32_t *__restrict__ starts, uint64_t nu, uint64_t n,
-                                  uint32_t *__restrict__ freqs)
+// tile_cnt -> exclusive offsets (in place), tile_first -> position of the first head AFTER the tile (in place),
+// total[0] = number of heads
+__global__ __launch_bounds__(1024) void rle_tile_scan_kernel(uint32_t *__restrict__ tile_cnt, uint32_t *__restrict__ tile_first,
+                                                              uint32_t n_tiles, uint32_t n, uint32_t *__restrict__ total)
 {
-    const uint64_t j = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (j < nu) freqs[j] = ((j + 1 < nu) ? starts[j + 1] : (uint32_t)n) - starts[j];
+    __shared__ uint32_t lds[16];
+    __shared__ uint32_t s_min[16];
+    uint32_t carry = 0;
+    for (uint32_t t0 = 0; t0 < n_tiles; t0 += 1024) {
+        const uint32_t t = t0 + threadIdx.x;
+        const uint32_t v = t < n_tiles ? tile_cnt[t] : 0u;
+        uint32_t all;
+        const uint32_t ex = psk_block_excl_scan_u32<1024>(v, &all, lds);
+        if (t < n_tiles) tile_cnt[t] = carry + ex;
+        carry += all;
+    }
+    if (threadIdx.x == 0) total[0] = carry;
+    // suffix minimum, exclusive: next[t] = min(first[t+1 ..]) or n; chunks from the back
+    uint32_t tail = n;  // minimum over everything behind the current chunk
+    const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
+    for (uint32_t done = 0; done < n_tiles; done += 1024) {
+        const uint32_t hi = n_tiles - done;                 // chunk = [lo, hi)
+        const uint32_t lo = hi > 1024 ? hi - 1024 : 0;
+        const uint32_t t = lo + threadIdx.x;
+        const uint32_t v = t < hi ? tile_first[t] : 0xffffffffu;
+        // inclusive suffix min within the wave (towards higher lanes), then across waves
+        uint32_t m = v;
+#pragma unroll
+        for (int d = 1; d < 64; d <<= 1) {
+            const uint32_t o = __shfl_down(m, d, 64);
+            if (lane + d < 64 && o < m) m = o;
+        }
+        __syncthreads();
+        if (lane == 0) s_min[wid] = m;  // minimum of the whole wave
+        __syncthreads();
+        uint32_t behind = tail;          // minimum of the waves behind this one + earlier chunks
+        for (int w = wid + 1; w < 16; w++) if (s_min[w] < behind) behind = s_min[w];
+        // exclusive: the inclusive suffix min of the next lane (or `behind` for the last lane)
+        uint32_t nxt = __shfl_down(m, 1, 64);
+        if (lane == 63) nxt = 0xffffffffu;
+        uint32_t res = nxt < behind ? nxt : behind;
+        uint32_t chunk_min = tail;
+        for (int w = 0; w < 16; w++) if (s_min[w] < chunk_min) chunk_min = s_min[w];
+        if (t < hi) tile_first[t] = res;
+        tail = chunk_min;
+        __syncthreads();
+    }
+}
+
+__global__ __launch_bounds__(RLE_THREADS) void rle_emit_kernel(const uint64_t *__restrict__ keys, uint64_t n,
+                                                               const uint32_t *__restrict__ tile_off,
+                                                               const uint32_t *__restrict__ tile_next,
+                                                               uint64_t *__restrict__ words, uint32_t *__restrict__ freqs)
+{
+    __shared__ uint32_t s_cnt[RLE_THREADS / 64], s_first[RLE_THREADS / 64];
+    const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
+    const uint64_t base = (uint64_t)blockIdx.x * RLE_TILE + (uint64_t)wid * RLE_WAVE_KEYS;
+    uint64_t mask[RLE_ROWS], key[RLE_ROWS];
+    uint32_t cnt = 0, first = 0xffffffffu;
+#pragma unroll
+    for (int r = 0; r < RLE_ROWS; r++) {
+        mask[r] = rle_row_heads(keys, n, base + (uint64_t)r * 64 + lane, &key[r]);
+        if (mask[r] && first == 0xffffffffu) first = (uint32_t)(base + (uint64_t)r * 64 + __builtin_ctzll(mask[r]));
+        cnt += __popcll(mask[r]);
+    }
+    if (lane == 0) { s_cnt[wid] = cnt; s_first[wid] = first; }
+    __syncthreads();
+    uint32_t out = tile_off[blockIdx.x];
+    for (int w = 0; w < wid; w++) out += s_cnt[w];
+    // first head behind this wave: a later wave of the tile, else the first head after the tile
+    uint32_t after = tile_next[blockIdx.x];
+    for (int w = RLE_THREADS / 64 - 1; w > wid; w--) if (s_first[w] != 0xffffffffu) after = s_first[w];
+    // position of the first head in a later row of this wave, per row (scalar, back to front)
+    uint32_t later[RLE_ROWS];
+    uint32_t nxt = after;
+#pragma unroll
+    for (int r = RLE_ROWS - 1; r >= 0; r--) {
+        later[r] = nxt;
+        if (mask[r]) nxt = (uint32_t)(base + (uint64_t)r * 64 + __builtin_ctzll(mask[r]));
+    }
+#pragma unroll
+    for (int r = 0; r < RLE_ROWS; r++) {
+        const uint64_t m = mask[r];
+        if ((m >> lane) & 1) {
+            const uint32_t pos = (uint32_t)(base + (uint64_t)r * 64 + lane);
+            const uint64_t above = (lane == 63) ? 0ull : (m >> (lane + 1));
+            const uint32_t next = above ? pos + 1 + (uint32_t)__builtin_ctzll(above) : later[r];
+            const uint32_t j = out + __popcll(m & psk_lanemask_lt(lane));
+            words[j] = key[r];
+            freqs[j] = next - pos;
+        }
+        out += __popcll(m);
+    }
 }
 
 // binary search of `n` query words in a sorted list; 0 if absent
@@ -386,15 +505,13 @@ static int count_from_stage(psk_ctx *ctx, int sample_idx, const uint8_t *stage, 
     if (n > 0) {
         uint64_t *sorted = nullptr;
         PSK_TRY(dev_radix_sort_u64(ctx, ctx->keysA.as<uint64_t>(), ctx->keysB.as<uint64_t>(), n, 0, 2 * ctx->k, &sorted));
-        uint64_t *other = (sorted == ctx->keysA.as<uint64_t>()) ? ctx->keysB.as<uint64_t>() : ctx->keysA.as<uint64_t>();
-        PSK_TRY(dev_reserve(ctx, ctx->flags, n * 4));
-        PSK_TRY(dev_reserve(ctx, ctx->starts, n * 4));
-        uint32_t *flags = ctx->flags.as<uint32_t>();
-        rle_flags_kernel<<<div_up(n, 256), 256, 0, ctx->stream>>>(sorted, n, flags);
+        const uint32_t n_tiles = (uint32_t)div_up(n, RLE_TILE);
+        PSK_TRY(dev_reserve(ctx, ctx->flags, (size_t)n_tiles * 4));
+        PSK_TRY(dev_reserve(ctx, ctx->starts, (size_t)n_tiles * 4));
+        uint32_t *t_off = ctx->flags.as<uint32_t>(), *t_next = ctx->starts.as<uint32_t>();
+        rle_tile_kernel<<<n_tiles, RLE_THREADS, 0, ctx->stream>>>(sorted, n, t_off, t_next);
         PSK_HIP(ctx, hipGetLastError());
-        PSK_TRY(dev_exclusive_scan_u32(ctx, flags, flags, n, d_n + 1));
-        // unique words go to the other key buffer, starts to ctx->starts
-        rle_scatter_kernel<<<div_up(n, 256), 256, 0, ctx->stream>>>(sorted, n, flags, other, ctx->starts.as<uint32_t>());
+        rle_tile_scan_kernel<<<1, 1024, 0, ctx->stream>>>(t_off, t_next, n_tiles, (uint32_t)n, d_n + 1);
         PSK_HIP(ctx, hipGetLastError());
         uint32_t nu32 = 0;
         PSK_HIP(ctx, hipMemcpyAsync(&nu32, d_n + 1, 4, hipMemcpyDeviceToHost, ctx->stream));
@@ -402,8 +519,7 @@ static int count_from_stage(psk_ctx *ctx, int sample_idx, const uint8_t *stage, 
         nu = nu32;
         PSK_TRY(arena_alloc(ctx, nu * 8, (void **)&L.words));
         PSK_TRY(arena_alloc(ctx, nu * 4, (void **)&L.freqs));
-        PSK_HIP(ctx, hipMemcpyAsync(L.words, other, nu * 8, hipMemcpyDeviceToDevice, ctx->stream));
-        rle_counts_kernel<<<div_up(nu, 256), 256, 0, ctx->stream>>>(ctx->starts.as<uint32_t>(), nu, n, L.freqs);
+        rle_emit_kernel<<<n_tiles, RLE_THREADS, 0, ctx->stream>>>(sorted, n, t_off, t_next, L.words, L.freqs);
         PSK_HIP(ctx, hipGetLastError());
         PSK_HIP(ctx, hipStreamSynchronize(ctx->stream));
     }
@@ -444,9 +560,8 @@ static int chain_enqueue(psk_ctx *ctx, CountLane &L, int sample_idx, const uint8
     PSK_TRY(dev_reserve(ctx, L.raw, padded));
     PSK_TRY(dev_reserve(ctx, L.keysA, n * 8));
     PSK_TRY(dev_reserve(ctx, L.keysB, n * 8));
-    PSK_TRY(dev_reserve(ctx, L.starts, n * 4));
+    PSK_TRY(dev_reserve(ctx, L.starts, (size_t)div_up(n, RLE_TILE) * 8));  // tile offsets | next-head positions
     PSK_TRY(dev_reserve(ctx, L.cnt, 64));
-    PSK_TRY(dev_reserve(ctx, ctx->flags, n * 4));
     // upload on the copy stream, after the extract of the sample that used this raw buffer before
     if (L.raw_used) PSK_HIP(ctx, hipStreamWaitEvent(ctx->copy_stream, L.raw_free, 0));
     PSK_HIP(ctx, hipMemcpyAsync(L.raw.p, stage, padded, hipMemcpyHostToDevice, ctx->copy_stream));
@@ -460,20 +575,19 @@ static int chain_enqueue(psk_ctx *ctx, CountLane &L, int sample_idx, const uint8
     L.raw_used = true;
     uint64_t *sorted = nullptr;
     PSK_TRY(dev_radix_sort_u64(ctx, L.keysA.as<uint64_t>(), L.keysB.as<uint64_t>(), n, 0, 2 * ctx->k, &sorted));
-    uint64_t *other = (sorted == L.keysA.as<uint64_t>()) ? L.keysB.as<uint64_t>() : L.keysA.as<uint64_t>();
-    uint32_t *flags = ctx->flags.as<uint32_t>();
-    rle_flags_kernel<<<div_up(n, 256), 256, 0, ctx->stream>>>(sorted, n, flags);
+    const uint32_t n_tiles = (uint32_t)div_up(n, RLE_TILE);
+    uint32_t *t_off = L.starts.as<uint32_t>(), *t_next = t_off + n_tiles;
+    rle_tile_kernel<<<n_tiles, RLE_THREADS, 0, ctx->stream>>>(sorted, n, t_off, t_next);
     PSK_HIP(ctx, hipGetLastError());
-    PSK_TRY(dev_exclusive_scan_u32(ctx, flags, flags, n, d_n + 1));
-    rle_scatter_kernel<<<div_up(n, 256), 256, 0, ctx->stream>>>(sorted, n, flags, other, L.starts.as<uint32_t>());
+    rle_tile_scan_kernel<<<1, 1024, 0, ctx->stream>>>(t_off, t_next, n_tiles, (uint32_t)n, d_n + 1);
     PSK_HIP(ctx, hipGetLastError());
     PSK_HIP(ctx, hipMemcpyAsync(L.pinned_cnt, d_n, 8, hipMemcpyDeviceToHost, ctx->stream));
     PSK_HIP(ctx, hipEventRecord(L.done, ctx->stream));
-    L.uniq = other;
+    L.uniq = sorted;  // the emit pass (chain_finalize) reads the sorted keys once the output size is known
     return PSK_OK;
 }
 
-// second half: arena allocation + copy-out of the sample whose chain ran on this set
+// second half: arena allocation + the emit pass (straight into the arena) of the sample whose chain ran on this set
 static int chain_finalize(psk_ctx *ctx, CountLane &L)
 {
     if (L.sample < 0) return PSK_OK;
@@ -489,8 +603,9 @@ static int chain_finalize(psk_ctx *ctx, CountLane &L)
         nu = L.pinned_cnt[1];
         PSK_TRY(arena_alloc(ctx, nu * 8, (void **)&S.words));
         PSK_TRY(arena_alloc(ctx, nu * 4, (void **)&S.freqs));
-        PSK_HIP(ctx, hipMemcpyAsync(S.words, L.uniq, nu * 8, hipMemcpyDeviceToDevice, ctx->stream));
-        rle_counts_kernel<<<div_up(nu, 256), 256, 0, ctx->stream>>>(L.starts.as<uint32_t>(), nu, L.n, S.freqs);
+        const uint32_t n_tiles = (uint32_t)div_up(L.n, RLE_TILE);
+        const uint32_t *t_off = L.starts.as<uint32_t>();
+        rle_emit_kernel<<<n_tiles, RLE_THREADS, 0, ctx->stream>>>(L.uniq, L.n, t_off, t_off + n_tiles, S.words, S.freqs);
         PSK_HIP(ctx, hipGetLastError());
     }
     S.n_unique = nu;
