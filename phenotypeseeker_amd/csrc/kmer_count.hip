@@ -175,7 +175,8 @@ extern "C" int64_t psk_frame_sequence(const uint8_t *bytes, size_t len, uint8_t 
 namespace {
 
 constexpr int EX_THREADS = 256;
-constexpr int EX_SEG = 32;  // window-end positions per thread
+constexpr int EX_SEG = 32;   // window-end positions per thread
+constexpr int EX_HALO = 32;  // bytes before the segment that are rolled first (k - 1 <= 31)
 
 struct Roll {
     uint64_t fw, rc;
@@ -196,8 +197,8 @@ __device__ __forceinline__ void roll_byte(Roll &r, uint32_t c, uint64_t mask, in
 
 // clean: bases and '\n' breaks, 16-byte aligned, padded with '\n' to a multiple of EX_SEG.
 // Every lane rolls EX_SEG consecutive window ends; the wave compacts its valid words into its own
-// 16 KiB LDS region (ballot ranks, wave-uniform running count), reserves its output range with ONE
-// atomic and spills the region with consecutive lanes on consecutive addresses.
+// 16 KiB LDS region (ballot ranks, wave-uniform running count); the workgroup reserves its output range
+// with ONE atomic and every wave spills its region with consecutive lanes on consecutive addresses.
 __global__ __launch_bounds__(EX_THREADS) void extract_kernel(const uint8_t *__restrict__ clean, uint64_t len, int k,
                                                               uint64_t lo, uint64_t hi, uint64_t *__restrict__ out,
                                                               uint32_t *__restrict__ n_out)
@@ -210,26 +211,33 @@ __global__ __launch_bounds__(EX_THREADS) void extract_kernel(const uint8_t *__re
     const int rcshift = 2 * (k - 1);
     const bool active = s < len;
 
-    uint32_t cur[8], prev[8];
+    uint32_t cur[EX_SEG / 4], prev[EX_HALO / 4];
 #pragma unroll
-    for (int j = 0; j < 8; j++) { cur[j] = 0x0a0a0a0au; prev[j] = 0x0a0a0a0au; }
+    for (int j = 0; j < EX_SEG / 4; j++) cur[j] = 0x0a0a0a0au;
+#pragma unroll
+    for (int j = 0; j < EX_HALO / 4; j++) prev[j] = 0x0a0a0a0au;
     if (active) {
         const uint4 *p = reinterpret_cast<const uint4 *>(clean + s);
-        uint4 a = p[0], b = p[1];
-        cur[0] = a.x; cur[1] = a.y; cur[2] = a.z; cur[3] = a.w;
-        cur[4] = b.x; cur[5] = b.y; cur[6] = b.z; cur[7] = b.w;
-        if (s >= EX_SEG) {
-            const uint4 *q = reinterpret_cast<const uint4 *>(clean + s - EX_SEG);
-            uint4 c = q[0], d = q[1];
-            prev[0] = c.x; prev[1] = c.y; prev[2] = c.z; prev[3] = c.w;
-            prev[4] = d.x; prev[5] = d.y; prev[6] = d.z; prev[7] = d.w;
+#pragma unroll
+        for (int q = 0; q < EX_SEG / 16; q++) {
+            const uint4 a = p[q];
+            cur[4 * q] = a.x; cur[4 * q + 1] = a.y; cur[4 * q + 2] = a.z; cur[4 * q + 3] = a.w;
+        }
+        // the EX_HALO bytes before s, 16 at a time (what lies before the buffer counts as a break)
+#pragma unroll
+        for (int q = 0; q < EX_HALO / 16; q++) {
+            const uint64_t back = (uint64_t)(EX_HALO / 16 - q) * 16;
+            if (s >= back) {
+                const uint4 c = *reinterpret_cast<const uint4 *>(clean + s - back);
+                prev[4 * q] = c.x; prev[4 * q + 1] = c.y; prev[4 * q + 2] = c.z; prev[4 * q + 3] = c.w;
+            }
         }
     }
     Roll r{0, 0, 0};
-    // warm-up over the k-1 bytes before s (k-1 <= 31 < EX_SEG)
+    // warm-up over the k-1 bytes before s (k-1 <= 31 < EX_HALO)
 #pragma unroll
-    for (int j = 0; j < EX_SEG; j++) {
-        if (j >= EX_SEG - (k - 1)) {
+    for (int j = 0; j < EX_HALO; j++) {
+        if (j >= EX_HALO - (k - 1)) {
             const uint32_t c = (prev[j >> 2] >> ((j & 3) * 8)) & 0xffu;
             roll_byte(r, c, mask, rcshift, k);
         }
@@ -245,9 +253,21 @@ __global__ __launch_bounds__(EX_THREADS) void extract_kernel(const uint8_t *__re
         if (valid) stage[wid][wcount + __popcll(bal & psk_lanemask_lt(lane))] = w;
         wcount += (uint32_t)__popcll(bal);
     }
-    uint32_t base = 0;
-    if (lane == 0 && wcount) base = atomicAdd(n_out, wcount);
-    base = __shfl(base, 0, 64);
+    // ONE reservation per workgroup: same-address atomics retire at ~11 ns each, so one per wave (2441 for a
+    // 5-Mbp sample) was 27 of the kernel's 45 us
+    __shared__ uint32_t s_wcount[EX_THREADS / 64];
+    __shared__ uint32_t s_base;
+    if (lane == 0) s_wcount[wid] = wcount;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        uint32_t tot = 0;
+#pragma unroll
+        for (int w = 0; w < EX_THREADS / 64; w++) tot += s_wcount[w];
+        s_base = tot ? atomicAdd(n_out, tot) : 0u;
+    }
+    __syncthreads();
+    uint32_t base = s_base;
+    for (int w = 0; w < wid; w++) base += s_wcount[w];
     for (uint32_t i = lane; i < wcount; i += 64) out[(uint64_t)base + i] = stage[wid][i];
 }
 
@@ -561,14 +581,18 @@ static int chain_enqueue(psk_ctx *ctx, CountLane &L, int sample_idx, const uint8
     PSK_TRY(dev_reserve(ctx, L.keysA, n * 8));
     PSK_TRY(dev_reserve(ctx, L.keysB, n * 8));
     PSK_TRY(dev_reserve(ctx, L.starts, (size_t)div_up(n, RLE_TILE) * 8));  // tile offsets | next-head positions
-    PSK_TRY(dev_reserve(ctx, L.cnt, 64));
+    PSK_TRY(dev_reserve(ctx, L.cnt, (size_t)CountLane::CNT_SLOTS * 16));
     // upload on the copy stream, after the extract of the sample that used this raw buffer before
     if (L.raw_used) PSK_HIP(ctx, hipStreamWaitEvent(ctx->copy_stream, L.raw_free, 0));
     PSK_HIP(ctx, hipMemcpyAsync(L.raw.p, stage, padded, hipMemcpyHostToDevice, ctx->copy_stream));
     PSK_HIP(ctx, hipEventRecord(L.raw_ready, ctx->copy_stream));
     PSK_HIP(ctx, hipStreamWaitEvent(ctx->stream, L.raw_ready, 0));
-    uint32_t *d_n = L.cnt.as<uint32_t>();
-    PSK_HIP(ctx, hipMemsetAsync(d_n, 0, 16, ctx->stream));
+    // every sample takes a fresh pre-zeroed counter slot (a 16-byte memset per sample is a 6 us launch)
+    if (L.cnt_slot == 0 || L.cnt_slot >= CountLane::CNT_SLOTS) {
+        PSK_HIP(ctx, hipMemsetAsync(L.cnt.p, 0, (size_t)CountLane::CNT_SLOTS * 16, ctx->stream));
+        L.cnt_slot = 0;
+    }
+    uint32_t *d_n = L.cnt.as<uint32_t>() + 4 * (size_t)L.cnt_slot++;
     PSK_TRY(launch_extract(ctx, L.raw.as<uint8_t>(), clean_len, ctx->k, ctx->slab_lo, ctx->slab_hi, L.keysA.as<uint64_t>(),
                            d_n));
     PSK_HIP(ctx, hipEventRecord(L.raw_free, ctx->stream));

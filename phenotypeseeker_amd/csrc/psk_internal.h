@@ -40,10 +40,12 @@ struct SampleList {
 // One of the two buffer sets of the pipelined batch counter (psk_count_kmers_batch): the chain of sample i
 // runs on set i & 1 while the host finalises sample i - 1 from the other set.
 struct CountLane {
+    static constexpr uint32_t CNT_SLOTS = 4096;
     DevBuf raw, keysA, keysB, starts, cnt;
     uint32_t *pinned_cnt = nullptr;  // pinned host landing: [0] windows seen by the GPU, [1] unique words
     hipEvent_t done = nullptr, raw_ready = nullptr, raw_free = nullptr;
     bool raw_used = false;
+    uint32_t cnt_slot = 0;           // next unused 16-byte counter slot of `cnt` (zeroed CNT_SLOTS at a time)
     int sample = -1;                 // sample whose chain is in flight on this set (-1: none)
     uint64_t n = 0;                  // its window count (known on the host from the framing)
     uint64_t *uniq = nullptr;        // device: its unique words (one of keysA / keysB)
