@@ -297,10 +297,13 @@ __device__ __forceinline__ uint64_t rle_row_heads(const uint64_t *__restrict__ k
     return __ballot(head);
 }
 
-__global__ __launch_bounds__(RLE_THREADS) void rle_tile_kernel(const uint64_t *__restrict__ keys, uint64_t n,
+// n_dev != nullptr: the key count sits in device memory (<= n_host, which sizes the grid)
+__global__ __launch_bounds__(RLE_THREADS) void rle_tile_kernel(const uint64_t *__restrict__ keys, uint64_t n_host,
+                                                               const uint32_t *__restrict__ n_dev,
                                                                uint32_t *__restrict__ tile_cnt,
                                                                uint32_t *__restrict__ tile_first)
 {
+    const uint64_t n = n_dev ? (uint64_t)*n_dev : n_host;
     __shared__ uint32_t s_cnt[RLE_THREADS / 64], s_first[RLE_THREADS / 64];
     const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
     const uint64_t base = (uint64_t)blockIdx.x * RLE_TILE + (uint64_t)wid * RLE_WAVE_KEYS;
@@ -325,8 +328,10 @@ __global__ __launch_bounds__(RLE_THREADS) void rle_tile_kernel(const uint64_t *_
 // tile_cnt -> exclusive offsets (in place), tile_first -> position of the first head AFTER the tile (in place),
 // total[0] = number of heads
 __global__ __launch_bounds__(1024) void rle_tile_scan_kernel(uint32_t *__restrict__ tile_cnt, uint32_t *__restrict__ tile_first,
-                                                              uint32_t n_tiles, uint32_t n, uint32_t *__restrict__ total)
+                                                              uint32_t n_tiles, uint32_t n_host, const uint32_t *__restrict__ n_dev,
+                                                              uint32_t *__restrict__ total)
 {
+    const uint32_t n = n_dev ? *n_dev : n_host;
     __shared__ uint32_t lds[16];
     __shared__ uint32_t s_min[16];
     uint32_t carry = 0;
@@ -529,9 +534,9 @@ static int count_from_stage(psk_ctx *ctx, int sample_idx, const uint8_t *stage, 
         PSK_TRY(dev_reserve(ctx, ctx->flags, (size_t)n_tiles * 4));
         PSK_TRY(dev_reserve(ctx, ctx->starts, (size_t)n_tiles * 4));
         uint32_t *t_off = ctx->flags.as<uint32_t>(), *t_next = ctx->starts.as<uint32_t>();
-        rle_tile_kernel<<<n_tiles, RLE_THREADS, 0, ctx->stream>>>(sorted, n, t_off, t_next);
+        rle_tile_kernel<<<n_tiles, RLE_THREADS, 0, ctx->stream>>>(sorted, n, nullptr, t_off, t_next);
         PSK_HIP(ctx, hipGetLastError());
-        rle_tile_scan_kernel<<<1, 1024, 0, ctx->stream>>>(t_off, t_next, n_tiles, (uint32_t)n, d_n + 1);
+        rle_tile_scan_kernel<<<1, 1024, 0, ctx->stream>>>(t_off, t_next, n_tiles, (uint32_t)n, nullptr, d_n + 1);
         PSK_HIP(ctx, hipGetLastError());
         uint32_t nu32 = 0;
         PSK_HIP(ctx, hipMemcpyAsync(&nu32, d_n + 1, 4, hipMemcpyDeviceToHost, ctx->stream));
@@ -574,6 +579,7 @@ static int chain_enqueue(psk_ctx *ctx, CountLane &L, int sample_idx, const uint8
     if (clean_len >= (1ull << 32)) return psk_fail(ctx, PSK_ERANGE, "sample larger than 4 Gbases");
     L.sample = sample_idx;
     L.n = n;
+    L.exact = ctx->slab_lo == 0 && ctx->slab_hi == 0;  // no slab filter: every window yields a word
     L.uniq = nullptr;
     if (n == 0) return PSK_OK;
     PSK_TRY(lane_prepare(ctx, L));
@@ -598,12 +604,15 @@ static int chain_enqueue(psk_ctx *ctx, CountLane &L, int sample_idx, const uint8
     PSK_HIP(ctx, hipEventRecord(L.raw_free, ctx->stream));
     L.raw_used = true;
     uint64_t *sorted = nullptr;
-    PSK_TRY(dev_radix_sort_u64(ctx, L.keysA.as<uint64_t>(), L.keysB.as<uint64_t>(), n, 0, 2 * ctx->k, &sorted));
+    // with a slab filter only the GPU knows how many words were kept: the launches cover the host's count
+    // (every window) and the kernels read the real one from d_n[0]
+    const uint32_t *n_dev = L.exact ? nullptr : d_n;
+    PSK_TRY(dev_radix_sort_u64(ctx, L.keysA.as<uint64_t>(), L.keysB.as<uint64_t>(), n, 0, 2 * ctx->k, &sorted, n_dev));
     const uint32_t n_tiles = (uint32_t)div_up(n, RLE_TILE);
     uint32_t *t_off = L.starts.as<uint32_t>(), *t_next = t_off + n_tiles;
-    rle_tile_kernel<<<n_tiles, RLE_THREADS, 0, ctx->stream>>>(sorted, n, t_off, t_next);
+    rle_tile_kernel<<<n_tiles, RLE_THREADS, 0, ctx->stream>>>(sorted, n, n_dev, t_off, t_next);
     PSK_HIP(ctx, hipGetLastError());
-    rle_tile_scan_kernel<<<1, 1024, 0, ctx->stream>>>(t_off, t_next, n_tiles, (uint32_t)n, d_n + 1);
+    rle_tile_scan_kernel<<<1, 1024, 0, ctx->stream>>>(t_off, t_next, n_tiles, (uint32_t)n, n_dev, d_n + 1);
     PSK_HIP(ctx, hipGetLastError());
     PSK_HIP(ctx, hipMemcpyAsync(L.pinned_cnt, d_n, 8, hipMemcpyDeviceToHost, ctx->stream));
     PSK_HIP(ctx, hipEventRecord(L.done, ctx->stream));
@@ -618,22 +627,26 @@ static int chain_finalize(psk_ctx *ctx, CountLane &L)
     SampleList &S = ctx->lists[L.sample];
     const int sample = L.sample;
     L.sample = -1;
-    uint64_t nu = 0;
+    uint64_t nu = 0, n_kept = 0;
     if (L.n > 0) {
         PSK_HIP(ctx, hipEventSynchronize(L.done));
-        if (L.pinned_cnt[0] != (uint32_t)L.n)
-            return psk_fail(ctx, PSK_ESTATE, "sample %d: the GPU saw %u windows, the framing counted %llu", sample,
-                            L.pinned_cnt[0], (unsigned long long)L.n);
+        const uint64_t n_gpu = L.pinned_cnt[0];
+        if (L.exact ? (n_gpu != L.n) : (n_gpu > L.n))
+            return psk_fail(ctx, PSK_ESTATE, "sample %d: the GPU kept %llu windows, the framing counted %llu", sample,
+                            (unsigned long long)n_gpu, (unsigned long long)L.n);
+        n_kept = n_gpu;
         nu = L.pinned_cnt[1];
         PSK_TRY(arena_alloc(ctx, nu * 8, (void **)&S.words));
         PSK_TRY(arena_alloc(ctx, nu * 4, (void **)&S.freqs));
-        const uint32_t n_tiles = (uint32_t)div_up(L.n, RLE_TILE);
+        const uint32_t n_tiles = (uint32_t)div_up(L.n, RLE_TILE);  // the layout of the tile arrays follows L.n
         const uint32_t *t_off = L.starts.as<uint32_t>();
-        rle_emit_kernel<<<n_tiles, RLE_THREADS, 0, ctx->stream>>>(L.uniq, L.n, t_off, t_off + n_tiles, S.words, S.freqs);
+        if (n_kept)
+            rle_emit_kernel<<<(uint32_t)div_up(n_kept, RLE_TILE), RLE_THREADS, 0, ctx->stream>>>(L.uniq, n_kept, t_off, t_off + n_tiles,
+                                                                                        S.words, S.freqs);
         PSK_HIP(ctx, hipGetLastError());
     }
     S.n_unique = nu;
-    S.n_total = L.n;
+    S.n_total = n_kept;
     S.done = true;
     return PSK_OK;
 }
@@ -684,9 +697,9 @@ extern "C" int psk_count_kmers_batch(psk_ctx *ctx, int first_sample_idx, int n, 
     if (n_threads < 1) n_threads = 1;
     if (n_threads > 16) n_threads = 16;
     if (n_threads > n) n_threads = n;
-    // whole-space runs take the pipelined path (see chain_enqueue); with a slab filter the window count is
-    // only known on the GPU and the samples go through count_from_stage one after the other
-    const bool pipelined = ctx->slab_lo == 0 && ctx->slab_hi == 0;
+    // every sample takes the pipelined path (see chain_enqueue); with a slab filter the host's window count is
+    // an upper bound and the kernels read the number of kept words from device memory
+    const bool pipelined = true;
     const int R = n_threads + 2;  // ring slots (the pipelined path releases a slot one sample late)
     size_t max_len = 0;
     for (int i = 0; i < n; i++) {

@@ -45,6 +45,7 @@ struct CountLane {
     uint32_t *pinned_cnt = nullptr;  // pinned host landing: [0] windows seen by the GPU, [1] unique words
     hipEvent_t done = nullptr, raw_ready = nullptr, raw_free = nullptr;
     bool raw_used = false;
+    bool exact = true;               // n is exact (no slab filter); otherwise an upper bound
     uint32_t cnt_slot = 0;           // next unused 16-byte counter slot of `cnt` (zeroed CNT_SLOTS at a time)
     int sample = -1;                 // sample whose chain is in flight on this set (-1: none)
     uint64_t n = 0;                  // its window count (known on the host from the framing)
@@ -135,11 +136,11 @@ int dev_exclusive_scan_u32(psk_ctx *ctx, const uint32_t *in, uint32_t *out, uint
 // Stable LSD radix sort of n u64 keys on bits [bit_lo, bit_hi).  Sorted data ends in *sorted_out
 // (either a or b).  n < 2^32.
 int dev_radix_sort_u64(psk_ctx *ctx, uint64_t *a, uint64_t *b, uint64_t n, int bit_lo, int bit_hi,
-                       uint64_t **sorted_out);
+                       uint64_t **sorted_out, const uint32_t *n_dev = nullptr);
 
 // Same with a u32 payload per key (va/vb double buffer); sorted payloads end in *sorted_vals_out.
 int dev_radix_sort_kv(psk_ctx *ctx, uint64_t *a, uint64_t *b, uint32_t *va, uint32_t *vb, uint64_t n, int bit_lo,
-                      int bit_hi, uint64_t **sorted_out, uint32_t **sorted_vals_out);
+                      int bit_hi, uint64_t **sorted_out, uint32_t **sorted_vals_out, const uint32_t *n_dev = nullptr);
 
 // ---- stages --------------------------------------------------------------------------------------
 int64_t frame_sequence_host(const uint8_t *bytes, size_t len, uint8_t *out, size_t out_cap);

@@ -20,11 +20,13 @@ constexpr int RS_KPT = 16;                      // keys per thread
 constexpr int RS_TILE = RS_THREADS * RS_KPT;    // 4096 keys per workgroup
 
 template <int RB>
-__global__ __launch_bounds__(RS_THREADS) void radix_hist_kernel(const uint64_t *__restrict__ keys, uint64_t n,
-                                                                 int shift, uint32_t dmask, uint32_t n_tiles,
+__global__ __launch_bounds__(RS_THREADS) void radix_hist_kernel(const uint64_t *__restrict__ keys, uint64_t n_host,
+                                                                 const uint32_t *__restrict__ n_dev, int shift,
+                                                                 uint32_t dmask, uint32_t n_tiles,
                                                                  uint32_t *__restrict__ hist)
 {
     constexpr int RADIX = 1 << RB, DPT = RADIX / RS_THREADS;  // digits per thread
+    const uint64_t n = n_dev ? (uint64_t)*n_dev : n_host;      // n_dev: key count produced on the device, <= n_host
     __shared__ uint32_t h[RADIX];
 #pragma unroll
     for (int e = 0; e < DPT; e++) h[e * RS_THREADS + threadIdx.x] = 0;
@@ -76,7 +78,8 @@ __global__ __launch_bounds__(RS_THREADS) void radix_digit_scan_kernel(uint32_t *
 // not fit one u64, i.e. 2k + ceil(log2 N) > 64).
 template <int RB, bool HAS_VAL>
 __global__ __launch_bounds__(RS_THREADS) void radix_scatter_kernel(const uint64_t *__restrict__ src,
-                                                                    uint64_t *__restrict__ dst, uint64_t n, int shift,
+                                                                    uint64_t *__restrict__ dst, uint64_t n_host,
+                                                                    const uint32_t *__restrict__ n_dev, int shift,
                                                                     uint32_t dmask, uint32_t n_tiles,
                                                                     const uint32_t *__restrict__ hist_scanned,
                                                                     const uint32_t *__restrict__ total,
@@ -91,7 +94,9 @@ __global__ __launch_bounds__(RS_THREADS) void radix_scatter_kernel(const uint64_
     __shared__ uint32_t scan_lds[RS_WAVES];
 
     const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+    const uint64_t n = n_dev ? (uint64_t)*n_dev : n_host;
     const uint64_t tile_base = (uint64_t)blockIdx.x * RS_TILE;
+    if (tile_base >= n) return;  // tiles beyond a device-side count (the grid covers the host's upper bound)
     const uint32_t n_valid = (uint32_t)((n - tile_base < (uint64_t)RS_TILE) ? (n - tile_base) : RS_TILE);
 
 #pragma unroll
@@ -179,19 +184,19 @@ __global__ __launch_bounds__(RS_THREADS) void radix_scatter_kernel(const uint64_
 }
 
 template <int RB>
-int radix_pass(psk_ctx *ctx, const uint64_t *src, uint64_t *dst, const uint32_t *vsrc, uint32_t *vdst, uint64_t n, int shift,
-               int nb, uint32_t n_tiles, uint32_t *hist, uint32_t *total)
+int radix_pass(psk_ctx *ctx, const uint64_t *src, uint64_t *dst, const uint32_t *vsrc, uint32_t *vdst, uint64_t n,
+               const uint32_t *n_dev, int shift, int nb, uint32_t n_tiles, uint32_t *hist, uint32_t *total)
 {
     const uint32_t dmask = (1u << nb) - 1u;
-    radix_hist_kernel<RB><<<n_tiles, RS_THREADS, 0, ctx->stream>>>(src, n, shift, dmask, n_tiles, hist);
+    radix_hist_kernel<RB><<<n_tiles, RS_THREADS, 0, ctx->stream>>>(src, n, n_dev, shift, dmask, n_tiles, hist);
     PSK_HIP(ctx, hipGetLastError());
     radix_digit_scan_kernel<<<1 << RB, RS_THREADS, 0, ctx->stream>>>(hist, n_tiles, total);
     PSK_HIP(ctx, hipGetLastError());
     if (vsrc)
-        radix_scatter_kernel<RB, true><<<n_tiles, RS_THREADS, 0, ctx->stream>>>(src, dst, n, shift, dmask, n_tiles, hist, total,
+        radix_scatter_kernel<RB, true><<<n_tiles, RS_THREADS, 0, ctx->stream>>>(src, dst, n, n_dev, shift, dmask, n_tiles, hist, total,
                                                                               vsrc, vdst);
     else
-        radix_scatter_kernel<RB, false><<<n_tiles, RS_THREADS, 0, ctx->stream>>>(src, dst, n, shift, dmask, n_tiles, hist,
+        radix_scatter_kernel<RB, false><<<n_tiles, RS_THREADS, 0, ctx->stream>>>(src, dst, n, n_dev, shift, dmask, n_tiles, hist,
                                                                                total, nullptr, nullptr);
     PSK_HIP(ctx, hipGetLastError());
     return PSK_OK;
@@ -200,13 +205,14 @@ int radix_pass(psk_ctx *ctx, const uint64_t *src, uint64_t *dst, const uint32_t 
 }  // namespace
 
 int dev_radix_sort_u64(psk_ctx *ctx, uint64_t *a, uint64_t *b, uint64_t n, int bit_lo, int bit_hi,
-                       uint64_t **sorted_out)
+                       uint64_t **sorted_out, const uint32_t *n_dev)
 {
-    return dev_radix_sort_kv(ctx, a, b, nullptr, nullptr, n, bit_lo, bit_hi, sorted_out, nullptr);
+    return dev_radix_sort_kv(ctx, a, b, nullptr, nullptr, n, bit_lo, bit_hi, sorted_out, nullptr, n_dev);
 }
 
+// n_dev != nullptr: the actual key count sits in device memory (<= n, which then only sizes the launches)
 int dev_radix_sort_kv(psk_ctx *ctx, uint64_t *a, uint64_t *b, uint32_t *va, uint32_t *vb, uint64_t n, int bit_lo,
-                      int bit_hi, uint64_t **sorted_out, uint32_t **sorted_vals_out)
+                      int bit_hi, uint64_t **sorted_out, uint32_t **sorted_vals_out, const uint32_t *n_dev)
 {
     *sorted_out = a;
     if (sorted_vals_out) *sorted_vals_out = va;
@@ -226,8 +232,8 @@ int dev_radix_sort_kv(psk_ctx *ctx, uint64_t *a, uint64_t *b, uint32_t *va, uint
     int shift = bit_lo;
     for (int ps = 0; ps < n_pass; ps++) {
         const int nb = base + (ps < rem ? 1 : 0);
-        if (nb > 8) PSK_TRY(radix_pass<9>(ctx, src, dst, vsrc, vdst, n, shift, nb, n_tiles, hist, total));
-        else PSK_TRY(radix_pass<8>(ctx, src, dst, vsrc, vdst, n, shift, nb, n_tiles, hist, total));
+        if (nb > 8) PSK_TRY(radix_pass<9>(ctx, src, dst, vsrc, vdst, n, n_dev, shift, nb, n_tiles, hist, total));
+        else PSK_TRY(radix_pass<8>(ctx, src, dst, vsrc, vdst, n, n_dev, shift, nb, n_tiles, hist, total));
         shift += nb;
         uint64_t *t = src; src = dst; dst = t;
         uint32_t *vt = vsrc; vsrc = vdst; vdst = vt;

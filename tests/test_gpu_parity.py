@@ -548,6 +548,36 @@ def test_batch_counting_equals_single_calls(ctx, oracle):
         ctx.count_kmers_batch(40, datas[:10], 2)   # runs past the declared sample count
 
 
+def test_batch_counting_with_slab_filter(ctx, oracle):
+    """The multi-GPU ingest path: psk_count_kmers_batch under a slab filter (the kept-word count only exists
+    on the device; launches are sized by the host's window count).  Slabs concatenate to the full lists,
+    including samples that keep nothing, an empty sample and a FASTQ one."""
+    from phenotypeseeker_amd.dist import slab_bounds
+    from phenotypeseeker_amd.synth import GenomeSet, fastq_reads
+    k = 13
+    gs = GenomeSet(5, 60_000, seed=17)
+    datas = [gs.sample(i)[1] for i in range(5)] + [b"", b">x\nACGTACGTACGTACGTACGTAAAAAAAAAAAAAAAAAAAAAAAAAAAAAA\n",
+                                                   fastq_reads(gs.codes(0), 300, 150, seed=[5, 1])]
+    ref = [oracle.count_kmers(d, k)[:2] for d in datas]
+    world = 4
+    got_w = [[] for _ in datas]
+    got_f = [[] for _ in datas]
+    for rank in range(world):
+        lo, hi = slab_bounds(k, world, rank)
+        ctx.begin(k, len(datas), lo, hi)
+        nu, nt = ctx.count_kmers_batch(0, datas, 3)
+        for i in range(len(datas)):
+            w, f = ctx.get_list(i, nu[i])
+            assert int(f.sum()) == nt[i]
+            if len(w):
+                assert w.min() >= lo and (hi == 0 or w.max() < hi)
+            got_w[i].append(w)
+            got_f[i].append(f)
+    for i, (rw, rf) in enumerate(ref):
+        assert np.array_equal(np.concatenate(got_w[i]), rw), i
+        assert np.array_equal(np.concatenate(got_f[i]), rf), i
+
+
 def test_fastq_reads_and_gzip_input(ctx, oracle, tmp_path):
     """cfg-5 shape at test size: raw reads as FASTQ (constant quality line 'I...'), gzip-compressed on
     disk; the file reader inflates on the host, the list must equal the oracle's on the inflated bytes."""
