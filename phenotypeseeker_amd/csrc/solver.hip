@@ -245,12 +245,18 @@ __global__ __launch_bounds__(SV_THREADS) void logreg_newglmnet_kernel(
 // inside the loops, only the LDS-resident per-sample arrays.  (The float form pays an L2 round trip per
 // 64 samples, ~7 us per coordinate at n = 2048 on a lone wave; this form ~0.3 us.)
 #define FLD(ptr) (f_lds ? *(ptr) : lane0_load((ptr), lane))
+// ALL_LDS: every array of the fit lives in LDS (the usual case: a few hundred samples, <= ~1500 distinct
+// columns).  The placement is then a compile-time fact, the pointers are LDS pointers and the loops use
+// ds_read / ds_write; with run-time placement flags they are generic pointers and every access is a flat load.
+template <bool ALL_LDS>
 __global__ __launch_bounds__(SV_THREADS) void logreg_newglmnet_bits_kernel(
     const uint64_t *__restrict__ colbits, const int8_t *__restrict__ ypm, const int32_t *__restrict__ fold, int n, int p,
     int W, const double *__restrict__ fit_param, const int32_t *__restrict__ fit_fold, double tol, int max_newton,
     double *__restrict__ coef, double *__restrict__ icpt, int32_t *__restrict__ iters, double *__restrict__ work,
-    int32_t *__restrict__ iwork, const int f_lds, const int s_lds, const int c_lds, const int q_lds)
+    int32_t *__restrict__ iwork, const int f_lds_rt, const int s_lds_rt, const int c_lds_rt, const int q_lds_rt)
 {
+    const int f_lds = ALL_LDS ? 1 : f_lds_rt, s_lds = ALL_LDS ? 1 : s_lds_rt, c_lds = ALL_LDS ? 1 : c_lds_rt,
+              q_lds = ALL_LDS ? 1 : q_lds_rt;
     extern __shared__ double sm_all[];
     double *Qm = sm_all;  // 64 x 64 Gram block of the small-active-set QP (q_lds)
     double *sm = sm_all + (q_lds ? 64 * 64 : 0);
@@ -709,10 +715,12 @@ extern "C" int psk_logreg_l1_fit(psk_ctx *ctx, const float *X, const int32_t *y0
         }
         SV_ALLOC(b.bits, bits.size() * 8);
         PSK_HIP(ctx, hipMemcpyAsync(b.bits, bits.data(), bits.size() * 8, hipMemcpyHostToDevice, ctx->stream));
+        const bool all_lds = f_lds && s_lds && c_lds && q_lds;
+        auto kern = all_lds ? logreg_newglmnet_bits_kernel<true> : logreg_newglmnet_bits_kernel<false>;
         if (lds_b > 64 * 1024)
-            PSK_HIP(ctx, hipFuncSetAttribute(reinterpret_cast<const void *>(logreg_newglmnet_bits_kernel),
-                                             hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_b));
-        logreg_newglmnet_bits_kernel<<<n_fits, SV_THREADS, lds_b, ctx->stream>>>(
+            PSK_HIP(ctx, hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                             (int)lds_b));
+        kern<<<n_fits, SV_THREADS, lds_b, ctx->stream>>>(
             (const uint64_t *)b.bits, (const int8_t *)b.y, (const int32_t *)b.fold, n, p, W, (const double *)b.param,
             (const int32_t *)b.ffold, tol, max_iter, (double *)b.coef, (double *)b.icpt, (int32_t *)b.iters,
             (double *)b.work, (int32_t *)b.iwork, f_lds, s_lds, c_lds, q_lds);
