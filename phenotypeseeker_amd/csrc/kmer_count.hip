@@ -700,12 +700,14 @@ extern "C" int psk_count_kmers_batch(psk_ctx *ctx, int first_sample_idx, int n, 
     // every sample takes the pipelined path (see chain_enqueue); with a slab filter the host's window count is
     // an upper bound and the kernels read the number of kept words from device memory
     const bool pipelined = true;
-    const int R = n_threads + 2;  // ring slots (the pipelined path releases a slot one sample late)
     size_t max_len = 0;
     for (int i = 0; i < n; i++) {
         if (!bytes[i] && lens[i]) return psk_fail(ctx, PSK_EINVAL, "null input %d", i);
         if (lens[i] > max_len) max_len = lens[i];
     }
+    // pinned ring: at most ~4 GiB of it (read-scale FASTQ samples are hundreds of MB each)
+    while (n_threads > 1 && (size_t)(n_threads + 2) * max_len > (4ull << 30)) n_threads--;
+    const int R = n_threads + 2;  // ring slots (the pipelined path releases a slot one sample late)
     if ((int)ctx->ring.size() < R) { ctx->ring.resize(R, nullptr); ctx->ring_cap.resize(R, 0); }
     for (int s = 0; s < R; s++) PSK_TRY(ensure_pinned(ctx, &ctx->ring[s], &ctx->ring_cap[s], max_len + 2 * EX_SEG));
 
