@@ -51,6 +51,45 @@ def measured_traffic(rows, wpr):
     return best
 
 
+def e2e_modeling(gs, n, k):
+    """BASELINE.json's second figure: wall-clock of `phenotypeseeker modeling data.pheno` from FASTA files on
+    disk to the written .pkl, on the same synthetic genomes, through the CLI entry point in this process
+    (its own context on the same GPU).  Reported beside `value`, never part of it."""
+    import shutil
+    import tempfile
+    from phenotypeseeker_amd.cli import build_parser
+    tmp = tempfile.mkdtemp(prefix="psk_bench_e2e_")
+    cwd = os.getcwd()
+    try:
+        rows = ["ID\tAddresses\tPheno"]
+        t0 = time.time()
+        for i in range(n):
+            name, fa = gs.sample(i)
+            with open(os.path.join(tmp, name + ".fasta"), "wb") as f:
+                f.write(fa)
+            rows.append("%s\t%s.fasta\t%d" % (name, name, gs.phenotype(i)))
+        with open(os.path.join(tmp, "data.pheno"), "w") as f:
+            f.write("\n".join(rows) + "\n")
+        t_write = time.time() - t0
+        os.chdir(tmp)
+        args = build_parser().parse_args(["modeling", "data.pheno", "-l", str(k)])
+        err = sys.stderr
+        sys.stderr = open(os.devnull, "w")
+        try:
+            t0 = time.time()
+            args.func(args)
+            wall = time.time() - t0
+        finally:
+            sys.stderr.close()
+            sys.stderr = err
+        made = sorted(f for f in os.listdir(".") if f.endswith(".pkl"))
+        return {"modeling_wall_s": round(wall, 3), "what": "phenotypeseeker modeling data.pheno: %d FASTA files on disk -> %s"
+                % (n, ", ".join(made) or "no model"), "write_dataset_s": round(t_write, 2)}
+    finally:
+        os.chdir(cwd)
+        shutil.rmtree(tmp, ignore_errors=True)
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -65,6 +104,8 @@ def main():
     ap.add_argument("--rows", type=int, default=1 << 25)
     ap.add_argument("--cpu-sample-rows", type=int, default=40_000_000)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-e2e", action="store_true",
+                    help="skip the end-to-end `phenotypeseeker modeling` wall-clock (FASTA files -> .pkl) on the same data")
     ap.add_argument("--backend", default=None, choices=[None, "nccl", "gloo"],
                     help="torch.distributed backend for N > 1 (default: nccl = RCCL when GPUs are visible). "
                          "gloo + --share-gpu lets two ranks exercise the N > 1 path on a one-GPU box.")
@@ -97,11 +138,11 @@ def main():
         ctx.begin(k, n)
         t_gen = t_cnt = 0.0
         tot_unique = 0
-        for lo in range(0, n, 16):
+        for lo in range(0, n, 64):
             t0 = time.time()
-            fas = [gs.sample(i)[1] for i in range(lo, min(lo + 16, n))]
+            fas = [gs.sample(i)[1] for i in range(lo, min(lo + 64, n))]
             t1 = time.time()
-            nus, _ = ctx.count_kmers_batch(lo, fas, 4)
+            nus, _ = ctx.count_kmers_batch(lo, fas, 8)
             t2 = time.time()
             t_gen += t1 - t0
             t_cnt += t2 - t1
@@ -213,6 +254,8 @@ def main():
                                          "oracle/psk_oracle.c orc_chi2_scan, %.1f s" % (reps, ns, n, dt),
                                "matches_gpu": same,
                                "reference_python_8proc_cells_per_s": 7.4e6}
+    if rank == 0 and world == 1 and args.workload == "fasta" and not args.no_e2e:
+        out["e2e"] = e2e_modeling(gs, n, k)
     if rank == 0:
         print(json.dumps(out))
     ctx.close()

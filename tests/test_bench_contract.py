@@ -31,3 +31,5 @@ def test_bench_json_contract():
     cb = d["cpu_baseline"]
     assert cb["kind"] == "port" and cb["cores"] == 1 and cb["value"] > 0 and cb["matches_gpu"] is True
     assert d["value"] > cb["value"]
+    e2e = d["e2e"]  # BASELINE.json's second figure rides along, outside `value`
+    assert e2e["modeling_wall_s"] > 0 and "log_reg_model_Pheno.pkl" in e2e["what"]

@@ -38,6 +38,25 @@ def test_tokenizer_cases_bit_exact(ctx, oracle):
             assert oracle.list_bytes(k, w, f) == ref, (data[:60], k)
 
 
+def test_tokenizer_cases_through_the_batch_path(ctx, oracle):
+    """The same crafted / fuzzed inputs through psk_count_kmers_batch: the pipelined path sizes its launches by
+    the window count the host framing produced and fails loudly if the GPU counts differently, so every case
+    also checks that the two tokeniser halves agree."""
+    by_k = {}
+    for data, k, ref in tokenizer_cases():
+        by_k.setdefault(k, []).append((data, ref))
+    for k, cases in sorted(by_k.items()):
+        ctx.begin(k, len(cases))
+        nu, nt = ctx.count_kmers_batch(0, [c[0] for c in cases], 3)
+        for i, (data, ref) in enumerate(cases):
+            w, f = ctx.get_list(i, nu[i])
+            if ref is None:
+                assert nu[i] == 0
+            else:
+                assert oracle.list_bytes(k, w, f) == ref, (data[:60], k)
+            assert int(f.astype(np.uint64).sum()) == nt[i]
+
+
 @pytest.mark.parametrize("k", [5, 13, 16, 21, 31, 32])
 def test_megabase_genome_list_bit_exact(ctx, oracle, k):
     from phenotypeseeker_amd.synth import GenomeSet
