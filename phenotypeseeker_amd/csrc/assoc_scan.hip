@@ -41,6 +41,7 @@ constexpr int SC_UNROLL = PSK_SC_UNROLL;
 // matrix with 1 % survivors ran 15x slower than the stream rate).
 constexpr int SC_NSEG = 256;
 constexpr int SC_CNT_STRIDE = 32;  // u32 per counter slot
+constexpr int SC_INL_WORDS = 16;   // mask words carried inside ScanArgs
 typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
 
 struct ScanArgs {
@@ -64,8 +65,15 @@ struct ScanArgs {
     uint64_t *res_row;
     double *res_stat, *res_p, *res_mx, *res_my;
     int32_t *res_nw;
-    uint32_t *counter;   // SC_NSEG slots, SC_CNT_STRIDE u32 apart
+    uint32_t *counter;   // SC_NSEG slots, SC_CNT_STRIDE u32 apart: [0] appended entries, [1] finished workgroups
     uint32_t seg_cap;    // entries per segment
+    // end of a scan: the last workgroup of a segment (chi2) / the segment's finalize workgroup (Welch) publishes
+    // the segment's count to final_counts (device, compact) and host_counts (pinned host memory, written
+    // straight from the kernel) and zeroes the counter for the next scan -- no memset, no read-back copy
+    uint32_t *final_counts, *host_counts;
+    // phenotype masks of up to 1024 samples travel in the kernel arguments (no upload per scan)
+    int inline_masks;
+    uint64_t m1_inl[SC_INL_WORDS], m0_inl[SC_INL_WORDS];
 };
 
 __device__ __forceinline__ uint64_t reserve_slot(const ScanArgs &P)
@@ -73,6 +81,26 @@ __device__ __forceinline__ uint64_t reserve_slot(const ScanArgs &P)
     const uint32_t seg = blockIdx.x & (SC_NSEG - 1);
     const uint32_t idx = atomicAdd(&P.counter[seg * SC_CNT_STRIDE], 1u);
     return (uint64_t)seg * P.seg_cap + (idx < P.seg_cap ? idx : P.seg_cap - 1);
+}
+
+// Called by every thread at the very end of a chi2 scan workgroup: the LAST workgroup of a segment to get here
+// publishes the segment's count and re-arms the counter (ticket = second word of the counter's 128-byte line).
+__device__ __forceinline__ void publish_segment(const ScanArgs &P)
+{
+    // No fence: the count lives in device-scope atomics only, and every append of this workgroup has returned
+    // its slot index (it was needed for the stores) before the barrier.  A __threadfence() here is an L2
+    // write-back + invalidate per workgroup on this multi-XCD part and tripled the kernel time (r01).
+    __syncthreads();
+    if (threadIdx.x != 0) return;
+    const uint32_t seg = blockIdx.x & (SC_NSEG - 1);
+    const uint32_t n_blocks = (gridDim.x - seg + SC_NSEG - 1) / SC_NSEG;  // workgroups that map to this segment
+    uint32_t *slot = &P.counter[seg * SC_CNT_STRIDE];
+    if (atomicAdd(slot + 1, 1u) == n_blocks - 1) {
+        const uint32_t c = atomicExch(slot, 0u);
+        slot[1] = 0;
+        P.final_counts[seg] = c;
+        P.host_counts[seg] = c;
+    }
 }
 
 // modeling.py:773-794 in the reference's operation order.
@@ -179,7 +207,10 @@ __global__ __launch_bounds__(SC_THREADS) void chi2_scan_kernel(const ScanArgs P)
     const uint64_t total_waves = (uint64_t)gridDim.x * (SC_THREADS / 64);
     const bool has_chunk = g < P.cpr;
     uint64_t m1a = 0, m1b = 0, m0a = 0, m0b = 0;
-    if (has_chunk) { m1a = P.m1[2 * g]; m1b = P.m1[2 * g + 1]; m0a = P.m0[2 * g]; m0b = P.m0[2 * g + 1]; }
+    if (has_chunk) {
+        if (P.inline_masks) { m1a = P.m1_inl[2 * g]; m1b = P.m1_inl[2 * g + 1]; m0a = P.m0_inl[2 * g]; m0b = P.m0_inl[2 * g + 1]; }
+        else { m1a = P.m1[2 * g]; m1b = P.m1[2 * g + 1]; m0a = P.m0[2 * g]; m0b = P.m0[2 * g + 1]; }
+    }
     uint64_t *q_row = s_qrow[WEIGHTED ? (threadIdx.x >> 6) : 0];
     int2 *q_val = s_qval[WEIGHTED ? (threadIdx.x >> 6) : 0];
     int q = 0;
@@ -281,6 +312,7 @@ __global__ __launch_bounds__(SC_THREADS) void chi2_scan_kernel(const ScanArgs P)
             }
         }
     }
+    publish_segment(P);
 }
 
 // ---- Student-t two-sided p-value: I_{df/(df+t^2)}(df/2, 1/2), Lentz continued fraction ---------
@@ -469,7 +501,11 @@ __global__ __launch_bounds__(256) void ttest_finalize_kernel(const ScanArgs P)
         if (threadIdx.x == 0) s_out = out + tot;
         __syncthreads();
     }
-    if (threadIdx.x == 0) P.counter[seg * SC_CNT_STRIDE] = s_out;
+    if (threadIdx.x == 0) {
+        P.counter[seg * SC_CNT_STRIDE] = 0;  // re-armed for the next scan
+        P.final_counts[seg] = s_out;
+        P.host_counts[seg] = s_out;
+    }
 }
 
 template <bool WT>
@@ -521,31 +557,30 @@ int setup_results(psk_ctx *ctx, ScanArgs &a, dim3 grid, int G, int unroll)
     a.res_mx = reinterpret_cast<double *>(b + cap * 24);
     a.res_my = reinterpret_cast<double *>(b + cap * 32);
     a.res_nw = reinterpret_cast<int32_t *>(b + cap * 40);
-    PSK_TRY(dev_reserve(ctx, ctx->res_count, SC_NSEG * SC_CNT_STRIDE * 4));
+    if (!ctx->res_count.p) {  // counters re-arm themselves at the end of every scan: zeroed once
+        PSK_TRY(dev_reserve(ctx, ctx->res_count, (SC_NSEG * SC_CNT_STRIDE + SC_NSEG) * 4));
+        PSK_HIP(ctx, hipMemsetAsync(ctx->res_count.p, 0, (SC_NSEG * SC_CNT_STRIDE + SC_NSEG) * 4, ctx->stream));
+    }
+    if (!ctx->cnt_pinned) PSK_HIP(ctx, hipHostMalloc(&ctx->cnt_pinned, SC_NSEG * 4, hipHostMallocDefault));
     a.counter = ctx->res_count.as<uint32_t>();
+    a.final_counts = a.counter + SC_NSEG * SC_CNT_STRIDE;
+    void *hc = nullptr;
+    PSK_HIP(ctx, hipHostGetDevicePointer(&hc, ctx->cnt_pinned, 0));
+    a.host_counts = static_cast<uint32_t *>(hc);
     a.seg_cap = (uint32_t)seg_cap;
     ctx->res_seg_cap = seg_cap;
     return PSK_OK;
 }
 
-// pulls the per-segment counters to the host; n_pass = their sum
-// stream-ordered read-back of the counters into pinned host memory (call before the final sync)
-int enqueue_counts_readback(psk_ctx *ctx, const ScanArgs &a)
-{
-    const size_t bytes = (size_t)SC_NSEG * SC_CNT_STRIDE * 4;
-    if (!ctx->cnt_pinned) PSK_HIP(ctx, hipHostMalloc(&ctx->cnt_pinned, bytes, hipHostMallocDefault));
-    PSK_HIP(ctx, hipMemcpyAsync(ctx->cnt_pinned, a.counter, bytes, hipMemcpyDeviceToHost, ctx->stream));
-    return PSK_OK;
-}
-
-// per-segment counters (already copied to pinned memory and synchronised); n_pass = their sum
+// per-segment counts as the kernels left them in pinned host memory (after the stream has been synchronised);
+// n_pass = their sum
 int fetch_counts(psk_ctx *ctx, const ScanArgs &a)
 {
     const uint32_t *raw = static_cast<const uint32_t *>(ctx->cnt_pinned);
     ctx->seg_counts.assign(SC_NSEG, 0);
     uint64_t tot = 0;
     for (int s = 0; s < SC_NSEG; s++) {
-        uint32_t c = raw[(size_t)s * SC_CNT_STRIDE];
+        const uint32_t c = raw[s];
         if (c > a.seg_cap) return psk_fail(ctx, PSK_ERANGE, "result segment %d overflowed (%u > %u)", s, c, a.seg_cap);
         ctx->seg_counts[s] = c;
         tot += c;
@@ -582,7 +617,7 @@ dim3 scan_grid(const psk_ctx *ctx, uint64_t M, int G, int unroll)
     static const int mult = [] { const char *e = getenv("PSK_GRID_MULT"); const int v = e ? atoi(e) : 0; return v > 0 ? v : PSK_SC_GRID_MULT; }();
     const uint64_t cap = (uint64_t)(ctx->n_cu > 0 ? ctx->n_cu : 256) * mult;
     if (blocks > cap) blocks = cap;
-    if (blocks < 1) blocks = 1;
+    if (blocks < SC_NSEG) blocks = SC_NSEG;  // every result segment needs a workgroup to publish its count
     return dim3((unsigned)blocks);
 }
 
@@ -592,14 +627,12 @@ int run_chi2(psk_ctx *ctx, ScanArgs &a, bool weighted, int reps, double *ms_tota
     const dim3 grid = scan_grid(ctx, a.M, G, SC_UNROLL);
     *ms_total = 0;
     for (int r = 0; r < reps; r++) {
-        PSK_HIP(ctx, hipMemsetAsync(a.counter, 0, SC_NSEG * SC_CNT_STRIDE * 4, ctx->stream));
         PSK_HIP(ctx, hipEventRecord(ctx->ev0, ctx->stream));
         if (weighted) launch_chi2<true>(G, grid, ctx->stream, a);
         else launch_chi2<false>(G, grid, ctx->stream, a);
         PSK_HIP(ctx, hipGetLastError());
         PSK_HIP(ctx, hipEventRecord(ctx->ev1, ctx->stream));
-        if (r == reps - 1) PSK_TRY(enqueue_counts_readback(ctx, a));  // rides on the same synchronisation
-        PSK_HIP(ctx, hipStreamSynchronize(ctx->stream));
+        PSK_HIP(ctx, hipStreamSynchronize(ctx->stream));  // the kernel has written the counts to pinned memory
         float ms = 0;
         PSK_HIP(ctx, hipEventElapsedTime(&ms, ctx->ev0, ctx->ev1));
         *ms_total += ms;
@@ -619,6 +652,8 @@ static int fill_chi2_args(psk_ctx *ctx, ScanArgs &a)
     a.m1 = ctx->mask1.as<uint64_t>();
     a.m0 = a.m1 + ctx->wpr;
     a.tab = reinterpret_cast<const double *>(a.m1 + 2 * (size_t)ctx->wpr);  // [sample][w if pheno 1 | w if pheno 0]
+    a.inline_masks = L.inline_masks;
+    if (L.inline_masks) { memcpy(a.m1_inl, L.m1, sizeof(a.m1_inl)); memcpy(a.m0_inl, L.m0, sizeof(a.m0_inl)); }
     a.min_samples = L.min_samples;
     a.max_samples = L.max_samples;
     a.pcut = L.pvalue_cutoff;
@@ -663,8 +698,17 @@ extern "C" int psk_chi2_scan(psk_ctx *ctx, const int8_t *pheno, const double *we
         if (pheno[i] == 1) { m1[i >> 6] |= 1ull << (i & 63); if (weights) w[2 * (size_t)i] = wi; W1 += wi; n1++; }
         else if (pheno[i] == 0) { m0[i >> 6] |= 1ull << (i & 63); if (weights) w[2 * (size_t)i + 1] = wi; W0 += wi; n0++; }
     }
+    // up to 1024 samples: the masks ride in the kernel arguments and an unweighted scan uploads nothing
+    ctx->last.inline_masks = wpr <= SC_INL_WORDS ? 1 : 0;
+    if (ctx->last.inline_masks) {
+        memset(ctx->last.m1, 0, sizeof(ctx->last.m1));
+        memset(ctx->last.m0, 0, sizeof(ctx->last.m0));
+        memcpy(ctx->last.m1, m1, (size_t)wpr * 8);
+        memcpy(ctx->last.m0, m0, (size_t)wpr * 8);
+    }
     PSK_TRY(dev_reserve(ctx, ctx->mask1, stage_bytes));
-    PSK_HIP(ctx, hipMemcpyAsync(ctx->mask1.p, m1, weights ? stage_bytes : n_mask * 8, hipMemcpyHostToDevice, ctx->stream));
+    if (weights || !ctx->last.inline_masks)
+        PSK_HIP(ctx, hipMemcpyAsync(ctx->mask1.p, m1, weights ? stage_bytes : n_mask * 8, hipMemcpyHostToDevice, ctx->stream));
 
     ctx->last.valid = true;
     ctx->last.weighted = weights != nullptr;
@@ -777,12 +821,10 @@ extern "C" int psk_ttest_scan(psk_ctx *ctx, const double *pheno, const uint8_t *
     ctx->last_scan_kind = 2;
     ctx->last.valid = false;
     if (ctx->n_kmers) {
-        PSK_HIP(ctx, hipMemsetAsync(a.counter, 0, SC_NSEG * SC_CNT_STRIDE * 4, ctx->stream));
         PSK_HIP(ctx, hipEventRecord(ctx->ev0, ctx->stream));
         launch_ttest(G, grid, ctx->stream, a, mu, !unit_w);
         PSK_HIP(ctx, hipGetLastError());
         PSK_HIP(ctx, hipEventRecord(ctx->ev1, ctx->stream));
-        PSK_TRY(enqueue_counts_readback(ctx, a));
         PSK_HIP(ctx, hipStreamSynchronize(ctx->stream));
         float ms = 0;
         PSK_HIP(ctx, hipEventElapsedTime(&ms, ctx->ev0, ctx->ev1));
@@ -867,7 +909,7 @@ __global__ void export_records_kernel(const uint8_t *__restrict__ res, uint64_t 
     __shared__ uint32_t cnt[SC_NSEG];
     __shared__ uint64_t s_off, s_total;
     const uint32_t seg = blockIdx.x;
-    cnt[threadIdx.x] = counters[threadIdx.x * SC_CNT_STRIDE];  // blockDim.x == SC_NSEG
+    cnt[threadIdx.x] = counters[threadIdx.x];  // the compact final counts; blockDim.x == SC_NSEG
     __syncthreads();
     if (threadIdx.x == 0) {
         uint64_t off = 0, tot = 0;
@@ -908,8 +950,9 @@ extern "C" int psk_export_survivors(psk_ctx *ctx, void *device_dst, uint64_t cap
     PSK_HIP(ctx, hipSetDevice(ctx->device));
     if (n_records) *n_records = ctx->n_pass;
     export_records_kernel<<<SC_NSEG, SC_NSEG, 0, ctx->stream>>>(
-        ctx->res.as<uint8_t>(), ctx->res_seg_cap * SC_NSEG, (uint32_t)ctx->res_seg_cap, ctx->res_count.as<uint32_t>(),
-        ctx->union_words.as<uint64_t>(), ctx->bits.as<uint64_t>(), ctx->wpr, static_cast<uint64_t *>(device_dst),
+        ctx->res.as<uint8_t>(), ctx->res_seg_cap * SC_NSEG, (uint32_t)ctx->res_seg_cap,
+        ctx->res_count.as<uint32_t>() + SC_NSEG * SC_CNT_STRIDE, ctx->union_words.as<uint64_t>(), ctx->bits.as<uint64_t>(),
+        ctx->wpr, static_cast<uint64_t *>(device_dst),
         cap_records);
     PSK_HIP(ctx, hipGetLastError());
     PSK_HIP(ctx, hipStreamSynchronize(ctx->stream));

@@ -60,6 +60,8 @@ struct ScanParams {  // what psk_rescan_timed needs to re-launch the last chi2 s
     int omit_B = 0;
     uint64_t n_kmers_global = 0;
     int n1 = 0, n0 = 0;      // class sizes of the last chi2 scan
+    int inline_masks = 0;    // phenotype masks small enough to ride in the kernel arguments
+    uint64_t m1[16] = {0}, m0[16] = {0};
     double W1 = 0, W0 = 0;   // class weight totals
 };
 
