@@ -163,7 +163,10 @@ __global__ __launch_bounds__(SV_THREADS) void logreg_newglmnet_kernel(
                 if (Gp < H * wp) z = -Gp / H;
                 else if (Gn > H * wp) z = -Gn / H;
                 else z = -wp;
-                if (fabs(z) < 1e-12) continue;
+                // liblinear skips |z| < 1e-12; a coefficient that has drifted to ~1e-17 must still be allowed to land
+                // on exactly 0, otherwise its +-1 subgradient term keeps the violation above the stopping threshold
+                // forever (r01: 5 of 143 fits of a 256 x 138 problem spun to max_iter)
+                if (fabs(z) < 1e-12 && !(z == -wp && wp != 0.0)) continue;
                 z = fmin(fmax(z, -10.0), 10.0);
                 if (lane == 0) wpd[j] = wp + z;
                 for (int i = lane; i < n; i += SV_THREADS) {
@@ -227,8 +230,24 @@ __global__ __launch_bounds__(SV_THREADS) void logreg_newglmnet_kernel(
             negsum *= 0.5;
             for (int i = lane; i < n; i += SV_THREADS) xTd[i] *= 0.5;
         }
-        if (!accepted) {  // the step was rejected 20 times: fall back to the current w
+        if (!accepted) {
+            // the step was rejected 20 times: fall back to the current w and, as liblinear does after "too many
+            // line search steps", rebuild exp(w.x) from w -- the multiplicatively updated copy has drifted and
+            // the gradient computed from it would reject every further step (r01: fits spinning to max_iter)
             for (int j = 0; j < P1; j++) { if (lane == 0) wpd[j] = w[j]; }
+            for (int i = lane; i < n; i += SV_THREADS) xTd[i] = 0.0;
+            for (int j = 0; j < P1; j++) {
+                const double wj = FLD(&w[j]);
+                if (wj == 0.0) continue;
+                const float *col = XT + (size_t)j * n;
+                for (int i = lane; i < n; i += SV_THREADS) xTd[i] += wj * (double)col[i];
+            }
+            for (int i = lane; i < n; i += SV_THREADS) {
+                if (fold[i] == tf) continue;
+                const double en = exp(xTd[i]);
+                const double tt = 1.0 / (1.0 + en);
+                ewx[i] = en; tau[i] = C * tt; D[i] = C * en * tt * tt;
+            }
         }
         if (iter == 1) inner_eps *= 0.25;
         Gmax_old = Gmax_new;
@@ -397,7 +416,7 @@ __global__ __launch_bounds__(SV_THREADS) void logreg_newglmnet_bits_kernel(
                     if (Gp < H * wp) z = -Gp * Hi;
                     else if (Gn > H * wp) z = -Gn * Hi;
                     else z = -wp;
-                    if (fabs(z) < 1e-12) continue;
+                    if (fabs(z) < 1e-12 && !(z == -wp && wp != 0.0)) continue;  // see the array form below
                     z = fmin(fmax(z, -10.0), 10.0);
                     if (!((have >> m) & 1)) {
                         have |= 1ull << m;
@@ -475,7 +494,10 @@ __global__ __launch_bounds__(SV_THREADS) void logreg_newglmnet_bits_kernel(
                 if (Gp < H * wp) z = -Gp / H;
                 else if (Gn > H * wp) z = -Gn / H;
                 else z = -wp;
-                if (fabs(z) < 1e-12) continue;
+                // liblinear skips |z| < 1e-12; a coefficient that has drifted to ~1e-17 must still be allowed to land
+                // on exactly 0, otherwise its +-1 subgradient term keeps the violation above the stopping threshold
+                // forever (r01: 5 of 143 fits of a 256 x 138 problem spun to max_iter)
+                if (fabs(z) < 1e-12 && !(z == -wp && wp != 0.0)) continue;
                 z = fmin(fmax(z, -10.0), 10.0);
                 if (lane == 0) wpd[j] = wp + z;
                 for (int t = 0; t < W; t++) {
@@ -544,7 +566,26 @@ __global__ __launch_bounds__(SV_THREADS) void logreg_newglmnet_bits_kernel(
             for (int t = 0; t < W; t++) xTd[t * 64 + lane] *= 0.5;
         }
         if (!accepted) {
+            // rejected 20 times: back to the current w, and exp(w.x) is rebuilt from w (see the float kernel)
             for (int j = 0; j < P1; j++) { if (lane == 0) wpd[j] = w[j]; }
+            for (int t = 0; t < W; t++) xTd[t * 64 + lane] = 0.0;
+            for (int j = 0; j < P1; j++) {
+                const double wj = FLD(&w[j]);
+                if (wj == 0.0) continue;
+                const uint64_t cw = load_col(j);
+                for (int t = 0; t < W; t++) {
+                    const uint64_t xw = psk_readlane_u64(cw, t);
+                    if ((xw >> lane) & 1) xTd[t * 64 + lane] += wj;
+                }
+            }
+            for (int t = 0; t < W; t++) {
+                const uint64_t tw = psk_readlane_u64(trainw, t);
+                if (!((tw >> lane) & 1)) continue;
+                const int i = t * 64 + lane;
+                const double en = exp(xTd[i]);
+                const double tt = 1.0 / (1.0 + en);
+                ewx[i] = en; tau[i] = C * tt; D[i] = C * en * tt * tt;
+            }
         }
         if (iter == 1) inner_eps *= 0.25;
         Gmax_old = Gmax_new;
@@ -703,7 +744,7 @@ extern "C" int psk_logreg_l1_fit(psk_ctx *ctx, const float *X, const int32_t *y0
         size_t left = lds_max;
         s_lds = sbytes <= left ? 1 : 0; left -= s_lds ? sbytes : 0;
         const size_t qbytes = 64 * 64 * 8;
-        const int q_lds = (s_lds && qbytes <= left) ? 1 : 0; left -= q_lds ? qbytes : 0;
+        const int q_lds = (s_lds && qbytes <= left && !getenv("PSK_NO_GRAM")) ? 1 : 0; left -= q_lds ? qbytes : 0;
         f_lds = fa <= left ? 1 : 0; left -= f_lds ? fa : 0;
         const int c_lds = cbytes <= left ? 1 : 0;
         const size_t lds_b = (s_lds ? sbytes : 0) + (q_lds ? qbytes : 0) + (f_lds ? fa : 0) + (c_lds ? cbytes : 0);

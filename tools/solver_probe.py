@@ -24,7 +24,7 @@ if sys.argv[1] == "dump":
                  iters=r[2], secs=time.time() - t)
         return r
     engine.PskContext._fit = spy
-    sys.argv = [sys.argv[0], sys.argv[2], sys.argv[3]]
+    sys.argv = [sys.argv[0], sys.argv[2], sys.argv[3]] + sys.argv[5:]
     exec(open(os.path.join(ROOT, "tools", "e2e_wallclock.py")).read())
 else:
     from phenotypeseeker_amd.engine import PskContext
