@@ -348,6 +348,30 @@ def test_l1_logreg_solver_reaches_liblinear_optimum(ctx):
                     assert a[k] == pytest.approx(b[k], rel=1e-3, abs=2e-4)
 
 
+def test_l1_logreg_converges_on_near_duplicate_columns(ctx):
+    """The (grid x fold) problem of a weighted 256-sample run: 138 distinct columns that differ from the gene
+    pattern in a few samples.  Every fit must stop by liblinear's rule well before max_iter (a coefficient
+    stuck at ~1e-17 once kept five of them spinning), and at the stop the rule must hold for the true
+    gradient."""
+    d = np.load(os.path.join(GOLDEN, "fit_near_duplicates.npz"))
+    X, y, fold, fp, ff = d["X"], d["y"], d["fold"], d["fit_param"], d["fit_fold"]
+    coef, icpt, iters = ctx.logreg_l1_fit(X, y, fold, fp, ff, tol=1e-4, max_iter=1000)
+    assert iters.max() < 100, iters.tolist()
+    ypm = 2.0 * y - 1.0
+    for j in range(0, len(fp), 7):
+        tr = fold != ff[j]
+        A = np.hstack([X[tr], np.ones((tr.sum(), 1))])
+        yt = ypm[tr]
+
+        def viol(th):
+            g = -fp[j] * (A.T @ (yt / (1.0 + np.exp(yt * (A @ th)))))
+            return np.where(th > 0, np.abs(g + 1), np.where(th < 0, np.abs(g - 1),
+                                                             np.maximum(0, np.maximum(-(g + 1), g - 1)))).sum()
+        th = np.append(coef[j], icpt[j])
+        eps = 1e-4 * max(min((yt > 0).sum(), (yt < 0).sum()), 1) / tr.sum()
+        assert viol(th) <= 1.5 * eps * viol(np.zeros_like(th)) + 1e-9, (j, fp[j], iters[j])
+
+
 def test_lasso_solver_matches_sklearn(ctx):
     z = np.load(os.path.join(GOLDEN, "model_kat.npz"))
     X, y = z["X2"], z["yc2"]
