@@ -190,6 +190,15 @@ int psk_count_dict(psk_ctx *ctx, const uint8_t *bytes, size_t len, int k, const 
 int psk_minhash_sketch(psk_ctx *ctx, const uint8_t *bytes, size_t len, int k, int sketch_size, uint32_t seed,
                        uint64_t *hashes_out, uint64_t *n_out);
 
+/* Pairwise comparison of n bottom-s sketches (was `mash dist reference.msh reference.msh`,
+ * Samples.get_mash_distances, modeling.py:411-421): for every pair the number of shared hashes and the
+ * denominator of Mash's Jaccard estimate (the merge stops after sketch_size distinct union hashes).
+ *   sketches[n][sketch_size]  ascending distinct hashes, rows padded; lens[n] = valid entries per row
+ *   common_out[n][n], denom_out[n][n]  symmetric; the host turns them into Mash distances
+ */
+int psk_mash_pairs(psk_ctx *ctx, const uint64_t *sketches, const uint32_t *lens, int n, int sketch_size,
+                   uint32_t *common_out, uint32_t *denom_out);
+
 /* ---- helpers shared with the host side ------------------------------------------------------ */
 /* Host-only: the cleaned sequence stream the tokeniser hands to the GPU (bases kept, window
  * breaks collapsed to '\n', everything else dropped).  Returns the length written (<= len), or

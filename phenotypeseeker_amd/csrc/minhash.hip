@@ -135,3 +135,68 @@ extern "C" int psk_minhash_sketch(psk_ctx *ctx, const uint8_t *bytes, size_t len
     *n_out = take;
     return PSK_OK;
 }
+
+// ---- pairwise sketch comparison (was `mash dist reference.msh reference.msh`, modeling.py:411-421) ----------
+// One thread per pair (r >= c): the merge of Mash's distance estimate -- walk both ascending sketches until
+// `s` distinct hashes of the union have been seen, count the shared ones; when a sketch runs out first the
+// denominator grows by what is left of the other, capped at s.  N = 1024 samples are 524,800 pairs of <= 2000
+// steps over 8 MB of sketches (L2-resident): milliseconds, against minutes for the same loops on the host.
+namespace {
+__global__ void mash_pairs_kernel(const uint64_t *__restrict__ sk, const uint32_t *__restrict__ lens, int n, int s,
+                                  uint32_t *__restrict__ common_out, uint32_t *__restrict__ denom_out)
+{
+    const uint64_t t = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const uint64_t n_pairs = (uint64_t)n * (n + 1) / 2;
+    if (t >= n_pairs) return;
+    // t -> (r, c) with c <= r, rows of the lower triangle in order
+    uint32_t r = (uint32_t)((sqrt(8.0 * (double)t + 1.0) - 1.0) * 0.5);
+    while ((uint64_t)r * (r + 1) / 2 > t) r--;
+    while ((uint64_t)(r + 1) * (r + 2) / 2 <= t) r++;
+    const uint32_t c = (uint32_t)(t - (uint64_t)r * (r + 1) / 2);
+    const uint64_t *a = sk + (uint64_t)r * s, *b = sk + (uint64_t)c * s;
+    const uint32_t na = lens[r], nb = lens[c];
+    uint32_t i = 0, j = 0, common = 0, denom = 0;
+    while (denom < (uint32_t)s && i < na && j < nb) {
+        const uint64_t x = a[i], y = b[j];
+        if (x < y) i++;
+        else if (x > y) j++;
+        else { i++; j++; common++; }
+        denom++;
+    }
+    if (denom < (uint32_t)s) {
+        if (i < na) denom += na - i;
+        if (j < nb) denom += nb - j;
+        if (denom > (uint32_t)s) denom = (uint32_t)s;
+    }
+    common_out[(uint64_t)r * n + c] = common;
+    denom_out[(uint64_t)r * n + c] = denom;
+    common_out[(uint64_t)c * n + r] = common;
+    denom_out[(uint64_t)c * n + r] = denom;
+}
+}  // namespace
+
+extern "C" int psk_mash_pairs(psk_ctx *ctx, const uint64_t *sketches, const uint32_t *lens, int n, int sketch_size,
+                              uint32_t *common_out, uint32_t *denom_out)
+{
+    if (!ctx) return PSK_EINVAL;
+    if (!sketches || !lens || !common_out || !denom_out) return psk_fail(ctx, PSK_EINVAL, "null buffer");
+    if (n < 1 || sketch_size < 1) return psk_fail(ctx, PSK_EINVAL, "bad shape n=%d s=%d", n, sketch_size);
+    for (int i = 0; i < n; i++)
+        if (lens[i] > (uint32_t)sketch_size) return psk_fail(ctx, PSK_EINVAL, "sketch %d longer than sketch_size", i);
+    PSK_HIP(ctx, hipSetDevice(ctx->device));
+    const size_t sk_bytes = (size_t)n * sketch_size * 8, nn = (size_t)n * n;
+    PSK_TRY(dev_reserve(ctx, ctx->keysA, sk_bytes + (size_t)n * 4));
+    PSK_TRY(dev_reserve(ctx, ctx->keysB, nn * 8));
+    uint64_t *d_sk = ctx->keysA.as<uint64_t>();
+    uint32_t *d_len = reinterpret_cast<uint32_t *>(ctx->keysA.as<uint8_t>() + sk_bytes);
+    uint32_t *d_common = ctx->keysB.as<uint32_t>(), *d_denom = d_common + nn;
+    PSK_HIP(ctx, hipMemcpyAsync(d_sk, sketches, sk_bytes, hipMemcpyHostToDevice, ctx->stream));
+    PSK_HIP(ctx, hipMemcpyAsync(d_len, lens, (size_t)n * 4, hipMemcpyHostToDevice, ctx->stream));
+    const uint64_t n_pairs = (uint64_t)n * (n + 1) / 2;
+    mash_pairs_kernel<<<div_up(n_pairs, 256), 256, 0, ctx->stream>>>(d_sk, d_len, n, sketch_size, d_common, d_denom);
+    PSK_HIP(ctx, hipGetLastError());
+    PSK_HIP(ctx, hipMemcpyAsync(common_out, d_common, nn * 4, hipMemcpyDeviceToHost, ctx->stream));
+    PSK_HIP(ctx, hipMemcpyAsync(denom_out, d_denom, nn * 4, hipMemcpyDeviceToHost, ctx->stream));
+    PSK_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    return PSK_OK;
+}

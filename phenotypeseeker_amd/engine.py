@@ -243,6 +243,21 @@ class PskContext:
                                                  _ptr(out), ctypes.byref(n)), "psk_minhash_sketch")
         return out[: n.value].copy()
 
+    def mash_pairs(self, sketches, sketch_size=1000):
+        """sketches: list of ascending hash lists.  Returns (common[n][n], denom[n][n]) of Mash's Jaccard estimate."""
+        n = len(sketches)
+        sk = np.zeros((n, int(sketch_size)), dtype=np.uint64)
+        lens = np.zeros(n, dtype=np.uint32)
+        for i, h in enumerate(sketches):
+            h = np.asarray(h, dtype=np.uint64)[: int(sketch_size)]
+            sk[i, : len(h)] = h
+            lens[i] = len(h)
+        common = np.zeros((n, n), dtype=np.uint32)
+        denom = np.zeros((n, n), dtype=np.uint32)
+        self._check(self._lib.psk_mash_pairs(self._h, _ptr(sk), _ptr(lens), n, int(sketch_size), _ptr(common), _ptr(denom)),
+                    "psk_mash_pairs")
+        return common, denom
+
     # -- prediction -------------------------------------------------------------------------------
     def count_dict(self, data, k, dict_words):
         data = bytes(data)

@@ -121,11 +121,12 @@ class Samples:
                     stderr_print.print_progress("lists generated.")
 
     @classmethod
-    def get_weights(cls):
-        """was: mash paste / mash dist -> NJ tree -> GSC weights (:392-503)"""
+    def get_weights(cls, ctx):
+        """was: mash paste / mash dist -> NJ tree -> GSC weights (:392-503); the pairwise sketch comparison runs
+        on the GPU (psk_mash_pairs)"""
         from . import weights as _w
         names = list(Input.samples.keys())
-        w, cls.tree = _w.weights_from_sketches(names, {n: Input.samples[n].sketch for n in names})
+        w, cls.tree = _w.weights_from_sketches(names, {n: Input.samples[n].sketch for n in names}, ctx=ctx)
         for name, value in w.items():
             Input.samples[name].weight = value
 
@@ -697,7 +698,7 @@ def modeling(args):
             if Samples.use_weights:
                 _err("\n" + GREEN % "Estimating the Mash distances between samples..." + "\n")
                 stderr_print(GREEN % "Calculating the GSC weights from mash distance matrix...")
-                Samples.get_weights()
+                Samples.get_weights(ctx)
             phenotypes.kmer_testing_setup(group.allreduce_sum(int(m_local)))
             for ph in Input.phenotypes_to_analyse.values():
                 ph.test_kmers_association_with_phenotype(ctx, group)

@@ -51,13 +51,32 @@ def mash_distance(a, b, k, sketch_size):
     return float("%g" % d), common, denom  # `mash dist` prints 6 significant digits
 
 
-def distance_matrix(names, sketches, k=21, sketch_size=1000):
+def distances_from_counts(common, denom, k):
+    """(shared, denominator) of every pair -> Mash distances as `mash dist` prints them (6 significant digits)."""
+    import numpy as np
+    common = np.asarray(common, dtype=np.float64)
+    denom = np.asarray(denom, dtype=np.float64)
+    with np.errstate(divide="ignore", invalid="ignore"):
+        jac = common / denom
+        d = -np.log(2.0 * jac / (1.0 + jac)) / k
+    d = np.where(common == denom, 0.0, np.where(common == 0, 1.0, d))
+    d = np.where(denom == 0, 1.0, d)
+    flat = d.ravel()
+    return np.array([float("%g" % v) for v in flat], dtype=np.float64).reshape(d.shape)
+
+
+def distance_matrix(names, sketches, k=21, sketch_size=1000, ctx=None):
     """names: sample names in data.pheno order; sketches: dict name -> hashes.
     `mash paste reference.msh K-mer_lists/*.msh` orders the sketches by FILE NAME (shell glob), while
     the reference labels the rows of the resulting table in data.pheno order (:415-428): when the
-    pheno file is not sorted by sample name the labels are permuted.  Reproduced here."""
+    pheno file is not sorted by sample name the labels are permuted.  Reproduced here.
+    With an engine context the N(N+1)/2 sketch merges run on the GPU (psk_mash_pairs) -- what modeling.py
+    does; the host loop below serves the CPU-only tests."""
     by_file = sorted(names)
     n = len(names)
+    if ctx is not None:
+        common, denom = ctx.mash_pairs([sketches[nm] for nm in by_file], sketch_size)
+        return list(names), distances_from_counts(common, denom, k).tolist()
     mat = [[0.0] * n for _ in range(n)]
     for r in range(n):
         for c in range(r + 1):
@@ -91,34 +110,41 @@ def nj(names, mat):
         root.add(clades[1])
         root.add(clades[0])
         return root
+    import numpy as np
+    dm = np.array(dm, dtype=np.float64)
+    lower = np.tril(np.ones((n, n), dtype=bool), -1)
     inner = None
     count = 0
-    while len(dm) > 2:
-        m = len(dm)
-        node_dist = [sum(dm[i]) / (m - 2) for i in range(m)]
-        min_dist = dm[1][0] - node_dist[1] - node_dist[0]
-        mi, mj = 0, 1
-        for i in range(1, m):
-            for j in range(i):
-                t = dm[i][j] - node_dist[i] - node_dist[j]
-                if min_dist > t:
-                    min_dist, mi, mj = t, i, j
+    m = n
+    while m > 2:
+        d = dm[:m, :m]
+        # the same IEEE operations in the same order as the scalar loops they replace: left-to-right row
+        # sums, (d[i][j] - nd[i]) - nd[j], first minimum in (i ascending, j < i ascending) scan order
+        node_dist = np.cumsum(d, axis=1)[:, -1] / (m - 2)
+        t = (d - node_dist[:, None]) - node_dist[None, :]
+        flat = int(np.argmin(np.where(lower[:m, :m], t, np.inf)))
+        mi, mj = divmod(flat, m)
+        if (mi, mj) == (1, 0):  # the scan starts from this pair with the indices the other way round
+            mi, mj = 0, 1
         c1, c2 = clades[mi], clades[mj]
         count += 1
         inner = _Node("Inner%d" % count)
         inner.add(c1)
         inner.add(c2)
-        c1.dist = (dm[mi][mj] + node_dist[mi] - node_dist[mj]) / 2.0
-        c2.dist = dm[mi][mj] - c1.dist
+        c1.dist = float((d[mi, mj] + node_dist[mi] - node_dist[mj]) / 2.0)
+        c2.dist = float(d[mi, mj] - c1.dist)
         clades[mj] = inner
         del clades[mi]
-        for kk in range(m):
-            if kk != mi and kk != mj:
-                v = (dm[mi][kk] + dm[mj][kk] - dm[mi][mj]) / 2.0
-                dm[mj][kk] = dm[kk][mj] = v
-        del dm[mi]
-        for row in dm:
-            del row[mi]
+        v = (d[mi, :] + d[mj, :] - d[mi, mj]) / 2.0
+        keep = np.ones(m, dtype=bool)
+        keep[mi] = keep[mj] = False
+        d[mj, keep] = v[keep]
+        d[keep, mj] = v[keep]
+        # delete row and column mi in place (order of the rest preserved)
+        dm[mi:m - 1, :m] = dm[mi + 1:m, :m].copy()
+        dm[:m - 1, mi:m - 1] = dm[:m - 1, mi + 1:m].copy()
+        m -= 1
+    dm = dm[:2, :2].tolist()
     if clades[0] is inner:
         clades[0].dist = 0.0
         clades[1].dist = dm[1][0]
@@ -170,7 +196,7 @@ def gsc_weights(root, min_val=1e-9, max_val=1e9):
     return {nd.name: nd.NodeWeight * len(leaves) for nd in leaves}
 
 
-def weights_from_sketches(names, sketches, k=21, sketch_size=1000):
-    labels, mat = distance_matrix(names, sketches, k, sketch_size)
+def weights_from_sketches(names, sketches, k=21, sketch_size=1000, ctx=None):
+    labels, mat = distance_matrix(names, sketches, k, sketch_size, ctx)
     tree = newick_round_trip(nj(labels, mat))
     return gsc_weights(tree), tree

@@ -107,3 +107,34 @@ def test_gpu_sketch_equals_mash(mash):
         assert ctx.minhash_sketch(mash["samples"][0]["fasta"], k=17, sketch_size=50).tolist() == mash["k17_s50_hashes"]
         assert ctx.minhash_sketch(mash["samples"][0]["fasta"], k=15, sketch_size=40).tolist() == mash["k15_s40_hashes"]
         assert len(ctx.minhash_sketch(b">e\nACGT\n")) == 0
+
+
+@pytest.mark.gpu
+def test_gpu_pairwise_distances_equal_mash_and_host(mash):
+    """psk_mash_pairs: the sketch merges of `mash dist` for every pair at once.  Against the distances the
+    bundled mash binary printed (tests/golden/mash.json) and against the host loop on short / empty /
+    overlapping sketches (the merge's early-exhaustion rule)."""
+    import numpy as np
+    from phenotypeseeker_amd import weights as W
+    from phenotypeseeker_amd.engine import PskContext
+    names = [s["name"] for s in mash["samples"]]
+    sk = {s["name"]: s["hashes"] for s in mash["samples"]}
+    with PskContext(0) as ctx:
+        labels, mat = W.distance_matrix(names, sk, ctx=ctx)
+        labels_h, mat_h = W.distance_matrix(names, sk)
+        assert labels == labels_h and np.array_equal(np.array(mat), np.array(mat_h))
+        rng = np.random.default_rng(4)
+        pool = np.unique(rng.integers(1, 1 << 40, 5000).astype(np.uint64))
+        odd = {"e": [], "one": [int(pool[3])], "few": sorted(int(v) for v in rng.choice(pool, 40, replace=False))}
+        for i in range(9):
+            odd["r%d" % i] = sorted(int(v) for v in rng.choice(pool, int(rng.integers(50, 1000)), replace=False))
+        odd["dup_of_r0"] = list(odd["r0"])
+        nm = list(odd)
+        _, got = W.distance_matrix(nm, odd, k=21, sketch_size=1000, ctx=ctx)
+        _, want = W.distance_matrix(nm, odd, k=21, sketch_size=1000)
+        assert np.array_equal(np.array(got), np.array(want))
+        common, denom = ctx.mash_pairs([odd[n] for n in sorted(nm)], 1000)
+        for a, na in enumerate(sorted(nm)):
+            for b, nb in enumerate(sorted(nm)):
+                _, c, d = W.mash_distance(odd[na], odd[nb], 21, 1000)
+                assert (int(common[a, b]), int(denom[a, b])) == (c, d), (na, nb)
