@@ -15,6 +15,8 @@
 // Latency-bound, f64 VALU; the roofline that matters for this stage is wall-clock, not bandwidth
 // (DESIGN.md).  The host removes duplicated columns first (model.GridSearch): k-mers of one gene share
 // one presence pattern, and an L1 optimum may put a pattern's weight on any one of its copies.
+#include <type_traits>
+
 #include "dev_utils.h"
 #include "psk_internal.h"
 
@@ -272,13 +274,14 @@ __global__ __launch_bounds__(SV_THREADS) void logreg_newglmnet_bits_kernel(
     const uint64_t *__restrict__ colbits, const int8_t *__restrict__ ypm, const int32_t *__restrict__ fold, int n, int p,
     int W, const double *__restrict__ fit_param, const int32_t *__restrict__ fit_fold, double tol, int max_newton,
     double *__restrict__ coef, double *__restrict__ icpt, int32_t *__restrict__ iters, double *__restrict__ work,
-    int32_t *__restrict__ iwork, const int f_lds_rt, const int s_lds_rt, const int c_lds_rt, const int q_lds_rt)
+    int32_t *__restrict__ iwork, const int f_lds_rt, const int s_lds_rt, const int c_lds_rt, const int q_doubles_i)
 {
+    const size_t q_doubles = (size_t)q_doubles_i;  // LDS doubles reserved for the Gram block
     const int f_lds = ALL_LDS ? 1 : f_lds_rt, s_lds = ALL_LDS ? 1 : s_lds_rt, c_lds = ALL_LDS ? 1 : c_lds_rt,
-              q_lds = ALL_LDS ? 1 : q_lds_rt;
+              q_lds = ALL_LDS ? 1 : (q_doubles_i > 0);
     extern __shared__ double sm_all[];
-    double *Qm = sm_all;  // 64 x 64 Gram block of the small-active-set QP (q_lds)
-    double *sm = sm_all + (q_lds ? 64 * 64 : 0);
+    double *Qm = sm_all;  // Gram block of the covariance-form QP: square when (64 NS)^2 fits, else packed triangle
+    double *sm = sm_all + q_doubles;
     const int fit = blockIdx.x, lane = threadIdx.x;
     const double C = fit_param[fit];
     const int tf = fit_fold[fit];
@@ -373,28 +376,61 @@ __global__ __launch_bounds__(SV_THREADS) void logreg_newglmnet_bits_kernel(
         for (int t = 0; t < W; t++) xTd[t * 64 + lane] = 0.0;
         double QP_Gmax_old = 1e300;
         int QP_active = active, iter = 0;
-        if (q_lds && active <= 64) {
-            // Covariance form of the same QP (active set small enough for one feature per lane): lane s
-            // owns feature act[s]; g = Gr + Q d with Q = X_A' D X_A (+ nu on the diagonal) is kept in a
-            // register per lane, so a coordinate step is three readlanes, the scalar update and one FMA
-            // instead of a reduction over the samples.  Columns of Q are built the first time a
-            // feature moves.  Same visiting order, shrinking and stopping rule as the loop below.
-            const bool mine = lane < active;
-            const int fj = mine ? act[lane] : 0;
-            double g = mine ? FLD(&Gr[fj]) : 0.0;
-            const double h = mine ? FLD(&Hd[fj]) : 1.0;
-            const double hinv = 1.0 / h;  // one division per feature and Newton step instead of one per coordinate step
-            const double wr = mine ? FLD(&w[fj]) : 0.0;
-            double wp_r = wr;
-            int perm = lane;
-            uint64_t have = 0;
+        // Covariance form of the same QP when the active set fits the Gram block: slot u = lane + 64 q owns
+        // feature act[u]; g = Gr + Q d with Q = X_A' D X_A (+ nu on the diagonal) lives in NS registers per
+        // lane, so a coordinate step is a few readlanes, the scalar update and one FMA per slot instead of a
+        // reduction over the samples.  Q is stored packed (lower triangle, qcap (qcap + 1) / 2 doubles of
+        // LDS) and a column is built the first time its feature moves.  Same visiting order, shrinking and
+        // stopping rule as the array form below.
+        auto gram_qp = [&](auto ns_tag, auto packed_tag) {
+            constexpr int NS = decltype(ns_tag)::value;
+            constexpr bool PACKED = decltype(packed_tag)::value;  // square (64 NS)^2 layout when it fits, else packed
+            int fjs[NS], perm[NS], kq[NS], tri[NS];
+            double g[NS], h[NS], hinv[NS], wr[NS], wpr[NS];
+            uint64_t have[NS];
+#pragma unroll
+            for (int q = 0; q < NS; q++) {
+                const int u = lane + 64 * q;
+                const bool mine = u < active;
+                fjs[q] = mine ? act[u] : 0;
+                g[q] = mine ? FLD(&Gr[fjs[q]]) : 0.0;
+                h[q] = mine ? FLD(&Hd[fjs[q]]) : 1.0;
+                hinv[q] = 1.0 / h[q];  // one division per feature and Newton step instead of one per coordinate step
+                wr[q] = mine ? FLD(&w[fjs[q]]) : 0.0;
+                wpr[q] = wr[q];
+                perm[q] = u;
+                have[q] = 0;
+                kq[q] = mine ? u : 0;  // idle slots read (and ignore) a valid entry
+                tri[q] = kq[q] * (kq[q] + 1) / 2;
+            }
+            // a[u >> 6] of lane u & 63 for a wave-uniform slot id u: uniform branches, one lane read each
+            auto pick_i = [&](const int *a, int u) {
+                const int ln = u & 63;
+                if (NS == 1 || u < 64) return __builtin_amdgcn_readlane(a[0], ln);
+                if (NS == 2 || u < 128) return __builtin_amdgcn_readlane(a[NS > 1 ? 1 : 0], ln);
+                return __builtin_amdgcn_readlane(a[NS > 2 ? 2 : 0], ln);
+            };
+            auto pick_d = [&](const double *a, int u) {
+                const int ln = u & 63;
+                if (NS == 1 || u < 64) return psk_readlane_f64(a[0], ln);
+                if (NS == 2 || u < 128) return psk_readlane_f64(a[NS > 1 ? 1 : 0], ln);
+                return psk_readlane_f64(a[NS > 2 ? 2 : 0], ln);
+            };
+            auto qidx = [&](int k, int m) {
+                if (!PACKED) return m * (64 * NS) + k;
+                const int hi = k > m ? k : m, lo = k > m ? m : k;
+                return hi * (hi + 1) / 2 + lo;
+            };
             while (iter < 1000) {
                 double QP_Gmax_new = 0.0, QP_Gnorm1_new = 0.0;
                 for (int sidx = 0; sidx < QP_active; sidx++) {
-                    const int m = __builtin_amdgcn_readlane(perm, sidx);
-                    double qcol = Qm[m * 64 + lane];
-                    const double G = psk_readlane_f64(g, m), H = psk_readlane_f64(h, m), Hi = psk_readlane_f64(hinv, m),
-                                 wp = psk_readlane_f64(wp_r, m);
+                    const int m = pick_i(perm, sidx);
+                    double qcol[NS];
+                    const int tri_m = m * (m + 1) / 2, sq_m = m * (64 * NS);
+#pragma unroll
+                    for (int q = 0; q < NS; q++)
+                        qcol[q] = Qm[PACKED ? (kq[q] > m ? tri[q] + m : tri_m + kq[q]) : sq_m + kq[q]];
+                    const double G = pick_d(g, m), H = pick_d(h, m), Hi = pick_d(hinv, m), wp = pick_d(wpr, m);
                     const double Gp = G + 1.0, Gn = G - 1.0;
                     double viol = 0.0;
                     if (wp == 0.0) {
@@ -402,9 +438,12 @@ __global__ __launch_bounds__(SV_THREADS) void logreg_newglmnet_bits_kernel(
                         else if (Gn > 0) viol = Gn;
                         else if (Gp > QP_Gmax_old / l && Gn < -QP_Gmax_old / l) {
                             QP_active--;
-                            const int last = __builtin_amdgcn_readlane(perm, QP_active);
-                            if (lane == sidx) perm = last;
-                            if (lane == QP_active) perm = m;
+                            const int last = pick_i(perm, QP_active);
+#pragma unroll
+                            for (int q = 0; q < NS; q++) {
+                                if (lane + 64 * q == sidx) perm[q] = last;
+                                if (lane + 64 * q == QP_active) perm[q] = m;
+                            }
                             sidx--;
                             continue;
                         }
@@ -418,24 +457,34 @@ __global__ __launch_bounds__(SV_THREADS) void logreg_newglmnet_bits_kernel(
                     else z = -wp;
                     if (fabs(z) < 1e-12 && !(z == -wp && wp != 0.0)) continue;  // see the array form below
                     z = fmin(fmax(z, -10.0), 10.0);
-                    if (!((have >> m) & 1)) {
-                        have |= 1ull << m;
-                        const int fm = __builtin_amdgcn_readlane(fj, m);
-                        double acc = 0.0;
-                        for (int t = 0; t < W; t++) {
-                            const uint64_t tw = psk_readlane_u64(trainw, t);
-                            uint64_t x = mine ? (cb[(size_t)fm * W + t] & cb[(size_t)fj * W + t] & tw) : 0ull;
-                            while (x) {
-                                acc += D[t * 64 + __builtin_ctzll(x)];
-                                x &= x - 1;
+                    bool built = false;
+#pragma unroll
+                    for (int q = 0; q < NS; q++) if ((m >> 6) == q) { built = (have[q] >> (m & 63)) & 1; have[q] |= 1ull << (m & 63); }
+                    if (!built) {
+                        const int fm = pick_i(fjs, m);
+#pragma unroll
+                        for (int q = 0; q < NS; q++) {
+                            const int k = lane + 64 * q;
+                            if (k >= active) continue;
+                            double acc = 0.0;
+                            for (int t = 0; t < W; t++) {
+                                const uint64_t tw = psk_readlane_u64(trainw, t);
+                                uint64_t x = cb[(size_t)fm * W + t] & cb[(size_t)fjs[q] * W + t] & tw;
+                                while (x) {
+                                    acc += D[t * 64 + __builtin_ctzll(x)];
+                                    x &= x - 1;
+                                }
                             }
+                            if (k == m) acc = h[q];
+                            Qm[qidx(k, m)] = acc;
+                            qcol[q] = acc;
                         }
-                        if (lane == m) acc = h;
-                        Qm[m * 64 + lane] = acc;
-                        qcol = acc;
                     }
-                    if (lane == m) wp_r += z;
-                    g += z * qcol;
+#pragma unroll
+                    for (int q = 0; q < NS; q++) {
+                        if ((m >> 6) == q && lane == (m & 63)) wpr[q] += z;  // the slot test is wave-uniform
+                        g[q] += z * qcol[q];
+                    }
                 }
                 iter++;
                 if (QP_Gnorm1_new <= inner_eps * Gnorm1_init) {
@@ -447,18 +496,43 @@ __global__ __launch_bounds__(SV_THREADS) void logreg_newglmnet_bits_kernel(
                 QP_Gmax_old = QP_Gmax_new;
             }
             // back to the array form: new visiting order, wpd, and xTd = X_A d
-            const int fnew = __shfl(fj, perm);
-            if (mine) { wpd[fj] = wp_r; act[lane] = fnew; }
-            const double dr = wp_r - wr;
-            for (int sidx = 0; sidx < active; sidx++) {
-                const double d = psk_readlane_f64(dr, sidx);
+            int act_new[NS];
+#pragma unroll
+            for (int q = 0; q < NS; q++) {
+                const int uu = perm[q];  // slot at position lane + 64 q
+                int f = 0;
+#pragma unroll
+                for (int q2 = 0; q2 < NS; q2++) {
+                    const int cand = __shfl(fjs[q2], uu & 63);
+                    if ((uu >> 6) == q2) f = cand;
+                }
+                act_new[q] = f;
+            }
+            double dr[NS];
+#pragma unroll
+            for (int q = 0; q < NS; q++) {
+                dr[q] = wpr[q] - wr[q];
+                if (lane + 64 * q < active) { wpd[fjs[q]] = wpr[q]; act[lane + 64 * q] = act_new[q]; }
+            }
+            for (int u = 0; u < active; u++) {
+                const double d = pick_d(dr, u);
                 if (d == 0.0) continue;
-                const uint64_t cw = load_col(__builtin_amdgcn_readlane(fj, sidx));
+                const uint64_t cw = load_col(pick_i(fjs, u));
                 for (int t = 0; t < W; t++) {
                     const uint64_t xw = psk_readlane_u64(cw, t);
                     if ((xw >> lane) & 1) xTd[t * 64 + lane] += d;
                 }
             }
+        };
+        using std::integral_constant;
+        if (q_lds && active <= 64 && q_doubles >= 64 * 64) {
+            gram_qp(integral_constant<int, 1>{}, integral_constant<bool, false>{});
+        } else if (q_lds && active <= 128 && q_doubles >= 128 * 128) {
+            gram_qp(integral_constant<int, 2>{}, integral_constant<bool, false>{});
+        } else if (q_lds && active <= 192 && (size_t)active * (active + 1) / 2 <= q_doubles) {
+            if (active <= 64) gram_qp(integral_constant<int, 1>{}, integral_constant<bool, true>{});
+            else if (active <= 128) gram_qp(integral_constant<int, 2>{}, integral_constant<bool, true>{});
+            else gram_qp(integral_constant<int, 3>{}, integral_constant<bool, true>{});
         } else
         while (iter < 1000) {
             double QP_Gmax_new = 0.0, QP_Gnorm1_new = 0.0;
@@ -743,11 +817,20 @@ extern "C" int psk_logreg_l1_fit(psk_ctx *ctx, const float *X, const int32_t *y0
         const size_t fa = fbytes + (((size_t)(p + 1) + 1) / 2) * 8, cbytes = (size_t)(p + 1) * W * 8;
         size_t left = lds_max;
         s_lds = sbytes <= left ? 1 : 0; left -= s_lds ? sbytes : 0;
-        const size_t qbytes = 64 * 64 * 8;
-        const int q_lds = (s_lds && qbytes <= left && !getenv("PSK_NO_GRAM")) ? 1 : 0; left -= q_lds ? qbytes : 0;
         f_lds = fa <= left ? 1 : 0; left -= f_lds ? fa : 0;
-        const int c_lds = cbytes <= left ? 1 : 0;
-        const size_t lds_b = (s_lds ? sbytes : 0) + (q_lds ? qbytes : 0) + (f_lds ? fa : 0) + (c_lds ? cbytes : 0);
+        const int c_lds = cbytes <= left ? 1 : 0; left -= c_lds ? cbytes : 0;
+        // the Gram block of the covariance-form QP takes what is left, up to the packed triangle of 192 features
+        // (a 128 x 128 square is preferred by the kernel when it fits)
+        size_t q_doubles = 0;
+        if (s_lds && !getenv("PSK_NO_GRAM")) {
+            q_doubles = left / 8;
+            const size_t most = (size_t)192 * 193 / 2;
+            if (q_doubles > most) q_doubles = most;
+            if (q_doubles < 36) q_doubles = 0;
+        }
+        const size_t qbytes = q_doubles * 8;
+        const int q_lds = q_doubles > 0;
+        const size_t lds_b = (s_lds ? sbytes : 0) + qbytes + (f_lds ? fa : 0) + (c_lds ? cbytes : 0);
         std::vector<uint64_t> bits((size_t)(p + 1) * W, 0);
         for (int i = 0; i < n; i++) {
             for (int j = 0; j < p; j++)
@@ -764,7 +847,7 @@ extern "C" int psk_logreg_l1_fit(psk_ctx *ctx, const float *X, const int32_t *y0
         kern<<<n_fits, SV_THREADS, lds_b, ctx->stream>>>(
             (const uint64_t *)b.bits, (const int8_t *)b.y, (const int32_t *)b.fold, n, p, W, (const double *)b.param,
             (const int32_t *)b.ffold, tol, max_iter, (double *)b.coef, (double *)b.icpt, (int32_t *)b.iters,
-            (double *)b.work, (int32_t *)b.iwork, f_lds, s_lds, c_lds, q_lds);
+            (double *)b.work, (int32_t *)b.iwork, f_lds, s_lds, c_lds, (int)q_doubles);
         PSK_HIP(ctx, hipGetLastError());
         PSK_HIP(ctx, hipStreamSynchronize(ctx->stream));  // `bits` (host) must outlive the copy
     } else {
