@@ -67,6 +67,16 @@ int psk_count_kmers(psk_ctx *ctx, int sample_idx, const uint8_t *bytes, size_t l
  * in order, so host framing overlaps device work.  n_unique / n_total: n entries each (may be NULL). */
 int psk_count_kmers_batch(psk_ctx *ctx, int first_sample_idx, int n, const uint8_t *const *bytes, const size_t *lens,
                           uint64_t *n_unique, uint64_t *n_total, int n_threads);
+/* The same call that also returns every sample's MinHash sketch (psk_minhash_sketch below) from the clean
+ * stream that is already on the device for counting: the `-w` path (get_kmer_lists + get_mash_sketches,
+ * modeling.py:303-315, :386-390) needs both and each file is framed and uploaded once.
+ *   sketch_k == 0: no sketches (hashes_out / n_hashes_out may be NULL)
+ *   hashes_out[n][sketch_size] ascending distinct hashes, n_hashes_out[n] = how many of each row are valid
+ */
+int psk_count_kmers_batch_sketch(psk_ctx *ctx, int first_sample_idx, int n, const uint8_t *const *bytes,
+                                 const size_t *lens, uint64_t *n_unique, uint64_t *n_total, int n_threads,
+                                 int sketch_k, int sketch_size, uint32_t sketch_seed, uint64_t *hashes_out,
+                                 uint64_t *n_hashes_out);
 /* Copies sample_idx's list to the host (for writing .list files / parity checks). */
 int psk_get_list(psk_ctx *ctx, int sample_idx, uint64_t *words, uint32_t *freqs, uint64_t cap);
 /* Frequencies of `n` given canonical words in sample_idx's list (0 if absent): the

@@ -23,6 +23,9 @@ _SIGNATURES = {
     "psk_count_kmers": (c.c_int, [c.c_void_p, c.c_int, c.c_char_p, c.c_size_t, _u64p, _u64p]),
     "psk_count_kmers_batch": (c.c_int, [c.c_void_p, c.c_int, c.c_int, c.POINTER(c.c_char_p), c.POINTER(c.c_size_t),
                                         c.c_void_p, c.c_void_p, c.c_int]),
+    "psk_count_kmers_batch_sketch": (c.c_int, [c.c_void_p, c.c_int, c.c_int, c.POINTER(c.c_char_p), c.POINTER(c.c_size_t),
+                                               c.c_void_p, c.c_void_p, c.c_int, c.c_int, c.c_int, c.c_uint32, c.c_void_p,
+                                               c.c_void_p]),
     "psk_get_list": (c.c_int, [c.c_void_p, c.c_int, c.c_void_p, c.c_void_p, c.c_uint64]),
     "psk_lookup_counts": (c.c_int, [c.c_void_p, c.c_int, c.c_void_p, c.c_uint64, c.c_void_p]),
     "psk_build_presence": (c.c_int, [c.c_void_p, _u64p]),

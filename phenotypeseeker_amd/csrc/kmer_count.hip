@@ -684,10 +684,28 @@ extern "C" int psk_count_kmers(psk_ctx *ctx, int sample_idx, const uint8_t *byte
 
 // Batch form: `n_threads` host threads frame samples ahead into a ring of pinned buffers while the calling
 // thread drives the GPU half of the samples in order, so host tokenisation overlaps device work.
+int sketch_from_device(psk_ctx *ctx, const uint8_t *d_clean, uint64_t clean_len, int k, int sketch_size, uint32_t seed,
+                       uint64_t *hashes_out, uint64_t *n_out);  // minhash.hip
+
 extern "C" int psk_count_kmers_batch(psk_ctx *ctx, int first_sample_idx, int n, const uint8_t *const *bytes,
                                      const size_t *lens, uint64_t *n_unique, uint64_t *n_total, int n_threads)
 {
+    return psk_count_kmers_batch_sketch(ctx, first_sample_idx, n, bytes, lens, n_unique, n_total, n_threads, 0, 0, 0, nullptr,
+                                        nullptr);
+}
+
+// Same, and (sketch_k > 0) the Mash-compatible MinHash sketch of every sample from the clean stream that is
+// already on the device for counting -- the `-w` path needs both and the host frames each file once.
+extern "C" int psk_count_kmers_batch_sketch(psk_ctx *ctx, int first_sample_idx, int n, const uint8_t *const *bytes,
+                                            const size_t *lens, uint64_t *n_unique, uint64_t *n_total, int n_threads,
+                                            int sketch_k, int sketch_size, uint32_t sketch_seed, uint64_t *hashes_out,
+                                            uint64_t *n_hashes_out)
+{
     if (!ctx) return PSK_EINVAL;
+    if (sketch_k != 0) {
+        if (sketch_k < 1 || sketch_k > 32 || sketch_size < 1) return psk_fail(ctx, PSK_EINVAL, "bad sketch parameters");
+        if (!hashes_out || !n_hashes_out) return psk_fail(ctx, PSK_EINVAL, "null sketch buffers");
+    }
     if (ctx->k == 0) return psk_fail(ctx, PSK_ESTATE, "psk_begin has not been called");
     if (n < 0 || first_sample_idx < 0 || first_sample_idx + n > ctx->n_samples)
         return psk_fail(ctx, PSK_EINVAL, "sample range out of bounds");
@@ -775,6 +793,14 @@ extern "C" int psk_count_kmers_batch(psk_ctx *ctx, int first_sample_idx, int n, 
             rc = chain_finalize(ctx, ctx->lane[(i - 1) & 1]);  // waits for chain i - 1: its upload is done too
             if (rc == PSK_OK) report(i - 1);
             release_upto(i);
+        }
+        if (rc == PSK_OK && sketch_k) {
+            // stream-ordered after the chain just queued; host-synchronous, so this lane's clean stream is not
+            // overwritten (sample i + 2) before the sketch has read it
+            n_hashes_out[i] = 0;
+            if (wins[i] > 0 || clen[i] > 0)
+                rc = sketch_from_device(ctx, ctx->lane[i & 1].raw.as<uint8_t>(), wins[i] ? clen[i] : 0, sketch_k, sketch_size,
+                                        sketch_seed, hashes_out + (size_t)i * sketch_size, n_hashes_out + i);
         }
     }
     if (pipelined) {

@@ -69,6 +69,27 @@ __global__ void kmer_hash_kernel(uint64_t *__restrict__ words, uint64_t n, int k
     if (i < n) words[i] = murmur3_kmer(words[i], k, seed) & mask;
 }
 
+// hash every word and keep (append, unordered) only the hashes <= limit: the bottom-s sketch of n uniform
+// hashes lies below ~ s/n of the hash space, so a limit at 8 s/n keeps ~8 s candidates instead of sorting all n
+__global__ void kmer_hash_filter_kernel(const uint64_t *__restrict__ words, uint64_t n, int k, uint64_t seed, uint64_t mask,
+                                        uint64_t limit, uint64_t *__restrict__ out, uint32_t *__restrict__ n_out)
+{
+    const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    uint64_t h = 0;
+    bool keep = false;
+    if (i < n) {
+        h = murmur3_kmer(words[i], k, seed) & mask;
+        keep = h <= limit;
+    }
+    const uint64_t bal = __ballot(keep);
+    if (!bal) return;
+    const int lane = threadIdx.x & 63;
+    uint32_t base = 0;
+    if (lane == 0) base = atomicAdd(n_out, (uint32_t)__popcll(bal));
+    base = __shfl(base, 0, 64);
+    if (keep) out[base + __popcll(bal & psk_lanemask_lt(lane))] = h;
+}
+
 __global__ void head_flags_kernel(const uint64_t *__restrict__ keys, uint64_t n, uint32_t *__restrict__ flags)
 {
     const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
@@ -89,6 +110,80 @@ __global__ void take_first_heads_kernel(const uint64_t *__restrict__ keys, uint6
 
 int upload_clean_stream(psk_ctx *ctx, const uint8_t *bytes, size_t len, uint64_t *clean_len);  // kmer_count.hip
 
+// sketch of a clean stream that already sits in device memory (stream-ordered after whatever produced it)
+int sketch_from_device(psk_ctx *ctx, const uint8_t *d_clean, uint64_t clean_len, int k, int sketch_size, uint32_t seed,
+                       uint64_t *hashes_out, uint64_t *n_out)
+{
+    *n_out = 0;
+    if (clean_len == 0) return PSK_OK;
+    if (clean_len >= (1ull << 32)) return psk_fail(ctx, PSK_ERANGE, "sample larger than 4 Gbases");
+    PSK_TRY(dev_reserve(ctx, ctx->keysA, clean_len * 8));
+    PSK_TRY(dev_reserve(ctx, ctx->keysB, clean_len * 8));
+    PSK_TRY(dev_reserve(ctx, ctx->misc, 64));
+    uint32_t *d_n = ctx->misc.as<uint32_t>() + 8;
+    PSK_HIP(ctx, hipMemsetAsync(d_n, 0, 16, ctx->stream));
+    PSK_TRY(launch_extract(ctx, d_clean, clean_len, k, 0, 0, ctx->keysA.as<uint64_t>(), d_n));
+    uint32_t n32 = 0;
+    PSK_HIP(ctx, hipMemcpyAsync(&n32, d_n, 4, hipMemcpyDeviceToHost, ctx->stream));
+    PSK_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    const uint64_t n = n32;
+    if (n == 0) return PSK_OK;
+    const bool wide = (k > 16);  // Mash keeps 64-bit hashes only when 4^k exceeds 2^32
+    const uint64_t mask = wide ? ~0ull : 0xffffffffull;
+    // candidates: hashes below 8 s/n of the hash space (the sketch is among them unless the sample is tiny or
+    // very repetitive -- then the count below comes up short and everything is sorted instead)
+    const double ratio = 8.0 * (double)sketch_size / (double)n;
+    uint64_t cand = 0;
+    if (ratio < 0.5) {
+        const uint64_t limit = wide ? (uint64_t)(ratio * 18446744073709551616.0) : (uint64_t)(ratio * 4294967296.0);
+        PSK_TRY(dev_reserve(ctx, ctx->valsA, n * 8));  // worst case: every hash is a candidate
+        kmer_hash_filter_kernel<<<div_up(n, 256), 256, 0, ctx->stream>>>(ctx->keysA.as<uint64_t>(), n, k, (uint64_t)seed, mask,
+                                                                       limit, ctx->valsA.as<uint64_t>(), d_n + 1);
+        PSK_HIP(ctx, hipGetLastError());
+        uint32_t c32 = 0;
+        PSK_HIP(ctx, hipMemcpyAsync(&c32, d_n + 1, 4, hipMemcpyDeviceToHost, ctx->stream));
+        PSK_HIP(ctx, hipStreamSynchronize(ctx->stream));
+        cand = c32;
+    }
+    uint64_t *keys = ctx->keysA.as<uint64_t>(), *spare = ctx->keysB.as<uint64_t>();
+    uint64_t n_sort = n;
+    bool filtered = cand >= (uint64_t)sketch_size;
+    for (int attempt = 0; attempt < 2; attempt++) {
+        if (filtered) {
+            // sort the candidates only; keysB is the spare, the unhashed words stay intact in keysA
+            keys = ctx->valsA.as<uint64_t>();
+            n_sort = cand;
+        } else {
+            kmer_hash_kernel<<<div_up(n, 256), 256, 0, ctx->stream>>>(ctx->keysA.as<uint64_t>(), n, k, (uint64_t)seed, mask);
+            PSK_HIP(ctx, hipGetLastError());
+            keys = ctx->keysA.as<uint64_t>();
+            n_sort = n;
+        }
+        uint64_t *sorted = nullptr;
+        PSK_TRY(dev_radix_sort_u64(ctx, keys, spare, n_sort, 0, wide ? 64 : 32, &sorted));
+        uint64_t *other = (sorted == keys) ? spare : keys;
+        PSK_TRY(dev_reserve(ctx, ctx->flags, n_sort * 4));
+        uint32_t *flags = ctx->flags.as<uint32_t>();
+        head_flags_kernel<<<div_up(n_sort, 256), 256, 0, ctx->stream>>>(sorted, n_sort, flags);
+        PSK_HIP(ctx, hipGetLastError());
+        PSK_TRY(dev_exclusive_scan_u32(ctx, flags, flags, n_sort, d_n + 2));
+        take_first_heads_kernel<<<div_up(n_sort, 256), 256, 0, ctx->stream>>>(sorted, n_sort, flags, (uint32_t)sketch_size, other);
+        PSK_HIP(ctx, hipGetLastError());
+        uint32_t nu = 0;
+        PSK_HIP(ctx, hipMemcpyAsync(&nu, d_n + 2, 4, hipMemcpyDeviceToHost, ctx->stream));
+        PSK_HIP(ctx, hipStreamSynchronize(ctx->stream));
+        if (filtered && nu < (uint32_t)sketch_size) {  // too many repeats among the candidates: sort everything
+            filtered = false;
+            continue;
+        }
+        const uint64_t take = nu < (uint32_t)sketch_size ? nu : (uint32_t)sketch_size;
+        if (take) PSK_HIP(ctx, hipMemcpy(hashes_out, other, take * 8, hipMemcpyDeviceToHost));
+        *n_out = take;
+        return PSK_OK;
+    }
+    return psk_fail(ctx, PSK_ESTATE, "sketch: unreachable");
+}
+
 extern "C" int psk_minhash_sketch(psk_ctx *ctx, const uint8_t *bytes, size_t len, int k, int sketch_size, uint32_t seed,
                                   uint64_t *hashes_out, uint64_t *n_out)
 {
@@ -99,41 +194,7 @@ extern "C" int psk_minhash_sketch(psk_ctx *ctx, const uint8_t *bytes, size_t len
     PSK_HIP(ctx, hipSetDevice(ctx->device));
     uint64_t clean_len = 0;
     PSK_TRY(upload_clean_stream(ctx, bytes, len, &clean_len));
-    *n_out = 0;
-    if (clean_len == 0) return PSK_OK;
-    if (clean_len >= (1ull << 32)) return psk_fail(ctx, PSK_ERANGE, "sample larger than 4 Gbases");
-    PSK_TRY(dev_reserve(ctx, ctx->keysA, clean_len * 8));
-    PSK_TRY(dev_reserve(ctx, ctx->keysB, clean_len * 8));
-    PSK_TRY(dev_reserve(ctx, ctx->misc, 64));
-    uint32_t *d_n = ctx->misc.as<uint32_t>() + 8;
-    PSK_HIP(ctx, hipMemsetAsync(d_n, 0, 8, ctx->stream));
-    PSK_TRY(launch_extract(ctx, ctx->raw.as<uint8_t>(), clean_len, k, 0, 0, ctx->keysA.as<uint64_t>(), d_n));
-    uint32_t n32 = 0;
-    PSK_HIP(ctx, hipMemcpyAsync(&n32, d_n, 4, hipMemcpyDeviceToHost, ctx->stream));
-    PSK_HIP(ctx, hipStreamSynchronize(ctx->stream));
-    const uint64_t n = n32;
-    if (n == 0) return PSK_OK;
-    const bool wide = (k > 16);  // Mash keeps 64-bit hashes only when 4^k exceeds 2^32
-    kmer_hash_kernel<<<div_up(n, 256), 256, 0, ctx->stream>>>(ctx->keysA.as<uint64_t>(), n, k, (uint64_t)seed,
-                                                             wide ? ~0ull : 0xffffffffull);
-    PSK_HIP(ctx, hipGetLastError());
-    uint64_t *sorted = nullptr;
-    PSK_TRY(dev_radix_sort_u64(ctx, ctx->keysA.as<uint64_t>(), ctx->keysB.as<uint64_t>(), n, 0, wide ? 64 : 32, &sorted));
-    uint64_t *other = (sorted == ctx->keysA.as<uint64_t>()) ? ctx->keysB.as<uint64_t>() : ctx->keysA.as<uint64_t>();
-    PSK_TRY(dev_reserve(ctx, ctx->flags, n * 4));
-    uint32_t *flags = ctx->flags.as<uint32_t>();
-    head_flags_kernel<<<div_up(n, 256), 256, 0, ctx->stream>>>(sorted, n, flags);
-    PSK_HIP(ctx, hipGetLastError());
-    PSK_TRY(dev_exclusive_scan_u32(ctx, flags, flags, n, d_n + 1));
-    take_first_heads_kernel<<<div_up(n, 256), 256, 0, ctx->stream>>>(sorted, n, flags, (uint32_t)sketch_size, other);
-    PSK_HIP(ctx, hipGetLastError());
-    uint32_t nu = 0;
-    PSK_HIP(ctx, hipMemcpyAsync(&nu, d_n + 1, 4, hipMemcpyDeviceToHost, ctx->stream));
-    PSK_HIP(ctx, hipStreamSynchronize(ctx->stream));
-    const uint64_t take = nu < (uint32_t)sketch_size ? nu : (uint32_t)sketch_size;
-    if (take) PSK_HIP(ctx, hipMemcpy(hashes_out, other, take * 8, hipMemcpyDeviceToHost));
-    *n_out = take;
-    return PSK_OK;
+    return sketch_from_device(ctx, ctx->raw.as<uint8_t>(), clean_len, k, sketch_size, seed, hashes_out, n_out);
 }
 
 // ---- pairwise sketch comparison (was `mash dist reference.msh reference.msh`, modeling.py:411-421) ----------

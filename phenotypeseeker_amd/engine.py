@@ -69,17 +69,28 @@ class PskContext:
                                               ctypes.byref(nt)), "psk_count_kmers")
         return nu.value, nt.value
 
-    def count_kmers_batch(self, first_idx, datas, n_threads=4):
-        """Counts several samples in one call; host tokenisation runs ahead on n_threads threads."""
+    def count_kmers_batch(self, first_idx, datas, n_threads=4, sketch=None):
+        """Counts several samples in one call; host tokenisation runs ahead on n_threads threads.
+        sketch=(k, size, seed): also returns every sample's MinHash sketch (third element: list of uint64 arrays),
+        computed from the clean stream that is on the device for counting anyway."""
         datas = [bytes(d) for d in datas]
         n = len(datas)
         arr = (ctypes.c_char_p * n)(*datas)
         lens = (ctypes.c_size_t * n)(*[len(d) for d in datas])
         nu = np.zeros(n, dtype=np.uint64)
         nt = np.zeros(n, dtype=np.uint64)
-        self._check(self._lib.psk_count_kmers_batch(self._h, int(first_idx), n, arr, lens, _ptr(nu), _ptr(nt),
-                                                    int(n_threads)), "psk_count_kmers_batch")
-        return nu.astype(np.int64).tolist(), nt.astype(np.int64).tolist()
+        if sketch is None:
+            self._check(self._lib.psk_count_kmers_batch(self._h, int(first_idx), n, arr, lens, _ptr(nu), _ptr(nt),
+                                                        int(n_threads)), "psk_count_kmers_batch")
+            return nu.astype(np.int64).tolist(), nt.astype(np.int64).tolist()
+        k, size, seed = sketch
+        hashes = np.zeros((n, int(size)), dtype=np.uint64)
+        nh = np.zeros(n, dtype=np.uint64)
+        self._check(self._lib.psk_count_kmers_batch_sketch(self._h, int(first_idx), n, arr, lens, _ptr(nu), _ptr(nt),
+                                                           int(n_threads), int(k), int(size), int(seed), _ptr(hashes),
+                                                           _ptr(nh)), "psk_count_kmers_batch_sketch")
+        return (nu.astype(np.int64).tolist(), nt.astype(np.int64).tolist(),
+                [hashes[i, : int(nh[i])].copy() for i in range(n)])
 
     def get_list(self, sample_idx, n_unique):
         words = np.empty(n_unique, dtype=np.uint64)

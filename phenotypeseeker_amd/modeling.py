@@ -112,11 +112,14 @@ class Samples:
                 datas = [f.result() for f in pending]
                 # the next chunk is read while this one is counted
                 pending = submit(bounds[bi + 1]) if bi + 1 < len(bounds) else []
-                nu, nt = ctx.count_kmers_batch(lo, datas, n_threads)
+                if cls.use_weights:  # was: mash sketch -r <address> -o K-mer_lists/<name>  (:386-390), k=21 s=1000 seed 42
+                    nu, nt, sk = ctx.count_kmers_batch(lo, datas, n_threads, sketch=(21, 1000, 42))
+                else:
+                    nu, nt = ctx.count_kmers_batch(lo, datas, n_threads)
                 for j, s in enumerate(part):
                     s.n_unique, s.n_total = nu[j], nt[j]
-                    if cls.use_weights:  # was: mash sketch -r <address> -o K-mer_lists/<name>  (:386-390)
-                        s.sketch = ctx.minhash_sketch(datas[j]).tolist()
+                    if cls.use_weights:
+                        s.sketch = sk[j].tolist()
                     stderr_print.currentSampleNum += 1
                     stderr_print.print_progress("lists generated.")
 

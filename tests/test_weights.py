@@ -138,3 +138,24 @@ def test_gpu_pairwise_distances_equal_mash_and_host(mash):
             for b, nb in enumerate(sorted(nm)):
                 _, c, d = W.mash_distance(odd[na], odd[nb], 21, 1000)
                 assert (int(common[a, b]), int(denom[a, b])) == (c, d), (na, nb)
+
+
+@pytest.mark.gpu
+def test_gpu_batch_sketch_equals_single_sketch(mash):
+    """psk_count_kmers_batch_sketch: sketches from the clean stream already on the device equal psk_minhash_sketch
+    (and therefore mash), also for an empty sample and one shorter than k."""
+    import numpy as np
+    from phenotypeseeker_amd.engine import PskContext
+    datas = [s["fasta"] for s in mash["samples"]] + [b"", b">tiny\nACGTACGT\n"]
+    with PskContext(0) as ctx:
+        ctx.begin(13, len(datas))
+        nu, nt, sk = ctx.count_kmers_batch(0, datas, 3, sketch=(21, 1000, 42))
+        for i, s in enumerate(mash["samples"]):
+            assert sk[i].tolist() == s["hashes"], s["name"]
+        assert len(sk[-1]) == 0 and len(sk[-2]) == 0
+        nu2, nt2 = ctx.count_kmers_batch(0, datas, 3)
+        assert (nu, nt) == (nu2, nt2)
+        one = ctx.minhash_sketch(datas[0], k=17, sketch_size=50)
+        ctx.begin(13, 1)
+        _, _, sk17 = ctx.count_kmers_batch(0, datas[:1], 1, sketch=(17, 50, 42))
+        assert np.array_equal(sk17[0], one)
