@@ -417,16 +417,29 @@ class phenotypes:
             order = sorted(range(len(pstr)), key=lambda i: (pstr[i], r["kmer"][i]))
             valid = [s.phenotypes[self.name] != "NA" and not isinstance(s.phenotypes[self.name], str) for s in samples]
             lines = []
-            for i in order:
-                with_names = [names[j] for j in range(len(names)) if r["presence"][i, j] and valid[j]]
-                stat = repr(formats.round2(r["stat"][i]))
-                if binary:
-                    fields = [r["kmer"][i], stat, pstr[i], str(int(r["n_with"][i])), " ".join(["|"] + with_names)]
-                else:
-                    fields = [r["kmer"][i], stat, pstr[i], repr(formats.round2(r["mean_x"][i])),
-                              repr(formats.round2(r["mean_y"][i])), str(int(r["n_with"][i])),
-                              " ".join(["|"] + with_names)]
-                lines.append("\t".join(fields))
+            if len(order):
+                # whole-array forms of the per-row work (a continuous phenotype can leave 10^5 rows): numpy's
+                # round is the same rint(x * 100) / 100 element by element as formats.round2
+                oi = np.array(order, dtype=np.int64)
+                stat_s = [repr(float(v)) for v in np.round(np.asarray(r["stat"], dtype=np.float64)[oi], 2)]
+                nw_s = [str(int(v)) for v in np.asarray(r["n_with"])[oi]]
+                shown = (np.asarray(r["presence"], dtype=bool) & np.array(valid, dtype=bool)[None, :])[oi]
+                rr, cc = np.nonzero(shown)  # row-major: the names of one row are consecutive, in sample order
+                ends = np.cumsum(np.bincount(rr, minlength=len(oi)))
+                who = np.array(names, dtype=object)[cc].tolist()
+                if not binary:
+                    mx_s = [repr(float(v)) for v in np.round(np.asarray(r["mean_x"], dtype=np.float64)[oi], 2)]
+                    my_s = [repr(float(v)) for v in np.round(np.asarray(r["mean_y"], dtype=np.float64)[oi], 2)]
+                lo = 0
+                for t, i in enumerate(order):
+                    hi = int(ends[t])
+                    tail = " ".join(["|"] + who[lo:hi])
+                    lo = hi
+                    if binary:
+                        fields = [r["kmer"][i], stat_s[t], pstr[i], nw_s[t], tail]
+                    else:
+                        fields = [r["kmer"][i], stat_s[t], pstr[i], mx_s[t], my_s[t], nw_s[t], tail]
+                    lines.append("\t".join(fields))
             if binary:
                 head, stem = "k-mer\tchi2\tp-value\tnum_samples_w_kmer\tsamples_with_kmer", "chi2"
             else:

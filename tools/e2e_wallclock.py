@@ -2,7 +2,7 @@
 """End-to-end `phenotypeseeker modeling` wall-clock (FASTA files on disk -> .pkl written), the second
 half of the north-star metric.  Writes a synthetic genome set to a scratch directory, runs the CLI
 entry point in-process and prints one JSON line with the stage timings.
-usage: tools/e2e_wallclock.py N LENGTH [extra CLI flags]"""
+usage: tools/e2e_wallclock.py N LENGTH [--continuous] [extra CLI flags]"""
 import json
 import os
 import shutil
@@ -17,6 +17,8 @@ from phenotypeseeker_amd.synth import GenomeSet  # noqa: E402
 
 n, length = int(sys.argv[1]), int(sys.argv[2])
 extra = sys.argv[3:]
+continuous = "--continuous" in extra  # tool flag: continuous phenotype column (Welch t-test + Lasso path)
+extra = [e for e in extra if e != "--continuous"]
 tmp = tempfile.mkdtemp(prefix="psk_e2e_")
 gs = GenomeSet(n, length, seed=12345)
 t0 = time.time()
@@ -25,7 +27,7 @@ for i in range(n):
     name, fa = gs.sample(i)
     with open(os.path.join(tmp, name + ".fasta"), "wb") as f:
         f.write(fa)
-    rows.append("%s\t%s.fasta\t%d" % (name, name, gs.phenotype(i)))
+    rows.append("%s\t%s.fasta\t%s" % (name, name, repr(round(gs.continuous_phenotype(i), 4)) if continuous else str(gs.phenotype(i))))
 with open(os.path.join(tmp, "data.pheno"), "w") as f:
     f.write("\n".join(rows) + "\n")
 t_write = time.time() - t0
