@@ -209,6 +209,15 @@ int psk_minhash_sketch(psk_ctx *ctx, const uint8_t *bytes, size_t len, int k, in
 int psk_mash_pairs(psk_ctx *ctx, const uint64_t *sketches, const uint32_t *lens, int n, int sketch_size,
                    uint32_t *common_out, uint32_t *denom_out);
 
+/* Neighbour joining of an n x n distance matrix (was Bio.Phylo.TreeConstruction.DistanceTreeConstructor.nj in
+ * Samples.get_weights, modeling.py:447-458): the n - 2 joins in order.  Join t merges the clades at POSITIONS
+ * mi_out[t] and mj_out[t] of the current clade list (the joined clade takes position mj, position mi is deleted),
+ * with branch lengths d1_out[t] (clade mi) and d2_out[t] (clade mj); last_out = the distance left between the final
+ * two clades.  Same arithmetic, scan order and tie-breaking as the library's scalar loops.  3 <= n <= 4096.
+ */
+int psk_nj_merges(psk_ctx *ctx, const double *dist, int n, int32_t *mi_out, int32_t *mj_out, double *d1_out,
+                  double *d2_out, double *last_out);
+
 /* ---- helpers shared with the host side ------------------------------------------------------ */
 /* Host-only: the cleaned sequence stream the tokeniser hands to the GPU (bases kept, window
  * breaks collapsed to '\n', everything else dropped).  Returns the length written (<= len), or

@@ -269,6 +269,19 @@ class PskContext:
                     "psk_mash_pairs")
         return common, denom
 
+    def nj_merges(self, dist):
+        """Neighbour-joining merge list of a symmetric distance matrix (psk_nj_merges)."""
+        d = np.ascontiguousarray(dist, dtype=np.float64)
+        n = d.shape[0]
+        mi = np.zeros(n - 2, dtype=np.int32)
+        mj = np.zeros(n - 2, dtype=np.int32)
+        d1 = np.zeros(n - 2)
+        d2 = np.zeros(n - 2)
+        last = np.zeros(1)
+        self._check(self._lib.psk_nj_merges(self._h, _ptr(d), n, _ptr(mi), _ptr(mj), _ptr(d1), _ptr(d2), _ptr(last)),
+                    "psk_nj_merges")
+        return mi, mj, d1, d2, float(last[0])
+
     # -- prediction -------------------------------------------------------------------------------
     def count_dict(self, data, k, dict_words):
         data = bytes(data)

@@ -76,7 +76,7 @@ def distance_matrix(names, sketches, k=21, sketch_size=1000, ctx=None):
     n = len(names)
     if ctx is not None:
         common, denom = ctx.mash_pairs([sketches[nm] for nm in by_file], sketch_size)
-        return list(names), distances_from_counts(common, denom, k).tolist()
+        return list(names), distances_from_counts(common, denom, k)  # numpy array: nj() takes it as it is
     mat = [[0.0] * n for _ in range(n)]
     for r in range(n):
         for c in range(r + 1):
@@ -96,11 +96,26 @@ class _Node:
         self.children.append(child)
 
 
-def nj(names, mat):
-    """Neighbour joining with Biopython's tie-breaking and rooting conventions (see module doc)."""
+def nj(names, mat, ctx=None):
+    """Neighbour joining with Biopython's tie-breaking and rooting conventions (see module doc).  With an engine
+    context the joins are computed on the GPU (psk_nj_merges) and only replayed here; the numpy loop below is
+    the same arithmetic on the host (CPU-only tests, and the check of the kernel)."""
     n = len(names)
-    dm = [[mat[i][j] for j in range(n)] for i in range(n)]
     clades = [_Node(nm) for nm in names]
+    if ctx is not None and 3 <= n <= 4096:
+        mi_a, mj_a, d1_a, d2_a, last = ctx.nj_merges(mat)
+        inner = None
+        for t in range(n - 2):
+            mi, mj = int(mi_a[t]), int(mj_a[t])
+            c1, c2 = clades[mi], clades[mj]
+            inner = _Node("Inner%d" % (t + 1))
+            inner.add(c1)
+            inner.add(c2)
+            c1.dist, c2.dist = float(d1_a[t]), float(d2_a[t])
+            clades[mj] = inner
+            del clades[mi]
+        return _nj_root(clades, inner, last)
+    dm = [[float(mat[i][j]) for j in range(n)] for i in range(n)]
     if n == 1:
         return clades[0]
     if n == 2:
@@ -144,18 +159,20 @@ def nj(names, mat):
         dm[mi:m - 1, :m] = dm[mi + 1:m, :m].copy()
         dm[:m - 1, mi:m - 1] = dm[:m - 1, mi + 1:m].copy()
         m -= 1
-    dm = dm[:2, :2].tolist()
+    return _nj_root(clades, inner, float(dm[1, 0]))
+
+
+def _nj_root(clades, inner, last):
+    """The library's last step: the two remaining clades are joined, the newer inner node becomes the root."""
     if clades[0] is inner:
         clades[0].dist = 0.0
-        clades[1].dist = dm[1][0]
+        clades[1].dist = last
         clades[0].add(clades[1])
-        root = clades[0]
-    else:
-        clades[0].dist = dm[1][0]
-        clades[1].dist = 0.0
-        clades[1].add(clades[0])
-        root = clades[1]
-    return root
+        return clades[0]
+    clades[0].dist = last
+    clades[1].dist = 0.0
+    clades[1].add(clades[0])
+    return clades[1]
 
 
 def _walk(node, order="pre"):
@@ -198,5 +215,5 @@ def gsc_weights(root, min_val=1e-9, max_val=1e9):
 
 def weights_from_sketches(names, sketches, k=21, sketch_size=1000, ctx=None):
     labels, mat = distance_matrix(names, sketches, k, sketch_size, ctx)
-    tree = newick_round_trip(nj(labels, mat))
+    tree = newick_round_trip(nj(labels, mat, ctx))
     return gsc_weights(tree), tree

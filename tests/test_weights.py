@@ -159,3 +159,42 @@ def test_gpu_batch_sketch_equals_single_sketch(mash):
         ctx.begin(13, 1)
         _, _, sk17 = ctx.count_kmers_batch(0, datas[:1], 1, sketch=(17, 50, 42))
         assert np.array_equal(sk17[0], one)
+
+
+@pytest.mark.gpu
+def test_gpu_neighbour_joining_is_bit_identical_to_the_host_loop():
+    """psk_nj_merges against weights.nj on the host: random matrices (Mash-like 6-digit values), matrices made
+    of a few repeated values (ties everywhere), sizes that cross the 1024-thread workgroup."""
+    import random
+    import time
+    from phenotypeseeker_amd import weights as W
+    from phenotypeseeker_amd.engine import PskContext
+
+    def rnd(n, seed, ties):
+        rng = random.Random(seed)
+        m = [[0.0] * n for _ in range(n)]
+        for i in range(n):
+            for j in range(i):
+                v = float("%g" % (rng.random() * 0.1)) if not ties else rng.choice([0.0, 0.001, 0.002, 0.0153, 1.0])
+                m[i][j] = m[j][i] = v
+        return m
+    with PskContext(0) as ctx:
+        for n in (3, 4, 5, 9, 33, 130):
+            for seed in range(4):
+                for ties in (False, True):
+                    names = ["s%d" % i for i in range(n)]
+                    mat = rnd(n, seed, ties)
+                    a = W.to_newick(W.newick_round_trip(W.nj(names, mat)))
+                    b = W.to_newick(W.newick_round_trip(W.nj(names, mat, ctx)))
+                    assert a == b, (n, seed, ties)
+                    assert W.gsc_weights(W.newick_round_trip(W.nj(names, mat))) == \
+                        W.gsc_weights(W.newick_round_trip(W.nj(names, mat, ctx)))
+        n = 1100
+        names = ["s%d" % i for i in range(n)]
+        mat = rnd(n, 5, False)
+        t = time.time()
+        b = W.nj(names, mat, ctx)
+        t_gpu = time.time() - t
+        a = W.nj(names, mat)
+        assert W.to_newick(a) == W.to_newick(b)
+        print("nj 1100 leaves: gpu path %.2f s" % t_gpu)
