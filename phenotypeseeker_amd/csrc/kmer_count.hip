@@ -717,7 +717,6 @@ extern "C" int psk_count_kmers_batch_sketch(psk_ctx *ctx, int first_sample_idx, 
     if (n_threads > n) n_threads = n;
     // every sample takes the pipelined path (see chain_enqueue); with a slab filter the host's window count is
     // an upper bound and the kernels read the number of kept words from device memory
-    const bool pipelined = true;
     size_t max_len = 0;
     for (int i = 0; i < n; i++) {
         if (!bytes[i] && lens[i]) return psk_fail(ctx, PSK_EINVAL, "null input %d", i);
@@ -781,12 +780,6 @@ extern "C" int psk_count_kmers_batch_sketch(psk_ctx *ctx, int first_sample_idx, 
         }
         if (rc != PSK_OK) break;
         uint8_t *stage = static_cast<uint8_t *>(ctx->ring[i % R]);
-        if (!pipelined) {
-            rc = count_from_stage(ctx, first_sample_idx + i, stage, clen[i], plen[i]);
-            if (rc == PSK_OK) report(i);
-            release_upto(i + 1);
-            continue;
-        }
         if (wins[i] >= (1ull << 32)) { rc = psk_fail(ctx, PSK_ERANGE, "sample with more than 2^32 windows"); break; }
         rc = chain_enqueue(ctx, ctx->lane[i & 1], first_sample_idx + i, stage, clen[i], plen[i], wins[i]);
         if (rc == PSK_OK && i > 0) {
@@ -803,12 +796,11 @@ extern "C" int psk_count_kmers_batch_sketch(psk_ctx *ctx, int first_sample_idx, 
                                         sketch_seed, hashes_out + (size_t)i * sketch_size, n_hashes_out + i);
         }
     }
-    if (pipelined) {
-        if (rc == PSK_OK && n > 0) {
-            rc = chain_finalize(ctx, ctx->lane[(n - 1) & 1]);
-            if (rc == PSK_OK) report(n - 1);
-        }
-        // nothing of this call may still be in flight when it returns (the ring and the caller's buffers)
+    if (rc == PSK_OK && n > 0) {
+        rc = chain_finalize(ctx, ctx->lane[(n - 1) & 1]);
+        if (rc == PSK_OK) report(n - 1);
+    }
+    {   // nothing of this call may still be in flight when it returns (the ring and the caller's buffers)
         const hipError_t e1 = hipStreamSynchronize(ctx->copy_stream ? ctx->copy_stream : ctx->stream);
         const hipError_t e2 = hipStreamSynchronize(ctx->stream);
         if (rc == PSK_OK && (e1 != hipSuccess || e2 != hipSuccess))
