@@ -89,6 +89,7 @@ __global__ __launch_bounds__(SV_THREADS) void logreg_newglmnet_kernel(
         if (lane == 0) { w[j] = 0.0; wpd[j] = 0.0; xjneg[j] = sneg; act[j] = j; }
     }
     double w_norm = 0.0, Gmax_old = 1e300, Gnorm1_init = -1.0, inner_eps = 1.0;
+    uint32_t rng = ((uint32_t)fit + 1u) * 2654435761u | 1u;  // per-fit xorshift state of the sweep permutations (lane 0's copy counts)
     int newton = 0;
     for (newton = 0; newton < max_newton; newton++) {
         double Gmax_new = 0.0, Gnorm1_new = 0.0;
@@ -133,6 +134,15 @@ __global__ __launch_bounds__(SV_THREADS) void logreg_newglmnet_kernel(
         double QP_Gmax_old = 1e300;
         int QP_active = active, iter = 0;
         while (iter < 1000) {
+            // liblinear visits the active coordinates in a fresh random order every sweep (solve_l1r_lr); a fixed cyclic
+            // order needs hundreds of times more sweeps on correlated columns (r01: 4.3 s against liblinear's 14 ms)
+            if (lane == 0) {
+                for (int jj = 0; jj + 1 < QP_active; jj++) {
+                    rng ^= rng << 13; rng ^= rng >> 17; rng ^= rng << 5;
+                    const int ii = jj + (int)(rng % (uint32_t)(QP_active - jj));
+                    const int32_t tt = act[ii]; act[ii] = act[jj]; act[jj] = tt;
+                }
+            }
             double QP_Gmax_new = 0.0, QP_Gnorm1_new = 0.0;
             for (int sidx = 0; sidx < QP_active; sidx++) {
                 const int j = __builtin_amdgcn_readfirstlane(lane == 0 ? act[sidx] : 0);
@@ -333,6 +343,7 @@ __global__ __launch_bounds__(SV_THREADS) void logreg_newglmnet_bits_kernel(
         if (lane == 0) { w[j] = 0.0; wpd[j] = 0.0; xjneg[j] = sneg; act[j] = j; }
     }
     double w_norm = 0.0, Gmax_old = 1e300, Gnorm1_init = -1.0, inner_eps = 1.0;
+    uint32_t rng = ((uint32_t)fit + 1u) * 2654435761u | 1u;  // per-fit xorshift state of the sweep permutations (lane 0's copy counts)
     int newton = 0;
     for (newton = 0; newton < max_newton; newton++) {
         double Gmax_new = 0.0, Gnorm1_new = 0.0;
@@ -525,6 +536,19 @@ __global__ __launch_bounds__(SV_THREADS) void logreg_newglmnet_bits_kernel(
                 return tmax < 1.0;
             };
             while (iter < 1000) {
+                if (f_lds) {  // fresh random visiting order (see the array form); `act` in LDS serves as the scratch
+#pragma unroll
+                    for (int q = 0; q < NS; q++) if (lane + 64 * q < QP_active) act[lane + 64 * q] = perm[q];
+                    if (lane == 0) {
+                        for (int jj = 0; jj + 1 < QP_active; jj++) {
+                            rng ^= rng << 13; rng ^= rng >> 17; rng ^= rng << 5;
+                            const int ii = jj + (int)(rng % (uint32_t)(QP_active - jj));
+                            const int32_t tt = act[ii]; act[ii] = act[jj]; act[jj] = tt;
+                        }
+                    }
+#pragma unroll
+                    for (int q = 0; q < NS; q++) if (lane + 64 * q < QP_active) perm[q] = act[lane + 64 * q];
+                }
                 double QP_Gmax_new = 0.0, QP_Gnorm1_new = 0.0;
                 for (int sidx = 0; sidx < QP_active; sidx++) {
                     const int m = pick_i(perm, sidx);
@@ -622,6 +646,15 @@ __global__ __launch_bounds__(SV_THREADS) void logreg_newglmnet_bits_kernel(
             else gram_qp(integral_constant<int, 3>{}, integral_constant<bool, true>{});
         } else
         while (iter < 1000) {
+            // liblinear visits the active coordinates in a fresh random order every sweep (solve_l1r_lr); a fixed cyclic
+            // order needs hundreds of times more sweeps on correlated columns (r01: 4.3 s against liblinear's 14 ms)
+            if (lane == 0) {
+                for (int jj = 0; jj + 1 < QP_active; jj++) {
+                    rng ^= rng << 13; rng ^= rng >> 17; rng ^= rng << 5;
+                    const int ii = jj + (int)(rng % (uint32_t)(QP_active - jj));
+                    const int32_t tt = act[ii]; act[ii] = act[jj]; act[jj] = tt;
+                }
+            }
             double QP_Gmax_new = 0.0, QP_Gnorm1_new = 0.0;
             for (int sidx = 0; sidx < QP_active; sidx++) {
                 const int j = f_lds ? act[sidx] : __builtin_amdgcn_readfirstlane(lane == 0 ? act[sidx] : 0);

@@ -13,8 +13,9 @@ sys.path.insert(0, ROOT)
 from phenotypeseeker_amd.engine import PskContext  # noqa: E402
 from phenotypeseeker_amd.model import GridSearch, L1LogisticRegression  # noqa: E402
 
-n, p = int(sys.argv[1]), int(sys.argv[2])
-dens = float(sys.argv[3]) if len(sys.argv) > 3 else 0.3
+args = [a for a in sys.argv[1:] if not a.startswith("--")]
+n, p = int(args[0]), int(args[1])
+dens = float(args[2]) if len(args) > 2 else 0.3
 rng = np.random.default_rng(1)
 X = (rng.random((n, p)) < dens).astype(np.float64)
 logit = 2.5 * X[:, 0] - 2.0 * X[:, 1] + 1.5 * X[:, 2] + 1.0 * X[:, 3] - 1.0
@@ -38,3 +39,19 @@ try:
         print("mean_test_score max abs diff: %.4f" % np.abs(sk.cv_results_["mean_test_score"] - gs.cv_results_["mean_test_score"]).max())
 except ImportError:
     pass
+if "--per-fit" in sys.argv:
+    from phenotypeseeker_amd import cv as _cv
+    folds = _cv.stratified_kfold(y, 10).astype(np.int32)
+    with PskContext(0) as ctx:
+        ctx.logreg_l1_fit(X[:, :8], y, folds, [1.0], [0], 1e-4, 1000)
+        for C in (1000.0, 31.6, 1.0, 0.1):
+            t = time.time()
+            c, b, it = ctx.logreg_l1_fit(X, y, folds, [C], [-1], 1e-4, 1000)
+            dt = time.time() - t
+            t = time.time()
+            with warnings.catch_warnings():
+                warnings.simplefilter("ignore")
+                m = LogisticRegression(penalty="l1", solver="liblinear", C=C, tol=1e-4, max_iter=1000).fit(X, y)
+            ds = time.time() - t
+            print("C=%-7g GPU %.3f s newton %3d nnz %4d | liblinear %.3f s newton %3d nnz %4d" % (
+                C, dt, it[0], (c[0] != 0).sum(), ds, m.n_iter_[0], (m.coef_ != 0).sum()))
