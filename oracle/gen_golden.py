@@ -424,6 +424,36 @@ def gen_model_l2_kat():
         out["ridge_gs_best_alpha2"], out["l2_gs_best_C1"], out["l2_gs_best_C2"]))
 
 
+def gen_model_mid_kat():
+    """Mid-size L1 logistic problems (the covariance-form QP with 2 and 3 feature slots per lane, random sweeps,
+    the CG accelerator): tightly converged liblinear objectives on a random sparse design and on a
+    near-duplicate one (columns = one pattern with a few flipped samples)."""
+    from sklearn.linear_model import LogisticRegression
+    rng = np.random.default_rng(2024)
+    n = 256
+    Xa = (rng.random((n, 100)) < 0.3)
+    logit = 2.5 * Xa[:, 0] - 2.0 * Xa[:, 1] + 1.5 * Xa[:, 2] + 1.0 * Xa[:, 3] - 1.0
+    ya = (rng.random(n) < 1 / (1 + np.exp(-logit))).astype(int)
+    base = rng.random(n) < 0.5
+    Xb = np.repeat(base[:, None], 150, axis=1)
+    for j in range(150):
+        flip = rng.choice(n, size=int(rng.integers(1, 6)), replace=False)
+        Xb[flip, j] = ~Xb[flip, j]
+    yb = (base ^ (rng.random(n) < 0.1)).astype(int)
+    Cs = [100.0, 3.1622776601683795, 0.31622776601683794]
+    out = {"Xa": np.packbits(Xa, axis=0), "ya": ya, "Xb": np.packbits(Xb, axis=0), "yb": yb, "n": np.array(n), "Cs": np.array(Cs)}
+    for tag, XX, yy in (("a", Xa.astype(np.float64), ya), ("b", Xb.astype(np.float64), yb)):
+        objs = []
+        ypm = 2.0 * yy - 1.0
+        for C in Cs:
+            m = LogisticRegression(penalty="l1", solver="liblinear", C=C, tol=1e-9, max_iter=100000).fit(XX, yy)
+            w, b = m.coef_[0], m.intercept_[0]
+            objs.append(np.abs(w).sum() + abs(b) + C * np.logaddexp(0, -ypm * (XX @ w + b)).sum())
+        out["obj_" + tag] = np.array(objs)
+    np.savez_compressed(os.path.join(GOLD, "model_mid_kat.npz"), **out)
+    print("mid-size model KATs:", out["obj_a"], out["obj_b"])
+
+
 def gen_gmer_counter():
     """prediction.py:72-80,145-148: db line 'KMER\\t1\\tKMER', output parsed at :82-100."""
     gs = GenomeSet(4, 6000, seed=31, gene_len=200)
@@ -514,7 +544,7 @@ def gen_split():
 
 if __name__ == "__main__":
     os.makedirs(GOLD, exist_ok=True)
-    what = sys.argv[1:] or ["tok", "ds", "chi2", "welch", "model", "model_l2", "gmer", "mash", "split"]
+    what = sys.argv[1:] or ["tok", "ds", "chi2", "welch", "model", "model_l2", "model_mid", "gmer", "mash", "split"]
     if "tok" in what:
         gen_tokenizer_cases()
     if "ds" in what:
@@ -529,6 +559,8 @@ if __name__ == "__main__":
         gen_model_kat()
     if "model_l2" in what:
         gen_model_l2_kat()
+    if "model_mid" in what:
+        gen_model_mid_kat()
     if "gmer" in what:
         gen_gmer_counter()
     if "mash" in what:

@@ -372,6 +372,32 @@ def test_l1_logreg_converges_on_near_duplicate_columns(ctx):
         assert viol(th) <= 1.5 * eps * viol(np.zeros_like(th)) + 1e-9, (j, fp[j], iters[j])
 
 
+def test_l1_logreg_mid_size_objectives_match_liblinear(ctx):
+    """256 samples x 100 random columns (two feature slots per lane in the covariance-form QP) and x 150
+    near-duplicate columns (three slots, packed Gram block, CG accelerator): the objective reached at a tight
+    tolerance equals tightly converged liblinear's (tests/golden/model_mid_kat.npz), and the default
+    tolerance stays within a fraction of a percent of it."""
+    from oracle import oracle_model as OM
+    z = np.load(os.path.join(GOLDEN, "model_mid_kat.npz"))
+    n = int(z["n"])
+    Cs = [float(c) for c in z["Cs"]]
+    for tag in ("a", "b"):
+        X = np.unpackbits(z["X" + tag], axis=0)[:n].astype(np.float64)
+        y = z["y" + tag]
+        zero = np.zeros(n, np.int32)
+        coef, icpt, iters = ctx.logreg_l1_fit(X, y, zero, Cs, [-1] * len(Cs), tol=1e-7, max_iter=300)
+        for j, C in enumerate(Cs):
+            obj = OM.logreg_l1_objective(X, y, coef[j], icpt[j], C)
+            # the near-duplicate design is ill-conditioned: at tol 1e-7 the objective is within 1e-5 (2e-7 at 1e-9,
+            # which takes 40 s)
+            assert obj == pytest.approx(float(z["obj_" + tag][j]), rel=2e-6 if tag == "a" else 2e-5), (tag, C, int(iters[j]))
+        coef, icpt, iters = ctx.logreg_l1_fit(X, y, zero, Cs, [-1] * len(Cs), tol=1e-4, max_iter=1000)
+        assert iters.max() < 100
+        for j, C in enumerate(Cs):
+            obj = OM.logreg_l1_objective(X, y, coef[j], icpt[j], C)
+            assert float(z["obj_" + tag][j]) * (1 - 1e-9) <= obj <= float(z["obj_" + tag][j]) * 1.005, (tag, C)
+
+
 def test_lasso_solver_matches_sklearn(ctx):
     z = np.load(os.path.join(GOLDEN, "model_kat.npz"))
     X, y = z["X2"], z["yc2"]
