@@ -138,6 +138,10 @@ int psk_get_results(psk_ctx *ctx, uint64_t *row_idx, uint64_t *words, double *st
  * record count.  The buffer can be handed to an RCCL all-gather as is (phenotypeseeker_amd/dist.py).
  * n_records returns the count; records beyond cap_records are dropped (caller retries with a larger cap). */
 int psk_export_survivors(psk_ctx *ctx, void *device_dst, uint64_t cap_records, uint64_t *n_records);
+/* The same export queued on the CALLER's stream (a hipStream_t, e.g. torch's current stream) and not waited for:
+ * work queued on that stream afterwards -- the RCCL all-gather -- is ordered behind it without a host
+ * synchronisation; the next scan of this context waits on the device for the export to finish. */
+int psk_export_survivors_async(psk_ctx *ctx, void *device_dst, uint64_t cap_records, void *stream);
 /* HIP-event duration of the last scan kernel launch in milliseconds (for bench.py). */
 double psk_last_scan_ms(const psk_ctx *ctx);
 /* Re-launches the last chi2 scan `reps` times back to back on the context's stream and

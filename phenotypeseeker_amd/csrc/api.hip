@@ -137,6 +137,7 @@ extern "C" void psk_free(psk_ctx *ctx)
     for (void *r : ctx->ring) if (r) (void)hipHostFree(r);
     if (ctx->ev0) (void)hipEventDestroy(ctx->ev0);
     if (ctx->ev1) (void)hipEventDestroy(ctx->ev1);
+    if (ctx->ev_export) (void)hipEventDestroy(ctx->ev_export);
     if (ctx->stream) (void)hipStreamDestroy(ctx->stream);
     delete ctx;
 }

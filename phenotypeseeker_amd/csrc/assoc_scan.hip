@@ -621,12 +621,22 @@ dim3 scan_grid(const psk_ctx *ctx, uint64_t M, int G, int unroll)
     return dim3((unsigned)blocks);
 }
 
+// an asynchronous export (psk_export_survivors_async) may still be reading the result arrays on another stream
+int wait_for_export(psk_ctx *ctx)
+{
+    if (!ctx->export_pending) return PSK_OK;
+    PSK_HIP(ctx, hipStreamWaitEvent(ctx->stream, ctx->ev_export, 0));
+    ctx->export_pending = false;
+    return PSK_OK;
+}
+
 int run_chi2(psk_ctx *ctx, ScanArgs &a, bool weighted, int reps, double *ms_total)
 {
     const int G = group_lanes(a.cpr);
     const dim3 grid = scan_grid(ctx, a.M, G, SC_UNROLL);
     *ms_total = 0;
     for (int r = 0; r < reps; r++) {
+        PSK_TRY(wait_for_export(ctx));
         PSK_HIP(ctx, hipEventRecord(ctx->ev0, ctx->stream));
         if (weighted) launch_chi2<true>(G, grid, ctx->stream, a);
         else launch_chi2<false>(G, grid, ctx->stream, a);
@@ -821,6 +831,7 @@ extern "C" int psk_ttest_scan(psk_ctx *ctx, const double *pheno, const uint8_t *
     ctx->last_scan_kind = 2;
     ctx->last.valid = false;
     if (ctx->n_kmers) {
+        PSK_TRY(wait_for_export(ctx));
         PSK_HIP(ctx, hipEventRecord(ctx->ev0, ctx->stream));
         launch_ttest(G, grid, ctx->stream, a, mu, !unit_w);
         PSK_HIP(ctx, hipGetLastError());
@@ -956,6 +967,27 @@ extern "C" int psk_export_survivors(psk_ctx *ctx, void *device_dst, uint64_t cap
         cap_records);
     PSK_HIP(ctx, hipGetLastError());
     PSK_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    return PSK_OK;
+}
+
+// The same export, queued on the CALLER's stream and not waited for: a collective queued on that stream next (RCCL
+// all_gather_into_tensor) is ordered after it without a host synchronisation, and the next scan of this context
+// waits (on the device) for the export before it overwrites the result arrays.
+extern "C" int psk_export_survivors_async(psk_ctx *ctx, void *device_dst, uint64_t cap_records, void *stream)
+{
+    if (!ctx) return PSK_EINVAL;
+    if (!ctx->last_scan_kind) return psk_fail(ctx, PSK_ESTATE, "no scan has been run");
+    if (!device_dst || cap_records < 1) return psk_fail(ctx, PSK_EINVAL, "bad destination");
+    PSK_HIP(ctx, hipSetDevice(ctx->device));
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    if (!ctx->ev_export) PSK_HIP(ctx, hipEventCreateWithFlags(&ctx->ev_export, hipEventDisableTiming));
+    export_records_kernel<<<SC_NSEG, SC_NSEG, 0, st>>>(
+        ctx->res.as<uint8_t>(), ctx->res_seg_cap * SC_NSEG, (uint32_t)ctx->res_seg_cap,
+        ctx->res_count.as<uint32_t>() + SC_NSEG * SC_CNT_STRIDE, ctx->union_words.as<uint64_t>(), ctx->bits.as<uint64_t>(),
+        ctx->wpr, static_cast<uint64_t *>(device_dst), cap_records);
+    PSK_HIP(ctx, hipGetLastError());
+    PSK_HIP(ctx, hipEventRecord(ctx->ev_export, st));
+    ctx->export_pending = true;
     return PSK_OK;
 }
 

@@ -69,6 +69,8 @@ struct psk_ctx {
     int device = 0;
     hipStream_t stream = nullptr;
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
+    hipEvent_t ev_export = nullptr;   // recorded on the caller's stream after an asynchronous survivor export
+    bool export_pending = false;      // the next scan must wait for it before it overwrites the result arrays
     std::string err;
     int n_cu = 0;
 

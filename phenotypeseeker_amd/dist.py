@@ -177,13 +177,17 @@ class SurvivorExchange:
         """Call right after a scan: packs this rank's survivors and launches the collective."""
         s = self.slot
         self.slot ^= 1
-        n_local = ctx.export_survivors(self.send[s].data_ptr(), self.cap)
         dist = self.g._dist
         if self.nccl:
+            # export and collective are both queued on torch's current stream: ordered on the device, the host
+            # does not wait for either (the next scan waits for the export inside libpsk)
+            ctx.export_survivors_async(self.send[s].data_ptr(), self.cap, self.torch.cuda.current_stream().cuda_stream)
+            n_local = None
             self.work[s] = dist.all_gather_into_tensor(self.recv[s], self.send[s], async_op=True)
-        else:
-            parts = list(self.recv[s].chunk(self.g.world))
-            self.work[s] = dist.all_gather(parts, self.send[s].cpu(), async_op=True)
+            return s, n_local
+        n_local = ctx.export_survivors(self.send[s].data_ptr(), self.cap)
+        parts = list(self.recv[s].chunk(self.g.world))
+        self.work[s] = dist.all_gather(parts, self.send[s].cpu(), async_op=True)
         return s, n_local
 
     def finish(self, s):
@@ -205,11 +209,9 @@ class SurvivorExchange:
         return res, np.ascontiguousarray(recs[:, 6:])
 
     def wait(self, s):
-        """Blocks until the collective of slot s has completed (so that its send buffer may be packed
-        again) without copying anything back."""
+        """Orders everything queued later behind the collective of slot s, so that its buffers may be packed again.
+        With nccl that is a stream-level wait (the host does not block); gloo completes on the host."""
         self.work[s].wait()
-        if self.nccl:
-            self.torch.cuda.current_stream().synchronize()
 
     def finish_counts(self, s):
         """Waits for slot s and reads back only the per-slab record counts (the records stay on the

@@ -185,6 +185,12 @@ class PskContext:
                                                    ctypes.byref(n)), "psk_export_survivors")
         return n.value
 
+    def export_survivors_async(self, device_ptr, cap_records, stream_handle):
+        """psk_export_survivors_async: the export is queued on `stream_handle` (a hipStream_t as an integer) and
+        not waited for.  The number of records is the n_pass the scan returned."""
+        self._check(self._lib.psk_export_survivors_async(self._h, ctypes.c_void_p(int(device_ptr)), int(cap_records),
+                                                         ctypes.c_void_p(int(stream_handle))), "psk_export_survivors_async")
+
     def last_scan_ms(self):
         return self._lib.psk_last_scan_ms(self._h)
 
