@@ -181,26 +181,38 @@ def main():
             else:
                 xch.wait(s_)                         # completion only: the slot's buffers are reused next step
 
-    def step():
-        npass = ctx.chi2_scan(pheno, None, 2, n - 2, 0.05, False, M_global)
-        ms = ctx.last_scan_ms()
-        if xch is not None:
-            s_, _ = xch.start(ctx)
+    scan_args = (pheno, None, 2, n - 2, 0.05, False, M_global)
+
+    def run_steps(count):
+        """`count` steps; returns (survivors of the last scan, kernel ms of every scan).  N = 1: scan, that is all.
+        N > 1: the scans are launched without waiting (psk_chi2_scan_begin) so that the host-side work of the
+        exchange -- pack the survivors, queue the all-gather -- happens while the NEXT scan streams its matrix;
+        every step still consists of one scan, one export and one all-gather."""
+        ms_all, npass = [], 0
+        if xch is None:
+            for _ in range(count):
+                npass = ctx.chi2_scan(*scan_args)
+                ms_all.append(ctx.last_scan_ms())
+            return npass, ms_all
+        ctx.chi2_scan_begin(*scan_args)
+        for i in range(count):
+            npass = ctx.scan_end()
+            ms_all.append(ctx.last_scan_ms())
+            s_ = xch.export(ctx)
+            if i + 1 < count:
+                ctx.chi2_scan_begin(*scan_args)
+            xch.collect(s_)
             pending.append(s_)
             if len(pending) > 1:
                 xch.wait(pending.pop(0))
-        return npass, ms
+        return npass, ms_all
 
-    for _ in range(args.warmup):
-        npass, _ = step()
+    npass, _ = run_steps(args.warmup) if args.warmup > 0 else (0, [])
     if xch is not None:
         drain(0)
     grp.barrier()
-    kernel_ms = []
     t0 = time.perf_counter()
-    for _ in range(args.steps):
-        npass, ms = step()
-        kernel_ms.append(ms)
+    npass, kernel_ms = run_steps(args.steps)
     if xch is not None:
         drain(0)   # the last exchange completes inside the timed region
     grp.barrier()

@@ -119,6 +119,13 @@ int psk_synth_presence(psk_ctx *ctx, uint64_t n_kmers, int n_samples, uint64_t s
  */
 int psk_chi2_scan(psk_ctx *ctx, const int8_t *pheno, const double *weights, int min_samples, int max_samples,
                   double pvalue_cutoff, int omit_B, uint64_t n_kmers_global, uint64_t *n_pass);
+/* The same scan in two halves: _begin launches it and returns, psk_scan_end waits for it and yields the number
+ * of surviving k-mers (also valid after a plain psk_chi2_scan / psk_ttest_scan: returns the last count).  Between
+ * the two the caller may queue unrelated work -- the multi-GPU step queues the all-gather of the PREVIOUS scan's
+ * survivors there; result-reading calls fail with PSK_ESTATE until psk_scan_end has run. */
+int psk_chi2_scan_begin(psk_ctx *ctx, const int8_t *pheno, const double *weights, int min_samples, int max_samples,
+                        double pvalue_cutoff, int omit_B, uint64_t n_kmers_global);
+int psk_scan_end(psk_ctx *ctx, uint64_t *n_pass);
 
 /* ---- a7: weighted Welch t-test scan ---------------------------------------------------------
  * Replaces conduct_t_test + get_samples_distribution_for_ttest (modeling.py:716-757) for one

@@ -678,11 +678,13 @@ static int fill_chi2_args(psk_ctx *ctx, ScanArgs &a)
     return setup_results(ctx, a, scan_grid(ctx, a.M, G, SC_UNROLL), G, SC_UNROLL);
 }
 
-extern "C" int psk_chi2_scan(psk_ctx *ctx, const int8_t *pheno, const double *weights, int min_samples,
-                             int max_samples, double pvalue_cutoff, int omit_B, uint64_t n_kmers_global,
-                             uint64_t *n_pass)
+// Launches the scan and returns without waiting; psk_scan_end collects it.  Lets a caller queue other work (the
+// survivor exchange of the previous scan) while the kernel streams the matrix.
+extern "C" int psk_chi2_scan_begin(psk_ctx *ctx, const int8_t *pheno, const double *weights, int min_samples,
+                                   int max_samples, double pvalue_cutoff, int omit_B, uint64_t n_kmers_global)
 {
     if (!ctx) return PSK_EINVAL;
+    if (ctx->scan_in_flight) return psk_fail(ctx, PSK_ESTATE, "a scan is in flight (psk_scan_end first)");
     if (!ctx->have_presence) return psk_fail(ctx, PSK_ESTATE, "no presence matrix (psk_build_presence first)");
     if (!pheno) return psk_fail(ctx, PSK_EINVAL, "null phenotype vector");
     if (n_kmers_global == 0) n_kmers_global = ctx->n_kmers ? ctx->n_kmers : 1;
@@ -734,18 +736,51 @@ extern "C" int psk_chi2_scan(psk_ctx *ctx, const int8_t *pheno, const double *we
     ctx->n_pass = 0;
     ctx->last_scan_kind = 1;
     if (ctx->n_kmers) {
-        double ms = 0;
-        PSK_TRY(run_chi2(ctx, a, ctx->last.weighted, 1, &ms));
+        const int G = group_lanes(a.cpr);
+        const dim3 grid = scan_grid(ctx, a.M, G, SC_UNROLL);
+        PSK_TRY(wait_for_export(ctx));
+        PSK_HIP(ctx, hipEventRecord(ctx->ev0, ctx->stream));
+        if (ctx->last.weighted) launch_chi2<true>(G, grid, ctx->stream, a);
+        else launch_chi2<false>(G, grid, ctx->stream, a);
+        PSK_HIP(ctx, hipGetLastError());
+        PSK_HIP(ctx, hipEventRecord(ctx->ev1, ctx->stream));
+        ctx->pending_seg_cap = a.seg_cap;
+        ctx->scan_in_flight = true;
+    }
+    return PSK_OK;
+}
+
+extern "C" int psk_scan_end(psk_ctx *ctx, uint64_t *n_pass)
+{
+    if (!ctx) return PSK_EINVAL;
+    if (ctx->scan_in_flight) {
+        PSK_HIP(ctx, hipSetDevice(ctx->device));
+        PSK_HIP(ctx, hipStreamSynchronize(ctx->stream));  // the kernel has written the counts to pinned memory
+        ctx->scan_in_flight = false;
+        float ms = 0;
+        PSK_HIP(ctx, hipEventElapsedTime(&ms, ctx->ev0, ctx->ev1));
         ctx->last_scan_ms = ms;
+        ScanArgs a = ScanArgs();
+        a.seg_cap = ctx->pending_seg_cap;
         PSK_TRY(fetch_counts(ctx, a));
     }
     if (n_pass) *n_pass = ctx->n_pass;
     return PSK_OK;
 }
 
+extern "C" int psk_chi2_scan(psk_ctx *ctx, const int8_t *pheno, const double *weights, int min_samples,
+                             int max_samples, double pvalue_cutoff, int omit_B, uint64_t n_kmers_global,
+                             uint64_t *n_pass)
+{
+    PSK_TRY(psk_chi2_scan_begin(ctx, pheno, weights, min_samples, max_samples, pvalue_cutoff, omit_B, n_kmers_global));
+    return psk_scan_end(ctx, n_pass);
+}
+
+
 extern "C" int psk_rescan_timed(psk_ctx *ctx, int reps, double *mean_ms)
 {
     if (!ctx) return PSK_EINVAL;
+    if (ctx->scan_in_flight) return psk_fail(ctx, PSK_ESTATE, "a scan is in flight (psk_scan_end first)");
     if (!ctx->have_presence || !ctx->last.valid || ctx->last_scan_kind != 1)
         return psk_fail(ctx, PSK_ESTATE, "no chi2 scan to repeat");
     if (reps < 1) return psk_fail(ctx, PSK_EINVAL, "reps must be >= 1");
@@ -766,6 +801,7 @@ extern "C" int psk_ttest_scan(psk_ctx *ctx, const double *pheno, const uint8_t *
                               uint64_t *n_pass)
 {
     if (!ctx) return PSK_EINVAL;
+    if (ctx->scan_in_flight) return psk_fail(ctx, PSK_ESTATE, "a scan is in flight (psk_scan_end first)");
     if (!ctx->have_presence) return psk_fail(ctx, PSK_ESTATE, "no presence matrix (psk_build_presence first)");
     if (!pheno || !valid) return psk_fail(ctx, PSK_EINVAL, "null phenotype vector");
     if (n_kmers_global == 0) n_kmers_global = ctx->n_kmers ? ctx->n_kmers : 1;
@@ -850,6 +886,7 @@ extern "C" int psk_get_results(psk_ctx *ctx, uint64_t *row_idx, uint64_t *words,
                                double *mean_x, double *mean_y, int32_t *n_with, uint64_t cap)
 {
     if (!ctx) return PSK_EINVAL;
+    if (ctx->scan_in_flight) return psk_fail(ctx, PSK_ESTATE, "a scan is in flight (psk_scan_end first)");
     if (!ctx->last_scan_kind) return psk_fail(ctx, PSK_ESTATE, "no scan has been run");
     const uint64_t n = ctx->n_pass;
     if (cap < n) return psk_fail(ctx, PSK_ERANGE, "buffer too small: %llu < %llu", (unsigned long long)cap,
@@ -956,6 +993,7 @@ __global__ void export_records_kernel(const uint8_t *__restrict__ res, uint64_t 
 extern "C" int psk_export_survivors(psk_ctx *ctx, void *device_dst, uint64_t cap_records, uint64_t *n_records)
 {
     if (!ctx) return PSK_EINVAL;
+    if (ctx->scan_in_flight) return psk_fail(ctx, PSK_ESTATE, "a scan is in flight (psk_scan_end first)");
     if (!ctx->last_scan_kind) return psk_fail(ctx, PSK_ESTATE, "no scan has been run");
     if (!device_dst || cap_records < 1) return psk_fail(ctx, PSK_EINVAL, "bad destination");
     PSK_HIP(ctx, hipSetDevice(ctx->device));
@@ -976,6 +1014,7 @@ extern "C" int psk_export_survivors(psk_ctx *ctx, void *device_dst, uint64_t cap
 extern "C" int psk_export_survivors_async(psk_ctx *ctx, void *device_dst, uint64_t cap_records, void *stream)
 {
     if (!ctx) return PSK_EINVAL;
+    if (ctx->scan_in_flight) return psk_fail(ctx, PSK_ESTATE, "a scan is in flight (psk_scan_end first)");
     if (!ctx->last_scan_kind) return psk_fail(ctx, PSK_ESTATE, "no scan has been run");
     if (!device_dst || cap_records < 1) return psk_fail(ctx, PSK_EINVAL, "bad destination");
     PSK_HIP(ctx, hipSetDevice(ctx->device));

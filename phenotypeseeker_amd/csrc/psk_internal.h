@@ -70,6 +70,8 @@ struct psk_ctx {
     hipStream_t stream = nullptr;
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
     hipEvent_t ev_export = nullptr;   // recorded on the caller's stream after an asynchronous survivor export
+    bool scan_in_flight = false;      // psk_chi2_scan_begin without its psk_scan_end yet
+    uint32_t pending_seg_cap = 0;
     bool export_pending = false;      // the next scan must wait for it before it overwrites the result arrays
     std::string err;
     int n_cu = 0;

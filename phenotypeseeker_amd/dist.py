@@ -173,22 +173,32 @@ class SurvivorExchange:
         self.recv = [torch.zeros(self.g.world * n, dtype=torch.int64, device=rdev) for _ in range(2)]
         self.nccl = nccl
 
-    def start(self, ctx):
-        """Call right after a scan: packs this rank's survivors and launches the collective."""
+    def export(self, ctx):
+        """First half of an exchange, right after a scan has ended: this rank's survivors are packed into the next
+        send buffer.  With nccl the pack is queued on torch's current stream and not waited for (the next scan of
+        `ctx` waits for it on the device), so the caller can launch that scan before calling collect()."""
         s = self.slot
         self.slot ^= 1
+        if self.nccl:
+            ctx.export_survivors_async(self.send[s].data_ptr(), self.cap, self.torch.cuda.current_stream().cuda_stream)
+        else:
+            ctx.export_survivors(self.send[s].data_ptr(), self.cap)
+        return s
+
+    def collect(self, s):
+        """Second half: queues the all-gather of slot s (ordered behind its export on the device)."""
         dist = self.g._dist
         if self.nccl:
-            # export and collective are both queued on torch's current stream: ordered on the device, the host
-            # does not wait for either (the next scan waits for the export inside libpsk)
-            ctx.export_survivors_async(self.send[s].data_ptr(), self.cap, self.torch.cuda.current_stream().cuda_stream)
-            n_local = None
             self.work[s] = dist.all_gather_into_tensor(self.recv[s], self.send[s], async_op=True)
-            return s, n_local
-        n_local = ctx.export_survivors(self.send[s].data_ptr(), self.cap)
-        parts = list(self.recv[s].chunk(self.g.world))
-        self.work[s] = dist.all_gather(parts, self.send[s].cpu(), async_op=True)
-        return s, n_local
+        else:
+            parts = list(self.recv[s].chunk(self.g.world))
+            self.work[s] = dist.all_gather(parts, self.send[s].cpu(), async_op=True)
+
+    def start(self, ctx):
+        """export() + collect() in one call; returns (slot, None)."""
+        s = self.export(ctx)
+        self.collect(s)
+        return s, None
 
     def finish(self, s):
         """Waits for slot s; returns (res dict, bits) of ALL slabs, ascending by word.  Returns None

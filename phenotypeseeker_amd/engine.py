@@ -159,6 +159,19 @@ class PskContext:
                                             ctypes.byref(n)), "psk_chi2_scan")
         return n.value
 
+    def chi2_scan_begin(self, pheno, weights, min_samples, max_samples, pvalue_cutoff, omit_B, n_kmers_global=0):
+        """Launches the scan and returns at once; scan_end() waits for it (psk_chi2_scan_begin / psk_scan_end)."""
+        ph = np.ascontiguousarray(pheno, dtype=np.int8)
+        w = None if weights is None else np.ascontiguousarray(weights, dtype=np.float64)
+        self._check(self._lib.psk_chi2_scan_begin(self._h, _ptr(ph), _ptr(w), int(min_samples), int(max_samples),
+                                                  float(pvalue_cutoff), int(bool(omit_B)), int(n_kmers_global)),
+                    "psk_chi2_scan_begin")
+
+    def scan_end(self):
+        n = ctypes.c_uint64()
+        self._check(self._lib.psk_scan_end(self._h, ctypes.byref(n)), "psk_scan_end")
+        return n.value
+
     def ttest_scan(self, values, valid, weights, min_samples, max_samples, pvalue_cutoff, n_kmers_global=0):
         v = np.ascontiguousarray(values, dtype=np.float64)
         ok = np.ascontiguousarray(valid, dtype=np.uint8)

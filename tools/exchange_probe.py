@@ -27,19 +27,33 @@ with PskContext(0) as ctx:
     ctx.synth_presence(m, n, seed=11)
     ph = (np.arange(n) % 2).astype(np.int8)
     x = dist.SurvivorExchange(g, ctx.presence_shape()[1], cap_records=1 << 20)
-    for mode in ("scan only", "scan + export + all-gather (double-buffered)"):
+    args = (ph, None, 2, n - 2, 0.05, False, m)
+    for mode in ("scan only", "scan + export + all-gather", "the same, next scan launched before the all-gather is queued"):
         pending = []
         for rep in range(2):
             t = time.perf_counter()
-            for _ in range(100):
-                ctx.chi2_scan(ph, None, 2, n - 2, 0.05, False, m)
-                if mode != "scan only":
-                    s, _ = x.start(ctx)
+            if mode.startswith("the same"):
+                ctx.chi2_scan_begin(*args)
+                for i in range(100):
+                    ctx.scan_end()
+                    s = x.export(ctx)
+                    if i + 1 < 100:
+                        ctx.chi2_scan_begin(*args)
+                    x.collect(s)
                     pending.append(s)
                     if len(pending) > 1:
                         x.wait(pending.pop(0))
+            else:
+                for _ in range(100):
+                    ctx.chi2_scan(*args)
+                    if mode != "scan only":
+                        s, _ = x.start(ctx)
+                        pending.append(s)
+                        if len(pending) > 1:
+                            x.wait(pending.pop(0))
             while pending:
                 x.wait(pending.pop(0))
+            torch.cuda.synchronize()
             dt = (time.perf_counter() - t) / 100
-        print("%-48s %.3f ms per step (scan kernel %.3f ms)" % (mode, dt * 1e3, ctx.last_scan_ms()))
+        print("%-62s %.3f ms per step (scan kernel %.3f ms)" % (mode, dt * 1e3, ctx.last_scan_ms()))
 g.close()
