@@ -124,7 +124,7 @@ def main():
     rank, world = grp.rank, grp.world
     n, k = args.samples, args.kmer
 
-    device = grp.local_rank
+    device = grp.device
     if args.share_gpu:
         import torch
         device = grp.local_rank % max(torch.cuda.device_count(), 1)

@@ -35,6 +35,7 @@ class Group:
         self.world = int(os.environ.get("WORLD_SIZE", "1"))
         self.rank = int(os.environ.get("RANK", "0"))
         self.local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+        self.device = self.local_rank   # GPU index of this rank (see init: PSK_SHARE_GPU)
         self._dist = None
         self._dev = None
 
@@ -45,11 +46,15 @@ class Group:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29533")
+        # test knobs for a box with fewer GPUs than ranks: PSK_DIST_BACKEND=gloo keeps the collectives on the host,
+        # PSK_SHARE_GPU=1 maps the ranks onto the visible GPUs modulo their count
         if backend is None:
-            backend = "nccl" if torch.cuda.is_available() else "gloo"
+            backend = os.environ.get("PSK_DIST_BACKEND") or ("nccl" if torch.cuda.is_available() else "gloo")
+        if os.environ.get("PSK_SHARE_GPU") == "1":
+            self.device = self.local_rank % max(torch.cuda.device_count(), 1)
         if backend == "nccl":
-            torch.cuda.set_device(self.local_rank)
-            self._dev = torch.device("cuda", self.local_rank)
+            torch.cuda.set_device(self.device)
+            self._dev = torch.device("cuda", self.device)
         else:
             self._dev = torch.device("cpu")
         if not dist.is_initialized():

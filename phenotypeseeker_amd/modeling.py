@@ -699,7 +699,7 @@ def modeling(args):
         args.kmerDB)
     Samples.use_weights = bool(getattr(args, "weights", False))
     group = _dist.Group().init()
-    ctx = PskContext(group.local_rank)
+    ctx = PskContext(group.device)
     try:
         if not Input.jump_to:
             k = int(Samples.kmer_length)

@@ -314,3 +314,31 @@ def test_l2_penalty_end_to_end(tmp_path):
         assert (m.predict(X) == y).mean() >= 0.9
         summary = open("summary_of_log_reg_analysis_Pheno.txt").read()
         assert "Parameters:\nLogisticRegression(max_iter=1000" in summary and "penalty='l1'" not in summary
+
+
+def test_two_rank_modeling_writes_the_same_files(tmp_path):
+    """SURVEY.md 8(e) invariant on the real pipeline: `phenotypeseeker modeling` under torch.distributed.run with two
+    ranks (both on the one visible GPU, gloo collectives: PSK_SHARE_GPU / PSK_DIST_BACKEND) -- each rank counts only
+    its slab of the word space, the survivors are all-gathered, rank 0 writes -- produces byte-identical result
+    tables and the same model as the one-rank run."""
+    import subprocess
+    import sys
+    import joblib
+    from helpers import ROOT
+    ds = load_dataset("ds_bonf")
+    one, two = tmp_path / "one", tmp_path / "two"
+    for d in (one, two):
+        d.mkdir()
+        _write_dataset(ds, str(d))
+    _run(one, ["modeling", "data.pheno"])
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", PSK_SHARE_GPU="1", PSK_DIST_BACKEND="gloo", OMP_NUM_THREADS="1")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+           "--master-port", "29619", os.path.join(ROOT, "scripts", "phenotypeseeker"), "modeling", "data.pheno"]
+    r = subprocess.run(cmd, env=env, cwd=str(two), timeout=600, capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr[-3000:]
+    for name in ("chi2_results_Pheno.tsv", "chi2_results_Pheno_top1000.tsv", "Pheno_MLdf.csv",
+                 "k-mers_and_coefficients_in_log_reg_model_Pheno.txt"):
+        assert (one / name).read_bytes() == (two / name).read_bytes(), name
+    a, b = joblib.load(str(one / "log_reg_model_Pheno.pkl")), joblib.load(str(two / "log_reg_model_Pheno.pkl"))
+    assert list(a["kmers"]) == list(b["kmers"])
+    assert np.array_equal(a["model"].best_estimator_.coef_, b["model"].best_estimator_.coef_)
