@@ -180,6 +180,8 @@ int sample_bits(int n_samples)
 
 }  // namespace
 
+int build_presence_tiled(psk_ctx *ctx, uint64_t total_pairs, uint64_t *n_kmers, int *done);  // presence_tiled.hip
+
 static int padded_wpr(int n_samples)
 {
     int w = (n_samples + 63) / 64;
@@ -213,6 +215,19 @@ extern "C" int psk_build_presence(psk_ctx *ctx, uint64_t *n_kmers)
         return PSK_OK;
     }
     PhaseTimer pt(ctx->stream);
+    {   // small word spaces: the sort-free tiled build (presence_tiled.hip)
+        uint64_t M = 0;
+        int done = 0;
+        PSK_TRY(build_presence_tiled(ctx, total, &M, &done));
+        if (done) {
+            pt.mark("tiled build");
+            ctx->n_kmers = M;
+            ctx->have_presence = true;
+            ctx->last.valid = false;
+            if (n_kmers) *n_kmers = M;
+            return PSK_OK;
+        }
+    }
     PSK_TRY(dev_reserve(ctx, ctx->keysA, total * 8));
     PSK_TRY(dev_reserve(ctx, ctx->keysB, total * 8));
     if (kv) {
