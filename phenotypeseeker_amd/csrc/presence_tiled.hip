@@ -14,8 +14,8 @@
 
 namespace {
 
-constexpr int PT_THREADS = 256;
-constexpr size_t PT_LDS_BYTES = 128 * 1024;
+constexpr int PT_THREADS = 1024;  // one 128 KB tile per CU, 16 waves on it
+constexpr size_t PT_LDS_MAX = 128 * 1024;
 
 struct ListRef {
     const uint64_t *words;
@@ -88,7 +88,7 @@ __global__ __launch_bounds__(PT_THREADS) void tile_fill_kernel(const ListRef *__
                                                                uint64_t *__restrict__ union_words,
                                                                uint64_t *__restrict__ bits)
 {
-    extern __shared__ uint64_t blk[];  // R x wpr words
+    extern __shared__ uint64_t blk[];  // wpr x R words, column-major (blk[col][row])
     __shared__ uint32_t scan_lds[PT_THREADS / 64];
     const uint32_t tile = blockIdx.x;
     const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
@@ -106,30 +106,33 @@ __global__ __launch_bounds__(PT_THREADS) void tile_fill_kernel(const ListRef *__
         const uint32_t col = (uint32_t)s >> 6;
         for (uint32_t j = a + lane; j < b; j += 64) {
             const uint32_t r = (uint32_t)(w[j] - tile_lo);
-            atomicOr(reinterpret_cast<unsigned long long *>(&blk[r * (uint32_t)wpr + col]), bit);
+            atomicOr(reinterpret_cast<unsigned long long *>(&blk[col * R + r]), bit);  // column-major: random rows spread over the banks
         }
     }
     __syncthreads();
-    // rank the non-empty rows: thread t owns rows t * RPT .. (consecutive, so one block scan orders them)
+    // rank the non-empty rows: thread t owns rows t * RPT .. (consecutive, so one block scan orders them), and lists
+    // them in LDS; the rows are then copied out by the whole workgroup with consecutive threads on consecutive
+    // addresses (a thread writing its own 32-byte rows was 13 of the build's 17 ms)
+    uint32_t *row_of = reinterpret_cast<uint32_t *>(blk + (size_t)R * wpr);  // R entries behind the block
     const uint32_t rpt = R / PT_THREADS;  // R is a multiple of PT_THREADS (host)
     uint32_t mine = 0;
+    uint32_t nonempty = 0;  // bit q: row t * rpt + q is occupied (rpt <= 32)
     for (uint32_t q = 0; q < rpt; q++) {
         const uint32_t r = threadIdx.x * rpt + q;
         uint64_t any = 0;
-        for (int c = 0; c < wpr; c++) any |= blk[r * (uint32_t)wpr + c];
-        mine += any ? 1u : 0u;
+        for (int c = 0; c < wpr; c++) any |= blk[(uint32_t)c * R + r];
+        if (any) { nonempty |= 1u << q; mine++; }
     }
     uint32_t all;
     uint32_t rank = psk_block_excl_scan_u32<PT_THREADS>(mine, &all, scan_lds);
-    for (uint32_t q = 0; q < rpt; q++) {
-        const uint32_t r = threadIdx.x * rpt + q;
-        uint64_t any = 0;
-        for (int c = 0; c < wpr; c++) any |= blk[r * (uint32_t)wpr + c];
-        if (!any) continue;
-        const uint64_t o = (uint64_t)out0 + rank++;
-        union_words[o] = tile_lo + r;
-        for (int c = 0; c < wpr; c++) bits[o * (uint64_t)wpr + c] = blk[r * (uint32_t)wpr + c];
-    }
+    for (uint32_t q = 0; q < rpt; q++)
+        if ((nonempty >> q) & 1) row_of[rank++] = threadIdx.x * rpt + q;
+    __syncthreads();
+    for (uint32_t i = threadIdx.x; i < n_rows; i += PT_THREADS) union_words[(uint64_t)out0 + i] = tile_lo + row_of[i];
+    const uint32_t n_out = n_rows * (uint32_t)wpr;
+    uint64_t *dst = bits + (uint64_t)out0 * wpr;
+    for (uint32_t e = threadIdx.x; e < n_out; e += PT_THREADS)
+        dst[e] = blk[(e % (uint32_t)wpr) * R + row_of[e / (uint32_t)wpr]];
 }
 
 }  // namespace
@@ -144,16 +147,25 @@ int build_presence_tiled(psk_ctx *ctx, uint64_t total_pairs, uint64_t *n_kmers, 
     const uint64_t space = 1ull << (2 * k);
     const uint64_t lo = ctx->slab_lo, hi = ctx->slab_hi ? ctx->slab_hi : space;
     const uint64_t span = hi - lo;
-    uint32_t R = (uint32_t)(PT_LDS_BYTES / ((size_t)wpr * 8));
-    uint32_t p2 = PT_THREADS;
-    while ((uint64_t)p2 * 2 <= R) p2 *= 2;
-    R = p2;
-    if (R < (uint32_t)PT_THREADS || (size_t)R * wpr * 8 > PT_LDS_BYTES) return PSK_OK;  // more than 4096 samples
-    const uint64_t n_tiles64 = (span + R - 1) / R;
-    // the tile table (n_samples x (tiles + 1) u32) must stay small next to the lists it indexes
-    if (n_tiles64 > (1u << 22) || (n_tiles64 + 1) * (uint64_t)n * 4 > (1ull << 30) ||
-        (n_tiles64 + 1) * (uint64_t)n > 4 * total_pairs + (1u << 20))
-        return PSK_OK;
+    // tile size: the smallest LDS block (more workgroups per CU) whose tile table stays under 256 MB; rows per
+    // thread are capped at 32 (a bit mask in tile_fill)
+    uint32_t R = 0;
+    uint64_t n_tiles64 = 0;
+    const size_t forced = getenv("PSK_TILE_LDS_KB") ? (size_t)atoi(getenv("PSK_TILE_LDS_KB")) * 1024 : 0;
+    for (size_t lds_try = forced ? forced : PT_LDS_MAX; lds_try <= PT_LDS_MAX; lds_try *= 2) {
+        uint32_t r = (uint32_t)(lds_try / ((size_t)wpr * 8 + 4));  // bit block + the 4-byte entry of the occupied-row list
+        uint32_t p2 = PT_THREADS;
+        while ((uint64_t)p2 * 2 <= r) p2 *= 2;
+        r = p2;
+        if (r > 32u * PT_THREADS) r = 32u * PT_THREADS;
+        if ((size_t)r * ((size_t)wpr * 8 + 4) > lds_try) { if (forced) break; continue; }  // too many samples for this block size
+        const uint64_t nt = (span + r - 1) / r;
+        if (nt <= (1u << 22) && (nt + 1) * (uint64_t)n * 4 <= (256ull << 20)) { R = r; n_tiles64 = nt; break; }
+        if (forced) break;
+    }
+    if (R == 0) return PSK_OK;
+    // ... and it must stay small next to the lists it indexes
+    if ((n_tiles64 + 1) * (uint64_t)n > 4 * total_pairs + (1u << 20)) return PSK_OK;
     const uint32_t n_tiles = (uint32_t)n_tiles64;
     std::vector<ListRef> refs(n);
     for (int i = 0; i < n; i++) {
@@ -185,7 +197,7 @@ int build_presence_tiled(psk_ctx *ctx, uint64_t total_pairs, uint64_t *n_kmers, 
     PSK_TRY(dev_reserve(ctx, ctx->union_words, M * 8));
     PSK_TRY(dev_reserve(ctx, ctx->bits, M * (uint64_t)wpr * 8));
     if (M) {
-        const size_t lds = (size_t)R * wpr * 8;
+        const size_t lds = (size_t)R * wpr * 8 + (size_t)R * 4;  // bit block + the list of occupied rows
         if (lds > 64 * 1024)
             PSK_HIP(ctx, hipFuncSetAttribute(reinterpret_cast<const void *>(tile_fill_kernel),
                                              hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
