@@ -15,7 +15,7 @@
 namespace {
 
 constexpr int PT_THREADS = 1024;  // one 128 KB tile per CU, 16 waves on it
-constexpr size_t PT_LDS_MAX = 128 * 1024;
+constexpr size_t PT_LDS_MAX = 156 * 1024;  // of the CU's 160 KB
 
 struct ListRef {
     const uint64_t *words;
@@ -50,7 +50,7 @@ __global__ void tile_starts_kernel(const ListRef *__restrict__ lists, int n_samp
 __global__ __launch_bounds__(PT_THREADS) void tile_count_kernel(const ListRef *__restrict__ lists, int n_samples,
                                                                 uint64_t lo, uint32_t R, uint32_t n_tiles,
                                                                 const uint32_t *__restrict__ start,
-                                                                uint32_t *__restrict__ tile_rows)
+                                                                uint32_t *__restrict__ tile_rows, int lane_per_sample)
 {
     extern __shared__ uint64_t occ[];  // R bits
     __shared__ uint32_t red[PT_THREADS / 64];
@@ -60,12 +60,23 @@ __global__ __launch_bounds__(PT_THREADS) void tile_count_kernel(const ListRef *_
     const uint64_t per = (uint64_t)n_tiles + 1;
     for (uint32_t i = threadIdx.x; i < R / 64; i += PT_THREADS) occ[i] = 0;
     __syncthreads();
-    for (int s = wid; s < n_samples; s += PT_THREADS / 64) {
-        const uint32_t a = start[(uint64_t)s * per + tile], b = start[(uint64_t)s * per + tile + 1];
-        const uint64_t *w = lists[s].words;
-        for (uint32_t j = a + lane; j < b; j += 64) {
-            const uint32_t r = (uint32_t)(w[j] - tile_lo);
-            atomicOr(reinterpret_cast<unsigned long long *>(&occ[r >> 6]), 1ull << (r & 63));
+    if (lane_per_sample) {  // short segments (many samples, small genomes): one sample per thread, its segment in sequence
+        for (int s = threadIdx.x; s < n_samples; s += PT_THREADS) {
+            const uint32_t a = start[(uint64_t)s * per + tile], b = start[(uint64_t)s * per + tile + 1];
+            const uint64_t *w = lists[s].words;
+            for (uint32_t j = a; j < b; j++) {
+                const uint32_t r = (uint32_t)(w[j] - tile_lo);
+                atomicOr(reinterpret_cast<unsigned long long *>(&occ[r >> 6]), 1ull << (r & 63));
+            }
+        }
+    } else {
+        for (int s = wid; s < n_samples; s += PT_THREADS / 64) {
+            const uint32_t a = start[(uint64_t)s * per + tile], b = start[(uint64_t)s * per + tile + 1];
+            const uint64_t *w = lists[s].words;
+            for (uint32_t j = a + lane; j < b; j += 64) {
+                const uint32_t r = (uint32_t)(w[j] - tile_lo);
+                atomicOr(reinterpret_cast<unsigned long long *>(&occ[r >> 6]), 1ull << (r & 63));
+            }
         }
     }
     __syncthreads();
@@ -86,7 +97,7 @@ __global__ __launch_bounds__(PT_THREADS) void tile_fill_kernel(const ListRef *__
                                                                const uint32_t *__restrict__ start,
                                                                const uint32_t *__restrict__ tile_off,
                                                                uint64_t *__restrict__ union_words,
-                                                               uint64_t *__restrict__ bits)
+                                                               uint64_t *__restrict__ bits, int lane_per_sample)
 {
     extern __shared__ uint64_t blk[];  // wpr x R words, column-major (blk[col][row])
     __shared__ uint32_t scan_lds[PT_THREADS / 64];
@@ -99,14 +110,27 @@ __global__ __launch_bounds__(PT_THREADS) void tile_fill_kernel(const ListRef *__
     if (n_rows == 0) return;  // uniform for the workgroup
     for (uint32_t i = threadIdx.x; i < R * (uint32_t)wpr; i += PT_THREADS) blk[i] = 0;
     __syncthreads();
-    for (int s = wid; s < n_samples; s += PT_THREADS / 64) {
-        const uint32_t a = start[(uint64_t)s * per + tile], b = start[(uint64_t)s * per + tile + 1];
-        const uint64_t *w = lists[s].words;
-        const uint64_t bit = 1ull << (s & 63);
-        const uint32_t col = (uint32_t)s >> 6;
-        for (uint32_t j = a + lane; j < b; j += 64) {
-            const uint32_t r = (uint32_t)(w[j] - tile_lo);
-            atomicOr(reinterpret_cast<unsigned long long *>(&blk[col * R + r]), bit);  // column-major: random rows spread over the banks
+    if (lane_per_sample) {
+        for (int s = threadIdx.x; s < n_samples; s += PT_THREADS) {
+            const uint32_t a = start[(uint64_t)s * per + tile], b = start[(uint64_t)s * per + tile + 1];
+            const uint64_t *w = lists[s].words;
+            const uint64_t bit = 1ull << (s & 63);
+            const uint32_t col = (uint32_t)s >> 6;
+            for (uint32_t j = a; j < b; j++) {
+                const uint32_t r = (uint32_t)(w[j] - tile_lo);
+                atomicOr(reinterpret_cast<unsigned long long *>(&blk[col * R + r]), bit);
+            }
+        }
+    } else {
+        for (int s = wid; s < n_samples; s += PT_THREADS / 64) {
+            const uint32_t a = start[(uint64_t)s * per + tile], b = start[(uint64_t)s * per + tile + 1];
+            const uint64_t *w = lists[s].words;
+            const uint64_t bit = 1ull << (s & 63);
+            const uint32_t col = (uint32_t)s >> 6;
+            for (uint32_t j = a + lane; j < b; j += 64) {
+                const uint32_t r = (uint32_t)(w[j] - tile_lo);
+                atomicOr(reinterpret_cast<unsigned long long *>(&blk[col * R + r]), bit);  // column-major: random rows spread over the banks
+            }
         }
     }
     __syncthreads();
@@ -147,7 +171,7 @@ int build_presence_tiled(psk_ctx *ctx, uint64_t total_pairs, uint64_t *n_kmers, 
     const uint64_t space = 1ull << (2 * k);
     const uint64_t lo = ctx->slab_lo, hi = ctx->slab_hi ? ctx->slab_hi : space;
     const uint64_t span = hi - lo;
-    // tile size: the smallest LDS block (more workgroups per CU) whose tile table stays under 256 MB; rows per
+    // tile size: the smallest LDS block (more workgroups per CU) whose tile table stays under 512 MB; rows per
     // thread are capped at 32 (a bit mask in tile_fill)
     uint32_t R = 0;
     uint64_t n_tiles64 = 0;
@@ -160,7 +184,7 @@ int build_presence_tiled(psk_ctx *ctx, uint64_t total_pairs, uint64_t *n_kmers, 
         if (r > 32u * PT_THREADS) r = 32u * PT_THREADS;
         if ((size_t)r * ((size_t)wpr * 8 + 4) > lds_try) { if (forced) break; continue; }  // too many samples for this block size
         const uint64_t nt = (span + r - 1) / r;
-        if (nt <= (1u << 22) && (nt + 1) * (uint64_t)n * 4 <= (256ull << 20)) { R = r; n_tiles64 = nt; break; }
+        if (nt <= (1u << 22) && (nt + 1) * (uint64_t)n * 4 <= (512ull << 20)) { R = r; n_tiles64 = nt; break; }
         if (forced) break;
     }
     if (R == 0) return PSK_OK;
@@ -186,7 +210,9 @@ int build_presence_tiled(psk_ctx *ctx, uint64_t total_pairs, uint64_t *n_kmers, 
     PSK_HIP(ctx, hipMemcpyAsync(d_refs, refs.data(), (size_t)n * sizeof(ListRef), hipMemcpyHostToDevice, ctx->stream));
     tile_starts_kernel<<<div_up(per * (uint64_t)n, 256), 256, 0, ctx->stream>>>(d_refs, n, lo, R, n_tiles, start);
     PSK_HIP(ctx, hipGetLastError());
-    tile_count_kernel<<<n_tiles, PT_THREADS, R / 8, ctx->stream>>>(d_refs, n, lo, R, n_tiles, start, tile_rows);
+    // average segment (words of one sample inside one tile) below half a wave: one sample per thread instead
+    const int lane_per_sample = total_pairs < (uint64_t)n * n_tiles * 32 ? 1 : 0;
+    tile_count_kernel<<<n_tiles, PT_THREADS, R / 8, ctx->stream>>>(d_refs, n, lo, R, n_tiles, start, tile_rows, lane_per_sample);
     PSK_HIP(ctx, hipGetLastError());
     PSK_HIP(ctx, hipMemsetAsync(tile_rows + n_tiles, 0, 4, ctx->stream));  // the scan's extra element: tile_off[n_tiles] = M
     PSK_TRY(dev_exclusive_scan_u32(ctx, tile_rows, tile_rows, (uint64_t)n_tiles + 1, d_m));
@@ -202,7 +228,7 @@ int build_presence_tiled(psk_ctx *ctx, uint64_t total_pairs, uint64_t *n_kmers, 
             PSK_HIP(ctx, hipFuncSetAttribute(reinterpret_cast<const void *>(tile_fill_kernel),
                                              hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
         tile_fill_kernel<<<n_tiles, PT_THREADS, lds, ctx->stream>>>(d_refs, n, wpr, lo, R, n_tiles, start, tile_rows,
-                                                                   ctx->union_words.as<uint64_t>(), ctx->bits.as<uint64_t>());
+                                                                   ctx->union_words.as<uint64_t>(), ctx->bits.as<uint64_t>(), lane_per_sample);
         PSK_HIP(ctx, hipGetLastError());
         PSK_HIP(ctx, hipStreamSynchronize(ctx->stream));
     }
