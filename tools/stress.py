@@ -1,0 +1,78 @@
+#!/usr/bin/env python3
+"""Randomised end-to-end check of the GPU path against the oracle (checker only): random sample sets (FASTA with
+breaks / lower case / empty samples, some FASTQ), random k, random slab; lists, union, presence bits and the
+chi2 survivors must be identical.  usage: tools/stress.py SECONDS [seed]"""
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+from oracle import oracle as O  # noqa: E402
+from phenotypeseeker_amd.engine import PskContext  # noqa: E402
+from phenotypeseeker_amd.synth import GenomeSet, fastq_reads  # noqa: E402
+
+budget = float(sys.argv[1]) if len(sys.argv) > 1 else 60.0
+seed = int(sys.argv[2]) if len(sys.argv) > 2 else 1
+rng = np.random.default_rng(seed)
+t_end = time.time() + budget
+rounds = 0
+with PskContext(0) as ctx:
+    while time.time() < t_end:
+        rounds += 1
+        n = int(rng.integers(1, 70))
+        length = int(rng.choice([300, 3000, 40_000, 150_000]))
+        k = int(rng.choice([1, 2, 5, 9, 11, 13, 13, 13, 14, 16, 21, 31, 32]))
+        gs = GenomeSet(n, length, seed=int(rng.integers(1, 1 << 30)), gene_len=min(200, length // 3))
+        datas = []
+        for i in range(n):
+            roll = rng.random()
+            if roll < 0.05:
+                datas.append(b"")
+                continue
+            if roll < 0.15:
+                datas.append(fastq_reads(gs.codes(i), int(rng.integers(1, 60)), 150, seed=[3, i]))
+                continue
+            b = bytearray(gs.sample(i)[1])
+            for pos in rng.integers(10, len(b), int(rng.integers(0, 30))):
+                if b[pos] != 10:
+                    b[pos] = ord("N") if pos % 3 else ord("a")
+            datas.append(bytes(b))
+        space = 1 << (2 * k)
+        if rng.random() < 0.5 or space < 8:
+            lo, hi = 0, 0
+        else:
+            world = int(rng.integers(2, 6))
+            rank = int(rng.integers(0, world))
+            lo, hi = (space * rank) // world, (0 if rank == world - 1 else (space * (rank + 1)) // world)
+        ctx.begin(k, n, lo, hi)
+        nu, nt = ctx.count_kmers_batch(0, datas, int(rng.integers(1, 9)))
+        ref_lists = []
+        for i in range(n):
+            w, f = ctx.get_list(i, nu[i])
+            ow, of = O.count_kmers(datas[i], k)[:2]
+            sel = (ow >= lo) & ((ow < hi) if hi else np.ones(len(ow), bool))
+            assert np.array_equal(w, ow[sel]) and np.array_equal(f, of[sel]), ("list", rounds, i, k, lo, hi)
+            ref_lists.append(ow[sel])
+        m = ctx.build_presence()
+        uw = O.union(ref_lists)
+        assert m == len(uw), ("union size", rounds, k, m, len(uw))
+        if m == 0:
+            continue
+        assert np.array_equal(ctx.get_union(), uw), ("union", rounds)
+        wpr = ctx.presence_shape()[1]
+        bits = O.presence_bits(ref_lists, uw, wpr=wpr)
+        assert np.array_equal(ctx.get_rows(np.arange(m, dtype=np.uint64)), bits), ("bits", rounds, k, n)
+        if n >= 4:
+            ph = rng.integers(-1, 2, n).astype(np.int8)
+            omit = bool(rng.random() < 0.5)
+            npass = ctx.chi2_scan(ph, None, 2, n - 2, 0.05, omit, m)
+            ref = O.chi2_scan(bits, ph.tolist(), np.ones(n), n, 2, n - 2, 0.05, omit, m)
+            keep = np.nonzero(ref["keep"])[0]
+            res = ctx.get_results(npass)
+            assert np.array_equal(np.sort(res["row"]), keep.astype(np.uint64)), ("scan rows", rounds, k, n)
+            order = np.argsort(res["row"])
+            assert np.array_equal(res["stat"][order], ref["stat"][keep]), ("scan stat", rounds)
+print("stress ok: %d rounds in %.0f s (seed %d)" % (rounds, budget, seed))
