@@ -77,6 +77,12 @@ int psk_count_kmers_batch_sketch(psk_ctx *ctx, int first_sample_idx, int n, cons
                                  const size_t *lens, uint64_t *n_unique, uint64_t *n_total, int n_threads,
                                  int sketch_k, int sketch_size, uint32_t sketch_seed, uint64_t *hashes_out,
                                  uint64_t *n_hashes_out);
+/* The same for UNCOMPRESSED files on disk (paths[i] of sizes[i] bytes): the framing threads read them, so no file
+ * image crosses the caller's language boundary.  Compressed inputs go through the in-memory forms after the host has
+ * inflated them (formats.read_sequence_file). */
+int psk_count_kmers_files(psk_ctx *ctx, int first_sample_idx, int n, const char *const *paths, const size_t *sizes,
+                          uint64_t *n_unique, uint64_t *n_total, int n_threads, int sketch_k, int sketch_size,
+                          uint32_t sketch_seed, uint64_t *hashes_out, uint64_t *n_hashes_out);
 /* Copies sample_idx's list to the host (for writing .list files / parity checks). */
 int psk_get_list(psk_ctx *ctx, int sample_idx, uint64_t *words, uint32_t *freqs, uint64_t cap);
 /* Frequencies of `n` given canonical words in sample_idx's list (0 if absent): the

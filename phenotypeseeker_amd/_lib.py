@@ -59,6 +59,9 @@ _SIGNATURES = {
     "psk_export_survivors_async": (c.c_int, [c.c_void_p, c.c_void_p, c.c_uint64, c.c_void_p]),
     "psk_chi2_scan_begin": (c.c_int, [c.c_void_p, c.c_void_p, c.c_void_p, c.c_int, c.c_int, c.c_double, c.c_int, c.c_uint64]),
     "psk_scan_end": (c.c_int, [c.c_void_p, _u64p]),
+    "psk_count_kmers_files": (c.c_int, [c.c_void_p, c.c_int, c.c_int, c.POINTER(c.c_char_p), c.POINTER(c.c_size_t),
+                                        c.c_void_p, c.c_void_p, c.c_int, c.c_int, c.c_int, c.c_uint32, c.c_void_p,
+                                        c.c_void_p]),
     "psk_frame_sequence": (c.c_int64, [c.c_char_p, c.c_size_t, c.c_void_p, c.c_size_t]),
 }
 

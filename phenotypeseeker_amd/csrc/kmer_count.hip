@@ -696,10 +696,27 @@ extern "C" int psk_count_kmers_batch(psk_ctx *ctx, int first_sample_idx, int n, 
 
 // Same, and (sketch_k > 0) the Mash-compatible MinHash sketch of every sample from the clean stream that is
 // already on the device for counting -- the `-w` path needs both and the host frames each file once.
-extern "C" int psk_count_kmers_batch_sketch(psk_ctx *ctx, int first_sample_idx, int n, const uint8_t *const *bytes,
-                                            const size_t *lens, uint64_t *n_unique, uint64_t *n_total, int n_threads,
-                                            int sketch_k, int sketch_size, uint32_t sketch_seed, uint64_t *hashes_out,
-                                            uint64_t *n_hashes_out)
+// reads a whole file into `buf` (worker thread); 0 on success
+static int read_whole_file(const char *path, size_t expect, std::vector<uint8_t> &buf)
+{
+    FILE *f = fopen(path, "rb");
+    if (!f) return -1;
+    buf.resize(expect ? expect : 1);
+    size_t got = 0;
+    while (got < expect) {
+        const size_t r = fread(buf.data() + got, 1, expect - got, f);
+        if (r == 0) break;
+        got += r;
+    }
+    fclose(f);
+    return got == expect ? 0 : -1;
+}
+
+// `paths` != nullptr: sample i is the file paths[i] of lens[i] bytes, read by the framing thread that takes it (plain
+// FASTA / FASTQ; compressed inputs come through the in-memory form after the host has inflated them)
+static int count_batch_impl(psk_ctx *ctx, int first_sample_idx, int n, const uint8_t *const *bytes, const char *const *paths,
+                            const size_t *lens, uint64_t *n_unique, uint64_t *n_total, int n_threads, int sketch_k,
+                            int sketch_size, uint32_t sketch_seed, uint64_t *hashes_out, uint64_t *n_hashes_out)
 {
     if (!ctx) return PSK_EINVAL;
     if (sketch_k != 0) {
@@ -710,7 +727,7 @@ extern "C" int psk_count_kmers_batch_sketch(psk_ctx *ctx, int first_sample_idx, 
     if (n < 0 || first_sample_idx < 0 || first_sample_idx + n > ctx->n_samples)
         return psk_fail(ctx, PSK_EINVAL, "sample range out of bounds");
     if (n == 0) return PSK_OK;
-    if (!bytes || !lens) return psk_fail(ctx, PSK_EINVAL, "null input");
+    if ((!bytes && !paths) || !lens) return psk_fail(ctx, PSK_EINVAL, "null input");
     PSK_HIP(ctx, hipSetDevice(ctx->device));
     if (n_threads < 1) n_threads = 1;
     if (n_threads > 16) n_threads = 16;
@@ -719,7 +736,7 @@ extern "C" int psk_count_kmers_batch_sketch(psk_ctx *ctx, int first_sample_idx, 
     // an upper bound and the kernels read the number of kept words from device memory
     size_t max_len = 0;
     for (int i = 0; i < n; i++) {
-        if (!bytes[i] && lens[i]) return psk_fail(ctx, PSK_EINVAL, "null input %d", i);
+        if (paths ? !paths[i] : (!bytes[i] && lens[i])) return psk_fail(ctx, PSK_EINVAL, "null input %d", i);
         if (lens[i] > max_len) max_len = lens[i];
     }
     // pinned ring: at most ~4 GiB of it (read-scale FASTQ samples are hundreds of MB each)
@@ -737,6 +754,7 @@ extern "C" int psk_count_kmers_batch_sketch(psk_ctx *ctx, int first_sample_idx, 
     std::atomic<int> next(0);
     const int k = ctx->k;
     auto worker = [&]() {
+        std::vector<uint8_t> file_buf;  // file image of the sample in hand (paths form)
         for (;;) {
             const int i = next.fetch_add(1);
             if (i >= n) return;
@@ -746,8 +764,14 @@ extern "C" int psk_count_kmers_batch_sketch(psk_ctx *ctx, int first_sample_idx, 
                 if (abort) return;
             }
             uint64_t c = 0, p = 0, w = 0;
-            const int rc = frame_into(static_cast<uint8_t *>(ctx->ring[i % R]), ctx->ring_cap[i % R], bytes[i], lens[i], &c, &p,
-                                      k, &w);
+            const uint8_t *src = bytes ? bytes[i] : nullptr;
+            int rc = 0;
+            if (paths) {
+                rc = read_whole_file(paths[i], lens[i], file_buf);
+                src = file_buf.data();
+            }
+            if (rc == 0)
+                rc = frame_into(static_cast<uint8_t *>(ctx->ring[i % R]), ctx->ring_cap[i % R], src, lens[i], &c, &p, k, &w);
             {
                 std::lock_guard<std::mutex> lk(mu);
                 clen[i] = c; plen[i] = p; wins[i] = w;
@@ -776,7 +800,9 @@ extern "C" int psk_count_kmers_batch_sketch(psk_ctx *ctx, int first_sample_idx, 
         {
             std::unique_lock<std::mutex> lk(mu);
             cv.wait(lk, [&] { return state[i] != 0; });
-            if (state[i] < 0) rc = psk_fail(ctx, PSK_ERANGE, "framing of sample %d failed", first_sample_idx + i);
+            if (state[i] < 0)
+                rc = psk_fail(ctx, PSK_ERANGE, paths ? "reading or framing sample %d (%s) failed" : "framing of sample %d failed",
+                              first_sample_idx + i, paths ? paths[i] : "");
         }
         if (rc != PSK_OK) break;
         uint8_t *stage = static_cast<uint8_t *>(ctx->ring[i % R]);
@@ -815,6 +841,25 @@ extern "C" int psk_count_kmers_batch_sketch(psk_ctx *ctx, int first_sample_idx, 
     cv.notify_all();
     for (auto &t : pool) t.join();
     return rc;
+}
+
+extern "C" int psk_count_kmers_batch_sketch(psk_ctx *ctx, int first_sample_idx, int n, const uint8_t *const *bytes,
+                                            const size_t *lens, uint64_t *n_unique, uint64_t *n_total, int n_threads,
+                                            int sketch_k, int sketch_size, uint32_t sketch_seed, uint64_t *hashes_out,
+                                            uint64_t *n_hashes_out)
+{
+    return count_batch_impl(ctx, first_sample_idx, n, bytes, nullptr, lens, n_unique, n_total, n_threads, sketch_k, sketch_size,
+                            sketch_seed, hashes_out, n_hashes_out);
+}
+
+// The same for uncompressed files on disk: the framing threads read them, so no file image crosses the caller's
+// language boundary (in Python: no bytes object per sample, no GIL hand-offs).
+extern "C" int psk_count_kmers_files(psk_ctx *ctx, int first_sample_idx, int n, const char *const *paths, const size_t *sizes,
+                                     uint64_t *n_unique, uint64_t *n_total, int n_threads, int sketch_k, int sketch_size,
+                                     uint32_t sketch_seed, uint64_t *hashes_out, uint64_t *n_hashes_out)
+{
+    return count_batch_impl(ctx, first_sample_idx, n, nullptr, paths, sizes, n_unique, n_total, n_threads, sketch_k, sketch_size,
+                            sketch_seed, hashes_out, n_hashes_out);
 }
 
 namespace {

@@ -1,5 +1,6 @@
 """PskContext: numpy-level wrapper over the C ABI (one context = one GPU = one rank)."""
 import ctypes
+import os
 
 import numpy as np
 
@@ -91,6 +92,26 @@ class PskContext:
                                                            _ptr(nh)), "psk_count_kmers_batch_sketch")
         return (nu.astype(np.int64).tolist(), nt.astype(np.int64).tolist(),
                 [hashes[i, : int(nh[i])].copy() for i in range(n)])
+
+    def count_kmers_files(self, first_idx, paths, n_threads=4, sketch=None):
+        """count_kmers_batch for UNCOMPRESSED files: the library's framing threads read them (psk_count_kmers_files).
+        Returns (n_unique, n_total[, sketches])."""
+        enc = [os.fsencode(p) for p in paths]
+        n = len(enc)
+        arr = (ctypes.c_char_p * n)(*enc)
+        sizes = (ctypes.c_size_t * n)(*[os.path.getsize(p) if os.path.exists(p) else 0 for p in paths])
+        nu = np.zeros(n, dtype=np.uint64)
+        nt = np.zeros(n, dtype=np.uint64)
+        k, size, seed = sketch if sketch is not None else (0, 1, 0)
+        hashes = np.zeros((n, int(size)), dtype=np.uint64) if sketch is not None else None
+        nh = np.zeros(n, dtype=np.uint64) if sketch is not None else None
+        self._check(self._lib.psk_count_kmers_files(self._h, int(first_idx), n, arr, sizes, _ptr(nu), _ptr(nt), int(n_threads),
+                                                    int(k), int(size), int(seed), _ptr(hashes), _ptr(nh)),
+                    "psk_count_kmers_files")
+        out = (nu.astype(np.int64).tolist(), nt.astype(np.int64).tolist())
+        if sketch is not None:
+            out += ([hashes[i, : int(nh[i])].copy() for i in range(n)],)
+        return out
 
     def get_list(self, sample_idx, n_unique):
         words = np.empty(n_unique, dtype=np.uint64)

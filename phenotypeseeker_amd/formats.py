@@ -59,6 +59,12 @@ def read_list(path):
     return int(h32[3]), rec["word"].copy(), rec["freq"].copy()
 
 
+def is_gzip(path):
+    """gzip by magic bytes, like read_sequence_file"""
+    with open(path, "rb") as f:
+        return f.read(2) == b"\x1f\x8b"
+
+
 def read_sequence_file(path):
     """File image handed to psk_count_kmers; .gz (by magic bytes) is inflated on the host."""
     with open(path, "rb") as f:

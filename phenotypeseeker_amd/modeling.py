@@ -88,8 +88,9 @@ class Samples:
 
     @classmethod
     def get_kmer_lists_batched(cls, ctx, samples, n_threads, chunk=None):
-        """All samples through psk_count_kmers_batch: files are read (and inflated) by a small thread
-        pool, host tokenisation runs ahead of the GPU inside the library."""
+        """All samples through the batch counter: uncompressed files are read by the library's framing threads
+        (psk_count_kmers_files); compressed ones are read and inflated by a small thread pool here and handed over in
+        memory (psk_count_kmers_batch).  Host tokenisation runs ahead of the GPU inside the library either way."""
         from concurrent.futures import ThreadPoolExecutor
         if chunk is None:  # about half a gigabyte of file images per call, two calls' worth in memory
             try:
@@ -97,6 +98,15 @@ class Samples:
             except OSError:
                 biggest = 1 << 29
             chunk = int(min(64, max(1, (1 << 29) // max(biggest, 1))))
+        sketch = (21, 1000, 42) if cls.use_weights else None  # was: mash sketch -r <address> (:386-390): k=21, s=1000, seed 42
+        # uncompressed inputs are read by the library's own framing threads (psk_count_kmers_files): no file image
+        # passes through Python.  Anything gzip-compressed takes the in-memory route below.
+        if not any(formats.is_gzip(s.address) for s in samples):
+            for lo in range(0, len(samples), chunk):
+                part = samples[lo:lo + chunk]
+                res = ctx.count_kmers_files(lo, [s.address for s in part], n_threads, sketch=sketch)
+                cls._record_lists(part, res)
+            return
         # chunk boundaries ramp up (8, 16, 32, ...): the first read is short, later calls amortise their set-up
         bounds, lo, step = [], 0, min(chunk, 8)
         while lo < len(samples):
@@ -112,16 +122,19 @@ class Samples:
                 datas = [f.result() for f in pending]
                 # the next chunk is read while this one is counted
                 pending = submit(bounds[bi + 1]) if bi + 1 < len(bounds) else []
-                if cls.use_weights:  # was: mash sketch -r <address> -o K-mer_lists/<name>  (:386-390), k=21 s=1000 seed 42
-                    nu, nt, sk = ctx.count_kmers_batch(lo, datas, n_threads, sketch=(21, 1000, 42))
-                else:
-                    nu, nt = ctx.count_kmers_batch(lo, datas, n_threads)
-                for j, s in enumerate(part):
-                    s.n_unique, s.n_total = nu[j], nt[j]
-                    if cls.use_weights:
-                        s.sketch = sk[j].tolist()
-                    stderr_print.currentSampleNum += 1
-                    stderr_print.print_progress("lists generated.")
+                cls._record_lists(part, ctx.count_kmers_batch(lo, datas, n_threads, sketch=sketch))
+
+    @classmethod
+    def _record_lists(cls, part, res):
+        """(n_unique, n_total[, sketches]) of one counting call -> the Samples objects, with the progress line."""
+        nu, nt = res[0], res[1]
+        sk = res[2] if len(res) > 2 else None
+        for j, s in enumerate(part):
+            s.n_unique, s.n_total = nu[j], nt[j]
+            if sk is not None:
+                s.sketch = sk[j].tolist()
+            stderr_print.currentSampleNum += 1
+            stderr_print.print_progress("lists generated.")
 
     @classmethod
     def get_weights(cls, ctx):

@@ -679,3 +679,34 @@ def test_randomised_pipeline_against_oracle():
     r = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "stress.py"), "8", "7"], cwd=ROOT, timeout=600,
                        capture_output=True, text=True)
     assert r.returncode == 0 and "stress ok" in r.stdout, (r.stdout[-500:], r.stderr[-2000:])
+
+
+def test_counting_from_files_equals_counting_from_memory(ctx, tmp_path):
+    """psk_count_kmers_files (the framing threads read the files) against psk_count_kmers_batch on the same bytes,
+    with and without sketches; an unreadable path fails loudly."""
+    from phenotypeseeker_amd._lib import PskError
+    ds = load_dataset("ds_bonf")
+    names = ds["names"][:12]
+    paths = []
+    for nm in names:
+        p = os.path.join(tmp_path, nm + ".seq")
+        with open(p, "wb") as f:
+            f.write(ds["files"][nm])
+        paths.append(p)
+    empty = os.path.join(tmp_path, "empty.seq")
+    open(empty, "wb").close()
+    paths.append(empty)
+    datas = [ds["files"][nm] for nm in names] + [b""]
+    k = ds["meta"]["k"]
+    ctx.begin(k, len(paths))
+    nu, nt, sk = ctx.count_kmers_files(0, paths, 3, sketch=(21, 1000, 42))
+    lists = [ctx.get_list(i, nu[i]) for i in range(len(paths))]
+    ctx.begin(k, len(paths))
+    nu2, nt2, sk2 = ctx.count_kmers_batch(0, datas, 3, sketch=(21, 1000, 42))
+    assert (nu, nt) == (nu2, nt2)
+    for i in range(len(paths)):
+        w, f = ctx.get_list(i, nu2[i])
+        assert np.array_equal(w, lists[i][0]) and np.array_equal(f, lists[i][1]) and np.array_equal(sk[i], sk2[i])
+    assert ctx.count_kmers_files(0, paths[:3], 2)[0] == nu[:3]
+    with pytest.raises(PskError, match="reading or framing"):
+        ctx.count_kmers_files(0, [paths[0], os.path.join(tmp_path, "missing.fa")], 2)
