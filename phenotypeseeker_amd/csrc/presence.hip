@@ -252,10 +252,11 @@ extern "C" int psk_build_presence(psk_ctx *ctx, uint64_t *n_kmers)
                               kv ? ctx->valsA.as<uint32_t>() : nullptr, kv ? ctx->valsB.as<uint32_t>() : nullptr, total,
                               sbits, sbits + 2 * ctx->k, &sorted, &sorted_vals));
     pt.mark("sort");
-    PSK_TRY(dev_reserve(ctx, ctx->flags, total * 4));
     PSK_TRY(dev_reserve(ctx, ctx->misc, 64));
+    // the row index of every pair goes into the sort's spare key buffer (8 B per pair of room for 4): one multi-GB
+    // allocation less -- device allocations of this size cost tens of ms per GB on a box whose memory has been used
+    uint32_t *flags = reinterpret_cast<uint32_t *>(sorted == ctx->keysA.as<uint64_t>() ? ctx->keysB.p : ctx->keysA.p);
     pt.mark("alloc flags");
-    uint32_t *flags = ctx->flags.as<uint32_t>();
     uint32_t *d_m = ctx->misc.as<uint32_t>() + 2;
     pair_head_flags_kernel<<<div_up(total, 256), 256, 0, ctx->stream>>>(sorted, total, sbits, flags);
     PSK_HIP(ctx, hipGetLastError());
