@@ -517,6 +517,11 @@ __global__ __launch_bounds__(SV_THREADS) void logreg_newglmnet_bits_kernel(
                     for (int q = 0; q < NS; q++) pd[q] = r[q] + beta * pd[q];
                     rs = rn;
                 }
+                // a direction that is not finite (breakdown of CG on a numerically singular block) is dropped
+                bool bad = false;
+#pragma unroll
+                for (int q = 0; q < NS; q++) bad |= !(fabs(dl[q]) < 1e300) || !(fabs(Qd[q]) < 1e300);
+                if (__ballot(bad)) return false;
                 // longest step in (0, 1] that keeps every sign
                 double tmax = 1.0;
 #pragma unroll
