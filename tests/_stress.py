@@ -1,7 +1,8 @@
 #!/usr/bin/env python3
 """Randomised end-to-end check of the GPU path against the oracle (checker only): random sample sets (FASTA with
 breaks / lower case / empty samples, some FASTQ), random k, random slab; lists, union, presence bits and the
-chi2 survivors must be identical.  usage: tools/stress.py SECONDS [seed]"""
+chi2 survivors must be identical.  Test infrastructure (it links the oracle): run by
+tests/test_gpu_parity.py::test_randomised_pipeline_against_oracle, or by hand: python tests/_stress.py SECONDS [seed]"""
 import os
 import sys
 import time

@@ -671,12 +671,12 @@ def test_fastq_reads_and_gzip_input(ctx, oracle, tmp_path):
 
 
 def test_randomised_pipeline_against_oracle():
-    """A few seconds of tools/stress.py: random sample sets, k and slabs through batch counting, presence build
+    """A few seconds of tests/_stress.py: random sample sets, k and slabs through batch counting, presence build
     (tiled and sort routes) and the chi2 scan, everything compared with the oracle for equality."""
     import subprocess
     import sys
     from helpers import ROOT
-    r = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "stress.py"), "8", "7"], cwd=ROOT, timeout=600,
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "tests", "_stress.py"), "8", "7"], cwd=ROOT, timeout=600,
                        capture_output=True, text=True)
     assert r.returncode == 0 and "stress ok" in r.stdout, (r.stdout[-500:], r.stderr[-2000:])
 

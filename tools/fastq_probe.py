@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """BASELINE config 5 at full per-sample size: ONE sample of READS x 150-bp FASTQ reads through
-psk_count_kmers; checks the size-independent properties (window count, sum of counts, sortedness, an
-oracle comparison on a prefix) and prints timings.  usage: tools/fastq_probe.py READS [k]"""
+psk_count_kmers; checks the size-independent properties (window count, sum of counts, sortedness) and prints
+timings (the oracle comparison of a prefix lives in tests/test_gpu_parity.py).  usage: tools/fastq_probe.py READS [k]"""
 import os
 import sys
 import time
@@ -31,14 +31,3 @@ with PskContext(0) as ctx:
     assert int(freqs.astype(np.uint64).sum()) == nt
     assert np.all(words[1:] > words[:-1])
     print("properties ok: windows, sum of counts, strictly ascending words; max count %d" % freqs.max())
-    # oracle on the first 20000 reads (4 lines each)
-    from oracle import oracle as O  # checker only
-    cut = 0
-    for _ in range(4 * 20000):
-        cut = data.index(b"\n", cut) + 1
-    ow, of = O.count_kmers(data[:cut], k)[:2]
-    ctx.begin(k, 1)
-    nu2, nt2 = ctx.count_kmers(0, data[:cut])
-    w2, f2 = ctx.get_list(0, nu2)
-    assert np.array_equal(w2, ow) and np.array_equal(f2, of)
-    print("prefix of 20000 reads equals the oracle (%d words)" % nu2)
