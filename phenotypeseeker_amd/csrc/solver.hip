@@ -38,8 +38,6 @@ __device__ __forceinline__ double lane0_load(const double *p, int lane)
     return psk_readlane_f64(v, 0);
 }
 
-__device__ __forceinline__ double log1pexp_from_e(double e) { return (e > 1e300) ? log(e) : log1p(e); }
-
 // L1 logistic regression by the improved GLMNET scheme (Yuan, Ho & Lin, JMLR 2012 -- the method behind
 // liblinear's L1R_LR solver, which is what the reference's LogisticRegression(penalty='l1',
 // solver='liblinear') runs): outer Newton iterations build a quadratic model from cached
