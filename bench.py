@@ -110,7 +110,13 @@ def main():
                     help="torch.distributed backend for N > 1 (default: nccl = RCCL when GPUs are visible). "
                          "gloo + --share-gpu lets two ranks exercise the N > 1 path on a one-GPU box.")
     ap.add_argument("--share-gpu", action="store_true", help="map ranks onto the visible GPUs modulo their count")
+    ap.add_argument("--force-exchange", action="store_true",
+                    help="N = 1 only: run the N > 1 step (scan + export + all-gather) on a one-rank group, to measure "
+                         "what the exchange adds per step on one GPU; the line carries \"exchange\": \"forced\"")
     args = ap.parse_args()
+    if args.force_exchange:
+        os.environ["PSK_WITH_TORCH"] = "1"
+        import torch  # noqa: F401  (before libpsk.so)
 
     from phenotypeseeker_amd import dist as psk_dist
     from phenotypeseeker_amd.engine import PskContext
@@ -120,7 +126,7 @@ def main():
     if grp.world != args.gpus:
         if grp.world == 1 and args.gpus > 1:
             sys.exit("bench.py --gpus %d must be launched with torch.distributed.run (one rank per GPU)" % args.gpus)
-    grp.init(args.backend)
+    grp.init(args.backend, force=args.force_exchange)
     rank, world = grp.rank, grp.world
     n, k = args.samples, args.kmer
 
@@ -166,7 +172,7 @@ def main():
     # is followed by one all-gather of its survivors.  The gather is device-to-device (RCCL) and
     # double-buffered, so the collective of scan i runs while scan i+1 streams the matrix -- as it
     # does in a run with several phenotypes.  N = 1 has no exchange.
-    xch = psk_dist.SurvivorExchange(grp, wpr) if world > 1 else None
+    xch = psk_dist.SurvivorExchange(grp, wpr) if world > 1 or args.force_exchange else None
     pending = []
     gathered = [0]
 
@@ -190,21 +196,22 @@ def main():
 
     def run_steps(count):
         """`count` steps; returns (survivors of the last scan, kernel ms of every scan).  N = 1: scan, that is all.
-        N > 1: the scans are launched without waiting (psk_chi2_scan_begin) so that the host-side work of the
-        exchange -- pack the survivors, queue the all-gather -- happens while the NEXT scan streams its matrix;
-        every step still consists of one scan, one export and one all-gather."""
+        N > 1: two scans are kept in flight (psk_chi2_scan_begin twice, two result sets), so the host-side work of
+        the exchange -- wait for scan i, pack its survivors, queue the all-gather -- happens while scan i + 1 streams
+        its matrix; every step still consists of one scan, one export and one all-gather."""
         ms_all, npass = [], 0
         if xch is None:
             for _ in range(count):
                 npass = ctx.chi2_scan(*scan_args)
                 ms_all.append(ctx.last_scan_ms())
             return npass, ms_all
-        ctx.chi2_scan_begin(*scan_args)
+        for _ in range(min(2, count)):
+            ctx.chi2_scan_begin(*scan_args)
         for i in range(count):
             npass = ctx.scan_end()
             ms_all.append(ctx.last_scan_ms())
             s_ = xch.export(ctx)
-            if i + 1 < count:
+            if i + 2 < count:
                 ctx.chi2_scan_begin(*scan_args)
             xch.collect(s_)
             pending.append(s_)
@@ -239,7 +246,7 @@ def main():
         "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "u64 popcount + f64",
         "data": "synthetic",
         "config": {"workload": workload, "n_samples": n, "k": k, "rows_per_gpu": int(M),
-                   "words_per_row_stored": wpr, "survivors": int(npass), "survivors_all_slabs": int(gathered[0]) if world > 1
+                   "words_per_row_stored": wpr, "survivors": int(npass), "survivors_all_slabs": int(gathered[0]) if xch is not None
                    else int(npass), "device": info["name"],
                    "setup_s": round(t_setup, 2), "ingest": ingest},
         "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
@@ -248,6 +255,8 @@ def main():
                      "stored_bytes_per_launch": int(M) * 8 * wpr},
     }
 
+    if args.force_exchange:
+        out["exchange"] = "forced"
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         # CPU baseline: the oracle's scan (C restatement of modeling.py:677-858, "port"), one
         # thread, on the first rows of the same matrix; checked equal to the GPU's answer first.
@@ -273,10 +282,14 @@ def main():
                                "reference_python_8proc_cells_per_s": 7.4e6}
     if rank == 0 and world == 1 and args.workload == "fasta" and not args.no_e2e:
         out["e2e"] = e2e_modeling(gs, n, k)
-    if rank == 0:
-        print(json.dumps(out))
     ctx.close()
     grp.close()
+    if rank == 0:
+        # RCCL prints a version banner through C stdio, which (piped) is flushed at exit, after Python's own
+        # buffer: flush it now so that the JSON line is the LAST line of stdout
+        import ctypes
+        ctypes.CDLL(None).fflush(None)
+        print(json.dumps(out), flush=True)
 
 
 if __name__ == "__main__":

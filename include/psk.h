@@ -125,10 +125,14 @@ int psk_synth_presence(psk_ctx *ctx, uint64_t n_kmers, int n_samples, uint64_t s
  */
 int psk_chi2_scan(psk_ctx *ctx, const int8_t *pheno, const double *weights, int min_samples, int max_samples,
                   double pvalue_cutoff, int omit_B, uint64_t n_kmers_global, uint64_t *n_pass);
-/* The same scan in two halves: _begin launches it and returns, psk_scan_end waits for it and yields the number
- * of surviving k-mers (also valid after a plain psk_chi2_scan / psk_ttest_scan: returns the last count).  Between
- * the two the caller may queue unrelated work -- the multi-GPU step queues the all-gather of the PREVIOUS scan's
- * survivors there; result-reading calls fail with PSK_ESTATE until psk_scan_end has run. */
+/* The same scan in two halves: _begin launches it and returns, psk_scan_end waits for the OLDEST scan in flight and
+ * yields its number of surviving k-mers (with none in flight: the last count again).  Up to two scans may be in
+ * flight -- there are two result sets -- so the multi-GPU step runs begin(i+1), end(i), export(i), begin(i+2),
+ * all-gather(i): the device always has the next scan queued while the host handles the previous one's survivors.
+ * The result calls (psk_get_results, psk_export_survivors*) read the last scan ENDED; a psk_chi2_scan_begin issued
+ * while another scan is in flight reuses that scan's result set (after any asynchronous export of it, on the
+ * device), after which those calls fail with PSK_ESTATE until the next psk_scan_end.  A third _begin, and the
+ * one-call scans while a scan is in flight, fail with PSK_ESTATE. */
 int psk_chi2_scan_begin(psk_ctx *ctx, const int8_t *pheno, const double *weights, int min_samples, int max_samples,
                         double pvalue_cutoff, int omit_B, uint64_t n_kmers_global);
 int psk_scan_end(psk_ctx *ctx, uint64_t *n_pass);
@@ -153,7 +157,7 @@ int psk_get_results(psk_ctx *ctx, uint64_t *row_idx, uint64_t *words, double *st
 int psk_export_survivors(psk_ctx *ctx, void *device_dst, uint64_t cap_records, uint64_t *n_records);
 /* The same export queued on the CALLER's stream (a hipStream_t, e.g. torch's current stream) and not waited for:
  * work queued on that stream afterwards -- the RCCL all-gather -- is ordered behind it without a host
- * synchronisation; the next scan of this context waits on the device for the export to finish. */
+ * synchronisation; the next scan that writes the same result set waits on the device for the export to finish. */
 int psk_export_survivors_async(psk_ctx *ctx, void *device_dst, uint64_t cap_records, void *stream);
 /* HIP-event duration of the last scan kernel launch in milliseconds (for bench.py). */
 double psk_last_scan_ms(const psk_ctx *ctx);

@@ -119,7 +119,7 @@ extern "C" void psk_free(psk_ctx *ctx)
     arena_release(ctx);
     DevBuf *bufs[] = {&ctx->raw, &ctx->keysA, &ctx->keysB, &ctx->valsA, &ctx->valsB, &ctx->hist, &ctx->scan_tmp, &ctx->flags, &ctx->starts,
                       &ctx->misc, &ctx->union_words, &ctx->bits, &ctx->mask1, &ctx->phe,
-                      &ctx->res, &ctx->res_count, &ctx->res_sorted};
+                      &ctx->slot[0].res, &ctx->slot[1].res, &ctx->res_count, &ctx->res_sorted};
     for (DevBuf *b : bufs) dev_release(*b);
     if (ctx->copy_stream) (void)hipStreamSynchronize(ctx->copy_stream);
     for (CountLane &L : ctx->lane) {
@@ -137,7 +137,8 @@ extern "C" void psk_free(psk_ctx *ctx)
     for (void *r : ctx->ring) if (r) (void)hipHostFree(r);
     if (ctx->ev0) (void)hipEventDestroy(ctx->ev0);
     if (ctx->ev1) (void)hipEventDestroy(ctx->ev1);
-    if (ctx->ev_export) (void)hipEventDestroy(ctx->ev_export);
+    for (ScanSlot &sl : ctx->slot)
+        for (hipEvent_t e : {sl.ev0, sl.ev1, sl.ev_export}) if (e) (void)hipEventDestroy(e);
     if (ctx->stream) (void)hipStreamDestroy(ctx->stream);
     delete ctx;
 }

@@ -538,7 +538,7 @@ int group_lanes(int cpr)
 
 // result arrays (SoA) inside ctx->res: row u64 | stat f64 | p f64 | mx f64 | my f64 | nw i32, each
 // SC_NSEG * seg_cap entries; seg_cap bounds the rows the blocks of one segment can visit
-int setup_results(psk_ctx *ctx, ScanArgs &a, dim3 grid, int G, int unroll)
+int setup_results(psk_ctx *ctx, ScanArgs &a, dim3 grid, int G, int unroll, int set)
 {
     const uint64_t rpw = 64 / G;
     const uint64_t n_steps = (a.M + rpw - 1) / rpw;
@@ -549,8 +549,9 @@ int setup_results(psk_ctx *ctx, ScanArgs &a, dim3 grid, int G, int unroll)
     if (seg_cap < 64) seg_cap = 64;
     if (seg_cap >= (1ull << 32)) return psk_fail(ctx, PSK_ERANGE, "result segment too large");
     const uint64_t cap = seg_cap * SC_NSEG;
-    PSK_TRY(dev_reserve(ctx, ctx->res, cap * 44 + 64));
-    uint8_t *b = ctx->res.as<uint8_t>();
+    DevBuf &rb = ctx->slot[set].res;
+    PSK_TRY(dev_reserve(ctx, rb, cap * 44 + 64));
+    uint8_t *b = rb.as<uint8_t>();
     a.res_row = reinterpret_cast<uint64_t *>(b);
     a.res_stat = reinterpret_cast<double *>(b + cap * 8);
     a.res_p = reinterpret_cast<double *>(b + cap * 16);
@@ -558,34 +559,39 @@ int setup_results(psk_ctx *ctx, ScanArgs &a, dim3 grid, int G, int unroll)
     a.res_my = reinterpret_cast<double *>(b + cap * 32);
     a.res_nw = reinterpret_cast<int32_t *>(b + cap * 40);
     if (!ctx->res_count.p) {  // counters re-arm themselves at the end of every scan: zeroed once
-        PSK_TRY(dev_reserve(ctx, ctx->res_count, (SC_NSEG * SC_CNT_STRIDE + SC_NSEG) * 4));
-        PSK_HIP(ctx, hipMemsetAsync(ctx->res_count.p, 0, (SC_NSEG * SC_CNT_STRIDE + SC_NSEG) * 4, ctx->stream));
+        PSK_TRY(dev_reserve(ctx, ctx->res_count, (SC_NSEG * SC_CNT_STRIDE + 2 * SC_NSEG) * 4));
+        PSK_HIP(ctx, hipMemsetAsync(ctx->res_count.p, 0, (SC_NSEG * SC_CNT_STRIDE + 2 * SC_NSEG) * 4, ctx->stream));
     }
-    if (!ctx->cnt_pinned) PSK_HIP(ctx, hipHostMalloc(&ctx->cnt_pinned, SC_NSEG * 4, hipHostMallocDefault));
+    if (!ctx->cnt_pinned) PSK_HIP(ctx, hipHostMalloc(&ctx->cnt_pinned, 2 * SC_NSEG * 4, hipHostMallocDefault));
     a.counter = ctx->res_count.as<uint32_t>();
-    a.final_counts = a.counter + SC_NSEG * SC_CNT_STRIDE;
+    a.final_counts = a.counter + SC_NSEG * SC_CNT_STRIDE + set * SC_NSEG;  // one compact array per result set
     void *hc = nullptr;
     PSK_HIP(ctx, hipHostGetDevicePointer(&hc, ctx->cnt_pinned, 0));
-    a.host_counts = static_cast<uint32_t *>(hc);
+    a.host_counts = static_cast<uint32_t *>(hc) + set * SC_NSEG;
     a.seg_cap = (uint32_t)seg_cap;
-    ctx->res_seg_cap = seg_cap;
+    ctx->slot[set].seg_cap = seg_cap;
+    if (set == ctx->res_set) ctx->results_valid = false;  // the last ended scan's results are about to go
     return PSK_OK;
 }
 
-// per-segment counts as the kernels left them in pinned host memory (after the stream has been synchronised);
-// n_pass = their sum
-int fetch_counts(psk_ctx *ctx, const ScanArgs &a)
+// per-segment counts of the scan that wrote result set `set`, as its kernels left them in pinned host memory (after
+// that scan has been waited for); n_pass = their sum.  The set becomes the one the result calls read.
+int fetch_counts(psk_ctx *ctx, int set)
 {
-    const uint32_t *raw = static_cast<const uint32_t *>(ctx->cnt_pinned);
+    const uint32_t *raw = static_cast<const uint32_t *>(ctx->cnt_pinned) + set * SC_NSEG;
+    const uint64_t seg_cap = ctx->slot[set].seg_cap;
     ctx->seg_counts.assign(SC_NSEG, 0);
     uint64_t tot = 0;
     for (int s = 0; s < SC_NSEG; s++) {
         const uint32_t c = raw[s];
-        if (c > a.seg_cap) return psk_fail(ctx, PSK_ERANGE, "result segment %d overflowed (%u > %u)", s, c, a.seg_cap);
+        if (c > seg_cap) return psk_fail(ctx, PSK_ERANGE, "result segment %d overflowed (%u > %llu)", s, c, (unsigned long long)seg_cap);
         ctx->seg_counts[s] = c;
         tot += c;
     }
     ctx->n_pass = tot;
+    ctx->res_set = set;
+    ctx->res_seg_cap = seg_cap;
+    ctx->results_valid = true;
     return PSK_OK;
 }
 
@@ -621,12 +627,24 @@ dim3 scan_grid(const psk_ctx *ctx, uint64_t M, int G, int unroll)
     return dim3((unsigned)blocks);
 }
 
-// an asynchronous export (psk_export_survivors_async) may still be reading the result arrays on another stream
-int wait_for_export(psk_ctx *ctx)
+// The result set the next scan writes: the one no scan in flight is writing and, if possible, the one no asynchronous
+// export (psk_export_survivors_async) is still reading; if it must be one with an export pending, the scan waits for
+// that export on the device.
+int pick_result_set(psk_ctx *ctx, int *set_out)
 {
-    if (!ctx->export_pending) return PSK_OK;
-    PSK_HIP(ctx, hipStreamWaitEvent(ctx->stream, ctx->ev_export, 0));
-    ctx->export_pending = false;
+    int set;
+    if (ctx->n_in_flight) set = ctx->slot[0].in_flight ? 1 : 0;
+    else set = ctx->slot[ctx->res_set].export_pending ? ctx->res_set ^ 1 : ctx->res_set;
+    ScanSlot &sl = ctx->slot[set];
+    if (sl.export_pending) {
+        PSK_HIP(ctx, hipStreamWaitEvent(ctx->stream, sl.ev_export, 0));
+        sl.export_pending = false;
+    }
+    if (!sl.ev0) {
+        PSK_HIP(ctx, hipEventCreate(&sl.ev0));
+        PSK_HIP(ctx, hipEventCreate(&sl.ev1));
+    }
+    *set_out = set;
     return PSK_OK;
 }
 
@@ -636,7 +654,6 @@ int run_chi2(psk_ctx *ctx, ScanArgs &a, bool weighted, int reps, double *ms_tota
     const dim3 grid = scan_grid(ctx, a.M, G, SC_UNROLL);
     *ms_total = 0;
     for (int r = 0; r < reps; r++) {
-        PSK_TRY(wait_for_export(ctx));
         PSK_HIP(ctx, hipEventRecord(ctx->ev0, ctx->stream));
         if (weighted) launch_chi2<true>(G, grid, ctx->stream, a);
         else launch_chi2<false>(G, grid, ctx->stream, a);
@@ -652,7 +669,7 @@ int run_chi2(psk_ctx *ctx, ScanArgs &a, bool weighted, int reps, double *ms_tota
 
 }  // namespace
 
-static int fill_chi2_args(psk_ctx *ctx, ScanArgs &a)
+static int fill_chi2_args(psk_ctx *ctx, ScanArgs &a, int set)
 {
     const ScanParams &L = ctx->last;
     a = ScanArgs();
@@ -675,7 +692,7 @@ static int fill_chi2_args(psk_ctx *ctx, ScanArgs &a)
     else if (pmax <= 0.0) a.thr = INFINITY;
     else a.thr = -2.0 * log(pmax);
     const int G = group_lanes(a.cpr);
-    return setup_results(ctx, a, scan_grid(ctx, a.M, G, SC_UNROLL), G, SC_UNROLL);
+    return setup_results(ctx, a, scan_grid(ctx, a.M, G, SC_UNROLL), G, SC_UNROLL, set);
 }
 
 // Launches the scan and returns without waiting; psk_scan_end collects it.  Lets a caller queue other work (the
@@ -684,7 +701,7 @@ extern "C" int psk_chi2_scan_begin(psk_ctx *ctx, const int8_t *pheno, const doub
                                    int max_samples, double pvalue_cutoff, int omit_B, uint64_t n_kmers_global)
 {
     if (!ctx) return PSK_EINVAL;
-    if (ctx->scan_in_flight) return psk_fail(ctx, PSK_ESTATE, "a scan is in flight (psk_scan_end first)");
+    if (ctx->n_in_flight >= 2) return psk_fail(ctx, PSK_ESTATE, "two scans are in flight (psk_scan_end first)");
     if (!ctx->have_presence) return psk_fail(ctx, PSK_ESTATE, "no presence matrix (psk_build_presence first)");
     if (!pheno) return psk_fail(ctx, PSK_EINVAL, "null phenotype vector");
     if (n_kmers_global == 0) n_kmers_global = ctx->n_kmers ? ctx->n_kmers : 1;
@@ -693,14 +710,17 @@ extern "C" int psk_chi2_scan_begin(psk_ctx *ctx, const int8_t *pheno, const doub
     // one pinned staging block [m1 | m0 | w1 | w0] and ONE stream-ordered upload (weights only when given)
     const size_t n_mask = 2 * (size_t)wpr, n_w = 2 * (size_t)wpr * 64;
     const size_t stage_bytes = (n_mask + n_w) * 8;
-    if (stage_bytes > ctx->scan_pinned_cap) {
+    int set = 0;
+    PSK_TRY(pick_result_set(ctx, &set));
+    if (2 * stage_bytes > ctx->scan_pinned_cap) {  // one staging block per result set: an upload may still be queued
+        if (ctx->n_in_flight) PSK_HIP(ctx, hipStreamSynchronize(ctx->stream));
         if (ctx->scan_pinned) (void)hipHostFree(ctx->scan_pinned);
         ctx->scan_pinned = nullptr;
         ctx->scan_pinned_cap = 0;
-        PSK_HIP(ctx, hipHostMalloc(&ctx->scan_pinned, stage_bytes, hipHostMallocDefault));
-        ctx->scan_pinned_cap = stage_bytes;
+        PSK_HIP(ctx, hipHostMalloc(&ctx->scan_pinned, 2 * stage_bytes, hipHostMallocDefault));
+        ctx->scan_pinned_cap = 2 * stage_bytes;
     }
-    uint64_t *m1 = static_cast<uint64_t *>(ctx->scan_pinned), *m0 = m1 + wpr;
+    uint64_t *m1 = reinterpret_cast<uint64_t *>(static_cast<uint8_t *>(ctx->scan_pinned) + set * stage_bytes), *m0 = m1 + wpr;
     double *w = reinterpret_cast<double *>(m1 + n_mask);
     memset(m1, 0, weights ? stage_bytes : n_mask * 8);
     double W1 = 0, W0 = 0;
@@ -730,22 +750,27 @@ extern "C" int psk_chi2_scan_begin(psk_ctx *ctx, const int8_t *pheno, const doub
     ctx->last.omit_B = omit_B ? 1 : 0;
     ctx->last.n_kmers_global = n_kmers_global;
     ScanArgs a;
-    PSK_TRY(fill_chi2_args(ctx, a));
+    PSK_TRY(fill_chi2_args(ctx, a, set));
     a.n1 = n1; a.n0 = n0; a.W1 = W1; a.W0 = W0;
     ctx->last.n1 = n1; ctx->last.n0 = n0; ctx->last.W1 = W1; ctx->last.W0 = W0;
-    ctx->n_pass = 0;
     ctx->last_scan_kind = 1;
     if (ctx->n_kmers) {
+        ScanSlot &sl = ctx->slot[set];
         const int G = group_lanes(a.cpr);
         const dim3 grid = scan_grid(ctx, a.M, G, SC_UNROLL);
-        PSK_TRY(wait_for_export(ctx));
-        PSK_HIP(ctx, hipEventRecord(ctx->ev0, ctx->stream));
+        PSK_HIP(ctx, hipEventRecord(sl.ev0, ctx->stream));
         if (ctx->last.weighted) launch_chi2<true>(G, grid, ctx->stream, a);
         else launch_chi2<false>(G, grid, ctx->stream, a);
         PSK_HIP(ctx, hipGetLastError());
-        PSK_HIP(ctx, hipEventRecord(ctx->ev1, ctx->stream));
-        ctx->pending_seg_cap = a.seg_cap;
-        ctx->scan_in_flight = true;
+        PSK_HIP(ctx, hipEventRecord(sl.ev1, ctx->stream));
+        sl.in_flight = true;
+        sl.seq = ++ctx->scan_seq;
+        ctx->n_in_flight++;
+    } else {  // nothing to scan: an empty result, at once
+        ctx->n_pass = 0;
+        ctx->seg_counts.assign(SC_NSEG, 0);
+        ctx->res_set = set;
+        ctx->results_valid = true;
     }
     return PSK_OK;
 }
@@ -753,16 +778,18 @@ extern "C" int psk_chi2_scan_begin(psk_ctx *ctx, const int8_t *pheno, const doub
 extern "C" int psk_scan_end(psk_ctx *ctx, uint64_t *n_pass)
 {
     if (!ctx) return PSK_EINVAL;
-    if (ctx->scan_in_flight) {
+    if (ctx->n_in_flight) {  // the oldest scan in flight
         PSK_HIP(ctx, hipSetDevice(ctx->device));
-        PSK_HIP(ctx, hipStreamSynchronize(ctx->stream));  // the kernel has written the counts to pinned memory
-        ctx->scan_in_flight = false;
+        int set = ctx->slot[0].in_flight ? 0 : 1;
+        if (ctx->slot[0].in_flight && ctx->slot[1].in_flight && ctx->slot[1].seq < ctx->slot[0].seq) set = 1;
+        ScanSlot &sl = ctx->slot[set];
+        PSK_HIP(ctx, hipEventSynchronize(sl.ev1));  // its kernels have written the counts to pinned memory
+        sl.in_flight = false;
+        ctx->n_in_flight--;
         float ms = 0;
-        PSK_HIP(ctx, hipEventElapsedTime(&ms, ctx->ev0, ctx->ev1));
+        PSK_HIP(ctx, hipEventElapsedTime(&ms, sl.ev0, sl.ev1));
         ctx->last_scan_ms = ms;
-        ScanArgs a = ScanArgs();
-        a.seg_cap = ctx->pending_seg_cap;
-        PSK_TRY(fetch_counts(ctx, a));
+        PSK_TRY(fetch_counts(ctx, set));
     }
     if (n_pass) *n_pass = ctx->n_pass;
     return PSK_OK;
@@ -772,6 +799,7 @@ extern "C" int psk_chi2_scan(psk_ctx *ctx, const int8_t *pheno, const double *we
                              int max_samples, double pvalue_cutoff, int omit_B, uint64_t n_kmers_global,
                              uint64_t *n_pass)
 {
+    if (ctx && ctx->n_in_flight) return psk_fail(ctx, PSK_ESTATE, "a scan is in flight (psk_scan_end first)");
     PSK_TRY(psk_chi2_scan_begin(ctx, pheno, weights, min_samples, max_samples, pvalue_cutoff, omit_B, n_kmers_global));
     return psk_scan_end(ctx, n_pass);
 }
@@ -780,18 +808,20 @@ extern "C" int psk_chi2_scan(psk_ctx *ctx, const int8_t *pheno, const double *we
 extern "C" int psk_rescan_timed(psk_ctx *ctx, int reps, double *mean_ms)
 {
     if (!ctx) return PSK_EINVAL;
-    if (ctx->scan_in_flight) return psk_fail(ctx, PSK_ESTATE, "a scan is in flight (psk_scan_end first)");
+    if (ctx->n_in_flight) return psk_fail(ctx, PSK_ESTATE, "a scan is in flight (psk_scan_end first)");
     if (!ctx->have_presence || !ctx->last.valid || ctx->last_scan_kind != 1)
         return psk_fail(ctx, PSK_ESTATE, "no chi2 scan to repeat");
     if (reps < 1) return psk_fail(ctx, PSK_EINVAL, "reps must be >= 1");
     PSK_HIP(ctx, hipSetDevice(ctx->device));
+    int set = 0;
+    PSK_TRY(pick_result_set(ctx, &set));
     ScanArgs a;
-    PSK_TRY(fill_chi2_args(ctx, a));
+    PSK_TRY(fill_chi2_args(ctx, a, set));
     a.n1 = ctx->last.n1; a.n0 = ctx->last.n0; a.W1 = ctx->last.W1; a.W0 = ctx->last.W0;
     double ms = 0;
     PSK_TRY(run_chi2(ctx, a, ctx->last.weighted, reps, &ms));
     ctx->last_scan_ms = ms / reps;
-    PSK_TRY(fetch_counts(ctx, a));
+    PSK_TRY(fetch_counts(ctx, set));
     if (mean_ms) *mean_ms = ms / reps;
     return PSK_OK;
 }
@@ -801,7 +831,7 @@ extern "C" int psk_ttest_scan(psk_ctx *ctx, const double *pheno, const uint8_t *
                               uint64_t *n_pass)
 {
     if (!ctx) return PSK_EINVAL;
-    if (ctx->scan_in_flight) return psk_fail(ctx, PSK_ESTATE, "a scan is in flight (psk_scan_end first)");
+    if (ctx->n_in_flight) return psk_fail(ctx, PSK_ESTATE, "a scan is in flight (psk_scan_end first)");
     if (!ctx->have_presence) return psk_fail(ctx, PSK_ESTATE, "no presence matrix (psk_build_presence first)");
     if (!pheno || !valid) return psk_fail(ctx, PSK_EINVAL, "null phenotype vector");
     if (n_kmers_global == 0) n_kmers_global = ctx->n_kmers ? ctx->n_kmers : 1;
@@ -860,14 +890,15 @@ extern "C" int psk_ttest_scan(psk_ctx *ctx, const double *pheno, const uint8_t *
             }
         a.tcrit = lo * (1.0 - 1e-12);  // err on the side of keeping candidates
     }
+    int set = 0;
+    PSK_TRY(pick_result_set(ctx, &set));
     const int G = group_lanes(a.cpr);
     const dim3 grid = scan_grid(ctx, a.M, G, SC_UNROLL);
-    PSK_TRY(setup_results(ctx, a, grid, G, SC_UNROLL));
+    PSK_TRY(setup_results(ctx, a, grid, G, SC_UNROLL, set));
     ctx->n_pass = 0;
     ctx->last_scan_kind = 2;
     ctx->last.valid = false;
     if (ctx->n_kmers) {
-        PSK_TRY(wait_for_export(ctx));
         PSK_HIP(ctx, hipEventRecord(ctx->ev0, ctx->stream));
         launch_ttest(G, grid, ctx->stream, a, mu, !unit_w);
         PSK_HIP(ctx, hipGetLastError());
@@ -876,7 +907,11 @@ extern "C" int psk_ttest_scan(psk_ctx *ctx, const double *pheno, const uint8_t *
         float ms = 0;
         PSK_HIP(ctx, hipEventElapsedTime(&ms, ctx->ev0, ctx->ev1));
         ctx->last_scan_ms = ms;
-        PSK_TRY(fetch_counts(ctx, a));
+        PSK_TRY(fetch_counts(ctx, set));
+    } else {
+        ctx->seg_counts.assign(SC_NSEG, 0);
+        ctx->res_set = set;
+        ctx->results_valid = true;
     }
     if (n_pass) *n_pass = ctx->n_pass;
     return PSK_OK;
@@ -886,8 +921,8 @@ extern "C" int psk_get_results(psk_ctx *ctx, uint64_t *row_idx, uint64_t *words,
                                double *mean_x, double *mean_y, int32_t *n_with, uint64_t cap)
 {
     if (!ctx) return PSK_EINVAL;
-    if (ctx->scan_in_flight) return psk_fail(ctx, PSK_ESTATE, "a scan is in flight (psk_scan_end first)");
     if (!ctx->last_scan_kind) return psk_fail(ctx, PSK_ESTATE, "no scan has been run");
+    if (!ctx->results_valid) return psk_fail(ctx, PSK_ESTATE, "no ended scan whose results are still held (psk_scan_end first)");
     const uint64_t n = ctx->n_pass;
     if (cap < n) return psk_fail(ctx, PSK_ERANGE, "buffer too small: %llu < %llu", (unsigned long long)cap,
                                  (unsigned long long)n);
@@ -903,7 +938,7 @@ extern "C" int psk_get_results(psk_ctx *ctx, uint64_t *row_idx, uint64_t *words,
         uint32_t *d_cnt = reinterpret_cast<uint32_t *>(aux + SC_NSEG * 8);
         PSK_HIP(ctx, hipMemcpyAsync(aux, offs.data(), SC_NSEG * 8, hipMemcpyHostToDevice, ctx->stream));
         PSK_HIP(ctx, hipMemcpyAsync(d_cnt, ctx->seg_counts.data(), SC_NSEG * 4, hipMemcpyHostToDevice, ctx->stream));
-        pack_segments_kernel<<<SC_NSEG, 256, 0, ctx->stream>>>(ctx->res.as<uint8_t>(), ctx->res_seg_cap * SC_NSEG,
+        pack_segments_kernel<<<SC_NSEG, 256, 0, ctx->stream>>>(ctx->slot[ctx->res_set].res.as<uint8_t>(), ctx->res_seg_cap * SC_NSEG,
                                                              (uint32_t)ctx->res_seg_cap, d_cnt,
                                                              reinterpret_cast<const uint64_t *>(aux),
                                                              ctx->res_sorted.as<uint8_t>(), n,
@@ -993,14 +1028,14 @@ __global__ void export_records_kernel(const uint8_t *__restrict__ res, uint64_t 
 extern "C" int psk_export_survivors(psk_ctx *ctx, void *device_dst, uint64_t cap_records, uint64_t *n_records)
 {
     if (!ctx) return PSK_EINVAL;
-    if (ctx->scan_in_flight) return psk_fail(ctx, PSK_ESTATE, "a scan is in flight (psk_scan_end first)");
     if (!ctx->last_scan_kind) return psk_fail(ctx, PSK_ESTATE, "no scan has been run");
+    if (!ctx->results_valid) return psk_fail(ctx, PSK_ESTATE, "no ended scan whose results are still held (psk_scan_end first)");
     if (!device_dst || cap_records < 1) return psk_fail(ctx, PSK_EINVAL, "bad destination");
     PSK_HIP(ctx, hipSetDevice(ctx->device));
     if (n_records) *n_records = ctx->n_pass;
     export_records_kernel<<<SC_NSEG, SC_NSEG, 0, ctx->stream>>>(
-        ctx->res.as<uint8_t>(), ctx->res_seg_cap * SC_NSEG, (uint32_t)ctx->res_seg_cap,
-        ctx->res_count.as<uint32_t>() + SC_NSEG * SC_CNT_STRIDE, ctx->union_words.as<uint64_t>(), ctx->bits.as<uint64_t>(),
+        ctx->slot[ctx->res_set].res.as<uint8_t>(), ctx->res_seg_cap * SC_NSEG, (uint32_t)ctx->res_seg_cap,
+        ctx->res_count.as<uint32_t>() + SC_NSEG * SC_CNT_STRIDE + ctx->res_set * SC_NSEG, ctx->union_words.as<uint64_t>(), ctx->bits.as<uint64_t>(),
         ctx->wpr, static_cast<uint64_t *>(device_dst),
         cap_records);
     PSK_HIP(ctx, hipGetLastError());
@@ -1014,19 +1049,20 @@ extern "C" int psk_export_survivors(psk_ctx *ctx, void *device_dst, uint64_t cap
 extern "C" int psk_export_survivors_async(psk_ctx *ctx, void *device_dst, uint64_t cap_records, void *stream)
 {
     if (!ctx) return PSK_EINVAL;
-    if (ctx->scan_in_flight) return psk_fail(ctx, PSK_ESTATE, "a scan is in flight (psk_scan_end first)");
     if (!ctx->last_scan_kind) return psk_fail(ctx, PSK_ESTATE, "no scan has been run");
+    if (!ctx->results_valid) return psk_fail(ctx, PSK_ESTATE, "no ended scan whose results are still held (psk_scan_end first)");
     if (!device_dst || cap_records < 1) return psk_fail(ctx, PSK_EINVAL, "bad destination");
     PSK_HIP(ctx, hipSetDevice(ctx->device));
     hipStream_t st = static_cast<hipStream_t>(stream);
-    if (!ctx->ev_export) PSK_HIP(ctx, hipEventCreateWithFlags(&ctx->ev_export, hipEventDisableTiming));
+    hipEvent_t &ev = ctx->slot[ctx->res_set].ev_export;
+    if (!ev) PSK_HIP(ctx, hipEventCreateWithFlags(&ev, hipEventDisableTiming));
     export_records_kernel<<<SC_NSEG, SC_NSEG, 0, st>>>(
-        ctx->res.as<uint8_t>(), ctx->res_seg_cap * SC_NSEG, (uint32_t)ctx->res_seg_cap,
-        ctx->res_count.as<uint32_t>() + SC_NSEG * SC_CNT_STRIDE, ctx->union_words.as<uint64_t>(), ctx->bits.as<uint64_t>(),
+        ctx->slot[ctx->res_set].res.as<uint8_t>(), ctx->res_seg_cap * SC_NSEG, (uint32_t)ctx->res_seg_cap,
+        ctx->res_count.as<uint32_t>() + SC_NSEG * SC_CNT_STRIDE + ctx->res_set * SC_NSEG, ctx->union_words.as<uint64_t>(), ctx->bits.as<uint64_t>(),
         ctx->wpr, static_cast<uint64_t *>(device_dst), cap_records);
     PSK_HIP(ctx, hipGetLastError());
-    PSK_HIP(ctx, hipEventRecord(ctx->ev_export, st));
-    ctx->export_pending = true;
+    PSK_HIP(ctx, hipEventRecord(ev, st));
+    ctx->slot[ctx->res_set].export_pending = true;
     return PSK_OK;
 }
 

@@ -65,14 +65,28 @@ struct ScanParams {  // what psk_rescan_timed needs to re-launch the last chi2 s
     double W1 = 0, W0 = 0;   // class weight totals
 };
 
+// One of the two result sets of the scans.
+struct ScanSlot {
+    DevBuf res;                      // SoA result arrays (setup_results)
+    hipEvent_t ev0 = nullptr, ev1 = nullptr;   // around the scan's kernels
+    hipEvent_t ev_export = nullptr;  // recorded on the caller's stream after an asynchronous export of this set
+    bool export_pending = false;     // the next scan that writes this set waits for ev_export on the device
+    bool in_flight = false;
+    uint64_t seq = 0;                // launch order
+    uint64_t seg_cap = 0;            // entries per result segment of the scan that wrote this set
+};
+
 struct psk_ctx {
     int device = 0;
     hipStream_t stream = nullptr;
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
-    hipEvent_t ev_export = nullptr;   // recorded on the caller's stream after an asynchronous survivor export
-    bool scan_in_flight = false;      // psk_chi2_scan_begin without its psk_scan_end yet
-    uint32_t pending_seg_cap = 0;
-    bool export_pending = false;      // the next scan must wait for it before it overwrites the result arrays
+    // Two result sets, so that up to two scans can be in flight (psk_chi2_scan_begin twice before psk_scan_end) and
+    // the asynchronous export of scan i's survivors overlaps scan i + 1: see ScanSlot.
+    ScanSlot slot[2];
+    int res_set = 0;                  // set of the last scan ENDED (= the one the result calls read)
+    bool results_valid = false;       // false once a later psk_chi2_scan_begin has taken that set again
+    int n_in_flight = 0;              // scans launched and not yet ended (0..2)
+    uint64_t scan_seq = 0;
     std::string err;
     int n_cu = 0;
 
@@ -102,7 +116,7 @@ struct psk_ctx {
     bool have_presence = false;
 
     // scan state
-    DevBuf mask1, phe, res, res_count, res_sorted;
+    DevBuf mask1, phe, res_count, res_sorted;
     uint64_t n_pass = 0;
     uint64_t res_seg_cap = 0;            // entries per result segment of the last scan
     std::vector<uint32_t> seg_counts;    // survivors per segment

@@ -36,5 +36,24 @@ with PskContext(0) as ctx:
     s1, _ = x.start(ctx)
     a, b = x.finish(s0), x.finish(s1)
     assert np.array_equal(a[0]["word"], ref["word"]) and np.array_equal(b[0]["word"], ref["word"])
+    # the multi-GPU step as bench.py runs it: two scans in flight, export + all-gather of scan i under scan i + 1,
+    # alternating phenotypes so that a mixed-up result set would show
+    phs = [ph, (np.arange(n) % 3 == 0).astype(np.int8)]
+    want = []
+    for q in phs:
+        c = ctx.chi2_scan(q, None, 2, n - 2, 0.05, False, m)
+        want.append(ctx.get_results(c)["word"])
+    assert not np.array_equal(want[0], want[1])
+    steps, slots = 9, []
+    ctx.chi2_scan_begin(phs[0], None, 2, n - 2, 0.05, False, m)
+    ctx.chi2_scan_begin(phs[1], None, 2, n - 2, 0.05, False, m)
+    for i in range(steps):
+        ctx.scan_end()
+        s = x.export(ctx)
+        if i + 2 < steps:
+            ctx.chi2_scan_begin(phs[i % 2], None, 2, n - 2, 0.05, False, m)
+        x.collect(s)
+        got = x.finish(s)
+        assert np.array_equal(got[0]["word"], want[i % 2]), i
 g.close()
 print("exchange ok", npass)

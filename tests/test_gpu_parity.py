@@ -312,6 +312,40 @@ def test_full_size_scan_properties(ctx):
         assert ra["stat"][j] == pytest.approx(chi, rel=1e-9)
 
 
+def test_two_scans_in_flight_equal_the_one_call_scans(ctx):
+    """psk_chi2_scan_begin twice, then psk_scan_end twice (two result sets): each ended scan's survivors equal the
+    one-call scan's, ends come in launch order, unweighted and weighted (per-set staging of masks and weights),
+    and the state errors of include/psk.h hold."""
+    n, m = 200, 400_000
+    ctx.synth_presence(m, n, seed=21)
+    rng = np.random.default_rng(5)
+    phs = [(np.arange(n) % 2).astype(np.int8), (rng.random(n) < 0.4).astype(np.int8),
+           np.where(rng.random(n) < 0.1, -1, (np.arange(n) // 3) % 2).astype(np.int8)]
+    for w in (None, rng.uniform(0.2, 3.0, n)):
+        want = []
+        for ph in phs:
+            c = ctx.chi2_scan(ph, w, 2, n - 2, 0.05, False, m)
+            want.append((c, ctx.get_results(c)))
+        assert want[0][0] > 0
+        ctx.chi2_scan_begin(phs[0], w, 2, n - 2, 0.05, False, m)
+        ctx.chi2_scan_begin(phs[1], w, 2, n - 2, 0.05, False, m)
+        with pytest.raises(RuntimeError):
+            ctx.chi2_scan_begin(phs[2], w, 2, n - 2, 0.05, False, m)       # a third
+        with pytest.raises(RuntimeError):
+            ctx.chi2_scan(phs[2], w, 2, n - 2, 0.05, False, m)             # one-call scan while scans are in flight
+        for i in range(3):
+            c = ctx.scan_end()
+            got = ctx.get_results(c)
+            assert c == want[i][0]
+            for key in ("row", "word", "stat", "p", "n_with"):
+                assert np.array_equal(got[key], want[i][1][key]), (i, key)
+            if i == 0:
+                ctx.chi2_scan_begin(phs[2], w, 2, n - 2, 0.05, False, m)   # takes the set just read
+                with pytest.raises(RuntimeError):
+                    ctx.get_results(c)                                      # ... whose results are gone
+        assert ctx.scan_end() == want[2][0]                                 # none in flight: the last count again
+
+
 def _pattern_sums(X, w):
     """coefficient mass per distinct column pattern (identical columns share it arbitrarily)"""
     pats = {}

@@ -28,11 +28,24 @@ with PskContext(0) as ctx:
     ph = (np.arange(n) % 2).astype(np.int8)
     x = dist.SurvivorExchange(g, ctx.presence_shape()[1], cap_records=1 << 20)
     args = (ph, None, 2, n - 2, 0.05, False, m)
-    for mode in ("scan only", "scan + export + all-gather", "the same, next scan launched before the all-gather is queued"):
+    for mode in ("scan only", "scan + export + all-gather", "the same, next scan launched before the all-gather is queued",
+                 "the same, two scans in flight"):
         pending = []
         for rep in range(2):
             t = time.perf_counter()
-            if mode.startswith("the same"):
+            if mode.endswith("two scans in flight"):
+                ctx.chi2_scan_begin(*args)
+                ctx.chi2_scan_begin(*args)
+                for i in range(100):
+                    ctx.scan_end()
+                    s = x.export(ctx)
+                    if i + 2 < 100:
+                        ctx.chi2_scan_begin(*args)
+                    x.collect(s)
+                    pending.append(s)
+                    if len(pending) > 1:
+                        x.wait(pending.pop(0))
+            elif mode.startswith("the same"):
                 ctx.chi2_scan_begin(*args)
                 for i in range(100):
                     ctx.scan_end()
