@@ -195,28 +195,25 @@ def main():
     ctx.rescan_timed(300)
 
     def run_steps(count):
-        """`count` steps; returns (survivors of the last scan, kernel ms of every scan).  N = 1: scan, that is all.
-        N > 1: two scans are kept in flight (psk_chi2_scan_begin twice, two result sets), so the host-side work of
-        the exchange -- wait for scan i, pack its survivors, queue the all-gather -- happens while scan i + 1 streams
-        its matrix; every step still consists of one scan, one export and one all-gather."""
+        """`count` steps; returns (survivors of the last scan, kernel ms of every scan).  Two scans are kept in flight
+        (psk_chi2_scan_begin twice, two result sets -- what modeling.py does over the phenotypes of a run), so the
+        host's part of a step -- wait for scan i and read its survivor count; N > 1: pack the survivors and queue the
+        all-gather -- happens while scan i + 1 streams its matrix.  Every step is one whole scan whose count reaches
+        the host inside the timed region, plus, for N > 1, one export and one all-gather."""
         ms_all, npass = [], 0
-        if xch is None:
-            for _ in range(count):
-                npass = ctx.chi2_scan(*scan_args)
-                ms_all.append(ctx.last_scan_ms())
-            return npass, ms_all
         for _ in range(min(2, count)):
             ctx.chi2_scan_begin(*scan_args)
         for i in range(count):
             npass = ctx.scan_end()
             ms_all.append(ctx.last_scan_ms())
-            s_ = xch.export(ctx)
+            s_ = xch.export(ctx) if xch is not None else None
             if i + 2 < count:
                 ctx.chi2_scan_begin(*scan_args)
-            xch.collect(s_)
-            pending.append(s_)
-            if len(pending) > 1:
-                xch.wait(pending.pop(0))
+            if xch is not None:
+                xch.collect(s_)
+                pending.append(s_)
+                if len(pending) > 1:
+                    xch.wait(pending.pop(0))
         return npass, ms_all
 
     npass, _ = run_steps(args.warmup) if args.warmup > 0 else (0, [])

@@ -129,10 +129,12 @@ int psk_chi2_scan(psk_ctx *ctx, const int8_t *pheno, const double *weights, int 
  * yields its number of surviving k-mers (with none in flight: the last count again).  Up to two scans may be in
  * flight -- there are two result sets -- so the multi-GPU step runs begin(i+1), end(i), export(i), begin(i+2),
  * all-gather(i): the device always has the next scan queued while the host handles the previous one's survivors.
- * The result calls (psk_get_results, psk_export_survivors*) read the last scan ENDED; a psk_chi2_scan_begin issued
- * while another scan is in flight reuses that scan's result set (after any asynchronous export of it, on the
- * device), after which those calls fail with PSK_ESTATE until the next psk_scan_end.  A third _begin, and the
- * one-call scans while a scan is in flight, fail with PSK_ESTATE. */
+ * The result calls (psk_get_results, psk_export_survivors*) read the last scan ENDED.  A psk_chi2_scan_begin issued
+ * with no scan in flight takes the OTHER result set, so the next scan can be launched before the last one's results
+ * are read (the pipeline over phenotypes: end(j), begin(j+1), read j); issued while a scan is in flight it takes
+ * the set of the last scan ended (after any asynchronous export of it, on the device), and the result calls fail
+ * with PSK_ESTATE until the next psk_scan_end.  A third _begin, and the one-call scans while a scan is in flight,
+ * fail with PSK_ESTATE. */
 int psk_chi2_scan_begin(psk_ctx *ctx, const int8_t *pheno, const double *weights, int min_samples, int max_samples,
                         double pvalue_cutoff, int omit_B, uint64_t n_kmers_global);
 int psk_scan_end(psk_ctx *ctx, uint64_t *n_pass);

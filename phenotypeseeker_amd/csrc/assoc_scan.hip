@@ -627,14 +627,16 @@ dim3 scan_grid(const psk_ctx *ctx, uint64_t M, int G, int unroll)
     return dim3((unsigned)blocks);
 }
 
-// The result set the next scan writes: the one no scan in flight is writing and, if possible, the one no asynchronous
-// export (psk_export_survivors_async) is still reading; if it must be one with an export pending, the scan waits for
-// that export on the device.
-int pick_result_set(psk_ctx *ctx, int *set_out)
+// The result set the next scan writes: the one no scan in flight is writing; with none in flight, the one no
+// asynchronous export (psk_export_survivors_async) is still reading and -- keep_results, the two-call form -- not the
+// one that holds the last ended scan's results, so that the caller can launch the next scan BEFORE it reads those.
+// If the set has an export pending, the scan waits for that export on the device.
+int pick_result_set(psk_ctx *ctx, int *set_out, bool keep_results = false)
 {
     int set;
     if (ctx->n_in_flight) set = ctx->slot[0].in_flight ? 1 : 0;
-    else set = ctx->slot[ctx->res_set].export_pending ? ctx->res_set ^ 1 : ctx->res_set;
+    else if (ctx->slot[ctx->res_set].export_pending || (keep_results && ctx->results_valid)) set = ctx->res_set ^ 1;
+    else set = ctx->res_set;
     ScanSlot &sl = ctx->slot[set];
     if (sl.export_pending) {
         PSK_HIP(ctx, hipStreamWaitEvent(ctx->stream, sl.ev_export, 0));
@@ -697,8 +699,8 @@ static int fill_chi2_args(psk_ctx *ctx, ScanArgs &a, int set)
 
 // Launches the scan and returns without waiting; psk_scan_end collects it.  Lets a caller queue other work (the
 // survivor exchange of the previous scan) while the kernel streams the matrix.
-extern "C" int psk_chi2_scan_begin(psk_ctx *ctx, const int8_t *pheno, const double *weights, int min_samples,
-                                   int max_samples, double pvalue_cutoff, int omit_B, uint64_t n_kmers_global)
+static int chi2_scan_launch(psk_ctx *ctx, const int8_t *pheno, const double *weights, int min_samples, int max_samples,
+                            double pvalue_cutoff, int omit_B, uint64_t n_kmers_global, bool keep_results)
 {
     if (!ctx) return PSK_EINVAL;
     if (ctx->n_in_flight >= 2) return psk_fail(ctx, PSK_ESTATE, "two scans are in flight (psk_scan_end first)");
@@ -711,7 +713,7 @@ extern "C" int psk_chi2_scan_begin(psk_ctx *ctx, const int8_t *pheno, const doub
     const size_t n_mask = 2 * (size_t)wpr, n_w = 2 * (size_t)wpr * 64;
     const size_t stage_bytes = (n_mask + n_w) * 8;
     int set = 0;
-    PSK_TRY(pick_result_set(ctx, &set));
+    PSK_TRY(pick_result_set(ctx, &set, keep_results));
     if (2 * stage_bytes > ctx->scan_pinned_cap) {  // one staging block per result set: an upload may still be queued
         if (ctx->n_in_flight) PSK_HIP(ctx, hipStreamSynchronize(ctx->stream));
         if (ctx->scan_pinned) (void)hipHostFree(ctx->scan_pinned);
@@ -775,6 +777,12 @@ extern "C" int psk_chi2_scan_begin(psk_ctx *ctx, const int8_t *pheno, const doub
     return PSK_OK;
 }
 
+extern "C" int psk_chi2_scan_begin(psk_ctx *ctx, const int8_t *pheno, const double *weights, int min_samples,
+                                   int max_samples, double pvalue_cutoff, int omit_B, uint64_t n_kmers_global)
+{
+    return chi2_scan_launch(ctx, pheno, weights, min_samples, max_samples, pvalue_cutoff, omit_B, n_kmers_global, true);
+}
+
 extern "C" int psk_scan_end(psk_ctx *ctx, uint64_t *n_pass)
 {
     if (!ctx) return PSK_EINVAL;
@@ -800,7 +808,7 @@ extern "C" int psk_chi2_scan(psk_ctx *ctx, const int8_t *pheno, const double *we
                              uint64_t *n_pass)
 {
     if (ctx && ctx->n_in_flight) return psk_fail(ctx, PSK_ESTATE, "a scan is in flight (psk_scan_end first)");
-    PSK_TRY(psk_chi2_scan_begin(ctx, pheno, weights, min_samples, max_samples, pvalue_cutoff, omit_B, n_kmers_global));
+    PSK_TRY(chi2_scan_launch(ctx, pheno, weights, min_samples, max_samples, pvalue_cutoff, omit_B, n_kmers_global, false));
     return psk_scan_end(ctx, n_pass);
 }
 

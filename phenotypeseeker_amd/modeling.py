@@ -339,6 +339,7 @@ class phenotypes:
         self.rows = None      # surviving k-mers of the scan (dict of arrays + kmer strings)
         self.ML = None        # selected design matrix etc.
         self.model_fitted = None
+        self._scan_launched = False
 
     # ---- association scan ----------------------------------------------------------------------
     @classmethod
@@ -364,16 +365,30 @@ class phenotypes:
                 vals[i], valid[i] = float(v), 1
         return vals, valid, (None if unit else weights)
 
-    def test_kmers_association_with_phenotype(self, ctx, group):
+    def launch_scan(self, ctx):
+        """Binary phenotypes: queues this phenotype's scan (psk_chi2_scan_begin) without waiting, so that it streams
+        the matrix while the host formats the previous phenotype's survivors."""
+        if self.pred_scale != "binary" or self._scan_launched:
+            return
+        a, _, w = self._phenotype_vectors()
+        ctx.chi2_scan_begin(a, w, Samples.min_samples, Samples.max_samples, self.pvalue_cutoff, self.omit_B,
+                            self.no_kmers_to_analyse)
+        self._scan_launched = True
+
+    def test_kmers_association_with_phenotype(self, ctx, group, nxt=None):
         """was: Pool.map(get_kmers_tested) over text chunks (:659-714).  One scan kernel launch
         per phenotype; with several GPUs every rank scans its slab and the survivors are
-        all-gathered in slab order."""
+        all-gathered in slab order.  `nxt`: the phenotype scanned next, launched as soon as this one's
+        scan has ended (its results live in the context's other result set)."""
         start = time.time()
         n = Samples.no_samples
         a, b, w = self._phenotype_vectors()
         if self.pred_scale == "binary":
-            npass = ctx.chi2_scan(a, w, Samples.min_samples, Samples.max_samples, self.pvalue_cutoff, self.omit_B,
-                                  self.no_kmers_to_analyse)
+            self.launch_scan(ctx)
+            npass = ctx.scan_end()
+            self._scan_launched = False
+            if nxt is not None and group.world == 1:
+                nxt.launch_scan(ctx)
         else:
             npass = ctx.ttest_scan(a, b, w, Samples.min_samples, Samples.max_samples, self.pvalue_cutoff,
                                    self.no_kmers_to_analyse)
@@ -729,8 +744,9 @@ def modeling(args):
                 stderr_print(GREEN % "Calculating the GSC weights from mash distance matrix...")
                 Samples.get_weights(ctx)
             phenotypes.kmer_testing_setup(group.allreduce_sum(int(m_local)))
-            for ph in Input.phenotypes_to_analyse.values():
-                ph.test_kmers_association_with_phenotype(ctx, group)
+            phs = list(Input.phenotypes_to_analyse.values())
+            for j, ph in enumerate(phs):
+                ph.test_kmers_association_with_phenotype(ctx, group, phs[j + 1] if j + 1 < len(phs) else None)
             Input.pop_phenos_out_of_kmers()
         # 'modelling' / 'modeling' both run the model stage; 'PCA' runs nothing (:1689)
         if not Input.jump_to or Input.jump_to in ("modelling", "modeling"):

@@ -342,3 +342,35 @@ def test_two_rank_modeling_writes_the_same_files(tmp_path):
     a, b = joblib.load(str(one / "log_reg_model_Pheno.pkl")), joblib.load(str(two / "log_reg_model_Pheno.pkl"))
     assert list(a["kmers"]) == list(b["kmers"])
     assert np.array_equal(a["model"].best_estimator_.coef_, b["model"].best_estimator_.coef_)
+
+
+def test_several_phenotypes_in_one_run_equal_one_run_each(tmp_path):
+    """The phenotypes of one `modeling` run are scanned as a pipeline (the scan of phenotype j + 1 is launched before
+    the survivors of j are read: two result sets in the context); every phenotype's files must equal those of a run
+    on that phenotype alone (--mpheno)."""
+    ds = load_dataset("ds_bonf")
+    both = tmp_path / "all"
+    both.mkdir()
+    _write_dataset(ds, str(both))
+    lines = open(both / "data.pheno").read().splitlines()
+    rng = np.random.default_rng(3)
+    head = lines[0].split("\t") + ["Flip", "Third", "Rand"]
+    rows = []
+    for i, l in enumerate(lines[1:]):
+        f = l.split("\t")
+        v = int(f[2]) if f[2] != "NA" else i % 2
+        rows.append(f + [str(1 - v), str(v if i % 5 else 1 - v), "NA" if i % 7 == 0 else str(int(rng.random() < 0.5))])
+    txt = "\n".join(["\t".join(head)] + ["\t".join(r) for r in rows]) + "\n"
+    open(both / "data.pheno", "w").write(txt)
+    _run(both, ["modeling", "data.pheno", "--pvalue", "0.5", "--omit_B_correction"])
+    for col, name in enumerate(head[2:], start=1):
+        one = tmp_path / ("only%d" % col)
+        one.mkdir()
+        _write_dataset(ds, str(one))
+        open(one / "data.pheno", "w").write(txt)
+        _run(one, ["modeling", "data.pheno", "--pvalue", "0.5", "--omit_B_correction", "--mpheno", str(col)])
+        for fn in ("chi2_results_%s.tsv" % name, "%s_MLdf.csv" % name,
+                   "k-mers_and_coefficients_in_log_reg_model_%s.txt" % name):
+            if os.path.exists(one / fn) or os.path.exists(both / fn):
+                assert open(one / fn).read() == open(both / fn).read(), fn
+        assert os.path.exists(both / ("chi2_results_%s.tsv" % name))
