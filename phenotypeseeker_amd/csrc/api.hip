@@ -123,9 +123,11 @@ extern "C" void psk_free(psk_ctx *ctx)
     for (DevBuf *b : bufs) dev_release(*b);
     if (ctx->copy_stream) (void)hipStreamSynchronize(ctx->copy_stream);
     for (CountLane &L : ctx->lane) {
-        DevBuf *lb[] = {&L.raw, &L.keysA, &L.keysB, &L.starts, &L.cnt};
+        DevBuf *lb[] = {&L.raw, &L.keysA, &L.keysB, &L.starts, &L.cnt, &L.sk_cand, &L.sk_out};
         for (DevBuf *b : lb) dev_release(*b);
         if (L.pinned_cnt) (void)hipHostFree(L.pinned_cnt);
+        if (L.sk_host) (void)hipHostFree(L.sk_host);
+        if (L.sk_done) (void)hipEventDestroy(L.sk_done);
         if (L.done) (void)hipEventDestroy(L.done);
         if (L.raw_ready) (void)hipEventDestroy(L.raw_ready);
         if (L.raw_free) (void)hipEventDestroy(L.raw_free);

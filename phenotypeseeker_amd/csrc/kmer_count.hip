@@ -684,6 +684,9 @@ extern "C" int psk_count_kmers(psk_ctx *ctx, int sample_idx, const uint8_t *byte
 
 // Batch form: `n_threads` host threads frame samples ahead into a ring of pinned buffers while the calling
 // thread drives the GPU half of the samples in order, so host tokenisation overlaps device work.
+int sketch_enqueue(psk_ctx *ctx, CountLane &L, const uint8_t *d_clean, uint64_t clean_len, int k, int sketch_size, uint32_t seed);
+int sketch_collect(psk_ctx *ctx, CountLane &L, const uint8_t *d_clean, uint64_t clean_len, int k, int sketch_size,
+                   uint32_t seed, uint64_t *hashes_out, uint64_t *n_out);
 int sketch_from_device(psk_ctx *ctx, const uint8_t *d_clean, uint64_t clean_len, int k, int sketch_size, uint32_t seed,
                        uint64_t *hashes_out, uint64_t *n_out);  // minhash.hip
 
@@ -795,7 +798,14 @@ static int count_batch_impl(psk_ctx *ctx, int first_sample_idx, int n, const uin
         if (n_unique) n_unique[i] = ctx->lists[first_sample_idx + i].n_unique;
         if (n_total) n_total[i] = ctx->lists[first_sample_idx + i].n_total;
     };
-    for (CountLane &L : ctx->lane) L.sample = -1;
+    for (CountLane &L : ctx->lane) { L.sample = -1; L.sk_state = 0; }
+    // clean-stream length the sketch of sample i reads (0: nothing was uploaded for it)
+    auto sk_len = [&](int i) -> uint64_t { return wins[i] ? clen[i] : 0; };
+    auto collect_sketch = [&](int i) {
+        CountLane &L = ctx->lane[i & 1];
+        return sketch_collect(ctx, L, L.raw.as<uint8_t>(), sk_len(i), sketch_k, sketch_size, sketch_seed,
+                              hashes_out + (size_t)i * sketch_size, n_hashes_out + i);
+    };
     for (int i = 0; i < n && rc == PSK_OK; i++) {
         {
             std::unique_lock<std::mutex> lk(mu);
@@ -811,20 +821,18 @@ static int count_batch_impl(psk_ctx *ctx, int first_sample_idx, int n, const uin
         if (rc == PSK_OK && i > 0) {
             rc = chain_finalize(ctx, ctx->lane[(i - 1) & 1]);  // waits for chain i - 1: its upload is done too
             if (rc == PSK_OK) report(i - 1);
+            if (rc == PSK_OK && sketch_k) rc = collect_sketch(i - 1);
             release_upto(i);
         }
-        if (rc == PSK_OK && sketch_k) {
-            // stream-ordered after the chain just queued; host-synchronous, so this lane's clean stream is not
-            // overwritten (sample i + 2) before the sketch has read it
-            n_hashes_out[i] = 0;
-            if (wins[i] > 0 || clen[i] > 0)
-                rc = sketch_from_device(ctx, ctx->lane[i & 1].raw.as<uint8_t>(), wins[i] ? clen[i] : 0, sketch_k, sketch_size,
-                                        sketch_seed, hashes_out + (size_t)i * sketch_size, n_hashes_out + i);
-        }
+        // the sketch of sample i: queued behind its chain, collected one sample later (after chain i + 1 has been
+        // queued, so the stream never runs dry; before sample i + 2 is uploaded into this lane's clean-stream buffer)
+        if (rc == PSK_OK && sketch_k)
+            rc = sketch_enqueue(ctx, ctx->lane[i & 1], ctx->lane[i & 1].raw.as<uint8_t>(), sk_len(i), sketch_k, sketch_size, sketch_seed);
     }
     if (rc == PSK_OK && n > 0) {
         rc = chain_finalize(ctx, ctx->lane[(n - 1) & 1]);
         if (rc == PSK_OK) report(n - 1);
+        if (rc == PSK_OK && sketch_k) rc = collect_sketch(n - 1);
     }
     {   // nothing of this call may still be in flight when it returns (the ring and the caller's buffers)
         const hipError_t e1 = hipStreamSynchronize(ctx->copy_stream ? ctx->copy_stream : ctx->stream);

@@ -71,10 +71,14 @@ __global__ void kmer_hash_kernel(uint64_t *__restrict__ words, uint64_t n, int k
 
 // hash every word and keep (append, unordered) only the hashes <= limit: the bottom-s sketch of n uniform
 // hashes lies below ~ s/n of the hash space, so a limit at 8 s/n keeps ~8 s candidates instead of sorting all n
-__global__ void kmer_hash_filter_kernel(const uint64_t *__restrict__ words, uint64_t n, int k, uint64_t seed, uint64_t mask,
-                                        uint64_t limit, uint64_t *__restrict__ out, uint32_t *__restrict__ n_out)
+// (n_dev: the word count when only the device knows it, n then bounds the launch; cap: entries `out` holds -- the
+// count keeps running beyond it, so the reader sees the overflow)
+__global__ void kmer_hash_filter_kernel(const uint64_t *__restrict__ words, uint64_t n, const uint32_t *__restrict__ n_dev,
+                                        int k, uint64_t seed, uint64_t mask, uint64_t limit, uint64_t *__restrict__ out,
+                                        uint32_t cap, uint32_t *__restrict__ n_out)
 {
     const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (n_dev) n = *n_dev;
     uint64_t h = 0;
     bool keep = false;
     if (i < n) {
@@ -87,7 +91,60 @@ __global__ void kmer_hash_filter_kernel(const uint64_t *__restrict__ words, uint
     uint32_t base = 0;
     if (lane == 0) base = atomicAdd(n_out, (uint32_t)__popcll(bal));
     base = __shfl(base, 0, 64);
-    if (keep) out[base + __popcll(bal & psk_lanemask_lt(lane))] = h;
+    const uint32_t at = base + (uint32_t)__popcll(bal & psk_lanemask_lt(lane));
+    if (keep && at < cap) out[at] = h;
+}
+
+// One workgroup: sorts the (few thousand) candidate hashes in LDS and writes the `s` smallest distinct ones.
+// res[0] = number of distinct candidates, or ~0 when the candidates do not fit / are fewer than s (the caller then
+// takes the general route); res[1 .. s] = the sketch.
+constexpr int SK_CAND_CAP = 8192;
+constexpr int SK_THREADS = 1024;
+__global__ __launch_bounds__(SK_THREADS) void sketch_select_kernel(const uint64_t *__restrict__ cand,
+                                                                    const uint32_t *__restrict__ n_cand, uint32_t s,
+                                                                    uint64_t *__restrict__ res)
+{
+    __shared__ uint64_t a[SK_CAND_CAP];
+    __shared__ uint32_t wave_tot[SK_THREADS / 64];
+    const uint32_t c = *n_cand;
+    const int tid = threadIdx.x;
+    if (c > (uint32_t)SK_CAND_CAP || c < s) {
+        if (tid == 0) res[0] = ~0ull;
+        return;
+    }
+    uint32_t P = SK_THREADS;  // power of two >= c, at least one element per thread
+    while (P < c) P <<= 1;
+    for (uint32_t i = tid; i < P; i += SK_THREADS) a[i] = i < c ? cand[i] : ~0ull;  // pads sort to the end
+    __syncthreads();
+    for (uint32_t len = 2; len <= P; len <<= 1)
+        for (uint32_t inc = len >> 1; inc > 0; inc >>= 1) {
+            for (uint32_t t = tid; t < P / 2; t += SK_THREADS) {
+                const uint32_t lo = ((t & ~(inc - 1)) << 1) | (t & (inc - 1)), hi = lo | inc;
+                const bool up = (lo & len) == 0;
+                const uint64_t x = a[lo], y = a[hi];
+                if ((x > y) == up) { a[lo] = y; a[hi] = x; }
+            }
+            __syncthreads();
+        }
+    // distinct values in order: thread t owns the consecutive elements [t * per, (t + 1) * per)
+    const uint32_t per = P / SK_THREADS, i0 = tid * per;
+    uint32_t heads = 0;
+    for (uint32_t i = i0; i < i0 + per; i++) heads += (i < c && (i == 0 || a[i] != a[i - 1])) ? 1u : 0u;
+    const int lane = tid & 63, wave = tid >> 6;
+    const uint32_t incl = psk_wave_incl_scan_u32(heads, lane);
+    if (lane == 63) wave_tot[wave] = incl;
+    __syncthreads();
+    uint32_t before = incl - heads, total = 0;
+    for (int w = 0; w < SK_THREADS / 64; w++) {
+        if (w < wave) before += wave_tot[w];
+        total += wave_tot[w];
+    }
+    for (uint32_t i = i0; i < i0 + per; i++)
+        if (i < c && (i == 0 || a[i] != a[i - 1])) {
+            if (before < s) res[1 + before] = a[i];
+            before++;
+        }
+    if (tid == 0) res[0] = total;
 }
 
 __global__ void head_flags_kernel(const uint64_t *__restrict__ keys, uint64_t n, uint32_t *__restrict__ flags)
@@ -137,8 +194,8 @@ int sketch_from_device(psk_ctx *ctx, const uint8_t *d_clean, uint64_t clean_len,
     if (ratio < 0.5) {
         const uint64_t limit = wide ? (uint64_t)(ratio * 18446744073709551616.0) : (uint64_t)(ratio * 4294967296.0);
         PSK_TRY(dev_reserve(ctx, ctx->valsA, n * 8));  // worst case: every hash is a candidate
-        kmer_hash_filter_kernel<<<div_up(n, 256), 256, 0, ctx->stream>>>(ctx->keysA.as<uint64_t>(), n, k, (uint64_t)seed, mask,
-                                                                       limit, ctx->valsA.as<uint64_t>(), d_n + 1);
+        kmer_hash_filter_kernel<<<div_up(n, 256), 256, 0, ctx->stream>>>(ctx->keysA.as<uint64_t>(), n, nullptr, k, (uint64_t)seed,
+                                                                       mask, limit, ctx->valsA.as<uint64_t>(), (uint32_t)n, d_n + 1);
         PSK_HIP(ctx, hipGetLastError());
         uint32_t c32 = 0;
         PSK_HIP(ctx, hipMemcpyAsync(&c32, d_n + 1, 4, hipMemcpyDeviceToHost, ctx->stream));
@@ -182,6 +239,68 @@ int sketch_from_device(psk_ctx *ctx, const uint8_t *d_clean, uint64_t clean_len,
         return PSK_OK;
     }
     return psk_fail(ctx, PSK_ESTATE, "sketch: unreachable");
+}
+
+// The batch counter's form of the same sketch: queued on the context's stream behind the counting chain of the
+// sample and NOT waited for.  extract (sketch k) -> hash + filter at 6 s / clean_len of the hash space (~6 s
+// candidates) -> one-workgroup LDS sort + distinct select -> result to pinned memory.  sketch_collect reads it one
+// sample later and falls back to sketch_from_device (tiny or very repetitive samples, sketch sizes whose candidates
+// do not fit the LDS sort) while the sample's clean stream is still in its lane.
+int sketch_enqueue(psk_ctx *ctx, CountLane &L, const uint8_t *d_clean, uint64_t clean_len, int k, int sketch_size, uint32_t seed)
+{
+    L.sk_state = 2;
+    if (clean_len == 0) return PSK_OK;
+    if (clean_len >= (1ull << 32)) return psk_fail(ctx, PSK_ERANGE, "sample larger than 4 Gbases");
+    const double ratio = 6.0 * (double)sketch_size / (double)clean_len;
+    if (!(ratio < 0.5) || 6ull * (uint64_t)sketch_size + 600 > (uint64_t)SK_CAND_CAP) return PSK_OK;  // general route
+    const bool wide = (k > 16);
+    const uint64_t mask = wide ? ~0ull : 0xffffffffull;
+    const uint64_t limit = wide ? (uint64_t)(ratio * 18446744073709551616.0) : (uint64_t)(ratio * 4294967296.0);
+    const size_t res_bytes = (1 + (size_t)sketch_size) * 8;
+    PSK_TRY(dev_reserve(ctx, ctx->keysA, clean_len * 8));
+    PSK_TRY(dev_reserve(ctx, L.sk_cand, 16 + (size_t)SK_CAND_CAP * 8));
+    PSK_TRY(dev_reserve(ctx, L.sk_out, res_bytes));
+    if (res_bytes > L.sk_host_cap) {
+        if (L.sk_host) (void)hipHostFree(L.sk_host);
+        L.sk_host = nullptr;
+        L.sk_host_cap = 0;
+        PSK_HIP(ctx, hipHostMalloc(reinterpret_cast<void **>(&L.sk_host), res_bytes, hipHostMallocDefault));
+        L.sk_host_cap = res_bytes;
+    }
+    if (!L.sk_done) PSK_HIP(ctx, hipEventCreateWithFlags(&L.sk_done, hipEventDisableTiming));
+    uint32_t *d_n = L.sk_cand.as<uint32_t>();
+    uint64_t *cand = L.sk_cand.as<uint64_t>() + 2;
+    PSK_HIP(ctx, hipMemsetAsync(d_n, 0, 16, ctx->stream));
+    PSK_TRY(launch_extract(ctx, d_clean, clean_len, k, 0, 0, ctx->keysA.as<uint64_t>(), d_n));
+    kmer_hash_filter_kernel<<<div_up(clean_len, 256), 256, 0, ctx->stream>>>(ctx->keysA.as<uint64_t>(), clean_len, d_n, k,
+                                                                           (uint64_t)seed, mask, limit, cand, (uint32_t)SK_CAND_CAP,
+                                                                           d_n + 1);
+    PSK_HIP(ctx, hipGetLastError());
+    sketch_select_kernel<<<1, SK_THREADS, 0, ctx->stream>>>(cand, d_n + 1, (uint32_t)sketch_size, L.sk_out.as<uint64_t>());
+    PSK_HIP(ctx, hipGetLastError());
+    PSK_HIP(ctx, hipMemcpyAsync(L.sk_host, L.sk_out.p, res_bytes, hipMemcpyDeviceToHost, ctx->stream));
+    PSK_HIP(ctx, hipEventRecord(L.sk_done, ctx->stream));
+    L.sk_state = 1;
+    return PSK_OK;
+}
+
+int sketch_collect(psk_ctx *ctx, CountLane &L, const uint8_t *d_clean, uint64_t clean_len, int k, int sketch_size,
+                   uint32_t seed, uint64_t *hashes_out, uint64_t *n_out)
+{
+    const int state = L.sk_state;
+    L.sk_state = 0;
+    *n_out = 0;
+    if (state == 0) return PSK_OK;
+    if (state == 1) {
+        PSK_HIP(ctx, hipEventSynchronize(L.sk_done));
+        const uint64_t distinct = L.sk_host[0];
+        if (distinct != ~0ull && distinct >= (uint64_t)sketch_size) {
+            memcpy(hashes_out, L.sk_host + 1, (size_t)sketch_size * 8);
+            *n_out = (uint64_t)sketch_size;
+            return PSK_OK;
+        }
+    }
+    return sketch_from_device(ctx, d_clean, clean_len, k, sketch_size, seed, hashes_out, n_out);
 }
 
 extern "C" int psk_minhash_sketch(psk_ctx *ctx, const uint8_t *bytes, size_t len, int k, int sketch_size, uint32_t seed,

@@ -50,6 +50,12 @@ struct CountLane {
     int sample = -1;                 // sample whose chain is in flight on this set (-1: none)
     uint64_t n = 0;                  // its window count (known on the host from the framing)
     uint64_t *uniq = nullptr;        // device: its unique words (one of keysA / keysB)
+    // asynchronous MinHash sketch of the same sample (minhash.hip: sketch_enqueue / sketch_collect)
+    DevBuf sk_cand, sk_out;          // [2 x u32 counters, pad | candidate hashes]; [distinct count | sketch]
+    uint64_t *sk_host = nullptr;     // pinned landing of sk_out
+    size_t sk_host_cap = 0;
+    hipEvent_t sk_done = nullptr;
+    int sk_state = 0;                // 0 none, 1 queued, 2 the synchronous route has to serve this sample
 };
 
 struct ScanParams {  // what psk_rescan_timed needs to re-launch the last chi2 scan

@@ -417,8 +417,9 @@ class phenotypes:
             if self.real_counts and npass:
                 counts = np.stack([ctx.lookup_counts(i, res["word"]) for i in range(n)], axis=1)
         k = int(Samples.kmer_length)
-        presence = ((bits[:, np.arange(n) >> 6] >> (np.arange(n, dtype=np.uint64) & np.uint64(63))) & np.uint64(1)) \
-            .astype(np.uint8) if len(bits) else np.zeros((0, n), np.uint8)
+        # bit i of a row = sample i (little-endian u64 words): one unpackbits over the byte view
+        presence = np.ascontiguousarray(np.unpackbits(np.ascontiguousarray(bits, dtype="<u8").view(np.uint8), axis=1,
+                                                      bitorder="little")[:, :n]) if len(bits) else np.zeros((0, n), np.uint8)
         self.rows = {"kmer": formats.words_to_kmers(res["word"], k), "stat": res["stat"], "p": res["p"],
                      "mean_x": res["mean_x"], "mean_y": res["mean_y"], "n_with": res["n_with"],
                      "presence": presence, "vector": counts.astype(np.int64) if counts is not None else presence}
@@ -702,9 +703,14 @@ class phenotypes:
         be = self.model_fitted.best_estimator_
         coefs = be.coef_[0] if self.pred_scale == "binary" else be.coef_
         X, index = self.ML["X"], self.ML["index"]
+        cols, rows = np.nonzero(np.asarray(X).T)  # column-major: the samples of one k-mer are consecutive, in order
+        ends = np.cumsum(np.bincount(cols, minlength=len(self.ML["kmers"])))
+        who = np.array(index, dtype=object)[rows].tolist()
+        lo = 0
         for j, kmer in enumerate(self.ML["kmers"]):
-            with_kmer = [index[i] for i in range(len(index)) if X[i, j] != 0]
-            out.write("%s\t%s\t%d\t| %s\n" % (kmer, repr(float(coefs[j])), len(with_kmer), " ".join(with_kmer)))
+            hi = int(ends[j])
+            out.write("%s\t%s\t%d\t| %s\n" % (kmer, repr(float(coefs[j])), hi - lo, " ".join(who[lo:hi])))
+            lo = hi
 
 
 def _metric_store():

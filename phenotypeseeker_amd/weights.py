@@ -61,8 +61,10 @@ def distances_from_counts(common, denom, k):
         d = -np.log(2.0 * jac / (1.0 + jac)) / k
     d = np.where(common == denom, 0.0, np.where(common == 0, 1.0, d))
     d = np.where(denom == 0, 1.0, d)
-    flat = d.ravel()
-    return np.array([float("%g" % v) for v in flat], dtype=np.float64).reshape(d.shape)
+    # the 6-digit rounding goes through text as mash's printf does; a distance depends on (shared, denominator)
+    # only, so each distinct value is formatted once
+    uniq, inverse = np.unique(d.ravel(), return_inverse=True)
+    return np.array([float("%g" % v) for v in uniq], dtype=np.float64)[inverse].reshape(d.shape)
 
 
 def distance_matrix(names, sketches, k=21, sketch_size=1000, ctx=None):

@@ -159,6 +159,21 @@ def test_gpu_batch_sketch_equals_single_sketch(mash):
         ctx.begin(13, 1)
         _, _, sk17 = ctx.count_kmers_batch(0, datas[:1], 1, sketch=(17, 50, 42))
         assert np.array_equal(sk17[0], one)
+        # the batch path's one-workgroup candidate sort against the general route (psk_minhash_sketch) where it has
+        # to give up: a 40-kbp unit repeated 30 times (the candidates hold fewer than s distinct hashes), a sketch
+        # size whose candidates do not fit it, samples around the size where filtering starts, N runs
+        rng = np.random.default_rng(8)
+        def genome(n):
+            return b">g\n" + bytes(rng.choice(np.frombuffer(b"ACGT", np.uint8), n)) + b"\n"
+        unit = genome(40_000)[3:-1]
+        odd = [b">rep\n" + unit * 30 + b"\n", genome(1_500_000), genome(11_000), genome(13_000), genome(2_000),
+               b">n\n" + unit[:30_000] + b"N" * 5000 + unit[30_000:] + b"\n"]
+        for kk, ss in ((21, 1000), (21, 2000), (16, 300), (32, 1000)):
+            ctx.begin(13, len(odd))
+            _, _, got = ctx.count_kmers_batch(0, odd, 3, sketch=(kk, ss, 42))
+            for i, d in enumerate(odd):
+                want = ctx.minhash_sketch(d, k=kk, sketch_size=ss)
+                assert np.array_equal(got[i], want), (kk, ss, i)
 
 
 @pytest.mark.gpu
