@@ -2,8 +2,9 @@
 // Samples.get_weights, modeling.py:447-458): N - 2 sequential joins, each O(m^2) work that parallelises --
 // row sums, the minimum of d[i][j] - r[i] - r[j] over the lower triangle, the update of one row/column.
 // One workgroup runs all joins (they are strictly sequential); the matrix stays in L2 (N = 1024: 8 MB), joined
-// rows are dropped from an index list instead of being moved.  The arithmetic is the reference library's, in
-// its order -- left-to-right row sums over the current order, (d - r_i) - r_j, first minimum in (i ascending,
+// rows are dropped from an index list (in LDS, with the node distances) instead of being moved.  Every thread walks
+// one column; the walk is latency-bound, so the loads of 8 steps are issued before their (ordered) adds / compares.
+// The arithmetic is the reference library's, in its order -- left-to-right row sums over the current order, (d - r_i) - r_j, first minimum in (i ascending,
 // j < i ascending) scan order, the scan's (1, 0) -> (0, 1) start-up quirk -- so the merge list (and the tree the
 // host builds from it) is bit-identical to the scalar loops (tests: against weights.nj on random matrices with
 // ties).  Compiled with -ffp-contract=off like the rest of the library.
@@ -13,18 +14,19 @@
 namespace {
 
 constexpr int NJ_THREADS = 1024;
+constexpr int NJ_MAX = 4 * NJ_THREADS;  // leaves: the index list and the node distances live in LDS (48 KB)
+constexpr int NJ_UNROLL = 8;
 
-__global__ __launch_bounds__(NJ_THREADS) void nj_kernel(double *__restrict__ D, int n, int32_t *__restrict__ idx_g,
-                                                        double *__restrict__ nd_g, int32_t *__restrict__ mi_out,
+__global__ __launch_bounds__(NJ_THREADS) void nj_kernel(double *__restrict__ D, int n, int32_t *__restrict__ mi_out,
                                                         int32_t *__restrict__ mj_out, double *__restrict__ d1_out,
                                                         double *__restrict__ d2_out, double *__restrict__ last_out)
 {
     __shared__ double s_val[NJ_THREADS];
     __shared__ int s_i[NJ_THREADS], s_j[NJ_THREADS];
     __shared__ int s_mi, s_mj;
+    __shared__ int32_t idx[NJ_MAX];   // position -> physical row/column
+    __shared__ double nd[NJ_MAX];
     const int tid = threadIdx.x;
-    int32_t *idx = idx_g;   // position -> physical row/column (global scratch: N can exceed what LDS holds)
-    double *nd = nd_g;
     for (int p = tid; p < n; p += NJ_THREADS) idx[p] = p;
     __syncthreads();
     int m = n;
@@ -34,7 +36,15 @@ __global__ __launch_bounds__(NJ_THREADS) void nj_kernel(double *__restrict__ D, 
         for (int p = tid; p < m; p += NJ_THREADS) {
             const int pi = idx[p];
             double acc = D[(size_t)idx[0] * n + pi];
-            for (int q = 1; q < m; q++) acc += D[(size_t)idx[q] * n + pi];
+            int q = 1;
+            for (; q + NJ_UNROLL <= m; q += NJ_UNROLL) {
+                double v[NJ_UNROLL];
+#pragma unroll
+                for (int u = 0; u < NJ_UNROLL; u++) v[u] = D[(size_t)idx[q + u] * n + pi];
+#pragma unroll
+                for (int u = 0; u < NJ_UNROLL; u++) acc += v[u];
+            }
+            for (; q < m; q++) acc += D[(size_t)idx[q] * n + pi];
             nd[p] = acc / (double)(m - 2);
         }
         __syncthreads();
@@ -47,7 +57,18 @@ __global__ __launch_bounds__(NJ_THREADS) void nj_kernel(double *__restrict__ D, 
             const double ri = nd[p];
             double rb = INFINITY;
             int rj = 0;
-            for (int q = 0; q < p; q++) {
+            int q = 0;
+            for (; q + NJ_UNROLL <= p; q += NJ_UNROLL) {
+                double v[NJ_UNROLL];
+#pragma unroll
+                for (int u = 0; u < NJ_UNROLL; u++) v[u] = D[(size_t)idx[q + u] * n + pi];
+#pragma unroll
+                for (int u = 0; u < NJ_UNROLL; u++) {
+                    const double t = (v[u] - ri) - nd[q + u];
+                    if (t < rb) { rb = t; rj = q + u; }
+                }
+            }
+            for (; q < p; q++) {
                 const double t = (D[(size_t)idx[q] * n + pi] - ri) - nd[q];
                 if (t < rb) { rb = t; rj = q; }
             }
@@ -105,20 +126,17 @@ extern "C" int psk_nj_merges(psk_ctx *ctx, const double *dist, int n, int32_t *m
 {
     if (!ctx) return PSK_EINVAL;
     if (!dist || !mi_out || !mj_out || !d1_out || !d2_out || !last_out) return psk_fail(ctx, PSK_EINVAL, "null buffer");
-    if (n < 3 || n > 4 * NJ_THREADS) return psk_fail(ctx, PSK_EINVAL, "neighbour joining on the GPU takes 3..%d leaves, got %d",
-                                                      4 * NJ_THREADS, n);
+    if (n < 3 || n > NJ_MAX) return psk_fail(ctx, PSK_EINVAL, "neighbour joining on the GPU takes 3..%d leaves, got %d", NJ_MAX, n);
     PSK_HIP(ctx, hipSetDevice(ctx->device));
     const size_t nn = (size_t)n * n;
-    const size_t bytes = nn * 8 + (size_t)n * (4 + 8) + (size_t)n * (4 + 4 + 8 + 8) + 64;
+    const size_t bytes = nn * 8 + (size_t)n * (4 + 4 + 8 + 8) + 64;
     PSK_TRY(dev_reserve(ctx, ctx->keysA, bytes));
     uint8_t *b = ctx->keysA.as<uint8_t>();
     double *D = reinterpret_cast<double *>(b);
-    double *nd = D + nn;
-    double *d1 = nd + n, *d2 = d1 + n, *last = d2 + n;
-    int32_t *idx = reinterpret_cast<int32_t *>(last + 1);
-    int32_t *mi = idx + n, *mj = mi + n;
+    double *d1 = D + nn, *d2 = d1 + n, *last = d2 + n;
+    int32_t *mi = reinterpret_cast<int32_t *>(last + 1), *mj = mi + n;
     PSK_HIP(ctx, hipMemcpyAsync(D, dist, nn * 8, hipMemcpyHostToDevice, ctx->stream));
-    nj_kernel<<<1, NJ_THREADS, 0, ctx->stream>>>(D, n, idx, nd, mi, mj, d1, d2, last);
+    nj_kernel<<<1, NJ_THREADS, 0, ctx->stream>>>(D, n, mi, mj, d1, d2, last);
     PSK_HIP(ctx, hipGetLastError());
     const size_t joins = (size_t)n - 2;
     PSK_HIP(ctx, hipMemcpyAsync(mi_out, mi, joins * 4, hipMemcpyDeviceToHost, ctx->stream));
