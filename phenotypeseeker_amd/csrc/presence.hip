@@ -203,9 +203,6 @@ extern "C" int psk_build_presence(psk_ctx *ctx, uint64_t *n_kmers)
     // travels as a u32 payload of the sort
     const bool kv = 2 * ctx->k + sbits > 64;
     if (kv) sbits = 0;
-    if (total >= (1ull << 32)) return psk_fail(ctx, PSK_ERANGE, "%llu (word, sample) pairs exceed 2^32 per GPU; "
-                                                                "shard the word space over more GPUs",
-                                               (unsigned long long)total);
     ctx->wpr = padded_wpr(ctx->n_samples);
     ctx->n_kmers = 0;
     ctx->have_presence = false;
@@ -228,6 +225,10 @@ extern "C" int psk_build_presence(psk_ctx *ctx, uint64_t *n_kmers)
             return PSK_OK;
         }
     }
+    // the sort route indexes the concatenated (word, sample) pairs in u32; the tiled build above has no such limit
+    if (total >= (1ull << 32)) return psk_fail(ctx, PSK_ERANGE, "%llu (word, sample) pairs exceed 2^32 per GPU for "
+                                                                "k = %d; shard the word space over more GPUs",
+                                               (unsigned long long)total, ctx->k);
     PSK_TRY(dev_reserve(ctx, ctx->keysA, total * 8));
     PSK_TRY(dev_reserve(ctx, ctx->keysB, total * 8));
     if (kv) {

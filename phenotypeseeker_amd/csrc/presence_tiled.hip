@@ -171,6 +171,9 @@ int build_presence_tiled(psk_ctx *ctx, uint64_t total_pairs, uint64_t *n_kmers, 
     const uint64_t space = 1ull << (2 * k);
     const uint64_t lo = ctx->slab_lo, hi = ctx->slab_hi ? ctx->slab_hi : space;
     const uint64_t span = hi - lo;
+    // rows are numbered in u32: the union of this slab must stay below 2^32 rows, which the pair count or the
+    // number of canonical words of the slab (at most span / 2 + 2^k palindromes) guarantees
+    if (total_pairs >= (1ull << 32) && span / 2 + (1ull << k) >= (1ull << 32)) return PSK_OK;
     // tile size: the smallest LDS block (more workgroups per CU) whose tile table stays under 512 MB; rows per
     // thread are capped at 32 (a bit mask in tile_fill)
     uint32_t R = 0;

@@ -61,17 +61,23 @@ _timed(_E.PskContext, "_fit")
 err = sys.stderr
 sys.stderr = open(os.devnull, "w")
 t0 = time.time()
-if os.environ.get("PSK_E2E_CPROFILE") == "1":   # host hot spots: top of the cumulative profile to stderr
-    import cProfile
-    import pstats
-    prof = cProfile.Profile()
-    prof.runcall(args.func, args)
-    wall = time.time() - t0
-    pstats.Stats(prof, stream=err).sort_stats("tottime").print_stats(22)
-    pstats.Stats(prof, stream=err).sort_stats("cumulative").print_stats("phenotypeseeker_amd|joblib|sklearn", 45)
-else:
-    args.func(args)
-    wall = time.time() - t0
+try:
+    if os.environ.get("PSK_E2E_CPROFILE") == "1":   # host hot spots: top of the cumulative profile to stderr
+        import cProfile
+        import pstats
+        prof = cProfile.Profile()
+        prof.runcall(args.func, args)
+        wall = time.time() - t0
+        pstats.Stats(prof, stream=err).sort_stats("tottime").print_stats(22)
+        pstats.Stats(prof, stream=err).sort_stats("cumulative").print_stats("phenotypeseeker_amd|joblib|sklearn", 45)
+    else:
+        args.func(args)
+        wall = time.time() - t0
+except BaseException as exc:   # the pipeline's own messages went to the muted stderr: say why it stopped
+    sys.stderr = err
+    print("modeling stopped after %.1f s: %r" % (time.time() - t0, exc), file=err)
+    shutil.rmtree(tmp, ignore_errors=True)
+    raise
 sys.stderr = err
 log = open("log.txt").read().strip().splitlines()
 out = {"samples": n, "length": length, "flags": extra, "write_dataset_s": round(t_write, 2), "modeling_wall_s": round(wall, 3), "stages_s": stage,
