@@ -799,11 +799,19 @@ static int count_batch_impl(psk_ctx *ctx, int first_sample_idx, int n, const uin
         if (n_total) n_total[i] = ctx->lists[first_sample_idx + i].n_total;
     };
     for (CountLane &L : ctx->lane) { L.sample = -1; L.sk_state = 0; }
-    // clean-stream length the sketch of sample i reads (0: nothing was uploaded for it)
-    auto sk_len = [&](int i) -> uint64_t { return wins[i] ? clen[i] : 0; };
-    auto collect_sketch = [&](int i) {
+    auto collect_sketch = [&](int i) -> int {
         CountLane &L = ctx->lane[i & 1];
-        return sketch_collect(ctx, L, L.raw.as<uint8_t>(), sk_len(i), sketch_k, sketch_size, sketch_seed,
+        if (wins[i] == 0) {
+            // no window of the counting k, so nothing was uploaded -- but the sketch's k may be shorter: take the
+            // clean stream from the ring slot (still held) through the synchronous route
+            n_hashes_out[i] = 0;
+            L.sk_state = 0;
+            if (clen[i] == 0) return PSK_OK;
+            PSK_TRY(dev_reserve(ctx, L.raw, plen[i]));
+            PSK_HIP(ctx, hipMemcpyAsync(L.raw.p, ctx->ring[i % R], plen[i], hipMemcpyHostToDevice, ctx->stream));
+            L.sk_state = 2;
+        }
+        return sketch_collect(ctx, L, L.raw.as<uint8_t>(), clen[i], sketch_k, sketch_size, sketch_seed,
                               hashes_out + (size_t)i * sketch_size, n_hashes_out + i);
     };
     for (int i = 0; i < n && rc == PSK_OK; i++) {
@@ -826,8 +834,8 @@ static int count_batch_impl(psk_ctx *ctx, int first_sample_idx, int n, const uin
         }
         // the sketch of sample i: queued behind its chain, collected one sample later (after chain i + 1 has been
         // queued, so the stream never runs dry; before sample i + 2 is uploaded into this lane's clean-stream buffer)
-        if (rc == PSK_OK && sketch_k)
-            rc = sketch_enqueue(ctx, ctx->lane[i & 1], ctx->lane[i & 1].raw.as<uint8_t>(), sk_len(i), sketch_k, sketch_size, sketch_seed);
+        if (rc == PSK_OK && sketch_k && wins[i] > 0)
+            rc = sketch_enqueue(ctx, ctx->lane[i & 1], ctx->lane[i & 1].raw.as<uint8_t>(), clen[i], sketch_k, sketch_size, sketch_seed);
     }
     if (rc == PSK_OK && n > 0) {
         rc = chain_finalize(ctx, ctx->lane[(n - 1) & 1]);

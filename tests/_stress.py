@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """Randomised end-to-end check of the GPU path against the oracle (checker only): random sample sets (FASTA with
 breaks / lower case / empty samples, some FASTQ), random k, random slab; lists, union, presence bits and the
-chi2 survivors must be identical.  Test infrastructure (it links the oracle): run by
+chi2 survivors must be identical; also the batch sketches, two scans in flight, the weighted chi2 and the Welch scan.  Test infrastructure (it links the oracle): run by
 tests/test_gpu_parity.py::test_randomised_pipeline_against_oracle, or by hand: python tests/_stress.py SECONDS [seed]"""
 import os
 import sys
@@ -12,6 +12,7 @@ import numpy as np
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 from oracle import oracle as O  # noqa: E402
+from oracle import oracle_weights as OW  # noqa: E402
 from phenotypeseeker_amd.engine import PskContext  # noqa: E402
 from phenotypeseeker_amd.synth import GenomeSet, fastq_reads  # noqa: E402
 
@@ -49,7 +50,16 @@ with PskContext(0) as ctx:
             rank = int(rng.integers(0, world))
             lo, hi = (space * rank) // world, (0 if rank == world - 1 else (space * (rank + 1)) // world)
         ctx.begin(k, n, lo, hi)
-        nu, nt = ctx.count_kmers_batch(0, datas, int(rng.integers(1, 9)))
+        do_sketch = length <= 3000 and rng.random() < 0.5   # the oracle's sketch is a pure-Python loop
+        sk_par = (int(rng.choice([21, 16, 11])), int(rng.choice([1000, 100, 30])), 42)
+        if do_sketch:
+            nu, nt, sks = ctx.count_kmers_batch(0, datas, int(rng.integers(1, 9)), sketch=sk_par)
+            for i in rng.choice(n, min(n, 3), replace=False):
+                want = OW.sketch(datas[i], k=sk_par[0], sketch_size=sk_par[1]) if not datas[i].startswith(b"@") else None
+                if want is not None:
+                    assert sks[i].tolist() == want, ("sketch", rounds, int(i), sk_par)
+        else:
+            nu, nt = ctx.count_kmers_batch(0, datas, int(rng.integers(1, 9)))
         ref_lists = []
         for i in range(n):
             w, f = ctx.get_list(i, nu[i])
@@ -76,4 +86,37 @@ with PskContext(0) as ctx:
             assert np.array_equal(np.sort(res["row"]), keep.astype(np.uint64)), ("scan rows", rounds, k, n)
             order = np.argsort(res["row"])
             assert np.array_equal(res["stat"][order], ref["stat"][keep]), ("scan stat", rounds)
+            # two scans in flight (two result sets): unweighted again + a weighted one, ended in launch order
+            wts = np.round(rng.uniform(0.2, 3.0, n), 6)
+            ph2 = rng.integers(-1, 2, n).astype(np.int8)
+            ctx.chi2_scan_begin(ph, None, 2, n - 2, 0.05, omit, m)
+            ctx.chi2_scan_begin(ph2, wts, 1, n - 1, 0.2, True, m)
+            c1 = ctx.scan_end()
+            r1 = ctx.get_results(c1)
+            assert np.array_equal(r1["row"], res["row"]) and np.array_equal(r1["stat"], res["stat"]), ("pipelined scan", rounds)
+            c2 = ctx.scan_end()
+            r2 = ctx.get_results(c2)
+            refw = O.chi2_scan(bits, ph2.tolist(), wts, n, 1, n - 1, 0.2, True, m)
+            keepw = np.nonzero(refw["keep"])[0]
+            gotw = dict(zip(r2["row"].tolist(), range(c2)))
+            both = [r for r in keepw.tolist() if r in gotw]   # a p within rounding of the cut-off may fall either way
+            assert len(both) >= len(keepw) - 2 and c2 - len(both) <= 2, ("weighted rows", rounds, len(keepw), c2)
+            gi = [gotw[r] for r in both]
+            assert np.allclose(r2["stat"][gi], refw["stat"][both], rtol=1e-9, atol=1e-12), ("weighted stat", rounds)
+            # Welch t-test on the same matrix
+            vals = np.round(rng.normal(3.0, 1.5, n), 4)
+            okv = rng.random(n) > 0.1
+            if okv.sum() >= 4:
+                pheno = [float(v) if o else "NA" for v, o in zip(vals, okv)]
+                tw = wts if rng.random() < 0.5 else np.ones(n)
+                reft = O.ttest_scan(bits, pheno, tw, n, 2, n - 2, 0.5, 1)
+                ct = ctx.ttest_scan(vals, okv, tw, 2, n - 2, 0.5, 1)
+                rt = ctx.get_results(ct)
+                keept = np.nonzero(reft["keep"])[0]
+                gott = dict(zip(rt["row"].tolist(), range(ct)))
+                botht = [r for r in keept.tolist() if r in gott]
+                assert len(botht) >= len(keept) - 2 and ct - len(botht) <= 2, ("t rows", rounds, len(keept), ct)
+                gi = [gott[r] for r in botht]
+                assert np.allclose(rt["stat"][gi], reft["stat"][botht], rtol=1e-7, atol=1e-10), ("t stat", rounds)
+                assert np.array_equal(rt["n_with"][gi], reft["n_with"][botht]), ("t n_with", rounds)
 print("stress ok: %d rounds in %.0f s (seed %d)" % (rounds, budget, seed))
