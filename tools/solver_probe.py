@@ -3,7 +3,6 @@
 usage: tools/solver_probe.py dump N LENGTH out.npz   -- run the pipeline, save the solver inputs
        tools/solver_probe.py time in.npz             -- time every fit of the saved problem alone"""
 import os
-import subprocess
 import sys
 import time
 
