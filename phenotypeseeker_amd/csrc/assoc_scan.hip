@@ -193,11 +193,17 @@ __device__ __forceinline__ int queue_pop64(uint64_t *q_row, int2 *q_val, int q, 
     return __builtin_amdgcn_readfirstlane(rest > 0 ? rest : 0);
 }
 
-template <int G, bool WEIGHTED>
+// MODE 0: unit weights, the exact evaluation in line -- the usual case, where almost no row passes the pre-test.
+// MODE 1: GSC weights: rows that pass the frequency filter are queued per wave and handled 64 at a time, one per lane.
+// MODE 2: unit weights, rows that pass the pre-test are queued the same way: a scan with many survivors
+//         (--omit_B_correction keeps ~pvalue of all rows) then evaluates 64 of them per pass instead of one or two
+//         lanes of a wave at a time.  Same formulas, same results as MODE 0 (the host picks, see pick_chi2_mode).
+template <int G, int MODE>
 __global__ __launch_bounds__(SC_THREADS) void chi2_scan_kernel(const ScanArgs P)
 {
-    __shared__ uint64_t s_qrow[WEIGHTED ? SC_THREADS / 64 : 1][WEIGHTED ? rq_cap(G) : 1];  // weighted only
-    __shared__ int2 s_qval[WEIGHTED ? SC_THREADS / 64 : 1][WEIGHTED ? rq_cap(G) : 1];
+    constexpr bool WEIGHTED = MODE == 1, QUEUED = MODE != 0;
+    __shared__ uint64_t s_qrow[QUEUED ? SC_THREADS / 64 : 1][QUEUED ? rq_cap(G) : 1];
+    __shared__ int2 s_qval[QUEUED ? SC_THREADS / 64 : 1][QUEUED ? rq_cap(G) : 1];
     constexpr int RPW = 64 / G;  // rows per wave step
     const int lane = threadIdx.x & 63;
     const int g = lane & (G - 1);
@@ -211,25 +217,32 @@ __global__ __launch_bounds__(SC_THREADS) void chi2_scan_kernel(const ScanArgs P)
         if (P.inline_masks) { m1a = P.m1_inl[2 * g]; m1b = P.m1_inl[2 * g + 1]; m0a = P.m0_inl[2 * g]; m0b = P.m0_inl[2 * g + 1]; }
         else { m1a = P.m1[2 * g]; m1b = P.m1[2 * g + 1]; m0a = P.m0[2 * g]; m0b = P.m0[2 * g + 1]; }
     }
-    uint64_t *q_row = s_qrow[WEIGHTED ? (threadIdx.x >> 6) : 0];
-    int2 *q_val = s_qval[WEIGHTED ? (threadIdx.x >> 6) : 0];
+    uint64_t *q_row = s_qrow[QUEUED ? (threadIdx.x >> 6) : 0];
+    int2 *q_val = s_qval[QUEUED ? (threadIdx.x >> 6) : 0];
     int q = 0;
-    // weighted: `cnt` queued rows, one per lane -- class weight sums in sample order, then the same
-    // pre-test / exact statistic / keep rule as the unweighted path.  (The unweighted path keeps its exact
-    // evaluation in line: queueing its pre-test survivors as well makes a scan with 1 % survivors 35 %
-    // faster but costs the usual sparse case 4 %, r01 A/B on cfg 2: 110.7 vs 115.2 us.)
+    // `cnt` queued rows, one per lane.  Weighted: class weight sums in sample order, then the same pre-test / exact
+    // statistic / keep rule as the unweighted path.  MODE 2: the row has passed the pre-test; (a, c) came with it.
+    // (Queueing costs the usual sparse case 4 % -- r01 A/B on cfg 2: 110.7 vs 115.2 us -- hence MODE 0.)
     auto process = [&](int cnt) {
         const bool act = lane < cnt;
         const uint64_t r = q_row[act ? lane : 0];
-        const int r_nw = q_val[act ? lane : 0].x;
-        double ws[2];
-        row_moments<2>(P.bits + r * (uint64_t)P.cpr, P.cpr, (cdptr)P.tab, ws);
-        if (!act) return;
-        const double A = ws[0], B = P.W1 - ws[0], C = ws[1], D = P.W0 - ws[1];
-        const double R1 = A + B, R0 = C + D, K1 = A + C, K0 = B + D, T = R1 + R0;
-        const double det = A * D - B * C;
-        const double lhs = T * det * det, rhs = P.thr * R1 * R0 * K1 * K0;
-        if (lhs < rhs * (1.0 - 1e-9)) return;
+        const int2 qv = q_val[act ? lane : 0];
+        int r_nw = qv.x;
+        double A, B, C, D;
+        if (WEIGHTED) {
+            double ws[2];
+            row_moments<2>(P.bits + r * (uint64_t)P.cpr, P.cpr, (cdptr)P.tab, ws);
+            if (!act) return;
+            A = ws[0]; B = P.W1 - ws[0]; C = ws[1]; D = P.W0 - ws[1];
+            const double R1 = A + B, R0 = C + D, K1 = A + C, K0 = B + D, T = R1 + R0;
+            const double det = A * D - B * C;
+            const double lhs = T * det * det, rhs = P.thr * R1 * R0 * K1 * K0;
+            if (lhs < rhs * (1.0 - 1e-9)) return;
+        } else {
+            if (!act) return;
+            A = (double)qv.x; B = (double)(P.n1 - qv.x); C = (double)qv.y; D = (double)(P.n0 - qv.y);
+            r_nw = qv.x + qv.y;
+        }
         const double stat = chi2_exact(A, B, C, D);
         const double p = exp(-0.5 * stat);
         const bool keep = (P.omit_B && p < P.pcut) || (p < P.pcut_bonf);
@@ -246,7 +259,7 @@ __global__ __launch_bounds__(SC_THREADS) void chi2_scan_kernel(const ScanArgs P)
     // down to empty (keeps its registers and code out of the streaming part)
     for (uint64_t s0 = wave_global * SC_UNROLL;; s0 += total_waves * SC_UNROLL) {
         const bool more = s0 < n_steps;
-        if (WEIGHTED) {
+        if (QUEUED) {
             while (q >= 64 || (!more && q > 0)) {
                 process(q < 64 ? q : 64);
                 q = queue_pop64(q_row, q_val, q, lane);
@@ -293,13 +306,17 @@ __global__ __launch_bounds__(SC_THREADS) void chi2_scan_kernel(const ScanArgs P)
                 q = queue_rows(freq_ok && g == 0, row, make_int2(n_w, 0), q_row, q_val, q, lane);
                 continue;
             }
-            if (!freq_ok || g != 0) continue;
             const double A = (double)a, B = (double)(P.n1 - (int)a), C = (double)c, D = (double)(P.n0 - (int)c);
             // division-free pre-test: chi2 = T (AD - BC)^2 / (R1 R0 K1 K0)
             const double R1 = A + B, R0 = C + D, K1 = A + C, K0 = B + D, T = R1 + R0;
             const double det = A * D - B * C;
             const double lhs = T * det * det, rhs = P.thr * R1 * R0 * K1 * K0;
-            if (lhs < rhs * (1.0 - 1e-9)) continue;  // NaN compares false -> falls through to the exact path
+            const bool cand = freq_ok && g == 0 && !(lhs < rhs * (1.0 - 1e-9));  // NaN compares false -> a candidate
+            if (MODE == 2) {
+                q = queue_rows(cand, row, make_int2((int)a, (int)c), q_row, q_val, q, lane);
+                continue;
+            }
+            if (!cand) continue;
             const double stat = chi2_exact(A, B, C, D);
             const double p = exp(-0.5 * stat);  // chi2.sf(stat, df = 2), modeling.py:782-792
             const bool keep = (P.omit_B && p < P.pcut) || (p < P.pcut_bonf);  // modeling.py:795
@@ -454,18 +471,40 @@ __global__ __launch_bounds__(SC_THREADS) void ttest_scan_kernel(const ScanArgs P
     }
 }
 
-template <bool WEIGHTED>
-void launch_chi2(int G, dim3 grid, hipStream_t st, const ScanArgs &a)
+template <int MODE>
+void launch_chi2_mode(int G, dim3 grid, hipStream_t st, const ScanArgs &a)
 {
     switch (G) {
-    case 1: chi2_scan_kernel<1, WEIGHTED><<<grid, SC_THREADS, 0, st>>>(a); break;
-    case 2: chi2_scan_kernel<2, WEIGHTED><<<grid, SC_THREADS, 0, st>>>(a); break;
-    case 4: chi2_scan_kernel<4, WEIGHTED><<<grid, SC_THREADS, 0, st>>>(a); break;
-    case 8: chi2_scan_kernel<8, WEIGHTED><<<grid, SC_THREADS, 0, st>>>(a); break;
-    case 16: chi2_scan_kernel<16, WEIGHTED><<<grid, SC_THREADS, 0, st>>>(a); break;
-    case 32: chi2_scan_kernel<32, WEIGHTED><<<grid, SC_THREADS, 0, st>>>(a); break;
-    default: chi2_scan_kernel<64, WEIGHTED><<<grid, SC_THREADS, 0, st>>>(a); break;
+    case 1: chi2_scan_kernel<1, MODE><<<grid, SC_THREADS, 0, st>>>(a); break;
+    case 2: chi2_scan_kernel<2, MODE><<<grid, SC_THREADS, 0, st>>>(a); break;
+    case 4: chi2_scan_kernel<4, MODE><<<grid, SC_THREADS, 0, st>>>(a); break;
+    case 8: chi2_scan_kernel<8, MODE><<<grid, SC_THREADS, 0, st>>>(a); break;
+    case 16: chi2_scan_kernel<16, MODE><<<grid, SC_THREADS, 0, st>>>(a); break;
+    case 32: chi2_scan_kernel<32, MODE><<<grid, SC_THREADS, 0, st>>>(a); break;
+    default: chi2_scan_kernel<64, MODE><<<grid, SC_THREADS, 0, st>>>(a); break;
     }
+}
+
+void launch_chi2(int mode, int G, dim3 grid, hipStream_t st, const ScanArgs &a)
+{
+    if (mode == 1) launch_chi2_mode<1>(G, grid, st, a);
+    else if (mode == 2) launch_chi2_mode<2>(G, grid, st, a);
+    else launch_chi2_mode<0>(G, grid, st, a);
+}
+
+// Kernel form of a chi2 scan.  Unit weights: MODE 2 (queued candidates) when many rows are expected to pass the
+// pre-test -- the last chi2 scan of this matrix kept more than 0.1 % of the rows, or, with no history, the keep rule
+// itself lets that many through under the null hypothesis (p < cut holds for a fraction `cut` of unassociated rows).
+// PSK_CHI2_MODE=0|2 forces one (A/B runs).
+int pick_chi2_mode(const psk_ctx *ctx, bool weighted, double pcut, double pcut_bonf, int omit_B)
+{
+    if (weighted) return 1;
+    static const int forced = [] { const char *e = getenv("PSK_CHI2_MODE"); return e ? atoi(e) : -1; }();
+    if (forced == 0 || forced == 2) return forced;
+    if (ctx->dense_hint >= 0) return ctx->dense_hint ? 2 : 0;
+    double expect = pcut_bonf;
+    if (omit_B && pcut > expect) expect = pcut;
+    return expect > 1e-3 ? 2 : 0;
 }
 
 // Second pass of the Welch scan: one workgroup per result segment turns (t, df) of every candidate into
@@ -657,8 +696,7 @@ int run_chi2(psk_ctx *ctx, ScanArgs &a, bool weighted, int reps, double *ms_tota
     *ms_total = 0;
     for (int r = 0; r < reps; r++) {
         PSK_HIP(ctx, hipEventRecord(ctx->ev0, ctx->stream));
-        if (weighted) launch_chi2<true>(G, grid, ctx->stream, a);
-        else launch_chi2<false>(G, grid, ctx->stream, a);
+        launch_chi2(pick_chi2_mode(ctx, weighted, a.pcut, a.pcut_bonf, a.omit_B), G, grid, ctx->stream, a);
         PSK_HIP(ctx, hipGetLastError());
         PSK_HIP(ctx, hipEventRecord(ctx->ev1, ctx->stream));
         PSK_HIP(ctx, hipStreamSynchronize(ctx->stream));  // the kernel has written the counts to pinned memory
@@ -761,8 +799,7 @@ static int chi2_scan_launch(psk_ctx *ctx, const int8_t *pheno, const double *wei
         const int G = group_lanes(a.cpr);
         const dim3 grid = scan_grid(ctx, a.M, G, SC_UNROLL);
         PSK_HIP(ctx, hipEventRecord(sl.ev0, ctx->stream));
-        if (ctx->last.weighted) launch_chi2<true>(G, grid, ctx->stream, a);
-        else launch_chi2<false>(G, grid, ctx->stream, a);
+        launch_chi2(pick_chi2_mode(ctx, ctx->last.weighted, a.pcut, a.pcut_bonf, a.omit_B), G, grid, ctx->stream, a);
         PSK_HIP(ctx, hipGetLastError());
         PSK_HIP(ctx, hipEventRecord(sl.ev1, ctx->stream));
         sl.in_flight = true;
@@ -798,6 +835,7 @@ extern "C" int psk_scan_end(psk_ctx *ctx, uint64_t *n_pass)
         PSK_HIP(ctx, hipEventElapsedTime(&ms, sl.ev0, sl.ev1));
         ctx->last_scan_ms = ms;
         PSK_TRY(fetch_counts(ctx, set));
+        ctx->dense_hint = ctx->n_pass * 1000 > ctx->n_kmers ? 1 : 0;  // only chi2 scans come through here
     }
     if (n_pass) *n_pass = ctx->n_pass;
     return PSK_OK;

@@ -208,6 +208,7 @@ extern "C" int psk_build_presence(psk_ctx *ctx, uint64_t *n_kmers)
     ctx->have_presence = false;
     if (total == 0) {
         ctx->have_presence = true;
+        ctx->dense_hint = -1;
         if (n_kmers) *n_kmers = 0;
         return PSK_OK;
     }
@@ -220,6 +221,7 @@ extern "C" int psk_build_presence(psk_ctx *ctx, uint64_t *n_kmers)
             pt.mark("tiled build");
             ctx->n_kmers = M;
             ctx->have_presence = true;
+            ctx->dense_hint = -1;
             ctx->last.valid = false;
             if (n_kmers) *n_kmers = M;
             return PSK_OK;
@@ -282,6 +284,7 @@ extern "C" int psk_build_presence(psk_ctx *ctx, uint64_t *n_kmers)
     pt.mark("fill");
     ctx->n_kmers = M;
     ctx->have_presence = true;
+    ctx->dense_hint = -1;
     ctx->last.valid = false;
     if (n_kmers) *n_kmers = M;
     return PSK_OK;
@@ -391,6 +394,7 @@ extern "C" int psk_set_presence(psk_ctx *ctx, const uint64_t *words, const uint6
     }
     PSK_HIP(ctx, hipStreamSynchronize(ctx->stream));
     ctx->have_presence = true;
+    ctx->dense_hint = -1;
     ctx->last.valid = false;
     return PSK_OK;
 }
@@ -413,6 +417,7 @@ extern "C" int psk_synth_presence(psk_ctx *ctx, uint64_t n_kmers, int n_samples,
     PSK_HIP(ctx, hipGetLastError());
     PSK_HIP(ctx, hipStreamSynchronize(ctx->stream));
     ctx->have_presence = true;
+    ctx->dense_hint = -1;
     ctx->last.valid = false;
     return PSK_OK;
 }

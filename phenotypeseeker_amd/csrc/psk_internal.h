@@ -127,6 +127,7 @@ struct psk_ctx {
     uint64_t res_seg_cap = 0;            // entries per result segment of the last scan
     std::vector<uint32_t> seg_counts;    // survivors per segment
     int last_scan_kind = 0;  // 1 chi2, 2 ttest
+    int dense_hint = -1;     // did the last chi2 scan of this matrix keep > 0.1 % of the rows?  (-1: no scan yet)
     double last_scan_ms = 0;
     ScanParams last;
 };
