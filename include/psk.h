@@ -85,6 +85,21 @@ int psk_count_kmers_files(psk_ctx *ctx, int first_sample_idx, int n, const char 
                           uint32_t sketch_seed, uint64_t *hashes_out, uint64_t *n_hashes_out);
 /* Copies sample_idx's list to the host (for writing .list files / parity checks). */
 int psk_get_list(psk_ctx *ctx, int sample_idx, uint64_t *words, uint32_t *freqs, uint64_t cap);
+/* ---- multi-GPU ingest: count each sample on ONE rank, exchange the slab ranges of the sorted lists ----------
+ * (no counterpart in the reference, which has no multi-process counting; see phenotypeseeker_amd/dist.py
+ * ListExchange.)  A slab of the word space is a contiguous range of a sorted list, so the hand-over is three calls:
+ *   psk_lists_split     offsets_out[i * n_bounds + b] = number of words of sample first + i below bounds[b]
+ *                       (bounds ascending; a bound of 0 after the first entry means "end of the word space")
+ *   psk_copy_list_range copies entries [start, start + count) of a list into DEVICE buffers (the send buffers of
+ *                       the all-to-all), on the context's stream, waited for
+ *   psk_set_list_device installs `n` (word, count) entries held in DEVICE memory -- ascending, inside this
+ *                       context's slab -- as the list of sample_idx (copied into the context's own storage) */
+int psk_lists_split(psk_ctx *ctx, int first_sample_idx, int n, const uint64_t *bounds, int n_bounds,
+                    uint64_t *offsets_out);
+int psk_copy_list_range(psk_ctx *ctx, int sample_idx, uint64_t start, uint64_t count, void *device_words_dst,
+                        void *device_freqs_dst);
+int psk_set_list_device(psk_ctx *ctx, int sample_idx, const void *device_words, const void *device_freqs, uint64_t n,
+                        uint64_t n_total);
 /* Frequencies of `n` given canonical words in sample_idx's list (0 if absent): the
  * `glistquery <sample>.list -l` mapping of modeling.py:324-329 restricted to the k-mers the
  * caller still needs (--real_counts columns of the ML matrix, modeling.py:693-695). */

@@ -908,6 +908,120 @@ extern "C" int psk_get_list(psk_ctx *ctx, int sample_idx, uint64_t *words, uint3
     return PSK_OK;
 }
 
+namespace {
+
+// thread (i, b): lower bound of bounds[b] in the sorted list of sample i
+struct SplitRef { const uint64_t *words; uint64_t n; };
+__global__ void lists_split_kernel(const SplitRef *__restrict__ refs, int n, const uint64_t *__restrict__ bounds, int n_bounds,
+                                   uint64_t *__restrict__ out)
+{
+    const int t = blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= n * n_bounds) return;
+    const int i = t / n_bounds, b = t % n_bounds;
+    const uint64_t key = bounds[b];
+    uint64_t lo = 0, hi = refs[i].n;
+    if (b > 0 && key == 0) lo = hi;  // "end of the word space"
+    const uint64_t *w = refs[i].words;
+    while (lo < hi) {
+        const uint64_t mid = (lo + hi) >> 1;
+        if (w[mid] < key) lo = mid + 1; else hi = mid;
+    }
+    out[t] = lo;
+}
+
+// 1 when words[0 .. n) ascend strictly and stay inside [lo, hi) (hi == 0: unbounded)
+__global__ void list_check_kernel(const uint64_t *__restrict__ words, uint64_t n, uint64_t lo, uint64_t hi, uint32_t *__restrict__ bad)
+{
+    const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const uint64_t w = words[i];
+    if ((i > 0 && words[i - 1] >= w) || w < lo || (hi && w >= hi)) atomicOr(bad, 1u);
+}
+
+}  // namespace
+
+extern "C" int psk_lists_split(psk_ctx *ctx, int first_sample_idx, int n, const uint64_t *bounds, int n_bounds,
+                               uint64_t *offsets_out)
+{
+    if (!ctx) return PSK_EINVAL;
+    if (n < 0 || first_sample_idx < 0 || first_sample_idx + n > ctx->n_samples)
+        return psk_fail(ctx, PSK_EINVAL, "sample range out of bounds");
+    if (n == 0 || n_bounds == 0) return PSK_OK;
+    if (!bounds || !offsets_out || n_bounds < 0) return psk_fail(ctx, PSK_EINVAL, "null buffer");
+    std::vector<SplitRef> refs(n);
+    for (int i = 0; i < n; i++) {
+        const SampleList &L = ctx->lists[first_sample_idx + i];
+        if (!L.done) return psk_fail(ctx, PSK_ESTATE, "sample %d has not been counted", first_sample_idx + i);
+        refs[i].words = L.words;
+        refs[i].n = L.n_unique;
+    }
+    PSK_HIP(ctx, hipSetDevice(ctx->device));
+    const size_t cells = (size_t)n * n_bounds;
+    const size_t b_refs = (size_t)n * sizeof(SplitRef), b_bounds = (size_t)n_bounds * 8;
+    PSK_TRY(dev_reserve(ctx, ctx->flags, b_refs + b_bounds + cells * 8));
+    uint8_t *base = ctx->flags.as<uint8_t>();
+    PSK_HIP(ctx, hipMemcpyAsync(base, refs.data(), b_refs, hipMemcpyHostToDevice, ctx->stream));
+    PSK_HIP(ctx, hipMemcpyAsync(base + b_refs, bounds, b_bounds, hipMemcpyHostToDevice, ctx->stream));
+    uint64_t *d_out = reinterpret_cast<uint64_t *>(base + b_refs + b_bounds);
+    lists_split_kernel<<<div_up(cells, 256), 256, 0, ctx->stream>>>(reinterpret_cast<const SplitRef *>(base), n,
+                                                                  reinterpret_cast<const uint64_t *>(base + b_refs), n_bounds, d_out);
+    PSK_HIP(ctx, hipGetLastError());
+    PSK_HIP(ctx, hipMemcpyAsync(offsets_out, d_out, cells * 8, hipMemcpyDeviceToHost, ctx->stream));
+    PSK_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    return PSK_OK;
+}
+
+extern "C" int psk_copy_list_range(psk_ctx *ctx, int sample_idx, uint64_t start, uint64_t count, void *device_words_dst,
+                                   void *device_freqs_dst)
+{
+    if (!ctx) return PSK_EINVAL;
+    if (sample_idx < 0 || sample_idx >= ctx->n_samples || !ctx->lists[sample_idx].done)
+        return psk_fail(ctx, PSK_ESTATE, "sample %d has not been counted", sample_idx);
+    const SampleList &L = ctx->lists[sample_idx];
+    if (start > L.n_unique || count > L.n_unique - start) return psk_fail(ctx, PSK_ERANGE, "range outside the list");
+    if (count == 0) return PSK_OK;
+    if (!device_words_dst || !device_freqs_dst) return psk_fail(ctx, PSK_EINVAL, "null buffer");
+    PSK_HIP(ctx, hipSetDevice(ctx->device));
+    PSK_HIP(ctx, hipMemcpyAsync(device_words_dst, L.words + start, count * 8, hipMemcpyDeviceToDevice, ctx->stream));
+    PSK_HIP(ctx, hipMemcpyAsync(device_freqs_dst, L.freqs + start, count * 4, hipMemcpyDeviceToDevice, ctx->stream));
+    PSK_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    return PSK_OK;
+}
+
+extern "C" int psk_set_list_device(psk_ctx *ctx, int sample_idx, const void *device_words, const void *device_freqs,
+                                   uint64_t n, uint64_t n_total)
+{
+    if (!ctx) return PSK_EINVAL;
+    if (ctx->k == 0) return psk_fail(ctx, PSK_ESTATE, "psk_begin has not been called");
+    if (sample_idx < 0 || sample_idx >= ctx->n_samples) return psk_fail(ctx, PSK_EINVAL, "sample index out of range");
+    if (n && (!device_words || !device_freqs)) return psk_fail(ctx, PSK_EINVAL, "null buffer");
+    if (n >= (1ull << 32)) return psk_fail(ctx, PSK_ERANGE, "list with more than 2^32 entries");
+    PSK_HIP(ctx, hipSetDevice(ctx->device));
+    SampleList &S = ctx->lists[sample_idx];
+    S = SampleList();
+    ctx->have_presence = false;
+    if (n) {
+        PSK_TRY(dev_reserve(ctx, ctx->misc, 64));
+        uint32_t *bad = ctx->misc.as<uint32_t>() + 12;
+        PSK_HIP(ctx, hipMemsetAsync(bad, 0, 4, ctx->stream));
+        list_check_kernel<<<div_up(n, 256), 256, 0, ctx->stream>>>(static_cast<const uint64_t *>(device_words), n, ctx->slab_lo,
+                                                                  ctx->slab_hi, bad);
+        PSK_HIP(ctx, hipGetLastError());
+        PSK_TRY(arena_alloc(ctx, n * 8, (void **)&S.words));
+        PSK_TRY(arena_alloc(ctx, n * 4, (void **)&S.freqs));
+        PSK_HIP(ctx, hipMemcpyAsync(S.words, device_words, n * 8, hipMemcpyDeviceToDevice, ctx->stream));
+        PSK_HIP(ctx, hipMemcpyAsync(S.freqs, device_freqs, n * 4, hipMemcpyDeviceToDevice, ctx->stream));
+        uint32_t h_bad = 0;
+        PSK_HIP(ctx, hipMemcpyAsync(&h_bad, bad, 4, hipMemcpyDeviceToHost, ctx->stream));
+        PSK_HIP(ctx, hipStreamSynchronize(ctx->stream));
+        if (h_bad) return psk_fail(ctx, PSK_EINVAL, "list of sample %d is not ascending inside the context's slab", sample_idx);
+    }
+    S.n_unique = n;
+    S.n_total = n_total;
+    S.done = true;
+    return PSK_OK;
+}
+
 extern "C" int psk_lookup_counts(psk_ctx *ctx, int sample_idx, const uint64_t *words, uint64_t n, uint32_t *freqs)
 {
     if (!ctx) return PSK_EINVAL;

@@ -244,3 +244,94 @@ class SurvivorExchange:
             if out is not None:
                 return out
             self._alloc(self.cap * 4)
+
+
+def owner_of(sample_idx, world):
+    """Rank that counts sample `sample_idx` in the sample-parallel ingest (round robin: neighbouring samples, which
+    tend to be of similar size, spread over the ranks)."""
+    return sample_idx % world
+
+
+class ListExchange:
+    """Multi-GPU ingest without redundant counting: every sample is counted, unfiltered, on ONE rank (context
+    `cnt_ctx`, samples numbered locally in ascending global order); a slab of the word space is a contiguous range
+    of the sorted list, so each rank then sends range s of each of its lists to rank s -- one all-to-all(v) of the
+    words and one of the counts (RCCL over xGMI with nccl; staged through host tensors with gloo) -- and installs
+    what it receives as the lists of its slab context (psk_set_list_device).  The lists every rank ends up with are
+    the ones it would have counted itself with the slab filter."""
+
+    def __init__(self, group, k):
+        import torch
+        self.g = group
+        self.torch = torch
+        self.k = int(k)
+        self.nccl = getattr(group, "backend", None) == "nccl"
+        self.dev = torch.device("cuda", torch.cuda.current_device()) if torch.cuda.is_available() else torch.device("cpu")
+
+    def _all_gather_i64(self, arr):
+        torch, dist = self.torch, self.g._dist
+        t = torch.from_numpy(np.ascontiguousarray(arr, dtype=np.int64)).to(self.g._dev)
+        outs = [torch.zeros_like(t) for _ in range(self.g.world)]
+        dist.all_gather(outs, t)
+        return [o.cpu().numpy() for o in outs]
+
+    def run(self, cnt_ctx, slab_ctx, n_samples, n_total_own):
+        """cnt_ctx holds the lists of this rank's samples (local index j = j-th sample i with owner_of(i) == rank);
+        slab_ctx has been begun with this rank's slab and n_samples.  Returns the number of (word, sample) pairs
+        installed."""
+        torch, dist = self.torch, self.g._dist
+        W, r = self.g.world, self.g.rank
+        own = [i for i in range(n_samples) if owner_of(i, W) == r]
+        per = (n_samples + W - 1) // W                       # rows of the count table, the same on every rank
+        bounds = [slab_bounds(self.k, W, d)[0] for d in range(W)] + [0]
+        cuts = cnt_ctx.lists_split(0, len(own), bounds) if own else np.zeros((0, W + 1), np.int64)
+        seg = np.zeros((per, W), dtype=np.int64)             # seg[j][d]: entries of my j-th sample that go to rank d
+        tot = np.zeros(per, dtype=np.int64)
+        if own:
+            seg[: len(own)] = np.diff(cuts, axis=1)
+            tot[: len(own)] = np.asarray(n_total_own, dtype=np.int64)
+        tables = self._all_gather_i64(np.concatenate([seg.ravel(), tot]))
+        seg_all = [t[: per * W].reshape(per, W) for t in tables]     # seg_all[src][j][dst]
+        tot_all = [t[per * W:] for t in tables]
+        send_counts = [int(seg[:, d].sum()) for d in range(W)]
+        recv_counts = [int(seg_all[src][:, r].sum()) for src in range(W)]
+        stage = self.dev if torch.cuda.is_available() else torch.device("cpu")
+        send_w = torch.empty(max(sum(send_counts), 1), dtype=torch.int64, device=stage)
+        send_f = torch.empty(max(sum(send_counts), 1), dtype=torch.int32, device=stage)
+        off = 0
+        for d in range(W):                                   # destination-major, my samples in order inside
+            for j in range(len(own)):
+                c = int(seg[j, d])
+                if c:
+                    cnt_ctx.copy_list_range(j, int(cuts[j, d]), c, send_w.data_ptr() + 8 * off, send_f.data_ptr() + 4 * off)
+                    off += c
+        n_recv = sum(recv_counts)
+        if self.nccl:
+            recv_w = torch.empty(max(n_recv, 1), dtype=torch.int64, device=stage)
+            recv_f = torch.empty(max(n_recv, 1), dtype=torch.int32, device=stage)
+            torch.cuda.synchronize()
+            dist.all_to_all_single(recv_w[:n_recv], send_w[: sum(send_counts)], recv_counts, send_counts)
+            dist.all_to_all_single(recv_f[:n_recv], send_f[: sum(send_counts)], recv_counts, send_counts)
+            torch.cuda.synchronize()
+        else:                                                # host-staged collectives, device buffers either side
+            hw = torch.empty(max(n_recv, 1), dtype=torch.int64)
+            hf = torch.empty(max(n_recv, 1), dtype=torch.int32)
+            dist.all_to_all_single(hw[:n_recv], send_w[: sum(send_counts)].cpu(), recv_counts, send_counts)
+            dist.all_to_all_single(hf[:n_recv], send_f[: sum(send_counts)].cpu(), recv_counts, send_counts)
+            recv_w, recv_f = hw.to(stage), hf.to(stage)
+            if torch.cuda.is_available():
+                torch.cuda.synchronize()
+        src_off = np.concatenate([[0], np.cumsum(recv_counts)])
+        pairs = 0
+        for src in range(W):
+            o = int(src_off[src])
+            j = 0
+            for i in range(n_samples):
+                if owner_of(i, W) != src:
+                    continue
+                c = int(seg_all[src][j, r])
+                slab_ctx.set_list_device(i, recv_w.data_ptr() + 8 * o, recv_f.data_ptr() + 4 * o, c, int(tot_all[src][j]))
+                o += c
+                pairs += c
+                j += 1
+        return pairs

@@ -119,6 +119,24 @@ class PskContext:
         self._check(self._lib.psk_get_list(self._h, int(sample_idx), _ptr(words), _ptr(freqs), n_unique), "psk_get_list")
         return words, freqs
 
+    # -- multi-GPU ingest: slab ranges of sorted lists (dist.ListExchange) ---------------------------
+    def lists_split(self, first_idx, n, bounds):
+        """offsets[i][b] = number of words of sample first_idx + i below bounds[b] (a 0 after the first bound = end)."""
+        b = np.ascontiguousarray(bounds, dtype=np.uint64)
+        out = np.zeros((int(n), len(b)), dtype=np.uint64)
+        self._check(self._lib.psk_lists_split(self._h, int(first_idx), int(n), _ptr(b), len(b), _ptr(out)), "psk_lists_split")
+        return out.astype(np.int64)
+
+    def copy_list_range(self, sample_idx, start, count, dev_words_ptr, dev_freqs_ptr):
+        """Entries [start, start + count) of a list -> DEVICE buffers given as raw pointers (torch's data_ptr())."""
+        self._check(self._lib.psk_copy_list_range(self._h, int(sample_idx), int(start), int(count), ctypes.c_void_p(dev_words_ptr),
+                                                  ctypes.c_void_p(dev_freqs_ptr)), "psk_copy_list_range")
+
+    def set_list_device(self, sample_idx, dev_words_ptr, dev_freqs_ptr, n, n_total=0):
+        """Installs n (word, count) entries held in DEVICE memory as the list of sample_idx."""
+        self._check(self._lib.psk_set_list_device(self._h, int(sample_idx), ctypes.c_void_p(dev_words_ptr),
+                                                  ctypes.c_void_p(dev_freqs_ptr), int(n), int(n_total)), "psk_set_list_device")
+
     def lookup_counts(self, sample_idx, words):
         words = np.ascontiguousarray(words, dtype=np.uint64)
         out = np.zeros(len(words), dtype=np.uint32)

@@ -125,6 +125,37 @@ class Samples:
                 cls._record_lists(part, ctx.count_kmers_batch(lo, datas, n_threads, sketch=sketch))
 
     @classmethod
+    def get_kmer_lists_exchanged(cls, ctx, group, samples, n_threads):
+        """Several ranks: every sample is counted on ONE rank (round robin, no slab filter, a second context on the
+        same GPU) and the slab ranges of the sorted lists are exchanged GPU to GPU (dist.ListExchange) -- each rank
+        ends up with the lists it would have counted itself with its slab filter, without every rank framing and
+        scanning every file.  With -w the sketches of a rank's samples are all-gathered (every rank computes the
+        weights, the scans need them)."""
+        W, r = group.world, group.rank
+        own = [s for i, s in enumerate(samples) if _dist.owner_of(i, W) == r]
+        k = int(cls.kmer_length)
+        cnt = PskContext(group.device)
+        try:
+            cnt.begin(k, max(len(own), 1))
+            if own:
+                cls.get_kmer_lists_batched(cnt, own, n_threads)
+            _dist.ListExchange(group, k).run(cnt, ctx, len(samples), [s.n_total for s in own])
+        finally:
+            cnt.close()
+        if cls.use_weights:
+            mine = [np.asarray(s.sketch, dtype=np.uint64) for s in own]
+            head = np.array([len(m) for m in mine], dtype=np.uint64)
+            blobs = group.allgather_bytes(np.uint64(len(mine)).tobytes() + head.tobytes() + b"".join(m.tobytes() for m in mine))
+            for src, blob in enumerate(blobs):
+                cntb = int(np.frombuffer(blob, dtype=np.uint64, count=1)[0])
+                lens = np.frombuffer(blob, dtype=np.uint64, count=cntb, offset=8).astype(np.int64)
+                off = 8 + 8 * cntb
+                theirs = [s for i, s in enumerate(samples) if _dist.owner_of(i, W) == src]
+                for s, ln in zip(theirs, lens):
+                    s.sketch = np.frombuffer(blob, dtype=np.uint64, count=int(ln), offset=off).tolist()
+                    off += 8 * int(ln)
+
+    @classmethod
     def _record_lists(cls, part, res):
         """(n_unique, n_total[, sketches]) of one counting call -> the Samples objects, with the progress line."""
         nu, nt = res[0], res[1]
@@ -740,7 +771,11 @@ def modeling(args):
             lo, hi = _dist.slab_bounds(k, group.world, group.rank)
             ctx.begin(k, Samples.no_samples, lo, hi)
             _err(GREEN % "Generating the k-mer lists for input samples:" + "\n")
-            Samples.get_kmer_lists_batched(ctx, list(Input.samples.values()), max(1, min(int(Input.num_threads), 8)))
+            n_thr = max(1, min(int(Input.num_threads), 8))
+            if group.world > 1 and os.environ.get("PSK_REDUNDANT_INGEST") != "1":
+                Samples.get_kmer_lists_exchanged(ctx, group, list(Input.samples.values()), n_thr)
+            else:   # one rank -- or, as an A/B knob, every rank counts every sample and keeps its slab
+                Samples.get_kmer_lists_batched(ctx, list(Input.samples.values()), n_thr)
             _err("\n" + GREEN % "Generating the k-mer feature vector." + "\n")
             m_local = Samples.get_feature_vector(ctx)
             _err(GREEN % "Mapping samples to the feature vector space:" + "\n")

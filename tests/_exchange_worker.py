@@ -55,5 +55,21 @@ with PskContext(0) as ctx:
         x.collect(s)
         got = x.finish(s)
         assert np.array_equal(got[0]["word"], want[i % 2]), i
+# the ingest exchange over nccl (one rank: the all-to-all is a device-to-device copy through RCCL): lists counted in
+# one context, moved, installed in another -> the same lists, the same matrix
+from phenotypeseeker_amd.synth import GenomeSet  # noqa: E402
+gs = GenomeSet(5, 40_000, seed=3, gene_len=300)
+datas = [gs.sample(i)[1] for i in range(5)]
+with PskContext(0) as cnt, PskContext(0) as slab:
+    cnt.begin(11, 5)
+    nu, nt = cnt.count_kmers_batch(0, datas, 2)
+    slab.begin(11, 5)
+    pairs = dist.ListExchange(g, 11).run(cnt, slab, 5, nt)
+    assert pairs == sum(nu)
+    for i in range(5):
+        a, b = cnt.get_list(i, nu[i]), slab.get_list(i, nu[i])
+        assert np.array_equal(a[0], b[0]) and np.array_equal(a[1], b[1]), i
+    assert cnt.build_presence() == slab.build_presence()
+    assert np.array_equal(cnt.get_union(), slab.get_union())
 g.close()
 print("exchange ok", npass)

@@ -316,11 +316,13 @@ def test_l2_penalty_end_to_end(tmp_path):
         assert "Parameters:\nLogisticRegression(max_iter=1000" in summary and "penalty='l1'" not in summary
 
 
-def test_two_rank_modeling_writes_the_same_files(tmp_path):
-    """SURVEY.md 8(e) invariant on the real pipeline: `phenotypeseeker modeling` under torch.distributed.run with two
-    ranks (both on the one visible GPU, gloo collectives: PSK_SHARE_GPU / PSK_DIST_BACKEND) -- each rank counts only
-    its slab of the word space, the survivors are all-gathered, rank 0 writes -- produces byte-identical result
-    tables and the same model as the one-rank run."""
+@pytest.mark.parametrize("ranks,flags,ingest", [(2, [], "exchange"), (2, [], "redundant"), (3, ["-w", "--omit_B_correction", "--n_kmers", "100"], "exchange")])
+def test_multi_rank_modeling_writes_the_same_files(tmp_path, ranks, flags, ingest):
+    """SURVEY.md 8(e) invariant on the real pipeline: `phenotypeseeker modeling` under torch.distributed.run with
+    several ranks (all on the one visible GPU, gloo collectives: PSK_SHARE_GPU / PSK_DIST_BACKEND) produces
+    byte-identical result tables and the same model as the one-rank run.  Ingest either way: every sample counted
+    on one rank and the slab ranges of the lists exchanged (dist.ListExchange, the default), or every rank counting
+    every sample with its slab filter (PSK_REDUNDANT_INGEST=1); -w adds the sketch all-gather."""
     import subprocess
     import sys
     import joblib
@@ -330,14 +332,16 @@ def test_two_rank_modeling_writes_the_same_files(tmp_path):
     for d in (one, two):
         d.mkdir()
         _write_dataset(ds, str(d))
-    _run(one, ["modeling", "data.pheno"])
-    env = dict(os.environ, MASTER_ADDR="127.0.0.1", PSK_SHARE_GPU="1", PSK_DIST_BACKEND="gloo", OMP_NUM_THREADS="1")
-    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
-           "--master-port", "29619", os.path.join(ROOT, "scripts", "phenotypeseeker"), "modeling", "data.pheno"]
+    _run(one, ["modeling", "data.pheno"] + flags)
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", PSK_SHARE_GPU="1", PSK_DIST_BACKEND="gloo", OMP_NUM_THREADS="1",
+               PSK_REDUNDANT_INGEST="1" if ingest == "redundant" else "0")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(ranks), "--master-addr",
+           "127.0.0.1", "--master-port", "29619", os.path.join(ROOT, "scripts", "phenotypeseeker"), "modeling",
+           "data.pheno"] + flags
     r = subprocess.run(cmd, env=env, cwd=str(two), timeout=600, capture_output=True, text=True)
     assert r.returncode == 0, r.stderr[-3000:]
-    for name in ("chi2_results_Pheno.tsv", "chi2_results_Pheno_top1000.tsv", "Pheno_MLdf.csv",
-                 "k-mers_and_coefficients_in_log_reg_model_Pheno.txt"):
+    top = "chi2_results_Pheno_top%d.tsv" % (100 if flags else 1000)
+    for name in ("chi2_results_Pheno.tsv", top, "Pheno_MLdf.csv", "k-mers_and_coefficients_in_log_reg_model_Pheno.txt"):
         assert (one / name).read_bytes() == (two / name).read_bytes(), name
     a, b = joblib.load(str(one / "log_reg_model_Pheno.pkl")), joblib.load(str(two / "log_reg_model_Pheno.pkl"))
     assert list(a["kmers"]) == list(b["kmers"])

@@ -681,6 +681,65 @@ def test_batch_counting_with_slab_filter(ctx, oracle):
         assert np.array_equal(np.concatenate(got_f[i]), rf), i
 
 
+def test_list_split_copy_and_install_reproduce_the_slab_lists(ctx, oracle):
+    """The multi-GPU ingest's three calls (psk_lists_split / psk_copy_list_range / psk_set_list_device): lists
+    counted without a slab filter, cut at the slab bounds and installed into a slab context, are the lists -- and give
+    the union and matrix -- that counting with the slab filter gives; a list that is not ascending inside the slab
+    is refused."""
+    import ctypes
+    from phenotypeseeker_amd import dist as D
+    from phenotypeseeker_amd.engine import PskContext
+    from phenotypeseeker_amd.synth import GenomeSet
+    hip = ctypes.CDLL("libamdhip64.so")
+    k, n, world = 9, 6, 3
+    gs = GenomeSet(n, 30_000, seed=5, gene_len=300)
+    datas = [gs.sample(i)[1] for i in range(n)] + []
+    datas[4] = b""                                          # an empty sample
+    ctx.begin(k, n)
+    nu, nt = ctx.count_kmers_batch(0, datas, 2)
+    bounds = [D.slab_bounds(k, world, d)[0] for d in range(world)] + [0]
+    cuts = ctx.lists_split(0, n, bounds)
+    full = [ctx.get_list(i, nu[i]) for i in range(n)]
+    for i in range(n):
+        want = [int(np.searchsorted(full[i][0], np.uint64(b))) for b in bounds[:-1]] + [nu[i]]
+        assert cuts[i].tolist() == want, i
+    dw, df = ctypes.c_void_p(), ctypes.c_void_p()
+    cap = max(max(nu), 1)
+    assert hip.hipMalloc(ctypes.byref(dw), ctypes.c_size_t(cap * 8)) == 0
+    assert hip.hipMalloc(ctypes.byref(df), ctypes.c_size_t(cap * 4)) == 0
+    try:
+        with PskContext(0) as slab, PskContext(0) as ref:
+            for d in range(world):
+                lo, hi = D.slab_bounds(k, world, d)
+                slab.begin(k, n, lo, hi)
+                ref.begin(k, n, lo, hi)
+                rnu, _ = ref.count_kmers_batch(0, datas, 2)
+                for i in range(n):
+                    c = int(cuts[i, d + 1] - cuts[i, d])
+                    ctx.copy_list_range(i, int(cuts[i, d]), c, dw.value, df.value)
+                    slab.set_list_device(i, dw.value, df.value, c, nt[i])
+                    assert c == rnu[i]
+                    a, b = slab.get_list(i, c), ref.get_list(i, c)
+                    assert np.array_equal(a[0], b[0]) and np.array_equal(a[1], b[1]), (d, i)
+                m1, m2 = slab.build_presence(), ref.build_presence()
+                assert m1 == m2
+                if m1:
+                    assert np.array_equal(slab.get_union(), ref.get_union())
+                    rows = np.arange(m1, dtype=np.uint64)
+                    assert np.array_equal(slab.get_rows(rows), ref.get_rows(rows))
+            # misuse: words outside the slab / not ascending
+            lo, hi = D.slab_bounds(k, world, 1)
+            slab.begin(k, n, lo, hi)
+            ctx.copy_list_range(0, 0, nu[0], dw.value, df.value)          # the whole list: starts below the slab
+            with pytest.raises(RuntimeError):
+                slab.set_list_device(0, dw.value, df.value, nu[0], 0)
+            with pytest.raises(RuntimeError):
+                ctx.copy_list_range(0, nu[0], 1, dw.value, df.value)      # beyond the end
+    finally:
+        hip.hipFree(dw)
+        hip.hipFree(df)
+
+
 def test_fastq_reads_and_gzip_input(ctx, oracle, tmp_path):
     """cfg-5 shape at test size: raw reads as FASTQ (constant quality line 'I...'), gzip-compressed on
     disk; the file reader inflates on the host, the list must equal the oracle's on the inflated bytes."""
