@@ -1,7 +1,8 @@
 """Worker for tests/test_dist_gloo.py (one rank of a world_size-2 gloo group on CPU).
 Each rank plays one slab of the range-sharded path with the oracle standing in for the GPU
 engine (no GPU in the CPU suite); what is under test is phenotypeseeker_amd.dist: slab bounds,
-the all-reduce of the union size and the all-gather(v)/merge of the per-slab survivors."""
+the all-reduce of the union size, the all-gather(v)/merge of the per-slab survivors, and the all-to-all of list
+ranges of the sample-parallel ingest (dist.ListExchange, host stand-ins for the two contexts)."""
 import os
 import sys
 
@@ -33,6 +34,59 @@ def slab_result(ds, lo, hi, m_global):
     return len(uw), out, bits[keep]
 
 
+class HostLists:
+    """Stands in for the counting context of dist.ListExchange: sorted lists in host memory."""
+
+    def __init__(self, lists):
+        self.lists = lists
+
+    def lists_split(self, first, n, bounds):
+        out = np.zeros((n, len(bounds)), dtype=np.int64)
+        for i in range(n):
+            w = self.lists[first + i][0]
+            for b, key in enumerate(bounds):
+                out[i, b] = len(w) if (b > 0 and key == 0) else int(np.searchsorted(w, np.uint64(key)))
+        return out
+
+    def copy_list_range(self, j, start, count, words_ptr, freqs_ptr):
+        import ctypes
+        w, f = self.lists[j]
+        ctypes.memmove(words_ptr, np.ascontiguousarray(w[start:start + count]).ctypes.data, count * 8)
+        ctypes.memmove(freqs_ptr, np.ascontiguousarray(f[start:start + count]).ctypes.data, count * 4)
+
+
+class HostSlab:
+    """Stands in for the slab context: keeps what psk_set_list_device would install."""
+
+    def __init__(self):
+        self.got = {}
+
+    def set_list_device(self, i, words_ptr, freqs_ptr, n, n_total=0):
+        import ctypes
+        w = np.ctypeslib.as_array((ctypes.c_uint64 * n).from_address(words_ptr)).copy() if n else np.zeros(0, np.uint64)
+        f = np.ctypeslib.as_array((ctypes.c_uint32 * n).from_address(freqs_ptr)).copy() if n else np.zeros(0, np.uint32)
+        self.got[i] = (w, f, n_total)
+
+
+def check_list_exchange(grp, ds):
+    """dist.ListExchange over gloo: every sample's list lives on ONE rank, after the all-to-all each rank must hold
+    the slab range of every sample's list."""
+    k, names, n = ds["meta"]["k"], ds["names"], len(ds["names"])
+    full = [O.count_kmers(ds["files"][nm], k)[:2] for nm in names]
+    own = [i for i in range(n) if dist.owner_of(i, grp.world) == grp.rank]
+    slab = HostSlab()
+    pairs = dist.ListExchange(grp, k).run(HostLists([full[i] for i in own]), slab, n, [int(full[i][1].sum()) for i in own])
+    lo, hi = dist.slab_bounds(k, grp.world, grp.rank)
+    assert sorted(slab.got) == list(range(n))
+    for i in range(n):
+        w, f = full[i]
+        sel = (w >= lo) & ((w < hi) if hi else np.ones(len(w), bool))
+        assert np.array_equal(slab.got[i][0], w[sel]) and np.array_equal(slab.got[i][1], f[sel]), i
+        assert slab.got[i][2] == int(f.sum())
+    assert pairs == sum(len(v[0]) for v in slab.got.values())
+    return pairs
+
+
 def main():
     out_path = sys.argv[1]
     grp = dist.Group().init("gloo")
@@ -43,11 +97,12 @@ def main():
     m_global = grp.allreduce_sum(int(m_local))
     _, res, bits = slab_result(ds, lo, hi, m_global)
     merged, mbits = dist.merge_candidates(grp.allgather_bytes(dist.pack_candidates(res, bits)))
+    pairs = grp.allreduce_sum(int(check_list_exchange(grp, ds)))
     tmax = grp.allreduce_max(float(grp.rank + 1))
     grp.barrier()
     if grp.rank == 0:
         np.savez(out_path, m_global=m_global, word=merged["word"], stat=merged["stat"], p=merged["p"],
-                 n_with=merged["n_with"], bits=mbits, tmax=tmax, world=grp.world)
+                 n_with=merged["n_with"], bits=mbits, tmax=tmax, world=grp.world, pairs=pairs)
     grp.close()
 
 

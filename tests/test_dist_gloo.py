@@ -50,6 +50,7 @@ def test_two_rank_gloo_run_equals_single_rank(tmp_path, oracle):
     wl = [oracle.count_kmers(ds["files"][nm], k)[0] for nm in names]
     uw = oracle.union(wl)
     assert int(z["m_global"]) == len(uw) == ds["meta"]["n_union"]
+    assert int(z["pairs"]) == sum(len(w) for w in wl)   # the list exchange moved every (word, sample) pair once
     bits = oracle.presence_bits(wl, uw, wpr=z["bits"].shape[1])
     ref = oracle.chi2_scan(bits, ds["pheno"], np.ones(n), n, 2, n - 2, 0.05, True, len(uw))
     keep = np.nonzero(ref["keep"])[0]
