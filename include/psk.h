@@ -90,16 +90,18 @@ int psk_get_list(psk_ctx *ctx, int sample_idx, uint64_t *words, uint32_t *freqs,
  * ListExchange.)  A slab of the word space is a contiguous range of a sorted list, so the hand-over is three calls:
  *   psk_lists_split     offsets_out[i * n_bounds + b] = number of words of sample first + i below bounds[b]
  *                       (bounds ascending; a bound of 0 after the first entry means "end of the word space")
- *   psk_copy_list_range copies entries [start, start + count) of a list into DEVICE buffers (the send buffers of
- *                       the all-to-all), on the context's stream, waited for
- *   psk_set_list_device installs `n` (word, count) entries held in DEVICE memory -- ascending, inside this
- *                       context's slab -- as the list of sample_idx (copied into the context's own storage) */
+ *   psk_copy_list_ranges  packs ranges [start[r], start[r] + count[r]) of the lists sample_idx[r], back to back,
+ *                         into DEVICE buffers (the send buffers of the all-to-all); waited for
+ *   psk_set_lists_device  installs n_lists lists held back to back in DEVICE memory -- count[r] (word, count)
+ *                         entries each, ascending, inside this context's slab (checked: PSK_EINVAL otherwise, and
+ *                         none of them is kept) -- as the lists of sample_idx[r]; they are copied into the
+ *                         context's own storage.  n_total[r] (may be NULL) is what psk_count_kmers would report. */
 int psk_lists_split(psk_ctx *ctx, int first_sample_idx, int n, const uint64_t *bounds, int n_bounds,
                     uint64_t *offsets_out);
-int psk_copy_list_range(psk_ctx *ctx, int sample_idx, uint64_t start, uint64_t count, void *device_words_dst,
-                        void *device_freqs_dst);
-int psk_set_list_device(psk_ctx *ctx, int sample_idx, const void *device_words, const void *device_freqs, uint64_t n,
-                        uint64_t n_total);
+int psk_copy_list_ranges(psk_ctx *ctx, int n_ranges, const int32_t *sample_idx, const uint64_t *start,
+                         const uint64_t *count, void *device_words_dst, void *device_freqs_dst);
+int psk_set_lists_device(psk_ctx *ctx, int n_lists, const int32_t *sample_idx, const uint64_t *count,
+                         const uint64_t *n_total, const void *device_words, const void *device_freqs);
 /* Frequencies of `n` given canonical words in sample_idx's list (0 if absent): the
  * `glistquery <sample>.list -l` mapping of modeling.py:324-329 restricted to the k-mers the
  * caller still needs (--real_counts columns of the ML matrix, modeling.py:693-695). */

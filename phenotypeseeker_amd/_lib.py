@@ -29,8 +29,8 @@ _SIGNATURES = {
     "psk_get_list": (c.c_int, [c.c_void_p, c.c_int, c.c_void_p, c.c_void_p, c.c_uint64]),
     "psk_lookup_counts": (c.c_int, [c.c_void_p, c.c_int, c.c_void_p, c.c_uint64, c.c_void_p]),
     "psk_lists_split": (c.c_int, [c.c_void_p, c.c_int, c.c_int, c.c_void_p, c.c_int, c.c_void_p]),
-    "psk_copy_list_range": (c.c_int, [c.c_void_p, c.c_int, c.c_uint64, c.c_uint64, c.c_void_p, c.c_void_p]),
-    "psk_set_list_device": (c.c_int, [c.c_void_p, c.c_int, c.c_void_p, c.c_void_p, c.c_uint64, c.c_uint64]),
+    "psk_copy_list_ranges": (c.c_int, [c.c_void_p, c.c_int, c.c_void_p, c.c_void_p, c.c_void_p, c.c_void_p, c.c_void_p]),
+    "psk_set_lists_device": (c.c_int, [c.c_void_p, c.c_int, c.c_void_p, c.c_void_p, c.c_void_p, c.c_void_p, c.c_void_p]),
     "psk_build_presence": (c.c_int, [c.c_void_p, _u64p]),
     "psk_presence_shape": (c.c_int, [c.c_void_p, _u64p, c.POINTER(c.c_int), c.POINTER(c.c_int)]),
     "psk_get_union": (c.c_int, [c.c_void_p, c.c_void_p, c.c_uint64]),

@@ -971,54 +971,87 @@ extern "C" int psk_lists_split(psk_ctx *ctx, int first_sample_idx, int n, const 
     return PSK_OK;
 }
 
-extern "C" int psk_copy_list_range(psk_ctx *ctx, int sample_idx, uint64_t start, uint64_t count, void *device_words_dst,
-                                   void *device_freqs_dst)
+extern "C" int psk_copy_list_ranges(psk_ctx *ctx, int n_ranges, const int32_t *sample_idx, const uint64_t *start,
+                                    const uint64_t *count, void *device_words_dst, void *device_freqs_dst)
 {
     if (!ctx) return PSK_EINVAL;
-    if (sample_idx < 0 || sample_idx >= ctx->n_samples || !ctx->lists[sample_idx].done)
-        return psk_fail(ctx, PSK_ESTATE, "sample %d has not been counted", sample_idx);
-    const SampleList &L = ctx->lists[sample_idx];
-    if (start > L.n_unique || count > L.n_unique - start) return psk_fail(ctx, PSK_ERANGE, "range outside the list");
-    if (count == 0) return PSK_OK;
+    if (n_ranges < 0) return psk_fail(ctx, PSK_EINVAL, "negative range count");
+    if (n_ranges == 0) return PSK_OK;
+    if (!sample_idx || !start || !count) return psk_fail(ctx, PSK_EINVAL, "null buffer");
+    uint64_t total = 0;
+    for (int r = 0; r < n_ranges; r++) {
+        const int si = sample_idx[r];
+        if (si < 0 || si >= ctx->n_samples || !ctx->lists[si].done)
+            return psk_fail(ctx, PSK_ESTATE, "sample %d has not been counted", si);
+        const SampleList &L = ctx->lists[si];
+        if (start[r] > L.n_unique || count[r] > L.n_unique - start[r])
+            return psk_fail(ctx, PSK_ERANGE, "range %d lies outside the list of sample %d", r, si);
+        total += count[r];
+    }
+    if (total == 0) return PSK_OK;
     if (!device_words_dst || !device_freqs_dst) return psk_fail(ctx, PSK_EINVAL, "null buffer");
     PSK_HIP(ctx, hipSetDevice(ctx->device));
-    PSK_HIP(ctx, hipMemcpyAsync(device_words_dst, L.words + start, count * 8, hipMemcpyDeviceToDevice, ctx->stream));
-    PSK_HIP(ctx, hipMemcpyAsync(device_freqs_dst, L.freqs + start, count * 4, hipMemcpyDeviceToDevice, ctx->stream));
+    uint64_t *dw = static_cast<uint64_t *>(device_words_dst);
+    uint32_t *df = static_cast<uint32_t *>(device_freqs_dst);
+    for (int r = 0; r < n_ranges; r++) {
+        if (count[r] == 0) continue;
+        const SampleList &L = ctx->lists[sample_idx[r]];
+        PSK_HIP(ctx, hipMemcpyAsync(dw, L.words + start[r], count[r] * 8, hipMemcpyDeviceToDevice, ctx->stream));
+        PSK_HIP(ctx, hipMemcpyAsync(df, L.freqs + start[r], count[r] * 4, hipMemcpyDeviceToDevice, ctx->stream));
+        dw += count[r];
+        df += count[r];
+    }
     PSK_HIP(ctx, hipStreamSynchronize(ctx->stream));
     return PSK_OK;
 }
 
-extern "C" int psk_set_list_device(psk_ctx *ctx, int sample_idx, const void *device_words, const void *device_freqs,
-                                   uint64_t n, uint64_t n_total)
+extern "C" int psk_set_lists_device(psk_ctx *ctx, int n_lists, const int32_t *sample_idx, const uint64_t *count,
+                                    const uint64_t *n_total, const void *device_words, const void *device_freqs)
 {
     if (!ctx) return PSK_EINVAL;
     if (ctx->k == 0) return psk_fail(ctx, PSK_ESTATE, "psk_begin has not been called");
-    if (sample_idx < 0 || sample_idx >= ctx->n_samples) return psk_fail(ctx, PSK_EINVAL, "sample index out of range");
-    if (n && (!device_words || !device_freqs)) return psk_fail(ctx, PSK_EINVAL, "null buffer");
-    if (n >= (1ull << 32)) return psk_fail(ctx, PSK_ERANGE, "list with more than 2^32 entries");
-    PSK_HIP(ctx, hipSetDevice(ctx->device));
-    SampleList &S = ctx->lists[sample_idx];
-    S = SampleList();
-    ctx->have_presence = false;
-    if (n) {
-        PSK_TRY(dev_reserve(ctx, ctx->misc, 64));
-        uint32_t *bad = ctx->misc.as<uint32_t>() + 12;
-        PSK_HIP(ctx, hipMemsetAsync(bad, 0, 4, ctx->stream));
-        list_check_kernel<<<div_up(n, 256), 256, 0, ctx->stream>>>(static_cast<const uint64_t *>(device_words), n, ctx->slab_lo,
-                                                                  ctx->slab_hi, bad);
-        PSK_HIP(ctx, hipGetLastError());
-        PSK_TRY(arena_alloc(ctx, n * 8, (void **)&S.words));
-        PSK_TRY(arena_alloc(ctx, n * 4, (void **)&S.freqs));
-        PSK_HIP(ctx, hipMemcpyAsync(S.words, device_words, n * 8, hipMemcpyDeviceToDevice, ctx->stream));
-        PSK_HIP(ctx, hipMemcpyAsync(S.freqs, device_freqs, n * 4, hipMemcpyDeviceToDevice, ctx->stream));
-        uint32_t h_bad = 0;
-        PSK_HIP(ctx, hipMemcpyAsync(&h_bad, bad, 4, hipMemcpyDeviceToHost, ctx->stream));
-        PSK_HIP(ctx, hipStreamSynchronize(ctx->stream));
-        if (h_bad) return psk_fail(ctx, PSK_EINVAL, "list of sample %d is not ascending inside the context's slab", sample_idx);
+    if (n_lists < 0) return psk_fail(ctx, PSK_EINVAL, "negative list count");
+    if (n_lists == 0) return PSK_OK;
+    if (!sample_idx || !count) return psk_fail(ctx, PSK_EINVAL, "null buffer");
+    uint64_t total = 0;
+    for (int r = 0; r < n_lists; r++) {
+        if (sample_idx[r] < 0 || sample_idx[r] >= ctx->n_samples) return psk_fail(ctx, PSK_EINVAL, "sample index out of range");
+        if (count[r] >= (1ull << 32)) return psk_fail(ctx, PSK_ERANGE, "list with more than 2^32 entries");
+        total += count[r];
     }
-    S.n_unique = n;
-    S.n_total = n_total;
-    S.done = true;
+    if (total && (!device_words || !device_freqs)) return psk_fail(ctx, PSK_EINVAL, "null buffer");
+    PSK_HIP(ctx, hipSetDevice(ctx->device));
+    ctx->have_presence = false;
+    PSK_TRY(dev_reserve(ctx, ctx->misc, 64));
+    uint32_t *bad = ctx->misc.as<uint32_t>() + 12;
+    PSK_HIP(ctx, hipMemsetAsync(bad, 0, 4, ctx->stream));
+    const uint64_t *sw = static_cast<const uint64_t *>(device_words);
+    const uint32_t *sf = static_cast<const uint32_t *>(device_freqs);
+    for (int r = 0; r < n_lists; r++) {
+        SampleList &S = ctx->lists[sample_idx[r]];
+        S = SampleList();
+        const uint64_t n = count[r];
+        if (n) {
+            list_check_kernel<<<div_up(n, 256), 256, 0, ctx->stream>>>(sw, n, ctx->slab_lo, ctx->slab_hi, bad);
+            PSK_HIP(ctx, hipGetLastError());
+            PSK_TRY(arena_alloc(ctx, n * 8, (void **)&S.words));
+            PSK_TRY(arena_alloc(ctx, n * 4, (void **)&S.freqs));
+            PSK_HIP(ctx, hipMemcpyAsync(S.words, sw, n * 8, hipMemcpyDeviceToDevice, ctx->stream));
+            PSK_HIP(ctx, hipMemcpyAsync(S.freqs, sf, n * 4, hipMemcpyDeviceToDevice, ctx->stream));
+            sw += n;
+            sf += n;
+        }
+        S.n_unique = n;
+        S.n_total = n_total ? n_total[r] : 0;
+        S.done = true;
+    }
+    uint32_t h_bad = 0;
+    PSK_HIP(ctx, hipMemcpyAsync(&h_bad, bad, 4, hipMemcpyDeviceToHost, ctx->stream));
+    PSK_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    if (h_bad) {
+        for (int r = 0; r < n_lists; r++) ctx->lists[sample_idx[r]] = SampleList();
+        return psk_fail(ctx, PSK_EINVAL, "a list does not ascend inside the context's slab");
+    }
     return PSK_OK;
 }
 

@@ -257,7 +257,7 @@ class ListExchange:
     `cnt_ctx`, samples numbered locally in ascending global order); a slab of the word space is a contiguous range
     of the sorted list, so each rank then sends range s of each of its lists to rank s -- one all-to-all(v) of the
     words and one of the counts (RCCL over xGMI with nccl; staged through host tensors with gloo) -- and installs
-    what it receives as the lists of its slab context (psk_set_list_device).  The lists every rank ends up with are
+    what it receives as the lists of its slab context (psk_set_lists_device).  The lists every rank ends up with are
     the ones it would have counted itself with the slab filter."""
 
     def __init__(self, group, k):
@@ -298,13 +298,11 @@ class ListExchange:
         stage = self.dev if torch.cuda.is_available() else torch.device("cpu")
         send_w = torch.empty(max(sum(send_counts), 1), dtype=torch.int64, device=stage)
         send_f = torch.empty(max(sum(send_counts), 1), dtype=torch.int32, device=stage)
-        off = 0
-        for d in range(W):                                   # destination-major, my samples in order inside
-            for j in range(len(own)):
-                c = int(seg[j, d])
-                if c:
-                    cnt_ctx.copy_list_range(j, int(cuts[j, d]), c, send_w.data_ptr() + 8 * off, send_f.data_ptr() + 4 * off)
-                    off += c
+        # destination-major, my samples in order inside: one packing call
+        rs = [(j, int(cuts[j, d]), int(seg[j, d])) for d in range(W) for j in range(len(own))]
+        if rs:
+            cnt_ctx.copy_list_ranges([x[0] for x in rs], [x[1] for x in rs], [x[2] for x in rs], send_w.data_ptr(),
+                                     send_f.data_ptr())
         n_recv = sum(recv_counts)
         if self.nccl:
             recv_w = torch.empty(max(n_recv, 1), dtype=torch.int64, device=stage)
@@ -321,17 +319,12 @@ class ListExchange:
             recv_w, recv_f = hw.to(stage), hf.to(stage)
             if torch.cuda.is_available():
                 torch.cuda.synchronize()
-        src_off = np.concatenate([[0], np.cumsum(recv_counts)])
-        pairs = 0
+        # what arrived is source-major, the source's samples in order inside: one installing call
+        idx, cnt, tot = [], [], []
         for src in range(W):
-            o = int(src_off[src])
-            j = 0
-            for i in range(n_samples):
-                if owner_of(i, W) != src:
-                    continue
-                c = int(seg_all[src][j, r])
-                slab_ctx.set_list_device(i, recv_w.data_ptr() + 8 * o, recv_f.data_ptr() + 4 * o, c, int(tot_all[src][j]))
-                o += c
-                pairs += c
-                j += 1
-        return pairs
+            theirs = [i for i in range(n_samples) if owner_of(i, W) == src]
+            idx += theirs
+            cnt += [int(seg_all[src][j, r]) for j in range(len(theirs))]
+            tot += [int(tot_all[src][j]) for j in range(len(theirs))]
+        slab_ctx.set_lists_device(idx, cnt, tot, recv_w.data_ptr(), recv_f.data_ptr())
+        return int(sum(cnt))

@@ -127,15 +127,22 @@ class PskContext:
         self._check(self._lib.psk_lists_split(self._h, int(first_idx), int(n), _ptr(b), len(b), _ptr(out)), "psk_lists_split")
         return out.astype(np.int64)
 
-    def copy_list_range(self, sample_idx, start, count, dev_words_ptr, dev_freqs_ptr):
-        """Entries [start, start + count) of a list -> DEVICE buffers given as raw pointers (torch's data_ptr())."""
-        self._check(self._lib.psk_copy_list_range(self._h, int(sample_idx), int(start), int(count), ctypes.c_void_p(dev_words_ptr),
-                                                  ctypes.c_void_p(dev_freqs_ptr)), "psk_copy_list_range")
+    def copy_list_ranges(self, sample_idx, start, count, dev_words_ptr, dev_freqs_ptr):
+        """Ranges [start[r], start[r] + count[r]) of the lists sample_idx[r], packed back to back into DEVICE buffers
+        given as raw pointers (torch's data_ptr())."""
+        si = np.ascontiguousarray(sample_idx, dtype=np.int32)
+        st = np.ascontiguousarray(start, dtype=np.uint64)
+        ct = np.ascontiguousarray(count, dtype=np.uint64)
+        self._check(self._lib.psk_copy_list_ranges(self._h, len(si), _ptr(si), _ptr(st), _ptr(ct), ctypes.c_void_p(dev_words_ptr),
+                                                   ctypes.c_void_p(dev_freqs_ptr)), "psk_copy_list_ranges")
 
-    def set_list_device(self, sample_idx, dev_words_ptr, dev_freqs_ptr, n, n_total=0):
-        """Installs n (word, count) entries held in DEVICE memory as the list of sample_idx."""
-        self._check(self._lib.psk_set_list_device(self._h, int(sample_idx), ctypes.c_void_p(dev_words_ptr),
-                                                  ctypes.c_void_p(dev_freqs_ptr), int(n), int(n_total)), "psk_set_list_device")
+    def set_lists_device(self, sample_idx, count, n_total, dev_words_ptr, dev_freqs_ptr):
+        """Installs len(sample_idx) lists held back to back in DEVICE memory as the lists of those samples."""
+        si = np.ascontiguousarray(sample_idx, dtype=np.int32)
+        ct = np.ascontiguousarray(count, dtype=np.uint64)
+        tot = np.ascontiguousarray(n_total, dtype=np.uint64)
+        self._check(self._lib.psk_set_lists_device(self._h, len(si), _ptr(si), _ptr(ct), _ptr(tot), ctypes.c_void_p(dev_words_ptr),
+                                                   ctypes.c_void_p(dev_freqs_ptr)), "psk_set_lists_device")
 
     def lookup_counts(self, sample_idx, words):
         words = np.ascontiguousarray(words, dtype=np.uint64)

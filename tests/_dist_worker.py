@@ -48,24 +48,30 @@ class HostLists:
                 out[i, b] = len(w) if (b > 0 and key == 0) else int(np.searchsorted(w, np.uint64(key)))
         return out
 
-    def copy_list_range(self, j, start, count, words_ptr, freqs_ptr):
+    def copy_list_ranges(self, sample_idx, start, count, words_ptr, freqs_ptr):
         import ctypes
-        w, f = self.lists[j]
-        ctypes.memmove(words_ptr, np.ascontiguousarray(w[start:start + count]).ctypes.data, count * 8)
-        ctypes.memmove(freqs_ptr, np.ascontiguousarray(f[start:start + count]).ctypes.data, count * 4)
+        off = 0
+        for j, st, c in zip(sample_idx, start, count):
+            w, f = self.lists[j]
+            ctypes.memmove(words_ptr + 8 * off, np.ascontiguousarray(w[st:st + c]).ctypes.data, c * 8)
+            ctypes.memmove(freqs_ptr + 4 * off, np.ascontiguousarray(f[st:st + c]).ctypes.data, c * 4)
+            off += c
 
 
 class HostSlab:
-    """Stands in for the slab context: keeps what psk_set_list_device would install."""
+    """Stands in for the slab context: keeps what psk_set_lists_device would install."""
 
     def __init__(self):
         self.got = {}
 
-    def set_list_device(self, i, words_ptr, freqs_ptr, n, n_total=0):
+    def set_lists_device(self, sample_idx, count, n_total, words_ptr, freqs_ptr):
         import ctypes
-        w = np.ctypeslib.as_array((ctypes.c_uint64 * n).from_address(words_ptr)).copy() if n else np.zeros(0, np.uint64)
-        f = np.ctypeslib.as_array((ctypes.c_uint32 * n).from_address(freqs_ptr)).copy() if n else np.zeros(0, np.uint32)
-        self.got[i] = (w, f, n_total)
+        off = 0
+        for i, n, tot in zip(sample_idx, count, n_total):
+            w = np.ctypeslib.as_array((ctypes.c_uint64 * n).from_address(words_ptr + 8 * off)).copy() if n else np.zeros(0, np.uint64)
+            f = np.ctypeslib.as_array((ctypes.c_uint32 * n).from_address(freqs_ptr + 4 * off)).copy() if n else np.zeros(0, np.uint32)
+            self.got[i] = (w, f, tot)
+            off += n
 
 
 def check_list_exchange(grp, ds):

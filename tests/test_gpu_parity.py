@@ -682,7 +682,7 @@ def test_batch_counting_with_slab_filter(ctx, oracle):
 
 
 def test_list_split_copy_and_install_reproduce_the_slab_lists(ctx, oracle):
-    """The multi-GPU ingest's three calls (psk_lists_split / psk_copy_list_range / psk_set_list_device): lists
+    """The multi-GPU ingest's three calls (psk_lists_split / psk_copy_list_ranges / psk_set_lists_device): lists
     counted without a slab filter, cut at the slab bounds and installed into a slab context, are the lists -- and give
     the union and matrix -- that counting with the slab filter gives; a list that is not ascending inside the slab
     is refused."""
@@ -704,7 +704,7 @@ def test_list_split_copy_and_install_reproduce_the_slab_lists(ctx, oracle):
         want = [int(np.searchsorted(full[i][0], np.uint64(b))) for b in bounds[:-1]] + [nu[i]]
         assert cuts[i].tolist() == want, i
     dw, df = ctypes.c_void_p(), ctypes.c_void_p()
-    cap = max(max(nu), 1)
+    cap = max(sum(nu), 1)
     assert hip.hipMalloc(ctypes.byref(dw), ctypes.c_size_t(cap * 8)) == 0
     assert hip.hipMalloc(ctypes.byref(df), ctypes.c_size_t(cap * 4)) == 0
     try:
@@ -714,12 +714,13 @@ def test_list_split_copy_and_install_reproduce_the_slab_lists(ctx, oracle):
                 slab.begin(k, n, lo, hi)
                 ref.begin(k, n, lo, hi)
                 rnu, _ = ref.count_kmers_batch(0, datas, 2)
+                cnt = [int(cuts[i, d + 1] - cuts[i, d]) for i in range(n)]
+                order = [3, 0, 5, 1, 4, 2]                       # any order, as long as both calls agree
+                ctx.copy_list_ranges(order, [int(cuts[i, d]) for i in order], [cnt[i] for i in order], dw.value, df.value)
+                slab.set_lists_device(order, [cnt[i] for i in order], [nt[i] for i in order], dw.value, df.value)
                 for i in range(n):
-                    c = int(cuts[i, d + 1] - cuts[i, d])
-                    ctx.copy_list_range(i, int(cuts[i, d]), c, dw.value, df.value)
-                    slab.set_list_device(i, dw.value, df.value, c, nt[i])
-                    assert c == rnu[i]
-                    a, b = slab.get_list(i, c), ref.get_list(i, c)
+                    assert cnt[i] == rnu[i]
+                    a, b = slab.get_list(i, cnt[i]), ref.get_list(i, cnt[i])
                     assert np.array_equal(a[0], b[0]) and np.array_equal(a[1], b[1]), (d, i)
                 m1, m2 = slab.build_presence(), ref.build_presence()
                 assert m1 == m2
@@ -730,11 +731,13 @@ def test_list_split_copy_and_install_reproduce_the_slab_lists(ctx, oracle):
             # misuse: words outside the slab / not ascending
             lo, hi = D.slab_bounds(k, world, 1)
             slab.begin(k, n, lo, hi)
-            ctx.copy_list_range(0, 0, nu[0], dw.value, df.value)          # the whole list: starts below the slab
+            ctx.copy_list_ranges([0], [0], [nu[0]], dw.value, df.value)    # the whole list: starts below the slab
             with pytest.raises(RuntimeError):
-                slab.set_list_device(0, dw.value, df.value, nu[0], 0)
+                slab.set_lists_device([0], [nu[0]], [0], dw.value, df.value)
             with pytest.raises(RuntimeError):
-                ctx.copy_list_range(0, nu[0], 1, dw.value, df.value)      # beyond the end
+                slab.get_list(0, 0)                                        # ... and nothing of it was kept
+            with pytest.raises(RuntimeError):
+                ctx.copy_list_ranges([0], [nu[0]], [1], dw.value, df.value)   # beyond the end
     finally:
         hip.hipFree(dw)
         hip.hipFree(df)
