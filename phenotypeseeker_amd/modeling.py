@@ -772,10 +772,20 @@ def modeling(args):
             ctx.begin(k, Samples.no_samples, lo, hi)
             _err(GREEN % "Generating the k-mer lists for input samples:" + "\n")
             n_thr = max(1, min(int(Input.num_threads), 8))
-            if group.world > 1 and os.environ.get("PSK_REDUNDANT_INGEST") != "1":
+            t_lists = time.time()
+            # several ranks: the list exchange when the collectives run GPU to GPU (nccl = RCCL); with gloo they are
+            # staged through the host (7 GB through TCP loopback for 2 x 128 genomes: 5.7 s against 0.12 s), so
+            # every rank counts everything there.  PSK_REDUNDANT_INGEST = 0 / 1 forces either.
+            knob = os.environ.get("PSK_REDUNDANT_INGEST")
+            exchange = group.world > 1 and (knob == "0" or (knob != "1" and getattr(group, "backend", None) == "nccl"))
+            if exchange:
                 Samples.get_kmer_lists_exchanged(ctx, group, list(Input.samples.values()), n_thr)
             else:   # one rank -- or, as an A/B knob, every rank counts every sample and keeps its slab
                 Samples.get_kmer_lists_batched(ctx, list(Input.samples.values()), n_thr)
+            if group.rank == 0:
+                with open("log.txt", "a") as log:
+                    log.write("Func get_kmer_lists took %s secs (%d rank(s)%s)\n"
+                              % (time.time() - t_lists, group.world, ", list exchange" if exchange else ""))
             _err("\n" + GREEN % "Generating the k-mer feature vector." + "\n")
             m_local = Samples.get_feature_vector(ctx)
             _err(GREEN % "Mapping samples to the feature vector space:" + "\n")
