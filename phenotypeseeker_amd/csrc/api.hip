@@ -166,6 +166,16 @@ extern "C" int psk_begin(psk_ctx *ctx, int k, int n_samples, uint64_t slab_lo, u
     if (n_samples < 1) return psk_fail(ctx, PSK_EINVAL, "n_samples must be >= 1");
     if (slab_hi != 0 && slab_hi <= slab_lo) return psk_fail(ctx, PSK_EINVAL, "empty slab");
     PSK_HIP(ctx, hipSetDevice(ctx->device));
+    // a new run: nothing of the previous one may still be in flight, and its scan results are gone
+    PSK_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    for (ScanSlot &sl : ctx->slot) {
+        if (sl.export_pending) PSK_HIP(ctx, hipEventSynchronize(sl.ev_export));  // an export on the caller's stream
+        sl.in_flight = false;
+        sl.export_pending = false;
+    }
+    ctx->n_in_flight = 0;
+    ctx->results_valid = false;
+    ctx->dense_hint = -1;
     reset_lists(ctx, n_samples);
     ctx->k = k;
     ctx->n_samples = n_samples;
