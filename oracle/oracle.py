@@ -48,6 +48,8 @@ def lib():
                                     c.c_int, c.c_double, c.c_int, c.c_uint64, c.c_void_p, c.c_void_p, c.c_void_p,
                                     c.c_void_p]
         L.orc_chi2_scan.restype = None
+        L.orc_chi2_scan_mt.argtypes = L.orc_chi2_scan.argtypes + [c.c_int]
+        L.orc_chi2_scan_mt.restype = c.c_int
         L.orc_ttest_row.argtypes = [c.c_void_p, c.c_void_p, c.c_void_p, c.c_void_p, c.c_int, c.c_int, c.c_int,
                                     c.POINTER(c.c_double), c.POINTER(c.c_double), c.POINTER(c.c_double),
                                     c.POINTER(c.c_double), c.POINTER(c.c_int)]
@@ -224,20 +226,34 @@ def chi2_keep(p, pvalue_cutoff, omit_B, n_kmers):
     return bool(lib().orc_chi2_keep(float(p), float(pvalue_cutoff), int(bool(omit_B)), int(n_kmers)))
 
 
-def chi2_scan(bits, pheno, weights, n_samples, min_samples, max_samples, pvalue_cutoff, omit_B, n_kmers):
-    """The hot loop modeling.py:677-714 over a bit matrix.  Returns dict of per-row arrays."""
+def chi2_scan(bits, pheno, weights, n_samples, min_samples, max_samples, pvalue_cutoff, omit_B, n_kmers, n_threads=1,
+              scratch=None):
+    """The hot loop modeling.py:677-714 over a bit matrix.  Returns dict of per-row arrays.  n_threads > 1: the rows
+    are cut into that many ranges, one POSIX thread each (orc_chi2_scan_mt).  scratch: a dict this call fills with
+    its output arrays and a later call of the same shape reuses (timed passes then measure the scan, not 21 bytes
+    per row of fresh zero pages)."""
     L = lib()
     bits = np.ascontiguousarray(bits, dtype=np.uint64)
     n_rows, wpr = bits.shape
     ph = _pheno_i8(pheno)
     w = np.ascontiguousarray(weights, dtype=np.float64)
-    keep = np.zeros(n_rows, dtype=np.uint8)
-    chi2 = np.zeros(n_rows, dtype=np.float64)
-    p = np.zeros(n_rows, dtype=np.float64)
-    n_with = np.zeros(n_rows, dtype=np.int32)
-    L.orc_chi2_scan(bits.ctypes.data, n_rows, wpr, ph.ctypes.data, w.ctypes.data, int(n_samples), int(min_samples),
-                    int(max_samples), float(pvalue_cutoff), int(bool(omit_B)), int(n_kmers), keep.ctypes.data,
-                    chi2.ctypes.data, p.ctypes.data, n_with.ctypes.data)
+    if scratch is not None and scratch.get("n_rows") == n_rows:
+        keep, chi2, p, n_with = scratch["arrays"]
+    else:
+        keep = np.zeros(n_rows, dtype=np.uint8)
+        chi2 = np.zeros(n_rows, dtype=np.float64)
+        p = np.zeros(n_rows, dtype=np.float64)
+        n_with = np.zeros(n_rows, dtype=np.int32)
+        if scratch is not None:
+            scratch["n_rows"], scratch["arrays"] = n_rows, (keep, chi2, p, n_with)
+    args = (bits.ctypes.data, n_rows, wpr, ph.ctypes.data, w.ctypes.data, int(n_samples), int(min_samples),
+            int(max_samples), float(pvalue_cutoff), int(bool(omit_B)), int(n_kmers), keep.ctypes.data,
+            chi2.ctypes.data, p.ctypes.data, n_with.ctypes.data)
+    if n_threads > 1:
+        if L.orc_chi2_scan_mt(*args, int(n_threads)) < 0:
+            raise MemoryError
+    else:
+        L.orc_chi2_scan(*args)
     return {"keep": keep.astype(bool), "stat": chi2, "p": p, "n_with": n_with}
 
 

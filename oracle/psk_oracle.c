@@ -17,6 +17,7 @@
  *
  * Plain scalar C, one thread.  Each function cites the reference lines it follows.
  */
+#include <pthread.h>
 #include <math.h>
 #include <stdint.h>
 #include <stdio.h>
@@ -301,6 +302,50 @@ void orc_chi2_scan(const uint64_t *bits, uint64_t n_rows, int wpr, const int8_t 
         }
     }
     free(pres);
+}
+
+/*
+ * orc_chi2_scan_mt: the same scan with the rows cut into n_threads contiguous ranges, one POSIX thread each (rows are
+ * independent: the reference itself runs them in a multiprocessing Pool over text chunks, modeling.py:659-675).
+ * bench.py times this as the all-cores CPU baseline.
+ */
+typedef struct {
+    const uint64_t *bits; uint64_t r0, r1; int wpr; const int8_t *pheno; const double *weight; int n_samples, min_samples,
+    max_samples; double pvalue_cutoff; int omit_B; uint64_t n_kmers; uint8_t *keep; double *chi2, *p; int32_t *n_with;
+} orc_scan_job;
+
+static void *orc_scan_worker(void *arg)
+{
+    const orc_scan_job *j = (const orc_scan_job *)arg;
+    orc_chi2_scan(j->bits + j->r0 * (uint64_t)j->wpr, j->r1 - j->r0, j->wpr, j->pheno, j->weight, j->n_samples, j->min_samples,
+                  j->max_samples, j->pvalue_cutoff, j->omit_B, j->n_kmers, j->keep + j->r0, j->chi2 + j->r0, j->p + j->r0,
+                  j->n_with + j->r0);
+    return NULL;
+}
+
+int orc_chi2_scan_mt(const uint64_t *bits, uint64_t n_rows, int wpr, const int8_t *pheno, const double *weight,
+                     int n_samples, int min_samples, int max_samples, double pvalue_cutoff, int omit_B,
+                     uint64_t n_kmers_to_analyse, uint8_t *keep, double *chi2, double *p, int32_t *n_with, int n_threads)
+{
+    if (n_threads < 1) n_threads = 1;
+    orc_scan_job *jobs = (orc_scan_job *)malloc((size_t)n_threads * sizeof(orc_scan_job));
+    pthread_t *tid = (pthread_t *)malloc((size_t)n_threads * sizeof(pthread_t));
+    if (!jobs || !tid) { free(jobs); free(tid); return -1; }
+    int started = 0, rc = 0;
+    for (int t = 0; t < n_threads; t++) {
+        orc_scan_job j = {bits, n_rows * (uint64_t)t / (uint64_t)n_threads, n_rows * (uint64_t)(t + 1) / (uint64_t)n_threads, wpr,
+                          pheno, weight, n_samples, min_samples, max_samples, pvalue_cutoff, omit_B, n_kmers_to_analyse,
+                          keep, chi2, p, n_with};
+        jobs[t] = j;
+        if (pthread_create(&tid[t], NULL, orc_scan_worker, &jobs[t]) != 0) { rc = -1; break; }
+        started++;
+    }
+    for (int t = 0; t < started; t++) pthread_join(tid[t], NULL);
+    if (rc != 0)  /* could not start every thread: finish the rest here */
+        for (int t = started; t < n_threads; t++) orc_scan_worker(&jobs[t]);
+    free(jobs);
+    free(tid);
+    return started;
 }
 
 /* ------------------------------------------------------------------------------------------
