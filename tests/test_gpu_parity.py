@@ -344,6 +344,25 @@ def test_two_scans_in_flight_equal_the_one_call_scans(ctx):
                 with pytest.raises(RuntimeError):
                     ctx.get_results(c)                                      # ... whose results are gone
         assert ctx.scan_end() == want[2][0]                                 # none in flight: the last count again
+    # the two forms of the unweighted kernel give the same rows: the first scan of a matrix with the Bonferroni rule runs
+    # the in-line form, it keeps > 0.1 % of these rows, so the repeat runs the queued form (pick_chi2_mode)
+    ctx.synth_presence(m, n, seed=22)
+    c1 = ctx.chi2_scan(phs[0], None, 2, n - 2, 0.05, False, m)
+    r1 = ctx.get_results(c1)
+    assert c1 > m // 1000
+    c2 = ctx.chi2_scan(phs[0], None, 2, n - 2, 0.05, False, m)
+    r2 = ctx.get_results(c2)
+    assert c1 == c2 and all(np.array_equal(r1[key], r2[key]) for key in ("row", "stat", "p", "n_with"))
+    # psk_begin with scans in flight: waits for them and starts from a clean scan state
+    ctx.chi2_scan_begin(phs[0], None, 2, n - 2, 0.05, False, m)
+    ctx.chi2_scan_begin(phs[1], None, 2, n - 2, 0.05, False, m)
+    ctx.begin(13, n)
+    with pytest.raises(RuntimeError):
+        ctx.get_results(1)
+    ctx.synth_presence(1000, n, seed=3)
+    ctx.chi2_scan_begin(phs[0], None, 2, n - 2, 0.05, False, 1000)
+    ctx.chi2_scan_begin(phs[0], None, 2, n - 2, 0.05, False, 1000)      # two again: the old ones no longer count
+    assert ctx.scan_end() == ctx.scan_end()
 
 
 def _pattern_sums(X, w):
