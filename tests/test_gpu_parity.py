@@ -210,7 +210,7 @@ def test_chi2_scan_vs_oracle(ctx, oracle, n, weighted):
             assert np.array_equal(res["n_with"][gi], ref["n_with"][common])
 
 
-@pytest.mark.parametrize("n", [12, 64, 100, 256, 1024])
+@pytest.mark.parametrize("n", [12, 64, 100, 256, 1024, 2048, 9000])
 @pytest.mark.parametrize("weighted", [False, True])
 def test_ttest_scan_vs_oracle(ctx, oracle, n, weighted):
     from phenotypeseeker_amd.engine import words_per_row
