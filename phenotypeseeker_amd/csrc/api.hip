@@ -128,11 +128,13 @@ extern "C" void psk_free(psk_ctx *ctx)
         if (L.pinned_cnt) (void)hipHostFree(L.pinned_cnt);
         if (L.sk_host) (void)hipHostFree(L.sk_host);
         if (L.sk_done) (void)hipEventDestroy(L.sk_done);
+        if (L.sk_filtered) (void)hipEventDestroy(L.sk_filtered);
         if (L.done) (void)hipEventDestroy(L.done);
         if (L.raw_ready) (void)hipEventDestroy(L.raw_ready);
         if (L.raw_free) (void)hipEventDestroy(L.raw_free);
     }
     if (ctx->copy_stream) (void)hipStreamDestroy(ctx->copy_stream);
+    if (ctx->sketch_stream) { (void)hipStreamSynchronize(ctx->sketch_stream); (void)hipStreamDestroy(ctx->sketch_stream); }
     if (ctx->pinned) (void)hipHostFree(ctx->pinned);
     if (ctx->scan_pinned) (void)hipHostFree(ctx->scan_pinned);
     if (ctx->cnt_pinned) (void)hipHostFree(ctx->cnt_pinned);

@@ -845,6 +845,7 @@ static int count_batch_impl(psk_ctx *ctx, int first_sample_idx, int n, const uin
     {   // nothing of this call may still be in flight when it returns (the ring and the caller's buffers)
         const hipError_t e1 = hipStreamSynchronize(ctx->copy_stream ? ctx->copy_stream : ctx->stream);
         const hipError_t e2 = hipStreamSynchronize(ctx->stream);
+        if (ctx->sketch_stream) (void)hipStreamSynchronize(ctx->sketch_stream);
         if (rc == PSK_OK && (e1 != hipSuccess || e2 != hipSuccess))
             rc = psk_fail(ctx, PSK_EHIP, "stream synchronisation failed: %s", hipGetErrorString(e1 != hipSuccess ? e1 : e2));
         for (CountLane &L : ctx->lane) L.sample = -1;

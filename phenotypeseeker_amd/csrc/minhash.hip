@@ -242,7 +242,7 @@ int sketch_from_device(psk_ctx *ctx, const uint8_t *d_clean, uint64_t clean_len,
 }
 
 // The batch counter's form of the same sketch: queued on the context's stream behind the counting chain of the
-// sample and NOT waited for.  extract (sketch k) -> hash + filter at 6 s / clean_len of the hash space (~6 s
+// sample and NOT waited for.  extract (sketch k) -> hash + filter at 4 s / clean_len of the hash space (~4 s
 // candidates) -> one-workgroup LDS sort + distinct select -> result to pinned memory.  sketch_collect reads it one
 // sample later and falls back to sketch_from_device (tiny or very repetitive samples, sketch sizes whose candidates
 // do not fit the LDS sort) while the sample's clean stream is still in its lane.
@@ -251,8 +251,8 @@ int sketch_enqueue(psk_ctx *ctx, CountLane &L, const uint8_t *d_clean, uint64_t 
     L.sk_state = 2;
     if (clean_len == 0) return PSK_OK;
     if (clean_len >= (1ull << 32)) return psk_fail(ctx, PSK_ERANGE, "sample larger than 4 Gbases");
-    const double ratio = 6.0 * (double)sketch_size / (double)clean_len;
-    if (!(ratio < 0.5) || 6ull * (uint64_t)sketch_size + 600 > (uint64_t)SK_CAND_CAP) return PSK_OK;  // general route
+    const double ratio = 4.0 * (double)sketch_size / (double)clean_len;
+    if (!(ratio < 0.5) || 4ull * (uint64_t)sketch_size + 600 > (uint64_t)SK_CAND_CAP) return PSK_OK;  // general route
     const bool wide = (k > 16);
     const uint64_t mask = wide ? ~0ull : 0xffffffffull;
     const uint64_t limit = wide ? (uint64_t)(ratio * 18446744073709551616.0) : (uint64_t)(ratio * 4294967296.0);
@@ -267,7 +267,11 @@ int sketch_enqueue(psk_ctx *ctx, CountLane &L, const uint8_t *d_clean, uint64_t 
         PSK_HIP(ctx, hipHostMalloc(reinterpret_cast<void **>(&L.sk_host), res_bytes, hipHostMallocDefault));
         L.sk_host_cap = res_bytes;
     }
-    if (!L.sk_done) PSK_HIP(ctx, hipEventCreateWithFlags(&L.sk_done, hipEventDisableTiming));
+    if (!L.sk_done) {
+        PSK_HIP(ctx, hipEventCreateWithFlags(&L.sk_done, hipEventDisableTiming));
+        PSK_HIP(ctx, hipEventCreateWithFlags(&L.sk_filtered, hipEventDisableTiming));
+    }
+    if (!ctx->sketch_stream) PSK_HIP(ctx, hipStreamCreateWithFlags(&ctx->sketch_stream, hipStreamNonBlocking));
     uint32_t *d_n = L.sk_cand.as<uint32_t>();
     uint64_t *cand = L.sk_cand.as<uint64_t>() + 2;
     PSK_HIP(ctx, hipMemsetAsync(d_n, 0, 16, ctx->stream));
@@ -276,10 +280,15 @@ int sketch_enqueue(psk_ctx *ctx, CountLane &L, const uint8_t *d_clean, uint64_t 
                                                                            (uint64_t)seed, mask, limit, cand, (uint32_t)SK_CAND_CAP,
                                                                            d_n + 1);
     PSK_HIP(ctx, hipGetLastError());
-    sketch_select_kernel<<<1, SK_THREADS, 0, ctx->stream>>>(cand, d_n + 1, (uint32_t)sketch_size, L.sk_out.as<uint64_t>());
+    // the select is ONE workgroup sorting a few thousand hashes: on its own stream it runs beside the next sample's
+    // counting chain instead of holding the whole GPU for its ~0.1 ms (this lane's candidate buffer is not written
+    // again before sketch_collect has waited for sk_done)
+    PSK_HIP(ctx, hipEventRecord(L.sk_filtered, ctx->stream));
+    PSK_HIP(ctx, hipStreamWaitEvent(ctx->sketch_stream, L.sk_filtered, 0));
+    sketch_select_kernel<<<1, SK_THREADS, 0, ctx->sketch_stream>>>(cand, d_n + 1, (uint32_t)sketch_size, L.sk_out.as<uint64_t>());
     PSK_HIP(ctx, hipGetLastError());
-    PSK_HIP(ctx, hipMemcpyAsync(L.sk_host, L.sk_out.p, res_bytes, hipMemcpyDeviceToHost, ctx->stream));
-    PSK_HIP(ctx, hipEventRecord(L.sk_done, ctx->stream));
+    PSK_HIP(ctx, hipMemcpyAsync(L.sk_host, L.sk_out.p, res_bytes, hipMemcpyDeviceToHost, ctx->sketch_stream));
+    PSK_HIP(ctx, hipEventRecord(L.sk_done, ctx->sketch_stream));
     L.sk_state = 1;
     return PSK_OK;
 }

@@ -54,7 +54,7 @@ struct CountLane {
     DevBuf sk_cand, sk_out;          // [2 x u32 counters, pad | candidate hashes]; [distinct count | sketch]
     uint64_t *sk_host = nullptr;     // pinned landing of sk_out
     size_t sk_host_cap = 0;
-    hipEvent_t sk_done = nullptr;
+    hipEvent_t sk_done = nullptr, sk_filtered = nullptr;
     int sk_state = 0;                // 0 none, 1 queued, 2 the synchronous route has to serve this sample
 };
 
@@ -114,6 +114,7 @@ struct psk_ctx {
     void *cnt_pinned = nullptr;   // pinned landing buffer of the scan's result counters
     CountLane lane[2];
     hipStream_t copy_stream = nullptr;  // uploads of the batch counter overlap the previous sample's kernels
+    hipStream_t sketch_stream = nullptr;  // the one-workgroup sketch select runs beside the next sample's chain
 
     // presence matrix
     uint64_t n_kmers = 0;
