@@ -1,7 +1,8 @@
 #!/usr/bin/env python3
 """Randomised end-to-end check of the GPU path against the oracle (checker only): random sample sets (FASTA with
 breaks / lower case / empty samples, some FASTQ), random k, random slab; lists, union, presence bits and the
-chi2 survivors must be identical; also the batch sketches, two scans in flight, the weighted chi2 and the Welch scan.  Test infrastructure (it links the oracle): run by
+chi2 survivors must be identical; also the batch sketches, two scans in flight, the weighted chi2, the Welch scan,
+the dictionary counting of `prediction` and the list cut points of the multi-GPU ingest.  Test infrastructure (it links the oracle): run by
 tests/test_gpu_parity.py::test_randomised_pipeline_against_oracle, or by hand: python tests/_stress.py SECONDS [seed]"""
 import os
 import sys
@@ -67,6 +68,24 @@ with PskContext(0) as ctx:
             sel = (ow >= lo) & ((ow < hi) if hi else np.ones(len(ow), bool))
             assert np.array_equal(w, ow[sel]) and np.array_equal(f, of[sel]), ("list", rounds, i, k, lo, hi)
             ref_lists.append(ow[sel])
+        if rounds % 4 == 0 and n >= 2:
+            # prediction's dictionary counting: a dictionary drawn from two samples' own words plus absent ones,
+            # counted in a third sample (distinct canonical words: duplicates corrupt gmer_counter's counts too)
+            pool = np.unique(np.concatenate([O.count_kmers(datas[0], k)[0][:40], O.count_kmers(datas[n - 1], k)[0][-40:],
+                                             rng.integers(0, 1 << min(2 * k, 62), 20).astype(np.uint64)]))
+            pool = np.array(sorted({int(O.canonical_word(int(w), k)) for w in pool}), dtype=np.uint64)
+            if len(pool) >= 3:
+                who = int(rng.integers(0, n))
+                assert np.array_equal(ctx.count_dict(datas[who], k, pool), O.count_dict(datas[who], k, pool)), ("dict", rounds, k)
+        if rounds % 3 == 0 and n >= 2 and not (lo or hi):
+            # the multi-GPU ingest's cut points: psk_lists_split against searchsorted on the lists just checked
+            world = int(rng.integers(2, 6))
+            if world <= space:
+                bounds = [(space * d) // world for d in range(world)] + [0]
+                cuts = ctx.lists_split(0, n, bounds)
+                for i in range(n):
+                    want = [int(np.searchsorted(ref_lists[i], np.uint64(b))) for b in bounds[:-1]] + [len(ref_lists[i])]
+                    assert cuts[i].tolist() == want, ("split", rounds, i, k)
         m = ctx.build_presence()
         uw = O.union(ref_lists)
         assert m == len(uw), ("union size", rounds, k, m, len(uw))
