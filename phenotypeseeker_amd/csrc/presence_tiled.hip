@@ -138,11 +138,14 @@ __global__ __launch_bounds__(PT_THREADS) void tile_fill_kernel(const ListRef *__
     // them in LDS; the rows are then copied out by the whole workgroup with consecutive threads on consecutive
     // addresses (a thread writing its own 32-byte rows was 13 of the build's 17 ms)
     uint32_t *row_of = reinterpret_cast<uint32_t *>(blk + (size_t)R * wpr);  // R entries behind the block
-    const uint32_t rpt = R / PT_THREADS;  // R is a multiple of PT_THREADS (host)
+    // R is a power of two (host): a multiple of PT_THREADS, or -- many samples, wide rows -- a fraction of it, and
+    // then only the first R threads own a row
+    const uint32_t rpt = R >= PT_THREADS ? R / PT_THREADS : 1;
     uint32_t mine = 0;
     uint32_t nonempty = 0;  // bit q: row t * rpt + q is occupied (rpt <= 32)
     for (uint32_t q = 0; q < rpt; q++) {
         const uint32_t r = threadIdx.x * rpt + q;
+        if (r >= R) break;
         uint64_t any = 0;
         for (int c = 0; c < wpr; c++) any |= blk[(uint32_t)c * R + r];
         if (any) { nonempty |= 1u << q; mine++; }
@@ -174,20 +177,22 @@ int build_presence_tiled(psk_ctx *ctx, uint64_t total_pairs, uint64_t *n_kmers, 
     // rows are numbered in u32: the union of this slab must stay below 2^32 rows, which the pair count or the
     // number of canonical words of the slab (at most span / 2 + 2^k palindromes) guarantees
     if (total_pairs >= (1ull << 32) && span / 2 + (1ull << k) >= (1ull << 32)) return PSK_OK;
-    // tile size: the smallest LDS block (more workgroups per CU) whose tile table stays under 512 MB; rows per
-    // thread are capped at 32 (a bit mask in tile_fill)
+    // tile size: the smallest LDS block (more workgroups per CU) whose tile table stays under 4 GB (and small next
+    // to the lists, below); rows per thread are capped at 32 (a bit mask in tile_fill); with thousands of samples a
+    // row is hundreds of bytes and a tile holds fewer rows than the workgroup has threads (down to 64)
     uint32_t R = 0;
     uint64_t n_tiles64 = 0;
     const size_t forced = getenv("PSK_TILE_LDS_KB") ? (size_t)atoi(getenv("PSK_TILE_LDS_KB")) * 1024 : 0;
     for (size_t lds_try = forced ? forced : PT_LDS_MAX; lds_try <= PT_LDS_MAX; lds_try *= 2) {
         uint32_t r = (uint32_t)(lds_try / ((size_t)wpr * 8 + 4));  // bit block + the 4-byte entry of the occupied-row list
-        uint32_t p2 = PT_THREADS;
+        if (r < 64) { if (forced) break; continue; }  // not even 64 rows fit: too many samples for this block size
+        uint32_t p2 = 64;
         while ((uint64_t)p2 * 2 <= r) p2 *= 2;
         r = p2;
         if (r > 32u * PT_THREADS) r = 32u * PT_THREADS;
         if ((size_t)r * ((size_t)wpr * 8 + 4) > lds_try) { if (forced) break; continue; }  // too many samples for this block size
         const uint64_t nt = (span + r - 1) / r;
-        if (nt <= (1u << 22) && (nt + 1) * (uint64_t)n * 4 <= (512ull << 20)) { R = r; n_tiles64 = nt; break; }
+        if (nt <= (1u << 22) && (nt + 1) * (uint64_t)n * 4 <= (4096ull << 20)) { R = r; n_tiles64 = nt; break; }
         if (forced) break;
     }
     if (R == 0) return PSK_OK;

@@ -286,7 +286,9 @@ __global__ __launch_bounds__(SV_THREADS) void logreg_newglmnet_bits_kernel(
     const int polish_reps)
 {
     const size_t q_doubles = (size_t)q_doubles_i;  // LDS doubles reserved for the Gram block
-    const int f_lds = ALL_LDS ? 1 : f_lds_rt, s_lds = ALL_LDS ? 1 : s_lds_rt, c_lds = ALL_LDS ? 1 : c_lds_rt,
+    // s_lds_rt: bit 0 = the two sample arrays every per-feature gradient pass reads (tau, D) are in LDS, bit 1 = the
+    // other three (exp(w.x), its trial value, x.d: a few passes per Newton step) are
+    const int f_lds = ALL_LDS ? 1 : f_lds_rt, s_mode = ALL_LDS ? 3 : s_lds_rt, c_lds = ALL_LDS ? 1 : c_lds_rt,
               q_lds = ALL_LDS ? 1 : (q_doubles_i > 0);
     extern __shared__ double sm_all[];
     double *Qm = sm_all;  // Gram block of the covariance-form QP: square when (64 NS)^2 fits, else packed triangle
@@ -296,19 +298,22 @@ __global__ __launch_bounds__(SV_THREADS) void logreg_newglmnet_bits_kernel(
     const int tf = fit_fold[fit];
     const int P1 = p + 1, NP = W * 64;  // sample arrays are padded to whole words
     double *gw = work + (size_t)fit * (5 * (size_t)P1 + 5 * (size_t)NP);
-    // LDS layout: [feature arrays 5*P1 | active list P1 ints (padded)] if f_lds, [sample arrays 5*NP] if s_lds,
-    // [column bit words P1*W] if c_lds
+    // LDS layout: [feature arrays 5*P1 | active list P1 ints (padded)] if f_lds, [tau, D: 2*NP] if s_mode & 1,
+    // [exp(w.x), its trial value, x.d: 3*NP] if s_mode & 2, [column bit words P1*W] if c_lds
     const size_t f_words = f_lds ? (5 * (size_t)P1 + (((size_t)P1 + 1) >> 1)) : 0;
     double *F = f_lds ? sm : gw;
-    double *S = s_lds ? (sm + f_words) : (gw + 5 * (size_t)P1);
+    const bool h_lds = (s_mode & 1) != 0, o_lds = (s_mode & 2) != 0;
+    double *Sg = gw + 5 * (size_t)P1;                                   // the global copies: ewx | ewxn | tau | D | xTd
+    double *hot = sm + f_words, *oth = sm + f_words + (h_lds ? 2 * (size_t)NP : 0);
     const uint64_t *cb = colbits;
     if (c_lds) {
-        uint64_t *lc = reinterpret_cast<uint64_t *>(sm + f_words + (s_lds ? 5 * (size_t)NP : 0));
+        uint64_t *lc = reinterpret_cast<uint64_t *>(sm + f_words + (h_lds ? 2 * (size_t)NP : 0) + (o_lds ? 3 * (size_t)NP : 0));
         for (size_t q = lane; q < (size_t)P1 * W; q += SV_THREADS) lc[q] = colbits[q];
         cb = lc;
     }
     double *w = F, *wpd = F + P1, *Hd = F + 2 * P1, *Gr = F + 3 * P1, *xjneg = F + 4 * P1;
-    double *ewx = S, *ewxn = S + NP, *tau = S + 2 * (size_t)NP, *D = S + 3 * (size_t)NP, *xTd = S + 4 * (size_t)NP;
+    double *tau = h_lds ? hot : Sg + 2 * (size_t)NP, *D = h_lds ? hot + NP : Sg + 3 * (size_t)NP;
+    double *ewx = o_lds ? oth : Sg, *ewxn = o_lds ? oth + NP : Sg + NP, *xTd = o_lds ? oth + 2 * (size_t)NP : Sg + 4 * (size_t)NP;
     int32_t *act = f_lds ? reinterpret_cast<int32_t *>(sm + 5 * (size_t)P1) : iwork + (size_t)fit * P1;
     const double nu = 1e-12, sigma = 0.01;
 
@@ -935,25 +940,51 @@ extern "C" int psk_logreg_l1_fit(psk_ctx *ctx, const float *X, const int32_t *y0
     PSK_HIP(ctx, hipMemcpyAsync(b.param, fit_param, (size_t)n_fits * 8, hipMemcpyHostToDevice, ctx->stream));
     PSK_HIP(ctx, hipMemcpyAsync(b.ffold, fit_fold, (size_t)n_fits * 4, hipMemcpyHostToDevice, ctx->stream));
     if (binary) {
-        // LDS budget of the bit-packed kernel: sample arrays first, then feature arrays + active list, then
-        // the column bit words themselves
+        // LDS budget of the bit-packed kernel.  The inner QP works on the Gram block, the per-feature arrays and the
+        // active list only, so those come first; the five sample arrays are streamed (coalesced) once per Newton
+        // step and line-search trial and move to global scratch when they do not fit beside the Gram block of the
+        // problem (thousands of samples: 5 x 2048 doubles are 80 KiB); the column bit words take what is left.
+        // (With the sample arrays first, a 2048-sample fit with 170 distinct patterns had room for 79 Gram columns,
+        // fell back to the array-form descent and took 0.5 s instead of 0.02 s, r01.)
         const size_t fa = fbytes + (((size_t)(p + 1) + 1) / 2) * 8, cbytes = (size_t)(p + 1) * W * 8;
+        const bool gram = !getenv("PSK_NO_GRAM");
+        const size_t pq = (size_t)(p + 1) < 192 ? (size_t)(p + 1) : 192;   // Gram columns the kernel can use
+        const size_t need_q = gram ? pq * (pq + 1) / 2 * 8 : 0;             // its packed triangle
         size_t left = lds_max;
-        s_lds = sbytes <= left ? 1 : 0; left -= s_lds ? sbytes : 0;
         f_lds = fa <= left ? 1 : 0; left -= f_lds ? fa : 0;
-        const int c_lds = cbytes <= left ? 1 : 0; left -= c_lds ? cbytes : 0;
-        // the Gram block of the covariance-form QP takes what is left, up to the packed triangle of 192 features
-        // (a 128 x 128 square is preferred by the kernel when it fits)
+        // sample arrays: all five when they fit beside the whole Gram block; else only the two hot ones (tau, D) if
+        // THAT makes room for the whole Gram block (thousands of samples, up to ~170 distinct patterns: the Gram form
+        // with its accelerator converges where the array form runs into its sweep limit, r01: 2048 x 170, objective sum
+        // of the grid 8.051e6 against 8.153e6, 0.73 s against 1.06 s); else all five again with a partial Gram block in
+        // what is left (the previous behaviour); the hot ones alone when five do not fit at all
+        const size_t hot_b = sbytes / 5 * 2;
+        if (sbytes + need_q <= left) s_lds = 3;
+        else if (gram && hot_b + need_q <= left) s_lds = 1;
+        else if (sbytes <= left) s_lds = 3;
+        else s_lds = hot_b <= left ? 1 : 0;
+        const size_t s_in_lds = s_lds == 3 ? sbytes : (s_lds == 1 ? hot_b : 0);
+        left -= s_in_lds;
+        // the Gram block: up to the packed triangle of 192 features (a 64 x 64 or 128 x 128 square is preferred by the
+        // kernel when it fits), before the column words
         size_t q_doubles = 0;
-        if (s_lds && !getenv("PSK_NO_GRAM")) {
-            q_doubles = left / 8;
-            const size_t most = (size_t)192 * 193 / 2;
-            if (q_doubles > most) q_doubles = most;
+        if (gram) {
+            const size_t square = pq <= 64 ? 64 * 64 : (pq <= 128 ? 128 * 128 : 0);
+            q_doubles = need_q / 8;
+            if (square * 8 <= left && square > q_doubles) q_doubles = square;
+            if (q_doubles * 8 > left) q_doubles = left / 8;
             if (q_doubles < 36) q_doubles = 0;
+        }
+        left -= q_doubles * 8;
+        const int c_lds = cbytes <= left ? 1 : 0; left -= c_lds ? cbytes : 0;
+        if (gram && left >= 8) {   // leftover goes to the Gram block too (a square layout may now fit)
+            const size_t most = (size_t)192 * 193 / 2;
+            size_t more = q_doubles + left / 8;
+            if (more > most) more = most;
+            q_doubles = more;
         }
         const size_t qbytes = q_doubles * 8;
         const int q_lds = q_doubles > 0;
-        const size_t lds_b = (s_lds ? sbytes : 0) + qbytes + (f_lds ? fa : 0) + (c_lds ? cbytes : 0);
+        const size_t lds_b = s_in_lds + qbytes + (f_lds ? fa : 0) + (c_lds ? cbytes : 0);
         std::vector<uint64_t> bits((size_t)(p + 1) * W, 0);
         for (int i = 0; i < n; i++) {
             for (int j = 0; j < p; j++)
@@ -962,7 +993,7 @@ extern "C" int psk_logreg_l1_fit(psk_ctx *ctx, const float *X, const int32_t *y0
         }
         SV_ALLOC(b.bits, bits.size() * 8);
         PSK_HIP(ctx, hipMemcpyAsync(b.bits, bits.data(), bits.size() * 8, hipMemcpyHostToDevice, ctx->stream));
-        const bool all_lds = f_lds && s_lds && c_lds && q_lds;
+        const bool all_lds = f_lds && s_lds == 3 && c_lds && q_lds;
         auto kern = all_lds ? logreg_newglmnet_bits_kernel<true> : logreg_newglmnet_bits_kernel<false>;
         if (lds_b > 64 * 1024)
             PSK_HIP(ctx, hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,

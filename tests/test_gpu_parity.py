@@ -582,6 +582,31 @@ def test_presence_when_word_and_sample_do_not_fit_one_u64(ctx, oracle, k, n, len
     assert np.array_equal(bits, oracle.presence_bits(lists, uw, wpr=bits.shape[1]))
 
 
+@pytest.mark.parametrize("k,n,length", [(9, 1300, 300), (11, 2048, 400), (10, 4100, 150), (8, 9000, 120)])
+def test_tiled_presence_build_with_thousands_of_samples(ctx, oracle, k, n, length, monkeypatch):
+    """Rows of hundreds of bytes: a tile of the sort-free build then holds fewer rows (512 ... 64) than its workgroup
+    has threads.  Union and every bit row against the oracle, and against the sort route on the same lists."""
+    from phenotypeseeker_amd.synth import GenomeSet
+    gs = GenomeSet(n, length, seed=k + n, gene_len=min(60, length // 3))
+    datas = [gs.sample(i)[1] for i in range(n)]
+    ctx.begin(k, n)
+    nus = []
+    for lo in range(0, n, 512):
+        nu, _ = ctx.count_kmers_batch(lo, datas[lo:lo + 512], 4)
+        nus += nu
+    lists = [oracle.count_kmers(d, k)[0] for d in datas]
+    assert nus == [len(w) for w in lists]
+    uw = oracle.union(lists)
+    m = ctx.build_presence()
+    assert m == len(uw) and np.array_equal(ctx.get_union(), uw)
+    wpr = ctx.presence_shape()[1]
+    rows = ctx.get_rows(np.arange(m, dtype=np.uint64))
+    assert np.array_equal(rows, oracle.presence_bits(lists, uw, wpr=wpr))
+    monkeypatch.setenv("PSK_NO_TILED_PRESENCE", "1")       # the same lists through the sort route
+    assert ctx.build_presence() == m
+    assert np.array_equal(ctx.get_union(), uw) and np.array_equal(ctx.get_rows(np.arange(m, dtype=np.uint64)), rows)
+
+
 def test_full_size_ingest_properties(ctx, oracle):
     """BASELINE config-2 sized ingest (256 x 5 Mbp, k = 13) checked through size-independent
     properties: every list is strictly ascending with sum(freq) = number of windows, the union is
