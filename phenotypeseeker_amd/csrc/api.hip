@@ -57,39 +57,18 @@ int arena_alloc(psk_ctx *ctx, size_t bytes, void **out)
     }
     const size_t sz = bytes > Arena::CHUNK ? bytes : Arena::CHUNK;
     void *p = nullptr;
-    if (sz == Arena::CHUNK && !A.ahead.empty()) {  // a chunk allocated ahead (nullptr if that failed)
-        p = A.ahead.front().get();
-        A.ahead.pop_front();
-    }
-    if (!p) {
-        hipError_t e = hipMalloc(&p, sz);
-        if (e != hipSuccess) return psk_fail(ctx, PSK_ENOMEM, "hipMalloc(%zu bytes) failed: %s", sz, hipGetErrorString(e));
-    }
+    hipError_t e = hipMalloc(&p, sz);
+    if (e != hipSuccess) return psk_fail(ctx, PSK_ENOMEM, "hipMalloc(%zu bytes) failed: %s", sz, hipGetErrorString(e));
     A.chunks.push_back(p);
     A.sizes.push_back(sz);
     A.cur = A.chunks.size() - 1;
     A.off = bytes;
     *out = p;
-    // a run that needs a second chunk is likely to need more: get the next one while this one fills
-    static const size_t n_ahead = [] { const char *e = getenv("PSK_ARENA_AHEAD"); return e ? (size_t)atoi(e) : Arena::AHEAD; }();
-    while (A.chunks.size() >= 2 && A.ahead.size() < n_ahead) {
-        const int dev = ctx->device;
-        A.ahead.push_back(std::async(std::launch::async, [dev]() -> void * {
-            void *q = nullptr;
-            if (hipSetDevice(dev) != hipSuccess || hipMalloc(&q, Arena::CHUNK) != hipSuccess) { (void)hipGetLastError(); return nullptr; }
-            return q;
-        }));
-    }
     return PSK_OK;
 }
 
 void arena_release(psk_ctx *ctx)
 {
-    for (auto &f : ctx->arena.ahead) {
-        void *q = f.get();
-        if (q) (void)hipFree(q);
-    }
-    ctx->arena.ahead.clear();
     for (void *p : ctx->arena.chunks) (void)hipFree(p);
     ctx->arena = Arena();
 }

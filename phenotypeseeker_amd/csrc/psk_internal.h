@@ -7,8 +7,6 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
-#include <deque>
-#include <future>
 #include <string>
 #include <vector>
 
@@ -29,10 +27,6 @@ struct Arena {
     std::vector<size_t> sizes;
     size_t cur = 0, off = 0;
     static constexpr size_t CHUNK = 1ull << 30;
-    // a few chunks are allocated ahead on helper threads: past the first tens of GiB a hipMalloc of 1 GiB takes ~30 ms
-    // (tools/malloc_probe.py), which the counting pipeline would otherwise wait for once per ~20 samples
-    std::deque<std::future<void *>> ahead;   // oldest first
-    static constexpr size_t AHEAD = 3;
 };
 
 struct SampleList {
