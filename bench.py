@@ -2,18 +2,24 @@
 """bench.py -- the north-star metric on MI355X: k-mer x sample chi-squared cells per second.
 
   python bench.py [--gpus N --steps K --warmup W]            (N = 1: plain process)
-  python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N ...   (one rank per GPU)
+  python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N ...   (one rank per GPU; the launcher
+      only supplies RANK / LOCAL_RANK / WORLD_SIZE / MASTER_*: this program never imports torch -- the
+      collectives are RCCL calls made by libpsk.so, phenotypeseeker_amd/dist.py)
 
-Workload (BASELINE.json configs[1]): synthetic 256 x 5-Mbp FASTA, binary phenotype, k = 13.
-The genome set is generated on the host, every sample is counted on the GPU (psk_count_kmers)
-and the union + bit-packed presence matrix is built on the GPU (psk_build_presence) BEFORE the
-timed region; the matrix is then resident in HBM.  One "step" = one pass of the chi-squared
-scan + filter over the whole resident matrix (psk_chi2_scan: kernel, survivor count read-back),
-followed on N > 1 by the two collectives of the sharded path (all-reduce of the union size,
-all-gather of the survivors).  value = rows x samples x steps / wall time, whole job.
+N = 1 (BASELINE.json configs[1]): synthetic 256 x 5-Mbp FASTA, binary phenotype, k = 13.  The genome set is
+generated on the host, every sample is counted on the GPU (psk_count_kmers_batch) and the union + bit-packed
+presence matrix is built on the GPU (psk_build_presence) BEFORE the timed region; the matrix is then resident
+in HBM.  One "step" = one pass of the chi-squared scan + filter over the whole resident matrix (kernel,
+survivor count read-back).  value = rows x samples x steps / wall time.
 
-N > 1 is weak scaling: every rank owns one slab of the word space and the slabs are the same
-size at every N (rank r's slab is generated from seed + r), so per-GPU work is fixed.
+N > 1 (BASELINE.json configs[2]): ONE synthetic 2,048 x 5-Mbp set, k = 16 -- the same genomes on every rank --
+with the canonical word space range-sharded over the N ranks at the quantiles of a pilot of the lists
+(dist.balanced_bounds), every rank keeping the words of its slab (--ingest filter: each rank tokenises every
+sample with the slab filter, no data-path collective; --ingest exchange: each sample is counted on one rank and
+the slab ranges of the lists are exchanged with one all-to-all over xGMI).  The union sizes are all-reduced once
+(the global Bonferroni denominator); a step = the scan of the rank's slab + the export and the all-gather of its
+survivors.  value = (global rows) x samples x steps / max-over-ranks wall time: the whole job.  The dataset is the
+same at every N > 1 (strong scaling over 2 / 4 / 8); the line carries the rows of every rank and max / mean.
 
 Printed JSON also carries "roofline" (dominant kernel = chi2_scan_kernel, HBM-bound; achieved =
 algorithmic bytes / mean HIP-event duration of the kernel over the timed steps) and
@@ -33,11 +39,20 @@ sys.path.insert(0, ROOT)
 HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: 8 TB/s spec (6.3 TB/s measured float4 copy)
 
 
+def scan_kernel_hash():
+    """sha256[:16] of the scan kernel's source: a committed traffic figure is only quoted for the kernel it was
+    measured on."""
+    import hashlib
+    with open(os.path.join(ROOT, "phenotypeseeker_amd", "csrc", "assoc_scan.hip"), "rb") as f:
+        return hashlib.sha256(f.read()).hexdigest()[:16]
+
+
 def measured_traffic(rows, wpr):
     """HBM bytes per launch of the scan kernel from the PMC passes (rocprofv3 --pmc FETCH_SIZE /
     WRITE_SIZE, separate runs, corrected as MI355X_MICROARCH.md prescribes) committed under
     profiles/ -- counters cannot be read from inside this process.  None when no committed
-    profile matches this workload's matrix shape."""
+    profile matches this workload's matrix shape, or when the profile was taken on another version of the kernel
+    (its "kernel_source_sha16" differs from the source's hash)."""
     import glob
     best = None
     for fn in sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_traffic_chi2_scan.json"))):
@@ -46,7 +61,7 @@ def measured_traffic(rows, wpr):
                 d = json.load(f)
         except (OSError, ValueError):
             continue
-        if d.get("rows") == rows and d.get("words_per_row_stored") == wpr:
+        if d.get("rows") == rows and d.get("words_per_row_stored") == wpr and d.get("kernel_source_sha16") == scan_kernel_hash():
             best = d.get("hbm_bytes_per_launch")
     return best
 
@@ -118,9 +133,12 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=50)
     ap.add_argument("--warmup", type=int, default=5)
-    ap.add_argument("--samples", type=int, default=256)
+    ap.add_argument("--samples", type=int, default=None, help="default 256 (N = 1) / 2048 (N > 1)")
     ap.add_argument("--length", type=int, default=5_000_000)
-    ap.add_argument("--kmer", type=int, default=13)
+    ap.add_argument("--kmer", type=int, default=None, help="default 13 (N = 1) / 16 (N > 1)")
+    ap.add_argument("--ingest", default="filter", choices=["filter", "exchange"],
+                    help="N > 1: every rank tokenises every sample and keeps its slab (filter), or every sample is "
+                         "counted on one rank and the list ranges are exchanged with an all-to-all (exchange)")
     ap.add_argument("--workload", default="fasta", choices=["fasta", "matrix"],
                     help="fasta: count synthetic genomes on the GPU (default, BASELINE cfg 2); "
                          "matrix: device-generated presence matrix of --rows rows (quick runs)")
@@ -129,18 +147,13 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-e2e", action="store_true",
                     help="skip the end-to-end `phenotypeseeker modeling` wall-clock (FASTA files -> .pkl) on the same data")
-    ap.add_argument("--backend", default=None, choices=[None, "nccl", "gloo"],
-                    help="torch.distributed backend for N > 1 (default: nccl = RCCL when GPUs are visible). "
-                         "gloo + --share-gpu lets two ranks exercise the N > 1 path on a one-GPU box.")
-    ap.add_argument("--share-gpu", action="store_true", help="map ranks onto the visible GPUs modulo their count")
+    ap.add_argument("--share-gpu", action="store_true",
+                    help="map ranks onto the visible GPUs modulo their count (tests on a one-GPU box, with the host "
+                         "transport named by PSK_DIST_TRANSPORT; RCCL refuses two ranks on one device)")
     ap.add_argument("--force-exchange", action="store_true",
                     help="N = 1 only: run the N > 1 step (scan + export + all-gather) on a one-rank group, to measure "
                          "what the exchange adds per step on one GPU; the line carries \"exchange\": \"forced\"")
     args = ap.parse_args()
-    if args.force_exchange:
-        os.environ["PSK_WITH_TORCH"] = "1"
-        import torch  # noqa: F401  (before libpsk.so)
-
     from phenotypeseeker_amd import dist as psk_dist
     from phenotypeseeker_amd.engine import PskContext
     from phenotypeseeker_amd.synth import GenomeSet
@@ -149,39 +162,74 @@ def main():
     if grp.world != args.gpus:
         if grp.world == 1 and args.gpus > 1:
             sys.exit("bench.py --gpus %d must be launched with torch.distributed.run (one rank per GPU)" % args.gpus)
-    grp.init(args.backend, force=args.force_exchange)
-    rank, world = grp.rank, grp.world
-    n, k = args.samples, args.kmer
-
-    device = grp.device
     if args.share_gpu:
-        import torch
-        device = grp.local_rank % max(torch.cuda.device_count(), 1)
-    ctx = PskContext(device)
+        os.environ["PSK_SHARE_GPU"] = "1"
+    grp.init(force=args.force_exchange)
+    rank, world = grp.rank, grp.world
+    sharded = world > 1
+    n = args.samples if args.samples is not None else (2048 if sharded else 256)
+    k = args.kmer if args.kmer is not None else (16 if sharded else 13)
+
+    ctx = PskContext(grp.device)
     info = ctx.device_info()
     t_setup = time.time()
     pheno = np.array([1 if i % 2 == 0 else 0 for i in range(n)], dtype=np.int8)
     ingest = {}
+    shard = None
     if args.workload == "fasta":
-        gs = GenomeSet(n, args.length, seed=12345 + rank)
-        ctx.begin(k, n)
-        t_gen = t_cnt = 0.0
+        gs = GenomeSet(n, args.length, seed=12345)        # ONE dataset: the same genomes on every rank
+        t_gen = t_cnt = t_xch = 0.0
         tot_unique = 0
-        for lo in range(0, n, 64):
+        lo_w = hi_w = 0
+        if sharded:
+            # pilot: rank r counts sample r whole; the quantiles of these lists cut the word space into slabs of equal
+            # row share (dist.balanced_bounds; one all-gather)
             t0 = time.time()
-            fas = [gs.sample(i)[1] for i in range(lo, min(lo + 64, n))]
-            t1 = time.time()
-            nus, _ = ctx.count_kmers_batch(lo, fas, 8)
-            t2 = time.time()
-            t_gen += t1 - t0
-            t_cnt += t2 - t1
-            tot_unique += sum(nus)
+            with PskContext(grp.device) as pc:
+                pc.begin(k, 1)
+                nu0, _ = pc.count_kmers(0, gs.sample(rank % n)[1])
+                pilot = pc.get_list(0, nu0)[0]
+            bounds = psk_dist.balanced_bounds(grp, k, [pilot])
+            lo_w, hi_w = bounds[rank], bounds[rank + 1]
+            t_pilot = time.time() - t0
+        ctx.begin(k, n, lo_w, hi_w)
+        if sharded and args.ingest == "exchange":
+            own = [i for i in range(n) if psk_dist.owner_of(i, world) == rank]
+            with PskContext(grp.device) as cnt:
+                cnt.begin(k, max(len(own), 1))
+                tots = []
+                for lo in range(0, len(own), 64):
+                    t0 = time.time()
+                    fas = [gs.sample(i)[1] for i in own[lo:lo + 64]]
+                    t1 = time.time()
+                    _, nts = cnt.count_kmers_batch(lo, fas, 8)
+                    t2 = time.time()
+                    tots += list(nts)
+                    t_gen += t1 - t0
+                    t_cnt += t2 - t1
+                t0 = time.time()
+                tot_unique = psk_dist.ListExchange(grp, k, bounds).run(cnt, ctx, n, tots)
+                t_xch = time.time() - t0
+        else:
+            for lo in range(0, n, 64):
+                t0 = time.time()
+                fas = [gs.sample(i)[1] for i in range(lo, min(lo + 64, n))]
+                t1 = time.time()
+                nus, _ = ctx.count_kmers_batch(lo, fas, 8)
+                t2 = time.time()
+                t_gen += t1 - t0
+                t_cnt += t2 - t1
+                tot_unique += sum(nus)
         t0 = time.time()
         M = ctx.build_presence()
         t_build = time.time() - t0
         ingest = {"generate_s": round(t_gen, 2), "count_s": round(t_cnt, 2), "presence_s": round(t_build, 2),
                   "pairs": tot_unique, "bases": n * args.length}
+        if sharded:
+            ingest.update({"mode": args.ingest, "pilot_s": round(t_pilot, 2), "exchange_s": round(t_xch, 2)})
         workload = "synthetic %d x %.1f-Mbp FASTA, binary phenotype, k=%d" % (n, args.length / 1e6, k)
+        if sharded:
+            workload += ", canonical word space range-sharded over %d GPUs" % world
     else:
         M = args.rows
         ctx.synth_presence(M, n, seed=7 + rank)
@@ -190,6 +238,7 @@ def main():
     t_setup = time.time() - t_setup
 
     M_global = grp.allreduce_sum(int(M))
+    rows_per_rank = [int(x) for x in grp.allgather_i64(np.array([int(M)]))[:, 0]]
 
     # The sharded path: the union size is all-reduced ONCE (Bonferroni denominator, above); every scan
     # is followed by one all-gather of its survivors.  The gather is device-to-device (RCCL) and
@@ -215,7 +264,7 @@ def main():
     # ingest ends with a few light kernels; measured right after it, the first ~50 scans run 4-5 % slower than the
     # steady state (r01: 117-121 us against 111-112 us per launch, the same for a 1000-step run either way).
     ctx.chi2_scan(*scan_args)
-    ctx.rescan_timed(300)
+    ctx.rescan_timed(int(min(300, max(3, 40.0 / max(ctx.last_scan_ms(), 0.01)))))
 
     def run_steps(count):
         """`count` steps; returns (survivors of the last scan, kernel ms of every scan).  Two scans are kept in flight
@@ -263,12 +312,16 @@ def main():
     out = {
         "metric": "k-mer x sample chi2 cells/sec", "value": value, "unit": "cells/s", "n_gpus": world,
         "steps": args.steps, "warmup": args.warmup, "ms_per_step": elapsed / args.steps * 1e3,
-        "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "u64 popcount + f64",
+        "higher_is_better": True, "scaling": "strong" if sharded else "weak", "vs_baseline": None,
+        "dtype": "u64 popcount + f64",
         "data": "synthetic",
         "config": {"workload": workload, "n_samples": n, "k": k, "rows_per_gpu": int(M),
                    "words_per_row_stored": wpr, "survivors": int(npass), "survivors_all_slabs": int(gathered[0]) if xch is not None
                    else int(npass), "device": info["name"],
-                   "setup_s": round(t_setup, 2), "ingest": ingest},
+                   "setup_s": round(t_setup, 2), "ingest": ingest,
+                   "rows_global": int(M_global), "rows_per_rank": rows_per_rank,
+                   "balance_max_over_mean": round(max(rows_per_rank) / (sum(rows_per_rank) / len(rows_per_rank)), 4),
+                   "collectives": grp.backend or "none"},
         "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                      "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "kernel": "chi2_scan_kernel",
                      "kernel_ms": mean_ms, "algorithmic_bytes_per_launch": alg_bytes,

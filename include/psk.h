@@ -258,6 +258,42 @@ int psk_mash_pairs(psk_ctx *ctx, const uint64_t *sketches, const uint32_t *lens,
 int psk_nj_merges(psk_ctx *ctx, const double *dist, int n, int32_t *mi_out, int32_t *mj_out, double *d1_out,
                   double *d2_out, double *last_out);
 
+/* ---- e: multi-GPU collectives (RCCL over xGMI, bound directly; librccl.so is opened on first use) ------------
+ * The reference has no multi-process path (its parallelism is Pool(num_threads) over text chunks,
+ * modeling.py:335-342, :660-675); these calls carry the three exchanges of the range-sharded path: the
+ * all-reduce of the slab union sizes (the global Bonferroni denominator of modeling.py:644/:795), the
+ * all-gather of the scan survivors and the all-to-all of list ranges (multi-GPU ingest).  One communicator per
+ * context, on its own HIP stream.
+ *   psk_comm_unique_id   rank 0: writes the 128-byte id of ncclGetUniqueId (returns its length); the caller's
+ *                        rendezvous (a file, a socket) carries it to the other ranks
+ *   psk_comm_init        every rank, same id: ncclCommInitRank on the context's GPU
+ *   psk_comm_allreduce   in place on `count` host values; dtype 0 = u64, 1 = f64; op 0 = sum, 1 = max
+ *   psk_comm_allgather_host     recv[world][bytes] <- every rank's send[bytes] (host buffers, waited for)
+ *   psk_comm_allgather_device   the same for DEVICE buffers, queued on the communicator's stream, not waited for
+ *   psk_comm_alltoallv_device   send_counts[d] elements (elem_bytes 4 or 8) to rank d, back to back in send_dev;
+ *                               recv_counts[s] elements from rank s, back to back in recv_dev; waited for
+ *   psk_comm_stream      the communicator's hipStream_t (hand it to psk_export_survivors_async so that the
+ *                        all-gather queued next is ordered behind the export on the device)
+ *   psk_comm_sync        waits for everything queued on that stream
+ */
+int psk_device_count(void);
+int psk_comm_unique_id(psk_ctx *ctx, uint8_t *id_out, int cap);
+int psk_comm_init(psk_ctx *ctx, const uint8_t *id, int id_len, int rank, int world);
+int psk_comm_free(psk_ctx *ctx);
+void *psk_comm_stream(psk_ctx *ctx);
+int psk_comm_sync(psk_ctx *ctx);
+int psk_comm_allreduce(psk_ctx *ctx, void *vals, int count, int dtype, int op);
+int psk_comm_allgather_host(psk_ctx *ctx, const void *send, void *recv, uint64_t bytes);
+int psk_comm_allgather_device(psk_ctx *ctx, const void *send_dev, void *recv_dev, uint64_t bytes);
+int psk_comm_alltoallv_device(psk_ctx *ctx, const void *send_dev, const uint64_t *send_counts, void *recv_dev,
+                              const uint64_t *recv_counts, int elem_bytes);
+/* Plain device buffers for the callers of the exchanges (send / receive buffers live outside the context), and
+ * waited-for copies: kind 0 host -> device, 1 device -> host, 2 device -> device; on_comm_stream != 0 orders the
+ * copy behind the collectives queued on the communicator's stream. */
+int psk_dev_alloc(psk_ctx *ctx, uint64_t bytes, void **out);
+int psk_dev_free(psk_ctx *ctx, void *p);
+int psk_dev_copy(psk_ctx *ctx, void *dst, const void *src, uint64_t bytes, int kind, int on_comm_stream);
+
 /* ---- helpers shared with the host side ------------------------------------------------------ */
 /* Host-only: the cleaned sequence stream the tokeniser hands to the GPU (bases kept, window
  * breaks collapsed to '\n', everything else dropped).  Returns the length written (<= len), or

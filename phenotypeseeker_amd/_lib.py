@@ -66,6 +66,19 @@ _SIGNATURES = {
                                         c.c_void_p, c.c_void_p, c.c_int, c.c_int, c.c_int, c.c_uint32, c.c_void_p,
                                         c.c_void_p]),
     "psk_frame_sequence": (c.c_int64, [c.c_char_p, c.c_size_t, c.c_void_p, c.c_size_t]),
+    "psk_device_count": (c.c_int, []),
+    "psk_comm_unique_id": (c.c_int, [c.c_void_p, c.c_void_p, c.c_int]),
+    "psk_comm_init": (c.c_int, [c.c_void_p, c.c_void_p, c.c_int, c.c_int, c.c_int]),
+    "psk_comm_free": (c.c_int, [c.c_void_p]),
+    "psk_comm_stream": (c.c_void_p, [c.c_void_p]),
+    "psk_comm_sync": (c.c_int, [c.c_void_p]),
+    "psk_comm_allreduce": (c.c_int, [c.c_void_p, c.c_void_p, c.c_int, c.c_int, c.c_int]),
+    "psk_comm_allgather_host": (c.c_int, [c.c_void_p, c.c_void_p, c.c_void_p, c.c_uint64]),
+    "psk_comm_allgather_device": (c.c_int, [c.c_void_p, c.c_void_p, c.c_void_p, c.c_uint64]),
+    "psk_comm_alltoallv_device": (c.c_int, [c.c_void_p, c.c_void_p, c.c_void_p, c.c_void_p, c.c_void_p, c.c_int]),
+    "psk_dev_alloc": (c.c_int, [c.c_void_p, c.c_uint64, c.POINTER(c.c_void_p)]),
+    "psk_dev_free": (c.c_int, [c.c_void_p, c.c_void_p]),
+    "psk_dev_copy": (c.c_int, [c.c_void_p, c.c_void_p, c.c_void_p, c.c_uint64, c.c_int, c.c_int]),
 }
 
 _lib = None
@@ -76,17 +89,6 @@ def load():
     global _lib
     if _lib is not None:
         return _lib
-    # PyTorch's ROCm wheel bundles its own HIP/HSA runtime under the same soname (libamdhip64.so.7) as
-    # the system one libpsk.so links to; two HSA runtimes in one process cannot both open the GPU.
-    # Whichever is loaded first serves both, and only "torch first" works -- so multi-rank runs (which
-    # use torch.distributed for the collectives) import torch before libpsk.so is opened.
-    if int(os.environ.get("WORLD_SIZE", "1")) > 1 or os.environ.get("PSK_WITH_TORCH") == "1":
-        import sys
-        if "torch" not in sys.modules:
-            try:
-                import torch  # noqa: F401
-            except ImportError:
-                pass
     if not os.path.exists(LIB_PATH):
         raise PskError("libpsk.so is missing (%s): build it with `python -c 'import __graft_entry__ as g; "
                        "g.build()'` or `make -C phenotypeseeker_amd/csrc`; there is no CPU fallback" % LIB_PATH)

@@ -115,6 +115,7 @@ extern "C" void psk_free(psk_ctx *ctx)
     if (!ctx) return;
     (void)hipSetDevice(ctx->device);
     if (ctx->stream) (void)hipStreamSynchronize(ctx->stream);
+    comm_release(ctx);
     reset_lists(ctx, 0);
     arena_release(ctx);
     DevBuf *bufs[] = {&ctx->raw, &ctx->keysA, &ctx->keysB, &ctx->valsA, &ctx->valsB, &ctx->hist, &ctx->scan_tmp, &ctx->flags, &ctx->starts,

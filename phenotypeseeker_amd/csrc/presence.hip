@@ -227,59 +227,122 @@ extern "C" int psk_build_presence(psk_ctx *ctx, uint64_t *n_kmers)
             return PSK_OK;
         }
     }
-    // the sort route indexes the concatenated (word, sample) pairs in u32; the tiled build above has no such limit
-    if (total >= (1ull << 32)) return psk_fail(ctx, PSK_ERANGE, "%llu (word, sample) pairs exceed 2^32 per GPU for "
-                                                                "k = %d; shard the word space over more GPUs",
-                                               (unsigned long long)total, ctx->k);
-    PSK_TRY(dev_reserve(ctx, ctx->keysA, total * 8));
-    PSK_TRY(dev_reserve(ctx, ctx->keysB, total * 8));
+    // The sort route indexes (word, sample) pairs in u32 and holds two 8-byte buffers of them: the word range of the
+    // slab is therefore cut into chunks of at most PAIR_CHUNK pairs (cut points at the quantiles of the longest list;
+    // a chunk of a sorted list is a contiguous range of it), each sorted on its own.  One chunk: one pass.  Several:
+    // a first pass counts the rows of every chunk, the matrix is allocated once, a second pass fills it.
+    uint64_t pair_chunk = 1ull << 30;
+    if (const char *e = getenv("PSK_PAIR_CHUNK")) { const uint64_t v = strtoull(e, nullptr, 10); if (v >= 1024) pair_chunk = v; }
+    if (pair_chunk >= (1ull << 32)) pair_chunk = (1ull << 32) - 1;
+    const int ns = ctx->n_samples;
+    std::vector<uint64_t> cut;  // cut[c * ns + i]: first entry of sample i's list that belongs to chunk c; n_chunks + 1 rows
+    int n_chunks = 1;
+    if (total > pair_chunk) {
+        int longest = 0;
+        for (int i = 1; i < ns; i++) if (ctx->lists[i].n_unique > ctx->lists[longest].n_unique) longest = i;
+        const SampleList &P = ctx->lists[longest];
+        int want = (int)((total + pair_chunk - 1) / pair_chunk) + 1;
+        for (int attempt = 0;; attempt++) {
+            if (attempt == 8 || (uint64_t)want > P.n_unique)
+                return psk_fail(ctx, PSK_ERANGE, "cannot cut %llu (word, sample) pairs into chunks of %llu",
+                                (unsigned long long)total, (unsigned long long)pair_chunk);
+            std::vector<uint64_t> bounds;  // ascending, distinct, none 0
+            for (int c = 1; c < want; c++) {
+                uint64_t w = 0;
+                PSK_HIP(ctx, hipMemcpy(&w, P.words + (P.n_unique * (uint64_t)c) / want, 8, hipMemcpyDeviceToHost));
+                if (w != 0 && (bounds.empty() || w > bounds.back())) bounds.push_back(w);
+            }
+            const int nb = (int)bounds.size();
+            std::vector<uint64_t> offs((size_t)ns * (nb ? nb : 1));
+            if (nb) PSK_TRY(psk_lists_split(ctx, 0, ns, bounds.data(), nb, offs.data()));
+            n_chunks = nb + 1;
+            cut.assign((size_t)(n_chunks + 1) * ns, 0);
+            uint64_t worst = 0;
+            for (int c = 0; c <= n_chunks; c++)
+                for (int i = 0; i < ns; i++)
+                    cut[(size_t)c * ns + i] = c == 0 ? 0 : c == n_chunks ? ctx->lists[i].n_unique : offs[(size_t)i * nb + (c - 1)];
+            for (int c = 0; c < n_chunks; c++) {
+                uint64_t t = 0;
+                for (int i = 0; i < ns; i++) t += cut[(size_t)(c + 1) * ns + i] - cut[(size_t)c * ns + i];
+                if (t > worst) worst = t;
+            }
+            if (worst <= pair_chunk + pair_chunk / 4 && worst < (1ull << 32)) break;
+            want *= 2;
+        }
+    } else {
+        cut.assign((size_t)2 * ns, 0);
+        for (int i = 0; i < ns; i++) cut[(size_t)ns + i] = ctx->lists[i].n_unique;
+    }
+    uint64_t cap_pairs = 0;
+    std::vector<uint64_t> chunk_total(n_chunks, 0);
+    for (int c = 0; c < n_chunks; c++) {
+        for (int i = 0; i < ns; i++) chunk_total[c] += cut[(size_t)(c + 1) * ns + i] - cut[(size_t)c * ns + i];
+        if (chunk_total[c] > cap_pairs) cap_pairs = chunk_total[c];
+    }
+    PSK_TRY(dev_reserve(ctx, ctx->keysA, cap_pairs * 8));
+    PSK_TRY(dev_reserve(ctx, ctx->keysB, cap_pairs * 8));
     if (kv) {
-        PSK_TRY(dev_reserve(ctx, ctx->valsA, total * 4));
-        PSK_TRY(dev_reserve(ctx, ctx->valsB, total * 4));
+        PSK_TRY(dev_reserve(ctx, ctx->valsA, cap_pairs * 4));
+        PSK_TRY(dev_reserve(ctx, ctx->valsB, cap_pairs * 4));
     }
-    pt.mark("alloc pairs");
-    uint64_t off = 0;
-    for (int i = 0; i < ctx->n_samples; i++) {
-        const SampleList &L = ctx->lists[i];
-        if (!L.n_unique) continue;
-        pack_pairs_kernel<<<div_up(L.n_unique, 256), 256, 0, ctx->stream>>>(
-            L.words, L.n_unique, sbits, (uint64_t)i, ctx->keysA.as<uint64_t>() + off,
-            kv ? ctx->valsA.as<uint32_t>() + off : nullptr);
-        PSK_HIP(ctx, hipGetLastError());
-        off += L.n_unique;
-    }
-    pt.mark("pack");
-    uint64_t *sorted = nullptr;
-    uint32_t *sorted_vals = nullptr;
-    PSK_TRY(dev_radix_sort_kv(ctx, ctx->keysA.as<uint64_t>(), ctx->keysB.as<uint64_t>(),
-                              kv ? ctx->valsA.as<uint32_t>() : nullptr, kv ? ctx->valsB.as<uint32_t>() : nullptr, total,
-                              sbits, sbits + 2 * ctx->k, &sorted, &sorted_vals));
-    pt.mark("sort");
     PSK_TRY(dev_reserve(ctx, ctx->misc, 64));
-    // the row index of every pair goes into the sort's spare key buffer (8 B per pair of room for 4): one multi-GB
-    // allocation less -- device allocations of this size cost tens of ms per GB on a box whose memory has been used
-    uint32_t *flags = reinterpret_cast<uint32_t *>(sorted == ctx->keysA.as<uint64_t>() ? ctx->keysB.p : ctx->keysA.p);
-    pt.mark("alloc flags");
     uint32_t *d_m = ctx->misc.as<uint32_t>() + 2;
-    pair_head_flags_kernel<<<div_up(total, 256), 256, 0, ctx->stream>>>(sorted, total, sbits, flags);
-    PSK_HIP(ctx, hipGetLastError());
-    pt.mark("head flags");
-    PSK_TRY(dev_exclusive_scan_u32(ctx, flags, flags, total, d_m));
-    pt.mark("scan");
-    uint32_t m32 = 0;
-    PSK_HIP(ctx, hipMemcpyAsync(&m32, d_m, 4, hipMemcpyDeviceToHost, ctx->stream));
-    PSK_HIP(ctx, hipStreamSynchronize(ctx->stream));
-    const uint64_t M = m32;
-    pt.mark("heads+scan");
+    pt.mark("alloc pairs");
+    // pack + sort + row numbering of chunk c; the sorted pairs, their payloads and the row index of every pair (kept
+    // in the sort's spare key buffer: one multi-GB allocation less) stay in the context's buffers
+    uint64_t *sorted = nullptr;
+    uint32_t *sorted_vals = nullptr, *flags = nullptr;
+    auto sort_chunk = [&](int c, uint64_t *rows_out) -> int {
+        uint64_t off = 0;
+        for (int i = 0; i < ns; i++) {
+            const SampleList &L = ctx->lists[i];
+            const uint64_t lo = cut[(size_t)c * ns + i], cnt = cut[(size_t)(c + 1) * ns + i] - lo;
+            if (!cnt) continue;
+            pack_pairs_kernel<<<div_up(cnt, 256), 256, 0, ctx->stream>>>(L.words + lo, cnt, sbits, (uint64_t)i,
+                                                                        ctx->keysA.as<uint64_t>() + off,
+                                                                        kv ? ctx->valsA.as<uint32_t>() + off : nullptr);
+            PSK_HIP(ctx, hipGetLastError());
+            off += cnt;
+        }
+        const uint64_t tc = chunk_total[c];
+        PSK_TRY(dev_radix_sort_kv(ctx, ctx->keysA.as<uint64_t>(), ctx->keysB.as<uint64_t>(),
+                                  kv ? ctx->valsA.as<uint32_t>() : nullptr, kv ? ctx->valsB.as<uint32_t>() : nullptr, tc, sbits,
+                                  sbits + 2 * ctx->k, &sorted, &sorted_vals));
+        flags = reinterpret_cast<uint32_t *>(sorted == ctx->keysA.as<uint64_t>() ? ctx->keysB.p : ctx->keysA.p);
+        pair_head_flags_kernel<<<div_up(tc, 256), 256, 0, ctx->stream>>>(sorted, tc, sbits, flags);
+        PSK_HIP(ctx, hipGetLastError());
+        PSK_TRY(dev_exclusive_scan_u32(ctx, flags, flags, tc, d_m));
+        uint32_t m32 = 0;
+        PSK_HIP(ctx, hipMemcpyAsync(&m32, d_m, 4, hipMemcpyDeviceToHost, ctx->stream));
+        PSK_HIP(ctx, hipStreamSynchronize(ctx->stream));
+        *rows_out = m32;
+        return PSK_OK;
+    };
+    std::vector<uint64_t> chunk_rows(n_chunks, 0);
+    uint64_t M = 0;
+    for (int c = 0; c < n_chunks; c++) {
+        if (chunk_total[c]) PSK_TRY(sort_chunk(c, &chunk_rows[c]));
+        M += chunk_rows[c];
+    }
+    pt.mark(n_chunks > 1 ? "count rows" : "pack+sort+heads");
     PSK_TRY(dev_reserve(ctx, ctx->union_words, M * 8));
     PSK_TRY(dev_reserve(ctx, ctx->bits, M * (uint64_t)ctx->wpr * 8));
     pt.mark("alloc matrix");
     PSK_HIP(ctx, hipMemsetAsync(ctx->bits.p, 0, M * (uint64_t)ctx->wpr * 8, ctx->stream));
     pt.mark("zero matrix");
-    presence_fill_kernel<<<div_up(total, 256), 256, 0, ctx->stream>>>(
-        sorted, total, sbits, flags, ctx->wpr, ctx->union_words.as<uint64_t>(),
-        reinterpret_cast<unsigned long long *>(ctx->bits.p), kv ? sorted_vals : nullptr);
-    PSK_HIP(ctx, hipGetLastError());
+    uint64_t base = 0;
+    for (int c = 0; c < n_chunks; c++) {
+        if (!chunk_total[c]) continue;
+        uint64_t again = chunk_rows[c];
+        if (n_chunks > 1) PSK_TRY(sort_chunk(c, &again));   // one chunk: its sorted pairs are still in place
+        if (again != chunk_rows[c]) return psk_fail(ctx, PSK_ESTATE, "chunk %d numbered %llu rows, then %llu", c,
+                                                    (unsigned long long)chunk_rows[c], (unsigned long long)again);
+        presence_fill_kernel<<<div_up(chunk_total[c], 256), 256, 0, ctx->stream>>>(
+            sorted, chunk_total[c], sbits, flags, ctx->wpr, ctx->union_words.as<uint64_t>() + base,
+            reinterpret_cast<unsigned long long *>(ctx->bits.p) + base * (uint64_t)ctx->wpr, kv ? sorted_vals : nullptr);
+        PSK_HIP(ctx, hipGetLastError());
+        base += chunk_rows[c];
+    }
     PSK_HIP(ctx, hipStreamSynchronize(ctx->stream));
     pt.mark("fill");
     ctx->n_kmers = M;

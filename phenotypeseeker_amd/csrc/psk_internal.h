@@ -131,6 +131,8 @@ struct psk_ctx {
     int dense_hint = -1;     // did the last chi2 scan of this matrix keep > 0.1 % of the rows?  (-1: no scan yet)
     double last_scan_ms = 0;
     ScanParams last;
+
+    void *comm = nullptr;    // PskComm (comm.hip): RCCL communicator + its stream, multi-GPU runs only
 };
 
 // ---- error helpers ----------------------------------------------------------------------------
@@ -155,6 +157,7 @@ void dev_release(DevBuf &b);
 void reset_lists(psk_ctx *ctx, int n_samples);
 int arena_alloc(psk_ctx *ctx, size_t bytes, void **out);   // 256-byte aligned, freed by reset_lists
 void arena_release(psk_ctx *ctx);  // frees the per-sample lists, resizes to n_samples
+void comm_release(psk_ctx *ctx);   // comm.hip: destroys the context's RCCL communicator, if any
 
 static inline unsigned div_up(uint64_t a, uint64_t b) { return (unsigned)((a + b - 1) / b); }
 

@@ -1,23 +1,35 @@
-"""Range sharding of the canonical k-mer word space over the GPUs of one node, and the two small
-collectives the sharded path needs:
+"""Range sharding of the canonical k-mer word space over the GPUs of one node, and the collectives the sharded
+path needs:
 
-  1. all-reduce(sum) of the per-slab union sizes -> the global Bonferroni denominator
+  1. balanced slab bounds: quantile cuts of a pilot of the lists (the reference's own chunking is perfectly
+     balanced -- round-robin `split -n r/<nt>`, modeling.py:335-342 --, and canonical words min(w, rc(w)) are
+     far from uniform over the 2k-bit space: density ~ 2(1 - u), 1.87x imbalanced at 8 uniform slabs);
+  2. all-reduce(sum) of the per-slab union sizes -> the global Bonferroni denominator
      (phenotypes.no_kmers_to_analyse, modeling.py:644,:738,:795) BEFORE any filtering;
-  2. all-gather(v) of each slab's surviving rows (word, statistic, p, n_with, presence bits).
+  3. all-gather(v) of each slab's surviving rows (word, statistic, p, n_with, presence bits);
+  4. all-to-all(v) of list ranges for the sample-parallel ingest.
 
-One process per GPU under torch.distributed (backend "nccl" = RCCL over xGMI on the GPU box,
-"gloo" in the CPU tests).  torch is plumbing here: the data path never leaves libpsk.so.  With
-world size 1 nothing in this module touches torch.
+One process per GPU.  The collectives run on RCCL over xGMI, bound directly by libpsk.so (csrc/comm.hip:
+ncclCommInitRank / ncclAllReduce / ncclAllGather / ncclSend+ncclRecv on the library's own stream); the 128-byte
+unique id travels through a rendezvous file.  No PyTorch anywhere in this package: tests that have no second GPU
+inject a host transport (tests/_gloo_transport.py, named by PSK_DIST_TRANSPORT=module:Class).  With world size 1
+nothing here touches a communicator.
 """
+import importlib
 import os
+import tempfile
+import time
 
 import numpy as np
 
+from .engine import PskContext
 
+
+# ---- slab bounds ---------------------------------------------------------------------------------------------
 def slab_bounds(k, world, rank):
-    """Contiguous slab [lo, hi) of the 2k-bit word space for `rank`; hi == 0 means "to the end"
-    (the psk_begin convention, needed because 4**32 does not fit in u64).  Concatenating the
-    slabs in rank order reproduces glistmaker's ascending list order."""
+    """UNIFORM contiguous slab [lo, hi) of the 2k-bit word space for `rank`; hi == 0 means "to the end"
+    (the psk_begin convention, needed because 4**32 does not fit in u64).  Kept as the fallback when no pilot is
+    available; runs use balanced_bounds()."""
     space = 1 << (2 * k)
     if world > space:
         raise ValueError("more ranks (%d) than canonical %d-mer words (%d)" % (world, k, space))
@@ -28,86 +40,238 @@ def slab_bounds(k, world, rank):
     return lo, hi
 
 
+def _legal_bounds(cuts, k, world):
+    """cuts: world - 1 ascending candidates -> world + 1 bounds [0, c1, ..., 0] with strictly increasing inner
+    entries inside the word space (empty slabs are not allowed by psk_begin)."""
+    space = 1 << (2 * k)
+    if world > space:
+        raise ValueError("more ranks (%d) than canonical %d-mer words (%d)" % (world, k, space))
+    out, prev = [0], 0
+    for r, c in enumerate(cuts):
+        c = int(c)
+        c = max(c, prev + 1)
+        c = min(c, space - (world - 1 - r))     # leave room for the slabs behind
+        out.append(c)
+        prev = c
+    out.append(0)
+    return out
+
+
+def canonical_cdf_bounds(k, world):
+    """Closed-form quantile cuts for uniformly random sequence: for a random k-mer w, P(min(w, rc(w)) >= x) is
+    close to (1 - x / 4^k)^2 (w and its reverse complement are nearly independent), so the q-quantile of the
+    canonical words sits at 4^k (1 - sqrt(1 - q)).  The default when no list has been counted yet."""
+    space = 1 << (2 * k)
+    cuts = [int(space * (1.0 - (1.0 - r / world) ** 0.5)) for r in range(1, world)]
+    return _legal_bounds(cuts, k, world)
+
+
+def pilot_points(words, n_points=8192):
+    """Evenly spaced quantile points of one sorted list (what a rank contributes to the bounds)."""
+    words = np.asarray(words, dtype=np.uint64)
+    if len(words) == 0:
+        return np.zeros(0, dtype=np.uint64)
+    idx = (np.arange(n_points, dtype=np.float64) + 0.5) * (len(words) / n_points)
+    return words[np.minimum(idx.astype(np.int64), len(words) - 1)]
+
+
+def quantile_bounds(points, k, world):
+    """points: quantile points of the pilot lists (any order) -> world + 1 bounds cutting them into equal parts.
+    No points: the closed form."""
+    pts = np.sort(np.asarray(points, dtype=np.uint64))
+    if len(pts) < 4 * world:
+        return canonical_cdf_bounds(k, world)
+    cuts = [int(pts[(len(pts) * r) // world]) for r in range(1, world)]
+    return _legal_bounds(cuts, k, world)
+
+
+def balanced_bounds(group, k, pilot_lists, n_points=8192):
+    """The same bounds on every rank: each rank contributes the quantile points of the lists it has in hand
+    (sorted word arrays, whole word space); one all-gather; equal-count cuts of the merged points."""
+    mine = [pilot_points(w, n_points) for w in pilot_lists if len(w)]
+    mine = np.concatenate(mine) if mine else np.zeros(0, dtype=np.uint64)
+    blobs = group.allgather_bytes(mine.tobytes())
+    pts = np.concatenate([np.frombuffer(b, dtype=np.uint64) for b in blobs]) if blobs else mine
+    return quantile_bounds(pts, k, group.world)
+
+
+# ---- transports ----------------------------------------------------------------------------------------------
+class DeviceBuffer:
+    """A plain allocation the exchanges pack into / receive into (device memory with the RCCL transport)."""
+
+    def __init__(self, ctx, nbytes):
+        self.ctx = ctx
+        self.nbytes = int(max(nbytes, 256))
+        self.ptr = ctx.dev_alloc(self.nbytes)
+
+    def free(self):
+        if self.ptr:
+            try:
+                self.ctx.dev_free(self.ptr)
+            finally:
+                self.ptr = 0
+
+    def __del__(self):
+        try:
+            self.free()
+        except Exception:
+            pass
+
+
+def _rendezvous_path():
+    p = os.environ.get("PSK_RDZV_FILE")
+    if p:
+        return p
+    # all ranks of one launch share the launcher as their parent (torch.distributed.run's agent, a test's Popen loop)
+    key = "%s_%s_%s_%d" % (os.environ.get("MASTER_ADDR", "127.0.0.1"), os.environ.get("MASTER_PORT", "0"),
+                           os.environ.get("TORCHELASTIC_RUN_ID", "none"), os.getppid())
+    return os.path.join(tempfile.gettempdir(), "psk_rdzv_" + "".join(c if c.isalnum() else "_" for c in key))
+
+
+def exchange_unique_id(rank, world, make_id, timeout=300.0, path=None):
+    """Rank 0 creates the id and publishes it atomically (write + rename) in the rendezvous file; the others poll
+    for it.  The file name carries the launcher's pid, so a later launch cannot pick up a stale id; rank 0 removes
+    the file once every rank has joined the communicator."""
+    path = path or _rendezvous_path()
+    if rank == 0:
+        uid = make_id()
+        tmp = "%s.%d.tmp" % (path, os.getpid())
+        with open(tmp, "wb") as f:
+            f.write(len(uid).to_bytes(4, "little") + uid)
+        os.replace(tmp, path)
+        return uid, path
+    t0 = time.time()
+    while True:
+        try:
+            with open(path, "rb") as f:
+                blob = f.read()
+            if len(blob) >= 4 and len(blob) == 4 + int.from_bytes(blob[:4], "little"):
+                return blob[4:], path
+        except OSError:
+            pass
+        if time.time() - t0 > timeout:
+            raise RuntimeError("rank %d: no unique id in %s after %.0f s (is rank 0 running?)" % (rank, path, timeout))
+        time.sleep(0.01)
+
+
+class RcclTransport:
+    """RCCL over xGMI through libpsk.so's own communicator (csrc/comm.hip)."""
+    name = "rccl"
+    device_memory = True
+
+    def __init__(self, rank, world, device):
+        self.rank, self.world, self.device = rank, world, device
+        self.ctx = PskContext(device)
+        uid, self._rdzv = exchange_unique_id(rank, world, self.ctx.comm_unique_id)
+        self.ctx.comm_init(uid, rank, world)
+        self.stream = self.ctx.comm_stream()
+        self.barrier()                      # every rank has joined: the file is no longer needed
+        if rank == 0:
+            try:
+                os.unlink(self._rdzv)
+            except OSError:
+                pass
+
+    def alloc(self, nbytes):
+        return DeviceBuffer(self.ctx, nbytes)
+
+    def to_host(self, buf, nbytes, offset=0):
+        return self.ctx.dev_download(buf.ptr + offset, nbytes, behind_collectives=True)
+
+    def allreduce(self, arr, op):
+        return self.ctx.comm_allreduce(arr, op)
+
+    def allgather_host(self, send_u8):
+        return self.ctx.comm_allgather_host(send_u8, self.world)
+
+    def allgather_device(self, send, recv, nbytes):
+        self.ctx.comm_allgather_device(send.ptr, recv.ptr, nbytes)
+
+    def alltoallv(self, send, send_counts, recv, recv_counts, elem_bytes):
+        self.ctx.comm_alltoallv_device(send.ptr, send_counts, recv.ptr, recv_counts, elem_bytes)
+
+    def sync(self):
+        self.ctx.comm_sync()
+
+    def barrier(self):
+        self.ctx.comm_allreduce(np.ones(1, dtype=np.uint64), "sum")
+
+    def close(self):
+        self.ctx.close()
+
+
 class Group:
-    """Thin view of the default torch.distributed process group (or a no-op for one rank)."""
+    """The ranks of one run (or a no-op for one rank).  RANK / WORLD_SIZE / LOCAL_RANK as torch.distributed.run
+    and every MPI-style launcher export them."""
 
     def __init__(self):
         self.world = int(os.environ.get("WORLD_SIZE", "1"))
         self.rank = int(os.environ.get("RANK", "0"))
         self.local_rank = int(os.environ.get("LOCAL_RANK", "0"))
         self.device = self.local_rank   # GPU index of this rank (see init: PSK_SHARE_GPU)
-        self._dist = None
-        self._dev = None
+        self.t = None                   # transport
+        self.backend = None
 
-    def init(self, backend=None, force=False):
+    def init(self, transport=None, force=False):
+        """transport: None (RCCL, or the class named by PSK_DIST_TRANSPORT=module:Class -- tests), or an
+        instance.  PSK_SHARE_GPU=1 maps the ranks onto the visible GPUs modulo their count (tests on a one-GPU
+        box; RCCL itself refuses two ranks on one GPU)."""
         if self.world == 1 and not force:
             return self
-        import torch
-        import torch.distributed as dist
-        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        os.environ.setdefault("MASTER_PORT", "29533")
-        # test knobs for a box with fewer GPUs than ranks: PSK_DIST_BACKEND=gloo keeps the collectives on the host,
-        # PSK_SHARE_GPU=1 maps the ranks onto the visible GPUs modulo their count
-        if backend is None:
-            backend = os.environ.get("PSK_DIST_BACKEND") or ("nccl" if torch.cuda.is_available() else "gloo")
+        spec = os.environ.get("PSK_DIST_TRANSPORT")
+        cls = None
+        if transport is None and spec:
+            mod, _, name = spec.partition(":")
+            cls = getattr(importlib.import_module(mod), name)      # before libpsk.so is opened (see the module's note)
         if os.environ.get("PSK_SHARE_GPU") == "1":
-            self.device = self.local_rank % max(torch.cuda.device_count(), 1)
-        if backend == "nccl":
-            torch.cuda.set_device(self.device)
-            self._dev = torch.device("cuda", self.device)
-        else:
-            self._dev = torch.device("cpu")
-        if not dist.is_initialized():
-            dist.init_process_group(backend=backend, rank=self.rank, world_size=self.world)
-        self._dist = dist
-        self.backend = backend
+            from . import _lib
+            self.device = self.local_rank % max(_lib.load().psk_device_count(), 1)
+        if transport is None:
+            transport = (cls or RcclTransport)(self.rank, self.world, self.device)
+        self.t = transport
+        self.backend = transport.name
         return self
 
     def barrier(self):
-        if self._dist is not None:
-            self._dist.barrier()
+        if self.t is not None:
+            self.t.barrier()
 
     def close(self):
-        if self._dist is not None and self._dist.is_initialized():
-            self._dist.destroy_process_group()
-        self._dist = None
+        if self.t is not None:
+            self.t.close()
+        self.t = None
 
-    # -- collectives on small host arrays ---------------------------------------------------------
+    # -- collectives on small host values ---------------------------------------------------------
     def allreduce_sum(self, value):
-        """Sum of a python int / float over ranks (exact for ints below 2^63)."""
-        if self._dist is None:
+        """Sum of a python int / float over ranks (exact for non-negative ints below 2^64)."""
+        if self.t is None:
             return value
-        import torch
-        is_int = isinstance(value, (int, np.integer))
-        t = torch.tensor([int(value) if is_int else float(value)],
-                         dtype=torch.int64 if is_int else torch.float64, device=self._dev)
-        self._dist.all_reduce(t, op=self._dist.ReduceOp.SUM)
-        return int(t.item()) if is_int else float(t.item())
+        if isinstance(value, (int, np.integer)):
+            return int(self.t.allreduce(np.array([int(value)], dtype=np.uint64), "sum")[0])
+        return float(self.t.allreduce(np.array([float(value)], dtype=np.float64), "sum")[0])
 
     def allreduce_max(self, value):
-        if self._dist is None:
+        if self.t is None:
             return float(value)
-        import torch
-        t = torch.tensor([float(value)], dtype=torch.float64, device=self._dev)
-        self._dist.all_reduce(t, op=self._dist.ReduceOp.MAX)
-        return float(t.item())
+        return float(self.t.allreduce(np.array([float(value)], dtype=np.float64), "max")[0])
+
+    def allgather_i64(self, arr):
+        """Equal-length int64 arrays -> [world, n]."""
+        a = np.ascontiguousarray(arr, dtype=np.int64)
+        if self.t is None:
+            return a[None, :]
+        return self.t.allgather_host(a.view(np.uint8)).view(np.int64).reshape(self.world, -1)
 
     def allgather_bytes(self, payload):
         """all-gather(v) of one bytes object per rank -> list of bytes in rank order."""
-        if self._dist is None:
+        if self.t is None:
             return [payload]
-        import torch
-        n = torch.tensor([len(payload)], dtype=torch.int64, device=self._dev)
-        sizes = [torch.zeros(1, dtype=torch.int64, device=self._dev) for _ in range(self.world)]
-        self._dist.all_gather(sizes, n)
-        sizes = [int(s.item()) for s in sizes]
-        cap = max(max(sizes), 1)
-        buf = torch.zeros(cap, dtype=torch.uint8, device=self._dev)
-        if len(payload):
-            buf[: len(payload)] = torch.frombuffer(bytearray(payload), dtype=torch.uint8).to(self._dev)
-        outs = [torch.zeros(cap, dtype=torch.uint8, device=self._dev) for _ in range(self.world)]
-        self._dist.all_gather(outs, buf)
-        return [bytes(o[:s].cpu().numpy().tobytes()) for o, s in zip(outs, sizes)]
+        sizes = self.allgather_i64(np.array([len(payload)]))[:, 0]
+        cap = int(max(int(sizes.max()), 8))
+        buf = np.zeros(cap, dtype=np.uint8)
+        buf[: len(payload)] = np.frombuffer(payload, dtype=np.uint8)
+        got = self.t.allgather_host(buf)
+        return [got[r, : int(sizes[r])].tobytes() for r in range(self.world)]
 
 
 _FIELDS = (("word", np.uint64), ("stat", np.float64), ("p", np.float64), ("mean_x", np.float64),
@@ -150,54 +314,45 @@ def merge_candidates(payloads):
 
 
 class SurvivorExchange:
-    """All-gather(v) of the scan survivors without leaving the GPU (RCCL over xGMI): every rank packs
-    its survivors into a fixed-capacity device buffer (psk_export_survivors), one
-    all_gather_into_tensor moves all slabs, and the copy is double-buffered so that the collective of
-    scan i overlaps scan i+1 (several phenotypes are scanned back to back).  With the gloo backend
-    (CPU tests, one-GPU dry runs) the packed buffer is staged through host tensors instead."""
+    """All-gather(v) of the scan survivors without leaving the GPU (RCCL over xGMI): every rank packs its
+    survivors into a fixed-capacity device buffer (psk_export_survivors_async, queued on the communicator's
+    stream), one ncclAllGather queued behind it moves all slabs, and the buffers are doubled so that the
+    collective of scan i overlaps scan i+1 (several phenotypes are scanned back to back).  A host transport
+    (tests) stages the packed buffer through host memory instead."""
 
     def __init__(self, group, words_per_row, cap_records=4096):
-        import torch
         self.g = group
+        self.t = group.t
         self.wpr = int(words_per_row)
         self.rec_words = 6 + self.wpr
-        self.torch = torch
         self.slot = 0
-        self.work = [None, None]
+        self.send = self.recv = None
         self._alloc(int(cap_records))
 
     def _alloc(self, cap):
-        torch = self.torch
+        for b in (self.send or []) + (self.recv or []):
+            b.free()
         self.cap = cap
-        n = (cap + 1) * self.rec_words
-        dev = torch.device("cuda", torch.cuda.current_device()) if torch.cuda.is_available() else torch.device("cpu")
-        self.dev = dev
-        self.send = [torch.zeros(n, dtype=torch.int64, device=dev) for _ in range(2)]
-        nccl = getattr(self.g, "backend", None) == "nccl"
-        rdev = dev if nccl else torch.device("cpu")
-        self.recv = [torch.zeros(self.g.world * n, dtype=torch.int64, device=rdev) for _ in range(2)]
-        self.nccl = nccl
+        self.nbytes = (cap + 1) * self.rec_words * 8
+        self.send = [self.t.alloc(self.nbytes) for _ in range(2)]
+        self.recv = [self.t.alloc(self.g.world * self.nbytes) for _ in range(2)]
 
     def export(self, ctx):
         """First half of an exchange, right after a scan has ended: this rank's survivors are packed into the next
-        send buffer.  With nccl the pack is queued on torch's current stream and not waited for (the next scan of
-        `ctx` waits for it on the device), so the caller can launch that scan before calling collect()."""
+        send buffer.  The pack is queued on the communicator's stream and not waited for (the next scan of `ctx`
+        that writes the same result set waits for it on the device), so the caller can launch that scan before
+        calling collect()."""
         s = self.slot
         self.slot ^= 1
-        if self.nccl:
-            ctx.export_survivors_async(self.send[s].data_ptr(), self.cap, self.torch.cuda.current_stream().cuda_stream)
+        if self.t.stream:
+            ctx.export_survivors_async(self.send[s].ptr, self.cap, self.t.stream)
         else:
-            ctx.export_survivors(self.send[s].data_ptr(), self.cap)
+            ctx.export_survivors(self.send[s].ptr, self.cap)
         return s
 
     def collect(self, s):
         """Second half: queues the all-gather of slot s (ordered behind its export on the device)."""
-        dist = self.g._dist
-        if self.nccl:
-            self.work[s] = dist.all_gather_into_tensor(self.recv[s], self.send[s], async_op=True)
-        else:
-            parts = list(self.recv[s].chunk(self.g.world))
-            self.work[s] = dist.all_gather(parts, self.send[s].cpu(), async_op=True)
+        self.t.allgather_device(self.send[s], self.recv[s], self.nbytes)
 
     def start(self, ctx):
         """export() + collect() in one call; returns (slot, None)."""
@@ -205,12 +360,15 @@ class SurvivorExchange:
         self.collect(s)
         return s, None
 
+    def _host_table(self, s):
+        full = self.t.to_host(self.recv[s], self.g.world * self.nbytes)
+        return full.view(np.uint64).reshape(self.g.world, self.cap + 1, self.rec_words)
+
     def finish(self, s):
         """Waits for slot s; returns (res dict, bits) of ALL slabs, ascending by word.  Returns None
         when some rank had more survivors than the buffers hold (caller grows and repeats the scan's
         exchange)."""
-        self.work[s].wait()
-        host = self.recv[s].cpu().numpy().view(np.uint64).reshape(self.g.world, self.cap + 1, self.rec_words)
+        host = self._host_table(s)
         counts = host[:, 0, 0].astype(np.int64)
         if (counts > self.cap).any():
             return None
@@ -224,16 +382,15 @@ class SurvivorExchange:
         return res, np.ascontiguousarray(recs[:, 6:])
 
     def wait(self, s):
-        """Orders everything queued later behind the collective of slot s, so that its buffers may be packed again.
-        With nccl that is a stream-level wait (the host does not block); gloo completes on the host."""
-        self.work[s].wait()
+        """Everything queued later on the communicator's stream (the next export into slot s) is ordered behind
+        the collective of slot s by the stream itself: nothing to do on the host."""
+        return None
 
     def finish_counts(self, s):
-        """Waits for slot s and reads back only the per-slab record counts (the records stay on the
-        device); used where the merged table is not needed on the host right away."""
-        self.work[s].wait()
-        hdr = self.recv[s].view(self.g.world, self.cap + 1, self.rec_words)[:, 0, 0]
-        return hdr.cpu().numpy().astype(np.int64)
+        """Waits for the collectives queued so far and reads back only the per-slab record counts of slot s (the
+        records stay on the device); used where the merged table is not needed on the host right away."""
+        return np.array([int(self.t.to_host(self.recv[s], 8, offset=r * self.nbytes).view(np.uint64)[0])
+                         for r in range(self.g.world)], dtype=np.int64)
 
     def gather(self, ctx):
         """Synchronous form used by the pipeline: exchange the survivors of the last scan, growing the
@@ -256,75 +413,55 @@ class ListExchange:
     """Multi-GPU ingest without redundant counting: every sample is counted, unfiltered, on ONE rank (context
     `cnt_ctx`, samples numbered locally in ascending global order); a slab of the word space is a contiguous range
     of the sorted list, so each rank then sends range s of each of its lists to rank s -- one all-to-all(v) of the
-    words and one of the counts (RCCL over xGMI with nccl; staged through host tensors with gloo) -- and installs
-    what it receives as the lists of its slab context (psk_set_lists_device).  The lists every rank ends up with are
-    the ones it would have counted itself with the slab filter."""
+    words and one of the counts (ncclSend / ncclRecv in one group over xGMI; staged through host memory by the
+    test transport) -- and installs what it receives as the lists of its slab context (psk_set_lists_device).  The
+    lists every rank ends up with are the ones it would have counted itself with the slab filter.
+    bounds: the world + 1 slab bounds every rank agreed on (balanced_bounds)."""
 
-    def __init__(self, group, k):
-        import torch
+    def __init__(self, group, k, bounds=None):
         self.g = group
-        self.torch = torch
+        self.t = group.t
         self.k = int(k)
-        self.nccl = getattr(group, "backend", None) == "nccl"
-        self.dev = torch.device("cuda", torch.cuda.current_device()) if torch.cuda.is_available() else torch.device("cpu")
-
-    def _all_gather_i64(self, arr):
-        torch, dist = self.torch, self.g._dist
-        t = torch.from_numpy(np.ascontiguousarray(arr, dtype=np.int64)).to(self.g._dev)
-        outs = [torch.zeros_like(t) for _ in range(self.g.world)]
-        dist.all_gather(outs, t)
-        return [o.cpu().numpy() for o in outs]
+        W = group.world
+        self.bounds = list(bounds) if bounds is not None else [slab_bounds(self.k, W, d)[0] for d in range(W)] + [0]
 
     def run(self, cnt_ctx, slab_ctx, n_samples, n_total_own):
         """cnt_ctx holds the lists of this rank's samples (local index j = j-th sample i with owner_of(i) == rank);
         slab_ctx has been begun with this rank's slab and n_samples.  Returns the number of (word, sample) pairs
         installed."""
-        torch, dist = self.torch, self.g._dist
         W, r = self.g.world, self.g.rank
         own = [i for i in range(n_samples) if owner_of(i, W) == r]
         per = (n_samples + W - 1) // W                       # rows of the count table, the same on every rank
-        bounds = [slab_bounds(self.k, W, d)[0] for d in range(W)] + [0]
-        cuts = cnt_ctx.lists_split(0, len(own), bounds) if own else np.zeros((0, W + 1), np.int64)
+        cuts = cnt_ctx.lists_split(0, len(own), self.bounds) if own else np.zeros((0, W + 1), np.int64)
         seg = np.zeros((per, W), dtype=np.int64)             # seg[j][d]: entries of my j-th sample that go to rank d
         tot = np.zeros(per, dtype=np.int64)
         if own:
             seg[: len(own)] = np.diff(cuts, axis=1)
             tot[: len(own)] = np.asarray(n_total_own, dtype=np.int64)
-        tables = self._all_gather_i64(np.concatenate([seg.ravel(), tot]))
+        tables = self.g.allgather_i64(np.concatenate([seg.ravel(), tot]))
         seg_all = [t[: per * W].reshape(per, W) for t in tables]     # seg_all[src][j][dst]
         tot_all = [t[per * W:] for t in tables]
         send_counts = [int(seg[:, d].sum()) for d in range(W)]
         recv_counts = [int(seg_all[src][:, r].sum()) for src in range(W)]
-        stage = self.dev if torch.cuda.is_available() else torch.device("cpu")
-        send_w = torch.empty(max(sum(send_counts), 1), dtype=torch.int64, device=stage)
-        send_f = torch.empty(max(sum(send_counts), 1), dtype=torch.int32, device=stage)
-        # destination-major, my samples in order inside: one packing call
-        rs = [(j, int(cuts[j, d]), int(seg[j, d])) for d in range(W) for j in range(len(own))]
-        if rs:
-            cnt_ctx.copy_list_ranges([x[0] for x in rs], [x[1] for x in rs], [x[2] for x in rs], send_w.data_ptr(),
-                                     send_f.data_ptr())
-        n_recv = sum(recv_counts)
-        if self.nccl:
-            recv_w = torch.empty(max(n_recv, 1), dtype=torch.int64, device=stage)
-            recv_f = torch.empty(max(n_recv, 1), dtype=torch.int32, device=stage)
-            torch.cuda.synchronize()
-            dist.all_to_all_single(recv_w[:n_recv], send_w[: sum(send_counts)], recv_counts, send_counts)
-            dist.all_to_all_single(recv_f[:n_recv], send_f[: sum(send_counts)], recv_counts, send_counts)
-            torch.cuda.synchronize()
-        else:                                                # host-staged collectives, device buffers either side
-            hw = torch.empty(max(n_recv, 1), dtype=torch.int64)
-            hf = torch.empty(max(n_recv, 1), dtype=torch.int32)
-            dist.all_to_all_single(hw[:n_recv], send_w[: sum(send_counts)].cpu(), recv_counts, send_counts)
-            dist.all_to_all_single(hf[:n_recv], send_f[: sum(send_counts)].cpu(), recv_counts, send_counts)
-            recv_w, recv_f = hw.to(stage), hf.to(stage)
-            if torch.cuda.is_available():
-                torch.cuda.synchronize()
-        # what arrived is source-major, the source's samples in order inside: one installing call
-        idx, cnt, tot = [], [], []
-        for src in range(W):
-            theirs = [i for i in range(n_samples) if owner_of(i, W) == src]
-            idx += theirs
-            cnt += [int(seg_all[src][j, r]) for j in range(len(theirs))]
-            tot += [int(tot_all[src][j]) for j in range(len(theirs))]
-        slab_ctx.set_lists_device(idx, cnt, tot, recv_w.data_ptr(), recv_f.data_ptr())
+        n_send, n_recv = sum(send_counts), sum(recv_counts)
+        send_w, send_f = self.t.alloc(n_send * 8), self.t.alloc(n_send * 4)
+        recv_w, recv_f = self.t.alloc(n_recv * 8), self.t.alloc(n_recv * 4)
+        try:
+            # destination-major, my samples in order inside: one packing call (waited for inside)
+            rs = [(j, int(cuts[j, d]), int(seg[j, d])) for d in range(W) for j in range(len(own))]
+            if rs:
+                cnt_ctx.copy_list_ranges([x[0] for x in rs], [x[1] for x in rs], [x[2] for x in rs], send_w.ptr, send_f.ptr)
+            self.t.alltoallv(send_w, send_counts, recv_w, recv_counts, 8)
+            self.t.alltoallv(send_f, send_counts, recv_f, recv_counts, 4)
+            # what arrived is source-major, the source's samples in order inside: one installing call
+            idx, cnt, tot = [], [], []
+            for src in range(W):
+                theirs = [i for i in range(n_samples) if owner_of(i, W) == src]
+                idx += theirs
+                cnt += [int(seg_all[src][j, r]) for j in range(len(theirs))]
+                tot += [int(tot_all[src][j]) for j in range(len(theirs))]
+            slab_ctx.set_lists_device(idx, cnt, tot, recv_w.ptr, recv_f.ptr)
+        finally:
+            for b in (send_w, send_f, recv_w, recv_f):
+                b.free()
         return int(sum(cnt))

@@ -250,6 +250,66 @@ class PskContext:
         self._check(self._lib.psk_export_survivors_async(self._h, ctypes.c_void_p(int(device_ptr)), int(cap_records),
                                                          ctypes.c_void_p(int(stream_handle))), "psk_export_survivors_async")
 
+    # -- multi-GPU collectives (RCCL, comm.hip) and plain device buffers ---------------------------
+    def comm_unique_id(self):
+        buf = ctypes.create_string_buffer(128)
+        n = self._lib.psk_comm_unique_id(self._h, buf, 128)
+        if n < 0:
+            self._check(n, "psk_comm_unique_id")
+        return buf.raw[:n]
+
+    def comm_init(self, uid, rank, world):
+        self._check(self._lib.psk_comm_init(self._h, bytes(uid), len(uid), int(rank), int(world)), "psk_comm_init")
+
+    def comm_stream(self):
+        return self._lib.psk_comm_stream(self._h) or 0
+
+    def comm_sync(self):
+        self._check(self._lib.psk_comm_sync(self._h), "psk_comm_sync")
+
+    def comm_allreduce(self, arr, op="sum"):
+        """In place on a contiguous uint64 or float64 array."""
+        assert arr.dtype in (np.uint64, np.float64) and arr.flags.c_contiguous
+        self._check(self._lib.psk_comm_allreduce(self._h, _ptr(arr), arr.size, 0 if arr.dtype == np.uint64 else 1,
+                                                 {"sum": 0, "max": 1}[op]), "psk_comm_allreduce")
+        return arr
+
+    def comm_allgather_host(self, send, world):
+        send = np.ascontiguousarray(send).view(np.uint8).ravel()
+        recv = np.empty((world, send.size), dtype=np.uint8)
+        self._check(self._lib.psk_comm_allgather_host(self._h, _ptr(send), _ptr(recv), send.size), "psk_comm_allgather_host")
+        return recv
+
+    def comm_allgather_device(self, send_ptr, recv_ptr, nbytes):
+        self._check(self._lib.psk_comm_allgather_device(self._h, ctypes.c_void_p(int(send_ptr)), ctypes.c_void_p(int(recv_ptr)),
+                                                        int(nbytes)), "psk_comm_allgather_device")
+
+    def comm_alltoallv_device(self, send_ptr, send_counts, recv_ptr, recv_counts, elem_bytes):
+        sc = np.ascontiguousarray(send_counts, dtype=np.uint64)
+        rc = np.ascontiguousarray(recv_counts, dtype=np.uint64)
+        self._check(self._lib.psk_comm_alltoallv_device(self._h, ctypes.c_void_p(int(send_ptr)), _ptr(sc),
+                                                        ctypes.c_void_p(int(recv_ptr)), _ptr(rc), int(elem_bytes)),
+                    "psk_comm_alltoallv_device")
+
+    def dev_alloc(self, nbytes):
+        p = ctypes.c_void_p()
+        self._check(self._lib.psk_dev_alloc(self._h, int(nbytes), ctypes.byref(p)), "psk_dev_alloc")
+        return p.value
+
+    def dev_free(self, ptr):
+        if ptr and getattr(self, "_h", None):
+            self._check(self._lib.psk_dev_free(self._h, ctypes.c_void_p(int(ptr))), "psk_dev_free")
+
+    def dev_download(self, ptr, nbytes, behind_collectives=False):
+        out = np.empty(int(nbytes), dtype=np.uint8)
+        self._check(self._lib.psk_dev_copy(self._h, _ptr(out), ctypes.c_void_p(int(ptr)), int(nbytes), 1,
+                                           1 if behind_collectives else 0), "psk_dev_copy")
+        return out
+
+    def dev_upload(self, ptr, arr):
+        a = np.ascontiguousarray(arr)
+        self._check(self._lib.psk_dev_copy(self._h, ctypes.c_void_p(int(ptr)), _ptr(a), a.nbytes, 0, 0), "psk_dev_copy")
+
     def last_scan_ms(self):
         return self._lib.psk_last_scan_ms(self._h)
 

@@ -125,21 +125,51 @@ class Samples:
                 cls._record_lists(part, ctx.count_kmers_batch(lo, datas, n_threads, sketch=sketch))
 
     @classmethod
-    def get_kmer_lists_exchanged(cls, ctx, group, samples, n_threads):
-        """Several ranks: every sample is counted on ONE rank (round robin, no slab filter, a second context on the
+    def _pilot_bounds(cls, group, k, cnt, counted):
+        """Balanced slab bounds (dist.balanced_bounds) from up to four of the lists this rank has counted in `cnt`
+        (whole word space): `counted` = [(local index, n_unique)]."""
+        pilot = [cnt.get_list(j, nu)[0] for j, nu in counted[:4]]
+        return _dist.balanced_bounds(group, k, pilot)
+
+    @classmethod
+    def get_kmer_lists_sharded(cls, ctx, group, samples, n_threads, exchange):
+        """Several ranks.  The word space is cut at the quantiles of a pilot of the lists, so that every rank gets
+        the same share of the rows (the reference's chunks are balanced too: round-robin `split -n r/<nt>`,
+        :335-342); `ctx` is begun with this rank's slab.
+        exchange: every sample is counted on ONE rank (round robin, no slab filter, a second context on the
         same GPU) and the slab ranges of the sorted lists are exchanged GPU to GPU (dist.ListExchange) -- each rank
         ends up with the lists it would have counted itself with its slab filter, without every rank framing and
-        scanning every file.  With -w the sketches of a rank's samples are all-gathered (every rank computes the
-        weights, the scans need them)."""
+        scanning every file.  Otherwise every rank counts every sample and keeps its slab (after a pilot of a few
+        samples, counted whole, has given the bounds).  With -w the sketches of a rank's samples are all-gathered
+        (every rank computes the weights, the scans need them)."""
         W, r = group.world, group.rank
-        own = [s for i, s in enumerate(samples) if _dist.owner_of(i, W) == r]
         k = int(cls.kmer_length)
+        n = len(samples)
+        if not exchange:
+            first = [i for i in range(min(n, max(W, 4))) if _dist.owner_of(i, W) == r]
+            with PskContext(group.device) as cnt:
+                cnt.begin(k, max(len(first), 1))
+                sketch_was, cls.use_weights = cls.use_weights, False       # the pilot needs no sketches
+                progress_was = stderr_print.currentSampleNum
+                try:
+                    if first:
+                        cls.get_kmer_lists_batched(cnt, [samples[i] for i in first], n_threads)
+                finally:
+                    cls.use_weights = sketch_was
+                    stderr_print.currentSampleNum = progress_was
+                bounds = cls._pilot_bounds(group, k, cnt, [(j, samples[i].n_unique) for j, i in enumerate(first)])
+            ctx.begin(k, n, bounds[r], bounds[r + 1])
+            cls.get_kmer_lists_batched(ctx, samples, n_threads)
+            return bounds
+        own = [s for i, s in enumerate(samples) if _dist.owner_of(i, W) == r]
         cnt = PskContext(group.device)
         try:
             cnt.begin(k, max(len(own), 1))
             if own:
                 cls.get_kmer_lists_batched(cnt, own, n_threads)
-            _dist.ListExchange(group, k).run(cnt, ctx, len(samples), [s.n_total for s in own])
+            bounds = cls._pilot_bounds(group, k, cnt, [(j, s.n_unique) for j, s in enumerate(own)])
+            ctx.begin(k, n, bounds[r], bounds[r + 1])
+            _dist.ListExchange(group, k, bounds).run(cnt, ctx, n, [s.n_total for s in own])
         finally:
             cnt.close()
         if cls.use_weights:
@@ -154,6 +184,7 @@ class Samples:
                 for s, ln in zip(theirs, lens):
                     s.sketch = np.frombuffer(blob, dtype=np.uint64, count=int(ln), offset=off).tolist()
                     off += 8 * int(ln)
+        return bounds
 
     @classmethod
     def _record_lists(cls, part, res):
@@ -768,19 +799,18 @@ def modeling(args):
     try:
         if not Input.jump_to:
             k = int(Samples.kmer_length)
-            lo, hi = _dist.slab_bounds(k, group.world, group.rank)
-            ctx.begin(k, Samples.no_samples, lo, hi)
             _err(GREEN % "Generating the k-mer lists for input samples:" + "\n")
             n_thr = max(1, min(int(Input.num_threads), 8))
             t_lists = time.time()
-            # several ranks: the list exchange when the collectives run GPU to GPU (nccl = RCCL); with gloo they are
+            # several ranks: the list exchange when the collectives run GPU to GPU (RCCL); with the host transport of the tests they are
             # staged through the host (7 GB through TCP loopback for 2 x 128 genomes: 5.7 s against 0.12 s), so
             # every rank counts everything there.  PSK_REDUNDANT_INGEST = 0 / 1 forces either.
             knob = os.environ.get("PSK_REDUNDANT_INGEST")
-            exchange = group.world > 1 and (knob == "0" or (knob != "1" and getattr(group, "backend", None) == "nccl"))
-            if exchange:
-                Samples.get_kmer_lists_exchanged(ctx, group, list(Input.samples.values()), n_thr)
-            else:   # one rank -- or, as an A/B knob, every rank counts every sample and keeps its slab
+            exchange = group.world > 1 and (knob == "0" or (knob != "1" and getattr(group, "backend", None) == "rccl"))
+            if group.world > 1:
+                Samples.get_kmer_lists_sharded(ctx, group, list(Input.samples.values()), n_thr, exchange)
+            else:
+                ctx.begin(k, Samples.no_samples)
                 Samples.get_kmer_lists_batched(ctx, list(Input.samples.values()), n_thr)
             if group.rank == 0:
                 with open("log.txt", "a") as log:

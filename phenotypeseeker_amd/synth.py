@@ -30,15 +30,26 @@ def wrap_fasta(name, codes, width=70):
 class GenomeSet:
     """Lazy generator: sample(i) -> (name, fasta_bytes); phenotype(i) -> 0/1."""
 
-    def __init__(self, n_samples, length, seed=12345, sub_rate=0.003, gene_len=2000, dropout=12):
+    def __init__(self, n_samples, length, seed=12345, sub_rate=0.003, gene_len=2000, dropout=12, gc=0.5, contigs=1):
+        """gc: G+C fraction of the ancestor and of the substituted bases (0.5 = uniform ACGT; C. difficile, the
+        reference's example organism, is at 0.29); contigs: FASTA records per sample (the genome is cut into that
+        many pieces of unequal length, as an assembly would be)."""
         self.n = int(n_samples)
         self.length = int(length)
         self.seed = int(seed)
         self.sub_rate = float(sub_rate)
         self.dropout = int(dropout)
+        self.gc = float(gc)
+        self.contigs = int(contigs)
         rng = np.random.default_rng(self.seed)
-        self.ancestor = rng.integers(0, 4, self.length, dtype=np.uint8)
-        self.gene = rng.integers(0, 4, int(gene_len), dtype=np.uint8)
+        self.ancestor = self._bases(rng, self.length)
+        self.gene = self._bases(rng, int(gene_len))
+
+    def _bases(self, rng, n):
+        if self.gc == 0.5:
+            return rng.integers(0, 4, n, dtype=np.uint8)       # the draw the committed fixtures were made with
+        at, gc = (1.0 - self.gc) / 2.0, self.gc / 2.0
+        return rng.choice(4, size=n, p=[at, gc, gc, at]).astype(np.uint8)   # A C G T
 
     def name(self, i):
         return "S%04d" % i
@@ -58,14 +69,22 @@ class GenomeSet:
         g = self.ancestor.copy()
         nsub = rng.binomial(self.length, self.sub_rate)
         pos = rng.integers(0, self.length, nsub)
-        g[pos] = rng.integers(0, 4, nsub, dtype=np.uint8)
+        g[pos] = self._bases(rng, nsub)
         if self.has_gene(i):
             h = self.length // 2
             g = np.concatenate([g[:h], self.gene, g[h:]])
         return g
 
     def sample(self, i):
-        return self.name(i), wrap_fasta(self.name(i) + "_c1", self.codes(i))
+        codes = self.codes(i)
+        if self.contigs <= 1:
+            return self.name(i), wrap_fasta(self.name(i) + "_c1", codes)
+        rng = np.random.default_rng([self.seed, 7919, i])
+        cuts = np.sort(rng.choice(np.arange(1, len(codes)), size=self.contigs - 1, replace=False))
+        parts = np.split(codes, cuts)
+        # assembler-style headers: name, length and coverage fields after a space
+        return self.name(i), b"".join(wrap_fasta("%s_c%d len=%d cov=%.1f" % (self.name(i), j + 1, len(p), 30 + j), p)
+                                      for j, p in enumerate(parts))
 
     def continuous_phenotype(self, i):
         """cfg 4: 2^(gene present) x lognormal noise."""

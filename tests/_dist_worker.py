@@ -81,8 +81,9 @@ def check_list_exchange(grp, ds):
     full = [O.count_kmers(ds["files"][nm], k)[:2] for nm in names]
     own = [i for i in range(n) if dist.owner_of(i, grp.world) == grp.rank]
     slab = HostSlab()
-    pairs = dist.ListExchange(grp, k).run(HostLists([full[i] for i in own]), slab, n, [int(full[i][1].sum()) for i in own])
-    lo, hi = dist.slab_bounds(k, grp.world, grp.rank)
+    bounds = dist.balanced_bounds(grp, k, [full[i][0] for i in own[:4]])
+    pairs = dist.ListExchange(grp, k, bounds).run(HostLists([full[i] for i in own]), slab, n, [int(full[i][1].sum()) for i in own])
+    lo, hi = bounds[grp.rank], bounds[grp.rank + 1]
     assert sorted(slab.got) == list(range(n))
     for i in range(n):
         w, f = full[i]
@@ -90,25 +91,29 @@ def check_list_exchange(grp, ds):
         assert np.array_equal(slab.got[i][0], w[sel]) and np.array_equal(slab.got[i][1], f[sel]), i
         assert slab.got[i][2] == int(f.sum())
     assert pairs == sum(len(v[0]) for v in slab.got.values())
-    return pairs
+    return pairs, bounds
 
 
 def main():
     out_path = sys.argv[1]
-    grp = dist.Group().init("gloo")
+    grp = dist.Group().init()       # PSK_DIST_TRANSPORT names the gloo transport of tests/
+    assert grp.backend == "gloo"
     ds = load_dataset("ds_omitB")
     k = ds["meta"]["k"]
-    lo, hi = dist.slab_bounds(k, grp.world, grp.rank)
+    pairs, bounds = check_list_exchange(grp, ds)
+    lo, hi = bounds[grp.rank], bounds[grp.rank + 1]
     m_local, _, _ = slab_result(ds, lo, hi, None)
+    shares = grp.allgather_i64(np.array([m_local]))[:, 0]
     m_global = grp.allreduce_sum(int(m_local))
     _, res, bits = slab_result(ds, lo, hi, m_global)
     merged, mbits = dist.merge_candidates(grp.allgather_bytes(dist.pack_candidates(res, bits)))
-    pairs = grp.allreduce_sum(int(check_list_exchange(grp, ds)))
+    pairs = grp.allreduce_sum(int(pairs))
     tmax = grp.allreduce_max(float(grp.rank + 1))
     grp.barrier()
     if grp.rank == 0:
         np.savez(out_path, m_global=m_global, word=merged["word"], stat=merged["stat"], p=merged["p"],
-                 n_with=merged["n_with"], bits=mbits, tmax=tmax, world=grp.world, pairs=pairs)
+                 n_with=merged["n_with"], bits=mbits, tmax=tmax, world=grp.world, pairs=pairs, shares=shares,
+                 bounds=np.array(bounds, dtype=np.uint64))
     grp.close()
 
 

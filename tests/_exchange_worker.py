@@ -1,22 +1,30 @@
-"""Worker for test_device_survivor_exchange_matches_get_results (fresh process, torch first)."""
+"""Worker for test_device_survivor_exchange_matches_get_results (fresh process): the RCCL transport of
+phenotypeseeker_amd.dist on a one-rank communicator -- unique id through the rendezvous file, ncclCommInitRank,
+all-reduce, all-gather (host and device buffers), all-to-all."""
 import os
 import sys
+import tempfile
 
 import numpy as np
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
-os.environ["PSK_WITH_TORCH"] = "1"
-os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-os.environ["MASTER_PORT"] = "29641"
-import torch  # noqa: E402,F401  (before libpsk.so)
+os.environ["PSK_RDZV_FILE"] = os.path.join(tempfile.mkdtemp(prefix="psk_rdzv_"), "id")
+os.environ.pop("PSK_DIST_TRANSPORT", None)
 
 from phenotypeseeker_amd import dist  # noqa: E402
 from phenotypeseeker_amd.engine import PskContext  # noqa: E402
 
+assert "torch" not in sys.modules
 g = dist.Group()
 g.world, g.rank, g.local_rank = 1, 0, 0
-g.init("nccl", force=True)
+g.init(force=True)
+assert g.backend == "rccl" and not os.path.exists(os.environ["PSK_RDZV_FILE"])
+assert g.allreduce_sum(41) == 41 and g.allreduce_sum(0.5) == 0.5 and g.allreduce_max(3.0) == 3.0
+assert g.allreduce_sum((1 << 63) + 5) == (1 << 63) + 5          # u64, not i64
+assert g.allgather_bytes(b"slab") == [b"slab"] and g.allgather_bytes(b"") == [b""]
+assert g.allgather_i64(np.array([-7, 9])).tolist() == [[-7, 9]]
+g.barrier()
 with PskContext(0) as ctx:
     n, m = 200, 300_000
     ctx.synth_presence(m, n, seed=11)
@@ -26,6 +34,7 @@ with PskContext(0) as ctx:
     ref = ctx.get_results(npass)
     ref_bits = ctx.get_rows(ref["row"])
     x = dist.SurvivorExchange(g, ctx.presence_shape()[1], cap_records=64)   # forces a regrow
+    assert x.t.stream
     res, bits = x.gather(ctx)
     assert x.cap >= npass
     for key in ("word", "stat", "p", "n_with"):
@@ -55,7 +64,7 @@ with PskContext(0) as ctx:
         x.collect(s)
         got = x.finish(s)
         assert np.array_equal(got[0]["word"], want[i % 2]), i
-# the ingest exchange over nccl (one rank: the all-to-all is a device-to-device copy through RCCL): lists counted in
+# the ingest exchange over RCCL (one rank: the all-to-all is a device-to-device copy through ncclSend / ncclRecv): lists counted in
 # one context, moved, installed in another -> the same lists, the same matrix
 from phenotypeseeker_amd.synth import GenomeSet  # noqa: E402
 gs = GenomeSet(5, 40_000, seed=3, gene_len=300)
@@ -71,5 +80,6 @@ with PskContext(0) as cnt, PskContext(0) as slab:
         assert np.array_equal(a[0], b[0]) and np.array_equal(a[1], b[1]), i
     assert cnt.build_presence() == slab.build_presence()
     assert np.array_equal(cnt.get_union(), slab.get_union())
+assert "torch" not in sys.modules
 g.close()
 print("exchange ok", npass)

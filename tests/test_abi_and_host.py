@@ -48,6 +48,25 @@ def test_product_never_imports_the_oracle():
                 assert "oracle" not in src.replace("oracle/gen_golden.py", ""), os.path.join(dirpath, fn)
 
 
+def test_product_never_imports_torch():
+    """north_star: Python host code over a ctypes C ABI, no PyTorch -- the collectives are RCCL calls made by
+    libpsk.so (csrc/comm.hip); torch appears only in tests/ (the gloo transport) and as the driver's launcher."""
+    import subprocess
+    import sys
+    pkg = os.path.join(ROOT, "phenotypeseeker_amd")
+    for dirpath, _, files in os.walk(pkg):
+        for fn in files:
+            if fn.endswith(".py"):
+                with open(os.path.join(dirpath, fn)) as f:
+                    src = f.read()
+                assert not re.search(r"^\s*(import|from)\s+torch\b", src, flags=re.M), os.path.join(dirpath, fn)
+    with open(os.path.join(ROOT, "bench.py")) as f:
+        assert not re.search(r"^\s*(import|from)\s+torch\b", f.read(), flags=re.M)
+    code = ("import sys; sys.path.insert(0, %r); import phenotypeseeker_amd.dist, phenotypeseeker_amd.modeling, "
+            "phenotypeseeker_amd.prediction, phenotypeseeker_amd.cli; assert 'torch' not in sys.modules" % ROOT)
+    assert subprocess.run([sys.executable, "-c", code], timeout=120).returncode == 0
+
+
 def _roll_clean(clean, k):
     """what the extract kernel computes from the clean stream, in plain Python"""
     mask = (1 << (2 * k)) - 1

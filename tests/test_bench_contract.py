@@ -33,3 +33,31 @@ def test_bench_json_contract():
     assert d["value"] > cb["value"]
     e2e = d["e2e"]  # BASELINE.json's second figure rides along, outside `value`
     assert e2e["modeling_wall_s"] > 0 and "log_reg_model_Pheno.pkl" in e2e["what"]
+
+
+def test_bench_two_ranks_run_the_sharded_pipeline():
+    """N > 1: ONE dataset, the word space cut at pilot quantiles, every rank its slab (both ingest modes), survivors
+    all-gathered; the line carries the rows of every rank, whose sum is the one-rank union.  Two ranks share the one
+    GPU here, so the collectives go through the gloo transport of tests/ (RCCL refuses two ranks per device)."""
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", PSK_DIST_TRANSPORT="_gloo_transport:GlooTransport", OMP_NUM_THREADS="1",
+               PYTHONPATH=os.path.join(ROOT, "tests") + os.pathsep + os.environ.get("PYTHONPATH", ""))
+    size = ["--samples", "24", "--length", "300000", "--kmer", "16", "--steps", "4", "--warmup", "1"]
+    one = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--no-cpu-baseline", "--no-e2e"] + size, cwd=ROOT,
+                         timeout=600, capture_output=True, text=True)
+    assert one.returncode == 0, one.stderr[-2000:]
+    d1 = json.loads(one.stdout.strip().splitlines()[-1])
+    for port, ingest in ((29631, "filter"), (29633, "exchange")):
+        cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+               "--master-port", str(port), os.path.join(ROOT, "bench.py"), "--gpus", "2", "--share-gpu", "--ingest", ingest] + size
+        r = subprocess.run(cmd, env=env, cwd=ROOT, timeout=900, capture_output=True, text=True)
+        assert r.returncode == 0, r.stderr[-3000:]
+        lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
+        assert len(lines) == 1
+        d = json.loads(lines[0])
+        cfg = d["config"]
+        assert d["n_gpus"] == 2 and d["scaling"] == "strong" and cfg["collectives"] == "gloo"
+        assert len(cfg["rows_per_rank"]) == 2 and sum(cfg["rows_per_rank"]) == cfg["rows_global"] == d1["config"]["rows_per_gpu"]
+        assert cfg["balance_max_over_mean"] <= 1.10
+        assert cfg["survivors_all_slabs"] == d1["config"]["survivors"]
+        assert cfg["ingest"]["mode"] == ingest and "range-sharded over 2 GPUs" in cfg["workload"]
+        assert d["value"] > 0 and "cpu_baseline" not in d

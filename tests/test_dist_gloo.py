@@ -22,6 +22,58 @@ def test_slab_bounds_tile_the_word_space():
             assert all(lo < (1 << 64) and hi < (1 << 64) for lo, hi in edges)
 
 
+def _slab_shares(union_words, bounds):
+    edges = [0] + [int(np.searchsorted(union_words, np.uint64(b))) for b in bounds[1:-1]] + [len(union_words)]
+    return np.diff(edges).astype(float)
+
+
+def test_balanced_bounds_on_uniform_and_at_rich_genomes(oracle):
+    """uniform cuts of the word space are 1.87x imbalanced at 8 ranks (canonical words have
+    density ~2(1-u)); the quantile cuts of a four-list pilot must hold max/mean <= 1.10 for W in {2, 4, 8}, on uniform
+    ACGT and on a 29 %-GC set (the reference's example organism), and so must the closed form on uniform sequence."""
+    from phenotypeseeker_amd import dist
+    from phenotypeseeker_amd.synth import GenomeSet
+    for gc, k in ((0.5, 13), (0.29, 13), (0.29, 16)):
+        gs = GenomeSet(6, 300_000, seed=5, gene_len=500, gc=gc, contigs=3)
+        lists = [oracle.count_kmers(gs.sample(i)[1], k)[0] for i in range(6)]
+        uw = oracle.union(lists)
+        for world in (2, 4, 8):
+            uni = _slab_shares(uw, [dist.slab_bounds(k, world, r)[0] for r in range(world)] + [0])
+            assert uni.max() / uni.mean() > 1.3                                    # what is being fixed
+            pts = np.concatenate([dist.pilot_points(w) for w in lists[:4]])
+            b = dist.quantile_bounds(pts, k, world)
+            assert b[0] == 0 and b[-1] == 0 and all(x < y for x, y in zip(b[:-2], b[1:-1]))
+            sh = _slab_shares(uw, b)
+            assert sh.max() / sh.mean() <= 1.10, (gc, k, world, sh)
+            if gc == 0.5:
+                sh = _slab_shares(uw, dist.canonical_cdf_bounds(k, world))
+                assert sh.max() / sh.mean() <= 1.10, ("closed form", k, world, sh)
+    # degenerate inputs still give legal bounds
+    assert dist.quantile_bounds(np.zeros(0, np.uint64), 2, 4)[1:-1] == sorted(set(dist.quantile_bounds(np.zeros(0, np.uint64), 2, 4)[1:-1]))
+    b = dist.quantile_bounds(np.full(100, 7, np.uint64), 3, 4)
+    assert all(x < y for x, y in zip(b[:-2], b[1:-1])) and b[-2] < 64
+
+
+def test_rendezvous_file_carries_the_unique_id(tmp_path):
+    """The RCCL unique id travels through a file: rank 0 publishes atomically, the others poll."""
+    import threading
+    from phenotypeseeker_amd import dist
+    path = os.path.join(tmp_path, "rdzv")
+    got = {}
+
+    def reader(r):
+        got[r] = dist.exchange_unique_id(r, 3, None, timeout=20, path=path)[0]
+
+    ts = [threading.Thread(target=reader, args=(r,)) for r in (1, 2)]
+    for t in ts:
+        t.start()
+    uid = bytes(range(128))
+    assert dist.exchange_unique_id(0, 3, lambda: uid, path=path)[0] == uid
+    for t in ts:
+        t.join()
+    assert got == {1: uid, 2: uid}
+
+
 def test_pack_merge_round_trip():
     from phenotypeseeker_amd import dist
     rng = np.random.default_rng(0)
@@ -38,13 +90,16 @@ def test_pack_merge_round_trip():
 
 def test_two_rank_gloo_run_equals_single_rank(tmp_path, oracle):
     out = os.path.join(tmp_path, "merged.npz")
-    env = dict(os.environ, MASTER_ADDR="127.0.0.1", OMP_NUM_THREADS="1")
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", OMP_NUM_THREADS="1", PSK_DIST_TRANSPORT="_gloo_transport:GlooTransport",
+               PYTHONPATH=os.path.join(ROOT, "tests") + os.pathsep + os.environ.get("PYTHONPATH", ""))
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr",
            "127.0.0.1", "--master-port", "29617", os.path.join(ROOT, "tests", "_dist_worker.py"), out]
     r = subprocess.run(cmd, env=env, cwd=ROOT, timeout=300, capture_output=True, text=True)
     assert r.returncode == 0, r.stderr[-2000:]
     z = np.load(out)
     assert int(z["world"]) == 2 and float(z["tmax"]) == 2.0
+    shares = z["shares"].astype(float)
+    assert shares.max() / shares.mean() <= 1.10, shares      # quantile cuts: the two slabs hold the same share of the rows
     ds = load_dataset("ds_omitB")
     k, names, n = ds["meta"]["k"], ds["names"], len(ds["names"])
     wl = [oracle.count_kmers(ds["files"][nm], k)[0] for nm in names]

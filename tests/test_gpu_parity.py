@@ -550,9 +550,9 @@ def test_l2_grid_search_matches_sklearn_cv(ctx):
 
 
 def test_device_survivor_exchange_matches_get_results():
-    """The multi-GPU hand-off (psk_export_survivors + RCCL all_gather_into_tensor) as a one-rank nccl
-    group, in a fresh process (torch's bundled HIP runtime must be loaded before libpsk.so, see
-    phenotypeseeker_amd/_lib.py): the gathered records equal psk_get_results / psk_get_rows."""
+    """The multi-GPU hand-off (psk_export_survivors_async + ncclAllGather on libpsk.so's own communicator, then
+    the list all-to-all through ncclSend / ncclRecv) as a one-rank RCCL group in a fresh process -- no torch in
+    it: the gathered records equal psk_get_results / psk_get_rows."""
     import subprocess
     import sys
     from helpers import ROOT
@@ -603,6 +603,29 @@ def test_tiled_presence_build_with_thousands_of_samples(ctx, oracle, k, n, lengt
     rows = ctx.get_rows(np.arange(m, dtype=np.uint64))
     assert np.array_equal(rows, oracle.presence_bits(lists, uw, wpr=wpr))
     monkeypatch.setenv("PSK_NO_TILED_PRESENCE", "1")       # the same lists through the sort route
+    assert ctx.build_presence() == m
+    assert np.array_equal(ctx.get_union(), uw) and np.array_equal(ctx.get_rows(np.arange(m, dtype=np.uint64)), rows)
+
+
+@pytest.mark.parametrize("k,n,length,chunk", [(16, 40, 30_000, 100_000), (31, 300, 900, 20_000), (13, 12, 60_000, 50_000)])
+def test_sort_route_in_word_range_chunks(ctx, oracle, k, n, length, chunk, monkeypatch):
+    """More (word, sample) pairs than one sort holds (2^32 per GPU; config 3 on two GPUs has 4.8 x 10^9 per rank): the
+    slab's word range is cut at list quantiles into chunks that are sorted on their own (PSK_PAIR_CHUNK shrinks the
+    chunk so that a small set takes a dozen of them).  Union and rows equal the one-chunk build and the oracle."""
+    from phenotypeseeker_amd.synth import GenomeSet
+    gs = GenomeSet(n, length, seed=k + n, gene_len=200, sub_rate=0.01)
+    datas = [gs.sample(i)[1] for i in range(n)]
+    datas[3] = b""
+    ctx.begin(k, n)
+    ctx.count_kmers_batch(0, datas, 4)
+    monkeypatch.setenv("PSK_NO_TILED_PRESENCE", "1")
+    m = ctx.build_presence()
+    uw, rows = ctx.get_union(), ctx.get_rows(np.arange(m, dtype=np.uint64))
+    lists = [oracle.count_kmers(d, k)[0] for d in datas]
+    assert np.array_equal(uw, oracle.union(lists))
+    assert np.array_equal(rows, oracle.presence_bits(lists, uw, wpr=ctx.presence_shape()[1]))
+    monkeypatch.setenv("PSK_PAIR_CHUNK", str(chunk))
+    assert sum(len(w) for w in lists) > 4 * chunk
     assert ctx.build_presence() == m
     assert np.array_equal(ctx.get_union(), uw) and np.array_equal(ctx.get_rows(np.arange(m, dtype=np.uint64)), rows)
 
