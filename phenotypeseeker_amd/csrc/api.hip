@@ -124,7 +124,8 @@ extern "C" void psk_free(psk_ctx *ctx)
     for (DevBuf *b : bufs) dev_release(*b);
     if (ctx->copy_stream) (void)hipStreamSynchronize(ctx->copy_stream);
     for (CountLane &L : ctx->lane) {
-        DevBuf *lb[] = {&L.raw, &L.keysA, &L.keysB, &L.starts, &L.cnt, &L.sk_cand, &L.sk_out};
+        DevBuf *lb[] = {&L.raw, &L.keysA, &L.keysB, &L.starts, &L.cnt, &L.sk_cand, &L.sk_out,
+                        &L.dc_part, &L.dc_wgoff, &L.dc_cnt, &L.dc_meta, &L.dc_mtemp};
         for (DevBuf *b : lb) dev_release(*b);
         if (L.pinned_cnt) (void)hipHostFree(L.pinned_cnt);
         if (L.sk_host) (void)hipHostFree(L.sk_host);
@@ -184,6 +185,7 @@ extern "C" int psk_begin(psk_ctx *ctx, int k, int n_samples, uint64_t slab_lo, u
     ctx->n_samples = n_samples;
     ctx->slab_lo = slab_lo;
     ctx->slab_hi = slab_hi;
+    dense_configure(ctx);
     ctx->n_kmers = 0;
     ctx->have_presence = false;
     ctx->last = ScanParams();

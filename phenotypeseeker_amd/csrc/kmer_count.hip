@@ -581,18 +581,31 @@ static int chain_enqueue(psk_ctx *ctx, CountLane &L, int sample_idx, const uint8
     L.n = n;
     L.exact = ctx->slab_lo == 0 && ctx->slab_hi == 0;  // no slab filter: every window yields a word
     L.uniq = nullptr;
-    if (n == 0) return PSK_OK;
+    L.dense = false;
+    if (n == 0) {
+        if (ctx->dense_mode) {   // an empty sample still owns a (zero) bitmap: the presence build reads every sample's
+            SampleList &S = ctx->lists[sample_idx];
+            const size_t bytes = (size_t)ctx->dense_nb * DC_BUCKET_WORDS * 8;
+            PSK_TRY(arena_alloc(ctx, bytes, (void **)&S.bitmap));
+            PSK_HIP(ctx, hipMemsetAsync(S.bitmap, 0, bytes, ctx->stream));
+            S.dense = true;
+        }
+        return PSK_OK;
+    }
     PSK_TRY(lane_prepare(ctx, L));
     PSK_TRY(dev_reserve(ctx, L.raw, padded));
-    PSK_TRY(dev_reserve(ctx, L.keysA, n * 8));
-    PSK_TRY(dev_reserve(ctx, L.keysB, n * 8));
-    PSK_TRY(dev_reserve(ctx, L.starts, (size_t)div_up(n, RLE_TILE) * 8));  // tile offsets | next-head positions
-    PSK_TRY(dev_reserve(ctx, L.cnt, (size_t)CountLane::CNT_SLOTS * 16));
+    if (!ctx->dense_mode) {
+        PSK_TRY(dev_reserve(ctx, L.keysA, n * 8));
+        PSK_TRY(dev_reserve(ctx, L.keysB, n * 8));
+        PSK_TRY(dev_reserve(ctx, L.starts, (size_t)div_up(n, RLE_TILE) * 8));  // tile offsets | next-head positions
+        PSK_TRY(dev_reserve(ctx, L.cnt, (size_t)CountLane::CNT_SLOTS * 16));
+    }
     // upload on the copy stream, after the extract of the sample that used this raw buffer before
     if (L.raw_used) PSK_HIP(ctx, hipStreamWaitEvent(ctx->copy_stream, L.raw_free, 0));
     PSK_HIP(ctx, hipMemcpyAsync(L.raw.p, stage, padded, hipMemcpyHostToDevice, ctx->copy_stream));
     PSK_HIP(ctx, hipEventRecord(L.raw_ready, ctx->copy_stream));
     PSK_HIP(ctx, hipStreamWaitEvent(ctx->stream, L.raw_ready, 0));
+    if (ctx->dense_mode) return dense_chain_enqueue(ctx, L, sample_idx, clean_len, n);   // 2k <= 26: no sort (dense_count.hip)
     // every sample takes a fresh pre-zeroed counter slot (a 16-byte memset per sample is a 6 us launch)
     if (L.cnt_slot == 0 || L.cnt_slot >= CountLane::CNT_SLOTS) {
         PSK_HIP(ctx, hipMemsetAsync(L.cnt.p, 0, (size_t)CountLane::CNT_SLOTS * 16, ctx->stream));
@@ -636,6 +649,16 @@ static int chain_finalize(psk_ctx *ctx, CountLane &L)
                             (unsigned long long)n_gpu, (unsigned long long)L.n);
         n_kept = n_gpu;
         nu = L.pinned_cnt[1];
+        if (L.dense) {
+            L.sample = sample;
+            const int rc = dense_chain_finalize(ctx, L, &n_kept, &nu);
+            L.sample = -1;
+            if (rc != PSK_OK) return rc;
+            S.n_unique = nu;
+            S.n_total = n_kept;
+            S.done = true;
+            return PSK_OK;
+        }
         PSK_TRY(arena_alloc(ctx, nu * 8, (void **)&S.words));
         PSK_TRY(arena_alloc(ctx, nu * 4, (void **)&S.freqs));
         const uint32_t n_tiles = (uint32_t)div_up(L.n, RLE_TILE);  // the layout of the tile arrays follows L.n
@@ -674,9 +697,18 @@ extern "C" int psk_count_kmers(psk_ctx *ctx, int sample_idx, const uint8_t *byte
     PSK_HIP(ctx, hipSetDevice(ctx->device));
     PSK_TRY(ensure_pinned(ctx, &ctx->pinned, &ctx->pinned_cap, len + 2 * EX_SEG));
     uint64_t clean_len = 0, padded = 0;
-    int rc = frame_into(static_cast<uint8_t *>(ctx->pinned), ctx->pinned_cap, bytes, len, &clean_len, &padded);
+    uint64_t wins = 0;
+    int rc = frame_into(static_cast<uint8_t *>(ctx->pinned), ctx->pinned_cap, bytes, len, &clean_len, &padded, ctx->k, &wins);
     if (rc) return psk_fail(ctx, rc, "framing failed");
-    PSK_TRY(count_from_stage(ctx, sample_idx, static_cast<uint8_t *>(ctx->pinned), clean_len, padded));
+    if (ctx->dense_mode) {   // the one-sample form of the pipelined chain
+        if (wins >= (1ull << 32)) return psk_fail(ctx, PSK_ERANGE, "sample with more than 2^32 windows");
+        for (CountLane &L : ctx->lane) { L.sample = -1; L.sk_state = 0; }
+        PSK_TRY(chain_enqueue(ctx, ctx->lane[0], sample_idx, static_cast<uint8_t *>(ctx->pinned), clean_len, padded, wins));
+        PSK_TRY(chain_finalize(ctx, ctx->lane[0]));
+        if (ctx->copy_stream) PSK_HIP(ctx, hipStreamSynchronize(ctx->copy_stream));
+        PSK_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    } else
+        PSK_TRY(count_from_stage(ctx, sample_idx, static_cast<uint8_t *>(ctx->pinned), clean_len, padded));
     if (n_unique) *n_unique = ctx->lists[sample_idx].n_unique;
     if (n_total) *n_total = ctx->lists[sample_idx].n_total;
     return PSK_OK;
@@ -898,10 +930,11 @@ extern "C" int psk_get_list(psk_ctx *ctx, int sample_idx, uint64_t *words, uint3
     if (!ctx) return PSK_EINVAL;
     if (sample_idx < 0 || sample_idx >= ctx->n_samples || !ctx->lists[sample_idx].done)
         return psk_fail(ctx, PSK_ESTATE, "sample %d has not been counted", sample_idx);
+    PSK_HIP(ctx, hipSetDevice(ctx->device));
+    PSK_TRY(dense_materialize(ctx, sample_idx, 1));
     const SampleList &L = ctx->lists[sample_idx];
     if (cap < L.n_unique) return psk_fail(ctx, PSK_ERANGE, "buffer too small: %llu < %llu", (unsigned long long)cap,
                                           (unsigned long long)L.n_unique);
-    PSK_HIP(ctx, hipSetDevice(ctx->device));
     if (L.n_unique) {
         if (words) PSK_HIP(ctx, hipMemcpy(words, L.words, L.n_unique * 8, hipMemcpyDeviceToHost));
         if (freqs) PSK_HIP(ctx, hipMemcpy(freqs, L.freqs, L.n_unique * 4, hipMemcpyDeviceToHost));
@@ -950,9 +983,13 @@ extern "C" int psk_lists_split(psk_ctx *ctx, int first_sample_idx, int n, const 
     if (n == 0 || n_bounds == 0) return PSK_OK;
     if (!bounds || !offsets_out || n_bounds < 0) return psk_fail(ctx, PSK_EINVAL, "null buffer");
     std::vector<SplitRef> refs(n);
+    for (int i = 0; i < n; i++)
+        if (!ctx->lists[first_sample_idx + i].done)
+            return psk_fail(ctx, PSK_ESTATE, "sample %d has not been counted", first_sample_idx + i);
+    PSK_HIP(ctx, hipSetDevice(ctx->device));
+    PSK_TRY(dense_materialize(ctx, first_sample_idx, n));
     for (int i = 0; i < n; i++) {
         const SampleList &L = ctx->lists[first_sample_idx + i];
-        if (!L.done) return psk_fail(ctx, PSK_ESTATE, "sample %d has not been counted", first_sample_idx + i);
         refs[i].words = L.words;
         refs[i].n = L.n_unique;
     }
@@ -980,10 +1017,12 @@ extern "C" int psk_copy_list_ranges(psk_ctx *ctx, int n_ranges, const int32_t *s
     if (n_ranges == 0) return PSK_OK;
     if (!sample_idx || !start || !count) return psk_fail(ctx, PSK_EINVAL, "null buffer");
     uint64_t total = 0;
+    PSK_HIP(ctx, hipSetDevice(ctx->device));
     for (int r = 0; r < n_ranges; r++) {
         const int si = sample_idx[r];
         if (si < 0 || si >= ctx->n_samples || !ctx->lists[si].done)
             return psk_fail(ctx, PSK_ESTATE, "sample %d has not been counted", si);
+        PSK_TRY(dense_materialize(ctx, si, 1));
         const SampleList &L = ctx->lists[si];
         if (start[r] > L.n_unique || count[r] > L.n_unique - start[r])
             return psk_fail(ctx, PSK_ERANGE, "range %d lies outside the list of sample %d", r, si);
@@ -1068,8 +1107,11 @@ extern "C" int psk_lookup_counts(psk_ctx *ctx, int sample_idx, const uint64_t *w
     PSK_TRY(dev_reserve(ctx, ctx->flags, n * 8));
     PSK_TRY(dev_reserve(ctx, ctx->starts, n * 4));
     PSK_HIP(ctx, hipMemcpyAsync(ctx->flags.p, words, n * 8, hipMemcpyHostToDevice, ctx->stream));
-    lookup_counts_kernel<<<div_up(n, 256), 256, 0, ctx->stream>>>(L.words, L.freqs, L.n_unique, ctx->flags.as<uint64_t>(),
-                                                                  n, ctx->starts.as<uint32_t>());
+    if (L.dense && !L.words)
+        PSK_TRY(dense_lookup_counts(ctx, L, ctx->flags.as<uint64_t>(), n, ctx->starts.as<uint32_t>()));
+    else
+        lookup_counts_kernel<<<div_up(n, 256), 256, 0, ctx->stream>>>(L.words, L.freqs, L.n_unique, ctx->flags.as<uint64_t>(),
+                                                                      n, ctx->starts.as<uint32_t>());
     PSK_HIP(ctx, hipGetLastError());
     PSK_HIP(ctx, hipMemcpyAsync(freqs, ctx->starts.p, n * 4, hipMemcpyDeviceToHost, ctx->stream));
     PSK_HIP(ctx, hipStreamSynchronize(ctx->stream));

@@ -213,6 +213,21 @@ extern "C" int psk_build_presence(psk_ctx *ctx, uint64_t *n_kmers)
         return PSK_OK;
     }
     PhaseTimer pt(ctx->stream);
+    {   // dense list form (2k <= 26): the bitmaps are transposed into the matrix (presence_dense.hip)
+        uint64_t M = 0;
+        int done = 0;
+        PSK_TRY(build_presence_dense(ctx, &M, &done));
+        if (done) {
+            pt.mark("dense build");
+            ctx->n_kmers = M;
+            ctx->have_presence = true;
+            ctx->dense_hint = -1;
+            ctx->last.valid = false;
+            if (n_kmers) *n_kmers = M;
+            return PSK_OK;
+        }
+        PSK_TRY(dense_materialize(ctx, 0, ctx->n_samples));   // the list routes below read words[]
+    }
     {   // small word spaces: the sort-free tiled build (presence_tiled.hip)
         uint64_t M = 0;
         int done = 0;

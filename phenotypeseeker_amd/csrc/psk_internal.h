@@ -29,12 +29,22 @@ struct Arena {
     static constexpr size_t CHUNK = 1ull << 30;
 };
 
+// A sample's list in one of two forms.  Sparse: words[] + freqs[] (every k).  Dense (2k <= 26, dense_count.hip):
+// a bitmap over the slab's buckets of the word space (bit v of the bitmap = word dense_b0 * 2^15 + v occurs) plus the
+// sorted words with a count of two or more -- 8 MB + a few MB per 5-Mbp sample at k = 13 instead of 56 MB, and what
+// the presence build transposes directly; words[] / freqs[] are materialised from it only when a caller asks for
+// them (psk_get_list, the list exchange).
 struct SampleList {
     uint64_t *words = nullptr;  // device, ascending canonical words (this slab)
     uint32_t *freqs = nullptr;  // device
     uint64_t n_unique = 0;
     uint64_t n_total = 0;
     bool done = false;
+    bool dense = false;
+    uint64_t *bitmap = nullptr;   // device, dense_nb * 512 u64
+    uint32_t *mwords = nullptr;   // device, ascending words (absolute, < 2^26) with count >= 2
+    uint32_t *mfreqs = nullptr;   // device, their counts
+    uint64_t n_multi = 0;
 };
 
 // One of the two buffer sets of the pipelined batch counter (psk_count_kmers_batch): the chain of sample i
@@ -56,6 +66,11 @@ struct CountLane {
     size_t sk_host_cap = 0;
     hipEvent_t sk_done = nullptr, sk_filtered = nullptr;
     int sk_state = 0;                // 0 none, 1 queued, 2 the synchronous route has to serve this sample
+    // dense counting (dense_count.hip): bucketed keys, per-(tile, bucket) offsets, counter-slot ring, per-bucket
+    // results of the sample in flight, multi-count entries before compaction
+    DevBuf dc_part, dc_wgoff, dc_cnt, dc_meta, dc_mtemp;
+    uint32_t dc_slot = 0;
+    bool dense = false;              // the chain in flight on this set is a dense one
 };
 
 struct ScanParams {  // what psk_rescan_timed needs to re-launch the last chi2 scan
@@ -102,6 +117,9 @@ struct psk_ctx {
     uint64_t slab_lo = 0, slab_hi = 0;  // slab_hi == 0: unbounded
     std::vector<SampleList> lists;
     Arena arena;
+    // dense list form (see SampleList): on for this run?  first bucket and number of buckets of the slab
+    bool dense_mode = false;
+    uint32_t dense_b0 = 0, dense_nb = 0;
 
     // scratch for per-sample counting
     DevBuf raw, keysA, keysB, valsA, valsB, hist, scan_tmp, flags, starts, misc;
@@ -178,3 +196,17 @@ int64_t frame_sequence_host(const uint8_t *bytes, size_t len, uint8_t *out, size
 // clean stream (device) -> canonical words inside [lo, hi) appended to out; *n_out (device u32) counts them
 int launch_extract(psk_ctx *ctx, const uint8_t *clean, uint64_t len, int k, uint64_t lo, uint64_t hi, uint64_t *out,
                    uint32_t *n_out);
+
+// ---- dense list form (dense_count.hip, presence_dense.hip) ---------------------------------------------------
+constexpr int DC_VB = 15;                  // word values per bucket: 2^15
+constexpr int DC_BUCKET_WORDS = 512;       // u64 bitmap words per bucket
+constexpr uint32_t DC_MAX_NB = 2048;       // 2k <= 26
+void dense_configure(psk_ctx *ctx);        // psk_begin: decides dense_mode / dense_b0 / dense_nb for the run
+// the dense counting chain of one sample on buffer set L (clean stream already queued for upload into L.raw);
+// n = its window count.  dense_chain_finalize (one sample later) places the multi-count entries in the arena.
+int dense_chain_enqueue(psk_ctx *ctx, CountLane &L, int sample_idx, uint64_t clean_len, uint64_t n);
+int dense_chain_finalize(psk_ctx *ctx, CountLane &L, uint64_t *n_kept, uint64_t *n_unique);
+// words[] / freqs[] of samples [first, first + n) from their dense form (no-op for sparse or materialised ones)
+int dense_materialize(psk_ctx *ctx, int first, int n);
+int dense_lookup_counts(psk_ctx *ctx, const SampleList &L, const uint64_t *d_query, uint64_t n, uint32_t *d_out);
+int build_presence_dense(psk_ctx *ctx, uint64_t *n_kmers, int *done);
