@@ -28,60 +28,78 @@ constexpr size_t DC_DENSE_BYTES_MAX = 64ull << 30;
 constexpr size_t DP_LDS_BYTES = (size_t)(DT_TILE + DC_MAX_NB + DC_MAX_NB / 2 + 16) * 4;   // 76 KB: two workgroups per CU
 constexpr size_t DCNT_LDS_BYTES = (size_t)(DC_VALS / 2 + 16) * 4;                         // 64 KB + scan scratch
 
-struct Roll32 {
-    uint32_t fw, rc;
-    int run;
+// ---- the 32 window ends of a thread, without a byte-by-byte roll ------------------------------------------------
+// A thread owns 32 consecutive bytes of the clean stream and reads the 16 before them (K - 1 <= 12).  The 48 bytes
+// become three bit streams, four bytes per multiply: F (2 bits per base, earlier bases more significant), R (the
+// complemented codes, later bases more significant) and B (1 bit per byte: not a base, i.e. a window break).  The
+// forward word of the window that ends at byte p is then one funnel shift of F, its reverse complement one funnel
+// shift of R, and "no break inside" one funnel shift of B -- with K a template parameter every shift amount is a
+// literal.  (Byte-by-byte rolling cost ~30 VALU instructions per window end: 13 us of the 17 us of the first cut's
+// histogram kernel, tools/dc_attrib.sh.)
+struct Streams {
+    uint32_t F[3], R[4], B[2];
 };
 
-__device__ __forceinline__ void roll32(Roll32 &r, uint32_t c, uint32_t mask, int rcshift, int k)
+__device__ __forceinline__ void pack4(uint32_t w, uint32_t &yf, uint32_t &yr, uint32_t &yb)
 {
-    if (c == '\n') {
-        r.run = 0;
-    } else {
-        const uint32_t code = ((c >> 1) ^ (c >> 2)) & 3u;  // A/a 0, C/c 1, G/g 2, T/t/U/u 3
-        r.fw = ((r.fw << 2) | code) & mask;
-        r.rc = (r.rc >> 2) | ((3u - code) << rcshift);
-        r.run = (r.run < k) ? r.run + 1 : k;
-    }
+    const uint32_t x = ((w >> 1) ^ (w >> 2)) & 0x03030303u;   // A/a 0, C/c 1, G/g 2, T/t/U/u 3, one code per byte
+    yf = (x * 0x40100401u) >> 24;                             // b0 << 6 | b1 << 4 | b2 << 2 | b3
+    yr = ((x ^ 0x03030303u) * 0x01041040u) >> 24;             // ~b0 | ~b1 << 2 | ~b2 << 4 | ~b3 << 6
+    yb = (((~w >> 6) & 0x01010101u) * 0x01020408u) >> 24;     // bit i: byte i has bit 6 clear (only '\n' in a clean stream)
 }
 
-// The thread's DT_SEG bytes at s and the 32 before them (what lies before the buffer counts as a break).
-struct Seg {
-    uint32_t cur[DT_SEG / 4], prev[8];
-};
-
-__device__ __forceinline__ void load_seg(Seg &g, const uint8_t *__restrict__ clean, uint64_t len, uint64_t s)
+__device__ __forceinline__ void load_streams(Streams &st, const uint8_t *__restrict__ clean, uint64_t len, uint64_t s)
 {
+    uint32_t raw[12];
 #pragma unroll
-    for (int j = 0; j < DT_SEG / 4; j++) g.cur[j] = 0x0a0a0a0au;
-#pragma unroll
-    for (int j = 0; j < 8; j++) g.prev[j] = 0x0a0a0a0au;
+    for (int j = 0; j < 12; j++) raw[j] = 0x0a0a0a0au;   // beyond either end of the buffer: breaks
     if (s < len) {
         const uint4 *p = reinterpret_cast<const uint4 *>(clean + s);
-#pragma unroll
-        for (int q = 0; q < DT_SEG / 16; q++) {
-            const uint4 a = p[q];
-            g.cur[4 * q] = a.x; g.cur[4 * q + 1] = a.y; g.cur[4 * q + 2] = a.z; g.cur[4 * q + 3] = a.w;
+        const uint4 a = p[0], b = p[1];
+        raw[4] = a.x; raw[5] = a.y; raw[6] = a.z; raw[7] = a.w;
+        raw[8] = b.x; raw[9] = b.y; raw[10] = b.z; raw[11] = b.w;
+        if (s >= 16) {
+            const uint4 h = *reinterpret_cast<const uint4 *>(clean + s - 16);
+            raw[0] = h.x; raw[1] = h.y; raw[2] = h.z; raw[3] = h.w;
         }
+    }
+    st.B[0] = st.B[1] = 0;
+    st.R[3] = 0;
 #pragma unroll
-        for (int q = 0; q < 2; q++) {
-            const uint64_t back = (uint64_t)(2 - q) * 16;
-            if (s >= back) {
-                const uint4 c = *reinterpret_cast<const uint4 *>(clean + s - back);
-                g.prev[4 * q] = c.x; g.prev[4 * q + 1] = c.y; g.prev[4 * q + 2] = c.z; g.prev[4 * q + 3] = c.w;
-            }
+    for (int q = 0; q < 3; q++) {   // 16 bytes = one dword of F and of R
+        uint32_t f = 0, r = 0;
+#pragma unroll
+        for (int e = 0; e < 4; e++) {
+            uint32_t yf, yr, yb;
+            pack4(raw[4 * q + e], yf, yr, yb);
+            f |= yf << (8 * (3 - e));
+            r |= yr << (8 * e);
+            const int bit = 16 * q + 4 * e;   // byte position of the group's first byte
+            st.B[bit >> 5] |= (yb & 0xfu) << (bit & 31);
         }
+        st.F[2 - q] = f;   // position p sits at bits 2 * (47 - p) of F ...
+        st.R[q] = r;       // ... and at bits 2 * p of R
     }
 }
 
-__device__ __forceinline__ Roll32 warm_up(const Seg &g, uint32_t mask, int rcshift, int k)
+__device__ __forceinline__ uint32_t funnel(uint32_t hi, uint32_t lo, int sh)   // (hi:lo) >> sh, sh in 0..31, low dword
 {
-    Roll32 r{0, 0, 0};
-#pragma unroll
-    for (int j = 0; j < 32; j++) {
-        if (j >= 32 - (k - 1)) roll32(r, (g.prev[j >> 2] >> ((j & 3) * 8)) & 0xffu, mask, rcshift, k);
-    }
-    return r;
+    return sh == 0 ? lo : __builtin_amdgcn_alignbit(hi, lo, (uint32_t)sh);
+}
+
+// canonical word of the window that ends at byte 16 + J of the thread's 48; false when a break lies inside it
+template <int K, int J>
+__device__ __forceinline__ bool window(const Streams &st, uint32_t &w)
+{
+    constexpr uint32_t mask = (1u << (2 * K)) - 1u;
+    constexpr int sf = 2 * (31 - J);            // bit offset of the window in F
+    constexpr int sr = 2 * (17 + J - K);        // ... in R
+    constexpr int sb = 17 + J - K;              // ... in B
+    const uint32_t fw = funnel(sf / 32 + 1 < 3 ? st.F[sf / 32 + 1] : 0u, st.F[sf / 32], sf & 31) & mask;
+    const uint32_t rc = funnel(st.R[sr / 32 + 1], st.R[sr / 32], sr & 31) & mask;
+    const uint32_t bm = (sb < 32 ? funnel(st.B[1], st.B[0], sb) : (st.B[1] >> (sb - 32))) & ((1u << K) - 1u);
+    w = fw < rc ? fw : rc;
+    return bm == 0;
 }
 
 // exclusive scan over a workgroup of DT_THREADS threads, one value per thread
@@ -90,7 +108,25 @@ __device__ __forceinline__ uint32_t block_scan512(uint32_t v, uint32_t *total, u
     return psk_block_excl_scan_u32<DT_THREADS>(v, total, lds);
 }
 
-__global__ __launch_bounds__(DT_THREADS) void dc_hist_kernel(const uint8_t *__restrict__ clean, uint64_t len, int k, uint32_t lo,
+template <int K, int J>
+struct ForEachWindow {
+    template <class F>
+    static __device__ __forceinline__ void run(const Streams &st, uint32_t lo, uint32_t hi, F &&f)
+    {
+        uint32_t w;
+        const bool ok = window<K, J>(st, w) && w >= lo && w < hi;
+        f(J, ok, w);
+        ForEachWindow<K, J + 1>::run(st, lo, hi, f);
+    }
+};
+template <int K>
+struct ForEachWindow<K, DT_SEG> {
+    template <class F>
+    static __device__ __forceinline__ void run(const Streams &, uint32_t, uint32_t, F &&) {}
+};
+
+template <int K>
+__global__ __launch_bounds__(DT_THREADS) void dc_hist_kernel(const uint8_t *__restrict__ clean, uint64_t len, uint32_t lo,
                                                               uint32_t hi, uint32_t b0, uint32_t nb, uint32_t *__restrict__ cnt,
                                                               uint32_t *__restrict__ wgoff)
 {
@@ -98,25 +134,29 @@ __global__ __launch_bounds__(DT_THREADS) void dc_hist_kernel(const uint8_t *__re
     for (uint32_t d = threadIdx.x; d < nb; d += DT_THREADS) h[d] = 0;
     __syncthreads();
     const uint64_t s = ((uint64_t)blockIdx.x * DT_THREADS + threadIdx.x) * DT_SEG;
-    const uint32_t mask = (1u << (2 * k)) - 1u;
-    const int rcshift = 2 * (k - 1);
-    Seg g;
-    load_seg(g, clean, len, s);
-    Roll32 r = warm_up(g, mask, rcshift, k);
-#pragma unroll
-    for (int j = 0; j < DT_SEG; j++) {
-        roll32(r, (g.cur[j >> 2] >> ((j & 3) * 8)) & 0xffu, mask, rcshift, k);
-        const uint32_t w = r.fw < r.rc ? r.fw : r.rc;
-        if (s + j < len && r.run >= k && w >= lo && w < hi) atomicAdd(&h[(w >> DC_VB) - b0], 1u);
-    }
+    Streams st;
+    load_streams(st, clean, len, s);
+    ForEachWindow<K, 0>::run(st, lo, hi, [&](int, bool ok, uint32_t w) {
+        if (ok) atomicAdd(&h[(w >> DC_VB) - b0], 1u);
+    });
     __syncthreads();
-    for (uint32_t d = threadIdx.x; d < nb; d += DT_THREADS) {
-        const uint32_t c = h[d];
-        if (c) wgoff[(uint64_t)blockIdx.x * nb + d] = atomicAdd(&cnt[d], c);
+    // the (up to four) returning atomics of a thread are issued back to back: one round trip, not four
+    uint32_t c[DC_MAX_NB / DT_THREADS], o[DC_MAX_NB / DT_THREADS];
+#pragma unroll
+    for (int e = 0; e < (int)(DC_MAX_NB / DT_THREADS); e++) {
+        const uint32_t d = e * DT_THREADS + threadIdx.x;
+        c[e] = d < nb ? h[d] : 0u;
     }
+#pragma unroll
+    for (int e = 0; e < (int)(DC_MAX_NB / DT_THREADS); e++)
+        if (c[e]) o[e] = atomicAdd(&cnt[e * DT_THREADS + threadIdx.x], c[e]);
+#pragma unroll
+    for (int e = 0; e < (int)(DC_MAX_NB / DT_THREADS); e++)
+        if (c[e]) wgoff[(uint64_t)blockIdx.x * nb + e * DT_THREADS + threadIdx.x] = o[e];
 }
 
-__global__ __launch_bounds__(DT_THREADS) void dc_partition_kernel(const uint8_t *__restrict__ clean, uint64_t len, int k, uint32_t lo,
+template <int K>
+__global__ __launch_bounds__(DT_THREADS) void dc_partition_kernel(const uint8_t *__restrict__ clean, uint64_t len, uint32_t lo,
                                                                    uint32_t hi, uint32_t b0, uint32_t nb,
                                                                    const uint32_t *__restrict__ cnt,
                                                                    const uint32_t *__restrict__ wgoff,
@@ -130,24 +170,18 @@ __global__ __launch_bounds__(DT_THREADS) void dc_partition_kernel(const uint8_t 
     for (uint32_t d = threadIdx.x; d < nb; d += DT_THREADS) h[d] = 0;
     __syncthreads();
     const uint64_t s = ((uint64_t)blockIdx.x * DT_THREADS + threadIdx.x) * DT_SEG;
-    const uint32_t mask = (1u << (2 * k)) - 1u;
-    const int rcshift = 2 * (k - 1);
-    Seg g;
-    load_seg(g, clean, len, s);
-    Roll32 r = warm_up(g, mask, rcshift, k);
+    Streams st;
+    load_streams(st, clean, len, s);
     uint32_t wv[DT_SEG];   // word relative to the first bucket, or ~0
     uint16_t rk[DT_SEG];   // rank inside (tile, bucket)
-#pragma unroll
-    for (int j = 0; j < DT_SEG; j++) {
-        roll32(r, (g.cur[j >> 2] >> ((j & 3) * 8)) & 0xffu, mask, rcshift, k);
-        const uint32_t w = r.fw < r.rc ? r.fw : r.rc;
+    ForEachWindow<K, 0>::run(st, lo, hi, [&](int j, bool ok, uint32_t w) {
         wv[j] = 0xffffffffu;
         rk[j] = 0;
-        if (s + j < len && r.run >= k && w >= lo && w < hi) {
+        if (ok) {
             wv[j] = w - (b0 << DC_VB);
             rk[j] = (uint16_t)atomicAdd(&h[wv[j] >> DC_VB], 1u);
         }
-    }
+    });
     __syncthreads();
     // thread t owns buckets 4t .. 4t + 3: local starts, global bucket bases, this tile's offset in each bucket
     uint32_t ltot;
@@ -195,12 +229,13 @@ __global__ __launch_bounds__(DT_THREADS) void dc_count_kernel(const uint16_t *__
                                                                const uint32_t *__restrict__ base, uint32_t b0,
                                                                uint64_t *__restrict__ bitmap, uint32_t *__restrict__ mt_w,
                                                                uint32_t *__restrict__ mt_f, uint32_t *__restrict__ uniq_out,
-                                                               uint32_t *__restrict__ multi_out)
+                                                               uint32_t *__restrict__ multi_out, const uint32_t *__restrict__ need)
 {
     extern __shared__ uint32_t dyn_lds[];   // DCNT_LDS_BYTES
     uint32_t *tbl = dyn_lds;                // 64 KB
     uint32_t *scan_lds = tbl + DC_VALS / 2;
     const uint32_t b = blockIdx.x, t = threadIdx.x;
+    if (need && !need[b]) return;   // second pass behind dc_count_sparse_kernel: only the buckets it left
     const uint32_t n = cnt[b];
     const size_t off = base[b];
     const uint32_t word0 = (b0 + b) << DC_VB;
@@ -212,9 +247,16 @@ __global__ __launch_bounds__(DT_THREADS) void dc_count_kernel(const uint16_t *__
 #pragma unroll
         for (int j = 0; j < 32; j++) tbl[j * DT_THREADS + t] = 0;
         __syncthreads();
-        for (uint32_t i = t; i < n; i += DT_THREADS) {
-            const uint32_t v = part[off + i];
-            atomicAdd(&tbl[((v >> 1) & 31u) * DT_THREADS + (v >> 6)], 1u << ((v & 1u) * 16));
+        for (uint32_t i0 = 0; i0 < n; i0 += 8 * DT_THREADS) {   // eight loads in flight per thread
+            uint32_t v[8];
+#pragma unroll
+            for (int e = 0; e < 8; e++) {
+                const uint32_t i = i0 + e * DT_THREADS + t;
+                v[e] = i < n ? (uint32_t)part[off + i] : 0xffffffffu;
+            }
+#pragma unroll
+            for (int e = 0; e < 8; e++)
+                if (v[e] != 0xffffffffu) atomicAdd(&tbl[((v[e] >> 1) & 31u) * DT_THREADS + (v[e] >> 6)], 1u << ((v[e] & 1u) * 16));
         }
         __syncthreads();
         uint32_t w[32], multi = 0;
@@ -283,38 +325,158 @@ __global__ __launch_bounds__(DT_THREADS) void dc_count_kernel(const uint16_t *__
     if (t == 0) { uniq_out[b] = utot; multi_out[b] = multi_total; }
 }
 
-// totals[0] = keys kept, [1] = distinct words, [2] = multi-count entries; moff = exclusive scan of multi
-__global__ __launch_bounds__(1024) void dc_totals_kernel(const uint32_t *__restrict__ cnt, const uint32_t *__restrict__ uniq,
-                                                         const uint32_t *__restrict__ multi, uint32_t nb,
-                                                         uint32_t *__restrict__ moff, uint32_t *__restrict__ totals)
+// The same outputs for a bucket with few keys (a genome: 2,400 keys in 32,768 values, 7 % of them repeats) at a
+// sixteenth of the LDS: instead of a counter per value, a presence bit per value (atomicOr; a key that finds its bit
+// set is a repeat), a second bit set for the values seen twice, and counters only for those -- indexed by the rank of
+// the value among the twice-seen ones, which the repeats increment.  8 workgroups per CU instead of 2, and 4 KB
+// instead of 64 KB to clear and read back per bucket.  A bucket with more than SP_MAXDUP repeats (or SP_MAXKEYS keys)
+// is left to dc_count_kernel: need[b] = 1.
+constexpr int SP_THREADS = 256;
+constexpr uint32_t SP_MAXDUP = 2048, SP_MAXKEYS = 16384;
+
+__global__ __launch_bounds__(SP_THREADS) void dc_count_sparse_kernel(const uint16_t *__restrict__ part, const uint32_t *__restrict__ cnt,
+                                                                      const uint32_t *__restrict__ base, uint32_t b0,
+                                                                      uint64_t *__restrict__ bitmap, uint32_t *__restrict__ mt_w,
+                                                                      uint32_t *__restrict__ mt_f, uint32_t *__restrict__ uniq_out,
+                                                                      uint32_t *__restrict__ multi_out, uint32_t *__restrict__ need)
 {
-    __shared__ uint32_t lds[16];
-    const uint32_t t = threadIdx.x;
-    uint32_t c = 0, u = 0, m[2] = {0, 0};
-#pragma unroll
-    for (int e = 0; e < 2; e++) {
-        const uint32_t d = t * 2 + e;
-        if (d < nb) { c += cnt[d]; u += uniq[d]; m[e] = multi[d]; }
+    __shared__ uint32_t seen[DC_VALS / 32], dup[DC_VALS / 32], rankb[DC_VALS / 32];   // 3 x 4 KB
+    __shared__ uint32_t dcnt[SP_MAXDUP];     // occurrences beyond the first, by rank of the value among the repeated ones
+    __shared__ uint16_t dlist[SP_MAXDUP];    // the repeats themselves
+    __shared__ uint32_t scan_lds[SP_THREADS / 64];
+    __shared__ uint32_t n_dup;
+    const uint32_t b = blockIdx.x, t = threadIdx.x;
+    const uint32_t n = cnt[b];
+    const size_t off = base[b];
+    if (n > SP_MAXKEYS) {
+        if (t == 0) { need[b] = 1; uniq_out[b] = 0; multi_out[b] = 0; }
+        return;
     }
-    uint32_t ctot, utot, mtot;
-    psk_block_excl_scan_u32<1024>(c, &ctot, lds);
-    psk_block_excl_scan_u32<1024>(u, &utot, lds);
-    uint32_t mex = psk_block_excl_scan_u32<1024>(m[0] + m[1], &mtot, lds);
 #pragma unroll
-    for (int e = 0; e < 2; e++) {
-        const uint32_t d = t * 2 + e;
-        if (d < nb) moff[d] = mex;
-        mex += m[e];
+    for (int e = 0; e < 4; e++) { seen[e * SP_THREADS + t] = 0; dup[e * SP_THREADS + t] = 0; }
+#pragma unroll
+    for (int e = 0; e < (int)(SP_MAXDUP / SP_THREADS); e++) dcnt[e * SP_THREADS + t] = 0;
+    if (t == 0) n_dup = 0;
+    __syncthreads();
+    for (uint32_t i0 = 0; i0 < n; i0 += 8 * SP_THREADS) {   // eight loads in flight per thread
+        uint32_t v[8];
+#pragma unroll
+        for (int e = 0; e < 8; e++) {
+            const uint32_t i = i0 + e * SP_THREADS + t;
+            v[e] = i < n ? (uint32_t)part[off + i] : 0xffffffffu;
+        }
+#pragma unroll
+        for (int e = 0; e < 8; e++) {
+            if (v[e] == 0xffffffffu) continue;
+            const uint32_t bit = 1u << (v[e] & 31u);
+            if (atomicOr(&seen[v[e] >> 5], bit) & bit) {
+                atomicOr(&dup[v[e] >> 5], bit);
+                const uint32_t pos = atomicAdd(&n_dup, 1u);
+                if (pos < SP_MAXDUP) dlist[pos] = (uint16_t)v[e];
+            }
+        }
     }
-    if (t == 0) { totals[0] = ctot; totals[1] = utot; totals[2] = mtot; totals[3] = 0; }
+    __syncthreads();
+    const uint32_t nd = n_dup;
+    if (nd > SP_MAXDUP) {   // uniform
+        if (t == 0) { need[b] = 1; uniq_out[b] = 0; multi_out[b] = 0; }
+        return;
+    }
+    // thread t owns words 4t .. 4t + 3 of the bit tables = values 128 t .. 128 t + 127 = bitmap words 2t, 2t + 1
+    uint32_t sw[4], dw[4], dsum = 0, usum = 0;
+#pragma unroll
+    for (int e = 0; e < 4; e++) {
+        sw[e] = seen[4 * t + e];
+        dw[e] = dup[4 * t + e];
+        usum += __popc(sw[e]);
+        dsum += __popc(dw[e]);
+    }
+    uint32_t multi_total, utot;
+    uint32_t rk = psk_block_excl_scan_u32<SP_THREADS>(dsum, &multi_total, scan_lds);
+    psk_block_excl_scan_u32<SP_THREADS>(usum, &utot, scan_lds);
+#pragma unroll
+    for (int e = 0; e < 4; e++) { rankb[4 * t + e] = rk; rk += __popc(dw[e]); }
+    reinterpret_cast<ulonglong2 *>(bitmap + (size_t)b * DC_BUCKET_WORDS)[t] =
+        make_ulonglong2((uint64_t)sw[0] | ((uint64_t)sw[1] << 32), (uint64_t)sw[2] | ((uint64_t)sw[3] << 32));
+    __syncthreads();
+    for (uint32_t i = t; i < nd; i += SP_THREADS) {
+        const uint32_t v = dlist[i];
+        atomicAdd(&dcnt[rankb[v >> 5] + __popc(dup[v >> 5] & ((1u << (v & 31u)) - 1u))], 1u);
+    }
+    __syncthreads();
+    if (dsum) {
+        const uint32_t word0 = (b0 + b) << DC_VB;
+        uint32_t r = rankb[4 * t];
+        const uint32_t dst = (uint32_t)(off / 2);
+#pragma unroll
+        for (int e = 0; e < 4; e++) {
+            uint32_t m = dw[e];
+            while (m) {
+                const int j = __builtin_ctz(m);
+                m &= m - 1;
+                mt_w[dst + r] = word0 + 128 * t + 32 * e + j;
+                mt_f[dst + r] = 1u + dcnt[r];
+                r++;
+            }
+        }
+    }
+    if (t == 0) { uniq_out[b] = utot; multi_out[b] = multi_total; need[b] = 0; }
 }
 
-__global__ void dc_compact_kernel(const uint32_t *__restrict__ mt_w, const uint32_t *__restrict__ mt_f,
-                                  const uint32_t *__restrict__ base, const uint32_t *__restrict__ multi,
-                                  const uint32_t *__restrict__ moff, uint32_t *__restrict__ dst_w, uint32_t *__restrict__ dst_f)
+// totals[0] = keys kept, [1] = distinct words, [2] = multi-count entries, [3] = buckets the sparse pass left to the
+// table pass -- also written straight into pinned host
+// memory (`host_totals`), which saves the copy kernel of a 16-byte device-to-host transfer
+__global__ __launch_bounds__(1024) void dc_totals_kernel(const uint32_t *__restrict__ cnt, const uint32_t *__restrict__ uniq,
+                                                         const uint32_t *__restrict__ multi, const uint32_t *__restrict__ need,
+                                                         uint32_t nb, uint32_t *__restrict__ totals,
+                                                         uint32_t *__restrict__ host_totals)
 {
-    const uint32_t b = blockIdx.x, n = multi[b], src = base[b] / 2, dst = moff[b];
-    for (uint32_t i = threadIdx.x; i < n; i += blockDim.x) {
+    __shared__ uint32_t lds[4][16];
+    const uint32_t t = threadIdx.x, lane = t & 63, wid = t >> 6;
+    uint32_t c = 0, u = 0, m = 0, nd = 0;
+#pragma unroll
+    for (int e = 0; e < 2; e++) {
+        const uint32_t d = e * 1024 + t;
+        if (d < nb) { c += cnt[d]; u += uniq[d]; m += multi[d]; nd += need ? need[d] : 0u; }
+    }
+#pragma unroll
+    for (int d = 32; d >= 1; d >>= 1) {
+        c += __shfl_xor(c, d, 64);
+        u += __shfl_xor(u, d, 64);
+        m += __shfl_xor(m, d, 64);
+        nd += __shfl_xor(nd, d, 64);
+    }
+    if (lane == 0) { lds[0][wid] = c; lds[1][wid] = u; lds[2][wid] = m; lds[3][wid] = nd; }
+    __syncthreads();
+    if (t < 4) {
+        uint32_t s = 0;
+#pragma unroll
+        for (int w = 0; w < 16; w++) s += lds[t][w];
+        totals[t] = s;
+        host_totals[t] = s;
+    }
+}
+
+// bucket b's multi-count entries -> their place in the arena block (offset = sum of multi[0 .. b))
+__global__ __launch_bounds__(256) void dc_compact_kernel(const uint32_t *__restrict__ mt_w, const uint32_t *__restrict__ mt_f,
+                                                         const uint32_t *__restrict__ base, const uint32_t *__restrict__ multi,
+                                                         uint32_t *__restrict__ dst_w, uint32_t *__restrict__ dst_f)
+{
+    __shared__ uint32_t lds[4];
+    const uint32_t b = blockIdx.x, t = threadIdx.x;
+    uint32_t below = 0;
+#pragma unroll
+    for (int e = 0; e < (int)(DC_MAX_NB / 256); e++) {
+        const uint32_t d = e * 256 + t;
+        if (d < b) below += multi[d];
+    }
+#pragma unroll
+    for (int d = 32; d >= 1; d >>= 1) below += __shfl_xor(below, d, 64);
+    if ((t & 63) == 0) lds[t >> 6] = below;
+    __syncthreads();
+    const uint32_t dst = lds[0] + lds[1] + lds[2] + lds[3];
+    const uint32_t n = multi[b], src = base[b] / 2;
+    for (uint32_t i = t; i < n; i += 256) {
         dst_w[dst + i] = mt_w[src + i];
         dst_f[dst + i] = mt_f[src + i];
     }
@@ -400,10 +562,67 @@ void dense_configure(psk_ctx *ctx)
     ctx->dense_nb = nb;
 }
 
+namespace {
+
+struct DcBufs {
+    uint32_t *cnt, *base, *uniq, *multi, *need, *totals, *mt_w, *mt_f;
+};
+
+DcBufs dc_bufs(const CountLane &L, uint32_t slot)
+{
+    uint32_t *meta = L.dc_meta.as<uint32_t>();
+    DcBufs d;
+    d.cnt = L.dc_cnt.as<uint32_t>() + (size_t)DC_MAX_NB * slot;
+    d.base = meta;
+    d.uniq = meta + DC_MAX_NB;
+    d.multi = meta + 2 * DC_MAX_NB;
+    d.need = meta + 3 * DC_MAX_NB;
+    d.totals = meta + 4 * DC_MAX_NB;
+    d.mt_w = L.dc_mtemp.as<uint32_t>();
+    d.mt_f = d.mt_w + (L.n / 2 + 2);
+    return d;
+}
+
+template <int K>
+int launch_tiles(psk_ctx *ctx, const CountLane &L, const DcBufs &d, uint64_t clean_len, uint32_t n_tiles, uint32_t lo, uint32_t hi)
+{
+    static bool lds_set = false;
+    if (!lds_set) {
+        PSK_HIP(ctx, hipFuncSetAttribute(reinterpret_cast<const void *>(dc_partition_kernel<K>),
+                                         hipFuncAttributeMaxDynamicSharedMemorySize, (int)DP_LDS_BYTES));
+        lds_set = true;
+    }
+    const uint8_t *clean = L.raw.as<uint8_t>();
+    dc_hist_kernel<K><<<n_tiles, DT_THREADS, 0, ctx->stream>>>(clean, clean_len, lo, hi, ctx->dense_b0, ctx->dense_nb, d.cnt,
+                                                               L.dc_wgoff.as<uint32_t>());
+    PSK_HIP(ctx, hipGetLastError());
+    dc_partition_kernel<K><<<n_tiles, DT_THREADS, DP_LDS_BYTES, ctx->stream>>>(clean, clean_len, lo, hi, ctx->dense_b0, ctx->dense_nb,
+                                                                              d.cnt, L.dc_wgoff.as<uint32_t>(), d.base,
+                                                                              L.dc_part.as<uint16_t>());
+    PSK_HIP(ctx, hipGetLastError());
+    return PSK_OK;
+}
+
+int launch_table_count(psk_ctx *ctx, const CountLane &L, const DcBufs &d, uint64_t *bitmap, const uint32_t *need)
+{
+    static bool lds_set = false;
+    if (!lds_set) {
+        PSK_HIP(ctx, hipFuncSetAttribute(reinterpret_cast<const void *>(dc_count_kernel),
+                                         hipFuncAttributeMaxDynamicSharedMemorySize, (int)DCNT_LDS_BYTES));
+        lds_set = true;
+    }
+    dc_count_kernel<<<ctx->dense_nb, DT_THREADS, DCNT_LDS_BYTES, ctx->stream>>>(L.dc_part.as<uint16_t>(), d.cnt, d.base, ctx->dense_b0,
+                                                                               bitmap, d.mt_w, d.mt_f, d.uniq, d.multi, need);
+    PSK_HIP(ctx, hipGetLastError());
+    return PSK_OK;
+}
+
+}  // namespace
+
 int dense_chain_enqueue(psk_ctx *ctx, CountLane &L, int sample_idx, uint64_t clean_len, uint64_t n)
 {
     SampleList &S = ctx->lists[sample_idx];
-    const uint32_t nb = ctx->dense_nb, b0 = ctx->dense_b0;
+    const uint32_t nb = ctx->dense_nb;
     const uint64_t space = 1ull << (2 * ctx->k);
     const uint32_t lo = (uint32_t)ctx->slab_lo;
     const uint32_t hi = (uint32_t)((ctx->slab_hi && ctx->slab_hi < space) ? ctx->slab_hi : space);
@@ -419,32 +638,26 @@ int dense_chain_enqueue(psk_ctx *ctx, CountLane &L, int sample_idx, uint64_t cle
         PSK_HIP(ctx, hipMemsetAsync(L.dc_cnt.p, 0, (size_t)DC_SLOTS * DC_MAX_NB * 4, ctx->stream));
         L.dc_slot = 0;
     }
-    uint32_t *cnt = L.dc_cnt.as<uint32_t>() + (size_t)DC_MAX_NB * L.dc_slot++;
-    uint32_t *meta = L.dc_meta.as<uint32_t>();
-    uint32_t *base = meta, *uniq = meta + DC_MAX_NB, *multi = meta + 2 * DC_MAX_NB, *moff = meta + 3 * DC_MAX_NB,
-             *totals = meta + 4 * DC_MAX_NB;
-    uint32_t *mt_w = L.dc_mtemp.as<uint32_t>(), *mt_f = mt_w + (n / 2 + 2);
-    const uint8_t *clean = L.raw.as<uint8_t>();
-    dc_hist_kernel<<<n_tiles, DT_THREADS, 0, ctx->stream>>>(clean, clean_len, ctx->k, lo, hi, b0, nb, cnt, L.dc_wgoff.as<uint32_t>());
-    PSK_HIP(ctx, hipGetLastError());
-    static bool lds_set = false;
-    if (!lds_set) {
-        PSK_HIP(ctx, hipFuncSetAttribute(reinterpret_cast<const void *>(dc_partition_kernel),
-                                         hipFuncAttributeMaxDynamicSharedMemorySize, (int)DP_LDS_BYTES));
-        PSK_HIP(ctx, hipFuncSetAttribute(reinterpret_cast<const void *>(dc_count_kernel),
-                                         hipFuncAttributeMaxDynamicSharedMemorySize, (int)DCNT_LDS_BYTES));
-        lds_set = true;
+    const DcBufs d = dc_bufs(L, L.dc_slot++);
+    switch (ctx->k) {
+    case 11: PSK_TRY(launch_tiles<11>(ctx, L, d, clean_len, n_tiles, lo, hi)); break;
+    case 12: PSK_TRY(launch_tiles<12>(ctx, L, d, clean_len, n_tiles, lo, hi)); break;
+    case 13: PSK_TRY(launch_tiles<13>(ctx, L, d, clean_len, n_tiles, lo, hi)); break;
+    default: return psk_fail(ctx, PSK_ESTATE, "dense counting is built for k = 11..13, not %d", ctx->k);
     }
-    dc_partition_kernel<<<n_tiles, DT_THREADS, DP_LDS_BYTES, ctx->stream>>>(clean, clean_len, ctx->k, lo, hi, b0, nb, cnt,
-                                                                  L.dc_wgoff.as<uint32_t>(), base, L.dc_part.as<uint16_t>());
-    PSK_HIP(ctx, hipGetLastError());
     PSK_HIP(ctx, hipEventRecord(L.raw_free, ctx->stream));
     L.raw_used = true;
-    dc_count_kernel<<<nb, DT_THREADS, DCNT_LDS_BYTES, ctx->stream>>>(L.dc_part.as<uint16_t>(), cnt, base, b0, S.bitmap, mt_w, mt_f, uniq, multi);
+    // few keys per bucket (a genome): the presence-bit pass, which leaves over-full buckets to the table pass that
+    // dense_chain_finalize runs when the totals report any; many (reads at depth): the table pass at once
+    const bool sparse = n / nb < 4096 && !getenv("PSK_DC_TABLE");
+    if (sparse)
+        dc_count_sparse_kernel<<<nb, SP_THREADS, 0, ctx->stream>>>(L.dc_part.as<uint16_t>(), d.cnt, d.base, ctx->dense_b0, S.bitmap,
+                                                                   d.mt_w, d.mt_f, d.uniq, d.multi, d.need);
+    else
+        PSK_TRY(launch_table_count(ctx, L, d, S.bitmap, nullptr));
     PSK_HIP(ctx, hipGetLastError());
-    dc_totals_kernel<<<1, 1024, 0, ctx->stream>>>(cnt, uniq, multi, nb, moff, totals);
+    dc_totals_kernel<<<1, 1024, 0, ctx->stream>>>(d.cnt, d.uniq, d.multi, sparse ? d.need : nullptr, nb, d.totals, L.pinned_cnt);
     PSK_HIP(ctx, hipGetLastError());
-    PSK_HIP(ctx, hipMemcpyAsync(L.pinned_cnt, totals, 16, hipMemcpyDeviceToHost, ctx->stream));
     PSK_HIP(ctx, hipEventRecord(L.done, ctx->stream));
     L.dense = true;
     return PSK_OK;
@@ -454,6 +667,15 @@ int dense_chain_enqueue(psk_ctx *ctx, CountLane &L, int sample_idx, uint64_t cle
 int dense_chain_finalize(psk_ctx *ctx, CountLane &L, uint64_t *n_kept, uint64_t *n_unique)
 {
     SampleList &S = ctx->lists[L.sample];
+    const DcBufs d = dc_bufs(L, L.dc_slot - 1);
+    if (L.pinned_cnt[3]) {
+        // some buckets were too full for the presence-bit pass: the table pass on those, then the totals again (the
+        // sample's buffers are untouched until the sample after next is queued on this set)
+        PSK_TRY(launch_table_count(ctx, L, d, S.bitmap, d.need));
+        dc_totals_kernel<<<1, 1024, 0, ctx->stream>>>(d.cnt, d.uniq, d.multi, nullptr, ctx->dense_nb, d.totals, L.pinned_cnt);
+        PSK_HIP(ctx, hipGetLastError());
+        PSK_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    }
     *n_kept = L.pinned_cnt[0];
     *n_unique = L.pinned_cnt[1];
     const uint64_t nm = L.pinned_cnt[2];
@@ -461,10 +683,7 @@ int dense_chain_finalize(psk_ctx *ctx, CountLane &L, uint64_t *n_kept, uint64_t 
     if (nm) {
         PSK_TRY(arena_alloc(ctx, nm * 4, (void **)&S.mwords));
         PSK_TRY(arena_alloc(ctx, nm * 4, (void **)&S.mfreqs));
-        uint32_t *meta = L.dc_meta.as<uint32_t>();
-        uint32_t *mt_w = L.dc_mtemp.as<uint32_t>(), *mt_f = mt_w + (L.n / 2 + 2);
-        dc_compact_kernel<<<ctx->dense_nb, 128, 0, ctx->stream>>>(mt_w, mt_f, meta, meta + 2 * DC_MAX_NB, meta + 3 * DC_MAX_NB,
-                                                                 S.mwords, S.mfreqs);
+        dc_compact_kernel<<<ctx->dense_nb, 256, 0, ctx->stream>>>(d.mt_w, d.mt_f, d.base, d.multi, S.mwords, S.mfreqs);
         PSK_HIP(ctx, hipGetLastError());
     }
     L.dense = false;

@@ -607,6 +607,85 @@ def test_tiled_presence_build_with_thousands_of_samples(ctx, oracle, k, n, lengt
     assert np.array_equal(ctx.get_union(), uw) and np.array_equal(ctx.get_rows(np.arange(m, dtype=np.uint64)), rows)
 
 
+@pytest.mark.parametrize("k", [11, 12, 13])
+def test_dense_counting_paths_agree_with_the_oracle(ctx, oracle, k, monkeypatch):
+    """k = 11..13 counts without a sort (dense_count.hip): the presence-bit pass for buckets with few keys, the
+    counter-table pass for the ones it leaves (more than 2048 repeats in a bucket: tandem repeats, homopolymers), the
+    table pass alone (PSK_DC_TABLE: what deep read sets take), 32-bit counters for buckets with 65,536 keys or more,
+    and the sort route (PSK_NO_DENSE) -- every list, every count, and the matrix equal the oracle's."""
+    from phenotypeseeker_amd.synth import GenomeSet
+    rng = np.random.default_rng(k)
+    gs = GenomeSet(3, 150_000, seed=31 + k, gene_len=300, gc=0.31, contigs=4)
+    unit = bytes(rng.choice(list(b"ACGT"), size=37).tolist())
+    datas = [gs.sample(i)[1] for i in range(3)]
+    datas.append(b">tandem\n" + unit * 6000 + b"\n>polyA\n" + b"A" * 70_000 + b"\n" + datas[0])      # over-full buckets
+    datas.append(b">deep\n" + (unit * 4 + b"N") * 3000 + bytes(rng.choice(list(b"ACGT"), size=400_000).tolist()) + b"\n")
+    datas.append(b"")
+    datas.append(b">short\nACGTACGTAC\n")
+    ref = [oracle.count_kmers(d, k) for d in datas]
+    lists = [r[0] for r in ref]
+    uw = oracle.union(lists)
+
+    def check(batch):
+        ctx.begin(k, len(datas))
+        if batch:
+            nu, nt = ctx.count_kmers_batch(0, datas, 3)
+        else:
+            got = [ctx.count_kmers(i, d) for i, d in enumerate(datas)]
+            nu, nt = [g[0] for g in got], [g[1] for g in got]
+        assert list(nu) == [len(r[0]) for r in ref] and list(nt) == [r[2] for r in ref]
+        q = np.concatenate([lists[3][::7], np.array([0, 1, (1 << (2 * k)) - 1], dtype=np.uint64)])
+        want = np.zeros(len(q), np.uint32)
+        pos = np.searchsorted(lists[3], q)
+        hit = (pos < len(lists[3])) & (lists[3][np.minimum(pos, len(lists[3]) - 1)] == q)
+        want[hit] = ref[3][1][pos[hit]]
+        assert np.array_equal(ctx.lookup_counts(3, q), want)                    # before any list is materialised
+        m = ctx.build_presence()
+        assert m == len(uw) and np.array_equal(ctx.get_union(), uw)
+        assert np.array_equal(ctx.get_rows(np.arange(m, dtype=np.uint64)), oracle.presence_bits(lists, uw, wpr=ctx.presence_shape()[1]))
+        for i, (w, f, _) in enumerate(ref):
+            gw, gf = ctx.get_list(i, nu[i])
+            assert np.array_equal(gw, w) and np.array_equal(gf, f), i
+
+    check(batch=True)
+    check(batch=False)
+    monkeypatch.setenv("PSK_DC_TABLE", "1")
+    check(batch=True)
+    monkeypatch.delenv("PSK_DC_TABLE")
+    monkeypatch.setenv("PSK_NO_DENSE_PRESENCE", "1")      # dense lists, list-based matrix build
+    check(batch=True)
+    monkeypatch.delenv("PSK_NO_DENSE_PRESENCE")
+    monkeypatch.setenv("PSK_NO_DENSE", "1")
+    check(batch=True)
+
+
+def test_dense_counting_under_a_slab_filter(ctx, oracle):
+    """The dense form with slab bounds that cut through buckets: the slabs' lists concatenate to the whole list and the
+    slabs' matrices to the whole matrix."""
+    from phenotypeseeker_amd.synth import GenomeSet
+    k = 13
+    gs = GenomeSet(6, 120_000, seed=77, gene_len=300)
+    datas = [gs.sample(i)[1] for i in range(6)]
+    ref = [oracle.count_kmers(d, k)[:2] for d in datas]
+    uw = oracle.union([r[0] for r in ref])
+    bounds = [0, 1_234_567, 1_234_567 + 40_000, 30_000_001, 0]
+    got_w, got_f, got_u, got_rows = [[] for _ in datas], [[] for _ in datas], [], []
+    for lo, hi in zip(bounds[:-1], bounds[1:]):
+        ctx.begin(k, len(datas), lo, hi)
+        nu, _ = ctx.count_kmers_batch(0, datas, 2)
+        m = ctx.build_presence()
+        got_u.append(ctx.get_union())
+        got_rows.append(ctx.get_rows(np.arange(m, dtype=np.uint64)))
+        for i in range(len(datas)):
+            w, f = ctx.get_list(i, nu[i])
+            got_w[i].append(w)
+            got_f[i].append(f)
+    for i, (w, f) in enumerate(ref):
+        assert np.array_equal(np.concatenate(got_w[i]), w) and np.array_equal(np.concatenate(got_f[i]), f), i
+    assert np.array_equal(np.concatenate(got_u), uw)
+    assert np.array_equal(np.concatenate(got_rows), oracle.presence_bits([r[0] for r in ref], uw, wpr=ctx.presence_shape()[1]))
+
+
 @pytest.mark.parametrize("k,n,length,chunk", [(16, 40, 30_000, 100_000), (31, 300, 900, 20_000), (13, 12, 60_000, 50_000)])
 def test_sort_route_in_word_range_chunks(ctx, oracle, k, n, length, chunk, monkeypatch):
     """More (word, sample) pairs than one sort holds (2^32 per GPU; config 3 on two GPUs has 4.8 x 10^9 per rank): the

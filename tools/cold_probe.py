@@ -38,10 +38,11 @@ for rnd in range(3):
         ctx.count_kmers_batch(lo, fas[lo:lo + 64], 8)
         calls.append(time.perf_counter() - t)
     tc = time.perf_counter()
-    M = ctx.build_presence()
+    M = ctx.build_presence() if not os.environ.get("PSK_PROBE_NOCHECK") else 1
     td = time.perf_counter()
     pheno = np.array([1 if i % 2 == 0 else 0 for i in range(n)], dtype=np.int8)
-    ctx.chi2_scan(pheno, None, 2, n - 2, 0.05, False, M)
+    if not os.environ.get("PSK_PROBE_NOCHECK"):
+        ctx.chi2_scan(pheno, None, 2, n - 2, 0.05, False, M)
     te = time.perf_counter()
     print("round %d: begin %.3f  count %.3f s (calls: %s)  presence %.3f  first scan %.4f  M=%d"
           % (rnd, tb - ta, tc - tb, " ".join("%.3f" % c for c in calls), td - tc, te - td, M), flush=True)
