@@ -56,6 +56,10 @@ _SIGNATURES = {
                                     c.c_void_p, c.c_int, c.c_double, c.c_int, c.c_int, c.c_void_p, c.c_void_p,
                                     c.c_void_p]),
     "psk_count_dict": (c.c_int, [c.c_void_p, c.c_char_p, c.c_size_t, c.c_int, c.c_void_p, c.c_uint64, c.c_void_p]),
+    "psk_count_dict_batch": (c.c_int, [c.c_void_p, c.c_int, c.POINTER(c.c_char_p), c.POINTER(c.c_size_t), c.c_int, c.c_void_p,
+                                       c.c_uint64, c.c_void_p, c.c_int]),
+    "psk_count_dict_files": (c.c_int, [c.c_void_p, c.c_int, c.POINTER(c.c_char_p), c.POINTER(c.c_size_t), c.c_int, c.c_void_p,
+                                       c.c_uint64, c.c_void_p, c.c_int]),
     "psk_minhash_sketch": (c.c_int, [c.c_void_p, c.c_char_p, c.c_size_t, c.c_int, c.c_int, c.c_uint32, c.c_void_p, _u64p]),
     "psk_mash_pairs": (c.c_int, [c.c_void_p, c.c_void_p, c.c_void_p, c.c_int, c.c_int, c.c_void_p, c.c_void_p]),
     "psk_nj_merges": (c.c_int, [c.c_void_p, c.c_void_p, c.c_int, c.c_void_p, c.c_void_p, c.c_void_p, c.c_void_p, c.c_void_p]),

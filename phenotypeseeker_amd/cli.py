@@ -105,7 +105,8 @@ def build_parser():
     pb.add_argument("inputfile1", help="Tab separated list of sample IDs and Fasta/Fastq file addresses.")
     pb.add_argument("inputfile2", help="Tab separated list of phenotypes to predict and model (.pkl) addresses.")
     pb.add_argument("-c", type=int, metavar="INT", default=1, help="K-mer frequency cut-off (default = 1).")
-    pb.add_argument("-nt", "--num_threads", type=int, metavar="INT", default=8, help="Accepted for compatibility.")
+    pb.add_argument("-nt", "--num_threads", type=int, metavar="INT", default=8,
+                    help="Host threads that read and frame the samples ahead of the GPU.")
     from . import prediction
     pb.set_defaults(func=prediction.prediction)
     return parser

@@ -438,20 +438,27 @@ __global__ void lookup_counts_kernel(const uint64_t *__restrict__ words, const u
     out[i] = (lo < nu && words[lo] == key) ? freqs[lo] : 0u;
 }
 
-// prediction path: every window's canonical word is probed in an LDS open-addressing table of the
-// dictionary; hits bump the dictionary entry's counter.
+// prediction path: every window's canonical word is probed in an open-addressing table of the dictionary; hits bump
+// the dictionary entry's counter.  A dictionary of up to DICT_SLOTS / 2 words (the reference's default model has
+// 1000 k-mers) keeps the table in LDS; a larger one (`--n_kmers 0` = no limit) is probed in global memory, where it
+// stays L2-resident.
 constexpr int DICT_SLOTS = 4096;  // power of two, >= 2 * n_dict
 __device__ __forceinline__ uint32_t dict_hash(uint64_t w) { return (uint32_t)((w * 0x9E3779B97F4A7C15ull) >> 40); }
 
+template <bool IN_LDS>
 __global__ __launch_bounds__(EX_THREADS) void dict_count_kernel(const uint8_t *__restrict__ clean, uint64_t len, int k,
                                                                  const uint64_t *__restrict__ slot_word,
-                                                                 const int32_t *__restrict__ slot_idx,
+                                                                 const int32_t *__restrict__ slot_idx, uint32_t slot_mask,
                                                                  uint32_t *__restrict__ counts)
 {
-    __shared__ uint64_t sw[DICT_SLOTS];
-    __shared__ int32_t si[DICT_SLOTS];
-    for (int i = threadIdx.x; i < DICT_SLOTS; i += EX_THREADS) { sw[i] = slot_word[i]; si[i] = slot_idx[i]; }
-    __syncthreads();
+    __shared__ uint64_t sw[IN_LDS ? DICT_SLOTS : 1];
+    __shared__ int32_t si[IN_LDS ? DICT_SLOTS : 1];
+    if (IN_LDS) {
+        for (int i = threadIdx.x; i < DICT_SLOTS; i += EX_THREADS) { sw[i] = slot_word[i]; si[i] = slot_idx[i]; }
+        __syncthreads();
+    }
+    const uint64_t *tw = IN_LDS ? sw : slot_word;
+    const int32_t *ti = IN_LDS ? si : slot_idx;
     const uint64_t g = (uint64_t)blockIdx.x * EX_THREADS + threadIdx.x;
     const uint64_t s = g * EX_SEG;
     if (s >= len) return;
@@ -464,10 +471,10 @@ __global__ __launch_bounds__(EX_THREADS) void dict_count_kernel(const uint8_t *_
         roll_byte(r, clean[s + j], mask, rcshift, k);
         if (r.run >= k) {
             const uint64_t w = (r.fw < r.rc) ? r.fw : r.rc;
-            uint32_t h = dict_hash(w) & (DICT_SLOTS - 1);
-            while (si[h] >= 0) {
-                if (sw[h] == w) { atomicAdd(&counts[si[h]], 1u); break; }
-                h = (h + 1) & (DICT_SLOTS - 1);
+            uint32_t h = dict_hash(w) & slot_mask;
+            while (ti[h] >= 0) {
+                if (tw[h] == w) { atomicAdd(&counts[ti[h]], 1u); break; }
+                h = (h + 1) & slot_mask;
             }
         }
     }
@@ -1118,47 +1125,193 @@ extern "C" int psk_lookup_counts(psk_ctx *ctx, int sample_idx, const uint64_t *w
     return PSK_OK;
 }
 
-extern "C" int psk_count_dict(psk_ctx *ctx, const uint8_t *bytes, size_t len, int k, const uint64_t *dict_words,
-                              uint64_t n_dict, uint32_t *counts_out)
+namespace {
+
+// host-built open-addressing table of the dictionary on the device: slot words | slot indices; duplicate dictionary
+// words share the first entry's slot (alias[d] = that entry)
+struct DictTable {
+    uint32_t n_slots = 0;
+    uint64_t *d_words = nullptr;
+    int32_t *d_idx = nullptr;
+    std::vector<int32_t> alias;
+};
+
+int build_dict_table(psk_ctx *ctx, const uint64_t *dict_words, uint64_t n_dict, DictTable &T)
+{
+    uint32_t n_slots = DICT_SLOTS;
+    while ((uint64_t)n_slots < 2 * n_dict) n_slots *= 2;
+    if (n_dict >= (1ull << 30)) return psk_fail(ctx, PSK_ERANGE, "dictionary of %llu k-mers", (unsigned long long)n_dict);
+    std::vector<uint64_t> sw(n_slots, 0);
+    std::vector<int32_t> si(n_slots, -1);
+    T.alias.assign(n_dict, -1);
+    for (uint64_t d = 0; d < n_dict; d++) {
+        const uint64_t w = dict_words[d];
+        uint32_t h = (uint32_t)((w * 0x9E3779B97F4A7C15ull) >> 40) & (n_slots - 1);
+        while (si[h] >= 0 && sw[h] != w) h = (h + 1) & (n_slots - 1);
+        if (si[h] >= 0) T.alias[d] = si[h];
+        else { sw[h] = w; si[h] = (int32_t)d; }
+    }
+    PSK_TRY(dev_reserve(ctx, ctx->flags, (size_t)n_slots * 12));
+    T.n_slots = n_slots;
+    T.d_words = ctx->flags.as<uint64_t>();
+    T.d_idx = reinterpret_cast<int32_t *>(ctx->flags.as<uint8_t>() + (size_t)n_slots * 8);
+    PSK_HIP(ctx, hipMemcpyAsync(T.d_words, sw.data(), (size_t)n_slots * 8, hipMemcpyHostToDevice, ctx->stream));
+    PSK_HIP(ctx, hipMemcpyAsync(T.d_idx, si.data(), (size_t)n_slots * 4, hipMemcpyHostToDevice, ctx->stream));
+    PSK_HIP(ctx, hipStreamSynchronize(ctx->stream));   // sw / si are locals
+    return PSK_OK;
+}
+
+void launch_dict_count(psk_ctx *ctx, const DictTable &T, const uint8_t *d_clean, uint64_t clean_len, int k, uint32_t *d_cnt)
+{
+    const uint64_t threads = (clean_len + EX_SEG - 1) / EX_SEG;
+    if (T.n_slots == DICT_SLOTS)
+        dict_count_kernel<true><<<div_up(threads, EX_THREADS), EX_THREADS, 0, ctx->stream>>>(d_clean, clean_len, k, T.d_words, T.d_idx,
+                                                                                          T.n_slots - 1, d_cnt);
+    else
+        dict_count_kernel<false><<<div_up(threads, EX_THREADS), EX_THREADS, 0, ctx->stream>>>(d_clean, clean_len, k, T.d_words, T.d_idx,
+                                                                                           T.n_slots - 1, d_cnt);
+}
+
+// n samples (file images, or paths of uncompressed files read by the framing threads) against one dictionary:
+// n_threads host threads frame ahead into the pinned ring, uploads alternate between the two buffer sets on the copy
+// stream, one kernel per sample, one read-back of counts_out[n][n_dict] at the end.
+int count_dict_impl(psk_ctx *ctx, int n, const uint8_t *const *bytes, const char *const *paths, const size_t *lens, int k,
+                    const uint64_t *dict_words, uint64_t n_dict, uint32_t *counts_out, int n_threads)
 {
     if (!ctx) return PSK_EINVAL;
     if (k < 1 || k > 32) return psk_fail(ctx, PSK_EINVAL, "k must be 1..32");
-    if (n_dict == 0) return PSK_OK;
-    if (!dict_words || !counts_out || (!bytes && len)) return psk_fail(ctx, PSK_EINVAL, "null buffer");
-    if (n_dict * 2 > DICT_SLOTS) return psk_fail(ctx, PSK_ERANGE, "dictionary of %llu k-mers exceeds %d",
-                                                  (unsigned long long)n_dict, DICT_SLOTS / 2);
+    if (n < 0) return psk_fail(ctx, PSK_EINVAL, "negative sample count");
+    if (n == 0 || n_dict == 0) return PSK_OK;
+    if (!dict_words || !counts_out || (!bytes && !paths) || !lens) return psk_fail(ctx, PSK_EINVAL, "null buffer");
     PSK_HIP(ctx, hipSetDevice(ctx->device));
-    // host-built open-addressing table; duplicate dictionary words share the first entry's slot
-    std::vector<uint64_t> sw(DICT_SLOTS, 0);
-    std::vector<int32_t> si(DICT_SLOTS, -1);
-    std::vector<int32_t> alias(n_dict, -1);
-    for (uint64_t d = 0; d < n_dict; d++) {
-        const uint64_t w = dict_words[d];
-        uint32_t h = (uint32_t)((w * 0x9E3779B97F4A7C15ull) >> 40) & (DICT_SLOTS - 1);
-        while (si[h] >= 0 && sw[h] != w) h = (h + 1) & (DICT_SLOTS - 1);
-        if (si[h] >= 0) alias[d] = si[h];
-        else { sw[h] = w; si[h] = (int32_t)d; }
+    DictTable T;
+    PSK_TRY(build_dict_table(ctx, dict_words, n_dict, T));
+    PSK_TRY(dev_reserve(ctx, ctx->starts, (size_t)n * n_dict * 4));
+    uint32_t *d_cnt = ctx->starts.as<uint32_t>();
+    PSK_HIP(ctx, hipMemsetAsync(d_cnt, 0, (size_t)n * n_dict * 4, ctx->stream));
+    if (n_threads < 1) n_threads = 1;
+    if (n_threads > 16) n_threads = 16;
+    if (n_threads > n) n_threads = n;
+    size_t max_len = 0;
+    for (int i = 0; i < n; i++) {
+        if (paths ? !paths[i] : (!bytes[i] && lens[i])) return psk_fail(ctx, PSK_EINVAL, "null input %d", i);
+        if (lens[i] > max_len) max_len = lens[i];
     }
-    uint64_t clean_len = 0;
-    PSK_TRY(upload_clean(ctx, bytes, len, &clean_len));
-    const size_t tbl = DICT_SLOTS * 8 + DICT_SLOTS * 4 + n_dict * 4;
-    PSK_TRY(dev_reserve(ctx, ctx->flags, tbl));
-    uint8_t *base = ctx->flags.as<uint8_t>();
-    uint64_t *d_sw = reinterpret_cast<uint64_t *>(base);
-    int32_t *d_si = reinterpret_cast<int32_t *>(base + DICT_SLOTS * 8);
-    uint32_t *d_cnt = reinterpret_cast<uint32_t *>(base + DICT_SLOTS * 12);
-    PSK_HIP(ctx, hipMemcpyAsync(d_sw, sw.data(), DICT_SLOTS * 8, hipMemcpyHostToDevice, ctx->stream));
-    PSK_HIP(ctx, hipMemcpyAsync(d_si, si.data(), DICT_SLOTS * 4, hipMemcpyHostToDevice, ctx->stream));
-    PSK_HIP(ctx, hipMemsetAsync(d_cnt, 0, n_dict * 4, ctx->stream));
-    if (clean_len) {
-        const uint64_t threads = (clean_len + EX_SEG - 1) / EX_SEG;
-        dict_count_kernel<<<div_up(threads, EX_THREADS), EX_THREADS, 0, ctx->stream>>>(ctx->raw.as<uint8_t>(), clean_len,
-                                                                                      k, d_sw, d_si, d_cnt);
+    while (n_threads > 1 && (size_t)(n_threads + 2) * max_len > (4ull << 30)) n_threads--;
+    const int R = n_threads + 2;
+    if ((int)ctx->ring.size() < R) { ctx->ring.resize(R, nullptr); ctx->ring_cap.resize(R, 0); }
+    for (int s = 0; s < R; s++) PSK_TRY(ensure_pinned(ctx, &ctx->ring[s], &ctx->ring_cap[s], max_len + 2 * EX_SEG));
+    for (CountLane &L : ctx->lane) PSK_TRY(lane_prepare(ctx, L));
+
+    std::mutex mu;
+    std::condition_variable cv;
+    std::vector<int> state(n, 0);
+    std::vector<uint64_t> clen(n, 0), plen(n, 0);
+    int consumed = 0;
+    bool abort = false;
+    std::atomic<int> next(0);
+    auto worker = [&]() {
+        std::vector<uint8_t> file_buf;
+        for (;;) {
+            const int i = next.fetch_add(1);
+            if (i >= n) return;
+            {
+                std::unique_lock<std::mutex> lk(mu);
+                cv.wait(lk, [&] { return abort || consumed > i - R; });
+                if (abort) return;
+            }
+            uint64_t c = 0, p = 0;
+            const uint8_t *src = bytes ? bytes[i] : nullptr;
+            int rc = 0;
+            if (paths) {
+                rc = read_whole_file(paths[i], lens[i], file_buf);
+                src = file_buf.data();
+            }
+            if (rc == 0) rc = frame_into(static_cast<uint8_t *>(ctx->ring[i % R]), ctx->ring_cap[i % R], src, lens[i], &c, &p);
+            {
+                std::lock_guard<std::mutex> lk(mu);
+                clen[i] = c; plen[i] = p;
+                state[i] = rc ? -1 : 1;
+            }
+            cv.notify_all();
+        }
+    };
+    std::vector<std::thread> pool;
+    for (int t = 0; t < n_threads; t++) pool.emplace_back(worker);
+    int rc = PSK_OK;
+    auto release_upto = [&](int upto) {
+        {
+            std::lock_guard<std::mutex> lk(mu);
+            consumed = upto;
+            if (rc != PSK_OK) abort = true;
+        }
+        cv.notify_all();
+    };
+    auto step = [&](int i) -> int {
+        CountLane &L = ctx->lane[i & 1];
+        PSK_TRY(dev_reserve(ctx, L.raw, plen[i]));
+        if (L.raw_used) PSK_HIP(ctx, hipStreamWaitEvent(ctx->copy_stream, L.raw_free, 0));
+        PSK_HIP(ctx, hipMemcpyAsync(L.raw.p, ctx->ring[i % R], plen[i], hipMemcpyHostToDevice, ctx->copy_stream));
+        PSK_HIP(ctx, hipEventRecord(L.raw_ready, ctx->copy_stream));
+        PSK_HIP(ctx, hipStreamWaitEvent(ctx->stream, L.raw_ready, 0));
+        if (clen[i]) launch_dict_count(ctx, T, L.raw.as<uint8_t>(), clen[i], k, d_cnt + (size_t)i * n_dict);
         PSK_HIP(ctx, hipGetLastError());
+        PSK_HIP(ctx, hipEventRecord(L.raw_free, ctx->stream));
+        L.raw_used = true;
+        return PSK_OK;
+    };
+    for (int i = 0; i < n && rc == PSK_OK; i++) {
+        {
+            std::unique_lock<std::mutex> lk(mu);
+            cv.wait(lk, [&] { return state[i] != 0; });
+            if (state[i] < 0) rc = psk_fail(ctx, PSK_ERANGE, "reading or framing sample %d failed", i);
+        }
+        if (rc != PSK_OK) break;
+        rc = step(i);
+        if (rc == PSK_OK && i > 0) {
+            // the upload of sample i - 1 has to be over before its ring slot is framed into again
+            if (hipEventSynchronize(ctx->lane[(i - 1) & 1].raw_ready) != hipSuccess) rc = psk_fail(ctx, PSK_EHIP, "event wait failed");
+            release_upto(i);
+        }
     }
-    PSK_HIP(ctx, hipMemcpyAsync(counts_out, d_cnt, n_dict * 4, hipMemcpyDeviceToHost, ctx->stream));
-    PSK_HIP(ctx, hipStreamSynchronize(ctx->stream));
-    for (uint64_t d = 0; d < n_dict; d++)
-        if (alias[d] >= 0) counts_out[d] = counts_out[alias[d]];
+    {
+        const hipError_t e1 = hipStreamSynchronize(ctx->copy_stream), e2 = hipStreamSynchronize(ctx->stream);
+        if (rc == PSK_OK && (e1 != hipSuccess || e2 != hipSuccess)) rc = psk_fail(ctx, PSK_EHIP, "stream synchronisation failed");
+    }
+    release_upto(n);
+    {
+        std::lock_guard<std::mutex> lk(mu);
+        if (rc != PSK_OK) abort = true;
+    }
+    cv.notify_all();
+    for (auto &t : pool) t.join();
+    if (rc != PSK_OK) return rc;
+    PSK_HIP(ctx, hipMemcpy(counts_out, d_cnt, (size_t)n * n_dict * 4, hipMemcpyDeviceToHost));
+    for (int i = 0; i < n; i++)
+        for (uint64_t d = 0; d < n_dict; d++)
+            if (T.alias[d] >= 0) counts_out[(size_t)i * n_dict + d] = counts_out[(size_t)i * n_dict + T.alias[d]];
     return PSK_OK;
+}
+
+}  // namespace
+
+extern "C" int psk_count_dict(psk_ctx *ctx, const uint8_t *bytes, size_t len, int k, const uint64_t *dict_words,
+                              uint64_t n_dict, uint32_t *counts_out)
+{
+    if (!bytes && len) return psk_fail(ctx, PSK_EINVAL, "null buffer");
+    static const uint8_t none = 0;
+    const uint8_t *one = bytes ? bytes : &none;
+    return count_dict_impl(ctx, 1, &one, nullptr, &len, k, dict_words, n_dict, counts_out, 1);
+}
+
+extern "C" int psk_count_dict_batch(psk_ctx *ctx, int n, const uint8_t *const *bytes, const size_t *lens, int k,
+                                    const uint64_t *dict_words, uint64_t n_dict, uint32_t *counts_out, int n_threads)
+{
+    return count_dict_impl(ctx, n, bytes, nullptr, lens, k, dict_words, n_dict, counts_out, n_threads);
+}
+
+extern "C" int psk_count_dict_files(psk_ctx *ctx, int n, const char *const *paths, const size_t *sizes, int k,
+                                    const uint64_t *dict_words, uint64_t n_dict, uint32_t *counts_out, int n_threads)
+{
+    return count_dict_impl(ctx, n, nullptr, paths, sizes, k, dict_words, n_dict, counts_out, n_threads);
 }

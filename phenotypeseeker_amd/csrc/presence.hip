@@ -191,6 +191,7 @@ static int padded_wpr(int n_samples)
 extern "C" int psk_build_presence(psk_ctx *ctx, uint64_t *n_kmers)
 {
     if (!ctx) return PSK_EINVAL;
+    if (ctx->n_in_flight > 0) return psk_fail(ctx, PSK_ESTATE, "a scan is in flight on this matrix: psk_scan_end first");
     if (ctx->k == 0) return psk_fail(ctx, PSK_ESTATE, "psk_begin has not been called");
     PSK_HIP(ctx, hipSetDevice(ctx->device));
     uint64_t total = 0;
@@ -413,6 +414,7 @@ extern "C" int psk_get_rows(psk_ctx *ctx, const uint64_t *row_idx, uint64_t n, u
 extern "C" int psk_intersect_db(psk_ctx *ctx, const uint64_t *db_words, uint64_t n_db, uint64_t *n_kmers)
 {
     if (!ctx) return PSK_EINVAL;
+    if (ctx->n_in_flight > 0) return psk_fail(ctx, PSK_ESTATE, "a scan is in flight on this matrix: psk_scan_end first");
     if (!ctx->have_presence) return psk_fail(ctx, PSK_ESTATE, "no presence matrix");
     PSK_HIP(ctx, hipSetDevice(ctx->device));
     const uint64_t M = ctx->n_kmers;
@@ -451,6 +453,7 @@ extern "C" int psk_set_presence(psk_ctx *ctx, const uint64_t *words, const uint6
                                 int words_per_row, int n_samples)
 {
     if (!ctx) return PSK_EINVAL;
+    if (ctx->n_in_flight > 0) return psk_fail(ctx, PSK_ESTATE, "a scan is in flight on this matrix: psk_scan_end first");
     if (n_samples < 1 || words_per_row != padded_wpr(n_samples))
         return psk_fail(ctx, PSK_EINVAL, "words_per_row must be %d for %d samples", padded_wpr(n_samples), n_samples);
     if (!bits && n_kmers) return psk_fail(ctx, PSK_EINVAL, "null matrix");
@@ -480,6 +483,7 @@ extern "C" int psk_set_presence(psk_ctx *ctx, const uint64_t *words, const uint6
 extern "C" int psk_synth_presence(psk_ctx *ctx, uint64_t n_kmers, int n_samples, uint64_t seed)
 {
     if (!ctx) return PSK_EINVAL;
+    if (ctx->n_in_flight > 0) return psk_fail(ctx, PSK_ESTATE, "a scan is in flight on this matrix: psk_scan_end first");
     if (n_samples < 1 || n_kmers < 1) return psk_fail(ctx, PSK_EINVAL, "bad shape");
     PSK_HIP(ctx, hipSetDevice(ctx->device));
     reset_lists(ctx, n_samples);

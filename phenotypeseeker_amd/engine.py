@@ -417,6 +417,33 @@ class PskContext:
         return out
 
 
+    def count_dict_batch(self, datas, k, dict_words, n_threads=4):
+        """psk_count_dict_batch: every sample (file image) against one dictionary -> counts[n][n_dict]."""
+        datas = [bytes(d) for d in datas]
+        n = len(datas)
+        d = np.ascontiguousarray(dict_words, dtype=np.uint64)
+        out = np.zeros((n, len(d)), dtype=np.uint32)
+        if n and len(d):
+            arr = (ctypes.c_char_p * n)(*datas)
+            lens = (ctypes.c_size_t * n)(*[len(x) for x in datas])
+            self._check(self._lib.psk_count_dict_batch(self._h, n, arr, lens, int(k), _ptr(d), len(d), _ptr(out), int(n_threads)),
+                        "psk_count_dict_batch")
+        return out
+
+    def count_dict_files(self, paths, k, dict_words, n_threads=4):
+        """psk_count_dict_files: the same for UNCOMPRESSED files, read by the library's framing threads."""
+        enc = [os.fsencode(p) for p in paths]
+        n = len(enc)
+        d = np.ascontiguousarray(dict_words, dtype=np.uint64)
+        out = np.zeros((n, len(d)), dtype=np.uint32)
+        if n and len(d):
+            arr = (ctypes.c_char_p * n)(*enc)
+            sizes = (ctypes.c_size_t * n)(*[os.path.getsize(p) for p in paths])
+            self._check(self._lib.psk_count_dict_files(self._h, n, arr, sizes, int(k), _ptr(d), len(d), _ptr(out), int(n_threads)),
+                        "psk_count_dict_files")
+        return out
+
+
 def frame_sequence(data):
     """Host-only tokeniser framing (psk_frame_sequence): the clean stream handed to the GPU."""
     lib = _lib.load()

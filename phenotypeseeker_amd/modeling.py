@@ -682,7 +682,17 @@ class phenotypes:
                 summary.write("\n### Outputting the model to a model file! ###\n")
         import joblib
         package = dict(self.model_package)
-        package.update({"model": self.model_fitted, "pca": self.pca, "pred_scale": self.pred_scale})
+        # The reference's .pkl holds scikit-learn objects and its loader is a plain joblib.load (prediction.py:124-129):
+        # with scikit-learn importable the fitted model is written as the equivalent GridSearchCV / LogisticRegression
+        # / Lasso / Ridge objects, so that the file loads where this package is absent.  PSK_NATIVE_PKL=1 keeps the
+        # package's own (scikit-learn-free) classes, which is also what is written when scikit-learn is missing.
+        model_out = self.model_fitted
+        if os.environ.get("PSK_NATIVE_PKL") != "1":
+            try:
+                model_out = self.model_fitted.to_sklearn()
+            except ImportError:
+                pass
+        package.update({"model": model_out, "pca": self.pca, "pred_scale": self.pred_scale})
         with open("%s_model_%s.pkl" % (short, self.name), "wb") as fh:
             joblib.dump(package, fh)
         self._write_model_coefficients(coeff)

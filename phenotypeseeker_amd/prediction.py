@@ -33,10 +33,20 @@ class Samples:
         fields = line.split()
         return cls(fields[0], fields[1])
 
-    def map_samples(self, ctx, pheno):
-        """was: gmer_counter -db K-mer_lists/k-mer_db_<pheno>.txt <address> (:72-80) followed by the
-        >= cutoff thresholding of kmer_counts (:82-100)."""
-        counts = ctx.count_dict(formats.read_sequence_file(self.address), pheno.k, pheno.words)
+    @classmethod
+    def map_samples(cls, ctx, samples, pheno, n_threads):
+        """was: Pool(num_threads).map over samples of `gmer_counter -db K-mer_lists/k-mer_db_<pheno>.txt <address>`
+        (:72-80, :150-163) followed by the >= cutoff thresholding of kmer_counts (:82-100).  All samples go through
+        one batched call: the library's threads read and frame the files ahead of the GPU (compressed inputs are
+        inflated here first), one kernel per sample, one read-back."""
+        paths = [s.address for s in samples]
+        if not any(formats.is_gzip(p) for p in paths):
+            counts = ctx.count_dict_files(paths, pheno.k, pheno.words, n_threads)
+        else:
+            counts = np.zeros((len(paths), len(pheno.words)), dtype=np.uint32)
+            for lo in range(0, len(paths), 32):     # bounded memory: 32 inflated files at a time
+                part = [formats.read_sequence_file(p) for p in paths[lo:lo + 32]]
+                counts[lo:lo + 32] = ctx.count_dict_batch(part, pheno.k, pheno.words, n_threads)
         return (counts >= Phenotypes.cutoff).astype(np.float64)
 
 
@@ -62,9 +72,8 @@ class Phenotypes:
             raise SystemExit("PCA models are outside the accelerated path.")
         return cls(name, pkg["model"], np.asarray(pkg["kmers"]), False, pkg["pred_scale"])
 
-    def get_inp_matrix(self, ctx):
-        for i, sample in enumerate(Input.samples.values()):
-            self.matrix[i, :] = sample.map_samples(ctx, self)
+    def get_inp_matrix(self, ctx, n_threads=8):
+        self.matrix[:, :] = Samples.map_samples(ctx, list(Input.samples.values()), self, n_threads)
 
     def predict(self):
         """predictions_<pheno>.txt (:165-182)"""
@@ -117,6 +126,6 @@ def prediction(args):
     with PskContext(0) as ctx:
         for pheno in Input.phenos.values():
             sys.stderr.write("\x1b[1;32mPredicting the phenotypes for %s.\x1b[0m\n" % pheno.name)
-            pheno.get_inp_matrix(ctx)
+            pheno.get_inp_matrix(ctx, max(1, min(int(getattr(args, "num_threads", 8) or 8), 16)))
             pheno.predict()
     sys.stderr.write("\n\x1b[1;1;101m######          PhenotypeSeeker prediction finished          ######\x1b[0m\n")

@@ -88,6 +88,26 @@ def test_modeling_and_prediction_end_to_end(tmp_path, tag, extra):
             assert int(p) == pred[non_na[name]]
             assert pr == str(round(proba[non_na[name]][1], 2))
 
+    # the .pkl is the reference's: scikit-learn objects behind a plain joblib.load (prediction.py:124-129), usable in
+    # a process that cannot import this package at all
+    import subprocess
+    import sys
+    np.save("X.npy", X)
+    code = ("import sys, joblib, numpy as np\n"
+            "sys.path = [p for p in sys.path if 'repo' not in p and p not in ('', '.')]\n"
+            "pkg = joblib.load('log_reg_model_Pheno.pkl')\n"
+            "assert 'phenotypeseeker_amd' not in sys.modules\n"
+            "m = pkg['model']\n"
+            "assert type(m).__module__.startswith('sklearn.') and type(m.best_estimator_).__name__ == 'LogisticRegression'\n"
+            "X = np.load('X.npy')\n"
+            "np.save('pred.npy', m.predict(X)); np.save('proba.npy', m.predict_proba(X))\n"
+            "print(len(m.cv_results_['params']), m.best_params_['C'], list(pkg['kmers'])[:1])\n")
+    env = {k_: v for k_, v in os.environ.items() if k_ != "PYTHONPATH"}
+    r = subprocess.run([sys.executable, "-c", code], cwd=str(tmp_path), env=env, capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stderr[-2000:]
+    assert np.array_equal(np.load("pred.npy"), pred) and np.allclose(np.load("proba.npy"), proba, rtol=1e-12, atol=0)
+    assert r.stdout.split()[0] == "13"
+
 
 def test_continuous_phenotype_end_to_end(tmp_path, oracle):
     """Welch t-test + Lasso path: the written t-test rows equal the oracle's, the model explains

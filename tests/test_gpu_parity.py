@@ -257,6 +257,54 @@ def test_count_dict_matches_gmer_counter(ctx, oracle):
         assert [int(b[2]) for b in body] == counts.tolist()
 
 
+def test_matrix_cannot_be_replaced_under_a_running_scan(ctx):
+    """the calls that replace or compact the matrix refuse while a scan is in flight."""
+    from phenotypeseeker_amd._lib import PskError
+    n, m = 64, 200_000
+    ctx.synth_presence(m, n, seed=3)
+    ph = (np.arange(n) % 2).astype(np.int8)
+    ctx.chi2_scan_begin(ph, None, 2, n - 2, 0.05, False, m)
+    for call in (lambda: ctx.synth_presence(m, n, seed=4), lambda: ctx.build_presence(),
+                 lambda: ctx.set_presence(np.zeros((4, 2), np.uint64), n), lambda: ctx.intersect_db(np.arange(5, dtype=np.uint64))):
+        with pytest.raises(PskError):
+            call()
+    a = ctx.scan_end()
+    assert a == ctx.chi2_scan(ph, None, 2, n - 2, 0.05, False, m)
+    ctx.synth_presence(m, n, seed=4)        # fine again
+
+
+def test_count_dict_with_large_dictionaries_and_in_batches(ctx, oracle, tmp_path):
+    """`--n_kmers 0` / `--n_kmers 5000` models have more than 2048 k-mers (the LDS table's limit): beyond
+    it the table is probed in global memory.  And the batched forms (what `prediction` calls: all samples in one go,
+    from memory or from files) equal one call per sample; counts are occurrences on both strands (the oracle's list),
+    duplicates of one canonical word share their count, absent words are 0."""
+    from phenotypeseeker_amd.synth import GenomeSet
+    rng = np.random.default_rng(5)
+    for k in (13, 21):
+        gs = GenomeSet(5, 80_000, seed=k, gene_len=300)
+        datas = [gs.sample(i)[1] for i in range(5)] + [b"", b">x\nACGT\n"]
+        lists = [oracle.count_kmers(d, k)[:2] for d in datas]
+        present = np.unique(np.concatenate([lists[0][0][::11], lists[1][0][::13]]))
+        absent = rng.integers(0, 1 << (2 * k), 3000).astype(np.uint64)
+        for n_dict in (1, 700, 2048, 2049, 6000, 40_000):
+            words = np.concatenate([present, absent])[:n_dict]
+            words = rng.permutation(np.concatenate([words, words[:5]]))          # with duplicates
+            want = np.zeros((len(datas), len(words)), np.uint32)
+            for i, (w, f) in enumerate(lists):
+                pos = np.searchsorted(w, words)
+                hit = (pos < len(w)) & (w[np.minimum(pos, max(len(w) - 1, 0))] == words) if len(w) else np.zeros(len(words), bool)
+                want[i, hit] = f[pos[hit]]
+            one = np.stack([ctx.count_dict(d, k, words) for d in datas])
+            assert np.array_equal(one, want), (k, n_dict)
+            assert np.array_equal(ctx.count_dict_batch(datas, k, words, 3), want)
+            paths = []
+            for i, d in enumerate(datas):
+                paths.append(os.path.join(tmp_path, "s%d.fa" % i))
+                with open(paths[-1], "wb") as f:
+                    f.write(d)
+            assert np.array_equal(ctx.count_dict_files(paths, k, words, 2), want)
+
+
 def test_full_size_fastq_sample_properties(ctx, oracle):
     """BASELINE config-5 sized sample (2 M reads x 150 bp, ~0.63 GB of FASTQ, 276 M windows): the window
     count is reads x (150 - k + 1), the counts add up to it, the words come back strictly ascending, and
