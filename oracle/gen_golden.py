@@ -29,6 +29,7 @@ import shutil
 import subprocess
 import sys
 import tempfile
+import time
 
 import numpy as np
 
@@ -223,6 +224,79 @@ def run_reference_dataset(tag, gs, na, flags, k=13, nt=4, fastq_for=()):
         json.dump(meta, f, indent=1, sort_keys=True)
     shutil.rmtree(tmp, ignore_errors=True)
     print(tag, "M =", meta["n_union"], "outputs:", meta["reference_outputs"])
+
+
+
+def run_reference_dataset_regenerated(tag, synth_kw, na, flag_sets, k=13, nt=8):
+    """A larger set whose inputs are NOT stored: the genomes come from phenotypeseeker_amd.synth with the parameters
+    kept in meta.json (the tests regenerate them and check their sha256), only what the reference made of them is
+    committed -- list hashes from glistmaker, the union from glistcompare, one glistquery mapping, and per flag set the
+    result tables of the unmodified modeling.py.  Used for the AT-rich, multi-contig set (29 % GC: the reference's
+    example organism, C. difficile)."""
+    out = os.path.join(GOLD, tag)
+    shutil.rmtree(out, ignore_errors=True)
+    os.makedirs(out)
+    tmp = tempfile.mkdtemp(prefix="psk_gold_")
+    gs = GenomeSet(**synth_kw)
+    rows = ["ID\tAddresses\tPheno"]
+    names, inputs = [], {}
+    for i in range(gs.n):
+        name, fa = gs.sample(i)
+        names.append(name)
+        fn = name + ".fasta"
+        with open(os.path.join(tmp, fn), "wb") as f:
+            f.write(fa)
+        inputs[name] = hashlib.sha256(fa).hexdigest()
+        rows.append("%s\t%s\t%s" % (name, fn, "NA" if i in na else gs.phenotype(i)))
+    pheno_txt = "\n".join(rows) + "\n"
+    for d in (tmp, out):
+        with open(os.path.join(d, "data.pheno"), "w") as f:
+            f.write(pheno_txt)
+    meta = {"k": k, "nt": nt, "synth": synth_kw, "inputs_sha256": inputs, "lists": {}, "runs": {}}
+    os.makedirs(os.path.join(tmp, "L"))
+    for name in names:
+        sh("glistmaker %s.fasta -o L/%s_0 -w %d -c 1" % (name, name, k), tmp)
+        with open(os.path.join(tmp, "L", "%s_0_%d.list" % (name, k)), "rb") as f:
+            data = f.read()
+        h64 = np.frombuffer(data, dtype="<u8", count=3, offset=16)
+        meta["lists"][name] = {"sha256": hashlib.sha256(data).hexdigest(), "n_unique": int(h64[0]), "n_total": int(h64[1])}
+    cur = "L/%s_0_%d.list" % (names[0], k)
+    for j, n in enumerate(names[1:]):
+        sh("glistcompare -u -o L/u%d %s L/%s_0_%d.list" % (j, cur, n, k), tmp)
+        cur = "L/u%d_%d_union.list" % (j, k)
+    with open(os.path.join(tmp, cur), "rb") as f:
+        udata = f.read()
+    urec = np.frombuffer(udata, dtype=np.dtype([("word", "<u8"), ("freq", "<u4")]),
+                         count=int(np.frombuffer(udata, dtype="<u8", count=1, offset=16)[0]), offset=40)
+    meta["n_union"] = int(len(urec))
+    meta["union_words_sha256"] = hashlib.sha256(np.ascontiguousarray(urec["word"]).tobytes()).hexdigest()
+    meta["union_freqs_sha256"] = hashlib.sha256(np.ascontiguousarray(urec["freq"]).tobytes()).hexdigest()
+    with open(os.path.join(tmp, "map0.txt"), "wb") as f:
+        sh("glistquery L/%s_0_%d.list -l %s" % (names[1], k, cur), tmp, stdout=f)
+    with open(os.path.join(tmp, "map0.txt"), "rb") as f:
+        meta["mapped_sample"] = names[1]
+        meta["mapped_sha256"] = hashlib.sha256(f.read()).hexdigest()
+    for run, flags in flag_sets.items():
+        rd = os.path.join(out, run)
+        os.makedirs(rd)
+        for fn in os.listdir(tmp):
+            if fn.startswith(("chi2_results_", "log.txt")) or fn.endswith(("_MLdf.csv", ".pkl")):
+                os.remove(os.path.join(tmp, fn))
+        t0 = time.time()
+        with open(os.path.join(tmp, "stderr_%s.txt" % run), "w") as err:
+            subprocess.run([sys.executable, os.path.join(HERE, "ref_shim.py"), "modeling", "data.pheno", "-nt", str(nt),
+                            "-l", str(k)] + flags, cwd=tmp, env=ENV, stderr=err, stdout=err)
+        kept = []
+        for fn in sorted(os.listdir(tmp)):
+            if fn.startswith("chi2_results_") or fn.endswith("_MLdf.csv"):
+                with open(os.path.join(tmp, fn), "rb") as f, gzip.GzipFile(os.path.join(rd, fn + ".gz"), "wb", mtime=0) as g:
+                    g.write(f.read())
+                kept.append(fn)
+        meta["runs"][run] = {"flags": flags, "outputs": kept, "reference_wall_s": round(time.time() - t0, 1)}
+    with open(os.path.join(out, "meta.json"), "w") as f:
+        json.dump(meta, f, indent=1, sort_keys=True)
+    shutil.rmtree(tmp, ignore_errors=True)
+    print(tag, "M =", meta["n_union"], meta["runs"])
 
 
 # ------------------------------------------------------------------------------------------
@@ -551,6 +625,9 @@ if __name__ == "__main__":
         run_reference_dataset("ds_omitB", GenomeSet(20, 10000, seed=11, gene_len=300), na={3, 14},
                               flags=["--omit_B_correction", "--n_kmers", "100"], fastq_for={5})
         run_reference_dataset("ds_bonf", GenomeSet(44, 6000, seed=23, gene_len=150), na={9}, flags=[])
+    if "atrich" in what:
+        run_reference_dataset_regenerated("ds_atrich", dict(n_samples=60, length=1_000_000, seed=29, gene_len=2000, gc=0.29, contigs=6),
+                                          na={4}, flag_sets={"bonf": [], "omitB": ["--omit_B_correction"]})
     if "chi2" in what:
         gen_chi2_kat()
     if "welch" in what:

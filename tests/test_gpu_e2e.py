@@ -109,6 +109,97 @@ def test_modeling_and_prediction_end_to_end(tmp_path, tag, extra):
     assert r.stdout.split()[0] == "13"
 
 
+def test_at_rich_multi_contig_set_matches_the_reference(tmp_path, oracle):
+    """every other golden set is uniform ACGT.  60 x 1 Mbp at 29 % GC (the reference's example
+    organism, C. difficile), six contigs per genome with assembler-style headers: the genomes are regenerated from
+    the parameters in meta.json (sha256 checked), the lists must hash to glistmaker's .list files, the union to
+    glistcompare's, one mapping to glistquery's text, and `modeling` with and without --omit_B_correction must write
+    the reference's result tables (unmodified modeling.py through oracle/ref_shim.py, 37-39 s per run on 8 cores)."""
+    import gzip
+    import hashlib
+    import json
+    from helpers import GOLDEN
+    from phenotypeseeker_amd.engine import PskContext
+    from phenotypeseeker_amd.synth import GenomeSet
+    gd = os.path.join(GOLDEN, "ds_atrich")
+    with open(os.path.join(gd, "meta.json")) as f:
+        meta = json.load(f)
+    gs = GenomeSet(**meta["synth"])
+    k = meta["k"]
+    names = []
+    for i in range(gs.n):
+        name, fa = gs.sample(i)
+        names.append(name)
+        assert hashlib.sha256(fa).hexdigest() == meta["inputs_sha256"][name]
+        with open(os.path.join(tmp_path, name + ".fasta"), "wb") as f:
+            f.write(fa)
+    with PskContext(0) as ctx:
+        ctx.begin(k, gs.n)
+        nu, nt = ctx.count_kmers_files(0, [os.path.join(tmp_path, n + ".fasta") for n in names], 4)
+        for i, n in enumerate(names):
+            m = meta["lists"][n]
+            assert (nu[i], nt[i]) == (m["n_unique"], m["n_total"]), n
+            if i % 6 == 0:
+                w, f = ctx.get_list(i, nu[i])
+                assert hashlib.sha256(oracle.list_bytes(k, w, f)).hexdigest() == m["sha256"], n
+        assert ctx.build_presence() == meta["n_union"]
+        uw = ctx.get_union()
+        assert hashlib.sha256(uw.tobytes()).hexdigest() == meta["union_words_sha256"]
+        ms = names.index(meta["mapped_sample"])
+        counts = ctx.lookup_counts(ms, uw)
+        from phenotypeseeker_amd import formats
+        kmers = formats.words_to_kmers(uw, k)
+        txt = "".join("%s\t%d\n" % kc for kc in zip(kmers, counts.tolist()))
+        assert hashlib.sha256(txt.encode()).hexdigest() == meta["mapped_sha256"]
+        # summed frequencies of the union (glistcompare -u adds them)
+        tot = np.zeros(len(uw), dtype=np.uint64)
+        for i in range(gs.n):
+            tot += ctx.lookup_counts(i, uw)
+        assert hashlib.sha256(tot.astype(np.uint32).tobytes()).hexdigest() == meta["union_freqs_sha256"]
+    import shutil
+    shutil.copy(os.path.join(gd, "data.pheno"), os.path.join(tmp_path, "data.pheno"))
+    for run, info in meta["runs"].items():
+        for fn in os.listdir(tmp_path):
+            if fn.startswith("chi2_results_") or fn.endswith("_MLdf.csv"):
+                os.remove(os.path.join(tmp_path, fn))
+        _run(tmp_path, ["modeling", "data.pheno"] + info["flags"])
+        with gzip.open(os.path.join(gd, run, "chi2_results_Pheno.tsv.gz"), "rt") as f:
+            ref = [tuple(l.rstrip("\n").split("\t")) for l in f]
+        head2, got = read_results_tsv("chi2_results_Pheno.tsv")
+        assert tuple(head2) == ref[0] and sorted(got) == sorted(ref[1:]), run
+        assert [g[2] for g in got] == [r[2] for r in ref[1:]], run               # the p-string order
+        with gzip.open(os.path.join(gd, run, "chi2_results_Pheno_top1000.tsv.gz"), "rt") as f:
+            ref_top = [l.rstrip("\n").split("\t") for l in f][1:]
+        _, got_top = read_results_tsv("chi2_results_Pheno_top1000.tsv")
+        assert [g[2] for g in got_top] == [r[2] for r in ref_top], run
+        with gzip.open(os.path.join(gd, run, "Pheno_MLdf.csv.gz"), "rt") as f:
+            ref_csv = list(csv.reader(f))
+        with open("Pheno_MLdf.csv") as f:
+            got_csv = list(csv.reader(f))
+        assert [r[0] for r in got_csv] == [r[0] for r in ref_csv] and [r[-2:] for r in got_csv] == [r[-2:] for r in ref_csv]
+        if len(ref) - 1 <= 1000:      # no tie class cut by the top-n boundary: the selected k-mers are the same set
+            assert sorted(got_csv[0][1:-2]) == sorted(ref_csv[0][1:-2])
+
+
+def test_cfg1_example_dataset(tmp_path):
+    """BASELINE config 1 (the reference's C. difficile example, /root/reference/example/test_PS_modeling.sh:12-25):
+    the 174 MB tarball is not reachable offline, so this runs only where PSK_CFG1_TARBALL points at it --
+    tools/cfg1_repro.py is the recipe (with --reference in the build container it runs the unmodified reference beside
+    the product and compares the filtered k-mer lists)."""
+    import subprocess
+    import sys
+    from helpers import ROOT
+    tarball = os.environ.get("PSK_CFG1_TARBALL")
+    if not tarball or not os.path.exists(tarball):
+        pytest.skip("PS_modeling_example_files.tar.gz is not available offline (set PSK_CFG1_TARBALL)")
+    cmd = [sys.executable, os.path.join(ROOT, "tools", "cfg1_repro.py"), tarball]
+    if os.path.isdir("/root/reference/bin"):
+        cmd.append("--reference")
+    r = subprocess.run(cmd, cwd=str(tmp_path), capture_output=True, text=True, timeout=3600)
+    assert r.returncode == 0, (r.stdout[-2000:], r.stderr[-2000:])
+    assert "chi2_results_" in r.stdout
+
+
 def test_continuous_phenotype_end_to_end(tmp_path, oracle):
     """Welch t-test + Lasso path: the written t-test rows equal the oracle's, the model explains
     the planted effect."""
