@@ -499,7 +499,8 @@ void launch_chi2(int mode, int G, dim3 grid, hipStream_t st, const ScanArgs &a)
 int pick_chi2_mode(const psk_ctx *ctx, bool weighted, double pcut, double pcut_bonf, int omit_B)
 {
     if (weighted) return 1;
-    static const int forced = [] { const char *e = getenv("PSK_CHI2_MODE"); return e ? atoi(e) : -1; }();
+    const char *env = getenv("PSK_CHI2_MODE");   // read per call: tests cross the two forms inside one process
+    const int forced = env ? atoi(env) : -1;
     if (forced == 0 || forced == 2) return forced;
     if (ctx->dense_hint >= 0) return ctx->dense_hint ? 2 : 0;
     double expect = pcut_bonf;

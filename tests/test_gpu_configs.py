@@ -1,0 +1,236 @@
+"""BASELINE.json configs 3, 4 and 5 exercised inside `pytest -m gpu`.  Config 2 has its
+full-size tests in test_gpu_parity.py, config 1 its recipe (tools/cfg1_repro.py, test_gpu_e2e.py::test_cfg1_example_dataset).
+
+Full-size workloads cannot be replayed through the oracle, so they are checked through size-independent properties and
+a CPU re-derivation of a sample of rows; the workloads that fit (config 4 at 256 genomes) are compared with the oracle
+row by row."""
+import os
+
+import numpy as np
+import pytest
+
+from helpers import read_results_tsv
+
+pytestmark = pytest.mark.gpu
+
+
+def _run(tmp, argv):
+    from phenotypeseeker_amd.cli import build_parser
+    os.chdir(tmp)
+    args = build_parser().parse_args(argv)
+    args.func(args)
+
+
+def test_cfg4_continuous_weighted_cli_run_matches_the_oracle(tmp_path, oracle):
+    """Config 4 as a workload: `modeling -w` on a continuous phenotype, 256 genomes (GSC weights from GPU MinHash
+    sketches, non-integer) -- the weighted Welch rows the CLI writes against oracle.ttest_scan run with the run's own
+    weights at 1e-8, and the Lasso model file."""
+    import joblib
+    from phenotypeseeker_amd import modeling as M
+    from phenotypeseeker_amd.synth import GenomeSet
+    n, L, k = 256, 60_000, 13
+    gs = GenomeSet(n, L, seed=404, gene_len=400, sub_rate=0.004)
+    rows, pheno = ["ID\tAddresses\tMIC"], []
+    os.chdir(tmp_path)
+    for i in range(n):
+        name, fa = gs.sample(i)
+        with open(name + ".fasta", "wb") as f:
+            f.write(fa)
+        v = "NA" if i in (7, 100) else repr(round(gs.continuous_phenotype(i), 4))
+        pheno.append(v)
+        rows.append("%s\t%s.fasta\t%s" % (name, name, v))
+    with open("data.pheno", "w") as f:
+        f.write("\n".join(rows) + "\n")
+    _run(tmp_path, ["modeling", "data.pheno", "-w", "--pvalue", "0.05"])
+    names = [gs.name(i) for i in range(n)]
+    w = np.array([M.Input.samples[nm].weight for nm in names], dtype=np.float64)
+    assert w.sum() == pytest.approx(n) and w.max() > 1.02 and w.min() < 0.98 and len(np.unique(np.round(w, 6))) > 50
+    head, got = read_results_tsv("t-test_results_MIC.tsv")
+    assert head[:3] == ["k-mer", "t-test", "p-value"] and len(got) > 100
+    wl = [oracle.count_kmers(gs.sample(i)[1], k)[0] for i in range(n)]
+    uw = oracle.union(wl)
+    bits = oracle.presence_bits(wl, uw)
+    ph = [("NA" if p == "NA" else float(p)) for p in pheno]
+    ref = oracle.ttest_scan(bits, ph, w, n, 2, n - 2, 0.05, len(uw))
+    keep = np.nonzero(ref["keep"])[0]
+    want = {oracle.word_to_kmer(uw[r], k): r for r in keep}
+    got_k = {g[0] for g in got}
+    # rows at the cut may flip between two evaluations of a weighted sum; everything else is the same set
+    assert len(got_k ^ set(want)) <= 2
+    checked = 0
+    for g in got:
+        r = want.get(g[0])
+        if r is None:
+            continue
+        # printed values are round(x, 2) / "%.2E": compare them with the oracle's at the printed precision ...
+        assert abs(float(g[1]) - ref["stat"][r]) <= 0.005 + 1e-8 * abs(ref["stat"][r]), g
+        assert abs(float(g[2]) - ref["p"][r]) <= 0.006 * ref["p"][r], g
+        assert abs(float(g[3]) - ref["mean_x"][r]) <= 0.0051 and abs(float(g[4]) - ref["mean_y"][r]) <= 0.0051
+        assert int(g[5]) == ref["n_with"][r]
+        checked += 1
+    assert checked >= len(want) - 2
+    # ... and the unrounded statistics through the library, at 1e-8
+    from phenotypeseeker_amd.engine import PskContext
+    with PskContext(0) as ctx:
+        ctx.begin(k, n)
+        ctx.count_kmers_batch(0, [gs.sample(i)[1] for i in range(n)], 4)
+        m = ctx.build_presence()
+        assert m == len(uw)
+        vals = np.array([0.0 if p == "NA" else float(p) for p in ph])
+        valid = np.array([p != "NA" for p in ph], dtype=np.uint8)
+        npass = ctx.ttest_scan(vals, valid, w, 2, n - 2, 0.05, m)
+        res = ctx.get_results(npass)
+    both = np.intersect1d(res["row"].astype(np.int64), keep)
+    assert len(both) >= len(keep) - 2 and abs(npass - len(keep)) <= 2
+    sel = np.searchsorted(res["row"].astype(np.int64), both)
+    for key in ("stat", "p", "mean_x", "mean_y"):
+        assert np.allclose(res[key][sel], ref[key][both], rtol=1e-8, atol=1e-300), key
+    pkg = joblib.load("linreg_model_MIC.pkl")
+    assert pkg["pred_scale"] == "continuous" and type(pkg["model"].best_estimator_).__name__ == "Lasso"
+
+
+def _popcount_columns(rows, n):
+    """column sums of a bit matrix [m][wpr] u64 -> per-sample counts"""
+    b = np.unpackbits(np.ascontiguousarray(rows, dtype="<u8").view(np.uint8), axis=1, bitorder="little")[:, :n]
+    return b.sum(axis=0, dtype=np.int64)
+
+
+def test_cfg3_full_size_slab_properties(oracle):
+    """Config 3, one rank's share at full size: 2,048 x 5 Mbp, k = 16, slab 0 of 8 of the balanced (quantile-cut) word
+    space.  Column sums of the matrix = list lengths inside the slab, rows strictly ascending and inside the slab, the
+    scan is idempotent and the two forms of the kernel agree, and 200 survivors re-derived on the CPU from their rows."""
+    from phenotypeseeker_amd import dist
+    from phenotypeseeker_amd.engine import PskContext
+    from phenotypeseeker_amd.synth import GenomeSet
+    n, L, k, world = 2048, 5_000_000, 16, 8
+    gs = GenomeSet(n, L, seed=12345)
+    with PskContext(0) as ctx:
+        ctx.begin(k, 1)
+        nu0, _ = ctx.count_kmers(0, gs.sample(0)[1])
+        pilot = ctx.get_list(0, nu0)[0]
+        bounds = dist.quantile_bounds(dist.pilot_points(pilot), k, world)
+        inside = int(np.searchsorted(pilot, np.uint64(bounds[1])))
+        assert abs(inside / len(pilot) - 1.0 / world) < 0.01          # the cut is where an eighth of the list ends
+        lo, hi = bounds[0], bounds[1]
+        ctx.begin(k, n, lo, hi)
+        nus = []
+        for s0 in range(0, n, 64):
+            nu, nt = ctx.count_kmers_batch(s0, [gs.sample(i)[1] for i in range(s0, min(s0 + 64, n))], 8)
+            nus += nu
+        m = ctx.build_presence()
+        _, wpr, _ = ctx.presence_shape()
+        assert wpr == 32 and m > 40_000_000
+        uw = ctx.get_union()
+        assert np.all(uw[1:] > uw[:-1]) and uw[0] >= lo and uw[-1] < hi
+        # column sums over a sixteenth of the rows at a time (the whole matrix is 11 GB)
+        sums = np.zeros(n, dtype=np.int64)
+        step = 1 << 20
+        for r0 in range(0, m, step):
+            rows = ctx.get_rows(np.arange(r0, min(r0 + step, m), dtype=np.uint64))
+            assert rows.any(axis=1).all()
+            sums += _popcount_columns(rows, n)
+        assert sums.tolist() == list(nus)
+        w0, _ = ctx.get_list(5, nus[5])
+        ow = oracle.count_kmers(gs.sample(5)[1], k)[0]
+        assert np.array_equal(w0, ow[(ow >= lo) & (ow < hi)])
+        pheno = np.array([gs.phenotype(i) for i in range(n)], dtype=np.int8)
+        m_global = 8 * m
+        a = ctx.chi2_scan(pheno, None, 2, n - 2, 0.05, False, m_global)
+        ra = ctx.get_results(a)
+        b = ctx.chi2_scan(pheno, None, 2, n - 2, 0.05, False, m_global)
+        rb = ctx.get_results(b)
+        assert a == b and a >= 100 and all(np.array_equal(ra[key], rb[key]) for key in ra)
+        os.environ["PSK_CHI2_MODE"] = "2"
+        try:
+            c = ctx.chi2_scan(pheno, None, 2, n - 2, 0.05, False, m_global)
+            rc = ctx.get_results(c)
+        finally:
+            del os.environ["PSK_CHI2_MODE"]
+        assert c == a and all(np.array_equal(ra[key], rc[key]) for key in ra)
+        pick = np.unique(np.linspace(0, a - 1, 200).astype(np.int64))
+        rows = ctx.get_rows(ra["row"][pick])
+        ref = oracle.chi2_scan(rows, pheno.tolist(), np.ones(n), n, 2, n - 2, 0.05, False, m_global)
+        assert ref["keep"].all()
+        assert np.array_equal(ref["stat"], ra["stat"][pick]) and np.array_equal(ref["p"], ra["p"][pick])
+        assert np.array_equal(ref["n_with"], ra["n_with"][pick])
+        assert np.array_equal(ra["word"][pick], uw[ra["row"][pick].astype(np.int64)])
+
+
+def _fastq_sample(codes, n_reads, read_len, seed, err=0.005):
+    """cfg-5 reads with fixed-width names, built without a Python loop over the reads."""
+    rng = np.random.default_rng(seed)
+    L = len(codes)
+    starts = rng.integers(0, L - read_len, n_reads)
+    reads = codes[starts[:, None] + np.arange(read_len)[None, :]]
+    mask = rng.random(reads.shape) < err
+    reads[mask] = rng.integers(0, 4, int(mask.sum()), dtype=np.uint8)
+    rec = np.empty((n_reads, 10 + read_len + 3 + read_len + 1), dtype=np.uint8)
+    digits = np.array(list(b"0123456789"), dtype=np.uint8)
+    idx = np.arange(n_reads)
+    rec[:, 0] = ord("@")
+    rec[:, 1] = ord("r")
+    for d in range(7):
+        rec[:, 2 + d] = digits[(idx // 10 ** (6 - d)) % 10]
+    rec[:, 9] = 10
+    rec[:, 10:10 + read_len] = np.frombuffer(b"ACGT", dtype=np.uint8)[reads]
+    rec[:, 10 + read_len] = 10
+    rec[:, 11 + read_len] = ord("+")
+    rec[:, 12 + read_len] = 10
+    rec[:, 13 + read_len:13 + 2 * read_len] = ord("I")
+    rec[:, -1] = 10
+    return rec.tobytes()
+
+
+def test_cfg5_full_size_fastq_samples_properties(tmp_path, oracle):
+    """Config 5 at full sample size: 8 samples x 2 M 150-bp reads (0.64 GB of FASTQ each, 276 M windows) through
+    psk_count_kmers_files, then the presence matrix and a scan.  Window counts, strictly ascending lists whose counts
+    add up, column sums = list lengths, the gene's k-mers found by the scan, a read prefix equal to the oracle."""
+    from phenotypeseeker_amd.engine import PskContext
+    from phenotypeseeker_amd.synth import GenomeSet
+    n, reads, rl, k = 8, 2_000_000, 150, 13
+    gs = GenomeSet(n, 5_000_000, seed=99)
+    paths = []
+    first = None
+    for i in range(n):
+        data = _fastq_sample(gs.codes(i), reads, rl, seed=[5, i])
+        if i == 0:
+            first = data[: 20000 * (13 + 2 * rl + 1)]
+        paths.append(os.path.join(tmp_path, "s%d.fastq" % i))
+        with open(paths[-1], "wb") as f:
+            f.write(data)
+        del data
+    with PskContext(0) as ctx:
+        ctx.begin(k, n)
+        nu, nt = ctx.count_kmers_files(0, paths, 8)
+        assert list(nt) == [reads * (rl - k + 1)] * n
+        ow, of, _ = oracle.count_kmers(first, k)
+        w0, f0 = ctx.get_list(0, nu[0])
+        assert np.all(w0[1:] > w0[:-1]) and int(f0.astype(np.uint64).sum()) == nt[0]
+        pos = np.searchsorted(w0, ow)
+        assert np.array_equal(w0[pos], ow) and np.all(f0[pos] >= of)      # the prefix's words are there, at least as often
+        m = ctx.build_presence()
+        uw = ctx.get_union()
+        assert m == len(uw) and np.all(uw[1:] > uw[:-1])
+        sums = np.zeros(n, dtype=np.int64)
+        for r0 in range(0, m, 1 << 21):
+            sums += _popcount_columns(ctx.get_rows(np.arange(r0, min(r0 + (1 << 21), m), dtype=np.uint64)), n)
+        assert sums.tolist() == list(nu)
+        assert np.array_equal(ctx.lookup_counts(0, w0[::1001]), f0[::1001])
+        pheno = np.array([gs.phenotype(i) for i in range(n)], dtype=np.int8)
+        npass = ctx.chi2_scan(pheno, None, 2, n - 2, 0.05, True, m)
+        res = ctx.get_results(npass)
+        if npass:
+            rows = ctx.get_rows(res["row"])
+            ref = oracle.chi2_scan(rows, pheno.tolist(), np.ones(n), n, 2, n - 2, 0.05, True, m)
+            assert ref["keep"].all() and np.array_equal(ref["stat"], res["stat"]) and np.array_equal(ref["n_with"], res["n_with"])
+        some = ctx.get_rows(np.arange(0, m, 997, dtype=np.uint64))
+        ref = oracle.chi2_scan(some, pheno.tolist(), np.ones(n), n, 2, n - 2, 0.05, True, m)
+        kept = np.nonzero(ref["keep"])[0] * 997
+        assert np.array_equal(np.intersect1d(res["row"].astype(np.int64), np.arange(0, m, 997)), kept)
+        # reads at 60x cover the 2-kbp gene completely: its k-mers are rows, and they split the samples by carrier status
+        gene_words = np.unique(oracle.count_kmers(b">g\n" + bytes(np.frombuffer(b"ACGT", dtype=np.uint8)[gs.gene]) + b"\n", k)[0])
+        carriers = sum(gs.has_gene(i) for i in range(n))
+        gpos = np.searchsorted(uw, gene_words)
+        assert np.array_equal(uw[gpos], gene_words)
+        grow = ctx.get_rows(gpos.astype(np.uint64))
+        assert (np.unpackbits(grow.view(np.uint8), axis=1, bitorder="little").sum(axis=1) >= carriers).all()
