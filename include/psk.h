@@ -307,6 +307,11 @@ int psk_dev_copy(psk_ctx *ctx, void *dst, const void *src, uint64_t bytes, int k
  * breaks collapsed to '\n', everything else dropped).  Returns the length written (<= len), or
  * a negative code.  Exposed for tests of the tokeniser contract. */
 int64_t psk_frame_sequence(const uint8_t *bytes, size_t len, uint8_t *out, size_t out_cap);
+/* The same stream as the GPU framing kernels produce it (the batch counters frame FASTA and four-line FASTQ on the
+ * device, csrc/frame_gpu.hip): identical except that runs of window breaks are not collapsed.  Returns the length
+ * written; PSK_ESTATE when the input is FASTQ that is not four lines per record (the host state machine frames
+ * those).  For tests of the tokeniser contract. */
+int64_t psk_frame_sequence_gpu(psk_ctx *ctx, const uint8_t *bytes, size_t len, uint8_t *out, size_t out_cap);
 
 #ifdef __cplusplus
 }

@@ -70,6 +70,7 @@ _SIGNATURES = {
                                         c.c_void_p, c.c_void_p, c.c_int, c.c_int, c.c_int, c.c_uint32, c.c_void_p,
                                         c.c_void_p]),
     "psk_frame_sequence": (c.c_int64, [c.c_char_p, c.c_size_t, c.c_void_p, c.c_size_t]),
+    "psk_frame_sequence_gpu": (c.c_int64, [c.c_void_p, c.c_char_p, c.c_size_t, c.c_void_p, c.c_size_t]),
     "psk_device_count": (c.c_int, []),
     "psk_comm_unique_id": (c.c_int, [c.c_void_p, c.c_void_p, c.c_int]),
     "psk_comm_init": (c.c_int, [c.c_void_p, c.c_void_p, c.c_int, c.c_int, c.c_int]),

@@ -125,7 +125,7 @@ extern "C" void psk_free(psk_ctx *ctx)
     if (ctx->copy_stream) (void)hipStreamSynchronize(ctx->copy_stream);
     for (CountLane &L : ctx->lane) {
         DevBuf *lb[] = {&L.raw, &L.keysA, &L.keysB, &L.starts, &L.cnt, &L.sk_cand, &L.sk_out,
-                        &L.dc_part, &L.dc_wgoff, &L.dc_cnt, &L.dc_meta, &L.dc_mtemp};
+                        &L.dc_part, &L.dc_wgoff, &L.dc_cnt, &L.dc_meta, &L.dc_mtemp, &L.rawin, &L.fr_scratch};
         for (DevBuf *b : lb) dev_release(*b);
         if (L.pinned_cnt) (void)hipHostFree(L.pinned_cnt);
         if (L.sk_host) (void)hipHostFree(L.sk_host);
@@ -134,8 +134,10 @@ extern "C" void psk_free(psk_ctx *ctx)
         if (L.done) (void)hipEventDestroy(L.done);
         if (L.raw_ready) (void)hipEventDestroy(L.raw_ready);
         if (L.raw_free) (void)hipEventDestroy(L.raw_free);
+        if (L.up_done) (void)hipEventDestroy(L.up_done);
     }
     if (ctx->copy_stream) (void)hipStreamDestroy(ctx->copy_stream);
+    if (ctx->frame_stream) { (void)hipStreamSynchronize(ctx->frame_stream); (void)hipStreamDestroy(ctx->frame_stream); }
     if (ctx->sketch_stream) { (void)hipStreamSynchronize(ctx->sketch_stream); (void)hipStreamDestroy(ctx->sketch_stream); }
     if (ctx->pinned) (void)hipHostFree(ctx->pinned);
     if (ctx->scan_pinned) (void)hipHostFree(ctx->scan_pinned);

@@ -1,0 +1,465 @@
+// Record framing on the GPU (the host half of a1's tokeniser, DESIGN.md "Tokeniser contract"): raw FASTA / FASTQ
+// file bytes in, the clean stream of kmer_count.hip out (bases kept, window breaks as '\n', everything else
+// dropped) -- so that the host only moves file bytes into pinned memory.  Replaces the sequential byte state machine
+// frame_sequence_counting() for the two shapes real inputs have; anything else stays with the host machine.
+//
+// FASTA.  Once the first record has started the machine has two states, header and sequence, and three byte
+// classes: '>' always leaves it in header, '\n' always in sequence, anything else changes nothing.  The state in
+// front of a byte is therefore decided by the LAST '>' or '\n' before it -- a "last marker" scan:
+//   fa_summary_kernel   per 4-KB tile: type of its last marker, bytes it emits if entered in sequence / in header
+//   frame_scan_kernel   one workgroup: entry state and output offset of every tile (the summaries compose
+//                       associatively), total = length of the clean stream, the '\n' padding behind it
+//   fa_emit_kernel      per tile again: entry state of every thread from wave ballots, bytes compacted through LDS
+// FASTQ.  Four-line records: the type of a line is its index mod 4, the index a count of the newlines before it:
+//   fq_lines_kernel     newlines per tile                    -> scan -> first line index of every tile
+//   fq_count_kernel     bytes emitted per tile, and the checks that make the line arithmetic equal to the state
+//                       machine: every header line starts with '@', every separator line with '+'
+//                       -> scan -> offsets;  fq_emit_kernel  compaction as above
+//   A file that fails a check (multi-line FASTQ, blank lines between records) is framed by the host machine.
+// Unlike the host machine the kernels do not collapse runs of breaks: '\n' '\n' costs a byte, not a window.
+// Byte shuffling at HBM speed (two reads, one write of the file): no MFMA.
+#include "dev_utils.h"
+#include "psk_internal.h"
+
+namespace {
+
+constexpr int FR_THREADS = 256;
+constexpr int FR_BPT = 16;                       // bytes per thread: one 16-byte load
+constexpr int FR_TILE = FR_THREADS * FR_BPT;     // 4096
+
+enum { MK_NONE = 0, MK_GT = 1, MK_NL = 2 };
+
+__device__ __forceinline__ bool is_base(uint32_t c)
+{
+    const uint32_t x = c | 0x20u;
+    return x == 'a' || x == 'c' || x == 'g' || x == 't' || x == 'u';
+}
+
+// what a byte emits in sequence text: 0 nothing (control bytes), else the byte to write (the base, or '\n' for a break)
+__device__ __forceinline__ uint32_t seq_out(uint32_t c)
+{
+    if (is_base(c)) return c;
+    return c < 32u ? 0u : (uint32_t)'\n';
+}
+
+struct Bytes16 {
+    uint32_t w[4];
+    __device__ __forceinline__ uint32_t at(int j) const { return (w[j >> 2] >> ((j & 3) * 8)) & 0xffu; }
+};
+
+// the thread's 16 bytes; positions at or beyond `len` read as 0x01 (a control byte: emits nothing, marks nothing)
+__device__ __forceinline__ Bytes16 load16(const uint8_t *__restrict__ raw, uint64_t len, uint64_t pos)
+{
+    Bytes16 b;
+    if (pos + FR_BPT <= len) {
+        const uint4 v = *reinterpret_cast<const uint4 *>(raw + pos);
+        b.w[0] = v.x; b.w[1] = v.y; b.w[2] = v.z; b.w[3] = v.w;
+    } else {
+#pragma unroll
+        for (int q = 0; q < 4; q++) {
+            uint32_t x = 0;
+#pragma unroll
+            for (int e = 0; e < 4; e++) {
+                const uint64_t p = pos + 4 * q + e;
+                x |= (uint32_t)(p < len ? raw[p] : (uint8_t)1) << (8 * e);
+            }
+            b.w[q] = x;
+        }
+    }
+    return b;
+}
+
+// ---- FASTA ------------------------------------------------------------------------------------------------------
+struct FaThread {
+    uint32_t last;      // MK_* of the thread's last marker
+    uint32_t cnt_seq;   // bytes emitted when the thread is entered in sequence state
+    uint32_t cnt_hdr;   // ... in header state
+};
+
+// state: true = header.  Emits through `put(byte)`.
+template <class P>
+__device__ __forceinline__ bool fa_walk(const Bytes16 &b, bool hdr, P &&put)
+{
+#pragma unroll
+    for (int j = 0; j < FR_BPT; j++) {
+        const uint32_t c = b.at(j);
+        if (hdr) {
+            if (c == '\n') { put((uint32_t)'\n'); hdr = false; }
+        } else if (c == '>') {
+            put((uint32_t)'\n');
+            hdr = true;
+        } else {
+            const uint32_t o = seq_out(c);
+            if (o) put(o);
+        }
+    }
+    return hdr;
+}
+
+__device__ __forceinline__ FaThread fa_thread(const Bytes16 &b)
+{
+    FaThread t;
+    uint32_t cs = 0, ch = 0;
+    fa_walk(b, false, [&](uint32_t) { cs++; });
+    fa_walk(b, true, [&](uint32_t) { ch++; });
+    t.cnt_seq = cs;
+    t.cnt_hdr = ch;
+    t.last = MK_NONE;
+#pragma unroll
+    for (int j = 0; j < FR_BPT; j++) {
+        const uint32_t c = b.at(j);
+        if (c == '>') t.last = MK_GT;
+        else if (c == '\n') t.last = MK_NL;
+    }
+    return t;
+}
+
+// entry state of every thread of the workgroup (true = header) given the tile's entry state; lds: 2 * (FR_THREADS / 64)
+__device__ __forceinline__ bool fa_entry_state(uint32_t last, bool tile_hdr, uint32_t *lds)
+{
+    const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
+    const uint64_t has = __ballot(last != MK_NONE), gt = __ballot(last == MK_GT);
+    // the wave's own last marker, for the waves behind it
+    if (lane == 0) {
+        lds[wid] = has ? 1u : 0u;
+        lds[FR_THREADS / 64 + wid] = has ? (uint32_t)((gt >> (63 - __builtin_clzll(has))) & 1ull) : 0u;
+    }
+    __syncthreads();
+    bool st = tile_hdr;
+    for (int w = 0; w < wid; w++)
+        if (lds[w]) st = lds[FR_THREADS / 64 + w] != 0;
+    const uint64_t below = has & psk_lanemask_lt(lane);
+    if (below) st = (gt >> (63 - __builtin_clzll(below))) & 1ull;
+    __syncthreads();
+    return st;
+}
+
+// per tile: {last marker, bytes if entered in sequence, bytes if entered in header, -}
+__global__ __launch_bounds__(FR_THREADS) void fa_summary_kernel(const uint8_t *__restrict__ raw, uint64_t len,
+                                                                 uint4 *__restrict__ summary)
+{
+    __shared__ uint32_t lds[2 * (FR_THREADS / 64)];
+    __shared__ uint32_t red[2][FR_THREADS / 64];
+    const uint64_t pos = ((uint64_t)blockIdx.x * FR_THREADS + threadIdx.x) * FR_BPT;
+    const FaThread t = fa_thread(load16(raw, len, pos));
+    // entered in sequence / in header: the threads up to the first marker follow the tile's entry state
+    const bool st_s = fa_entry_state(t.last, false, lds);
+    const bool st_h = fa_entry_state(t.last, true, lds);
+    uint32_t cs = st_s ? t.cnt_hdr : t.cnt_seq, ch = st_h ? t.cnt_hdr : t.cnt_seq;
+#pragma unroll
+    for (int d = 32; d >= 1; d >>= 1) { cs += __shfl_xor(cs, d, 64); ch += __shfl_xor(ch, d, 64); }
+    const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
+    const uint64_t has = __ballot(t.last != MK_NONE), gt = __ballot(t.last == MK_GT);
+    __shared__ uint32_t wlast[FR_THREADS / 64];
+    if (lane == 0) {
+        red[0][wid] = cs;
+        red[1][wid] = ch;
+        wlast[wid] = has ? (((gt >> (63 - __builtin_clzll(has))) & 1ull) ? MK_GT : MK_NL) : MK_NONE;
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        uint32_t a = 0, b = 0, last = MK_NONE;
+        for (int w = 0; w < FR_THREADS / 64; w++) { a += red[0][w]; b += red[1][w]; if (wlast[w] != MK_NONE) last = wlast[w]; }
+        summary[blockIdx.x] = make_uint4(last, a, b, 0u);
+    }
+}
+
+// One workgroup.  mode 0 (FASTA): summary[t] = {last marker, bytes if entered in sequence, bytes if entered in
+// header}: writes entry[t] = {entry state, output offset}.  mode 1: summary[t].x = a count: entry[t] = {exclusive
+// sum, -} (used for the newline counts and, again, for the byte counts of FASTQ tiles).  total_out[0] = the total;
+// pad != nullptr: 64 '\n' behind the clean stream.  host_out (pinned) receives {total, flags[0]}.
+__global__ __launch_bounds__(1024) void frame_scan_kernel(const uint4 *__restrict__ summary, uint32_t n_tiles, int mode,
+                                                          uint2 *__restrict__ entry, uint8_t *__restrict__ pad,
+                                                          const uint32_t *__restrict__ flags, uint64_t *__restrict__ host_out)
+{
+    __shared__ uint32_t lds[16];
+    __shared__ uint32_t w_has[16], w_gt[16];
+    const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
+    uint32_t carry = 0;
+    bool carry_hdr = false;   // FASTA: the file starts at its first '>' in "sequence" state (that byte opens the header)
+    for (uint32_t t0 = 0; t0 < n_tiles; t0 += 1024) {
+        const uint32_t t = t0 + threadIdx.x;
+        const uint4 s = t < n_tiles ? summary[t] : make_uint4(0u, 0u, 0u, 0u);
+        bool hdr = false;
+        uint32_t cnt = s.x;
+        if (mode == 0) {
+            // entry state: last marker of the tiles before this one in the chunk, else the carry
+            const uint64_t has = __ballot(s.x != MK_NONE), gt = __ballot(s.x == MK_GT);
+            if (lane == 0) {
+                w_has[wid] = has ? 1u : 0u;
+                w_gt[wid] = has ? (uint32_t)((gt >> (63 - __builtin_clzll(has))) & 1ull) : 0u;
+            }
+            __syncthreads();
+            hdr = carry_hdr;
+            for (int w = 0; w < wid; w++)
+                if (w_has[w]) hdr = w_gt[w] != 0;
+            const uint64_t below = has & psk_lanemask_lt(lane);
+            if (below) hdr = (gt >> (63 - __builtin_clzll(below))) & 1ull;
+            bool next = carry_hdr;
+            for (int w = 0; w < 16; w++)
+                if (w_has[w]) next = w_gt[w] != 0;
+            __syncthreads();
+            carry_hdr = next;
+            cnt = hdr ? s.z : s.y;
+        }
+        uint32_t all;
+        const uint32_t ex = psk_block_excl_scan_u32<1024>(cnt, &all, lds);
+        if (t < n_tiles) entry[t] = make_uint2(mode == 0 ? (hdr ? 1u : 0u) : carry + ex, carry + ex);
+        carry += all;
+    }
+    if (pad && threadIdx.x < 64) pad[(uint64_t)carry + threadIdx.x] = '\n';
+    if (threadIdx.x == 0 && host_out) { host_out[0] = carry; host_out[1] = flags ? flags[0] : 0u; }
+}
+
+// compaction of a tile's bytes: every thread stores what it emits at its exclusive offset in an LDS stage, the
+// workgroup copies the stage out with consecutive threads on consecutive bytes
+struct Emitter {
+    uint8_t *stage;
+    uint32_t at;
+    __device__ __forceinline__ void operator()(uint32_t c) { stage[at++] = (uint8_t)c; }
+};
+
+__global__ __launch_bounds__(FR_THREADS) void fa_emit_kernel(const uint8_t *__restrict__ raw, uint64_t len,
+                                                              const uint2 *__restrict__ entry, uint8_t *__restrict__ clean)
+{
+    __shared__ uint32_t lds[2 * (FR_THREADS / 64)];
+    __shared__ uint32_t scan_lds[FR_THREADS / 64];
+    __shared__ uint8_t stage[FR_TILE];
+    const uint64_t pos = ((uint64_t)blockIdx.x * FR_THREADS + threadIdx.x) * FR_BPT;
+    const Bytes16 b = load16(raw, len, pos);
+    const FaThread t = fa_thread(b);
+    const uint2 e = entry[blockIdx.x];
+    const bool hdr = fa_entry_state(t.last, e.x != 0, lds);
+    uint32_t total;
+    const uint32_t off = psk_block_excl_scan_u32<FR_THREADS>(hdr ? t.cnt_hdr : t.cnt_seq, &total, scan_lds);
+    Emitter em{stage, off};
+    fa_walk(b, hdr, em);
+    __syncthreads();
+    uint8_t *dst = clean + e.y;
+    for (uint32_t i = threadIdx.x; i < total; i += FR_THREADS) dst[i] = stage[i];
+}
+
+// ---- FASTQ (four-line records) --------------------------------------------------------------------------------------
+__global__ __launch_bounds__(FR_THREADS) void fq_lines_kernel(const uint8_t *__restrict__ raw, uint64_t len, uint4 *__restrict__ summary)
+{
+    __shared__ uint32_t red[FR_THREADS / 64];
+    const uint64_t pos = ((uint64_t)blockIdx.x * FR_THREADS + threadIdx.x) * FR_BPT;
+    const Bytes16 b = load16(raw, len, pos);
+    uint32_t c = 0;
+#pragma unroll
+    for (int j = 0; j < FR_BPT; j++) c += b.at(j) == '\n';
+#pragma unroll
+    for (int d = 32; d >= 1; d >>= 1) c += __shfl_xor(c, d, 64);
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = c;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        uint32_t s = 0;
+        for (int w = 0; w < FR_THREADS / 64; w++) s += red[w];
+        summary[blockIdx.x] = make_uint4(s, 0u, 0u, 0u);
+    }
+}
+
+// line = index of the line the thread's first byte is on; first: that byte is the first of its line.
+// Line types: 0 header, 1 sequence, 2 separator, 3 quality.  Returns false when a header line does not start with
+// '@' or a separator line not with '+' (the line arithmetic then differs from the state machine).
+template <class P>
+__device__ __forceinline__ bool fq_walk(const Bytes16 &b, uint64_t pos, uint64_t len, uint32_t line, bool first, P &&put)
+{
+    bool ok = true;
+#pragma unroll
+    for (int j = 0; j < FR_BPT; j++) {
+        const uint32_t c = b.at(j);
+        const uint32_t ty = line & 3u;
+        if (pos + j < len) {
+            if (first) {
+                if (ty == 0 && c != '@') ok = false;
+                if (ty == 2 && c != '+') ok = false;
+            }
+            if (c == '\n') {
+                if (ty == 0) put((uint32_t)'\n');   // the read's window break
+                line++;
+                first = true;
+            } else {
+                first = false;
+                if (ty == 1) {
+                    const uint32_t o = seq_out(c);
+                    if (o) put(o);
+                }
+            }
+        }
+    }
+    return ok;
+}
+
+// the thread's line index and whether its first byte starts a line: newline ranks inside the workgroup
+__device__ __forceinline__ void fq_thread_line(const uint8_t *__restrict__ raw, const Bytes16 &b, uint64_t pos, uint32_t tile_line,
+                                               uint32_t *scan_lds, uint32_t &line, bool &first)
+{
+    uint32_t c = 0;
+#pragma unroll
+    for (int j = 0; j < FR_BPT; j++) c += b.at(j) == '\n';
+    uint32_t total;
+    line = tile_line + psk_block_excl_scan_u32<FR_THREADS>(c, &total, scan_lds);
+    first = pos == 0 || raw[pos - 1] == '\n';
+}
+
+template <bool EMIT>
+__global__ __launch_bounds__(FR_THREADS) void fq_pass_kernel(const uint8_t *__restrict__ raw, uint64_t len,
+                                                              const uint2 *__restrict__ line_entry, uint4 *__restrict__ summary,
+                                                              const uint2 *__restrict__ out_entry, uint8_t *__restrict__ clean,
+                                                              uint32_t *__restrict__ flags)
+{
+    __shared__ uint32_t scan_lds[FR_THREADS / 64];
+    __shared__ uint8_t stage[EMIT ? FR_TILE : 1];   // a thread emits at most one byte per byte it reads
+    const uint64_t pos = ((uint64_t)blockIdx.x * FR_THREADS + threadIdx.x) * FR_BPT;
+    const Bytes16 b = load16(raw, len, pos);
+    uint32_t line;
+    bool first;
+    fq_thread_line(raw, b, pos, line_entry[blockIdx.x].x, scan_lds, line, first);
+    if (pos >= len) first = false;
+    uint32_t cnt = 0;
+    const bool ok = fq_walk(b, pos, len, line, first, [&](uint32_t) { cnt++; });
+    if (!ok) atomicOr(flags, 1u);
+    uint32_t total;
+    const uint32_t off = psk_block_excl_scan_u32<FR_THREADS>(cnt, &total, scan_lds);
+    if (!EMIT) {
+        if (threadIdx.x == 0) summary[blockIdx.x] = make_uint4(total, 0u, 0u, 0u);
+        return;
+    }
+    Emitter em{stage, off};
+    fq_walk(b, pos, len, line, first, em);
+    __syncthreads();
+    uint8_t *dst = clean + out_entry[blockIdx.x].y;
+    for (uint32_t i = threadIdx.x; i < total; i += FR_THREADS) dst[i] = stage[i];
+}
+
+}  // namespace
+
+// Host pre-pass of one file image (a worker thread): the input ends at its first NUL and starts at its first '>' or
+// '@'; that byte decides the format.  Returns 1 FASTA, 2 FASTQ, 0 nothing to frame (no record).
+int frame_probe(const uint8_t *bytes, size_t len, size_t *start, size_t *end)
+{
+    // `len` already stops at the first NUL when the caller has looked for it (parallel_fill); look again, cheaply, only
+    // in what the record search below touches
+    *end = len;
+    // first '>' or '@', a block at a time: the first record starts within the first bytes of any real file, and a
+    // whole-file memchr for a byte that never occurs (no '>' in a FASTQ file) costs 30 ms per 0.6 GB
+    for (size_t lo = 0; lo < len; lo += 4096) {
+        const size_t n = len - lo < 4096 ? len - lo : 4096;
+        const uint8_t *z = static_cast<const uint8_t *>(memchr(bytes + lo, 0, n));
+        const size_t m = z ? (size_t)(z - (bytes + lo)) : n;
+        const uint8_t *gt = static_cast<const uint8_t *>(m ? memchr(bytes + lo, '>', m) : nullptr);
+        const size_t gm = gt ? (size_t)(gt - (bytes + lo)) : m;
+        const uint8_t *at = static_cast<const uint8_t *>(gm ? memchr(bytes + lo, '@', gm) : nullptr);
+        if (at || gt) {
+            if (!z) {   // the input ends at its first NUL, wherever that is
+                const void *zz = memchr(bytes + lo + n, 0, len - lo - n);
+                if (zz) *end = (size_t)(static_cast<const uint8_t *>(zz) - bytes);
+            } else {
+                *end = lo + m;
+            }
+            *start = lo + (at ? (size_t)(at - (bytes + lo)) : gm);
+            return at ? 2 : 1;
+        }
+        if (z) { *end = lo + m; break; }
+    }
+    *start = *end;
+    return 0;
+}
+
+// the same when the caller knows where the first NUL is (nul_at = len if there is none)
+int frame_probe_known_end(const uint8_t *bytes, size_t nul_at, size_t *start, size_t *end)
+{
+    *end = nul_at;
+    for (size_t lo = 0; lo < nul_at; lo += 4096) {
+        const size_t n = nul_at - lo < 4096 ? nul_at - lo : 4096;
+        const uint8_t *gt = static_cast<const uint8_t *>(memchr(bytes + lo, '>', n));
+        const size_t gm = gt ? (size_t)(gt - (bytes + lo)) : n;
+        const uint8_t *at = static_cast<const uint8_t *>(gm ? memchr(bytes + lo, '@', gm) : nullptr);
+        if (at || gt) {
+            *start = lo + (at ? (size_t)(at - (bytes + lo)) : gm);
+            return at ? 2 : 1;
+        }
+    }
+    *start = nul_at;
+    return 0;
+}
+
+size_t frame_gpu_scratch_bytes(uint64_t raw_len)
+{
+    const uint64_t n_tiles = (raw_len + FR_TILE - 1) / FR_TILE + 1;
+    return (size_t)n_tiles * (16 + 8 + 8) + 256;
+}
+
+// Queues the framing of d_raw[0 .. raw_len) (format 1 / 2 as frame_probe reports, starting at the record's first
+// byte) on `stream`: clean stream into d_clean (capacity raw_len + 128), {clean length, irregular flag} into
+// host_out (pinned) when the stream reaches that point.  scratch: frame_gpu_scratch_bytes(raw_len) device bytes.
+int frame_gpu_enqueue(psk_ctx *ctx, hipStream_t stream, int format, const uint8_t *d_raw, uint64_t raw_len, uint8_t *d_clean,
+                      void *scratch, uint64_t *host_out)
+{
+    if (raw_len >= (1ull << 32)) return psk_fail(ctx, PSK_ERANGE, "sample larger than 4 GB");
+    const uint32_t n_tiles = (uint32_t)((raw_len + FR_TILE - 1) / FR_TILE);
+    uint4 *summary = static_cast<uint4 *>(scratch);
+    uint2 *entry_a = reinterpret_cast<uint2 *>(summary + n_tiles + 1);
+    uint2 *entry_b = entry_a + n_tiles + 1;
+    uint32_t *flags = reinterpret_cast<uint32_t *>(entry_b + n_tiles + 1);
+    if (n_tiles == 0) {
+        frame_scan_kernel<<<1, 1024, 0, stream>>>(summary, 0, 1, entry_a, d_clean, nullptr, host_out);
+        PSK_HIP(ctx, hipGetLastError());
+        return PSK_OK;
+    }
+    if (format == 1) {
+        fa_summary_kernel<<<n_tiles, FR_THREADS, 0, stream>>>(d_raw, raw_len, summary);
+        PSK_HIP(ctx, hipGetLastError());
+        frame_scan_kernel<<<1, 1024, 0, stream>>>(summary, n_tiles, 0, entry_a, d_clean, nullptr, host_out);
+        PSK_HIP(ctx, hipGetLastError());
+        fa_emit_kernel<<<n_tiles, FR_THREADS, 0, stream>>>(d_raw, raw_len, entry_a, d_clean);
+        PSK_HIP(ctx, hipGetLastError());
+        return PSK_OK;
+    }
+    PSK_HIP(ctx, hipMemsetAsync(flags, 0, 4, stream));
+    fq_lines_kernel<<<n_tiles, FR_THREADS, 0, stream>>>(d_raw, raw_len, summary);
+    PSK_HIP(ctx, hipGetLastError());
+    frame_scan_kernel<<<1, 1024, 0, stream>>>(summary, n_tiles, 1, entry_a, nullptr, nullptr, nullptr);
+    PSK_HIP(ctx, hipGetLastError());
+    fq_pass_kernel<false><<<n_tiles, FR_THREADS, 0, stream>>>(d_raw, raw_len, entry_a, summary, nullptr, nullptr, flags);
+    PSK_HIP(ctx, hipGetLastError());
+    frame_scan_kernel<<<1, 1024, 0, stream>>>(summary, n_tiles, 1, entry_b, d_clean, flags, host_out);
+    PSK_HIP(ctx, hipGetLastError());
+    fq_pass_kernel<true><<<n_tiles, FR_THREADS, 0, stream>>>(d_raw, raw_len, entry_a, summary, entry_b, d_clean, flags);
+    PSK_HIP(ctx, hipGetLastError());
+    return PSK_OK;
+}
+
+// The clean stream as these kernels produce it, for tests of the tokeniser contract (psk.h).
+extern "C" int64_t psk_frame_sequence_gpu(psk_ctx *ctx, const uint8_t *bytes, size_t len, uint8_t *out, size_t out_cap)
+{
+    if (!ctx) return PSK_EINVAL;
+    if ((!bytes && len) || !out) return psk_fail(ctx, PSK_EINVAL, "null buffer");
+    if (hipSetDevice(ctx->device) != hipSuccess) return psk_fail(ctx, PSK_EHIP, "hipSetDevice failed");
+    size_t st = 0, en = 0;
+    const int format = frame_probe(bytes, len, &st, &en);
+    if (format == 0) return 0;
+    const uint64_t rl = en - st;
+    DevBuf raw, clean, scratch;
+    uint64_t *res = nullptr;
+    int64_t rc = PSK_OK;
+    auto fail = [&](int code, const char *what) { rc = psk_fail(ctx, code, "%s", what); };
+    if (dev_reserve(ctx, raw, rl + 64) || dev_reserve(ctx, clean, rl + 128) || dev_reserve(ctx, scratch, frame_gpu_scratch_bytes(rl)))
+        rc = PSK_ENOMEM;
+    if (rc == PSK_OK && hipHostMalloc(reinterpret_cast<void **>(&res), 64, hipHostMallocDefault) != hipSuccess) fail(PSK_ENOMEM, "hipHostMalloc failed");
+    if (rc == PSK_OK && hipMemcpyAsync(raw.p, bytes + st, rl, hipMemcpyHostToDevice, ctx->stream) != hipSuccess) fail(PSK_EHIP, "upload failed");
+    if (rc == PSK_OK) rc = frame_gpu_enqueue(ctx, ctx->stream, format, raw.as<uint8_t>(), rl, clean.as<uint8_t>(), scratch.p, res);
+    if (rc == PSK_OK && hipStreamSynchronize(ctx->stream) != hipSuccess) fail(PSK_EHIP, "framing kernels failed");
+    if (rc == PSK_OK) {
+        if (format == 2 && res[1]) rc = psk_fail(ctx, PSK_ESTATE, "not four-line FASTQ: the host state machine frames this input");
+        else if (res[0] > out_cap) rc = psk_fail(ctx, PSK_ERANGE, "output buffer too small");
+        else if (res[0] && hipMemcpy(out, clean.p, res[0], hipMemcpyDeviceToHost) != hipSuccess) fail(PSK_EHIP, "download failed");
+        else rc = (int64_t)res[0];
+    }
+    if (res) (void)hipHostFree(res);
+    dev_release(raw);
+    dev_release(clean);
+    dev_release(scratch);
+    return rc;
+}

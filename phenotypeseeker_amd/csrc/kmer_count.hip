@@ -13,7 +13,11 @@
 #if defined(__SSE2__)
 #include <emmintrin.h>
 #endif
+#include <fcntl.h>
+#include <unistd.h>
+
 #include <atomic>
+#include <chrono>
 #include <condition_variable>
 #include <mutex>
 #include <thread>
@@ -512,55 +516,6 @@ static int frame_into(uint8_t *stage, size_t stage_cap, const uint8_t *bytes, si
     return PSK_OK;
 }
 
-// GPU half of a1: clean stream (pinned host memory) -> sorted unique words + counts in the arena
-static int count_from_stage(psk_ctx *ctx, int sample_idx, const uint8_t *stage, uint64_t clean_len, uint64_t padded)
-{
-    SampleList &L = ctx->lists[sample_idx];
-    L = SampleList();  // a re-counted sample simply takes fresh arena space
-    ctx->have_presence = false;
-    if (clean_len >= (1ull << 32)) return psk_fail(ctx, PSK_ERANGE, "sample larger than 4 Gbases");
-    PSK_TRY(dev_reserve(ctx, ctx->raw, padded));
-    PSK_HIP(ctx, hipMemcpyAsync(ctx->raw.p, stage, padded, hipMemcpyHostToDevice, ctx->stream));
-    const uint64_t cap = clean_len ? clean_len : 1;
-    PSK_TRY(dev_reserve(ctx, ctx->keysA, cap * 8));
-    PSK_TRY(dev_reserve(ctx, ctx->keysB, cap * 8));
-    PSK_TRY(dev_reserve(ctx, ctx->misc, 64));
-    uint32_t *d_n = ctx->misc.as<uint32_t>();
-    PSK_HIP(ctx, hipMemsetAsync(d_n, 0, 16, ctx->stream));
-    PSK_TRY(launch_extract(ctx, ctx->raw.as<uint8_t>(), clean_len, ctx->k, ctx->slab_lo, ctx->slab_hi,
-                           ctx->keysA.as<uint64_t>(), d_n));
-    uint32_t n32 = 0;
-    PSK_HIP(ctx, hipMemcpyAsync(&n32, d_n, 4, hipMemcpyDeviceToHost, ctx->stream));
-    PSK_HIP(ctx, hipStreamSynchronize(ctx->stream));
-    const uint64_t n = n32;
-    uint64_t nu = 0;
-    if (n > 0) {
-        uint64_t *sorted = nullptr;
-        PSK_TRY(dev_radix_sort_u64(ctx, ctx->keysA.as<uint64_t>(), ctx->keysB.as<uint64_t>(), n, 0, 2 * ctx->k, &sorted));
-        const uint32_t n_tiles = (uint32_t)div_up(n, RLE_TILE);
-        PSK_TRY(dev_reserve(ctx, ctx->flags, (size_t)n_tiles * 4));
-        PSK_TRY(dev_reserve(ctx, ctx->starts, (size_t)n_tiles * 4));
-        uint32_t *t_off = ctx->flags.as<uint32_t>(), *t_next = ctx->starts.as<uint32_t>();
-        rle_tile_kernel<<<n_tiles, RLE_THREADS, 0, ctx->stream>>>(sorted, n, nullptr, t_off, t_next);
-        PSK_HIP(ctx, hipGetLastError());
-        rle_tile_scan_kernel<<<1, 1024, 0, ctx->stream>>>(t_off, t_next, n_tiles, (uint32_t)n, nullptr, d_n + 1);
-        PSK_HIP(ctx, hipGetLastError());
-        uint32_t nu32 = 0;
-        PSK_HIP(ctx, hipMemcpyAsync(&nu32, d_n + 1, 4, hipMemcpyDeviceToHost, ctx->stream));
-        PSK_HIP(ctx, hipStreamSynchronize(ctx->stream));
-        nu = nu32;
-        PSK_TRY(arena_alloc(ctx, nu * 8, (void **)&L.words));
-        PSK_TRY(arena_alloc(ctx, nu * 4, (void **)&L.freqs));
-        rle_emit_kernel<<<n_tiles, RLE_THREADS, 0, ctx->stream>>>(sorted, n, t_off, t_next, L.words, L.freqs);
-        PSK_HIP(ctx, hipGetLastError());
-        PSK_HIP(ctx, hipStreamSynchronize(ctx->stream));
-    }
-    L.n_unique = nu;
-    L.n_total = n;
-    L.done = true;
-    return PSK_OK;
-}
-
 // ---- pipelined form of the GPU half (psk_count_kmers_batch, whole-space runs) ---------------------
 // The window count is known from the framing, so nothing has to come back from the GPU before the sort is
 // launched; the only value the host needs -- the number of unique words, for the arena allocation -- is
@@ -572,21 +527,64 @@ static int lane_prepare(psk_ctx *ctx, CountLane &L)
         PSK_HIP(ctx, hipEventCreateWithFlags(&L.done, hipEventDisableTiming));
         PSK_HIP(ctx, hipEventCreateWithFlags(&L.raw_ready, hipEventDisableTiming));
         PSK_HIP(ctx, hipEventCreateWithFlags(&L.raw_free, hipEventDisableTiming));
+        PSK_HIP(ctx, hipEventCreateWithFlags(&L.up_done, hipEventDisableTiming));
         PSK_HIP(ctx, hipHostMalloc(reinterpret_cast<void **>(&L.pinned_cnt), 64, hipHostMallocDefault));
     }
     if (!ctx->copy_stream) PSK_HIP(ctx, hipStreamCreateWithFlags(&ctx->copy_stream, hipStreamNonBlocking));
+    if (!ctx->frame_stream) PSK_HIP(ctx, hipStreamCreateWithFlags(&ctx->frame_stream, hipStreamNonBlocking));
     return PSK_OK;
 }
 
-static int chain_enqueue(psk_ctx *ctx, CountLane &L, int sample_idx, const uint8_t *stage, uint64_t clean_len,
-                         uint64_t padded, uint64_t n)
+int frame_gpu_enqueue(psk_ctx *ctx, hipStream_t stream, int format, const uint8_t *d_raw, uint64_t raw_len, uint8_t *d_clean,
+                      void *scratch, uint64_t *host_out);   // frame_gpu.hip
+size_t frame_gpu_scratch_bytes(uint64_t raw_len);
+int frame_probe(const uint8_t *bytes, size_t len, size_t *start, size_t *end);
+int frame_probe_known_end(const uint8_t *bytes, size_t nul_at, size_t *start, size_t *end);
+
+// {clean length, irregular flag} of a sample framed on the GPU land here (pinned, behind the lane's counters)
+static inline uint64_t *lane_frame_result(CountLane &L) { return reinterpret_cast<uint64_t *>(L.pinned_cnt + 8); }
+
+// Stage A of a sample on buffer set L, on the copy stream: the upload and, for raw file bytes (format 1 FASTA,
+// 2 FASTQ; frame_gpu.hip), the framing kernels that turn them into the clean stream.  format 0: `src` is a clean
+// stream the host framed, `bytes` its padded length.  L.raw_ready fires when the clean stream is in L.raw.
+static int chain_upload(psk_ctx *ctx, CountLane &L, const uint8_t *src, uint64_t bytes, int format)
+{
+    PSK_TRY(lane_prepare(ctx, L));
+    if (bytes == 0) return PSK_OK;
+    if (bytes >= (1ull << 32)) return psk_fail(ctx, PSK_ERANGE, "sample larger than 4 GB");
+    // after the last reader of this set's clean stream (the sample before last)
+    if (L.raw_used) PSK_HIP(ctx, hipStreamWaitEvent(ctx->copy_stream, L.raw_free, 0));
+    if (format == 0) {
+        PSK_TRY(dev_reserve(ctx, L.raw, bytes));
+        PSK_HIP(ctx, hipMemcpyAsync(L.raw.p, src, bytes, hipMemcpyHostToDevice, ctx->copy_stream));
+    } else {
+        PSK_TRY(dev_reserve(ctx, L.rawin, bytes + 64));
+        PSK_TRY(dev_reserve(ctx, L.raw, bytes + 128));
+        PSK_TRY(dev_reserve(ctx, L.fr_scratch, frame_gpu_scratch_bytes(bytes)));
+        PSK_HIP(ctx, hipMemcpyAsync(L.rawin.p, src, bytes, hipMemcpyHostToDevice, ctx->copy_stream));
+        // the framing kernels run on their own stream: the copy stream goes on with the next sample's upload (PCIe is
+        // the slowest stage of the ingest: ~100 us per 5-Mbp sample against ~25 us of framing and ~60 us of counting)
+        PSK_HIP(ctx, hipEventRecord(L.up_done, ctx->copy_stream));
+        PSK_HIP(ctx, hipStreamWaitEvent(ctx->frame_stream, L.up_done, 0));
+        PSK_TRY(frame_gpu_enqueue(ctx, ctx->frame_stream, format, L.rawin.as<uint8_t>(), bytes, L.raw.as<uint8_t>(), L.fr_scratch.p,
+                                  lane_frame_result(L)));
+        PSK_HIP(ctx, hipEventRecord(L.raw_ready, ctx->frame_stream));
+        return PSK_OK;
+    }
+    PSK_HIP(ctx, hipEventRecord(L.raw_ready, ctx->copy_stream));
+    return PSK_OK;
+}
+
+// Stage B: the counting chain of the sample whose clean stream stage A put (or is putting) into L.raw.
+// n = number of k-base windows (exact from the host's framing; the clean length, an upper bound, after the GPU's).
+static int chain_compute(psk_ctx *ctx, CountLane &L, int sample_idx, uint64_t clean_len, uint64_t n, bool n_exact)
 {
     ctx->lists[sample_idx] = SampleList();
     ctx->have_presence = false;
     if (clean_len >= (1ull << 32)) return psk_fail(ctx, PSK_ERANGE, "sample larger than 4 Gbases");
     L.sample = sample_idx;
     L.n = n;
-    L.exact = ctx->slab_lo == 0 && ctx->slab_hi == 0;  // no slab filter: every window yields a word
+    L.exact = n_exact && ctx->slab_lo == 0 && ctx->slab_hi == 0;  // no slab filter: every window yields a word
     L.uniq = nullptr;
     L.dense = false;
     if (n == 0) {
@@ -599,18 +597,12 @@ static int chain_enqueue(psk_ctx *ctx, CountLane &L, int sample_idx, const uint8
         }
         return PSK_OK;
     }
-    PSK_TRY(lane_prepare(ctx, L));
-    PSK_TRY(dev_reserve(ctx, L.raw, padded));
     if (!ctx->dense_mode) {
         PSK_TRY(dev_reserve(ctx, L.keysA, n * 8));
         PSK_TRY(dev_reserve(ctx, L.keysB, n * 8));
         PSK_TRY(dev_reserve(ctx, L.starts, (size_t)div_up(n, RLE_TILE) * 8));  // tile offsets | next-head positions
         PSK_TRY(dev_reserve(ctx, L.cnt, (size_t)CountLane::CNT_SLOTS * 16));
     }
-    // upload on the copy stream, after the extract of the sample that used this raw buffer before
-    if (L.raw_used) PSK_HIP(ctx, hipStreamWaitEvent(ctx->copy_stream, L.raw_free, 0));
-    PSK_HIP(ctx, hipMemcpyAsync(L.raw.p, stage, padded, hipMemcpyHostToDevice, ctx->copy_stream));
-    PSK_HIP(ctx, hipEventRecord(L.raw_ready, ctx->copy_stream));
     PSK_HIP(ctx, hipStreamWaitEvent(ctx->stream, L.raw_ready, 0));
     if (ctx->dense_mode) return dense_chain_enqueue(ctx, L, sample_idx, clean_len, n);   // 2k <= 26: no sort (dense_count.hip)
     // every sample takes a fresh pre-zeroed counter slot (a 16-byte memset per sample is a 6 us launch)
@@ -694,6 +686,11 @@ static int ensure_pinned(psk_ctx *ctx, void **buf, size_t *cap, size_t need)
     return PSK_OK;
 }
 
+static int count_batch_impl(psk_ctx *ctx, int first_sample_idx, int n, const uint8_t *const *bytes, const char *const *paths,
+                            const size_t *lens, uint64_t *n_unique, uint64_t *n_total, int n_threads, int sketch_k,
+                            int sketch_size, uint32_t sketch_seed, uint64_t *hashes_out, uint64_t *n_hashes_out);
+
+// one sample = a batch of one: the same framing (on the GPU for FASTA / four-line FASTQ) and the same chain
 extern "C" int psk_count_kmers(psk_ctx *ctx, int sample_idx, const uint8_t *bytes, size_t len, uint64_t *n_unique,
                                uint64_t *n_total)
 {
@@ -701,24 +698,9 @@ extern "C" int psk_count_kmers(psk_ctx *ctx, int sample_idx, const uint8_t *byte
     if (ctx->k == 0) return psk_fail(ctx, PSK_ESTATE, "psk_begin has not been called");
     if (sample_idx < 0 || sample_idx >= ctx->n_samples) return psk_fail(ctx, PSK_EINVAL, "sample_idx out of range");
     if (!bytes && len) return psk_fail(ctx, PSK_EINVAL, "null input");
-    PSK_HIP(ctx, hipSetDevice(ctx->device));
-    PSK_TRY(ensure_pinned(ctx, &ctx->pinned, &ctx->pinned_cap, len + 2 * EX_SEG));
-    uint64_t clean_len = 0, padded = 0;
-    uint64_t wins = 0;
-    int rc = frame_into(static_cast<uint8_t *>(ctx->pinned), ctx->pinned_cap, bytes, len, &clean_len, &padded, ctx->k, &wins);
-    if (rc) return psk_fail(ctx, rc, "framing failed");
-    if (ctx->dense_mode) {   // the one-sample form of the pipelined chain
-        if (wins >= (1ull << 32)) return psk_fail(ctx, PSK_ERANGE, "sample with more than 2^32 windows");
-        for (CountLane &L : ctx->lane) { L.sample = -1; L.sk_state = 0; }
-        PSK_TRY(chain_enqueue(ctx, ctx->lane[0], sample_idx, static_cast<uint8_t *>(ctx->pinned), clean_len, padded, wins));
-        PSK_TRY(chain_finalize(ctx, ctx->lane[0]));
-        if (ctx->copy_stream) PSK_HIP(ctx, hipStreamSynchronize(ctx->copy_stream));
-        PSK_HIP(ctx, hipStreamSynchronize(ctx->stream));
-    } else
-        PSK_TRY(count_from_stage(ctx, sample_idx, static_cast<uint8_t *>(ctx->pinned), clean_len, padded));
-    if (n_unique) *n_unique = ctx->lists[sample_idx].n_unique;
-    if (n_total) *n_total = ctx->lists[sample_idx].n_total;
-    return PSK_OK;
+    static const uint8_t none = 0;
+    const uint8_t *one = bytes ? bytes : &none;
+    return count_batch_impl(ctx, sample_idx, 1, &one, nullptr, &len, n_unique, n_total, 1, 0, 0, 0, nullptr, nullptr);
 }
 
 // Batch form: `n_threads` host threads frame samples ahead into a ring of pinned buffers while the calling
@@ -754,6 +736,47 @@ static int read_whole_file(const char *path, size_t expect, std::vector<uint8_t>
     return got == expect ? 0 : -1;
 }
 
+// Large samples (read sets: hundreds of MB) are moved into the pinned slot by several threads -- one thread copies
+// at ~10 GB/s, which was the whole cost of a 0.63-GB FASTQ sample (60 ms of 61) -- and the same threads look for the
+// NUL that ends the input.  src != nullptr: memcpy; else pread of `path`.  Returns 0, *nul_at = first NUL or len.
+static int parallel_fill(uint8_t *dst, const uint8_t *src, const char *path, size_t len, int helpers, size_t *nul_at)
+{
+    if (helpers < 1) helpers = 1;
+    if (helpers > 16) helpers = 16;
+    int fd = -1;
+    if (!src) {
+        fd = open(path, O_RDONLY);
+        if (fd < 0) return -1;
+    }
+    std::vector<size_t> nul((size_t)helpers, len);
+    std::vector<int> bad((size_t)helpers, 0);
+    const size_t slice = ((len + helpers - 1) / helpers + 4095) & ~size_t(4095);
+    auto work = [&](int h) {
+        const size_t lo = (size_t)h * slice, hi = lo + slice < len ? lo + slice : len;
+        if (lo >= hi) return;
+        if (src) memcpy(dst + lo, src + lo, hi - lo);
+        else {
+            size_t got = lo;
+            while (got < hi) {
+                const ssize_t r = pread(fd, dst + got, hi - got, (off_t)got);
+                if (r <= 0) { bad[h] = 1; return; }
+                got += (size_t)r;
+            }
+        }
+        const void *z = memchr(dst + lo, 0, hi - lo);
+        if (z) nul[h] = (size_t)(static_cast<const uint8_t *>(z) - dst);
+    };
+    std::vector<std::thread> ts;
+    for (int h = 1; h < helpers; h++) ts.emplace_back(work, h);
+    work(0);
+    for (auto &t : ts) t.join();
+    if (fd >= 0) close(fd);
+    size_t first = len;
+    for (int h = 0; h < helpers; h++) { if (bad[h]) return -1; if (nul[h] < first) first = nul[h]; }
+    *nul_at = first;
+    return 0;
+}
+
 // `paths` != nullptr: sample i is the file paths[i] of lens[i] bytes, read by the framing thread that takes it (plain
 // FASTA / FASTQ; compressed inputs come through the in-memory form after the host has inflated them)
 static int count_batch_impl(psk_ctx *ctx, int first_sample_idx, int n, const uint8_t *const *bytes, const char *const *paths,
@@ -773,8 +796,9 @@ static int count_batch_impl(psk_ctx *ctx, int first_sample_idx, int n, const uin
     PSK_HIP(ctx, hipSetDevice(ctx->device));
     if (n_threads < 1) n_threads = 1;
     if (n_threads > 16) n_threads = 16;
+    const int fill_helpers = n_threads >= 2 * n ? n_threads / n : (n == 1 ? 8 : 1);   // threads per large sample's copy
     if (n_threads > n) n_threads = n;
-    // every sample takes the pipelined path (see chain_enqueue); with a slab filter the host's window count is
+    // every sample takes the pipelined path (chain_upload / chain_compute); with a slab filter the host's window count is
     // an upper bound and the kernels read the number of kept words from device memory
     size_t max_len = 0;
     for (int i = 0; i < n; i++) {
@@ -782,21 +806,33 @@ static int count_batch_impl(psk_ctx *ctx, int first_sample_idx, int n, const uin
         if (lens[i] > max_len) max_len = lens[i];
     }
     // pinned ring: at most ~4 GiB of it (read-scale FASTQ samples are hundreds of MB each)
-    while (n_threads > 1 && (size_t)(n_threads + 2) * max_len > (4ull << 30)) n_threads--;
-    const int R = n_threads + 2;  // ring slots (the pipelined path releases a slot one sample late)
+    while (n_threads > 1 && (size_t)(n_threads + 4) * max_len > (4ull << 30)) n_threads--;
+    const int R = n_threads + 4;  // ring slots: two being uploaded / framed ahead, one whose chain is in flight, one released late
     if ((int)ctx->ring.size() < R) { ctx->ring.resize(R, nullptr); ctx->ring_cap.resize(R, 0); }
     for (int s = 0; s < R; s++) PSK_TRY(ensure_pinned(ctx, &ctx->ring[s], &ctx->ring_cap[s], max_len + 2 * EX_SEG));
+    // FASTA and four-line FASTQ are framed on the GPU (frame_gpu.hip): the worker threads then only move file bytes
+    // into pinned memory.  PSK_HOST_FRAMING=1 keeps the host state machine for everything (A/B runs, tests).
+    const bool gpu_framing = getenv("PSK_HOST_FRAMING") == nullptr;
 
     std::mutex mu;
     std::condition_variable cv;
-    std::vector<int> state(n, 0);          // 0 pending, 1 framed, -1 framing failed
-    std::vector<uint64_t> clen(n, 0), plen(n, 0), wins(n, 0);
+    std::vector<int> state(n, 0);          // 0 pending, 1 ready, -1 reading / framing failed
+    std::vector<int> fmt(n, 0);            // 0 the ring slot holds a clean stream (host framing); 1 / 2 raw FASTA / FASTQ bytes
+    std::vector<uint64_t> clen(n, 0), plen(n, 0), wins(n, 0), roff(n, 0), rlen(n, 0);
     int consumed = 0;                      // samples whose ring slot may be overwritten
     bool abort = false;
     std::atomic<int> next(0);
     const int k = ctx->k;
+    // PSK_TRACE: where the calling thread waits (stderr, one line per call)
+    const bool trace = getenv("PSK_TRACE") != nullptr;
+    double t_worker = 0, t_frame = 0, t_final = 0;
+    std::atomic<long long> t_fill_us(0);
+    const auto t_call = std::chrono::steady_clock::now();
+    auto since = [](std::chrono::steady_clock::time_point t0) {
+        return std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+    };
     auto worker = [&]() {
-        std::vector<uint8_t> file_buf;  // file image of the sample in hand (paths form)
+        std::vector<uint8_t> file_buf;  // file image of the sample in hand (paths form, host framing)
         for (;;) {
             const int i = next.fetch_add(1);
             if (i >= n) return;
@@ -805,19 +841,37 @@ static int count_batch_impl(psk_ctx *ctx, int first_sample_idx, int n, const uin
                 cv.wait(lk, [&] { return abort || consumed > i - R; });  // slot i % R is free again
                 if (abort) return;
             }
-            uint64_t c = 0, p = 0, w = 0;
-            const uint8_t *src = bytes ? bytes[i] : nullptr;
-            int rc = 0;
-            if (paths) {
-                rc = read_whole_file(paths[i], lens[i], file_buf);
-                src = file_buf.data();
+            uint8_t *slot = static_cast<uint8_t *>(ctx->ring[i % R]);
+            uint64_t c = 0, p = 0, w = 0, ro = 0, rl = 0;
+            int rc = 0, f = 0;
+            if (gpu_framing) {
+                // file bytes straight into the pinned slot (by several threads when the sample is large and threads
+                // are idle); the probe finds where the records start and end
+                size_t nul_at = lens[i];
+                const auto tf = std::chrono::steady_clock::now();
+                rc = parallel_fill(slot, paths ? nullptr : bytes[i], paths ? paths[i] : nullptr, lens[i],
+                                   lens[i] >= (32u << 20) ? fill_helpers : 1, &nul_at);
+                t_fill_us += (long long)(std::chrono::duration<double>(std::chrono::steady_clock::now() - tf).count() * 1e6);
+                if (rc == 0 && paths && lens[i] >= 2 && slot[0] == 0x1f && slot[1] == 0x8b) rc = -2;   // gzip: the caller inflates
+                if (rc == 0) {
+                    size_t st = 0, en = 0;
+                    f = frame_probe_known_end(slot, nul_at, &st, &en);   // parallel_fill has found the NUL, if any
+                    ro = st;
+                    rl = en - st;
+                }
+            } else {
+                const uint8_t *src = bytes ? bytes[i] : nullptr;
+                if (paths) {
+                    rc = read_whole_file(paths[i], lens[i], file_buf);
+                    src = file_buf.data();
+                    if (rc == 0 && lens[i] >= 2 && src[0] == 0x1f && src[1] == 0x8b) rc = -2;
+                }
+                if (rc == 0) rc = frame_into(slot, ctx->ring_cap[i % R], src, lens[i], &c, &p, k, &w);
             }
-            if (rc == 0)
-                rc = frame_into(static_cast<uint8_t *>(ctx->ring[i % R]), ctx->ring_cap[i % R], src, lens[i], &c, &p, k, &w);
             {
                 std::lock_guard<std::mutex> lk(mu);
-                clen[i] = c; plen[i] = p; wins[i] = w;
-                state[i] = rc ? -1 : 1;
+                clen[i] = c; plen[i] = p; wins[i] = w; fmt[i] = f; roff[i] = ro; rlen[i] = rl;
+                state[i] = rc == -2 ? -2 : rc ? -1 : 1;
             }
             cv.notify_all();
         }
@@ -839,34 +893,78 @@ static int count_batch_impl(psk_ctx *ctx, int first_sample_idx, int n, const uin
     };
     for (CountLane &L : ctx->lane) { L.sample = -1; L.sk_state = 0; }
     auto collect_sketch = [&](int i) -> int {
-        CountLane &L = ctx->lane[i & 1];
+        CountLane &L = ctx->lane[i % 3];
         if (wins[i] == 0) {
-            // no window of the counting k, so nothing was uploaded -- but the sketch's k may be shorter: take the
-            // clean stream from the ring slot (still held) through the synchronous route
+            // no window of the counting k, so nothing was counted -- but the sketch's k may be shorter: take the
+            // clean stream (host framing: from the ring slot, still held) through the synchronous route
             n_hashes_out[i] = 0;
             L.sk_state = 0;
             if (clen[i] == 0) return PSK_OK;
-            PSK_TRY(dev_reserve(ctx, L.raw, plen[i]));
-            PSK_HIP(ctx, hipMemcpyAsync(L.raw.p, ctx->ring[i % R], plen[i], hipMemcpyHostToDevice, ctx->stream));
+            if (fmt[i] == 0) {
+                PSK_TRY(dev_reserve(ctx, L.raw, plen[i]));
+                PSK_HIP(ctx, hipMemcpyAsync(L.raw.p, ctx->ring[i % R], plen[i], hipMemcpyHostToDevice, ctx->stream));
+            }
             L.sk_state = 2;
         }
         return sketch_collect(ctx, L, L.raw.as<uint8_t>(), clen[i], sketch_k, sketch_size, sketch_seed,
                               hashes_out + (size_t)i * sketch_size, n_hashes_out + i);
     };
-    for (int i = 0; i < n && rc == PSK_OK; i++) {
+    // stage A of sample i (waits for its worker): upload + GPU framing on the copy stream
+    auto stage_a = [&](int i) -> int {
         {
+            const auto t0 = std::chrono::steady_clock::now();
             std::unique_lock<std::mutex> lk(mu);
             cv.wait(lk, [&] { return state[i] != 0; });
+            t_worker += since(t0);
+            if (state[i] == -2)
+                return psk_fail(ctx, PSK_EINVAL, "sample %d (%s) is gzip-compressed: inflate it and use the in-memory call",
+                                first_sample_idx + i, paths[i]);
             if (state[i] < 0)
-                rc = psk_fail(ctx, PSK_ERANGE, paths ? "reading or framing sample %d (%s) failed" : "framing of sample %d failed",
-                              first_sample_idx + i, paths ? paths[i] : "");
+                return psk_fail(ctx, PSK_ERANGE, paths ? "reading or framing sample %d (%s) failed" : "framing of sample %d failed",
+                                first_sample_idx + i, paths ? paths[i] : "");
         }
-        if (rc != PSK_OK) break;
-        uint8_t *stage = static_cast<uint8_t *>(ctx->ring[i % R]);
-        if (wins[i] >= (1ull << 32)) { rc = psk_fail(ctx, PSK_ERANGE, "sample with more than 2^32 windows"); break; }
-        rc = chain_enqueue(ctx, ctx->lane[i & 1], first_sample_idx + i, stage, clen[i], plen[i], wins[i]);
+        const uint8_t *slot = static_cast<const uint8_t *>(ctx->ring[i % R]);
+        if (fmt[i]) return chain_upload(ctx, ctx->lane[i % 3], slot + roff[i], rlen[i], fmt[i]);
+        if (wins[i] >= (1ull << 32)) return psk_fail(ctx, PSK_ERANGE, "sample with more than 2^32 windows");
+        return chain_upload(ctx, ctx->lane[i % 3], slot, wins[i] ? plen[i] : 0, 0);
+    };
+    // stage B: the counting chain, once the length of the clean stream is known on the host
+    auto stage_b = [&](int i) -> int {
+        CountLane &L = ctx->lane[i % 3];
+        if (fmt[i] && rlen[i]) {
+            const auto t0 = std::chrono::steady_clock::now();
+            PSK_HIP(ctx, hipEventSynchronize(L.raw_ready));   // the GPU is busy with the chain of sample i - 1 meanwhile
+            t_frame += since(t0);
+            const uint64_t *res = lane_frame_result(L);
+            if (fmt[i] == 2 && res[1]) {
+                // not four-line FASTQ (multi-line records, blank lines): the host state machine frames this sample
+                PSK_TRY(ensure_pinned(ctx, &ctx->pinned, &ctx->pinned_cap, rlen[i] + 2 * EX_SEG));
+                uint64_t c = 0, p = 0, w = 0;
+                const int frc = frame_into(static_cast<uint8_t *>(ctx->pinned), ctx->pinned_cap,
+                                           static_cast<const uint8_t *>(ctx->ring[i % R]) + roff[i], rlen[i], &c, &p, k, &w);
+                if (frc) return psk_fail(ctx, frc, "framing of sample %d failed", first_sample_idx + i);
+                clen[i] = c; plen[i] = p; wins[i] = w; fmt[i] = 0;
+                PSK_TRY(chain_upload(ctx, L, static_cast<const uint8_t *>(ctx->pinned), w ? p : 0, 0));
+                PSK_HIP(ctx, hipEventSynchronize(L.raw_ready));   // ctx->pinned is reused by the next such sample
+                return chain_compute(ctx, L, first_sample_idx + i, c, w, true);
+            }
+            clen[i] = res[0];
+            wins[i] = res[0];   // an upper bound of the window count: sizes the buffers, the GPU counts the windows
+            return chain_compute(ctx, L, first_sample_idx + i, clen[i], wins[i], false);
+        }
+        return chain_compute(ctx, L, first_sample_idx + i, clen[i], wins[i], true);
+    };
+    // Samples i + 1 and i + 2 are uploaded and framed on the copy stream while chain i runs: the host's wait for the
+    // framed length of sample i (stage B) then finds it long done (with one sample ahead the wait sat on the critical
+    // path: 200 us per 5-Mbp sample instead of 145).
+    rc = stage_a(0);
+    if (rc == PSK_OK && n > 1) rc = stage_a(1);
+    for (int i = 0; i < n && rc == PSK_OK; i++) {
+        rc = stage_b(i);
         if (rc == PSK_OK && i > 0) {
-            rc = chain_finalize(ctx, ctx->lane[(i - 1) & 1]);  // waits for chain i - 1: its upload is done too
+            const auto t0 = std::chrono::steady_clock::now();
+            rc = chain_finalize(ctx, ctx->lane[(i - 1) % 3]);  // waits for chain i - 1: its upload is done too
+            t_final += since(t0);
             if (rc == PSK_OK) report(i - 1);
             if (rc == PSK_OK && sketch_k) rc = collect_sketch(i - 1);
             release_upto(i);
@@ -874,15 +972,18 @@ static int count_batch_impl(psk_ctx *ctx, int first_sample_idx, int n, const uin
         // the sketch of sample i: queued behind its chain, collected one sample later (after chain i + 1 has been
         // queued, so the stream never runs dry; before sample i + 2 is uploaded into this lane's clean-stream buffer)
         if (rc == PSK_OK && sketch_k && wins[i] > 0)
-            rc = sketch_enqueue(ctx, ctx->lane[i & 1], ctx->lane[i & 1].raw.as<uint8_t>(), clen[i], sketch_k, sketch_size, sketch_seed);
+            rc = sketch_enqueue(ctx, ctx->lane[i % 3], ctx->lane[i % 3].raw.as<uint8_t>(), clen[i], sketch_k, sketch_size, sketch_seed);
+        // set (i + 2) % 3 is free again: chain i - 1 has been finalised and its sketch collected
+        if (rc == PSK_OK && i + 2 < n) rc = stage_a(i + 2);
     }
     if (rc == PSK_OK && n > 0) {
-        rc = chain_finalize(ctx, ctx->lane[(n - 1) & 1]);
+        rc = chain_finalize(ctx, ctx->lane[(n - 1) % 3]);
         if (rc == PSK_OK) report(n - 1);
         if (rc == PSK_OK && sketch_k) rc = collect_sketch(n - 1);
     }
     {   // nothing of this call may still be in flight when it returns (the ring and the caller's buffers)
         const hipError_t e1 = hipStreamSynchronize(ctx->copy_stream ? ctx->copy_stream : ctx->stream);
+        if (ctx->frame_stream) (void)hipStreamSynchronize(ctx->frame_stream);
         const hipError_t e2 = hipStreamSynchronize(ctx->stream);
         if (ctx->sketch_stream) (void)hipStreamSynchronize(ctx->sketch_stream);
         if (rc == PSK_OK && (e1 != hipSuccess || e2 != hipSuccess))
@@ -896,6 +997,10 @@ static int count_batch_impl(psk_ctx *ctx, int first_sample_idx, int n, const uin
     }
     cv.notify_all();
     for (auto &t : pool) t.join();
+    if (trace)
+        fprintf(stderr, "[psk] count batch: %d samples %.1f ms; the caller waited %.1f ms for the host threads (their fills: %.1f ms "
+                        "in all), %.1f ms for uploads + framing, %.1f ms for chains\n", n, since(t_call) * 1e3, t_worker * 1e3,
+                t_fill_us.load() / 1e3, t_frame * 1e3, t_final * 1e3);
     return rc;
 }
 
@@ -1226,12 +1331,13 @@ int count_dict_impl(psk_ctx *ctx, int n, const uint8_t *const *bytes, const char
             if (paths) {
                 rc = read_whole_file(paths[i], lens[i], file_buf);
                 src = file_buf.data();
+                if (rc == 0 && lens[i] >= 2 && src[0] == 0x1f && src[1] == 0x8b) rc = -2;   // gzip: the caller inflates
             }
             if (rc == 0) rc = frame_into(static_cast<uint8_t *>(ctx->ring[i % R]), ctx->ring_cap[i % R], src, lens[i], &c, &p);
             {
                 std::lock_guard<std::mutex> lk(mu);
                 clen[i] = c; plen[i] = p;
-                state[i] = rc ? -1 : 1;
+                state[i] = rc == -2 ? -2 : rc ? -1 : 1;
             }
             cv.notify_all();
         }
@@ -1248,7 +1354,7 @@ int count_dict_impl(psk_ctx *ctx, int n, const uint8_t *const *bytes, const char
         cv.notify_all();
     };
     auto step = [&](int i) -> int {
-        CountLane &L = ctx->lane[i & 1];
+        CountLane &L = ctx->lane[i % 3];
         PSK_TRY(dev_reserve(ctx, L.raw, plen[i]));
         if (L.raw_used) PSK_HIP(ctx, hipStreamWaitEvent(ctx->copy_stream, L.raw_free, 0));
         PSK_HIP(ctx, hipMemcpyAsync(L.raw.p, ctx->ring[i % R], plen[i], hipMemcpyHostToDevice, ctx->copy_stream));
@@ -1264,13 +1370,14 @@ int count_dict_impl(psk_ctx *ctx, int n, const uint8_t *const *bytes, const char
         {
             std::unique_lock<std::mutex> lk(mu);
             cv.wait(lk, [&] { return state[i] != 0; });
-            if (state[i] < 0) rc = psk_fail(ctx, PSK_ERANGE, "reading or framing sample %d failed", i);
+            if (state[i] == -2) rc = psk_fail(ctx, PSK_EINVAL, "sample %d (%s) is gzip-compressed: inflate it and use the in-memory call", i, paths[i]);
+            else if (state[i] < 0) rc = psk_fail(ctx, PSK_ERANGE, "reading or framing sample %d failed", i);
         }
         if (rc != PSK_OK) break;
         rc = step(i);
         if (rc == PSK_OK && i > 0) {
             // the upload of sample i - 1 has to be over before its ring slot is framed into again
-            if (hipEventSynchronize(ctx->lane[(i - 1) & 1].raw_ready) != hipSuccess) rc = psk_fail(ctx, PSK_EHIP, "event wait failed");
+            if (hipEventSynchronize(ctx->lane[(i - 1) % 3].raw_ready) != hipSuccess) rc = psk_fail(ctx, PSK_EHIP, "event wait failed");
             release_upto(i);
         }
     }

@@ -47,13 +47,15 @@ struct SampleList {
     uint64_t n_multi = 0;
 };
 
-// One of the two buffer sets of the pipelined batch counter (psk_count_kmers_batch): the chain of sample i
-// runs on set i & 1 while the host finalises sample i - 1 from the other set.
+// One of the three buffer sets of the pipelined batch counter (psk_count_kmers_batch): the chain of sample i
+// runs on set i % 3 while the host finalises sample i - 1 from its set and samples i + 1, i + 2 are uploaded and
+// framed into theirs on the copy stream.
 struct CountLane {
     static constexpr uint32_t CNT_SLOTS = 4096;
     DevBuf raw, keysA, keysB, starts, cnt;
+    DevBuf rawin, fr_scratch;        // file bytes as uploaded and the tile tables of the GPU framing (frame_gpu.hip)
     uint32_t *pinned_cnt = nullptr;  // pinned host landing: [0] windows seen by the GPU, [1] unique words
-    hipEvent_t done = nullptr, raw_ready = nullptr, raw_free = nullptr;
+    hipEvent_t done = nullptr, raw_ready = nullptr, raw_free = nullptr, up_done = nullptr;
     bool raw_used = false;
     bool exact = true;               // n is exact (no slab filter); otherwise an upper bound
     uint32_t cnt_slot = 0;           // next unused 16-byte counter slot of `cnt` (zeroed CNT_SLOTS at a time)
@@ -130,8 +132,9 @@ struct psk_ctx {
     void *scan_pinned = nullptr;  // pinned staging for the scan's masks / weights
     size_t scan_pinned_cap = 0;
     void *cnt_pinned = nullptr;   // pinned landing buffer of the scan's result counters
-    CountLane lane[2];
+    CountLane lane[3];   // sample i runs on set i % 3: i + 1 and i + 2 are uploaded / framed ahead while chain i runs
     hipStream_t copy_stream = nullptr;  // uploads of the batch counter overlap the previous sample's kernels
+    hipStream_t frame_stream = nullptr; // the GPU framing of sample i + 1 runs beside upload i + 2 and chain i
     hipStream_t sketch_stream = nullptr;  // the one-workgroup sketch select runs beside the next sample's chain
 
     // presence matrix

@@ -17,6 +17,13 @@ def _ptr(a):
     return None if a is None else a.ctypes.data
 
 
+def _file_size(path):
+    try:
+        return os.stat(path).st_size
+    except OSError:
+        return 0
+
+
 class PskContext:
     def __init__(self, device=0):
         self._lib = _lib.load()
@@ -99,7 +106,7 @@ class PskContext:
         enc = [os.fsencode(p) for p in paths]
         n = len(enc)
         arr = (ctypes.c_char_p * n)(*enc)
-        sizes = (ctypes.c_size_t * n)(*[os.path.getsize(p) if os.path.exists(p) else 0 for p in paths])
+        sizes = (ctypes.c_size_t * n)(*[_file_size(p) for p in paths])
         nu = np.zeros(n, dtype=np.uint64)
         nt = np.zeros(n, dtype=np.uint64)
         k, size, seed = sketch if sketch is not None else (0, 1, 0)
@@ -442,6 +449,19 @@ class PskContext:
             self._check(self._lib.psk_count_dict_files(self._h, n, arr, sizes, int(k), _ptr(d), len(d), _ptr(out), int(n_threads)),
                         "psk_count_dict_files")
         return out
+
+
+    def frame_sequence_gpu(self, data):
+        """psk_frame_sequence_gpu: the clean stream as the device framing produces it, or None when the input is FASTQ
+        that the host state machine has to frame (not four lines per record)."""
+        data = bytes(data)
+        out = np.empty(len(data) + 128, dtype=np.uint8)
+        n = self._lib.psk_frame_sequence_gpu(self._h, data, len(data), _ptr(out), out.size)
+        if n == -5:
+            return None
+        if n < 0:
+            self._check(int(n), "psk_frame_sequence_gpu")
+        return out[:n].tobytes()
 
 
 def frame_sequence(data):

@@ -25,6 +25,7 @@ import numpy as np
 from . import dist as _dist
 from . import formats, metrics, _stats
 from .engine import PskContext
+from ._lib import PskError
 from .model import GridSearch, L1LogisticRegression, L2LogisticRegression, LassoRegression, RidgeRegression
 
 RED_BANNER = "\x1b[1;1;101m%s\x1b[0m\n"
@@ -94,19 +95,26 @@ class Samples:
         from concurrent.futures import ThreadPoolExecutor
         if chunk is None:  # about half a gigabyte of file images per call, two calls' worth in memory
             try:
-                biggest = max(os.path.getsize(s.address) for s in samples)
+                biggest = max(os.stat(s.address).st_size for s in samples[:: max(1, len(samples) // 16)])
             except OSError:
                 biggest = 1 << 29
             chunk = int(min(64, max(1, (1 << 29) // max(biggest, 1))))
         sketch = (21, 1000, 42) if cls.use_weights else None  # was: mash sketch -r <address> (:386-390): k=21, s=1000, seed 42
-        # uncompressed inputs are read by the library's own framing threads (psk_count_kmers_files): no file image
-        # passes through Python.  Anything gzip-compressed takes the in-memory route below.
-        if not any(formats.is_gzip(s.address) for s in samples):
-            for lo in range(0, len(samples), chunk):
-                part = samples[lo:lo + chunk]
-                res = ctx.count_kmers_files(lo, [s.address for s in part], n_threads, sketch=sketch)
-                cls._record_lists(part, res)
-            return
+        # uncompressed inputs are read by the library's own threads (psk_count_kmers_files): no file image passes through
+        # Python.  The library refuses a gzip-compressed file (by its magic bytes): the whole set then takes the
+        # in-memory route below, where the files are inflated first.
+        if not any(s.address.endswith(".gz") for s in samples):
+            try:
+                done = []
+                for lo in range(0, len(samples), chunk):
+                    part = samples[lo:lo + chunk]
+                    done.append((part, ctx.count_kmers_files(lo, [s.address for s in part], n_threads, sketch=sketch)))
+                for part, res in done:
+                    cls._record_lists(part, res)
+                return
+            except PskError as exc:
+                if "gzip" not in str(exc):
+                    raise
         # chunk boundaries ramp up (8, 16, 32, ...): the first read is short, later calls amortise their set-up
         bounds, lo, step = [], 0, min(chunk, 8)
         while lo < len(samples):
@@ -688,6 +696,7 @@ class phenotypes:
         # package's own (scikit-learn-free) classes, which is also what is written when scikit-learn is missing.
         model_out = self.model_fitted
         if os.environ.get("PSK_NATIVE_PKL") != "1":
+            _sklearn_warm_up(wait=True)
             try:
                 model_out = self.model_fitted.to_sklearn()
             except ImportError:
@@ -790,8 +799,33 @@ def _metric_store():
                             "Pr", "MCC", "kappa", "VME", "ME", "F1_sc")}
 
 
+_sklearn_thread = None
+
+
+def _sklearn_warm_up(wait=False):
+    """The .pkl is written as scikit-learn objects; importing scikit-learn costs 0.3-0.5 s, as much as the rest of a
+    256-genome run.  The import runs on a helper thread from the start of `modeling`, beside the counting and the
+    scan (which spend their time inside libpsk.so, outside the interpreter lock); the writer joins it."""
+    global _sklearn_thread
+    if _sklearn_thread is None:
+        import threading
+
+        def _imp():
+            try:
+                import sklearn.linear_model  # noqa: F401
+                import sklearn.model_selection  # noqa: F401
+            except ImportError:
+                pass
+        _sklearn_thread = threading.Thread(target=_imp, daemon=True)
+        _sklearn_thread.start()
+    if wait:
+        _sklearn_thread.join()
+
+
 def modeling(args):
     """The main function of `phenotypeseeker modeling` (:1624-1709)."""
+    if os.environ.get("PSK_NATIVE_PKL") != "1":
+        _sklearn_warm_up()
     _err(RED_BANNER % "######                   PhenotypeSeeker                   ######")
     _err(RED_BANNER % "######                      modeling                       ######" + "\n")
     Input.reset()

@@ -9,6 +9,7 @@ from collections import OrderedDict
 import numpy as np
 
 from . import formats
+from ._lib import PskError
 from .engine import PskContext
 
 
@@ -40,9 +41,14 @@ class Samples:
         one batched call: the library's threads read and frame the files ahead of the GPU (compressed inputs are
         inflated here first), one kernel per sample, one read-back."""
         paths = [s.address for s in samples]
-        if not any(formats.is_gzip(p) for p in paths):
-            counts = ctx.count_dict_files(paths, pheno.k, pheno.words, n_threads)
-        else:
+        counts = None
+        if not any(p.endswith(".gz") for p in paths):
+            try:
+                counts = ctx.count_dict_files(paths, pheno.k, pheno.words, n_threads)
+            except PskError as exc:       # a gzip-compressed file without the suffix: inflate on the host
+                if "gzip" not in str(exc):
+                    raise
+        if counts is None:
             counts = np.zeros((len(paths), len(pheno.words)), dtype=np.uint32)
             for lo in range(0, len(paths), 32):     # bounded memory: 32 inflated files at a time
                 part = [formats.read_sequence_file(p) for p in paths[lo:lo + 32]]

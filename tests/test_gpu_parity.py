@@ -655,6 +655,70 @@ def test_tiled_presence_build_with_thousands_of_samples(ctx, oracle, k, n, lengt
     assert np.array_equal(ctx.get_union(), uw) and np.array_equal(ctx.get_rows(np.arange(m, dtype=np.uint64)), rows)
 
 
+def _collapse(clean):
+    """runs of window breaks -> one, none in front (what the host machine writes)"""
+    out = bytearray()
+    for c in clean:
+        if c == 10 and (not out or out[-1] == 10):
+            continue
+        out.append(c)
+    return bytes(out)
+
+
+def test_gpu_framing_equals_the_host_state_machine(ctx, oracle, monkeypatch):
+    """record framing on the device (frame_gpu.hip).  On all 161 probed tokeniser cases, on FASTA
+    with every awkward byte (headers inside lines, control bytes, IUPAC codes, '>' in sequence, CRLF, no final
+    newline, text before the first record, NUL) and on four-line FASTQ the device's clean stream equals the host
+    machine's up to collapsed breaks; FASTQ that is not four lines per record is handed back to the host machine; and
+    the lists counted with device framing equal those counted with host framing and glistmaker's."""
+    from helpers import tokenizer_cases
+    from phenotypeseeker_amd.engine import frame_sequence
+    from phenotypeseeker_amd.synth import GenomeSet, fastq_reads
+    rng = np.random.default_rng(11)
+    gs = GenomeSet(3, 30_000, seed=8, gene_len=200, contigs=5)
+    extra = [gs.sample(0)[1], gs.sample(1)[1].replace(b"\n", b"\r\n"), b"junk before\n" + gs.sample(2)[1][:-1],
+             fastq_reads(gs.codes(0), 400, 100, seed=[1, 2]), fastq_reads(gs.codes(1), 50, 150, seed=[1, 3])[:-1],
+             b">only header", b">h\n", b"@r\nACGT\n+\nIIII\n", b"@r\nACGTNNACGT\n+r\n@@@@@@@@@@\n@s\nGGGGCCCC\n+\n>>>>>>>>\n",
+             b">a\nACGT>b\nGGGG\n>c\n\n\nTT\x01\x02TT\n", b">x\nACGT\x00ACGT\n", b"@r\nAC\nGT\n+\nIIII\n", b"@r\nACGT\n+\nIIII\n\n@s\nACGT\n+\nIIII\n"]
+    body = bytearray(rng.integers(1, 256, 60_000, dtype=np.uint8).tobytes())
+    extra.append(b">fuzz\n" + bytes(body))                           # every byte value but NUL, '>' and '\n' sprinkled in
+    n_gpu = n_host = 0
+    cases = [(d, k) for d, k, _ in tokenizer_cases()] + [(d, 13) for d in extra]
+    for data, k in cases:
+        want = frame_sequence(data)
+        got = ctx.frame_sequence_gpu(data)
+        if got is None:
+            n_host += 1
+            continue
+        n_gpu += 1
+        assert _collapse(got) == _collapse(want), data[:80]
+    assert n_gpu > 120 and n_host >= 2
+    assert ctx.frame_sequence_gpu(extra[-3]) is None and ctx.frame_sequence_gpu(extra[-2]) is None   # multi-line / blank-line FASTQ
+    # lists: device framing (default) against host framing and the reference's
+    for data, k, ref in tokenizer_cases():
+        if ref is None or not 1 <= k <= 32:
+            continue
+        ctx.begin(k, 1)
+        nu, nt = ctx.count_kmers_batch(0, [data], 1)
+        w, f = ctx.get_list(0, nu[0])
+        assert oracle.list_bytes(k, w, f) == ref, data[:60]
+    datas = extra + [b""]
+    for k in (13, 16):
+        ctx.begin(k, len(datas))
+        nu, nt = ctx.count_kmers_batch(0, datas, 3)
+        lists = [ctx.get_list(i, nu[i]) for i in range(len(datas))]
+        monkeypatch.setenv("PSK_HOST_FRAMING", "1")
+        ctx.begin(k, len(datas))
+        nu2, nt2 = ctx.count_kmers_batch(0, datas, 3)
+        monkeypatch.delenv("PSK_HOST_FRAMING")
+        assert list(nu) == list(nu2) and list(nt) == list(nt2)
+        for i, d in enumerate(datas):
+            a, b = ctx.get_list(i, nu2[i])
+            ow, of, ont = oracle.count_kmers(d, k)
+            assert np.array_equal(a, lists[i][0]) and np.array_equal(b, lists[i][1]), i
+            assert np.array_equal(a, ow) and np.array_equal(b, of) and nt[i] == ont, i
+
+
 @pytest.mark.parametrize("k", [11, 12, 13])
 def test_dense_counting_paths_agree_with_the_oracle(ctx, oracle, k, monkeypatch):
     """k = 11..13 counts without a sort (dense_count.hip): the presence-bit pass for buckets with few keys, the

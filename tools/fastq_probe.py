@@ -27,6 +27,22 @@ with PskContext(0) as ctx:
         dt = time.time() - t
         print("count: %.3f s  (%.2f GB/s of file bytes)  n_unique %d n_total %d" % (dt, len(data) / dt / 1e9, nu, nt), flush=True)
     assert nt == reads * (150 - k + 1), (nt, reads * (150 - k + 1))
+    os.environ["PSK_HOST_FRAMING"] = "1"
+    t = time.time()
+    nu2, nt2 = ctx.count_kmers(0, data)
+    dt = time.time() - t
+    del os.environ["PSK_HOST_FRAMING"]
+    print("host framing: %.3f s  (%.2f GB/s of file bytes)" % (dt, len(data) / dt / 1e9), flush=True)
+    assert (nu2, nt2) == (nu, nt)
+    path = "/tmp/psk_fastq_probe.fastq"
+    with open(path, "wb") as f:
+        f.write(data)
+    for rep in range(2):
+        t = time.time()
+        ctx.count_kmers_files(0, [path], 1)
+        dt = time.time() - t
+        print("from a file: %.3f s  (%.2f GB/s of file bytes)" % (dt, len(data) / dt / 1e9), flush=True)
+    os.remove(path)
     words, freqs = ctx.get_list(0, nu)
     assert int(freqs.astype(np.uint64).sum()) == nt
     assert np.all(words[1:] > words[:-1])
