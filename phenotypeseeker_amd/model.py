@@ -231,6 +231,30 @@ class GridSearch:
     def score(self, X, y):
         return self.best_estimator_.score(X, y)
 
+    def to_sklearn_shell(self):
+        """The same model as to_sklearn() builds, described for skpickle.dumps (no scikit-learn import), or None when
+        the installed scikit-learn has no template."""
+        from . import skpickle as sp
+        be = self.best_estimator_
+        if isinstance(be, L1LogisticRegression):
+            kw = dict(penalty=be.penalty, solver=be.solver, tol=be.tol, max_iter=int(be.max_iter))
+            est = sp.make("LogisticRegression", C=be.C, classes_=np.array([0, 1]), coef_=be.coef_.copy(),
+                          intercept_=be.intercept_.copy(), n_iter_=np.array([0], dtype=np.int32),
+                          n_features_in_=be.n_features_in_, **kw)
+            proto = sp.make("LogisticRegression", **kw)
+        else:
+            name = "Ridge" if isinstance(be, RidgeRegression) else "Lasso"
+            kw = dict(tol=be.tol, max_iter=int(be.max_iter))
+            est = sp.make(name, alpha=be.alpha, coef_=be.coef_.copy(), intercept_=be.intercept_,
+                          n_iter_=None if name == "Ridge" else 0, n_features_in_=be.n_features_in_, **kw)
+            proto = sp.make(name, **kw)
+        if est is None or proto is None:
+            return None
+        return sp.make("GridSearchCV", estimator=proto, param_grid=self.param_grid, cv=self.cv, best_estimator_=est,
+                       best_params_=dict(self.best_params_), best_index_=self.best_index_, best_score_=self.best_score_,
+                       cv_results_=dict(self.cv_results_), n_splits_=self.n_splits_, refit_time_=0.0, multimetric_=False,
+                       scorer_=None)
+
     def to_sklearn(self):
         """The same fitted model as real scikit-learn objects (for users whose downstream code
         insists on them); needs scikit-learn importable."""

@@ -688,22 +688,31 @@ class phenotypes:
                 summary.write("\n### Outputting the last model trained on whole data to a model file! ###\n")
             else:
                 summary.write("\n### Outputting the model to a model file! ###\n")
-        import joblib
         package = dict(self.model_package)
         # The reference's .pkl holds scikit-learn objects and its loader is a plain joblib.load (prediction.py:124-129):
-        # with scikit-learn importable the fitted model is written as the equivalent GridSearchCV / LogisticRegression
-        # / Lasso / Ridge objects, so that the file loads where this package is absent.  PSK_NATIVE_PKL=1 keeps the
-        # package's own (scikit-learn-free) classes, which is also what is written when scikit-learn is missing.
-        model_out = self.model_fitted
+        # the fitted model is written as the equivalent GridSearchCV / LogisticRegression / Lasso / Ridge objects, so
+        # that the file loads where this package is absent.  PSK_NATIVE_PKL=1 keeps the package's own
+        # (scikit-learn-free) classes, which is also what is written when scikit-learn is missing.
+        package.update({"pca": self.pca, "pred_scale": self.pred_scale})
+        blob = None
         if os.environ.get("PSK_NATIVE_PKL") != "1":
-            _sklearn_warm_up(wait=True)
-            try:
-                model_out = self.model_fitted.to_sklearn()
-            except ImportError:
-                pass
-        package.update({"model": model_out, "pca": self.pca, "pred_scale": self.pred_scale})
+            from . import skpickle
+            shell = self.model_fitted.to_sklearn_shell()          # no scikit-learn import (skpickle.py)
+            if shell is not None:
+                blob = skpickle.dumps(dict(package, model=shell))
+            else:                                                   # a scikit-learn version without a template: import it
+                try:
+                    package["model"] = self.model_fitted.to_sklearn()
+                except ImportError:
+                    package["model"] = self.model_fitted
+        else:
+            package["model"] = self.model_fitted
         with open("%s_model_%s.pkl" % (short, self.name), "wb") as fh:
-            joblib.dump(package, fh)
+            if blob is not None:
+                fh.write(blob)
+            else:
+                import joblib
+                joblib.dump(package, fh)
         self._write_model_coefficients(coeff)
         summary.close()
         coeff.close()
@@ -799,33 +808,8 @@ def _metric_store():
                             "Pr", "MCC", "kappa", "VME", "ME", "F1_sc")}
 
 
-_sklearn_thread = None
-
-
-def _sklearn_warm_up(wait=False):
-    """The .pkl is written as scikit-learn objects; importing scikit-learn costs 0.3-0.5 s, as much as the rest of a
-    256-genome run.  The import runs on a helper thread from the start of `modeling`, beside the counting and the
-    scan (which spend their time inside libpsk.so, outside the interpreter lock); the writer joins it."""
-    global _sklearn_thread
-    if _sklearn_thread is None:
-        import threading
-
-        def _imp():
-            try:
-                import sklearn.linear_model  # noqa: F401
-                import sklearn.model_selection  # noqa: F401
-            except ImportError:
-                pass
-        _sklearn_thread = threading.Thread(target=_imp, daemon=True)
-        _sklearn_thread.start()
-    if wait:
-        _sklearn_thread.join()
-
-
 def modeling(args):
     """The main function of `phenotypeseeker modeling` (:1624-1709)."""
-    if os.environ.get("PSK_NATIVE_PKL") != "1":
-        _sklearn_warm_up()
     _err(RED_BANNER % "######                   PhenotypeSeeker                   ######")
     _err(RED_BANNER % "######                      modeling                       ######" + "\n")
     Input.reset()

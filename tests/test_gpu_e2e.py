@@ -181,6 +181,46 @@ def test_at_rich_multi_contig_set_matches_the_reference(tmp_path, oracle):
             assert sorted(got_csv[0][1:-2]) == sorted(ref_csv[0][1:-2])
 
 
+def test_gzip_inputs_with_and_without_the_suffix(tmp_path):
+    """Compressed inputs are inflated on the host and take the in-memory calls; a gzip file that does not say so in its
+    name is recognised by the library (magic bytes) and the run falls back the same way: result tables and predictions
+    equal the plain run's."""
+    import gzip
+    ds = load_dataset("ds_bonf")
+    plain, packed = tmp_path / "plain", tmp_path / "packed"
+    for d in (plain, packed):
+        d.mkdir()
+        _write_dataset(ds, str(d))
+    rows = open(packed / "data.pheno").read().splitlines()
+    out = [rows[0]]
+    for j, line in enumerate(rows[1:]):
+        name, fn, ph = line.split()
+        raw = open(packed / fn, "rb").read()
+        if j % 3 == 0:      # compressed, named .gz
+            with gzip.open(packed / (fn + ".gz"), "wb") as f:
+                f.write(raw)
+            os.remove(packed / fn)
+            fn += ".gz"
+        elif j % 3 == 1:    # compressed, name unchanged
+            with gzip.open(packed / fn, "wb") as f:
+                f.write(raw)
+        out.append("\t".join([name, fn, ph]))
+    open(packed / "data.pheno", "w").write("\n".join(out) + "\n")
+    _run(plain, ["modeling", "data.pheno"])
+    _run(packed, ["modeling", "data.pheno"])
+    for fn in ("chi2_results_Pheno.tsv", "Pheno_MLdf.csv", "k-mers_and_coefficients_in_log_reg_model_Pheno.txt"):
+        assert (plain / fn).read_bytes() == (packed / fn).read_bytes(), fn
+    # the same through prediction on the samples whose file name says nothing (plain, or gzip without the suffix: the
+    # file call is refused and the run inflates them)
+    for d in (plain, packed):
+        lines = open(d / "data.pheno").read().splitlines()[1:]
+        open(d / "samples.txt", "w").write("".join("\t".join(l.split()[:2]) + "\n" for j, l in enumerate(lines) if j % 3))
+        open(d / "phenos.txt", "w").write("Pheno\tlog_reg_model_Pheno.pkl\n")
+        _run(d, ["prediction", "samples.txt", "phenos.txt"])
+    assert (plain / "predictions_Pheno.txt").read_bytes() == (packed / "predictions_Pheno.txt").read_bytes()
+    assert len((plain / "predictions_Pheno.txt").read_text().splitlines()) > 20
+
+
 def test_cfg1_example_dataset(tmp_path):
     """BASELINE config 1 (the reference's C. difficile example, /root/reference/example/test_PS_modeling.sh:12-25):
     the 174 MB tarball is not reachable offline, so this runs only where PSK_CFG1_TARBALL points at it --

@@ -10,6 +10,9 @@ import pytest
 from helpers import load_dataset, read_results_tsv
 
 
+ROOT_DIR = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
 def _write_dataset(ds, tmp):
     for name, data in ds["files"].items():
         fn = [l.split()[1] for l in open(os.path.join(ds["dir"], "data.pheno")).read().splitlines()[1:]
@@ -152,3 +155,65 @@ def test_metrics_match_sklearn():
         assert Mx.matthews(y, p) == pytest.approx(sk.matthews_corrcoef(y, p))
         assert Mx.cohen_kappa(y, p) == pytest.approx(sk.cohen_kappa_score(y, p))
         assert Mx.classification_report(y, p) == sk.classification_report(y, p, target_names=["sensitive", "resistant"])
+
+
+def test_model_files_are_scikit_learn_pickles_written_without_importing_it(tmp_path):
+    """the .pkl holds scikit-learn objects (the reference's loader is a plain joblib.load,
+    /root/reference/PhenotypeSeeker/prediction.py:124-129).  skpickle writes them from recorded class templates
+    without importing scikit-learn; a process that has scikit-learn but not this package loads the file and predicts
+    exactly what to_sklearn()'s objects (built through the real constructors) predict."""
+    import subprocess
+    import sys
+    import numpy as np
+    from phenotypeseeker_amd import model as M, skpickle
+    rng = np.random.default_rng(2)
+    X = (rng.random((30, 7)) < 0.4).astype(np.float64)
+    files = {}
+    for kind in ("logistic", "lasso", "ridge"):
+        if kind == "logistic":
+            est = M.L1LogisticRegression(C=10.0, tol=1e-4, max_iter=1000)
+            est.coef_, est.intercept_ = rng.normal(size=(1, 7)), rng.normal(size=1)
+            gs = M.GridSearch(M.L1LogisticRegression(tol=1e-4, max_iter=1000), "C", [0.1, 10.0], 3)
+            gs.best_params_ = {"C": 10.0}
+        else:
+            cls = M.LassoRegression if kind == "lasso" else M.RidgeRegression
+            est = cls(alpha=0.5)
+            est.coef_, est.intercept_ = rng.normal(size=7), float(rng.normal())
+            gs = M.GridSearch(cls(), "alpha", [2.0, 0.5], 3)
+            gs.best_params_ = {"alpha": 0.5}
+        est.n_features_in_ = 7
+        gs.best_estimator_, gs.best_index_, gs.best_score_, gs.n_splits_ = est, 1, 0.75, 3
+        gs.cv_results_ = {"mean_test_score": np.array([0.5, 0.75]), "std_test_score": np.array([0.1, 0.2]),
+                          "params": [{gs.param_name: v} for v in gs.param_grid[gs.param_name]]}
+        shell = gs.to_sklearn_shell()
+        assert shell is not None, "no template for the installed scikit-learn: run tools/make_sklearn_shells.py"
+        blob = skpickle.dumps({"model": shell, "kmers": np.array(["ACGT", "TTTT"], dtype=object), "pca": False, "pred_scale": "binary"})
+        files[kind] = os.path.join(tmp_path, kind + ".pkl")
+        with open(files[kind], "wb") as f:
+            f.write(blob)
+        np.save(os.path.join(tmp_path, kind + "_want.npy"), gs.predict(X))
+        if kind == "logistic":
+            np.save(os.path.join(tmp_path, "proba_want.npy"), gs.predict_proba(X))
+    np.save(os.path.join(tmp_path, "X.npy"), X)
+    code = ("import sys, joblib, numpy as np, warnings\n"
+            "warnings.simplefilter('error')\n"
+            "sys.path = [p for p in sys.path if 'repo' not in p and p not in ('', '.')]\n"
+            "X = np.load('X.npy')\n"
+            "for kind, cls in (('logistic', 'LogisticRegression'), ('lasso', 'Lasso'), ('ridge', 'Ridge')):\n"
+            "    pkg = joblib.load(kind + '.pkl')\n"
+            "    m = pkg['model']\n"
+            "    assert type(m).__module__ == 'sklearn.model_selection._search' and type(m.best_estimator_).__name__ == cls\n"
+            "    assert np.allclose(m.predict(X), np.load(kind + '_want.npy'), rtol=1e-12, atol=1e-12)\n"
+            "    assert list(pkg['kmers']) == ['ACGT', 'TTTT'] and pkg['pca'] is False\n"
+            "    assert m.cv_results_['params'][1] == m.best_params_ and m.get_params()['cv'] == 3\n"
+            "    repr(m); m.best_estimator_.get_params()\n"
+            "    if kind == 'logistic':\n"
+            "        assert np.allclose(m.predict_proba(X), np.load('proba_want.npy'), rtol=1e-12)\n"
+            "assert 'phenotypeseeker_amd' not in sys.modules\n")
+    env = {k: v for k, v in os.environ.items() if k != "PYTHONPATH"}
+    r = subprocess.run([sys.executable, "-c", code], cwd=str(tmp_path), env=env, capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stderr[-3000:]
+    # and the writer itself never pulled scikit-learn in
+    probe = ("import sys; sys.path.insert(0, %r); from phenotypeseeker_amd import skpickle, model; "
+             "assert skpickle.template('Lasso') is not None; assert 'sklearn' not in sys.modules" % ROOT_DIR)
+    assert subprocess.run([sys.executable, "-c", probe], timeout=120).returncode == 0
