@@ -120,7 +120,7 @@ extern "C" void psk_free(psk_ctx *ctx)
     arena_release(ctx);
     DevBuf *bufs[] = {&ctx->raw, &ctx->keysA, &ctx->keysB, &ctx->valsA, &ctx->valsB, &ctx->hist, &ctx->scan_tmp, &ctx->flags, &ctx->starts,
                       &ctx->misc, &ctx->union_words, &ctx->bits, &ctx->mask1, &ctx->phe,
-                      &ctx->slot[0].res, &ctx->slot[1].res, &ctx->res_count, &ctx->res_sorted};
+                      &ctx->slot[0].res, &ctx->slot[1].res, &ctx->res_count, &ctx->res_sorted, &ctx->lut};
     for (DevBuf *b : bufs) dev_release(*b);
     if (ctx->copy_stream) (void)hipStreamSynchronize(ctx->copy_stream);
     for (CountLane &L : ctx->lane) {

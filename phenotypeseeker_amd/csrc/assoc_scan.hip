@@ -35,6 +35,8 @@ namespace {
 #define PSK_SC_NT 1
 #endif
 constexpr int SC_THREADS = 256;
+constexpr int SC_LUT_THREADS = 1024;   // workgroup of the moment scans that keep their nibble tables in LDS (one per CU)
+constexpr size_t SC_LUT_MAX_BYTES = 100 * 1024;
 constexpr int SC_UNROLL = PSK_SC_UNROLL;
 // Survivors are appended to SC_NSEG independent segments (segment = blockIdx % SC_NSEG), each with its
 // own counter on its own 128-byte line: one shared counter serialises at ~11 ns per append (r01: a
@@ -51,6 +53,8 @@ struct ScanArgs {
     // chi2
     const uint64_t *m1, *m0;   // phenotype == 1 / == 0 masks (wpr words each)
     const double *tab;         // per-sample table of the lane-per-row pass: [wpr*64][NM] doubles (see row_moments)
+    const double *lut;         // the same table summed over every subset of each group of 4 samples (row_moments_lut)
+    int c_lut;                 // ... for the first c_lut chunks of a row; the rest of the row takes the per-sample form
     int n1, n0;                // popcounts of the masks
     double W1, W0;             // weight totals of the two phenotype classes
     // t-test
@@ -127,12 +131,15 @@ __device__ __forceinline__ double chi2_exact(double A, double B, double C, doubl
 // data cache into SGPRs (constant address space => s_load), not through LDS or the vector pipe.  A cell
 // costs 2 + NM VALU ops: the presence bit becomes 0.0 / 1.0 (v_bfe_i32 + v_and 0x3FF00000 on the high
 // word), then one v_fma_f64 per moment with the table entry as an SGPR operand -- no cross-lane
-// reduction at all, and the sums run in sample order like the reference's Python loops.
+// reduction at all.  The sums associate differently from the reference's sample-order loops (two interleaved
+// accumulators here, groups of four samples in the table form below): weighted statistics agree with the
+// reference to ~1e-15 relative, not to the last bit (DESIGN.md "Exactness strategy").
 // (r01: the previous whole-wave-per-row form spent ~1000 cycles per row in LDS latency and three DPP wave
 // sums: 11.1 ms for 16 M x 1024 with a third of the rows passing.)
 typedef const __attribute__((address_space(4))) double *cdptr;
 // queue entries per wave: < 64 carried over + <= 64 / G appended per step of an unrolled batch
-constexpr int rq_cap(int G) { return 64 + (64 / G) * SC_UNROLL; }
+constexpr int rq_cap(int G, int unroll = SC_UNROLL) { return 64 + (64 / G) * unroll; }
+constexpr int SC_LUT_UNROLL = 8;   // rows in flight per lane group of the table-in-LDS kernels (half the waves per CU)
 
 template <int NM>
 __device__ __forceinline__ void row_moments(const u32x4 *__restrict__ rp, int cpr, cdptr tab, double *acc)
@@ -162,6 +169,82 @@ __device__ __forceinline__ void row_moments(const u32x4 *__restrict__ rp, int cp
     }
 #pragma unroll
     for (int m = 0; m < NM; m++) acc[m] = a0[m] + a1[m];
+}
+
+// The same sums from a nibble table: lut[g][p][0..NM) = sum of tab[4 g + b] over the bits b set in p (ascending b), for
+// every group g of 4 samples and every 4-bit pattern p, held in LDS.  A lane then spends one nibble extract, one
+// address and ONE LDS read + NM adds per FOUR samples instead of (2 + NM) VALU instructions per sample: the lanes of
+// a wave (64 different rows) look up the same group at the same time, so their 16 possible addresses are 16 x NM x 8
+// consecutive bytes -- for NM = 2 exactly the 64 banks, without a conflict; equal patterns are broadcast.
+// (r01: the per-sample form was f64-VALU bound, 0.76 ms for 16 M x 1024 with 20 % of the rows passing.)
+// The sums associate differently from the reference's sample-order loops: a group's members are added first, then
+// the groups in order (two interleaved accumulators, as before) -- 1e-15 relative, see DESIGN.md "Exactness".
+template <int NM>
+__global__ void moment_lut_kernel(const double *__restrict__ tab, int n_groups, double *__restrict__ lut)
+{
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n_groups * 16) return;
+    const int g = i >> 4, p = i & 15;
+#pragma unroll
+    for (int m = 0; m < NM; m++) {
+        double s = 0.0;
+#pragma unroll
+        for (int b = 0; b < 4; b++)
+            if ((p >> b) & 1) s += tab[(size_t)(4 * g + b) * NM + m];
+        lut[(size_t)i * NM + m] = s;
+    }
+}
+
+template <int NM>
+__device__ __forceinline__ void row_moments_lut(const u32x4 *__restrict__ rp, int cpr, const double *lut, double *acc)
+{
+    double a0[NM], a1[NM];
+#pragma unroll
+    for (int m = 0; m < NM; m++) { a0[m] = 0.0; a1[m] = 0.0; }
+    u32x4 y = rp[0];
+    for (int ch = 0; ch < cpr; ch++) {
+        const uint32_t w4[4] = {y.x, y.y, y.z, y.w};
+        if (ch + 1 < cpr) y = rp[ch + 1];
+        const double *lp = lut + (size_t)ch * 32 * 16 * NM;   // 32 groups of 4 samples per 16-byte chunk
+#pragma unroll
+        for (int h = 0; h < 4; h++) {
+#pragma unroll
+            for (int k = 0; k < 8; k += 2) {
+                const double *e0 = lp + ((h * 8 + k) * 16 + ((w4[h] >> (4 * k)) & 15u)) * NM;
+                const double *e1 = lp + ((h * 8 + k + 1) * 16 + ((w4[h] >> (4 * k + 4)) & 15u)) * NM;
+#pragma unroll
+                for (int m = 0; m < NM; m++) { a0[m] += e0[m]; a1[m] += e1[m]; }
+            }
+        }
+    }
+#pragma unroll
+    for (int m = 0; m < NM; m++) acc[m] = a0[m] + a1[m];
+}
+
+// Both forms in one row, for rows whose table does not fit the LDS: the first c_lut chunks through the nibble table, the
+// others per sample.  (Splitting a row that does fit in halves, to keep the LDS pipe and the f64 VALU busy at the same
+// time, did not pay: 16 M x 1024 with a fifth of the rows passing took 0.66 ms against 0.63 ms with the whole row in
+// the table and 0.75 ms per sample, r02.  8 M x 2048, where half the row fits: 0.67 ms against 0.95 ms per sample.)
+template <int NM>
+__device__ __forceinline__ void row_moments_mixed(const u32x4 *__restrict__ rp, int cpr, int c_lut, const double *lut, cdptr tab,
+                                                  double *acc)
+{
+    double a[NM], b[NM];
+    row_moments_lut<NM>(rp, c_lut, lut, a);
+#pragma unroll
+    for (int m = 0; m < NM; m++) b[m] = 0.0;
+    if (c_lut < cpr) row_moments<NM>(rp + c_lut, cpr - c_lut, tab + (size_t)c_lut * 128 * NM, b);
+#pragma unroll
+    for (int m = 0; m < NM; m++) acc[m] = a[m] + b[m];
+}
+
+// the workgroup's copy of the nibble table: global -> LDS, 16 bytes per thread and step
+__device__ __forceinline__ void load_lut(double *lds, const double *__restrict__ g, int n_doubles, int threads)
+{
+    const double2 *src = reinterpret_cast<const double2 *>(g);
+    double2 *dst = reinterpret_cast<double2 *>(lds);
+    for (int i = threadIdx.x; i < n_doubles / 2; i += threads) dst[i] = src[i];
+    __syncthreads();
 }
 
 // appends the rows flagged in this step (one flag per lane group leader) to the wave's queue
@@ -198,19 +281,23 @@ __device__ __forceinline__ int queue_pop64(uint64_t *q_row, int2 *q_val, int q, 
 // MODE 2: unit weights, rows that pass the pre-test are queued the same way: a scan with many survivors
 //         (--omit_B_correction keeps ~pvalue of all rows) then evaluates 64 of them per pass instead of one or two
 //         lanes of a wave at a time.  Same formulas, same results as MODE 0 (the host picks, see pick_chi2_mode).
-template <int G, int MODE>
-__global__ __launch_bounds__(SC_THREADS) void chi2_scan_kernel(const ScanArgs P)
+template <int G, int MODE, bool LUT = false>
+__global__ __launch_bounds__(LUT ? SC_LUT_THREADS : SC_THREADS) void chi2_scan_kernel(const ScanArgs P)
 {
     constexpr bool WEIGHTED = MODE == 1, QUEUED = MODE != 0;
-    __shared__ uint64_t s_qrow[QUEUED ? SC_THREADS / 64 : 1][QUEUED ? rq_cap(G) : 1];
-    __shared__ int2 s_qval[QUEUED ? SC_THREADS / 64 : 1][QUEUED ? rq_cap(G) : 1];
+    constexpr int THREADS = LUT ? SC_LUT_THREADS : SC_THREADS;
+    constexpr int UNR = LUT ? SC_LUT_UNROLL : SC_UNROLL;
+    __shared__ uint64_t s_qrow[QUEUED ? THREADS / 64 : 1][QUEUED ? rq_cap(G, UNR) : 1];
+    __shared__ int2 s_qval[QUEUED ? THREADS / 64 : 1][QUEUED ? rq_cap(G, UNR) : 1];
+    extern __shared__ double s_lut[];   // LUT: the nibble table of row_moments_lut
+    if (LUT) load_lut(s_lut, P.lut, P.c_lut * 32 * 16 * 2, THREADS);
     constexpr int RPW = 64 / G;  // rows per wave step
     const int lane = threadIdx.x & 63;
     const int g = lane & (G - 1);
     const int rsub = lane / G;
     const uint64_t n_steps = (P.M + RPW - 1) / RPW;
-    const uint64_t wave_global = (uint64_t)blockIdx.x * (SC_THREADS / 64) + (threadIdx.x >> 6);
-    const uint64_t total_waves = (uint64_t)gridDim.x * (SC_THREADS / 64);
+    const uint64_t wave_global = (uint64_t)blockIdx.x * (THREADS / 64) + (threadIdx.x >> 6);
+    const uint64_t total_waves = (uint64_t)gridDim.x * (THREADS / 64);
     const bool has_chunk = g < P.cpr;
     uint64_t m1a = 0, m1b = 0, m0a = 0, m0b = 0;
     if (has_chunk) {
@@ -231,7 +318,8 @@ __global__ __launch_bounds__(SC_THREADS) void chi2_scan_kernel(const ScanArgs P)
         double A, B, C, D;
         if (WEIGHTED) {
             double ws[2];
-            row_moments<2>(P.bits + r * (uint64_t)P.cpr, P.cpr, (cdptr)P.tab, ws);
+            if (LUT) row_moments_mixed<2>(P.bits + r * (uint64_t)P.cpr, P.cpr, P.c_lut, s_lut, (cdptr)P.tab, ws);
+            else row_moments<2>(P.bits + r * (uint64_t)P.cpr, P.cpr, (cdptr)P.tab, ws);
             if (!act) return;
             A = ws[0]; B = P.W1 - ws[0]; C = ws[1]; D = P.W0 - ws[1];
             const double R1 = A + B, R0 = C + D, K1 = A + C, K0 = B + D, T = R1 + R0;
@@ -257,7 +345,7 @@ __global__ __launch_bounds__(SC_THREADS) void chi2_scan_kernel(const ScanArgs P)
 
     // one copy of process(): the queue is drained after each unrolled batch and, once the rows run out,
     // down to empty (keeps its registers and code out of the streaming part)
-    for (uint64_t s0 = wave_global * SC_UNROLL;; s0 += total_waves * SC_UNROLL) {
+    for (uint64_t s0 = wave_global * UNR;; s0 += total_waves * UNR) {
         const bool more = s0 < n_steps;
         if (QUEUED) {
             while (q >= 64 || (!more && q > 0)) {
@@ -266,9 +354,9 @@ __global__ __launch_bounds__(SC_THREADS) void chi2_scan_kernel(const ScanArgs P)
             }
         }
         if (!more) break;
-        u32x4 x[SC_UNROLL];
+        u32x4 x[UNR];
 #pragma unroll
-        for (int u = 0; u < SC_UNROLL; u++) {
+        for (int u = 0; u < UNR; u++) {
             const uint64_t row = (s0 + u) * RPW + rsub;
             x[u] = (u32x4)(0u);
             if (row < P.M && has_chunk) {
@@ -280,7 +368,7 @@ __global__ __launch_bounds__(SC_THREADS) void chi2_scan_kernel(const ScanArgs P)
             }
         }
 #pragma unroll
-        for (int u = 0; u < SC_UNROLL; u++) {
+        for (int u = 0; u < UNR; u++) {
             const uint64_t row = (s0 + u) * RPW + rsub;
             const uint64_t xa = ((uint64_t)x[u].y << 32) | x[u].x, xb = ((uint64_t)x[u].w << 32) | x[u].z;
             uint32_t a = __popcll(xa & m1a) + __popcll(xb & m1b);
@@ -383,19 +471,23 @@ __device__ __attribute__((noinline)) double dev_t_two_sided_p(double t, double d
 // follows from the totals -- then means, variances, t and the Satterthwaite df in the same lane.
 // Table layout: unit weights tab[s] = {u, u*u} (n comes from the popcount); GSC weights {w, w*u, w*u*u};
 // zeros for NA samples and padding.
-template <int G, bool WT>
-__global__ __launch_bounds__(SC_THREADS) void ttest_scan_kernel(const ScanArgs P, const double mu)
+template <int G, bool WT, bool LUT = false>
+__global__ __launch_bounds__(LUT ? SC_LUT_THREADS : SC_THREADS) void ttest_scan_kernel(const ScanArgs P, const double mu)
 {
-    __shared__ uint64_t s_qrow[SC_THREADS / 64][rq_cap(G)];
-    __shared__ int2 s_qval[SC_THREADS / 64][rq_cap(G)];
+    constexpr int THREADS = LUT ? SC_LUT_THREADS : SC_THREADS;
+    constexpr int UNR = LUT ? SC_LUT_UNROLL : SC_UNROLL;
+    __shared__ uint64_t s_qrow[THREADS / 64][rq_cap(G, UNR)];
+    __shared__ int2 s_qval[THREADS / 64][rq_cap(G, UNR)];
     constexpr int RPW = 64 / G;
     constexpr int NM = WT ? 3 : 2;
+    extern __shared__ double s_lut[];   // LUT: the nibble table of row_moments_lut
+    if (LUT) load_lut(s_lut, P.lut, P.c_lut * 32 * 16 * NM, THREADS);
     const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
     const int g = lane & (G - 1);
     const int rsub = lane / G;
     const uint64_t n_steps = (P.M + RPW - 1) / RPW;
-    const uint64_t wave_global = (uint64_t)blockIdx.x * (SC_THREADS / 64) + wid;
-    const uint64_t total_waves = (uint64_t)gridDim.x * (SC_THREADS / 64);
+    const uint64_t wave_global = (uint64_t)blockIdx.x * (THREADS / 64) + wid;
+    const uint64_t total_waves = (uint64_t)gridDim.x * (THREADS / 64);
     const bool has_chunk = g < P.cpr;
     uint64_t mva = 0, mvb = 0;
     if (has_chunk) { mva = P.mvalid[2 * g]; mvb = P.mvalid[2 * g + 1]; }
@@ -408,7 +500,8 @@ __global__ __launch_bounds__(SC_THREADS) void ttest_scan_kernel(const ScanArgs P
         const uint64_t r = q_row[act ? lane : 0];
         const int r_nw = q_val[act ? lane : 0].x;
         double mo[NM];
-        row_moments<NM>(P.bits + r * (uint64_t)P.cpr, P.cpr, (cdptr)P.tab, mo);
+        if (LUT) row_moments_mixed<NM>(P.bits + r * (uint64_t)P.cpr, P.cpr, P.c_lut, s_lut, (cdptr)P.tab, mo);
+        else row_moments<NM>(P.bits + r * (uint64_t)P.cpr, P.cpr, (cdptr)P.tab, mo);
         if (!act) return;
         const double nx = WT ? mo[0] : (double)r_nw, sx = mo[NM - 2], qx = mo[NM - 1];
         const double ny = P.W1 - nx, sy = P.W0 - sx, qy = P.thr - qx;  // totals: W1 = sum w, W0 = sum w*u, thr = sum w*u^2
@@ -437,22 +530,22 @@ __global__ __launch_bounds__(SC_THREADS) void ttest_scan_kernel(const ScanArgs P
 
     // one copy of process(): the queue is drained after each unrolled batch and, once the rows run out,
     // down to empty (keeps its registers and code out of the streaming part)
-    for (uint64_t s0 = wave_global * SC_UNROLL;; s0 += total_waves * SC_UNROLL) {
+    for (uint64_t s0 = wave_global * UNR;; s0 += total_waves * UNR) {
         const bool more = s0 < n_steps;
         while (q >= 64 || (!more && q > 0)) {
             process(q < 64 ? q : 64);
             q = queue_pop64(q_row, q_val, q, lane);
         }
         if (!more) break;
-        u32x4 x[SC_UNROLL];
+        u32x4 x[UNR];
 #pragma unroll
-        for (int u = 0; u < SC_UNROLL; u++) {
+        for (int u = 0; u < UNR; u++) {
             const uint64_t row = (s0 + u) * RPW + rsub;
             x[u] = (u32x4)(0u);
             if (row < P.M && has_chunk) x[u] = __builtin_nontemporal_load(&P.bits[row * (uint64_t)P.cpr + g]);
         }
 #pragma unroll
-        for (int u = 0; u < SC_UNROLL; u++) {
+        for (int u = 0; u < UNR; u++) {
             const uint64_t row = (s0 + u) * RPW + rsub;
             const uint64_t xa = ((uint64_t)x[u].y << 32) | x[u].x, xb = ((uint64_t)x[u].w << 32) | x[u].z;
             uint32_t cnt = __popcll(xa & mva) + __popcll(xb & mvb);
@@ -485,9 +578,43 @@ void launch_chi2_mode(int G, dim3 grid, hipStream_t st, const ScanArgs &a)
     }
 }
 
+// bytes of the nibble table of row_moments_lut for `chunks` 16-byte chunks of a row and NM moments
+size_t lut_bytes(int chunks, int nm) { return (size_t)chunks * 32 * 16 * nm * 8; }
+// chunks of a row that go through the table: all of them when the table fits the LDS (up to 1536 samples with two
+// moments, 1024 with three), else as many as fit -- the rest of the row takes the per-sample form (row_moments_mixed);
+// 0 = the per-sample kernels (PSK_NO_LUT, or rows wider than 16 lanes)
+int lut_chunks(int cpr, int nm)
+{
+    if (getenv("PSK_NO_LUT") || cpr > 16) return 0;
+    int c = getenv("PSK_LUT_HALF") ? (cpr + 1) / 2 : cpr;
+    while (c > 0 && lut_bytes(c, nm) > SC_LUT_MAX_BYTES) c--;
+    return c;
+}
+
+template <class K>
+int launch_lut_kernel(K kern, dim3 grid, size_t lds, hipStream_t st, const ScanArgs &a)
+{
+    (void)hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    kern<<<grid, SC_LUT_THREADS, lds, st>>>(a);
+    return 0;
+}
+
+void launch_chi2_lut(int G, dim3 grid, hipStream_t st, const ScanArgs &a)
+{
+    const size_t lds = lut_bytes(a.c_lut, 2);
+    switch (G) {
+    case 1: launch_lut_kernel(chi2_scan_kernel<1, 1, true>, grid, lds, st, a); break;
+    case 2: launch_lut_kernel(chi2_scan_kernel<2, 1, true>, grid, lds, st, a); break;
+    case 4: launch_lut_kernel(chi2_scan_kernel<4, 1, true>, grid, lds, st, a); break;
+    case 8: launch_lut_kernel(chi2_scan_kernel<8, 1, true>, grid, lds, st, a); break;
+    default: launch_lut_kernel(chi2_scan_kernel<16, 1, true>, grid, lds, st, a); break;
+    }
+}
+
 void launch_chi2(int mode, int G, dim3 grid, hipStream_t st, const ScanArgs &a)
 {
-    if (mode == 1) launch_chi2_mode<1>(G, grid, st, a);
+    if (mode == 1 && a.lut) launch_chi2_lut(G, grid, st, a);
+    else if (mode == 1) launch_chi2_mode<1>(G, grid, st, a);
     else if (mode == 2) launch_chi2_mode<2>(G, grid, st, a);
     else launch_chi2_mode<0>(G, grid, st, a);
 }
@@ -562,11 +689,46 @@ void launch_ttest_w(int G, dim3 grid, hipStream_t st, const ScanArgs &a, double 
     }
 }
 
+template <class K>
+void launch_lut_ttest(K kern, dim3 grid, size_t lds, hipStream_t st, const ScanArgs &a, double mu)
+{
+    (void)hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    kern<<<grid, SC_LUT_THREADS, lds, st>>>(a, mu);
+}
+
+template <bool WT>
+void launch_ttest_lut(int G, dim3 grid, hipStream_t st, const ScanArgs &a, double mu)
+{
+    const size_t lds = lut_bytes(a.c_lut, WT ? 3 : 2);
+    switch (G) {
+    case 1: launch_lut_ttest(ttest_scan_kernel<1, WT, true>, grid, lds, st, a, mu); break;
+    case 2: launch_lut_ttest(ttest_scan_kernel<2, WT, true>, grid, lds, st, a, mu); break;
+    case 4: launch_lut_ttest(ttest_scan_kernel<4, WT, true>, grid, lds, st, a, mu); break;
+    case 8: launch_lut_ttest(ttest_scan_kernel<8, WT, true>, grid, lds, st, a, mu); break;
+    default: launch_lut_ttest(ttest_scan_kernel<16, WT, true>, grid, lds, st, a, mu); break;
+    }
+}
+
 void launch_ttest(int G, dim3 grid, hipStream_t st, const ScanArgs &a, double mu, bool weighted)
 {
-    if (weighted) launch_ttest_w<true>(G, grid, st, a, mu);
+    if (a.lut) {
+        if (weighted) launch_ttest_lut<true>(G, grid, st, a, mu);
+        else launch_ttest_lut<false>(G, grid, st, a, mu);
+    } else if (weighted) launch_ttest_w<true>(G, grid, st, a, mu);
     else launch_ttest_w<false>(G, grid, st, a, mu);
     ttest_finalize_kernel<<<SC_NSEG, 256, 0, st>>>(a);
+}
+
+// builds the nibble table of `tab` (cpr * 128 samples x nm moments, already on the device) into ctx->lut
+int build_moment_lut(psk_ctx *ctx, const double *tab, int chunks, int nm, const double **lut_out)
+{
+    const int n_groups = chunks * 32;
+    PSK_TRY(dev_reserve(ctx, ctx->lut, lut_bytes(chunks, nm)));
+    if (nm == 2) moment_lut_kernel<2><<<div_up((uint64_t)n_groups * 16, 256), 256, 0, ctx->stream>>>(tab, n_groups, ctx->lut.as<double>());
+    else moment_lut_kernel<3><<<div_up((uint64_t)n_groups * 16, 256), 256, 0, ctx->stream>>>(tab, n_groups, ctx->lut.as<double>());
+    PSK_HIP(ctx, hipGetLastError());
+    *lut_out = ctx->lut.as<double>();
+    return PSK_OK;
 }
 
 int group_lanes(int cpr)
@@ -578,14 +740,14 @@ int group_lanes(int cpr)
 
 // result arrays (SoA) inside ctx->res: row u64 | stat f64 | p f64 | mx f64 | my f64 | nw i32, each
 // SC_NSEG * seg_cap entries; seg_cap bounds the rows the blocks of one segment can visit
-int setup_results(psk_ctx *ctx, ScanArgs &a, dim3 grid, int G, int unroll, int set)
+int setup_results(psk_ctx *ctx, ScanArgs &a, dim3 grid, int G, int unroll, int set, int threads = SC_THREADS)
 {
     const uint64_t rpw = 64 / G;
     const uint64_t n_steps = (a.M + rpw - 1) / rpw;
-    const uint64_t total_waves = (uint64_t)grid.x * (SC_THREADS / 64);
+    const uint64_t total_waves = (uint64_t)grid.x * (threads / 64);
     const uint64_t iters = (n_steps + total_waves * unroll - 1) / (total_waves * unroll);
     const uint64_t blocks_per_seg = ((uint64_t)grid.x + SC_NSEG - 1) / SC_NSEG;
-    uint64_t seg_cap = blocks_per_seg * (SC_THREADS / 64) * iters * unroll * rpw;
+    uint64_t seg_cap = blocks_per_seg * (threads / 64) * iters * unroll * rpw;
     if (seg_cap < 64) seg_cap = 64;
     if (seg_cap >= (1ull << 32)) return psk_fail(ctx, PSK_ERANGE, "result segment too large");
     const uint64_t cap = seg_cap * SC_NSEG;
@@ -654,8 +816,11 @@ __global__ void pack_segments_kernel(const uint8_t *__restrict__ src, uint64_t c
     }
 }
 
-dim3 scan_grid(const psk_ctx *ctx, uint64_t M, int G, int unroll)
+dim3 scan_grid(const psk_ctx *ctx, uint64_t M, int G, int unroll, bool lut = false)
 {
+    // the table-in-LDS form: one 1024-thread workgroup per CU (its 64-120 KB of LDS admit no second one), and one
+    // per result segment at least
+    if (lut) return dim3((unsigned)std::max(SC_NSEG, ctx->n_cu > 0 ? ctx->n_cu : 256));
     const uint64_t rpw = 64 / G;
     const uint64_t steps = (M + rpw - 1) / rpw;
     const uint64_t waves = (steps + unroll - 1) / unroll;
@@ -693,7 +858,7 @@ int pick_result_set(psk_ctx *ctx, int *set_out, bool keep_results = false)
 int run_chi2(psk_ctx *ctx, ScanArgs &a, bool weighted, int reps, double *ms_total)
 {
     const int G = group_lanes(a.cpr);
-    const dim3 grid = scan_grid(ctx, a.M, G, SC_UNROLL);
+    const dim3 grid = scan_grid(ctx, a.M, G, SC_UNROLL, a.lut != nullptr);
     *ms_total = 0;
     for (int r = 0; r < reps; r++) {
         PSK_HIP(ctx, hipEventRecord(ctx->ev0, ctx->stream));
@@ -733,7 +898,10 @@ static int fill_chi2_args(psk_ctx *ctx, ScanArgs &a, int set)
     else if (pmax <= 0.0) a.thr = INFINITY;
     else a.thr = -2.0 * log(pmax);
     const int G = group_lanes(a.cpr);
-    return setup_results(ctx, a, scan_grid(ctx, a.M, G, SC_UNROLL), G, SC_UNROLL, set);
+    a.lut = (L.weighted && ctx->lut_valid) ? ctx->lut.as<double>() : nullptr;
+    a.c_lut = a.lut ? lut_chunks(a.cpr, 2) : 0;
+    return setup_results(ctx, a, scan_grid(ctx, a.M, G, SC_UNROLL, a.lut != nullptr), G, a.lut ? SC_LUT_UNROLL : SC_UNROLL, set,
+                         a.lut ? SC_LUT_THREADS : SC_THREADS);
 }
 
 // Launches the scan and returns without waiting; psk_scan_end collects it.  Lets a caller queue other work (the
@@ -783,6 +951,13 @@ static int chi2_scan_launch(psk_ctx *ctx, const int8_t *pheno, const double *wei
     if (weights || !ctx->last.inline_masks)
         PSK_HIP(ctx, hipMemcpyAsync(ctx->mask1.p, m1, weights ? stage_bytes : n_mask * 8, hipMemcpyHostToDevice, ctx->stream));
 
+    ctx->lut_valid = false;
+    if (weights && lut_chunks(wpr / 2, 2) > 0) {   // class-weight sums from a nibble table in LDS (row_moments_lut)
+        const double *lut = nullptr;
+        PSK_TRY(build_moment_lut(ctx, reinterpret_cast<const double *>(ctx->mask1.as<uint64_t>() + 2 * (size_t)wpr),
+                                 lut_chunks(wpr / 2, 2), 2, &lut));
+        ctx->lut_valid = true;
+    }
     ctx->last.valid = true;
     ctx->last.weighted = weights != nullptr;
     ctx->last.min_samples = min_samples;
@@ -798,7 +973,7 @@ static int chi2_scan_launch(psk_ctx *ctx, const int8_t *pheno, const double *wei
     if (ctx->n_kmers) {
         ScanSlot &sl = ctx->slot[set];
         const int G = group_lanes(a.cpr);
-        const dim3 grid = scan_grid(ctx, a.M, G, SC_UNROLL);
+        const dim3 grid = scan_grid(ctx, a.M, G, SC_UNROLL, a.lut != nullptr);
         PSK_HIP(ctx, hipEventRecord(sl.ev0, ctx->stream));
         launch_chi2(pick_chi2_mode(ctx, ctx->last.weighted, a.pcut, a.pcut_bonf, a.omit_B), G, grid, ctx->stream, a);
         PSK_HIP(ctx, hipGetLastError());
@@ -940,8 +1115,11 @@ extern "C" int psk_ttest_scan(psk_ctx *ctx, const double *pheno, const uint8_t *
     int set = 0;
     PSK_TRY(pick_result_set(ctx, &set));
     const int G = group_lanes(a.cpr);
-    const dim3 grid = scan_grid(ctx, a.M, G, SC_UNROLL);
-    PSK_TRY(setup_results(ctx, a, grid, G, SC_UNROLL, set));
+    ctx->lut_valid = false;   // the table buffer is shared with the weighted chi2 scan
+    a.c_lut = lut_chunks(a.cpr, NM);
+    if (a.c_lut > 0) PSK_TRY(build_moment_lut(ctx, a.tab, a.c_lut, NM, &a.lut));
+    const dim3 grid = scan_grid(ctx, a.M, G, SC_UNROLL, a.lut != nullptr);
+    PSK_TRY(setup_results(ctx, a, grid, G, a.lut ? SC_LUT_UNROLL : SC_UNROLL, set, a.lut ? SC_LUT_THREADS : SC_THREADS));
     ctx->n_pass = 0;
     ctx->last_scan_kind = 2;
     ctx->last.valid = false;

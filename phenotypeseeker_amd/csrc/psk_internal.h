@@ -145,6 +145,8 @@ struct psk_ctx {
 
     // scan state
     DevBuf mask1, phe, res_count, res_sorted;
+    DevBuf lut;                          // nibble table of the moment scans (assoc_scan.hip row_moments_lut)
+    bool lut_valid = false;              // ... holds the table of the last weighted chi2 scan
     uint64_t n_pass = 0;
     uint64_t res_seg_cap = 0;            // entries per result segment of the last scan
     std::vector<uint32_t> seg_counts;    // survivors per segment
