@@ -1,20 +1,30 @@
 #!/bin/bash
 # Regenerates the rocprofv3 evidence of a round on the GPU box (run through gpurun from the repo root):
-#   tools/make_profiles.sh r01
-# Writes gpurun_out/profiles_<tag>/: kernel-trace stats of `python3 bench.py`, the bench line under the profiler
-# and unprofiled, and two separate --pmc passes (FETCH_SIZE, WRITE_SIZE; no tracing flags with counters).
+#   tools/make_profiles.sh r02
+# Writes gpurun_out/profiles_<tag>/<workload>/: kernel-trace stats, the program's own output, and (bench, cfg3slab,
+# ingest) two separate --pmc passes (FETCH_SIZE, WRITE_SIZE; no tracing flags with counters).  tools/summarise_profiles.py
+# turns that into the committed files under profiles/.
 set -u
-TAG=${1:-r01}
+TAG=${1:-r02}
 ROOT=${GRAFT_REPO_ROOT:-$PWD}
 OUT=$ROOT/gpurun_out/profiles_$TAG
 mkdir -p "$OUT"
 cd /tmp && export TMPDIR=/tmp
-ARGS="--steps 50 --warmup 5 --no-cpu-baseline"
-python3 "$ROOT/bench.py" $ARGS > "$OUT/bench_unprofiled.json" 2> "$OUT/bench_unprofiled.err"
-rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/trace" -o bench -- python3 "$ROOT/bench.py" $ARGS \
-    > "$OUT/bench_under_rocprof.json" 2> "$OUT/trace.err"
-rocprofv3 --pmc FETCH_SIZE --output-format csv -d "$OUT/pmc_fetch" -o bench -- python3 "$ROOT/bench.py" $ARGS \
-    > /dev/null 2> "$OUT/pmc_fetch.err"
-rocprofv3 --pmc WRITE_SIZE --output-format csv -d "$OUT/pmc_write" -o bench -- python3 "$ROOT/bench.py" $ARGS \
-    > /dev/null 2> "$OUT/pmc_write.err"
-find "$OUT" -name "*.csv" | head -20
+prof() {   # name pmc(0/1) program args...
+  local name=$1 pmc=$2; shift 2
+  local d=$OUT/$name; mkdir -p "$d"
+  rocprofv3 --kernel-trace --stats --output-format csv -d "$d/trace" -o run -- python3 "$@" > "$d/stdout.txt" 2> "$d/trace.err"
+  if [ "$pmc" = "1" ]; then
+    rocprofv3 --pmc FETCH_SIZE --output-format csv -d "$d/pmc_fetch" -o run -- python3 "$@" > /dev/null 2> "$d/pmc_fetch.err"
+    rocprofv3 --pmc WRITE_SIZE --output-format csv -d "$d/pmc_write" -o run -- python3 "$@" > /dev/null 2> "$d/pmc_write.err"
+  fi
+}
+BENCH="--steps 50 --warmup 5 --no-cpu-baseline"
+python3 "$ROOT/bench.py" $BENCH > "$OUT/bench_unprofiled.json" 2> "$OUT/bench_unprofiled.err"
+prof bench 1 "$ROOT/bench.py" $BENCH
+prof ingest 1 "$ROOT/tools/profile_workloads.py" ingest
+prof cfg3slab 1 "$ROOT/tools/profile_workloads.py" cfg3slab
+prof moments 0 "$ROOT/tools/profile_workloads.py" moments
+prof fastq 0 "$ROOT/tools/profile_workloads.py" fastq
+prof solver 0 "$ROOT/tools/profile_workloads.py" solver
+du -sh "$OUT"

@@ -1,0 +1,129 @@
+#!/usr/bin/env python3
+"""The workloads whose kernels are profiled for profiles/ (tools/make_profiles.sh runs each under rocprofv3):
+  cfg3slab   one rank's full-size share of config 3: 2,048 x 5 Mbp, k = 16, balanced slab 0 of 8; 10 scans of the
+             6-GB matrix (well beyond the 256-MiB Infinity Cache)
+  moments    the f64 scans on a device-generated 16 M x 1024 matrix: Welch t, GSC-weighted chi2, weighted Welch t
+  fastq      one config-5 sample: 2 M x 150-bp reads, 0.63 GB of FASTQ, framed and counted
+  ingest     config 2's ingest alone: 256 x 5 Mbp, k = 13, counted three times + presence build
+  solver     the L1 (grid value, fold) fits of two recorded runs (143 fits each)
+Each prints one JSON line: the algorithmic bytes per launch of its kernels (what `frac` in profiles/ is computed from).
+usage: tools/profile_workloads.py NAME"""
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+from phenotypeseeker_amd.engine import PskContext  # noqa: E402
+from phenotypeseeker_amd.synth import GenomeSet  # noqa: E402
+
+what = sys.argv[1]
+out = {"workload": what, "algorithmic_bytes_per_launch": {}, "notes": {}}
+alg = out["algorithmic_bytes_per_launch"]
+
+if what == "cfg3slab":
+    from phenotypeseeker_amd import dist
+    n, L, k, world = 2048, 5_000_000, 16, 8
+    gs = GenomeSet(n, L, seed=12345)
+    with PskContext(0) as ctx:
+        ctx.begin(k, 1)
+        nu0, _ = ctx.count_kmers(0, gs.sample(0)[1])
+        bounds = dist.quantile_bounds(dist.pilot_points(ctx.get_list(0, nu0)[0]), k, world)
+        ctx.begin(k, n, bounds[0], bounds[1])
+        t0 = time.time()
+        pairs = 0
+        for s0 in range(0, n, 64):
+            nu, _ = ctx.count_kmers_batch(s0, [gs.sample(i)[1] for i in range(s0, min(s0 + 64, n))], 8)
+            pairs += sum(nu)
+        t1 = time.time()
+        m = ctx.build_presence()
+        t2 = time.time()
+        ph = np.array([gs.phenotype(i) for i in range(n)], dtype=np.int8)
+        ctx.chi2_scan(ph, None, 2, n - 2, 0.05, False, 8 * m)
+        ms = ctx.rescan_timed(10)
+        out["notes"] = {"rows": m, "pairs": pairs, "generate_and_count_s": round(t1 - t0, 2), "presence_s": round(t2 - t1, 2),
+                        "scan_ms": ms, "matrix_GB": m * 256 / 1e9}
+        alg["chi2_scan_kernel"] = m * 256
+elif what == "moments":
+    M, N = 16_000_000, 1024
+    rng = np.random.default_rng(3)
+    with PskContext(0) as ctx:
+        ctx.begin(16, N)
+        ctx.synth_presence(M, N, 7)
+        ph = (np.arange(N) % 2).astype(np.int8)
+        vals = rng.normal(0, 1, N) + ph * 0.3
+        w = rng.uniform(0.5, 1.5, N)
+        ones = np.ones(N, np.uint8)
+        t = {}
+        for rep in range(3):
+            ctx.chi2_scan(ph, None, 2, N - 2, 0.05, False, M); t["chi2"] = ctx.last_scan_ms()
+            ctx.chi2_scan(ph, w, 2, N - 2, 0.05, False, M); t["chi2_weighted"] = ctx.last_scan_ms()
+            ctx.ttest_scan(vals, ones, None, 2, N - 2, 0.05, M); t["ttest"] = ctx.last_scan_ms()
+            ctx.ttest_scan(vals, ones, w, 2, N - 2, 0.05, M); t["ttest_weighted"] = ctx.last_scan_ms()
+        out["notes"] = {"rows": M, "samples": N, "event_ms": t}
+        for name in ("chi2_scan_kernel", "ttest_scan_kernel"):
+            alg[name] = M * (N // 8)
+elif what == "fastq":
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    from test_gpu_configs import _fastq_sample
+    gs = GenomeSet(1, 5_000_000, seed=99)
+    data = _fastq_sample(gs.codes(0), 2_000_000, 150, seed=[5, 0])
+    with PskContext(0) as ctx:
+        ctx.begin(13, 1)
+        ts = []
+        for rep in range(4):
+            t0 = time.time()
+            nu, nt = ctx.count_kmers_batch(0, [data], 8)
+            ts.append(round(time.time() - t0, 4))
+        out["notes"] = {"file_bytes": len(data), "windows": int(nt[0]), "unique": int(nu[0]), "wall_s": ts,
+                        "GBps_of_file_bytes": round(len(data) / min(ts) / 1e9, 1)}
+        clean = 2_000_000 * 151
+        for name in ("fq_lines_kernel", "fq_pass_kernel"):
+            alg[name] = len(data)
+        alg["dc_hist_kernel"] = clean
+        alg["dc_partition_kernel"] = clean + 2 * int(nt[0])
+        alg["dc_count_kernel"] = 2 * int(nt[0]) + (1 << 26) // 8
+elif what == "ingest":
+    n, L, k = 256, 5_000_000, 13
+    gs = GenomeSet(n, L, seed=12345)
+    fas = [gs.sample(i)[1] for i in range(n)]
+    with PskContext(0) as ctx:
+        ts = []
+        for rnd in range(3):
+            ctx.begin(k, n)
+            t0 = time.time()
+            tot = 0
+            for lo in range(0, n, 64):
+                nu, _ = ctx.count_kmers_batch(lo, fas[lo:lo + 64], 8)
+                tot += sum(nu)
+            t1 = time.time()
+            m = ctx.build_presence()
+            ts.append((round(t1 - t0, 4), round(time.time() - t1, 4)))
+        out["notes"] = {"count_s, presence_s per round": ts, "rows": m, "pairs": tot}
+        raw = len(fas[0])
+        alg["fa_summary_kernel"] = raw
+        alg["fa_emit_kernel"] = raw + L
+        alg["dc_hist_kernel"] = L
+        alg["dc_partition_kernel"] = L + 2 * L
+        alg["dc_count_sparse_kernel"] = 2 * L + (1 << 26) // 8
+        alg["pd_or_kernel"] = n * ((1 << 26) // 8)
+        alg["pd_transpose_kernel"] = n * ((1 << 26) // 8) + m * 32 + m * 8
+elif what == "solver":
+    # the (grid value, fold) fits of two recorded runs: 256 samples x 138 distinct columns, 2048 x 169
+    with PskContext(0) as ctx:
+        for tag in ("fit256", "fit2048"):
+            z = np.load(os.path.join(ROOT, "tools", "data", tag + ".npz"))
+            X, y = z["X"].astype(np.float32), z["y"].astype(np.int32)
+            ts = []
+            for rep in range(2):
+                t0 = time.time()
+                ctx.logreg_l1_fit(X, y, z["fold"].astype(np.int32), z["fit_param"], z["fit_fold"].astype(np.int32), float(z["tol"]),
+                                  int(z["max_iter"]))
+                ts.append(round(time.time() - t0, 4))
+            out["notes"][tag] = {"X": list(X.shape), "fits": int(len(z["fit_param"])), "wall_s": ts}
+else:
+    raise SystemExit("unknown workload " + what)
+print(json.dumps(out), flush=True)
