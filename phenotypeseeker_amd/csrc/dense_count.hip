@@ -35,7 +35,7 @@ constexpr size_t DCNT_LDS_BYTES = (size_t)(DC_VALS / 2 + 16) * 4;               
 // forward word of the window that ends at byte p is then one funnel shift of F, its reverse complement one funnel
 // shift of R, and "no break inside" one funnel shift of B -- with K a template parameter every shift amount is a
 // literal.  (Byte-by-byte rolling cost ~30 VALU instructions per window end: 13 us of the 17 us of the first cut's
-// histogram kernel, tools/dc_attrib.sh.)
+// histogram kernel, measured by switching parts of the kernels off.)
 struct Streams {
     uint32_t F[3], R[4], B[2];
 };
