@@ -807,7 +807,8 @@ static int count_batch_impl(psk_ctx *ctx, int first_sample_idx, int n, const uin
     }
     // pinned ring: at most ~4 GiB of it (read-scale FASTQ samples are hundreds of MB each)
     while (n_threads > 1 && (size_t)(n_threads + 4) * max_len > (4ull << 30)) n_threads--;
-    const int R = n_threads + 4;  // ring slots: two being uploaded / framed ahead, one whose chain is in flight, one released late
+    const int R = n < n_threads + 4 ? n : n_threads + 4;  // ring slots: two being uploaded / framed ahead, one whose chain is in
+                                                          // flight, one released late -- never more than there are samples
     if ((int)ctx->ring.size() < R) { ctx->ring.resize(R, nullptr); ctx->ring_cap.resize(R, 0); }
     for (int s = 0; s < R; s++) PSK_TRY(ensure_pinned(ctx, &ctx->ring[s], &ctx->ring_cap[s], max_len + 2 * EX_SEG));
     // FASTA and four-line FASTQ are framed on the GPU (frame_gpu.hip): the worker threads then only move file bytes

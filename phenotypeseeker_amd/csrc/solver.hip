@@ -277,13 +277,15 @@ __global__ __launch_bounds__(SV_THREADS) void logreg_newglmnet_kernel(
 // ALL_LDS: every array of the fit lives in LDS (the usual case: a few hundred samples, <= ~1500 distinct
 // columns).  The placement is then a compile-time fact, the pointers are LDS pointers and the loops use
 // ds_read / ds_write; with run-time placement flags they are generic pointers and every access is a flat load.
-template <bool ALL_LDS>
+// WMREG: 0, or the number of sample words per lane the register form of the descent holds (16 or 32; see cd_regs) --
+// a template parameter so that its 2 x WMREG doubles per lane do not weigh on the register allocation of the other forms.
+template <bool ALL_LDS, int WMREG>
 __global__ __launch_bounds__(SV_THREADS) void logreg_newglmnet_bits_kernel(
     const uint64_t *__restrict__ colbits, const int8_t *__restrict__ ypm, const int32_t *__restrict__ fold, int n, int p,
     int W, const double *__restrict__ fit_param, const int32_t *__restrict__ fit_fold, double tol, int max_newton,
     double *__restrict__ coef, double *__restrict__ icpt, int32_t *__restrict__ iters, double *__restrict__ work,
     int32_t *__restrict__ iwork, const int f_lds_rt, const int s_lds_rt, const int c_lds_rt, const int q_doubles_i, const int cg_max,
-    const int polish_reps)
+    const int polish_reps, const uint64_t *__restrict__ colT)
 {
     const size_t q_doubles = (size_t)q_doubles_i;  // LDS doubles reserved for the Gram block
     // s_lds_rt: bit 0 = the two sample arrays every per-feature gradient pass reads (tau, D) are in LDS, bit 1 = the
@@ -652,7 +654,92 @@ __global__ __launch_bounds__(SV_THREADS) void logreg_newglmnet_bits_kernel(
             if (active <= 64) gram_qp(integral_constant<int, 1>{}, integral_constant<bool, true>{});
             else if (active <= 128) gram_qp(integral_constant<int, 2>{}, integral_constant<bool, true>{});
             else gram_qp(integral_constant<int, 3>{}, integral_constant<bool, true>{});
-        } else
+        } else {
+        // Array form with the samples in REGISTERS (up to 2048 samples): lane l owns samples l, l + 64, ..., so D and
+        // x.d of a fit are W doubles per lane each, and the column of a coordinate arrives TRANSPOSED (colT: bit t of
+        // lane l's word = sample 64 t + l) -- one coalesced load, requested a step ahead, no lane reads.  A coordinate
+        // step is then W predicated FMAs, one wave sum and W predicated adds, without an LDS access; with the arrays in
+        // LDS every word step waited for two LDS reads (~100 clocks: the loop is not unrolled, W is a run-time value)
+        // and a step took ~1 us (r02: 2048 samples x 907 columns, 16 M steps = the 16 s of that grid).  Same visiting
+        // order, same sums in the same order as the LDS form below (which serves W > 32).
+        auto cd_regs = [&](auto wm_tag) {
+            constexpr int WM = decltype(wm_tag)::value;
+            double Dr[WM], Xr[WM];
+            uint64_t tmask = 0;   // the lane's training samples, transposed like colT
+#pragma unroll
+            for (int t = 0; t < WM; t++) {
+                const bool in = t < W;
+                Dr[t] = in ? D[t * 64 + lane] : 0.0;
+                Xr[t] = in ? xTd[t * 64 + lane] : 0.0;
+                const uint64_t tw = psk_readlane_u64(trainw, in ? t : 0);
+                if (in && ((tw >> lane) & 1)) tmask |= 1ull << t;
+            }
+            auto act_at = [&](int sx) { return f_lds ? act[sx] : __builtin_amdgcn_readfirstlane(lane == 0 ? act[sx] : 0); };
+            auto col_t = [&](int j) { return colT[(size_t)j * 64 + lane] & tmask; };
+            while (iter < 1000) {
+                if (lane == 0) {   // a fresh random visiting order every sweep, as liblinear's solve_l1r_lr
+                    for (int jj = 0; jj + 1 < QP_active; jj++) {
+                        rng ^= rng << 13; rng ^= rng >> 17; rng ^= rng << 5;
+                        const int ii = jj + (int)(rng % (uint32_t)(QP_active - jj));
+                        const int32_t tt = act[ii]; act[ii] = act[jj]; act[jj] = tt;
+                    }
+                }
+                double QP_Gmax_new = 0.0, QP_Gnorm1_new = 0.0;
+                int j_next = QP_active > 0 ? act_at(0) : 0;
+                uint64_t m_next = QP_active > 0 ? col_t(j_next) : 0ull;
+                for (int sidx = 0; sidx < QP_active; sidx++) {
+                    const int j = j_next;
+                    const uint64_t m = m_next;
+                    if (sidx + 1 < QP_active) { j_next = act_at(sidx + 1); m_next = col_t(j_next); }
+                    const double H = FLD(&Hd[j]);
+                    const double wp = FLD(&wpd[j]);
+                    double G = 0.0;
+#pragma unroll
+                    for (int t = 0; t < WM; t++)
+                        if ((m >> t) & 1) G += Dr[t] * Xr[t];
+                    G = psk_wave_sum_f64_dpp(G) + FLD(&Gr[j]) + (wp - FLD(&w[j])) * nu;
+                    const double Gp = G + 1.0, Gn = G - 1.0;
+                    double viol = 0.0;
+                    if (wp == 0.0) {
+                        if (Gp < 0) viol = -Gp;
+                        else if (Gn > 0) viol = Gn;
+                        else if (Gp > QP_Gmax_old / l && Gn < -QP_Gmax_old / l) {
+                            QP_active--;
+                            if (lane == 0) { const int32_t tt = act[sidx]; act[sidx] = act[QP_active]; act[QP_active] = tt; }
+                            if (sidx < QP_active) { j_next = act_at(sidx); m_next = col_t(j_next); }   // swapped in: visited next
+                            sidx--;
+                            continue;
+                        }
+                    } else if (wp > 0) viol = fabs(Gp);
+                    else viol = fabs(Gn);
+                    if (viol > QP_Gmax_new) QP_Gmax_new = viol;
+                    QP_Gnorm1_new += viol;
+                    double z;
+                    if (Gp < H * wp) z = -Gp / H;
+                    else if (Gn > H * wp) z = -Gn / H;
+                    else z = -wp;
+                    if (fabs(z) < 1e-12 && !(z == -wp && wp != 0.0)) continue;  // see the LDS form below
+                    z = fmin(fmax(z, -10.0), 10.0);
+                    if (lane == 0) wpd[j] = wp + z;
+#pragma unroll
+                    for (int t = 0; t < WM; t++)
+                        if ((m >> t) & 1) Xr[t] += z;
+                }
+                iter++;
+                if (QP_Gnorm1_new <= inner_eps * Gnorm1_init) {
+                    if (QP_active == active) break;
+                    QP_active = active;
+                    QP_Gmax_old = 1e300;
+                    continue;
+                }
+                QP_Gmax_old = QP_Gmax_new;
+            }
+#pragma unroll
+            for (int t = 0; t < WM; t++)
+                if (t < W) xTd[t * 64 + lane] = Xr[t];
+        };
+        if (WMREG > 0) cd_regs(integral_constant<int, (WMREG > 0 ? WMREG : 1)>{});
+        else
         while (iter < 1000) {
             // liblinear visits the active coordinates in a fresh random order every sweep (solve_l1r_lr); a fixed cyclic
             // order needs hundreds of times more sweeps on correlated columns (r01: 4.3 s against liblinear's 14 ms)
@@ -715,6 +802,7 @@ __global__ __launch_bounds__(SV_THREADS) void logreg_newglmnet_bits_kernel(
                 continue;
             }
             QP_Gmax_old = QP_Gmax_new;
+        }
         }
 
         double delta = 0.0, w_norm_new = 0.0;
@@ -879,10 +967,10 @@ void transpose_f32(const float *X, int n, int p, std::vector<float> &XT)
 
 struct SolverBufs {
     void *xt = nullptr, *y = nullptr, *fold = nullptr, *param = nullptr, *ffold = nullptr, *coef = nullptr,
-         *icpt = nullptr, *iters = nullptr, *work = nullptr, *iwork = nullptr, *bits = nullptr;
+         *icpt = nullptr, *iters = nullptr, *work = nullptr, *iwork = nullptr, *bits = nullptr, *bitsT = nullptr;
     ~SolverBufs()
     {
-        void *ps[] = {xt, y, fold, param, ffold, coef, icpt, iters, work, iwork, bits};
+        void *ps[] = {xt, y, fold, param, ffold, coef, icpt, iters, work, iwork, bits, bitsT};
         for (void *q : ps) if (q) (void)hipFree(q);
     }
 };
@@ -993,8 +1081,29 @@ extern "C" int psk_logreg_l1_fit(psk_ctx *ctx, const float *X, const int32_t *y0
         }
         SV_ALLOC(b.bits, bits.size() * 8);
         PSK_HIP(ctx, hipMemcpyAsync(b.bits, bits.data(), bits.size() * 8, hipMemcpyHostToDevice, ctx->stream));
+        // the same columns transposed for the register form of the descent (n <= 2048): bit t of word l = sample 64 t + l
+        // (not built when every Newton step can take the Gram form: the register form's kernel would only cost registers)
+        const bool always_gram = q_doubles > 0 && p + 1 <= 192 && q_doubles >= need_q / 8;
+        std::vector<uint64_t> bitsT(W <= 32 && !always_gram && !getenv("PSK_NO_CD_REGS") ? (size_t)(p + 1) * 64 : 0, 0);
+        if (!bitsT.empty()) {
+            for (int j = 0; j <= p; j++)
+                for (int t = 0; t < W; t++) {
+                    uint64_t x = bits[(size_t)j * W + t];
+                    while (x) {
+                        const int l = __builtin_ctzll(x);
+                        x &= x - 1;
+                        bitsT[(size_t)j * 64 + l] |= 1ull << t;
+                    }
+                }
+            SV_ALLOC(b.bitsT, bitsT.size() * 8);
+            PSK_HIP(ctx, hipMemcpyAsync(b.bitsT, bitsT.data(), bitsT.size() * 8, hipMemcpyHostToDevice, ctx->stream));
+        }
         const bool all_lds = f_lds && s_lds == 3 && c_lds && q_lds;
-        auto kern = all_lds ? logreg_newglmnet_bits_kernel<true> : logreg_newglmnet_bits_kernel<false>;
+        const int wmreg = bitsT.empty() ? 0 : (W <= 16 ? 16 : 32);
+        auto kern = all_lds ? (wmreg == 0 ? logreg_newglmnet_bits_kernel<true, 0> : wmreg == 16 ? logreg_newglmnet_bits_kernel<true, 16>
+                                                                                               : logreg_newglmnet_bits_kernel<true, 32>)
+                            : (wmreg == 0 ? logreg_newglmnet_bits_kernel<false, 0> : wmreg == 16 ? logreg_newglmnet_bits_kernel<false, 16>
+                                                                                                : logreg_newglmnet_bits_kernel<false, 32>);
         if (lds_b > 64 * 1024)
             PSK_HIP(ctx, hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,
                                              (int)lds_b));
@@ -1003,7 +1112,8 @@ extern "C" int psk_logreg_l1_fit(psk_ctx *ctx, const float *X, const int32_t *y0
             (const int32_t *)b.ffold, tol, max_iter, (double *)b.coef, (double *)b.icpt, (int32_t *)b.iters,
             (double *)b.work, (int32_t *)b.iwork, f_lds, s_lds, c_lds, (int)q_doubles,
             getenv("PSK_CG_MAX") ? atoi(getenv("PSK_CG_MAX")) : 16,             // CG steps per polish
-            getenv("PSK_POLISH_REPS") ? atoi(getenv("PSK_POLISH_REPS")) : 64);  // polishes in a row while signs change
+            getenv("PSK_POLISH_REPS") ? atoi(getenv("PSK_POLISH_REPS")) : 64,   // polishes in a row while signs change
+            (const uint64_t *)b.bitsT);
         PSK_HIP(ctx, hipGetLastError());
         PSK_HIP(ctx, hipStreamSynchronize(ctx->stream));  // `bits` (host) must outlive the copy
     } else {

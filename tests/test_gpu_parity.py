@@ -499,6 +499,41 @@ def test_l1_logreg_mid_size_objectives_match_liblinear(ctx):
             assert float(z["obj_" + tag][j]) * (1 - 1e-9) <= obj <= float(z["obj_" + tag][j]) * 1.005, (tag, C)
 
 
+@pytest.mark.parametrize("n", [700, 2048])
+def test_l1_logreg_register_form_equals_lds_form(ctx, n, monkeypatch):
+    """More distinct columns than the Gram block holds (250 > 192) and n <= 2048: the descent keeps the samples in
+    registers and reads transposed columns.  Same sums in the same order as the LDS form (PSK_NO_CD_REGS=1), so the
+    coefficients are identical bit for bit; and the stop is liblinear's."""
+    rng = np.random.default_rng(n)
+    p = 250
+    base = rng.random((n, 12)) < 0.4
+    X = (base[:, rng.integers(0, 12, p)] ^ (rng.random((n, p)) < 0.08)).astype(np.float32)
+    y = (base[:, 0] ^ (rng.random(n) < 0.15)).astype(np.int32)
+    fold = (np.arange(n) % 3).astype(np.int32)
+    fp = np.array([0.01, 0.01, 0.1, 1.0, 1.0], np.float64)
+    ff = np.array([-1, 0, 1, 2, -1], np.int32)
+    a = ctx.logreg_l1_fit(X, y, fold, fp, ff, tol=1e-4, max_iter=1000)
+    monkeypatch.setenv("PSK_NO_CD_REGS", "1")
+    b = ctx.logreg_l1_fit(X, y, fold, fp, ff, tol=1e-4, max_iter=1000)
+    monkeypatch.delenv("PSK_NO_CD_REGS")
+    assert np.array_equal(a[2], b[2]) and a[2].max() < 200, (a[2], b[2])
+    assert np.array_equal(a[0], b[0]) and np.array_equal(a[1], b[1])
+    assert all((c != 0).sum() > 0 for c in a[0][2:])
+    ypm = 2.0 * y - 1.0
+    for j in range(len(fp)):
+        tr = fold != ff[j]
+        A = np.hstack([X[tr].astype(np.float64), np.ones((tr.sum(), 1))])
+        yt = ypm[tr]
+
+        def viol(th):
+            g = -fp[j] * (A.T @ (yt / (1.0 + np.exp(yt * (A @ th)))))
+            return np.where(th > 0, np.abs(g + 1), np.where(th < 0, np.abs(g - 1),
+                                                             np.maximum(0, np.maximum(-(g + 1), g - 1)))).sum()
+        th = np.append(a[0][j], a[1][j])
+        eps = 1e-4 * max(min((yt > 0).sum(), (yt < 0).sum()), 1) / tr.sum()
+        assert viol(th) <= 1.5 * eps * viol(np.zeros_like(th)) + 1e-9, (j, fp[j], a[2][j])
+
+
 def test_lasso_solver_matches_sklearn(ctx):
     z = np.load(os.path.join(GOLDEN, "model_kat.npz"))
     X, y = z["X2"], z["yc2"]
