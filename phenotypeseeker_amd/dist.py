@@ -17,6 +17,7 @@ nothing here touches a communicator.
 """
 import importlib
 import os
+import sys
 import tempfile
 import time
 
@@ -162,10 +163,14 @@ class RcclTransport:
     def __init__(self, rank, world, device):
         self.rank, self.world, self.device = rank, world, device
         self.ctx = PskContext(device)
-        uid, self._rdzv = exchange_unique_id(rank, world, self.ctx.comm_unique_id)
-        self.ctx.comm_init(uid, rank, world)
-        self.stream = self.ctx.comm_stream()
-        self.barrier()                      # every rank has joined: the file is no longer needed
+        try:
+            uid, self._rdzv = exchange_unique_id(rank, world, self.ctx.comm_unique_id)
+            self.ctx.comm_init(uid, rank, world)
+            self.stream = self.ctx.comm_stream()
+            self.barrier()                  # every rank has joined: the file is no longer needed
+        except Exception:
+            self.ctx.close()
+            raise
         if rank == 0:
             try:
                 os.unlink(self._rdzv)
@@ -200,6 +205,155 @@ class RcclTransport:
         self.ctx.close()
 
 
+class HostFileTransport:
+    """The same collectives through files in a directory beside the rendezvous file (ranks of ONE node): what a run
+    falls back to -- loudly, and named in `Group.backend` -- when RCCL cannot form the communicator (two ranks mapped
+    onto one GPU; a node without peer access).  Collective `seq` of rank r is the file `<seq>.<r>`, published by
+    rename; a rank removes its file of collective seq - 2 when it has finished seq - 1 (every rank has then read
+    it).  Device buffers are staged through the host.  Unset with PSK_DIST_STRICT=1."""
+    name = "host-files"
+    device_memory = True
+    stream = 0          # no collective stream: exports are the waited-for form
+
+    def __init__(self, rank, world, device, path=None, timeout=600.0):
+        self.rank, self.world, self.device, self.timeout = rank, world, device, timeout
+        self.dir = (path or _rendezvous_path()) + ".d"
+        os.makedirs(self.dir, exist_ok=True)
+        self.seq = 0
+        self.ctx = PskContext(device)
+        self.barrier()
+
+    def _name(self, seq, r):
+        return os.path.join(self.dir, "%d.%d" % (seq, r))
+
+    def _exchange(self, payload):
+        """all-gather(v) of one bytes object per rank."""
+        seq, self.seq = self.seq, self.seq + 1
+        tmp = self._name(seq, self.rank) + ".tmp"
+        with open(tmp, "wb") as f:
+            f.write(payload)
+        os.replace(tmp, self._name(seq, self.rank))
+        out = []
+        t0 = time.time()
+        for r in range(self.world):
+            if r == self.rank:
+                out.append(payload)
+                continue
+            while True:
+                try:
+                    with open(self._name(seq, r), "rb") as f:
+                        out.append(f.read())
+                    break
+                except OSError:
+                    if time.time() - t0 > self.timeout:
+                        raise RuntimeError("rank %d: collective %d timed out waiting for rank %d" % (self.rank, seq, r))
+                    time.sleep(0.0005)
+        if seq >= 2:
+            try:
+                os.unlink(self._name(seq - 2, self.rank))
+            except OSError:
+                pass
+        return out
+
+    def alloc(self, nbytes):
+        return DeviceBuffer(self.ctx, nbytes)
+
+    def to_host(self, buf, nbytes, offset=0):
+        return self.ctx.dev_download(buf.ptr + offset, nbytes)
+
+    def allreduce(self, arr, op):
+        got = np.stack([np.frombuffer(b, dtype=arr.dtype) for b in self._exchange(arr.tobytes())])
+        arr[...] = (got.sum(axis=0, dtype=arr.dtype) if op == "sum" else got.max(axis=0)).reshape(arr.shape)
+        return arr
+
+    def allgather_host(self, send_u8):
+        send = np.ascontiguousarray(send_u8).view(np.uint8).ravel()
+        return np.stack([np.frombuffer(b, dtype=np.uint8) for b in self._exchange(send.tobytes())])
+
+    def allgather_device(self, send, recv, nbytes):
+        got = self.allgather_host(self.to_host(send, nbytes)) if nbytes else None
+        if nbytes:
+            self.ctx.dev_upload(recv.ptr, got)
+
+    def alltoallv(self, send, send_counts, recv, recv_counts, elem_bytes):
+        sc = [int(c) * elem_bytes for c in send_counts]
+        src = self.to_host(send, sum(sc)).tobytes() if sum(sc) else b""
+        head = np.array(sc, dtype=np.int64).tobytes()
+        parts = []
+        for r, blob in enumerate(self._exchange(head + src)):
+            their = np.frombuffer(blob, dtype=np.int64, count=self.world)
+            off = 8 * self.world + int(their[: self.rank].sum())
+            parts.append(blob[off: off + int(their[self.rank])])
+            assert len(parts[-1]) == int(recv_counts[r]) * elem_bytes
+        got = np.frombuffer(b"".join(parts), dtype=np.uint8)
+        if got.size:
+            self.ctx.dev_upload(recv.ptr, got)
+
+    def sync(self):
+        pass
+
+    def barrier(self):
+        self._exchange(b"\0")
+
+    def close(self):
+        for seq in (self.seq - 2, self.seq - 1):
+            if seq >= 0:
+                try:
+                    os.unlink(self._name(seq, self.rank))
+                except OSError:
+                    pass
+        try:
+            os.rmdir(self.dir)
+        except OSError:
+            pass
+        self.ctx.close()
+
+
+def _rccl_or_host_files(rank, world, device):
+    """RCCL; when the communicator cannot be formed on some rank every rank learns it (one status file per rank next
+    to the rendezvous file) and all of them take the host-file transport together."""
+    path = _rendezvous_path()
+    t, err = None, ""
+    try:
+        t = RcclTransport(rank, world, device)
+    except Exception as e:      # PskError from psk_comm_init, or the rendezvous timing out
+        if os.environ.get("PSK_DIST_STRICT") == "1":
+            raise
+        err = "%s: %s" % (type(e).__name__, e)
+    if os.environ.get("PSK_DIST_STRICT") == "1":
+        return t
+    mine = "%s.st.%d" % (path, rank)
+    with open(mine + ".tmp", "w") as f:
+        f.write(err)
+    os.replace(mine + ".tmp", mine)
+    errs, t0 = [], time.time()
+    for r in range(world):
+        while True:
+            try:
+                with open("%s.st.%d" % (path, r)) as f:
+                    errs.append(f.read())
+                break
+            except OSError:
+                if time.time() - t0 > 600:
+                    raise RuntimeError("rank %d: no transport status from rank %d" % (rank, r))
+                time.sleep(0.005)
+    bad = [(r, e) for r, e in enumerate(errs) if e]
+    if bad:
+        if t is not None:
+            t.close()
+        if rank == 0:
+            sys.stderr.write("phenotypeseeker_amd.dist: RCCL communicator not formed (rank %d: %s); collectives go "
+                             "through host files in %s.d (PSK_DIST_STRICT=1 makes this an error)\n" % (bad[0][0], bad[0][1], path))
+        t = HostFileTransport(rank, world, device, path)
+        t.fallback_reason = bad[0][1]
+    t.barrier()
+    try:
+        os.unlink(mine)
+    except OSError:
+        pass
+    return t
+
+
 class Group:
     """The ranks of one run (or a no-op for one rank).  RANK / WORLD_SIZE / LOCAL_RANK as torch.distributed.run
     and every MPI-style launcher export them."""
@@ -227,7 +381,7 @@ class Group:
             from . import _lib
             self.device = self.local_rank % max(_lib.load().psk_device_count(), 1)
         if transport is None:
-            transport = (cls or RcclTransport)(self.rank, self.world, self.device)
+            transport = cls(self.rank, self.world, self.device) if cls else _rccl_or_host_files(self.rank, self.world, self.device)
         self.t = transport
         self.backend = transport.name
         return self

@@ -46,16 +46,24 @@ def test_bench_two_ranks_run_the_sharded_pipeline():
                          timeout=600, capture_output=True, text=True)
     assert one.returncode == 0, one.stderr[-2000:]
     d1 = json.loads(one.stdout.strip().splitlines()[-1])
-    for port, ingest in ((29631, "filter"), (29633, "exchange")):
+    for port, ingest, transport in ((29631, "filter", "gloo"), (29633, "exchange", "gloo"), (29635, "filter", "host-files"),
+                                    (29637, "exchange", "host-files")):
+        # without a named transport RCCL is tried, refuses the shared GPU on both ranks, and the run falls back -- loudly --
+        # to the host-file transport of dist.py
+        env_t = env if transport == "gloo" else {k_: v for k_, v in env.items() if k_ != "PSK_DIST_TRANSPORT"}
         cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
                "--master-port", str(port), os.path.join(ROOT, "bench.py"), "--gpus", "2", "--share-gpu", "--ingest", ingest] + size
-        r = subprocess.run(cmd, env=env, cwd=ROOT, timeout=900, capture_output=True, text=True)
+        r = subprocess.run(cmd, env=env_t, cwd=ROOT, timeout=900, capture_output=True, text=True)
         assert r.returncode == 0, r.stderr[-3000:]
         lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
         assert len(lines) == 1
         d = json.loads(lines[0])
         cfg = d["config"]
-        assert d["n_gpus"] == 2 and d["scaling"] == "strong" and cfg["collectives"] == "gloo"
+        assert d["n_gpus"] == 2 and d["scaling"] == "strong"
+        if transport == "gloo":
+            assert cfg["collectives"] == "gloo"
+        else:
+            assert cfg["collectives"].startswith("host-files (fallback: ") and "RCCL communicator not formed" in r.stderr
         assert len(cfg["rows_per_rank"]) == 2 and sum(cfg["rows_per_rank"]) == cfg["rows_global"] == d1["config"]["rows_per_gpu"]
         assert cfg["balance_max_over_mean"] <= 1.10
         assert cfg["survivors_all_slabs"] == d1["config"]["survivors"]
