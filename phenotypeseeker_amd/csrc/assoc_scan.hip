@@ -132,8 +132,9 @@ __device__ __forceinline__ double chi2_exact(double A, double B, double C, doubl
 // costs 2 + NM VALU ops: the presence bit becomes 0.0 / 1.0 (v_bfe_i32 + v_and 0x3FF00000 on the high
 // word), then one v_fma_f64 per moment with the table entry as an SGPR operand -- no cross-lane
 // reduction at all.  The sums associate differently from the reference's sample-order loops (two interleaved
-// accumulators here, groups of four samples in the table form below): weighted statistics agree with the
-// reference to ~1e-15 relative, not to the last bit (DESIGN.md "Exactness strategy").
+// accumulators here, groups of four samples in the table form below): ~1e-15 relative from the reference.  The Welch
+// statistics are used as they come (compared at 1e-8); the weighted chi2 uses these sums for its pre-test only and
+// re-sums the candidates in the reference's order (chi2w_finalize_kernel; DESIGN.md "Exactness strategy").
 // (r01: the previous whole-wave-per-row form spent ~1000 cycles per row in LDS latency and three DPP wave
 // sums: 11.1 ms for 16 M x 1024 with a third of the rows passing.)
 typedef const __attribute__((address_space(4))) double *cdptr;
@@ -281,6 +282,37 @@ __device__ __forceinline__ int queue_pop64(uint64_t *q_row, int2 *q_val, int q, 
 // MODE 2: unit weights, rows that pass the pre-test are queued the same way: a scan with many survivors
 //         (--omit_B_correction keeps ~pvalue of all rows) then evaluates 64 of them per pass instead of one or two
 //         lanes of a wave at a time.  Same formulas, same results as MODE 0 (the host picks, see pick_chi2_mode).
+// The weighted 2 x 2 table of one row per lane exactly as the reference accumulates it (modeling.py:809-823): every
+// sample in order adds its weight to ONE of the four cells; here the other three get + 0.0, which changes nothing
+// (and a weight times 1.0 or 0.0 is exact, so one fma per cell is that addition).
+// tab[2 s] = weight of a phenotype-1 sample, tab[2 s + 1] = of a phenotype-0 sample (0 for NA and padding); all lanes
+// visit sample s together, so the entries are scalar loads.
+__device__ __forceinline__ void row_cells_exact(const u32x4 *__restrict__ rp, int cpr, cdptr tab, double &A, double &B, double &C,
+                                                double &D)
+{
+    double a = 0.0, b = 0.0, c = 0.0, d = 0.0;
+    for (int ch = 0; ch < cpr; ch++) {
+        const u32x4 y = rp[ch];
+        const uint32_t w4[4] = {y.x, y.y, y.z, y.w};
+        cdptr tp = tab + (size_t)ch * 256;
+#pragma unroll
+        for (int h = 0; h < 4; h++) {
+#pragma unroll 4
+            for (int s = 0; s < 32; s++) {
+                // f = 1.0 / 0.0 for a present / absent sample, g = 1 - f: fma(f, t, a) is a + t or a + 0.0, rounded once
+                const uint32_t fh = (uint32_t)(((int32_t)(w4[h] << (31 - s))) >> 31) & 0x3FF00000u;
+                const double f = __hiloint2double((int)fh, 0), g = __hiloint2double((int)(fh ^ 0x3FF00000u), 0);
+                const double t1 = tp[(h * 32 + s) * 2], t0 = tp[(h * 32 + s) * 2 + 1];
+                a = fma(f, t1, a);
+                b = fma(g, t1, b);
+                c = fma(f, t0, c);
+                d = fma(g, t0, d);
+            }
+        }
+    }
+    A = a; B = b; C = c; D = d;
+}
+
 template <int G, int MODE, bool LUT = false>
 __global__ __launch_bounds__(LUT ? SC_LUT_THREADS : SC_THREADS) void chi2_scan_kernel(const ScanArgs P)
 {
@@ -320,12 +352,18 @@ __global__ __launch_bounds__(LUT ? SC_LUT_THREADS : SC_THREADS) void chi2_scan_k
             double ws[2];
             if (LUT) row_moments_mixed<2>(P.bits + r * (uint64_t)P.cpr, P.cpr, P.c_lut, s_lut, (cdptr)P.tab, ws);
             else row_moments<2>(P.bits + r * (uint64_t)P.cpr, P.cpr, (cdptr)P.tab, ws);
-            if (!act) return;
             A = ws[0]; B = P.W1 - ws[0]; C = ws[1]; D = P.W0 - ws[1];
             const double R1 = A + B, R0 = C + D, K1 = A + C, K0 = B + D, T = R1 + R0;
             const double det = A * D - B * C;
             const double lhs = T * det * det, rhs = P.thr * R1 * R0 * K1 * K0;
-            if (lhs < rhs * (1.0 - 1e-9)) return;
+            // candidates only: chi2w_finalize_kernel gives them the reference's own cells and decides (the sums here
+            // associate differently, ~1e-15: hence the 1e-9 margin)
+            if (act && !(lhs < rhs * (1.0 - 1e-9))) {
+                const uint64_t idx = reserve_slot(P);
+                P.res_row[idx] = r;
+                P.res_nw[idx] = r_nw;
+            }
+            return;
         } else {
             if (!act) return;
             A = (double)qv.x; B = (double)(P.n1 - qv.x); C = (double)qv.y; D = (double)(P.n0 - qv.y);
@@ -417,7 +455,54 @@ __global__ __launch_bounds__(LUT ? SC_LUT_THREADS : SC_THREADS) void chi2_scan_k
             }
         }
     }
-    publish_segment(P);
+    if (!WEIGHTED) publish_segment(P);   // weighted: chi2w_finalize_kernel publishes
+}
+
+// Second pass of the weighted chi2 scan: one workgroup per result segment, one candidate per lane.  The 2 x 2 table is
+// summed again exactly as the reference does it (row_cells_exact), so the statistic, round(chi2, 2) and "%.2E" of the
+// p-value are the reference's to the last bit; then the keep rule of modeling.py:795 and the compaction of the segment
+// in place.  (Doing this inside the scan kernel, per 64 queued rows with at least one candidate, cost 2.3 ms instead of
+// 0.6 ms for 16 M x 1024: the sample-order sums are a dependent chain of 1024 f64 adds whatever the number of live lanes.)
+constexpr int SC_FIN_THREADS = 1024;   // four waves per SIMD: the scalar loads of the table entries need the cover
+__global__ __launch_bounds__(SC_FIN_THREADS) void chi2w_finalize_kernel(const ScanArgs P)
+{
+    __shared__ uint32_t scan_lds[SC_FIN_THREADS / 64];
+    __shared__ uint32_t s_out;
+    const uint32_t seg = blockIdx.x;
+    const uint32_t c = P.counter[seg * SC_CNT_STRIDE];
+    const uint64_t base = (uint64_t)seg * P.seg_cap;
+    if (threadIdx.x == 0) s_out = 0;
+    __syncthreads();
+    for (uint32_t s0 = 0; s0 < c; s0 += SC_FIN_THREADS) {
+        const uint32_t i = s0 + threadIdx.x;
+        const bool valid = i < c;
+        const uint64_t row = valid ? P.res_row[base + i] : 0;
+        const int32_t nw = valid ? P.res_nw[base + i] : 0;
+        double stat = 0.0, p = 1.0;
+        bool keep = false;
+        if (__any(valid)) {
+            double A, B, C, D;
+            row_cells_exact(P.bits + row * (uint64_t)P.cpr, P.cpr, (cdptr)P.tab, A, B, C, D);
+            stat = chi2_exact(A, B, C, D);
+            p = exp(-0.5 * stat);
+            keep = valid && ((P.omit_B && p < P.pcut) || (p < P.pcut_bonf));
+        }
+        uint32_t tot;
+        const uint32_t pos = psk_block_excl_scan_u32<SC_FIN_THREADS>(keep ? 1u : 0u, &tot, scan_lds);  // barriers inside
+        const uint32_t out = s_out;
+        if (keep) {
+            const uint64_t o = base + out + pos;  // <= base + i: compaction only moves entries down
+            P.res_row[o] = row; P.res_stat[o] = stat; P.res_p[o] = p; P.res_nw[o] = nw;
+        }
+        __syncthreads();
+        if (threadIdx.x == 0) s_out = out + tot;
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) {
+        P.counter[seg * SC_CNT_STRIDE] = 0;  // re-armed for the next scan
+        P.final_counts[seg] = s_out;
+        P.host_counts[seg] = s_out;
+    }
 }
 
 // ---- Student-t two-sided p-value: I_{df/(df+t^2)}(df/2, 1/2), Lentz continued fraction ---------
@@ -613,8 +698,11 @@ void launch_chi2_lut(int G, dim3 grid, hipStream_t st, const ScanArgs &a)
 
 void launch_chi2(int mode, int G, dim3 grid, hipStream_t st, const ScanArgs &a)
 {
-    if (mode == 1 && a.lut) launch_chi2_lut(G, grid, st, a);
-    else if (mode == 1) launch_chi2_mode<1>(G, grid, st, a);
+    if (mode == 1) {
+        if (a.lut) launch_chi2_lut(G, grid, st, a);
+        else launch_chi2_mode<1>(G, grid, st, a);
+        chi2w_finalize_kernel<<<SC_NSEG, SC_FIN_THREADS, 0, st>>>(a);
+    }
     else if (mode == 2) launch_chi2_mode<2>(G, grid, st, a);
     else launch_chi2_mode<0>(G, grid, st, a);
 }
