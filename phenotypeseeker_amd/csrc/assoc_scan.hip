@@ -35,7 +35,10 @@ namespace {
 #define PSK_SC_NT 1
 #endif
 constexpr int SC_THREADS = 256;
-constexpr int SC_LUT_THREADS = 1024;   // workgroup of the moment scans that keep their nibble tables in LDS (one per CU)
+#ifndef PSK_LUT_THREADS
+#define PSK_LUT_THREADS 1024
+#endif
+constexpr int SC_LUT_THREADS = PSK_LUT_THREADS;   // workgroup of the moment scans that keep their nibble tables in LDS (one per CU)
 constexpr size_t SC_LUT_MAX_BYTES = 100 * 1024;
 constexpr int SC_UNROLL = PSK_SC_UNROLL;
 // Survivors are appended to SC_NSEG independent segments (segment = blockIdx % SC_NSEG), each with its
@@ -140,7 +143,15 @@ __device__ __forceinline__ double chi2_exact(double A, double B, double C, doubl
 typedef const __attribute__((address_space(4))) double *cdptr;
 // queue entries per wave: < 64 carried over + <= 64 / G appended per step of an unrolled batch
 constexpr int rq_cap(int G, int unroll = SC_UNROLL) { return 64 + (64 / G) * unroll; }
-constexpr int SC_LUT_UNROLL = 8;   // rows in flight per lane group of the table-in-LDS kernels (half the waves per CU)
+#ifndef PSK_LUT_UNROLL
+#define PSK_LUT_UNROLL 8
+#endif
+#ifndef PSK_LUT_NT
+#define PSK_LUT_NT 1     // streaming loads of the table-in-LDS kernels carry the nontemporal hint
+#endif
+// rows in flight per lane group of the table-in-LDS kernels (half the waves per CU of the plain ones); fewer where a
+// wave step covers many rows, so that the waves' queues stay small beside the table
+constexpr int lut_unroll(int G) { return G == 1 ? (PSK_LUT_UNROLL < 4 ? PSK_LUT_UNROLL : 4) : G == 2 ? (PSK_LUT_UNROLL < 8 ? PSK_LUT_UNROLL : 8) : PSK_LUT_UNROLL; }
 
 template <int NM>
 __device__ __forceinline__ void row_moments(const u32x4 *__restrict__ rp, int cpr, cdptr tab, double *acc)
@@ -196,25 +207,43 @@ __global__ void moment_lut_kernel(const double *__restrict__ tab, int n_groups, 
     }
 }
 
+// The row itself is read SC_LUT_PF chunks at a time, all loads issued before the first lookup: read one chunk ahead
+// (r02 at first) every chunk paid a global-load latency of its own, and THAT, not the LDS pipe, set the time of the pass
+// (~8 us per 64 rows of 1024 samples against 1.7 us of lookups).
+constexpr int SC_LUT_PF = 8;
 template <int NM>
 __device__ __forceinline__ void row_moments_lut(const u32x4 *__restrict__ rp, int cpr, const double *lut, double *acc)
 {
     double a0[NM], a1[NM];
 #pragma unroll
     for (int m = 0; m < NM; m++) { a0[m] = 0.0; a1[m] = 0.0; }
-    u32x4 y = rp[0];
-    for (int ch = 0; ch < cpr; ch++) {
-        const uint32_t w4[4] = {y.x, y.y, y.z, y.w};
-        if (ch + 1 < cpr) y = rp[ch + 1];
-        const double *lp = lut + (size_t)ch * 32 * 16 * NM;   // 32 groups of 4 samples per 16-byte chunk
+    for (int c0 = 0; c0 < cpr; c0 += SC_LUT_PF) {
+        u32x4 y[SC_LUT_PF];
 #pragma unroll
-        for (int h = 0; h < 4; h++) {
+        for (int i = 0; i < SC_LUT_PF; i++) y[i] = c0 + i < cpr ? rp[c0 + i] : (u32x4)(0u);
 #pragma unroll
-            for (int k = 0; k < 8; k += 2) {
-                const double *e0 = lp + ((h * 8 + k) * 16 + ((w4[h] >> (4 * k)) & 15u)) * NM;
-                const double *e1 = lp + ((h * 8 + k + 1) * 16 + ((w4[h] >> (4 * k + 4)) & 15u)) * NM;
+        for (int i = 0; i < SC_LUT_PF; i++) {
+            if (c0 + i >= cpr) break;
+            const uint32_t w4[4] = {y[i].x, y[i].y, y[i].z, y[i].w};
+            const double *lp = lut + (size_t)(c0 + i) * 32 * 16 * NM;   // 32 groups of 4 samples per 16-byte chunk
 #pragma unroll
-                for (int m = 0; m < NM; m++) { a0[m] += e0[m]; a1[m] += e1[m]; }
+            for (int h = 0; h < 4; h++) {
+#pragma unroll
+                for (int k = 0; k < 8; k += 2) {
+                    const double *e0 = lp + ((h * 8 + k) * 16 + ((w4[h] >> (4 * k)) & 15u)) * NM;
+                    const double *e1 = lp + ((h * 8 + k + 1) * 16 + ((w4[h] >> (4 * k + 4)) & 15u)) * NM;
+                    if (NM == 2) {
+                        // ONE 16-byte read per entry (ds_read_b128: 4 LDS cycles, banks mod 64, the 16 entries of a
+                        // group = the 64 banks).  Read as two doubles it became ds_read2_b64 -- 8 cycles, banks mod 32,
+                        // every group 2-way conflicted: 41 % of the LDS cycles of the pass (SQ_LDS_BANK_CONFLICT, r02)
+                        const double2 v0 = *reinterpret_cast<const double2 *>(__builtin_assume_aligned(e0, 16));
+                        const double2 v1 = *reinterpret_cast<const double2 *>(__builtin_assume_aligned(e1, 16));
+                        a0[0] += v0.x; a0[NM - 1] += v0.y; a1[0] += v1.x; a1[NM - 1] += v1.y;
+                    } else {
+#pragma unroll
+                        for (int m = 0; m < NM; m++) { a0[m] += e0[m]; a1[m] += e1[m]; }
+                    }
+                }
             }
         }
     }
@@ -318,10 +347,10 @@ __global__ __launch_bounds__(LUT ? SC_LUT_THREADS : SC_THREADS) void chi2_scan_k
 {
     constexpr bool WEIGHTED = MODE == 1, QUEUED = MODE != 0;
     constexpr int THREADS = LUT ? SC_LUT_THREADS : SC_THREADS;
-    constexpr int UNR = LUT ? SC_LUT_UNROLL : SC_UNROLL;
+    constexpr int UNR = LUT ? lut_unroll(G) : SC_UNROLL;
     __shared__ uint64_t s_qrow[QUEUED ? THREADS / 64 : 1][QUEUED ? rq_cap(G, UNR) : 1];
     __shared__ int2 s_qval[QUEUED ? THREADS / 64 : 1][QUEUED ? rq_cap(G, UNR) : 1];
-    extern __shared__ double s_lut[];   // LUT: the nibble table of row_moments_lut
+    extern __shared__ __attribute__((aligned(16))) double s_lut[];   // LUT: the nibble table of row_moments_lut
     if (LUT) load_lut(s_lut, P.lut, P.c_lut * 32 * 16 * 2, THREADS);
     constexpr int RPW = 64 / G;  // rows per wave step
     const int lane = threadIdx.x & 63;
@@ -399,7 +428,8 @@ __global__ __launch_bounds__(LUT ? SC_LUT_THREADS : SC_THREADS) void chi2_scan_k
             x[u] = (u32x4)(0u);
             if (row < P.M && has_chunk) {
 #if PSK_SC_NT
-                x[u] = __builtin_nontemporal_load(&P.bits[row * (uint64_t)P.cpr + g]);
+                if (LUT && !PSK_LUT_NT) x[u] = P.bits[row * (uint64_t)P.cpr + g];
+                else x[u] = __builtin_nontemporal_load(&P.bits[row * (uint64_t)P.cpr + g]);
 #else
                 x[u] = P.bits[row * (uint64_t)P.cpr + g];
 #endif
@@ -560,12 +590,12 @@ template <int G, bool WT, bool LUT = false>
 __global__ __launch_bounds__(LUT ? SC_LUT_THREADS : SC_THREADS) void ttest_scan_kernel(const ScanArgs P, const double mu)
 {
     constexpr int THREADS = LUT ? SC_LUT_THREADS : SC_THREADS;
-    constexpr int UNR = LUT ? SC_LUT_UNROLL : SC_UNROLL;
+    constexpr int UNR = LUT ? lut_unroll(G) : SC_UNROLL;
     __shared__ uint64_t s_qrow[THREADS / 64][rq_cap(G, UNR)];
     __shared__ int2 s_qval[THREADS / 64][rq_cap(G, UNR)];
     constexpr int RPW = 64 / G;
     constexpr int NM = WT ? 3 : 2;
-    extern __shared__ double s_lut[];   // LUT: the nibble table of row_moments_lut
+    extern __shared__ __attribute__((aligned(16))) double s_lut[];   // LUT: the nibble table of row_moments_lut
     if (LUT) load_lut(s_lut, P.lut, P.c_lut * 32 * 16 * NM, THREADS);
     const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
     const int g = lane & (G - 1);
@@ -627,7 +657,8 @@ __global__ __launch_bounds__(LUT ? SC_LUT_THREADS : SC_THREADS) void ttest_scan_
         for (int u = 0; u < UNR; u++) {
             const uint64_t row = (s0 + u) * RPW + rsub;
             x[u] = (u32x4)(0u);
-            if (row < P.M && has_chunk) x[u] = __builtin_nontemporal_load(&P.bits[row * (uint64_t)P.cpr + g]);
+            if (row < P.M && has_chunk)
+                x[u] = (LUT && !PSK_LUT_NT) ? P.bits[row * (uint64_t)P.cpr + g] : __builtin_nontemporal_load(&P.bits[row * (uint64_t)P.cpr + g]);
         }
 #pragma unroll
         for (int u = 0; u < UNR; u++) {
@@ -988,7 +1019,7 @@ static int fill_chi2_args(psk_ctx *ctx, ScanArgs &a, int set)
     const int G = group_lanes(a.cpr);
     a.lut = (L.weighted && ctx->lut_valid) ? ctx->lut.as<double>() : nullptr;
     a.c_lut = a.lut ? lut_chunks(a.cpr, 2) : 0;
-    return setup_results(ctx, a, scan_grid(ctx, a.M, G, SC_UNROLL, a.lut != nullptr), G, a.lut ? SC_LUT_UNROLL : SC_UNROLL, set,
+    return setup_results(ctx, a, scan_grid(ctx, a.M, G, SC_UNROLL, a.lut != nullptr), G, a.lut ? lut_unroll(G) : SC_UNROLL, set,
                          a.lut ? SC_LUT_THREADS : SC_THREADS);
 }
 
@@ -1207,7 +1238,7 @@ extern "C" int psk_ttest_scan(psk_ctx *ctx, const double *pheno, const uint8_t *
     a.c_lut = lut_chunks(a.cpr, NM);
     if (a.c_lut > 0) PSK_TRY(build_moment_lut(ctx, a.tab, a.c_lut, NM, &a.lut));
     const dim3 grid = scan_grid(ctx, a.M, G, SC_UNROLL, a.lut != nullptr);
-    PSK_TRY(setup_results(ctx, a, grid, G, a.lut ? SC_LUT_UNROLL : SC_UNROLL, set, a.lut ? SC_LUT_THREADS : SC_THREADS));
+    PSK_TRY(setup_results(ctx, a, grid, G, a.lut ? lut_unroll(G) : SC_UNROLL, set, a.lut ? SC_LUT_THREADS : SC_THREADS));
     ctx->n_pass = 0;
     ctx->last_scan_kind = 2;
     ctx->last.valid = false;

@@ -5,7 +5,7 @@
   moments    the f64 scans on a device-generated 16 M x 1024 matrix: Welch t, GSC-weighted chi2, weighted Welch t
   fastq      one config-5 sample: 2 M x 150-bp reads, 0.63 GB of FASTQ, framed and counted
   ingest     config 2's ingest alone: 256 x 5 Mbp, k = 13, counted three times + presence build
-  solver     the L1 (grid value, fold) fits of two recorded runs (143 fits each)
+  solver     the L1 (grid value, fold) fits of three recorded runs (143 fits each)
 Each prints one JSON line: the algorithmic bytes per launch of its kernels (what `frac` in profiles/ is computed from).
 usage: tools/profile_workloads.py NAME"""
 import json
@@ -57,13 +57,13 @@ elif what == "moments":
         vals = rng.normal(0, 1, N) + ph * 0.3
         w = rng.uniform(0.5, 1.5, N)
         ones = np.ones(N, np.uint8)
-        t = {}
+        t, kept = {}, {}
         for rep in range(3):
-            ctx.chi2_scan(ph, None, 2, N - 2, 0.05, False, M); t["chi2"] = ctx.last_scan_ms()
-            ctx.chi2_scan(ph, w, 2, N - 2, 0.05, False, M); t["chi2_weighted"] = ctx.last_scan_ms()
-            ctx.ttest_scan(vals, ones, None, 2, N - 2, 0.05, M); t["ttest"] = ctx.last_scan_ms()
-            ctx.ttest_scan(vals, ones, w, 2, N - 2, 0.05, M); t["ttest_weighted"] = ctx.last_scan_ms()
-        out["notes"] = {"rows": M, "samples": N, "event_ms": t}
+            kept["chi2"] = ctx.chi2_scan(ph, None, 2, N - 2, 0.05, False, M); t["chi2"] = ctx.last_scan_ms()
+            kept["chi2_weighted"] = ctx.chi2_scan(ph, w, 2, N - 2, 0.05, False, M); t["chi2_weighted"] = ctx.last_scan_ms()
+            kept["ttest"] = ctx.ttest_scan(vals, ones, None, 2, N - 2, 0.05, M); t["ttest"] = ctx.last_scan_ms()
+            kept["ttest_weighted"] = ctx.ttest_scan(vals, ones, w, 2, N - 2, 0.05, M); t["ttest_weighted"] = ctx.last_scan_ms()
+        out["notes"] = {"rows": M, "samples": N, "event_ms": t, "rows_kept": {k_: int(v) for k_, v in kept.items()}}
         for name in ("chi2_scan_kernel", "ttest_scan_kernel"):
             alg[name] = M * (N // 8)
 elif what == "fastq":
@@ -124,6 +124,12 @@ elif what == "solver":
                                   int(z["max_iter"]))
                 ts.append(round(time.time() - t0, 4))
             out["notes"][tag] = {"X": list(X.shape), "fits": int(len(z["fit_param"])), "wall_s": ts}
+        # the grid of a 2048-genome run whose 1000 selected k-mers have 907 distinct patterns (register form of the descent)
+        d = np.load(os.path.join(ROOT, "tools", "data", "fit2048_907.npz"))
+        X = np.unpackbits(d["Xbits"], axis=1)[:, : int(d["p"])].astype(np.float32)
+        t0 = time.time()
+        ctx.logreg_l1_fit(X, d["y"], d["fold"], d["fit_param"], d["fit_fold"], float(d["tol"]), int(d["max_iter"]))
+        out["notes"]["fit2048_907"] = {"X": list(X.shape), "fits": int(len(d["fit_param"])), "wall_s": [round(time.time() - t0, 3)]}
 else:
     raise SystemExit("unknown workload " + what)
 print(json.dumps(out), flush=True)
