@@ -203,7 +203,9 @@ __global__ void moment_lut_kernel(const double *__restrict__ tab, int n_groups, 
 #pragma unroll
         for (int b = 0; b < 4; b++)
             if ((p >> b) & 1) s += tab[(size_t)(4 * g + b) * NM + m];
-        lut[(size_t)i * NM + m] = s;
+        // NM = 3: the first two moments as 16-byte pairs, the third in a table of its own behind them (row_moments_lut)
+        if (NM == 3) lut[m < 2 ? (size_t)i * 2 + m : (size_t)n_groups * 32 + i] = s;
+        else lut[(size_t)i * NM + m] = s;
     }
 }
 
@@ -225,14 +227,24 @@ __device__ __forceinline__ void row_moments_lut(const u32x4 *__restrict__ rp, in
         for (int i = 0; i < SC_LUT_PF; i++) {
             if (c0 + i >= cpr) break;
             const uint32_t w4[4] = {y[i].x, y[i].y, y[i].z, y[i].w};
-            const double *lp = lut + (size_t)(c0 + i) * 32 * 16 * NM;   // 32 groups of 4 samples per 16-byte chunk
+            // 32 groups of 4 samples per 16-byte chunk.  NM = 3: entries of 24 bytes were read as ds_read2_b64 + ds_read_b64
+            // (8 + 2 LDS cycles, banks mod 32); pairs {m0, m1} and a separate table of m2 are a ds_read_b128 and a
+            // ds_read_b64 (4 + 2 cycles, both conflict-free: 16 entries = 64 resp. 32 of the 64 banks)
+            const double *lp = lut + (size_t)(c0 + i) * 32 * 16 * (NM == 3 ? 2 : NM);
+            const double *lp2 = lut + (size_t)cpr * 32 * 16 * 2 + (size_t)(c0 + i) * 32 * 16;   // NM = 3 only
 #pragma unroll
             for (int h = 0; h < 4; h++) {
 #pragma unroll
                 for (int k = 0; k < 8; k += 2) {
-                    const double *e0 = lp + ((h * 8 + k) * 16 + ((w4[h] >> (4 * k)) & 15u)) * NM;
-                    const double *e1 = lp + ((h * 8 + k + 1) * 16 + ((w4[h] >> (4 * k + 4)) & 15u)) * NM;
-                    if (NM == 2) {
+                    const uint32_t i0 = (h * 8 + k) * 16 + ((w4[h] >> (4 * k)) & 15u), i1 = (h * 8 + k + 1) * 16 + ((w4[h] >> (4 * k + 4)) & 15u);
+                    const double *e0 = lp + i0 * (NM == 3 ? 2 : NM);
+                    const double *e1 = lp + i1 * (NM == 3 ? 2 : NM);
+                    if (NM == 3) {
+                        const double2 v0 = *reinterpret_cast<const double2 *>(__builtin_assume_aligned(e0, 16));
+                        const double2 v1 = *reinterpret_cast<const double2 *>(__builtin_assume_aligned(e1, 16));
+                        a0[0] += v0.x; a0[1] += v0.y; a1[0] += v1.x; a1[1] += v1.y;
+                        a0[NM - 1] += lp2[i0]; a1[NM - 1] += lp2[i1];
+                    } else if (NM == 2) {
                         // ONE 16-byte read per entry (ds_read_b128: 4 LDS cycles, banks mod 64, the 16 entries of a
                         // group = the 64 banks).  Read as two doubles it became ds_read2_b64 -- 8 cycles, banks mod 32,
                         // every group 2-way conflicted: 41 % of the LDS cycles of the pass (SQ_LDS_BANK_CONFLICT, r02)
