@@ -15,6 +15,8 @@ unique id travels through a rendezvous file.  No PyTorch anywhere in this packag
 inject a host transport (tests/_gloo_transport.py, named by PSK_DIST_TRANSPORT=module:Class).  With world size 1
 nothing here touches a communicator.
 """
+import contextlib
+import ctypes
 import importlib
 import os
 import sys
@@ -155,6 +157,23 @@ def exchange_unique_id(rank, world, make_id, timeout=300.0, path=None):
         time.sleep(0.01)
 
 
+@contextlib.contextmanager
+def _stdout_to_stderr():
+    """File descriptor 1 points at stderr while the block runs (C stdio flushed on both sides)."""
+    libc = ctypes.CDLL(None)
+    sys.stdout.flush()
+    libc.fflush(None)
+    saved = os.dup(1)
+    os.dup2(2, 1)
+    try:
+        yield
+    finally:
+        sys.stdout.flush()
+        libc.fflush(None)
+        os.dup2(saved, 1)
+        os.close(saved)
+
+
 class RcclTransport:
     """RCCL over xGMI through libpsk.so's own communicator (csrc/comm.hip)."""
     name = "rccl"
@@ -165,7 +184,8 @@ class RcclTransport:
         self.ctx = PskContext(device)
         try:
             uid, self._rdzv = exchange_unique_id(rank, world, self.ctx.comm_unique_id)
-            self.ctx.comm_init(uid, rank, world)
+            with _stdout_to_stderr():       # RCCL prints a version banner on stdout; a caller's stdout may be a protocol
+                self.ctx.comm_init(uid, rank, world)
             self.stream = self.ctx.comm_stream()
             self.barrier()                  # every rank has joined: the file is no longer needed
         except Exception:
