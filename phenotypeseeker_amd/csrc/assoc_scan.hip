@@ -323,37 +323,6 @@ __device__ __forceinline__ int queue_pop64(uint64_t *q_row, int2 *q_val, int q, 
 // MODE 2: unit weights, rows that pass the pre-test are queued the same way: a scan with many survivors
 //         (--omit_B_correction keeps ~pvalue of all rows) then evaluates 64 of them per pass instead of one or two
 //         lanes of a wave at a time.  Same formulas, same results as MODE 0 (the host picks, see pick_chi2_mode).
-// The weighted 2 x 2 table of one row per lane exactly as the reference accumulates it (modeling.py:809-823): every
-// sample in order adds its weight to ONE of the four cells; here the other three get + 0.0, which changes nothing
-// (and a weight times 1.0 or 0.0 is exact, so one fma per cell is that addition).
-// tab[2 s] = weight of a phenotype-1 sample, tab[2 s + 1] = of a phenotype-0 sample (0 for NA and padding); all lanes
-// visit sample s together, so the entries are scalar loads.
-__device__ __forceinline__ void row_cells_exact(const u32x4 *__restrict__ rp, int cpr, cdptr tab, double &A, double &B, double &C,
-                                                double &D)
-{
-    double a = 0.0, b = 0.0, c = 0.0, d = 0.0;
-    for (int ch = 0; ch < cpr; ch++) {
-        const u32x4 y = rp[ch];
-        const uint32_t w4[4] = {y.x, y.y, y.z, y.w};
-        cdptr tp = tab + (size_t)ch * 256;
-#pragma unroll
-        for (int h = 0; h < 4; h++) {
-#pragma unroll 4
-            for (int s = 0; s < 32; s++) {
-                // f = 1.0 / 0.0 for a present / absent sample, g = 1 - f: fma(f, t, a) is a + t or a + 0.0, rounded once
-                const uint32_t fh = (uint32_t)(((int32_t)(w4[h] << (31 - s))) >> 31) & 0x3FF00000u;
-                const double f = __hiloint2double((int)fh, 0), g = __hiloint2double((int)(fh ^ 0x3FF00000u), 0);
-                const double t1 = tp[(h * 32 + s) * 2], t0 = tp[(h * 32 + s) * 2 + 1];
-                a = fma(f, t1, a);
-                b = fma(g, t1, b);
-                c = fma(f, t0, c);
-                d = fma(g, t0, d);
-            }
-        }
-    }
-    A = a; B = b; C = c; D = d;
-}
-
 template <int G, int MODE, bool LUT = false>
 __global__ __launch_bounds__(LUT ? SC_LUT_THREADS : SC_THREADS) void chi2_scan_kernel(const ScanArgs P)
 {
@@ -501,15 +470,23 @@ __global__ __launch_bounds__(LUT ? SC_LUT_THREADS : SC_THREADS) void chi2_scan_k
 }
 
 // Second pass of the weighted chi2 scan: one workgroup per result segment, one candidate per lane.  The 2 x 2 table is
-// summed again exactly as the reference does it (row_cells_exact), so the statistic, round(chi2, 2) and "%.2E" of the
+// summed again exactly as the reference does it (modeling.py:809-823: every sample in order adds its weight to ONE of
+// the four cells; here the other three get + 0.0, and a weight times 1.0 or 0.0 is exact, so one fma per cell IS that
+// addition), so the statistic, round(chi2, 2) and "%.2E" of the
 // p-value are the reference's to the last bit; then the keep rule of modeling.py:795 and the compaction of the segment
 // in place.  (Doing this inside the scan kernel, per 64 queued rows with at least one candidate, cost 2.3 ms instead of
 // 0.6 ms for 16 M x 1024: the sample-order sums are a dependent chain of 1024 f64 adds whatever the number of live lanes.)
-constexpr int SC_FIN_THREADS = 1024;   // four waves per SIMD: the scalar loads of the table entries need the cover
+constexpr int SC_FIN_THREADS = 1024;
+constexpr int SC_FIN_BLK = 16;         // chunks (of 128 samples) of the weight table staged in LDS at a time: 32 KB
 __global__ __launch_bounds__(SC_FIN_THREADS) void chi2w_finalize_kernel(const ScanArgs P)
 {
     __shared__ uint32_t scan_lds[SC_FIN_THREADS / 64];
     __shared__ uint32_t s_out;
+    // {weight if phenotype 1, weight if phenotype 0} of the samples of the current block: every lane reads the SAME
+    // entry at the same time (one broadcast ds_read_b128).  As scalar loads from global memory the entries cost
+    // ~330 cycles per sample (0.14 ms for 160 k candidates of 1024 samples); from LDS the pass is its 4 + 3 VALU
+    // operations per sample.
+    __shared__ double2 s_tab[SC_FIN_BLK * 128];
     const uint32_t seg = blockIdx.x;
     const uint32_t c = P.counter[seg * SC_CNT_STRIDE];
     const uint64_t base = (uint64_t)seg * P.seg_cap;
@@ -520,12 +497,39 @@ __global__ __launch_bounds__(SC_FIN_THREADS) void chi2w_finalize_kernel(const Sc
         const bool valid = i < c;
         const uint64_t row = valid ? P.res_row[base + i] : 0;
         const int32_t nw = valid ? P.res_nw[base + i] : 0;
+        const bool wave_any = __any(valid);
+        const u32x4 *rp = P.bits + row * (uint64_t)P.cpr;
+        // the four cells, sample by sample
+        double ca = 0.0, cb = 0.0, cc = 0.0, cd = 0.0;
+        for (int c0 = 0; c0 < P.cpr; c0 += SC_FIN_BLK) {
+            const int nc = P.cpr - c0 < SC_FIN_BLK ? P.cpr - c0 : SC_FIN_BLK;
+            __syncthreads();   // the previous block has been consumed
+            for (int e = threadIdx.x; e < nc * 128; e += SC_FIN_THREADS)
+                s_tab[e] = reinterpret_cast<const double2 *>(P.tab)[(size_t)c0 * 128 + e];
+            __syncthreads();
+            if (!wave_any) continue;
+            for (int ch = 0; ch < nc; ch++) {
+                const u32x4 y = rp[c0 + ch];
+                const uint32_t w4[4] = {y.x, y.y, y.z, y.w};
+#pragma unroll
+                for (int h = 0; h < 4; h++) {
+#pragma unroll 8
+                    for (int sb = 0; sb < 32; sb++) {
+                        const uint32_t fh = (uint32_t)(((int32_t)(w4[h] << (31 - sb))) >> 31) & 0x3FF00000u;
+                        const double f = __hiloint2double((int)fh, 0), g = __hiloint2double((int)(fh ^ 0x3FF00000u), 0);
+                        const double2 t = s_tab[ch * 128 + h * 32 + sb];
+                        ca = fma(f, t.x, ca);
+                        cb = fma(g, t.x, cb);
+                        cc = fma(f, t.y, cc);
+                        cd = fma(g, t.y, cd);
+                    }
+                }
+            }
+        }
         double stat = 0.0, p = 1.0;
         bool keep = false;
-        if (__any(valid)) {
-            double A, B, C, D;
-            row_cells_exact(P.bits + row * (uint64_t)P.cpr, P.cpr, (cdptr)P.tab, A, B, C, D);
-            stat = chi2_exact(A, B, C, D);
+        if (wave_any) {
+            stat = chi2_exact(ca, cb, cc, cd);
             p = exp(-0.5 * stat);
             keep = valid && ((P.omit_B && p < P.pcut) || (p < P.pcut_bonf));
         }
