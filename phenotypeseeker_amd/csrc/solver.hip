@@ -274,6 +274,37 @@ __global__ __launch_bounds__(SV_THREADS) void logreg_newglmnet_kernel(
 // inside the loops, only the LDS-resident per-sample arrays.  (The float form pays an L2 round trip per
 // 64 samples, ~7 us per coordinate at n = 2048 on a lone wave; this form ~0.3 us.)
 #define FLD(ptr) (f_lds ? *(ptr) : lane0_load((ptr), lane))
+// ---- additions under a lane mask held in SGPRs (register form of the descent, cd_regs) -----------------------------------
+// `if (bit) g += p` compiles to v_and + v_cmp + v_add_f64 + 2 v_cndmask with the add and the selects on one dependent
+// chain: a lone wave on its SIMD pays their latencies 32 times per coordinate step.  Here the condition is a wave mask
+// in an SGPR pair (one v_bfe + v_cmp per word, shared by the gradient pass and the update pass of the step) that becomes
+// EXEC for ONE v_add_f64; lanes outside the mask keep their value.  Same operations in the same order as the plain
+// form, so the sums are identical bit for bit.  EXEC is saved and restored around each group of eight.
+#define PSK_MASKED_STEP(i) "s_mov_b64 exec, %[m" #i "]\n\tv_add_f64 %[g], %[g], %[p" #i "]\n\t"
+__device__ __forceinline__ void masked_sum8(double &g, const uint64_t *m, const double *p)
+{
+    uint64_t sv;
+    asm volatile("s_mov_b64 %[sv], exec\n\t" PSK_MASKED_STEP(0) PSK_MASKED_STEP(1) PSK_MASKED_STEP(2) PSK_MASKED_STEP(3)
+                 PSK_MASKED_STEP(4) PSK_MASKED_STEP(5) PSK_MASKED_STEP(6) PSK_MASKED_STEP(7) "s_mov_b64 exec, %[sv]"
+                 : [g] "+v"(g), [sv] "=&s"(sv)
+                 : [m0] "s"(m[0]), [m1] "s"(m[1]), [m2] "s"(m[2]), [m3] "s"(m[3]), [m4] "s"(m[4]), [m5] "s"(m[5]), [m6] "s"(m[6]),
+                   [m7] "s"(m[7]), [p0] "v"(p[0]), [p1] "v"(p[1]), [p2] "v"(p[2]), [p3] "v"(p[3]), [p4] "v"(p[4]), [p5] "v"(p[5]),
+                   [p6] "v"(p[6]), [p7] "v"(p[7]));
+}
+#undef PSK_MASKED_STEP
+#define PSK_MASKED_STEP(i) "s_mov_b64 exec, %[m" #i "]\n\tv_add_f64 %[x" #i "], %[x" #i "], %[z]\n\t"
+__device__ __forceinline__ void masked_add8(double *x, const uint64_t *m, double z)
+{
+    uint64_t sv;
+    asm volatile("s_mov_b64 %[sv], exec\n\t" PSK_MASKED_STEP(0) PSK_MASKED_STEP(1) PSK_MASKED_STEP(2) PSK_MASKED_STEP(3)
+                 PSK_MASKED_STEP(4) PSK_MASKED_STEP(5) PSK_MASKED_STEP(6) PSK_MASKED_STEP(7) "s_mov_b64 exec, %[sv]"
+                 : [x0] "+v"(x[0]), [x1] "+v"(x[1]), [x2] "+v"(x[2]), [x3] "+v"(x[3]), [x4] "+v"(x[4]), [x5] "+v"(x[5]),
+                   [x6] "+v"(x[6]), [x7] "+v"(x[7]), [sv] "=&s"(sv)
+                 : [m0] "s"(m[0]), [m1] "s"(m[1]), [m2] "s"(m[2]), [m3] "s"(m[3]), [m4] "s"(m[4]), [m5] "s"(m[5]), [m6] "s"(m[6]),
+                   [m7] "s"(m[7]), [z] "v"(z));
+}
+#undef PSK_MASKED_STEP
+
 // ALL_LDS: every array of the fit lives in LDS (the usual case: a few hundred samples, <= ~1500 distinct
 // columns).  The placement is then a compile-time fact, the pointers are LDS pointers and the loops use
 // ds_read / ds_write; with run-time placement flags they are generic pointers and every access is a flat load.
@@ -298,6 +329,10 @@ __global__ __launch_bounds__(SV_THREADS) void logreg_newglmnet_bits_kernel(
     const int fit = blockIdx.x, lane = threadIdx.x;
     const double C = fit_param[fit];
     const int tf = fit_fold[fit];
+#ifdef PSK_SV_STATS
+    long long stat_sweeps = 0, stat_visits = 0, stat_t_cd = 0, stat_t0 = 0;
+    const long long stat_start = clock64();
+#endif
     const int P1 = p + 1, NP = W * 64;  // sample arrays are padded to whole words
     double *gw = work + (size_t)fit * (5 * (size_t)P1 + 5 * (size_t)NP);
     // LDS layout: [feature arrays 5*P1 | active list P1 ints (padded)] if f_lds, [tau, D: 2*NP] if s_mode & 1,
@@ -694,9 +729,15 @@ __global__ __launch_bounds__(SV_THREADS) void logreg_newglmnet_bits_kernel(
                     const double H = FLD(&Hd[j]);
                     const double wp = FLD(&wpd[j]);
                     double G = 0.0;
+                    uint64_t M[WM];   // word t of the column as a wave mask: the lanes whose sample 64 t + lane has the k-mer
+                    double P[WM];
 #pragma unroll
-                    for (int t = 0; t < WM; t++)
-                        if ((m >> t) & 1) G += Dr[t] * Xr[t];
+                    for (int t = 0; t < WM; t++) {
+                        M[t] = __ballot((m >> t) & 1ull);
+                        P[t] = Dr[t] * Xr[t];
+                    }
+#pragma unroll
+                    for (int t = 0; t < WM; t += 8) masked_sum8(G, M + t, P + t);
                     G = psk_wave_sum_f64_dpp(G) + FLD(&Gr[j]) + (wp - FLD(&w[j])) * nu;
                     const double Gp = G + 1.0, Gn = G - 1.0;
                     double viol = 0.0;
@@ -722,8 +763,7 @@ __global__ __launch_bounds__(SV_THREADS) void logreg_newglmnet_bits_kernel(
                     z = fmin(fmax(z, -10.0), 10.0);
                     if (lane == 0) wpd[j] = wp + z;
 #pragma unroll
-                    for (int t = 0; t < WM; t++)
-                        if ((m >> t) & 1) Xr[t] += z;
+                    for (int t = 0; t < WM; t += 8) masked_add8(Xr + t, M + t, z);
                 }
                 iter++;
                 if (QP_Gnorm1_new <= inner_eps * Gnorm1_init) {
@@ -738,8 +778,17 @@ __global__ __launch_bounds__(SV_THREADS) void logreg_newglmnet_bits_kernel(
             for (int t = 0; t < WM; t++)
                 if (t < W) xTd[t * 64 + lane] = Xr[t];
         };
-        if (WMREG > 0) cd_regs(integral_constant<int, (WMREG > 0 ? WMREG : 1)>{});
-        else
+#ifdef PSK_SV_STATS
+        stat_t0 = clock64();
+#endif
+        if (WMREG > 0) {
+            cd_regs(integral_constant<int, (WMREG > 0 ? WMREG : 1)>{});
+#ifdef PSK_SV_STATS
+            stat_t_cd += clock64() - stat_t0;
+            stat_sweeps += iter;
+            stat_visits += (long long)iter * active;
+#endif
+        } else
         while (iter < 1000) {
             // liblinear visits the active coordinates in a fresh random order every sweep (solve_l1r_lr); a fixed cyclic
             // order needs hundreds of times more sweeps on correlated columns (r01: 4.3 s against liblinear's 14 ms)
@@ -882,6 +931,11 @@ __global__ __launch_bounds__(SV_THREADS) void logreg_newglmnet_bits_kernel(
     }
     for (int j = 0; j < p; j++) { if (lane == 0) coef[(size_t)fit * p + j] = w[j]; }
     if (lane == 0) { icpt[fit] = w[p]; iters[fit] = newton; }
+#ifdef PSK_SV_STATS
+    if (lane == 0)
+        printf("fit %d C %g newton %d sweeps %lld visits<= %lld cd_cycles %lld total_cycles %lld\n", fit, C, newton, stat_sweeps, stat_visits,
+               stat_t_cd, (long long)(clock64() - stat_start));
+#endif
 }
 #undef FLD
 
