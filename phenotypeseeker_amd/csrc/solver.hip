@@ -27,6 +27,11 @@ namespace {
 // latency from ~5 us (r01 block version) to well under 1 us; all fits of a grid search still run in one
 // launch, one wave per CU.
 constexpr int SV_THREADS = 64;
+#ifndef PSK_SV_WAVES
+#define PSK_SV_WAVES 4
+#endif
+constexpr int SV_COOP_WAVES = PSK_SV_WAVES;                      // waves of a fit in the register form of the descent (cd_coop)
+constexpr int SV_COOP_THREADS = 64 * SV_COOP_WAVES;
 constexpr int SV_LDS_N = 4096;   // samples whose per-fit state fits the 64 KiB of dynamic LDS
 
 // Per-fit scalars that lane 0 writes to global memory (w[j], column means, norms) are read back by
@@ -274,12 +279,12 @@ __global__ __launch_bounds__(SV_THREADS) void logreg_newglmnet_kernel(
 // inside the loops, only the LDS-resident per-sample arrays.  (The float form pays an L2 round trip per
 // 64 samples, ~7 us per coordinate at n = 2048 on a lone wave; this form ~0.3 us.)
 #define FLD(ptr) (f_lds ? *(ptr) : lane0_load((ptr), lane))
-// ---- additions under a lane mask held in SGPRs (register form of the descent, cd_regs) -----------------------------------
+// ---- additions under a lane mask held in SGPRs (register form of the descent, cd_coop) -----------------------------------
 // `if (bit) g += p` compiles to v_and + v_cmp + v_add_f64 + 2 v_cndmask with the add and the selects on one dependent
 // chain: a lone wave on its SIMD pays their latencies 32 times per coordinate step.  Here the condition is a wave mask
 // in an SGPR pair (one v_bfe + v_cmp per word, shared by the gradient pass and the update pass of the step) that becomes
 // EXEC for ONE v_add_f64; lanes outside the mask keep their value.  Same operations in the same order as the plain
-// form, so the sums are identical bit for bit.  EXEC is saved and restored around each group of eight.
+// form.  EXEC is saved and restored around each group.
 #define PSK_MASKED_STEP(i) "s_mov_b64 exec, %[m" #i "]\n\tv_add_f64 %[g], %[g], %[p" #i "]\n\t"
 __device__ __forceinline__ void masked_sum8(double &g, const uint64_t *m, const double *p)
 {
@@ -291,8 +296,39 @@ __device__ __forceinline__ void masked_sum8(double &g, const uint64_t *m, const 
                    [m7] "s"(m[7]), [p0] "v"(p[0]), [p1] "v"(p[1]), [p2] "v"(p[2]), [p3] "v"(p[3]), [p4] "v"(p[4]), [p5] "v"(p[5]),
                    [p6] "v"(p[6]), [p7] "v"(p[7]));
 }
+__device__ __forceinline__ void masked_sum2(double &g, const uint64_t *m, const double *p)
+{
+    uint64_t sv;
+    asm volatile("s_mov_b64 %[sv], exec\n\t" PSK_MASKED_STEP(0) PSK_MASKED_STEP(1) "s_mov_b64 exec, %[sv]"
+                 : [g] "+v"(g), [sv] "=&s"(sv)
+                 : [m0] "s"(m[0]), [m1] "s"(m[1]), [p0] "v"(p[0]), [p1] "v"(p[1]));
+}
+__device__ __forceinline__ void masked_sum4(double &g, const uint64_t *m, const double *p)
+{
+    uint64_t sv;
+    asm volatile("s_mov_b64 %[sv], exec\n\t" PSK_MASKED_STEP(0) PSK_MASKED_STEP(1) PSK_MASKED_STEP(2) PSK_MASKED_STEP(3)
+                 "s_mov_b64 exec, %[sv]"
+                 : [g] "+v"(g), [sv] "=&s"(sv)
+                 : [m0] "s"(m[0]), [m1] "s"(m[1]), [m2] "s"(m[2]), [m3] "s"(m[3]), [p0] "v"(p[0]), [p1] "v"(p[1]), [p2] "v"(p[2]),
+                   [p3] "v"(p[3]));
+}
 #undef PSK_MASKED_STEP
 #define PSK_MASKED_STEP(i) "s_mov_b64 exec, %[m" #i "]\n\tv_add_f64 %[x" #i "], %[x" #i "], %[z]\n\t"
+__device__ __forceinline__ void masked_add2(double *x, const uint64_t *m, double z)
+{
+    uint64_t sv;
+    asm volatile("s_mov_b64 %[sv], exec\n\t" PSK_MASKED_STEP(0) PSK_MASKED_STEP(1) "s_mov_b64 exec, %[sv]"
+                 : [x0] "+v"(x[0]), [x1] "+v"(x[1]), [sv] "=&s"(sv)
+                 : [m0] "s"(m[0]), [m1] "s"(m[1]), [z] "v"(z));
+}
+__device__ __forceinline__ void masked_add4(double *x, const uint64_t *m, double z)
+{
+    uint64_t sv;
+    asm volatile("s_mov_b64 %[sv], exec\n\t" PSK_MASKED_STEP(0) PSK_MASKED_STEP(1) PSK_MASKED_STEP(2) PSK_MASKED_STEP(3)
+                 "s_mov_b64 exec, %[sv]"
+                 : [x0] "+v"(x[0]), [x1] "+v"(x[1]), [x2] "+v"(x[2]), [x3] "+v"(x[3]), [sv] "=&s"(sv)
+                 : [m0] "s"(m[0]), [m1] "s"(m[1]), [m2] "s"(m[2]), [m3] "s"(m[3]), [z] "v"(z));
+}
 __device__ __forceinline__ void masked_add8(double *x, const uint64_t *m, double z)
 {
     uint64_t sv;
@@ -308,10 +344,10 @@ __device__ __forceinline__ void masked_add8(double *x, const uint64_t *m, double
 // ALL_LDS: every array of the fit lives in LDS (the usual case: a few hundred samples, <= ~1500 distinct
 // columns).  The placement is then a compile-time fact, the pointers are LDS pointers and the loops use
 // ds_read / ds_write; with run-time placement flags they are generic pointers and every access is a flat load.
-// WMREG: 0, or the number of sample words per lane the register form of the descent holds (16 or 32; see cd_regs) --
+// WMREG: 0, or the number of sample words per lane the register form of the descent holds (16 or 32, a quarter of them in each of its four waves; see cd_coop) --
 // a template parameter so that its 2 x WMREG doubles per lane do not weigh on the register allocation of the other forms.
 template <bool ALL_LDS, int WMREG>
-__global__ __launch_bounds__(SV_THREADS) void logreg_newglmnet_bits_kernel(
+__global__ __launch_bounds__(WMREG > 0 ? SV_COOP_THREADS : SV_THREADS) void logreg_newglmnet_bits_kernel(
     const uint64_t *__restrict__ colbits, const int8_t *__restrict__ ypm, const int32_t *__restrict__ fold, int n, int p,
     int W, const double *__restrict__ fit_param, const int32_t *__restrict__ fit_fold, double tol, int max_newton,
     double *__restrict__ coef, double *__restrict__ icpt, int32_t *__restrict__ iters, double *__restrict__ work,
@@ -326,7 +362,7 @@ __global__ __launch_bounds__(SV_THREADS) void logreg_newglmnet_bits_kernel(
     extern __shared__ double sm_all[];
     double *Qm = sm_all;  // Gram block of the covariance-form QP: square when (64 NS)^2 fits, else packed triangle
     double *sm = sm_all + q_doubles;
-    const int fit = blockIdx.x, lane = threadIdx.x;
+    const int fit = blockIdx.x, lane = threadIdx.x & 63, wave = threadIdx.x >> 6;   // waves 1..3 exist in the register form only (cd_coop)
     const double C = fit_param[fit];
     const int tf = fit_fold[fit];
 #ifdef PSK_SV_STATS
@@ -345,7 +381,8 @@ __global__ __launch_bounds__(SV_THREADS) void logreg_newglmnet_bits_kernel(
     const uint64_t *cb = colbits;
     if (c_lds) {
         uint64_t *lc = reinterpret_cast<uint64_t *>(sm + f_words + (h_lds ? 2 * (size_t)NP : 0) + (o_lds ? 3 * (size_t)NP : 0));
-        for (size_t q = lane; q < (size_t)P1 * W; q += SV_THREADS) lc[q] = colbits[q];
+        if (wave == 0)
+            for (size_t q = lane; q < (size_t)P1 * W; q += SV_THREADS) lc[q] = colbits[q];
         cb = lc;
     }
     double *w = F, *wpd = F + P1, *Hd = F + 2 * P1, *Gr = F + 3 * P1, *xjneg = F + 4 * P1;
@@ -353,6 +390,129 @@ __global__ __launch_bounds__(SV_THREADS) void logreg_newglmnet_bits_kernel(
     double *ewx = o_lds ? oth : Sg, *ewxn = o_lds ? oth + NP : Sg + NP, *xTd = o_lds ? oth + 2 * (size_t)NP : Sg + 4 * (size_t)NP;
     int32_t *act = f_lds ? reinterpret_cast<int32_t *>(sm + 5 * (size_t)P1) : iwork + (size_t)fit * P1;
     const double nu = 1e-12, sigma = 0.01;
+
+    uint32_t rng = ((uint32_t)fit + 1u) * 2654435761u | 1u;  // per-fit xorshift state of the sweep permutations (lane 0's copy counts)
+    // what wave 0 hands to the other waves of the register form at the start of a descent, and their partial sums
+    struct CdShared { double QP_Gmax_old, inner_eps, Gnorm1_init, l; int QP_active, active, cmd, pad; };
+    __shared__ CdShared s_cd;
+    __shared__ double s_part[2][SV_COOP_WAVES];
+    // Register form of the array descent, FOUR waves per fit (WMREG > 0).  A coordinate visit is ~450 instructions
+    // when one wave does it, ~230 of them per-word work (32 words: masks, products, masked additions, the update);
+    // a lone wave issues one instruction per 4 cycles, so the visit took ~2,800 cycles whatever else the CU had
+    // free.  Here wave v owns words [v WM/4, (v + 1) WM/4) of every column -- D and x.d of those samples in its
+    // registers -- sums its part of the gradient, and the four partial sums meet in LDS behind ONE barrier per
+    // visit; every wave then takes the same decisions from the same bits (shrinking, step, stop), only wave 0
+    // writes the shared state (coefficients, visiting order).  Waves 1..3 wait in helper_loop between descents.
+    auto cd_coop = [&](auto wm_tag) -> int {
+        constexpr int WM = decltype(wm_tag)::value, WQ = WM / SV_COOP_WAVES;
+        const int t0 = wave * WQ;
+        double QP_Gmax_old_c = s_cd.QP_Gmax_old;
+        const double inner_eps_c = s_cd.inner_eps, Gnorm1_init_c = s_cd.Gnorm1_init, l_c = s_cd.l;
+        int QP_active_c = s_cd.QP_active, iter_c = 0;
+        const int active_c = s_cd.active;
+        double Dr[WQ], Xr[WQ];
+        uint64_t tmask = 0;   // the lane's training samples among this wave's words, transposed like colT
+#pragma unroll
+        for (int q = 0; q < WQ; q++) {
+            const int t = t0 + q, i = t * 64 + lane;
+            const bool in = t < W;
+            Dr[q] = in ? D[i] : 0.0;
+            Xr[q] = in ? xTd[i] : 0.0;
+            if (in && i < n && fold[i] != tf) tmask |= 1ull << t;
+        }
+        auto act_at = [&](int sx) { return f_lds ? act[sx] : __builtin_amdgcn_readfirstlane(lane == 0 ? act[sx] : 0); };
+        auto col_t = [&](int j) { return (colT[(size_t)j * 64 + lane] & tmask) >> t0; };   // bit q = word t0 + q
+        int visit = 0;
+        while (iter_c < 1000) {
+            __syncthreads();   // every wave has left the previous sweep: the order may change
+            if (wave == 0 && lane == 0) {   // a fresh random visiting order every sweep, as liblinear's solve_l1r_lr
+                for (int jj = 0; jj + 1 < QP_active_c; jj++) {
+                    rng ^= rng << 13; rng ^= rng >> 17; rng ^= rng << 5;
+                    const int ii = jj + (int)(rng % (uint32_t)(QP_active_c - jj));
+                    const int32_t tt = act[ii]; act[ii] = act[jj]; act[jj] = tt;
+                }
+            }
+            __syncthreads();
+            double QP_Gmax_new = 0.0, QP_Gnorm1_new = 0.0;
+            int j_next = QP_active_c > 0 ? act_at(0) : 0;
+            uint64_t m_next = QP_active_c > 0 ? col_t(j_next) : 0ull;
+            for (int sidx = 0; sidx < QP_active_c; sidx++) {
+                const int j = j_next;
+                const uint64_t m = m_next;
+                if (sidx + 1 < QP_active_c) { j_next = act_at(sidx + 1); m_next = col_t(j_next); }
+                const double H = FLD(&Hd[j]);
+                const double wp = FLD(&wpd[j]);
+                uint64_t M[WQ];   // word t0 + q of the column as a wave mask: the lanes whose sample has the k-mer
+                double P[WQ];
+#pragma unroll
+                for (int q = 0; q < WQ; q++) {
+                    M[q] = __ballot((m >> q) & 1ull);
+                    P[q] = Dr[q] * Xr[q];
+                }
+                double Gw = 0.0;
+                if (WQ == 8) masked_sum8(Gw, M, P);
+                else if (WQ == 4) masked_sum4(Gw, M, P);
+                else masked_sum2(Gw, M, P);
+                Gw = psk_wave_sum_f64_dpp(Gw);
+                const int slot = visit & 1;   // two sets of partial sums: a wave may enter the next visit while another still reads
+                visit++;
+                if (lane == 0) s_part[slot][wave] = Gw;
+                __syncthreads();
+                double Gs = s_part[slot][0];
+#pragma unroll
+                for (int v = 1; v < SV_COOP_WAVES; v++) Gs += s_part[slot][v];
+                const double G = Gs + FLD(&Gr[j]) + (wp - FLD(&w[j])) * nu;
+                const double Gp = G + 1.0, Gn = G - 1.0;
+                double viol = 0.0;
+                if (wp == 0.0) {
+                    if (Gp < 0) viol = -Gp;
+                    else if (Gn > 0) viol = Gn;
+                    else if (Gp > QP_Gmax_old_c / l_c && Gn < -QP_Gmax_old_c / l_c) {
+                        QP_active_c--;
+                        if (wave == 0 && lane == 0) { const int32_t tt = act[sidx]; act[sidx] = act[QP_active_c]; act[QP_active_c] = tt; }
+                        __syncthreads();   // (every wave is here: the same G)
+                        if (sidx < QP_active_c) { j_next = act_at(sidx); m_next = col_t(j_next); }   // swapped in: visited next
+                        sidx--;
+                        continue;
+                    }
+                } else if (wp > 0) viol = fabs(Gp);
+                else viol = fabs(Gn);
+                if (viol > QP_Gmax_new) QP_Gmax_new = viol;
+                QP_Gnorm1_new += viol;
+                double z;
+                if (Gp < H * wp) z = -Gp / H;
+                else if (Gn > H * wp) z = -Gn / H;
+                else z = -wp;
+                if (fabs(z) < 1e-12 && !(z == -wp && wp != 0.0)) continue;  // see the LDS form below
+                z = fmin(fmax(z, -10.0), 10.0);
+                if (wave == 0 && lane == 0) wpd[j] = wp + z;
+                if (WQ == 8) masked_add8(Xr, M, z);
+                else if (WQ == 4) masked_add4(Xr, M, z);
+                else masked_add2(Xr, M, z);
+            }
+            iter_c++;
+            if (QP_Gnorm1_new <= inner_eps_c * Gnorm1_init_c) {
+                if (QP_active_c == active_c) break;
+                QP_active_c = active_c;
+                QP_Gmax_old_c = 1e300;
+                continue;
+            }
+            QP_Gmax_old_c = QP_Gmax_new;
+        }
+#pragma unroll
+        for (int q = 0; q < WQ; q++)
+            if (t0 + q < W) xTd[(t0 + q) * 64 + lane] = Xr[q];
+        __syncthreads();   // x.d is whole again: wave 0 goes on to the line search, the others back to helper_loop
+        return iter_c;
+    };
+    if (WMREG > 0 && wave != 0) {   // helper_loop: waves 1..3 join every descent of wave 0 and leave with it
+        for (;;) {
+            __syncthreads();
+            if (s_cd.cmd == 2) break;
+            cd_coop(std::integral_constant<int, (WMREG > 0 ? WMREG : 32)>{});
+        }
+        return;
+    }
 
     // training mask and (training & y = -1) mask of this fit: lane t keeps word t (W <= 64, i.e. n <= 4096)
     uint64_t trainw = 0, negw = 0;
@@ -383,7 +543,6 @@ __global__ __launch_bounds__(SV_THREADS) void logreg_newglmnet_bits_kernel(
         if (lane == 0) { w[j] = 0.0; wpd[j] = 0.0; xjneg[j] = sneg; act[j] = j; }
     }
     double w_norm = 0.0, Gmax_old = 1e300, Gnorm1_init = -1.0, inner_eps = 1.0;
-    uint32_t rng = ((uint32_t)fit + 1u) * 2654435761u | 1u;  // per-fit xorshift state of the sweep permutations (lane 0's copy counts)
     int newton = 0;
     for (newton = 0; newton < max_newton; newton++) {
         double Gmax_new = 0.0, Gnorm1_new = 0.0;
@@ -697,92 +856,16 @@ __global__ __launch_bounds__(SV_THREADS) void logreg_newglmnet_bits_kernel(
         // LDS every word step waited for two LDS reads (~100 clocks: the loop is not unrolled, W is a run-time value)
         // and a step took ~1 us (r02: 2048 samples x 907 columns, 16 M steps = the 16 s of that grid).  Same visiting
         // order, same sums in the same order as the LDS form below (which serves W > 32).
-        auto cd_regs = [&](auto wm_tag) {
-            constexpr int WM = decltype(wm_tag)::value;
-            double Dr[WM], Xr[WM];
-            uint64_t tmask = 0;   // the lane's training samples, transposed like colT
-#pragma unroll
-            for (int t = 0; t < WM; t++) {
-                const bool in = t < W;
-                Dr[t] = in ? D[t * 64 + lane] : 0.0;
-                Xr[t] = in ? xTd[t * 64 + lane] : 0.0;
-                const uint64_t tw = psk_readlane_u64(trainw, in ? t : 0);
-                if (in && ((tw >> lane) & 1)) tmask |= 1ull << t;
-            }
-            auto act_at = [&](int sx) { return f_lds ? act[sx] : __builtin_amdgcn_readfirstlane(lane == 0 ? act[sx] : 0); };
-            auto col_t = [&](int j) { return colT[(size_t)j * 64 + lane] & tmask; };
-            while (iter < 1000) {
-                if (lane == 0) {   // a fresh random visiting order every sweep, as liblinear's solve_l1r_lr
-                    for (int jj = 0; jj + 1 < QP_active; jj++) {
-                        rng ^= rng << 13; rng ^= rng >> 17; rng ^= rng << 5;
-                        const int ii = jj + (int)(rng % (uint32_t)(QP_active - jj));
-                        const int32_t tt = act[ii]; act[ii] = act[jj]; act[jj] = tt;
-                    }
-                }
-                double QP_Gmax_new = 0.0, QP_Gnorm1_new = 0.0;
-                int j_next = QP_active > 0 ? act_at(0) : 0;
-                uint64_t m_next = QP_active > 0 ? col_t(j_next) : 0ull;
-                for (int sidx = 0; sidx < QP_active; sidx++) {
-                    const int j = j_next;
-                    const uint64_t m = m_next;
-                    if (sidx + 1 < QP_active) { j_next = act_at(sidx + 1); m_next = col_t(j_next); }
-                    const double H = FLD(&Hd[j]);
-                    const double wp = FLD(&wpd[j]);
-                    double G = 0.0;
-                    uint64_t M[WM];   // word t of the column as a wave mask: the lanes whose sample 64 t + lane has the k-mer
-                    double P[WM];
-#pragma unroll
-                    for (int t = 0; t < WM; t++) {
-                        M[t] = __ballot((m >> t) & 1ull);
-                        P[t] = Dr[t] * Xr[t];
-                    }
-#pragma unroll
-                    for (int t = 0; t < WM; t += 8) masked_sum8(G, M + t, P + t);
-                    G = psk_wave_sum_f64_dpp(G) + FLD(&Gr[j]) + (wp - FLD(&w[j])) * nu;
-                    const double Gp = G + 1.0, Gn = G - 1.0;
-                    double viol = 0.0;
-                    if (wp == 0.0) {
-                        if (Gp < 0) viol = -Gp;
-                        else if (Gn > 0) viol = Gn;
-                        else if (Gp > QP_Gmax_old / l && Gn < -QP_Gmax_old / l) {
-                            QP_active--;
-                            if (lane == 0) { const int32_t tt = act[sidx]; act[sidx] = act[QP_active]; act[QP_active] = tt; }
-                            if (sidx < QP_active) { j_next = act_at(sidx); m_next = col_t(j_next); }   // swapped in: visited next
-                            sidx--;
-                            continue;
-                        }
-                    } else if (wp > 0) viol = fabs(Gp);
-                    else viol = fabs(Gn);
-                    if (viol > QP_Gmax_new) QP_Gmax_new = viol;
-                    QP_Gnorm1_new += viol;
-                    double z;
-                    if (Gp < H * wp) z = -Gp / H;
-                    else if (Gn > H * wp) z = -Gn / H;
-                    else z = -wp;
-                    if (fabs(z) < 1e-12 && !(z == -wp && wp != 0.0)) continue;  // see the LDS form below
-                    z = fmin(fmax(z, -10.0), 10.0);
-                    if (lane == 0) wpd[j] = wp + z;
-#pragma unroll
-                    for (int t = 0; t < WM; t += 8) masked_add8(Xr + t, M + t, z);
-                }
-                iter++;
-                if (QP_Gnorm1_new <= inner_eps * Gnorm1_init) {
-                    if (QP_active == active) break;
-                    QP_active = active;
-                    QP_Gmax_old = 1e300;
-                    continue;
-                }
-                QP_Gmax_old = QP_Gmax_new;
-            }
-#pragma unroll
-            for (int t = 0; t < WM; t++)
-                if (t < W) xTd[t * 64 + lane] = Xr[t];
-        };
 #ifdef PSK_SV_STATS
         stat_t0 = clock64();
 #endif
         if (WMREG > 0) {
-            cd_regs(integral_constant<int, (WMREG > 0 ? WMREG : 1)>{});
+            if (lane == 0) {
+                s_cd.QP_Gmax_old = QP_Gmax_old; s_cd.inner_eps = inner_eps; s_cd.Gnorm1_init = Gnorm1_init; s_cd.l = l;
+                s_cd.QP_active = QP_active; s_cd.active = active; s_cd.cmd = 1;
+            }
+            __syncthreads();   // releases waves 1..3 (helper_loop); x.d = 0 and this Newton step's D are visible to them
+            iter = cd_coop(std::integral_constant<int, (WMREG > 0 ? WMREG : 32)>{});
 #ifdef PSK_SV_STATS
             stat_t_cd += clock64() - stat_t0;
             stat_sweeps += iter;
@@ -931,6 +1014,10 @@ __global__ __launch_bounds__(SV_THREADS) void logreg_newglmnet_bits_kernel(
     }
     for (int j = 0; j < p; j++) { if (lane == 0) coef[(size_t)fit * p + j] = w[j]; }
     if (lane == 0) { icpt[fit] = w[p]; iters[fit] = newton; }
+    if (WMREG > 0) {   // the other waves leave helper_loop
+        if (lane == 0) s_cd.cmd = 2;
+        __syncthreads();
+    }
 #ifdef PSK_SV_STATS
     if (lane == 0)
         printf("fit %d C %g newton %d sweeps %lld visits<= %lld cd_cycles %lld total_cycles %lld\n", fit, C, newton, stat_sweeps, stat_visits,
@@ -1161,7 +1248,7 @@ extern "C" int psk_logreg_l1_fit(psk_ctx *ctx, const float *X, const int32_t *y0
         if (lds_b > 64 * 1024)
             PSK_HIP(ctx, hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,
                                              (int)lds_b));
-        kern<<<n_fits, SV_THREADS, lds_b, ctx->stream>>>(
+        kern<<<n_fits, wmreg > 0 ? SV_COOP_THREADS : SV_THREADS, lds_b, ctx->stream>>>(
             (const uint64_t *)b.bits, (const int8_t *)b.y, (const int32_t *)b.fold, n, p, W, (const double *)b.param,
             (const int32_t *)b.ffold, tol, max_iter, (double *)b.coef, (double *)b.icpt, (int32_t *)b.iters,
             (double *)b.work, (int32_t *)b.iwork, f_lds, s_lds, c_lds, (int)q_doubles,

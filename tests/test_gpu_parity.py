@@ -494,9 +494,10 @@ def test_l1_logreg_mid_size_objectives_match_liblinear(ctx):
 
 @pytest.mark.parametrize("n", [700, 2048])
 def test_l1_logreg_register_form_equals_lds_form(ctx, n, monkeypatch):
-    """More distinct columns than the Gram block holds (250 > 192) and n <= 2048: the descent keeps the samples in
-    registers and reads transposed columns.  Same sums in the same order as the LDS form (PSK_NO_CD_REGS=1), so the
-    coefficients are identical bit for bit; and the stop is liblinear's."""
+    """More distinct columns than the Gram block holds (250 > 192) and n <= 2048: the descent runs on four waves per
+    fit, each with a quarter of the samples in registers (cd_coop).  The same algorithm as the one-wave LDS form
+    (PSK_NO_CD_REGS=1) with the gradient's partial sums associated differently: both stop by liblinear's rule, and
+    their objectives agree far inside the stopping tolerance."""
     rng = np.random.default_rng(n)
     p = 250
     base = rng.random((n, 12)) < 0.4
@@ -506,11 +507,12 @@ def test_l1_logreg_register_form_equals_lds_form(ctx, n, monkeypatch):
     fp = np.array([0.01, 0.01, 0.1, 1.0, 1.0], np.float64)
     ff = np.array([-1, 0, 1, 2, -1], np.int32)
     a = ctx.logreg_l1_fit(X, y, fold, fp, ff, tol=1e-4, max_iter=1000)
+    a2 = ctx.logreg_l1_fit(X, y, fold, fp, ff, tol=1e-4, max_iter=1000)
+    assert all(np.array_equal(u, v) for u, v in zip(a, a2))      # four waves, one answer: deterministic
     monkeypatch.setenv("PSK_NO_CD_REGS", "1")
     b = ctx.logreg_l1_fit(X, y, fold, fp, ff, tol=1e-4, max_iter=1000)
     monkeypatch.delenv("PSK_NO_CD_REGS")
-    assert np.array_equal(a[2], b[2]) and a[2].max() < 200, (a[2], b[2])
-    assert np.array_equal(a[0], b[0]) and np.array_equal(a[1], b[1])
+    assert a[2].max() < 200 and b[2].max() < 200, (a[2], b[2])
     assert all((c != 0).sum() > 0 for c in a[0][2:])
     ypm = 2.0 * y - 1.0
     for j in range(len(fp)):
@@ -518,13 +520,18 @@ def test_l1_logreg_register_form_equals_lds_form(ctx, n, monkeypatch):
         A = np.hstack([X[tr].astype(np.float64), np.ones((tr.sum(), 1))])
         yt = ypm[tr]
 
+        def obj(th):
+            return np.abs(th).sum() + fp[j] * np.logaddexp(0, -yt * (A @ th)).sum()
+
         def viol(th):
             g = -fp[j] * (A.T @ (yt / (1.0 + np.exp(yt * (A @ th)))))
             return np.where(th > 0, np.abs(g + 1), np.where(th < 0, np.abs(g - 1),
                                                              np.maximum(0, np.maximum(-(g + 1), g - 1)))).sum()
-        th = np.append(a[0][j], a[1][j])
         eps = 1e-4 * max(min((yt > 0).sum(), (yt < 0).sum()), 1) / tr.sum()
-        assert viol(th) <= 1.5 * eps * viol(np.zeros_like(th)) + 1e-9, (j, fp[j], a[2][j])
+        for r in (a, b):
+            th = np.append(r[0][j], r[1][j])
+            assert viol(th) <= 1.5 * eps * viol(np.zeros_like(th)) + 1e-9, (j, fp[j], r[2][j])
+        assert obj(np.append(a[0][j], a[1][j])) == pytest.approx(obj(np.append(b[0][j], b[1][j])), rel=1e-5)
 
 
 def test_lasso_solver_matches_sklearn(ctx):

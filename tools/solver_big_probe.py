@@ -3,9 +3,8 @@
 stage was 16.6 s of that run's 17.5 s): whole-call time, time per grid value (its 11 fits as one call), Newton counts
 and the objective of every fit, so that solver variants can be compared.  usage: tools/solver_big_probe.py [per-C]
 (A library built with `make EXTRA=-DPSK_SV_STATS` prints per fit: Newton steps, inner sweeps, coordinate visits, and the
-clock cycles inside the descent and in total -- r02: ~2,600 cycles per coordinate visit whatever the problem size, i.e. the
-lone wave's dependent chain (masks, 32 additions, the wave sum, the f64 division), not its instruction count; the grid's
-wall-clock is its slowest fit: 4,586 sweeps over ~900 coordinates.)"""
+clock cycles inside the descent and in total -- r02: ~2,800 cycles per coordinate visit on one wave (~450 instructions at a lone
+wave's issue rate), ~2,000 on four; the grid's wall-clock is its slowest fit: 4,586 sweeps over ~900 coordinates.)"""
 import os
 import sys
 import time
