@@ -128,6 +128,62 @@ def e2e_modeling(gs, n, k):
         shutil.rmtree(tmp, ignore_errors=True)
 
 
+def e2e_modeling_sharded(grp, gs, n, k, args):
+    """The same figure with several ranks: rank 0 writes the FASTA files once, then EVERY rank starts
+    `phenotypeseeker modeling data.pheno` as a child process (RANK / LOCAL_RANK / WORLD_SIZE as this launch has them, a
+    rendezvous file of its own) in that directory; the wall-clock is the slowest rank's, process start to exit.  The
+    children share the GPUs with this process, which has released its matrix by then.  Any failure is reported, not raised: the
+    line's `value` does not depend on this leg."""
+    import shutil
+    import subprocess
+    import tempfile
+    rank = grp.rank
+    tmp, t_write = "", 0.0
+    try:
+        if rank == 0:
+            tmp = tempfile.mkdtemp(prefix="psk_bench_e2e_")
+            rows = ["ID\tAddresses\tPheno"]
+            t0 = time.time()
+            for i in range(n):
+                name, fa = gs.sample(i)
+                with open(os.path.join(tmp, name + ".fasta"), "wb") as f:
+                    f.write(fa)
+                rows.append("%s\t%s.fasta\t%d" % (name, name, gs.phenotype(i)))
+            with open(os.path.join(tmp, "data.pheno"), "w") as f:
+                f.write("\n".join(rows) + "\n")
+            t_write = time.time() - t0
+        tmp = grp.allgather_bytes(tmp.encode())[0].decode()
+        env = dict(os.environ, PSK_RDZV_FILE=os.path.join(tmp, ".rendezvous"),
+                   PSK_REDUNDANT_INGEST="1" if args.ingest == "filter" else "0")
+        here = os.path.dirname(os.path.abspath(__file__))
+        env["PYTHONPATH"] = here + os.pathsep + env.get("PYTHONPATH", "")
+        cmd = [sys.executable, os.path.join(here, "scripts", "phenotypeseeker"), "modeling", "data.pheno", "-l", str(k)]
+        t0 = time.time()
+        r = subprocess.run(cmd, cwd=tmp, env=env, stdout=subprocess.DEVNULL, stderr=subprocess.PIPE, timeout=1800)
+        wall = time.time() - t0
+        worst = grp.allreduce_max(wall)
+        failed = grp.allreduce_sum(1 if r.returncode != 0 else 0)
+        made = sorted(f for f in os.listdir(tmp) if f.endswith(".pkl")) if rank == 0 else []
+        res = {"modeling_wall_s": round(worst, 3), "ranks": grp.world, "ingest": args.ingest,
+               "what": "phenotypeseeker modeling data.pheno as %d child processes (one per rank, started after the files were "
+                       "written): %d FASTA files on disk -> %s" % (grp.world, n, ", ".join(made) or "no model"),
+               "write_dataset_s": round(t_write, 2)}
+        if rank == 0 and not made and not failed:
+            res["error"] = "no .pkl written; rank 0: %s" % r.stderr.decode(errors="replace")[-600:]
+        if failed:
+            res["error"] = "%d rank(s) failed; rank %d: %s" % (failed, rank, r.stderr.decode(errors="replace")[-400:])
+        return res
+    except Exception as e:   # noqa: BLE001 -- reported in the line
+        return {"error": "%s: %s" % (type(e).__name__, e)}
+    finally:
+        try:
+            grp.barrier()
+        except Exception:   # noqa: BLE001
+            pass
+        if rank == 0 and tmp:
+            shutil.rmtree(tmp, ignore_errors=True)
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -374,7 +430,9 @@ def main():
                                "reference_python_8proc_cells_per_s": 7.4e6}
     if rank == 0 and world == 1 and args.workload == "fasta" and not args.no_e2e:
         out["e2e"] = e2e_modeling(gs, n, k)
-    ctx.close()
+    ctx.close()   # the matrix and the lists go before the CLI children of the next leg bring their own
+    if world > 1 and args.workload == "fasta" and not args.no_e2e:
+        out["e2e"] = e2e_modeling_sharded(grp, gs, n, k, args)
     grp.close()
     if rank == 0:
         # RCCL prints a version banner through C stdio, which (piped) is flushed at exit, after Python's own
