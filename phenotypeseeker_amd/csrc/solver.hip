@@ -344,7 +344,7 @@ __device__ __forceinline__ void masked_add8(double *x, const uint64_t *m, double
 // ALL_LDS: every array of the fit lives in LDS (the usual case: a few hundred samples, <= ~1500 distinct
 // columns).  The placement is then a compile-time fact, the pointers are LDS pointers and the loops use
 // ds_read / ds_write; with run-time placement flags they are generic pointers and every access is a flat load.
-// WMREG: 0, or the number of sample words per lane the register form of the descent holds (16 or 32, a quarter of them in each of its four waves; see cd_coop) --
+// WMREG: 0, or the number of sample words per lane the register form of the descent holds (16, 32 or 64, a quarter of them in each of its four waves; see cd_coop) --
 // a template parameter so that its 2 x WMREG doubles per lane do not weigh on the register allocation of the other forms.
 template <bool ALL_LDS, int WMREG>
 __global__ __launch_bounds__(WMREG > 0 ? SV_COOP_THREADS : SV_THREADS) void logreg_newglmnet_bits_kernel(
@@ -450,7 +450,8 @@ __global__ __launch_bounds__(WMREG > 0 ? SV_COOP_THREADS : SV_THREADS) void logr
                     P[q] = Dr[q] * Xr[q];
                 }
                 double Gw = 0.0;
-                if (WQ == 8) masked_sum8(Gw, M, P);
+                if (WQ == 16) { masked_sum8(Gw, M, P); masked_sum8(Gw, M + (WQ == 16 ? 8 : 0), P + (WQ == 16 ? 8 : 0)); }
+                else if (WQ == 8) masked_sum8(Gw, M, P);
                 else if (WQ == 4) masked_sum4(Gw, M, P);
                 else masked_sum2(Gw, M, P);
                 Gw = psk_wave_sum_f64_dpp(Gw);
@@ -486,7 +487,8 @@ __global__ __launch_bounds__(WMREG > 0 ? SV_COOP_THREADS : SV_THREADS) void logr
                 if (fabs(z) < 1e-12 && !(z == -wp && wp != 0.0)) continue;  // see the LDS form below
                 z = fmin(fmax(z, -10.0), 10.0);
                 if (wave == 0 && lane == 0) wpd[j] = wp + z;
-                if (WQ == 8) masked_add8(Xr, M, z);
+                if (WQ == 16) { masked_add8(Xr, M, z); masked_add8(Xr + (WQ == 16 ? 8 : 0), M + (WQ == 16 ? 8 : 0), z); }
+                else if (WQ == 8) masked_add8(Xr, M, z);
                 else if (WQ == 4) masked_add4(Xr, M, z);
                 else masked_add2(Xr, M, z);
             }
@@ -1222,10 +1224,10 @@ extern "C" int psk_logreg_l1_fit(psk_ctx *ctx, const float *X, const int32_t *y0
         }
         SV_ALLOC(b.bits, bits.size() * 8);
         PSK_HIP(ctx, hipMemcpyAsync(b.bits, bits.data(), bits.size() * 8, hipMemcpyHostToDevice, ctx->stream));
-        // the same columns transposed for the register form of the descent (n <= 2048): bit t of word l = sample 64 t + l
+        // the same columns transposed for the register form of the descent: bit t of word l = sample 64 t + l
         // (not built when every Newton step can take the Gram form: the register form's kernel would only cost registers)
         const bool always_gram = q_doubles > 0 && p + 1 <= 192 && q_doubles >= need_q / 8;
-        std::vector<uint64_t> bitsT(W <= 32 && !always_gram && !getenv("PSK_NO_CD_REGS") ? (size_t)(p + 1) * 64 : 0, 0);
+        std::vector<uint64_t> bitsT(!always_gram && !getenv("PSK_NO_CD_REGS") ? (size_t)(p + 1) * 64 : 0, 0);
         if (!bitsT.empty()) {
             for (int j = 0; j <= p; j++)
                 for (int t = 0; t < W; t++) {
@@ -1240,11 +1242,13 @@ extern "C" int psk_logreg_l1_fit(psk_ctx *ctx, const float *X, const int32_t *y0
             PSK_HIP(ctx, hipMemcpyAsync(b.bitsT, bitsT.data(), bitsT.size() * 8, hipMemcpyHostToDevice, ctx->stream));
         }
         const bool all_lds = f_lds && s_lds == 3 && c_lds && q_lds;
-        const int wmreg = bitsT.empty() ? 0 : (W <= 16 ? 16 : 32);
-        auto kern = all_lds ? (wmreg == 0 ? logreg_newglmnet_bits_kernel<true, 0> : wmreg == 16 ? logreg_newglmnet_bits_kernel<true, 16>
-                                                                                               : logreg_newglmnet_bits_kernel<true, 32>)
-                            : (wmreg == 0 ? logreg_newglmnet_bits_kernel<false, 0> : wmreg == 16 ? logreg_newglmnet_bits_kernel<false, 16>
-                                                                                                : logreg_newglmnet_bits_kernel<false, 32>);
+        const int wmreg = bitsT.empty() ? 0 : (W <= 16 ? 16 : W <= 32 ? 32 : 64);
+        auto pick = [&](auto all) {
+            constexpr bool A = decltype(all)::value;
+            return wmreg == 0 ? logreg_newglmnet_bits_kernel<A, 0> : wmreg == 16 ? logreg_newglmnet_bits_kernel<A, 16>
+                 : wmreg == 32 ? logreg_newglmnet_bits_kernel<A, 32> : logreg_newglmnet_bits_kernel<A, 64>;
+        };
+        auto kern = all_lds ? pick(std::true_type{}) : pick(std::false_type{});
         if (lds_b > 64 * 1024)
             PSK_HIP(ctx, hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,
                                              (int)lds_b));

@@ -492,9 +492,9 @@ def test_l1_logreg_mid_size_objectives_match_liblinear(ctx):
             assert float(z["obj_" + tag][j]) * (1 - 1e-9) <= obj <= float(z["obj_" + tag][j]) * 1.005, (tag, C)
 
 
-@pytest.mark.parametrize("n", [700, 2048])
+@pytest.mark.parametrize("n", [700, 2048, 3000, 4096])
 def test_l1_logreg_register_form_equals_lds_form(ctx, n, monkeypatch):
-    """More distinct columns than the Gram block holds (250 > 192) and n <= 2048: the descent runs on four waves per
+    """More distinct columns than the Gram block holds (250 > 192): the descent runs on four waves per
     fit, each with a quarter of the samples in registers (cd_coop).  The same algorithm as the one-wave LDS form
     (PSK_NO_CD_REGS=1) with the gradient's partial sums associated differently: both stop by liblinear's rule, and
     their objectives agree far inside the stopping tolerance."""
