@@ -366,7 +366,7 @@ __global__ __launch_bounds__(WMREG > 0 ? SV_COOP_THREADS : SV_THREADS) void logr
     const double C = fit_param[fit];
     const int tf = fit_fold[fit];
 #ifdef PSK_SV_STATS
-    long long stat_sweeps = 0, stat_visits = 0, stat_t_cd = 0, stat_t0 = 0;
+    long long stat_sweeps = 0, stat_visits = 0, stat_t_cd = 0, stat_t0 = 0, stat_t_gram = 0, stat_t_build = 0, stat_builds = 0, stat_t_polish = 0, stat_gram_sweeps = 0;
     const long long stat_start = clock64();
 #endif
     const int P1 = p + 1, NP = W * 64;  // sample arrays are padded to whole words
@@ -393,9 +393,46 @@ __global__ __launch_bounds__(WMREG > 0 ? SV_COOP_THREADS : SV_THREADS) void logr
 
     uint32_t rng = ((uint32_t)fit + 1u) * 2654435761u | 1u;  // per-fit xorshift state of the sweep permutations (lane 0's copy counts)
     // what wave 0 hands to the other waves of the register form at the start of a descent, and their partial sums
-    struct CdShared { double QP_Gmax_old, inner_eps, Gnorm1_init, l; int QP_active, active, cmd, pad; };
+    struct CdShared { double QP_Gmax_old, inner_eps, Gnorm1_init, l; int QP_active, active, cmd, fm; };
     __shared__ CdShared s_cd;
     __shared__ double s_part[2][SV_COOP_WAVES];
+    __shared__ double s_qpart[SV_COOP_WAVES][192];   // build_coop: a wave's part of Q[k][m] for every slot k of the Gram block
+    __shared__ int32_t s_fj[192];                    // ... and the feature of every slot (the QP uses `act` as scratch)
+    // Column m of the Gram block, Q[k][m] = sum over the training samples that have both k-mers of D, on the fit's four
+    // waves: wave v sums its quarter of the sample words for every slot k (column words transposed, the pair's AND as
+    // EXEC masks, D of its samples in registers -- the operation of cd_coop's gradient pass) and the partial sums meet
+    // in s_qpart.  One lane per slot walking the set bits of the AND through LDS (r01) took ~340,000 cycles per column:
+    // 65-85 % of the covariance form's time at 2048 samples x 169 columns (per-fit statistics, r02).
+    auto build_coop = [&](auto wm_tag) {
+        constexpr int WM = decltype(wm_tag)::value, WQ = WM / SV_COOP_WAVES;
+        const int t0 = wave * WQ, fm = s_cd.fm, na = s_cd.active;
+        double Dq[WQ];
+        uint64_t tmask = 0;
+#pragma unroll
+        for (int q = 0; q < WQ; q++) {
+            const int t = t0 + q, i = t * 64 + lane;
+            const bool in = t < W;
+            Dq[q] = in ? D[i] : 0.0;
+            if (in && i < n && fold[i] != tf) tmask |= 1ull << t;
+        }
+        const uint64_t mm = (colT[(size_t)fm * 64 + lane] & tmask) >> t0;
+        uint64_t x_next = na > 0 ? mm & (colT[(size_t)s_fj[0] * 64 + lane] >> t0) : 0ull;
+        for (int u = 0; u < na; u++) {
+            const uint64_t x = x_next;
+            if (u + 1 < na) x_next = mm & (colT[(size_t)s_fj[u + 1] * 64 + lane] >> t0);
+            uint64_t M[WQ];
+#pragma unroll
+            for (int q = 0; q < WQ; q++) M[q] = __ballot((x >> q) & 1ull);
+            double g = 0.0;
+            if (WQ == 16) { masked_sum8(g, M, Dq); masked_sum8(g, M + (WQ == 16 ? 8 : 0), Dq + (WQ == 16 ? 8 : 0)); }
+            else if (WQ == 8) masked_sum8(g, M, Dq);
+            else if (WQ == 4) masked_sum4(g, M, Dq);
+            else masked_sum2(g, M, Dq);
+            g = psk_wave_sum_f64_dpp(g);
+            if (lane == 0) s_qpart[wave][u] = g;
+        }
+        __syncthreads();   // the partial sums of every slot are in place
+    };
     // Register form of the array descent, FOUR waves per fit (WMREG > 0).  A coordinate visit is ~450 instructions
     // when one wave does it, ~230 of them per-word work (32 words: masks, products, masked additions, the update);
     // a lone wave issues one instruction per 4 cycles, so the visit took ~2,800 cycles whatever else the CU had
@@ -507,11 +544,13 @@ __global__ __launch_bounds__(WMREG > 0 ? SV_COOP_THREADS : SV_THREADS) void logr
         __syncthreads();   // x.d is whole again: wave 0 goes on to the line search, the others back to helper_loop
         return iter_c;
     };
-    if (WMREG > 0 && wave != 0) {   // helper_loop: waves 1..3 join every descent of wave 0 and leave with it
+    if (WMREG > 0 && wave != 0) {   // helper_loop: waves 1..3 join every descent / column build of wave 0 and leave with it
         for (;;) {
             __syncthreads();
-            if (s_cd.cmd == 2) break;
-            cd_coop(std::integral_constant<int, (WMREG > 0 ? WMREG : 32)>{});
+            const int cmd = s_cd.cmd;
+            if (cmd == 2) break;
+            if (cmd == 3) build_coop(std::integral_constant<int, (WMREG > 0 ? WMREG : 32)>{});
+            else cd_coop(std::integral_constant<int, (WMREG > 0 ? WMREG : 32)>{});
         }
         return;
     }
@@ -615,6 +654,7 @@ __global__ __launch_bounds__(WMREG > 0 ? SV_COOP_THREADS : SV_THREADS) void logr
                 have[q] = 0;
                 kq[q] = mine ? u : 0;  // idle slots read (and ignore) a valid entry
                 tri[q] = kq[q] * (kq[q] + 1) / 2;
+                if (WMREG > 0 && mine) s_fj[u] = fjs[q];   // for build_coop (read behind the barrier that releases it)
             }
             // a[u >> 6] of lane u & 63 for a wave-uniform slot id u: uniform branches, one lane read each
             auto pick_i = [&](const int *a, int u) {
@@ -641,6 +681,22 @@ __global__ __launch_bounds__(WMREG > 0 ? SV_COOP_THREADS : SV_THREADS) void logr
                 for (int q = 0; q < NS; q++) if ((m >> 6) == q) { built = (have[q] >> (m & 63)) & 1; have[q] |= 1ull << (m & 63); }
                 if (built) return false;
                 const int fm = pick_i(fjs, m);
+                if (WMREG > 0) {
+                    if (lane == 0) { s_cd.cmd = 3; s_cd.fm = fm; s_cd.active = active; }
+                    __syncthreads();   // releases waves 1..3 into build_coop
+                    build_coop(std::integral_constant<int, (WMREG > 0 ? WMREG : 32)>{});
+#pragma unroll
+                    for (int q = 0; q < NS; q++) {
+                        const int k = lane + 64 * q;
+                        if (k >= active) continue;
+                        double acc = s_qpart[0][k];
+#pragma unroll
+                        for (int v = 1; v < SV_COOP_WAVES; v++) acc += s_qpart[v][k];
+                        if (k == m) acc = h[q];
+                        Qm[qidx(k, m)] = acc;
+                    }
+                    return true;
+                }
 #pragma unroll
                 for (int q = 0; q < NS; q++) {
                     const int k = lane + 64 * q;
@@ -790,9 +846,16 @@ __global__ __launch_bounds__(WMREG > 0 ? SV_COOP_THREADS : SV_THREADS) void logr
                     else z = -wp;
                     if (fabs(z) < 1e-12 && !(z == -wp && wp != 0.0)) continue;  // see the array form below
                     z = fmin(fmax(z, -10.0), 10.0);
+#ifdef PSK_SV_STATS
+                    const long long stat_b0 = clock64();
+#endif
                     if (ensure_col(m)) {
 #pragma unroll
                         for (int q = 0; q < NS; q++) qcol[q] = Qm[qidx(kq[q], m)];
+#ifdef PSK_SV_STATS
+                        stat_t_build += clock64() - stat_b0;
+                        stat_builds++;
+#endif
                     }
 #pragma unroll
                     for (int q = 0; q < NS; q++) {
@@ -809,7 +872,13 @@ __global__ __launch_bounds__(WMREG > 0 ? SV_COOP_THREADS : SV_THREADS) void logr
                 }
                 QP_Gmax_old = QP_Gmax_new;
                 if (iter >= 4 && (iter & (iter - 1)) == 0) {  // after sweeps 4, 8, 16, ...
+#ifdef PSK_SV_STATS
+                    const long long stat_p0 = clock64();
+#endif
                     for (int rep = 0; rep < polish_reps && polish(); rep++) {}
+#ifdef PSK_SV_STATS
+                    stat_t_polish += clock64() - stat_p0;
+#endif
                 }
             }
             // back to the array form: new visiting order, wpd, and xTd = X_A d
@@ -842,6 +911,11 @@ __global__ __launch_bounds__(WMREG > 0 ? SV_COOP_THREADS : SV_THREADS) void logr
             }
         };
         using std::integral_constant;
+#ifdef PSK_SV_STATS
+        stat_t0 = clock64();
+        const long long stat_g0 = stat_t0;
+        const long long stat_cd_before = stat_t_cd;
+#endif
         if (q_lds && active <= 64 && q_doubles >= 64 * 64) {
             gram_qp(integral_constant<int, 1>{}, integral_constant<bool, false>{});
         } else if (q_lds && active <= 128 && q_doubles >= 128 * 128) {
@@ -851,13 +925,13 @@ __global__ __launch_bounds__(WMREG > 0 ? SV_COOP_THREADS : SV_THREADS) void logr
             else if (active <= 128) gram_qp(integral_constant<int, 2>{}, integral_constant<bool, true>{});
             else gram_qp(integral_constant<int, 3>{}, integral_constant<bool, true>{});
         } else {
-        // Array form with the samples in REGISTERS (up to 2048 samples): lane l owns samples l, l + 64, ..., so D and
+        // Array form with the samples in REGISTERS: lane l owns samples l, l + 64, ..., so D and
         // x.d of a fit are W doubles per lane each, and the column of a coordinate arrives TRANSPOSED (colT: bit t of
         // lane l's word = sample 64 t + l) -- one coalesced load, requested a step ahead, no lane reads.  A coordinate
         // step is then W predicated FMAs, one wave sum and W predicated adds, without an LDS access; with the arrays in
         // LDS every word step waited for two LDS reads (~100 clocks: the loop is not unrolled, W is a run-time value)
         // and a step took ~1 us (r02: 2048 samples x 907 columns, 16 M steps = the 16 s of that grid).  Same visiting
-        // order, same sums in the same order as the LDS form below (which serves W > 32).
+        // order as the LDS form below (PSK_NO_CD_REGS); four waves share the words of a fit: cd_coop above.
 #ifdef PSK_SV_STATS
         stat_t0 = clock64();
 #endif
@@ -1011,6 +1085,9 @@ __global__ __launch_bounds__(WMREG > 0 ? SV_COOP_THREADS : SV_THREADS) void logr
                 ewx[i] = en; tau[i] = C * tt; D[i] = C * en * tt * tt;
             }
         }
+#ifdef PSK_SV_STATS
+        if (stat_t_cd == stat_cd_before) { stat_t_gram += clock64() - stat_g0; stat_gram_sweeps += iter; }
+#endif
         if (iter == 1) inner_eps *= 0.25;
         Gmax_old = Gmax_new;
     }
@@ -1022,8 +1099,9 @@ __global__ __launch_bounds__(WMREG > 0 ? SV_COOP_THREADS : SV_THREADS) void logr
     }
 #ifdef PSK_SV_STATS
     if (lane == 0)
-        printf("fit %d C %g newton %d sweeps %lld visits<= %lld cd_cycles %lld total_cycles %lld\n", fit, C, newton, stat_sweeps, stat_visits,
-               stat_t_cd, (long long)(clock64() - stat_start));
+        printf("fit %d C %g newton %d sweeps %lld visits<= %lld cd_cycles %lld total_cycles %lld gram_cycles %lld gram_sweeps %lld builds %lld build_cycles %lld polish_cycles %lld\n",
+               fit, C, newton, stat_sweeps, stat_visits, stat_t_cd, (long long)(clock64() - stat_start), stat_t_gram, stat_gram_sweeps, stat_builds,
+               stat_t_build, stat_t_polish);
 #endif
 }
 #undef FLD
@@ -1158,7 +1236,7 @@ extern "C" int psk_logreg_l1_fit(psk_ctx *ctx, const float *X, const int32_t *y0
     const size_t n_state = binary ? (size_t)W * 64 : (size_t)n;
     // placement of the per-fit state: everything in LDS when it fits the 160 KiB of a CU, else the sample
     // arrays only, else global scratch
-    const size_t fbytes = 5 * (size_t)(p + 1) * 8, sbytes = 5 * n_state * 8, lds_max = 160 * 1024 - 512;
+    const size_t fbytes = 5 * (size_t)(p + 1) * 8, sbytes = 5 * n_state * 8, lds_max = 160 * 1024 - 8192;   // the kernels' static LDS (cooperation state of the bit-packed kernel: ~7 KB) comes on top
     int f_lds = 0, s_lds = 0;
     if (fbytes + sbytes <= lds_max) f_lds = s_lds = 1;
     else if (sbytes <= lds_max) s_lds = 1;
@@ -1225,9 +1303,7 @@ extern "C" int psk_logreg_l1_fit(psk_ctx *ctx, const float *X, const int32_t *y0
         SV_ALLOC(b.bits, bits.size() * 8);
         PSK_HIP(ctx, hipMemcpyAsync(b.bits, bits.data(), bits.size() * 8, hipMemcpyHostToDevice, ctx->stream));
         // the same columns transposed for the register form of the descent: bit t of word l = sample 64 t + l
-        // (not built when every Newton step can take the Gram form: the register form's kernel would only cost registers)
-        const bool always_gram = q_doubles > 0 && p + 1 <= 192 && q_doubles >= need_q / 8;
-        std::vector<uint64_t> bitsT(!always_gram && !getenv("PSK_NO_CD_REGS") ? (size_t)(p + 1) * 64 : 0, 0);
+        std::vector<uint64_t> bitsT(!getenv("PSK_NO_CD_REGS") ? (size_t)(p + 1) * 64 : 0, 0);
         if (!bitsT.empty()) {
             for (int j = 0; j <= p; j++)
                 for (int t = 0; t < W; t++) {
