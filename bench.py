@@ -159,7 +159,8 @@ def e2e_modeling_sharded(grp, gs, n, k, args):
         env["PYTHONPATH"] = here + os.pathsep + env.get("PYTHONPATH", "")
         cmd = [sys.executable, os.path.join(here, "scripts", "phenotypeseeker"), "modeling", "data.pheno", "-l", str(k)]
         t0 = time.time()
-        r = subprocess.run(cmd, cwd=tmp, env=env, stdout=subprocess.DEVNULL, stderr=subprocess.PIPE, timeout=1800)
+        r = subprocess.run(cmd, cwd=tmp, env=env, stdout=subprocess.DEVNULL, stderr=None if os.environ.get("PSK_TRACE") else subprocess.PIPE,
+                           timeout=1800)
         wall = time.time() - t0
         worst = grp.allreduce_max(wall)
         failed = grp.allreduce_sum(1 if r.returncode != 0 else 0)
@@ -169,9 +170,9 @@ def e2e_modeling_sharded(grp, gs, n, k, args):
                        "written): %d FASTA files on disk -> %s" % (grp.world, n, ", ".join(made) or "no model"),
                "write_dataset_s": round(t_write, 2)}
         if rank == 0 and not made and not failed:
-            res["error"] = "no .pkl written; rank 0: %s" % r.stderr.decode(errors="replace")[-600:]
+            res["error"] = "no .pkl written; rank 0: %s" % (r.stderr or b"").decode(errors="replace")[-600:]
         if failed:
-            res["error"] = "%d rank(s) failed; rank %d: %s" % (failed, rank, r.stderr.decode(errors="replace")[-400:])
+            res["error"] = "%d rank(s) failed; rank %d: %s" % (failed, rank, (r.stderr or b"").decode(errors="replace")[-400:])
         return res
     except Exception as e:   # noqa: BLE001 -- reported in the line
         return {"error": "%s: %s" % (type(e).__name__, e)}

@@ -120,7 +120,7 @@ extern "C" void psk_free(psk_ctx *ctx)
     arena_release(ctx);
     DevBuf *bufs[] = {&ctx->raw, &ctx->keysA, &ctx->keysB, &ctx->valsA, &ctx->valsB, &ctx->hist, &ctx->scan_tmp, &ctx->flags, &ctx->starts,
                       &ctx->misc, &ctx->union_words, &ctx->bits, &ctx->mask1, &ctx->phe,
-                      &ctx->slot[0].res, &ctx->slot[1].res, &ctx->res_count, &ctx->res_sorted, &ctx->lut};
+                      &ctx->slot[0].res, &ctx->slot[1].res, &ctx->res_count, &ctx->res_sorted, &ctx->lut, &ctx->bs_spl, &ctx->bs_ct};
     for (DevBuf *b : bufs) dev_release(*b);
     if (ctx->copy_stream) (void)hipStreamSynchronize(ctx->copy_stream);
     for (CountLane &L : ctx->lane) {
@@ -188,6 +188,8 @@ extern "C" int psk_begin(psk_ctx *ctx, int k, int n_samples, uint64_t slab_lo, u
     ctx->slab_lo = slab_lo;
     ctx->slab_hi = slab_hi;
     dense_configure(ctx);
+    ctx->bs_ready = false;   // the splitters of the bucketed sort belong to a run (its k, its slab)
+    for (CountLane &L : ctx->lane) L.dc_slot = 0;   // the dense and the bucketed route lay the counter ring out differently: zero it again
     ctx->n_kmers = 0;
     ctx->have_presence = false;
     ctx->last = ScanParams();

@@ -1,0 +1,531 @@
+// a1 for 32-bit word spaces beyond the dense form (k = 14..16): a bucketed sort instead of four radix passes
+// (replaces bin/glistmaker; modeling.py:303-315).  The radix route runs 17 launches per sample (extract, 4 x
+// (histogram, digit scan, scatter), 3 for the run lengths) -- 250-300 us for a 5-Mbp genome, and hardly less for the
+// 600,000 words a rank keeps of it under an 8-way slab filter, because every launch has its floor.  Here the word space
+// is cut into buckets of equal COUNT, about 2,400 words each (64..2,048 buckets) -- the splitters are quantiles of the
+// first list of the run, so that an AT-rich genome fills them as evenly as a uniform one -- and a sample is counted by
+//   bs_hist_kernel       tile of 16,384 bases per workgroup: canonical words (kmer_windows.h), slab filter, bucket from a
+//                        coarse cell table + a short search over the splitters in LDS, histogram; one returning atomic per non-empty
+//                        (tile, bucket) reserves the tile's range in the bucket
+//   bs_partition_kernel  the same tile again: rank inside (tile, bucket) from a returning LDS atomic, the tile's words
+//                        bucketed in LDS and spilled in bucket runs
+//   bs_sort_kernel       one workgroup per bucket: its ~2,400 words dealt into 2,048 sub-bins of its range in LDS and
+//                        straightened by insertion, run lengths from a scan of the run heads, unique words + counts
+//                        written over the bucket's own key range
+//   bs_totals_kernel     unique counts -> offsets, totals to the host
+//   bs_compact_kernel    (one sample later, once the host has sized the arena block) packs words (u64) + counts
+// The output is the ordinary sparse list.  A bucket that outgrows the LDS sort (a sample unlike the one the splitters
+// came from) sends the sample through the radix sort of its partitioned words instead (bucket_chain_finalize).
+// Integer work, LDS / HBM bound: no MFMA.
+#include "dev_utils.h"
+#include "psk_internal.h"
+#include "kmer_windows.h"
+
+namespace {
+
+constexpr int BT_THREADS = 512;
+constexpr int BT_TILE = BT_THREADS * KW_SEG;        // 16,384 bases per workgroup
+constexpr uint32_t BS_SLOTS = 32;                   // pre-zeroed counter slots per buffer set
+#ifndef PSK_BS_SORT_THREADS
+#define PSK_BS_SORT_THREADS 1024
+#endif
+constexpr int BS_SORT_THREADS = PSK_BS_SORT_THREADS;
+#ifndef PSK_BS_CAPMAX
+#define PSK_BS_CAPMAX 8192
+#endif
+constexpr uint32_t BS_CAP_MAX = PSK_BS_CAPMAX;      // words a bucket may hold for the LDS sort
+constexpr size_t BP_LDS_BYTES = (size_t)(BT_TILE + BS_NB + BS_NB / 2 + BS_NB + 16 + 2056) * 4;   // stage | h | lstart | splitters | scan | cells
+constexpr size_t BSORT_LDS_BYTES = (size_t)(2 * BS_CAP_MAX + 2 * 2048 + 32) * 4;          // words | sorted words | sub-bin starts | fills | scan
+
+// The bucket of a word = the largest b with spl[b] <= w (spl[0] = the first word of the slab).  A binary search over the splitters is eleven
+// dependent LDS reads per window; a coarse table over 4,096 equal cells of the run's word range (ct[c] = bucket of the
+// cell's first word) leaves a search over the one to three buckets that meet the cell.
+constexpr int BS_CELLS = 4096;
+struct BsMap {
+    uint32_t lo;      // first word of the range the cells cover (the slab's)
+    uint32_t shift;   // cell = (w - lo) >> shift
+    uint32_t nb;      // buckets in use (a power of two, 64..2048): about 2,400 words each
+};
+
+__device__ __forceinline__ uint32_t bucket_search(const uint32_t *spl, uint32_t nb, uint32_t w)
+{
+    uint32_t b = 0;
+    for (uint32_t step = nb >> 1; step > 0; step >>= 1)
+        if (spl[b + step] <= w) b += step;
+    return b;
+}
+
+__device__ __forceinline__ uint32_t bucket_of(const uint32_t *spl, const uint16_t *ct, const BsMap &mp, uint32_t w)
+{
+    uint32_t c = (w - mp.lo) >> mp.shift;
+    c = c < (uint32_t)BS_CELLS ? c : (uint32_t)BS_CELLS - 1u;
+    uint32_t b = ct[c], e = ct[c + 1];
+    while (b < e) {
+        const uint32_t mid = (b + e + 1u) >> 1;
+        if (spl[mid] <= w) b = mid;
+        else e = mid - 1u;
+    }
+    return b;
+}
+
+// splitters = every (nu / nb)-th word of a sorted list of this run; then the coarse table
+__global__ void bs_splitters_kernel(const uint64_t *__restrict__ words, uint64_t nu, uint32_t nb, uint32_t lo, uint32_t *__restrict__ spl)
+{
+    const uint32_t b = blockIdx.x * blockDim.x + threadIdx.x;
+    if (b >= BS_NB) return;
+    spl[b] = b == 0 ? lo :   // the first bucket begins where the slab does: a bucket's range is what its sub-bins divide
+             (b < nb ? (uint32_t)words[(uint64_t)b * nu / nb] : 0xffffffffu);
+}
+
+__global__ void bs_cells_kernel(const uint32_t *__restrict__ spl, BsMap mp, uint16_t *__restrict__ ct)
+{
+    const uint32_t c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c > (uint32_t)BS_CELLS) return;
+    const uint64_t first = (uint64_t)mp.lo + ((uint64_t)c << mp.shift);
+    ct[c] = (uint16_t)(c == (uint32_t)BS_CELLS || first > 0xffffffffull ? mp.nb - 1u : bucket_search(spl, mp.nb, (uint32_t)first));
+}
+
+// the workgroup's copies of the splitters and the cells
+__device__ __forceinline__ void load_map(uint32_t *spl, uint16_t *ct, const uint32_t *__restrict__ spl_g, const uint16_t *__restrict__ ct_g,
+                                         int threads)
+{
+    for (uint32_t d = threadIdx.x; d < BS_NB; d += threads) spl[d] = spl_g[d];
+    for (uint32_t d = threadIdx.x; d <= (uint32_t)BS_CELLS; d += threads) ct[d] = ct_g[d];
+}
+
+template <int K>
+__global__ __launch_bounds__(BT_THREADS) void bs_hist_kernel(const uint8_t *__restrict__ clean, uint64_t len, uint32_t lo, uint32_t hi,
+                                                              const uint32_t *__restrict__ spl_g, const uint16_t *__restrict__ ct_g,
+                                                              const BsMap mp, uint32_t *__restrict__ cnt, uint32_t *__restrict__ wgoff)
+{
+    __shared__ uint32_t h[BS_NB];
+    __shared__ uint32_t spl[BS_NB];
+    __shared__ uint16_t ct[BS_CELLS + 2];
+    for (uint32_t d = threadIdx.x; d < BS_NB; d += BT_THREADS) h[d] = 0;
+    load_map(spl, ct, spl_g, ct_g, BT_THREADS);
+    __syncthreads();
+    const uint64_t s = ((uint64_t)blockIdx.x * BT_THREADS + threadIdx.x) * KW_SEG;
+    Streams st;
+    load_streams(st, clean, len, s);
+    ForEachWindow<K, 0>::run(st, lo, hi, [&](int, bool ok, uint32_t w) {
+        if (ok) atomicAdd(&h[bucket_of(spl, ct, mp, w)], 1u);
+    });
+    __syncthreads();
+    uint32_t c[BS_NB / BT_THREADS], o[BS_NB / BT_THREADS];
+#pragma unroll
+    for (int e = 0; e < (int)(BS_NB / BT_THREADS); e++) c[e] = h[e * BT_THREADS + threadIdx.x];
+#pragma unroll
+    for (int e = 0; e < (int)(BS_NB / BT_THREADS); e++)
+        if (c[e]) o[e] = atomicAdd(&cnt[e * BT_THREADS + threadIdx.x], c[e]);
+#pragma unroll
+    for (int e = 0; e < (int)(BS_NB / BT_THREADS); e++)
+        if (c[e]) wgoff[(uint64_t)blockIdx.x * BS_NB + e * BT_THREADS + threadIdx.x] = o[e];
+}
+
+template <int K>
+__global__ __launch_bounds__(BT_THREADS) void bs_partition_kernel(const uint8_t *__restrict__ clean, uint64_t len, uint32_t lo,
+                                                                   uint32_t hi, const uint32_t *__restrict__ spl_g,
+                                                                   const uint16_t *__restrict__ ct_g, const BsMap mp,
+                                                                   const uint32_t *__restrict__ cnt, const uint32_t *__restrict__ wgoff,
+                                                                   uint32_t *__restrict__ base_out, uint32_t *__restrict__ part)
+{
+    extern __shared__ uint32_t dyn_lds[];                 // BP_LDS_BYTES
+    uint32_t *stage = dyn_lds;                            // 64 KB: the tile's words, bucketed
+    uint32_t *h = stage + BT_TILE;                        // counts, then (start of this tile's range in the bucket) - (local start)
+    uint16_t *lstart = reinterpret_cast<uint16_t *>(h + BS_NB);
+    uint32_t *spl = h + BS_NB + BS_NB / 2;
+    uint32_t *scan_lds = spl + BS_NB;
+    uint16_t *ct = reinterpret_cast<uint16_t *>(scan_lds + 16);
+    for (uint32_t d = threadIdx.x; d < BS_NB; d += BT_THREADS) h[d] = 0;
+    load_map(spl, ct, spl_g, ct_g, BT_THREADS);
+    __syncthreads();
+    const uint64_t s = ((uint64_t)blockIdx.x * BT_THREADS + threadIdx.x) * KW_SEG;
+    Streams st;
+    load_streams(st, clean, len, s);
+    uint32_t wv[KW_SEG];   // the word (a valid canonical word is never 0xffffffff: its reverse complement would be 0)
+    uint32_t rb[KW_SEG];   // bucket << 16 | rank inside (tile, bucket)
+    ForEachWindow<K, 0>::run(st, lo, hi, [&](int j, bool ok, uint32_t w) {
+        wv[j] = 0xffffffffu;
+        rb[j] = 0;
+        if (ok) {
+            const uint32_t b = bucket_of(spl, ct, mp, w);
+            wv[j] = w;
+            rb[j] = (b << 16) | atomicAdd(&h[b], 1u);
+        }
+    });
+    __syncthreads();
+    // thread t owns buckets 4t .. 4t + 3: local starts, global bucket bases, this tile's offset in each bucket
+    uint32_t ltot;
+    {
+        uint32_t c4[4], g4[4], lsum = 0, gsum = 0;
+        const uint32_t d0 = threadIdx.x * 4;
+#pragma unroll
+        for (int e = 0; e < 4; e++) {
+            c4[e] = h[d0 + e];
+            g4[e] = cnt[d0 + e];
+            lsum += c4[e];
+            gsum += g4[e];
+        }
+        uint32_t gtot;
+        uint32_t lex = psk_block_excl_scan_u32<BT_THREADS>(lsum, &ltot, scan_lds);
+        uint32_t gex = psk_block_excl_scan_u32<BT_THREADS>(gsum, &gtot, scan_lds);
+#pragma unroll
+        for (int e = 0; e < 4; e++) {
+            const uint32_t d = d0 + e;
+            lstart[d] = (uint16_t)lex;
+            h[d] = gex + (c4[e] ? wgoff[(uint64_t)blockIdx.x * BS_NB + d] : 0u) - lex;
+            if (blockIdx.x == 0) base_out[d] = gex;
+            lex += c4[e];
+            gex += g4[e];
+        }
+    }
+    __syncthreads();
+    // the bucket of a staged word is found again from the splitters when it is spilled (a second table of 16,384
+    // bucket ids would not leave room for the workgroup's other arrays)
+#pragma unroll
+    for (int j = 0; j < KW_SEG; j++)
+        if (wv[j] != 0xffffffffu) stage[(uint32_t)lstart[rb[j] >> 16] + (rb[j] & 0xffffu)] = wv[j];
+    __syncthreads();
+    for (uint32_t i = threadIdx.x; i < ltot; i += BT_THREADS) {
+        const uint32_t w = stage[i];
+        part[(size_t)(uint32_t)(h[bucket_of(spl, ct, mp, w)] + i)] = w;
+    }
+}
+
+// One workgroup per bucket: sort, run lengths.  The words of a bucket spread evenly over its narrow range (the buckets
+// have equal counts), so they are dealt into 2,048 sub-bins by the top bits of (word - first word of the bucket) -- one
+// or two words per sub-bin -- and a thread straightens its four sub-bins by insertion: four barriers instead of the 78
+// of a bitonic network over 4,096 keys (33 us per bucket against 5).  A sub-bin with more than BS_BIN_MAX words (the
+// sample is unlike the one the splitters came from) sends the sample to the fall-back, like a bucket beyond `cap`.
+// wtmp / ctmp: unique words and their counts, written from base[b] on (a bucket has at most cnt[b] of them and the
+// buckets' key ranges lie back to back).
+constexpr uint32_t BS_BINS = 2048;
+constexpr uint32_t BS_BIN_MAX = 192;
+__global__ __launch_bounds__(BS_SORT_THREADS) void bs_sort_kernel(const uint32_t *__restrict__ part, const uint32_t *__restrict__ cnt,
+                                                                   const uint32_t *__restrict__ base, const uint32_t *__restrict__ spl,
+                                                                   uint32_t nb, uint32_t last_word, uint32_t cap, uint32_t *__restrict__ wtmp,
+                                                                   uint32_t *__restrict__ ctmp, uint32_t *__restrict__ uniq_out,
+                                                                   uint32_t *__restrict__ flag)
+{
+    constexpr int BPT = BS_BINS / BS_SORT_THREADS;   // sub-bins per thread
+    extern __shared__ uint32_t dyn_lds[];   // BSORT_LDS_BYTES
+    uint32_t *kin = dyn_lds;                // the bucket's words as they come; later the run lengths
+    uint32_t *key = kin + BS_CAP_MAX;       // ... dealt into sub-bins, then sorted
+    uint32_t *start = key + BS_CAP_MAX;     // sub-bin counts -> starts
+    uint32_t *fill = start + BS_BINS;
+    uint32_t *scan_lds = fill + BS_BINS;
+    const uint32_t b = blockIdx.x, t = threadIdx.x;
+#ifdef PSK_BS_STAMPS
+    long long *stamps = reinterpret_cast<long long *>(flag + 2);
+    if (b == 100 && t == 0) stamps[6] = clock64();
+#endif
+    const uint32_t n = cnt[b];
+    if (n == 0) { if (t == 0) uniq_out[b] = 0; return; }
+    if (n > cap) {   // not this way: the host sends the sample through the radix sort (bucket_chain_finalize)
+        if (t == 0) { uniq_out[b] = 0; atomicOr(flag, 1u); }
+        return;
+    }
+    const size_t off = base[b];
+    const uint32_t first = spl[b], last = b + 1 < nb ? spl[b + 1] - 1u : last_word;   // the bucket's words lie in [first, last]
+    const uint32_t span = last - first;
+    const uint32_t sh = span < BS_BINS ? 0u : (32u - (uint32_t)__builtin_clz(span)) - 11u;   // (w - first) >> sh < 2048
+    for (uint32_t i = t; i < BS_BINS; i += BS_SORT_THREADS) start[i] = 0;
+    __syncthreads();
+#ifdef PSK_BS_STAMPS
+    if (b == 100 && t == 0) stamps[0] = clock64();
+#endif
+    for (uint32_t i = t; i < n; i += BS_SORT_THREADS) {
+        const uint32_t w = part[off + i];
+        kin[i] = w;
+        atomicAdd(&start[(w - first) >> sh], 1u);
+    }
+    __syncthreads();
+#ifdef PSK_BS_STAMPS
+    if (b == 100 && t == 0) stamps[1] = clock64();
+#endif
+    {
+        uint32_t c4[BPT], sum = 0, big = 0;
+#pragma unroll
+        for (int e = 0; e < BPT; e++) { c4[e] = start[BPT * t + e]; sum += c4[e]; big |= c4[e] > BS_BIN_MAX; }
+        uint32_t tot;
+        uint32_t ex = psk_block_excl_scan_u32<BS_SORT_THREADS>(sum, &tot, scan_lds);
+        const uint32_t any_big = psk_block_excl_scan_u32<BS_SORT_THREADS>(big, &tot, scan_lds) + big;   // tot = number of threads with one
+        (void)any_big;
+        if (tot) {   // uniform: every thread has the same total
+            if (t == 0) { uniq_out[b] = 0; atomicOr(flag, 1u); }
+            return;
+        }
+#pragma unroll
+        for (int e = 0; e < BPT; e++) { start[BPT * t + e] = ex; fill[BPT * t + e] = ex; ex += c4[e]; }
+    }
+#ifdef PSK_BS_STAMPS
+    if (b == 100 && t == 0) stamps[2] = clock64();
+#endif
+    __syncthreads();
+    for (uint32_t i = t; i < n; i += BS_SORT_THREADS) {
+        const uint32_t w = kin[i];
+        key[atomicAdd(&fill[(w - first) >> sh], 1u)] = w;
+    }
+    __syncthreads();
+#ifdef PSK_BS_STAMPS
+    if (b == 100 && t == 0) stamps[3] = clock64();
+#endif
+    // thread t straightens its BPT consecutive sub-bins as ONE stretch (every word of a sub-bin is below every word of the
+    // next): up to 16 words in registers through Batcher's odd-even merge network (63 compare-exchanges, no LDS round
+    // trips -- insertion inside LDS, a few dependent reads per step with the lanes of a wave waiting for the longest
+    // sub-bin, was 60 % of the kernel); longer stretches (rare) by insertion in LDS
+    {
+        const uint32_t lo = start[BPT * t], hi = fill[BPT * t + BPT - 1], m = hi - lo;
+        if (m > 16) {
+            for (uint32_t i = lo + 1; i < hi; i++) {
+                const uint32_t x = key[i];
+                uint32_t j = i;
+                while (j > lo && key[j - 1] > x) { key[j] = key[j - 1]; j--; }
+                key[j] = x;
+            }
+        } else if (m > 1) {
+            uint32_t r[16];
+#pragma unroll
+            for (int i = 0; i < 16; i++) r[i] = (uint32_t)i < m ? key[lo + i] : 0xffffffffu;
+#pragma unroll
+            for (int p = 1; p < 16; p *= 2)
+#pragma unroll
+                for (int k = p; k >= 1; k /= 2)
+#pragma unroll
+                    for (int j = k % p; j <= 16 - 1 - k; j += 2 * k)
+#pragma unroll
+                        for (int i = 0; i <= (k - 1 < 16 - j - k - 1 ? k - 1 : 16 - j - k - 1); i++)
+                            if ((i + j) / (2 * p) == (i + j + k) / (2 * p)) {
+                                const uint32_t x = r[i + j], y = r[i + j + k];
+                                r[i + j] = x < y ? x : y;
+                                r[i + j + k] = x < y ? y : x;
+                            }
+#pragma unroll
+            for (int i = 0; i < 16; i++)
+                if ((uint32_t)i < m) key[lo + i] = r[i];
+        }
+    }
+    __syncthreads();
+#ifdef PSK_BS_STAMPS
+    if (b == 100 && t == 0) stamps[4] = clock64();
+#endif
+    // run lengths: thread t owns the sorted words [t c, (t + 1) c); it counts the run heads in its stretch, one scan gives
+    // their ranks, and every head writes its word and its position (kin) -- the length of run r is then the difference of
+    // the positions of heads r + 1 and r
+    const uint32_t c = (n + BS_SORT_THREADS - 1) / BS_SORT_THREADS;
+    const uint32_t i0 = t * c < n ? t * c : n, i1 = i0 + c < n ? i0 + c : n;
+    uint32_t heads = 0;
+    for (uint32_t i = i0; i < i1; i++) heads += (i == 0 || key[i - 1] != key[i]) ? 1u : 0u;
+    uint32_t nu;
+    uint32_t r = psk_block_excl_scan_u32<BS_SORT_THREADS>(heads, &nu, scan_lds);
+    for (uint32_t i = i0; i < i1; i++)
+        if (i == 0 || key[i - 1] != key[i]) {
+            kin[r] = i;
+            wtmp[off + r] = key[i];
+            r++;
+        }
+    __syncthreads();
+    for (uint32_t q = t; q < nu; q += BS_SORT_THREADS) ctmp[off + q] = (q + 1 < nu ? kin[q + 1] : n) - kin[q];
+#ifdef PSK_BS_STAMPS
+    if (b == 100 && t == 0) stamps[5] = clock64();
+#endif
+    if (t == 0) uniq_out[b] = nu;
+}
+
+// uniq -> offsets of the buckets in the list; totals: host[0] = words kept, [1] = unique words, [3] = a bucket overflowed
+__global__ __launch_bounds__(1024) void bs_totals_kernel(const uint32_t *__restrict__ cnt, const uint32_t *__restrict__ uniq,
+                                                         uint32_t *__restrict__ uoff, const uint32_t *__restrict__ flag,
+                                                         uint32_t nb, uint32_t *__restrict__ host)
+{
+    __shared__ uint32_t scan_lds[16];
+    const uint32_t t = threadIdx.x;
+    const uint32_t u0 = 2 * t < nb ? uniq[2 * t] : 0u, u1 = 2 * t + 1 < nb ? uniq[2 * t + 1] : 0u, c = cnt[2 * t] + cnt[2 * t + 1];
+    uint32_t utot, ctot;
+    const uint32_t ex = psk_block_excl_scan_u32<1024>(u0 + u1, &utot, scan_lds);
+    psk_block_excl_scan_u32<1024>(c, &ctot, scan_lds);
+    uoff[2 * t] = ex;
+    uoff[2 * t + 1] = ex + u0;
+    if (t == 0) { host[0] = ctot; host[1] = utot; host[2] = 0; host[3] = *flag; }
+}
+
+__global__ void bs_compact_kernel(const uint32_t *__restrict__ wtmp, const uint32_t *__restrict__ ctmp, const uint32_t *__restrict__ base,
+                                  const uint32_t *__restrict__ uniq, const uint32_t *__restrict__ uoff, uint64_t *__restrict__ words,
+                                  uint32_t *__restrict__ freqs)
+{
+    const uint32_t b = blockIdx.x, n = uniq[b];
+    const size_t src = base[b], dst = uoff[b];
+    for (uint32_t i = threadIdx.x; i < n; i += blockDim.x) {
+        words[dst + i] = wtmp[src + i];
+        freqs[dst + i] = ctmp[src + i];
+    }
+}
+
+// the partitioned words of a sample as u64 keys for the radix sort (the fall-back)
+__global__ void bs_expand_kernel(const uint32_t *__restrict__ part, uint64_t n, uint64_t *__restrict__ keys)
+{
+    const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) keys[i] = part[i];
+}
+
+struct BsBufs {
+    uint32_t *cnt, *flag, *base, *uniq, *uoff;
+};
+
+BsBufs bs_bufs(const CountLane &L, uint32_t slot)
+{
+    BsBufs d;
+    d.cnt = L.dc_cnt.as<uint32_t>() + (size_t)slot * (BS_NB + 16);
+    d.flag = d.cnt + BS_NB;
+    d.base = L.dc_meta.as<uint32_t>();
+    d.uniq = d.base + BS_NB;
+    d.uoff = d.uniq + BS_NB;
+    return d;
+}
+
+uint32_t bs_cap()
+{
+    const char *e = getenv("PSK_BS_CAP");   // tests: a small capacity forces the fall-back (read per call)
+    const long v = e ? atol(e) : 0;
+    return (uint32_t)(v > 0 && v < (long)BS_CAP_MAX ? v : (long)BS_CAP_MAX);
+}
+
+template <int K>
+int launch_tiles(psk_ctx *ctx, CountLane &L, const BsBufs &d, uint64_t clean_len, uint32_t n_tiles, uint32_t lo, uint32_t hi)
+{
+    const BsMap mp{ctx->bs_lo, ctx->bs_shift, ctx->bs_nb};
+    const uint16_t *ct = ctx->bs_ct.as<uint16_t>();
+    bs_hist_kernel<K><<<n_tiles, BT_THREADS, 0, ctx->stream>>>(L.raw.as<uint8_t>(), clean_len, lo, hi, ctx->bs_spl.as<uint32_t>(), ct, mp, d.cnt,
+                                                               L.dc_wgoff.as<uint32_t>());
+    PSK_HIP(ctx, hipGetLastError());
+    static bool attr_set = false;
+    if (!attr_set) {
+        PSK_HIP(ctx, hipFuncSetAttribute(reinterpret_cast<const void *>(bs_partition_kernel<K>),
+                                         hipFuncAttributeMaxDynamicSharedMemorySize, (int)BP_LDS_BYTES));
+        attr_set = true;
+    }
+    bs_partition_kernel<K><<<n_tiles, BT_THREADS, BP_LDS_BYTES, ctx->stream>>>(L.raw.as<uint8_t>(), clean_len, lo, hi,
+                                                                              ctx->bs_spl.as<uint32_t>(), ct, mp, d.cnt,
+                                                                              L.dc_wgoff.as<uint32_t>(), d.base, L.dc_part.as<uint32_t>());
+    PSK_HIP(ctx, hipGetLastError());
+    return PSK_OK;
+}
+
+}  // namespace
+
+// n = the sample's windows (an upper bound of its words under a slab filter: bs_keep is the share the run's first list kept).
+// A sample that would put more than half the LDS sort's capacity into an average bucket (reads at depth) keeps the radix
+// route: its buckets would overflow and the work would be done twice.
+bool bucket_route_ok(const psk_ctx *ctx, uint64_t n)
+{
+    if (!ctx->bs_ready || ctx->dense_mode || ctx->k < 14 || ctx->k > 16) return false;
+    return (double)n * ctx->bs_keep / ctx->bs_nb <= 0.5 * BS_CAP_MAX;
+}
+
+// after a sample of the run has gone through the radix route: its list gives the splitters of the later ones
+int bucket_splitters_from(psk_ctx *ctx, const SampleList &S, uint64_t windows)
+{
+    if (ctx->bs_ready || ctx->dense_mode || ctx->k < 14 || ctx->k > 16 || S.n_unique < 32768 || !S.words) return PSK_OK;
+    if (getenv("PSK_NO_BUCKET_SORT")) return PSK_OK;   // read per call: tests cross the two routes in one process
+    // about 2,400 words per bucket (the LDS sort takes 8,192): a genome gives 2,048 buckets, a rank's eighth of it 256
+    uint32_t nb = 64;
+    while (nb < BS_NB && (uint64_t)nb * 2400 < S.n_unique) nb <<= 1;
+    const uint64_t space = 1ull << (2 * ctx->k);
+    const uint64_t lo = ctx->slab_lo, hi = (ctx->slab_hi && ctx->slab_hi < space) ? ctx->slab_hi : space;
+    uint32_t shift = 0;
+    while (((hi - lo - 1) >> shift) >= (uint64_t)BS_CELLS) shift++;
+    ctx->bs_nb = nb;
+    ctx->bs_keep = windows ? (double)S.n_total / (double)windows : 1.0;
+    if (ctx->bs_keep > 1.0) ctx->bs_keep = 1.0;
+    ctx->bs_lo = (uint32_t)lo;
+    ctx->bs_shift = shift;
+    PSK_TRY(dev_reserve(ctx, ctx->bs_spl, (size_t)BS_NB * 4));
+    PSK_TRY(dev_reserve(ctx, ctx->bs_ct, (size_t)(BS_CELLS + 2) * 2));
+    bs_splitters_kernel<<<div_up(BS_NB, 256), 256, 0, ctx->stream>>>(S.words, S.n_unique, nb, ctx->bs_lo, ctx->bs_spl.as<uint32_t>());
+    PSK_HIP(ctx, hipGetLastError());
+    bs_cells_kernel<<<div_up(BS_CELLS + 1, 256), 256, 0, ctx->stream>>>(ctx->bs_spl.as<uint32_t>(), BsMap{ctx->bs_lo, shift, nb},
+                                                                       ctx->bs_ct.as<uint16_t>());
+    PSK_HIP(ctx, hipGetLastError());
+    ctx->bs_ready = true;
+    return PSK_OK;
+}
+
+int bucket_chain_enqueue(psk_ctx *ctx, CountLane &L, int sample_idx, uint64_t clean_len, uint64_t n)
+{
+    (void)sample_idx;
+    const uint64_t space = 1ull << (2 * ctx->k);
+    const uint32_t lo = (uint32_t)ctx->slab_lo;
+    const uint32_t hi = (ctx->slab_hi && ctx->slab_hi < space && ctx->slab_hi <= 0xffffffffull) ? (uint32_t)ctx->slab_hi
+                        : (space > 0xffffffffull ? 0xffffffffu : (uint32_t)space);   // no canonical word is 0xffffffff
+    const uint32_t n_tiles = div_up(clean_len, BT_TILE);
+    PSK_TRY(dev_reserve(ctx, L.dc_part, n * 4 + 64));
+    PSK_TRY(dev_reserve(ctx, L.dc_wgoff, (size_t)n_tiles * BS_NB * 4));
+    PSK_TRY(dev_reserve(ctx, L.dc_cnt, (size_t)BS_SLOTS * (BS_NB + 16) * 4));
+    PSK_TRY(dev_reserve(ctx, L.dc_meta, (size_t)(4 * BS_NB + 4) * 4));
+    PSK_TRY(dev_reserve(ctx, L.dc_mtemp, n * 8 + 64));
+    if (L.dc_slot == 0 || L.dc_slot >= BS_SLOTS) {
+        PSK_HIP(ctx, hipMemsetAsync(L.dc_cnt.p, 0, (size_t)BS_SLOTS * (BS_NB + 16) * 4, ctx->stream));
+        L.dc_slot = 0;
+    }
+    const BsBufs d = bs_bufs(L, L.dc_slot++);
+    switch (ctx->k) {
+    case 14: PSK_TRY(launch_tiles<14>(ctx, L, d, clean_len, n_tiles, lo, hi)); break;
+    case 15: PSK_TRY(launch_tiles<15>(ctx, L, d, clean_len, n_tiles, lo, hi)); break;
+    case 16: PSK_TRY(launch_tiles<16>(ctx, L, d, clean_len, n_tiles, lo, hi)); break;
+    default: return psk_fail(ctx, PSK_ESTATE, "the bucketed sort is built for k = 14..16, not %d", ctx->k);
+    }
+    PSK_HIP(ctx, hipEventRecord(L.raw_free, ctx->stream));
+    L.raw_used = true;
+    static bool attr_set = false;
+    if (!attr_set) {
+        PSK_HIP(ctx, hipFuncSetAttribute(reinterpret_cast<const void *>(bs_sort_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                         (int)BSORT_LDS_BYTES));
+        attr_set = true;
+    }
+    uint32_t *wtmp = L.dc_mtemp.as<uint32_t>(), *ctmp = wtmp + n + 8;
+    bs_sort_kernel<<<ctx->bs_nb, BS_SORT_THREADS, BSORT_LDS_BYTES, ctx->stream>>>(L.dc_part.as<uint32_t>(), d.cnt, d.base, ctx->bs_spl.as<uint32_t>(),
+                                                                                  ctx->bs_nb, hi - 1u, bs_cap(), wtmp, ctmp, d.uniq, d.flag);
+    PSK_HIP(ctx, hipGetLastError());
+    bs_totals_kernel<<<1, 1024, 0, ctx->stream>>>(d.cnt, d.uniq, d.uoff, d.flag, ctx->bs_nb, L.pinned_cnt);
+    PSK_HIP(ctx, hipGetLastError());
+    PSK_HIP(ctx, hipEventRecord(L.done, ctx->stream));
+    L.bs = true;
+    return PSK_OK;
+}
+
+// after hipEventSynchronize(L.done): the arena block and the packing pass; or, when a bucket overflowed, the radix sort of
+// the partitioned words (they are all there, bucket by bucket) and the ordinary run-length passes
+int bucket_chain_finalize(psk_ctx *ctx, CountLane &L, SampleList &S, uint64_t n_kept, uint64_t nu, bool *fell_back)
+{
+    const BsBufs d = bs_bufs(L, L.dc_slot - 1);
+    L.bs = false;
+    *fell_back = false;
+#ifdef PSK_BS_STAMPS
+    {
+        long long st[7];
+        (void)hipMemcpy(st, d.flag + 2, sizeof(st), hipMemcpyDeviceToHost);
+        fprintf(stderr, "bs_sort bucket 100: prologue %lld  zero %lld  deal-count %lld  scan %lld  deal %lld  sort %lld  runs %lld  (cycles)\n",
+                st[0] - st[6], 0ll, st[1] - st[0], st[2] - st[1], st[3] - st[2], st[4] - st[3], st[5] - st[4]);
+    }
+#endif
+    if (L.pinned_cnt[3]) {
+        if (getenv("PSK_TRACE")) fprintf(stderr, "bucketed sort: a sample takes the fall-back (a bucket or a sub-bin overflowed)\n");
+        *fell_back = true;
+        return PSK_OK;   // the caller runs the radix route on dc_part (bucket_fallback_keys)
+    }
+    if (!nu) return PSK_OK;
+    PSK_TRY(arena_alloc(ctx, nu * 8, (void **)&S.words));
+    PSK_TRY(arena_alloc(ctx, nu * 4, (void **)&S.freqs));
+    const uint32_t *wtmp = L.dc_mtemp.as<uint32_t>(), *ctmp = wtmp + L.n + 8;
+    (void)n_kept;
+    bs_compact_kernel<<<ctx->bs_nb, 256, 0, ctx->stream>>>(wtmp, ctmp, d.base, d.uniq, d.uoff, S.words, S.freqs);
+    PSK_HIP(ctx, hipGetLastError());
+    return PSK_OK;
+}
+
+// the fall-back's input: the n_kept partitioned words of the sample on this set as u64 keys in `keys`
+int bucket_fallback_keys(psk_ctx *ctx, CountLane &L, uint64_t n_kept, uint64_t *keys)
+{
+    if (n_kept) bs_expand_kernel<<<div_up(n_kept, 256), 256, 0, ctx->stream>>>(L.dc_part.as<uint32_t>(), n_kept, keys);
+    PSK_HIP(ctx, hipGetLastError());
+    return PSK_OK;
+}

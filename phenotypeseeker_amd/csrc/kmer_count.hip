@@ -587,6 +587,7 @@ static int chain_compute(psk_ctx *ctx, CountLane &L, int sample_idx, uint64_t cl
     L.exact = n_exact && ctx->slab_lo == 0 && ctx->slab_hi == 0;  // no slab filter: every window yields a word
     L.uniq = nullptr;
     L.dense = false;
+    L.bs = false;
     if (n == 0) {
         if (ctx->dense_mode) {   // an empty sample still owns a (zero) bitmap: the presence build reads every sample's
             SampleList &S = ctx->lists[sample_idx];
@@ -605,6 +606,7 @@ static int chain_compute(psk_ctx *ctx, CountLane &L, int sample_idx, uint64_t cl
     }
     PSK_HIP(ctx, hipStreamWaitEvent(ctx->stream, L.raw_ready, 0));
     if (ctx->dense_mode) return dense_chain_enqueue(ctx, L, sample_idx, clean_len, n);   // 2k <= 26: no sort (dense_count.hip)
+    if (bucket_route_ok(ctx, n)) return bucket_chain_enqueue(ctx, L, sample_idx, clean_len, n);   // k = 14..16, splitters known
     // every sample takes a fresh pre-zeroed counter slot (a 16-byte memset per sample is a 6 us launch)
     if (L.cnt_slot == 0 || L.cnt_slot >= CountLane::CNT_SLOTS) {
         PSK_HIP(ctx, hipMemsetAsync(L.cnt.p, 0, (size_t)CountLane::CNT_SLOTS * 16, ctx->stream));
@@ -638,6 +640,7 @@ static int chain_finalize(psk_ctx *ctx, CountLane &L)
     if (L.sample < 0) return PSK_OK;
     SampleList &S = ctx->lists[L.sample];
     const int sample = L.sample;
+    const uint64_t windows = L.n;
     L.sample = -1;
     uint64_t nu = 0, n_kept = 0;
     if (L.n > 0) {
@@ -658,6 +661,34 @@ static int chain_finalize(psk_ctx *ctx, CountLane &L)
             S.done = true;
             return PSK_OK;
         }
+        if (L.bs) {
+            bool fell_back = false;
+            PSK_TRY(bucket_chain_finalize(ctx, L, S, n_kept, nu, &fell_back));
+            if (!fell_back) {
+                S.n_unique = nu;
+                S.n_total = n_kept;
+                S.done = true;
+                return PSK_OK;
+            }
+            // a bucket outgrew the LDS sort: the partitioned words through the radix sort and the run-length passes, waited for
+            // (rare: a sample unlike the one the splitters were taken from)
+            uint64_t *sorted = nullptr;
+            PSK_TRY(bucket_fallback_keys(ctx, L, n_kept, L.keysA.as<uint64_t>()));
+            PSK_TRY(dev_radix_sort_u64(ctx, L.keysA.as<uint64_t>(), L.keysB.as<uint64_t>(), n_kept, 0, 2 * ctx->k, &sorted, nullptr));
+            uint32_t *d_n = L.cnt.as<uint32_t>() + 4 * (size_t)(CountLane::CNT_SLOTS - 1);
+            const uint32_t nt = (uint32_t)div_up(L.n, RLE_TILE);
+            uint32_t *t_off = L.starts.as<uint32_t>(), *t_next = t_off + nt;
+            if (n_kept) {
+                rle_tile_kernel<<<(uint32_t)div_up(n_kept, RLE_TILE), RLE_THREADS, 0, ctx->stream>>>(sorted, n_kept, nullptr, t_off, t_next);
+                rle_tile_scan_kernel<<<1, 1024, 0, ctx->stream>>>(t_off, t_next, (uint32_t)div_up(n_kept, RLE_TILE), (uint32_t)n_kept, nullptr,
+                                                                 d_n + 1);
+            }
+            PSK_HIP(ctx, hipGetLastError());
+            PSK_HIP(ctx, hipMemcpyAsync(L.pinned_cnt + 1, d_n + 1, 4, hipMemcpyDeviceToHost, ctx->stream));
+            PSK_HIP(ctx, hipStreamSynchronize(ctx->stream));
+            nu = n_kept ? L.pinned_cnt[1] : 0;
+            L.uniq = sorted;
+        }
         PSK_TRY(arena_alloc(ctx, nu * 8, (void **)&S.words));
         PSK_TRY(arena_alloc(ctx, nu * 4, (void **)&S.freqs));
         const uint32_t n_tiles = (uint32_t)div_up(L.n, RLE_TILE);  // the layout of the tile arrays follows L.n
@@ -670,6 +701,7 @@ static int chain_finalize(psk_ctx *ctx, CountLane &L)
     S.n_unique = nu;
     S.n_total = n_kept;
     S.done = true;
+    PSK_TRY(bucket_splitters_from(ctx, S, windows));   // k = 14..16: the later samples of the run take the bucketed sort
     return PSK_OK;
 }
 

@@ -73,6 +73,7 @@ struct CountLane {
     DevBuf dc_part, dc_wgoff, dc_cnt, dc_meta, dc_mtemp;
     uint32_t dc_slot = 0;
     bool dense = false;              // the chain in flight on this set is a dense one
+    bool bs = false;                 // ... a bucketed-sort one (bucket_count.hip; it borrows the dc_* buffers)
 };
 
 struct ScanParams {  // what psk_rescan_timed needs to re-launch the last chi2 scan
@@ -122,6 +123,11 @@ struct psk_ctx {
     // dense list form (see SampleList): on for this run?  first bucket and number of buckets of the slab
     bool dense_mode = false;
     uint32_t dense_b0 = 0, dense_nb = 0;
+    // bucketed sort of k = 14..16 (bucket_count.hip): 2,048 splitters taken from the first list of the run
+    DevBuf bs_spl, bs_ct;             // splitters; bucket of the first word of each of 4,096 cells of the run's word range
+    bool bs_ready = false;
+    uint32_t bs_nb = 0, bs_lo = 0, bs_shift = 0;
+    double bs_keep = 1.0;             // share of a sample's windows the slab keeps (from that list)
 
     // scratch for per-sample counting
     DevBuf raw, keysA, keysB, valsA, valsB, hist, scan_tmp, flags, starts, misc;
@@ -215,3 +221,11 @@ int dense_chain_finalize(psk_ctx *ctx, CountLane &L, uint64_t *n_kept, uint64_t 
 int dense_materialize(psk_ctx *ctx, int first, int n);
 int dense_lookup_counts(psk_ctx *ctx, const SampleList &L, const uint64_t *d_query, uint64_t n, uint32_t *d_out);
 int build_presence_dense(psk_ctx *ctx, uint64_t *n_kmers, int *done);
+
+// ---- bucketed sort for k = 14..16 (bucket_count.hip) ----------------------------------------------------------------
+constexpr uint32_t BS_NB = 2048;           // most buckets of equal count a run uses (splitters = quantiles of one of its lists)
+bool bucket_route_ok(const psk_ctx *ctx, uint64_t n);
+int bucket_splitters_from(psk_ctx *ctx, const SampleList &S, uint64_t windows);
+int bucket_chain_enqueue(psk_ctx *ctx, CountLane &L, int sample_idx, uint64_t clean_len, uint64_t n);
+int bucket_chain_finalize(psk_ctx *ctx, CountLane &L, SampleList &S, uint64_t n_kept, uint64_t nu, bool *fell_back);
+int bucket_fallback_keys(psk_ctx *ctx, CountLane &L, uint64_t n_kept, uint64_t *keys);

@@ -316,14 +316,27 @@ class HostFileTransport:
         self._exchange(b"\0")
 
     def close(self):
-        for seq in (self.seq - 2, self.seq - 1):
-            if seq >= 0:
-                try:
-                    os.unlink(self._name(seq, self.rank))
-                except OSError:
-                    pass
+        """A rank's last files may be removed only when every rank has read them, i.e. has arrived here too: each
+        rank leaves a marker, waits for all of them (or for the directory to be gone: rank 0 cleans up last), and
+        only then removes what it wrote.  (Removing them at once let a fast rank take its last file away from
+        under a slower one, which then sat out the whole timeout.)"""
+        import shutil
         try:
-            os.rmdir(self.dir)
+            with open(os.path.join(self.dir, "done.%d" % self.rank), "w"):
+                pass
+            t0 = time.time()
+            while time.time() - t0 < 120.0:
+                if not os.path.isdir(self.dir) or all(os.path.exists(os.path.join(self.dir, "done.%d" % r)) for r in range(self.world)):
+                    break
+                time.sleep(0.002)
+            for seq in (self.seq - 2, self.seq - 1):
+                if seq >= 0:
+                    try:
+                        os.unlink(self._name(seq, self.rank))
+                    except OSError:
+                        pass
+            if self.rank == 0:
+                shutil.rmtree(self.dir, ignore_errors=True)
         except OSError:
             pass
         self.ctx.close()

@@ -808,6 +808,53 @@ def test_dense_counting_paths_agree_with_the_oracle(ctx, oracle, k, monkeypatch)
     check(batch=True)
 
 
+@pytest.mark.parametrize("k", [14, 15, 16])
+def test_bucketed_sort_route_equals_the_radix_route_and_the_oracle(ctx, oracle, k, monkeypatch, capfd):
+    """k = 14..16 (bucket_count.hip): once a list of the run has given the splitters the later samples are counted by
+    partition + one LDS sort per bucket.  Same lists as the radix route (PSK_NO_BUCKET_SORT) and as the oracle: uniform
+    and AT-rich genomes in one run (the splitters come from the first), a sample with a tandem repeat and a homopolymer
+    (one word 70,000 times), an empty and a tiny one; whole space and under a slab filter; and with a bucket capacity of
+    64 words (PSK_BS_CAP), which sends every later sample through the fall-back."""
+    from phenotypeseeker_amd.synth import GenomeSet
+    rng = np.random.default_rng(k)
+    gs = GenomeSet(3, 220_000, seed=5 + k, gene_len=300)
+    at = GenomeSet(2, 180_000, seed=9 + k, gene_len=300, gc=0.29, contigs=5)
+    unit = bytes(rng.choice(list(b"ACGT"), size=41).tolist())
+    datas = [gs.sample(0)[1], gs.sample(1)[1], at.sample(0)[1], gs.sample(2)[1], at.sample(1)[1],
+             b">tandem\n" + unit * 5000 + b"\n>polyA\n" + b"A" * 70_000 + b"\n" + gs.sample(1)[1], b"", b">short\nACGTACGTACGTACGTACGT\n"]
+    ref = [oracle.count_kmers(d, k) for d in datas]
+    space = 1 << (2 * k)
+
+    def run(lo, hi, batch):
+        ctx.begin(k, len(datas), lo, hi)
+        if batch:
+            nu, nt = ctx.count_kmers_batch(0, datas, 3)
+        else:
+            got = [ctx.count_kmers(i, d) for i, d in enumerate(datas)]
+            nu, nt = [g[0] for g in got], [g[1] for g in got]
+        out = []
+        for i, (w, f, _) in enumerate(ref):
+            sel = (w >= lo) & (w < (hi or space))
+            gw, gf = ctx.get_list(i, nu[i])
+            assert np.array_equal(gw, w[sel]) and np.array_equal(gf, f[sel]), (i, lo, hi, batch)
+            out.append((gw, gf))
+        return out
+
+    monkeypatch.setenv("PSK_TRACE", "1")
+    for lo, hi in ((0, 0), (space // 5, space // 2), (space - space // 3, space)):
+        capfd.readouterr()
+        run(lo, hi, True)
+        # only the sample with 70,000 copies of one word may leave the bucketed route (genomes do not: the splitters fit them)
+        assert capfd.readouterr().err.count("takes the fall-back") <= 1, (lo, hi)
+        run(lo, hi, False)
+    monkeypatch.setenv("PSK_BS_CAP", "64")
+    run(0, 0, True)
+    run(space // 5, space // 2, True)
+    monkeypatch.delenv("PSK_BS_CAP")
+    monkeypatch.setenv("PSK_NO_BUCKET_SORT", "1")
+    run(0, 0, True)
+
+
 def test_dense_counting_under_a_slab_filter(ctx, oracle):
     """The dense form with slab bounds that cut through buckets: the slabs' lists concatenate to the whole list and the
     slabs' matrices to the whole matrix."""
