@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """The workloads whose kernels are profiled for profiles/ (tools/make_profiles.sh runs each under rocprofv3):
-  cfg3slab   one rank's full-size share of config 3: 2,048 x 5 Mbp, k = 16, balanced slab 0 of 8; 10 scans of the
-             6-GB matrix (well beyond the 256-MiB Infinity Cache)
+  cfg3slab   one rank's full-size share of config 3: 2,048 x 5 Mbp, k = 16, balanced slab 0 of 8 (counted by the bucketed
+             sort of bucket_count.hip); 10 scans of the 6-GB matrix (well beyond the 256-MiB Infinity Cache)
   moments    the f64 scans on a device-generated 16 M x 1024 matrix: Welch t, GSC-weighted chi2, weighted Welch t
   fastq      one config-5 sample: 2 M x 150-bp reads, 0.63 GB of FASTQ, framed and counted
   ingest     config 2's ingest alone: 256 x 5 Mbp, k = 13, counted three times + presence build
@@ -47,6 +47,11 @@ if what == "cfg3slab":
         out["notes"] = {"rows": m, "pairs": pairs, "generate_and_count_s": round(t1 - t0, 2), "presence_s": round(t2 - t1, 2),
                         "scan_ms": ms, "matrix_GB": m * 256 / 1e9}
         alg["chi2_scan_kernel"] = m * 256
+        kept = pairs // n                       # words of a sample inside the slab (its unique words: a genome has few repeats)
+        alg["bs_hist_kernel"] = L
+        alg["bs_partition_kernel"] = L + 4 * kept
+        alg["bs_sort_kernel"] = 4 * kept + 8 * kept
+        alg["bs_compact_kernel"] = 8 * kept + 12 * kept
 elif what == "moments":
     M, N = 16_000_000, 1024
     rng = np.random.default_rng(3)
