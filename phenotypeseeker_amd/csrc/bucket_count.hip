@@ -34,7 +34,7 @@ constexpr int BS_SORT_THREADS = PSK_BS_SORT_THREADS;
 #define PSK_BS_CAPMAX 8192
 #endif
 constexpr uint32_t BS_CAP_MAX = PSK_BS_CAPMAX;      // words a bucket may hold for the LDS sort
-constexpr size_t BP_LDS_BYTES = (size_t)(BT_TILE + BS_NB + BS_NB / 2 + BS_NB + 16 + 2056) * 4;   // stage | h | lstart | splitters | scan | cells
+constexpr size_t BP_LDS_BYTES = (size_t)(BT_TILE + BS_NB + BS_NB / 2 + BS_NB + 16 + 2056 + BT_TILE / 2) * 4;   // stage | h | lstart | splitters | scan | cells | buckets of the staged words
 constexpr size_t BSORT_LDS_BYTES = (size_t)(2 * BS_CAP_MAX + 2 * 2048 + 32) * 4;          // words | sorted words | sub-bin starts | fills | scan
 
 // The bucket of a word = the largest b with spl[b] <= w (spl[0] = the first word of the slab).  A binary search over the splitters is eleven
@@ -136,6 +136,7 @@ __global__ __launch_bounds__(BT_THREADS) void bs_partition_kernel(const uint8_t 
     uint32_t *spl = h + BS_NB + BS_NB / 2;
     uint32_t *scan_lds = spl + BS_NB;
     uint16_t *ct = reinterpret_cast<uint16_t *>(scan_lds + 16);
+    uint16_t *stageb = reinterpret_cast<uint16_t *>(scan_lds + 16 + 2056);   // the bucket of every staged word
     for (uint32_t d = threadIdx.x; d < BS_NB; d += BT_THREADS) h[d] = 0;
     load_map(spl, ct, spl_g, ct_g, BT_THREADS);
     __syncthreads();
@@ -180,16 +181,15 @@ __global__ __launch_bounds__(BT_THREADS) void bs_partition_kernel(const uint8_t 
         }
     }
     __syncthreads();
-    // the bucket of a staged word is found again from the splitters when it is spilled (a second table of 16,384
-    // bucket ids would not leave room for the workgroup's other arrays)
 #pragma unroll
     for (int j = 0; j < KW_SEG; j++)
-        if (wv[j] != 0xffffffffu) stage[(uint32_t)lstart[rb[j] >> 16] + (rb[j] & 0xffffu)] = wv[j];
+        if (wv[j] != 0xffffffffu) {
+            const uint32_t at = (uint32_t)lstart[rb[j] >> 16] + (rb[j] & 0xffffu);
+            stage[at] = wv[j];
+            stageb[at] = (uint16_t)(rb[j] >> 16);
+        }
     __syncthreads();
-    for (uint32_t i = threadIdx.x; i < ltot; i += BT_THREADS) {
-        const uint32_t w = stage[i];
-        part[(size_t)(uint32_t)(h[bucket_of(spl, ct, mp, w)] + i)] = w;
-    }
+    for (uint32_t i = threadIdx.x; i < ltot; i += BT_THREADS) part[(size_t)(uint32_t)(h[stageb[i]] + i)] = stage[i];
 }
 
 // One workgroup per bucket: sort, run lengths.  The words of a bucket spread evenly over its narrow range (the buckets
@@ -348,6 +348,7 @@ __global__ __launch_bounds__(1024) void bs_totals_kernel(const uint32_t *__restr
     if (t == 0) { host[0] = ctot; host[1] = utot; host[2] = 0; host[3] = *flag; }
 }
 
+// (one flat pass with a search over the offsets per element was slower: 41 us against 26 for a whole genome)
 __global__ void bs_compact_kernel(const uint32_t *__restrict__ wtmp, const uint32_t *__restrict__ ctmp, const uint32_t *__restrict__ base,
                                   const uint32_t *__restrict__ uniq, const uint32_t *__restrict__ uoff, uint64_t *__restrict__ words,
                                   uint32_t *__restrict__ freqs)
@@ -517,7 +518,7 @@ int bucket_chain_finalize(psk_ctx *ctx, CountLane &L, SampleList &S, uint64_t n_
     PSK_TRY(arena_alloc(ctx, nu * 4, (void **)&S.freqs));
     const uint32_t *wtmp = L.dc_mtemp.as<uint32_t>(), *ctmp = wtmp + L.n + 8;
     (void)n_kept;
-    bs_compact_kernel<<<ctx->bs_nb, 256, 0, ctx->stream>>>(wtmp, ctmp, d.base, d.uniq, d.uoff, S.words, S.freqs);
+    bs_compact_kernel<<<ctx->bs_nb, 512, 0, ctx->stream>>>(wtmp, ctmp, d.base, d.uniq, d.uoff, S.words, S.freqs);
     PSK_HIP(ctx, hipGetLastError());
     return PSK_OK;
 }
