@@ -201,20 +201,19 @@ __global__ __launch_bounds__(BT_THREADS) void bs_partition_kernel(const uint8_t 
 // buckets' key ranges lie back to back).
 constexpr uint32_t BS_BINS = 2048;
 constexpr uint32_t BS_BIN_MAX = 192;
-__global__ __launch_bounds__(BS_SORT_THREADS) void bs_sort_kernel(const uint32_t *__restrict__ part, const uint32_t *__restrict__ cnt,
+__device__ __forceinline__ void bs_sort_bucket(const uint32_t b, const uint32_t *__restrict__ part, const uint32_t *__restrict__ cnt,
                                                                    const uint32_t *__restrict__ base, const uint32_t *__restrict__ spl,
                                                                    uint32_t nb, uint32_t last_word, uint32_t cap, uint32_t *__restrict__ wtmp,
                                                                    uint32_t *__restrict__ ctmp, uint32_t *__restrict__ uniq_out,
-                                                                   uint32_t *__restrict__ flag)
+                                                                   uint32_t *__restrict__ flag, uint32_t *dyn_lds)
 {
     constexpr int BPT = BS_BINS / BS_SORT_THREADS;   // sub-bins per thread
-    extern __shared__ uint32_t dyn_lds[];   // BSORT_LDS_BYTES
     uint32_t *kin = dyn_lds;                // the bucket's words as they come; later the run lengths
     uint32_t *key = kin + BS_CAP_MAX;       // ... dealt into sub-bins, then sorted
     uint32_t *start = key + BS_CAP_MAX;     // sub-bin counts -> starts
     uint32_t *fill = start + BS_BINS;
     uint32_t *scan_lds = fill + BS_BINS;
-    const uint32_t b = blockIdx.x, t = threadIdx.x;
+    const uint32_t t = threadIdx.x;
 #ifdef PSK_BS_STAMPS
     long long *stamps = reinterpret_cast<long long *>(flag + 2);
     if (b == 100 && t == 0) stamps[6] = clock64();
@@ -247,11 +246,10 @@ __global__ __launch_bounds__(BS_SORT_THREADS) void bs_sort_kernel(const uint32_t
         uint32_t c4[BPT], sum = 0, big = 0;
 #pragma unroll
         for (int e = 0; e < BPT; e++) { c4[e] = start[BPT * t + e]; sum += c4[e]; big |= c4[e] > BS_BIN_MAX; }
+        // one scan for both: the sub-bin counts in the low bits, "a sub-bin of mine is too full" in bit 24 and up
         uint32_t tot;
-        uint32_t ex = psk_block_excl_scan_u32<BS_SORT_THREADS>(sum, &tot, scan_lds);
-        const uint32_t any_big = psk_block_excl_scan_u32<BS_SORT_THREADS>(big, &tot, scan_lds) + big;   // tot = number of threads with one
-        (void)any_big;
-        if (tot) {   // uniform: every thread has the same total
+        uint32_t ex = psk_block_excl_scan_u32<BS_SORT_THREADS>(sum | (big << 24), &tot, scan_lds) & 0xffffffu;
+        if (tot >> 24) {   // uniform: every thread has the same total
             if (t == 0) { uniq_out[b] = 0; atomicOr(flag, 1u); }
             return;
         }
@@ -330,6 +328,21 @@ __global__ __launch_bounds__(BS_SORT_THREADS) void bs_sort_kernel(const uint32_t
     if (b == 100 && t == 0) stamps[5] = clock64();
 #endif
     if (t == 0) uniq_out[b] = nu;
+}
+
+// a workgroup takes buckets blockIdx.x, blockIdx.x + gridDim.x, ...: one resident set of workgroups for the whole sample (two
+// per CU by LDS) instead of four launch rounds of them
+__global__ __launch_bounds__(BS_SORT_THREADS) void bs_sort_kernel(const uint32_t *__restrict__ part, const uint32_t *__restrict__ cnt,
+                                                                   const uint32_t *__restrict__ base, const uint32_t *__restrict__ spl,
+                                                                   uint32_t nb, uint32_t last_word, uint32_t cap, uint32_t *__restrict__ wtmp,
+                                                                   uint32_t *__restrict__ ctmp, uint32_t *__restrict__ uniq_out,
+                                                                   uint32_t *__restrict__ flag)
+{
+    extern __shared__ uint32_t dyn_lds[];   // BSORT_LDS_BYTES
+    for (uint32_t b = blockIdx.x; b < nb; b += gridDim.x) {
+        bs_sort_bucket(b, part, cnt, base, spl, nb, last_word, cap, wtmp, ctmp, uniq_out, flag, dyn_lds);
+        __syncthreads();   // the next bucket reuses the arrays
+    }
 }
 
 // uniq -> offsets of the buckets in the list; totals: host[0] = words kept, [1] = unique words, [3] = a bucket overflowed
@@ -483,7 +496,8 @@ int bucket_chain_enqueue(psk_ctx *ctx, CountLane &L, int sample_idx, uint64_t cl
         attr_set = true;
     }
     uint32_t *wtmp = L.dc_mtemp.as<uint32_t>(), *ctmp = wtmp + n + 8;
-    bs_sort_kernel<<<ctx->bs_nb, BS_SORT_THREADS, BSORT_LDS_BYTES, ctx->stream>>>(L.dc_part.as<uint32_t>(), d.cnt, d.base, ctx->bs_spl.as<uint32_t>(),
+    const uint32_t sort_wgs = ctx->bs_nb < 2u * (uint32_t)(ctx->n_cu > 0 ? ctx->n_cu : 256) ? ctx->bs_nb : 2u * (uint32_t)(ctx->n_cu > 0 ? ctx->n_cu : 256);
+    bs_sort_kernel<<<sort_wgs, BS_SORT_THREADS, BSORT_LDS_BYTES, ctx->stream>>>(L.dc_part.as<uint32_t>(), d.cnt, d.base, ctx->bs_spl.as<uint32_t>(),
                                                                                   ctx->bs_nb, hi - 1u, bs_cap(), wtmp, ctmp, d.uniq, d.flag);
     PSK_HIP(ctx, hipGetLastError());
     bs_totals_kernel<<<1, 1024, 0, ctx->stream>>>(d.cnt, d.uniq, d.uoff, d.flag, ctx->bs_nb, L.pinned_cnt);
