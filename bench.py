@@ -138,41 +138,55 @@ def e2e_modeling_sharded(grp, gs, n, k, args):
     import subprocess
     import tempfile
     rank = grp.rank
-    tmp, t_write = "", 0.0
+    tmp, tmp_made, t_write = "", "", 0.0
     try:
+        made_dir, write_err = "", ""
         if rank == 0:
-            tmp = tempfile.mkdtemp(prefix="psk_bench_e2e_")
-            rows = ["ID\tAddresses\tPheno"]
-            t0 = time.time()
-            for i in range(n):
-                name, fa = gs.sample(i)
-                with open(os.path.join(tmp, name + ".fasta"), "wb") as f:
-                    f.write(fa)
-                rows.append("%s\t%s.fasta\t%d" % (name, name, gs.phenotype(i)))
-            with open(os.path.join(tmp, "data.pheno"), "w") as f:
-                f.write("\n".join(rows) + "\n")
-            t_write = time.time() - t0
-        tmp = grp.allgather_bytes(tmp.encode())[0].decode()
+            try:
+                made_dir = tempfile.mkdtemp(prefix="psk_bench_e2e_")
+                rows = ["ID\tAddresses\tPheno"]
+                t0 = time.time()
+                for i in range(n):
+                    name, fa = gs.sample(i)
+                    with open(os.path.join(made_dir, name + ".fasta"), "wb") as f:
+                        f.write(fa)
+                    rows.append("%s\t%s.fasta\t%d" % (name, name, gs.phenotype(i)))
+                with open(os.path.join(made_dir, "data.pheno"), "w") as f:
+                    f.write("\n".join(rows) + "\n")
+                t_write = time.time() - t0
+            except Exception as e:   # noqa: BLE001 -- every rank learns it through the all-gather below
+                write_err = "%s: %s" % (type(e).__name__, e)
+        tmp = grp.allgather_bytes(("" if write_err else made_dir).encode())[0].decode()
+        if rank == 0:
+            tmp_made = made_dir
+        if not tmp:
+            return {"error": "the dataset could not be written" + (": " + write_err if write_err else "")}
         env = dict(os.environ, PSK_RDZV_FILE=os.path.join(tmp, ".rendezvous"),
                    PSK_REDUNDANT_INGEST="1" if args.ingest == "filter" else "0")
         here = os.path.dirname(os.path.abspath(__file__))
         env["PYTHONPATH"] = here + os.pathsep + env.get("PYTHONPATH", "")
         cmd = [sys.executable, os.path.join(here, "scripts", "phenotypeseeker"), "modeling", "data.pheno", "-l", str(k)]
+        # whatever happens to this rank's child, every rank makes the same two collectives below
         t0 = time.time()
-        r = subprocess.run(cmd, cwd=tmp, env=env, stdout=subprocess.DEVNULL, stderr=None if os.environ.get("PSK_TRACE") else subprocess.PIPE,
-                           timeout=1800)
+        rc, err_tail = 0, ""
+        try:
+            r = subprocess.run(cmd, cwd=tmp, env=env, stdout=subprocess.DEVNULL, stderr=None if os.environ.get("PSK_TRACE") else subprocess.PIPE,
+                               timeout=900)
+            rc, err_tail = r.returncode, (r.stderr or b"").decode(errors="replace")[-600:]
+        except Exception as e:   # noqa: BLE001 -- a child that hangs is killed by the timeout
+            rc, err_tail = -1, "%s: %s" % (type(e).__name__, e)
         wall = time.time() - t0
         worst = grp.allreduce_max(wall)
-        failed = grp.allreduce_sum(1 if r.returncode != 0 else 0)
+        failed = grp.allreduce_sum(1 if rc != 0 else 0)
         made = sorted(f for f in os.listdir(tmp) if f.endswith(".pkl")) if rank == 0 else []
         res = {"modeling_wall_s": round(worst, 3), "ranks": grp.world, "ingest": args.ingest,
                "what": "phenotypeseeker modeling data.pheno as %d child processes (one per rank, started after the files were "
                        "written): %d FASTA files on disk -> %s" % (grp.world, n, ", ".join(made) or "no model"),
                "write_dataset_s": round(t_write, 2)}
         if rank == 0 and not made and not failed:
-            res["error"] = "no .pkl written; rank 0: %s" % (r.stderr or b"").decode(errors="replace")[-600:]
+            res["error"] = "no .pkl written; rank 0: %s" % err_tail
         if failed:
-            res["error"] = "%d rank(s) failed; rank %d: %s" % (failed, rank, (r.stderr or b"").decode(errors="replace")[-400:])
+            res["error"] = "%d rank(s) failed; rank %d: %s" % (failed, rank, err_tail[-400:])
         return res
     except Exception as e:   # noqa: BLE001 -- reported in the line
         return {"error": "%s: %s" % (type(e).__name__, e)}
@@ -181,8 +195,8 @@ def e2e_modeling_sharded(grp, gs, n, k, args):
             grp.barrier()
         except Exception:   # noqa: BLE001
             pass
-        if rank == 0 and tmp:
-            shutil.rmtree(tmp, ignore_errors=True)
+        if rank == 0 and tmp_made:
+            shutil.rmtree(tmp_made, ignore_errors=True)
 
 
 def main():
