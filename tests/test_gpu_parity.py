@@ -494,7 +494,7 @@ def test_l1_logreg_mid_size_objectives_match_liblinear(ctx):
             assert float(z["obj_" + tag][j]) * (1 - 1e-9) <= obj <= float(z["obj_" + tag][j]) * 1.01, (tag, C)
 
 
-@pytest.mark.parametrize("n", [700, 2048, 3000, 4096])
+@pytest.mark.parametrize("n", [40, 130, 700, 2048, 3000, 4096])
 def test_l1_logreg_register_form_equals_lds_form(ctx, n, monkeypatch):
     """More distinct columns than the Gram block holds (250 > 192): the descent runs on four waves per
     fit, each with a quarter of the samples in registers (cd_coop).  The same algorithm as the one-wave LDS form
@@ -515,7 +515,7 @@ def test_l1_logreg_register_form_equals_lds_form(ctx, n, monkeypatch):
     b = ctx.logreg_l1_fit(X, y, fold, fp, ff, tol=1e-4, max_iter=1000)
     monkeypatch.delenv("PSK_NO_CD_REGS")
     assert a[2].max() < 200 and b[2].max() < 200, (a[2], b[2])
-    assert all((c != 0).sum() > 0 for c in a[0][2:])
+    assert n < 700 or all((c != 0).sum() > 0 for c in a[0][2:])   # (a few dozen samples may leave the weak fits at zero)
     ypm = 2.0 * y - 1.0
     for j in range(len(fp)):
         tr = fold != ff[j]
