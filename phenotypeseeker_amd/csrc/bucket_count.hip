@@ -9,8 +9,8 @@
 //                        (tile, bucket) reserves the tile's range in the bucket
 //   bs_partition_kernel  the same tile again: rank inside (tile, bucket) from a returning LDS atomic, the tile's words
 //                        bucketed in LDS and spilled in bucket runs
-//   bs_sort_kernel       one workgroup per bucket: its ~2,400 words dealt into 2,048 sub-bins of its range in LDS and
-//                        straightened by insertion, run lengths from a scan of the run heads, unique words + counts
+//   bs_sort_kernel       a bucket at a time per workgroup: its ~2,400 words dealt into 2,048 sub-bins of its range in LDS,
+//                        stretches of <= 16 words sorted in registers, run lengths from a scan of the run heads, unique words + counts
 //                        written over the bucket's own key range
 //   bs_totals_kernel     unique counts -> offsets, totals to the host
 //   bs_compact_kernel    (one sample later, once the host has sized the arena block) packs words (u64) + counts
@@ -194,8 +194,8 @@ __global__ __launch_bounds__(BT_THREADS) void bs_partition_kernel(const uint8_t 
 
 // One workgroup per bucket: sort, run lengths.  The words of a bucket spread evenly over its narrow range (the buckets
 // have equal counts), so they are dealt into 2,048 sub-bins by the top bits of (word - first word of the bucket) -- one
-// or two words per sub-bin -- and a thread straightens its four sub-bins by insertion: four barriers instead of the 78
-// of a bitonic network over 4,096 keys (33 us per bucket against 5).  A sub-bin with more than BS_BIN_MAX words (the
+// or two words per sub-bin -- and a thread straightens the stretch of its consecutive sub-bins in registers: a handful
+// of barriers instead of the 78 of a bitonic network over 4,096 keys (33 us per bucket against 15).  A sub-bin with more than BS_BIN_MAX words (the
 // sample is unlike the one the splitters came from) sends the sample to the fall-back, like a bucket beyond `cap`.
 // wtmp / ctmp: unique words and their counts, written from base[b] on (a bucket has at most cnt[b] of them and the
 // buckets' key ranges lie back to back).
