@@ -39,7 +39,7 @@ constexpr int SC_THREADS = 256;
 #define PSK_LUT_THREADS 1024
 #endif
 constexpr int SC_LUT_THREADS = PSK_LUT_THREADS;   // workgroup of the moment scans that keep their nibble tables in LDS (one per CU)
-constexpr size_t SC_LUT_MAX_BYTES = 100 * 1024;
+constexpr size_t SC_LUT_MAX_BYTES = 132 * 1024;
 constexpr int SC_UNROLL = PSK_SC_UNROLL;
 // Survivors are appended to SC_NSEG independent segments (segment = blockIdx % SC_NSEG), each with its
 // own counter on its own 128-byte line: one shared counter serialises at ~11 ns per append (r01: a
