@@ -1178,6 +1178,146 @@ __global__ __launch_bounds__(SV_THREADS) void lasso_kernel(const float *__restri
     if (lane == 0) { icpt[fit] = ym - acc; iters[fit] = sweep; }
 }
 
+// Lasso on a 0/1 design (presence / absence: the default), four waves per fit, the samples in registers -- the layout and
+// the EXEC-masked sums of cd_coop.  With x in {0, 1} the coordinate step of the kernel above needs no pass over all the
+// samples: the residual is kept as r_i = r'_i + c (c: one scalar for the -dd * mean terms every training sample gets), so
+//   sum (x - m) r  =  (S1 + c cnt) - m (R + c n),   S1 = sum of r' over the samples that have the k-mer (a masked sum),
+//   R = sum of r' over the training samples (kept up to date),  cnt = their number with the k-mer,
+// and the update is r' -= dd on those samples (a masked add), c += dd m, R -= dd cnt.  Same cyclic order, same soft
+// threshold, same stop as lasso_kernel; column means and norms from the counts (x^2 = x).  The float kernel read a
+// column of n floats from L2 per coordinate (~2.6 us at 1,024 samples); here it is one transposed word per lane, asked
+// for a step ahead.  LDS: w | mean | norm | count, p doubles each.
+template <int WM>
+__global__ __launch_bounds__(SV_COOP_THREADS) void lasso_bits_kernel(const uint64_t *__restrict__ colT, const double *__restrict__ y,
+                                                                      const int32_t *__restrict__ fold, int n, int p, int W,
+                                                                      const double *__restrict__ fit_param,
+                                                                      const int32_t *__restrict__ fit_fold, double tol, int max_iter,
+                                                                      double *__restrict__ coef, double *__restrict__ icpt,
+                                                                      int32_t *__restrict__ iters)
+{
+    constexpr int WQ = WM / SV_COOP_WAVES;
+    extern __shared__ double sm[];
+    __shared__ double s_part[2][SV_COOP_WAVES];
+    __shared__ double s_tot[2][SV_COOP_WAVES];
+    double *w = sm, *mean = sm + p, *nrm = sm + 2 * (size_t)p, *cntd = sm + 3 * (size_t)p;
+    uint32_t *cpart = reinterpret_cast<uint32_t *>(sm + 4 * (size_t)p);   // [wave][p] counts of this wave's samples
+    const int fit = blockIdx.x, lane = threadIdx.x & 63, wave = threadIdx.x >> 6, t0 = wave * WQ;
+    const double alpha = fit_param[fit];
+    const int tf = fit_fold[fit];
+    // this wave's training samples and their y
+    double R[WQ];
+    uint64_t tmask = 0;
+    double sy = 0.0, cn = 0.0;
+#pragma unroll
+    for (int q = 0; q < WQ; q++) {
+        const int t = t0 + q, i = t * 64 + lane;
+        const bool tr = t < W && i < n && fold[i] != tf;
+        R[q] = tr ? y[i] : 0.0;
+        if (tr) { tmask |= 1ull << t; sy += R[q]; cn += 1.0; }
+    }
+    sy = psk_wave_sum_f64_dpp(sy);
+    cn = psk_wave_sum_f64_dpp(cn);
+    if (lane == 0) { s_part[0][wave] = sy; s_tot[0][wave] = cn; }
+    // this wave's share of every column's count
+    for (int j = 0; j < p; j++) {
+        const uint64_t x = colT[(size_t)j * 64 + lane] & tmask;
+        uint32_t c = (uint32_t)__popcll(x);
+#pragma unroll
+        for (int d = 32; d > 0; d >>= 1) c += __shfl_xor(c, d, 64);
+        if (lane == 0) cpart[(size_t)wave * p + j] = c;
+    }
+    __syncthreads();
+    double ysum = s_part[0][0], ntrain = s_tot[0][0];
+#pragma unroll
+    for (int v = 1; v < SV_COOP_WAVES; v++) { ysum += s_part[0][v]; ntrain += s_tot[0][v]; }
+    const double ym = ysum / ntrain;
+#pragma unroll
+    for (int q = 0; q < WQ; q++)
+        if ((tmask >> (t0 + q)) & 1) R[q] -= ym;
+    for (int j = threadIdx.x; j < p; j += SV_COOP_THREADS) {
+        uint32_t c = 0;
+#pragma unroll
+        for (int v = 0; v < SV_COOP_WAVES; v++) c += cpart[(size_t)v * p + j];
+        const double s1 = (double)c, m = s1 / ntrain;
+        cntd[j] = s1;
+        mean[j] = m;
+        nrm[j] = s1 - ntrain * m * m;   // sum (x - m)^2 with x^2 = x
+        w[j] = 0.0;
+    }
+    // R' = sum of r' over the training samples: every wave sums its own, all of them add the four parts
+    double Rw = 0.0;
+#pragma unroll
+    for (int q = 0; q < WQ; q++) Rw += R[q];
+    Rw = psk_wave_sum_f64_dpp(Rw);
+    if (lane == 0) s_part[1][wave] = Rw;
+    __syncthreads();
+    double Rp = s_part[1][0];
+#pragma unroll
+    for (int v = 1; v < SV_COOP_WAVES; v++) Rp += s_part[1][v];
+    __syncthreads();
+    double c = 0.0;
+    int sweep = 0, visit = 0;
+    auto col_t = [&](int j) { return (colT[(size_t)j * 64 + lane] & tmask) >> t0; };
+    for (sweep = 0; sweep < max_iter; sweep++) {
+        double dmax = 0.0, wmax = 0.0;
+        uint64_t m_next = p > 0 ? col_t(0) : 0ull;
+        for (int j = 0; j < p; j++) {
+            const uint64_t x = m_next;
+            if (j + 1 < p) m_next = col_t(j + 1);
+            const double nj = nrm[j];
+            if (!(nj > 1e-12)) continue;
+            const double mj = mean[j], wj = w[j], cj = cntd[j];
+            uint64_t M[WQ];
+#pragma unroll
+            for (int q = 0; q < WQ; q++) M[q] = __ballot((x >> q) & 1ull);
+            double S = 0.0;
+            if (WQ == 16) { masked_sum8(S, M, R); masked_sum8(S, M + (WQ == 16 ? 8 : 0), R + (WQ == 16 ? 8 : 0)); }
+            else if (WQ == 8) masked_sum8(S, M, R);
+            else masked_sum4(S, M, R);
+            S = psk_wave_sum_f64_dpp(S);
+            const int slot = visit & 1;
+            visit++;
+            if (lane == 0) s_part[slot][wave] = S;
+            __syncthreads();
+            double S1 = s_part[slot][0];
+#pragma unroll
+            for (int v = 1; v < SV_COOP_WAVES; v++) S1 += s_part[slot][v];
+            const double rho = ((S1 + c * cj) - mj * (Rp + c * ntrain)) + nj * wj;
+            const double mag = fabs(rho) - alpha * ntrain;
+            const double nw = (mag > 0.0) ? ((rho > 0 ? mag : -mag) / nj) : 0.0;
+            const double dd = nw - wj;
+            if (dd != 0.0) {
+                const double nd = -dd;
+                if (WQ == 16) { masked_add8(R, M, nd); masked_add8(R + (WQ == 16 ? 8 : 0), M + (WQ == 16 ? 8 : 0), nd); }
+                else if (WQ == 8) masked_add8(R, M, nd);
+                else masked_add4(R, M, nd);
+                c += dd * mj;
+                Rp -= dd * cj;
+                if (threadIdx.x == 0) w[j] = nw;   // read again a sweep later, many barriers from here
+            }
+            if (fabs(dd) > dmax) dmax = fabs(dd);
+            if (fabs(nw) > wmax) wmax = fabs(nw);
+        }
+        __syncthreads();   // w of this sweep is in place for the next one (and for the end)
+        if (dmax == 0.0 || dmax <= tol * (wmax > 1e-300 ? wmax : 1e-300)) { sweep++; break; }
+    }
+    double acc = 0.0;
+    for (int j = threadIdx.x; j < p; j += SV_COOP_THREADS) {
+        coef[(size_t)fit * p + j] = w[j];
+        acc += mean[j] * w[j];
+    }
+    acc = psk_wave_sum_f64_dpp(acc);
+    if (lane == 0) s_tot[1][wave] = acc;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        double a = s_tot[1][0];
+#pragma unroll
+        for (int v = 1; v < SV_COOP_WAVES; v++) a += s_tot[1][v];
+        icpt[fit] = ym - a;
+        iters[fit] = sweep;
+    }
+}
+
 // host: transpose X[n][p] -> XT[p+1][n]
 void transpose_f32(const float *X, int n, int p, std::vector<float> &XT)
 {
@@ -1374,6 +1514,37 @@ extern "C" int psk_lasso_fit(psk_ctx *ctx, const float *X, const double *y, int 
     SV_ALLOC(b.coef, (size_t)n_fits * p * 8);
     SV_ALLOC(b.icpt, (size_t)n_fits * 8);
     SV_ALLOC(b.iters, (size_t)n_fits * 4);
+    // presence/absence design (every entry 0 or 1), its per-column state in LDS -> the bit-packed four-wave kernel
+    bool binary = n <= 4096 && !getenv("PSK_NO_LASSO_BITS");
+    for (size_t q = 0; binary && q < (size_t)n * p; q++) binary = (X[q] == 0.0f || X[q] == 1.0f);
+    const size_t lds_bits = (size_t)p * (4 * 8 + SV_COOP_WAVES * 4);
+    if (binary && lds_bits <= 150 * 1024) {
+        const int W = (n + 63) / 64;
+        std::vector<uint64_t> bitsT((size_t)p * 64, 0);   // word l of column j: bit t = sample 64 t + l
+        for (int i = 0; i < n; i++)
+            for (int j = 0; j < p; j++)
+                if (X[(size_t)i * p + j] != 0.0f) bitsT[(size_t)j * 64 + (i & 63)] |= 1ull << (i >> 6);
+        SV_ALLOC(b.bitsT, bitsT.size() * 8);
+        PSK_HIP(ctx, hipMemcpyAsync(b.bitsT, bitsT.data(), bitsT.size() * 8, hipMemcpyHostToDevice, ctx->stream));
+        PSK_HIP(ctx, hipMemcpyAsync(b.y, y, (size_t)n * 8, hipMemcpyHostToDevice, ctx->stream));
+        PSK_HIP(ctx, hipMemcpyAsync(b.fold, fold, (size_t)n * 4, hipMemcpyHostToDevice, ctx->stream));
+        PSK_HIP(ctx, hipMemcpyAsync(b.param, fit_param, (size_t)n_fits * 8, hipMemcpyHostToDevice, ctx->stream));
+        PSK_HIP(ctx, hipMemcpyAsync(b.ffold, fit_fold, (size_t)n_fits * 4, hipMemcpyHostToDevice, ctx->stream));
+        auto kern = W <= 16 ? lasso_bits_kernel<16> : W <= 32 ? lasso_bits_kernel<32> : lasso_bits_kernel<64>;
+        if (lds_bits > 64 * 1024)
+            PSK_HIP(ctx, hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bits));
+        kern<<<n_fits, SV_COOP_THREADS, lds_bits, ctx->stream>>>((const uint64_t *)b.bitsT, (const double *)b.y, (const int32_t *)b.fold, n, p, W,
+                                                                 (const double *)b.param, (const int32_t *)b.ffold, tol, max_iter,
+                                                                 (double *)b.coef, (double *)b.icpt, (int32_t *)b.iters);
+        PSK_HIP(ctx, hipGetLastError());
+        PSK_HIP(ctx, hipMemcpyAsync(coef_out, b.coef, (size_t)n_fits * p * 8, hipMemcpyDeviceToHost, ctx->stream));
+        PSK_HIP(ctx, hipMemcpyAsync(icpt_out, b.icpt, (size_t)n_fits * 8, hipMemcpyDeviceToHost, ctx->stream));
+        std::vector<int32_t> itb(n_fits);
+        PSK_HIP(ctx, hipMemcpyAsync(itb.data(), b.iters, (size_t)n_fits * 4, hipMemcpyDeviceToHost, ctx->stream));
+        PSK_HIP(ctx, hipStreamSynchronize(ctx->stream));   // bitsT (host) must outlive its copy
+        if (iters_out) memcpy(iters_out, itb.data(), (size_t)n_fits * 4);
+        return PSK_OK;
+    }
     const int use_lds = n <= 2 * SV_LDS_N ? 1 : 0;   // one residual array: 8 KiB samples fit
     const size_t lds = use_lds ? (size_t)n * sizeof(double) : 0;
     SV_ALLOC(b.work, (size_t)n_fits * (2 * (size_t)p + n) * 8);

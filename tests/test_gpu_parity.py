@@ -546,6 +546,28 @@ def test_lasso_solver_matches_sklearn(ctx):
     assert np.allclose(icpt, z["lasso_icpt2"], rtol=1e-8)
 
 
+@pytest.mark.parametrize("n", [90, 1000, 2500])
+def test_lasso_bit_packed_kernel_equals_the_float_kernel(ctx, n, monkeypatch):
+    """0/1 designs take the four-wave bit-packed Lasso (masked sums over the samples that have the k-mer, the residual
+    as r' + c); the float kernel (PSK_NO_LASSO_BITS, also what --real_counts uses) is the same cyclic descent: run to
+    convergence the two agree on every fit of a (value, fold) grid, folds and NA-free rows included."""
+    rng = np.random.default_rng(n)
+    p = 120
+    base = rng.random((n, 10)) < 0.4
+    X = (base[:, rng.integers(0, 10, p)] ^ (rng.random((n, p)) < 0.1)).astype(np.float32)
+    X[:, 7] = 1.0                      # a constant column: zero norm, skipped
+    X[:, 8] = X[:, 9]                  # a duplicated one
+    y = X[:, :6].astype(np.float64) @ rng.normal(0, 1, 6) + rng.normal(0, 0.3, n)
+    fold = (np.arange(n) % 4).astype(np.int32)
+    fp = np.array([0.3, 0.03, 0.03, 0.003, 0.003], np.float64)
+    ff = np.array([-1, 0, 3, 1, -1], np.int32)
+    a = ctx.lasso_fit(X, y, fold, fp, ff, tol=1e-12, max_iter=100000)
+    monkeypatch.setenv("PSK_NO_LASSO_BITS", "1")
+    b = ctx.lasso_fit(X, y, fold, fp, ff, tol=1e-12, max_iter=100000)
+    assert np.allclose(a[0], b[0], rtol=1e-7, atol=1e-9) and np.allclose(a[1], b[1], rtol=1e-9, atol=1e-10)
+    assert (a[0][1:] != 0).any(axis=1).all() and np.all(a[0][:, 7] == 0)
+
+
 def test_grid_search_matches_sklearn_cv(ctx):
     from phenotypeseeker_amd.model import GridSearch, L1LogisticRegression, LassoRegression
     z = np.load(os.path.join(GOLDEN, "model_kat.npz"))
