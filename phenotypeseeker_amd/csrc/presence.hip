@@ -28,14 +28,25 @@ struct PhaseTimer {
     }
 };
 
-// vals == nullptr: pair = word << sbits | sample in one u64; else key = word, payload = sample
-__global__ void pack_pairs_kernel(const uint64_t *__restrict__ words, uint64_t n, int sbits, uint64_t sample,
-                                  uint64_t *__restrict__ out, uint32_t *__restrict__ vals)
+// vals == nullptr: pair = word << sbits | sample in one u64; else key = word, payload = sample;
+// every sample of a chunk in ONE launch (a launch per sample and chunk: 12,288 of them for config 3's 2,048
+// samples, a quarter of the build's GPU time and as much again in launch overhead): block (s, b) packs slice b of sample s
+struct PackRef {
+    const uint64_t *words;   // first word of the sample's range in this chunk
+    uint64_t count, offset;  // its length and where its pairs go
+};
+constexpr int PACK_SLICES = 8;
+__global__ __launch_bounds__(256) void pack_pairs_batch_kernel(const PackRef *__restrict__ refs, int sbits, uint64_t *__restrict__ out,
+                                                               uint32_t *__restrict__ vals)
 {
-    const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= n) return;
-    if (vals) { out[i] = words[i]; vals[i] = (uint32_t)sample; }
-    else out[i] = (words[i] << sbits) | sample;
+    const int s = blockIdx.x / PACK_SLICES, b = blockIdx.x % PACK_SLICES;
+    const PackRef r = refs[s];
+    const uint64_t per = (r.count + PACK_SLICES - 1) / PACK_SLICES, i0 = (uint64_t)b * per;
+    const uint64_t i1 = i0 + per < r.count ? i0 + per : r.count;
+    for (uint64_t i = i0 + threadIdx.x; i < i1; i += 256) {
+        if (vals) { out[r.offset + i] = r.words[i]; vals[r.offset + i] = (uint32_t)s; }
+        else out[r.offset + i] = (r.words[i] << sbits) | (uint64_t)s;
+    }
 }
 
 __global__ void pair_head_flags_kernel(const uint64_t *__restrict__ pairs, uint64_t n, int sbits,
@@ -310,16 +321,19 @@ extern "C" int psk_build_presence(psk_ctx *ctx, uint64_t *n_kmers)
     uint32_t *sorted_vals = nullptr, *flags = nullptr;
     auto sort_chunk = [&](int c, uint64_t *rows_out) -> int {
         uint64_t off = 0;
+        std::vector<PackRef> refs(ns);
         for (int i = 0; i < ns; i++) {
             const SampleList &L = ctx->lists[i];
             const uint64_t lo = cut[(size_t)c * ns + i], cnt = cut[(size_t)(c + 1) * ns + i] - lo;
-            if (!cnt) continue;
-            pack_pairs_kernel<<<div_up(cnt, 256), 256, 0, ctx->stream>>>(L.words + lo, cnt, sbits, (uint64_t)i,
-                                                                        ctx->keysA.as<uint64_t>() + off,
-                                                                        kv ? ctx->valsA.as<uint32_t>() + off : nullptr);
-            PSK_HIP(ctx, hipGetLastError());
+            refs[i] = PackRef{cnt ? L.words + lo : nullptr, cnt, off};
             off += cnt;
         }
+        PSK_TRY(dev_reserve(ctx, ctx->starts, (size_t)ns * sizeof(PackRef)));
+        PSK_HIP(ctx, hipMemcpyAsync(ctx->starts.p, refs.data(), (size_t)ns * sizeof(PackRef), hipMemcpyHostToDevice, ctx->stream));
+        PSK_HIP(ctx, hipStreamSynchronize(ctx->stream));   // `refs` is pageable host memory
+        pack_pairs_batch_kernel<<<ns * PACK_SLICES, 256, 0, ctx->stream>>>(ctx->starts.as<PackRef>(), sbits, ctx->keysA.as<uint64_t>(),
+                                                                         kv ? ctx->valsA.as<uint32_t>() : nullptr);
+        PSK_HIP(ctx, hipGetLastError());
         const uint64_t tc = chunk_total[c];
         PSK_TRY(dev_radix_sort_kv(ctx, ctx->keysA.as<uint64_t>(), ctx->keysB.as<uint64_t>(),
                                   kv ? ctx->valsA.as<uint32_t>() : nullptr, kv ? ctx->valsB.as<uint32_t>() : nullptr, tc, sbits,
