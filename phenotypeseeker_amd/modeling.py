@@ -566,9 +566,10 @@ class phenotypes:
         ml = self.ML
         with open(self.name + "_MLdf.csv", "w") as f:
             f.write(",".join([""] + ml["kmers"] + ["weights", "phenotype"]) + "\n")
+            X = np.asarray(ml["X"]).astype(np.int64, copy=False).tolist()   # python ints: str() of numpy scalars is 5x slower
             for i, name in enumerate(ml["index"]):
                 w, p = ml["weights"][i], ml["phenotype"][i]
-                f.write(",".join([name] + [str(int(v)) for v in ml["X"][i]] +
+                f.write(",".join([name] + list(map(str, X[i])) +
                                  [repr(w) if isinstance(w, float) else str(w),
                                   repr(p) if isinstance(p, float) else str(p)]) + "\n")
 
