@@ -112,3 +112,55 @@ def test_two_rank_gloo_run_equals_single_rank(tmp_path, oracle):
     assert np.array_equal(z["word"], uw[keep])
     assert np.array_equal(z["stat"], ref["stat"][keep]) and np.array_equal(z["p"], ref["p"][keep])
     assert np.array_equal(z["n_with"], ref["n_with"][keep]) and np.array_equal(z["bits"], bits[keep])
+
+
+def test_host_file_transport_collectives_and_close(tmp_path):
+    """The transport the ranks fall back to when RCCL cannot form the communicator: all-reduce, all-gather and the
+    closing handshake with four threads as ranks of unequal speed (the context that stages device buffers is stubbed:
+    no GPU here).  A rank used to remove its last file at close() before a slower rank had read it -- the slower one
+    then sat out the whole timeout."""
+    import threading
+    import time
+    from phenotypeseeker_amd import dist
+
+    class NoCtx:
+        def __init__(self, device):
+            pass
+
+        def close(self):
+            pass
+
+    real = dist.PskContext
+    dist.PskContext = NoCtx
+    try:
+        world, out, errs = 4, {}, []
+
+        def rank_main(r):
+            try:
+                t = dist.HostFileTransport(r, world, 0, path=str(tmp_path / "rdzv"), timeout=30.0)
+                for it in range(6):
+                    s = t.allreduce(np.array([r + it], dtype=np.uint64), "sum")
+                    m = t.allreduce(np.array([float(r * it)]), "max")
+                    g = t.allgather_host(np.full(5 + it, r, dtype=np.uint8))
+                    assert int(s[0]) == sum(range(world)) + world * it and float(m[0]) == float((world - 1) * it)
+                    assert g.shape == (world, 5 + it) and all((g[q] == q).all() for q in range(world))
+                    if r == it % world:
+                        time.sleep(0.05)          # a straggler, a different one every round
+                if r != 0:
+                    time.sleep(0.2 * r)           # the others reach close() long after rank 0's last collective
+                t0 = time.time()
+                t.close()
+                out[r] = time.time() - t0
+            except Exception as e:  # noqa: BLE001
+                errs.append((r, repr(e)))
+
+        th = [threading.Thread(target=rank_main, args=(r,)) for r in range(world)]
+        for x in th:
+            x.start()
+        for x in th:
+            x.join(60)
+        assert not errs, errs
+        assert sorted(out) == list(range(world)) and max(out.values()) < 5.0
+        assert not os.path.exists(str(tmp_path / "rdzv") + ".d")      # rank 0 removed the directory last
+    finally:
+        dist.PskContext = real
