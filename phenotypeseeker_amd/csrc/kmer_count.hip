@@ -828,8 +828,7 @@ static int count_batch_impl(psk_ctx *ctx, int first_sample_idx, int n, const uin
     PSK_HIP(ctx, hipSetDevice(ctx->device));
     if (n_threads < 1) n_threads = 1;
     if (n_threads > 16) n_threads = 16;
-    const int fill_helpers = n_threads >= 2 * n ? n_threads / n : (n == 1 ? 8 : 1);   // threads per large sample's copy
-    if (n_threads > n) n_threads = n;
+    int fill_helpers = n_threads >= 2 * n ? n_threads / n : (n == 1 ? 8 : 1);   // threads per large sample's copy
     // every sample takes the pipelined path (chain_upload / chain_compute); with a slab filter the host's window count is
     // an upper bound and the kernels read the number of kept words from device memory
     size_t max_len = 0;
@@ -837,6 +836,15 @@ static int count_batch_impl(psk_ctx *ctx, int first_sample_idx, int n, const uin
         if (paths ? !paths[i] : (!bytes[i] && lens[i])) return psk_fail(ctx, PSK_EINVAL, "null input %d", i);
         if (lens[i] > max_len) max_len = lens[i];
     }
+    // read sets (hundreds of MB a sample): the copies into pinned memory share the host's memory bandwidth, so six of
+    // them at once all finish late and the first upload waits for them (r02: 6 x 0.63 GB, 87 ms before the first byte
+    // moved, 137 ms in all).  One sample at a time with every thread on its copy finishes a sample every ~15 ms and the
+    // uploads run beside the next copies.
+    if (max_len >= (64u << 20) && n > 1) {
+        fill_helpers = n_threads > 8 ? 8 : n_threads;
+        n_threads = 1;
+    }
+    if (n_threads > n) n_threads = n;
     // pinned ring: at most ~4 GiB of it (read-scale FASTQ samples are hundreds of MB each)
     while (n_threads > 1 && (size_t)(n_threads + 4) * max_len > (4ull << 30)) n_threads--;
     const int R = n < n_threads + 4 ? n : n_threads + 4;  // ring slots: two being uploaded / framed ahead, one whose chain is in
