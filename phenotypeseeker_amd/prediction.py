@@ -2,6 +2,7 @@
 prediction.py; line numbers cite it).  The `gmer_counter -db` subprocess per sample (:72-80) is
 replaced by psk_count_dict; the k-mer text database and the per-sample count files are never
 written.  The model file is the reference's joblib dict {'model', 'kmers', 'pca', 'pred_scale'}."""
+import os
 import sys
 import time
 from collections import OrderedDict
@@ -71,9 +72,14 @@ class Phenotypes:
     @classmethod
     def from_inputfile(cls, line):
         """'<phenotype> <model.pkl>' (:123-143)"""
-        import joblib
+        from . import skpickle
         name, path = line.split()[0], line.split()[1]
-        pkg = joblib.load(path)
+        # a plain pickle of a linear model (what `modeling` writes) is read without importing joblib / scikit-learn
+        # (0.5-2 s of a run that otherwise takes half a second); anything else goes through joblib.load as in the reference
+        pkg = None if os.environ.get("PSK_JOBLIB_LOAD") else skpickle.load_linear_package(path)
+        if pkg is None:
+            import joblib
+            pkg = joblib.load(path)
         if pkg.get("pca"):
             raise SystemExit("PCA models are outside the accelerated path.")
         return cls(name, pkg["model"], np.asarray(pkg["kmers"]), False, pkg["pred_scale"])

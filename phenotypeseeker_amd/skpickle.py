@@ -88,3 +88,95 @@ def dumps(obj):
     _emit(obj, out)
     out.append(b".")
     return b"".join(out)
+
+
+# ---- reading a model file for `prediction` without importing scikit-learn ----------------------------------------
+class _Stub:
+    """Stands in for any scikit-learn class while a model file is unpickled: keeps the attribute dictionary."""
+
+    def __init__(self, *args, **kwargs):
+        pass
+
+    def __setstate__(self, state):
+        if isinstance(state, dict):
+            self.__dict__.update(state)
+        elif isinstance(state, tuple) and len(state) == 2:       # (dict, slots)
+            for part in state:
+                if isinstance(part, dict):
+                    self.__dict__.update(part)
+
+
+class _StubUnpickler(pickle.Unpickler):
+    _made = {}
+
+    def find_class(self, module, name):
+        if module.split(".")[0] == "sklearn":
+            key = (module, name)
+            if key not in self._made:
+                self._made[key] = type(name, (_Stub,), {"__module__": module})
+            return self._made[key]
+        return super().find_class(module, name)
+
+
+class LinearModel:
+    """What `prediction` needs of a fitted (GridSearchCV of a) linear estimator: predict / predict_proba with the
+    expressions scikit-learn evaluates (linear_model/_base.py: X @ coef_.T + intercept_; classes_[scores > 0];
+    expit(scores) for the liblinear / one-vs-rest probability of a binary problem)."""
+
+    def __init__(self, coef, intercept, classes):
+        import numpy as np
+        self.coef_, self.intercept_ = np.asarray(coef, dtype=np.float64), np.asarray(intercept, dtype=np.float64)
+        self.classes_ = None if classes is None else np.asarray(classes)
+
+    def _scores(self, X):
+        import numpy as np
+        X = np.asarray(X, dtype=np.float64)
+        if self.classes_ is None:
+            return X @ self.coef_.T + self.intercept_ if self.coef_.ndim == 2 else X @ self.coef_ + self.intercept_
+        s = X @ self.coef_.T + self.intercept_
+        return s.ravel() if s.ndim == 2 and s.shape[1] == 1 else s
+
+    def predict(self, X):
+        import numpy as np
+        s = self._scores(X)
+        if self.classes_ is None:
+            return s
+        return self.classes_[(s > 0).astype(np.int64)]
+
+    def predict_proba(self, X):
+        import numpy as np
+        s = self._scores(X)
+        p = 1.0 / (1.0 + np.exp(-s))
+        return np.vstack([1.0 - p, p]).T
+
+
+def load_linear_package(path):
+    """The model package of `path` ({'model', 'kmers', 'pca', 'pred_scale'}) with 'model' as a LinearModel -- for files
+    that are plain pickles of a (grid search over a) binary linear classifier or a linear regressor, which is what
+    `modeling` writes.  None for anything else (joblib-wrapped arrays, multi-class models, other estimators, a PCA
+    pipeline): the caller then takes joblib.load and scikit-learn itself."""
+    try:
+        with open(path, "rb") as f:
+            pkg = _StubUnpickler(f).load()
+        if not isinstance(pkg, dict) or pkg.get("pca") or "model" not in pkg:
+            return None
+        m = pkg["model"]
+        est = getattr(m, "best_estimator_", m)
+        kind = type(est).__name__
+        coef, icpt = getattr(est, "coef_", None), getattr(est, "intercept_", None)
+        if coef is None or icpt is None:
+            return None
+        if kind in ("LogisticRegression",):
+            classes = getattr(est, "classes_", None)
+            if classes is None or len(classes) != 2 or getattr(coef, "shape", (0,))[0] != 1:
+                return None
+            model = LinearModel(coef, icpt, classes)
+        elif kind in ("Lasso", "Ridge"):
+            model = LinearModel(coef, icpt, None)
+        else:
+            return None
+        out = dict(pkg)
+        out["model"] = model
+        return out
+    except Exception:   # noqa: BLE001 -- any surprise: the ordinary loader decides
+        return None

@@ -217,3 +217,52 @@ def test_model_files_are_scikit_learn_pickles_written_without_importing_it(tmp_p
     probe = ("import sys; sys.path.insert(0, %r); from phenotypeseeker_amd import skpickle, model; "
              "assert skpickle.template('Lasso') is not None; assert 'sklearn' not in sys.modules" % ROOT_DIR)
     assert subprocess.run([sys.executable, "-c", probe], timeout=120).returncode == 0
+
+
+def test_prediction_reads_linear_models_without_scikit_learn(tmp_path):
+    """`prediction` reads a plain-pickle model file of a linear estimator through stub classes and applies it with
+    scikit-learn's own expressions: the same labels, probabilities and regression values as joblib.load + scikit-learn,
+    and scikit-learn is never imported.  Files it cannot take (joblib-wrapped arrays, as the reference writes them)
+    return None, and the ordinary loader serves them."""
+    import subprocess
+    import sys
+    import joblib
+    import numpy as np
+    from phenotypeseeker_amd import model as M, skpickle
+    rng = np.random.default_rng(4)
+    X = (rng.random((40, 9)) < 0.4).astype(np.float64)
+    for kind in ("logistic", "lasso", "ridge"):
+        if kind == "logistic":
+            est = M.L1LogisticRegression(C=10.0, tol=1e-4, max_iter=1000)
+            est.coef_, est.intercept_ = rng.normal(size=(1, 9)), rng.normal(size=1)
+            gs = M.GridSearch(M.L1LogisticRegression(tol=1e-4, max_iter=1000), "C", [0.1, 10.0], 3)
+            gs.best_params_ = {"C": 10.0}
+        else:
+            cls = M.LassoRegression if kind == "lasso" else M.RidgeRegression
+            est = cls(alpha=0.5)
+            est.coef_, est.intercept_ = rng.normal(size=9), float(rng.normal())
+            gs = M.GridSearch(cls(), "alpha", [2.0, 0.5], 3)
+            gs.best_params_ = {"alpha": 0.5}
+        est.n_features_in_ = 9
+        gs.best_estimator_, gs.best_index_, gs.best_score_, gs.n_splits_ = est, 1, 0.75, 3
+        gs.cv_results_ = {"mean_test_score": np.array([0.5, 0.75]), "std_test_score": np.array([0.1, 0.2]),
+                          "params": [{gs.param_name: v} for v in gs.param_grid[gs.param_name]]}
+        path = os.path.join(tmp_path, kind + ".pkl")
+        with open(path, "wb") as f:
+            f.write(skpickle.dumps({"model": gs.to_sklearn_shell(), "kmers": np.array(["ACGT", "TTTT"], dtype=object), "pca": False,
+                                    "pred_scale": "binary" if kind == "logistic" else "continuous"}))
+        fast, ref = skpickle.load_linear_package(path), joblib.load(path)
+        assert fast is not None and list(fast["kmers"]) == ["ACGT", "TTTT"] and fast["pred_scale"] == ref["pred_scale"]
+        assert np.array_equal(fast["model"].predict(X), ref["model"].predict(X))
+        if kind == "logistic":
+            assert np.allclose(fast["model"].predict_proba(X), ref["model"].predict_proba(X), rtol=1e-14)
+            assert [str(round(p[1], 2)) for p in fast["model"].predict_proba(X)] == [str(round(p[1], 2)) for p in ref["model"].predict_proba(X)]
+        # what joblib.dump writes (arrays outside the pickle stream, as the reference's files are): not for the fast reader
+        jpath = os.path.join(tmp_path, kind + "_joblib.pkl")
+        joblib.dump(ref, jpath)
+        assert skpickle.load_linear_package(jpath) is None or np.array_equal(skpickle.load_linear_package(jpath)["model"].predict(X),
+                                                                             ref["model"].predict(X))
+    probe = ("import sys; sys.path.insert(0, %r); from phenotypeseeker_amd import skpickle; "
+             "assert skpickle.load_linear_package(%r) is not None; assert 'sklearn' not in sys.modules and 'joblib' not in sys.modules"
+             % (ROOT_DIR, os.path.join(str(tmp_path), "logistic.pkl")))
+    assert subprocess.run([sys.executable, "-c", probe], timeout=120).returncode == 0
