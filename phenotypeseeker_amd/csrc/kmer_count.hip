@@ -17,6 +17,7 @@
 #include <unistd.h>
 
 #include <atomic>
+#include <functional>
 #include <chrono>
 #include <condition_variable>
 #include <mutex>
@@ -718,9 +719,14 @@ static int ensure_pinned(psk_ctx *ctx, void **buf, size_t *cap, size_t need)
     return PSK_OK;
 }
 
+// `consumer` != nullptr (prediction: count_dict_impl): the framed clean stream of sample i on buffer set L goes to it instead
+// of the counting chain -- consumer(L, i, clean_len) queues its kernel on ctx->stream -- and no list is made; k_window is
+// then the k of the windows (psk_begin need not have been called)
+typedef std::function<int(CountLane &, int, uint64_t)> StreamConsumer;
 static int count_batch_impl(psk_ctx *ctx, int first_sample_idx, int n, const uint8_t *const *bytes, const char *const *paths,
                             const size_t *lens, uint64_t *n_unique, uint64_t *n_total, int n_threads, int sketch_k,
-                            int sketch_size, uint32_t sketch_seed, uint64_t *hashes_out, uint64_t *n_hashes_out);
+                            int sketch_size, uint32_t sketch_seed, uint64_t *hashes_out, uint64_t *n_hashes_out,
+                            int k_window = 0, const StreamConsumer *consumer = nullptr);
 
 // one sample = a batch of one: the same framing (on the GPU for FASTA / four-line FASTQ) and the same chain
 extern "C" int psk_count_kmers(psk_ctx *ctx, int sample_idx, const uint8_t *bytes, size_t len, uint64_t *n_unique,
@@ -813,16 +819,19 @@ static int parallel_fill(uint8_t *dst, const uint8_t *src, const char *path, siz
 // FASTA / FASTQ; compressed inputs come through the in-memory form after the host has inflated them)
 static int count_batch_impl(psk_ctx *ctx, int first_sample_idx, int n, const uint8_t *const *bytes, const char *const *paths,
                             const size_t *lens, uint64_t *n_unique, uint64_t *n_total, int n_threads, int sketch_k,
-                            int sketch_size, uint32_t sketch_seed, uint64_t *hashes_out, uint64_t *n_hashes_out)
+                            int sketch_size, uint32_t sketch_seed, uint64_t *hashes_out, uint64_t *n_hashes_out, int k_window,
+                            const StreamConsumer *consumer)
 {
     if (!ctx) return PSK_EINVAL;
     if (sketch_k != 0) {
         if (sketch_k < 1 || sketch_k > 32 || sketch_size < 1) return psk_fail(ctx, PSK_EINVAL, "bad sketch parameters");
         if (!hashes_out || !n_hashes_out) return psk_fail(ctx, PSK_EINVAL, "null sketch buffers");
     }
-    if (ctx->k == 0) return psk_fail(ctx, PSK_ESTATE, "psk_begin has not been called");
-    if (n < 0 || first_sample_idx < 0 || first_sample_idx + n > ctx->n_samples)
-        return psk_fail(ctx, PSK_EINVAL, "sample range out of bounds");
+    if (!consumer) {
+        if (ctx->k == 0) return psk_fail(ctx, PSK_ESTATE, "psk_begin has not been called");
+        if (n < 0 || first_sample_idx < 0 || first_sample_idx + n > ctx->n_samples)
+            return psk_fail(ctx, PSK_EINVAL, "sample range out of bounds");
+    }
     if (n == 0) return PSK_OK;
     if ((!bytes && !paths) || !lens) return psk_fail(ctx, PSK_EINVAL, "null input");
     PSK_HIP(ctx, hipSetDevice(ctx->device));
@@ -863,7 +872,7 @@ static int count_batch_impl(psk_ctx *ctx, int first_sample_idx, int n, const uin
     int consumed = 0;                      // samples whose ring slot may be overwritten
     bool abort = false;
     std::atomic<int> next(0);
-    const int k = ctx->k;
+    const int k = consumer ? k_window : ctx->k;
     // PSK_TRACE: where the calling thread waits (stderr, one line per call)
     const bool trace = getenv("PSK_TRACE") != nullptr;
     double t_worker = 0, t_frame = 0, t_final = 0;
@@ -970,6 +979,10 @@ static int count_batch_impl(psk_ctx *ctx, int first_sample_idx, int n, const uin
         return chain_upload(ctx, ctx->lane[i % 3], slot, wins[i] ? plen[i] : 0, 0);
     };
     // stage B: the counting chain, once the length of the clean stream is known on the host
+    auto consume = [&](CountLane &L, int i, uint64_t clean_len, uint64_t n_windows, bool exact) -> int {
+        if (consumer) return (clean_len && n_windows) ? (*consumer)(L, i, clean_len) : PSK_OK;
+        return chain_compute(ctx, L, first_sample_idx + i, clean_len, n_windows, exact);
+    };
     auto stage_b = [&](int i) -> int {
         CountLane &L = ctx->lane[i % 3];
         if (fmt[i] && rlen[i]) {
@@ -987,13 +1000,13 @@ static int count_batch_impl(psk_ctx *ctx, int first_sample_idx, int n, const uin
                 clen[i] = c; plen[i] = p; wins[i] = w; fmt[i] = 0;
                 PSK_TRY(chain_upload(ctx, L, static_cast<const uint8_t *>(ctx->pinned), w ? p : 0, 0));
                 PSK_HIP(ctx, hipEventSynchronize(L.raw_ready));   // ctx->pinned is reused by the next such sample
-                return chain_compute(ctx, L, first_sample_idx + i, c, w, true);
+                return consume(L, i, c, w, true);
             }
             clen[i] = res[0];
             wins[i] = res[0];   // an upper bound of the window count: sizes the buffers, the GPU counts the windows
-            return chain_compute(ctx, L, first_sample_idx + i, clen[i], wins[i], false);
+            return consume(L, i, clen[i], wins[i], false);
         }
-        return chain_compute(ctx, L, first_sample_idx + i, clen[i], wins[i], true);
+        return consume(L, i, clen[i], wins[i], true);
     };
     // Samples i + 1 and i + 2 are uploaded and framed on the copy stream while chain i runs: the host's wait for the
     // framed length of sample i (stage B) then finds it long done (with one sample ahead the wait sat on the critical
@@ -1004,9 +1017,13 @@ static int count_batch_impl(psk_ctx *ctx, int first_sample_idx, int n, const uin
         rc = stage_b(i);
         if (rc == PSK_OK && i > 0) {
             const auto t0 = std::chrono::steady_clock::now();
-            rc = chain_finalize(ctx, ctx->lane[(i - 1) % 3]);  // waits for chain i - 1: its upload is done too
+            if (consumer) {   // no list to finalise: the upload of sample i - 1 has to be over before its ring slot is reused
+                if (hipEventSynchronize(ctx->lane[(i - 1) % 3].raw_ready) != hipSuccess) rc = psk_fail(ctx, PSK_EHIP, "event wait failed");
+            } else {
+                rc = chain_finalize(ctx, ctx->lane[(i - 1) % 3]);  // waits for chain i - 1: its upload is done too
+            }
             t_final += since(t0);
-            if (rc == PSK_OK) report(i - 1);
+            if (rc == PSK_OK && !consumer) report(i - 1);
             if (rc == PSK_OK && sketch_k) rc = collect_sketch(i - 1);
             release_upto(i);
         }
@@ -1017,7 +1034,7 @@ static int count_batch_impl(psk_ctx *ctx, int first_sample_idx, int n, const uin
         // set (i + 2) % 3 is free again: chain i - 1 has been finalised and its sketch collected
         if (rc == PSK_OK && i + 2 < n) rc = stage_a(i + 2);
     }
-    if (rc == PSK_OK && n > 0) {
+    if (rc == PSK_OK && n > 0 && !consumer) {
         rc = chain_finalize(ctx, ctx->lane[(n - 1) % 3]);
         if (rc == PSK_OK) report(n - 1);
         if (rc == PSK_OK && sketch_k) rc = collect_sketch(n - 1);
@@ -1335,105 +1352,19 @@ int count_dict_impl(psk_ctx *ctx, int n, const uint8_t *const *bytes, const char
     PSK_TRY(dev_reserve(ctx, ctx->starts, (size_t)n * n_dict * 4));
     uint32_t *d_cnt = ctx->starts.as<uint32_t>();
     PSK_HIP(ctx, hipMemsetAsync(d_cnt, 0, (size_t)n * n_dict * 4, ctx->stream));
-    if (n_threads < 1) n_threads = 1;
-    if (n_threads > 16) n_threads = 16;
-    if (n_threads > n) n_threads = n;
-    size_t max_len = 0;
-    for (int i = 0; i < n; i++) {
+    for (int i = 0; i < n; i++)
         if (paths ? !paths[i] : (!bytes[i] && lens[i])) return psk_fail(ctx, PSK_EINVAL, "null input %d", i);
-        if (lens[i] > max_len) max_len = lens[i];
-    }
-    while (n_threads > 1 && (size_t)(n_threads + 2) * max_len > (4ull << 30)) n_threads--;
-    const int R = n_threads + 2;
-    if ((int)ctx->ring.size() < R) { ctx->ring.resize(R, nullptr); ctx->ring_cap.resize(R, 0); }
-    for (int s = 0; s < R; s++) PSK_TRY(ensure_pinned(ctx, &ctx->ring[s], &ctx->ring_cap[s], max_len + 2 * EX_SEG));
-    for (CountLane &L : ctx->lane) PSK_TRY(lane_prepare(ctx, L));
-
-    std::mutex mu;
-    std::condition_variable cv;
-    std::vector<int> state(n, 0);
-    std::vector<uint64_t> clen(n, 0), plen(n, 0);
-    int consumed = 0;
-    bool abort = false;
-    std::atomic<int> next(0);
-    auto worker = [&]() {
-        std::vector<uint8_t> file_buf;
-        for (;;) {
-            const int i = next.fetch_add(1);
-            if (i >= n) return;
-            {
-                std::unique_lock<std::mutex> lk(mu);
-                cv.wait(lk, [&] { return abort || consumed > i - R; });
-                if (abort) return;
-            }
-            uint64_t c = 0, p = 0;
-            const uint8_t *src = bytes ? bytes[i] : nullptr;
-            int rc = 0;
-            if (paths) {
-                rc = read_whole_file(paths[i], lens[i], file_buf);
-                src = file_buf.data();
-                if (rc == 0 && lens[i] >= 2 && src[0] == 0x1f && src[1] == 0x8b) rc = -2;   // gzip: the caller inflates
-            }
-            if (rc == 0) rc = frame_into(static_cast<uint8_t *>(ctx->ring[i % R]), ctx->ring_cap[i % R], src, lens[i], &c, &p);
-            {
-                std::lock_guard<std::mutex> lk(mu);
-                clen[i] = c; plen[i] = p;
-                state[i] = rc == -2 ? -2 : rc ? -1 : 1;
-            }
-            cv.notify_all();
-        }
-    };
-    std::vector<std::thread> pool;
-    for (int t = 0; t < n_threads; t++) pool.emplace_back(worker);
-    int rc = PSK_OK;
-    auto release_upto = [&](int upto) {
-        {
-            std::lock_guard<std::mutex> lk(mu);
-            consumed = upto;
-            if (rc != PSK_OK) abort = true;
-        }
-        cv.notify_all();
-    };
-    auto step = [&](int i) -> int {
-        CountLane &L = ctx->lane[i % 3];
-        PSK_TRY(dev_reserve(ctx, L.raw, plen[i]));
-        if (L.raw_used) PSK_HIP(ctx, hipStreamWaitEvent(ctx->copy_stream, L.raw_free, 0));
-        PSK_HIP(ctx, hipMemcpyAsync(L.raw.p, ctx->ring[i % R], plen[i], hipMemcpyHostToDevice, ctx->copy_stream));
-        PSK_HIP(ctx, hipEventRecord(L.raw_ready, ctx->copy_stream));
+    // the ingest of the counting path (pinned ring, upload + framing on the GPU two samples ahead) with the dictionary
+    // kernel in the place of the counting chain
+    const StreamConsumer look_up = [&](CountLane &L, int i, uint64_t clean_len) -> int {
         PSK_HIP(ctx, hipStreamWaitEvent(ctx->stream, L.raw_ready, 0));
-        if (clen[i]) launch_dict_count(ctx, T, L.raw.as<uint8_t>(), clen[i], k, d_cnt + (size_t)i * n_dict);
+        launch_dict_count(ctx, T, L.raw.as<uint8_t>(), clean_len, k, d_cnt + (size_t)i * n_dict);
         PSK_HIP(ctx, hipGetLastError());
         PSK_HIP(ctx, hipEventRecord(L.raw_free, ctx->stream));
         L.raw_used = true;
         return PSK_OK;
     };
-    for (int i = 0; i < n && rc == PSK_OK; i++) {
-        {
-            std::unique_lock<std::mutex> lk(mu);
-            cv.wait(lk, [&] { return state[i] != 0; });
-            if (state[i] == -2) rc = psk_fail(ctx, PSK_EINVAL, "sample %d (%s) is gzip-compressed: inflate it and use the in-memory call", i, paths[i]);
-            else if (state[i] < 0) rc = psk_fail(ctx, PSK_ERANGE, "reading or framing sample %d failed", i);
-        }
-        if (rc != PSK_OK) break;
-        rc = step(i);
-        if (rc == PSK_OK && i > 0) {
-            // the upload of sample i - 1 has to be over before its ring slot is framed into again
-            if (hipEventSynchronize(ctx->lane[(i - 1) % 3].raw_ready) != hipSuccess) rc = psk_fail(ctx, PSK_EHIP, "event wait failed");
-            release_upto(i);
-        }
-    }
-    {
-        const hipError_t e1 = hipStreamSynchronize(ctx->copy_stream), e2 = hipStreamSynchronize(ctx->stream);
-        if (rc == PSK_OK && (e1 != hipSuccess || e2 != hipSuccess)) rc = psk_fail(ctx, PSK_EHIP, "stream synchronisation failed");
-    }
-    release_upto(n);
-    {
-        std::lock_guard<std::mutex> lk(mu);
-        if (rc != PSK_OK) abort = true;
-    }
-    cv.notify_all();
-    for (auto &t : pool) t.join();
-    if (rc != PSK_OK) return rc;
+    PSK_TRY(count_batch_impl(ctx, 0, n, bytes, paths, lens, nullptr, nullptr, n_threads, 0, 0, 0, nullptr, nullptr, k, &look_up));
     PSK_HIP(ctx, hipMemcpy(counts_out, d_cnt, (size_t)n * n_dict * 4, hipMemcpyDeviceToHost));
     for (int i = 0; i < n; i++)
         for (uint64_t d = 0; d < n_dict; d++)
