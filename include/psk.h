@@ -230,7 +230,8 @@ int psk_logreg_l2_fit(psk_ctx *ctx, const float *X, const int32_t *y01, int n, i
 int psk_count_dict(psk_ctx *ctx, const uint8_t *bytes, size_t len, int k, const uint64_t *dict_words,
                    uint64_t n_dict, uint32_t *counts_out);
 /* All samples of a prediction run against one dictionary (the Pool.map over samples of prediction.py:150-163):
- * n_threads host threads frame ahead of the GPU, one kernel per sample, one read-back.  counts_out[n][n_dict].
+ * the ingest of psk_count_kmers_batch (n_threads host threads move file bytes into pinned memory, FASTA and four-line
+ * FASTQ are framed on the GPU) with one dictionary kernel per sample and one read-back.  counts_out[n][n_dict].
  * _files: paths of UNCOMPRESSED files of sizes[i] bytes, read by the framing threads.  Any dictionary size: up to
  * 2048 words the table lives in LDS, beyond that in global memory (`--n_kmers 0` models). */
 int psk_count_dict_batch(psk_ctx *ctx, int n, const uint8_t *const *bytes, const size_t *lens, int k,
