@@ -1,10 +1,16 @@
 #!/usr/bin/env python3
 """bench.py -- the north-star metric on MI355X: k-mer x sample chi-squared cells per second.
 
-  python bench.py [--gpus N --steps K --warmup W]            (N = 1: plain process)
-  python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N ...   (one rank per GPU; the launcher
-      only supplies RANK / LOCAL_RANK / WORLD_SIZE / MASTER_*: this program never imports torch -- the
-      collectives are RCCL calls made by libpsk.so, phenotypeseeker_amd/dist.py)
+  python bench.py [--gpus N --steps K --warmup W]
+      N = 1: plain process.  N > 1 with no WORLD_SIZE in the environment: this process -- which makes no GPU call --
+      starts one child per GPU itself (phenotypeseeker_amd/launch.py: RANK / LOCAL_RANK / WORLD_SIZE, a private
+      rendezvous directory), relays rank 0's JSON line as the last line of stdout and exits with the worst child's
+      code; the reference's own parallel axis needs no launcher either (Pool(num_threads), modeling.py:1649-1663).
+  <any launcher that exports RANK / LOCAL_RANK / WORLD_SIZE> bench.py --gpus N ...   (one rank per GPU; the driver's
+      launcher does: only those variables are read -- this program never imports torch, the collectives are RCCL
+      calls made by libpsk.so, phenotypeseeker_amd/dist.py)
+  With every rank on its own GPU the collectives are RCCL or the run FAILS (rc != 0): the host-file transport is an
+  opt-in of the one-GPU test boxes (--share-gpu), and a line measured over it says "scaling": "invalid ...".
 
 N = 1 (BASELINE.json configs[1]): synthetic 256 x 5-Mbp FASTA, binary phenotype, k = 13.  The genome set is
 generated on the host, every sample is counted on the GPU (psk_count_kmers_batch) and the union + bit-packed
@@ -131,7 +137,7 @@ def e2e_modeling(gs, n, k):
 def e2e_modeling_sharded(grp, gs, n, k, args):
     """The same figure with several ranks: rank 0 writes the FASTA files once, then EVERY rank starts
     `phenotypeseeker modeling data.pheno` as a child process (RANK / LOCAL_RANK / WORLD_SIZE as this launch has them, a
-    rendezvous file of its own) in that directory; the wall-clock is the slowest rank's, process start to exit.  The
+    rendezvous directory of its own) in that directory; the wall-clock is the slowest rank's, process start to exit.  The
     children share the GPUs with this process, which has released its matrix by then.  Any failure is reported, not raised: the
     line's `value` does not depend on this leg."""
     import shutil
@@ -161,7 +167,7 @@ def e2e_modeling_sharded(grp, gs, n, k, args):
             tmp_made = made_dir
         if not tmp:
             return {"error": "the dataset could not be written" + (": " + write_err if write_err else "")}
-        env = dict(os.environ, PSK_RDZV_FILE=os.path.join(tmp, ".rendezvous"),
+        env = dict(os.environ, PSK_RDZV_DIR=os.path.join(tmp, ".rendezvous"),     # a meeting place of their own
                    PSK_REDUNDANT_INGEST="1" if args.ingest == "filter" else "0")
         here = os.path.dirname(os.path.abspath(__file__))
         env["PYTHONPATH"] = here + os.pathsep + env.get("PYTHONPATH", "")
@@ -225,17 +231,21 @@ def main():
                     help="N = 1 only: run the N > 1 step (scan + export + all-gather) on a one-rank group, to measure "
                          "what the exchange adds per step on one GPU; the line carries \"exchange\": \"forced\"")
     args = ap.parse_args()
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        # launcher-free: fan out here, before anything of this process has touched the GPU (launch.py imports the
+        # standard library only; the children are fresh processes, not an exec of a process that has initialised HIP)
+        from phenotypeseeker_amd import launch
+        sys.exit(launch.spawn_ranks([os.path.abspath(__file__)] + sys.argv[1:], args.gpus, share_gpu=args.share_gpu))
     from phenotypeseeker_amd import dist as psk_dist
     from phenotypeseeker_amd.engine import PskContext
     from phenotypeseeker_amd.synth import GenomeSet
 
     grp = psk_dist.Group()
     if grp.world != args.gpus:
-        if grp.world == 1 and args.gpus > 1:
-            sys.exit("bench.py --gpus %d must be launched with torch.distributed.run (one rank per GPU)" % args.gpus)
+        sys.exit("bench.py --gpus %d but WORLD_SIZE=%d in the environment" % (args.gpus, grp.world))
     if args.share_gpu:
-        os.environ["PSK_SHARE_GPU"] = "1"
-    grp.init(force=args.force_exchange)
+        os.environ["PSK_SHARE_GPU"] = "1"     # ranks modulo the visible GPUs; opts into the host-file transport (tests)
+    grp.init(force=args.force_exchange)       # RCCL, or an error: see dist._rccl_or_host_files
     rank, world = grp.rank, grp.world
     sharded = world > 1
     n = args.samples if args.samples is not None else (2048 if sharded else 256)
@@ -386,10 +396,14 @@ def main():
     mean_ms = float(np.mean(kernel_ms))
     achieved = alg_bytes / (mean_ms * 1e-3) / 1e9
     traffic = measured_traffic(int(M), wpr)
+    # a multi-rank figure is a scaling point only when its collectives ran on RCCL with one GPU per rank
+    real_multi = sharded and grp.backend == "rccl" and grp.rccl_ranks == world and not args.share_gpu
+    scaling = "weak" if not sharded else ("strong" if real_multi else
+                                          "invalid (%s collectives%s: not a scaling point)" % (grp.backend, ", ranks share GPUs" if args.share_gpu else ""))
     out = {
         "metric": "k-mer x sample chi2 cells/sec", "value": value, "unit": "cells/s", "n_gpus": world,
         "steps": args.steps, "warmup": args.warmup, "ms_per_step": elapsed / args.steps * 1e3,
-        "higher_is_better": True, "scaling": "strong" if sharded else "weak", "vs_baseline": None,
+        "higher_is_better": True, "scaling": scaling, "vs_baseline": None,
         "dtype": "u64 popcount + f64",
         "data": "synthetic",
         "config": {"workload": workload, "n_samples": n, "k": k, "rows_per_gpu": int(M),
@@ -406,6 +420,8 @@ def main():
                      "stored_bytes_per_launch": int(M) * 8 * wpr},
     }
 
+    if sharded or args.force_exchange:
+        out["rccl_ranks"] = grp.rccl_ranks     # ncclCommCount of the communicator the collectives ran on (0: not RCCL)
     if args.force_exchange:
         out["exchange"] = "forced"
     if rank == 0 and world == 1 and not args.no_cpu_baseline:

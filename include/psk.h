@@ -30,7 +30,8 @@ enum {
     PSK_ENOMEM = -2,   /* host or device allocation failed */
     PSK_EHIP = -3,     /* a HIP runtime call failed */
     PSK_ERANGE = -4,   /* caller buffer too small / size limit exceeded */
-    PSK_ESTATE = -5    /* required earlier stage has not been run */
+    PSK_ESTATE = -5,   /* required earlier stage has not been run */
+    PSK_EGZIP = -6     /* a FILE input is gzip-compressed (magic bytes): the caller inflates it and uses the in-memory call */
 };
 
 /* ---- lifecycle --------------------------------------------------------------------------- */
@@ -276,6 +277,8 @@ int psk_nj_merges(psk_ctx *ctx, const double *dist, int n, int32_t *mi_out, int3
  *   psk_comm_unique_id   rank 0: writes the 128-byte id of ncclGetUniqueId (returns its length); the caller's
  *                        rendezvous (a file, a socket) carries it to the other ranks
  *   psk_comm_init        every rank, same id: ncclCommInitRank on the context's GPU
+ *   psk_comm_size        ncclCommCount of the communicator (>= 1; < 0 on error): what a multi-GPU measurement quotes
+ *                        as proof that its collectives ran on RCCL with every rank joined
  *   psk_comm_allreduce   in place on `count` host values; dtype 0 = u64, 1 = f64; op 0 = sum, 1 = max
  *   psk_comm_allgather_host     recv[world][bytes] <- every rank's send[bytes] (host buffers, waited for)
  *   psk_comm_allgather_device   the same for DEVICE buffers, queued on the communicator's stream, not waited for
@@ -288,6 +291,7 @@ int psk_nj_merges(psk_ctx *ctx, const double *dist, int n, int32_t *mi_out, int3
 int psk_device_count(void);
 int psk_comm_unique_id(psk_ctx *ctx, uint8_t *id_out, int cap);
 int psk_comm_init(psk_ctx *ctx, const uint8_t *id, int id_len, int rank, int world);
+int psk_comm_size(psk_ctx *ctx);
 int psk_comm_free(psk_ctx *ctx);
 void *psk_comm_stream(psk_ctx *ctx);
 int psk_comm_sync(psk_ctx *ctx);

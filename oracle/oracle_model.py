@@ -177,3 +177,95 @@ def grid_search(X, y, grid, kind, cv):
     w, b = fit(X, y, grid[best])
     return {"mean_test_score": mean, "std_test_score": scores.std(axis=1), "best_index": best, "coef": w,
             "intercept": b, "folds": folds}
+
+
+def collapse_columns(X):
+    """distinct column patterns of X in order of first appearance: (Xu, group) with X[:, j] == Xu[:, group[j]]"""
+    X = np.asarray(X, dtype=np.float64)
+    seen, group, keep = {}, np.empty(X.shape[1], dtype=np.int64), []
+    for j in range(X.shape[1]):
+        key = X[:, j].tobytes()
+        if key not in seen:
+            seen[key] = len(keep)
+            keep.append(j)
+        group[j] = seen[key]
+    return X[:, keep], group
+
+
+def logreg_l1_arbiter(X, y01, C, w_hint, b_hint, support_tol=1e-9, max_rounds=50):
+    """The exact optimum of liblinear's L1R_LR objective (modeling.py:1011-1014) by an active-set Newton solve --
+    the ARBITER between two approximate solvers (the HIP solver and the liblinear fixture), better than either:
+    identical columns are collapsed to one (their coefficient SUM is what is unique), the support and the signs
+    are taken from the hint, the smooth problem  s.theta_A + C sum log(1 + exp(-y A theta))  is solved on that
+    support by damped Newton steps in f64 until its gradient is below 2e-14 (or no step improves it), and the KKT conditions of
+    the full problem are then checked: sign agreement on the support, |grad_j| <= 1 off it.  A violated
+    condition moves the coordinate in / out of the support and the solve repeats.
+    Returns dict(w_groups (per distinct pattern), group (column -> pattern), b, kkt (max violation),
+    rank_deficient (the support's columns are dependent: only A.theta is unique then))."""
+    Xu, group = collapse_columns(X)
+    n, pu = Xu.shape
+    A = np.hstack([Xu, np.ones((n, 1))])        # the intercept is a penalised constant feature
+    ypm = 2.0 * np.asarray(y01, dtype=np.float64) - 1.0
+    th = np.zeros(pu + 1)
+    np.add.at(th, group, np.asarray(w_hint, dtype=np.float64))
+    th[pu] = b_hint
+    act = np.abs(th) > support_tol
+    sgn = np.sign(th)
+    th[~act] = 0.0
+
+    def grad_loss(t):
+        z = A @ t
+        s = 1.0 / (1.0 + np.exp(ypm * z))       # sigma(-y z)
+        return -C * (A.T @ (ypm * s)), s
+
+    def obj(t):
+        return np.abs(t).sum() + C * np.logaddexp(0.0, -ypm * (A @ t)).sum()
+    rank_def = False
+    for _ in range(max_rounds):
+        idx = np.nonzero(act)[0]
+        for _it in range(200):
+            g, s = grad_loss(th)
+            gs = g[idx] + sgn[idx]
+            if idx.size == 0 or np.abs(gs).max() < 2e-14:
+                break
+            Aa = A[:, idx]
+            H = C * (Aa.T * (s * (1.0 - s))) @ Aa
+            try:
+                d = -np.linalg.solve(H, gs)
+                if not np.all(np.isfinite(d)):
+                    raise np.linalg.LinAlgError
+            except np.linalg.LinAlgError:
+                rank_def = True
+                d = -np.linalg.lstsq(H, gs, rcond=1e-13)[0]
+            # the step may not carry a coordinate across zero (the smooth model is only valid on this orthant)
+            t = 1.0
+            cross = (th[idx] + d) * sgn[idx] < 0
+            if cross.any():
+                t = min(1.0, float(np.min(-th[idx][cross] / d[cross])))
+            f0 = obj(th)
+            while t > 1e-14:
+                cand = th.copy()
+                cand[idx] += t * d
+                if obj(cand) <= f0 + 1e-4 * t * (gs @ d) or t * np.abs(d).max() < 1e-15:
+                    break
+                t *= 0.5
+            th = cand
+            hit = idx[np.abs(th[idx]) < 1e-15 * max(1.0, np.abs(th).max())]
+            if hit.size and cross.any():
+                th[hit] = 0.0
+                act[hit] = False
+                idx = np.nonzero(act)[0]
+        g, _ = grad_loss(th)
+        viol_in = (~act) & (np.abs(g) > 1.0 + 1e-12)
+        if not viol_in.any():
+            break
+        j = int(np.argmax(np.where(viol_in, np.abs(g), 0.0)))
+        act[j] = True
+        sgn[j] = -np.sign(g[j])
+    g, _ = grad_loss(th)
+    kkt = max(float(np.abs(g[act] + np.sign(th[act])).max()) if act.any() else 0.0,
+              float(np.maximum(np.abs(g[~act]) - 1.0, 0.0).max()) if (~act).any() else 0.0)
+    if act.any() and act.sum() > np.linalg.matrix_rank(A[:, act]):
+        rank_def = True
+    return {"w_groups": th[:pu].copy(), "group": group, "b": float(th[pu]), "kkt": kkt, "rank_deficient": rank_def,
+            "objective": obj(th), "linpred": A @ th}

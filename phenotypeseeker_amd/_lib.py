@@ -7,7 +7,14 @@ LIB_PATH = os.environ.get("PSK_LIB") or os.path.join(_HERE, "libpsk.so")  # PSK_
 
 
 class PskError(RuntimeError):
-    pass
+    """`code`: the negative PSK_E* value of include/psk.h the call returned (None when the failure is the loader's)."""
+
+    def __init__(self, msg, code=None):
+        super().__init__(msg)
+        self.code = code
+
+
+PSK_EGZIP = -6    # include/psk.h: a file input is gzip-compressed; the caller inflates it and uses the in-memory call
 
 
 c = ctypes
@@ -74,6 +81,7 @@ _SIGNATURES = {
     "psk_device_count": (c.c_int, []),
     "psk_comm_unique_id": (c.c_int, [c.c_void_p, c.c_void_p, c.c_int]),
     "psk_comm_init": (c.c_int, [c.c_void_p, c.c_void_p, c.c_int, c.c_int, c.c_int]),
+    "psk_comm_size": (c.c_int, [c.c_void_p]),
     "psk_comm_free": (c.c_int, [c.c_void_p]),
     "psk_comm_stream": (c.c_void_p, [c.c_void_p]),
     "psk_comm_sync": (c.c_int, [c.c_void_p]),

@@ -113,6 +113,18 @@ def build_parser():
 
 
 def main(argv=None):
+    # PSK_GPUS=N (N > 1) and no launcher in sight: this process, before it has loaded anything that could touch the GPU,
+    # starts one rank per GPU itself (launch.py) -- the reference's parallel axis, `-nt`, needs no outside launcher
+    # either (modeling.py:1649-1663).  Under a launcher that exports RANK / WORLD_SIZE the ranks come here directly.
+    import os
+    n_gpus = int(os.environ.get("PSK_GPUS", "0") or 0)
+    if n_gpus > 1 and "WORLD_SIZE" not in os.environ:
+        from . import launch
+        root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+        env = {"PYTHONPATH": root + os.pathsep + os.environ.get("PYTHONPATH", "")}
+        rest = list(sys.argv[1:] if argv is None else argv)
+        sys.exit(launch.spawn_ranks(["-m", "phenotypeseeker_amd.cli"] + rest, n_gpus,
+                                    share_gpu=os.environ.get("PSK_SHARE_GPU") == "1", env_extra=env))
     parser = build_parser()
     args = parser.parse_args(argv)
     if not hasattr(args, "func"):

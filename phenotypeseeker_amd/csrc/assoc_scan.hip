@@ -58,6 +58,7 @@ struct ScanArgs {
     const double *tab;         // per-sample table of the lane-per-row pass: [wpr*64][NM] doubles (see row_moments)
     const double *lut;         // the same table summed over every subset of each group of 4 samples (row_moments_lut)
     int c_lut;                 // ... for the first c_lut chunks of a row; the rest of the row takes the per-sample form
+    const double *raw;         // Welch: {weight (0 for NA), phenotype value (0 for NA)} per sample, for the exact second pass
     int n1, n0;                // popcounts of the masks
     double W1, W0;             // weight totals of the two phenotype classes
     // t-test
@@ -642,19 +643,13 @@ __global__ __launch_bounds__(LUT ? SC_LUT_THREADS : SC_THREADS) void ttest_scan_
         const double semsum = sem1 + sem2;
         const double tstat = (dx - dy) / sqrt(semsum);
         // Student's t has heavier tails than the normal, p_t >= erfc(|t|/sqrt 2): rows with
-        // |t| <= t_crit (erfc(t_crit/sqrt 2) = cut, solved on the host) cannot pass.  Candidates are
-        // stored with their Satterthwaite df in the p slot; ttest_finalize_kernel turns that into
-        // the exact p-value and drops the ones that fail (keeps erfc / incomplete-beta code, and
-        // its ~90 VGPRs, out of this kernel).
+        // |t| <= t_crit (erfc(t_crit/sqrt 2) = cut, solved on the host, less a margin far above the ~1e-15 by which these
+        // sums differ from the sample-order ones) cannot pass.  Candidates are stored as (row, n_with) only:
+        // ttest_finalize_kernel sums their moments again in the reference's order and decides (keeps erfc /
+        // incomplete-beta code, and its ~90 VGPRs, out of this kernel).
         if (fabs(tstat) > P.tcrit) {
-            const double z1 = (sem1 / semsum) * (sem1 / semsum) / (nx - 1.0);
-            const double z2 = (sem2 / semsum) * (sem2 / semsum) / (ny - 1.0);
             const uint64_t idx = reserve_slot(P);
             P.res_row[idx] = r;
-            P.res_stat[idx] = tstat;
-            P.res_p[idx] = 1.0 / (z1 + z2);
-            P.res_mx[idx] = mu + dx;
-            P.res_my[idx] = mu + dy;
             P.res_nw[idx] = r_nw;
         }
     };
@@ -770,34 +765,86 @@ int pick_chi2_mode(const psk_ctx *ctx, bool weighted, double pcut, double pcut_b
     return expect > 1e-3 ? 2 : 0;
 }
 
-// Second pass of the Welch scan: one workgroup per result segment turns (t, df) of every candidate into
-// the two-sided p-value, keeps p < cut / M (modeling.py:738) and compacts the segment in place.
-__global__ __launch_bounds__(256) void ttest_finalize_kernel(const ScanArgs P)
+// Second pass of the Welch scan: one workgroup per result segment, one candidate per lane.  The candidate's moments are
+// summed AGAIN in the reference's order -- conduct_t_test / get_samples_distribution_for_ttest (modeling.py:716-757)
+// hand the two groups' values and weights, in sample order, to a weighted DescrStatsW: per group sum w and sum w v, the
+// weighted mean, then sum w (v - mean)^2 (ddof = 0), std_meandiff_separatevar and the Satterthwaite df -- with every
+// operation an IEEE double operation in that order (this file is compiled with -ffp-contract=off; a weight times 1.0 or
+// 0.0 is exact, so `fma(present ? 1 : 0, term, acc)` IS the conditional addition), so t, the two means, round(t, 2)
+// and the "%.2E" of the p-value follow from the same bits as a sample-order CPU evaluation (r02: moments from the scan kernel's nibble-table
+// sums, ~1e-15 off, and up to two rows flipping at the cut).  Then the two-sided p, the keep rule p < cut / M
+// (modeling.py:738) and the compaction of the segment in place.  Candidates are the rows whose scan-kernel |t| exceeds
+// a bound no passing row can be under (psk_ttest_scan: t_crit), so the scan kernel's own sums decide nothing.
+__global__ __launch_bounds__(SC_FIN_THREADS) void ttest_finalize_kernel(const ScanArgs P)
 {
-    __shared__ uint32_t scan_lds[4];
+    __shared__ uint32_t scan_lds[SC_FIN_THREADS / 64];
     __shared__ uint32_t s_out;
+    __shared__ double2 s_tab[SC_FIN_BLK * 128];   // {weight, value} of the samples of the current block (broadcast reads)
     const uint32_t seg = blockIdx.x;
     const uint32_t c = P.counter[seg * SC_CNT_STRIDE];
     const uint64_t base = (uint64_t)seg * P.seg_cap;
     if (threadIdx.x == 0) s_out = 0;
     __syncthreads();
-    for (uint32_t s0 = 0; s0 < c; s0 += 256) {
+    for (uint32_t s0 = 0; s0 < c; s0 += SC_FIN_THREADS) {
         const uint32_t i = s0 + threadIdx.x;
         const bool valid = i < c;
-        uint64_t row = 0; double t = 0, p = 0, mx = 0, my = 0; int32_t nw = 0;
+        const uint64_t row = valid ? P.res_row[base + i] : 0;
+        const int32_t nw = valid ? P.res_nw[base + i] : 0;
+        const bool wave_any = __any(valid);
+        const u32x4 *rp = P.bits + row * (uint64_t)P.cpr;
+        double nx = 0.0, ny = 0.0, sx = 0.0, sy = 0.0, qx = 0.0, qy = 0.0, mx = 0.0, my = 0.0;
+        for (int pass = 0; pass < 2; pass++) {
+            if (pass == 1) { mx = sx / nx; my = sy / ny; }
+            for (int c0 = 0; c0 < P.cpr; c0 += SC_FIN_BLK) {
+                const int nc = P.cpr - c0 < SC_FIN_BLK ? P.cpr - c0 : SC_FIN_BLK;
+                __syncthreads();   // the previous block has been consumed
+                for (int e = threadIdx.x; e < nc * 128; e += SC_FIN_THREADS)
+                    s_tab[e] = reinterpret_cast<const double2 *>(P.raw)[(size_t)c0 * 128 + e];
+                __syncthreads();
+                if (!wave_any) continue;
+                for (int ch = 0; ch < nc; ch++) {
+                    const u32x4 y = rp[c0 + ch];
+                    const uint32_t w4[4] = {y.x, y.y, y.z, y.w};
+#pragma unroll
+                    for (int h = 0; h < 4; h++) {
+#pragma unroll 8
+                        for (int sb = 0; sb < 32; sb++) {
+                            const uint32_t fh = (uint32_t)(((int32_t)(w4[h] << (31 - sb))) >> 31) & 0x3FF00000u;
+                            const double f = __hiloint2double((int)fh, 0), g = __hiloint2double((int)(fh ^ 0x3FF00000u), 0);
+                            const double2 t = s_tab[ch * 128 + h * 32 + sb];   // NA samples and padding: {0, 0}
+                            if (pass == 0) {
+                                const double wv = t.x * t.y;
+                                nx = fma(f, t.x, nx); sx = fma(f, wv, sx);
+                                ny = fma(g, t.x, ny); sy = fma(g, wv, sy);
+                            } else {
+                                const double d = t.y - (fh ? mx : my);
+                                const double term = (t.x * d) * d;
+                                qx = fma(f, term, qx);
+                                qy = fma(g, term, qy);
+                            }
+                        }
+                    }
+                }
+            }
+        }
+        double tstat = 0.0, p = 1.0;
         bool keep = false;
         if (valid) {
-            row = P.res_row[base + i]; t = P.res_stat[base + i]; mx = P.res_mx[base + i]; my = P.res_my[base + i];
-            nw = P.res_nw[base + i];
-            p = dev_t_two_sided_p(t, P.res_p[base + i]);
+            const double vx = qx / nx, vy = qy / ny;          // ddof = 0
+            const double sem1 = vx / (nx - 1.0), sem2 = vy / (ny - 1.0);
+            const double semsum = sem1 + sem2;
+            tstat = (mx - my) / sqrt(semsum);
+            const double z1 = (sem1 / semsum) * (sem1 / semsum) / (nx - 1.0);
+            const double z2 = (sem2 / semsum) * (sem2 / semsum) / (ny - 1.0);
+            p = dev_t_two_sided_p(tstat, 1.0 / (z1 + z2));
             keep = p < P.pcut_bonf;
         }
         uint32_t tot;
-        const uint32_t pos = psk_block_excl_scan_u32<256>(keep ? 1u : 0u, &tot, scan_lds);  // barriers inside
+        const uint32_t pos = psk_block_excl_scan_u32<SC_FIN_THREADS>(keep ? 1u : 0u, &tot, scan_lds);  // barriers inside
         const uint32_t out = s_out;
         if (keep) {
             const uint64_t o = base + out + pos;  // <= base + i: compaction only moves entries down
-            P.res_row[o] = row; P.res_stat[o] = t; P.res_p[o] = p; P.res_mx[o] = mx; P.res_my[o] = my; P.res_nw[o] = nw;
+            P.res_row[o] = row; P.res_stat[o] = tstat; P.res_p[o] = p; P.res_mx[o] = mx; P.res_my[o] = my; P.res_nw[o] = nw;
         }
         __syncthreads();
         if (threadIdx.x == 0) s_out = out + tot;
@@ -851,7 +898,7 @@ void launch_ttest(int G, dim3 grid, hipStream_t st, const ScanArgs &a, double mu
         else launch_ttest_lut<false>(G, grid, st, a, mu);
     } else if (weighted) launch_ttest_w<true>(G, grid, st, a, mu);
     else launch_ttest_w<false>(G, grid, st, a, mu);
-    ttest_finalize_kernel<<<SC_NSEG, 256, 0, st>>>(a);
+    ttest_finalize_kernel<<<SC_NSEG, SC_FIN_THREADS, 0, st>>>(a);
 }
 
 // builds the nibble table of `tab` (cpr * 128 samples x nm moments, already on the device) into ctx->lut
@@ -1198,7 +1245,8 @@ extern "C" int psk_ttest_scan(psk_ctx *ctx, const double *pheno, const uint8_t *
     bool unit_w = true;
     for (int i = 0; weights && i < N; i++) if (valid[i] && weights[i] != 1.0) unit_w = false;
     const int NM = unit_w ? 2 : 3;
-    std::vector<double> vw((size_t)NM * wpr * 64, 0.0);  // row_moments table: {u, u^2} or {w, w u, w u^2} per sample
+    const size_t raw_off = (size_t)NM * wpr * 64;             // the exact pass's {weight, value} pairs follow the moment table
+    std::vector<double> vw(raw_off + (size_t)2 * wpr * 64, 0.0);  // row_moments table: {u, u^2} or {w, w u, w u^2} per sample
     int nvalid = 0;
     double sw = 0.0, swv = 0.0;
     for (int i = 0; i < N; i++) {
@@ -1216,6 +1264,7 @@ extern "C" int psk_ttest_scan(psk_ctx *ctx, const double *pheno, const uint8_t *
         if (unit_w) { vw[2 * (size_t)i] = u; vw[2 * (size_t)i + 1] = u * u; }
         else { vw[3 * (size_t)i] = wi; vw[3 * (size_t)i + 1] = wi * u; vw[3 * (size_t)i + 2] = wi * u * u; }
         tot_w += wi; tot_wu += wi * u; tot_wuu += wi * u * u;
+        vw[raw_off + 2 * (size_t)i] = wi; vw[raw_off + 2 * (size_t)i + 1] = pheno[i];
         nvalid++;
     }
     PSK_TRY(dev_reserve(ctx, ctx->mask1, wpr * 8));
@@ -1229,6 +1278,7 @@ extern "C" int psk_ttest_scan(psk_ctx *ctx, const double *pheno, const uint8_t *
     a.cpr = wpr / 2;
     a.mvalid = ctx->mask1.as<uint64_t>();
     a.tab = ctx->phe.as<double>();
+    a.raw = a.tab + raw_off;
     a.nvalid = nvalid;
     a.min_samples = min_samples;
     a.max_samples = max_samples;
@@ -1245,7 +1295,7 @@ extern "C" int psk_ttest_scan(psk_ctx *ctx, const double *pheno, const uint8_t *
                 const double mid = 0.5 * (lo + hi);
                 if (std::erfc(mid * 0.70710678118654752440) >= cut) lo = mid; else hi = mid;
             }
-        a.tcrit = lo * (1.0 - 1e-12);  // err on the side of keeping candidates
+        a.tcrit = cut < 1.0 ? lo * (1.0 - 1e-9) : -1.0;  // err on the side of keeping candidates (the exact pass decides)
     }
     int set = 0;
     PSK_TRY(pick_result_set(ctx, &set));

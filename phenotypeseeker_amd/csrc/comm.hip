@@ -17,6 +17,7 @@ struct RcclApi {
     ncclResult_t (*GetUniqueId)(ncclUniqueId *) = nullptr;
     ncclResult_t (*CommInitRank)(ncclComm_t *, int, ncclUniqueId, int) = nullptr;
     ncclResult_t (*CommDestroy)(ncclComm_t) = nullptr;
+    ncclResult_t (*CommCount)(const ncclComm_t, int *) = nullptr;
     ncclResult_t (*AllReduce)(const void *, void *, size_t, ncclDataType_t, ncclRedOp_t, ncclComm_t, hipStream_t) = nullptr;
     ncclResult_t (*AllGather)(const void *, void *, size_t, ncclDataType_t, ncclComm_t, hipStream_t) = nullptr;
     ncclResult_t (*Send)(const void *, size_t, ncclDataType_t, int, ncclComm_t, hipStream_t) = nullptr;
@@ -47,6 +48,7 @@ int load_rccl(psk_ctx *ctx)
     PSK_SYM(GetUniqueId, "ncclGetUniqueId")
     PSK_SYM(CommInitRank, "ncclCommInitRank")
     PSK_SYM(CommDestroy, "ncclCommDestroy")
+    PSK_SYM(CommCount, "ncclCommCount")
     PSK_SYM(AllReduce, "ncclAllReduce")
     PSK_SYM(AllGather, "ncclAllGather")
     PSK_SYM(Send, "ncclSend")
@@ -140,6 +142,17 @@ extern "C" int psk_comm_init(psk_ctx *ctx, const uint8_t *id, int id_len, int ra
     return PSK_OK;
 }
 
+// Ranks of the communicator as RCCL itself counts them (ncclCommCount): what a multi-GPU measurement quotes as
+// proof that its collectives ran on RCCL with every rank joined.  < 0 on error (no communicator: PSK_ESTATE).
+extern "C" int psk_comm_size(psk_ctx *ctx)
+{
+    PskComm *c = comm_of(ctx);
+    if (!c || !c->comm) return psk_fail(ctx, PSK_ESTATE, "no communicator");
+    int n = 0;
+    PSK_NCCL(ctx, g_rccl.CommCount(c->comm, &n));
+    return n;
+}
+
 extern "C" int psk_comm_free(psk_ctx *ctx)
 {
     if (!ctx) return PSK_EINVAL;
@@ -224,13 +237,17 @@ extern "C" int psk_comm_alltoallv_device(psk_ctx *ctx, const void *send_dev, con
     for (int r = 0; r < c->world; r++) { tot_s += send_counts[r]; tot_r += recv_counts[r]; }
     if ((tot_s && !send_dev) || (tot_r && !recv_dev)) return psk_fail(ctx, PSK_EINVAL, "null buffer");
     PSK_NCCL(ctx, g_rccl.GroupStart());
-    for (int r = 0; r < c->world; r++) {
-        if (send_counts[r]) PSK_NCCL(ctx, g_rccl.Send(sp, (size_t)send_counts[r], dt, r, c->comm, c->stream));
-        if (recv_counts[r]) PSK_NCCL(ctx, g_rccl.Recv(rp, (size_t)recv_counts[r], dt, r, c->comm, c->stream));
+    // an error between GroupStart and GroupEnd must not leave the group open: remember it, close the group, report it
+    ncclResult_t bad = ncclSuccess;
+    for (int r = 0; r < c->world && bad == ncclSuccess; r++) {
+        if (send_counts[r]) bad = g_rccl.Send(sp, (size_t)send_counts[r], dt, r, c->comm, c->stream);
+        if (recv_counts[r] && bad == ncclSuccess) bad = g_rccl.Recv(rp, (size_t)recv_counts[r], dt, r, c->comm, c->stream);
         sp += send_counts[r] * (uint64_t)elem_bytes;
         rp += recv_counts[r] * (uint64_t)elem_bytes;
     }
-    PSK_NCCL(ctx, g_rccl.GroupEnd());
+    const ncclResult_t ended = g_rccl.GroupEnd();
+    if (bad != ncclSuccess) return psk_fail(ctx, PSK_EHIP, "ncclSend / ncclRecv failed inside the all-to-all group: %s", g_rccl.GetErrorString(bad));
+    PSK_NCCL(ctx, ended);
     PSK_HIP(ctx, hipStreamSynchronize(c->stream));
     return PSK_OK;
 }

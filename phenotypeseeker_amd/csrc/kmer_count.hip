@@ -967,7 +967,7 @@ static int count_batch_impl(psk_ctx *ctx, int first_sample_idx, int n, const uin
             cv.wait(lk, [&] { return state[i] != 0; });
             t_worker += since(t0);
             if (state[i] == -2)
-                return psk_fail(ctx, PSK_EINVAL, "sample %d (%s) is gzip-compressed: inflate it and use the in-memory call",
+                return psk_fail(ctx, PSK_EGZIP, "sample %d (%s) is gzip-compressed: inflate it and use the in-memory call",
                                 first_sample_idx + i, paths[i]);
             if (state[i] < 0)
                 return psk_fail(ctx, PSK_ERANGE, paths ? "reading or framing sample %d (%s) failed" : "framing of sample %d failed",

@@ -192,6 +192,7 @@ int sample_bits(int n_samples)
 }  // namespace
 
 int build_presence_tiled(psk_ctx *ctx, uint64_t total_pairs, uint64_t *n_kmers, int *done);  // presence_tiled.hip
+int build_presence_merge(psk_ctx *ctx, uint64_t total_pairs, uint64_t *n_kmers, int *done);  // presence_merge.hip
 
 static int padded_wpr(int n_samples)
 {
@@ -246,6 +247,20 @@ extern "C" int psk_build_presence(psk_ctx *ctx, uint64_t *n_kmers)
         PSK_TRY(build_presence_tiled(ctx, total, &M, &done));
         if (done) {
             pt.mark("tiled build");
+            ctx->n_kmers = M;
+            ctx->have_presence = true;
+            ctx->dense_hint = -1;
+            ctx->last.valid = false;
+            if (n_kmers) *n_kmers = M;
+            return PSK_OK;
+        }
+    }
+    {   // word spaces of up to 2^34 values (k <= 17): the streaming merge of the sorted lists (presence_merge.hip)
+        uint64_t M = 0;
+        int done = 0;
+        PSK_TRY(build_presence_merge(ctx, total, &M, &done));
+        if (done) {
+            pt.mark("merge build");
             ctx->n_kmers = M;
             ctx->have_presence = true;
             ctx->dense_hint = -1;

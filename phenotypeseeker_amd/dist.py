@@ -11,7 +11,8 @@ path needs:
 
 One process per GPU.  The collectives run on RCCL over xGMI, bound directly by libpsk.so (csrc/comm.hip:
 ncclCommInitRank / ncclAllReduce / ncclAllGather / ncclSend+ncclRecv on the library's own stream); the 128-byte
-unique id travels through a rendezvous file.  No PyTorch anywhere in this package: tests that have no second GPU
+unique id travels through a private rendezvous directory of the launch (launch.py, or a per-user 0700 directory keyed
+by the launcher process).  No PyTorch anywhere in this package: tests that have no second GPU
 inject a host transport (tests/_gloo_transport.py, named by PSK_DIST_TRANSPORT=module:Class).  With world size 1
 nothing here touches a communicator.
 """
@@ -121,39 +122,107 @@ class DeviceBuffer:
             pass
 
 
-def _rendezvous_path():
-    p = os.environ.get("PSK_RDZV_FILE")
-    if p:
-        return p
-    # all ranks of one launch share the launcher as their parent (torch.distributed.run's agent, a test's Popen loop)
-    key = "%s_%s_%s_%d" % (os.environ.get("MASTER_ADDR", "127.0.0.1"), os.environ.get("MASTER_PORT", "0"),
-                           os.environ.get("TORCHELASTIC_RUN_ID", "none"), os.getppid())
-    return os.path.join(tempfile.gettempdir(), "psk_rdzv_" + "".join(c if c.isalnum() else "_" for c in key))
+_MAGIC = b"PSKRDZV1"
+_rdzv_seq = [0]     # transports this process has formed: every rank forms them in the same order, so the n-th one of a
+                    # launch meets under the same names on every rank
 
 
-def exchange_unique_id(rank, world, make_id, timeout=300.0, path=None):
-    """Rank 0 creates the id and publishes it atomically (write + rename) in the rendezvous file; the others poll
-    for it.  The file name carries the launcher's pid, so a later launch cannot pick up a stale id; rank 0 removes
-    the file once every rank has joined the communicator."""
-    path = path or _rendezvous_path()
+def _parent_start_ticks():
+    """Start time (clock ticks since boot) of the parent process, from /proc/<ppid>/stat: together with its pid it
+    names ONE launcher process for ever -- a later launcher that gets the same pid has another start time."""
+    try:
+        with open("/proc/%d/stat" % os.getppid(), "rb") as f:
+            return f.read().rsplit(b")", 1)[1].split()[19].decode()
+    except (OSError, IndexError):
+        return "0"
+
+
+def _private_dir(path):
+    """mkdir -p `path` with mode 0700 and refuse a directory that somebody else owns, that others can write, or that is
+    a symlink (a multi-user box: nobody may plant ids or status files where the ranks meet)."""
+    try:
+        os.mkdir(path, 0o700)
+    except FileExistsError:
+        pass
+    st = os.lstat(path)
+    import stat as _stat
+    if not _stat.S_ISDIR(st.st_mode) or st.st_uid != os.getuid() or (st.st_mode & 0o022):
+        raise RuntimeError("rendezvous directory %s is not a private directory of this user (owner %d, mode %o): set "
+                           "PSK_RDZV_DIR to a fresh directory of your own" % (path, st.st_uid, st.st_mode & 0o777))
+    return path
+
+
+def _rendezvous():
+    """(directory, nonce) where the ranks of THIS launch meet.
+      * PSK_RDZV_DIR + PSK_LAUNCH_NONCE: set by this package's own launcher (launch.spawn_ranks): a mkdtemp directory
+        made for the launch, and a random nonce every id blob must carry;
+      * PSK_RDZV_FILE (a path the caller promises is fresh for this launch): the directory `<file>.rdzv`;
+      * otherwise a per-user 0700 directory under the temp dir, then one per launch keyed by MASTER_ADDR / MASTER_PORT /
+        the run id AND the launcher process (pid + start time of the parent all ranks share -- torchrun's agent, a
+        test's Popen loop), so that a stale file of an earlier or crashed launch can never be met.
+    Ranks that do not share a parent (one `bash -c` or srun wrapper per rank) must be given PSK_RDZV_DIR (or
+    PSK_RDZV_FILE) by whoever starts them: the error of the rendezvous timing out says so."""
+    nonce = os.environ.get("PSK_LAUNCH_NONCE", "")
+    d = os.environ.get("PSK_RDZV_DIR")
+    if d:
+        return _private_dir(d), nonce
+    f = os.environ.get("PSK_RDZV_FILE")
+    if f:
+        return _private_dir(f + ".rdzv"), nonce
+    key = "%s_%s_%s_%d_%s" % (os.environ.get("MASTER_ADDR", "127.0.0.1"), os.environ.get("MASTER_PORT", "0"),
+                              os.environ.get("TORCHELASTIC_RUN_ID", "none"), os.getppid(), _parent_start_ticks())
+    key = "".join(c if c.isalnum() else "_" for c in key)
+    base = _private_dir(os.path.join(tempfile.gettempdir(), "psk_rdzv_u%d" % os.getuid()))
+    return _private_dir(os.path.join(base, key)), nonce or key
+
+
+def _publish(path, payload):
+    """Atomic, exclusive publication: the temporary is created with O_EXCL (nobody's planted file is followed), then
+    renamed over the name."""
+    tmp = "%s.%d.tmp" % (path, os.getpid())
+    try:
+        os.unlink(tmp)
+    except OSError:
+        pass
+    fd = os.open(tmp, os.O_WRONLY | os.O_CREAT | os.O_EXCL, 0o600)
+    with os.fdopen(fd, "wb") as fh:
+        fh.write(payload)
+    os.replace(tmp, path)
+
+
+def exchange_unique_id(rank, world, make_id, timeout=300.0, rdzv=None, seq=0):
+    """Rank 0 removes whatever an earlier transport of the same name left behind (id, collective files),
+    creates the id and publishes it as MAGIC | nonce | id; the others poll for a blob that carries THIS launch's nonce
+    (anything else -- a stale or foreign file -- is ignored).  Returns (id, path of the id file): rank 0 unlinks it once
+    every rank has joined the communicator, and on failure."""
+    d, nonce = rdzv or _rendezvous()
+    path = os.path.join(d, "id.%d" % seq)
+    nb = nonce.encode()
     if rank == 0:
+        import shutil
+        for name in os.listdir(d):
+            if name == "id.%d" % seq or name == "coll.%d" % seq:     # (status files are written by ranks that may be ahead of rank 0)
+                full = os.path.join(d, name)
+                shutil.rmtree(full, ignore_errors=True) if os.path.isdir(full) else os.unlink(full)
         uid = make_id()
-        tmp = "%s.%d.tmp" % (path, os.getpid())
-        with open(tmp, "wb") as f:
-            f.write(len(uid).to_bytes(4, "little") + uid)
-        os.replace(tmp, path)
+        _publish(path, _MAGIC + len(nb).to_bytes(2, "little") + nb + len(uid).to_bytes(4, "little") + uid)
         return uid, path
     t0 = time.time()
     while True:
         try:
             with open(path, "rb") as f:
                 blob = f.read()
-            if len(blob) >= 4 and len(blob) == 4 + int.from_bytes(blob[:4], "little"):
-                return blob[4:], path
+            if blob[:8] == _MAGIC and len(blob) >= 14:
+                ln = int.from_bytes(blob[8:10], "little")
+                if blob[10:10 + ln] == nb and len(blob) >= 14 + ln:
+                    lu = int.from_bytes(blob[10 + ln:14 + ln], "little")
+                    if len(blob) == 14 + ln + lu:
+                        return blob[14 + ln:], path
         except OSError:
             pass
         if time.time() - t0 > timeout:
-            raise RuntimeError("rank %d: no unique id in %s after %.0f s (is rank 0 running?)" % (rank, path, timeout))
+            raise RuntimeError("rank %d: no unique id of this launch in %s after %.0f s (is rank 0 running?  Ranks that do "
+                               "not share a parent process must be given the same PSK_RDZV_DIR)" % (rank, path, timeout))
         time.sleep(0.01)
 
 
@@ -179,23 +248,28 @@ class RcclTransport:
     name = "rccl"
     device_memory = True
 
-    def __init__(self, rank, world, device):
+    def __init__(self, rank, world, device, rdzv=None, seq=0):
         self.rank, self.world, self.device = rank, world, device
         self.ctx = PskContext(device)
+        self._rdzv = None
         try:
-            uid, self._rdzv = exchange_unique_id(rank, world, self.ctx.comm_unique_id)
+            uid, self._rdzv = exchange_unique_id(rank, world, self.ctx.comm_unique_id, rdzv=rdzv, seq=seq)
             with _stdout_to_stderr():       # RCCL prints a version banner on stdout; a caller's stdout may be a protocol
                 self.ctx.comm_init(uid, rank, world)
             self.stream = self.ctx.comm_stream()
             self.barrier()                  # every rank has joined: the file is no longer needed
+            self.n_ranks = self.ctx.comm_size()     # ncclCommCount: what a measurement quotes as "rccl_ranks"
+            if self.n_ranks != world:
+                raise RuntimeError("ncclCommCount = %d in a world of %d" % (self.n_ranks, world))
         except Exception:
             self.ctx.close()
             raise
-        if rank == 0:
-            try:
-                os.unlink(self._rdzv)
-            except OSError:
-                pass
+        finally:
+            if rank == 0 and self._rdzv:    # joined, or failed: either way the id is not left behind
+                try:
+                    os.unlink(self._rdzv)
+                except OSError:
+                    pass
 
     def alloc(self, nbytes):
         return DeviceBuffer(self.ctx, nbytes)
@@ -227,18 +301,20 @@ class RcclTransport:
 
 class HostFileTransport:
     """The same collectives through files in a directory beside the rendezvous file (ranks of ONE node): what a run
-    falls back to -- loudly, and named in `Group.backend` -- when RCCL cannot form the communicator (two ranks mapped
-    onto one GPU; a node without peer access).  Collective `seq` of rank r is the file `<seq>.<r>`, published by
-    rename; a rank removes its file of collective seq - 2 when it has finished seq - 1 (every rank has then read
-    it).  Device buffers are staged through the host.  Unset with PSK_DIST_STRICT=1."""
+    falls back to -- loudly, and named in `Group.backend` -- when RCCL cannot form the communicator AND the run has
+    opted in (PSK_DIST_ALLOW_HOST_FILES=1, or PSK_SHARE_GPU=1: several ranks mapped onto one GPU, which RCCL refuses --
+    the one-GPU test boxes); without the opt-in a failed communicator is an error (see _rccl_or_host_files).  Collective
+    `seq` of rank r is the file `<seq>.<r>` in a 0700 directory of this launch, published by rename; a rank removes its
+    file of collective seq - 2 when it has finished seq - 1 (every rank has then read it).  Device buffers are staged
+    through the host.  NOT a performance path: a measurement taken over it says so ("scaling": "invalid ...")."""
     name = "host-files"
     device_memory = True
     stream = 0          # no collective stream: exports are the waited-for form
 
-    def __init__(self, rank, world, device, path=None, timeout=600.0):
+    def __init__(self, rank, world, device, rdzv=None, seq=0, timeout=600.0):
         self.rank, self.world, self.device, self.timeout = rank, world, device, timeout
-        self.dir = (path or _rendezvous_path()) + ".d"
-        os.makedirs(self.dir, exist_ok=True)
+        d, _ = rdzv or _rendezvous()
+        self.dir = _private_dir(os.path.join(d, "coll.%d" % seq))
         self.seq = 0
         self.ctx = PskContext(device)
         self.barrier()
@@ -249,10 +325,7 @@ class HostFileTransport:
     def _exchange(self, payload):
         """all-gather(v) of one bytes object per rank."""
         seq, self.seq = self.seq, self.seq + 1
-        tmp = self._name(seq, self.rank) + ".tmp"
-        with open(tmp, "wb") as f:
-            f.write(payload)
-        os.replace(tmp, self._name(seq, self.rank))
+        _publish(self._name(seq, self.rank), payload)
         out = []
         t0 = time.time()
         for r in range(self.world):
@@ -342,48 +415,77 @@ class HostFileTransport:
         self.ctx.close()
 
 
-def _rccl_or_host_files(rank, world, device):
-    """RCCL; when the communicator cannot be formed on some rank every rank learns it (one status file per rank next
-    to the rendezvous file) and all of them take the host-file transport together."""
-    path = _rendezvous_path()
-    t, err = None, ""
-    try:
-        t = RcclTransport(rank, world, device)
-    except Exception as e:      # PskError from psk_comm_init, or the rendezvous timing out
-        if os.environ.get("PSK_DIST_STRICT") == "1":
-            raise
-        err = "%s: %s" % (type(e).__name__, e)
+def host_files_allowed():
+    """The host-file fallback is OPT-IN: PSK_DIST_ALLOW_HOST_FILES=1, or PSK_SHARE_GPU=1 (ranks share GPUs, where RCCL
+    cannot work at all).  PSK_DIST_STRICT=1 wins over both."""
     if os.environ.get("PSK_DIST_STRICT") == "1":
-        return t
-    mine = "%s.st.%d" % (path, rank)
-    with open(mine + ".tmp", "w") as f:
-        f.write(err)
-    os.replace(mine + ".tmp", mine)
-    errs, t0 = [], time.time()
+        return False
+    return os.environ.get("PSK_DIST_ALLOW_HOST_FILES") == "1" or os.environ.get("PSK_SHARE_GPU") == "1"
+
+
+def _exchange_status(d, prefix, rank, world, text, timeout=600.0):
+    """Every rank publishes one short text under `<prefix>.<rank>` and reads everybody's: [text of rank 0, ...]."""
+    _publish(os.path.join(d, "%s.%d" % (prefix, rank)), (text or "ok").encode())
+    out, t0 = [], time.time()
     for r in range(world):
         while True:
             try:
-                with open("%s.st.%d" % (path, r)) as f:
-                    errs.append(f.read())
+                with open(os.path.join(d, "%s.%d" % (prefix, r))) as f:
+                    out.append(f.read())
                 break
             except OSError:
-                if time.time() - t0 > 600:
-                    raise RuntimeError("rank %d: no transport status from rank %d" % (rank, r))
+                if time.time() - t0 > timeout:
+                    raise RuntimeError("rank %d: no status `%s` from rank %d after %.0f s%s"
+                                       % (rank, prefix, r, timeout, ("; this rank: " + text) if text else ""))
                 time.sleep(0.005)
-    bad = [(r, e) for r, e in enumerate(errs) if e]
+    return out
+
+
+def _rccl_or_host_files(rank, world, device):
+    """RCCL.  Two rounds of one status file per rank in the launch's rendezvous directory make every decision a
+    decision of ALL ranks: (1) before anybody enters ncclCommInitRank -- which blocks until every rank has called it --
+    each rank says whether it has its GPU (a rank without a device would leave the others waiting for ever); (2) after
+    it, whether the communicator was formed.  When some rank failed, all ranks raise together: a run whose ranks have
+    their own GPUs never continues on anything but RCCL, so a curve measured through /tmp files cannot pass for a
+    result -- unless the run has opted into the host-file transport (host_files_allowed), which all ranks
+    then take together, with a warning on stderr and the reason in `fallback_reason`."""
+    rdzv = _rendezvous()
+    seq = _rdzv_seq[0]
+    _rdzv_seq[0] += 1
+    d = rdzv[0]
+    t, err = None, ""
+    try:
+        probe = PskContext(device)      # does this rank's GPU exist?
+        probe.close()
+    except Exception as e:
+        err = "%s: %s" % (type(e).__name__, e)
+    errs = _exchange_status(d, "rd.%d" % seq, rank, world, err)
+    if all(e == "ok" for e in errs):
+        try:
+            t = RcclTransport(rank, world, device, rdzv=rdzv, seq=seq)
+        except Exception as e:      # PskError from psk_comm_init, or the rendezvous timing out
+            err = "%s: %s" % (type(e).__name__, e)
+        errs = _exchange_status(d, "st.%d" % seq, rank, world, err)
+    bad = [(r, e) for r, e in enumerate(errs) if e != "ok"]
     if bad:
         if t is not None:
             t.close()
+        if not host_files_allowed():
+            raise RuntimeError("RCCL communicator not formed (rank %d: %s).  Every rank has its own GPU, so nothing else "
+                               "will do; tests on a one-GPU box opt into the host-file transport with PSK_SHARE_GPU=1 or "
+                               "PSK_DIST_ALLOW_HOST_FILES=1" % bad[0])
         if rank == 0:
             sys.stderr.write("phenotypeseeker_amd.dist: RCCL communicator not formed (rank %d: %s); collectives go "
-                             "through host files in %s.d (PSK_DIST_STRICT=1 makes this an error)\n" % (bad[0][0], bad[0][1], path))
-        t = HostFileTransport(rank, world, device, path)
+                             "through host files in %s (allowed by PSK_SHARE_GPU / PSK_DIST_ALLOW_HOST_FILES)\n"
+                             % (bad[0][0], bad[0][1], d))
+        t = HostFileTransport(rank, world, device, rdzv=rdzv, seq=seq)
         t.fallback_reason = bad[0][1]
-    t.barrier()
-    try:
-        os.unlink(mine)
-    except OSError:
-        pass
+    t.barrier()     # everybody has read every status file
+    for prefix in ("rd", "st"):
+        try:
+            os.unlink(os.path.join(d, "%s.%d.%d" % (prefix, seq, rank)))
+        except OSError:
+            pass
     return t
 
 
@@ -398,6 +500,7 @@ class Group:
         self.device = self.local_rank   # GPU index of this rank (see init: PSK_SHARE_GPU)
         self.t = None                   # transport
         self.backend = None
+        self.rccl_ranks = 0
 
     def init(self, transport=None, force=False):
         """transport: None (RCCL, or the class named by PSK_DIST_TRANSPORT=module:Class -- tests), or an
@@ -417,6 +520,7 @@ class Group:
             transport = cls(self.rank, self.world, self.device) if cls else _rccl_or_host_files(self.rank, self.world, self.device)
         self.t = transport
         self.backend = transport.name
+        self.rccl_ranks = int(getattr(transport, "n_ranks", 0))     # ncclCommCount; 0 unless the transport IS RCCL
         return self
 
     def barrier(self):

@@ -39,7 +39,7 @@ class PskContext:
     # -- plumbing -------------------------------------------------------------------------------
     def _check(self, rc, what):
         if rc != 0:
-            raise PskError("%s failed (%d): %s" % (what, rc, self._lib.psk_last_error(self._h).decode()))
+            raise PskError("%s failed (%d): %s" % (what, rc, self._lib.psk_last_error(self._h).decode()), code=rc)
 
     def close(self):
         if getattr(self, "_h", None):
@@ -267,6 +267,13 @@ class PskContext:
 
     def comm_init(self, uid, rank, world):
         self._check(self._lib.psk_comm_init(self._h, bytes(uid), len(uid), int(rank), int(world)), "psk_comm_init")
+
+    def comm_size(self):
+        """ncclCommCount of this context's communicator."""
+        n = self._lib.psk_comm_size(self._h)
+        if n < 0:
+            self._check(n, "psk_comm_size")
+        return n
 
     def comm_stream(self):
         return self._lib.psk_comm_stream(self._h) or 0

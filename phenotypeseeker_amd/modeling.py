@@ -25,7 +25,7 @@ import numpy as np
 from . import dist as _dist
 from . import formats, metrics, _stats
 from .engine import PskContext
-from ._lib import PskError
+from ._lib import PSK_EGZIP, PskError
 from .model import GridSearch, L1LogisticRegression, L2LogisticRegression, LassoRegression, RidgeRegression
 
 RED_BANNER = "\x1b[1;1;101m%s\x1b[0m\n"
@@ -100,21 +100,12 @@ class Samples:
                 biggest = 1 << 29
             chunk = int(min(64, max(1, (1 << 29) // max(biggest, 1))))
         sketch = (21, 1000, 42) if cls.use_weights else None  # was: mash sketch -r <address> (:386-390): k=21, s=1000, seed 42
-        # uncompressed inputs are read by the library's own threads (psk_count_kmers_files): no file image passes through
-        # Python.  The library refuses a gzip-compressed file (by its magic bytes): the whole set then takes the
-        # in-memory route below, where the files are inflated first.
-        if not any(s.address.endswith(".gz") for s in samples):
-            try:
-                done = []
-                for lo in range(0, len(samples), chunk):
-                    part = samples[lo:lo + chunk]
-                    done.append((part, ctx.count_kmers_files(lo, [s.address for s in part], n_threads, sketch=sketch)))
-                for part, res in done:
-                    cls._record_lists(part, res)
-                return
-            except PskError as exc:
-                if "gzip" not in str(exc):
-                    raise
+        # Uncompressed inputs are read by the library's own threads (psk_count_kmers_files): no file image passes through
+        # Python.  Compressed ones (gzip by its magic bytes -- two bytes per file, probed by the thread pool; the
+        # suffix alone is not trusted) are inflated here and handed over in memory.  The route is chosen PER CHUNK, so a
+        # compressed file in a later chunk never sends the samples already counted through the context again (ADVICE
+        # r02: the old whole-set fallback recounted from sample 0 and held their list memory twice).  The library
+        # checks the magic bytes too and answers PSK_EGZIP: a file that changed under the probe still ends up inflated.
         # chunk boundaries ramp up (8, 16, 32, ...): the first read is short, later calls amortise their set-up
         bounds, lo, step = [], 0, min(chunk, 8)
         while lo < len(samples):
@@ -122,15 +113,25 @@ class Samples:
             lo += step
             step = min(chunk, step * 2)
         with ThreadPoolExecutor(max_workers=n_threads) as pool:
-            def submit(b):
+            zipped = list(pool.map(lambda s: s.address.endswith(".gz") or formats.is_gzip(s.address), samples))
+
+            def submit(b):   # the compressed chunks are read (and inflated) one chunk ahead of the counting
+                if b is None or not any(zipped[b[0]:b[1]]):
+                    return None
                 return [pool.submit(formats.read_sequence_file, s.address) for s in samples[b[0]:b[1]]]
-            pending = submit(bounds[0])
+            pending = submit(bounds[0]) if bounds else None
             for bi, (lo, hi) in enumerate(bounds):
                 part = samples[lo:hi]
-                datas = [f.result() for f in pending]
-                # the next chunk is read while this one is counted
-                pending = submit(bounds[bi + 1]) if bi + 1 < len(bounds) else []
-                cls._record_lists(part, ctx.count_kmers_batch(lo, datas, n_threads, sketch=sketch))
+                reads, pending = pending, submit(bounds[bi + 1] if bi + 1 < len(bounds) else None)
+                if reads is None:
+                    try:
+                        cls._record_lists(part, ctx.count_kmers_files(lo, [s.address for s in part], n_threads, sketch=sketch))
+                        continue
+                    except PskError as exc:
+                        if exc.code != PSK_EGZIP:
+                            raise
+                    reads = [pool.submit(formats.read_sequence_file, s.address) for s in part]
+                cls._record_lists(part, ctx.count_kmers_batch(lo, [f.result() for f in reads], n_threads, sketch=sketch))
 
     @classmethod
     def _pilot_bounds(cls, group, k, cnt, counted):

@@ -10,7 +10,7 @@ from collections import OrderedDict
 import numpy as np
 
 from . import formats
-from ._lib import PskError
+from ._lib import PSK_EGZIP, PskError
 from .engine import PskContext
 
 
@@ -43,11 +43,13 @@ class Samples:
         inflated here first), one kernel per sample, one read-back."""
         paths = [s.address for s in samples]
         counts = None
-        if not any(p.endswith(".gz") for p in paths):
+        # gzip by the magic bytes (two bytes per file; the suffix alone is not trusted): such files are inflated here
+        zipped = any(p.endswith(".gz") or formats.is_gzip(p) for p in paths)
+        if not zipped:
             try:
                 counts = ctx.count_dict_files(paths, pheno.k, pheno.words, n_threads)
-            except PskError as exc:       # a gzip-compressed file without the suffix: inflate on the host
-                if "gzip" not in str(exc):
+            except PskError as exc:       # the library checks the magic bytes too (a file that changed under the probe)
+                if exc.code != PSK_EGZIP:
                     raise
         if counts is None:
             counts = np.zeros((len(paths), len(pheno.words)), dtype=np.uint32)

@@ -19,7 +19,8 @@ assert "torch" not in sys.modules
 g = dist.Group()
 g.world, g.rank, g.local_rank = 1, 0, 0
 g.init(force=True)
-assert g.backend == "rccl" and not os.path.exists(os.environ["PSK_RDZV_FILE"])
+assert g.backend == "rccl" and g.rccl_ranks == 1             # ncclCommCount
+assert os.listdir(os.environ["PSK_RDZV_FILE"] + ".rdzv") == []  # id and status files are gone once every rank has joined
 assert g.allreduce_sum(41) == 41 and g.allreduce_sum(0.5) == 0.5 and g.allreduce_max(3.0) == 3.0
 assert g.allreduce_sum((1 << 63) + 5) == (1 << 63) + 5          # u64, not i64
 assert g.allgather_bytes(b"slab") == [b"slab"] and g.allgather_bytes(b"") == [b""]

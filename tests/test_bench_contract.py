@@ -48,20 +48,23 @@ def test_bench_two_ranks_run_the_sharded_pipeline():
     d1 = json.loads(one.stdout.strip().splitlines()[-1])
     for port, ingest, transport in ((29631, "filter", "gloo"), (29633, "exchange", "gloo"), (29635, "filter", "host-files"),
                                     (29637, "exchange", "host-files")):
-        # without a named transport RCCL is tried, refuses the shared GPU on both ranks, and the run falls back -- loudly --
-        # to the host-file transport of dist.py
-        env_t = env if transport == "gloo" else {k_: v for k_, v in env.items() if k_ != "PSK_DIST_TRANSPORT"}
-        cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
-               "--master-port", str(port), os.path.join(ROOT, "bench.py"), "--gpus", "2", "--share-gpu", "--ingest", ingest] + size
+        # `python bench.py --gpus 2` with NO outside launcher: bench.py itself starts the two ranks (launch.py).  Without
+        # a named transport RCCL is tried, refuses the shared GPU on both ranks, and -- because --share-gpu opts into it --
+        # the run falls back, loudly, to the host-file transport of dist.py
+        env_t = dict(env, MASTER_PORT=str(port)) if transport == "gloo" else {k_: v for k_, v in env.items() if k_ != "PSK_DIST_TRANSPORT"}
+        for var in ("WORLD_SIZE", "RANK", "LOCAL_RANK"):
+            env_t.pop(var, None)
+        cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--share-gpu", "--ingest", ingest] + size
         if transport == "gloo":
-            cmd.append("--no-e2e")   # the CLI children of the e2e leg would open a second torch process group on the launcher's store
+            cmd.append("--no-e2e")   # the CLI children of the e2e leg would open a second gloo group on the same port
         r = subprocess.run(cmd, env=env_t, cwd=ROOT, timeout=900, capture_output=True, text=True)
         assert r.returncode == 0, r.stderr[-3000:]
-        lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
-        assert len(lines) == 1
-        d = json.loads(lines[0])
+        lines = [l for l in r.stdout.splitlines() if l.strip()]
+        assert lines[-1].startswith("{") and sum(l.startswith("{") for l in lines) == 1     # rank 0's line, relayed last
+        d = json.loads(lines[-1])
         cfg = d["config"]
-        assert d["n_gpus"] == 2 and d["scaling"] == "strong"
+        # two ranks on one GPU over a host transport: a correctness run, and the line says so
+        assert d["n_gpus"] == 2 and d["scaling"].startswith("invalid (") and d["rccl_ranks"] == 0
         if transport == "gloo":
             assert cfg["collectives"] == "gloo"
         else:
@@ -75,3 +78,22 @@ def test_bench_two_ranks_run_the_sharded_pipeline():
             e2e = d["e2e"]
             assert "error" not in e2e, e2e
             assert e2e["modeling_wall_s"] > 0 and e2e["ranks"] == 2 and "log_reg_model_Pheno.pkl" in e2e["what"]
+
+
+def test_bench_without_rccl_and_without_the_opt_in_fails():
+    """Un-fakeable N > 1 (VERDICT r02 / ADVICE r02): two ranks that CLAIM a GPU each (no --share-gpu) on a one-GPU box --
+    rank 1's device does not exist, RCCL cannot form the communicator -- must not fall back to host files: rc != 0 and
+    no JSON line.  With `--force-exchange` on one GPU the step runs on a one-rank RCCL communicator and quotes
+    ncclCommCount."""
+    env = {k_: v for k_, v in os.environ.items() if k_ not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "PSK_DIST_TRANSPORT", "PSK_SHARE_GPU",
+                                                            "PSK_DIST_ALLOW_HOST_FILES")}
+    size = ["--samples", "64", "--length", "200000", "--kmer", "16", "--steps", "3", "--warmup", "1", "--no-e2e", "--no-cpu-baseline"]
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2"] + size, env=env, cwd=ROOT, timeout=600,
+                       capture_output=True, text=True)
+    assert r.returncode != 0
+    assert not [l for l in r.stdout.splitlines() if l.startswith("{")]
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "1", "--force-exchange"] + size, env=env, cwd=ROOT,
+                       timeout=600, capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr[-2000:]
+    d = json.loads(r.stdout.strip().splitlines()[-1])
+    assert d["rccl_ranks"] == 1 and d["config"]["collectives"] == "rccl" and d["scaling"] == "weak"

@@ -5,6 +5,7 @@ import subprocess
 import sys
 
 import numpy as np
+import pytest
 
 from helpers import ROOT, load_dataset
 
@@ -54,24 +55,137 @@ def test_balanced_bounds_on_uniform_and_at_rich_genomes(oracle):
     assert all(x < y for x, y in zip(b[:-2], b[1:-1])) and b[-2] < 64
 
 
-def test_rendezvous_file_carries_the_unique_id(tmp_path):
-    """The RCCL unique id travels through a file: rank 0 publishes atomically, the others poll."""
+def test_rendezvous_carries_the_unique_id_and_ignores_stale_or_foreign_files(tmp_path):
+    """The RCCL unique id travels through a private directory: rank 0 publishes atomically, the others poll.  A blob
+    without this launch's nonce (a stale file of a crashed run, somebody else's file) is never accepted, rank 0 clears
+    what an earlier transport of the same name left behind, and a directory others can write is refused."""
     import threading
     from phenotypeseeker_amd import dist
-    path = os.path.join(tmp_path, "rdzv")
+    d = dist._private_dir(os.path.join(tmp_path, "rdzv"))
+    assert os.stat(d).st_mode & 0o077 == 0
+    # leftovers of an earlier launch under the same names: an id with another nonce, a collective directory
+    dist._publish(os.path.join(d, "id.0"), dist._MAGIC + (3).to_bytes(2, "little") + b"old" + (4).to_bytes(4, "little") + b"dead")
+    os.mkdir(os.path.join(d, "coll.0"))
     got = {}
 
     def reader(r):
-        got[r] = dist.exchange_unique_id(r, 3, None, timeout=20, path=path)[0]
+        got[r] = dist.exchange_unique_id(r, 3, None, timeout=20, rdzv=(d, "nonce-of-this-launch"))[0]
 
     ts = [threading.Thread(target=reader, args=(r,)) for r in (1, 2)]
     for t in ts:
         t.start()
+    import time
+    time.sleep(0.3)
+    assert got == {}                       # the stale id is there, and nobody took it
     uid = bytes(range(128))
-    assert dist.exchange_unique_id(0, 3, lambda: uid, path=path)[0] == uid
+    assert dist.exchange_unique_id(0, 3, lambda: uid, rdzv=(d, "nonce-of-this-launch"))[0] == uid
     for t in ts:
         t.join()
     assert got == {1: uid, 2: uid}
+    assert sorted(os.listdir(d)) == ["id.0"]      # rank 0 removed the leftovers before publishing
+    with pytest.raises(RuntimeError):
+        dist.exchange_unique_id(1, 2, None, timeout=0.3, rdzv=(d, "another-launch"))
+    loose = os.path.join(tmp_path, "loose")
+    os.mkdir(loose, 0o777)
+    os.chmod(loose, 0o777)
+    with pytest.raises(RuntimeError):
+        dist._private_dir(loose)
+    # the default meeting place is keyed by the launcher process: pid AND start time of the parent
+    for var in ("PSK_RDZV_DIR", "PSK_RDZV_FILE", "PSK_LAUNCH_NONCE"):
+        os.environ.pop(var, None)
+    d1, n1 = dist._rendezvous()
+    assert str(os.getppid()) in os.path.basename(d1) and dist._parent_start_ticks() in os.path.basename(d1) and n1
+    assert os.stat(os.path.dirname(d1)).st_mode & 0o077 == 0
+    os.rmdir(d1)
+
+
+def test_launcher_starts_ranks_relays_rank0_and_returns_the_worst_code(tmp_path):
+    """launch.spawn_ranks (what `bench.py --gpus N` and `PSK_GPUS=N phenotypeseeker ...` use instead of an outside
+    launcher): one child per rank with RANK / LOCAL_RANK / WORLD_SIZE, a private rendezvous directory and a nonce;
+    rank 0's stdout is the launcher's, the other ranks' goes to stderr; the exit code is the worst rank's, and a rank
+    that hangs after another has failed is terminated."""
+    prog = os.path.join(tmp_path, "rank.py")
+    with open(prog, "w") as f:
+        f.write("import os, sys, time\n"
+                "r, w = int(os.environ['RANK']), int(os.environ['WORLD_SIZE'])\n"
+                "d = os.environ['PSK_RDZV_DIR']\n"
+                "assert os.stat(d).st_mode & 0o077 == 0 and len(os.environ['PSK_LAUNCH_NONCE']) == 32 and os.environ['LOCAL_RANK'] == str(r)\n"
+                "print('line of rank %d of %d' % (r, w), flush=True)\n"
+                "mode = sys.argv[1]\n"
+                "if mode == 'fail' and r == 1: sys.exit(7)\n"
+                "if mode == 'fail' and r == 2: time.sleep(600)\n")
+    code = "import sys; sys.path.insert(0, %r); from phenotypeseeker_amd import launch; sys.exit(launch.spawn_ranks([%r, sys.argv[1]], 3, grace_s=1.0))" % (ROOT, prog)
+    r = subprocess.run([sys.executable, "-c", code, "ok"], capture_output=True, text=True, timeout=120)
+    assert r.returncode == 0 and r.stdout.splitlines() == ["line of rank 0 of 3"]
+    assert "line of rank 1 of 3" in r.stderr and "line of rank 2 of 3" in r.stderr
+    import time
+    t0 = time.time()
+    r = subprocess.run([sys.executable, "-c", code, "fail"], capture_output=True, text=True, timeout=120)
+    assert r.returncode == 7 and time.time() - t0 < 60 and "rank 1 exited with code 7" in r.stderr
+
+
+def test_status_rounds_make_a_failed_rank_everybodys_failure(tmp_path, monkeypatch):
+    """dist._rccl_or_host_files without a GPU (the context is stubbed): a rank that has no device says so BEFORE anybody
+    would enter ncclCommInitRank, and every rank raises -- no fallback unless the run opted in; with the
+    opt-in all ranks take the host-file transport together and carry the reason."""
+    import threading
+    from phenotypeseeker_amd import dist
+
+    class Ctx:
+        def __init__(self, device):
+            if device == 1 and Ctx.break_rank1:
+                raise RuntimeError("no such device")
+
+        def close(self):
+            pass
+    Ctx.break_rank1 = True
+
+    class NoRccl:
+        def __init__(self, rank, world, device, rdzv=None, seq=0):
+            raise AssertionError("ncclCommInitRank must not be reached when a rank has reported a failure")
+    monkeypatch.setattr(dist, "PskContext", Ctx)
+    monkeypatch.setattr(dist, "RcclTransport", NoRccl)
+    monkeypatch.setenv("PSK_RDZV_DIR", str(tmp_path / "meet"))
+    monkeypatch.setenv("PSK_LAUNCH_NONCE", "n1")
+    for var in ("PSK_SHARE_GPU", "PSK_DIST_ALLOW_HOST_FILES", "PSK_DIST_STRICT"):
+        monkeypatch.delenv(var, raising=False)
+    out = {}
+
+    class FirstTransport(list):        # the two "processes" are threads of one module: both form their FIRST transport
+        def __getitem__(self, i):
+            return 0
+
+        def __setitem__(self, i, v):
+            pass
+    monkeypatch.setattr(dist, "_rdzv_seq", FirstTransport([0]))
+
+    def rank_main(r):
+        try:
+            t = dist._rccl_or_host_files(r, 2, r)
+            out[r] = (t.name, getattr(t, "fallback_reason", None))
+            t.close()
+        except Exception as e:  # noqa: BLE001
+            out[r] = repr(e)
+    for allow in (False, True):
+        if allow:
+            monkeypatch.setenv("PSK_DIST_ALLOW_HOST_FILES", "1")
+            monkeypatch.setenv("PSK_RDZV_DIR", str(tmp_path / "meet2"))      # another launch: another meeting place
+            Ctx.break_rank1 = False       # the stand-in for "RCCL refuses": the device is there, the communicator is not
+
+            class Refuses:
+                def __init__(self, rank, world, device, rdzv=None, seq=0):
+                    raise RuntimeError("two ranks on one device")
+            monkeypatch.setattr(dist, "RcclTransport", Refuses)
+        out.clear()
+        th = [threading.Thread(target=rank_main, args=(r,)) for r in range(2)]
+        for x in th:
+            x.start()
+        for x in th:
+            x.join(60)
+        if not allow:
+            assert all("RCCL communicator not formed (rank 1" in out[r] and "no such device" in out[r] for r in range(2)), out
+        else:
+            assert out == {0: ("host-files", "RuntimeError: two ranks on one device"), 1: ("host-files", "RuntimeError: two ranks on one device")}
 
 
 def test_pack_merge_round_trip():
@@ -92,8 +206,12 @@ def test_two_rank_gloo_run_equals_single_rank(tmp_path, oracle):
     out = os.path.join(tmp_path, "merged.npz")
     env = dict(os.environ, MASTER_ADDR="127.0.0.1", OMP_NUM_THREADS="1", PSK_DIST_TRANSPORT="_gloo_transport:GlooTransport",
                PYTHONPATH=os.path.join(ROOT, "tests") + os.pathsep + os.environ.get("PYTHONPATH", ""))
-    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr",
-           "127.0.0.1", "--master-port", "29617", os.path.join(ROOT, "tests", "_dist_worker.py"), out]
+    env["MASTER_PORT"] = "29617"
+    for var in ("WORLD_SIZE", "RANK", "LOCAL_RANK"):
+        env.pop(var, None)
+    # the package's own launcher (launch.spawn_ranks): no outside launcher anywhere in the tests
+    code = "import sys; sys.path.insert(0, %r); from phenotypeseeker_amd import launch; sys.exit(launch.spawn_ranks(sys.argv[1:], 2))" % ROOT
+    cmd = [sys.executable, "-c", code, os.path.join(ROOT, "tests", "_dist_worker.py"), out]
     r = subprocess.run(cmd, env=env, cwd=ROOT, timeout=300, capture_output=True, text=True)
     assert r.returncode == 0, r.stderr[-2000:]
     z = np.load(out)
@@ -134,10 +252,11 @@ def test_host_file_transport_collectives_and_close(tmp_path):
     dist.PskContext = NoCtx
     try:
         world, out, errs = 4, {}, []
+        rd = dist._private_dir(str(tmp_path / "rdzv"))
 
         def rank_main(r):
             try:
-                t = dist.HostFileTransport(r, world, 0, path=str(tmp_path / "rdzv"), timeout=30.0)
+                t = dist.HostFileTransport(r, world, 0, rdzv=(rd, ""), seq=3, timeout=30.0)
                 for it in range(6):
                     s = t.allreduce(np.array([r + it], dtype=np.uint64), "sum")
                     m = t.allreduce(np.array([float(r * it)]), "max")
@@ -161,6 +280,6 @@ def test_host_file_transport_collectives_and_close(tmp_path):
             x.join(60)
         assert not errs, errs
         assert sorted(out) == list(range(world)) and max(out.values()) < 5.0
-        assert not os.path.exists(str(tmp_path / "rdzv") + ".d")      # rank 0 removed the directory last
+        assert os.listdir(rd) == []      # rank 0 removed the collective directory last
     finally:
         dist.PskContext = real

@@ -466,8 +466,8 @@ def test_l2_penalty_end_to_end(tmp_path):
 
 @pytest.mark.parametrize("ranks,flags,ingest", [(2, [], "exchange"), (2, [], "redundant"), (3, ["-w", "--omit_B_correction", "--n_kmers", "100"], "exchange")])
 def test_multi_rank_modeling_writes_the_same_files(tmp_path, ranks, flags, ingest):
-    """SURVEY.md 8(e) invariant on the real pipeline: `phenotypeseeker modeling` under torch.distributed.run with
-    several ranks (all on the one visible GPU, collectives through the gloo transport of tests/: PSK_SHARE_GPU /
+    """SURVEY.md 8(e) invariant on the real pipeline: `PSK_GPUS=<ranks> phenotypeseeker modeling` -- the CLI starts its
+    own ranks (launch.py; no outside launcher) -- with several ranks (all on the one visible GPU, collectives through the gloo transport of tests/: PSK_SHARE_GPU /
     PSK_DIST_TRANSPORT -- RCCL refuses two ranks on one device) and balanced, quantile-cut slabs produces
     byte-identical result tables and the same model as the one-rank run.  Ingest either way: every sample counted
     on one rank and the slab ranges of the lists exchanged (dist.ListExchange, the default), or every rank counting
@@ -485,9 +485,10 @@ def test_multi_rank_modeling_writes_the_same_files(tmp_path, ranks, flags, inges
     env = dict(os.environ, MASTER_ADDR="127.0.0.1", PSK_SHARE_GPU="1", PSK_DIST_TRANSPORT="_gloo_transport:GlooTransport",
                PYTHONPATH=os.path.join(ROOT, "tests") + os.pathsep + os.environ.get("PYTHONPATH", ""), OMP_NUM_THREADS="1",
                PSK_REDUNDANT_INGEST="1" if ingest == "redundant" else "0")
-    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(ranks), "--master-addr",
-           "127.0.0.1", "--master-port", "29619", os.path.join(ROOT, "scripts", "phenotypeseeker"), "modeling",
-           "data.pheno"] + flags
+    env.update(PSK_GPUS=str(ranks), MASTER_PORT="29619")
+    for var in ("WORLD_SIZE", "RANK", "LOCAL_RANK"):
+        env.pop(var, None)
+    cmd = [sys.executable, os.path.join(ROOT, "scripts", "phenotypeseeker"), "modeling", "data.pheno"] + flags
     r = subprocess.run(cmd, env=env, cwd=str(two), timeout=600, capture_output=True, text=True)
     assert r.returncode == 0, r.stderr[-3000:]
     top = "chi2_results_Pheno_top%d.tsv" % (100 if flags else 1000)

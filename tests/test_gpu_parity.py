@@ -226,16 +226,17 @@ def test_ttest_scan_vs_oracle(ctx, oracle, n, weighted):
         npass = ctx.ttest_scan(vals, valid, weights if weighted else None, mn, mx, cut, nk)
         res = ctx.get_results(npass)
         keep = np.nonzero(ref["keep"])[0]
-        got = dict(zip(res["row"].tolist(), range(npass)))
-        common = [r for r in keep.tolist() if r in got]
-        assert len(common) >= len(keep) - 2 and npass - len(common) <= 2
-        assert len(common) > 0 or len(keep) == 0
-        gi = [got[r] for r in common]
-        assert np.allclose(res["stat"][gi], ref["stat"][common], rtol=T_RTOL, atol=1e-12)
-        assert np.allclose(res["p"][gi], ref["p"][common], rtol=1e-6, atol=1e-300)
-        assert np.allclose(res["mean_x"][gi], ref["mean_x"][common], rtol=1e-12)
-        assert np.allclose(res["mean_y"][gi], ref["mean_y"][common], rtol=1e-12)
-        assert np.array_equal(res["n_with"][gi], ref["n_with"][common])
+        # the candidates' moments are summed again in the reference's (= the oracle's) sample order by the second
+        # kernel: the SAME rows, t and the two means bit for bit, and every printed field string-identical (r02 allowed
+        # two rows to flip at the cut and compared values at 1e-8)
+        assert np.array_equal(res["row"], keep.astype(np.uint64))
+        assert np.array_equal(res["stat"], ref["stat"][keep])
+        assert np.array_equal(res["mean_x"], ref["mean_x"][keep]) and np.array_equal(res["mean_y"], ref["mean_y"][keep])
+        assert np.array_equal(res["n_with"], ref["n_with"][keep])
+        assert np.allclose(res["p"], ref["p"][keep], rtol=1e-10, atol=1e-300)   # lgamma / exp / log of two libms
+        differing = sum(("%.2E" % a) != ("%.2E" % b) for a, b in zip(res["p"], ref["p"][keep]))
+        differing += sum(oracle.round2(a) != oracle.round2(b) for a, b in zip(res["stat"], ref["stat"][keep]))
+        assert differing == 0
 
 
 def test_count_dict_matches_gmer_counter(ctx, oracle):
@@ -416,30 +417,32 @@ def _pattern_sums(X, w):
 
 
 def test_l1_logreg_solver_reaches_liblinear_optimum(ctx):
-    """a10 contract: objective, ||w||_1+|b|, linear predictor on the training rows and the
-    per-distinct-pattern coefficient sums of the converged scikit-learn/liblinear solution."""
+    """a10 contract at north_star's tolerance: coefficients (per distinct column pattern where columns repeat), intercept
+    and the linear predictor on the training rows within 1e-6 RELATIVE of the exact optimum of liblinear's objective.
+    The comparator is the arbiter of oracle_model (active-set Newton, KKT residual < 1e-12 -- better than either
+    approximate solver); the liblinear fixture is held to it on the CPU side (test_oracle_golden).  r02 compared at 1e-3
+    because it ran the HIP solver at tol = 1e-8: at tol = 1e-12 the solver is 1e-8 from the optimum, the converged
+    liblinear fixture 6e-7 (tools/a10_probe.py) -- the stopping tolerance was the limiting side, not the solver."""
     from oracle import oracle_model as OM
     z = np.load(os.path.join(GOLDEN, "model_kat.npz"))
-    for tag, cis in (("1", (3, 4, 6, 9, 12)), ("2", (0, 2, 4, 6, 9, 12))):
+    for tag in ("1", "2"):
         X, y = z["X" + tag], z["y" + tag]
-        Cs = [float(z["Cs"][ci]) for ci in cis]
-        coef, icpt, iters = ctx.logreg_l1_fit(X, y, np.zeros(len(y), np.int32), Cs, [-1] * len(Cs), tol=1e-8,
-                                              max_iter=3000)
-        for j, ci in enumerate(cis):
-            C = Cs[j]
-            obj = OM.logreg_l1_objective(X, y, coef[j], icpt[j], C)
-            ref_obj = float(z["logreg_obj" + tag][ci])
-            assert obj == pytest.approx(ref_obj, rel=1e-6), (tag, C, iters[j])
-            rw, rb = z["logreg_coef" + tag][ci], float(z["logreg_icpt" + tag][ci])
-            assert np.allclose(X @ coef[j] + icpt[j], X @ rw + rb, rtol=1e-3, atol=2e-3), (tag, C)
-            assert np.abs(coef[j]).sum() + abs(icpt[j]) == pytest.approx(np.abs(rw).sum() + abs(rb), rel=1e-3, abs=1e-4)
-            if tag == "2":  # no duplicated columns here: the coefficients themselves are unique
-                assert np.allclose(coef[j], rw, rtol=1e-3, atol=2e-4), (C,)
-                assert icpt[j] == pytest.approx(rb, rel=1e-3, abs=2e-4)
-            else:
-                a, b = _pattern_sums(X, coef[j]), _pattern_sums(X, rw)
-                for k in a:
-                    assert a[k] == pytest.approx(b[k], rel=1e-3, abs=2e-4)
+        Cs = [float(c) for c in z["Cs"]]
+        coef, icpt, iters = ctx.logreg_l1_fit(X, y, np.zeros(len(y), np.int32), Cs, [-1] * len(Cs), tol=1e-12,
+                                              max_iter=5000)
+        for ci, C in enumerate(Cs):
+            assert iters[ci] < 5000, (tag, C)
+            a = OM.logreg_l1_arbiter(X, y, C, z["logreg_coef" + tag][ci], float(z["logreg_icpt" + tag][ci]))
+            assert a["kkt"] < 1e-12 and not a["rank_deficient"]
+            sums = np.zeros(len(a["w_groups"]))
+            np.add.at(sums, a["group"], coef[ci])                  # design 2 has no repeated column: the coefficients
+            assert np.array_equal(sums == 0, a["w_groups"] == 0), (tag, C)      # the same support, exact zeros off it
+            assert np.allclose(sums, a["w_groups"], rtol=1e-6, atol=0), (tag, C)
+            assert icpt[ci] == pytest.approx(a["b"], rel=1e-6, abs=0)
+            assert np.allclose(X @ coef[ci] + icpt[ci], a["linpred"], rtol=1e-6, atol=1e-12), (tag, C)
+            obj = OM.logreg_l1_objective(X, y, coef[ci], icpt[ci], C)
+            assert obj == pytest.approx(a["objective"], rel=1e-12)
+            assert obj == pytest.approx(float(z["logreg_obj" + tag][ci]), rel=1e-9)          # and the liblinear fixture's
 
 
 def test_l1_logreg_converges_on_near_duplicate_columns(ctx):
@@ -916,6 +919,7 @@ def test_sort_route_in_word_range_chunks(ctx, oracle, k, n, length, chunk, monke
     ctx.begin(k, n)
     ctx.count_kmers_batch(0, datas, 4)
     monkeypatch.setenv("PSK_NO_TILED_PRESENCE", "1")
+    monkeypatch.setenv("PSK_NO_MERGE_PRESENCE", "1")      # the sort route itself (r03: k <= 17 takes the streaming merge)
     m = ctx.build_presence()
     uw, rows = ctx.get_union(), ctx.get_rows(np.arange(m, dtype=np.uint64))
     lists = [oracle.count_kmers(d, k)[0] for d in datas]
@@ -925,6 +929,46 @@ def test_sort_route_in_word_range_chunks(ctx, oracle, k, n, length, chunk, monke
     assert sum(len(w) for w in lists) > 4 * chunk
     assert ctx.build_presence() == m
     assert np.array_equal(ctx.get_union(), uw) and np.array_equal(ctx.get_rows(np.arange(m, dtype=np.uint64)), rows)
+
+
+@pytest.mark.parametrize("k,n,length,env", [
+    (16, 40, 30_000, {}),                                                    # one wave, default tiles
+    (16, 70, 20_000, {"PSK_MERGE_TILE_PAIRS": "64"}),                        # two waves, thousands of tiny tiles
+    (14, 130, 9_000, {"PSK_MERGE_RCAP": "7", "PSK_MERGE_TILE_PAIRS": "500"}),  # padded column; tiles streamed in batches of 7 rows
+    (15, 1100, 3_000, {"PSK_MERGE_TILE_PAIRS": "3000"}),                     # two sample groups (global bitmap by atomics)
+    (16, 1100, 2_000, {"PSK_MERGE_RCAP": "40", "PSK_MERGE_RANGES": "3"}),    # two groups, batches, three long ranges
+    (17, 24, 50_000, {"PSK_MERGE_RANGES": "1"}),                             # k = 17, the widest eligible space; one range
+])
+def test_merge_presence_build_equals_the_oracle_and_the_sort_route(ctx, oracle, k, n, length, env, monkeypatch):
+    """r03: the presence build for k >= 14 is a streaming 64-way merge of the sorted lists per wave (presence_merge.hip)
+    instead of a sort of all (word, sample) pairs.  Union and every row equal the oracle's and the sort route's, with
+    empty samples, identical samples, a slab filter, tiles of every size, tiles streamed in several batches of rows,
+    and more than 1,024 samples (two workgroups per tile range)."""
+    from phenotypeseeker_amd.synth import GenomeSet
+    gs = GenomeSet(n, length, seed=3 * k + n, gene_len=150, sub_rate=0.01)
+    datas = [gs.sample(i)[1] for i in range(n)]
+    datas[3] = b""
+    datas[n - 1] = b""
+    datas[5] = datas[4]
+    lists = [oracle.count_kmers(d, k)[0] for d in datas]
+    monkeypatch.setenv("PSK_NO_TILED_PRESENCE", "1")
+    monkeypatch.setenv("PSK_TRACE", "1")
+    for name, val in env.items():
+        monkeypatch.setenv(name, val)
+    for lo, hi in ((0, 0), (int(lists[0][len(lists[0]) // 3]) + 1, int(lists[0][2 * len(lists[0]) // 3]) + 7)):
+        ctx.begin(k, n, lo, hi)
+        for s0 in range(0, n, 64):
+            ctx.count_kmers_batch(s0, datas[s0:s0 + 64], 4)
+        kept = [w[(w >= lo) & ((w < hi) if hi else np.ones(len(w), bool))] for w in lists]
+        monkeypatch.delenv("PSK_NO_MERGE_PRESENCE", raising=False)
+        m = ctx.build_presence()
+        uw, rows = ctx.get_union(), ctx.get_rows(np.arange(m, dtype=np.uint64))
+        want = oracle.union(kept)
+        assert m == len(want) and np.array_equal(uw, want), (lo, hi)
+        assert np.array_equal(rows, oracle.presence_bits(kept, uw, wpr=ctx.presence_shape()[1]))
+        monkeypatch.setenv("PSK_NO_MERGE_PRESENCE", "1")
+        assert ctx.build_presence() == m
+        assert np.array_equal(ctx.get_union(), uw) and np.array_equal(ctx.get_rows(np.arange(m, dtype=np.uint64)), rows)
 
 
 def test_full_size_ingest_properties(ctx, oracle):
