@@ -32,7 +32,7 @@ namespace {
 constexpr int PM_GROUP = 1024;          // samples per workgroup: 16 waves x 64 lanes
 constexpr int PM_COLS = PM_GROUP / 64;  // u64 columns of a row one group writes
 constexpr uint32_t PM_BMW = 2048;       // most bitmap words (64 word values each) a tile may span: 16 KB + 8 KB of ranks
-constexpr uint64_t PM_SENT = ~0ull;     // "no word": beyond any canonical word of an eligible run (2k <= 34)
+constexpr uint64_t PM_SENT = ~0ull;     // "no word" in the pilot: beyond any canonical word
 constexpr size_t PM_LDS_MAX = 144 * 1024;
 
 struct PmList {
@@ -40,66 +40,148 @@ struct PmList {
     uint64_t n;
 };
 
-__device__ __forceinline__ uint64_t pm_dpp_u64(uint64_t v, const int tag)
+typedef unsigned long long pm_u64x2 __attribute__((ext_vector_type(2)));
+typedef const __attribute__((address_space(1))) pm_u64x2 *pm_gvec;   // global address space: global_load_dwordx4, not flat
+
+__device__ __forceinline__ uint32_t pm_dpp(uint32_t v, const int tag)
 {
-    int lo = (int)(uint32_t)v, hi = (int)(uint32_t)(v >> 32);
+    int x = (int)v;
     switch (tag) {  // constant-folded (the builtin wants an immediate control word)
-    case 0: lo = __builtin_amdgcn_update_dpp(lo, lo, 0xB1, 0xF, 0xF, false); hi = __builtin_amdgcn_update_dpp(hi, hi, 0xB1, 0xF, 0xF, false); break;    // quad_perm [1,0,3,2]
-    case 1: lo = __builtin_amdgcn_update_dpp(lo, lo, 0x4E, 0xF, 0xF, false); hi = __builtin_amdgcn_update_dpp(hi, hi, 0x4E, 0xF, 0xF, false); break;    // quad_perm [2,3,0,1]
-    case 2: lo = __builtin_amdgcn_update_dpp(lo, lo, 0x141, 0xF, 0xF, false); hi = __builtin_amdgcn_update_dpp(hi, hi, 0x141, 0xF, 0xF, false); break;  // row_half_mirror
-    default: lo = __builtin_amdgcn_update_dpp(lo, lo, 0x140, 0xF, 0xF, false); hi = __builtin_amdgcn_update_dpp(hi, hi, 0x140, 0xF, 0xF, false); break; // row_mirror
+    case 0: x = __builtin_amdgcn_update_dpp(x, x, 0xB1, 0xF, 0xF, false); break;    // quad_perm [1,0,3,2]
+    case 1: x = __builtin_amdgcn_update_dpp(x, x, 0x4E, 0xF, 0xF, false); break;    // quad_perm [2,3,0,1]
+    case 2: x = __builtin_amdgcn_update_dpp(x, x, 0x141, 0xF, 0xF, false); break;   // row_half_mirror
+    default: x = __builtin_amdgcn_update_dpp(x, x, 0x140, 0xF, 0xF, false); break;  // row_mirror
     }
-    return ((uint64_t)(uint32_t)hi << 32) | (uint32_t)lo;
+    return (uint32_t)x;
 }
+__device__ __forceinline__ uint64_t pm_dpp(uint64_t v, const int tag)
+{
+    return ((uint64_t)pm_dpp((uint32_t)(v >> 32), tag) << 32) | pm_dpp((uint32_t)v, tag);
+}
+__device__ __forceinline__ uint32_t pm_readlane(uint32_t v, int l) { return (uint32_t)__builtin_amdgcn_readlane((int)v, l); }
+__device__ __forceinline__ uint64_t pm_readlane(uint64_t v, int l) { return psk_readlane_u64(v, l); }
 
 // minimum over the 64 lanes, wave-uniform; all lanes active.  Quad steps, then the mirrors act as xor-4 / xor-8
 // butterflies on values that are already uniform per quad / per 8; the four rows meet through scalar lane reads.
-__device__ __forceinline__ uint64_t pm_wave_min(uint64_t v)
+// 32-bit words: the minimum with the DPP operand inside the v_min (one instruction per butterfly step instead of a
+// copy, a DPP move and the min).  A DPP operand may not be read for two wait states after the VALU write that
+// produced it (s_nop 1; the assembler does not add it inside inline asm).
+__device__ __forceinline__ uint32_t pm_wave_min(uint32_t v)
 {
-    uint64_t o;
-    o = pm_dpp_u64(v, 0); v = o < v ? o : v;
-    o = pm_dpp_u64(v, 1); v = o < v ? o : v;
-    o = pm_dpp_u64(v, 2); v = o < v ? o : v;
-    o = pm_dpp_u64(v, 3); v = o < v ? o : v;
-    const uint64_t a = psk_readlane_u64(v, 0), b = psk_readlane_u64(v, 16), c = psk_readlane_u64(v, 32), d = psk_readlane_u64(v, 48);
-    const uint64_t ab = a < b ? a : b, cd = c < d ? c : d;
+    asm volatile("s_nop 1\n\t"
+                 "v_min_u32_dpp %0, %0, %0 quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf\n\t"
+                 "s_nop 1\n\t"
+                 "v_min_u32_dpp %0, %0, %0 quad_perm:[2,3,0,1] row_mask:0xf bank_mask:0xf\n\t"
+                 "s_nop 1\n\t"
+                 "v_min_u32_dpp %0, %0, %0 row_half_mirror row_mask:0xf bank_mask:0xf\n\t"
+                 "s_nop 1\n\t"
+                 "v_min_u32_dpp %0, %0, %0 row_mirror row_mask:0xf bank_mask:0xf\n\t"
+                 "s_nop 1"
+                 : "+v"(v));
+    const uint32_t a = pm_readlane(v, 0), b = pm_readlane(v, 16), c = pm_readlane(v, 32), d = pm_readlane(v, 48);
+    const uint32_t ab = a < b ? a : b, cd = c < d ? c : d;
     return ab < cd ? ab : cd;
 }
 
-// A lane's cursor into its list: the next four words in registers (w0 is the current one), the four after them
-// requested ahead.  The loads of the block behind are issued when a block becomes current, so they have four
-// advances of this lane to land.
-struct PmCursor {
-    const uint64_t *w;
-    uint32_t next, end;   // index of the first word of the block that is still to be requested; list length
-    uint64_t a0, a1, a2, a3, b0, b1, b2, b3;
-    uint32_t left;        // words of the current block not yet consumed (incl. a0)
+template <typename W>
+__device__ __forceinline__ W pm_wave_min(W v)
+{
+    W o;
+    o = pm_dpp(v, 0); v = o < v ? o : v;
+    o = pm_dpp(v, 1); v = o < v ? o : v;
+    o = pm_dpp(v, 2); v = o < v ? o : v;
+    o = pm_dpp(v, 3); v = o < v ? o : v;
+    const W a = pm_readlane(v, 0), b = pm_readlane(v, 16), c = pm_readlane(v, 32), d = pm_readlane(v, 48);
+    const W ab = a < b ? a : b, cd = c < d ? c : d;
+    return ab < cd ? ab : cd;
+}
 
-    __device__ __forceinline__ void fetch_b()
+// A lane's cursor into its list.  W = uint32_t: words relative to the slab's base (word spaces of up to 2^32 values:
+// every k <= 16), W = uint64_t otherwise; the all-ones value means "no word" (never a canonical word: the reverse
+// complement of T...T is A...A).
+// The lane holds a window of two 32-byte-aligned blocks of four words in registers (r[0..7]), the index i of its
+// current word inside the window, and the block behind the window (p[0..3]), requested ahead.  Loads happen ONLY in
+// refill(), which the whole wave runs when some lane has used its window up: every lane that is past its first block
+// moves the window one block on and requests the block after, so after a refill every lane has at least five words
+// ahead, the merge loop runs at least five iterations without touching memory, and a requested block has that long
+// to arrive.  (First cut: each lane prefetched its next block on its own, in the loop; the compiler has to wait for ALL
+// outstanding loads before the next use of any of them, so with the lanes out of phase nearly every iteration paid a
+// full memory latency: 13.8 + 21.2 ms for config 3's slab.)
+template <typename W>
+struct PmCursor {
+    static constexpr W SENT = (W)~(W)0;
+    const uint64_t *w;     // the list, shifted down so that block b = w[4 b .. 4 b + 3] is 32-byte aligned
+    uint32_t first, end;   // the list's words are w[first .. end)
+    uint32_t last_blk;     // block of the list's last word
+    uint32_t blk;          // block index of r[0..3]
+    uint32_t i;            // current word = r[i]; i == 8: the window is used up
+    uint64_t base;
+    W r[8], cur;
+    pm_u64x2 px, py;       // the block behind the window as it was loaded, requested one refill ahead (see refill); it is
+                           // converted only when it moves into the window -- touching it earlier would make the
+                           // compiler wait for the load right where it was issued
+
+    __device__ __forceinline__ W conv(uint64_t x, uint32_t idx) const
     {
-        const uint32_t p = next;
-        b0 = p < end ? w[p] : PM_SENT;
-        b1 = p + 1 < end ? w[p + 1] : PM_SENT;
-        b2 = p + 2 < end ? w[p + 2] : PM_SENT;
-        b3 = p + 3 < end ? w[p + 3] : PM_SENT;
-        next = p + 4 < end ? p + 4 : end;
+        // the test of the high half is always true for W = uint32_t (the words of an eligible slab are within 2^32 of its
+        // base); it keeps the high registers of a requested block alive until the block is taken -- dead, the compiler
+        // reuses them as temporaries right behind the load and has to wait for the load first
+        const uint64_t d = x - base;
+        return (idx >= first && idx < end && (sizeof(W) == 8 || (d >> 32) == 0)) ? (W)d : SENT;
     }
-    __device__ __forceinline__ void seek(const uint64_t *words, uint32_t n, uint32_t pos)
+    // raw block b -> px, py (not waited for).  Always a load, never a branch: a block beyond the list is read from the
+    // list's last block instead (take() turns indices beyond the end into "no word" whatever was read), because a
+    // conditional assignment makes the compiler load into temporaries and copy -- i.e. wait -- on the spot.  A 32-byte
+    // sector that holds at least one word of the list lies inside the list's allocation.
+    __device__ __forceinline__ void request(uint32_t b)
     {
-        w = words; end = n; next = pos < n ? pos : n;
-        fetch_b();
-        a0 = b0; a1 = b1; a2 = b2; a3 = b3;
-        left = 4;
-        fetch_b();
+        const uint32_t bb = b < last_blk ? b : last_blk;
+        const pm_gvec p = (pm_gvec)(uintptr_t)(w + 4 * (size_t)bb);
+        px = p[0]; py = p[1];
+    }
+    __device__ __forceinline__ void take(uint32_t b, W *dst) const   // block b, requested before, into the window
+    {
+        dst[0] = conv(px.x, 4 * b); dst[1] = conv(px.y, 4 * b + 1); dst[2] = conv(py.x, 4 * b + 2); dst[3] = conv(py.y, 4 * b + 3);   // beyond the end: SENT
+    }
+    __device__ __forceinline__ void select()
+    {
+        const W s01 = (i & 1) ? r[1] : r[0], s23 = (i & 1) ? r[3] : r[2], s45 = (i & 1) ? r[5] : r[4], s67 = (i & 1) ? r[7] : r[6];
+        const W t0 = (i & 2) ? s23 : s01, t1 = (i & 2) ? s67 : s45;
+        cur = (i & 4) ? t1 : t0;
+    }
+    // pos: index into the list of the word to stand on (pos == n: at the end)
+    // words == nullptr or n == 0 (no sample in this lane, an empty list): `spare` (32-byte aligned, 32 bytes) is read instead
+    __device__ __forceinline__ void seek(const uint64_t *words, uint32_t n, uint32_t pos, uint64_t base_, const uint64_t *spare)
+    {
+        if (!words || n == 0) { words = spare; n = 0; }
+        const uint32_t mis = (uint32_t)(((uintptr_t)words >> 3) & 3);
+        w = words - mis; first = mis; end = n + mis; base = base_;
+        last_blk = end ? (end - 1) >> 2 : 0;
+        const uint32_t q = pos + mis;
+        blk = q >> 2; i = q & 3;
+        request(blk); take(blk, r);
+        request(blk + 1); take(blk + 1, r + 4);
+        request(blk + 2);
+        select();
+    }
+    __device__ __forceinline__ uint32_t position() const { return 4 * blk + i - first; }   // index into the list of the current word
+    __device__ __forceinline__ bool dry() const { return i >= 8; }
+    // wave-uniform call.  The block that moves into the window was requested at the lane's PREVIOUS refill (or seek), at
+    // least five iterations of the merge loop ago; the one requested here is not waited for until the next refill.
+    __device__ __forceinline__ void refill()
+    {
+        if (i >= 4) {
+            r[0] = r[4]; r[1] = r[5]; r[2] = r[6]; r[3] = r[7];
+            blk++; i -= 4;
+            take(blk + 1, r + 4);
+            request(blk + 2);
+            select();
+        }
     }
     __device__ __forceinline__ void advance()
     {
-        a0 = a1; a1 = a2; a2 = a3; a3 = PM_SENT;
-        if (--left == 0) {
-            a0 = b0; a1 = b1; a2 = b2; a3 = b3;
-            left = 4;
-            fetch_b();
-        }
+        i++;
+        select();   // i == 8: some value of the window; the loop refills before it looks at `cur` again
     }
 };
 
@@ -114,33 +196,38 @@ __device__ __forceinline__ uint32_t pm_lower_bound(const uint64_t *w, uint32_t n
 }
 
 // pass 1: the word values that occur, per tile in LDS, then into the global occupancy bitmap
+template <typename W>
 __global__ __launch_bounds__(PM_GROUP) void pm_mark_kernel(const PmList *__restrict__ lists, int n_samples,
                                                            const uint64_t *__restrict__ bounds, uint32_t n_tiles,
                                                            uint32_t tiles_per_range, uint64_t base,
-                                                           unsigned long long *__restrict__ gbm, int single_group)
+                                                           unsigned long long *__restrict__ gbm, int single_group,
+                                                           const uint64_t *__restrict__ spare)
 {
     __shared__ unsigned long long bm[PM_BMW];
     const int lane = threadIdx.x & 63;
     const int s = blockIdx.y * PM_GROUP + threadIdx.x;
     const uint32_t t0 = blockIdx.x * tiles_per_range;
     const uint32_t t1 = t0 + tiles_per_range < n_tiles ? t0 + tiles_per_range : n_tiles;
-    PmCursor cur;
+    PmCursor<W> cur;
     if (s < n_samples) {
         const PmList L = lists[s];
-        cur.seek(L.words, (uint32_t)L.n, pm_lower_bound(L.words, (uint32_t)L.n, bounds[t0]));
+        cur.seek(L.words, (uint32_t)L.n, pm_lower_bound(L.words, (uint32_t)L.n, bounds[t0]), base, spare);
     } else {
-        cur.seek(nullptr, 0, 0);
+        cur.seek(nullptr, 0, 0, base, spare);
     }
     for (uint32_t t = t0; t < t1; t++) {
         const uint64_t lo = bounds[t], hi = bounds[t + 1];
+        const W lo_w = (W)(lo - base), hi_w = (W)(hi - base - 1);   // inclusive upper end: hi - base may be 2^32
         const uint32_t nbw = (uint32_t)((hi - lo + 63) >> 6);
         for (uint32_t i = threadIdx.x; i < nbw; i += blockDim.x) bm[i] = 0;
         __syncthreads();
         for (;;) {
-            const uint64_t cand = cur.a0 < hi ? cur.a0 : PM_SENT;
-            const uint64_t m = pm_wave_min(cand);
-            if (m == PM_SENT) break;
-            if (lane == 0) atomicOr(&bm[(m - lo) >> 6], 1ull << ((m - lo) & 63));
+            if (__any(cur.dry())) cur.refill();
+            const W cand = cur.cur <= hi_w ? cur.cur : PmCursor<W>::SENT;
+            const W m = pm_wave_min(cand);
+            if (m == PmCursor<W>::SENT) break;
+            const uint32_t v = (uint32_t)(m - lo_w);
+            if (lane == 0) atomicOr(&bm[v >> 6], 1ull << (v & 63));
             if (cand == m) cur.advance();
         }
         __syncthreads();
@@ -172,13 +259,14 @@ __global__ void pm_tile_rows_kernel(const uint32_t *__restrict__ rank, const uin
 }
 
 // pass 2: the same stream; every wave stores its ballots into its column of the tile's block
+template <typename W>
 __global__ __launch_bounds__(PM_GROUP) void pm_fill_kernel(const PmList *__restrict__ lists, int n_samples, int wpr,
                                                            const uint64_t *__restrict__ bounds, uint32_t n_tiles,
                                                            uint32_t tiles_per_range, uint64_t base,
                                                            const unsigned long long *__restrict__ gbm,
                                                            const uint32_t *__restrict__ rank, uint32_t r_cap,
                                                            uint32_t bmw_max, uint64_t *__restrict__ union_words,
-                                                           uint64_t *__restrict__ bits)
+                                                           uint64_t *__restrict__ bits, const uint64_t *__restrict__ spare)
 {
     extern __shared__ __attribute__((aligned(16))) unsigned long long pm_lds[];
     unsigned long long *bm = pm_lds;                                        // bmw_max
@@ -193,41 +281,47 @@ __global__ __launch_bounds__(PM_GROUP) void pm_fill_kernel(const PmList *__restr
     const uint64_t *lw = nullptr;
     uint32_t ln = 0;
     if (s < n_samples) { const PmList L = lists[s]; lw = L.words; ln = (uint32_t)L.n; }
-    PmCursor cur;
-    uint32_t pos = lw ? pm_lower_bound(lw, ln, bounds[t0]) : 0;   // index of the lane's first word of the current tile
-    cur.seek(lw, ln, pos);
+    PmCursor<W> cur;
+    cur.seek(lw, ln, lw ? pm_lower_bound(lw, ln, bounds[t0]) : 0, base, spare);
     for (uint32_t t = t0; t < t1; t++) {
         const uint64_t lo = bounds[t], hi = bounds[t + 1];
+        const W lo_w = (W)(lo - base), hi_w = (W)(hi - base - 1);
         const uint32_t nbw = (uint32_t)((hi - lo + 63) >> 6);
         const uint64_t w0 = (lo - base) >> 6;
         for (uint32_t i = threadIdx.x; i < nbw; i += blockDim.x) bm[i] = gbm[w0 + i];
         for (uint32_t i = threadIdx.x; i <= nbw; i += blockDim.x) rk[i] = rank[w0 + i];
         __syncthreads();
         const uint32_t row0 = rk[0], rows = rk[nbw] - row0;
-        uint32_t consumed = 0;   // words of this lane that belong to the tile (for the cursor of the next tile)
+        const uint32_t pos = rows > r_cap ? cur.position() : 0;   // where this lane's words of the tile begin (several batches only)
         for (uint32_t b0 = 0; b0 < rows; b0 += r_cap) {
             const uint32_t rb = rows - b0 < r_cap ? rows - b0 : r_cap;
             for (uint32_t i = threadIdx.x; i < rb * (uint32_t)cols; i += blockDim.x) blk[i] = 0;
             __syncthreads();
-            if (b0 > 0) cur.seek(lw, ln, pos);   // a tile with more rows than the block holds is streamed once per batch
-            uint32_t adv = 0;
+            if (b0 > 0) cur.seek(lw, ln, pos, base, spare);   // a tile with more rows than the block holds is streamed once per batch
             for (;;) {
-                const uint64_t cand = cur.a0 < hi ? cur.a0 : PM_SENT;
-                const uint64_t m = pm_wave_min(cand);
-                if (m == PM_SENT) break;
+                if (__any(cur.dry())) cur.refill();
+                const W cand = cur.cur <= hi_w ? cur.cur : PmCursor<W>::SENT;
+                const W m = pm_wave_min(cand);
+                if (m == PmCursor<W>::SENT) break;
                 const bool hit = cand == m;
                 const uint64_t mask = __ballot(hit);
-                const uint32_t i = (uint32_t)(m - lo);
+                const uint32_t i = (uint32_t)(m - lo_w);
                 const uint32_t r = rk[i >> 6] - row0 + (uint32_t)__popcll(bm[i >> 6] & ((1ull << (i & 63)) - 1ull)) - b0;
                 if (lane == 0 && r < rb && wave < cols) blk[(uint32_t)wave * rb + r] = mask;   // r is unsigned: rows of earlier batches wrap
-                if (hit) { cur.advance(); adv++; }
+                if (hit) cur.advance();
             }
-            consumed = adv;
             __syncthreads();
             uint64_t *dst = bits + (uint64_t)(row0 + b0) * wpr + (uint64_t)group * PM_COLS;
-            for (uint32_t e = threadIdx.x; e < rb * (uint32_t)cols; e += blockDim.x) {
-                const uint32_t r = e / (uint32_t)cols, c = e % (uint32_t)cols;
-                dst[(uint64_t)r * wpr + c] = blk[c * rb + r];
+            if (cols == PM_COLS) {   // a full group: shifts instead of a division by a run-time value per element
+                for (uint32_t e = threadIdx.x; e < rb * (uint32_t)PM_COLS; e += blockDim.x) {
+                    const uint32_t r = e / PM_COLS, c = e % PM_COLS;
+                    dst[(uint64_t)r * wpr + c] = blk[c * rb + r];
+                }
+            } else {
+                for (uint32_t e = threadIdx.x; e < rb * (uint32_t)cols; e += blockDim.x) {
+                    const uint32_t r = e / (uint32_t)cols, c = e % (uint32_t)cols;
+                    dst[(uint64_t)r * wpr + c] = blk[c * rb + r];
+                }
             }
             __syncthreads();
         }
@@ -241,10 +335,6 @@ __global__ __launch_bounds__(PM_GROUP) void pm_fill_kernel(const PmList *__restr
                 }
             }
         }
-        if (rows == 0) {   // nothing was streamed (no word of the tile in any sample of any group): nothing consumed
-            consumed = 0;
-        }
-        pos += consumed;
         __syncthreads();   // bm / rk are rewritten by the next tile
     }
 }
@@ -363,8 +453,9 @@ int build_presence_merge(psk_ctx *ctx, uint64_t total_pairs, uint64_t *n_kmers, 
     n_ranges = (n_tiles + tiles_per_range - 1) / tiles_per_range;
     // ---- buffers: bounds | occupancy bitmap | ranks | rows per tile ---------------------------------------------------
     const uint64_t n_bmw = span >> 6;
-    PSK_TRY(dev_reserve(ctx, ctx->flags, (size_t)(n_tiles + 1) * 8 + (size_t)n_tiles * 4 + 64));
-    uint64_t *d_bounds = ctx->flags.as<uint64_t>();
+    PSK_TRY(dev_reserve(ctx, ctx->flags, 64 + (size_t)(n_tiles + 1) * 8 + (size_t)n_tiles * 4 + 64));
+    const uint64_t *d_spare = ctx->flags.as<uint64_t>();      // 64 bytes the lanes without a list read (contents irrelevant)
+    uint64_t *d_bounds = ctx->flags.as<uint64_t>() + 8;
     uint32_t *d_rows = reinterpret_cast<uint32_t *>(d_bounds + n_tiles + 1);
     PSK_TRY(dev_reserve(ctx, ctx->keysA, n_bmw * 8 + 64));
     PSK_TRY(dev_reserve(ctx, ctx->keysB, (n_bmw + 1) * 4 + 64));
@@ -376,7 +467,9 @@ int build_presence_merge(psk_ctx *ctx, uint64_t total_pairs, uint64_t *n_kmers, 
     if (n_groups > 1) PSK_HIP(ctx, hipMemsetAsync(gbm, 0, n_bmw * 8, ctx->stream));
     const dim3 grid((unsigned)n_ranges, (unsigned)n_groups);
     mark("bounds + buffers");
-    pm_mark_kernel<<<grid, threads, 0, ctx->stream>>>(d_refs, n, d_bounds, n_tiles, tiles_per_range, base, gbm, n_groups == 1);
+    const bool w32 = span <= (1ull << 32);   // words relative to the slab's base fit 32 bits: every k <= 16
+    if (w32) pm_mark_kernel<uint32_t><<<grid, threads, 0, ctx->stream>>>(d_refs, n, d_bounds, n_tiles, tiles_per_range, base, gbm, n_groups == 1, d_spare);
+    else pm_mark_kernel<uint64_t><<<grid, threads, 0, ctx->stream>>>(d_refs, n, d_bounds, n_tiles, tiles_per_range, base, gbm, n_groups == 1, d_spare);
     PSK_HIP(ctx, hipGetLastError());
     mark("pm_mark");
     pm_popcount_kernel<<<div_up(n_bmw + 1, 256), 256, 0, ctx->stream>>>(gbm, n_bmw, rank);
@@ -399,15 +492,28 @@ int build_presence_merge(psk_ctx *ctx, uint64_t total_pairs, uint64_t *n_kmers, 
     if (M) {
         const int cols0 = wpr < PM_COLS ? wpr : PM_COLS;
         const size_t head = (size_t)bmw_max * 8 + (size_t)((bmw_max + 2) >> 1) * 8;
+        // rows a block holds: what fits beside the bitmap -- but sized for the bulk of the tiles (99.5th percentile of
+        // their row counts, and <= 72 KB so that two workgroups share a CU), not for the one tile in a thousand that the
+        // pilot cut too wide: those are streamed in several batches (first cut: the widest tile of config 3's slab, 2,461
+        // rows against a mean of 152, made every workgroup reserve 147 KB of LDS: one workgroup per CU, 13.6 ms)
         uint32_t r_cap = (uint32_t)((PM_LDS_MAX - head) / ((size_t)cols0 * 8));
-        if (const char *e = getenv("PSK_MERGE_RCAP")) { const uint32_t v = (uint32_t)atoi(e); if (v >= 1 && v < r_cap) r_cap = v; }   // tests: force batches
+        if (const char *pe = getenv("PSK_MERGE_RCAP_PCT")) {   // A/B: size the block for a percentile of the tiles, batches for the rest
+            const double pct = atof(pe);
+            std::vector<uint32_t> sorted_rows(rows);
+            const size_t q = (size_t)((double)(n_tiles - 1) * (pct > 0 && pct <= 1 ? pct : 0.995));
+            std::nth_element(sorted_rows.begin(), sorted_rows.begin() + q, sorted_rows.end());
+            uint32_t bulk = sorted_rows[q] < 64 ? 64 : sorted_rows[q];
+            const size_t two_per_cu = 72 * 1024;
+            if (head + (size_t)cols0 * 8 * 64 <= two_per_cu) bulk = std::min<uint32_t>(bulk, (uint32_t)((two_per_cu - head) / ((size_t)cols0 * 8)));
+            if (bulk < r_cap) r_cap = bulk;
+        }
         const uint32_t rb_max = rows_max < r_cap ? rows_max : r_cap;
         const size_t lds = head + (size_t)cols0 * rb_max * 8;
+        auto fill = w32 ? pm_fill_kernel<uint32_t> : pm_fill_kernel<uint64_t>;
         if (lds > 64 * 1024)
-            PSK_HIP(ctx, hipFuncSetAttribute(reinterpret_cast<const void *>(pm_fill_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
-                                             (int)lds));
-        pm_fill_kernel<<<grid, threads, lds, ctx->stream>>>(d_refs, n, wpr, d_bounds, n_tiles, tiles_per_range, base, gbm, rank, r_cap,
-                                                           bmw_max, ctx->union_words.as<uint64_t>(), ctx->bits.as<uint64_t>());
+            PSK_HIP(ctx, hipFuncSetAttribute(reinterpret_cast<const void *>(fill), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        fill<<<grid, threads, lds, ctx->stream>>>(d_refs, n, wpr, d_bounds, n_tiles, tiles_per_range, base, gbm, rank, r_cap, bmw_max,
+                                                  ctx->union_words.as<uint64_t>(), ctx->bits.as<uint64_t>(), d_spare);
         PSK_HIP(ctx, hipGetLastError());
         PSK_HIP(ctx, hipStreamSynchronize(ctx->stream));
     }
