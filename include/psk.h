@@ -128,7 +128,9 @@ int psk_intersect_db(psk_ctx *ctx, const uint64_t *db_words, uint64_t n_db, uint
 int psk_set_presence(psk_ctx *ctx, const uint64_t *words, const uint64_t *bits, uint64_t n_kmers,
                      int words_per_row, int n_samples);
 /* Fills the resident matrix with a synthetic pattern on the device (benchmark only):
- * row r is present in sample i with a probability that depends on r; see DESIGN.md. */
+ * row r is present in sample i with a probability that depends on r; see DESIGN.md.  Bits 48..63 of `seed`, when not
+ * zero, thin the 1 % of "gene" rows (the rows that survive a scan against the even/odd phenotype) to that many in 10,000
+ * of them: 80 gives BASELINE config 2's survivor share. */
 int psk_synth_presence(psk_ctx *ctx, uint64_t n_kmers, int n_samples, uint64_t seed);
 
 /* ---- a4-a6: chi-squared scan ---------------------------------------------------------------

@@ -59,6 +59,9 @@ struct ScanArgs {
     const double *lut;         // the same table summed over every subset of each group of 4 samples (row_moments_lut)
     int c_lut;                 // ... for the first c_lut chunks of a row; the rest of the row takes the per-sample form
     const double *raw;         // Welch: {weight (0 for NA), phenotype value (0 for NA)} per sample, for the exact second pass
+    const float *lut6;         // f32 six-bit table of the same moments (row_moments_f32) -- candidate selection only
+    double e0, e1, e2;         // ... and what its sums may be off by: |sum w| <= e0, |sum w u| <= e1, |sum w u^2| <= e2 (chi2: e0 = class 1, e1 = class 0)
+    double eref;               // Welch: what the REFERENCE's own arithmetic may be off by in a group mean (it sums the raw, unshifted values)
     int n1, n0;                // popcounts of the masks
     double W1, W0;             // weight totals of the two phenotype classes
     // t-test
@@ -264,6 +267,77 @@ __device__ __forceinline__ void row_moments_lut(const u32x4 *__restrict__ rp, in
     for (int m = 0; m < NM; m++) acc[m] = a0[m] + a1[m];
 }
 
+// ---- six-bit tables in f32: candidate selection at a third of the cost ------------------------------------------------
+// Since r03 every moment scan decides in a second kernel that re-sums its candidates exactly (chi2w_finalize_kernel,
+// ttest_finalize_kernel), so the sums of the streaming kernel only have to be good enough to not MISS a candidate.  They are
+// therefore taken in f32 from a table over groups of SIX samples: a 16-byte chunk of a row is 21 six-bit groups + one
+// two-bit group, i.e. 22 lookups instead of 32; an entry of two moments is 8 bytes (one ds_read_b64, 4 LDS cycles
+// instead of 8) and is accumulated by ONE v_pk_add_f32 (4 VALU cycles instead of two v_add_f64 = 16).  The kernel turns
+// the f32 sums into an UPPER bound of the statistic with the rounding-error bounds the host derives from the table
+// itself (e0, e1, e2: (additions per accumulator + 3) x 2^-24 x the sum of the absolute terms over all samples, which
+// bounds the error of any subset's f32 sum), and every row whose bound reaches the threshold is a candidate.
+// Layout: per chunk 21 x 64 + 4 = SC_L6_ENTRIES entries; float2 {m0, m1} per entry, then -- three moments -- one float
+// per entry in a second table behind the first.  1,024 samples: 86 KB (two moments), 129 KB (three).
+constexpr int SC_L6_ENTRIES = 21 * 64 + 4;
+__host__ __device__ inline size_t lut6_bytes(int chunks, int nm) { return (size_t)chunks * SC_L6_ENTRIES * (nm == 3 ? 12 : 8); }
+
+template <int NM>
+__global__ void moment_lut6_kernel(const double *__restrict__ tab, int chunks, float *__restrict__ lut)
+{
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= chunks * SC_L6_ENTRIES) return;
+    const int ch = i / SC_L6_ENTRIES, e = i % SC_L6_ENTRIES;
+    const int j = e < 21 * 64 ? e >> 6 : 21, p = e < 21 * 64 ? e & 63 : e - 21 * 64, width = j < 21 ? 6 : 2;
+    const size_t s0 = (size_t)ch * 128 + 6 * j;
+#pragma unroll
+    for (int m = 0; m < NM; m++) {
+        double s = 0.0;
+        for (int b = 0; b < width; b++)
+            if ((p >> b) & 1) s += tab[(s0 + b) * NM + m];
+        if (m < 2) lut[(size_t)i * 2 + m] = (float)s;
+        else lut[(size_t)chunks * SC_L6_ENTRIES * 2 + i] = (float)s;
+    }
+}
+
+typedef float sc_f32x2 __attribute__((ext_vector_type(2)));
+
+// f32 sums of NM moments over the present samples of one row (one row per lane), from the six-bit tables in LDS
+template <int NM>
+__device__ __forceinline__ void row_moments_f32(const u32x4 *__restrict__ rp, int cpr, const float *lut, double *acc)
+{
+    sc_f32x2 a0 = {0.f, 0.f}, a1 = {0.f, 0.f};
+    float c0 = 0.f, c1 = 0.f;
+    const float *lut3 = lut + (size_t)cpr * SC_L6_ENTRIES * 2;   // NM = 3 only
+    for (int g0 = 0; g0 < cpr; g0 += SC_LUT_PF) {
+        u32x4 y[SC_LUT_PF];
+#pragma unroll
+        for (int i = 0; i < SC_LUT_PF; i++) y[i] = g0 + i < cpr ? rp[g0 + i] : (u32x4)(0u);
+#pragma unroll
+        for (int i = 0; i < SC_LUT_PF; i++) {
+            if (g0 + i >= cpr) break;
+            const uint32_t w4[5] = {y[i].x, y[i].y, y[i].z, y[i].w, 0u};
+            const sc_f32x2 *lp = reinterpret_cast<const sc_f32x2 *>(lut) + (size_t)(g0 + i) * SC_L6_ENTRIES;
+            const float *lp3 = lut3 + (size_t)(g0 + i) * SC_L6_ENTRIES;
+#pragma unroll
+            for (int j = 0; j < 22; j++) {
+                const int o = 6 * j, wi = o >> 5, sh = o & 31;
+                uint32_t idx;
+                if (j == 21) idx = w4[3] >> 30;
+                else if (sh <= 26) idx = (w4[wi] >> sh) & 63u;
+                else idx = __builtin_amdgcn_alignbit(w4[wi + 1], w4[wi], sh) & 63u;
+                const uint32_t e = (uint32_t)j * 64u + idx;
+                const sc_f32x2 v = lp[e];
+                if (j & 1) a1 += v; else a0 += v;
+                if (NM == 3) { if (j & 1) c1 += lp3[e]; else c0 += lp3[e]; }
+            }
+        }
+    }
+    const sc_f32x2 a = a0 + a1;
+    acc[0] = (double)a.x;
+    acc[1] = (double)a.y;
+    if (NM == 3) acc[2] = (double)(c0 + c1);
+}
+
 // Both forms in one row, for rows whose table does not fit the LDS: the first c_lut chunks through the nibble table, the
 // others per sample.  (Splitting a row that does fit in halves, to keep the LDS pipe and the f64 VALU busy at the same
 // time, did not pay: 16 M x 1024 with a fifth of the rows passing took 0.66 ms against 0.63 ms with the whole row in
@@ -324,7 +398,7 @@ __device__ __forceinline__ int queue_pop64(uint64_t *q_row, int2 *q_val, int q, 
 // MODE 2: unit weights, rows that pass the pre-test are queued the same way: a scan with many survivors
 //         (--omit_B_correction keeps ~pvalue of all rows) then evaluates 64 of them per pass instead of one or two
 //         lanes of a wave at a time.  Same formulas, same results as MODE 0 (the host picks, see pick_chi2_mode).
-template <int G, int MODE, bool LUT = false>
+template <int G, int MODE, bool LUT = false, bool F32 = false>
 __global__ __launch_bounds__(LUT ? SC_LUT_THREADS : SC_THREADS) void chi2_scan_kernel(const ScanArgs P)
 {
     constexpr bool WEIGHTED = MODE == 1, QUEUED = MODE != 0;
@@ -332,8 +406,9 @@ __global__ __launch_bounds__(LUT ? SC_LUT_THREADS : SC_THREADS) void chi2_scan_k
     constexpr int UNR = LUT ? lut_unroll(G) : SC_UNROLL;
     __shared__ uint64_t s_qrow[QUEUED ? THREADS / 64 : 1][QUEUED ? rq_cap(G, UNR) : 1];
     __shared__ int2 s_qval[QUEUED ? THREADS / 64 : 1][QUEUED ? rq_cap(G, UNR) : 1];
-    extern __shared__ __attribute__((aligned(16))) double s_lut[];   // LUT: the nibble table of row_moments_lut
-    if (LUT) load_lut(s_lut, P.lut, P.c_lut * 32 * 16 * 2, THREADS);
+    extern __shared__ __attribute__((aligned(16))) double s_lut[];   // LUT: the nibble table of row_moments_lut / the six-bit f32 table
+    if (LUT && F32) load_lut(s_lut, reinterpret_cast<const double *>(P.lut6), (int)(lut6_bytes(P.cpr, 2) / 8), THREADS);
+    else if (LUT) load_lut(s_lut, P.lut, P.c_lut * 32 * 16 * 2, THREADS);
     constexpr int RPW = 64 / G;  // rows per wave step
     const int lane = threadIdx.x & 63;
     const int g = lane & (G - 1);
@@ -359,7 +434,22 @@ __global__ __launch_bounds__(LUT ? SC_LUT_THREADS : SC_THREADS) void chi2_scan_k
         const int2 qv = q_val[act ? lane : 0];
         int r_nw = qv.x;
         double A, B, C, D;
-        if (WEIGHTED) {
+        if (WEIGHTED && F32) {
+            // f32 class-weight sums (A, C may be off by e0, e1): an UPPER bound of the statistic decides who is a candidate.
+            // det = AD - BC = A W0 - C W1 is linear in the two sums; the column totals shrink by the error
+            double ws[2];
+            row_moments_f32<2>(P.bits + r * (uint64_t)P.cpr, P.cpr, reinterpret_cast<const float *>(s_lut), ws);
+            const double T = P.W1 + P.W0, err = P.e0 + P.e1;
+            const double det = fabs(ws[0] * P.W0 - ws[1] * P.W1) + (P.e0 * P.W0 + P.e1 * P.W1);
+            const double K1 = (ws[0] + ws[1]) - err, K0 = (T - (ws[0] + ws[1])) - err;
+            const bool cand = !(K1 > 0.0 && K0 > 0.0) || !(T * det * det < P.thr * P.W1 * P.W0 * K1 * K0 * (1.0 - 1e-9));
+            if (act && cand) {
+                const uint64_t idx = reserve_slot(P);
+                P.res_row[idx] = r;
+                P.res_nw[idx] = r_nw;
+            }
+            return;
+        } else if (WEIGHTED) {
             double ws[2];
             if (LUT) row_moments_mixed<2>(P.bits + r * (uint64_t)P.cpr, P.cpr, P.c_lut, s_lut, (cdptr)P.tab, ws);
             else row_moments<2>(P.bits + r * (uint64_t)P.cpr, P.cpr, (cdptr)P.tab, ws);
@@ -603,7 +693,7 @@ __device__ __attribute__((noinline)) double dev_t_two_sided_p(double t, double d
 // follows from the totals -- then means, variances, t and the Satterthwaite df in the same lane.
 // Table layout: unit weights tab[s] = {u, u*u} (n comes from the popcount); GSC weights {w, w*u, w*u*u};
 // zeros for NA samples and padding.
-template <int G, bool WT, bool LUT = false>
+template <int G, bool WT, bool LUT = false, bool F32 = false>
 __global__ __launch_bounds__(LUT ? SC_LUT_THREADS : SC_THREADS) void ttest_scan_kernel(const ScanArgs P, const double mu)
 {
     constexpr int THREADS = LUT ? SC_LUT_THREADS : SC_THREADS;
@@ -612,8 +702,9 @@ __global__ __launch_bounds__(LUT ? SC_LUT_THREADS : SC_THREADS) void ttest_scan_
     __shared__ int2 s_qval[THREADS / 64][rq_cap(G, UNR)];
     constexpr int RPW = 64 / G;
     constexpr int NM = WT ? 3 : 2;
-    extern __shared__ __attribute__((aligned(16))) double s_lut[];   // LUT: the nibble table of row_moments_lut
-    if (LUT) load_lut(s_lut, P.lut, P.c_lut * 32 * 16 * NM, THREADS);
+    extern __shared__ __attribute__((aligned(16))) double s_lut[];   // LUT: the nibble table of row_moments_lut / the six-bit f32 table
+    if (LUT && F32) load_lut(s_lut, reinterpret_cast<const double *>(P.lut6), (int)(lut6_bytes(P.cpr, NM) / 8), THREADS);
+    else if (LUT) load_lut(s_lut, P.lut, P.c_lut * 32 * 16 * NM, THREADS);
     const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
     const int g = lane & (G - 1);
     const int rsub = lane / G;
@@ -632,11 +723,35 @@ __global__ __launch_bounds__(LUT ? SC_LUT_THREADS : SC_THREADS) void ttest_scan_
         const uint64_t r = q_row[act ? lane : 0];
         const int r_nw = q_val[act ? lane : 0].x;
         double mo[NM];
-        if (LUT) row_moments_mixed<NM>(P.bits + r * (uint64_t)P.cpr, P.cpr, P.c_lut, s_lut, (cdptr)P.tab, mo);
+        if (F32) row_moments_f32<NM>(P.bits + r * (uint64_t)P.cpr, P.cpr, reinterpret_cast<const float *>(s_lut), mo);
+        else if (LUT) row_moments_mixed<NM>(P.bits + r * (uint64_t)P.cpr, P.cpr, P.c_lut, s_lut, (cdptr)P.tab, mo);
         else row_moments<NM>(P.bits + r * (uint64_t)P.cpr, P.cpr, (cdptr)P.tab, mo);
         if (!act) return;
         const double nx = WT ? mo[0] : (double)r_nw, sx = mo[NM - 2], qx = mo[NM - 1];
         const double ny = P.W1 - nx, sy = P.W0 - sx, qy = P.thr - qx;  // totals: W1 = sum w, W0 = sum w*u, thr = sum w*u^2
+        if (F32) {
+            // the sums are f32 sums, off by at most e0 (sum w; 0 with unit weights: the popcount), e1 (sum w u), e2 (sum w u^2):
+            // an UPPER bound of |t| -- the largest difference of the means over the smallest standard error the bounds
+            // allow -- decides who is a candidate (ttest_finalize_kernel computes the statistic itself)
+            const double e0 = WT ? P.e0 : 0.0;
+            const double nxl = nx - e0, nyl = ny - e0, nxh = nx + e0, nyh = ny + e0;
+            bool cand = !(nxl > 1.0 && nyl > 1.0);
+            if (!cand) {
+                const double ax = fabs(sx) + P.e1, ay = fabs(sy) + P.e1;
+                // (+ 2 eref: the exact pass reproduces the reference's sums of the RAW values, whose means are only good to
+                // ~n eps max|v| -- a phenotype of 1e6 +- 1e-3 makes that visible in t, and such a row must still be offered)
+                const double dmax = fabs(sx / nx - sy / ny) + P.e1 * (1.0 / nxl + 1.0 / nyl) + ax * e0 / (nxl * nxl) + ay * e0 / (nyl * nyl) + 2.0 * P.eref;
+                const double vx = fmax((qx - P.e2) - ax * ax / nxl, 0.0) / nxh, vy = fmax((qy - P.e2) - ay * ay / nyl, 0.0) / nyh;
+                const double sem = vx / (nxh - 1.0) + vy / (nyh - 1.0);
+                cand = !(sem > 0.0) || !(dmax / sqrt(sem) <= P.tcrit);
+            }
+            if (cand) {
+                const uint64_t idx = reserve_slot(P);
+                P.res_row[idx] = r;
+                P.res_nw[idx] = r_nw;
+            }
+            return;
+        }
         const double dx = sx / nx, dy = sy / ny;              // group means minus mu
         const double vx = (qx - sx * dx) / nx, vy = (qy - sy * dy) / ny;  // ddof = 0
         const double sem1 = vx / (nx - 1.0), sem2 = vy / (ny - 1.0);
@@ -647,7 +762,7 @@ __global__ __launch_bounds__(LUT ? SC_LUT_THREADS : SC_THREADS) void ttest_scan_
         // sums differ from the sample-order ones) cannot pass.  Candidates are stored as (row, n_with) only:
         // ttest_finalize_kernel sums their moments again in the reference's order and decides (keeps erfc /
         // incomplete-beta code, and its ~90 VGPRs, out of this kernel).
-        if (fabs(tstat) > P.tcrit) {
+        if (!(fabs(tstat) + 2.0 * P.eref / sqrt(semsum) <= P.tcrit)) {   // eref: see ScanArgs; NaN: the exact pass drops it
             const uint64_t idx = reserve_slot(P);
             P.res_row[idx] = r;
             P.res_nw[idx] = r_nw;
@@ -728,6 +843,17 @@ int launch_lut_kernel(K kern, dim3 grid, size_t lds, hipStream_t st, const ScanA
 
 void launch_chi2_lut(int G, dim3 grid, hipStream_t st, const ScanArgs &a)
 {
+    if (a.lut6) {
+        const size_t lds6 = lut6_bytes(a.cpr, 2);
+        switch (G) {
+        case 1: launch_lut_kernel(chi2_scan_kernel<1, 1, true, true>, grid, lds6, st, a); break;
+        case 2: launch_lut_kernel(chi2_scan_kernel<2, 1, true, true>, grid, lds6, st, a); break;
+        case 4: launch_lut_kernel(chi2_scan_kernel<4, 1, true, true>, grid, lds6, st, a); break;
+        case 8: launch_lut_kernel(chi2_scan_kernel<8, 1, true, true>, grid, lds6, st, a); break;
+        default: launch_lut_kernel(chi2_scan_kernel<16, 1, true, true>, grid, lds6, st, a); break;
+        }
+        return;
+    }
     const size_t lds = lut_bytes(a.c_lut, 2);
     switch (G) {
     case 1: launch_lut_kernel(chi2_scan_kernel<1, 1, true>, grid, lds, st, a); break;
@@ -741,7 +867,7 @@ void launch_chi2_lut(int G, dim3 grid, hipStream_t st, const ScanArgs &a)
 void launch_chi2(int mode, int G, dim3 grid, hipStream_t st, const ScanArgs &a)
 {
     if (mode == 1) {
-        if (a.lut) launch_chi2_lut(G, grid, st, a);
+        if (a.lut || a.lut6) launch_chi2_lut(G, grid, st, a);
         else launch_chi2_mode<1>(G, grid, st, a);
         chi2w_finalize_kernel<<<SC_NSEG, SC_FIN_THREADS, 0, st>>>(a);
     }
@@ -775,11 +901,12 @@ int pick_chi2_mode(const psk_ctx *ctx, bool weighted, double pcut, double pcut_b
 // sums, ~1e-15 off, and up to two rows flipping at the cut).  Then the two-sided p, the keep rule p < cut / M
 // (modeling.py:738) and the compaction of the segment in place.  Candidates are the rows whose scan-kernel |t| exceeds
 // a bound no passing row can be under (psk_ttest_scan: t_crit), so the scan kernel's own sums decide nothing.
+template <bool WT>
 __global__ __launch_bounds__(SC_FIN_THREADS) void ttest_finalize_kernel(const ScanArgs P)
 {
     __shared__ uint32_t scan_lds[SC_FIN_THREADS / 64];
     __shared__ uint32_t s_out;
-    __shared__ double2 s_tab[SC_FIN_BLK * 128];   // {weight, value} of the samples of the current block (broadcast reads)
+    __shared__ double2 s_tab[SC_FIN_BLK * 128];   // pass 1: {weight, weight * value}, pass 2: {weight, value} of the samples of the current block (broadcast reads)
     const uint32_t seg = blockIdx.x;
     const uint32_t c = P.counter[seg * SC_CNT_STRIDE];
     const uint64_t base = (uint64_t)seg * P.seg_cap;
@@ -792,18 +919,35 @@ __global__ __launch_bounds__(SC_FIN_THREADS) void ttest_finalize_kernel(const Sc
         const int32_t nw = valid ? P.res_nw[base + i] : 0;
         const bool wave_any = __any(valid);
         const u32x4 *rp = P.bits + row * (uint64_t)P.cpr;
+        // One lane walks its candidate's 2 x n_samples dependent additions (rocprof, r03: 82 us at 1,024 samples whatever the
+        // number of candidates).  A weight times 1.0 or 0.0 is exact, so fma(present ? 1 : 0, term, acc) IS the conditional
+        // addition; the product w v comes out of the staged table, and with unit weights the two weight sums are the counts
+        // the scan kernel already has.  Tried and dropped (r03): a branch on the bit instead of the 0/1 factors (94 / 107 us:
+        // both sides of a divergent branch issue), and chains of precomputed addends summed by one lane per chain (69 us per
+        // two batches of four candidates, and any segment beyond the batches still pays the 82).
         double nx = 0.0, ny = 0.0, sx = 0.0, sy = 0.0, qx = 0.0, qy = 0.0, mx = 0.0, my = 0.0;
         for (int pass = 0; pass < 2; pass++) {
-            if (pass == 1) { mx = sx / nx; my = sy / ny; }
+            if (pass == 1) {
+                if (!WT) { nx = (double)nw; ny = (double)(P.nvalid - nw); }   // sums of ones: exact
+                mx = sx / nx; my = sy / ny;
+            }
             for (int c0 = 0; c0 < P.cpr; c0 += SC_FIN_BLK) {
                 const int nc = P.cpr - c0 < SC_FIN_BLK ? P.cpr - c0 : SC_FIN_BLK;
                 __syncthreads();   // the previous block has been consumed
-                for (int e = threadIdx.x; e < nc * 128; e += SC_FIN_THREADS)
-                    s_tab[e] = reinterpret_cast<const double2 *>(P.raw)[(size_t)c0 * 128 + e];
+                for (int e = threadIdx.x; e < nc * 128; e += SC_FIN_THREADS) {
+                    double2 t = reinterpret_cast<const double2 *>(P.raw)[(size_t)c0 * 128 + e];   // NA and padding: {0, 0}
+                    if (pass == 0) t.y = t.x * t.y;
+                    s_tab[e] = t;
+                }
                 __syncthreads();
                 if (!wave_any) continue;
+                // the row's chunks are requested two ahead: read where they are used, every 16-byte chunk cost this lone
+                // lane a whole memory latency (16 of them per candidate at 1,024 samples: half of the kernel's 82 us)
+                u32x4 y0 = rp[c0], y1 = nc > 1 ? rp[c0 + 1] : (u32x4)(0u);
                 for (int ch = 0; ch < nc; ch++) {
-                    const u32x4 y = rp[c0 + ch];
+                    const u32x4 y = y0;
+                    y0 = y1;
+                    if (ch + 2 < nc) y1 = rp[c0 + ch + 2];
                     const uint32_t w4[4] = {y.x, y.y, y.z, y.w};
 #pragma unroll
                     for (int h = 0; h < 4; h++) {
@@ -811,14 +955,15 @@ __global__ __launch_bounds__(SC_FIN_THREADS) void ttest_finalize_kernel(const Sc
                         for (int sb = 0; sb < 32; sb++) {
                             const uint32_t fh = (uint32_t)(((int32_t)(w4[h] << (31 - sb))) >> 31) & 0x3FF00000u;
                             const double f = __hiloint2double((int)fh, 0), g = __hiloint2double((int)(fh ^ 0x3FF00000u), 0);
-                            const double2 t = s_tab[ch * 128 + h * 32 + sb];   // NA samples and padding: {0, 0}
+                            const double2 t = s_tab[ch * 128 + h * 32 + sb];
                             if (pass == 0) {
-                                const double wv = t.x * t.y;
-                                nx = fma(f, t.x, nx); sx = fma(f, wv, sx);
-                                ny = fma(g, t.x, ny); sy = fma(g, wv, sy);
+                                if (WT) { nx = fma(f, t.x, nx); ny = fma(g, t.x, ny); }
+                                sx = fma(f, t.y, sx);
+                                sy = fma(g, t.y, sy);
                             } else {
                                 const double d = t.y - (fh ? mx : my);
-                                const double term = (t.x * d) * d;
+                                // unit weights: (1 d) d = d d; an NA sample (weight 0 in the table) adds nothing to either group
+                                const double term = WT ? (t.x * d) * d : (t.x != 0.0 ? d * d : 0.0);
                                 qx = fma(f, term, qx);
                                 qy = fma(g, term, qy);
                             }
@@ -881,6 +1026,17 @@ void launch_lut_ttest(K kern, dim3 grid, size_t lds, hipStream_t st, const ScanA
 template <bool WT>
 void launch_ttest_lut(int G, dim3 grid, hipStream_t st, const ScanArgs &a, double mu)
 {
+    if (a.lut6) {
+        const size_t lds6 = lut6_bytes(a.cpr, WT ? 3 : 2);
+        switch (G) {
+        case 1: launch_lut_ttest(ttest_scan_kernel<1, WT, true, true>, grid, lds6, st, a, mu); break;
+        case 2: launch_lut_ttest(ttest_scan_kernel<2, WT, true, true>, grid, lds6, st, a, mu); break;
+        case 4: launch_lut_ttest(ttest_scan_kernel<4, WT, true, true>, grid, lds6, st, a, mu); break;
+        case 8: launch_lut_ttest(ttest_scan_kernel<8, WT, true, true>, grid, lds6, st, a, mu); break;
+        default: launch_lut_ttest(ttest_scan_kernel<16, WT, true, true>, grid, lds6, st, a, mu); break;
+        }
+        return;
+    }
     const size_t lds = lut_bytes(a.c_lut, WT ? 3 : 2);
     switch (G) {
     case 1: launch_lut_ttest(ttest_scan_kernel<1, WT, true>, grid, lds, st, a, mu); break;
@@ -893,12 +1049,13 @@ void launch_ttest_lut(int G, dim3 grid, hipStream_t st, const ScanArgs &a, doubl
 
 void launch_ttest(int G, dim3 grid, hipStream_t st, const ScanArgs &a, double mu, bool weighted)
 {
-    if (a.lut) {
+    if (a.lut || a.lut6) {
         if (weighted) launch_ttest_lut<true>(G, grid, st, a, mu);
         else launch_ttest_lut<false>(G, grid, st, a, mu);
     } else if (weighted) launch_ttest_w<true>(G, grid, st, a, mu);
     else launch_ttest_w<false>(G, grid, st, a, mu);
-    ttest_finalize_kernel<<<SC_NSEG, SC_FIN_THREADS, 0, st>>>(a);
+    if (weighted) ttest_finalize_kernel<true><<<SC_NSEG, SC_FIN_THREADS, 0, st>>>(a);
+    else ttest_finalize_kernel<false><<<SC_NSEG, SC_FIN_THREADS, 0, st>>>(a);
 }
 
 // builds the nibble table of `tab` (cpr * 128 samples x nm moments, already on the device) into ctx->lut
@@ -912,6 +1069,24 @@ int build_moment_lut(psk_ctx *ctx, const double *tab, int chunks, int nm, const 
     *lut_out = ctx->lut.as<double>();
     return PSK_OK;
 }
+
+// the six-bit f32 table of `tab` for a whole row (cpr chunks), when it fits the LDS beside the kernels' queues; PSK_LUT_F64
+// keeps the nibble table in f64 (A/B runs).  *lut6_out = nullptr: not this time.
+int build_moment_lut6(psk_ctx *ctx, const double *tab, int cpr, int nm, const float **lut6_out)
+{
+    *lut6_out = nullptr;
+    if (getenv("PSK_NO_LUT") || getenv("PSK_LUT_F64") || cpr > 16 || lut6_bytes(cpr, nm) > SC_LUT_MAX_BYTES) return PSK_OK;
+    PSK_TRY(dev_reserve(ctx, ctx->lut, lut6_bytes(cpr, nm)));
+    const int n = cpr * SC_L6_ENTRIES;
+    if (nm == 2) moment_lut6_kernel<2><<<div_up((uint64_t)n, 256), 256, 0, ctx->stream>>>(tab, cpr, ctx->lut.as<float>());
+    else moment_lut6_kernel<3><<<div_up((uint64_t)n, 256), 256, 0, ctx->stream>>>(tab, cpr, ctx->lut.as<float>());
+    PSK_HIP(ctx, hipGetLastError());
+    *lut6_out = ctx->lut.as<float>();
+    return PSK_OK;
+}
+// (additions per accumulator + rounding of the entry and of the final sums) x 2^-24, with room: what an f32 sum of
+// row_moments_f32 may be off by, relative to the sum of the absolute values of ALL the terms of the table
+double lut6_gamma(int cpr) { return ((double)(cpr * 22) / 2.0 + 8.0) * 5.9604644775390625e-08 * 1.01; }
 
 int group_lanes(int cpr)
 {
@@ -1040,7 +1215,7 @@ int pick_result_set(psk_ctx *ctx, int *set_out, bool keep_results = false)
 int run_chi2(psk_ctx *ctx, ScanArgs &a, bool weighted, int reps, double *ms_total)
 {
     const int G = group_lanes(a.cpr);
-    const dim3 grid = scan_grid(ctx, a.M, G, SC_UNROLL, a.lut != nullptr);
+    const dim3 grid = scan_grid(ctx, a.M, G, SC_UNROLL, a.lut != nullptr || a.lut6 != nullptr);
     *ms_total = 0;
     for (int r = 0; r < reps; r++) {
         PSK_HIP(ctx, hipEventRecord(ctx->ev0, ctx->stream));
@@ -1080,10 +1255,17 @@ static int fill_chi2_args(psk_ctx *ctx, ScanArgs &a, int set)
     else if (pmax <= 0.0) a.thr = INFINITY;
     else a.thr = -2.0 * log(pmax);
     const int G = group_lanes(a.cpr);
-    a.lut = (L.weighted && ctx->lut_valid) ? ctx->lut.as<double>() : nullptr;
+    a.lut6 = (L.weighted && ctx->lut6_valid) ? ctx->lut.as<float>() : nullptr;
+    a.lut = (L.weighted && ctx->lut_valid && !a.lut6) ? ctx->lut.as<double>() : nullptr;
     a.c_lut = a.lut ? lut_chunks(a.cpr, 2) : 0;
-    return setup_results(ctx, a, scan_grid(ctx, a.M, G, SC_UNROLL, a.lut != nullptr), G, a.lut ? lut_unroll(G) : SC_UNROLL, set,
-                         a.lut ? SC_LUT_THREADS : SC_THREADS);
+    a.W1 = L.W1; a.W0 = L.W0;
+    if (a.lut6) {   // what the f32 class-weight sums may be off by (row_moments_f32)
+        a.e0 = lut6_gamma(a.cpr) * L.W1 + 1e-36;
+        a.e1 = lut6_gamma(a.cpr) * L.W0 + 1e-36;
+    }
+    const bool table = a.lut != nullptr || a.lut6 != nullptr;
+    return setup_results(ctx, a, scan_grid(ctx, a.M, G, SC_UNROLL, table), G, table ? lut_unroll(G) : SC_UNROLL, set,
+                         table ? SC_LUT_THREADS : SC_THREADS);
 }
 
 // Launches the scan and returns without waiting; psk_scan_end collects it.  Lets a caller queue other work (the
@@ -1134,11 +1316,17 @@ static int chi2_scan_launch(psk_ctx *ctx, const int8_t *pheno, const double *wei
         PSK_HIP(ctx, hipMemcpyAsync(ctx->mask1.p, m1, weights ? stage_bytes : n_mask * 8, hipMemcpyHostToDevice, ctx->stream));
 
     ctx->lut_valid = false;
-    if (weights && lut_chunks(wpr / 2, 2) > 0) {   // class-weight sums from a nibble table in LDS (row_moments_lut)
-        const double *lut = nullptr;
-        PSK_TRY(build_moment_lut(ctx, reinterpret_cast<const double *>(ctx->mask1.as<uint64_t>() + 2 * (size_t)wpr),
-                                 lut_chunks(wpr / 2, 2), 2, &lut));
-        ctx->lut_valid = true;
+    ctx->lut6_valid = false;
+    if (weights) {   // class-weight sums from a table in LDS: six-bit groups in f32 (row_moments_f32) when a row's table fits, else nibbles in f64
+        const double *wtab = reinterpret_cast<const double *>(ctx->mask1.as<uint64_t>() + 2 * (size_t)wpr);
+        const float *lut6 = nullptr;
+        PSK_TRY(build_moment_lut6(ctx, wtab, wpr / 2, 2, &lut6));
+        if (lut6) ctx->lut6_valid = true;
+        else if (lut_chunks(wpr / 2, 2) > 0) {
+            const double *lut = nullptr;
+            PSK_TRY(build_moment_lut(ctx, wtab, lut_chunks(wpr / 2, 2), 2, &lut));
+            ctx->lut_valid = true;
+        }
     }
     ctx->last.valid = true;
     ctx->last.weighted = weights != nullptr;
@@ -1147,15 +1335,15 @@ static int chi2_scan_launch(psk_ctx *ctx, const int8_t *pheno, const double *wei
     ctx->last.pvalue_cutoff = pvalue_cutoff;
     ctx->last.omit_B = omit_B ? 1 : 0;
     ctx->last.n_kmers_global = n_kmers_global;
+    ctx->last.n1 = n1; ctx->last.n0 = n0; ctx->last.W1 = W1; ctx->last.W0 = W0;
     ScanArgs a;
     PSK_TRY(fill_chi2_args(ctx, a, set));
-    a.n1 = n1; a.n0 = n0; a.W1 = W1; a.W0 = W0;
-    ctx->last.n1 = n1; ctx->last.n0 = n0; ctx->last.W1 = W1; ctx->last.W0 = W0;
+    a.n1 = n1; a.n0 = n0;
     ctx->last_scan_kind = 1;
     if (ctx->n_kmers) {
         ScanSlot &sl = ctx->slot[set];
         const int G = group_lanes(a.cpr);
-        const dim3 grid = scan_grid(ctx, a.M, G, SC_UNROLL, a.lut != nullptr);
+        const dim3 grid = scan_grid(ctx, a.M, G, SC_UNROLL, a.lut != nullptr || a.lut6 != nullptr);
         PSK_HIP(ctx, hipEventRecord(sl.ev0, ctx->stream));
         launch_chi2(pick_chi2_mode(ctx, ctx->last.weighted, a.pcut, a.pcut_bonf, a.omit_B), G, grid, ctx->stream, a);
         PSK_HIP(ctx, hipGetLastError());
@@ -1256,11 +1444,22 @@ extern "C" int psk_ttest_scan(psk_ctx *ctx, const double *pheno, const uint8_t *
         swv += wi * pheno[i];
     }
     const double mu = sw > 0 ? swv / sw : 0.0;  // the kernel accumulates moments of (value - mu)
-    double tot_w = 0.0, tot_wu = 0.0, tot_wuu = 0.0;
+    // ... scaled by a power of two (exact; t does not change) so that the spread is ~1: the f32 table of the candidate
+    // pass then neither underflows nor overflows whatever unit the phenotype is in
+    double scale = 1.0;
+    {
+        double ss = 0.0;
+        for (int i = 0; i < N; i++) if (valid[i]) { const double u = pheno[i] - mu; ss += (weights ? weights[i] : 1.0) * u * u; }
+        const double sd = sw > 0 ? std::sqrt(ss / sw) : 0.0;
+        if (sd > 0 && std::isfinite(sd)) { int ex = 0; (void)std::frexp(sd, &ex); scale = std::ldexp(1.0, 1 - ex); }
+    }
+    double tot_w = 0.0, tot_wu = 0.0, tot_wuu = 0.0, abs_wu = 0.0, max_abs_v = 0.0;
     for (int i = 0; i < N; i++) {
         if (!valid[i]) continue;
         mv[i >> 6] |= 1ull << (i & 63);
-        const double u = pheno[i] - mu, wi = weights ? weights[i] : 1.0;
+        const double u = (pheno[i] - mu) * scale, wi = weights ? weights[i] : 1.0;
+        abs_wu += std::fabs(wi * u);
+        max_abs_v = std::max(max_abs_v, std::fabs(pheno[i]));
         if (unit_w) { vw[2 * (size_t)i] = u; vw[2 * (size_t)i + 1] = u * u; }
         else { vw[3 * (size_t)i] = wi; vw[3 * (size_t)i + 1] = wi * u; vw[3 * (size_t)i + 2] = wi * u * u; }
         tot_w += wi; tot_wu += wi * u; tot_wuu += wi * u * u;
@@ -1301,10 +1500,19 @@ extern "C" int psk_ttest_scan(psk_ctx *ctx, const double *pheno, const uint8_t *
     PSK_TRY(pick_result_set(ctx, &set));
     const int G = group_lanes(a.cpr);
     ctx->lut_valid = false;   // the table buffer is shared with the weighted chi2 scan
-    a.c_lut = lut_chunks(a.cpr, NM);
-    if (a.c_lut > 0) PSK_TRY(build_moment_lut(ctx, a.tab, a.c_lut, NM, &a.lut));
-    const dim3 grid = scan_grid(ctx, a.M, G, SC_UNROLL, a.lut != nullptr);
-    PSK_TRY(setup_results(ctx, a, grid, G, a.lut ? lut_unroll(G) : SC_UNROLL, set, a.lut ? SC_LUT_THREADS : SC_THREADS));
+    ctx->lut6_valid = false;
+    a.eref = 4.0 * (double)N * 1.1102230246251565e-16 * max_abs_v * scale;   // in the kernel's (shifted, scaled) units
+    PSK_TRY(build_moment_lut6(ctx, a.tab, a.cpr, NM, &a.lut6));
+    if (a.lut6) {   // what the f32 sums of the candidate pass may be off by (row_moments_f32)
+        const double gm = lut6_gamma(a.cpr);
+        a.e0 = gm * tot_w + 1e-36; a.e1 = gm * abs_wu + 1e-36; a.e2 = gm * tot_wuu + 1e-36;
+    } else {
+        a.c_lut = lut_chunks(a.cpr, NM);
+        if (a.c_lut > 0) PSK_TRY(build_moment_lut(ctx, a.tab, a.c_lut, NM, &a.lut));
+    }
+    const bool table = a.lut != nullptr || a.lut6 != nullptr;
+    const dim3 grid = scan_grid(ctx, a.M, G, SC_UNROLL, table);
+    PSK_TRY(setup_results(ctx, a, grid, G, table ? lut_unroll(G) : SC_UNROLL, set, table ? SC_LUT_THREADS : SC_THREADS));
     ctx->n_pass = 0;
     ctx->last_scan_kind = 2;
     ctx->last.valid = false;

@@ -159,7 +159,10 @@ __global__ void synth_presence_kernel(uint64_t *__restrict__ bits, uint64_t m, i
         const int s = (int)((hr >> 20) % (uint64_t)n_samples);
         if (((hr >> 50) & 3) == 0 && s >= base && s < base + 64) word &= ~(1ull << (s - base));
     } else {
-        const bool gene = cls == 99;
+        // seed bits 48..63 (benchmark knob): keep only that many in 10,000 of the gene rows (0: all of them, 1 % of the matrix);
+        // the others become random-density rows.  80 gives config 2's share of survivors (0.008 %).
+        const uint32_t keep = (uint32_t)(seed >> 48);
+        const bool gene = cls == 99 && (keep == 0 || (uint32_t)((hr >> 33) % 10000u) < keep);
         const uint32_t dens = (uint32_t)((hr >> 24) & 0xff);  // per-row density /256
         for (int b = 0; b < 64; b += 8) {
             uint64_t h = splitmix64(hr ^ ((uint64_t)(c * 8 + (b >> 3)) * 0x2545F4914F6CDD1Dull));

@@ -153,6 +153,7 @@ struct psk_ctx {
     DevBuf mask1, phe, res_count, res_sorted;
     DevBuf lut;                          // nibble table of the moment scans (assoc_scan.hip row_moments_lut)
     bool lut_valid = false;              // ... holds the table of the last weighted chi2 scan
+    bool lut6_valid = false;             // ... in its six-bit f32 form (row_moments_f32)
     uint64_t n_pass = 0;
     uint64_t res_seg_cap = 0;            // entries per result segment of the last scan
     std::vector<uint32_t> seg_counts;    // survivors per segment

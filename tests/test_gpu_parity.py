@@ -239,6 +239,48 @@ def test_ttest_scan_vs_oracle(ctx, oracle, n, weighted):
         assert differing == 0
 
 
+@pytest.mark.parametrize("n,offset,scale,wspread", [(1024, 0.0, 1.0, 0.0), (1024, 1e6, 1e-3, 2.5), (700, -3e3, 1e-12, 1.0), (384, 5.0, 1e9, 3.0),
+                                                    (2048, 0.0, 1.0, 0.5)])
+def test_moment_scans_miss_no_candidate_on_badly_scaled_data(ctx, oracle, n, offset, scale, wspread):
+    """r03: the streaming kernels of the Welch and weighted chi2 scans pick their candidates from f32 sums over six-bit
+    tables and an upper bound of the statistic built from rounding-error bounds; the second kernel decides exactly.
+    So the kept rows must equal the oracle's whatever the phenotype's unit (offsets of 1e6 against a spread of 1e-3,
+    values of 1e-12 or 1e9), with weights over six orders of magnitude, and with cuts that put many rows near the
+    threshold.  (2,048 samples: the six-bit table does not fit the LDS, the f64 nibble table serves.)"""
+    from phenotypeseeker_amd.engine import words_per_row
+    rng = np.random.default_rng(int(n + wspread * 10))
+    m = 6000
+    wpr = words_per_row(n)
+    bits = _random_matrix(rng, m, n, wpr)
+    base = rng.normal(0.0, 1.0, n)
+    vals = offset + scale * base
+    valid = rng.random(n) > 0.03
+    for r in range(0, m, 3):  # planted associations of every strength, so that rows sit on both sides of every cut
+        row = base + rng.normal(0, rng.uniform(0.3, 3.0), n) > rng.uniform(-0.5, 1.0)
+        bits[r] = 0
+        for i in np.nonzero(row)[0]:
+            bits[r, i >> 6] |= np.uint64(1) << np.uint64(i & 63)
+    weights = np.exp(rng.normal(0.0, wspread, n)) if wspread else np.ones(n)
+    pheno = [float(v) if ok else "NA" for v, ok in zip(vals, valid)]
+    ctx.set_presence(bits, n)
+    for cut, nk in ((0.05, 1), (0.05, m), (1e-6, m), (0.9, 1)):
+        ref = oracle.ttest_scan(bits, pheno, weights, n, 2, n - 2, cut, nk)
+        npass = ctx.ttest_scan(vals, valid, weights if wspread else None, 2, n - 2, cut, nk)
+        res = ctx.get_results(npass)
+        keep = np.nonzero(ref["keep"])[0]
+        assert np.array_equal(res["row"], keep.astype(np.uint64)), (cut, nk, npass, len(keep))
+        assert np.array_equal(res["stat"], ref["stat"][keep])
+    ph01 = [(int(b > 0) if ok else "NA") for b, ok in zip(base, valid)]
+    ph8 = np.array([(-1 if p == "NA" else p) for p in ph01], dtype=np.int8)
+    for cut, omit, nk in ((0.05, True, m), (0.05, False, m), (1e-9, False, m)):
+        ref = oracle.chi2_scan(bits, ph01, weights, n, 2, n - 2, cut, omit, nk)
+        npass = ctx.chi2_scan(ph8, weights if wspread else None, 2, n - 2, cut, omit, nk)
+        res = ctx.get_results(npass)
+        keep = np.nonzero(ref["keep"])[0]
+        assert np.array_equal(res["row"], keep.astype(np.uint64)), (cut, omit)
+        assert np.array_equal(res["stat"], ref["stat"][keep])
+
+
 def test_count_dict_matches_gmer_counter(ctx, oracle):
     with open(os.path.join(GOLDEN, "gmer_counter.json")) as f:
         d = json.load(f)

@@ -1,6 +1,8 @@
 #!/usr/bin/env python3
 """Unweighted chi2 scan across sample counts: kernel time and achieved GB/s of algorithmic bytes (M * 8 * ceil(N/64))
-at ~0.75 GB of matrix per shape.  usage: tools/shape_probe.py [N ...]"""
+at ~2 GB of matrix per shape (far beyond the 256-MiB Infinity Cache), once with the synthetic matrix's 1 % of surviving
+rows and once with config 2's share (0.008 %).  Output committed as profiles/r03_shapes.md.
+usage: tools/shape_probe.py [N ...]"""
 import os
 import sys
 
@@ -11,17 +13,23 @@ sys.path.insert(0, ROOT)
 from phenotypeseeker_amd.engine import PskContext  # noqa: E402
 
 shapes = [int(a) for a in sys.argv[1:]] or [64, 128, 256, 512, 1024, 2048, 4096]
+print("| samples | lanes per row | rows | survivors | kernel ms | algorithmic GB/s | frac of 8 TB/s | stored GB/s |")
+print("|---:|---:|---:|---:|---:|---:|---:|---:|")
 with PskContext(0) as ctx:
     for N in shapes:
         words = (N + 63) // 64
         _, wpr = 0, words + (words & 1) if words > 1 else 2
-        M = int(0.75e9 // (8 * max(wpr, 2)))
-        ctx.begin(16, N)
-        ctx.synth_presence(M, N, 7)
-        wpr = ctx.presence_shape()[1]
-        ph = (np.arange(N) % 2).astype(np.int8)
-        n = ctx.chi2_scan(ph, None, 2, N - 2, 0.05, False, M)
-        ctx.rescan_timed(200)
-        ms = ctx.rescan_timed(200)
-        print("N %5d  wpr %3d  rows %9d  survivors %7d  kernel %.4f ms  algorithmic %.0f GB/s  stored %.0f GB/s"
-              % (N, wpr, M, n, ms, M * 8 * words / ms / 1e6, M * 8 * wpr / ms / 1e6), flush=True)
+        M = int(2.0e9 // (8 * max(wpr, 2)))
+        G = 1
+        while G < wpr // 2:
+            G *= 2
+        for keep in (0, 80):
+            ctx.begin(16, N)
+            ctx.synth_presence(M, N, 7 | (keep << 48))
+            wpr = ctx.presence_shape()[1]
+            ph = (np.arange(N) % 2).astype(np.int8)
+            n = ctx.chi2_scan(ph, None, 2, N - 2, 0.05, False, M)
+            ctx.rescan_timed(50)
+            ms = ctx.rescan_timed(100)
+            print("| %d | %d | %d | %d (%.3f %%) | %.4f | %.0f | %.3f | %.0f |"
+                  % (N, G, M, n, 100.0 * n / M, ms, M * 8 * words / ms / 1e6, M * 8 * words / ms / 1e6 / 8000, M * 8 * wpr / ms / 1e6), flush=True)
