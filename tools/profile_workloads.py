@@ -6,6 +6,10 @@
   fastq      one config-5 sample: 2 M x 150-bp reads, 0.63 GB of FASTQ, framed and counted
   ingest     config 2's ingest alone: 256 x 5 Mbp, k = 13, counted three times + presence build
   solver     the L1 (grid value, fold) fits of three recorded runs (143 fits each)
+  predict    `prediction` counting (f1): 256 x 5 Mbp against a 1,000-word model dictionary, and a 5,000-word one (global table)
+  weights    the -w side path (f2) at 1,024 samples: MinHash sketches beside the counting (hash filter + select), the
+             523,776 pair merges of mash_pairs_kernel, neighbour joining of the 1,024 leaves
+  lasso      the bit-packed Lasso grid (13 alphas x 10 folds + refits) of a 1,024-sample continuous run
 Each prints one JSON line: the algorithmic bytes per launch of its kernels (what `frac` in profiles/ is computed from).
 usage: tools/profile_workloads.py NAME"""
 import json
@@ -52,6 +56,11 @@ if what == "cfg3slab":
         alg["bs_partition_kernel"] = L + 4 * kept
         alg["bs_sort_kernel"] = 4 * kept + 8 * kept
         alg["bs_compact_kernel"] = 8 * kept + 12 * kept
+        # presence build, streaming merge (12 B x pairs read + the matrix written; the merge reads the 8-byte
+        # words only, and twice -- once per pass): pm_mark = 8 B x pairs + the occupancy bitmap, pm_fill = 8 B x pairs +
+        # the matrix + the union words
+        alg["pm_mark_kernel"] = 8 * pairs
+        alg["pm_fill_kernel"] = 8 * pairs + m * 256 + m * 8
 elif what == "moments":
     M, N = 16_000_000, 1024
     rng = np.random.default_rng(3)
@@ -142,6 +151,62 @@ elif what == "solver":
         t0 = time.time()
         ctx.logreg_l1_fit(X, d["y"], d["fold"], d["fit_param"], d["fit_fold"], float(d["tol"]), int(d["max_iter"]))
         out["notes"]["fit2048_907"] = {"X": list(X.shape), "fits": int(len(d["fit_param"])), "wall_s": [round(time.time() - t0, 3)]}
+elif what == "predict":
+    n, L, k = 256, 5_000_000, 13
+    gs = GenomeSet(n, L, seed=12345)
+    fas = [gs.sample(i)[1] for i in range(n)]
+    with PskContext(0) as ctx:
+        ctx.begin(k, 1)
+        nu, _ = ctx.count_kmers(0, fas[0])
+        words = ctx.get_list(0, nu)[0]
+        ts = {}
+        for nd in (1000, 5000):
+            d = words[:: max(1, len(words) // nd)][:nd]
+            for rep in range(2):
+                t0 = time.time()
+                for lo in range(0, n, 64):
+                    ctx.count_dict_batch(fas[lo:lo + 64], k, d, 8)
+                ts[nd] = round(time.time() - t0, 4)
+        out["notes"] = {"samples": n, "wall_s_by_dictionary_size": ts}
+        alg["dict_count_kernel"] = L                    # 1 B per base: the clean stream is read once, the table sits in LDS / L2
+elif what == "weights":
+    n, L = 1024, 5_000_000
+    gs = GenomeSet(n, L, seed=4242)
+    from phenotypeseeker_amd import weights as Wt
+    with PskContext(0) as ctx:
+        ctx.begin(13, n)
+        sketches, t0 = [], time.time()
+        for lo in range(0, n, 64):
+            _, _, sk = ctx.count_kmers_batch(lo, [gs.sample(i)[1] for i in range(lo, lo + 64)], 8, sketch=(21, 1000, 42))
+            sketches += sk
+        t1 = time.time()
+        common, denom = ctx.mash_pairs(sketches, 1000)
+        t2 = time.time()
+        dist = Wt.distances_from_counts(common, denom, 21)
+        t3 = time.time()
+        ctx.nj_merges(dist)
+        t4 = time.time()
+        out["notes"] = {"samples": n, "generate_count_sketch_s": round(t1 - t0, 2), "mash_pairs_s": round(t2 - t1, 4),
+                        "distances_host_s": round(t3 - t2, 4), "nj_s": round(t4 - t3, 4)}
+        alg["kmer_hash_filter_kernel"] = 8 * L        # one 8-byte window word per base position (k = 21 extract output) read once
+        alg["mash_pairs_kernel"] = n * (n + 1) // 2 * 2 * 8 * 1000      # two sketches of 1,000 hashes per pair (L2-resident: a latency bound, not HBM)
+        alg["nj_kernel"] = sum(m * m // 2 * 8 for m in range(3, n + 1))   # the lower triangle once per join (L2-resident)
+elif what == "lasso":
+    d = np.load(os.path.join(ROOT, "tools", "data", "fit2048_907.npz"))
+    X = np.unpackbits(d["Xbits"], axis=1)[:1024, : int(d["p"])].astype(np.float32)
+    rng = np.random.default_rng(5)
+    y = 2.0 * X[:, 3] - 1.5 * X[:, 40] + rng.normal(0, 0.5, 1024)
+    fold = (np.arange(1024) * 10 // 1024).astype(np.int32)
+    alphas = np.logspace(-3, 3, 13)
+    fp = np.concatenate([np.repeat(alphas, 10), alphas])
+    ff = np.concatenate([np.tile(np.arange(10), 13), np.full(13, -1)]).astype(np.int32)
+    with PskContext(0) as ctx:
+        ts = []
+        for rep in range(2):
+            t0 = time.time()
+            ctx.lasso_fit(X, y, fold, fp, ff, 1e-4, 1000)
+            ts.append(round(time.time() - t0, 4))
+        out["notes"] = {"X": list(X.shape), "fits": int(len(fp)), "wall_s": ts}
 else:
     raise SystemExit("unknown workload " + what)
 print(json.dumps(out), flush=True)
