@@ -99,25 +99,33 @@ __device__ __forceinline__ W pm_wave_min(W v)
 // A lane's cursor into its list.  W = uint32_t: words relative to the slab's base (word spaces of up to 2^32 values:
 // every k <= 16), W = uint64_t otherwise; the all-ones value means "no word" (never a canonical word: the reverse
 // complement of T...T is A...A).
-// The lane holds a window of two 32-byte-aligned blocks of four words in registers (r[0..7]), the index i of its
-// current word inside the window, and the block behind the window (p[0..3]), requested ahead.  Loads happen ONLY in
-// refill(), which the whole wave runs when some lane has used its window up: every lane that is past its first block
-// moves the window one block on and requests the block after, so after a refill every lane has at least five words
-// ahead, the merge loop runs at least five iterations without touching memory, and a requested block has that long
-// to arrive.  (First cut: each lane prefetched its next block on its own, in the loop; the compiler has to wait for ALL
-// outstanding loads before the next use of any of them, so with the lanes out of phase nearly every iteration paid a
-// full memory latency: 13.8 + 21.2 ms for config 3's slab.)
-template <typename W>
+// The lane holds a window of two aligned blocks of B words in registers (r[0 .. 2B)), the index i of its current word
+// inside the window, and the block behind the window (pv), requested ahead.  Loads happen ONLY in refill(), which the
+// whole wave runs when some lane has used its window up: every lane that is past its first block moves the window one
+// block on and requests the block after, so after a refill every lane has at least B + 1 words ahead, the merge loop
+// runs at least B + 1 iterations without touching memory, and a requested block has that long to arrive.  (First cut:
+// each lane prefetched its next block on its own, in the loop; the compiler has to wait for ALL outstanding loads before
+// the next use of any of them, so with the lanes out of phase nearly every iteration paid a full memory latency: 13.8 +
+// 21.2 ms for config 3's slab.)  B = 8: a block is 64 bytes -- with 32-byte blocks every 128-byte line of a list went
+// through the L2 four times (each lane comes back to its line four refills later, 8 MB of lines in flight per XCD
+// against 4 MB of L2): 73 GB of L2 fills for the 20.5 GB the two passes read (PMC, r03).
+#ifndef PSK_PM_BLOCK
+#define PSK_PM_BLOCK 8
+#endif
+#ifndef PSK_PM_NT
+#define PSK_PM_NT 0
+#endif
+template <typename W, int B = PSK_PM_BLOCK>
 struct PmCursor {
     static constexpr W SENT = (W)~(W)0;
-    const uint64_t *w;     // the list, shifted down so that block b = w[4 b .. 4 b + 3] is 32-byte aligned
+    const uint64_t *w;     // the list, shifted down so that block b = w[B b .. B b + B - 1] is aligned to its size
     uint32_t first, end;   // the list's words are w[first .. end)
     uint32_t last_blk;     // block of the list's last word
-    uint32_t blk;          // block index of r[0..3]
-    uint32_t i;            // current word = r[i]; i == 8: the window is used up
+    uint32_t blk;          // block index of r[0 .. B)
+    uint32_t i;            // current word = r[i]; i == 2 B: the window is used up
     uint64_t base;
-    W r[8], cur;
-    pm_u64x2 px, py;       // the block behind the window as it was loaded, requested one refill ahead (see refill); it is
+    W r[2 * B], cur;
+    pm_u64x2 pv[B / 2];    // the block behind the window as it was loaded, requested one refill ahead (see refill); it is
                            // converted only when it moves into the window -- touching it earlier would make the
                            // compiler wait for the load right where it was issued
 
@@ -129,51 +137,70 @@ struct PmCursor {
         const uint64_t d = x - base;
         return (idx >= first && idx < end && (sizeof(W) == 8 || (d >> 32) == 0)) ? (W)d : SENT;
     }
-    // raw block b -> px, py (not waited for).  Always a load, never a branch: a block beyond the list is read from the
+    // raw block b -> pv (not waited for).  Always a load, never a branch: a block beyond the list is read from the
     // list's last block instead (take() turns indices beyond the end into "no word" whatever was read), because a
-    // conditional assignment makes the compiler load into temporaries and copy -- i.e. wait -- on the spot.  A 32-byte
-    // sector that holds at least one word of the list lies inside the list's allocation.
+    // conditional assignment makes the compiler load into temporaries and copy -- i.e. wait -- on the spot.  An aligned
+    // block that holds at least one word of the list lies inside the list's (256-byte granular) allocation.
     __device__ __forceinline__ void request(uint32_t b)
     {
         const uint32_t bb = b < last_blk ? b : last_blk;
-        const pm_gvec p = (pm_gvec)(uintptr_t)(w + 4 * (size_t)bb);
-        px = p[0]; py = p[1];
+        const pm_gvec p = (pm_gvec)(uintptr_t)(w + B * (size_t)bb);
+#pragma unroll
+        for (int k = 0; k < B / 2; k++) pv[k] = PSK_PM_NT ? __builtin_nontemporal_load(&p[k]) : p[k];
     }
     __device__ __forceinline__ void take(uint32_t b, W *dst) const   // block b, requested before, into the window
     {
-        dst[0] = conv(px.x, 4 * b); dst[1] = conv(px.y, 4 * b + 1); dst[2] = conv(py.x, 4 * b + 2); dst[3] = conv(py.y, 4 * b + 3);   // beyond the end: SENT
+#pragma unroll
+        for (int k = 0; k < B / 2; k++) {
+            dst[2 * k] = conv(pv[k].x, B * b + 2 * k);           // beyond the end: SENT
+            dst[2 * k + 1] = conv(pv[k].y, B * b + 2 * k + 1);
+        }
     }
-    __device__ __forceinline__ void select()
+    // v[i] for i < N by a binary tree of selects: bit 0 of i halves the candidates, then bit 1, ... (N - 1 v_cndmask; written
+    // as a recursion over constant sizes -- as a loop over a run-time step the compiler fell back to comparing i with every
+    // index for every element: 700 instructions per advance)
+    template <int N>
+    static __device__ __forceinline__ W pick(const W *v, uint32_t i)
     {
-        const W s01 = (i & 1) ? r[1] : r[0], s23 = (i & 1) ? r[3] : r[2], s45 = (i & 1) ? r[5] : r[4], s67 = (i & 1) ? r[7] : r[6];
-        const W t0 = (i & 2) ? s23 : s01, t1 = (i & 2) ? s67 : s45;
-        cur = (i & 4) ? t1 : t0;
+        if constexpr (N == 1) {
+            return v[0];
+        } else {
+            // (b & m) | (a & ~m) with m = all ones when the bit is set: one v_bfi_b32.  Written as `bit ? b : a` the compiler
+            // turns the pair into an indexed read of a stack array -- scratch memory inside the merge loop
+            W h[N / 2];
+            const W m = (W)0 - (W)(i & 1u);
+#pragma unroll
+            for (int k = 0; k < N / 2; k++) h[k] = (v[2 * k + 1] & m) | (v[2 * k] & ~m);
+            return pick<N / 2>(h, i >> 1);
+        }
     }
+    __device__ __forceinline__ void select() { cur = pick<2 * B>(r, i); }   // i == 2 B reads r[0]: the loop refills before it looks
     // pos: index into the list of the word to stand on (pos == n: at the end)
-    // words == nullptr or n == 0 (no sample in this lane, an empty list): `spare` (32-byte aligned, 32 bytes) is read instead
+    // words == nullptr or n == 0 (no sample in this lane, an empty list): `spare` (64-byte aligned, 64 bytes) is read instead
     __device__ __forceinline__ void seek(const uint64_t *words, uint32_t n, uint32_t pos, uint64_t base_, const uint64_t *spare)
     {
         if (!words || n == 0) { words = spare; n = 0; }
-        const uint32_t mis = (uint32_t)(((uintptr_t)words >> 3) & 3);
+        const uint32_t mis = (uint32_t)(((uintptr_t)words >> 3) & (B - 1));
         w = words - mis; first = mis; end = n + mis; base = base_;
-        last_blk = end ? (end - 1) >> 2 : 0;
+        last_blk = end ? (end - 1) / B : 0;
         const uint32_t q = pos + mis;
-        blk = q >> 2; i = q & 3;
+        blk = q / B; i = q % B;
         request(blk); take(blk, r);
-        request(blk + 1); take(blk + 1, r + 4);
+        request(blk + 1); take(blk + 1, r + B);
         request(blk + 2);
         select();
     }
-    __device__ __forceinline__ uint32_t position() const { return 4 * blk + i - first; }   // index into the list of the current word
-    __device__ __forceinline__ bool dry() const { return i >= 8; }
+    __device__ __forceinline__ uint32_t position() const { return B * blk + i - first; }   // index into the list of the current word
+    __device__ __forceinline__ bool dry() const { return i >= 2 * B; }
     // wave-uniform call.  The block that moves into the window was requested at the lane's PREVIOUS refill (or seek), at
-    // least five iterations of the merge loop ago; the one requested here is not waited for until the next refill.
+    // least B + 1 iterations of the merge loop ago; the one requested here is not waited for until the next refill.
     __device__ __forceinline__ void refill()
     {
-        if (i >= 4) {
-            r[0] = r[4]; r[1] = r[5]; r[2] = r[6]; r[3] = r[7];
-            blk++; i -= 4;
-            take(blk + 1, r + 4);
+        if (i >= B) {
+#pragma unroll
+            for (int k = 0; k < B; k++) r[k] = r[B + k];
+            blk++; i -= B;
+            take(blk + 1, r + B);
             request(blk + 2);
             select();
         }
@@ -181,7 +208,7 @@ struct PmCursor {
     __device__ __forceinline__ void advance()
     {
         i++;
-        select();   // i == 8: some value of the window; the loop refills before it looks at `cur` again
+        select();   // i == 2 B: some value of the window; the loop refills before it looks at `cur` again
     }
 };
 
