@@ -1,8 +1,8 @@
 #!/usr/bin/env python3
 """The L1-logistic grid of a 2,048-genome run whose 1,000 selected k-mers have 907 distinct patterns (tools/data/fit2048_907.npz:
 143 fits, the register form of the descent): wall-clock, Newton steps, and the objective every fit reached -- with the
-matrix-free conjugate-gradient accelerator (default) and without it (PSK_NO_CG_COOP=1).
-usage: tools/solver_grid_probe.py [cg|nocg|both]"""
+library as built, and -- for A/B runs of an experimental descent -- with the variable named by PSK_PROBE_OFF_VAR set to 1.
+usage: tools/solver_grid_probe.py [new|old|both]"""
 import os
 import sys
 import time
@@ -13,7 +13,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 from phenotypeseeker_amd.engine import PskContext  # noqa: E402
 
-mode = sys.argv[1] if len(sys.argv) > 1 else "both"
+mode = sys.argv[1] if len(sys.argv) > 1 else "new"
 d = np.load(os.path.join(ROOT, "tools", "data", "fit2048_907.npz"))
 X = np.unpackbits(d["Xbits"], axis=1)[:, : int(d["p"])].astype(np.float32)
 y, fold, fp, ff = d["y"], d["fold"], d["fit_param"], d["fit_fold"]
@@ -30,11 +30,12 @@ def objectives(coef, icpt):
 
 
 res = {}
-for tag in (["cg", "nocg"] if mode == "both" else [mode]):
-    if tag == "nocg":
-        os.environ["PSK_NO_CG_COOP"] = "1"
+OFF = os.environ.get("PSK_PROBE_OFF_VAR", "PSK_EXPERIMENT_OFF")
+for tag in (["new", "old"] if mode == "both" else [mode]):
+    if tag == "old":
+        os.environ[OFF] = "1"
     else:
-        os.environ.pop("PSK_NO_CG_COOP", None)
+        os.environ.pop(OFF, None)
     with PskContext(0) as ctx:
         ctx.logreg_l1_fit(X[:, :50], y, fold, fp[:2], ff[:2], 1e-4, 50)       # code objects, buffers
         t0 = time.time()
@@ -45,5 +46,5 @@ for tag in (["cg", "nocg"] if mode == "both" else [mode]):
     print("%-5s wall %.3f s  Newton steps max %d mean %.1f  objective sum %.6e  nnz mean %.0f" % (
         tag, wall, iters.max(), iters.mean(), obj.sum(), (coef != 0).sum(axis=1).mean()), flush=True)
 if len(res) == 2:
-    rel = (res["cg"] - res["nocg"]) / res["nocg"]
-    print("objective cg vs nocg: worst +%.2e best %.2e (relative; negative = the accelerated run ends lower)" % (rel.max(), rel.min()))
+    rel = (res["new"] - res["old"]) / res["old"]
+    print("objective new vs old: worst +%.2e best %.2e (relative; negative = the new form ends lower)" % (rel.max(), rel.min()))
