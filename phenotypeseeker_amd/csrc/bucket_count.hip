@@ -411,11 +411,10 @@ int launch_tiles(psk_ctx *ctx, CountLane &L, const BsBufs &d, uint64_t clean_len
     bs_hist_kernel<K><<<n_tiles, BT_THREADS, 0, ctx->stream>>>(L.raw.as<uint8_t>(), clean_len, lo, hi, ctx->bs_spl.as<uint32_t>(), ct, mp, d.cnt,
                                                                L.dc_wgoff.as<uint32_t>());
     PSK_HIP(ctx, hipGetLastError());
-    static bool attr_set = false;
-    if (!attr_set) {
+    static PerDeviceOnce attr_set;
+    if (attr_set.first(ctx->device)) {
         PSK_HIP(ctx, hipFuncSetAttribute(reinterpret_cast<const void *>(bs_partition_kernel<K>),
                                          hipFuncAttributeMaxDynamicSharedMemorySize, (int)BP_LDS_BYTES));
-        attr_set = true;
     }
     bs_partition_kernel<K><<<n_tiles, BT_THREADS, BP_LDS_BYTES, ctx->stream>>>(L.raw.as<uint8_t>(), clean_len, lo, hi,
                                                                               ctx->bs_spl.as<uint32_t>(), ct, mp, d.cnt,
@@ -489,11 +488,10 @@ int bucket_chain_enqueue(psk_ctx *ctx, CountLane &L, int sample_idx, uint64_t cl
     }
     PSK_HIP(ctx, hipEventRecord(L.raw_free, ctx->stream));
     L.raw_used = true;
-    static bool attr_set = false;
-    if (!attr_set) {
+    static PerDeviceOnce attr_set;
+    if (attr_set.first(ctx->device)) {
         PSK_HIP(ctx, hipFuncSetAttribute(reinterpret_cast<const void *>(bs_sort_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
                                          (int)BSORT_LDS_BYTES));
-        attr_set = true;
     }
     uint32_t *wtmp = L.dc_mtemp.as<uint32_t>(), *ctmp = wtmp + n + 8;
     const uint32_t sort_wgs = ctx->bs_nb < 2u * (uint32_t)(ctx->n_cu > 0 ? ctx->n_cu : 256) ? ctx->bs_nb : 2u * (uint32_t)(ctx->n_cu > 0 ? ctx->n_cu : 256);

@@ -496,11 +496,10 @@ DcBufs dc_bufs(const CountLane &L, uint32_t slot)
 template <int K>
 int launch_tiles(psk_ctx *ctx, const CountLane &L, const DcBufs &d, uint64_t clean_len, uint32_t n_tiles, uint32_t lo, uint32_t hi)
 {
-    static bool lds_set = false;
-    if (!lds_set) {
+    static PerDeviceOnce lds_set;
+    if (lds_set.first(ctx->device)) {
         PSK_HIP(ctx, hipFuncSetAttribute(reinterpret_cast<const void *>(dc_partition_kernel<K>),
                                          hipFuncAttributeMaxDynamicSharedMemorySize, (int)DP_LDS_BYTES));
-        lds_set = true;
     }
     const uint8_t *clean = L.raw.as<uint8_t>();
     dc_hist_kernel<K><<<n_tiles, DT_THREADS, 0, ctx->stream>>>(clean, clean_len, lo, hi, ctx->dense_b0, ctx->dense_nb, d.cnt,
@@ -515,11 +514,10 @@ int launch_tiles(psk_ctx *ctx, const CountLane &L, const DcBufs &d, uint64_t cle
 
 int launch_table_count(psk_ctx *ctx, const CountLane &L, const DcBufs &d, uint64_t *bitmap, const uint32_t *need)
 {
-    static bool lds_set = false;
-    if (!lds_set) {
+    static PerDeviceOnce lds_set;
+    if (lds_set.first(ctx->device)) {
         PSK_HIP(ctx, hipFuncSetAttribute(reinterpret_cast<const void *>(dc_count_kernel),
                                          hipFuncAttributeMaxDynamicSharedMemorySize, (int)DCNT_LDS_BYTES));
-        lds_set = true;
     }
     dc_count_kernel<<<ctx->dense_nb, DT_THREADS, DCNT_LDS_BYTES, ctx->stream>>>(L.dc_part.as<uint16_t>(), d.cnt, d.base, ctx->dense_b0,
                                                                                bitmap, d.mt_w, d.mt_f, d.uniq, d.multi, need);

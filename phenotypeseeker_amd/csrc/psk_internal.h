@@ -191,6 +191,19 @@ void comm_release(psk_ctx *ctx);   // comm.hip: destroys the context's RCCL comm
 
 static inline unsigned div_up(uint64_t a, uint64_t b) { return (unsigned)((a + b - 1) / b); }
 
+// hipFuncSetAttribute(MaxDynamicSharedMemorySize) applies to the CURRENT device: "done once" has to be remembered per
+// device, and contexts may count from different threads (a function-local `static bool` let a second GPU launch
+// the 64-76 KB kernels without the attribute).  One of these per kernel; first(device) is true exactly once per device.
+#include <atomic>
+struct PerDeviceOnce {
+    std::atomic<uint64_t> seen[4] = {};   // 256 devices
+    bool first(int device)
+    {
+        const uint64_t bit = 1ull << (device & 63);
+        return (seen[(device >> 6) & 3].fetch_or(bit) & bit) == 0;
+    }
+};
+
 // ---- device primitives (scan.hip / radix_sort.hip) ---------------------------------------------
 // Exclusive prefix sum of n u32 values (in == out allowed).  total_out (device u32*) may be null.
 int dev_exclusive_scan_u32(psk_ctx *ctx, const uint32_t *in, uint32_t *out, uint64_t n, uint32_t *total_out);

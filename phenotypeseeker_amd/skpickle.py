@@ -110,6 +110,10 @@ class _StubUnpickler(pickle.Unpickler):
     _made = {}
 
     def find_class(self, module, name):
+        if module.split(".")[0] == "joblib":
+            # a joblib-wrapped file carries raw array bytes inline behind a NumpyArrayWrapper: read as pickle opcodes they
+            # are garbage -- stop here, the caller takes joblib.load
+            raise pickle.UnpicklingError("joblib-wrapped arrays: not a plain pickle")
         if module.split(".")[0] == "sklearn":
             key = (module, name)
             if key not in self._made:
@@ -146,7 +150,9 @@ class LinearModel:
     def predict_proba(self, X):
         import numpy as np
         s = self._scores(X)
-        p = 1.0 / (1.0 + np.exp(-s))
+        # scipy.special.expit, without the overflow warning of exp(-s) at strongly negative scores
+        e = np.exp(-np.abs(s))
+        p = np.where(s >= 0, 1.0 / (1.0 + e), e / (1.0 + e))
         return np.vstack([1.0 - p, p]).T
 
 
@@ -169,6 +175,10 @@ def load_linear_package(path):
         if kind in ("LogisticRegression",):
             classes = getattr(est, "classes_", None)
             if classes is None or len(classes) != 2 or getattr(coef, "shape", (0,))[0] != 1:
+                return None
+            # a binary model saved with multi_class='multinomial' has softmax([-d, d]) = expit(2 d) probabilities in
+            # scikit-learn, not expit(d): leave it to joblib.load + scikit-learn
+            if getattr(est, "multi_class", "auto") not in ("auto", "ovr", "deprecated", "warn"):
                 return None
             model = LinearModel(coef, icpt, classes)
         elif kind in ("Lasso", "Ridge"):

@@ -97,3 +97,23 @@ def test_bench_without_rccl_and_without_the_opt_in_fails():
     assert r.returncode == 0, r.stderr[-2000:]
     d = json.loads(r.stdout.strip().splitlines()[-1])
     assert d["rccl_ranks"] == 1 and d["config"]["collectives"] == "rccl" and d["scaling"] == "weak"
+
+
+def test_bench_under_the_drivers_launcher():
+    """The driver starts N > 1 as `python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N`: the ranks then
+    come with RANK / LOCAL_RANK / WORLD_SIZE in their environment and bench.py must NOT start ranks of its own; they meet in
+    the per-user rendezvous directory keyed by the launcher process (no PSK_RDZV_DIR).  Two ranks on the one GPU here
+    (--share-gpu: host-file collectives, so the line says "invalid"); torch is the launcher only -- the ranks never import it."""
+    env = {k_: v for k_, v in os.environ.items() if k_ not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "PSK_DIST_TRANSPORT", "PSK_RDZV_DIR",
+                                                            "PSK_RDZV_FILE", "PSK_LAUNCH_NONCE")}
+    launcher = "torch.distributed" + ".run"
+    cmd = [sys.executable, "-m", launcher, "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1", "--master-port", "29641",
+           os.path.join(ROOT, "bench.py"), "--gpus", "2", "--share-gpu", "--samples", "64", "--length", "200000", "--kmer", "16",
+           "--steps", "3", "--warmup", "1", "--no-e2e"]
+    r = subprocess.run(cmd, env=env, cwd=ROOT, timeout=900, capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr[-3000:]
+    lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 2 and d["scaling"].startswith("invalid (") and d["config"]["collectives"].startswith("host-files")
+    assert len(d["config"]["rows_per_rank"]) == 2 and d["value"] > 0

@@ -266,3 +266,42 @@ def test_prediction_reads_linear_models_without_scikit_learn(tmp_path):
              "assert skpickle.load_linear_package(%r) is not None; assert 'sklearn' not in sys.modules and 'joblib' not in sys.modules"
              % (ROOT_DIR, os.path.join(str(tmp_path), "logistic.pkl")))
     assert subprocess.run([sys.executable, "-c", probe], timeout=120).returncode == 0
+
+
+def test_linear_package_loader_leaves_what_it_cannot_reproduce_to_scikit_learn(tmp_path):
+    """ADVICE r02 on skpickle.load_linear_package: a binary LogisticRegression saved with multi_class='multinomial' has
+    softmax([-d, d]) = expit(2 d) probabilities in scikit-learn -- the stub loader must return None for it (joblib.load +
+    scikit-learn then apply the model); a joblib-wrapped file (arrays stored raw behind NumpyArrayWrapper) is refused at
+    its first joblib class instead of reading array bytes as opcodes; and the probabilities of the models it does take
+    are scipy's expit without overflow warnings at scores of -800."""
+    import pickle
+    import warnings
+    import joblib
+    import numpy as np
+    from sklearn.linear_model import LogisticRegression
+    from phenotypeseeker_amd import skpickle
+    rng = np.random.default_rng(4)
+    X = (rng.random((40, 5)) < 0.5).astype(np.float64)
+    y = (X[:, 0] + X[:, 1] > 0.5).astype(int)
+    est = LogisticRegression(penalty="l1", solver="liblinear", C=10.0).fit(X, y)
+    pkg = {"model": est, "kmers": np.array(list("ACGTA"), dtype=object), "pca": False, "pred_scale": "binary"}
+    plain = os.path.join(tmp_path, "plain.pkl")
+    with open(plain, "wb") as f:
+        pickle.dump(pkg, f, protocol=4)
+    fast = skpickle.load_linear_package(plain)
+    assert fast is not None
+    big = np.array([[800.0, 0, 0, 0, 0], [-800.0, 0, 0, 0, 0]]) / max(abs(est.coef_[0, 0]), 1e-3)
+    with warnings.catch_warnings():
+        warnings.simplefilter("error")
+        pr = fast["model"].predict_proba(np.vstack([X, big]))
+    assert np.allclose(pr[:40], est.predict_proba(X), rtol=1e-12, atol=0) and np.all(np.isfinite(pr))
+    est.multi_class = "multinomial"          # what an older scikit-learn records for LogisticRegression(multi_class='multinomial')
+    multi = os.path.join(tmp_path, "multi.pkl")
+    with open(multi, "wb") as f:
+        pickle.dump(pkg, f, protocol=4)
+    assert skpickle.load_linear_package(multi) is None
+    del est.multi_class
+    wrapped = os.path.join(tmp_path, "wrapped.pkl")
+    pkg["kmers"] = np.arange(100_000)         # a large numeric array: joblib stores it raw behind a NumpyArrayWrapper
+    joblib.dump(pkg, wrapped)
+    assert skpickle.load_linear_package(wrapped) is None
