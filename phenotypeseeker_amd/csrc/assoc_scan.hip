@@ -24,7 +24,7 @@
 
 namespace {
 
-// tuning knobs (overridable at build time for A/B runs: tools/scan_variants.sh)
+// tuning knobs (overridable at build time for A/B runs: make EXTRA=-DPSK_SC_UNROLL=...)
 #ifndef PSK_SC_UNROLL
 #define PSK_SC_UNROLL 4
 #endif
