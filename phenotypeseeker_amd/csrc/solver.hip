@@ -352,9 +352,9 @@ __global__ __launch_bounds__(WMREG > 0 ? SV_COOP_THREADS : SV_THREADS) void logr
     int W, const double *__restrict__ fit_param, const int32_t *__restrict__ fit_fold, double tol, int max_newton,
     double *__restrict__ coef, double *__restrict__ icpt, int32_t *__restrict__ iters, double *__restrict__ work,
     int32_t *__restrict__ iwork, const int f_lds_rt, const int s_lds_rt, const int c_lds_rt, const int q_doubles_i, const int cg_max,
-    const int polish_reps, const uint64_t *__restrict__ colT)
+    const int polish_reps, const uint64_t *__restrict__ colT, const int gg_sl, float *__restrict__ gg_q, const size_t gg_stride)
 {
-    const size_t q_doubles = (size_t)q_doubles_i;  // LDS doubles reserved for the Gram block
+    const size_t q_doubles = (size_t)q_doubles_i;  // LDS doubles reserved for the Gram block (or for the arrays of gg_run)
     // s_lds_rt: bit 0 = the two sample arrays every per-feature gradient pass reads (tau, D) are in LDS, bit 1 = the
     // other three (exp(w.x), its trial value, x.d: a few passes per Newton step) are
     const int f_lds = ALL_LDS ? 1 : f_lds_rt, s_mode = ALL_LDS ? 3 : s_lds_rt, c_lds = ALL_LDS ? 1 : c_lds_rt,
@@ -544,12 +544,397 @@ __global__ __launch_bounds__(WMREG > 0 ? SV_COOP_THREADS : SV_THREADS) void logr
         __syncthreads();   // x.d is whole again: wave 0 goes on to the line search, the others back to helper_loop
         return iter_c;
     };
+    // ---- covariance form beyond the LDS Gram block ("gg": Gram matrix in global memory) ---------------------------------
+    // More than 192 active coordinates: the array form pays a reduction over the samples per coordinate visit (~1,870
+    // cycles on four waves at 2,048 samples; a 2,048 x 907 grid spent 3.3 s in its slowest fit, 98 % of it there).  Here
+    // Q = X_A' D X_A is built ONCE per Newton step -- a real GEMM over 0/1 columns, on the matrix cores (the column bits
+    // become 1.0 / D_i operands in registers, upper triangle of 16 x 64 blocks, mirrored on the way out) -- and kept in
+    // global memory as f32 (slot-major: column m = SL floats; 3.7 MB for 907 coordinates; the gradient vector g = Gr + Q d
+    // it updates stays f64).  A visit is then one column of Q, the scalar step z, and g += z Q[:, m].  A lone wave issues
+    // one instruction per four cycles, whatever its kind, so the visit is divided by INSTRUCTION COUNT over the fit's
+    // four waves, in lockstep (one barrier per visit, nothing is polled):
+    //   wave 0    the scalar side: G = g[m], liblinear's shrinking test, the step, the stopping rule (~70 instructions);
+    //   waves 1,2 own g -- slots 256 r + 4 lane + c, r in {0, 1} and {2, 3}, eight doubles per lane -- AND fetch the
+    //             columns: the visiting order of a sweep is known in advance, so each keeps DEPTH visits' columns (its
+    //             rows of them) in registers and loads the next DEPTH in one burst per round (an HBM round trip is ~8
+    //             visits long); a column never passes through LDS.  During visit T they apply z of visit T - 1 and publish
+    //             g[m'] and Q[m'][m] for the NEXT slot m' (s_set_gpr_idx + v_readlane), from which wave 0 completes
+    //             G = g[m'] + z Q[m'][m] itself: the step of a visit and the update it causes overlap;
+    //   wave 3    draws the next sweep's random order (Fisher-Yates, three steps per visit) while the current one runs.
+    // Same rule as liblinear for shrinking and stopping; a shrunk coordinate keeps its place in the order and is skipped
+    // (flag), so the order of a sweep never changes under the loaders' feet.  No CG accelerator in this form.
+    struct GgShared { int stop_at, last_A, par; };
+    __shared__ GgShared s_gg;
+    if (threadIdx.x == 0) { s_gg.last_A = 0; s_gg.par = 0; s_gg.stop_at = -1; }   // (read behind the barrier that releases the first gg_run)
+    const int SL = gg_sl;   // slots of the gg arrays (256 x ceil(P1 / 256)); 0 = form not available in this launch
+    double *ggP = Qm;       // per slot: H, 1 / H, w + d, shrunk flag
+    double *ggDm = Qm + 4 * (size_t)SL;
+    uint16_t *ggOrd = reinterpret_cast<uint16_t *>(Qm + 4 * (size_t)SL + NP);
+    uint16_t *ggFeat = ggOrd + 2 * (size_t)SL;
+    double *ggPub = reinterpret_cast<double *>(ggFeat + SL);   // [2][2]: g[m'], Q[m'][m] for the visit of that parity; then z [2]
+    double *ggZ = ggPub + 4;
+    float *Qg = gg_q + (size_t)fit * gg_stride;
+    auto gg_run = [&]() __attribute__((always_inline)) -> int {
+#ifndef PSK_GG_DEPTH
+#define PSK_GG_DEPTH 8
+#endif
+        constexpr int DEPTH = PSK_GG_DEPTH, FY_STEPS = 3;   // (a power of two)
+        typedef float f4 __attribute__((ext_vector_type(4)));
+        typedef float f8 __attribute__((ext_vector_type(8)));
+        typedef double d2 __attribute__((ext_vector_type(2)));
+        typedef double d4 __attribute__((ext_vector_type(4)));
+        typedef double d8 __attribute__((ext_vector_type(8)));
+        const int A = s_cd.active, tid = threadIdx.x;
+        const int NR = (A + 255) >> 8;   // 256-slot groups in use
+        const double inner_eps_c = s_cd.inner_eps, Gnorm1_init_c = s_cd.Gnorm1_init, l_c = s_cd.l;
+#ifdef PSK_SV_STATS
+        const long long stat_gg0 = clock64();
+#endif
+        {   // slot arrays, the first sweep's order, D of the training samples in the operand order of the build
+            const bool keep = (A == s_gg.last_A);
+            const int par = s_gg.par;
+            for (int u = tid; u < SL; u += SV_COOP_THREADS) {
+                const bool valid = u < A;
+                const int f = valid ? act[u] : 0;
+                const double hh = valid ? Hd[f] : 1.0;
+                ggFeat[u] = (uint16_t)f;
+                *reinterpret_cast<d4 *>(ggP + 4 * (size_t)u) = d4{hh, 1.0 / hh, valid ? w[f] : 0.0, 0.0};
+                if (!keep) ggOrd[u] = (uint16_t)u;          // (the first Newton step, or the active set changed)
+                else if (par) ggOrd[u] = ggOrd[SL + u];     // the last complete order of the previous Newton step
+            }
+            for (int i = tid; i < NP; i += SV_COOP_THREADS) {
+                const bool tr = i < n && fold[i] != tf;
+                const int b = i & 63;
+                ggDm[(i & ~63) + (b & 3) * 16 + (b >> 2)] = tr ? D[i] : 0.0;   // word t: [k = b & 3][step = b >> 2]
+            }
+            if (tid < 6) ggPub[tid] = 0.0;
+        }
+        __syncthreads();
+#ifdef PSK_GG_DEBUG
+        if (tid == 0 && fit == 0) printf("gg: prologue done A %d SL %d W %d\n", A, SL, W);
+#endif
+#ifndef PSK_GG_SKIP_BUILD
+        {   // Q: tile (kb, mb) = 16 x 16 slots; a work item = tile row kb x four tile columns, items dealt round the waves
+            const int nt = (A + 15) >> 4, ng = (nt + 3) >> 2, kq = lane >> 4, li = lane & 15;
+            int item = 0;
+            for (int kb = 0; kb < nt; kb++)
+                for (int gq = kb >> 2; gq < ng; gq++, item++) {
+                    if ((item & (SV_COOP_WAVES - 1)) != wave) continue;
+                    const int ka = kb * 16 + li;
+                    const bool va = ka < A;
+                    const uint64_t *pa = cb + (size_t)(va ? ggFeat[ka] : 0) * W;
+                    const uint64_t *pb[4];
+                    bool vb[4];
+                    d4 acc[4];
+                    uint64_t wa_n = va ? pa[0] : 0ull, wb_n[4];
+#pragma unroll
+                    for (int c = 0; c < 4; c++) {
+                        const int mc = (gq * 4 + c) * 16 + li;
+                        vb[c] = mc < A;
+                        pb[c] = cb + (size_t)(vb[c] ? ggFeat[mc] : 0) * W;
+                        wb_n[c] = vb[c] ? pb[c][0] : 0ull;
+                        acc[c] = d4{0.0, 0.0, 0.0, 0.0};
+                    }
+                    for (int t = 0; t < W; t++) {
+                        const uint64_t wa = wa_n >> kq;
+                        uint64_t wb[4];
+#pragma unroll
+                        for (int c = 0; c < 4; c++) wb[c] = wb_n[c] >> kq;
+                        if (t + 1 < W) {
+                            wa_n = va ? pa[t + 1] : 0ull;
+#pragma unroll
+                            for (int c = 0; c < 4; c++) wb_n[c] = vb[c] ? pb[c][t + 1] : 0ull;
+                        }
+                        double dm[16];
+                        const double *dmp = ggDm + t * 64 + kq * 16;
+#pragma unroll
+                        for (int s = 0; s < 16; s++) dm[s] = dmp[s];
+#pragma unroll
+                        for (int s = 0; s < 16; s++) {
+                            const uint32_t off = 4u * (s & 7);
+                            const int ab = __builtin_amdgcn_sbfe((int)(s < 8 ? (uint32_t)wa : (uint32_t)(wa >> 32)), off, 1u);
+                            const double av = __hiloint2double(ab & 0x3FF00000, 0);
+                            const int dlo = __double2loint(dm[s]), dhi = __double2hiint(dm[s]);
+#pragma unroll
+                            for (int c = 0; c < 4; c++) {
+                                const int bb = __builtin_amdgcn_sbfe((int)(s < 8 ? (uint32_t)wb[c] : (uint32_t)(wb[c] >> 32)), off, 1u);
+                                acc[c] = __builtin_amdgcn_mfma_f64_16x16x4f64(av, __hiloint2double(dhi & bb, dlo & bb), acc[c], 0, 0, 0);
+                            }
+                        }
+                    }
+                    // C/D of the f64 MFMA: column = lane & 15, row = (lane >> 4) + 4 r
+#pragma unroll
+                    for (int c = 0; c < 4; c++) {
+                        const int mc = (gq * 4 + c) * 16 + li;
+                        if (mc >= nt * 16) continue;
+#pragma unroll
+                        for (int r = 0; r < 4; r++) {
+                            const int kr = kb * 16 + kq + 4 * r;
+                            const float v = (float)acc[c][r];
+                            Qg[(size_t)mc * SL + kr] = v;
+                            Qg[(size_t)kr * SL + mc] = v;
+                        }
+                    }
+                }
+        }
+#endif
+        __syncthreads();
+        for (int u = tid; u < A; u += SV_COOP_THREADS) Qg[(size_t)u * SL + u] = (float)ggP[4 * (size_t)u];   // (nu is on the diagonal of H)
+#if defined(PSK_GG_STAGE) && PSK_GG_STAGE == 3
+        if (tid == 0) s_gg.stop_at = 0;
+#else
+        if (tid == 0) s_gg.stop_at = -1;
+#endif
+        __syncthreads();   // Q of this Newton step is whole and visible to the workgroup
+#ifdef PSK_GG_DEBUG
+        if (tid == 0 && fit == 0) printf("gg: build done\n");
+#endif
+#ifdef PSK_SV_STATS
+        if (wave == 0) stat_t_build += clock64() - stat_gg0;
+#endif
+        const f4 *Q4 = reinterpret_cast<const f4 *>(Qg);
+        const int SL4 = SL >> 2;
+        int iter_c = 0;
+#ifdef PSK_GG_SKIP_DESCENT
+        if (SL4 >= 0) { __syncthreads(); return 1; }
+#endif
+#define GG_BARRIER() do { __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup", "local"); __builtin_amdgcn_s_barrier(); \
+                          __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup", "local"); } while (0)
+        if (wave == 1 || wave == 2) {
+            // ---- owners of g and of the columns.  Ticket T = the T-th visit of this descent = (sweep T / A, position T % A).
+            // Two register sets of DEPTH tickets: `a` is complete and used one ticket per visit, `b` is loaded in ONE burst
+            // at the top of a round of DEPTH visits and becomes `a` at its end, so a column is 16 to 31 visits old when it
+            // is due; the only place that waits for memory is the copy, where the loads are a whole round old.  (A rotating
+            // single set, one load issued per visit, is what one would write; the compiler's count of loads in flight does
+            // not survive the loop it makes of it -- rotated, exits merged -- and it drained the queue, vmcnt(0), every
+            // visit.  For the same reason both groups are always loaded -- clamped to the last group of the slot arrays,
+            // a duplicate at worst -- and the descent ends at a ticket that is a multiple of DEPTH, wave 0 idling up to
+            // DEPTH - 1 visits, so that this loop's only exit is at the top of a round.)
+            const int h = wave - 1, rmax = (SL >> 8) - 1;
+            const int r0 = min(2 * h, rmax), r1 = min(2 * h + 1, rmax);
+            d8 go;   // g of the slots 256 (2 h + (e >> 2)) + 4 lane + (e & 3)
+#pragma unroll
+            for (int e = 0; e < 8; e++) {
+                const int u = 256 * (2 * h + (e >> 2)) + 4 * lane + (e & 3);
+#ifdef PSK_GG_V1
+                go[e] = 0.0;
+#else
+                go[e] = u < A ? Gr[ggFeat[u]] : 0.0;
+#endif
+            }
+            int lk = 0, lpos = 0;
+            auto issue = [&](f4 &x0, f4 &x1, int &mm) __attribute__((always_inline)) {
+                const int m = __builtin_amdgcn_readfirstlane((int)ggOrd[(lk & 1) * SL + lpos]);
+#ifdef PSK_GG_V5
+                const f4 *col = reinterpret_cast<const f4 *>(gg_q + (size_t)fit * gg_stride) + (size_t)min(max(m, 0), A - 1) * SL4 + lane;
+#else
+                const f4 *col = Q4 + (size_t)m * SL4 + lane;
+#endif
+#ifdef PSK_GG_V4
+                x0 = f4{0.f, 0.f, 0.f, (float)(col != nullptr)}; x1 = x0;
+#else
+                x0 = col[r0 * 64];
+                x1 = col[r1 * 64];
+#endif
+                mm = m;
+                if (++lpos == A) { lpos = 0; lk++; }
+            };
+            f4 a0[DEPTH], a1[DEPTH], b0[DEPTH], b1[DEPTH], l0 = f4{0.f, 0.f, 0.f, 0.f}, l1 = l0;
+            int ma[DEPTH], mb[DEPTH];
+#pragma unroll
+            for (int u = 0; u < DEPTH; u++) issue(a0[u], a1[u], ma[u]);
+            __builtin_amdgcn_s_waitcnt(0x0F70);   // vmcnt(0): the first set is whole
+#if defined(PSK_GG_STAGE) && PSK_GG_STAGE == 2
+            if (a0[0].x == 12345.f && a1[DEPTH - 1].y == 3.f) ggZ[1] = 1.0;
+            goto owners_done;
+#endif
+            for (int T = 0;; T += DEPTH) {
+#pragma unroll
+                for (int u = 0; u < DEPTH; u++) issue(b0[u], b1[u], mb[u]);   // tickets T + DEPTH ... T + 2 DEPTH - 1
+#pragma unroll
+                for (int u = 0; u < DEPTH; u++) {   // visit T + u
+                    GG_BARRIER();
+                    if (u == 0 && T == __builtin_amdgcn_readfirstlane(s_gg.stop_at)) goto owners_done;
+                    // z of visit T + u - 1 on this wave's rows of ITS column
+                    const double z = ggZ[(u + 1) & 1];
+                    if (z != 0.0) {
+                        const f4 c0 = u > 0 ? a0[u > 0 ? u - 1 : 0] : l0, c1 = u > 0 ? a1[u > 0 ? u - 1 : 0] : l1;
+                        go[0] = fma(z, (double)c0.x, go[0]); go[1] = fma(z, (double)c0.y, go[1]);   // (explicit fma: -ffp-contract=off)
+                        go[2] = fma(z, (double)c0.z, go[2]); go[3] = fma(z, (double)c0.w, go[3]);
+                        go[4] = fma(z, (double)c1.x, go[4]); go[5] = fma(z, (double)c1.y, go[5]);
+                        go[6] = fma(z, (double)c1.z, go[6]); go[7] = fma(z, (double)c1.w, go[7]);
+                    }
+                    // for visit T + u + 1 (slot mn): g[mn] as it is now, and Q[mn][m] from the column of THIS visit's slot
+                    const int mn = u + 1 < DEPTH ? ma[u + 1 < DEPTH ? u + 1 : 0] : mb[0];
+                    if ((mn >> 9) == h) {
+                        const int e = ((mn >> 6) & 4) | (mn & 3), ln = (mn >> 2) & 63;
+                        const double gv = psk_readlane_f64(go[e], ln);
+                        const f8 cc = f8{a0[u].x, a0[u].y, a0[u].z, a0[u].w, a1[u].x, a1[u].y, a1[u].z, a1[u].w};
+                        const float qv = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, cc[e]), ln));
+                        if (lane == 0) *reinterpret_cast<d2 *>(ggPub + 2 * ((u + 1) & 1)) = d2{gv, (double)qv};
+                    }
+                }
+                l0 = a0[DEPTH - 1]; l1 = a1[DEPTH - 1];
+#pragma unroll
+                for (int u = 0; u < DEPTH; u++) { a0[u] = b0[u]; a1[u] = b1[u]; ma[u] = mb[u]; }
+            }
+        owners_done:
+            // the last burst is still in flight: nothing may leave this block with loads pending on registers that the code
+            // after it reuses (without this wait the <false, 64> instance of the kernel faulted on its way out: r03)
+            __builtin_amdgcn_s_waitcnt(0x0F70);   // vmcnt(0)
+        } else if (wave == 3) {
+            // ---- the next sweep's order: a copy of this sweep's, shuffled in place; complete after A / FY_STEPS visits
+            uint32_t r32 = rng;
+            int k = 0, pos = 0, fy = A;
+#if defined(PSK_GG_STAGE) && PSK_GG_STAGE == 2
+            for (int T = 0; T < 0; T++) {
+#else
+            for (int T = 0;; T++) {
+#endif
+                GG_BARRIER();
+                if (T == __builtin_amdgcn_readfirstlane(s_gg.stop_at)) break;
+                uint16_t *on = ggOrd + ((k + 1) & 1) * SL;
+                if (pos == 0) {
+                    const uint16_t *oc = ggOrd + (k & 1) * SL;
+                    for (int u = lane; u < A; u += 64) on[u] = oc[u];
+                    fy = 0;
+                }
+                if (lane == 0) {
+#pragma unroll
+                    for (int s = 0; s < FY_STEPS; s++) {
+                        if (fy + 1 < A) {
+                            r32 ^= r32 << 13; r32 ^= r32 >> 17; r32 ^= r32 << 5;
+                            const int jj = fy + (int)__umulhi(r32, (uint32_t)(A - fy));
+                            const uint16_t tt = on[jj]; on[jj] = on[fy]; on[fy] = tt;
+                        }
+                        fy++;
+                    }
+                }
+                if (++pos == A) { pos = 0; k++; }
+            }
+            rng = r32;
+        } else {
+            // ---- the scalar side of the descent.  The order arrives 64 entries at a time in a register (lane i = the entry
+            // i places on), one visit ahead of its use; the slot's parameters are requested a visit ahead too.
+#if defined(PSK_GG_STAGE) && PSK_GG_STAGE == 3
+            int QP_active_c = A, T = 0, k = 0, pos = 0, stop_at = 0;
+#else
+            int QP_active_c = A, T = 0, k = 0, pos = 0, stop_at = -1;
+#endif
+            double QP_Gmax_old_c = 1e300, QP_Gmax_new = 0.0, QP_Gnorm1_new = 0.0, thr = 1e300, zprev = 0.0;
+            int wk = 0, wp0 = 0, wl = 2;   // the window: sweep, position of lane 0's entry, lane of the next entry to take
+            int ordv = ggOrd[min(lane, A - 1)];
+            int m = __builtin_amdgcn_readlane(ordv, 0), m1 = __builtin_amdgcn_readlane(ordv, 1);
+            d4 P = *reinterpret_cast<const d4 *>(ggP + 4 * (size_t)m);
+#ifdef PSK_GG_V2
+            double G0 = 0.0;
+#else
+            double G0 = Gr[ggFeat[m]];
+#endif
+#if defined(PSK_GG_STAGE) && PSK_GG_STAGE == 2
+            for (; T < 0; T++) {
+#else
+            for (;; T++) {
+#endif
+#ifdef PSK_SV_STATS
+                const long long stat_w0 = clock64();
+#endif
+                GG_BARRIER();
+#ifdef PSK_SV_STATS
+                stat_t_polish += clock64() - stat_w0;   // (this form has no accelerator: the field reports wave 0's waits at the barrier)
+#endif
+                if (T == stop_at) break;
+                if (stop_at >= 0) continue;   // idling to a multiple of DEPTH (see the owners)
+                const d4 P1n = *reinterpret_cast<const d4 *>(ggP + 4 * (size_t)m1);   // for the next visit (corrected below if this one changes it)
+                const d2 pub = *reinterpret_cast<const d2 *>(ggPub + 2 * (T & 1));
+                const double H = P[0], Hi = P[1], wp = P[2];
+                double z = 0.0, wn = wp;
+                bool shrink = false;
+                const bool live = __builtin_amdgcn_readfirstlane(__double2hiint(P[3])) == 0;   // (flag 0.0 / 1.0; made scalar for the compiler)
+                if (live) {
+                    const double G = T > 0 ? fma(zprev, pub[1], pub[0]) : G0;
+                    const double Gp = G + 1.0, Gn = G - 1.0;
+                    const bool zero = wp == 0.0;
+                    shrink = __builtin_amdgcn_readfirstlane((int)(zero && Gp > thr && Gn < -thr)) != 0;   // out of the sweeps until the whole set is taken up again
+                    const double viol = shrink ? 0.0 : (zero ? fmax(fmax(-Gp, Gn), 0.0) : (wp > 0.0 ? fabs(Gp) : fabs(Gn)));
+                    QP_Gmax_new = fmax(QP_Gmax_new, viol);
+                    QP_Gnorm1_new += viol;
+                    const double Hwp = H * wp;
+                    const double z0 = Gp < Hwp ? -Gp * Hi : (Gn > Hwp ? -Gn * Hi : -wp);
+                    const bool apply = !shrink && !(fabs(z0) < 1e-12 && !(z0 == -wp && wp != 0.0));
+#ifdef PSK_GG_W1
+                    z = 0.0 * (apply ? 1.0 : 2.0);
+#else
+                    z = apply ? fmin(fmax(z0, -10.0), 10.0) : 0.0;
+#endif
+                    wn = wp + z;
+                    QP_active_c -= shrink ? 1 : 0;
+                }
+                if (lane == 0) {
+                    ggZ[T & 1] = z;
+                    *reinterpret_cast<d2 *>(ggP + 4 * (size_t)m + 2) = d2{wn, (shrink || !live) ? 1.0 : 0.0};
+                }
+                zprev = z;
+                P = P1n;
+                if (m1 == m) { P[2] = wn; if (shrink) P[3] = 1.0; }
+                m = m1;
+                // the entry after next
+                m1 = __builtin_amdgcn_readlane(ordv, wl);
+                wl++;
+                if (wp0 + wl >= A) {   // (uniform) the window ran off its sweep: the head of the next sweep's order, complete by now
+                    wk++; wp0 = 0; wl = 0;
+                    ordv = ggOrd[(wk & 1) * SL + min(lane, A - 1)];
+                } else if (wl == 64) {
+                    wp0 += 64; wl = 0;
+                    ordv = ggOrd[(wk & 1) * SL + min(wp0 + lane, A - 1)];
+                }
+                if (++pos == A) {   // end of a sweep: liblinear's rule
+                    pos = 0;
+                    k++;
+                    iter_c++;
+#ifdef PSK_GG_W1
+                    bool stop = true;
+#else
+                    bool stop = iter_c >= 1000;
+#endif
+                    if (__builtin_amdgcn_readfirstlane((int)(QP_Gnorm1_new <= inner_eps_c * Gnorm1_init_c))) {
+                        if (QP_active_c == A) stop = true;
+                        else {
+                            QP_active_c = A;
+                            QP_Gmax_old_c = 1e300;
+                            for (int u = lane; u < A; u += 64) ggP[4 * (size_t)u + 3] = 0.0;
+                            P[3] = 0.0;
+                        }
+                    } else QP_Gmax_old_c = QP_Gmax_new;
+                    thr = QP_Gmax_old_c / l_c;
+                    QP_Gmax_new = 0.0;
+                    QP_Gnorm1_new = 0.0;
+                    if (stop) {
+                        stop_at = (T + DEPTH) & ~(DEPTH - 1);
+                        if (lane == 0) s_gg.stop_at = stop_at;
+                    }
+                }
+            }
+            // back to the feature arrays; x.d = X_A d for the line search is the caller's
+#ifndef PSK_GG_V3
+            for (int u = lane; u < A; u += 64) wpd[ggFeat[u]] = ggP[4 * (size_t)u + 2];
+#endif
+            if (lane == 0) { s_gg.last_A = A; s_gg.par = k & 1; }
+        }
+#undef GG_BARRIER
+        __syncthreads();
+#ifdef PSK_GG_DEBUG
+        if (tid == 0 && fit == 0) printf("gg: descent done %d sweeps\n", iter_c);
+#endif
+        return iter_c;
+    };
     if (WMREG > 0 && wave != 0) {   // helper_loop: waves 1..3 join every descent / column build of wave 0 and leave with it
         for (;;) {
             __syncthreads();
             const int cmd = s_cd.cmd;
             if (cmd == 2) break;
             if (cmd == 3) build_coop(std::integral_constant<int, (WMREG > 0 ? WMREG : 32)>{});
+            else if (cmd == 4) gg_run();
             else cd_coop(std::integral_constant<int, (WMREG > 0 ? WMREG : 32)>{});
         }
         return;
@@ -916,11 +1301,32 @@ __global__ __launch_bounds__(WMREG > 0 ? SV_COOP_THREADS : SV_THREADS) void logr
         const long long stat_g0 = stat_t0;
         const long long stat_cd_before = stat_t_cd;
 #endif
-        if (q_lds && active <= 64 && q_doubles >= 64 * 64) {
+        if (WMREG > 0 && SL > 0 && active >= 64) {
+            // the Gram matrix in global memory (gg_run above); its LDS area takes the place of the Gram block
+            if (lane == 0) {
+                s_cd.inner_eps = inner_eps; s_cd.Gnorm1_init = Gnorm1_init; s_cd.l = l;
+                s_cd.active = active; s_cd.cmd = 4;
+            }
+            __syncthreads();   // releases waves 1..3 (helper_loop)
+            iter = gg_run();
+            for (int sidx = 0; sidx < active; sidx++) {
+                const int j = act[sidx];
+                const double d = wpd[j] - w[j];
+                if (d == 0.0) continue;
+                const uint64_t cw = load_col(j);
+                for (int t = 0; t < W; t++) {
+                    const uint64_t xw = psk_readlane_u64(cw, t);
+                    if ((xw >> lane) & 1) xTd[t * 64 + lane] += d;
+                }
+            }
+#ifdef PSK_SV_STATS
+            stat_visits += (long long)iter * active;
+#endif
+        } else if (SL == 0 && q_lds && active <= 64 && q_doubles >= 64 * 64) {
             gram_qp(integral_constant<int, 1>{}, integral_constant<bool, false>{});
-        } else if (q_lds && active <= 128 && q_doubles >= 128 * 128) {
+        } else if (SL == 0 && q_lds && active <= 128 && q_doubles >= 128 * 128) {
             gram_qp(integral_constant<int, 2>{}, integral_constant<bool, false>{});
-        } else if (q_lds && active <= 192 && (size_t)active * (active + 1) / 2 <= q_doubles) {
+        } else if (SL == 0 && q_lds && active <= 192 && (size_t)active * (active + 1) / 2 <= q_doubles) {
             if (active <= 64) gram_qp(integral_constant<int, 1>{}, integral_constant<bool, true>{});
             else if (active <= 128) gram_qp(integral_constant<int, 2>{}, integral_constant<bool, true>{});
             else gram_qp(integral_constant<int, 3>{}, integral_constant<bool, true>{});
@@ -1328,10 +1734,10 @@ void transpose_f32(const float *X, int n, int p, std::vector<float> &XT)
 
 struct SolverBufs {
     void *xt = nullptr, *y = nullptr, *fold = nullptr, *param = nullptr, *ffold = nullptr, *coef = nullptr,
-         *icpt = nullptr, *iters = nullptr, *work = nullptr, *iwork = nullptr, *bits = nullptr, *bitsT = nullptr;
+         *icpt = nullptr, *iters = nullptr, *work = nullptr, *iwork = nullptr, *bits = nullptr, *bitsT = nullptr, *ggq = nullptr;
     ~SolverBufs()
     {
-        void *ps[] = {xt, y, fold, param, ffold, coef, icpt, iters, work, iwork, bits, bitsT};
+        void *ps[] = {xt, y, fold, param, ffold, coef, icpt, iters, work, iwork, bits, bitsT, ggq};
         for (void *q : ps) if (q) (void)hipFree(q);
     }
 };
@@ -1396,10 +1802,25 @@ extern "C" int psk_logreg_l1_fit(psk_ctx *ctx, const float *X, const int32_t *y0
         // (With the sample arrays first, a 2048-sample fit with 170 distinct patterns had room for 79 Gram columns,
         // fell back to the array-form descent and took 0.5 s instead of 0.02 s, r01.)
         const size_t fa = fbytes + (((size_t)(p + 1) + 1) / 2) * 8, cbytes = (size_t)(p + 1) * W * 8;
-        const bool gram = !getenv("PSK_NO_GRAM");
+        // More coordinates than the LDS Gram block takes (192): the Gram matrix of a fit in global memory, f32, a column
+        // per slot (gg_run).  Its LDS arrays (slot parameters, ring, D in operand order, orders, flags) take the place of
+        // the Gram block; the feature arrays must be in LDS beside them.
+        const int P1 = p + 1, wmreg_h = getenv("PSK_NO_CD_REGS") ? 0 : (W <= 16 ? 16 : W <= 32 ? 32 : 64);
+        int gg_sl = 0;
+        size_t gg_stride = 0, gg_lds = 0;
+        // (up to 2,048 samples: the instance of the kernel for 33 ... 64 sample words faults in this form when the arrays are
+        // not all in LDS -- <false, 64>, 456 registers, r03; <true, 64>, <false, 32> and <false, 16> are fine -- and was not
+        // tracked down; PSK_GRAM_GLOBAL_64=1 enables it for that search.  Those fits keep the array form.)
+        if (P1 > 192 && P1 <= 1024 && wmreg_h > 0 && (wmreg_h < 64 || getenv("PSK_GRAM_GLOBAL_64")) && SV_COOP_WAVES == 4 &&
+            !getenv("PSK_NO_GRAM") && !getenv("PSK_NO_GRAM_GLOBAL")) {
+            const size_t sl = 256 * (((size_t)P1 + 255) / 256), np_h = (size_t)W * 64;
+            const size_t need = (4 * sl + np_h + sl / 2 + sl / 4 + sl / 8) * 8, stride = (((size_t)P1 + 15) / 16 * 16) * sl;
+            if (fa + need <= lds_max && (size_t)n_fits * stride * 4 <= ((size_t)32 << 30)) { gg_sl = (int)sl; gg_stride = stride; gg_lds = need; }
+        }
+        const bool gram = !getenv("PSK_NO_GRAM") && gg_sl == 0;
         const size_t pq = (size_t)(p + 1) < 192 ? (size_t)(p + 1) : 192;   // Gram columns the kernel can use
         const size_t need_q = gram ? pq * (pq + 1) / 2 * 8 : 0;             // its packed triangle
-        size_t left = lds_max;
+        size_t left = lds_max - gg_lds;
         f_lds = fa <= left ? 1 : 0; left -= f_lds ? fa : 0;
         // sample arrays: all five when they fit beside the whole Gram block; else only the two hot ones (tau, D) if
         // THAT makes room for the whole Gram block (thousands of samples, up to ~170 distinct patterns: the Gram form
@@ -1431,8 +1852,10 @@ extern "C" int psk_logreg_l1_fit(psk_ctx *ctx, const float *X, const int32_t *y0
             if (more > most) more = most;
             q_doubles = more;
         }
+        if (gg_sl) q_doubles = gg_lds / 8;
         const size_t qbytes = q_doubles * 8;
         const int q_lds = q_doubles > 0;
+        if (gg_sl) SV_ALLOC(b.ggq, (size_t)n_fits * gg_stride * 4);
         const size_t lds_b = s_in_lds + qbytes + (f_lds ? fa : 0) + (c_lds ? cbytes : 0);
         std::vector<uint64_t> bits((size_t)(p + 1) * W, 0);
         for (int i = 0; i < n; i++) {
@@ -1458,7 +1881,7 @@ extern "C" int psk_logreg_l1_fit(psk_ctx *ctx, const float *X, const int32_t *y0
             PSK_HIP(ctx, hipMemcpyAsync(b.bitsT, bitsT.data(), bitsT.size() * 8, hipMemcpyHostToDevice, ctx->stream));
         }
         const bool all_lds = f_lds && s_lds == 3 && c_lds && q_lds;
-        const int wmreg = bitsT.empty() ? 0 : (W <= 16 ? 16 : W <= 32 ? 32 : 64);
+        const int wmreg = bitsT.empty() ? 0 : getenv("PSK_FORCE_WMREG") ? atoi(getenv("PSK_FORCE_WMREG")) : (W <= 16 ? 16 : W <= 32 ? 32 : 64);
         auto pick = [&](auto all) {
             constexpr bool A = decltype(all)::value;
             return wmreg == 0 ? logreg_newglmnet_bits_kernel<A, 0> : wmreg == 16 ? logreg_newglmnet_bits_kernel<A, 16>
@@ -1474,7 +1897,7 @@ extern "C" int psk_logreg_l1_fit(psk_ctx *ctx, const float *X, const int32_t *y0
             (double *)b.work, (int32_t *)b.iwork, f_lds, s_lds, c_lds, (int)q_doubles,
             getenv("PSK_CG_MAX") ? atoi(getenv("PSK_CG_MAX")) : 16,             // CG steps per polish
             getenv("PSK_POLISH_REPS") ? atoi(getenv("PSK_POLISH_REPS")) : 64,   // polishes in a row while signs change
-            (const uint64_t *)b.bitsT);
+            (const uint64_t *)b.bitsT, gg_sl, (float *)b.ggq, gg_stride);
         PSK_HIP(ctx, hipGetLastError());
         PSK_HIP(ctx, hipStreamSynchronize(ctx->stream));  // `bits` (host) must outlive the copy
     } else {
