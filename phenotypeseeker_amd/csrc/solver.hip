@@ -610,10 +610,6 @@ __global__ __launch_bounds__(WMREG > 0 ? SV_COOP_THREADS : SV_THREADS) void logr
             if (tid < 6) ggPub[tid] = 0.0;
         }
         __syncthreads();
-#ifdef PSK_GG_DEBUG
-        if (tid == 0 && fit == 0) printf("gg: prologue done A %d SL %d W %d\n", A, SL, W);
-#endif
-#ifndef PSK_GG_SKIP_BUILD
         {   // Q: tile (kb, mb) = 16 x 16 slots; a work item = tile row kb x four tile columns, items dealt round the waves
             const int nt = (A + 15) >> 4, ng = (nt + 3) >> 2, kq = lane >> 4, li = lane & 15;
             int item = 0;
@@ -677,27 +673,16 @@ __global__ __launch_bounds__(WMREG > 0 ? SV_COOP_THREADS : SV_THREADS) void logr
                     }
                 }
         }
-#endif
         __syncthreads();
         for (int u = tid; u < A; u += SV_COOP_THREADS) Qg[(size_t)u * SL + u] = (float)ggP[4 * (size_t)u];   // (nu is on the diagonal of H)
-#if defined(PSK_GG_STAGE) && PSK_GG_STAGE == 3
-        if (tid == 0) s_gg.stop_at = 0;
-#else
         if (tid == 0) s_gg.stop_at = -1;
-#endif
         __syncthreads();   // Q of this Newton step is whole and visible to the workgroup
-#ifdef PSK_GG_DEBUG
-        if (tid == 0 && fit == 0) printf("gg: build done\n");
-#endif
 #ifdef PSK_SV_STATS
         if (wave == 0) stat_t_build += clock64() - stat_gg0;
 #endif
         const f4 *Q4 = reinterpret_cast<const f4 *>(Qg);
         const int SL4 = SL >> 2;
         int iter_c = 0;
-#ifdef PSK_GG_SKIP_DESCENT
-        if (SL4 >= 0) { __syncthreads(); return 1; }
-#endif
 #define GG_BARRIER() do { __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup", "local"); __builtin_amdgcn_s_barrier(); \
                           __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup", "local"); } while (0)
         if (wave == 1 || wave == 2) {
@@ -710,32 +695,20 @@ __global__ __launch_bounds__(WMREG > 0 ? SV_COOP_THREADS : SV_THREADS) void logr
             // visit.  For the same reason both groups are always loaded -- clamped to the last group of the slot arrays,
             // a duplicate at worst -- and the descent ends at a ticket that is a multiple of DEPTH, wave 0 idling up to
             // DEPTH - 1 visits, so that this loop's only exit is at the top of a round.)
-            const int h = wave - 1, rmax = (SL >> 8) - 1;
+            const int h = __builtin_amdgcn_readfirstlane(wave) - 1, rmax = (SL >> 8) - 1;
             const int r0 = min(2 * h, rmax), r1 = min(2 * h + 1, rmax);
             d8 go;   // g of the slots 256 (2 h + (e >> 2)) + 4 lane + (e & 3)
 #pragma unroll
             for (int e = 0; e < 8; e++) {
                 const int u = 256 * (2 * h + (e >> 2)) + 4 * lane + (e & 3);
-#ifdef PSK_GG_V1
-                go[e] = 0.0;
-#else
                 go[e] = u < A ? Gr[ggFeat[u]] : 0.0;
-#endif
             }
             int lk = 0, lpos = 0;
             auto issue = [&](f4 &x0, f4 &x1, int &mm) __attribute__((always_inline)) {
                 const int m = __builtin_amdgcn_readfirstlane((int)ggOrd[(lk & 1) * SL + lpos]);
-#ifdef PSK_GG_V5
-                const f4 *col = reinterpret_cast<const f4 *>(gg_q + (size_t)fit * gg_stride) + (size_t)min(max(m, 0), A - 1) * SL4 + lane;
-#else
                 const f4 *col = Q4 + (size_t)m * SL4 + lane;
-#endif
-#ifdef PSK_GG_V4
-                x0 = f4{0.f, 0.f, 0.f, (float)(col != nullptr)}; x1 = x0;
-#else
                 x0 = col[r0 * 64];
                 x1 = col[r1 * 64];
-#endif
                 mm = m;
                 if (++lpos == A) { lpos = 0; lk++; }
             };
@@ -744,10 +717,6 @@ __global__ __launch_bounds__(WMREG > 0 ? SV_COOP_THREADS : SV_THREADS) void logr
 #pragma unroll
             for (int u = 0; u < DEPTH; u++) issue(a0[u], a1[u], ma[u]);
             __builtin_amdgcn_s_waitcnt(0x0F70);   // vmcnt(0): the first set is whole
-#if defined(PSK_GG_STAGE) && PSK_GG_STAGE == 2
-            if (a0[0].x == 12345.f && a1[DEPTH - 1].y == 3.f) ggZ[1] = 1.0;
-            goto owners_done;
-#endif
             for (int T = 0;; T += DEPTH) {
 #pragma unroll
                 for (int u = 0; u < DEPTH; u++) issue(b0[u], b1[u], mb[u]);   // tickets T + DEPTH ... T + 2 DEPTH - 1
@@ -757,7 +726,7 @@ __global__ __launch_bounds__(WMREG > 0 ? SV_COOP_THREADS : SV_THREADS) void logr
                     if (u == 0 && T == __builtin_amdgcn_readfirstlane(s_gg.stop_at)) goto owners_done;
                     // z of visit T + u - 1 on this wave's rows of ITS column
                     const double z = ggZ[(u + 1) & 1];
-                    if (z != 0.0) {
+                    {   // (a zero step takes the same instructions: a branch costs more than eight multiply-adds)
                         const f4 c0 = u > 0 ? a0[u > 0 ? u - 1 : 0] : l0, c1 = u > 0 ? a1[u > 0 ? u - 1 : 0] : l1;
                         go[0] = fma(z, (double)c0.x, go[0]); go[1] = fma(z, (double)c0.y, go[1]);   // (explicit fma: -ffp-contract=off)
                         go[2] = fma(z, (double)c0.z, go[2]); go[3] = fma(z, (double)c0.w, go[3]);
@@ -786,11 +755,7 @@ __global__ __launch_bounds__(WMREG > 0 ? SV_COOP_THREADS : SV_THREADS) void logr
             // ---- the next sweep's order: a copy of this sweep's, shuffled in place; complete after A / FY_STEPS visits
             uint32_t r32 = rng;
             int k = 0, pos = 0, fy = A;
-#if defined(PSK_GG_STAGE) && PSK_GG_STAGE == 2
-            for (int T = 0; T < 0; T++) {
-#else
             for (int T = 0;; T++) {
-#endif
                 GG_BARRIER();
                 if (T == __builtin_amdgcn_readfirstlane(s_gg.stop_at)) break;
                 uint16_t *on = ggOrd + ((k + 1) & 1) * SL;
@@ -806,6 +771,9 @@ __global__ __launch_bounds__(WMREG > 0 ? SV_COOP_THREADS : SV_THREADS) void logr
                             r32 ^= r32 << 13; r32 ^= r32 >> 17; r32 ^= r32 << 5;
                             const int jj = fy + (int)__umulhi(r32, (uint32_t)(A - fy));
                             const uint16_t tt = on[jj]; on[jj] = on[fy]; on[fy] = tt;
+                        } else if (fy + 1 == A) {   // done; a sweep never starts on the slot the previous one ended on (wave 0
+                            const uint16_t f0 = on[0], f1 = on[1];   // reads a slot's parameters while the previous visit writes its own)
+                            if (f0 == ggOrd[(k & 1) * SL + A - 1]) { on[0] = f1; on[1] = f0; }
                         }
                         fy++;
                     }
@@ -815,27 +783,20 @@ __global__ __launch_bounds__(WMREG > 0 ? SV_COOP_THREADS : SV_THREADS) void logr
             rng = r32;
         } else {
             // ---- the scalar side of the descent.  The order arrives 64 entries at a time in a register (lane i = the entry
-            // i places on), one visit ahead of its use; the slot's parameters are requested a visit ahead too.
-#if defined(PSK_GG_STAGE) && PSK_GG_STAGE == 3
-            int QP_active_c = A, T = 0, k = 0, pos = 0, stop_at = 0;
-#else
-            int QP_active_c = A, T = 0, k = 0, pos = 0, stop_at = -1;
-#endif
-            double QP_Gmax_old_c = 1e300, QP_Gmax_new = 0.0, QP_Gnorm1_new = 0.0, thr = 1e300, zprev = 0.0;
-            int wk = 0, wp0 = 0, wl = 2;   // the window: sweep, position of lane 0's entry, lane of the next entry to take
+            // i places on), the slot's parameters are requested a visit ahead.  Every lane computes the same step.  The
+            // values come from LDS through an address with an opaque zero added, so that the compiler takes them for
+            // lane-varying and turns the rule into selects: as wave-uniform values it made ~20 scalar branches per visit of
+            // it, and a v_cmp -> s_cbranch pair costs a lone wave 30 to 60 cycles (tools/_variants/ubench.hip, r03), a select 5.
+            int dz;
+            asm volatile("v_mov_b32 %0, 0" : "=v"(dz));
+            int T = 0, k = 0, pos = 0, stop_at = -1, nshrunk = 0;
+            double QP_Gmax_new = 0.0, QP_Gnorm1_new = 0.0, thr = 1e300, zprev = 0.0, QP_Gmax_old_c = 1e300;
+            int wk = 0, wp0 = 0, wl = 2, wend = min(64, A);   // the window: sweep, position of lane 0's entry, next lane, lanes in use
             int ordv = ggOrd[min(lane, A - 1)];
             int m = __builtin_amdgcn_readlane(ordv, 0), m1 = __builtin_amdgcn_readlane(ordv, 1);
-            d4 P = *reinterpret_cast<const d4 *>(ggP + 4 * (size_t)m);
-#ifdef PSK_GG_V2
-            double G0 = 0.0;
-#else
-            double G0 = Gr[ggFeat[m]];
-#endif
-#if defined(PSK_GG_STAGE) && PSK_GG_STAGE == 2
-            for (; T < 0; T++) {
-#else
+            d4 P = *reinterpret_cast<const d4 *>(ggP + 4 * (size_t)m + dz);
+            if (lane == 0) *reinterpret_cast<d2 *>(ggPub) = d2{Gr[ggFeat[m]], 0.0};   // visit 0: G = g[m] itself (z of "visit -1" is 0)
             for (;; T++) {
-#endif
 #ifdef PSK_SV_STATS
                 const long long stat_w0 = clock64();
 #endif
@@ -843,89 +804,72 @@ __global__ __launch_bounds__(WMREG > 0 ? SV_COOP_THREADS : SV_THREADS) void logr
 #ifdef PSK_SV_STATS
                 stat_t_polish += clock64() - stat_w0;   // (this form has no accelerator: the field reports wave 0's waits at the barrier)
 #endif
-                if (T == stop_at) break;
-                if (stop_at >= 0) continue;   // idling to a multiple of DEPTH (see the owners)
-                const d4 P1n = *reinterpret_cast<const d4 *>(ggP + 4 * (size_t)m1);   // for the next visit (corrected below if this one changes it)
-                const d2 pub = *reinterpret_cast<const d2 *>(ggPub + 2 * (T & 1));
+                const d4 P1n = *reinterpret_cast<const d4 *>(ggP + 4 * (size_t)m1 + dz);   // for the next visit (never this visit's slot: see wave 3)
+                const d2 pub = *reinterpret_cast<const d2 *>(ggPub + 2 * (T & 1) + dz);
                 const double H = P[0], Hi = P[1], wp = P[2];
-                double z = 0.0, wn = wp;
-                bool shrink = false;
-                const bool live = __builtin_amdgcn_readfirstlane(__double2hiint(P[3])) == 0;   // (flag 0.0 / 1.0; made scalar for the compiler)
-                if (live) {
-                    const double G = T > 0 ? fma(zprev, pub[1], pub[0]) : G0;
-                    const double Gp = G + 1.0, Gn = G - 1.0;
-                    const bool zero = wp == 0.0;
-                    shrink = __builtin_amdgcn_readfirstlane((int)(zero && Gp > thr && Gn < -thr)) != 0;   // out of the sweeps until the whole set is taken up again
-                    const double viol = shrink ? 0.0 : (zero ? fmax(fmax(-Gp, Gn), 0.0) : (wp > 0.0 ? fabs(Gp) : fabs(Gn)));
-                    QP_Gmax_new = fmax(QP_Gmax_new, viol);
-                    QP_Gnorm1_new += viol;
-                    const double Hwp = H * wp;
-                    const double z0 = Gp < Hwp ? -Gp * Hi : (Gn > Hwp ? -Gn * Hi : -wp);
-                    const bool apply = !shrink && !(fabs(z0) < 1e-12 && !(z0 == -wp && wp != 0.0));
-#ifdef PSK_GG_W1
-                    z = 0.0 * (apply ? 1.0 : 2.0);
-#else
-                    z = apply ? fmin(fmax(z0, -10.0), 10.0) : 0.0;
-#endif
-                    wn = wp + z;
-                    QP_active_c -= shrink ? 1 : 0;
-                }
+                const bool live = P[3] == 0.0;
+                const double G = fma(zprev, pub[1], pub[0]);
+                const double Gp = G + 1.0, Gn = G - 1.0;
+                const bool zero = wp == 0.0;
+                const bool shrink = live && zero && Gp > thr && Gn < -thr;   // out of the sweeps until the whole set is taken up again
+                const bool counted = live && !shrink;
+                const double v0 = fmax(fmax(-Gp, Gn), 0.0), v1 = fabs(wp > 0.0 ? Gp : Gn);
+                const double viol = counted ? (zero ? v0 : v1) : 0.0;
+                QP_Gmax_new = fmax(QP_Gmax_new, viol);
+                QP_Gnorm1_new += viol;
+                const double Hwp = H * wp;
+                const double z0 = Gp < Hwp ? -Gp * Hi : (Gn > Hwp ? -Gn * Hi : -wp);
+                const bool apply = counted && !(fabs(z0) < 1e-12 && !(z0 == -wp && !zero));
+                const double z = apply ? fmin(fmax(z0, -10.0), 10.0) : 0.0;
+                const double wn = wp + z;
+                nshrunk += shrink ? 1 : 0;
                 if (lane == 0) {
                     ggZ[T & 1] = z;
                     *reinterpret_cast<d2 *>(ggP + 4 * (size_t)m + 2) = d2{wn, (shrink || !live) ? 1.0 : 0.0};
                 }
                 zprev = z;
                 P = P1n;
-                if (m1 == m) { P[2] = wn; if (shrink) P[3] = 1.0; }
                 m = m1;
-                // the entry after next
-                m1 = __builtin_amdgcn_readlane(ordv, wl);
-                wl++;
-                if (wp0 + wl >= A) {   // (uniform) the window ran off its sweep: the head of the next sweep's order, complete by now
-                    wk++; wp0 = 0; wl = 0;
-                    ordv = ggOrd[(wk & 1) * SL + min(lane, A - 1)];
-                } else if (wl == 64) {
-                    wp0 += 64; wl = 0;
+                m1 = __builtin_amdgcn_readlane(ordv, wl);   // the entry after next
+                if (++wl == wend) {   // the window is used up: the next 64 entries of this sweep, or the head of the next sweep's order
+                    wp0 += 64;
+                    if (wp0 >= A) { wk++; wp0 = 0; }
+                    wl = 0;
+                    wend = min(64, A - wp0);
                     ordv = ggOrd[(wk & 1) * SL + min(wp0 + lane, A - 1)];
                 }
                 if (++pos == A) {   // end of a sweep: liblinear's rule
                     pos = 0;
                     k++;
                     iter_c++;
-#ifdef PSK_GG_W1
-                    bool stop = true;
-#else
                     bool stop = iter_c >= 1000;
-#endif
+                    const double gmax = psk_readlane_f64(QP_Gmax_new, 0);
                     if (__builtin_amdgcn_readfirstlane((int)(QP_Gnorm1_new <= inner_eps_c * Gnorm1_init_c))) {
-                        if (QP_active_c == A) stop = true;
+                        if (__builtin_amdgcn_readfirstlane(nshrunk) == 0) stop = true;
                         else {
-                            QP_active_c = A;
+                            nshrunk = 0;
                             QP_Gmax_old_c = 1e300;
                             for (int u = lane; u < A; u += 64) ggP[4 * (size_t)u + 3] = 0.0;
                             P[3] = 0.0;
                         }
-                    } else QP_Gmax_old_c = QP_Gmax_new;
+                    } else QP_Gmax_old_c = gmax;
                     thr = QP_Gmax_old_c / l_c;
                     QP_Gmax_new = 0.0;
                     QP_Gnorm1_new = 0.0;
-                    if (stop) {
+                    if (stop) {   // the descent ends at a multiple of DEPTH (see the owners): idle until then
                         stop_at = (T + DEPTH) & ~(DEPTH - 1);
                         if (lane == 0) s_gg.stop_at = stop_at;
+                        for (int Ti = T + 1; Ti <= stop_at; Ti++) GG_BARRIER();
+                        break;
                     }
                 }
             }
             // back to the feature arrays; x.d = X_A d for the line search is the caller's
-#ifndef PSK_GG_V3
             for (int u = lane; u < A; u += 64) wpd[ggFeat[u]] = ggP[4 * (size_t)u + 2];
-#endif
             if (lane == 0) { s_gg.last_A = A; s_gg.par = k & 1; }
         }
 #undef GG_BARRIER
         __syncthreads();
-#ifdef PSK_GG_DEBUG
-        if (tid == 0 && fit == 0) printf("gg: descent done %d sweeps\n", iter_c);
-#endif
         return iter_c;
     };
     if (WMREG > 0 && wave != 0) {   // helper_loop: waves 1..3 join every descent / column build of wave 0 and leave with it
