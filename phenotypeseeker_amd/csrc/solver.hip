@@ -567,7 +567,8 @@ __global__ __launch_bounds__(WMREG > 0 ? SV_COOP_THREADS : SV_THREADS) void logr
     __shared__ GgShared s_gg;
     if (threadIdx.x == 0) { s_gg.last_A = 0; s_gg.par = 0; s_gg.stop_at = -1; }   // (read behind the barrier that releases the first gg_run)
     const int SL = gg_sl;   // slots of the gg arrays (256 x ceil(P1 / 256)); 0 = form not available in this launch
-    double *ggP = Qm;       // per slot: H, 1 / H, w + d, shrunk flag
+    double *ggP = Qm;       // per slot: 1 / H (NaN while the slot is shrunk out of the sweeps), w + d
+    double *ggH = Qm + 2 * (size_t)SL;
     double *ggDm = Qm + 4 * (size_t)SL;
     uint16_t *ggOrd = reinterpret_cast<uint16_t *>(Qm + 4 * (size_t)SL + NP);
     uint16_t *ggFeat = ggOrd + 2 * (size_t)SL;
@@ -598,7 +599,8 @@ __global__ __launch_bounds__(WMREG > 0 ? SV_COOP_THREADS : SV_THREADS) void logr
                 const int f = valid ? act[u] : 0;
                 const double hh = valid ? Hd[f] : 1.0;
                 ggFeat[u] = (uint16_t)f;
-                *reinterpret_cast<d4 *>(ggP + 4 * (size_t)u) = d4{hh, 1.0 / hh, valid ? w[f] : 0.0, 0.0};
+                *reinterpret_cast<d2 *>(ggP + 2 * (size_t)u) = d2{1.0 / hh, valid ? w[f] : 0.0};
+                ggH[u] = hh;
                 if (!keep) ggOrd[u] = (uint16_t)u;          // (the first Newton step, or the active set changed)
                 else if (par) ggOrd[u] = ggOrd[SL + u];     // the last complete order of the previous Newton step
             }
@@ -674,7 +676,7 @@ __global__ __launch_bounds__(WMREG > 0 ? SV_COOP_THREADS : SV_THREADS) void logr
                 }
         }
         __syncthreads();
-        for (int u = tid; u < A; u += SV_COOP_THREADS) Qg[(size_t)u * SL + u] = (float)ggP[4 * (size_t)u];   // (nu is on the diagonal of H)
+        for (int u = tid; u < A; u += SV_COOP_THREADS) Qg[(size_t)u * SL + u] = (float)ggH[u];   // (nu is on the diagonal of H)
         if (tid == 0) s_gg.stop_at = -1;
         __syncthreads();   // Q of this Newton step is whole and visible to the workgroup
 #ifdef PSK_SV_STATS
@@ -789,12 +791,15 @@ __global__ __launch_bounds__(WMREG > 0 ? SV_COOP_THREADS : SV_THREADS) void logr
             // it, and a v_cmp -> s_cbranch pair costs a lone wave 30 to 60 cycles (tools/_variants/ubench.hip, r03), a select 5.
             int dz;
             asm volatile("v_mov_b32 %0, 0" : "=v"(dz));
+            // (v_max / v_min as they are: fmax() and fmin() first quieten their operands, an instruction each)
+            auto vmax = [](double x, double y) __attribute__((always_inline)) { double r; asm("v_max_f64 %0, %1, %2" : "=v"(r) : "v"(x), "v"(y)); return r; };
+            auto vmin = [](double x, double y) __attribute__((always_inline)) { double r; asm("v_min_f64 %0, %1, %2" : "=v"(r) : "v"(x), "v"(y)); return r; };
             int T = 0, k = 0, pos = 0, stop_at = -1, nshrunk = 0;
-            double QP_Gmax_new = 0.0, QP_Gnorm1_new = 0.0, thr = 1e300, zprev = 0.0, QP_Gmax_old_c = 1e300;
+            double QP_Gmax_new = 0.0, QP_Gnorm1_new = 0.0, omt = -1e300, zprev = 0.0, QP_Gmax_old_c = 1e300;
             int wk = 0, wp0 = 0, wl = 2, wend = min(64, A);   // the window: sweep, position of lane 0's entry, next lane, lanes in use
             int ordv = ggOrd[min(lane, A - 1)];
             int m = __builtin_amdgcn_readlane(ordv, 0), m1 = __builtin_amdgcn_readlane(ordv, 1);
-            d4 P = *reinterpret_cast<const d4 *>(ggP + 4 * (size_t)m + dz);
+            d2 P = *reinterpret_cast<const d2 *>(ggP + 2 * (size_t)m + dz);
             if (lane == 0) *reinterpret_cast<d2 *>(ggPub) = d2{Gr[ggFeat[m]], 0.0};   // visit 0: G = g[m] itself (z of "visit -1" is 0)
             for (;; T++) {
 #ifdef PSK_SV_STATS
@@ -804,28 +809,31 @@ __global__ __launch_bounds__(WMREG > 0 ? SV_COOP_THREADS : SV_THREADS) void logr
 #ifdef PSK_SV_STATS
                 stat_t_polish += clock64() - stat_w0;   // (this form has no accelerator: the field reports wave 0's waits at the barrier)
 #endif
-                const d4 P1n = *reinterpret_cast<const d4 *>(ggP + 4 * (size_t)m1 + dz);   // for the next visit (never this visit's slot: see wave 3)
+                const d2 P1n = *reinterpret_cast<const d2 *>(ggP + 2 * (size_t)m1 + dz);   // for the next visit (never this visit's slot: see wave 3)
                 const d2 pub = *reinterpret_cast<const d2 *>(ggPub + 2 * (T & 1) + dz);
-                const double H = P[0], Hi = P[1], wp = P[2];
-                const bool live = P[3] == 0.0;
-                const double G = fma(zprev, pub[1], pub[0]);
-                const double Gp = G + 1.0, Gn = G - 1.0;
-                const bool zero = wp == 0.0;
-                const bool shrink = live && zero && Gp > thr && Gn < -thr;   // out of the sweeps until the whole set is taken up again
+                // liblinear's visit of a coordinate of the quadratic model, in the soft-threshold form: with u = w - G / H the
+                // minimiser is u - clamp(u, -1 / H, 1 / H) -- the same point as its three-way rule (exactly 0 when |u| <= 1 / H)
+                // from 5 instructions instead of 12; its violation |G + sign(w)| or, at w = 0, max(|G| - 1, 0); its shrinking
+                // test G + 1 > thr and G - 1 < -thr as |G| < 1 - thr.  (Its skip of steps below 1e-12 saves the array form a
+                // pass over the samples; here a step costs the same whatever its size, so every step is taken.)
+                const double Hi = P[0], wp = P[1];
+                const bool live = Hi == Hi, zero = wp == 0.0;
+                const double G = fma(zprev, pub[1], pub[0]), aG = fabs(G);
+                const bool shrink = live && zero && aG < omt;   // out of the sweeps until the whole set is taken up again
                 const bool counted = live && !shrink;
-                const double v0 = fmax(fmax(-Gp, Gn), 0.0), v1 = fabs(wp > 0.0 ? Gp : Gn);
-                const double viol = counted ? (zero ? v0 : v1) : 0.0;
-                QP_Gmax_new = fmax(QP_Gmax_new, viol);
+                const double vz = vmax(aG - 1.0, 0.0), vn = fabs(G + copysign(1.0, wp));
+                const double viol = counted ? (zero ? vz : vn) : 0.0;
+                QP_Gmax_new = vmax(QP_Gmax_new, viol);
                 QP_Gnorm1_new += viol;
-                const double Hwp = H * wp;
-                const double z0 = Gp < Hwp ? -Gp * Hi : (Gn > Hwp ? -Gn * Hi : -wp);
-                const bool apply = counted && !(fabs(z0) < 1e-12 && !(z0 == -wp && !zero));
-                const double z = apply ? fmin(fmax(z0, -10.0), 10.0) : 0.0;
+                const double u = fma(-G, Hi, wp);
+                const double wnew = u - vmin(vmax(u, -Hi), Hi);
+                const double z = counted ? vmin(vmax(wnew - wp, -10.0), 10.0) : 0.0;
                 const double wn = wp + z;
                 nshrunk += shrink ? 1 : 0;
                 if (lane == 0) {
                     ggZ[T & 1] = z;
-                    *reinterpret_cast<d2 *>(ggP + 4 * (size_t)m + 2) = d2{wn, (shrink || !live) ? 1.0 : 0.0};
+                    ggP[2 * (size_t)m + 1] = wn;
+                    if (shrink) ggP[2 * (size_t)m] = __builtin_nan("");
                 }
                 zprev = z;
                 P = P1n;
@@ -849,11 +857,11 @@ __global__ __launch_bounds__(WMREG > 0 ? SV_COOP_THREADS : SV_THREADS) void logr
                         else {
                             nshrunk = 0;
                             QP_Gmax_old_c = 1e300;
-                            for (int u = lane; u < A; u += 64) ggP[4 * (size_t)u + 3] = 0.0;
-                            P[3] = 0.0;
+                            for (int u2 = lane; u2 < A; u2 += 64) ggP[2 * (size_t)u2] = 1.0 / ggH[u2];
+                            P = *reinterpret_cast<const d2 *>(ggP + 2 * (size_t)m + dz);
                         }
                     } else QP_Gmax_old_c = gmax;
-                    thr = QP_Gmax_old_c / l_c;
+                    omt = 1.0 - QP_Gmax_old_c / l_c;
                     QP_Gmax_new = 0.0;
                     QP_Gnorm1_new = 0.0;
                     if (stop) {   // the descent ends at a multiple of DEPTH (see the owners): idle until then
@@ -865,7 +873,7 @@ __global__ __launch_bounds__(WMREG > 0 ? SV_COOP_THREADS : SV_THREADS) void logr
                 }
             }
             // back to the feature arrays; x.d = X_A d for the line search is the caller's
-            for (int u = lane; u < A; u += 64) wpd[ggFeat[u]] = ggP[4 * (size_t)u + 2];
+            for (int u = lane; u < A; u += 64) wpd[ggFeat[u]] = ggP[2 * (size_t)u + 1];
             if (lane == 0) { s_gg.last_A = A; s_gg.par = k & 1; }
         }
 #undef GG_BARRIER
