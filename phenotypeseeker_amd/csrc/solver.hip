@@ -569,11 +569,13 @@ __global__ __launch_bounds__(WMREG > 0 ? SV_COOP_THREADS : SV_THREADS) void logr
     const int SL = gg_sl;   // slots of the gg arrays (256 x ceil(P1 / 256)); 0 = form not available in this launch
     double *ggP = Qm;       // per slot: 1 / H (NaN while the slot is shrunk out of the sweeps), w + d
     double *ggH = Qm + 2 * (size_t)SL;
-    double *ggDm = Qm + 4 * (size_t)SL;
+    uint16_t *ggDs = reinterpret_cast<uint16_t *>(Qm + 4 * (size_t)SL);   // D of the training samples as two bf16 parts [2][NP]
     uint16_t *ggOrd = reinterpret_cast<uint16_t *>(Qm + 4 * (size_t)SL + NP);
     uint16_t *ggFeat = ggOrd + 2 * (size_t)SL;
     double *ggPub = reinterpret_cast<double *>(ggFeat + SL);   // [2][2]: g[m'], Q[m'][m] for the visit of that parity; then z [2]
     double *ggZ = ggPub + 4;
+    typedef uint32_t u4 __attribute__((ext_vector_type(4)));
+    u4 *ggT1 = reinterpret_cast<u4 *>(reinterpret_cast<uint8_t *>(ggFeat + SL) + SL), *ggT2 = ggT1 + 256;   // byte -> eight bf16 ones / masks
     float *Qg = gg_q + (size_t)fit * gg_stride;
     auto gg_run = [&]() __attribute__((always_inline)) -> int {
 #ifndef PSK_GG_DEPTH
@@ -582,6 +584,7 @@ __global__ __launch_bounds__(WMREG > 0 ? SV_COOP_THREADS : SV_THREADS) void logr
         constexpr int DEPTH = PSK_GG_DEPTH, FY_STEPS = 3;   // (a power of two)
         typedef float f4 __attribute__((ext_vector_type(4)));
         typedef float f8 __attribute__((ext_vector_type(8)));
+        typedef __bf16 bf8 __attribute__((ext_vector_type(8)));
         typedef double d2 __attribute__((ext_vector_type(2)));
         typedef double d4 __attribute__((ext_vector_type(4)));
         typedef double d8 __attribute__((ext_vector_type(8)));
@@ -604,15 +607,39 @@ __global__ __launch_bounds__(WMREG > 0 ? SV_COOP_THREADS : SV_THREADS) void logr
                 if (!keep) ggOrd[u] = (uint16_t)u;          // (the first Newton step, or the active set changed)
                 else if (par) ggOrd[u] = ggOrd[SL + u];     // the last complete order of the previous Newton step
             }
+            // D of the training samples as the sum of two bf16 (truncated: the weights the matrix cores see never exceed D, so
+            // Q' + (H - diag Q') stays positive semidefinite), and the two byte -> eight-bf16 tables of the build
             for (int i = tid; i < NP; i += SV_COOP_THREADS) {
                 const bool tr = i < n && fold[i] != tf;
-                const int b = i & 63;
-                ggDm[(i & ~63) + (b & 3) * 16 + (b >> 2)] = tr ? D[i] : 0.0;   // word t: [k = b & 3][step = b >> 2]
+                const float d32 = tr ? (float)D[i] : 0.f;
+                const uint32_t b1 = __float_as_uint(d32) & 0xFFFF0000u;
+                const float r32 = tr ? (float)(D[i] - (double)__uint_as_float(b1)) : 0.f;
+                ggDs[i] = (uint16_t)(b1 >> 16);
+                ggDs[NP + i] = (uint16_t)(__float_as_uint(r32 > 0.f ? r32 : 0.f) >> 16);
+            }
+            {
+                const uint32_t b = tid & 255;
+                uint32_t one[4], msk[4];
+#pragma unroll
+                for (int i = 0; i < 4; i++) {
+                    const uint32_t lo = (b >> (2 * i)) & 1u, hi = (b >> (2 * i + 1)) & 1u;
+                    one[i] = lo * 0x3F80u + hi * 0x3F800000u;
+                    msk[i] = lo * 0xFFFFu + hi * 0xFFFF0000u;
+                }
+                if (tid < 256) {
+                    ggT1[b] = u4{one[0], one[1], one[2], one[3]};
+                    ggT2[b] = u4{msk[0], msk[1], msk[2], msk[3]};
+                }
             }
             if (tid < 6) ggPub[tid] = 0.0;
         }
         __syncthreads();
-        {   // Q: tile (kb, mb) = 16 x 16 slots; a work item = tile row kb x four tile columns, items dealt round the waves
+        {   // Q: tile (kb, mb) = 16 x 16 slots; a work item = tile row kb x four tile columns, items dealt round the waves.
+            // v_mfma_f32_16x16x32_bf16 sums over 32 samples at a time: lane l holds, of its row (column) l & 15, the eight
+            // samples 8 (l >> 4) ... + 7 of the chunk -- one BYTE of the column's bit word, expanded through the tables: 1.0 / 0
+            // for the A side, D's two bf16 parts under the byte's mask for the B side (two products per tile and chunk).
+            // (r03's first version fed v_mfma_f64_16x16x4 bit by bit: 27 M cycles per Newton step at 907 coordinates, a
+            // seventh of a fit.)
             const int nt = (A + 15) >> 4, ng = (nt + 3) >> 2, kq = lane >> 4, li = lane & 15;
             int item = 0;
             for (int kb = 0; kb < nt; kb++)
@@ -623,7 +650,7 @@ __global__ __launch_bounds__(WMREG > 0 ? SV_COOP_THREADS : SV_THREADS) void logr
                     const uint64_t *pa = cb + (size_t)(va ? ggFeat[ka] : 0) * W;
                     const uint64_t *pb[4];
                     bool vb[4];
-                    d4 acc[4];
+                    f4 acc[4];
                     uint64_t wa_n = va ? pa[0] : 0ull, wb_n[4];
 #pragma unroll
                     for (int c = 0; c < 4; c++) {
@@ -631,47 +658,41 @@ __global__ __launch_bounds__(WMREG > 0 ? SV_COOP_THREADS : SV_THREADS) void logr
                         vb[c] = mc < A;
                         pb[c] = cb + (size_t)(vb[c] ? ggFeat[mc] : 0) * W;
                         wb_n[c] = vb[c] ? pb[c][0] : 0ull;
-                        acc[c] = d4{0.0, 0.0, 0.0, 0.0};
+                        acc[c] = f4{0.f, 0.f, 0.f, 0.f};
                     }
                     for (int t = 0; t < W; t++) {
-                        const uint64_t wa = wa_n >> kq;
+                        const uint64_t wa = wa_n;
                         uint64_t wb[4];
 #pragma unroll
-                        for (int c = 0; c < 4; c++) wb[c] = wb_n[c] >> kq;
+                        for (int c = 0; c < 4; c++) wb[c] = wb_n[c];
                         if (t + 1 < W) {
                             wa_n = va ? pa[t + 1] : 0ull;
 #pragma unroll
                             for (int c = 0; c < 4; c++) wb_n[c] = vb[c] ? pb[c][t + 1] : 0ull;
                         }
-                        double dm[16];
-                        const double *dmp = ggDm + t * 64 + kq * 16;
 #pragma unroll
-                        for (int s = 0; s < 16; s++) dm[s] = dmp[s];
-#pragma unroll
-                        for (int s = 0; s < 16; s++) {
-                            const uint32_t off = 4u * (s & 7);
-                            const int ab = __builtin_amdgcn_sbfe((int)(s < 8 ? (uint32_t)wa : (uint32_t)(wa >> 32)), off, 1u);
-                            const double av = __hiloint2double(ab & 0x3FF00000, 0);
-                            const int dlo = __double2loint(dm[s]), dhi = __double2hiint(dm[s]);
+                        for (int c2 = 0; c2 < 2; c2++) {
+                            const uint32_t ha = c2 ? (uint32_t)(wa >> 32) : (uint32_t)wa;
+                            const u4 av = ggT1[(ha >> (8 * kq)) & 0xFFu];
+                            const u4 d1 = *reinterpret_cast<const u4 *>(ggDs + t * 64 + c2 * 32 + kq * 8);
+                            const u4 d2 = *reinterpret_cast<const u4 *>(ggDs + NP + t * 64 + c2 * 32 + kq * 8);
 #pragma unroll
                             for (int c = 0; c < 4; c++) {
-                                const int bb = __builtin_amdgcn_sbfe((int)(s < 8 ? (uint32_t)wb[c] : (uint32_t)(wb[c] >> 32)), off, 1u);
-                                acc[c] = __builtin_amdgcn_mfma_f64_16x16x4f64(av, __hiloint2double(dhi & bb, dlo & bb), acc[c], 0, 0, 0);
+                                const uint32_t hb = c2 ? (uint32_t)(wb[c] >> 32) : (uint32_t)wb[c];
+                                const u4 mk = ggT2[(hb >> (8 * kq)) & 0xFFu];
+                                acc[c] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf8, av), __builtin_bit_cast(bf8, d1 & mk), acc[c], 0, 0, 0);
+                                acc[c] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf8, av), __builtin_bit_cast(bf8, d2 & mk), acc[c], 0, 0, 0);
                             }
                         }
                     }
-                    // C/D of the f64 MFMA: column = lane & 15, row = (lane >> 4) + 4 r
+                    // C/D: column = lane & 15, rows 4 (lane >> 4) ... + 3
 #pragma unroll
                     for (int c = 0; c < 4; c++) {
-                        const int mc = (gq * 4 + c) * 16 + li;
+                        const int mc = (gq * 4 + c) * 16 + li, kr = kb * 16 + 4 * kq;
                         if (mc >= nt * 16) continue;
+                        *reinterpret_cast<f4 *>(Qg + (size_t)mc * SL + kr) = acc[c];
 #pragma unroll
-                        for (int r = 0; r < 4; r++) {
-                            const int kr = kb * 16 + kq + 4 * r;
-                            const float v = (float)acc[c][r];
-                            Qg[(size_t)mc * SL + kr] = v;
-                            Qg[(size_t)kr * SL + mc] = v;
-                        }
+                        for (int r = 0; r < 4; r++) Qg[(size_t)(kr + r) * SL + mc] = acc[c][r];
                     }
                 }
         }
@@ -1766,7 +1787,7 @@ extern "C" int psk_logreg_l1_fit(psk_ctx *ctx, const float *X, const int32_t *y0
         if (P1 > 192 && P1 <= 1024 && wmreg_h > 0 && (wmreg_h < 64 || getenv("PSK_GRAM_GLOBAL_64")) && SV_COOP_WAVES == 4 &&
             !getenv("PSK_NO_GRAM") && !getenv("PSK_NO_GRAM_GLOBAL")) {
             const size_t sl = 256 * (((size_t)P1 + 255) / 256), np_h = (size_t)W * 64;
-            const size_t need = (4 * sl + np_h + sl / 2 + sl / 4 + sl / 8) * 8, stride = (((size_t)P1 + 15) / 16 * 16) * sl;
+            const size_t need = (4 * sl + np_h + sl / 2 + sl / 4 + sl / 8) * 8 + 8192, stride = (((size_t)P1 + 15) / 16 * 16) * sl;
             if (fa + need <= lds_max && (size_t)n_fits * stride * 4 <= ((size_t)32 << 30)) { gg_sl = (int)sl; gg_stride = stride; gg_lds = need; }
         }
         const bool gram = !getenv("PSK_NO_GRAM") && gg_sl == 0;
