@@ -563,17 +563,17 @@ __global__ __launch_bounds__(WMREG > 0 ? SV_COOP_THREADS : SV_THREADS) void logr
     //   wave 3    draws the next sweep's random order (Fisher-Yates, three steps per visit) while the current one runs.
     // Same rule as liblinear for shrinking and stopping; a shrunk coordinate keeps its place in the order and is skipped
     // (flag), so the order of a sweep never changes under the loaders' feet.  No CG accelerator in this form.
-    struct GgShared { int stop_at, last_A, par; };
+    struct GgShared { int stop_at, last_A, par, iters; };
     __shared__ GgShared s_gg;
     if (threadIdx.x == 0) { s_gg.last_A = 0; s_gg.par = 0; s_gg.stop_at = -1; }   // (read behind the barrier that releases the first gg_run)
     const int SL = gg_sl;   // slots of the gg arrays (256 x ceil(P1 / 256)); 0 = form not available in this launch
-    double *ggP = Qm;       // per slot: 1 / H (NaN while the slot is shrunk out of the sweeps), w + d
+    double *ggP = Qm;       // per slot: 1 / H (0 while the slot is shrunk out of the sweeps), w + d
     double *ggH = Qm + 2 * (size_t)SL;
     uint16_t *ggDs = reinterpret_cast<uint16_t *>(Qm + 4 * (size_t)SL);   // D of the training samples as two bf16 parts [2][NP]
     uint16_t *ggOrd = reinterpret_cast<uint16_t *>(Qm + 4 * (size_t)SL + NP);
     uint16_t *ggFeat = ggOrd + 2 * (size_t)SL;
     double *ggPub = reinterpret_cast<double *>(ggFeat + SL);   // [2][2]: g[m'], Q[m'][m] for the visit of that parity; then z [2]
-    double *ggZ = ggPub + 4;
+    double *ggZG = ggPub + 4;                                  // [2][2]: the step and G of the visit of that parity
     typedef uint32_t u4 __attribute__((ext_vector_type(4)));
     u4 *ggT1 = reinterpret_cast<u4 *>(reinterpret_cast<uint8_t *>(ggFeat + SL) + SL), *ggT2 = ggT1 + 256;   // byte -> eight bf16 ones / masks
     float *Qg = gg_q + (size_t)fit * gg_stride;
@@ -581,7 +581,7 @@ __global__ __launch_bounds__(WMREG > 0 ? SV_COOP_THREADS : SV_THREADS) void logr
 #ifndef PSK_GG_DEPTH
 #define PSK_GG_DEPTH 8
 #endif
-        constexpr int DEPTH = PSK_GG_DEPTH, FY_STEPS = 3;   // (a power of two)
+        constexpr int DEPTH = PSK_GG_DEPTH;   // (a power of two)
         typedef float f4 __attribute__((ext_vector_type(4)));
         typedef float f8 __attribute__((ext_vector_type(8)));
         typedef __bf16 bf8 __attribute__((ext_vector_type(8)));
@@ -631,7 +631,7 @@ __global__ __launch_bounds__(WMREG > 0 ? SV_COOP_THREADS : SV_THREADS) void logr
                     ggT2[b] = u4{msk[0], msk[1], msk[2], msk[3]};
                 }
             }
-            if (tid < 6) ggPub[tid] = 0.0;
+            if (tid < 8) ggPub[tid] = 0.0;
         }
         __syncthreads();
         {   // Q: tile (kb, mb) = 16 x 16 slots; a work item = tile row kb x four tile columns, items dealt round the waves.
@@ -726,103 +726,194 @@ __global__ __launch_bounds__(WMREG > 0 ? SV_COOP_THREADS : SV_THREADS) void logr
                 const int u = 256 * (2 * h + (e >> 2)) + 4 * lane + (e & 3);
                 go[e] = u < A ? Gr[ggFeat[u]] : 0.0;
             }
+            // a round's DEPTH tickets: their slots through ONE read of the order (lane u = ticket u of the round, across the
+            // end of a sweep into the next order), then per ticket a lane read, the column's base and two loads
+            const char *Qb = reinterpret_cast<const char *>(Qg);
+            const uint32_t colb = (uint32_t)SL * 4u, vo0 = (uint32_t)(r0 * 64 + lane) * 16u, vo1 = (uint32_t)(r1 * 64 + lane) * 16u;
             int lk = 0, lpos = 0;
-            auto issue = [&](f4 &x0, f4 &x1, int &mm) __attribute__((always_inline)) {
-                const int m = __builtin_amdgcn_readfirstlane((int)ggOrd[(lk & 1) * SL + lpos]);
-                const f4 *col = Q4 + (size_t)m * SL4 + lane;
-                x0 = col[r0 * 64];
-                x1 = col[r1 * 64];
-                mm = m;
-                if (++lpos == A) { lpos = 0; lk++; }
+            auto round_order = [&]() __attribute__((always_inline)) {
+                int pp = lpos + (lane & (DEPTH - 1)), kk = lk;
+                if (pp >= A) { pp -= A; kk++; }
+                const int ov = ggOrd[(kk & 1) * SL + pp];
+                lpos += DEPTH;
+                if (lpos >= A) { lpos -= A; lk++; }
+                return ov;
             };
-            f4 a0[DEPTH], a1[DEPTH], b0[DEPTH], b1[DEPTH], l0 = f4{0.f, 0.f, 0.f, 0.f}, l1 = l0;
+            auto issue = [&](f8 &x, int &mm, int ov, int u) __attribute__((always_inline)) {
+                const int m = __builtin_amdgcn_readlane(ov, u);
+                const char *col = Qb + (size_t)((uint32_t)m * colb);
+                const f4 x0 = *reinterpret_cast<const f4 *>(col + vo0), x1 = *reinterpret_cast<const f4 *>(col + vo1);
+                x = f8{x0.x, x0.y, x0.z, x0.w, x1.x, x1.y, x1.z, x1.w};
+                mm = m;
+            };
+            f8 a[DEPTH], b[DEPTH], lst = f8{0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
             int ma[DEPTH], mb[DEPTH];
+            {
+                const int ov = round_order();
 #pragma unroll
-            for (int u = 0; u < DEPTH; u++) issue(a0[u], a1[u], ma[u]);
+                for (int u = 0; u < DEPTH; u++) issue(a[u], ma[u], ov, u);
+            }
             __builtin_amdgcn_s_waitcnt(0x0F70);   // vmcnt(0): the first set is whole
             for (int T = 0;; T += DEPTH) {
+                {
+                    const int ov = round_order();
 #pragma unroll
-                for (int u = 0; u < DEPTH; u++) issue(b0[u], b1[u], mb[u]);   // tickets T + DEPTH ... T + 2 DEPTH - 1
+                    for (int u = 0; u < DEPTH; u++) issue(b[u], mb[u], ov, u);   // tickets T + DEPTH ... T + 2 DEPTH - 1
+                }
 #pragma unroll
                 for (int u = 0; u < DEPTH; u++) {   // visit T + u
                     GG_BARRIER();
                     if (u == 0 && T == __builtin_amdgcn_readfirstlane(s_gg.stop_at)) goto owners_done;
-                    // z of visit T + u - 1 on this wave's rows of ITS column
-                    const double z = ggZ[(u + 1) & 1];
-                    {   // (a zero step takes the same instructions: a branch costs more than eight multiply-adds)
-                        const f4 c0 = u > 0 ? a0[u > 0 ? u - 1 : 0] : l0, c1 = u > 0 ? a1[u > 0 ? u - 1 : 0] : l1;
-                        go[0] = fma(z, (double)c0.x, go[0]); go[1] = fma(z, (double)c0.y, go[1]);   // (explicit fma: -ffp-contract=off)
-                        go[2] = fma(z, (double)c0.z, go[2]); go[3] = fma(z, (double)c0.w, go[3]);
-                        go[4] = fma(z, (double)c1.x, go[4]); go[5] = fma(z, (double)c1.y, go[5]);
-                        go[6] = fma(z, (double)c1.z, go[6]); go[7] = fma(z, (double)c1.w, go[7]);
-                    }
-                    // for visit T + u + 1 (slot mn): g[mn] as it is now, and Q[mn][m] from the column of THIS visit's slot
+                    const double z = ggZG[2 * ((u + 1) & 1)];   // of visit T + u - 1: asked for now, applied last
+                    const f8 prev = u > 0 ? a[u > 0 ? u - 1 : 0] : lst;   // the column of that visit's slot
+                    // for visit T + u + 1 (slot mn): g[mn] BEFORE that step, Q[mn][slot of T + u - 1] and Q[mn][slot of T + u]:
+                    // wave 0 adds the two steps it knows by then
                     const int mn = u + 1 < DEPTH ? ma[u + 1 < DEPTH ? u + 1 : 0] : mb[0];
                     if ((mn >> 9) == h) {
                         const int e = ((mn >> 6) & 4) | (mn & 3), ln = (mn >> 2) & 63;
                         const double gv = psk_readlane_f64(go[e], ln);
-                        const f8 cc = f8{a0[u].x, a0[u].y, a0[u].z, a0[u].w, a1[u].x, a1[u].y, a1[u].z, a1[u].w};
-                        const float qv = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, cc[e]), ln));
-                        if (lane == 0) *reinterpret_cast<d2 *>(ggPub + 2 * ((u + 1) & 1)) = d2{gv, (double)qv};
+                        const int q1 = __builtin_amdgcn_readlane(__builtin_bit_cast(int, prev[e]), ln);
+                        const int q2 = __builtin_amdgcn_readlane(__builtin_bit_cast(int, a[u][e]), ln);
+                        if (lane == 0) *reinterpret_cast<u4 *>(ggPub + 2 * ((u + 1) & 1)) = u4{(uint32_t)__double2loint(gv), (uint32_t)__double2hiint(gv), (uint32_t)q1, (uint32_t)q2};
                     }
-                }
-                l0 = a0[DEPTH - 1]; l1 = a1[DEPTH - 1];
+                    // (a zero step takes the same instructions: a branch costs more than eight multiply-adds; explicit fma:
+                    // the file is built with -ffp-contract=off)
 #pragma unroll
-                for (int u = 0; u < DEPTH; u++) { a0[u] = b0[u]; a1[u] = b1[u]; ma[u] = mb[u]; }
+                    for (int e = 0; e < 8; e++) go[e] = fma(z, (double)prev[e], go[e]);
+                }
+                lst = a[DEPTH - 1];
+#pragma unroll
+                for (int u = 0; u < DEPTH; u++) { a[u] = b[u]; ma[u] = mb[u]; }
             }
         owners_done:
             // the last burst is still in flight: nothing may leave this block with loads pending on registers that the code
             // after it reuses (without this wait the <false, 64> instance of the kernel faulted on its way out: r03)
             __builtin_amdgcn_s_waitcnt(0x0F70);   // vmcnt(0)
         } else if (wave == 3) {
-            // ---- the next sweep's order: a copy of this sweep's, shuffled in place; complete after A / FY_STEPS visits
+            // ---- liblinear's bookkeeping, one visit behind the steps, and the next sweep's order.  Visit V's violation, its
+            // shrinking test (the marker 1 / H = 0 goes into the slot's place: the slot is visited again a sweep later at the
+            // earliest) and, after a sweep's last visit, the stopping rule -- all from G of the visit, which wave 0 leaves
+            // beside its step, and the slot's parameters as they were BEFORE the step (read two visits ahead of the step).  A
+            // verdict therefore takes effect a visit or two into the next sweep: the end of the descent at the next ticket
+            // that is a multiple of DEPTH (a few more coordinate steps on the same model), the return of the shrunk slots and
+            // the new shrinking threshold likewise.  The values pass through an address with an opaque zero added (see wave 0).
+            int dz;
+            asm volatile("v_mov_b32 %0, 0" : "=v"(dz));
+            auto vmax = [](double x, double y) __attribute__((always_inline)) { double r; asm("v_max_f64 %0, %1, %2" : "=v"(r) : "v"(x), "v"(y)); return r; };
             uint32_t r32 = rng;
-            int k = 0, pos = 0, fy = A;
+            int k = 0, pos = 0, stop_at = -1, sweeps = 0, nshrunk = 0;
+            int k2 = 0, p2 = 2;   // where the order entry of visit T + 2 is
+            int mprev = 0, mcur = ggOrd[0], mn1 = ggOrd[1];
+            d2 Pa = d2{0.0, 0.0}, Pb = *reinterpret_cast<const d2 *>(ggP + 2 * (size_t)mcur + dz);
+            double Gmax = 0.0, Gnorm1 = 0.0, Gmax_old = 1e300, omt = -1e300;
             for (int T = 0;; T++) {
                 GG_BARRIER();
-                if (T == __builtin_amdgcn_readfirstlane(s_gg.stop_at)) break;
-                uint16_t *on = ggOrd + ((k + 1) & 1) * SL;
-                if (pos == 0) {
-                    const uint16_t *oc = ggOrd + (k & 1) * SL;
-                    for (int u = lane; u < A; u += 64) on[u] = oc[u];
-                    fy = 0;
-                }
-                if (lane == 0) {
-#pragma unroll
-                    for (int s = 0; s < FY_STEPS; s++) {
-                        if (fy + 1 < A) {
-                            r32 ^= r32 << 13; r32 ^= r32 >> 17; r32 ^= r32 << 5;
-                            const int jj = fy + (int)__umulhi(r32, (uint32_t)(A - fy));
-                            const uint16_t tt = on[jj]; on[jj] = on[fy]; on[fy] = tt;
-                        } else if (fy + 1 == A) {   // done; a sweep never starts on the slot the previous one ended on (wave 0
-                            const uint16_t f0 = on[0], f1 = on[1];   // reads a slot's parameters while the previous visit writes its own)
-                            if (f0 == ggOrd[(k & 1) * SL + A - 1]) { on[0] = f1; on[1] = f0; }
+                if (T == stop_at) break;
+                const int mn2 = ggOrd[(k2 & 1) * SL + p2];
+                if (T > 0) {   // visit T - 1 (slot mprev, parameters Pa)
+                    const double G = ggZG[2 * ((T - 1) & 1) + 1 + dz];
+                    const double Hi = Pa[0], wp = Pa[1], aG = fabs(G);
+                    const bool live = Hi != 0.0, zero = wp == 0.0;
+                    const bool shrink = live && zero && aG < omt;   // out of the sweeps until the whole set is taken up again
+                    const double vz = vmax(aG - 1.0, 0.0), vn = fabs(G + copysign(1.0, wp));
+                    const double viol = live ? (zero ? vz : vn) : 0.0;   // (0 for the visit that shrinks: |G| < 1)
+                    Gmax = vmax(Gmax, viol);
+                    Gnorm1 += viol;
+                    nshrunk += shrink ? 1 : 0;
+                    if (lane == 0 && shrink) ggP[2 * (size_t)mprev] = 0.0;
+                    if (pos == 0) {   // that was the last visit of sweep k - 1: liblinear's rule
+                        sweeps++;
+                        bool stop = sweeps >= 1000;
+                        const double gmax = psk_readlane_f64(Gmax, 0);
+                        if (__builtin_amdgcn_readfirstlane((int)(Gnorm1 <= inner_eps_c * Gnorm1_init_c))) {
+                            if (__builtin_amdgcn_readfirstlane(nshrunk) == 0) stop = true;
+                            else {
+                                nshrunk = 0;
+                                Gmax_old = 1e300;
+                                for (int u2 = lane; u2 < A; u2 += 64) ggP[2 * (size_t)u2] = 1.0 / ggH[u2];
+                                if (Pb[0] == 0.0) Pb[0] = 1.0 / ggH[mcur];   // (the copies held for the next two visits)
+                            }
+                        } else Gmax_old = gmax;
+                        omt = 1.0 - Gmax_old / l_c;
+                        Gmax = 0.0;
+                        Gnorm1 = 0.0;
+                        if (stop && stop_at < 0) {
+                            stop_at = (T + 1 + DEPTH) & ~(DEPTH - 1);   // >= T + 2: every wave reads it behind a later barrier
+                            if (lane == 0) { s_gg.stop_at = stop_at; s_gg.iters = sweeps; }
                         }
-                        fy++;
+                    }
+                }
+                const d2 Pc = *reinterpret_cast<const d2 *>(ggP + 2 * (size_t)mn1 + dz);   // of visit T + 1, before its step (and after a return of the shrunk slots)
+                if (pos == 0) {
+                    // the next sweep's order, whole, at the first visit of this one (a few thousand cycles, once per sweep): the
+                    // slots sorted by a random 11-bit key -- histogram, offsets, scatter through LDS counters in the place of the
+                    // build's tables; equal keys keep the counters' order.  (A Fisher-Yates step per visit, r03's first version,
+                    // is two dependent LDS round trips: ~130 cycles of a wave that now has the visit's bookkeeping to do.)
+                    uint16_t *on = ggOrd + ((k + 1) & 1) * SL;
+                    uint32_t *bins = reinterpret_cast<uint32_t *>(ggT1);   // 2048 counters
+                    r32 ^= r32 << 13; r32 ^= r32 >> 17; r32 ^= r32 << 5;
+                    const uint32_t seed = (uint32_t)__builtin_amdgcn_readfirstlane((int)r32);
+#pragma unroll
+                    for (int i = 0; i < 32; i++) bins[lane + 64 * i] = 0u;
+                    uint32_t keyv[16];
+#pragma unroll
+                    for (int e = 0; e < 16; e++) {
+                        const int u = lane + 64 * e;
+                        uint32_t x = ((uint32_t)u + 1u) * 0x9E3779B1u ^ seed;
+                        x ^= x >> 15; x *= 0x85EBCA77u; x ^= x >> 13;
+                        keyv[e] = x >> 21;
+                        if (u < A) atomicAdd(&bins[keyv[e]], 1u);
+                    }
+                    uint32_t run = 0;   // this lane's 32 counters -> exclusive offsets
+#pragma unroll
+                    for (int i = 0; i < 32; i++) { const uint32_t c = bins[lane * 32 + i]; bins[lane * 32 + i] = run; run += c; }
+                    const uint32_t base = psk_wave_incl_scan_u32(run, lane) - run;
+#pragma unroll
+                    for (int i = 0; i < 32; i++) bins[lane * 32 + i] += base;
+#pragma unroll
+                    for (int e = 0; e < 16; e++) {
+                        const int u = lane + 64 * e;
+                        if (u < A) on[atomicAdd(&bins[keyv[e]], 1u)] = (uint16_t)u;
+                    }
+                    // a sweep never starts on the slot the previous one ended on (a slot's parameters are read while the
+                    // previous visit writes its own)
+                    if (lane == 0) {
+                        const uint16_t f0 = on[0], f1 = on[1];
+                        if (f0 == ggOrd[(k & 1) * SL + A - 1]) { on[0] = f1; on[1] = f0; }
                     }
                 }
                 if (++pos == A) { pos = 0; k++; }
+                if (++p2 == A) { p2 = 0; k2++; }
+                mprev = mcur; mcur = mn1; mn1 = mn2;
+                Pa = Pb; Pb = Pc;
             }
             rng = r32;
+            if (lane == 0) { s_gg.last_A = A; s_gg.par = k & 1; if (stop_at < 0) s_gg.iters = sweeps; }
         } else {
-            // ---- the scalar side of the descent.  The order arrives 64 entries at a time in a register (lane i = the entry
-            // i places on), the slot's parameters are requested a visit ahead.  Every lane computes the same step.  The
-            // values come from LDS through an address with an opaque zero added, so that the compiler takes them for
-            // lane-varying and turns the rule into selects: as wave-uniform values it made ~20 scalar branches per visit of
-            // it, and a v_cmp -> s_cbranch pair costs a lone wave 30 to 60 cycles (tools/_variants/ubench.hip, r03), a select 5.
+            // ---- the steps.  G of the visit's slot = what its owner left (g two steps ago and the two entries of Q) plus the
+            // two steps since; the slot's 1 / H and w, requested a visit ahead; the soft-threshold form of liblinear's step:
+            // with u = w - G / H the minimiser of the one-variable model is u - clamp(u, -1 / H, 1 / H) -- the same point as
+            // its three-way rule, exactly 0 when |u| <= 1 / H, from 5 instructions instead of 12.  (Its skip of steps below
+            // 1e-12 saves the array form a pass over the samples; here a step costs the same whatever its size, so every step
+            // is taken.)  A shrunk slot has 1 / H = 0 in its place and w = 0, and its step comes out as exactly 0 from the same
+            // arithmetic (u = 0, clamp(0, -0, 0) = 0); so does the step of the visit that shrinks it (|G| < 1 - thr <= 1 means
+            // |u| <= 1 / H): this wave needs no flag at all -- violations, shrinking and the stopping rule are wave 3's.
+            // The order arrives 64 entries at a time in a register (lane i = the entry i places on).  Every lane computes the
+            // same step; the values pass through an address with an opaque zero added, so that the compiler takes them for
+            // lane-varying and builds selects: as wave-uniform values it made ~20 scalar branches per visit of the rule, and a
+            // v_cmp -> s_cbranch pair costs a lone wave 30 to 60 cycles (tools/_variants/ubench.hip, r03), a select 5.
             int dz;
             asm volatile("v_mov_b32 %0, 0" : "=v"(dz));
             // (v_max / v_min as they are: fmax() and fmin() first quieten their operands, an instruction each)
             auto vmax = [](double x, double y) __attribute__((always_inline)) { double r; asm("v_max_f64 %0, %1, %2" : "=v"(r) : "v"(x), "v"(y)); return r; };
             auto vmin = [](double x, double y) __attribute__((always_inline)) { double r; asm("v_min_f64 %0, %1, %2" : "=v"(r) : "v"(x), "v"(y)); return r; };
-            int T = 0, k = 0, pos = 0, stop_at = -1, nshrunk = 0;
-            double QP_Gmax_new = 0.0, QP_Gnorm1_new = 0.0, omt = -1e300, zprev = 0.0, QP_Gmax_old_c = 1e300;
+            double zprev = 0.0, zprev2 = 0.0;
             int wk = 0, wp0 = 0, wl = 2, wend = min(64, A);   // the window: sweep, position of lane 0's entry, next lane, lanes in use
             int ordv = ggOrd[min(lane, A - 1)];
             int m = __builtin_amdgcn_readlane(ordv, 0), m1 = __builtin_amdgcn_readlane(ordv, 1);
             d2 P = *reinterpret_cast<const d2 *>(ggP + 2 * (size_t)m + dz);
-            if (lane == 0) *reinterpret_cast<d2 *>(ggPub) = d2{Gr[ggFeat[m]], 0.0};   // visit 0: G = g[m] itself (z of "visit -1" is 0)
-            for (;; T++) {
+            if (lane == 0) *reinterpret_cast<d2 *>(ggPub) = d2{Gr[ggFeat[m]], 0.0};   // visit 0: G = g[m] itself (no step before it)
+            for (int T = 0;; T++) {
 #ifdef PSK_SV_STATS
                 const long long stat_w0 = clock64();
 #endif
@@ -830,32 +921,19 @@ __global__ __launch_bounds__(WMREG > 0 ? SV_COOP_THREADS : SV_THREADS) void logr
 #ifdef PSK_SV_STATS
                 stat_t_polish += clock64() - stat_w0;   // (this form has no accelerator: the field reports wave 0's waits at the barrier)
 #endif
+                if ((T & (DEPTH - 1)) == 0 && T == __builtin_amdgcn_readfirstlane(s_gg.stop_at)) break;
+                const d2 pubd = *reinterpret_cast<const d2 *>(ggPub + 2 * (T & 1) + dz);   // g[m] two steps ago | Q[m][m''], Q[m][m'] (two floats)
                 const d2 P1n = *reinterpret_cast<const d2 *>(ggP + 2 * (size_t)m1 + dz);   // for the next visit (never this visit's slot: see wave 3)
-                const d2 pub = *reinterpret_cast<const d2 *>(ggPub + 2 * (T & 1) + dz);
-                // liblinear's visit of a coordinate of the quadratic model, in the soft-threshold form: with u = w - G / H the
-                // minimiser is u - clamp(u, -1 / H, 1 / H) -- the same point as its three-way rule (exactly 0 when |u| <= 1 / H)
-                // from 5 instructions instead of 12; its violation |G + sign(w)| or, at w = 0, max(|G| - 1, 0); its shrinking
-                // test G + 1 > thr and G - 1 < -thr as |G| < 1 - thr.  (Its skip of steps below 1e-12 saves the array form a
-                // pass over the samples; here a step costs the same whatever its size, so every step is taken.)
                 const double Hi = P[0], wp = P[1];
-                const bool live = Hi == Hi, zero = wp == 0.0;
-                const double G = fma(zprev, pub[1], pub[0]), aG = fabs(G);
-                const bool shrink = live && zero && aG < omt;   // out of the sweeps until the whole set is taken up again
-                const bool counted = live && !shrink;
-                const double vz = vmax(aG - 1.0, 0.0), vn = fabs(G + copysign(1.0, wp));
-                const double viol = counted ? (zero ? vz : vn) : 0.0;
-                QP_Gmax_new = vmax(QP_Gmax_new, viol);
-                QP_Gnorm1_new += viol;
+                const double G = fma(zprev, (double)__int_as_float(__double2hiint(pubd[1])), fma(zprev2, (double)__int_as_float(__double2loint(pubd[1])), pubd[0]));
                 const double u = fma(-G, Hi, wp);
                 const double wnew = u - vmin(vmax(u, -Hi), Hi);
-                const double z = counted ? vmin(vmax(wnew - wp, -10.0), 10.0) : 0.0;
-                const double wn = wp + z;
-                nshrunk += shrink ? 1 : 0;
+                const double z = vmin(vmax(wnew - wp, -10.0), 10.0);
                 if (lane == 0) {
-                    ggZ[T & 1] = z;
-                    ggP[2 * (size_t)m + 1] = wn;
-                    if (shrink) ggP[2 * (size_t)m] = __builtin_nan("");
+                    *reinterpret_cast<d2 *>(ggZG + 2 * (T & 1)) = d2{z, G};
+                    ggP[2 * (size_t)m + 1] = wp + z;
                 }
+                zprev2 = zprev;
                 zprev = z;
                 P = P1n;
                 m = m1;
@@ -867,38 +945,13 @@ __global__ __launch_bounds__(WMREG > 0 ? SV_COOP_THREADS : SV_THREADS) void logr
                     wend = min(64, A - wp0);
                     ordv = ggOrd[(wk & 1) * SL + min(wp0 + lane, A - 1)];
                 }
-                if (++pos == A) {   // end of a sweep: liblinear's rule
-                    pos = 0;
-                    k++;
-                    iter_c++;
-                    bool stop = iter_c >= 1000;
-                    const double gmax = psk_readlane_f64(QP_Gmax_new, 0);
-                    if (__builtin_amdgcn_readfirstlane((int)(QP_Gnorm1_new <= inner_eps_c * Gnorm1_init_c))) {
-                        if (__builtin_amdgcn_readfirstlane(nshrunk) == 0) stop = true;
-                        else {
-                            nshrunk = 0;
-                            QP_Gmax_old_c = 1e300;
-                            for (int u2 = lane; u2 < A; u2 += 64) ggP[2 * (size_t)u2] = 1.0 / ggH[u2];
-                            P = *reinterpret_cast<const d2 *>(ggP + 2 * (size_t)m + dz);
-                        }
-                    } else QP_Gmax_old_c = gmax;
-                    omt = 1.0 - QP_Gmax_old_c / l_c;
-                    QP_Gmax_new = 0.0;
-                    QP_Gnorm1_new = 0.0;
-                    if (stop) {   // the descent ends at a multiple of DEPTH (see the owners): idle until then
-                        stop_at = (T + DEPTH) & ~(DEPTH - 1);
-                        if (lane == 0) s_gg.stop_at = stop_at;
-                        for (int Ti = T + 1; Ti <= stop_at; Ti++) GG_BARRIER();
-                        break;
-                    }
-                }
             }
             // back to the feature arrays; x.d = X_A d for the line search is the caller's
             for (int u = lane; u < A; u += 64) wpd[ggFeat[u]] = ggP[2 * (size_t)u + 1];
-            if (lane == 0) { s_gg.last_A = A; s_gg.par = k & 1; }
         }
 #undef GG_BARRIER
         __syncthreads();
+        iter_c = s_gg.iters;
         return iter_c;
     };
     if (WMREG > 0 && wave != 0) {   // helper_loop: waves 1..3 join every descent / column build of wave 0 and leave with it
