@@ -565,6 +565,10 @@ __global__ __launch_bounds__(WMREG > 0 ? SV_COOP_THREADS : SV_THREADS) void logr
     // (flag), so the order of a sweep never changes under the loaders' feet.  No CG accelerator in this form.
     struct GgShared { int stop_at, last_A, par, iters; };
     __shared__ GgShared s_gg;
+#ifdef PSK_SV_STATS
+    __shared__ long long s_stat_wait[4];
+    if (threadIdx.x < 4) s_stat_wait[threadIdx.x] = 0;
+#endif
     if (threadIdx.x == 0) { s_gg.last_A = 0; s_gg.par = 0; s_gg.stop_at = -1; }   // (read behind the barrier that releases the first gg_run)
     const int SL = gg_sl;   // slots of the gg arrays (256 x ceil(P1 / 256)); 0 = form not available in this launch
     double *ggP = Qm;       // per slot: 1 / H (0 while the slot is shrunk out of the sweeps), w + d
@@ -706,8 +710,15 @@ __global__ __launch_bounds__(WMREG > 0 ? SV_COOP_THREADS : SV_THREADS) void logr
         const f4 *Q4 = reinterpret_cast<const f4 *>(Qg);
         const int SL4 = SL >> 2;
         int iter_c = 0;
+#ifdef PSK_SV_STATS
+        long long stat_bw = 0;   // this wave's cycles at the barrier of the descent (-> s_stat_wait, printed with the fit's statistics)
+#define GG_BARRIER() do { const long long stat_b0 = clock64(); __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup", "local"); \
+                          __builtin_amdgcn_s_barrier(); __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup", "local"); \
+                          stat_bw += clock64() - stat_b0; } while (0)
+#else
 #define GG_BARRIER() do { __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup", "local"); __builtin_amdgcn_s_barrier(); \
                           __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup", "local"); } while (0)
+#endif
         if (wave == 1 || wave == 2) {
             // ---- owners of g and of the columns.  Ticket T = the T-th visit of this descent = (sweep T / A, position T % A).
             // Two register sets of DEPTH tickets: `a` is complete and used one ticket per visit, `b` is loaded in ONE burst
@@ -801,17 +812,18 @@ __global__ __launch_bounds__(WMREG > 0 ? SV_COOP_THREADS : SV_THREADS) void logr
             asm volatile("v_mov_b32 %0, 0" : "=v"(dz));
             auto vmax = [](double x, double y) __attribute__((always_inline)) { double r; asm("v_max_f64 %0, %1, %2" : "=v"(r) : "v"(x), "v"(y)); return r; };
             uint32_t r32 = rng;
-            int k = 0, pos = 0, stop_at = -1, sweeps = 0, nshrunk = 0;
+            int sweeps = 0, nshrunk = 0;
             int k2 = 0, p2 = 2;   // where the order entry of visit T + 2 is
             int mprev = 0, mcur = ggOrd[0], mn1 = ggOrd[1];
             d2 Pa = d2{0.0, 0.0}, Pb = *reinterpret_cast<const d2 *>(ggP + 2 * (size_t)mcur + dz);
             double Gmax = 0.0, Gnorm1 = 0.0, Gmax_old = 1e300, omt = -1e300;
+            int stop_at = -1;
             for (int T = 0;; T++) {
                 GG_BARRIER();
                 if (T == stop_at) break;
                 const int mn2 = ggOrd[(k2 & 1) * SL + p2];
-                if (T > 0) {   // visit T - 1 (slot mprev, parameters Pa)
-                    const double G = ggZG[2 * ((T - 1) & 1) + 1 + dz];
+                {   // visit T - 1 (slot mprev, parameters Pa; at T = 0 a slot with 1 / H = 0 and G = 0: nothing)
+                    const double G = ggZG[2 * ((T + 1) & 1) + 1 + dz];
                     const double Hi = Pa[0], wp = Pa[1], aG = fabs(G);
                     const bool live = Hi != 0.0, zero = wp == 0.0;
                     const bool shrink = live && zero && aG < omt;   // out of the sweeps until the whole set is taken up again
@@ -821,7 +833,9 @@ __global__ __launch_bounds__(WMREG > 0 ? SV_COOP_THREADS : SV_THREADS) void logr
                     Gnorm1 += viol;
                     nshrunk += shrink ? 1 : 0;
                     if (lane == 0 && shrink) ggP[2 * (size_t)mprev] = 0.0;
-                    if (pos == 0) {   // that was the last visit of sweep k - 1: liblinear's rule
+                }
+                if (__builtin_expect(p2 == 2, 0)) {   // visit T is the first of sweep k2
+                    if (T > 0) {   // so T - 1 was the last of a sweep: liblinear's rule
                         sweeps++;
                         bool stop = sweeps >= 1000;
                         const double gmax = psk_readlane_f64(Gmax, 0);
@@ -838,18 +852,15 @@ __global__ __launch_bounds__(WMREG > 0 ? SV_COOP_THREADS : SV_THREADS) void logr
                         Gmax = 0.0;
                         Gnorm1 = 0.0;
                         if (stop && stop_at < 0) {
-                            stop_at = (T + 1 + DEPTH) & ~(DEPTH - 1);   // >= T + 2: every wave reads it behind a later barrier
+                            stop_at = __builtin_amdgcn_readfirstlane((T + 1 + DEPTH) & ~(DEPTH - 1));   // >= T + 2: every wave reads it behind a later barrier
                             if (lane == 0) { s_gg.stop_at = stop_at; s_gg.iters = sweeps; }
                         }
                     }
-                }
-                const d2 Pc = *reinterpret_cast<const d2 *>(ggP + 2 * (size_t)mn1 + dz);   // of visit T + 1, before its step (and after a return of the shrunk slots)
-                if (pos == 0) {
-                    // the next sweep's order, whole, at the first visit of this one (a few thousand cycles, once per sweep): the
-                    // slots sorted by a random 11-bit key -- histogram, offsets, scatter through LDS counters in the place of the
-                    // build's tables; equal keys keep the counters' order.  (A Fisher-Yates step per visit, r03's first version,
-                    // is two dependent LDS round trips: ~130 cycles of a wave that now has the visit's bookkeeping to do.)
-                    uint16_t *on = ggOrd + ((k + 1) & 1) * SL;
+                    // the next sweep's order, whole (a few thousand cycles, once per sweep): the slots sorted by a random 11-bit
+                    // key -- histogram, offsets, scatter through LDS counters in the place of the build's tables; equal keys keep
+                    // the counters' order.  (A Fisher-Yates step per visit, r03's first version, is two dependent LDS round
+                    // trips: ~130 cycles of a wave that now has the visit's bookkeeping to do.)
+                    uint16_t *on = ggOrd + ((k2 + 1) & 1) * SL;
                     uint32_t *bins = reinterpret_cast<uint32_t *>(ggT1);   // 2048 counters
                     r32 ^= r32 << 13; r32 ^= r32 >> 17; r32 ^= r32 << 5;
                     const uint32_t seed = (uint32_t)__builtin_amdgcn_readfirstlane((int)r32);
@@ -879,16 +890,16 @@ __global__ __launch_bounds__(WMREG > 0 ? SV_COOP_THREADS : SV_THREADS) void logr
                     // previous visit writes its own)
                     if (lane == 0) {
                         const uint16_t f0 = on[0], f1 = on[1];
-                        if (f0 == ggOrd[(k & 1) * SL + A - 1]) { on[0] = f1; on[1] = f0; }
+                        if (f0 == ggOrd[(k2 & 1) * SL + A - 1]) { on[0] = f1; on[1] = f0; }
                     }
                 }
-                if (++pos == A) { pos = 0; k++; }
+                const d2 Pc = *reinterpret_cast<const d2 *>(ggP + 2 * (size_t)mn1 + dz);   // of visit T + 1, before its step (and after a return of the shrunk slots)
                 if (++p2 == A) { p2 = 0; k2++; }
                 mprev = mcur; mcur = mn1; mn1 = mn2;
                 Pa = Pb; Pb = Pc;
             }
             rng = r32;
-            if (lane == 0) { s_gg.last_A = A; s_gg.par = k & 1; if (stop_at < 0) s_gg.iters = sweeps; }
+            if (lane == 0) { s_gg.last_A = A; s_gg.par = (p2 >= 2 ? k2 : k2 - 1) & 1; }   // the order of the sweep under way: complete
         } else {
             // ---- the steps.  G of the visit's slot = what its owner left (g two steps ago and the two entries of Q) plus the
             // two steps since; the slot's 1 / H and w, requested a visit ahead; the soft-threshold form of liblinear's step:
@@ -913,16 +924,10 @@ __global__ __launch_bounds__(WMREG > 0 ? SV_COOP_THREADS : SV_THREADS) void logr
             int m = __builtin_amdgcn_readlane(ordv, 0), m1 = __builtin_amdgcn_readlane(ordv, 1);
             d2 P = *reinterpret_cast<const d2 *>(ggP + 2 * (size_t)m + dz);
             if (lane == 0) *reinterpret_cast<d2 *>(ggPub) = d2{Gr[ggFeat[m]], 0.0};   // visit 0: G = g[m] itself (no step before it)
-            for (int T = 0;; T++) {
-#ifdef PSK_SV_STATS
-                const long long stat_w0 = clock64();
-#endif
-                GG_BARRIER();
-#ifdef PSK_SV_STATS
-                stat_t_polish += clock64() - stat_w0;   // (this form has no accelerator: the field reports wave 0's waits at the barrier)
-#endif
-                if ((T & (DEPTH - 1)) == 0 && T == __builtin_amdgcn_readfirstlane(s_gg.stop_at)) break;
-                const d2 pubd = *reinterpret_cast<const d2 *>(ggPub + 2 * (T & 1) + dz);   // g[m] two steps ago | Q[m][m''], Q[m][m'] (two floats)
+            // (a round of DEPTH visits per pass of the loop, like the owners: the end of the descent is looked for once per
+            // round, and the parity of a visit is a constant)
+            auto visit = [&](int par) __attribute__((always_inline)) {
+                const d2 pubd = *reinterpret_cast<const d2 *>(ggPub + 2 * par + dz);   // g[m] two steps ago | Q[m][m''], Q[m][m'] (two floats)
                 const d2 P1n = *reinterpret_cast<const d2 *>(ggP + 2 * (size_t)m1 + dz);   // for the next visit (never this visit's slot: see wave 3)
                 const double Hi = P[0], wp = P[1];
                 const double G = fma(zprev, (double)__int_as_float(__double2hiint(pubd[1])), fma(zprev2, (double)__int_as_float(__double2loint(pubd[1])), pubd[0]));
@@ -930,7 +935,7 @@ __global__ __launch_bounds__(WMREG > 0 ? SV_COOP_THREADS : SV_THREADS) void logr
                 const double wnew = u - vmin(vmax(u, -Hi), Hi);
                 const double z = vmin(vmax(wnew - wp, -10.0), 10.0);
                 if (lane == 0) {
-                    *reinterpret_cast<d2 *>(ggZG + 2 * (T & 1)) = d2{z, G};
+                    *reinterpret_cast<d2 *>(ggZG + 2 * par) = d2{z, G};
                     ggP[2 * (size_t)m + 1] = wp + z;
                 }
                 zprev2 = zprev;
@@ -945,11 +950,24 @@ __global__ __launch_bounds__(WMREG > 0 ? SV_COOP_THREADS : SV_THREADS) void logr
                     wend = min(64, A - wp0);
                     ordv = ggOrd[(wk & 1) * SL + min(wp0 + lane, A - 1)];
                 }
+            };
+            for (int T = 0;; T += DEPTH) {
+#pragma unroll
+                for (int u = 0; u < DEPTH; u++) {
+                    GG_BARRIER();
+                    if (u == 0 && T == __builtin_amdgcn_readfirstlane(s_gg.stop_at)) goto steps_done;
+                    visit(u & 1);
+                }
             }
+        steps_done:;
             // back to the feature arrays; x.d = X_A d for the line search is the caller's
             for (int u = lane; u < A; u += 64) wpd[ggFeat[u]] = ggP[2 * (size_t)u + 1];
         }
 #undef GG_BARRIER
+#ifdef PSK_SV_STATS
+        if (lane == 0) atomicAdd(reinterpret_cast<unsigned long long *>(&s_stat_wait[wave]), (unsigned long long)stat_bw);
+        if (wave == 0) stat_t_polish += stat_bw;   // (this form has no accelerator: the field reports wave 0's waits at the barrier)
+#endif
         __syncthreads();
         iter_c = s_gg.iters;
         return iter_c;
@@ -1530,6 +1548,8 @@ __global__ __launch_bounds__(WMREG > 0 ? SV_COOP_THREADS : SV_THREADS) void logr
         __syncthreads();
     }
 #ifdef PSK_SV_STATS
+    if (lane == 0 && SL > 0)
+        printf("fit %d waits at the descent's barrier: wave0 %lld wave1 %lld wave2 %lld wave3 %lld\n", fit, s_stat_wait[0], s_stat_wait[1], s_stat_wait[2], s_stat_wait[3]);
     if (lane == 0)
         printf("fit %d C %g newton %d sweeps %lld visits<= %lld cd_cycles %lld total_cycles %lld gram_cycles %lld gram_sweeps %lld builds %lld build_cycles %lld polish_cycles %lld\n",
                fit, C, newton, stat_sweeps, stat_visits, stat_t_cd, (long long)(clock64() - stat_start), stat_t_gram, stat_gram_sweeps, stat_builds,
