@@ -822,6 +822,7 @@ __global__ __launch_bounds__(WMREG > 0 ? SV_COOP_THREADS : SV_THREADS) void logr
                 GG_BARRIER();
                 if (T == stop_at) break;
                 const int mn2 = ggOrd[(k2 & 1) * SL + p2];
+                d2 Pc = *reinterpret_cast<const d2 *>(ggP + 2 * (size_t)mn1 + dz);   // of visit T + 1, before its step
                 {   // visit T - 1 (slot mprev, parameters Pa; at T = 0 a slot with 1 / H = 0 and G = 0: nothing)
                     const double G = ggZG[2 * ((T + 1) & 1) + 1 + dz];
                     const double Hi = Pa[0], wp = Pa[1], aG = fabs(G);
@@ -846,6 +847,7 @@ __global__ __launch_bounds__(WMREG > 0 ? SV_COOP_THREADS : SV_THREADS) void logr
                                 Gmax_old = 1e300;
                                 for (int u2 = lane; u2 < A; u2 += 64) ggP[2 * (size_t)u2] = 1.0 / ggH[u2];
                                 if (Pb[0] == 0.0) Pb[0] = 1.0 / ggH[mcur];   // (the copies held for the next two visits)
+                                if (Pc[0] == 0.0) Pc[0] = 1.0 / ggH[mn1];
                             }
                         } else Gmax_old = gmax;
                         omt = 1.0 - Gmax_old / l_c;
@@ -893,7 +895,6 @@ __global__ __launch_bounds__(WMREG > 0 ? SV_COOP_THREADS : SV_THREADS) void logr
                         if (f0 == ggOrd[(k2 & 1) * SL + A - 1]) { on[0] = f1; on[1] = f0; }
                     }
                 }
-                const d2 Pc = *reinterpret_cast<const d2 *>(ggP + 2 * (size_t)mn1 + dz);   // of visit T + 1, before its step (and after a return of the shrunk slots)
                 if (++p2 == A) { p2 = 0; k2++; }
                 mprev = mcur; mcur = mn1; mn1 = mn2;
                 Pa = Pb; Pb = Pc;
@@ -1854,11 +1855,7 @@ extern "C" int psk_logreg_l1_fit(psk_ctx *ctx, const float *X, const int32_t *y0
         const int P1 = p + 1, wmreg_h = getenv("PSK_NO_CD_REGS") ? 0 : (W <= 16 ? 16 : W <= 32 ? 32 : 64);
         int gg_sl = 0;
         size_t gg_stride = 0, gg_lds = 0;
-        // (up to 2,048 samples: the instance of the kernel for 33 ... 64 sample words faults in this form when the arrays are
-        // not all in LDS -- <false, 64>, 456 registers, r03; <true, 64>, <false, 32> and <false, 16> are fine -- and was not
-        // tracked down; PSK_GRAM_GLOBAL_64=1 enables it for that search.  Those fits keep the array form.)
-        if (P1 > 192 && P1 <= 1024 && wmreg_h > 0 && (wmreg_h < 64 || getenv("PSK_GRAM_GLOBAL_64")) && SV_COOP_WAVES == 4 &&
-            !getenv("PSK_NO_GRAM") && !getenv("PSK_NO_GRAM_GLOBAL")) {
+        if (P1 > 192 && P1 <= 1024 && wmreg_h > 0 && SV_COOP_WAVES == 4 && !getenv("PSK_NO_GRAM") && !getenv("PSK_NO_GRAM_GLOBAL")) {
             const size_t sl = 256 * (((size_t)P1 + 255) / 256), np_h = (size_t)W * 64;
             const size_t need = (4 * sl + np_h + sl / 2 + sl / 4 + sl / 8) * 8 + 8192, stride = (((size_t)P1 + 15) / 16 * 16) * sl;
             if (fa + need <= lds_max && (size_t)n_fits * stride * 4 <= ((size_t)32 << 30)) { gg_sl = (int)sl; gg_stride = stride; gg_lds = need; }

@@ -146,7 +146,7 @@ elif what == "solver":
                 ts.append(round(time.time() - t0, 4))
             out["notes"][tag] = {"X": list(X.shape), "fits": int(len(z["fit_param"])), "wall_s": ts}
         # the grid of a 2048-genome run whose 1000 selected k-mers have 907 distinct patterns (register form of the descent)
-        d = np.load(os.path.join(ROOT, "tools", "data", "fit2048_907.npz"))
+        d = np.load(os.path.join(ROOT, "tests", "golden", "fit2048_907.npz"))
         X = np.unpackbits(d["Xbits"], axis=1)[:, : int(d["p"])].astype(np.float32)
         t0 = time.time()
         ctx.logreg_l1_fit(X, d["y"], d["fold"], d["fit_param"], d["fit_fold"], float(d["tol"]), int(d["max_iter"]))
@@ -192,7 +192,7 @@ elif what == "weights":
         alg["mash_pairs_kernel"] = n * (n + 1) // 2 * 2 * 8 * 1000      # two sketches of 1,000 hashes per pair (L2-resident: a latency bound, not HBM)
         alg["nj_kernel"] = sum(m * m // 2 * 8 for m in range(3, n + 1))   # the lower triangle once per join (L2-resident)
 elif what == "lasso":
-    d = np.load(os.path.join(ROOT, "tools", "data", "fit2048_907.npz"))
+    d = np.load(os.path.join(ROOT, "tests", "golden", "fit2048_907.npz"))
     X = np.unpackbits(d["Xbits"], axis=1)[:1024, : int(d["p"])].astype(np.float32)
     rng = np.random.default_rng(5)
     y = 2.0 * X[:, 3] - 1.5 * X[:, 40] + rng.normal(0, 0.5, 1024)

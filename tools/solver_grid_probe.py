@@ -1,5 +1,5 @@
 #!/usr/bin/env python3
-"""The L1-logistic grid of a 2,048-genome run whose 1,000 selected k-mers have 907 distinct patterns (tools/data/fit2048_907.npz:
+"""The L1-logistic grid of a 2,048-genome run whose 1,000 selected k-mers have 907 distinct patterns (tests/golden/fit2048_907.npz:
 143 fits, the register form of the descent): wall-clock, Newton steps, and the objective every fit reached -- with the
 library as built, and -- for A/B runs of an experimental descent -- with the variable named by PSK_PROBE_OFF_VAR set to 1.
 usage: tools/solver_grid_probe.py [new|old|both]"""
@@ -14,7 +14,7 @@ sys.path.insert(0, ROOT)
 from phenotypeseeker_amd.engine import PskContext  # noqa: E402
 
 mode = sys.argv[1] if len(sys.argv) > 1 else "new"
-d = np.load(os.path.join(ROOT, "tools", "data", "fit2048_907.npz"))
+d = np.load(os.path.join(ROOT, "tests", "golden", "fit2048_907.npz"))
 X = np.unpackbits(d["Xbits"], axis=1)[:, : int(d["p"])].astype(np.float32)
 y, fold, fp, ff = d["y"], d["fold"], d["fit_param"], d["fit_fold"]
 ypm = 2.0 * y - 1.0
