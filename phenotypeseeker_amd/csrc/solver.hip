@@ -547,22 +547,27 @@ __global__ __launch_bounds__(WMREG > 0 ? SV_COOP_THREADS : SV_THREADS) void logr
     // ---- covariance form beyond the LDS Gram block ("gg": Gram matrix in global memory) ---------------------------------
     // More than 192 active coordinates: the array form pays a reduction over the samples per coordinate visit (~1,870
     // cycles on four waves at 2,048 samples; a 2,048 x 907 grid spent 3.3 s in its slowest fit, 98 % of it there).  Here
-    // Q = X_A' D X_A is built ONCE per Newton step -- a real GEMM over 0/1 columns, on the matrix cores (the column bits
-    // become 1.0 / D_i operands in registers, upper triangle of 16 x 64 blocks, mirrored on the way out) -- and kept in
-    // global memory as f32 (slot-major: column m = SL floats; 3.7 MB for 907 coordinates; the gradient vector g = Gr + Q d
-    // it updates stays f64).  A visit is then one column of Q, the scalar step z, and g += z Q[:, m].  A lone wave issues
-    // one instruction per four cycles, whatever its kind, so the visit is divided by INSTRUCTION COUNT over the fit's
-    // four waves, in lockstep (one barrier per visit, nothing is polled):
-    //   wave 0    the scalar side: G = g[m], liblinear's shrinking test, the step, the stopping rule (~70 instructions);
-    //   waves 1,2 own g -- slots 256 r + 4 lane + c, r in {0, 1} and {2, 3}, eight doubles per lane -- AND fetch the
-    //             columns: the visiting order of a sweep is known in advance, so each keeps DEPTH visits' columns (its
-    //             rows of them) in registers and loads the next DEPTH in one burst per round (an HBM round trip is ~8
-    //             visits long); a column never passes through LDS.  During visit T they apply z of visit T - 1 and publish
-    //             g[m'] and Q[m'][m] for the NEXT slot m' (s_set_gpr_idx + v_readlane), from which wave 0 completes
-    //             G = g[m'] + z Q[m'][m] itself: the step of a visit and the update it causes overlap;
-    //   wave 3    draws the next sweep's random order (Fisher-Yates, three steps per visit) while the current one runs.
-    // Same rule as liblinear for shrinking and stopping; a shrunk coordinate keeps its place in the order and is skipped
-    // (flag), so the order of a sweep never changes under the loaders' feet.  No CG accelerator in this form.
+    // Q = X_A' D X_A is built ONCE per Newton step -- a real GEMM over 0/1 columns, on the bf16 matrix cores (32 samples per
+    // product: a byte of a column's bit word becomes eight 1.0 / 0 through a table, D is the sum of two bf16 parts under the
+    // other column's byte as a mask; f32 sums; upper triangle of 16 x 64 blocks, mirrored on the way out; ~5 M cycles at
+    // 907 coordinates) -- and kept in global memory as f32 (slot-major: column m = SL floats, 3.7 MB for 907 coordinates;
+    // the gradient vector g = Gr + Q d it updates stays f64).  A visit is then one column of Q, the step z, and
+    // g += z Q[:, m].  What a visit costs is INSTRUCTIONS: a lone wave issues one every 5.5 cycles at best, 8 when it
+    // depends on the one before, and pays 30 to 60 cycles for every branch it takes or v_cmp it branches on
+    // (tools/_variants/ubench.hip, r03).  So the visit is divided over the fit's four waves, in lockstep -- one barrier per
+    // visit, nothing is polled -- and written without branches on the common path:
+    //   wave 0    the steps: G of the slot, the soft-threshold step, the new coefficient (~40 instructions);
+    //   waves 1,2 own g -- slots 256 r + 4 lane + c, r in {0, 1} and {2, 3}, eight doubles per lane -- AND fetch the columns:
+    //             the visiting order of a sweep is known in advance, so each keeps DEPTH visits' columns (its rows of them)
+    //             in registers and loads the next DEPTH in one burst per round; a column never passes through LDS.  During
+    //             visit T they publish, for the NEXT visit's slot m', g[m'] as it is (two steps behind) with Q[m'][m''] and
+    //             Q[m'][m] (s_set_gpr_idx + v_readlane), then apply the step of visit T - 1; wave 0 completes
+    //             G = g[m'] + z'' Q[m'][m''] + z Q[m'][m] itself: a step and the update it causes overlap;
+    //   wave 3    liblinear's books, one visit behind: violations, the shrinking test, the stopping rule after a sweep's last
+    //             visit; and the next sweep's random order, drawn whole at the sweep's first visit.
+    // Same rule as liblinear for shrinking and stopping; a shrunk coordinate keeps its place in the order with 1 / H = 0 in
+    // its place (its step is then exactly 0), so the order of a sweep never changes under the owners' feet.  No CG
+    // accelerator in this form.  2,048 x 907 grid: 3.3 s -> 0.91 s (tests/golden/fit2048_907.npz).
     struct GgShared { int stop_at, last_A, par, iters; };
     __shared__ GgShared s_gg;
 #ifdef PSK_SV_STATS
@@ -576,7 +581,7 @@ __global__ __launch_bounds__(WMREG > 0 ? SV_COOP_THREADS : SV_THREADS) void logr
     uint16_t *ggDs = reinterpret_cast<uint16_t *>(Qm + 4 * (size_t)SL);   // D of the training samples as two bf16 parts [2][NP]
     uint16_t *ggOrd = reinterpret_cast<uint16_t *>(Qm + 4 * (size_t)SL + NP);
     uint16_t *ggFeat = ggOrd + 2 * (size_t)SL;
-    double *ggPub = reinterpret_cast<double *>(ggFeat + SL);   // [2][2]: g[m'], Q[m'][m] for the visit of that parity; then z [2]
+    double *ggPub = reinterpret_cast<double *>(ggFeat + SL);   // [2]: g[m'] | Q[m'][m''], Q[m'][m] (two floats) for the visit of that parity
     double *ggZG = ggPub + 4;                                  // [2][2]: the step and G of the visit of that parity
     typedef uint32_t u4 __attribute__((ext_vector_type(4)));
     u4 *ggT1 = reinterpret_cast<u4 *>(reinterpret_cast<uint8_t *>(ggFeat + SL) + SL), *ggT2 = ggT1 + 256;   // byte -> eight bf16 ones / masks
@@ -590,15 +595,13 @@ __global__ __launch_bounds__(WMREG > 0 ? SV_COOP_THREADS : SV_THREADS) void logr
         typedef float f8 __attribute__((ext_vector_type(8)));
         typedef __bf16 bf8 __attribute__((ext_vector_type(8)));
         typedef double d2 __attribute__((ext_vector_type(2)));
-        typedef double d4 __attribute__((ext_vector_type(4)));
         typedef double d8 __attribute__((ext_vector_type(8)));
         const int A = s_cd.active, tid = threadIdx.x;
-        const int NR = (A + 255) >> 8;   // 256-slot groups in use
         const double inner_eps_c = s_cd.inner_eps, Gnorm1_init_c = s_cd.Gnorm1_init, l_c = s_cd.l;
 #ifdef PSK_SV_STATS
         const long long stat_gg0 = clock64();
 #endif
-        {   // slot arrays, the first sweep's order, D of the training samples in the operand order of the build
+        {   // slot arrays, the first sweep's order, D of the training samples, the build's tables
             const bool keep = (A == s_gg.last_A);
             const int par = s_gg.par;
             for (int u = tid; u < SL; u += SV_COOP_THREADS) {
@@ -707,8 +710,6 @@ __global__ __launch_bounds__(WMREG > 0 ? SV_COOP_THREADS : SV_THREADS) void logr
 #ifdef PSK_SV_STATS
         if (wave == 0) stat_t_build += clock64() - stat_gg0;
 #endif
-        const f4 *Q4 = reinterpret_cast<const f4 *>(Qg);
-        const int SL4 = SL >> 2;
         int iter_c = 0;
 #ifdef PSK_SV_STATS
         long long stat_bw = 0;   // this wave's cycles at the barrier of the descent (-> s_stat_wait, printed with the fit's statistics)
@@ -722,13 +723,13 @@ __global__ __launch_bounds__(WMREG > 0 ? SV_COOP_THREADS : SV_THREADS) void logr
         if (wave == 1 || wave == 2) {
             // ---- owners of g and of the columns.  Ticket T = the T-th visit of this descent = (sweep T / A, position T % A).
             // Two register sets of DEPTH tickets: `a` is complete and used one ticket per visit, `b` is loaded in ONE burst
-            // at the top of a round of DEPTH visits and becomes `a` at its end, so a column is 16 to 31 visits old when it
-            // is due; the only place that waits for memory is the copy, where the loads are a whole round old.  (A rotating
+            // at the top of a round of DEPTH visits and becomes `a` at its end, so a column is DEPTH to 2 DEPTH - 1 visits old when
+            // it is due; the only place that waits for memory is the copy, where the loads are a whole round old.  (A rotating
             // single set, one load issued per visit, is what one would write; the compiler's count of loads in flight does
             // not survive the loop it makes of it -- rotated, exits merged -- and it drained the queue, vmcnt(0), every
             // visit.  For the same reason both groups are always loaded -- clamped to the last group of the slot arrays,
-            // a duplicate at worst -- and the descent ends at a ticket that is a multiple of DEPTH, wave 0 idling up to
-            // DEPTH - 1 visits, so that this loop's only exit is at the top of a round.)
+            // a duplicate at worst -- and the descent ends at a ticket that is a multiple of DEPTH (a few more steps on the
+            // same model), so that this loop's only exit is at the top of a round.)
             const int h = __builtin_amdgcn_readfirstlane(wave) - 1, rmax = (SL >> 8) - 1;
             const int r0 = min(2 * h, rmax), r1 = min(2 * h + 1, rmax);
             d8 go;   // g of the slots 256 (2 h + (e >> 2)) + 4 lane + (e & 3)
