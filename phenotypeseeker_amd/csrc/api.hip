@@ -18,7 +18,8 @@ int psk_fail(psk_ctx *ctx, int code, const char *fmt, ...)
 int dev_reserve(psk_ctx *ctx, DevBuf &b, size_t bytes)
 {
     if (bytes <= b.cap && b.p) return PSK_OK;
-    if (b.p) { (void)hipFree(b.p); b.p = nullptr; b.cap = 0; }
+    if (b.p && !b.borrowed) (void)hipFree(b.p);
+    b.p = nullptr; b.cap = 0; b.borrowed = false;
     size_t want = bytes + bytes / 8 + 256;  // slack so that slowly growing samples do not realloc each time
     hipError_t e = hipMalloc(&b.p, want);
     if (e != hipSuccess) {
@@ -36,9 +37,10 @@ int dev_reserve(psk_ctx *ctx, DevBuf &b, size_t bytes)
 
 void dev_release(DevBuf &b)
 {
-    if (b.p) (void)hipFree(b.p);
+    if (b.p && !b.borrowed) (void)hipFree(b.p);
     b.p = nullptr;
     b.cap = 0;
+    b.borrowed = false;
 }
 
 int arena_alloc(psk_ctx *ctx, size_t bytes, void **out)
@@ -127,7 +129,8 @@ extern "C" void psk_free(psk_ctx *ctx)
         DevBuf *lb[] = {&L.raw, &L.keysA, &L.keysB, &L.starts, &L.cnt, &L.sk_cand, &L.sk_out,
                         &L.dc_part, &L.dc_wgoff, &L.dc_cnt, &L.dc_meta, &L.dc_mtemp, &L.rawin, &L.fr_scratch};
         for (DevBuf *b : lb) dev_release(*b);
-        if (L.pinned_cnt) (void)hipHostFree(L.pinned_cnt);
+        if (L.pinned_cnt && !(ctx->lane_pinned && L.pinned_cnt >= ctx->lane_pinned && L.pinned_cnt < ctx->lane_pinned + 16 * psk_ctx::LANES))
+            (void)hipHostFree(L.pinned_cnt);
         if (L.sk_host) (void)hipHostFree(L.sk_host);
         if (L.sk_done) (void)hipEventDestroy(L.sk_done);
         if (L.sk_filtered) (void)hipEventDestroy(L.sk_filtered);
@@ -136,6 +139,8 @@ extern "C" void psk_free(psk_ctx *ctx)
         if (L.raw_free) (void)hipEventDestroy(L.raw_free);
         if (L.up_done) (void)hipEventDestroy(L.up_done);
     }
+    dev_release(ctx->lane_slab);
+    if (ctx->lane_pinned) (void)hipHostFree(ctx->lane_pinned);
     if (ctx->copy_stream) (void)hipStreamDestroy(ctx->copy_stream);
     if (ctx->frame_stream) { (void)hipStreamSynchronize(ctx->frame_stream); (void)hipStreamDestroy(ctx->frame_stream); }
     if (ctx->sketch_stream) { (void)hipStreamSynchronize(ctx->sketch_stream); (void)hipStreamDestroy(ctx->sketch_stream); }

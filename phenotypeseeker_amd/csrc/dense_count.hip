@@ -35,15 +35,42 @@ __device__ __forceinline__ uint32_t block_scan512(uint32_t v, uint32_t *total, u
     return psk_block_excl_scan_u32<DT_THREADS>(v, total, lds);
 }
 
+// ---- a group of samples per launch (dense_group_enqueue) ---------------------------------------------------------------
+// One 5-Mbp genome is 306 tiles: barely more than one workgroup per CU, so each of its launches lasts as long as ONE tile
+// (15 to 21 us) plus its ramp, whatever the GPU could do beside it, and the two single-workgroup kernels are pure launch
+// floor -- 62 us of kernels per genome at 1 TB/s (r02).  The kernels below are the same bodies with a sample dimension:
+// the tile kernels find their sample from the first tile of each (at most DC_GROUP entries in the kernel arguments), the
+// per-bucket kernels take it from blockIdx.y.
+constexpr int DC_GROUP = 8;
+struct DcItem {
+    const uint8_t *clean;
+    uint64_t len;
+    uint32_t *cnt, *wgoff, *base;
+    uint16_t *part;
+    uint64_t *bitmap;
+    uint32_t *mt_w, *mt_f, *uniq, *multi, *need, *totals, *host_totals, *dst_w, *dst_f;
+    uint32_t tile0;   // first tile of the sample in the group's grid
+};
+struct DcBatch {
+    uint32_t n, lo, hi, b0, nb;
+    DcItem it[DC_GROUP];
+};
+__device__ __forceinline__ uint32_t dc_batch_sample(const DcBatch &p, uint32_t tile)
+{
+    uint32_t s = 0;
+#pragma unroll
+    for (int q = 1; q < DC_GROUP; q++) s += (q < (int)p.n && tile >= p.it[q].tile0) ? 1u : 0u;
+    return s;
+}
+
 template <int K>
-__global__ __launch_bounds__(DT_THREADS) void dc_hist_kernel(const uint8_t *__restrict__ clean, uint64_t len, uint32_t lo,
-                                                              uint32_t hi, uint32_t b0, uint32_t nb, uint32_t *__restrict__ cnt,
-                                                              uint32_t *__restrict__ wgoff)
+__device__ __forceinline__ void dc_hist_body(const uint8_t *__restrict__ clean, uint64_t len, uint32_t lo, uint32_t hi, uint32_t b0,
+                                             uint32_t nb, uint32_t *__restrict__ cnt, uint32_t *__restrict__ wgoff, const uint32_t tile)
 {
     __shared__ uint32_t h[DC_MAX_NB];
     for (uint32_t d = threadIdx.x; d < nb; d += DT_THREADS) h[d] = 0;
     __syncthreads();
-    const uint64_t s = ((uint64_t)blockIdx.x * DT_THREADS + threadIdx.x) * DT_SEG;
+    const uint64_t s = ((uint64_t)tile * DT_THREADS + threadIdx.x) * DT_SEG;
     Streams st;
     load_streams(st, clean, len, s);
     ForEachWindow<K, 0>::run(st, lo, hi, [&](int, bool ok, uint32_t w) {
@@ -62,15 +89,28 @@ __global__ __launch_bounds__(DT_THREADS) void dc_hist_kernel(const uint8_t *__re
         if (c[e]) o[e] = atomicAdd(&cnt[e * DT_THREADS + threadIdx.x], c[e]);
 #pragma unroll
     for (int e = 0; e < (int)(DC_MAX_NB / DT_THREADS); e++)
-        if (c[e]) wgoff[(uint64_t)blockIdx.x * nb + e * DT_THREADS + threadIdx.x] = o[e];
+        if (c[e]) wgoff[(uint64_t)tile * nb + e * DT_THREADS + threadIdx.x] = o[e];
+}
+template <int K>
+__global__ __launch_bounds__(DT_THREADS) void dc_hist_kernel(const uint8_t *__restrict__ clean, uint64_t len, uint32_t lo,
+                                                              uint32_t hi, uint32_t b0, uint32_t nb, uint32_t *__restrict__ cnt,
+                                                              uint32_t *__restrict__ wgoff)
+{
+    dc_hist_body<K>(clean, len, lo, hi, b0, nb, cnt, wgoff, blockIdx.x);
+}
+template <int K>
+__global__ __launch_bounds__(DT_THREADS) void dc_hist_batch_kernel(const DcBatch p)
+{
+    const uint32_t s = dc_batch_sample(p, blockIdx.x);
+    const DcItem &it = p.it[s];
+    dc_hist_body<K>(it.clean, it.len, p.lo, p.hi, p.b0, p.nb, it.cnt, it.wgoff, blockIdx.x - it.tile0);
 }
 
 template <int K>
-__global__ __launch_bounds__(DT_THREADS) void dc_partition_kernel(const uint8_t *__restrict__ clean, uint64_t len, uint32_t lo,
-                                                                   uint32_t hi, uint32_t b0, uint32_t nb,
-                                                                   const uint32_t *__restrict__ cnt,
-                                                                   const uint32_t *__restrict__ wgoff,
-                                                                   uint32_t *__restrict__ base_out, uint16_t *__restrict__ part)
+__device__ __forceinline__ void dc_partition_body(const uint8_t *__restrict__ clean, uint64_t len, uint32_t lo, uint32_t hi,
+                                                  uint32_t b0, uint32_t nb, const uint32_t *__restrict__ cnt,
+                                                  const uint32_t *__restrict__ wgoff, uint32_t *__restrict__ base_out,
+                                                  uint16_t *__restrict__ part, const uint32_t tile)
 {
     extern __shared__ uint32_t dyn_lds[];                 // DP_LDS_BYTES
     uint32_t *stage = dyn_lds;                            // 64 KB: (bucket << 15 | value), bucketed
@@ -79,7 +119,7 @@ __global__ __launch_bounds__(DT_THREADS) void dc_partition_kernel(const uint8_t 
     uint32_t *scan_lds = h + DC_MAX_NB + DC_MAX_NB / 2;
     for (uint32_t d = threadIdx.x; d < nb; d += DT_THREADS) h[d] = 0;
     __syncthreads();
-    const uint64_t s = ((uint64_t)blockIdx.x * DT_THREADS + threadIdx.x) * DT_SEG;
+    const uint64_t s = ((uint64_t)tile * DT_THREADS + threadIdx.x) * DT_SEG;
     Streams st;
     load_streams(st, clean, len, s);
     uint32_t wv[DT_SEG];   // word relative to the first bucket, or ~0
@@ -114,8 +154,8 @@ __global__ __launch_bounds__(DT_THREADS) void dc_partition_kernel(const uint8_t 
             const uint32_t d = d0 + e;
             if (d < nb) {
                 lstart[d] = (uint16_t)lex;
-                h[d] = gex + (c4[e] ? wgoff[(uint64_t)blockIdx.x * nb + d] : 0u) - lex;
-                if (blockIdx.x == 0) base_out[d] = gex;
+                h[d] = gex + (c4[e] ? wgoff[(uint64_t)tile * nb + d] : 0u) - lex;
+                if (tile == 0) base_out[d] = gex;
             }
             lex += c4[e];
             gex += g4[e];
@@ -130,6 +170,23 @@ __global__ __launch_bounds__(DT_THREADS) void dc_partition_kernel(const uint8_t 
         const uint32_t e = stage[i];
         part[(size_t)(uint32_t)(h[e >> DC_VB] + i)] = (uint16_t)(e & (DC_VALS - 1));
     }
+}
+
+template <int K>
+__global__ __launch_bounds__(DT_THREADS) void dc_partition_kernel(const uint8_t *__restrict__ clean, uint64_t len, uint32_t lo,
+                                                                   uint32_t hi, uint32_t b0, uint32_t nb,
+                                                                   const uint32_t *__restrict__ cnt,
+                                                                   const uint32_t *__restrict__ wgoff,
+                                                                   uint32_t *__restrict__ base_out, uint16_t *__restrict__ part)
+{
+    dc_partition_body<K>(clean, len, lo, hi, b0, nb, cnt, wgoff, base_out, part, blockIdx.x);
+}
+template <int K>
+__global__ __launch_bounds__(DT_THREADS) void dc_partition_batch_kernel(const DcBatch p)
+{
+    const uint32_t s = dc_batch_sample(p, blockIdx.x);
+    const DcItem &it = p.it[s];
+    dc_partition_body<K>(it.clean, it.len, p.lo, p.hi, p.b0, p.nb, it.cnt, it.wgoff, it.base, it.part, blockIdx.x - it.tile0);
 }
 
 // One workgroup per bucket.  bitmap: this sample's, DC_BUCKET_WORDS u64 per bucket.  mt_w / mt_f: multi-count
@@ -244,18 +301,18 @@ __global__ __launch_bounds__(DT_THREADS) void dc_count_kernel(const uint16_t *__
 constexpr int SP_THREADS = 256;
 constexpr uint32_t SP_MAXDUP = 2048, SP_MAXKEYS = 16384;
 
-__global__ __launch_bounds__(SP_THREADS) void dc_count_sparse_kernel(const uint16_t *__restrict__ part, const uint32_t *__restrict__ cnt,
-                                                                      const uint32_t *__restrict__ base, uint32_t b0,
-                                                                      uint64_t *__restrict__ bitmap, uint32_t *__restrict__ mt_w,
-                                                                      uint32_t *__restrict__ mt_f, uint32_t *__restrict__ uniq_out,
-                                                                      uint32_t *__restrict__ multi_out, uint32_t *__restrict__ need)
+__device__ __forceinline__ void dc_count_sparse_body(const uint16_t *__restrict__ part, const uint32_t *__restrict__ cnt,
+                                                     const uint32_t *__restrict__ base, uint32_t b0, uint64_t *__restrict__ bitmap,
+                                                     uint32_t *__restrict__ mt_w, uint32_t *__restrict__ mt_f,
+                                                     uint32_t *__restrict__ uniq_out, uint32_t *__restrict__ multi_out,
+                                                     uint32_t *__restrict__ need, const uint32_t bucket)
 {
     __shared__ uint32_t seen[DC_VALS / 32], dup[DC_VALS / 32], rankb[DC_VALS / 32];   // 3 x 4 KB
     __shared__ uint32_t dcnt[SP_MAXDUP];     // occurrences beyond the first, by rank of the value among the repeated ones
     __shared__ uint16_t dlist[SP_MAXDUP];    // the repeats themselves
     __shared__ uint32_t scan_lds[SP_THREADS / 64];
     __shared__ uint32_t n_dup;
-    const uint32_t b = blockIdx.x, t = threadIdx.x;
+    const uint32_t b = bucket, t = threadIdx.x;
     const uint32_t n = cnt[b];
     const size_t off = base[b];
     if (n > SP_MAXKEYS) {
@@ -332,14 +389,26 @@ __global__ __launch_bounds__(SP_THREADS) void dc_count_sparse_kernel(const uint1
     }
     if (t == 0) { uniq_out[b] = utot; multi_out[b] = multi_total; need[b] = 0; }
 }
+__global__ __launch_bounds__(SP_THREADS) void dc_count_sparse_kernel(const uint16_t *__restrict__ part, const uint32_t *__restrict__ cnt,
+                                                                      const uint32_t *__restrict__ base, uint32_t b0,
+                                                                      uint64_t *__restrict__ bitmap, uint32_t *__restrict__ mt_w,
+                                                                      uint32_t *__restrict__ mt_f, uint32_t *__restrict__ uniq_out,
+                                                                      uint32_t *__restrict__ multi_out, uint32_t *__restrict__ need)
+{
+    dc_count_sparse_body(part, cnt, base, b0, bitmap, mt_w, mt_f, uniq_out, multi_out, need, blockIdx.x);
+}
+__global__ __launch_bounds__(SP_THREADS) void dc_count_sparse_batch_kernel(const DcBatch p)
+{
+    const DcItem &it = p.it[blockIdx.y];
+    dc_count_sparse_body(it.part, it.cnt, it.base, p.b0, it.bitmap, it.mt_w, it.mt_f, it.uniq, it.multi, it.need, blockIdx.x);
+}
 
 // totals[0] = keys kept, [1] = distinct words, [2] = multi-count entries, [3] = buckets the sparse pass left to the
 // table pass -- also written straight into pinned host
 // memory (`host_totals`), which saves the copy kernel of a 16-byte device-to-host transfer
-__global__ __launch_bounds__(1024) void dc_totals_kernel(const uint32_t *__restrict__ cnt, const uint32_t *__restrict__ uniq,
-                                                         const uint32_t *__restrict__ multi, const uint32_t *__restrict__ need,
-                                                         uint32_t nb, uint32_t *__restrict__ totals,
-                                                         uint32_t *__restrict__ host_totals)
+__device__ __forceinline__ void dc_totals_body(const uint32_t *__restrict__ cnt, const uint32_t *__restrict__ uniq,
+                                               const uint32_t *__restrict__ multi, const uint32_t *__restrict__ need, uint32_t nb,
+                                               uint32_t *__restrict__ totals, uint32_t *__restrict__ host_totals)
 {
     __shared__ uint32_t lds[4][16];
     const uint32_t t = threadIdx.x, lane = t & 63, wid = t >> 6;
@@ -367,13 +436,26 @@ __global__ __launch_bounds__(1024) void dc_totals_kernel(const uint32_t *__restr
     }
 }
 
+__global__ __launch_bounds__(1024) void dc_totals_kernel(const uint32_t *__restrict__ cnt, const uint32_t *__restrict__ uniq,
+                                                         const uint32_t *__restrict__ multi, const uint32_t *__restrict__ need,
+                                                         uint32_t nb, uint32_t *__restrict__ totals,
+                                                         uint32_t *__restrict__ host_totals)
+{
+    dc_totals_body(cnt, uniq, multi, need, nb, totals, host_totals);
+}
+__global__ __launch_bounds__(1024) void dc_totals_batch_kernel(const DcBatch p)
+{
+    const DcItem &it = p.it[blockIdx.x];
+    dc_totals_body(it.cnt, it.uniq, it.multi, it.need, p.nb, it.totals, it.host_totals);
+}
+
 // bucket b's multi-count entries -> their place in the arena block (offset = sum of multi[0 .. b))
-__global__ __launch_bounds__(256) void dc_compact_kernel(const uint32_t *__restrict__ mt_w, const uint32_t *__restrict__ mt_f,
-                                                         const uint32_t *__restrict__ base, const uint32_t *__restrict__ multi,
-                                                         uint32_t *__restrict__ dst_w, uint32_t *__restrict__ dst_f)
+__device__ __forceinline__ void dc_compact_body(const uint32_t *__restrict__ mt_w, const uint32_t *__restrict__ mt_f,
+                                                const uint32_t *__restrict__ base, const uint32_t *__restrict__ multi,
+                                                uint32_t *__restrict__ dst_w, uint32_t *__restrict__ dst_f, const uint32_t bucket)
 {
     __shared__ uint32_t lds[4];
-    const uint32_t b = blockIdx.x, t = threadIdx.x;
+    const uint32_t b = bucket, t = threadIdx.x;
     uint32_t below = 0;
 #pragma unroll
     for (int e = 0; e < (int)(DC_MAX_NB / 256); e++) {
@@ -390,6 +472,17 @@ __global__ __launch_bounds__(256) void dc_compact_kernel(const uint32_t *__restr
         dst_w[dst + i] = mt_w[src + i];
         dst_f[dst + i] = mt_f[src + i];
     }
+}
+__global__ __launch_bounds__(256) void dc_compact_kernel(const uint32_t *__restrict__ mt_w, const uint32_t *__restrict__ mt_f,
+                                                         const uint32_t *__restrict__ base, const uint32_t *__restrict__ multi,
+                                                         uint32_t *__restrict__ dst_w, uint32_t *__restrict__ dst_f)
+{
+    dc_compact_body(mt_w, mt_f, base, multi, dst_w, dst_f, blockIdx.x);
+}
+__global__ __launch_bounds__(256) void dc_compact_batch_kernel(const DcBatch p)
+{
+    const DcItem &it = p.it[blockIdx.y];
+    dc_compact_body(it.mt_w, it.mt_f, it.base, it.multi, it.dst_w, it.dst_f, blockIdx.x);
 }
 
 // ---- dense form -> words[] / freqs[] ---------------------------------------------------------------------------
@@ -591,10 +684,141 @@ int dense_chain_finalize(psk_ctx *ctx, CountLane &L, uint64_t *n_kept, uint64_t 
     if (nm) {
         PSK_TRY(arena_alloc(ctx, nm * 4, (void **)&S.mwords));
         PSK_TRY(arena_alloc(ctx, nm * 4, (void **)&S.mfreqs));
-        dc_compact_kernel<<<ctx->dense_nb, 256, 0, ctx->stream>>>(d.mt_w, d.mt_f, d.base, d.multi, S.mwords, S.mfreqs);
-        PSK_HIP(ctx, hipGetLastError());
+        if (!L.dc_defer_compact) {
+            dc_compact_kernel<<<ctx->dense_nb, 256, 0, ctx->stream>>>(d.mt_w, d.mt_f, d.base, d.multi, S.mwords, S.mfreqs);
+            PSK_HIP(ctx, hipGetLastError());
+        }
     }
     L.dense = false;
+    return PSK_OK;
+}
+
+// ---- a group of samples in one launch chain (psk_count_kmers_batch, genomes at k = 11..13) -------------------------------
+int dense_group_size()
+{
+    static const int g = [] {
+        const char *e = getenv("PSK_DC_GROUP");
+        int v = e ? atoi(e) : DC_GROUP;
+        return v < 1 ? 1 : (v > DC_GROUP ? DC_GROUP : v);
+    }();
+    return g;
+}
+
+void dense_lane_bytes(const psk_ctx *ctx, size_t max_len, size_t out[5])
+{
+    out[0] = max_len * 2 + 64;                                           // dc_part
+    out[1] = (size_t)div_up(max_len, DT_TILE) * ctx->dense_nb * 4;       // dc_wgoff
+    out[2] = (size_t)DC_SLOTS * DC_MAX_NB * 4;                           // dc_cnt
+    out[3] = (size_t)(4 * DC_MAX_NB + 4) * 4;                            // dc_meta
+    out[4] = (max_len / 2 + 2) * 8;                                      // dc_mtemp
+}
+
+// may this sample's chain ride in a group?  (few keys per bucket: the presence-bit pass; read sets take the table pass alone)
+bool dense_group_ok(const psk_ctx *ctx, uint64_t n) { return ctx->dense_mode && n > 0 && n / ctx->dense_nb < 4096 && !getenv("PSK_DC_TABLE"); }
+
+template <int K>
+static int launch_group_tiles(psk_ctx *ctx, const DcBatch &p, uint32_t tiles)
+{
+    static PerDeviceOnce lds_set;
+    if (lds_set.first(ctx->device)) {
+        PSK_HIP(ctx, hipFuncSetAttribute(reinterpret_cast<const void *>(dc_partition_batch_kernel<K>),
+                                         hipFuncAttributeMaxDynamicSharedMemorySize, (int)DP_LDS_BYTES));
+    }
+    dc_hist_batch_kernel<K><<<tiles, DT_THREADS, 0, ctx->stream>>>(p);
+    PSK_HIP(ctx, hipGetLastError());
+    dc_partition_batch_kernel<K><<<tiles, DT_THREADS, DP_LDS_BYTES, ctx->stream>>>(p);
+    PSK_HIP(ctx, hipGetLastError());
+    return PSK_OK;
+}
+
+// The chains of `count` samples (each on its own buffer set, clean stream resident, dense_group_ok) as ONE chain: what
+// dense_chain_enqueue does per sample, with every launch covering the group.  Each set's events fire as for its own chain.
+int dense_group_enqueue(psk_ctx *ctx, CountLane *const *lanes, const int *sample_idx, const uint64_t *clean_len, const uint64_t *n,
+                        int count)
+{
+    if (count < 1 || count > DC_GROUP) return psk_fail(ctx, PSK_EINVAL, "bad group size %d", count);
+    const uint32_t nb = ctx->dense_nb;
+    const uint64_t space = 1ull << (2 * ctx->k);
+    DcBatch p;
+    memset(&p, 0, sizeof(p));
+    p.n = (uint32_t)count;
+    p.lo = (uint32_t)ctx->slab_lo;
+    p.hi = (uint32_t)((ctx->slab_hi && ctx->slab_hi < space) ? ctx->slab_hi : space);
+    p.b0 = ctx->dense_b0;
+    p.nb = nb;
+    uint32_t tiles = 0;
+    for (int s = 0; s < count; s++) {
+        CountLane &L = *lanes[s];
+        SampleList &S = ctx->lists[sample_idx[s]];
+        S.dense = true;
+        PSK_TRY(arena_alloc(ctx, (size_t)nb * DC_BUCKET_WORDS * 8, (void **)&S.bitmap));
+        const uint32_t n_tiles = div_up(clean_len[s], DT_TILE);
+        PSK_TRY(dev_reserve(ctx, L.dc_part, n[s] * 2 + 64));
+        PSK_TRY(dev_reserve(ctx, L.dc_wgoff, (size_t)n_tiles * nb * 4));
+        PSK_TRY(dev_reserve(ctx, L.dc_cnt, (size_t)DC_SLOTS * DC_MAX_NB * 4));
+        PSK_TRY(dev_reserve(ctx, L.dc_meta, (size_t)(4 * DC_MAX_NB + 4) * 4));
+        PSK_TRY(dev_reserve(ctx, L.dc_mtemp, (n[s] / 2 + 2) * 8));
+        if (L.dc_slot == 0 || L.dc_slot >= DC_SLOTS) {
+            PSK_HIP(ctx, hipMemsetAsync(L.dc_cnt.p, 0, (size_t)DC_SLOTS * DC_MAX_NB * 4, ctx->stream));
+            L.dc_slot = 0;
+        }
+        const DcBufs d = dc_bufs(L, L.dc_slot++);
+        DcItem &it = p.it[s];
+        it.clean = L.raw.as<uint8_t>();
+        it.len = clean_len[s];
+        it.cnt = d.cnt; it.wgoff = L.dc_wgoff.as<uint32_t>(); it.base = d.base;
+        it.part = L.dc_part.as<uint16_t>();
+        it.bitmap = S.bitmap;
+        it.mt_w = d.mt_w; it.mt_f = d.mt_f; it.uniq = d.uniq; it.multi = d.multi; it.need = d.need; it.totals = d.totals;
+        it.host_totals = L.pinned_cnt;
+        it.tile0 = tiles;
+        tiles += n_tiles;
+    }
+    switch (ctx->k) {
+    case 11: PSK_TRY(launch_group_tiles<11>(ctx, p, tiles)); break;
+    case 12: PSK_TRY(launch_group_tiles<12>(ctx, p, tiles)); break;
+    case 13: PSK_TRY(launch_group_tiles<13>(ctx, p, tiles)); break;
+    default: return psk_fail(ctx, PSK_ESTATE, "dense counting is built for k = 11..13, not %d", ctx->k);
+    }
+    for (int s = 0; s < count; s++) {
+        PSK_HIP(ctx, hipEventRecord(lanes[s]->raw_free, ctx->stream));
+        lanes[s]->raw_used = true;
+    }
+    dc_count_sparse_batch_kernel<<<dim3(nb, (uint32_t)count), SP_THREADS, 0, ctx->stream>>>(p);
+    PSK_HIP(ctx, hipGetLastError());
+    dc_totals_batch_kernel<<<(uint32_t)count, 1024, 0, ctx->stream>>>(p);
+    PSK_HIP(ctx, hipGetLastError());
+    PSK_HIP(ctx, hipEventRecord(lanes[count - 1]->done, ctx->stream));
+    for (int s = 0; s < count; s++) {
+        if (s + 1 < count) PSK_HIP(ctx, hipEventRecord(lanes[s]->done, ctx->stream));
+        lanes[s]->dense = true;
+        lanes[s]->dc_defer_compact = true;
+    }
+    return PSK_OK;
+}
+
+// after chain_finalize of every set of the group (which sized and allocated the multi-count blocks): ONE compaction launch
+int dense_group_compact(psk_ctx *ctx, CountLane *const *lanes, const int *sample_idx, int count)
+{
+    DcBatch p;
+    memset(&p, 0, sizeof(p));
+    p.nb = ctx->dense_nb;
+    uint32_t m = 0;
+    for (int s = 0; s < count; s++) {
+        CountLane &L = *lanes[s];
+        L.dc_defer_compact = false;
+        const SampleList &S = ctx->lists[sample_idx[s]];
+        if (!S.dense || !S.n_multi) continue;
+        const DcBufs d = dc_bufs(L, L.dc_slot - 1);
+        DcItem &it = p.it[m++];
+        it.mt_w = d.mt_w; it.mt_f = d.mt_f; it.base = d.base; it.multi = d.multi;
+        it.dst_w = S.mwords; it.dst_f = S.mfreqs;
+    }
+    p.n = m;
+    if (m) {
+        dc_compact_batch_kernel<<<dim3(ctx->dense_nb, m), 256, 0, ctx->stream>>>(p);
+        PSK_HIP(ctx, hipGetLastError());
+    }
     return PSK_OK;
 }
 

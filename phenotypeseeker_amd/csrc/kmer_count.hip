@@ -529,8 +529,8 @@ static int lane_prepare(psk_ctx *ctx, CountLane &L)
         PSK_HIP(ctx, hipEventCreateWithFlags(&L.raw_ready, hipEventDisableTiming));
         PSK_HIP(ctx, hipEventCreateWithFlags(&L.raw_free, hipEventDisableTiming));
         PSK_HIP(ctx, hipEventCreateWithFlags(&L.up_done, hipEventDisableTiming));
-        PSK_HIP(ctx, hipHostMalloc(reinterpret_cast<void **>(&L.pinned_cnt), 64, hipHostMallocDefault));
     }
+    if (!L.pinned_cnt) PSK_HIP(ctx, hipHostMalloc(reinterpret_cast<void **>(&L.pinned_cnt), 64, hipHostMallocDefault));
     if (!ctx->copy_stream) PSK_HIP(ctx, hipStreamCreateWithFlags(&ctx->copy_stream, hipStreamNonBlocking));
     if (!ctx->frame_stream) PSK_HIP(ctx, hipStreamCreateWithFlags(&ctx->frame_stream, hipStreamNonBlocking));
     return PSK_OK;
@@ -541,6 +541,61 @@ int frame_gpu_enqueue(psk_ctx *ctx, hipStream_t stream, int format, const uint8_
 size_t frame_gpu_scratch_bytes(uint64_t raw_len);
 int frame_probe(const uint8_t *bytes, size_t len, size_t *start, size_t *end);
 int frame_probe_known_end(const uint8_t *bytes, size_t nul_at, size_t *start, size_t *end);
+
+// A grouped batch rotates 3 G buffer sets of eight device buffers each: carved out of ONE allocation (and one pinned block
+// for the sets' counters) sized for the batch's longest sample, instead of ~170 hipMallocs on a cold context.  Buffers a
+// set already owns and that are large enough stay as they are.  Nothing of an earlier batch is in flight here.
+static int carve_lanes(psk_ctx *ctx, int n_lanes, size_t max_len, bool gpu_framing)
+{
+    size_t dcb[5];
+    dense_lane_bytes(ctx, max_len, dcb);
+    const size_t want[8] = {max_len + 128 + 2 * EX_SEG, gpu_framing ? max_len + 64 : 0, gpu_framing ? frame_gpu_scratch_bytes(max_len) : 0,
+                            dcb[0], dcb[1], dcb[2], dcb[3], dcb[4]};
+    auto bufs_of = [](CountLane &L, DevBuf *out[8]) {
+        out[0] = &L.raw; out[1] = &L.rawin; out[2] = &L.fr_scratch; out[3] = &L.dc_part; out[4] = &L.dc_wgoff; out[5] = &L.dc_cnt;
+        out[6] = &L.dc_meta; out[7] = &L.dc_mtemp;
+    };
+    size_t per_lane = 0;
+    for (size_t w : want) per_lane += (w + w / 8 + 511) & ~size_t(255);
+    const size_t total = per_lane * (size_t)n_lanes;
+    bool need = false;
+    for (int l = 0; l < n_lanes && !need; l++) {
+        DevBuf *b[8];
+        bufs_of(ctx->lane[l], b);
+        for (int q = 0; q < 8; q++) need = need || (want[q] && !(b[q]->p && b[q]->cap >= want[q]));
+    }
+    if (need) {
+        // a new layout: every buffer carved out of the slab so far is forgotten first (the slices of two layouts overlap)
+        for (CountLane &L : ctx->lane) {
+            DevBuf *b[8];
+            bufs_of(L, b);
+            for (int q = 0; q < 8; q++)
+                if (b[q]->borrowed) { b[q]->p = nullptr; b[q]->cap = 0; b[q]->borrowed = false; }
+        }
+        PSK_TRY(dev_reserve(ctx, ctx->lane_slab, total));
+        // carve: set l takes slice l; a buffer that is its set's own and large enough is left alone
+        for (int l = 0; l < n_lanes; l++) {
+            DevBuf *b[8];
+            bufs_of(ctx->lane[l], b);
+            size_t off = per_lane * (size_t)l;
+            for (int q = 0; q < 8; q++) {
+                const size_t sz = (want[q] + want[q] / 8 + 511) & ~size_t(255);
+                if (want[q] && !(b[q]->p && b[q]->cap >= want[q])) {
+                    if (b[q]->p && !b[q]->borrowed) (void)hipFree(b[q]->p);
+                    b[q]->p = static_cast<uint8_t *>(ctx->lane_slab.p) + off;
+                    b[q]->cap = sz;
+                    b[q]->borrowed = true;
+                    if (q == 5) ctx->lane[l].dc_slot = 0;   // a fresh counter ring: zeroed before its first use
+                }
+                off += sz;
+            }
+        }
+    }
+    if (!ctx->lane_pinned) PSK_HIP(ctx, hipHostMalloc(reinterpret_cast<void **>(&ctx->lane_pinned), (size_t)16 * 4 * psk_ctx::LANES, hipHostMallocDefault));
+    for (int l = 0; l < n_lanes; l++)
+        if (!ctx->lane[l].pinned_cnt) ctx->lane[l].pinned_cnt = ctx->lane_pinned + 16 * l;
+    return PSK_OK;
+}
 
 // {clean length, irregular flag} of a sample framed on the GPU land here (pinned, behind the lane's counters)
 static inline uint64_t *lane_frame_result(CountLane &L) { return reinterpret_cast<uint64_t *>(L.pinned_cnt + 8); }
@@ -606,7 +661,14 @@ static int chain_compute(psk_ctx *ctx, CountLane &L, int sample_idx, uint64_t cl
         PSK_TRY(dev_reserve(ctx, L.cnt, (size_t)CountLane::CNT_SLOTS * 16));
     }
     PSK_HIP(ctx, hipStreamWaitEvent(ctx->stream, L.raw_ready, 0));
-    if (ctx->dense_mode) return dense_chain_enqueue(ctx, L, sample_idx, clean_len, n);   // 2k <= 26: no sort (dense_count.hip)
+    if (ctx->dense_mode) {   // 2k <= 26: no sort (dense_count.hip)
+        if (ctx->dense_defer && dense_group_ok(ctx, n)) {   // a genome of a batch: its chain is launched with its group's
+            L.group_pending = true;
+            L.clean_len = clean_len;
+            return PSK_OK;
+        }
+        return dense_chain_enqueue(ctx, L, sample_idx, clean_len, n);
+    }
     if (bucket_route_ok(ctx, n)) return bucket_chain_enqueue(ctx, L, sample_idx, clean_len, n);   // k = 14..16, splitters known
     // every sample takes a fresh pre-zeroed counter slot (a 16-byte memset per sample is a 6 us launch)
     if (L.cnt_slot == 0 || L.cnt_slot >= CountLane::CNT_SLOTS) {
@@ -856,8 +918,13 @@ static int count_batch_impl(psk_ctx *ctx, int first_sample_idx, int n, const uin
     if (n_threads > n) n_threads = n;
     // pinned ring: at most ~4 GiB of it (read-scale FASTQ samples are hundreds of MB each)
     while (n_threads > 1 && (size_t)(n_threads + 4) * max_len > (4ull << 30)) n_threads--;
-    const int R = n < n_threads + 4 ? n : n_threads + 4;  // ring slots: two being uploaded / framed ahead, one whose chain is in
-                                                          // flight, one released late -- never more than there are samples
+    // genomes at k <= 13 (dense counting) go through the counting kernels in groups of G: one launch chain per group
+    const int G = (!consumer && ctx->dense_mode && n > 1 && max_len < (64u << 20)) ? dense_group_size() : 1;
+    const bool grouped = G > 1;
+    const int NL = grouped ? 3 * G : 3;   // buffer sets in rotation
+    const int want_ring = grouped ? G + n_threads + 4 : n_threads + 4;   // (grouped: a slot is released as soon as its upload is over)
+    const int R = n < want_ring ? n : want_ring;  // ring slots: two (groups) being uploaded / framed ahead, one whose chain is in
+                                                  // flight, one released late -- never more than there are samples
     if ((int)ctx->ring.size() < R) { ctx->ring.resize(R, nullptr); ctx->ring_cap.resize(R, 0); }
     for (int s = 0; s < R; s++) PSK_TRY(ensure_pinned(ctx, &ctx->ring[s], &ctx->ring_cap[s], max_len + 2 * EX_SEG));
     // FASTA and four-line FASTQ are framed on the GPU (frame_gpu.hip): the worker threads then only move file bytes
@@ -868,6 +935,7 @@ static int count_batch_impl(psk_ctx *ctx, int first_sample_idx, int n, const uin
     std::condition_variable cv;
     std::vector<int> state(n, 0);          // 0 pending, 1 ready, -1 reading / framing failed
     std::vector<int> fmt(n, 0);            // 0 the ring slot holds a clean stream (host framing); 1 / 2 raw FASTA / FASTQ bytes
+    std::vector<char> pre_up(n, 0);        // (grouped batches) a windowless sample's clean stream is already in its set's buffer
     std::vector<uint64_t> clen(n, 0), plen(n, 0), wins(n, 0), roff(n, 0), rlen(n, 0);
     int consumed = 0;                      // samples whose ring slot may be overwritten
     bool abort = false;
@@ -943,14 +1011,14 @@ static int count_batch_impl(psk_ctx *ctx, int first_sample_idx, int n, const uin
     };
     for (CountLane &L : ctx->lane) { L.sample = -1; L.sk_state = 0; }
     auto collect_sketch = [&](int i) -> int {
-        CountLane &L = ctx->lane[i % 3];
+        CountLane &L = ctx->lane[i % NL];
         if (wins[i] == 0) {
             // no window of the counting k, so nothing was counted -- but the sketch's k may be shorter: take the
             // clean stream (host framing: from the ring slot, still held) through the synchronous route
             n_hashes_out[i] = 0;
             L.sk_state = 0;
             if (clen[i] == 0) return PSK_OK;
-            if (fmt[i] == 0) {
+            if (fmt[i] == 0 && !pre_up[i]) {
                 PSK_TRY(dev_reserve(ctx, L.raw, plen[i]));
                 PSK_HIP(ctx, hipMemcpyAsync(L.raw.p, ctx->ring[i % R], plen[i], hipMemcpyHostToDevice, ctx->stream));
             }
@@ -974,9 +1042,9 @@ static int count_batch_impl(psk_ctx *ctx, int first_sample_idx, int n, const uin
                                 first_sample_idx + i, paths ? paths[i] : "");
         }
         const uint8_t *slot = static_cast<const uint8_t *>(ctx->ring[i % R]);
-        if (fmt[i]) return chain_upload(ctx, ctx->lane[i % 3], slot + roff[i], rlen[i], fmt[i]);
+        if (fmt[i]) return chain_upload(ctx, ctx->lane[i % NL], slot + roff[i], rlen[i], fmt[i]);
         if (wins[i] >= (1ull << 32)) return psk_fail(ctx, PSK_ERANGE, "sample with more than 2^32 windows");
-        return chain_upload(ctx, ctx->lane[i % 3], slot, wins[i] ? plen[i] : 0, 0);
+        return chain_upload(ctx, ctx->lane[i % NL], slot, wins[i] ? plen[i] : 0, 0);
     };
     // stage B: the counting chain, once the length of the clean stream is known on the host
     auto consume = [&](CountLane &L, int i, uint64_t clean_len, uint64_t n_windows, bool exact) -> int {
@@ -984,7 +1052,7 @@ static int count_batch_impl(psk_ctx *ctx, int first_sample_idx, int n, const uin
         return chain_compute(ctx, L, first_sample_idx + i, clean_len, n_windows, exact);
     };
     auto stage_b = [&](int i) -> int {
-        CountLane &L = ctx->lane[i % 3];
+        CountLane &L = ctx->lane[i % NL];
         if (fmt[i] && rlen[i]) {
             const auto t0 = std::chrono::steady_clock::now();
             PSK_HIP(ctx, hipEventSynchronize(L.raw_ready));   // the GPU is busy with the chain of sample i - 1 meanwhile
@@ -1008,6 +1076,78 @@ static int count_batch_impl(psk_ctx *ctx, int first_sample_idx, int n, const uin
         }
         return consume(L, i, clen[i], wins[i], true);
     };
+    if (grouped) rc = carve_lanes(ctx, NL, max_len, gpu_framing);
+    if (rc != PSK_OK) {
+    } else if (grouped) {
+        // Groups of G samples: a group's uploads and framing run two groups ahead on the copy / framing streams; its samples'
+        // host halves (the framed length, the arena blocks) are done one by one, then ONE launch chain counts the group
+        // (dense_group_enqueue); the group before it is finalised meanwhile -- sizes read back, multi-count blocks
+        // allocated, one compaction launch, sketches collected -- which frees its buffer sets for the group after next.
+        ctx->dense_defer = true;
+        int next_a = 0, released = 0;
+        auto pump_a = [&](int upto) { while (rc == PSK_OK && next_a < n && next_a < upto) rc = stage_a(next_a++); };
+        auto finalize_group = [&](int lo, int hi) -> int {
+            CountLane *gl[8];
+            int gs[8], cnt = 0;
+            const auto t0 = std::chrono::steady_clock::now();
+            for (int i = lo; i < hi; i++) {
+                CountLane &L = ctx->lane[i % NL];
+                const bool in_group = L.dc_defer_compact;
+                PSK_TRY(chain_finalize(ctx, L));
+                if (in_group) { gl[cnt] = &L; gs[cnt] = first_sample_idx + i; cnt++; }
+            }
+            if (cnt) PSK_TRY(dense_group_compact(ctx, gl, gs, cnt));
+            t_final += since(t0);
+            for (int i = lo; i < hi; i++) {
+                report(i);
+                if (sketch_k) PSK_TRY(collect_sketch(i));
+            }
+            if (hi > released) { released = hi; release_upto(hi); }
+            return PSK_OK;
+        };
+        pump_a(G);
+        int prev_lo = -1, prev_hi = -1;
+        for (int lo = 0; lo < n && rc == PSK_OK; lo += G) {
+            const int hi = lo + G < n ? lo + G : n;
+            CountLane *gl[8];
+            int gs[8], cnt = 0;
+            uint64_t gc[8], gn[8];
+            for (int i = lo; i < hi && rc == PSK_OK; i++) {
+                rc = stage_b(i);   // a genome's chain stays pending; anything else (an empty sample, a read set) is queued here
+                CountLane &L = ctx->lane[i % NL];
+                // the pinned slot goes back as soon as the upload is over (framed on the GPU: stage B has waited for the
+                // framing; framed on the host: wait for the copy here -- it ran G samples ahead), so the ring needs G + a few
+                // slots, not three groups' worth (a cold context pays ~2 ms per pinned slot).  A sample too short for a
+                // window of the counting k whose sketch will still want its clean stream: uploaded now.
+                if (rc == PSK_OK && !fmt[i] && wins[i] > 0 && hipEventSynchronize(L.raw_ready) != hipSuccess)
+                    rc = psk_fail(ctx, PSK_EHIP, "event wait failed");
+                if (rc == PSK_OK && sketch_k && wins[i] == 0 && fmt[i] == 0 && clen[i]) {
+                    rc = dev_reserve(ctx, L.raw, plen[i]);
+                    if (rc == PSK_OK && (hipMemcpyAsync(L.raw.p, ctx->ring[i % R], plen[i], hipMemcpyHostToDevice, ctx->stream) != hipSuccess ||
+                                         hipStreamSynchronize(ctx->stream) != hipSuccess))
+                        rc = psk_fail(ctx, PSK_EHIP, "upload of a short sample failed");
+                    pre_up[i] = 1;
+                }
+                if (rc == PSK_OK) { released = i + 1; release_upto(released); }
+                // the copy stream is kept G samples ahead (their buffer sets are those of the group before last: finalised)
+                pump_a(i + 1 + G);
+                if (rc == PSK_OK && L.group_pending) {
+                    L.group_pending = false;
+                    gl[cnt] = &L; gs[cnt] = first_sample_idx + i; gc[cnt] = L.clean_len; gn[cnt] = L.n;
+                    cnt++;
+                }
+            }
+            if (rc == PSK_OK && cnt) rc = dense_group_enqueue(ctx, gl, gs, gc, gn, cnt);
+            for (int i = lo; i < hi && rc == PSK_OK; i++)
+                if (sketch_k && wins[i] > 0)
+                    rc = sketch_enqueue(ctx, ctx->lane[i % NL], ctx->lane[i % NL].raw.as<uint8_t>(), clen[i], sketch_k, sketch_size, sketch_seed);
+            if (rc == PSK_OK && prev_lo >= 0) rc = finalize_group(prev_lo, prev_hi);
+            prev_lo = lo; prev_hi = hi;
+        }
+        if (rc == PSK_OK && prev_lo >= 0) rc = finalize_group(prev_lo, prev_hi);
+        ctx->dense_defer = false;
+        for (CountLane &L : ctx->lane) { L.group_pending = false; L.dc_defer_compact = false; }
+    } else {
     // Samples i + 1 and i + 2 are uploaded and framed on the copy stream while chain i runs: the host's wait for the
     // framed length of sample i (stage B) then finds it long done (with one sample ahead the wait sat on the critical
     // path: 200 us per 5-Mbp sample instead of 145).
@@ -1038,6 +1178,7 @@ static int count_batch_impl(psk_ctx *ctx, int first_sample_idx, int n, const uin
         rc = chain_finalize(ctx, ctx->lane[(n - 1) % 3]);
         if (rc == PSK_OK) report(n - 1);
         if (rc == PSK_OK && sketch_k) rc = collect_sketch(n - 1);
+    }
     }
     {   // nothing of this call may still be in flight when it returns (the ring and the caller's buffers)
         const hipError_t e1 = hipStreamSynchronize(ctx->copy_stream ? ctx->copy_stream : ctx->stream);

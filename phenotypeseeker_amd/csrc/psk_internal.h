@@ -16,6 +16,7 @@
 struct DevBuf {
     void *p = nullptr;
     size_t cap = 0;  // bytes
+    bool borrowed = false;  // p points into a slab someone else owns (psk_ctx::lane_slab): never freed through this buffer
     template <class T> T *as() const { return reinterpret_cast<T *>(p); }
 };
 
@@ -73,6 +74,9 @@ struct CountLane {
     DevBuf dc_part, dc_wgoff, dc_cnt, dc_meta, dc_mtemp;
     uint32_t dc_slot = 0;
     bool dense = false;              // the chain in flight on this set is a dense one
+    bool dc_defer_compact = false;   // ... queued as part of a group (dense_group_enqueue): the group compacts in one launch
+    bool group_pending = false;      // chain_compute left this sample's dense chain to its group (clean_len: its clean stream)
+    uint64_t clean_len = 0;
     bool bs = false;                 // ... a bucketed-sort one (bucket_count.hip; it borrows the dc_* buffers)
 };
 
@@ -122,6 +126,7 @@ struct psk_ctx {
     Arena arena;
     // dense list form (see SampleList): on for this run?  first bucket and number of buckets of the slab
     bool dense_mode = false;
+    bool dense_defer = false;        // psk_count_kmers_batch is collecting genomes into launch groups (dense_group_enqueue)
     uint32_t dense_b0 = 0, dense_nb = 0;
     // bucketed sort of k = 14..16 (bucket_count.hip): 2,048 splitters taken from the first list of the run
     DevBuf bs_spl, bs_ct;             // splitters; bucket of the first word of each of 4,096 cells of the run's word range
@@ -138,7 +143,11 @@ struct psk_ctx {
     void *scan_pinned = nullptr;  // pinned staging for the scan's masks / weights
     size_t scan_pinned_cap = 0;
     void *cnt_pinned = nullptr;   // pinned landing buffer of the scan's result counters
-    CountLane lane[3];   // sample i runs on set i % 3: i + 1 and i + 2 are uploaded / framed ahead while chain i runs
+    static constexpr int LANES = 24;
+    DevBuf lane_slab;        // one allocation behind the buffer sets of a grouped batch (a cold run paid 60 ms for 170 hipMallocs)
+    uint32_t *lane_pinned = nullptr;   // ... and one pinned block behind their counters (16 u32 per set)
+    CountLane lane[LANES];   // sample i runs on set i % 3: i + 1 and i + 2 are uploaded / framed ahead while chain i runs; in groups
+                             // of G genomes (dense counting) on set i % (3 G): two groups ahead, one in flight
     hipStream_t copy_stream = nullptr;  // uploads of the batch counter overlap the previous sample's kernels
     hipStream_t frame_stream = nullptr; // the GPU framing of sample i + 1 runs beside upload i + 2 and chain i
     hipStream_t sketch_stream = nullptr;  // the one-workgroup sketch select runs beside the next sample's chain
@@ -231,6 +240,13 @@ void dense_configure(psk_ctx *ctx);        // psk_begin: decides dense_mode / de
 // n = its window count.  dense_chain_finalize (one sample later) places the multi-count entries in the arena.
 int dense_chain_enqueue(psk_ctx *ctx, CountLane &L, int sample_idx, uint64_t clean_len, uint64_t n);
 int dense_chain_finalize(psk_ctx *ctx, CountLane &L, uint64_t *n_kept, uint64_t *n_unique);
+int dense_group_size();   // samples per launch chain (PSK_DC_GROUP, default and at most 8)
+bool dense_group_ok(const psk_ctx *ctx, uint64_t n);
+int dense_group_enqueue(psk_ctx *ctx, CountLane *const *lanes, const int *sample_idx, const uint64_t *clean_len, const uint64_t *n,
+                        int count);
+int dense_group_compact(psk_ctx *ctx, CountLane *const *lanes, const int *sample_idx, int count);
+// bytes of the five dc_* buffers of one buffer set for samples of up to max_len clean bases (dc_part, dc_wgoff, dc_cnt, dc_meta, dc_mtemp)
+void dense_lane_bytes(const psk_ctx *ctx, size_t max_len, size_t out[5]);
 // words[] / freqs[] of samples [first, first + n) from their dense form (no-op for sparse or materialised ones)
 int dense_materialize(psk_ctx *ctx, int first, int n);
 int dense_lookup_counts(psk_ctx *ctx, const SampleList &L, const uint64_t *d_query, uint64_t n, uint32_t *d_out);
