@@ -93,10 +93,35 @@ __device__ __forceinline__ void load_map(uint32_t *spl, uint16_t *ct, const uint
     for (uint32_t d = threadIdx.x; d <= (uint32_t)BS_CELLS; d += threads) ct[d] = ct_g[d];
 }
 
+// ---- a group of samples per launch (bucket_group_enqueue; see dense_count.hip: a genome is one tile per CU) ---------------
+constexpr int BS_GROUP = 8;
+struct BsItem {
+    const uint8_t *clean;
+    uint64_t len;
+    uint32_t *cnt, *wgoff, *base, *part, *wtmp, *ctmp, *uniq, *uoff, *flag, *host;
+    uint64_t *words;
+    uint32_t *freqs;
+    uint32_t tile0;   // first tile of the sample in the group's grid
+};
+struct BsBatch {
+    uint32_t n, lo, hi, last_word, cap;
+    BsMap mp;
+    const uint32_t *spl;
+    const uint16_t *ct;
+    BsItem it[BS_GROUP];
+};
+__device__ __forceinline__ uint32_t bs_batch_sample(const BsBatch &p, uint32_t tile)
+{
+    uint32_t s = 0;
+#pragma unroll
+    for (int q = 1; q < BS_GROUP; q++) s += (q < (int)p.n && tile >= p.it[q].tile0) ? 1u : 0u;
+    return s;
+}
+
 template <int K>
-__global__ __launch_bounds__(BT_THREADS) void bs_hist_kernel(const uint8_t *__restrict__ clean, uint64_t len, uint32_t lo, uint32_t hi,
-                                                              const uint32_t *__restrict__ spl_g, const uint16_t *__restrict__ ct_g,
-                                                              const BsMap mp, uint32_t *__restrict__ cnt, uint32_t *__restrict__ wgoff)
+__device__ __forceinline__ void bs_hist_body(const uint8_t *__restrict__ clean, uint64_t len, uint32_t lo, uint32_t hi,
+                                             const uint32_t *__restrict__ spl_g, const uint16_t *__restrict__ ct_g, const BsMap mp,
+                                             uint32_t *__restrict__ cnt, uint32_t *__restrict__ wgoff, const uint32_t tile)
 {
     __shared__ uint32_t h[BS_NB];
     __shared__ uint32_t spl[BS_NB];
@@ -104,7 +129,7 @@ __global__ __launch_bounds__(BT_THREADS) void bs_hist_kernel(const uint8_t *__re
     for (uint32_t d = threadIdx.x; d < BS_NB; d += BT_THREADS) h[d] = 0;
     load_map(spl, ct, spl_g, ct_g, BT_THREADS);
     __syncthreads();
-    const uint64_t s = ((uint64_t)blockIdx.x * BT_THREADS + threadIdx.x) * KW_SEG;
+    const uint64_t s = ((uint64_t)tile * BT_THREADS + threadIdx.x) * KW_SEG;
     Streams st;
     load_streams(st, clean, len, s);
     ForEachWindow<K, 0>::run(st, lo, hi, [&](int, bool ok, uint32_t w) {
@@ -119,15 +144,27 @@ __global__ __launch_bounds__(BT_THREADS) void bs_hist_kernel(const uint8_t *__re
         if (c[e]) o[e] = atomicAdd(&cnt[e * BT_THREADS + threadIdx.x], c[e]);
 #pragma unroll
     for (int e = 0; e < (int)(BS_NB / BT_THREADS); e++)
-        if (c[e]) wgoff[(uint64_t)blockIdx.x * BS_NB + e * BT_THREADS + threadIdx.x] = o[e];
+        if (c[e]) wgoff[(uint64_t)tile * BS_NB + e * BT_THREADS + threadIdx.x] = o[e];
+}
+template <int K>
+__global__ __launch_bounds__(BT_THREADS) void bs_hist_kernel(const uint8_t *__restrict__ clean, uint64_t len, uint32_t lo, uint32_t hi,
+                                                              const uint32_t *__restrict__ spl_g, const uint16_t *__restrict__ ct_g,
+                                                              const BsMap mp, uint32_t *__restrict__ cnt, uint32_t *__restrict__ wgoff)
+{
+    bs_hist_body<K>(clean, len, lo, hi, spl_g, ct_g, mp, cnt, wgoff, blockIdx.x);
+}
+template <int K>
+__global__ __launch_bounds__(BT_THREADS) void bs_hist_batch_kernel(const BsBatch p)
+{
+    const BsItem &it = p.it[bs_batch_sample(p, blockIdx.x)];
+    bs_hist_body<K>(it.clean, it.len, p.lo, p.hi, p.spl, p.ct, p.mp, it.cnt, it.wgoff, blockIdx.x - it.tile0);
 }
 
 template <int K>
-__global__ __launch_bounds__(BT_THREADS) void bs_partition_kernel(const uint8_t *__restrict__ clean, uint64_t len, uint32_t lo,
-                                                                   uint32_t hi, const uint32_t *__restrict__ spl_g,
-                                                                   const uint16_t *__restrict__ ct_g, const BsMap mp,
-                                                                   const uint32_t *__restrict__ cnt, const uint32_t *__restrict__ wgoff,
-                                                                   uint32_t *__restrict__ base_out, uint32_t *__restrict__ part)
+__device__ __forceinline__ void bs_partition_body(const uint8_t *__restrict__ clean, uint64_t len, uint32_t lo, uint32_t hi,
+                                                  const uint32_t *__restrict__ spl_g, const uint16_t *__restrict__ ct_g, const BsMap mp,
+                                                  const uint32_t *__restrict__ cnt, const uint32_t *__restrict__ wgoff,
+                                                  uint32_t *__restrict__ base_out, uint32_t *__restrict__ part, const uint32_t tile)
 {
     extern __shared__ uint32_t dyn_lds[];                 // BP_LDS_BYTES
     uint32_t *stage = dyn_lds;                            // 64 KB: the tile's words, bucketed
@@ -140,7 +177,7 @@ __global__ __launch_bounds__(BT_THREADS) void bs_partition_kernel(const uint8_t 
     for (uint32_t d = threadIdx.x; d < BS_NB; d += BT_THREADS) h[d] = 0;
     load_map(spl, ct, spl_g, ct_g, BT_THREADS);
     __syncthreads();
-    const uint64_t s = ((uint64_t)blockIdx.x * BT_THREADS + threadIdx.x) * KW_SEG;
+    const uint64_t s = ((uint64_t)tile * BT_THREADS + threadIdx.x) * KW_SEG;
     Streams st;
     load_streams(st, clean, len, s);
     uint32_t wv[KW_SEG];   // the word (a valid canonical word is never 0xffffffff: its reverse complement would be 0)
@@ -174,8 +211,8 @@ __global__ __launch_bounds__(BT_THREADS) void bs_partition_kernel(const uint8_t 
         for (int e = 0; e < 4; e++) {
             const uint32_t d = d0 + e;
             lstart[d] = (uint16_t)lex;
-            h[d] = gex + (c4[e] ? wgoff[(uint64_t)blockIdx.x * BS_NB + d] : 0u) - lex;
-            if (blockIdx.x == 0) base_out[d] = gex;
+            h[d] = gex + (c4[e] ? wgoff[(uint64_t)tile * BS_NB + d] : 0u) - lex;
+            if (tile == 0) base_out[d] = gex;
             lex += c4[e];
             gex += g4[e];
         }
@@ -190,6 +227,21 @@ __global__ __launch_bounds__(BT_THREADS) void bs_partition_kernel(const uint8_t 
         }
     __syncthreads();
     for (uint32_t i = threadIdx.x; i < ltot; i += BT_THREADS) part[(size_t)(uint32_t)(h[stageb[i]] + i)] = stage[i];
+}
+template <int K>
+__global__ __launch_bounds__(BT_THREADS) void bs_partition_kernel(const uint8_t *__restrict__ clean, uint64_t len, uint32_t lo,
+                                                                   uint32_t hi, const uint32_t *__restrict__ spl_g,
+                                                                   const uint16_t *__restrict__ ct_g, const BsMap mp,
+                                                                   const uint32_t *__restrict__ cnt, const uint32_t *__restrict__ wgoff,
+                                                                   uint32_t *__restrict__ base_out, uint32_t *__restrict__ part)
+{
+    bs_partition_body<K>(clean, len, lo, hi, spl_g, ct_g, mp, cnt, wgoff, base_out, part, blockIdx.x);
+}
+template <int K>
+__global__ __launch_bounds__(BT_THREADS) void bs_partition_batch_kernel(const BsBatch p)
+{
+    const BsItem &it = p.it[bs_batch_sample(p, blockIdx.x)];
+    bs_partition_body<K>(it.clean, it.len, p.lo, p.hi, p.spl, p.ct, p.mp, it.cnt, it.wgoff, it.base, it.part, blockIdx.x - it.tile0);
 }
 
 // One workgroup per bucket: sort, run lengths.  The words of a bucket spread evenly over its narrow range (the buckets
@@ -345,10 +397,20 @@ __global__ __launch_bounds__(BS_SORT_THREADS) void bs_sort_kernel(const uint32_t
     }
 }
 
+__global__ __launch_bounds__(BS_SORT_THREADS) void bs_sort_batch_kernel(const BsBatch p)
+{
+    extern __shared__ uint32_t dyn_lds[];   // BSORT_LDS_BYTES
+    const BsItem &it = p.it[blockIdx.y];
+    for (uint32_t b = blockIdx.x; b < p.mp.nb; b += gridDim.x) {
+        bs_sort_bucket(b, it.part, it.cnt, it.base, p.spl, p.mp.nb, p.last_word, p.cap, it.wtmp, it.ctmp, it.uniq, it.flag, dyn_lds);
+        __syncthreads();
+    }
+}
+
 // uniq -> offsets of the buckets in the list; totals: host[0] = words kept, [1] = unique words, [3] = a bucket overflowed
-__global__ __launch_bounds__(1024) void bs_totals_kernel(const uint32_t *__restrict__ cnt, const uint32_t *__restrict__ uniq,
-                                                         uint32_t *__restrict__ uoff, const uint32_t *__restrict__ flag,
-                                                         uint32_t nb, uint32_t *__restrict__ host)
+__device__ __forceinline__ void bs_totals_body(const uint32_t *__restrict__ cnt, const uint32_t *__restrict__ uniq,
+                                               uint32_t *__restrict__ uoff, const uint32_t *__restrict__ flag, uint32_t nb,
+                                               uint32_t *__restrict__ host)
 {
     __shared__ uint32_t scan_lds[16];
     const uint32_t t = threadIdx.x;
@@ -361,17 +423,41 @@ __global__ __launch_bounds__(1024) void bs_totals_kernel(const uint32_t *__restr
     if (t == 0) { host[0] = ctot; host[1] = utot; host[2] = 0; host[3] = *flag; }
 }
 
-// (one flat pass with a search over the offsets per element was slower: 41 us against 26 for a whole genome)
-__global__ void bs_compact_kernel(const uint32_t *__restrict__ wtmp, const uint32_t *__restrict__ ctmp, const uint32_t *__restrict__ base,
-                                  const uint32_t *__restrict__ uniq, const uint32_t *__restrict__ uoff, uint64_t *__restrict__ words,
-                                  uint32_t *__restrict__ freqs)
+__global__ __launch_bounds__(1024) void bs_totals_kernel(const uint32_t *__restrict__ cnt, const uint32_t *__restrict__ uniq,
+                                                         uint32_t *__restrict__ uoff, const uint32_t *__restrict__ flag,
+                                                         uint32_t nb, uint32_t *__restrict__ host)
 {
-    const uint32_t b = blockIdx.x, n = uniq[b];
+    bs_totals_body(cnt, uniq, uoff, flag, nb, host);
+}
+__global__ __launch_bounds__(1024) void bs_totals_batch_kernel(const BsBatch p)
+{
+    const BsItem &it = p.it[blockIdx.x];
+    bs_totals_body(it.cnt, it.uniq, it.uoff, it.flag, p.mp.nb, it.host);
+}
+
+// (one flat pass with a search over the offsets per element was slower: 41 us against 26 for a whole genome)
+__device__ __forceinline__ void bs_compact_body(const uint32_t *__restrict__ wtmp, const uint32_t *__restrict__ ctmp,
+                                                const uint32_t *__restrict__ base, const uint32_t *__restrict__ uniq,
+                                                const uint32_t *__restrict__ uoff, uint64_t *__restrict__ words,
+                                                uint32_t *__restrict__ freqs, const uint32_t bucket)
+{
+    const uint32_t b = bucket, n = uniq[b];
     const size_t src = base[b], dst = uoff[b];
     for (uint32_t i = threadIdx.x; i < n; i += blockDim.x) {
         words[dst + i] = wtmp[src + i];
         freqs[dst + i] = ctmp[src + i];
     }
+}
+__global__ void bs_compact_kernel(const uint32_t *__restrict__ wtmp, const uint32_t *__restrict__ ctmp, const uint32_t *__restrict__ base,
+                                  const uint32_t *__restrict__ uniq, const uint32_t *__restrict__ uoff, uint64_t *__restrict__ words,
+                                  uint32_t *__restrict__ freqs)
+{
+    bs_compact_body(wtmp, ctmp, base, uniq, uoff, words, freqs, blockIdx.x);
+}
+__global__ void bs_compact_batch_kernel(const BsBatch p)
+{
+    const BsItem &it = p.it[blockIdx.y];
+    bs_compact_body(it.wtmp, it.ctmp, it.base, it.uniq, it.uoff, it.words, it.freqs, blockIdx.x);
 }
 
 // the partitioned words of a sample as u64 keys for the radix sort (the fall-back)
@@ -530,8 +616,130 @@ int bucket_chain_finalize(psk_ctx *ctx, CountLane &L, SampleList &S, uint64_t n_
     PSK_TRY(arena_alloc(ctx, nu * 4, (void **)&S.freqs));
     const uint32_t *wtmp = L.dc_mtemp.as<uint32_t>(), *ctmp = wtmp + L.n + 8;
     (void)n_kept;
+    if (L.dc_defer_compact) return PSK_OK;   // the group packs in one launch (bucket_group_compact)
     bs_compact_kernel<<<ctx->bs_nb, 512, 0, ctx->stream>>>(wtmp, ctmp, d.base, d.uniq, d.uoff, S.words, S.freqs);
     PSK_HIP(ctx, hipGetLastError());
+    return PSK_OK;
+}
+
+// ---- a group of samples in one launch chain (as dense_group_enqueue) --------------------------------------------------------
+void bucket_lane_bytes(size_t max_len, size_t out[5])
+{
+    out[0] = max_len * 4 + 64;                                   // dc_part
+    out[1] = (size_t)div_up(max_len, BT_TILE) * BS_NB * 4;       // dc_wgoff
+    out[2] = (size_t)BS_SLOTS * (BS_NB + 16) * 4;                // dc_cnt
+    out[3] = (size_t)(4 * BS_NB + 4) * 4;                        // dc_meta
+    out[4] = max_len * 8 + 64;                                   // dc_mtemp
+}
+
+template <int K>
+static int launch_group_tiles(psk_ctx *ctx, const BsBatch &p, uint32_t tiles)
+{
+    bs_hist_batch_kernel<K><<<tiles, BT_THREADS, 0, ctx->stream>>>(p);
+    PSK_HIP(ctx, hipGetLastError());
+    static PerDeviceOnce attr_set;
+    if (attr_set.first(ctx->device)) {
+        PSK_HIP(ctx, hipFuncSetAttribute(reinterpret_cast<const void *>(bs_partition_batch_kernel<K>),
+                                         hipFuncAttributeMaxDynamicSharedMemorySize, (int)BP_LDS_BYTES));
+    }
+    bs_partition_batch_kernel<K><<<tiles, BT_THREADS, BP_LDS_BYTES, ctx->stream>>>(p);
+    PSK_HIP(ctx, hipGetLastError());
+    return PSK_OK;
+}
+
+int bucket_group_enqueue(psk_ctx *ctx, CountLane *const *lanes, const int *sample_idx, const uint64_t *clean_len, const uint64_t *n,
+                         int count)
+{
+    (void)sample_idx;
+    if (count < 1 || count > BS_GROUP) return psk_fail(ctx, PSK_EINVAL, "bad group size %d", count);
+    const uint64_t space = 1ull << (2 * ctx->k);
+    BsBatch p;
+    memset(&p, 0, sizeof(p));
+    p.n = (uint32_t)count;
+    p.lo = (uint32_t)ctx->slab_lo;
+    p.hi = (ctx->slab_hi && ctx->slab_hi < space && ctx->slab_hi <= 0xffffffffull) ? (uint32_t)ctx->slab_hi
+           : (space > 0xffffffffull ? 0xffffffffu : (uint32_t)space);   // no canonical word is 0xffffffff
+    p.last_word = p.hi - 1u;
+    p.cap = bs_cap();
+    p.mp = BsMap{ctx->bs_lo, ctx->bs_shift, ctx->bs_nb};
+    p.spl = ctx->bs_spl.as<uint32_t>();
+    p.ct = ctx->bs_ct.as<uint16_t>();
+    uint32_t tiles = 0;
+    for (int s = 0; s < count; s++) {
+        CountLane &L = *lanes[s];
+        const uint32_t n_tiles = div_up(clean_len[s], BT_TILE);
+        PSK_TRY(dev_reserve(ctx, L.dc_part, n[s] * 4 + 64));
+        PSK_TRY(dev_reserve(ctx, L.dc_wgoff, (size_t)n_tiles * BS_NB * 4));
+        PSK_TRY(dev_reserve(ctx, L.dc_cnt, (size_t)BS_SLOTS * (BS_NB + 16) * 4));
+        PSK_TRY(dev_reserve(ctx, L.dc_meta, (size_t)(4 * BS_NB + 4) * 4));
+        PSK_TRY(dev_reserve(ctx, L.dc_mtemp, n[s] * 8 + 64));
+        if (L.dc_slot == 0 || L.dc_slot >= BS_SLOTS) {
+            PSK_HIP(ctx, hipMemsetAsync(L.dc_cnt.p, 0, (size_t)BS_SLOTS * (BS_NB + 16) * 4, ctx->stream));
+            L.dc_slot = 0;
+        }
+        const BsBufs d = bs_bufs(L, L.dc_slot++);
+        BsItem &it = p.it[s];
+        it.clean = L.raw.as<uint8_t>();
+        it.len = clean_len[s];
+        it.cnt = d.cnt; it.wgoff = L.dc_wgoff.as<uint32_t>(); it.base = d.base; it.part = L.dc_part.as<uint32_t>();
+        it.wtmp = L.dc_mtemp.as<uint32_t>(); it.ctmp = it.wtmp + n[s] + 8;
+        it.uniq = d.uniq; it.uoff = d.uoff; it.flag = d.flag; it.host = L.pinned_cnt;
+        it.tile0 = tiles;
+        tiles += n_tiles;
+    }
+    switch (ctx->k) {
+    case 14: PSK_TRY(launch_group_tiles<14>(ctx, p, tiles)); break;
+    case 15: PSK_TRY(launch_group_tiles<15>(ctx, p, tiles)); break;
+    case 16: PSK_TRY(launch_group_tiles<16>(ctx, p, tiles)); break;
+    default: return psk_fail(ctx, PSK_ESTATE, "the bucketed sort is built for k = 14..16, not %d", ctx->k);
+    }
+    for (int s = 0; s < count; s++) {
+        PSK_HIP(ctx, hipEventRecord(lanes[s]->raw_free, ctx->stream));
+        lanes[s]->raw_used = true;
+    }
+    static PerDeviceOnce attr_set;
+    if (attr_set.first(ctx->device)) {
+        PSK_HIP(ctx, hipFuncSetAttribute(reinterpret_cast<const void *>(bs_sort_batch_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                         (int)BSORT_LDS_BYTES));
+    }
+    const uint32_t wg_all = 2u * (uint32_t)(ctx->n_cu > 0 ? ctx->n_cu : 256);   // one resident set of workgroups for the whole group
+    uint32_t per = (wg_all + (uint32_t)count - 1) / (uint32_t)count;
+    if (per > ctx->bs_nb) per = ctx->bs_nb;
+    if (per < 1) per = 1;
+    bs_sort_batch_kernel<<<dim3(per, (uint32_t)count), BS_SORT_THREADS, BSORT_LDS_BYTES, ctx->stream>>>(p);
+    PSK_HIP(ctx, hipGetLastError());
+    bs_totals_batch_kernel<<<(uint32_t)count, 1024, 0, ctx->stream>>>(p);
+    PSK_HIP(ctx, hipGetLastError());
+    for (int s = 0; s < count; s++) {
+        PSK_HIP(ctx, hipEventRecord(lanes[s]->done, ctx->stream));
+        lanes[s]->bs = true;
+        lanes[s]->dc_defer_compact = true;
+    }
+    return PSK_OK;
+}
+
+// after chain_finalize of every set of the group (which sized and allocated the lists): ONE packing launch
+int bucket_group_compact(psk_ctx *ctx, CountLane *const *lanes, const int *sample_idx, int count)
+{
+    BsBatch p;
+    memset(&p, 0, sizeof(p));
+    uint32_t m = 0;
+    for (int s = 0; s < count; s++) {
+        CountLane &L = *lanes[s];
+        L.dc_defer_compact = false;
+        const SampleList &S = ctx->lists[sample_idx[s]];
+        if (!S.n_unique || !S.words) continue;
+        const BsBufs d = bs_bufs(L, L.dc_slot - 1);
+        BsItem &it = p.it[m++];
+        it.wtmp = L.dc_mtemp.as<uint32_t>(); it.ctmp = it.wtmp + L.n + 8;
+        it.base = d.base; it.uniq = d.uniq; it.uoff = d.uoff;
+        it.words = S.words; it.freqs = S.freqs;
+    }
+    p.n = m;
+    if (m) {
+        bs_compact_batch_kernel<<<dim3(ctx->bs_nb, m), 512, 0, ctx->stream>>>(p);
+        PSK_HIP(ctx, hipGetLastError());
+    }
     return PSK_OK;
 }
 

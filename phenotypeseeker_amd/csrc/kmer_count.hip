@@ -548,7 +548,8 @@ int frame_probe_known_end(const uint8_t *bytes, size_t nul_at, size_t *start, si
 static int carve_lanes(psk_ctx *ctx, int n_lanes, size_t max_len, bool gpu_framing)
 {
     size_t dcb[5];
-    dense_lane_bytes(ctx, max_len, dcb);
+    if (ctx->dense_mode) dense_lane_bytes(ctx, max_len, dcb);
+    else bucket_lane_bytes(max_len, dcb);
     const size_t want[8] = {max_len + 128 + 2 * EX_SEG, gpu_framing ? max_len + 64 : 0, gpu_framing ? frame_gpu_scratch_bytes(max_len) : 0,
                             dcb[0], dcb[1], dcb[2], dcb[3], dcb[4]};
     auto bufs_of = [](CountLane &L, DevBuf *out[8]) {
@@ -631,6 +632,16 @@ static int chain_upload(psk_ctx *ctx, CountLane &L, const uint8_t *src, uint64_t
     return PSK_OK;
 }
 
+// the buffers of the radix route (and of the bucketed sort's fall-back onto it)
+static int radix_lane_reserve(psk_ctx *ctx, CountLane &L, uint64_t n)
+{
+    PSK_TRY(dev_reserve(ctx, L.keysA, n * 8));
+    PSK_TRY(dev_reserve(ctx, L.keysB, n * 8));
+    PSK_TRY(dev_reserve(ctx, L.starts, (size_t)div_up(n, RLE_TILE) * 8));  // tile offsets | next-head positions
+    PSK_TRY(dev_reserve(ctx, L.cnt, (size_t)CountLane::CNT_SLOTS * 16));
+    return PSK_OK;
+}
+
 // Stage B: the counting chain of the sample whose clean stream stage A put (or is putting) into L.raw.
 // n = number of k-base windows (exact from the host's framing; the clean length, an upper bound, after the GPU's).
 static int chain_compute(psk_ctx *ctx, CountLane &L, int sample_idx, uint64_t clean_len, uint64_t n, bool n_exact)
@@ -654,12 +665,6 @@ static int chain_compute(psk_ctx *ctx, CountLane &L, int sample_idx, uint64_t cl
         }
         return PSK_OK;
     }
-    if (!ctx->dense_mode) {
-        PSK_TRY(dev_reserve(ctx, L.keysA, n * 8));
-        PSK_TRY(dev_reserve(ctx, L.keysB, n * 8));
-        PSK_TRY(dev_reserve(ctx, L.starts, (size_t)div_up(n, RLE_TILE) * 8));  // tile offsets | next-head positions
-        PSK_TRY(dev_reserve(ctx, L.cnt, (size_t)CountLane::CNT_SLOTS * 16));
-    }
     PSK_HIP(ctx, hipStreamWaitEvent(ctx->stream, L.raw_ready, 0));
     if (ctx->dense_mode) {   // 2k <= 26: no sort (dense_count.hip)
         if (ctx->dense_defer && dense_group_ok(ctx, n)) {   // a genome of a batch: its chain is launched with its group's
@@ -669,7 +674,15 @@ static int chain_compute(psk_ctx *ctx, CountLane &L, int sample_idx, uint64_t cl
         }
         return dense_chain_enqueue(ctx, L, sample_idx, clean_len, n);
     }
-    if (bucket_route_ok(ctx, n)) return bucket_chain_enqueue(ctx, L, sample_idx, clean_len, n);   // k = 14..16, splitters known
+    if (bucket_route_ok(ctx, n)) {   // k = 14..16, splitters known
+        if (ctx->dense_defer) {      // a genome of a batch: its chain is launched with its group's
+            L.group_pending = true;
+            L.clean_len = clean_len;
+            return PSK_OK;
+        }
+        return bucket_chain_enqueue(ctx, L, sample_idx, clean_len, n);
+    }
+    PSK_TRY(radix_lane_reserve(ctx, L, n));
     // every sample takes a fresh pre-zeroed counter slot (a 16-byte memset per sample is a 6 us launch)
     if (L.cnt_slot == 0 || L.cnt_slot >= CountLane::CNT_SLOTS) {
         PSK_HIP(ctx, hipMemsetAsync(L.cnt.p, 0, (size_t)CountLane::CNT_SLOTS * 16, ctx->stream));
@@ -736,6 +749,8 @@ static int chain_finalize(psk_ctx *ctx, CountLane &L)
             // a bucket outgrew the LDS sort: the partitioned words through the radix sort and the run-length passes, waited for
             // (rare: a sample unlike the one the splitters were taken from)
             uint64_t *sorted = nullptr;
+            L.dc_defer_compact = false;   // (in a group: this sample's list is made here, not by the group's packing launch)
+            PSK_TRY(radix_lane_reserve(ctx, L, L.n));
             PSK_TRY(bucket_fallback_keys(ctx, L, n_kept, L.keysA.as<uint64_t>()));
             PSK_TRY(dev_radix_sort_u64(ctx, L.keysA.as<uint64_t>(), L.keysB.as<uint64_t>(), n_kept, 0, 2 * ctx->k, &sorted, nullptr));
             uint32_t *d_n = L.cnt.as<uint32_t>() + 4 * (size_t)(CountLane::CNT_SLOTS - 1);
@@ -919,7 +934,8 @@ static int count_batch_impl(psk_ctx *ctx, int first_sample_idx, int n, const uin
     // pinned ring: at most ~4 GiB of it (read-scale FASTQ samples are hundreds of MB each)
     while (n_threads > 1 && (size_t)(n_threads + 4) * max_len > (4ull << 30)) n_threads--;
     // genomes at k <= 13 (dense counting) go through the counting kernels in groups of G: one launch chain per group
-    const int G = (!consumer && ctx->dense_mode && n > 1 && max_len < (64u << 20)) ? dense_group_size() : 1;
+    const bool bucket_run = !ctx->dense_mode && ctx->k >= 14 && ctx->k <= 16 && !getenv("PSK_NO_BUCKET_SORT");
+    const int G = (!consumer && (ctx->dense_mode || bucket_run) && n > 1 && max_len < (64u << 20)) ? dense_group_size() : 1;
     const bool grouped = G > 1;
     const int NL = grouped ? 3 * G : 3;   // buffer sets in rotation
     const int want_ring = grouped ? G + n_threads + 4 : n_threads + 4;   // (grouped: a slot is released as soon as its upload is over)
@@ -1092,11 +1108,10 @@ static int count_batch_impl(psk_ctx *ctx, int first_sample_idx, int n, const uin
             const auto t0 = std::chrono::steady_clock::now();
             for (int i = lo; i < hi; i++) {
                 CountLane &L = ctx->lane[i % NL];
-                const bool in_group = L.dc_defer_compact;
                 PSK_TRY(chain_finalize(ctx, L));
-                if (in_group) { gl[cnt] = &L; gs[cnt] = first_sample_idx + i; cnt++; }
+                if (L.dc_defer_compact) { gl[cnt] = &L; gs[cnt] = first_sample_idx + i; cnt++; }   // sized and allocated; packed below
             }
-            if (cnt) PSK_TRY(dense_group_compact(ctx, gl, gs, cnt));
+            if (cnt) PSK_TRY(ctx->dense_mode ? dense_group_compact(ctx, gl, gs, cnt) : bucket_group_compact(ctx, gl, gs, cnt));
             t_final += since(t0);
             for (int i = lo; i < hi; i++) {
                 report(i);
@@ -1107,8 +1122,11 @@ static int count_batch_impl(psk_ctx *ctx, int first_sample_idx, int n, const uin
         };
         pump_a(G);
         int prev_lo = -1, prev_hi = -1;
-        for (int lo = 0; lo < n && rc == PSK_OK; lo += G) {
-            const int hi = lo + G < n ? lo + G : n;
+        for (int lo = 0, hi = 0; lo < n && rc == PSK_OK; lo = hi) {
+            // (k = 14..16: the first sample of a run goes through the radix route alone and is finalised at once -- its list
+            // gives the splitters of the bucketed sort that every later sample, grouped, takes)
+            const bool alone = bucket_run && !ctx->bs_ready;
+            hi = alone ? lo + 1 : (lo + G < n ? lo + G : n);
             CountLane *gl[8];
             int gs[8], cnt = 0;
             uint64_t gc[8], gn[8];
@@ -1137,12 +1155,13 @@ static int count_batch_impl(psk_ctx *ctx, int first_sample_idx, int n, const uin
                     cnt++;
                 }
             }
-            if (rc == PSK_OK && cnt) rc = dense_group_enqueue(ctx, gl, gs, gc, gn, cnt);
+            if (rc == PSK_OK && cnt) rc = ctx->dense_mode ? dense_group_enqueue(ctx, gl, gs, gc, gn, cnt) : bucket_group_enqueue(ctx, gl, gs, gc, gn, cnt);
             for (int i = lo; i < hi && rc == PSK_OK; i++)
                 if (sketch_k && wins[i] > 0)
                     rc = sketch_enqueue(ctx, ctx->lane[i % NL], ctx->lane[i % NL].raw.as<uint8_t>(), clen[i], sketch_k, sketch_size, sketch_seed);
             if (rc == PSK_OK && prev_lo >= 0) rc = finalize_group(prev_lo, prev_hi);
             prev_lo = lo; prev_hi = hi;
+            if (rc == PSK_OK && alone) { rc = finalize_group(lo, hi); prev_lo = -1; }
         }
         if (rc == PSK_OK && prev_lo >= 0) rc = finalize_group(prev_lo, prev_hi);
         ctx->dense_defer = false;

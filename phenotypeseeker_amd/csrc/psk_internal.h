@@ -245,6 +245,11 @@ bool dense_group_ok(const psk_ctx *ctx, uint64_t n);
 int dense_group_enqueue(psk_ctx *ctx, CountLane *const *lanes, const int *sample_idx, const uint64_t *clean_len, const uint64_t *n,
                         int count);
 int dense_group_compact(psk_ctx *ctx, CountLane *const *lanes, const int *sample_idx, int count);
+// the same for the bucketed sort (k = 14..16, bucket_count.hip)
+int bucket_group_enqueue(psk_ctx *ctx, CountLane *const *lanes, const int *sample_idx, const uint64_t *clean_len, const uint64_t *n,
+                         int count);
+int bucket_group_compact(psk_ctx *ctx, CountLane *const *lanes, const int *sample_idx, int count);
+void bucket_lane_bytes(size_t max_len, size_t out[5]);
 // bytes of the five dc_* buffers of one buffer set for samples of up to max_len clean bases (dc_part, dc_wgoff, dc_cnt, dc_meta, dc_mtemp)
 void dense_lane_bytes(const psk_ctx *ctx, size_t max_len, size_t out[5]);
 // words[] / freqs[] of samples [first, first + n) from their dense form (no-op for sparse or materialised ones)
