@@ -56,6 +56,8 @@ if what == "cfg3slab":
         alg["bs_partition_kernel"] = L + 4 * kept
         alg["bs_sort_kernel"] = 4 * kept + 8 * kept
         alg["bs_compact_kernel"] = 8 * kept + 12 * kept
+        for name in ("bs_hist", "bs_partition", "bs_sort", "bs_compact"):   # a launch of the grouped chain covers eight genomes
+            alg[name + "_batch_kernel"] = 8 * alg[name + "_kernel"]
         # presence build, streaming merge (12 B x pairs read + the matrix written; the merge reads the 8-byte
         # words only, and twice -- once per pass): pm_mark = 8 B x pairs + the occupancy bitmap, pm_fill = 8 B x pairs +
         # the matrix + the union words
@@ -130,6 +132,8 @@ elif what == "ingest":
         alg["dc_hist_kernel"] = L
         alg["dc_partition_kernel"] = L + 2 * L
         alg["dc_count_sparse_kernel"] = 2 * L + (1 << 26) // 8
+        for name in ("dc_hist", "dc_partition", "dc_count_sparse"):   # a launch of the grouped chain covers eight genomes
+            alg[name + "_batch_kernel"] = 8 * alg[name + "_kernel"]
         alg["pd_or_kernel"] = n * ((1 << 26) // 8)
         alg["pd_transpose_kernel"] = n * ((1 << 26) // 8) + m * 32 + m * 8
 elif what == "solver":
