@@ -696,12 +696,9 @@ int dense_chain_finalize(psk_ctx *ctx, CountLane &L, uint64_t *n_kept, uint64_t 
 // ---- a group of samples in one launch chain (psk_count_kmers_batch, genomes at k = 11..13) -------------------------------
 int dense_group_size()
 {
-    static const int g = [] {
-        const char *e = getenv("PSK_DC_GROUP");
-        int v = e ? atoi(e) : DC_GROUP;
-        return v < 1 ? 1 : (v > DC_GROUP ? DC_GROUP : v);
-    }();
-    return g;
+    const char *e = getenv("PSK_DC_GROUP");   // read per call: tests cross group sizes in one process
+    const int v = e ? atoi(e) : DC_GROUP;
+    return v < 1 ? 1 : (v > DC_GROUP ? DC_GROUP : v);
 }
 
 void dense_lane_bytes(const psk_ctx *ctx, size_t max_len, size_t out[5])

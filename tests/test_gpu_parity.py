@@ -1148,6 +1148,43 @@ def test_batch_counting_equals_single_calls(ctx, oracle):
         ctx.count_kmers_batch(40, datas[:10], 2)   # runs past the declared sample count
 
 
+@pytest.mark.parametrize("k,slab", [(13, False), (12, True), (16, False), (15, True)])
+def test_grouped_counting_chains_equal_the_oracle_and_the_one_sample_chains(ctx, oracle, monkeypatch, k, slab):
+    """The genomes of a batch go through the counting kernels in groups (r03: a sample dimension in the kernels of the dense
+    chain, k <= 13, and of the bucketed sort, k = 14..16): groups of 8, of 3 and the one-sample chain (PSK_DC_GROUP) give the
+    lists of the oracle bit for bit -- with a ragged last group, an empty sample and a windowless one in the middle, a FASTQ
+    sample, MinHash sketches riding along, and under a slab filter."""
+    from phenotypeseeker_amd.dist import slab_bounds
+    from phenotypeseeker_amd.synth import GenomeSet, fastq_reads
+    n_gen = 21
+    gs = GenomeSet(n_gen, 150_000 if k >= 14 else 60_000, seed=100 + k)
+    datas = [gs.sample(i)[1] for i in range(n_gen)]
+    datas[5] = b""
+    datas[11] = b">tiny\nACGTACGTAC\n"
+    datas[17] = fastq_reads(gs.codes(3), 400, 150, seed=[k, 2])
+    lo, hi = slab_bounds(k, 3, 1) if slab else (0, 0)
+    ref = []
+    for d in datas:
+        w, f = oracle.count_kmers(d, k)[:2]
+        sel = (w >= lo) & ((w < hi) if hi else np.ones(len(w), bool))
+        ref.append((w[sel], f[sel]))
+    sk = None
+    for group in ("8", "3", "1"):
+        monkeypatch.setenv("PSK_DC_GROUP", group)
+        ctx.begin(k, len(datas), lo, hi)
+        out = ctx.count_kmers_batch(0, datas, 4, sketch=(21, 64, 42))
+        nu, nt = out[0], out[1]
+        for i, (rw, rf) in enumerate(ref):
+            w, f = ctx.get_list(i, nu[i])
+            assert (nu[i], nt[i]) == (len(rw), int(rf.sum())), (group, i)
+            assert np.array_equal(w, rw) and np.array_equal(f, rf), (group, i)
+        if sk is None:
+            sk = [np.array(h) for h in out[2]]
+        else:
+            assert all(np.array_equal(a, np.array(b)) for a, b in zip(sk, out[2])), group
+    monkeypatch.delenv("PSK_DC_GROUP")
+
+
 def test_batch_counting_with_slab_filter(ctx, oracle):
     """The multi-GPU ingest path: psk_count_kmers_batch under a slab filter (the kept-word count only exists
     on the device; launches are sized by the host's window count).  Slabs concatenate to the full lists,
