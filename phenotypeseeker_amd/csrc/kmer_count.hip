@@ -517,11 +517,15 @@ static int frame_into(uint8_t *stage, size_t stage_cap, const uint8_t *bytes, si
     return PSK_OK;
 }
 
-// ---- pipelined form of the GPU half (psk_count_kmers_batch, whole-space runs) ---------------------
-// The window count is known from the framing, so nothing has to come back from the GPU before the sort is
-// launched; the only value the host needs -- the number of unique words, for the arena allocation -- is
-// picked up one sample late: chain i is queued on buffer set i & 1, then sample i - 1 is finalised (its
-// event has long fired while chain i keeps the GPU busy).  Uploads run on their own stream.
+// ---- pipelined form of the GPU half (psk_count_kmers_batch) ------------------------------------------------------------
+// The window count is known from the framing (or bounded by it), so nothing has to come back from the GPU before a chain is
+// launched; the only values the host needs -- the number of unique words, for the arena allocation -- are picked up
+// late.  Two shapes of the loop in count_batch_impl:
+//   one sample per chain (read sets, k >= 17, prediction's consumer, PSK_DC_GROUP=1): chain i is queued on buffer set i % 3,
+//     then sample i - 1 is finalised (its event has long fired while chain i keeps the GPU busy); samples i + 1 and i + 2
+//     are uploaded and framed ahead on their own streams;
+//   groups of G = 8 genomes per chain (k <= 16, r03): 3 G buffer sets, a group's uploads and framing run ahead, one
+//     launch chain counts the group (dense_group_enqueue / bucket_group_enqueue), the group before it is finalised meanwhile.
 static int lane_prepare(psk_ctx *ctx, CountLane &L)
 {
     if (!L.done) {
