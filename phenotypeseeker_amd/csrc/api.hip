@@ -142,6 +142,7 @@ extern "C" void psk_free(psk_ctx *ctx)
     dev_release(ctx->lane_slab);
     if (ctx->lane_pinned) (void)hipHostFree(ctx->lane_pinned);
     if (ctx->copy_stream) (void)hipStreamDestroy(ctx->copy_stream);
+    for (hipStream_t &cs : ctx->copy_more) if (cs) { (void)hipStreamSynchronize(cs); (void)hipStreamDestroy(cs); cs = nullptr; }
     if (ctx->frame_stream) { (void)hipStreamSynchronize(ctx->frame_stream); (void)hipStreamDestroy(ctx->frame_stream); }
     if (ctx->sketch_stream) { (void)hipStreamSynchronize(ctx->sketch_stream); (void)hipStreamDestroy(ctx->sketch_stream); }
     if (ctx->pinned) (void)hipHostFree(ctx->pinned);

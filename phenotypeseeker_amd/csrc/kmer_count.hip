@@ -536,6 +536,7 @@ static int lane_prepare(psk_ctx *ctx, CountLane &L)
     }
     if (!L.pinned_cnt) PSK_HIP(ctx, hipHostMalloc(reinterpret_cast<void **>(&L.pinned_cnt), 64, hipHostMallocDefault));
     if (!ctx->copy_stream) PSK_HIP(ctx, hipStreamCreateWithFlags(&ctx->copy_stream, hipStreamNonBlocking));
+    for (hipStream_t &cs : ctx->copy_more) if (!cs) PSK_HIP(ctx, hipStreamCreateWithFlags(&cs, hipStreamNonBlocking));
     if (!ctx->frame_stream) PSK_HIP(ctx, hipStreamCreateWithFlags(&ctx->frame_stream, hipStreamNonBlocking));
     return PSK_OK;
 }
@@ -613,26 +614,35 @@ static int chain_upload(psk_ctx *ctx, CountLane &L, const uint8_t *src, uint64_t
     PSK_TRY(lane_prepare(ctx, L));
     if (bytes == 0) return PSK_OK;
     if (bytes >= (1ull << 32)) return psk_fail(ctx, PSK_ERANGE, "sample larger than 4 GB");
+    // uploads rotate over two copy streams (PSK_COPY_STREAMS = 1..4): with one, the next copy is only queued when the
+    // previous one has gone -- 256 genomes took 38-40 ms, with two 33-36 (r03; a stream per buffer set: set index mod streams)
+    static const int n_cs = [] {
+        const char *e = getenv("PSK_COPY_STREAMS");
+        const int v = e ? atoi(e) : 2;
+        return v < 1 ? 1 : (v > 4 ? 4 : v);
+    }();
+    const int which = (int)((&L - ctx->lane) % n_cs);
+    hipStream_t cs = which ? ctx->copy_more[which - 1] : ctx->copy_stream;
     // after the last reader of this set's clean stream (the sample before last)
-    if (L.raw_used) PSK_HIP(ctx, hipStreamWaitEvent(ctx->copy_stream, L.raw_free, 0));
+    if (L.raw_used) PSK_HIP(ctx, hipStreamWaitEvent(cs, L.raw_free, 0));
     if (format == 0) {
         PSK_TRY(dev_reserve(ctx, L.raw, bytes));
-        PSK_HIP(ctx, hipMemcpyAsync(L.raw.p, src, bytes, hipMemcpyHostToDevice, ctx->copy_stream));
+        PSK_HIP(ctx, hipMemcpyAsync(L.raw.p, src, bytes, hipMemcpyHostToDevice, cs));
     } else {
         PSK_TRY(dev_reserve(ctx, L.rawin, bytes + 64));
         PSK_TRY(dev_reserve(ctx, L.raw, bytes + 128));
         PSK_TRY(dev_reserve(ctx, L.fr_scratch, frame_gpu_scratch_bytes(bytes)));
-        PSK_HIP(ctx, hipMemcpyAsync(L.rawin.p, src, bytes, hipMemcpyHostToDevice, ctx->copy_stream));
+        PSK_HIP(ctx, hipMemcpyAsync(L.rawin.p, src, bytes, hipMemcpyHostToDevice, cs));
         // the framing kernels run on their own stream: the copy stream goes on with the next sample's upload (PCIe is
         // the slowest stage of the ingest: ~100 us per 5-Mbp sample against ~25 us of framing and ~60 us of counting)
-        PSK_HIP(ctx, hipEventRecord(L.up_done, ctx->copy_stream));
+        PSK_HIP(ctx, hipEventRecord(L.up_done, cs));
         PSK_HIP(ctx, hipStreamWaitEvent(ctx->frame_stream, L.up_done, 0));
         PSK_TRY(frame_gpu_enqueue(ctx, ctx->frame_stream, format, L.rawin.as<uint8_t>(), bytes, L.raw.as<uint8_t>(), L.fr_scratch.p,
                                   lane_frame_result(L)));
         PSK_HIP(ctx, hipEventRecord(L.raw_ready, ctx->frame_stream));
         return PSK_OK;
     }
-    PSK_HIP(ctx, hipEventRecord(L.raw_ready, ctx->copy_stream));
+    PSK_HIP(ctx, hipEventRecord(L.raw_ready, cs));
     return PSK_OK;
 }
 
@@ -1205,6 +1215,7 @@ static int count_batch_impl(psk_ctx *ctx, int first_sample_idx, int n, const uin
     }
     {   // nothing of this call may still be in flight when it returns (the ring and the caller's buffers)
         const hipError_t e1 = hipStreamSynchronize(ctx->copy_stream ? ctx->copy_stream : ctx->stream);
+        for (hipStream_t cs2 : ctx->copy_more) if (cs2) (void)hipStreamSynchronize(cs2);
         if (ctx->frame_stream) (void)hipStreamSynchronize(ctx->frame_stream);
         const hipError_t e2 = hipStreamSynchronize(ctx->stream);
         if (ctx->sketch_stream) (void)hipStreamSynchronize(ctx->sketch_stream);

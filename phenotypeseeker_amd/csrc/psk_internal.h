@@ -149,6 +149,7 @@ struct psk_ctx {
     CountLane lane[LANES];   // sample i runs on set i % 3: i + 1 and i + 2 are uploaded / framed ahead while chain i runs; in groups
                              // of G genomes (dense counting) on set i % (3 G): two groups ahead, one in flight
     hipStream_t copy_stream = nullptr;  // uploads of the batch counter overlap the previous sample's kernels
+    hipStream_t copy_more[3] = {nullptr, nullptr, nullptr};   // ... and rotate over up to four streams (PSK_COPY_STREAMS, default 2): a copy is queued while one runs
     hipStream_t frame_stream = nullptr; // the GPU framing of sample i + 1 runs beside upload i + 2 and chain i
     hipStream_t sketch_stream = nullptr;  // the one-workgroup sketch select runs beside the next sample's chain
 
