@@ -599,6 +599,32 @@ def test_l1_logreg_three_forms_of_the_descent_agree(ctx, n, monkeypatch):
         assert np.allclose(objs["gram-global"], objs[tag], rtol=1e-5, atol=0), tag
 
 
+def test_l1_logreg_gram_global_form_reaches_the_same_optimum_at_a_tight_tolerance(ctx, monkeypatch):
+    """The Gram matrix of the global form is f32 sums of bf16-split weights: an approximate Hessian, so its Newton steps
+    converge linearly near the optimum (more of them than the array form's) -- to the SAME optimum: at tol = 1e-9 the
+    objectives agree to 1e-13 and every coefficient to 1e-6 of the largest (measured: 2e-16 and 2e-9 ... 2e-8)."""
+    n, p = 700, 250
+    rng = np.random.default_rng(n + p)
+    base = rng.random((n, 12)) < 0.4
+    X = (base[:, rng.integers(0, 12, p)] ^ (rng.random((n, p)) < 0.08)).astype(np.float32)
+    y = (base[:, 0] ^ (rng.random(n) < 0.15)).astype(np.int32)
+    fold = (np.arange(n) % 3).astype(np.int32)
+    fp = np.array([0.1, 1.0, 1.0], np.float64)
+    ff = np.array([0, 1, -1], np.int32)
+    a = ctx.logreg_l1_fit(X, y, fold, fp, ff, tol=1e-9, max_iter=3000)
+    monkeypatch.setenv("PSK_NO_GRAM_GLOBAL", "1")
+    b = ctx.logreg_l1_fit(X, y, fold, fp, ff, tol=1e-9, max_iter=3000)
+    monkeypatch.delenv("PSK_NO_GRAM_GLOBAL")
+    assert a[2].max() < 3000 and b[2].max() < 3000, (a[2], b[2])
+    ypm = 2.0 * y - 1.0
+    oa, ob = _l1_objectives(X, ypm, fold, fp, ff, a[0], a[1]), _l1_objectives(X, ypm, fold, fp, ff, b[0], b[1])
+    assert np.allclose(oa, ob, rtol=1e-13, atol=0), oa / ob - 1
+    for j in range(len(fp)):
+        scale = max(np.abs(b[0][j]).max(), abs(b[1][j]))
+        assert np.abs(a[0][j] - b[0][j]).max() <= 1e-6 * scale and abs(a[1][j] - b[1][j]) <= 1e-6 * scale, j
+        assert np.array_equal(a[0][j] != 0, b[0][j] != 0), j      # the same support
+
+
 def test_l1_logreg_gram_global_form_on_the_2048_x_907_grid(ctx, monkeypatch):
     """the grid of a 2,048-genome run whose 1,000 selected k-mers have 907 distinct patterns (143 fits; at
     C >= 100 every coefficient ends non-zero, the slowest fit takes ~3,500 sweeps of 907 coordinates).  The Gram form in
