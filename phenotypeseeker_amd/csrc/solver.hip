@@ -1859,7 +1859,11 @@ extern "C" int psk_logreg_l1_fit(psk_ctx *ctx, const float *X, const int32_t *y0
         if (P1 > 192 && P1 <= 1024 && wmreg_h > 0 && SV_COOP_WAVES == 4 && !getenv("PSK_NO_GRAM") && !getenv("PSK_NO_GRAM_GLOBAL")) {
             const size_t sl = 256 * (((size_t)P1 + 255) / 256), np_h = (size_t)W * 64;
             const size_t need = (4 * sl + np_h + sl / 2 + sl / 4 + sl / 8) * 8 + 8192, stride = (((size_t)P1 + 15) / 16 * 16) * sl;
-            if (fa + need <= lds_max && (size_t)n_fits * stride * 4 <= ((size_t)32 << 30)) { gg_sl = (int)sl; gg_stride = stride; gg_lds = need; }
+            if (fa + need <= lds_max && (size_t)n_fits * stride * 4 <= ((size_t)32 << 30)) {
+                // (a device too full for the Gram matrices keeps the array form: slower, the same optimum)
+                if (hipMalloc(&b.ggq, (size_t)n_fits * stride * 4) == hipSuccess) { gg_sl = (int)sl; gg_stride = stride; gg_lds = need; }
+                else { (void)hipGetLastError(); b.ggq = nullptr; }
+            }
         }
         const bool gram = !getenv("PSK_NO_GRAM") && gg_sl == 0;
         const size_t pq = (size_t)(p + 1) < 192 ? (size_t)(p + 1) : 192;   // Gram columns the kernel can use
@@ -1899,7 +1903,6 @@ extern "C" int psk_logreg_l1_fit(psk_ctx *ctx, const float *X, const int32_t *y0
         if (gg_sl) q_doubles = gg_lds / 8;
         const size_t qbytes = q_doubles * 8;
         const int q_lds = q_doubles > 0;
-        if (gg_sl) SV_ALLOC(b.ggq, (size_t)n_fits * gg_stride * 4);
         const size_t lds_b = s_in_lds + qbytes + (f_lds ? fa : 0) + (c_lds ? cbytes : 0);
         std::vector<uint64_t> bits((size_t)(p + 1) * W, 0);
         for (int i = 0; i < n; i++) {
