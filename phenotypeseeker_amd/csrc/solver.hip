@@ -582,9 +582,10 @@ __global__ __launch_bounds__(WMREG > 0 ? SV_COOP_THREADS : SV_THREADS) void logr
     uint16_t *ggOrd = reinterpret_cast<uint16_t *>(Qm + 4 * (size_t)SL + NP);
     uint16_t *ggFeat = ggOrd + 2 * (size_t)SL;
     double *ggPub = reinterpret_cast<double *>(ggFeat + SL);   // [2]: g[m'] | Q[m'][m''], Q[m'][m] (two floats) for the visit of that parity
-    double *ggZG = ggPub + 4;                                  // [2][2]: the step and G of the visit of that parity
+    double *ggZG = ggPub + 4;                                  // [2][6]: the step, G, and for wave 3 the slot's 1 / H and w before the step, the slot
     typedef uint32_t u4 __attribute__((ext_vector_type(4)));
     u4 *ggT1 = reinterpret_cast<u4 *>(reinterpret_cast<uint8_t *>(ggFeat + SL) + SL), *ggT2 = ggT1 + 256;   // byte -> eight bf16 ones / masks
+    float *ggCol = reinterpret_cast<float *>(ggT2 + 256);   // [2 owner waves][2 parities][64 lanes x 8]: a visit's column, the owner's rows
     float *Qg = gg_q + (size_t)fit * gg_stride;
     auto gg_run = [&]() __attribute__((always_inline)) -> int {
 #ifndef PSK_GG_DEPTH
@@ -638,7 +639,8 @@ __global__ __launch_bounds__(WMREG > 0 ? SV_COOP_THREADS : SV_THREADS) void logr
                     ggT2[b] = u4{msk[0], msk[1], msk[2], msk[3]};
                 }
             }
-            if (tid < 8) ggPub[tid] = 0.0;
+            if (tid < 16) ggPub[tid] = 0.0;
+            for (int i = tid; i < 2048; i += SV_COOP_THREADS) ggCol[i] = 0.f;   // (the column "before the first visit")
         }
         __syncthreads();
         {   // Q: tile (kb, mb) = 16 x 16 slots; a work item = tile row kb x four tile columns, items dealt round the waves.
@@ -732,6 +734,8 @@ __global__ __launch_bounds__(WMREG > 0 ? SV_COOP_THREADS : SV_THREADS) void logr
             // same model), so that this loop's only exit is at the top of a round.)
             const int h = __builtin_amdgcn_readfirstlane(wave) - 1, rmax = (SL >> 8) - 1;
             const int r0 = min(2 * h, rmax), r1 = min(2 * h + 1, rmax);
+            int dzo;
+            asm volatile("v_mov_b32 %0, 0" : "=v"(dzo));   // (keeps the two LDS reads of a pick per-lane loads: no scalar detour)
             d8 go;   // g of the slots 256 (2 h + (e >> 2)) + 4 lane + (e & 3)
 #pragma unroll
             for (int e = 0; e < 8; e++) {
@@ -776,17 +780,25 @@ __global__ __launch_bounds__(WMREG > 0 ? SV_COOP_THREADS : SV_THREADS) void logr
                 for (int u = 0; u < DEPTH; u++) {   // visit T + u
                     GG_BARRIER();
                     if (u == 0 && T == __builtin_amdgcn_readfirstlane(s_gg.stop_at)) goto owners_done;
-                    const double z = ggZG[2 * ((u + 1) & 1)];   // of visit T + u - 1: asked for now, applied last
+                    const double z = ggZG[6 * ((u + 1) & 1)];   // of visit T + u - 1: asked for now, applied last
                     const f8 prev = u > 0 ? a[u > 0 ? u - 1 : 0] : lst;   // the column of that visit's slot
                     // for visit T + u + 1 (slot mn): g[mn] BEFORE that step, Q[mn][slot of T + u - 1] and Q[mn][slot of T + u]:
                     // wave 0 adds the two steps it knows by then
                     const int mn = u + 1 < DEPTH ? ma[u + 1 < DEPTH ? u + 1 : 0] : mb[0];
+                    // The two entries of Q come out of LDS: this wave's eight floats per lane of the visit's column go into a
+                    // 2-KB buffer (two of them, by the visit's parity: the previous visit's column is still in the other), and
+                    // the wanted element is ONE uniform read.  Picking it from the registers is a seven-deep select per
+                    // column -- the compiler expands a run-time index into eight floats to v_cndmask chains, 28 instructions
+                    // for the two -- and made these waves the slowest of the four.  (__builtin_bit_cast(int, vec[e]) with a
+                    // run-time e compiles to element 0 with this hipcc: r03's first versions ran on Q[m'][.] of the wrong
+                    // row for hours and converged all the same -- the outer Newton loop is forgiving.)
+                    float *cb_cur = ggCol + (h * 2 + (u & 1)) * 512, *cb_prev = ggCol + (h * 2 + ((u + 1) & 1)) * 512;
+                    *reinterpret_cast<f8 *>(cb_cur + 8 * lane) = a[u];
                     if ((mn >> 9) == h) {
                         const int e = ((mn >> 6) & 4) | (mn & 3), ln = (mn >> 2) & 63;
                         const double gv = psk_readlane_f64(go[e], ln);
-                        const int q1 = __builtin_amdgcn_readlane(__builtin_bit_cast(int, prev[e]), ln);
-                        const int q2 = __builtin_amdgcn_readlane(__builtin_bit_cast(int, a[u][e]), ln);
-                        if (lane == 0) *reinterpret_cast<u4 *>(ggPub + 2 * ((u + 1) & 1)) = u4{(uint32_t)__double2loint(gv), (uint32_t)__double2hiint(gv), (uint32_t)q1, (uint32_t)q2};
+                        const float q1f = cb_prev[8 * ln + e + dzo], q2f = cb_cur[8 * ln + e + dzo];
+                        if (lane == 0) *reinterpret_cast<u4 *>(ggPub + 2 * ((u + 1) & 1)) = u4{(uint32_t)__double2loint(gv), (uint32_t)__double2hiint(gv), __float_as_uint(q1f), __float_as_uint(q2f)};
                     }
                     // (a zero step takes the same instructions: a branch costs more than eight multiply-adds; explicit fma:
                     // the file is built with -ffp-contract=off)
@@ -814,18 +826,17 @@ __global__ __launch_bounds__(WMREG > 0 ? SV_COOP_THREADS : SV_THREADS) void logr
             auto vmax = [](double x, double y) __attribute__((always_inline)) { double r; asm("v_max_f64 %0, %1, %2" : "=v"(r) : "v"(x), "v"(y)); return r; };
             uint32_t r32 = rng;
             int sweeps = 0, nshrunk = 0;
-            int k2 = 0, p2 = 2;   // where the order entry of visit T + 2 is
-            int mprev = 0, mcur = ggOrd[0], mn1 = ggOrd[1];
-            d2 Pa = d2{0.0, 0.0}, Pb = *reinterpret_cast<const d2 *>(ggP + 2 * (size_t)mcur + dz);
+            int k2 = 0, p2 = 2;   // sweep and position of visit T + 2 (p2 == 2: visit T is the first of sweep k2)
             double Gmax = 0.0, Gnorm1 = 0.0, Gmax_old = 1e300, omt = -1e300;
             int stop_at = -1;
             for (int T = 0;; T++) {
                 GG_BARRIER();
                 if (T == stop_at) break;
-                const int mn2 = ggOrd[(k2 & 1) * SL + p2];
-                d2 Pc = *reinterpret_cast<const d2 *>(ggP + 2 * (size_t)mn1 + dz);   // of visit T + 1, before its step
-                {   // visit T - 1 (slot mprev, parameters Pa; at T = 0 a slot with 1 / H = 0 and G = 0: nothing)
-                    const double G = ggZG[2 * ((T + 1) & 1) + 1 + dz];
+                {   // visit T - 1, as wave 0 left it: G, the slot's 1 / H and w before the step, the slot (at T = 0 zeros: nothing)
+                    const double *rec = ggZG + 6 * ((T + 1) & 1) + dz;
+                    const d2 zg = *reinterpret_cast<const d2 *>(rec), Pa = *reinterpret_cast<const d2 *>(rec + 2);
+                    const int mprev = reinterpret_cast<const int *>(rec + 4)[0];
+                    const double G = zg[1];
                     const double Hi = Pa[0], wp = Pa[1], aG = fabs(G);
                     const bool live = Hi != 0.0, zero = wp == 0.0;
                     const bool shrink = live && zero && aG < omt;   // out of the sweeps until the whole set is taken up again
@@ -846,9 +857,7 @@ __global__ __launch_bounds__(WMREG > 0 ? SV_COOP_THREADS : SV_THREADS) void logr
                             else {
                                 nshrunk = 0;
                                 Gmax_old = 1e300;
-                                for (int u2 = lane; u2 < A; u2 += 64) ggP[2 * (size_t)u2] = 1.0 / ggH[u2];
-                                if (Pb[0] == 0.0) Pb[0] = 1.0 / ggH[mcur];   // (the copies held for the next two visits)
-                                if (Pc[0] == 0.0) Pc[0] = 1.0 / ggH[mn1];
+                                for (int u2 = lane; u2 < A; u2 += 64) ggP[2 * (size_t)u2] = 1.0 / ggH[u2];   // (wave 0 may have asked for one of these a moment ago: that visit is then skipped once more)
                             }
                         } else Gmax_old = gmax;
                         omt = 1.0 - Gmax_old / l_c;
@@ -896,9 +905,7 @@ __global__ __launch_bounds__(WMREG > 0 ? SV_COOP_THREADS : SV_THREADS) void logr
                         if (f0 == ggOrd[(k2 & 1) * SL + A - 1]) { on[0] = f1; on[1] = f0; }
                     }
                 }
-                if (++p2 == A) { p2 = 0; k2++; }
-                mprev = mcur; mcur = mn1; mn1 = mn2;
-                Pa = Pb; Pb = Pc;
+                if (__builtin_expect(++p2 == A, 0)) { p2 = 0; k2++; }
             }
             rng = r32;
             if (lane == 0) { s_gg.last_A = A; s_gg.par = (p2 >= 2 ? k2 : k2 - 1) & 1; }   // the order of the sweep under way: complete
@@ -921,6 +928,9 @@ __global__ __launch_bounds__(WMREG > 0 ? SV_COOP_THREADS : SV_THREADS) void logr
             auto vmax = [](double x, double y) __attribute__((always_inline)) { double r; asm("v_max_f64 %0, %1, %2" : "=v"(r) : "v"(x), "v"(y)); return r; };
             auto vmin = [](double x, double y) __attribute__((always_inline)) { double r; asm("v_min_f64 %0, %1, %2" : "=v"(r) : "v"(x), "v"(y)); return r; };
             double zprev = 0.0, zprev2 = 0.0;
+#ifdef PSK_GG_CHECK
+            int gg_chk = 0;
+#endif
             int wk = 0, wp0 = 0, wl = 2, wend = min(64, A);   // the window: sweep, position of lane 0's entry, next lane, lanes in use
             int ordv = ggOrd[min(lane, A - 1)];
             int m = __builtin_amdgcn_readlane(ordv, 0), m1 = __builtin_amdgcn_readlane(ordv, 1);
@@ -933,11 +943,21 @@ __global__ __launch_bounds__(WMREG > 0 ? SV_COOP_THREADS : SV_THREADS) void logr
                 const d2 P1n = *reinterpret_cast<const d2 *>(ggP + 2 * (size_t)m1 + dz);   // for the next visit (never this visit's slot: see wave 3)
                 const double Hi = P[0], wp = P[1];
                 const double G = fma(zprev, (double)__int_as_float(__double2hiint(pubd[1])), fma(zprev2, (double)__int_as_float(__double2loint(pubd[1])), pubd[0]));
+#ifdef PSK_GG_CHECK
+                if (fit == 0 && (gg_chk++ % 1009) == 0 && gg_chk < 60000) {   // G against its definition Gr[m] + sum_k Q[k][m] d_k
+                    double acc = 0.0;
+                    for (int kk = lane; kk < A; kk += 64) acc += (double)Qg[(size_t)m * SL + kk] * (ggP[2 * (size_t)kk + 1] - w[ggFeat[kk]]);
+                    acc = psk_wave_sum_f64_dpp(acc) + Gr[ggFeat[m]];
+                    if (lane == 0) printf("gg check: visit %d slot %d G %.12e true %.12e diff %.3e\n", gg_chk, m, G, acc, G - acc);
+                }
+#endif
                 const double u = fma(-G, Hi, wp);
                 const double wnew = u - vmin(vmax(u, -Hi), Hi);
                 const double z = vmin(vmax(wnew - wp, -10.0), 10.0);
                 if (lane == 0) {
-                    *reinterpret_cast<d2 *>(ggZG + 2 * par) = d2{z, G};
+                    *reinterpret_cast<d2 *>(ggZG + 6 * par) = d2{z, G};
+                    *reinterpret_cast<d2 *>(ggZG + 6 * par + 2) = P;          // for wave 3: the slot's parameters before the step
+                    reinterpret_cast<int *>(ggZG + 6 * par + 4)[0] = m;       // ... and the slot
                     ggP[2 * (size_t)m + 1] = wp + z;
                 }
                 zprev2 = zprev;
@@ -945,7 +965,7 @@ __global__ __launch_bounds__(WMREG > 0 ? SV_COOP_THREADS : SV_THREADS) void logr
                 P = P1n;
                 m = m1;
                 m1 = __builtin_amdgcn_readlane(ordv, wl);   // the entry after next
-                if (++wl == wend) {   // the window is used up: the next 64 entries of this sweep, or the head of the next sweep's order
+                if (__builtin_expect(++wl == wend, 0)) {   // the window is used up: the next 64 entries of this sweep, or the head of the next sweep's order
                     wp0 += 64;
                     if (wp0 >= A) { wk++; wp0 = 0; }
                     wl = 0;
@@ -1858,7 +1878,8 @@ extern "C" int psk_logreg_l1_fit(psk_ctx *ctx, const float *X, const int32_t *y0
         size_t gg_stride = 0, gg_lds = 0;
         if (P1 > 192 && P1 <= 1024 && wmreg_h > 0 && SV_COOP_WAVES == 4 && !getenv("PSK_NO_GRAM") && !getenv("PSK_NO_GRAM_GLOBAL")) {
             const size_t sl = 256 * (((size_t)P1 + 255) / 256), np_h = (size_t)W * 64;
-            const size_t need = (4 * sl + np_h + sl / 2 + sl / 4 + sl / 8) * 8 + 8192, stride = (((size_t)P1 + 15) / 16 * 16) * sl;
+            // (+ the build's tables / wave 3's counters, + the owners' column buffers)
+            const size_t need = (4 * sl + np_h + sl / 2 + sl / 4 + sl / 8) * 8 + 8192 + 8192, stride = (((size_t)P1 + 15) / 16 * 16) * sl;
             if (fa + need <= lds_max && (size_t)n_fits * stride * 4 <= ((size_t)32 << 30)) {
                 // (a device too full for the Gram matrices keeps the array form: slower, the same optimum)
                 if (hipMalloc(&b.ggq, (size_t)n_fits * stride * 4) == hipSuccess) { gg_sl = (int)sl; gg_stride = stride; gg_lds = need; }
