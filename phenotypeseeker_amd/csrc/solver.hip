@@ -794,16 +794,22 @@ __global__ __launch_bounds__(WMREG > 0 ? SV_COOP_THREADS : SV_THREADS) void logr
                     // row for hours and converged all the same -- the outer Newton loop is forgiving.)
                     float *cb_cur = ggCol + (h * 2 + (u & 1)) * 512, *cb_prev = ggCol + (h * 2 + ((u + 1) & 1)) * 512;
                     *reinterpret_cast<f8 *>(cb_cur + 8 * lane) = a[u];
-                    if ((mn >> 9) == h) {
+                    const bool own = (mn >> 9) == h;
+                    double gv = 0.0;
+                    float q1f = 0.f, q2f = 0.f;
+                    if (own) {   // g[mn] before the step below; the two reads come back while the step is applied
                         const int e = ((mn >> 6) & 4) | (mn & 3), ln = (mn >> 2) & 63;
-                        const double gv = psk_readlane_f64(go[e], ln);
-                        const float q1f = cb_prev[8 * ln + e + dzo], q2f = cb_cur[8 * ln + e + dzo];
-                        if (lane == 0) *reinterpret_cast<u4 *>(ggPub + 2 * ((u + 1) & 1)) = u4{(uint32_t)__double2loint(gv), (uint32_t)__double2hiint(gv), __float_as_uint(q1f), __float_as_uint(q2f)};
+                        gv = psk_readlane_f64(go[e], ln);
+                        q1f = cb_prev[8 * ln + e + dzo];
+                        q2f = cb_cur[8 * ln + e + dzo];
                     }
                     // (a zero step takes the same instructions: a branch costs more than eight multiply-adds; explicit fma:
                     // the file is built with -ffp-contract=off)
 #pragma unroll
                     for (int e = 0; e < 8; e++) go[e] = fma(z, (double)prev[e], go[e]);
+                    __builtin_amdgcn_sched_barrier(0);   // (the compiler would hoist the publication -- and its wait for the two reads -- above the step)
+                    if (own && lane == 0)
+                        *reinterpret_cast<u4 *>(ggPub + 2 * ((u + 1) & 1)) = u4{(uint32_t)__double2loint(gv), (uint32_t)__double2hiint(gv), __float_as_uint(q1f), __float_as_uint(q2f)};
                 }
                 lst = a[DEPTH - 1];
 #pragma unroll
