@@ -581,15 +581,15 @@ __global__ __launch_bounds__(WMREG > 0 ? SV_COOP_THREADS : SV_THREADS) void logr
     uint16_t *ggDs = reinterpret_cast<uint16_t *>(Qm + 4 * (size_t)SL);   // D of the training samples as two bf16 parts [2][NP]
     uint16_t *ggOrd = reinterpret_cast<uint16_t *>(Qm + 4 * (size_t)SL + NP);
     uint16_t *ggFeat = ggOrd + 2 * (size_t)SL;
-    double *ggPub = reinterpret_cast<double *>(ggFeat + SL);   // [2]: g[m'] | Q[m'][m''], Q[m'][m] (two floats) for the visit of that parity
-    double *ggZG = ggPub + 4;                                  // [2][6]: the step, G, and for wave 3 the slot's 1 / H and w before the step, the slot
+    double *ggPub = reinterpret_cast<double *>(ggFeat + SL);   // [2][6]: for the pair of that interval's parity: g[c] | Q[c][a], Q[c][b] ; g[d] | Q[d][a], Q[d][b] ; Q[d][c]
+    double *ggZG = ggPub + 12;                                 // [2][10]: wave 0's record of an interval (ggRec below)
     typedef uint32_t u4 __attribute__((ext_vector_type(4)));
     u4 *ggT1 = reinterpret_cast<u4 *>(reinterpret_cast<uint8_t *>(ggFeat + SL) + SL), *ggT2 = ggT1 + 256;   // byte -> eight bf16 ones / masks
-    float *ggCol = reinterpret_cast<float *>(ggT2 + 256);   // [2 owner waves][2 parities][64 lanes x 8]: a visit's column, the owner's rows
+    float *ggCol = reinterpret_cast<float *>(ggT2 + 256);   // [2 owner waves][2 parities][2 of a pair][64 lanes x 8]: a ticket's column, the owner's rows
     float *Qg = gg_q + (size_t)fit * gg_stride;
     auto gg_run = [&]() __attribute__((always_inline)) -> int {
 #ifndef PSK_GG_DEPTH
-#define PSK_GG_DEPTH 8
+#define PSK_GG_DEPTH 16
 #endif
         constexpr int DEPTH = PSK_GG_DEPTH;   // (a power of two)
         typedef float f4 __attribute__((ext_vector_type(4)));
@@ -639,8 +639,8 @@ __global__ __launch_bounds__(WMREG > 0 ? SV_COOP_THREADS : SV_THREADS) void logr
                     ggT2[b] = u4{msk[0], msk[1], msk[2], msk[3]};
                 }
             }
-            if (tid < 16) ggPub[tid] = 0.0;
-            for (int i = tid; i < 2048; i += SV_COOP_THREADS) ggCol[i] = 0.f;   // (the column "before the first visit")
+            if (tid < 32) ggPub[tid] = 0.0;
+            for (int i = tid; i < 4096; i += SV_COOP_THREADS) ggCol[i] = 0.f;
         }
         __syncthreads();
         {   // Q: tile (kb, mb) = 16 x 16 slots; a work item = tile row kb x four tile columns, items dealt round the waves.
@@ -722,20 +722,27 @@ __global__ __launch_bounds__(WMREG > 0 ? SV_COOP_THREADS : SV_THREADS) void logr
 #define GG_BARRIER() do { __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup", "local"); __builtin_amdgcn_s_barrier(); \
                           __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup", "local"); } while (0)
 #endif
+        // ---- TWO visits per barrier interval.  Interval I steps the slots of tickets a = 2 I and b = 2 I + 1 (ticket T = the
+        // T-th visit of this descent = sweep T / A, position T % A).  What one interval costs beside its instructions -- the
+        // barrier, an LDS round trip per hand-over, the drain of the writes before the barrier -- is paid once for two steps.
+        // During interval I: wave 0 steps a and b from what the owners left in interval I - 1; the owners apply the steps of
+        // pair I - 1 and leave, for pair I + 1 (tickets c, d), g[c], g[d] as they then are -- two steps behind c, three
+        // behind d -- with the entries of Q that link them to a, b (and d to c); wave 3 books pair I - 1.
+        double *ggRec = ggZG;   // [2][10]: z_a z_b | G_a G_b | (1/H, w)_a | (1/H, w)_b | slots a, b -- by the interval's parity
         if (wave == 1 || wave == 2) {
-            // ---- owners of g and of the columns.  Ticket T = the T-th visit of this descent = (sweep T / A, position T % A).
-            // Two register sets of DEPTH tickets: `a` is complete and used one ticket per visit, `b` is loaded in ONE burst
-            // at the top of a round of DEPTH visits and becomes `a` at its end, so a column is DEPTH to 2 DEPTH - 1 visits old when
-            // it is due; the only place that waits for memory is the copy, where the loads are a whole round old.  (A rotating
-            // single set, one load issued per visit, is what one would write; the compiler's count of loads in flight does
-            // not survive the loop it makes of it -- rotated, exits merged -- and it drained the queue, vmcnt(0), every
-            // visit.  For the same reason both groups are always loaded -- clamped to the last group of the slot arrays,
-            // a duplicate at worst -- and the descent ends at a ticket that is a multiple of DEPTH (a few more steps on the
-            // same model), so that this loop's only exit is at the top of a round.)
+            // ---- owners of g and of the columns.  Two register sets of DEPTH tickets: `a` is complete and used two tickets per
+            // interval, `b` is loaded in ONE burst at the top of a round of DEPTH / 2 intervals and becomes `a` at its end,
+            // so a column is DEPTH to 2 DEPTH - 1 visits old when it is due; the only place that waits for memory is the
+            // copy, where the loads are a whole round old.  (A rotating single set, one load issued per visit, is what one
+            // would write; the compiler's count of loads in flight does not survive the loop it makes of it -- rotated, exits
+            // merged -- and it drained the queue, vmcnt(0), every visit.  For the same reason both groups are always loaded
+            // -- clamped to the last group of the slot arrays, a duplicate at worst -- and the descent ends at a ticket that
+            // is a multiple of DEPTH (a few more steps on the same model), so that this loop's only exit is at the top of a
+            // round.)
             const int h = __builtin_amdgcn_readfirstlane(wave) - 1, rmax = (SL >> 8) - 1;
             const int r0 = min(2 * h, rmax), r1 = min(2 * h + 1, rmax);
             int dzo;
-            asm volatile("v_mov_b32 %0, 0" : "=v"(dzo));   // (keeps the two LDS reads of a pick per-lane loads: no scalar detour)
+            asm volatile("v_mov_b32 %0, 0" : "=v"(dzo));   // (keeps the LDS reads of a pick per-lane loads: no scalar detour)
             d8 go;   // g of the slots 256 (2 h + (e >> 2)) + 4 lane + (e & 3)
 #pragma unroll
             for (int e = 0; e < 8; e++) {
@@ -762,7 +769,10 @@ __global__ __launch_bounds__(WMREG > 0 ? SV_COOP_THREADS : SV_THREADS) void logr
                 x = f8{x0.x, x0.y, x0.z, x0.w, x1.x, x1.y, x1.z, x1.w};
                 mm = m;
             };
-            f8 a[DEPTH], b[DEPTH], lst = f8{0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+            // this wave's rows of a ticket's column, in LDS for the picks: [parity of the interval that wrote it][first / second
+            // of its pair]: interval I writes the columns of pair I + 1, those of pair I (written by I - 1) are still there
+            auto colbuf = [&](int par, int which) __attribute__((always_inline)) { return ggCol + ((h * 2 + par) * 2 + which) * 512; };
+            f8 a[DEPTH], b[DEPTH], l0 = f8{0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f}, l1 = l0;   // l0, l1: the last pair of the round before
             int ma[DEPTH], mb[DEPTH];
             {
                 const int ov = round_order();
@@ -770,6 +780,8 @@ __global__ __launch_bounds__(WMREG > 0 ? SV_COOP_THREADS : SV_THREADS) void logr
                 for (int u = 0; u < DEPTH; u++) issue(a[u], ma[u], ov, u);
             }
             __builtin_amdgcn_s_waitcnt(0x0F70);   // vmcnt(0): the first set is whole
+            *reinterpret_cast<f8 *>(colbuf(1, 0) + 8 * lane) = a[0];   // pair 0's columns, "written by interval -1"
+            *reinterpret_cast<f8 *>(colbuf(1, 1) + 8 * lane) = a[1];
             for (int T = 0;; T += DEPTH) {
                 {
                     const int ov = round_order();
@@ -777,73 +789,86 @@ __global__ __launch_bounds__(WMREG > 0 ? SV_COOP_THREADS : SV_THREADS) void logr
                     for (int u = 0; u < DEPTH; u++) issue(b[u], mb[u], ov, u);   // tickets T + DEPTH ... T + 2 DEPTH - 1
                 }
 #pragma unroll
-                for (int u = 0; u < DEPTH; u++) {   // visit T + u
+                for (int j = 0; j < DEPTH / 2; j++) {   // interval (T + 2 j) / 2: tickets T + 2 j, T + 2 j + 1 are being stepped
                     GG_BARRIER();
-                    if (u == 0 && T == __builtin_amdgcn_readfirstlane(s_gg.stop_at)) goto owners_done;
-                    const double z = ggZG[6 * ((u + 1) & 1)];   // of visit T + u - 1: asked for now, applied last
-                    const f8 prev = u > 0 ? a[u > 0 ? u - 1 : 0] : lst;   // the column of that visit's slot
-                    // for visit T + u + 1 (slot mn): g[mn] BEFORE that step, Q[mn][slot of T + u - 1] and Q[mn][slot of T + u]:
-                    // wave 0 adds the two steps it knows by then
-                    const int mn = u + 1 < DEPTH ? ma[u + 1 < DEPTH ? u + 1 : 0] : mb[0];
-                    // The two entries of Q come out of LDS: this wave's eight floats per lane of the visit's column go into a
-                    // 2-KB buffer (two of them, by the visit's parity: the previous visit's column is still in the other), and
-                    // the wanted element is ONE uniform read.  Picking it from the registers is a seven-deep select per
-                    // column -- the compiler expands a run-time index into eight floats to v_cndmask chains, 28 instructions
-                    // for the two -- and made these waves the slowest of the four.  (__builtin_bit_cast(int, vec[e]) with a
-                    // run-time e compiles to element 0 with this hipcc: r03's first versions ran on Q[m'][.] of the wrong
-                    // row for hours and converged all the same -- the outer Newton loop is forgiving.)
-                    float *cb_cur = ggCol + (h * 2 + (u & 1)) * 512, *cb_prev = ggCol + (h * 2 + ((u + 1) & 1)) * 512;
-                    *reinterpret_cast<f8 *>(cb_cur + 8 * lane) = a[u];
-                    const bool own = (mn >> 9) == h;
-                    double gv = 0.0;
-                    float q1f = 0.f, q2f = 0.f;
-                    if (own) {   // g[mn] before the step below; the two reads come back while the step is applied
-                        const int e = ((mn >> 6) & 4) | (mn & 3), ln = (mn >> 2) & 63;
-                        gv = psk_readlane_f64(go[e], ln);
-                        q1f = cb_prev[8 * ln + e + dzo];
-                        q2f = cb_cur[8 * ln + e + dzo];
+                    if (j == 0 && T == __builtin_amdgcn_readfirstlane(s_gg.stop_at)) goto owners_done;
+                    const int par = j & 1;   // (DEPTH / 2 is even: the parity of the interval is that of j)
+                    const d2 zz = *reinterpret_cast<const d2 *>(ggRec + 10 * (par ^ 1));   // the steps of the pair before: asked for now, applied below
+                    // the columns of the next pair go to LDS
+                    const f8 cn0 = 2 * j + 2 < DEPTH ? a[2 * j + 2 < DEPTH ? 2 * j + 2 : 0] : b[0];
+                    const f8 cn1 = 2 * j + 3 < DEPTH ? a[2 * j + 3 < DEPTH ? 2 * j + 3 : 0] : b[1];
+                    const int mc = 2 * j + 2 < DEPTH ? ma[2 * j + 2 < DEPTH ? 2 * j + 2 : 0] : mb[0];
+                    const int md = 2 * j + 3 < DEPTH ? ma[2 * j + 3 < DEPTH ? 2 * j + 3 : 0] : mb[1];
+                    *reinterpret_cast<f8 *>(colbuf(par, 0) + 8 * lane) = cn0;
+                    *reinterpret_cast<f8 *>(colbuf(par, 1) + 8 * lane) = cn1;
+                    // the entries of Q for the next pair: rows c and d of the columns of a, b (and row d of c's), asked for now
+                    const bool own_c = (mc >> 9) == h, own_d = (md >> 9) == h;
+                    const int ec = ((mc >> 6) & 4) | (mc & 3), lc = (mc >> 2) & 63, ed = ((md >> 6) & 4) | (md & 3), ld = (md >> 2) & 63;
+                    float q_ca = 0.f, q_cb = 0.f, q_da = 0.f, q_db = 0.f, q_dc = 0.f;
+                    if (own_c) {
+                        q_ca = colbuf(par ^ 1, 0)[8 * lc + ec + dzo];
+                        q_cb = colbuf(par ^ 1, 1)[8 * lc + ec + dzo];
                     }
-                    // (a zero step takes the same instructions: a branch costs more than eight multiply-adds; explicit fma:
-                    // the file is built with -ffp-contract=off)
+                    if (own_d) {
+                        q_da = colbuf(par ^ 1, 0)[8 * ld + ed + dzo];
+                        q_db = colbuf(par ^ 1, 1)[8 * ld + ed + dzo];
+                        q_dc = colbuf(par, 0)[8 * ld + ed + dzo];
+                    }
+                    // the steps of the pair before, on this wave's rows of THEIR columns (a zero step takes the same
+                    // instructions: a branch costs more than eight multiply-adds; explicit fma: -ffp-contract=off)
+                    const f8 p0 = j > 0 ? a[j > 0 ? 2 * j - 2 : 0] : l0, p1 = j > 0 ? a[j > 0 ? 2 * j - 1 : 0] : l1;
 #pragma unroll
-                    for (int e = 0; e < 8; e++) go[e] = fma(z, (double)prev[e], go[e]);
-                    __builtin_amdgcn_sched_barrier(0);   // (the compiler would hoist the publication -- and its wait for the two reads -- above the step)
-                    if (own && lane == 0)
-                        *reinterpret_cast<u4 *>(ggPub + 2 * ((u + 1) & 1)) = u4{(uint32_t)__double2loint(gv), (uint32_t)__double2hiint(gv), __float_as_uint(q1f), __float_as_uint(q2f)};
+                    for (int e = 0; e < 8; e++) go[e] = fma(zz[0], (double)p0[e], go[e]);
+#pragma unroll
+                    for (int e = 0; e < 8; e++) go[e] = fma(zz[1], (double)p1[e], go[e]);
+                    // g of the next pair's slots as it is now: two steps behind c, three behind d
+                    if (own_c) {
+                        const double gv = psk_readlane_f64(go[ec], lc);
+                        if (lane == 0) *reinterpret_cast<u4 *>(ggPub + 6 * par) = u4{(uint32_t)__double2loint(gv), (uint32_t)__double2hiint(gv), __float_as_uint(q_ca), __float_as_uint(q_cb)};
+                    }
+                    if (own_d) {
+                        const double gv = psk_readlane_f64(go[ed], ld);
+                        if (lane == 0) {
+                            *reinterpret_cast<u4 *>(ggPub + 6 * par + 2) = u4{(uint32_t)__double2loint(gv), (uint32_t)__double2hiint(gv), __float_as_uint(q_da), __float_as_uint(q_db)};
+                            reinterpret_cast<float *>(ggPub + 6 * par + 4)[0] = q_dc;
+                        }
+                    }
                 }
-                lst = a[DEPTH - 1];
+                l0 = a[DEPTH - 2]; l1 = a[DEPTH - 1];
 #pragma unroll
                 for (int u = 0; u < DEPTH; u++) { a[u] = b[u]; ma[u] = mb[u]; }
             }
         owners_done:
             // the last burst is still in flight: nothing may leave this block with loads pending on registers that the code
-            // after it reuses (without this wait the <false, 64> instance of the kernel faulted on its way out: r03)
+            // after it reuses
             __builtin_amdgcn_s_waitcnt(0x0F70);   // vmcnt(0)
         } else if (wave == 3) {
-            // ---- liblinear's bookkeeping, one visit behind the steps, and the next sweep's order.  Visit V's violation, its
-            // shrinking test (the marker 1 / H = 0 goes into the slot's place: the slot is visited again a sweep later at the
-            // earliest) and, after a sweep's last visit, the stopping rule -- all from G of the visit, which wave 0 leaves
-            // beside its step, and the slot's parameters as they were BEFORE the step (read two visits ahead of the step).  A
-            // verdict therefore takes effect a visit or two into the next sweep: the end of the descent at the next ticket
-            // that is a multiple of DEPTH (a few more coordinate steps on the same model), the return of the shrunk slots and
-            // the new shrinking threshold likewise.  The values pass through an address with an opaque zero added (see wave 0).
+            // ---- liblinear's books, one interval behind the steps, and the next sweep's order.  The violations of the two
+            // visits of pair I - 1, their shrinking tests (the marker 1 / H = 0 goes into the slot's place: the slot is visited
+            // again a sweep later at the earliest) and, after a sweep's last visit, the stopping rule -- all from the record
+            // wave 0 left: G of the visits and the slots' parameters as they were BEFORE the steps.  A verdict therefore takes
+            // effect a few visits into the next sweep: the end of the descent at the next ticket that is a multiple of DEPTH
+            // (a few more coordinate steps on the same model), the return of the shrunk slots and the new shrinking threshold
+            // likewise.  The values pass through an address with an opaque zero added (see wave 0).
             int dz;
             asm volatile("v_mov_b32 %0, 0" : "=v"(dz));
             auto vmax = [](double x, double y) __attribute__((always_inline)) { double r; asm("v_max_f64 %0, %1, %2" : "=v"(r) : "v"(x), "v"(y)); return r; };
             uint32_t r32 = rng;
             int sweeps = 0, nshrunk = 0;
-            int k2 = 0, p2 = 2;   // sweep and position of visit T + 2 (p2 == 2: visit T is the first of sweep k2)
+            int kq = 0, pq = -2;   // sweep and position of the FIRST visit of the pair being booked (pair I - 1; before the descent: none)
             double Gmax = 0.0, Gnorm1 = 0.0, Gmax_old = 1e300, omt = -1e300;
             int stop_at = -1;
-            for (int T = 0;; T++) {
+            bool gen = true;   // a sweep has begun whose successor's order is still to be drawn (the first sweep's, at once)
+            for (int I = 0;; I++) {
                 GG_BARRIER();
-                if (T == stop_at) break;
-                {   // visit T - 1, as wave 0 left it: G, the slot's 1 / H and w before the step, the slot (at T = 0 zeros: nothing)
-                    const double *rec = ggZG + 6 * ((T + 1) & 1) + dz;
-                    const d2 zg = *reinterpret_cast<const d2 *>(rec), Pa = *reinterpret_cast<const d2 *>(rec + 2);
-                    const int mprev = reinterpret_cast<const int *>(rec + 4)[0];
-                    const double G = zg[1];
-                    const double Hi = Pa[0], wp = Pa[1], aG = fabs(G);
+                if (2 * I == stop_at) break;
+                const double *rec = ggRec + 10 * ((I + 1) & 1) + dz;
+                const d2 GG = *reinterpret_cast<const d2 *>(rec + 2), Pa = *reinterpret_cast<const d2 *>(rec + 4), Pb = *reinterpret_cast<const d2 *>(rec + 6);
+                const int sa = reinterpret_cast<const int *>(rec + 8)[0], sb = reinterpret_cast<const int *>(rec + 8)[1];
+                bool sweep_ended = false;
+#pragma unroll
+                for (int v = 0; v < 2; v++) {   // the two visits of pair I - 1 (at I = 0 the record is zeros: 1 / H = 0, nothing)
+                    const double G = GG[v], Hi = v ? Pb[0] : Pa[0], wp = v ? Pb[1] : Pa[1], aG = fabs(G);
                     const bool live = Hi != 0.0, zero = wp == 0.0;
                     const bool shrink = live && zero && aG < omt;   // out of the sweeps until the whole set is taken up again
                     const double vz = vmax(aG - 1.0, 0.0), vn = fabs(G + copysign(1.0, wp));
@@ -851,10 +876,9 @@ __global__ __launch_bounds__(WMREG > 0 ? SV_COOP_THREADS : SV_THREADS) void logr
                     Gmax = vmax(Gmax, viol);
                     Gnorm1 += viol;
                     nshrunk += shrink ? 1 : 0;
-                    if (lane == 0 && shrink) ggP[2 * (size_t)mprev] = 0.0;
-                }
-                if (__builtin_expect(p2 == 2, 0)) {   // visit T is the first of sweep k2
-                    if (T > 0) {   // so T - 1 was the last of a sweep: liblinear's rule
+                    if (lane == 0 && shrink) ggP[2 * (size_t)(v ? sb : sa)] = 0.0;
+                    if (__builtin_expect(I > 0 && pq + v == A - 1, 0)) {   // that was the last visit of a sweep: liblinear's rule
+                        sweep_ended = true;
                         sweeps++;
                         bool stop = sweeps >= 1000;
                         const double gmax = psk_readlane_f64(Gmax, 0);
@@ -870,15 +894,27 @@ __global__ __launch_bounds__(WMREG > 0 ? SV_COOP_THREADS : SV_THREADS) void logr
                         Gmax = 0.0;
                         Gnorm1 = 0.0;
                         if (stop && stop_at < 0) {
-                            stop_at = __builtin_amdgcn_readfirstlane((T + 1 + DEPTH) & ~(DEPTH - 1));   // >= T + 2: every wave reads it behind a later barrier
+                            stop_at = __builtin_amdgcn_readfirstlane((2 * I + 2 + DEPTH) & ~(DEPTH - 1));   // > 2 I + 2: every wave reads it behind a later barrier
                             if (lane == 0) { s_gg.stop_at = stop_at; s_gg.iters = sweeps; }
                         }
                     }
-                    // the next sweep's order, whole (a few thousand cycles, once per sweep): the slots sorted by a random 11-bit
-                    // key -- histogram, offsets, scatter through LDS counters in the place of the build's tables; equal keys keep
-                    // the counters' order.  (A Fisher-Yates step per visit, r03's first version, is two dependent LDS round
-                    // trips: ~130 cycles of a wave that now has the visit's bookkeeping to do.)
-                    uint16_t *on = ggOrd + ((k2 + 1) & 1) * SL;
+                }
+                if (I > 0) {
+                    pq += 2;
+                    if (pq >= A) { pq -= A; kq++; }
+                } else pq = 0;
+                if (__builtin_expect(sweep_ended, 0)) gen = true;
+                if (__builtin_expect(gen, 0)) {
+                    // the order of the sweep after the one now under way, whole (a few thousand cycles, once per sweep): the slots
+                    // sorted by a random 11-bit key -- histogram, offsets, scatter through LDS counters in the place of the
+                    // build's tables; equal keys keep the counters' order.  (A Fisher-Yates step per visit, r03's first version,
+                    // is two dependent LDS round trips: ~130 cycles of a wave that has the visits' bookkeeping to do.)  The sweep
+                    // under way: the one the pair now being stepped (I) belongs to with its second visit.
+                    gen = false;
+                    int kc = kq, pc = pq + 1;   // pair I's second visit (pq is pair I's first by now)
+                    if (pc >= A) { pc -= A; kc++; }
+                    uint16_t *on = ggOrd + ((kc + 1) & 1) * SL;
+                    const uint16_t *oc = ggOrd + (kc & 1) * SL;
                     uint32_t *bins = reinterpret_cast<uint32_t *>(ggT1);   // 2048 counters
                     r32 ^= r32 << 13; r32 ^= r32 >> 17; r32 ^= r32 << 5;
                     const uint32_t seed = (uint32_t)__builtin_amdgcn_readfirstlane((int)r32);
@@ -904,73 +940,51 @@ __global__ __launch_bounds__(WMREG > 0 ? SV_COOP_THREADS : SV_THREADS) void logr
                         const int u = lane + 64 * e;
                         if (u < A) on[atomicAdd(&bins[keyv[e]], 1u)] = (uint16_t)u;
                     }
-                    // a sweep never starts on the slot the previous one ended on (a slot's parameters are read while the
-                    // previous visit writes its own)
+                    // a sweep's first two slots are none of the previous sweep's last two (a pair's parameters are asked for
+                    // while the pair before it is written)
                     if (lane == 0) {
-                        const uint16_t f0 = on[0], f1 = on[1];
-                        if (f0 == ggOrd[(k2 & 1) * SL + A - 1]) { on[0] = f1; on[1] = f0; }
+                        const uint16_t t0 = oc[A - 1], t1 = oc[A - 2];
+                        int cand = 2;
+                        for (int q = 0; q < 2; q++)
+                            while (on[q] == t0 || on[q] == t1) { const uint16_t x = on[q]; on[q] = on[cand]; on[cand] = x; cand++; }
                     }
                 }
-                if (__builtin_expect(++p2 == A, 0)) { p2 = 0; k2++; }
             }
             rng = r32;
-            if (lane == 0) { s_gg.last_A = A; s_gg.par = (p2 >= 2 ? k2 : k2 - 1) & 1; }   // the order of the sweep under way: complete
+            // the order of the sweep under way at the end is complete: the next Newton step starts from it
+            if (lane == 0) { s_gg.last_A = A; s_gg.par = kq & 1; }
         } else {
-            // ---- the steps.  G of the visit's slot = what its owner left (g two steps ago and the two entries of Q) plus the
-            // two steps since; the slot's 1 / H and w, requested a visit ahead; the soft-threshold form of liblinear's step:
-            // with u = w - G / H the minimiser of the one-variable model is u - clamp(u, -1 / H, 1 / H) -- the same point as
-            // its three-way rule, exactly 0 when |u| <= 1 / H, from 5 instructions instead of 12.  (Its skip of steps below
-            // 1e-12 saves the array form a pass over the samples; here a step costs the same whatever its size, so every step
-            // is taken.)  A shrunk slot has 1 / H = 0 in its place and w = 0, and its step comes out as exactly 0 from the same
-            // arithmetic (u = 0, clamp(0, -0, 0) = 0); so does the step of the visit that shrinks it (|G| < 1 - thr <= 1 means
-            // |u| <= 1 / H): this wave needs no flag at all -- violations, shrinking and the stopping rule are wave 3's.
-            // The order arrives 64 entries at a time in a register (lane i = the entry i places on).  Every lane computes the
-            // same step; the values pass through an address with an opaque zero added, so that the compiler takes them for
-            // lane-varying and builds selects: as wave-uniform values it made ~20 scalar branches per visit of the rule, and a
-            // v_cmp -> s_cbranch pair costs a lone wave 30 to 60 cycles (tools/_variants/ubench.hip, r03), a select 5.
+            // ---- the steps.  G of a slot = what its owner left (g some steps ago and the entries of Q that link it to the
+            // slots stepped since) plus those steps; the slot's 1 / H and w, requested an interval ahead; the soft-threshold
+            // form of liblinear's step: with u = w - G / H the minimiser of the one-variable model is
+            // u - clamp(u, -1 / H, 1 / H) -- the same point as its three-way rule, exactly 0 when |u| <= 1 / H, from 5
+            // instructions instead of 12.  (Its skip of steps below 1e-12 saves the array form a pass over the samples; here a
+            // step costs the same whatever its size, so every step is taken.)  A shrunk slot has 1 / H = 0 in its place and
+            // w = 0, and its step comes out as exactly 0 from the same arithmetic (u = 0, clamp(0, -0, 0) = 0); so does the
+            // step of the visit that shrinks it (|G| < 1 - thr <= 1 means |u| <= 1 / H): this wave needs no flag at all --
+            // violations, shrinking and the stopping rule are wave 3's.  The order arrives 64 entries at a time in a register
+            // (lane i = the entry i places on).  Every lane computes the same steps; the values pass through an address with
+            // an opaque zero added, so that the compiler takes them for lane-varying and builds selects: as wave-uniform
+            // values it made ~20 scalar branches per visit of the rule, and a v_cmp -> s_cbranch pair costs a lone wave 30 to
+            // 60 cycles (tools/_variants/ubench.hip, r03), a select 5.
             int dz;
             asm volatile("v_mov_b32 %0, 0" : "=v"(dz));
             // (v_max / v_min as they are: fmax() and fmin() first quieten their operands, an instruction each)
             auto vmax = [](double x, double y) __attribute__((always_inline)) { double r; asm("v_max_f64 %0, %1, %2" : "=v"(r) : "v"(x), "v"(y)); return r; };
             auto vmin = [](double x, double y) __attribute__((always_inline)) { double r; asm("v_min_f64 %0, %1, %2" : "=v"(r) : "v"(x), "v"(y)); return r; };
-            double zprev = 0.0, zprev2 = 0.0;
+            auto step = [&](double G, double Hi, double wp) __attribute__((always_inline)) {
+                const double u = fma(-G, Hi, wp);
+                const double wnew = u - vmin(vmax(u, -Hi), Hi);
+                return vmin(vmax(wnew - wp, -10.0), 10.0);
+            };
+            double zpa = 0.0, zpb = 0.0;   // the steps of the pair before
 #ifdef PSK_GG_CHECK
             int gg_chk = 0;
 #endif
             int wk = 0, wp0 = 0, wl = 2, wend = min(64, A);   // the window: sweep, position of lane 0's entry, next lane, lanes in use
             int ordv = ggOrd[min(lane, A - 1)];
-            int m = __builtin_amdgcn_readlane(ordv, 0), m1 = __builtin_amdgcn_readlane(ordv, 1);
-            d2 P = *reinterpret_cast<const d2 *>(ggP + 2 * (size_t)m + dz);
-            if (lane == 0) *reinterpret_cast<d2 *>(ggPub) = d2{Gr[ggFeat[m]], 0.0};   // visit 0: G = g[m] itself (no step before it)
-            // (a round of DEPTH visits per pass of the loop, like the owners: the end of the descent is looked for once per
-            // round, and the parity of a visit is a constant)
-            auto visit = [&](int par) __attribute__((always_inline)) {
-                const d2 pubd = *reinterpret_cast<const d2 *>(ggPub + 2 * par + dz);   // g[m] two steps ago | Q[m][m''], Q[m][m'] (two floats)
-                const d2 P1n = *reinterpret_cast<const d2 *>(ggP + 2 * (size_t)m1 + dz);   // for the next visit (never this visit's slot: see wave 3)
-                const double Hi = P[0], wp = P[1];
-                const double G = fma(zprev, (double)__int_as_float(__double2hiint(pubd[1])), fma(zprev2, (double)__int_as_float(__double2loint(pubd[1])), pubd[0]));
-#ifdef PSK_GG_CHECK
-                if (fit == 0 && (gg_chk++ % 1009) == 0 && gg_chk < 60000) {   // G against its definition Gr[m] + sum_k Q[k][m] d_k
-                    double acc = 0.0;
-                    for (int kk = lane; kk < A; kk += 64) acc += (double)Qg[(size_t)m * SL + kk] * (ggP[2 * (size_t)kk + 1] - w[ggFeat[kk]]);
-                    acc = psk_wave_sum_f64_dpp(acc) + Gr[ggFeat[m]];
-                    if (lane == 0) printf("gg check: visit %d slot %d G %.12e true %.12e diff %.3e\n", gg_chk, m, G, acc, G - acc);
-                }
-#endif
-                const double u = fma(-G, Hi, wp);
-                const double wnew = u - vmin(vmax(u, -Hi), Hi);
-                const double z = vmin(vmax(wnew - wp, -10.0), 10.0);
-                if (lane == 0) {
-                    *reinterpret_cast<d2 *>(ggZG + 6 * par) = d2{z, G};
-                    *reinterpret_cast<d2 *>(ggZG + 6 * par + 2) = P;          // for wave 3: the slot's parameters before the step
-                    reinterpret_cast<int *>(ggZG + 6 * par + 4)[0] = m;       // ... and the slot
-                    ggP[2 * (size_t)m + 1] = wp + z;
-                }
-                zprev2 = zprev;
-                zprev = z;
-                P = P1n;
-                m = m1;
-                m1 = __builtin_amdgcn_readlane(ordv, wl);   // the entry after next
+            auto next_slot = [&]() __attribute__((always_inline)) {
+                const int mnext = __builtin_amdgcn_readlane(ordv, wl);
                 if (__builtin_expect(++wl == wend, 0)) {   // the window is used up: the next 64 entries of this sweep, or the head of the next sweep's order
                     wp0 += 64;
                     if (wp0 >= A) { wk++; wp0 = 0; }
@@ -978,13 +992,65 @@ __global__ __launch_bounds__(WMREG > 0 ? SV_COOP_THREADS : SV_THREADS) void logr
                     wend = min(64, A - wp0);
                     ordv = ggOrd[(wk & 1) * SL + min(wp0 + lane, A - 1)];
                 }
+                return mnext;
+            };
+            int m_a = __builtin_amdgcn_readlane(ordv, 0), m_b = __builtin_amdgcn_readlane(ordv, 1);
+            d2 P_a = *reinterpret_cast<const d2 *>(ggP + 2 * (size_t)m_a + dz), P_b = *reinterpret_cast<const d2 *>(ggP + 2 * (size_t)m_b + dz);
+            if (lane == 0) {   // pair 0: g[a], g[b] themselves, and the one entry of Q that links b to a
+                *reinterpret_cast<d2 *>(ggPub + 6) = d2{Gr[ggFeat[m_a]], 0.0};
+                *reinterpret_cast<d2 *>(ggPub + 6 + 2) = d2{Gr[ggFeat[m_b]], 0.0};
+                reinterpret_cast<float *>(ggPub + 6 + 4)[0] = Qg[(size_t)m_a * SL + m_b];
+            }
+            // (a round of DEPTH / 2 intervals per pass of the loop, like the owners: the end of the descent is looked for once
+            // per round, and the parity of an interval is a constant)
+            auto interval = [&](int par) __attribute__((always_inline)) {
+                // what the owners left for this pair in the interval before: parity par ^ 1
+                const double *pub = ggPub + 6 * (par ^ 1) + dz;
+                const d2 ea = *reinterpret_cast<const d2 *>(pub), eb = *reinterpret_cast<const d2 *>(pub + 2);
+                const float q_ba = reinterpret_cast<const float *>(pub + 4)[0];
+                const int m_c = next_slot(), m_d = next_slot();
+                const d2 P_c = *reinterpret_cast<const d2 *>(ggP + 2 * (size_t)m_c + dz), P_d = *reinterpret_cast<const d2 *>(ggP + 2 * (size_t)m_d + dz);
+                const double G_a = fma(zpb, (double)__int_as_float(__double2hiint(ea[1])), fma(zpa, (double)__int_as_float(__double2loint(ea[1])), ea[0]));
+#ifdef PSK_GG_CHECK
+                if (fit == 0 && (gg_chk++ % 509) == 0 && gg_chk < 30000) {   // G against its definition Gr[m] + sum_k Q[k][m] d_k
+                    double acc = 0.0;
+                    for (int kk = lane; kk < A; kk += 64) acc += (double)Qg[(size_t)m_a * SL + kk] * (ggP[2 * (size_t)kk + 1] - w[ggFeat[kk]]);
+                    acc = psk_wave_sum_f64_dpp(acc) + Gr[ggFeat[m_a]];
+                    if (lane == 0) printf("gg check a: interval %d slot %d G %.12e true %.12e diff %.3e\n", gg_chk, m_a, G_a, acc, G_a - acc);
+                }
+#endif
+                const double z_a = step(G_a, P_a[0], P_a[1]);
+                const double G_b = fma(z_a, (double)q_ba, fma(zpb, (double)__int_as_float(__double2hiint(eb[1])), fma(zpa, (double)__int_as_float(__double2loint(eb[1])), eb[0])));
+#ifdef PSK_GG_CHECK
+                if (fit == 0 && (gg_chk % 509) == 1 && gg_chk < 30000) {   // the same for b: w of slot a is not written yet, its step is added by hand
+                    double acc = 0.0;
+                    for (int kk = lane; kk < A; kk += 64) acc += (double)Qg[(size_t)m_b * SL + kk] * (ggP[2 * (size_t)kk + 1] + (kk == m_a ? z_a : 0.0) - w[ggFeat[kk]]);
+                    acc = psk_wave_sum_f64_dpp(acc) + Gr[ggFeat[m_b]];
+                    if (lane == 0) printf("gg check b: interval %d slot %d G %.12e true %.12e diff %.3e\n", gg_chk, m_b, G_b, acc, G_b - acc);
+                }
+#endif
+                const double z_b = step(G_b, P_b[0], P_b[1]);
+                if (lane == 0) {
+                    double *rec = ggRec + 10 * par;
+                    *reinterpret_cast<d2 *>(rec) = d2{z_a, z_b};
+                    *reinterpret_cast<d2 *>(rec + 2) = d2{G_a, G_b};
+                    *reinterpret_cast<d2 *>(rec + 4) = P_a;
+                    *reinterpret_cast<d2 *>(rec + 6) = P_b;
+                    reinterpret_cast<int *>(rec + 8)[0] = m_a;
+                    reinterpret_cast<int *>(rec + 8)[1] = m_b;
+                    ggP[2 * (size_t)m_a + 1] = P_a[1] + z_a;
+                    ggP[2 * (size_t)m_b + 1] = P_b[1] + z_b;
+                }
+                zpa = z_a; zpb = z_b;
+                P_a = P_c; P_b = P_d;
+                m_a = m_c; m_b = m_d;
             };
             for (int T = 0;; T += DEPTH) {
 #pragma unroll
-                for (int u = 0; u < DEPTH; u++) {
+                for (int j = 0; j < DEPTH / 2; j++) {
                     GG_BARRIER();
-                    if (u == 0 && T == __builtin_amdgcn_readfirstlane(s_gg.stop_at)) goto steps_done;
-                    visit(u & 1);
+                    if (j == 0 && T == __builtin_amdgcn_readfirstlane(s_gg.stop_at)) goto steps_done;
+                    interval(j & 1);
                 }
             }
         steps_done:;
@@ -1885,7 +1951,7 @@ extern "C" int psk_logreg_l1_fit(psk_ctx *ctx, const float *X, const int32_t *y0
         if (P1 > 192 && P1 <= 1024 && wmreg_h > 0 && SV_COOP_WAVES == 4 && !getenv("PSK_NO_GRAM") && !getenv("PSK_NO_GRAM_GLOBAL")) {
             const size_t sl = 256 * (((size_t)P1 + 255) / 256), np_h = (size_t)W * 64;
             // (+ the build's tables / wave 3's counters, + the owners' column buffers)
-            const size_t need = (4 * sl + np_h + sl / 2 + sl / 4 + sl / 8) * 8 + 8192 + 8192, stride = (((size_t)P1 + 15) / 16 * 16) * sl;
+            const size_t need = (4 * sl + np_h + sl / 2 + sl / 4 + sl / 8) * 8 + 8192 + 16384, stride = (((size_t)P1 + 15) / 16 * 16) * sl;
             if (fa + need <= lds_max && (size_t)n_fits * stride * 4 <= ((size_t)32 << 30)) {
                 // (a device too full for the Gram matrices keeps the array form: slower, the same optimum)
                 if (hipMalloc(&b.ggq, (size_t)n_fits * stride * 4) == hipSuccess) { gg_sl = (int)sl; gg_stride = stride; gg_lds = need; }
