@@ -772,17 +772,18 @@ __global__ __launch_bounds__(WMREG > 0 ? SV_COOP_THREADS : SV_THREADS) void logr
             // this wave's rows of a ticket's column, in LDS for the picks: [parity of the interval that wrote it][first / second
             // of its pair]: interval I writes the columns of pair I + 1, those of pair I (written by I - 1) are still there
             auto colbuf = [&](int par, int which) __attribute__((always_inline)) { return ggCol + ((h * 2 + par) * 2 + which) * 512; };
-            f8 a[DEPTH], b[DEPTH], l0 = f8{0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f}, l1 = l0;   // l0, l1: the last pair of the round before
-            int ma[DEPTH], mb[DEPTH];
+            f8 sa_[DEPTH], sb_[DEPTH], l0 = f8{0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f}, l1 = l0;   // l0, l1: the last pair of the round before
+            int ma_[DEPTH], mb_[DEPTH];
             {
                 const int ov = round_order();
 #pragma unroll
-                for (int u = 0; u < DEPTH; u++) issue(a[u], ma[u], ov, u);
+                for (int u = 0; u < DEPTH; u++) issue(sa_[u], ma_[u], ov, u);
             }
             __builtin_amdgcn_s_waitcnt(0x0F70);   // vmcnt(0): the first set is whole
-            *reinterpret_cast<f8 *>(colbuf(1, 0) + 8 * lane) = a[0];   // pair 0's columns, "written by interval -1"
-            *reinterpret_cast<f8 *>(colbuf(1, 1) + 8 * lane) = a[1];
-            for (int T = 0;; T += DEPTH) {
+            *reinterpret_cast<f8 *>(colbuf(1, 0) + 8 * lane) = sa_[0];   // pair 0's columns, "written by interval -1"
+            *reinterpret_cast<f8 *>(colbuf(1, 1) + 8 * lane) = sa_[1];
+            // one round: the set `a` is used, the set `b` loaded; the two sets swap roles from round to round (no copy)
+            auto round = [&](f8 (&a)[DEPTH], int (&ma)[DEPTH], f8 (&b)[DEPTH], int (&mb)[DEPTH], int T) __attribute__((always_inline)) -> bool {
                 {
                     const int ov = round_order();
 #pragma unroll
@@ -791,7 +792,7 @@ __global__ __launch_bounds__(WMREG > 0 ? SV_COOP_THREADS : SV_THREADS) void logr
 #pragma unroll
                 for (int j = 0; j < DEPTH / 2; j++) {   // interval (T + 2 j) / 2: tickets T + 2 j, T + 2 j + 1 are being stepped
                     GG_BARRIER();
-                    if (j == 0 && T == __builtin_amdgcn_readfirstlane(s_gg.stop_at)) goto owners_done;
+                    if (j == 0 && T == __builtin_amdgcn_readfirstlane(s_gg.stop_at)) return true;
                     const int par = j & 1;   // (DEPTH / 2 is even: the parity of the interval is that of j)
                     const d2 zz = *reinterpret_cast<const d2 *>(ggRec + 10 * (par ^ 1));   // the steps of the pair before: asked for now, applied below
                     // the columns of the next pair go to LDS
@@ -835,8 +836,11 @@ __global__ __launch_bounds__(WMREG > 0 ? SV_COOP_THREADS : SV_THREADS) void logr
                     }
                 }
                 l0 = a[DEPTH - 2]; l1 = a[DEPTH - 1];
-#pragma unroll
-                for (int u = 0; u < DEPTH; u++) { a[u] = b[u]; ma[u] = mb[u]; }
+                return false;
+            };
+            for (int T = 0;; T += 2 * DEPTH) {
+                if (round(sa_, ma_, sb_, mb_, T)) break;
+                if (round(sb_, mb_, sa_, ma_, T + DEPTH)) break;
             }
         owners_done:
             // the last burst is still in flight: nothing may leave this block with loads pending on registers that the code
