@@ -554,20 +554,22 @@ __global__ __launch_bounds__(WMREG > 0 ? SV_COOP_THREADS : SV_THREADS) void logr
     // the gradient vector g = Gr + Q d it updates stays f64).  A visit is then one column of Q, the step z, and
     // g += z Q[:, m].  What a visit costs is INSTRUCTIONS: a lone wave issues one every 5.5 cycles at best, 8 when it
     // depends on the one before, and pays 30 to 60 cycles for every branch it takes or v_cmp it branches on
-    // (tools/_variants/ubench.hip, r03).  So the visit is divided over the fit's four waves, in lockstep -- one barrier per
-    // visit, nothing is polled -- and written without branches on the common path:
-    //   wave 0    the steps: G of the slot, the soft-threshold step, the new coefficient (~40 instructions);
+    // (tools/_variants/ubench.hip, r03).  So the visits are divided over the fit's four waves, in lockstep -- one barrier per
+    // TWO visits, nothing is polled -- and written without branches on the common path:
+    //   wave 0    the steps: G of the slot, the soft-threshold step, the new coefficient (~55 instructions per pair);
     //   waves 1,2 own g -- slots 256 r + 4 lane + c, r in {0, 1} and {2, 3}, eight doubles per lane -- AND fetch the columns:
-    //             the visiting order of a sweep is known in advance, so each keeps DEPTH visits' columns (its rows of them)
-    //             in registers and loads the next DEPTH in one burst per round; a column never passes through LDS.  During
-    //             visit T they publish, for the NEXT visit's slot m', g[m'] as it is (two steps behind) with Q[m'][m''] and
-    //             Q[m'][m] (s_set_gpr_idx + v_readlane), then apply the step of visit T - 1; wave 0 completes
-    //             G = g[m'] + z'' Q[m'][m''] + z Q[m'][m] itself: a step and the update it causes overlap;
-    //   wave 3    liblinear's books, one visit behind: violations, the shrinking test, the stopping rule after a sweep's last
-    //             visit; and the next sweep's random order, drawn whole at the sweep's first visit.
+    //             the visiting order of a sweep is known in advance, so each keeps DEPTH tickets' columns (its rows of them)
+    //             in registers and loads the next DEPTH in one burst per round; a column never passes through LDS on its way
+    //             to g.  In an interval they apply the steps of the pair before and leave, for the NEXT pair's slots, g as
+    //             it then is (s_set_gpr_idx + v_readlane) with the entries of Q that link those slots to the pair being
+    //             stepped (from small LDS copies of their rows of the columns concerned); wave 0 completes G itself: steps
+    //             and the updates they cause overlap;
+    //   wave 3    liblinear's books, one interval behind: violations, the shrinking test, the stopping rule after a sweep's
+    //             last visit; and the next sweep's random order, drawn whole when a sweep begins.
     // Same rule as liblinear for shrinking and stopping; a shrunk coordinate keeps its place in the order with 1 / H = 0 in
     // its place (its step is then exactly 0), so the order of a sweep never changes under the owners' feet.  No CG
-    // accelerator in this form.  2,048 x 907 grid: 3.3 s -> 0.91 s (tests/golden/fit2048_907.npz).
+    // accelerator in this form.  2,048 x 907 grid: 3.3 s -> 1.03 s (tests/golden/fit2048_907.npz); -DPSK_GG_CHECK prints G
+    // against its definition every few hundred visits (1e-12).
     struct GgShared { int stop_at, last_A, par, iters; };
     __shared__ GgShared s_gg;
 #ifdef PSK_SV_STATS

@@ -629,7 +629,7 @@ def test_l1_logreg_gram_global_form_on_the_2048_x_907_grid(ctx, monkeypatch):
     """the grid of a 2,048-genome run whose 1,000 selected k-mers have 907 distinct patterns (143 fits; at
     C >= 100 every coefficient ends non-zero, the slowest fit takes ~3,500 sweeps of 907 coordinates).  The Gram form in
     global memory must stop every fit by liblinear's rule, reach the objectives of the array form (which took 3.3 s), and
-    do so in about a second -- 0.9 s measured; the bound leaves room for a loaded box."""
+    do so in about a second -- 1.03 s measured; the bound leaves room for a loaded box."""
     import time
     d = np.load(os.path.join(GOLDEN, "fit2048_907.npz"))
     X = np.unpackbits(d["Xbits"], axis=1)[:, : int(d["p"])].astype(np.float32)
