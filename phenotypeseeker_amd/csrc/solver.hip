@@ -1070,7 +1070,97 @@ __global__ __launch_bounds__(WMREG > 0 ? SV_COOP_THREADS : SV_THREADS) void logr
 #endif
         __syncthreads();
         iter_c = s_gg.iters;
+        {   // x.d = X_A d for the line search: every wave its words of the samples (transposed columns, eight loads in
+            // flight), the additions of a sample in the order of the active list as the one-wave loop had them
+            constexpr int WMc = WMREG > 0 ? WMREG : 32, WQ = WMc / SV_COOP_WAVES;
+            const int t0 = wave * WQ;
+            uint64_t tmask = 0;
+            double Xr[WQ];
+#pragma unroll
+            for (int q = 0; q < WQ; q++) {
+                const int t = t0 + q, i = t * 64 + lane;
+                Xr[q] = 0.0;
+                if (t < W && i < n && fold[i] != tf) tmask |= 1ull << t;
+            }
+            for (int u0 = 0; u0 < A; u0 += 8) {
+                uint64_t x[8];
+                double dd[8];
+#pragma unroll
+                for (int c = 0; c < 8; c++) {
+                    const int u = u0 + c < A ? u0 + c : A - 1;
+                    const int f = ggFeat[u];
+                    dd[c] = u0 + c < A ? ggP[2 * (size_t)u + 1] - w[f] : 0.0;
+                    x[c] = (colT[(size_t)f * 64 + lane] & tmask) >> t0;
+                }
+#pragma unroll
+                for (int c = 0; c < 8; c++)
+#pragma unroll
+                    for (int q = 0; q < WQ; q++) Xr[q] += ((x[c] >> q) & 1ull) ? dd[c] : 0.0;
+            }
+#pragma unroll
+            for (int q = 0; q < WQ; q++)
+                if (t0 + q < W) xTd[(t0 + q) * 64 + lane] = Xr[q];
+            __syncthreads();
+        }
         return iter_c;
+    };
+    // The gradient pass at the top of a Newton step on the fit's four waves (gg form): wave v sums D and tau over its
+    // words of every column (build_coop's masks), SL / 4 columns between barriers, and the parts meet in the slot arrays
+    // of the gg area (free between descents: the visiting order kept for the next descent lies behind them).
+    // Wave 0 then walks the active list with the gradients in place -- liblinear's order, shrinking and sums.
+    auto grad_coop = [&](auto wm_tag) {
+        constexpr int WM = decltype(wm_tag)::value, WQ = WM / SV_COOP_WAVES;
+        const int t0 = wave * WQ, tid = threadIdx.x;
+        double Dq[WQ], Tq[WQ];
+        uint64_t tmask = 0;
+#pragma unroll
+        for (int q = 0; q < WQ; q++) {
+            const int t = t0 + q, i = t * 64 + lane;
+            const bool in = t < W;
+            Dq[q] = in ? D[i] : 0.0;
+            Tq[q] = in ? tau[i] : 0.0;
+            if (in && i < n && fold[i] != tf) tmask |= 1ull << t;
+        }
+        const int CH = SL / 4;   // (64 .. 256 columns: two buffers of 8 CH doubles = the 4 SL doubles of the slot arrays)
+        for (int c0 = 0, cpar = 0; c0 < P1; c0 += CH, cpar ^= 1) {
+            double *buf = Qm + (size_t)cpar * 8 * CH;   // [CH columns][4 waves]{sum of D, sum of tau}
+            const int cn = P1 - c0 < CH ? P1 - c0 : CH;
+            for (int u0 = 0; u0 < cn; u0 += 8) {
+                uint64_t x[8];
+#pragma unroll
+                for (int c = 0; c < 8; c++) {
+                    const int jj = c0 + u0 + c < P1 ? c0 + u0 + c : P1 - 1;
+                    x[c] = (colT[(size_t)jj * 64 + lane] & tmask) >> t0;
+                }
+#pragma unroll
+                for (int c = 0; c < 8; c++) {
+                    uint64_t M[WQ];
+#pragma unroll
+                    for (int q = 0; q < WQ; q++) M[q] = __ballot((x[c] >> q) & 1ull);
+                    double hd = 0.0, tm = 0.0;
+                    if (WQ == 16) {
+                        masked_sum8(hd, M, Dq); masked_sum8(hd, M + (WQ == 16 ? 8 : 0), Dq + (WQ == 16 ? 8 : 0));
+                        masked_sum8(tm, M, Tq); masked_sum8(tm, M + (WQ == 16 ? 8 : 0), Tq + (WQ == 16 ? 8 : 0));
+                    } else if (WQ == 8) { masked_sum8(hd, M, Dq); masked_sum8(tm, M, Tq); }
+                    else if (WQ == 4) { masked_sum4(hd, M, Dq); masked_sum4(tm, M, Tq); }
+                    else { masked_sum2(hd, M, Dq); masked_sum2(tm, M, Tq); }
+                    hd = psk_wave_sum_f64_dpp(hd);
+                    tm = psk_wave_sum_f64_dpp(tm);
+                    if (lane == 0 && u0 + c < cn) {
+                        buf[((size_t)(u0 + c) * 4 + wave) * 2] = hd;
+                        buf[((size_t)(u0 + c) * 4 + wave) * 2 + 1] = tm;
+                    }
+                }
+            }
+            __syncthreads();
+            if (tid < cn) {
+                const double *b = buf + (size_t)tid * 8;
+                const int j = c0 + tid;
+                Hd[j] = ((b[0] + b[2]) + (b[4] + b[6])) + nu;
+                Gr[j] = -((b[1] + b[3]) + (b[5] + b[7])) + xjneg[j];
+            }
+        }
+        __syncthreads();
     };
     if (WMREG > 0 && wave != 0) {   // helper_loop: waves 1..3 join every descent / column build of wave 0 and leave with it
         for (;;) {
@@ -1079,6 +1169,7 @@ __global__ __launch_bounds__(WMREG > 0 ? SV_COOP_THREADS : SV_THREADS) void logr
             if (cmd == 2) break;
             if (cmd == 3) build_coop(std::integral_constant<int, (WMREG > 0 ? WMREG : 32)>{});
             else if (cmd == 4) gg_run();
+            else if (cmd == 5) grad_coop(std::integral_constant<int, (WMREG > 0 ? WMREG : 32)>{});
             else cd_coop(std::integral_constant<int, (WMREG > 0 ? WMREG : 32)>{});
         }
         return;
@@ -1117,9 +1208,34 @@ __global__ __launch_bounds__(WMREG > 0 ? SV_COOP_THREADS : SV_THREADS) void logr
     for (newton = 0; newton < max_newton; newton++) {
         double Gmax_new = 0.0, Gnorm1_new = 0.0;
         int active = P1;
+        const bool grad4 = WMREG > 0 && gg_sl > 0 && f_lds;   // the four-wave pass (grad_coop)
+        if (grad4) {
+            if (lane == 0) s_cd.cmd = 5;
+            __syncthreads();   // releases waves 1..3 (helper_loop)
+            grad_coop(std::integral_constant<int, (WMREG > 0 ? WMREG : 32)>{});
+        }
         for (int sidx = 0; sidx < active; sidx++) {
             const int j = f_lds ? act[sidx] : __builtin_amdgcn_readfirstlane(lane == 0 ? act[sidx] : 0);
             double hd = 0.0, tmp = 0.0;
+            if (grad4) {
+                const double grad = Gr[j], wj = w[j];
+                const double Gp = grad + 1.0, Gn = grad - 1.0;
+                double viol = 0.0;
+                if (wj == 0.0) {
+                    if (Gp < 0) viol = -Gp;
+                    else if (Gn > 0) viol = Gn;
+                    else if (Gp > Gmax_old / l && Gn < -Gmax_old / l) {
+                        active--;
+                        if (lane == 0) { const int32_t tt = act[sidx]; act[sidx] = act[active]; act[active] = tt; }
+                        sidx--;
+                        continue;
+                    }
+                } else if (wj > 0) viol = fabs(Gp);
+                else viol = fabs(Gn);
+                if (viol > Gmax_new) Gmax_new = viol;
+                Gnorm1_new += viol;
+                continue;
+            }
             {
                 const uint64_t cw = load_col(j);
                 for (int t = 0; t < W; t++) {
@@ -1452,17 +1568,7 @@ __global__ __launch_bounds__(WMREG > 0 ? SV_COOP_THREADS : SV_THREADS) void logr
                 s_cd.active = active; s_cd.cmd = 4;
             }
             __syncthreads();   // releases waves 1..3 (helper_loop)
-            iter = gg_run();
-            for (int sidx = 0; sidx < active; sidx++) {
-                const int j = act[sidx];
-                const double d = wpd[j] - w[j];
-                if (d == 0.0) continue;
-                const uint64_t cw = load_col(j);
-                for (int t = 0; t < W; t++) {
-                    const uint64_t xw = psk_readlane_u64(cw, t);
-                    if ((xw >> lane) & 1) xTd[t * 64 + lane] += d;
-                }
-            }
+            iter = gg_run();   // (leaves x.d = X_A d in place)
 #ifdef PSK_SV_STATS
             stat_visits += (long long)iter * active;
 #endif
