@@ -352,7 +352,8 @@ __global__ __launch_bounds__(WMREG > 0 ? SV_COOP_THREADS : SV_THREADS) void logr
     int W, const double *__restrict__ fit_param, const int32_t *__restrict__ fit_fold, double tol, int max_newton,
     double *__restrict__ coef, double *__restrict__ icpt, int32_t *__restrict__ iters, double *__restrict__ work,
     int32_t *__restrict__ iwork, const int f_lds_rt, const int s_lds_rt, const int c_lds_rt, const int q_doubles_i, const int cg_max,
-    const int polish_reps, const uint64_t *__restrict__ colT, const int gg_sl, float *__restrict__ gg_q, const size_t gg_stride)
+    const int polish_reps, const uint64_t *__restrict__ colT, const int gg_sl, float *__restrict__ gg_q, const size_t gg_stride,
+    const int gg_polish_from)
 {
     const size_t q_doubles = (size_t)q_doubles_i;  // LDS doubles reserved for the Gram block (or for the arrays of gg_run)
     // s_lds_rt: bit 0 = the two sample arrays every per-feature gradient pass reads (tau, D) are in LDS, bit 1 = the
@@ -570,16 +571,18 @@ __global__ __launch_bounds__(WMREG > 0 ? SV_COOP_THREADS : SV_THREADS) void logr
     // its place (its step is then exactly 0), so the order of a sweep never changes under the owners' feet.  No CG
     // accelerator in this form.  2,048 x 907 grid: 3.3 s -> 1.03 s (tests/golden/fit2048_907.npz); -DPSK_GG_CHECK prints G
     // against its definition every few hundred visits (1e-12).
-    struct GgShared { int stop_at, last_A, par, iters; };
+    struct GgShared { int stop_at, last_A, par, iters, polish, nF, sweeps, nshrunk; uint32_t r32; double Gmax_old; };
     __shared__ GgShared s_gg;
 #ifdef PSK_SV_STATS
-    __shared__ long long s_stat_wait[4];
+    __shared__ long long s_stat_wait[4], s_stat_dead;   // (s_stat_dead: visits of the gg descent to slots that were shrunk out)
     if (threadIdx.x < 4) s_stat_wait[threadIdx.x] = 0;
+    if (threadIdx.x == 0) s_stat_dead = 0;
 #endif
-    if (threadIdx.x == 0) { s_gg.last_A = 0; s_gg.par = 0; s_gg.stop_at = -1; }   // (read behind the barrier that releases the first gg_run)
+    if (threadIdx.x == 0) { s_gg.last_A = 0; s_gg.par = 0; s_gg.stop_at = -1; s_gg.polish = 0; s_gg.nF = 0; }   // (read behind the barrier that releases the first gg_run)
     const int SL = gg_sl;   // slots of the gg arrays (256 x ceil(P1 / 256)); 0 = form not available in this launch
     double *ggP = Qm;       // per slot: 1 / H (0 while the slot is shrunk out of the sweeps), w + d
     double *ggH = Qm + 2 * (size_t)SL;
+    double *ggG = Qm + 3 * (size_t)SL;   // g of every slot between the segments of a descent (the owners keep it in registers within one)
     uint16_t *ggDs = reinterpret_cast<uint16_t *>(Qm + 4 * (size_t)SL);   // D of the training samples as two bf16 parts [2][NP]
     uint16_t *ggOrd = reinterpret_cast<uint16_t *>(Qm + 4 * (size_t)SL + NP);
     uint16_t *ggFeat = ggOrd + 2 * (size_t)SL;
@@ -589,6 +592,140 @@ __global__ __launch_bounds__(WMREG > 0 ? SV_COOP_THREADS : SV_THREADS) void logr
     u4 *ggT1 = reinterpret_cast<u4 *>(reinterpret_cast<uint8_t *>(ggFeat + SL) + SL), *ggT2 = ggT1 + 256;   // byte -> eight bf16 ones / masks
     float *ggCol = reinterpret_cast<float *>(ggT2 + 256);   // [2 owner waves][2 parities][2 of a pair][64 lanes x 8]: a ticket's column, the owner's rows
     float *Qg = gg_q + (size_t)fit * gg_stride;
+    // The accelerator of the LDS Gram form (polish, below) for this form, on the fit's 256 threads: with the signs of the
+    // non-zero coordinates held fixed the model restricted to them is a plain quadratic; a few conjugate-gradient steps on
+    // Q_FF delta = -(g_F + sign_F) give a descent direction, the step stops where the first coordinate would change sign
+    // (it lands on exactly 0).  Thread t keeps slots 4 t ... 4 t + 3 of every vector; the direction is broadcast through LDS
+    // and a product Q_{:,F} p reads the columns of F from global memory (rows of all slots: g of the others moves too).
+    // Returns true when the step was cut short (the caller repeats).  Any point is a valid iterate of the descent.
+    auto gg_polish = [&](int A) -> bool {
+        const int tid = threadIdx.x;
+        const bool on = 4 * tid < SL;   // thread t keeps slots 4 t ... 4 t + 3 of every vector (one 16-byte load per column of Q)
+        typedef float f4 __attribute__((ext_vector_type(4)));
+        double *pdL = reinterpret_cast<double *>(ggCol);          // the direction, by slot (the owners' column buffers rest)
+        uint16_t *flist = reinterpret_cast<uint16_t *>(ggT1);     // the slots of F (wave 3's counters rest)
+        int slot = 0;
+        auto block_sum = [&](double x) {
+            x = psk_wave_sum_f64_dpp(x);
+            if (lane == 0) s_part[slot][wave] = x;
+            __syncthreads();
+            const double r = (s_part[slot][0] + s_part[slot][1]) + (s_part[slot][2] + s_part[slot][3]);
+            slot ^= 1;
+            return r;
+        };
+        bool inF[4];
+        double sg[4], wp[4], r[4], pd[4], dl[4], Qd[4], Qp[4];
+        double rs = 0.0;
+#pragma unroll
+        for (int e = 0; e < 4; e++) {
+            const int u = 4 * tid + e;
+            const bool valid = u < A;
+            wp[e] = valid ? ggP[2 * (size_t)u + 1] : 0.0;
+            inF[e] = valid && wp[e] != 0.0;
+            sg[e] = wp[e] > 0.0 ? 1.0 : -1.0;
+            r[e] = inF[e] ? -(ggG[valid ? u : 0] + sg[e]) : 0.0;
+            pd[e] = r[e];
+            dl[e] = 0.0;
+            Qd[e] = 0.0;
+            rs += r[e] * r[e];
+            if (on) pdL[u] = pd[e];
+        }
+        if (wave == 0) {   // F in slot order
+            int cnt = 0;
+            for (int base = 0; base < A; base += 64) {
+                const int u = base + lane;
+                const bool f = u < A && ggP[2 * (size_t)(u < A ? u : 0) + 1] != 0.0;
+                const uint64_t m = __ballot(f);
+                if (f) flist[cnt + __popcll(m & ((1ull << lane) - 1ull))] = (uint16_t)u;
+                cnt += __popcll(m);
+            }
+            if (lane == 0) s_gg.nF = cnt;
+        }
+        rs = block_sum(rs);   // (its barrier also publishes the direction and F)
+        const double b2 = rs;
+        if (!(b2 > 0.0)) return false;
+        const int nF = s_gg.nF;
+        const float *Qt = Qg + (on ? 4 * tid : 0);
+        for (int it = 0; it < cg_max; it++) {
+#pragma unroll
+            for (int e = 0; e < 4; e++) Qp[e] = 0.0;
+            int i = 0;
+            for (; i + 8 <= nF; i += 8) {   // eight columns requested together
+                int v[8];
+                double pv[8];
+                f4 q[8];
+#pragma unroll
+                for (int c = 0; c < 8; c++) { v[c] = flist[i + c]; pv[c] = pdL[v[c]]; }
+#pragma unroll
+                for (int c = 0; c < 8; c++) q[c] = *reinterpret_cast<const f4 *>(Qt + (size_t)v[c] * SL);
+#pragma unroll
+                for (int c = 0; c < 8; c++)
+#pragma unroll
+                    for (int e = 0; e < 4; e++) Qp[e] = fma(pv[c], (double)q[c][e], Qp[e]);
+            }
+            for (; i < nF; i++) {
+                const int v = flist[i];
+                const double pv = pdL[v];
+                const f4 q = *reinterpret_cast<const f4 *>(Qt + (size_t)v * SL);
+#pragma unroll
+                for (int e = 0; e < 4; e++) Qp[e] = fma(pv, (double)q[e], Qp[e]);
+            }
+            double pq = 0.0;
+#pragma unroll
+            for (int e = 0; e < 4; e++) pq += inF[e] ? pd[e] * Qp[e] : 0.0;
+            pq = block_sum(pq);
+            if (!(pq > 0.0)) break;
+            const double a = rs / pq;
+            double rn = 0.0;
+#pragma unroll
+            for (int e = 0; e < 4; e++) {
+                dl[e] += a * pd[e];
+                Qd[e] += a * Qp[e];
+                r[e] = inF[e] ? r[e] - a * Qp[e] : 0.0;
+                rn += r[e] * r[e];
+            }
+            rn = block_sum(rn);   // (every thread has read the direction of this step by now)
+            if (!(rn > 1e-18 * b2)) break;
+            const double beta = rn / rs;
+#pragma unroll
+            for (int e = 0; e < 4; e++) {
+                pd[e] = r[e] + beta * pd[e];
+                if (on) pdL[4 * tid + e] = pd[e];
+            }
+            rs = rn;
+            __syncthreads();
+        }
+        // a direction that is not finite (breakdown of CG on a numerically singular block) is dropped
+        double bad = 0.0;
+#pragma unroll
+        for (int e = 0; e < 4; e++) bad += (!(fabs(dl[e]) < 1e300) || !(fabs(Qd[e]) < 1e300)) ? 1.0 : 0.0;
+        if (block_sum(bad) != 0.0) return false;
+        // longest step in (0, 1] that keeps every sign
+        double tmax = 1.0;
+#pragma unroll
+        for (int e = 0; e < 4; e++)
+            if (inF[e] && (wp[e] + dl[e]) * sg[e] <= 0.0) tmax = fmin(tmax, -wp[e] / dl[e]);
+#pragma unroll
+        for (int d = 32; d > 0; d >>= 1) tmax = fmin(tmax, psk_shfl_xor_f64(tmax, d));
+        if (lane == 0) s_part[slot][wave] = tmax;
+        __syncthreads();
+        tmax = fmin(fmin(s_part[slot][0], s_part[slot][1]), fmin(s_part[slot][2], s_part[slot][3]));
+        slot ^= 1;
+        if (!(tmax > 0.0)) return false;
+#pragma unroll
+        for (int e = 0; e < 4; e++) {
+            const int u = 4 * tid + e;
+            if (u < A) {
+                if (inF[e]) {
+                    const bool hits = (wp[e] + dl[e]) * sg[e] <= 0.0 && -wp[e] / dl[e] <= tmax;
+                    ggP[2 * (size_t)u + 1] = hits ? 0.0 : wp[e] + tmax * dl[e];
+                }
+                ggG[u] += tmax * Qd[e];
+            }
+        }
+        __syncthreads();
+        return tmax < 1.0;
+    };
     auto gg_run = [&]() __attribute__((always_inline)) -> int {
 #ifndef PSK_GG_DEPTH
 #define PSK_GG_DEPTH 16
@@ -614,6 +751,7 @@ __global__ __launch_bounds__(WMREG > 0 ? SV_COOP_THREADS : SV_THREADS) void logr
                 ggFeat[u] = (uint16_t)f;
                 *reinterpret_cast<d2 *>(ggP + 2 * (size_t)u) = d2{1.0 / hh, valid ? w[f] : 0.0};
                 ggH[u] = hh;
+                ggG[u] = valid ? Gr[f] : 0.0;
                 if (!keep) ggOrd[u] = (uint16_t)u;          // (the first Newton step, or the active set changed)
                 else if (par) ggOrd[u] = ggOrd[SL + u];     // the last complete order of the previous Newton step
             }
@@ -731,6 +869,11 @@ __global__ __launch_bounds__(WMREG > 0 ? SV_COOP_THREADS : SV_THREADS) void logr
         // pair I - 1 and leave, for pair I + 1 (tickets c, d), g[c], g[d] as they then are -- two steps behind c, three
         // behind d -- with the entries of Q that link them to a, b (and d to c); wave 3 books pair I - 1.
         double *ggRec = ggZG;   // [2][10]: z_a z_b | G_a G_b | (1/H, w)_a | (1/H, w)_b | slots a, b -- by the interval's parity
+        // (wave 3's books that outlive a segment of the descent -- a segment ends where the accelerator is called, gg_polish
+        // above -- rest in s_gg between segments)
+        if (tid == 0) { s_gg.sweeps = 0; s_gg.nshrunk = 0; s_gg.Gmax_old = 1e300; s_gg.r32 = rng; }
+        __syncthreads();
+        for (;;) {   // segments of the descent
         if (wave == 1 || wave == 2) {
             // ---- owners of g and of the columns.  Two register sets of DEPTH tickets: `a` is complete and used two tickets per
             // interval, `b` is loaded in ONE burst at the top of a round of DEPTH / 2 intervals and becomes `a` at its end,
@@ -749,7 +892,7 @@ __global__ __launch_bounds__(WMREG > 0 ? SV_COOP_THREADS : SV_THREADS) void logr
 #pragma unroll
             for (int e = 0; e < 8; e++) {
                 const int u = 256 * (2 * h + (e >> 2)) + 4 * lane + (e & 3);
-                go[e] = u < A ? Gr[ggFeat[u]] : 0.0;
+                go[e] = u < A ? ggG[u] : 0.0;
             }
             // a round's DEPTH tickets: their slots through ONE read of the order (lane u = ticket u of the round, across the
             // end of a sweep into the next order), then per ticket a lane read, the column's base and two loads
@@ -848,6 +991,19 @@ __global__ __launch_bounds__(WMREG > 0 ? SV_COOP_THREADS : SV_THREADS) void logr
             // the last burst is still in flight: nothing may leave this block with loads pending on registers that the code
             // after it reuses
             __builtin_amdgcn_s_waitcnt(0x0F70);   // vmcnt(0)
+            {   // the steps of the segment's last pair (wave 0's record of the interval before this round's top), then g goes
+                // to LDS: the accelerator and the next segment start from it
+                const d2 zz = *reinterpret_cast<const d2 *>(ggRec + 10 * ((DEPTH / 2 - 1) & 1));
+#pragma unroll
+                for (int e = 0; e < 8; e++) go[e] = fma(zz[0], (double)l0[e], go[e]);
+#pragma unroll
+                for (int e = 0; e < 8; e++) go[e] = fma(zz[1], (double)l1[e], go[e]);
+#pragma unroll
+                for (int e = 0; e < 8; e++) {
+                    const int u = 256 * (2 * h + (e >> 2)) + 4 * lane + (e & 3);
+                    if (u < A) ggG[u] = go[e];
+                }
+            }
         } else if (wave == 3) {
             // ---- liblinear's books, one interval behind the steps, and the next sweep's order.  The violations of the two
             // visits of pair I - 1, their shrinking tests (the marker 1 / H = 0 goes into the slot's place: the slot is visited
@@ -859,10 +1015,10 @@ __global__ __launch_bounds__(WMREG > 0 ? SV_COOP_THREADS : SV_THREADS) void logr
             int dz;
             asm volatile("v_mov_b32 %0, 0" : "=v"(dz));
             auto vmax = [](double x, double y) __attribute__((always_inline)) { double r; asm("v_max_f64 %0, %1, %2" : "=v"(r) : "v"(x), "v"(y)); return r; };
-            uint32_t r32 = rng;
-            int sweeps = 0, nshrunk = 0;
+            uint32_t r32 = s_gg.r32;
+            int sweeps = s_gg.sweeps, nshrunk = s_gg.nshrunk;
             int kq = 0, pq = -2;   // sweep and position of the FIRST visit of the pair being booked (pair I - 1; before the descent: none)
-            double Gmax = 0.0, Gnorm1 = 0.0, Gmax_old = 1e300, omt = -1e300;
+            double Gmax = 0.0, Gnorm1 = 0.0, Gmax_old = s_gg.Gmax_old, omt = 1.0 - Gmax_old / l_c;
             int stop_at = -1;
             bool gen = true;   // a sweep has begun whose successor's order is still to be drawn (the first sweep's, at once)
             for (int I = 0;; I++) {
@@ -876,6 +1032,9 @@ __global__ __launch_bounds__(WMREG > 0 ? SV_COOP_THREADS : SV_THREADS) void logr
                 for (int v = 0; v < 2; v++) {   // the two visits of pair I - 1 (at I = 0 the record is zeros: 1 / H = 0, nothing)
                     const double G = GG[v], Hi = v ? Pb[0] : Pa[0], wp = v ? Pb[1] : Pa[1], aG = fabs(G);
                     const bool live = Hi != 0.0, zero = wp == 0.0;
+#ifdef PSK_SV_STATS
+                    if (lane == 0 && !live && I > 0) s_stat_dead++;
+#endif
                     const bool shrink = live && zero && aG < omt;   // out of the sweeps until the whole set is taken up again
                     const double vz = vmax(aG - 1.0, 0.0), vn = fabs(G + copysign(1.0, wp));
                     const double viol = live ? (zero ? vz : vn) : 0.0;   // (0 for the visit that shrinks: |G| < 1)
@@ -899,9 +1058,11 @@ __global__ __launch_bounds__(WMREG > 0 ? SV_COOP_THREADS : SV_THREADS) void logr
                         omt = 1.0 - Gmax_old / l_c;
                         Gmax = 0.0;
                         Gnorm1 = 0.0;
-                        if (stop && stop_at < 0) {
+                        // the accelerator after sweeps 4, 8, 16, ... (the schedule of the LDS Gram form): the segment ends like the descent
+                        const bool pol = !stop && cg_max > 0 && sweeps >= gg_polish_from && (sweeps & (sweeps - 1)) == 0;
+                        if ((stop || pol) && stop_at < 0) {
                             stop_at = __builtin_amdgcn_readfirstlane((2 * I + 2 + DEPTH) & ~(DEPTH - 1));   // > 2 I + 2: every wave reads it behind a later barrier
-                            if (lane == 0) { s_gg.stop_at = stop_at; s_gg.iters = sweeps; }
+                            if (lane == 0) { s_gg.stop_at = stop_at; s_gg.iters = sweeps; s_gg.polish = pol ? 1 : 0; }
                         }
                     }
                 }
@@ -956,9 +1117,8 @@ __global__ __launch_bounds__(WMREG > 0 ? SV_COOP_THREADS : SV_THREADS) void logr
                     }
                 }
             }
-            rng = r32;
-            // the order of the sweep under way at the end is complete: the next Newton step starts from it
-            if (lane == 0) { s_gg.last_A = A; s_gg.par = kq & 1; }
+            // the order of the sweep under way at the end is complete: the next segment / Newton step starts from it
+            if (lane == 0) { s_gg.last_A = A; s_gg.par = kq & 1; s_gg.sweeps = sweeps; s_gg.nshrunk = nshrunk; s_gg.Gmax_old = Gmax_old; s_gg.r32 = r32; }
         } else {
             // ---- the steps.  G of a slot = what its owner left (g some steps ago and the entries of Q that link it to the
             // slots stepped since) plus those steps; the slot's 1 / H and w, requested an interval ahead; the soft-threshold
@@ -1003,8 +1163,8 @@ __global__ __launch_bounds__(WMREG > 0 ? SV_COOP_THREADS : SV_THREADS) void logr
             int m_a = __builtin_amdgcn_readlane(ordv, 0), m_b = __builtin_amdgcn_readlane(ordv, 1);
             d2 P_a = *reinterpret_cast<const d2 *>(ggP + 2 * (size_t)m_a + dz), P_b = *reinterpret_cast<const d2 *>(ggP + 2 * (size_t)m_b + dz);
             if (lane == 0) {   // pair 0: g[a], g[b] themselves, and the one entry of Q that links b to a
-                *reinterpret_cast<d2 *>(ggPub + 6) = d2{Gr[ggFeat[m_a]], 0.0};
-                *reinterpret_cast<d2 *>(ggPub + 6 + 2) = d2{Gr[ggFeat[m_b]], 0.0};
+                *reinterpret_cast<d2 *>(ggPub + 6) = d2{ggG[m_a], 0.0};
+                *reinterpret_cast<d2 *>(ggPub + 6 + 2) = d2{ggG[m_b], 0.0};
                 reinterpret_cast<float *>(ggPub + 6 + 4)[0] = Qg[(size_t)m_a * SL + m_b];
             }
             // (a round of DEPTH / 2 intervals per pass of the loop, like the owners: the end of the descent is looked for once
@@ -1060,13 +1220,34 @@ __global__ __launch_bounds__(WMREG > 0 ? SV_COOP_THREADS : SV_THREADS) void logr
                 }
             }
         steps_done:;
-            // back to the feature arrays; x.d = X_A d for the line search is the caller's
-            for (int u = lane; u < A; u += 64) wpd[ggFeat[u]] = ggP[2 * (size_t)u + 1];
         }
+        __syncthreads();   // the segment is over for every wave: g, w + d and the order under way are in LDS
+        if (!s_gg.polish) break;
+        {
+#ifdef PSK_SV_STATS
+            const long long stat_p0 = clock64();
+#endif
+            for (int rep = 0; rep < polish_reps && gg_polish(A); rep++) {}
+            // the next segment: a new descent from this point, in the order of the sweep that was under way
+            const int par = s_gg.par;
+            for (int u = tid; u < SL; u += SV_COOP_THREADS)
+                if (par) ggOrd[u] = ggOrd[SL + u];
+            if (tid < 32) ggPub[tid] = 0.0;
+            for (int i = tid; i < 4096; i += SV_COOP_THREADS) ggCol[i] = 0.f;
+            if (tid == 0) { s_gg.stop_at = -1; s_gg.polish = 0; }
+            __syncthreads();
+#ifdef PSK_SV_STATS
+            if (wave == 0) stat_t_polish += clock64() - stat_p0;
+#endif
+        }
+        }   // segments
+        rng = s_gg.r32;
+        // back to the feature arrays
+        if (wave == 0)
+            for (int u = lane; u < A; u += 64) wpd[ggFeat[u]] = ggP[2 * (size_t)u + 1];
 #undef GG_BARRIER
 #ifdef PSK_SV_STATS
         if (lane == 0) atomicAdd(reinterpret_cast<unsigned long long *>(&s_stat_wait[wave]), (unsigned long long)stat_bw);
-        if (wave == 0) stat_t_polish += stat_bw;   // (this form has no accelerator: the field reports wave 0's waits at the barrier)
 #endif
         __syncthreads();
         iter_c = s_gg.iters;
@@ -1755,7 +1936,7 @@ __global__ __launch_bounds__(WMREG > 0 ? SV_COOP_THREADS : SV_THREADS) void logr
     }
 #ifdef PSK_SV_STATS
     if (lane == 0 && SL > 0)
-        printf("fit %d waits at the descent's barrier: wave0 %lld wave1 %lld wave2 %lld wave3 %lld\n", fit, s_stat_wait[0], s_stat_wait[1], s_stat_wait[2], s_stat_wait[3]);
+        printf("fit %d waits at the descent's barrier: wave0 %lld wave1 %lld wave2 %lld wave3 %lld; visits to shrunk slots %lld\n", fit, s_stat_wait[0], s_stat_wait[1], s_stat_wait[2], s_stat_wait[3], s_stat_dead);
     if (lane == 0)
         printf("fit %d C %g newton %d sweeps %lld visits<= %lld cd_cycles %lld total_cycles %lld gram_cycles %lld gram_sweeps %lld builds %lld build_cycles %lld polish_cycles %lld\n",
                fit, C, newton, stat_sweeps, stat_visits, stat_t_cd, (long long)(clock64() - stat_start), stat_t_gram, stat_gram_sweeps, stat_builds,
@@ -2147,9 +2328,13 @@ extern "C" int psk_logreg_l1_fit(psk_ctx *ctx, const float *X, const int32_t *y0
             (const uint64_t *)b.bits, (const int8_t *)b.y, (const int32_t *)b.fold, n, p, W, (const double *)b.param,
             (const int32_t *)b.ffold, tol, max_iter, (double *)b.coef, (double *)b.icpt, (int32_t *)b.iters,
             (double *)b.work, (int32_t *)b.iwork, f_lds, s_lds, c_lds, (int)q_doubles,
-            getenv("PSK_CG_MAX") ? atoi(getenv("PSK_CG_MAX")) : 16,             // CG steps per polish
+            // CG steps per polish: short runs, many repeats -- the Gram-global form pays a pass over Q_F in L2 per CG step
+            // (r03, 2048 x 907 grid: 3 or 4 steps x 64 repeats 0.20-0.23 s, 6 x 64 0.32 s, none 0.94 s; with four-byte loads 4 x 64
+            // 0.41 s, 8 x 16 1.0 s, 16 x 64 4.2 s)
+            getenv("PSK_CG_MAX") ? atoi(getenv("PSK_CG_MAX")) : (gg_sl ? 4 : 16),
             getenv("PSK_POLISH_REPS") ? atoi(getenv("PSK_POLISH_REPS")) : 64,   // polishes in a row while signs change
-            (const uint64_t *)b.bitsT, gg_sl, (float *)b.ggq, gg_stride);
+            (const uint64_t *)b.bitsT, gg_sl, (float *)b.ggq, gg_stride,
+            getenv("PSK_GG_POLISH_FROM") ? atoi(getenv("PSK_GG_POLISH_FROM")) : 32);   // first polish of a descent after this many sweeps
         PSK_HIP(ctx, hipGetLastError());
         PSK_HIP(ctx, hipStreamSynchronize(ctx->stream));  // `bits` (host) must outlive the copy
     } else {

@@ -627,9 +627,11 @@ def test_l1_logreg_gram_global_form_reaches_the_same_optimum_at_a_tight_toleranc
 
 def test_l1_logreg_gram_global_form_on_the_2048_x_907_grid(ctx, monkeypatch):
     """the grid of a 2,048-genome run whose 1,000 selected k-mers have 907 distinct patterns (143 fits; at
-    C >= 100 every coefficient ends non-zero, the slowest fit takes ~3,500 sweeps of 907 coordinates).  The Gram form in
-    global memory must stop every fit by liblinear's rule, reach the objectives of the array form (which took 3.3 s), and
-    do so in about a second -- 1.03 s measured; the bound leaves room for a loaded box."""
+    C >= 100 every coefficient ends non-zero, plain coordinate descent needs ~4,700 sweeps of 907 coordinates for the
+    slowest fit).  The Gram form in global memory -- with its accelerator, conjugate-gradient steps on the free set -- must
+    stop every fit by liblinear's rule, end no higher than the array form (which took 3.3 s) beyond what the rule leaves
+    open, and do so well inside a second: 0.33 s measured (0.90 s without the accelerator); the bound leaves room for a
+    loaded box."""
     import time
     d = np.load(os.path.join(GOLDEN, "fit2048_907.npz"))
     X = np.unpackbits(d["Xbits"], axis=1)[:, : int(d["p"])].astype(np.float32)
@@ -640,7 +642,7 @@ def test_l1_logreg_gram_global_form_on_the_2048_x_907_grid(ctx, monkeypatch):
     coef, icpt, iters = ctx.logreg_l1_fit(X, y, fold, fp, ff, float(d["tol"]), int(d["max_iter"]))
     wall = time.time() - t0
     assert iters.max() < 100, iters.max()
-    assert wall < 1.5, wall
+    assert wall < 0.8, wall
     again = ctx.logreg_l1_fit(X, y, fold, fp, ff, float(d["tol"]), int(d["max_iter"]))
     assert np.array_equal(coef, again[0]) and np.array_equal(icpt, again[1])
     _l1_stop_rule_holds(X, ypm, fold, fp, ff, coef, icpt, iters, range(0, len(fp), 9), tol=float(d["tol"]))
@@ -648,10 +650,11 @@ def test_l1_logreg_gram_global_form_on_the_2048_x_907_grid(ctx, monkeypatch):
     ref = ctx.logreg_l1_fit(X, y, fold, fp, ff, float(d["tol"]), int(d["max_iter"]))
     monkeypatch.delenv("PSK_NO_GRAM_GLOBAL")
     o_new, o_ref = _l1_objectives(X, ypm, fold, fp, ff, coef, icpt), _l1_objectives(X, ypm, fold, fp, ff, ref[0], ref[1])
-    # both stop by the same rule -- a bound on the violation, not on the objective: the large fits end within a per-mille of
-    # each other, a fit with C = 0.03 (objective 23) 1.4 % apart
-    assert np.allclose(o_new, o_ref, rtol=3e-2, atol=0), float(np.abs(o_new / o_ref - 1).max())
-    assert -1e-2 < o_new.sum() / o_ref.sum() - 1 < 5e-4     # (in total a little LOWER than the array form's: -0.19 % measured)
+    # both stop by the same rule -- a bound on the violation, not on the objective, which at tol = 1e-4 leaves a few per cent
+    # open on these ill-conditioned fits: measured -3.3 % ... +1.7 % fit by fit, the accelerated form 1.8 % LOWER in total
+    rel = o_new / o_ref - 1
+    assert rel.max() < 3e-2 and rel.min() > -8e-2, (float(rel.max()), float(rel.min()))
+    assert -6e-2 < o_new.sum() / o_ref.sum() - 1 < 5e-4
 
 
 def test_lasso_solver_matches_sklearn(ctx):
