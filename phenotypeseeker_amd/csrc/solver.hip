@@ -568,9 +568,11 @@ __global__ __launch_bounds__(WMREG > 0 ? SV_COOP_THREADS : SV_THREADS) void logr
     //   wave 3    liblinear's books, one interval behind: violations, the shrinking test, the stopping rule after a sweep's
     //             last visit; and the next sweep's random order, drawn whole when a sweep begins.
     // Same rule as liblinear for shrinking and stopping; a shrunk coordinate keeps its place in the order with 1 / H = 0 in
-    // its place (its step is then exactly 0), so the order of a sweep never changes under the owners' feet.  No CG
-    // accelerator in this form.  2,048 x 907 grid: 3.3 s -> 1.03 s (tests/golden/fit2048_907.npz); -DPSK_GG_CHECK prints G
-    // against its definition every few hundred visits (1e-12).
+    // its place (its step is then exactly 0), so the order of a sweep never changes under the owners' feet.  The descent
+    // runs in SEGMENTS: after sweeps 32, 64, 128, ... wave 3 ends one the way it ends the descent, g goes to LDS, the 256
+    // threads take conjugate-gradient steps on the free set (gg_polish) and the next segment starts from that point.
+    // 2,048 x 907 grid: 3.3 s -> 1.03 s -> 0.23 s with the accelerator (tests/golden/fit2048_907.npz); -DPSK_GG_CHECK
+    // prints G against its definition every few hundred visits (1e-12).
     struct GgShared { int stop_at, last_A, par, iters, polish, nF, sweeps, nshrunk; uint32_t r32; double Gmax_old; };
     __shared__ GgShared s_gg;
 #ifdef PSK_SV_STATS
@@ -598,7 +600,7 @@ __global__ __launch_bounds__(WMREG > 0 ? SV_COOP_THREADS : SV_THREADS) void logr
     // (it lands on exactly 0).  Thread t keeps slots 4 t ... 4 t + 3 of every vector; the direction is broadcast through LDS
     // and a product Q_{:,F} p reads the columns of F from global memory (rows of all slots: g of the others moves too).
     // Returns true when the step was cut short (the caller repeats).  Any point is a valid iterate of the descent.
-    auto gg_polish = [&](int A) -> bool {
+    auto gg_polish = [&](int A, int cg_n, double &t_out) -> bool {
         const int tid = threadIdx.x;
         const bool on = 4 * tid < SL;   // thread t keeps slots 4 t ... 4 t + 3 of every vector (one 16-byte load per column of Q)
         typedef float f4 __attribute__((ext_vector_type(4)));
@@ -643,10 +645,11 @@ __global__ __launch_bounds__(WMREG > 0 ? SV_COOP_THREADS : SV_THREADS) void logr
         }
         rs = block_sum(rs);   // (its barrier also publishes the direction and F)
         const double b2 = rs;
+        t_out = 1.0;
         if (!(b2 > 0.0)) return false;
         const int nF = s_gg.nF;
         const float *Qt = Qg + (on ? 4 * tid : 0);
-        for (int it = 0; it < cg_max; it++) {
+        for (int it = 0; it < cg_n; it++) {
 #pragma unroll
             for (int e = 0; e < 4; e++) Qp[e] = 0.0;
             int i = 0;
@@ -712,6 +715,7 @@ __global__ __launch_bounds__(WMREG > 0 ? SV_COOP_THREADS : SV_THREADS) void logr
         tmax = fmin(fmin(s_part[slot][0], s_part[slot][1]), fmin(s_part[slot][2], s_part[slot][3]));
         slot ^= 1;
         if (!(tmax > 0.0)) return false;
+        t_out = tmax;
 #pragma unroll
         for (int e = 0; e < 4; e++) {
             const int u = 4 * tid + e;
@@ -1058,7 +1062,7 @@ __global__ __launch_bounds__(WMREG > 0 ? SV_COOP_THREADS : SV_THREADS) void logr
                         omt = 1.0 - Gmax_old / l_c;
                         Gmax = 0.0;
                         Gnorm1 = 0.0;
-                        // the accelerator after sweeps 4, 8, 16, ... (the schedule of the LDS Gram form): the segment ends like the descent
+                        // the accelerator after sweeps gg_polish_from, 2 gg_polish_from, ... (powers of two): the segment ends like the descent
                         const bool pol = !stop && cg_max > 0 && sweeps >= gg_polish_from && (sweeps & (sweeps - 1)) == 0;
                         if ((stop || pol) && stop_at < 0) {
                             stop_at = __builtin_amdgcn_readfirstlane((2 * I + 2 + DEPTH) & ~(DEPTH - 1));   // > 2 I + 2: every wave reads it behind a later barrier
@@ -1227,7 +1231,13 @@ __global__ __launch_bounds__(WMREG > 0 ? SV_COOP_THREADS : SV_THREADS) void logr
 #ifdef PSK_SV_STATS
             const long long stat_p0 = clock64();
 #endif
-            for (int rep = 0; rep < polish_reps && gg_polish(A); rep++) {}
+            // long CG runs pay when the step they buy is taken whole; while steps are cut short early (many small coefficients
+            // on their way to zero: each repeat lands one of them) short runs with many repeats do (2048 x 907 grid: 4 steps
+            // x 64 repeats 0.23 s, 6 x 64 0.32 s; 1500 x 400: 16 steps 0.37 s, 4 steps 1.25 s; near-separable 256 x 70: 16
+            // steps 65 Newton steps at most, 4 steps 350)
+            double t_last = 1.0;
+            const int cg_short = cg_max < 4 ? cg_max : (cg_max / 4 > 4 ? cg_max / 4 : 4);
+            for (int rep = 0; rep < polish_reps && gg_polish(A, t_last >= 0.5 ? cg_max : cg_short, t_last); rep++) {}
             // the next segment: a new descent from this point, in the order of the sweep that was under way
             const int par = s_gg.par;
             for (int u = tid; u < SL; u += SV_COOP_THREADS)
@@ -2241,7 +2251,13 @@ extern "C" int psk_logreg_l1_fit(psk_ctx *ctx, const float *X, const int32_t *y0
         const int P1 = p + 1, wmreg_h = getenv("PSK_NO_CD_REGS") ? 0 : (W <= 16 ? 16 : W <= 32 ? 32 : 64);
         int gg_sl = 0;
         size_t gg_stride = 0, gg_lds = 0;
-        if (P1 > 192 && P1 <= 1024 && wmreg_h > 0 && SV_COOP_WAVES == 4 && !getenv("PSK_NO_GRAM") && !getenv("PSK_NO_GRAM_GLOBAL")) {
+        // up to 192 columns the LDS Gram form (exact f64 Hessian, columns built sample by sample) keeps the designs with
+        // fewer than 1,024 samples: its builds are cheap there and an ill-conditioned fit at a tight tolerance converges in
+        // fewer Newton steps than with the f32 / bf16-split Q of the global form (256 x 150 near-duplicates at tol = 1e-7:
+        // inside 300 steps against not); from 1,024 samples on the global form is 3-10 x faster (2048 x 169 grid 0.27 ->
+        // 0.10 s, 2000 x 150: 0.14 -> 0.012 s)
+        const int gg_min_p1 = getenv("PSK_GG_MIN_P1") ? atoi(getenv("PSK_GG_MIN_P1")) : (n >= 1024 ? 64 : 192);
+        if (P1 > gg_min_p1 && P1 <= 1024 && wmreg_h > 0 && SV_COOP_WAVES == 4 && !getenv("PSK_NO_GRAM") && !getenv("PSK_NO_GRAM_GLOBAL")) {
             const size_t sl = 256 * (((size_t)P1 + 255) / 256), np_h = (size_t)W * 64;
             // (+ the build's tables / wave 3's counters, + the owners' column buffers)
             const size_t need = (4 * sl + np_h + sl / 2 + sl / 4 + sl / 8) * 8 + 8192 + 16384, stride = (((size_t)P1 + 15) / 16 * 16) * sl;
@@ -2328,10 +2344,8 @@ extern "C" int psk_logreg_l1_fit(psk_ctx *ctx, const float *X, const int32_t *y0
             (const uint64_t *)b.bits, (const int8_t *)b.y, (const int32_t *)b.fold, n, p, W, (const double *)b.param,
             (const int32_t *)b.ffold, tol, max_iter, (double *)b.coef, (double *)b.icpt, (int32_t *)b.iters,
             (double *)b.work, (int32_t *)b.iwork, f_lds, s_lds, c_lds, (int)q_doubles,
-            // CG steps per polish: short runs, many repeats -- the Gram-global form pays a pass over Q_F in L2 per CG step
-            // (r03, 2048 x 907 grid: 3 or 4 steps x 64 repeats 0.20-0.23 s, 6 x 64 0.32 s, none 0.94 s; with four-byte loads 4 x 64
-            // 0.41 s, 8 x 16 1.0 s, 16 x 64 4.2 s)
-            getenv("PSK_CG_MAX") ? atoi(getenv("PSK_CG_MAX")) : (gg_sl ? 4 : 16),
+            // CG steps per polish (the Gram-global form uses a quarter of them, at least 4, while steps are cut short early)
+            getenv("PSK_CG_MAX") ? atoi(getenv("PSK_CG_MAX")) : 16,
             getenv("PSK_POLISH_REPS") ? atoi(getenv("PSK_POLISH_REPS")) : 64,   // polishes in a row while signs change
             (const uint64_t *)b.bitsT, gg_sl, (float *)b.ggq, gg_stride,
             getenv("PSK_GG_POLISH_FROM") ? atoi(getenv("PSK_GG_POLISH_FROM")) : 32);   // first polish of a descent after this many sweeps

@@ -625,6 +625,33 @@ def test_l1_logreg_gram_global_form_reaches_the_same_optimum_at_a_tight_toleranc
         assert np.array_equal(a[0][j] != 0, b[0][j] != 0), j      # the same support
 
 
+def test_l1_logreg_accelerated_descent_ends_where_the_plain_one_does(ctx, monkeypatch):
+    """The Gram-global form interrupts a crawling descent for conjugate-gradient steps on the free set (gg_polish).  Any
+    point is a valid iterate, so the stopping rule and the optimum are those of the plain descent (PSK_CG_MAX=0): on an
+    ill-conditioned design (600 near-duplicate columns of 40 factors, C up to 100) both stop by liblinear's rule; at
+    tol = 1e-8 the objectives agree to 1e-8 (measured 3e-10; the coefficients themselves to 1e-4: flat directions), at the
+    default tolerance the accelerated fits end at or below the plain ones (measured 0 ... -1.8 %)."""
+    n, p = 500, 600
+    rng = np.random.default_rng(n + p)
+    base = rng.random((n, 40)) < 0.35
+    X = (base[:, rng.integers(0, 40, p)] ^ (rng.random((n, p)) < 0.05)).astype(np.float32)
+    y = ((base[:, 0] & base[:, 3]) ^ (rng.random(n) < 0.1)).astype(np.int32)
+    fold = (np.arange(n) % 5).astype(np.int32)
+    fp = np.array([1.0, 10.0, 100.0, 100.0])
+    ff = np.array([-1, 2, -1, 3], np.int32)
+    ypm = 2.0 * y - 1.0
+    for tol, lo, hi in ((1e-4, -5e-2, 1e-3), (1e-8, -1e-8, 1e-8)):
+        a = ctx.logreg_l1_fit(X, y, fold, fp, ff, tol=tol, max_iter=3000)
+        monkeypatch.setenv("PSK_CG_MAX", "0")
+        b = ctx.logreg_l1_fit(X, y, fold, fp, ff, tol=tol, max_iter=3000)
+        monkeypatch.delenv("PSK_CG_MAX")
+        assert a[2].max() < 3000 and b[2].max() < 3000, (a[2], b[2])
+        _l1_stop_rule_holds(X, ypm, fold, fp, ff, a[0], a[1], a[2], range(len(fp)), tol=tol)
+        _l1_stop_rule_holds(X, ypm, fold, fp, ff, b[0], b[1], b[2], range(len(fp)), tol=tol)
+        rel = _l1_objectives(X, ypm, fold, fp, ff, a[0], a[1]) / _l1_objectives(X, ypm, fold, fp, ff, b[0], b[1]) - 1
+        assert rel.min() > lo and rel.max() < hi, (tol, rel)
+
+
 def test_l1_logreg_gram_global_form_on_the_2048_x_907_grid(ctx, monkeypatch):
     """the grid of a 2,048-genome run whose 1,000 selected k-mers have 907 distinct patterns (143 fits; at
     C >= 100 every coefficient ends non-zero, plain coordinate descent needs ~4,700 sweeps of 907 coordinates for the
