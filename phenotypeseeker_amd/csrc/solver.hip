@@ -991,7 +991,6 @@ __global__ __launch_bounds__(WMREG > 0 ? SV_COOP_THREADS : SV_THREADS) void logr
                 if (round(sa_, ma_, sb_, mb_, T)) break;
                 if (round(sb_, mb_, sa_, ma_, T + DEPTH)) break;
             }
-        owners_done:
             // the last burst is still in flight: nothing may leave this block with loads pending on registers that the code
             // after it reuses
             __builtin_amdgcn_s_waitcnt(0x0F70);   // vmcnt(0)
