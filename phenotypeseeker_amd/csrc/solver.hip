@@ -285,6 +285,13 @@ __global__ __launch_bounds__(SV_THREADS) void logreg_newglmnet_kernel(
 // in an SGPR pair (one v_bfe + v_cmp per word, shared by the gradient pass and the update pass of the step) that becomes
 // EXEC for ONE v_add_f64; lanes outside the mask keep their value.  Same operations in the same order as the plain
 // form.  EXEC is saved and restored around each group.
+// repeats of the Gram-global form's accelerator at a call after `sweeps` sweeps of the descent: polish_reps > 0: that many;
+// polish_reps < 0: as many as the descent has needed sweeps so far, at most -polish_reps
+__device__ __forceinline__ int gg_polish_repeats(int polish_reps, int sweeps)
+{
+    if (polish_reps >= 0) return polish_reps;
+    return sweeps < -polish_reps ? sweeps : -polish_reps;
+}
 #define PSK_MASKED_STEP(i) "s_mov_b64 exec, %[m" #i "]\n\tv_add_f64 %[g], %[g], %[p" #i "]\n\t"
 __device__ __forceinline__ void masked_sum8(double &g, const uint64_t *m, const double *p)
 {
@@ -1236,7 +1243,8 @@ __global__ __launch_bounds__(WMREG > 0 ? SV_COOP_THREADS : SV_THREADS) void logr
             // steps 65 Newton steps at most, 4 steps 350)
             double t_last = 1.0;
             const int cg_short = cg_max < 4 ? cg_max : (cg_max / 4 > 4 ? cg_max / 4 : 4);
-            for (int rep = 0; rep < polish_reps && gg_polish(A, t_last >= 0.5 ? cg_max : cg_short, t_last); rep++) {}
+            const int reps_now = gg_polish_repeats(polish_reps, s_gg.iters);
+            for (int rep = 0; rep < reps_now && gg_polish(A, t_last >= 0.5 ? cg_max : cg_short, t_last); rep++) {}
             // the next segment: a new descent from this point, in the order of the sweep that was under way
             const int par = s_gg.par;
             for (int u = tid; u < SL; u += SV_COOP_THREADS)
@@ -2254,7 +2262,7 @@ extern "C" int psk_logreg_l1_fit(psk_ctx *ctx, const float *X, const int32_t *y0
         // fewer than 1,024 samples: its builds are cheap there and an ill-conditioned fit at a tight tolerance converges in
         // fewer Newton steps than with the f32 / bf16-split Q of the global form (256 x 150 near-duplicates at tol = 1e-7:
         // inside 300 steps against not); from 1,024 samples on the global form is 3-10 x faster (2048 x 169 grid 0.27 ->
-        // 0.10 s, 2000 x 150: 0.14 -> 0.012 s)
+        // 0.03 s, 2000 x 150: 0.14 -> 0.012 s)
         const int gg_min_p1 = getenv("PSK_GG_MIN_P1") ? atoi(getenv("PSK_GG_MIN_P1")) : (n >= 1024 ? 64 : 192);
         if (P1 > gg_min_p1 && P1 <= 1024 && wmreg_h > 0 && SV_COOP_WAVES == 4 && !getenv("PSK_NO_GRAM") && !getenv("PSK_NO_GRAM_GLOBAL")) {
             const size_t sl = 256 * (((size_t)P1 + 255) / 256), np_h = (size_t)W * 64;
@@ -2345,7 +2353,10 @@ extern "C" int psk_logreg_l1_fit(psk_ctx *ctx, const float *X, const int32_t *y0
             (double *)b.work, (int32_t *)b.iwork, f_lds, s_lds, c_lds, (int)q_doubles,
             // CG steps per polish (the Gram-global form uses a quarter of them, at least 4, while steps are cut short early)
             getenv("PSK_CG_MAX") ? atoi(getenv("PSK_CG_MAX")) : 16,
-            getenv("PSK_POLISH_REPS") ? atoi(getenv("PSK_POLISH_REPS")) : 64,   // polishes in a row while signs change
+            // polishes in a row while signs change; negative (the Gram-global form's default): as many as the descent has needed
+            // sweeps when the accelerator is called (32, 64, 128), at most that many -- the 2048 x 169 grid 0.105 -> 0.031 s, the
+            // 2048 x 907 grid 0.236 -> 0.245 s against a fixed 64
+            getenv("PSK_POLISH_REPS") ? atoi(getenv("PSK_POLISH_REPS")) : (gg_sl ? -128 : 64),
             (const uint64_t *)b.bitsT, gg_sl, (float *)b.ggq, gg_stride,
             getenv("PSK_GG_POLISH_FROM") ? atoi(getenv("PSK_GG_POLISH_FROM")) : 32);   // first polish of a descent after this many sweeps
         PSK_HIP(ctx, hipGetLastError());
