@@ -1241,10 +1241,13 @@ __global__ __launch_bounds__(WMREG > 0 ? SV_COOP_THREADS : SV_THREADS) void logr
             // on their way to zero: each repeat lands one of them) short runs with many repeats do (2048 x 907 grid: 4 steps
             // x 64 repeats 0.23 s, 6 x 64 0.32 s; 1500 x 400: 16 steps 0.37 s, 4 steps 1.25 s; near-separable 256 x 70: 16
             // steps 65 Newton steps at most, 4 steps 350)
+#ifndef PSK_GG_TDEEP
+#define PSK_GG_TDEEP 0.5   // a step of at least this share of the way: the next CG run is a long one
+#endif
             double t_last = 1.0;
             const int cg_short = cg_max < 4 ? cg_max : (cg_max / 4 > 4 ? cg_max / 4 : 4);
             const int reps_now = gg_polish_repeats(polish_reps, s_gg.iters);
-            for (int rep = 0; rep < reps_now && gg_polish(A, t_last >= 0.5 ? cg_max : cg_short, t_last); rep++) {}
+            for (int rep = 0; rep < reps_now && gg_polish(A, t_last >= PSK_GG_TDEEP ? cg_max : cg_short, t_last); rep++) {}
             // the next segment: a new descent from this point, in the order of the sweep that was under way
             const int par = s_gg.par;
             for (int u = tid; u < SL; u += SV_COOP_THREADS)
