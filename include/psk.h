@@ -199,7 +199,7 @@ int psk_rescan_timed(psk_ctx *ctx, int reps, double *mean_ms);
  * Logistic: liblinear's L1R_LR objective ||w||_1 + |b| + C sum log(1+exp(-y(w.x+b))).
  * Lasso: (1/2n)||y - Xw - b||^2 + alpha ||w||_1, unpenalised intercept.
  * Device scratch for the duration of the call: the design in both orientations and the per-fit state (a few MB); a 0/1
- * design of up to 4096 samples with 193..1024 columns also takes a per-fit Gram matrix, n_fits x ~4 p^2 bytes
+ * design of up to 4096 samples with 193..1024 columns (65..1024 from 1,024 samples on) also takes a per-fit Gram matrix, n_fits x ~4 p^2 bytes
  * (0.5 GB for 143 fits of 907 columns; the form is skipped beyond 32 GB).
  */
 int psk_logreg_l1_fit(psk_ctx *ctx, const float *X, const int32_t *y01, int n, int p, const int32_t *fold,
