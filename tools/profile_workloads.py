@@ -9,6 +9,7 @@
   predict    `prediction` counting (f1): 256 x 5 Mbp against a 1,000-word model dictionary, and a 5,000-word one (global table)
   weights    the -w side path (f2) at 1,024 samples: MinHash sketches beside the counting (hash filter + select), the
              523,776 pair merges of mash_pairs_kernel, neighbour joining of the 1,024 leaves
+  solver4096 the same grid on a 4,096 x 1,000 design (the 64-word instance of the L1 kernel)
   lasso      the bit-packed Lasso grid (13 alphas x 10 folds + refits) of a 1,024-sample continuous run
 Each prints one JSON line: the algorithmic bytes per launch of its kernels (what `frac` in profiles/ is computed from).
 usage: tools/profile_workloads.py NAME"""
@@ -155,6 +156,28 @@ elif what == "solver":
         t0 = time.time()
         ctx.logreg_l1_fit(X, d["y"], d["fold"], d["fit_param"], d["fit_fold"], float(d["tol"]), int(d["max_iter"]))
         out["notes"]["fit2048_907"] = {"X": list(X.shape), "fits": int(len(d["fit_param"])), "wall_s": [round(time.time() - t0, 3)]}
+elif what == "solver4096":
+    # the 33..64-word instance of the L1 kernel (2,049 .. 4,096 samples).  A 4,096 x 1,000 design grown from the
+    # recorded 2,048 x 907 one: every genome once more with 2 % of its k-mer calls flipped, 93 further columns = existing ones
+    # with 1 % flips, labels of the second half with 5 % noise; the reference's grid (13 C x 10 folds + 13 refits = 143 fits)
+    d = np.load(os.path.join(ROOT, "tests", "golden", "fit2048_907.npz"))
+    X0 = np.unpackbits(d["Xbits"], axis=1)[:, : int(d["p"])].astype(bool)
+    rng = np.random.default_rng(4096)
+    X1 = np.vstack([X0, X0 ^ (rng.random(X0.shape) < 0.02)])
+    extra = X1[:, rng.integers(0, X1.shape[1], 93)] ^ (rng.random((4096, 93)) < 0.01)
+    X = np.hstack([X1, extra]).astype(np.float32)
+    y0 = d["y"].astype(np.int32)
+    y = np.concatenate([y0, y0 ^ (rng.random(2048) < 0.05)]).astype(np.int32)
+    fold = np.concatenate([d["fold"], d["fold"]]).astype(np.int32)
+    with PskContext(0) as ctx:
+        ctx.logreg_l1_fit(X[:, :50], y, fold, d["fit_param"][:2], d["fit_fold"][:2], 1e-4, 50)
+        ts, its = [], None
+        for rep in range(2):
+            t0 = time.time()
+            coef, icpt, its = ctx.logreg_l1_fit(X, y, fold, d["fit_param"], d["fit_fold"], float(d["tol"]), int(d["max_iter"]))
+            ts.append(round(time.time() - t0, 3))
+        out["notes"] = {"X": list(X.shape), "fits": int(len(d["fit_param"])), "wall_s": ts, "newton_max": int(its.max()),
+                        "newton_mean": round(float(its.mean()), 1), "nnz_mean": round(float((coef != 0).sum(axis=1).mean()), 1)}
 elif what == "predict":
     n, L, k = 256, 5_000_000, 13
     gs = GenomeSet(n, L, seed=12345)
