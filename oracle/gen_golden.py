@@ -528,6 +528,145 @@ def gen_model_mid_kat():
     print("mid-size model KATs:", out["obj_a"], out["obj_b"])
 
 
+def large_designs():
+    """The three designs of model_large_kat.npz: (tag, X bool [n][p], y int [n]).  'g' is the (2,048 x 907) top-1000 design of a
+    2,048-genome run (tests/golden/fit2048_907.npz: the columns our own pipeline selected -- an INPUT; everything stored about
+    it below is scikit-learn's output), 'h' and 'i' are near-duplicate designs (columns = one of nb factors with a few
+    samples flipped) on either side of the 1,024-sample border: 1,500 x 300 and 300 x 400."""
+    d = np.load(os.path.join(GOLD, "fit2048_907.npz"))
+    out = [("g", np.unpackbits(d["Xbits"], axis=1)[:, : int(d["p"])].astype(bool), d["y"].astype(int))]
+    rng = np.random.default_rng(4242)
+    for tag, n, p, nb, flip, noise in (("h", 1500, 300, 20, 0.03, 0.05), ("i", 300, 400, 30, 0.04, 0.08)):
+        base = rng.random((n, nb)) < 0.35
+        X = base[:, rng.integers(0, nb, p)] ^ (rng.random((n, p)) < flip)
+        y = ((base[:, 0] & base[:, 3]) ^ (rng.random(n) < noise)).astype(int)
+        assert len({X[:, j].tobytes() for j in range(p)}) == p      # distinct columns: coefficients are comparable one by one
+        out.append((tag, X, y))
+    return out
+
+
+def gen_model_large_kat(only=None):
+    """reference outputs for the solver forms that carry every large fit (Gram matrix in global memory: more
+    than 192 distinct columns at any n, more than 64 from 1,024 samples on; and the four-wave array form behind it).
+    modeling.py:1011-1014 (LogisticRegression(penalty='l1', solver='liblinear')), :1078-1085 + :1208-1216 (GridSearchCV over
+    C = 1 / logspace(-3, 3, 13), cv = min(min class, 10) from :1512-1524, accuracy, refit).  Per design:
+      * liblinear run as tightly as it converges in minutes (tol 1e-8 up to C = 10, 1e-6 at C = 100) at C in {0.01 .. 100} on
+        all samples and on two training folds of the StratifiedKFold split: coefficients, intercept, objective, n_iter;
+      * the exact optimum next to it: oracle_model.logreg_l1_arbiter seeded with liblinear's point (active-set Newton until
+        the KKT residual of liblinear's own objective is < 1e-10 max(1, C) -- a certificate anyone can re-check from the stored
+        point with one gradient evaluation, tests/test_oracle_golden.py does);
+      * GridSearchCV exactly as the reference configures it (tol = 1e-4, max_iter = 1000; the reference leaves
+        random_state = None, i.e. liblinear's coordinate order changes from run to run, so three seeds are recorded: their
+        spread is what 'the same scores as scikit-learn' can mean)."""
+    import oracle_model as OM
+    from sklearn.linear_model import LogisticRegression
+    from sklearn.model_selection import GridSearchCV, StratifiedKFold
+    Cs_fit = [0.01, 0.1, 1.0, 10.0, 100.0]
+    grid = [1 / a for a in np.logspace(-3, 3, 13)]
+    path = os.path.join(GOLD, "model_large_kat.npz")
+    out = dict(np.load(path)) if (only and os.path.exists(path)) else {}
+    out["Cs_fit"], out["grid"] = np.array(Cs_fit), np.array(grid)
+    for tag, Xb, y in large_designs():
+        if only and tag not in only:
+            continue
+        n, p = Xb.shape
+        X = Xb.astype(np.float64)
+        cv = int(min(np.bincount(y).min(), 10))
+        fold = np.full(n, -1)
+        for f, (_, te) in enumerate(StratifiedKFold(n_splits=cv).split(X, y)):
+            fold[te] = f
+        held = [-1, 0, cv - 3]
+        if tag != "g":
+            out["X_" + tag] = np.packbits(Xb, axis=0)
+            out["y_" + tag] = y
+        out["n_" + tag], out["fold_" + tag], out["held_" + tag] = np.array(n), fold, np.array(held)
+        rec = {k: [] for k in ("lib_coef", "lib_icpt", "lib_obj", "lib_tol", "lib_niter", "lib_secs", "arb_coef", "arb_group", "arb_icpt",
+                               "arb_obj", "arb_kkt", "fit_C", "fit_held")}
+        for hf in held:
+            tr = fold != hf
+            Xt, yt = X[tr], y[tr]
+            ypm = 2.0 * yt - 1.0
+            for C in Cs_fit:
+                tol = 1e-8 if C <= 10 else 1e-6
+                t0 = time.time()
+                m = LogisticRegression(penalty="l1", solver="liblinear", C=C, tol=tol, max_iter=1000000, random_state=0).fit(Xt, yt)
+                secs = time.time() - t0
+                w, b = m.coef_[0].copy(), float(m.intercept_[0])
+                obj = np.abs(w).sum() + abs(b) + C * np.logaddexp(0, -ypm * (Xt @ w + b)).sum()
+                a = OM.logreg_l1_arbiter(Xt, yt, C, w, b, max_rounds=400)
+                # (the residual's floor is the rounding of the gradient's sums, ~ C n 2^-53 per coordinate: 1e-9 at C = 100)
+                assert a["kkt"] < 1e-10 * max(1.0, C) and not a["rank_deficient"], (tag, hf, C, a["kkt"], a["rank_deficient"])
+                # on a training fold two columns may differ in held-out rows only: the arbiter collapses them and the SUM of
+                # their coefficients is what is unique -- stored on the first column of each group, the groups beside it
+                grp = a["group"]
+                first = np.full(len(a["w_groups"]), -1)
+                for j in range(p - 1, -1, -1):
+                    first[grp[j]] = j
+                aw = np.zeros(p)
+                aw[first] = a["w_groups"]
+                assert a["objective"] <= obj * (1 + 1e-14), (tag, hf, C, a["objective"], obj)
+                for k, v in (("lib_coef", w), ("lib_icpt", b), ("lib_obj", obj), ("lib_tol", tol), ("lib_niter", int(m.n_iter_[0])),
+                             ("lib_secs", secs), ("arb_coef", aw), ("arb_group", grp), ("arb_icpt", a["b"]), ("arb_obj", a["objective"]),
+                             ("arb_kkt", a["kkt"]), ("fit_C", C), ("fit_held", hf)):
+                    rec[k].append(v)
+                print("large KAT %s held %2d C %-6g liblinear %.1fs n_iter %d obj %.12g; arbiter obj %.12g (rel %.1e) kkt %.1e nnz %d"
+                      % (tag, hf, C, secs, m.n_iter_[0], obj, a["objective"], obj / a["objective"] - 1, a["kkt"],
+                         int((a["w_groups"] != 0).sum())), flush=True)
+        for k, v in rec.items():
+            out[k + "_" + tag] = np.array(v)
+        sc, best = [], []
+        for seed in (0, 1, 2):
+            t0 = time.time()
+            gs = GridSearchCV(LogisticRegression(penalty="l1", solver="liblinear", tol=1e-4, max_iter=1000, random_state=seed),
+                              {"C": grid}, cv=cv, n_jobs=6).fit(X, y)
+            sc.append(np.array([gs.cv_results_["split%d_test_score" % f] for f in range(cv)]).T)   # [candidate][fold]
+            best.append(gs.best_params_["C"])
+            print("large KAT %s GridSearchCV seed %d: %.0fs best C %g mean scores %s" % (
+                tag, seed, time.time() - t0, best[-1], np.round(gs.cv_results_["mean_test_score"], 4).tolist()), flush=True)
+        out["gs_split_scores_" + tag] = np.array(sc)          # [seed][candidate][fold]
+        out["gs_best_C_" + tag] = np.array(best)
+        np.savez_compressed(path, **out)
+    np.savez_compressed(path, **out)
+
+
+def gen_lasso_large_kat():
+    """scikit-learn's Lasso exactly as the reference configures it (modeling.py:999-1000: Lasso(max_iter=1000,
+    tol=1e-4); :1041 alpha = logspace(-3, 3, 13); GridSearchCV with cv = 10, R^2) on a 1,024 x 907 design -- the first 1,024
+    genomes of fit2048_907.npz with a continuous phenotype carried by two k-mers --: per alpha, on all samples and on two
+    training folds of KFold(10): coef_, intercept_, n_iter_ (several fits end at the 1,000-sweep limit: the fixture pins the
+    point scikit-learn's cyclic descent has reached THEN, not an optimum) and dual_gap_; plus the grid search's scores."""
+    import warnings
+    from sklearn.linear_model import Lasso
+    from sklearn.model_selection import GridSearchCV, KFold
+    d = np.load(os.path.join(GOLD, "fit2048_907.npz"))
+    X = np.unpackbits(d["Xbits"], axis=1)[:1024, : int(d["p"])].astype(np.float64)
+    rng = np.random.default_rng(5)
+    y = 2.0 * X[:, 3] - 1.5 * X[:, 40] + rng.normal(0, 0.5, 1024)
+    alphas = np.logspace(-3, 3, 13)
+    fold = np.full(1024, -1)
+    for f, (_, te) in enumerate(KFold(n_splits=10).split(X)):
+        fold[te] = f
+    out = {"y": y, "alphas": alphas, "fold": fold, "held": np.array([-1, 0, 6])}
+    rec = {k: [] for k in ("coef", "icpt", "n_iter", "gap", "fit_alpha", "fit_held")}
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        for hf in out["held"]:
+            tr = fold != hf
+            for a in alphas:
+                m = Lasso(alpha=a, tol=1e-4, max_iter=1000).fit(X[tr], y[tr])
+                for k, v in (("coef", m.coef_), ("icpt", m.intercept_), ("n_iter", m.n_iter_), ("gap", m.dual_gap_), ("fit_alpha", a),
+                             ("fit_held", hf)):
+                    rec[k].append(v)
+                print("lasso KAT held %2d alpha %-8g n_iter %4d gap %.3e nnz %d" % (hf, a, m.n_iter_, m.dual_gap_, (m.coef_ != 0).sum()), flush=True)
+        gs = GridSearchCV(Lasso(tol=1e-4, max_iter=1000), {"alpha": alphas}, cv=10).fit(X, y)
+    for k, v in rec.items():
+        out[k] = np.array(v)
+    out["gs_split_scores"] = np.array([gs.cv_results_["split%d_test_score" % f] for f in range(10)]).T
+    out["gs_best_alpha"] = np.array(gs.best_params_["alpha"])
+    np.savez_compressed(os.path.join(GOLD, "lasso_large_kat.npz"), **out)
+    print("lasso large KAT: best alpha", out["gs_best_alpha"], "mean scores", np.round(gs.cv_results_["mean_test_score"], 5).tolist())
+
+
 def gen_gmer_counter():
     """prediction.py:72-80,145-148: db line 'KMER\\t1\\tKMER', output parsed at :82-100."""
     gs = GenomeSet(4, 6000, seed=31, gene_len=200)
@@ -638,6 +777,13 @@ if __name__ == "__main__":
         gen_model_l2_kat()
     if "model_mid" in what:
         gen_model_mid_kat()
+    if "lasso_large" in what:
+        gen_lasso_large_kat()
+    if "model_large" in what:      # ~25 min (liblinear at C = 10 / 100 on the 2,048 x 907 design: 2 min per fit); not in the default list
+        gen_model_large_kat()
+    for w_ in what:
+        if w_.startswith("model_large:"):
+            gen_model_large_kat(only=w_.split(":")[1].split(","))
     if "gmer" in what:
         gen_gmer_counter()
     if "mash" in what:

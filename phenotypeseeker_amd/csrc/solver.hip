@@ -15,6 +15,7 @@
 // Latency-bound, f64 VALU; the roofline that matters for this stage is wall-clock, not bandwidth
 // (DESIGN.md).  The host removes duplicated columns first (model.GridSearch): k-mers of one gene share
 // one presence pattern, and an L1 optimum may put a pattern's weight on any one of its copies.
+#include <algorithm>
 #include <cerrno>
 
 #include "solver_common.h"
@@ -71,7 +72,7 @@ __global__ __launch_bounds__(SV_THREADS) void logreg_newglmnet_kernel(
     }
     double w_norm = 0.0, Gmax_old = 1e300, Gnorm1_init = -1.0, inner_eps = 1.0;
     uint32_t rng = ((uint32_t)fit + 1u) * 2654435761u | 1u;  // per-fit xorshift state of the sweep permutations (lane 0's copy counts)
-    int newton = 0;
+    int newton = 0, floor_steps = 0;   // floor_steps: Newton steps in a row taken inside the line search's rounding noise
     for (newton = 0; newton < max_newton; newton++) {
         double Gmax_new = 0.0, Gnorm1_new = 0.0;
         int active = P1;
@@ -190,7 +191,7 @@ __global__ __launch_bounds__(SV_THREADS) void logreg_newglmnet_kernel(
         for (int i = lane; i < n; i += SV_THREADS)
             if (fold[i] != tf && ypm[i] < 0) negsum += C * xTd[i];
         negsum = psk_wave_sum_f64_dpp(negsum);
-        bool accepted = false;
+        bool accepted = false, floor_rebuild = false;
         for (int ls = 0; ls < 20; ls++) {
             double cs = 0.0;
             for (int i = lane; i < n; i += SV_THREADS) {
@@ -201,7 +202,17 @@ __global__ __launch_bounds__(SV_THREADS) void logreg_newglmnet_kernel(
                 cs += C * log((1.0 + en) / (ex + en));
             }
             const double cond = w_norm_new - w_norm + negsum - sigma * delta + psk_wave_sum_f64_dpp(cs);
-            if (cond <= 0.0) {
+            // liblinear accepts when cond <= 0.  Close to the optimum the decrease the model predicts sinks below what the sum of
+            // l logarithms can resolve in doubles (~C l 2^-52): the sign of cond is then noise, twenty halvings only make the
+            // step smaller, and a fit run at a tolerance near that floor repeats the same rejected step until max_iter (r04:
+            // fits at tol = 1e-12 either stopped after ~100 Newton steps or never).  A step whose cond is inside the noise is
+            // taken whole -- near the optimum the quadratic model is the better judge -- and exp(w.x) is then rebuilt from w
+            // (below: accepting such steps without it, the multiplicatively updated copy drifted over thousands of them and one
+            // fit "converged" 26 % away); three such steps in a row end the fit: it is where doubles can take it.  At the
+            // tolerances the reference runs at |cond| is many orders above the noise and nothing changes.
+            const bool in_noise = cond > 0.0 && cond <= 4.0 * 2.220446049250313e-16 * C * l;
+            floor_steps = in_noise ? floor_steps + 1 : (cond <= 0.0 ? 0 : floor_steps);
+            if (cond <= 0.0 || in_noise) {
                 w_norm = w_norm_new;
                 for (int j = 0; j < P1; j++) { if (lane == 0) w[j] = wpd[j]; }
                 for (int i = lane; i < n; i += SV_THREADS) {
@@ -211,6 +222,7 @@ __global__ __launch_bounds__(SV_THREADS) void logreg_newglmnet_kernel(
                     ewx[i] = en; tau[i] = C * tt; D[i] = C * en * tt * tt;
                 }
                 accepted = true;
+                floor_rebuild = in_noise;
                 break;
             }
             w_norm_new = 0.0;
@@ -223,7 +235,7 @@ __global__ __launch_bounds__(SV_THREADS) void logreg_newglmnet_kernel(
             negsum *= 0.5;
             for (int i = lane; i < n; i += SV_THREADS) xTd[i] *= 0.5;
         }
-        if (!accepted) {
+        if (!accepted || floor_rebuild) {
             // the step was rejected 20 times: fall back to the current w and, as liblinear does after "too many
             // line search steps", rebuild exp(w.x) from w -- the multiplicatively updated copy has drifted and
             // the gradient computed from it would reject every further step (r01: fits spinning to max_iter)
@@ -243,6 +255,7 @@ __global__ __launch_bounds__(SV_THREADS) void logreg_newglmnet_kernel(
             }
         }
         if (iter == 1) inner_eps *= 0.25;
+        if (floor_steps >= 3) { newton++; break; }   // at the floor of what doubles resolve (see the line search)
         Gmax_old = Gmax_new;
     }
     for (int j = 0; j < p; j++) { if (lane == 0) coef[(size_t)fit * p + j] = w[j]; }
@@ -273,7 +286,14 @@ __global__ __launch_bounds__(SV_THREADS) void lasso_kernel(const float *__restri
     sy = psk_wave_sum_f64_dpp(sy);
     const double ntrain = psk_wave_sum_f64_dpp(cnt);
     const double ym = sy / ntrain;
-    for (int i = lane; i < n; i += SV_THREADS) r[i] = (fold[i] != tf) ? (y[i] - ym) : 0.0;
+    double yy = 0.0;   // y'y of the centred problem: scikit-learn's gap tolerance is tol y'y
+    for (int i = lane; i < n; i += SV_THREADS) {
+        const double d = (fold[i] != tf) ? (y[i] - ym) : 0.0;
+        r[i] = d;
+        yy += d * d;
+    }
+    yy = psk_wave_sum_f64_dpp(yy);
+    const double an = alpha * ntrain, tol_s = tol * yy;
     for (int j = 0; j < p; j++) {
         const float *col = XT + (size_t)j * n;
         double s1 = 0, s2 = 0;
@@ -302,7 +322,7 @@ __global__ __launch_bounds__(SV_THREADS) void lasso_kernel(const float *__restri
             for (int i = lane; i < n; i += SV_THREADS)
                 if (fold[i] != tf) s += ((double)col[i] - m) * r[i];
             const double rho = psk_wave_sum_f64_dpp(s) + nj * wj;
-            const double mag = fabs(rho) - alpha * ntrain;
+            const double mag = fabs(rho) - an;
             const double nw = (mag > 0.0) ? ((rho > 0 ? mag : -mag) / nj) : 0.0;
             const double dd = nw - wj;
             if (dd != 0.0) {
@@ -315,7 +335,31 @@ __global__ __launch_bounds__(SV_THREADS) void lasso_kernel(const float *__restri
             if (fabs(dd) > dmax) dmax = fabs(dd);
             if (fabs(nw) > wmax) wmax = fabs(nw);
         }
-        if (dmax == 0.0 || dmax <= tol * (wmax > 1e-300 ? wmax : 1e-300)) { sweep++; break; }
+        // scikit-learn's stop (enet_coordinate_descent): after a sweep whose largest step is below tol x the largest
+        // coefficient -- or the last sweep allowed -- the duality gap is evaluated and the descent ends when gap < tol y'y
+        if (wmax == 0.0 || dmax / wmax < tol || sweep == max_iter - 1) {
+            double dual = 0.0, l1 = 0.0;
+            for (int j = 0; j < p; j++) {
+                const float *col = XT + (size_t)j * n;
+                const double m = lane0_load(&xm[j], lane);
+                double s = 0.0;
+                for (int i = lane; i < n; i += SV_THREADS)
+                    if (fold[i] != tf) s += ((double)col[i] - m) * r[i];
+                s = psk_wave_sum_f64_dpp(s);
+                dual = fmax(dual, fabs(s));
+                l1 += fabs(lane0_load(&w[j], lane));
+            }
+            double rr = 0.0, ry = 0.0;
+            for (int i = lane; i < n; i += SV_THREADS)
+                if (fold[i] != tf) { rr += r[i] * r[i]; ry += r[i] * (y[i] - ym); }
+            rr = psk_wave_sum_f64_dpp(rr);
+            ry = psk_wave_sum_f64_dpp(ry);
+            double cst = 1.0, gap;
+            if (dual > an) { cst = an / dual; gap = 0.5 * (rr + rr * (cst * cst)); }
+            else gap = rr;
+            gap += an * l1 - cst * ry;
+            if (gap < tol_s) { sweep++; break; }
+        }
     }
     double acc = 0.0;
     for (int j = 0; j < p; j++) acc += lane0_load(&xm[j], lane) * lane0_load(&w[j], lane);
@@ -349,7 +393,7 @@ __global__ __launch_bounds__(SV_COOP_THREADS) void lasso_bits_kernel(const uint6
     const double alpha = fit_param[fit];
     const int tf = fit_fold[fit];
     // this wave's training samples and their y
-    double R[WQ];
+    double R[WQ], Yc[WQ];
     uint64_t tmask = 0;
     double sy = 0.0, cn = 0.0;
 #pragma unroll
@@ -375,9 +419,15 @@ __global__ __launch_bounds__(SV_COOP_THREADS) void lasso_bits_kernel(const uint6
 #pragma unroll
     for (int v = 1; v < SV_COOP_WAVES; v++) { ysum += s_part[0][v]; ntrain += s_tot[0][v]; }
     const double ym = ysum / ntrain;
+    double yyw = 0.0;
 #pragma unroll
-    for (int q = 0; q < WQ; q++)
+    for (int q = 0; q < WQ; q++) {
         if ((tmask >> (t0 + q)) & 1) R[q] -= ym;
+        Yc[q] = R[q];            // the centred y of the training samples (0 elsewhere): R'y of the duality gap
+        yyw += R[q] * R[q];
+    }
+    yyw = psk_wave_sum_f64_dpp(yyw);
+    if (lane == 0) s_tot[1][wave] = yyw;
     for (int j = threadIdx.x; j < p; j += SV_COOP_THREADS) {
         uint32_t c = 0;
 #pragma unroll
@@ -395,10 +445,11 @@ __global__ __launch_bounds__(SV_COOP_THREADS) void lasso_bits_kernel(const uint6
     Rw = psk_wave_sum_f64_dpp(Rw);
     if (lane == 0) s_part[1][wave] = Rw;
     __syncthreads();
-    double Rp = s_part[1][0];
+    double Rp = s_part[1][0], yy = s_tot[1][0];
 #pragma unroll
-    for (int v = 1; v < SV_COOP_WAVES; v++) Rp += s_part[1][v];
+    for (int v = 1; v < SV_COOP_WAVES; v++) { Rp += s_part[1][v]; yy += s_tot[1][v]; }
     __syncthreads();
+    const double an = alpha * ntrain, tol_s = tol * yy;
     double c = 0.0;
     int sweep = 0, visit = 0;
     auto col_t = [&](int j) { return (colT[(size_t)j * 64 + lane] & tmask) >> t0; };
@@ -427,7 +478,7 @@ __global__ __launch_bounds__(SV_COOP_THREADS) void lasso_bits_kernel(const uint6
 #pragma unroll
             for (int v = 1; v < SV_COOP_WAVES; v++) S1 += s_part[slot][v];
             const double rho = ((S1 + c * cj) - mj * (Rp + c * ntrain)) + nj * wj;
-            const double mag = fabs(rho) - alpha * ntrain;
+            const double mag = fabs(rho) - an;
             const double nw = (mag > 0.0) ? ((rho > 0 ? mag : -mag) / nj) : 0.0;
             const double dd = nw - wj;
             if (dd != 0.0) {
@@ -443,7 +494,50 @@ __global__ __launch_bounds__(SV_COOP_THREADS) void lasso_bits_kernel(const uint6
             if (fabs(nw) > wmax) wmax = fabs(nw);
         }
         __syncthreads();   // w of this sweep is in place for the next one (and for the end)
-        if (dmax == 0.0 || dmax <= tol * (wmax > 1e-300 ? wmax : 1e-300)) { sweep++; break; }
+        // scikit-learn's stop (see lasso_kernel): the duality gap, when it would evaluate it.  X'R of every column is one
+        // more pass of masked sums (no steps), R'R and R'y come from the registers (r = r' + c on the training samples)
+        if (wmax == 0.0 || dmax / wmax < tol || sweep == max_iter - 1) {
+            double dual = 0.0, l1 = 0.0;
+            uint64_t mg_next = p > 0 ? col_t(0) : 0ull;
+            for (int j = 0; j < p; j++) {
+                const uint64_t x = mg_next;
+                if (j + 1 < p) mg_next = col_t(j + 1);
+                uint64_t M[WQ];
+#pragma unroll
+                for (int q = 0; q < WQ; q++) M[q] = __ballot((x >> q) & 1ull);
+                double S = 0.0;
+                if (WQ == 16) { masked_sum8(S, M, R); masked_sum8(S, M + (WQ == 16 ? 8 : 0), R + (WQ == 16 ? 8 : 0)); }
+                else if (WQ == 8) masked_sum8(S, M, R);
+                else masked_sum4(S, M, R);
+                S = psk_wave_sum_f64_dpp(S);
+                const int slot = visit & 1;
+                visit++;
+                if (lane == 0) s_part[slot][wave] = S;
+                __syncthreads();
+                double S1 = s_part[slot][0];
+#pragma unroll
+                for (int v = 1; v < SV_COOP_WAVES; v++) S1 += s_part[slot][v];
+                dual = fmax(dual, fabs((S1 + c * cntd[j]) - mean[j] * (Rp + c * ntrain)));
+                l1 += fabs(w[j]);
+            }
+            double rr = 0.0, ry = 0.0;
+#pragma unroll
+            for (int q = 0; q < WQ; q++)
+                if ((tmask >> (t0 + q)) & 1) { const double rv = R[q] + c; rr += rv * rv; ry += rv * Yc[q]; }
+            rr = psk_wave_sum_f64_dpp(rr);
+            ry = psk_wave_sum_f64_dpp(ry);
+            __syncthreads();
+            if (lane == 0) { s_part[0][wave] = rr; s_part[1][wave] = ry; }
+            __syncthreads();
+            rr = (s_part[0][0] + s_part[0][1]) + (s_part[0][2] + s_part[0][3]);
+            ry = (s_part[1][0] + s_part[1][1]) + (s_part[1][2] + s_part[1][3]);
+            __syncthreads();
+            double cst = 1.0, gap;
+            if (dual > an) { cst = an / dual; gap = 0.5 * (rr + rr * (cst * cst)); }
+            else gap = rr;
+            gap += an * l1 - cst * ry;
+            if (gap < tol_s) { sweep++; break; }
+        }
     }
     double acc = 0.0;
     for (int j = threadIdx.x; j < p; j += SV_COOP_THREADS) {
@@ -719,9 +813,85 @@ extern "C" int psk_lasso_fit(psk_ctx *ctx, const float *X, const double *y, int 
     SV_ALLOC(b.coef, (size_t)n_fits * p * 8);
     SV_ALLOC(b.icpt, (size_t)n_fits * 8);
     SV_ALLOC(b.iters, (size_t)n_fits * 4);
-    // presence/absence design (every entry 0 or 1), its per-column state in LDS -> the bit-packed four-wave kernel
+    // presence/absence design (every entry 0 or 1): the covariance form (solver_lasso.hip) up to 1,024 columns, else the
+    // four-wave kernel on the bit-packed samples (per-column state in LDS); PSK_NO_LASSO_COV / PSK_NO_LASSO_BITS for A/B runs
     bool binary = n <= 4096 && !env_flag("PSK_NO_LASSO_BITS");
     for (size_t q = 0; binary && q < (size_t)n * p; q++) binary = (X[q] == 0.0f || X[q] == 1.0f);
+    if (binary && p <= 1024 && !env_flag("PSK_NO_LASSO_COV")) {
+        const int W = (n + 63) / 64, PP = 64 * ((p + 63) / 64);
+        // the distinct held-out folds of the call: fits of one fold share its counts
+        std::vector<int32_t> fold_ids, fidx(n_fits);
+        for (int j = 0; j < n_fits; j++) {
+            size_t q = 0;
+            while (q < fold_ids.size() && fold_ids[q] != fit_fold[j]) q++;
+            if (q == fold_ids.size()) fold_ids.push_back(fit_fold[j]);
+            fidx[j] = (int32_t)q;
+        }
+        const int F = (int)fold_ids.size();
+        if ((size_t)F * PP * PP * 2 <= ((size_t)2 << 30)) {
+            std::vector<uint64_t> bits((size_t)PP * W, 0), tmask((size_t)F * W, 0);
+            for (int i = 0; i < n; i++)
+                for (int j = 0; j < p; j++)
+                    if (X[(size_t)i * p + j] != 0.0f) bits[(size_t)j * W + (i >> 6)] |= 1ull << (i & 63);
+            std::vector<double> yc((size_t)F * n, 0.0), fstat((size_t)F * 4, 0.0);
+            for (int f = 0; f < F; f++) {
+                double sy = 0.0, cnt = 0.0, yy = 0.0;
+                for (int i = 0; i < n; i++)
+                    if (fold[i] != fold_ids[f]) { sy += y[i]; cnt += 1.0; tmask[(size_t)f * W + (i >> 6)] |= 1ull << (i & 63); }
+                if (cnt < 1.0) return psk_fail(ctx, PSK_EINVAL, "fold %d leaves no training sample", fold_ids[f]);
+                const double ym = sy / cnt;
+                for (int i = 0; i < n; i++)
+                    if (fold[i] != fold_ids[f]) { const double d = y[i] - ym; yc[(size_t)f * n + i] = d; yy += d * d; }
+                fstat[4 * f] = ym; fstat[4 * f + 1] = yy; fstat[4 * f + 2] = cnt;
+            }
+            // Workgroups go round the eight XCDs (workgroup b runs on XCD b % 8), each with its own 4-MB L2: the fits are
+            // ordered by fold and XCD x takes a contiguous stretch of that order, so that the fits sharing an L2 read the
+            // same one or two count matrices (1.6 MB each at 907 columns)
+            std::vector<int32_t> order(n_fits);
+            for (int j = 0; j < n_fits; j++) order[j] = j;
+            std::stable_sort(order.begin(), order.end(), [&](int32_t u, int32_t v) { return fidx[u] < fidx[v]; });
+            const int G = (n_fits + 7) / 8, n_blocks = 8 * G;
+            std::vector<int32_t> block_fit(n_blocks, -1);
+            for (int bq = 0; bq < n_blocks; bq++) {
+                const int sidx = (bq % 8) * G + bq / 8;
+                if (sidx < n_fits) block_fit[bq] = order[sidx];
+            }
+            void *d_bits = nullptr, *d_tmask = nullptr, *d_yc = nullptr, *d_fstat = nullptr, *d_C = nullptr, *d_Dg = nullptr, *d_q0 = nullptr,
+                 *d_bf = nullptr, *d_fidx = nullptr;
+            struct Free { std::vector<void **> v; ~Free() { for (void **q : v) if (*q) (void)hipFree(*q); } } fr;
+            fr.v = {&d_bits, &d_tmask, &d_yc, &d_fstat, &d_C, &d_Dg, &d_q0, &d_bf, &d_fidx};
+            SV_ALLOC(d_bits, bits.size() * 8);
+            SV_ALLOC(d_tmask, tmask.size() * 8);
+            SV_ALLOC(d_yc, yc.size() * 8);
+            SV_ALLOC(d_fstat, fstat.size() * 8);
+            SV_ALLOC(d_C, (size_t)F * PP * PP * 2);
+            SV_ALLOC(d_Dg, (size_t)F * (PP / 64) * 4096 * 8);
+            SV_ALLOC(d_q0, (size_t)F * PP * 8);
+            SV_ALLOC(d_bf, (size_t)n_blocks * 4);
+            SV_ALLOC(d_fidx, (size_t)n_fits * 4);
+            PSK_HIP(ctx, hipMemcpyAsync(d_bits, bits.data(), bits.size() * 8, hipMemcpyHostToDevice, ctx->stream));
+            PSK_HIP(ctx, hipMemcpyAsync(d_tmask, tmask.data(), tmask.size() * 8, hipMemcpyHostToDevice, ctx->stream));
+            PSK_HIP(ctx, hipMemcpyAsync(d_yc, yc.data(), yc.size() * 8, hipMemcpyHostToDevice, ctx->stream));
+            PSK_HIP(ctx, hipMemcpyAsync(d_fstat, fstat.data(), fstat.size() * 8, hipMemcpyHostToDevice, ctx->stream));
+            PSK_HIP(ctx, hipMemcpyAsync(d_bf, block_fit.data(), (size_t)n_blocks * 4, hipMemcpyHostToDevice, ctx->stream));
+            PSK_HIP(ctx, hipMemcpyAsync(d_fidx, fidx.data(), (size_t)n_fits * 4, hipMemcpyHostToDevice, ctx->stream));
+            PSK_HIP(ctx, hipMemcpyAsync(b.param, fit_param, (size_t)n_fits * 8, hipMemcpyHostToDevice, ctx->stream));
+            psk_lasso_cov_args A;
+            A.bits = (const uint64_t *)d_bits; A.tmask = (const uint64_t *)d_tmask; A.yc = (const double *)d_yc;
+            A.fstat = (const double *)d_fstat; A.C = (uint16_t *)d_C; A.Dg = (double *)d_Dg; A.q0 = (double *)d_q0;
+            A.block_fit = (const int32_t *)d_bf; A.fit_param = (const double *)b.param; A.fit_fidx = (const int32_t *)d_fidx;
+            A.n = n; A.p = p; A.PP = PP; A.W = W; A.n_folds = F; A.n_blocks = n_blocks; A.max_iter = max_iter; A.tol = tol;
+            A.coef = (double *)b.coef; A.icpt = (double *)b.icpt; A.gaps = nullptr; A.iters = (int32_t *)b.iters; A.stream = ctx->stream;
+            PSK_HIP(ctx, psk_lasso_cov_launch(A));
+            PSK_HIP(ctx, hipMemcpyAsync(coef_out, b.coef, (size_t)n_fits * p * 8, hipMemcpyDeviceToHost, ctx->stream));
+            PSK_HIP(ctx, hipMemcpyAsync(icpt_out, b.icpt, (size_t)n_fits * 8, hipMemcpyDeviceToHost, ctx->stream));
+            std::vector<int32_t> itc(n_fits);
+            PSK_HIP(ctx, hipMemcpyAsync(itc.data(), b.iters, (size_t)n_fits * 4, hipMemcpyDeviceToHost, ctx->stream));
+            PSK_HIP(ctx, hipStreamSynchronize(ctx->stream));   // the host vectors must outlive their copies
+            if (iters_out) memcpy(iters_out, itc.data(), (size_t)n_fits * 4);
+            return PSK_OK;
+        }
+    }
     const size_t lds_bits = (size_t)p * (4 * 8 + SV_COOP_WAVES * 4);
     if (binary && lds_bits <= 150 * 1024) {
         const int W = (n + 63) / 64;

@@ -112,3 +112,23 @@ struct psk_l1_bits_launch {
 // LDS Gram block / array forms (solver_l1_gram.hip) and the Gram matrix in global memory (solver_l1_gg.hip)
 hipError_t psk_l1_bits_launch_gram(const psk_l1_bits_launch &a);
 hipError_t psk_l1_bits_launch_gg(const psk_l1_bits_launch &a);
+
+// What psk_lasso_fit hands to the covariance-form Lasso (solver_lasso.hip): the co-occurrence counts of every held-out
+// fold, then one workgroup per fit.
+struct psk_lasso_cov_args {
+    const uint64_t *bits;      // [PP][W] column bit words (sample i = bit i & 63 of word i >> 6), zero rows beyond p
+    const uint64_t *tmask;     // [n_folds][W] training samples of a fold
+    const double *yc;          // [n_folds][n] y - mean over the fold's training samples, 0 for the others
+    const double *fstat;       // [n_folds][4]: mean of y, sum of squares of the centred y, training samples, -
+    uint16_t *C;               // [n_folds][PP / 64][PP / 64] tiles of 64 x 64 co-occurrence counts, a tile as [8][64 rows][8] (out)
+    double *Dg, *q0;           // [n_folds][PP / 64][64][64] centred diagonal blocks, [n_folds][PP] X'y (out)
+    const int32_t *block_fit;  // [n_blocks] the fit a workgroup solves (-1: none)
+    const double *fit_param;
+    const int32_t *fit_fidx;   // [n_fits] index of the fit's fold
+    int n, p, PP, W, n_folds, n_blocks, max_iter;
+    double tol;
+    double *coef, *icpt, *gaps;
+    int32_t *iters;
+    hipStream_t stream;
+};
+hipError_t psk_lasso_cov_launch(const psk_lasso_cov_args &a);

@@ -1091,7 +1091,7 @@ __global__ __launch_bounds__(WMREG > 0 ? SV_COOP_THREADS : SV_THREADS) void logr
         if (lane == 0) { w[j] = 0.0; wpd[j] = 0.0; xjneg[j] = sneg; act[j] = j; }
     }
     double w_norm = 0.0, Gmax_old = 1e300, Gnorm1_init = -1.0, inner_eps = 1.0;
-    int newton = 0;
+    int newton = 0, floor_steps = 0;   // floor_steps: Newton steps in a row taken inside the line search's rounding noise
     for (newton = 0; newton < max_newton; newton++) {
         double Gmax_new = 0.0, Gnorm1_new = 0.0;
         int active = P1;
@@ -1579,7 +1579,7 @@ __global__ __launch_bounds__(WMREG > 0 ? SV_COOP_THREADS : SV_THREADS) void logr
             if ((nw >> lane) & 1) negsum += C * xTd[t * 64 + lane];
         }
         negsum = psk_wave_sum_f64_dpp(negsum);
-        bool accepted = false;
+        bool accepted = false, floor_rebuild = false;
         for (int ls = 0; ls < 20; ls++) {
             double cs = 0.0;
             for (int t = 0; t < W; t++) {
@@ -1592,7 +1592,17 @@ __global__ __launch_bounds__(WMREG > 0 ? SV_COOP_THREADS : SV_THREADS) void logr
                 cs += C * log((1.0 + en) / (ex + en));
             }
             const double cond = w_norm_new - w_norm + negsum - sigma * delta + psk_wave_sum_f64_dpp(cs);
-            if (cond <= 0.0) {
+            // liblinear accepts when cond <= 0.  Close to the optimum the decrease the model predicts sinks below what the sum of
+            // l logarithms can resolve in doubles (~C l 2^-52): the sign of cond is then noise, twenty halvings only make the
+            // step smaller, and a fit run at a tolerance near that floor repeats the same rejected step until max_iter (r04:
+            // fits at tol = 1e-12 either stopped after ~100 Newton steps or never).  A step whose cond is inside the noise is
+            // taken whole -- near the optimum the quadratic model is the better judge -- and exp(w.x) is then rebuilt from w
+            // (below: accepting such steps without it, the multiplicatively updated copy drifted over thousands of them and one
+            // fit "converged" 26 % away); three such steps in a row end the fit: it is where doubles can take it.  At the
+            // tolerances the reference runs at |cond| is many orders above the noise and nothing changes.
+            const bool in_noise = cond > 0.0 && cond <= 4.0 * 2.220446049250313e-16 * C * l;
+            floor_steps = in_noise ? floor_steps + 1 : (cond <= 0.0 ? 0 : floor_steps);
+            if (cond <= 0.0 || in_noise) {
                 w_norm = w_norm_new;
                 for (int j = 0; j < P1; j++) { if (lane == 0) w[j] = wpd[j]; }
                 for (int t = 0; t < W; t++) {
@@ -1604,6 +1614,7 @@ __global__ __launch_bounds__(WMREG > 0 ? SV_COOP_THREADS : SV_THREADS) void logr
                     ewx[i] = en; tau[i] = C * tt; D[i] = C * en * tt * tt;
                 }
                 accepted = true;
+                floor_rebuild = in_noise;
                 break;
             }
             w_norm_new = 0.0;
@@ -1616,7 +1627,7 @@ __global__ __launch_bounds__(WMREG > 0 ? SV_COOP_THREADS : SV_THREADS) void logr
             negsum *= 0.5;
             for (int t = 0; t < W; t++) xTd[t * 64 + lane] *= 0.5;
         }
-        if (!accepted) {
+        if (!accepted || floor_rebuild) {
             // rejected 20 times: back to the current w, and exp(w.x) is rebuilt from w (see the float kernel)
             for (int j = 0; j < P1; j++) { if (lane == 0) wpd[j] = w[j]; }
             for (int t = 0; t < W; t++) xTd[t * 64 + lane] = 0.0;
@@ -1642,6 +1653,7 @@ __global__ __launch_bounds__(WMREG > 0 ? SV_COOP_THREADS : SV_THREADS) void logr
         if (stat_t_cd == stat_cd_before) { stat_t_gram += clock64() - stat_g0; stat_gram_sweeps += iter; }
 #endif
         if (iter == 1) inner_eps *= 0.25;
+        if (floor_steps >= 3) { newton++; break; }   // at the floor of what doubles resolve (see the line search)
         Gmax_old = Gmax_new;
     }
     for (int j = 0; j < p; j++) { if (lane == 0) coef[(size_t)fit * p + j] = w[j]; }

@@ -97,7 +97,12 @@ class L2LogisticRegression(L1LogisticRegression):
 class LassoRegression:
     """(1/2n)||y - Xw - b||^2 + alpha ||w||_1."""
     _is_classifier = False
+    # scikit-learn's cyclic descent visits every column, copies included, and a fit that ends at the sweep limit has walked a
+    # path the copies were part of (r04: the grid search of a 1,024 x 907 design was 2e-3 off in R^2 on its unconverged row
+    # with the copies removed).  Up to 1,024 columns -- the covariance form of solver_lasso.hip -- every column is kept;
+    # beyond that (--n_kmers 0 models) each distinct pattern is solved once: the same optimum where the descent converges.
     _dedupe = True
+    _dedupe_above = 1024
     _sk_name = "Lasso"
 
     def __init__(self, alpha=1.0, tol=1e-4, max_iter=1000):
@@ -174,7 +179,7 @@ class GridSearch:
         # Identical columns (k-mers of one gene share a presence pattern) are solved once: an L1
         # optimum may place a pattern's weight on any of its copies, here on the first (which is also
         # what cyclic coordinate descent -- scikit-learn's Lasso -- does).
-        if self.estimator._dedupe:
+        if self.estimator._dedupe and X_full.shape[1] > getattr(self.estimator, "_dedupe_above", 0):
             X, first, inverse = _unique_columns(X_full)
         else:  # an L2 optimum spreads a pattern's weight over its copies: every column stays
             X, first = X_full, np.arange(X_full.shape[1])

@@ -50,3 +50,18 @@ def tokenizer_cases():
 def fmt_float_like_pandas(x):
     """How pandas.to_csv prints the object-dtype float the reference stores (repr of float)."""
     return repr(float(x))
+
+
+def large_design(z, tag):
+    """A design of tests/golden/model_large_kat.npz (oracle/gen_golden.py::gen_model_large_kat): (X float32 [n][p], y int32,
+    fold int32).  'g' is the recorded 2,048 x 907 design of fit2048_907.npz, 'h' and 'i' are stored bit-packed."""
+    import numpy as np
+    n = int(z["n_" + tag])
+    if tag == "g":
+        d = np.load(os.path.join(GOLDEN, "fit2048_907.npz"))
+        X = np.unpackbits(d["Xbits"], axis=1)[:, : int(d["p"])]
+        y = d["y"]
+    else:
+        X = np.unpackbits(z["X_" + tag], axis=0)[:n]
+        y = z["y_" + tag]
+    return X.astype(np.float32), y.astype(np.int32), z["fold_" + tag].astype(np.int32)

@@ -710,14 +710,167 @@ def test_l1_logreg_gram_global_form_on_the_2048_x_907_grid(ctx, monkeypatch):
     assert -6e-2 < o_new.sum() / o_ref.sum() - 1 < 5e-4
 
 
-def test_lasso_solver_matches_sklearn(ctx):
-    z = np.load(os.path.join(GOLDEN, "model_kat.npz"))
-    X, y = z["X2"], z["yc2"]
-    alphas = [float(a) for a in z["alphas"]]
-    coef, icpt, iters = ctx.lasso_fit(X, y, np.zeros(len(y), np.int32), alphas, [-1] * len(alphas), tol=1e-13,
-                                      max_iter=200000)
-    assert np.allclose(coef, z["lasso_coef2"], rtol=1e-6, atol=1e-8)
-    assert np.allclose(icpt, z["lasso_icpt2"], rtol=1e-8)
+@pytest.mark.parametrize("form", ["gram-global", "four-wave arrays"])
+@pytest.mark.parametrize("tag", ["g", "h", "i"])
+def test_l1_logreg_large_forms_reach_the_certified_liblinear_optimum(ctx, monkeypatch, tag, form):
+    """VERDICT r03 #1 -- a10's contract for the solver forms that carry every large fit.  tests/golden/model_large_kat.npz
+    holds, for the 2,048 x 907 design of a 2,048-genome run ('g'), a 1,500 x 300 ('h') and a 300 x 400 ('i') near-duplicate
+    design, scikit-learn's liblinear fits at C = 0.01 .. 100 on all samples and on two training folds, and beside each the
+    exact optimum of liblinear's objective (the arbiter seeded with liblinear's point; its KKT certificate is re-checked
+    from the stored numbers by tests/test_oracle_golden.py -- liblinear itself stops 6e-8 (C = 10) to 4e-4 (C = 100) above
+    it in the objective).  The default form (Gram matrix in global memory, bf16-MFMA Hessian, CG accelerator) AND the
+    four-wave array form (PSK_NO_GRAM_GLOBAL=1), run to a tight tolerance, must reach: the objective to 1e-8 relative
+    (measured <= 3e-12), the linear predictor Xw + b on the training rows, the coefficient sum of every distinct column
+    pattern and the intercept to 1e-6 of the largest ('h', 'i': measured <= 3e-8; 'g': see the bar below).
+    Tolerances: liblinear's rule is relative to the violation at w = 0, so what it leaves in the coefficients grows with
+    C and with the conditioning: 1e-10 leaves 1e-8 on 'h' but 4e-6 on 'i' and 5e-5 on 'g' at C = 100, hence 1e-12 there
+    (near the floor of what the line search resolves in doubles a fit ends after three Newton steps inside its rounding noise:
+    solver_l1_bits.h).  The array form without the accelerator needs more than 300 Newton steps of thousands of sweeps for 'g' at
+    C >= 10 at such a tolerance (minutes per fit): there it is held to the optimum at the reference's tolerance, below."""
+    from helpers import large_design
+    z = np.load(os.path.join(GOLDEN, "model_large_kat.npz"))
+    X, y, fold = large_design(z, tag)
+    fp, ff = z["fit_C_" + tag].astype(np.float64), z["fit_held_" + tag].astype(np.int32)
+    sel = np.arange(len(fp))
+    tol = {"g": 1e-12, "h": 1e-10, "i": 1e-12}[tag]
+    if form != "gram-global":
+        monkeypatch.setenv("PSK_NO_GRAM_GLOBAL", "1")
+        if tag == "g":
+            sel = sel[fp <= 1.0]
+        if tag == "i":
+            tol = 1e-11
+    # 'g' (907 columns, 2,048 samples): the bar on coefficients is 5e-6 (measured 1e-10 .. 2.8e-6 at C <= 10); at C = 100 its
+    # training folds are all but separable along some direction -- the objective is flat there to 5e-10 while the linear
+    # predictor still moves by 12 % (one fit: 4,700 Newton steps to meet the rule at 1e-12, then 26 % from the optimum in
+    # its coefficients and 4.6e-10 in its objective; liblinear stops 3.4e-4 above it) -- no gradient rule pins coefficients
+    # there: those three fits are held to the objective alone, and the step cap ends them
+    max_iter = 400 if tag == "g" else 5000
+    coef, icpt, iters = ctx.logreg_l1_fit(X, y, fold, fp[sel], ff[sel], tol=tol, max_iter=max_iter)
+    assert iters[fp[sel] <= 10].max() < max_iter, iters.tolist()
+    Xd, ypm = X.astype(np.float64), 2.0 * y - 1.0
+    for q, j in enumerate(sel):
+        bar = 5e-6 if tag == "g" else 1e-6
+        tr = fold != ff[j]
+        aw, ab, grp = z["arb_coef_" + tag][j], float(z["arb_icpt_" + tag][j]), z["arb_group_" + tag][j]
+        lin, alin = Xd[tr] @ coef[q] + icpt[q], Xd[tr] @ aw + ab
+        obj = np.abs(coef[q]).sum() + abs(icpt[q]) + fp[j] * np.logaddexp(0.0, -ypm[tr] * lin).sum()
+        assert obj == pytest.approx(float(z["arb_obj_" + tag][j]), rel=1e-8), (tag, form, j, fp[j], ff[j], int(iters[q]))
+        if tag == "g" and fp[j] > 10:
+            continue
+        assert np.abs(lin - alin).max() <= bar * max(np.abs(alin).max(), 1e-300), (tag, form, j, np.abs(lin - alin).max())
+        sums, asums = np.zeros(grp.max() + 1), np.zeros(grp.max() + 1)
+        np.add.at(sums, grp, coef[q])
+        np.add.at(asums, grp, aw)
+        scale = max(np.abs(asums).max(), abs(ab), 1e-300)
+        assert np.abs(sums - asums).max() <= bar * scale, (tag, form, j, fp[j], np.abs(sums - asums).max() / scale)
+        assert abs(icpt[q] - ab) <= bar * scale, (tag, form, j)
+        # the same support: zero where the optimum is zero (to the same dust), non-zero where it is not
+        assert np.all(np.abs(sums[asums == 0]) <= 1e-6 * scale) and np.all(sums[np.abs(asums) > 1e-5 * scale] != 0), (tag, form, j)
+
+
+@pytest.mark.parametrize("form", ["gram-global", "four-wave arrays"])
+def test_l1_logreg_large_forms_at_the_reference_tolerance(ctx, monkeypatch, form):
+    """... and at the tolerance the reference runs at (tol = 1e-4, modeling.py:241 of the CLI): all 15 recorded fits of the
+    2,048 x 907 design, both forms.  A stopping rule bounds the violation, not the objective: the fits end at or above the
+    certified optimum (never below it -- a lower value would mean the wrong objective) and within 5 % of it (measured:
+    the accelerated form <= 0.6 %, the plain array descent <= 2.9 %; liblinear's own fits at tol = 1e-6 stop 0.04 % above)."""
+    from helpers import large_design
+    z = np.load(os.path.join(GOLDEN, "model_large_kat.npz"))
+    X, y, fold = large_design(z, "g")
+    fp, ff = z["fit_C_g"].astype(np.float64), z["fit_held_g"].astype(np.int32)
+    if form != "gram-global":
+        monkeypatch.setenv("PSK_NO_GRAM_GLOBAL", "1")
+    coef, icpt, iters = ctx.logreg_l1_fit(X, y, fold, fp, ff, tol=1e-4, max_iter=1000)
+    assert iters.max() < 1000
+    ypm = 2.0 * y - 1.0
+    _l1_stop_rule_holds(X, ypm, fold, fp, ff, coef, icpt, iters, range(len(fp)), tol=1e-4)
+    rel = _l1_objectives(X, ypm, fold, fp, ff, coef, icpt) / z["arb_obj_g"] - 1
+    assert rel.min() > -1e-12 and rel.max() < 5e-2, (form, float(rel.min()), float(rel.max()))
+
+
+@pytest.mark.parametrize("tag", ["g", "h", "i"])
+def test_grid_search_on_large_designs_matches_sklearn_gridsearchcv(ctx, tag):
+    """The grid search exactly as the reference configures it (modeling.py:1078-1085, :1208-1216, :1512-1524: 13 values of C,
+    cv = min(min class, 10), accuracy, tol = 1e-4, max_iter = 1000) on the three large designs, against scikit-learn's
+    GridSearchCV(LogisticRegression(penalty='l1', solver='liblinear')) recorded under three seeds of liblinear's coordinate
+    order (the reference leaves random_state=None: scikit-learn's own scores move from run to run).  Folds identical.
+    Candidates with C <= 1 -- where liblinear's fits are converged at this tolerance and where every one of the three designs
+    has its best candidate --: every (candidate, fold) score within ONE test sample of a recorded run's ('i' at C = 1000: two).
+    Candidates with C > 1 on the 907-column design: there scikit-learn's score is a property of how far from the optimum
+    liblinear's rule stops it (0.04 % .. 3 % in the objective) -- its own seeds differ by up to 4 test samples per fold, and
+    the closer a solver gets to the optimum of these over-fitted models the LOWER the held-out accuracy (ours at tol = 1e-8:
+    0.83 .. 0.89 against 0.895 .. 0.907) -- ours end nearer the optimum (test_l1_logreg_large_forms_at_the_reference_
+    tolerance) and score 0.5 .. 1.1 % lower: held to 2 % in the mean.  The same C is chosen whenever the recorded runs agree
+    on it and their best two candidates are more than one test sample per fold apart (on 'g' scikit-learn has five
+    candidates tied at 0.9165 and takes the first; ours has one of them a sample lower and takes the second)."""
+    from helpers import large_design
+    from phenotypeseeker_amd.model import GridSearch, L1LogisticRegression
+    z = np.load(os.path.join(GOLDEN, "model_large_kat.npz"))
+    X, y, fold = large_design(z, tag)
+    grid = [float(c) for c in z["grid"]]
+    cv = int(min(np.bincount(y).min(), 10))
+    gs = GridSearch(L1LogisticRegression(tol=1e-4, max_iter=1000), "C", grid, cv).fit(X, y, ctx)
+    assert np.array_equal(gs.test_folds_, fold)
+    ref = z["gs_split_scores_" + tag]                       # [seed][candidate][fold]
+    ours = np.array([gs.cv_results_["split%d_test_score" % f] for f in range(cv)]).T
+    one = 1.0 / np.bincount(fold)                           # one test sample, per fold
+    d = np.abs(ours[None] - ref).min(axis=0) / one[None, :]  # test samples to the nearest recorded run, per (candidate, fold)
+    small = np.array(grid) <= 1.0 + 1e-12
+    assert np.all(d[small] <= 1.0 + 1e-9), (tag, d[small].max())
+    assert np.all(d[~small] <= (8.0 if tag == "g" else 2.0) + 1e-9), (tag, d[~small].max())
+    rm, om = ref.mean(axis=2), ours.mean(axis=1)
+    assert np.all(om >= rm.min(axis=0) - 0.02) and np.all(om <= rm.max(axis=0) + 0.02), (tag, om, rm)
+    best = z["gs_best_C_" + tag]
+    top2 = np.sort(rm, axis=1)[:, -2:]
+    if np.all(best == best[0]) and np.all(top2[:, 1] - top2[:, 0] > one.mean()):
+        assert gs.best_params_["C"] == pytest.approx(float(best[0]))
+    else:
+        assert tag == "g"      # (the tie described above)
+
+
+def _lasso_large():
+    z = np.load(os.path.join(GOLDEN, "lasso_large_kat.npz"))
+    d = np.load(os.path.join(GOLDEN, "fit2048_907.npz"))
+    X = np.unpackbits(d["Xbits"], axis=1)[:1024, : int(d["p"])].astype(np.float32)
+    return z, X
+
+
+def test_lasso_covariance_form_walks_sklearns_path(ctx, monkeypatch):
+    """VERDICT r03 #3.  tests/golden/lasso_large_kat.npz: scikit-learn's Lasso as the reference configures it (tol = 1e-4,
+    max_iter = 1000) on a 1,024 x 907 design, 13 alphas on all samples and on two training folds.  The covariance form
+    (solver_lasso.hip) is the same cyclic descent with the same stop -- the duality gap, evaluated when scikit-learn
+    evaluates it -- so it must END WHERE SCIKIT-LEARN ENDS: the same number of sweeps for every fit (1 ... 894, and 1,000
+    where the limit cuts the descent off: there the fixture is no optimum, only the point the walk has reached), the
+    coefficients to 1e-6 of the largest one and the intercept to 1e-6.  The four-wave kernel on the samples
+    (PSK_NO_LASSO_COV=1: the fallback beyond 1,024 columns) and the float kernel (PSK_NO_LASSO_BITS=1: --real_counts) walk
+    the same path."""
+    z, X = _lasso_large()
+    fp, ff = z["fit_alpha"].astype(np.float64), z["fit_held"].astype(np.int32)
+    for env in (None, "PSK_NO_LASSO_COV", "PSK_NO_LASSO_BITS"):
+        if env:
+            monkeypatch.setenv(env, "1")
+        coef, icpt, iters = ctx.lasso_fit(X, z["y"], z["fold"].astype(np.int32), fp, ff, tol=1e-4, max_iter=1000)
+        if env:
+            monkeypatch.delenv(env)
+        assert np.array_equal(iters, z["n_iter"]), (env, iters.tolist(), z["n_iter"].tolist())
+        for j in range(len(fp)):
+            scale = max(np.abs(z["coef"][j]).max(), 1e-300)
+            assert np.abs(coef[j] - z["coef"][j]).max() <= 1e-6 * scale, (env, j, fp[j], int(iters[j]))
+            assert np.array_equal(coef[j] != 0, z["coef"][j] != 0), (env, j)
+            assert icpt[j] == pytest.approx(float(z["icpt"][j]), rel=1e-6, abs=1e-9), (env, j)
+
+
+def test_lasso_grid_search_on_the_large_design_matches_sklearn(ctx):
+    """... and the grid search around it (modeling.py:1078-1080, :1208-1216: cv = 10 contiguous folds, R^2): every
+    (alpha, fold) score and the chosen alpha equal GridSearchCV's.  (model.GridSearch solves each distinct column pattern
+    once; a pattern's copies take no weight in scikit-learn's walk either, beyond rounding dust.)"""
+    from phenotypeseeker_amd.model import GridSearch, LassoRegression
+    z, X = _lasso_large()
+    gs = GridSearch(LassoRegression(tol=1e-4, max_iter=1000), "alpha", [float(a) for a in z["alphas"]], 10).fit(X, z["y"], ctx)
+    assert np.array_equal(gs.test_folds_, z["fold"])
+    ours = np.array([gs.cv_results_["split%d_test_score" % f] for f in range(10)]).T
+    assert np.allclose(ours, z["gs_split_scores"], rtol=1e-5, atol=1e-7), np.abs(ours - z["gs_split_scores"]).max()
+    assert gs.best_params_["alpha"] == pytest.approx(float(z["gs_best_alpha"]))
 
 
 @pytest.mark.parametrize("n", [90, 1000, 2500])
