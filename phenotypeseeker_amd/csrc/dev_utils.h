@@ -78,6 +78,16 @@ __device__ __forceinline__ double psk_wave_sum_f64_dpp(double v)
     return (psk_readlane_f64(v, 0) + psk_readlane_f64(v, 16)) + (psk_readlane_f64(v, 32) + psk_readlane_f64(v, 48));
 }
 
+// Maximum over the 64 lanes, result uniform (same butterflies as the sum; NaN-free inputs).
+__device__ __forceinline__ double psk_wave_max_f64_dpp(double v)
+{
+    v = fmax(v, psk_dpp_f64(v, 0));
+    v = fmax(v, psk_dpp_f64(v, 1));
+    v = fmax(v, psk_dpp_f64(v, 2));
+    v = fmax(v, psk_dpp_f64(v, 3));
+    return fmax(fmax(psk_readlane_f64(v, 0), psk_readlane_f64(v, 16)), fmax(psk_readlane_f64(v, 32), psk_readlane_f64(v, 48)));
+}
+
 __device__ __forceinline__ uint64_t psk_readlane_u64(uint64_t v, int lane_uniform)
 {
     const uint32_t lo = (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)v, lane_uniform);

@@ -195,13 +195,72 @@ __global__ __launch_bounds__(LC_THREADS) void lasso_cov_kernel(
         }
         gr = (gr - (((acc[0] + acc[1]) + (acc[2] + acc[3])) + ((acc[4] + acc[5]) + (acc[6] + acc[7])))) + cr * R.s;
     };
-    // brings row `only` (or every row: -1) up to date with the periods before `upto`.  The latest period's block, when xA
-    // does not hold it (the wave that stepped a block has that block's steps AND the ones before it to apply), is asked for
-    // first, row r + 1's while row r is worked on: its latency passes behind the multiply-adds.  ONE call site and one
-    // instance of the 64 multiply-adds per row: with the three call sites and three sources of the first version the loop
-    // body was ~100 KB of code for four waves that each walk a different part of it -- more than the instruction cache.
+    // The same for a period in which few coordinates moved (late sweeps: the support is a tenth of the columns and only it
+    // moves): a multiply-add per NON-ZERO step -- the count picked out of the lane's 32 registers by a wave-uniform index,
+    // the step by a lane read -- instead of 64: ~80 cycles per non-zero step against ~4,000 for the full row.
+    auto consume_sparse = [&](double &gr, double cr, const u4 (&x)[8], int P) __attribute__((always_inline)) {
+        typedef uint32_t v32 __attribute__((ext_vector_type(32)));
+        const LcRec &R = rec[P & 3];
+        const uint64_t nzv = R.nz;
+        uint64_t m = ((uint64_t)(uint32_t)__builtin_amdgcn_readfirstlane((int)(nzv >> 32)) << 32) |
+                     (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)nzv);
+        const double ddv = R.dd[lane];   // lane l holds step l
+        v32 xv;
+#pragma unroll
+        for (int e = 0; e < 8; e++)
+#pragma unroll
+            for (int h = 0; h < 4; h++) xv[4 * e + h] = x[e][h];
+        double acc = 0.0;
+        while (m) {
+            const int j = __builtin_ctzll(m);
+            m &= m - 1;
+            const uint32_t v = xv[j >> 1];
+            const uint32_t cc = (v >> ((j & 1) * 16)) & 0xFFFFu;
+            acc = fma(psk_readlane_f64(ddv, j), (double)cc, acc);
+        }
+        gr = (gr - acc) + cr * R.s;
+    };
+    // ... and for ALL the rows of this wave at once, when their counts against the period's block are the ones in xA: one
+    // walk over the non-zero steps, the lane read of the step and the register index shared by the four rows, whose
+    // multiply-adds are independent of each other (a row at a time, a non-zero step was a chain of ~12 dependent
+    // instructions: ~2,000 cycles per row and period where this takes ~1,500 for the four)
+    auto consume_sparse_rows = [&](int P, unsigned rows) __attribute__((always_inline)) {
+        typedef uint32_t v32 __attribute__((ext_vector_type(32)));
+        const LcRec &R = rec[P & 3];
+        const uint64_t nzv = R.nz;
+        uint64_t m = ((uint64_t)(uint32_t)__builtin_amdgcn_readfirstlane((int)(nzv >> 32)) << 32) |
+                     (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)nzv);
+        const double ddv = R.dd[lane];
+        v32 xv[R4];
+        double acc[R4];
+#pragma unroll
+        for (int r = 0; r < R4; r++) {
+            acc[r] = 0.0;
+#pragma unroll
+            for (int e = 0; e < 8; e++)
+#pragma unroll
+                for (int h = 0; h < 4; h++) xv[r][4 * e + h] = xA[r][e][h];
+        }
+        while (m) {
+            const int j = __builtin_ctzll(m);
+            m &= m - 1;
+            const double ddj = psk_readlane_f64(ddv, j);
+            const int idx = j >> 1, sh = (j & 1) * 16;
+#pragma unroll
+            for (int r = 0; r < R4; r++) acc[r] = fma(ddj, (double)((xv[r][idx] >> sh) & 0xFFFFu), acc[r]);
+        }
+#pragma unroll
+        for (int r = 0; r < R4; r++)
+            if ((rows >> r) & 1u) g[r] = (g[r] - acc[r]) + cnt[r] * R.s;
+    };
+    // brings row `only` (or every row: -1) up to date with the periods before `upto`, period by period.  Rows whose counts
+    // against the period's block are in xA and a period with few non-zero steps: all rows at once (above).  Else row by row;
+    // a block that is not in xA (the wave that stepped a block while the period before it was dense has that period's
+    // steps left for its other rows) is loaded for row r + 1 while row r is worked on.  ONE call site and one instance of
+    // the 64 multiply-adds per row: with three call sites and three chunk sources the loop body was ~100 KB of code for four
+    // waves that each walk a different part of it -- more than the instruction cache.
 #ifdef PSK_LC_STATS
-    long long st_rows = 0, st_fresh = 0, st_wait = 0;
+    long long st_rows = 0, st_fresh = 0, st_wait = 0, st_joint = 0;
 #endif
     auto bring = [&](int upto, int only) __attribute__((always_inline)) {
 #ifdef PSK_LC_STATS
@@ -211,44 +270,55 @@ __global__ __launch_bounds__(LC_THREADS) void lasso_cov_kernel(
             st_wait += clock64() - w0;
         }
 #endif
-        u4 xB[2][8];
-        const int Pl = upto - 1, bl = Pl >= 0 ? Pl % nb : -1;
-        const bool useB = Pl >= 0 && bl != blkA;
-        auto wantsB = [&](int r) __attribute__((always_inline)) { return useB && (only < 0 || r == only) && ap[r] <= Pl && needs(4 * r + wave, Pl); };
-        auto askB = [&](int r) __attribute__((always_inline)) {
-            const u4 *src = chunk(4 * r + wave, bl);
+        int Pmin = upto;
 #pragma unroll
-            for (int e = 0; e < 8; e++) xB[r & 1][e] = src[64 * e];
-        };
-        if (wantsB(0)) askB(0);
+        for (int r = 0; r < R4; r++)
+            if ((only < 0 || r == only) && ap[r] < Pmin) Pmin = ap[r];
+        for (int P = Pmin; P < upto; P++) {
+            unsigned rows = 0;   // the rows that receive period P now (wave-uniform)
 #pragma unroll
-        for (int r = 0; r < R4; r++) {
-            if (r + 1 < R4 && wantsB(r + 1)) askB(r + 1);
-            if (only < 0 || r == only) {
-                const int cb = 4 * r + wave;
-                for (int P = ap[r]; P < upto; P++) {
-                    if (!needs(cb, P)) continue;
+            for (int r = 0; r < R4; r++)
+                if ((only < 0 || r == only) && ap[r] <= P && needs(4 * r + wave, P)) rows |= 1u << r;
+            if (rows == 0) continue;
+            const bool sparse = __popcll(rec[P & 3].nz) <= 16, inA = P % nb == blkA;
+            if (sparse && inA) {
+#ifdef PSK_LC_STATS
+                st_joint++;
+#endif
+                consume_sparse_rows(P, rows);
+                continue;
+            }
+            u4 xB[2][8];
+            auto askB = [&](int r) __attribute__((always_inline)) {
+                const u4 *src = chunk(4 * r + wave, P % nb);
+#pragma unroll
+                for (int e = 0; e < 8; e++) xB[r & 1][e] = src[64 * e];
+            };
+            if (!inA && (rows & 1u)) askB(0);
+#pragma unroll
+            for (int r = 0; r < R4; r++) {
+                if (!inA && r + 1 < R4 && ((rows >> (r + 1)) & 1u)) askB(r + 1);
+                if ((rows >> r) & 1u) {
                     u4 x[8];
-                    if (P % nb == blkA) {
+                    if (inA) {
 #pragma unroll
                         for (int e = 0; e < 8; e++) x[e] = xA[r][e];
-                    } else if (P == Pl) {
+                    } else {
 #pragma unroll
                         for (int e = 0; e < 8; e++) x[e] = xB[r & 1][e];
-                    } else {   // (two periods behind and not in xA: only when one wave steps two blocks in a row)
-                        const u4 *src = chunk(cb, P % nb);
-#pragma unroll
-                        for (int e = 0; e < 8; e++) x[e] = src[64 * e];
                     }
 #ifdef PSK_LC_STATS
                     st_rows++;
-                    if (P % nb != blkA) st_fresh++;
+                    if (!inA) st_fresh++;
 #endif
-                    consume(g[r], cnt[r], x, P);
+                    if (sparse) consume_sparse(g[r], cnt[r], x, P);
+                    else consume(g[r], cnt[r], x, P);
                 }
-                ap[r] = upto;
             }
         }
+#pragma unroll
+        for (int r = 0; r < R4; r++)
+            if (only < 0 || r == only) ap[r] = upto;
     };
     // The 64 steps of a block read one column of its diagonal block each: from LDS, where the wave has put the block
     // while it was not stepping (read from global memory as the steps went -- eight loads ahead -- a step took ~700 cycles:
@@ -289,7 +359,11 @@ __global__ __launch_bounds__(LC_THREADS) void lasso_cov_kernel(
         const bool swept = T > 0 && c == 0;
         const bool chk = swept && rec[(T - 1) & 3].check != 0;
         // this period's steps need the stepped block's rows up to date; a gap needs every row
-        bring(T, (wave == sw && !chk) ? rs : -1);
+        // (the stepping wave: only the block's rows while the period before it was dense -- the rest waits a period, four
+        // rows of 64 multiply-adds would sit in front of the steps --; every row when few steps were taken: the joint walk is
+        // cheap, nothing is left over, and the wave asks for its counts against this block like everybody else)
+        const bool lean = T > 0 && __popcll(rec[(T - 1) & 3].nz) <= 16;
+        bring(T, (wave == sw && !chk && !lean) ? rs : -1);
         if (swept) sweeps++;
         if (chk) {
             // the gap as scikit-learn evaluates it, from g = X'R, w, X'y and y'y
@@ -303,8 +377,7 @@ __global__ __launch_bounds__(LC_THREADS) void lasso_cov_kernel(
                 wq += wv[r] * xty;
                 l1 += fabs(wv[r]);
             }
-#pragma unroll
-            for (int d = 32; d > 0; d >>= 1) dn = fmax(dn, psk_shfl_xor_f64(dn, d));
+            dn = psk_wave_max_f64_dpp(dn);
             wg = psk_wave_sum_f64_dpp(wg);
             wq = psk_wave_sum_f64_dpp(wq);
             l1 = psk_wave_sum_f64_dpp(l1);
@@ -337,8 +410,33 @@ __global__ __launch_bounds__(LC_THREADS) void lasso_cov_kernel(
             double ddc = 0.0;
             // a block whose coordinates are all at zero and inside the dead zone cannot move: every step would be exactly 0
             const bool quiet = (ws == 0.0 && fabs(gs) <= an) || is == 0.0;
-            if (__ballot(!quiet) != 0ull) {
-                if (lds_blk != c) stage(c);   // (only when this wave steps two blocks in a row: the sweep's wrap with nb = 4 m + 1)
+            const uint64_t loud = __ballot(!quiet);
+            if (loud != 0ull && lds_blk != c) stage(c);   // (only when this wave steps two blocks in a row: the sweep's wrap with nb = 4 m + 1)
+            if (loud != 0ull && __popcll(loud) <= 24) {
+                // Few coordinates of the block can move: only they are stepped.  A coordinate at zero inside the dead zone takes
+                // a step of exactly 0 whenever it is visited, and what it sees only changes when ANOTHER coordinate moves -- so
+                // from the current position the next coordinate that is NOT in that state is found by one ballot, stepped, and
+                // the search goes on behind it with the updated g: the visits skipped are exactly the no-ops of the full walk.
+                const double *dg = lq + lane;
+                int pos = 0;
+                while (pos < 64) {
+                    const double t = fma(ws, ns, gs);
+                    const bool act = is != 0.0 && (ws != 0.0 || fabs(t) > an);
+                    const uint64_t mk = __ballot(act) & (~0ull << pos);
+                    if (mk == 0ull) break;
+                    const int j = __builtin_ctzll(mk);
+                    const double qj = dg[j * 64];
+                    const double mag = fabs(t) - an;
+                    const double wn = copysign(mag > 0.0 ? mag : 0.0, t) * is;
+                    const double ddl = wn - ws;
+                    const double ddj = psk_readlane_f64(ddl, j);
+                    const bool me = lane == j;
+                    ws = me ? wn : ws;
+                    ddc = me ? ddl : ddc;
+                    gs = fma(-ddj, qj, gs);
+                    pos = j + 1;
+                }
+            } else if (loud != 0ull) {
                 const double *dg = lq + lane;
                 double q[8];
 #pragma unroll
@@ -364,7 +462,7 @@ __global__ __launch_bounds__(LC_THREADS) void lasso_cov_kernel(
                 }
             }
 #ifdef PSK_LC_STATS
-            if (__ballot(!quiet) == 0ull) st_quiet++;
+            if (loud == 0ull) st_quiet++;
 #endif
             LC_T(st_seq);
 #pragma unroll
@@ -375,14 +473,19 @@ __global__ __launch_bounds__(LC_THREADS) void lasso_cov_kernel(
             R.dd[lane] = ddc;
             const uint64_t nz = __ballot(ddc != 0.0);
             const double sv = psk_wave_sum_f64_dpp(ddc * cs) * inv_n;
-            double dm = fabs(ddc), wm = fabs(ws);
-#pragma unroll
-            for (int d = 32; d > 0; d >>= 1) { dm = fmax(dm, psk_shfl_xor_f64(dm, d)); wm = fmax(wm, psk_shfl_xor_f64(wm, d)); }
+            // (DPP butterflies: the shuffle form is twelve ds_bpermute round trips, ~1,500 cycles on the steps' critical path)
+            const double dm = psk_wave_max_f64_dpp(fabs(ddc)), wm = psk_wave_max_f64_dpp(fabs(ws));
             const double dmax = fmax(c == 0 ? 0.0 : s_dmax, dm), wmax = fmax(c == 0 ? 0.0 : s_wmax, wm);
             const bool last = c == nb - 1;
             const int check = last && (wmax == 0.0 || dmax / wmax < tol || sweeps == max_iter - 1);
             if (lane == 0) { R.s = sv; R.nz = nz; R.check = check; s_dmax = dmax; s_wmax = wmax; }
             LC_T(st_pub);
+        }
+        bool all_up = true;   // every row of this wave has every period before this one (the stepping wave: if it took the lean way)
+#pragma unroll
+        for (int r = 0; r < R4; r++) all_up = all_up && ap[r] >= T;
+        if (wave == sw && !all_up) {
+            // (its other rows still need the counts in xA)
         } else {
             LC_T(st_bring_o);
             // ---- everybody else asks for its rows' counts against the block being stepped now, and puts the block it
@@ -395,7 +498,7 @@ __global__ __launch_bounds__(LC_THREADS) void lasso_cov_kernel(
                     for (int e = 0; e < 8; e++) xA[r][e] = src[64 * e];
                 }
             blkA = c;
-            {
+            if (wave != sw) {
                 int cn = c + ((wave - c) & 3);
                 if (cn >= nb) cn = wave;
                 if (wave < nb && cn != lds_blk) stage(cn);
@@ -409,7 +512,7 @@ __global__ __launch_bounds__(LC_THREADS) void lasso_cov_kernel(
     if (lane == 0 && sweeps >= max_iter)
         printf("fit %d wave %d sweeps %d periods %d: total %lld  step-bring %lld seq %lld publish %lld | bring %lld prefetch %lld | barrier %lld  quiet blocks %lld\n",
                fit, wave, sweeps, sweeps * nb, (long long)(clock64() - st_start), st_bring_s, st_seq, st_pub, st_bring_o, st_pref, st_bar, st_quiet);
-    if (lane == 0 && sweeps >= max_iter) printf("fit %d wave %d row passes %lld (fresh %lld) wait for prefetched loads %lld\n", fit, wave, st_rows, st_fresh, st_wait);
+    if (lane == 0 && sweeps >= max_iter) printf("fit %d wave %d row passes %lld (fresh %lld) joint sparse passes %lld wait for prefetched loads %lld\n", fit, wave, st_rows, st_fresh, st_joint, st_wait);
 #endif
 #undef LC_T
     // coefficients and the intercept of the uncentred problem: mean_y - sum mean_k w_k
