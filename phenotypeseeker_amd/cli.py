@@ -116,15 +116,26 @@ def main(argv=None):
     # PSK_GPUS=N (N > 1) and no launcher in sight: this process, before it has loaded anything that could touch the GPU,
     # starts one rank per GPU itself (launch.py) -- the reference's parallel axis, `-nt`, needs no outside launcher
     # either (modeling.py:1649-1663).  Under a launcher that exports RANK / WORLD_SIZE the ranks come here directly.
+    # Only `modeling` is sharded.  `prediction` counts a fixed dictionary per sample on one GPU and writes
+    # predictions_<name>.txt / log.txt without looking at RANK: N copies of it would race on the same files and do the work
+    # N times; --help / --version need no rank at all.  The sub-command is read off the raw arguments, before
+    # anything that could load libpsk is imported, so the parent of a fan-out stays free of the GPU.
     import os
-    n_gpus = int(os.environ.get("PSK_GPUS", "0") or 0)
-    if n_gpus > 1 and "WORLD_SIZE" not in os.environ:
+    rest = list(sys.argv[1:] if argv is None else argv)
+    try:
+        n_gpus = int(os.environ.get("PSK_GPUS", "0") or 0)
+    except ValueError:
+        sys.exit("PSK_GPUS=%s: expected the number of GPUs" % os.environ.get("PSK_GPUS"))
+    sub = next((a for a in rest if not a.startswith("-")), None)
+    wants_help = any(a in ("-h", "--help", "--version") for a in rest)
+    if n_gpus > 1 and "WORLD_SIZE" not in os.environ and sub == "modeling" and not wants_help:
         from . import launch
         root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
         env = {"PYTHONPATH": root + os.pathsep + os.environ.get("PYTHONPATH", "")}
-        rest = list(sys.argv[1:] if argv is None else argv)
         sys.exit(launch.spawn_ranks(["-m", "phenotypeseeker_amd.cli"] + rest, n_gpus,
                                     share_gpu=os.environ.get("PSK_SHARE_GPU") == "1", env_extra=env))
+    if n_gpus > 1 and "WORLD_SIZE" not in os.environ and sub == "prediction" and not wants_help:
+        sys.stderr.write("PSK_GPUS=%d: `prediction` is not sharded, it runs on one GPU\n" % n_gpus)
     parser = build_parser()
     args = parser.parse_args(argv)
     if not hasattr(args, "func"):

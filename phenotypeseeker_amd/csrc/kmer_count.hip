@@ -550,13 +550,37 @@ int frame_probe_known_end(const uint8_t *bytes, size_t nul_at, size_t *start, si
 // A grouped batch rotates 3 G buffer sets of eight device buffers each: carved out of ONE allocation (and one pinned block
 // for the sets' counters) sized for the batch's longest sample, instead of ~170 hipMallocs on a cold context.  Buffers a
 // set already owns and that are large enough stay as they are.  Nothing of an earlier batch is in flight here.
-static int carve_lanes(psk_ctx *ctx, int n_lanes, size_t max_len, bool gpu_framing)
+static void lane_set_wants(psk_ctx *ctx, size_t max_len, bool gpu_framing, size_t want[8])
 {
     size_t dcb[5];
     if (ctx->dense_mode) dense_lane_bytes(ctx, max_len, dcb);
     else bucket_lane_bytes(max_len, dcb);
-    const size_t want[8] = {max_len + 128 + 2 * EX_SEG, gpu_framing ? max_len + 64 : 0, gpu_framing ? frame_gpu_scratch_bytes(max_len) : 0,
-                            dcb[0], dcb[1], dcb[2], dcb[3], dcb[4]};
+    const size_t w[8] = {max_len + 128 + 2 * EX_SEG, gpu_framing ? max_len + 64 : 0, gpu_framing ? frame_gpu_scratch_bytes(max_len) : 0,
+                         dcb[0], dcb[1], dcb[2], dcb[3], dcb[4]};
+    for (int q = 0; q < 8; q++) want[q] = w[q];
+}
+// bytes of ONE buffer set of a grouped batch whose longest sample has max_len bytes
+static size_t lane_set_bytes(psk_ctx *ctx, size_t max_len, bool gpu_framing)
+{
+    size_t want[8], per_lane = 0;
+    lane_set_wants(ctx, max_len, gpu_framing, want);
+    for (int q = 0; q < 8; q++) per_lane += (want[q] + want[q] / 8 + 511) & ~size_t(255);
+    return per_lane;
+}
+// the slices carved out of the slab are forgotten (before a new layout, and when psk_begin gives a large slab back)
+void psk_forget_lane_slices(psk_ctx *ctx)
+{
+    for (CountLane &L : ctx->lane) {
+        DevBuf *b[8] = {&L.raw, &L.rawin, &L.fr_scratch, &L.dc_part, &L.dc_wgoff, &L.dc_cnt, &L.dc_meta, &L.dc_mtemp};
+        for (int q = 0; q < 8; q++)
+            if (b[q]->borrowed) { b[q]->p = nullptr; b[q]->cap = 0; b[q]->borrowed = false; }
+    }
+}
+
+static int carve_lanes(psk_ctx *ctx, int n_lanes, size_t max_len, bool gpu_framing)
+{
+    size_t want[8];
+    lane_set_wants(ctx, max_len, gpu_framing, want);
     auto bufs_of = [](CountLane &L, DevBuf *out[8]) {
         out[0] = &L.raw; out[1] = &L.rawin; out[2] = &L.fr_scratch; out[3] = &L.dc_part; out[4] = &L.dc_wgoff; out[5] = &L.dc_cnt;
         out[6] = &L.dc_meta; out[7] = &L.dc_mtemp;
@@ -572,12 +596,7 @@ static int carve_lanes(psk_ctx *ctx, int n_lanes, size_t max_len, bool gpu_frami
     }
     if (need) {
         // a new layout: every buffer carved out of the slab so far is forgotten first (the slices of two layouts overlap)
-        for (CountLane &L : ctx->lane) {
-            DevBuf *b[8];
-            bufs_of(L, b);
-            for (int q = 0; q < 8; q++)
-                if (b[q]->borrowed) { b[q]->p = nullptr; b[q]->cap = 0; b[q]->borrowed = false; }
-        }
+        psk_forget_lane_slices(ctx);
         PSK_TRY(dev_reserve(ctx, ctx->lane_slab, total));
         // carve: set l takes slice l; a buffer that is its set's own and large enough is left alone
         for (int l = 0; l < n_lanes; l++) {
@@ -949,7 +968,20 @@ static int count_batch_impl(psk_ctx *ctx, int first_sample_idx, int n, const uin
     while (n_threads > 1 && (size_t)(n_threads + 4) * max_len > (4ull << 30)) n_threads--;
     // genomes at k <= 13 (dense counting) go through the counting kernels in groups of G: one launch chain per group
     const bool bucket_run = !ctx->dense_mode && ctx->k >= 14 && ctx->k <= 16 && !getenv("PSK_NO_BUCKET_SORT");
-    const int G = (!consumer && (ctx->dense_mode || bucket_run) && n > 1 && max_len < (64u << 20)) ? dense_group_size() : 1;
+    int G = (!consumer && (ctx->dense_mode || bucket_run) && n > 1 && max_len < (64u << 20)) ? dense_group_size() : 1;
+    if (G > 1) {
+        // The 3 G buffer sets of a grouped batch are one slab sized for the batch's longest sample: ~16 bytes per base on the
+        // bucketed route -- 1.8 GB for 5-Mbp genomes, but 23 GB for samples just under the 64-MB grouping limit.
+        // Smaller groups when the slab would pass a quarter of the device's free memory (what the context already holds
+        // counts as free) or 8 GiB; G = 1 is the one-sample chain, which needs no slab at all.
+        size_t free_b = 0, total_b = 0;
+        if (hipMemGetInfo(&free_b, &total_b) != hipSuccess) { (void)hipGetLastError(); free_b = (size_t)16 << 30; }
+        size_t cap = (free_b + ctx->lane_slab.cap) / 4;
+        if (cap > ((size_t)8 << 30)) cap = (size_t)8 << 30;
+        // (frames on the GPU unless PSK_HOST_FRAMING: the larger of the two layouts is budgeted)
+        const size_t per_set = lane_set_bytes(ctx, max_len, true);
+        while (G > 1 && (size_t)3 * G * per_set > cap) G /= 2;
+    }
     const bool grouped = G > 1;
     const int NL = grouped ? 3 * G : 3;   // buffer sets in rotation
     const int want_ring = grouped ? G + n_threads + 4 : n_threads + 4;   // (grouped: a slot is released as soon as its upload is over)

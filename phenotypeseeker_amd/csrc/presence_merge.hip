@@ -494,7 +494,10 @@ int build_presence_merge(psk_ctx *ctx, uint64_t total_pairs, uint64_t *n_kmers, 
     if (n_groups > 1) PSK_HIP(ctx, hipMemsetAsync(gbm, 0, n_bmw * 8, ctx->stream));
     const dim3 grid((unsigned)n_ranges, (unsigned)n_groups);
     mark("bounds + buffers");
-    const bool w32 = span <= (1ull << 32);   // words relative to the slab's base fit 32 bits: every k <= 16
+    // words relative to the slab's base fit 32 bits (every k <= 16) -- with 0xFFFFFFFF to spare: the 32-bit cursors use it as
+    // "no word left".  The whole k = 16 space is safe (T...T is never canonical); a k = 17 slab cut at list quantiles whose
+    // 64-aligned span is exactly 2^32 could hold a real word there: it takes the 64-bit cursors
+    const bool w32 = span < (1ull << 32) || (span == (1ull << 32) && base == 0 && k == 16);
     if (w32) pm_mark_kernel<uint32_t><<<grid, threads, 0, ctx->stream>>>(d_refs, n, d_bounds, n_tiles, tiles_per_range, base, gbm, n_groups == 1, d_spare);
     else pm_mark_kernel<uint64_t><<<grid, threads, 0, ctx->stream>>>(d_refs, n, d_bounds, n_tiles, tiles_per_range, base, gbm, n_groups == 1, d_spare);
     PSK_HIP(ctx, hipGetLastError());

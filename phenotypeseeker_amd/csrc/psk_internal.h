@@ -177,6 +177,7 @@ struct psk_ctx {
 
 // ---- error helpers ----------------------------------------------------------------------------
 int psk_fail(psk_ctx *ctx, int code, const char *fmt, ...);
+void psk_forget_lane_slices(psk_ctx *ctx);   // kmer_count.hip
 
 #define PSK_HIP(ctx, call)                                                                            \
     do {                                                                                              \

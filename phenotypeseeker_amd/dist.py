@@ -16,6 +16,7 @@ by the launcher process).  No PyTorch anywhere in this package: tests that have 
 inject a host transport (tests/_gloo_transport.py, named by PSK_DIST_TRANSPORT=module:Class).  With world size 1
 nothing here touches a communicator.
 """
+import atexit
 import contextlib
 import ctypes
 import importlib
@@ -163,17 +164,35 @@ def _rendezvous():
     Ranks that do not share a parent (one `bash -c` or srun wrapper per rank) must be given PSK_RDZV_DIR (or
     PSK_RDZV_FILE) by whoever starts them: the error of the rendezvous timing out says so."""
     nonce = os.environ.get("PSK_LAUNCH_NONCE", "")
+    # without a nonce from the launcher the ranks derive one they all arrive at: the process they share as a parent (pid +
+    # start time).  A directory the caller supplies may hold the id and status files of an earlier, crashed launch: with
+    # this every file of THIS launch is told from those (ADVICE r03: the status files carried no tag at all)
+    derived = "p%d_%s" % (os.getppid(), _parent_start_ticks())
     d = os.environ.get("PSK_RDZV_DIR")
     if d:
-        return _private_dir(d), nonce
+        return _private_dir(d), nonce or derived
     f = os.environ.get("PSK_RDZV_FILE")
     if f:
-        return _private_dir(f + ".rdzv"), nonce
+        return _private_dir(f + ".rdzv"), nonce or derived
     key = "%s_%s_%s_%d_%s" % (os.environ.get("MASTER_ADDR", "127.0.0.1"), os.environ.get("MASTER_PORT", "0"),
                               os.environ.get("TORCHELASTIC_RUN_ID", "none"), os.getppid(), _parent_start_ticks())
     key = "".join(c if c.isalnum() else "_" for c in key)
     base = _private_dir(os.path.join(tempfile.gettempdir(), "psk_rdzv_u%d" % os.getuid()))
-    return _private_dir(os.path.join(base, key)), nonce or key
+    path = _private_dir(os.path.join(base, key))
+    if path not in _keyed_dirs:      # a directory made for this launch alone: gone with the process when it is empty
+        _keyed_dirs.add(path)
+        atexit.register(_rmdir_quietly, path)
+    return path, nonce or key
+
+
+_keyed_dirs = set()
+
+
+def _rmdir_quietly(path):
+    try:
+        os.rmdir(path)
+    except OSError:
+        pass
 
 
 def _publish(path, payload):
@@ -423,15 +442,21 @@ def host_files_allowed():
     return os.environ.get("PSK_DIST_ALLOW_HOST_FILES") == "1" or os.environ.get("PSK_SHARE_GPU") == "1"
 
 
-def _exchange_status(d, prefix, rank, world, text, timeout=600.0):
-    """Every rank publishes one short text under `<prefix>.<rank>` and reads everybody's: [text of rank 0, ...]."""
-    _publish(os.path.join(d, "%s.%d" % (prefix, rank)), (text or "ok").encode())
+def _exchange_status(d, prefix, rank, world, text, timeout=600.0, nonce=""):
+    """Every rank publishes one short text under `<prefix>.<rank>` and reads everybody's: [text of rank 0, ...].  A status is
+    MAGIC | nonce | text, like the id blob: a file that carries another launch's nonce (or none) is a leftover and is
+    waited out, not read."""
+    tag = _MAGIC + len(nonce.encode()).to_bytes(2, "little") + nonce.encode()
+    _publish(os.path.join(d, "%s.%d" % (prefix, rank)), tag + (text or "ok").encode())
     out, t0 = [], time.time()
     for r in range(world):
         while True:
             try:
-                with open(os.path.join(d, "%s.%d" % (prefix, r))) as f:
-                    out.append(f.read())
+                with open(os.path.join(d, "%s.%d" % (prefix, r)), "rb") as f:
+                    blob = f.read()
+                if blob[:len(tag)] != tag:
+                    raise OSError("a status file of another launch")
+                out.append(blob[len(tag):].decode(errors="replace"))
                 break
             except OSError:
                 if time.time() - t0 > timeout:
@@ -459,13 +484,13 @@ def _rccl_or_host_files(rank, world, device):
         probe.close()
     except Exception as e:
         err = "%s: %s" % (type(e).__name__, e)
-    errs = _exchange_status(d, "rd.%d" % seq, rank, world, err)
+    errs = _exchange_status(d, "rd.%d" % seq, rank, world, err, nonce=rdzv[1])
     if all(e == "ok" for e in errs):
         try:
             t = RcclTransport(rank, world, device, rdzv=rdzv, seq=seq)
         except Exception as e:      # PskError from psk_comm_init, or the rendezvous timing out
             err = "%s: %s" % (type(e).__name__, e)
-        errs = _exchange_status(d, "st.%d" % seq, rank, world, err)
+        errs = _exchange_status(d, "st.%d" % seq, rank, world, err, nonce=rdzv[1])
     bad = [(r, e) for r, e in enumerate(errs) if e != "ok"]
     if bad:
         if t is not None:

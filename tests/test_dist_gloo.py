@@ -283,3 +283,62 @@ def test_host_file_transport_collectives_and_close(tmp_path):
         assert os.listdir(rd) == []      # rank 0 removed the collective directory last
     finally:
         dist.PskContext = real
+
+
+def test_psk_gpus_fans_out_modeling_only(monkeypatch, capsys):
+    """`PSK_GPUS=N phenotypeseeker ...` starts ranks for `modeling` only -- `prediction` is not rank-aware (N copies
+    would race on predictions_<name>.txt and log.txt), --help / --version need none.  The decision is taken from the raw
+    arguments before anything GPU-bound is imported."""
+    from phenotypeseeker_amd import cli, launch
+    calls = []
+    monkeypatch.setattr(launch, "spawn_ranks", lambda argv, n, **kw: calls.append((list(argv), n)) or 0)
+    monkeypatch.setenv("PSK_GPUS", "4")
+    monkeypatch.delenv("WORLD_SIZE", raising=False)
+    with pytest.raises(SystemExit) as e:
+        cli.main(["modeling", "data.pheno", "-w"])
+    assert e.value.code == 0 and calls == [(["-m", "phenotypeseeker_amd.cli", "modeling", "data.pheno", "-w"], 4)]
+    for argv in (["--help"], ["modeling", "--help"], ["--version"]):
+        with pytest.raises(SystemExit):
+            cli.main(argv)
+    assert len(calls) == 1                       # no ranks for help / version
+    ran = []
+    from phenotypeseeker_amd import prediction
+    monkeypatch.setattr(prediction, "prediction", lambda args: ran.append(args))
+    cli.main(["prediction", "in1.txt", "in2.txt"])
+    assert len(calls) == 1 and len(ran) == 1     # one process, the sub-command itself
+    assert "not sharded" in capsys.readouterr().err
+    monkeypatch.setenv("WORLD_SIZE", "4")        # under an outside launcher the ranks come here directly
+    ran_m = []
+    from phenotypeseeker_amd import modeling
+    monkeypatch.setattr(modeling, "modeling", lambda args: ran_m.append(args))
+    cli.main(["modeling", "data.pheno"])
+    assert len(calls) == 1 and len(ran_m) == 1
+    monkeypatch.setenv("PSK_GPUS", "many")
+    monkeypatch.delenv("WORLD_SIZE")
+    with pytest.raises(SystemExit) as e:
+        cli.main(["modeling", "data.pheno"])
+    assert "PSK_GPUS" in str(e.value.code)
+
+
+def test_status_files_of_another_launch_are_not_read(tmp_path):
+    """the status rounds of the RCCL bring-up (`rd.<seq>.<rank>`, `st.<seq>.<rank>`) carry the launch's nonce like
+    the id blob does: what a crashed earlier launch left in a caller-supplied rendezvous directory -- an 'ok' without a
+    tag, or with another launch's -- is waited out instead of being taken for this launch's answer."""
+    import threading
+    from phenotypeseeker_amd import dist
+    d = str(tmp_path)
+    with open(os.path.join(d, "rd.0.1"), "wb") as f:
+        f.write(b"ok")                                            # r03's format, stale
+    with pytest.raises(RuntimeError, match="no status"):
+        dist._exchange_status(d, "rd.0", 0, 2, "", timeout=0.3, nonce="this-launch")
+    tag = dist._MAGIC + (5).to_bytes(2, "little") + b"other"
+    with open(os.path.join(d, "rd.0.1"), "wb") as f:
+        f.write(tag + b"ok")                                      # another launch's
+    with pytest.raises(RuntimeError, match="no status"):
+        dist._exchange_status(d, "rd.0", 0, 2, "", timeout=0.3, nonce="this-launch")
+    got = {}
+    t = threading.Thread(target=lambda: got.setdefault(1, dist._exchange_status(d, "rd.0", 1, 2, "no GPU", timeout=5.0, nonce="this-launch")))
+    t.start()
+    got[0] = dist._exchange_status(d, "rd.0", 0, 2, "", timeout=5.0, nonce="this-launch")
+    t.join()
+    assert got[0] == got[1] == ["ok", "no GPU"]

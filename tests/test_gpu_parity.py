@@ -824,8 +824,9 @@ def test_grid_search_on_large_designs_matches_sklearn_gridsearchcv(ctx, tag):
     top2 = np.sort(rm, axis=1)[:, -2:]
     if np.all(best == best[0]) and np.all(top2[:, 1] - top2[:, 0] > one.mean()):
         assert gs.best_params_["C"] == pytest.approx(float(best[0]))
-    else:
-        assert tag == "g"      # (the tie described above)
+    # in any case one of the candidates scikit-learn has within one test sample per fold of its best
+    near = np.nonzero(rm.max(axis=0) >= rm.max() - one.mean() - 1e-12)[0]
+    assert any(gs.best_params_["C"] == pytest.approx(grid[c]) for c in near), (tag, gs.best_params_["C"], [grid[c] for c in near])
 
 
 def _lasso_large():
