@@ -121,6 +121,20 @@ int psk_presence_shape(psk_ctx *ctx, uint64_t *n_kmers, int *words_per_row, int 
 int psk_get_union(psk_ctx *ctx, uint64_t *words, uint64_t cap);
 /* Gathers `n` rows (by row index) of the matrix: bits_out[n][words_per_row]. */
 int psk_get_rows(psk_ctx *ctx, const uint64_t *row_idx, uint64_t n, uint64_t *bits_out);
+/* a9, phenotypes.get_ML_df (modeling.py:1112-1145, rows built at :739 / :796): writes `path` = <test>_results_<pheno>.tsv --
+ * `header`, then one line per k-mer that passed the scan: k-mer, round(stat, 2), "%.2E" % p, [round(mean_x, 2),
+ * round(mean_y, 2) when kind = 1 (t-test),] n_with, "| " + the names of the VALID samples (valid[i] != 0: phenotype not NA)
+ * whose bit is set in the k-mer's row -- and, when path_top is not NULL, its first n_top lines again as `path_top`
+ * (:1133-1136).  Lines are ordered by the p-value STRINGS as the reference orders them (:1128), ties by k-mer;
+ * order_out[n_rows] receives that order (row indices).  words[n_rows] 2-bit words of length k; bits[n_rows][wpr] as
+ * psk_get_rows returns them; names = the sample names back to back, name i = bytes [name_off[i], name_off[i + 1]).
+ * Host code (no GPU work; ctx may be NULL: it only carries the error text).  Every byte equals what the reference's
+ * DataFrame.to_csv wrote for the same rows: floats as Python's repr, tests/golden/ds_* hold the files. */
+int psk_write_result_tables(psk_ctx *ctx, const char *path, const char *path_top, int64_t n_top, const char *header, int kind,
+                            int64_t n_rows, const uint64_t *words, int k, const double *stat, const double *p,
+                            const double *mean_x, const double *mean_y, const int32_t *n_with, const uint64_t *bits,
+                            int words_per_row, int n_samples, const uint8_t *valid, const char *names, const int64_t *name_off,
+                            int64_t *order_out);
 /* `--kmerDB`: keeps only rows whose word occurs in the (sorted, canonical) db word list --
  * `glistcompare -i` of Samples.get_db_kmers, modeling.py:367-372. */
 int psk_intersect_db(psk_ctx *ctx, const uint64_t *db_words, uint64_t n_db, uint64_t *n_kmers);

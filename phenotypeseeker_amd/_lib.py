@@ -35,6 +35,9 @@ _SIGNATURES = {
                                                c.c_void_p]),
     "psk_get_list": (c.c_int, [c.c_void_p, c.c_int, c.c_void_p, c.c_void_p, c.c_uint64]),
     "psk_lookup_counts": (c.c_int, [c.c_void_p, c.c_int, c.c_void_p, c.c_uint64, c.c_void_p]),
+    "psk_write_result_tables": (c.c_int, [c.c_void_p, c.c_char_p, c.c_char_p, c.c_int64, c.c_char_p, c.c_int, c.c_int64, c.c_void_p,
+                                          c.c_int, c.c_void_p, c.c_void_p, c.c_void_p, c.c_void_p, c.c_void_p, c.c_void_p, c.c_int,
+                                          c.c_int, c.c_void_p, c.c_char_p, c.c_void_p, c.c_void_p]),
     "psk_lists_split": (c.c_int, [c.c_void_p, c.c_int, c.c_int, c.c_void_p, c.c_int, c.c_void_p]),
     "psk_copy_list_ranges": (c.c_int, [c.c_void_p, c.c_int, c.c_void_p, c.c_void_p, c.c_void_p, c.c_void_p, c.c_void_p]),
     "psk_set_lists_device": (c.c_int, [c.c_void_p, c.c_int, c.c_void_p, c.c_void_p, c.c_void_p, c.c_void_p, c.c_void_p]),

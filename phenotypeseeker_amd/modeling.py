@@ -14,6 +14,7 @@ calls (phenotypeseeker_amd.engine); everything here is orchestration and formatt
 
 A single process drives the GPU (no fork pools: the HIP runtime is not fork-safe).
 """
+import ctypes
 import math
 import os
 import sys
@@ -25,6 +26,7 @@ import numpy as np
 from . import dist as _dist
 from . import formats, metrics, _stats
 from .engine import PskContext
+from . import _lib
 from ._lib import PSK_EGZIP, PskError
 from .model import GridSearch, L1LogisticRegression, L2LogisticRegression, LassoRegression, RidgeRegression
 
@@ -487,15 +489,13 @@ class phenotypes:
             bits = ctx.get_rows(res["row"])
             if self.real_counts and npass:
                 counts = np.stack([ctx.lookup_counts(i, res["word"]) for i in range(n)], axis=1)
-        k = int(Samples.kmer_length)
-        # bit i of a row = sample i (little-endian u64 words): one unpackbits over the byte view
-        presence = np.ascontiguousarray(np.unpackbits(np.ascontiguousarray(bits, dtype="<u8").view(np.uint8), axis=1,
-                                                      bitorder="little")[:, :n]) if len(bits) else np.zeros((0, n), np.uint8)
-        self.rows = {"kmer": formats.words_to_kmers(res["word"], k), "stat": res["stat"], "p": res["p"],
+        # (the k-mer text and the 0/1 columns of the rows are made in get_ML_df, for the rows that are selected only: a
+        # continuous phenotype leaves 10^5 rows of which 1,000 go on)
+        self.rows = {"word": np.ascontiguousarray(res["word"], dtype=np.uint64), "bits": bits, "stat": res["stat"], "p": res["p"],
                      "mean_x": res["mean_x"], "mean_y": res["mean_y"], "n_with": res["n_with"],
-                     "presence": presence, "vector": counts.astype(np.int64) if counts is not None else presence}
+                     "vector": counts.astype(np.int64) if counts is not None else None}
         _err("\t%s: 100%% tests conducted.\n" % self.name)
-        if len(self.rows["kmer"]) == 0:
+        if len(self.rows["word"]) == 0:
             self.no_results.append(self.name)
         with open("log.txt", "a") as log:
             log.write("Func test_kmers_association_with_phenotype took %s secs (scan kernel %.3f ms)\n"
@@ -511,50 +511,58 @@ class phenotypes:
         else:
             r = self.rows
             binary = self.pred_scale == "binary"
-            pstr = [formats.pstring(p) for p in r["p"]]
-            # the reference sorts the columns by the p-value STRINGS (:1128); ties, which numpy's
-            # unstable sort leaves in an arbitrary order there, are broken by k-mer text here
-            order = sorted(range(len(pstr)), key=lambda i: (pstr[i], r["kmer"][i]))
             valid = [s.phenotypes[self.name] != "NA" and not isinstance(s.phenotypes[self.name], str) for s in samples]
-            lines = []
-            if len(order):
-                # whole-array forms of the per-row work (a continuous phenotype can leave 10^5 rows): numpy's
-                # round is the same rint(x * 100) / 100 element by element as formats.round2
-                oi = np.array(order, dtype=np.int64)
-                stat_s = [repr(float(v)) for v in np.round(np.asarray(r["stat"], dtype=np.float64)[oi], 2)]
-                nw_s = [str(int(v)) for v in np.asarray(r["n_with"])[oi]]
-                shown = (np.asarray(r["presence"], dtype=bool) & np.array(valid, dtype=bool)[None, :])[oi]
-                rr, cc = np.nonzero(shown)  # row-major: the names of one row are consecutive, in sample order
-                ends = np.cumsum(np.bincount(rr, minlength=len(oi)))
-                who = np.array(names, dtype=object)[cc].tolist()
-                if not binary:
-                    mx_s = [repr(float(v)) for v in np.round(np.asarray(r["mean_x"], dtype=np.float64)[oi], 2)]
-                    my_s = [repr(float(v)) for v in np.round(np.asarray(r["mean_y"], dtype=np.float64)[oi], 2)]
-                lo = 0
-                for t, i in enumerate(order):
-                    hi = int(ends[t])
-                    tail = " ".join(["|"] + who[lo:hi])
-                    lo = hi
-                    if binary:
-                        fields = [r["kmer"][i], stat_s[t], pstr[i], nw_s[t], tail]
-                    else:
-                        fields = [r["kmer"][i], stat_s[t], pstr[i], mx_s[t], my_s[t], nw_s[t], tail]
-                    lines.append("\t".join(fields))
             if binary:
                 head, stem = "k-mer\tchi2\tp-value\tnum_samples_w_kmer\tsamples_with_kmer", "chi2"
             else:
                 head, stem = ("k-mer\tt-test\tp-value\t+_group_mean\t-_group_mean\tnum_samples_w_kmer\t"
                               "samples_with_kmer"), "t-test"
-            with open("%s_results_%s.tsv" % (stem, self.name), "w") as f:
-                f.write("\n".join([head] + lines) + "\n")
+            # The tables are formatted and written by libpsk (psk_write_result_tables: host threads; a continuous phenotype
+            # leaves 10^5 rows with 3 x 10^7 sample names -- 0.6 s of Python string work in r03).  It also returns the order
+            # of the lines: the reference sorts the columns by the p-value STRINGS (:1128); ties, which numpy's unstable
+            # sort leaves in an arbitrary order there, are broken by k-mer text
+            words = r.get("word")
+            if words is None:     # (rows handed over as text and 0/1 columns: tests/test_host_modeling.py)
+                words = np.array([formats.kmer_to_word(km) for km in r["kmer"]], dtype=np.uint64)
+            n_rows = len(words)
+            bits = r.get("bits")
+            if bits is None:
+                pres = np.asarray(r["presence"], dtype=np.uint8).reshape(n_rows, len(names))
+                wpr = (len(names) + 63) // 64
+                padded = np.zeros((n_rows, wpr * 64), np.uint8)
+                padded[:, :len(names)] = pres != 0
+                bits = np.packbits(padded, axis=1, bitorder="little").view("<u8")
+            bits = np.ascontiguousarray(bits, dtype=np.uint64).reshape(n_rows, -1)
+            enc = [nm.encode() for nm in names]
+            off = np.zeros(len(enc) + 1, dtype=np.int64)
+            off[1:] = np.cumsum([len(e) for e in enc])
+            order_arr = np.zeros(n_rows, dtype=np.int64)
+            arr = {key: np.ascontiguousarray(r[key], dtype=np.float64) for key in ("stat", "p", "mean_x", "mean_y")}
+            n_with = np.ascontiguousarray(r["n_with"], dtype=np.int32)
+            words = np.ascontiguousarray(words, dtype=np.uint64)
+            vmask = np.array(valid, dtype=np.uint8)
+            top_path = ("%s_results_%s_top%s.tsv" % (stem, self.name, self.kmer_limit)).encode() if self.kmer_limit else None
+            lib = _lib.load()
+            vp = lambda a: a.ctypes.data_as(ctypes.c_void_p)
+            rc = lib.psk_write_result_tables(None, ("%s_results_%s.tsv" % (stem, self.name)).encode(), top_path,
+                                             int(self.kmer_limit or 0), head.encode(), 0 if binary else 1, n_rows, vp(words),
+                                             int(Samples.kmer_length), vp(arr["stat"]), vp(arr["p"]), vp(arr["mean_x"]),
+                                             vp(arr["mean_y"]), vp(n_with), vp(bits), bits.shape[1] if n_rows else 1, len(names),
+                                             vp(vmask), b"".join(enc), vp(off), vp(order_arr))
+            if rc != 0:
+                raise PskError("psk_write_result_tables failed (%d)" % rc, rc)
+            order = order_arr.tolist()
             if self.kmer_limit:
                 order = order[: self.kmer_limit]
-                with open("%s_results_%s_top%s.tsv" % (stem, self.name, self.kmer_limit), "w") as f:
-                    f.write("\n".join([head] + lines[: self.kmer_limit]) + "\n")
             keep = [j for j in range(len(names)) if valid[j]]
-            self.ML = {"kmers": [r["kmer"][i] for i in order],
+            sel = np.array(order, dtype=np.int64)
+            if r.get("vector") is not None:      # --real_counts: the counts of the selected k-mers
+                vec = np.asarray(r["vector"])[sel]
+            else:                                # bit i of a row = sample i (little-endian u64 words)
+                vec = np.unpackbits(np.ascontiguousarray(bits[sel], dtype="<u8").view(np.uint8), axis=1, bitorder="little")[:, :len(names)]
+            self.ML = {"kmers": formats.words_to_kmers(np.asarray(words)[sel], int(Samples.kmer_length)),
                        "index": [names[j] for j in keep],
-                       "X": r["vector"][order][:, keep].T.astype(np.int64) if order else np.zeros((len(keep), 0), np.int64),
+                       "X": vec[:, keep].T.astype(np.int64) if order else np.zeros((len(keep), 0), np.int64),
                        "weights": [samples[j].weight for j in keep],
                        "phenotype": [samples[j].phenotypes[self.name] for j in keep]}
             self._write_MLdf()

@@ -137,3 +137,78 @@ def test_train_test_split_matches_sklearn_fixture():
     for c in cases:
         tr, te = cv.train_test_split_indices(c["n"], c["test_size"], None if c["y"] is None else np.array(c["y"]), 55)
         assert list(tr) == c["train"] and list(te) == c["test"]
+
+
+def _python_result_table(head, kind, kmers, stat, p, mx, my, n_with, presence, valid, names):
+    """The writer of r01-r03 (pure Python, the DataFrame.to_csv text of modeling.py:1112-1145): the reference the C writer
+    is held to byte for byte."""
+    import numpy as np
+    pstr = ["%.2E" % v for v in p]
+    order = sorted(range(len(pstr)), key=lambda i: (pstr[i], kmers[i]))
+    lines = []
+    for i in order:
+        who = [names[j] for j in range(len(names)) if presence[i][j] and valid[j]]
+        tail = " ".join(["|"] + who)
+        f = [kmers[i], repr(float(np.round(np.float64(stat[i]), 2))), pstr[i]]
+        if kind == 1:
+            f += [repr(float(np.round(np.float64(mx[i]), 2))), repr(float(np.round(np.float64(my[i]), 2)))]
+        lines.append("\t".join(f + [str(int(n_with[i])), tail]))
+    return order, ("\n".join([head] + lines) + "\n").encode()
+
+
+def test_result_tables_written_by_libpsk_equal_the_python_writer(tmp_path):
+    """psk_write_result_tables (a9, host code in libpsk): the files and the line order equal the Python writer's on random
+    rows with the awkward doubles in them -- whole numbers ('3.0'), values that switch repr() to exponent notation
+    (1e-05, 1e+16, 1.5e-07), negative zero, huge and tiny statistics, p-values down to subnormals, inf and nan --, with NA
+    samples, sample names of several bytes per character, both table kinds, with and without the top file, zero rows."""
+    import ctypes
+    import numpy as np
+    from phenotypeseeker_amd import _lib, formats
+    lib = _lib.load()
+    rng = np.random.default_rng(12)
+    vp = lambda a: a.ctypes.data_as(ctypes.c_void_p)
+    for case in range(12):
+        n = int(rng.integers(1, 200))
+        m = 0 if case == 0 else int(rng.integers(1, 6000 if case == 11 else 300))
+        k = int(rng.choice([5, 13, 16, 32]))
+        kind = case & 1
+        names = [("s%d" % i) if i % 7 else ("Tõnu_%d·x" % i) for i in range(n)]
+        valid = (rng.random(n) < 0.9).astype(np.uint8)
+        words = rng.integers(0, 1 << min(2 * k, 62), m, dtype=np.uint64)
+        special = np.array([0.0, -0.0, 3.0, 100.0, 1e-5, 1.5e-7, 1e16, 123456789012345678.0, 0.005, 0.015, 2.675, -7.125, 1e15,
+                            1234.5678, 9.999e-5, 1e22, float("inf"), float("-inf"), float("nan"), 0.00049, 5e-324])
+        def vals():
+            v = rng.normal(0, 1, m) * 10.0 ** rng.integers(-8, 20, m)
+            pick = rng.random(m) < 0.3
+            v[pick] = rng.choice(special, pick.sum())
+            return v
+        stat, mx, my = vals(), vals(), vals()
+        p = 10.0 ** -rng.uniform(0, 320, m)
+        pp = rng.random(m) < 0.3
+        p[pp] = rng.choice([1.23e-5, 1.234e-5, 1.0, 9.995e-3, 5e-324, 0.0], pp.sum())
+        pres = (rng.random((m, n)) < rng.uniform(0.05, 0.9)).astype(np.uint8)
+        n_with = pres.sum(axis=1).astype(np.int32)
+        wpr = (n + 63) // 64
+        pad = np.zeros((m, wpr * 64), np.uint8)
+        pad[:, :n] = pres
+        bits = np.ascontiguousarray(np.packbits(pad, axis=1, bitorder="little").view("<u8")).reshape(m, wpr)
+        enc = [s.encode() for s in names]
+        off = np.zeros(n + 1, np.int64)
+        off[1:] = np.cumsum([len(e) for e in enc])
+        head = "k-mer\tstat\tp-value\tn\tsamples" if kind == 0 else "k-mer\tt\tp\t+\t-\tn\tsamples"
+        n_top = int(rng.integers(0, 50))
+        order = np.zeros(m, np.int64)
+        path, top = str(tmp_path / ("t%d.tsv" % case)).encode(), str(tmp_path / ("t%d_top.tsv" % case)).encode()
+        rc = lib.psk_write_result_tables(None, path, top if case % 3 else None, n_top, head.encode(), kind, m, vp(words), k, vp(stat), vp(p),
+                                         vp(mx), vp(my), vp(n_with), vp(bits), wpr, n, vp(valid), b"".join(enc), vp(off), vp(order))
+        assert rc == 0
+        kmers = formats.words_to_kmers(words, k)
+        want_order, want = _python_result_table(head, kind, kmers, stat, p, mx, my, n_with, pres, valid, names)
+        assert order.tolist() == want_order, case
+        with open(path, "rb") as f:
+            assert f.read() == want, case
+        if case % 3:
+            with open(top, "rb") as f:
+                assert f.read() == b"\n".join(want.split(b"\n")[: 1 + min(n_top, m)]) + b"\n", case
+    assert lib.psk_write_result_tables(None, None, None, 0, b"h", 0, 0, None, 13, None, None, None, None, None, None, 1, 1, None, None, None,
+                                       None) == -1

@@ -6,6 +6,7 @@ import gzip
 import json
 import os
 
+import numpy as np
 import pytest
 
 from helpers import GOLDEN
@@ -213,3 +214,37 @@ def test_gpu_neighbour_joining_is_bit_identical_to_the_host_loop():
         a = W.nj(names, mat)
         assert W.to_newick(a) == W.to_newick(b)
         print("nj 1100 leaves: gpu path %.2f s" % t_gpu)
+
+
+@pytest.mark.gpu
+def test_gpu_neighbour_joining_on_many_workgroups_equals_the_one_workgroup_kernel(monkeypatch):
+    """r04: nj_grid_kernel (a workgroup per 64 columns of the matrix, three exchanges per join through agent-scope atomics;
+    what psk_nj_merges runs from 512 leaves on, forced here for the small sizes) against nj_kernel (PSK_NJ_ONE_WG=1): the
+    merge lists -- pairs, both branch lengths, the last distance -- bit for bit, at sizes on either side of the 64-column
+    blocks and of the load batches, with ties everywhere and without; and faster where it is the default (1,024 leaves:
+    67 against 92 ms; 2,500: 0.4 against 1.2 s)."""
+    import time
+    from phenotypeseeker_amd.engine import PskContext
+    rng = np.random.default_rng(77)
+    monkeypatch.setenv("PSK_NJ_GRID", "1")
+    with PskContext(0) as ctx:
+        for n in (3, 4, 31, 33, 64, 65, 129, 200, 513, 1024, 1100, 2500):
+            for ties in (False, True):
+                if ties:
+                    half = rng.choice([0.0, 0.001, 0.002, 0.0153, 1.0], (n, n))
+                else:
+                    half = np.round(rng.random((n, n)) * 0.1, 6)
+                mat = np.tril(half, -1)
+                mat = mat + mat.T
+                t0 = time.time()
+                a = ctx.nj_merges(mat)
+                t_grid = time.time() - t0
+                monkeypatch.setenv("PSK_NJ_ONE_WG", "1")
+                t0 = time.time()
+                b = ctx.nj_merges(mat)
+                t_one = time.time() - t0
+                monkeypatch.delenv("PSK_NJ_ONE_WG")
+                for u, v in zip(a, b):
+                    assert np.array_equal(np.asarray(u), np.asarray(v)), (n, ties)
+                if n >= 1024:
+                    assert t_grid < t_one, (n, t_grid, t_one)

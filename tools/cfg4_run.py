@@ -29,11 +29,16 @@ with open(os.path.join(tmp, "data.pheno"), "w") as f:
 print("dataset written in %.1f s" % (time.time() - t0), flush=True)
 env = dict(os.environ, PYTHONPATH=ROOT + os.pathsep + os.environ.get("PYTHONPATH", ""))
 t0 = time.time()
-r = subprocess.run([sys.executable, os.path.join(ROOT, "scripts", "phenotypeseeker"), "modeling", "data.pheno", "-w"], cwd=tmp, env=env,
-                   stdout=subprocess.DEVNULL, stderr=subprocess.PIPE)
+cmd = [sys.executable, os.path.join(ROOT, "scripts", "phenotypeseeker"), "modeling", "data.pheno", "-w"]
+if os.environ.get("PSK_PROFILE"):   # where the host time goes: the CLI under cProfile, the 30 heaviest calls by cumulative time
+    cmd = [sys.executable, "-m", "cProfile", "-o", os.path.join(tmp, "prof.out")] + cmd[1:]
+r = subprocess.run(cmd, cwd=tmp, env=env, stdout=subprocess.DEVNULL, stderr=subprocess.PIPE)
 print("modeling -w: %.2f s, rc %d" % (time.time() - t0, r.returncode))
 if r.returncode:
     print(r.stderr.decode(errors="replace")[-1500:])
 print(open(os.path.join(tmp, "log.txt")).read())
+if os.environ.get("PSK_PROFILE"):
+    import pstats
+    pstats.Stats(os.path.join(tmp, "prof.out")).sort_stats("cumulative").print_stats(45)
 print(sorted(f for f in os.listdir(tmp) if not f.endswith(".fasta")))
 subprocess.run(["rm", "-rf", tmp])
