@@ -95,10 +95,37 @@ def host_cpus():
     return max(1, min(n, 512))
 
 
-def e2e_modeling(gs, n, k):
+def _drop_from_page_cache(path):
+    """fsync + POSIX_FADV_DONTNEED: the file's pages leave the page cache, the next reader gets them from the device."""
+    fd = os.open(path, os.O_RDONLY)
+    try:
+        os.fsync(fd)
+        os.posix_fadvise(fd, 0, 0, os.POSIX_FADV_DONTNEED)
+    finally:
+        os.close(fd)
+
+
+def _read_phases(d, world):
+    """The per-rank phase tables `phenotypeseeker modeling` leaves in its working directory (modeling.Phases): where the
+    wall-clock of the end-to-end leg went -- process start, HIP start-up, rendezvous, ingest, presence, scan, gather, model,
+    teardown -- per rank: {"rank<r>": {"total_s": ..., "phases_s": {...}}}."""
+    out = {}
+    for r in range(world):
+        try:
+            with open(os.path.join(d, "phases_rank%d.json" % r)) as f:
+                rec = json.load(f)
+            out["rank%d" % r] = {"total_s": rec["total_s"], "phases_s": rec["phases_s"]}
+        except (OSError, ValueError, KeyError):
+            out["rank%d" % r] = None
+    return out
+
+
+def e2e_modeling(gs, n, k, cold=False):
     """BASELINE.json's second figure: wall-clock of `phenotypeseeker modeling data.pheno` from FASTA files on
     disk to the written .pkl, on the same synthetic genomes, through the CLI entry point in this process
-    (its own context on the same GPU).  Reported beside `value`, never part of it."""
+    (its own context on the same GPU).  Reported beside `value`, never part of it.  The FASTA files were written by this
+    process a moment earlier: the run reads them from the PAGE CACHE, not from a device -- the record says so
+    (`input_files`); `--e2e-cold` drops them from the cache first (fsync + posix_fadvise(DONTNEED)) and says that."""
     import shutil
     import tempfile
     from phenotypeseeker_amd.cli import build_parser
@@ -115,6 +142,9 @@ def e2e_modeling(gs, n, k):
         with open(os.path.join(tmp, "data.pheno"), "w") as f:
             f.write("\n".join(rows) + "\n")
         t_write = time.time() - t0
+        if cold:
+            for i in range(n):
+                _drop_from_page_cache(os.path.join(tmp, gs.name(i) + ".fasta"))
         os.chdir(tmp)
         args = build_parser().parse_args(["modeling", "data.pheno", "-l", str(k)])
         err = sys.stderr
@@ -128,7 +158,9 @@ def e2e_modeling(gs, n, k):
             sys.stderr = err
         made = sorted(f for f in os.listdir(".") if f.endswith(".pkl"))
         return {"modeling_wall_s": round(wall, 3), "what": "phenotypeseeker modeling data.pheno: %d FASTA files on disk -> %s"
-                % (n, ", ".join(made) or "no model"), "write_dataset_s": round(t_write, 2)}
+                % (n, ", ".join(made) or "no model"), "write_dataset_s": round(t_write, 2), "phases": _read_phases(".", 1),
+                "input_files": "dropped from the page cache before the run (fsync + posix_fadvise DONTNEED)" if cold else
+                               "page cache (written by this process a moment earlier; --e2e-cold drops them first)"}
     finally:
         os.chdir(cwd)
         shutil.rmtree(tmp, ignore_errors=True)
@@ -186,6 +218,7 @@ def e2e_modeling_sharded(grp, gs, n, k, args):
         failed = grp.allreduce_sum(1 if rc != 0 else 0)
         made = sorted(f for f in os.listdir(tmp) if f.endswith(".pkl")) if rank == 0 else []
         res = {"modeling_wall_s": round(worst, 3), "ranks": grp.world, "ingest": args.ingest,
+               "phases": _read_phases(tmp, grp.world) if rank == 0 else None,
                "what": "phenotypeseeker modeling data.pheno as %d child processes (one per rank, started after the files were "
                        "written): %d FASTA files on disk -> %s" % (grp.world, n, ", ".join(made) or "no model"),
                "write_dataset_s": round(t_write, 2)}
@@ -213,9 +246,10 @@ def main():
     ap.add_argument("--samples", type=int, default=None, help="default 256 (N = 1) / 2048 (N > 1)")
     ap.add_argument("--length", type=int, default=5_000_000)
     ap.add_argument("--kmer", type=int, default=None, help="default 13 (N = 1) / 16 (N > 1)")
-    ap.add_argument("--ingest", default="filter", choices=["filter", "exchange"],
+    ap.add_argument("--ingest", default="auto", choices=["auto", "filter", "exchange"],
                     help="N > 1: every rank tokenises every sample and keeps its slab (filter), or every sample is "
-                         "counted on one rank and the list ranges are exchanged with an all-to-all (exchange)")
+                         "counted on one rank and the list ranges are exchanged with an all-to-all (exchange); auto = the "
+                         "CLI's rule: exchange when the collectives are RCCL, filter on a host transport (DESIGN.md section 8)")
     ap.add_argument("--workload", default="fasta", choices=["fasta", "matrix"],
                     help="fasta: count synthetic genomes on the GPU (default, BASELINE cfg 2); "
                          "matrix: device-generated presence matrix of --rows rows (quick runs)")
@@ -224,6 +258,8 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-e2e", action="store_true",
                     help="skip the end-to-end `phenotypeseeker modeling` wall-clock (FASTA files -> .pkl) on the same data")
+    ap.add_argument("--e2e-cold", action="store_true",
+                    help="drop the FASTA files of the end-to-end leg from the page cache before the run (N = 1)")
     ap.add_argument("--share-gpu", action="store_true",
                     help="map ranks onto the visible GPUs modulo their count (tests on a one-GPU box, with the host "
                          "transport named by PSK_DIST_TRANSPORT; RCCL refuses two ranks on one device)")
@@ -248,6 +284,12 @@ def main():
     grp.init(force=args.force_exchange)       # RCCL, or an error: see dist._rccl_or_host_files
     rank, world = grp.rank, grp.world
     sharded = world > 1
+    if args.ingest == "auto":
+        # what a rank moves at config 3 (2,048 x 5 Mbp, k = 16, 8 ranks): filter = ALL 10.2 GB of FASTA read from the host's
+        # files by every rank and sent over its PCIe link (8 x 10 GB of host reads in all); exchange = an eighth of the files
+        # per rank (1.3 GB), then 7/8 of 12 B x 1.28 G pairs = 13.4 GB per rank GPU to GPU over seven xGMI links at once.
+        # The host side is the scarce one: exchange wherever the collectives are RCCL (as the CLI does)
+        args.ingest = "exchange" if getattr(grp, "backend", None) == "rccl" else "filter"
     n = args.samples if args.samples is not None else (2048 if sharded else 256)
     k = args.kmer if args.kmer is not None else (16 if sharded else 13)
 
@@ -460,7 +502,7 @@ def main():
                                "matches_gpu": same,
                                "reference_python_8proc_cells_per_s": 7.4e6}
     if rank == 0 and world == 1 and args.workload == "fasta" and not args.no_e2e:
-        out["e2e"] = e2e_modeling(gs, n, k)
+        out["e2e"] = e2e_modeling(gs, n, k, cold=args.e2e_cold)
     ctx.close()   # the matrix and the lists go before the CLI children of the next leg bring their own
     if world > 1 and args.workload == "fasta" and not args.no_e2e:
         out["e2e"] = e2e_modeling_sharded(grp, gs, n, k, args)

@@ -140,8 +140,13 @@ def main(argv=None):
     args = parser.parse_args(argv)
     if not hasattr(args, "func"):
         parser.error("too few arguments")
+    if argv is None or getattr(main, "_is_process", False):
+        # the CLI IS the process: its phase table (modeling.Phases) starts where the process did
+        from .modeling import process_start_epoch
+        args._t0 = process_start_epoch()
     args.func(args)
 
 
 if __name__ == "__main__":
+    main._is_process = True
     main(sys.argv[1:])

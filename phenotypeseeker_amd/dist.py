@@ -466,6 +466,11 @@ def _exchange_status(d, prefix, rank, world, text, timeout=600.0, nonce=""):
     return out
 
 
+# where the time of the last communicator bring-up went (read by modeling.Phases: the first run on several GPUs should say
+# how much of its start-up is HIP, how much the status rounds, how much ncclCommInitRank)
+init_times = {}
+
+
 def _rccl_or_host_files(rank, world, device):
     """RCCL.  Two rounds of one status file per rank in the launch's rendezvous directory make every decision a
     decision of ALL ranks: (1) before anybody enters ncclCommInitRank -- which blocks until every rank has called it --
@@ -479,18 +484,27 @@ def _rccl_or_host_files(rank, world, device):
     _rdzv_seq[0] += 1
     d = rdzv[0]
     t, err = None, ""
+    init_times.clear()
+    t0 = time.time()
     try:
         probe = PskContext(device)      # does this rank's GPU exist?
         probe.close()
     except Exception as e:
         err = "%s: %s" % (type(e).__name__, e)
+    init_times["HIP runtime, context"] = time.time() - t0
+    t0 = time.time()
     errs = _exchange_status(d, "rd.%d" % seq, rank, world, err, nonce=rdzv[1])
+    init_times["waiting for every rank's GPU probe"] = time.time() - t0
     if all(e == "ok" for e in errs):
+        t0 = time.time()
         try:
             t = RcclTransport(rank, world, device, rdzv=rdzv, seq=seq)
         except Exception as e:      # PskError from psk_comm_init, or the rendezvous timing out
             err = "%s: %s" % (type(e).__name__, e)
+        init_times["unique id + ncclCommInitRank" + ("" if t is not None else " (refused)")] = time.time() - t0
+        t0 = time.time()
         errs = _exchange_status(d, "st.%d" % seq, rank, world, err, nonce=rdzv[1])
+        init_times["waiting for every rank's communicator"] = time.time() - t0
     bad = [(r, e) for r, e in enumerate(errs) if e != "ok"]
     if bad:
         if t is not None:

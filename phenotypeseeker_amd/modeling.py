@@ -471,7 +471,10 @@ class phenotypes:
             if phenotypes._exchange is None:
                 phenotypes._exchange = _dist.SurvivorExchange(group, ctx.presence_shape()[1])
             local = ctx.get_results(npass) if self.real_counts else None
+            t_g = time.time()
             res, bits = phenotypes._exchange.gather(ctx)
+            if Phases.current is not None:
+                Phases.current.move("scan", "survivor all-gather", time.time() - t_g)
             if self.real_counts:
                 mine = np.stack([ctx.lookup_counts(i, local["word"]) for i in range(n)], axis=1) if npass else \
                     np.zeros((0, n), np.uint32)
@@ -818,8 +821,57 @@ def _metric_store():
                             "Pr", "MCC", "kappa", "VME", "ME", "F1_sc")}
 
 
+def process_start_epoch():
+    """When this process was started (epoch seconds): field 22 of /proc/self/stat, clock ticks after boot."""
+    try:
+        with open("/proc/self/stat") as f:
+            ticks = float(f.read().rsplit(")", 1)[1].split()[19])
+        with open("/proc/uptime") as f:
+            up = float(f.read().split()[0])
+        return time.time() - (up - ticks / os.sysconf("SC_CLK_TCK"))
+    except (OSError, ValueError, IndexError):
+        return time.time()
+
+
+class Phases:
+    """Where the wall-clock of a run goes, by phase and by rank -- so that the first run on several GPUs produces a number
+    somebody can read (eight ranks sharing one GPU took 5.4 s for a set one rank does in 0.2 s, and
+    nothing said how much of it was eight interpreters and eight HIP start-ups).  mark(name) closes the phase that began at
+    the mark before it; the table goes to phases_rank<r>.json in the working directory (and, rank 0, into log.txt); its
+    entries sum to `total_s` by construction.  t0: the process's start when the CLI is the process (cli.main), else
+    the call."""
+    current = None
+
+    def __init__(self, t0=None):
+        self.t0 = self.last = time.time() if t0 is None else t0
+        self.table = OrderedDict()
+
+    def mark(self, name):
+        now = time.time()
+        self.table[name] = self.table.get(name, 0.0) + (now - self.last)
+        self.last = now
+
+    def move(self, src, dst, secs):
+        """`secs` of what will be booked under `src` belong to `dst` (a step timed inside another phase)."""
+        self.table[dst] = self.table.get(dst, 0.0) + secs
+        self.table[src] = self.table.get(src, 0.0) - secs
+
+    def write(self, rank, world):
+        rec = {"rank": rank, "world": world, "total_s": round(self.last - self.t0, 4),
+               "phases_s": OrderedDict((k, round(v, 4)) for k, v in self.table.items())}
+        import json
+        with open("phases_rank%d.json" % rank, "w") as f:
+            json.dump(rec, f)
+        if rank == 0:
+            with open("log.txt", "a") as log:
+                log.write("Phases of rank 0 (s): %s; total %.3f\n" % (", ".join("%s %.3f" % kv for kv in rec["phases_s"].items()), rec["total_s"]))
+        return rec
+
+
 def modeling(args):
     """The main function of `phenotypeseeker modeling` (:1624-1709)."""
+    ph_t = Phases.current = Phases(getattr(args, "_t0", None))
+    ph_t.mark("process start, interpreter, imports")
     _err(RED_BANNER % "######                   PhenotypeSeeker                   ######")
     _err(RED_BANNER % "######                      modeling                       ######" + "\n")
     Input.reset()
@@ -832,8 +884,13 @@ def modeling(args):
         args.train_on_whole, args.logreg_solver, args.jump_to, args.pca, args.real_counts, args.omit_B_correction,
         args.kmerDB)
     Samples.use_weights = bool(getattr(args, "weights", False))
+    ph_t.mark("arguments, data.pheno")
     group = _dist.Group().init()
+    ph_t.mark("rendezvous, communicator (ncclCommInitRank)")
+    for name, secs in _dist.init_times.items():     # the bring-up's own steps (the GPU probe in it pays the HIP start-up)
+        ph_t.move("rendezvous, communicator (ncclCommInitRank)", name if name.startswith("HIP") else "rendezvous: " + name, secs)
     ctx = PskContext(group.device)
+    ph_t.mark("HIP runtime, context")
     try:
         if not Input.jump_to:
             k = int(Samples.kmer_length)
@@ -854,18 +911,23 @@ def modeling(args):
                 with open("log.txt", "a") as log:
                     log.write("Func get_kmer_lists took %s secs (%d rank(s)%s)\n"
                               % (time.time() - t_lists, group.world, ", list exchange" if exchange else ""))
+            ph_t.mark("ingest: k-mer lists" + (" (list exchange)" if exchange else " (every rank filters its slab)" if group.world > 1 else ""))
             _err("\n" + GREEN % "Generating the k-mer feature vector." + "\n")
             m_local = Samples.get_feature_vector(ctx)
+            ph_t.mark("presence matrix")
             _err(GREEN % "Mapping samples to the feature vector space:" + "\n")
             stderr_print("\t%d of %d samples mapped." % (Samples.no_samples, Samples.no_samples))
             if Samples.use_weights:
                 _err("\n" + GREEN % "Estimating the Mash distances between samples..." + "\n")
                 stderr_print(GREEN % "Calculating the GSC weights from mash distance matrix...")
                 Samples.get_weights(ctx)
+                ph_t.mark("weights: sketches, distances, NJ, GSC")
             phenotypes.kmer_testing_setup(group.allreduce_sum(int(m_local)))
+            ph_t.mark("all-reduce of the union size")
             phs = list(Input.phenotypes_to_analyse.values())
             for j, ph in enumerate(phs):
                 ph.test_kmers_association_with_phenotype(ctx, group, phs[j + 1] if j + 1 < len(phs) else None)
+            ph_t.mark("scan")      # (the survivors' all-gather inside it is moved to its own line: Phases.move)
             Input.pop_phenos_out_of_kmers()
         # 'modelling' / 'modeling' both run the model stage; 'PCA' runs nothing (:1689)
         if not Input.jump_to or Input.jump_to in ("modelling", "modeling"):
@@ -875,10 +937,14 @@ def modeling(args):
             if group.rank == 0:
                 for ph in Input.phenotypes_to_analyse.values():
                     ph.machine_learning_modelling(ctx)
+            ph_t.mark("model: result tables, grid search, model files")
             group.barrier()
+            ph_t.mark("waiting for rank 0's model")
         if getattr(args, "assembly", False):
             _err(YELLOW % "-a/--assembly is outside the accelerated path and is skipped.")
     finally:
         ctx.close()
         group.close()
+        ph_t.mark("teardown: buffers, communicator")
+        ph_t.write(group.rank, group.world)
     _err("\n" + RED_BANNER % "######          PhenotypeSeeker modeling finished          ######")

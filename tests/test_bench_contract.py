@@ -33,6 +33,13 @@ def test_bench_json_contract():
     assert d["value"] > cb["value"]
     e2e = d["e2e"]  # BASELINE.json's second figure rides along, outside `value`
     assert e2e["modeling_wall_s"] > 0 and "log_reg_model_Pheno.pkl" in e2e["what"]
+    assert e2e["input_files"].startswith("page cache")          # (the files were written a moment earlier: it says so)
+    # ... with its phase table: the phases of the run sum to its wall-clock
+    ph = e2e["phases"]["rank0"]
+    assert abs(sum(ph["phases_s"].values()) - ph["total_s"]) < 1e-2
+    assert abs(ph["total_s"] - e2e["modeling_wall_s"]) <= 0.05 * e2e["modeling_wall_s"] + 0.01, (ph, e2e["modeling_wall_s"])
+    for key in ("HIP runtime, context", "ingest: k-mer lists", "presence matrix", "scan", "model: result tables, grid search, model files"):
+        assert key in ph["phases_s"], ph
 
 
 def test_bench_two_ranks_run_the_sharded_pipeline():
@@ -78,6 +85,16 @@ def test_bench_two_ranks_run_the_sharded_pipeline():
             e2e = d["e2e"]
             assert "error" not in e2e, e2e
             assert e2e["modeling_wall_s"] > 0 and e2e["ranks"] == 2 and "log_reg_model_Pheno.pkl" in e2e["what"]
+            # every rank's phase table, process start to teardown: the slowest rank's total is the leg's wall-clock less
+            # what the interpreter needs to exit (5 % + 0.15 s)
+            ph = e2e["phases"]
+            assert set(ph) == {"rank0", "rank1"} and all(v is not None for v in ph.values()), ph
+            for v in ph.values():
+                assert abs(sum(v["phases_s"].values()) - v["total_s"]) < 1e-2
+                assert any(k.startswith("process start") for k in v["phases_s"]) and any(k.startswith("rendezvous") for k in v["phases_s"])
+                assert any(k.startswith("ingest: k-mer lists (") for k in v["phases_s"]) and "survivor all-gather" in v["phases_s"]
+            slowest = max(v["total_s"] for v in ph.values())
+            assert slowest <= e2e["modeling_wall_s"] + 0.01 and e2e["modeling_wall_s"] - slowest <= 0.05 * e2e["modeling_wall_s"] + 0.15, (slowest, e2e["modeling_wall_s"])
 
 
 def test_bench_without_rccl_and_without_the_opt_in_fails():
