@@ -96,6 +96,16 @@ __device__ __forceinline__ W pm_wave_min(W v)
     return ab < cd ? ab : cd;
 }
 
+// The minimum when lane 0 already stands on it -- every word all the wave's samples share, 95 % of the iterations at
+// config 3 --: one lane read and one compare instead of the butterflies (4 DPP steps with their wait states, 4 lane reads)
+template <typename W>
+__device__ __forceinline__ W pm_wave_min_guess(W cand)
+{
+    const W m0 = pm_readlane(cand, 0);
+    if (__ballot(cand < m0) == 0ull) return m0;
+    return pm_wave_min(cand);
+}
+
 // A lane's cursor into its list.  W = uint32_t: words relative to the slab's base (word spaces of up to 2^32 values:
 // every k <= 16), W = uint64_t otherwise; the all-ones value means "no word" (never a canonical word: the reverse
 // complement of T...T is A...A).
@@ -115,16 +125,27 @@ __device__ __forceinline__ W pm_wave_min(W v)
 #ifndef PSK_PM_NT
 #define PSK_PM_NT 0
 #endif
+// r04: for 32-bit words the window is a RING IN LDS (2 B words per lane, word-major: slot j of every lane of the workgroup
+// side by side, so that lanes standing on different slots still hit 32 different banks).  The window in registers cost the
+// merge loop a 15-deep tree of v_bfi per advance (a run-time index into registers does not exist) and B moves per
+// refill; in LDS an advance is one ds_read.  The loops are VALU-issue bound (~75 instructions per wave iteration, 43 M
+// iterations per pass at config 3: pm_mark 6.8 + pm_fill 14.2 ms, r03); 64-bit words (k = 17 slabs) keep the registers:
+// their ring would be 128 KB.
 template <typename W, int B = PSK_PM_BLOCK>
 struct PmCursor {
     static constexpr W SENT = (W)~(W)0;
+    static constexpr bool RING = sizeof(W) == 4;
+    static constexpr int NREG = RING ? 1 : 2 * B;
+    W *ring;               // RING: this lane's slot 0; slot j at ring[j * stride]
+    uint32_t stride, off;  // RING: lanes per workgroup; the slot of window position 0 (0 or B: the halves swap roles at a refill)
     const uint64_t *w;     // the list, shifted down so that block b = w[B b .. B b + B - 1] is aligned to its size
     uint32_t first, end;   // the list's words are w[first .. end)
     uint32_t last_blk;     // block of the list's last word
     uint32_t blk;          // block index of r[0 .. B)
     uint32_t i;            // current word = r[i]; i == 2 B: the window is used up
     uint64_t base;
-    W r[2 * B], cur;
+    W r[NREG], cur;
+    W nxt;                 // RING: the word behind the current one, read an iteration ahead (an advance never waits for LDS)
     pm_u64x2 pv[B / 2];    // the block behind the window as it was loaded, requested one refill ahead (see refill); it is
                            // converted only when it moves into the window -- touching it earlier would make the
                            // compiler wait for the load right where it was issued
@@ -148,12 +169,20 @@ struct PmCursor {
 #pragma unroll
         for (int k = 0; k < B / 2; k++) pv[k] = PSK_PM_NT ? __builtin_nontemporal_load(&p[k]) : p[k];
     }
-    __device__ __forceinline__ void take(uint32_t b, W *dst) const   // block b, requested before, into the window
+    // block b, requested before, into window positions [B half, B half + B)
+    __device__ __forceinline__ void take(uint32_t b, int half)
     {
 #pragma unroll
         for (int k = 0; k < B / 2; k++) {
-            dst[2 * k] = conv(pv[k].x, B * b + 2 * k);           // beyond the end: SENT
-            dst[2 * k + 1] = conv(pv[k].y, B * b + 2 * k + 1);
+            const W x0 = conv(pv[k].x, B * b + 2 * k), x1 = conv(pv[k].y, B * b + 2 * k + 1);   // beyond the end: SENT
+            if constexpr (RING) {
+                const uint32_t s0 = (uint32_t)(B * half + 2 * k + off) & (2 * B - 1);
+                ring[s0 * stride] = x0;
+                ring[(s0 + 1) * stride] = x1;     // (2 k + off is even: no wrap inside the pair)
+            } else {
+                r[(B * half + 2 * k) % NREG] = x0;
+                r[(B * half + 2 * k + 1) % NREG] = x1;
+            }
         }
     }
     // v[i] for i < N by a binary tree of selects: bit 0 of i halves the candidates, then bit 1, ... (N - 1 v_cndmask; written
@@ -174,7 +203,14 @@ struct PmCursor {
             return pick<N / 2>(h, i >> 1);
         }
     }
-    __device__ __forceinline__ void select() { cur = pick<2 * B>(r, i); }   // i == 2 B reads r[0]: the loop refills before it looks
+    // i == 2 B reads position 0: the loop refills before it looks
+    __device__ __forceinline__ void select()
+    {
+        if constexpr (RING) {
+            cur = ring[((i + off) & (2 * B - 1)) * stride];
+            nxt = ring[((i + 1 + off) & (2 * B - 1)) * stride];   // (i + 1 == 2 B: some slot; it only ever becomes `cur` of a dry window)
+        } else cur = pick<NREG>(r, i);
+    }
     // pos: index into the list of the word to stand on (pos == n: at the end)
     // words == nullptr or n == 0 (no sample in this lane, an empty list): `spare` (64-byte aligned, 64 bytes) is read instead
     __device__ __forceinline__ void seek(const uint64_t *words, uint32_t n, uint32_t pos, uint64_t base_, const uint64_t *spare)
@@ -184,12 +220,14 @@ struct PmCursor {
         w = words - mis; first = mis; end = n + mis; base = base_;
         last_blk = end ? (end - 1) / B : 0;
         const uint32_t q = pos + mis;
-        blk = q / B; i = q % B;
-        request(blk); take(blk, r);
-        request(blk + 1); take(blk + 1, r + B);
+        blk = q / B; i = q % B; off = 0;
+        request(blk); take(blk, 0);
+        request(blk + 1); take(blk + 1, 1);
         request(blk + 2);
         select();
     }
+    // RING: where this lane's ring lives (before the first seek)
+    __device__ __forceinline__ void attach(W *lane_slot0, uint32_t lanes) { ring = lane_slot0; stride = lanes; off = 0; }
     __device__ __forceinline__ uint32_t position() const { return B * blk + i - first; }   // index into the list of the current word
     __device__ __forceinline__ bool dry() const { return i >= 2 * B; }
     // wave-uniform call.  The block that moves into the window was requested at the lane's PREVIOUS refill (or seek), at
@@ -197,10 +235,13 @@ struct PmCursor {
     __device__ __forceinline__ void refill()
     {
         if (i >= B) {
+            if constexpr (RING) off ^= B;   // the second half becomes the first; the block behind it goes where the first was
+            else {
 #pragma unroll
-            for (int k = 0; k < B; k++) r[k] = r[B + k];
+                for (int k = 0; k < B; k++) r[k % NREG] = r[(B + k) % NREG];
+            }
             blk++; i -= B;
-            take(blk + 1, r + B);
+            take(blk + 1, 1);
             request(blk + 2);
             select();
         }
@@ -208,7 +249,10 @@ struct PmCursor {
     __device__ __forceinline__ void advance()
     {
         i++;
-        select();   // i == 2 B: some value of the window; the loop refills before it looks at `cur` again
+        if constexpr (RING) {
+            cur = nxt;
+            nxt = ring[((i + 1 + off) & (2 * B - 1)) * stride];
+        } else select();   // i == 2 B: some value of the window; the loop refills before it looks at `cur` again
     }
 };
 
@@ -231,11 +275,13 @@ __global__ __launch_bounds__(PM_GROUP) void pm_mark_kernel(const PmList *__restr
                                                            const uint64_t *__restrict__ spare)
 {
     __shared__ unsigned long long bm[PM_BMW];
+    extern __shared__ __attribute__((aligned(16))) unsigned long long pm_ring_lds[];   // (32-bit words) the lanes' windows
     const int lane = threadIdx.x & 63;
     const int s = blockIdx.y * PM_GROUP + threadIdx.x;
     const uint32_t t0 = blockIdx.x * tiles_per_range;
     const uint32_t t1 = t0 + tiles_per_range < n_tiles ? t0 + tiles_per_range : n_tiles;
     PmCursor<W> cur;
+    if constexpr (PmCursor<W>::RING) cur.attach(reinterpret_cast<W *>(pm_ring_lds) + threadIdx.x, blockDim.x);
     if (s < n_samples) {
         const PmList L = lists[s];
         cur.seek(L.words, (uint32_t)L.n, pm_lower_bound(L.words, (uint32_t)L.n, bounds[t0]), base, spare);
@@ -251,7 +297,7 @@ __global__ __launch_bounds__(PM_GROUP) void pm_mark_kernel(const PmList *__restr
         for (;;) {
             if (__any(cur.dry())) cur.refill();
             const W cand = cur.cur <= hi_w ? cur.cur : PmCursor<W>::SENT;
-            const W m = pm_wave_min(cand);
+            const W m = pm_wave_min_guess(cand);
             if (m == PmCursor<W>::SENT) break;
             const uint32_t v = (uint32_t)(m - lo_w);
             if (lane == 0) atomicOr(&bm[v >> 6], 1ull << (v & 63));
@@ -286,8 +332,11 @@ __global__ void pm_tile_rows_kernel(const uint32_t *__restrict__ rank, const uin
 }
 
 // pass 2: the same stream; every wave stores its ballots into its column of the tile's block
+#ifndef PSK_PM_FILL_WGS
+#define PSK_PM_FILL_WGS 1
+#endif
 template <typename W>
-__global__ __launch_bounds__(PM_GROUP) void pm_fill_kernel(const PmList *__restrict__ lists, int n_samples, int wpr,
+__global__ __launch_bounds__(PM_GROUP, PSK_PM_FILL_WGS) void pm_fill_kernel(const PmList *__restrict__ lists, int n_samples, int wpr,
                                                            const uint64_t *__restrict__ bounds, uint32_t n_tiles,
                                                            uint32_t tiles_per_range, uint64_t base,
                                                            const unsigned long long *__restrict__ gbm,
@@ -295,10 +344,12 @@ __global__ __launch_bounds__(PM_GROUP) void pm_fill_kernel(const PmList *__restr
                                                            uint32_t bmw_max, uint64_t *__restrict__ union_words,
                                                            uint64_t *__restrict__ bits, const uint64_t *__restrict__ spare)
 {
-    extern __shared__ __attribute__((aligned(16))) unsigned long long pm_lds[];
+    extern __shared__ __attribute__((aligned(16))) unsigned long long pm_lds_all[];
+    // (32-bit words) the lanes' windows first: 2 B words per lane
+    unsigned long long *pm_lds = pm_lds_all + (PmCursor<W>::RING ? (size_t)blockDim.x * PSK_PM_BLOCK * 2 * sizeof(W) / 8 : 0);
     unsigned long long *bm = pm_lds;                                        // bmw_max
     uint32_t *rk = reinterpret_cast<uint32_t *>(pm_lds + bmw_max);          // bmw_max + 1 (padded to even)
-    unsigned long long *blk = pm_lds + bmw_max + ((bmw_max + 2) >> 1);      // cols x rows of the batch, column-major
+    unsigned long long *blk = pm_lds + bmw_max + ((bmw_max + 2) >> 1);      // rows x cols of the batch, row-major (r04: the copy-out reads it with consecutive threads on consecutive words; column-major, rows a multiple of 16 put a wave's 16 columns on one bank)
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int group = blockIdx.y;
     const int s = group * PM_GROUP + threadIdx.x;
@@ -309,6 +360,7 @@ __global__ __launch_bounds__(PM_GROUP) void pm_fill_kernel(const PmList *__restr
     uint32_t ln = 0;
     if (s < n_samples) { const PmList L = lists[s]; lw = L.words; ln = (uint32_t)L.n; }
     PmCursor<W> cur;
+    if constexpr (PmCursor<W>::RING) cur.attach(reinterpret_cast<W *>(pm_lds_all) + threadIdx.x, blockDim.x);
     cur.seek(lw, ln, lw ? pm_lower_bound(lw, ln, bounds[t0]) : 0, base, spare);
     for (uint32_t t = t0; t < t1; t++) {
         const uint64_t lo = bounds[t], hi = bounds[t + 1];
@@ -328,13 +380,13 @@ __global__ __launch_bounds__(PM_GROUP) void pm_fill_kernel(const PmList *__restr
             for (;;) {
                 if (__any(cur.dry())) cur.refill();
                 const W cand = cur.cur <= hi_w ? cur.cur : PmCursor<W>::SENT;
-                const W m = pm_wave_min(cand);
+                const W m = pm_wave_min_guess(cand);
                 if (m == PmCursor<W>::SENT) break;
                 const bool hit = cand == m;
                 const uint64_t mask = __ballot(hit);
                 const uint32_t i = (uint32_t)(m - lo_w);
                 const uint32_t r = rk[i >> 6] - row0 + (uint32_t)__popcll(bm[i >> 6] & ((1ull << (i & 63)) - 1ull)) - b0;
-                if (lane == 0 && r < rb && wave < cols) blk[(uint32_t)wave * rb + r] = mask;   // r is unsigned: rows of earlier batches wrap
+                if (lane == 0 && r < rb && wave < cols) blk[r * (uint32_t)cols + (uint32_t)wave] = mask;   // r is unsigned: rows of earlier batches wrap
                 if (hit) cur.advance();
             }
             __syncthreads();
@@ -342,12 +394,12 @@ __global__ __launch_bounds__(PM_GROUP) void pm_fill_kernel(const PmList *__restr
             if (cols == PM_COLS) {   // a full group: shifts instead of a division by a run-time value per element
                 for (uint32_t e = threadIdx.x; e < rb * (uint32_t)PM_COLS; e += blockDim.x) {
                     const uint32_t r = e / PM_COLS, c = e % PM_COLS;
-                    dst[(uint64_t)r * wpr + c] = blk[c * rb + r];
+                    dst[(uint64_t)r * wpr + c] = blk[e];
                 }
             } else {
                 for (uint32_t e = threadIdx.x; e < rb * (uint32_t)cols; e += blockDim.x) {
                     const uint32_t r = e / (uint32_t)cols, c = e % (uint32_t)cols;
-                    dst[(uint64_t)r * wpr + c] = blk[c * rb + r];
+                    dst[(uint64_t)r * wpr + c] = blk[e];
                 }
             }
             __syncthreads();
@@ -498,7 +550,10 @@ int build_presence_merge(psk_ctx *ctx, uint64_t total_pairs, uint64_t *n_kmers, 
     // "no word left".  The whole k = 16 space is safe (T...T is never canonical); a k = 17 slab cut at list quantiles whose
     // 64-aligned span is exactly 2^32 could hold a real word there: it takes the 64-bit cursors
     const bool w32 = span < (1ull << 32) || (span == (1ull << 32) && base == 0 && k == 16);
-    if (w32) pm_mark_kernel<uint32_t><<<grid, threads, 0, ctx->stream>>>(d_refs, n, d_bounds, n_tiles, tiles_per_range, base, gbm, n_groups == 1, d_spare);
+    const size_t ring_bytes = w32 ? (size_t)threads * PSK_PM_BLOCK * 2 * 4 : 0;   // the lanes' windows (32-bit words): 64 KB for 1,024 lanes
+    if (w32 && ring_bytes + PM_BMW * 8 > 64 * 1024)
+        PSK_HIP(ctx, hipFuncSetAttribute(reinterpret_cast<const void *>(pm_mark_kernel<uint32_t>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)ring_bytes));
+    if (w32) pm_mark_kernel<uint32_t><<<grid, threads, ring_bytes, ctx->stream>>>(d_refs, n, d_bounds, n_tiles, tiles_per_range, base, gbm, n_groups == 1, d_spare);
     else pm_mark_kernel<uint64_t><<<grid, threads, 0, ctx->stream>>>(d_refs, n, d_bounds, n_tiles, tiles_per_range, base, gbm, n_groups == 1, d_spare);
     PSK_HIP(ctx, hipGetLastError());
     mark("pm_mark");
@@ -521,21 +576,26 @@ int build_presence_merge(psk_ctx *ctx, uint64_t total_pairs, uint64_t *n_kmers, 
     mark("alloc matrix");
     if (M) {
         const int cols0 = wpr < PM_COLS ? wpr : PM_COLS;
-        const size_t head = (size_t)bmw_max * 8 + (size_t)((bmw_max + 2) >> 1) * 8;
+        const size_t head = ring_bytes + (size_t)bmw_max * 8 + (size_t)((bmw_max + 2) >> 1) * 8;
         // rows a block holds: what fits beside the bitmap -- but sized for the bulk of the tiles (99.5th percentile of
         // their row counts, and <= 72 KB so that two workgroups share a CU), not for the one tile in a thousand that the
         // pilot cut too wide: those are streamed in several batches (first cut: the widest tile of config 3's slab, 2,461
         // rows against a mean of 152, made every workgroup reserve 147 KB of LDS: one workgroup per CU, 13.6 ms)
         uint32_t r_cap = (uint32_t)((PM_LDS_MAX - head) / ((size_t)cols0 * 8));
-        if (const char *pe = getenv("PSK_MERGE_RCAP_PCT")) {   // A/B: size the block for a percentile of the tiles, batches for the rest
-            const double pct = atof(pe);
+        {   // two workgroups per CU (78 KB each) whenever the bulk of the tiles -- the 99.5th percentile of their row counts, or
+            // PSK_MERGE_RCAP_PCT -- fits a block of that size; the few wider tiles are streamed in batches
+            double pct = 0.995;
+            if (const char *pe = getenv("PSK_MERGE_RCAP_PCT")) { const double v = atof(pe); if (v > 0 && v <= 1) pct = v; }
             std::vector<uint32_t> sorted_rows(rows);
-            const size_t q = (size_t)((double)(n_tiles - 1) * (pct > 0 && pct <= 1 ? pct : 0.995));
+            const size_t q = (size_t)((double)(n_tiles - 1) * pct);
             std::nth_element(sorted_rows.begin(), sorted_rows.begin() + q, sorted_rows.end());
-            uint32_t bulk = sorted_rows[q] < 64 ? 64 : sorted_rows[q];
-            const size_t two_per_cu = 72 * 1024;
-            if (head + (size_t)cols0 * 8 * 64 <= two_per_cu) bulk = std::min<uint32_t>(bulk, (uint32_t)((two_per_cu - head) / ((size_t)cols0 * 8)));
-            if (bulk < r_cap) r_cap = bulk;
+            const uint32_t bulk = sorted_rows[q] < 64 ? 64 : sorted_rows[q];
+            const size_t two_per_cu = 78 * 1024;
+            // (only a build whose fill kernel fits two workgroups per CU by its registers asks for it -- EXTRA="-DPSK_PM_BLOCK=4
+            // -DPSK_PM_FILL_WGS=8": 57 VGPRs, a 32-KB ring; measured no faster than one workgroup with 64-byte blocks: fill 13.0
+            // against 13.6 ms, mark 6.2 against 5.3)
+            if ((PSK_PM_FILL_WGS >= 8 || getenv("PSK_MERGE_RCAP_PCT")) && head + (size_t)cols0 * 8 * bulk <= two_per_cu)
+                r_cap = std::min<uint32_t>(r_cap, (uint32_t)((two_per_cu - head) / ((size_t)cols0 * 8)));
         }
         const uint32_t rb_max = rows_max < r_cap ? rows_max : r_cap;
         const size_t lds = head + (size_t)cols0 * rb_max * 8;
