@@ -294,15 +294,24 @@ __global__ __launch_bounds__(PM_GROUP) void pm_mark_kernel(const PmList *__restr
         const uint32_t nbw = (uint32_t)((hi - lo + 63) >> 6);
         for (uint32_t i = threadIdx.x; i < nbw; i += blockDim.x) bm[i] = 0;
         __syncthreads();
+        // the words found go into the bitmap 64 at a time, lane j the j-th of them (one atomic of one lane per iteration was a
+        // wave instruction per word; this is one per 64)
+        uint32_t my_v = 0;
+        int cnt = 0;
         for (;;) {
             if (__any(cur.dry())) cur.refill();
             const W cand = cur.cur <= hi_w ? cur.cur : PmCursor<W>::SENT;
             const W m = pm_wave_min_guess(cand);
             if (m == PmCursor<W>::SENT) break;
             const uint32_t v = (uint32_t)(m - lo_w);
-            if (lane == 0) atomicOr(&bm[v >> 6], 1ull << (v & 63));
+            if (lane == cnt) my_v = v;
+            if (++cnt == 64) {
+                atomicOr(&bm[my_v >> 6], 1ull << (my_v & 63));
+                cnt = 0;
+            }
             if (cand == m) cur.advance();
         }
+        if (lane < cnt) atomicOr(&bm[my_v >> 6], 1ull << (my_v & 63));
         __syncthreads();
         unsigned long long *g = gbm + ((lo - base) >> 6);
         for (uint32_t i = threadIdx.x; i < nbw; i += blockDim.x) {
@@ -377,6 +386,20 @@ __global__ __launch_bounds__(PM_GROUP, PSK_PM_FILL_WGS) void pm_fill_kernel(cons
             for (uint32_t i = threadIdx.x; i < rb * (uint32_t)cols; i += blockDim.x) blk[i] = 0;
             __syncthreads();
             if (b0 > 0) cur.seek(lw, ln, pos, base, spare);   // a tile with more rows than the block holds is streamed once per batch
+            // A word's row = rank of its bitmap word + the set bits below it: two LDS reads, a popcount and the store -- per
+            // iteration they were ~20 wave-uniform instructions behind an LDS round trip (pm_fill: 5.5 G instructions against
+            // pm_mark's 3.6 G for the same stream, PMC r04).  Lane j keeps the j-th word and its ballot instead, and every 64
+            // words the lanes look their rows up side by side.
+            uint32_t my_i = 0;
+            uint64_t my_mask = 0;
+            int cnt = 0;
+            auto flush = [&](int have) __attribute__((always_inline)) {
+                if (lane < have && wave < cols) {
+                    const uint32_t wq = my_i >> 6;
+                    const uint32_t r = rk[wq] - row0 + (uint32_t)__popcll(bm[wq] & ((1ull << (my_i & 63)) - 1ull)) - b0;
+                    if (r < rb) blk[r * (uint32_t)cols + (uint32_t)wave] = my_mask;   // r is unsigned: rows of earlier batches wrap
+                }
+            };
             for (;;) {
                 if (__any(cur.dry())) cur.refill();
                 const W cand = cur.cur <= hi_w ? cur.cur : PmCursor<W>::SENT;
@@ -384,11 +407,11 @@ __global__ __launch_bounds__(PM_GROUP, PSK_PM_FILL_WGS) void pm_fill_kernel(cons
                 if (m == PmCursor<W>::SENT) break;
                 const bool hit = cand == m;
                 const uint64_t mask = __ballot(hit);
-                const uint32_t i = (uint32_t)(m - lo_w);
-                const uint32_t r = rk[i >> 6] - row0 + (uint32_t)__popcll(bm[i >> 6] & ((1ull << (i & 63)) - 1ull)) - b0;
-                if (lane == 0 && r < rb && wave < cols) blk[r * (uint32_t)cols + (uint32_t)wave] = mask;   // r is unsigned: rows of earlier batches wrap
+                if (lane == cnt) { my_i = (uint32_t)(m - lo_w); my_mask = mask; }
+                if (++cnt == 64) { flush(64); cnt = 0; }
                 if (hit) cur.advance();
             }
+            flush(cnt);
             __syncthreads();
             uint64_t *dst = bits + (uint64_t)(row0 + b0) * wpr + (uint64_t)group * PM_COLS;
             if (cols == PM_COLS) {   // a full group: shifts instead of a division by a run-time value per element
