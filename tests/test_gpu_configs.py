@@ -299,3 +299,105 @@ def test_cfg5_full_size_fastq_samples_properties(tmp_path, oracle):
         assert np.array_equal(uw[gpos], gene_words)
         grow = ctx.get_rows(gpos.astype(np.uint64))
         assert (np.unpackbits(grow.view(np.uint8), axis=1, bitorder="little").sum(axis=1) >= carriers).all()
+
+
+def test_cfg3_whole_dataset_on_one_gpu_equals_its_eight_slabs(oracle):
+    """BASELINE config 3 at FULL size on one GPU (r03 ran it as a scratch script): 2,048 x 5 Mbp, k = 16 --
+    10.2 G (word, sample) pairs, 188 M union rows, a 48-GB matrix -- and then the same dataset as the eight ranks of a node
+    would hold it, slab by slab (bounds at the pilot's quantiles, every slab its own count / build / scan with the global
+    Bonferroni denominator).  Size-independent properties: the slab unions are disjoint, ascending, and concatenate to the
+    one-GPU union word for word; the pairs of the slabs add up to the pairs of the whole; the survivors of the eight slab
+    scans, in slab order, are the survivors of the one-GPU scan -- same words, statistic, p, counts, bit for bit."""
+    from phenotypeseeker_amd import dist
+    from phenotypeseeker_amd.engine import PskContext
+    from phenotypeseeker_amd.synth import GenomeSet
+    n, L, k, world = 2048, 5_000_000, 16, 8
+    gs = GenomeSet(n, L, seed=12345)
+    fas = [gs.sample(i)[1] for i in range(n)]          # 10 GB of FASTA in host memory: nine passes over it
+    pheno = np.array([gs.phenotype(i) for i in range(n)], dtype=np.int8)
+
+    def run(ctx, lo, hi, m_global):
+        ctx.begin(k, n, lo, hi)
+        nus = []
+        for s0 in range(0, n, 64):
+            nu, _ = ctx.count_kmers_batch(s0, fas[s0:s0 + 64], 8)
+            nus += nu
+        m = ctx.build_presence()
+        uw = ctx.get_union()
+        assert len(uw) == m and np.all(uw[1:] > uw[:-1])
+        res = None
+        if m_global:
+            c = ctx.chi2_scan(pheno, None, 2, n - 2, 0.05, False, m_global)
+            res = ctx.get_results(c)
+        return nus, uw, res
+
+    with PskContext(0) as ctx:
+        ctx.begin(k, 1)
+        nu0, _ = ctx.count_kmers(0, fas[0])
+        bounds = dist.quantile_bounds(dist.pilot_points(ctx.get_list(0, nu0)[0]), k, world)
+        nus_all, uw_all, _ = run(ctx, 0, 0, 0)
+        m_all = len(uw_all)
+        assert 180_000_000 < m_all < 200_000_000 and ctx.presence_shape()[1] == 32
+        c = ctx.chi2_scan(pheno, None, 2, n - 2, 0.05, False, m_all)
+        res_all = ctx.get_results(c)
+        assert c >= 1000
+        keys = ("word", "stat", "p", "n_with")
+        got = {key: [] for key in keys}
+        pairs = np.zeros(n, dtype=np.int64)
+        off = 0
+        for s in range(world):
+            nus, uw, res = run(ctx, bounds[s], bounds[s + 1], m_all)
+            assert uw[0] >= bounds[s] and (bounds[s + 1] == 0 or uw[-1] < bounds[s + 1] or s == world - 1)
+            assert np.array_equal(uw, uw_all[off:off + len(uw)]), s       # the slab's union IS that stretch of the whole
+            assert abs(len(uw) / m_all - 1.0 / world) < 0.02              # balanced slabs
+            off += len(uw)
+            pairs += np.array(nus, dtype=np.int64)
+            for key in keys:
+                got[key].append(res[key])
+        assert off == m_all and pairs.tolist() == list(nus_all)
+        for key in keys:
+            assert np.array_equal(np.concatenate(got[key]), res_all[key]), key
+
+
+def test_cfg5_thirty_two_full_size_fastq_samples(oracle):
+    """Config 5 with 32 of its 512 samples at full size (the 8-sample test goes through files): 32 x 2 M 150-bp
+    reads, 0.64 GB of FASTQ each, generated and handed over four at a time (20 GB in all never sit in host memory at once).
+    Window counts, ascending lists whose counts add up, column sums of the matrix = list lengths, the scan's survivors
+    equal to the oracle's on a sample of the rows, the gene's k-mers present in every carrier."""
+    from phenotypeseeker_amd.engine import PskContext
+    from phenotypeseeker_amd.synth import GenomeSet
+    n, reads, rl, k = 32, 2_000_000, 150, 13
+    gs = GenomeSet(n, 5_000_000, seed=99)
+    with PskContext(0) as ctx:
+        ctx.begin(k, n)
+        nu, nt = [], []
+        for s0 in range(0, n, 4):
+            batch = [_fastq_sample(gs.codes(i), reads, rl, seed=[5, i]) for i in range(s0, s0 + 4)]
+            a, b = ctx.count_kmers_batch(s0, batch, 8)
+            nu += list(a)
+            nt += list(b)
+            del batch
+        assert nt == [reads * (rl - k + 1)] * n
+        for i in (0, 17, 31):
+            w0, f0 = ctx.get_list(i, nu[i])
+            assert np.all(w0[1:] > w0[:-1]) and int(f0.astype(np.uint64).sum()) == nt[i]
+        m = ctx.build_presence()
+        uw = ctx.get_union()
+        assert m == len(uw) and np.all(uw[1:] > uw[:-1])
+        sums = np.zeros(n, dtype=np.int64)
+        for r0 in range(0, m, 1 << 21):
+            sums += _popcount_columns(ctx.get_rows(np.arange(r0, min(r0 + (1 << 21), m), dtype=np.uint64)), n)
+        assert sums.tolist() == list(nu)
+        pheno = np.array([gs.phenotype(i) for i in range(n)], dtype=np.int8)
+        npass = ctx.chi2_scan(pheno, None, 2, n - 2, 0.05, True, m)
+        res = ctx.get_results(npass)
+        some = ctx.get_rows(np.arange(0, m, 499, dtype=np.uint64))
+        ref = oracle.chi2_scan(some, pheno.tolist(), np.ones(n), n, 2, n - 2, 0.05, True, m)
+        kept = np.nonzero(ref["keep"])[0] * 499
+        assert np.array_equal(np.intersect1d(res["row"].astype(np.int64), np.arange(0, m, 499)), kept)
+        gene_words = np.unique(oracle.count_kmers(b">g\n" + bytes(np.frombuffer(b"ACGT", dtype=np.uint8)[gs.gene]) + b"\n", k)[0])
+        carriers = sum(gs.has_gene(i) for i in range(n))
+        gpos = np.searchsorted(uw, gene_words)
+        assert np.array_equal(uw[gpos], gene_words)
+        grow = ctx.get_rows(gpos.astype(np.uint64))
+        assert (np.unpackbits(grow.view(np.uint8), axis=1, bitorder="little").sum(axis=1) >= carriers).all()
