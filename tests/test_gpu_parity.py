@@ -829,6 +829,52 @@ def test_grid_search_on_large_designs_matches_sklearn_gridsearchcv(ctx, tag):
     assert any(gs.best_params_["C"] == pytest.approx(grid[c]) for c in near), (tag, gs.best_params_["C"], [grid[c] for c in near])
 
 
+def test_solver_form_knobs_are_validated_and_every_one_of_them_runs(ctx, monkeypatch):
+    """the PSK_* variables that pick solver forms are reachable from a user's shell.  Garbage and
+    out-of-range values are refused (PSK_EINVAL with the variable's name) instead of atoi()'s silent zero; every knob at a
+    legal value gives a fit that stops by liblinear's rule with the objective of the default form (1e-3: the forms differ
+    in what the rule leaves open, not in the optimum)."""
+    from phenotypeseeker_amd._lib import PskError
+    rng = np.random.default_rng(5)
+    n, p = 1100, 230
+    base = rng.random((n, 10)) < 0.4
+    X = (base[:, rng.integers(0, 10, p)] ^ (rng.random((n, p)) < 0.06)).astype(np.float32)
+    y = (base[:, 0] ^ (rng.random(n) < 0.1)).astype(np.int32)
+    fold = (np.arange(n) % 3).astype(np.int32)
+    fp, ff = np.array([0.1, 1.0, 1.0]), np.array([-1, 0, 2], np.int32)
+    ypm = 2.0 * y - 1.0
+    ref = ctx.logreg_l1_fit(X, y, fold, fp, ff, tol=1e-6, max_iter=2000)
+    o_ref = _l1_objectives(X, ypm, fold, fp, ff, ref[0], ref[1])
+    for var, bad in (("PSK_GG_MIN_P1", ["abc", "0", "-3", "12x", "99999999"]), ("PSK_FORCE_WMREG", ["8", "48", "sixteen", "16"]),
+                     ("PSK_CG_MAX", ["-1", "1e3", "100000"]), ("PSK_POLISH_REPS", ["many", "999999"]),
+                     ("PSK_GG_POLISH_FROM", ["0", "-4", "5000", " "])):
+        for val in bad:
+            monkeypatch.setenv(var, val)
+            with pytest.raises(PskError) as e:
+                ctx.logreg_l1_fit(X, y, fold, fp, ff, tol=1e-4, max_iter=100)
+            assert e.value.code == -1 and var in str(e.value), (var, val, str(e.value))   # (16 words hold 1,024 samples: fewer than the design's 1,100)
+            monkeypatch.delenv(var)
+    good = [("PSK_GG_MIN_P1", "100"), ("PSK_GG_MIN_P1", "500"), ("PSK_FORCE_WMREG", "32"), ("PSK_FORCE_WMREG", "64"), ("PSK_CG_MAX", "0"),
+            ("PSK_CG_MAX", "4"), ("PSK_CG_MAX", "64"), ("PSK_POLISH_REPS", "0"), ("PSK_POLISH_REPS", "8"), ("PSK_POLISH_REPS", "-32"),
+            ("PSK_GG_POLISH_FROM", "1"), ("PSK_GG_POLISH_FROM", "8"), ("PSK_GG_POLISH_FROM", "1000"), ("PSK_NO_GRAM", "1"),
+            ("PSK_NO_GRAM_GLOBAL", "1"), ("PSK_NO_CD_REGS", "1"), ("PSK_NO_GRAM", "0")]
+    for var, val in good:
+        monkeypatch.setenv(var, val)
+        r = ctx.logreg_l1_fit(X, y, fold, fp, ff, tol=1e-6, max_iter=2000)
+        monkeypatch.delenv(var)
+        assert r[2].max() < 2000, (var, val, r[2])
+        _l1_stop_rule_holds(X, ypm, fold, fp, ff, r[0], r[1], r[2], range(len(fp)), tol=1e-6)
+        assert np.allclose(_l1_objectives(X, ypm, fold, fp, ff, r[0], r[1]), o_ref, rtol=1e-3, atol=0), (var, val)
+    # the Lasso's two: the residual forms walk the covariance form's path (test_lasso_covariance_form_walks_sklearns_path)
+    yc = X[:, :5].astype(np.float64) @ rng.normal(0, 1, 5) + rng.normal(0, 0.3, n)
+    a = ctx.lasso_fit(X, yc, fold, [0.01, 0.1], [-1, 1], tol=1e-4, max_iter=1000)
+    for var in ("PSK_NO_LASSO_COV", "PSK_NO_LASSO_BITS"):
+        monkeypatch.setenv(var, "1")
+        b = ctx.lasso_fit(X, yc, fold, [0.01, 0.1], [-1, 1], tol=1e-4, max_iter=1000)
+        monkeypatch.delenv(var)
+        assert np.array_equal(a[2], b[2]) and np.allclose(a[0], b[0], rtol=1e-7, atol=1e-10), var
+
+
 def _lasso_large():
     z = np.load(os.path.join(GOLDEN, "lasso_large_kat.npz"))
     d = np.load(os.path.join(GOLDEN, "fit2048_907.npz"))
