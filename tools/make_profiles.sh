@@ -5,7 +5,7 @@
 # ingest) two separate --pmc passes (FETCH_SIZE, WRITE_SIZE; no tracing flags with counters).  tools/summarise_profiles.py
 # turns that into the committed files under profiles/.
 set -u
-TAG=${1:-r03}
+TAG=${1:-r04}
 ROOT=${GRAFT_REPO_ROOT:-$PWD}
 OUT=$ROOT/gpurun_out/profiles_$TAG
 mkdir -p "$OUT"
@@ -28,6 +28,7 @@ prof cfg3slab 1 "$ROOT/tools/profile_workloads.py" cfg3slab
 prof moments 0 "$ROOT/tools/profile_workloads.py" moments
 prof fastq 0 "$ROOT/tools/profile_workloads.py" fastq
 prof solver 0 "$ROOT/tools/profile_workloads.py" solver
+prof solver4096 0 "$ROOT/tools/profile_workloads.py" solver4096
 prof predict 0 "$ROOT/tools/profile_workloads.py" predict
 prof weights 0 "$ROOT/tools/profile_workloads.py" weights
 prof lasso 0 "$ROOT/tools/profile_workloads.py" lasso
