@@ -113,7 +113,7 @@ int psk_lookup_counts(psk_ctx *ctx, int sample_idx, const uint64_t *words, uint6
  * modeling.py:350-380) and the per-sample `glistquery ... -l feature_vector.list` + `split`
  * text mapping (Samples.map_samples, modeling.py:317-348).  Result, resident in HBM:
  *   words[M]            ascending canonical words of the union (this slab)
- *   bits[M][wpr]        u64 words, sample i = bit (i & 63) of word (i >> 6), wpr even
+ *   bits[M][wpr]        u64 words, sample i = bit (i & 63) of word (i >> 6); wpr = 1 up to 64 samples, else even
  * n_kmers = M is this slab's share of phenotypes.no_kmers_to_analyse (modeling.py:644).
  */
 int psk_build_presence(psk_ctx *ctx, uint64_t *n_kmers);

@@ -9,6 +9,9 @@
 // consecutive lanes -> consecutive addresses), popcounts its two words against the phenotype
 // masks and the group combines with xor-shuffles.  A wave covers 64/G rows per step and keeps
 // UNROLL steps of loads in flight.  HBM-read bound: 1 bit per k-mer x sample cell; no LDS, no MFMA.
+// Up to 64 samples (r04; the reference's own example set has ~30) a row is ONE u64 (wpr = 1) and a lane's
+// 16-byte load holds two rows: the kernels' G = 0 instantiations ("half a lane per row", 128 rows per wave
+// step); masks and per-sample tables stay padded to a whole 16-byte chunk (cpr = 1).
 //
 // Exactness: the 2x2 table is integer (unit weights), and the statistic is evaluated with the
 // reference's own operation order in IEEE double (this file is compiled with -ffp-contract=off),
@@ -52,7 +55,8 @@ typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
 struct ScanArgs {
     const u32x4 *bits;
     uint64_t M;
-    int cpr;  // 16-byte chunks per row = wpr / 2
+    int cpr;  // 16-byte chunks per row = wpr / 2 (1 when half)
+    int half; // rows are ONE u64 (<= 64 samples): row r sits at byte 8 r; masks / tables as for one chunk
     // chi2
     const uint64_t *m1, *m0;   // phenotype == 1 / == 0 masks (wpr words each)
     const double *tab;         // per-sample table of the lane-per-row pass: [wpr*64][NM] doubles (see row_moments)
@@ -130,6 +134,27 @@ __device__ __forceinline__ double chi2_exact(double A, double B, double C, doubl
 }
 
 
+// ---- rows -----------------------------------------------------------------------------------------
+// G = 0 stands for "half a lane per row" (8-byte rows, two per 16-byte load)
+constexpr int sc_rpw(int G) { return G == 0 ? 128 : 64 / G; }   // rows per wave step
+constexpr int sc_lanes(int G) { return G == 0 ? 1 : G; }        // lanes that share a load group
+template <bool HALF>
+__device__ __forceinline__ const u32x4 *sc_row_ptr(const ScanArgs &P, uint64_t r)
+{
+    if (HALF) return reinterpret_cast<const u32x4 *>(reinterpret_cast<const uint2 *>(P.bits) + r);
+    return P.bits + r * (uint64_t)P.cpr;
+}
+// chunk ch of the row at rp; an 8-byte row is its chunk 0 with an empty upper half
+template <bool HALF>
+__device__ __forceinline__ u32x4 sc_ld_chunk(const u32x4 *__restrict__ rp, int ch)
+{
+    if (HALF) {
+        const uint2 v = *reinterpret_cast<const uint2 *>(rp);
+        return (u32x4){v.x, v.y, 0u, 0u};
+    }
+    return rp[ch];
+}
+
 // ---- lane-per-row moments -----------------------------------------------------------------------
 // Rows that pass the popcount frequency filter need f64 sums over their present samples (class weight
 // sums for the weighted chi2, weighted moments for Welch).  They are queued per wave and handled 64 at a
@@ -146,7 +171,7 @@ __device__ __forceinline__ double chi2_exact(double A, double B, double C, doubl
 // sums: 11.1 ms for 16 M x 1024 with a third of the rows passing.)
 typedef const __attribute__((address_space(4))) double *cdptr;
 // queue entries per wave: < 64 carried over + <= 64 / G appended per step of an unrolled batch
-constexpr int rq_cap(int G, int unroll = SC_UNROLL) { return 64 + (64 / G) * unroll; }
+constexpr int rq_cap(int G, int unroll = SC_UNROLL) { return 64 + (G == 0 ? 128 : 64 / G) * unroll; }
 #ifndef PSK_LUT_UNROLL
 #define PSK_LUT_UNROLL 8
 #endif
@@ -155,21 +180,21 @@ constexpr int rq_cap(int G, int unroll = SC_UNROLL) { return 64 + (64 / G) * unr
 #endif
 // rows in flight per lane group of the table-in-LDS kernels (half the waves per CU of the plain ones); fewer where a
 // wave step covers many rows, so that the waves' queues stay small beside the table
-constexpr int lut_unroll(int G) { return G == 1 ? (PSK_LUT_UNROLL < 4 ? PSK_LUT_UNROLL : 4) : G == 2 ? (PSK_LUT_UNROLL < 8 ? PSK_LUT_UNROLL : 8) : PSK_LUT_UNROLL; }
+constexpr int lut_unroll(int G) { return G == 0 ? (PSK_LUT_UNROLL < 2 ? PSK_LUT_UNROLL : 2) : G == 1 ? (PSK_LUT_UNROLL < 4 ? PSK_LUT_UNROLL : 4) : G == 2 ? (PSK_LUT_UNROLL < 8 ? PSK_LUT_UNROLL : 8) : PSK_LUT_UNROLL; }
 
-template <int NM>
+template <int NM, bool HALF = false>
 __device__ __forceinline__ void row_moments(const u32x4 *__restrict__ rp, int cpr, cdptr tab, double *acc)
 {
     double a0[NM], a1[NM];
 #pragma unroll
     for (int m = 0; m < NM; m++) { a0[m] = 0.0; a1[m] = 0.0; }
-    u32x4 y = rp[0];
+    u32x4 y = sc_ld_chunk<HALF>(rp, 0);
     for (int ch = 0; ch < cpr; ch++) {
         const uint32_t w4[4] = {y.x, y.y, y.z, y.w};
         if (ch + 1 < cpr) y = rp[ch + 1];
         cdptr tp = tab + (size_t)ch * 128 * NM;
 #pragma unroll
-        for (int h = 0; h < 4; h++) {
+        for (int h = 0; h < (HALF ? 2 : 4); h++) {
 #pragma unroll
             for (int b = 0; b < 32; b += 2) {
                 const uint32_t h0 = (uint32_t)(((int32_t)(w4[h] << (31 - b))) >> 31) & 0x3FF00000u;
@@ -217,7 +242,7 @@ __global__ void moment_lut_kernel(const double *__restrict__ tab, int n_groups, 
 // (r02 at first) every chunk paid a global-load latency of its own, and THAT, not the LDS pipe, set the time of the pass
 // (~8 us per 64 rows of 1024 samples against 1.7 us of lookups).
 constexpr int SC_LUT_PF = 8;
-template <int NM>
+template <int NM, bool HALF = false>
 __device__ __forceinline__ void row_moments_lut(const u32x4 *__restrict__ rp, int cpr, const double *lut, double *acc)
 {
     double a0[NM], a1[NM];
@@ -226,7 +251,7 @@ __device__ __forceinline__ void row_moments_lut(const u32x4 *__restrict__ rp, in
     for (int c0 = 0; c0 < cpr; c0 += SC_LUT_PF) {
         u32x4 y[SC_LUT_PF];
 #pragma unroll
-        for (int i = 0; i < SC_LUT_PF; i++) y[i] = c0 + i < cpr ? rp[c0 + i] : (u32x4)(0u);
+        for (int i = 0; i < SC_LUT_PF; i++) y[i] = c0 + i < cpr ? sc_ld_chunk<HALF>(rp, c0 + i) : (u32x4)(0u);
 #pragma unroll
         for (int i = 0; i < SC_LUT_PF; i++) {
             if (c0 + i >= cpr) break;
@@ -237,7 +262,7 @@ __device__ __forceinline__ void row_moments_lut(const u32x4 *__restrict__ rp, in
             const double *lp = lut + (size_t)(c0 + i) * 32 * 16 * (NM == 3 ? 2 : NM);
             const double *lp2 = lut + (size_t)cpr * 32 * 16 * 2 + (size_t)(c0 + i) * 32 * 16;   // NM = 3 only
 #pragma unroll
-            for (int h = 0; h < 4; h++) {
+            for (int h = 0; h < (HALF ? 2 : 4); h++) {
 #pragma unroll
                 for (int k = 0; k < 8; k += 2) {
                     const uint32_t i0 = (h * 8 + k) * 16 + ((w4[h] >> (4 * k)) & 15u), i1 = (h * 8 + k + 1) * 16 + ((w4[h] >> (4 * k + 4)) & 15u);
@@ -302,7 +327,7 @@ __global__ void moment_lut6_kernel(const double *__restrict__ tab, int chunks, f
 typedef float sc_f32x2 __attribute__((ext_vector_type(2)));
 
 // f32 sums of NM moments over the present samples of one row (one row per lane), from the six-bit tables in LDS
-template <int NM>
+template <int NM, bool HALF = false>
 __device__ __forceinline__ void row_moments_f32(const u32x4 *__restrict__ rp, int cpr, const float *lut, double *acc)
 {
     sc_f32x2 a0 = {0.f, 0.f}, a1 = {0.f, 0.f};
@@ -311,7 +336,7 @@ __device__ __forceinline__ void row_moments_f32(const u32x4 *__restrict__ rp, in
     for (int g0 = 0; g0 < cpr; g0 += SC_LUT_PF) {
         u32x4 y[SC_LUT_PF];
 #pragma unroll
-        for (int i = 0; i < SC_LUT_PF; i++) y[i] = g0 + i < cpr ? rp[g0 + i] : (u32x4)(0u);
+        for (int i = 0; i < SC_LUT_PF; i++) y[i] = g0 + i < cpr ? sc_ld_chunk<HALF>(rp, g0 + i) : (u32x4)(0u);
 #pragma unroll
         for (int i = 0; i < SC_LUT_PF; i++) {
             if (g0 + i >= cpr) break;
@@ -319,7 +344,7 @@ __device__ __forceinline__ void row_moments_f32(const u32x4 *__restrict__ rp, in
             const sc_f32x2 *lp = reinterpret_cast<const sc_f32x2 *>(lut) + (size_t)(g0 + i) * SC_L6_ENTRIES;
             const float *lp3 = lut3 + (size_t)(g0 + i) * SC_L6_ENTRIES;
 #pragma unroll
-            for (int j = 0; j < 22; j++) {
+            for (int j = 0; j < (HALF ? 11 : 22); j++) {   // an 8-byte row: samples 0 ... 63 lie in groups 0 ... 10
                 const int o = 6 * j, wi = o >> 5, sh = o & 31;
                 uint32_t idx;
                 if (j == 21) idx = w4[3] >> 30;
@@ -342,15 +367,15 @@ __device__ __forceinline__ void row_moments_f32(const u32x4 *__restrict__ rp, in
 // others per sample.  (Splitting a row that does fit in halves, to keep the LDS pipe and the f64 VALU busy at the same
 // time, did not pay: 16 M x 1024 with a fifth of the rows passing took 0.66 ms against 0.63 ms with the whole row in
 // the table and 0.75 ms per sample, r02.  8 M x 2048, where half the row fits: 0.67 ms against 0.95 ms per sample.)
-template <int NM>
+template <int NM, bool HALF = false>
 __device__ __forceinline__ void row_moments_mixed(const u32x4 *__restrict__ rp, int cpr, int c_lut, const double *lut, cdptr tab,
                                                   double *acc)
 {
     double a[NM], b[NM];
-    row_moments_lut<NM>(rp, c_lut, lut, a);
+    row_moments_lut<NM, HALF>(rp, c_lut, lut, a);
 #pragma unroll
     for (int m = 0; m < NM; m++) b[m] = 0.0;
-    if (c_lut < cpr) row_moments<NM>(rp + c_lut, cpr - c_lut, tab + (size_t)c_lut * 128 * NM, b);
+    if (c_lut < cpr) row_moments<NM, HALF>(rp + c_lut, cpr - c_lut, tab + (size_t)c_lut * 128 * NM, b);   // (half: c_lut is 0 or 1 = cpr)
 #pragma unroll
     for (int m = 0; m < NM; m++) acc[m] = a[m] + b[m];
 }
@@ -402,6 +427,8 @@ template <int G, int MODE, bool LUT = false, bool F32 = false>
 __global__ __launch_bounds__(LUT ? SC_LUT_THREADS : SC_THREADS) void chi2_scan_kernel(const ScanArgs P)
 {
     constexpr bool WEIGHTED = MODE == 1, QUEUED = MODE != 0;
+    constexpr bool HALF = G == 0;          // 8-byte rows, two per load
+    constexpr int GL = sc_lanes(G), NSUB = HALF ? 2 : 1;
     constexpr int THREADS = LUT ? SC_LUT_THREADS : SC_THREADS;
     constexpr int UNR = LUT ? lut_unroll(G) : SC_UNROLL;
     __shared__ uint64_t s_qrow[QUEUED ? THREADS / 64 : 1][QUEUED ? rq_cap(G, UNR) : 1];
@@ -409,10 +436,10 @@ __global__ __launch_bounds__(LUT ? SC_LUT_THREADS : SC_THREADS) void chi2_scan_k
     extern __shared__ __attribute__((aligned(16))) double s_lut[];   // LUT: the nibble table of row_moments_lut / the six-bit f32 table
     if (LUT && F32) load_lut(s_lut, reinterpret_cast<const double *>(P.lut6), (int)(lut6_bytes(P.cpr, 2) / 8), THREADS);
     else if (LUT) load_lut(s_lut, P.lut, P.c_lut * 32 * 16 * 2, THREADS);
-    constexpr int RPW = 64 / G;  // rows per wave step
+    constexpr int RPW = sc_rpw(G);  // rows per wave step
     const int lane = threadIdx.x & 63;
-    const int g = lane & (G - 1);
-    const int rsub = lane / G;
+    const int g = lane & (GL - 1);
+    const int rsub = HALF ? 2 * lane : lane / GL;
     const uint64_t n_steps = (P.M + RPW - 1) / RPW;
     const uint64_t wave_global = (uint64_t)blockIdx.x * (THREADS / 64) + (threadIdx.x >> 6);
     const uint64_t total_waves = (uint64_t)gridDim.x * (THREADS / 64);
@@ -438,7 +465,7 @@ __global__ __launch_bounds__(LUT ? SC_LUT_THREADS : SC_THREADS) void chi2_scan_k
             // f32 class-weight sums (A, C may be off by e0, e1): an UPPER bound of the statistic decides who is a candidate.
             // det = AD - BC = A W0 - C W1 is linear in the two sums; the column totals shrink by the error
             double ws[2];
-            row_moments_f32<2>(P.bits + r * (uint64_t)P.cpr, P.cpr, reinterpret_cast<const float *>(s_lut), ws);
+            row_moments_f32<2, HALF>(sc_row_ptr<HALF>(P, r), P.cpr, reinterpret_cast<const float *>(s_lut), ws);
             const double T = P.W1 + P.W0, err = P.e0 + P.e1;
             const double det = fabs(ws[0] * P.W0 - ws[1] * P.W1) + (P.e0 * P.W0 + P.e1 * P.W1);
             const double K1 = (ws[0] + ws[1]) - err, K0 = (T - (ws[0] + ws[1])) - err;
@@ -451,8 +478,8 @@ __global__ __launch_bounds__(LUT ? SC_LUT_THREADS : SC_THREADS) void chi2_scan_k
             return;
         } else if (WEIGHTED) {
             double ws[2];
-            if (LUT) row_moments_mixed<2>(P.bits + r * (uint64_t)P.cpr, P.cpr, P.c_lut, s_lut, (cdptr)P.tab, ws);
-            else row_moments<2>(P.bits + r * (uint64_t)P.cpr, P.cpr, (cdptr)P.tab, ws);
+            if (LUT) row_moments_mixed<2, HALF>(sc_row_ptr<HALF>(P, r), P.cpr, P.c_lut, s_lut, (cdptr)P.tab, ws);
+            else row_moments<2, HALF>(sc_row_ptr<HALF>(P, r), P.cpr, (cdptr)P.tab, ws);
             A = ws[0]; B = P.W1 - ws[0]; C = ws[1]; D = P.W0 - ws[1];
             const double R1 = A + B, R0 = C + D, K1 = A + C, K0 = B + D, T = R1 + R0;
             const double det = A * D - B * C;
@@ -498,7 +525,11 @@ __global__ __launch_bounds__(LUT ? SC_LUT_THREADS : SC_THREADS) void chi2_scan_k
         for (int u = 0; u < UNR; u++) {
             const uint64_t row = (s0 + u) * RPW + rsub;
             x[u] = (u32x4)(0u);
-            if (row < P.M && has_chunk) {
+            if (HALF) {   // rows `row` and `row + 1` in one 16-byte load (the matrix starts 16-byte aligned and `row` is even)
+                const u32x4 *pp = reinterpret_cast<const u32x4 *>(reinterpret_cast<const uint2 *>(P.bits) + row);
+                if (row + 1 < P.M) x[u] = __builtin_nontemporal_load(pp);
+                else if (row < P.M) { const uint2 v = *reinterpret_cast<const uint2 *>(pp); x[u].x = v.x; x[u].y = v.y; }   // the odd last row
+            } else if (row < P.M && has_chunk) {
 #if PSK_SC_NT
                 if (LUT && !PSK_LUT_NT) x[u] = P.bits[row * (uint64_t)P.cpr + g];
                 else x[u] = __builtin_nontemporal_load(&P.bits[row * (uint64_t)P.cpr + g]);
@@ -508,14 +539,17 @@ __global__ __launch_bounds__(LUT ? SC_LUT_THREADS : SC_THREADS) void chi2_scan_k
             }
         }
 #pragma unroll
-        for (int u = 0; u < UNR; u++) {
-            const uint64_t row = (s0 + u) * RPW + rsub;
-            const uint64_t xa = ((uint64_t)x[u].y << 32) | x[u].x, xb = ((uint64_t)x[u].w << 32) | x[u].z;
-            uint32_t a = __popcll(xa & m1a) + __popcll(xb & m1b);
-            uint32_t c = __popcll(xa & m0a) + __popcll(xb & m0b);
-            if (P.cpr > G) {  // rows wider than 64 chunks (more than 8192 samples)
+        for (int u = 0; u < UNR; u++)
+#pragma unroll
+          for (int sub = 0; sub < NSUB; sub++) {
+            const uint64_t row = (s0 + u) * RPW + rsub + sub;
+            const uint64_t xa = sub ? (((uint64_t)x[u].w << 32) | x[u].z) : (((uint64_t)x[u].y << 32) | x[u].x);
+            const uint64_t xb = HALF ? 0ull : (((uint64_t)x[u].w << 32) | x[u].z);
+            uint32_t a = __popcll(xa & m1a) + (HALF ? 0u : (uint32_t)__popcll(xb & m1b));
+            uint32_t c = __popcll(xa & m0a) + (HALF ? 0u : (uint32_t)__popcll(xb & m0b));
+            if (!HALF && P.cpr > GL) {  // rows wider than 64 chunks (more than 8192 samples)
                 if (row < P.M)
-                    for (int ch = g + G; ch < P.cpr; ch += G) {
+                    for (int ch = g + GL; ch < P.cpr; ch += GL) {
                         const u32x4 y = P.bits[row * (uint64_t)P.cpr + ch];
                         const uint64_t ya = ((uint64_t)y.y << 32) | y.x, yb = ((uint64_t)y.w << 32) | y.z;
                         a += __popcll(ya & P.m1[2 * ch]) + __popcll(yb & P.m1[2 * ch + 1]);
@@ -523,7 +557,7 @@ __global__ __launch_bounds__(LUT ? SC_LUT_THREADS : SC_THREADS) void chi2_scan_k
                     }
             }
 #pragma unroll
-            for (int d = G / 2; d > 0; d >>= 1) {
+            for (int d = GL / 2; d > 0; d >>= 1) {
                 a += __shfl_xor(a, d, 64);
                 c += __shfl_xor(c, d, 64);
             }
@@ -589,7 +623,7 @@ __global__ __launch_bounds__(SC_FIN_THREADS) void chi2w_finalize_kernel(const Sc
         const uint64_t row = valid ? P.res_row[base + i] : 0;
         const int32_t nw = valid ? P.res_nw[base + i] : 0;
         const bool wave_any = __any(valid);
-        const u32x4 *rp = P.bits + row * (uint64_t)P.cpr;
+        const u32x4 *rp = P.half ? sc_row_ptr<true>(P, row) : sc_row_ptr<false>(P, row);
         // the four cells, sample by sample
         double ca = 0.0, cb = 0.0, cc = 0.0, cd = 0.0;
         for (int c0 = 0; c0 < P.cpr; c0 += SC_FIN_BLK) {
@@ -600,7 +634,7 @@ __global__ __launch_bounds__(SC_FIN_THREADS) void chi2w_finalize_kernel(const Sc
             __syncthreads();
             if (!wave_any) continue;
             for (int ch = 0; ch < nc; ch++) {
-                const u32x4 y = rp[c0 + ch];
+                const u32x4 y = P.half ? sc_ld_chunk<true>(rp, 0) : rp[c0 + ch];   // (an 8-byte row: samples 64 ... 127 have zero weights)
                 const uint32_t w4[4] = {y.x, y.y, y.z, y.w};
 #pragma unroll
                 for (int h = 0; h < 4; h++) {
@@ -696,18 +730,20 @@ __device__ __attribute__((noinline)) double dev_t_two_sided_p(double t, double d
 template <int G, bool WT, bool LUT = false, bool F32 = false>
 __global__ __launch_bounds__(LUT ? SC_LUT_THREADS : SC_THREADS) void ttest_scan_kernel(const ScanArgs P, const double mu)
 {
+    constexpr bool HALF = G == 0;          // 8-byte rows, two per load
+    constexpr int GL = sc_lanes(G), NSUB = HALF ? 2 : 1;
     constexpr int THREADS = LUT ? SC_LUT_THREADS : SC_THREADS;
     constexpr int UNR = LUT ? lut_unroll(G) : SC_UNROLL;
     __shared__ uint64_t s_qrow[THREADS / 64][rq_cap(G, UNR)];
     __shared__ int2 s_qval[THREADS / 64][rq_cap(G, UNR)];
-    constexpr int RPW = 64 / G;
+    constexpr int RPW = sc_rpw(G);
     constexpr int NM = WT ? 3 : 2;
     extern __shared__ __attribute__((aligned(16))) double s_lut[];   // LUT: the nibble table of row_moments_lut / the six-bit f32 table
     if (LUT && F32) load_lut(s_lut, reinterpret_cast<const double *>(P.lut6), (int)(lut6_bytes(P.cpr, NM) / 8), THREADS);
     else if (LUT) load_lut(s_lut, P.lut, P.c_lut * 32 * 16 * NM, THREADS);
     const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
-    const int g = lane & (G - 1);
-    const int rsub = lane / G;
+    const int g = lane & (GL - 1);
+    const int rsub = HALF ? 2 * lane : lane / GL;
     const uint64_t n_steps = (P.M + RPW - 1) / RPW;
     const uint64_t wave_global = (uint64_t)blockIdx.x * (THREADS / 64) + wid;
     const uint64_t total_waves = (uint64_t)gridDim.x * (THREADS / 64);
@@ -723,9 +759,9 @@ __global__ __launch_bounds__(LUT ? SC_LUT_THREADS : SC_THREADS) void ttest_scan_
         const uint64_t r = q_row[act ? lane : 0];
         const int r_nw = q_val[act ? lane : 0].x;
         double mo[NM];
-        if (F32) row_moments_f32<NM>(P.bits + r * (uint64_t)P.cpr, P.cpr, reinterpret_cast<const float *>(s_lut), mo);
-        else if (LUT) row_moments_mixed<NM>(P.bits + r * (uint64_t)P.cpr, P.cpr, P.c_lut, s_lut, (cdptr)P.tab, mo);
-        else row_moments<NM>(P.bits + r * (uint64_t)P.cpr, P.cpr, (cdptr)P.tab, mo);
+        if (F32) row_moments_f32<NM, HALF>(sc_row_ptr<HALF>(P, r), P.cpr, reinterpret_cast<const float *>(s_lut), mo);
+        else if (LUT) row_moments_mixed<NM, HALF>(sc_row_ptr<HALF>(P, r), P.cpr, P.c_lut, s_lut, (cdptr)P.tab, mo);
+        else row_moments<NM, HALF>(sc_row_ptr<HALF>(P, r), P.cpr, (cdptr)P.tab, mo);
         if (!act) return;
         const double nx = WT ? mo[0] : (double)r_nw, sx = mo[NM - 2], qx = mo[NM - 1];
         const double ny = P.W1 - nx, sy = P.W0 - sx, qy = P.thr - qx;  // totals: W1 = sum w, W0 = sum w*u, thr = sum w*u^2
@@ -783,22 +819,29 @@ __global__ __launch_bounds__(LUT ? SC_LUT_THREADS : SC_THREADS) void ttest_scan_
         for (int u = 0; u < UNR; u++) {
             const uint64_t row = (s0 + u) * RPW + rsub;
             x[u] = (u32x4)(0u);
-            if (row < P.M && has_chunk)
+            if (HALF) {   // rows `row` and `row + 1` in one 16-byte load
+                const u32x4 *pp = reinterpret_cast<const u32x4 *>(reinterpret_cast<const uint2 *>(P.bits) + row);
+                if (row + 1 < P.M) x[u] = __builtin_nontemporal_load(pp);
+                else if (row < P.M) { const uint2 v = *reinterpret_cast<const uint2 *>(pp); x[u].x = v.x; x[u].y = v.y; }   // the odd last row
+            } else if (row < P.M && has_chunk)
                 x[u] = (LUT && !PSK_LUT_NT) ? P.bits[row * (uint64_t)P.cpr + g] : __builtin_nontemporal_load(&P.bits[row * (uint64_t)P.cpr + g]);
         }
 #pragma unroll
-        for (int u = 0; u < UNR; u++) {
-            const uint64_t row = (s0 + u) * RPW + rsub;
-            const uint64_t xa = ((uint64_t)x[u].y << 32) | x[u].x, xb = ((uint64_t)x[u].w << 32) | x[u].z;
-            uint32_t cnt = __popcll(xa & mva) + __popcll(xb & mvb);
-            if (P.cpr > G && row < P.M)
-                for (int ch = g + G; ch < P.cpr; ch += G) {
+        for (int u = 0; u < UNR; u++)
+#pragma unroll
+          for (int sub = 0; sub < NSUB; sub++) {
+            const uint64_t row = (s0 + u) * RPW + rsub + sub;
+            const uint64_t xa = sub ? (((uint64_t)x[u].w << 32) | x[u].z) : (((uint64_t)x[u].y << 32) | x[u].x);
+            const uint64_t xb = HALF ? 0ull : (((uint64_t)x[u].w << 32) | x[u].z);
+            uint32_t cnt = __popcll(xa & mva) + (HALF ? 0u : (uint32_t)__popcll(xb & mvb));
+            if (!HALF && P.cpr > GL && row < P.M)
+                for (int ch = g + GL; ch < P.cpr; ch += GL) {
                     const u32x4 y = P.bits[row * (uint64_t)P.cpr + ch];
                     cnt += __popcll((((uint64_t)y.y << 32) | y.x) & P.mvalid[2 * ch]) +
                            __popcll((((uint64_t)y.w << 32) | y.z) & P.mvalid[2 * ch + 1]);
                 }
 #pragma unroll
-            for (int d = G / 2; d > 0; d >>= 1) cnt += __shfl_xor(cnt, d, 64);
+            for (int d = GL / 2; d > 0; d >>= 1) cnt += __shfl_xor(cnt, d, 64);
             const int n_w = (int)cnt, n_wo = P.nvalid - (int)cnt;
             const bool freq_ok = (row < P.M) && !(n_w < P.min_samples || n_wo < 2 || n_w > P.max_samples);
             q = queue_rows(freq_ok && g == 0, row, make_int2(n_w, 0), q_row, q_val, q, lane);
@@ -810,6 +853,7 @@ template <int MODE>
 void launch_chi2_mode(int G, dim3 grid, hipStream_t st, const ScanArgs &a)
 {
     switch (G) {
+    case 0: chi2_scan_kernel<0, MODE><<<grid, SC_THREADS, 0, st>>>(a); break;
     case 1: chi2_scan_kernel<1, MODE><<<grid, SC_THREADS, 0, st>>>(a); break;
     case 2: chi2_scan_kernel<2, MODE><<<grid, SC_THREADS, 0, st>>>(a); break;
     case 4: chi2_scan_kernel<4, MODE><<<grid, SC_THREADS, 0, st>>>(a); break;
@@ -846,6 +890,7 @@ void launch_chi2_lut(int G, dim3 grid, hipStream_t st, const ScanArgs &a)
     if (a.lut6) {
         const size_t lds6 = lut6_bytes(a.cpr, 2);
         switch (G) {
+        case 0: launch_lut_kernel(chi2_scan_kernel<0, 1, true, true>, grid, lds6, st, a); break;
         case 1: launch_lut_kernel(chi2_scan_kernel<1, 1, true, true>, grid, lds6, st, a); break;
         case 2: launch_lut_kernel(chi2_scan_kernel<2, 1, true, true>, grid, lds6, st, a); break;
         case 4: launch_lut_kernel(chi2_scan_kernel<4, 1, true, true>, grid, lds6, st, a); break;
@@ -856,6 +901,7 @@ void launch_chi2_lut(int G, dim3 grid, hipStream_t st, const ScanArgs &a)
     }
     const size_t lds = lut_bytes(a.c_lut, 2);
     switch (G) {
+    case 0: launch_lut_kernel(chi2_scan_kernel<0, 1, true>, grid, lds, st, a); break;
     case 1: launch_lut_kernel(chi2_scan_kernel<1, 1, true>, grid, lds, st, a); break;
     case 2: launch_lut_kernel(chi2_scan_kernel<2, 1, true>, grid, lds, st, a); break;
     case 4: launch_lut_kernel(chi2_scan_kernel<4, 1, true>, grid, lds, st, a); break;
@@ -918,7 +964,7 @@ __global__ __launch_bounds__(SC_FIN_THREADS) void ttest_finalize_kernel(const Sc
         const uint64_t row = valid ? P.res_row[base + i] : 0;
         const int32_t nw = valid ? P.res_nw[base + i] : 0;
         const bool wave_any = __any(valid);
-        const u32x4 *rp = P.bits + row * (uint64_t)P.cpr;
+        const u32x4 *rp = P.half ? sc_row_ptr<true>(P, row) : sc_row_ptr<false>(P, row);
         // One lane walks its candidate's 2 x n_samples dependent additions (rocprof, r03: 82 us at 1,024 samples whatever the
         // number of candidates).  A weight times 1.0 or 0.0 is exact, so fma(present ? 1 : 0, term, acc) IS the conditional
         // addition; the product w v comes out of the staged table, and with unit weights the two weight sums are the counts
@@ -943,7 +989,7 @@ __global__ __launch_bounds__(SC_FIN_THREADS) void ttest_finalize_kernel(const Sc
                 if (!wave_any) continue;
                 // the row's chunks are requested two ahead: read where they are used, every 16-byte chunk cost this lone
                 // lane a whole memory latency (16 of them per candidate at 1,024 samples: half of the kernel's 82 us)
-                u32x4 y0 = rp[c0], y1 = nc > 1 ? rp[c0 + 1] : (u32x4)(0u);
+                u32x4 y0 = P.half ? sc_ld_chunk<true>(rp, 0) : rp[c0], y1 = nc > 1 ? rp[c0 + 1] : (u32x4)(0u);   // (an 8-byte row: the table's samples 64 ... 127 are {0, 0})
                 for (int ch = 0; ch < nc; ch++) {
                     const u32x4 y = y0;
                     y0 = y1;
@@ -1006,6 +1052,7 @@ template <bool WT>
 void launch_ttest_w(int G, dim3 grid, hipStream_t st, const ScanArgs &a, double mu)
 {
     switch (G) {
+    case 0: ttest_scan_kernel<0, WT><<<grid, SC_THREADS, 0, st>>>(a, mu); break;
     case 1: ttest_scan_kernel<1, WT><<<grid, SC_THREADS, 0, st>>>(a, mu); break;
     case 2: ttest_scan_kernel<2, WT><<<grid, SC_THREADS, 0, st>>>(a, mu); break;
     case 4: ttest_scan_kernel<4, WT><<<grid, SC_THREADS, 0, st>>>(a, mu); break;
@@ -1029,6 +1076,7 @@ void launch_ttest_lut(int G, dim3 grid, hipStream_t st, const ScanArgs &a, doubl
     if (a.lut6) {
         const size_t lds6 = lut6_bytes(a.cpr, WT ? 3 : 2);
         switch (G) {
+        case 0: launch_lut_ttest(ttest_scan_kernel<0, WT, true, true>, grid, lds6, st, a, mu); break;
         case 1: launch_lut_ttest(ttest_scan_kernel<1, WT, true, true>, grid, lds6, st, a, mu); break;
         case 2: launch_lut_ttest(ttest_scan_kernel<2, WT, true, true>, grid, lds6, st, a, mu); break;
         case 4: launch_lut_ttest(ttest_scan_kernel<4, WT, true, true>, grid, lds6, st, a, mu); break;
@@ -1039,6 +1087,7 @@ void launch_ttest_lut(int G, dim3 grid, hipStream_t st, const ScanArgs &a, doubl
     }
     const size_t lds = lut_bytes(a.c_lut, WT ? 3 : 2);
     switch (G) {
+    case 0: launch_lut_ttest(ttest_scan_kernel<0, WT, true>, grid, lds, st, a, mu); break;
     case 1: launch_lut_ttest(ttest_scan_kernel<1, WT, true>, grid, lds, st, a, mu); break;
     case 2: launch_lut_ttest(ttest_scan_kernel<2, WT, true>, grid, lds, st, a, mu); break;
     case 4: launch_lut_ttest(ttest_scan_kernel<4, WT, true>, grid, lds, st, a, mu); break;
@@ -1088,10 +1137,15 @@ int build_moment_lut6(psk_ctx *ctx, const double *tab, int cpr, int nm, const fl
 // row_moments_f32 may be off by, relative to the sum of the absolute values of ALL the terms of the table
 double lut6_gamma(int cpr) { return ((double)(cpr * 22) / 2.0 + 8.0) * 5.9604644775390625e-08 * 1.01; }
 
-int group_lanes(int cpr)
+// u64 words of a phenotype mask / 64-sample blocks of a per-sample table: the row's words rounded up to a whole chunk
+int mask_words(const psk_ctx *ctx) { return (ctx->wpr + 1) & ~1; }
+
+// lanes that own one row; 0 = half a lane (8-byte rows: chi2_scan_kernel's G = 0)
+int group_lanes(const ScanArgs &a)
 {
+    if (a.half) return 0;
     int G = 1;
-    while (G < cpr && G < 64) G <<= 1;
+    while (G < a.cpr && G < 64) G <<= 1;
     return G;
 }
 
@@ -1099,7 +1153,7 @@ int group_lanes(int cpr)
 // SC_NSEG * seg_cap entries; seg_cap bounds the rows the blocks of one segment can visit
 int setup_results(psk_ctx *ctx, ScanArgs &a, dim3 grid, int G, int unroll, int set, int threads = SC_THREADS)
 {
-    const uint64_t rpw = 64 / G;
+    const uint64_t rpw = sc_rpw(G);
     const uint64_t n_steps = (a.M + rpw - 1) / rpw;
     const uint64_t total_waves = (uint64_t)grid.x * (threads / 64);
     const uint64_t iters = (n_steps + total_waves * unroll - 1) / (total_waves * unroll);
@@ -1178,7 +1232,7 @@ dim3 scan_grid(const psk_ctx *ctx, uint64_t M, int G, int unroll, bool lut = fal
     // the table-in-LDS form: one 1024-thread workgroup per CU (its 64-120 KB of LDS admit no second one), and one
     // per result segment at least
     if (lut) return dim3((unsigned)std::max(SC_NSEG, ctx->n_cu > 0 ? ctx->n_cu : 256));
-    const uint64_t rpw = 64 / G;
+    const uint64_t rpw = sc_rpw(G);
     const uint64_t steps = (M + rpw - 1) / rpw;
     const uint64_t waves = (steps + unroll - 1) / unroll;
     uint64_t blocks = (waves + SC_THREADS / 64 - 1) / (SC_THREADS / 64);
@@ -1214,7 +1268,7 @@ int pick_result_set(psk_ctx *ctx, int *set_out, bool keep_results = false)
 
 int run_chi2(psk_ctx *ctx, ScanArgs &a, bool weighted, int reps, double *ms_total)
 {
-    const int G = group_lanes(a.cpr);
+    const int G = group_lanes(a);
     const dim3 grid = scan_grid(ctx, a.M, G, SC_UNROLL, a.lut != nullptr || a.lut6 != nullptr);
     *ms_total = 0;
     for (int r = 0; r < reps; r++) {
@@ -1238,10 +1292,12 @@ static int fill_chi2_args(psk_ctx *ctx, ScanArgs &a, int set)
     a = ScanArgs();
     a.bits = reinterpret_cast<const u32x4 *>(ctx->bits.p);
     a.M = ctx->n_kmers;
-    a.cpr = ctx->wpr / 2;
+    const int mw = mask_words(ctx);
+    a.cpr = mw / 2;
+    a.half = ctx->wpr == 1;
     a.m1 = ctx->mask1.as<uint64_t>();
-    a.m0 = a.m1 + ctx->wpr;
-    a.tab = reinterpret_cast<const double *>(a.m1 + 2 * (size_t)ctx->wpr);  // [sample][w if pheno 1 | w if pheno 0]
+    a.m0 = a.m1 + mw;
+    a.tab = reinterpret_cast<const double *>(a.m1 + 2 * (size_t)mw);  // [sample][w if pheno 1 | w if pheno 0]
     a.inline_masks = L.inline_masks;
     if (L.inline_masks) { memcpy(a.m1_inl, L.m1, sizeof(a.m1_inl)); memcpy(a.m0_inl, L.m0, sizeof(a.m0_inl)); }
     a.min_samples = L.min_samples;
@@ -1254,7 +1310,7 @@ static int fill_chi2_args(psk_ctx *ctx, ScanArgs &a, int set)
     if (pmax >= 1.0) a.thr = 0.0;
     else if (pmax <= 0.0) a.thr = INFINITY;
     else a.thr = -2.0 * log(pmax);
-    const int G = group_lanes(a.cpr);
+    const int G = group_lanes(a);
     a.lut6 = (L.weighted && ctx->lut6_valid) ? ctx->lut.as<float>() : nullptr;
     a.lut = (L.weighted && ctx->lut_valid && !a.lut6) ? ctx->lut.as<double>() : nullptr;
     a.c_lut = a.lut ? lut_chunks(a.cpr, 2) : 0;
@@ -1279,7 +1335,7 @@ static int chi2_scan_launch(psk_ctx *ctx, const int8_t *pheno, const double *wei
     if (!pheno) return psk_fail(ctx, PSK_EINVAL, "null phenotype vector");
     if (n_kmers_global == 0) n_kmers_global = ctx->n_kmers ? ctx->n_kmers : 1;
     PSK_HIP(ctx, hipSetDevice(ctx->device));
-    const int N = ctx->n_samples, wpr = ctx->wpr;
+    const int N = ctx->n_samples, wpr = mask_words(ctx);   // masks and tables: whole 16-byte chunks, also for 8-byte rows
     // one pinned staging block [m1 | m0 | w1 | w0] and ONE stream-ordered upload (weights only when given)
     const size_t n_mask = 2 * (size_t)wpr, n_w = 2 * (size_t)wpr * 64;
     const size_t stage_bytes = (n_mask + n_w) * 8;
@@ -1342,7 +1398,7 @@ static int chi2_scan_launch(psk_ctx *ctx, const int8_t *pheno, const double *wei
     ctx->last_scan_kind = 1;
     if (ctx->n_kmers) {
         ScanSlot &sl = ctx->slot[set];
-        const int G = group_lanes(a.cpr);
+        const int G = group_lanes(a);
         const dim3 grid = scan_grid(ctx, a.M, G, SC_UNROLL, a.lut != nullptr || a.lut6 != nullptr);
         PSK_HIP(ctx, hipEventRecord(sl.ev0, ctx->stream));
         launch_chi2(pick_chi2_mode(ctx, ctx->last.weighted, a.pcut, a.pcut_bonf, a.omit_B), G, grid, ctx->stream, a);
@@ -1428,7 +1484,7 @@ extern "C" int psk_ttest_scan(psk_ctx *ctx, const double *pheno, const uint8_t *
     if (!pheno || !valid) return psk_fail(ctx, PSK_EINVAL, "null phenotype vector");
     if (n_kmers_global == 0) n_kmers_global = ctx->n_kmers ? ctx->n_kmers : 1;
     PSK_HIP(ctx, hipSetDevice(ctx->device));
-    const int N = ctx->n_samples, wpr = ctx->wpr;
+    const int N = ctx->n_samples, wpr = mask_words(ctx);   // masks and tables: whole 16-byte chunks, also for 8-byte rows
     std::vector<uint64_t> mv(wpr, 0);
     bool unit_w = true;
     for (int i = 0; weights && i < N; i++) if (valid[i] && weights[i] != 1.0) unit_w = false;
@@ -1475,6 +1531,7 @@ extern "C" int psk_ttest_scan(psk_ctx *ctx, const double *pheno, const uint8_t *
     a.bits = reinterpret_cast<const u32x4 *>(ctx->bits.p);
     a.M = ctx->n_kmers;
     a.cpr = wpr / 2;
+    a.half = ctx->wpr == 1;
     a.mvalid = ctx->mask1.as<uint64_t>();
     a.tab = ctx->phe.as<double>();
     a.raw = a.tab + raw_off;
@@ -1498,7 +1555,7 @@ extern "C" int psk_ttest_scan(psk_ctx *ctx, const double *pheno, const uint8_t *
     }
     int set = 0;
     PSK_TRY(pick_result_set(ctx, &set));
-    const int G = group_lanes(a.cpr);
+    const int G = group_lanes(a);
     ctx->lut_valid = false;   // the table buffer is shared with the weighted chi2 scan
     ctx->lut6_valid = false;
     a.eref = 4.0 * (double)N * 1.1102230246251565e-16 * max_abs_v * scale;   // in the kernel's (shifted, scaled) units

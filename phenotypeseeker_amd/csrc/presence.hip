@@ -200,7 +200,8 @@ int build_presence_merge(psk_ctx *ctx, uint64_t total_pairs, uint64_t *n_kmers, 
 static int padded_wpr(int n_samples)
 {
     int w = (n_samples + 63) / 64;
-    return (w + 1) & ~1;  // even: rows are 16-byte aligned
+    if (w == 1) return 1;  // up to 64 samples: 8-byte rows, two per 16-byte load of the scans (assoc_scan.hip, G = 0)
+    return (w + 1) & ~1;   // even: rows are 16-byte aligned
 }
 
 extern "C" int psk_build_presence(psk_ctx *ctx, uint64_t *n_kmers)

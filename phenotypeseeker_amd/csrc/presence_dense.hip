@@ -104,7 +104,7 @@ __global__ __launch_bounds__(PD_THREADS) void pd_transpose_kernel(const uint64_t
             tile[sl * PD_ROWLEN + 2 * pr + 1] = v.y;
         }
         __syncthreads();
-        const int words_here = (wpr - gq * 4) < 4 ? (wpr - gq * 4) : 4;   // 2 or 4: wpr is even
+        const int words_here = (wpr - gq * 4) < 4 ? (wpr - gq * 4) : 4;   // 2 or 4: wpr is even -- or 1 (up to 64 samples)
 #pragma unroll
         for (int xi = 0; xi < PD_CHUNK / 4; xi++) {
             const int xw = wid * (PD_CHUNK / 4) + xi;
@@ -119,7 +119,8 @@ __global__ __launch_bounds__(PD_THREADS) void pd_transpose_kernel(const uint64_t
             if ((o >> lane) & 1ull) {
                 const uint64_t r = (uint64_t)s_off[xw] + (uint32_t)__popcll(o & psk_lanemask_lt(lane));
                 uint64_t *dst = bits + r * (uint64_t)wpr + gq * 4;
-                *reinterpret_cast<ulonglong2 *>(dst) = make_ulonglong2(b[0], b[1]);
+                if (words_here == 1) *dst = b[0];
+                else *reinterpret_cast<ulonglong2 *>(dst) = make_ulonglong2(b[0], b[1]);
                 if (words_here == 4) *reinterpret_cast<ulonglong2 *>(dst + 2) = make_ulonglong2(b[2], b[3]);
                 if (gq == 0) union_words[r] = word0 + (x0 + xw) * 64 + lane;
             }

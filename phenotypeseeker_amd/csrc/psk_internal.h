@@ -155,7 +155,7 @@ struct psk_ctx {
 
     // presence matrix
     uint64_t n_kmers = 0;
-    int wpr = 0;  // u64 words per row (even)
+    int wpr = 0;  // u64 words per row: 1 up to 64 samples, else even
     DevBuf union_words, bits;
     bool have_presence = false;
 

@@ -9,8 +9,9 @@ from ._lib import PskError
 
 
 def words_per_row(n_samples):
-    """u64 words per presence row: ceil(n/64) rounded up to even (rows are 16-byte aligned)."""
-    return (((n_samples + 63) // 64) + 1) & ~1
+    """u64 words per presence row: 1 up to 64 samples, else ceil(n/64) rounded up to even (rows are 16-byte aligned)."""
+    w = (n_samples + 63) // 64
+    return 1 if w <= 1 else (w + 1) & ~1
 
 
 def _ptr(a):

@@ -24,7 +24,7 @@ def slab_result(ds, lo, hi, m_global):
         w = O.count_kmers(ds["files"][nm], k)[0]
         wl.append(w[(w >= lo) & ((w < hi) if hi else np.ones(len(w), bool))])
     uw = O.union(wl)
-    bits = O.presence_bits(wl, uw, wpr=(((n + 63) // 64) + 1) & ~1)
+    bits = O.presence_bits(wl, uw)
     if m_global is None:
         return len(uw), None, None
     res = O.chi2_scan(bits, ds["pheno"], np.ones(n), n, 2, n - 2, 0.05, True, m_global)

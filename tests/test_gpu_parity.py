@@ -203,6 +203,65 @@ def test_chi2_scan_vs_oracle(ctx, oracle, n, weighted):
         assert [oracle.round2(x) for x in res["stat"]] == [oracle.round2(x) for x in ref["stat"][keep]]
 
 
+@pytest.mark.parametrize("n,m", [(3, 1), (5, 2), (30, 4097), (31, 127), (64, 6001), (64, 128 * 4 * 3 + 1), (33, 70_001)])
+def test_eight_byte_rows_every_scan_form(ctx, oracle, n, m):
+    """r04: up to 64 samples a row of the matrix is ONE u64 and a lane's 16-byte load holds two rows (the scans' G = 0
+    instantiations).  Odd row counts (the last load is half a load), a single row, row counts around a whole number of wave
+    steps; unit-weight chi2 in both of its forms, weighted chi2 and both Welch scans through every table form."""
+    from phenotypeseeker_amd.engine import words_per_row
+    assert words_per_row(n) == 1
+    rng = np.random.default_rng(n * 1000 + m)
+    bits = _random_matrix(rng, m, n, 1)
+    base = rng.normal(0.0, 1.0, n)
+    for r in range(0, m, 3):
+        row = base + rng.normal(0, rng.uniform(0.3, 2.0), n) > rng.uniform(-0.5, 0.8)
+        bits[r, 0] = np.uint64(sum(1 << int(i) for i in np.nonzero(row)[0]))
+    bits[m - 1, 0] = np.uint64(sum(1 << int(i) for i in np.nonzero(base > 0)[0]))   # the last row is a hit
+    ctx.set_presence(bits, n)
+    assert ctx.presence_shape()[1] == 1
+    assert np.array_equal(ctx.get_rows(np.arange(m, dtype=np.uint64)), bits)
+    valid = rng.random(n) > 0.05
+    valid[:2] = True
+    ph01 = [(int(b > 0) if ok else "NA") for b, ok in zip(base, valid)]
+    ph8 = np.array([(-1 if p == "NA" else p) for p in ph01], dtype=np.int8)
+    vals = np.round(3.0 + 1.5 * base, 4)
+    pheno = [float(v) if ok else "NA" for v, ok in zip(vals, valid)]
+    weights = np.round(rng.uniform(0.2, 3.0, n), 6)
+    saved = {k_: os.environ.get(k_) for k_ in ("PSK_CHI2_MODE", "PSK_NO_LUT", "PSK_LUT_F64")}
+    try:
+        for env in ({}, {"PSK_CHI2_MODE": "0"}, {"PSK_CHI2_MODE": "2"}, {"PSK_NO_LUT": "1"}, {"PSK_LUT_F64": "1"}):
+            for k_ in saved:
+                os.environ.pop(k_, None)
+            os.environ.update(env)
+            for w in (None, weights):
+                for cut, omit, nk in ((0.05, True, m), (0.05, False, m), (1.5, True, 10)):
+                    ref = oracle.chi2_scan(bits, ph01, w if w is not None else np.ones(n), n, 1, n, cut, omit, nk)
+                    npass = ctx.chi2_scan(ph8, w, 1, n, cut, omit, nk)
+                    res = ctx.get_results(npass)
+                    keep = np.nonzero(ref["keep"])[0]
+                    assert np.array_equal(res["row"], keep.astype(np.uint64)), (env, cut, omit)
+                    assert np.array_equal(res["n_with"], ref["n_with"][keep])
+                    if w is not None:
+                        assert np.array_equal(res["stat"], ref["stat"][keep])
+                    assert np.allclose(res["stat"], ref["stat"][keep], rtol=CHI2_RTOL, atol=0)
+                    assert [oracle.pstring(x) for x in res["p"]] == [oracle.pstring(x) for x in ref["p"][keep]]
+                if n < 6:
+                    continue
+                for cut, nk in ((0.05, 1), (0.9, 1), (0.05, m)):
+                    ref = oracle.ttest_scan(bits, pheno, w if w is not None else np.ones(n), n, 2, n - 2, cut, nk)
+                    npass = ctx.ttest_scan(vals, valid, w, 2, n - 2, cut, nk)
+                    res = ctx.get_results(npass)
+                    keep = np.nonzero(ref["keep"])[0]
+                    assert np.array_equal(res["row"], keep.astype(np.uint64)), (env, cut, nk)
+                    assert np.array_equal(res["stat"], ref["stat"][keep])
+                    assert np.array_equal(res["mean_x"], ref["mean_x"][keep]) and np.array_equal(res["mean_y"], ref["mean_y"][keep])
+    finally:
+        for k_, v in saved.items():
+            os.environ.pop(k_, None)
+            if v is not None:
+                os.environ[k_] = v
+
+
 @pytest.mark.parametrize("n", [12, 64, 100, 256, 1024, 2048, 9000])
 @pytest.mark.parametrize("weighted", [False, True])
 def test_ttest_scan_vs_oracle(ctx, oracle, n, weighted):

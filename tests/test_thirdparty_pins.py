@@ -31,7 +31,7 @@ def check_welch(d, oracle):
     for c in d["cases"]:
         x, y, xw, yw = (np.array(c[k_], dtype=np.float64) for k_ in ("x", "y", "xw", "yw"))
         n = len(x) + len(y)
-        wpr = (((n + 63) // 64) + 1) & ~1
+        wpr = (n + 63) // 64
         bits = np.zeros((1, wpr), dtype=np.uint64)
         for i in range(len(x)):
             bits[0, i >> 6] |= np.uint64(1) << np.uint64(i & 63)
@@ -84,7 +84,7 @@ def test_pin_plumbing_on_self_generated_files(tmp_path, oracle):
     cases = []
     for x, y, xw, yw in pin.welch_cases():
         n = len(x) + len(y)
-        wpr = (((n + 63) // 64) + 1) & ~1
+        wpr = (n + 63) // 64
         bits = np.zeros((1, wpr), dtype=np.uint64)
         for i in range(len(x)):
             bits[0, i >> 6] |= np.uint64(1) << np.uint64(i & 63)
