@@ -248,3 +248,41 @@ def test_gpu_neighbour_joining_on_many_workgroups_equals_the_one_workgroup_kerne
                     assert np.array_equal(np.asarray(u), np.asarray(v)), (n, ties)
                 if n >= 1024:
                     assert t_grid < t_one, (n, t_grid, t_one)
+
+
+@pytest.mark.gpu
+def test_gpu_neighbour_joining_in_lds_equals_the_one_workgroup_kernel(monkeypatch):
+    """r04: nj_lds_kernel (a workgroup per C = 64 ... 8 columns of the matrix, the slices resident in LDS for the whole tree,
+    joined-away rows as rows of -0.0, exchanges that carry the join number in every word; what psk_nj_merges runs from 288 to
+    2,048 leaves) against nj_kernel (PSK_NJ_ONE_WG=1): pairs, both branch lengths and the last distance bit for bit -- at
+    sizes around every slice width (64 / 32 / 16 / 8 columns: up to 256 / 512 / 1,024 / 2,048 leaves), with ties everywhere
+    and without, forced below its threshold for the smallest trees -- and several times faster where it is the default."""
+    import time
+    from phenotypeseeker_amd.engine import PskContext
+    rng = np.random.default_rng(99)
+    monkeypatch.setenv("PSK_NJ_LDS_MIN", "3")
+    monkeypatch.setenv("PSK_TRACE", "1")
+    with PskContext(0) as ctx:
+        for n in (3, 4, 5, 17, 63, 64, 65, 129, 256, 257, 300, 512, 513, 777, 1024, 1025, 1500, 2048):
+            for ties in (False, True):
+                if ties:
+                    half = rng.choice([0.0, 0.001, 0.002, 0.0153, 1.0], (n, n))
+                else:
+                    half = np.round(rng.random((n, n)) * 0.1, 6)
+                mat = np.tril(half, -1)
+                mat = mat + mat.T
+                a = ctx.nj_merges(mat)      # (the first call of a size also grows the context's buffers)
+                t0 = time.time()
+                a2 = ctx.nj_merges(mat)
+                t_lds = time.time() - t0
+                monkeypatch.setenv("PSK_NJ_ONE_WG", "1")
+                t0 = time.time()
+                b = ctx.nj_merges(mat)
+                t_one = time.time() - t0
+                monkeypatch.delenv("PSK_NJ_ONE_WG")
+                for u, v, u2 in zip(a, b, a2):
+                    assert np.array_equal(np.asarray(u), np.asarray(v)), (n, ties)
+                    assert np.array_equal(np.asarray(u2), np.asarray(v)), (n, ties)
+                print("nj %d leaves%s: lds %.1f ms, one workgroup %.1f ms" % (n, " (ties)" if ties else "", 1e3 * t_lds, 1e3 * t_one))
+                if n >= 1024:
+                    assert 3 * t_lds < t_one, (n, t_lds, t_one)
