@@ -29,7 +29,10 @@
 
 namespace {
 
-constexpr int PM_GROUP = 1024;          // samples per workgroup: 16 waves x 64 lanes
+#ifndef PSK_PM_GROUP
+#define PSK_PM_GROUP 1024
+#endif
+constexpr int PM_GROUP = PSK_PM_GROUP;  // samples per workgroup: 16 waves x 64 lanes
 constexpr int PM_COLS = PM_GROUP / 64;  // u64 columns of a row one group writes
 constexpr uint32_t PM_BMW = 2048;       // most bitmap words (64 word values each) a tile may span: 16 KB + 8 KB of ranks
 constexpr uint64_t PM_SENT = ~0ull;     // "no word" in the pilot: beyond any canonical word
@@ -267,12 +270,29 @@ __device__ __forceinline__ uint32_t pm_lower_bound(const uint64_t *w, uint32_t n
 }
 
 // pass 1: the word values that occur, per tile in LDS, then into the global occupancy bitmap
+// r04: the pass also leaves what its waves found -- (word, ballot) of every iteration, 64 at a time, lane j the j-th -- as
+// RECORDS in chunks of a pool (PmRec): pass 2 then does not merge the lists again, it replays the records (pm_replay_kernel:
+// a wave per chunk, lane j looks up the row of its word and stores its ballot).  A chunk is claimed with one returning
+// atomic, asked for a chunk ahead (its latency is 64 iterations old when the id is needed).  The pool holds a twelfth of
+// the pairs; a data set whose samples share too little for that (iterations ~ pairs) overflows it, the flag is set, the
+// bitmap is complete all the same and the build takes the merging pass 2 (pm_fill_kernel) as before.
+constexpr int PM_REC_REGIONS = 16;   // the pool is cut into regions with a counter each (ONE counter serialises: ~11 ns per
+constexpr int PM_REC_BLOCK = 8;      // returning atomic, 1 M claims = 11 ms -- pm_mark 4.7 -> 13 ms); a claim is 8 chunks
+constexpr int PM_REC_CTR_STRIDE = 32;   // u32 between two counters: a 128-byte line each
+struct PmRec {
+    uint32_t *ctr;          // [PM_REC_CTR_STRIDE r] chunks claimed in region r; [PM_REC_CTR_STRIDE PM_REC_REGIONS] overflow
+    uint2 *hdr;             // per chunk {column (wave of 64 samples), records}; zeroed before the launch
+    void *words;            // W[64] per chunk
+    unsigned long long *masks;   // u64[64] per chunk
+    uint32_t region_chunks; // chunks per region; 0: no records
+};
+
 template <typename W>
 __global__ __launch_bounds__(PM_GROUP) void pm_mark_kernel(const PmList *__restrict__ lists, int n_samples,
                                                            const uint64_t *__restrict__ bounds, uint32_t n_tiles,
                                                            uint32_t tiles_per_range, uint64_t base,
                                                            unsigned long long *__restrict__ gbm, int single_group,
-                                                           const uint64_t *__restrict__ spare)
+                                                           const uint64_t *__restrict__ spare, const PmRec rec)
 {
     __shared__ unsigned long long bm[PM_BMW];
     extern __shared__ __attribute__((aligned(16))) unsigned long long pm_ring_lds[];   // (32-bit words) the lanes' windows
@@ -288,6 +308,33 @@ __global__ __launch_bounds__(PM_GROUP) void pm_mark_kernel(const PmList *__restr
     } else {
         cur.seek(nullptr, 0, 0, base, spare);
     }
+    // records: lane j keeps the j-th (word, ballot) since the last chunk went out; they run on across the tiles
+    const bool recs = rec.region_chunks != 0;
+    const uint32_t col = (uint32_t)(s >> 6);
+    W rec_m = 0;
+    uint64_t rec_mask = 0;
+    int rcnt = 0;
+    // the chunk being filled = ch_cur (region-relative; a claim is PM_REC_BLOCK chunks); lane 0 holds the next claim, asked for
+    // when this one was begun (not waited for until it is needed)
+    const uint32_t region = (blockIdx.x + blockIdx.y) % PM_REC_REGIONS;
+    uint32_t *my_ctr = rec.ctr + region * PM_REC_CTR_STRIDE;
+    const size_t region0 = (size_t)region * rec.region_chunks;
+    uint32_t ch_cur = 0, ch_ahead = 0;
+    if (recs) {
+        if (lane == 0) ch_cur = atomicAdd(my_ctr, (uint32_t)PM_REC_BLOCK);
+        ch_cur = (uint32_t)__builtin_amdgcn_readfirstlane((int)ch_cur);
+        if (lane == 0) ch_ahead = atomicAdd(my_ctr, (uint32_t)PM_REC_BLOCK);
+    }
+    auto rec_flush = [&](int have) __attribute__((always_inline)) {
+        if (ch_cur < rec.region_chunks) {
+            const size_t ch = region0 + ch_cur;
+            if (lane < have) {
+                reinterpret_cast<W *>(rec.words)[ch * 64 + lane] = rec_m;
+                rec.masks[ch * 64 + lane] = rec_mask;
+            }
+            if (lane == 0) rec.hdr[ch] = make_uint2(col, (uint32_t)have);
+        } else if (lane == 0 && have) rec.ctr[PM_REC_REGIONS * PM_REC_CTR_STRIDE] = 1u;   // the region is full: pass 2 merges again
+    };
     for (uint32_t t = t0; t < t1; t++) {
         const uint64_t lo = bounds[t], hi = bounds[t + 1];
         const W lo_w = (W)(lo - base), hi_w = (W)(hi - base - 1);   // inclusive upper end: hi - base may be 2^32
@@ -304,12 +351,25 @@ __global__ __launch_bounds__(PM_GROUP) void pm_mark_kernel(const PmList *__restr
             const W m = pm_wave_min_guess(cand);
             if (m == PmCursor<W>::SENT) break;
             const uint32_t v = (uint32_t)(m - lo_w);
+            const bool hit = cand == m;
             if (lane == cnt) my_v = v;
             if (++cnt == 64) {
                 atomicOr(&bm[my_v >> 6], 1ull << (my_v & 63));
                 cnt = 0;
             }
-            if (cand == m) cur.advance();
+            if (recs) {
+                const uint64_t mask = __ballot(hit);
+                if (lane == rcnt) { rec_m = m; rec_mask = mask; }
+                if (++rcnt == 64) {
+                    rec_flush(64);
+                    rcnt = 0;
+                    if ((++ch_cur & (PM_REC_BLOCK - 1)) == 0) {   // (claims are multiples of PM_REC_BLOCK)
+                        ch_cur = (uint32_t)__builtin_amdgcn_readfirstlane((int)ch_ahead);
+                        if (lane == 0) ch_ahead = atomicAdd(my_ctr, (uint32_t)PM_REC_BLOCK);
+                    }
+                }
+            }
+            if (hit) cur.advance();
         }
         if (lane < cnt) atomicOr(&bm[my_v >> 6], 1ull << (my_v & 63));
         __syncthreads();
@@ -320,6 +380,41 @@ __global__ __launch_bounds__(PM_GROUP) void pm_mark_kernel(const PmList *__restr
             else if (v) atomicOr(&g[i], v);
         }
         __syncthreads();
+    }
+    if (recs) rec_flush(rcnt);   // (the chunk claimed ahead stays empty: its header is zero)
+}
+
+// pass 2 from the records: a wave per chunk; lane j: row of its word = rank of its bitmap word + the set bits below it, its
+// ballot goes to its wave's column of that row.  The matrix has been zeroed: a (row, column) no record names stays 0.
+template <typename W>
+__global__ __launch_bounds__(256) void pm_replay_kernel(const PmRec rec, uint32_t n_chunks, const unsigned long long *__restrict__ gbm,
+                                                        const uint32_t *__restrict__ rank, int wpr, uint64_t *__restrict__ bits)
+{
+    // n_chunks: the most any region has claimed; blockIdx.y: the region
+    const uint32_t rel = blockIdx.x * 4 + (threadIdx.x >> 6);
+    const int lane = threadIdx.x & 63;
+    if (rel >= n_chunks) return;
+    const size_t ch = (size_t)blockIdx.y * rec.region_chunks + rel;
+    const uint2 h = rec.hdr[ch];
+    if ((uint32_t)lane >= h.y) return;
+    const W m = reinterpret_cast<const W *>(rec.words)[ch * 64 + lane];
+    const unsigned long long mask = rec.masks[ch * 64 + lane];
+    const uint64_t wq = (uint64_t)m >> 6;
+    const uint64_t r = (uint64_t)rank[wq] + (uint32_t)__popcll(gbm[wq] & ((1ull << ((uint32_t)m & 63)) - 1ull));
+    bits[r * (uint64_t)wpr + h.x] = mask;
+}
+
+// the union words: the set bits of the occupancy bitmap, in order
+__global__ void pm_union_kernel(const unsigned long long *__restrict__ gbm, const uint32_t *__restrict__ rank, uint64_t n_words,
+                                uint64_t base, uint64_t *__restrict__ union_words)
+{
+    const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n_words) return;
+    unsigned long long v = gbm[i];
+    uint32_t r = rank[i];
+    while (v) {
+        union_words[r++] = base + (i << 6) + (uint64_t)__builtin_ctzll(v);
+        v &= v - 1;
     }
 }
 
@@ -340,6 +435,12 @@ __global__ void pm_tile_rows_kernel(const uint32_t *__restrict__ rank, const uin
     rows[t] = rank[b] - rank[a];
 }
 
+#ifdef PSK_PM_STATS
+__device__ unsigned long long pm_stats[16];
+#define PM_ST(k) { if (lane == 0) { const unsigned long long now = wall_clock64(); st[k] += now - st_c; st_c = now; } }
+#else
+#define PM_ST(k)
+#endif
 // pass 2: the same stream; every wave stores its ballots into its column of the tile's block
 #ifndef PSK_PM_FILL_WGS
 #define PSK_PM_FILL_WGS 1
@@ -371,6 +472,9 @@ __global__ __launch_bounds__(PM_GROUP, PSK_PM_FILL_WGS) void pm_fill_kernel(cons
     PmCursor<W> cur;
     if constexpr (PmCursor<W>::RING) cur.attach(reinterpret_cast<W *>(pm_lds_all) + threadIdx.x, blockDim.x);
     cur.seek(lw, ln, lw ? pm_lower_bound(lw, ln, bounds[t0]) : 0, base, spare);
+#ifdef PSK_PM_STATS
+    unsigned long long st[8] = {0, 0, 0, 0, 0, 0, 0, 0}, st_c = wall_clock64(), st_iter = 0;
+#endif
     for (uint32_t t = t0; t < t1; t++) {
         const uint64_t lo = bounds[t], hi = bounds[t + 1];
         const W lo_w = (W)(lo - base), hi_w = (W)(hi - base - 1);
@@ -379,12 +483,14 @@ __global__ __launch_bounds__(PM_GROUP, PSK_PM_FILL_WGS) void pm_fill_kernel(cons
         for (uint32_t i = threadIdx.x; i < nbw; i += blockDim.x) bm[i] = gbm[w0 + i];
         for (uint32_t i = threadIdx.x; i <= nbw; i += blockDim.x) rk[i] = rank[w0 + i];
         __syncthreads();
+        PM_ST(0)
         const uint32_t row0 = rk[0], rows = rk[nbw] - row0;
         const uint32_t pos = rows > r_cap ? cur.position() : 0;   // where this lane's words of the tile begin (several batches only)
         for (uint32_t b0 = 0; b0 < rows; b0 += r_cap) {
             const uint32_t rb = rows - b0 < r_cap ? rows - b0 : r_cap;
             for (uint32_t i = threadIdx.x; i < rb * (uint32_t)cols; i += blockDim.x) blk[i] = 0;
             __syncthreads();
+            PM_ST(1)
             if (b0 > 0) cur.seek(lw, ln, pos, base, spare);   // a tile with more rows than the block holds is streamed once per batch
             // A word's row = rank of its bitmap word + the set bits below it: two LDS reads, a popcount and the store -- per
             // iteration they were ~20 wave-uniform instructions behind an LDS round trip (pm_fill: 5.5 G instructions against
@@ -410,9 +516,14 @@ __global__ __launch_bounds__(PM_GROUP, PSK_PM_FILL_WGS) void pm_fill_kernel(cons
                 if (lane == cnt) { my_i = (uint32_t)(m - lo_w); my_mask = mask; }
                 if (++cnt == 64) { flush(64); cnt = 0; }
                 if (hit) cur.advance();
+#ifdef PSK_PM_STATS
+                st_iter++;
+#endif
             }
             flush(cnt);
+            PM_ST(2)
             __syncthreads();
+            PM_ST(3)
             uint64_t *dst = bits + (uint64_t)(row0 + b0) * wpr + (uint64_t)group * PM_COLS;
             if (cols == PM_COLS) {   // a full group: shifts instead of a division by a run-time value per element
                 for (uint32_t e = threadIdx.x; e < rb * (uint32_t)PM_COLS; e += blockDim.x) {
@@ -426,6 +537,7 @@ __global__ __launch_bounds__(PM_GROUP, PSK_PM_FILL_WGS) void pm_fill_kernel(cons
                 }
             }
             __syncthreads();
+            PM_ST(4)
         }
         if (group == 0) {   // the union words of the tile: the set bits of its bitmap, in order
             for (uint32_t i = threadIdx.x; i < nbw; i += blockDim.x) {
@@ -438,7 +550,15 @@ __global__ __launch_bounds__(PM_GROUP, PSK_PM_FILL_WGS) void pm_fill_kernel(cons
             }
         }
         __syncthreads();   // bm / rk are rewritten by the next tile
+        PM_ST(5)
     }
+#ifdef PSK_PM_STATS
+    if (lane == 0) {
+        for (int k = 0; k < 6; k++) atomicAdd(&pm_stats[k], st[k]);
+        atomicAdd(&pm_stats[6], st_iter);
+        atomicAdd(&pm_stats[7], 1ull);
+    }
+#endif
 }
 
 // evenly spaced entries of a few lists: the pilot the tile bounds are cut from
@@ -576,8 +696,36 @@ int build_presence_merge(psk_ctx *ctx, uint64_t total_pairs, uint64_t *n_kmers, 
     const size_t ring_bytes = w32 ? (size_t)threads * PSK_PM_BLOCK * 2 * 4 : 0;   // the lanes' windows (32-bit words): 64 KB for 1,024 lanes
     if (w32 && ring_bytes + PM_BMW * 8 > 64 * 1024)
         PSK_HIP(ctx, hipFuncSetAttribute(reinterpret_cast<const void *>(pm_mark_kernel<uint32_t>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)ring_bytes));
-    if (w32) pm_mark_kernel<uint32_t><<<grid, threads, ring_bytes, ctx->stream>>>(d_refs, n, d_bounds, n_tiles, tiles_per_range, base, gbm, n_groups == 1, d_spare);
-    else pm_mark_kernel<uint64_t><<<grid, threads, 0, ctx->stream>>>(d_refs, n, d_bounds, n_tiles, tiles_per_range, base, gbm, n_groups == 1, d_spare);
+    // records of pass 1 for pass 2 (PmRec): a pool of pairs / PSK_MERGE_REC_DIV records (default 12; 0: none, pass 2 merges)
+    PmRec rec = {nullptr, nullptr, nullptr, nullptr, 0};   // (region_chunks = 0: no records)
+    {
+        uint64_t div = 12;
+        if (const char *e = getenv("PSK_MERGE_REC_DIV")) div = strtoull(e, nullptr, 10);
+        if (div) {
+            // + every wave's claims under way (two) and the one it ends in; a region takes what the ranges that map to it need:
+            // half as much again for their imbalance
+            uint64_t chunks = total_pairs / div / 64 + 3 * PM_REC_BLOCK * (uint64_t)n_ranges * n_groups * (threads / 64);
+            uint64_t region_chunks = ((chunks + chunks / 2) / PM_REC_REGIONS + PM_REC_BLOCK) & ~(uint64_t)(PM_REC_BLOCK - 1);
+            if (const char *e = getenv("PSK_MERGE_REC_REGION")) {   // (tests: a region too small on purpose)
+                const uint64_t v = strtoull(e, nullptr, 10);
+                if (v >= 1 && v < (1ull << 26)) region_chunks = (v + PM_REC_BLOCK - 1) & ~(uint64_t)(PM_REC_BLOCK - 1);
+            }
+            chunks = region_chunks * PM_REC_REGIONS;
+            if (chunks < (1ull << 31)) {
+                const size_t wbytes = w32 ? 4 : 8, ctr_bytes = (size_t)(PM_REC_REGIONS + 1) * PM_REC_CTR_STRIDE * 4;
+                PSK_TRY(dev_reserve(ctx, ctx->valsA, chunks * 64 * (wbytes + 8)));
+                PSK_TRY(dev_reserve(ctx, ctx->valsB, ctr_bytes + chunks * 8));
+                rec.ctr = ctx->valsB.as<uint32_t>();
+                rec.hdr = reinterpret_cast<uint2 *>(ctx->valsB.as<uint8_t>() + ctr_bytes);
+                rec.masks = ctx->valsA.as<unsigned long long>();
+                rec.words = ctx->valsA.as<uint8_t>() + chunks * 64 * 8;
+                rec.region_chunks = (uint32_t)region_chunks;
+                PSK_HIP(ctx, hipMemsetAsync(ctx->valsB.p, 0, ctr_bytes + chunks * 8, ctx->stream));
+            }
+        }
+    }
+    if (w32) pm_mark_kernel<uint32_t><<<grid, threads, ring_bytes, ctx->stream>>>(d_refs, n, d_bounds, n_tiles, tiles_per_range, base, gbm, n_groups == 1, d_spare, rec);
+    else pm_mark_kernel<uint64_t><<<grid, threads, 0, ctx->stream>>>(d_refs, n, d_bounds, n_tiles, tiles_per_range, base, gbm, n_groups == 1, d_spare, rec);
     PSK_HIP(ctx, hipGetLastError());
     mark("pm_mark");
     pm_popcount_kernel<<<div_up(n_bmw + 1, 256), 256, 0, ctx->stream>>>(gbm, n_bmw, rank);
@@ -589,6 +737,8 @@ int build_presence_merge(psk_ctx *ctx, uint64_t total_pairs, uint64_t *n_kmers, 
     uint32_t m32 = 0;
     PSK_HIP(ctx, hipMemcpyAsync(rows.data(), d_rows, (size_t)n_tiles * 4, hipMemcpyDeviceToHost, ctx->stream));
     PSK_HIP(ctx, hipMemcpyAsync(&m32, d_m, 4, hipMemcpyDeviceToHost, ctx->stream));
+    uint32_t rec_state[(PM_REC_REGIONS + 1) * PM_REC_CTR_STRIDE] = {0};   // chunks claimed per region, overflow
+    if (rec.region_chunks) PSK_HIP(ctx, hipMemcpyAsync(rec_state, rec.ctr, sizeof(rec_state), hipMemcpyDeviceToHost, ctx->stream));
     PSK_HIP(ctx, hipStreamSynchronize(ctx->stream));   // `bounds` (host) has been copied as well
     mark("ranks");
     const uint64_t M = m32;
@@ -597,7 +747,21 @@ int build_presence_merge(psk_ctx *ctx, uint64_t total_pairs, uint64_t *n_kmers, 
     PSK_TRY(dev_reserve(ctx, ctx->union_words, (M ? M : 1) * 8));
     PSK_TRY(dev_reserve(ctx, ctx->bits, (M ? M : 1) * (uint64_t)wpr * 8));
     mark("alloc matrix");
-    if (M) {
+    const bool replay = rec.region_chunks && !rec_state[PM_REC_REGIONS * PM_REC_CTR_STRIDE];
+    if (M && replay) {
+        uint32_t n_chunks = 0;   // the most a region has claimed
+        for (int r = 0; r < PM_REC_REGIONS; r++) n_chunks = std::max(n_chunks, std::min(rec_state[r * PM_REC_CTR_STRIDE], rec.region_chunks));
+        PSK_HIP(ctx, hipMemsetAsync(ctx->bits.p, 0, M * (uint64_t)wpr * 8, ctx->stream));
+        const dim3 rgrid((unsigned)div_up(n_chunks, 4), PM_REC_REGIONS);
+        if (w32) pm_replay_kernel<uint32_t><<<rgrid, 256, 0, ctx->stream>>>(rec, n_chunks, gbm, rank, wpr, ctx->bits.as<uint64_t>());
+        else pm_replay_kernel<uint64_t><<<rgrid, 256, 0, ctx->stream>>>(rec, n_chunks, gbm, rank, wpr, ctx->bits.as<uint64_t>());
+        PSK_HIP(ctx, hipGetLastError());
+        pm_union_kernel<<<div_up(n_bmw, 256), 256, 0, ctx->stream>>>(gbm, rank, n_bmw, base, ctx->union_words.as<uint64_t>());
+        PSK_HIP(ctx, hipGetLastError());
+        PSK_HIP(ctx, hipStreamSynchronize(ctx->stream));
+        if (trace) fprintf(stderr, "[psk]   merge records: at most %u chunks of 64 in a region (of %u), %d regions\n", n_chunks, rec.region_chunks, PM_REC_REGIONS);
+    } else if (M) {
+        if (trace && rec.region_chunks) fprintf(stderr, "[psk]   merge records: a region of %u chunks overflowed, pass 2 merges\n", rec.region_chunks);
         const int cols0 = wpr < PM_COLS ? wpr : PM_COLS;
         const size_t head = ring_bytes + (size_t)bmw_max * 8 + (size_t)((bmw_max + 2) >> 1) * 8;
         // rows a block holds: what fits beside the bitmap -- but sized for the bulk of the tiles (99.5th percentile of
@@ -631,6 +795,17 @@ int build_presence_merge(psk_ctx *ctx, uint64_t total_pairs, uint64_t *n_kmers, 
         PSK_HIP(ctx, hipStreamSynchronize(ctx->stream));
     }
     mark("pm_fill");
+#ifdef PSK_PM_STATS
+    {
+        unsigned long long h[16];
+        (void)hipMemcpyFromSymbol(h, HIP_SYMBOL(pm_stats), sizeof(h));
+        const double w = (double)h[7];   // waves
+        fprintf(stderr, "[psk] pm_fill per wave (us of 100 MHz ticks / 100): loads+sync %.1f, zero+sync %.1f, merge %.1f, wait %.1f, copy-out %.1f, union+sync %.1f; iterations %.0f per wave\n",
+                h[0] / w / 100, h[1] / w / 100, h[2] / w / 100, h[3] / w / 100, h[4] / w / 100, h[5] / w / 100, h[6] / w);
+        unsigned long long z[16] = {0};
+        (void)hipMemcpyToSymbol(HIP_SYMBOL(pm_stats), z, sizeof(z));
+    }
+#endif
     if (getenv("PSK_TRACE"))
         fprintf(stderr, "[psk] merge build: %u tiles (%llu pairs each wanted), %llu ranges x %d groups of %d threads, widest tile %u bitmap words, most rows %u\n",
                 n_tiles, (unsigned long long)pairs_per_tile, (unsigned long long)n_ranges, n_groups, threads, bmw_max, rows_max);

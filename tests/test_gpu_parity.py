@@ -1396,6 +1396,13 @@ def test_merge_presence_build_equals_the_oracle_and_the_sort_route(ctx, oracle, 
         want = oracle.union(kept)
         assert m == len(want) and np.array_equal(uw, want), (lo, hi)
         assert np.array_equal(rows, oracle.presence_bits(kept, uw, wpr=ctx.presence_shape()[1]))
+        # r04: pass 2 replays the records pass 1 left (the default, above); without records it merges the lists again
+        # (PSK_MERGE_REC_DIV=0), and so it does when the record pool overflows (regions of eight chunks)
+        for name, val in (("PSK_MERGE_REC_DIV", "0"), ("PSK_MERGE_REC_REGION", "8")):
+            monkeypatch.setenv(name, val)
+            assert ctx.build_presence() == m
+            assert np.array_equal(ctx.get_union(), uw) and np.array_equal(ctx.get_rows(np.arange(m, dtype=np.uint64)), rows), name
+            monkeypatch.delenv(name)
         monkeypatch.setenv("PSK_NO_MERGE_PRESENCE", "1")
         assert ctx.build_presence() == m
         assert np.array_equal(ctx.get_union(), uw) and np.array_equal(ctx.get_rows(np.arange(m, dtype=np.uint64)), rows)
