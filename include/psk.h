@@ -135,6 +135,13 @@ int psk_write_result_tables(psk_ctx *ctx, const char *path, const char *path_top
                             const double *mean_x, const double *mean_y, const int32_t *n_with, const uint64_t *bits,
                             int words_per_row, int n_samples, const uint8_t *valid, const char *names, const int64_t *name_off,
                             int64_t *order_out);
+/* a11, write_model_coefficients_to_file (modeling.py:1414-1455): APPENDS to `path` (whose header line the caller has written)
+ * one line per k-mer of the model: k-mer \t repr(coefficient) \t number of samples with it \t "| " + their names.  kmers /
+ * kmer_off and names / name_off: texts back to back with their offsets; x[n_samples][n_kmers] (int64, row-major): the model
+ * matrix of <pheno>_MLdf.csv, a sample carries a k-mer where it is not 0.  Host code; ctx may be NULL. */
+int psk_write_model_coefficients(psk_ctx *ctx, const char *path, int64_t n_kmers, const char *kmers, const int64_t *kmer_off,
+                                 const double *coefs, const int64_t *x, int64_t n_samples, const char *names,
+                                 const int64_t *name_off);
 /* `--kmerDB`: keeps only rows whose word occurs in the (sorted, canonical) db word list --
  * `glistcompare -i` of Samples.get_db_kmers, modeling.py:367-372. */
 int psk_intersect_db(psk_ctx *ctx, const uint64_t *db_words, uint64_t n_db, uint64_t *n_kmers);

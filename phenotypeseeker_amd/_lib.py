@@ -38,6 +38,8 @@ _SIGNATURES = {
     "psk_write_result_tables": (c.c_int, [c.c_void_p, c.c_char_p, c.c_char_p, c.c_int64, c.c_char_p, c.c_int, c.c_int64, c.c_void_p,
                                           c.c_int, c.c_void_p, c.c_void_p, c.c_void_p, c.c_void_p, c.c_void_p, c.c_void_p, c.c_int,
                                           c.c_int, c.c_void_p, c.c_char_p, c.c_void_p, c.c_void_p]),
+    "psk_write_model_coefficients": (c.c_int, [c.c_void_p, c.c_char_p, c.c_int64, c.c_char_p, c.c_void_p, c.c_void_p, c.c_void_p,
+                                               c.c_int64, c.c_char_p, c.c_void_p]),
     "psk_lists_split": (c.c_int, [c.c_void_p, c.c_int, c.c_int, c.c_void_p, c.c_int, c.c_void_p]),
     "psk_copy_list_ranges": (c.c_int, [c.c_void_p, c.c_int, c.c_void_p, c.c_void_p, c.c_void_p, c.c_void_p, c.c_void_p]),
     "psk_set_lists_device": (c.c_int, [c.c_void_p, c.c_int, c.c_void_p, c.c_void_p, c.c_void_p, c.c_void_p, c.c_void_p]),

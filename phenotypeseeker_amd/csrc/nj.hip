@@ -413,28 +413,40 @@ __device__ __forceinline__ double njl_chain(const double2 *__restrict__ p, int p
 {
     // (a lone wave issues an instruction every ~5 cycles whatever it is: with a run-time stride every read had its own
     // address arithmetic, ~120 instructions per 32 additions = 21 cycles per addition; with the stride a constant the
-    // sixteen reads of a round are immediates off one pointer)
+    // sixteen reads of a round are immediates off one pointer -- and still the compiler loaded the next block early into
+    // fresh registers and copied: 16 v_mov_b64 per round, 13 cycles per addition.  So the reads are written out: the
+    // compiler sees eight registers go into an asm and come out of it, the s_waitcnt that makes them valid is part of the
+    // asm that hands them to the additions.  LDS returns in order: when at most eight reads are outstanding, the eight
+    // issued before them have landed.)
+    typedef double njl_d2 __attribute__((ext_vector_type(2)));
     double acc = -0.0;
-    double2 A[8], B[8];
-    const double2 *q = p;
-#pragma unroll
-    for (int u = 0; u < 8; u++) A[u] = q[u * STRIDE];
+    njl_d2 A[8], B[8];
+    uint32_t q = (uint32_t)(uintptr_t)p;   // LDS byte address
+    const uint32_t q0 = q;
+#define NJL_RD(dst, addr, off) asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(dst) : "v"(addr), "n"(off))
+#define NJL_RD8(X, addr, base) { NJL_RD(X[0], addr, (base + 0) * STRIDE * 16); NJL_RD(X[1], addr, (base + 1) * STRIDE * 16); \
+                                 NJL_RD(X[2], addr, (base + 2) * STRIDE * 16); NJL_RD(X[3], addr, (base + 3) * STRIDE * 16); \
+                                 NJL_RD(X[4], addr, (base + 4) * STRIDE * 16); NJL_RD(X[5], addr, (base + 5) * STRIDE * 16); \
+                                 NJL_RD(X[6], addr, (base + 6) * STRIDE * 16); NJL_RD(X[7], addr, (base + 7) * STRIDE * 16); }
+#define NJL_WAIT8(X) asm volatile("s_waitcnt lgkmcnt(8)" : "+v"(X[0]), "+v"(X[1]), "+v"(X[2]), "+v"(X[3]), "+v"(X[4]), "+v"(X[5]), "+v"(X[6]), "+v"(X[7]))
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // nothing of the compiler's is in flight when the counting begins
+    NJL_RD8(A, q, 0)
     for (int r = 0; r < pairs; r += 16) {
-        const double2 *qn = r + 16 < pairs ? q + 16 * STRIDE : p;   // (the last round loads the first block again, for nobody)
-        __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-        for (int u = 0; u < 8; u++) B[u] = q[(8 + u) * STRIDE];
-        __builtin_amdgcn_sched_barrier(0);
+        const uint32_t qn = r + 16 < pairs ? q + 16 * STRIDE * 16 : q0;   // (the last round loads the first block again, for nobody)
+        NJL_RD8(B, q, 8)
+        NJL_WAIT8(A);
 #pragma unroll
         for (int u = 0; u < 8; u++) { acc += A[u].x; acc += A[u].y; }
-        __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-        for (int u = 0; u < 8; u++) A[u] = qn[u * STRIDE];
-        __builtin_amdgcn_sched_barrier(0);
+        NJL_RD8(A, qn, 0)
+        NJL_WAIT8(B);
 #pragma unroll
         for (int u = 0; u < 8; u++) { acc += B[u].x; acc += B[u].y; }
         q = qn;
     }
+    asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(A[0]), "+v"(A[1]), "+v"(A[2]), "+v"(A[3]), "+v"(A[4]), "+v"(A[5]), "+v"(A[6]), "+v"(A[7]));   // the stray last block
+#undef NJL_RD
+#undef NJL_RD8
+#undef NJL_WAIT8
     return acc;
 }
 

@@ -583,12 +583,23 @@ class phenotypes:
         ml = self.ML
         with open(self.name + "_MLdf.csv", "w") as f:
             f.write(",".join([""] + ml["kmers"] + ["weights", "phenotype"]) + "\n")
-            X = np.asarray(ml["X"]).astype(np.int64, copy=False).tolist()   # python ints: str() of numpy scalars is 5x slower
+            Xa = np.asarray(ml["X"]).astype(np.int64, copy=False)
+            # 0/1 columns (anything of one digit): ",d,d,...": one byte matrix for all rows instead of a str() and a join per
+            # cell (2,048 x 1,000: 74 -> 6 ms); --real_counts with counts of several digits keeps the general writer
+            digits = Xa.size > 0 and Xa.ndim == 2 and int(Xa.min()) >= 0 and int(Xa.max()) <= 9
+            if digits:
+                cells = np.empty((Xa.shape[0], 2 * Xa.shape[1]), dtype=np.uint8)
+                cells[:, 0::2] = ord(",")
+                cells[:, 1::2] = Xa + ord("0")
+            else:
+                X = Xa.tolist()   # python ints: str() of numpy scalars is 5x slower
             for i, name in enumerate(ml["index"]):
                 w, p = ml["weights"][i], ml["phenotype"][i]
-                f.write(",".join([name] + list(map(str, X[i])) +
-                                 [repr(w) if isinstance(w, float) else str(w),
-                                  repr(p) if isinstance(p, float) else str(p)]) + "\n")
+                tail = [repr(w) if isinstance(w, float) else str(w), repr(p) if isinstance(p, float) else str(p)]
+                if digits:
+                    f.write(name + cells[i].tobytes().decode("ascii") + "," + ",".join(tail) + "\n")
+                else:
+                    f.write(",".join([name] + list(map(str, X[i])) + tail) + "\n")
 
     def _load_MLdf(self):
         with open(self.name + "_MLdf.csv") as f:
@@ -810,15 +821,22 @@ class phenotypes:
         out.write("K-mer\tcoef._in_" + self.model_name_short + "_model\tNo._of_samples_with_k-mer\tSamples_with_k-mer\n")
         be = self.model_fitted.best_estimator_
         coefs = be.coef_[0] if self.pred_scale == "binary" else be.coef_
-        X, index = self.ML["X"], self.ML["index"]
-        cols, rows = np.nonzero(np.asarray(X).T)  # column-major: the samples of one k-mer are consecutive, in order
-        ends = np.cumsum(np.bincount(cols, minlength=len(self.ML["kmers"])))
-        who = np.array(index, dtype=object)[rows].tolist()
-        lo = 0
-        for j, kmer in enumerate(self.ML["kmers"]):
-            hi = int(ends[j])
-            out.write("%s\t%s\t%d\t| %s\n" % (kmer, repr(float(coefs[j])), hi - lo, " ".join(who[lo:hi])))
-            lo = hi
+        X, index, kmers = self.ML["X"], self.ML["index"], self.ML["kmers"]
+        # the lines are formatted by libpsk (psk_write_model_coefficients: a 2,048-sample model names a million samples --
+        # 0.07 s of joins here); it appends to the file whose header this function has just written
+        out.flush()
+        kenc, nenc = [km.encode() for km in kmers], [nm.encode() for nm in index]
+        koff = np.zeros(len(kenc) + 1, dtype=np.int64)
+        koff[1:] = np.cumsum([len(e) for e in kenc])
+        noff = np.zeros(len(nenc) + 1, dtype=np.int64)
+        noff[1:] = np.cumsum([len(e) for e in nenc])
+        Xa = np.ascontiguousarray(np.asarray(X).reshape(len(nenc), len(kenc)), dtype=np.int64)
+        cf = np.ascontiguousarray(np.asarray(coefs, dtype=np.float64).reshape(-1)[:len(kenc)])
+        vp = lambda a: a.ctypes.data_as(ctypes.c_void_p)
+        rc = _lib.load().psk_write_model_coefficients(None, os.fsencode(out.name), len(kenc), b"".join(kenc), vp(koff), vp(cf), vp(Xa),
+                                                      len(nenc), b"".join(nenc), vp(noff))
+        if rc != 0:
+            raise PskError("psk_write_model_coefficients failed (%d)" % rc, rc)
 
 
 def _metric_store():

@@ -213,3 +213,32 @@ def test_result_tables_written_by_libpsk_equal_the_python_writer(tmp_path):
                 assert f.read() == b"\n".join(want.split(b"\n")[: 1 + min(n_top, m)]) + b"\n", case
     assert lib.psk_write_result_tables(None, None, None, 0, b"h", 0, 0, None, 13, None, None, None, None, None, None, 1, 1, None, None, None,
                                        None) == -1
+
+
+def test_model_coefficient_writer_equals_the_python_lines(tmp_path):
+    """r04: psk_write_model_coefficients (host code in libpsk) appends the lines of the coefficient file exactly as the Python
+    writer formatted them: "%s\\t%s\\t%d\\t| %s\\n" % (k-mer, repr(coef), count, " ".join(names)) -- awkward doubles, k-mers no
+    sample carries ("| " with its trailing space), names of every length."""
+    import ctypes
+    from phenotypeseeker_amd import _lib
+    lib = _lib.load()
+    rng = np.random.default_rng(11)
+    for n, p in ((1, 1), (7, 13), (130, 40), (0, 3), (5, 0)):
+        names = ["s%d%s" % (i, "x" * int(rng.integers(0, 9))) for i in range(n)]
+        kmers = ["".join(rng.choice(list("ACGT"), 13)) for _ in range(p)]
+        X = (rng.random((n, p)) < 0.3).astype(np.int64) * rng.integers(1, 5, (n, p))
+        if p > 1:
+            X[:, 1] = 0
+        coefs = np.concatenate([[0.0, -0.0, 1e-5, 123456789012345680.0, 1e16, 0.1 + 0.2, -3.5e-310][:p], rng.normal(0, 1, max(p - 7, 0))])[:p]
+        want = "".join("%s\t%s\t%d\t| %s\n" % (kmers[j], repr(float(coefs[j])), int((X[:, j] != 0).sum()),
+                                              " ".join(names[i] for i in range(n) if X[i, j] != 0)) for j in range(p))
+        path = tmp_path / ("coef_%d_%d.txt" % (n, p))
+        path.write_text("header\n")
+        kenc, nenc = [k.encode() for k in kmers], [m.encode() for m in names]
+        koff = np.zeros(p + 1, dtype=np.int64); koff[1:] = np.cumsum([len(e) for e in kenc])
+        noff = np.zeros(n + 1, dtype=np.int64); noff[1:] = np.cumsum([len(e) for e in nenc])
+        Xa, cf = np.ascontiguousarray(X), np.ascontiguousarray(coefs, dtype=np.float64)
+        vp = lambda a: a.ctypes.data_as(ctypes.c_void_p)
+        rc = lib.psk_write_model_coefficients(None, str(path).encode(), p, b"".join(kenc), vp(koff), vp(cf), vp(Xa), n, b"".join(nenc), vp(noff))
+        assert rc == 0
+        assert path.read_text() == "header\n" + want
