@@ -64,6 +64,12 @@ if what == "cfg3slab":
         # the matrix + the union words
         alg["pm_mark_kernel"] = 8 * pairs
         alg["pm_fill_kernel"] = 8 * pairs + m * 256 + m * 8
+        # r04: pass 2 replays the records of pass 1 -- 12 B per (word, ballot) record read, one 8-byte word per record written
+        # into the zeroed matrix; the records of this slab: one per merge iteration, ~ pairs / 20 (the trace line says how many
+        # chunks of 64); the union kernel reads the bitmap + ranks and writes the words
+        recs = pairs // 20
+        alg["pm_replay_kernel"] = 12 * recs + 8 * recs
+        alg["pm_union_kernel"] = (bounds[1] - bounds[0]) // 64 * 12 + m * 8
 elif what == "moments":
     M, N = 16_000_000, 1024
     rng = np.random.default_rng(3)
@@ -218,6 +224,8 @@ elif what == "weights":
         alg["kmer_hash_filter_kernel"] = 8 * L        # one 8-byte window word per base position (k = 21 extract output) read once
         alg["mash_pairs_kernel"] = n * (n + 1) // 2 * 2 * 8 * 1000      # two sketches of 1,000 hashes per pair (L2-resident: a latency bound, not HBM)
         alg["nj_kernel"] = sum(m * m // 2 * 8 for m in range(3, n + 1))   # the lower triangle once per join (L2-resident)
+        alg["nj_grid_kernel"] = alg["nj_kernel"]
+        alg["nj_lds_kernel"] = n * n * 8                                    # r04: the matrix read ONCE from memory; every join works in LDS
 elif what == "lasso":
     d = np.load(os.path.join(ROOT, "tests", "golden", "fit2048_907.npz"))
     X = np.unpackbits(d["Xbits"], axis=1)[:1024, : int(d["p"])].astype(np.float32)
