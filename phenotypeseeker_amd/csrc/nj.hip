@@ -774,11 +774,18 @@ extern "C" int psk_nj_merges(psk_ctx *ctx, const double *dist, int n, int32_t *m
     // slice fits the compute units; PSK_NJ_LDS=0 switches it off
     const bool one_wg = one && *one && strcmp(one, "0") != 0;
     const char *lds_knob = getenv("PSK_NJ_LDS"), *lds_min = getenv("PSK_NJ_LDS_MIN");
+    int lds_from = 288;
+    if (lds_min && *lds_min) {   // (a knob of the tests: a whole number of leaves, 3 ... NJ_MAX)
+        char *end = nullptr;
+        const long v = strtol(lds_min, &end, 10);
+        if (*end || v < 3 || v > NJ_MAX) return psk_fail(ctx, PSK_EINVAL, "PSK_NJ_LDS_MIN=%s: expected a number of leaves, 3 ... %d", lds_min, NJ_MAX);
+        lds_from = (int)v;
+    }
     const int n_pad = (n + 31) & ~31;
     int lgC = 6;
     while (lgC > 3 && (size_t)n_pad * 8 * (1u << lgC) > NJL_SLICE_BYTES) lgC--;
     const int nwg_l = (n + (1 << lgC) - 1) >> lgC;
-    if (!one_wg && !(lds_knob && strcmp(lds_knob, "0") == 0) && !getenv("PSK_NJ_GRID") && n >= (lds_min ? atoi(lds_min) : 288) &&
+    if (!one_wg && !(lds_knob && strcmp(lds_knob, "0") == 0) && !getenv("PSK_NJ_GRID") && n >= lds_from &&
         n <= NJL_MAXN && nwg_l <= NJL_T && nwg_l <= (ctx->n_cu > 0 ? ctx->n_cu : 256)) {
         const size_t xbytes = sizeof(NjlShared) + 2 * (size_t)n * sizeof(NjlX) + (size_t)nwg_l * sizeof(NjlCandX);
         PSK_TRY(dev_reserve(ctx, ctx->keysB, xbytes));

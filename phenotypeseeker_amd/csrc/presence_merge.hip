@@ -700,7 +700,11 @@ int build_presence_merge(psk_ctx *ctx, uint64_t total_pairs, uint64_t *n_kmers, 
     PmRec rec = {nullptr, nullptr, nullptr, nullptr, 0};   // (region_chunks = 0: no records)
     {
         uint64_t div = 12;
-        if (const char *e = getenv("PSK_MERGE_REC_DIV")) div = strtoull(e, nullptr, 10);
+        if (const char *e = getenv("PSK_MERGE_REC_DIV")) {
+            char *end = nullptr;
+            div = strtoull(e, &end, 10);
+            if (!*e || *end) return psk_fail(ctx, PSK_EINVAL, "PSK_MERGE_REC_DIV=%s: expected a whole number (0 = no records)", e);
+        }
         if (div) {
             // + every wave's claims under way (two) and the one it ends in; a region takes what the ranges that map to it need:
             // half as much again for their imbalance
