@@ -286,3 +286,30 @@ def test_gpu_neighbour_joining_in_lds_equals_the_one_workgroup_kernel(monkeypatc
                 print("nj %d leaves%s: lds %.1f ms, one workgroup %.1f ms" % (n, " (ties)" if ties else "", 1e3 * t_lds, 1e3 * t_one))
                 if n >= 1024:
                     assert 3 * t_lds < t_one, (n, t_lds, t_one)
+
+
+@pytest.mark.gpu
+def test_form_knobs_of_neighbour_joining_and_of_the_merge_build_are_validated(monkeypatch):
+    """A knob that does not parse is an error that names it (VERDICT r03 #11), not atoi's idea of it."""
+    from phenotypeseeker_amd._lib import PskError
+    from phenotypeseeker_amd.engine import PskContext
+    from phenotypeseeker_amd.synth import GenomeSet
+    mat = np.ones((5, 5)) - np.eye(5)
+    with PskContext(0) as ctx:
+        for bad in ("abc", "2", "12x", "99999"):
+            monkeypatch.setenv("PSK_NJ_LDS_MIN", bad)
+            with pytest.raises(PskError, match="PSK_NJ_LDS_MIN"):
+                ctx.nj_merges(mat)
+        monkeypatch.setenv("PSK_NJ_LDS_MIN", "3")
+        assert len(ctx.nj_merges(mat)[0]) == 3
+        monkeypatch.delenv("PSK_NJ_LDS_MIN")
+        gs = GenomeSet(4, 5000, seed=1, gene_len=100)
+        ctx.begin(16, 4)
+        ctx.count_kmers_batch(0, [gs.sample(i)[1] for i in range(4)], 2)
+        monkeypatch.setenv("PSK_NO_TILED_PRESENCE", "1")
+        for bad in ("x", "1.5", "12 "):
+            monkeypatch.setenv("PSK_MERGE_REC_DIV", bad)
+            with pytest.raises(PskError, match="PSK_MERGE_REC_DIV"):
+                ctx.build_presence()
+        monkeypatch.setenv("PSK_MERGE_REC_DIV", "7")
+        assert ctx.build_presence() > 0
