@@ -144,7 +144,16 @@ def main(argv=None):
         # the CLI IS the process: its phase table (modeling.Phases) starts where the process did
         from .modeling import process_start_epoch
         args._t0 = process_start_epoch()
+        # (r04: 0.55 -> 0.49 s for 256 genomes as a fresh process: unpinning the ring, destroying the streams and the HIP
+        # runtime's own exit handlers are work nobody waits for)
+        args._fast_exit = os.environ.get("PSK_FAST_EXIT", "1") != "0"
     args.func(args)
+    if getattr(args, "_fast_exit", False):
+        # the CLI is the process and its work is done (every output file is closed): leave without the interpreter's and the
+        # HIP runtime's tear-down -- the driver reclaims the device memory with the process (PSK_FAST_EXIT=0 keeps the tidy exit)
+        sys.stdout.flush()
+        sys.stderr.flush()
+        os._exit(0)
 
 
 if __name__ == "__main__":

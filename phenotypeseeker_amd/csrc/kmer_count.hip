@@ -526,6 +526,18 @@ static int frame_into(uint8_t *stage, size_t stage_cap, const uint8_t *bytes, si
 //     are uploaded and framed ahead on their own streams;
 //   groups of G = 8 genomes per chain (k <= 16, r03): 3 G buffer sets, a group's uploads and framing run ahead, one
 //     launch chain counts the group (dense_group_enqueue / bucket_group_enqueue), the group before it is finalised meanwhile.
+// uploads rotate over two copy streams (PSK_COPY_STREAMS = 1..4): with one, the next copy is only queued when the
+// previous one has gone -- 256 genomes took 38-40 ms, with two 33-36 (r03; a stream per buffer set: set index mod streams)
+static int copy_stream_count()
+{
+    static const int n_cs = [] {
+        const char *e = getenv("PSK_COPY_STREAMS");
+        const int v = e ? atoi(e) : 2;
+        return v < 1 ? 1 : (v > 4 ? 4 : v);
+    }();
+    return n_cs;
+}
+
 static int lane_prepare(psk_ctx *ctx, CountLane &L)
 {
     if (!L.done) {
@@ -535,9 +547,26 @@ static int lane_prepare(psk_ctx *ctx, CountLane &L)
         PSK_HIP(ctx, hipEventCreateWithFlags(&L.up_done, hipEventDisableTiming));
     }
     if (!L.pinned_cnt) PSK_HIP(ctx, hipHostMalloc(reinterpret_cast<void **>(&L.pinned_cnt), 64, hipHostMallocDefault));
-    if (!ctx->copy_stream) PSK_HIP(ctx, hipStreamCreateWithFlags(&ctx->copy_stream, hipStreamNonBlocking));
-    for (hipStream_t &cs : ctx->copy_more) if (!cs) PSK_HIP(ctx, hipStreamCreateWithFlags(&cs, hipStreamNonBlocking));
-    if (!ctx->frame_stream) PSK_HIP(ctx, hipStreamCreateWithFlags(&ctx->frame_stream, hipStreamNonBlocking));
+    if (!ctx->copy_stream || !ctx->frame_stream) {
+        // A process's first upload: the streams of the ingest.  hipStreamCreate costs ~7.5 ms apiece (a hardware queue), and all
+        // five of r03 (copy + three more + framing, whatever PSK_COPY_STREAMS said) were created here one after the other: 40 of
+        // the 55 ms of a process's first counting call (r04, PSK_TRACE).  Only the copy streams in use now, and together
+        std::vector<hipStream_t *> want;
+        if (!ctx->copy_stream) want.push_back(&ctx->copy_stream);
+        for (int c = 0; c + 1 < copy_stream_count() && c < 3; c++) if (!ctx->copy_more[c]) want.push_back(&ctx->copy_more[c]);
+        if (!ctx->frame_stream) want.push_back(&ctx->frame_stream);
+        std::vector<hipError_t> err(want.size(), hipSuccess);
+        std::vector<std::thread> th;
+        for (size_t q = 1; q < want.size(); q++)
+            th.emplace_back([&, q] {
+                err[q] = hipSetDevice(ctx->device);
+                if (err[q] == hipSuccess) err[q] = hipStreamCreateWithFlags(want[q], hipStreamNonBlocking);
+            });
+        if (!want.empty()) err[0] = hipStreamCreateWithFlags(want[0], hipStreamNonBlocking);
+        for (auto &t : th) t.join();
+        for (hipError_t e : err)
+            if (e != hipSuccess) return psk_fail(ctx, PSK_EHIP, "hipStreamCreate failed: %s", hipGetErrorString(e));
+    }
     return PSK_OK;
 }
 
@@ -633,14 +662,7 @@ static int chain_upload(psk_ctx *ctx, CountLane &L, const uint8_t *src, uint64_t
     PSK_TRY(lane_prepare(ctx, L));
     if (bytes == 0) return PSK_OK;
     if (bytes >= (1ull << 32)) return psk_fail(ctx, PSK_ERANGE, "sample larger than 4 GB");
-    // uploads rotate over two copy streams (PSK_COPY_STREAMS = 1..4): with one, the next copy is only queued when the
-    // previous one has gone -- 256 genomes took 38-40 ms, with two 33-36 (r03; a stream per buffer set: set index mod streams)
-    static const int n_cs = [] {
-        const char *e = getenv("PSK_COPY_STREAMS");
-        const int v = e ? atoi(e) : 2;
-        return v < 1 ? 1 : (v > 4 ? 4 : v);
-    }();
-    const int which = (int)((&L - ctx->lane) % n_cs);
+    const int which = (int)((&L - ctx->lane) % copy_stream_count());
     hipStream_t cs = which ? ctx->copy_more[which - 1] : ctx->copy_stream;
     // after the last reader of this set's clean stream (the sample before last)
     if (L.raw_used) PSK_HIP(ctx, hipStreamWaitEvent(cs, L.raw_free, 0));
@@ -988,7 +1010,11 @@ static int count_batch_impl(psk_ctx *ctx, int first_sample_idx, int n, const uin
     const int R = n < want_ring ? n : want_ring;  // ring slots: two (groups) being uploaded / framed ahead, one whose chain is in
                                                   // flight, one released late -- never more than there are samples
     if ((int)ctx->ring.size() < R) { ctx->ring.resize(R, nullptr); ctx->ring_cap.resize(R, 0); }
-    for (int s = 0; s < R; s++) PSK_TRY(ensure_pinned(ctx, &ctx->ring[s], &ctx->ring_cap[s], max_len + 2 * EX_SEG));
+    // A slot that is missing or too small is pinned by the worker that first fills it (sample i < R is the first user of slot
+    // i, and nobody else touches the slot before that sample is ready) -- r04: all R slots up front, ~2 ms of page pinning each,
+    // were 16-40 ms in front of the first upload of a process's first calls (20 slots for 5-Mbp genomes); now the first upload
+    // waits for one slot and the others are pinned beside it, by the threads that would otherwise wait for their turn
+    const size_t slot_need = max_len + 2 * EX_SEG;
     // FASTA and four-line FASTQ are framed on the GPU (frame_gpu.hip): the worker threads then only move file bytes
     // into pinned memory.  PSK_HOST_FRAMING=1 keeps the host state machine for everything (A/B runs, tests).
     const bool gpu_framing = getenv("PSK_HOST_FRAMING") == nullptr;
@@ -1021,10 +1047,15 @@ static int count_batch_impl(psk_ctx *ctx, int first_sample_idx, int n, const uin
                 cv.wait(lk, [&] { return abort || consumed > i - R; });  // slot i % R is free again
                 if (abort) return;
             }
-            uint8_t *slot = static_cast<uint8_t *>(ctx->ring[i % R]);
             uint64_t c = 0, p = 0, w = 0, ro = 0, rl = 0;
             int rc = 0, f = 0;
-            if (gpu_framing) {
+            if (i < R && (!ctx->ring[i] || ctx->ring_cap[i] < slot_need)) {
+                if (hipSetDevice(ctx->device) != hipSuccess || ensure_pinned(ctx, &ctx->ring[i], &ctx->ring_cap[i], slot_need) != PSK_OK) rc = -3;
+            }
+            uint8_t *slot = static_cast<uint8_t *>(ctx->ring[i % R]);
+            if (rc) {
+                // (no pinned memory: reported below)
+            } else if (gpu_framing) {
                 // file bytes straight into the pinned slot (by several threads when the sample is large and threads
                 // are idle); the probe finds where the records start and end
                 size_t nul_at = lens[i];
@@ -1051,7 +1082,7 @@ static int count_batch_impl(psk_ctx *ctx, int first_sample_idx, int n, const uin
             {
                 std::lock_guard<std::mutex> lk(mu);
                 clen[i] = c; plen[i] = p; wins[i] = w; fmt[i] = f; roff[i] = ro; rlen[i] = rl;
-                state[i] = rc == -2 ? -2 : rc ? -1 : 1;
+                state[i] = rc == -2 ? -2 : rc == -3 ? -3 : rc ? -1 : 1;
             }
             cv.notify_all();
         }
@@ -1099,6 +1130,7 @@ static int count_batch_impl(psk_ctx *ctx, int first_sample_idx, int n, const uin
             if (state[i] == -2)
                 return psk_fail(ctx, PSK_EGZIP, "sample %d (%s) is gzip-compressed: inflate it and use the in-memory call",
                                 first_sample_idx + i, paths[i]);
+            if (state[i] == -3) return psk_fail(ctx, PSK_ENOMEM, "no pinned memory for sample %d (hipHostMalloc of %zu bytes failed)", first_sample_idx + i, slot_need);
             if (state[i] < 0)
                 return psk_fail(ctx, PSK_ERANGE, paths ? "reading or framing sample %d (%s) failed" : "framing of sample %d failed",
                                 first_sample_idx + i, paths ? paths[i] : "");
@@ -1139,6 +1171,7 @@ static int count_batch_impl(psk_ctx *ctx, int first_sample_idx, int n, const uin
         return consume(L, i, clen[i], wins[i], true);
     };
     if (grouped) rc = carve_lanes(ctx, NL, max_len, gpu_framing);
+    const double t_setup = since(t_call);   // (PSK_TRACE: buffer sets carved, threads started)
     if (rc != PSK_OK) {
     } else if (grouped) {
         // Groups of G samples: a group's uploads and framing run two groups ahead on the copy / framing streams; its samples'
@@ -1264,8 +1297,8 @@ static int count_batch_impl(psk_ctx *ctx, int first_sample_idx, int n, const uin
     for (auto &t : pool) t.join();
     if (trace)
         fprintf(stderr, "[psk] count batch: %d samples %.1f ms; the caller waited %.1f ms for the host threads (their fills: %.1f ms "
-                        "in all), %.1f ms for uploads + framing, %.1f ms for chains\n", n, since(t_call) * 1e3, t_worker * 1e3,
-                t_fill_us.load() / 1e3, t_frame * 1e3, t_final * 1e3);
+                        "in all), %.1f ms for uploads + framing, %.1f ms for chains; set-up %.1f ms\n", n, since(t_call) * 1e3, t_worker * 1e3,
+                t_fill_us.load() / 1e3, t_frame * 1e3, t_final * 1e3, t_setup * 1e3);
     return rc;
 }
 

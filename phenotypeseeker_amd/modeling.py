@@ -966,7 +966,8 @@ def modeling(args):
         if getattr(args, "assembly", False):
             _err(YELLOW % "-a/--assembly is outside the accelerated path and is skipped.")
     finally:
-        ctx.close()
+        if not getattr(args, "_fast_exit", False):   # (a CLI process about to leave: the driver frees the device memory with it)
+            ctx.close()
         group.close()
         ph_t.mark("teardown: buffers, communicator")
         ph_t.write(group.rank, group.world)
