@@ -509,24 +509,56 @@ __device__ __forceinline__ bool njl_before(const NjlBest &a, const NjlBest &b)  
 {
     return a.val < b.val || (a.val == b.val && (a.i < b.i || (a.i == b.i && a.j < b.j)));
 }
-// minimum over the workgroup, in every thread (s_red: 4 entries; two barriers)
-__device__ __forceinline__ NjlBest njl_wg_min(NjlBest v, NjlBest *s_red)
+// minimum over the workgroup by (value, i, j), in every thread (s_red: 4 entries; two barriers).  In a wave: the minimum of
+// the values by four DPP steps inside the rows of 16 lanes and three scalar minima of the row leaders, then -- among the
+// lanes that hold it -- the minimum of i << 16 | j the same way, then the winner's d[i][j] by a lane read: ~50
+// instructions without an LDS round trip (six ds_bpermute rounds of six registers each before: a third of a join's 3 us
+// between the scan and the candidates' exchange).  i, j < 2^16 (2,048 leaves at most); i = 0x7fffffff: no candidate.
+__device__ __forceinline__ uint32_t njl_dpp_u32(uint32_t v, const int tag)
 {
-#pragma unroll
-    for (int d = 32; d > 0; d >>= 1) {
-        NjlBest o;
-        o.val = psk_shfl_xor_f64(v.val, d); o.dij = psk_shfl_xor_f64(v.dij, d);
-        o.i = __shfl_xor(v.i, d, 64); o.j = __shfl_xor(v.j, d, 64);
-        if (njl_before(o, v)) v = o;
+    int x = (int)v;
+    switch (tag) {  // constant-folded (the builtin wants an immediate control word)
+    case 0: x = __builtin_amdgcn_update_dpp(x, x, 0xB1, 0xF, 0xF, false); break;    // quad_perm [1,0,3,2]
+    case 1: x = __builtin_amdgcn_update_dpp(x, x, 0x4E, 0xF, 0xF, false); break;    // quad_perm [2,3,0,1]
+    case 2: x = __builtin_amdgcn_update_dpp(x, x, 0x141, 0xF, 0xF, false); break;   // row_half_mirror
+    default: x = __builtin_amdgcn_update_dpp(x, x, 0x140, 0xF, 0xF, false); break;  // row_mirror
     }
+    return (uint32_t)x;
+}
+__device__ __forceinline__ NjlBest njl_wg_min(NjlBest c, NjlBest *s_red)
+{
+    double v = c.val;
+    v = fmin(v, psk_dpp_f64(v, 0));
+    v = fmin(v, psk_dpp_f64(v, 1));
+    v = fmin(v, psk_dpp_f64(v, 2));
+    v = fmin(v, psk_dpp_f64(v, 3));
+    const double m = fmin(fmin(psk_readlane_f64(v, 0), psk_readlane_f64(v, 16)), fmin(psk_readlane_f64(v, 32), psk_readlane_f64(v, 48)));
+    const bool have = (unsigned)c.i < 0x10000u && (unsigned)c.j < 0x10000u;
+    uint32_t key = have && c.val == m ? ((uint32_t)c.i << 16) | (uint32_t)c.j : 0xFFFFFFFFu;
+    uint32_t k = key, o;
+    o = njl_dpp_u32(k, 0); k = o < k ? o : k;
+    o = njl_dpp_u32(k, 1); k = o < k ? o : k;
+    o = njl_dpp_u32(k, 2); k = o < k ? o : k;
+    o = njl_dpp_u32(k, 3); k = o < k ? o : k;
+    const uint32_t k0 = (uint32_t)__builtin_amdgcn_readlane((int)k, 0), k1 = (uint32_t)__builtin_amdgcn_readlane((int)k, 16);
+    const uint32_t k2 = (uint32_t)__builtin_amdgcn_readlane((int)k, 32), k3 = (uint32_t)__builtin_amdgcn_readlane((int)k, 48);
+    const uint32_t k01 = k0 < k1 ? k0 : k1, k23 = k2 < k3 ? k2 : k3, kmin = k01 < k23 ? k01 : k23;
+    NjlBest w;
+    w.val = m; w.dij = 0.0; w.i = 0x7fffffff; w.j = 0x7fffffff;
+    if (kmin != 0xFFFFFFFFu) {   // (wave-uniform)
+        const uint64_t who = __ballot(key == kmin);
+        const int lw = __builtin_ctzll(who);
+        w.dij = psk_readlane_f64(c.dij, lw);
+        w.i = (int)(kmin >> 16); w.j = (int)(kmin & 0xFFFFu);
+    } else w.val = INFINITY;
     __syncthreads();   // (the previous use of s_red is over)
-    if ((threadIdx.x & 63) == 0) s_red[threadIdx.x >> 6] = v;
+    if ((threadIdx.x & 63) == 0) s_red[threadIdx.x >> 6] = w;
     __syncthreads();
     NjlBest r = s_red[0];
 #pragma unroll
-    for (int w = 1; w < NJL_T / 64; w++) {
-        const NjlBest o = s_red[w];
-        if (njl_before(o, r)) r = o;
+    for (int q = 1; q < NJL_T / 64; q++) {
+        const NjlBest o2 = s_red[q];
+        if (njl_before(o2, r)) r = o2;
     }
     return r;
 }
