@@ -41,26 +41,55 @@ __global__ __launch_bounds__(256) void pd_or_kernel(const uint64_t *const *__res
     (void)n_words;
 }
 
-__device__ __forceinline__ uint64_t shfl_xor_u64(uint64_t v, int d)
+// 64 x 64 bit matrix, row l in lane l -> its transpose, row j in lane j: the recursive swap of the off-diagonal blocks, six
+// stages (block sizes 32 ... 1), WITHOUT the LDS (r04).  As xor-shuffles the partner's word cost two ds_bpermute per stage --
+// twelve per block, and the kernel was bound by them (2.4 TB/s).  On gfx950 the two stages that cross rows of 16 lanes are
+// lane-swap instructions: v_permlane32_swap(lo, hi) leaves {lo: own or partner's low dword, hi: ...} exactly as stage 32 wants
+// them (ONE instruction), v_permlane16_swap(d & 0xFFFF, d >> 16) hands every row the two halves it keeps, per dword; the four
+// stages inside a row fetch the partner's dword by DPP (quad permutations for xor 1 / 2; a row shift left in the banks whose
+// lanes have the bit clear and a row shift right in the others for xor 4 / 8) and merge with a rotate and a bit-field
+// insert whose per-lane mask says which half is kept.
+template <int J>
+__device__ __forceinline__ uint32_t pd_partner_dpp(uint32_t v)
 {
-    const uint32_t lo = (uint32_t)__shfl_xor((int)(uint32_t)v, d, 64);
-    const uint32_t hi = (uint32_t)__shfl_xor((int)(uint32_t)(v >> 32), d, 64);
-    return ((uint64_t)hi << 32) | lo;
+    const int x = (int)v;
+    if (J == 1) return (uint32_t)__builtin_amdgcn_update_dpp(x, x, 0xB1, 0xF, 0xF, false);   // quad_perm [1,0,3,2]
+    if (J == 2) return (uint32_t)__builtin_amdgcn_update_dpp(x, x, 0x4E, 0xF, 0xF, false);   // quad_perm [2,3,0,1]
+    if (J == 4) {
+        const int p = __builtin_amdgcn_update_dpp(x, x, 0x104, 0xF, 0x5, false);     // row_shl:4: lane l takes l + 4 (banks 0, 2)
+        return (uint32_t)__builtin_amdgcn_update_dpp(p, x, 0x114, 0xF, 0xA, false);  // row_shr:4: lane l takes l - 4 (banks 1, 3)
+    }
+    const int p = __builtin_amdgcn_update_dpp(x, x, 0x108, 0xF, 0x3, false);         // row_shl:8 (banks 0, 1)
+    return (uint32_t)__builtin_amdgcn_update_dpp(p, x, 0x118, 0xF, 0xC, false);      // row_shr:8 (banks 2, 3)
 }
-
-// 64 x 64 bit matrix, row l in lane l -> its transpose, row j in lane j (recursive swap of the off-diagonal blocks)
+template <int J>
+__device__ __forceinline__ uint32_t pd_stage_dpp(uint32_t a, int lane)
+{
+    constexpr uint32_t M = J == 8 ? 0x00FF00FFu : J == 4 ? 0x0F0F0F0Fu : J == 2 ? 0x33333333u : 0x55555555u;
+    const uint32_t p = pd_partner_dpp<J>(a);
+    const bool odd = (lane & J) != 0;
+    const uint32_t s = __builtin_amdgcn_alignbit(p, p, odd ? J : 32 - J);   // bit clear: p << J, set: p >> J (as rotations: the mask drops what wraps)
+    const uint32_t mk = odd ? ~M : M;
+    return (mk & a) | (~mk & s);
+}
 __device__ __forceinline__ uint64_t transpose64(uint64_t a, int lane)
 {
-    const uint64_t masks[6] = {0x00000000FFFFFFFFull, 0x0000FFFF0000FFFFull, 0x00FF00FF00FF00FFull,
-                               0x0F0F0F0F0F0F0F0Full, 0x3333333333333333ull, 0x5555555555555555ull};
-#pragma unroll
-    for (int st = 0; st < 6; st++) {
-        const int j = 32 >> st;
-        const uint64_t m = masks[st];
-        const uint64_t p = shfl_xor_u64(a, j);
-        a = (lane & j) ? (((p >> j) & m) | (a & ~m)) : ((a & m) | ((p & m) << j));
+    uint32_t lo = (uint32_t)a, hi = (uint32_t)(a >> 32);
+    {
+        const auto r = __builtin_amdgcn_permlane32_swap(lo, hi, false, false);
+        lo = r[0]; hi = r[1];
     }
-    return a;
+    {
+        const auto r = __builtin_amdgcn_permlane16_swap(lo & 0xFFFFu, lo >> 16, false, false);
+        lo = r[0] | (r[1] << 16);
+        const auto q = __builtin_amdgcn_permlane16_swap(hi & 0xFFFFu, hi >> 16, false, false);
+        hi = q[0] | (q[1] << 16);
+    }
+    lo = pd_stage_dpp<8>(lo, lane); hi = pd_stage_dpp<8>(hi, lane);
+    lo = pd_stage_dpp<4>(lo, lane); hi = pd_stage_dpp<4>(hi, lane);
+    lo = pd_stage_dpp<2>(lo, lane); hi = pd_stage_dpp<2>(hi, lane);
+    lo = pd_stage_dpp<1>(lo, lane); hi = pd_stage_dpp<1>(hi, lane);
+    return ((uint64_t)hi << 32) | lo;
 }
 
 __global__ __launch_bounds__(PD_THREADS) void pd_transpose_kernel(const uint64_t *const *__restrict__ bitmaps, int n, int wpr,
