@@ -732,6 +732,136 @@ def gen_mash():
     print("mash sketches:", [len(s["hashes"]) for s in out["samples"]])
 
 
+def gen_gsc_kat():
+    """the parts of the -w path that ARE reference code, run as the reference runs them (through
+    ref_shim.load_modeling(), nothing altered):
+      plumbing  Samples.get_mash_sketches (:386-390), get_mash_distances (:402-412; bin/mash 2.2 from /root/reference/bin),
+                _mash_output_to_distance_matrix (:415-428) and _distance_matrix_modifier (:431-444) on small genome sets:
+                one whose data.pheno is name-sorted, one that is not (the rows of distances.mat are then labelled with
+                the wrong samples: mash paste takes K-mer_lists/*.msh in glob order, the labels come in pheno order) and
+                whose names sort differently with and without the '.msh' suffix;
+      gsc       Samples.GSC_weights_from_newick(path, normalize="mean1") (:461-476 -> clip_branch_lengths /
+                set_branch_sum / set_node_weight :478-503) on newick texts: hand-written ones (two leaves, a three-child
+                root, zero / negative / huge branch lengths, a caterpillar) and neighbour-joining trees of 3 ... 200
+                leaves.  ete3 is absent: the Tree the reference instantiates at :465 is oracle_weights.Tree -- OUR
+                newick parser and node class; every number after the parse is computed by the reference's functions;
+      chains    plumbing -> (neighbour joining + "%1.5f" newick: oracle_weights.nj_newick, OURS, Biopython is absent --
+                parity unpinned for that link) -> gsc, per genome set: the weights a `-w` run must end up with.
+    """
+    import ref_shim
+    import oracle_weights as OW
+    M = ref_shim.load_modeling()
+    M.Tree = OW.Tree
+    env_run = lambda cmd, cwd: subprocess.run(cmd, shell=True, cwd=cwd, env=ENV, capture_output=True, text=True)
+    os.environ["PATH"] = ENV["PATH"]           # the reference shells out to `mash` by name
+    out = {"source": "PhenotypeSeeker.modeling.Samples.{get_mash_sketches, get_mash_distances, _mash_output_to_distance_matrix, "
+                     "_distance_matrix_modifier, GSC_weights_from_newick} (modeling.py:386-503) through oracle/ref_shim.py; mash 2.2 "
+                     "(reference bin/).  NOT the reference's: the newick parser / Tree class (oracle_weights.Tree in ete3.Tree's "
+                     "place) and, in 'chains', the neighbour joining + newick text (oracle_weights.nj_newick in Biopython's place).",
+           "plumbing": [], "gsc": [], "chains": {}}
+
+    def plumbing(tag, names, fastas):
+        tmp = tempfile.mkdtemp(prefix="psk_gsc_")
+        cwd = os.getcwd()
+        os.chdir(tmp)
+        try:
+            os.makedirs("K-mer_lists")
+            M.Input.samples = M.OrderedDict()
+            M.Samples.no_samples = 0
+            for nm, fa in zip(names, fastas):
+                addr = nm + (".fastq" if fa[:1] == b"@" else ".fasta")
+                with open(addr, "wb") as f:
+                    f.write(fa)
+                M.Input.samples[nm] = M.Samples(nm, addr, {"P": 1}, 1)
+            for smp in M.Input.samples.values():
+                smp.get_mash_sketches()
+            hashes = {nm: json.loads(env_run("mash info -d K-mer_lists/%s.msh" % nm, tmp).stdout)["sketches"][0]["hashes"]
+                      for nm in names}
+            M.Samples.get_mash_distances()
+            M.Samples._mash_output_to_distance_matrix(list(M.Input.samples.keys()), "mash_distances.mat")
+            lower = M.Samples._distance_matrix_modifier("distances.mat")
+            rec = {"tag": tag, "names": list(names), "hashes": hashes,
+                   "fasta_gz_b64": {nm: b64(gzip.compress(fa, mtime=0)) for nm, fa in zip(names, fastas)},
+                   "mash_distances_mat": open("mash_distances.mat").read(), "distances_mat": open("distances.mat").read(),
+                   "lower_triangle": lower}
+        finally:
+            os.chdir(cwd)
+            shutil.rmtree(tmp, ignore_errors=True)
+        return rec
+
+    def gsc(newick, note):
+        with tempfile.TemporaryDirectory() as tmp:
+            path = os.path.join(tmp, "tree_newick.txt")
+            with open(path, "w") as f:
+                f.write(newick)
+            w = M.Samples.GSC_weights_from_newick(path, normalize="mean1")
+        return {"note": note, "newick": newick, "weights": {k: float(v) for k, v in w.items()}}
+
+    def chain(rec):
+        names = rec["names"]
+        full = [[0.0] * len(names) for _ in names]
+        for i, row in enumerate(rec["lower_triangle"]):
+            for j, v in enumerate(row):
+                full[i][j] = full[j][i] = v
+        nw = OW.nj_newick(names, full)
+        g = gsc(nw, "chain " + rec["tag"])
+        return {"names": names, "newick": nw, "weights": g["weights"]}
+
+    gs = GenomeSet(6, 9000, seed=301, gene_len=300)
+    out["plumbing"].append(plumbing("sorted6", [gs.name(i) for i in range(6)], [gs.sample(i)[1] for i in range(6)]))
+    gs = GenomeSet(9, 8000, seed=302, gene_len=300, sub_rate=0.01)
+    odd = ["zeta", "alpha", "S1", "S1-2", "S1+x", "mid", "Beta", "beta", "a_b"]
+    fas = []
+    for i, nm in enumerate(odd):
+        fa = gs.sample(i)[1]
+        if nm == "mid":       # a distant sample: no shared hashes with some of the others
+            fa = GenomeSet(1, 8000, seed=999).sample(0)[1]
+        fas.append(fa)
+    out["plumbing"].append(plumbing("shuffled9", odd, fas))
+    # the e2e set of the GPU tests (20 samples, one of them FASTQ reads), as the reference's `-w` sees it
+    from helpers_golden import load_dataset_files
+    names, files = load_dataset_files(os.path.join(GOLD, "ds_omitB"))
+    rec = plumbing("ds_omitB", names, [files[nm] for nm in names])
+    rec.pop("fasta_gz_b64")                    # the inputs are tests/golden/ds_omitB/*.gz
+    out["plumbing"].append(rec)
+    for rec in out["plumbing"]:
+        out["chains"][rec["tag"]] = chain(rec)
+
+    hand = [
+        ("(A:1,B:2);", "two leaves"),
+        ("(A:0.5,B:0.5)Inner:0.00000;", "two leaves as Biopython roots them"),
+        ("(A:1,B:2,C:3)Inner1:0.00000;", "three-child root"),
+        ("((A:1,B:2)Inner1:1.5,(C:1,D:3)Inner2:0.5);", "two cherries"),
+        ("((A:0.00000,B:0.00000)Inner1:0.00000,C:0.01234,D:0.00000)Inner2:0.00000;", "zero lengths: all clipped to 1e-9"),
+        ("((A:-0.00012,B:0.00410)Inner1:0.00100,C:-0.00001,D:0.02000)Inner2:0.00000;", "negative lengths (NJ produces them): clipped"),
+        ("((A:2e9,B:1)Inner1:3e10,C:5)Inner2:0;", "lengths above 1e9: clipped"),
+        ("((((A:1,B:1)I1:1,C:1)I2:1,D:1)I3:1,E:1)I4:0;", "caterpillar"),
+        ("((A:0.1,B:0.2,C:0.3,D:0.4)I1:0.5,E:0.6)I2:0;", "four-child inner node"),
+        ("(A:1e-9,B:1e-9,C:1e-9)R:0;", "lengths at the lower clip"),
+        ("((A:0.00001,B:0.00001)Inner1:0.00001,(C:0.12345,D:0.54321)Inner2:0.33333,E:0.99999)Inner3:0.00000;", "five digits"),
+        ("((A,B)I1,C)I2;", "no lengths at all: the parser's defaults (1.0; root 0.0)"),
+    ]
+    for nw, note in hand:
+        out["gsc"].append(gsc(nw, note))
+    rng = np.random.default_rng(606)
+    for n in (3, 4, 5, 6, 7, 8, 10, 13, 17, 24, 33, 50, 77, 100, 150, 200):
+        for kind in ("mash-like", "ties", "clonal"):
+            if kind == "mash-like":
+                half = np.array([[float("%g" % v) for v in row] for row in rng.random((n, n)) * 0.1])
+            elif kind == "ties":
+                half = rng.choice([0.0, 0.001, 0.002, 0.0153, 1.0], (n, n))
+            else:                 # a few clones + noise of the size of mash's 6th digit: near-zero and negative branches
+                grp = rng.integers(0, max(2, n // 4), n)
+                half = np.where(grp[:, None] == grp[None, :], 0.0, 0.02) + np.round(rng.random((n, n)) * 1e-4, 6)
+            m = np.tril(half, -1)
+            m = m + m.T
+            nw = OW.nj_newick(["s%d" % i for i in range(n)], m)
+            out["gsc"].append(gsc(nw, "neighbour joining (oracle_weights.nj_newick) of a %s %d x %d matrix" % (kind, n, n)))
+    with open(os.path.join(GOLD, "gsc_kat.json"), "w") as f:
+        json.dump(out, f)
+    print("gsc KATs: plumbing", [r["tag"] for r in out["plumbing"]], "gsc cases", len(out["gsc"]), "chains", list(out["chains"]))
+
+
 def gen_split():
     """modeling.py:924-934: train_test_split(ML_df, test_size, random_state=55, stratify=...)."""
     from sklearn.model_selection import train_test_split
@@ -757,7 +887,7 @@ def gen_split():
 
 if __name__ == "__main__":
     os.makedirs(GOLD, exist_ok=True)
-    what = sys.argv[1:] or ["tok", "ds", "chi2", "welch", "model", "model_l2", "model_mid", "gmer", "mash", "split"]
+    what = sys.argv[1:] or ["tok", "ds", "chi2", "welch", "model", "model_l2", "model_mid", "gmer", "mash", "split", "gsc"]
     if "tok" in what:
         gen_tokenizer_cases()
     if "ds" in what:
@@ -790,3 +920,5 @@ if __name__ == "__main__":
         gen_mash()
     if "split" in what:
         gen_split()
+    if "gsc" in what:
+        gen_gsc_kat()

@@ -619,3 +619,65 @@ int orc_lasso_fit(const double *X, const double *y, int n, int p, double alpha, 
     free(Xc); free(xm); free(norms); free(r); free(w);
     return sweep;
 }
+
+/* ------------------------------------------------------------------------------------------
+ * 7. Neighbour joining of the -w path (Samples._distance_matrix_to_phyloxml, modeling.py:447-452:
+ *    Bio.Phylo.TreeConstruction.DistanceTreeConstructor().nj(dm)).
+ *    THIRD PARTY, ABSENT HERE: Biopython 1.76 (pinned in the reference's install notes) is not
+ *    installed in the build container and not vendored under /root/reference, so this is a
+ *    restatement of the library's published algorithm (Saitou & Nei 1987 in the form of
+ *    Bio/Phylo/TreeConstruction.py: node_dist[i] = (sum_j d[i][j]) / (m - 2); the pair (i, j), j < i,
+ *    that minimises d[i][j] - node_dist[i] - node_dist[j], scanned i ascending then j ascending
+ *    and replaced on a STRICTLY smaller value only, the scan starting from the pair (1, 0) taken
+ *    with min_i = 0, min_j = 1; branch of the first clade (d + nd[i] - nd[j]) / 2, of the second
+ *    d - that; the joined node takes index min_j with d[min_j][k] = (d[min_i][k] + d[min_j][k]
+ *    - d[min_i][min_j]) / 2, index min_i is deleted) -- PARITY UNPINNED for ties and rounding.
+ *    It exists so that the GPU kernels (csrc/nj.hip) and the product's host loop
+ *    (phenotypeseeker_amd/weights.py::nj) are compared with something that is neither.
+ *    Plain O(n^3) loops on a full n x n copy; sums left to right; -ffp-contract=off.
+ *    mi/mj/d1/d2: n - 2 joins (indices into the CURRENT clade list); *last: the distance of
+ *    the two clades that remain.  n >= 3.
+ * ------------------------------------------------------------------------------------------ */
+int orc_nj(int n, const double *mat, int32_t *mi_out, int32_t *mj_out, double *d1_out, double *d2_out, double *last)
+{
+    if (n < 3) return -1;
+    double *d = (double *)malloc(sizeof(double) * (size_t)n * n);
+    double *nd = (double *)malloc(sizeof(double) * (size_t)n);
+    if (!d || !nd) { free(d); free(nd); return -2; }
+    memcpy(d, mat, sizeof(double) * (size_t)n * n);
+    int m = n, t = 0;
+    /* d is kept as an m x m matrix with row stride n */
+    while (m > 2) {
+        for (int i = 0; i < m; i++) {
+            double s = 0.0;
+            for (int j = 0; j < m; j++) s += d[(size_t)i * n + j];
+            nd[i] = s / (double)(m - 2);
+        }
+        double min_dist = d[(size_t)1 * n + 0] - nd[1] - nd[0];
+        int min_i = 0, min_j = 1;
+        for (int i = 1; i < m; i++)
+            for (int j = 0; j < i; j++) {
+                double temp = d[(size_t)i * n + j] - nd[i] - nd[j];
+                if (min_dist > temp) { min_dist = temp; min_i = i; min_j = j; }
+            }
+        double dij = d[(size_t)min_i * n + min_j];
+        double b1 = (dij + nd[min_i] - nd[min_j]) / 2.0;
+        mi_out[t] = min_i; mj_out[t] = min_j; d1_out[t] = b1; d2_out[t] = dij - b1;
+        t++;
+        for (int k = 0; k < m; k++)
+            if (k != min_i && k != min_j) {
+                double v = (d[(size_t)min_i * n + k] + d[(size_t)min_j * n + k] - dij) / 2.0;
+                d[(size_t)min_j * n + k] = v;
+                d[(size_t)k * n + min_j] = v;
+            }
+        /* delete row and column min_i */
+        for (int i = min_i; i < m - 1; i++)
+            for (int j = 0; j < m; j++) d[(size_t)i * n + j] = d[(size_t)(i + 1) * n + j];
+        for (int i = 0; i < m - 1; i++)
+            for (int j = min_i; j < m - 1; j++) d[(size_t)i * n + j] = d[(size_t)i * n + j + 1];
+        m--;
+    }
+    *last = d[(size_t)1 * n + 0];
+    free(d); free(nd);
+    return 0;
+}

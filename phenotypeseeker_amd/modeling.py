@@ -217,12 +217,14 @@ class Samples:
             stderr_print.print_progress("lists generated.")
 
     @classmethod
-    def get_weights(cls, ctx):
+    def get_weights(cls, ctx, write_files=True):
         """was: mash paste / mash dist -> NJ tree -> GSC weights (:392-503); the pairwise sketch comparison runs
-        on the GPU (psk_mash_pairs)"""
+        on the GPU (psk_mash_pairs).  Like the reference the run leaves `distances.mat` (:415-428) and
+        `tree_newick.txt` (:455-458) in the working directory (rank 0 writes them)."""
         from . import weights as _w
         names = list(Input.samples.keys())
-        w, cls.tree = _w.weights_from_sketches(names, {n: Input.samples[n].sketch for n in names}, ctx=ctx)
+        w, cls.tree = _w.weights_from_sketches(names, {n: Input.samples[n].sketch for n in names}, ctx=ctx,
+                                               files_dir="." if write_files else None)
         for name, value in w.items():
             Input.samples[name].weight = value
 
@@ -945,7 +947,7 @@ def modeling(args):
             if Samples.use_weights:
                 _err("\n" + GREEN % "Estimating the Mash distances between samples..." + "\n")
                 stderr_print(GREEN % "Calculating the GSC weights from mash distance matrix...")
-                Samples.get_weights(ctx)
+                Samples.get_weights(ctx, write_files=group.rank == 0)
                 ph_t.mark("weights: sketches, distances, NJ, GSC")
             phenotypes.kmer_testing_setup(group.allreduce_sum(int(m_local)))
             ph_t.mark("all-reduce of the union size")

@@ -74,7 +74,7 @@ def distance_matrix(names, sketches, k=21, sketch_size=1000, ctx=None):
     pheno file is not sorted by sample name the labels are permuted.  Reproduced here.
     With an engine context the N(N+1)/2 sketch merges run on the GPU (psk_mash_pairs) -- what modeling.py
     does; the host loop below serves the CPU-only tests."""
-    by_file = sorted(names)
+    by_file = glob_order(names)
     n = len(names)
     if ctx is not None:
         common, denom = ctx.mash_pairs([sketches[nm] for nm in by_file], sketch_size)
@@ -85,6 +85,28 @@ def distance_matrix(names, sketches, k=21, sketch_size=1000, ctx=None):
             d = mash_distance(sketches[by_file[r]], sketches[by_file[c]], k, sketch_size)[0]
             mat[r][c] = mat[c][r] = d
     return list(names), mat
+
+
+def glob_order(names):
+    """The order in which `mash paste reference.msh K-mer_lists/*.msh` (:406) takes the sketches: the shell sorts the
+    FILE names, <name>.msh, bytewise (C locale) -- "S1-2.msh" comes before "S1.msh" although "S1" < "S1-2"."""
+    return sorted(names, key=lambda nm: (nm + ".msh").encode())
+
+
+def lower_triangle(mat):
+    """The rows Bio's _DistanceMatrix takes: row i = its first i + 1 entries (_distance_matrix_modifier, :431-444)."""
+    return [[float(mat[i][j]) for j in range(i + 1)] for i in range(len(mat))]
+
+
+def distances_mat_text(labels, mat):
+    """`distances.mat` as _mash_output_to_distance_matrix writes it (:415-428): per row the label, then a tab and the
+    distance as `mash dist` printed it (C++ stream default: "%g") for every column; rows joined by a newline, none at
+    the end."""
+    import numpy as np
+    m = np.asarray(mat, dtype=np.float64).reshape(len(labels), len(labels))
+    uniq, inverse = np.unique(m.ravel(), return_inverse=True)        # (a million cells hold a few thousand distinct values)
+    cells = np.array(["\t%g" % v for v in uniq], dtype=object)[inverse].reshape(m.shape)
+    return "\n".join(labels[i] + "".join(cells[i]) for i in range(len(labels)))
 
 
 class _Node:
@@ -178,12 +200,18 @@ def _nj_root(clades, inner, last):
 
 
 def _walk(node, order="pre"):
-    if order == "pre":
-        yield node
-    for c in node.children:
-        yield from _walk(c, order)
-    if order == "post":
-        yield node
+    """Depth first, children left to right; without recursion (a neighbour-joining tree of a clonal set is a
+    caterpillar as deep as it has leaves)."""
+    stack = [(node, 0)]
+    while stack:
+        nd, k = stack.pop()
+        if k == 0 and order == "pre":
+            yield nd
+        if k < len(nd.children):
+            stack.append((nd, k + 1))
+            stack.append((nd.children[k], 0))
+        elif order == "post":
+            yield nd
 
 
 def newick_round_trip(root):
@@ -194,28 +222,93 @@ def newick_round_trip(root):
 
 
 def to_newick(root):
-    def rec(nd):
-        inner = "(" + ",".join(rec(c) for c in nd.children) + ")" if nd.children else ""
-        return "%s%s:%1.5f" % (inner, nd.name, nd.dist)
-    return rec(root) + ";"
+    text = {}
+    for nd in _walk(root, "post"):
+        inner = "(" + ",".join(text.pop(id(c)) for c in nd.children) + ")" if nd.children else ""
+        text[id(nd)] = "%s%s:%1.5f" % (inner, nd.name, nd.dist)
+    return text[id(root)] + ";"
+
+
+def from_newick(text):
+    """Newick text with internal node names and branch lengths (what Bio.Phylo.convert leaves in tree_newick.txt and
+    ete3.Tree(path, format=1) reads back, :455-465) -> the tree of _Node.  A node without a length gets ete3's
+    defaults: 1.0, the root 0.0."""
+    text = text.strip()
+    if not text.endswith(";"):
+        raise ValueError("newick text must end with ';'")
+    root = cur = _Node("", 0.0)
+    stack = []
+    i, n = 0, len(text) - 1
+    while i < n:
+        ch = text[i]
+        if ch == "(" or ch == ",":
+            if ch == "(":
+                stack.append(cur)
+            elif not stack:
+                raise ValueError("newick: ',' outside of parentheses")
+            child = _Node("", 1.0)
+            stack[-1].add(child)
+            cur = child
+            i += 1
+        elif ch == ")":
+            if not stack:
+                raise ValueError("newick: unbalanced ')'")
+            cur = stack.pop()
+            i += 1
+        else:
+            j = i
+            while j < n and text[j] not in "(),":
+                j += 1
+            label = text[i:j]
+            if ":" in label:
+                label, length = label.rsplit(":", 1)
+                cur.dist = float(length)
+            cur.name = label.strip()
+            i = j
+    if stack:
+        raise ValueError("newick: unbalanced '('")
+    return root
 
 
 def gsc_weights(root, min_val=1e-9, max_val=1e9):
-    """Leaf name -> GSC weight scaled to mean 1 (normalize='mean1', :461-503)."""
+    """Leaf name -> GSC weight scaled to mean 1 (GSC_weights_from_newick(normalize='mean1'), :461-503).  The same
+    IEEE operations in the same order as clip_branch_lengths / set_branch_sum / set_node_weight: a node's BranchSum is
+    ((0 + c1.BranchSum) + c1.dist) + c2.BranchSum ... over its children left to right; pinned bit for bit by
+    tests/golden/gsc_kat.json (the reference's functions on the same trees)."""
     for nd in _walk(root):
-        nd.dist = min(max(nd.dist, min_val), max_val)
+        if nd.dist > max_val:
+            nd.dist = max_val
+        elif nd.dist < min_val:
+            nd.dist = min_val
     for nd in _walk(root, "post"):
-        nd.BranchSum = sum(c.BranchSum + c.dist for c in nd.children)
+        total = 0
+        for c in nd.children:
+            total += c.BranchSum
+            total += c.dist
+        nd.BranchSum = total
     for nd in _walk(root):
         if nd.up is None:
             nd.NodeWeight = 1.0
         else:
             nd.NodeWeight = nd.up.NodeWeight * (nd.dist + nd.BranchSum) / nd.up.BranchSum
-    leaves = [nd for nd in _walk(root) if not nd.children]
-    return {nd.name: nd.NodeWeight * len(leaves) for nd in leaves}
+    weights = {}
+    for nd in _walk(root):
+        if not nd.children:
+            weights[nd.name] = nd.NodeWeight
+    return {k: v * len(weights) for k, v in weights.items()}
 
 
-def weights_from_sketches(names, sketches, k=21, sketch_size=1000, ctx=None):
+def weights_from_sketches(names, sketches, k=21, sketch_size=1000, ctx=None, files_dir=None):
+    """Samples.get_weights (:392-400).  files_dir: where to leave `distances.mat` and `tree_newick.txt`, the two
+    intermediate files of the reference's chain that are its own formats (mash_distances.mat / reference.msh /
+    tree_xml.txt are Mash's and Biopython's)."""
+    import os
     labels, mat = distance_matrix(names, sketches, k, sketch_size, ctx)
+    if files_dir is not None:
+        with open(os.path.join(files_dir, "distances.mat"), "w") as f:
+            f.write(distances_mat_text(labels, mat))
     tree = newick_round_trip(nj(labels, mat, ctx))
+    if files_dir is not None:
+        with open(os.path.join(files_dir, "tree_newick.txt"), "w") as f:
+            f.write(to_newick(tree) + "\n")
     return gsc_weights(tree), tree

@@ -283,25 +283,28 @@ def test_continuous_phenotype_end_to_end(tmp_path, oracle):
 
 def test_weighted_modeling_end_to_end(tmp_path, oracle):
     """-w: GPU MinHash sketches -> Mash distances -> NJ -> GSC weights -> weighted chi2 scan.
-    The weights the CLI used must equal the ones derived from the oracle's sketches, and the written
-    rows must equal the oracle's weighted scan with those weights."""
-    from oracle import oracle_weights as OW
-    from phenotypeseeker_amd import modeling as M, weights as W
+    The weights the CLI used must equal tests/golden/gsc_kat.json's chain for this genome set -- real `mash`, the
+    reference's own distance-matrix plumbing and GSC recursion (modeling.py:386-444, :461-503), the oracle's neighbour
+    joining between them -- `distances.mat` must be the reference's file byte for byte, and the written rows must equal
+    the oracle's weighted scan with those weights."""
+    import json
+    from helpers import GOLDEN
+    from phenotypeseeker_amd import modeling as M
+    with open(os.path.join(GOLDEN, "gsc_kat.json")) as f:
+        kat = json.load(f)
     ds = load_dataset("ds_omitB")
     _write_dataset(ds, str(tmp_path))
     _run(tmp_path, ["modeling", "data.pheno", "-w", "--omit_B_correction", "--n_kmers", "100"])
     names, n, k = ds["names"], len(ds["names"]), ds["meta"]["k"]
     got_w = [M.Input.samples[nm].weight for nm in names]
-    # sample 5 is FASTQ in this dataset: the oracle sketch works on FASTA text, so sketch the reads' sequences
-    sk = {}
-    for nm in names:
-        data = ds["files"][nm]
-        if data[:1] == b"@":
-            lines = data.decode().split("\n")
-            data = "".join(">r\n%s\n" % lines[i + 1] for i in range(0, len(lines) - 1, 4)).encode()
-        sk[nm] = OW.sketch(data)
-    want_w, _ = W.weights_from_sketches(names, sk)
-    assert np.allclose(got_w, [want_w[nm] for nm in names], rtol=1e-12)
+    plumbing = next(r for r in kat["plumbing"] if r["tag"] == "ds_omitB")
+    chain = kat["chains"]["ds_omitB"]
+    assert chain["names"] == names
+    for nm in names:      # the GPU sketches are mash's (sample 5 is FASTQ reads: `mash sketch -r` takes them as they are)
+        assert M.Input.samples[nm].sketch == plumbing["hashes"][nm], nm
+    assert open("distances.mat").read() == plumbing["distances_mat"]
+    assert open("tree_newick.txt").read() == chain["newick"] + "\n"
+    assert got_w == [chain["weights"][nm] for nm in names]
     assert sum(got_w) == pytest.approx(n) and max(got_w) > 1.0 > min(got_w)
     wl = [oracle.count_kmers(ds["files"][nm], k)[0] for nm in names]
     uw = oracle.union(wl)

@@ -1,6 +1,9 @@
-"""-w path: MinHash sketches and Mash distances against the bundled mash binary's output
-(tests/golden/mash.json); neighbour joining + GSC weights on properties (their third-party
-implementations, Biopython / ete3, are absent: parity unpinned)."""
+"""-w path.  MinHash sketches and Mash distances against the bundled mash binary's output (tests/golden/mash.json);
+the distance-matrix plumbing and the GSC recursion against what the REFERENCE'S OWN functions returned
+(tests/golden/gsc_kat.json: modeling.py:415-444 and :461-503 run through oracle/ref_shim.py, generator
+oracle/gen_golden.py::gen_gsc_kat); neighbour joining against the oracle's plain O(n^3) restatement (orc_nj) --
+Biopython / ete3 themselves are absent, so the joins' tie-breaking, the "%1.5f" newick text and the parser's defaults
+stay PARITY UNPINNED."""
 import base64
 import gzip
 import json
@@ -50,6 +53,93 @@ def test_distance_matrix_reproduces_the_glob_order_labelling():
     assert labels == ["b", "a", "c"]           # labels in data.pheno order ...
     d_ab = W.mash_distance(sk["a"], sk["b"], 21, 4)[0]
     assert mat[0][1] == d_ab and mat[0][2] == 1.0 and mat[1][2] == 1.0   # ... rows in file-name order a, b, c
+
+
+@pytest.fixture(scope="module")
+def gsc_kat():
+    with open(os.path.join(GOLDEN, "gsc_kat.json")) as f:
+        return json.load(f)
+
+
+def _rnd_matrix(n, rng, kind):
+    if kind == "ties":
+        half = rng.choice([0.0, 0.001, 0.002, 0.0153, 1.0], (n, n))
+    else:
+        half = np.round(rng.random((n, n)) * 0.1, 6)
+    mat = np.tril(half, -1)
+    return mat + mat.T
+
+
+def test_distance_plumbing_equals_the_reference(gsc_kat):
+    """distances.mat byte for byte and the lower triangle handed to the tree builder `==` what
+    Samples._mash_output_to_distance_matrix / _distance_matrix_modifier (modeling.py:415-444) produced from the real
+    `mash dist` table -- including the set whose pheno order is not the glob order (permuted labels, the reference's
+    behaviour) and whose names order differently with the '.msh' suffix."""
+    from phenotypeseeker_amd import weights as W
+    assert {r["tag"] for r in gsc_kat["plumbing"]} >= {"sorted6", "shuffled9", "ds_omitB"}
+    for r in gsc_kat["plumbing"]:
+        labels, mat = W.distance_matrix(r["names"], r["hashes"])
+        assert W.distances_mat_text(labels, mat) == r["distances_mat"], r["tag"]
+        assert W.lower_triangle(mat) == r["lower_triangle"], r["tag"]
+        # the third column of the mash table, row-major, is the matrix
+        col3 = [float(l.split("\t")[2]) for l in r["mash_distances_mat"].strip().split("\n")]
+        assert np.array_equal(np.asarray(mat, dtype=np.float64).ravel(), np.array(col3)), r["tag"]
+    shuffled = next(r for r in gsc_kat["plumbing"] if r["tag"] == "shuffled9")
+    assert W.glob_order(shuffled["names"]) != sorted(shuffled["names"]) != shuffled["names"]
+
+
+def test_gsc_weights_equal_the_reference_bit_for_bit(gsc_kat):
+    """Samples.GSC_weights_from_newick(normalize='mean1') (modeling.py:461-503) on 60 trees -- 2 ... 200 leaves, a
+    three-child root, zero / negative / huge lengths (the clip), caterpillars: the same doubles (the tolerance the verdict
+    asked for is 1e-12 relative; the sums are taken in the reference's order, so it is 0)."""
+    from phenotypeseeker_amd import weights as W
+    assert len(gsc_kat["gsc"]) >= 20
+    sizes = set()
+    for c in gsc_kat["gsc"]:
+        got = W.gsc_weights(W.from_newick(c["newick"]))
+        assert got == c["weights"], c["note"]
+        assert list(got) == list(c["weights"])          # leaves in the reference's iteration order
+        sizes.add(len(got))
+    assert min(sizes) == 2 and max(sizes) == 200
+
+
+def test_whole_weight_chain_equals_the_fixture(gsc_kat):
+    """hashes -> distances -> neighbour joining -> newick -> GSC: the tree text and the weights of the three genome
+    sets equal the chain [reference plumbing -> oracle NJ + newick -> reference GSC] of the fixture; and the two files a
+    `-w` run leaves behind are the reference's."""
+    import tempfile
+    from phenotypeseeker_amd import weights as W
+    for r in gsc_kat["plumbing"]:
+        c = gsc_kat["chains"][r["tag"]]
+        with tempfile.TemporaryDirectory() as tmp:
+            w, tree = W.weights_from_sketches(r["names"], r["hashes"], files_dir=tmp)
+            assert open(os.path.join(tmp, "distances.mat")).read() == r["distances_mat"]
+            assert open(os.path.join(tmp, "tree_newick.txt")).read() == c["newick"] + "\n"
+        assert W.to_newick(tree) == c["newick"], r["tag"]
+        assert w == c["weights"], r["tag"]
+
+
+def test_host_neighbour_joining_equals_the_oracle():
+    """weights.nj (numpy, the host form of the product) against orc_nj (plain C loops, oracle/psk_oracle.c section 7):
+    pairs, branch lengths and the last distance as written to newick, with ties everywhere and without."""
+    from oracle import oracle_weights as OW
+    from phenotypeseeker_amd import weights as W
+    rng = np.random.default_rng(12)
+    for n in (3, 4, 5, 6, 9, 17, 33, 64, 130, 257):
+        for kind in ("plain", "ties"):
+            mat = _rnd_matrix(n, rng, kind)
+            names = ["s%d" % i for i in range(n)]
+            assert W.to_newick(W.newick_round_trip(W.nj(names, mat.tolist()))) == OW.nj_newick(names, mat), (n, kind)
+
+
+def test_newick_reader_round_trips_and_rejects_garbage():
+    from phenotypeseeker_amd import weights as W
+    t = W.from_newick("((A:1,B:2)Inner1:1.5,(C:1,D:3)Inner2:0.5)Inner3:0.00000;\n")
+    assert W.to_newick(t) == "((A:1.00000,B:2.00000)Inner1:1.50000,(C:1.00000,D:3.00000)Inner2:0.50000)Inner3:0.00000;"
+    assert [c.name for c in t.children] == ["Inner1", "Inner2"] and t.children[0].up is t
+    for bad in ("(A:1,B:2)", "(A:1,B:2));", "((A:1,B:2);", "A:1,B:2;"):
+        with pytest.raises(ValueError):
+            W.from_newick(bad)
 
 
 def _tree_leaves(root):
@@ -178,9 +268,11 @@ def test_gpu_batch_sketch_equals_single_sketch(mash):
 
 
 @pytest.mark.gpu
-def test_gpu_neighbour_joining_is_bit_identical_to_the_host_loop():
-    """psk_nj_merges against weights.nj on the host: random matrices (Mash-like 6-digit values), matrices made
-    of a few repeated values (ties everywhere), sizes that cross the 1024-thread workgroup."""
+def test_gpu_neighbour_joining_is_bit_identical_to_the_oracle_and_the_host_loop():
+    """psk_nj_merges against the ORACLE's neighbour joining (orc_nj: plain C loops, nothing of the product in it) and
+    against weights.nj on the host: random matrices (Mash-like 6-digit values), matrices made of a few repeated values
+    (ties everywhere), sizes that cross the 1024-thread workgroup."""
+    from oracle import oracle_weights as OW
     import random
     import time
     from phenotypeseeker_amd import weights as W
@@ -202,7 +294,9 @@ def test_gpu_neighbour_joining_is_bit_identical_to_the_host_loop():
                     mat = rnd(n, seed, ties)
                     a = W.to_newick(W.newick_round_trip(W.nj(names, mat)))
                     b = W.to_newick(W.newick_round_trip(W.nj(names, mat, ctx)))
-                    assert a == b, (n, seed, ties)
+                    assert a == b == OW.nj_newick(names, mat), (n, seed, ties)
+                    for u, v in zip(ctx.nj_merges(mat), OW.nj_merges(mat)):
+                        assert np.array_equal(np.asarray(u), np.asarray(v)), (n, seed, ties)
                     assert W.gsc_weights(W.newick_round_trip(W.nj(names, mat))) == \
                         W.gsc_weights(W.newick_round_trip(W.nj(names, mat, ctx)))
         n = 1100
@@ -213,6 +307,8 @@ def test_gpu_neighbour_joining_is_bit_identical_to_the_host_loop():
         t_gpu = time.time() - t
         a = W.nj(names, mat)
         assert W.to_newick(a) == W.to_newick(b)
+        for u, v in zip(ctx.nj_merges(mat), OW.nj_merges(mat)):
+            assert np.array_equal(np.asarray(u), np.asarray(v))
         print("nj 1100 leaves: gpu path %.2f s" % t_gpu)
 
 
@@ -224,6 +320,7 @@ def test_gpu_neighbour_joining_on_many_workgroups_equals_the_one_workgroup_kerne
     blocks and of the load batches, with ties everywhere and without; and faster where it is the default (1,024 leaves:
     67 against 92 ms; 2,500: 0.4 against 1.2 s)."""
     import time
+    from oracle import oracle_weights as OW
     from phenotypeseeker_amd.engine import PskContext
     rng = np.random.default_rng(77)
     monkeypatch.setenv("PSK_NJ_GRID", "1")
@@ -246,6 +343,9 @@ def test_gpu_neighbour_joining_on_many_workgroups_equals_the_one_workgroup_kerne
                 monkeypatch.delenv("PSK_NJ_ONE_WG")
                 for u, v in zip(a, b):
                     assert np.array_equal(np.asarray(u), np.asarray(v)), (n, ties)
+                if n <= 1100:        # and both equal the oracle's plain loops (orc_nj: 0.6 s at 1,100 leaves)
+                    for u, w_ in zip(a, OW.nj_merges(mat)):
+                        assert np.array_equal(np.asarray(u), np.asarray(w_)), (n, ties, "oracle")
                 if n >= 1024:
                     assert t_grid < t_one, (n, t_grid, t_one)
 
@@ -258,6 +358,7 @@ def test_gpu_neighbour_joining_in_lds_equals_the_one_workgroup_kernel(monkeypatc
     sizes around every slice width (64 / 32 / 16 / 8 columns: up to 256 / 512 / 1,024 / 2,048 leaves), with ties everywhere
     and without, forced below its threshold for the smallest trees -- and several times faster where it is the default."""
     import time
+    from oracle import oracle_weights as OW
     from phenotypeseeker_amd.engine import PskContext
     rng = np.random.default_rng(99)
     monkeypatch.setenv("PSK_NJ_LDS_MIN", "3")
@@ -283,6 +384,9 @@ def test_gpu_neighbour_joining_in_lds_equals_the_one_workgroup_kernel(monkeypatc
                 for u, v, u2 in zip(a, b, a2):
                     assert np.array_equal(np.asarray(u), np.asarray(v)), (n, ties)
                     assert np.array_equal(np.asarray(u2), np.asarray(v)), (n, ties)
+                if n <= 1100 or (n == 2048 and not ties):     # the oracle's plain loops: 5 s at 2,048 leaves
+                    for u, w_ in zip(a, OW.nj_merges(mat)):
+                        assert np.array_equal(np.asarray(u), np.asarray(w_)), (n, ties, "oracle")
                 print("nj %d leaves%s: lds %.1f ms, one workgroup %.1f ms" % (n, " (ties)" if ties else "", 1e3 * t_lds, 1e3 * t_one))
                 if n >= 1024:
                     assert 3 * t_lds < t_one, (n, t_lds, t_one)
