@@ -276,9 +276,23 @@ def main():
     from phenotypeseeker_amd.engine import PskContext
     from phenotypeseeker_amd.synth import GenomeSet
 
+    from phenotypeseeker_amd import watchdog
+
     grp = psk_dist.Group()
     if grp.world != args.gpus:
         sys.exit("bench.py --gpus %d but WORLD_SIZE=%d in the environment" % (args.gpus, grp.world))
+    # a launch that runs into its deadline (launch.spawn_ranks: PSK_LAUNCH_TIMEOUT) asks every rank where it is: the rank
+    # answers SIGUSR1 with phases_rank<r>.json -- the phase and the call it is stuck in
+    t_proc = time.time()
+    done_phases = {}
+
+    def phase(name, _last=[None, t_proc]):
+        if _last[0] is not None:
+            done_phases[_last[0]] = round(done_phases.get(_last[0], 0.0) + time.time() - _last[1], 4)
+        _last[0], _last[1] = name, time.time()
+        watchdog.enter(name)
+    watchdog.install(grp.rank, grp.world, lambda: {"total_s": round(time.time() - t_proc, 4), "phases_s": dict(done_phases)})
+    phase("rendezvous, communicator (ncclCommInitRank)")
     if args.share_gpu:
         os.environ["PSK_SHARE_GPU"] = "1"     # ranks modulo the visible GPUs; opts into the host-file transport (tests)
     grp.init(force=args.force_exchange)       # RCCL, or an error: see dist._rccl_or_host_files
@@ -293,9 +307,11 @@ def main():
     n = args.samples if args.samples is not None else (2048 if sharded else 256)
     k = args.kmer if args.kmer is not None else (16 if sharded else 13)
 
+    phase("HIP runtime, context")
     ctx = PskContext(grp.device)
     info = ctx.device_info()
     t_setup = time.time()
+    phase("ingest: pilot, k-mer lists, list exchange")
     pheno = np.array([1 if i % 2 == 0 else 0 for i in range(n)], dtype=np.int8)
     ingest = {}
     shard = None
@@ -345,6 +361,7 @@ def main():
                 t_cnt += t2 - t1
                 call_s.append(round(t2 - t1, 4))
                 tot_unique += sum(nus)
+        phase("presence matrix")
         t0 = time.time()
         M = ctx.build_presence()
         t_build = time.time() - t0
@@ -365,6 +382,7 @@ def main():
     _, wpr, _ = ctx.presence_shape()
     t_setup = time.time() - t_setup
 
+    phase("all-reduce of the union size")
     M_global = grp.allreduce_sum(int(M))
     rows_per_rank = [int(x) for x in grp.allgather_i64(np.array([int(M)]))[:, 0]]
 
@@ -391,6 +409,7 @@ def main():
     # Untimed, before the W warm-up steps: ~40 ms of back-to-back scans so that the GPU's clocks have settled.  The
     # ingest ends with a few light kernels; measured right after it, the first ~50 scans run 4-5 % slower than the
     # steady state (r01: 117-121 us against 111-112 us per launch, the same for a 1000-step run either way).
+    phase("clock-settling scans")
     ctx.chi2_scan(*scan_args)          # the first launch also loads the kernel's code object
     warm_ms = ctx.rescan_timed(3)
     ctx.rescan_timed(int(min(300, max(3, 40.0 / max(warm_ms, 0.01)))))
@@ -417,16 +436,19 @@ def main():
                     xch.wait(pending.pop(0))
         return npass, ms_all
 
+    phase("warm-up steps (scan + survivors' all-gather)")
     npass, _ = run_steps(args.warmup) if args.warmup > 0 else (0, [])
     if xch is not None:
         drain(0)
     grp.barrier()
+    phase("timed steps (scan + survivors' all-gather)")
     t0 = time.perf_counter()
     npass, kernel_ms = run_steps(args.steps)
     if xch is not None:
         drain(0)   # the last exchange completes inside the timed region
     grp.barrier()
     elapsed = time.perf_counter() - t0
+    phase("reductions of the result line, roofline, CPU baseline, e2e leg")
     elapsed = grp.allreduce_max(elapsed)
     cells_total = grp.allreduce_sum(int(M) * n) * args.steps
     value = cells_total / elapsed

@@ -862,6 +862,78 @@ def gen_gsc_kat():
     print("gsc KATs: plumbing", [r["tag"] for r in out["plumbing"]], "gsc cases", len(out["gsc"]), "chains", list(out["chains"]))
 
 
+def gen_model_files():
+    """the a11 artefacts as the REFERENCE writes them (modeling.py:975-988 model package, :1219-1412 summary,
+    :1414-1455 coefficient table), kept under tests/golden/<set>/model/:
+      ds_omitB, ds_bonf   the whole unmodified pipeline again (its chi2 tables and _MLdf.csv must equal the committed ones),
+                          keeping summary_of_log_reg_analysis_Pheno.txt, k-mers_and_coefficients_in_log_reg_model_Pheno.txt
+                          and log_reg_model_Pheno.pkl (liblinear is unseeded there: grid scores / C / coefficients are ONE
+                          draw; the .pkl is that draw's fitted GridSearchCV, so the text files can be re-derived from it);
+      ds_cont             `modeling data.pheno -jt modelling` on a committed MIC_MLdf.csv (ds_omitB's reference-written
+                          k-mer columns, unit weights, a continuous phenotype 2^(gene) x lognormal noise): the regressor
+                          branch -- Lasso grid, MSE / R^2 / Spearman / Pearson / within-one-dilution lines -- which needs no
+                          statsmodels; plus the hold-out and outer-CV layouts (-ts 0.25, -cv1 3) of the same set."""
+    keep = lambda fn: fn.startswith(("summary_of_", "k-mers_and_coefficients_")) or fn.endswith(".pkl")
+
+    def run_ref(tmp, argv):
+        with open(os.path.join(tmp, "stderr.txt"), "a") as err:
+            r = subprocess.run([sys.executable, os.path.join(HERE, "ref_shim.py"), "modeling", "data.pheno"] + argv,
+                               cwd=tmp, env=ENV, stderr=err, stdout=err)
+        assert r.returncode == 0, open(os.path.join(tmp, "stderr.txt")).read()[-3000:]
+
+    from helpers_golden import load_dataset_files
+    for tag in ("ds_omitB", "ds_bonf"):
+        src = os.path.join(GOLD, tag)
+        with open(os.path.join(src, "meta.json")) as f:
+            meta = json.load(f)
+        tmp = tempfile.mkdtemp(prefix="psk_model_")
+        names, files = load_dataset_files(src)
+        shutil.copy(os.path.join(src, "data.pheno"), tmp)
+        for line in open(os.path.join(src, "data.pheno")).read().splitlines()[1:]:
+            nm, fn = line.split()[:2]
+            with open(os.path.join(tmp, fn), "wb") as f:
+                f.write(files[nm])
+        run_ref(tmp, ["-nt", str(meta["nt"]), "-l", str(meta["k"])] + meta["flags"])
+        for fn in meta["reference_outputs"]:
+            assert open(os.path.join(tmp, fn), "rb").read() == open(os.path.join(src, fn), "rb").read(), (tag, fn)
+        out = os.path.join(src, "model")
+        shutil.rmtree(out, ignore_errors=True)
+        os.makedirs(out)
+        kept = sorted(fn for fn in os.listdir(tmp) if keep(fn))
+        for fn in kept:
+            shutil.copy(os.path.join(tmp, fn), os.path.join(out, fn))
+        print(tag, "model files:", kept)
+        shutil.rmtree(tmp, ignore_errors=True)
+
+    # the continuous set
+    import pandas as pd
+    out = os.path.join(GOLD, "ds_cont")
+    shutil.rmtree(out, ignore_errors=True)
+    os.makedirs(out)
+    gs = GenomeSet(20, 10000, seed=11, gene_len=300)          # ds_omitB's genomes (same NA rows: 3 and 14)
+    rows = ["ID\tAddresses\tMIC"]
+    for i in range(gs.n):
+        rows.append("%s\t%s.fasta\t%s" % (gs.name(i), gs.name(i), "NA" if i in (3, 14) else repr(round(gs.continuous_phenotype(i), 4))))
+    df = pd.read_csv(os.path.join(GOLD, "ds_omitB", "Pheno_MLdf.csv"), index_col=0)
+    df["weights"] = 1
+    df["phenotype"] = [round(gs.continuous_phenotype(int(nm[1:])), 4) for nm in df.index]
+    for sub, argv in (("whole", []), ("holdout", ["-ts", "0.25"]), ("outer_cv", ["-cv1", "3"])):
+        tmp = tempfile.mkdtemp(prefix="psk_model_")
+        with open(os.path.join(tmp, "data.pheno"), "w") as f:
+            f.write("\n".join(rows) + "\n")
+        df.to_csv(os.path.join(tmp, "MIC_MLdf.csv"))
+        run_ref(tmp, ["-jt", "modelling"] + argv)
+        os.makedirs(os.path.join(out, sub))
+        kept = sorted(fn for fn in os.listdir(tmp) if keep(fn))
+        for fn in kept:
+            shutil.copy(os.path.join(tmp, fn), os.path.join(out, sub, fn))
+        if sub == "whole":
+            shutil.copy(os.path.join(tmp, "data.pheno"), out)
+            shutil.copy(os.path.join(tmp, "MIC_MLdf.csv"), out)
+        print("ds_cont", sub, kept)
+        shutil.rmtree(tmp, ignore_errors=True)
+
+
 def gen_split():
     """modeling.py:924-934: train_test_split(ML_df, test_size, random_state=55, stratify=...)."""
     from sklearn.model_selection import train_test_split
@@ -922,3 +994,5 @@ if __name__ == "__main__":
         gen_split()
     if "gsc" in what:
         gen_gsc_kat()
+    if "model_files" in what:
+        gen_model_files()

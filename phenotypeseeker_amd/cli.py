@@ -144,21 +144,7 @@ def main(argv=None):
         # the CLI IS the process: its phase table (modeling.Phases) starts where the process did
         from .modeling import process_start_epoch
         args._t0 = process_start_epoch()
-        # (r04: 0.55 -> 0.49 s for 256 genomes as a fresh process: unpinning the ring, destroying the streams and the HIP
-        # runtime's own exit handlers are work nobody waits for)
-        # -- unless somebody is waiting for the exit handlers: a Python profiler (cProfile writes its file at exit), rocprofv3
-        # (its tool library finalises at exit), an interactive interpreter
-        observed = sys.getprofile() is not None or sys.gettrace() is not None or bool(sys.flags.inspect) or \
-            any(v in os.environ for v in ("ROCP_TOOL_LIBRARIES", "ROCPROFILER_REGISTER_FORCE_LOAD", "HSA_TOOLS_LIB")) or \
-            "rocprof" in os.environ.get("LD_PRELOAD", "")
-        args._fast_exit = os.environ.get("PSK_FAST_EXIT", "1") != "0" and not observed
     args.func(args)
-    if getattr(args, "_fast_exit", False):
-        # the CLI is the process and its work is done (every output file is closed): leave without the interpreter's and the
-        # HIP runtime's tear-down -- the driver reclaims the device memory with the process (PSK_FAST_EXIT=0 keeps the tidy exit)
-        sys.stdout.flush()
-        sys.stderr.flush()
-        os._exit(0)
 
 
 if __name__ == "__main__":

@@ -162,18 +162,20 @@ def _rendezvous():
         the run id AND the launcher process (pid + start time of the parent all ranks share -- torchrun's agent, a
         test's Popen loop), so that a stale file of an earlier or crashed launch can never be met.
     Ranks that do not share a parent (one `bash -c` or srun wrapper per rank) must be given PSK_RDZV_DIR (or
-    PSK_RDZV_FILE) by whoever starts them: the error of the rendezvous timing out says so."""
+    PSK_RDZV_FILE) by whoever starts them -- a directory that is fresh for the launch, or any directory plus one
+    PSK_LAUNCH_NONCE per launch: the error of the rendezvous timing out says so."""
     nonce = os.environ.get("PSK_LAUNCH_NONCE", "")
-    # without a nonce from the launcher the ranks derive one they all arrive at: the process they share as a parent (pid +
-    # start time).  A directory the caller supplies may hold the id and status files of an earlier, crashed launch: with
-    # this every file of THIS launch is told from those (ADVICE r03: the status files carried no tag at all)
-    derived = "p%d_%s" % (os.getppid(), _parent_start_ticks())
+    # A directory the CALLER supplies is for ranks that need not share a parent (one srun / `bash -c` wrapper per rank):
+    # nothing those ranks could derive from their own process tree is the same on all of them (ADVICE r04: a nonce made of
+    # the parent's pid + start time made such ranks reject each other's files until the timeout).  So there the tag every
+    # id / status file carries is PSK_LAUNCH_NONCE as given -- empty when the caller gives none, who then promises that the
+    # directory is fresh for this launch (a leftover rd./st. file of a crashed launch under the same names WOULD be read)
     d = os.environ.get("PSK_RDZV_DIR")
     if d:
-        return _private_dir(d), nonce or derived
+        return _private_dir(d), nonce
     f = os.environ.get("PSK_RDZV_FILE")
     if f:
-        return _private_dir(f + ".rdzv"), nonce or derived
+        return _private_dir(f + ".rdzv"), nonce
     key = "%s_%s_%s_%d_%s" % (os.environ.get("MASTER_ADDR", "127.0.0.1"), os.environ.get("MASTER_PORT", "0"),
                               os.environ.get("TORCHELASTIC_RUN_ID", "none"), os.getppid(), _parent_start_ticks())
     key = "".join(c if c.isalnum() else "_" for c in key)
@@ -241,8 +243,22 @@ def exchange_unique_id(rank, world, make_id, timeout=300.0, rdzv=None, seq=0):
             pass
         if time.time() - t0 > timeout:
             raise RuntimeError("rank %d: no unique id of this launch in %s after %.0f s (is rank 0 running?  Ranks that do "
-                               "not share a parent process must be given the same PSK_RDZV_DIR)" % (rank, path, timeout))
+                               "not share a parent process must be given the same PSK_RDZV_DIR -- fresh for the launch, or "
+                               "with the same PSK_LAUNCH_NONCE on every rank)" % (rank, path, timeout))
         time.sleep(0.01)
+
+
+def _tail_of(path, n_lines=6, max_chars=1500):
+    """The last lines of a small text file, on one line; "" when there is none."""
+    if not path:
+        return ""
+    try:
+        with open(path, "rb") as f:
+            text = f.read()[-8192:].decode(errors="replace")
+    except OSError:
+        return ""
+    lines = [ln.strip() for ln in text.splitlines() if ln.strip()]
+    return " | ".join(lines[-n_lines:])[-max_chars:]
 
 
 @contextlib.contextmanager
@@ -272,9 +288,32 @@ class RcclTransport:
         self.ctx = PskContext(device)
         self._rdzv = None
         try:
-            uid, self._rdzv = exchange_unique_id(rank, world, self.ctx.comm_unique_id, rdzv=rdzv, seq=seq)
-            with _stdout_to_stderr():       # RCCL prints a version banner on stdout; a caller's stdout may be a protocol
-                self.ctx.comm_init(uid, rank, world)
+            from . import watchdog
+            with watchdog.blocking("waiting for rank 0's RCCL unique id (rendezvous directory)"):
+                uid, self._rdzv = exchange_unique_id(rank, world, self.ctx.comm_unique_id, rdzv=rdzv, seq=seq)
+            # RCCL's own account of a refused bring-up is on its debug channel: unless the caller has set that channel up,
+            # warnings go to a file of this rank in the rendezvous directory, and a failure quotes its last lines
+            dbg = None
+            if "NCCL_DEBUG" not in os.environ and "NCCL_DEBUG_FILE" not in os.environ and self._rdzv:
+                dbg = os.path.join(os.path.dirname(self._rdzv), "nccl_warn.%d.%d.log" % (seq, rank))
+                os.environ["NCCL_DEBUG"], os.environ["NCCL_DEBUG_FILE"] = "WARN", dbg
+            try:
+                with _stdout_to_stderr(), watchdog.blocking("ncclCommInitRank (%d ranks)" % world):
+                    # (RCCL prints a version banner on stdout; a caller's stdout may be a protocol)
+                    self.ctx.comm_init(uid, rank, world)
+            except Exception as e:
+                tail = _tail_of(dbg)
+                if tail:
+                    e.args = ("%s; RCCL said: %s" % (e, tail),) + tuple(e.args[1:])
+                raise
+            finally:
+                if dbg:
+                    for var in ("NCCL_DEBUG", "NCCL_DEBUG_FILE"):
+                        os.environ.pop(var, None)
+                    try:
+                        os.unlink(dbg)
+                    except OSError:
+                        pass
             self.stream = self.ctx.comm_stream()
             self.barrier()                  # every rank has joined: the file is no longer needed
             self.n_ranks = self.ctx.comm_size()     # ncclCommCount: what a measurement quotes as "rccl_ranks"
@@ -460,8 +499,9 @@ def _exchange_status(d, prefix, rank, world, text, timeout=600.0, nonce=""):
                 break
             except OSError:
                 if time.time() - t0 > timeout:
-                    raise RuntimeError("rank %d: no status `%s` from rank %d after %.0f s%s"
-                                       % (rank, prefix, r, timeout, ("; this rank: " + text) if text else ""))
+                    raise RuntimeError("rank %d: no status `%s` from rank %d after %.0f s in %s (ranks that do not share a parent "
+                                       "process need the same PSK_RDZV_DIR and, unless it is fresh, the same PSK_LAUNCH_NONCE)%s"
+                                       % (rank, prefix, r, timeout, d, ("; this rank: " + text) if text else ""))
                 time.sleep(0.005)
     return out
 
@@ -562,13 +602,19 @@ class Group:
         self.rccl_ranks = int(getattr(transport, "n_ranks", 0))     # ncclCommCount; 0 unless the transport IS RCCL
         return self
 
+    def _blocking(self, what):
+        from . import watchdog
+        return watchdog.blocking("%s (%s, %d ranks)" % (what, self.backend, self.world))
+
     def barrier(self):
         if self.t is not None:
-            self.t.barrier()
+            with self._blocking("barrier"):
+                self.t.barrier()
 
     def close(self):
         if self.t is not None:
-            self.t.close()
+            with self._blocking("communicator teardown"):
+                self.t.close()
         self.t = None
 
     # -- collectives on small host values ---------------------------------------------------------
@@ -576,21 +622,24 @@ class Group:
         """Sum of a python int / float over ranks (exact for non-negative ints below 2^64)."""
         if self.t is None:
             return value
-        if isinstance(value, (int, np.integer)):
-            return int(self.t.allreduce(np.array([int(value)], dtype=np.uint64), "sum")[0])
-        return float(self.t.allreduce(np.array([float(value)], dtype=np.float64), "sum")[0])
+        with self._blocking("all-reduce(sum)"):
+            if isinstance(value, (int, np.integer)):
+                return int(self.t.allreduce(np.array([int(value)], dtype=np.uint64), "sum")[0])
+            return float(self.t.allreduce(np.array([float(value)], dtype=np.float64), "sum")[0])
 
     def allreduce_max(self, value):
         if self.t is None:
             return float(value)
-        return float(self.t.allreduce(np.array([float(value)], dtype=np.float64), "max")[0])
+        with self._blocking("all-reduce(max)"):
+            return float(self.t.allreduce(np.array([float(value)], dtype=np.float64), "max")[0])
 
     def allgather_i64(self, arr):
         """Equal-length int64 arrays -> [world, n]."""
         a = np.ascontiguousarray(arr, dtype=np.int64)
         if self.t is None:
             return a[None, :]
-        return self.t.allgather_host(a.view(np.uint8)).view(np.int64).reshape(self.world, -1)
+        with self._blocking("all-gather of %d bytes per rank" % a.nbytes):
+            return self.t.allgather_host(a.view(np.uint8)).view(np.int64).reshape(self.world, -1)
 
     def allgather_bytes(self, payload):
         """all-gather(v) of one bytes object per rank -> list of bytes in rank order."""
@@ -600,7 +649,8 @@ class Group:
         cap = int(max(int(sizes.max()), 8))
         buf = np.zeros(cap, dtype=np.uint8)
         buf[: len(payload)] = np.frombuffer(payload, dtype=np.uint8)
-        got = self.t.allgather_host(buf)
+        with self._blocking("all-gather(v) of up to %d bytes per rank" % cap):
+            got = self.t.allgather_host(buf)
         return [got[r, : int(sizes[r])].tobytes() for r in range(self.world)]
 
 
@@ -691,7 +741,8 @@ class SurvivorExchange:
         return s, None
 
     def _host_table(self, s):
-        full = self.t.to_host(self.recv[s], self.g.world * self.nbytes)
+        with self.g._blocking("waiting for the survivors' all-gather (%d bytes per rank)" % self.nbytes):
+            full = self.t.to_host(self.recv[s], self.g.world * self.nbytes)
         return full.view(np.uint64).reshape(self.g.world, self.cap + 1, self.rec_words)
 
     def finish(self, s):
@@ -719,8 +770,9 @@ class SurvivorExchange:
     def finish_counts(self, s):
         """Waits for the collectives queued so far and reads back only the per-slab record counts of slot s (the
         records stay on the device); used where the merged table is not needed on the host right away."""
-        return np.array([int(self.t.to_host(self.recv[s], 8, offset=r * self.nbytes).view(np.uint64)[0])
-                         for r in range(self.g.world)], dtype=np.int64)
+        with self.g._blocking("waiting for the survivors' all-gather (%d bytes per rank)" % self.nbytes):
+            return np.array([int(self.t.to_host(self.recv[s], 8, offset=r * self.nbytes).view(np.uint64)[0])
+                             for r in range(self.g.world)], dtype=np.int64)
 
     def gather(self, ctx):
         """Synchronous form used by the pipeline: exchange the survivors of the last scan, growing the
@@ -781,16 +833,17 @@ class ListExchange:
             rs = [(j, int(cuts[j, d]), int(seg[j, d])) for d in range(W) for j in range(len(own))]
             if rs:
                 cnt_ctx.copy_list_ranges([x[0] for x in rs], [x[1] for x in rs], [x[2] for x in rs], send_w.ptr, send_f.ptr)
-            self.t.alltoallv(send_w, send_counts, recv_w, recv_counts, 8)
-            self.t.alltoallv(send_f, send_counts, recv_f, recv_counts, 4)
-            # what arrived is source-major, the source's samples in order inside: one installing call
+            # what arrives is source-major, the source's samples in order inside: one installing call
             idx, cnt, tot = [], [], []
             for src in range(W):
                 theirs = [i for i in range(n_samples) if owner_of(i, W) == src]
                 idx += theirs
                 cnt += [int(seg_all[src][j, r]) for j in range(len(theirs))]
                 tot += [int(tot_all[src][j]) for j in range(len(theirs))]
-            slab_ctx.set_lists_device(idx, cnt, tot, recv_w.ptr, recv_f.ptr)
+            with self.g._blocking("all-to-all(v) of the lists: %d pairs out, %d in" % (n_send, n_recv)):
+                self.t.alltoallv(send_w, send_counts, recv_w, recv_counts, 8)
+                self.t.alltoallv(send_f, send_counts, recv_f, recv_counts, 4)
+                slab_ctx.set_lists_device(idx, cnt, tot, recv_w.ptr, recv_f.ptr)     # (waits for the collectives' stream)
         finally:
             for b in (send_w, send_f, recv_w, recv_f):
                 b.free()

@@ -8,7 +8,10 @@ RANK / LOCAL_RANK / WORLD_SIZE and a PRIVATE rendezvous directory of this launch
 nobody can predict or pre-create) plus a nonce the rendezvous blob must carry, relays the children's output, and
 exits with the worst child's exit code.  Rank 0's stdout is the parent's stdout (its last line is the program's
 result line); the other ranks' stdout goes to stderr.  When one rank fails the others get a grace period and are
-then terminated -- by their exact pids, never by pattern.  A launcher that already exported WORLD_SIZE
+then terminated -- by their exact pids, never by pattern.  The launch as a whole has a deadline (PSK_LAUNCH_TIMEOUT seconds,
+default 900: well under the 1,800 s after which a driver kills the job without a trace): when it passes, every rank still
+running is sent SIGUSR1 -- a rank answers by writing phases_rank<r>.json with the phase and the call it is stuck in
+(watchdog.py) --, then terminated by pid, and the launcher leaves with 124 (what `timeout` returns).  A launcher that already exported WORLD_SIZE
 (`torchrun`-style, srun, mpirun) is honoured instead: the programs only read RANK / LOCAL_RANK / WORLD_SIZE.
 """
 import os
@@ -25,9 +28,20 @@ def launched_by_outside_launcher():
     return "WORLD_SIZE" in os.environ and "RANK" in os.environ
 
 
-def spawn_ranks(argv, world, share_gpu=False, env_extra=None, grace_s=15.0):
+def launch_timeout():
+    """PSK_LAUNCH_TIMEOUT in seconds (0 or negative: no deadline)."""
+    raw = os.environ.get("PSK_LAUNCH_TIMEOUT", "900")
+    try:
+        return float(raw)
+    except ValueError:
+        sys.exit("PSK_LAUNCH_TIMEOUT=%s: expected a number of seconds" % raw)
+
+
+def spawn_ranks(argv, world, share_gpu=False, env_extra=None, grace_s=15.0, deadline_s=None, report_s=3.0):
     """Runs `sys.executable argv...` as `world` rank processes; returns the exit code to leave with (0 only when
-    every rank returned 0)."""
+    every rank returned 0; 124 when the launch ran into its deadline -- deadline_s, default PSK_LAUNCH_TIMEOUT)."""
+    if deadline_s is None:
+        deadline_s = launch_timeout()
     rdzv = tempfile.mkdtemp(prefix="psk_launch_")          # 0700, unpredictable: the ranks' private meeting place
     nonce = secrets.token_hex(16)
     base = dict(os.environ)
@@ -56,7 +70,24 @@ def spawn_ranks(argv, world, share_gpu=False, env_extra=None, grace_s=15.0):
         old = {s: signal.signal(s, forward) for s in (signal.SIGINT, signal.SIGTERM)}
         try:
             first_fail = None
+            t_start = time.time()
+            timed_out = False
             while any(p.poll() is None for p in procs):
+                if deadline_s and deadline_s > 0 and not timed_out and time.time() - t_start > deadline_s:
+                    timed_out = True
+                    live = [r for r, p in enumerate(procs) if p.poll() is None]
+                    sys.stderr.write("psk launch: deadline of %.0f s passed (PSK_LAUNCH_TIMEOUT) with rank(s) %s still running; "
+                                     "asking them where they are (SIGUSR1 -> phases_rank<r>.json), then terminating them\n"
+                                     % (deadline_s, ", ".join(map(str, live))))
+                    sys.stderr.flush()
+                    for p in procs:
+                        if p.poll() is None:
+                            try:
+                                p.send_signal(signal.SIGUSR1)
+                            except OSError:
+                                pass
+                    time.sleep(report_s)
+                    first_fail = time.time() - grace_s - 1.0      # (no further grace: straight to terminate / kill below)
                 bad = [p for p in procs if p.poll() not in (None, 0)]
                 if bad and first_fail is None:
                     first_fail = time.time()
@@ -78,6 +109,8 @@ def spawn_ranks(argv, world, share_gpu=False, env_extra=None, grace_s=15.0):
             for s, h in old.items():
                 signal.signal(s, h)
         codes = [p.wait() for p in procs if p.pid not in reaped]
+        if timed_out:
+            return 124
         # a rank killed by signal n reports 128 + n, as a shell does; the worst rank decides
         return max([0] + [(c if c > 0 else 128 - c) for c in codes if c != 0])
     finally:

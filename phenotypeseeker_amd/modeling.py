@@ -18,6 +18,7 @@ import ctypes
 import math
 import os
 import sys
+import threading
 import time
 from collections import OrderedDict
 
@@ -766,8 +767,10 @@ class phenotypes:
         """(:1239-1253, :1255-1288, :1314-1380); `store` collects the per-split metrics for the means."""
         pred = self.model_fitted.predict(X)
         out.write("\nModel predictions on samples:\nSample_ID Acutal_phenotype Predicted_phenotype\n")
-        for name, actual, p in zip(index, y, pred):
-            out.write("%s %s %s\n" % (name, actual, p))
+        # the printed value is a ONE-ROW prediction, as the reference computes it (:1245-1249): a regressor's last digit is the
+        # BLAS sum's, which is not the same for a row alone and for the row inside the matrix; the metrics use `pred`
+        for i, (name, actual) in enumerate(zip(index, y)):
+            out.write("%s %s %s\n" % (name, actual, self.model_fitted.predict(X[i:i + 1])[0]))
         out.write("\n")
 
         def keep(key, value):
@@ -873,6 +876,15 @@ class Phases:
         self.t0 = self.last = time.time() if t0 is None else t0
         self.table = OrderedDict()
 
+    def enter(self, name):
+        """Names the phase that starts now -- what a rank that hangs in it reports (watchdog.py); mark() still books it."""
+        from . import watchdog
+        watchdog.enter(name)
+
+    def snapshot(self):
+        """The finished phases, for the table of a rank that is stuck in the next one."""
+        return {"total_s": round(time.time() - self.t0, 4), "phases_s": OrderedDict((k, round(v, 4)) for k, v in list(self.table.items()))}
+
     def mark(self, name):
         now = time.time()
         self.table[name] = self.table.get(name, 0.0) + (now - self.last)
@@ -899,6 +911,11 @@ def modeling(args):
     """The main function of `phenotypeseeker modeling` (:1624-1709)."""
     ph_t = Phases.current = Phases(getattr(args, "_t0", None))
     ph_t.mark("process start, interpreter, imports")
+    if threading.current_thread() is threading.main_thread():
+        # a launch that runs into its deadline (launch.spawn_ranks: PSK_LAUNCH_TIMEOUT) asks every rank where it is
+        from . import watchdog
+        watchdog.install(os.environ.get("RANK", "0"), os.environ.get("WORLD_SIZE", "1"), ph_t.snapshot)
+    ph_t.enter("arguments, data.pheno")
     _err(RED_BANNER % "######                   PhenotypeSeeker                   ######")
     _err(RED_BANNER % "######                      modeling                       ######" + "\n")
     Input.reset()
@@ -912,10 +929,12 @@ def modeling(args):
         args.kmerDB)
     Samples.use_weights = bool(getattr(args, "weights", False))
     ph_t.mark("arguments, data.pheno")
+    ph_t.enter("rendezvous, communicator (ncclCommInitRank)")
     group = _dist.Group().init()
     ph_t.mark("rendezvous, communicator (ncclCommInitRank)")
     for name, secs in _dist.init_times.items():     # the bring-up's own steps (the GPU probe in it pays the HIP start-up)
         ph_t.move("rendezvous, communicator (ncclCommInitRank)", name if name.startswith("HIP") else "rendezvous: " + name, secs)
+    ph_t.enter("HIP runtime, context")
     ctx = PskContext(group.device)
     ph_t.mark("HIP runtime, context")
     try:
@@ -923,6 +942,8 @@ def modeling(args):
             k = int(Samples.kmer_length)
             _err(GREEN % "Generating the k-mer lists for input samples:" + "\n")
             n_thr = max(1, min(int(Input.num_threads), 8))
+            ph_t.enter("ingest: k-mer lists")
+            ph_t.enter("ingest: k-mer lists")
             t_lists = time.time()
             # several ranks: the list exchange when the collectives run GPU to GPU (RCCL); with the host transport of the tests they are
             # staged through the host (7 GB through TCP loopback for 2 x 128 genomes: 5.7 s against 0.12 s), so
@@ -940,6 +961,7 @@ def modeling(args):
                               % (time.time() - t_lists, group.world, ", list exchange" if exchange else ""))
             ph_t.mark("ingest: k-mer lists" + (" (list exchange)" if exchange else " (every rank filters its slab)" if group.world > 1 else ""))
             _err("\n" + GREEN % "Generating the k-mer feature vector." + "\n")
+            ph_t.enter("presence matrix")
             m_local = Samples.get_feature_vector(ctx)
             ph_t.mark("presence matrix")
             _err(GREEN % "Mapping samples to the feature vector space:" + "\n")
@@ -947,11 +969,14 @@ def modeling(args):
             if Samples.use_weights:
                 _err("\n" + GREEN % "Estimating the Mash distances between samples..." + "\n")
                 stderr_print(GREEN % "Calculating the GSC weights from mash distance matrix...")
+                ph_t.enter("weights: sketches, distances, NJ, GSC")
                 Samples.get_weights(ctx, write_files=group.rank == 0)
                 ph_t.mark("weights: sketches, distances, NJ, GSC")
+            ph_t.enter("all-reduce of the union size")
             phenotypes.kmer_testing_setup(group.allreduce_sum(int(m_local)))
             ph_t.mark("all-reduce of the union size")
             phs = list(Input.phenotypes_to_analyse.values())
+            ph_t.enter("scan")
             for j, ph in enumerate(phs):
                 ph.test_kmers_association_with_phenotype(ctx, group, phs[j + 1] if j + 1 < len(phs) else None)
             ph_t.mark("scan")      # (the survivors' all-gather inside it is moved to its own line: Phases.move)
@@ -961,17 +986,19 @@ def modeling(args):
             if Input.jump_to:
                 Input.jump_to = "modelling"
             _err(GREEN % ("Generating the " + phenotypes.model_name_long + " model for phenotype: ") + "\n")
+            ph_t.enter("model: result tables, grid search, model files")
             if group.rank == 0:
                 for ph in Input.phenotypes_to_analyse.values():
                     ph.machine_learning_modelling(ctx)
             ph_t.mark("model: result tables, grid search, model files")
+            ph_t.enter("waiting for rank 0's model")
             group.barrier()
             ph_t.mark("waiting for rank 0's model")
         if getattr(args, "assembly", False):
             _err(YELLOW % "-a/--assembly is outside the accelerated path and is skipped.")
     finally:
-        if not getattr(args, "_fast_exit", False):   # (a CLI process about to leave: the driver frees the device memory with it)
-            ctx.close()
+        ph_t.enter("teardown: buffers, communicator")
+        ctx.close()
         group.close()
         ph_t.mark("teardown: buffers, communicator")
         ph_t.write(group.rank, group.world)

@@ -342,3 +342,71 @@ def test_status_files_of_another_launch_are_not_read(tmp_path):
     got[0] = dist._exchange_status(d, "rd.0", 0, 2, "", timeout=5.0, nonce="this-launch")
     t.join()
     assert got[0] == got[1] == ["ok", "no GPU"]
+
+
+@pytest.mark.parametrize("mode", ["all-hang", "rank1-hangs"])
+def test_launch_deadline_leaves_stuck_phase_tables_and_a_nonzero_code(tmp_path, mode):
+    """ranks that hang in a collective (all of them, or one while the others have left) are not waited for
+    until somebody's 1,800-s kill: the launch has its own deadline (PSK_LAUNCH_TIMEOUT), at which every live rank is asked
+    where it is (SIGUSR1), answers with phases_rank<r>.json -- finished phases, the phase it is in, the call it is blocked in;
+    written by a thread, the main thread never comes back from the call -- and is then terminated by pid; the launcher
+    returns 124 well inside the deadline + report + kill budget."""
+    import json
+    import time
+    code = ("import sys, os\nsys.path.insert(0, %r)\nfrom phenotypeseeker_amd import launch\n"
+            "sys.exit(launch.spawn_ranks([%r, %r], 2))\n" % (ROOT, os.path.join(ROOT, "tests", "_hang_worker.py"), mode))
+    env = dict(os.environ, PSK_LAUNCH_TIMEOUT="2")
+    env.pop("WORLD_SIZE", None)
+    t0 = time.time()
+    r = subprocess.run([sys.executable, "-c", code], cwd=str(tmp_path), env=env, capture_output=True, text=True, timeout=120)
+    took = time.time() - t0
+    assert r.returncode == 124, (r.returncode, r.stderr[-2000:])
+    assert took < 2 + 3 + 5 + 10, took
+    assert "deadline of 2 s passed (PSK_LAUNCH_TIMEOUT)" in r.stderr
+    stuck = [1] if mode == "rank1-hangs" else [0, 1]
+    for rank in stuck:
+        with open(os.path.join(tmp_path, "phases_rank%d.json" % rank)) as f:
+            rec = json.load(f)
+        assert rec["stuck"] is True and rec["rank"] == rank and rec["world"] == 2
+        assert rec["stuck_in"] == "all-reduce of the union size"
+        assert rec["blocked_in_call"] == "all-reduce(sum) (test-transport, 2 ranks)" and rec["blocked_for_s"] >= 1.0
+        assert list(rec["phases_s"]) == ["arguments, data.pheno", "presence matrix"]
+        assert "rank %d/2: stuck in phase `all-reduce of the union size`" % rank in r.stderr
+    if mode == "rank1-hangs":
+        assert not os.path.exists(os.path.join(tmp_path, "phases_rank0.json")) and "rank 0 done" in r.stdout
+    # no deadline: PSK_LAUNCH_TIMEOUT=0 is honoured (the launch then ends with its ranks); a value that is no number is refused
+    from phenotypeseeker_amd import launch
+    os.environ["PSK_LAUNCH_TIMEOUT"] = "soon"
+    try:
+        with pytest.raises(SystemExit):
+            launch.launch_timeout()
+    finally:
+        del os.environ["PSK_LAUNCH_TIMEOUT"]
+    assert launch.launch_timeout() == 900.0
+
+
+def test_ranks_started_by_different_parents_meet_in_a_supplied_directory(tmp_path):
+    """PSK_RDZV_DIR without PSK_LAUNCH_NONCE is for ranks that do NOT share a parent (one wrapper per
+    rank).  Each rank here is the child of its own shell; the tag of the id / status files must not depend on the parent
+    (r04 derived it from the parent's pid + start time: such ranks rejected each other's files until the timeout)."""
+    meet = str(tmp_path / "meet")
+    code = ("import os, sys\nsys.path.insert(0, %r)\nfrom phenotypeseeker_amd import dist\n"
+            "r = int(os.environ['RANK'])\n"
+            "d, nonce = dist._rendezvous()\n"
+            "print('nonce=%%r ppid=%%d' %% (nonce, os.getppid()))\n"
+            "uid, _ = dist.exchange_unique_id(r, 2, lambda: b'U' * 128, timeout=20, rdzv=(d, nonce))\n"
+            "st = dist._exchange_status(d, 'rd.0', r, 2, '', timeout=20, nonce=nonce)\n"
+            "assert uid == b'U' * 128 and st == ['ok', 'ok'], (uid, st)\n" % ROOT)
+    script = tmp_path / "rank.py"
+    script.write_text(code)
+    procs = []
+    for rank in (1, 0):
+        env = {k_: v for k_, v in os.environ.items() if k_ not in ("PSK_LAUNCH_NONCE", "PSK_RDZV_FILE")}
+        env.update(PSK_RDZV_DIR=meet, RANK=str(rank), WORLD_SIZE="2")
+        # `sh -c "python ...; true"`: the shell stays the parent of the rank (no exec), one shell per rank
+        procs.append(subprocess.Popen(["sh", "-c", "%s %s; rc=$?; exit $rc" % (sys.executable, script)], env=env,
+                                      stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True))
+    outs = [p.communicate(timeout=60) for p in procs]
+    assert [p.returncode for p in procs] == [0, 0], outs
+    ppids = {o[0].split("ppid=")[1].strip() for o in outs}
+    assert len(ppids) == 2 and all("nonce=''" in o[0] for o in outs)

@@ -305,3 +305,83 @@ def test_linear_package_loader_leaves_what_it_cannot_reproduce_to_scikit_learn(t
     pkg["kmers"] = np.arange(100_000)         # a large numeric array: joblib stores it raw behind a NumpyArrayWrapper
     joblib.dump(pkg, wrapped)
     assert skpickle.load_linear_package(wrapped) is None
+
+
+class _RefModel:
+    """The reference's fitted GridSearchCV (tests/golden/<set>/model/*.pkl, written by the unmodified modeling.py) behind
+    the estimator boundary: scikit-learn >= 1.x returns Python floats from score() where the writers (like the reference's,
+    modeling.py:1316-1356) call .round() on numpy ones -- oracle/ref_shim.py wraps the same call for the reference."""
+
+    def __init__(self, fitted):
+        self._m = fitted
+
+    def __getattr__(self, name):
+        return getattr(self._m, name)
+
+    def score(self, X, y):
+        return np.float64(self._m.score(X, y))
+
+
+_MODEL_CASES = [
+    ("ds_omitB", "model", "Pheno", "log_reg", ["--omit_B_correction", "--n_kmers", "100"]),
+    ("ds_bonf", "model", "Pheno", "log_reg", []),
+    ("ds_cont", "whole", "MIC", "linreg", []),
+    ("ds_cont", "holdout", "MIC", "linreg", ["-ts", "0.25"]),
+]
+
+
+@pytest.mark.parametrize("tag,sub,pheno,short,extra", _MODEL_CASES)
+def test_summary_and_coefficient_files_equal_the_reference_byte_for_byte(tmp_path, monkeypatch, tag, sub, pheno, short, extra):
+    """a11 formats.  The reference's own fitted model (the .pkl it wrote) is handed to THIS
+    package's writers in the fit's place: summary_of_<model>_analysis_<pheno>.txt (modeling.py:1219-1412) and
+    k-mers_and_coefficients_in_<model>_model_<pheno>.txt (:1414-1455) must then be the reference's files byte for byte --
+    classifier and regressor branch, whole-set and hold-out layout -- since nothing but formatting is left to differ."""
+    import joblib
+    from helpers import GOLDEN
+    from phenotypeseeker_amd import modeling as M
+    gd = os.path.join(GOLDEN, tag)
+    os.chdir(tmp_path)
+    for fn in ("data.pheno", pheno + "_MLdf.csv"):
+        with open(os.path.join(gd, fn)) as f, open(fn, "w") as g:
+            g.write(f.read())
+    a = _args(["-jt", "modelling"] + extra)
+    M.Input.reset()
+    M.Input.get_input_data(a.inputfile, a.take_logs, a.mpheno)
+    M.Input.Input_args(a.alphas, a.alpha_min, a.alpha_max, a.n_alphas, a.gammas, a.gamma_min, a.gamma_max, a.n_gammas,
+                       a.min, a.max, a.kmer_length, a.cutoff, a.num_threads, a.pvalue, a.n_kmers, a.binary_classifier,
+                       a.regressor, a.penalty, a.max_iter, a.tolerance, a.l1_ratio, a.n_splits_cv_outer, a.kernel,
+                       a.n_iter, a.n_splits_cv_inner, a.testset_size, a.train_on_whole, a.logreg_solver, a.jump_to,
+                       a.pca, a.real_counts, a.omit_B_correction, a.kmerDB)
+    ref_dir = os.path.join(gd, sub)
+    pkg = joblib.load(os.path.join(ref_dir, "%s_model_%s.pkl" % (short, pheno)))
+    ph = M.Input.phenotypes_to_analyse[pheno]
+    fits = []
+
+    def fit_is_the_reference_model(self, ctx, X, y):
+        fits.append(X.shape)
+        self.model = pkg["model"].estimator
+        self.model_fitted = _RefModel(pkg["model"])
+    monkeypatch.setattr(M.phenotypes, "_fit", fit_is_the_reference_model)
+    monkeypatch.setenv("PSK_NATIVE_PKL", "1")
+    ph.machine_learning_modelling(None)
+    assert len(fits) == 1
+    for fn in ("summary_of_%s_analysis_%s.txt" % (short, pheno), "k-mers_and_coefficients_in_%s_model_%s.txt" % (short, pheno)):
+        got, want = open(fn).read(), open(os.path.join(ref_dir, fn)).read()
+        if got != want:
+            # ONE line may differ, and only where the reference itself is not reproducible: "Average precision" ranks the
+            # samples by predict_proba, whose BLAS sum over liblinear's ~100 non-zero near-duplicate coefficients differs in the
+            # last bit between a C- and a Fortran-ordered X (the reference hands over a DataFrame whose layout depends on how
+            # it was built); scores that are equal in exact arithmetic then tie or not.  Both layouts' values are computed
+            # here with scikit-learn: the reference's line and this package's must each be one of them.
+            from sklearn.metrics import average_precision_score
+            g, w = got.splitlines(), want.splitlines()
+            assert len(g) == len(w), fn
+            diff = [i for i in range(len(g)) if g[i] != w[i]]
+            assert diff and all(g[i].startswith("Average precision: ") for i in diff), (fn, [(g[i], w[i]) for i in diff][:3])
+            X = np.asarray(ph.ML["X"], dtype=np.float64)
+            y = np.asarray(ph.ML["phenotype"], dtype=np.int64)
+            assert len(diff) == 1 and X.shape[0] == len(y)          # (whole-set layout: one report)
+            ap = {"Average precision: %s" % np.float64(average_precision_score(y, pkg["model"].predict_proba(lay(X))[:, 1])).round(2)
+                  for lay in (np.ascontiguousarray, np.asfortranarray)}
+            assert len(ap) == 2 and g[diff[0]] in ap and w[diff[0]] in ap, (ap, g[diff[0]], w[diff[0]])
+    assert list(pkg["kmers"]) == list(ph.ML["kmers"]) and pkg["pred_scale"] == ph.pred_scale and pkg["pca"] is False
