@@ -934,6 +934,39 @@ def gen_model_files():
         shutil.rmtree(tmp, ignore_errors=True)
 
 
+def gen_prediction_of_product_pkl():
+    """VERDICT r04 #2, the reverse direction of the .pkl contract: model files THIS package wrote on the GPU box
+    (tools/capture_product_run.py -> gpurun_out/product_run/<set>/) are handed to the REFERENCE's prediction.py
+    (prediction.py:185-204, with bin/gmer_counter doing the counting) on the same samples; the .pkl and the reference's
+    predictions_<pheno>.txt are committed under tests/golden/product_pkl/<set>/.  The -m gpu suite then runs this
+    package's `prediction` on the committed .pkl and compares byte for byte."""
+    from helpers_golden import load_dataset_files
+    src_root = os.path.join(ROOT, "gpurun_out", "product_run")
+    for tag, pheno, short in (("ds_omitB", "Pheno", "log_reg"), ("ds_bonf", "Pheno", "log_reg"), ("ds_cont", "MIC", "linreg")):
+        src = os.path.join(src_root, tag)
+        pkl = "%s_model_%s.pkl" % (short, pheno)
+        names, files = load_dataset_files(os.path.join(GOLD, "ds_omitB" if tag == "ds_cont" else tag))
+        tmp = tempfile.mkdtemp(prefix="psk_pred_")
+        for fn in ("samples.txt", "phenos.txt", pkl):
+            shutil.copy(os.path.join(src, fn), tmp)
+        for line in open(os.path.join(tmp, "samples.txt")).read().splitlines():
+            nm, fn = line.split()[:2]
+            with open(os.path.join(tmp, fn), "wb") as f:
+                f.write(files[nm])
+        with open(os.path.join(tmp, "stderr.txt"), "w") as err:
+            r = subprocess.run([sys.executable, os.path.join(HERE, "ref_shim.py"), "prediction", "samples.txt", "phenos.txt"],
+                               cwd=tmp, env=ENV, stderr=err, stdout=err)
+        assert r.returncode == 0, open(os.path.join(tmp, "stderr.txt")).read()[-3000:]
+        out = os.path.join(GOLD, "product_pkl", tag)
+        shutil.rmtree(out, ignore_errors=True)
+        os.makedirs(out)
+        for fn in ("samples.txt", "phenos.txt", pkl, "predictions_%s.txt" % pheno):
+            shutil.copy(os.path.join(tmp, fn), os.path.join(out, fn))
+        same = open(os.path.join(tmp, "predictions_%s.txt" % pheno)).read() == open(os.path.join(src, "predictions_%s.txt" % pheno)).read()
+        print(tag, "reference prediction.py on the product's .pkl: written; equal to the product's own predictions:", same)
+        shutil.rmtree(tmp, ignore_errors=True)
+
+
 def gen_split():
     """modeling.py:924-934: train_test_split(ML_df, test_size, random_state=55, stratify=...)."""
     from sklearn.model_selection import train_test_split
@@ -996,3 +1029,5 @@ if __name__ == "__main__":
         gen_gsc_kat()
     if "model_files" in what:
         gen_model_files()
+    if "product_pkl" in what:      # needs gpurun_out/product_run/ (tools/capture_product_run.py on the GPU box)
+        gen_prediction_of_product_pkl()

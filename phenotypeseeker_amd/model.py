@@ -136,9 +136,17 @@ class LassoRegression:
         return np.asarray(X, dtype=np.float64) @ self.coef_ + self.intercept_
 
     def score(self, X, y):
+        """R^2 as sklearn.metrics.r2_score returns it (what GridSearchCV scores a regressor with, modeling.py:1208-1216):
+        undefined -- nan -- on fewer than two samples (a 10-fold split of fewer than 20 samples has such folds: the
+        reference's summary then prints `nan (+/-nan)` for every alpha); a constant target scores 1.0 when it is predicted
+        exactly and 0.0 otherwise (force_finite)."""
         y = np.asarray(y, dtype=np.float64)
+        if len(y) < 2:
+            return np.float64(np.nan)
         res = ((y - self.predict(X)) ** 2).sum()
         tot = ((y - y.mean()) ** 2).sum()
+        if tot == 0.0:
+            return np.float64(1.0 if res == 0.0 else 0.0)
         return np.float64(1.0 - res / tot)
 
 
@@ -209,7 +217,7 @@ class GridSearch:
         std = scores.std(axis=1)
         self.cv_results_ = {"mean_test_score": mean, "std_test_score": std,
                             "params": [{self.param_name: g} for g in grid],
-                            "rank_test_score": _rank_min(-mean)}
+                            "rank_test_score": _rank_with_nan(mean)}
         for f in range(self.cv):
             self.cv_results_["split%d_test_score" % f] = scores[:, f]
         self.best_index_ = int(np.argmin(self.cv_results_["rank_test_score"]))
@@ -304,6 +312,15 @@ def _unique_columns(X):
         inverse[j] = u
     first = np.array(first, dtype=np.int64)
     return np.ascontiguousarray(X[:, first]) if len(first) else X[:, :0], first, inverse
+
+
+def _rank_with_nan(mean):
+    """GridSearchCV's rank_test_score (sklearn/model_selection/_search.py::_store): rank 1 for everything when every mean
+    is nan (the first candidate is then the best one), else nan counts as worse than the worst finite mean."""
+    mean = np.asarray(mean, dtype=np.float64)
+    if np.isnan(mean).all():
+        return np.ones(len(mean), dtype=np.int32)
+    return _rank_min(-np.nan_to_num(mean, nan=np.nanmin(mean) - 1.0))
 
 
 def _rank_min(a):

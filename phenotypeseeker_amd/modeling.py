@@ -655,8 +655,9 @@ class phenotypes:
                 return L2LogisticRegression(tol=self.tol, max_iter=self.max_iter, solver=self.logreg_solver), "C", grid
             return L1LogisticRegression(tol=self.tol, max_iter=self.max_iter), "C", grid
         if self.penalty == "L2":
-            return RidgeRegression(tol=self.tol, max_iter=self.max_iter), "alpha", [float(a) for a in self.alphas]
-        return LassoRegression(tol=self.tol, max_iter=self.max_iter), "alpha", [float(a) for a in self.alphas]
+            return RidgeRegression(tol=self.tol, max_iter=self.max_iter), "alpha", [np.float64(a) for a in self.alphas]
+        # (numpy scalars, as the reference's {'alpha': np.logspace(...)} grid holds them: the summary prints the params' repr)
+        return LassoRegression(tol=self.tol, max_iter=self.max_iter), "alpha", [np.float64(a) for a in self.alphas]
 
     def _fit(self, ctx, X, y):
         est, pname, grid = self._new_estimator()

@@ -65,3 +65,37 @@ def large_design(z, tag):
         X = np.unpackbits(z["X_" + tag], axis=0)[:n]
         y = z["y_" + tag]
     return X.astype(np.float32), y.astype(np.int32), z["fold_" + tag].astype(np.int32)
+
+
+def _num(tok):
+    t = tok.strip("(),:;[]{}'")
+    try:
+        return float(t)
+    except ValueError:
+        return None
+
+
+def assert_text_equal_up_to_numbers(got, want, rel=1e-6, abs_=1e-9, what=""):
+    """Line by line, token by token: text tokens identical, numeric tokens within rel / abs_ (nan == nan)."""
+    import math
+    g, w = got.splitlines(), want.splitlines()
+    assert len(g) == len(w), "%s: %d lines against %d" % (what, len(g), len(w))
+    for i, (a, b) in enumerate(zip(g, w)):
+        if a == b:
+            continue
+        ta, tb = a.split(), b.split()
+        assert len(ta) == len(tb), "%s line %d: %r != %r" % (what, i + 1, a, b)
+        for x, y in zip(ta, tb):
+            if x == y:
+                continue
+            fx, fy = _num(x), _num(y)
+            assert fx is not None and fy is not None, "%s line %d: %r != %r" % (what, i + 1, a, b)
+            if math.isnan(fx) and math.isnan(fy):
+                continue
+            assert abs(fx - fy) <= abs_ + rel * abs(fy), "%s line %d: %r != %r (%s vs %s)" % (what, i + 1, a, b, x, y)
+
+
+def mask_numbers(line):
+    """Every numeric token of a line replaced by '#': what is left of a summary line when liblinear's unseeded,
+    unconverged coefficients decide its numbers."""
+    return " ".join("#" if _num(t) is not None else t for t in line.split())

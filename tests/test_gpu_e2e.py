@@ -532,3 +532,87 @@ def test_several_phenotypes_in_one_run_equal_one_run_each(tmp_path):
             if os.path.exists(one / fn) or os.path.exists(both / fn):
                 assert open(one / fn).read() == open(both / fn).read(), fn
         assert os.path.exists(both / ("chi2_results_%s.tsv" % name))
+
+
+@pytest.mark.parametrize("tag,pheno,short", [("ds_omitB", "Pheno", "log_reg"), ("ds_bonf", "Pheno", "log_reg"), ("ds_cont", "MIC", "linreg")])
+def test_prediction_on_a_committed_model_file_equals_the_references_prediction(tmp_path, tag, pheno, short):
+    """The .pkl contract in the reverse direction: tests/golden/product_pkl/<set>/*.pkl is a model file THIS
+    package wrote on a GPU box; predictions_<pheno>.txt beside it was written by the REFERENCE's prediction.py (185-204) after
+    a plain joblib.load of that file, bin/gmer_counter counting the k-mers (oracle/gen_golden.py::
+    gen_prediction_of_product_pkl).  `phenotypeseeker prediction` of this package on the same file and samples must write
+    the same bytes."""
+    import shutil
+    from helpers import GOLDEN
+    gd = os.path.join(GOLDEN, "product_pkl", tag)
+    ds = load_dataset("ds_omitB" if tag == "ds_cont" else tag)
+    _write_dataset(ds, str(tmp_path))
+    for fn in ("samples.txt", "phenos.txt", "%s_model_%s.pkl" % (short, pheno)):
+        shutil.copy(os.path.join(gd, fn), str(tmp_path))
+    _run(tmp_path, ["prediction", "samples.txt", "phenos.txt"])
+    fn = "predictions_%s.txt" % pheno
+    assert open(fn).read() == open(os.path.join(gd, fn)).read()
+
+
+@pytest.mark.parametrize("sub,extra", [("whole", []), ("holdout", ["-ts", "0.25"]), ("outer_cv", ["-cv1", "3"])])
+def test_regressor_files_equal_the_reference_written_ones(tmp_path, sub, extra):
+    """a11, regressor branch: the reference ran `modeling data.pheno -jt modelling` (+ -ts 0.25 /
+    -cv1 3) on tests/golden/ds_cont/MIC_MLdf.csv (oracle/gen_golden.py::gen_model_files); scikit-learn's Lasso is
+    deterministic, so THIS package's run of the same command must write the same summary -- grid scores (nan where a
+    10-fold split of 18 samples leaves one-sample folds), best alpha, per-sample predictions, MSE / R^2 / Spearman /
+    Pearson / one-dilution lines, every layout line -- and the same coefficient table: text identical, numbers within 1e-6
+    relative (north_star's bound for regression coefficients; in practice the last digit of the printed doubles)."""
+    import shutil
+    from helpers import GOLDEN, assert_text_equal_up_to_numbers
+    gd = os.path.join(GOLDEN, "ds_cont")
+    for fn in ("data.pheno", "MIC_MLdf.csv"):
+        shutil.copy(os.path.join(gd, fn), str(tmp_path))
+    _run(tmp_path, ["modeling", "data.pheno", "-jt", "modelling"] + extra)
+    fn = "summary_of_linreg_analysis_MIC.txt"
+    assert_text_equal_up_to_numbers(open(fn).read(), open(os.path.join(gd, sub, fn)).read(), rel=1e-6, abs_=1e-9, what=sub + " summary")
+    fn = "k-mers_and_coefficients_in_linreg_model_MIC.txt"
+    got = [l.split("\t") for l in open(fn).read().splitlines()]
+    want = [l.split("\t") for l in open(os.path.join(gd, sub, fn)).read().splitlines()]
+    assert got[0] == want[0] and len(got) == len(want)
+    assert [(g[0], g[2], g[3]) for g in got[1:]] == [(w[0], w[2], w[3]) for w in want[1:]]
+    assert np.allclose([float(g[1]) for g in got[1:]], [float(w[1]) for w in want[1:]], rtol=1e-6, atol=1e-9)
+
+
+@pytest.mark.parametrize("tag,extra", [("ds_omitB", ["--omit_B_correction", "--n_kmers", "100"]), ("ds_bonf", [])])
+def test_classifier_files_against_the_reference_written_ones(tmp_path, tag, extra):
+    """a11, classifier branch: the whole pipeline on the golden genome sets against the summary / coefficient table the
+    unmodified reference wrote for them (tests/golden/<set>/model/).  liblinear runs unseeded and unconverged there (SURVEY
+    Q6: two reference runs differ in grid scores, C and coefficients), so those NUMBERS are masked -- every line must still
+    be the same line: same text, same number of numeric fields, the grid's parameter dicts, sample ids and actual
+    phenotypes identical, the chosen C one of the grid's; the coefficient table names the same k-mers with the same carrier
+    counts and sample lists.  (That the writers reproduce the reference's bytes when the numbers ARE the same is
+    tests/test_host_modeling.py::test_summary_and_coefficient_files_equal_the_reference_byte_for_byte.)"""
+    from helpers import mask_numbers
+    ds = load_dataset(tag)
+    _write_dataset(ds, str(tmp_path))
+    _run(tmp_path, ["modeling", "data.pheno"] + extra)
+    ref = os.path.join(ds["dir"], "model")
+    fn = "summary_of_log_reg_analysis_Pheno.txt"
+    g, w = open(fn).read().splitlines(), open(os.path.join(ref, fn)).read().splitlines()
+    assert len(g) == len(w)
+    in_predictions = False
+    for a, b in zip(g, w):
+        assert mask_numbers(a) == mask_numbers(b), (a, b)
+        if a.startswith("Sample_ID "):
+            in_predictions = True
+        elif in_predictions and not a.strip():
+            in_predictions = False
+        elif in_predictions:
+            assert a.split()[:2] == b.split()[:2], (a, b)               # sample id and actual phenotype
+        if " for {" in a:
+            assert a.split(" for ")[1] == b.split(" for ")[1], (a, b)    # the parameter dict of a grid-score line
+        if a.startswith("C : "):
+            assert any(abs(float(a[4:]) - 1.0 / al) <= 1e-12 / al for al in np.logspace(-3, 3, 13)), a
+    fn = "k-mers_and_coefficients_in_log_reg_model_Pheno.txt"
+    got = [l.split("\t") for l in open(fn).read().splitlines()]
+    want = [l.split("\t") for l in open(os.path.join(ref, fn)).read().splitlines()]
+    assert got[0] == want[0] and len(got) == len(want)
+    if tag == "ds_bonf":         # (no cut inside a p-value tie class: the same k-mers; ds_omitB cuts 100 out of a larger class)
+        assert sorted((x[0], x[2], x[3]) for x in got[1:]) == sorted((x[0], x[2], x[3]) for x in want[1:])
+    else:
+        both = {x[0]: (x[2], x[3]) for x in want[1:]}
+        assert all(both[x[0]] == (x[2], x[3]) for x in got[1:] if x[0] in both)
