@@ -705,6 +705,10 @@ int build_presence_merge(psk_ctx *ctx, uint64_t total_pairs, uint64_t *n_kmers, 
             div = strtoull(e, &end, 10);
             if (!*e || *end) return psk_fail(ctx, PSK_EINVAL, "PSK_MERGE_REC_DIV=%s: expected a whole number (0 = no records)", e);
         }
+        // The pool has a fixed part -- every wave's claims, whatever it holds -- of about a gigabyte: a build of a few million
+        // pairs gains nothing from records (its merging pass 2 takes microseconds) and is spared that reservation, unless the
+        // knob asks for records explicitly (tests of the replay on small sets)
+        if (div && total_pairs < (16ull << 20) && !getenv("PSK_MERGE_REC_DIV")) div = 0;
         if (div) {
             // + every wave's claims under way (two) and the one it ends in; a region takes what the ranges that map to it need:
             // half as much again for their imbalance
@@ -717,14 +721,20 @@ int build_presence_merge(psk_ctx *ctx, uint64_t total_pairs, uint64_t *n_kmers, 
             chunks = region_chunks * PM_REC_REGIONS;
             if (chunks < (1ull << 31)) {
                 const size_t wbytes = w32 ? 4 : 8, ctr_bytes = (size_t)(PM_REC_REGIONS + 1) * PM_REC_CTR_STRIDE * 4;
-                PSK_TRY(dev_reserve(ctx, ctx->valsA, chunks * 64 * (wbytes + 8)));
-                PSK_TRY(dev_reserve(ctx, ctx->valsB, ctr_bytes + chunks * 8));
-                rec.ctr = ctx->valsB.as<uint32_t>();
-                rec.hdr = reinterpret_cast<uint2 *>(ctx->valsB.as<uint8_t>() + ctr_bytes);
-                rec.masks = ctx->valsA.as<unsigned long long>();
-                rec.words = ctx->valsA.as<uint8_t>() + chunks * 64 * 8;
-                rec.region_chunks = (uint32_t)region_chunks;
-                PSK_HIP(ctx, hipMemsetAsync(ctx->valsB.p, 0, ctr_bytes + chunks * 8, ctx->stream));
+                // a pool that cannot be had (memory held by the lists and the matrix of a large run) costs the replay, not the
+                // build: without records pass 2 merges again
+                if (dev_reserve(ctx, ctx->valsA, chunks * 64 * (wbytes + 8)) == PSK_OK &&
+                    dev_reserve(ctx, ctx->valsB, ctr_bytes + chunks * 8) == PSK_OK) {
+                    rec.ctr = ctx->valsB.as<uint32_t>();
+                    rec.hdr = reinterpret_cast<uint2 *>(ctx->valsB.as<uint8_t>() + ctr_bytes);
+                    rec.masks = ctx->valsA.as<unsigned long long>();
+                    rec.words = ctx->valsA.as<uint8_t>() + chunks * 64 * 8;
+                    rec.region_chunks = (uint32_t)region_chunks;
+                    PSK_HIP(ctx, hipMemsetAsync(ctx->valsB.p, 0, ctr_bytes + chunks * 8, ctx->stream));
+                } else {
+                    ctx->err.clear();
+                    (void)hipGetLastError();
+                }
             }
         }
     }

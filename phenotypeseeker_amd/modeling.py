@@ -545,7 +545,8 @@ class phenotypes:
                 padded = np.zeros((n_rows, wpr * 64), np.uint8)
                 padded[:, :len(names)] = pres != 0
                 bits = np.packbits(padded, axis=1, bitorder="little").view("<u8")
-            bits = np.ascontiguousarray(bits, dtype=np.uint64).reshape(n_rows, -1)
+            # (no surviving row: numpy cannot infer -1 for an empty array; the table is then the header line alone)
+            bits = np.ascontiguousarray(bits, dtype=np.uint64).reshape(n_rows, -1 if n_rows else (len(names) + 63) // 64)
             enc = [nm.encode() for nm in names]
             off = np.zeros(len(enc) + 1, dtype=np.int64)
             off[1:] = np.cumsum([len(e) for e in enc])
@@ -669,7 +670,7 @@ class phenotypes:
         self.get_ML_df()
         short = self.model_name_short
         summary = open("summary_of_%s_analysis_%s.txt" % (short, self.name), "w")
-        coeff = open("k-mers_and_coefficients_in_%s_model_%s.txt" % (short, self.name), "w")
+        coeff_path = "k-mers_and_coefficients_in_%s_model_%s.txt" % (short, self.name)
         X = self.ML["X"].astype(np.float64)
         index = list(self.ML["index"])
         binary = self.pred_scale == "binary"
@@ -748,9 +749,8 @@ class phenotypes:
             else:
                 import joblib
                 joblib.dump(package, fh)
-        self._write_model_coefficients(coeff)
+        self._write_model_coefficients(coeff_path)
         summary.close()
-        coeff.close()
 
     def _cross_validation_results(self, out):
         """(:1219-1237)"""
@@ -824,15 +824,16 @@ class phenotypes:
                            ("Cohen kappa", "kappa"), ("Very major error rate", "VME"), ("Major error rate", "ME")):
             out.write("%s: %s\n" % (label, mean[key]))
 
-    def _write_model_coefficients(self, out):
-        """(:1414-1455)"""
-        out.write("K-mer\tcoef._in_" + self.model_name_short + "_model\tNo._of_samples_with_k-mer\tSamples_with_k-mer\n")
+    def _write_model_coefficients(self, path):
+        """(:1414-1455).  The header is written and the file CLOSED here; libpsk then appends the lines to `path` (no Python
+        file object is shared with it: a stale offset could overwrite what it wrote)."""
+        with open(path, "w") as out:
+            out.write("K-mer\tcoef._in_" + self.model_name_short + "_model\tNo._of_samples_with_k-mer\tSamples_with_k-mer\n")
         be = self.model_fitted.best_estimator_
         coefs = be.coef_[0] if self.pred_scale == "binary" else be.coef_
         X, index, kmers = self.ML["X"], self.ML["index"], self.ML["kmers"]
         # the lines are formatted by libpsk (psk_write_model_coefficients: a 2,048-sample model names a million samples --
         # 0.07 s of joins here); it appends to the file whose header this function has just written
-        out.flush()
         kenc, nenc = [km.encode() for km in kmers], [nm.encode() for nm in index]
         koff = np.zeros(len(kenc) + 1, dtype=np.int64)
         koff[1:] = np.cumsum([len(e) for e in kenc])
@@ -841,7 +842,7 @@ class phenotypes:
         Xa = np.ascontiguousarray(np.asarray(X).reshape(len(nenc), len(kenc)), dtype=np.int64)
         cf = np.ascontiguousarray(np.asarray(coefs, dtype=np.float64).reshape(-1)[:len(kenc)])
         vp = lambda a: a.ctypes.data_as(ctypes.c_void_p)
-        rc = _lib.load().psk_write_model_coefficients(None, os.fsencode(out.name), len(kenc), b"".join(kenc), vp(koff), vp(cf), vp(Xa),
+        rc = _lib.load().psk_write_model_coefficients(None, os.fsencode(path), len(kenc), b"".join(kenc), vp(koff), vp(cf), vp(Xa),
                                                       len(nenc), b"".join(nenc), vp(noff))
         if rc != 0:
             raise PskError("psk_write_model_coefficients failed (%d)" % rc, rc)

@@ -1391,18 +1391,24 @@ def test_merge_presence_build_equals_the_oracle_and_the_sort_route(ctx, oracle, 
             ctx.count_kmers_batch(s0, datas[s0:s0 + 64], 4)
         kept = [w[(w >= lo) & ((w < hi) if hi else np.ones(len(w), bool))] for w in lists]
         monkeypatch.delenv("PSK_NO_MERGE_PRESENCE", raising=False)
+        # r04: pass 2 replays the records pass 1 left -- the default from 16 M pairs on (r05: smaller builds skip the pool's
+        # fixed gigabyte), asked for here by the knob
+        monkeypatch.setenv("PSK_MERGE_REC_DIV", "12")
         m = ctx.build_presence()
+        monkeypatch.delenv("PSK_MERGE_REC_DIV")
         uw, rows = ctx.get_union(), ctx.get_rows(np.arange(m, dtype=np.uint64))
         want = oracle.union(kept)
         assert m == len(want) and np.array_equal(uw, want), (lo, hi)
         assert np.array_equal(rows, oracle.presence_bits(kept, uw, wpr=ctx.presence_shape()[1]))
-        # r04: pass 2 replays the records pass 1 left (the default, above); without records it merges the lists again
-        # (PSK_MERGE_REC_DIV=0), and so it does when the record pool overflows (regions of eight chunks)
-        for name, val in (("PSK_MERGE_REC_DIV", "0"), ("PSK_MERGE_REC_REGION", "8")):
-            monkeypatch.setenv(name, val)
+        # without records pass 2 merges the lists again (the default at this size, and PSK_MERGE_REC_DIV=0), and so it does
+        # when the record pool overflows (regions of eight chunks)
+        for envs in ({}, {"PSK_MERGE_REC_DIV": "0"}, {"PSK_MERGE_REC_DIV": "12", "PSK_MERGE_REC_REGION": "8"}):
+            for name, val in envs.items():
+                monkeypatch.setenv(name, val)
             assert ctx.build_presence() == m
-            assert np.array_equal(ctx.get_union(), uw) and np.array_equal(ctx.get_rows(np.arange(m, dtype=np.uint64)), rows), name
-            monkeypatch.delenv(name)
+            assert np.array_equal(ctx.get_union(), uw) and np.array_equal(ctx.get_rows(np.arange(m, dtype=np.uint64)), rows), envs
+            for name in envs:
+                monkeypatch.delenv(name)
         monkeypatch.setenv("PSK_NO_MERGE_PRESENCE", "1")
         assert ctx.build_presence() == m
         assert np.array_equal(ctx.get_union(), uw) and np.array_equal(ctx.get_rows(np.arange(m, dtype=np.uint64)), rows)

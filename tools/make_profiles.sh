@@ -1,35 +1,52 @@
 #!/bin/bash
 # Regenerates the rocprofv3 evidence of a round on the GPU box (run through gpurun from the repo root):
-#   tools/make_profiles.sh r03
-# Writes gpurun_out/profiles_<tag>/<workload>/: kernel-trace stats, the program's own output, and (bench, cfg3slab,
-# ingest) two separate --pmc passes (FETCH_SIZE, WRITE_SIZE; no tracing flags with counters).  tools/summarise_profiles.py
+#   tools/make_profiles.sh r05 [workload ...]
+# Writes gpurun_out/profiles_<tag>/<workload>/: kernel-trace stats, the program's own output, and one directory per --pmc
+# pass (counters are collected in passes of their own, never together with a tracing flag).  tools/summarise_profiles.py
 # turns that into the committed files under profiles/.
+#   pass names: fetch = FETCH_SIZE, write = WRITE_SIZE, rdreq / wrreq = the raw L2 -> fabric request counters FETCH_SIZE /
+#   WRITE_SIZE are derived from (how many requests, how many of them short), hit = L2 hits / misses, lds = the SQ's LDS
+#   counters (bank-conflict cycles, LDS-active cycles, LDS instructions, issue stalls on the LDS) with the wave-cycle split
 set -u
-TAG=${1:-r04}
+TAG=${1:-r05}
+shift || true
+ONLY="$*"
 ROOT=${GRAFT_REPO_ROOT:-$PWD}
 OUT=$ROOT/gpurun_out/profiles_$TAG
 mkdir -p "$OUT"
 cd /tmp && export TMPDIR=/tmp
-prof() {   # name pmc(0/1) program args...
-  local name=$1 pmc=$2; shift 2
+pmc_of() {
+  case $1 in
+    fetch) echo "FETCH_SIZE";;
+    write) echo "WRITE_SIZE";;
+    rdreq) echo "TCC_EA0_RDREQ_sum TCC_EA0_RDREQ_32B_sum";;
+    wrreq) echo "TCC_EA0_WRREQ_sum TCC_EA0_WRREQ_64B_sum";;
+    hit)   echo "TCC_HIT_sum TCC_MISS_sum";;
+    lds)   echo "SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_INSTS_LDS SQ_WAIT_INST_LDS SQ_WAVE_CYCLES SQ_WAIT_INST_ANY SQ_WAIT_ANY SQ_ACTIVE_INST_ANY";;
+  esac
+}
+wanted() { [ -z "$ONLY" ] || [[ " $ONLY " == *" $1 "* ]]; }
+prof() {   # name "pass pass ..." program args...      (the program itself after `--`: no env / bash -c hop under the profiler)
+  local name=$1 passes=$2; shift 2
+  wanted "$name" || return 0
   local d=$OUT/$name; mkdir -p "$d"
   # (every run under its own time limit: a hung profile must not hold the GPU box until gpurun's limit)
-  timeout 400 rocprofv3 --kernel-trace --stats --output-format csv -d "$d/trace" -o run -- python3 "$@" > "$d/stdout.txt" 2> "$d/trace.err"
-  if [ "$pmc" = "1" ]; then
-    timeout 400 rocprofv3 --pmc FETCH_SIZE --output-format csv -d "$d/pmc_fetch" -o run -- python3 "$@" > /dev/null 2> "$d/pmc_fetch.err"
-    timeout 400 rocprofv3 --pmc WRITE_SIZE --output-format csv -d "$d/pmc_write" -o run -- python3 "$@" > /dev/null 2> "$d/pmc_write.err"
-  fi
+  timeout 400 rocprofv3 --kernel-trace --stats --output-format csv -d "$d/trace" -o run -- "$@" > "$d/stdout.txt" 2> "$d/trace.err"
+  for p in $passes; do
+    timeout 400 rocprofv3 --pmc $(pmc_of $p) --output-format csv -d "$d/pmc_$p" -o run -- "$@" > /dev/null 2> "$d/pmc_$p.err"
+  done
 }
 BENCH="--steps 50 --warmup 5 --no-cpu-baseline"
-python3 "$ROOT/bench.py" $BENCH > "$OUT/bench_unprofiled.json" 2> "$OUT/bench_unprofiled.err"
-prof bench 1 "$ROOT/bench.py" $BENCH
-prof ingest 1 "$ROOT/tools/profile_workloads.py" ingest
-prof cfg3slab 1 "$ROOT/tools/profile_workloads.py" cfg3slab
-prof moments 0 "$ROOT/tools/profile_workloads.py" moments
-prof fastq 0 "$ROOT/tools/profile_workloads.py" fastq
-prof solver 0 "$ROOT/tools/profile_workloads.py" solver
-prof solver4096 0 "$ROOT/tools/profile_workloads.py" solver4096
-prof predict 0 "$ROOT/tools/profile_workloads.py" predict
-prof weights 0 "$ROOT/tools/profile_workloads.py" weights
-prof lasso 0 "$ROOT/tools/profile_workloads.py" lasso
+if wanted bench; then python3 "$ROOT/bench.py" $BENCH > "$OUT/bench_unprofiled.json" 2> "$OUT/bench_unprofiled.err"; fi
+prof calib "fetch write rdreq wrreq hit" "$ROOT/tools/calib/pmc_calib" 3
+prof bench "fetch write" python3 "$ROOT/bench.py" $BENCH
+prof ingest "fetch write rdreq wrreq" python3 "$ROOT/tools/profile_workloads.py" ingest
+prof cfg3slab "fetch write rdreq wrreq" python3 "$ROOT/tools/profile_workloads.py" cfg3slab
+prof moments "fetch write lds" python3 "$ROOT/tools/profile_workloads.py" moments
+prof fastq "" python3 "$ROOT/tools/profile_workloads.py" fastq
+prof solver "" python3 "$ROOT/tools/profile_workloads.py" solver
+prof solver4096 "" python3 "$ROOT/tools/profile_workloads.py" solver4096
+prof predict "" python3 "$ROOT/tools/profile_workloads.py" predict
+prof weights "" python3 "$ROOT/tools/profile_workloads.py" weights
+prof lasso "" python3 "$ROOT/tools/profile_workloads.py" lasso
 du -sh "$OUT"
