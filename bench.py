@@ -464,7 +464,7 @@ def main():
     # stream-read ceiling"): a kernel that only reads the matrix, 16 B per lane, as many launches as the timed steps, its clocks
     # settled like the scan's -- outside the timed region
     ctx.stream_read_ceiling(3)
-    ceil_ms, ceil_bytes = ctx.stream_read_ceiling(max(args.steps, 10))
+    ceil_ms, ceil_bytes, ceil_shape = ctx.stream_read_ceiling(max(args.steps, 10))
     ceiling = ceil_bytes / (ceil_ms * 1e-3) / 1e9
     stored_rate = int(M) * 8 * wpr / (mean_ms * 1e-3) / 1e9      # bytes of the matrix as stored (= algorithmic unless rows are padded)
     # a multi-rank figure is a scaling point only when its collectives ran on RCCL with one GPU per rank
@@ -489,10 +489,10 @@ def main():
                      "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "kernel": "chi2_scan_kernel",
                      "kernel_ms": mean_ms, "algorithmic_bytes_per_launch": alg_bytes,
                      "stored_bytes_per_launch": int(M) * 8 * wpr,
-                     "measured_stream_ceiling": {"GBps": ceiling, "kernel": "stream_read_kernel", "kernel_ms": ceil_ms,
+                     "measured_stream_ceiling": {"GBps": ceiling, "kernel": "stream_read_kernel (%s)" % ceil_shape, "kernel_ms": ceil_ms,
                                                  "bytes_per_launch": int(ceil_bytes), "frac_of_peak": ceiling / HBM_PEAK_GBS,
-                                                 "what": "the same matrix read once per launch by a kernel that does nothing else, timed "
-                                                         "with HIP events in this run"},
+                                                 "what": "the same matrix read once per launch by a kernel that does nothing else (the fastest "
+                                                         "of four shapes), timed with HIP events in this run"},
                      "frac_of_measured_ceiling": stored_rate / ceiling},
     }
 

@@ -211,8 +211,10 @@ int psk_rescan_timed(psk_ctx *ctx, int reps, double *mean_ms);
 /* Measurement only (the scan's achieved bandwidth is quoted "against both the 8 TB/s spec and
  * the measured stream-read ceiling"; no reference call site -- the reference has no notion of bandwidth): reads the
  * presence matrix of the context once per launch with a kernel that does nothing else (16 B per lane), `reps` launches
- * timed with HIP events on the context's stream.  *bytes_per_launch = rows x 8 x words per row as stored. */
-int psk_stream_read_ceiling(psk_ctx *ctx, int reps, double *mean_ms, uint64_t *bytes_per_launch);
+ * timed with HIP events on the context's stream.  Four shapes of that kernel are timed (grid-stride or the scan's own
+ * wave-contiguous pieces, non-temporal or plain loads): the fastest is the ceiling, *shape (0..3) says which.
+ * *bytes_per_launch = rows x 8 x words per row as stored. */
+int psk_stream_read_ceiling(psk_ctx *ctx, int reps, double *mean_ms, uint64_t *bytes_per_launch, int *shape);
 
 /* ---- a10: L1 models over the selected k-mers ------------------------------------------------
  * Replaces the estimator fits behind GridSearchCV (modeling.py:994-1014, :1075-1085,

@@ -334,11 +334,12 @@ class PskContext:
         return ms.value
 
     def stream_read_ceiling(self, reps):
-        """(mean ms, bytes) of a plain 16-B-per-lane read of the presence matrix: the stream-read ceiling the scan's
-        achieved bandwidth is quoted against (psk_stream_read_ceiling)."""
-        ms, nb = ctypes.c_double(), ctypes.c_uint64()
-        self._check(self._lib.psk_stream_read_ceiling(self._h, int(reps), ctypes.byref(ms), ctypes.byref(nb)), "psk_stream_read_ceiling")
-        return ms.value, nb.value
+        """(mean ms, bytes, shape) of the fastest plain 16-B-per-lane read of the presence matrix: the stream-read ceiling
+        the scan's achieved bandwidth is quoted against (psk_stream_read_ceiling)."""
+        ms, nb, shape = ctypes.c_double(), ctypes.c_uint64(), ctypes.c_int()
+        self._check(self._lib.psk_stream_read_ceiling(self._h, int(reps), ctypes.byref(ms), ctypes.byref(nb), ctypes.byref(shape)),
+                    "psk_stream_read_ceiling")
+        return ms.value, nb.value, ("grid-stride, non-temporal", "grid-stride", "wave-contiguous, non-temporal", "wave-contiguous")[shape.value]
 
     # -- models -----------------------------------------------------------------------------------
     def _fit(self, fn, name, X, y, ydtype, fold, fit_param, fit_fold, tol, max_iter):

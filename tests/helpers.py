@@ -69,6 +69,8 @@ def large_design(z, tag):
 
 def _num(tok):
     t = tok.strip("(),:;[]{}'")
+    if t.startswith("+/-"):          # "(+/-0.234)" of a grid-score line
+        t = t[3:]
     try:
         return float(t)
     except ValueError:

@@ -359,45 +359,80 @@ def test_cfg3_whole_dataset_on_one_gpu_equals_its_eight_slabs(oracle):
             assert np.array_equal(np.concatenate(got[key]), res_all[key]), key
 
 
-def test_cfg5_thirty_two_full_size_fastq_samples(oracle):
-    """Config 5 with 32 of its 512 samples at full size (the 8-sample test goes through files): 32 x 2 M 150-bp
-    reads, 0.64 GB of FASTQ each, generated and handed over four at a time (20 GB in all never sit in host memory at once).
-    Window counts, ascending lists whose counts add up, column sums of the matrix = list lengths, the scan's survivors
-    equal to the oracle's on a sample of the rows, the gene's k-mers present in every carrier."""
+def test_cfg5_one_ranks_share_of_full_size_fastq_samples_through_the_list_exchange(oracle):
+    """Config 5 at ONE RANK'S SHARE of the 8-GPU split (VERDICT r04 #6a; r03/r04 ran 32 samples counted in place): 64 of its 512
+    samples at full size -- 2 M 150-bp reads, 0.64 GB of FASTQ each, generated and handed over four at a time (41 GB in all
+    never sit in host memory at once) -- through the sample-parallel ingest of the sharded path: counted in a counting
+    context, moved by dist.ListExchange over an RCCL communicator (one rank: ncclSend / ncclRecv to itself, the
+    `--force-exchange` form) into the slab context, matrix built there.  Window counts, ascending lists whose counts add
+    up, the exchanged lists equal to lists counted in place, column sums of the matrix = list lengths, the scan's
+    survivors equal to the oracle's on a sample of the rows, the gene's k-mers present in every carrier."""
+    import tempfile
+    from phenotypeseeker_amd import dist
     from phenotypeseeker_amd.engine import PskContext
     from phenotypeseeker_amd.synth import GenomeSet
-    n, reads, rl, k = 32, 2_000_000, 150, 13
+    n, reads, rl, k = 64, 2_000_000, 150, 13
     gs = GenomeSet(n, 5_000_000, seed=99)
-    with PskContext(0) as ctx:
-        ctx.begin(k, n)
-        nu, nt = [], []
-        for s0 in range(0, n, 4):
-            batch = [_fastq_sample(gs.codes(i), reads, rl, seed=[5, i]) for i in range(s0, s0 + 4)]
-            a, b = ctx.count_kmers_batch(s0, batch, 8)
-            nu += list(a)
-            nt += list(b)
-            del batch
-        assert nt == [reads * (rl - k + 1)] * n
-        for i in (0, 17, 31):
-            w0, f0 = ctx.get_list(i, nu[i])
-            assert np.all(w0[1:] > w0[:-1]) and int(f0.astype(np.uint64).sum()) == nt[i]
-        m = ctx.build_presence()
-        uw = ctx.get_union()
-        assert m == len(uw) and np.all(uw[1:] > uw[:-1])
-        sums = np.zeros(n, dtype=np.int64)
-        for r0 in range(0, m, 1 << 21):
-            sums += _popcount_columns(ctx.get_rows(np.arange(r0, min(r0 + (1 << 21), m), dtype=np.uint64)), n)
-        assert sums.tolist() == list(nu)
-        pheno = np.array([gs.phenotype(i) for i in range(n)], dtype=np.int8)
-        npass = ctx.chi2_scan(pheno, None, 2, n - 2, 0.05, True, m)
-        res = ctx.get_results(npass)
-        some = ctx.get_rows(np.arange(0, m, 499, dtype=np.uint64))
-        ref = oracle.chi2_scan(some, pheno.tolist(), np.ones(n), n, 2, n - 2, 0.05, True, m)
-        kept = np.nonzero(ref["keep"])[0] * 499
-        assert np.array_equal(np.intersect1d(res["row"].astype(np.int64), np.arange(0, m, 499)), kept)
-        gene_words = np.unique(oracle.count_kmers(b">g\n" + bytes(np.frombuffer(b"ACGT", dtype=np.uint8)[gs.gene]) + b"\n", k)[0])
-        carriers = sum(gs.has_gene(i) for i in range(n))
-        gpos = np.searchsorted(uw, gene_words)
-        assert np.array_equal(uw[gpos], gene_words)
-        grow = ctx.get_rows(gpos.astype(np.uint64))
-        assert (np.unpackbits(grow.view(np.uint8), axis=1, bitorder="little").sum(axis=1) >= carriers).all()
+    old = {v: os.environ.get(v) for v in ("PSK_RDZV_FILE", "PSK_DIST_TRANSPORT", "PSK_RDZV_DIR", "PSK_LAUNCH_NONCE")}
+    os.environ["PSK_RDZV_FILE"] = os.path.join(tempfile.mkdtemp(prefix="psk_rdzv_"), "id")
+    for v in ("PSK_DIST_TRANSPORT", "PSK_RDZV_DIR", "PSK_LAUNCH_NONCE"):
+        os.environ.pop(v, None)
+    g = dist.Group()
+    g.world, g.rank, g.local_rank = 1, 0, 0
+    try:
+        g.init(force=True)
+        assert g.backend == "rccl" and g.rccl_ranks == 1
+        with PskContext(0) as cnt, PskContext(0) as ctx:
+            cnt.begin(k, n)
+            nu, nt = [], []
+            for s0 in range(0, n, 4):
+                batch = [_fastq_sample(gs.codes(i), reads, rl, seed=[5, i]) for i in range(s0, s0 + 4)]
+                a, b = cnt.count_kmers_batch(s0, batch, 8)
+                nu += list(a)
+                nt += list(b)
+                if s0 == 16:      # three samples counted in place as well, in the context the exchange fills
+                    keep_batch = batch[1]
+                del batch
+            assert nt == [reads * (rl - k + 1)] * n
+            ctx.begin(k, n)
+            pairs = dist.ListExchange(g, k).run(cnt, ctx, n, nt)
+            assert pairs == sum(nu)
+            for i in (0, 17, 63):
+                w0, f0 = ctx.get_list(i, nu[i])
+                assert np.all(w0[1:] > w0[:-1]) and int(f0.astype(np.uint64).sum()) == nt[i]
+                w1, f1 = cnt.get_list(i, nu[i])
+                assert np.array_equal(w0, w1) and np.array_equal(f0, f1), i
+            with PskContext(0) as solo:          # sample 17 counted in place: the list the exchange delivered
+                solo.begin(k, 1)
+                a, b = solo.count_kmers_batch(0, [keep_batch], 2)
+                ws, fs = solo.get_list(0, a[0])
+                w0, f0 = ctx.get_list(17, nu[17])
+                assert a[0] == nu[17] and np.array_equal(ws, w0) and np.array_equal(fs, f0)
+            del keep_batch
+            m = ctx.build_presence()
+            uw = ctx.get_union()
+            assert m == len(uw) and np.all(uw[1:] > uw[:-1])
+            sums = np.zeros(n, dtype=np.int64)
+            for r0 in range(0, m, 1 << 21):
+                sums += _popcount_columns(ctx.get_rows(np.arange(r0, min(r0 + (1 << 21), m), dtype=np.uint64)), n)
+            assert sums.tolist() == list(nu)
+            pheno = np.array([gs.phenotype(i) for i in range(n)], dtype=np.int8)
+            npass = ctx.chi2_scan(pheno, None, 2, n - 2, 0.05, True, m)
+            res = ctx.get_results(npass)
+            some = ctx.get_rows(np.arange(0, m, 499, dtype=np.uint64))
+            ref = oracle.chi2_scan(some, pheno.tolist(), np.ones(n), n, 2, n - 2, 0.05, True, m)
+            kept = np.nonzero(ref["keep"])[0] * 499
+            assert np.array_equal(np.intersect1d(res["row"].astype(np.int64), np.arange(0, m, 499)), kept)
+            gene_words = np.unique(oracle.count_kmers(b">g\n" + bytes(np.frombuffer(b"ACGT", dtype=np.uint8)[gs.gene]) + b"\n", k)[0])
+            carriers = sum(gs.has_gene(i) for i in range(n))
+            gpos = np.searchsorted(uw, gene_words)
+            assert np.array_equal(uw[gpos], gene_words)
+            grow = ctx.get_rows(gpos.astype(np.uint64))
+            assert (np.unpackbits(grow.view(np.uint8), axis=1, bitorder="little").sum(axis=1) >= carriers).all()
+    finally:
+        g.close()
+        for v, val in old.items():
+            if val is None:
+                os.environ.pop(v, None)
+            else:
+                os.environ[v] = val
