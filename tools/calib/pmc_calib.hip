@@ -38,7 +38,7 @@ __global__ __launch_bounds__(256) void calib_read_coalesced(const T *__restrict_
 {
     uint32_t acc = 0;
     for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (size_t)gridDim.x * 256) acc ^= fold<T>(p[i]);
-    if (acc == 0x9e3779b9u) *sink = acc;
+    if (acc == 0x5bu && n == ~(size_t)0) *sink = acc;   // (never true at run time, not provably so: keeps the loads)
 }
 
 // every lane walks its OWN contiguous stream, 16 bytes a step (presence_merge.hip pm_mark: 64 lists per wave)
@@ -48,7 +48,7 @@ __global__ __launch_bounds__(64) void calib_read16_lane_streams(const uint4 *__r
     const uint4 *q = p + lane * per_lane_vec;
     uint32_t acc = 0;
     for (size_t i = 0; i < per_lane_vec; i++) acc ^= fold<uint4>(q[i]);
-    if (acc == 0x9e3779b9u) *sink = acc;
+    if (acc == 0x5bu && per_lane_vec == ~(size_t)0) *sink = acc;   // (never true at run time, not provably so: keeps the loads)
 }
 
 // a byte stream cut into 64-byte per-lane segments, each read as four 16-byte loads by its lane (dense_count.hip /
@@ -61,7 +61,7 @@ __global__ __launch_bounds__(256) void calib_read16_lane_segments(const uint4 *_
 #pragma unroll
         for (int j = 0; j < 4; j++) acc ^= fold<uint4>(q[j]);
     }
-    if (acc == 0x9e3779b9u) *sink = acc;
+    if (acc == 0x5bu && n_seg == ~(size_t)0) *sink = acc;   // (never true at run time, not provably so: keeps the loads)
 }
 
 // random probes of a large table (rank lookups, dictionary probes): one T per lane at a hashed index
@@ -71,7 +71,7 @@ __global__ __launch_bounds__(256) void calib_read_gather(const T *__restrict__ p
     uint32_t acc = 0;
     for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n_probes; i += (size_t)gridDim.x * 256)
         acc ^= fold<T>(p[mix(i) % n_table]);
-    if (acc == 0x9e3779b9u) *sink = acc;
+    if (acc == 0x5bu && n_probes == ~(size_t)0) *sink = acc;   // (never true at run time, not provably so: keeps the loads)
 }
 
 // ---- writes ------------------------------------------------------------------------------------------------------

@@ -12,6 +12,14 @@ table -- the filtered k-mer list north_star asks to reproduce is chi2_results_<p
 where /root/reference and its bundled binaries exist: the build container) the unmodified reference is run on the same
 files through oracle/ref_shim.py and the tables are compared: same rows, same p-value strings in the same order.
 PSK_CFG1_TARBALL names the tarball for tests/test_gpu_e2e.py::test_cfg1_example_dataset, which skips without it.
+
+The GPU and the reference never meet in one place here (the GPU box has no /root/reference, the build container no GPU),
+so the two halves can run apart:
+    GPU box:          tools/cfg1_repro.py T.tar.gz --save-product DIR      (this package's tables are kept in DIR)
+    build container:  tools/cfg1_repro.py T.tar.gz --reference --product-from DIR
+r05: executed end to end that way on a stand-in tarball of the same layout (tools/make_cfg1_standin.py: the 60 AT-rich
+1-Mbp genomes of tests/golden/ds_atrich under PS_modeling_example_files/, data.pheno addressing them relative to the
+directory the tarball is unpacked in) -- profiles/r05_cfg1_standin.txt.
 """
 import argparse
 import hashlib
@@ -118,6 +126,8 @@ def main():
     ap.add_argument("--omit_B_correction", action="store_true")
     ap.add_argument("--reference", action="store_true", help="also run /root/reference through oracle/ref_shim.py and compare")
     ap.add_argument("--keep", action="store_true")
+    ap.add_argument("--save-product", metavar="DIR", help="keep this package's result tables in DIR (GPU half of a split run)")
+    ap.add_argument("--product-from", metavar="DIR", help="take this package's tables from DIR instead of running it (reference half)")
     a = ap.parse_args()
     flags = ["--omit_B_correction"] if a.omit_B_correction else []
     tmp = tempfile.mkdtemp(prefix="psk_cfg1_")
@@ -126,9 +136,18 @@ def main():
         ours_dir, ref_dir = os.path.join(tmp, "ours"), os.path.join(tmp, "ref")
         os.makedirs(ours_dir)
         absolutise(os.path.join(data_dir, "data.pheno"), data_dir, os.path.join(tmp, "data.pheno"))
-        wall = run_product(os.path.join(tmp, "data.pheno"), ours_dir, flags)
-        ours = tables(ours_dir)
-        print("product: %.2f s, %d tables" % (wall, len(ours)))
+        if a.product_from:
+            ours = tables(a.product_from)
+            print("product: %d tables taken from %s" % (len(ours), a.product_from))
+        else:
+            wall = run_product(os.path.join(tmp, "data.pheno"), ours_dir, flags)
+            ours = tables(ours_dir)
+            print("product: %.2f s, %d tables" % (wall, len(ours)))
+        if a.save_product:
+            os.makedirs(a.save_product, exist_ok=True)
+            for fn, blob in ours.items():
+                with open(os.path.join(a.save_product, fn), "wb") as f:
+                    f.write(blob)
         for fn, blob in ours.items():
             print("  %-50s %8d rows  sha256 %s" % (fn, blob.count(b"\n") - 1, hashlib.sha256(blob).hexdigest()))
         if a.reference:
