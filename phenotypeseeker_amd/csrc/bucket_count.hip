@@ -1,4 +1,6 @@
-// a1 for 32-bit word spaces beyond the dense form (k = 14..16): a bucketed sort instead of four radix passes
+// a1 for the word spaces beyond the dense form (k = 14..32; r05: the 64-bit words of k = 17..32 as well -- every kernel below is a
+// template over the word type W = uint32_t (k <= 16, 512-thread tiles of 16,384 bases) | uint64_t (k >= 17, 256-thread tiles of
+// 8,192 bases: a tile's staged words are 64 KB of LDS either way)): a bucketed sort instead of four (eight) radix passes
 // (replaces bin/glistmaker; modeling.py:303-315).  The radix route runs 17 launches per sample (extract, 4 x
 // (histogram, digit scan, scatter), 3 for the run lengths) -- 250-300 us for a 5-Mbp genome, and hardly less for the
 // 600,000 words a rank keeps of it under an 8-way slab filter, because every launch has its floor.  Here the word space
@@ -23,8 +25,8 @@
 
 namespace {
 
-constexpr int BT_THREADS = 512;
-constexpr int BT_TILE = BT_THREADS * KW_SEG;        // 16,384 bases per workgroup
+// threads of a counting tile: 512 x 32 window ends = 16,384 bases for 32-bit words, 256 x 32 = 8,192 for 64-bit ones
+template <typename W> struct BsGeo { static constexpr int THREADS = sizeof(W) == 4 ? 512 : 256; static constexpr int TILE = THREADS * KW_SEG; };
 constexpr uint32_t BS_SLOTS = 32;                   // pre-zeroed counter slots per buffer set
 #ifndef PSK_BS_SORT_THREADS
 #define PSK_BS_SORT_THREADS 1024
@@ -34,20 +36,27 @@ constexpr int BS_SORT_THREADS = PSK_BS_SORT_THREADS;
 #define PSK_BS_CAPMAX 8192
 #endif
 constexpr uint32_t BS_CAP_MAX = PSK_BS_CAPMAX;      // words a bucket may hold for the LDS sort
-constexpr size_t BP_LDS_BYTES = (size_t)(BT_TILE + BS_NB + BS_NB / 2 + BS_NB + 16 + 2056 + BT_TILE / 2) * 4;   // stage | h | lstart | splitters | scan | cells | buckets of the staged words
-constexpr size_t BSORT_LDS_BYTES = (size_t)(2 * BS_CAP_MAX + 2 * 2048 + 32) * 4;          // words | sorted words | sub-bin starts | fills | scan
+// stage | splitters | h | lstart | scan | cells | buckets of the staged words   (32-bit words: 127 KB; 64-bit: 116 KB)
+template <typename W> constexpr size_t bp_lds_bytes()
+{
+    return (size_t)BsGeo<W>::TILE * sizeof(W) + (size_t)BS_NB * sizeof(W) + (size_t)(BS_NB + BS_NB / 2 + 16 + 2056) * 4 + (size_t)BsGeo<W>::TILE * 2;
+}
+// words | sorted words | sub-bin starts | fills | scan   (32-bit words: 82 KB, two workgroups per CU; 64-bit: 148 KB, one)
+template <typename W> constexpr size_t bsort_lds_bytes() { return (size_t)2 * BS_CAP_MAX * sizeof(W) + (size_t)(2 * 2048 + 32) * 4; }
 
 // The bucket of a word = the largest b with spl[b] <= w (spl[0] = the first word of the slab).  A binary search over the splitters is eleven
 // dependent LDS reads per window; a coarse table over 4,096 equal cells of the run's word range (ct[c] = bucket of the
 // cell's first word) leaves a search over the one to three buckets that meet the cell.
 constexpr int BS_CELLS = 4096;
+template <typename W>
 struct BsMap {
-    uint32_t lo;      // first word of the range the cells cover (the slab's)
+    W lo;             // first word of the range the cells cover (the slab's)
     uint32_t shift;   // cell = (w - lo) >> shift
     uint32_t nb;      // buckets in use (a power of two, 64..2048): about 2,400 words each
 };
 
-__device__ __forceinline__ uint32_t bucket_search(const uint32_t *spl, uint32_t nb, uint32_t w)
+template <typename W>
+__device__ __forceinline__ uint32_t bucket_search(const W *spl, uint32_t nb, W w)
 {
     uint32_t b = 0;
     for (uint32_t step = nb >> 1; step > 0; step >>= 1)
@@ -55,10 +64,11 @@ __device__ __forceinline__ uint32_t bucket_search(const uint32_t *spl, uint32_t 
     return b;
 }
 
-__device__ __forceinline__ uint32_t bucket_of(const uint32_t *spl, const uint16_t *ct, const BsMap &mp, uint32_t w)
+template <typename W>
+__device__ __forceinline__ uint32_t bucket_of(const W *spl, const uint16_t *ct, const BsMap<W> &mp, W w)
 {
-    uint32_t c = (w - mp.lo) >> mp.shift;
-    c = c < (uint32_t)BS_CELLS ? c : (uint32_t)BS_CELLS - 1u;
+    const W cw = (w - mp.lo) >> mp.shift;
+    const uint32_t c = cw < (W)BS_CELLS ? (uint32_t)cw : (uint32_t)BS_CELLS - 1u;
     uint32_t b = ct[c], e = ct[c + 1];
     while (b < e) {
         const uint32_t mid = (b + e + 1u) >> 1;
@@ -69,24 +79,29 @@ __device__ __forceinline__ uint32_t bucket_of(const uint32_t *spl, const uint16_
 }
 
 // splitters = every (nu / nb)-th word of a sorted list of this run; then the coarse table
-__global__ void bs_splitters_kernel(const uint64_t *__restrict__ words, uint64_t nu, uint32_t nb, uint32_t lo, uint32_t *__restrict__ spl)
+template <typename W>
+__global__ void bs_splitters_kernel(const uint64_t *__restrict__ words, uint64_t nu, uint32_t nb, W lo, W *__restrict__ spl)
 {
     const uint32_t b = blockIdx.x * blockDim.x + threadIdx.x;
     if (b >= BS_NB) return;
     spl[b] = b == 0 ? lo :   // the first bucket begins where the slab does: a bucket's range is what its sub-bins divide
-             (b < nb ? (uint32_t)words[(uint64_t)b * nu / nb] : 0xffffffffu);
+             (b < nb ? (W)words[(uint64_t)b * nu / nb] : (W)~(W)0);
 }
 
-__global__ void bs_cells_kernel(const uint32_t *__restrict__ spl, BsMap mp, uint16_t *__restrict__ ct)
+template <typename W>
+__global__ void bs_cells_kernel(const W *__restrict__ spl, BsMap<W> mp, uint16_t *__restrict__ ct)
 {
     const uint32_t c = blockIdx.x * blockDim.x + threadIdx.x;
     if (c > (uint32_t)BS_CELLS) return;
-    const uint64_t first = (uint64_t)mp.lo + ((uint64_t)c << mp.shift);
-    ct[c] = (uint16_t)(c == (uint32_t)BS_CELLS || first > 0xffffffffull ? mp.nb - 1u : bucket_search(spl, mp.nb, (uint32_t)first));
+    // the first word of cell c, or "beyond the last word" (c << shift stays below 2^64: c < 2^12, shift <= 52)
+    const uint64_t off = (uint64_t)c << mp.shift, first = (uint64_t)mp.lo + off;
+    const bool beyond = c == (uint32_t)BS_CELLS || first < off || first > (uint64_t)(W)~(W)0;
+    ct[c] = (uint16_t)(beyond ? mp.nb - 1u : bucket_search<W>(spl, mp.nb, (W)first));
 }
 
 // the workgroup's copies of the splitters and the cells
-__device__ __forceinline__ void load_map(uint32_t *spl, uint16_t *ct, const uint32_t *__restrict__ spl_g, const uint16_t *__restrict__ ct_g,
+template <typename W>
+__device__ __forceinline__ void load_map(W *spl, uint16_t *ct, const W *__restrict__ spl_g, const uint16_t *__restrict__ ct_g,
                                          int threads)
 {
     for (uint32_t d = threadIdx.x; d < BS_NB; d += threads) spl[d] = spl_g[d];
@@ -95,22 +110,27 @@ __device__ __forceinline__ void load_map(uint32_t *spl, uint16_t *ct, const uint
 
 // ---- a group of samples per launch (bucket_group_enqueue; see dense_count.hip: a genome is one tile per CU) ---------------
 constexpr int BS_GROUP = 8;
+template <typename W>
 struct BsItem {
     const uint8_t *clean;
     uint64_t len;
-    uint32_t *cnt, *wgoff, *base, *part, *wtmp, *ctmp, *uniq, *uoff, *flag, *host;
+    uint32_t *cnt, *wgoff, *base, *ctmp, *uniq, *uoff, *flag, *host;
+    W *part, *wtmp;
     uint64_t *words;
     uint32_t *freqs;
     uint32_t tile0;   // first tile of the sample in the group's grid
 };
+template <typename W>
 struct BsBatch {
-    uint32_t n, lo, hi, last_word, cap;
-    BsMap mp;
-    const uint32_t *spl;
+    uint32_t n, cap;
+    W lo, hi, last_word;
+    BsMap<W> mp;
+    const W *spl;
     const uint16_t *ct;
-    BsItem it[BS_GROUP];
+    BsItem<W> it[BS_GROUP];
 };
-__device__ __forceinline__ uint32_t bs_batch_sample(const BsBatch &p, uint32_t tile)
+template <typename W>
+__device__ __forceinline__ uint32_t bs_batch_sample(const BsBatch<W> &p, uint32_t tile)
 {
     uint32_t s = 0;
 #pragma unroll
@@ -119,21 +139,24 @@ __device__ __forceinline__ uint32_t bs_batch_sample(const BsBatch &p, uint32_t t
 }
 
 template <int K>
-__device__ __forceinline__ void bs_hist_body(const uint8_t *__restrict__ clean, uint64_t len, uint32_t lo, uint32_t hi,
-                                             const uint32_t *__restrict__ spl_g, const uint16_t *__restrict__ ct_g, const BsMap mp,
+__device__ __forceinline__ void bs_hist_body(const uint8_t *__restrict__ clean, uint64_t len, typename Windows<K>::Word lo,
+                                             typename Windows<K>::Word hi, const typename Windows<K>::Word *__restrict__ spl_g,
+                                             const uint16_t *__restrict__ ct_g, const BsMap<typename Windows<K>::Word> mp,
                                              uint32_t *__restrict__ cnt, uint32_t *__restrict__ wgoff, const uint32_t tile)
 {
+    typedef typename Windows<K>::Word W;
+    constexpr int BT_THREADS = BsGeo<W>::THREADS;
     __shared__ uint32_t h[BS_NB];
-    __shared__ uint32_t spl[BS_NB];
+    __shared__ W spl[BS_NB];
     __shared__ uint16_t ct[BS_CELLS + 2];
     for (uint32_t d = threadIdx.x; d < BS_NB; d += BT_THREADS) h[d] = 0;
-    load_map(spl, ct, spl_g, ct_g, BT_THREADS);
+    load_map<W>(spl, ct, spl_g, ct_g, BT_THREADS);
     __syncthreads();
     const uint64_t s = ((uint64_t)tile * BT_THREADS + threadIdx.x) * KW_SEG;
-    Streams st;
+    typename Windows<K>::St st;
     load_streams(st, clean, len, s);
-    ForEachWindow<K, 0>::run(st, lo, hi, [&](int, bool ok, uint32_t w) {
-        if (ok) atomicAdd(&h[bucket_of(spl, ct, mp, w)], 1u);
+    Windows<K>::run(st, lo, hi, [&](int, bool ok, W w) {
+        if (ok) atomicAdd(&h[bucket_of<W>(spl, ct, mp, w)], 1u);
     });
     __syncthreads();
     uint32_t c[BS_NB / BT_THREADS], o[BS_NB / BT_THREADS];
@@ -147,58 +170,65 @@ __device__ __forceinline__ void bs_hist_body(const uint8_t *__restrict__ clean, 
         if (c[e]) wgoff[(uint64_t)tile * BS_NB + e * BT_THREADS + threadIdx.x] = o[e];
 }
 template <int K>
-__global__ __launch_bounds__(BT_THREADS) void bs_hist_kernel(const uint8_t *__restrict__ clean, uint64_t len, uint32_t lo, uint32_t hi,
-                                                              const uint32_t *__restrict__ spl_g, const uint16_t *__restrict__ ct_g,
-                                                              const BsMap mp, uint32_t *__restrict__ cnt, uint32_t *__restrict__ wgoff)
+__global__ __launch_bounds__(BsGeo<typename Windows<K>::Word>::THREADS) void bs_hist_kernel(
+    const uint8_t *__restrict__ clean, uint64_t len, typename Windows<K>::Word lo, typename Windows<K>::Word hi,
+    const typename Windows<K>::Word *__restrict__ spl_g, const uint16_t *__restrict__ ct_g, const BsMap<typename Windows<K>::Word> mp,
+    uint32_t *__restrict__ cnt, uint32_t *__restrict__ wgoff)
 {
     bs_hist_body<K>(clean, len, lo, hi, spl_g, ct_g, mp, cnt, wgoff, blockIdx.x);
 }
 template <int K>
-__global__ __launch_bounds__(BT_THREADS) void bs_hist_batch_kernel(const BsBatch p)
+__global__ __launch_bounds__(BsGeo<typename Windows<K>::Word>::THREADS) void bs_hist_batch_kernel(const BsBatch<typename Windows<K>::Word> p)
 {
-    const BsItem &it = p.it[bs_batch_sample(p, blockIdx.x)];
+    const BsItem<typename Windows<K>::Word> &it = p.it[bs_batch_sample(p, blockIdx.x)];
     bs_hist_body<K>(it.clean, it.len, p.lo, p.hi, p.spl, p.ct, p.mp, it.cnt, it.wgoff, blockIdx.x - it.tile0);
 }
 
 template <int K>
-__device__ __forceinline__ void bs_partition_body(const uint8_t *__restrict__ clean, uint64_t len, uint32_t lo, uint32_t hi,
-                                                  const uint32_t *__restrict__ spl_g, const uint16_t *__restrict__ ct_g, const BsMap mp,
+__device__ __forceinline__ void bs_partition_body(const uint8_t *__restrict__ clean, uint64_t len, typename Windows<K>::Word lo,
+                                                  typename Windows<K>::Word hi, const typename Windows<K>::Word *__restrict__ spl_g,
+                                                  const uint16_t *__restrict__ ct_g, const BsMap<typename Windows<K>::Word> mp,
                                                   const uint32_t *__restrict__ cnt, const uint32_t *__restrict__ wgoff,
-                                                  uint32_t *__restrict__ base_out, uint32_t *__restrict__ part, const uint32_t tile)
+                                                  uint32_t *__restrict__ base_out, typename Windows<K>::Word *__restrict__ part,
+                                                  const uint32_t tile)
 {
-    extern __shared__ uint32_t dyn_lds[];                 // BP_LDS_BYTES
-    uint32_t *stage = dyn_lds;                            // 64 KB: the tile's words, bucketed
-    uint32_t *h = stage + BT_TILE;                        // counts, then (start of this tile's range in the bucket) - (local start)
+    typedef typename Windows<K>::Word W;
+    constexpr int BT_THREADS = BsGeo<W>::THREADS, BT_TILE = BsGeo<W>::TILE;
+    constexpr int BPT = BS_NB / BT_THREADS;               // buckets a thread owns in the offsets step: 4 (32-bit words) or 8
+    extern __shared__ uint64_t dyn_lds64[];               // bp_lds_bytes<W>()
+    W *stage = reinterpret_cast<W *>(dyn_lds64);          // 64 KB: the tile's words, bucketed
+    W *spl = stage + BT_TILE;
+    uint32_t *h = reinterpret_cast<uint32_t *>(spl + BS_NB);   // counts, then (start of this tile's range in the bucket) - (local start)
     uint16_t *lstart = reinterpret_cast<uint16_t *>(h + BS_NB);
-    uint32_t *spl = h + BS_NB + BS_NB / 2;
-    uint32_t *scan_lds = spl + BS_NB;
+    uint32_t *scan_lds = h + BS_NB + BS_NB / 2;
     uint16_t *ct = reinterpret_cast<uint16_t *>(scan_lds + 16);
     uint16_t *stageb = reinterpret_cast<uint16_t *>(scan_lds + 16 + 2056);   // the bucket of every staged word
+    constexpr W NONE = (W)~(W)0;                          // (a valid canonical word is never all ones: its reverse complement would be 0)
     for (uint32_t d = threadIdx.x; d < BS_NB; d += BT_THREADS) h[d] = 0;
-    load_map(spl, ct, spl_g, ct_g, BT_THREADS);
+    load_map<W>(spl, ct, spl_g, ct_g, BT_THREADS);
     __syncthreads();
     const uint64_t s = ((uint64_t)tile * BT_THREADS + threadIdx.x) * KW_SEG;
-    Streams st;
+    typename Windows<K>::St st;
     load_streams(st, clean, len, s);
-    uint32_t wv[KW_SEG];   // the word (a valid canonical word is never 0xffffffff: its reverse complement would be 0)
+    W wv[KW_SEG];          // the word
     uint32_t rb[KW_SEG];   // bucket << 16 | rank inside (tile, bucket)
-    ForEachWindow<K, 0>::run(st, lo, hi, [&](int j, bool ok, uint32_t w) {
-        wv[j] = 0xffffffffu;
+    Windows<K>::run(st, lo, hi, [&](int j, bool ok, W w) {
+        wv[j] = NONE;
         rb[j] = 0;
         if (ok) {
-            const uint32_t b = bucket_of(spl, ct, mp, w);
+            const uint32_t b = bucket_of<W>(spl, ct, mp, w);
             wv[j] = w;
             rb[j] = (b << 16) | atomicAdd(&h[b], 1u);
         }
     });
     __syncthreads();
-    // thread t owns buckets 4t .. 4t + 3: local starts, global bucket bases, this tile's offset in each bucket
+    // thread t owns buckets BPT t .. BPT t + BPT - 1: local starts, global bucket bases, this tile's offset in each bucket
     uint32_t ltot;
     {
-        uint32_t c4[4], g4[4], lsum = 0, gsum = 0;
-        const uint32_t d0 = threadIdx.x * 4;
+        uint32_t c4[BPT], g4[BPT], lsum = 0, gsum = 0;
+        const uint32_t d0 = threadIdx.x * BPT;
 #pragma unroll
-        for (int e = 0; e < 4; e++) {
+        for (int e = 0; e < BPT; e++) {
             c4[e] = h[d0 + e];
             g4[e] = cnt[d0 + e];
             lsum += c4[e];
@@ -208,7 +238,7 @@ __device__ __forceinline__ void bs_partition_body(const uint8_t *__restrict__ cl
         uint32_t lex = psk_block_excl_scan_u32<BT_THREADS>(lsum, &ltot, scan_lds);
         uint32_t gex = psk_block_excl_scan_u32<BT_THREADS>(gsum, &gtot, scan_lds);
 #pragma unroll
-        for (int e = 0; e < 4; e++) {
+        for (int e = 0; e < BPT; e++) {
             const uint32_t d = d0 + e;
             lstart[d] = (uint16_t)lex;
             h[d] = gex + (c4[e] ? wgoff[(uint64_t)tile * BS_NB + d] : 0u) - lex;
@@ -220,7 +250,7 @@ __device__ __forceinline__ void bs_partition_body(const uint8_t *__restrict__ cl
     __syncthreads();
 #pragma unroll
     for (int j = 0; j < KW_SEG; j++)
-        if (wv[j] != 0xffffffffu) {
+        if (wv[j] != NONE) {
             const uint32_t at = (uint32_t)lstart[rb[j] >> 16] + (rb[j] & 0xffffu);
             stage[at] = wv[j];
             stageb[at] = (uint16_t)(rb[j] >> 16);
@@ -229,18 +259,18 @@ __device__ __forceinline__ void bs_partition_body(const uint8_t *__restrict__ cl
     for (uint32_t i = threadIdx.x; i < ltot; i += BT_THREADS) part[(size_t)(uint32_t)(h[stageb[i]] + i)] = stage[i];
 }
 template <int K>
-__global__ __launch_bounds__(BT_THREADS) void bs_partition_kernel(const uint8_t *__restrict__ clean, uint64_t len, uint32_t lo,
-                                                                   uint32_t hi, const uint32_t *__restrict__ spl_g,
-                                                                   const uint16_t *__restrict__ ct_g, const BsMap mp,
-                                                                   const uint32_t *__restrict__ cnt, const uint32_t *__restrict__ wgoff,
-                                                                   uint32_t *__restrict__ base_out, uint32_t *__restrict__ part)
+__global__ __launch_bounds__(BsGeo<typename Windows<K>::Word>::THREADS) void bs_partition_kernel(
+    const uint8_t *__restrict__ clean, uint64_t len, typename Windows<K>::Word lo, typename Windows<K>::Word hi,
+    const typename Windows<K>::Word *__restrict__ spl_g, const uint16_t *__restrict__ ct_g, const BsMap<typename Windows<K>::Word> mp,
+    const uint32_t *__restrict__ cnt, const uint32_t *__restrict__ wgoff, uint32_t *__restrict__ base_out,
+    typename Windows<K>::Word *__restrict__ part)
 {
     bs_partition_body<K>(clean, len, lo, hi, spl_g, ct_g, mp, cnt, wgoff, base_out, part, blockIdx.x);
 }
 template <int K>
-__global__ __launch_bounds__(BT_THREADS) void bs_partition_batch_kernel(const BsBatch p)
+__global__ __launch_bounds__(BsGeo<typename Windows<K>::Word>::THREADS) void bs_partition_batch_kernel(const BsBatch<typename Windows<K>::Word> p)
 {
-    const BsItem &it = p.it[bs_batch_sample(p, blockIdx.x)];
+    const BsItem<typename Windows<K>::Word> &it = p.it[bs_batch_sample(p, blockIdx.x)];
     bs_partition_body<K>(it.clean, it.len, p.lo, p.hi, p.spl, p.ct, p.mp, it.cnt, it.wgoff, it.base, it.part, blockIdx.x - it.tile0);
 }
 
@@ -253,16 +283,18 @@ __global__ __launch_bounds__(BT_THREADS) void bs_partition_batch_kernel(const Bs
 // buckets' key ranges lie back to back).
 constexpr uint32_t BS_BINS = 2048;
 constexpr uint32_t BS_BIN_MAX = 192;
-__device__ __forceinline__ void bs_sort_bucket(const uint32_t b, const uint32_t *__restrict__ part, const uint32_t *__restrict__ cnt,
-                                                                   const uint32_t *__restrict__ base, const uint32_t *__restrict__ spl,
-                                                                   uint32_t nb, uint32_t last_word, uint32_t cap, uint32_t *__restrict__ wtmp,
-                                                                   uint32_t *__restrict__ ctmp, uint32_t *__restrict__ uniq_out,
-                                                                   uint32_t *__restrict__ flag, uint32_t *dyn_lds)
+template <typename W>
+__device__ __forceinline__ void bs_sort_bucket(const uint32_t b, const W *__restrict__ part, const uint32_t *__restrict__ cnt,
+                                               const uint32_t *__restrict__ base, const W *__restrict__ spl,
+                                               uint32_t nb, W last_word, uint32_t cap, W *__restrict__ wtmp,
+                                               uint32_t *__restrict__ ctmp, uint32_t *__restrict__ uniq_out,
+                                               uint32_t *__restrict__ flag, uint64_t *dyn_lds)
 {
     constexpr int BPT = BS_BINS / BS_SORT_THREADS;   // sub-bins per thread
-    uint32_t *kin = dyn_lds;                // the bucket's words as they come; later the run lengths
-    uint32_t *key = kin + BS_CAP_MAX;       // ... dealt into sub-bins, then sorted
-    uint32_t *start = key + BS_CAP_MAX;     // sub-bin counts -> starts
+    constexpr W NONE = (W)~(W)0;
+    W *kin = reinterpret_cast<W *>(dyn_lds);   // the bucket's words as they come; later the positions of the run heads
+    W *key = kin + BS_CAP_MAX;              // ... dealt into sub-bins, then sorted
+    uint32_t *start = reinterpret_cast<uint32_t *>(key + BS_CAP_MAX);     // sub-bin counts -> starts
     uint32_t *fill = start + BS_BINS;
     uint32_t *scan_lds = fill + BS_BINS;
     const uint32_t t = threadIdx.x;
@@ -277,18 +309,18 @@ __device__ __forceinline__ void bs_sort_bucket(const uint32_t b, const uint32_t 
         return;
     }
     const size_t off = base[b];
-    const uint32_t first = spl[b], last = b + 1 < nb ? spl[b + 1] - 1u : last_word;   // the bucket's words lie in [first, last]
-    const uint32_t span = last - first;
-    const uint32_t sh = span < BS_BINS ? 0u : (32u - (uint32_t)__builtin_clz(span)) - 11u;   // (w - first) >> sh < 2048
+    const W first = spl[b], last = b + 1 < nb ? (W)(spl[b + 1] - 1u) : last_word;   // the bucket's words lie in [first, last]
+    const W span = last - first;
+    const uint32_t sh = span < (W)BS_BINS ? 0u : (64u - (uint32_t)__builtin_clzll((unsigned long long)span)) - 11u;   // (w - first) >> sh < 2048
     for (uint32_t i = t; i < BS_BINS; i += BS_SORT_THREADS) start[i] = 0;
     __syncthreads();
 #ifdef PSK_BS_STAMPS
     if (b == 100 && t == 0) stamps[0] = clock64();
 #endif
     for (uint32_t i = t; i < n; i += BS_SORT_THREADS) {
-        const uint32_t w = part[off + i];
+        const W w = part[off + i];
         kin[i] = w;
-        atomicAdd(&start[(w - first) >> sh], 1u);
+        atomicAdd(&start[(uint32_t)((w - first) >> sh)], 1u);
     }
     __syncthreads();
 #ifdef PSK_BS_STAMPS
@@ -313,8 +345,8 @@ __device__ __forceinline__ void bs_sort_bucket(const uint32_t b, const uint32_t 
 #endif
     __syncthreads();
     for (uint32_t i = t; i < n; i += BS_SORT_THREADS) {
-        const uint32_t w = kin[i];
-        key[atomicAdd(&fill[(w - first) >> sh], 1u)] = w;
+        const W w = kin[i];
+        key[atomicAdd(&fill[(uint32_t)((w - first) >> sh)], 1u)] = w;
     }
     __syncthreads();
 #ifdef PSK_BS_STAMPS
@@ -328,15 +360,15 @@ __device__ __forceinline__ void bs_sort_bucket(const uint32_t b, const uint32_t 
         const uint32_t lo = start[BPT * t], hi = fill[BPT * t + BPT - 1], m = hi - lo;
         if (m > 16) {
             for (uint32_t i = lo + 1; i < hi; i++) {
-                const uint32_t x = key[i];
+                const W x = key[i];
                 uint32_t j = i;
                 while (j > lo && key[j - 1] > x) { key[j] = key[j - 1]; j--; }
                 key[j] = x;
             }
         } else if (m > 1) {
-            uint32_t r[16];
+            W r[16];
 #pragma unroll
-            for (int i = 0; i < 16; i++) r[i] = (uint32_t)i < m ? key[lo + i] : 0xffffffffu;
+            for (int i = 0; i < 16; i++) r[i] = (uint32_t)i < m ? key[lo + i] : NONE;
 #pragma unroll
             for (int p = 1; p < 16; p *= 2)
 #pragma unroll
@@ -346,7 +378,7 @@ __device__ __forceinline__ void bs_sort_bucket(const uint32_t b, const uint32_t 
 #pragma unroll
                         for (int i = 0; i <= (k - 1 < 16 - j - k - 1 ? k - 1 : 16 - j - k - 1); i++)
                             if ((i + j) / (2 * p) == (i + j + k) / (2 * p)) {
-                                const uint32_t x = r[i + j], y = r[i + j + k];
+                                const W x = r[i + j], y = r[i + j + k];
                                 r[i + j] = x < y ? x : y;
                                 r[i + j + k] = x < y ? y : x;
                             }
@@ -370,12 +402,12 @@ __device__ __forceinline__ void bs_sort_bucket(const uint32_t b, const uint32_t 
     uint32_t r = psk_block_excl_scan_u32<BS_SORT_THREADS>(heads, &nu, scan_lds);
     for (uint32_t i = i0; i < i1; i++)
         if (i == 0 || key[i - 1] != key[i]) {
-            kin[r] = i;
+            kin[r] = (W)i;
             wtmp[off + r] = key[i];
             r++;
         }
     __syncthreads();
-    for (uint32_t q = t; q < nu; q += BS_SORT_THREADS) ctmp[off + q] = (q + 1 < nu ? kin[q + 1] : n) - kin[q];
+    for (uint32_t q = t; q < nu; q += BS_SORT_THREADS) ctmp[off + q] = (q + 1 < nu ? (uint32_t)kin[q + 1] : n) - (uint32_t)kin[q];
 #ifdef PSK_BS_STAMPS
     if (b == 100 && t == 0) stamps[5] = clock64();
 #endif
@@ -383,26 +415,28 @@ __device__ __forceinline__ void bs_sort_bucket(const uint32_t b, const uint32_t 
 }
 
 // a workgroup takes buckets blockIdx.x, blockIdx.x + gridDim.x, ...: one resident set of workgroups for the whole sample (two
-// per CU by LDS) instead of four launch rounds of them
-__global__ __launch_bounds__(BS_SORT_THREADS) void bs_sort_kernel(const uint32_t *__restrict__ part, const uint32_t *__restrict__ cnt,
-                                                                   const uint32_t *__restrict__ base, const uint32_t *__restrict__ spl,
-                                                                   uint32_t nb, uint32_t last_word, uint32_t cap, uint32_t *__restrict__ wtmp,
+// per CU by LDS; one with 64-bit words) instead of four launch rounds of them
+template <typename W>
+__global__ __launch_bounds__(BS_SORT_THREADS) void bs_sort_kernel(const W *__restrict__ part, const uint32_t *__restrict__ cnt,
+                                                                   const uint32_t *__restrict__ base, const W *__restrict__ spl,
+                                                                   uint32_t nb, W last_word, uint32_t cap, W *__restrict__ wtmp,
                                                                    uint32_t *__restrict__ ctmp, uint32_t *__restrict__ uniq_out,
                                                                    uint32_t *__restrict__ flag)
 {
-    extern __shared__ uint32_t dyn_lds[];   // BSORT_LDS_BYTES
+    extern __shared__ uint64_t dyn_lds64[];   // bsort_lds_bytes<W>()
     for (uint32_t b = blockIdx.x; b < nb; b += gridDim.x) {
-        bs_sort_bucket(b, part, cnt, base, spl, nb, last_word, cap, wtmp, ctmp, uniq_out, flag, dyn_lds);
+        bs_sort_bucket<W>(b, part, cnt, base, spl, nb, last_word, cap, wtmp, ctmp, uniq_out, flag, dyn_lds64);
         __syncthreads();   // the next bucket reuses the arrays
     }
 }
 
-__global__ __launch_bounds__(BS_SORT_THREADS) void bs_sort_batch_kernel(const BsBatch p)
+template <typename W>
+__global__ __launch_bounds__(BS_SORT_THREADS) void bs_sort_batch_kernel(const BsBatch<W> p)
 {
-    extern __shared__ uint32_t dyn_lds[];   // BSORT_LDS_BYTES
-    const BsItem &it = p.it[blockIdx.y];
+    extern __shared__ uint64_t dyn_lds64[];   // bsort_lds_bytes<W>()
+    const BsItem<W> &it = p.it[blockIdx.y];
     for (uint32_t b = blockIdx.x; b < p.mp.nb; b += gridDim.x) {
-        bs_sort_bucket(b, it.part, it.cnt, it.base, p.spl, p.mp.nb, p.last_word, p.cap, it.wtmp, it.ctmp, it.uniq, it.flag, dyn_lds);
+        bs_sort_bucket<W>(b, it.part, it.cnt, it.base, p.spl, p.mp.nb, p.last_word, p.cap, it.wtmp, it.ctmp, it.uniq, it.flag, dyn_lds64);
         __syncthreads();
     }
 }
@@ -429,14 +463,16 @@ __global__ __launch_bounds__(1024) void bs_totals_kernel(const uint32_t *__restr
 {
     bs_totals_body(cnt, uniq, uoff, flag, nb, host);
 }
-__global__ __launch_bounds__(1024) void bs_totals_batch_kernel(const BsBatch p)
+template <typename W>
+__global__ __launch_bounds__(1024) void bs_totals_batch_kernel(const BsBatch<W> p)
 {
-    const BsItem &it = p.it[blockIdx.x];
+    const BsItem<W> &it = p.it[blockIdx.x];
     bs_totals_body(it.cnt, it.uniq, it.uoff, it.flag, p.mp.nb, it.host);
 }
 
 // (one flat pass with a search over the offsets per element was slower: 41 us against 26 for a whole genome)
-__device__ __forceinline__ void bs_compact_body(const uint32_t *__restrict__ wtmp, const uint32_t *__restrict__ ctmp,
+template <typename W>
+__device__ __forceinline__ void bs_compact_body(const W *__restrict__ wtmp, const uint32_t *__restrict__ ctmp,
                                                 const uint32_t *__restrict__ base, const uint32_t *__restrict__ uniq,
                                                 const uint32_t *__restrict__ uoff, uint64_t *__restrict__ words,
                                                 uint32_t *__restrict__ freqs, const uint32_t bucket)
@@ -448,20 +484,23 @@ __device__ __forceinline__ void bs_compact_body(const uint32_t *__restrict__ wtm
         freqs[dst + i] = ctmp[src + i];
     }
 }
-__global__ void bs_compact_kernel(const uint32_t *__restrict__ wtmp, const uint32_t *__restrict__ ctmp, const uint32_t *__restrict__ base,
+template <typename W>
+__global__ void bs_compact_kernel(const W *__restrict__ wtmp, const uint32_t *__restrict__ ctmp, const uint32_t *__restrict__ base,
                                   const uint32_t *__restrict__ uniq, const uint32_t *__restrict__ uoff, uint64_t *__restrict__ words,
                                   uint32_t *__restrict__ freqs)
 {
-    bs_compact_body(wtmp, ctmp, base, uniq, uoff, words, freqs, blockIdx.x);
+    bs_compact_body<W>(wtmp, ctmp, base, uniq, uoff, words, freqs, blockIdx.x);
 }
-__global__ void bs_compact_batch_kernel(const BsBatch p)
+template <typename W>
+__global__ void bs_compact_batch_kernel(const BsBatch<W> p)
 {
-    const BsItem &it = p.it[blockIdx.y];
-    bs_compact_body(it.wtmp, it.ctmp, it.base, it.uniq, it.uoff, it.words, it.freqs, blockIdx.x);
+    const BsItem<W> &it = p.it[blockIdx.y];
+    bs_compact_body<W>(it.wtmp, it.ctmp, it.base, it.uniq, it.uoff, it.words, it.freqs, blockIdx.x);
 }
 
 // the partitioned words of a sample as u64 keys for the radix sort (the fall-back)
-__global__ void bs_expand_kernel(const uint32_t *__restrict__ part, uint64_t n, uint64_t *__restrict__ keys)
+template <typename W>
+__global__ void bs_expand_kernel(const W *__restrict__ part, uint64_t n, uint64_t *__restrict__ keys)
 {
     const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i < n) keys[i] = part[i];
@@ -490,24 +529,245 @@ uint32_t bs_cap()
 }
 
 template <int K>
-int launch_tiles(psk_ctx *ctx, CountLane &L, const BsBufs &d, uint64_t clean_len, uint32_t n_tiles, uint32_t lo, uint32_t hi)
+int launch_tiles(psk_ctx *ctx, CountLane &L, const BsBufs &d, uint64_t clean_len, uint32_t n_tiles, typename Windows<K>::Word lo,
+                 typename Windows<K>::Word hi)
 {
-    const BsMap mp{ctx->bs_lo, ctx->bs_shift, ctx->bs_nb};
+    typedef typename Windows<K>::Word W;
+    constexpr int BT_THREADS = BsGeo<W>::THREADS;
+    const BsMap<W> mp{(W)ctx->bs_lo, ctx->bs_shift, ctx->bs_nb};
     const uint16_t *ct = ctx->bs_ct.as<uint16_t>();
-    bs_hist_kernel<K><<<n_tiles, BT_THREADS, 0, ctx->stream>>>(L.raw.as<uint8_t>(), clean_len, lo, hi, ctx->bs_spl.as<uint32_t>(), ct, mp, d.cnt,
+    bs_hist_kernel<K><<<n_tiles, BT_THREADS, 0, ctx->stream>>>(L.raw.as<uint8_t>(), clean_len, lo, hi, ctx->bs_spl.as<W>(), ct, mp, d.cnt,
                                                                L.dc_wgoff.as<uint32_t>());
     PSK_HIP(ctx, hipGetLastError());
     static PerDeviceOnce attr_set;
     if (attr_set.first(ctx->device)) {
         PSK_HIP(ctx, hipFuncSetAttribute(reinterpret_cast<const void *>(bs_partition_kernel<K>),
-                                         hipFuncAttributeMaxDynamicSharedMemorySize, (int)BP_LDS_BYTES));
+                                         hipFuncAttributeMaxDynamicSharedMemorySize, (int)bp_lds_bytes<W>()));
     }
-    bs_partition_kernel<K><<<n_tiles, BT_THREADS, BP_LDS_BYTES, ctx->stream>>>(L.raw.as<uint8_t>(), clean_len, lo, hi,
-                                                                              ctx->bs_spl.as<uint32_t>(), ct, mp, d.cnt,
-                                                                              L.dc_wgoff.as<uint32_t>(), d.base, L.dc_part.as<uint32_t>());
+    bs_partition_kernel<K><<<n_tiles, BT_THREADS, bp_lds_bytes<W>(), ctx->stream>>>(L.raw.as<uint8_t>(), clean_len, lo, hi,
+                                                                                  ctx->bs_spl.as<W>(), ct, mp, d.cnt,
+                                                                                  L.dc_wgoff.as<uint32_t>(), d.base, L.dc_part.as<W>());
     PSK_HIP(ctx, hipGetLastError());
     return PSK_OK;
 }
+
+// k -> the instantiation: F<K>::run(args...) for the K of width W (14..16 | 17..32)
+template <typename W, template <int> class F, typename... A>
+int for_k(psk_ctx *ctx, A &&...a)
+{
+    switch (ctx->k) {
+#define PSK_BS_CASE(K_) case K_: if constexpr (sizeof(typename Windows<K_>::Word) == sizeof(W)) return F<K_>::run(ctx, a...); else break;
+    PSK_BS_CASE(14) PSK_BS_CASE(15) PSK_BS_CASE(16) PSK_BS_CASE(17) PSK_BS_CASE(18) PSK_BS_CASE(19) PSK_BS_CASE(20) PSK_BS_CASE(21)
+    PSK_BS_CASE(22) PSK_BS_CASE(23) PSK_BS_CASE(24) PSK_BS_CASE(25) PSK_BS_CASE(26) PSK_BS_CASE(27) PSK_BS_CASE(28) PSK_BS_CASE(29)
+    PSK_BS_CASE(30) PSK_BS_CASE(31) PSK_BS_CASE(32)
+#undef PSK_BS_CASE
+    default: break;
+    }
+    return psk_fail(ctx, PSK_ESTATE, "the bucketed sort of %d-byte words is not built for k = %d", (int)sizeof(W), ctx->k);
+}
+
+// the slab's bounds as words of the run's width: [lo, hi), hi = the first word beyond the slab or the space (all ones where that
+// is 2^32 / 2^64: no canonical word is all ones)
+template <typename W>
+void slab_bounds_w(const psk_ctx *ctx, W *lo, W *hi)
+{
+    const W none = (W)~(W)0;
+    const int bits = 2 * ctx->k;
+    const bool whole = bits >= (int)(8 * sizeof(W));                    // the space fills the word: k = 16 / k = 32
+    const uint64_t space = bits >= 64 ? 0 : (1ull << bits);
+    *lo = (W)ctx->slab_lo;
+    if (ctx->slab_hi && (bits >= 64 || ctx->slab_hi < space) && ctx->slab_hi <= (uint64_t)none) *hi = (W)ctx->slab_hi;
+    else *hi = whole ? none : (W)space;
+}
+
+template <typename W>
+int chain_enqueue_w(psk_ctx *ctx, CountLane &L, uint64_t clean_len, uint64_t n);
+
+template <int K>
+struct ChainTiles {
+    static int run(psk_ctx *ctx, CountLane &L, const BsBufs &d, uint64_t clean_len, uint32_t n_tiles)
+    {
+        typename Windows<K>::Word lo, hi;
+        slab_bounds_w(ctx, &lo, &hi);
+        return launch_tiles<K>(ctx, L, d, clean_len, n_tiles, lo, hi);
+    }
+};
+
+template <typename W>
+int chain_enqueue_w(psk_ctx *ctx, CountLane &L, uint64_t clean_len, uint64_t n)
+{
+    W lo, hi;
+    slab_bounds_w(ctx, &lo, &hi);
+    const uint32_t n_tiles = div_up(clean_len, BsGeo<W>::TILE);
+    PSK_TRY(dev_reserve(ctx, L.dc_part, n * sizeof(W) + 64));
+    PSK_TRY(dev_reserve(ctx, L.dc_wgoff, (size_t)n_tiles * BS_NB * 4));
+    PSK_TRY(dev_reserve(ctx, L.dc_cnt, (size_t)BS_SLOTS * (BS_NB + 16) * 4));
+    PSK_TRY(dev_reserve(ctx, L.dc_meta, (size_t)(4 * BS_NB + 4) * 4));
+    PSK_TRY(dev_reserve(ctx, L.dc_mtemp, (n + 8) * (sizeof(W) + 4) + 64));
+    if (L.dc_slot == 0 || L.dc_slot >= BS_SLOTS) {
+        PSK_HIP(ctx, hipMemsetAsync(L.dc_cnt.p, 0, (size_t)BS_SLOTS * (BS_NB + 16) * 4, ctx->stream));
+        L.dc_slot = 0;
+    }
+    const BsBufs d = bs_bufs(L, L.dc_slot++);
+    PSK_TRY((for_k<W, ChainTiles>(ctx, L, d, clean_len, n_tiles)));
+    PSK_HIP(ctx, hipEventRecord(L.raw_free, ctx->stream));
+    L.raw_used = true;
+    static PerDeviceOnce attr_set;
+    if (attr_set.first(ctx->device)) {
+        PSK_HIP(ctx, hipFuncSetAttribute(reinterpret_cast<const void *>(bs_sort_kernel<W>), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                         (int)bsort_lds_bytes<W>()));
+    }
+    W *wtmp = L.dc_mtemp.as<W>();
+    uint32_t *ctmp = reinterpret_cast<uint32_t *>(wtmp + n + 8);
+    const uint32_t resident = (sizeof(W) == 4 ? 2u : 1u) * (uint32_t)(ctx->n_cu > 0 ? ctx->n_cu : 256);
+    const uint32_t sort_wgs = ctx->bs_nb < resident ? ctx->bs_nb : resident;
+    bs_sort_kernel<W><<<sort_wgs, BS_SORT_THREADS, bsort_lds_bytes<W>(), ctx->stream>>>(L.dc_part.as<W>(), d.cnt, d.base, ctx->bs_spl.as<W>(),
+                                                                                          ctx->bs_nb, (W)(hi - 1u), bs_cap(), wtmp, ctmp, d.uniq, d.flag);
+    PSK_HIP(ctx, hipGetLastError());
+    bs_totals_kernel<<<1, 1024, 0, ctx->stream>>>(d.cnt, d.uniq, d.uoff, d.flag, ctx->bs_nb, L.pinned_cnt);
+    PSK_HIP(ctx, hipGetLastError());
+    PSK_HIP(ctx, hipEventRecord(L.done, ctx->stream));
+    L.bs = true;
+    return PSK_OK;
+}
+
+template <typename W>
+int splitters_from_w(psk_ctx *ctx, const SampleList &S, uint32_t nb)
+{
+    W lo, hi;
+    slab_bounds_w(ctx, &lo, &hi);
+    // cells over [lo, hi): (hi - lo - 1) >> shift < BS_CELLS   (hi = all ones stands for one more: the difference is a cell at most)
+    uint32_t shift = 0;
+    while (((uint64_t)(W)(hi - lo - 1u) >> shift) >= (uint64_t)BS_CELLS) shift++;
+    ctx->bs_lo = (uint64_t)lo;
+    ctx->bs_shift = shift;
+    PSK_TRY(dev_reserve(ctx, ctx->bs_spl, (size_t)BS_NB * sizeof(W)));
+    PSK_TRY(dev_reserve(ctx, ctx->bs_ct, (size_t)(BS_CELLS + 2) * 2));
+    bs_splitters_kernel<W><<<div_up(BS_NB, 256), 256, 0, ctx->stream>>>(S.words, S.n_unique, nb, lo, ctx->bs_spl.as<W>());
+    PSK_HIP(ctx, hipGetLastError());
+    bs_cells_kernel<W><<<div_up(BS_CELLS + 1, 256), 256, 0, ctx->stream>>>(ctx->bs_spl.as<W>(), BsMap<W>{lo, shift, nb}, ctx->bs_ct.as<uint16_t>());
+    PSK_HIP(ctx, hipGetLastError());
+    return PSK_OK;
+}
+
+template <typename W>
+int chain_finalize_w(psk_ctx *ctx, CountLane &L, SampleList &S, const BsBufs &d)
+{
+    const W *wtmp = L.dc_mtemp.as<W>();
+    const uint32_t *ctmp = reinterpret_cast<const uint32_t *>(wtmp + L.n + 8);
+    bs_compact_kernel<W><<<ctx->bs_nb, 512, 0, ctx->stream>>>(wtmp, ctmp, d.base, d.uniq, d.uoff, S.words, S.freqs);
+    PSK_HIP(ctx, hipGetLastError());
+    return PSK_OK;
+}
+
+template <int K>
+struct GroupTiles {
+    static int run(psk_ctx *ctx, const BsBatch<typename Windows<K>::Word> &p, uint32_t tiles)
+    {
+        typedef typename Windows<K>::Word W;
+        constexpr int BT_THREADS = BsGeo<W>::THREADS;
+        bs_hist_batch_kernel<K><<<tiles, BT_THREADS, 0, ctx->stream>>>(p);
+        PSK_HIP(ctx, hipGetLastError());
+        static PerDeviceOnce attr_set;
+        if (attr_set.first(ctx->device)) {
+            PSK_HIP(ctx, hipFuncSetAttribute(reinterpret_cast<const void *>(bs_partition_batch_kernel<K>),
+                                             hipFuncAttributeMaxDynamicSharedMemorySize, (int)bp_lds_bytes<W>()));
+        }
+        bs_partition_batch_kernel<K><<<tiles, BT_THREADS, bp_lds_bytes<W>(), ctx->stream>>>(p);
+        PSK_HIP(ctx, hipGetLastError());
+        return PSK_OK;
+    }
+};
+
+template <typename W>
+int group_enqueue_w(psk_ctx *ctx, CountLane *const *lanes, const uint64_t *clean_len, const uint64_t *n, int count)
+{
+    BsBatch<W> p;
+    memset(&p, 0, sizeof(p));
+    p.n = (uint32_t)count;
+    slab_bounds_w(ctx, &p.lo, &p.hi);
+    p.last_word = (W)(p.hi - 1u);
+    p.cap = bs_cap();
+    p.mp = BsMap<W>{(W)ctx->bs_lo, ctx->bs_shift, ctx->bs_nb};
+    p.spl = ctx->bs_spl.as<W>();
+    p.ct = ctx->bs_ct.as<uint16_t>();
+    uint32_t tiles = 0;
+    for (int s = 0; s < count; s++) {
+        CountLane &L = *lanes[s];
+        const uint32_t n_tiles = div_up(clean_len[s], BsGeo<W>::TILE);
+        PSK_TRY(dev_reserve(ctx, L.dc_part, n[s] * sizeof(W) + 64));
+        PSK_TRY(dev_reserve(ctx, L.dc_wgoff, (size_t)n_tiles * BS_NB * 4));
+        PSK_TRY(dev_reserve(ctx, L.dc_cnt, (size_t)BS_SLOTS * (BS_NB + 16) * 4));
+        PSK_TRY(dev_reserve(ctx, L.dc_meta, (size_t)(4 * BS_NB + 4) * 4));
+        PSK_TRY(dev_reserve(ctx, L.dc_mtemp, (n[s] + 8) * (sizeof(W) + 4) + 64));
+        if (L.dc_slot == 0 || L.dc_slot >= BS_SLOTS) {
+            PSK_HIP(ctx, hipMemsetAsync(L.dc_cnt.p, 0, (size_t)BS_SLOTS * (BS_NB + 16) * 4, ctx->stream));
+            L.dc_slot = 0;
+        }
+        const BsBufs d = bs_bufs(L, L.dc_slot++);
+        BsItem<W> &it = p.it[s];
+        it.clean = L.raw.as<uint8_t>();
+        it.len = clean_len[s];
+        it.cnt = d.cnt; it.wgoff = L.dc_wgoff.as<uint32_t>(); it.base = d.base; it.part = L.dc_part.as<W>();
+        it.wtmp = L.dc_mtemp.as<W>(); it.ctmp = reinterpret_cast<uint32_t *>(it.wtmp + n[s] + 8);
+        it.uniq = d.uniq; it.uoff = d.uoff; it.flag = d.flag; it.host = L.pinned_cnt;
+        it.tile0 = tiles;
+        tiles += n_tiles;
+    }
+    PSK_TRY((for_k<W, GroupTiles>(ctx, p, tiles)));
+    for (int s = 0; s < count; s++) {
+        PSK_HIP(ctx, hipEventRecord(lanes[s]->raw_free, ctx->stream));
+        lanes[s]->raw_used = true;
+    }
+    static PerDeviceOnce attr_set;
+    if (attr_set.first(ctx->device)) {
+        PSK_HIP(ctx, hipFuncSetAttribute(reinterpret_cast<const void *>(bs_sort_batch_kernel<W>), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                         (int)bsort_lds_bytes<W>()));
+    }
+    // one resident set of workgroups for the whole group (two per CU by LDS; one with 64-bit words)
+    const uint32_t wg_all = (sizeof(W) == 4 ? 2u : 1u) * (uint32_t)(ctx->n_cu > 0 ? ctx->n_cu : 256);
+    uint32_t per = (wg_all + (uint32_t)count - 1) / (uint32_t)count;
+    if (per > ctx->bs_nb) per = ctx->bs_nb;
+    if (per < 1) per = 1;
+    bs_sort_batch_kernel<W><<<dim3(per, (uint32_t)count), BS_SORT_THREADS, bsort_lds_bytes<W>(), ctx->stream>>>(p);
+    PSK_HIP(ctx, hipGetLastError());
+    bs_totals_batch_kernel<W><<<(uint32_t)count, 1024, 0, ctx->stream>>>(p);
+    PSK_HIP(ctx, hipGetLastError());
+    for (int s = 0; s < count; s++) {
+        PSK_HIP(ctx, hipEventRecord(lanes[s]->done, ctx->stream));
+        lanes[s]->bs = true;
+        lanes[s]->dc_defer_compact = true;
+    }
+    return PSK_OK;
+}
+
+template <typename W>
+int group_compact_w(psk_ctx *ctx, CountLane *const *lanes, const int *sample_idx, int count)
+{
+    BsBatch<W> p;
+    memset(&p, 0, sizeof(p));
+    uint32_t m = 0;
+    for (int s = 0; s < count; s++) {
+        CountLane &L = *lanes[s];
+        L.dc_defer_compact = false;
+        const SampleList &S = ctx->lists[sample_idx[s]];
+        if (!S.n_unique || !S.words) continue;
+        const BsBufs d = bs_bufs(L, L.dc_slot - 1);
+        BsItem<W> &it = p.it[m++];
+        it.wtmp = L.dc_mtemp.as<W>(); it.ctmp = reinterpret_cast<uint32_t *>(it.wtmp + L.n + 8);
+        it.base = d.base; it.uniq = d.uniq; it.uoff = d.uoff;
+        it.words = S.words; it.freqs = S.freqs;
+    }
+    p.n = m;
+    if (m) {
+        bs_compact_batch_kernel<W><<<dim3(ctx->bs_nb, m), 512, 0, ctx->stream>>>(p);
+        PSK_HIP(ctx, hipGetLastError());
+    }
+    return PSK_OK;
+}
+
+inline bool bs_wide(const psk_ctx *ctx) { return ctx->k > 16; }
+inline bool bs_k_ok(const psk_ctx *ctx) { return ctx->k >= 14 && ctx->k <= 32; }
 
 }  // namespace
 
@@ -516,34 +776,22 @@ int launch_tiles(psk_ctx *ctx, CountLane &L, const BsBufs &d, uint64_t clean_len
 // route: its buckets would overflow and the work would be done twice.
 bool bucket_route_ok(const psk_ctx *ctx, uint64_t n)
 {
-    if (!ctx->bs_ready || ctx->dense_mode || ctx->k < 14 || ctx->k > 16) return false;
+    if (!ctx->bs_ready || ctx->dense_mode || !bs_k_ok(ctx)) return false;
     return (double)n * ctx->bs_keep / ctx->bs_nb <= 0.5 * BS_CAP_MAX;
 }
 
 // after a sample of the run has gone through the radix route: its list gives the splitters of the later ones
 int bucket_splitters_from(psk_ctx *ctx, const SampleList &S, uint64_t windows)
 {
-    if (ctx->bs_ready || ctx->dense_mode || ctx->k < 14 || ctx->k > 16 || S.n_unique < 32768 || !S.words) return PSK_OK;
+    if (ctx->bs_ready || ctx->dense_mode || !bs_k_ok(ctx) || S.n_unique < 32768 || !S.words) return PSK_OK;
     if (getenv("PSK_NO_BUCKET_SORT")) return PSK_OK;   // read per call: tests cross the two routes in one process
     // about 2,400 words per bucket (the LDS sort takes 8,192): a genome gives 2,048 buckets, a rank's eighth of it 256
     uint32_t nb = 64;
     while (nb < BS_NB && (uint64_t)nb * 2400 < S.n_unique) nb <<= 1;
-    const uint64_t space = 1ull << (2 * ctx->k);
-    const uint64_t lo = ctx->slab_lo, hi = (ctx->slab_hi && ctx->slab_hi < space) ? ctx->slab_hi : space;
-    uint32_t shift = 0;
-    while (((hi - lo - 1) >> shift) >= (uint64_t)BS_CELLS) shift++;
     ctx->bs_nb = nb;
     ctx->bs_keep = windows ? (double)S.n_total / (double)windows : 1.0;
     if (ctx->bs_keep > 1.0) ctx->bs_keep = 1.0;
-    ctx->bs_lo = (uint32_t)lo;
-    ctx->bs_shift = shift;
-    PSK_TRY(dev_reserve(ctx, ctx->bs_spl, (size_t)BS_NB * 4));
-    PSK_TRY(dev_reserve(ctx, ctx->bs_ct, (size_t)(BS_CELLS + 2) * 2));
-    bs_splitters_kernel<<<div_up(BS_NB, 256), 256, 0, ctx->stream>>>(S.words, S.n_unique, nb, ctx->bs_lo, ctx->bs_spl.as<uint32_t>());
-    PSK_HIP(ctx, hipGetLastError());
-    bs_cells_kernel<<<div_up(BS_CELLS + 1, 256), 256, 0, ctx->stream>>>(ctx->bs_spl.as<uint32_t>(), BsMap{ctx->bs_lo, shift, nb},
-                                                                       ctx->bs_ct.as<uint16_t>());
-    PSK_HIP(ctx, hipGetLastError());
+    PSK_TRY(bs_wide(ctx) ? splitters_from_w<uint64_t>(ctx, S, nb) : splitters_from_w<uint32_t>(ctx, S, nb));
     ctx->bs_ready = true;
     return PSK_OK;
 }
@@ -551,44 +799,7 @@ int bucket_splitters_from(psk_ctx *ctx, const SampleList &S, uint64_t windows)
 int bucket_chain_enqueue(psk_ctx *ctx, CountLane &L, int sample_idx, uint64_t clean_len, uint64_t n)
 {
     (void)sample_idx;
-    const uint64_t space = 1ull << (2 * ctx->k);
-    const uint32_t lo = (uint32_t)ctx->slab_lo;
-    const uint32_t hi = (ctx->slab_hi && ctx->slab_hi < space && ctx->slab_hi <= 0xffffffffull) ? (uint32_t)ctx->slab_hi
-                        : (space > 0xffffffffull ? 0xffffffffu : (uint32_t)space);   // no canonical word is 0xffffffff
-    const uint32_t n_tiles = div_up(clean_len, BT_TILE);
-    PSK_TRY(dev_reserve(ctx, L.dc_part, n * 4 + 64));
-    PSK_TRY(dev_reserve(ctx, L.dc_wgoff, (size_t)n_tiles * BS_NB * 4));
-    PSK_TRY(dev_reserve(ctx, L.dc_cnt, (size_t)BS_SLOTS * (BS_NB + 16) * 4));
-    PSK_TRY(dev_reserve(ctx, L.dc_meta, (size_t)(4 * BS_NB + 4) * 4));
-    PSK_TRY(dev_reserve(ctx, L.dc_mtemp, n * 8 + 64));
-    if (L.dc_slot == 0 || L.dc_slot >= BS_SLOTS) {
-        PSK_HIP(ctx, hipMemsetAsync(L.dc_cnt.p, 0, (size_t)BS_SLOTS * (BS_NB + 16) * 4, ctx->stream));
-        L.dc_slot = 0;
-    }
-    const BsBufs d = bs_bufs(L, L.dc_slot++);
-    switch (ctx->k) {
-    case 14: PSK_TRY(launch_tiles<14>(ctx, L, d, clean_len, n_tiles, lo, hi)); break;
-    case 15: PSK_TRY(launch_tiles<15>(ctx, L, d, clean_len, n_tiles, lo, hi)); break;
-    case 16: PSK_TRY(launch_tiles<16>(ctx, L, d, clean_len, n_tiles, lo, hi)); break;
-    default: return psk_fail(ctx, PSK_ESTATE, "the bucketed sort is built for k = 14..16, not %d", ctx->k);
-    }
-    PSK_HIP(ctx, hipEventRecord(L.raw_free, ctx->stream));
-    L.raw_used = true;
-    static PerDeviceOnce attr_set;
-    if (attr_set.first(ctx->device)) {
-        PSK_HIP(ctx, hipFuncSetAttribute(reinterpret_cast<const void *>(bs_sort_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
-                                         (int)BSORT_LDS_BYTES));
-    }
-    uint32_t *wtmp = L.dc_mtemp.as<uint32_t>(), *ctmp = wtmp + n + 8;
-    const uint32_t sort_wgs = ctx->bs_nb < 2u * (uint32_t)(ctx->n_cu > 0 ? ctx->n_cu : 256) ? ctx->bs_nb : 2u * (uint32_t)(ctx->n_cu > 0 ? ctx->n_cu : 256);
-    bs_sort_kernel<<<sort_wgs, BS_SORT_THREADS, BSORT_LDS_BYTES, ctx->stream>>>(L.dc_part.as<uint32_t>(), d.cnt, d.base, ctx->bs_spl.as<uint32_t>(),
-                                                                                  ctx->bs_nb, hi - 1u, bs_cap(), wtmp, ctmp, d.uniq, d.flag);
-    PSK_HIP(ctx, hipGetLastError());
-    bs_totals_kernel<<<1, 1024, 0, ctx->stream>>>(d.cnt, d.uniq, d.uoff, d.flag, ctx->bs_nb, L.pinned_cnt);
-    PSK_HIP(ctx, hipGetLastError());
-    PSK_HIP(ctx, hipEventRecord(L.done, ctx->stream));
-    L.bs = true;
-    return PSK_OK;
+    return bs_wide(ctx) ? chain_enqueue_w<uint64_t>(ctx, L, clean_len, n) : chain_enqueue_w<uint32_t>(ctx, L, clean_len, n);
 }
 
 // after hipEventSynchronize(L.done): the arena block and the packing pass; or, when a bucket overflowed, the radix sort of
@@ -614,37 +825,20 @@ int bucket_chain_finalize(psk_ctx *ctx, CountLane &L, SampleList &S, uint64_t n_
     if (!nu) return PSK_OK;
     PSK_TRY(arena_alloc(ctx, nu * 8, (void **)&S.words));
     PSK_TRY(arena_alloc(ctx, nu * 4, (void **)&S.freqs));
-    const uint32_t *wtmp = L.dc_mtemp.as<uint32_t>(), *ctmp = wtmp + L.n + 8;
     (void)n_kept;
     if (L.dc_defer_compact) return PSK_OK;   // the group packs in one launch (bucket_group_compact)
-    bs_compact_kernel<<<ctx->bs_nb, 512, 0, ctx->stream>>>(wtmp, ctmp, d.base, d.uniq, d.uoff, S.words, S.freqs);
-    PSK_HIP(ctx, hipGetLastError());
-    return PSK_OK;
+    return bs_wide(ctx) ? chain_finalize_w<uint64_t>(ctx, L, S, d) : chain_finalize_w<uint32_t>(ctx, L, S, d);
 }
 
 // ---- a group of samples in one launch chain (as dense_group_enqueue) --------------------------------------------------------
-void bucket_lane_bytes(size_t max_len, size_t out[5])
+void bucket_lane_bytes(const psk_ctx *ctx, size_t max_len, size_t out[5])
 {
-    out[0] = max_len * 4 + 64;                                   // dc_part
-    out[1] = (size_t)div_up(max_len, BT_TILE) * BS_NB * 4;       // dc_wgoff
+    const size_t wb = bs_wide(ctx) ? 8 : 4, tile = bs_wide(ctx) ? (size_t)BsGeo<uint64_t>::TILE : (size_t)BsGeo<uint32_t>::TILE;
+    out[0] = max_len * wb + 64;                                  // dc_part
+    out[1] = (size_t)div_up(max_len, tile) * BS_NB * 4;          // dc_wgoff
     out[2] = (size_t)BS_SLOTS * (BS_NB + 16) * 4;                // dc_cnt
     out[3] = (size_t)(4 * BS_NB + 4) * 4;                        // dc_meta
-    out[4] = max_len * 8 + 64;                                   // dc_mtemp
-}
-
-template <int K>
-static int launch_group_tiles(psk_ctx *ctx, const BsBatch &p, uint32_t tiles)
-{
-    bs_hist_batch_kernel<K><<<tiles, BT_THREADS, 0, ctx->stream>>>(p);
-    PSK_HIP(ctx, hipGetLastError());
-    static PerDeviceOnce attr_set;
-    if (attr_set.first(ctx->device)) {
-        PSK_HIP(ctx, hipFuncSetAttribute(reinterpret_cast<const void *>(bs_partition_batch_kernel<K>),
-                                         hipFuncAttributeMaxDynamicSharedMemorySize, (int)BP_LDS_BYTES));
-    }
-    bs_partition_batch_kernel<K><<<tiles, BT_THREADS, BP_LDS_BYTES, ctx->stream>>>(p);
-    PSK_HIP(ctx, hipGetLastError());
-    return PSK_OK;
+    out[4] = (max_len + 8) * (wb + 4) + 64;                      // dc_mtemp
 }
 
 int bucket_group_enqueue(psk_ctx *ctx, CountLane *const *lanes, const int *sample_idx, const uint64_t *clean_len, const uint64_t *n,
@@ -652,101 +846,22 @@ int bucket_group_enqueue(psk_ctx *ctx, CountLane *const *lanes, const int *sampl
 {
     (void)sample_idx;
     if (count < 1 || count > BS_GROUP) return psk_fail(ctx, PSK_EINVAL, "bad group size %d", count);
-    const uint64_t space = 1ull << (2 * ctx->k);
-    BsBatch p;
-    memset(&p, 0, sizeof(p));
-    p.n = (uint32_t)count;
-    p.lo = (uint32_t)ctx->slab_lo;
-    p.hi = (ctx->slab_hi && ctx->slab_hi < space && ctx->slab_hi <= 0xffffffffull) ? (uint32_t)ctx->slab_hi
-           : (space > 0xffffffffull ? 0xffffffffu : (uint32_t)space);   // no canonical word is 0xffffffff
-    p.last_word = p.hi - 1u;
-    p.cap = bs_cap();
-    p.mp = BsMap{ctx->bs_lo, ctx->bs_shift, ctx->bs_nb};
-    p.spl = ctx->bs_spl.as<uint32_t>();
-    p.ct = ctx->bs_ct.as<uint16_t>();
-    uint32_t tiles = 0;
-    for (int s = 0; s < count; s++) {
-        CountLane &L = *lanes[s];
-        const uint32_t n_tiles = div_up(clean_len[s], BT_TILE);
-        PSK_TRY(dev_reserve(ctx, L.dc_part, n[s] * 4 + 64));
-        PSK_TRY(dev_reserve(ctx, L.dc_wgoff, (size_t)n_tiles * BS_NB * 4));
-        PSK_TRY(dev_reserve(ctx, L.dc_cnt, (size_t)BS_SLOTS * (BS_NB + 16) * 4));
-        PSK_TRY(dev_reserve(ctx, L.dc_meta, (size_t)(4 * BS_NB + 4) * 4));
-        PSK_TRY(dev_reserve(ctx, L.dc_mtemp, n[s] * 8 + 64));
-        if (L.dc_slot == 0 || L.dc_slot >= BS_SLOTS) {
-            PSK_HIP(ctx, hipMemsetAsync(L.dc_cnt.p, 0, (size_t)BS_SLOTS * (BS_NB + 16) * 4, ctx->stream));
-            L.dc_slot = 0;
-        }
-        const BsBufs d = bs_bufs(L, L.dc_slot++);
-        BsItem &it = p.it[s];
-        it.clean = L.raw.as<uint8_t>();
-        it.len = clean_len[s];
-        it.cnt = d.cnt; it.wgoff = L.dc_wgoff.as<uint32_t>(); it.base = d.base; it.part = L.dc_part.as<uint32_t>();
-        it.wtmp = L.dc_mtemp.as<uint32_t>(); it.ctmp = it.wtmp + n[s] + 8;
-        it.uniq = d.uniq; it.uoff = d.uoff; it.flag = d.flag; it.host = L.pinned_cnt;
-        it.tile0 = tiles;
-        tiles += n_tiles;
-    }
-    switch (ctx->k) {
-    case 14: PSK_TRY(launch_group_tiles<14>(ctx, p, tiles)); break;
-    case 15: PSK_TRY(launch_group_tiles<15>(ctx, p, tiles)); break;
-    case 16: PSK_TRY(launch_group_tiles<16>(ctx, p, tiles)); break;
-    default: return psk_fail(ctx, PSK_ESTATE, "the bucketed sort is built for k = 14..16, not %d", ctx->k);
-    }
-    for (int s = 0; s < count; s++) {
-        PSK_HIP(ctx, hipEventRecord(lanes[s]->raw_free, ctx->stream));
-        lanes[s]->raw_used = true;
-    }
-    static PerDeviceOnce attr_set;
-    if (attr_set.first(ctx->device)) {
-        PSK_HIP(ctx, hipFuncSetAttribute(reinterpret_cast<const void *>(bs_sort_batch_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
-                                         (int)BSORT_LDS_BYTES));
-    }
-    const uint32_t wg_all = 2u * (uint32_t)(ctx->n_cu > 0 ? ctx->n_cu : 256);   // one resident set of workgroups for the whole group
-    uint32_t per = (wg_all + (uint32_t)count - 1) / (uint32_t)count;
-    if (per > ctx->bs_nb) per = ctx->bs_nb;
-    if (per < 1) per = 1;
-    bs_sort_batch_kernel<<<dim3(per, (uint32_t)count), BS_SORT_THREADS, BSORT_LDS_BYTES, ctx->stream>>>(p);
-    PSK_HIP(ctx, hipGetLastError());
-    bs_totals_batch_kernel<<<(uint32_t)count, 1024, 0, ctx->stream>>>(p);
-    PSK_HIP(ctx, hipGetLastError());
-    for (int s = 0; s < count; s++) {
-        PSK_HIP(ctx, hipEventRecord(lanes[s]->done, ctx->stream));
-        lanes[s]->bs = true;
-        lanes[s]->dc_defer_compact = true;
-    }
-    return PSK_OK;
+    return bs_wide(ctx) ? group_enqueue_w<uint64_t>(ctx, lanes, clean_len, n, count) : group_enqueue_w<uint32_t>(ctx, lanes, clean_len, n, count);
 }
 
 // after chain_finalize of every set of the group (which sized and allocated the lists): ONE packing launch
 int bucket_group_compact(psk_ctx *ctx, CountLane *const *lanes, const int *sample_idx, int count)
 {
-    BsBatch p;
-    memset(&p, 0, sizeof(p));
-    uint32_t m = 0;
-    for (int s = 0; s < count; s++) {
-        CountLane &L = *lanes[s];
-        L.dc_defer_compact = false;
-        const SampleList &S = ctx->lists[sample_idx[s]];
-        if (!S.n_unique || !S.words) continue;
-        const BsBufs d = bs_bufs(L, L.dc_slot - 1);
-        BsItem &it = p.it[m++];
-        it.wtmp = L.dc_mtemp.as<uint32_t>(); it.ctmp = it.wtmp + L.n + 8;
-        it.base = d.base; it.uniq = d.uniq; it.uoff = d.uoff;
-        it.words = S.words; it.freqs = S.freqs;
-    }
-    p.n = m;
-    if (m) {
-        bs_compact_batch_kernel<<<dim3(ctx->bs_nb, m), 512, 0, ctx->stream>>>(p);
-        PSK_HIP(ctx, hipGetLastError());
-    }
-    return PSK_OK;
+    return bs_wide(ctx) ? group_compact_w<uint64_t>(ctx, lanes, sample_idx, count) : group_compact_w<uint32_t>(ctx, lanes, sample_idx, count);
 }
 
 // the fall-back's input: the n_kept partitioned words of the sample on this set as u64 keys in `keys`
 int bucket_fallback_keys(psk_ctx *ctx, CountLane &L, uint64_t n_kept, uint64_t *keys)
 {
-    if (n_kept) bs_expand_kernel<<<div_up(n_kept, 256), 256, 0, ctx->stream>>>(L.dc_part.as<uint32_t>(), n_kept, keys);
+    if (n_kept) {
+        if (bs_wide(ctx)) bs_expand_kernel<uint64_t><<<div_up(n_kept, 256), 256, 0, ctx->stream>>>(L.dc_part.as<uint64_t>(), n_kept, keys);
+        else bs_expand_kernel<uint32_t><<<div_up(n_kept, 256), 256, 0, ctx->stream>>>(L.dc_part.as<uint32_t>(), n_kept, keys);
+    }
     PSK_HIP(ctx, hipGetLastError());
     return PSK_OK;
 }

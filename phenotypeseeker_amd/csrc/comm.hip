@@ -8,6 +8,8 @@
 #include <dlfcn.h>
 #include <rccl/rccl.h>
 
+#include <algorithm>
+
 #include "psk_internal.h"
 
 namespace {
@@ -239,9 +241,15 @@ extern "C" int psk_comm_alltoallv_device(psk_ctx *ctx, const void *send_dev, con
     PSK_NCCL(ctx, g_rccl.GroupStart());
     // an error between GroupStart and GroupEnd must not leave the group open: remember it, close the group, report it
     ncclResult_t bad = ncclSuccess;
+    // a message is cut into pieces of at most 2^27 elements (1 GiB of words): one ncclSend of 10.7 GB -- a rank's share of config 5
+    // sent to itself on a one-rank communicator -- arrived damaged (r05: the receiving context found lists that did not ascend);
+    // sends and receives between two ranks are matched in the order they are posted, so the pieces pair up
+    const uint64_t piece = 1ull << 27;
     for (int r = 0; r < c->world && bad == ncclSuccess; r++) {
-        if (send_counts[r]) bad = g_rccl.Send(sp, (size_t)send_counts[r], dt, r, c->comm, c->stream);
-        if (recv_counts[r] && bad == ncclSuccess) bad = g_rccl.Recv(rp, (size_t)recv_counts[r], dt, r, c->comm, c->stream);
+        for (uint64_t off = 0; off < send_counts[r] && bad == ncclSuccess; off += piece)
+            bad = g_rccl.Send(sp + off * (uint64_t)elem_bytes, (size_t)std::min(piece, send_counts[r] - off), dt, r, c->comm, c->stream);
+        for (uint64_t off = 0; off < recv_counts[r] && bad == ncclSuccess; off += piece)
+            bad = g_rccl.Recv(rp + off * (uint64_t)elem_bytes, (size_t)std::min(piece, recv_counts[r] - off), dt, r, c->comm, c->stream);
         sp += send_counts[r] * (uint64_t)elem_bytes;
         rp += recv_counts[r] * (uint64_t)elem_bytes;
     }

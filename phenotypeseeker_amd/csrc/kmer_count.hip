@@ -583,7 +583,7 @@ static void lane_set_wants(psk_ctx *ctx, size_t max_len, bool gpu_framing, size_
 {
     size_t dcb[5];
     if (ctx->dense_mode) dense_lane_bytes(ctx, max_len, dcb);
-    else bucket_lane_bytes(max_len, dcb);
+    else bucket_lane_bytes(ctx, max_len, dcb);
     const size_t w[8] = {max_len + 128 + 2 * EX_SEG, gpu_framing ? max_len + 64 : 0, gpu_framing ? frame_gpu_scratch_bytes(max_len) : 0,
                          dcb[0], dcb[1], dcb[2], dcb[3], dcb[4]};
     for (int q = 0; q < 8; q++) want[q] = w[q];
@@ -989,7 +989,7 @@ static int count_batch_impl(psk_ctx *ctx, int first_sample_idx, int n, const uin
     // pinned ring: at most ~4 GiB of it (read-scale FASTQ samples are hundreds of MB each)
     while (n_threads > 1 && (size_t)(n_threads + 4) * max_len > (4ull << 30)) n_threads--;
     // genomes at k <= 13 (dense counting) go through the counting kernels in groups of G: one launch chain per group
-    const bool bucket_run = !ctx->dense_mode && ctx->k >= 14 && ctx->k <= 16 && !getenv("PSK_NO_BUCKET_SORT");
+    const bool bucket_run = !ctx->dense_mode && ctx->k >= 14 && ctx->k <= 32 && !getenv("PSK_NO_BUCKET_SORT");
     int G = (!consumer && (ctx->dense_mode || bucket_run) && n > 1 && max_len < (64u << 20)) ? dense_group_size() : 1;
     if (G > 1) {
         // The 3 G buffer sets of a grouped batch are one slab sized for the batch's longest sample: ~16 bytes per base on the

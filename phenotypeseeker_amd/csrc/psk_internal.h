@@ -128,10 +128,11 @@ struct psk_ctx {
     bool dense_mode = false;
     bool dense_defer = false;        // psk_count_kmers_batch is collecting genomes into launch groups (dense_group_enqueue)
     uint32_t dense_b0 = 0, dense_nb = 0;
-    // bucketed sort of k = 14..16 (bucket_count.hip): 2,048 splitters taken from the first list of the run
+    // bucketed sort of k = 14..32 (bucket_count.hip): 2,048 splitters taken from the first list of the run
     DevBuf bs_spl, bs_ct;             // splitters; bucket of the first word of each of 4,096 cells of the run's word range
     bool bs_ready = false;
-    uint32_t bs_nb = 0, bs_lo = 0, bs_shift = 0;
+    uint32_t bs_nb = 0, bs_shift = 0;
+    uint64_t bs_lo = 0;               // first word of the cells' range (the slab's)
     double bs_keep = 1.0;             // share of a sample's windows the slab keeps (from that list)
 
     // scratch for per-sample counting
@@ -247,11 +248,11 @@ bool dense_group_ok(const psk_ctx *ctx, uint64_t n);
 int dense_group_enqueue(psk_ctx *ctx, CountLane *const *lanes, const int *sample_idx, const uint64_t *clean_len, const uint64_t *n,
                         int count);
 int dense_group_compact(psk_ctx *ctx, CountLane *const *lanes, const int *sample_idx, int count);
-// the same for the bucketed sort (k = 14..16, bucket_count.hip)
+// the same for the bucketed sort (k = 14..32, bucket_count.hip)
 int bucket_group_enqueue(psk_ctx *ctx, CountLane *const *lanes, const int *sample_idx, const uint64_t *clean_len, const uint64_t *n,
                          int count);
 int bucket_group_compact(psk_ctx *ctx, CountLane *const *lanes, const int *sample_idx, int count);
-void bucket_lane_bytes(size_t max_len, size_t out[5]);
+void bucket_lane_bytes(const psk_ctx *ctx, size_t max_len, size_t out[5]);
 // bytes of the five dc_* buffers of one buffer set for samples of up to max_len clean bases (dc_part, dc_wgoff, dc_cnt, dc_meta, dc_mtemp)
 void dense_lane_bytes(const psk_ctx *ctx, size_t max_len, size_t out[5]);
 // words[] / freqs[] of samples [first, first + n) from their dense form (no-op for sparse or materialised ones)
@@ -259,7 +260,7 @@ int dense_materialize(psk_ctx *ctx, int first, int n);
 int dense_lookup_counts(psk_ctx *ctx, const SampleList &L, const uint64_t *d_query, uint64_t n, uint32_t *d_out);
 int build_presence_dense(psk_ctx *ctx, uint64_t *n_kmers, int *done);
 
-// ---- bucketed sort for k = 14..16 (bucket_count.hip) ----------------------------------------------------------------
+// ---- bucketed sort for k = 14..32 (bucket_count.hip) ----------------------------------------------------------------
 constexpr uint32_t BS_NB = 2048;           // most buckets of equal count a run uses (splitters = quantiles of one of its lists)
 bool bucket_route_ok(const psk_ctx *ctx, uint64_t n);
 int bucket_splitters_from(psk_ctx *ctx, const SampleList &S, uint64_t windows);

@@ -1263,9 +1263,10 @@ def test_dense_counting_paths_agree_with_the_oracle(ctx, oracle, k, monkeypatch)
     check(batch=True)
 
 
-@pytest.mark.parametrize("k", [14, 15, 16])
+@pytest.mark.parametrize("k", [14, 15, 16, 17, 18, 21, 27, 31, 32])
 def test_bucketed_sort_route_equals_the_radix_route_and_the_oracle(ctx, oracle, k, monkeypatch, capfd):
-    """k = 14..16 (bucket_count.hip): once a list of the run has given the splitters the later samples are counted by
+    """k = 14..32 (bucket_count.hip; r05: the 64-bit words of k >= 17 as well -- what `glistmaker -w <k>` is asked for at
+    modeling.py:309-310 for any `-l` up to 32): once a list of the run has given the splitters the later samples are counted by
     partition + one LDS sort per bucket.  Same lists as the radix route (PSK_NO_BUCKET_SORT) and as the oracle: uniform
     and AT-rich genomes in one run (the splitters come from the first), a sample with a tandem repeat and a homopolymer
     (one word 70,000 times), an empty and a tiny one; whole space and under a slab filter; and with a bucket capacity of
@@ -1281,7 +1282,7 @@ def test_bucketed_sort_route_equals_the_radix_route_and_the_oracle(ctx, oracle, 
     space = 1 << (2 * k)
 
     def run(lo, hi, batch):
-        ctx.begin(k, len(datas), lo, hi)
+        ctx.begin(k, len(datas), lo, hi if hi < space else 0)      # (0: no upper bound -- 4^32 does not fit the argument)
         if batch:
             nu, nt = ctx.count_kmers_batch(0, datas, 3)
         else:

@@ -49,4 +49,5 @@ prof solver4096 "" python3 "$ROOT/tools/profile_workloads.py" solver4096
 prof predict "" python3 "$ROOT/tools/profile_workloads.py" predict
 prof weights "" python3 "$ROOT/tools/profile_workloads.py" weights
 prof lasso "" python3 "$ROOT/tools/profile_workloads.py" lasso
+for K in 16 18 21 27 31 32; do prof kwide$K "" python3 "$ROOT/tools/profile_workloads.py" kwide $K; done
 du -sh "$OUT"

@@ -70,6 +70,32 @@ if what == "cfg3slab":
         recs = pairs // 20
         alg["pm_replay_kernel"] = 12 * recs + 8 * recs
         alg["pm_union_kernel"] = (bounds[1] - bounds[0]) // 64 * 12 + m * 8
+elif what == "kwide":
+    # r05: counting and presence build beyond the 32-bit word spaces (k = 17..32: `-l` accepts them, scripts/phenotypeseeker:89-92) next
+    # to k = 16 -- a rank's 1/8 slab of 256 x 5 Mbp (the kernels per genome under the slab filter), then the whole space of 64 genomes
+    from phenotypeseeker_amd import dist
+    k = int(sys.argv[2])
+    n, L, world = 256, 5_000_000, 8
+    gs = GenomeSet(n, L, seed=12345)
+    fas = [gs.sample(i)[1] for i in range(n)]
+    with PskContext(0) as ctx:
+        ctx.begin(k, 1)
+        nu0, _ = ctx.count_kmers(0, fas[0])
+        bounds = dist.quantile_bounds(dist.pilot_points(ctx.get_list(0, nu0)[0]), k, world)
+        res = {}
+        for label, lo, hi, m_ in (("slab", bounds[0], bounds[1], n), ("whole", 0, 0, 64)):
+            ctx.begin(k, m_, lo, hi)
+            t0 = time.time()
+            pairs = 0
+            for s0 in range(0, m_, 64):
+                nu, _ = ctx.count_kmers_batch(s0, fas[s0:s0 + 64], 8)
+                pairs += sum(nu)
+            t1 = time.time()
+            m = ctx.build_presence()
+            t2 = time.time()
+            res[label] = {"genomes": m_, "pairs": pairs, "rows": m, "count_wall_s": round(t1 - t0, 4), "count_wall_us_per_genome": round(1e6 * (t1 - t0) / m_, 1),
+                          "presence_s": round(t2 - t1, 4)}
+        out["notes"] = {"k": k, **res}
 elif what == "moments":
     M, N = 16_000_000, 1024
     rng = np.random.default_rng(3)
