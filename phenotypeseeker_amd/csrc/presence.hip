@@ -196,6 +196,7 @@ int sample_bits(int n_samples)
 
 int build_presence_tiled(psk_ctx *ctx, uint64_t total_pairs, uint64_t *n_kmers, int *done);  // presence_tiled.hip
 int build_presence_merge(psk_ctx *ctx, uint64_t total_pairs, uint64_t *n_kmers, int *done);  // presence_merge.hip
+int build_presence_merge_wide(psk_ctx *ctx, uint64_t total_pairs, uint64_t *n_kmers, int *done);  // presence_merge.hip
 
 static int padded_wpr(int n_samples)
 {
@@ -265,6 +266,20 @@ extern "C" int psk_build_presence(psk_ctx *ctx, uint64_t *n_kmers)
         PSK_TRY(build_presence_merge(ctx, total, &M, &done));
         if (done) {
             pt.mark("merge build");
+            ctx->n_kmers = M;
+            ctx->have_presence = true;
+            ctx->dense_hint = -1;
+            ctx->last.valid = false;
+            if (n_kmers) *n_kmers = M;
+            return PSK_OK;
+        }
+    }
+    {   // wider word spaces (k >= 18): the same streaming merge without a value bitmap -- union and rows from its records (r05)
+        uint64_t M = 0;
+        int done = 0;
+        PSK_TRY(build_presence_merge_wide(ctx, total, &M, &done));
+        if (done) {
+            pt.mark("wide merge build");
             ctx->n_kmers = M;
             ctx->have_presence = true;
             ctx->dense_hint = -1;

@@ -287,7 +287,10 @@ struct PmRec {
     uint32_t region_chunks; // chunks per region; 0: no records
 };
 
-template <typename W>
+// BITMAP = false (r05, word spaces beyond 2^34 values: k >= 18): no occupancy bitmap -- a bit per word VALUE is what such a
+// space cannot have -- the pass only leaves its records; the union is then the sorted distinct record words and a record's
+// row its rank among them (build_presence_merge_wide below).
+template <typename W, bool BITMAP = true>
 __global__ __launch_bounds__(PM_GROUP) void pm_mark_kernel(const PmList *__restrict__ lists, int n_samples,
                                                            const uint64_t *__restrict__ bounds, uint32_t n_tiles,
                                                            uint32_t tiles_per_range, uint64_t base,
@@ -338,9 +341,11 @@ __global__ __launch_bounds__(PM_GROUP) void pm_mark_kernel(const PmList *__restr
     for (uint32_t t = t0; t < t1; t++) {
         const uint64_t lo = bounds[t], hi = bounds[t + 1];
         const W lo_w = (W)(lo - base), hi_w = (W)(hi - base - 1);   // inclusive upper end: hi - base may be 2^32
-        const uint32_t nbw = (uint32_t)((hi - lo + 63) >> 6);
-        for (uint32_t i = threadIdx.x; i < nbw; i += blockDim.x) bm[i] = 0;
-        __syncthreads();
+        const uint32_t nbw = BITMAP ? (uint32_t)((hi - lo + 63) >> 6) : 0u;
+        if (BITMAP) {
+            for (uint32_t i = threadIdx.x; i < nbw; i += blockDim.x) bm[i] = 0;
+            __syncthreads();
+        }
         // the words found go into the bitmap 64 at a time, lane j the j-th of them (one atomic of one lane per iteration was a
         // wave instruction per word; this is one per 64)
         uint32_t my_v = 0;
@@ -350,12 +355,14 @@ __global__ __launch_bounds__(PM_GROUP) void pm_mark_kernel(const PmList *__restr
             const W cand = cur.cur <= hi_w ? cur.cur : PmCursor<W>::SENT;
             const W m = pm_wave_min_guess(cand);
             if (m == PmCursor<W>::SENT) break;
-            const uint32_t v = (uint32_t)(m - lo_w);
             const bool hit = cand == m;
-            if (lane == cnt) my_v = v;
-            if (++cnt == 64) {
-                atomicOr(&bm[my_v >> 6], 1ull << (my_v & 63));
-                cnt = 0;
+            if (BITMAP) {
+                const uint32_t v = (uint32_t)(m - lo_w);
+                if (lane == cnt) my_v = v;
+                if (++cnt == 64) {
+                    atomicOr(&bm[my_v >> 6], 1ull << (my_v & 63));
+                    cnt = 0;
+                }
             }
             if (recs) {
                 const uint64_t mask = __ballot(hit);
@@ -371,17 +378,86 @@ __global__ __launch_bounds__(PM_GROUP) void pm_mark_kernel(const PmList *__restr
             }
             if (hit) cur.advance();
         }
-        if (lane < cnt) atomicOr(&bm[my_v >> 6], 1ull << (my_v & 63));
-        __syncthreads();
-        unsigned long long *g = gbm + ((lo - base) >> 6);
-        for (uint32_t i = threadIdx.x; i < nbw; i += blockDim.x) {
-            const unsigned long long v = bm[i];
-            if (single_group) g[i] = v;
-            else if (v) atomicOr(&g[i], v);
+        if (BITMAP) {
+            if (lane < cnt) atomicOr(&bm[my_v >> 6], 1ull << (my_v & 63));
+            __syncthreads();
+            unsigned long long *g = gbm + ((lo - base) >> 6);
+            for (uint32_t i = threadIdx.x; i < nbw; i += blockDim.x) {
+                const unsigned long long v = bm[i];
+                if (single_group) g[i] = v;
+                else if (v) atomicOr(&g[i], v);
+            }
+            __syncthreads();
         }
-        __syncthreads();
     }
     if (recs) rec_flush(rcnt);   // (the chunk claimed ahead stays empty: its header is zero)
+}
+
+// ---- word spaces without a value bitmap (k >= 18): union and rows from the records ------------------------------------------------
+// records of every chunk -> one dense key array (chunk c's records at off[c] ..): a wave per chunk
+__global__ __launch_bounds__(256) void pmw_chunk_counts_kernel(const uint2 *__restrict__ hdr, uint64_t n_chunks, uint32_t *__restrict__ cnt)
+{
+    const uint64_t c = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (c < n_chunks) cnt[c] = hdr[c].y;
+    else if (c == n_chunks) cnt[c] = 0;   // the scan's extra element: off[n_chunks] = records in all
+}
+__global__ __launch_bounds__(256) void pmw_gather_kernel(const uint2 *__restrict__ hdr, const uint64_t *__restrict__ words, uint64_t n_chunks,
+                                                         const uint32_t *__restrict__ off, uint64_t *__restrict__ keys)
+{
+    const uint64_t c = (uint64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+    const uint32_t lane = threadIdx.x & 63;
+    if (c >= n_chunks) return;
+    if (lane < hdr[c].y) keys[(uint64_t)off[c] + lane] = words[c * 64 + lane];
+}
+// heads of the runs of equal keys (the distinct words); then, the heads ranked by a scan, the union
+__global__ __launch_bounds__(256) void pmw_heads_kernel(const uint64_t *__restrict__ keys, uint64_t n, uint32_t *__restrict__ head)
+{
+    const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) head[i] = (i == 0 || keys[i - 1] != keys[i]) ? 1u : 0u;
+    else if (i == n) head[i] = 0;
+}
+__global__ __launch_bounds__(256) void pmw_union_kernel(const uint64_t *__restrict__ keys, uint64_t n, const uint32_t *__restrict__ rank,
+                                                        uint64_t *__restrict__ union_words)
+{
+    const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n && (i == 0 || keys[i - 1] != keys[i])) union_words[rank[i]] = keys[i];
+}
+// cells[c] = first row whose word is >= lo + (c << shift): a record's row is then a search over one cell of the union
+__global__ __launch_bounds__(256) void pmw_cells_kernel(const uint64_t *__restrict__ uw, uint32_t m, uint64_t lo, uint32_t shift, uint32_t n_cells,
+                                                        uint32_t *__restrict__ cells)
+{
+    const uint32_t c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c > n_cells) return;
+    const uint64_t off = (uint64_t)c << shift, key = lo + off;
+    uint32_t a = 0, b = m;
+    if (c == n_cells || (shift && (off >> shift) != c) || key < off) a = m;   // beyond the last word value
+    else
+        while (a < b) {
+            const uint32_t mid = (a + b) >> 1;
+            if (uw[mid] < key) a = mid + 1; else b = mid;
+        }
+    cells[c] = a;
+}
+// pass 2 from the records (as pm_replay_kernel): the row of a word = its place in the union, found inside its cell
+__global__ __launch_bounds__(256) void pmw_replay_kernel(const PmRec rec, uint64_t n_chunks, const uint64_t *__restrict__ uw,
+                                                         const uint32_t *__restrict__ cells, uint64_t lo, uint32_t shift, uint32_t n_cells,
+                                                         int wpr, uint64_t *__restrict__ bits)
+{
+    const uint64_t ch = (uint64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+    const int lane = threadIdx.x & 63;
+    if (ch >= n_chunks) return;
+    const uint2 h = rec.hdr[ch];
+    if ((uint32_t)lane >= h.y) return;
+    const uint64_t m = reinterpret_cast<const uint64_t *>(rec.words)[ch * 64 + lane];
+    const unsigned long long mask = rec.masks[ch * 64 + lane];
+    uint64_t c = (m - lo) >> shift;
+    if (c >= n_cells) c = n_cells - 1;
+    uint32_t a = cells[c], b = cells[c + 1];
+    while (a < b) {
+        const uint32_t mid = (a + b) >> 1;
+        if (uw[mid] < m) a = mid + 1; else b = mid;
+    }
+    bits[(uint64_t)a * (uint64_t)wpr + h.x] = mask;
 }
 
 // pass 2 from the records: a wave per chunk; lane j: row of its word = rank of its bitmap word + the set bits below it, its
@@ -603,6 +679,8 @@ int build_presence_merge(psk_ctx *ctx, uint64_t total_pairs, uint64_t *n_kmers, 
     const uint64_t span = top - base;
     // one bit (+ half a rank byte) per word value of the slab: up to 2^34 values = 2 GB + 1 GB; rows are ranked in u32
     if (span > (1ull << 34)) return PSK_OK;
+    // (r05) beyond k = 17 a narrow slab still has thousands of word values per word that occurs: the bitmap-free form is for those
+    if (k >= 18 && span / 1024 > total_pairs) return PSK_OK;
     if (total_pairs >= (1ull << 32) && span / 2 + (1ull << k) >= (1ull << 32)) return PSK_OK;
     for (int i = 0; i < n; i++)
         if (ctx->lists[i].n_unique >= (1ull << 32)) return PSK_OK;
@@ -823,6 +901,186 @@ int build_presence_merge(psk_ctx *ctx, uint64_t total_pairs, uint64_t *n_kmers, 
     if (getenv("PSK_TRACE"))
         fprintf(stderr, "[psk] merge build: %u tiles (%llu pairs each wanted), %llu ranges x %d groups of %d threads, widest tile %u bitmap words, most rows %u\n",
                 n_tiles, (unsigned long long)pairs_per_tile, (unsigned long long)n_ranges, n_groups, threads, bmw_max, rows_max);
+    *n_kmers = M;
+    *done = 1;
+    return PSK_OK;
+}
+
+// ---- r05: the merge build without a value bitmap (word spaces beyond 2^34 values: k >= 18) -------------------------------------
+// The same streaming 64-way merge per wave (pm_mark_kernel<uint64_t, false>) leaves its (word, ballot) records; the union is the
+// sorted distinct record words (one radix sort of the RECORD words -- a twentieth of the pairs at config 3's sharing, against the
+// sort route's sort of every (word, sample) pair), a record's row is its word's place in the union (a cell table + a short
+// search), and pass 2 is the replay: one 8-byte store per record into the zeroed matrix.  When the samples share too little for
+// the record pool (records ~ pairs) the build declines and the sort route takes over.
+// Returns PSK_OK and sets *done = 1 when it ran.
+int build_presence_merge_wide(psk_ctx *ctx, uint64_t total_pairs, uint64_t *n_kmers, int *done)
+{
+    *done = 0;
+    if (getenv("PSK_NO_MERGE_PRESENCE") || getenv("PSK_NO_WIDE_MERGE")) return PSK_OK;
+    const bool trace = getenv("PSK_TRACE") != nullptr;
+    auto t_prev = std::chrono::steady_clock::now();
+    auto mark = [&](const char *what) {
+        if (!trace) return;
+        (void)hipStreamSynchronize(ctx->stream);
+        const auto t = std::chrono::steady_clock::now();
+        fprintf(stderr, "[psk]   wide merge %-14s %8.3f ms\n", what, std::chrono::duration<double, std::milli>(t - t_prev).count());
+        t_prev = t;
+    };
+    const int k = ctx->k, n = ctx->n_samples, wpr = ctx->wpr;
+    if (k < 1 || k > 32 || n < 1 || total_pairs == 0) return PSK_OK;
+    for (int i = 0; i < n; i++)
+        if (ctx->lists[i].n_unique >= (1ull << 32)) return PSK_OK;
+    const uint64_t lo = ctx->slab_lo;
+    const uint64_t hi = ctx->slab_hi ? ctx->slab_hi : (k == 32 ? ~0ull : (1ull << (2 * k)));   // exclusive; no canonical word is all ones
+    if (hi <= lo) return PSK_OK;
+    // ---- tile bounds: pair quantiles of a pilot (they only cut the stream into ranges of work: no bitmap depends on them) ----
+    uint64_t pairs_per_tile = 8192;
+    if (const char *e = getenv("PSK_MERGE_TILE_PAIRS")) { const uint64_t v = strtoull(e, nullptr, 10); if (v >= 64) pairs_per_tile = v; }
+    uint64_t want = (total_pairs + pairs_per_tile - 1) / pairs_per_tile;
+    if (want < 1) want = 1;
+    if (want > (1ull << 24)) want = 1ull << 24;
+    const int n_pick = n < 64 ? n : 64;
+    std::vector<int32_t> pick(n_pick);
+    for (int i = 0; i < n_pick; i++) pick[i] = (int32_t)(((int64_t)i * n) / n_pick);
+    uint64_t per_list = (4 * want + n_pick - 1) / n_pick;
+    if (per_list < 64) per_list = 64;
+    if (per_list > (1u << 22)) per_list = 1u << 22;
+    const uint64_t n_pilot = per_list * (uint64_t)n_pick;
+    std::vector<PmList> refs(n);
+    for (int i = 0; i < n; i++) { refs[i].words = ctx->lists[i].words; refs[i].n = ctx->lists[i].n_unique; }
+    PSK_TRY(dev_reserve(ctx, ctx->starts, (size_t)n * sizeof(PmList) + (size_t)n_pick * 4 + 64));
+    PmList *d_refs = ctx->starts.as<PmList>();
+    int32_t *d_pick = reinterpret_cast<int32_t *>(d_refs + n);
+    PSK_HIP(ctx, hipMemcpyAsync(d_refs, refs.data(), (size_t)n * sizeof(PmList), hipMemcpyHostToDevice, ctx->stream));
+    PSK_HIP(ctx, hipMemcpyAsync(d_pick, pick.data(), (size_t)n_pick * 4, hipMemcpyHostToDevice, ctx->stream));
+    PSK_TRY(dev_reserve(ctx, ctx->keysA, n_pilot * 8));
+    PSK_TRY(dev_reserve(ctx, ctx->keysB, n_pilot * 8));
+    pm_pilot_kernel<<<div_up(n_pilot, 256), 256, 0, ctx->stream>>>(d_refs, d_pick, n_pick, (uint32_t)per_list, ctx->keysA.as<uint64_t>());
+    PSK_HIP(ctx, hipGetLastError());
+    uint64_t *sorted = nullptr;
+    PSK_TRY(dev_radix_sort_u64(ctx, ctx->keysA.as<uint64_t>(), ctx->keysB.as<uint64_t>(), n_pilot, 0, 64, &sorted));
+    std::vector<uint64_t> pilot(n_pilot);
+    PSK_HIP(ctx, hipMemcpyAsync(pilot.data(), sorted, n_pilot * 8, hipMemcpyDeviceToHost, ctx->stream));
+    PSK_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    mark("pilot + sort");
+    while (!pilot.empty() && pilot.back() == PM_SENT) pilot.pop_back();
+    std::vector<uint64_t> bounds;
+    bounds.push_back(lo);
+    if (!pilot.empty())
+        for (uint64_t j = 1; j < want; j++) {
+            const uint64_t v = pilot[(size_t)((pilot.size() * j) / want)];
+            if (v > bounds.back() && v < hi) bounds.push_back(v);
+        }
+    bounds.push_back(hi);
+    const uint32_t n_tiles = (uint32_t)(bounds.size() - 1);
+    const int n_groups = (n + PM_GROUP - 1) / PM_GROUP;
+    const int threads = n >= PM_GROUP ? PM_GROUP : ((n + 63) / 64) * 64;
+    uint64_t n_ranges = ((uint64_t)(ctx->n_cu > 0 ? ctx->n_cu : 256) * 8 * (PM_GROUP / threads)) / n_groups;
+    if (const char *e = getenv("PSK_MERGE_RANGES")) { const uint64_t v = strtoull(e, nullptr, 10); if (v >= 1) n_ranges = v; }
+    if (n_ranges > n_tiles) n_ranges = n_tiles;
+    if (n_ranges < 1) n_ranges = 1;
+    const uint32_t tiles_per_range = (uint32_t)((n_tiles + n_ranges - 1) / n_ranges);
+    n_ranges = (n_tiles + tiles_per_range - 1) / tiles_per_range;
+    PSK_TRY(dev_reserve(ctx, ctx->flags, 64 + (size_t)(n_tiles + 1) * 8 + 64));
+    const uint64_t *d_spare = ctx->flags.as<uint64_t>();
+    uint64_t *d_bounds = ctx->flags.as<uint64_t>() + 8;
+    PSK_HIP(ctx, hipMemcpyAsync(d_bounds, bounds.data(), (size_t)(n_tiles + 1) * 8, hipMemcpyHostToDevice, ctx->stream));
+    // ---- the record pool: pairs / PSK_MERGE_REC_DIV records (default 12) + every wave's claims under way ------------------------
+    uint64_t div = 12;
+    if (const char *e = getenv("PSK_MERGE_REC_DIV")) {
+        char *end = nullptr;
+        div = strtoull(e, &end, 10);
+        if (!*e || *end) return psk_fail(ctx, PSK_EINVAL, "PSK_MERGE_REC_DIV=%s: expected a whole number (0 = no records)", e);
+    }
+    if (div == 0) return PSK_OK;   // no records, no wide merge: the sort route
+    uint64_t chunks = total_pairs / div / 64 + 3 * PM_REC_BLOCK * (uint64_t)n_ranges * n_groups * (threads / 64);
+    uint64_t region_chunks = ((chunks + chunks / 2) / PM_REC_REGIONS + PM_REC_BLOCK) & ~(uint64_t)(PM_REC_BLOCK - 1);
+    if (const char *e = getenv("PSK_MERGE_REC_REGION")) {
+        const uint64_t v = strtoull(e, nullptr, 10);
+        if (v >= 1 && v < (1ull << 26)) region_chunks = (v + PM_REC_BLOCK - 1) & ~(uint64_t)(PM_REC_BLOCK - 1);
+    }
+    chunks = region_chunks * PM_REC_REGIONS;
+    if (chunks >= (1ull << 26)) return PSK_OK;          // records are numbered in u32: 64 x chunks < 2^32
+    const size_t ctr_bytes = (size_t)(PM_REC_REGIONS + 1) * PM_REC_CTR_STRIDE * 4;
+    if (dev_reserve(ctx, ctx->valsA, chunks * 64 * 16) != PSK_OK || dev_reserve(ctx, ctx->valsB, ctr_bytes + chunks * 8) != PSK_OK) {
+        ctx->err.clear();
+        (void)hipGetLastError();
+        return PSK_OK;
+    }
+    PmRec rec;
+    rec.ctr = ctx->valsB.as<uint32_t>();
+    rec.hdr = reinterpret_cast<uint2 *>(ctx->valsB.as<uint8_t>() + ctr_bytes);
+    rec.masks = ctx->valsA.as<unsigned long long>();
+    rec.words = ctx->valsA.as<uint8_t>() + chunks * 64 * 8;
+    rec.region_chunks = (uint32_t)region_chunks;
+    PSK_HIP(ctx, hipMemsetAsync(ctx->valsB.p, 0, ctr_bytes + chunks * 8, ctx->stream));
+    mark("bounds + buffers");
+    const dim3 grid((unsigned)n_ranges, (unsigned)n_groups);
+    pm_mark_kernel<uint64_t, false><<<grid, threads, 0, ctx->stream>>>(d_refs, n, d_bounds, n_tiles, tiles_per_range, 0ull, nullptr, 0, d_spare, rec);
+    PSK_HIP(ctx, hipGetLastError());
+    uint32_t rec_state[(PM_REC_REGIONS + 1) * PM_REC_CTR_STRIDE] = {0};
+    PSK_HIP(ctx, hipMemcpyAsync(rec_state, rec.ctr, sizeof(rec_state), hipMemcpyDeviceToHost, ctx->stream));
+    PSK_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    mark("pm_mark (records)");
+    if (rec_state[PM_REC_REGIONS * PM_REC_CTR_STRIDE]) {
+        if (trace) fprintf(stderr, "[psk]   wide merge: a record region of %u chunks overflowed (the samples share too little): the sort route\n", rec.region_chunks);
+        return PSK_OK;
+    }
+    // ---- the record words, dense: chunk counts -> offsets -> keys ------------------------------------------------------------
+    PSK_TRY(dev_reserve(ctx, ctx->misc, 64));
+    uint32_t *d_tot = ctx->misc.as<uint32_t>() + 2;
+    const size_t cells_at = ((size_t)(chunks + 2) * 4 + 255) & ~(size_t)255;
+    PSK_TRY(dev_reserve(ctx, ctx->raw, cells_at + (((size_t)1 << 22) + 2) * 4));   // chunk offsets | the cell table of the replay
+    uint32_t *d_off = ctx->raw.as<uint32_t>();
+    pmw_chunk_counts_kernel<<<div_up(chunks + 1, 256), 256, 0, ctx->stream>>>(rec.hdr, chunks, d_off);
+    PSK_HIP(ctx, hipGetLastError());
+    PSK_TRY(dev_exclusive_scan_u32(ctx, d_off, d_off, chunks + 1, d_tot));
+    uint32_t n_rec = 0;
+    PSK_HIP(ctx, hipMemcpyAsync(&n_rec, d_tot, 4, hipMemcpyDeviceToHost, ctx->stream));
+    PSK_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    PSK_TRY(dev_reserve(ctx, ctx->keysA, ((size_t)n_rec + 1) * 8));
+    PSK_TRY(dev_reserve(ctx, ctx->keysB, ((size_t)n_rec + 1) * 8));
+    pmw_gather_kernel<<<div_up(chunks, 4), 256, 0, ctx->stream>>>(rec.hdr, reinterpret_cast<const uint64_t *>(rec.words), chunks, d_off,
+                                                               ctx->keysA.as<uint64_t>());
+    PSK_HIP(ctx, hipGetLastError());
+    mark("record words");
+    uint64_t *keys = ctx->keysA.as<uint64_t>();
+    if (n_rec) PSK_TRY(dev_radix_sort_u64(ctx, ctx->keysA.as<uint64_t>(), ctx->keysB.as<uint64_t>(), n_rec, 0, 2 * k, &keys));
+    mark("sort of the words");
+    // ---- distinct words = the union; their places = the rows ------------------------------------------------------------------
+    PSK_TRY(dev_reserve(ctx, ctx->hist, ((size_t)n_rec + 2) * 4));   // (the sort, which uses this buffer, is over)
+    uint32_t *d_head = ctx->hist.as<uint32_t>();
+    pmw_heads_kernel<<<div_up((uint64_t)n_rec + 1, 256), 256, 0, ctx->stream>>>(keys, n_rec, d_head);
+    PSK_HIP(ctx, hipGetLastError());
+    PSK_TRY(dev_exclusive_scan_u32(ctx, d_head, d_head, (uint64_t)n_rec + 1, d_tot));
+    uint32_t m32 = 0;
+    PSK_HIP(ctx, hipMemcpyAsync(&m32, d_tot, 4, hipMemcpyDeviceToHost, ctx->stream));
+    PSK_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    const uint64_t M = m32;
+    PSK_TRY(dev_reserve(ctx, ctx->union_words, (M ? M : 1) * 8));
+    PSK_TRY(dev_reserve(ctx, ctx->bits, (M ? M : 1) * (uint64_t)wpr * 8));
+    if (M) {
+        pmw_union_kernel<<<div_up(n_rec, 256), 256, 0, ctx->stream>>>(keys, n_rec, d_head, ctx->union_words.as<uint64_t>());
+        PSK_HIP(ctx, hipGetLastError());
+        // cells over [lo, hi): about four rows each, at most 2^22 of them
+        uint32_t n_cells = 1024;
+        while (n_cells < (1u << 22) && (uint64_t)n_cells * 4 < M) n_cells <<= 1;
+        uint32_t shift = 0;
+        while (((hi - 1 - lo) >> shift) >= (uint64_t)n_cells) shift++;
+        uint32_t *d_cells = reinterpret_cast<uint32_t *>(ctx->raw.as<uint8_t>() + cells_at);
+        pmw_cells_kernel<<<div_up(n_cells + 1, 256), 256, 0, ctx->stream>>>(ctx->union_words.as<uint64_t>(), (uint32_t)M, lo, shift, n_cells, d_cells);
+        PSK_HIP(ctx, hipGetLastError());
+        mark("union + cells");
+        PSK_HIP(ctx, hipMemsetAsync(ctx->bits.p, 0, M * (uint64_t)wpr * 8, ctx->stream));
+        pmw_replay_kernel<<<div_up(chunks, 4), 256, 0, ctx->stream>>>(rec, chunks, ctx->union_words.as<uint64_t>(), d_cells, lo, shift, n_cells, wpr,
+                                                                   ctx->bits.as<uint64_t>());
+        PSK_HIP(ctx, hipGetLastError());
+        PSK_HIP(ctx, hipStreamSynchronize(ctx->stream));
+        mark("memset + replay");
+    }
+    if (trace)
+        fprintf(stderr, "[psk] wide merge build: %u tiles, %llu ranges x %d groups of %d threads, %u records for %llu pairs, %llu rows\n", n_tiles,
+                (unsigned long long)n_ranges, n_groups, threads, n_rec, (unsigned long long)total_pairs, (unsigned long long)M);
     *n_kmers = M;
     *done = 1;
     return PSK_OK;

@@ -1415,6 +1415,56 @@ def test_merge_presence_build_equals_the_oracle_and_the_sort_route(ctx, oracle, 
         assert np.array_equal(ctx.get_union(), uw) and np.array_equal(ctx.get_rows(np.arange(m, dtype=np.uint64)), rows)
 
 
+@pytest.mark.parametrize("k,n,length,env", [
+    (18, 40, 30_000, {}),                                                    # one wave
+    (21, 70, 20_000, {"PSK_MERGE_TILE_PAIRS": "64"}),                        # two waves, thousands of tiny tiles
+    (27, 130, 9_000, {"PSK_MERGE_TILE_PAIRS": "500"}),                       # padded column
+    (31, 1100, 3_000, {"PSK_MERGE_TILE_PAIRS": "3000"}),                     # two sample groups: two record streams per range
+    (32, 1100, 2_000, {"PSK_MERGE_RANGES": "3"}),                            # the whole 64-bit space, three long ranges
+    (19, 24, 50_000, {"PSK_MERGE_RANGES": "1"}),                             # one range
+])
+def test_wide_merge_presence_build_equals_the_oracle_and_the_sort_route(ctx, oracle, k, n, length, env, monkeypatch, capfd):
+    """r05: the presence build beyond the value-bitmap spaces (k >= 18; `-l` takes up to 32, scripts/phenotypeseeker:89-92, and
+    the reference's union / mapping, modeling.py:317-380, are the same glistcompare / glistquery calls at any k): the streaming
+    merge leaves (word, ballot) records, the union is the sorted distinct record words, the rows are filled by replaying the
+    records (presence_merge.hip build_presence_merge_wide).  Union and every row equal the oracle's and the sort route's, with
+    empty samples, identical samples, a slab filter, more than 1,024 samples; a record pool that is too small (samples that
+    share nothing, or PSK_MERGE_REC_REGION) hands the build to the sort route, with the same result."""
+    from phenotypeseeker_amd.synth import GenomeSet
+    gs = GenomeSet(n, length, seed=3 * k + n, gene_len=150, sub_rate=0.01)
+    datas = [gs.sample(i)[1] for i in range(n)]
+    datas[3] = b""
+    datas[n - 1] = b""
+    datas[5] = datas[4]
+    lists = [oracle.count_kmers(d, k)[0] for d in datas]
+    monkeypatch.setenv("PSK_TRACE", "1")
+    for name, val in env.items():
+        monkeypatch.setenv(name, val)
+    for lo, hi in ((0, 0), (int(lists[0][len(lists[0]) // 3]) + 1, int(lists[0][2 * len(lists[0]) // 3]) + 7)):
+        ctx.begin(k, n, lo, hi)
+        for s0 in range(0, n, 64):
+            ctx.count_kmers_batch(s0, datas[s0:s0 + 64], 4)
+        kept = [w[(w >= lo) & ((w < hi) if hi else np.ones(len(w), bool))] for w in lists]
+        capfd.readouterr()
+        m = ctx.build_presence()
+        assert "wide merge build:" in capfd.readouterr().err, (lo, hi)      # the route under test ran
+        uw, rows = ctx.get_union(), ctx.get_rows(np.arange(m, dtype=np.uint64))
+        want = oracle.union(kept)
+        assert m == len(want) and np.array_equal(uw, want), (lo, hi)
+        assert np.array_equal(rows, oracle.presence_bits(kept, uw, wpr=ctx.presence_shape()[1]))
+        # a record region of eight chunks overflows: the sort route takes over; and the sort route asked for by the knob
+        for envs, said in (({"PSK_MERGE_REC_REGION": "8"}, "overflowed"), ({"PSK_NO_WIDE_MERGE": "1"}, None)):
+            for name, val in envs.items():
+                monkeypatch.setenv(name, val)
+            capfd.readouterr()
+            assert ctx.build_presence() == m
+            err = capfd.readouterr().err
+            assert "wide merge build:" not in err and (said is None or said in err or n < 64), envs
+            assert np.array_equal(ctx.get_union(), uw) and np.array_equal(ctx.get_rows(np.arange(m, dtype=np.uint64)), rows), envs
+            for name in envs:
+                monkeypatch.delenv(name)
+
+
 def test_full_size_ingest_properties(ctx, oracle):
     """BASELINE config-2 sized ingest (256 x 5 Mbp, k = 13) checked through size-independent
     properties: every list is strictly ascending with sum(freq) = number of windows, the union is
