@@ -49,5 +49,10 @@ prof solver4096 "" python3 "$ROOT/tools/profile_workloads.py" solver4096
 prof predict "" python3 "$ROOT/tools/profile_workloads.py" predict
 prof weights "" python3 "$ROOT/tools/profile_workloads.py" weights
 prof lasso "" python3 "$ROOT/tools/profile_workloads.py" lasso
-for K in 16 18 21 27 31 32; do prof kwide$K "" python3 "$ROOT/tools/profile_workloads.py" kwide $K; done
+for K in 16 21 31; do
+  prof kslab$K "" python3 "$ROOT/tools/profile_workloads.py" kwide $K slab      # counting under a rank's 1/8 slab filter, 256 genomes
+  prof kwhole$K "" python3 "$ROOT/tools/profile_workloads.py" kwide $K whole    # ... the whole word space, 64 genomes
+done
+prof cfg3slab21 "" python3 "$ROOT/tools/profile_workloads.py" cfg3slab 21
+prof cfg3slab31 "" python3 "$ROOT/tools/profile_workloads.py" cfg3slab 31
 du -sh "$OUT"

@@ -31,7 +31,7 @@ alg = out["algorithmic_bytes_per_launch"]
 
 if what == "cfg3slab":
     from phenotypeseeker_amd import dist
-    n, L, k, world = 2048, 5_000_000, 16, 8
+    n, L, k, world = 2048, 5_000_000, (int(sys.argv[2]) if len(sys.argv) > 2 else 16), 8     # (r05: `cfg3slab 21` / `cfg3slab 31`: the same slab at a 64-bit word length)
     gs = GenomeSet(n, L, seed=12345)
     with PskContext(0) as ctx:
         ctx.begin(k, 1)
@@ -49,7 +49,7 @@ if what == "cfg3slab":
         ph = np.array([gs.phenotype(i) for i in range(n)], dtype=np.int8)
         ctx.chi2_scan(ph, None, 2, n - 2, 0.05, False, 8 * m)
         ms = ctx.rescan_timed(10)
-        out["notes"] = {"rows": m, "pairs": pairs, "generate_and_count_s": round(t1 - t0, 2), "presence_s": round(t2 - t1, 2),
+        out["notes"] = {"rows": m, "pairs": pairs, "generate_and_count_s": round(t1 - t0, 2), "presence_s": round(t2 - t1, 4), "k": k,
                         "scan_ms": ms, "matrix_GB": m * 256 / 1e9}
         alg["chi2_scan_kernel"] = m * 256
         kept = pairs // n                       # words of a sample inside the slab (its unique words: a genome has few repeats)
@@ -83,7 +83,10 @@ elif what == "kwide":
         nu0, _ = ctx.count_kmers(0, fas[0])
         bounds = dist.quantile_bounds(dist.pilot_points(ctx.get_list(0, nu0)[0]), k, world)
         res = {}
+        modes = sys.argv[3:] or ["slab", "whole"]
         for label, lo, hi, m_ in (("slab", bounds[0], bounds[1], n), ("whole", 0, 0, 64)):
+            if label not in modes:
+                continue
             ctx.begin(k, m_, lo, hi)
             t0 = time.time()
             pairs = 0
