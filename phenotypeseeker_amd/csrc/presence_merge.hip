@@ -134,10 +134,10 @@ __device__ __forceinline__ W pm_wave_min_guess(W cand)
 // refill; in LDS an advance is one ds_read.  The loops are VALU-issue bound (~75 instructions per wave iteration, 43 M
 // iterations per pass at config 3: pm_mark 6.8 + pm_fill 14.2 ms, r03); 64-bit words (k = 17 slabs) keep the registers:
 // their ring would be 128 KB.
-template <typename W, int B = PSK_PM_BLOCK>
+template <typename W, int B = PSK_PM_BLOCK, bool RING_ = (sizeof(W) == 4)>
 struct PmCursor {
     static constexpr W SENT = (W)~(W)0;
-    static constexpr bool RING = sizeof(W) == 4;
+    static constexpr bool RING = RING_;   // (r05: 64-bit words ride the ring too where the kernel has the LDS for it -- the bitmap-free pass 1)
     static constexpr int NREG = RING ? 1 : 2 * B;
     W *ring;               // RING: this lane's slot 0; slot j at ring[j * stride]
     uint32_t stride, off;  // RING: lanes per workgroup; the slot of window position 0 (0 or B: the halves swap roles at a refill)
@@ -297,14 +297,15 @@ __global__ __launch_bounds__(PM_GROUP) void pm_mark_kernel(const PmList *__restr
                                                            unsigned long long *__restrict__ gbm, int single_group,
                                                            const uint64_t *__restrict__ spare, const PmRec rec)
 {
-    __shared__ unsigned long long bm[PM_BMW];
-    extern __shared__ __attribute__((aligned(16))) unsigned long long pm_ring_lds[];   // (32-bit words) the lanes' windows
+    __shared__ unsigned long long bm[BITMAP ? PM_BMW : 1];
+    extern __shared__ __attribute__((aligned(16))) unsigned long long pm_ring_lds[];   // the lanes' windows (32-bit words; 64-bit ones without the bitmap: 128 KB)
+    typedef PmCursor<W, PSK_PM_BLOCK, (sizeof(W) == 4 || !BITMAP)> Cur;
     const int lane = threadIdx.x & 63;
     const int s = blockIdx.y * PM_GROUP + threadIdx.x;
     const uint32_t t0 = blockIdx.x * tiles_per_range;
     const uint32_t t1 = t0 + tiles_per_range < n_tiles ? t0 + tiles_per_range : n_tiles;
-    PmCursor<W> cur;
-    if constexpr (PmCursor<W>::RING) cur.attach(reinterpret_cast<W *>(pm_ring_lds) + threadIdx.x, blockDim.x);
+    Cur cur;
+    if constexpr (Cur::RING) cur.attach(reinterpret_cast<W *>(pm_ring_lds) + threadIdx.x, blockDim.x);
     if (s < n_samples) {
         const PmList L = lists[s];
         cur.seek(L.words, (uint32_t)L.n, pm_lower_bound(L.words, (uint32_t)L.n, bounds[t0]), base, spare);
@@ -352,9 +353,9 @@ __global__ __launch_bounds__(PM_GROUP) void pm_mark_kernel(const PmList *__restr
         int cnt = 0;
         for (;;) {
             if (__any(cur.dry())) cur.refill();
-            const W cand = cur.cur <= hi_w ? cur.cur : PmCursor<W>::SENT;
+            const W cand = cur.cur <= hi_w ? cur.cur : Cur::SENT;
             const W m = pm_wave_min_guess(cand);
-            if (m == PmCursor<W>::SENT) break;
+            if (m == Cur::SENT) break;
             const bool hit = cand == m;
             if (BITMAP) {
                 const uint32_t v = (uint32_t)(m - lo_w);
@@ -958,7 +959,8 @@ int build_presence_merge_wide(psk_ctx *ctx, uint64_t total_pairs, uint64_t *n_km
     pm_pilot_kernel<<<div_up(n_pilot, 256), 256, 0, ctx->stream>>>(d_refs, d_pick, n_pick, (uint32_t)per_list, ctx->keysA.as<uint64_t>());
     PSK_HIP(ctx, hipGetLastError());
     uint64_t *sorted = nullptr;
-    PSK_TRY(dev_radix_sort_u64(ctx, ctx->keysA.as<uint64_t>(), ctx->keysB.as<uint64_t>(), n_pilot, 0, 64, &sorted));
+    // (the sentinels of empty lists sort last on the low 2k bits alone: all ones there is no canonical word)
+    PSK_TRY(dev_radix_sort_u64(ctx, ctx->keysA.as<uint64_t>(), ctx->keysB.as<uint64_t>(), n_pilot, 0, 2 * k, &sorted));
     std::vector<uint64_t> pilot(n_pilot);
     PSK_HIP(ctx, hipMemcpyAsync(pilot.data(), sorted, n_pilot * 8, hipMemcpyDeviceToHost, ctx->stream));
     PSK_HIP(ctx, hipStreamSynchronize(ctx->stream));
@@ -1016,7 +1018,10 @@ int build_presence_merge_wide(psk_ctx *ctx, uint64_t total_pairs, uint64_t *n_km
     PSK_HIP(ctx, hipMemsetAsync(ctx->valsB.p, 0, ctr_bytes + chunks * 8, ctx->stream));
     mark("bounds + buffers");
     const dim3 grid((unsigned)n_ranges, (unsigned)n_groups);
-    pm_mark_kernel<uint64_t, false><<<grid, threads, 0, ctx->stream>>>(d_refs, n, d_bounds, n_tiles, tiles_per_range, 0ull, nullptr, 0, d_spare, rec);
+    const size_t ring_bytes = (size_t)threads * PSK_PM_BLOCK * 2 * 8;   // the lanes' windows (64-bit words): 128 KB for 1,024 lanes
+    if (ring_bytes > 64 * 1024)
+        PSK_HIP(ctx, hipFuncSetAttribute(reinterpret_cast<const void *>(pm_mark_kernel<uint64_t, false>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)ring_bytes));
+    pm_mark_kernel<uint64_t, false><<<grid, threads, ring_bytes, ctx->stream>>>(d_refs, n, d_bounds, n_tiles, tiles_per_range, 0ull, nullptr, 0, d_spare, rec);
     PSK_HIP(ctx, hipGetLastError());
     uint32_t rec_state[(PM_REC_REGIONS + 1) * PM_REC_CTR_STRIDE] = {0};
     PSK_HIP(ctx, hipMemcpyAsync(rec_state, rec.ctr, sizeof(rec_state), hipMemcpyDeviceToHost, ctx->stream));
