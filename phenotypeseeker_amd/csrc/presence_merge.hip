@@ -304,13 +304,17 @@ __global__ __launch_bounds__(PM_GROUP) void pm_mark_kernel(const PmList *__restr
     const int s = blockIdx.y * PM_GROUP + threadIdx.x;
     const uint32_t t0 = blockIdx.x * tiles_per_range;
     const uint32_t t1 = t0 + tiles_per_range < n_tiles ? t0 + tiles_per_range : n_tiles;
+    // bitmap-free pass with 32-bit cursors (r05): the words of THIS range relative to its first bound -- the host takes this
+    // instantiation when every range of the launch spans less than 2^32 - 1 word values (k = 21 under a slab filter: 2^29); the
+    // records carry the absolute 64-bit words again
+    const uint64_t base_r = (!BITMAP && sizeof(W) == 4) ? bounds[t0] : base;
     Cur cur;
     if constexpr (Cur::RING) cur.attach(reinterpret_cast<W *>(pm_ring_lds) + threadIdx.x, blockDim.x);
     if (s < n_samples) {
         const PmList L = lists[s];
-        cur.seek(L.words, (uint32_t)L.n, pm_lower_bound(L.words, (uint32_t)L.n, bounds[t0]), base, spare);
+        cur.seek(L.words, (uint32_t)L.n, pm_lower_bound(L.words, (uint32_t)L.n, bounds[t0]), base_r, spare);
     } else {
-        cur.seek(nullptr, 0, 0, base, spare);
+        cur.seek(nullptr, 0, 0, base_r, spare);
     }
     // records: lane j keeps the j-th (word, ballot) since the last chunk went out; they run on across the tiles
     const bool recs = rec.region_chunks != 0;
@@ -333,7 +337,8 @@ __global__ __launch_bounds__(PM_GROUP) void pm_mark_kernel(const PmList *__restr
         if (ch_cur < rec.region_chunks) {
             const size_t ch = region0 + ch_cur;
             if (lane < have) {
-                reinterpret_cast<W *>(rec.words)[ch * 64 + lane] = rec_m;
+                if (BITMAP) reinterpret_cast<W *>(rec.words)[ch * 64 + lane] = rec_m;
+                else reinterpret_cast<uint64_t *>(rec.words)[ch * 64 + lane] = base_r + (uint64_t)rec_m;
                 rec.masks[ch * 64 + lane] = rec_mask;
             }
             if (lane == 0) rec.hdr[ch] = make_uint2(col, (uint32_t)have);
@@ -341,7 +346,7 @@ __global__ __launch_bounds__(PM_GROUP) void pm_mark_kernel(const PmList *__restr
     };
     for (uint32_t t = t0; t < t1; t++) {
         const uint64_t lo = bounds[t], hi = bounds[t + 1];
-        const W lo_w = (W)(lo - base), hi_w = (W)(hi - base - 1);   // inclusive upper end: hi - base may be 2^32
+        const W lo_w = (W)(lo - base_r), hi_w = (W)(hi - base_r - 1);   // inclusive upper end: hi - base may be 2^32
         const uint32_t nbw = BITMAP ? (uint32_t)((hi - lo + 63) >> 6) : 0u;
         if (BITMAP) {
             for (uint32_t i = threadIdx.x; i < nbw; i += blockDim.x) bm[i] = 0;
@@ -1018,10 +1023,18 @@ int build_presence_merge_wide(psk_ctx *ctx, uint64_t total_pairs, uint64_t *n_km
     PSK_HIP(ctx, hipMemsetAsync(ctx->valsB.p, 0, ctr_bytes + chunks * 8, ctx->stream));
     mark("bounds + buffers");
     const dim3 grid((unsigned)n_ranges, (unsigned)n_groups);
-    const size_t ring_bytes = (size_t)threads * PSK_PM_BLOCK * 2 * 8;   // the lanes' windows (64-bit words): 128 KB for 1,024 lanes
-    if (ring_bytes > 64 * 1024)
-        PSK_HIP(ctx, hipFuncSetAttribute(reinterpret_cast<const void *>(pm_mark_kernel<uint64_t, false>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)ring_bytes));
-    pm_mark_kernel<uint64_t, false><<<grid, threads, ring_bytes, ctx->stream>>>(d_refs, n, d_bounds, n_tiles, tiles_per_range, 0ull, nullptr, 0, d_spare, rec);
+    // 32-bit cursors (words relative to the range's first bound; the inline-asm DPP minimum, a 64-KB ring) when every range of the
+    // launch spans less than 2^32 - 1 word values, 64-bit ones (a 128-KB ring) otherwise
+    bool narrow = !getenv("PSK_WIDE_MERGE_64");
+    for (uint64_t r0 = 0; r0 < n_tiles && narrow; r0 += tiles_per_range) {
+        const uint64_t r1 = std::min<uint64_t>(r0 + tiles_per_range, n_tiles);
+        if (bounds[r1] - bounds[r0] >= 0xfffffffeull) narrow = false;
+    }
+    const size_t ring_bytes = (size_t)threads * PSK_PM_BLOCK * 2 * (narrow ? 4 : 8);   // the lanes' windows: 64 / 128 KB for 1,024 lanes
+    auto mark_k = narrow ? pm_mark_kernel<uint32_t, false> : pm_mark_kernel<uint64_t, false>;
+    if (ring_bytes > 48 * 1024)
+        PSK_HIP(ctx, hipFuncSetAttribute(reinterpret_cast<const void *>(mark_k), hipFuncAttributeMaxDynamicSharedMemorySize, (int)ring_bytes));
+    mark_k<<<grid, threads, ring_bytes, ctx->stream>>>(d_refs, n, d_bounds, n_tiles, tiles_per_range, 0ull, nullptr, 0, d_spare, rec);
     PSK_HIP(ctx, hipGetLastError());
     uint32_t rec_state[(PM_REC_REGIONS + 1) * PM_REC_CTR_STRIDE] = {0};
     PSK_HIP(ctx, hipMemcpyAsync(rec_state, rec.ctr, sizeof(rec_state), hipMemcpyDeviceToHost, ctx->stream));
@@ -1062,8 +1075,10 @@ int build_presence_merge_wide(psk_ctx *ctx, uint64_t total_pairs, uint64_t *n_km
     PSK_HIP(ctx, hipMemcpyAsync(&m32, d_tot, 4, hipMemcpyDeviceToHost, ctx->stream));
     PSK_HIP(ctx, hipStreamSynchronize(ctx->stream));
     const uint64_t M = m32;
+    mark("heads + ranks");
     PSK_TRY(dev_reserve(ctx, ctx->union_words, (M ? M : 1) * 8));
     PSK_TRY(dev_reserve(ctx, ctx->bits, (M ? M : 1) * (uint64_t)wpr * 8));
+    mark("alloc matrix");
     if (M) {
         pmw_union_kernel<<<div_up(n_rec, 256), 256, 0, ctx->stream>>>(keys, n_rec, d_head, ctx->union_words.as<uint64_t>());
         PSK_HIP(ctx, hipGetLastError());
@@ -1084,8 +1099,8 @@ int build_presence_merge_wide(psk_ctx *ctx, uint64_t total_pairs, uint64_t *n_km
         mark("memset + replay");
     }
     if (trace)
-        fprintf(stderr, "[psk] wide merge build: %u tiles, %llu ranges x %d groups of %d threads, %u records for %llu pairs, %llu rows\n", n_tiles,
-                (unsigned long long)n_ranges, n_groups, threads, n_rec, (unsigned long long)total_pairs, (unsigned long long)M);
+        fprintf(stderr, "[psk] wide merge build: %u tiles, %llu ranges x %d groups of %d threads (%d-bit cursors), %u records for %llu pairs, %llu rows\n", n_tiles,
+                (unsigned long long)n_ranges, n_groups, threads, narrow ? 32 : 64, n_rec, (unsigned long long)total_pairs, (unsigned long long)M);
     *n_kmers = M;
     *done = 1;
     return PSK_OK;
