@@ -1001,7 +1001,10 @@ int build_presence_merge_wide(psk_ctx *ctx, uint64_t total_pairs, uint64_t *n_km
     }
     if (div == 0) return PSK_OK;   // no records, no wide merge: the sort route
     uint64_t chunks = total_pairs / div / 64 + 3 * PM_REC_BLOCK * (uint64_t)n_ranges * n_groups * (threads / 64);
-    uint64_t region_chunks = ((chunks + chunks / 2) / PM_REC_REGIONS + PM_REC_BLOCK) & ~(uint64_t)(PM_REC_BLOCK - 1);
+    // a workgroup's records all go to ONE region ((range + group) mod 16): with fewer workgroups than regions only that many
+    // regions are ever used, and here -- unlike in the bitmap build, whose pass 2 can merge again -- an overflow costs the route
+    const uint64_t regions_used = std::min<uint64_t>(PM_REC_REGIONS, n_ranges * (uint64_t)n_groups);
+    uint64_t region_chunks = ((chunks + chunks / 2) / regions_used + PM_REC_BLOCK) & ~(uint64_t)(PM_REC_BLOCK - 1);
     if (const char *e = getenv("PSK_MERGE_REC_REGION")) {
         const uint64_t v = strtoull(e, nullptr, 10);
         if (v >= 1 && v < (1ull << 26)) region_chunks = (v + PM_REC_BLOCK - 1) & ~(uint64_t)(PM_REC_BLOCK - 1);
