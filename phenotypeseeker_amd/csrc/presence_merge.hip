@@ -993,7 +993,8 @@ int build_presence_merge_wide(psk_ctx *ctx, uint64_t total_pairs, uint64_t *n_km
     uint64_t *d_bounds = ctx->flags.as<uint64_t>() + 8;
     PSK_HIP(ctx, hipMemcpyAsync(d_bounds, bounds.data(), (size_t)(n_tiles + 1) * 8, hipMemcpyHostToDevice, ctx->stream));
     // ---- the record pool: pairs / PSK_MERGE_REC_DIV records (default 12) + every wave's claims under way ------------------------
-    uint64_t div = 12;
+    // (a record stands for the samples of one wave that share a word: a few dozen samples cannot share twelve-fold)
+    uint64_t div = std::min<uint64_t>(12, std::max<uint64_t>(2, (uint64_t)n / 8));
     if (const char *e = getenv("PSK_MERGE_REC_DIV")) {
         char *end = nullptr;
         div = strtoull(e, &end, 10);
