@@ -734,7 +734,10 @@ def test_l1_logreg_gram_global_form_from_1024_samples_on(ctx, monkeypatch, n, p,
     assert np.isfinite(a[0]).all() and a[2].max() < 1000, a[2]
     _l1_stop_rule_holds(X, ypm, fold, fp, ff, a[0], a[1], a[2], range(len(fp)), tol=1e-4)
     rel = _l1_objectives(X, ypm, fold, fp, ff, a[0], a[1]) / _l1_objectives(X, ypm, fold, fp, ff, b[0], b[1]) - 1
-    assert rel.max() < 1e-3 and rel.min() > -5e-2, rel
+    # C = 1000 at tol = 1e-4 is where liblinear's rule stops both forms far from the optimum and from each other: either may be the
+    # lower one by a few per cent, and not the same one every run (r05: +3.4 % once in three runs of the suite, -1.6 % in r04) --
+    # the bound is symmetric there; up to C = 100 the new form ends at most 1e-3 above the old
+    assert rel[:-1].max() < 1e-3 and rel.max() < 5e-2 and rel.min() > -5e-2, rel
 
 
 def test_l1_logreg_gram_global_form_on_the_2048_x_907_grid(ctx, monkeypatch):
