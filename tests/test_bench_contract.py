@@ -97,6 +97,34 @@ def test_bench_two_ranks_run_the_sharded_pipeline():
             assert slowest <= e2e["modeling_wall_s"] + 0.01 and e2e["modeling_wall_s"] - slowest <= 0.05 * e2e["modeling_wall_s"] + 0.15, (slowest, e2e["modeling_wall_s"])
 
 
+def test_bench_eight_ranks_on_one_gpu_exchange_and_filter():
+    """The 8-GPU preflight: `bench.py --gpus 8` exactly as the driver's scaling run will start it -- no outside
+    launcher, eight ranks of launch.py -- with the one GPU of this box shared (--share-gpu: RCCL refuses, all ranks fall back
+    together to the host-file transport and the line says "invalid").  Both ingest modes: the union is the one-rank union, cut
+    into eight balanced slabs, the survivors of all slabs are the one-rank survivors, `ingest.exchange_s` and `rccl_ranks` are
+    in the line; the refusal quotes what RCCL itself said."""
+    env = {k_: v for k_, v in os.environ.items() if k_ not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "PSK_DIST_TRANSPORT", "PSK_RDZV_DIR",
+                                                            "PSK_RDZV_FILE", "PSK_LAUNCH_NONCE")}
+    size = ["--samples", "64", "--length", "200000", "--kmer", "16", "--steps", "3", "--warmup", "1", "--no-e2e", "--no-cpu-baseline"]
+    one = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py")] + size, cwd=ROOT, env=env, timeout=600, capture_output=True, text=True)
+    assert one.returncode == 0, one.stderr[-2000:]
+    d1 = json.loads(one.stdout.strip().splitlines()[-1])
+    for ingest in ("exchange", "filter"):
+        r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "8", "--share-gpu", "--ingest", ingest] + size,
+                           env=dict(env, PSK_LAUNCH_TIMEOUT="600"), cwd=ROOT, timeout=900, capture_output=True, text=True)
+        assert r.returncode == 0, r.stderr[-3000:]
+        d = json.loads([l for l in r.stdout.splitlines() if l.startswith("{")][-1])
+        cfg = d["config"]
+        assert d["n_gpus"] == 8 and d["scaling"].startswith("invalid (") and d["rccl_ranks"] == 0
+        assert cfg["collectives"].startswith("host-files (fallback: ") and "RCCL communicator not formed" in r.stderr
+        assert len(cfg["rows_per_rank"]) == 8 and sum(cfg["rows_per_rank"]) == cfg["rows_global"] == d1["config"]["rows_per_gpu"]
+        assert cfg["balance_max_over_mean"] <= 1.15
+        assert cfg["survivors_all_slabs"] == d1["config"]["survivors"]
+        assert cfg["ingest"]["mode"] == ingest and "exchange_s" in cfg["ingest"] and "range-sharded over 8 GPUs" in cfg["workload"]
+        if ingest == "exchange":
+            print("eight ranks, one GPU:", cfg["collectives"][:300])
+
+
 def test_bench_without_rccl_and_without_the_opt_in_fails():
     """Un-fakeable N > 1 (VERDICT r02 / ADVICE r02): two ranks that CLAIM a GPU each (no --share-gpu) on a one-GPU box --
     rank 1's device does not exist, RCCL cannot form the communicator -- must not fall back to host files: rc != 0 and
