@@ -289,15 +289,17 @@ class RcclTransport:
         self._rdzv = None
         try:
             from . import watchdog
-            with watchdog.blocking("waiting for rank 0's RCCL unique id (rendezvous directory)"):
-                uid, self._rdzv = exchange_unique_id(rank, world, self.ctx.comm_unique_id, rdzv=rdzv, seq=seq)
-            # RCCL's own account of a refused bring-up is on its debug channel: unless the caller has set that channel up,
-            # warnings go to a file of this rank in the rendezvous directory, and a failure quotes its last lines
+            # RCCL's own account of a refused bring-up is on its debug channel, which it reads ONCE, at its first call in the
+            # process (rank 0: ncclGetUniqueId): unless the caller has set that channel up, warnings go to a file of this rank in
+            # the rendezvous directory from before that call on, and a failure quotes its last lines
             dbg = None
-            if "NCCL_DEBUG" not in os.environ and "NCCL_DEBUG_FILE" not in os.environ and self._rdzv:
-                dbg = os.path.join(os.path.dirname(self._rdzv), "nccl_warn.%d.%d.log" % (seq, rank))
+            if "NCCL_DEBUG" not in os.environ and "NCCL_DEBUG_FILE" not in os.environ:
+                where = (rdzv or _rendezvous())[0]
+                dbg = os.path.join(where, "nccl_warn.%d.%d.log" % (seq, rank))
                 os.environ["NCCL_DEBUG"], os.environ["NCCL_DEBUG_FILE"] = "WARN", dbg
             try:
+                with watchdog.blocking("waiting for rank 0's RCCL unique id (rendezvous directory)"):
+                    uid, self._rdzv = exchange_unique_id(rank, world, self.ctx.comm_unique_id, rdzv=rdzv, seq=seq)
                 with _stdout_to_stderr(), watchdog.blocking("ncclCommInitRank (%d ranks)" % world):
                     # (RCCL prints a version banner on stdout; a caller's stdout may be a protocol)
                     self.ctx.comm_init(uid, rank, world)

@@ -53,10 +53,11 @@ if what == "cfg3slab":
                         "scan_ms": ms, "matrix_GB": m * 256 / 1e9}
         alg["chi2_scan_kernel"] = m * 256
         kept = pairs // n                       # words of a sample inside the slab (its unique words: a genome has few repeats)
+        wb = 4 if k <= 16 else 8                # bytes of a partitioned word (bucket_count.hip: 32-bit words up to k = 16)
         alg["bs_hist_kernel"] = L
-        alg["bs_partition_kernel"] = L + 4 * kept
-        alg["bs_sort_kernel"] = 4 * kept + 8 * kept
-        alg["bs_compact_kernel"] = 8 * kept + 12 * kept
+        alg["bs_partition_kernel"] = L + wb * kept
+        alg["bs_sort_kernel"] = wb * kept + (wb + 4) * kept
+        alg["bs_compact_kernel"] = (wb + 4) * kept + 12 * kept
         for name in ("bs_hist", "bs_partition", "bs_sort", "bs_compact"):   # a launch of the grouped chain covers eight genomes
             alg[name + "_batch_kernel"] = 8 * alg[name + "_kernel"]
         # presence build, streaming merge (12 B x pairs read + the matrix written; the merge reads the 8-byte

@@ -226,11 +226,11 @@ for wl in sorted(os.listdir(src)):
                     k, us.get(k, 0.0), c.get("SQ_INSTS_LDS", 0), c.get("SQ_LDS_IDX_ACTIVE", 0) / wc,
                     c.get("SQ_LDS_BANK_CONFLICT", 0) / max(c.get("SQ_LDS_IDX_ACTIVE", 1), 1), c.get("SQ_WAIT_INST_LDS", 0) / wc,
                     c.get("SQ_WAIT_ANY", 0) / wc, c.get("SQ_WAIT_INST_ANY", 0) / wc, c.get("SQ_ACTIVE_INST_ANY", 0) / wc))
-            f.write("\nReading: the LDS is busy 6-14 %% of the wave cycles and holds up issue for 0.5-2 %% of them; the waves of every scan -- "
-                    "plain or with moments -- are parked on memory for 52-57 %%.  The moment scans are NOT LDS-bound (DESIGN.md said so until "
-                    "r04 without a counter): they are the plain scan of this shape (0.66-0.68 of the HBM peak at 1 %% surviving rows) plus "
-                    "10-15 %% more issue slots for the f64 moment work, under the same memory-latency bound.  The weighted forms do conflict in "
-                    "the LDS (17-31 %% of its busy cycles: the per-wave row queue), which is 2-4 %% of their wave cycles.\n")
+            f.write("\nReading: the LDS is busy 6-14 % of the wave cycles and holds up issue for 0.5-2 % of them; the waves of every scan -- "
+                    "plain or with moments -- are parked on memory for 52-57 %.  The moment scans are NOT LDS-bound (DESIGN.md said so until "
+                    "r04 without a counter): they are the plain scan of this shape (0.66-0.68 of the HBM peak at 1 % surviving rows) plus "
+                    "10-15 % more issue slots for the f64 moment work, under the same memory-latency bound.  The weighted forms do conflict in "
+                    "the LDS (17-31 % of its busy cycles: the per-wave row queue), which is 2-4 % of their wave cycles.\n")
 
 with open(os.path.join(dst, tag + "_rooflines.json"), "w") as f:
     json.dump(table, f, indent=1)
