@@ -484,7 +484,7 @@ def main():
                    "rows_global": int(M_global), "rows_per_rank": rows_per_rank,
                    "balance_max_over_mean": round(max(rows_per_rank) / (sum(rows_per_rank) / len(rows_per_rank)), 4),
                    "collectives": (grp.backend or "none") +
-                   (" (fallback: %s)" % grp.t.fallback_reason[:200] if getattr(grp.t, "fallback_reason", None) else "")},
+                   (" (fallback: %s)" % grp.t.fallback_reason[:700] if getattr(grp.t, "fallback_reason", None) else "")},
         "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                      "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "kernel": "chi2_scan_kernel",
                      "kernel_ms": mean_ms, "algorithmic_bytes_per_launch": alg_bytes,

@@ -257,7 +257,13 @@ def _tail_of(path, n_lines=6, max_chars=1500):
             text = f.read()[-8192:].decode(errors="replace")
     except OSError:
         return ""
-    lines = [ln.strip() for ln in text.splitlines() if ln.strip()]
+    lines = []
+    for ln in text.splitlines():
+        ln = ln.strip()
+        if "NCCL WARN" in ln:       # (RCCL prefixes a time stamp, host:pid:tid and its source path: the message is what follows)
+            ln = ln[ln.index("NCCL WARN"):]
+        if ln and (not lines or lines[-1] != ln):
+            lines.append(ln)
     return " | ".join(lines[-n_lines:])[-max_chars:]
 
 

@@ -122,7 +122,8 @@ def test_bench_eight_ranks_on_one_gpu_exchange_and_filter():
         assert cfg["survivors_all_slabs"] == d1["config"]["survivors"]
         assert cfg["ingest"]["mode"] == ingest and "exchange_s" in cfg["ingest"] and "range-sharded over 8 GPUs" in cfg["workload"]
         if ingest == "exchange":
-            print("eight ranks, one GPU:", cfg["collectives"][:300])
+            print("eight ranks, one GPU:", cfg["collectives"])
+            assert "RCCL said: " in cfg["collectives"] and "NCCL WARN" in cfg["collectives"]    # the refusal in RCCL's own words
 
 
 def test_bench_without_rccl_and_without_the_opt_in_fails():
