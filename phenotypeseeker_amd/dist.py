@@ -298,8 +298,9 @@ class RcclTransport:
             # RCCL's own account of a refused bring-up is on its debug channel, which it reads ONCE, at its first call in the
             # process (rank 0: ncclGetUniqueId): unless the caller has set that channel up, warnings go to a file of this rank in
             # the rendezvous directory from before that call on, and a failure quotes its last lines
-            dbg = None
-            if "NCCL_DEBUG" not in os.environ and "NCCL_DEBUG_FILE" not in os.environ:
+            dbg, dbg_was = None, os.environ.get("NCCL_DEBUG")
+            # ("VERSION" -- the banner only, what this pool's boxes export -- counts as not set up: WARN prints the banner too)
+            if (dbg_was is None or dbg_was.upper() == "VERSION") and "NCCL_DEBUG_FILE" not in os.environ:
                 where = (rdzv or _rendezvous())[0]
                 dbg = os.path.join(where, "nccl_warn.%d.%d.log" % (seq, rank))
                 os.environ["NCCL_DEBUG"], os.environ["NCCL_DEBUG_FILE"] = "WARN", dbg
@@ -316,8 +317,11 @@ class RcclTransport:
                 raise
             finally:
                 if dbg:
-                    for var in ("NCCL_DEBUG", "NCCL_DEBUG_FILE"):
-                        os.environ.pop(var, None)
+                    os.environ.pop("NCCL_DEBUG_FILE", None)
+                    if dbg_was is None:
+                        os.environ.pop("NCCL_DEBUG", None)
+                    else:
+                        os.environ["NCCL_DEBUG"] = dbg_was
                     try:
                         os.unlink(dbg)
                     except OSError:
