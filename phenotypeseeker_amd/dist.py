@@ -262,6 +262,8 @@ def _tail_of(path, n_lines=6, max_chars=1500):
         ln = ln.strip()
         if "NCCL WARN" in ln:       # (RCCL prefixes a time stamp, host:pid:tid and its source path: the message is what follows)
             ln = ln[ln.index("NCCL WARN"):]
+        if "Could not read node #" in ln:      # (rocm-smi's topology files of GPUs the container does not see: a dozen per call)
+            continue
         if ln and (not lines or lines[-1] != ln):
             lines.append(ln)
     return " | ".join(lines[-n_lines:])[-max_chars:]
