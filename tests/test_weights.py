@@ -417,3 +417,31 @@ def test_form_knobs_of_neighbour_joining_and_of_the_merge_build_are_validated(mo
                 ctx.build_presence()
         monkeypatch.setenv("PSK_MERGE_REC_DIV", "7")
         assert ctx.build_presence() > 0
+
+
+def test_oracle_neighbour_joining_on_the_textbook_example():
+    """orc_nj (the checker of the GPU neighbour joining) on the five-taxon example of the neighbour-joining literature
+    (Saitou & Nei's method as tabulated in the Wikipedia article: a, b joined first with branches 2 and 3 -- although (d, e) ties
+    with them in Q --, then c at 4 from the new node, the inner branches 3 and 2, d and e at 2 and 1): the joins, the branch
+    lengths, and every leaf-to-leaf path of the written tree equal to the input distances (the matrix is additive)."""
+    from oracle import oracle_weights as OW
+    D = np.array([[0, 5, 9, 9, 8], [5, 0, 10, 10, 9], [9, 10, 0, 8, 7], [9, 10, 8, 0, 3], [8, 9, 7, 3, 0]], dtype=np.float64)
+    mi, mj, d1, d2, last = OW.nj_merges(D)
+    assert (int(mi[0]), int(mj[0])) == (0, 1) and (d1[0], d2[0]) == (2.0, 3.0)          # a, b first: the tie with (d, e) goes to the earlier pair
+    names = list("abcde")
+    t = OW.Tree(OW.nj_newick(names, D))
+    leaves = {n.name: n for n in t.iter_leaves()}
+
+    def up(n):
+        out = []
+        while n is not None:
+            out.append(n)
+            n = n.up
+        return out
+    for i, a in enumerate(names):
+        for j, b in enumerate(names):
+            if i < j:
+                pa, pb = up(leaves[a]), up(leaves[b])
+                common = next(x for x in pa if x in pb)
+                assert sum(x.dist for x in pa[:pa.index(common)]) + sum(x.dist for x in pb[:pb.index(common)]) == D[i, j], (a, b)
+    assert sorted(round(l.dist, 5) for l in leaves.values()) == [1.0, 2.0, 2.0, 3.0, 4.0]
