@@ -25,9 +25,9 @@ rounds = 0
 with PskContext(0) as ctx:
     while time.time() < t_end:
         rounds += 1
-        n = int(rng.integers(1, 70))
+        n = int(rng.integers(1, 70)) if rng.random() < 0.8 else int(rng.integers(70, 200))     # (beyond 64 / 128: several waves per merge range)
         length = int(rng.choice([300, 3000, 40_000, 150_000]))
-        k = int(rng.choice([1, 2, 5, 9, 11, 13, 13, 13, 14, 16, 21, 31, 32]))
+        k = int(rng.choice([1, 2, 5, 9, 11, 13, 13, 13, 14, 16, 17, 18, 21, 24, 27, 31, 32]))
         gs = GenomeSet(n, length, seed=int(rng.integers(1, 1 << 30)), gene_len=min(200, length // 3))
         datas = []
         for i in range(n):
