@@ -292,6 +292,11 @@ def main():
         _last[0], _last[1] = name, time.time()
         watchdog.enter(name)
     watchdog.install(grp.rank, grp.world, lambda: {"total_s": round(time.time() - t_proc, 4), "phases_s": dict(done_phases)})
+    if grp.world > 1 and os.environ.get("PSK_LAUNCHER") != "psk":
+        # ranks of somebody else's launcher (the driver's torch.distributed.run): nobody above them keeps the deadline, so
+        # every rank keeps it itself -- table, then exit 124
+        from phenotypeseeker_amd import launch as _launch
+        watchdog.self_deadline(_launch.launch_timeout())
     phase("rendezvous, communicator (ncclCommInitRank)")
     if args.share_gpu:
         os.environ["PSK_SHARE_GPU"] = "1"     # ranks modulo the visible GPUs; opts into the host-file transport (tests)

@@ -133,7 +133,8 @@ def main(argv=None):
         root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
         env = {"PYTHONPATH": root + os.pathsep + os.environ.get("PYTHONPATH", "")}
         sys.exit(launch.spawn_ranks(["-m", "phenotypeseeker_amd.cli"] + rest, n_gpus,
-                                    share_gpu=os.environ.get("PSK_SHARE_GPU") == "1", env_extra=env))
+                                    share_gpu=os.environ.get("PSK_SHARE_GPU") == "1", env_extra=env,
+                                    deadline_s=launch.launch_timeout(default=0)))    # (a modeling run has no deadline unless the user sets one)
     if n_gpus > 1 and "WORLD_SIZE" not in os.environ and sub == "prediction" and not wants_help:
         sys.stderr.write("PSK_GPUS=%d: `prediction` is not sharded, it runs on one GPU\n" % n_gpus)
     parser = build_parser()

@@ -9,7 +9,7 @@ nobody can predict or pre-create) plus a nonce the rendezvous blob must carry, r
 exits with the worst child's exit code.  Rank 0's stdout is the parent's stdout (its last line is the program's
 result line); the other ranks' stdout goes to stderr.  When one rank fails the others get a grace period and are
 then terminated -- by their exact pids, never by pattern.  The launch as a whole has a deadline (PSK_LAUNCH_TIMEOUT seconds,
-default 900: well under the 1,800 s after which a driver kills the job without a trace): when it passes, every rank still
+default 900 for bench.py -- well under the 1,800 s after which a driver kills the job without a trace --, none for the CLI): when it passes, every rank still
 running is sent SIGUSR1 -- a rank answers by writing phases_rank<r>.json with the phase and the call it is stuck in
 (watchdog.py) --, then terminated by pid, and the launcher leaves with 124 (what `timeout` returns).  A launcher that already exported WORLD_SIZE
 (`torchrun`-style, srun, mpirun) is honoured instead: the programs only read RANK / LOCAL_RANK / WORLD_SIZE.
@@ -28,9 +28,11 @@ def launched_by_outside_launcher():
     return "WORLD_SIZE" in os.environ and "RANK" in os.environ
 
 
-def launch_timeout():
-    """PSK_LAUNCH_TIMEOUT in seconds (0 or negative: no deadline)."""
-    raw = os.environ.get("PSK_LAUNCH_TIMEOUT", "900")
+def launch_timeout(default=900.0):
+    """PSK_LAUNCH_TIMEOUT in seconds (0 or negative: no deadline).  default: what holds without the variable -- 900 for the
+    benchmark (a bounded job under a driver that kills at 1,800), none for `phenotypeseeker modeling` (a run over thousands of
+    read sets may rightly take hours: there the deadline is the user's to set)."""
+    raw = os.environ.get("PSK_LAUNCH_TIMEOUT", str(default))
     try:
         return float(raw)
     except ValueError:

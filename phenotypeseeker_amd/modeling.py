@@ -913,10 +913,16 @@ def modeling(args):
     """The main function of `phenotypeseeker modeling` (:1624-1709)."""
     ph_t = Phases.current = Phases(getattr(args, "_t0", None))
     ph_t.mark("process start, interpreter, imports")
-    if threading.current_thread() is threading.main_thread():
-        # a launch that runs into its deadline (launch.spawn_ranks: PSK_LAUNCH_TIMEOUT) asks every rank where it is
+    ours = os.environ.get("PSK_LAUNCHER") == "psk"
+    if (ours or getattr(args, "_t0", None) is not None) and threading.current_thread() is threading.main_thread():
+        # a rank of this package's own launcher, or the CLI as a process of its own: a launch that runs into its deadline
+        # (launch.spawn_ranks: PSK_LAUNCH_TIMEOUT) asks every rank where it is.  (Only there: the answer takes over SIGUSR1 and
+        # the interpreter's wake-up descriptor, which a host application that merely calls modeling() may be using itself.)
         from . import watchdog
         watchdog.install(os.environ.get("RANK", "0"), os.environ.get("WORLD_SIZE", "1"), ph_t.snapshot)
+        if not ours and int(os.environ.get("WORLD_SIZE", "1")) > 1:    # somebody else's launcher: every rank keeps the deadline itself
+            from . import launch as _launch
+            watchdog.self_deadline(_launch.launch_timeout(default=0))     # (only when PSK_LAUNCH_TIMEOUT is set)
     ph_t.enter("arguments, data.pheno")
     _err(RED_BANNER % "######                   PhenotypeSeeker                   ######")
     _err(RED_BANNER % "######                      modeling                       ######" + "\n")

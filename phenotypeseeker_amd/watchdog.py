@@ -109,3 +109,21 @@ def install(rank, world, snapshot=None, directory=None):
                     sys.stderr.write("psk rank %d: could not write the stuck-phase table: %s\n" % (_state["rank"], e))
     threading.Thread(target=listen, name="psk-watchdog", daemon=True).start()
     _state["installed"] = True
+
+
+def self_deadline(seconds, code=124):
+    """For ranks that somebody else's launcher started (torchrun, srun: no launch.spawn_ranks above them to keep the deadline):
+    after `seconds` this rank writes its stuck-phase table itself and leaves with `code` -- the other ranks' timers, set to the
+    same deadline, do the same within the skew of their starts; a launcher that tears the job down on the first exit finds
+    the tables already written.  0 or negative: no deadline."""
+    if not seconds or seconds <= 0:
+        return
+
+    def run():
+        time.sleep(seconds)
+        try:
+            sys.stderr.write("psk rank %d/%d: deadline of %.0f s passed (PSK_LAUNCH_TIMEOUT)\n" % (_state["rank"], _state["world"], seconds))
+            dump()
+        finally:
+            os._exit(code)
+    threading.Thread(target=run, name="psk-deadline", daemon=True).start()

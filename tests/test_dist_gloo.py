@@ -410,3 +410,22 @@ def test_ranks_started_by_different_parents_meet_in_a_supplied_directory(tmp_pat
     assert [p.returncode for p in procs] == [0, 0], outs
     ppids = {o[0].split("ppid=")[1].strip() for o in outs}
     assert len(ppids) == 2 and all("nonce=''" in o[0] for o in outs)
+
+
+def test_a_rank_of_an_outside_launcher_keeps_the_deadline_itself(tmp_path):
+    """Under the driver's `torch.distributed.run` (or srun) no launch.spawn_ranks sits above the ranks: every rank then keeps
+    PSK_LAUNCH_TIMEOUT itself -- its own stuck-phase table, then exit code 124 (watchdog.self_deadline)."""
+    import json
+    import time
+    code = ("import os, sys, time\nsys.path.insert(0, %r)\nfrom phenotypeseeker_amd import watchdog\n"
+            "watchdog.install(os.environ['RANK'], os.environ['WORLD_SIZE'], lambda: {'phases_s': {'ingest': 0.5}})\n"
+            "watchdog.enter('scan')\nwatchdog.self_deadline(1.5)\n"
+            "with watchdog.blocking('all-gather (rccl, 8 ranks)'):\n    r, w = os.pipe(); os.read(r, 1)\n" % ROOT)
+    t0 = time.time()
+    r = subprocess.run([sys.executable, "-c", code], cwd=str(tmp_path), env=dict(os.environ, RANK="3", WORLD_SIZE="8"),
+                       capture_output=True, text=True, timeout=60)
+    assert r.returncode == 124 and time.time() - t0 < 20, (r.returncode, r.stderr[-1000:])
+    with open(os.path.join(tmp_path, "phases_rank3.json")) as f:
+        rec = json.load(f)
+    assert rec["stuck_in"] == "scan" and rec["blocked_in_call"] == "all-gather (rccl, 8 ranks)" and rec["world"] == 8
+    assert rec["phases_s"] == {"ingest": 0.5} and "deadline of 2 s passed" in r.stderr or "deadline of 1 s passed" in r.stderr
