@@ -1,4 +1,5 @@
-"""CPU oracle for the MinHash sketch of the -w path (pure Python; small inputs only).
+"""CPU oracle for the -w path: the MinHash sketch (pure Python; small inputs only) and, r05, neighbour joining + the newick
+text + the Tree class that stands in for ete3 when oracle/gen_golden.py runs the reference's GSC code (second half of the file).
 TEST INFRASTRUCTURE ONLY.  Restates Mash 2.2's sketching (third-party, bundled as bin/mash; source
 not vendored): canonical k-mer = min(k-mer, reverse complement) as strings, MurmurHash3_x64_128
 (seed 42) of the ASCII k-mer, first 8 digest bytes, bottom-s distinct hashes.  Pinned by

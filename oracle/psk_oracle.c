@@ -13,7 +13,9 @@
  * generator: oracle/gen_golden.py.  The weighted Welch test is pinned against
  * scipy.stats.ttest_ind(equal_var=False) at unit weights only (statsmodels, the library the
  * reference calls at modeling.py:734, is not installed here): "parity unpinned" for
- * non-unit weights.
+ * non-unit weights.  Section 7 (r05), the neighbour joining of the -w path, restates Biopython 1.76
+ * (absent here, not vendored): "parity unpinned" as well -- it is the checker the GPU kernels and
+ * the product's host loop are compared with, so that they are not compared with each other.
  *
  * Plain scalar C, one thread.  Each function cites the reference lines it follows.
  */
