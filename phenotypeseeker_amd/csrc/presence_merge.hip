@@ -301,7 +301,7 @@ __global__ __launch_bounds__(PM_GROUP) void pm_mark_kernel(const PmList *__restr
     extern __shared__ __attribute__((aligned(16))) unsigned long long pm_ring_lds[];   // the lanes' windows (32-bit words; 64-bit ones without the bitmap: 128 KB)
     typedef PmCursor<W, PSK_PM_BLOCK, (sizeof(W) == 4 || !BITMAP)> Cur;
     const int lane = threadIdx.x & 63;
-    const int s = blockIdx.y * PM_GROUP + threadIdx.x;
+    const int s = blockIdx.y * (BITMAP ? PM_GROUP : (int)blockDim.x) + threadIdx.x;   // (bitmap-free: the group is the workgroup, 512 lanes with 64-bit cursors)
     const uint32_t t0 = blockIdx.x * tiles_per_range;
     const uint32_t t1 = t0 + tiles_per_range < n_tiles ? t0 + tiles_per_range : n_tiles;
     // bitmap-free pass with 32-bit cursors (r05): the words of THIS range relative to its first bound -- the host takes this
@@ -980,14 +980,34 @@ int build_presence_merge_wide(psk_ctx *ctx, uint64_t total_pairs, uint64_t *n_km
         }
     bounds.push_back(hi);
     const uint32_t n_tiles = (uint32_t)(bounds.size() - 1);
-    const int n_groups = (n + PM_GROUP - 1) / PM_GROUP;
-    const int threads = n >= PM_GROUP ? PM_GROUP : ((n + 63) / 64) * 64;
-    uint64_t n_ranges = ((uint64_t)(ctx->n_cu > 0 ? ctx->n_cu : 256) * 8 * (PM_GROUP / threads)) / n_groups;
-    if (const char *e = getenv("PSK_MERGE_RANGES")) { const uint64_t v = strtoull(e, nullptr, 10); if (v >= 1) n_ranges = v; }
-    if (n_ranges > n_tiles) n_ranges = n_tiles;
-    if (n_ranges < 1) n_ranges = 1;
-    const uint32_t tiles_per_range = (uint32_t)((n_tiles + n_ranges - 1) / n_ranges);
-    n_ranges = (n_tiles + tiles_per_range - 1) / tiles_per_range;
+    // launch shape: groups of `gsz` samples (one workgroup each), ranges of consecutive tiles
+    int n_groups = 0, threads = 0;
+    uint64_t n_ranges = 0;
+    uint32_t tiles_per_range = 0;
+    auto shape = [&](int gsz) {
+        n_groups = (n + gsz - 1) / gsz;
+        threads = n >= gsz ? gsz : ((n + 63) / 64) * 64;
+        n_ranges = ((uint64_t)(ctx->n_cu > 0 ? ctx->n_cu : 256) * 8 * (PM_GROUP / threads)) / n_groups;
+        if (const char *e = getenv("PSK_MERGE_RANGES")) { const uint64_t v = strtoull(e, nullptr, 10); if (v >= 1) n_ranges = v; }
+        if (n_ranges > n_tiles) n_ranges = n_tiles;
+        if (n_ranges < 1) n_ranges = 1;
+        tiles_per_range = (uint32_t)((n_tiles + n_ranges - 1) / n_ranges);
+        n_ranges = (n_tiles + tiles_per_range - 1) / tiles_per_range;
+    };
+    shape(PM_GROUP);
+    // 32-bit cursors (words relative to the range's first bound; the inline-asm DPP minimum, a 64-KB ring) when every range of the
+    // launch spans less than 2^32 - 1 word values; else 64-bit ones, in groups of 512 samples: their ring is 128 bytes per lane, and
+    // 64 KB of it per workgroup leave room for two workgroups on a CU
+    bool narrow = !getenv("PSK_WIDE_MERGE_64");
+    for (uint64_t r0 = 0; r0 < n_tiles && narrow; r0 += tiles_per_range) {
+        const uint64_t r1 = std::min<uint64_t>(r0 + tiles_per_range, n_tiles);
+        if (bounds[r1] - bounds[r0] >= 0xfffffffeull) narrow = false;
+    }
+    if (!narrow) {
+        int gsz = 512;
+        if (const char *e = getenv("PSK_WIDE_GROUP")) { const int v = atoi(e); if (v == 256 || v == 512 || v == 1024) gsz = v; }
+        shape(gsz);
+    }
     PSK_TRY(dev_reserve(ctx, ctx->flags, 64 + (size_t)(n_tiles + 1) * 8 + 64));
     const uint64_t *d_spare = ctx->flags.as<uint64_t>();
     uint64_t *d_bounds = ctx->flags.as<uint64_t>() + 8;
@@ -1027,13 +1047,6 @@ int build_presence_merge_wide(psk_ctx *ctx, uint64_t total_pairs, uint64_t *n_km
     PSK_HIP(ctx, hipMemsetAsync(ctx->valsB.p, 0, ctr_bytes + chunks * 8, ctx->stream));
     mark("bounds + buffers");
     const dim3 grid((unsigned)n_ranges, (unsigned)n_groups);
-    // 32-bit cursors (words relative to the range's first bound; the inline-asm DPP minimum, a 64-KB ring) when every range of the
-    // launch spans less than 2^32 - 1 word values, 64-bit ones (a 128-KB ring) otherwise
-    bool narrow = !getenv("PSK_WIDE_MERGE_64");
-    for (uint64_t r0 = 0; r0 < n_tiles && narrow; r0 += tiles_per_range) {
-        const uint64_t r1 = std::min<uint64_t>(r0 + tiles_per_range, n_tiles);
-        if (bounds[r1] - bounds[r0] >= 0xfffffffeull) narrow = false;
-    }
     const size_t ring_bytes = (size_t)threads * PSK_PM_BLOCK * 2 * (narrow ? 4 : 8);   // the lanes' windows: 64 / 128 KB for 1,024 lanes
     auto mark_k = narrow ? pm_mark_kernel<uint32_t, false> : pm_mark_kernel<uint64_t, false>;
     if (ring_bytes > 48 * 1024)
