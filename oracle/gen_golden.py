@@ -999,6 +999,8 @@ if __name__ == "__main__":
         run_reference_dataset("ds_omitB", GenomeSet(20, 10000, seed=11, gene_len=300), na={3, 14},
                               flags=["--omit_B_correction", "--n_kmers", "100"], fastq_for={5})
         run_reference_dataset("ds_bonf", GenomeSet(44, 6000, seed=23, gene_len=150), na={9}, flags=[])
+    if "k21" in what:      # r05: the 64-bit word routes (k >= 17) against the reference itself, whole pipeline: `-l 21`
+        run_reference_dataset("ds_k21", GenomeSet(44, 6000, seed=23, gene_len=150), na={9}, flags=[], k=21)
     if "atrich" in what:
         run_reference_dataset_regenerated("ds_atrich", dict(n_samples=60, length=1_000_000, seed=29, gene_len=2000, gc=0.29, contigs=6),
                                           na={4}, flag_sets={"bonf": [], "omitB": ["--omit_B_correction"]})

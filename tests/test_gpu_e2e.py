@@ -19,7 +19,7 @@ def _run(tmp, argv):
     args.func(args)
 
 
-@pytest.mark.parametrize("tag,extra", [("ds_omitB", ["--omit_B_correction", "--n_kmers", "100"]), ("ds_bonf", [])])
+@pytest.mark.parametrize("tag,extra", [("ds_omitB", ["--omit_B_correction", "--n_kmers", "100"]), ("ds_bonf", []), ("ds_k21", ["-l", "21"])])
 def test_modeling_and_prediction_end_to_end(tmp_path, tag, extra):
     import joblib
     ds = load_dataset(tag)
@@ -29,7 +29,7 @@ def test_modeling_and_prediction_end_to_end(tmp_path, tag, extra):
     head2, got = read_results_tsv("chi2_results_Pheno.tsv")
     assert head2 == head and sorted(got) == sorted(ref)
     assert [g[2] for g in got] == [r[2] for r in ref]
-    limit = 100 if extra else 1000
+    limit = 100 if "--n_kmers" in extra else 1000
     _, ref_top = read_results_tsv(os.path.join(ds["dir"], "chi2_results_Pheno_top%d.tsv" % limit))
     _, got_top = read_results_tsv("chi2_results_Pheno_top%d.tsv" % limit)
     assert [g[2] for g in got_top] == [r[2] for r in ref_top]
@@ -38,7 +38,7 @@ def test_modeling_and_prediction_end_to_end(tmp_path, tag, extra):
     with open("Pheno_MLdf.csv") as f:
         got_csv = list(csv.reader(f))
     assert [r[0] for r in got_csv] == [r[0] for r in ref_csv] and [r[-2:] for r in got_csv] == [r[-2:] for r in ref_csv]
-    if not extra:
+    if "--n_kmers" not in extra:
         assert sorted(got_csv[0][1:-2]) == sorted(ref_csv[0][1:-2])
     # model artefacts
     pkg = joblib.load("log_reg_model_Pheno.pkl")
@@ -467,7 +467,8 @@ def test_l2_penalty_end_to_end(tmp_path):
         assert "Parameters:\nLogisticRegression(max_iter=1000" in summary and "penalty='l1'" not in summary
 
 
-@pytest.mark.parametrize("ranks,flags,ingest", [(2, [], "exchange"), (2, [], "redundant"), (3, ["-w", "--omit_B_correction", "--n_kmers", "100"], "exchange")])
+@pytest.mark.parametrize("ranks,flags,ingest", [(2, [], "exchange"), (2, [], "redundant"), (3, ["-w", "--omit_B_correction", "--n_kmers", "100"], "exchange"),
+                                                (2, ["-l", "21"], "exchange"), (3, ["-l", "31", "--omit_B_correction"], "redundant")])
 def test_multi_rank_modeling_writes_the_same_files(tmp_path, ranks, flags, ingest):
     """SURVEY.md 8(e) invariant on the real pipeline: `PSK_GPUS=<ranks> phenotypeseeker modeling` -- the CLI starts its
     own ranks (launch.py; no outside launcher) -- with several ranks (all on the one visible GPU, collectives through the gloo transport of tests/: PSK_SHARE_GPU /
@@ -494,7 +495,7 @@ def test_multi_rank_modeling_writes_the_same_files(tmp_path, ranks, flags, inges
     cmd = [sys.executable, os.path.join(ROOT, "scripts", "phenotypeseeker"), "modeling", "data.pheno"] + flags
     r = subprocess.run(cmd, env=env, cwd=str(two), timeout=600, capture_output=True, text=True)
     assert r.returncode == 0, r.stderr[-3000:]
-    top = "chi2_results_Pheno_top%d.tsv" % (100 if flags else 1000)
+    top = "chi2_results_Pheno_top%d.tsv" % (100 if "--n_kmers" in flags else 1000)
     for name in ("chi2_results_Pheno.tsv", top, "Pheno_MLdf.csv", "k-mers_and_coefficients_in_log_reg_model_Pheno.txt"):
         assert (one / name).read_bytes() == (two / name).read_bytes(), name
     a, b = joblib.load(str(one / "log_reg_model_Pheno.pkl")), joblib.load(str(two / "log_reg_model_Pheno.pkl"))

@@ -98,7 +98,7 @@ def test_slab_sharding_concatenates_to_full_list(ctx, oracle):
     assert np.array_equal(np.concatenate(parts_f), of)
 
 
-@pytest.mark.parametrize("tag", ["ds_omitB", "ds_bonf"])
+@pytest.mark.parametrize("tag", ["ds_omitB", "ds_bonf", "ds_k21"])       # (ds_k21, r05: the reference run with `-l 21` -- 64-bit words)
 def test_dataset_union_and_presence(ctx, oracle, tag):
     ds = load_dataset(tag)
     k, names = ds["meta"]["k"], ds["names"]
@@ -125,7 +125,7 @@ def test_dataset_union_and_presence(ctx, oracle, tag):
     assert hashlib.sha256(txt.encode()).hexdigest() == ds["meta"]["mapped_sha256"]
 
 
-@pytest.mark.parametrize("tag,omit_B", [("ds_omitB", True), ("ds_bonf", False)])
+@pytest.mark.parametrize("tag,omit_B", [("ds_omitB", True), ("ds_bonf", False), ("ds_k21", False)])
 def test_chi2_results_match_reference_tsv(ctx, oracle, tag, omit_B):
     ds = load_dataset(tag)
     k, names = ds["meta"]["k"], ds["names"]

@@ -83,14 +83,14 @@ def test_rejects_options_outside_the_hot_path(tmp_path):
     assert M.phenotypes.penalty == "L2" and M.phenotypes.logreg_solver == "lbfgs"
 
 
-@pytest.mark.parametrize("tag,extra", [("ds_omitB", ["--omit_B_correction", "--n_kmers", "100"]), ("ds_bonf", [])])
+@pytest.mark.parametrize("tag,extra", [("ds_omitB", ["--omit_B_correction", "--n_kmers", "100"]), ("ds_bonf", []), ("ds_k21", ["-l", "21"])])
 def test_selection_stage_matches_reference_files(tmp_path, oracle, tag, extra):
     M, ds = _setup(tmp_path, tag, extra)
     k, names, n = ds["meta"]["k"], ds["names"], len(ds["names"])
     wl = [oracle.count_kmers(ds["files"][nm], k)[0] for nm in names]
     uw = oracle.union(wl)
     bits = oracle.presence_bits(wl, uw)
-    res = oracle.chi2_scan(bits, ds["pheno"], np.ones(n), n, 2, n - 2, 0.05, bool(extra), len(uw))
+    res = oracle.chi2_scan(bits, ds["pheno"], np.ones(n), n, 2, n - 2, 0.05, "--omit_B_correction" in extra, len(uw))
     keep = np.nonzero(res["keep"])[0]
     pres = np.array([[(int(bits[r, i >> 6]) >> (i & 63)) & 1 for i in range(n)] for r in keep], dtype=np.uint8)
     ph = M.Input.phenotypes_to_analyse["Pheno"]

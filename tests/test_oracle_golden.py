@@ -21,7 +21,7 @@ def test_tokenizer_cases_byte_identical_to_glistmaker(oracle):
             assert oracle.list_bytes(k, w, f) == ref, (data[:60], k)
 
 
-@pytest.mark.parametrize("tag", ["ds_omitB", "ds_bonf"])
+@pytest.mark.parametrize("tag", ["ds_omitB", "ds_bonf", "ds_k21"])
 def test_dataset_lists_union_mapping(oracle, tag):
     ds = load_dataset(tag)
     k = ds["meta"]["k"]
@@ -66,7 +66,7 @@ def _oracle_rows(oracle, ds, omit_B, pvalue=0.05):
     return rows
 
 
-@pytest.mark.parametrize("tag,omit_B", [("ds_omitB", True), ("ds_bonf", False)])
+@pytest.mark.parametrize("tag,omit_B", [("ds_omitB", True), ("ds_bonf", False), ("ds_k21", False)])
 def test_chi2_results_tsv_matches_reference(oracle, tag, omit_B):
     ds = load_dataset(tag)
     rows = _oracle_rows(oracle, ds, omit_B)
