@@ -110,7 +110,10 @@ class Samples:
         # r02: the old whole-set fallback recounted from sample 0 and held their list memory twice).  The library
         # checks the magic bytes too and answers PSK_EGZIP: a file that changed under the probe still ends up inflated.
         # chunk boundaries ramp up (8, 16, 32, ...): the first read is short, later calls amortise their set-up
-        with ThreadPoolExecutor(max_workers=n_threads) as pool:
+        # the inflating pool may use every thread `-nt` grants (zlib releases the GIL: a compressed read set inflates at ~0.3 GB/s
+        # per thread, twenty times below what the GPU ingests -- r04's cap of 8 was the framing threads', which these are not)
+        inflaters = max(n_threads, min(int(getattr(Input, "num_threads", n_threads) or n_threads), os.cpu_count() or n_threads))
+        with ThreadPoolExecutor(max_workers=inflaters) as pool:
             # (two bytes per file, read here: through the pool the 1,024 futures of a 1,024-genome run cost 45 ms, the reads 10)
             zipped = [s.address.endswith(".gz") or formats.is_gzip(s.address) for s in samples]
             # (plain files never sit in this process's memory -- the library streams them through its pinned ring --, so
