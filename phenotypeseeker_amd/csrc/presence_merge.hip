@@ -407,13 +407,14 @@ __global__ __launch_bounds__(256) void pmw_chunk_counts_kernel(const uint2 *__re
     if (c < n_chunks) cnt[c] = hdr[c].y;
     else if (c == n_chunks) cnt[c] = 0;   // the scan's extra element: off[n_chunks] = records in all
 }
+// (keys relative to the slab's first word: the sort then runs over the bits of the slab's span, not of the whole space)
 __global__ __launch_bounds__(256) void pmw_gather_kernel(const uint2 *__restrict__ hdr, const uint64_t *__restrict__ words, uint64_t n_chunks,
-                                                         const uint32_t *__restrict__ off, uint64_t *__restrict__ keys)
+                                                         const uint32_t *__restrict__ off, uint64_t lo, uint64_t *__restrict__ keys)
 {
     const uint64_t c = (uint64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
     const uint32_t lane = threadIdx.x & 63;
     if (c >= n_chunks) return;
-    if (lane < hdr[c].y) keys[(uint64_t)off[c] + lane] = words[c * 64 + lane];
+    if (lane < hdr[c].y) keys[(uint64_t)off[c] + lane] = words[c * 64 + lane] - lo;
 }
 // heads of the runs of equal keys (the distinct words); then, the heads ranked by a scan, the union
 __global__ __launch_bounds__(256) void pmw_heads_kernel(const uint64_t *__restrict__ keys, uint64_t n, uint32_t *__restrict__ head)
@@ -423,10 +424,10 @@ __global__ __launch_bounds__(256) void pmw_heads_kernel(const uint64_t *__restri
     else if (i == n) head[i] = 0;
 }
 __global__ __launch_bounds__(256) void pmw_union_kernel(const uint64_t *__restrict__ keys, uint64_t n, const uint32_t *__restrict__ rank,
-                                                        uint64_t *__restrict__ union_words)
+                                                        uint64_t lo, uint64_t *__restrict__ union_words)
 {
     const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (i < n && (i == 0 || keys[i - 1] != keys[i])) union_words[rank[i]] = keys[i];
+    if (i < n && (i == 0 || keys[i - 1] != keys[i])) union_words[rank[i]] = keys[i] + lo;
 }
 // cells[c] = first row whose word is >= lo + (c << shift): a record's row is then a search over one cell of the union
 __global__ __launch_bounds__(256) void pmw_cells_kernel(const uint64_t *__restrict__ uw, uint32_t m, uint64_t lo, uint32_t shift, uint32_t n_cells,
@@ -1075,12 +1076,14 @@ int build_presence_merge_wide(psk_ctx *ctx, uint64_t total_pairs, uint64_t *n_km
     PSK_HIP(ctx, hipStreamSynchronize(ctx->stream));
     PSK_TRY(dev_reserve(ctx, ctx->keysA, ((size_t)n_rec + 1) * 8));
     PSK_TRY(dev_reserve(ctx, ctx->keysB, ((size_t)n_rec + 1) * 8));
-    pmw_gather_kernel<<<div_up(chunks, 4), 256, 0, ctx->stream>>>(rec.hdr, reinterpret_cast<const uint64_t *>(rec.words), chunks, d_off,
+    pmw_gather_kernel<<<div_up(chunks, 4), 256, 0, ctx->stream>>>(rec.hdr, reinterpret_cast<const uint64_t *>(rec.words), chunks, d_off, lo,
                                                                ctx->keysA.as<uint64_t>());
     PSK_HIP(ctx, hipGetLastError());
     mark("record words");
     uint64_t *keys = ctx->keysA.as<uint64_t>();
-    if (n_rec) PSK_TRY(dev_radix_sort_u64(ctx, ctx->keysA.as<uint64_t>(), ctx->keysB.as<uint64_t>(), n_rec, 0, 2 * k, &keys));
+    int key_bits = 1;
+    while (key_bits < 64 && ((hi - 1 - lo) >> key_bits) != 0) key_bits++;
+    if (n_rec) PSK_TRY(dev_radix_sort_u64(ctx, ctx->keysA.as<uint64_t>(), ctx->keysB.as<uint64_t>(), n_rec, 0, key_bits, &keys));
     mark("sort of the words");
     // ---- distinct words = the union; their places = the rows ------------------------------------------------------------------
     PSK_TRY(dev_reserve(ctx, ctx->hist, ((size_t)n_rec + 2) * 4));   // (the sort, which uses this buffer, is over)
@@ -1097,7 +1100,7 @@ int build_presence_merge_wide(psk_ctx *ctx, uint64_t total_pairs, uint64_t *n_km
     PSK_TRY(dev_reserve(ctx, ctx->bits, (M ? M : 1) * (uint64_t)wpr * 8));
     mark("alloc matrix");
     if (M) {
-        pmw_union_kernel<<<div_up(n_rec, 256), 256, 0, ctx->stream>>>(keys, n_rec, d_head, ctx->union_words.as<uint64_t>());
+        pmw_union_kernel<<<div_up(n_rec, 256), 256, 0, ctx->stream>>>(keys, n_rec, d_head, lo, ctx->union_words.as<uint64_t>());
         PSK_HIP(ctx, hipGetLastError());
         // cells over [lo, hi): about four rows each, at most 2^22 of them
         uint32_t n_cells = 1024;
