@@ -45,6 +45,17 @@ def test_cfg4_continuous_weighted_cli_run_matches_the_oracle(tmp_path, oracle):
     names = [gs.name(i) for i in range(n)]
     w = np.array([M.Input.samples[nm].weight for nm in names], dtype=np.float64)
     assert w.sum() == pytest.approx(n) and w.max() > 1.02 and w.min() < 0.98 and len(np.unique(np.round(w, 6))) > 50
+    # the weights themselves (they were only ever fed back to the oracle): the run's sketches -> distances
+    # (the formats of distances.mat, byte for byte what the run left behind) -> the ORACLE's neighbour joining and newick text
+    # (orc_nj, nothing of the product in it) -> the GSC recursion that tests/golden/gsc_kat.json pins to the reference
+    from oracle import oracle_weights as OW
+    from phenotypeseeker_amd import weights as W
+    labels, mat = W.distance_matrix(names, {nm: M.Input.samples[nm].sketch for nm in names})
+    assert open("distances.mat").read() == W.distances_mat_text(labels, mat)
+    newick = OW.nj_newick(labels, np.asarray(mat, dtype=np.float64))
+    assert open("tree_newick.txt").read() == newick + "\n"
+    want_w = W.gsc_weights(W.from_newick(newick))
+    assert w.tolist() == [want_w[nm] for nm in names]
     head, got = read_results_tsv("t-test_results_MIC.tsv")
     assert head[:3] == ["k-mer", "t-test", "p-value"] and len(got) > 100
     wl = [oracle.count_kmers(gs.sample(i)[1], k)[0] for i in range(n)]
