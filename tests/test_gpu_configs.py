@@ -125,6 +125,18 @@ def test_cfg4_full_size_cli_run_properties(tmp_path, oracle):
     names = [gs.name(i) for i in range(n)]
     w = np.array([M.Input.samples[nm].weight for nm in names], dtype=np.float64)
     assert w.sum() == pytest.approx(n, rel=1e-9) and w.min() > 0 and len(np.unique(np.round(w, 6))) > 100
+    # the weights themselves: the matrix the run left in distances.mat -> the ORACLE's neighbour joining (orc_nj: 1,024 leaves
+    # in half a second) and newick text -> the GSC recursion pinned to the reference (tests/golden/gsc_kat.json)
+    from oracle import oracle_weights as OW
+    from phenotypeseeker_amd import weights as W
+    dm = [l.split("\t") for l in open("distances.mat").read().split("\n")]
+    assert [r[0] for r in dm] == names and all(len(r) == n + 1 for r in dm)
+    mat = np.array([[float(x) for x in r[1:]] for r in dm])
+    assert np.array_equal(mat, mat.T) and (np.diag(mat) == 0).all()
+    newick = OW.nj_newick(names, mat)
+    assert open("tree_newick.txt").read() == newick + "\n"
+    want_w = W.gsc_weights(W.from_newick(newick))
+    assert w.tolist() == [want_w[nm] for nm in names]
     head, got = read_results_tsv("t-test_results_MIC.tsv")
     assert head[:3] == ["k-mer", "t-test", "p-value"] and len(got) >= 500          # the 2-kbp gene's k-mers at least
     printed = {g[0]: g[1:6] for g in got}
