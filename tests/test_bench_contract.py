@@ -32,7 +32,7 @@ def test_bench_json_contract():
     # in the same run (this test's matrix is a few megabytes: it sits in the caches, so the ceiling may exceed the HBM spec here --
     # but not by the factor of r05's first probe, which lost its loads to the optimiser and claimed 123 TB/s at full size)
     ceil = rf["measured_stream_ceiling"]
-    assert 0 < ceil["GBps"] < 60000 and ceil["bytes_per_launch"] == rf["stored_bytes_per_launch"] and "stream_read_kernel" in ceil["kernel"]
+    assert 0 < ceil["GBps"] < 60000 and 0 <= rf["stored_bytes_per_launch"] - ceil["bytes_per_launch"] < 16 and "stream_read_kernel" in ceil["kernel"]
     assert abs(rf["frac_of_measured_ceiling"] - (rf["stored_bytes_per_launch"] / (rf["kernel_ms"] * 1e-3) / 1e9) / ceil["GBps"]) < 1e-9
     assert 0.05 < rf["frac_of_measured_ceiling"] < 3.0
     cb = d["cpu_baseline"]
