@@ -92,8 +92,9 @@ def test_bench_two_ranks_run_the_sharded_pipeline():
             e2e = d["e2e"]
             assert "error" not in e2e, e2e
             assert e2e["modeling_wall_s"] > 0 and e2e["ranks"] == 2 and "log_reg_model_Pheno.pkl" in e2e["what"]
-            # every rank's phase table, process start to teardown: the slowest rank's total is the leg's wall-clock less
-            # what the interpreter needs to exit (5 % + 0.15 s)
+            # every rank's phase table, process start to teardown: the slowest rank's total is the leg's wall-clock less what
+            # the interpreter and the HIP runtime need to exit -- r05: the CLI no longer leaves through os._exit, so that part
+            # is the honest one now (0.3-0.6 s for two ranks that share a GPU; 15 % + 0.5 s allowed)
             ph = e2e["phases"]
             assert set(ph) == {"rank0", "rank1"} and all(v is not None for v in ph.values()), ph
             for v in ph.values():
@@ -101,7 +102,7 @@ def test_bench_two_ranks_run_the_sharded_pipeline():
                 assert any(k.startswith("process start") for k in v["phases_s"]) and any(k.startswith("rendezvous") for k in v["phases_s"])
                 assert any(k.startswith("ingest: k-mer lists (") for k in v["phases_s"]) and "survivor all-gather" in v["phases_s"]
             slowest = max(v["total_s"] for v in ph.values())
-            assert slowest <= e2e["modeling_wall_s"] + 0.01 and e2e["modeling_wall_s"] - slowest <= 0.05 * e2e["modeling_wall_s"] + 0.15, (slowest, e2e["modeling_wall_s"])
+            assert slowest <= e2e["modeling_wall_s"] + 0.01 and e2e["modeling_wall_s"] - slowest <= 0.15 * e2e["modeling_wall_s"] + 0.5, (slowest, e2e["modeling_wall_s"])
 
 
 def test_bench_eight_ranks_on_one_gpu_exchange_and_filter():
