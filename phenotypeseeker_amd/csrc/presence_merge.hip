@@ -401,20 +401,24 @@ __global__ __launch_bounds__(PM_GROUP) void pm_mark_kernel(const PmList *__restr
 
 // ---- word spaces without a value bitmap (k >= 18): union and rows from the records ------------------------------------------------
 // records of every chunk -> one dense key array (chunk c's records at off[c] ..): a wave per chunk
-__global__ __launch_bounds__(256) void pmw_chunk_counts_kernel(const uint2 *__restrict__ hdr, uint64_t n_chunks, uint32_t *__restrict__ cnt)
+// (only the chunks a region has CLAIMED are looked at -- n_rel of them per region, the most any region claimed: the pool is three
+// times that; dense index d = region * n_rel + rel stands for chunk region * region_chunks + rel)
+__global__ __launch_bounds__(256) void pmw_chunk_counts_kernel(const uint2 *__restrict__ hdr, uint32_t region_chunks, uint32_t n_rel,
+                                                               uint32_t *__restrict__ cnt)
 {
-    const uint64_t c = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (c < n_chunks) cnt[c] = hdr[c].y;
-    else if (c == n_chunks) cnt[c] = 0;   // the scan's extra element: off[n_chunks] = records in all
+    const uint64_t d = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x, n = (uint64_t)n_rel * PM_REC_REGIONS;
+    if (d < n) cnt[d] = hdr[(d / n_rel) * region_chunks + d % n_rel].y;
+    else if (d == n) cnt[d] = 0;   // the scan's extra element: off[n] = records in all
 }
 // (keys relative to the slab's first word: the sort then runs over the bits of the slab's span, not of the whole space)
-__global__ __launch_bounds__(256) void pmw_gather_kernel(const uint2 *__restrict__ hdr, const uint64_t *__restrict__ words, uint64_t n_chunks,
-                                                         const uint32_t *__restrict__ off, uint64_t lo, uint64_t *__restrict__ keys)
+__global__ __launch_bounds__(256) void pmw_gather_kernel(const uint2 *__restrict__ hdr, const uint64_t *__restrict__ words, uint32_t region_chunks,
+                                                         uint32_t n_rel, const uint32_t *__restrict__ off, uint64_t lo, uint64_t *__restrict__ keys)
 {
-    const uint64_t c = (uint64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+    const uint32_t rel = blockIdx.x * 4 + (threadIdx.x >> 6);
     const uint32_t lane = threadIdx.x & 63;
-    if (c >= n_chunks) return;
-    if (lane < hdr[c].y) keys[(uint64_t)off[c] + lane] = words[c * 64 + lane] - lo;
+    if (rel >= n_rel) return;
+    const uint64_t c = (uint64_t)blockIdx.y * region_chunks + rel, d = (uint64_t)blockIdx.y * n_rel + rel;
+    if (lane < hdr[c].y) keys[(uint64_t)off[d] + lane] = words[c * 64 + lane] - lo;
 }
 // heads of the runs of equal keys (the distinct words); then, the heads ranked by a scan, the union
 __global__ __launch_bounds__(256) void pmw_heads_kernel(const uint64_t *__restrict__ keys, uint64_t n, uint32_t *__restrict__ head)
@@ -446,13 +450,14 @@ __global__ __launch_bounds__(256) void pmw_cells_kernel(const uint64_t *__restri
     cells[c] = a;
 }
 // pass 2 from the records (as pm_replay_kernel): the row of a word = its place in the union, found inside its cell
-__global__ __launch_bounds__(256) void pmw_replay_kernel(const PmRec rec, uint64_t n_chunks, const uint64_t *__restrict__ uw,
+__global__ __launch_bounds__(256) void pmw_replay_kernel(const PmRec rec, uint32_t n_rel, const uint64_t *__restrict__ uw,
                                                          const uint32_t *__restrict__ cells, uint64_t lo, uint32_t shift, uint32_t n_cells,
                                                          int wpr, uint64_t *__restrict__ bits)
 {
-    const uint64_t ch = (uint64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+    const uint32_t rel = blockIdx.x * 4 + (threadIdx.x >> 6);
     const int lane = threadIdx.x & 63;
-    if (ch >= n_chunks) return;
+    if (rel >= n_rel) return;
+    const uint64_t ch = (uint64_t)blockIdx.y * rec.region_chunks + rel;
     const uint2 h = rec.hdr[ch];
     if ((uint32_t)lane >= h.y) return;
     const uint64_t m = reinterpret_cast<const uint64_t *>(rec.words)[ch * 64 + lane];
@@ -1065,19 +1070,23 @@ int build_presence_merge_wide(psk_ctx *ctx, uint64_t total_pairs, uint64_t *n_km
     // ---- the record words, dense: chunk counts -> offsets -> keys ------------------------------------------------------------
     PSK_TRY(dev_reserve(ctx, ctx->misc, 64));
     uint32_t *d_tot = ctx->misc.as<uint32_t>() + 2;
-    const size_t cells_at = ((size_t)(chunks + 2) * 4 + 255) & ~(size_t)255;
+    uint32_t n_rel = 0;      // the most chunks a region has claimed
+    for (int r = 0; r < PM_REC_REGIONS; r++) n_rel = std::max(n_rel, std::min(rec_state[r * PM_REC_CTR_STRIDE], rec.region_chunks));
+    const uint64_t n_dense = (uint64_t)n_rel * PM_REC_REGIONS;
+    const size_t cells_at = ((size_t)(n_dense + 2) * 4 + 255) & ~(size_t)255;
     PSK_TRY(dev_reserve(ctx, ctx->raw, cells_at + (((size_t)1 << 22) + 2) * 4));   // chunk offsets | the cell table of the replay
     uint32_t *d_off = ctx->raw.as<uint32_t>();
-    pmw_chunk_counts_kernel<<<div_up(chunks + 1, 256), 256, 0, ctx->stream>>>(rec.hdr, chunks, d_off);
+    pmw_chunk_counts_kernel<<<div_up(n_dense + 1, 256), 256, 0, ctx->stream>>>(rec.hdr, rec.region_chunks, n_rel, d_off);
     PSK_HIP(ctx, hipGetLastError());
-    PSK_TRY(dev_exclusive_scan_u32(ctx, d_off, d_off, chunks + 1, d_tot));
+    PSK_TRY(dev_exclusive_scan_u32(ctx, d_off, d_off, n_dense + 1, d_tot));
     uint32_t n_rec = 0;
     PSK_HIP(ctx, hipMemcpyAsync(&n_rec, d_tot, 4, hipMemcpyDeviceToHost, ctx->stream));
     PSK_HIP(ctx, hipStreamSynchronize(ctx->stream));
     PSK_TRY(dev_reserve(ctx, ctx->keysA, ((size_t)n_rec + 1) * 8));
     PSK_TRY(dev_reserve(ctx, ctx->keysB, ((size_t)n_rec + 1) * 8));
-    pmw_gather_kernel<<<div_up(chunks, 4), 256, 0, ctx->stream>>>(rec.hdr, reinterpret_cast<const uint64_t *>(rec.words), chunks, d_off, lo,
-                                                               ctx->keysA.as<uint64_t>());
+    if (n_rel)
+        pmw_gather_kernel<<<dim3(div_up(n_rel, 4), PM_REC_REGIONS), 256, 0, ctx->stream>>>(rec.hdr, reinterpret_cast<const uint64_t *>(rec.words),
+                                                                                         rec.region_chunks, n_rel, d_off, lo, ctx->keysA.as<uint64_t>());
     PSK_HIP(ctx, hipGetLastError());
     mark("record words");
     uint64_t *keys = ctx->keysA.as<uint64_t>();
@@ -1112,8 +1121,8 @@ int build_presence_merge_wide(psk_ctx *ctx, uint64_t total_pairs, uint64_t *n_km
         PSK_HIP(ctx, hipGetLastError());
         mark("union + cells");
         PSK_HIP(ctx, hipMemsetAsync(ctx->bits.p, 0, M * (uint64_t)wpr * 8, ctx->stream));
-        pmw_replay_kernel<<<div_up(chunks, 4), 256, 0, ctx->stream>>>(rec, chunks, ctx->union_words.as<uint64_t>(), d_cells, lo, shift, n_cells, wpr,
-                                                                   ctx->bits.as<uint64_t>());
+        pmw_replay_kernel<<<dim3(div_up(n_rel, 4), PM_REC_REGIONS), 256, 0, ctx->stream>>>(rec, n_rel, ctx->union_words.as<uint64_t>(), d_cells, lo, shift,
+                                                                                         n_cells, wpr, ctx->bits.as<uint64_t>());
         PSK_HIP(ctx, hipGetLastError());
         PSK_HIP(ctx, hipStreamSynchronize(ctx->stream));
         mark("memset + replay");
