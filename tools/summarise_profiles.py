@@ -239,18 +239,27 @@ with open(os.path.join(dst, tag + "_rooflines.md"), "w") as f:
     f.write("HBM-side traffic per launch from the counters: %s; %s -- calibrated on known byte counts in `%s_pmc_calibration.md`.  "
             "`read req` = TCC_EA0_RDREQ per launch (x 128 B = the read column; 32-byte requests: none in any kernel), `write req (64 B)` = "
             "TCC_EA0_WRREQ and how many of them are full 64-byte requests (the rest are 32-byte sectors of partial stores).\n\n" % (READ_RULE, WRITE_RULE, tag))
-    f.write("| workload | kernel | calls | avg us | algorithmic bytes / launch | achieved GB/s | frac of 8 TB/s | read bytes (2 x FETCH) | write bytes (WRITE_SIZE) | traffic / algorithmic | read req | write req (64 B) |\n")
-    f.write("|---|---|---:|---:|---:|---:|---:|---:|---:|---:|---:|---:|\n")
+    f.write("| workload | kernel | calls | avg us | algorithmic bytes / launch | achieved GB/s | frac of 8 TB/s | read bytes (2 x FETCH) | write bytes (WRITE_SIZE) | traffic / algorithmic | read req | write req (64 B) | correction and why |\n")
+    f.write("|---|---|---:|---:|---:|---:|---:|---:|---:|---:|---:|---:|---|\n")
     for r in table:
         if r["total_ms"] < 0.05 and not r["algorithmic_bytes_per_launch"]:
             continue
         tr, a = r["hbm_traffic_bytes_per_launch"], r["algorithmic_bytes_per_launch"]
-        f.write("| %s | `%s` | %d | %.2f | %s | %s | %s | %s | %s | %s | %s | %s |\n" % (
+        why = "-"
+        if r["read_bytes_per_launch"] is not None:
+            why = "reads x 2: 128-B line requests tallied at 64 B (every access shape, calibration rows 1-9)"
+            if "WRREQ" in r and r["WRREQ"] > 0:
+                full = r.get("WRREQ_64B", 0) / r["WRREQ"]
+                why += "; writes x 1: %.0f %% of the write requests are full 64-B ones" % (100 * full) if full >= 0.9 else \
+                       "; writes as counted, but %.0f %% of the requests are 32-B sectors of partial stores (x 4 for 8-byte stores, calibration row 14)" % (100 * (1 - full))
+            elif r["write_bytes_per_launch"]:
+                why += "; writes x 1 (request sizes not collected for this workload)"
+        f.write("| %s | `%s` | %d | %.2f | %s | %s | %s | %s | %s | %s | %s | %s | %s |\n" % (
             r["workload"], r["kernel"], r["calls"], r["avg_us"], "%d" % a if a else "-",
             "%.0f" % r["achieved_GBps"] if r["achieved_GBps"] else "-", "%.3f" % r["frac_of_8TBps"] if r["frac_of_8TBps"] else "-",
             "%d" % r["read_bytes_per_launch"] if r["read_bytes_per_launch"] is not None else "-",
             "%d" % r["write_bytes_per_launch"] if r["write_bytes_per_launch"] is not None else "-",
             "%.2f" % (tr / a) if tr and a else "-",
             "%.4g" % r["RDREQ"] if "RDREQ" in r else "-",
-            "%.4g (%.4g)" % (r["WRREQ"], r.get("WRREQ_64B", 0)) if "WRREQ" in r else "-"))
+            "%.4g (%.4g)" % (r["WRREQ"], r.get("WRREQ_64B", 0)) if "WRREQ" in r else "-", why))
 print(open(os.path.join(dst, tag + "_rooflines.md")).read())
