@@ -468,7 +468,8 @@ def test_l2_penalty_end_to_end(tmp_path):
 
 
 @pytest.mark.parametrize("ranks,flags,ingest", [(2, [], "exchange"), (2, [], "redundant"), (3, ["-w", "--omit_B_correction", "--n_kmers", "100"], "exchange"),
-                                                (2, ["-l", "21"], "exchange"), (3, ["-l", "31", "--omit_B_correction"], "redundant")])
+                                                (2, ["-l", "21"], "exchange"), (3, ["-l", "31", "--omit_B_correction"], "redundant"),
+                                                (4, [], "redundant"), (8, [], "exchange")])      # (byte-identical for G in {1, 2, 4, 8})
 def test_multi_rank_modeling_writes_the_same_files(tmp_path, ranks, flags, ingest):
     """SURVEY.md 8(e) invariant on the real pipeline: `PSK_GPUS=<ranks> phenotypeseeker modeling` -- the CLI starts its
     own ranks (launch.py; no outside launcher) -- with several ranks (all on the one visible GPU, collectives through the gloo transport of tests/: PSK_SHARE_GPU /
