@@ -98,7 +98,7 @@ def main():
     out_path = sys.argv[1]
     grp = dist.Group().init()       # PSK_DIST_TRANSPORT names the gloo transport of tests/
     assert grp.backend == "gloo"
-    ds = load_dataset("ds_omitB")
+    ds = load_dataset(os.environ.get("PSK_TEST_DATASET", "ds_omitB"))
     k = ds["meta"]["k"]
     pairs, bounds = check_list_exchange(grp, ds)
     lo, hi = bounds[grp.rank], bounds[grp.rank + 1]

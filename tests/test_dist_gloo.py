@@ -202,11 +202,13 @@ def test_pack_merge_round_trip():
     assert np.array_equal(bits, np.concatenate([p[1] for p in parts]))
 
 
-def test_two_rank_gloo_run_equals_single_rank(tmp_path, oracle):
+@pytest.mark.parametrize("tag,port", [("ds_omitB", "29617"), ("ds_k21", "29627")])      # (ds_k21: 64-bit words, slab bounds beyond 2^32)
+def test_two_rank_gloo_run_equals_single_rank(tmp_path, oracle, tag, port):
     out = os.path.join(tmp_path, "merged.npz")
     env = dict(os.environ, MASTER_ADDR="127.0.0.1", OMP_NUM_THREADS="1", PSK_DIST_TRANSPORT="_gloo_transport:GlooTransport",
                PYTHONPATH=os.path.join(ROOT, "tests") + os.pathsep + os.environ.get("PYTHONPATH", ""))
-    env["MASTER_PORT"] = "29617"
+    env["MASTER_PORT"] = port
+    env["PSK_TEST_DATASET"] = tag
     for var in ("WORLD_SIZE", "RANK", "LOCAL_RANK"):
         env.pop(var, None)
     # the package's own launcher (launch.spawn_ranks): no outside launcher anywhere in the tests
@@ -218,7 +220,7 @@ def test_two_rank_gloo_run_equals_single_rank(tmp_path, oracle):
     assert int(z["world"]) == 2 and float(z["tmax"]) == 2.0
     shares = z["shares"].astype(float)
     assert shares.max() / shares.mean() <= 1.10, shares      # quantile cuts: the two slabs hold the same share of the rows
-    ds = load_dataset("ds_omitB")
+    ds = load_dataset(tag)
     k, names, n = ds["meta"]["k"], ds["names"], len(ds["names"])
     wl = [oracle.count_kmers(ds["files"][nm], k)[0] for nm in names]
     uw = oracle.union(wl)
