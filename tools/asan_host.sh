@@ -15,13 +15,14 @@ gcc -O1 -g -fPIC -Wall -std=c11 -ffp-contract=off -fsanitize=address,undefined -
 cp oracle/libpsk_oracle.so "$OUT/oracle_orig.so"
 trap 'cp "$OUT/oracle_orig.so" "$ROOT/oracle/libpsk_oracle.so"' EXIT
 cp "$OUT/libpsk_oracle.so" oracle/libpsk_oracle.so
-ASAN_OPTIONS=detect_leaks=0 LD_PRELOAD=$GCC_ASAN python -m pytest tests/test_oracle_golden.py tests/test_host_modeling.py -x -q
+ASAN_OPTIONS=detect_leaks=0 LD_PRELOAD=$GCC_ASAN python -m pytest tests/test_oracle_golden.py tests/test_host_modeling.py tests/test_weights.py -x -q -m "not gpu"
 cp "$OUT/oracle_orig.so" oracle/libpsk_oracle.so
 
-SRCS="api scan radix_sort kmer_count presence assoc_scan solver solver_l2 minhash nj presence_tiled"
+SRCS=$(sed -n 's/^SRCS := //p' phenotypeseeker_amd/csrc/Makefile | sed 's/\.hip//g')      # every translation unit of the library
 for f in $SRCS; do
     /opt/rocm/bin/hipcc -O1 -g -std=c++17 -fPIC --offload-arch=gfx950 -ffp-contract=off -Xarch_host -fsanitize=address \
         -c phenotypeseeker_amd/csrc/$f.hip -o "$OUT/$f.o" &
+    while [ "$(jobs -r | wc -l)" -ge 8 ]; do sleep 0.5; done      # (eight compilers at a time: the build box has eight cores)
 done
 wait
 OBJS=""
