@@ -1423,6 +1423,7 @@ def test_merge_presence_build_equals_the_oracle_and_the_sort_route(ctx, oracle, 
     (21, 70, 20_000, {"PSK_MERGE_TILE_PAIRS": "64"}),                        # two waves, thousands of tiny tiles
     (27, 130, 9_000, {"PSK_MERGE_TILE_PAIRS": "500"}),                       # padded column
     (31, 1100, 3_000, {"PSK_MERGE_TILE_PAIRS": "3000"}),                     # two sample groups: two record streams per range
+    (18, 1100, 3_000, {"PSK_MERGE_TILE_PAIRS": "3000"}),                     # ... with 32-bit cursors (ranges of 2^26 word values)
     (32, 1100, 2_000, {"PSK_MERGE_REC_DIV": "1"}),                           # the whole 64-bit space (a mutation costs 32 k-mers: the samples share too little for the default pool)
     (18, 300, 6_000, {"PSK_WIDE_MERGE_64": "1"}),                            # 64-bit cursors where the 32-bit ones would do (the first case)
     (19, 24, 50_000, {"PSK_MERGE_RANGES": "1", "PSK_MERGE_REC_DIV": "2"}),   # one range, one wave: every distinct word is a record
