@@ -1005,10 +1005,13 @@ int build_presence_merge_wide(psk_ctx *ctx, uint64_t total_pairs, uint64_t *n_km
     // launch spans less than 2^32 - 1 word values; else 64-bit ones, in groups of 512 samples: their ring is 128 bytes per lane, and
     // 64 KB of it per workgroup leave room for two workgroups on a CU
     bool narrow = !getenv("PSK_WIDE_MERGE_64");
-    for (uint64_t r0 = 0; r0 < n_tiles && narrow; r0 += tiles_per_range) {
+    uint64_t widest = 0;
+    for (uint64_t r0 = 0; r0 < n_tiles; r0 += tiles_per_range) {
         const uint64_t r1 = std::min<uint64_t>(r0 + tiles_per_range, n_tiles);
-        if (bounds[r1] - bounds[r0] >= 0xfffffffeull) narrow = false;
+        widest = std::max(widest, bounds[r1] - bounds[r0]);
     }
+    if (widest >= 0xfffffffeull) narrow = false;
+    if (trace) fprintf(stderr, "[psk]   wide merge: %u tiles, %u per range, widest range %llu word values\n", n_tiles, tiles_per_range, (unsigned long long)widest);
     if (!narrow) {
         int gsz = 512;
         if (const char *e = getenv("PSK_WIDE_GROUP")) { const int v = atoi(e); if (v == 256 || v == 512 || v == 1024) gsz = v; }
