@@ -985,7 +985,7 @@ int build_presence_merge_wide(psk_ctx *ctx, uint64_t total_pairs, uint64_t *n_km
             if (v > bounds.back() && v < hi) bounds.push_back(v);
         }
     bounds.push_back(hi);
-    const uint32_t n_tiles = (uint32_t)(bounds.size() - 1);
+    uint32_t n_tiles = (uint32_t)(bounds.size() - 1);
     // launch shape: groups of `gsz` samples (one workgroup each), ranges of consecutive tiles
     int n_groups = 0, threads = 0;
     uint64_t n_ranges = 0;
@@ -1003,14 +1003,34 @@ int build_presence_merge_wide(psk_ctx *ctx, uint64_t total_pairs, uint64_t *n_km
     shape(PM_GROUP);
     // 32-bit cursors (words relative to the range's first bound; the inline-asm DPP minimum, a 64-KB ring) when every range of the
     // launch spans less than 2^32 - 1 word values; else 64-bit ones, in groups of 512 samples: their ring is 128 bytes per lane, and
-    // 64 KB of it per workgroup leave room for two workgroups on a CU
+    // 64 KB of it per workgroup leave room for two workgroups on a CU.  Tiles are cut at pair quantiles of a pilot, so a few come out
+    // many times wider than the rest: a tile wider than its share of a range's 2^32 is cut further, by value (a bound may be any
+    // word value) -- unless that would more than double the tiles (a space as sparse as k = 31's: the 64-bit cursors are for it)
     bool narrow = !getenv("PSK_WIDE_MERGE_64");
+    const uint64_t limit = 0xfffffffdull;
     uint64_t widest = 0;
+    for (int round = 0; narrow && round < 4; round++) {
+        const uint64_t cap = limit / tiles_per_range;
+        uint64_t extra = 0;
+        for (uint32_t t = 0; t < n_tiles; t++) extra += (bounds[t + 1] - bounds[t] - 1) / cap;
+        if (extra == 0) break;
+        if (extra > n_tiles) { narrow = false; break; }
+        std::vector<uint64_t> cut;
+        cut.reserve(bounds.size() + extra);
+        for (uint32_t t = 0; t < n_tiles; t++) {
+            const uint64_t a0 = bounds[t], span = bounds[t + 1] - a0, parts = (span - 1) / cap + 1;
+            for (uint64_t q = 0; q < parts; q++) cut.push_back(a0 + (span / parts) * q + std::min<uint64_t>(q, span % parts));
+        }
+        cut.push_back(bounds[n_tiles]);
+        bounds.swap(cut);
+        n_tiles = (uint32_t)(bounds.size() - 1);
+        shape(PM_GROUP);
+    }
     for (uint64_t r0 = 0; r0 < n_tiles; r0 += tiles_per_range) {
         const uint64_t r1 = std::min<uint64_t>(r0 + tiles_per_range, n_tiles);
         widest = std::max(widest, bounds[r1] - bounds[r0]);
     }
-    if (widest >= 0xfffffffeull) narrow = false;
+    if (widest > limit) narrow = false;
     if (trace) fprintf(stderr, "[psk]   wide merge: %u tiles, %u per range, widest range %llu word values\n", n_tiles, tiles_per_range, (unsigned long long)widest);
     if (!narrow) {
         int gsz = 512;
