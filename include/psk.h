@@ -96,11 +96,15 @@ int psk_get_list(psk_ctx *ctx, int sample_idx, uint64_t *words, uint32_t *freqs,
  *   psk_set_lists_device  installs n_lists lists held back to back in DEVICE memory -- count[r] (word, count)
  *                         entries each, ascending, inside this context's slab (checked: PSK_EINVAL otherwise, and
  *                         none of them is kept) -- as the lists of sample_idx[r]; they are copied into the
- *                         context's own storage.  n_total[r] (may be NULL) is what psk_count_kmers would report. */
+ *                         context's own storage.  n_total[r] (may be NULL) is what psk_count_kmers would report.
+ *   psk_release_lists   gives the device memory of this context's lists back (every sample is "not counted"
+ *                       again): the counting context's lists are dead once they are packed, and at N = 2 of
+ *                       config 3 they are 61 GB that the receive buffers need */
 int psk_lists_split(psk_ctx *ctx, int first_sample_idx, int n, const uint64_t *bounds, int n_bounds,
                     uint64_t *offsets_out);
 int psk_copy_list_ranges(psk_ctx *ctx, int n_ranges, const int32_t *sample_idx, const uint64_t *start,
                          const uint64_t *count, void *device_words_dst, void *device_freqs_dst);
+int psk_release_lists(psk_ctx *ctx);
 int psk_set_lists_device(psk_ctx *ctx, int n_lists, const int32_t *sample_idx, const uint64_t *count,
                          const uint64_t *n_total, const void *device_words, const void *device_freqs);
 /* Frequencies of `n` given canonical words in sample_idx's list (0 if absent): the

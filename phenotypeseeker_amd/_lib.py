@@ -41,6 +41,7 @@ _SIGNATURES = {
     "psk_write_model_coefficients": (c.c_int, [c.c_void_p, c.c_char_p, c.c_int64, c.c_char_p, c.c_void_p, c.c_void_p, c.c_void_p,
                                                c.c_int64, c.c_char_p, c.c_void_p]),
     "psk_lists_split": (c.c_int, [c.c_void_p, c.c_int, c.c_int, c.c_void_p, c.c_int, c.c_void_p]),
+    "psk_release_lists": (c.c_int, [c.c_void_p]),
     "psk_copy_list_ranges": (c.c_int, [c.c_void_p, c.c_int, c.c_void_p, c.c_void_p, c.c_void_p, c.c_void_p, c.c_void_p]),
     "psk_set_lists_device": (c.c_int, [c.c_void_p, c.c_int, c.c_void_p, c.c_void_p, c.c_void_p, c.c_void_p, c.c_void_p]),
     "psk_build_presence": (c.c_int, [c.c_void_p, _u64p]),

@@ -1455,6 +1455,19 @@ extern "C" int psk_copy_list_ranges(psk_ctx *ctx, int n_ranges, const int32_t *s
     return PSK_OK;
 }
 
+extern "C" int psk_release_lists(psk_ctx *ctx)
+{
+    if (!ctx) return PSK_EINVAL;
+    PSK_HIP(ctx, hipSetDevice(ctx->device));
+    PSK_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    for (hipStream_t st : {ctx->copy_stream, ctx->copy_more[0], ctx->copy_more[1], ctx->copy_more[2], ctx->frame_stream, ctx->sketch_stream})
+        if (st) PSK_HIP(ctx, hipStreamSynchronize(st));
+    reset_lists(ctx, ctx->n_samples);   // every sample is "not counted" again
+    arena_release(ctx);                 // and the chunks go back to the device, not to the next run
+    ctx->have_presence = false;
+    return PSK_OK;
+}
+
 extern "C" int psk_set_lists_device(psk_ctx *ctx, int n_lists, const int32_t *sample_idx, const uint64_t *count,
                                     const uint64_t *n_total, const void *device_words, const void *device_freqs)
 {

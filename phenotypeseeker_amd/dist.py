@@ -822,9 +822,9 @@ class ListExchange:
         self.bounds = list(bounds) if bounds is not None else [slab_bounds(self.k, W, d)[0] for d in range(W)] + [0]
 
     def run(self, cnt_ctx, slab_ctx, n_samples, n_total_own):
-        """cnt_ctx holds the lists of this rank's samples (local index j = j-th sample i with owner_of(i) == rank);
-        slab_ctx has been begun with this rank's slab and n_samples.  Returns the number of (word, sample) pairs
-        installed."""
+        """cnt_ctx holds the lists of this rank's samples (local index j = j-th sample i with owner_of(i) == rank) and
+        does not hold them any more when this returns (PskContext.release_lists); slab_ctx has been begun with this
+        rank's slab and n_samples.  Returns the number of (word, sample) pairs installed."""
         W, r = self.g.world, self.g.rank
         own = [i for i in range(n_samples) if owner_of(i, W) == r]
         per = (n_samples + W - 1) // W                       # rows of the count table, the same on every rank
@@ -840,13 +840,22 @@ class ListExchange:
         send_counts = [int(seg[:, d].sum()) for d in range(W)]
         recv_counts = [int(seg_all[src][:, r].sum()) for src in range(W)]
         n_send, n_recv = sum(send_counts), sum(recv_counts)
-        send_w, send_f = self.t.alloc(n_send * 8), self.t.alloc(n_send * 4)
-        recv_w, recv_f = self.t.alloc(n_recv * 8), self.t.alloc(n_recv * 4)
+        bufs = []
         try:
+            send_w, send_f = self.t.alloc(n_send * 8), self.t.alloc(n_send * 4)
+            bufs += [send_w, send_f]
             # destination-major, my samples in order inside: one packing call (waited for inside)
             rs = [(j, int(cuts[j, d]), int(seg[j, d])) for d in range(W) for j in range(len(own))]
             if rs:
                 cnt_ctx.copy_list_ranges([x[0] for x in rs], [x[1] for x in rs], [x[2] for x in rs], send_w.ptr, send_f.ptr)
+            # packed, the counting context's lists are dead: they go back to the device BEFORE the receive buffers are
+            # taken.  At N = 2 of config 3 a rank holds 61 GB of lists; lists + send + receive + the slab context's copy
+            # would stand at 244 GB of the 288, without them the peak is 183 GB.  (cnt_ctx is the caller's to close.)
+            release = getattr(cnt_ctx, "release_lists", None)
+            if release is not None:
+                release()
+            recv_w, recv_f = self.t.alloc(n_recv * 8), self.t.alloc(n_recv * 4)
+            bufs += [recv_w, recv_f]
             # what arrives is source-major, the source's samples in order inside: one installing call
             idx, cnt, tot = [], [], []
             for src in range(W):
@@ -859,6 +868,6 @@ class ListExchange:
                 self.t.alltoallv(send_f, send_counts, recv_f, recv_counts, 4)
                 slab_ctx.set_lists_device(idx, cnt, tot, recv_w.ptr, recv_f.ptr)     # (waits for the collectives' stream)
         finally:
-            for b in (send_w, send_f, recv_w, recv_f):
+            for b in bufs:
                 b.free()
         return int(sum(cnt))

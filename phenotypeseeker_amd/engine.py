@@ -144,6 +144,10 @@ class PskContext:
         self._check(self._lib.psk_copy_list_ranges(self._h, len(si), _ptr(si), _ptr(st), _ptr(ct), ctypes.c_void_p(dev_words_ptr),
                                                    ctypes.c_void_p(dev_freqs_ptr)), "psk_copy_list_ranges")
 
+    def release_lists(self):
+        """Gives the device memory of the lists back; every sample is "not counted" again."""
+        self._check(self._lib.psk_release_lists(self._h), "psk_release_lists")
+
     def set_lists_device(self, sample_idx, count, n_total, dev_words_ptr, dev_freqs_ptr):
         """Installs len(sample_idx) lists held back to back in DEVICE memory as the lists of those samples."""
         si = np.ascontiguousarray(sample_idx, dtype=np.int32)

@@ -74,13 +74,15 @@ with PskContext(0) as cnt, PskContext(0) as slab:
     cnt.begin(11, 5)
     nu, nt = cnt.count_kmers_batch(0, datas, 2)
     slab.begin(11, 5)
-    pairs = dist.ListExchange(g, 11).run(cnt, slab, 5, nt)
+    counted = [cnt.get_list(i, nu[i]) for i in range(5)]
+    m_cnt, union_cnt = cnt.build_presence(), cnt.get_union()
+    pairs = dist.ListExchange(g, 11).run(cnt, slab, 5, nt)      # (releases the lists of cnt)
     assert pairs == sum(nu)
     for i in range(5):
-        a, b = cnt.get_list(i, nu[i]), slab.get_list(i, nu[i])
+        a, b = counted[i], slab.get_list(i, nu[i])
         assert np.array_equal(a[0], b[0]) and np.array_equal(a[1], b[1]), i
-    assert cnt.build_presence() == slab.build_presence()
-    assert np.array_equal(cnt.get_union(), slab.get_union())
+    assert m_cnt == slab.build_presence()
+    assert np.array_equal(union_cnt, slab.get_union())
 assert "torch" not in sys.modules
 g.close()
 print("exchange ok", npass)

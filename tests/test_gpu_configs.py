@@ -392,7 +392,7 @@ def test_cfg5_one_ranks_share_of_full_size_fastq_samples_through_the_list_exchan
     survivors equal to the oracle's on a sample of the rows, the gene's k-mers present in every carrier."""
     import tempfile
     from phenotypeseeker_amd import dist
-    from phenotypeseeker_amd.engine import PskContext
+    from phenotypeseeker_amd.engine import PskContext, PskError
     from phenotypeseeker_amd.synth import GenomeSet
     n, reads, rl, k = 64, 2_000_000, 150, 13
     gs = GenomeSet(n, 5_000_000, seed=99)
@@ -418,12 +418,15 @@ def test_cfg5_one_ranks_share_of_full_size_fastq_samples_through_the_list_exchan
                 del batch
             assert nt == [reads * (rl - k + 1)] * n
             ctx.begin(k, n)
+            counted = {i: cnt.get_list(i, nu[i]) for i in (0, 17, 63)}     # (the exchange releases the counting context's lists)
             pairs = dist.ListExchange(g, k).run(cnt, ctx, n, nt)
             assert pairs == sum(nu)
+            with pytest.raises(PskError, match="has not been counted"):
+                cnt.get_list(0, nu[0])
             for i in (0, 17, 63):
                 w0, f0 = ctx.get_list(i, nu[i])
                 assert np.all(w0[1:] > w0[:-1]) and int(f0.astype(np.uint64).sum()) == nt[i]
-                w1, f1 = cnt.get_list(i, nu[i])
+                w1, f1 = counted[i]
                 assert np.array_equal(w0, w1) and np.array_equal(f0, f1), i
             with PskContext(0) as solo:          # sample 17 counted in place: the list the exchange delivered
                 solo.begin(k, 1)
