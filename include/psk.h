@@ -84,6 +84,15 @@ int psk_count_kmers_batch_sketch(psk_ctx *ctx, int first_sample_idx, int n, cons
 int psk_count_kmers_files(psk_ctx *ctx, int first_sample_idx, int n, const char *const *paths, const size_t *sizes,
                           uint64_t *n_unique, uint64_t *n_total, int n_threads, int sketch_k, int sketch_size,
                           uint32_t sketch_seed, uint64_t *hashes_out, uint64_t *n_hashes_out);
+/* .gz inputs ("FASTA/FASTQ(.gz)", glistmaker's zlib reader: SURVEY.md section 2 row 9).  psk_count_kmers /
+ * psk_count_kmers_batch / psk_count_kmers_files take a gzip image (magic bytes 1f 8b) as it is: the compressed bytes
+ * cross PCIe and DEFLATE is decoded on the device (csrc/gz_inflate.hip); a member the device route declines goes
+ * through zlib on the host.  This entry point is the inflate on its own -- tests and measurements: n gzip images ->
+ * their text (out[i], of capacity out_cap[i], may be NULL: lengths only).  route[i]: 1 decoded on the device, 2 the same,
+ * a BGZF file (its members found by their BSIZE fields), 0 zlib on the host.  device_ms: wall-clock of the device route,
+ * upload included. */
+int psk_gz_inflate(psk_ctx *ctx, int n, const uint8_t *const *data, const size_t *sizes, uint8_t *const *out,
+                   const size_t *out_cap, uint64_t *out_len, int32_t *route, double *device_ms);
 /* Copies sample_idx's list to the host (for writing .list files / parity checks). */
 int psk_get_list(psk_ctx *ctx, int sample_idx, uint64_t *words, uint32_t *freqs, uint64_t cap);
 /* ---- multi-GPU ingest: count each sample on ONE rank, exchange the slab ranges of the sorted lists ----------

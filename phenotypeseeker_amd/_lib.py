@@ -41,6 +41,8 @@ _SIGNATURES = {
     "psk_write_model_coefficients": (c.c_int, [c.c_void_p, c.c_char_p, c.c_int64, c.c_char_p, c.c_void_p, c.c_void_p, c.c_void_p,
                                                c.c_int64, c.c_char_p, c.c_void_p]),
     "psk_lists_split": (c.c_int, [c.c_void_p, c.c_int, c.c_int, c.c_void_p, c.c_int, c.c_void_p]),
+    "psk_gz_inflate": (c.c_int, [c.c_void_p, c.c_int, c.c_void_p, c.c_void_p, c.c_void_p, c.c_void_p, c.c_void_p, c.c_void_p,
+                                  c.POINTER(c.c_double)]),
     "psk_release_lists": (c.c_int, [c.c_void_p]),
     "psk_copy_list_ranges": (c.c_int, [c.c_void_p, c.c_int, c.c_void_p, c.c_void_p, c.c_void_p, c.c_void_p, c.c_void_p]),
     "psk_set_lists_device": (c.c_int, [c.c_void_p, c.c_int, c.c_void_p, c.c_void_p, c.c_void_p, c.c_void_p, c.c_void_p]),

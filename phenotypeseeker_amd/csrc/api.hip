@@ -139,6 +139,7 @@ extern "C" void psk_free(psk_ctx *ctx)
         if (L.raw_free) (void)hipEventDestroy(L.raw_free);
         if (L.up_done) (void)hipEventDestroy(L.up_done);
     }
+    gz_release(ctx);
     dev_release(ctx->lane_slab);
     if (ctx->lane_pinned) (void)hipHostFree(ctx->lane_pinned);
     if (ctx->copy_stream) (void)hipStreamDestroy(ctx->copy_stream);
@@ -197,6 +198,7 @@ extern "C" int psk_begin(psk_ctx *ctx, int k, int n_samples, uint64_t slab_lo, u
     ctx->bs_ready = false;   // the splitters of the bucketed sort belong to a run (its k, its slab)
     for (CountLane &L : ctx->lane) L.dc_slot = 0;   // the dense and the bucketed route lay the counter ring out differently: zero it again
     // a large slab of a grouped batch (long samples) does not stay beside the lists and the matrix of the next run
+    gz_release(ctx);
     if (ctx->lane_slab.cap > ((size_t)4 << 30)) {
         psk_forget_lane_slices(ctx);
         dev_release(ctx->lane_slab);

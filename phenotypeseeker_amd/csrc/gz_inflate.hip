@@ -1,0 +1,1272 @@
+// .gz inputs (row a1's "FASTA/FASTQ(.gz)"): DEFLATE decoded on the GPU.
+//
+// The reference hands the path of a .gz file to glistmaker, whose zlib reader inflates it on one host thread per file
+// (SURVEY.md section 2 row 9, Appendix B).  Until r05 this package did the same on a pool of host threads -- ~0.35 GB/s
+// per thread of inflated text against the ~45 GB/s a PCIe link moves, so a read set in its usual form (.fastq.gz) was
+// bound by the host's inflate, twenty times below the upload (missing #7).  Here the COMPRESSED image
+// crosses PCIe (a quarter of the bytes) and is inflated on the device.
+//
+// A DEFLATE stream is serial twice over: a Huffman code has to be decoded to know where the next one starts, and a
+// match copies from the 32 KB of text before it.  The way around both is the one pugz / rapidgzip take on CPUs
+// (Kerbiriou & Chikhi 2019; Knespel & Brunst 2023), laid out for 64-lane waves:
+//   1. gz_find_kernel     the stream is cut every `chunk` bytes; one wave per cut tests the bit offsets after it, 64 at
+//                         a time, for a dynamic-Huffman block header that parses completely (precode and both codes
+//                         complete, end-of-block coded): the first one that does is the chunk's start.
+//   2. gz_decode_kernel<false>   one LANE per chunk decodes from its start to the block end that coincides with a
+//                         later chunk's start, counting what it would write.  (A false positive of step 1 never
+//                         coincides with anything: the host's walk along the links from the true start of the member
+//                         drops it, and the chunk before it simply runs on.)
+//   3. host: the chain of chunks of every file, their output offsets; further members (cat a.gz b.gz; BGZF blocks
+//      are found by their BSIZE fields without any search), ISIZE checked.
+//   4. gz_decode_kernel<true>    the same decode, now writing 16-bit symbols: a byte, or -- for a match that reaches
+//                         back beyond the chunk's start -- 256 + its position in the unknown 32-KB window; copies of
+//                         such symbols copy the marker.
+//   5. gz_tails_kernel    one workgroup per file walks its chunks in order and resolves the last 32 KB of each (the
+//                         window of the next one);  gz_resolve_kernel then resolves everything else at once.
+// The decoder keeps both Huffman codes of a block as canonical-code limits in REGISTERS (the code length of the next
+// symbol is a chain of 14 compares, no table walk) and the symbols in LDS, 608 B per lane: four waves a CU.
+// A member the device declines (a block that runs on for megabytes without a dynamic header, a chain of more members
+// than the rounds allowed here, corrupt data) goes through zlib on the host, which also words the error.
+#include "dev_utils.h"
+#include "psk_internal.h"
+
+#include <zlib.h>
+
+#include <algorithm>
+#include <chrono>
+#include <cstdlib>
+#include <cstring>
+#include <string>
+#include <vector>
+
+namespace {
+
+constexpr uint64_t GZ_NONE = ~0ull;
+constexpr int GZ_FINAL = -1, GZ_ERROR = -2, GZ_OVERRUN = -3, GZ_STOP = -5;
+constexpr int GZ_WIN = 32768;
+
+// ---- the bit stream: 32-bit aligned loads into a 64-bit buffer, at least 32 valid bits after need32() ------------
+struct BitIn {
+    const uint32_t *w;  // the word after `ahead`
+    uint32_t ahead;     // loaded one refill early: its latency passes while the symbols before it are decoded
+    uint64_t bb;
+    int bc;
+    __device__ __forceinline__ void init(const uint8_t *base, uint64_t bit)
+    {
+        w = reinterpret_cast<const uint32_t *>(base) + (bit >> 5);
+        bb = *w++;
+        ahead = *w++;
+        const int skip = (int)(bit & 31);
+        bb >>= skip;
+        bc = 32 - skip;
+        need32();
+    }
+    __device__ __forceinline__ void need32()
+    {
+        if (bc < 32) {
+            bb |= (uint64_t)ahead << bc;
+            bc += 32;
+            ahead = *w++;
+        }
+    }
+    __device__ __forceinline__ uint32_t peek(int n) const { return (uint32_t)bb & ((1u << n) - 1u); }
+    __device__ __forceinline__ void drop(int n)
+    {
+        bb >>= n;
+        bc -= n;
+    }
+    __device__ __forceinline__ uint32_t take(int n)
+    {
+        const uint32_t v = peek(n);
+        drop(n);
+        return v;
+    }
+    __device__ __forceinline__ uint64_t pos(const uint8_t *base) const
+    {
+        return (uint64_t)(reinterpret_cast<const uint8_t *>(w - 1) - base) * 8 - (uint64_t)bc;
+    }
+    __device__ __forceinline__ bool beyond(const uint32_t *endw) const { return w - 1 > endw; }
+};
+
+// sixteen 16-bit counters in registers, addressable by a run-time index
+struct Pk16 {
+    uint64_t a0 = 0, a1 = 0, a2 = 0, a3 = 0;
+    __device__ __forceinline__ uint32_t get(int i) const
+    {
+        // (masks, not selects: a chain of selects over four values is what the compiler turns into an array in scratch memory)
+        const int q = i >> 2;
+        const uint64_t w = (a0 & (0 - (uint64_t)(q == 0))) | (a1 & (0 - (uint64_t)(q == 1))) | (a2 & (0 - (uint64_t)(q == 2))) | (a3 & (0 - (uint64_t)(q == 3)));
+        return (uint32_t)(w >> ((i & 3) * 16)) & 0xffffu;
+    }
+    __device__ __forceinline__ void add(int i, uint32_t v)
+    {
+        const uint64_t inc = (uint64_t)v << ((i & 3) * 16);
+        const int q = i >> 2;
+        a0 += inc & (0 - (uint64_t)(q == 0));
+        a1 += inc & (0 - (uint64_t)(q == 1));
+        a2 += inc & (0 - (uint64_t)(q == 2));
+        a3 += inc & (0 - (uint64_t)(q == 3));
+    }
+    __device__ __forceinline__ uint32_t sum_from_1() const   // counters 1..15 (no field overflows: at most 320 symbols)
+    {
+        const uint64_t u = (a0 & ~0xffffull) + a1 + a2 + a3;
+        return (uint32_t)((u & 0xffff) + ((u >> 16) & 0xffff) + ((u >> 32) & 0xffff) + ((u >> 48) & 0xffff));
+    }
+};
+
+// A canonical Huffman code as DEFLATE defines it (RFC 1951 3.2.2), held as one limit and one base per code length:
+// with the next MAXL bits of the stream as a number whose most significant bit is the first bit read, the symbol has
+// the smallest length l with rev < lim[l], and it is entry bas[l] + (rev >> (MAXL - l)) of the symbols sorted by
+// (length, value).  lim[] never decreases, so the length is 1 + the number of limits rev has reached.
+template <int MAXL>
+struct Huff {
+    uint32_t lim[MAXL + 1];
+    int32_t step[MAXL + 1];   // step[l] = bas[l + 1] - bas[l] (step[0] = bas[1]): the base is summed up along the compares, so
+                              // that every access has a constant index and the arrays stay in registers
+    // 1: over-subscribed.  *complete: every bit pattern is a code.
+    __device__ __forceinline__ int build(const Pk16 &cnt, bool *complete)
+    {
+        uint32_t first = 0, off = 0;
+        int32_t prev = 0;
+        int bad = 0;
+#pragma unroll
+        for (int l = 1; l <= MAXL; l++) {
+            const uint32_t c = cnt.get(l);
+            first <<= 1;
+            const int32_t bas = (int32_t)off - (int32_t)first;
+            step[l - 1] = bas - prev;
+            prev = bas;
+            first += c;
+            off += c;
+            if (first > (1u << l)) bad = 1;
+            lim[l] = first << (MAXL - l);
+        }
+        *complete = first == (1u << MAXL);
+        return bad;
+    }
+    // the code length (MAXL + 1: the bits are no code of this set); *idx: which of the sorted symbols
+    __device__ __forceinline__ int decode(uint32_t rev, int *idx) const
+    {
+        int L = 1;
+        int32_t b = step[0];
+#pragma unroll
+        for (int l = 1; l < MAXL; l++) {
+            const bool ge = rev >= lim[l];
+            L += ge ? 1 : 0;
+            b += ge ? step[l] : 0;
+        }
+        *idx = b + (int32_t)(rev >> (MAXL - L));
+        return rev >= lim[MAXL] ? MAXL + 1 : L;
+    }
+};
+
+struct Precode {
+    Huff<7> h;
+    uint64_t lo, hi;  // its symbols in canonical order, 5 bits each (12 + 7)
+    __device__ __forceinline__ int symbol(int idx) const { return (int)((idx < 12 ? lo >> (5 * idx) : hi >> (5 * (idx - 12))) & 31); }
+};
+
+// HLIT, HDIST, HCLEN and the code-length code (RFC 1951 3.2.7); 1: not a header zlib would accept
+__device__ __forceinline__ int gz_read_precode(BitIn &in, int &hlit, int &hdist, Precode &pc)
+{
+    in.need32();
+    hlit = (int)in.take(5) + 257;
+    hdist = (int)in.take(5) + 1;
+    const int hclen = (int)in.take(4) + 4;
+    if (hlit > 286 || hdist > 30) return 1;
+    constexpr int order[19] = {16, 17, 18, 0, 8, 7, 9, 6, 10, 5, 11, 4, 12, 3, 13, 2, 14, 1, 15};
+    uint64_t pl = 0;  // 3 bits per symbol of the code-length alphabet
+#pragma unroll
+    for (int i = 0; i < 19; i++) {
+        if ((i & 7) == 0) in.need32();
+        if (i < hclen) pl |= (uint64_t)in.take(3) << (3 * order[i]);
+    }
+    Pk16 cnt;
+#pragma unroll
+    for (int s = 0; s < 19; s++) cnt.add((int)(pl >> (3 * s)) & 7, 1);
+    bool complete;
+    if (pc.h.build(cnt, &complete) || !complete) return 1;  // (inftrees.c: an incomplete CODES set is an error)
+    Pk16 offs;
+    {
+        uint32_t o = 0;
+#pragma unroll
+        for (int l = 1; l <= 7; l++) {
+            offs.add(l, o);
+            o += cnt.get(l);
+        }
+    }
+    pc.lo = pc.hi = 0;
+#pragma unroll
+    for (int s = 0; s < 19; s++) {
+        const int l = (int)(pl >> (3 * s)) & 7;
+        if (l) {
+            const int idx = (int)offs.get(l);
+            offs.add(l, 1);
+            if (idx < 12) pc.lo |= (uint64_t)s << (5 * idx);
+            else pc.hi |= (uint64_t)s << (5 * (idx - 12));
+        }
+    }
+    return 0;
+}
+
+// the hlit + hdist code lengths, run-length coded in the code-length alphabet; emit(first symbol, run, length)
+template <class Emit>
+__device__ __forceinline__ int gz_read_lengths(BitIn &in, const uint32_t *endw, int total, const Precode &pc, Emit &&emit)
+{
+    int i = 0, prev = 0;
+    while (i < total) {
+        if (in.beyond(endw)) return 1;
+        in.need32();
+        int idx;
+        const int L = pc.h.decode(__brev(in.peek(7)) >> 25, &idx);
+        if (L > 7) return 1;
+        in.drop(L);
+        const int sym = pc.symbol(idx);
+        int rep, len;
+        if (sym < 16) {
+            rep = 1;
+            len = prev = sym;
+        } else if (sym == 16) {
+            if (i == 0) return 1;
+            rep = 3 + (int)in.take(2);
+            len = prev;
+        } else if (sym == 17) {
+            rep = 3 + (int)in.take(3);
+            len = prev = 0;
+        } else {
+            rep = 11 + (int)in.take(7);
+            len = prev = 0;
+        }
+        if (i + rep > total) return 1;
+        emit(i, rep, len);
+        i += rep;
+    }
+    return 0;
+}
+
+// what inftrees.c accepts of a literal/length or distance code: complete, or one code of one bit, or (distances) none
+__device__ __forceinline__ bool gz_code_acceptable(const Pk16 &cnt, bool complete, bool may_be_empty)
+{
+    if (complete) return true;
+    const uint32_t n = cnt.sum_from_1();
+    if (n == 0) return may_be_empty;
+    return n == 1 && cnt.get(1) == 1;
+}
+
+// counts of the code lengths of a dynamic block; the stream is left behind the lengths.  1: not acceptable
+__device__ __forceinline__ int gz_count_lengths(BitIn &in, const uint32_t *endw, int hlit, int hdist, const Precode &pc, Pk16 &lc, Pk16 &dc)
+{
+    bool eob = false;
+    const int rc = gz_read_lengths(in, endw, hlit + hdist, pc, [&](int i, int rep, int len) {
+        int nl = hlit - i;
+        nl = nl < 0 ? 0 : (nl > rep ? rep : nl);
+        lc.add(len, (uint32_t)nl);
+        dc.add(len, (uint32_t)(rep - nl));
+        if (len && i <= 256 && i + rep > 256) eob = true;
+    });
+    return rc || !eob;   // (inflate.c: "invalid code -- missing end-of-block")
+}
+
+// ---- step 1: where a dynamic block starts ---------------------------------------------------------------------
+__device__ __forceinline__ bool gz_plausible_header(const uint8_t *comp, uint64_t bit, const uint32_t *endw)
+{
+    BitIn in;
+    in.init(comp, bit);
+    if (in.peek(3) != 4) return false;  // BFINAL = 0, BTYPE = 10 (read least significant bit first)
+    in.drop(3);
+    int hlit, hdist;
+    Precode pc;
+    if (gz_read_precode(in, hlit, hdist, pc)) return false;
+    Pk16 lc, dc;
+    if (gz_count_lengths(in, endw, hlit, hdist, pc, lc, dc)) return false;
+    Huff<15> h;
+    bool complete;
+    if (h.build(lc, &complete) || !gz_code_acceptable(lc, complete, false)) return false;
+    if (h.build(dc, &complete) || !gz_code_acceptable(dc, complete, true)) return false;
+    return true;
+}
+
+// one wave per search: the first bit offset in [from, to) at which a dynamic block header parses
+__global__ __launch_bounds__(64) void gz_find_kernel(const uint8_t *comp, const uint64_t *from, const uint64_t *to, const uint64_t *end_byte,
+                                                      int n, uint64_t *found)
+{
+    const int c = blockIdx.x, lane = threadIdx.x;
+    if (c >= n) return;
+    const uint64_t b0 = from[c], b1 = to[c];
+    const uint32_t *endw = reinterpret_cast<const uint32_t *>(comp + end_byte[c]) + 2;
+    uint64_t hit = GZ_NONE;
+    for (uint64_t b = b0; b < b1; b += 64) {
+        const uint64_t bit = b + lane;
+        const bool ok = bit < b1 && gz_plausible_header(comp, bit, endw);
+        const uint64_t m = __ballot(ok);
+        if (m) {
+            hit = b + (uint64_t)__ffsll((long long)m) - 1;
+            break;
+        }
+    }
+    if (lane == 0) found[c] = hit;
+}
+
+// ---- steps 2 and 4: the decoder, one lane per chunk -------------------------------------------------------------
+struct GzDecodeArgs {
+    const uint8_t *comp;         // every file's image, 16-byte aligned, zeros between them
+    const uint64_t *start_bit;   // per chunk; GZ_NONE: nothing starts in this chunk
+    const uint64_t *end_byte;    // per chunk: where its file's image ends
+    const uint8_t *true_start;   // per chunk: a member starts here (no text before it)
+    uint16_t *long_syms;         // per chunk 320 u16: the symbols whose codes are longer than the tables' index
+    // counting pass: the starts a block end may coincide with, ascending, entries [cand_from, cand_to) of cand_bit
+    const uint64_t *cand_bit;
+    const uint32_t *cand_from, *cand_to;
+    uint64_t max_span_bits;
+    // writing pass
+    const uint64_t *stop_bit, *out_off, *rec_off, *want_len, *want_rec;
+    uint16_t *sym;
+    uint2 *rec;                  // a match: {where in the chunk's text, length | distance << 16}
+    // results
+    uint64_t *out_len, *n_rec, *end_bit;
+    int32_t *link;               // counting: entry of cand_bit reached, or GZ_FINAL / GZ_ERROR / GZ_OVERRUN; writing: GZ_STOP / GZ_FINAL / GZ_ERROR
+    int n;
+};
+
+constexpr int GZ_LIT_BITS = 8, GZ_DIST_BITS = 6;
+constexpr int GZ_LDS_U16 = ((1 << GZ_LIT_BITS) + (1 << GZ_DIST_BITS)) * 64;   // 40 KB a wave: four waves a CU
+
+// The codes of a block, per lane: a table over the next 8 (6) bits of the stream in LDS -- {code length, symbol}, 0 for the
+// prefix of a longer code -- and, for the longer codes, the canonical limits in registers and the sorted symbols in
+// global memory (a FASTQ block has a handful of them).
+struct LongCodes {
+    uint32_t lim[16];   // only the entries above the table's index width are used
+    int32_t step[16];
+    int32_t base;       // of the first length the table does not cover
+    template <int FROM>
+    __device__ __forceinline__ void take(const Huff<15> &h)
+    {
+        int32_t b = 0;
+#pragma unroll
+        for (int l = 0; l < FROM; l++) b += h.step[l];
+        base = b;
+#pragma unroll
+        for (int l = FROM; l <= 15; l++) {
+            lim[l] = h.lim[l];
+            step[l] = h.step[l];
+        }
+    }
+    // rev: the next 15 bits, first bit most significant, known not to start a code shorter than FROM
+    template <int FROM>
+    __device__ __forceinline__ int decode(uint32_t rev, int *idx) const
+    {
+        int L = FROM;
+        int32_t b = base;
+#pragma unroll
+        for (int l = FROM; l < 15; l++) {
+            const bool ge = rev >= lim[l];
+            L += ge ? 1 : 0;
+            b += ge ? step[l] : 0;
+        }
+        *idx = b + (int32_t)(rev >> (15 - L));
+        return rev >= lim[15] ? 16 : L;
+    }
+};
+
+template <bool WRITE>
+__global__ __launch_bounds__(64) void gz_decode_kernel(GzDecodeArgs a)
+{
+    extern __shared__ uint16_t gz_lds[];
+    const int lane = threadIdx.x;
+    const int c = blockIdx.x * 64 + lane;
+    if (c >= a.n) return;
+    const uint64_t start = a.start_bit[c];
+    if (start == GZ_NONE) return;
+    uint16_t *lt = gz_lds + lane;                               // entry t of this lane: lt[t * 64]
+    uint16_t *dt = gz_lds + (1 << GZ_LIT_BITS) * 64 + lane;
+    uint16_t *lsym = a.long_syms + (size_t)c * 320, *dsym = lsym + 288;
+    const uint8_t *comp = a.comp;
+    const uint32_t *endw = reinterpret_cast<const uint32_t *>(comp + a.end_byte[c]) + 2;
+    const bool true_start = a.true_start[c] != 0;
+    uint32_t nc = WRITE ? 0 : a.cand_from[c];
+    const uint32_t nc_end = WRITE ? 0 : a.cand_to[c];
+    const uint64_t stop = WRITE ? a.stop_bit[c] : 0;
+    uint16_t *out = WRITE ? a.sym + a.out_off[c] : nullptr;
+    uint2 *rec = WRITE ? a.rec + a.rec_off[c] : nullptr;
+
+    BitIn in;
+    in.init(comp, start);
+    LongCodes ll, ld;
+    uint64_t pos = 0, nrec = 0;
+    int link = GZ_ERROR;
+    bool final = false;
+    for (;;) {  // blocks
+        const uint64_t bit = in.pos(comp);
+        if (final) {
+            link = GZ_FINAL;
+            break;
+        }
+        if (WRITE) {
+            if (bit >= stop) {
+                link = bit == stop ? GZ_STOP : GZ_ERROR;
+                break;
+            }
+        } else {
+            while (nc < nc_end && a.cand_bit[nc] < bit) nc++;
+            if (nc < nc_end && a.cand_bit[nc] == bit) {
+                link = (int)nc;
+                break;
+            }
+            if (bit - start > a.max_span_bits) {
+                link = GZ_OVERRUN;
+                break;
+            }
+        }
+        if (in.beyond(endw) || pos >= (1ull << 32)) break;
+        in.need32();
+        final = in.take(1) != 0;
+        const uint32_t type = in.take(2);
+        if (type == 3) break;
+        if (type == 0) {  // stored
+            in.drop(in.bc & 7);
+            in.need32();
+            const uint32_t len = in.take(16);
+            in.need32();
+            const uint32_t nlen = in.take(16);
+            if ((len ^ nlen) != 0xffffu) break;
+            bool bad = false;
+            for (uint32_t j = 0; j < len; j++) {
+                if (in.beyond(endw)) {
+                    bad = true;
+                    break;
+                }
+                in.need32();
+                const uint32_t b = in.take(8);
+                if (WRITE) out[pos] = (uint16_t)b;
+                pos++;
+            }
+            if (bad) break;
+            continue;
+        }
+        // ---- the block's two codes ----
+        {
+            Pk16 lc, dc;
+            int hlit = 288, hdist = 32;
+            Precode pc;
+            BitIn lengths_at = in;
+            if (type == 1) {  // the fixed code (RFC 1951 3.2.6)
+                lc.add(7, 24);
+                lc.add(8, 152);
+                lc.add(9, 112);
+                dc.add(5, 32);
+            } else {
+                if (gz_read_precode(in, hlit, hdist, pc)) break;
+                lengths_at = in;
+                if (gz_count_lengths(in, endw, hlit, hdist, pc, lc, dc)) break;
+            }
+            Huff<15> h;
+            bool lcomplete, dcomplete;
+            if (h.build(lc, &lcomplete) || !gz_code_acceptable(lc, lcomplete, false)) break;
+            ll.take<GZ_LIT_BITS + 1>(h);
+            Pk16 lcode, loff, dcode, doff;   // per length: the next code, the next place among the sorted symbols
+            {
+                uint32_t first = 0, o = 0;
+#pragma unroll
+                for (int l = 1; l <= 15; l++) {
+                    first <<= 1;
+                    lcode.add(l, first);
+                    loff.add(l, o);
+                    first += lc.get(l);
+                    o += lc.get(l);
+                }
+            }
+            if (h.build(dc, &dcomplete) || !gz_code_acceptable(dc, dcomplete, true)) break;
+            ld.take<GZ_DIST_BITS + 1>(h);
+            {
+                uint32_t first = 0, o = 0;
+#pragma unroll
+                for (int l = 1; l <= 15; l++) {
+                    first <<= 1;
+                    dcode.add(l, first);
+                    doff.add(l, o);
+                    first += dc.get(l);
+                    o += dc.get(l);
+                }
+            }
+            // an incomplete code leaves bit patterns that are no code: they must not find an entry of the block before
+            if (!lcomplete)
+                for (int t = 0; t < (1 << GZ_LIT_BITS); t++) lt[t * 64] = 0;
+            if (!dcomplete)
+                for (int t = 0; t < (1 << GZ_DIST_BITS); t++) dt[t * 64] = 0;
+            auto place = [&](int i, int rep, int len) {
+                if (!len) return;
+                for (int j = i; j < i + rep; j++) {
+                    const bool is_lit = j < hlit;
+                    const uint32_t code = is_lit ? lcode.get(len) : dcode.get(len);
+                    const uint32_t at = is_lit ? loff.get(len) : doff.get(len);
+                    if (is_lit) {
+                        lcode.add(len, 1);
+                        loff.add(len, 1);
+                    } else {
+                        dcode.add(len, 1);
+                        doff.add(len, 1);
+                    }
+                    const uint32_t r = __brev(code) >> (32 - len);   // the code as the stream presents it: first bit lowest
+                    const int bits = is_lit ? GZ_LIT_BITS : GZ_DIST_BITS;
+                    uint16_t *tab = is_lit ? lt : dt;
+                    const int value = is_lit ? j : j - hlit;
+                    if (len <= bits) {
+                        const uint16_t e = (uint16_t)((value << 4) | len);
+                        for (uint32_t t = r; t < (1u << bits); t += 1u << len) tab[t * 64] = e;
+                    } else {
+                        tab[(r & ((1u << bits) - 1)) * 64] = 0;
+                        (is_lit ? lsym : dsym)[at] = (uint16_t)value;
+                    }
+                }
+            };
+            if (type == 1) {
+                place(0, 144, 8);
+                place(144, 112, 9);
+                place(256, 24, 7);
+                place(280, 8, 8);
+                place(288, 32, 5);
+            } else {
+                in = lengths_at;
+                (void)gz_read_lengths(in, endw, hlit + hdist, pc, place);
+            }
+        }
+        // ---- the block's symbols ----
+        bool bad = true;
+        for (;;) {
+            if (in.beyond(endw)) break;
+            in.need32();
+            uint32_t e = lt[in.peek(GZ_LIT_BITS) * 64];
+            int len = (int)(e & 15);
+            uint32_t s = e >> 4;
+            if (len == 0) {
+                int idx;
+                len = ll.decode<GZ_LIT_BITS + 1>(__brev(in.peek(15)) >> 17, &idx);
+                if (len > 15) break;
+                s = lsym[idx];
+            }
+            in.drop(len);
+            if (s < 256) {
+                if (WRITE) out[pos] = (uint16_t)s;
+                pos++;
+                continue;
+            }
+            if (s == 256) {
+                bad = false;
+                break;
+            }
+            const int i = (int)s - 257;
+            if (i > 28) break;
+            const int eb = i < 8 || i == 28 ? 0 : (i - 4) >> 2;
+            const uint32_t mlen = (i < 8 ? 3u + i : i == 28 ? 258u : 3u + ((4u + (i & 3)) << eb)) + in.take(eb);
+            in.need32();
+            e = dt[in.peek(GZ_DIST_BITS) * 64];
+            len = (int)(e & 15);
+            uint32_t ds = e >> 4;
+            if (len == 0) {
+                int idx;
+                len = ld.decode<GZ_DIST_BITS + 1>(__brev(in.peek(15)) >> 17, &idx);
+                if (len > 15) break;
+                ds = dsym[idx];
+            }
+            in.drop(len);
+            if (ds >= 30) break;
+            const int db = ds < 4 ? 0 : (int)(ds >> 1) - 1;
+            const uint32_t dist = (ds < 4 ? ds + 1 : 1u + ((2u + (ds & 1)) << db)) + in.take(db);
+            if ((true_start && dist > pos) || ((pos + mlen) >> 32)) break;   // (inflate.c: "invalid distance too far back")
+            if (WRITE) rec[nrec] = make_uint2((uint32_t)pos, mlen | (dist << 16));
+            nrec++;
+            pos += mlen;
+        }
+        if (bad) break;
+    }
+    a.out_len[c] = pos;
+    a.n_rec[c] = nrec;
+    a.end_bit[c] = in.pos(comp);
+    if (WRITE && link != GZ_ERROR && (pos != a.want_len[c] || nrec != a.want_rec[c])) link = GZ_ERROR;
+    a.link[c] = link;
+}
+
+// ---- step 4b: the matches -----------------------------------------------------------------------------------------
+// One wave per chunk, 64 matches at a time, one per lane: a match whose source holds nothing that an earlier match of the
+// same 64 writes is copied at once (sixty-four loads in flight instead of one), the others in the rounds after the ones
+// they wait for.  A source that lies before the chunk is a marker: 256 + its place in the unknown window.
+__global__ __launch_bounds__(256) void gz_copy_kernel(uint16_t *sym, const uint2 *rec, const uint64_t *rec_off, const uint64_t *n_rec,
+                                                       const uint64_t *out_off, int n_chunks)
+{
+    const int lane = threadIdx.x & 63;
+    const int c = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (c >= n_chunks) return;
+    uint16_t *out = sym + out_off[c];
+    const uint2 *r = rec + rec_off[c];
+    const uint64_t n = n_rec[c];
+    for (uint64_t g = 0; g < n; g += 64) {
+        const bool valid = g + lane < n;
+        const uint2 x = valid ? r[g + lane] : make_uint2(0, 0);
+        const uint32_t d = x.x, len = x.y & 0xffffu, dist = x.y >> 16;
+        const int64_t s = (int64_t)d - (int64_t)dist;
+        const int64_t e = s + len < (int64_t)d ? s + len : (int64_t)d;   // (an overlapping match reads only what lies before it)
+        const uint32_t d0 = (uint32_t)__builtin_amdgcn_readfirstlane((int)d);
+        uint64_t dep = 0;
+        if (__ballot(valid && e > (int64_t)d0)) {
+            const int n_here = (int)(n - g < 64 ? n - g : 64);
+            for (int j = 0; j + 1 < n_here; j++) {
+                const uint32_t dj = (uint32_t)__builtin_amdgcn_readlane((int)d, j), ej = dj + (uint32_t)__builtin_amdgcn_readlane((int)len, j);
+                if (j < lane && (int64_t)dj < e && (int64_t)ej > s) dep |= 1ull << j;
+            }
+        }
+        uint64_t done = ~__ballot(valid);
+        while (~done) {
+            const bool ready = !((done >> lane) & 1) && (dep & ~done) == 0;
+            if (ready) {
+                uint16_t *dst = out + d;
+                uint32_t k = 0;   // j mod dist
+                for (uint32_t j = 0; j < len; j += 8) {
+                    uint16_t v[8];
+#pragma unroll
+                    for (int i = 0; i < 8; i++) {
+                        const int64_t at = s + k;
+                        v[i] = at < 0 ? (uint16_t)(256 + GZ_WIN + at) : (j + i < len ? out[at] : (uint16_t)0);
+                        k = k + 1 == dist ? 0 : k + 1;
+                    }
+#pragma unroll
+                    for (int i = 0; i < 8; i++)
+                        if (j + i < len) dst[j + i] = v[i];
+                }
+            }
+            // what this round wrote, the next one (and the next 64 matches) may read: the readers are lanes of this very wave,
+            // so the stores only have to have left it (a fence of agent scope writes the L2 back on a part with eight of them)
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+            done |= __ballot(ready);
+        }
+    }
+}
+
+// ---- step 5: markers to bytes -----------------------------------------------------------------------------------
+// Both kernels also note where a file's text has its first NUL byte (the framing ends an input there: frame_gpu.hip).
+// One workgroup per file, its chunks in stream order: the last 32 KB of each, whose markers point into the last 32 KB
+// before the chunk -- resolved by the iterations before.
+__global__ __launch_bounds__(1024) void gz_tails_kernel(const uint16_t *sym, uint8_t *out, const uint64_t *off, const uint64_t *len,
+                                                         const uint32_t *file_first, unsigned long long *first_nul)
+{
+    const uint32_t c0 = file_first[blockIdx.x], c1 = file_first[blockIdx.x + 1];
+    for (uint32_t c = c0; c < c1; c++) {
+        const uint64_t L = len[c], t = L < GZ_WIN ? L : GZ_WIN, base = off[c] + L - t, win = off[c] - GZ_WIN;
+        for (uint64_t i = threadIdx.x; i < t; i += 1024) {
+            const uint32_t s = sym[base + i];
+            const uint8_t b = s < 256 ? (uint8_t)s : out[win + (s - 256)];
+            out[base + i] = b;
+            if (b == 0) atomicMin(first_nul + blockIdx.x, (unsigned long long)(base + i));
+        }
+        __syncthreads();
+    }
+}
+
+// everything but the tails: eight symbols a thread (one 16-byte load, one 8-byte store where the eight lie in one chunk)
+__global__ __launch_bounds__(256) void gz_resolve_kernel(const uint16_t *sym, uint8_t *out, const uint64_t *off, const uint64_t *len,
+                                                          const uint32_t *chunk_file, int n_chunks, uint64_t total, unsigned long long *first_nul)
+{
+    const uint64_t p0 = ((uint64_t)blockIdx.x * 256 + threadIdx.x) * 8;
+    if (p0 >= total) return;
+    int lo = 0, hi = n_chunks;   // the last chunk that starts at or before p0
+    while (hi - lo > 1) {
+        const int mid = (lo + hi) >> 1;
+        if (off[mid] <= p0) lo = mid;
+        else hi = mid;
+    }
+    int c = lo;
+    const uint4 raw = *reinterpret_cast<const uint4 *>(sym + p0);   // (p0 is a multiple of 8 symbols; the buffer has 64 bytes to spare)
+    const uint32_t w[4] = {raw.x, raw.y, raw.z, raw.w};
+    uint64_t o = off[c], L = len[c];
+    if (p0 >= o && p0 + 8 <= o + L - (L < GZ_WIN ? L : GZ_WIN)) {
+        // the usual case: all eight inside one chunk and before its tail
+        uint64_t packed = 0;
+#pragma unroll
+        for (int j = 0; j < 8; j++) {
+            const uint32_t s = (w[j >> 1] >> ((j & 1) * 16)) & 0xffffu;
+            const uint8_t b = s < 256 ? (uint8_t)s : out[o - GZ_WIN + (s - 256)];
+            packed |= (uint64_t)b << (8 * j);
+            if (b == 0) atomicMin(first_nul + chunk_file[c], (unsigned long long)(p0 + j));
+        }
+        *reinterpret_cast<uint64_t *>(out + p0) = packed;
+        return;
+    }
+    for (int j = 0; j < 8; j++) {
+        const uint64_t p = p0 + j;
+        if (p >= total) break;
+        while (c + 1 < n_chunks && p >= off[c + 1]) c++;
+        o = off[c];
+        L = len[c];
+        if (p < o || p >= o + L) continue;                      // the padding between two files
+        if (p >= o + L - (L < GZ_WIN ? L : GZ_WIN)) continue;   // a tail: gz_tails_kernel wrote it
+        const uint32_t s = (w[j >> 1] >> ((j & 1) * 16)) & 0xffffu;
+        const uint8_t b = s < 256 ? (uint8_t)s : out[o - GZ_WIN + (s - 256)];
+        out[p] = b;
+        if (b == 0) atomicMin(first_nul + chunk_file[c], (unsigned long long)p);
+    }
+}
+
+// ---- host side -----------------------------------------------------------------------------------------------
+struct GzMemberHead {
+    size_t deflate_at = 0;   // offset of the DEFLATE data in the file
+    uint32_t bsize = 0;      // BGZF: length of the whole member (0: not a BGZF member)
+};
+
+// RFC 1952 2.3; false: no gzip member starts at `at`
+bool gz_parse_member_header(const uint8_t *d, size_t n, size_t at, GzMemberHead *h)
+{
+    if (at + 18 > n || d[at] != 0x1f || d[at + 1] != 0x8b || d[at + 2] != 8) return false;
+    const uint8_t flg = d[at + 3];
+    if (flg & 0xe0) return false;
+    size_t p = at + 10;
+    h->bsize = 0;
+    if (flg & 4) {
+        if (p + 2 > n) return false;
+        const size_t xlen = d[p] | (d[p + 1] << 8);
+        p += 2;
+        if (p + xlen > n) return false;
+        for (size_t q = p; q + 4 <= p + xlen;) {
+            const size_t sl = d[q + 2] | (d[q + 3] << 8);
+            if (d[q] == 'B' && d[q + 1] == 'C' && sl == 2 && q + 6 <= p + xlen) h->bsize = (uint32_t)(d[q + 4] | (d[q + 5] << 8)) + 1;
+            q += 4 + sl;
+        }
+        p += xlen;
+    }
+    if (flg & 8) {
+        while (p < n && d[p]) p++;
+        p++;
+    }
+    if (flg & 16) {
+        while (p < n && d[p]) p++;
+        p++;
+    }
+    if (flg & 2) p += 2;
+    if (p + 8 > n) return false;
+    h->deflate_at = p;
+    return true;
+}
+
+uint32_t gz_le32(const uint8_t *p) { return (uint32_t)p[0] | ((uint32_t)p[1] << 8) | ((uint32_t)p[2] << 16) | ((uint32_t)p[3] << 24); }
+
+struct GzChunk {
+    int file;
+    uint64_t start_bit;   // in the device image (GZ_NONE until found)
+    uint64_t seek_from, seek_to;   // bits: where gz_find_kernel looks (seek_from == seek_to: the start is known)
+    bool true_start;
+    // results of the counting pass
+    uint64_t out_len = 0, n_rec = 0, end_bit = 0;
+    int32_t link = GZ_ERROR;
+    bool counted = false;
+};
+
+struct GzFile {
+    const uint8_t *data;
+    size_t size;
+    uint64_t at;          // offset of the image in the device buffer
+    bool bgzf = false;
+    bool device_ok = true;
+    std::vector<int> chain;      // its chunks in stream order
+    uint64_t out_off = 0, out_len = 0;
+    int nul_slot = -1;    // its entry of the writing pass's per-file tables
+};
+
+size_t gz_env(const char *name, size_t dflt)
+{
+    const char *s = std::getenv(name);
+    return s && *s ? (size_t)std::strtoull(s, nullptr, 10) : dflt;
+}
+
+int gz_host_inflate(psk_ctx *ctx, const uint8_t *d, size_t n, std::vector<uint8_t> &out)
+{
+    out.clear();
+    z_stream z;
+    std::memset(&z, 0, sizeof z);
+    if (inflateInit2(&z, 15 + 16) != Z_OK) return psk_fail(ctx, PSK_EINVAL, "zlib: inflateInit2 failed");
+    out.resize(std::max<size_t>(n * 4, (size_t)1 << 16));
+    size_t ip = 0, have = 0;
+    for (;;) {
+        if (have == out.size()) out.resize(out.size() * 2);
+        const uInt in_now = (uInt)std::min<size_t>(n - ip, (size_t)1 << 30), room = (uInt)std::min<size_t>(out.size() - have, (size_t)1 << 30);
+        z.next_in = const_cast<Bytef *>(d + ip);
+        z.avail_in = in_now;
+        z.next_out = out.data() + have;
+        z.avail_out = room;
+        const int rc = inflate(&z, Z_NO_FLUSH);
+        ip += in_now - z.avail_in;
+        have += room - z.avail_out;
+        if (rc == Z_STREAM_END) {
+            while (ip < n && d[ip] == 0) ip++;   // padding; a further member?  (gzip.decompress reads them all)
+            if (ip >= n) break;
+            if (inflateReset(&z) != Z_OK) {
+                inflateEnd(&z);
+                return psk_fail(ctx, PSK_EINVAL, "zlib: inflateReset failed");
+            }
+            continue;
+        }
+        if (rc == Z_OK || (rc == Z_BUF_ERROR && ip < n)) continue;
+        const std::string msg = rc == Z_BUF_ERROR ? "it ends inside a member" : (z.msg ? z.msg : "data error");
+        inflateEnd(&z);
+        return psk_fail(ctx, PSK_EINVAL, "not a valid gzip file: %s", msg.c_str());
+    }
+    inflateEnd(&z);
+    out.resize(have);
+    return PSK_OK;
+}
+
+}  // namespace
+
+// Inflates n gzip images.  The text of file i is out_dev[res[i].off, + res[i].len) when res[i].on_device, else
+// res[i].host (zlib on the host: the device route declined the file; *declined counts them).
+int gz_inflate_group(psk_ctx *ctx, int n, const uint8_t *const *data, const size_t *sizes, DevBuf &comp_buf, DevBuf &sym_buf, DevBuf &rec_buf, DevBuf &out_buf,
+                     DevBuf &tab_buf, std::vector<GzInflated> &res, double *device_ms, bool host_only)
+{
+    res.assign((size_t)n, GzInflated());
+    if (device_ms) *device_ms = 0.0;
+    if (n <= 0) return PSK_OK;
+    if (host_only) {
+        for (int i = 0; i < n; i++) {
+            PSK_TRY(gz_host_inflate(ctx, data[i], sizes[i], res[(size_t)i].host));
+            res[(size_t)i].len = res[(size_t)i].host.size();
+        }
+        return PSK_OK;
+    }
+    PSK_HIP(ctx, hipSetDevice(ctx->device));
+    hipStream_t st = ctx->stream;
+    std::vector<GzFile> files((size_t)n);
+    uint64_t comp_total = 0;
+    for (int i = 0; i < n; i++) {
+        files[i].data = data[i];
+        files[i].size = sizes[i];
+        files[i].at = comp_total;
+        comp_total += (sizes[i] + 16 + 15) & ~(size_t)15;
+    }
+    comp_total += 64;
+    // ---- the chunks --------------------------------------------------------------------------------------------
+    size_t deflate_bytes = 0;
+    for (int i = 0; i < n; i++) deflate_bytes += sizes[i];
+    const size_t want_lanes = gz_env("PSK_GZ_LANES", 32768);
+    size_t chunk = gz_env("PSK_GZ_CHUNK", 0);
+    if (!chunk) chunk = std::min<size_t>(std::max<size_t>(deflate_bytes / want_lanes, 32 << 10), 4 << 20);
+    chunk = (chunk + 3) & ~(size_t)3;
+    std::vector<GzChunk> ch;
+    std::vector<std::pair<int, int>> file_chunks((size_t)n);   // [first, last) of its regular chunks
+    for (int i = 0; i < n; i++) {
+        GzFile &f = files[i];
+        GzMemberHead h;
+        file_chunks[i] = {(int)ch.size(), (int)ch.size()};
+        if (!gz_parse_member_header(f.data, f.size, 0, &h)) {
+            f.device_ok = false;
+            continue;
+        }
+        if (h.bsize) {
+            // BGZF: every member says how long it is -- one chunk per member, nothing to search for
+            f.bgzf = true;
+            size_t at = 0;
+            bool ok = true;
+            while (at < f.size) {
+                GzMemberHead m;
+                if (!gz_parse_member_header(f.data, f.size, at, &m) || !m.bsize || at + m.bsize > f.size || m.deflate_at + 8 > at + m.bsize) {
+                    ok = false;
+                    break;
+                }
+                GzChunk c;
+                c.file = i;
+                c.start_bit = (f.at + m.deflate_at) * 8;
+                c.seek_from = c.seek_to = 0;
+                c.true_start = true;
+                ch.push_back(c);
+                at += m.bsize;
+            }
+            if (!ok) {
+                ch.resize((size_t)file_chunks[i].first);
+                f.bgzf = false;
+                f.device_ok = false;
+                continue;
+            }
+        } else {
+            const size_t d0 = h.deflate_at, d1 = f.size - 8;
+            for (size_t at = d0; at < d1 || at == d0; at += chunk) {
+                GzChunk c;
+                c.file = i;
+                c.true_start = at == d0;
+                c.start_bit = at == d0 ? (f.at + d0) * 8 : GZ_NONE;
+                c.seek_from = at == d0 ? 0 : (f.at + at) * 8;
+                c.seek_to = at == d0 ? 0 : (f.at + std::min(at + chunk, d1)) * 8;
+                ch.push_back(c);
+            }
+        }
+        file_chunks[i].second = (int)ch.size();
+    }
+    const auto t_begin = std::chrono::steady_clock::now();
+    // ---- the images ---------------------------------------------------------------------------------------------
+    PSK_TRY(dev_reserve(ctx, comp_buf, comp_total));
+    PSK_HIP(ctx, hipMemsetAsync(comp_buf.p, 0, comp_total, st));
+    for (int i = 0; i < n; i++)
+        if (files[i].device_ok && sizes[i])
+            PSK_HIP(ctx, hipMemcpyAsync(comp_buf.as<uint8_t>() + files[i].at, data[i], sizes[i], hipMemcpyHostToDevice, st));
+    const uint8_t *d_comp = comp_buf.as<uint8_t>();
+
+    // device tables of one pass over `m` chunks, carved out of tab_buf
+    auto carve = [&](size_t &off, size_t bytes) {
+        const size_t at = off;
+        off += (bytes + 255) & ~(size_t)255;
+        return at;
+    };
+    std::vector<int> todo;   // chunks of the coming counting pass
+    for (size_t c = 0; c < ch.size(); c++) todo.push_back((int)c);
+    std::vector<uint8_t> stage;
+    int rounds = 0;
+    const int max_rounds = (int)gz_env("PSK_GZ_ROUNDS", 24);
+    // ---- step 1: the starts ---------------------------------------------------------------------------------------
+    {
+        std::vector<int> seek;
+        for (size_t c = 0; c < ch.size(); c++)
+            if (ch[c].seek_to > ch[c].seek_from) seek.push_back((int)c);
+        if (!seek.empty()) {
+            const size_t m = seek.size();
+            size_t off = 0;
+            const size_t o_from = carve(off, m * 8), o_to = carve(off, m * 8), o_end = carve(off, m * 8), o_found = carve(off, m * 8);
+            PSK_TRY(dev_reserve(ctx, tab_buf, off));
+            stage.assign(o_found, 0);
+            for (size_t j = 0; j < m; j++) {
+                const GzChunk &c = ch[(size_t)seek[j]];
+                reinterpret_cast<uint64_t *>(stage.data() + o_from)[j] = c.seek_from;
+                reinterpret_cast<uint64_t *>(stage.data() + o_to)[j] = c.seek_to;
+                reinterpret_cast<uint64_t *>(stage.data() + o_end)[j] = files[(size_t)c.file].at + files[(size_t)c.file].size;
+            }
+            uint8_t *t = tab_buf.as<uint8_t>();
+            PSK_HIP(ctx, hipMemcpyAsync(t, stage.data(), o_found, hipMemcpyHostToDevice, st));
+            gz_find_kernel<<<dim3((unsigned)m), dim3(64), 0, st>>>(d_comp, reinterpret_cast<const uint64_t *>(t + o_from),
+                                                                 reinterpret_cast<const uint64_t *>(t + o_to),
+                                                                 reinterpret_cast<const uint64_t *>(t + o_end), (int)m,
+                                                                 reinterpret_cast<uint64_t *>(t + o_found));
+            PSK_HIP(ctx, hipGetLastError());
+            std::vector<uint64_t> found(m);
+            PSK_HIP(ctx, hipMemcpyAsync(found.data(), t + o_found, m * 8, hipMemcpyDeviceToHost, st));
+            PSK_HIP(ctx, hipStreamSynchronize(st));
+            for (size_t j = 0; j < m; j++) ch[(size_t)seek[j]].start_bit = found[j];
+        }
+    }
+    // the starts a block end may coincide with: per file, ascending
+    std::vector<uint64_t> cand_bit;
+    std::vector<int> cand_chunk;
+    std::vector<std::pair<uint32_t, uint32_t>> file_cands((size_t)n);
+    auto rebuild_cands = [&]() {
+        cand_bit.clear();
+        cand_chunk.clear();
+        for (int i = 0; i < n; i++) {
+            std::vector<std::pair<uint64_t, int>> v;
+            for (size_t c = 0; c < ch.size(); c++)
+                if (ch[c].file == i && ch[c].start_bit != GZ_NONE) v.push_back({ch[c].start_bit, (int)c});
+            std::sort(v.begin(), v.end());
+            file_cands[(size_t)i].first = (uint32_t)cand_bit.size();
+            for (auto &e : v) {
+                cand_bit.push_back(e.first);
+                cand_chunk.push_back(e.second);
+            }
+            file_cands[(size_t)i].second = (uint32_t)cand_bit.size();
+        }
+    };
+    // ---- steps 2 + 3: counting passes until every file's chain reaches its end ----------------------------------------
+    const uint64_t max_span_bits = (uint64_t)std::max<size_t>(chunk * 8, gz_env("PSK_GZ_MAX_SPAN", 8 << 20)) * 8;
+    std::vector<int> next_chunk((size_t)n, -1);   // per file: the chunk its chain follows next (-1: the chain has reached the end)
+    for (int i = 0; i < n; i++) next_chunk[(size_t)i] = files[(size_t)i].device_ok && file_chunks[(size_t)i].second > file_chunks[(size_t)i].first ? file_chunks[(size_t)i].first : -1;
+    while (!todo.empty()) {
+        if (++rounds > max_rounds) {
+            for (int c : todo) files[(size_t)ch[(size_t)c].file].device_ok = false;
+            break;
+        }
+        rebuild_cands();
+        const size_t m = todo.size();
+        size_t off = 0;
+        const size_t o_start = carve(off, m * 8), o_end = carve(off, m * 8), o_true = carve(off, m), o_cf = carve(off, m * 4), o_ct = carve(off, m * 4),
+                     o_cand = carve(off, cand_bit.size() * 8 + 8);
+        const size_t o_in_end = off;
+        const size_t o_len = carve(off, m * 8), o_nrec = carve(off, m * 8), o_ebit = carve(off, m * 8), o_link = carve(off, m * 4),
+                     o_long = carve(off, m * 640);
+        PSK_TRY(dev_reserve(ctx, tab_buf, off));
+        stage.assign(o_in_end, 0);
+        for (size_t j = 0; j < m; j++) {
+            const GzChunk &c = ch[(size_t)todo[j]];
+            const GzFile &f = files[(size_t)c.file];
+            reinterpret_cast<uint64_t *>(stage.data() + o_start)[j] = f.device_ok ? c.start_bit : GZ_NONE;
+            reinterpret_cast<uint64_t *>(stage.data() + o_end)[j] = f.at + f.size;
+            stage[o_true + j] = c.true_start ? 1 : 0;
+            // its candidates: those of its file that start after it
+            const auto &fc = file_cands[(size_t)c.file];
+            const uint32_t from = (uint32_t)(std::upper_bound(cand_bit.begin() + fc.first, cand_bit.begin() + fc.second, c.start_bit) - cand_bit.begin());
+            reinterpret_cast<uint32_t *>(stage.data() + o_cf)[j] = c.start_bit == GZ_NONE ? fc.second : from;
+            reinterpret_cast<uint32_t *>(stage.data() + o_ct)[j] = fc.second;
+        }
+        if (!cand_bit.empty()) std::memcpy(stage.data() + o_cand, cand_bit.data(), cand_bit.size() * 8);
+        uint8_t *t = tab_buf.as<uint8_t>();
+        PSK_HIP(ctx, hipMemcpyAsync(t, stage.data(), o_in_end, hipMemcpyHostToDevice, st));
+        GzDecodeArgs a;
+        std::memset(&a, 0, sizeof a);
+        a.comp = d_comp;
+        a.start_bit = reinterpret_cast<const uint64_t *>(t + o_start);
+        a.end_byte = reinterpret_cast<const uint64_t *>(t + o_end);
+        a.true_start = t + o_true;
+        a.cand_bit = reinterpret_cast<const uint64_t *>(t + o_cand);
+        a.cand_from = reinterpret_cast<const uint32_t *>(t + o_cf);
+        a.cand_to = reinterpret_cast<const uint32_t *>(t + o_ct);
+        a.max_span_bits = max_span_bits;
+        a.long_syms = reinterpret_cast<uint16_t *>(t + o_long);
+        a.out_len = reinterpret_cast<uint64_t *>(t + o_len);
+        a.n_rec = reinterpret_cast<uint64_t *>(t + o_nrec);
+        a.end_bit = reinterpret_cast<uint64_t *>(t + o_ebit);
+        a.link = reinterpret_cast<int32_t *>(t + o_link);
+        a.n = (int)m;
+        PSK_HIP(ctx, hipMemsetAsync(t + o_link, 0xfe, m * 4, st));   // (a chunk without a start keeps a negative link)
+        gz_decode_kernel<false><<<dim3((unsigned)div_up((uint64_t)m, 64)), dim3(64), GZ_LDS_U16 * 2, st>>>(a);
+        PSK_HIP(ctx, hipGetLastError());
+        std::vector<uint64_t> r_len(m), r_ebit(m), r_nrec(m);
+        std::vector<int32_t> r_link(m);
+        PSK_HIP(ctx, hipMemcpyAsync(r_len.data(), t + o_len, m * 8, hipMemcpyDeviceToHost, st));
+        PSK_HIP(ctx, hipMemcpyAsync(r_nrec.data(), t + o_nrec, m * 8, hipMemcpyDeviceToHost, st));
+        PSK_HIP(ctx, hipMemcpyAsync(r_ebit.data(), t + o_ebit, m * 8, hipMemcpyDeviceToHost, st));
+        PSK_HIP(ctx, hipMemcpyAsync(r_link.data(), t + o_link, m * 4, hipMemcpyDeviceToHost, st));
+        PSK_HIP(ctx, hipStreamSynchronize(st));
+        for (size_t j = 0; j < m; j++) {
+            GzChunk &c = ch[(size_t)todo[j]];
+            if (c.start_bit == GZ_NONE || !files[(size_t)c.file].device_ok) continue;
+            c.counted = true;
+            c.out_len = r_len[j];
+            c.n_rec = r_nrec[j];
+            c.end_bit = r_ebit[j];
+            c.link = r_link[j] >= 0 ? cand_chunk[(size_t)r_link[j]] : r_link[j];
+        }
+        todo.clear();
+        // the walk along the links
+        for (int i = 0; i < n; i++) {
+            GzFile &f = files[(size_t)i];
+            while (f.device_ok && next_chunk[(size_t)i] >= 0) {
+                const int cidx = next_chunk[(size_t)i];
+                GzChunk &c = ch[(size_t)cidx];
+                if (!c.counted) break;   // in `todo`: the next round
+                f.chain.push_back(cidx);
+                if (c.link >= 0) {
+                    next_chunk[(size_t)i] = c.link;
+                    continue;
+                }
+                if (c.link != GZ_FINAL) {
+                    f.device_ok = false;   // an error, or a block that ran on and on: zlib decides what it is
+                    break;
+                }
+                // the member's trailer; another member behind it?
+                const uint64_t trailer = (c.end_bit + 7) / 8 - f.at;
+                if (trailer + 8 > f.size) {
+                    f.device_ok = false;
+                    break;
+                }
+                size_t next = (size_t)trailer + 8;
+                {
+                    // ISIZE of the member that just ended: the bytes since its true start
+                    uint64_t member = 0;
+                    for (size_t q = f.chain.size(); q-- > 0;) {
+                        member += ch[(size_t)f.chain[q]].out_len;
+                        if (ch[(size_t)f.chain[q]].true_start) break;
+                    }
+                    if ((uint32_t)member != gz_le32(f.data + trailer + 4)) {
+                        f.device_ok = false;
+                        break;
+                    }
+                }
+                while (next < f.size && f.data[next] == 0) next++;   // padding (gzip.decompress skips it as well)
+                if (next >= f.size) {
+                    next_chunk[(size_t)i] = -1;
+                    break;
+                }
+                if (f.bgzf) {
+                    // the next member is the next chunk of the file
+                    next_chunk[(size_t)i] = cidx + 1 < file_chunks[(size_t)i].second ? cidx + 1 : -1;
+                    if (next_chunk[(size_t)i] < 0) f.device_ok = false;
+                    continue;
+                }
+                GzMemberHead h;
+                if (!gz_parse_member_header(f.data, f.size, next, &h)) {
+                    f.device_ok = false;
+                    break;
+                }
+                // a member in the middle of the file: it starts a chain of its own (a chunk whose found start this is
+                // becomes its first link; else one more chunk, counted in the next round)
+                const uint64_t sbit = (f.at + h.deflate_at) * 8;
+                int have = -1;
+                for (int q = file_chunks[(size_t)i].first; q < (int)ch.size(); q++)
+                    if (ch[(size_t)q].file == i && ch[(size_t)q].start_bit == sbit) have = q;
+                if (have >= 0) {
+                    ch[(size_t)have].true_start = true;   // (what it counted stays right: a valid stream has no match reaching back here)
+                    next_chunk[(size_t)i] = have;
+                    continue;
+                }
+                GzChunk extra;
+                extra.file = i;
+                extra.start_bit = sbit;
+                extra.seek_from = extra.seek_to = 0;
+                extra.true_start = true;
+                ch.push_back(extra);
+                todo.push_back((int)ch.size() - 1);
+                next_chunk[(size_t)i] = (int)ch.size() - 1;
+                break;
+            }
+        }
+    }
+    // ---- the layout of the text -----------------------------------------------------------------------------------
+    uint64_t total = GZ_WIN;   // (room before the first file: a marker of a corrupt stream reads inside the buffer)
+    std::vector<int> order;    // the chunks of the writing pass, file by file, in stream order
+    std::vector<uint32_t> file_first;
+    std::vector<uint64_t> c_off, c_rec;
+    uint64_t total_rec = 0;
+    for (int i = 0; i < n; i++) {
+        GzFile &f = files[(size_t)i];
+        if (!f.device_ok) continue;
+        total = (total + 63) & ~63ull;
+        f.out_off = total;
+        f.nul_slot = (int)file_first.size();
+        file_first.push_back((uint32_t)order.size());
+        for (int c : f.chain) {
+            order.push_back(c);
+            c_off.push_back(total);
+            total += ch[(size_t)c].out_len;
+            c_rec.push_back(total_rec);
+            total_rec += ch[(size_t)c].n_rec;
+        }
+        f.out_len = total - f.out_off;
+    }
+    file_first.push_back((uint32_t)order.size());
+    total = (total + 63) & ~63ull;
+    const size_t m = order.size();
+    std::vector<unsigned long long> nul_at;   // per file of the writing pass: where its text has its first NUL (in out_buf), ~0: nowhere
+    if (m) {
+        PSK_TRY(dev_reserve(ctx, sym_buf, total * 2 + 64));
+        PSK_TRY(dev_reserve(ctx, out_buf, total + 64));
+        PSK_TRY(dev_reserve(ctx, rec_buf, total_rec * 8 + 64));
+        size_t off = 0;
+        const size_t o_start = carve(off, m * 8), o_end = carve(off, m * 8), o_true = carve(off, m), o_stop = carve(off, m * 8), o_off = carve(off, m * 8),
+                     o_want = carve(off, m * 8), o_roff = carve(off, m * 8), o_wrec = carve(off, m * 8), o_ff = carve(off, file_first.size() * 4),
+                     o_cfile = carve(off, m * 4), o_nul = carve(off, file_first.size() * 8);
+        const size_t o_in_end = off;
+        const size_t o_len = carve(off, m * 8), o_nrec = carve(off, m * 8), o_ebit = carve(off, m * 8), o_link = carve(off, m * 4),
+                     o_long = carve(off, m * 640);
+        PSK_TRY(dev_reserve(ctx, tab_buf, off));
+        stage.assign(o_in_end, 0);
+        for (size_t j = 0; j < m; j++) {
+            const GzChunk &c = ch[(size_t)order[j]];
+            const GzFile &f = files[(size_t)c.file];
+            reinterpret_cast<uint64_t *>(stage.data() + o_start)[j] = c.start_bit;
+            reinterpret_cast<uint64_t *>(stage.data() + o_end)[j] = f.at + f.size;
+            stage[o_true + j] = c.true_start ? 1 : 0;
+            reinterpret_cast<uint64_t *>(stage.data() + o_stop)[j] = c.link == GZ_FINAL ? GZ_NONE : c.end_bit;
+            reinterpret_cast<uint64_t *>(stage.data() + o_off)[j] = c_off[j];
+            reinterpret_cast<uint64_t *>(stage.data() + o_want)[j] = c.out_len;
+            reinterpret_cast<uint64_t *>(stage.data() + o_roff)[j] = c_rec[j];
+            reinterpret_cast<uint64_t *>(stage.data() + o_wrec)[j] = c.n_rec;
+        }
+        std::memcpy(stage.data() + o_ff, file_first.data(), file_first.size() * 4);
+        for (size_t fi = 0; fi + 1 < file_first.size(); fi++)
+            for (uint32_t j = file_first[fi]; j < file_first[fi + 1]; j++) reinterpret_cast<uint32_t *>(stage.data() + o_cfile)[j] = (uint32_t)fi;
+        std::memset(stage.data() + o_nul, 0xff, file_first.size() * 8);
+        uint8_t *t = tab_buf.as<uint8_t>();
+        PSK_HIP(ctx, hipMemcpyAsync(t, stage.data(), o_in_end, hipMemcpyHostToDevice, st));
+        GzDecodeArgs a;
+        std::memset(&a, 0, sizeof a);
+        a.comp = d_comp;
+        a.start_bit = reinterpret_cast<const uint64_t *>(t + o_start);
+        a.end_byte = reinterpret_cast<const uint64_t *>(t + o_end);
+        a.true_start = t + o_true;
+        a.stop_bit = reinterpret_cast<const uint64_t *>(t + o_stop);
+        a.out_off = reinterpret_cast<const uint64_t *>(t + o_off);
+        a.want_len = reinterpret_cast<const uint64_t *>(t + o_want);
+        a.rec_off = reinterpret_cast<const uint64_t *>(t + o_roff);
+        a.want_rec = reinterpret_cast<const uint64_t *>(t + o_wrec);
+        a.sym = sym_buf.as<uint16_t>();
+        a.rec = rec_buf.as<uint2>();
+        a.long_syms = reinterpret_cast<uint16_t *>(t + o_long);
+        a.out_len = reinterpret_cast<uint64_t *>(t + o_len);
+        a.n_rec = reinterpret_cast<uint64_t *>(t + o_nrec);
+        a.end_bit = reinterpret_cast<uint64_t *>(t + o_ebit);
+        a.link = reinterpret_cast<int32_t *>(t + o_link);
+        a.n = (int)m;
+        gz_decode_kernel<true><<<dim3((unsigned)div_up((uint64_t)m, 64)), dim3(64), GZ_LDS_U16 * 2, st>>>(a);
+        PSK_HIP(ctx, hipGetLastError());
+        const uint64_t *d_off = reinterpret_cast<const uint64_t *>(t + o_off), *d_len = reinterpret_cast<const uint64_t *>(t + o_want);
+        gz_copy_kernel<<<dim3((unsigned)div_up((uint64_t)m, 4)), dim3(256), 0, st>>>(sym_buf.as<uint16_t>(), rec_buf.as<uint2>(), a.rec_off, a.want_rec, d_off, (int)m);
+        PSK_HIP(ctx, hipGetLastError());
+        unsigned long long *d_nul = reinterpret_cast<unsigned long long *>(t + o_nul);
+        gz_tails_kernel<<<dim3((unsigned)(file_first.size() - 1)), dim3(1024), 0, st>>>(sym_buf.as<uint16_t>(), out_buf.as<uint8_t>(), d_off, d_len,
+                                                                                     reinterpret_cast<const uint32_t *>(t + o_ff), d_nul);
+        PSK_HIP(ctx, hipGetLastError());
+        gz_resolve_kernel<<<dim3((unsigned)div_up(total, (uint64_t)256 * 8)), dim3(256), 0, st>>>(sym_buf.as<uint16_t>(), out_buf.as<uint8_t>(), d_off, d_len,
+                                                                                              reinterpret_cast<const uint32_t *>(t + o_cfile), (int)m, total,
+                                                                                              d_nul);
+        PSK_HIP(ctx, hipGetLastError());
+        nul_at.resize(file_first.size());
+        PSK_HIP(ctx, hipMemcpyAsync(nul_at.data(), d_nul, file_first.size() * 8, hipMemcpyDeviceToHost, st));
+        std::vector<int32_t> r_link(m);
+        PSK_HIP(ctx, hipMemcpyAsync(r_link.data(), t + o_link, m * 4, hipMemcpyDeviceToHost, st));
+        PSK_HIP(ctx, hipStreamSynchronize(st));
+        for (size_t j = 0; j < m; j++)
+            if (r_link[j] == GZ_ERROR)   // the second decode disagrees with the first: nothing of this file is trusted
+                files[(size_t)ch[(size_t)order[j]].file].device_ok = false;
+    }
+    if (device_ms) *device_ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t_begin).count();
+    int declined = 0;
+    for (int i = 0; i < n; i++) {
+        const GzFile &f = files[(size_t)i];
+        GzInflated &r = res[(size_t)i];
+        r.on_device = f.device_ok;
+        r.bgzf = f.bgzf;
+        r.chunks = (int)f.chain.size();
+        if (f.device_ok) {
+            r.off = f.out_off;
+            r.len = f.out_len;
+            r.first_nul = r.len;
+            if (f.nul_slot >= 0 && (size_t)f.nul_slot < nul_at.size() && nul_at[(size_t)f.nul_slot] != ~0ull) r.first_nul = nul_at[(size_t)f.nul_slot] - f.out_off;
+        } else {
+            declined++;
+            PSK_TRY(gz_host_inflate(ctx, f.data, f.size, r.host));
+            r.len = r.host.size();
+        }
+    }
+    if (std::getenv("PSK_TRACE"))
+        std::fprintf(stderr, "[psk] gz inflate: %d files, %zu chunks of %zu KB, %d counting round(s), %d declined (zlib on the host)\n", n, ch.size(),
+                     chunk >> 10, rounds, declined);
+    return PSK_OK;
+}
+
+void gz_release(psk_ctx *ctx)
+{
+    for (DevBuf *b : {&ctx->gz_comp, &ctx->gz_sym, &ctx->gz_rec, &ctx->gz_out, &ctx->gz_tab}) dev_release(*b);
+}
+
+// ---- C-ABI: the inflate on its own (tests, measurements) ------------------------------------------------------------
+extern "C" int psk_gz_inflate(psk_ctx *ctx, int n, const uint8_t *const *data, const size_t *sizes, uint8_t *const *out, const size_t *out_cap,
+                              uint64_t *out_len, int32_t *route, double *device_ms)
+{
+    if (!ctx) return PSK_EINVAL;
+    if (n < 0 || (n && (!data || !sizes || !out_len))) return psk_fail(ctx, PSK_EINVAL, "null buffer");
+    std::vector<GzInflated> res;
+    DevBuf comp, sym, recb, outb, tab;
+    int rc = gz_inflate_group(ctx, n, data, sizes, comp, sym, recb, outb, tab, res, device_ms);
+    if (rc == PSK_OK) {
+        for (int i = 0; i < n && rc == PSK_OK; i++) {
+            const GzInflated &r = res[(size_t)i];
+            out_len[i] = r.len;
+            if (route) route[i] = r.on_device ? (r.bgzf ? 2 : 1) : 0;
+            if (!out || !out[i]) continue;
+            if (!out_cap || out_cap[i] < r.len) {
+                rc = psk_fail(ctx, PSK_ERANGE, "file %d inflates to %llu bytes, the buffer holds %llu", i, (unsigned long long)r.len,
+                              (unsigned long long)(out_cap ? out_cap[i] : 0));
+                break;
+            }
+            if (r.on_device) {
+                if (r.len && hipMemcpy(out[i], outb.as<uint8_t>() + r.off, r.len, hipMemcpyDeviceToHost) != hipSuccess)
+                    rc = psk_fail(ctx, PSK_EHIP, "copying the inflated text failed");
+            } else if (r.len) {
+                std::memcpy(out[i], r.host.data(), r.len);
+            }
+        }
+    }
+    for (DevBuf *b : {&comp, &sym, &recb, &outb, &tab}) dev_release(*b);
+    return rc;
+}

@@ -657,7 +657,7 @@ static inline uint64_t *lane_frame_result(CountLane &L) { return reinterpret_cas
 // Stage A of a sample on buffer set L, on the copy stream: the upload and, for raw file bytes (format 1 FASTA,
 // 2 FASTQ; frame_gpu.hip), the framing kernels that turn them into the clean stream.  format 0: `src` is a clean
 // stream the host framed, `bytes` its padded length.  L.raw_ready fires when the clean stream is in L.raw.
-static int chain_upload(psk_ctx *ctx, CountLane &L, const uint8_t *src, uint64_t bytes, int format)
+static int chain_upload(psk_ctx *ctx, CountLane &L, const uint8_t *src, uint64_t bytes, int format, bool src_on_device = false)
 {
     PSK_TRY(lane_prepare(ctx, L));
     if (bytes == 0) return PSK_OK;
@@ -673,7 +673,7 @@ static int chain_upload(psk_ctx *ctx, CountLane &L, const uint8_t *src, uint64_t
         PSK_TRY(dev_reserve(ctx, L.rawin, bytes + 64));
         PSK_TRY(dev_reserve(ctx, L.raw, bytes + 128));
         PSK_TRY(dev_reserve(ctx, L.fr_scratch, frame_gpu_scratch_bytes(bytes)));
-        PSK_HIP(ctx, hipMemcpyAsync(L.rawin.p, src, bytes, hipMemcpyHostToDevice, cs));
+        PSK_HIP(ctx, hipMemcpyAsync(L.rawin.p, src, bytes, src_on_device ? hipMemcpyDeviceToDevice : hipMemcpyHostToDevice, cs));   // (a .gz sample: its text was inflated on the device)
         // the framing kernels run on their own stream: the copy stream goes on with the next sample's upload (PCIe is
         // the slowest stage of the ingest: ~100 us per 5-Mbp sample against ~25 us of framing and ~60 us of counting)
         PSK_HIP(ctx, hipEventRecord(L.up_done, cs));
@@ -949,10 +949,16 @@ static int parallel_fill(uint8_t *dst, const uint8_t *src, const char *path, siz
 
 // `paths` != nullptr: sample i is the file paths[i] of lens[i] bytes, read by the framing thread that takes it (plain
 // FASTA / FASTQ; compressed inputs come through the in-memory form after the host has inflated them)
-static int count_batch_impl(psk_ctx *ctx, int first_sample_idx, int n, const uint8_t *const *bytes, const char *const *paths,
+// gzs (may be null): sample i with gzs[i].dev != nullptr is a .gz input whose text is already on the device
+struct GzSample {
+    const uint8_t *dev = nullptr;
+    int fmt = 0;                 // as frame_probe reports
+    uint64_t roff = 0, rlen = 0; // its records
+};
+static int count_batch_core(psk_ctx *ctx, int first_sample_idx, int n, const uint8_t *const *bytes, const char *const *paths,
                             const size_t *lens, uint64_t *n_unique, uint64_t *n_total, int n_threads, int sketch_k,
                             int sketch_size, uint32_t sketch_seed, uint64_t *hashes_out, uint64_t *n_hashes_out, int k_window,
-                            const StreamConsumer *consumer)
+                            const StreamConsumer *consumer, const GzSample *gzs)
 {
     if (!ctx) return PSK_EINVAL;
     if (sketch_k != 0) {
@@ -966,6 +972,9 @@ static int count_batch_impl(psk_ctx *ctx, int first_sample_idx, int n, const uin
     }
     if (n == 0) return PSK_OK;
     if ((!bytes && !paths) || !lens) return psk_fail(ctx, PSK_EINVAL, "null input");
+    auto on_device = [&](int i) { return gzs && gzs[i].dev != nullptr; };
+    auto bytes_of = [&](int i) -> const uint8_t * { return bytes ? bytes[i] : nullptr; };
+    auto path_of = [&](int i) -> const char * { return (bytes && bytes[i]) || !paths ? nullptr : paths[i]; };
     PSK_HIP(ctx, hipSetDevice(ctx->device));
     if (n_threads < 1) n_threads = 1;
     if (n_threads > 16) n_threads = 16;
@@ -974,7 +983,7 @@ static int count_batch_impl(psk_ctx *ctx, int first_sample_idx, int n, const uin
     // an upper bound and the kernels read the number of kept words from device memory
     size_t max_len = 0;
     for (int i = 0; i < n; i++) {
-        if (paths ? !paths[i] : (!bytes[i] && lens[i])) return psk_fail(ctx, PSK_EINVAL, "null input %d", i);
+        if (!on_device(i) && !bytes_of(i) && !path_of(i) && lens[i]) return psk_fail(ctx, PSK_EINVAL, "null input %d", i);
         if (lens[i] > max_len) max_len = lens[i];
     }
     // read sets (hundreds of MB a sample): the copies into pinned memory share the host's memory bandwidth, so six of
@@ -1014,7 +1023,12 @@ static int count_batch_impl(psk_ctx *ctx, int first_sample_idx, int n, const uin
     // i, and nobody else touches the slot before that sample is ready) -- r04: all R slots up front, ~2 ms of page pinning each,
     // were 16-40 ms in front of the first upload of a process's first calls (20 slots for 5-Mbp genomes); now the first upload
     // waits for one slot and the others are pinned beside it, by the threads that would otherwise wait for their turn
-    const size_t slot_need = max_len + 2 * EX_SEG;
+    size_t max_host_len = 0;   // (the text of a .gz sample inflated on the device needs no pinned slot)
+    for (int i = 0; i < n; i++)
+        if (!on_device(i) && lens[i] > max_host_len) max_host_len = lens[i];
+    bool any_host = false;
+    for (int i = 0; i < n; i++) any_host = any_host || !on_device(i);
+    const size_t slot_need = any_host ? max_host_len + 2 * EX_SEG : 0;
     // FASTA and four-line FASTQ are framed on the GPU (frame_gpu.hip): the worker threads then only move file bytes
     // into pinned memory.  PSK_HOST_FRAMING=1 keeps the host state machine for everything (A/B runs, tests).
     const bool gpu_framing = getenv("PSK_HOST_FRAMING") == nullptr;
@@ -1049,21 +1063,24 @@ static int count_batch_impl(psk_ctx *ctx, int first_sample_idx, int n, const uin
             }
             uint64_t c = 0, p = 0, w = 0, ro = 0, rl = 0;
             int rc = 0, f = 0;
-            if (i < R && (!ctx->ring[i] || ctx->ring_cap[i] < slot_need)) {
+            if (slot_need && i < R && (!ctx->ring[i] || ctx->ring_cap[i] < slot_need)) {
                 if (hipSetDevice(ctx->device) != hipSuccess || ensure_pinned(ctx, &ctx->ring[i], &ctx->ring_cap[i], slot_need) != PSK_OK) rc = -3;
             }
             uint8_t *slot = static_cast<uint8_t *>(ctx->ring[i % R]);
             if (rc) {
                 // (no pinned memory: reported below)
+            } else if (on_device(i)) {
+                f = gzs[i].fmt;
+                ro = gzs[i].roff;
+                rl = gzs[i].rlen;
             } else if (gpu_framing) {
                 // file bytes straight into the pinned slot (by several threads when the sample is large and threads
                 // are idle); the probe finds where the records start and end
                 size_t nul_at = lens[i];
                 const auto tf = std::chrono::steady_clock::now();
-                rc = parallel_fill(slot, paths ? nullptr : bytes[i], paths ? paths[i] : nullptr, lens[i],
-                                   lens[i] >= (32u << 20) ? fill_helpers : 1, &nul_at);
+                rc = parallel_fill(slot, bytes_of(i), path_of(i), lens[i], lens[i] >= (32u << 20) ? fill_helpers : 1, &nul_at);
                 t_fill_us += (long long)(std::chrono::duration<double>(std::chrono::steady_clock::now() - tf).count() * 1e6);
-                if (rc == 0 && paths && lens[i] >= 2 && slot[0] == 0x1f && slot[1] == 0x8b) rc = -2;   // gzip: the caller inflates
+                if (rc == 0 && path_of(i) && lens[i] >= 2 && slot[0] == 0x1f && slot[1] == 0x8b) rc = -2;   // gzip (PSK_NO_GPU_GZ): the caller inflates
                 if (rc == 0) {
                     size_t st = 0, en = 0;
                     f = frame_probe_known_end(slot, nul_at, &st, &en);   // parallel_fill has found the NUL, if any
@@ -1071,9 +1088,9 @@ static int count_batch_impl(psk_ctx *ctx, int first_sample_idx, int n, const uin
                     rl = en - st;
                 }
             } else {
-                const uint8_t *src = bytes ? bytes[i] : nullptr;
-                if (paths) {
-                    rc = read_whole_file(paths[i], lens[i], file_buf);
+                const uint8_t *src = bytes_of(i);
+                if (path_of(i)) {
+                    rc = read_whole_file(path_of(i), lens[i], file_buf);
                     src = file_buf.data();
                     if (rc == 0 && lens[i] >= 2 && src[0] == 0x1f && src[1] == 0x8b) rc = -2;
                 }
@@ -1129,12 +1146,13 @@ static int count_batch_impl(psk_ctx *ctx, int first_sample_idx, int n, const uin
             t_worker += since(t0);
             if (state[i] == -2)
                 return psk_fail(ctx, PSK_EGZIP, "sample %d (%s) is gzip-compressed: inflate it and use the in-memory call",
-                                first_sample_idx + i, paths[i]);
+                                first_sample_idx + i, path_of(i) ? path_of(i) : "");
             if (state[i] == -3) return psk_fail(ctx, PSK_ENOMEM, "no pinned memory for sample %d (hipHostMalloc of %zu bytes failed)", first_sample_idx + i, slot_need);
             if (state[i] < 0)
-                return psk_fail(ctx, PSK_ERANGE, paths ? "reading or framing sample %d (%s) failed" : "framing of sample %d failed",
-                                first_sample_idx + i, paths ? paths[i] : "");
+                return psk_fail(ctx, PSK_ERANGE, path_of(i) ? "reading or framing sample %d (%s) failed" : "framing of sample %d failed",
+                                first_sample_idx + i, path_of(i) ? path_of(i) : "");
         }
+        if (on_device(i) && fmt[i]) return chain_upload(ctx, ctx->lane[i % NL], gzs[i].dev + roff[i], rlen[i], fmt[i], true);
         const uint8_t *slot = static_cast<const uint8_t *>(ctx->ring[i % R]);
         if (fmt[i]) return chain_upload(ctx, ctx->lane[i % NL], slot + roff[i], rlen[i], fmt[i]);
         if (wins[i] >= (1ull << 32)) return psk_fail(ctx, PSK_ERANGE, "sample with more than 2^32 windows");
@@ -1156,8 +1174,14 @@ static int count_batch_impl(psk_ctx *ctx, int first_sample_idx, int n, const uin
                 // not four-line FASTQ (multi-line records, blank lines): the host state machine frames this sample
                 PSK_TRY(ensure_pinned(ctx, &ctx->pinned, &ctx->pinned_cap, rlen[i] + 2 * EX_SEG));
                 uint64_t c = 0, p = 0, w = 0;
-                const int frc = frame_into(static_cast<uint8_t *>(ctx->pinned), ctx->pinned_cap,
-                                           static_cast<const uint8_t *>(ctx->ring[i % R]) + roff[i], rlen[i], &c, &p, k, &w);
+                std::vector<uint8_t> text;   // (a .gz sample inflated on the device: its text comes back for the host's state machine)
+                const uint8_t *records = on_device(i) ? nullptr : static_cast<const uint8_t *>(ctx->ring[i % R]) + roff[i];
+                if (!records) {
+                    text.resize(rlen[i]);
+                    PSK_HIP(ctx, hipMemcpy(text.data(), gzs[i].dev + roff[i], rlen[i], hipMemcpyDeviceToHost));
+                    records = text.data();
+                }
+                const int frc = frame_into(static_cast<uint8_t *>(ctx->pinned), ctx->pinned_cap, records, rlen[i], &c, &p, k, &w);
                 if (frc) return psk_fail(ctx, frc, "framing of sample %d failed", first_sample_idx + i);
                 clen[i] = c; plen[i] = p; wins[i] = w; fmt[i] = 0;
                 PSK_TRY(chain_upload(ctx, L, static_cast<const uint8_t *>(ctx->pinned), w ? p : 0, 0));
@@ -1300,6 +1324,165 @@ static int count_batch_impl(psk_ctx *ctx, int first_sample_idx, int n, const uin
                         "in all), %.1f ms for uploads + framing, %.1f ms for chains; set-up %.1f ms\n", n, since(t_call) * 1e3, t_worker * 1e3,
                 t_fill_us.load() / 1e3, t_frame * 1e3, t_final * 1e3, t_setup * 1e3);
     return rc;
+}
+
+// The batch as the entry points hand it over.  Samples that are gzip images (magic bytes; glistmaker reads .gz through zlib:
+// SURVEY.md section 2 row 9) are inflated on the device first (gz_inflate.hip) -- every .gz sample of a run in one go, runs
+// cut where the text would pass PSK_GZ_GROUP_MB (6 GiB) -- and their chains then start from text that is already in device
+// memory; a member the device route declines has been inflated by zlib on the host and goes on as an in-memory sample.
+static int count_batch_impl(psk_ctx *ctx, int first_sample_idx, int n, const uint8_t *const *bytes, const char *const *paths,
+                            const size_t *lens, uint64_t *n_unique, uint64_t *n_total, int n_threads, int sketch_k,
+                            int sketch_size, uint32_t sketch_seed, uint64_t *hashes_out, uint64_t *n_hashes_out, int k_window,
+                            const StreamConsumer *consumer)
+{
+    auto core = [&](int lo, int cnt, const uint8_t *const *b, const char *const *p, const size_t *l, const GzSample *g) {
+        return count_batch_core(ctx, first_sample_idx + lo, cnt, b, p, l, n_unique ? n_unique + lo : nullptr, n_total ? n_total + lo : nullptr,
+                                n_threads, sketch_k, sketch_size, sketch_seed, hashes_out ? hashes_out + (size_t)lo * sketch_size : nullptr,
+                                n_hashes_out ? n_hashes_out + lo : nullptr, k_window, consumer, g);
+    };
+    if (!ctx || n <= 0 || (!bytes && !paths) || !lens || getenv("PSK_NO_GPU_GZ")) return core(0, n, bytes, paths, lens, nullptr);
+    std::vector<char> is_gz((size_t)n, 0);
+    bool any = false;
+    for (int i = 0; i < n; i++) {
+        uint8_t m[2] = {0, 0};
+        if (lens[i] < 18) continue;
+        if (bytes && bytes[i]) {
+            m[0] = bytes[i][0];
+            m[1] = bytes[i][1];
+        } else if (paths && paths[i]) {
+            FILE *f = fopen(paths[i], "rb");
+            if (f) {
+                if (fread(m, 1, 2, f) != 2) m[0] = 0;
+                fclose(f);
+            }
+        }
+        is_gz[(size_t)i] = m[0] == 0x1f && m[1] == 0x8b;
+        any = any || is_gz[(size_t)i];
+    }
+    if (!any) return core(0, n, bytes, paths, lens, nullptr);
+    PSK_HIP(ctx, hipSetDevice(ctx->device));
+    // the compressed images of the files (a quarter of the text) are read run by run, by the threads the framing would use
+    std::vector<std::vector<uint8_t>> held((size_t)n);
+    auto read_images = [&](const std::vector<int> &idx) -> int {
+        std::atomic<int> next(0), failed(-1);
+        auto reader = [&]() {
+            for (;;) {
+                const int j = next.fetch_add(1);
+                if (j >= (int)idx.size()) return;
+                const int i = idx[(size_t)j];
+                if (bytes && bytes[i]) continue;
+                if (read_whole_file(paths[i], lens[i], held[(size_t)i])) failed = i;
+            }
+        };
+        std::vector<std::thread> pool;
+        const int nt = n_threads < 1 ? 1 : (n_threads > 16 ? 16 : n_threads);
+        for (int t = 1; t < nt && t < (int)idx.size(); t++) pool.emplace_back(reader);
+        reader();
+        for (auto &t : pool) t.join();
+        if (failed >= 0) return psk_fail(ctx, PSK_ERANGE, "reading sample %d (%s) failed", first_sample_idx + failed.load(), paths[failed.load()]);
+        return PSK_OK;
+    };
+    // ISIZE of the last member (the text of a one-member file, modulo 2^32): what a run's budget is counted in
+    auto isize_of = [&](int i) -> size_t {
+        uint8_t d[4] = {0, 0, 0, 0};
+        if (bytes && bytes[i]) {
+            memcpy(d, bytes[i] + lens[i] - 4, 4);
+        } else {
+            FILE *f = fopen(paths[i], "rb");
+            if (f) {
+                if (fseek(f, -4, SEEK_END) != 0 || fread(d, 1, 4, f) != 4) memset(d, 0, 4);
+                fclose(f);
+            }
+        }
+        return (size_t)d[0] | ((size_t)d[1] << 8) | ((size_t)d[2] << 16) | ((size_t)d[3] << 24);
+    };
+    auto image = [&](int i) -> const uint8_t * { return bytes && bytes[i] ? bytes[i] : held[(size_t)i].data(); };
+    const char *gm = getenv("PSK_GZ_GROUP_MB");
+    const size_t budget = (size_t)(gm && *gm ? strtoull(gm, nullptr, 10) : 6144) << 20;
+    const bool host_only = getenv("PSK_HOST_FRAMING") != nullptr;   // (the A/B knob of the host's state machine: the host's inflate with it)
+    std::vector<const uint8_t *> eb((size_t)n, nullptr);
+    std::vector<const char *> ep((size_t)n, nullptr);
+    std::vector<size_t> el((size_t)n, 0);
+    std::vector<GzSample> gs((size_t)n);
+    const bool trace = getenv("PSK_TRACE") != nullptr;
+    for (int lo = 0; lo < n;) {
+        int hi = lo;
+        size_t est = 0;
+        std::vector<int> idx;
+        while (hi < n) {
+            size_t e = 0;
+            if (is_gz[(size_t)hi]) {
+                e = isize_of(hi);
+                if (e < 3 * lens[hi]) e = 3 * lens[hi];
+            }
+            if (hi > lo && est + e > budget) break;
+            est += e;
+            if (is_gz[(size_t)hi]) idx.push_back(hi);
+            hi++;
+        }
+        std::vector<GzInflated> res(idx.size());
+        if (!idx.empty()) {
+            const auto t0 = std::chrono::steady_clock::now();
+            PSK_TRY(read_images(idx));
+            std::vector<const uint8_t *> ptrs;
+            std::vector<size_t> sizes;
+            for (int i : idx) {
+                ptrs.push_back(image(i));
+                sizes.push_back(lens[i]);
+            }
+            PSK_TRY(gz_inflate_group(ctx, (int)idx.size(), ptrs.data(), sizes.data(), ctx->gz_comp, ctx->gz_sym, ctx->gz_rec, ctx->gz_out, ctx->gz_tab, res,
+                                     nullptr, host_only));
+            if (trace) {
+                size_t text = 0, comp = 0;
+                for (size_t j = 0; j < idx.size(); j++) {
+                    text += res[j].len;
+                    comp += sizes[j];
+                }
+                const double ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
+                fprintf(stderr, "[psk] count batch: %zu .gz samples, %.1f MB -> %.1f MB of text in %.1f ms\n", idx.size(), comp / 1e6, text / 1e6, ms);
+            }
+        }
+        for (int i = lo; i < hi; i++) {
+            eb[(size_t)i] = bytes ? bytes[i] : nullptr;
+            ep[(size_t)i] = paths ? paths[i] : nullptr;
+            el[(size_t)i] = lens[i];
+            gs[(size_t)i] = GzSample();
+        }
+        std::vector<uint8_t> head;
+        for (size_t j = 0; j < idx.size(); j++) {
+            const int i = idx[j];
+            GzInflated &r = res[j];
+            ep[(size_t)i] = nullptr;
+            if (r.on_device) {
+                // where the records start decides the format (frame_probe): the first bytes of the text come back for that
+                const uint8_t *text = ctx->gz_out.as<uint8_t>() + r.off;
+                const size_t end = r.first_nul < r.len ? r.first_nul : r.len, look = end < 65536 ? end : 65536;
+                head.resize(look + 1);
+                if (look) PSK_HIP(ctx, hipMemcpy(head.data(), text, look, hipMemcpyDeviceToHost));
+                size_t st = 0, en = 0;
+                const int f = frame_probe_known_end(head.data(), look, &st, &en);
+                if (f || look == end) {
+                    gs[(size_t)i].dev = text;
+                    gs[(size_t)i].fmt = f;
+                    gs[(size_t)i].roff = f ? st : end;
+                    gs[(size_t)i].rlen = f ? end - st : 0;
+                    eb[(size_t)i] = nullptr;
+                    el[(size_t)i] = r.len;
+                    continue;
+                }
+                // no record in the first 64 KB: the whole text comes back and takes the in-memory route
+                r.host.resize(r.len);
+                PSK_HIP(ctx, hipMemcpy(r.host.data(), text, r.len, hipMemcpyDeviceToHost));
+                r.on_device = false;
+            }
+            eb[(size_t)i] = r.host.data();
+            el[(size_t)i] = r.host.size();
+        }
+        PSK_TRY(core(lo, hi - lo, eb.data() + lo, ep.data() + lo, el.data() + lo, gs.data() + lo));
+        for (int i : idx) std::vector<uint8_t>().swap(held[(size_t)i]);
+        lo = hi;
+    }
+    return PSK_OK;
 }
 
 extern "C" int psk_count_kmers_batch_sketch(psk_ctx *ctx, int first_sample_idx, int n, const uint8_t *const *bytes,

@@ -211,6 +211,7 @@ extern "C" int psk_build_presence(psk_ctx *ctx, uint64_t *n_kmers)
     if (ctx->n_in_flight > 0) return psk_fail(ctx, PSK_ESTATE, "a scan is in flight on this matrix: psk_scan_end first");
     if (ctx->k == 0) return psk_fail(ctx, PSK_ESTATE, "psk_begin has not been called");
     PSK_HIP(ctx, hipSetDevice(ctx->device));
+    gz_release(ctx);   // the ingest is over: what the .gz inputs were inflated in goes back before the matrix is allocated
     uint64_t total = 0;
     for (int i = 0; i < ctx->n_samples; i++) {
         if (!ctx->lists[i].done) return psk_fail(ctx, PSK_ESTATE, "sample %d has not been counted", i);

@@ -145,6 +145,7 @@ struct psk_ctx {
     size_t scan_pinned_cap = 0;
     void *cnt_pinned = nullptr;   // pinned landing buffer of the scan's result counters
     static constexpr int LANES = 24;
+    DevBuf gz_comp, gz_sym, gz_rec, gz_out, gz_tab;   // gz_inflate.hip: images, symbols, matches, text, tables of the group in hand (given back by psk_build_presence)
     DevBuf lane_slab;        // one allocation behind the buffer sets of a grouped batch (a cold run paid 60 ms for 170 hipMallocs)
     uint32_t *lane_pinned = nullptr;   // ... and one pinned block behind their counters (16 u32 per set)
     CountLane lane[LANES];   // sample i runs on set i % 3: i + 1 and i + 2 are uploaded / framed ahead while chain i runs; in groups
@@ -200,6 +201,18 @@ void reset_lists(psk_ctx *ctx, int n_samples);
 int arena_alloc(psk_ctx *ctx, size_t bytes, void **out);   // 256-byte aligned, freed by reset_lists
 void arena_release(psk_ctx *ctx);  // frees the per-sample lists, resizes to n_samples
 void comm_release(psk_ctx *ctx);   // comm.hip: destroys the context's RCCL communicator, if any
+
+// gz_inflate.hip: the text of one .gz image -- in the group's device buffer, or (the device route declined it) from zlib
+struct GzInflated {
+    bool on_device = false, bgzf = false;
+    int chunks = 0;
+    uint64_t off = 0, len = 0;
+    uint64_t first_nul = 0;   // on_device: where the text has its first NUL byte (len: nowhere)
+    std::vector<uint8_t> host;
+};
+void gz_release(psk_ctx *ctx);   // gives the five buffers above back to the device
+int gz_inflate_group(psk_ctx *ctx, int n, const uint8_t *const *data, const size_t *sizes, DevBuf &comp_buf, DevBuf &sym_buf, DevBuf &rec_buf, DevBuf &out_buf,
+                     DevBuf &tab_buf, std::vector<GzInflated> &res, double *device_ms, bool host_only = false);
 
 static inline unsigned div_up(uint64_t a, uint64_t b) { return (unsigned)((a + b - 1) / b); }
 

@@ -127,6 +127,25 @@ class PskContext:
         self._check(self._lib.psk_get_list(self._h, int(sample_idx), _ptr(words), _ptr(freqs), n_unique), "psk_get_list")
         return words, freqs
 
+    def gz_inflate(self, images, want_text=True):
+        """The text of gzip images, inflated on the device (csrc/gz_inflate.hip).  Returns (texts or None, lengths, routes,
+        device_ms); routes: 1 device, 2 device (BGZF), 0 zlib on the host.  want_text=False: lengths only (measurements)."""
+        images = [bytes(b) for b in images]
+        n = len(images)
+        ptrs = (ctypes.c_char_p * max(n, 1))(*images)
+        sizes = (ctypes.c_size_t * max(n, 1))(*[len(b) for b in images])
+        lens = np.zeros(max(n, 1), dtype=np.uint64)
+        route = np.zeros(max(n, 1), dtype=np.int32)
+        ms = ctypes.c_double()
+        self._check(self._lib.psk_gz_inflate(self._h, n, ptrs, sizes, None, None, _ptr(lens), _ptr(route), ctypes.byref(ms)), "psk_gz_inflate")
+        if not want_text:
+            return None, lens[:n].tolist(), route[:n].tolist(), ms.value
+        bufs = [np.empty(max(int(l), 1), dtype=np.uint8) for l in lens[:n]]
+        outp = (ctypes.c_void_p * max(n, 1))(*[b.ctypes.data for b in bufs])
+        caps = (ctypes.c_size_t * max(n, 1))(*[len(b) for b in bufs])
+        self._check(self._lib.psk_gz_inflate(self._h, n, ptrs, sizes, outp, caps, _ptr(lens), _ptr(route), ctypes.byref(ms)), "psk_gz_inflate")
+        return [b[:int(l)].tobytes() for b, l in zip(bufs, lens[:n])], lens[:n].tolist(), route[:n].tolist(), ms.value
+
     # -- multi-GPU ingest: slab ranges of sorted lists (dist.ListExchange) ---------------------------
     def lists_split(self, first_idx, n, bounds):
         """offsets[i][b] = number of words of sample first_idx + i below bounds[b] (a 0 after the first bound = end)."""

@@ -92,9 +92,10 @@ class Samples:
 
     @classmethod
     def get_kmer_lists_batched(cls, ctx, samples, n_threads, chunk=None):
-        """All samples through the batch counter: uncompressed files are read by the library's framing threads
-        (psk_count_kmers_files); compressed ones are read and inflated by a small thread pool here and handed over in
-        memory (psk_count_kmers_batch).  Host tokenisation runs ahead of the GPU inside the library either way."""
+        """All samples through the batch counter: the files are read by the library's own threads
+        (psk_count_kmers_files), .gz ones as they are -- the compressed image crosses PCIe and is inflated on the device
+        (csrc/gz_inflate.hip; r05).  With PSK_NO_GPU_GZ=1 compressed files are read and inflated by a thread pool here and
+        handed over in memory (psk_count_kmers_batch), as until r04."""
         from concurrent.futures import ThreadPoolExecutor
         if chunk is None:  # about half a gigabyte of file images per call, two calls' worth in memory
             try:
@@ -115,7 +116,8 @@ class Samples:
         inflaters = max(n_threads, min(int(getattr(Input, "num_threads", n_threads) or n_threads), os.cpu_count() or n_threads))
         with ThreadPoolExecutor(max_workers=inflaters) as pool:
             # (two bytes per file, read here: through the pool the 1,024 futures of a 1,024-genome run cost 45 ms, the reads 10)
-            zipped = [s.address.endswith(".gz") or formats.is_gzip(s.address) for s in samples]
+            host_inflate = bool(os.environ.get("PSK_NO_GPU_GZ"))
+            zipped = [host_inflate and (s.address.endswith(".gz") or formats.is_gzip(s.address)) for s in samples]
             # (plain files never sit in this process's memory -- the library streams them through its pinned ring --, so
             # their calls grow to 512 samples: a call ends with its pipeline drained, ~3 ms each at 64 samples per call, 60 ms
             # of a 1,024-genome ingest (r04, PSK_TRACE); compressed ones keep the half gigabyte per call)

@@ -1,0 +1,212 @@
+"""Row a1's "(.gz)": DEFLATE decoded on the device (csrc/gz_inflate.hip) against zlib -- byte for byte.
+
+glistmaker reads .gz through zlib (Appendix B: "`.gz` accepted, output cmp-identical to plain"),
+so the checker is zlib itself (Python's gzip / zlib modules); the k-mer lists of .gz inputs are compared with the lists of
+the same text uploaded plain (which the glistmaker fixtures pin).  Every case asserts the ROUTE as well: a device decoder
+that quietly declined everything would pass a comparison of texts through its zlib fall-back."""
+import gzip
+import io
+import os
+import struct
+import zlib
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+
+def _fasta(n_bases, seed, width=60):
+    rng = np.random.default_rng(seed)
+    seq = np.frombuffer(b"ACGT", dtype=np.uint8)[rng.integers(0, 4, n_bases)]
+    # genes repeated here and there: matches at long distances
+    for _ in range(n_bases // 5000):
+        a, b, ln = int(rng.integers(0, n_bases - 600)), int(rng.integers(0, n_bases - 600)), int(rng.integers(30, 500))
+        seq[b:b + ln] = seq[a:a + ln]
+    lines = [b">contig_%d some description" % seed]
+    s = seq.tobytes()
+    lines += [s[i:i + width] for i in range(0, len(s), width)]
+    return b"\n".join(lines) + b"\n"
+
+
+def _fastq(n_reads, seed, rl=150):
+    rng = np.random.default_rng(seed)
+    genome = np.frombuffer(b"ACGT", dtype=np.uint8)[rng.integers(0, 4, 200_000)]
+    out = io.BytesIO()
+    for i in range(n_reads):
+        at = int(rng.integers(0, len(genome) - rl))
+        q = (rng.integers(0, 41, rl) + 33).astype(np.uint8)
+        out.write(b"@read_%d/1\n" % i + genome[at:at + rl].tobytes() + b"\n+\n" + q.tobytes() + b"\n")
+    return out.getvalue()
+
+
+def _bgzf(text, block=0xff00):
+    """BGZF as bgzip writes it: members of at most 64 KB with a 'BC' extra field holding their length, then the empty
+    end-of-file member."""
+    out = io.BytesIO()
+    pieces = [text[i:i + block] for i in range(0, len(text), block)] + [b""]
+    for piece in pieces:
+        co = zlib.compressobj(6, zlib.DEFLATED, -15)
+        raw = co.compress(piece) + co.flush()
+        bsize = 12 + 6 + len(raw) + 8
+        out.write(b"\x1f\x8b\x08\x04" + b"\0\0\0\0" + b"\0\xff" + struct.pack("<H", 6) + b"BC" + struct.pack("<HH", 2, bsize - 1))
+        out.write(raw + struct.pack("<II", zlib.crc32(piece), len(piece) & 0xffffffff))
+    return out.getvalue()
+
+
+def _named(text, level=6):
+    b = io.BytesIO()
+    with gzip.GzipFile(filename="reads_of_sample_1.fastq", mode="wb", fileobj=b, compresslevel=level, mtime=0) as f:
+        f.write(text)
+    return b.getvalue()
+
+
+def _cases():
+    rng = np.random.default_rng(7)
+    fa, fq = _fasta(400_000, 1), _fastq(3000, 2)
+    cases = {
+        "fasta level 6": gzip.compress(fa, 6),
+        "fasta level 1": gzip.compress(fa, 1),
+        "fasta level 9": gzip.compress(fa, 9),
+        "fastq level 6": gzip.compress(fq, 6),
+        "fastq with a name in the header": _named(fq),
+        "empty text": gzip.compress(b""),
+        "one byte": gzip.compress(b">"),
+        "incompressible (stored blocks)": gzip.compress(rng.integers(0, 256, 200_000, dtype=np.uint8).tobytes(), 6),
+        "one long run (distance 1)": gzip.compress(b"A" * 300_000 + b"\n", 9),
+        "short period": gzip.compress(b"ACGTTGCA" * 40_000, 6),
+        "fixed-code block": gzip.compress(b">s\nACGT\n", 6),
+        "two members": gzip.compress(fa[:150_000]) + gzip.compress(fq[:100_000]),
+        "five members and padding": b"".join(gzip.compress(fa[i * 40_000:(i + 1) * 40_000], 4) for i in range(5)) + b"\0" * 37,
+        "bgzf": _bgzf(fq),
+        "bgzf of nothing": _bgzf(b""),
+        "level 0": gzip.compress(fa[:100_000], 0),
+    }
+    return cases
+
+
+@pytest.mark.parametrize("chunk", [0, 4096, 20_000])
+def test_device_inflate_equals_zlib(chunk, monkeypatch):
+    """Every case in ONE call (files of a group are laid out and decoded together); chunk: the default cut (one chunk per
+    32 KB of a small file) and two small ones, so that texts of a few hundred KB are cut dozens of times."""
+    from phenotypeseeker_amd.engine import PskContext
+    if chunk:
+        monkeypatch.setenv("PSK_GZ_CHUNK", str(chunk))
+    cases = _cases()
+    names = list(cases)
+    with PskContext(0) as ctx:
+        texts, lens, routes, _ = ctx.gz_inflate([cases[k] for k in names])
+    for name, text, ln, route in zip(names, texts, lens, routes):
+        want = gzip.decompress(cases[name])
+        assert ln == len(want), (name, ln, len(want))
+        assert text == want, (name, next(i for i in range(len(want)) if text[i] != want[i]))
+        assert route == (2 if name.startswith("bgzf") else 1), (name, route)
+
+
+def test_many_chunks_and_links(monkeypatch):
+    """A 6-MB text: ~45 chunks by default; with a small cut several hundred, most of them starting on a header the search
+    found, every one linked to the next by the counting pass."""
+    from phenotypeseeker_amd.engine import PskContext
+    fa = _fasta(6_000_000, 11)
+    gz = gzip.compress(fa, 6)
+    for chunk in (0, 8192):
+        if chunk:
+            monkeypatch.setenv("PSK_GZ_CHUNK", str(chunk))
+        with PskContext(0) as ctx:
+            texts, lens, routes, _ = ctx.gz_inflate([gz, gz[:]])
+        assert routes == [1, 1] and texts[0] == fa and texts[1] == fa
+
+
+def test_corrupt_and_truncated_files_are_errors():
+    """What zlib refuses, the device route hands to zlib, and zlib's words are the error."""
+    from phenotypeseeker_amd.engine import PskContext, PskError
+    fa = _fasta(200_000, 3)
+    gz = bytearray(gzip.compress(fa, 6))
+    with PskContext(0) as ctx:
+        bad = bytes(gz[:len(gz) // 2])
+        with pytest.raises(PskError, match="not a valid gzip file"):
+            ctx.gz_inflate([bad])
+        flipped = bytearray(gz)
+        flipped[len(gz) // 2] ^= 0x55
+        try:
+            texts, _, routes, _ = ctx.gz_inflate([bytes(flipped)])
+        except PskError as e:
+            assert "not a valid gzip file" in str(e)
+        else:   # a flip zlib does not notice before the check sums either way: then the texts agree
+            assert texts[0] == zlib.decompress(bytes(flipped), 31)
+        with pytest.raises(PskError, match="not a valid gzip file"):
+            ctx.gz_inflate([b"\x1f\x8b\x08\x00 this is not deflate data, but it is long enough to be looked at"])
+        # and the context is still good
+        texts, _, routes, _ = ctx.gz_inflate([bytes(gz)])
+        assert texts[0] == fa and routes == [1]
+
+
+def _multi_line_fastq(n_reads, seed):
+    """Sequence and quality wrapped over two lines each: not four-line FASTQ, so the GPU framing hands the sample to the
+    host's state machine."""
+    rng = np.random.default_rng(seed)
+    out = io.BytesIO()
+    for i in range(n_reads):
+        seq = np.frombuffer(b"ACGT", dtype=np.uint8)[rng.integers(0, 4, 120)].tobytes()
+        out.write(b"@r%d\n" % i + seq[:70] + b"\n" + seq[70:] + b"\n+\n" + b"I" * 70 + b"\n" + b"I" * 50 + b"\n")
+    return out.getvalue()
+
+
+@pytest.mark.parametrize("k", [13, 16, 21])
+def test_counting_gz_samples_equals_counting_their_text(k, tmp_path, monkeypatch):
+    """.gz samples through the batch counter -- as images in memory and as files, mixed with plain samples, with sketches --
+    give the lists and sketches of their text; so do two runs of a call cut by a small PSK_GZ_GROUP_MB, an empty member and a
+    multi-line FASTQ file whose text has to come back for the host's state machine."""
+    from phenotypeseeker_amd.engine import PskContext
+    texts = [_fasta(150_000, 21), _fastq(1500, 22), _fasta(90_000, 23), b"", _multi_line_fastq(400, 24), _fastq(900, 25), b">only a header\n",
+             _fasta(60_000, 26)]
+    packed = [gzip.compress(t, 6) if i != 2 else t for i, t in enumerate(texts)]     # sample 2 stays plain
+    packed[5] = _bgzf(texts[5])
+    n = len(texts)
+    sk = (21, 1000, 42)
+    with PskContext(0) as ctx:
+        ctx.begin(k, n)
+        nu0, nt0, sk0 = ctx.count_kmers_batch(0, texts, 4, sketch=sk)
+        want = [ctx.get_list(i, nu0[i]) for i in range(n)]
+        for group_mb in (None, "1"):
+            if group_mb:
+                monkeypatch.setenv("PSK_GZ_GROUP_MB", group_mb)     # (1 MB of text a run: the call is cut into several)
+            ctx.begin(k, n)
+            nu1, nt1, sk1 = ctx.count_kmers_batch(0, packed, 4, sketch=sk)
+            assert list(nu1) == list(nu0) and list(nt1) == list(nt0)
+            for i in range(n):
+                w, f = ctx.get_list(i, nu1[i])
+                assert np.array_equal(w, want[i][0]) and np.array_equal(f, want[i][1]), (i, group_mb)
+                assert np.array_equal(sk1[i], sk0[i]), i
+        # the same from files, one sample at a time as well
+        paths = []
+        for i, b in enumerate(packed):
+            p = os.path.join(tmp_path, "s%d.%s" % (i, "seq" if i % 2 else "seq.gz"))     # (the name says nothing: magic bytes decide)
+            with open(p, "wb") as f:
+                f.write(b)
+            paths.append(p)
+        ctx.begin(k, n)
+        nu2, nt2 = ctx.count_kmers_files(0, paths, 4)
+        assert list(nu2) == list(nu0) and list(nt2) == list(nt0)
+        for i in range(n):
+            w, f = ctx.get_list(i, nu2[i])
+            assert np.array_equal(w, want[i][0]) and np.array_equal(f, want[i][1]), i
+        ctx.begin(k, 1)
+        nu3, nt3 = ctx.count_kmers(0, packed[1])
+        w, f = ctx.get_list(0, nu3)
+        assert nu3 == nu0[1] and np.array_equal(w, want[1][0]) and np.array_equal(f, want[1][1])
+
+
+def test_without_the_device_route_files_are_refused_as_before(tmp_path, monkeypatch):
+    """PSK_NO_GPU_GZ=1: a .gz FILE is answered with PSK_EGZIP (the caller inflates: modeling.py's thread pool), as until r04."""
+    from phenotypeseeker_amd._lib import PSK_EGZIP
+    from phenotypeseeker_amd.engine import PskContext, PskError
+    p = os.path.join(tmp_path, "a.fasta.gz")
+    with open(p, "wb") as f:
+        f.write(gzip.compress(_fasta(50_000, 5)))
+    monkeypatch.setenv("PSK_NO_GPU_GZ", "1")
+    with PskContext(0) as ctx:
+        ctx.begin(13, 1)
+        with pytest.raises(PskError) as e:
+            ctx.count_kmers_files(0, [p], 2)
+        assert e.value.code == PSK_EGZIP

@@ -1,0 +1,74 @@
+#!/usr/bin/env python3
+"""Throughput of the device inflate (csrc/gz_inflate.hip) on synthetic .fastq.gz / .fasta.gz images, with zlib on one host
+thread beside it.  python tools/gz_bench.py [fastq|fasta] [files] [MB of text per file] [level] [reps]"""
+import gzip
+import os
+import sys
+import time
+import zlib
+from concurrent.futures import ProcessPoolExecutor
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+
+
+def make(args):
+    kind, mb, seed, level = args
+    rng = np.random.default_rng(seed)
+    n = mb << 20
+    if kind == "fasta":
+        seq = np.frombuffer(b"ACGT", dtype=np.uint8)[rng.integers(0, 4, n)]
+        s = seq.tobytes()
+        text = b">contig\n" + b"\n".join(s[i:i + 60] for i in range(0, len(s), 60)) + b"\n"
+    else:
+        rl = 150
+        genome = np.frombuffer(b"ACGT", dtype=np.uint8)[rng.integers(0, 4, 5_000_000)]
+        n_reads = n // (2 * rl + 20)
+        at = rng.integers(0, len(genome) - rl, n_reads)
+        # qualities as sequencers write them: a few values, long runs
+        q = np.repeat((rng.choice([2, 14, 21, 27, 32, 36, 37], n_reads * 10, p=[.02, .03, .05, .1, .2, .3, .3]) + 33).astype(np.uint8), 15)
+        parts = []
+        for i in range(n_reads):
+            parts.append(b"@SIM:1:FCX:1:%d:%d:%d 1:N:0:ATCACG\n" % (i % 16, i * 7 % 20000, i * 13 % 20000))
+            parts.append(genome[at[i]:at[i] + rl].tobytes())
+            parts.append(b"\n+\n")
+            parts.append(q[i * rl:(i + 1) * rl].tobytes())
+            parts.append(b"\n")
+        text = b"".join(parts)
+    return gzip.compress(text, level), len(text), zlib.crc32(text)
+
+
+def main():
+    kind = sys.argv[1] if len(sys.argv) > 1 else "fastq"
+    files = int(sys.argv[2]) if len(sys.argv) > 2 else 8
+    mb = int(sys.argv[3]) if len(sys.argv) > 3 else 64
+    level = int(sys.argv[4]) if len(sys.argv) > 4 else 6
+    reps = int(sys.argv[5]) if len(sys.argv) > 5 else 3
+    t0 = time.time()
+    with ProcessPoolExecutor(min(files, os.cpu_count() or 4)) as ex:
+        made = list(ex.map(make, [(kind, mb, 100 + i, level) for i in range(files)]))
+    images = [m[0] for m in made]
+    text_bytes = sum(m[1] for m in made)
+    comp_bytes = sum(len(b) for b in images)
+    print("%d %s files: %.1f MB of text, %.1f MB compressed (level %d), made in %.1f s" % (files, kind, text_bytes / 1e6, comp_bytes / 1e6, level, time.time() - t0))
+    t0 = time.time()
+    one = zlib.decompress(images[0], 31)
+    t_host = time.time() - t0
+    print("zlib, one host thread: %.3f s for file 0 = %.3f GB/s of text" % (t_host, len(one) / t_host / 1e9))
+    from phenotypeseeker_amd.engine import PskContext
+    with PskContext(0) as ctx:
+        for r in range(reps):
+            t0 = time.time()
+            _, lens, routes, ms = ctx.gz_inflate(images, want_text=False)
+            wall = time.time() - t0
+            assert lens == [m[1] for m in made], "lengths differ"
+            print("device inflate: %.1f ms (call %.1f ms) = %.2f GB/s of text; routes %s" % (ms, wall * 1e3, text_bytes / ms / 1e6, sorted(set(routes))))
+        texts, _, _, _ = ctx.gz_inflate(images[:2])
+        assert [zlib.crc32(t) for t in texts] == [m[2] for m in made[:2]], "text differs"
+    print("ok")
+
+
+if __name__ == "__main__":
+    main()
