@@ -33,10 +33,12 @@
 #include <zlib.h>
 
 #include <algorithm>
+#include <atomic>
 #include <chrono>
 #include <cstdlib>
 #include <cstring>
 #include <string>
+#include <thread>
 #include <vector>
 
 namespace {
@@ -286,23 +288,96 @@ __device__ __forceinline__ bool gz_plausible_header(const uint8_t *comp, uint64_
     return true;
 }
 
-// one wave per search: the first bit offset in [from, to) at which a dynamic block header parses
+// the first 17 bits of a dynamic block that is not the last: BFINAL = 0, BTYPE = 10 (least significant bit first), HLIT and
+// HDIST in range -- one offset in nine passes
+__device__ __forceinline__ bool gz_header_start_ok(const uint8_t *comp, uint64_t bit)
+{
+    const uint32_t *w = reinterpret_cast<const uint32_t *>(comp) + (bit >> 5);
+    const uint64_t two = (uint64_t)w[0] | ((uint64_t)w[1] << 32);
+    const uint32_t v = (uint32_t)(two >> (bit & 31));
+    return (v & 7u) == 4u && ((v >> 3) & 31u) <= 29u && ((v >> 8) & 31u) <= 29u;
+}
+
+// the code-length code of such a header is complete (Kraft sum 1): one survivor in a few dozen
+__device__ __forceinline__ bool gz_precode_complete(const uint8_t *comp, uint64_t bit)
+{
+    BitIn in;
+    in.init(comp, bit + 13);
+    const int hclen = (int)in.take(4) + 4;
+    uint32_t sum = 0;
+#pragma unroll
+    for (int i = 0; i < 19; i++) {
+        if ((i & 7) == 0) in.need32();
+        if (i < hclen) {
+            const uint32_t l = in.take(3);
+            sum += l ? 128u >> l : 0u;
+        }
+    }
+    return sum == 128u;
+}
+
+// One wave per search: the first bit offset in [from, to) at which a dynamic block header parses.  Three sieves, each run
+// on FULL waves: the offsets that pass one wait in a queue (LDS, in order) until sixty-four of them are there for the next
+// -- the complete parse costs thousands of instructions and one offset in a thousand gets that far; run where it arises,
+// it would be executed by one lane while sixty-three wait.
 __global__ __launch_bounds__(64) void gz_find_kernel(const uint8_t *comp, const uint64_t *from, const uint64_t *to, const uint64_t *end_byte,
                                                       int n, uint64_t *found)
 {
+    __shared__ uint32_t q1[128], q2[128];
     const int c = blockIdx.x, lane = threadIdx.x;
     if (c >= n) return;
     const uint64_t b0 = from[c], b1 = to[c];
     const uint32_t *endw = reinterpret_cast<const uint32_t *>(comp + end_byte[c]) + 2;
+    uint32_t n1 = 0, n2 = 0;
     uint64_t hit = GZ_NONE;
-    for (uint64_t b = b0; b < b1; b += 64) {
-        const uint64_t bit = b + lane;
-        const bool ok = bit < b1 && gz_plausible_header(comp, bit, endw);
+    auto push = [&](uint32_t *q, uint32_t &nq, bool ok, uint32_t value) {
         const uint64_t m = __ballot(ok);
-        if (m) {
-            hit = b + (uint64_t)__ffsll((long long)m) - 1;
-            break;
+        if (ok) q[nq + __popcll(m & ((1ull << lane) - 1))] = value;
+        nq += (uint32_t)__popcll(m);
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+    };
+    // the complete parse of the first 64 (or all, at the end) of q2
+    auto sieve3 = [&](uint32_t take) {
+        const bool have = (uint32_t)lane < take;
+        const uint32_t off = have ? q2[lane] : 0;
+        const bool ok = have && gz_plausible_header(comp, b0 + off, endw);
+        const uint64_t m = __ballot(ok);
+        if (m) hit = b0 + (uint64_t)__builtin_amdgcn_readlane((int)off, __ffsll((long long)m) - 1);
+        const uint32_t rest = n2 - take;   // (the queue moves down)
+        const uint32_t moved = (uint32_t)lane < rest ? q2[take + lane] : 0;
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+        if ((uint32_t)lane < rest) q2[lane] = moved;
+        n2 = rest;
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+    };
+    auto sieve2 = [&](uint32_t take) {
+        const bool have = (uint32_t)lane < take;
+        const uint32_t off = have ? q1[lane] : 0;
+        const bool ok = have && gz_precode_complete(comp, b0 + off);
+        const uint32_t rest = n1 - take;
+        const uint32_t moved = (uint32_t)lane < rest ? q1[take + lane] : 0;
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+        if ((uint32_t)lane < rest) q1[lane] = moved;
+        n1 = rest;
+        push(q2, n2, ok, off);
+    };
+    for (uint64_t b = b0; b < b1 && hit == GZ_NONE; b += 64) {
+        const uint64_t bit = b + lane;
+        push(q1, n1, bit < b1 && gz_header_start_ok(comp, bit), (uint32_t)(bit - b0));
+        if (n1 >= 64) {
+            sieve2(64);
+            // (sixteen, not sixty-four: a header that has come this far is usually the true one, and the search would run on
+            // for another 64 K offsets before it is looked at)
+            if (n2 >= 16) sieve3(n2 < 64 ? n2 : 64);
         }
+    }
+    while (hit == GZ_NONE && (n1 || n2)) {
+        if (n1) sieve2(n1 < 64 ? n1 : 64);
+        while (hit == GZ_NONE && n2 && (n2 >= 64 || !n1)) sieve3(n2 < 64 ? n2 : 64);
     }
     if (lane == 0) found[c] = hit;
 }
@@ -590,55 +665,170 @@ __global__ __launch_bounds__(64) void gz_decode_kernel(GzDecodeArgs a)
 // One wave per chunk, 64 matches at a time, one per lane: a match whose source holds nothing that an earlier match of the
 // same 64 writes is copied at once (sixty-four loads in flight instead of one), the others in the rounds after the ones
 // they wait for.  A source that lies before the chunk is a marker: 256 + its place in the unknown window.
+constexpr int GZ_COPY_WIDE = 2;   // 16-byte pieces a lane has in flight
+
 __global__ __launch_bounds__(256) void gz_copy_kernel(uint16_t *sym, const uint2 *rec, const uint64_t *rec_off, const uint64_t *n_rec,
-                                                       const uint64_t *out_off, int n_chunks)
+                                                       const uint64_t *out_off, int n_chunks, unsigned long long *stats)
 {
-    const int lane = threadIdx.x & 63;
-    const int c = blockIdx.x * 4 + (threadIdx.x >> 6);
+    __shared__ uint32_t g_d[4][64], g_e[4][64], g_ld[4][64];   // the 64 matches in hand: first and last + 1 symbol written; length | distance << 16
+    __shared__ long long g_s[4][64];                           // where they read (after the redirections below)
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    const int c = blockIdx.x * 4 + wv;
     if (c >= n_chunks) return;
     uint16_t *out = sym + out_off[c];
     const uint2 *r = rec + rec_off[c];
     const uint64_t n = n_rec[c];
+    auto wave_sync = [] {
+        // the readers are lanes of this very wave: the stores only have to have left it (a fence of agent scope writes the
+        // L2 back on a part with eight of them)
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+    };
+    const uint2 none = make_uint2(0xffffffffu, 0);
+    uint2 x = lane < n ? r[lane] : none;
     for (uint64_t g = 0; g < n; g += 64) {
         const bool valid = g + lane < n;
-        const uint2 x = valid ? r[g + lane] : make_uint2(0, 0);
+        const uint2 nx = g + 64 + lane < n ? r[g + 64 + lane] : none;   // (the next 64, on their way while these are copied)
         const uint32_t d = x.x, len = x.y & 0xffffu, dist = x.y >> 16;
-        const int64_t s = (int64_t)d - (int64_t)dist;
-        const int64_t e = s + len < (int64_t)d ? s + len : (int64_t)d;   // (an overlapping match reads only what lies before it)
+        int64_t s = (int64_t)d - (int64_t)dist;
+        const int64_t span = len < dist ? len : dist;   // (an overlapping match reads only the `dist` symbols before it)
         const uint32_t d0 = (uint32_t)__builtin_amdgcn_readfirstlane((int)d);
         uint64_t dep = 0;
-        if (__ballot(valid && e > (int64_t)d0)) {
-            const int n_here = (int)(n - g < 64 ? n - g : 64);
-            for (int j = 0; j + 1 < n_here; j++) {
-                const uint32_t dj = (uint32_t)__builtin_amdgcn_readlane((int)d, j), ej = dj + (uint32_t)__builtin_amdgcn_readlane((int)len, j);
-                if (j < lane && (int64_t)dj < e && (int64_t)ej > s) dep |= 1ull << j;
+        if (stats && lane == 0) atomicAdd(stats + 0, 1ull);
+        if (__ballot(valid && s + span > (int64_t)d0)) {
+            // Some match reads what a match of these 64 writes.  A chain of them -- the header of a read copied from the header
+            // of the read before, that one from the one before it -- would be copied link by link, a memory round trip each;
+            // but a match that reads INSIDE an earlier (non-overlapping) match reads what that one read: it is pointed there,
+            // again and again, until its source is text that is already in place.
+            if (stats && lane == 0) atomicAdd(stats + 2, 1ull);
+            g_d[wv][lane] = d;
+            g_e[wv][lane] = valid ? d + len : 0xffffffffu;
+            g_ld[wv][lane] = x.y;
+            g_s[wv][lane] = s;
+            wave_sync();
+            // the first earlier match that ends behind `from` (the matches write ascending, disjoint ranges)
+            auto first_ending_behind = [&](int64_t from) {
+                int lo = -1, hi = lane;
+                while (hi - lo > 1) {
+                    const int mid = (lo + hi) >> 1;
+                    if ((int64_t)g_e[wv][mid] > from) hi = mid;
+                    else lo = mid;
+                }
+                return hi;   // lane: none
+            };
+            for (int hop = 0; hop < 64; hop++) {
+                bool moved = false;
+                if (valid && s >= (int64_t)d0) {
+                    const int i = first_ending_behind(s);
+                    if (i < lane) {
+                        const uint32_t di = g_d[wv][i], ldi = g_ld[wv][i], li = ldi & 0xffffu, disti = ldi >> 16;
+                        if ((int64_t)di <= s && s + span <= (int64_t)di + li && disti >= li) {
+                            s = g_s[wv][i] + (s - (int64_t)di);
+                            moved = true;
+                        }
+                    }
+                }
+                if (!__ballot(moved)) break;
+                if (stats && lane == 0) atomicAdd(stats + 3, 1ull);
+                if (moved) g_s[wv][lane] = s;   // (later matches pointed at this one follow it)
+                wave_sync();
+            }
+            // what is left: a match that reads part of what earlier ones write waits for them -- they are neighbours
+            const int64_t e = s + span;
+            if (valid && e > (int64_t)d0) {
+                const int i0 = first_ending_behind(s);
+                if (i0 < lane && (int64_t)g_d[wv][i0] < e) {
+                    int lo = i0, hi = lane;   // the last earlier match that starts before e
+                    while (hi - lo > 1) {
+                        const int mid = (lo + hi) >> 1;
+                        if ((int64_t)g_d[wv][mid] < e) lo = mid;
+                        else hi = mid;
+                    }
+                    dep = ((lo == 63 ? 0ull : (1ull << (lo + 1))) - 1ull) & ~((1ull << i0) - 1ull);
+                }
             }
         }
         uint64_t done = ~__ballot(valid);
+        if (stats) {
+            const uint64_t dm = __ballot(dep != 0);
+            if (lane == 0) atomicAdd(stats + 5, (unsigned long long)__popcll(dm));
+        }
+        // mode of the copy: 0 sixteen bytes a request (the addresses are two-byte aligned only: gfx950 takes unaligned global
+        // accesses); 1 a run whose period divides eight: one 16-byte pattern fills it; 2 symbol by symbol (markers before the
+        // chunk, other overlaps)
+        const int mode = s >= 0 && dist >= len ? 0 : (s >= 0 && (dist == 1 || dist == 2 || dist == 4) ? 1 : 2);
         while (~done) {
             const bool ready = !((done >> lane) & 1) && (dep & ~done) == 0;
-            if (ready) {
-                uint16_t *dst = out + d;
+            if (stats && lane == 0) atomicAdd(stats + 1, 1ull);
+            uint16_t *dst = out + d;
+            const uint16_t *src = out + s;
+            // ---- loads of everything this round copies in 16-byte pieces, then the stores: a load queued behind a store waits
+            // for the store's acknowledgement as well (one counter for both on this part)
+            uint32_t longest = ready && mode != 2 ? len : 0;
+            for (int o = 32; o; o >>= 1) {
+                const uint32_t t = (uint32_t)__shfl_xor((int)longest, o, 64);
+                longest = t > longest ? t : longest;
+            }
+            uint4 pat = make_uint4(0, 0, 0, 0);
+            if (ready && mode == 1) {
+                uint16_t p[4];
+#pragma unroll
+                for (int i = 0; i < 4; i++) p[i] = src[i % (int)dist];
+                const uint32_t lo = p[0] | ((uint32_t)p[1] << 16), hi = p[2] | ((uint32_t)p[3] << 16);
+                pat = make_uint4(lo, hi, lo, hi);
+            }
+            for (uint32_t j0 = 0; j0 < longest; j0 += 8 * GZ_COPY_WIDE) {
+                const bool here = ready && mode != 2 && j0 < len;
+                const uint32_t n_here = here ? (len - j0 < 8 * GZ_COPY_WIDE ? len - j0 : 8 * GZ_COPY_WIDE) : 0, nv = n_here >> 3, nt = n_here & 7;
+                uint4 v[GZ_COPY_WIDE];
+                uint16_t t[7];
+                if (mode == 0) {
+#pragma unroll
+                    for (int i = 0; i < GZ_COPY_WIDE; i++)
+                        if ((uint32_t)i < nv) __builtin_memcpy(&v[i], src + j0 + 8 * i, 16);
+#pragma unroll
+                    for (int i = 0; i < 7; i++)
+                        if ((uint32_t)i < nt) t[i] = src[j0 + 8 * nv + i];
+                } else {
+#pragma unroll
+                    for (int i = 0; i < GZ_COPY_WIDE; i++) v[i] = pat;
+#pragma unroll
+                    for (int i = 0; i < 7; i++) t[i] = (uint16_t)((i & 1 ? (i & 2 ? pat.y : pat.x) >> 16 : (i & 2 ? pat.y : pat.x)) & 0xffffu);
+                }
+#pragma unroll
+                for (int i = 0; i < GZ_COPY_WIDE; i++)
+                    if ((uint32_t)i < nv) __builtin_memcpy(dst + j0 + 8 * i, &v[i], 16);
+#pragma unroll
+                for (int i = 0; i < 7; i++)
+                    if ((uint32_t)i < nt) dst[j0 + 8 * nv + i] = t[i];
+            }
+            // ---- the rest, eight symbols at a time; the sources wrap at `dist` (an overlapping match repeats its first
+            // `dist` symbols), so every load reads text written before this match
+            if (__ballot(ready && mode == 2)) {
                 uint32_t k = 0;   // j mod dist
-                for (uint32_t j = 0; j < len; j += 8) {
+                uint32_t slow = ready && mode == 2 ? len : 0;
+                for (int o = 32; o; o >>= 1) {
+                    const uint32_t t = (uint32_t)__shfl_xor((int)slow, o, 64);
+                    slow = t > slow ? t : slow;
+                }
+                for (uint32_t j = 0; j < slow; j += 8) {
+                    const bool here = ready && mode == 2;
                     uint16_t v[8];
 #pragma unroll
                     for (int i = 0; i < 8; i++) {
                         const int64_t at = s + k;
-                        v[i] = at < 0 ? (uint16_t)(256 + GZ_WIN + at) : (j + i < len ? out[at] : (uint16_t)0);
+                        v[i] = at < 0 ? (uint16_t)(256 + GZ_WIN + at) : (here && j + i < len ? out[at] : (uint16_t)0);
                         k = k + 1 == dist ? 0 : k + 1;
                     }
 #pragma unroll
                     for (int i = 0; i < 8; i++)
-                        if (j + i < len) dst[j + i] = v[i];
+                        if (here && j + i < len) dst[j + i] = v[i];
                 }
             }
-            // what this round wrote, the next one (and the next 64 matches) may read: the readers are lanes of this very wave,
-            // so the stores only have to have left it (a fence of agent scope writes the L2 back on a part with eight of them)
-            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
-            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+            wave_sync();   // what this round wrote, the next one (and the next 64 matches) may read
             done |= __ballot(ready);
         }
+        x = nx;
     }
 }
 
@@ -649,16 +839,46 @@ __global__ __launch_bounds__(256) void gz_copy_kernel(uint16_t *sym, const uint2
 __global__ __launch_bounds__(1024) void gz_tails_kernel(const uint16_t *sym, uint8_t *out, const uint64_t *off, const uint64_t *len,
                                                          const uint32_t *file_first, unsigned long long *first_nul)
 {
+    // the window of the chunk in hand -- the 32 KB of text before it -- as a ring in LDS: position w is ring[(head + w) % 32K];
+    // the symbols of the next chunk's tail are loaded while this one's are resolved (a file's chunks are a serial chain:
+    // what is waited for per link is what the chain costs)
+    __shared__ uint8_t ring[GZ_WIN];
     const uint32_t c0 = file_first[blockIdx.x], c1 = file_first[blockIdx.x + 1];
-    for (uint32_t c = c0; c < c1; c++) {
-        const uint64_t L = len[c], t = L < GZ_WIN ? L : GZ_WIN, base = off[c] + L - t, win = off[c] - GZ_WIN;
-        for (uint64_t i = threadIdx.x; i < t; i += 1024) {
-            const uint32_t s = sym[base + i];
-            const uint8_t b = s < 256 ? (uint8_t)s : out[win + (s - 256)];
-            out[base + i] = b;
-            if (b == 0) atomicMin(first_nul + blockIdx.x, (unsigned long long)(base + i));
+    const uint32_t tid = threadIdx.x;
+    uint32_t head = 0;
+    uint16_t cur[32], nxt[32];
+    auto load = [&](uint32_t c, uint16_t (&v)[32]) {
+        const uint64_t L = len[c], t = L < GZ_WIN ? L : GZ_WIN, base = off[c] + L - t;
+#pragma unroll
+        for (int j = 0; j < 32; j++) {
+            const uint32_t i = tid + j * 1024;
+            v[j] = i < t ? sym[base + i] : (uint16_t)0;
         }
+    };
+    if (c0 < c1) load(c0, cur);
+    for (uint32_t c = c0; c < c1; c++) {
+        if (c + 1 < c1) load(c + 1, nxt);
+        const uint64_t L = len[c], t = L < GZ_WIN ? L : GZ_WIN, base = off[c] + L - t;
+        uint8_t b[32];
+#pragma unroll
+        for (int j = 0; j < 32; j++) {
+            const uint32_t s = cur[j];
+            b[j] = s < 256 ? (uint8_t)s : ring[(head + (s - 256)) & (GZ_WIN - 1)];
+        }
+        __syncthreads();   // every marker has been looked up: the ring may take the new text
+#pragma unroll
+        for (int j = 0; j < 32; j++) {
+            const uint32_t i = tid + j * 1024;
+            if (i < t) {
+                ring[(head + i) & (GZ_WIN - 1)] = b[j];
+                out[base + i] = b[j];
+                if (b[j] == 0) atomicMin(first_nul + blockIdx.x, (unsigned long long)(base + i));
+            }
+        }
+        head = (head + (uint32_t)t) & (GZ_WIN - 1);
         __syncthreads();
+#pragma unroll
+        for (int j = 0; j < 32; j++) cur[j] = nxt[j];
     }
 }
 
@@ -703,6 +923,96 @@ __global__ __launch_bounds__(256) void gz_resolve_kernel(const uint16_t *sym, ui
         const uint8_t b = s < 256 ? (uint8_t)s : out[o - GZ_WIN + (s - 256)];
         out[p] = b;
         if (b == 0) atomicMin(first_nul + chunk_file[c], (unsigned long long)p);
+    }
+}
+
+// ---- step 6: the check sums ------------------------------------------------------------------------------------------
+// zlib ends a member by comparing the CRC-32 of its text with the trailer (inflate.c: "incorrect data check"); so does this.
+// A thread takes 4 KB of the text buffer: the CRC of every piece of a member inside it, moved to the member's end by a
+// multiplication with x^(8 * bytes behind the piece) modulo the CRC polynomial (the algebra of zlib's crc32_combine: the CRC
+// of a concatenation is the XOR of its pieces' CRCs so moved), XORed into the member's accumulator.
+constexpr uint32_t GZ_CRC_POLY = 0xedb88320u;
+constexpr int GZ_CRC_SEG = 4096;
+
+__device__ __forceinline__ uint32_t gz_mulmod(uint32_t a, uint32_t b)   // a(x) * b(x) mod P, bit 31 = x^0
+{
+    uint32_t p = 0;
+#pragma unroll 4
+    for (int i = 0; i < 32; i++) {
+        p ^= (a & 0x80000000u) ? b : 0u;
+        a <<= 1;
+        b = (b >> 1) ^ ((b & 1u) ? GZ_CRC_POLY : 0u);
+    }
+    return p;
+}
+
+__global__ __launch_bounds__(256) void gz_crc_kernel(const uint8_t *out, const uint64_t *m_begin, const uint64_t *m_len, int n_members, uint64_t first,
+                                                      uint64_t total, uint32_t *acc)
+{
+    __shared__ uint32_t tab[4][256];
+    __shared__ uint32_t x2n[32];   // x^(2^k) mod P
+    for (int i = threadIdx.x; i < 256; i += 256) {
+        uint32_t c = (uint32_t)i;
+        for (int k = 0; k < 8; k++) c = (c >> 1) ^ ((c & 1u) ? GZ_CRC_POLY : 0u);
+        tab[0][i] = c;
+    }
+    __syncthreads();
+    for (int i = threadIdx.x; i < 256; i += 256) {
+        uint32_t c = tab[0][i];
+        for (int t = 1; t < 4; t++) {
+            c = tab[0][c & 0xff] ^ (c >> 8);
+            tab[t][i] = c;
+        }
+    }
+    if (threadIdx.x == 0) {
+        uint32_t p = 1u << 30;   // x^1
+        x2n[0] = p;
+        for (int k = 1; k < 32; k++) x2n[k] = p = gz_mulmod(p, p);
+    }
+    __syncthreads();
+    const uint64_t p0 = first + ((uint64_t)blockIdx.x * 256 + threadIdx.x) * GZ_CRC_SEG;
+    if (p0 >= total) return;
+    const uint64_t p1 = p0 + GZ_CRC_SEG < total ? p0 + GZ_CRC_SEG : total;
+    int lo = -1, hi = n_members;   // the first member that ends behind p0
+    while (hi - lo > 1) {
+        const int mid = (lo + hi) >> 1;
+        if (m_begin[mid] + m_len[mid] > p0) hi = mid;
+        else lo = mid;
+    }
+    for (int m = hi; m < n_members; m++) {
+        const uint64_t b = m_begin[m], e = b + m_len[m];
+        if (b >= p1) break;
+        const uint64_t q0 = b > p0 ? b : p0, q1 = e < p1 ? e : p1;
+        if (q0 >= q1) continue;
+        uint32_t c = 0xffffffffu;
+        uint64_t q = q0;
+        while (q < q1 && (q & 3)) c = tab[0][(c ^ out[q++]) & 0xff] ^ (c >> 8);
+        while (q + 4 <= q1 && (q & 15)) {
+            c ^= *reinterpret_cast<const uint32_t *>(out + q);
+            c = tab[3][c & 0xff] ^ tab[2][(c >> 8) & 0xff] ^ tab[1][(c >> 16) & 0xff] ^ tab[0][c >> 24];
+            q += 4;
+        }
+        for (; q + 16 <= q1; q += 16) {
+            const uint4 v = *reinterpret_cast<const uint4 *>(out + q);
+            const uint32_t w[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+            for (int j = 0; j < 4; j++) {
+                c ^= w[j];
+                c = tab[3][c & 0xff] ^ tab[2][(c >> 8) & 0xff] ^ tab[1][(c >> 16) & 0xff] ^ tab[0][c >> 24];
+            }
+        }
+        for (; q + 4 <= q1; q += 4) {
+            c ^= *reinterpret_cast<const uint32_t *>(out + q);
+            c = tab[3][c & 0xff] ^ tab[2][(c >> 8) & 0xff] ^ tab[1][(c >> 16) & 0xff] ^ tab[0][c >> 24];
+        }
+        while (q < q1) c = tab[0][(c ^ out[q++]) & 0xff] ^ (c >> 8);
+        c ^= 0xffffffffu;
+        // behind the piece, inside the member: e - q1 bytes
+        uint64_t nbytes = e - q1;
+        uint32_t mul = 0x80000000u;   // x^0
+        for (int k = 3; nbytes; nbytes >>= 1, k++)
+            if (nbytes & 1) mul = gz_mulmod(x2n[k & 31], mul);
+        atomicXor(acc + m, gz_mulmod(mul, c));
     }
 }
 
@@ -776,12 +1086,16 @@ size_t gz_env(const char *name, size_t dflt)
     return s && *s ? (size_t)std::strtoull(s, nullptr, 10) : dflt;
 }
 
-int gz_host_inflate(psk_ctx *ctx, const uint8_t *d, size_t n, std::vector<uint8_t> &out)
+// zlib, every member of the file (what gzip.decompress and glistmaker's reader do); false: *err says why not
+bool gz_host_inflate(const uint8_t *d, size_t n, std::vector<uint8_t> &out, std::string *err)
 {
     out.clear();
     z_stream z;
     std::memset(&z, 0, sizeof z);
-    if (inflateInit2(&z, 15 + 16) != Z_OK) return psk_fail(ctx, PSK_EINVAL, "zlib: inflateInit2 failed");
+    if (inflateInit2(&z, 15 + 16) != Z_OK) {
+        *err = "zlib: inflateInit2 failed";
+        return false;
+    }
     out.resize(std::max<size_t>(n * 4, (size_t)1 << 16));
     size_t ip = 0, have = 0;
     for (;;) {
@@ -795,22 +1109,23 @@ int gz_host_inflate(psk_ctx *ctx, const uint8_t *d, size_t n, std::vector<uint8_
         ip += in_now - z.avail_in;
         have += room - z.avail_out;
         if (rc == Z_STREAM_END) {
-            while (ip < n && d[ip] == 0) ip++;   // padding; a further member?  (gzip.decompress reads them all)
+            while (ip < n && d[ip] == 0) ip++;   // padding; a further member?
             if (ip >= n) break;
             if (inflateReset(&z) != Z_OK) {
                 inflateEnd(&z);
-                return psk_fail(ctx, PSK_EINVAL, "zlib: inflateReset failed");
+                *err = "zlib: inflateReset failed";
+                return false;
             }
             continue;
         }
         if (rc == Z_OK || (rc == Z_BUF_ERROR && ip < n)) continue;
-        const std::string msg = rc == Z_BUF_ERROR ? "it ends inside a member" : (z.msg ? z.msg : "data error");
+        *err = std::string("not a valid gzip file: ") + (rc == Z_BUF_ERROR ? "it ends inside a member" : (z.msg ? z.msg : "data error"));
         inflateEnd(&z);
-        return psk_fail(ctx, PSK_EINVAL, "not a valid gzip file: %s", msg.c_str());
+        return false;
     }
     inflateEnd(&z);
     out.resize(have);
-    return PSK_OK;
+    return true;
 }
 
 }  // namespace
@@ -818,16 +1133,37 @@ int gz_host_inflate(psk_ctx *ctx, const uint8_t *d, size_t n, std::vector<uint8_
 // Inflates n gzip images.  The text of file i is out_dev[res[i].off, + res[i].len) when res[i].on_device, else
 // res[i].host (zlib on the host: the device route declined the file; *declined counts them).
 int gz_inflate_group(psk_ctx *ctx, int n, const uint8_t *const *data, const size_t *sizes, DevBuf &comp_buf, DevBuf &sym_buf, DevBuf &rec_buf, DevBuf &out_buf,
-                     DevBuf &tab_buf, std::vector<GzInflated> &res, double *device_ms, bool host_only)
+                     DevBuf &tab_buf, std::vector<GzInflated> &res, double *device_ms, bool host_only, int host_threads)
 {
     res.assign((size_t)n, GzInflated());
     if (device_ms) *device_ms = 0.0;
     if (n <= 0) return PSK_OK;
-    if (host_only) {
-        for (int i = 0; i < n; i++) {
-            PSK_TRY(gz_host_inflate(ctx, data[i], sizes[i], res[(size_t)i].host));
-            res[(size_t)i].len = res[(size_t)i].host.size();
-        }
+    // Few blocks, few lanes: a DEFLATE block is decoded by ONE lane, three orders of magnitude slower than a host core decodes
+    // it, so the device wins by numbers only -- from some tens of megabytes of compressed input on (PSK_GZ_DEVICE_MIN_MB, 48).
+    // Below that the members go through zlib on `host_threads` threads (what glistmaker does per file).
+    size_t comp_bytes = 0;
+    for (int i = 0; i < n; i++) comp_bytes += sizes[i];
+    if (host_only || comp_bytes < (gz_env("PSK_GZ_DEVICE_MIN_MB", 48) << 20)) {
+        std::atomic<int> next(0), bad(0);
+        std::vector<std::string> errs((size_t)n);
+        auto work = [&]() {
+            for (;;) {
+                const int i = next.fetch_add(1);
+                if (i >= n) return;
+                if (!gz_host_inflate(data[i], sizes[i], res[(size_t)i].host, &errs[(size_t)i])) bad = 1;
+                res[(size_t)i].len = res[(size_t)i].host.size();
+            }
+        };
+        std::vector<std::thread> pool;
+        const int nt = host_threads < 1 ? 1 : (host_threads > 32 ? 32 : host_threads);
+        for (int t = 1; t < nt && t < n; t++) pool.emplace_back(work);
+        work();
+        for (auto &t : pool) t.join();
+        if (bad)
+            for (int i = 0; i < n; i++)
+                if (!errs[(size_t)i].empty()) return psk_fail(ctx, PSK_EINVAL, "%s", errs[(size_t)i].c_str());
+        if (std::getenv("PSK_TRACE"))
+            std::fprintf(stderr, "[psk] gz inflate: %d files, %.1f MB compressed: zlib on %d host threads\n", n, comp_bytes / 1e6, nt < n ? nt : n);
         return PSK_OK;
     }
     PSK_HIP(ctx, hipSetDevice(ctx->device));
@@ -844,7 +1180,7 @@ int gz_inflate_group(psk_ctx *ctx, int n, const uint8_t *const *data, const size
     // ---- the chunks --------------------------------------------------------------------------------------------
     size_t deflate_bytes = 0;
     for (int i = 0; i < n; i++) deflate_bytes += sizes[i];
-    const size_t want_lanes = gz_env("PSK_GZ_LANES", 32768);
+    const size_t want_lanes = gz_env("PSK_GZ_LANES", 65536);   // four waves on each of 256 CUs
     size_t chunk = gz_env("PSK_GZ_CHUNK", 0);
     if (!chunk) chunk = std::min<size_t>(std::max<size_t>(deflate_bytes / want_lanes, 32 << 10), 4 << 20);
     chunk = (chunk + 3) & ~(size_t)3;
@@ -898,6 +1234,18 @@ int gz_inflate_group(psk_ctx *ctx, int n, const uint8_t *const *data, const size
         file_chunks[i].second = (int)ch.size();
     }
     const auto t_begin = std::chrono::steady_clock::now();
+    const bool trace = std::getenv("PSK_TRACE") != nullptr;
+    auto t_last = t_begin;
+    std::string phases;
+    auto lap = [&](const char *what) {
+        if (!trace) return;
+        (void)hipStreamSynchronize(st);
+        const auto now = std::chrono::steady_clock::now();
+        char buf[96];
+        std::snprintf(buf, sizeof buf, " %s %.1f", what, std::chrono::duration<double, std::milli>(now - t_last).count());
+        phases += buf;
+        t_last = now;
+    };
     // ---- the images ---------------------------------------------------------------------------------------------
     PSK_TRY(dev_reserve(ctx, comp_buf, comp_total));
     PSK_HIP(ctx, hipMemsetAsync(comp_buf.p, 0, comp_total, st));
@@ -905,6 +1253,7 @@ int gz_inflate_group(psk_ctx *ctx, int n, const uint8_t *const *data, const size
         if (files[i].device_ok && sizes[i])
             PSK_HIP(ctx, hipMemcpyAsync(comp_buf.as<uint8_t>() + files[i].at, data[i], sizes[i], hipMemcpyHostToDevice, st));
     const uint8_t *d_comp = comp_buf.as<uint8_t>();
+    lap("upload");
 
     // device tables of one pass over `m` chunks, carved out of tab_buf
     auto carve = [&](size_t &off, size_t bytes) {
@@ -947,6 +1296,7 @@ int gz_inflate_group(psk_ctx *ctx, int n, const uint8_t *const *data, const size
             for (size_t j = 0; j < m; j++) ch[(size_t)seek[j]].start_bit = found[j];
         }
     }
+    lap("find");
     // the starts a block end may coincide with: per file, ascending
     std::vector<uint64_t> cand_bit;
     std::vector<int> cand_chunk;
@@ -1111,11 +1461,14 @@ int gz_inflate_group(psk_ctx *ctx, int n, const uint8_t *const *data, const size
             }
         }
     }
+    lap("count");
     // ---- the layout of the text -----------------------------------------------------------------------------------
     uint64_t total = GZ_WIN;   // (room before the first file: a marker of a corrupt stream reads inside the buffer)
     std::vector<int> order;    // the chunks of the writing pass, file by file, in stream order
     std::vector<uint32_t> file_first;
-    std::vector<uint64_t> c_off, c_rec;
+    std::vector<uint64_t> c_off, c_rec, m_begin, m_len;   // (m_*: the members, in the order of the text buffer)
+    std::vector<uint32_t> m_crc;
+    std::vector<int> m_file;
     uint64_t total_rec = 0;
     for (int i = 0; i < n; i++) {
         GzFile &f = files[(size_t)i];
@@ -1125,11 +1478,18 @@ int gz_inflate_group(psk_ctx *ctx, int n, const uint8_t *const *data, const size
         f.nul_slot = (int)file_first.size();
         file_first.push_back((uint32_t)order.size());
         for (int c : f.chain) {
+            const GzChunk &k = ch[(size_t)c];
             order.push_back(c);
             c_off.push_back(total);
-            total += ch[(size_t)c].out_len;
+            if (k.true_start) m_begin.push_back(total);
+            total += k.out_len;
             c_rec.push_back(total_rec);
-            total_rec += ch[(size_t)c].n_rec;
+            total_rec += k.n_rec;
+            if (k.link == GZ_FINAL) {   // the member's trailer: CRC-32, ISIZE
+                m_len.push_back(total - m_begin.back());
+                m_crc.push_back(gz_le32(f.data + ((k.end_bit + 7) / 8 - f.at)));
+                m_file.push_back(i);
+            }
         }
         f.out_len = total - f.out_off;
     }
@@ -1141,6 +1501,7 @@ int gz_inflate_group(psk_ctx *ctx, int n, const uint8_t *const *data, const size
         PSK_TRY(dev_reserve(ctx, sym_buf, total * 2 + 64));
         PSK_TRY(dev_reserve(ctx, out_buf, total + 64));
         PSK_TRY(dev_reserve(ctx, rec_buf, total_rec * 8 + 64));
+        lap("buffers");
         size_t off = 0;
         const size_t o_start = carve(off, m * 8), o_end = carve(off, m * 8), o_true = carve(off, m), o_stop = carve(off, m * 8), o_off = carve(off, m * 8),
                      o_want = carve(off, m * 8), o_roff = carve(off, m * 8), o_wrec = carve(off, m * 8), o_ff = carve(off, file_first.size() * 4),
@@ -1148,6 +1509,7 @@ int gz_inflate_group(psk_ctx *ctx, int n, const uint8_t *const *data, const size
         const size_t o_in_end = off;
         const size_t o_len = carve(off, m * 8), o_nrec = carve(off, m * 8), o_ebit = carve(off, m * 8), o_link = carve(off, m * 4),
                      o_long = carve(off, m * 640);
+        const size_t o_members = carve(off, 2 * ((m_begin.size() * 8 + 255) & ~(size_t)255) + m_begin.size() * 4 + 256);
         PSK_TRY(dev_reserve(ctx, tab_buf, off));
         stage.assign(o_in_end, 0);
         for (size_t j = 0; j < m; j++) {
@@ -1190,8 +1552,23 @@ int gz_inflate_group(psk_ctx *ctx, int n, const uint8_t *const *data, const size
         gz_decode_kernel<true><<<dim3((unsigned)div_up((uint64_t)m, 64)), dim3(64), GZ_LDS_U16 * 2, st>>>(a);
         PSK_HIP(ctx, hipGetLastError());
         const uint64_t *d_off = reinterpret_cast<const uint64_t *>(t + o_off), *d_len = reinterpret_cast<const uint64_t *>(t + o_want);
-        gz_copy_kernel<<<dim3((unsigned)div_up((uint64_t)m, 4)), dim3(256), 0, st>>>(sym_buf.as<uint16_t>(), rec_buf.as<uint2>(), a.rec_off, a.want_rec, d_off, (int)m);
+        unsigned long long *d_stats = nullptr;
+        if (std::getenv("PSK_GZ_STATS")) {
+            PSK_HIP(ctx, hipMalloc(reinterpret_cast<void **>(&d_stats), 64));
+            PSK_HIP(ctx, hipMemsetAsync(d_stats, 0, 64, st));
+        }
+        gz_copy_kernel<<<dim3((unsigned)div_up((uint64_t)m, 4)), dim3(256), 0, st>>>(sym_buf.as<uint16_t>(), rec_buf.as<uint2>(), a.rec_off, a.want_rec, d_off, (int)m,
+                                                                                   d_stats);
         PSK_HIP(ctx, hipGetLastError());
+        if (d_stats) {
+            unsigned long long hs[8];
+            PSK_HIP(ctx, hipStreamSynchronize(st));
+            PSK_HIP(ctx, hipMemcpy(hs, d_stats, 64, hipMemcpyDeviceToHost));
+            (void)hipFree(d_stats);
+            std::fprintf(stderr, "[psk] gz copy: %llu matches in %llu groups of 64, %llu with a source inside the group, %llu redirection hops, %llu matches left waiting, "
+                                 "%llu rounds\n",
+                         (unsigned long long)total_rec, hs[0], hs[2], hs[3], hs[5], hs[1]);
+        }
         unsigned long long *d_nul = reinterpret_cast<unsigned long long *>(t + o_nul);
         gz_tails_kernel<<<dim3((unsigned)(file_first.size() - 1)), dim3(1024), 0, st>>>(sym_buf.as<uint16_t>(), out_buf.as<uint8_t>(), d_off, d_len,
                                                                                      reinterpret_cast<const uint32_t *>(t + o_ff), d_nul);
@@ -1202,12 +1579,33 @@ int gz_inflate_group(psk_ctx *ctx, int n, const uint8_t *const *data, const size
         PSK_HIP(ctx, hipGetLastError());
         nul_at.resize(file_first.size());
         PSK_HIP(ctx, hipMemcpyAsync(nul_at.data(), d_nul, file_first.size() * 8, hipMemcpyDeviceToHost, st));
+        // the members' check sums (the tables go behind the writing pass's: tab_buf is grown before the pass, not here)
+        std::vector<uint32_t> crc_got(m_begin.size(), 0);
+        const bool check_crc = m_begin.size() == m_len.size() && !m_begin.empty() && !std::getenv("PSK_GZ_NO_CRC");
+        if (check_crc) {
+            const size_t nm = m_begin.size();
+            uint8_t *mt = tab_buf.as<uint8_t>() + o_members;
+            PSK_HIP(ctx, hipMemcpyAsync(mt, m_begin.data(), nm * 8, hipMemcpyHostToDevice, st));
+            PSK_HIP(ctx, hipMemcpyAsync(mt + ((nm * 8 + 255) & ~(size_t)255), m_len.data(), nm * 8, hipMemcpyHostToDevice, st));
+            uint32_t *d_acc = reinterpret_cast<uint32_t *>(mt + 2 * ((nm * 8 + 255) & ~(size_t)255));
+            PSK_HIP(ctx, hipMemsetAsync(d_acc, 0, nm * 4, st));
+            const uint64_t span = total - GZ_WIN;
+            gz_crc_kernel<<<dim3((unsigned)div_up(span, (uint64_t)256 * GZ_CRC_SEG)), dim3(256), 0, st>>>(
+                out_buf.as<uint8_t>(), reinterpret_cast<const uint64_t *>(mt), reinterpret_cast<const uint64_t *>(mt + ((nm * 8 + 255) & ~(size_t)255)), (int)nm,
+                (uint64_t)GZ_WIN, total, d_acc);
+            PSK_HIP(ctx, hipGetLastError());
+            PSK_HIP(ctx, hipMemcpyAsync(crc_got.data(), d_acc, nm * 4, hipMemcpyDeviceToHost, st));
+        }
         std::vector<int32_t> r_link(m);
         PSK_HIP(ctx, hipMemcpyAsync(r_link.data(), t + o_link, m * 4, hipMemcpyDeviceToHost, st));
         PSK_HIP(ctx, hipStreamSynchronize(st));
+        lap("write + matches + markers + crc");
         for (size_t j = 0; j < m; j++)
             if (r_link[j] == GZ_ERROR)   // the second decode disagrees with the first: nothing of this file is trusted
                 files[(size_t)ch[(size_t)order[j]].file].device_ok = false;
+        if (check_crc)
+            for (size_t q = 0; q < m_crc.size(); q++)
+                if (crc_got[q] != m_crc[q]) files[(size_t)m_file[q]].device_ok = false;   // zlib will say "incorrect data check"
     }
     if (device_ms) *device_ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t_begin).count();
     int declined = 0;
@@ -1224,13 +1622,14 @@ int gz_inflate_group(psk_ctx *ctx, int n, const uint8_t *const *data, const size
             if (f.nul_slot >= 0 && (size_t)f.nul_slot < nul_at.size() && nul_at[(size_t)f.nul_slot] != ~0ull) r.first_nul = nul_at[(size_t)f.nul_slot] - f.out_off;
         } else {
             declined++;
-            PSK_TRY(gz_host_inflate(ctx, f.data, f.size, r.host));
+            std::string why;
+            if (!gz_host_inflate(f.data, f.size, r.host, &why)) return psk_fail(ctx, PSK_EINVAL, "%s", why.c_str());
             r.len = r.host.size();
         }
     }
-    if (std::getenv("PSK_TRACE"))
-        std::fprintf(stderr, "[psk] gz inflate: %d files, %zu chunks of %zu KB, %d counting round(s), %d declined (zlib on the host)\n", n, ch.size(),
-                     chunk >> 10, rounds, declined);
+    if (trace)
+        std::fprintf(stderr, "[psk] gz inflate: %d files, %zu chunks of %zu KB, %d counting round(s), %d declined (zlib on the host); ms:%s\n", n, ch.size(),
+                     chunk >> 10, rounds, declined, phases.c_str());
     return PSK_OK;
 }
 
@@ -1246,8 +1645,9 @@ extern "C" int psk_gz_inflate(psk_ctx *ctx, int n, const uint8_t *const *data, c
     if (!ctx) return PSK_EINVAL;
     if (n < 0 || (n && (!data || !sizes || !out_len))) return psk_fail(ctx, PSK_EINVAL, "null buffer");
     std::vector<GzInflated> res;
-    DevBuf comp, sym, recb, outb, tab;
-    int rc = gz_inflate_group(ctx, n, data, sizes, comp, sym, recb, outb, tab, res, device_ms);
+    // (the context's buffers, kept for the next call: psk_begin / psk_build_presence / psk_free give them back)
+    DevBuf &outb = ctx->gz_out;
+    int rc = gz_inflate_group(ctx, n, data, sizes, ctx->gz_comp, ctx->gz_sym, ctx->gz_rec, ctx->gz_out, ctx->gz_tab, res, device_ms);
     if (rc == PSK_OK) {
         for (int i = 0; i < n && rc == PSK_OK; i++) {
             const GzInflated &r = res[(size_t)i];
@@ -1267,6 +1667,5 @@ extern "C" int psk_gz_inflate(psk_ctx *ctx, int n, const uint8_t *const *data, c
             }
         }
     }
-    for (DevBuf *b : {&comp, &sym, &recb, &outb, &tab}) dev_release(*b);
     return rc;
 }

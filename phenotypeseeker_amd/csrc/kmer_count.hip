@@ -1431,7 +1431,7 @@ static int count_batch_impl(psk_ctx *ctx, int first_sample_idx, int n, const uin
                 sizes.push_back(lens[i]);
             }
             PSK_TRY(gz_inflate_group(ctx, (int)idx.size(), ptrs.data(), sizes.data(), ctx->gz_comp, ctx->gz_sym, ctx->gz_rec, ctx->gz_out, ctx->gz_tab, res,
-                                     nullptr, host_only));
+                                     nullptr, host_only, n_threads));
             if (trace) {
                 size_t text = 0, comp = 0;
                 for (size_t j = 0; j < idx.size(); j++) {

@@ -16,6 +16,13 @@ import pytest
 pytestmark = pytest.mark.gpu
 
 
+@pytest.fixture(autouse=True)
+def _device_route_for_small_inputs(monkeypatch):
+    """The library sends groups of less than 48 MB of compressed input through zlib on host threads (a DEFLATE block is
+    decoded by one lane: the device wins by numbers only); the tests' inputs are small, and they are about the device."""
+    monkeypatch.setenv("PSK_GZ_DEVICE_MIN_MB", "0")
+
+
 def _fasta(n_bases, seed, width=60):
     rng = np.random.default_rng(seed)
     seq = np.frombuffer(b"ACGT", dtype=np.uint8)[rng.integers(0, 4, n_bases)]
@@ -136,6 +143,24 @@ def test_corrupt_and_truncated_files_are_errors():
             assert texts[0] == zlib.decompress(bytes(flipped), 31)
         with pytest.raises(PskError, match="not a valid gzip file"):
             ctx.gz_inflate([b"\x1f\x8b\x08\x00 this is not deflate data, but it is long enough to be looked at"])
+        # a flip that leaves a valid DEFLATE stream (a byte of a stored block; a literal of a compressed one): only the
+        # check sum of the member knows -- zlib's "incorrect data check", and the device route's
+        stored = bytearray(gzip.compress(fa[:50_000], 0))
+        stored[len(stored) // 2] ^= 0x01
+        with pytest.raises(PskError, match="incorrect data check"):
+            ctx.gz_inflate([bytes(stored)])
+        for at in range(len(gz) // 3, len(gz) // 3 + 40):
+            flipped = bytearray(gz)
+            flipped[at] ^= 0x04
+            try:
+                want = zlib.decompress(bytes(flipped), 31)
+            except zlib.error:
+                want = None
+            try:
+                got = ctx.gz_inflate([bytes(flipped)])[0][0]
+            except PskError:
+                got = None
+            assert got == want, at
         # and the context is still good
         texts, _, routes, _ = ctx.gz_inflate([bytes(gz)])
         assert texts[0] == fa and routes == [1]
@@ -210,3 +235,18 @@ def test_without_the_device_route_files_are_refused_as_before(tmp_path, monkeypa
         with pytest.raises(PskError) as e:
             ctx.count_kmers_files(0, [p], 2)
         assert e.value.code == PSK_EGZIP
+
+
+def test_small_groups_go_through_zlib_on_host_threads(monkeypatch):
+    """The default: below PSK_GZ_DEVICE_MIN_MB of compressed input a group is inflated by zlib (route 0), above it on the
+    device (route 1) -- the same text either way."""
+    from phenotypeseeker_amd.engine import PskContext
+    fa = _fasta(300_000, 31)
+    images = [gzip.compress(fa, 6), gzip.compress(fa[:100_000], 1), _bgzf(fa[:50_000])]
+    with PskContext(0) as ctx:
+        monkeypatch.delenv("PSK_GZ_DEVICE_MIN_MB")
+        texts, _, routes, _ = ctx.gz_inflate(images)
+        assert routes == [0, 0, 0] and texts == [fa, fa[:100_000], fa[:50_000]]
+        monkeypatch.setenv("PSK_GZ_DEVICE_MIN_MB", "0")
+        texts, _, routes, _ = ctx.gz_inflate(images)
+        assert routes == [1, 1, 2] and texts == [fa, fa[:100_000], fa[:50_000]]

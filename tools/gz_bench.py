@@ -40,6 +40,40 @@ def make(args):
     return gzip.compress(text, level), len(text), zlib.crc32(text)
 
 
+def make_fastq_like(args):
+    """One config-5-sized sample written twice: <dir>/s<i>.fastq and .fastq.gz (level 6).  Returns (plain path, gz path,
+    text bytes, gz bytes).  Reads of 150 bp drawn from a 5-Mbp genome with 0.5 % errors; names as an Illumina run writes
+    them; qualities from the eight bins of a NovaSeq, in runs."""
+    d, i, n_reads = args
+    rng = np.random.default_rng(1000 + i)
+    rl = 150
+    genome = np.frombuffer(b"ACGT", dtype=np.uint8)[rng.integers(0, 4, 5_000_000)]
+    parts = []
+    for r0 in range(0, n_reads, 100_000):     # (in blocks: the index arrays of two million reads at once are gigabytes)
+        nb = min(100_000, n_reads - r0)
+        at = rng.integers(0, len(genome) - rl, nb)
+        reads = genome[at[:, None] + np.arange(rl)[None, :]]
+        wrong = rng.integers(0, reads.size, int(reads.size * 0.005))
+        reads.reshape(-1)[wrong] = np.frombuffer(b"ACGT", dtype=np.uint8)[rng.integers(0, 4, len(wrong))]
+        runs = rng.choice(np.frombuffer(b"#+5?FFFF", dtype=np.uint8), (nb, 10), p=[.02, .03, .05, .1, .2, .2, .2, .2])
+        qual = np.repeat(runs, 15, axis=1)
+        for j in range(nb):
+            r = r0 + j
+            parts.append(b"@A00123:45:HXXXXXXXX:1:%d:%d:%d 1:N:0:ATCACGTT+AGGCTATA\n" % (1101 + r % 78, 1000 + r * 7 % 30000, 1000 + r * 13 % 35000))
+            parts.append(reads[j].tobytes())
+            parts.append(b"\n+\n")
+            parts.append(qual[j].tobytes())
+            parts.append(b"\n")
+    text = b"".join(parts)
+    plain, packed = os.path.join(d, "s%d.fastq" % i), os.path.join(d, "s%d.fastq.gz" % i)
+    with open(plain, "wb") as f:
+        f.write(text)
+    gz = gzip.compress(text, 6)
+    with open(packed, "wb") as f:
+        f.write(gz)
+    return plain, packed, len(text), len(gz)
+
+
 def main():
     kind = sys.argv[1] if len(sys.argv) > 1 else "fastq"
     files = int(sys.argv[2]) if len(sys.argv) > 2 else 8

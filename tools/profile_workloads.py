@@ -4,6 +4,8 @@
              sort of bucket_count.hip); 10 scans of the 6-GB matrix (well beyond the 256-MiB Infinity Cache)
   moments    the f64 scans on a device-generated 16 M x 1024 matrix: Welch t, GSC-weighted chi2, weighted Welch t
   fastq      one config-5 sample: 2 M x 150-bp reads, 0.63 GB of FASTQ, framed and counted
+  fastqgz    r05: N (default 16) config-5 samples as .fastq.gz files: counted from plain files, from the .gz files (inflated on the
+             device), the inflate alone, zlib on one host thread beside it
   ingest     config 2's ingest alone: 256 x 5 Mbp, k = 13, counted three times + presence build
   solver     the L1 (grid value, fold) fits of three recorded runs (143 fits each)
   predict    `prediction` counting (f1): 256 x 5 Mbp against a 1,000-word model dictionary, and a 5,000-word one (global table)
@@ -146,6 +148,47 @@ elif what == "fastq":
         alg["dc_hist_kernel"] = clean
         alg["dc_partition_kernel"] = clean + 2 * int(nt[0])
         alg["dc_count_kernel"] = 2 * int(nt[0]) + (1 << 26) // 8
+elif what == "fastqgz":
+    # r05: config-5 samples as sequencers ship them -- .fastq.gz.  N samples of 2 M x 150-bp reads (0.63 GB of text each,
+    # qualities in runs as Illumina bins them), gzip level 6, counted from files: plain, then compressed (the images cross
+    # PCIe and are inflated on the device: csrc/gz_inflate.hip), with zlib on one host thread beside it
+    import gzip
+    import shutil
+    import tempfile
+    import zlib
+    from concurrent.futures import ProcessPoolExecutor
+    sys.path.insert(0, os.path.join(ROOT, "tools"))
+    from gz_bench import make_fastq_like
+    n = int(sys.argv[2]) if len(sys.argv) > 2 else 16
+    tmp = tempfile.mkdtemp(prefix="psk_fastqgz_")
+    try:
+        t0 = time.time()
+        with ProcessPoolExecutor(min(n, os.cpu_count() or 4)) as ex:
+            made = list(ex.map(make_fastq_like, [(tmp, i, 2_000_000) for i in range(n)]))
+        t_make = time.time() - t0
+        plain, packed = [m[0] for m in made], [m[1] for m in made]
+        text_bytes, comp_bytes = sum(m[2] for m in made), sum(m[3] for m in made)
+        t0 = time.time()
+        with open(packed[0], "rb") as f:
+            one = zlib.decompress(f.read(), 31)
+        t_zlib = time.time() - t0
+        with PskContext(0) as ctx:
+            res = {}
+            for name, paths in (("plain", plain), ("gz", packed), ("plain_again", plain), ("gz_again", packed)):
+                ctx.begin(13, n)
+                t0 = time.time()
+                nu, nt = ctx.count_kmers_files(0, paths, 8)
+                res[name] = (round(time.time() - t0, 3), list(nu), list(nt))
+            assert res["plain"][1:] == res["gz"][1:] == res["gz_again"][1:], "the lists of the .gz samples differ"
+            _, _, routes, ms = ctx.gz_inflate([open(p, "rb").read() for p in packed], want_text=False)
+        out["notes"] = {"samples": n, "text_bytes": text_bytes, "gz_bytes": comp_bytes, "made_in_s": round(t_make, 1),
+                        "count_from_plain_files_s": [res["plain"][0], res["plain_again"][0]],
+                        "count_from_gz_files_s": [res["gz"][0], res["gz_again"][0]],
+                        "inflate_alone_ms": round(ms, 1), "inflate_alone_GBps_of_text": round(text_bytes / ms / 1e6, 1),
+                        "routes": sorted(set(routes)),
+                        "zlib_one_host_thread_GBps_of_text": round(len(one) / t_zlib / 1e9, 3)}
+    finally:
+        shutil.rmtree(tmp, ignore_errors=True)
 elif what == "ingest":
     n, L, k = 256, 5_000_000, 13
     gs = GenomeSet(n, L, seed=12345)
