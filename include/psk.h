@@ -31,7 +31,8 @@ enum {
     PSK_EHIP = -3,     /* a HIP runtime call failed */
     PSK_ERANGE = -4,   /* caller buffer too small / size limit exceeded */
     PSK_ESTATE = -5,   /* required earlier stage has not been run */
-    PSK_EGZIP = -6     /* a FILE input is gzip-compressed (magic bytes): the caller inflates it and uses the in-memory call */
+    PSK_EGZIP = -6     /* (with PSK_NO_GPU_GZ=1 only; r05: .gz inputs are inflated by the library) a FILE input is gzip-compressed
+                          (magic bytes): the caller inflates it and uses the in-memory call */
 };
 
 /* ---- lifecycle --------------------------------------------------------------------------- */
@@ -79,15 +80,16 @@ int psk_count_kmers_batch_sketch(psk_ctx *ctx, int first_sample_idx, int n, cons
                                  int sketch_k, int sketch_size, uint32_t sketch_seed, uint64_t *hashes_out,
                                  uint64_t *n_hashes_out);
 /* The same for UNCOMPRESSED files on disk (paths[i] of sizes[i] bytes): the framing threads read them, so no file
- * image crosses the caller's language boundary.  Compressed inputs go through the in-memory forms after the host has
- * inflated them (formats.read_sequence_file). */
+ * image crosses the caller's language boundary.  A .gz file is read as it is and inflated by the library (psk_gz_inflate
+ * below says how). */
 int psk_count_kmers_files(psk_ctx *ctx, int first_sample_idx, int n, const char *const *paths, const size_t *sizes,
                           uint64_t *n_unique, uint64_t *n_total, int n_threads, int sketch_k, int sketch_size,
                           uint32_t sketch_seed, uint64_t *hashes_out, uint64_t *n_hashes_out);
 /* .gz inputs ("FASTA/FASTQ(.gz)", glistmaker's zlib reader: SURVEY.md section 2 row 9).  psk_count_kmers /
  * psk_count_kmers_batch / psk_count_kmers_files take a gzip image (magic bytes 1f 8b) as it is: the compressed bytes
- * cross PCIe and DEFLATE is decoded on the device (csrc/gz_inflate.hip); a member the device route declines goes
- * through zlib on the host.  This entry point is the inflate on its own -- tests and measurements: n gzip images ->
+ * cross PCIe and DEFLATE is decoded on the device (csrc/gz_inflate.hip) -- all .gz samples of a call together, 6 GiB of text
+ * at a time (PSK_GZ_GROUP_MB); a group of less than 48 MB of compressed input (PSK_GZ_DEVICE_MIN_MB) and a member the device
+ * route declines go through zlib on the call's host threads.  This entry point is the inflate on its own -- tests and measurements: n gzip images ->
  * their text (out[i], of capacity out_cap[i], may be NULL: lengths only).  route[i]: 1 decoded on the device, 2 the same,
  * a BGZF file (its members found by their BSIZE fields), 0 zlib on the host.  device_ms: wall-clock of the device route,
  * upload included. */

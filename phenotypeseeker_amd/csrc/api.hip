@@ -198,7 +198,6 @@ extern "C" int psk_begin(psk_ctx *ctx, int k, int n_samples, uint64_t slab_lo, u
     ctx->bs_ready = false;   // the splitters of the bucketed sort belong to a run (its k, its slab)
     for (CountLane &L : ctx->lane) L.dc_slot = 0;   // the dense and the bucketed route lay the counter ring out differently: zero it again
     // a large slab of a grouped batch (long samples) does not stay beside the lists and the matrix of the next run
-    gz_release(ctx);
     if (ctx->lane_slab.cap > ((size_t)4 << 30)) {
         psk_forget_lane_slices(ctx);
         dev_release(ctx->lane_slab);

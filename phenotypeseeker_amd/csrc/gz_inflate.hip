@@ -1,32 +1,39 @@
 // .gz inputs (row a1's "FASTA/FASTQ(.gz)"): DEFLATE decoded on the GPU.
 //
 // The reference hands the path of a .gz file to glistmaker, whose zlib reader inflates it on one host thread per file
-// (SURVEY.md section 2 row 9, Appendix B).  Until r05 this package did the same on a pool of host threads -- ~0.35 GB/s
-// per thread of inflated text against the ~45 GB/s a PCIe link moves, so a read set in its usual form (.fastq.gz) was
-// bound by the host's inflate, twenty times below the upload (missing #7).  Here the COMPRESSED image
-// crosses PCIe (a quarter of the bytes) and is inflated on the device.
+// (SURVEY.md section 2 row 9, Appendix B).  Until r05 this package did the same on a pool of host threads -- ~0.5 GB/s of
+// text per thread against the ~45 GB/s a PCIe link moves, so a read set in its usual form (.fastq.gz) was bound by the
+// host's inflate (missing #7).  Here the COMPRESSED image crosses PCIe (a fifth of the bytes) and is inflated
+// on the device: 2 GB of .fastq.gz -> 9 GB of text in 0.24 s, upload included (tools/gz_bench.py; profiles/r05_gz_*).
 //
-// A DEFLATE stream is serial twice over: a Huffman code has to be decoded to know where the next one starts, and a
-// match copies from the 32 KB of text before it.  The way around both is the one pugz / rapidgzip take on CPUs
-// (Kerbiriou & Chikhi 2019; Knespel & Brunst 2023), laid out for 64-lane waves:
-//   1. gz_find_kernel     the stream is cut every `chunk` bytes; one wave per cut tests the bit offsets after it, 64 at
-//                         a time, for a dynamic-Huffman block header that parses completely (precode and both codes
-//                         complete, end-of-block coded): the first one that does is the chunk's start.
-//   2. gz_decode_kernel<false>   one LANE per chunk decodes from its start to the block end that coincides with a
-//                         later chunk's start, counting what it would write.  (A false positive of step 1 never
-//                         coincides with anything: the host's walk along the links from the true start of the member
-//                         drops it, and the chunk before it simply runs on.)
-//   3. host: the chain of chunks of every file, their output offsets; further members (cat a.gz b.gz; BGZF blocks
-//      are found by their BSIZE fields without any search), ISIZE checked.
-//   4. gz_decode_kernel<true>    the same decode, now writing 16-bit symbols: a byte, or -- for a match that reaches
-//                         back beyond the chunk's start -- 256 + its position in the unknown 32-KB window; copies of
-//                         such symbols copy the marker.
-//   5. gz_tails_kernel    one workgroup per file walks its chunks in order and resolves the last 32 KB of each (the
-//                         window of the next one);  gz_resolve_kernel then resolves everything else at once.
-// The decoder keeps both Huffman codes of a block as canonical-code limits in REGISTERS (the code length of the next
-// symbol is a chain of 14 compares, no table walk) and the symbols in LDS, 608 B per lane: four waves a CU.
-// A member the device declines (a block that runs on for megabytes without a dynamic header, a chain of more members
-// than the rounds allowed here, corrupt data) goes through zlib on the host, which also words the error.
+// A DEFLATE stream is serial twice over: a Huffman code has to be decoded to know where the next one starts, and a match
+// copies from the 32 KB of text before it.  The way around both is the one pugz / rapidgzip take on CPUs (Kerbiriou &
+// Chikhi 2019; Knespel & Brunst 2023) -- find block starts inside the stream, decode from each with the window unknown,
+// resolve the unknowns afterwards -- laid out for 64-lane waves and a quarter of a million lanes:
+//   1. gz_find_kernel     the stream is cut every `chunk` bytes (32 KB or more: 65,536 chunks fill the part); one wave per
+//                         cut sieves the bit offsets behind it for a dynamic-Huffman block header that parses completely
+//                         (code-length code, both codes complete or what zlib accepts instead, end-of-block coded).
+//   2. gz_decode_kernel<false>   one LANE per chunk decodes from its start to the block end that coincides with a later
+//                         chunk's start, counting the text and the matches it would write.  (A false positive of step 1
+//                         never coincides with anything: the host's walk along the links from the true start of the
+//                         member drops it, and the chunk before it simply runs on.)
+//   3. host               the chain of chunks of every file, their places in the text; further members (cat a.gz b.gz:
+//                         one more round of step 2 per member the search did not happen on; BGZF members are found by
+//                         their BSIZE fields without any search); ISIZE checked.
+//   4. gz_decode_kernel<true>    the same decode, now writing: literals as 16-bit symbols where they belong, matches as
+//                         records {place, length, distance}.
+//      gz_copy_kernel     one wave per chunk copies its matches, 64 at a time: a source before the chunk's start becomes
+//                         a marker -- 256 + its place in the unknown 32-KB window --, copies of markers copy the marker.
+//   5. gz_tails_kernel    one workgroup per file walks its chunks in order and resolves the last 32 KB of each (the window
+//                         of the next one, kept in LDS); gz_resolve_kernel then resolves everything else at once.
+//   6. gz_crc_kernel      the CRC-32 of every member against its trailer (pieces of 4 KB, combined by multiplication
+//                         modulo the CRC polynomial).
+// The decoder's tables are per lane: {length, symbol} over the next 8 (6) bits of the stream in LDS -- 640 B a lane, four waves
+// a CU --, the canonical limits of the longer codes in registers, their symbols in global memory.
+// What one lane decodes, it decodes a thousand times slower than a host core: the device wins by numbers only.  A group of
+// less than PSK_GZ_DEVICE_MIN_MB (48) of compressed input therefore goes through zlib on the call's host threads -- what
+// glistmaker does --, and so does a member the device declines (a block that runs on for megabytes without a dynamic
+// header, more members than the rounds allowed here, corrupt data: zlib then words the error).
 #include "dev_utils.h"
 #include "psk_internal.h"
 
@@ -1645,7 +1652,7 @@ extern "C" int psk_gz_inflate(psk_ctx *ctx, int n, const uint8_t *const *data, c
     if (!ctx) return PSK_EINVAL;
     if (n < 0 || (n && (!data || !sizes || !out_len))) return psk_fail(ctx, PSK_EINVAL, "null buffer");
     std::vector<GzInflated> res;
-    // (the context's buffers, kept for the next call: psk_begin / psk_build_presence / psk_free give them back)
+    // (the context's buffers, kept for the next call: psk_build_presence / psk_free give them back)
     DevBuf &outb = ctx->gz_out;
     int rc = gz_inflate_group(ctx, n, data, sizes, ctx->gz_comp, ctx->gz_sym, ctx->gz_rec, ctx->gz_out, ctx->gz_tab, res, device_ms);
     if (rc == PSK_OK) {
