@@ -28,8 +28,8 @@
 //                         of the next one, kept in LDS); gz_resolve_kernel then resolves everything else at once.
 //   6. gz_crc_kernel      the CRC-32 of every member against its trailer (pieces of 4 KB, combined by multiplication
 //                         modulo the CRC polynomial).
-// The decoder's tables are per lane: {length, symbol} over the next 8 (6) bits of the stream in LDS -- 640 B a lane, four waves
-// a CU --, the canonical limits of the longer codes in registers, their symbols in global memory.
+// The decoder's tables are per lane: {length, symbol} over the next 8 (5) bits of the stream in LDS -- 640 B a lane, four waves
+// a CU --, the canonical limits of the longer codes in registers, their symbols in LDS / registers (the overflow in global memory).
 // What one lane decodes, it decodes a thousand times slower than a host core: the device wins by numbers only.  A group of
 // less than PSK_GZ_DEVICE_MIN_MB (48) of compressed input therefore goes through zlib on the call's host threads -- what
 // glistmaker does --, and so does a member the device declines (a block that runs on for megabytes without a dynamic
@@ -410,12 +410,13 @@ struct GzDecodeArgs {
     int n;
 };
 
-constexpr int GZ_LIT_BITS = 8, GZ_DIST_BITS = 6;
-constexpr int GZ_LDS_U16 = ((1 << GZ_LIT_BITS) + (1 << GZ_DIST_BITS)) * 64;   // 40 KB a wave: four waves a CU
+constexpr int GZ_LIT_BITS = 8, GZ_DIST_BITS = 5, GZ_LONG_LDS = 32;
+constexpr int GZ_LDS_U16 = ((1 << GZ_LIT_BITS) + (1 << GZ_DIST_BITS) + GZ_LONG_LDS) * 64;   // 40 KB a wave: four waves a CU
 
-// The codes of a block, per lane: a table over the next 8 (6) bits of the stream in LDS -- {code length, symbol}, 0 for the
-// prefix of a longer code -- and, for the longer codes, the canonical limits in registers and the sorted symbols in
-// global memory (a FASTQ block has a handful of them).
+// The codes of a block, per lane: a table over the next 8 (5) bits of the stream in LDS -- {code length, symbol}, 0 for the
+// prefix of a longer code -- and, for the longer codes, the canonical limits in registers and the sorted symbols: the first
+// 32 literal/length ones in LDS, the distance ones packed into three registers, the rest (rare) in global memory.  A global
+// load in the symbol loop stalls the WAVE for a memory latency whenever any of its 64 lanes takes it.
 struct LongCodes {
     uint32_t lim[16];   // only the entries above the table's index width are used
     int32_t step[16];
@@ -461,7 +462,10 @@ __global__ __launch_bounds__(64) void gz_decode_kernel(GzDecodeArgs a)
     if (start == GZ_NONE) return;
     uint16_t *lt = gz_lds + lane;                               // entry t of this lane: lt[t * 64]
     uint16_t *dt = gz_lds + (1 << GZ_LIT_BITS) * 64 + lane;
-    uint16_t *lsym = a.long_syms + (size_t)c * 320, *dsym = lsym + 288;
+    uint16_t *ls = gz_lds + ((1 << GZ_LIT_BITS) + (1 << GZ_DIST_BITS)) * 64 + lane;   // long literal/length symbol i: ls[i * 64]
+    uint16_t *lsym = a.long_syms + (size_t)c * 320;
+    uint64_t dpk0 = 0, dpk1 = 0, dpk2 = 0;   // the long distance symbols, 5 bits each, twelve a register
+    uint32_t l_short = 0, d_short = 0;       // how many symbols the tables hold themselves
     const uint8_t *comp = a.comp;
     const uint32_t *endw = reinterpret_cast<const uint32_t *>(comp + a.end_byte[c]) + 2;
     const bool true_start = a.true_start[c] != 0;
@@ -570,6 +574,13 @@ __global__ __launch_bounds__(64) void gz_decode_kernel(GzDecodeArgs a)
                     o += dc.get(l);
                 }
             }
+            l_short = d_short = 0;
+#pragma unroll
+            for (int l = 1; l <= 15; l++) {
+                if (l <= GZ_LIT_BITS) l_short += lc.get(l);
+                if (l <= GZ_DIST_BITS) d_short += dc.get(l);
+            }
+            dpk0 = dpk1 = dpk2 = 0;
             // an incomplete code leaves bit patterns that are no code: they must not find an entry of the block before
             if (!lcomplete)
                 for (int t = 0; t < (1 << GZ_LIT_BITS); t++) lt[t * 64] = 0;
@@ -597,7 +608,17 @@ __global__ __launch_bounds__(64) void gz_decode_kernel(GzDecodeArgs a)
                         for (uint32_t t = r; t < (1u << bits); t += 1u << len) tab[t * 64] = e;
                     } else {
                         tab[(r & ((1u << bits) - 1)) * 64] = 0;
-                        (is_lit ? lsym : dsym)[at] = (uint16_t)value;
+                        if (is_lit) {
+                            const uint32_t rel = at - l_short;
+                            if (rel < GZ_LONG_LDS) ls[rel * 64] = (uint16_t)value;
+                            else lsym[at] = (uint16_t)value;
+                        } else {
+                            const uint32_t rel = at - d_short, q = rel / 12, sh = 5 * (rel % 12);
+                            const uint64_t bits5 = (uint64_t)value << sh;
+                            dpk0 |= q == 0 ? bits5 : 0;
+                            dpk1 |= q == 1 ? bits5 : 0;
+                            dpk2 |= q == 2 ? bits5 : 0;
+                        }
                     }
                 }
             };
@@ -624,7 +645,8 @@ __global__ __launch_bounds__(64) void gz_decode_kernel(GzDecodeArgs a)
                 int idx;
                 len = ll.decode<GZ_LIT_BITS + 1>(__brev(in.peek(15)) >> 17, &idx);
                 if (len > 15) break;
-                s = lsym[idx];
+                const uint32_t rel = (uint32_t)idx - l_short;
+                s = rel < GZ_LONG_LDS ? ls[rel * 64] : lsym[idx];
             }
             in.drop(len);
             if (s < 256) {
@@ -648,7 +670,8 @@ __global__ __launch_bounds__(64) void gz_decode_kernel(GzDecodeArgs a)
                 int idx;
                 len = ld.decode<GZ_DIST_BITS + 1>(__brev(in.peek(15)) >> 17, &idx);
                 if (len > 15) break;
-                ds = dsym[idx];
+                const uint32_t rel = (uint32_t)idx - d_short, q = rel / 12;
+                ds = (uint32_t)((q == 0 ? dpk0 : q == 1 ? dpk1 : dpk2) >> (5 * (rel % 12))) & 31;
             }
             in.drop(len);
             if (ds >= 30) break;
