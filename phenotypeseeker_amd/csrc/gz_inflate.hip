@@ -1022,6 +1022,20 @@ __global__ __launch_bounds__(256) void gz_crc_kernel(const uint8_t *out, const u
             c = tab[3][c & 0xff] ^ tab[2][(c >> 8) & 0xff] ^ tab[1][(c >> 16) & 0xff] ^ tab[0][c >> 24];
             q += 4;
         }
+        for (; q + 128 <= q1; q += 128) {   // a whole line a lane: each line of the text is fetched once
+            uint4 v[8];
+#pragma unroll
+            for (int i = 0; i < 8; i++) v[i] = *reinterpret_cast<const uint4 *>(out + q + 16 * i);
+#pragma unroll
+            for (int i = 0; i < 8; i++) {
+                const uint32_t w[4] = {v[i].x, v[i].y, v[i].z, v[i].w};
+#pragma unroll
+                for (int j = 0; j < 4; j++) {
+                    c ^= w[j];
+                    c = tab[3][c & 0xff] ^ tab[2][(c >> 8) & 0xff] ^ tab[1][(c >> 16) & 0xff] ^ tab[0][c >> 24];
+                }
+            }
+        }
         for (; q + 16 <= q1; q += 16) {
             const uint4 v = *reinterpret_cast<const uint4 *>(out + q);
             const uint32_t w[4] = {v.x, v.y, v.z, v.w};

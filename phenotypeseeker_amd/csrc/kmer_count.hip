@@ -1160,7 +1160,7 @@ static int count_batch_core(psk_ctx *ctx, int first_sample_idx, int n, const uin
     };
     // stage B: the counting chain, once the length of the clean stream is known on the host
     auto consume = [&](CountLane &L, int i, uint64_t clean_len, uint64_t n_windows, bool exact) -> int {
-        if (consumer) return (clean_len && n_windows) ? (*consumer)(L, i, clean_len) : PSK_OK;
+        if (consumer) return (clean_len && n_windows) ? (*consumer)(L, first_sample_idx + i, clean_len) : PSK_OK;   // (its callers count from 0; a call cut into runs goes on counting)
         return chain_compute(ctx, L, first_sample_idx + i, clean_len, n_windows, exact);
     };
     auto stage_b = [&](int i) -> int {

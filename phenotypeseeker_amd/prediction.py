@@ -43,8 +43,9 @@ class Samples:
         inflated here first), one kernel per sample, one read-back."""
         paths = [s.address for s in samples]
         counts = None
-        # gzip by the magic bytes (two bytes per file; the suffix alone is not trusted): such files are inflated here
-        zipped = any(p.endswith(".gz") or formats.is_gzip(p) for p in paths)
+        # .gz files go to the library as they are (r05: it inflates them, on the GPU when there is enough of them); with
+        # PSK_NO_GPU_GZ=1 they are recognised here by their magic bytes (the suffix alone is not trusted) and inflated here
+        zipped = bool(os.environ.get("PSK_NO_GPU_GZ")) and any(p.endswith(".gz") or formats.is_gzip(p) for p in paths)
         if not zipped:
             try:
                 counts = ctx.count_dict_files(paths, pheno.k, pheno.words, n_threads)

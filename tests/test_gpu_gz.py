@@ -250,3 +250,29 @@ def test_small_groups_go_through_zlib_on_host_threads(monkeypatch):
         monkeypatch.setenv("PSK_GZ_DEVICE_MIN_MB", "0")
         texts, _, routes, _ = ctx.gz_inflate(images)
         assert routes == [1, 1, 2] and texts == [fa, fa[:100_000], fa[:50_000]]
+
+
+def test_dictionary_counting_of_gz_samples(tmp_path, monkeypatch):
+    """`prediction`'s counting (psk_count_dict_files / _batch) takes .gz samples as they are as well; a call cut into several
+    inflate runs still fills every sample's row."""
+    from phenotypeseeker_amd.engine import PskContext
+    k = 13
+    texts = [_fasta(120_000, 40 + i) for i in range(5)] + [_fastq(800, 50)]
+    with PskContext(0) as ctx:
+        ctx.begin(k, 1)
+        nu, _ = ctx.count_kmers(0, texts[0])
+        words = ctx.get_list(0, nu)[0][::97][:300].copy()
+        want = ctx.count_dict_batch(texts, k, words, 4)
+        assert int(want.sum()) > 0
+        packed = [gzip.compress(t, 6) for t in texts]
+        paths = []
+        for i, b in enumerate(packed):
+            p = os.path.join(tmp_path, "p%d.fa.gz" % i)
+            with open(p, "wb") as f:
+                f.write(b)
+            paths.append(p)
+        for group_mb in (None, "1"):
+            if group_mb:
+                monkeypatch.setenv("PSK_GZ_GROUP_MB", group_mb)
+            assert np.array_equal(ctx.count_dict_batch(packed, k, words, 4), want)
+            assert np.array_equal(ctx.count_dict_files(paths, k, words, 4), want)

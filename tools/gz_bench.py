@@ -91,7 +91,9 @@ def main():
     one = zlib.decompress(images[0], 31)
     t_host = time.time() - t0
     print("zlib, one host thread: %.3f s for file 0 = %.3f GB/s of text" % (t_host, len(one) / t_host / 1e9))
+    import json
     from phenotypeseeker_amd.engine import PskContext
+    best = None
     with PskContext(0) as ctx:
         for r in range(reps):
             t0 = time.time()
@@ -99,9 +101,18 @@ def main():
             wall = time.time() - t0
             assert lens == [m[1] for m in made], "lengths differ"
             print("device inflate: %.1f ms (call %.1f ms) = %.2f GB/s of text; routes %s" % (ms, wall * 1e3, text_bytes / ms / 1e6, sorted(set(routes))))
+            best = ms if best is None or ms < best else best
         texts, _, _, _ = ctx.gz_inflate(images[:2])
         assert [zlib.crc32(t) for t in texts] == [m[2] for m in made[:2]], "text differs"
     print("ok")
+    # (for tools/summarise_profiles.py: what the streaming kernels of the inflate move per launch at the least -- the 16-bit
+    # symbols read and the text written by gz_resolve_kernel, the text read by gz_crc_kernel; the decoders are bound by the
+    # latency of one lane's serial work, not by bytes: no figure for them)
+    print(json.dumps({"workload": "gzinflate", "algorithmic_bytes_per_launch": {"gz_resolve_kernel": 3 * text_bytes, "gz_crc_kernel": text_bytes},
+                      "notes": {"files": files, "kind": kind, "gzip_level": level, "text_bytes": text_bytes, "gz_bytes": comp_bytes,
+                                "device_inflate_ms_best": round(best, 1), "GBps_of_text": round(text_bytes / best / 1e6, 1),
+                                "GBps_of_compressed_input": round(comp_bytes / best / 1e6, 1),
+                                "zlib_one_host_thread_GBps_of_text": round(len(one) / t_host / 1e9, 3)}}))
 
 
 if __name__ == "__main__":
