@@ -1633,8 +1633,9 @@ int gz_inflate_group(psk_ctx *ctx, int n, const uint8_t *const *data, const size
             PSK_HIP(ctx, hipMemcpyAsync(mt + ((nm * 8 + 255) & ~(size_t)255), m_len.data(), nm * 8, hipMemcpyHostToDevice, st));
             uint32_t *d_acc = reinterpret_cast<uint32_t *>(mt + 2 * ((nm * 8 + 255) & ~(size_t)255));
             PSK_HIP(ctx, hipMemsetAsync(d_acc, 0, nm * 4, st));
-            const uint64_t span = total - GZ_WIN;
-            gz_crc_kernel<<<dim3((unsigned)div_up(span, (uint64_t)256 * GZ_CRC_SEG)), dim3(256), 0, st>>>(
+            const uint64_t span = total - GZ_WIN;   // (nothing but empty texts: no launch; the check sums of empty members are 0)
+            if (span)
+                gz_crc_kernel<<<dim3((unsigned)div_up(span, (uint64_t)256 * GZ_CRC_SEG)), dim3(256), 0, st>>>(
                 out_buf.as<uint8_t>(), reinterpret_cast<const uint64_t *>(mt), reinterpret_cast<const uint64_t *>(mt + ((nm * 8 + 255) & ~(size_t)255)), (int)nm,
                 (uint64_t)GZ_WIN, total, d_acc);
             PSK_HIP(ctx, hipGetLastError());

@@ -2,7 +2,8 @@
 """Randomised end-to-end check of the GPU path against the oracle (checker only): random sample sets (FASTA with
 breaks / lower case / empty samples, some FASTQ), random k, random slab; lists, union, presence bits and the
 chi2 survivors must be identical; also the batch sketches, two scans in flight, the weighted chi2, the Welch scan,
-the dictionary counting of `prediction` and the list cut points of the multi-GPU ingest.  Test infrastructure (it links the oracle): run by
+the dictionary counting of `prediction`, the list cut points of the multi-GPU ingest and (r05) samples that arrive
+gzip-compressed (inflated on the device).  Test infrastructure (it links the oracle): run by
 tests/test_gpu_parity.py::test_randomised_pipeline_against_oracle, or by hand: python tests/_stress.py SECONDS [seed]"""
 import os
 import sys
@@ -17,6 +18,9 @@ from oracle import oracle_weights as OW  # noqa: E402
 from phenotypeseeker_amd.engine import PskContext  # noqa: E402
 from phenotypeseeker_amd.synth import GenomeSet, fastq_reads  # noqa: E402
 
+import gzip  # noqa: E402
+
+os.environ.setdefault("PSK_GZ_DEVICE_MIN_MB", "0")     # (.gz samples, however small, through the device inflate)
 budget = float(sys.argv[1]) if len(sys.argv) > 1 else 60.0
 seed = int(sys.argv[2]) if len(sys.argv) > 2 else 1
 rng = np.random.default_rng(seed)
@@ -53,14 +57,20 @@ with PskContext(0) as ctx:
         ctx.begin(k, n, lo, hi)
         do_sketch = length <= 3000 and rng.random() < 0.5   # the oracle's sketch is a pure-Python loop
         sk_par = (int(rng.choice([21, 16, 11])), int(rng.choice([1000, 100, 30])), 42)
+        # some samples arrive gzip-compressed (r05: inflated on the device; the lists are those of the text)
+        sent = [gzip.compress(d, int(rng.choice([1, 6, 9]))) if rng.random() < 0.15 else d for d in datas]
+        if rng.random() < 0.3:
+            os.environ["PSK_GZ_CHUNK"] = str(int(rng.choice([2048, 8192, 30000])))
+        else:
+            os.environ.pop("PSK_GZ_CHUNK", None)
         if do_sketch:
-            nu, nt, sks = ctx.count_kmers_batch(0, datas, int(rng.integers(1, 9)), sketch=sk_par)
+            nu, nt, sks = ctx.count_kmers_batch(0, sent, int(rng.integers(1, 9)), sketch=sk_par)
             for i in rng.choice(n, min(n, 3), replace=False):
                 want = OW.sketch(datas[i], k=sk_par[0], sketch_size=sk_par[1]) if not datas[i].startswith(b"@") else None
                 if want is not None:
                     assert sks[i].tolist() == want, ("sketch", rounds, int(i), sk_par)
         else:
-            nu, nt = ctx.count_kmers_batch(0, datas, int(rng.integers(1, 9)))
+            nu, nt = ctx.count_kmers_batch(0, sent, int(rng.integers(1, 9)))
         ref_lists = []
         for i in range(n):
             w, f = ctx.get_list(i, nu[i])

@@ -276,3 +276,15 @@ def test_dictionary_counting_of_gz_samples(tmp_path, monkeypatch):
                 monkeypatch.setenv("PSK_GZ_GROUP_MB", group_mb)
             assert np.array_equal(ctx.count_dict_batch(packed, k, words, 4), want)
             assert np.array_equal(ctx.count_dict_files(paths, k, words, 4), want)
+
+
+def test_a_call_of_nothing_but_empty_texts():
+    """(found by tests/_stress.py: with no text at all there is nothing for the check-sum kernel to be launched over)"""
+    from phenotypeseeker_amd.engine import PskContext
+    empty = gzip.compress(b"")
+    with PskContext(0) as ctx:
+        texts, lens, routes, _ = ctx.gz_inflate([empty, empty])
+        assert texts == [b"", b""] and lens == [0, 0] and routes == [1, 1]
+        ctx.begin(13, 2)
+        nu, nt = ctx.count_kmers_batch(0, [empty, empty], 2)
+        assert list(nu) == [0, 0] and list(nt) == [0, 0]
