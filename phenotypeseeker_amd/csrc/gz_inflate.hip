@@ -1681,6 +1681,9 @@ int gz_inflate_group(psk_ctx *ctx, int n, const uint8_t *const *data, const size
 void gz_release(psk_ctx *ctx)
 {
     for (DevBuf *b : {&ctx->gz_comp, &ctx->gz_sym, &ctx->gz_rec, &ctx->gz_out, &ctx->gz_tab}) dev_release(*b);
+    std::free(ctx->gz_host);
+    ctx->gz_host = nullptr;
+    ctx->gz_host_cap = 0;
 }
 
 // ---- C-ABI: the inflate on its own (tests, measurements) ------------------------------------------------------------

@@ -20,6 +20,7 @@
 #include <functional>
 #include <chrono>
 #include <condition_variable>
+#include <memory>
 #include <mutex>
 #include <thread>
 
@@ -1328,7 +1329,7 @@ static int count_batch_core(psk_ctx *ctx, int first_sample_idx, int n, const uin
 
 // The batch as the entry points hand it over.  Samples that are gzip images (magic bytes; glistmaker reads .gz through zlib:
 // SURVEY.md section 2 row 9) are inflated on the device first (gz_inflate.hip) -- every .gz sample of a run in one go, runs
-// cut where the text would pass PSK_GZ_GROUP_MB (6 GiB) -- and their chains then start from text that is already in device
+// cut where the text would pass PSK_GZ_GROUP_MB (12 GiB: ~2 GB of compressed input is what fills the part's 65,536 decoding lanes) -- and their chains then start from text that is already in device
 // memory; a member the device route declines has been inflated by zlib on the host and goes on as an in-memory sample.
 static int count_batch_impl(psk_ctx *ctx, int first_sample_idx, int n, const uint8_t *const *bytes, const char *const *paths,
                             const size_t *lens, uint64_t *n_unique, uint64_t *n_total, int n_threads, int sketch_k,
@@ -1362,8 +1363,24 @@ static int count_batch_impl(psk_ctx *ctx, int first_sample_idx, int n, const uin
     if (!any) return core(0, n, bytes, paths, lens, nullptr);
     PSK_HIP(ctx, hipSetDevice(ctx->device));
     // the compressed images of the files (a quarter of the text) are read run by run, by the threads the framing would use
-    std::vector<std::vector<uint8_t>> held((size_t)n);
+    std::vector<uint8_t *> held((size_t)n, nullptr);   // slices of ctx->gz_host
     auto read_images = [&](const std::vector<int> &idx) -> int {
+        size_t need = 0;
+        for (int i : idx)
+            if (!(bytes && bytes[i])) need += (lens[i] + 63) & ~(size_t)63;
+        if (need > ctx->gz_host_cap) {
+            std::free(ctx->gz_host);
+            ctx->gz_host_cap = 0;
+            ctx->gz_host = static_cast<uint8_t *>(std::malloc(need + need / 8));
+            if (!ctx->gz_host) return psk_fail(ctx, PSK_ENOMEM, "no host memory for %zu bytes of compressed input", need);
+            ctx->gz_host_cap = need + need / 8;
+        }
+        size_t at = 0;
+        for (int i : idx)
+            if (!(bytes && bytes[i])) {
+                held[(size_t)i] = ctx->gz_host + at;
+                at += (lens[i] + 63) & ~(size_t)63;
+            }
         std::atomic<int> next(0), failed(-1);
         auto reader = [&]() {
             for (;;) {
@@ -1371,7 +1388,17 @@ static int count_batch_impl(psk_ctx *ctx, int first_sample_idx, int n, const uin
                 if (j >= (int)idx.size()) return;
                 const int i = idx[(size_t)j];
                 if (bytes && bytes[i]) continue;
-                if (read_whole_file(paths[i], lens[i], held[(size_t)i])) failed = i;
+                FILE *f = fopen(paths[i], "rb");
+                size_t got = 0;
+                if (f) {
+                    while (got < lens[i]) {
+                        const size_t r = fread(held[(size_t)i] + got, 1, lens[i] - got, f);
+                        if (r == 0) break;
+                        got += r;
+                    }
+                    fclose(f);
+                }
+                if (!f || got != lens[i]) failed = i;
             }
         };
         std::vector<std::thread> pool;
@@ -1396,15 +1423,16 @@ static int count_batch_impl(psk_ctx *ctx, int first_sample_idx, int n, const uin
         }
         return (size_t)d[0] | ((size_t)d[1] << 8) | ((size_t)d[2] << 16) | ((size_t)d[3] << 24);
     };
-    auto image = [&](int i) -> const uint8_t * { return bytes && bytes[i] ? bytes[i] : held[(size_t)i].data(); };
+    auto image = [&](int i) -> const uint8_t * { return bytes && bytes[i] ? bytes[i] : held[(size_t)i]; };
     const char *gm = getenv("PSK_GZ_GROUP_MB");
-    const size_t budget = (size_t)(gm && *gm ? strtoull(gm, nullptr, 10) : 6144) << 20;
+    const size_t budget = (size_t)(gm && *gm ? strtoull(gm, nullptr, 10) : 12288) << 20;
     const bool host_only = getenv("PSK_HOST_FRAMING") != nullptr;   // (the A/B knob of the host's state machine: the host's inflate with it)
     std::vector<const uint8_t *> eb((size_t)n, nullptr);
     std::vector<const char *> ep((size_t)n, nullptr);
     std::vector<size_t> el((size_t)n, 0);
     std::vector<GzSample> gs((size_t)n);
     const bool trace = getenv("PSK_TRACE") != nullptr;
+    const auto t_all = std::chrono::steady_clock::now();
     for (int lo = 0; lo < n;) {
         int hi = lo;
         size_t est = 0;
@@ -1421,9 +1449,11 @@ static int count_batch_impl(psk_ctx *ctx, int first_sample_idx, int n, const uin
             hi++;
         }
         std::vector<GzInflated> res(idx.size());
+        double ms_read = 0;
         if (!idx.empty()) {
             const auto t0 = std::chrono::steady_clock::now();
             PSK_TRY(read_images(idx));
+            ms_read = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
             std::vector<const uint8_t *> ptrs;
             std::vector<size_t> sizes;
             for (int i : idx) {
@@ -1439,7 +1469,8 @@ static int count_batch_impl(psk_ctx *ctx, int first_sample_idx, int n, const uin
                     comp += sizes[j];
                 }
                 const double ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
-                fprintf(stderr, "[psk] count batch: %zu .gz samples, %.1f MB -> %.1f MB of text in %.1f ms\n", idx.size(), comp / 1e6, text / 1e6, ms);
+                fprintf(stderr, "[psk] count batch: %zu .gz samples, %.1f MB -> %.1f MB of text in %.1f ms (%.1f of them reading the files)\n", idx.size(),
+                        comp / 1e6, text / 1e6, ms, ms_read);
             }
         }
         for (int i = lo; i < hi; i++) {
@@ -1478,8 +1509,12 @@ static int count_batch_impl(psk_ctx *ctx, int first_sample_idx, int n, const uin
             eb[(size_t)i] = r.host.data();
             el[(size_t)i] = r.host.size();
         }
+        const auto t_core = std::chrono::steady_clock::now();
         PSK_TRY(core(lo, hi - lo, eb.data() + lo, ep.data() + lo, el.data() + lo, gs.data() + lo));
-        for (int i : idx) std::vector<uint8_t>().swap(held[(size_t)i]);
+        if (trace)
+            fprintf(stderr, "[psk] count batch: samples %d..%d counted in %.1f ms; %.1f ms since the call began\n", lo, hi - 1,
+                    std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t_core).count(),
+                    std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t_all).count());
         lo = hi;
     }
     return PSK_OK;

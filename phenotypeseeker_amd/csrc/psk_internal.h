@@ -145,6 +145,8 @@ struct psk_ctx {
     size_t scan_pinned_cap = 0;
     void *cnt_pinned = nullptr;   // pinned landing buffer of the scan's result counters
     static constexpr int LANES = 24;
+    uint8_t *gz_host = nullptr;   // the compressed images of the files of the run in hand (host memory, kept like the device buffers:
+    size_t gz_host_cap = 0;       // fresh pages for 2 GB and their release cost 0.3 s a call)
     DevBuf gz_comp, gz_sym, gz_rec, gz_out, gz_tab;   // gz_inflate.hip: images, symbols, matches, text, tables of the group in hand (kept from call to call -- a hipMalloc of these costs ~30 ms per GB --; given back by psk_build_presence and psk_free)
     DevBuf lane_slab;        // one allocation behind the buffer sets of a grouped batch (a cold run paid 60 ms for 170 hipMallocs)
     uint32_t *lane_pinned = nullptr;   // ... and one pinned block behind their counters (16 u32 per set)

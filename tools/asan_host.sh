@@ -27,7 +27,7 @@ done
 wait
 OBJS=""
 for f in $SRCS; do OBJS="$OBJS $OUT/$f.o"; done
-/opt/rocm/bin/hipcc -shared -fPIC --offload-arch=gfx950 -fsanitize=address -o "$OUT/libpsk.so" $OBJS -lpthread
+/opt/rocm/bin/hipcc -shared -fPIC --offload-arch=gfx950 -fsanitize=address -o "$OUT/libpsk.so" $OBJS -lpthread -lz
 CLANG_ASAN=$(/opt/rocm/lib/llvm/bin/clang++ -print-file-name=libclang_rt.asan-x86_64.so)
 PSK_LIB="$OUT/libpsk.so" ASAN_OPTIONS=detect_leaks=0 LD_PRELOAD=$CLANG_ASAN python -m pytest tests/test_abi_and_host.py -x -q
 PSK_LIB="$OUT/libpsk.so" ASAN_OPTIONS=detect_leaks=0 LD_PRELOAD=$CLANG_ASAN python tools/fuzz_framing.py 1 30000
