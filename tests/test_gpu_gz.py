@@ -89,6 +89,14 @@ def _cases():
         "bgzf of nothing": _bgzf(b""),
         "level 0": gzip.compress(fa[:100_000], 0),
     }
+    # GNU gzip has a deflate of its own (not zlib's: other block sizes, other choices of match); --rsyncable restarts often
+    import shutil
+    import subprocess
+    if shutil.which("gzip"):
+        for flags in (["-1"], ["-6"], ["-9"], ["-6", "--rsyncable"]):
+            r = subprocess.run(["gzip", "-c"] + flags, input=fq + fa, capture_output=True)
+            if r.returncode == 0:
+                cases["GNU gzip " + " ".join(flags)] = r.stdout
     return cases
 
 
@@ -288,3 +296,17 @@ def test_a_call_of_nothing_but_empty_texts():
         ctx.begin(13, 2)
         nu, nt = ctx.count_kmers_batch(0, [empty, empty], 2)
         assert list(nu) == [0, 0] and list(nt) == [0, 0]
+
+
+def test_a_file_the_device_declines_goes_through_zlib(monkeypatch):
+    """Incompressible data: stored blocks only, no dynamic header for the search to find, so the first chunk runs on and on --
+    beyond PSK_GZ_MAX_SPAN the device gives the file to zlib (route 0), the others of the call stay on the device."""
+    from phenotypeseeker_amd.engine import PskContext
+    rng = np.random.default_rng(3)
+    noise = rng.integers(0, 256, 600_000, dtype=np.uint8).tobytes()
+    fa = _fasta(200_000, 61)
+    monkeypatch.setenv("PSK_GZ_MAX_SPAN", "100000")
+    monkeypatch.setenv("PSK_GZ_CHUNK", "16384")
+    with PskContext(0) as ctx:
+        texts, _, routes, _ = ctx.gz_inflate([gzip.compress(fa, 6), gzip.compress(noise, 6), gzip.compress(fa[::-1], 6)])
+    assert routes == [1, 0, 1] and texts == [fa, noise, fa[::-1]]
