@@ -181,11 +181,17 @@ def test_at_rich_multi_contig_set_matches_the_reference(tmp_path, oracle):
             assert sorted(got_csv[0][1:-2]) == sorted(ref_csv[0][1:-2])
 
 
-def test_gzip_inputs_with_and_without_the_suffix(tmp_path):
-    """Compressed inputs are inflated on the host and take the in-memory calls; a gzip file that does not say so in its
-    name is recognised by the library (magic bytes) and the run falls back the same way: result tables and predictions
-    equal the plain run's."""
+@pytest.mark.parametrize("route", ["default", "device", "r04"])
+def test_gzip_inputs_with_and_without_the_suffix(tmp_path, route, monkeypatch):
+    """Compressed inputs go to the library as they are (r05), whatever their names say (magic bytes decide): result tables and
+    predictions equal the plain run's.  route: default -- this small a set is inflated by zlib on the library's host threads;
+    device -- on the GPU (PSK_GZ_DEVICE_MIN_MB=0; csrc/gz_inflate.hip); r04 -- PSK_NO_GPU_GZ=1: the library refuses .gz files
+    (PSK_EGZIP) and modeling.py / prediction.py inflate them and take the in-memory calls."""
     import gzip
+    if route == "device":
+        monkeypatch.setenv("PSK_GZ_DEVICE_MIN_MB", "0")
+    elif route == "r04":
+        monkeypatch.setenv("PSK_NO_GPU_GZ", "1")
     ds = load_dataset("ds_bonf")
     plain, packed = tmp_path / "plain", tmp_path / "packed"
     for d in (plain, packed):
