@@ -715,7 +715,7 @@ __global__ __launch_bounds__(256) void gz_copy_kernel(uint16_t *sym, const uint2
         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
     };
     const uint2 none = make_uint2(0xffffffffu, 0);
-    uint2 x = lane < n ? r[lane] : none;
+    uint2 x = (uint64_t)lane < n ? r[lane] : none;
     for (uint64_t g = 0; g < n; g += 64) {
         const bool valid = g + lane < n;
         const uint2 nx = g + 64 + lane < n ? r[g + 64 + lane] : none;   // (the next 64, on their way while these are copied)
