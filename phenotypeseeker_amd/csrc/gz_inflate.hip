@@ -912,47 +912,50 @@ __global__ __launch_bounds__(1024) void gz_tails_kernel(const uint16_t *sym, uin
     }
 }
 
-// everything but the tails: eight symbols a thread (one 16-byte load, one 8-byte store where the eight lie in one chunk)
+// everything but the tails: a workgroup per chunk, the chunk's window -- the 32 KB of text before it, which gz_tails_kernel has
+// written -- in LDS, so that a marker costs an LDS look-up, not a one-byte load from global memory; eight symbols a thread and step
+// (one 16-byte load, one 8-byte store; the addresses are two-byte / one-byte aligned only: gfx950 takes unaligned global accesses)
 __global__ __launch_bounds__(256) void gz_resolve_kernel(const uint16_t *sym, uint8_t *out, const uint64_t *off, const uint64_t *len,
-                                                          const uint32_t *chunk_file, int n_chunks, uint64_t total, unsigned long long *first_nul)
+                                                          const uint32_t *chunk_file, unsigned long long *first_nul)
 {
-    const uint64_t p0 = ((uint64_t)blockIdx.x * 256 + threadIdx.x) * 8;
-    if (p0 >= total) return;
-    int lo = 0, hi = n_chunks;   // the last chunk that starts at or before p0
-    while (hi - lo > 1) {
-        const int mid = (lo + hi) >> 1;
-        if (off[mid] <= p0) lo = mid;
-        else hi = mid;
+    __shared__ uint8_t win[GZ_WIN];
+    const uint32_t c = blockIdx.x, tid = threadIdx.x;
+    const uint64_t o = off[c], L = len[c], body = L - (L < GZ_WIN ? L : GZ_WIN);
+    if (body == 0) return;
+    for (uint32_t i = tid * 16; i < GZ_WIN; i += 256 * 16) {
+        uint4 v;
+        __builtin_memcpy(&v, out + o - GZ_WIN + i, 16);
+        *reinterpret_cast<uint4 *>(win + i) = v;
     }
-    int c = lo;
-    const uint4 raw = *reinterpret_cast<const uint4 *>(sym + p0);   // (p0 is a multiple of 8 symbols; the buffer has 64 bytes to spare)
-    const uint32_t w[4] = {raw.x, raw.y, raw.z, raw.w};
-    uint64_t o = off[c], L = len[c];
-    if (p0 >= o && p0 + 8 <= o + L - (L < GZ_WIN ? L : GZ_WIN)) {
-        // the usual case: all eight inside one chunk and before its tail
-        uint64_t packed = 0;
+    __syncthreads();
+    const uint32_t file = chunk_file[c];
+    for (uint64_t j0 = (uint64_t)tid * 8; j0 < body; j0 += 256 * 8) {
+        const uint64_t p = o + j0;
+        if (j0 + 8 <= body) {
+            uint4 raw;
+            __builtin_memcpy(&raw, sym + p, 16);
+            const uint32_t w[4] = {raw.x, raw.y, raw.z, raw.w};
+            uint64_t packed = 0;
+            bool nul = false;
 #pragma unroll
-        for (int j = 0; j < 8; j++) {
-            const uint32_t s = (w[j >> 1] >> ((j & 1) * 16)) & 0xffffu;
-            const uint8_t b = s < 256 ? (uint8_t)s : out[o - GZ_WIN + (s - 256)];
-            packed |= (uint64_t)b << (8 * j);
-            if (b == 0) atomicMin(first_nul + chunk_file[c], (unsigned long long)(p0 + j));
+            for (int j = 0; j < 8; j++) {
+                const uint32_t s = (w[j >> 1] >> ((j & 1) * 16)) & 0xffffu;
+                const uint8_t b = s < 256 ? (uint8_t)s : win[s - 256];
+                packed |= (uint64_t)b << (8 * j);
+                nul = nul || b == 0;
+            }
+            __builtin_memcpy(out + p, &packed, 8);
+            if (nul)
+                for (int j = 0; j < 8; j++)
+                    if (((packed >> (8 * j)) & 0xff) == 0) atomicMin(first_nul + file, (unsigned long long)(p + j));
+        } else {
+            for (uint64_t j = j0; j < body; j++) {
+                const uint32_t s = sym[o + j];
+                const uint8_t b = s < 256 ? (uint8_t)s : win[s - 256];
+                out[o + j] = b;
+                if (b == 0) atomicMin(first_nul + file, (unsigned long long)(o + j));
+            }
         }
-        *reinterpret_cast<uint64_t *>(out + p0) = packed;
-        return;
-    }
-    for (int j = 0; j < 8; j++) {
-        const uint64_t p = p0 + j;
-        if (p >= total) break;
-        while (c + 1 < n_chunks && p >= off[c + 1]) c++;
-        o = off[c];
-        L = len[c];
-        if (p < o || p >= o + L) continue;                      // the padding between two files
-        if (p >= o + L - (L < GZ_WIN ? L : GZ_WIN)) continue;   // a tail: gz_tails_kernel wrote it
-        const uint32_t s = (w[j >> 1] >> ((j & 1) * 16)) & 0xffffu;
-        const uint8_t b = s < 256 ? (uint8_t)s : out[o - GZ_WIN + (s - 256)];
-        out[p] = b;
-        if (b == 0) atomicMin(first_nul + chunk_file[c], (unsigned long long)p);
     }
 }
 
@@ -1001,7 +1004,6 @@ __global__ __launch_bounds__(256) void gz_crc_kernel(const uint8_t *out, const u
     }
     __syncthreads();
     const uint64_t p0 = first + ((uint64_t)blockIdx.x * 256 + threadIdx.x) * GZ_CRC_SEG;
-    if (p0 >= total) return;
     const uint64_t p1 = p0 + GZ_CRC_SEG < total ? p0 + GZ_CRC_SEG : total;
     int lo = -1, hi = n_members;   // the first member that ends behind p0
     while (hi - lo > 1) {
@@ -1009,7 +1011,11 @@ __global__ __launch_bounds__(256) void gz_crc_kernel(const uint8_t *out, const u
         if (m_begin[mid] + m_len[mid] > p0) hi = mid;
         else lo = mid;
     }
-    for (int m = hi; m < n_members; m++) {
+    // the first piece of a thread goes into its wave's sum where the whole wave works on one member (nearly always: a
+    // member is megabytes, a wave's share 256 KB) -- a million atomics on one file's accumulator take their turns in the L2
+    int my_m = -1;
+    uint32_t my_v = 0;
+    for (int m = hi; m < n_members && p0 < total; m++) {
         const uint64_t b = m_begin[m], e = b + m_len[m];
         if (b >= p1) break;
         const uint64_t q0 = b > p0 ? b : p0, q1 = e < p1 ? e : p1;
@@ -1056,7 +1062,21 @@ __global__ __launch_bounds__(256) void gz_crc_kernel(const uint8_t *out, const u
         uint32_t mul = 0x80000000u;   // x^0
         for (int k = 3; nbytes; nbytes >>= 1, k++)
             if (nbytes & 1) mul = gz_mulmod(x2n[k & 31], mul);
-        atomicXor(acc + m, gz_mulmod(mul, c));
+        const uint32_t v = gz_mulmod(mul, c);
+        if (my_m < 0) {
+            my_m = m;
+            my_v = v;
+        } else {
+            atomicXor(acc + m, v);
+        }
+    }
+    const int m0 = __builtin_amdgcn_readfirstlane(my_m);
+    if (__ballot(my_m != m0 && my_m >= 0) == 0 && m0 >= 0) {
+        uint32_t v = my_m == m0 ? my_v : 0u;
+        for (int o = 32; o; o >>= 1) v ^= (uint32_t)__shfl_xor((int)v, o, 64);
+        if ((threadIdx.x & 63) == 0) atomicXor(acc + m0, v);
+    } else if (my_m >= 0) {
+        atomicXor(acc + my_m, my_v);
     }
 }
 
@@ -1617,9 +1637,8 @@ int gz_inflate_group(psk_ctx *ctx, int n, const uint8_t *const *data, const size
         gz_tails_kernel<<<dim3((unsigned)(file_first.size() - 1)), dim3(1024), 0, st>>>(sym_buf.as<uint16_t>(), out_buf.as<uint8_t>(), d_off, d_len,
                                                                                      reinterpret_cast<const uint32_t *>(t + o_ff), d_nul);
         PSK_HIP(ctx, hipGetLastError());
-        gz_resolve_kernel<<<dim3((unsigned)div_up(total, (uint64_t)256 * 8)), dim3(256), 0, st>>>(sym_buf.as<uint16_t>(), out_buf.as<uint8_t>(), d_off, d_len,
-                                                                                              reinterpret_cast<const uint32_t *>(t + o_cfile), (int)m, total,
-                                                                                              d_nul);
+        gz_resolve_kernel<<<dim3((unsigned)m), dim3(256), 0, st>>>(sym_buf.as<uint16_t>(), out_buf.as<uint8_t>(), d_off, d_len,
+                                                                   reinterpret_cast<const uint32_t *>(t + o_cfile), d_nul);
         PSK_HIP(ctx, hipGetLastError());
         nul_at.resize(file_first.size());
         PSK_HIP(ctx, hipMemcpyAsync(nul_at.data(), d_nul, file_first.size() * 8, hipMemcpyDeviceToHost, st));
