@@ -296,13 +296,18 @@ __device__ __forceinline__ bool gz_plausible_header(const uint8_t *comp, uint64_
 }
 
 // the first 17 bits of a dynamic block that is not the last: BFINAL = 0, BTYPE = 10 (least significant bit first), HLIT and
-// HDIST in range -- one offset in nine passes
-__device__ __forceinline__ bool gz_header_start_ok(const uint8_t *comp, uint64_t bit)
+// HDIST in range -- one offset in nine passes.  Four consecutive offsets from one 64-bit window: a bit per offset.
+__device__ __forceinline__ uint32_t gz_header_starts_ok(const uint8_t *comp, uint64_t bit)
 {
     const uint32_t *w = reinterpret_cast<const uint32_t *>(comp) + (bit >> 5);
-    const uint64_t two = (uint64_t)w[0] | ((uint64_t)w[1] << 32);
-    const uint32_t v = (uint32_t)(two >> (bit & 31));
-    return (v & 7u) == 4u && ((v >> 3) & 31u) <= 29u && ((v >> 8) & 31u) <= 29u;
+    const uint64_t two = ((uint64_t)w[0] | ((uint64_t)w[1] << 32)) >> (bit & 31);   // (31 + 3 + 17 bits at most)
+    uint32_t ok = 0;
+#pragma unroll
+    for (int k = 0; k < 4; k++) {
+        const uint32_t v = (uint32_t)(two >> k);
+        ok |= ((v & 7u) == 4u && ((v >> 3) & 31u) <= 29u && ((v >> 8) & 31u) <= 29u) ? 1u << k : 0u;
+    }
+    return ok;
 }
 
 // the code-length code of such a header is complete (Kraft sum 1): one survivor in a few dozen
@@ -330,19 +335,20 @@ __device__ __forceinline__ bool gz_precode_complete(const uint8_t *comp, uint64_
 __global__ __launch_bounds__(64) void gz_find_kernel(const uint8_t *comp, const uint64_t *from, const uint64_t *to, const uint64_t *end_byte,
                                                       int n, uint64_t *found)
 {
-    __shared__ uint32_t q1[128], q2[128];
+    __shared__ uint32_t q1[64 + 256], q2[128];
     const int c = blockIdx.x, lane = threadIdx.x;
     if (c >= n) return;
     const uint64_t b0 = from[c], b1 = to[c];
     const uint32_t *endw = reinterpret_cast<const uint32_t *>(comp + end_byte[c]) + 2;
     uint32_t n1 = 0, n2 = 0;
     uint64_t hit = GZ_NONE;
+    // (the queues are one wave's: its DS instructions execute in order, so a lane reads what another wrote an instruction
+    // earlier without any wait; the barrier only keeps the compiler from moving them)
     auto push = [&](uint32_t *q, uint32_t &nq, bool ok, uint32_t value) {
         const uint64_t m = __ballot(ok);
         if (ok) q[nq + __popcll(m & ((1ull << lane) - 1))] = value;
         nq += (uint32_t)__popcll(m);
-        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
-        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+        __builtin_amdgcn_wave_barrier();
     };
     // the complete parse of the first 64 (or all, at the end) of q2
     auto sieve3 = [&](uint32_t take) {
@@ -353,29 +359,40 @@ __global__ __launch_bounds__(64) void gz_find_kernel(const uint8_t *comp, const 
         if (m) hit = b0 + (uint64_t)__builtin_amdgcn_readlane((int)off, __ffsll((long long)m) - 1);
         const uint32_t rest = n2 - take;   // (the queue moves down)
         const uint32_t moved = (uint32_t)lane < rest ? q2[take + lane] : 0;
-        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
-        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+        __builtin_amdgcn_wave_barrier();
         if ((uint32_t)lane < rest) q2[lane] = moved;
         n2 = rest;
-        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
-        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+        __builtin_amdgcn_wave_barrier();
     };
     auto sieve2 = [&](uint32_t take) {
         const bool have = (uint32_t)lane < take;
         const uint32_t off = have ? q1[lane] : 0;
         const bool ok = have && gz_precode_complete(comp, b0 + off);
+        // (the queue moves down: up to 256 entries wait behind the 64 taken)
         const uint32_t rest = n1 - take;
-        const uint32_t moved = (uint32_t)lane < rest ? q1[take + lane] : 0;
-        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
-        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
-        if ((uint32_t)lane < rest) q1[lane] = moved;
+        uint32_t moved[4];
+#pragma unroll
+        for (int i = 0; i < 4; i++) moved[i] = (uint32_t)lane + 64 * i < rest ? q1[take + lane + 64 * i] : 0;
+        __builtin_amdgcn_wave_barrier();
+#pragma unroll
+        for (int i = 0; i < 4; i++)
+            if ((uint32_t)lane + 64 * i < rest) q1[lane + 64 * i] = moved[i];
         n1 = rest;
         push(q2, n2, ok, off);
     };
-    for (uint64_t b = b0; b < b1 && hit == GZ_NONE; b += 64) {
-        const uint64_t bit = b + lane;
-        push(q1, n1, bit < b1 && gz_header_start_ok(comp, bit), (uint32_t)(bit - b0));
-        if (n1 >= 64) {
+    for (uint64_t b = b0; b < b1 && hit == GZ_NONE; b += 256) {
+        // lane l: offsets b + 4 l .. + 3; its survivors go into the queue in order, behind those of the lanes before it
+        const uint64_t bit = b + 4 * lane;
+        uint32_t ok = bit < b1 ? gz_header_starts_ok(comp, bit) : 0;
+        if (bit + 4 > b1) ok &= bit < b1 ? (1u << (b1 - bit)) - 1u : 0u;
+        const uint32_t cnt = (uint32_t)__popc(ok), upto = psk_wave_incl_scan_u32(cnt, lane);
+        uint32_t at = n1 + upto - cnt;
+#pragma unroll
+        for (int k = 0; k < 4; k++)
+            if (ok & (1u << k)) q1[at++] = (uint32_t)(bit - b0) + k;
+        n1 += (uint32_t)__builtin_amdgcn_readlane((int)upto, 63);
+        __builtin_amdgcn_wave_barrier();
+        while (n1 >= 64 && hit == GZ_NONE) {
             sieve2(64);
             // (sixteen, not sixty-four: a header that has come this far is usually the true one, and the search would run on
             // for another 64 K offsets before it is looked at)
@@ -735,7 +752,7 @@ __global__ __launch_bounds__(256) void gz_copy_kernel(uint16_t *sym, const uint2
             g_e[wv][lane] = valid ? d + len : 0xffffffffu;
             g_ld[wv][lane] = x.y;
             g_s[wv][lane] = s;
-            wave_sync();
+            __builtin_amdgcn_wave_barrier();   // (LDS of one wave: its DS instructions execute in order; nothing to wait for)
             // the first earlier match that ends behind `from` (the matches write ascending, disjoint ranges)
             auto first_ending_behind = [&](int64_t from) {
                 int lo = -1, hi = lane;
@@ -761,7 +778,7 @@ __global__ __launch_bounds__(256) void gz_copy_kernel(uint16_t *sym, const uint2
                 if (!__ballot(moved)) break;
                 if (stats && lane == 0) atomicAdd(stats + 3, 1ull);
                 if (moved) g_s[wv][lane] = s;   // (later matches pointed at this one follow it)
-                wave_sync();
+                __builtin_amdgcn_wave_barrier();
             }
             // what is left: a match that reads part of what earlier ones write waits for them -- they are neighbours
             const int64_t e = s + span;
