@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """Throughput of the device inflate (csrc/gz_inflate.hip) on synthetic .fastq.gz / .fasta.gz images, with zlib on one host
-thread beside it.  python tools/gz_bench.py [fastq|fasta] [files] [MB of text per file] [level] [reps]"""
+thread beside it.  python tools/gz_bench.py [fastq|fasta] [files] [MB of text per file] [level] [reps] [noverify]"""
 import gzip
 import os
 import sys
@@ -102,8 +102,9 @@ def main():
             assert lens == [m[1] for m in made], "lengths differ"
             print("device inflate: %.1f ms (call %.1f ms) = %.2f GB/s of text; routes %s" % (ms, wall * 1e3, text_bytes / ms / 1e6, sorted(set(routes))))
             best = ms if best is None or ms < best else best
-        texts, _, _, _ = ctx.gz_inflate(images[:2])
-        assert [zlib.crc32(t) for t in texts] == [m[2] for m in made[:2]], "text differs"
+        if "noverify" not in sys.argv:      # (under the profiler: every launch of the same size, so that the means mean something;
+            texts, _, _, _ = ctx.gz_inflate(images[:2])     # the lengths are compared above and the device checks the CRC-32 itself)
+            assert [zlib.crc32(t) for t in texts] == [m[2] for m in made[:2]], "text differs"
     print("ok")
     # (for tools/summarise_profiles.py: what the streaming kernels of the inflate move per launch at the least -- the 16-bit
     # symbols read and the text written by gz_resolve_kernel, the text read by gz_crc_kernel; the decoders are bound by the
