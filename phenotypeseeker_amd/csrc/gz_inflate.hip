@@ -491,6 +491,8 @@ __global__ __launch_bounds__(64) void gz_decode_kernel(GzDecodeArgs a)
     const uint64_t stop = WRITE ? a.stop_bit[c] : 0;
     uint16_t *out = WRITE ? a.sym + a.out_off[c] : nullptr;
     uint2 *rec = WRITE ? a.rec + a.rec_off[c] : nullptr;
+    // (the writing pass never writes beyond what the counting pass counted, whatever it decodes)
+    const uint64_t room_text = WRITE ? a.want_len[c] : ~0ull, room_rec = WRITE ? a.want_rec[c] : ~0ull;
 
     BitIn in;
     in.init(comp, start);
@@ -540,6 +542,10 @@ __global__ __launch_bounds__(64) void gz_decode_kernel(GzDecodeArgs a)
                 }
                 in.need32();
                 const uint32_t b = in.take(8);
+                if (WRITE && pos >= room_text) {
+                    bad = true;
+                    break;
+                }
                 if (WRITE) out[pos] = (uint16_t)b;
                 pos++;
             }
@@ -667,6 +673,7 @@ __global__ __launch_bounds__(64) void gz_decode_kernel(GzDecodeArgs a)
             }
             in.drop(len);
             if (s < 256) {
+                if (WRITE && pos >= room_text) break;
                 if (WRITE) out[pos] = (uint16_t)s;
                 pos++;
                 continue;
@@ -695,6 +702,7 @@ __global__ __launch_bounds__(64) void gz_decode_kernel(GzDecodeArgs a)
             const int db = ds < 4 ? 0 : (int)(ds >> 1) - 1;
             const uint32_t dist = (ds < 4 ? ds + 1 : 1u + ((2u + (ds & 1)) << db)) + in.take(db);
             if ((true_start && dist > pos) || ((pos + mlen) >> 32)) break;   // (inflate.c: "invalid distance too far back")
+            if (WRITE && (nrec >= room_rec || pos + mlen > room_text)) break;
             if (WRITE) rec[nrec] = make_uint2((uint32_t)pos, mlen | (dist << 16));
             nrec++;
             pos += mlen;
