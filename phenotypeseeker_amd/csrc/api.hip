@@ -1,6 +1,8 @@
 // Context lifecycle, error reporting and device-memory helpers of libpsk.so.
 #include "psk_internal.h"
 
+#include <mutex>
+
 static thread_local std::string g_init_error;
 
 int psk_fail(psk_ctx *ctx, int code, const char *fmt, ...)
@@ -10,6 +12,8 @@ int psk_fail(psk_ctx *ctx, int code, const char *fmt, ...)
     va_start(ap, fmt);
     vsnprintf(buf, sizeof buf, fmt, ap);
     va_end(ap);
+    static std::mutex mu;   // (a call's look-ahead thread -- the next run of .gz samples -- may fail beside the calling thread)
+    std::lock_guard<std::mutex> lk(mu);
     if (ctx) ctx->err = buf;
     else g_init_error = buf;
     return code;
@@ -140,6 +144,7 @@ extern "C" void psk_free(psk_ctx *ctx)
         if (L.up_done) (void)hipEventDestroy(L.up_done);
     }
     gz_release(ctx);
+    if (ctx->gz_stream) (void)hipStreamDestroy(ctx->gz_stream);
     dev_release(ctx->lane_slab);
     if (ctx->lane_pinned) (void)hipHostFree(ctx->lane_pinned);
     if (ctx->copy_stream) (void)hipStreamDestroy(ctx->copy_stream);

@@ -1222,7 +1222,7 @@ bool gz_host_inflate(const uint8_t *d, size_t n, std::vector<uint8_t> &out, std:
 // Inflates n gzip images.  The text of file i is out_dev[res[i].off, + res[i].len) when res[i].on_device, else
 // res[i].host (zlib on the host: the device route declined the file; *declined counts them).
 int gz_inflate_group(psk_ctx *ctx, int n, const uint8_t *const *data, const size_t *sizes, DevBuf &comp_buf, DevBuf &sym_buf, DevBuf &rec_buf, DevBuf &out_buf,
-                     DevBuf &tab_buf, std::vector<GzInflated> &res, double *device_ms, bool host_only, int host_threads)
+                     DevBuf &tab_buf, std::vector<GzInflated> &res, double *device_ms, bool host_only, int host_threads, hipStream_t on_stream)
 {
     res.assign((size_t)n, GzInflated());
     if (device_ms) *device_ms = 0.0;
@@ -1256,7 +1256,7 @@ int gz_inflate_group(psk_ctx *ctx, int n, const uint8_t *const *data, const size
         return PSK_OK;
     }
     PSK_HIP(ctx, hipSetDevice(ctx->device));
-    hipStream_t st = ctx->stream;
+    hipStream_t st = on_stream ? on_stream : ctx->stream;
     std::vector<GzFile> files((size_t)n);
     uint64_t comp_total = 0;
     for (int i = 0; i < n; i++) {
@@ -1724,10 +1724,12 @@ int gz_inflate_group(psk_ctx *ctx, int n, const uint8_t *const *data, const size
 
 void gz_release(psk_ctx *ctx)
 {
-    for (DevBuf *b : {&ctx->gz_comp, &ctx->gz_sym, &ctx->gz_rec, &ctx->gz_out, &ctx->gz_tab}) dev_release(*b);
-    std::free(ctx->gz_host);
-    ctx->gz_host = nullptr;
-    ctx->gz_host_cap = 0;
+    for (DevBuf *b : {&ctx->gz_comp[0], &ctx->gz_comp[1], &ctx->gz_out[0], &ctx->gz_out[1], &ctx->gz_sym, &ctx->gz_rec, &ctx->gz_tab}) dev_release(*b);
+    for (int q = 0; q < 2; q++) {
+        std::free(ctx->gz_host[q]);
+        ctx->gz_host[q] = nullptr;
+        ctx->gz_host_cap[q] = 0;
+    }
 }
 
 // ---- C-ABI: the inflate on its own (tests, measurements) ------------------------------------------------------------
@@ -1738,8 +1740,8 @@ extern "C" int psk_gz_inflate(psk_ctx *ctx, int n, const uint8_t *const *data, c
     if (n < 0 || (n && (!data || !sizes || !out_len))) return psk_fail(ctx, PSK_EINVAL, "null buffer");
     std::vector<GzInflated> res;
     // (the context's buffers, kept for the next call: psk_build_presence / psk_free give them back)
-    DevBuf &outb = ctx->gz_out;
-    int rc = gz_inflate_group(ctx, n, data, sizes, ctx->gz_comp, ctx->gz_sym, ctx->gz_rec, ctx->gz_out, ctx->gz_tab, res, device_ms);
+    DevBuf &outb = ctx->gz_out[0];
+    int rc = gz_inflate_group(ctx, n, data, sizes, ctx->gz_comp[0], ctx->gz_sym, ctx->gz_rec, ctx->gz_out[0], ctx->gz_tab, res, device_ms);
     if (rc == PSK_OK) {
         for (int i = 0; i < n && rc == PSK_OK; i++) {
             const GzInflated &r = res[(size_t)i];

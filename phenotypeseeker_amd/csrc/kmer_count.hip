@@ -1362,53 +1362,17 @@ static int count_batch_impl(psk_ctx *ctx, int first_sample_idx, int n, const uin
     }
     if (!any) return core(0, n, bytes, paths, lens, nullptr);
     PSK_HIP(ctx, hipSetDevice(ctx->device));
-    // the compressed images of the files (a quarter of the text) are read run by run, by the threads the framing would use
-    std::vector<uint8_t *> held((size_t)n, nullptr);   // slices of ctx->gz_host
-    auto read_images = [&](const std::vector<int> &idx) -> int {
-        size_t need = 0;
-        for (int i : idx)
-            if (!(bytes && bytes[i])) need += (lens[i] + 63) & ~(size_t)63;
-        if (need > ctx->gz_host_cap) {
-            std::free(ctx->gz_host);
-            ctx->gz_host_cap = 0;
-            ctx->gz_host = static_cast<uint8_t *>(std::malloc(need + need / 8));
-            if (!ctx->gz_host) return psk_fail(ctx, PSK_ENOMEM, "no host memory for %zu bytes of compressed input", need);
-            ctx->gz_host_cap = need + need / 8;
-        }
-        size_t at = 0;
-        for (int i : idx)
-            if (!(bytes && bytes[i])) {
-                held[(size_t)i] = ctx->gz_host + at;
-                at += (lens[i] + 63) & ~(size_t)63;
-            }
-        std::atomic<int> next(0), failed(-1);
-        auto reader = [&]() {
-            for (;;) {
-                const int j = next.fetch_add(1);
-                if (j >= (int)idx.size()) return;
-                const int i = idx[(size_t)j];
-                if (bytes && bytes[i]) continue;
-                FILE *f = fopen(paths[i], "rb");
-                size_t got = 0;
-                if (f) {
-                    while (got < lens[i]) {
-                        const size_t r = fread(held[(size_t)i] + got, 1, lens[i] - got, f);
-                        if (r == 0) break;
-                        got += r;
-                    }
-                    fclose(f);
-                }
-                if (!f || got != lens[i]) failed = i;
-            }
-        };
-        std::vector<std::thread> pool;
-        const int nt = n_threads < 1 ? 1 : (n_threads > 16 ? 16 : n_threads);
-        for (int t = 1; t < nt && t < (int)idx.size(); t++) pool.emplace_back(reader);
-        reader();
-        for (auto &t : pool) t.join();
-        if (failed >= 0) return psk_fail(ctx, PSK_ERANGE, "reading sample %d (%s) failed", first_sample_idx + failed.load(), paths[failed.load()]);
-        return PSK_OK;
-    };
+    if (!ctx->gz_stream) PSK_HIP(ctx, hipStreamCreateWithFlags(&ctx->gz_stream, hipStreamNonBlocking));
+    const char *gm = getenv("PSK_GZ_GROUP_MB");
+    const size_t budget = (size_t)(gm && *gm ? strtoull(gm, nullptr, 10) : 12288) << 20;
+    const bool host_only = getenv("PSK_HOST_FRAMING") != nullptr;   // (the A/B knob of the host's state machine: the host's inflate with it)
+    const bool trace = getenv("PSK_TRACE") != nullptr;
+    std::vector<uint8_t *> held((size_t)n, nullptr);   // where the compressed image of a .gz FILE is (a slice of ctx->gz_host[set])
+    std::vector<const uint8_t *> eb((size_t)n, nullptr);
+    std::vector<const char *> ep((size_t)n, nullptr);
+    std::vector<size_t> el((size_t)n, 0);
+    std::vector<GzSample> gs((size_t)n);
+    auto image = [&](int i) -> const uint8_t * { return bytes && bytes[i] ? bytes[i] : held[(size_t)i]; };
     // ISIZE of the last member (the text of a one-member file, modulo 2^32): what a run's budget is counted in
     auto isize_of = [&](int i) -> size_t {
         uint8_t d[4] = {0, 0, 0, 0};
@@ -1423,73 +1387,115 @@ static int count_batch_impl(psk_ctx *ctx, int first_sample_idx, int n, const uin
         }
         return (size_t)d[0] | ((size_t)d[1] << 8) | ((size_t)d[2] << 16) | ((size_t)d[3] << 24);
     };
-    auto image = [&](int i) -> const uint8_t * { return bytes && bytes[i] ? bytes[i] : held[(size_t)i]; };
-    const char *gm = getenv("PSK_GZ_GROUP_MB");
-    const size_t budget = (size_t)(gm && *gm ? strtoull(gm, nullptr, 10) : 12288) << 20;
-    const bool host_only = getenv("PSK_HOST_FRAMING") != nullptr;   // (the A/B knob of the host's state machine: the host's inflate with it)
-    std::vector<const uint8_t *> eb((size_t)n, nullptr);
-    std::vector<const char *> ep((size_t)n, nullptr);
-    std::vector<size_t> el((size_t)n, 0);
-    std::vector<GzSample> gs((size_t)n);
-    const bool trace = getenv("PSK_TRACE") != nullptr;
-    const auto t_all = std::chrono::steady_clock::now();
-    for (int lo = 0; lo < n;) {
-        int hi = lo;
+    // A run: samples [lo, hi) of the call, cut where the text of its .gz samples would pass the budget.  prepare() reads the
+    // images of its .gz files (by the threads the framing would use), inflates them into buffer set `set` and says where
+    // each sample's records are; the run's chains then start from text in device memory.  The NEXT run is prepared by a
+    // thread of its own while this one is counted (two buffer sets, the inflate on its own stream).
+    struct Run {
+        int lo = 0, hi = 0, set = 0, rc = PSK_OK;
+        std::vector<int> idx;            // its .gz samples
+        std::vector<GzInflated> res;
+    };
+    auto plan = [&](int lo, int set) {
+        Run r;
+        r.lo = r.hi = lo;
+        r.set = set;
         size_t est = 0;
-        std::vector<int> idx;
-        while (hi < n) {
+        while (r.hi < n) {
             size_t e = 0;
-            if (is_gz[(size_t)hi]) {
-                e = isize_of(hi);
-                if (e < 3 * lens[hi]) e = 3 * lens[hi];
+            if (is_gz[(size_t)r.hi]) {
+                e = isize_of(r.hi);
+                if (e < 3 * lens[r.hi]) e = 3 * lens[r.hi];
             }
-            if (hi > lo && est + e > budget) break;
+            if (r.hi > lo && est + e > budget) break;
             est += e;
-            if (is_gz[(size_t)hi]) idx.push_back(hi);
-            hi++;
+            if (is_gz[(size_t)r.hi]) r.idx.push_back(r.hi);
+            r.hi++;
         }
-        std::vector<GzInflated> res(idx.size());
-        double ms_read = 0;
-        if (!idx.empty()) {
-            const auto t0 = std::chrono::steady_clock::now();
-            PSK_TRY(read_images(idx));
-            ms_read = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
-            std::vector<const uint8_t *> ptrs;
-            std::vector<size_t> sizes;
-            for (int i : idx) {
-                ptrs.push_back(image(i));
-                sizes.push_back(lens[i]);
+        return r;
+    };
+    auto read_images = [&](Run &r) -> int {
+        size_t need = 0;
+        for (int i : r.idx)
+            if (!(bytes && bytes[i])) need += (lens[i] + 63) & ~(size_t)63;
+        uint8_t *&host = ctx->gz_host[r.set];
+        size_t &cap = ctx->gz_host_cap[r.set];
+        if (need > cap) {
+            std::free(host);
+            cap = 0;
+            host = static_cast<uint8_t *>(std::malloc(need + need / 8));
+            if (!host) return psk_fail(ctx, PSK_ENOMEM, "no host memory for %zu bytes of compressed input", need);
+            cap = need + need / 8;
+        }
+        size_t at = 0;
+        for (int i : r.idx)
+            if (!(bytes && bytes[i])) {
+                held[(size_t)i] = host + at;
+                at += (lens[i] + 63) & ~(size_t)63;
             }
-            PSK_TRY(gz_inflate_group(ctx, (int)idx.size(), ptrs.data(), sizes.data(), ctx->gz_comp, ctx->gz_sym, ctx->gz_rec, ctx->gz_out, ctx->gz_tab, res,
-                                     nullptr, host_only, n_threads));
-            if (trace) {
-                size_t text = 0, comp = 0;
-                for (size_t j = 0; j < idx.size(); j++) {
-                    text += res[j].len;
-                    comp += sizes[j];
+        std::atomic<int> next(0), failed(-1);
+        auto reader = [&]() {
+            for (;;) {
+                const int j = next.fetch_add(1);
+                if (j >= (int)r.idx.size()) return;
+                const int i = r.idx[(size_t)j];
+                if (bytes && bytes[i]) continue;
+                FILE *f = fopen(paths[i], "rb");
+                size_t got = 0;
+                if (f) {
+                    while (got < lens[i]) {
+                        const size_t rd = fread(held[(size_t)i] + got, 1, lens[i] - got, f);
+                        if (rd == 0) break;
+                        got += rd;
+                    }
+                    fclose(f);
                 }
-                const double ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
-                fprintf(stderr, "[psk] count batch: %zu .gz samples, %.1f MB -> %.1f MB of text in %.1f ms (%.1f of them reading the files)\n", idx.size(),
-                        comp / 1e6, text / 1e6, ms, ms_read);
+                if (!f || got != lens[i]) failed = i;
             }
-        }
-        for (int i = lo; i < hi; i++) {
+        };
+        std::vector<std::thread> pool;
+        const int nt = n_threads < 1 ? 1 : (n_threads > 16 ? 16 : n_threads);
+        for (int t = 1; t < nt && t < (int)r.idx.size(); t++) pool.emplace_back(reader);
+        reader();
+        for (auto &t : pool) t.join();
+        if (failed >= 0) return psk_fail(ctx, PSK_ERANGE, "reading sample %d (%s) failed", first_sample_idx + failed.load(), paths[failed.load()]);
+        return PSK_OK;
+    };
+    auto prepare = [&](Run &r) -> int {
+        for (int i = r.lo; i < r.hi; i++) {
             eb[(size_t)i] = bytes ? bytes[i] : nullptr;
             ep[(size_t)i] = paths ? paths[i] : nullptr;
             el[(size_t)i] = lens[i];
             gs[(size_t)i] = GzSample();
         }
+        if (r.idx.empty()) return PSK_OK;
+        PSK_HIP(ctx, hipSetDevice(ctx->device));
+        const auto t0 = std::chrono::steady_clock::now();
+        PSK_TRY(read_images(r));
+        const double ms_read = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
+        std::vector<const uint8_t *> ptrs;
+        std::vector<size_t> sizes;
+        for (int i : r.idx) {
+            ptrs.push_back(image(i));
+            sizes.push_back(lens[i]);
+        }
+        DevBuf &out = ctx->gz_out[r.set];
+        PSK_TRY(gz_inflate_group(ctx, (int)r.idx.size(), ptrs.data(), sizes.data(), ctx->gz_comp[r.set], ctx->gz_sym, ctx->gz_rec, out, ctx->gz_tab, r.res, nullptr,
+                                 host_only, n_threads, ctx->gz_stream));
         std::vector<uint8_t> head;
-        for (size_t j = 0; j < idx.size(); j++) {
-            const int i = idx[j];
-            GzInflated &r = res[j];
+        for (size_t j = 0; j < r.idx.size(); j++) {
+            const int i = r.idx[j];
+            GzInflated &g = r.res[j];
             ep[(size_t)i] = nullptr;
-            if (r.on_device) {
+            if (g.on_device) {
                 // where the records start decides the format (frame_probe): the first bytes of the text come back for that
-                const uint8_t *text = ctx->gz_out.as<uint8_t>() + r.off;
-                const size_t end = r.first_nul < r.len ? r.first_nul : r.len, look = end < 65536 ? end : 65536;
+                const uint8_t *text = out.as<uint8_t>() + g.off;
+                const size_t end = g.first_nul < g.len ? g.first_nul : g.len, look = end < 65536 ? end : 65536;
                 head.resize(look + 1);
-                if (look) PSK_HIP(ctx, hipMemcpy(head.data(), text, look, hipMemcpyDeviceToHost));
+                if (look) {
+                    PSK_HIP(ctx, hipMemcpyAsync(head.data(), text, look, hipMemcpyDeviceToHost, ctx->gz_stream));
+                    PSK_HIP(ctx, hipStreamSynchronize(ctx->gz_stream));
+                }
                 size_t st = 0, en = 0;
                 const int f = frame_probe_known_end(head.data(), look, &st, &en);
                 if (f || look == end) {
@@ -1498,24 +1504,58 @@ static int count_batch_impl(psk_ctx *ctx, int first_sample_idx, int n, const uin
                     gs[(size_t)i].roff = f ? st : end;
                     gs[(size_t)i].rlen = f ? end - st : 0;
                     eb[(size_t)i] = nullptr;
-                    el[(size_t)i] = r.len;
+                    el[(size_t)i] = g.len;
                     continue;
                 }
                 // no record in the first 64 KB: the whole text comes back and takes the in-memory route
-                r.host.resize(r.len);
-                PSK_HIP(ctx, hipMemcpy(r.host.data(), text, r.len, hipMemcpyDeviceToHost));
-                r.on_device = false;
+                g.host.resize(g.len);
+                PSK_HIP(ctx, hipMemcpyAsync(g.host.data(), text, g.len, hipMemcpyDeviceToHost, ctx->gz_stream));
+                PSK_HIP(ctx, hipStreamSynchronize(ctx->gz_stream));
+                g.on_device = false;
             }
-            eb[(size_t)i] = r.host.data();
-            el[(size_t)i] = r.host.size();
+            eb[(size_t)i] = g.host.data();
+            el[(size_t)i] = g.host.size();
+        }
+        if (trace) {
+            size_t text = 0, comp = 0;
+            for (size_t j = 0; j < r.idx.size(); j++) {
+                text += r.res[j].len;
+                comp += sizes[j];
+            }
+            fprintf(stderr, "[psk] count batch: samples %d..%d: %zu .gz ones, %.1f MB -> %.1f MB of text in %.1f ms (%.1f of them reading the files)\n", r.lo,
+                    r.hi - 1, r.idx.size(), comp / 1e6, text / 1e6, std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count(),
+                    ms_read);
+        }
+        return PSK_OK;
+    };
+    const auto t_all = std::chrono::steady_clock::now();
+    const bool look_ahead = getenv("PSK_GZ_NO_LOOKAHEAD") == nullptr;
+    Run cur = plan(0, 0);
+    PSK_TRY(prepare(cur));
+    for (;;) {
+        Run nxt;
+        std::thread ahead;
+        const bool more = cur.hi < n;
+        if (more) {
+            nxt = plan(cur.hi, 1 - cur.set);
+            if (look_ahead) ahead = std::thread([&] { nxt.rc = prepare(nxt); });
         }
         const auto t_core = std::chrono::steady_clock::now();
-        PSK_TRY(core(lo, hi - lo, eb.data() + lo, ep.data() + lo, el.data() + lo, gs.data() + lo));
+        const int rc = core(cur.lo, cur.hi - cur.lo, eb.data() + cur.lo, ep.data() + cur.lo, el.data() + cur.lo, gs.data() + cur.lo);
         if (trace)
-            fprintf(stderr, "[psk] count batch: samples %d..%d counted in %.1f ms; %.1f ms since the call began\n", lo, hi - 1,
+            fprintf(stderr, "[psk] count batch: samples %d..%d counted in %.1f ms; %.1f ms since the call began\n", cur.lo, cur.hi - 1,
                     std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t_core).count(),
                     std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t_all).count());
-        lo = hi;
+        const std::string why = rc != PSK_OK ? ctx->err : std::string();
+        if (ahead.joinable()) ahead.join();
+        else if (more && rc == PSK_OK) nxt.rc = prepare(nxt);
+        if (rc != PSK_OK) {
+            ctx->err = why;   // (the error of the run that was counted, not of the one behind it)
+            return rc;
+        }
+        if (!more) break;
+        if (nxt.rc != PSK_OK) return nxt.rc;
+        cur = std::move(nxt);
     }
     return PSK_OK;
 }

@@ -145,9 +145,15 @@ struct psk_ctx {
     size_t scan_pinned_cap = 0;
     void *cnt_pinned = nullptr;   // pinned landing buffer of the scan's result counters
     static constexpr int LANES = 24;
-    uint8_t *gz_host = nullptr;   // the compressed images of the files of the run in hand (host memory, kept like the device buffers:
-    size_t gz_host_cap = 0;       // fresh pages for 2 GB and their release cost 0.3 s a call)
-    DevBuf gz_comp, gz_sym, gz_rec, gz_out, gz_tab;   // gz_inflate.hip: images, symbols, matches, text, tables of the group in hand (kept from call to call -- a hipMalloc of these costs ~30 ms per GB --; given back by psk_build_presence and psk_free)
+    // .gz inputs (gz_inflate.hip): what a run of them is inflated in.  Two sets of the buffers that outlive the inflate -- the
+    // compressed images in host memory, their copy and the text on the device --, because the next run of a call is read and
+    // inflated (on gz_stream, by a thread of its own) while the chains of this one count; symbols, matches and tables are the
+    // inflate's own.  Kept from call to call (a hipMalloc of these costs ~30 ms per GB, fresh host pages and their release
+    // 0.3 s per 2 GB); given back by psk_build_presence and psk_free.
+    uint8_t *gz_host[2] = {nullptr, nullptr};
+    size_t gz_host_cap[2] = {0, 0};
+    DevBuf gz_comp[2], gz_out[2], gz_sym, gz_rec, gz_tab;
+    hipStream_t gz_stream = nullptr;
     DevBuf lane_slab;        // one allocation behind the buffer sets of a grouped batch (a cold run paid 60 ms for 170 hipMallocs)
     uint32_t *lane_pinned = nullptr;   // ... and one pinned block behind their counters (16 u32 per set)
     CountLane lane[LANES];   // sample i runs on set i % 3: i + 1 and i + 2 are uploaded / framed ahead while chain i runs; in groups
@@ -214,7 +220,8 @@ struct GzInflated {
 };
 void gz_release(psk_ctx *ctx);   // gives the five buffers above back to the device
 int gz_inflate_group(psk_ctx *ctx, int n, const uint8_t *const *data, const size_t *sizes, DevBuf &comp_buf, DevBuf &sym_buf, DevBuf &rec_buf, DevBuf &out_buf,
-                     DevBuf &tab_buf, std::vector<GzInflated> &res, double *device_ms, bool host_only = false, int host_threads = 8);
+                     DevBuf &tab_buf, std::vector<GzInflated> &res, double *device_ms, bool host_only = false, int host_threads = 8,
+                     hipStream_t on_stream = nullptr);
 
 static inline unsigned div_up(uint64_t a, uint64_t b) { return (unsigned)((a + b - 1) / b); }
 
