@@ -89,6 +89,20 @@ def _cases():
         "bgzf of nothing": _bgzf(b""),
         "level 0": gzip.compress(fa[:100_000], 0),
     }
+    # zlib's other strategies and memory levels: Huffman codes only (no match), runs only (distance 1), the FIXED code for every
+    # block, small blocks (memLevel 1: a block every few hundred symbols -- thousands of headers), large ones
+    for name, level, mem, strategy in (("huffman only", 6, 8, zlib.Z_HUFFMAN_ONLY), ("rle", 6, 8, zlib.Z_RLE), ("fixed code", 6, 8, zlib.Z_FIXED),
+                                       ("filtered", 6, 8, zlib.Z_FILTERED), ("memLevel 1", 6, 1, zlib.Z_DEFAULT_STRATEGY),
+                                       ("memLevel 9 level 9", 9, 9, zlib.Z_DEFAULT_STRATEGY), ("fixed code, small blocks", 1, 1, zlib.Z_FIXED)):
+        co = zlib.compressobj(level, zlib.DEFLATED, 31, mem, strategy)
+        cases["zlib " + name] = co.compress(fq[:300_000] + fa[:200_000]) + co.flush()
+    # sync and full flushes in the middle of a stream (empty stored blocks; a full flush also forgets the window)
+    co = zlib.compressobj(6, zlib.DEFLATED, 31)
+    parts = []
+    for i in range(0, 400_000, 50_000):
+        parts.append(co.compress(fa[i:i + 50_000]))
+        parts.append(co.flush(zlib.Z_SYNC_FLUSH if (i // 50_000) % 2 else zlib.Z_FULL_FLUSH))
+    cases["zlib with sync and full flushes"] = b"".join(parts) + co.flush()
     # GNU gzip has a deflate of its own (not zlib's: other block sizes, other choices of match); --rsyncable restarts often
     import shutil
     import subprocess
