@@ -892,8 +892,9 @@ __global__ __launch_bounds__(256) void gz_copy_kernel(uint16_t *sym, const uint2
 // One workgroup per file, its chunks in stream order: the last 32 KB of each, whose markers point into the last 32 KB
 // before the chunk -- resolved by the iterations before.
 __global__ __launch_bounds__(1024) void gz_tails_kernel(const uint16_t *sym, uint8_t *out, const uint64_t *off, const uint64_t *len,
-                                                         const uint32_t *file_first, unsigned long long *first_nul)
+                                                         const uint32_t *file_first, const uint8_t *no_window, unsigned long long *first_nul)
 {
+    if (no_window[blockIdx.x]) return;   // every chunk a member of its own (BGZF: tens of thousands a file): gz_resolve_kernel does them whole
     // the window of the chunk in hand -- the 32 KB of text before it -- as a ring in LDS: position w is ring[(head + w) % 32K];
     // the symbols of the next chunk's tail are loaded while this one's are resolved (a file's chunks are a serial chain:
     // what is waited for per link is what the chain costs)
@@ -941,19 +942,21 @@ __global__ __launch_bounds__(1024) void gz_tails_kernel(const uint16_t *sym, uin
 // written -- in LDS, so that a marker costs an LDS look-up, not a one-byte load from global memory; eight symbols a thread and step
 // (one 16-byte load, one 8-byte store; the addresses are two-byte / one-byte aligned only: gfx950 takes unaligned global accesses)
 __global__ __launch_bounds__(256) void gz_resolve_kernel(const uint16_t *sym, uint8_t *out, const uint64_t *off, const uint64_t *len,
-                                                          const uint32_t *chunk_file, unsigned long long *first_nul)
+                                                          const uint32_t *chunk_file, const uint8_t *no_window, unsigned long long *first_nul)
 {
     __shared__ uint8_t win[GZ_WIN];
     const uint32_t c = blockIdx.x, tid = threadIdx.x;
-    const uint64_t o = off[c], L = len[c], body = L - (L < GZ_WIN ? L : GZ_WIN);
-    if (body == 0) return;
-    for (uint32_t i = tid * 16; i < GZ_WIN; i += 256 * 16) {
-        uint4 v;
-        __builtin_memcpy(&v, out + o - GZ_WIN + i, 16);
-        *reinterpret_cast<uint4 *>(win + i) = v;
-    }
-    __syncthreads();
     const uint32_t file = chunk_file[c];
+    const bool whole = no_window[file] != 0;   // (a file of members only: no markers, no tails)
+    const uint64_t o = off[c], L = len[c], body = whole ? L : L - (L < GZ_WIN ? L : GZ_WIN);
+    if (body == 0) return;
+    if (!whole)
+        for (uint32_t i = tid * 16; i < GZ_WIN; i += 256 * 16) {
+            uint4 v;
+            __builtin_memcpy(&v, out + o - GZ_WIN + i, 16);
+            *reinterpret_cast<uint4 *>(win + i) = v;
+        }
+    __syncthreads();
     for (uint64_t j0 = (uint64_t)tid * 8; j0 < body; j0 += 256 * 8) {
         const uint64_t p = o + j0;
         if (j0 + 8 <= body) {
@@ -1594,7 +1597,7 @@ int gz_inflate_group(psk_ctx *ctx, int n, const uint8_t *const *data, const size
         size_t off = 0;
         const size_t o_start = carve(off, m * 8), o_end = carve(off, m * 8), o_true = carve(off, m), o_stop = carve(off, m * 8), o_off = carve(off, m * 8),
                      o_want = carve(off, m * 8), o_roff = carve(off, m * 8), o_wrec = carve(off, m * 8), o_ff = carve(off, file_first.size() * 4),
-                     o_cfile = carve(off, m * 4), o_nul = carve(off, file_first.size() * 8);
+                     o_cfile = carve(off, m * 4), o_nul = carve(off, file_first.size() * 8), o_nowin = carve(off, file_first.size());
         const size_t o_in_end = off;
         const size_t o_len = carve(off, m * 8), o_nrec = carve(off, m * 8), o_ebit = carve(off, m * 8), o_link = carve(off, m * 4),
                      o_long = carve(off, m * 640);
@@ -1617,6 +1620,11 @@ int gz_inflate_group(psk_ctx *ctx, int n, const uint8_t *const *data, const size
         for (size_t fi = 0; fi + 1 < file_first.size(); fi++)
             for (uint32_t j = file_first[fi]; j < file_first[fi + 1]; j++) reinterpret_cast<uint32_t *>(stage.data() + o_cfile)[j] = (uint32_t)fi;
         std::memset(stage.data() + o_nul, 0xff, file_first.size() * 8);
+        for (size_t fi = 0; fi + 1 < file_first.size(); fi++) {
+            bool members_only = true;
+            for (uint32_t j = file_first[fi]; j < file_first[fi + 1]; j++) members_only = members_only && ch[(size_t)order[j]].true_start;
+            stage[o_nowin + fi] = members_only ? 1 : 0;
+        }
         uint8_t *t = tab_buf.as<uint8_t>();
         PSK_HIP(ctx, hipMemcpyAsync(t, stage.data(), o_in_end, hipMemcpyHostToDevice, st));
         GzDecodeArgs a;
@@ -1660,10 +1668,10 @@ int gz_inflate_group(psk_ctx *ctx, int n, const uint8_t *const *data, const size
         }
         unsigned long long *d_nul = reinterpret_cast<unsigned long long *>(t + o_nul);
         gz_tails_kernel<<<dim3((unsigned)(file_first.size() - 1)), dim3(1024), 0, st>>>(sym_buf.as<uint16_t>(), out_buf.as<uint8_t>(), d_off, d_len,
-                                                                                     reinterpret_cast<const uint32_t *>(t + o_ff), d_nul);
+                                                                                     reinterpret_cast<const uint32_t *>(t + o_ff), t + o_nowin, d_nul);
         PSK_HIP(ctx, hipGetLastError());
         gz_resolve_kernel<<<dim3((unsigned)m), dim3(256), 0, st>>>(sym_buf.as<uint16_t>(), out_buf.as<uint8_t>(), d_off, d_len,
-                                                                   reinterpret_cast<const uint32_t *>(t + o_cfile), d_nul);
+                                                                   reinterpret_cast<const uint32_t *>(t + o_cfile), t + o_nowin, d_nul);
         PSK_HIP(ctx, hipGetLastError());
         nul_at.resize(file_first.size());
         PSK_HIP(ctx, hipMemcpyAsync(nul_at.data(), d_nul, file_first.size() * 8, hipMemcpyDeviceToHost, st));

@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """Throughput of the device inflate (csrc/gz_inflate.hip) on synthetic .fastq.gz / .fasta.gz images, with zlib on one host
-thread beside it.  python tools/gz_bench.py [fastq|fasta] [files] [MB of text per file] [level] [reps] [noverify]"""
+thread beside it.  python tools/gz_bench.py [fastq|fasta|bgzf] [files] [MB of text per file] [level] [reps] [noverify]"""
 import gzip
 import os
 import sys
@@ -37,6 +37,16 @@ def make(args):
             parts.append(q[i * rl:(i + 1) * rl].tobytes())
             parts.append(b"\n")
         text = b"".join(parts)
+    if kind == "bgzf":       # as bgzip writes it: members of at most 64 KB, each with its length in a 'BC' extra field
+        import struct
+        out = []
+        for i in list(range(0, len(text), 0xff00)) + [len(text)]:
+            piece = text[i:i + 0xff00] if i < len(text) else b""
+            co = zlib.compressobj(level, zlib.DEFLATED, -15)
+            raw = co.compress(piece) + co.flush()
+            out.append(b"\x1f\x8b\x08\x04\0\0\0\0\0\xff" + struct.pack("<H", 6) + b"BC" + struct.pack("<HH", 2, 12 + 6 + len(raw) + 8 - 1))
+            out.append(raw + struct.pack("<II", zlib.crc32(piece), len(piece) & 0xffffffff))
+        return b"".join(out), len(text), zlib.crc32(text)
     return gzip.compress(text, level), len(text), zlib.crc32(text)
 
 
