@@ -110,6 +110,7 @@ def main():
             _, lens, routes, ms = ctx.gz_inflate(images, want_text=False)
             wall = time.time() - t0
             assert lens == [m[1] for m in made], "lengths differ"
+            ms = ms or wall * 1e3       # (zlib on the library's host threads -- PSK_GZ_DEVICE_MIN_MB -- reports no device time)
             print("device inflate: %.1f ms (call %.1f ms) = %.2f GB/s of text; routes %s" % (ms, wall * 1e3, text_bytes / ms / 1e6, sorted(set(routes))))
             best = ms if best is None or ms < best else best
         if "noverify" not in sys.argv:      # (under the profiler: every launch of the same size, so that the means mean something;
