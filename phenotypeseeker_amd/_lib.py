@@ -14,7 +14,7 @@ class PskError(RuntimeError):
         self.code = code
 
 
-PSK_EGZIP = -6    # include/psk.h: a file input is gzip-compressed; the caller inflates it and uses the in-memory call
+PSK_EGZIP = -6    # include/psk.h: (PSK_NO_GPU_GZ=1 only, since r05) a file input is gzip-compressed; the caller inflates it and uses the in-memory call
 
 
 c = ctypes

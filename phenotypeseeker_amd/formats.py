@@ -66,7 +66,8 @@ def is_gzip(path):
 
 
 def read_sequence_file(path):
-    """File image handed to psk_count_kmers; .gz (by magic bytes) is inflated on the host."""
+    """The text of a sequence file; .gz (by magic bytes) inflated here.  Since r05 only the routes that want the text on the
+    host call this (PSK_NO_GPU_GZ=1, one sample at a time, the --kmerDB file): the counting calls take .gz images as they are."""
     with open(path, "rb") as f:
         data = f.read()
     if data[:2] == b"\x1f\x8b":
