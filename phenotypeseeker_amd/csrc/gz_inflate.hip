@@ -1222,10 +1222,30 @@ bool gz_host_inflate(const uint8_t *d, size_t n, std::vector<uint8_t> &out, std:
 
 }  // namespace
 
+// Where the images of a group lie in its device buffer (16-byte aligned, at least 16 zero bytes behind each); returns its size.
+uint64_t gz_image_layout(int n, const size_t *sizes, uint64_t *at)
+{
+    uint64_t total = 0;
+    for (int i = 0; i < n; i++) {
+        at[i] = total;
+        total += (sizes[i] + 16 + 15) & ~(size_t)15;
+    }
+    return total + 64;
+}
+
+// Whether a group of this size is inflated on the device at all (else: zlib on host threads, nothing to upload).
+bool gz_group_on_device(int n, const size_t *sizes, bool host_only)
+{
+    size_t comp_bytes = 0;
+    for (int i = 0; i < n; i++) comp_bytes += sizes[i];
+    return !host_only && comp_bytes >= (gz_env("PSK_GZ_DEVICE_MIN_MB", 48) << 20);
+}
+
 // Inflates n gzip images.  The text of file i is out_dev[res[i].off, + res[i].len) when res[i].on_device, else
 // res[i].host (zlib on the host: the device route declined the file; *declined counts them).
 int gz_inflate_group(psk_ctx *ctx, int n, const uint8_t *const *data, const size_t *sizes, DevBuf &comp_buf, DevBuf &sym_buf, DevBuf &rec_buf, DevBuf &out_buf,
-                     DevBuf &tab_buf, std::vector<GzInflated> &res, double *device_ms, bool host_only, int host_threads, hipStream_t on_stream)
+                     DevBuf &tab_buf, std::vector<GzInflated> &res, double *device_ms, bool host_only, int host_threads, hipStream_t on_stream,
+                     bool images_uploaded)
 {
     res.assign((size_t)n, GzInflated());
     if (device_ms) *device_ms = 0.0;
@@ -1235,7 +1255,7 @@ int gz_inflate_group(psk_ctx *ctx, int n, const uint8_t *const *data, const size
     // Below that the members go through zlib on `host_threads` threads (what glistmaker does per file).
     size_t comp_bytes = 0;
     for (int i = 0; i < n; i++) comp_bytes += sizes[i];
-    if (host_only || comp_bytes < (gz_env("PSK_GZ_DEVICE_MIN_MB", 48) << 20)) {
+    if (!gz_group_on_device(n, sizes, host_only)) {
         std::atomic<int> next(0), bad(0);
         std::vector<std::string> errs((size_t)n);
         auto work = [&]() {
@@ -1261,14 +1281,13 @@ int gz_inflate_group(psk_ctx *ctx, int n, const uint8_t *const *data, const size
     PSK_HIP(ctx, hipSetDevice(ctx->device));
     hipStream_t st = on_stream ? on_stream : ctx->stream;
     std::vector<GzFile> files((size_t)n);
-    uint64_t comp_total = 0;
+    std::vector<uint64_t> at((size_t)n);
+    const uint64_t comp_total = gz_image_layout(n, sizes, at.data());
     for (int i = 0; i < n; i++) {
         files[i].data = data[i];
         files[i].size = sizes[i];
-        files[i].at = comp_total;
-        comp_total += (sizes[i] + 16 + 15) & ~(size_t)15;
+        files[i].at = at[(size_t)i];
     }
-    comp_total += 64;
     // ---- the chunks --------------------------------------------------------------------------------------------
     size_t deflate_bytes = 0;
     for (int i = 0; i < n; i++) deflate_bytes += sizes[i];
@@ -1339,11 +1358,13 @@ int gz_inflate_group(psk_ctx *ctx, int n, const uint8_t *const *data, const size
         t_last = now;
     };
     // ---- the images ---------------------------------------------------------------------------------------------
-    PSK_TRY(dev_reserve(ctx, comp_buf, comp_total));
-    PSK_HIP(ctx, hipMemsetAsync(comp_buf.p, 0, comp_total, st));
-    for (int i = 0; i < n; i++)
-        if (files[i].device_ok && sizes[i])
-            PSK_HIP(ctx, hipMemcpyAsync(comp_buf.as<uint8_t>() + files[i].at, data[i], sizes[i], hipMemcpyHostToDevice, st));
+    if (!images_uploaded) {   // (the counting calls upload each image as soon as it is read: gz_image_layout says where)
+        PSK_TRY(dev_reserve(ctx, comp_buf, comp_total));
+        PSK_HIP(ctx, hipMemsetAsync(comp_buf.p, 0, comp_total, st));
+        for (int i = 0; i < n; i++)
+            if (files[i].device_ok && sizes[i])
+                PSK_HIP(ctx, hipMemcpyAsync(comp_buf.as<uint8_t>() + files[i].at, data[i], sizes[i], hipMemcpyHostToDevice, st));
+    }
     const uint8_t *d_comp = comp_buf.as<uint8_t>();
     lap("upload");
 

@@ -1414,7 +1414,8 @@ static int count_batch_impl(psk_ctx *ctx, int first_sample_idx, int n, const uin
         }
         return r;
     };
-    auto read_images = [&](Run &r) -> int {
+    // (up != nullptr: the device buffer of the run's images; file j of the run goes to up + at[j] as soon as it has been read)
+    auto read_images = [&](Run &r, uint8_t *up, const uint64_t *at) -> int {
         size_t need = 0;
         for (int i : r.idx)
             if (!(bytes && bytes[i])) need += (lens[i] + 63) & ~(size_t)63;
@@ -1427,19 +1428,23 @@ static int count_batch_impl(psk_ctx *ctx, int first_sample_idx, int n, const uin
             if (!host) return psk_fail(ctx, PSK_ENOMEM, "no host memory for %zu bytes of compressed input", need);
             cap = need + need / 8;
         }
-        size_t at = 0;
+        size_t used = 0;
         for (int i : r.idx)
             if (!(bytes && bytes[i])) {
-                held[(size_t)i] = host + at;
-                at += (lens[i] + 63) & ~(size_t)63;
+                held[(size_t)i] = host + used;
+                used += (lens[i] + 63) & ~(size_t)63;
             }
-        std::atomic<int> next(0), failed(-1);
+        std::atomic<int> next(0), failed(-1), up_failed(0);
         auto reader = [&]() {
+            if (up && hipSetDevice(ctx->device) != hipSuccess) up_failed = 1;
             for (;;) {
                 const int j = next.fetch_add(1);
                 if (j >= (int)r.idx.size()) return;
                 const int i = r.idx[(size_t)j];
-                if (bytes && bytes[i]) continue;
+                if (bytes && bytes[i]) {
+                    if (up && lens[i] && hipMemcpyAsync(up + at[j], bytes[i], lens[i], hipMemcpyHostToDevice, ctx->gz_stream) != hipSuccess) up_failed = 1;
+                    continue;
+                }
                 FILE *f = fopen(paths[i], "rb");
                 size_t got = 0;
                 if (f) {
@@ -1451,6 +1456,7 @@ static int count_batch_impl(psk_ctx *ctx, int first_sample_idx, int n, const uin
                     fclose(f);
                 }
                 if (!f || got != lens[i]) failed = i;
+                else if (up && lens[i] && hipMemcpyAsync(up + at[j], held[(size_t)i], lens[i], hipMemcpyHostToDevice, ctx->gz_stream) != hipSuccess) up_failed = 1;
             }
         };
         std::vector<std::thread> pool;
@@ -1459,6 +1465,7 @@ static int count_batch_impl(psk_ctx *ctx, int first_sample_idx, int n, const uin
         reader();
         for (auto &t : pool) t.join();
         if (failed >= 0) return psk_fail(ctx, PSK_ERANGE, "reading sample %d (%s) failed", first_sample_idx + failed.load(), paths[failed.load()]);
+        if (up_failed) return psk_fail(ctx, PSK_EHIP, "uploading the compressed images failed");
         return PSK_OK;
     };
     auto prepare = [&](Run &r) -> int {
@@ -1471,17 +1478,23 @@ static int count_batch_impl(psk_ctx *ctx, int first_sample_idx, int n, const uin
         if (r.idx.empty()) return PSK_OK;
         PSK_HIP(ctx, hipSetDevice(ctx->device));
         const auto t0 = std::chrono::steady_clock::now();
-        PSK_TRY(read_images(r));
+        std::vector<size_t> sizes;
+        for (int i : r.idx) sizes.push_back(lens[i]);
+        // a run the device inflates: every image is uploaded as soon as it has been read (the reads of the others go on beside it)
+        const bool on_device = gz_group_on_device((int)r.idx.size(), sizes.data(), host_only);
+        std::vector<uint64_t> at(r.idx.size());
+        if (on_device) {
+            const uint64_t total = gz_image_layout((int)r.idx.size(), sizes.data(), at.data());
+            PSK_TRY(dev_reserve(ctx, ctx->gz_comp[r.set], total));
+            PSK_HIP(ctx, hipMemsetAsync(ctx->gz_comp[r.set].p, 0, total, ctx->gz_stream));
+        }
+        PSK_TRY(read_images(r, on_device ? ctx->gz_comp[r.set].as<uint8_t>() : nullptr, at.data()));
         const double ms_read = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
         std::vector<const uint8_t *> ptrs;
-        std::vector<size_t> sizes;
-        for (int i : r.idx) {
-            ptrs.push_back(image(i));
-            sizes.push_back(lens[i]);
-        }
+        for (int i : r.idx) ptrs.push_back(image(i));
         DevBuf &out = ctx->gz_out[r.set];
         PSK_TRY(gz_inflate_group(ctx, (int)r.idx.size(), ptrs.data(), sizes.data(), ctx->gz_comp[r.set], ctx->gz_sym, ctx->gz_rec, out, ctx->gz_tab, r.res, nullptr,
-                                 host_only, n_threads, ctx->gz_stream));
+                                 host_only, n_threads, ctx->gz_stream, on_device));
         std::vector<uint8_t> head;
         for (size_t j = 0; j < r.idx.size(); j++) {
             const int i = r.idx[j];
