@@ -44,7 +44,7 @@ prof ingest "fetch write rdreq wrreq" python3 "$ROOT/tools/profile_workloads.py"
 prof cfg3slab "fetch write rdreq wrreq" python3 "$ROOT/tools/profile_workloads.py" cfg3slab
 prof moments "fetch write lds" python3 "$ROOT/tools/profile_workloads.py" moments
 prof fastq "" python3 "$ROOT/tools/profile_workloads.py" fastq
-prof gzinflate "fetch write" python3 "$ROOT/tools/gz_bench.py" fastq 64 128 6 3 noverify          # r05: 64 x 144 MB of .fastq.gz text inflated on the device
+prof gzinflate "fetch write lds" python3 "$ROOT/tools/gz_bench.py" fastq 64 128 6 3 noverify          # r05: 64 x 144 MB of .fastq.gz text inflated on the device
 prof fastqgz "" python3 "$ROOT/tools/profile_workloads.py" fastqgz 16                   # ... and 16 config-5 samples counted from .fastq.gz files
 prof solver "" python3 "$ROOT/tools/profile_workloads.py" solver
 prof solver4096 "" python3 "$ROOT/tools/profile_workloads.py" solver4096
