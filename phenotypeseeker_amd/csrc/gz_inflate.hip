@@ -669,7 +669,13 @@ __global__ __launch_bounds__(64) void gz_decode_kernel(GzDecodeArgs a)
                 len = ll.decode<GZ_LIT_BITS + 1>(__brev(in.peek(15)) >> 17, &idx);
                 if (len > 15) break;
                 const uint32_t rel = (uint32_t)idx - l_short;
-                s = rel < GZ_LONG_LDS ? ls[rel * 64] : lsym[idx];
+                s = ls[(rel < GZ_LONG_LDS ? rel : 0) * 64];
+                if (rel >= GZ_LONG_LDS) {
+                    // (rare.  The wait is HERE so that the common path carries no pending global load of a symbol: a wait for
+                    // one where the paths join would also wait, in every iteration, for the input word that was just asked for)
+                    s = lsym[idx];
+                    __builtin_amdgcn_s_waitcnt(0x0f70);   // vmcnt(0)
+                }
             }
             in.drop(len);
             if (s < 256) {
