@@ -207,6 +207,33 @@ for wl in sorted(os.listdir(src)):
                                          "gfx950 a read request is a 128-B line tallied at 64 B, so read bytes = 2 x FETCH_SIZE x 1024; "
                                          "WRITE_SIZE is exact for full 64-B requests.  Separate --pmc passes, no tracing flags." % tag,
                            "hbm_bytes_per_launch": int((2 * fe + wr) * 1024)}, f, indent=1)
+    # the device inflate: what its kernels wait for
+    if wl == "gzinflate" and any("SQ_WAVE_CYCLES" in c for c in cnt.values()):
+        us = {short(r["Name"]): float(r["AverageNs"]) / 1e3 for r in rows}
+        with open(os.path.join(dst, "%s_gzinflate_sq.md" % tag), "w") as f:
+            f.write("# %s: the kernels of the device inflate under the SQ's wait and LDS counters (one --pmc pass; means of three launches)\n\n" % tag)
+            f.write("Workload: `tools/gz_bench.py fastq 64 128 6 3 noverify` -- 64 .fastq.gz images, 1.93 GB -> 9.2 GB of text.  Shares of "
+                    "SQ_WAVE_CYCLES: parked = SQ_WAIT_ANY (s_waitcnt: memory, LDS), issue-stalled = SQ_WAIT_INST_ANY, issuing = SQ_ACTIVE_INST_ANY; "
+                    "LDS busy = SQ_LDS_IDX_ACTIVE, of which bank conflicts = SQ_LDS_BANK_CONFLICT.\n\n")
+            f.write("| kernel | us | parked | issue-stalled | issuing | LDS busy / wave cycles | bank conflicts / LDS busy | read bytes (2 x FETCH_SIZE) | write bytes |\n")
+            f.write("|---|---:|---:|---:|---:|---:|---:|---:|---:|\n")
+            for k in ("gz_find_kernel", "gz_decode_kernel<false>", "gz_decode_kernel<true>", "gz_copy_kernel", "gz_tails_kernel", "gz_resolve_kernel", "gz_crc_kernel"):
+                c = {n: v[1] for n, v in cnt.get(k, {}).items()}
+                if "SQ_WAVE_CYCLES" not in c:
+                    continue
+                wc = c["SQ_WAVE_CYCLES"]
+                f.write("| `%s` | %.0f | %.2f | %.2f | %.2f | %.3f | %.2f | %.2f GB | %.2f GB |\n" % (
+                    k, us.get(k, 0.0), c.get("SQ_WAIT_ANY", 0) / wc, c.get("SQ_WAIT_INST_ANY", 0) / wc, c.get("SQ_ACTIVE_INST_ANY", 0) / wc,
+                    c.get("SQ_LDS_IDX_ACTIVE", 0) / wc, c.get("SQ_LDS_BANK_CONFLICT", 0) / max(c.get("SQ_LDS_IDX_ACTIVE", 1), 1),
+                    2 * c.get("FETCH_SIZE", 0) * 1024 / 1e9, c.get("WRITE_SIZE", 0) * 1024 / 1e9))
+            f.write("\nReading: the two decoding passes are ISSUING for about two fifths of their wave cycles with ONE wave a SIMD (their LDS tables allow no "
+                    "more): what a lane waits for is mostly its own chain of dependent instructions (a symbol is ~40 instructions of the literal path plus ~100 "
+                    "of the match path, both executed by a wave whose lanes disagree) and, for 40-50 %, the s_waitcnt of an LDS look-up or of the 4-byte input "
+                    "load of whichever lane has run dry -- in the writing pass that wait also covers the stores issued since (one counter for loads and "
+                    "stores); the LDS itself is idle (1 % busy).  `gz_copy_kernel` is parked on memory for three quarters of its cycles at 5 waves a SIMD and "
+                    "fetches 4.5 x the 16-bit text it copies from -- latency, hidden only by the number of resident waves (4 / 8 / 16 waves a CU: 105 / 79 / "
+                    "53 ms).  `gz_resolve_kernel` and `gz_crc_kernel` stream (0.66 / 0.61 of 8 TB/s in algorithmic bytes); the search is two fifths issuing, two "
+                    "fifths waiting.\n")
     # the moment scans: what the SQ says bounds them
     if wl == "moments" and any("SQ_WAVE_CYCLES" in c for c in cnt.values()):
         with open(os.path.join(dst, "%s_moments_lds.md" % tag), "w") as f:
