@@ -53,11 +53,17 @@ def make(args):
 def make_fastq_like(args):
     """One config-5-sized sample written twice: <dir>/s<i>.fastq and .fastq.gz (level 6).  Returns (plain path, gz path,
     text bytes, gz bytes).  Reads of 150 bp drawn from a 5-Mbp genome with 0.5 % errors; names as an Illumina run writes
-    them; qualities from the eight bins of a NovaSeq, in runs."""
-    d, i, n_reads = args
+    them; qualities from the eight bins of a NovaSeq, in runs.  args: (directory, i, reads[, GenomeSet parameters (n, length,
+    seed): the genome is sample i of that set -- related genomes, a phenotype -- instead of a random one; only the .gz is kept])."""
+    d, i, n_reads = args[:3]
     rng = np.random.default_rng(1000 + i)
     rl = 150
-    genome = np.frombuffer(b"ACGT", dtype=np.uint8)[rng.integers(0, 4, 5_000_000)]
+    if len(args) > 3:
+        sys.path.insert(0, ROOT)
+        from phenotypeseeker_amd.synth import GenomeSet
+        genome = np.frombuffer(b"ACGT", dtype=np.uint8)[GenomeSet(*args[3]).codes(i)]
+    else:
+        genome = np.frombuffer(b"ACGT", dtype=np.uint8)[rng.integers(0, 4, 5_000_000)]
     parts = []
     for r0 in range(0, n_reads, 100_000):     # (in blocks: the index arrays of two million reads at once are gigabytes)
         nb = min(100_000, n_reads - r0)
@@ -76,8 +82,9 @@ def make_fastq_like(args):
             parts.append(b"\n")
     text = b"".join(parts)
     plain, packed = os.path.join(d, "s%d.fastq" % i), os.path.join(d, "s%d.fastq.gz" % i)
-    with open(plain, "wb") as f:
-        f.write(text)
+    if len(args) <= 3:
+        with open(plain, "wb") as f:
+            f.write(text)
     gz = gzip.compress(text, 6)
     with open(packed, "wb") as f:
         f.write(gz)

@@ -45,6 +45,7 @@ prof cfg3slab "fetch write rdreq wrreq" python3 "$ROOT/tools/profile_workloads.p
 prof moments "fetch write lds" python3 "$ROOT/tools/profile_workloads.py" moments
 prof fastq "" python3 "$ROOT/tools/profile_workloads.py" fastq
 prof gzinflate "fetch write lds" python3 "$ROOT/tools/gz_bench.py" fastq 64 128 6 3 noverify          # r05: 64 x 144 MB of .fastq.gz text inflated on the device
+prof cfg5gz "" python3 "$ROOT/tools/profile_workloads.py" cfg5gz 64                      # ... and `phenotypeseeker modeling` on 64 of them, end to end (two minutes of generating first)
 prof fastqgz "" python3 "$ROOT/tools/profile_workloads.py" fastqgz 16                   # ... and 16 config-5 samples counted from .fastq.gz files
 prof solver "" python3 "$ROOT/tools/profile_workloads.py" solver
 prof solver4096 "" python3 "$ROOT/tools/profile_workloads.py" solver4096

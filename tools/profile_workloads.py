@@ -6,6 +6,8 @@
   fastq      one config-5 sample: 2 M x 150-bp reads, 0.63 GB of FASTQ, framed and counted
   fastqgz    r05: N (default 16) config-5 samples as .fastq.gz files: counted from plain files, from the .gz files (inflated on the
              device), the inflate alone, zlib on one host thread beside it
+  cfg5gz     r05: `phenotypeseeker modeling` on N (default 64) config-5 read sets as .fastq.gz files, with the device inflate and with
+             the r04 route (a Python thread pool inflates)
   ingest     config 2's ingest alone: 256 x 5 Mbp, k = 13, counted three times + presence build
   solver     the L1 (grid value, fold) fits of three recorded runs (143 fits each)
   predict    `prediction` counting (f1): 256 x 5 Mbp against a 1,000-word model dictionary, and a 5,000-word one (global table)
@@ -190,6 +192,66 @@ elif what == "fastqgz":
                         "routes": sorted(set(routes)),
                         "zlib_one_host_thread_GBps_of_text": round(len(one) / t_zlib / 1e9, 3)}
     finally:
+        shutil.rmtree(tmp, ignore_errors=True)
+elif what == "cfg5gz":
+    # r05: `phenotypeseeker modeling` end to end on read sets as sequencers ship them: N (default 64) samples of 2 M x 150-bp reads
+    # (60 x coverage of related 5-Mbp genomes with a phenotype: synth.GenomeSet) as .fastq.gz files, k = 13 -- with the device
+    # inflate, and with PSK_NO_GPU_GZ=1 (the r04 route: a thread pool of this process inflates, the text crosses PCIe)
+    import shutil
+    import tempfile
+    from concurrent.futures import ProcessPoolExecutor
+    sys.path.insert(0, os.path.join(ROOT, "tools"))
+    from gz_bench import make_fastq_like
+    from phenotypeseeker_amd.cli import build_parser
+    n = int(sys.argv[2]) if len(sys.argv) > 2 else 64
+    reads = int(sys.argv[3]) if len(sys.argv) > 3 else 2_000_000
+    tmp = tempfile.mkdtemp(prefix="psk_cfg5gz_")
+    cwd = os.getcwd()
+    try:
+        gs_par = (n, 5_000_000, 4242)
+        gs = GenomeSet(*gs_par)
+        t0 = time.time()
+        with ProcessPoolExecutor(min(n, os.cpu_count() or 4)) as ex:
+            made = list(ex.map(make_fastq_like, [(tmp, i, reads, gs_par) for i in range(n)]))
+        t_make = time.time() - t0
+        with open(os.path.join(tmp, "data.pheno"), "w") as f:
+            f.write("ID\tAddresses\tPheno\n" + "".join("%s\t%s\t%d\n" % (gs.name(i), os.path.basename(made[i][1]), gs.phenotype(i)) for i in range(n)))
+        walls = {}
+        for route in ("device", "device_again", "r04_python_pool"):
+            d = os.path.join(tmp, route)
+            os.mkdir(d)
+            for m in made:
+                os.symlink(m[1], os.path.join(d, os.path.basename(m[1])))
+            shutil.copy(os.path.join(tmp, "data.pheno"), d)
+            os.chdir(d)
+            if route == "r04_python_pool":
+                os.environ["PSK_NO_GPU_GZ"] = "1"
+            args = build_parser().parse_args(["modeling", "data.pheno", "-l", "13", "--num_threads", "16"])
+            t0 = time.time()
+            try:
+                args.func(args)
+            except SystemExit:      # (no k-mer passes the test on a toy set: the CLI says so and leaves)
+                pass
+            walls[route] = round(time.time() - t0, 2)
+            os.environ.pop("PSK_NO_GPU_GZ", None)
+            try:
+                with open("phases_rank0.json") as f:
+                    walls[route + "_phases"] = {k_: round(v, 3) for k_, v in json.load(f)["phases_s"].items() if v >= 0.01}
+            except (OSError, ValueError, KeyError):
+                pass
+            walls[route + "_made"] = sorted(x for x in os.listdir(".") if x.endswith(".pkl"))
+            os.chdir(cwd)
+        def table(route):
+            try:
+                with open(os.path.join(tmp, route, "chi2_results_Pheno.tsv"), "rb") as f:
+                    return f.read()
+            except OSError:
+                return None
+        same = table("device") is not None and table("device") == table("r04_python_pool")
+        out["notes"] = {"samples": n, "reads_per_sample": reads, "text_bytes": sum(m[2] for m in made), "gz_bytes": sum(m[3] for m in made),
+                        "made_in_s": round(t_make, 1), "modeling_wall_s": walls, "chi2_tables_identical": same}
+    finally:
+        os.chdir(cwd)
         shutil.rmtree(tmp, ignore_errors=True)
 elif what == "ingest":
     n, L, k = 256, 5_000_000, 13
