@@ -145,6 +145,7 @@ extern "C" void psk_free(psk_ctx *ctx)
     }
     gz_release(ctx);
     if (ctx->gz_stream) (void)hipStreamDestroy(ctx->gz_stream);
+    if (ctx->gz_up_stream) (void)hipStreamDestroy(ctx->gz_up_stream);
     dev_release(ctx->lane_slab);
     if (ctx->lane_pinned) (void)hipHostFree(ctx->lane_pinned);
     if (ctx->copy_stream) (void)hipStreamDestroy(ctx->copy_stream);

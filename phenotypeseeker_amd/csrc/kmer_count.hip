@@ -1363,6 +1363,7 @@ static int count_batch_impl(psk_ctx *ctx, int first_sample_idx, int n, const uin
     if (!any) return core(0, n, bytes, paths, lens, nullptr);
     PSK_HIP(ctx, hipSetDevice(ctx->device));
     if (!ctx->gz_stream) PSK_HIP(ctx, hipStreamCreateWithFlags(&ctx->gz_stream, hipStreamNonBlocking));
+    if (!ctx->gz_up_stream) PSK_HIP(ctx, hipStreamCreateWithFlags(&ctx->gz_up_stream, hipStreamNonBlocking));
     const char *gm = getenv("PSK_GZ_GROUP_MB");
     const size_t budget = (size_t)(gm && *gm ? strtoull(gm, nullptr, 10) : 12288) << 20;
     const bool host_only = getenv("PSK_HOST_FRAMING") != nullptr;   // (the A/B knob of the host's state machine: the host's inflate with it)
@@ -1387,14 +1388,17 @@ static int count_batch_impl(psk_ctx *ctx, int first_sample_idx, int n, const uin
         }
         return (size_t)d[0] | ((size_t)d[1] << 8) | ((size_t)d[2] << 16) | ((size_t)d[3] << 24);
     };
-    // A run: samples [lo, hi) of the call, cut where the text of its .gz samples would pass the budget.  prepare() reads the
-    // images of its .gz files (by the threads the framing would use), inflates them into buffer set `set` and says where
-    // each sample's records are; the run's chains then start from text in device memory.  The NEXT run is prepared by a
-    // thread of its own while this one is counted (two buffer sets, the inflate on its own stream).
+    // A run: samples [lo, hi) of the call, cut where the text of its .gz samples would pass the budget.  Its images are read (by the
+    // threads the framing would use) and inflated into buffer set `set`; its chains then start from text in device memory.
     struct Run {
-        int lo = 0, hi = 0, set = 0, rc = PSK_OK;
+        int lo = 0, hi = 0, set = 0;
         std::vector<int> idx;            // its .gz samples
+        std::vector<size_t> sizes;       // ... their images' sizes, where they lie in the device buffer
+        std::vector<uint64_t> at;
+        bool on_device = false;          // the device inflates them (else: zlib on host threads)
         std::vector<GzInflated> res;
+        std::chrono::steady_clock::time_point t0;
+        double ms_read = 0;
     };
     auto plan = [&](int lo, int set) {
         Run r;
@@ -1442,7 +1446,7 @@ static int count_batch_impl(psk_ctx *ctx, int first_sample_idx, int n, const uin
                 if (j >= (int)r.idx.size()) return;
                 const int i = r.idx[(size_t)j];
                 if (bytes && bytes[i]) {
-                    if (up && lens[i] && hipMemcpyAsync(up + at[j], bytes[i], lens[i], hipMemcpyHostToDevice, ctx->gz_stream) != hipSuccess) up_failed = 1;
+                    if (up && lens[i] && hipMemcpyAsync(up + at[j], bytes[i], lens[i], hipMemcpyHostToDevice, ctx->gz_up_stream) != hipSuccess) up_failed = 1;
                     continue;
                 }
                 FILE *f = fopen(paths[i], "rb");
@@ -1456,7 +1460,7 @@ static int count_batch_impl(psk_ctx *ctx, int first_sample_idx, int n, const uin
                     fclose(f);
                 }
                 if (!f || got != lens[i]) failed = i;
-                else if (up && lens[i] && hipMemcpyAsync(up + at[j], held[(size_t)i], lens[i], hipMemcpyHostToDevice, ctx->gz_stream) != hipSuccess) up_failed = 1;
+                else if (up && lens[i] && hipMemcpyAsync(up + at[j], held[(size_t)i], lens[i], hipMemcpyHostToDevice, ctx->gz_up_stream) != hipSuccess) up_failed = 1;
             }
         };
         std::vector<std::thread> pool;
@@ -1468,7 +1472,8 @@ static int count_batch_impl(psk_ctx *ctx, int first_sample_idx, int n, const uin
         if (up_failed) return psk_fail(ctx, PSK_EHIP, "uploading the compressed images failed");
         return PSK_OK;
     };
-    auto prepare = [&](Run &r) -> int {
+    // stage 1 of a run: its images read (and, for a run the device inflates, uploaded as they arrive, on a stream of their own)
+    auto stage_read = [&](Run &r) -> int {
         for (int i = r.lo; i < r.hi; i++) {
             eb[(size_t)i] = bytes ? bytes[i] : nullptr;
             ep[(size_t)i] = paths ? paths[i] : nullptr;
@@ -1477,24 +1482,30 @@ static int count_batch_impl(psk_ctx *ctx, int first_sample_idx, int n, const uin
         }
         if (r.idx.empty()) return PSK_OK;
         PSK_HIP(ctx, hipSetDevice(ctx->device));
-        const auto t0 = std::chrono::steady_clock::now();
-        std::vector<size_t> sizes;
-        for (int i : r.idx) sizes.push_back(lens[i]);
-        // a run the device inflates: every image is uploaded as soon as it has been read (the reads of the others go on beside it)
-        const bool on_device = gz_group_on_device((int)r.idx.size(), sizes.data(), host_only);
-        std::vector<uint64_t> at(r.idx.size());
-        if (on_device) {
-            const uint64_t total = gz_image_layout((int)r.idx.size(), sizes.data(), at.data());
+        r.t0 = std::chrono::steady_clock::now();
+        for (int i : r.idx) r.sizes.push_back(lens[i]);
+        r.on_device = gz_group_on_device((int)r.idx.size(), r.sizes.data(), host_only);
+        r.at.resize(r.idx.size());
+        if (r.on_device) {
+            const uint64_t total = gz_image_layout((int)r.idx.size(), r.sizes.data(), r.at.data());
             PSK_TRY(dev_reserve(ctx, ctx->gz_comp[r.set], total));
-            PSK_HIP(ctx, hipMemsetAsync(ctx->gz_comp[r.set].p, 0, total, ctx->gz_stream));
+            PSK_HIP(ctx, hipMemsetAsync(ctx->gz_comp[r.set].p, 0, total, ctx->gz_up_stream));
         }
-        PSK_TRY(read_images(r, on_device ? ctx->gz_comp[r.set].as<uint8_t>() : nullptr, at.data()));
-        const double ms_read = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
+        PSK_TRY(read_images(r, r.on_device ? ctx->gz_comp[r.set].as<uint8_t>() : nullptr, r.at.data()));
+        if (r.on_device) PSK_HIP(ctx, hipStreamSynchronize(ctx->gz_up_stream));
+        r.ms_read = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - r.t0).count();
+        return PSK_OK;
+    };
+    // stage 2: inflated, and where each sample's records are
+    auto stage_inflate = [&](Run &r) -> int {
+        if (r.idx.empty()) return PSK_OK;
+        PSK_HIP(ctx, hipSetDevice(ctx->device));
+        const auto t1 = std::chrono::steady_clock::now();
         std::vector<const uint8_t *> ptrs;
         for (int i : r.idx) ptrs.push_back(image(i));
         DevBuf &out = ctx->gz_out[r.set];
-        PSK_TRY(gz_inflate_group(ctx, (int)r.idx.size(), ptrs.data(), sizes.data(), ctx->gz_comp[r.set], ctx->gz_sym, ctx->gz_rec, out, ctx->gz_tab, r.res, nullptr,
-                                 host_only, n_threads, ctx->gz_stream, on_device));
+        PSK_TRY(gz_inflate_group(ctx, (int)r.idx.size(), ptrs.data(), r.sizes.data(), ctx->gz_comp[r.set], ctx->gz_sym, ctx->gz_rec, out, ctx->gz_tab, r.res, nullptr,
+                                 host_only, n_threads, ctx->gz_stream, r.on_device));
         std::vector<uint8_t> head;
         for (size_t j = 0; j < r.idx.size(); j++) {
             const int i = r.idx[j];
@@ -1533,42 +1544,92 @@ static int count_batch_impl(psk_ctx *ctx, int first_sample_idx, int n, const uin
             size_t text = 0, comp = 0;
             for (size_t j = 0; j < r.idx.size(); j++) {
                 text += r.res[j].len;
-                comp += sizes[j];
+                comp += r.sizes[j];
             }
-            fprintf(stderr, "[psk] count batch: samples %d..%d: %zu .gz ones, %.1f MB -> %.1f MB of text in %.1f ms (%.1f of them reading the files)\n", r.lo,
-                    r.hi - 1, r.idx.size(), comp / 1e6, text / 1e6, std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count(),
-                    ms_read);
+            fprintf(stderr, "[psk] count batch: samples %d..%d: %zu .gz ones, %.1f MB read in %.1f ms, -> %.1f MB of text in %.1f ms\n", r.lo, r.hi - 1,
+                    r.idx.size(), comp / 1e6, r.ms_read, text / 1e6, std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t1).count());
         }
         return PSK_OK;
     };
-    const auto t_all = std::chrono::steady_clock::now();
-    const bool look_ahead = getenv("PSK_GZ_NO_LOOKAHEAD") == nullptr;
-    Run cur = plan(0, 0);
-    PSK_TRY(prepare(cur));
-    for (;;) {
-        Run nxt;
-        std::thread ahead;
-        const bool more = cur.hi < n;
-        if (more) {
-            nxt = plan(cur.hi, 1 - cur.set);
-            if (look_ahead) ahead = std::thread([&] { nxt.rc = prepare(nxt); });
-        }
+    auto stage_count = [&](Run &r, std::chrono::steady_clock::time_point t_all) -> int {
         const auto t_core = std::chrono::steady_clock::now();
-        const int rc = core(cur.lo, cur.hi - cur.lo, eb.data() + cur.lo, ep.data() + cur.lo, el.data() + cur.lo, gs.data() + cur.lo);
+        const int rc = core(r.lo, r.hi - r.lo, eb.data() + r.lo, ep.data() + r.lo, el.data() + r.lo, gs.data() + r.lo);
         if (trace)
-            fprintf(stderr, "[psk] count batch: samples %d..%d counted in %.1f ms; %.1f ms since the call began\n", cur.lo, cur.hi - 1,
+            fprintf(stderr, "[psk] count batch: samples %d..%d counted in %.1f ms; %.1f ms since the call began\n", r.lo, r.hi - 1,
                     std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t_core).count(),
                     std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t_all).count());
-        const std::string why = rc != PSK_OK ? ctx->err : std::string();
-        if (ahead.joinable()) ahead.join();
-        else if (more && rc == PSK_OK) nxt.rc = prepare(nxt);
-        if (rc != PSK_OK) {
-            ctx->err = why;   // (the error of the run that was counted, not of the one behind it)
-            return rc;
+        return rc;
+    };
+    // The runs of the call, and the three stages as a pipeline over them: run k + 2 is read while run k + 1 is inflated while run
+    // k is counted -- two buffer sets (run k's are run k - 2's: its images are read when run k - 2 has been inflated, its text is
+    // written when run k - 2 has been counted), a thread for each of the first two stages, the calling thread counts.
+    std::vector<Run> runs;
+    for (int lo = 0; lo < n;) {
+        runs.push_back(plan(lo, (int)runs.size() & 1));
+        lo = runs.back().hi;
+    }
+    const int R = (int)runs.size();
+    const auto t_all = std::chrono::steady_clock::now();
+    if (R == 1 || getenv("PSK_GZ_NO_LOOKAHEAD")) {
+        for (Run &r : runs) {
+            PSK_TRY(stage_read(r));
+            PSK_TRY(stage_inflate(r));
+            PSK_TRY(stage_count(r, t_all));
         }
-        if (!more) break;
-        if (nxt.rc != PSK_OK) return nxt.rc;
-        cur = std::move(nxt);
+        return PSK_OK;
+    }
+    std::mutex pm;
+    std::condition_variable pcv;
+    int read_done = 0, inflate_done = 0, count_done = 0, failed_rc = PSK_OK;
+    std::string failed_why;
+    auto fail = [&](int rc) {   // (the first failure is the call's; the others stop at their next wait)
+        std::lock_guard<std::mutex> lk(pm);
+        if (failed_rc == PSK_OK) {
+            failed_rc = rc;
+            failed_why = ctx->err;
+        }
+        pcv.notify_all();
+    };
+    auto wait_for = [&](const int &counter, int at_least) {
+        std::unique_lock<std::mutex> lk(pm);
+        pcv.wait(lk, [&] { return failed_rc != PSK_OK || counter >= at_least; });
+        return failed_rc == PSK_OK;
+    };
+    auto advance = [&](int &counter) {
+        std::lock_guard<std::mutex> lk(pm);
+        counter++;
+        pcv.notify_all();
+    };
+    std::thread reader([&] {
+        for (int k = 0; k < R; k++) {
+            if (!wait_for(inflate_done, k - 1)) return;   // (the images of run k - 2 have been used)
+            const int rc = stage_read(runs[(size_t)k]);
+            if (rc != PSK_OK) return fail(rc);
+            advance(read_done);
+        }
+    });
+    std::thread inflater([&] {
+        for (int k = 0; k < R; k++) {
+            if (!wait_for(read_done, k + 1) || !wait_for(count_done, k - 1)) return;   // (the text of run k - 2 has been counted)
+            const int rc = stage_inflate(runs[(size_t)k]);
+            if (rc != PSK_OK) return fail(rc);
+            advance(inflate_done);
+        }
+    });
+    for (int k = 0; k < R; k++) {
+        if (!wait_for(inflate_done, k + 1)) break;
+        const int rc = stage_count(runs[(size_t)k], t_all);
+        if (rc != PSK_OK) {
+            fail(rc);
+            break;
+        }
+        advance(count_done);
+    }
+    reader.join();
+    inflater.join();
+    if (failed_rc != PSK_OK) {
+        ctx->err = failed_why;
+        return failed_rc;
     }
     return PSK_OK;
 }

@@ -146,14 +146,14 @@ struct psk_ctx {
     void *cnt_pinned = nullptr;   // pinned landing buffer of the scan's result counters
     static constexpr int LANES = 24;
     // .gz inputs (gz_inflate.hip): what a run of them is inflated in.  Two sets of the buffers that outlive the inflate -- the
-    // compressed images in host memory, their copy and the text on the device --, because the next run of a call is read and
-    // inflated (on gz_stream, by a thread of its own) while the chains of this one count; symbols, matches and tables are the
+    // compressed images in host memory, their copy and the text on the device --, because a call's runs are a pipeline: one is
+    // read and uploaded while the one before it is inflated (on gz_stream) while the one before that is counted; symbols, matches and tables are the
     // inflate's own.  Kept from call to call (a hipMalloc of these costs ~30 ms per GB, fresh host pages and their release
     // 0.3 s per 2 GB); given back by psk_build_presence and psk_free.
     uint8_t *gz_host[2] = {nullptr, nullptr};
     size_t gz_host_cap[2] = {0, 0};
     DevBuf gz_comp[2], gz_out[2], gz_sym, gz_rec, gz_tab;
-    hipStream_t gz_stream = nullptr;
+    hipStream_t gz_stream = nullptr, gz_up_stream = nullptr;   // the inflate's kernels; the uploads of the run after it
     DevBuf lane_slab;        // one allocation behind the buffer sets of a grouped batch (a cold run paid 60 ms for 170 hipMallocs)
     uint32_t *lane_pinned = nullptr;   // ... and one pinned block behind their counters (16 u32 per set)
     CountLane lane[LANES];   // sample i runs on set i % 3: i + 1 and i + 2 are uploaded / framed ahead while chain i runs; in groups
