@@ -215,9 +215,11 @@ def test_counting_gz_samples_equals_counting_their_text(k, tmp_path, monkeypatch
         ctx.begin(k, n)
         nu0, nt0, sk0 = ctx.count_kmers_batch(0, texts, 4, sketch=sk)
         want = [ctx.get_list(i, nu0[i]) for i in range(n)]
-        for group_mb in (None, "1"):
+        for group_mb, one_by_one in ((None, False), ("1", False), ("1", True)):
             if group_mb:
-                monkeypatch.setenv("PSK_GZ_GROUP_MB", group_mb)     # (1 MB of text a run: the call is cut into several)
+                monkeypatch.setenv("PSK_GZ_GROUP_MB", group_mb)     # (1 MB of text a run: the call is cut into several --
+            if one_by_one:                                          # read | inflated | counted as a pipeline, or one after the other)
+                monkeypatch.setenv("PSK_GZ_NO_LOOKAHEAD", "1")
             ctx.begin(k, n)
             nu1, nt1, sk1 = ctx.count_kmers_batch(0, packed, 4, sketch=sk)
             assert list(nu1) == list(nu0) and list(nt1) == list(nt0)
@@ -225,6 +227,7 @@ def test_counting_gz_samples_equals_counting_their_text(k, tmp_path, monkeypatch
                 w, f = ctx.get_list(i, nu1[i])
                 assert np.array_equal(w, want[i][0]) and np.array_equal(f, want[i][1]), (i, group_mb)
                 assert np.array_equal(sk1[i], sk0[i]), i
+        monkeypatch.delenv("PSK_GZ_NO_LOOKAHEAD")
         # the same from files, one sample at a time as well
         paths = []
         for i, b in enumerate(packed):
