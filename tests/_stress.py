@@ -63,6 +63,10 @@ with PskContext(0) as ctx:
             os.environ["PSK_GZ_CHUNK"] = str(int(rng.choice([2048, 8192, 30000])))
         else:
             os.environ.pop("PSK_GZ_CHUNK", None)
+        if rng.random() < 0.3:      # the call cut into runs of ~1 MB of text: read | inflated | counted as a pipeline of threads
+            os.environ["PSK_GZ_GROUP_MB"] = "1"
+        else:
+            os.environ.pop("PSK_GZ_GROUP_MB", None)
         if do_sketch:
             nu, nt, sks = ctx.count_kmers_batch(0, sent, int(rng.integers(1, 9)), sketch=sk_par)
             for i in rng.choice(n, min(n, 3), replace=False):
