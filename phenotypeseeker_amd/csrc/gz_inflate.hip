@@ -31,8 +31,8 @@
 // The decoder's tables are per lane: {length, symbol} over the next 8 (5) bits of the stream in LDS -- 640 B a lane, four waves
 // a CU --, the canonical limits of the longer codes in registers, their symbols in LDS / registers (the overflow in global memory).
 // What one lane decodes, it decodes a thousand times slower than a host core: the device wins by numbers only.  A group of
-// less than PSK_GZ_DEVICE_MIN_MB (48) of compressed input therefore goes through zlib on the call's host threads -- what
-// glistmaker does --, and so does a member the device declines (a block that runs on for megabytes without a dynamic
+// few small files therefore goes through zlib on the call's host threads (gz_group_on_device: an estimate of both routes' times)
+// -- what glistmaker does --, and so does a member the device declines (a block that runs on for megabytes without a dynamic
 // header, more members than the rounds allowed here, corrupt data: zlib then words the error).
 #include "dev_utils.h"
 #include "psk_internal.h"
@@ -1239,12 +1239,22 @@ uint64_t gz_image_layout(int n, const size_t *sizes, uint64_t *at)
     return total + 64;
 }
 
-// Whether a group of this size is inflated on the device at all (else: zlib on host threads, nothing to upload).
-bool gz_group_on_device(int n, const size_t *sizes, bool host_only)
+// Whether a group is inflated on the device at all (else: zlib on host threads, nothing to upload).  The device route has a floor
+// of ~40 ms -- its serial passes over one DEFLATE block take that long whatever the number of blocks -- and then runs at ~10 GB/s of
+// compressed input; zlib inflates ~0.45 GB/s of text per thread, one file a thread (4 x the compressed bytes stand for the text).
+// Measured (r05): 8 / 16 / 32 genomes of 5 Mbp as .fasta.gz: device 40 / 41 / 43 ms, eight host threads 12 / 37 / 77; four
+// .fastq.gz files of 64 MB of text: 38 against 224 (four files keep four threads busy).  PSK_GZ_DEVICE_MIN_MB replaces the
+// estimate by a threshold on the compressed megabytes.
+bool gz_group_on_device(int n, const size_t *sizes, bool host_only, int host_threads)
 {
+    if (host_only || n <= 0) return false;
     size_t comp_bytes = 0;
     for (int i = 0; i < n; i++) comp_bytes += sizes[i];
-    return !host_only && comp_bytes >= (gz_env("PSK_GZ_DEVICE_MIN_MB", 48) << 20);
+    const char *fixed = std::getenv("PSK_GZ_DEVICE_MIN_MB");
+    if (fixed && *fixed) return comp_bytes >= (gz_env("PSK_GZ_DEVICE_MIN_MB", 48) << 20);
+    const int threads = std::max(1, std::min(n, std::min(host_threads < 1 ? 1 : host_threads, 32)));
+    const double host_ms = 4.0 * (double)comp_bytes / (0.45e6 * threads), device_ms = 40.0 + (double)comp_bytes / 10e6;
+    return device_ms < host_ms;
 }
 
 // Inflates n gzip images.  The text of file i is out_dev[res[i].off, + res[i].len) when res[i].on_device, else
@@ -1257,11 +1267,11 @@ int gz_inflate_group(psk_ctx *ctx, int n, const uint8_t *const *data, const size
     if (device_ms) *device_ms = 0.0;
     if (n <= 0) return PSK_OK;
     // Few blocks, few lanes: a DEFLATE block is decoded by ONE lane, three orders of magnitude slower than a host core decodes
-    // it, so the device wins by numbers only -- from some tens of megabytes of compressed input on (PSK_GZ_DEVICE_MIN_MB, 48).
-    // Below that the members go through zlib on `host_threads` threads (what glistmaker does per file).
+    // it, so the device wins by numbers only (gz_group_on_device).  A group it would not win goes through zlib on
+    // `host_threads` threads (what glistmaker does per file).
     size_t comp_bytes = 0;
     for (int i = 0; i < n; i++) comp_bytes += sizes[i];
-    if (!gz_group_on_device(n, sizes, host_only)) {
+    if (!gz_group_on_device(n, sizes, host_only, host_threads)) {
         std::atomic<int> next(0), bad(0);
         std::vector<std::string> errs((size_t)n);
         auto work = [&]() {
@@ -1299,7 +1309,7 @@ int gz_inflate_group(psk_ctx *ctx, int n, const uint8_t *const *data, const size
     for (int i = 0; i < n; i++) deflate_bytes += sizes[i];
     const size_t want_lanes = gz_env("PSK_GZ_LANES", 65536);   // four waves on each of 256 CUs
     size_t chunk = gz_env("PSK_GZ_CHUNK", 0);
-    if (!chunk) chunk = std::min<size_t>(std::max<size_t>(deflate_bytes / want_lanes, 32 << 10), 4 << 20);
+    if (!chunk) chunk = std::min<size_t>(std::max<size_t>(deflate_bytes / want_lanes, 16 << 10), 4 << 20);   // (16 KB: less than a block of most encoders -- two cuts in one block find the same start and one of the two lanes idles, but a group that cannot fill the part anyway is cut at every block: 1.15 GB of FASTQ text 69 -> 51 ms)
     chunk = (chunk + 3) & ~(size_t)3;
     std::vector<GzChunk> ch;
     std::vector<std::pair<int, int>> file_chunks((size_t)n);   // [first, last) of its regular chunks

@@ -1484,7 +1484,7 @@ static int count_batch_impl(psk_ctx *ctx, int first_sample_idx, int n, const uin
         PSK_HIP(ctx, hipSetDevice(ctx->device));
         r.t0 = std::chrono::steady_clock::now();
         for (int i : r.idx) r.sizes.push_back(lens[i]);
-        r.on_device = gz_group_on_device((int)r.idx.size(), r.sizes.data(), host_only);
+        r.on_device = gz_group_on_device((int)r.idx.size(), r.sizes.data(), host_only, n_threads);
         r.at.resize(r.idx.size());
         if (r.on_device) {
             const uint64_t total = gz_image_layout((int)r.idx.size(), r.sizes.data(), r.at.data());

@@ -223,7 +223,7 @@ int gz_inflate_group(psk_ctx *ctx, int n, const uint8_t *const *data, const size
                      DevBuf &tab_buf, std::vector<GzInflated> &res, double *device_ms, bool host_only = false, int host_threads = 8,
                      hipStream_t on_stream = nullptr, bool images_uploaded = false);
 uint64_t gz_image_layout(int n, const size_t *sizes, uint64_t *at);
-bool gz_group_on_device(int n, const size_t *sizes, bool host_only);
+bool gz_group_on_device(int n, const size_t *sizes, bool host_only, int host_threads);
 
 static inline unsigned div_up(uint64_t a, uint64_t b) { return (unsigned)((a + b - 1) / b); }
 

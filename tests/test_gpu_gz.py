@@ -18,7 +18,7 @@ pytestmark = pytest.mark.gpu
 
 @pytest.fixture(autouse=True)
 def _device_route_for_small_inputs(monkeypatch):
-    """The library sends groups of less than 48 MB of compressed input through zlib on host threads (a DEFLATE block is
+    """The library sends a few small files through zlib on host threads (the device route has a floor of ~40 ms: a DEFLATE block is
     decoded by one lane: the device wins by numbers only); the tests' inputs are small, and they are about the device."""
     monkeypatch.setenv("PSK_GZ_DEVICE_MIN_MB", "0")
 
@@ -263,8 +263,8 @@ def test_without_the_device_route_files_are_refused_as_before(tmp_path, monkeypa
 
 
 def test_small_groups_go_through_zlib_on_host_threads(monkeypatch):
-    """The default: below PSK_GZ_DEVICE_MIN_MB of compressed input a group is inflated by zlib (route 0), above it on the
-    device (route 1) -- the same text either way."""
+    """The default: a few small files are inflated by zlib on host threads (route 0: the library's estimate of both routes says
+    that is faster), larger groups on the device (route 1) -- the same text either way."""
     from phenotypeseeker_amd.engine import PskContext
     fa = _fasta(300_000, 31)
     images = [gzip.compress(fa, 6), gzip.compress(fa[:100_000], 1), _bgzf(fa[:50_000])]
