@@ -10,7 +10,7 @@
 // copies from the 32 KB of text before it.  The way around both is the one pugz / rapidgzip take on CPUs (Kerbiriou &
 // Chikhi 2019; Knespel & Brunst 2023) -- find block starts inside the stream, decode from each with the window unknown,
 // resolve the unknowns afterwards -- laid out for 64-lane waves and a quarter of a million lanes:
-//   1. gz_find_kernel     the stream is cut every `chunk` bytes (32 KB or more: 65,536 chunks fill the part); one wave per
+//   1. gz_find_kernel     the stream is cut every `chunk` bytes (16 KB or more: 65,536 chunks fill the part); one wave per
 //                         cut sieves the bit offsets behind it for a dynamic-Huffman block header that parses completely
 //                         (code-length code, both codes complete or what zlib accepts instead, end-of-block coded).
 //   2. gz_decode_kernel<false>   one LANE per chunk decodes from its start to the block end that coincides with a later
