@@ -4,7 +4,7 @@
 // (SURVEY.md section 2 row 9, Appendix B).  Until r05 this package did the same on a pool of host threads -- ~0.5 GB/s of
 // text per thread against the ~45 GB/s a PCIe link moves, so a read set in its usual form (.fastq.gz) was bound by the
 // host's inflate (missing #7).  Here the COMPRESSED image crosses PCIe (a fifth of the bytes) and is inflated
-// on the device: 2 GB of .fastq.gz -> 9 GB of text in 0.2 s, upload included (tools/gz_bench.py; profiles/r05_gz_*).
+// on the device: 2 GB of .fastq.gz -> 9 GB of text in 0.18 s, upload included (tools/gz_bench.py; profiles/r05_gz_*).
 //
 // A DEFLATE stream is serial twice over: a Huffman code has to be decoded to know where the next one starts, and a match
 // copies from the 32 KB of text before it.  The way around both is the one pugz / rapidgzip take on CPUs (Kerbiriou &
