@@ -657,9 +657,11 @@ __global__ __launch_bounds__(64) void gz_decode_kernel(GzDecodeArgs a)
             }
         }
         // ---- the block's symbols ----
-        bool bad = true;
+        // (one way out of the loop: an error only raises a flag and lets the iteration finish on harmless values -- every `break`
+        // of its own costs the wave a round of exec-mask bookkeeping in EVERY iteration)
+        bool bad = false;
         for (;;) {
-            if (in.beyond(endw)) break;
+            bool stop = in.beyond(endw);
             in.need32();
             uint32_t e = lt[in.peek(GZ_LIT_BITS) * 64];
             int len = (int)(e & 15);
@@ -667,8 +669,10 @@ __global__ __launch_bounds__(64) void gz_decode_kernel(GzDecodeArgs a)
             if (len == 0) {
                 int idx;
                 len = ll.decode<GZ_LIT_BITS + 1>(__brev(in.peek(15)) >> 17, &idx);
-                if (len > 15) break;
-                const uint32_t rel = (uint32_t)idx - l_short;
+                const bool none = len > 15;
+                stop = stop || none;
+                len = none ? 1 : len;
+                const uint32_t rel = none ? 0 : (uint32_t)idx - l_short;
                 s = ls[(rel < GZ_LONG_LDS ? rel : 0) * 64];
                 if (rel >= GZ_LONG_LDS) {
                     // (rare.  The wait is HERE so that the common path carries no pending global load of a symbol: a wait for
@@ -679,39 +683,49 @@ __global__ __launch_bounds__(64) void gz_decode_kernel(GzDecodeArgs a)
             }
             in.drop(len);
             if (s < 256) {
-                if (WRITE && pos >= room_text) break;
-                if (WRITE) out[pos] = (uint16_t)s;
+                const bool room = !WRITE || pos < room_text;
+                if (WRITE && room && !stop) out[pos] = (uint16_t)s;
+                stop = stop || !room;
                 pos++;
-                continue;
+            } else if (s == 256) {
+                bad = stop;   // the end of the block -- unless something before it was wrong
+                break;
+            } else {
+                const int i = (int)s - 257;
+                stop = stop || i > 28;
+                const int eb = i < 8 || i >= 28 ? 0 : (i - 4) >> 2;
+                const uint32_t mlen = (i < 8 ? 3u + i : i >= 28 ? 258u : 3u + ((4u + (i & 3)) << eb)) + in.take(eb);
+                in.need32();
+                e = dt[in.peek(GZ_DIST_BITS) * 64];
+                len = (int)(e & 15);
+                uint32_t ds = e >> 4;
+                if (len == 0) {
+                    int idx;
+                    len = ld.decode<GZ_DIST_BITS + 1>(__brev(in.peek(15)) >> 17, &idx);
+                    const bool none = len > 15;
+                    stop = stop || none;
+                    len = none ? 1 : len;
+                    const uint32_t rel = none ? 0 : (uint32_t)idx - d_short, q = rel / 12;
+                    ds = (uint32_t)((q == 0 ? dpk0 : q == 1 ? dpk1 : dpk2) >> (5 * (rel % 12))) & 31;
+                }
+                in.drop(len);
+                stop = stop || ds >= 30;
+                ds = ds >= 30 ? 0 : ds;
+                const int db = ds < 4 ? 0 : (int)(ds >> 1) - 1;
+                const uint32_t dist = (ds < 4 ? ds + 1 : 1u + ((2u + (ds & 1)) << db)) + in.take(db);
+                stop = stop || (true_start && dist > pos) || ((pos + mlen) >> 32);   // (inflate.c: "invalid distance too far back")
+                if (WRITE) {
+                    const bool room = nrec < room_rec && pos + mlen <= room_text;
+                    if (room && !stop) rec[nrec] = make_uint2((uint32_t)pos, mlen | (dist << 16));
+                    stop = stop || !room;
+                }
+                nrec++;
+                pos += mlen;
             }
-            if (s == 256) {
-                bad = false;
+            if (stop) {
+                bad = true;
                 break;
             }
-            const int i = (int)s - 257;
-            if (i > 28) break;
-            const int eb = i < 8 || i == 28 ? 0 : (i - 4) >> 2;
-            const uint32_t mlen = (i < 8 ? 3u + i : i == 28 ? 258u : 3u + ((4u + (i & 3)) << eb)) + in.take(eb);
-            in.need32();
-            e = dt[in.peek(GZ_DIST_BITS) * 64];
-            len = (int)(e & 15);
-            uint32_t ds = e >> 4;
-            if (len == 0) {
-                int idx;
-                len = ld.decode<GZ_DIST_BITS + 1>(__brev(in.peek(15)) >> 17, &idx);
-                if (len > 15) break;
-                const uint32_t rel = (uint32_t)idx - d_short, q = rel / 12;
-                ds = (uint32_t)((q == 0 ? dpk0 : q == 1 ? dpk1 : dpk2) >> (5 * (rel % 12))) & 31;
-            }
-            in.drop(len);
-            if (ds >= 30) break;
-            const int db = ds < 4 ? 0 : (int)(ds >> 1) - 1;
-            const uint32_t dist = (ds < 4 ? ds + 1 : 1u + ((2u + (ds & 1)) << db)) + in.take(db);
-            if ((true_start && dist > pos) || ((pos + mlen) >> 32)) break;   // (inflate.c: "invalid distance too far back")
-            if (WRITE && (nrec >= room_rec || pos + mlen > room_text)) break;
-            if (WRITE) rec[nrec] = make_uint2((uint32_t)pos, mlen | (dist << 16));
-            nrec++;
-            pos += mlen;
         }
         if (bad) break;
     }
