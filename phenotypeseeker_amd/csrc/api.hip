@@ -5,6 +5,8 @@
 
 static thread_local std::string g_init_error;
 
+static std::mutex g_err_mu;
+
 int psk_fail(psk_ctx *ctx, int code, const char *fmt, ...)
 {
     char buf[512];
@@ -12,11 +14,22 @@ int psk_fail(psk_ctx *ctx, int code, const char *fmt, ...)
     va_start(ap, fmt);
     vsnprintf(buf, sizeof buf, fmt, ap);
     va_end(ap);
-    static std::mutex mu;   // (a call's look-ahead thread -- the next run of .gz samples -- may fail beside the calling thread)
-    std::lock_guard<std::mutex> lk(mu);
+    std::lock_guard<std::mutex> lk(g_err_mu);   // (the stages of a call's .gz pipeline run in threads of their own and may fail side by side)
     if (ctx) ctx->err = buf;
     else g_init_error = buf;
     return code;
+}
+
+std::string psk_error_text(psk_ctx *ctx)
+{
+    std::lock_guard<std::mutex> lk(g_err_mu);
+    return ctx ? ctx->err : g_init_error;
+}
+
+void psk_set_error_text(psk_ctx *ctx, const std::string &text)
+{
+    std::lock_guard<std::mutex> lk(g_err_mu);
+    if (ctx) ctx->err = text;
 }
 
 int dev_reserve(psk_ctx *ctx, DevBuf &b, size_t bytes)

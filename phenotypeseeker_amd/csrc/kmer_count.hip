@@ -1586,7 +1586,7 @@ static int count_batch_impl(psk_ctx *ctx, int first_sample_idx, int n, const uin
         std::lock_guard<std::mutex> lk(pm);
         if (failed_rc == PSK_OK) {
             failed_rc = rc;
-            failed_why = ctx->err;
+            failed_why = psk_error_text(ctx);
         }
         pcv.notify_all();
     };
@@ -1628,7 +1628,7 @@ static int count_batch_impl(psk_ctx *ctx, int first_sample_idx, int n, const uin
     reader.join();
     inflater.join();
     if (failed_rc != PSK_OK) {
-        ctx->err = failed_why;
+        psk_set_error_text(ctx, failed_why);
         return failed_rc;
     }
     return PSK_OK;

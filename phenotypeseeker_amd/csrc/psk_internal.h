@@ -187,6 +187,8 @@ struct psk_ctx {
 
 // ---- error helpers ----------------------------------------------------------------------------
 int psk_fail(psk_ctx *ctx, int code, const char *fmt, ...);
+std::string psk_error_text(psk_ctx *ctx);                        // (copies under the lock psk_fail writes under)
+void psk_set_error_text(psk_ctx *ctx, const std::string &text);
 void psk_forget_lane_slices(psk_ctx *ctx);   // kmer_count.hip
 
 #define PSK_HIP(ctx, call)                                                                            \
