@@ -327,3 +327,22 @@ def test_a_file_the_device_declines_goes_through_zlib(monkeypatch):
     with PskContext(0) as ctx:
         texts, _, routes, _ = ctx.gz_inflate([gzip.compress(fa, 6), gzip.compress(noise, 6), gzip.compress(fa[::-1], 6)])
     assert routes == [1, 0, 1] and texts == [fa, noise, fa[::-1]]
+
+
+def test_a_corrupt_sample_in_the_middle_of_a_call_cut_into_runs(monkeypatch):
+    """The stages of a call's runs are threads (read | inflate | count): the failure of one of them ends the call with its
+    words, nothing hangs, and the context goes on working."""
+    from phenotypeseeker_amd.engine import PskContext, PskError
+    texts = [_fasta(80_000, 70 + i) for i in range(6)]
+    packed = [gzip.compress(t, 6) for t in texts]
+    packed[3] = packed[3][:len(packed[3]) // 2]
+    monkeypatch.setenv("PSK_GZ_GROUP_MB", "1")      # (runs of one or two samples)
+    with PskContext(0) as ctx:
+        ctx.begin(13, 6)
+        with pytest.raises(PskError, match="not a valid gzip file"):
+            ctx.count_kmers_batch(0, packed, 4)
+        ctx.begin(13, 6)
+        nu, nt = ctx.count_kmers_batch(0, [gzip.compress(t, 6) for t in texts], 4)
+        ctx.begin(13, 6)
+        nu0, nt0 = ctx.count_kmers_batch(0, texts, 4)
+        assert list(nu) == list(nu0) and list(nt) == list(nt0)
