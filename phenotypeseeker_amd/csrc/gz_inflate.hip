@@ -661,7 +661,7 @@ __global__ __launch_bounds__(64) void gz_decode_kernel(GzDecodeArgs a)
         // of its own costs the wave a round of exec-mask bookkeeping in EVERY iteration)
         bool bad = false;
         for (;;) {
-            bool stop = in.beyond(endw);
+            bool wrong = in.beyond(endw);
             in.need32();
             uint32_t e = lt[in.peek(GZ_LIT_BITS) * 64];
             int len = (int)(e & 15);
@@ -670,7 +670,7 @@ __global__ __launch_bounds__(64) void gz_decode_kernel(GzDecodeArgs a)
                 int idx;
                 len = ll.decode<GZ_LIT_BITS + 1>(__brev(in.peek(15)) >> 17, &idx);
                 const bool none = len > 15;
-                stop = stop || none;
+                wrong = wrong || none;
                 len = none ? 1 : len;
                 const uint32_t rel = none ? 0 : (uint32_t)idx - l_short;
                 s = ls[(rel < GZ_LONG_LDS ? rel : 0) * 64];
@@ -684,15 +684,15 @@ __global__ __launch_bounds__(64) void gz_decode_kernel(GzDecodeArgs a)
             in.drop(len);
             if (s < 256) {
                 const bool room = !WRITE || pos < room_text;
-                if (WRITE && room && !stop) out[pos] = (uint16_t)s;
-                stop = stop || !room;
+                if (WRITE && room && !wrong) out[pos] = (uint16_t)s;
+                wrong = wrong || !room;
                 pos++;
             } else if (s == 256) {
-                bad = stop;   // the end of the block -- unless something before it was wrong
+                bad = wrong;   // the end of the block -- unless something before it was wrong
                 break;
             } else {
                 const int i = (int)s - 257;
-                stop = stop || i > 28;
+                wrong = wrong || i > 28;
                 const int eb = i < 8 || i >= 28 ? 0 : (i - 4) >> 2;
                 const uint32_t mlen = (i < 8 ? 3u + i : i >= 28 ? 258u : 3u + ((4u + (i & 3)) << eb)) + in.take(eb);
                 in.need32();
@@ -703,26 +703,26 @@ __global__ __launch_bounds__(64) void gz_decode_kernel(GzDecodeArgs a)
                     int idx;
                     len = ld.decode<GZ_DIST_BITS + 1>(__brev(in.peek(15)) >> 17, &idx);
                     const bool none = len > 15;
-                    stop = stop || none;
+                    wrong = wrong || none;
                     len = none ? 1 : len;
                     const uint32_t rel = none ? 0 : (uint32_t)idx - d_short, q = rel / 12;
                     ds = (uint32_t)((q == 0 ? dpk0 : q == 1 ? dpk1 : dpk2) >> (5 * (rel % 12))) & 31;
                 }
                 in.drop(len);
-                stop = stop || ds >= 30;
+                wrong = wrong || ds >= 30;
                 ds = ds >= 30 ? 0 : ds;
                 const int db = ds < 4 ? 0 : (int)(ds >> 1) - 1;
                 const uint32_t dist = (ds < 4 ? ds + 1 : 1u + ((2u + (ds & 1)) << db)) + in.take(db);
-                stop = stop || (true_start && dist > pos) || ((pos + mlen) >> 32);   // (inflate.c: "invalid distance too far back")
+                wrong = wrong || (true_start && dist > pos) || ((pos + mlen) >> 32);   // (inflate.c: "invalid distance too far back")
                 if (WRITE) {
                     const bool room = nrec < room_rec && pos + mlen <= room_text;
-                    if (room && !stop) rec[nrec] = make_uint2((uint32_t)pos, mlen | (dist << 16));
-                    stop = stop || !room;
+                    if (room && !wrong) rec[nrec] = make_uint2((uint32_t)pos, mlen | (dist << 16));
+                    wrong = wrong || !room;
                 }
                 nrec++;
                 pos += mlen;
             }
-            if (stop) {
+            if (wrong) {
                 bad = true;
                 break;
             }
@@ -1311,12 +1311,12 @@ int gz_inflate_group(psk_ctx *ctx, int n, const uint8_t *const *data, const size
     PSK_HIP(ctx, hipSetDevice(ctx->device));
     hipStream_t st = on_stream ? on_stream : ctx->stream;
     std::vector<GzFile> files((size_t)n);
-    std::vector<uint64_t> at((size_t)n);
-    const uint64_t comp_total = gz_image_layout(n, sizes, at.data());
+    std::vector<uint64_t> image_at((size_t)n);
+    const uint64_t comp_total = gz_image_layout(n, sizes, image_at.data());
     for (int i = 0; i < n; i++) {
         files[i].data = data[i];
         files[i].size = sizes[i];
-        files[i].at = at[(size_t)i];
+        files[i].at = image_at[(size_t)i];
     }
     // ---- the chunks --------------------------------------------------------------------------------------------
     size_t deflate_bytes = 0;
