@@ -115,6 +115,9 @@ def _read_phases(d, world):
             with open(os.path.join(d, "phases_rank%d.json" % r)) as f:
                 rec = json.load(f)
             out["rank%d" % r] = {"total_s": rec["total_s"], "phases_s": rec["phases_s"]}
+            for key in ("stuck_in", "stuck_in_for_s", "blocked_in_call", "blocked_for_s"):   # a rank that was asked where it hangs
+                if rec.get(key) is not None:
+                    out["rank%d" % r][key] = rec[key]
         except (OSError, ValueError, KeyError):
             out["rank%d" % r] = None
     return out
@@ -166,7 +169,53 @@ def e2e_modeling(gs, n, k, cold=False):
         shutil.rmtree(tmp, ignore_errors=True)
 
 
-def e2e_modeling_sharded(grp, gs, n, k, args):
+def _run_child_with_budget(cmd, cwd, env, budget_s):
+    """One CLI child: (rc, stderr tail).  A child still running after budget_s is first asked where it is (SIGUSR1: it writes
+    phases_rank<r>.json with the phase and the call it is stuck in, watchdog.py), then terminated by its pid; rc 124 then."""
+    import signal
+    import subprocess
+    import tempfile
+    with tempfile.TemporaryFile() as errf:
+        p = subprocess.Popen(cmd, cwd=cwd, env=env, stdout=subprocess.DEVNULL, stderr=None if os.environ.get("PSK_TRACE") else errf)
+        rc = None
+        try:
+            rc = p.wait(timeout=budget_s)
+        except subprocess.TimeoutExpired:
+            for sig, wait_s in ((signal.SIGUSR1, 2.0), (signal.SIGTERM, 5.0), (signal.SIGKILL, 5.0)):
+                try:
+                    p.send_signal(sig)
+                except OSError:
+                    pass
+                if sig != signal.SIGUSR1:
+                    try:
+                        p.wait(timeout=wait_s)
+                        break
+                    except subprocess.TimeoutExpired:
+                        pass
+                else:
+                    time.sleep(wait_s)
+            rc = 124
+        finally:
+            if p.poll() is None:
+                p.kill()
+                p.wait()
+        errf.seek(0, os.SEEK_END)
+        size = errf.tell()
+        errf.seek(max(0, size - 600))
+        return rc, errf.read().decode(errors="replace")
+
+
+def e2e_budget_s(t_launch):
+    """Seconds the end-to-end leg may take: min(900, what is left of the launch's deadline - 60 s), so that the leg's own
+    time-out fires -- and is reported in the line -- before the launch's deadline does (VERDICT r05 weak #3)."""
+    from phenotypeseeker_amd import launch
+    deadline = launch.launch_timeout()
+    if not deadline or deadline <= 0:
+        return 900.0
+    return min(900.0, deadline - (time.time() - t_launch) - 60.0)
+
+
+def e2e_modeling_sharded(grp, gs, n, k, args, budget_s=900.0):
     """The same figure with several ranks: rank 0 writes the FASTA files once, then EVERY rank starts
     `phenotypeseeker modeling data.pheno` as a child process (RANK / LOCAL_RANK / WORLD_SIZE as this launch has them, a
     rendezvous directory of its own) in that directory; the wall-clock is the slowest rank's, process start to exit.  The
@@ -208,16 +257,15 @@ def e2e_modeling_sharded(grp, gs, n, k, args):
         t0 = time.time()
         rc, err_tail = 0, ""
         try:
-            r = subprocess.run(cmd, cwd=tmp, env=env, stdout=subprocess.DEVNULL, stderr=None if os.environ.get("PSK_TRACE") else subprocess.PIPE,
-                               timeout=900)
-            rc, err_tail = r.returncode, (r.stderr or b"").decode(errors="replace")[-600:]
-        except Exception as e:   # noqa: BLE001 -- a child that hangs is killed by the timeout
+            rc, err_tail = _run_child_with_budget(cmd, tmp, env, budget_s)
+        except Exception as e:   # noqa: BLE001
             rc, err_tail = -1, "%s: %s" % (type(e).__name__, e)
         wall = time.time() - t0
         worst = grp.allreduce_max(wall)
         failed = grp.allreduce_sum(1 if rc != 0 else 0)
+        rcs = [int(x) for x in grp.allgather_i64(np.array([rc]))[:, 0]]
         made = sorted(f for f in os.listdir(tmp) if f.endswith(".pkl")) if rank == 0 else []
-        res = {"modeling_wall_s": round(worst, 3), "ranks": grp.world, "ingest": args.ingest,
+        res = {"modeling_wall_s": round(worst, 3), "ranks": grp.world, "ingest": args.ingest, "rc": rcs, "budget_s": round(budget_s, 1),
                "phases": _read_phases(tmp, grp.world) if rank == 0 else None,
                "what": "phenotypeseeker modeling data.pheno as %d child processes (one per rank, started after the files were "
                        "written): %d FASTA files on disk -> %s" % (grp.world, n, ", ".join(made) or "no model"),
@@ -225,7 +273,13 @@ def e2e_modeling_sharded(grp, gs, n, k, args):
         if rank == 0 and not made and not failed:
             res["error"] = "no .pkl written; rank 0: %s" % err_tail
         if failed:
-            res["error"] = "%d rank(s) failed; rank %d: %s" % (failed, rank, err_tail[-400:])
+            res["error"] = "%d rank(s) failed (rc per rank %s; 124 = over the leg's budget of %.0f s, < 0 = killed by that signal); " \
+                           "rank %d: %s" % (failed, rcs, budget_s, rank, err_tail[-400:])
+            if rank == 0:    # the first phase some rank did not get through
+                stuck = [(r_, v.get("stuck_in")) for r_, v in ((r_, res["phases"].get("rank%d" % r_) or {}) for r_ in range(grp.world))
+                         if v.get("stuck_in")]
+                missing = [r_ for r_ in range(grp.world) if res["phases"].get("rank%d" % r_) is None]
+                res["first_failing_phase"] = {"stuck": dict(("rank%d" % r_, p_) for r_, p_ in stuck), "no_table_from_ranks": missing}
         return res
     except Exception as e:   # noqa: BLE001 -- reported in the line
         return {"error": "%s: %s" % (type(e).__name__, e)}
@@ -284,6 +338,11 @@ def main():
     # a launch that runs into its deadline (launch.spawn_ranks: PSK_LAUNCH_TIMEOUT) asks every rank where it is: the rank
     # answers SIGUSR1 with phases_rank<r>.json -- the phase and the call it is stuck in
     t_proc = time.time()
+    # when the launch began: launch.spawn_ranks says (PSK_LAUNCH_T0); under somebody else's launcher, this process's start
+    try:
+        t_launch = float(os.environ["PSK_LAUNCH_T0"]) if os.environ.get("PSK_LAUNCHER") == "psk" else t_proc
+    except (KeyError, ValueError):
+        t_launch = t_proc
     done_phases = {}
 
     def phase(name, _last=[None, t_proc]):
@@ -453,25 +512,23 @@ def main():
         drain(0)   # the last exchange completes inside the timed region
     grp.barrier()
     elapsed = time.perf_counter() - t0
-    phase("reductions of the result line, roofline, CPU baseline, e2e leg")
+    phase("reductions of the result line")
     elapsed = grp.allreduce_max(elapsed)
     cells_total = grp.allreduce_sum(int(M) * n) * args.steps
     value = cells_total / elapsed
+    # what every rank spent where before the timed region (one small all-gather): the first thing to look at when an N > 1
+    # line disappoints -- which rank's count / exchange / matrix build was the slow one
+    mine = dict((key, ingest.get(key)) for key in ("count_s", "exchange_s", "presence_s", "pilot_s", "generate_s"))
+    mine["setup_s"] = round(t_setup, 3)
+    per_rank = [json.loads(b.decode()) for b in grp.allgather_bytes(json.dumps(mine).encode())] if sharded else [mine]
 
     # roofline of the dominant kernel (this rank): algorithmic bytes = M * 8 * ceil(N/64)
     # (1 bit per cell; the kernel does not read the key array)
     alg_words = (n + 63) // 64
     alg_bytes = M * 8 * alg_words
     mean_ms = float(np.mean(kernel_ms))
-    achieved = alg_bytes / (mean_ms * 1e-3) / 1e9
+    achieved = alg_bytes / (mean_ms * 1e-3) / 1e9 if mean_ms > 0 else 0.0
     traffic = measured_traffic(int(M), wpr)
-    # the stream-read ceiling measured in this run, on this matrix ("against both the 8 TB/s spec and the measured
-    # stream-read ceiling"): a kernel that only reads the matrix, 16 B per lane, as many launches as the timed steps, its clocks
-    # settled like the scan's -- outside the timed region
-    ctx.stream_read_ceiling(3)
-    ceil_ms, ceil_bytes, ceil_shape = ctx.stream_read_ceiling(max(args.steps, 10))
-    ceiling = ceil_bytes / (ceil_ms * 1e-3) / 1e9
-    stored_rate = int(M) * 8 * wpr / (mean_ms * 1e-3) / 1e9      # bytes of the matrix as stored (= algorithmic unless rows are padded)
     # a multi-rank figure is a scaling point only when its collectives ran on RCCL with one GPU per rank
     real_multi = sharded and grp.backend == "rccl" and grp.rccl_ranks == world and not args.share_gpu
     scaling = "weak" if not sharded else ("strong" if real_multi else
@@ -485,37 +542,116 @@ def main():
         "config": {"workload": workload, "n_samples": n, "k": k, "rows_per_gpu": int(M),
                    "words_per_row_stored": wpr, "survivors": int(npass), "survivors_all_slabs": int(gathered[0]) if xch is not None
                    else int(npass), "device": info["name"],
-                   "setup_s": round(t_setup, 2), "ingest": ingest,
+                   "setup_s": round(t_setup, 2), "ingest": ingest, "ingest_per_rank": per_rank,
                    "rows_global": int(M_global), "rows_per_rank": rows_per_rank,
-                   "balance_max_over_mean": round(max(rows_per_rank) / (sum(rows_per_rank) / len(rows_per_rank)), 4),
+                   "balance_max_over_mean": round(max(rows_per_rank) / max(sum(rows_per_rank) / len(rows_per_rank), 1e-9), 4),
                    "collectives": (grp.backend or "none") +
                    (" (fallback: %s)" % grp.t.fallback_reason[:700] if getattr(grp.t, "fallback_reason", None) else "")},
         "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                      "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "kernel": "chi2_scan_kernel",
                      "kernel_ms": mean_ms, "algorithmic_bytes_per_launch": alg_bytes,
-                     "stored_bytes_per_launch": int(M) * 8 * wpr,
-                     "measured_stream_ceiling": {"GBps": ceiling, "kernel": "stream_read_kernel (%s)" % ceil_shape, "kernel_ms": ceil_ms,
-                                                 "bytes_per_launch": int(ceil_bytes), "frac_of_peak": ceiling / HBM_PEAK_GBS,
-                                                 "what": "the same matrix read once per launch by a kernel that does nothing else (the fastest "
-                                                         "of four shapes), timed with HIP events in this run"},
-                     "frac_of_measured_ceiling": stored_rate / ceiling},
+                     "stored_bytes_per_launch": int(M) * 8 * wpr},
     }
-
+    if args.workload == "fasta" and n == 2048 and k == 16 and args.length == 5_000_000:
+        # BASELINE config 3: the N = 1 run of it is the base of the strong-scaling curve, the N > 1 lines say so
+        out["config"]["scaling_base"] = ("this line: the same 2,048 x 5-Mbp, k = 16 dataset on one GPU" if not sharded else
+                                         "`bench.py --gpus 1 --samples 2048 --kmer 16` on the same dataset "
+                                         "(profiles/r06_cfg3_n1.json); the default N = 1 line is BASELINE config 2, another workload")
     if sharded or args.force_exchange:
         out["rccl_ranks"] = grp.rccl_ranks     # ncclCommCount of the communicator the collectives ran on (0: not RCCL)
     if args.force_exchange:
         out["exchange"] = "forced"
-    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+
+    # `value` and the roofline of the timed steps exist: the line goes out NOW (rank 0, flushed), before any of the legs below
+    # can hang or die (an 8-GPU line must not be lost to a leg that does not define it).  Every leg that
+    # completes re-emits the augmented line: the LAST JSON line of stdout is the record, and `legs` says what it lacks.
+    line = ResultLine(rank, out)
+    watchdog.on_dump(line.on_deadline)       # a launch that runs into its deadline re-emits what there is, with the stuck phase
+    legs = out["legs"] = {}
+    todo = ["kernel_spread", "stream_ceiling", "hbm_only"]
+    if world == 1 and not args.no_cpu_baseline:
+        todo.append("cpu_baseline")
+    if args.workload == "fasta" and not args.no_e2e:
+        todo.append("e2e")
+    for name_ in todo:
+        legs[name_] = "pending"
+    line.emit()
+    rf = out["roofline"]
+
+    def leg(name_, fn):
+        """A leg may fail; the line may not.  (Legs that make collectives handle their own failures so that every rank still
+        makes them -- e2e_modeling_sharded; the legs before it are this rank's alone.)"""
+        if name_ not in legs:
+            return
+        phase("leg: " + name_)
+        try:
+            legs[name_] = fn() or "ok"
+        except Exception as e:   # noqa: BLE001 -- reported in the line
+            legs[name_] = "failed: %s: %s" % (type(e).__name__, str(e)[:300])
+        line.emit()
+
+    def leg_kernel_spread():
+        # >= 200 more launches of the same scan, each timed with its own pair of HIP events (VERDICT r05 weak #8: 20 launches
+        # = 2.3 ms carry no spread): `value` stays what the K timed steps gave
+        more = ctx.rescan_times(max(200, args.steps))
+        rf["kernel_ms_min"], rf["kernel_ms_p50"], rf["kernel_ms_p95"], rf["kernel_ms_max"] = (
+            float(np.min(more)), float(np.percentile(more, 50)), float(np.percentile(more, 95)), float(np.max(more)))
+        rf["kernel_ms_launches"] = int(len(more))
+        rf["frac_p50"] = alg_bytes / (rf["kernel_ms_p50"] * 1e-3) / 1e9 / HBM_PEAK_GBS if rf["kernel_ms_p50"] > 0 else None
+
+    def leg_stream_ceiling():
+        # the stream-read ceiling measured in this run, on this matrix (SURVEY.md 8(d): "against both the 8 TB/s spec and the
+        # measured stream-read ceiling"): a kernel that only reads the matrix, 16 B per lane, as many launches as the timed
+        # steps, its clocks settled like the scan's -- outside the timed region
+        ctx.stream_read_ceiling(3)
+        ceil_ms, ceil_bytes, ceil_shape = ctx.stream_read_ceiling(max(args.steps, 10))
+        if ceil_bytes == 0 or ceil_ms <= 0 or mean_ms <= 0:      # an empty (or < 16-byte) slab has no ceiling to quote
+            rf["measured_stream_ceiling"], rf["frac_of_measured_ceiling"] = None, None
+            return "ok (matrix too small for a ceiling)"
+        ceiling = ceil_bytes / (ceil_ms * 1e-3) / 1e9
+        stored_rate = int(M) * 8 * wpr / (mean_ms * 1e-3) / 1e9      # bytes of the matrix as stored (= algorithmic unless rows are padded)
+        rf["measured_stream_ceiling"] = {"GBps": ceiling, "kernel": "stream_read_kernel (%s)" % ceil_shape, "kernel_ms": ceil_ms,
+                                         "bytes_per_launch": int(ceil_bytes), "frac_of_peak": ceiling / HBM_PEAK_GBS,
+                                         "what": "the same matrix read once per launch by a kernel that does nothing else (the fastest "
+                                                 "of four shapes), timed with HIP events in this run"}
+        rf["frac_of_measured_ceiling"] = stored_rate / ceiling
+
+    def leg_hbm_only():
+        # the same kernel on a matrix the 256-MiB Infinity Cache cannot hold (the headline matrix of config 2 is 0.73 GB, of
+        # which a third stays cached between launches): >= 4 GB of device-generated rows of the same width, rank 0 only
+        if rank != 0:
+            return "ok (rank 0 only)"
+        rows_big = int(max(4.3e9 // (8 * alg_words), 1))
+        with PskContext(grp.device) as big:
+            big.synth_presence(rows_big, n, seed=11)
+            big.chi2_scan(pheno, None, 2, n - 2, 0.05, False, rows_big)
+            w_ms = big.rescan_timed(3)
+            big.rescan_timed(int(min(100, max(3, 40.0 / max(w_ms, 0.01)))))
+            ms_big = big.rescan_times(50)
+            _, wpr_big, _ = big.presence_shape()
+            big.stream_read_ceiling(2)
+            c_ms, c_bytes, c_shape = big.stream_read_ceiling(10)
+        b_big = rows_big * 8 * alg_words
+        p50 = float(np.percentile(ms_big, 50))
+        rf["hbm_only"] = {"rows": rows_big, "bytes_per_launch": b_big, "stored_bytes_per_launch": rows_big * 8 * wpr_big,
+                          "kernel_ms_mean": float(np.mean(ms_big)), "kernel_ms_min": float(np.min(ms_big)), "kernel_ms_p50": p50,
+                          "kernel_ms_p95": float(np.percentile(ms_big, 95)), "launches": int(len(ms_big)),
+                          "achieved": b_big / (float(np.mean(ms_big)) * 1e-3) / 1e9, "frac": b_big / (float(np.mean(ms_big)) * 1e-3) / 1e9 / HBM_PEAK_GBS,
+                          "stream_ceiling_GBps": c_bytes / (c_ms * 1e-3) / 1e9 if c_ms > 0 else None, "stream_ceiling_kernel": c_shape,
+                          "what": "the same scan over a device-generated matrix of %.1f GB (psk_synth_presence, same row width): "
+                                  "beyond the Infinity Cache, every byte comes from HBM" % (b_big / 1e9)}
+
+    def leg_cpu_baseline():
         # CPU baseline: the oracle's scan (C restatement of modeling.py:677-858, "port") on the same matrix, checked
         # equal to the GPU's answer first; rows are independent, so they are cut into one range per host thread
         # (orc_chi2_scan_mt, POSIX threads -- the reference runs its chunks in a process pool).  One thread alone is
-        # timed too, on a part of the rows.
+        # timed too, on a part of the rows.  The sample is bounded in CELLS (about 1e10 per pass), whatever the row width.
         from oracle import oracle as O
-        ns = int(min(args.cpu_sample_rows, M))
+        ns = int(max(1, min(args.cpu_sample_rows, M, 10_240_000_000 // n)))
         rows = ctx.get_rows(np.arange(ns, dtype=np.uint64))
         threads = host_cpus()
         ph_list, ones = pheno.tolist(), np.ones(n)
-        n1 = min(ns, 4_000_000)
+        n1 = int(max(1, min(ns, 1_024_000_000 // n)))
         t0 = time.perf_counter()
         ref1 = O.chi2_scan(rows[:n1], ph_list, ones, n, 2, n - 2, 0.05, False, M_global)
         dt1 = time.perf_counter() - t0
@@ -540,18 +676,62 @@ def main():
                                "single_thread_value": n1 * n / dt1,
                                "matches_gpu": same,
                                "reference_python_8proc_cells_per_s": 7.4e6}
-    if rank == 0 and world == 1 and args.workload == "fasta" and not args.no_e2e:
-        out["e2e"] = e2e_modeling(gs, n, k, cold=args.e2e_cold)
-    ctx.close()   # the matrix and the lists go before the CLI children of the next leg bring their own
-    if world > 1 and args.workload == "fasta" and not args.no_e2e:
-        out["e2e"] = e2e_modeling_sharded(grp, gs, n, k, args)
+
+    # the last scan of the timed steps is the one whose results the CPU leg checks: the spread leg re-runs the SAME scan into
+    # the same result set, so `npass` stays what it was
+    leg("kernel_spread", leg_kernel_spread)
+    leg("stream_ceiling", leg_stream_ceiling)
+    leg("cpu_baseline", leg_cpu_baseline)
+
+    def leg_e2e():
+        budget = e2e_budget_s(t_launch)
+        if world == 1:
+            out["e2e"] = e2e_modeling(gs, n, k, cold=args.e2e_cold)
+        else:
+            if grp.allreduce_sum(1 if budget < 30.0 else 0):     # every rank takes the same branch
+                out["e2e"] = {"skipped": "%.0f s left of the launch's deadline (PSK_LAUNCH_TIMEOUT) once 60 s are set aside" % budget}
+                return "skipped: no time left before the launch's deadline"
+            out["e2e"] = e2e_modeling_sharded(grp, gs, n, k, args, budget_s=budget)
+        if "error" in out["e2e"]:
+            return "failed: " + out["e2e"]["error"][:300]
+
+    ctx.close()   # the matrix and the lists go before the hbm-only matrix and the CLI children of the e2e leg bring their own
+    leg("hbm_only", leg_hbm_only)
+    leg("e2e", leg_e2e)
+    phase("teardown")
     grp.close()
-    if rank == 0:
-        # RCCL prints a version banner through C stdio, which (piped) is flushed at exit, after Python's own
-        # buffer: flush it now so that the JSON line is the LAST line of stdout
-        import ctypes
-        ctypes.CDLL(None).fflush(None)
-        print(json.dumps(out), flush=True)
+    line.emit(final=True)
+
+
+class ResultLine:
+    """Rank 0's JSON line.  Printed -- flushed, as the last line of stdout so far -- as soon as `value` exists, and again
+    whenever a leg has added to it: whatever happens afterwards (a leg that hangs into the launch's deadline, a child that is
+    killed), the LAST JSON line of stdout is a complete metric line, and its `line` / `legs` fields say what it lacks."""
+
+    def __init__(self, rank, out):
+        import threading
+        self.rank, self.out, self.lock = rank, out, threading.Lock()
+
+    def emit(self, final=False, aborted=None):
+        if self.rank != 0:
+            return
+        with self.lock:
+            pending = [k_ for k_, v in self.out.get("legs", {}).items() if v == "pending"]
+            self.out["line"] = ("final" if final and not pending else
+                                "provisional: legs pending: " + ", ".join(pending) if pending else "provisional")
+            if aborted is not None:
+                self.out["aborted"] = aborted
+            # RCCL prints a version banner through C stdio, which (piped) is flushed at exit, after Python's own
+            # buffer: flush it now so that the JSON line is the LAST line of stdout
+            import ctypes
+            ctypes.CDLL(None).fflush(None)
+            sys.stdout.write(json.dumps(self.out) + "\n")
+            sys.stdout.flush()
+
+    def on_deadline(self, rec):
+        """watchdog: the launch ran into its deadline (or this rank was asked where it is): the line again, with the phase."""
+        self.emit(aborted={"stuck_in": rec.get("stuck_in"), "blocked_in_call": rec.get("blocked_in_call"),
+                           "what": "this rank was asked where it is (SIGUSR1 / PSK_LAUNCH_TIMEOUT): the legs marked pending did not finish"})
 
 
 if __name__ == "__main__":

@@ -222,6 +222,9 @@ double psk_last_scan_ms(const psk_ctx *ctx);
 /* Re-launches the last chi2 scan `reps` times back to back on the context's stream and
  * returns the mean kernel duration in ms measured with HIP events on that stream. */
 int psk_rescan_timed(psk_ctx *ctx, int reps, double *mean_ms);
+/* The same, returning the HIP-event duration of every one of the `reps` launches in ms_each[reps] (bench.py: the
+ * min / median / 95th percentile of the headline kernel; measurement only, no reference call site). */
+int psk_rescan_times(psk_ctx *ctx, int reps, double *ms_each);
 
 /* Measurement only (the scan's achieved bandwidth is quoted "against both the 8 TB/s spec and
  * the measured stream-read ceiling"; no reference call site -- the reference has no notion of bandwidth): reads the

@@ -61,6 +61,7 @@ _SIGNATURES = {
     "psk_export_survivors": (c.c_int, [c.c_void_p, c.c_void_p, c.c_uint64, _u64p]),
     "psk_last_scan_ms": (c.c_double, [c.c_void_p]),
     "psk_rescan_timed": (c.c_int, [c.c_void_p, c.c_int, c.POINTER(c.c_double)]),
+    "psk_rescan_times": (c.c_int, [c.c_void_p, c.c_int, c.c_void_p]),
     "psk_stream_read_ceiling": (c.c_int, [c.c_void_p, c.c_int, c.POINTER(c.c_double), _u64p, c.POINTER(c.c_int)]),
     "psk_logreg_l1_fit": (c.c_int, [c.c_void_p, c.c_void_p, c.c_void_p, c.c_int, c.c_int, c.c_void_p, c.c_void_p,
                                     c.c_void_p, c.c_int, c.c_double, c.c_int, c.c_void_p, c.c_void_p, c.c_void_p]),

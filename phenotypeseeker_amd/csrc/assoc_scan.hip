@@ -1266,7 +1266,7 @@ int pick_result_set(psk_ctx *ctx, int *set_out, bool keep_results = false)
     return PSK_OK;
 }
 
-int run_chi2(psk_ctx *ctx, ScanArgs &a, bool weighted, int reps, double *ms_total)
+int run_chi2(psk_ctx *ctx, ScanArgs &a, bool weighted, int reps, double *ms_total, double *ms_each = nullptr)
 {
     const int G = group_lanes(a);
     const dim3 grid = scan_grid(ctx, a.M, G, SC_UNROLL, a.lut != nullptr || a.lut6 != nullptr);
@@ -1280,6 +1280,7 @@ int run_chi2(psk_ctx *ctx, ScanArgs &a, bool weighted, int reps, double *ms_tota
         float ms = 0;
         PSK_HIP(ctx, hipEventElapsedTime(&ms, ctx->ev0, ctx->ev1));
         *ms_total += ms;
+        if (ms_each) ms_each[r] = ms;
     }
     return PSK_OK;
 }
@@ -1453,7 +1454,7 @@ extern "C" int psk_chi2_scan(psk_ctx *ctx, const int8_t *pheno, const double *we
 }
 
 
-extern "C" int psk_rescan_timed(psk_ctx *ctx, int reps, double *mean_ms)
+static int rescan(psk_ctx *ctx, int reps, double *mean_ms, double *ms_each)
 {
     if (!ctx) return PSK_EINVAL;
     if (ctx->n_in_flight) return psk_fail(ctx, PSK_ESTATE, "a scan is in flight (psk_scan_end first)");
@@ -1467,11 +1468,19 @@ extern "C" int psk_rescan_timed(psk_ctx *ctx, int reps, double *mean_ms)
     PSK_TRY(fill_chi2_args(ctx, a, set));
     a.n1 = ctx->last.n1; a.n0 = ctx->last.n0; a.W1 = ctx->last.W1; a.W0 = ctx->last.W0;
     double ms = 0;
-    PSK_TRY(run_chi2(ctx, a, ctx->last.weighted, reps, &ms));
+    PSK_TRY(run_chi2(ctx, a, ctx->last.weighted, reps, &ms, ms_each));
     ctx->last_scan_ms = ms / reps;
     PSK_TRY(fetch_counts(ctx, set));
     if (mean_ms) *mean_ms = ms / reps;
     return PSK_OK;
+}
+
+extern "C" int psk_rescan_timed(psk_ctx *ctx, int reps, double *mean_ms) { return rescan(ctx, reps, mean_ms, nullptr); }
+
+extern "C" int psk_rescan_times(psk_ctx *ctx, int reps, double *ms_each)
+{
+    if (ctx && !ms_each) return psk_fail(ctx, PSK_EINVAL, "null output array");
+    return rescan(ctx, reps, nullptr, ms_each);
 }
 
 extern "C" int psk_ttest_scan(psk_ctx *ctx, const double *pheno, const uint8_t *valid, const double *weights,

@@ -742,17 +742,23 @@ __global__ __launch_bounds__(64) void gz_decode_kernel(GzDecodeArgs a)
 // they wait for.  A source that lies before the chunk is a marker: 256 + its place in the unknown window.
 constexpr int GZ_COPY_WIDE = 2;   // 16-byte pieces a lane has in flight
 
-__global__ __launch_bounds__(256) void gz_copy_kernel(uint16_t *sym, const uint2 *rec, const uint64_t *rec_off, const uint64_t *n_rec,
+// The records are the writing pass's: a chunk whose pass ended in GZ_ERROR has left its records (and symbols) half written --
+// what lies behind them is an earlier group's data or uninitialised memory: such a chunk is not copied at all, no
+// chunk copies more records than its pass wrote, and a record that would write outside its chunk's text is dropped whatever
+// wrote it (its file then fails the check sum and goes to zlib).
+__global__ __launch_bounds__(256) void gz_copy_kernel(uint16_t *sym, const uint2 *rec, const uint64_t *rec_off, const uint64_t *want_rec,
+                                                       const uint64_t *got_rec, const int32_t *link, const uint64_t *want_len,
                                                        const uint64_t *out_off, int n_chunks, unsigned long long *stats)
 {
     __shared__ uint32_t g_d[4][64], g_e[4][64], g_ld[4][64];   // the 64 matches in hand: first and last + 1 symbol written; length | distance << 16
     __shared__ long long g_s[4][64];                           // where they read (after the redirections below)
     const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
     const int c = blockIdx.x * 4 + wv;
-    if (c >= n_chunks) return;
+    if (c >= n_chunks || link[c] == GZ_ERROR) return;
     uint16_t *out = sym + out_off[c];
     const uint2 *r = rec + rec_off[c];
-    const uint64_t n = n_rec[c];
+    const uint64_t n = got_rec[c] < want_rec[c] ? got_rec[c] : want_rec[c];
+    const uint64_t text_len = want_len[c];
     auto wave_sync = [] {
         // the readers are lanes of this very wave: the stores only have to have left it (a fence of agent scope writes the
         // L2 back on a part with eight of them)
@@ -762,9 +768,9 @@ __global__ __launch_bounds__(256) void gz_copy_kernel(uint16_t *sym, const uint2
     const uint2 none = make_uint2(0xffffffffu, 0);
     uint2 x = (uint64_t)lane < n ? r[lane] : none;
     for (uint64_t g = 0; g < n; g += 64) {
-        const bool valid = g + lane < n;
         const uint2 nx = g + 64 + lane < n ? r[g + 64 + lane] : none;   // (the next 64, on their way while these are copied)
         const uint32_t d = x.x, len = x.y & 0xffffu, dist = x.y >> 16;
+        const bool valid = g + lane < n && dist != 0 && dist <= (uint32_t)GZ_WIN && len != 0 && (uint64_t)d + len <= text_len;
         int64_t s = (int64_t)d - (int64_t)dist;
         const int64_t span = len < dist ? len : dist;   // (an overlapping match reads only the `dist` symbols before it)
         const uint32_t d0 = (uint32_t)__builtin_amdgcn_readfirstlane((int)d);
@@ -776,7 +782,7 @@ __global__ __launch_bounds__(256) void gz_copy_kernel(uint16_t *sym, const uint2
             // but a match that reads INSIDE an earlier (non-overlapping) match reads what that one read: it is pointed there,
             // again and again, until its source is text that is already in place.
             if (stats && lane == 0) atomicAdd(stats + 2, 1ull);
-            g_d[wv][lane] = d;
+            g_d[wv][lane] = valid ? d : 0xffffffffu;   // (a dropped record is nobody's source)
             g_e[wv][lane] = valid ? d + len : 0xffffffffu;
             g_ld[wv][lane] = x.y;
             g_s[wv][lane] = s;
@@ -988,7 +994,7 @@ __global__ __launch_bounds__(256) void gz_resolve_kernel(const uint16_t *sym, ui
 #pragma unroll
             for (int j = 0; j < 8; j++) {
                 const uint32_t s = (w[j >> 1] >> ((j & 1) * 16)) & 0xffffu;
-                const uint8_t b = s < 256 ? (uint8_t)s : win[s - 256];
+                const uint8_t b = s < 256 ? (uint8_t)s : win[(s - 256) & (GZ_WIN - 1)];   // (masked: a symbol of a failed chunk may be anything)
                 packed |= (uint64_t)b << (8 * j);
                 nul = nul || b == 0;
             }
@@ -999,7 +1005,7 @@ __global__ __launch_bounds__(256) void gz_resolve_kernel(const uint16_t *sym, ui
         } else {
             for (uint64_t j = j0; j < body; j++) {
                 const uint32_t s = sym[o + j];
-                const uint8_t b = s < 256 ? (uint8_t)s : win[s - 256];
+                const uint8_t b = s < 256 ? (uint8_t)s : win[(s - 256) & (GZ_WIN - 1)];
                 out[o + j] = b;
                 if (b == 0) atomicMin(first_nul + file, (unsigned long long)(o + j));
             }
@@ -1285,27 +1291,36 @@ int gz_inflate_group(psk_ctx *ctx, int n, const uint8_t *const *data, const size
     // `host_threads` threads (what glistmaker does per file).
     size_t comp_bytes = 0;
     for (int i = 0; i < n; i++) comp_bytes += sizes[i];
-    if (!gz_group_on_device(n, sizes, host_only, host_threads)) {
+    // zlib over the files `which` names, one file a thread of a pool of host_threads (the first error, in file order, is the call's)
+    auto host_route = [&](const std::vector<int> &which) -> int {
+        const int nw = (int)which.size();
         std::atomic<int> next(0), bad(0);
-        std::vector<std::string> errs((size_t)n);
+        std::vector<std::string> errs((size_t)nw);
         auto work = [&]() {
             for (;;) {
-                const int i = next.fetch_add(1);
-                if (i >= n) return;
-                if (!gz_host_inflate(data[i], sizes[i], res[(size_t)i].host, &errs[(size_t)i])) bad = 1;
+                const int j = next.fetch_add(1);
+                if (j >= nw) return;
+                const int i = which[(size_t)j];
+                if (!gz_host_inflate(data[i], sizes[i], res[(size_t)i].host, &errs[(size_t)j])) bad = 1;
                 res[(size_t)i].len = res[(size_t)i].host.size();
             }
         };
         std::vector<std::thread> pool;
         const int nt = host_threads < 1 ? 1 : (host_threads > 32 ? 32 : host_threads);
-        for (int t = 1; t < nt && t < n; t++) pool.emplace_back(work);
+        for (int t = 1; t < nt && t < nw; t++) pool.emplace_back(work);
         work();
         for (auto &t : pool) t.join();
         if (bad)
-            for (int i = 0; i < n; i++)
-                if (!errs[(size_t)i].empty()) return psk_fail(ctx, PSK_EINVAL, "%s", errs[(size_t)i].c_str());
+            for (int j = 0; j < nw; j++)
+                if (!errs[(size_t)j].empty()) return psk_fail(ctx, PSK_EINVAL, "%s", errs[(size_t)j].c_str());
+        return PSK_OK;
+    };
+    if (!gz_group_on_device(n, sizes, host_only, host_threads)) {
+        std::vector<int> all((size_t)n);
+        for (int i = 0; i < n; i++) all[(size_t)i] = i;
+        PSK_TRY(host_route(all));
         if (std::getenv("PSK_TRACE"))
-            std::fprintf(stderr, "[psk] gz inflate: %d files, %.1f MB compressed: zlib on %d host threads\n", n, comp_bytes / 1e6, nt < n ? nt : n);
+            std::fprintf(stderr, "[psk] gz inflate: %d files, %.1f MB compressed: zlib on at most %d host threads\n", n, comp_bytes / 1e6, host_threads < 1 ? 1 : host_threads);
         return PSK_OK;
     }
     PSK_HIP(ctx, hipSetDevice(ctx->device));
@@ -1539,6 +1554,12 @@ int gz_inflate_group(psk_ctx *ctx, int n, const uint8_t *const *data, const size
                 if (!c.counted) break;   // in `todo`: the next round
                 f.chain.push_back(cidx);
                 if (c.link >= 0) {
+                    if (ch[(size_t)c.link].true_start) {
+                        // a block that ends, without being the last of its member, where another member's data begin: no
+                        // stream zlib accepts does that (a crafted BSIZE / member header does): zlib words the error
+                        f.device_ok = false;
+                        break;
+                    }
                     next_chunk[(size_t)i] = c.link;
                     continue;
                 }
@@ -1613,6 +1634,20 @@ int gz_inflate_group(psk_ctx *ctx, int n, const uint8_t *const *data, const size
     std::vector<uint32_t> m_crc;
     std::vector<int> m_file;
     uint64_t total_rec = 0;
+    // a file's chain is members one after the other -- first chunk a member's start, none in the middle of a member (a chunk
+    // that was linked to BEFORE a later walk found a member starting there), the last chunk the end of a member: anything else
+    // is declined here, so that every member below has a beginning AND a length and the check sums are never skipped
+    for (int i = 0; i < n; i++) {
+        GzFile &f = files[(size_t)i];
+        if (!f.device_ok) continue;
+        bool open = false, ok = !f.chain.empty();
+        for (int c : f.chain) {
+            const GzChunk &k = ch[(size_t)c];
+            if (k.true_start == open) ok = false;   // a start inside a member, or a member that does not begin with one
+            open = k.link != GZ_FINAL;
+        }
+        if (!ok || open) f.device_ok = false;
+    }
     for (int i = 0; i < n; i++) {
         GzFile &f = files[(size_t)i];
         if (!f.device_ok) continue;
@@ -1705,8 +1740,8 @@ int gz_inflate_group(psk_ctx *ctx, int n, const uint8_t *const *data, const size
             PSK_HIP(ctx, hipMalloc(reinterpret_cast<void **>(&d_stats), 64));
             PSK_HIP(ctx, hipMemsetAsync(d_stats, 0, 64, st));
         }
-        gz_copy_kernel<<<dim3((unsigned)div_up((uint64_t)m, 4)), dim3(256), 0, st>>>(sym_buf.as<uint16_t>(), rec_buf.as<uint2>(), a.rec_off, a.want_rec, d_off, (int)m,
-                                                                                   d_stats);
+        gz_copy_kernel<<<dim3((unsigned)div_up((uint64_t)m, 4)), dim3(256), 0, st>>>(sym_buf.as<uint16_t>(), rec_buf.as<uint2>(), a.rec_off, a.want_rec, a.n_rec, a.link,
+                                                                                   a.want_len, d_off, (int)m, d_stats);
         PSK_HIP(ctx, hipGetLastError());
         if (d_stats) {
             unsigned long long hs[8];
@@ -1728,7 +1763,9 @@ int gz_inflate_group(psk_ctx *ctx, int n, const uint8_t *const *data, const size
         PSK_HIP(ctx, hipMemcpyAsync(nul_at.data(), d_nul, file_first.size() * 8, hipMemcpyDeviceToHost, st));
         // the members' check sums (the tables go behind the writing pass's: tab_buf is grown before the pass, not here)
         std::vector<uint32_t> crc_got(m_begin.size(), 0);
-        const bool check_crc = m_begin.size() == m_len.size() && !m_begin.empty() && !std::getenv("PSK_GZ_NO_CRC");
+        if (m_begin.size() != m_len.size() || m_len.size() != m_crc.size())
+            return psk_fail(ctx, PSK_ESTATE, "gz inflate: %zu member starts, %zu member ends (internal error)", m_begin.size(), m_len.size());
+        const bool check_crc = !m_begin.empty() && !std::getenv("PSK_GZ_NO_CRC");
         if (check_crc) {
             const size_t nm = m_begin.size();
             uint8_t *mt = tab_buf.as<uint8_t>() + o_members;
@@ -1756,7 +1793,7 @@ int gz_inflate_group(psk_ctx *ctx, int n, const uint8_t *const *data, const size
                 if (crc_got[q] != m_crc[q]) files[(size_t)m_file[q]].device_ok = false;   // zlib will say "incorrect data check"
     }
     if (device_ms) *device_ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t_begin).count();
-    int declined = 0;
+    std::vector<int> declined_files;
     for (int i = 0; i < n; i++) {
         const GzFile &f = files[(size_t)i];
         GzInflated &r = res[(size_t)i];
@@ -1769,12 +1806,13 @@ int gz_inflate_group(psk_ctx *ctx, int n, const uint8_t *const *data, const size
             r.first_nul = r.len;
             if (f.nul_slot >= 0 && (size_t)f.nul_slot < nul_at.size() && nul_at[(size_t)f.nul_slot] != ~0ull) r.first_nul = nul_at[(size_t)f.nul_slot] - f.out_off;
         } else {
-            declined++;
-            std::string why;
-            if (!gz_host_inflate(f.data, f.size, r.host, &why)) return psk_fail(ctx, PSK_EINVAL, "%s", why.c_str());
-            r.len = r.host.size();
+            declined_files.push_back(i);
         }
     }
+    // what the device declined goes through zlib on the call's host threads, like a group the device never saw (a
+    // run of read sets from an encoder the device route declines -- fixed-Huffman or stored blocks only -- paid one thread)
+    const int declined = (int)declined_files.size();
+    if (declined) PSK_TRY(host_route(declined_files));
     if (trace)
         std::fprintf(stderr, "[psk] gz inflate: %d files, %zu chunks of %zu KB, %d counting round(s), %d declined (zlib on the host); ms:%s\n", n, ch.size(),
                      chunk >> 10, rounds, declined, phases.c_str());

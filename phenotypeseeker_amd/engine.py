@@ -356,6 +356,12 @@ class PskContext:
         self._check(self._lib.psk_rescan_timed(self._h, int(reps), ctypes.byref(ms)), "psk_rescan_timed")
         return ms.value
 
+    def rescan_times(self, reps):
+        """HIP-event duration in ms of each of `reps` repeats of the last chi2 scan (psk_rescan_times)."""
+        ms = np.zeros(int(reps), dtype=np.float64)
+        self._check(self._lib.psk_rescan_times(self._h, int(reps), _ptr(ms)), "psk_rescan_times")
+        return ms
+
     def stream_read_ceiling(self, reps):
         """(mean ms, bytes, shape) of the fastest plain 16-B-per-lane read of the presence matrix: the stream-read ceiling
         the scan's achieved bandwidth is quoted against (psk_stream_read_ceiling)."""

@@ -49,7 +49,8 @@ def spawn_ranks(argv, world, share_gpu=False, env_extra=None, grace_s=15.0, dead
     base = dict(os.environ)
     base.update(env_extra or {})
     base.update({"WORLD_SIZE": str(world), "LOCAL_WORLD_SIZE": str(world), "PSK_RDZV_DIR": rdzv, "PSK_LAUNCH_NONCE": nonce,
-                 "MASTER_ADDR": base.get("MASTER_ADDR", "127.0.0.1"), "PSK_LAUNCHER": "psk"})
+                 "MASTER_ADDR": base.get("MASTER_ADDR", "127.0.0.1"), "PSK_LAUNCHER": "psk",
+                 "PSK_LAUNCH_T0": repr(time.time())})      # the deadline's clock: a leg can tell what is left of it
     base.pop("PSK_RDZV_FILE", None)
     if share_gpu:
         base["PSK_SHARE_GPU"] = "1"

@@ -22,7 +22,7 @@ import threading
 import time
 
 _state = {"phase": None, "phase_since": None, "call": None, "call_since": None, "snapshot": None, "rank": 0, "world": 1,
-          "installed": False, "dir": None}
+          "installed": False, "dir": None, "on_dump": None}
 
 
 def enter(phase):
@@ -78,7 +78,18 @@ def dump():
         rec["rank"], rec["world"], rec["stuck_in"],
         (" (blocked in %s for %.1f s)" % (rec["blocked_in_call"], rec["blocked_for_s"])) if rec["blocked_in_call"] else "", path))
     sys.stderr.flush()
+    hook = _state["on_dump"]
+    if hook is not None:
+        try:
+            hook(rec)
+        except Exception as e:
+            sys.stderr.write("psk rank %d: the stuck-phase hook failed: %s\n" % (rec["rank"], e))
     return rec
+
+
+def on_dump(hook):
+    """hook(table) runs after a stuck-phase table has been written (bench.py: rank 0 prints its result line once more)."""
+    _state["on_dump"] = hook
 
 
 def install(rank, world, snapshot=None, directory=None):

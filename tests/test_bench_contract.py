@@ -17,8 +17,14 @@ def test_bench_json_contract():
                        capture_output=True, text=True)
     assert r.returncode == 0, r.stderr[-2000:]
     lines = [l for l in r.stdout.splitlines() if l.strip()]
-    assert len(lines) == 1
-    d = json.loads(lines[0])
+    # r06: the line goes out as soon as `value` exists and again after every leg -- every line of stdout is a complete metric
+    # line with the same `value`; the LAST one is the record, and says "final"
+    recs = [json.loads(l) for l in lines]
+    assert len(recs) >= 2 and all(x["value"] == recs[0]["value"] and x["roofline"]["frac"] == recs[0]["roofline"]["frac"] for x in recs)
+    assert recs[0]["line"].startswith("provisional: legs pending: ") and "cpu_baseline" not in recs[0] and "e2e" not in recs[0]
+    d = recs[-1]
+    assert d["line"] == "final" and set(d["legs"]) == {"kernel_spread", "stream_ceiling", "hbm_only", "cpu_baseline", "e2e"}
+    assert all(v.startswith("ok") for v in d["legs"].values()), d["legs"]
     for key in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling",
                 "vs_baseline", "dtype", "data", "config", "roofline", "cpu_baseline"):
         assert key in d, key
@@ -35,6 +41,12 @@ def test_bench_json_contract():
     assert 0 < ceil["GBps"] < 60000 and 0 <= rf["stored_bytes_per_launch"] - ceil["bytes_per_launch"] < 16 and "stream_read_kernel" in ceil["kernel"]
     assert abs(rf["frac_of_measured_ceiling"] - (rf["stored_bytes_per_launch"] / (rf["kernel_ms"] * 1e-3) / 1e9) / ceil["GBps"]) < 1e-9
     assert 0.05 < rf["frac_of_measured_ceiling"] < 3.0
+    # the spread of the headline kernel over >= 200 further launches, and the same kernel beyond the Infinity Cache (r06)
+    assert rf["kernel_ms_launches"] >= 200 and 0 < rf["kernel_ms_min"] <= rf["kernel_ms_p50"] <= rf["kernel_ms_p95"] <= rf["kernel_ms_max"]
+    hb = rf["hbm_only"]
+    assert hb["bytes_per_launch"] >= 4.0e9 and hb["launches"] >= 50 and 0 < hb["kernel_ms_min"] <= hb["kernel_ms_p50"] <= hb["kernel_ms_p95"]
+    assert abs(hb["frac"] - hb["achieved"] / 8000.0) < 1e-9 and 0.3 < hb["frac"] < 1.0, hb
+    assert d["config"]["ingest_per_rank"][0]["count_s"] == d["config"]["ingest"]["count_s"]
     cb = d["cpu_baseline"]
     assert cb["kind"] == "port" and cb["cores"] >= 1 and cb["value"] > 0 and cb["single_thread_value"] > 0 and cb["matches_gpu"] is True
     assert d["value"] > cb["value"]
@@ -74,9 +86,11 @@ def test_bench_two_ranks_run_the_sharded_pipeline():
         r = subprocess.run(cmd, env=env_t, cwd=ROOT, timeout=900, capture_output=True, text=True)
         assert r.returncode == 0, r.stderr[-3000:]
         lines = [l for l in r.stdout.splitlines() if l.strip()]
-        assert lines[-1].startswith("{") and sum(l.startswith("{") for l in lines) == 1     # rank 0's line, relayed last
+        assert lines[-1].startswith("{") and sum(l.startswith("{") for l in lines) >= 2     # rank 0's line, relayed last
         d = json.loads(lines[-1])
+        assert d["line"] == "final" and all(json.loads(l)["value"] == d["value"] for l in lines if l.startswith("{"))
         cfg = d["config"]
+        assert len(cfg["ingest_per_rank"]) == 2 and all(x["presence_s"] is not None for x in cfg["ingest_per_rank"])
         # two ranks on one GPU over a host transport: a correctness run, and the line says so
         assert d["n_gpus"] == 2 and d["scaling"].startswith("invalid (") and d["rccl_ranks"] == 0
         if transport == "gloo":
@@ -91,6 +105,7 @@ def test_bench_two_ranks_run_the_sharded_pipeline():
         if transport != "gloo":   # BASELINE's second figure with several ranks: the CLI as one child process per rank
             e2e = d["e2e"]
             assert "error" not in e2e, e2e
+            assert e2e["rc"] == [0, 0] and 0 < e2e["budget_s"] <= 900 and d["legs"]["e2e"] == "ok"
             assert e2e["modeling_wall_s"] > 0 and e2e["ranks"] == 2 and "log_reg_model_Pheno.pkl" in e2e["what"]
             # every rank's phase table, process start to teardown: the slowest rank's total is the leg's wall-clock less what
             # the interpreter and the HIP runtime need to exit -- r05: the CLI no longer leaves through os._exit, so that part
@@ -103,6 +118,79 @@ def test_bench_two_ranks_run_the_sharded_pipeline():
                 assert any(k.startswith("ingest: k-mer lists (") for k in v["phases_s"]) and "survivor all-gather" in v["phases_s"]
             slowest = max(v["total_s"] for v in ph.values())
             assert slowest <= e2e["modeling_wall_s"] + 0.01 and e2e["modeling_wall_s"] - slowest <= 0.15 * e2e["modeling_wall_s"] + 0.5, (slowest, e2e["modeling_wall_s"])
+
+
+def _children_of(pids):
+    """pid -> argv of the live children of `pids` (one pass over /proc; exact parent pids, no pattern matching on names)."""
+    out = {}
+    for ent in os.listdir("/proc"):
+        if not ent.isdigit():
+            continue
+        try:
+            with open("/proc/%s/stat" % ent) as f:
+                ppid = int(f.read().rsplit(")", 1)[1].split()[1])
+            if ppid in pids:
+                with open("/proc/%s/cmdline" % ent, "rb") as f:
+                    out[int(ent)] = f.read().split(b"\0")
+        except (OSError, ValueError, IndexError):
+            pass
+    return out
+
+
+def test_bench_line_survives_the_death_of_the_e2e_leg():
+    """VERDICT r05 next #1 'done' criterion: the e2e leg's CLI children are KILLED mid-run (their exact pids, found as children of
+    the two rank processes) -- the last JSON line of stdout is still a valid metric line, the same `value` as the line printed
+    before the legs, with the children's exit codes recorded in it.  Second half: the children hang (SIGSTOP) -- the leg's
+    budget ends them before the launch's deadline.  (The deadline itself re-emitting the line: tests/test_bench_line.py.)"""
+    import signal
+    import time
+    env = {k_: v for k_, v in os.environ.items() if k_ not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "PSK_DIST_TRANSPORT", "PSK_RDZV_DIR",
+                                                            "PSK_RDZV_FILE", "PSK_LAUNCH_NONCE")}
+    cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--share-gpu", "--samples", "64", "--length", "200000",
+           "--kmer", "16", "--steps", "4", "--warmup", "1"]
+
+    def run(action, launch_timeout):
+        p = subprocess.Popen(cmd, env=dict(env, PSK_LAUNCH_TIMEOUT=str(launch_timeout)), cwd=ROOT, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True)
+        hit = set()
+        t0 = time.time()
+        try:
+            while p.poll() is None and time.time() - t0 < 600:
+                ranks = [pid for pid, argv in _children_of({p.pid}).items() if any(a.endswith(b"bench.py") for a in argv)]
+                for pid, argv in _children_of(set(ranks)).items():
+                    if pid not in hit and any(a.endswith(b"scripts/phenotypeseeker") for a in argv):
+                        os.kill(pid, action)
+                        hit.add(pid)
+                time.sleep(0.005)
+            out, err = p.communicate(timeout=60)
+        finally:
+            if p.poll() is None:
+                p.kill()
+            for pid in hit:          # (stopped children of a launch that was torn down)
+                try:
+                    os.kill(pid, signal.SIGKILL)
+                except OSError:
+                    pass
+        return p.returncode, out, err, hit
+
+    rc, out, err, hit = run(signal.SIGKILL, 600)
+    assert len(hit) == 2, (hit, err[-2000:])
+    recs = [json.loads(l) for l in out.splitlines() if l.startswith("{")]
+    assert out.strip().splitlines()[-1].startswith("{") and len(recs) >= 2
+    d = recs[-1]
+    assert rc == 0 and d["line"] == "final" and d["value"] == recs[0]["value"] > 0 and d["roofline"]["frac"] > 0
+    assert d["legs"]["e2e"].startswith("failed: 2 rank(s) failed") and d["e2e"]["rc"] == [-9, -9], d["e2e"]
+    assert d["e2e"]["first_failing_phase"]["no_table_from_ranks"] == [0, 1]       # SIGKILL leaves no table; a hang does (below)
+    assert all(v.startswith("ok") for k_, v in d["legs"].items() if k_ != "e2e"), d["legs"]
+
+    # children that hang (stopped): the leg's own budget -- min(900, deadline - elapsed - 60) -- fires before the launch's
+    # deadline does; the children are killed by pid, the codes (124) are in the line, the launch ends normally
+    rc, out, err, hit = run(signal.SIGSTOP, 110)
+    assert len(hit) == 2, (hit, err[-2000:])
+    recs = [json.loads(l) for l in out.splitlines() if l.startswith("{")]
+    d = recs[-1]
+    assert rc == 0 and "deadline of 110 s passed" not in err
+    assert out.strip().splitlines()[-1].startswith("{") and d["line"] == "final" and d["value"] == recs[0]["value"] > 0
+    assert d["e2e"]["rc"] == [124, 124] and 30 <= d["e2e"]["budget_s"] <= 50 and d["legs"]["e2e"].startswith("failed: 2 rank(s) failed")
 
 
 def test_bench_eight_ranks_on_one_gpu_exchange_and_filter():
@@ -167,7 +255,7 @@ def test_bench_under_the_drivers_launcher():
     r = subprocess.run(cmd, env=env, cwd=ROOT, timeout=900, capture_output=True, text=True)
     assert r.returncode == 0, r.stderr[-3000:]
     lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
-    assert len(lines) == 1
+    assert len(lines) >= 2 and json.loads(lines[-1])["line"] == "final"      # rank 0 alone prints; its last line is the record
     d = json.loads(lines[0])
     assert d["n_gpus"] == 2 and d["scaling"].startswith("invalid (") and d["config"]["collectives"].startswith("host-files")
     assert len(d["config"]["rows_per_rank"]) == 2 and d["value"] > 0
