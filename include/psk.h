@@ -91,8 +91,11 @@ int psk_count_kmers_files(psk_ctx *ctx, int first_sample_idx, int n, const char 
  * at a time (PSK_GZ_GROUP_MB); a group of so few small files that zlib would be faster (the device route has a floor of ~40 ms) and a member the device
  * route declines go through zlib on the call's host threads.  This entry point is the inflate on its own -- tests and measurements: n gzip images ->
  * their text (out[i], of capacity out_cap[i], may be NULL: lengths only).  route[i]: 1 decoded on the device, 2 the same,
- * a BGZF file (its members found by their BSIZE fields), 0 zlib on the host.  device_ms: wall-clock of the device route,
- * upload included. */
+ * a BGZF file (its members found by their BSIZE fields), 0 zlib on the host, -1 zlib refused the file.  A refused file fails
+ * the call (PSK_EINVAL, zlib's words for the first one, as glistmaker's reader fails) -- after every file has been tried: with
+ * `route` given, the texts and lengths of the other files are delivered all the same.  device_ms: wall-clock of the device
+ * route, upload included.  PSK_GZ_GUARD=1 (the fuzz test): 64-KB guard bands around the device buffers, checked after the
+ * last kernel (PSK_ESTATE when one was written to). */
 int psk_gz_inflate(psk_ctx *ctx, int n, const uint8_t *const *data, const size_t *sizes, uint8_t *const *out,
                    const size_t *out_cap, uint64_t *out_len, int32_t *route, double *device_ms);
 /* Copies sample_idx's list to the host (for writing .list files / parity checks). */

@@ -1134,6 +1134,22 @@ __global__ __launch_bounds__(256) void gz_crc_kernel(const uint8_t *out, const u
     }
 }
 
+// ---- guard bands (PSK_GZ_GUARD=1: the fuzz test's mode) ---------------------------------------------------------
+// 64 KB of 0xA5 before and after the text, symbol and match buffers; counted after the last kernel: a decoder of untrusted
+// bytes that writes one byte outside what the counting pass laid out is caught here (GPU AddressSanitizer is not available).
+constexpr size_t GZ_GUARD = 65536;
+constexpr int GZ_GUARD_BYTE = 0xA5;
+struct GzGuardBands {
+    const uint8_t *band[6];
+};
+__global__ __launch_bounds__(256) void gz_guard_check_kernel(GzGuardBands g, uint32_t *damaged)
+{
+    const uint8_t *b = g.band[blockIdx.y];
+    uint32_t bad = 0;
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < GZ_GUARD; i += (size_t)gridDim.x * 256) bad += b[i] != (uint8_t)GZ_GUARD_BYTE;
+    if (bad) atomicAdd(damaged, bad);
+}
+
 // ---- host side -----------------------------------------------------------------------------------------------
 struct GzMemberHead {
     size_t deflate_at = 0;   // offset of the DEFLATE data in the file
@@ -1301,7 +1317,11 @@ int gz_inflate_group(psk_ctx *ctx, int n, const uint8_t *const *data, const size
                 const int j = next.fetch_add(1);
                 if (j >= nw) return;
                 const int i = which[(size_t)j];
-                if (!gz_host_inflate(data[i], sizes[i], res[(size_t)i].host, &errs[(size_t)j])) bad = 1;
+                if (!gz_host_inflate(data[i], sizes[i], res[(size_t)i].host, &errs[(size_t)j])) {
+                    bad = 1;
+                    res[(size_t)i].error = errs[(size_t)j];   // (every file is tried: psk_gz_inflate reports per file)
+                    res[(size_t)i].host.clear();
+                }
                 res[(size_t)i].len = res[(size_t)i].host.size();
             }
         };
@@ -1675,10 +1695,25 @@ int gz_inflate_group(psk_ctx *ctx, int n, const uint8_t *const *data, const size
     total = (total + 63) & ~63ull;
     const size_t m = order.size();
     std::vector<unsigned long long> nul_at;   // per file of the writing pass: where its text has its first NUL (in out_buf), ~0: nowhere
+    const size_t guard = std::getenv("PSK_GZ_GUARD") ? GZ_GUARD : 0;
+    uint32_t guard_damage = 0;
     if (m) {
-        PSK_TRY(dev_reserve(ctx, sym_buf, total * 2 + 64));
-        PSK_TRY(dev_reserve(ctx, out_buf, total + 64));
-        PSK_TRY(dev_reserve(ctx, rec_buf, total_rec * 8 + 64));
+        PSK_TRY(dev_reserve(ctx, sym_buf, total * 2 + 64 + 2 * guard));
+        PSK_TRY(dev_reserve(ctx, out_buf, total + 64 + 2 * guard));
+        PSK_TRY(dev_reserve(ctx, rec_buf, total_rec * 8 + 64 + 2 * guard));
+        // (the buffers proper start behind the leading band; the 64 bytes of slack the wide loads may touch stay in front of the trailing one)
+        uint16_t *const d_sym = reinterpret_cast<uint16_t *>(sym_buf.as<uint8_t>() + guard);
+        uint8_t *const d_text = out_buf.as<uint8_t>() + guard;
+        uint2 *const d_rec = reinterpret_cast<uint2 *>(rec_buf.as<uint8_t>() + guard);
+        GzGuardBands bands;
+        if (guard) {
+            uint8_t *b[6] = {sym_buf.as<uint8_t>(), sym_buf.as<uint8_t>() + guard + total * 2 + 64, out_buf.as<uint8_t>(), out_buf.as<uint8_t>() + guard + total + 64,
+                             rec_buf.as<uint8_t>(), rec_buf.as<uint8_t>() + guard + total_rec * 8 + 64};
+            for (int q = 0; q < 6; q++) {
+                bands.band[q] = b[q];
+                PSK_HIP(ctx, hipMemsetAsync(b[q], GZ_GUARD_BYTE, guard, st));
+            }
+        }
         lap("buffers");
         size_t off = 0;
         const size_t o_start = carve(off, m * 8), o_end = carve(off, m * 8), o_true = carve(off, m), o_stop = carve(off, m * 8), o_off = carve(off, m * 8),
@@ -1688,6 +1723,7 @@ int gz_inflate_group(psk_ctx *ctx, int n, const uint8_t *const *data, const size
         const size_t o_len = carve(off, m * 8), o_nrec = carve(off, m * 8), o_ebit = carve(off, m * 8), o_link = carve(off, m * 4),
                      o_long = carve(off, m * 640);
         const size_t o_members = carve(off, 2 * ((m_begin.size() * 8 + 255) & ~(size_t)255) + m_begin.size() * 4 + 256);
+        const size_t o_guard = carve(off, 256);
         PSK_TRY(dev_reserve(ctx, tab_buf, off));
         stage.assign(o_in_end, 0);
         for (size_t j = 0; j < m; j++) {
@@ -1724,8 +1760,8 @@ int gz_inflate_group(psk_ctx *ctx, int n, const uint8_t *const *data, const size
         a.want_len = reinterpret_cast<const uint64_t *>(t + o_want);
         a.rec_off = reinterpret_cast<const uint64_t *>(t + o_roff);
         a.want_rec = reinterpret_cast<const uint64_t *>(t + o_wrec);
-        a.sym = sym_buf.as<uint16_t>();
-        a.rec = rec_buf.as<uint2>();
+        a.sym = d_sym;
+        a.rec = d_rec;
         a.long_syms = reinterpret_cast<uint16_t *>(t + o_long);
         a.out_len = reinterpret_cast<uint64_t *>(t + o_len);
         a.n_rec = reinterpret_cast<uint64_t *>(t + o_nrec);
@@ -1740,7 +1776,7 @@ int gz_inflate_group(psk_ctx *ctx, int n, const uint8_t *const *data, const size
             PSK_HIP(ctx, hipMalloc(reinterpret_cast<void **>(&d_stats), 64));
             PSK_HIP(ctx, hipMemsetAsync(d_stats, 0, 64, st));
         }
-        gz_copy_kernel<<<dim3((unsigned)div_up((uint64_t)m, 4)), dim3(256), 0, st>>>(sym_buf.as<uint16_t>(), rec_buf.as<uint2>(), a.rec_off, a.want_rec, a.n_rec, a.link,
+        gz_copy_kernel<<<dim3((unsigned)div_up((uint64_t)m, 4)), dim3(256), 0, st>>>(d_sym, d_rec, a.rec_off, a.want_rec, a.n_rec, a.link,
                                                                                    a.want_len, d_off, (int)m, d_stats);
         PSK_HIP(ctx, hipGetLastError());
         if (d_stats) {
@@ -1753,10 +1789,10 @@ int gz_inflate_group(psk_ctx *ctx, int n, const uint8_t *const *data, const size
                          (unsigned long long)total_rec, hs[0], hs[2], hs[3], hs[5], hs[1]);
         }
         unsigned long long *d_nul = reinterpret_cast<unsigned long long *>(t + o_nul);
-        gz_tails_kernel<<<dim3((unsigned)(file_first.size() - 1)), dim3(1024), 0, st>>>(sym_buf.as<uint16_t>(), out_buf.as<uint8_t>(), d_off, d_len,
+        gz_tails_kernel<<<dim3((unsigned)(file_first.size() - 1)), dim3(1024), 0, st>>>(d_sym, d_text, d_off, d_len,
                                                                                      reinterpret_cast<const uint32_t *>(t + o_ff), t + o_nowin, d_nul);
         PSK_HIP(ctx, hipGetLastError());
-        gz_resolve_kernel<<<dim3((unsigned)m), dim3(256), 0, st>>>(sym_buf.as<uint16_t>(), out_buf.as<uint8_t>(), d_off, d_len,
+        gz_resolve_kernel<<<dim3((unsigned)m), dim3(256), 0, st>>>(d_sym, d_text, d_off, d_len,
                                                                    reinterpret_cast<const uint32_t *>(t + o_cfile), t + o_nowin, d_nul);
         PSK_HIP(ctx, hipGetLastError());
         nul_at.resize(file_first.size());
@@ -1776,15 +1812,24 @@ int gz_inflate_group(psk_ctx *ctx, int n, const uint8_t *const *data, const size
             const uint64_t span = total - GZ_WIN;   // (nothing but empty texts: no launch; the check sums of empty members are 0)
             if (span)
                 gz_crc_kernel<<<dim3((unsigned)div_up(span, (uint64_t)256 * GZ_CRC_SEG)), dim3(256), 0, st>>>(
-                out_buf.as<uint8_t>(), reinterpret_cast<const uint64_t *>(mt), reinterpret_cast<const uint64_t *>(mt + ((nm * 8 + 255) & ~(size_t)255)), (int)nm,
+                d_text, reinterpret_cast<const uint64_t *>(mt), reinterpret_cast<const uint64_t *>(mt + ((nm * 8 + 255) & ~(size_t)255)), (int)nm,
                 (uint64_t)GZ_WIN, total, d_acc);
             PSK_HIP(ctx, hipGetLastError());
             PSK_HIP(ctx, hipMemcpyAsync(crc_got.data(), d_acc, nm * 4, hipMemcpyDeviceToHost, st));
         }
         std::vector<int32_t> r_link(m);
         PSK_HIP(ctx, hipMemcpyAsync(r_link.data(), t + o_link, m * 4, hipMemcpyDeviceToHost, st));
+        if (guard) {
+            uint32_t *d_damaged = reinterpret_cast<uint32_t *>(t + o_guard);
+            PSK_HIP(ctx, hipMemsetAsync(d_damaged, 0, 4, st));
+            gz_guard_check_kernel<<<dim3(16, 6), dim3(256), 0, st>>>(bands, d_damaged);
+            PSK_HIP(ctx, hipGetLastError());
+            PSK_HIP(ctx, hipMemcpyAsync(&guard_damage, d_damaged, 4, hipMemcpyDeviceToHost, st));
+        }
         PSK_HIP(ctx, hipStreamSynchronize(st));
         lap("write + matches + markers + crc");
+        if (guard_damage)
+            return psk_fail(ctx, PSK_ESTATE, "gz inflate: %u bytes of the guard bands around the text / symbol / match buffers were overwritten", guard_damage);
         for (size_t j = 0; j < m; j++)
             if (r_link[j] == GZ_ERROR)   // the second decode disagrees with the first: nothing of this file is trusted
                 files[(size_t)ch[(size_t)order[j]].file].device_ok = false;
@@ -1801,7 +1846,7 @@ int gz_inflate_group(psk_ctx *ctx, int n, const uint8_t *const *data, const size
         r.bgzf = f.bgzf;
         r.chunks = (int)f.chain.size();
         if (f.device_ok) {
-            r.off = f.out_off;
+            r.off = f.out_off + guard;   // (relative to the buffer the caller holds: the leading band is in front)
             r.len = f.out_len;
             r.first_nul = r.len;
             if (f.nul_slot >= 0 && (size_t)f.nul_slot < nul_at.size() && nul_at[(size_t)f.nul_slot] != ~0ull) r.first_nul = nul_at[(size_t)f.nul_slot] - f.out_off;
@@ -1821,12 +1866,24 @@ int gz_inflate_group(psk_ctx *ctx, int n, const uint8_t *const *data, const size
 
 void gz_release(psk_ctx *ctx)
 {
-    for (DevBuf *b : {&ctx->gz_comp[0], &ctx->gz_comp[1], &ctx->gz_out[0], &ctx->gz_out[1], &ctx->gz_sym, &ctx->gz_rec, &ctx->gz_tab}) dev_release(*b);
+    const bool trace = std::getenv("PSK_TRACE") != nullptr;
+    const auto t0 = std::chrono::steady_clock::now();
+    size_t dev_bytes = 0, host_bytes = 0;
+    for (DevBuf *b : {&ctx->gz_comp[0], &ctx->gz_comp[1], &ctx->gz_out[0], &ctx->gz_out[1], &ctx->gz_sym, &ctx->gz_rec, &ctx->gz_tab}) {
+        dev_bytes += b->cap;
+        dev_release(*b);
+    }
+    const auto t1 = std::chrono::steady_clock::now();
     for (int q = 0; q < 2; q++) {
+        host_bytes += ctx->gz_host_cap[q];
         std::free(ctx->gz_host[q]);
         ctx->gz_host[q] = nullptr;
         ctx->gz_host_cap[q] = 0;
     }
+    if (trace && (dev_bytes || host_bytes))
+        std::fprintf(stderr, "[psk] gz release: %.1f GB of device buffers in %.1f ms, %.1f GB of host buffers in %.1f ms\n", dev_bytes / 1e9,
+                     std::chrono::duration<double, std::milli>(t1 - t0).count(), host_bytes / 1e9,
+                     std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t1).count());
 }
 
 // ---- C-ABI: the inflate on its own (tests, measurements) ------------------------------------------------------------
@@ -1839,12 +1896,19 @@ extern "C" int psk_gz_inflate(psk_ctx *ctx, int n, const uint8_t *const *data, c
     // (the context's buffers, kept for the next call: psk_build_presence / psk_free give them back)
     DevBuf &outb = ctx->gz_out[0];
     int rc = gz_inflate_group(ctx, n, data, sizes, ctx->gz_comp[0], ctx->gz_sym, ctx->gz_rec, ctx->gz_out[0], ctx->gz_tab, res, device_ms);
-    if (rc == PSK_OK) {
+    // a file zlib refuses fails the call (PSK_EINVAL, zlib's words for the first such file) -- but every file has been tried: with
+    // `route` given, route[i] = -1 marks the refused ones and the others' texts are delivered all the same
+    bool per_file = false;
+    if (rc == PSK_EINVAL && route && res.size() == (size_t)n)
+        for (const GzInflated &r : res) per_file = per_file || !r.error.empty();
+    if (rc == PSK_OK || per_file) {
+        const int rc_files = rc;
+        rc = PSK_OK;
         for (int i = 0; i < n && rc == PSK_OK; i++) {
             const GzInflated &r = res[(size_t)i];
             out_len[i] = r.len;
-            if (route) route[i] = r.on_device ? (r.bgzf ? 2 : 1) : 0;
-            if (!out || !out[i]) continue;
+            if (route) route[i] = !r.error.empty() ? -1 : r.on_device ? (r.bgzf ? 2 : 1) : 0;
+            if (!out || !out[i] || !r.error.empty()) continue;
             if (!out_cap || out_cap[i] < r.len) {
                 rc = psk_fail(ctx, PSK_ERANGE, "file %d inflates to %llu bytes, the buffer holds %llu", i, (unsigned long long)r.len,
                               (unsigned long long)(out_cap ? out_cap[i] : 0));
@@ -1857,6 +1921,7 @@ extern "C" int psk_gz_inflate(psk_ctx *ctx, int n, const uint8_t *const *data, c
                 std::memcpy(out[i], r.host.data(), r.len);
             }
         }
+        if (rc == PSK_OK) rc = rc_files;   // (the message of the first refused file is still the context's last error)
     }
     return rc;
 }

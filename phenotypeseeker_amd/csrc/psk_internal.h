@@ -219,6 +219,7 @@ struct GzInflated {
     uint64_t off = 0, len = 0;
     uint64_t first_nul = 0;   // on_device: where the text has its first NUL byte (len: nowhere)
     std::vector<uint8_t> host;
+    std::string error;        // zlib refused the file: why
 };
 void gz_release(psk_ctx *ctx);   // gives the five buffers above back to the device
 int gz_inflate_group(psk_ctx *ctx, int n, const uint8_t *const *data, const size_t *sizes, DevBuf &comp_buf, DevBuf &sym_buf, DevBuf &rec_buf, DevBuf &out_buf,

@@ -127,9 +127,10 @@ class PskContext:
         self._check(self._lib.psk_get_list(self._h, int(sample_idx), _ptr(words), _ptr(freqs), n_unique), "psk_get_list")
         return words, freqs
 
-    def gz_inflate(self, images, want_text=True):
+    def gz_inflate(self, images, want_text=True, per_file=False):
         """The text of gzip images, inflated on the device (csrc/gz_inflate.hip).  Returns (texts or None, lengths, routes,
-        device_ms); routes: 1 device, 2 device (BGZF), 0 zlib on the host.  want_text=False: lengths only (measurements)."""
+        device_ms); routes: 1 device, 2 device (BGZF), 0 zlib on the host.  want_text=False: lengths only (measurements).
+        A file zlib refuses raises PskError (zlib's words) -- per_file=True instead returns route -1 and text None for it."""
         images = [bytes(b) for b in images]
         n = len(images)
         ptrs = (ctypes.c_char_p * max(n, 1))(*images)
@@ -137,14 +138,21 @@ class PskContext:
         lens = np.zeros(max(n, 1), dtype=np.uint64)
         route = np.zeros(max(n, 1), dtype=np.int32)
         ms = ctypes.c_double()
-        self._check(self._lib.psk_gz_inflate(self._h, n, ptrs, sizes, None, None, _ptr(lens), _ptr(route), ctypes.byref(ms)), "psk_gz_inflate")
+
+        def call(outp, caps):
+            route[:] = 0
+            rc = self._lib.psk_gz_inflate(self._h, n, ptrs, sizes, outp, caps, _ptr(lens), _ptr(route), ctypes.byref(ms))
+            if not (per_file and rc == -1 and (route[:n] == -1).any()):     # PSK_EINVAL with the refused files marked
+                self._check(rc, "psk_gz_inflate")
+        call(None, None)
         if not want_text:
             return None, lens[:n].tolist(), route[:n].tolist(), ms.value
         bufs = [np.empty(max(int(l), 1), dtype=np.uint8) for l in lens[:n]]
         outp = (ctypes.c_void_p * max(n, 1))(*[b.ctypes.data for b in bufs])
         caps = (ctypes.c_size_t * max(n, 1))(*[len(b) for b in bufs])
-        self._check(self._lib.psk_gz_inflate(self._h, n, ptrs, sizes, outp, caps, _ptr(lens), _ptr(route), ctypes.byref(ms)), "psk_gz_inflate")
-        return [b[:int(l)].tobytes() for b, l in zip(bufs, lens[:n])], lens[:n].tolist(), route[:n].tolist(), ms.value
+        call(outp, caps)
+        return ([None if r == -1 else b[:int(l)].tobytes() for b, l, r in zip(bufs, lens[:n], route[:n])], lens[:n].tolist(),
+                route[:n].tolist(), ms.value)
 
     # -- multi-GPU ingest: slab ranges of sorted lists (dist.ListExchange) ---------------------------
     def lists_split(self, first_idx, n, bounds):

@@ -1,7 +1,9 @@
 #!/usr/bin/env python3
 """Wall-clock of `phenotypeseeker modeling` as a fresh PROCESS (start to exit, what a user's shell sees) on a synthetic data set
 written to disk once: the BASELINE's second figure.  Each run is its own subprocess; the phase table of log.txt follows.
-usage (GPU box): tools/cli_wallclock.py N_GENOMES [--continuous] [--runs R] [--env NAME=VAL ...] [-- extra CLI flags]"""
+usage (GPU box): tools/cli_wallclock.py N_GENOMES [--continuous] [--runs R] [--pause S] [--env NAME=VAL ...] [-- extra CLI flags]
+--pause S: sleep S seconds between the runs (r06: a process that starts right after one that held ~170 GB of device memory has
+exited pays for the driver's clearing of that memory -- config 3's runs 1, 2 took 6.6 s where run 0 took 1.1 s)"""
 import os
 import subprocess
 import sys
@@ -21,6 +23,7 @@ if "--" in argv:
 n = int(argv[0])
 continuous = "--continuous" in argv
 runs = int(argv[argv.index("--runs") + 1]) if "--runs" in argv else 2
+pause = float(argv[argv.index("--pause") + 1]) if "--pause" in argv else 0.0
 envs = [a for i, a in enumerate(argv) if i > 0 and argv[i - 1] == "--env"]
 gs = GenomeSet(n, 5_000_000, seed=4242)
 rng = np.random.default_rng(7)
@@ -42,7 +45,10 @@ for e in envs:
 cmd = [sys.executable, os.path.join(ROOT, "scripts", "phenotypeseeker"), "modeling", "data.pheno"] + extra
 for r in range(runs):
     if os.path.exists(os.path.join(tmp, "log.txt")):
+        print("".join(l for l in open(os.path.join(tmp, "log.txt")) if l.startswith("Phases of rank 0")), end="", flush=True)
         os.remove(os.path.join(tmp, "log.txt"))
+    if r and pause:
+        time.sleep(pause)
     t0 = time.time()
     p = subprocess.run(cmd, cwd=tmp, env=env, stdout=subprocess.DEVNULL, stderr=subprocess.PIPE)
     print("run %d: modeling %s%s: %.3f s, rc %d" % (r, " ".join(extra), (" [" + " ".join(envs) + "]") if envs else "", time.time() - t0, p.returncode), flush=True)
