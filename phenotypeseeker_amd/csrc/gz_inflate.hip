@@ -37,6 +37,7 @@
 #include "dev_utils.h"
 #include "psk_internal.h"
 
+#include <sys/mman.h>
 #include <zlib.h>
 
 #include <algorithm>
@@ -1864,7 +1865,16 @@ int gz_inflate_group(psk_ctx *ctx, int n, const uint8_t *const *data, const size
     return PSK_OK;
 }
 
-void gz_release(psk_ctx *ctx)
+uint8_t *gz_host_alloc(size_t bytes)
+{
+    constexpr size_t HUGE = (size_t)2 << 20;
+    const size_t want = (bytes + HUGE - 1) & ~(HUGE - 1);
+    void *p = std::aligned_alloc(HUGE, want ? want : HUGE);
+    if (p) (void)madvise(p, want ? want : HUGE, MADV_HUGEPAGE);   // (advice: where transparent huge pages are off, ordinary pages as before)
+    return static_cast<uint8_t *>(p);
+}
+
+void gz_release(psk_ctx *ctx, bool wait)
 {
     const bool trace = std::getenv("PSK_TRACE") != nullptr;
     const auto t0 = std::chrono::steady_clock::now();
@@ -1874,15 +1884,27 @@ void gz_release(psk_ctx *ctx)
         dev_release(*b);
     }
     const auto t1 = std::chrono::steady_clock::now();
+    if (ctx->gz_reaper.joinable()) ctx->gz_reaper.join();
+    uint8_t *gone[2] = {ctx->gz_host[0], ctx->gz_host[1]};
     for (int q = 0; q < 2; q++) {
         host_bytes += ctx->gz_host_cap[q];
-        std::free(ctx->gz_host[q]);
         ctx->gz_host[q] = nullptr;
         ctx->gz_host_cap[q] = 0;
     }
+    if (gone[0] || gone[1]) {
+        ctx->gz_reaper = std::thread([gone, trace, host_bytes] {
+            const auto h0 = std::chrono::steady_clock::now();
+            std::free(gone[0]);
+            std::free(gone[1]);
+            if (trace)
+                std::fprintf(stderr, "[psk] gz release: %.1f GB of host buffers given back in %.1f ms (helper thread)\n", host_bytes / 1e9,
+                             std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - h0).count());
+        });
+    }
+    if (wait && ctx->gz_reaper.joinable()) ctx->gz_reaper.join();
     if (trace && (dev_bytes || host_bytes))
-        std::fprintf(stderr, "[psk] gz release: %.1f GB of device buffers in %.1f ms, %.1f GB of host buffers in %.1f ms\n", dev_bytes / 1e9,
-                     std::chrono::duration<double, std::milli>(t1 - t0).count(), host_bytes / 1e9,
+        std::fprintf(stderr, "[psk] gz release: %.1f GB of device buffers in %.1f ms; %.1f GB of host buffers %s: %.1f ms\n", dev_bytes / 1e9,
+                     std::chrono::duration<double, std::milli>(t1 - t0).count(), host_bytes / 1e9, wait ? "waited for" : "handed to a helper thread",
                      std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t1).count());
 }
 

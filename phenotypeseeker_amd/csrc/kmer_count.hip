@@ -1426,9 +1426,10 @@ static int count_batch_impl(psk_ctx *ctx, int first_sample_idx, int n, const uin
         uint8_t *&host = ctx->gz_host[r.set];
         size_t &cap = ctx->gz_host_cap[r.set];
         if (need > cap) {
+            if (ctx->gz_reaper.joinable()) ctx->gz_reaper.join();
             std::free(host);
             cap = 0;
-            host = static_cast<uint8_t *>(std::malloc(need + need / 8));
+            host = gz_host_alloc(need + need / 8);
             if (!host) return psk_fail(ctx, PSK_ENOMEM, "no host memory for %zu bytes of compressed input", need);
             cap = need + need / 8;
         }

@@ -8,6 +8,7 @@
 #include <cstdlib>
 #include <cstring>
 #include <string>
+#include <thread>
 #include <vector>
 
 #include "../../include/psk.h"
@@ -152,6 +153,7 @@ struct psk_ctx {
     // 0.3 s per 2 GB); given back by psk_build_presence and psk_free.
     uint8_t *gz_host[2] = {nullptr, nullptr};
     size_t gz_host_cap[2] = {0, 0};
+    std::thread gz_reaper;   // gives gz_host back off the caller's critical path (gz_release: 5 GB of host pages took 0.56 s to unmap)
     DevBuf gz_comp[2], gz_out[2], gz_sym, gz_rec, gz_tab;
     hipStream_t gz_stream = nullptr, gz_up_stream = nullptr;   // the inflate's kernels; the uploads of the run after it
     DevBuf lane_slab;        // one allocation behind the buffer sets of a grouped batch (a cold run paid 60 ms for 170 hipMallocs)
@@ -221,7 +223,11 @@ struct GzInflated {
     std::vector<uint8_t> host;
     std::string error;        // zlib refused the file: why
 };
-void gz_release(psk_ctx *ctx);   // gives the five buffers above back to the device
+// gives the device buffers above back at once (milliseconds) and the host images on a helper thread (r06: psk_build_presence spent
+// 0.53-0.56 s of cfg5gz's 2.3 s unmapping 5.2 GB of host pages; the 69.6 GB of device buffers took 2 ms); wait: join that thread
+// (psk_free, and whoever needs gz_host again)
+void gz_release(psk_ctx *ctx, bool wait = false);
+uint8_t *gz_host_alloc(size_t bytes);   // 2-MiB aligned, MADV_HUGEPAGE: a few thousand pages to fault in and to release instead of a million
 int gz_inflate_group(psk_ctx *ctx, int n, const uint8_t *const *data, const size_t *sizes, DevBuf &comp_buf, DevBuf &sym_buf, DevBuf &rec_buf, DevBuf &out_buf,
                      DevBuf &tab_buf, std::vector<GzInflated> &res, double *device_ms, bool host_only = false, int host_threads = 8,
                      hipStream_t on_stream = nullptr, bool images_uploaded = false);

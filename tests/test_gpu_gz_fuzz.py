@@ -43,8 +43,9 @@ def _text(rng, kind, size):
     if kind == "fasta":
         seq = np.frombuffer(b"ACGT", dtype=np.uint8)[rng.integers(0, 4, size)]
         for _ in range(max(1, size // 3000)):
-            a, b, ln = (int(rng.integers(0, max(1, size - 400))) for _ in range(2)) + (int(rng.integers(20, 300)),)
-            seq[b:b + ln] = seq[a:a + ln][:len(seq[b:b + ln])]
+            a, b = (int(rng.integers(0, max(1, size - 400))) for _ in range(2))
+            ln = int(rng.integers(20, 300))
+            seq[b:b + ln] = seq[a:a + ln].copy()[:len(seq[b:b + ln])]
         s = seq.tobytes()
         return b">c some description\n" + b"\n".join(s[i:i + 60] for i in range(0, len(s), 60)) + b"\n"
     if kind == "fastq":
@@ -102,8 +103,9 @@ def _corpus(rng):
 def _mutants(rng, base, want):
     """`want` mutated files, the kinds of VERDICT r05 next #3 in turn."""
     out = []
-    kinds = ("flips", "truncate", "header17", "lengths", "too_far_back", "trailer", "bsize", "stored", "gzip_header", "splice", "burst")
+    kinds = ("flips", "truncate", "header17", "lengths", "too_far_back", "trailer", "bsize", "stored", "gzip_header", "splice", "burst", "valid_variant")
     dict_text = _text(rng, "fasta", 4000)
+    strategies = (zlib.Z_DEFAULT_STRATEGY, zlib.Z_FILTERED, zlib.Z_HUFFMAN_ONLY, zlib.Z_RLE, zlib.Z_FIXED)
     while len(out) < want:
         kind = kinds[len(out) % len(kinds)]
         m = bytearray(base[int(rng.integers(0, len(base)))])
@@ -164,6 +166,14 @@ def _mutants(rng, base, want):
                 m = m + bytearray(rng.integers(0, 256, int(rng.integers(1, 40))).astype(np.uint8).tobytes())
             else:
                 m = m + bytearray(o[:int(rng.integers(1, 30))])
+        elif kind == "valid_variant":       # streams zlib ACCEPTS, of unusual make: tiny blocks (memLevel 1), every strategy, several members
+            parts = []
+            for _ in range(int(rng.integers(1, 5))):
+                t = _text(rng, ("fasta", "fastq", "runs", "noise")[int(rng.integers(0, 4))], int(rng.integers(1, 20000)))
+                co = zlib.compressobj(int(rng.integers(0, 10)), zlib.DEFLATED, 16 + int(rng.integers(9, 16)), int(rng.integers(1, 10)),
+                                      strategies[int(rng.integers(0, len(strategies)))])
+                parts.append(co.compress(t) + co.flush() + b"\0" * int(rng.integers(0, 3) == 0))
+            m = bytearray(b"".join(parts))
         else:                               # burst: a run of random bytes inside the stream
             at, ln = int(rng.integers(10, n)), int(rng.integers(1, 64))
             m[at:at + ln] = rng.integers(0, 256, len(m[at:at + ln])).astype(np.uint8).tobytes()
@@ -208,6 +218,7 @@ def test_twenty_thousand_mutated_members_never_leave_their_buffers(monkeypatch):
     # the mutators do what they say: every kind produced files zlib refuses AND files it accepts or the device decoded
     for kind in ("flips", "truncate", "header17", "lengths", "too_far_back", "trailer", "bsize", "stored", "gzip_header", "splice", "burst"):
         assert tally.get((kind, "refused"), 0) > 0, kind
+    assert tally.get(("valid_variant", "refused"), 0) == 0 and tally.get(("valid_variant", "device"), 0) > 300
     assert sum(v for (k, how), v in tally.items() if how == "device") > 1000
     assert took < 120.0, took
 
