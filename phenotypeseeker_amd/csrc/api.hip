@@ -156,7 +156,7 @@ extern "C" void psk_free(psk_ctx *ctx)
         if (L.raw_free) (void)hipEventDestroy(L.raw_free);
         if (L.up_done) (void)hipEventDestroy(L.up_done);
     }
-    gz_release(ctx, true);
+    gz_release(ctx);
     if (ctx->gz_stream) (void)hipStreamDestroy(ctx->gz_stream);
     if (ctx->gz_up_stream) (void)hipStreamDestroy(ctx->gz_up_stream);
     dev_release(ctx->lane_slab);

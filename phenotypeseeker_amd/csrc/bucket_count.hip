@@ -28,26 +28,30 @@ namespace {
 // threads of a counting tile: 512 x 32 window ends = 16,384 bases for 32-bit words, 256 x 32 = 8,192 for 64-bit ones
 template <typename W> struct BsGeo { static constexpr int THREADS = sizeof(W) == 4 ? 512 : 256; static constexpr int TILE = THREADS * KW_SEG; };
 constexpr uint32_t BS_SLOTS = 32;                   // pre-zeroed counter slots per buffer set
-#ifndef PSK_BS_SORT_THREADS
-#define PSK_BS_SORT_THREADS 1024
-#endif
-constexpr int BS_SORT_THREADS = PSK_BS_SORT_THREADS;
+// threads of a sorting workgroup.  r06: TWO workgroups per CU for either width -- a bucket's sort is a chain of short steps between
+// barriers, and a second bucket in flight is what fills the waits (r05: the 64-bit instance held the bucket twice in 148 KB of LDS:
+// one workgroup per CU; the 32-bit one was 256 bytes over half the CU's 160 KB, so it ran alone as well).  64-bit words: 512 threads
+// (90 VGPRs: 2 x 8 waves per CU = 4 per SIMD), 32-bit: 1,024 (60 VGPRs).
+template <typename W> struct SortGeo {
+    static constexpr int THREADS = sizeof(W) == 4 ? 1024 : 512;
+    static constexpr int WAVES_PER_SIMD = sizeof(W) == 4 ? 8 : 4;   // two workgroups: what the register budget has to allow
+};
 #ifndef PSK_BS_CAPMAX
-#define PSK_BS_CAPMAX 8192
+#define PSK_BS_CAPMAX 8128
 #endif
-constexpr uint32_t BS_CAP_MAX = PSK_BS_CAPMAX;      // words a bucket may hold for the LDS sort
-// stage | splitters | h | lstart | scan | cells | buckets of the staged words   (32-bit words: 127 KB; 64-bit: 116 KB)
+constexpr uint32_t BS_CAP_MAX = PSK_BS_CAPMAX;      // words a bucket may hold for the LDS sort (8,128 x 8 B + 16.1 KB = 81.5 KB: two per CU)
+constexpr int BS_CELLS = 4096;                      // cells of the coarse table over the run's word range
+// stage | splitters | h | lstart | scan | cells | buckets of the staged words   (32-bit words: 135 KB; 64-bit: 124 KB)
 template <typename W> constexpr size_t bp_lds_bytes()
 {
-    return (size_t)BsGeo<W>::TILE * sizeof(W) + (size_t)BS_NB * sizeof(W) + (size_t)(BS_NB + BS_NB / 2 + 16 + 2056) * 4 + (size_t)BsGeo<W>::TILE * 2;
+    return (size_t)BsGeo<W>::TILE * sizeof(W) + (size_t)BS_NB * sizeof(W) + (size_t)(BS_NB + BS_NB / 2 + 16 + BS_CELLS) * 4 + (size_t)BsGeo<W>::TILE * 2;
 }
-// words | sorted words | sub-bin starts | fills | scan   (32-bit words: 82 KB, two workgroups per CU; 64-bit: 148 KB, one)
-template <typename W> constexpr size_t bsort_lds_bytes() { return (size_t)2 * BS_CAP_MAX * sizeof(W) + (size_t)(2 * 2048 + 32) * 4; }
+// the bucket's words in sub-bin order | sub-bin starts | fills | scan   (32-bit words: 49 KB; 64-bit: 81.5 KB: two workgroups per CU)
+template <typename W> constexpr size_t bsort_lds_bytes() { return (size_t)BS_CAP_MAX * sizeof(W) + (size_t)(2 * 2048 + 32) * 4; }
 
 // The bucket of a word = the largest b with spl[b] <= w (spl[0] = the first word of the slab).  A binary search over the splitters is eleven
 // dependent LDS reads per window; a coarse table over 4,096 equal cells of the run's word range (ct[c] = bucket of the
 // cell's first word) leaves a search over the one to three buckets that meet the cell.
-constexpr int BS_CELLS = 4096;
 template <typename W>
 struct BsMap {
     W lo;             // first word of the range the cells cover (the slab's)
@@ -64,18 +68,55 @@ __device__ __forceinline__ uint32_t bucket_search(const W *spl, uint32_t nb, W w
     return b;
 }
 
-template <typename W>
-__device__ __forceinline__ uint32_t bucket_of(const W *spl, const uint16_t *ct, const BsMap<W> &mp, W w)
+// r06: the buckets of G windows at once.  One look-up is a chain of dependent LDS reads -- cell, then splitters -- and the counting
+// kernels run ONE wave per SIMD (their LDS leaves room for one workgroup per CU), so nothing hides a read's latency but
+// the thread's own independent work: 32 look-ups one after the other, each with its own loop, cost 3-4 exposed LDS round trips
+// per window (bs_partition_batch_kernel<21>: 432 us per 8 genomes, 0.032 of the HBM roofline; hardly fewer under a slab filter that
+// drops 7 windows of 8 -- it was never the atomics).  Here the cells of G windows are read together (ct2[c] = first bucket of cell
+// c | first bucket of cell c + 1 << 16: one read), then the two splitters that decide a cell meeting up to three buckets -- both
+// addresses known from the cell, so the 2 G reads are independent --, then a compare: two round trips per G windows.  A cell that
+// meets more than three buckets (a run unlike the sample the splitters came from) takes the search loop afterwards.
+#ifndef PSK_BS_G
+#define PSK_BS_G 8
+#endif
+constexpr int BS_G = PSK_BS_G;
+template <typename W, int G>
+__device__ __forceinline__ void buckets_of(const W *spl, const uint32_t *ct2, const BsMap<W> &mp, const W *w, uint32_t *b)
 {
-    const W cw = (w - mp.lo) >> mp.shift;
-    const uint32_t c = cw < (W)BS_CELLS ? (uint32_t)cw : (uint32_t)BS_CELLS - 1u;
-    uint32_t b = ct[c], e = ct[c + 1];
-    while (b < e) {
-        const uint32_t mid = (b + e + 1u) >> 1;
-        if (spl[mid] <= w) b = mid;
-        else e = mid - 1u;
+    uint32_t be[G];
+#pragma unroll
+    for (int j = 0; j < G; j++) {
+        const W cw = (w[j] - mp.lo) >> mp.shift;   // (a word that is none -- all ones -- or outside the slab lands in some cell: harmless)
+        be[j] = ct2[cw < (W)BS_CELLS ? (uint32_t)cw : (uint32_t)BS_CELLS - 1u];
     }
-    return b;
+    W p1[G], p2[G];
+#pragma unroll
+    for (int j = 0; j < G; j++) {
+        const uint32_t b0 = be[j] & 0xffffu, e = be[j] >> 16;
+        p1[j] = spl[b0 + 1u < e ? b0 + 1u : e];
+        p2[j] = spl[b0 + 2u < e ? b0 + 2u : e];
+    }
+    bool far = false;
+#pragma unroll
+    for (int j = 0; j < G; j++) {
+        const uint32_t b0 = be[j] & 0xffffu, e = be[j] >> 16;
+        b[j] = b0 + ((b0 + 1u <= e && p1[j] <= w[j]) ? 1u : 0u) + ((b0 + 2u <= e && p2[j] <= w[j]) ? 1u : 0u);
+        far = far || e > b0 + 2u;
+    }
+    if (__ballot(far)) {
+#pragma unroll
+        for (int j = 0; j < G; j++) {
+            uint32_t lo = be[j] & 0xffffu, hi = be[j] >> 16;
+            if (hi > lo + 2u) {
+                while (lo < hi) {
+                    const uint32_t mid = (lo + hi + 1u) >> 1;
+                    if (spl[mid] <= w[j]) lo = mid;
+                    else hi = mid - 1u;
+                }
+                b[j] = lo;
+            }
+        }
+    }
 }
 
 // splitters = every (nu / nb)-th word of a sorted list of this run; then the coarse table
@@ -99,13 +140,12 @@ __global__ void bs_cells_kernel(const W *__restrict__ spl, BsMap<W> mp, uint16_t
     ct[c] = (uint16_t)(beyond ? mp.nb - 1u : bucket_search<W>(spl, mp.nb, (W)first));
 }
 
-// the workgroup's copies of the splitters and the cells
+// the workgroup's copies of the splitters and the cells (the cells as pairs: see buckets_of)
 template <typename W>
-__device__ __forceinline__ void load_map(W *spl, uint16_t *ct, const W *__restrict__ spl_g, const uint16_t *__restrict__ ct_g,
-                                         int threads)
+__device__ __forceinline__ void load_map2(W *spl, uint32_t *ct2, const W *__restrict__ spl_g, const uint16_t *__restrict__ ct_g, int threads)
 {
     for (uint32_t d = threadIdx.x; d < BS_NB; d += threads) spl[d] = spl_g[d];
-    for (uint32_t d = threadIdx.x; d <= (uint32_t)BS_CELLS; d += threads) ct[d] = ct_g[d];
+    for (uint32_t d = threadIdx.x; d < (uint32_t)BS_CELLS; d += threads) ct2[d] = (uint32_t)ct_g[d] | ((uint32_t)ct_g[d + 1] << 16);
 }
 
 // ---- a group of samples per launch (bucket_group_enqueue; see dense_count.hip: a genome is one tile per CU) ---------------
@@ -148,16 +188,24 @@ __device__ __forceinline__ void bs_hist_body(const uint8_t *__restrict__ clean, 
     constexpr int BT_THREADS = BsGeo<W>::THREADS;
     __shared__ uint32_t h[BS_NB];
     __shared__ W spl[BS_NB];
-    __shared__ uint16_t ct[BS_CELLS + 2];
+    __shared__ uint32_t ct2[BS_CELLS];
+    constexpr W NONE = (W)~(W)0;                          // (a valid canonical word is never all ones: its reverse complement would be 0)
     for (uint32_t d = threadIdx.x; d < BS_NB; d += BT_THREADS) h[d] = 0;
-    load_map<W>(spl, ct, spl_g, ct_g, BT_THREADS);
+    load_map2<W>(spl, ct2, spl_g, ct_g, BT_THREADS);
     __syncthreads();
     const uint64_t s = ((uint64_t)tile * BT_THREADS + threadIdx.x) * KW_SEG;
     typename Windows<K>::St st;
     load_streams(st, clean, len, s);
-    Windows<K>::run(st, lo, hi, [&](int, bool ok, W w) {
-        if (ok) atomicAdd(&h[bucket_of<W>(spl, ct, mp, w)], 1u);
-    });
+    W wv[KW_SEG];
+    Windows<K>::run(st, lo, hi, [&](int j, bool ok, W w) { wv[j] = ok ? w : NONE; });
+#pragma unroll
+    for (int g = 0; g < KW_SEG; g += BS_G) {
+        uint32_t b[BS_G];
+        buckets_of<W, BS_G>(spl, ct2, mp, wv + g, b);
+#pragma unroll
+        for (int j = 0; j < BS_G; j++)
+            if (wv[g + j] != NONE) atomicAdd(&h[b[j]], 1u);
+    }
     __syncthreads();
     uint32_t c[BS_NB / BT_THREADS], o[BS_NB / BT_THREADS];
 #pragma unroll
@@ -201,26 +249,28 @@ __device__ __forceinline__ void bs_partition_body(const uint8_t *__restrict__ cl
     uint32_t *h = reinterpret_cast<uint32_t *>(spl + BS_NB);   // counts, then (start of this tile's range in the bucket) - (local start)
     uint16_t *lstart = reinterpret_cast<uint16_t *>(h + BS_NB);
     uint32_t *scan_lds = h + BS_NB + BS_NB / 2;
-    uint16_t *ct = reinterpret_cast<uint16_t *>(scan_lds + 16);
-    uint16_t *stageb = reinterpret_cast<uint16_t *>(scan_lds + 16 + 2056);   // the bucket of every staged word
+    uint32_t *ct2 = scan_lds + 16;
+    uint16_t *stageb = reinterpret_cast<uint16_t *>(scan_lds + 16 + BS_CELLS);   // the bucket of every staged word
     constexpr W NONE = (W)~(W)0;                          // (a valid canonical word is never all ones: its reverse complement would be 0)
     for (uint32_t d = threadIdx.x; d < BS_NB; d += BT_THREADS) h[d] = 0;
-    load_map<W>(spl, ct, spl_g, ct_g, BT_THREADS);
+    load_map2<W>(spl, ct2, spl_g, ct_g, BT_THREADS);
     __syncthreads();
     const uint64_t s = ((uint64_t)tile * BT_THREADS + threadIdx.x) * KW_SEG;
     typename Windows<K>::St st;
     load_streams(st, clean, len, s);
     W wv[KW_SEG];          // the word
     uint32_t rb[KW_SEG];   // bucket << 16 | rank inside (tile, bucket)
-    Windows<K>::run(st, lo, hi, [&](int j, bool ok, W w) {
-        wv[j] = NONE;
-        rb[j] = 0;
-        if (ok) {
-            const uint32_t b = bucket_of<W>(spl, ct, mp, w);
-            wv[j] = w;
-            rb[j] = (b << 16) | atomicAdd(&h[b], 1u);
-        }
-    });
+    Windows<K>::run(st, lo, hi, [&](int j, bool ok, W w) { wv[j] = ok ? w : NONE; });
+#pragma unroll
+    for (int g = 0; g < KW_SEG; g += BS_G) {
+        uint32_t b[BS_G];
+        buckets_of<W, BS_G>(spl, ct2, mp, wv + g, b);
+        // (the ranks: G returning atomics in flight, their results waited for together)
+#pragma unroll
+        for (int j = 0; j < BS_G; j++) rb[g + j] = wv[g + j] != NONE ? atomicAdd(&h[b[j]], 1u) : 0u;
+#pragma unroll
+        for (int j = 0; j < BS_G; j++) rb[g + j] |= b[j] << 16;
+    }
     __syncthreads();
     // thread t owns buckets BPT t .. BPT t + BPT - 1: local starts, global bucket bases, this tile's offset in each bucket
     uint32_t ltot;
@@ -290,13 +340,16 @@ __device__ __forceinline__ void bs_sort_bucket(const uint32_t b, const W *__rest
                                                uint32_t *__restrict__ ctmp, uint32_t *__restrict__ uniq_out,
                                                uint32_t *__restrict__ flag, uint64_t *dyn_lds)
 {
-    constexpr int BPT = BS_BINS / BS_SORT_THREADS;   // sub-bins per thread
+    constexpr int T = SortGeo<W>::THREADS;
+    constexpr int BPT = BS_BINS / T;        // sub-bins per thread
+    constexpr int KEEP = 6;                 // words a thread holds in registers between the counting and the dealing pass (a bucket of
+                                            // <= KEEP x T words -- every ordinary one -- is read from global memory once)
     constexpr W NONE = (W)~(W)0;
-    W *kin = reinterpret_cast<W *>(dyn_lds);   // the bucket's words as they come; later the positions of the run heads
-    W *key = kin + BS_CAP_MAX;              // ... dealt into sub-bins, then sorted
+    W *key = reinterpret_cast<W *>(dyn_lds);   // the bucket's words dealt into sub-bins, then sorted
     uint32_t *start = reinterpret_cast<uint32_t *>(key + BS_CAP_MAX);     // sub-bin counts -> starts
     uint32_t *fill = start + BS_BINS;
     uint32_t *scan_lds = fill + BS_BINS;
+    uint16_t *pos = reinterpret_cast<uint16_t *>(start);   // after the sort: where the run heads are (start and fill are done with by then)
     const uint32_t t = threadIdx.x;
 #ifdef PSK_BS_STAMPS
     long long *stamps = reinterpret_cast<long long *>(flag + 2);
@@ -312,16 +365,18 @@ __device__ __forceinline__ void bs_sort_bucket(const uint32_t b, const W *__rest
     const W first = spl[b], last = b + 1 < nb ? (W)(spl[b + 1] - 1u) : last_word;   // the bucket's words lie in [first, last]
     const W span = last - first;
     const uint32_t sh = span < (W)BS_BINS ? 0u : (64u - (uint32_t)__builtin_clzll((unsigned long long)span)) - 11u;   // (w - first) >> sh < 2048
-    for (uint32_t i = t; i < BS_BINS; i += BS_SORT_THREADS) start[i] = 0;
+    W held[KEEP];
+#pragma unroll
+    for (int q = 0; q < KEEP; q++) held[q] = t + q * T < n ? part[off + t + q * T] : NONE;
+    for (uint32_t i = t; i < BS_BINS; i += T) start[i] = 0;
     __syncthreads();
 #ifdef PSK_BS_STAMPS
     if (b == 100 && t == 0) stamps[0] = clock64();
 #endif
-    for (uint32_t i = t; i < n; i += BS_SORT_THREADS) {
-        const W w = part[off + i];
-        kin[i] = w;
-        atomicAdd(&start[(uint32_t)((w - first) >> sh)], 1u);
-    }
+#pragma unroll
+    for (int q = 0; q < KEEP; q++)
+        if (t + q * T < n) atomicAdd(&start[(uint32_t)((held[q] - first) >> sh)], 1u);
+    for (uint32_t i = t + KEEP * T; i < n; i += T) atomicAdd(&start[(uint32_t)((part[off + i] - first) >> sh)], 1u);
     __syncthreads();
 #ifdef PSK_BS_STAMPS
     if (b == 100 && t == 0) stamps[1] = clock64();
@@ -332,7 +387,7 @@ __device__ __forceinline__ void bs_sort_bucket(const uint32_t b, const W *__rest
         for (int e = 0; e < BPT; e++) { c4[e] = start[BPT * t + e]; sum += c4[e]; big |= c4[e] > BS_BIN_MAX; }
         // one scan for both: the sub-bin counts in the low bits, "a sub-bin of mine is too full" in bit 24 and up
         uint32_t tot;
-        uint32_t ex = psk_block_excl_scan_u32<BS_SORT_THREADS>(sum | (big << 24), &tot, scan_lds) & 0xffffffu;
+        uint32_t ex = psk_block_excl_scan_u32<T>(sum | (big << 24), &tot, scan_lds) & 0xffffffu;
         if (tot >> 24) {   // uniform: every thread has the same total
             if (t == 0) { uniq_out[b] = 0; atomicOr(flag, 1u); }
             return;
@@ -344,8 +399,11 @@ __device__ __forceinline__ void bs_sort_bucket(const uint32_t b, const W *__rest
     if (b == 100 && t == 0) stamps[2] = clock64();
 #endif
     __syncthreads();
-    for (uint32_t i = t; i < n; i += BS_SORT_THREADS) {
-        const W w = kin[i];
+#pragma unroll
+    for (int q = 0; q < KEEP; q++)
+        if (t + q * T < n) key[atomicAdd(&fill[(uint32_t)((held[q] - first) >> sh)], 1u)] = held[q];
+    for (uint32_t i = t + KEEP * T; i < n; i += T) {
+        const W w = part[off + i];
         key[atomicAdd(&fill[(uint32_t)((w - first) >> sh)], 1u)] = w;
     }
     __syncthreads();
@@ -392,22 +450,22 @@ __device__ __forceinline__ void bs_sort_bucket(const uint32_t b, const W *__rest
     if (b == 100 && t == 0) stamps[4] = clock64();
 #endif
     // run lengths: thread t owns the sorted words [t c, (t + 1) c); it counts the run heads in its stretch, one scan gives
-    // their ranks, and every head writes its word and its position (kin) -- the length of run r is then the difference of
+    // their ranks, and every head writes its word and its position (pos) -- the length of run r is then the difference of
     // the positions of heads r + 1 and r
-    const uint32_t c = (n + BS_SORT_THREADS - 1) / BS_SORT_THREADS;
+    const uint32_t c = (n + T - 1) / T;
     const uint32_t i0 = t * c < n ? t * c : n, i1 = i0 + c < n ? i0 + c : n;
     uint32_t heads = 0;
     for (uint32_t i = i0; i < i1; i++) heads += (i == 0 || key[i - 1] != key[i]) ? 1u : 0u;
     uint32_t nu;
-    uint32_t r = psk_block_excl_scan_u32<BS_SORT_THREADS>(heads, &nu, scan_lds);
+    uint32_t r = psk_block_excl_scan_u32<T>(heads, &nu, scan_lds);
     for (uint32_t i = i0; i < i1; i++)
         if (i == 0 || key[i - 1] != key[i]) {
-            kin[r] = (W)i;
+            pos[r] = (uint16_t)i;
             wtmp[off + r] = key[i];
             r++;
         }
     __syncthreads();
-    for (uint32_t q = t; q < nu; q += BS_SORT_THREADS) ctmp[off + q] = (q + 1 < nu ? (uint32_t)kin[q + 1] : n) - (uint32_t)kin[q];
+    for (uint32_t q = t; q < nu; q += T) ctmp[off + q] = (q + 1 < nu ? (uint32_t)pos[q + 1] : n) - (uint32_t)pos[q];
 #ifdef PSK_BS_STAMPS
     if (b == 100 && t == 0) stamps[5] = clock64();
 #endif
@@ -415,9 +473,9 @@ __device__ __forceinline__ void bs_sort_bucket(const uint32_t b, const W *__rest
 }
 
 // a workgroup takes buckets blockIdx.x, blockIdx.x + gridDim.x, ...: one resident set of workgroups for the whole sample (two
-// per CU by LDS; one with 64-bit words) instead of four launch rounds of them
+// per CU) instead of four launch rounds of them
 template <typename W>
-__global__ __launch_bounds__(BS_SORT_THREADS) void bs_sort_kernel(const W *__restrict__ part, const uint32_t *__restrict__ cnt,
+__global__ __launch_bounds__(SortGeo<W>::THREADS, SortGeo<W>::WAVES_PER_SIMD) void bs_sort_kernel(const W *__restrict__ part, const uint32_t *__restrict__ cnt,
                                                                    const uint32_t *__restrict__ base, const W *__restrict__ spl,
                                                                    uint32_t nb, W last_word, uint32_t cap, W *__restrict__ wtmp,
                                                                    uint32_t *__restrict__ ctmp, uint32_t *__restrict__ uniq_out,
@@ -431,7 +489,7 @@ __global__ __launch_bounds__(BS_SORT_THREADS) void bs_sort_kernel(const W *__res
 }
 
 template <typename W>
-__global__ __launch_bounds__(BS_SORT_THREADS) void bs_sort_batch_kernel(const BsBatch<W> p)
+__global__ __launch_bounds__(SortGeo<W>::THREADS, SortGeo<W>::WAVES_PER_SIMD) void bs_sort_batch_kernel(const BsBatch<W> p)
 {
     extern __shared__ uint64_t dyn_lds64[];   // bsort_lds_bytes<W>()
     const BsItem<W> &it = p.it[blockIdx.y];
@@ -619,9 +677,9 @@ int chain_enqueue_w(psk_ctx *ctx, CountLane &L, uint64_t clean_len, uint64_t n)
     }
     W *wtmp = L.dc_mtemp.as<W>();
     uint32_t *ctmp = reinterpret_cast<uint32_t *>(wtmp + n + 8);
-    const uint32_t resident = (sizeof(W) == 4 ? 2u : 1u) * (uint32_t)(ctx->n_cu > 0 ? ctx->n_cu : 256);
+    const uint32_t resident = 2u * (uint32_t)(ctx->n_cu > 0 ? ctx->n_cu : 256);
     const uint32_t sort_wgs = ctx->bs_nb < resident ? ctx->bs_nb : resident;
-    bs_sort_kernel<W><<<sort_wgs, BS_SORT_THREADS, bsort_lds_bytes<W>(), ctx->stream>>>(L.dc_part.as<W>(), d.cnt, d.base, ctx->bs_spl.as<W>(),
+    bs_sort_kernel<W><<<sort_wgs, SortGeo<W>::THREADS, bsort_lds_bytes<W>(), ctx->stream>>>(L.dc_part.as<W>(), d.cnt, d.base, ctx->bs_spl.as<W>(),
                                                                                           ctx->bs_nb, (W)(hi - 1u), bs_cap(), wtmp, ctmp, d.uniq, d.flag);
     PSK_HIP(ctx, hipGetLastError());
     bs_totals_kernel<<<1, 1024, 0, ctx->stream>>>(d.cnt, d.uniq, d.uoff, d.flag, ctx->bs_nb, L.pinned_cnt);
@@ -725,11 +783,11 @@ int group_enqueue_w(psk_ctx *ctx, CountLane *const *lanes, const uint64_t *clean
                                          (int)bsort_lds_bytes<W>()));
     }
     // one resident set of workgroups for the whole group (two per CU by LDS; one with 64-bit words)
-    const uint32_t wg_all = (sizeof(W) == 4 ? 2u : 1u) * (uint32_t)(ctx->n_cu > 0 ? ctx->n_cu : 256);
+    const uint32_t wg_all = 2u * (uint32_t)(ctx->n_cu > 0 ? ctx->n_cu : 256);
     uint32_t per = (wg_all + (uint32_t)count - 1) / (uint32_t)count;
     if (per > ctx->bs_nb) per = ctx->bs_nb;
     if (per < 1) per = 1;
-    bs_sort_batch_kernel<W><<<dim3(per, (uint32_t)count), BS_SORT_THREADS, bsort_lds_bytes<W>(), ctx->stream>>>(p);
+    bs_sort_batch_kernel<W><<<dim3(per, (uint32_t)count), SortGeo<W>::THREADS, bsort_lds_bytes<W>(), ctx->stream>>>(p);
     PSK_HIP(ctx, hipGetLastError());
     bs_totals_batch_kernel<W><<<(uint32_t)count, 1024, 0, ctx->stream>>>(p);
     PSK_HIP(ctx, hipGetLastError());

@@ -15,7 +15,14 @@
 //   fq_count_kernel     bytes emitted per tile, and the checks that make the line arithmetic equal to the state
 //                       machine: every header line starts with '@', every separator line with '+'
 //                       -> scan -> offsets;  fq_emit_kernel  compaction as above
-//   A file that fails a check (multi-line FASTQ, blank lines between records) is framed by the host machine.
+//   A file that fails a check (multi-line FASTQ, blank lines between records) takes the general route (r06; until then: the host):
+// FASTQ, any line structure.  What the state machine does with a LINE is decided by the line before it and by the line's first
+// byte -- header -> sequence; sequence -> '+' line | sequence continued (whose first byte the machine swallows: glistmaker's
+// positional reading) | an empty line; '+' -> quality; quality / skipped -> '@' header | skipped -- : every line
+// start is a map over eight line kinds (24 bits), maps compose associatively, so the kind of every line is a scan of maps:
+//   fqg_pass_kernel<0>  per tile: the composition of its line starts' maps       -> frame_scan_kernel (mode 2) -> kind in force at every tile's first byte
+//   fqg_pass_kernel<1>  bytes emitted per tile (kinds of the threads' lines from a scan of maps inside the tile) -> scan -> offsets
+//   fqg_pass_kernel<2>  compaction as above
 // Unlike the host machine the kernels do not collapse runs of breaks: '\n' '\n' costs a byte, not a window.
 // Byte shuffling at HBM speed (two reads, one write of the file): no MFMA.
 #include "dev_utils.h"
@@ -333,6 +340,168 @@ __global__ __launch_bounds__(FR_THREADS) void fq_pass_kernel(const uint8_t *__re
     copy_out(stage, total, clean + out_entry[blockIdx.x].y);
 }
 
+// ---- FASTQ, any line structure (r06) -----------------------------------------------------------------------------------------
+// Line kinds.  SEQ0: a sequence line read from its first byte (the line behind a header, or behind a swallowed empty line); SEQ1: a
+// continued sequence line -- the machine consumes the byte behind a sequence line's '\n' (kmer_count.hip: frame_sequence_counting,
+// "the byte after a sequence newline is consumed"), so its first byte emits nothing; SEQE: that byte was the '\n' of an empty line;
+// SKIP: a line behind the quality line that does not start with '@' (further quality lines); SKIPE: an empty such line -- its '\n' is
+// taken for the line's first byte, so the line BEHIND it is skipped whatever it starts with.
+enum { LK_HDR = 0, LK_SEQ0 = 1, LK_SEQ1 = 2, LK_SEQE = 3, LK_PLUS = 4, LK_QUAL = 5, LK_SKIP = 6, LK_SKIPE = 7 };
+enum { LC_AT = 0, LC_PLUS = 1, LC_NL = 2, LC_OTHER = 3 };   // classes of a line's first byte
+constexpr uint32_t lk_map(int k0, int k1, int k2, int k3, int k4, int k5, int k6, int k7)
+{
+    return (uint32_t)k0 | ((uint32_t)k1 << 3) | ((uint32_t)k2 << 6) | ((uint32_t)k3 << 9) | ((uint32_t)k4 << 12) | ((uint32_t)k5 << 15) | ((uint32_t)k6 << 18) |
+           ((uint32_t)k7 << 21);
+}
+constexpr uint32_t LK_IDENTITY = lk_map(0, 1, 2, 3, 4, 5, 6, 7);
+constexpr uint32_t LK_FIRST = lk_map(LK_HDR, LK_HDR, LK_HDR, LK_HDR, LK_HDR, LK_HDR, LK_HDR, LK_HDR);   // the record region starts at a header
+// kind of a line by the kind before it (position in the map), per class of its first byte
+constexpr uint32_t LK_BY_CLASS[4] = {
+    /* '@'   */ lk_map(LK_SEQ0, LK_SEQ1, LK_SEQ1, LK_SEQ0, LK_QUAL, LK_HDR, LK_HDR, LK_SKIP),
+    /* '+'   */ lk_map(LK_SEQ0, LK_PLUS, LK_PLUS, LK_SEQ0, LK_QUAL, LK_SKIP, LK_SKIP, LK_SKIP),
+    /* '\n'  */ lk_map(LK_SEQ0, LK_SEQE, LK_SEQE, LK_SEQ0, LK_QUAL, LK_SKIPE, LK_SKIPE, LK_SKIP),
+    /* other */ lk_map(LK_SEQ0, LK_SEQ1, LK_SEQ1, LK_SEQ0, LK_QUAL, LK_SKIP, LK_SKIP, LK_SKIP)};
+__device__ __forceinline__ uint32_t lk_apply(uint32_t map, uint32_t kind) { return (map >> (3u * kind)) & 7u; }
+__device__ __forceinline__ uint32_t lk_then(uint32_t first, uint32_t second)   // the map "first, then second"
+{
+    uint32_t r = 0;
+#pragma unroll
+    for (int k = 0; k < 8; k++) r |= lk_apply(second, lk_apply(first, (uint32_t)k)) << (3 * k);
+    return r;
+}
+__device__ __forceinline__ uint32_t lk_class_map(uint32_t cls)
+{
+    return cls == LC_AT ? LK_BY_CLASS[0] : cls == LC_PLUS ? LK_BY_CLASS[1] : cls == LC_NL ? LK_BY_CLASS[2] : LK_BY_CLASS[3];
+}
+
+// the thread's 16 bytes: F = first bytes of lines; the map of its line starts in order; walk(): kinds and emission
+struct FqgThread {
+    uint32_t F, map;
+};
+__device__ __forceinline__ FqgThread fqg_thread(const Masks16 &m, bool first_in, bool file_start)
+{
+    FqgThread t;
+    t.F = ((m.nl << 1) | (first_in ? 1u : 0u)) & m.valid;
+    t.map = LK_IDENTITY;
+    uint32_t f = t.F;
+    while (f) {
+        const int j = __ffs(f) - 1;
+        f &= f - 1u;
+        const uint32_t cls = ((m.at >> j) & 1u) ? LC_AT : ((m.plus >> j) & 1u) ? LC_PLUS : ((m.nl >> j) & 1u) ? LC_NL : LC_OTHER;
+        t.map = lk_then(t.map, (file_start && j == 0) ? LK_FIRST : lk_class_map(cls));
+    }
+    return t;
+}
+// emission of the 16 bytes given the kind in force in front of them
+__device__ __forceinline__ void fqg_walk(const Masks16 &m, const FqgThread &t, bool file_start, uint32_t kind, uint32_t &emit, uint32_t &keep)
+{
+    emit = keep = 0;
+    const uint32_t brk = ~(m.base | m.ctl) & 0xFFFFu;
+#pragma unroll
+    for (int j = 0; j < FR_BPT; j++) {
+        const uint32_t bit = 1u << j;
+        const bool first = (t.F & bit) != 0;
+        if (first) {
+            const uint32_t cls = (m.at & bit) ? LC_AT : (m.plus & bit) ? LC_PLUS : (m.nl & bit) ? LC_NL : LC_OTHER;
+            kind = (file_start && j == 0) ? (uint32_t)LK_HDR : lk_apply(lk_class_map(cls), kind);
+        }
+        if (!(m.valid & bit)) continue;
+        if (kind == LK_HDR) {
+            if (m.nl & bit) emit |= bit;                            // the break between reads
+        } else if (kind == LK_SEQ0 || (kind == LK_SEQ1 && !first)) {
+            if (m.base & bit) { emit |= bit; keep |= bit; }
+            else if (brk & bit) emit |= bit;                         // (control bytes -- '\n', '\r' -- emit nothing)
+        }
+    }
+}
+
+// exclusive scan of the threads' maps over the workgroup (maps compose in thread order); lds: FR_THREADS / 64 words
+__device__ __forceinline__ uint32_t fqg_block_excl_scan(uint32_t map, uint32_t *lds, uint32_t *all)
+{
+    const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
+    uint32_t inc = map;
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) {
+        const uint32_t up = (uint32_t)__shfl_up((int)inc, d, 64);
+        if (lane >= d) inc = lk_then(up, inc);
+    }
+    if (lane == 63) lds[wid] = inc;
+    __syncthreads();
+    uint32_t before = LK_IDENTITY, total = LK_IDENTITY;
+    for (int w = 0; w < FR_THREADS / 64; w++) {
+        if (w < wid) before = lk_then(before, lds[w]);
+        total = lk_then(total, lds[w]);
+    }
+    uint32_t ex = (uint32_t)__shfl_up((int)inc, 1, 64);
+    if (lane == 0) ex = LK_IDENTITY;
+    __syncthreads();
+    *all = total;
+    return lk_then(before, ex);
+}
+
+// PASS 0: summary[tile].x = the tile's map.  PASS 1: the bytes the tile emits (kind_entry[tile].x = kind in force at its first
+// byte).  PASS 2: emission.
+template <int PASS>
+__global__ __launch_bounds__(FR_THREADS) void fqg_pass_kernel(const uint8_t *__restrict__ raw, uint64_t len, const uint2 *__restrict__ kind_entry,
+                                                               uint4 *__restrict__ summary, const uint2 *__restrict__ out_entry,
+                                                               uint8_t *__restrict__ clean)
+{
+    __shared__ uint32_t lds[FR_THREADS / 64];
+    __shared__ uint32_t scan_lds[FR_THREADS / 64];
+    __shared__ uint8_t stage[PASS == 2 ? FR_TILE : 1];
+    const uint64_t pos = ((uint64_t)blockIdx.x * FR_THREADS + threadIdx.x) * FR_BPT;
+    const Bytes16 b = load16(raw, len, pos);
+    const Masks16 m = classify(b, pos, len);
+    const bool first_in = pos < len && (pos == 0 || raw[pos - 1] == '\n');
+    const FqgThread t = fqg_thread(m, first_in, pos == 0);
+    uint32_t all;
+    const uint32_t before = fqg_block_excl_scan(t.map, lds, &all);
+    if (PASS == 0) {
+        if (threadIdx.x == 0) summary[blockIdx.x] = make_uint4(all, 0u, 0u, 0u);
+        return;
+    }
+    uint32_t emit, keep;
+    fqg_walk(m, t, pos == 0, lk_apply(before, kind_entry[blockIdx.x].x), emit, keep);
+    uint32_t total;
+    const uint32_t off = psk_block_excl_scan_u32<FR_THREADS>(__popc(emit), &total, scan_lds);
+    if (PASS == 1) {
+        if (threadIdx.x == 0) summary[blockIdx.x] = make_uint4(total, 0u, 0u, 0u);
+        return;
+    }
+    emit16(b, emit, keep, stage, off);
+    __syncthreads();
+    copy_out(stage, total, clean + out_entry[blockIdx.x].y);
+}
+
+// one workgroup: entry[t].x = the kind in force at tile t's first byte = the maps of the tiles before it applied in order
+__global__ __launch_bounds__(1024) void fqg_scan_kernel(const uint4 *__restrict__ summary, uint32_t n_tiles, uint2 *__restrict__ entry)
+{
+    __shared__ uint32_t lds[16];
+    const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
+    uint32_t carry = LK_IDENTITY;   // (applied to any kind: the first tile's first byte forces a header anyway)
+    for (uint32_t t0 = 0; t0 < n_tiles; t0 += 1024) {
+        const uint32_t t = t0 + threadIdx.x;
+        uint32_t inc = t < n_tiles ? summary[t].x : LK_IDENTITY;
+#pragma unroll
+        for (int d = 1; d < 64; d <<= 1) {
+            const uint32_t up = (uint32_t)__shfl_up((int)inc, d, 64);
+            if (lane >= d) inc = lk_then(up, inc);
+        }
+        if (lane == 63) lds[wid] = inc;
+        __syncthreads();
+        uint32_t before = carry, total = carry;
+        for (int w = 0; w < 16; w++) {
+            if (w < wid) before = lk_then(before, lds[w]);
+            total = lk_then(total, lds[w]);
+        }
+        uint32_t ex = (uint32_t)__shfl_up((int)inc, 1, 64);
+        if (lane == 0) ex = LK_IDENTITY;
+        if (t < n_tiles) entry[t] = make_uint2(lk_apply(lk_then(before, ex), (uint32_t)LK_HDR), 0u);
+        __syncthreads();
+        carry = total;
+    }
+}
+
 }  // namespace
 
 // Host pre-pass of one file image (a worker thread): the input ends at its first NUL and starts at its first '>' or
@@ -392,7 +561,7 @@ size_t frame_gpu_scratch_bytes(uint64_t raw_len)
 }
 
 // Queues the framing of d_raw[0 .. raw_len) (format 1 / 2 as frame_probe reports, starting at the record's first
-// byte) on `stream`: clean stream into d_clean (capacity raw_len + 128), {clean length, irregular flag} into
+// byte; 3: FASTQ that is not four-line FASTQ -- format 2 came back with the irregular flag -- through the scan of line kinds) on `stream`: clean stream into d_clean (capacity raw_len + 128), {clean length, irregular flag} into
 // host_out (pinned) when the stream reaches that point.  scratch: frame_gpu_scratch_bytes(raw_len) device bytes.
 int frame_gpu_enqueue(psk_ctx *ctx, hipStream_t stream, int format, const uint8_t *d_raw, uint64_t raw_len, uint8_t *d_clean,
                       void *scratch, uint64_t *host_out)
@@ -414,6 +583,19 @@ int frame_gpu_enqueue(psk_ctx *ctx, hipStream_t stream, int format, const uint8_
         frame_scan_kernel<<<1, 1024, 0, stream>>>(summary, n_tiles, 0, entry_a, d_clean, nullptr, host_out);
         PSK_HIP(ctx, hipGetLastError());
         fa_emit_kernel<<<n_tiles, FR_THREADS, 0, stream>>>(d_raw, raw_len, entry_a, d_clean);
+        PSK_HIP(ctx, hipGetLastError());
+        return PSK_OK;
+    }
+    if (format == 3) {   // FASTQ of any line structure (records over several lines, blank lines): the scan of line kinds
+        fqg_pass_kernel<0><<<n_tiles, FR_THREADS, 0, stream>>>(d_raw, raw_len, nullptr, summary, nullptr, nullptr);
+        PSK_HIP(ctx, hipGetLastError());
+        fqg_scan_kernel<<<1, 1024, 0, stream>>>(summary, n_tiles, entry_a);
+        PSK_HIP(ctx, hipGetLastError());
+        fqg_pass_kernel<1><<<n_tiles, FR_THREADS, 0, stream>>>(d_raw, raw_len, entry_a, summary, nullptr, nullptr);
+        PSK_HIP(ctx, hipGetLastError());
+        frame_scan_kernel<<<1, 1024, 0, stream>>>(summary, n_tiles, 1, entry_b, d_clean, nullptr, host_out);
+        PSK_HIP(ctx, hipGetLastError());
+        fqg_pass_kernel<2><<<n_tiles, FR_THREADS, 0, stream>>>(d_raw, raw_len, entry_a, summary, entry_b, d_clean);
         PSK_HIP(ctx, hipGetLastError());
         return PSK_OK;
     }
@@ -451,9 +633,12 @@ extern "C" int64_t psk_frame_sequence_gpu(psk_ctx *ctx, const uint8_t *bytes, si
     if (rc == PSK_OK && hipMemcpyAsync(raw.p, bytes + st, rl, hipMemcpyHostToDevice, ctx->stream) != hipSuccess) fail(PSK_EHIP, "upload failed");
     if (rc == PSK_OK) rc = frame_gpu_enqueue(ctx, ctx->stream, format, raw.as<uint8_t>(), rl, clean.as<uint8_t>(), scratch.p, res);
     if (rc == PSK_OK && hipStreamSynchronize(ctx->stream) != hipSuccess) fail(PSK_EHIP, "framing kernels failed");
+    if (rc == PSK_OK && format == 2 && res[1]) {   // not four-line FASTQ: the general route (what kmer_count.hip does with such a sample)
+        rc = frame_gpu_enqueue(ctx, ctx->stream, 3, raw.as<uint8_t>(), rl, clean.as<uint8_t>(), scratch.p, res);
+        if (rc == PSK_OK && hipStreamSynchronize(ctx->stream) != hipSuccess) fail(PSK_EHIP, "framing kernels failed");
+    }
     if (rc == PSK_OK) {
-        if (format == 2 && res[1]) rc = psk_fail(ctx, PSK_ESTATE, "not four-line FASTQ: the host state machine frames this input");
-        else if (res[0] > out_cap) rc = psk_fail(ctx, PSK_ERANGE, "output buffer too small");
+        if (res[0] > out_cap) rc = psk_fail(ctx, PSK_ERANGE, "output buffer too small");
         else if (res[0] && hipMemcpy(out, clean.p, res[0], hipMemcpyDeviceToHost) != hipSuccess) fail(PSK_EHIP, "download failed");
         else rc = (int64_t)res[0];
     }

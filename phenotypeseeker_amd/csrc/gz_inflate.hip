@@ -37,7 +37,6 @@
 #include "dev_utils.h"
 #include "psk_internal.h"
 
-#include <sys/mman.h>
 #include <zlib.h>
 
 #include <algorithm>
@@ -1865,47 +1864,46 @@ int gz_inflate_group(psk_ctx *ctx, int n, const uint8_t *const *data, const size
     return PSK_OK;
 }
 
-uint8_t *gz_host_alloc(size_t bytes)
+void gz_release_device(psk_ctx *ctx)
 {
-    constexpr size_t HUGE = (size_t)2 << 20;
-    const size_t want = (bytes + HUGE - 1) & ~(HUGE - 1);
-    void *p = std::aligned_alloc(HUGE, want ? want : HUGE);
-    if (p) (void)madvise(p, want ? want : HUGE, MADV_HUGEPAGE);   // (advice: where transparent huge pages are off, ordinary pages as before)
-    return static_cast<uint8_t *>(p);
-}
-
-void gz_release(psk_ctx *ctx, bool wait)
-{
-    const bool trace = std::getenv("PSK_TRACE") != nullptr;
     const auto t0 = std::chrono::steady_clock::now();
-    size_t dev_bytes = 0, host_bytes = 0;
+    size_t dev_bytes = 0;
     for (DevBuf *b : {&ctx->gz_comp[0], &ctx->gz_comp[1], &ctx->gz_out[0], &ctx->gz_out[1], &ctx->gz_sym, &ctx->gz_rec, &ctx->gz_tab}) {
         dev_bytes += b->cap;
         dev_release(*b);
     }
-    const auto t1 = std::chrono::steady_clock::now();
+    if (dev_bytes && std::getenv("PSK_TRACE"))
+        std::fprintf(stderr, "[psk] gz release: %.1f GB of device buffers in %.1f ms\n", dev_bytes / 1e9,
+                     std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count());
+}
+
+void gz_release_host(psk_ctx *ctx, bool wait)
+{
+    const bool trace = std::getenv("PSK_TRACE") != nullptr;
     if (ctx->gz_reaper.joinable()) ctx->gz_reaper.join();
     uint8_t *gone[2] = {ctx->gz_host[0], ctx->gz_host[1]};
+    size_t host_bytes = 0;
     for (int q = 0; q < 2; q++) {
         host_bytes += ctx->gz_host_cap[q];
         ctx->gz_host[q] = nullptr;
         ctx->gz_host_cap[q] = 0;
     }
-    if (gone[0] || gone[1]) {
-        ctx->gz_reaper = std::thread([gone, trace, host_bytes] {
-            const auto h0 = std::chrono::steady_clock::now();
-            std::free(gone[0]);
-            std::free(gone[1]);
-            if (trace)
-                std::fprintf(stderr, "[psk] gz release: %.1f GB of host buffers given back in %.1f ms (helper thread)\n", host_bytes / 1e9,
-                             std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - h0).count());
-        });
-    }
-    if (wait && ctx->gz_reaper.joinable()) ctx->gz_reaper.join();
-    if (trace && (dev_bytes || host_bytes))
-        std::fprintf(stderr, "[psk] gz release: %.1f GB of device buffers in %.1f ms; %.1f GB of host buffers %s: %.1f ms\n", dev_bytes / 1e9,
-                     std::chrono::duration<double, std::milli>(t1 - t0).count(), host_bytes / 1e9, wait ? "waited for" : "handed to a helper thread",
-                     std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t1).count());
+    if (!gone[0] && !gone[1]) return;
+    ctx->gz_reaper = std::thread([gone, trace, host_bytes] {
+        const auto h0 = std::chrono::steady_clock::now();
+        std::free(gone[0]);
+        std::free(gone[1]);
+        if (trace)
+            std::fprintf(stderr, "[psk] gz release: %.1f GB of host buffers given back in %.1f ms (helper thread)\n", host_bytes / 1e9,
+                         std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - h0).count());
+    });
+    if (wait) ctx->gz_reaper.join();
+}
+
+void gz_release(psk_ctx *ctx)
+{
+    gz_release_device(ctx);
+    gz_release_host(ctx, true);
 }
 
 // ---- C-ABI: the inflate on its own (tests, measurements) ------------------------------------------------------------

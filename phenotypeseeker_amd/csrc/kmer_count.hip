@@ -1171,8 +1171,8 @@ static int count_batch_core(psk_ctx *ctx, int first_sample_idx, int n, const uin
             PSK_HIP(ctx, hipEventSynchronize(L.raw_ready));   // the GPU is busy with the chain of sample i - 1 meanwhile
             t_frame += since(t0);
             const uint64_t *res = lane_frame_result(L);
-            if (fmt[i] == 2 && res[1]) {
-                // not four-line FASTQ (multi-line records, blank lines): the host state machine frames this sample
+            if (fmt[i] == 2 && res[1] && getenv("PSK_HOST_WRAPPED_FASTQ")) {
+                // (r05's route, kept as the A/B knob: the host state machine frames a FASTQ sample that is not four-line FASTQ)
                 PSK_TRY(ensure_pinned(ctx, &ctx->pinned, &ctx->pinned_cap, rlen[i] + 2 * EX_SEG));
                 uint64_t c = 0, p = 0, w = 0;
                 std::vector<uint8_t> text;   // (a .gz sample inflated on the device: its text comes back for the host's state machine)
@@ -1188,6 +1188,17 @@ static int count_batch_core(psk_ctx *ctx, int first_sample_idx, int n, const uin
                 PSK_TRY(chain_upload(ctx, L, static_cast<const uint8_t *>(ctx->pinned), w ? p : 0, 0));
                 PSK_HIP(ctx, hipEventSynchronize(L.raw_ready));   // ctx->pinned is reused by the next such sample
                 return consume(L, i, c, w, true);
+            }
+            if (fmt[i] == 2 && res[1]) {
+                // not four-line FASTQ (records over several lines, blank lines between them): framed again, on the device, by the
+                // scan of line kinds (frame_gpu.hip, format 3; r06 -- until then the host's state machine took such a sample); the
+                // raw bytes are still in the lane's input buffer
+                if (getenv("PSK_TRACE"))
+                    fprintf(stderr, "[psk] sample %d: FASTQ, but not four lines a record: framed on the device by the scan of line kinds\n", first_sample_idx + i);
+                PSK_TRY(frame_gpu_enqueue(ctx, ctx->frame_stream, 3, L.rawin.as<uint8_t>(), rlen[i], L.raw.as<uint8_t>(), L.fr_scratch.p, lane_frame_result(L)));
+                PSK_HIP(ctx, hipEventRecord(L.raw_ready, ctx->frame_stream));
+                PSK_HIP(ctx, hipEventSynchronize(L.raw_ready));
+                res = lane_frame_result(L);
             }
             clen[i] = res[0];
             wins[i] = res[0];   // an upper bound of the window count: sizes the buffers, the GPU counts the windows
@@ -1429,7 +1440,7 @@ static int count_batch_impl(psk_ctx *ctx, int first_sample_idx, int n, const uin
             if (ctx->gz_reaper.joinable()) ctx->gz_reaper.join();
             std::free(host);
             cap = 0;
-            host = gz_host_alloc(need + need / 8);
+            host = static_cast<uint8_t *>(std::malloc(need + need / 8));
             if (!host) return psk_fail(ctx, PSK_ENOMEM, "no host memory for %zu bytes of compressed input", need);
             cap = need + need / 8;
         }

@@ -205,13 +205,25 @@ static int padded_wpr(int n_samples)
     return (w + 1) & ~1;   // even: rows are 16-byte aligned
 }
 
+static int build_presence_impl(psk_ctx *ctx, uint64_t *n_kmers);
+
 extern "C" int psk_build_presence(psk_ctx *ctx, uint64_t *n_kmers)
 {
     if (!ctx) return PSK_EINVAL;
     if (ctx->n_in_flight > 0) return psk_fail(ctx, PSK_ESTATE, "a scan is in flight on this matrix: psk_scan_end first");
     if (ctx->k == 0) return psk_fail(ctx, PSK_ESTATE, "psk_begin has not been called");
     PSK_HIP(ctx, hipSetDevice(ctx->device));
-    gz_release(ctx);   // the ingest is over: what the .gz inputs were inflated in goes back before the matrix is allocated
+    // the ingest is over: the device buffers the .gz inputs were inflated in go back before the matrix is allocated (milliseconds);
+    // their host images -- gigabytes of pages: 0.5 s to unmap -- are handed to a helper thread once the build is done with its own
+    // allocations (psk_internal.h: gz_release_host)
+    gz_release_device(ctx);
+    const int rc = build_presence_impl(ctx, n_kmers);
+    gz_release_host(ctx, false);
+    return rc;
+}
+
+static int build_presence_impl(psk_ctx *ctx, uint64_t *n_kmers)
+{
     uint64_t total = 0;
     for (int i = 0; i < ctx->n_samples; i++) {
         if (!ctx->lists[i].done) return psk_fail(ctx, PSK_ESTATE, "sample %d has not been counted", i);

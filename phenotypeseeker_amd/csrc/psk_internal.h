@@ -223,11 +223,13 @@ struct GzInflated {
     std::vector<uint8_t> host;
     std::string error;        // zlib refused the file: why
 };
-// gives the device buffers above back at once (milliseconds) and the host images on a helper thread (r06: psk_build_presence spent
-// 0.53-0.56 s of cfg5gz's 2.3 s unmapping 5.2 GB of host pages; the 69.6 GB of device buffers took 2 ms); wait: join that thread
-// (psk_free, and whoever needs gz_host again)
-void gz_release(psk_ctx *ctx, bool wait = false);
-uint8_t *gz_host_alloc(size_t bytes);   // 2-MiB aligned, MADV_HUGEPAGE: a few thousand pages to fault in and to release instead of a million
+// r06: what psk_build_presence paid for the .gz inputs' buffers was the HOST's side -- 5.2 GB of compressed images: 0.53-0.56 s to
+// unmap, of cfg5gz's 2.3 s -- not the device's (69.6 GB: 2 ms; tools/free_probe.py).  gz_release_device: at the start of the matrix
+// build (the memory is wanted); gz_release_host: on a helper thread started when the build has been queued (a thread that unmaps
+// holds the address-space lock the build's own allocations need); wait: join it (psk_free; whoever needs gz_host again joins too).
+void gz_release_device(psk_ctx *ctx);
+void gz_release_host(psk_ctx *ctx, bool wait);
+void gz_release(psk_ctx *ctx);   // both, waited for (psk_free)
 int gz_inflate_group(psk_ctx *ctx, int n, const uint8_t *const *data, const size_t *sizes, DevBuf &comp_buf, DevBuf &sym_buf, DevBuf &rec_buf, DevBuf &out_buf,
                      DevBuf &tab_buf, std::vector<GzInflated> &res, double *device_ms, bool host_only = false, int host_threads = 8,
                      hipStream_t on_stream = nullptr, bool images_uploaded = false);

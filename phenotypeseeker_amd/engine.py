@@ -505,8 +505,8 @@ class PskContext:
 
 
     def frame_sequence_gpu(self, data):
-        """psk_frame_sequence_gpu: the clean stream as the device framing produces it, or None when the input is FASTQ
-        that the host state machine has to frame (not four lines per record)."""
+        """psk_frame_sequence_gpu: the clean stream as the device framing produces it (r06: FASTQ that is not four lines per
+        record included -- the scan of line kinds of frame_gpu.hip; until r05 such input came back as None: the host's)."""
         data = bytes(data)
         out = np.empty(len(data) + 128, dtype=np.uint8)
         n = self._lib.psk_frame_sequence_gpu(self._h, data, len(data), _ptr(out), out.size)

@@ -1160,12 +1160,12 @@ def _collapse(clean):
     return bytes(out)
 
 
-def test_gpu_framing_equals_the_host_state_machine(ctx, oracle, monkeypatch):
+def test_gpu_framing_equals_the_host_state_machine(ctx, oracle, monkeypatch, capfd):
     """record framing on the device (frame_gpu.hip).  On all 161 probed tokeniser cases, on FASTA
     with every awkward byte (headers inside lines, control bytes, IUPAC codes, '>' in sequence, CRLF, no final
-    newline, text before the first record, NUL) and on four-line FASTQ the device's clean stream equals the host
-    machine's up to collapsed breaks; FASTQ that is not four lines per record is handed back to the host machine; and
-    the lists counted with device framing equal those counted with host framing and glistmaker's."""
+    newline, text before the first record, NUL), on four-line FASTQ and (r06) on FASTQ that is NOT four lines per record the
+    device's clean stream equals the host machine's up to collapsed breaks; and the lists counted with device framing equal
+    those counted with host framing and glistmaker's (37 of the reference's 161 fixtures are such irregular FASTQ)."""
     from helpers import tokenizer_cases
     from phenotypeseeker_amd.engine import frame_sequence
     from phenotypeseeker_amd.synth import GenomeSet, fastq_reads
@@ -1177,18 +1177,39 @@ def test_gpu_framing_equals_the_host_state_machine(ctx, oracle, monkeypatch):
              b">a\nACGT>b\nGGGG\n>c\n\n\nTT\x01\x02TT\n", b">x\nACGT\x00ACGT\n", b"@r\nAC\nGT\n+\nIIII\n", b"@r\nACGT\n+\nIIII\n\n@s\nACGT\n+\nIIII\n"]
     body = bytearray(rng.integers(1, 256, 60_000, dtype=np.uint8).tobytes())
     extra.append(b">fuzz\n" + bytes(body))                           # every byte value but NUL, '>' and '\n' sprinkled in
-    n_gpu = n_host = 0
+    # r06: FASTQ that is NOT four lines per record is framed on the device too (the scan of line kinds) -- sequences and
+    # qualities over several lines (the machine swallows the first byte of a continued sequence line), blank lines inside and
+    # between records, quality lines that begin with '@', a FASTA record behind a FASTQ one, CRLF: more cases of that kind
+    wrapped = [b"@r\nAC\nGT\n+\nIIII\n", b"@r\nACGT\n+\nIIII\n\n@s\nACGT\n+\nIIII\n",
+               b"@r1\nACGTACGTAC\nGGGTTTAAAC\nCCA\n+r1\nIIIIIIIIII\nIIIIIIIIII\nIII\n@r2\nTTTTGGGGCCCCAAAA\n+\n@IIIIIIIIIIIIIII\n@r3\nACGTAACC\n+\nIIIIIIII\n",
+               b"@r\r\nACGTACGT\r\nTTGGCCAA\r\n+\r\nIIIIIIII\r\nIIIIIIII\r\n@s\r\nGGGGCCCC\r\n+\r\nIIIIIIII\r\n",
+               b"@r\nACGT\n\nTTGG\n\n\nCCAA\n+\nIIII\n\n\n@s\nGGGG\n+\n\nIIII\n@t\nAAAA\n+\nIIII\n",
+               b"@r\n+ACGT\nTTTT\n+\nIIII\n@s\n\nACGT\n+\nIIII\n", b"@r\nACGT\n@notaheader\nGGGG\n+\nIIII\nIIII\n@s\nCCCCAAAA\n+\nIIIIIIII\n",
+               b"@r\nACGTNNNNACGT\nNNNN\nACGTACGT\n+\n" + b"I" * 24 + b"\n>fasta_behind\nACGTACGTACGT\n@s\nTTTTTTTTGGGG\n+\nIIIIIIIIIIII\n",
+               b"@r\nACGT", b"@r\nACGT\nAC", b"@r\nACGT\n+", b"@r\nACGT\n+\nII\nII", b"text first\nmore @r\nACGTACGT\nACGT\n+\nIIIIIIII\nIIII\n"]
+    reads = fastq_reads(gs.codes(2), 300, 150, seed=[4, 5]).split(b"\n")
+    big = bytearray()
+    for q in range(0, len(reads) - 3, 4):     # every record's sequence and quality over lines of 60, a blank line behind every third
+        h, sq, pl, ql = reads[q:q + 4]
+        big += h + b"\n" + b"\n".join(sq[c:c + 60] for c in range(0, len(sq), 60)) + b"\n" + pl + b"\n" + b"\n".join(ql[c:c + 60] for c in range(0, len(ql), 60)) + b"\n"
+        if (q // 4) % 3 == 2:
+            big += b"\n"
+    wrapped.append(bytes(big))                 # 60 KB: tiles, waves and threads that begin inside every kind of line
+    extra += wrapped
+    n_gpu = n_irregular = 0
     cases = [(d, k) for d, k, _ in tokenizer_cases()] + [(d, 13) for d in extra]
     for data, k in cases:
         want = frame_sequence(data)
         got = ctx.frame_sequence_gpu(data)
-        if got is None:
-            n_host += 1
-            continue
+        assert got is not None, data[:80]      # nothing is handed to the host's state machine any more
         n_gpu += 1
         assert _collapse(got) == _collapse(want), data[:80]
-    assert n_gpu > 120 and n_host >= 2
-    assert ctx.frame_sequence_gpu(extra[-3]) is None and ctx.frame_sequence_gpu(extra[-2]) is None   # multi-line / blank-line FASTQ
+        at, gt = data.find(b"@"), data.find(b">")
+        if at >= 0 and (gt < 0 or at < gt):
+            lines = data[at:].split(b"\n")
+            lines = lines[:-1] if lines[-1] == b"" else lines
+            n_irregular += any((j % 4 == 0 and not l.startswith(b"@")) or (j % 4 == 2 and not l.startswith(b"+")) for j, l in enumerate(lines))
+    assert n_gpu > 170 and n_irregular >= 45, (n_gpu, n_irregular)
     # lists: device framing (default) against host framing and the reference's
     for data, k, ref in tokenizer_cases():
         if ref is None or not 1 <= k <= 32:
@@ -1200,7 +1221,14 @@ def test_gpu_framing_equals_the_host_state_machine(ctx, oracle, monkeypatch):
     datas = extra + [b""]
     for k in (13, 16):
         ctx.begin(k, len(datas))
+        monkeypatch.setenv("PSK_TRACE", "1")
+        capfd.readouterr()
         nu, nt = ctx.count_kmers_batch(0, datas, 3)
+        monkeypatch.delenv("PSK_TRACE")
+        # the DEVICE route for the samples that are not four-line FASTQ, by the library's own account
+        said = capfd.readouterr().err
+        on_device = [int(l.split("sample ")[1].split(":")[0]) for l in said.splitlines() if "framed on the device by the scan of line kinds" in l]
+        assert len(on_device) >= len(wrapped) - 4 and len(extra) - 1 in on_device, on_device     # (the truncated ones may be regular)
         lists = [ctx.get_list(i, nu[i]) for i in range(len(datas))]
         monkeypatch.setenv("PSK_HOST_FRAMING", "1")
         ctx.begin(k, len(datas))

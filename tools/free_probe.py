@@ -50,7 +50,31 @@ def child(gb):
     # no hipFree: the driver takes the memory back when the process is gone
 
 
+def alloc_child(sizes_gb):
+    """A fresh process: hipMalloc of each size in turn (kept), each touched; prints the milliseconds of every hipMalloc."""
+    chk(hip.hipSetDevice(0), "hipSetDevice")
+    hip.hipFree(None)
+    ms = []
+    for gb in sizes_gb:
+        t0 = time.time()
+        p = malloc(int(gb * GB))
+        ms.append(round((time.time() - t0) * 1e3, 2))
+        touch(p, int(gb * GB))
+        sync()
+    print(json.dumps(ms))
+
+
 def main():
+    if len(sys.argv) > 1 and sys.argv[1] == "allocs":
+        # r06: is it the SIZE of one hipMalloc that is slow (24 GB: 750 ms, <= 12 GB: 0.2 ms in the first table), or the total?
+        res = {}
+        for name, sizes in (("1x24", [24]), ("2x12", [12, 12]), ("3x8", [8, 8, 8]), ("6x4", [4] * 6), ("1x16", [16]), ("1x13", [13]), ("1x20", [20]),
+                            ("12 then 24", [12, 24]), ("8x12", [12] * 8), ("2x48", [48, 48])):
+            p = subprocess.run([sys.executable, __file__, "alloc_child"] + [str(x) for x in sizes], capture_output=True, text=True)
+            res[name] = json.loads(p.stdout.strip().splitlines()[-1]) if p.returncode == 0 else "failed: " + p.stderr[-200:]
+            time.sleep(3)     # (the driver clears what the child held)
+        print(json.dumps({"hipMalloc_ms_fresh_process": res}, indent=1))
+        return
     chk(hip.hipSetDevice(0), "hipSetDevice")
     hip.hipFree(None)
     out = {"hipFree_ms_by_GB": {}, "hipMalloc_ms_by_GB": {}}
@@ -162,5 +186,7 @@ def main():
 if __name__ == "__main__":
     if len(sys.argv) > 2 and sys.argv[1] == "child":
         child(float(sys.argv[2]))
+    elif len(sys.argv) > 2 and sys.argv[1] == "alloc_child":
+        alloc_child([float(x) for x in sys.argv[2:]])
     else:
         main()
