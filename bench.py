@@ -303,7 +303,7 @@ def main():
     ap.add_argument("--ingest", default="auto", choices=["auto", "filter", "exchange"],
                     help="N > 1: every rank tokenises every sample and keeps its slab (filter), or every sample is "
                          "counted on one rank and the list ranges are exchanged with an all-to-all (exchange); auto = the "
-                         "CLI's rule: exchange when the collectives are RCCL, filter on a host transport (DESIGN.md section 8)")
+                         "CLI's rule: exchange when the collectives are RCCL, filter on a host transport (DESIGN.md section 7)")
     ap.add_argument("--workload", default="fasta", choices=["fasta", "matrix"],
                     help="fasta: count synthetic genomes on the GPU (default, BASELINE cfg 2); "
                          "matrix: device-generated presence matrix of --rows rows (quick runs)")

@@ -740,13 +740,20 @@ __global__ __launch_bounds__(64) void gz_decode_kernel(GzDecodeArgs a)
 // One wave per chunk, 64 matches at a time, one per lane: a match whose source holds nothing that an earlier match of the
 // same 64 writes is copied at once (sixty-four loads in flight instead of one), the others in the rounds after the ones
 // they wait for.  A source that lies before the chunk is a marker: 256 + its place in the unknown window.
+// (r06: the same copies through a ring of the chunk's text in LDS -- one wave a chunk, 76 KB, literals streamed in and text streamed
+// out in 16-byte pieces: every symbol once in, once out instead of 4.7 x -- were correct (all of tests/test_gpu_gz*.py) and SEVEN
+// TIMES SLOWER, 344 ms against 48: two chunks a CU instead of twenty, and nothing hides the LDS round trip of a symbol-by-symbol
+// copy of up to 258 symbols.  What this kernel is bound by is waves in flight, not bytes.  docs/NOTEBOOK.md, round 6.)
 constexpr int GZ_COPY_WIDE = 2;   // 16-byte pieces a lane has in flight
 
 // The records are the writing pass's: a chunk whose pass ended in GZ_ERROR has left its records (and symbols) half written --
 // what lies behind them is an earlier group's data or uninitialised memory: such a chunk is not copied at all, no
 // chunk copies more records than its pass wrote, and a record that would write outside its chunk's text is dropped whatever
 // wrote it (its file then fails the check sum and goes to zlib).
-__global__ __launch_bounds__(256) void gz_copy_kernel(uint16_t *sym, const uint2 *rec, const uint64_t *rec_off, const uint64_t *want_rec,
+#ifndef PSK_GZ_COPY_WAVES
+#define PSK_GZ_COPY_WAVES 5   // waves a SIMD the register budget allows (r05: 94 VGPRs = 5)
+#endif
+__global__ __launch_bounds__(256, PSK_GZ_COPY_WAVES) void gz_copy_kernel(uint16_t *sym, const uint2 *rec, const uint64_t *rec_off, const uint64_t *want_rec,
                                                        const uint64_t *got_rec, const int32_t *link, const uint64_t *want_len,
                                                        const uint64_t *out_off, int n_chunks, unsigned long long *stats)
 {
@@ -910,172 +917,6 @@ __global__ __launch_bounds__(256) void gz_copy_kernel(uint16_t *sym, const uint2
             done |= __ballot(ready);
         }
         x = nx;
-    }
-}
-
-// ---- step 4b, r06: the same through a window in LDS ---------------------------------------------------------------------------------
-// r05's kernel above reads every match's source from global memory: a chunk's 64 KB of window is one of tens of thousands in
-// flight, so no line survives in a cache between two matches that touch it -- 86 GB fetched to copy 18 GB of symbols
-// (profiles/r05_gzinflate_pmc.csv), the wave parked on memory 78 % of its cycles.  Here ONE wave owns a chunk and a ring of its
-// text in LDS: GZC_WIN symbols of history (a match reaches back at most 32,768) + GZC_SPAN for the matches in hand + room to fill
-// ahead.  Literals stream into the ring in 16-byte pieces, the matches -- 64 at a time, dependencies resolved as above -- copy
-// ring to ring, finished text streams out in 16-byte pieces: every symbol crosses the memory system once in, once out.
-constexpr uint32_t GZC_WIN = 32768, GZC_SPAN = 4096, GZC_FILL = 1024;
-constexpr uint32_t GZC_R = GZC_WIN + GZC_SPAN + 2 * GZC_FILL;   // 38,912 symbols = 76 KB: two chunks a CU
-constexpr size_t GZC_LDS = (size_t)GZC_R * 2 + 64 * (4 + 4 + 4 + 8);
-
-__global__ __launch_bounds__(64) void gz_copy_lds_kernel(uint16_t *sym, const uint2 *rec, const uint64_t *rec_off, const uint64_t *want_rec,
-                                                          const uint64_t *got_rec, const int32_t *link, const uint64_t *want_len,
-                                                          const uint64_t *out_off, int n_chunks)
-{
-    extern __shared__ uint16_t gzc_lds[];
-    uint16_t *ring = gzc_lds;                                              // position p of the chunk's text: ring[p % GZC_R]
-    long long *g_s = reinterpret_cast<long long *>(ring + GZC_R);          // the 64 matches in hand (see gz_copy_kernel)
-    uint32_t *g_d = reinterpret_cast<uint32_t *>(g_s + 64), *g_e = g_d + 64, *g_ld = g_e + 64;
-    const int lane = threadIdx.x, c = blockIdx.x;
-    if (c >= n_chunks || link[c] == GZ_ERROR) return;
-    uint16_t *out = sym + out_off[c];
-    const uint2 *r = rec + rec_off[c];
-    const uint64_t n = got_rec[c] < want_rec[c] ? got_rec[c] : want_rec[c];
-    const uint64_t text_len = want_len[c];
-    const uint2 none = make_uint2(0xffffffffu, 0);
-    uint64_t F = 0, D = 0;   // the ring holds the text of [D, F) that is not yet written back (positions < D are out, >= F not in); multiples of 8 (F: or the end)
-    auto ring_write8 = [&](uint64_t p, const uint4 &v) { *reinterpret_cast<uint4 *>(ring + (uint32_t)(p % GZC_R)) = v; };   // (p, GZC_R multiples of 8: aligned, no wrap inside)
-    auto drain = [&](uint64_t hi) {   // text of [D, hi) back to global memory, 16 bytes a lane
-        for (uint64_t p = D + (uint64_t)lane * 8; p + 8 <= hi; p += 512) {
-            const uint4 v = *reinterpret_cast<const uint4 *>(ring + (uint32_t)(p % GZC_R));
-            __builtin_memcpy(out + p, &v, 16);
-        }
-    };
-    for (uint64_t g = 0; g < n;) {
-        const uint2 x = g + lane < n ? r[g + lane] : none;
-        const uint32_t d = x.x, len = x.y & 0xffffu, dist = x.y >> 16;
-        const bool ok = g + lane < n && dist != 0 && dist <= GZC_WIN && len != 0 && (uint64_t)d + len <= text_len;
-        const uint32_t d0 = (uint32_t)__builtin_amdgcn_readfirstlane((int)d);
-        // the matches of this round: the leading ones that end within GZC_SPAN of the first one's start (ascending, as the decoder
-        // wrote them; a record that is not -- only a damaged file has one -- is left out, as is everything behind the first that does not fit)
-        const bool fits = ok && d >= d0 && (uint64_t)d + len - d0 <= GZC_SPAN;
-        const uint64_t stop = __ballot(g + lane < n && !fits);
-        const int take = stop ? ((stop & 1ull) ? 1 : __ffsll((long long)stop) - 1) : (int)(n - g < 64 ? n - g : 64);
-        const bool valid = fits && lane < take;
-        uint32_t end = valid ? d + len : 0;
-        for (int o = 32; o; o >>= 1) {
-            const uint32_t t = (uint32_t)__shfl_xor((int)end, o, 64);
-            end = t > end ? t : end;
-        }
-        if (!__ballot(valid)) {
-            g += (uint64_t)take;
-            continue;
-        }
-        // ---- what is final goes out, what the round reads and writes comes in -----------------------------------------------------------------
-        {
-            const uint64_t before = (uint64_t)(d0 & ~7u);   // everything in front of the first match in hand is final
-            const uint64_t hi = before < F ? before : F;
-            if (hi > D) {
-                drain(hi);
-                D = hi;
-            }
-            const uint64_t need_from = d0 > GZC_WIN ? (uint64_t)((d0 - GZC_WIN) & ~7u) : 0;
-            if (need_from > F) D = F = need_from;   // (a stretch of literals longer than the window: nobody reads its middle; it is in place already)
-            uint64_t fill_to = ((uint64_t)end + GZC_FILL - 1) & ~(uint64_t)(GZC_FILL - 1);
-            if (fill_to > text_len) fill_to = text_len;
-            for (uint64_t p = F + (uint64_t)lane * 8; p < fill_to; p += 512) {
-                uint4 v;
-                __builtin_memcpy(&v, out + p, 16);
-                ring_write8(p, v);
-            }
-            if (fill_to > F) F = fill_to;
-        }
-        __builtin_amdgcn_wave_barrier();
-        // ---- the dependencies among the round's matches (gz_copy_kernel's reasoning) ------------------------------------------------------
-        int64_t s = (int64_t)d - (int64_t)dist;
-        const int64_t span = len < dist ? len : dist;
-        uint64_t dep = 0;
-        if (__ballot(valid && s + span > (int64_t)d0)) {
-            g_d[lane] = valid ? d : 0xffffffffu;
-            g_e[lane] = valid ? d + len : 0xffffffffu;
-            g_ld[lane] = x.y;
-            g_s[lane] = s;
-            __builtin_amdgcn_wave_barrier();
-            auto first_ending_behind = [&](int64_t from) {
-                int lo = -1, hi = lane;
-                while (hi - lo > 1) {
-                    const int mid = (lo + hi) >> 1;
-                    if ((int64_t)g_e[mid] > from) hi = mid;
-                    else lo = mid;
-                }
-                return hi;
-            };
-            for (int hop = 0; hop < 64; hop++) {
-                bool moved = false;
-                if (valid && s >= (int64_t)d0) {
-                    const int i = first_ending_behind(s);
-                    if (i < lane) {
-                        const uint32_t di = g_d[i], ldi = g_ld[i], li = ldi & 0xffffu, disti = ldi >> 16;
-                        if ((int64_t)di <= s && s + span <= (int64_t)di + li && disti >= li) {
-                            s = g_s[i] + (s - (int64_t)di);
-                            moved = true;
-                        }
-                    }
-                }
-                if (!__ballot(moved)) break;
-                if (moved) g_s[lane] = s;
-                __builtin_amdgcn_wave_barrier();
-            }
-            const int64_t e = s + span;
-            if (valid && e > (int64_t)d0) {
-                const int i0 = first_ending_behind(s);
-                if (i0 < lane && (int64_t)g_d[i0] < e) {
-                    int lo = i0, hi = lane;
-                    while (hi - lo > 1) {
-                        const int mid = (lo + hi) >> 1;
-                        if ((int64_t)g_d[mid] < e) lo = mid;
-                        else hi = mid;
-                    }
-                    dep = ((lo == 63 ? 0ull : (1ull << (lo + 1))) - 1ull) & ~((1ull << i0) - 1ull);
-                }
-            }
-        }
-        // ---- the copies: ring to ring, a symbol a step; a source in front of the chunk is a marker; an overlapping match repeats its first `dist` symbols
-        uint64_t done = ~__ballot(valid);
-        // (a redirected source may lie further back than the window -- but never behind D's predecessor in the ring: it is text some match
-        // of THIS round copies from, i.e. at most GZC_WIN behind that match)
-        const uint32_t rs0 = (uint32_t)(((s % (int64_t)GZC_R) + (int64_t)GZC_R) % (int64_t)GZC_R), rd0 = (uint32_t)(d % GZC_R);   // (rs0 = s mod R also for a source in front of the chunk: the ring index follows `at` across 0)
-        while (~done) {
-            const bool ready = !((done >> lane) & 1) && (dep & ~done) == 0;
-            uint32_t longest = ready ? len : 0;
-            for (int o = 32; o; o >>= 1) {
-                const uint32_t t = (uint32_t)__shfl_xor((int)longest, o, 64);
-                longest = t > longest ? t : longest;
-            }
-            uint32_t rs = rs0, rd = rd0, k = 0;
-            int64_t at = s;
-            for (uint32_t j = 0; j < longest; j++) {
-                if (ready && j < len) {
-                    const uint16_t v = at < 0 ? (uint16_t)(256 + (int64_t)GZ_WIN + at) : ring[rs];
-                    ring[rd] = v;
-                    rd = rd + 1 == GZC_R ? 0 : rd + 1;
-                    k++;
-                    at++;
-                    rs = rs + 1 == GZC_R ? 0 : rs + 1;
-                    if (k == dist) {   // (only an overlapping match gets here before it ends)
-                        k = 0;
-                        at = s;
-                        rs = rs0;
-                    }
-                }
-            }
-            __builtin_amdgcn_wave_barrier();   // (one wave's DS instructions execute in order: what this round wrote, the next one reads)
-            done |= __ballot(ready);
-        }
-        g += (uint64_t)take;
-    }
-    // what is still in the ring
-    const uint64_t hi = F < text_len ? F : text_len;
-    if (hi > D) {
-        drain(hi);
-        const uint64_t whole = D + ((hi - D) & ~(uint64_t)7);
-        for (uint64_t p = whole + lane; p < hi; p += 64) out[p] = ring[(uint32_t)(p % GZC_R)];
     }
 }
 
@@ -1942,15 +1783,8 @@ int gz_inflate_group(psk_ctx *ctx, int n, const uint8_t *const *data, const size
             PSK_HIP(ctx, hipMalloc(reinterpret_cast<void **>(&d_stats), 64));
             PSK_HIP(ctx, hipMemsetAsync(d_stats, 0, 64, st));
         }
-        if (d_stats || std::getenv("PSK_GZ_COPY_GLOBAL")) {   // (r05's kernel: the A/B knob, and the one that counts its rounds)
-            gz_copy_kernel<<<dim3((unsigned)div_up((uint64_t)m, 4)), dim3(256), 0, st>>>(d_sym, d_rec, a.rec_off, a.want_rec, a.n_rec, a.link,
-                                                                                       a.want_len, d_off, (int)m, d_stats);
-        } else {
-            static PerDeviceOnce lds_set;
-            if (lds_set.first(ctx->device))
-                PSK_HIP(ctx, hipFuncSetAttribute(reinterpret_cast<const void *>(gz_copy_lds_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)GZC_LDS));
-            gz_copy_lds_kernel<<<dim3((unsigned)m), dim3(64), GZC_LDS, st>>>(d_sym, d_rec, a.rec_off, a.want_rec, a.n_rec, a.link, a.want_len, d_off, (int)m);
-        }
+        gz_copy_kernel<<<dim3((unsigned)div_up((uint64_t)m, 4)), dim3(256), 0, st>>>(d_sym, d_rec, a.rec_off, a.want_rec, a.n_rec, a.link,
+                                                                                   a.want_len, d_off, (int)m, d_stats);
         PSK_HIP(ctx, hipGetLastError());
         if (d_stats) {
             unsigned long long hs[8];

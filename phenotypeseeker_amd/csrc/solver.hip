@@ -584,7 +584,7 @@ int check_fit_args(psk_ctx *ctx, const void *X, const void *y, int n, int p, con
     return PSK_OK;
 }
 
-// The PSK_* variables that pick kernel forms (DESIGN.md section 8, A/B runs and tests): a flag counts when it is set to
+// The PSK_* variables that pick kernel forms (docs/KNOBS.md: A/B runs and tests): a flag counts when it is set to
 // anything but "" or "0"; an integer must parse completely and lie in its range -- atoi() made 0 of garbage and took any
 // number, and a forced register form narrower than the design or a negative CG count are reachable from a user's shell.
 bool env_flag(const char *name)

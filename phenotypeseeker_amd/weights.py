@@ -13,7 +13,7 @@
 Parity: sketches and distances are pinned against the bundled mash binary
 (tests/golden/mash.json).  Biopython 1.76 / ete3 3.1.1 are not installed in the build container,
 so the tree step is restated from their documented behaviour: PARITY UNPINNED for nj + newick
-rounding (DESIGN.md section 6).
+rounding (DESIGN.md section 5).
 """
 import math
 

@@ -3,7 +3,7 @@ the distance-matrix plumbing and the GSC recursion against what the REFERENCE'S 
 (tests/golden/gsc_kat.json: modeling.py:415-444 and :461-503 run through oracle/ref_shim.py, generator
 oracle/gen_golden.py::gen_gsc_kat); neighbour joining against the oracle's plain O(n^3) restatement (orc_nj) --
 Biopython / ete3 themselves are absent, so the joins' tie-breaking, the "%1.5f" newick text and the parser's defaults
-stay PARITY UNPINNED (DESIGN.md section 6)."""
+stay PARITY UNPINNED (DESIGN.md section 5)."""
 import base64
 import gzip
 import json
