@@ -37,6 +37,7 @@
 #include "dev_utils.h"
 #include "psk_internal.h"
 
+#include <sys/mman.h>
 #include <zlib.h>
 
 #include <algorithm>
@@ -750,10 +751,9 @@ constexpr int GZ_COPY_WIDE = 2;   // 16-byte pieces a lane has in flight
 // what lies behind them is an earlier group's data or uninitialised memory: such a chunk is not copied at all, no
 // chunk copies more records than its pass wrote, and a record that would write outside its chunk's text is dropped whatever
 // wrote it (its file then fails the check sum and goes to zlib).
-#ifndef PSK_GZ_COPY_WAVES
-#define PSK_GZ_COPY_WAVES 5   // waves a SIMD the register budget allows (r05: 94 VGPRs = 5)
-#endif
-__global__ __launch_bounds__(256, PSK_GZ_COPY_WAVES) void gz_copy_kernel(uint16_t *sym, const uint2 *rec, const uint64_t *rec_off, const uint64_t *want_rec,
+// (r06, same question from the other side: forcing the register budget down to 6 / 8 waves a SIMD -- 80 / 64 VGPRs with 64 / 128 bytes
+// of scratch a lane -- made it slower too: 48.6 -> 51.8 / 57.1 ms.)
+__global__ __launch_bounds__(256) void gz_copy_kernel(uint16_t *sym, const uint2 *rec, const uint64_t *rec_off, const uint64_t *want_rec,
                                                        const uint64_t *got_rec, const int32_t *link, const uint64_t *want_len,
                                                        const uint64_t *out_off, int n_chunks, unsigned long long *stats)
 {
@@ -1887,6 +1887,20 @@ void gz_release_device(psk_ctx *ctx)
 void gz_release_host(psk_ctx *ctx, bool wait)
 {
     const bool trace = std::getenv("PSK_TRACE") != nullptr;
+    {
+        const auto m0 = std::chrono::steady_clock::now();
+        size_t bytes = 0;
+        for (auto &set : ctx->gz_maps) {
+            for (auto &m : set) {
+                munmap(m.first, m.second);
+                bytes += m.second;
+            }
+            set.clear();
+        }
+        if (trace && bytes)
+            std::fprintf(stderr, "[psk] gz release: %.1f GB of mapped .gz files unmapped in %.1f ms\n", bytes / 1e9,
+                         std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - m0).count());
+    }
     if (ctx->gz_reaper.joinable()) ctx->gz_reaper.join();
     uint8_t *gone[2] = {ctx->gz_host[0], ctx->gz_host[1]};
     size_t host_bytes = 0;

@@ -7,6 +7,10 @@
 //                                slab filter, per-wave LDS compaction + one reservation per wave
 //          dev_radix_sort_u64    LSD radix sort on the 2k significant bits
 //          rle_* kernels         run heads -> unique words + u32 frequencies
+#include <fcntl.h>
+#include <sys/mman.h>
+#include <sys/stat.h>
+#include <unistd.h>
 #include "dev_utils.h"
 #include "psk_internal.h"
 
@@ -1431,9 +1435,36 @@ static int count_batch_impl(psk_ctx *ctx, int first_sample_idx, int n, const uin
     };
     // (up != nullptr: the device buffer of the run's images; file j of the run goes to up + at[j] as soon as it has been read)
     auto read_images = [&](Run &r, uint8_t *up, const uint64_t *at) -> int {
+        // r06: a .gz FILE is not read into host memory of the library's own any more -- it is MAPPED (read-only, private), the upload
+        // copies out of the mapping (the page cache's pages: no fresh anonymous pages to fault in, 0.3 s per 2 GB), and what the host
+        // itself reads of an image -- member headers, trailers, the whole of a file the device declines -- it reads there too.  Giving 5.2 GB
+        // of such buffers back cost psk_build_presence 0.5 s of cfg5gz's 2.3 s (on a helper thread the same half second was spent by
+        // whoever next touched the address space); an unmapped file gives no page back.  PSK_GZ_READ=1: r05's buffers (and what a
+        // file that cannot be mapped gets).
+        const bool map_files = !getenv("PSK_GZ_READ");
+        std::vector<std::pair<void *, size_t>> &maps = ctx->gz_maps[r.set];
+        for (auto &m : maps) munmap(m.first, m.second);   // (the run before last of this set: inflated and counted)
+        maps.clear();
         size_t need = 0;
-        for (int i : r.idx)
-            if (!(bytes && bytes[i])) need += (lens[i] + 63) & ~(size_t)63;
+        std::vector<char> mapped((size_t)n, 0);
+        for (int i : r.idx) {
+            if (bytes && bytes[i]) continue;
+            if (map_files && lens[i]) {
+                const int fd = open(paths[i], O_RDONLY | O_CLOEXEC);
+                struct stat sb;
+                void *m = MAP_FAILED;
+                if (fd >= 0 && fstat(fd, &sb) == 0 && (size_t)sb.st_size >= lens[i]) m = mmap(nullptr, lens[i], PROT_READ, MAP_PRIVATE, fd, 0);
+                if (fd >= 0) close(fd);
+                if (m != MAP_FAILED) {
+                    (void)madvise(m, lens[i], MADV_SEQUENTIAL);
+                    maps.push_back({m, lens[i]});
+                    held[(size_t)i] = static_cast<uint8_t *>(m);
+                    mapped[(size_t)i] = 1;
+                    continue;
+                }
+            }
+            need += (lens[i] + 63) & ~(size_t)63;
+        }
         uint8_t *&host = ctx->gz_host[r.set];
         size_t &cap = ctx->gz_host_cap[r.set];
         if (need > cap) {
@@ -1446,7 +1477,7 @@ static int count_batch_impl(psk_ctx *ctx, int first_sample_idx, int n, const uin
         }
         size_t used = 0;
         for (int i : r.idx)
-            if (!(bytes && bytes[i])) {
+            if (!(bytes && bytes[i]) && !mapped[(size_t)i]) {
                 held[(size_t)i] = host + used;
                 used += (lens[i] + 63) & ~(size_t)63;
             }
@@ -1459,6 +1490,10 @@ static int count_batch_impl(psk_ctx *ctx, int first_sample_idx, int n, const uin
                 const int i = r.idx[(size_t)j];
                 if (bytes && bytes[i]) {
                     if (up && lens[i] && hipMemcpyAsync(up + at[j], bytes[i], lens[i], hipMemcpyHostToDevice, ctx->gz_up_stream) != hipSuccess) up_failed = 1;
+                    continue;
+                }
+                if (mapped[(size_t)i]) {
+                    if (up && lens[i] && hipMemcpyAsync(up + at[j], held[(size_t)i], lens[i], hipMemcpyHostToDevice, ctx->gz_up_stream) != hipSuccess) up_failed = 1;
                     continue;
                 }
                 FILE *f = fopen(paths[i], "rb");

@@ -9,6 +9,7 @@
 #include <cstring>
 #include <string>
 #include <thread>
+#include <utility>
 #include <vector>
 
 #include "../../include/psk.h"
@@ -153,6 +154,7 @@ struct psk_ctx {
     // 0.3 s per 2 GB); given back by psk_build_presence and psk_free.
     uint8_t *gz_host[2] = {nullptr, nullptr};
     size_t gz_host_cap[2] = {0, 0};
+    std::vector<std::pair<void *, size_t>> gz_maps[2];   // r06: .gz FILES are mapped, not read into gz_host (which in-memory callers and unmappable files still use)
     std::thread gz_reaper;   // gives gz_host back off the caller's critical path (gz_release: 5 GB of host pages took 0.56 s to unmap)
     DevBuf gz_comp[2], gz_out[2], gz_sym, gz_rec, gz_tab;
     hipStream_t gz_stream = nullptr, gz_up_stream = nullptr;   // the inflate's kernels; the uploads of the run after it
