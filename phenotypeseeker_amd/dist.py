@@ -153,6 +153,20 @@ def _private_dir(path):
     return path
 
 
+def _launcher_wide_tag():
+    """A tag for the id / status files of a caller-supplied rendezvous directory when PSK_LAUNCH_NONCE is not given: made only of
+    what is THE SAME on every rank of one launch and differs between launches; "" when nothing of the kind exists."""
+    env = os.environ
+    clean = lambda t: "".join(c if c.isalnum() else "_" for c in t)   # noqa: E731
+    if env.get("TORCHELASTIC_RUN_ID") and env.get("TORCHELASTIC_RUN_ID") != "none":
+        return clean("te_%s_%s" % (env["TORCHELASTIC_RUN_ID"], env.get("TORCHELASTIC_RESTART_COUNT", "0")))
+    if env.get("SLURM_JOB_ID"):
+        return clean("sl_%s_%s" % (env["SLURM_JOB_ID"], env.get("SLURM_STEP_ID", "0")))
+    if env.get("LOCAL_WORLD_SIZE") and env.get("LOCAL_WORLD_SIZE") == env.get("WORLD_SIZE"):
+        return clean("pp_%d_%s" % (os.getppid(), _parent_start_ticks()))
+    return ""
+
+
 def _rendezvous():
     """(directory, nonce) where the ranks of THIS launch meet.
       * PSK_RDZV_DIR + PSK_LAUNCH_NONCE: set by this package's own launcher (launch.spawn_ranks): a mkdtemp directory
@@ -170,6 +184,13 @@ def _rendezvous():
     # the parent's pid + start time made such ranks reject each other's files until the timeout).  So there the tag every
     # id / status file carries is PSK_LAUNCH_NONCE as given -- empty when the caller gives none, who then promises that the
     # directory is fresh for this launch (a leftover rd./st. file of a crashed launch under the same names WOULD be read)
+    # (with no nonce given, a tag is still derived where something launcher-wide and equal on every rank exists -- the
+    # elastic launcher's run id + restart count, Slurm's job + step id, or, when every rank of the job is a child of one launcher on
+    # this node (LOCAL_WORLD_SIZE == WORLD_SIZE: torchrun with a fixed PSK_RDZV_DIR, the common case), that parent's pid + start
+    # time -- so that a rank never reads the unique id a crashed earlier launch left under the same names; only ranks with none of
+    # these keep the empty tag and the promise of a fresh directory)
+    if not nonce:
+        nonce = _launcher_wide_tag()
     d = os.environ.get("PSK_RDZV_DIR")
     if d:
         return _private_dir(d), nonce

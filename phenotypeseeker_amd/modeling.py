@@ -956,7 +956,6 @@ def modeling(args):
             _err(GREEN % "Generating the k-mer lists for input samples:" + "\n")
             n_thr = max(1, min(int(Input.num_threads), 8))
             ph_t.enter("ingest: k-mer lists")
-            ph_t.enter("ingest: k-mer lists")
             t_lists = time.time()
             # several ranks: the list exchange when the collectives run GPU to GPU (RCCL); with the host transport of the tests they are
             # staged through the host (7 GB through TCP loopback for 2 x 128 genomes: 5.7 s against 0.12 s), so

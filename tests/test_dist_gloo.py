@@ -431,3 +431,32 @@ def test_a_rank_of_an_outside_launcher_keeps_the_deadline_itself(tmp_path):
         rec = json.load(f)
     assert rec["stuck_in"] == "scan" and rec["blocked_in_call"] == "all-gather (rccl, 8 ranks)" and rec["world"] == 8
     assert rec["phases_s"] == {"ingest": 0.5} and "deadline of 2 s passed" in r.stderr or "deadline of 1 s passed" in r.stderr
+
+
+def test_a_supplied_rendezvous_directory_gets_a_launcher_wide_tag_where_one_exists(monkeypatch, tmp_path):
+    """PSK_RDZV_DIR without PSK_LAUNCH_NONCE used to mean an EMPTY tag on the id / status files -- a rank of the next
+    launch could read the RCCL unique id a crashed launch left there.  Now the tag is made of what is equal on every rank of one
+    launch and differs between launches, when there is such a thing: the elastic launcher's run id + restart count, Slurm's job +
+    step, or the common parent when all ranks of the job are children of one launcher on this node; else it stays empty (ranks of
+    different parents: the test above)."""
+    from phenotypeseeker_amd import dist
+    for var in ("PSK_LAUNCH_NONCE", "PSK_RDZV_FILE", "TORCHELASTIC_RUN_ID", "TORCHELASTIC_RESTART_COUNT", "SLURM_JOB_ID", "SLURM_STEP_ID",
+                "LOCAL_WORLD_SIZE", "WORLD_SIZE"):
+        monkeypatch.delenv(var, raising=False)
+    monkeypatch.setenv("PSK_RDZV_DIR", str(tmp_path / "meet"))
+    assert dist._rendezvous() == (str(tmp_path / "meet"), "")
+    monkeypatch.setenv("WORLD_SIZE", "8")
+    monkeypatch.setenv("LOCAL_WORLD_SIZE", "4")                     # two nodes: no common parent
+    assert dist._rendezvous()[1] == ""
+    monkeypatch.setenv("LOCAL_WORLD_SIZE", "8")                     # every rank a child of this node's launcher
+    tag = dist._rendezvous()[1]
+    assert tag.startswith("pp_%d_" % os.getppid()) and tag == dist._rendezvous()[1]
+    monkeypatch.setenv("SLURM_JOB_ID", "4711")
+    monkeypatch.setenv("SLURM_STEP_ID", "2")
+    assert dist._rendezvous()[1] == "sl_4711_2"
+    monkeypatch.setenv("TORCHELASTIC_RUN_ID", "run-a")
+    assert dist._rendezvous()[1] == "te_run_a_0"
+    monkeypatch.setenv("TORCHELASTIC_RESTART_COUNT", "3")           # a restarted gang must not meet the files of the attempt before
+    assert dist._rendezvous()[1] == "te_run_a_3"
+    monkeypatch.setenv("PSK_LAUNCH_NONCE", "given")                 # what the caller gives wins
+    assert dist._rendezvous()[1] == "given"

@@ -217,7 +217,9 @@ elif what == "cfg5gz":
         with open(os.path.join(tmp, "data.pheno"), "w") as f:
             f.write("ID\tAddresses\tPheno\n" + "".join("%s\t%s\t%d\n" % (gs.name(i), os.path.basename(made[i][1]), gs.phenotype(i)) for i in range(n)))
         walls = {}
-        for route in ("device", "device_again", "r04_python_pool"):
+        # r06: `cfg5gz N READS 12288,6144,4096` = the device route at these run sizes (PSK_GZ_GROUP_MB) instead of the three routes
+        groups = [g for g in (sys.argv[4].split(",") if len(sys.argv) > 4 else []) if g]
+        for route in (["device_g" + g for g in groups] if groups else ["device", "device_again", "r04_python_pool"]):
             d = os.path.join(tmp, route)
             os.mkdir(d)
             for m in made:
@@ -226,6 +228,9 @@ elif what == "cfg5gz":
             os.chdir(d)
             if route == "r04_python_pool":
                 os.environ["PSK_NO_GPU_GZ"] = "1"
+            if route.startswith("device_g"):
+                os.environ["PSK_GZ_GROUP_MB"] = route[len("device_g"):]
+                time.sleep(8)      # (the driver clears what the run before held: hipMalloc waits for that)
             args = build_parser().parse_args(["modeling", "data.pheno", "-l", "13", "--num_threads", "16"])
             t0 = time.time()
             try:
@@ -234,6 +239,7 @@ elif what == "cfg5gz":
                 pass
             walls[route] = round(time.time() - t0, 2)
             os.environ.pop("PSK_NO_GPU_GZ", None)
+            os.environ.pop("PSK_GZ_GROUP_MB", None)
             try:
                 with open("phases_rank0.json") as f:
                     walls[route + "_phases"] = {k_: round(v, 3) for k_, v in json.load(f)["phases_s"].items() if v >= 0.01}
@@ -247,7 +253,8 @@ elif what == "cfg5gz":
                     return f.read()
             except OSError:
                 return None
-        same = table("device") is not None and table("device") == table("r04_python_pool")
+        same = (table("device") is not None and table("device") == table("r04_python_pool")) if not groups else \
+            all(table("device_g" + g) is not None and table("device_g" + g) == table("device_g" + groups[0]) for g in groups)
         out["notes"] = {"samples": n, "reads_per_sample": reads, "text_bytes": sum(m[2] for m in made), "gz_bytes": sum(m[3] for m in made),
                         "made_in_s": round(t_make, 1), "modeling_wall_s": walls, "chi2_tables_identical": same}
     finally:
