@@ -87,7 +87,7 @@ int psk_count_kmers_files(psk_ctx *ctx, int first_sample_idx, int n, const char 
                           uint32_t sketch_seed, uint64_t *hashes_out, uint64_t *n_hashes_out);
 /* .gz inputs ("FASTA/FASTQ(.gz)", glistmaker's zlib reader: SURVEY.md section 2 row 9).  psk_count_kmers /
  * psk_count_kmers_batch / psk_count_kmers_files take a gzip image (magic bytes 1f 8b) as it is: the compressed bytes
- * cross PCIe and DEFLATE is decoded on the device (csrc/gz_inflate.hip) -- all .gz samples of a call together, 12 GiB of text
+ * cross PCIe and DEFLATE is decoded on the device (csrc/gz_inflate.hip) -- all .gz samples of a call together, 8 GiB of text
  * at a time (PSK_GZ_GROUP_MB); a group of so few small files that zlib would be faster (the device route has a floor of ~40 ms) and a member the device
  * route declines go through zlib on the call's host threads.  This entry point is the inflate on its own -- tests and measurements: n gzip images ->
  * their text (out[i], of capacity out_cap[i], may be NULL: lengths only).  route[i]: 1 decoded on the device, 2 the same,

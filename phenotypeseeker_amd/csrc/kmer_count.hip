@@ -1344,7 +1344,7 @@ static int count_batch_core(psk_ctx *ctx, int first_sample_idx, int n, const uin
 
 // The batch as the entry points hand it over.  Samples that are gzip images (magic bytes; glistmaker reads .gz through zlib:
 // SURVEY.md section 2 row 9) are inflated on the device first (gz_inflate.hip) -- every .gz sample of a run in one go, runs
-// cut where the text would pass PSK_GZ_GROUP_MB (12 GiB: ~2 GB of compressed input is what fills the part's 65,536 decoding lanes) -- and their chains then start from text that is already in device
+// cut where the text would pass PSK_GZ_GROUP_MB (8 GiB -- r06; ~1.5 GB of compressed input, 65,536 decoding lanes of 23 KB each: with r05's 12 GiB the inflate's buffers were 70 GB, and what a hipMalloc beyond the first ~40 GB of a process costs on this pool -- 20-30 ms per GB, tools/free_probe.py -- made 64 read sets take 2.1 s to the .pkl where 8-GiB runs take 1.27, 6-GiB 1.4, 4-GiB 1.56: profiles/r06_cfg5gz_groups.json) -- and their chains then start from text that is already in device
 // memory; a member the device route declines has been inflated by zlib on the host and goes on as an in-memory sample.
 static int count_batch_impl(psk_ctx *ctx, int first_sample_idx, int n, const uint8_t *const *bytes, const char *const *paths,
                             const size_t *lens, uint64_t *n_unique, uint64_t *n_total, int n_threads, int sketch_k,
@@ -1380,7 +1380,7 @@ static int count_batch_impl(psk_ctx *ctx, int first_sample_idx, int n, const uin
     if (!ctx->gz_stream) PSK_HIP(ctx, hipStreamCreateWithFlags(&ctx->gz_stream, hipStreamNonBlocking));
     if (!ctx->gz_up_stream) PSK_HIP(ctx, hipStreamCreateWithFlags(&ctx->gz_up_stream, hipStreamNonBlocking));
     const char *gm = getenv("PSK_GZ_GROUP_MB");
-    const size_t budget = (size_t)(gm && *gm ? strtoull(gm, nullptr, 10) : 12288) << 20;
+    const size_t budget = (size_t)(gm && *gm ? strtoull(gm, nullptr, 10) : 8192) << 20;
     const bool host_only = getenv("PSK_HOST_FRAMING") != nullptr;   // (the A/B knob of the host's state machine: the host's inflate with it)
     const bool trace = getenv("PSK_TRACE") != nullptr;
     std::vector<uint8_t *> held((size_t)n, nullptr);   // where the compressed image of a .gz FILE is (a slice of ctx->gz_host[set])

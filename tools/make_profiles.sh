@@ -8,7 +8,7 @@
 #   WRITE_SIZE are derived from (how many requests, how many of them short), hit = L2 hits / misses, lds = the SQ's LDS
 #   counters (bank-conflict cycles, LDS-active cycles, LDS instructions, issue stalls on the LDS) with the wave-cycle split
 set -u
-TAG=${1:-r05}
+TAG=${1:-r06}
 shift || true
 ONLY="$*"
 ROOT=${GRAFT_REPO_ROOT:-$PWD}
@@ -44,6 +44,7 @@ prof ingest "fetch write rdreq wrreq" python3 "$ROOT/tools/profile_workloads.py"
 prof cfg3slab "fetch write rdreq wrreq" python3 "$ROOT/tools/profile_workloads.py" cfg3slab
 prof moments "fetch write lds" python3 "$ROOT/tools/profile_workloads.py" moments
 prof fastq "" python3 "$ROOT/tools/profile_workloads.py" fastq
+prof fastqwrapped "" python3 "$ROOT/tools/profile_workloads.py" fastqwrapped           # r06: FASTQ that is not four lines a record, device against host framing
 prof gzinflate "fetch write lds" python3 "$ROOT/tools/gz_bench.py" fastq 64 128 6 3 noverify          # r05: 64 x 144 MB of .fastq.gz text inflated on the device
 prof cfg5gz "" python3 "$ROOT/tools/profile_workloads.py" cfg5gz 64                      # ... and `phenotypeseeker modeling` on 64 of them, end to end (two minutes of generating first)
 prof fastqgz "" python3 "$ROOT/tools/profile_workloads.py" fastqgz 16                   # ... and 16 config-5 samples counted from .fastq.gz files

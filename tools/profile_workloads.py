@@ -4,6 +4,7 @@
              sort of bucket_count.hip); 10 scans of the 6-GB matrix (well beyond the 256-MiB Infinity Cache)
   moments    the f64 scans on a device-generated 16 M x 1024 matrix: Welch t, GSC-weighted chi2, weighted Welch t
   fastq      one config-5 sample: 2 M x 150-bp reads, 0.63 GB of FASTQ, framed and counted
+  fastqwrapped r06: that sample with its lines wrapped at 60 columns: the device's scan of line kinds against the host's state machine
   fastqgz    r05: N (default 16) config-5 samples as .fastq.gz files: counted from plain files, from the .gz files (inflated on the
              device), the inflate alone, zlib on one host thread beside it
   cfg5gz     r05: `phenotypeseeker modeling` on N (default 64) config-5 read sets as .fastq.gz files, with the device inflate and with
@@ -150,6 +151,41 @@ elif what == "fastq":
         alg["dc_hist_kernel"] = clean
         alg["dc_partition_kernel"] = clean + 2 * int(nt[0])
         alg["dc_count_kernel"] = 2 * int(nt[0]) + (1 << 26) // 8
+elif what == "fastqwrapped":
+    # r06: the same config-5 sample with its sequence and quality lines wrapped at 60 columns -- FASTQ that is not four lines a record:
+    # framed on the device by the scan of line kinds (frame_gpu.hip, format 3) against r05's route (PSK_HOST_WRAPPED_FASTQ=1: the host's
+    # state machine) and against the four-line file; the lists are equal by construction of the file only where the machine's quirk (the
+    # first byte of a continued sequence line is swallowed) allows -- so the wrapped file is compared with ITSELF on the two routes
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    from test_gpu_configs import _fastq_sample
+    gs = GenomeSet(1, 5_000_000, seed=99)
+    data = _fastq_sample(gs.codes(0), 2_000_000, 150, seed=[5, 0])
+    lines = data.split(b"\n")
+    wrapped = bytearray()
+    for q in range(0, len(lines) - 3, 4):
+        h, sq, pl, ql = lines[q:q + 4]
+        wrapped += h + b"\n" + sq[:60] + b"\n" + sq[60:120] + b"\n" + sq[120:] + b"\n" + pl + b"\n" + ql[:60] + b"\n" + ql[60:120] + b"\n" + ql[120:] + b"\n"
+    wrapped = bytes(wrapped)
+    res = {}
+    with PskContext(0) as ctx:
+        for label, payload, env in (("four_line", data, None), ("wrapped_device", wrapped, None), ("wrapped_host", wrapped, "PSK_HOST_WRAPPED_FASTQ")):
+            if env:
+                os.environ[env] = "1"
+            ts = []
+            for rep in range(4):
+                ctx.begin(13, 1)
+                t0 = time.time()
+                nu, nt = ctx.count_kmers_batch(0, [payload], 8)
+                ts.append(round(time.time() - t0, 4))
+            w, f = ctx.get_list(0, nu[0])
+            if env:
+                os.environ.pop(env)
+            res[label] = {"file_bytes": len(payload), "wall_s": ts, "GBps_of_file_bytes": round(len(payload) / min(ts) / 1e9, 1), "unique": int(nu[0]),
+                          "windows": int(nt[0]), "list_sha": __import__("hashlib").sha256(w.tobytes() + f.tobytes()).hexdigest()[:16]}
+    res["wrapped_routes_agree"] = res["wrapped_device"]["list_sha"] == res["wrapped_host"]["list_sha"]
+    out["notes"] = res
+    for name in ("fqg_pass_kernel",):
+        alg[name] = len(wrapped)
 elif what == "fastqgz":
     # r05: config-5 samples as sequencers ship them -- .fastq.gz.  N samples of 2 M x 150-bp reads (0.63 GB of text each,
     # qualities in runs as Illumina bins them), gzip level 6, counted from files: plain, then compressed (the images cross
@@ -219,7 +255,7 @@ elif what == "cfg5gz":
         walls = {}
         # r06: `cfg5gz N READS 12288,6144,4096` = the device route at these run sizes (PSK_GZ_GROUP_MB) instead of the three routes
         groups = [g for g in (sys.argv[4].split(",") if len(sys.argv) > 4 else []) if g]
-        for route in (["device_g" + g for g in groups] if groups else ["device", "device_again", "r04_python_pool"]):
+        for route in (["device_g%s_%d" % (g, q) for q, g in enumerate(groups)] if groups else ["device", "device_again", "r04_python_pool"]):
             d = os.path.join(tmp, route)
             os.mkdir(d)
             for m in made:
@@ -229,7 +265,7 @@ elif what == "cfg5gz":
             if route == "r04_python_pool":
                 os.environ["PSK_NO_GPU_GZ"] = "1"
             if route.startswith("device_g"):
-                os.environ["PSK_GZ_GROUP_MB"] = route[len("device_g"):]
+                os.environ["PSK_GZ_GROUP_MB"] = route[len("device_g"):].split("_")[0]
                 time.sleep(8)      # (the driver clears what the run before held: hipMalloc waits for that)
             args = build_parser().parse_args(["modeling", "data.pheno", "-l", "13", "--num_threads", "16"])
             t0 = time.time()
@@ -254,7 +290,7 @@ elif what == "cfg5gz":
             except OSError:
                 return None
         same = (table("device") is not None and table("device") == table("r04_python_pool")) if not groups else \
-            all(table("device_g" + g) is not None and table("device_g" + g) == table("device_g" + groups[0]) for g in groups)
+            all(table("device_g%s_%d" % (g, q)) is not None and table("device_g%s_%d" % (g, q)) == table("device_g%s_0" % groups[0]) for q, g in enumerate(groups))
         out["notes"] = {"samples": n, "reads_per_sample": reads, "text_bytes": sum(m[2] for m in made), "gz_bytes": sum(m[3] for m in made),
                         "made_in_s": round(t_make, 1), "modeling_wall_s": walls, "chi2_tables_identical": same}
     finally:
