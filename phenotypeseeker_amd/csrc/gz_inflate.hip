@@ -1503,7 +1503,11 @@ int gz_inflate_group(psk_ctx *ctx, int n, const uint8_t *const *data, const size
         }
     };
     // ---- steps 2 + 3: counting passes until every file's chain reaches its end ----------------------------------------
-    const uint64_t max_span_bits = (uint64_t)std::max<size_t>(chunk * 8, gz_env("PSK_GZ_MAX_SPAN", 8 << 20)) * 8;
+    // how far ONE lane may decode without meeting a found start.  A lane decodes ~1.4 MB of compressed input a second (65,536 of them:
+    // 1.9 GB in 21 ms), so this is the bound on what a file with no dynamic block headers -- stored or fixed-code blocks only, or one
+    // crafted to look so -- can cost the call before zlib gets it: 1 MiB = 0.75 s (r05: 8 MiB = 6 s, and again in every round of a
+    // file of several such members).  Blocks of the usual encoders end far sooner (zlib: tens of KB; pigz 128 KB; libdeflate <= ~300 KB).
+    const uint64_t max_span_bits = (uint64_t)std::max<size_t>(chunk * 8, gz_env("PSK_GZ_MAX_SPAN", 1 << 20)) * 8;
     std::vector<int> next_chunk((size_t)n, -1);   // per file: the chunk its chain follows next (-1: the chain has reached the end)
     for (int i = 0; i < n; i++) next_chunk[(size_t)i] = files[(size_t)i].device_ok && file_chunks[(size_t)i].second > file_chunks[(size_t)i].first ? file_chunks[(size_t)i].first : -1;
     while (!todo.empty()) {

@@ -242,3 +242,28 @@ def test_a_member_whose_text_crosses_four_gigabytes():
         fa = _text(np.random.default_rng(5), "fasta", 100_000)
         texts, _, r2, _ = ctx.gz_inflate([gzip.compress(fa, 6)])
         assert texts[0] == fa and r2 == [1]
+
+
+def test_files_without_a_dynamic_block_cost_the_call_a_bounded_time():
+    """No bound on how long a malformed member may keep a lane spinning: a member of fixed-code blocks only, one
+    of stored blocks only and one that is a single 12-MB stored-looking stretch of noise have no dynamic header for the search to
+    find -- the first chunk's lane runs on until PSK_GZ_MAX_SPAN (1 MiB: ~0.75 s of one lane) and the file goes to zlib; files of
+    five such members do not multiply that.  Texts equal zlib's, the good files among them stay on the device, the call is quick."""
+    from phenotypeseeker_amd.engine import PskContext
+    rng = np.random.default_rng(9)
+    fa = _text(rng, "fasta", 6_000_000)
+    noise = rng.integers(0, 256, 12_000_000, dtype=np.uint8).tobytes()
+    fixed = _member(fa, 6, zlib.Z_FIXED)
+    stored = _member(noise, 0)
+    many = b"".join(_member(fa[i * 1_000_000:(i + 1) * 1_000_000], 6, zlib.Z_FIXED) for i in range(5))
+    good = gzip.compress(fa[:2_000_000], 6)
+    files = [good, fixed, stored, many, gzip.compress(noise, 6), good]
+    want = [zlib_all(f) for f in files]
+    with PskContext(0) as ctx:
+        ctx.gz_inflate([good])          # (the context's first call pays the allocations)
+        t0 = time.time()
+        texts, lens, routes, device_ms = ctx.gz_inflate(files)
+        took = time.time() - t0
+    assert texts == want and routes[0] == 1 and routes[-1] == 1 and routes[1:5] == [0, 0, 0, 0], routes
+    print("files without a dynamic block: %.2f s for the call, %.0f ms on the device" % (took, device_ms))
+    assert device_ms < 4000.0 and took < 12.0, (took, device_ms)
