@@ -286,7 +286,7 @@ int psk_logreg_l2_fit(psk_ctx *ctx, const float *X, const int32_t *y01, int n, i
 int psk_count_dict(psk_ctx *ctx, const uint8_t *bytes, size_t len, int k, const uint64_t *dict_words,
                    uint64_t n_dict, uint32_t *counts_out);
 /* All samples of a prediction run against one dictionary (the Pool.map over samples of prediction.py:150-163):
- * the ingest of psk_count_kmers_batch (n_threads host threads move file bytes into pinned memory, FASTA and four-line
+ * the ingest of psk_count_kmers_batch (n_threads host threads move file bytes into pinned memory, FASTA and
  * FASTQ are framed on the GPU) with one dictionary kernel per sample and one read-back.  counts_out[n][n_dict].
  * _files: paths of UNCOMPRESSED files of sizes[i] bytes, read by the framing threads.  Any dictionary size: up to
  * 2048 words the table lives in LDS, beyond that in global memory (`--n_kmers 0` models). */
@@ -367,10 +367,9 @@ int psk_dev_copy(psk_ctx *ctx, void *dst, const void *src, uint64_t bytes, int k
  * breaks collapsed to '\n', everything else dropped).  Returns the length written (<= len), or
  * a negative code.  Exposed for tests of the tokeniser contract. */
 int64_t psk_frame_sequence(const uint8_t *bytes, size_t len, uint8_t *out, size_t out_cap);
-/* The same stream as the GPU framing kernels produce it (the batch counters frame FASTA and four-line FASTQ on the
- * device, csrc/frame_gpu.hip): identical except that runs of window breaks are not collapsed.  Returns the length
- * written; PSK_ESTATE when the input is FASTQ that is not four lines per record (the host state machine frames
- * those).  For tests of the tokeniser contract. */
+/* The same stream as the GPU framing kernels produce it (the batch counters frame FASTA and FASTQ on the device,
+ * csrc/frame_gpu.hip; r06: FASTQ that is not four lines per record too -- the scan of line kinds): identical except that
+ * runs of window breaks are not collapsed.  Returns the length written.  For tests of the tokeniser contract. */
 int64_t psk_frame_sequence_gpu(psk_ctx *ctx, const uint8_t *bytes, size_t len, uint8_t *out, size_t out_cap);
 
 #ifdef __cplusplus
