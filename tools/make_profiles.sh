@@ -36,10 +36,11 @@ prof() {   # name "pass pass ..." program args...      (the program itself after
     timeout 400 rocprofv3 --pmc $(pmc_of $p) --output-format csv -d "$d/pmc_$p" -o run -- "$@" > /dev/null 2> "$d/pmc_$p.err"
   done
 }
-BENCH="--steps 50 --warmup 5 --no-cpu-baseline"
-if wanted bench; then python3 "$ROOT/bench.py" $BENCH > "$OUT/bench_unprofiled.json" 2> "$OUT/bench_unprofiled.err"; fi
+BENCH="--steps 50 --warmup 5 --no-cpu-baseline --no-hbm-only"   # (--no-hbm-only: the headline kernel's average covers the headline matrix only; `hbmonly` below is the 4.3-GB matrix)
+if wanted bench; then python3 "$ROOT/bench.py" $BENCH 2> "$OUT/bench_unprofiled.err" | tail -1 > "$OUT/bench_unprofiled.json"; fi   # (r06: the line is printed after every leg; the last one is the record)
 prof calib "fetch write rdreq wrreq hit" "$ROOT/tools/calib/pmc_calib" 3
 prof bench "fetch write" python3 "$ROOT/bench.py" $BENCH
+prof hbmonly "fetch write" python3 "$ROOT/bench.py" --workload matrix --rows 134375000 --steps 50 --warmup 5 --no-cpu-baseline --no-hbm-only --no-e2e   # r06: the same kernel beyond the Infinity Cache
 prof ingest "fetch write rdreq wrreq" python3 "$ROOT/tools/profile_workloads.py" ingest
 prof cfg3slab "fetch write rdreq wrreq" python3 "$ROOT/tools/profile_workloads.py" cfg3slab
 prof moments "fetch write lds" python3 "$ROOT/tools/profile_workloads.py" moments

@@ -160,7 +160,7 @@ for wl in sorted(os.listdir(src)):
     with open(os.path.join(dst, "%s_%s_output.json" % (tag, wl)), "w") as f:
         json.dump(info, f, indent=1, sort_keys=True)
     alg = info.get("algorithmic_bytes_per_launch", {})
-    if wl == "bench" and info:
+    if wl in ("bench", "hbmonly") and info:
         alg = {"chi2_scan_kernel": info["roofline"]["algorithmic_bytes_per_launch"]}
     cnt = counters_of(d)
     if cnt:
@@ -190,7 +190,7 @@ for wl in sorted(os.listdir(src)):
             if cn in c:
                 rec[key] = round(c[cn][1], 1)
         table.append(rec)
-    if wl == "bench" and info:
+    if wl in ("bench", "hbmonly") and info:
         shutil.copy(os.path.join(src, "bench_unprofiled.json"), os.path.join(dst, "%s_bench_cfg2_unprofiled.json" % tag))
         scan = [k for k in cnt if k.startswith("chi2_scan_kernel") and "FETCH_SIZE" in cnt[k]]
         if scan:
