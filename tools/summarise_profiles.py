@@ -191,7 +191,8 @@ for wl in sorted(os.listdir(src)):
                 rec[key] = round(c[cn][1], 1)
         table.append(rec)
     if wl in ("bench", "hbmonly") and info:
-        shutil.copy(os.path.join(src, "bench_unprofiled.json"), os.path.join(dst, "%s_bench_cfg2_unprofiled.json" % tag))
+        if wl == "bench":
+            shutil.copy(os.path.join(src, "bench_unprofiled.json"), os.path.join(dst, "%s_bench_cfg2_unprofiled.json" % tag))
         scan = [k for k in cnt if k.startswith("chi2_scan_kernel") and "FETCH_SIZE" in cnt[k]]
         if scan:
             k = max(scan, key=lambda k_: cnt[k_]["FETCH_SIZE"][0])
@@ -199,7 +200,8 @@ for wl in sorted(os.listdir(src)):
                 sha = hashlib.sha256(f.read()).hexdigest()[:16]
             cfg = info["config"]
             fe, wr = cnt[k]["FETCH_SIZE"][1], cnt[k].get("WRITE_SIZE", (0, 0.0))[1]
-            with open(os.path.join(dst, "%s_traffic_chi2_scan.json" % tag), "w") as f:
+            # (one file per matrix: bench.py quotes the one whose rows and row width are its own)
+            with open(os.path.join(dst, "%s_traffic_chi2_scan%s.json" % (tag, "" if wl == "bench" else "_" + wl)), "w") as f:
                 json.dump({"round": int(tag[1:3]), "kernel": k, "workload": cfg["workload"], "rows": cfg["rows_per_gpu"],
                            "words_per_row_stored": cfg["words_per_row_stored"], "kernel_source_sha16": sha,
                            "FETCH_SIZE_KB_mean_per_launch": fe, "WRITE_SIZE_KB_mean_per_launch": wr,
