@@ -61,7 +61,7 @@ def measured_traffic(rows, wpr):
     (its "kernel_source_sha16" differs from the source's hash)."""
     import glob
     best = None
-    for fn in sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_traffic_chi2_scan.json"))):
+    for fn in sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_traffic_chi2_scan*.json"))):
         try:
             with open(fn) as f:
                 d = json.load(f)
@@ -641,6 +641,7 @@ def main():
         rf["hbm_only"] = {"rows": rows_big, "survivors": int(big_npass), "bytes_per_launch": b_big, "stored_bytes_per_launch": rows_big * 8 * wpr_big,
                           "kernel_ms_mean": float(np.mean(ms_big)), "kernel_ms_min": float(np.min(ms_big)), "kernel_ms_p50": p50,
                           "kernel_ms_p95": float(np.percentile(ms_big, 95)), "launches": int(len(ms_big)),
+                          "traffic": measured_traffic(rows_big, wpr_big),
                           "achieved": b_big / (float(np.mean(ms_big)) * 1e-3) / 1e9, "frac": b_big / (float(np.mean(ms_big)) * 1e-3) / 1e9 / HBM_PEAK_GBS,
                           "stream_ceiling_GBps": c_bytes / (c_ms * 1e-3) / 1e9 if c_ms > 0 else None, "stream_ceiling_kernel": c_shape,
                           "what": "the same scan over a device-generated matrix of %.1f GB (psk_synth_presence, same row width): "
