@@ -32,9 +32,16 @@ constexpr uint32_t BS_SLOTS = 32;                   // pre-zeroed counter slots 
 // barriers, and a second bucket in flight is what fills the waits (r05: the 64-bit instance held the bucket twice in 148 KB of LDS:
 // one workgroup per CU; the 32-bit one was 256 bytes over half the CU's 160 KB, so it ran alone as well).  64-bit words: 512 threads
 // (90 VGPRs: 2 x 8 waves per CU = 4 per SIMD), 32-bit: 1,024 (60 VGPRs).
+#ifndef PSK_BS_SORT32_THREADS
+#define PSK_BS_SORT32_THREADS 1024
+#endif
+#ifndef PSK_BS_SORT32_WGS
+#define PSK_BS_SORT32_WGS 2       // workgroups per CU of the 32-bit instance (49 KB of LDS each)
+#endif
 template <typename W> struct SortGeo {
-    static constexpr int THREADS = sizeof(W) == 4 ? 1024 : 512;
-    static constexpr int WAVES_PER_SIMD = sizeof(W) == 4 ? 8 : 4;   // two workgroups: what the register budget has to allow
+    static constexpr int THREADS = sizeof(W) == 4 ? PSK_BS_SORT32_THREADS : 512;
+    static constexpr int WGS_PER_CU = sizeof(W) == 4 ? PSK_BS_SORT32_WGS : 2;
+    static constexpr int WAVES_PER_SIMD = THREADS / 64 * WGS_PER_CU / 4;   // what the register budget has to allow
 };
 #ifndef PSK_BS_CAPMAX
 #define PSK_BS_CAPMAX 8128
@@ -677,7 +684,7 @@ int chain_enqueue_w(psk_ctx *ctx, CountLane &L, uint64_t clean_len, uint64_t n)
     }
     W *wtmp = L.dc_mtemp.as<W>();
     uint32_t *ctmp = reinterpret_cast<uint32_t *>(wtmp + n + 8);
-    const uint32_t resident = 2u * (uint32_t)(ctx->n_cu > 0 ? ctx->n_cu : 256);
+    const uint32_t resident = (uint32_t)SortGeo<W>::WGS_PER_CU * (uint32_t)(ctx->n_cu > 0 ? ctx->n_cu : 256);
     const uint32_t sort_wgs = ctx->bs_nb < resident ? ctx->bs_nb : resident;
     bs_sort_kernel<W><<<sort_wgs, SortGeo<W>::THREADS, bsort_lds_bytes<W>(), ctx->stream>>>(L.dc_part.as<W>(), d.cnt, d.base, ctx->bs_spl.as<W>(),
                                                                                           ctx->bs_nb, (W)(hi - 1u), bs_cap(), wtmp, ctmp, d.uniq, d.flag);
@@ -783,7 +790,7 @@ int group_enqueue_w(psk_ctx *ctx, CountLane *const *lanes, const uint64_t *clean
                                          (int)bsort_lds_bytes<W>()));
     }
     // one resident set of workgroups for the whole group (two per CU by LDS; one with 64-bit words)
-    const uint32_t wg_all = 2u * (uint32_t)(ctx->n_cu > 0 ? ctx->n_cu : 256);
+    const uint32_t wg_all = (uint32_t)SortGeo<W>::WGS_PER_CU * (uint32_t)(ctx->n_cu > 0 ? ctx->n_cu : 256);
     uint32_t per = (wg_all + (uint32_t)count - 1) / (uint32_t)count;
     if (per > ctx->bs_nb) per = ctx->bs_nb;
     if (per < 1) per = 1;
