@@ -31,12 +31,14 @@ constexpr uint32_t BS_SLOTS = 32;                   // pre-zeroed counter slots 
 // threads of a sorting workgroup.  r06: TWO workgroups per CU for either width -- a bucket's sort is a chain of short steps between
 // barriers, and a second bucket in flight is what fills the waits (r05: the 64-bit instance held the bucket twice in 148 KB of LDS:
 // one workgroup per CU; the 32-bit one was 256 bytes over half the CU's 160 KB, so it ran alone as well).  64-bit words: 512 threads
-// (90 VGPRs: 2 x 8 waves per CU = 4 per SIMD), 32-bit: 1,024 (60 VGPRs).
+// (90 VGPRs: 2 x 8 waves per CU = 4 per SIMD), 32-bit: 512 threads, three workgroups per CU.
+// (the 32-bit instance, 49 KB of LDS a workgroup: 512 threads x 3 per CU against 1,024 x 2 -- sort 356 -> 292 us per 8 genomes at k = 16
+// whole-space, 78 -> 49 under a 1/8 slab; 512 x 2: 310 / 53)
 #ifndef PSK_BS_SORT32_THREADS
-#define PSK_BS_SORT32_THREADS 1024
+#define PSK_BS_SORT32_THREADS 512
 #endif
 #ifndef PSK_BS_SORT32_WGS
-#define PSK_BS_SORT32_WGS 2       // workgroups per CU of the 32-bit instance (49 KB of LDS each)
+#define PSK_BS_SORT32_WGS 3
 #endif
 template <typename W> struct SortGeo {
     static constexpr int THREADS = sizeof(W) == 4 ? PSK_BS_SORT32_THREADS : 512;
