@@ -238,6 +238,7 @@ def test_counting_gz_samples_equals_counting_their_text(k, tmp_path, monkeypatch
         # (r06: .gz files are MAPPED read-only and uploaded out of the mapping; PSK_GZ_READ=1 is r05's route -- read into host buffers of
         # the library -- which a file that cannot be mapped still takes: both, and a call cut into runs so that mappings are given back
         # while later runs are read)
+        monkeypatch.delenv("PSK_GZ_GROUP_MB", raising=False)
         for read_route, group_mb in ((None, None), ("1", None), (None, "1")):
             if read_route:
                 monkeypatch.setenv("PSK_GZ_READ", read_route)
