@@ -1,6 +1,8 @@
 // Context lifecycle, error reporting and device-memory helpers of libpsk.so.
 #include "psk_internal.h"
 
+#include <chrono>
+
 #include <mutex>
 
 static thread_local std::string g_init_error;
@@ -86,6 +88,65 @@ int arena_alloc(psk_ctx *ctx, size_t bytes, void **out)
     return PSK_OK;
 }
 
+namespace {
+struct PinnedCache {
+    struct Entry { void *p; size_t cap; int device; };
+    std::mutex mu;
+    std::vector<Entry> held;
+    size_t bytes = 0;
+};
+PinnedCache g_pinned;
+size_t pinned_cache_limit()
+{
+    const char *e = getenv("PSK_PINNED_CACHE_MB");
+    return (size_t)(e && *e ? strtoull(e, nullptr, 10) : 1024) << 20;
+}
+}  // namespace
+
+int pinned_acquire(psk_ctx *ctx, size_t need, void **buf, size_t *cap)
+{
+    {
+        std::lock_guard<std::mutex> lk(g_pinned.mu);
+        size_t best = g_pinned.held.size();
+        for (size_t i = 0; i < g_pinned.held.size(); i++) {   // the smallest cached buffer of this device that is large enough (and not four times too large)
+            const PinnedCache::Entry &e = g_pinned.held[i];
+            if (e.device != ctx->device || e.cap < need || e.cap / 4 > need) continue;
+            if (best == g_pinned.held.size() || e.cap < g_pinned.held[best].cap) best = i;
+        }
+        if (best < g_pinned.held.size()) {
+            *buf = g_pinned.held[best].p;
+            *cap = g_pinned.held[best].cap;
+            g_pinned.bytes -= g_pinned.held[best].cap;
+            g_pinned.held.erase(g_pinned.held.begin() + (long)best);
+            return PSK_OK;
+        }
+    }
+    const size_t want = need + need / 4;
+    hipError_t e = hipHostMalloc(buf, want, hipHostMallocDefault);
+    if (e != hipSuccess) {
+        *buf = nullptr;
+        *cap = 0;
+        (void)hipGetLastError();
+        return psk_fail(ctx, PSK_ENOMEM, "hipHostMalloc(%zu) failed: %s", want, hipGetErrorString(e));
+    }
+    *cap = want;
+    return PSK_OK;
+}
+
+void pinned_release(psk_ctx *ctx, void *buf, size_t cap)
+{
+    if (!buf) return;
+    {
+        std::lock_guard<std::mutex> lk(g_pinned.mu);
+        if (cap && g_pinned.bytes + cap <= pinned_cache_limit()) {
+            g_pinned.held.push_back({buf, cap, ctx->device});
+            g_pinned.bytes += cap;
+            return;
+        }
+    }
+    (void)hipHostFree(buf);
+}
+
 void arena_release(psk_ctx *ctx)
 {
     for (void *p : ctx->arena.chunks) (void)hipFree(p);
@@ -134,13 +195,22 @@ extern "C" void psk_free(psk_ctx *ctx)
     if (!ctx) return;
     (void)hipSetDevice(ctx->device);
     if (ctx->stream) (void)hipStreamSynchronize(ctx->stream);
+    const bool trace = getenv("PSK_TRACE") != nullptr;
+    const auto t0 = std::chrono::steady_clock::now();
+    auto lap = [&](const char *what) {
+        if (trace) fprintf(stderr, "[psk] psk_free: %s at %.1f ms\n", what, std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count());
+    };
     comm_release(ctx);
     reset_lists(ctx, 0);
+    const size_t n_chunks = ctx->arena.chunks.size();
     arena_release(ctx);
+    if (trace) fprintf(stderr, "[psk] psk_free: %zu arena chunks\n", n_chunks);
+    lap("arena released");
     DevBuf *bufs[] = {&ctx->raw, &ctx->keysA, &ctx->keysB, &ctx->valsA, &ctx->valsB, &ctx->hist, &ctx->scan_tmp, &ctx->flags, &ctx->starts,
                       &ctx->misc, &ctx->union_words, &ctx->bits, &ctx->mask1, &ctx->phe,
                       &ctx->slot[0].res, &ctx->slot[1].res, &ctx->res_count, &ctx->res_sorted, &ctx->lut, &ctx->bs_spl, &ctx->bs_ct};
     for (DevBuf *b : bufs) dev_release(*b);
+    lap("matrix, union, scan buffers released");
     if (ctx->copy_stream) (void)hipStreamSynchronize(ctx->copy_stream);
     for (CountLane &L : ctx->lane) {
         DevBuf *lb[] = {&L.raw, &L.keysA, &L.keysB, &L.starts, &L.cnt, &L.sk_cand, &L.sk_out,
@@ -156,6 +226,7 @@ extern "C" void psk_free(psk_ctx *ctx)
         if (L.raw_free) (void)hipEventDestroy(L.raw_free);
         if (L.up_done) (void)hipEventDestroy(L.up_done);
     }
+    lap("lane buffers and events released");
     gz_release(ctx);
     if (ctx->gz_stream) (void)hipStreamDestroy(ctx->gz_stream);
     if (ctx->gz_up_stream) (void)hipStreamDestroy(ctx->gz_up_stream);
@@ -165,15 +236,19 @@ extern "C" void psk_free(psk_ctx *ctx)
     for (hipStream_t &cs : ctx->copy_more) if (cs) { (void)hipStreamSynchronize(cs); (void)hipStreamDestroy(cs); cs = nullptr; }
     if (ctx->frame_stream) { (void)hipStreamSynchronize(ctx->frame_stream); (void)hipStreamDestroy(ctx->frame_stream); }
     if (ctx->sketch_stream) { (void)hipStreamSynchronize(ctx->sketch_stream); (void)hipStreamDestroy(ctx->sketch_stream); }
-    if (ctx->pinned) (void)hipHostFree(ctx->pinned);
+    lap("gz buffers, lane slab, streams released");
+    pinned_release(ctx, ctx->pinned, ctx->pinned_cap);
     if (ctx->scan_pinned) (void)hipHostFree(ctx->scan_pinned);
     if (ctx->cnt_pinned) (void)hipHostFree(ctx->cnt_pinned);
-    for (void *r : ctx->ring) if (r) (void)hipHostFree(r);
+    for (size_t r = 0; r < ctx->ring.size(); r++) pinned_release(ctx, ctx->ring[r], r < ctx->ring_cap.size() ? ctx->ring_cap[r] : 0);   // (into the process's cache: psk_internal.h)
+    if (trace) fprintf(stderr, "[psk] psk_free: %zu ring slots\n", ctx->ring.size());
+    lap("pinned ring released");
     if (ctx->ev0) (void)hipEventDestroy(ctx->ev0);
     if (ctx->ev1) (void)hipEventDestroy(ctx->ev1);
     for (ScanSlot &sl : ctx->slot)
         for (hipEvent_t e : {sl.ev0, sl.ev1, sl.ev_export}) if (e) (void)hipEventDestroy(e);
     if (ctx->stream) (void)hipStreamDestroy(ctx->stream);
+    lap("events, main stream released");
     delete ctx;
 }
 

@@ -846,14 +846,10 @@ static int chain_finalize(psk_ctx *ctx, CountLane &L)
 static int ensure_pinned(psk_ctx *ctx, void **buf, size_t *cap, size_t need)
 {
     if (need <= *cap && *buf) return PSK_OK;
-    if (*buf) (void)hipHostFree(*buf);
+    pinned_release(ctx, *buf, *cap);   // (r06: pinned buffers come from, and go back to, a process-wide cache: api.hip)
     *buf = nullptr;
     *cap = 0;
-    const size_t want = need + need / 4;
-    hipError_t e = hipHostMalloc(buf, want, hipHostMallocDefault);
-    if (e != hipSuccess) return psk_fail(ctx, PSK_ENOMEM, "hipHostMalloc(%zu) failed: %s", want, hipGetErrorString(e));
-    *cap = want;
-    return PSK_OK;
+    return pinned_acquire(ctx, need, buf, cap);
 }
 
 // `consumer` != nullptr (prediction: count_dict_impl): the framed clean stream of sample i on buffer set L goes to it instead

@@ -238,6 +238,13 @@ int gz_inflate_group(psk_ctx *ctx, int n, const uint8_t *const *data, const size
 uint64_t gz_image_layout(int n, const size_t *sizes, uint64_t *at);
 bool gz_group_on_device(int n, const size_t *sizes, bool host_only, int host_threads);
 
+// r06: pinned host buffers outlive their context in a process-wide cache (api.hip).  Unpinning is slow -- the 20 slots of the batch
+// counter's ring cost psk_free 28 ms of a 0.59-s `phenotypeseeker modeling` process, and a second context of the process (bench.py's
+// e2e leg, a host application that runs several analyses) pinned them all over again in its first counting call.  At most
+// PSK_PINNED_CACHE_MB (default 1024; 0: no cache) are held, per device; what a process holds at its exit goes with the process.
+int pinned_acquire(psk_ctx *ctx, size_t need, void **buf, size_t *cap);   // *buf of *cap >= need bytes, from the cache or hipHostMalloc
+void pinned_release(psk_ctx *ctx, void *buf, size_t cap);                 // into the cache, or hipHostFree when the cache is full
+
 static inline unsigned div_up(uint64_t a, uint64_t b) { return (unsigned)((a + b - 1) / b); }
 
 // hipFuncSetAttribute(MaxDynamicSharedMemorySize) applies to the CURRENT device: "done once" has to be remembered per
