@@ -230,7 +230,9 @@ extern "C" void psk_free(psk_ctx *ctx)
     gz_release(ctx);
     if (ctx->gz_stream) (void)hipStreamDestroy(ctx->gz_stream);
     if (ctx->gz_up_stream) (void)hipStreamDestroy(ctx->gz_up_stream);
+    if (trace) fprintf(stderr, "[psk] psk_free: lane slab of %.2f GB\n", ctx->lane_slab.cap / 1e9);
     dev_release(ctx->lane_slab);
+    lap("lane slab released");
     if (ctx->lane_pinned) (void)hipHostFree(ctx->lane_pinned);
     if (ctx->copy_stream) (void)hipStreamDestroy(ctx->copy_stream);
     for (hipStream_t &cs : ctx->copy_more) if (cs) { (void)hipStreamSynchronize(cs); (void)hipStreamDestroy(cs); cs = nullptr; }
