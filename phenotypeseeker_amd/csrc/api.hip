@@ -76,7 +76,10 @@ int arena_alloc(psk_ctx *ctx, size_t bytes, void **out)
         A.cur++;
         A.off = 0;
     }
-    const size_t sz = bytes > Arena::CHUNK ? bytes : Arena::CHUNK;
+    // (r06: the first chunks are 1 GiB, those of a run that has already taken eight of them 4 GiB: config 3 on one GPU holds 122 GB of
+    // lists -- 118 hipMallocs while it counts and 118 hipFrees at its end, 20-90 ms each way)
+    const size_t step = A.chunks.size() < 8 ? Arena::CHUNK : 4 * Arena::CHUNK;
+    const size_t sz = bytes > step ? bytes : step;
     void *p = nullptr;
     hipError_t e = hipMalloc(&p, sz);
     if (e != hipSuccess) return psk_fail(ctx, PSK_ENOMEM, "hipMalloc(%zu bytes) failed: %s", sz, hipGetErrorString(e));
