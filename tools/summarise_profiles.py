@@ -192,7 +192,9 @@ for wl in sorted(os.listdir(src)):
         table.append(rec)
     if wl in ("bench", "hbmonly") and info:
         if wl == "bench":
-            shutil.copy(os.path.join(src, "bench_unprofiled.json"), os.path.join(dst, "%s_bench_cfg2_unprofiled.json" % tag))
+            unprof, kept = os.path.join(src, "bench_unprofiled.json"), os.path.join(dst, "%s_bench_cfg2_unprofiled.json" % tag)
+            if not os.path.exists(kept) or os.path.getmtime(unprof) > os.path.getmtime(kept):   # (a later record committed by hand stays)
+                shutil.copy(unprof, kept)
         scan = [k for k in cnt if k.startswith("chi2_scan_kernel") and "FETCH_SIZE" in cnt[k]]
         if scan:
             k = max(scan, key=lambda k_: cnt[k_]["FETCH_SIZE"][0])
